@@ -1,0 +1,155 @@
+/*
+ * mgn_hip.h -- C ABI of the MI355X-native MeshGraphNets Encode-Process-Decode engine.
+ *
+ * This is the drop-in boundary for the ONE hot path of una-auxme/MeshGraphNets.jl: everything the
+ * reference obtains from `using GraphNetCore` (reference src/MeshGraphNets.jl:8) that runs per
+ * ODE right-hand side / per training datapoint.  A thin Julia `ccall` shim (julia/MGNHip.jl) or the
+ * Python ctypes host (meshgraphnets.jl_amd/engine.py) binds exactly these symbols; see
+ * INTEGRATION.md.  No C++ types, no torch types: plain pointers and sizes.
+ *
+ * Conventions
+ *   - All matrices are C row-major [count][feat] == the bytes of Julia's column-major (feat x count).
+ *   - Every function returns 0 (MGN_OK) or a negative mgn_status; text via mgn_last_error().
+ *   - A handle is NOT thread-safe; one in-flight call per handle (the reference calls the model
+ *     strictly sequentially from one task: ODE RHS inside `solve`, src/solve.jl:53-61).
+ *   - Host-pointer entry points copy in/out and return after the D2H copy; `_dev` entry points take
+ *     device pointers, enqueue on the handle's stream (mgn_set_stream) and do not synchronise.
+ *   - The engine owns all device memory it allocates; caller owns every buffer it passes in.
+ *   - There is no CPU fallback: without a HIP device every compute entry point fails with MGN_E_HIP.
+ */
+#ifndef MGN_HIP_H
+#define MGN_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum mgn_status {
+    MGN_OK = 0,
+    MGN_E_ARG = -1,   /* bad argument (reference: ArgumentError / DimensionMismatch)            */
+    MGN_E_HIP = -2,   /* HIP runtime error / no device                                          */
+    MGN_E_STATE = -3, /* call order violated (e.g. forward before set_params / set_graph)       */
+    MGN_E_OOM = -4,   /* device or host allocation failed                                       */
+    MGN_E_UNSUPPORTED = -5
+} mgn_status;
+
+typedef enum mgn_dtype { MGN_F32 = 0, MGN_BF16 = 1 } mgn_dtype;
+
+/* Mirrors the arguments of GraphNetCore.load(quantities, dims, e_norms, n_norms, o_norms, outputs,
+ * mps, layer_size, hidden_layers, opt, device, path) at reference src/MeshGraphNets.jl:282-285:
+ *   Fn = quantities, Fe = dims+1 (src/graph.jl:49-52), O = outputs, L = layer_size.            */
+typedef struct mgn_config {
+    int32_t Fn;            /* node input width  (cylinder_flow: 9 = velocity 2 + one-hot 7)       */
+    int32_t Fe;            /* edge input width  (2-D mesh: 3 = rel pos 2 + norm)                  */
+    int32_t O;             /* output width      (cylinder_flow: 2)                                */
+    int32_t L;             /* latent width `layer_size`; HIP path supports 32, 64, 128            */
+    int32_t hidden_layers; /* hidden layers per MLP; HIP path supports 2 (3 Dense), the default   */
+    int32_t mps;           /* message passing steps                                               */
+    int32_t dtype;         /* mgn_dtype; MGN_F32 implemented                                      */
+    int32_t rank;          /* this process's partition, 0 <= rank < nranks                        */
+    int32_t nranks;        /* number of edge-cut partitions (1 = whole mesh on this GPU)          */
+    int32_t device;        /* HIP device ordinal, -1 = current device, MGN_DEVICE_NONE = host-only handle */
+} mgn_config;
+
+/* A handle created with device == MGN_DEVICE_NONE owns no GPU state: only mgn_set_graph and the partition
+ * introspection calls work on it (host logic: receiver sort, CSR, edge-cut partition, halo lists); every
+ * compute entry point returns MGN_E_HIP.  It exists so that the partitioner can be used and tested on
+ * hosts without a GPU; it is not a CPU compute path. */
+#define MGN_DEVICE_NONE (-2)
+
+typedef struct mgn_engine mgn_handle;
+
+/* ---- lifecycle ------------------------------------------------------------------------------ */
+int mgn_create(const mgn_config* cfg, mgn_handle** out);
+void mgn_destroy(mgn_handle* h);
+const char* mgn_last_error(const mgn_handle* h); /* h may be NULL: error of the last failed mgn_create */
+int mgn_set_stream(mgn_handle* h, void* hip_stream); /* NULL = engine's own stream (default)   */
+int mgn_synchronize(mgn_handle* h);
+
+/* ---- parameters: mgn.ps (reference src/MeshGraphNets.jl:288,376-377) ------------------------- */
+/* Packed order (MGN-spec v1): enc-node, enc-edge, step1-edge, step1-node, ..., decoder;
+ * within an MLP W1,b1,W2,b2,W3,b3,[ln_scale,ln_bias]; each W row-major [in][out].               */
+size_t mgn_param_count(const mgn_config* cfg);
+int mgn_set_params(mgn_handle* h, const float* packed, size_t n);
+int mgn_get_params(mgn_handle* h, float* packed, size_t n);
+
+/* ---- normalisers: mgn.n_norm / e_norm / o_norm frozen to per-feature affine maps --------------
+ * forward:  y = x*scale + shift  (covers NormaliserOfflineMinMax, OfflineMeanStd and a frozen
+ * NormaliserOnline; reference src/MeshGraphNets.jl:79-203, applied src/graph.jl:80-93);
+ * inverse_data(o_norm, y) = y*out_scale + out_shift (src/solve.jl:205-210).
+ * Any pointer may be NULL = identity.  Used by mgn_ode_step only.                                */
+int mgn_set_norms(mgn_handle* h, const float* node_scale, const float* node_shift, /* [Fn] */
+                  const float* edge_scale, const float* edge_shift,               /* [Fe] */
+                  const float* out_scale, const float* out_shift);                /* [O]  */
+
+/* ---- graph: once per trajectory, like create_base_graph (reference src/graph.jl:25-55, called at
+ * src/MeshGraphNets.jl:360,418,596).  Sort-by-receiver, CSR, tiling and (nranks>1) the edge-cut
+ * partition + halo lists are built here.  index_base is 1 at the Julia boundary (src/graph.jl:31-34).
+ * mesh_pos [N][pos_dim] is optional; it drives the geometric partition when nranks > 1.         */
+int mgn_set_graph(mgn_handle* h, int32_t N, int64_t E, const int32_t* senders, const int32_t* receivers,
+                  int32_t index_base, const float* mesh_pos, int32_t pos_dim);
+
+/* Partition introspection (nranks == 1: n_own = N, n_halo = 0, e_local = E). */
+int mgn_partition_info(const mgn_handle* h, int32_t* n_own, int32_t* n_halo, int64_t* e_local);
+int mgn_owned_nodes(const mgn_handle* h, int32_t* global_ids /* [n_own], 0-based */);
+int mgn_local_edges(const mgn_handle* h, int64_t* global_edge_ids /* [e_local], engine order */);
+int mgn_halo_counts(const mgn_handle* h, int32_t* send_rows /* [nranks] */, int32_t* recv_rows /* [nranks] */);
+int mgn_halo_nodes(const mgn_handle* h, int32_t* global_ids /* [n_halo], grouped by owner rank */);
+int mgn_halo_send_index(const mgn_handle* h, int32_t* local_rows /* [sum(send_rows)] owned local rows, peer-major */);
+/* local (receiver-sorted) edge list: snd may index halo rows (>= n_own); rowptr is CSR by receiver */
+int mgn_local_graph(const mgn_handle* h, int32_t* snd /* [e_local] */, int32_t* rcv /* [e_local] */, int32_t* rowptr /* [n_own+1] */);
+int mgn_node_owner(const mgn_handle* h, int32_t* owner /* [N] rank owning each global node */);
+
+/* ---- the model: mgn.model(graph, ps, st) -> output (reference src/solve.jl:200) ---------------
+ * nf [N][Fn], ef [E][Fe] are the FeatureGraph fields (already normalised, src/graph.jl:87-96);
+ * out [N][O].  With nranks > 1 pass the GLOBAL arrays; only owned rows of `out` are written and the
+ * caller drives the halo exchange through mgn_fwd_* below (see engine.py).                      */
+int mgn_forward(mgn_handle* h, const float* nf, const float* ef, float* out);
+
+/* ---- the fused RHS: ode_step (reference src/solve.jl:188-219) incl. build_graph (src/graph.jl:75-97)
+ * x [N][O] state, node_type_onehot [N][Fn-O] (raw), ef_raw [E][Fe] (raw edge_features),
+ * val_mask [N] (0/1; reference repeats it over the O rows, src/MeshGraphNets.jl:588-591), may be NULL.
+ * dxdt [N][O] = inverse_data(o_norm, model(graph)) .* val_mask.                                 */
+int mgn_ode_step(mgn_handle* h, const float* x, const float* node_type_onehot, const float* ef_raw,
+                 const float* val_mask, float* dxdt);
+
+/* ---- the benchmarked unit: nsteps processor steps on given latents -------------
+ * v [N][L], e [E][L] in caller order, updated in place (host buffers).                          */
+int mgn_processor_steps(mgn_handle* h, float* v, float* e, int32_t nsteps);
+
+/* Device-resident variant: latents live in the engine (import/randn them first); nothing crosses
+ * PCIe.  Single partition only; enqueues 2*nsteps kernels (+1 projection) on the stream.        */
+int mgn_latents_import(mgn_handle* h, const float* v, const float* e);   /* host, GLOBAL arrays   */
+int mgn_latents_export(mgn_handle* h, float* v, float* e);               /* host, owned rows only */
+int mgn_latents_randn(mgn_handle* h, uint64_t seed); /* N(0,1) keyed by GLOBAL node/edge id      */
+int mgn_latents_checksum(mgn_handle* h, double* sum_v, double* sum_e, double* sumsq_v, double* sumsq_e);
+int mgn_processor_steps_dev(mgn_handle* h, int32_t nsteps);
+
+/* ---- fine-grained stages (multi-partition driver; each enqueues on the stream) ----------------
+ * Order per forward:   enc -> [halo] -> for k: edge(k) -> node(k) -> [halo] -> ... -> dec
+ * Order per processor: begin -> [halo] -> for k: edge(k) -> node(k) -> [halo]
+ * [halo] = mgn_halo_pack -> exchange rows between ranks (RCCL all-to-all-v) -> mgn_halo_unpack.    */
+int mgn_fwd_upload(mgn_handle* h, const float* nf, const float* ef); /* host GLOBAL arrays -> device local */
+int mgn_fwd_encode(mgn_handle* h);
+int mgn_proc_begin(mgn_handle* h);                      /* project P,Q of step 0 from current v     */
+int mgn_proc_edge(mgn_handle* h, int32_t k);
+int mgn_proc_node(mgn_handle* h, int32_t k, int32_t project_next); /* project_next: also emit P,Q of step k+1 */
+int mgn_fwd_decode(mgn_handle* h);
+int mgn_fwd_download(mgn_handle* h, float* out);        /* host GLOBAL [N][O]; owned rows written   */
+int mgn_halo_bytes_per_row(const mgn_handle* h);
+int mgn_halo_pack(mgn_handle* h, void* send_dev);       /* device buffer, sum(send_rows) rows       */
+int mgn_halo_unpack(mgn_handle* h, const void* recv_dev); /* device buffer, sum(recv_rows) rows     */
+
+/* ---- measurement hooks ------------------------------------------------------------------------ */
+/* Average device time (HIP events on the launch stream) of each kernel family since the last reset:
+ * ms[0]=edge step, ms[1]=node step, ms[2]=encode, ms[3]=decode, ms[4]=halo pack/unpack; counts alike. */
+int mgn_profile_enable(mgn_handle* h, int32_t on);
+int mgn_profile_read(mgn_handle* h, double ms_avg[8], int64_t counts[8]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MGN_HIP_H */

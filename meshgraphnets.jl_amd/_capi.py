@@ -1,0 +1,104 @@
+"""ctypes binding of include/mgn_hip.h -- one prototype per declared symbol, nothing else.
+
+The product path fails loudly when the HIP extension is missing: `load()` raises, there is no
+fallback implementation anywhere in this package.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "lib", "libmgn_hip.so")
+
+MGN_DEVICE_NONE = -2
+MGN_OK, MGN_E_ARG, MGN_E_HIP, MGN_E_STATE, MGN_E_OOM, MGN_E_UNSUPPORTED = 0, -1, -2, -3, -4, -5
+STATUS_NAMES = {0: "MGN_OK", -1: "MGN_E_ARG", -2: "MGN_E_HIP", -3: "MGN_E_STATE", -4: "MGN_E_OOM", -5: "MGN_E_UNSUPPORTED"}
+
+
+class MgnConfig(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in
+                ("Fn", "Fe", "O", "L", "hidden_layers", "mps", "dtype", "rank", "nranks", "device")]
+
+
+_f32p = C.POINTER(C.c_float)
+_i32p = C.POINTER(C.c_int32)
+_i64p = C.POINTER(C.c_int64)
+_f64p = C.POINTER(C.c_double)
+_H = C.c_void_p
+
+# name -> (restype, argtypes): must list exactly the symbols of include/mgn_hip.h (tests check this)
+PROTOTYPES = {
+    "mgn_create": (C.c_int, [C.POINTER(MgnConfig), C.POINTER(_H)]),
+    "mgn_destroy": (None, [_H]),
+    "mgn_last_error": (C.c_char_p, [_H]),
+    "mgn_set_stream": (C.c_int, [_H, C.c_void_p]),
+    "mgn_synchronize": (C.c_int, [_H]),
+    "mgn_param_count": (C.c_size_t, [C.POINTER(MgnConfig)]),
+    "mgn_set_params": (C.c_int, [_H, _f32p, C.c_size_t]),
+    "mgn_get_params": (C.c_int, [_H, _f32p, C.c_size_t]),
+    "mgn_set_norms": (C.c_int, [_H, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p]),
+    "mgn_set_graph": (C.c_int, [_H, C.c_int32, C.c_int64, _i32p, _i32p, C.c_int32, _f32p, C.c_int32]),
+    "mgn_partition_info": (C.c_int, [_H, _i32p, _i32p, _i64p]),
+    "mgn_owned_nodes": (C.c_int, [_H, _i32p]),
+    "mgn_local_edges": (C.c_int, [_H, _i64p]),
+    "mgn_halo_counts": (C.c_int, [_H, _i32p, _i32p]),
+    "mgn_halo_nodes": (C.c_int, [_H, _i32p]),
+    "mgn_halo_send_index": (C.c_int, [_H, _i32p]),
+    "mgn_local_graph": (C.c_int, [_H, _i32p, _i32p, _i32p]),
+    "mgn_node_owner": (C.c_int, [_H, _i32p]),
+    "mgn_forward": (C.c_int, [_H, _f32p, _f32p, _f32p]),
+    "mgn_ode_step": (C.c_int, [_H, _f32p, _f32p, _f32p, _f32p, _f32p]),
+    "mgn_processor_steps": (C.c_int, [_H, _f32p, _f32p, C.c_int32]),
+    "mgn_latents_import": (C.c_int, [_H, _f32p, _f32p]),
+    "mgn_latents_export": (C.c_int, [_H, _f32p, _f32p]),
+    "mgn_latents_randn": (C.c_int, [_H, C.c_uint64]),
+    "mgn_latents_checksum": (C.c_int, [_H, _f64p, _f64p, _f64p, _f64p]),
+    "mgn_processor_steps_dev": (C.c_int, [_H, C.c_int32]),
+    "mgn_fwd_upload": (C.c_int, [_H, _f32p, _f32p]),
+    "mgn_fwd_encode": (C.c_int, [_H]),
+    "mgn_proc_begin": (C.c_int, [_H]),
+    "mgn_proc_edge": (C.c_int, [_H, C.c_int32]),
+    "mgn_proc_node": (C.c_int, [_H, C.c_int32, C.c_int32]),
+    "mgn_fwd_decode": (C.c_int, [_H]),
+    "mgn_fwd_download": (C.c_int, [_H, _f32p]),
+    "mgn_halo_bytes_per_row": (C.c_int, [_H]),
+    "mgn_halo_pack": (C.c_int, [_H, C.c_void_p]),
+    "mgn_halo_unpack": (C.c_int, [_H, C.c_void_p]),
+    "mgn_profile_enable": (C.c_int, [_H, C.c_int32]),
+    "mgn_profile_read": (C.c_int, [_H, _f64p, _i64p]),
+}
+
+_lib = None
+
+
+def load(path: str | None = None):
+    """dlopen libmgn_hip.so and attach prototypes.  Raises if the extension has not been built."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise RuntimeError(
+            f"HIP extension {p} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  This package has no CPU fallback.")
+    lib = C.CDLL(p, mode=C.RTLD_LOCAL)
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    if path is None:
+        _lib = lib
+    return lib
+
+
+def f32(a):
+    return a.ctypes.data_as(_f32p) if a is not None else None
+
+
+def i32(a):
+    return a.ctypes.data_as(_i32p) if a is not None else None
+
+
+def i64(a):
+    return a.ctypes.data_as(_i64p) if a is not None else None

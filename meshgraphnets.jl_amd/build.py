@@ -1,0 +1,87 @@
+"""Build the in-tree native pieces.
+
+  libmgn_hip.so   HIP kernels + C ABI (include/mgn_hip.h) for gfx950      [hipcc, cross-compiles w/o GPU]
+  oracle/_build/libmgn_ref.so   fp32 C restatement of MGN-spec (test checker + CPU baseline)  [gcc]
+
+Artifacts are git-ignored but travel to the GPU box with the gpurun snapshot.
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+CSRC = os.path.join(HERE, "csrc")
+LIBDIR = os.path.join(HERE, "lib")
+LIB = os.path.join(LIBDIR, "libmgn_hip.so")
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+REF_LIB = os.path.join(ORACLE_DIR, "_build", "libmgn_ref.so")
+
+HIP_SOURCES = ["kernels.hip", "mgn_api.cpp", "graph_host.cpp"]
+HIP_HEADERS = ["kernels.h", "graph_host.h", os.path.join(ROOT, "include", "mgn_hip.h")]
+
+
+def _newer(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def hipcc_path():
+    for c in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if c and os.path.exists(c):
+            return c
+    raise RuntimeError("hipcc not found; the HIP extension cannot be built")
+
+
+def build_hip(force=False, verbose=True):
+    srcs = [os.path.join(CSRC, s) for s in HIP_SOURCES]
+    deps = srcs + [h if os.path.isabs(h) else os.path.join(CSRC, h) for h in HIP_HEADERS]
+    if not force and not _newer(LIB, deps):
+        return LIB
+    os.makedirs(LIBDIR, exist_ok=True)
+    objdir = os.path.join(LIBDIR, "_obj")
+    os.makedirs(objdir, exist_ok=True)
+    hipcc = hipcc_path()
+    common = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-I", os.path.join(ROOT, "include")]
+    objs = []
+    for s in srcs:
+        o = os.path.join(objdir, os.path.basename(s) + ".o")
+        if force or _newer(o, deps):
+            cmd = [hipcc] + common + ["-c", s, "-o", o]
+            if verbose:
+                print("[build]", " ".join(cmd), flush=True)
+            subprocess.check_call(cmd)
+        objs.append(o)
+    cmd = [hipcc, "-shared", "-fPIC", "--offload-arch=gfx950", "-o", LIB] + objs
+    if verbose:
+        print("[build]", " ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return LIB
+
+
+def build_ref(force=False, verbose=True):
+    src = os.path.join(ORACLE_DIR, "mgn_ref.c")
+    if not os.path.exists(src):
+        return None
+    if not force and not _newer(REF_LIB, [src]):
+        return REF_LIB
+    os.makedirs(os.path.dirname(REF_LIB), exist_ok=True)
+    cmd = ["gcc", "-O3", "-march=x86-64-v3", "-fopenmp", "-fPIC", "-shared", "-o", REF_LIB, src, "-lm"]
+    if verbose:
+        print("[build]", " ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return REF_LIB
+
+
+def build_all(force=False, verbose=True):
+    return build_hip(force, verbose), build_ref(force, verbose)
+
+
+if __name__ == "__main__":
+    build_all(force="--force" in sys.argv)
+    print("ok")

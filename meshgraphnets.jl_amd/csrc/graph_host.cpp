@@ -1,0 +1,160 @@
+// Host-side graph preparation (see graph_host.h).  Amortised once per trajectory, exactly where the
+// reference builds its static graph: create_base_graph, reference src/graph.jl:25-55, called at
+// src/MeshGraphNets.jl:360,418,596.  The reference keeps edges in triangles_to_edges order and
+// scatters with atomics (NNlib); this engine re-orders edges by receiver so that the scatter-add
+// becomes a segmented sum, and (nranks > 1) cuts the mesh by node ownership.
+#include "graph_host.h"
+
+#include <algorithm>
+#include <numeric>
+
+namespace mgn {
+
+namespace {
+
+void rcb_rec(std::vector<int32_t>& idx, int64_t lo, int64_t hi, int32_t part0, int32_t parts, const float* pos,
+             int32_t dim, std::vector<int32_t>& owner) {
+    if (parts <= 1 || hi - lo <= 0) {
+        for (int64_t i = lo; i < hi; ++i) owner[idx[i]] = part0;
+        return;
+    }
+    int axis = 0;
+    float best = -1.f;
+    for (int d = 0; d < dim; ++d) {
+        float mn = pos[(int64_t)idx[lo] * dim + d], mx = mn;
+        for (int64_t i = lo + 1; i < hi; ++i) {
+            const float v = pos[(int64_t)idx[i] * dim + d];
+            mn = std::min(mn, v);
+            mx = std::max(mx, v);
+        }
+        if (mx - mn > best) {
+            best = mx - mn;
+            axis = d;
+        }
+    }
+    const int32_t pl = parts / 2;
+    const int64_t nleft = (hi - lo) * pl / parts;
+    auto cmp = [&](int32_t a, int32_t b) {
+        const float va = pos[(int64_t)a * dim + axis], vb = pos[(int64_t)b * dim + axis];
+        return va < vb || (va == vb && a < b);
+    };
+    std::nth_element(idx.begin() + lo, idx.begin() + lo + nleft, idx.begin() + hi, cmp);
+    rcb_rec(idx, lo, lo + nleft, part0, pl, pos, dim, owner);
+    rcb_rec(idx, lo + nleft, hi, part0 + pl, parts - pl, pos, dim, owner);
+}
+
+}  // namespace
+
+void rcb_partition(int32_t N, const float* pos, int32_t pos_dim, int32_t parts, std::vector<int32_t>& owner) {
+    owner.assign(N, 0);
+    if (parts <= 1) return;
+    if (!pos || pos_dim <= 0) {
+        for (int32_t i = 0; i < N; ++i) owner[i] = (int32_t)(((int64_t)i * parts) / N);
+        return;
+    }
+    std::vector<int32_t> idx(N);
+    std::iota(idx.begin(), idx.end(), 0);
+    rcb_rec(idx, 0, N, 0, parts, pos, pos_dim, owner);
+}
+
+std::string build_local_graph(int32_t N, int64_t E, const int32_t* senders, const int32_t* receivers, int32_t index_base,
+                              const float* pos, int32_t pos_dim, int32_t rank, int32_t nranks, LocalGraph& g) {
+    if (N < 0 || E < 0) return "negative N or E";
+    if (E > 0 && (!senders || !receivers)) return "null senders/receivers";
+    if (nranks < 1 || rank < 0 || rank >= nranks) return "bad rank/nranks";
+    if (E >= ((int64_t)1 << 31)) return "E >= 2^31 not supported";
+    for (int64_t i = 0; i < E; ++i) {
+        const int64_t s = (int64_t)senders[i] - index_base, r = (int64_t)receivers[i] - index_base;
+        if (s < 0 || s >= N || r < 0 || r >= N) return "edge index out of range at edge " + std::to_string(i);
+    }
+    g = LocalGraph();
+    g.N = N;
+    g.E = E;
+    g.rank = rank;
+    g.nranks = nranks;
+    rcb_partition(N, pos, pos_dim, nranks, g.owner);
+
+    // owned nodes, ascending global id
+    std::vector<int32_t> g2l(N, -1);
+    for (int32_t i = 0; i < N; ++i)
+        if (g.owner[i] == rank) {
+            g2l[i] = (int32_t)g.own_gid.size();
+            g.own_gid.push_back(i);
+        }
+    g.n_own = (int32_t)g.own_gid.size();
+
+    // local edges = edges whose receiver is owned; count per receiver for the stable counting sort
+    g.rowptr.assign((size_t)g.n_own + 1, 0);
+    int64_t el = 0;
+    for (int64_t i = 0; i < E; ++i) {
+        const int32_t r = receivers[i] - index_base;
+        if (g.owner[r] == rank) {
+            ++g.rowptr[(size_t)g2l[r] + 1];
+            ++el;
+        }
+    }
+    g.e_local = el;
+    for (int32_t i = 0; i < g.n_own; ++i) g.rowptr[(size_t)i + 1] += g.rowptr[i];
+
+    // halo nodes: remote senders of local edges, grouped by owner rank then ascending gid
+    {
+        std::vector<uint8_t> is_halo(N, 0);
+        for (int64_t i = 0; i < E; ++i) {
+            const int32_t s = senders[i] - index_base, r = receivers[i] - index_base;
+            if (g.owner[r] == rank && g.owner[s] != rank) is_halo[s] = 1;
+        }
+        g.recv_rows.assign(nranks, 0);
+        for (int32_t i = 0; i < N; ++i)
+            if (is_halo[i]) ++g.recv_rows[g.owner[i]];
+        std::vector<int32_t> off(nranks + 1, 0);
+        for (int32_t q = 0; q < nranks; ++q) off[q + 1] = off[q] + g.recv_rows[q];
+        g.n_halo = off[nranks];
+        g.halo_gid.assign(g.n_halo, 0);
+        std::vector<int32_t> cur(off.begin(), off.end() - 1);
+        for (int32_t i = 0; i < N; ++i)  // ascending gid inside each owner group
+            if (is_halo[i]) {
+                const int32_t q = g.owner[i];
+                g2l[i] = g.n_own + cur[q];
+                g.halo_gid[cur[q]++] = i;
+            }
+    }
+
+    // fill local edges in receiver-sorted, input-stable order
+    g.snd.assign(el, 0);
+    g.rcv.assign(el, 0);
+    g.edge_gid.assign(el, 0);
+    {
+        std::vector<int32_t> cur(g.rowptr.begin(), g.rowptr.end() - 1);
+        for (int64_t i = 0; i < E; ++i) {
+            const int32_t s = senders[i] - index_base, r = receivers[i] - index_base;
+            if (g.owner[r] != rank) continue;
+            const int32_t lr = g2l[r];
+            const int32_t p = cur[lr]++;
+            g.snd[p] = g2l[s];
+            g.rcv[p] = lr;
+            g.edge_gid[p] = i;
+        }
+    }
+
+    // send lists: my owned nodes that are senders of edges received on peer q (unique, ascending gid)
+    g.send_rows.assign(nranks, 0);
+    g.send_idx.clear();
+    if (nranks > 1) {
+        std::vector<std::vector<int32_t>> lists(nranks);
+        for (int64_t i = 0; i < E; ++i) {
+            const int32_t s = senders[i] - index_base, r = receivers[i] - index_base;
+            const int32_t q = g.owner[r];
+            if (g.owner[s] == rank && q != rank) lists[q].push_back(s);
+        }
+        for (int32_t q = 0; q < nranks; ++q) {
+            auto& l = lists[q];
+            std::sort(l.begin(), l.end());
+            l.erase(std::unique(l.begin(), l.end()), l.end());
+            g.send_rows[q] = (int32_t)l.size();
+            for (int32_t gid : l) g.send_idx.push_back(g2l[gid]);
+        }
+    }
+    return std::string();
+}
+
+}  // namespace mgn

@@ -1,0 +1,37 @@
+// Host-side graph preparation: receiver sort, CSR, edge-cut partition (RCB), halo lists.
+// Pure C++ (no HIP): exercised on CPU by tests through the mgn_* introspection entry points.
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+namespace mgn {
+
+struct LocalGraph {
+    int32_t N = 0;              // global nodes
+    int64_t E = 0;              // global edges
+    int32_t rank = 0, nranks = 1;
+    int32_t n_own = 0, n_halo = 0;
+    int64_t e_local = 0;
+    std::vector<int32_t> own_gid;    // [n_own] global id of owned node i (ascending)
+    std::vector<int32_t> halo_gid;   // [n_halo] grouped by owner rank, ascending gid inside a group
+    std::vector<int64_t> edge_gid;   // [e_local] global edge id, engine (receiver-sorted, stable) order
+    std::vector<int32_t> snd, rcv;   // [e_local] local indices; snd may be >= n_own (halo)
+    std::vector<int32_t> rowptr;     // [n_own+1] CSR by receiver
+    std::vector<int32_t> send_rows;  // [nranks] rows this rank sends to each peer per exchange
+    std::vector<int32_t> recv_rows;  // [nranks] rows received from each peer (== halo group sizes)
+    std::vector<int32_t> send_idx;   // [sum(send_rows)] local (owned) row of each sent row, peer-major
+    std::vector<int32_t> owner;      // [N] owner rank of every global node (kept for tests/introspection)
+};
+
+// Deterministic recursive coordinate bisection of N points into `parts` parts of near-equal count
+// (split the longer bounding-box axis at the count-proportional median).  pos may be null: then
+// contiguous index blocks.  Every rank computes the same answer from the same inputs.
+void rcb_partition(int32_t N, const float* pos, int32_t pos_dim, int32_t parts, std::vector<int32_t>& owner);
+
+// Build rank `rank`'s local graph.  senders/receivers are global ids with the given index base.
+// Returns empty string on success, else an error message.
+std::string build_local_graph(int32_t N, int64_t E, const int32_t* senders, const int32_t* receivers, int32_t index_base,
+                              const float* pos, int32_t pos_dim, int32_t rank, int32_t nranks, LocalGraph& g);
+
+}  // namespace mgn

@@ -1,0 +1,94 @@
+// Kernel argument blocks and launch wrappers shared by kernels.hip and mgn_api.cpp.
+// Internal to the engine; the public boundary is include/mgn_hip.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace mgn {
+
+constexpr int TILE = 32;        // rows (edges or nodes) per wave tile == MFMA 32x32 N dimension
+constexpr int MAX_CHUNKS = 6;   // weight chunks (L x L, fragment order) a fused kernel may chain
+
+// Table slots (each L floats, fragment order) inside a kernel's `tabs` block.
+enum { T_B1 = 0, T_B2, T_B3, T_GAMMA, T_BETA, T_BQ, T_COUNT };
+
+struct EdgeArgs {
+    const int32_t* snd;     // [E] local sender index (may point into halo rows of P)
+    const int32_t* rcv;     // [E] local receiver index, non-decreasing
+    int64_t E;
+    int32_t ntiles;
+    const float* P;         // [n_own+n_halo][L]  v * W1[0:L]      (sender part of edge-MLP layer 1)
+    const float* Q;         // [n_own][L]         v * W1[L:2L]+b1  (receiver part + bias)
+    float* Elat;            // [E][L] edge latents, updated in place
+    float* AGG;             // [n_own+1][L] per-receiver sums of e' (row n_own stays zero)
+    float* CARRY;           // [2*ntiles][L] partial sums of receiver segments that straddle tiles
+    const float* chunk[MAX_CHUNKS];  // 0:W2 1:W3 2:W1[2L:3L]   (fragment order)
+    const float* tabs;      // T_COUNT * L floats (fragment order): b2,b3 in T_B2,T_B3; LN in T_GAMMA,T_BETA
+};
+
+struct NodeArgs {
+    int32_t n;              // owned nodes
+    int32_t ntiles;
+    const int32_t* rowptr;  // [n+1] CSR by receiver over the local (receiver-sorted) edge list
+    float* V;               // [n][L] node latents, updated in place
+    const float* AGG;
+    const float* CARRY;
+    float* P;
+    float* Q;
+    const float* chunk[MAX_CHUNKS];  // 0:W2 1:W3 2:W1[0:L] 3:W1[L:2L] 4:WP(next) 5:WQ(next)
+    const float* tabs;      // b1,b2,b3,gamma,beta,bq
+    int32_t mode;           // 0: MLP only (last step)  1: MLP + project P,Q  2: project only
+};
+
+struct EncNodeArgs {
+    int32_t n, ntiles;
+    const int32_t* gid;     // [n] global node id of each owned node (row into srcA/srcB)
+    const float* srcA; int32_t wa;  // [N][wa]  first wa input features
+    const float* srcB; int32_t wb;  // [N][wb]  remaining features (may be null, wb = 0)
+    const float* scale;     // [Fn] input affine (normaliser), may be null
+    const float* shift;
+    const float* w1f;       // [Fn][L] first-layer weights, fragment order per input feature
+    float* V; float* P; float* Q;
+    const float* chunk[MAX_CHUNKS];  // 0:W2 1:W3 2:WP 3:WQ
+    const float* tabs;
+};
+
+struct EncEdgeArgs {
+    int64_t E; int32_t ntiles;
+    const int64_t* gid;     // [E] global edge id of each local edge (row into ef)
+    const float* ef; int32_t Fe;
+    const float* scale; const float* shift;
+    const float* w1f;
+    float* Elat;
+    const float* chunk[MAX_CHUNKS];  // 0:W2 1:W3
+    const float* tabs;
+};
+
+struct DecArgs {
+    int32_t n, ntiles;
+    const float* V;
+    const float* w3f;       // [O][L] last-layer weights, fragment order per output
+    const float* b3;        // [O]
+    int32_t O;
+    const float* oscale; const float* oshift;  // [O] inverse normaliser, may be null
+    const float* mask;      // [N] global val_mask, may be null
+    const int32_t* gid;
+    float* out;             // [n][O] local order
+    const float* chunk[MAX_CHUNKS];  // 0:W1 1:W2
+    const float* tabs;      // b1,b2
+};
+
+struct LaunchCfg { int blocks; int threads; size_t lds; };
+
+// L in {32,64,128}.  All return hipError_t of the launch.
+hipError_t launch_edge_step(int L, const EdgeArgs& a, hipStream_t s);
+hipError_t launch_node_step(int L, const NodeArgs& a, hipStream_t s);
+hipError_t launch_enc_node(int L, const EncNodeArgs& a, hipStream_t s);
+hipError_t launch_enc_edge(int L, const EncEdgeArgs& a, hipStream_t s);
+hipError_t launch_decode(int L, const DecArgs& a, hipStream_t s);
+hipError_t launch_gather_rows(const float* src, const int32_t* idx, float* dst, int64_t rows, int L, hipStream_t s);
+hipError_t launch_randn_rows(float* dst, const int64_t* gid64, const int32_t* gid32, int64_t rows, int L,
+                             uint64_t seed, hipStream_t s);
+hipError_t launch_checksum(const float* src, int64_t n, double* out2, hipStream_t s);
+
+}  // namespace mgn

@@ -1,0 +1,677 @@
+// CDNA4 (gfx950) kernels of the MeshGraphNets Encode-Process-Decode hot path.
+//
+// Replaces what GraphNetCore.jl/Lux/NNlib execute for `mgn.model(graph, ps, st)` (reference
+// src/solve.jl:200): per processor step gather v[:,senders]/v[:,receivers], edge MLP + LayerNorm,
+// scatter-add by receiver, node MLP + LayerNorm, residuals.
+//
+// Design ("lane-per-row"):
+//   * One wave owns a tile of 32 rows (edges or nodes).  Lane l = (c = l&31, h = l>>5) owns row c and
+//     half of its L features.  The MLP is computed TRANSPOSED on v_mfma_f32_32x32x2_f32:
+//         D[feature][row] += W^T[feature][k] * X^T[k][row]
+//     so the A operand is a weight fragment (pre-permuted on the host, one 16-byte read per lane per
+//     k-step for L=128) and the B operand is ONE VGPR of the lane's own row.  The accumulator of layer
+//     i (lane (c,h), register rho -> feature phi(rho,h) = 32(rho>>4) + (rho&3) + 8((rho&15)>>2) + 4h)
+//     is used verbatim as the B operand of layer i+1: k-step j consumes register j, the weights are
+//     stored in that k order.  Activations never leave registers between layers; no LDS round trip,
+//     no barrier; LayerNorm is an in-lane sum + one cross-half exchange; residuals are in-register.
+//   * Waves are independent (no __syncthreads after the weight preload), so the two waves resident on
+//     each SIMD overlap one wave's gather / LayerNorm / stores with the other's MFMA chain.
+//   * fp32 weights of one fused MLP exceed LDS (3 x 64 KiB), so two L x L chunks live in LDS for the
+//     whole (persistent) launch and the rest stream from L2 through a small register ring.
+//   * Edge-MLP layer 1 is factored: [v_s; v_r; e] W1 = P[s] + Q[r] + e W1e with P = v W1s,
+//     Q = v W1r + b1 computed per NODE by the previous node kernel (E/N ~ 6 fewer MFMA flops on the
+//     two node-side blocks).  The gather therefore initialises the layer-1 accumulator directly.
+//   * Scatter-add: edges are receiver-sorted once per trajectory; a wave does a segmented inclusive
+//     scan across its 32 lanes (DPP row shifts), segment tails store whole rows with plain stores;
+//     segments that straddle tiles go to per-tile carry rows that the node kernel adds.  No atomics,
+//     no zero-fill pass, bitwise reproducible.
+#include "kernels.h"
+
+namespace mgn {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+#define DEVINL __device__ __forceinline__
+// Re-derive the lane id through an opaque asm once per tile: every address and table read that depends
+// on it then stays INSIDE the persistent tile loop.  Without this hipcc hoists ~250 loop-invariant LDS
+// table reads and 64-bit weight addresses out of the loop and spills them all to scratch.
+#define OPAQUE_LANE()                          \
+    int lane = lane0;                          \
+    asm volatile("" : "+v"(lane));             \
+    const int c = lane & 31, h = lane >> 5
+constexpr float LN_EPS = 1e-5f;
+constexpr int NUM_XCD = 8;
+
+// ------------------------------------------------------------------------------------------------
+// fragment <-> row helpers.  Row r of an [rows][L] array; lane half h owns float4 pieces 8t+2g+h.
+// ------------------------------------------------------------------------------------------------
+template <int NT>
+DEVINL void load_frag(f32x16 (&x)[NT], const float* __restrict__ row, int h) {
+    const f32x4* r4 = reinterpret_cast<const f32x4*>(row) + h;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 v = r4[8 * t + 2 * g];
+            x[t][4 * g + 0] = v[0]; x[t][4 * g + 1] = v[1]; x[t][4 * g + 2] = v[2]; x[t][4 * g + 3] = v[3];
+        }
+}
+
+template <int NT>
+DEVINL void add_frag(f32x16 (&x)[NT], const float* __restrict__ row, int h) {
+    const f32x4* r4 = reinterpret_cast<const f32x4*>(row) + h;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 v = r4[8 * t + 2 * g];
+            x[t][4 * g + 0] += v[0]; x[t][4 * g + 1] += v[1]; x[t][4 * g + 2] += v[2]; x[t][4 * g + 3] += v[3];
+        }
+}
+
+template <int NT>
+DEVINL void store_frag(float* __restrict__ row, const f32x16 (&x)[NT], int h) {
+    f32x4* r4 = reinterpret_cast<f32x4*>(row) + h;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            f32x4 v;
+            v[0] = x[t][4 * g + 0]; v[1] = x[t][4 * g + 1]; v[2] = x[t][4 * g + 2]; v[3] = x[t][4 * g + 3];
+            r4[8 * t + 2 * g] = v;
+        }
+}
+
+// table (bias / gamma / beta) in fragment order: float4 tab[4*NT][2]
+template <int NT>
+DEVINL void tab_frag(f32x16 (&x)[NT], const float* tab, int h) {
+    const f32x4* t4 = reinterpret_cast<const f32x4*>(tab) + h;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 v = t4[2 * (4 * t + g)];
+            x[t][4 * g + 0] = v[0]; x[t][4 * g + 1] = v[1]; x[t][4 * g + 2] = v[2]; x[t][4 * g + 3] = v[3];
+        }
+}
+
+template <int NT>
+DEVINL void zero_frag(f32x16 (&x)[NT]) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int k = 0; k < 16; ++k) x[t][k] = 0.f;
+}
+
+template <int NT>
+DEVINL void relu_frag(f32x16 (&x)[NT]) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int k = 0; k < 16; ++k) x[t][k] = fmaxf(x[t][k], 0.f);
+}
+
+// ------------------------------------------------------------------------------------------------
+// One L x L weight chunk:  acc[feature][row] += W^T * in   (16*NT k-steps x NT MFMA 32x32x2 f32)
+// Weight fragment layout (host: pack_chunk): w[(j*64 + lane)*NT + t] = W[kbase + phi(j,h)][32t + i],
+// lane = 32h + i.  RES: w is in LDS; else global (L2-resident), streamed through a register ring.
+// ------------------------------------------------------------------------------------------------
+template <int NT> struct AVec;
+template <> struct AVec<4> { typedef f32x4 T; };
+template <> struct AVec<2> { typedef f32x2 T; };
+template <> struct AVec<1> { typedef float T; };
+
+template <int NT> DEVINL float aget(const typename AVec<NT>::T& a, int t) { return a[t]; }
+template <> DEVINL float aget<1>(const float& a, int) { return a; }
+
+template <int NT, bool RES>
+DEVINL void mfma_chunk(f32x16 (&acc)[NT], const f32x16 (&in)[NT], const float* w, int lane) {
+    typedef typename AVec<NT>::T AV;
+    constexpr int J = 16 * NT;
+    const AV* wv = reinterpret_cast<const AV*>(w) + lane;
+    if constexpr (RES) {
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+            const AV a = wv[j * 64];
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(aget<NT>(a, t), in[j >> 4][j & 15], acc[t], 0, 0, 0);
+        }
+    } else {
+        constexpr int PF = 4;  // k-steps in flight: 4 x (NT MFMA x 64 cyc) of cover for an L2 hit
+        AV ring[PF];
+#pragma unroll
+        for (int p = 0; p < PF; ++p) ring[p] = wv[p * 64];
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+            const AV a = ring[j % PF];
+            if (j + PF < J) ring[j % PF] = wv[(j + PF) * 64];
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(aget<NT>(a, t), in[j >> 4][j & 15], acc[t], 0, 0, 0);
+        }
+    }
+}
+
+// LayerNorm over the row's L features: 16*NT in this lane + 16*NT in lane^32.  Biased variance.
+template <int NT>
+DEVINL void layer_norm_frag(f32x16 (&x)[NT], const float* gamma, const float* beta, int h) {
+    constexpr float invL = 1.0f / (32 * NT);
+    float s = 0.f;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int k = 0; k < 16; ++k) s += x[t][k];
+    s += __shfl_xor(s, 32, 64);
+    const float mean = s * invL;
+    float q = 0.f;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const float d = x[t][k] - mean;
+            x[t][k] = d;
+            q += d * d;
+        }
+    q += __shfl_xor(q, 32, 64);
+    const float rstd = 1.0f / sqrtf(q * invL + LN_EPS);
+    const f32x4* g4 = reinterpret_cast<const f32x4*>(gamma) + h;
+    const f32x4* b4 = reinterpret_cast<const f32x4*>(beta) + h;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 gv = g4[2 * (4 * t + g)];
+            const f32x4 bv = b4[2 * (4 * t + g)];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) x[t][4 * g + i] = x[t][4 * g + i] * rstd * gv[i] + bv[i];
+        }
+}
+
+// ------------------------------------------------------------------------------------------------
+// cooperative global -> LDS copy of resident weight chunks + tables (once per block; persistent grid)
+// ------------------------------------------------------------------------------------------------
+DEVINL void copy_to_lds(float* dst, const float* __restrict__ src, int nfloats) {
+    const f32x4* s4 = reinterpret_cast<const f32x4*>(src);
+    f32x4* d4 = reinterpret_cast<f32x4*>(dst);
+    for (int i = threadIdx.x; i < nfloats / 4; i += blockDim.x) d4[i] = s4[i];
+}
+
+// XCD-aware persistent tile walk: blocks b and b+8 share an XCD (round-robin dispatch), so every XCD
+// gets one contiguous range of tiles and its waves sweep it interleaved -> gathered P/Q rows of
+// neighbouring tiles are served by that XCD's L2.  Speed only; any placement is correct.
+struct TileWalk {
+    int tile, end, stride;
+    DEVINL TileWalk(int ntiles, int wave) {
+        const int xcd = blockIdx.x % NUM_XCD;
+        const int wpb = blockDim.x >> 6;
+        const int per = (ntiles + NUM_XCD - 1) / NUM_XCD;
+        const int nb = (gridDim.x - xcd + NUM_XCD - 1) / NUM_XCD;  // blocks on this XCD label
+        tile = xcd * per + (blockIdx.x / NUM_XCD) * wpb + wave;
+        end = min(xcd * per + per, ntiles);
+        stride = nb * wpb;
+    }
+};
+
+template <int CTRL, int ROWMASK>
+DEVINL float dpp_zero(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROWMASK, 0xF, true));
+}
+
+// ================================================================================================
+// Processor edge step (K3+K4+K5): gather, edge MLP, LayerNorm, residual, segmented scatter.
+// chunk[0]=W2 chunk[1]=W3 chunk[2]=W1[2L:3L];  NRES leading chunks are LDS-resident.
+// ================================================================================================
+template <int NT, int NRES>
+__global__ __launch_bounds__(512, 2) void k_edge_step(const EdgeArgs a) {
+    constexpr int L = 32 * NT, CH = 16 * NT * 64 * NT;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+#pragma unroll
+    for (int r = 0; r < NRES; ++r) copy_to_lds(smem + r * CH, a.chunk[r], CH);
+    float* tb = smem + NRES * CH;
+    copy_to_lds(tb, a.tabs, T_COUNT * L);
+    __syncthreads();
+
+    const int lane0 = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const float* w2 = NRES > 0 ? smem : a.chunk[0];
+    const float* w3 = NRES > 1 ? smem + CH : a.chunk[1];
+    const float* w1 = NRES > 2 ? smem + 2 * CH : a.chunk[2];
+
+    for (TileWalk tw(a.ntiles, wave); tw.tile < tw.end; tw.tile += tw.stride) {
+        OPAQUE_LANE();
+        const int tile = tw.tile;
+        const int64_t e0 = (int64_t)tile * TILE;
+        const int64_t eid = e0 + c;
+        const bool valid = eid < a.E;
+        const int s = valid ? a.snd[eid] : 0;
+        const int r = valid ? a.rcv[eid] : 0;
+        float* erow = a.Elat + (valid ? eid : 0) * L;
+
+        f32x16 x[NT], acc[NT], y[NT];
+        load_frag<NT>(acc, a.P + (int64_t)s * L, h);
+        add_frag<NT>(acc, a.Q + (int64_t)r * L, h);
+        load_frag<NT>(x, erow, h);
+
+        mfma_chunk<NT, (NRES > 2)>(acc, x, w1, lane);          // layer 1 (edge part; P,Q,b1 preloaded)
+        relu_frag<NT>(acc);
+        tab_frag<NT>(y, tb + T_B2 * L, h);
+        mfma_chunk<NT, (NRES > 0)>(y, acc, w2, lane);          // layer 2
+        relu_frag<NT>(y);
+        tab_frag<NT>(acc, tb + T_B3 * L, h);
+        mfma_chunk<NT, (NRES > 1)>(acc, y, w3, lane);          // layer 3
+        layer_norm_frag<NT>(acc, tb + T_GAMMA * L, tb + T_BETA * L, h);   // acc = e'
+
+#pragma unroll
+        for (int t = 0; t < NT; ++t) x[t] += acc[t];            // e <- e + e'
+        if (valid) store_frag<NT>(erow, x, h);
+
+        // ---- segmented sum of e' over runs of equal receiver (both halves see the same structure)
+        const int reff = valid ? r : (-1 - c);
+        const int rprev = __shfl_up(reff, 1, 32);
+        const int rnext = __shfl_down(reff, 1, 32);
+        const bool head = (c == 0) || (reff != rprev);
+        const unsigned hm = (unsigned)__ballot(head);
+        const int start = 31 - __clz((int)(hm & (0xFFFFFFFFu >> (31 - c))));
+        const int st_in = max(start, c & 16);
+        const bool c1 = (c - 1 >= st_in), c2 = (c - 2 >= st_in), c4 = (c - 4 >= st_in), c8 = (c - 8 >= st_in);
+        const bool cx = (c >= 16) && (start <= 15);
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                // DPP reads must run with every lane active (an EXEC-masked source lane reads as 0), so the
+                // shifted value is formed unconditionally and selected afterwards (v_add_dpp + v_cndmask).
+                float v = acc[t][k];
+                float u;
+                u = v + dpp_zero<0x111, 0xF>(v); v = c1 ? u : v;   // row_shr:1
+                u = v + dpp_zero<0x112, 0xF>(v); v = c2 ? u : v;   // row_shr:2
+                u = v + dpp_zero<0x114, 0xF>(v); v = c4 ? u : v;   // row_shr:4
+                u = v + dpp_zero<0x118, 0xF>(v); v = c8 ? u : v;   // row_shr:8
+                u = v + dpp_zero<0x142, 0xA>(v); v = cx ? u : v;   // row_bcast:15 into rows 1 and 3
+                acc[t][k] = v;
+            }
+        const bool tail = valid && ((c == 31) || (reff != rnext));
+        const int r_before = (tile > 0) ? a.rcv[e0 - 1] : -1;                 // wave-uniform
+        const int r_after = (e0 + TILE < a.E) ? a.rcv[e0 + TILE] : -2;        // wave-uniform
+        const int r_first = __builtin_amdgcn_readfirstlane(reff);
+        const bool sl = (start == 0) && (r_before == r_first);
+        const bool sr = (c == 31) && (r_after == reff);
+        float* dst = sl ? a.CARRY + (int64_t)(2 * tile) * L
+                        : (sr ? a.CARRY + (int64_t)(2 * tile + 1) * L : a.AGG + (int64_t)r * L);
+        if (tail) store_frag<NT>(dst, acc, h);
+    }
+}
+
+// ================================================================================================
+// Processor node step (K6) + projection of next step's P,Q.
+// chunk[0]=W2 chunk[1]=W3 chunk[2]=W1[0:L] chunk[3]=W1[L:2L] chunk[4]=WP chunk[5]=WQ
+// ================================================================================================
+template <int NT, int NRES>
+__global__ __launch_bounds__(512, 2) void k_node_step(const NodeArgs a) {
+    constexpr int L = 32 * NT, CH = 16 * NT * 64 * NT;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    if (a.mode != 2) {
+#pragma unroll
+        for (int r = 0; r < (NRES < 4 ? NRES : 4); ++r) copy_to_lds(smem + r * CH, a.chunk[r], CH);
+    }
+    if (NRES > 4) {
+#pragma unroll
+        for (int r = 4; r < NRES; ++r) copy_to_lds(smem + r * CH, a.chunk[r], CH);
+    }
+    float* tb = smem + NRES * CH;
+    copy_to_lds(tb, a.tabs, T_COUNT * L);
+    __syncthreads();
+
+    const int lane0 = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const float* w2 = NRES > 0 ? smem : a.chunk[0];
+    const float* w3 = NRES > 1 ? smem + CH : a.chunk[1];
+    const float* w1v = NRES > 2 ? smem + 2 * CH : a.chunk[2];
+    const float* w1a = NRES > 3 ? smem + 3 * CH : a.chunk[3];
+    const float* wp = NRES > 4 ? smem + 4 * CH : a.chunk[4];
+    const float* wq = NRES > 5 ? smem + 5 * CH : a.chunk[5];
+
+    for (TileWalk tw(a.ntiles, wave); tw.tile < tw.end; tw.tile += tw.stride) {
+        OPAQUE_LANE();
+        const int n = tw.tile * TILE + c;
+        const bool valid = n < a.n;
+        const int nn = valid ? n : 0;
+        float* vrow = a.V + (int64_t)nn * L;
+        f32x16 v[NT], acc[NT], y[NT];
+        load_frag<NT>(v, vrow, h);
+
+        if (a.mode != 2) {
+            // aggregated messages: AGG row, or carry rows when the receiver's edge run straddles tiles
+            const int a0 = valid ? a.rowptr[nn] : 0, a1 = valid ? a.rowptr[nn + 1] : 0;
+            const int T1 = a0 >> 5, T2 = (a1 - 1) >> 5;
+            const int extra = (a1 > a0 && T2 > T1) ? (T2 - T1) : 0;
+            const float* src0 = (a1 == a0) ? a.AGG + (int64_t)a.n * L
+                                           : (extra ? a.CARRY + (int64_t)(2 * T1 + 1) * L : a.AGG + (int64_t)nn * L);
+            load_frag<NT>(y, src0, h);
+            for (int q = 1; __any(q <= extra); ++q)
+                if (q <= extra) add_frag<NT>(y, a.CARRY + (int64_t)(2 * (T1 + q)) * L, h);
+
+            tab_frag<NT>(acc, tb + T_B1 * L, h);
+            mfma_chunk<NT, (NRES > 2)>(acc, v, w1v, lane);     // layer 1, node part
+            mfma_chunk<NT, (NRES > 3)>(acc, y, w1a, lane);     // layer 1, aggregate part
+            relu_frag<NT>(acc);
+            tab_frag<NT>(y, tb + T_B2 * L, h);
+            mfma_chunk<NT, (NRES > 0)>(y, acc, w2, lane);      // layer 2
+            relu_frag<NT>(y);
+            tab_frag<NT>(acc, tb + T_B3 * L, h);
+            mfma_chunk<NT, (NRES > 1)>(acc, y, w3, lane);      // layer 3
+            layer_norm_frag<NT>(acc, tb + T_GAMMA * L, tb + T_BETA * L, h);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) v[t] += acc[t];        // v <- v + v'
+            if (valid) store_frag<NT>(vrow, v, h);
+        }
+        if (a.mode != 0) {
+            zero_frag<NT>(acc);
+            mfma_chunk<NT, (NRES > 4)>(acc, v, wp, lane);
+            if (valid) store_frag<NT>(a.P + (int64_t)nn * L, acc, h);
+            tab_frag<NT>(y, tb + T_BQ * L, h);
+            mfma_chunk<NT, (NRES > 5)>(y, v, wq, lane);
+            if (valid) store_frag<NT>(a.Q + (int64_t)nn * L, y, h);
+        }
+    }
+}
+
+// first dense layer with a tiny input width: acc[feature] = b1 + sum_k x[k] * W1[k][feature]  (VALU)
+template <int NT>
+DEVINL void first_layer(f32x16 (&acc)[NT], const float* w1f, int k, float xk, int h) {
+    constexpr int L = 32 * NT;
+    const f32x4* w4 = reinterpret_cast<const f32x4*>(w1f + (int64_t)k * L) + h;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 w = w4[2 * (4 * t + g)];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[t][4 * g + i] = fmaf(xk, w[i], acc[t][4 * g + i]);
+        }
+}
+
+// ================================================================================================
+// Encoder, node side (K0a+K1) + projection of step-0 P,Q.  chunk[0]=W2 [1]=W3 [2]=WP [3]=WQ
+// ================================================================================================
+template <int NT, int NRES>
+__global__ __launch_bounds__(512, 2) void k_enc_node(const EncNodeArgs a) {
+    constexpr int L = 32 * NT, CH = 16 * NT * 64 * NT;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+#pragma unroll
+    for (int r = 0; r < NRES; ++r) copy_to_lds(smem + r * CH, a.chunk[r], CH);
+    float* tb = smem + NRES * CH;
+    copy_to_lds(tb, a.tabs, T_COUNT * L);
+    __syncthreads();
+    const int lane0 = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const float* w2 = NRES > 0 ? smem : a.chunk[0];
+    const float* w3 = NRES > 1 ? smem + CH : a.chunk[1];
+    const float* wp = NRES > 2 ? smem + 2 * CH : a.chunk[2];
+    const float* wq = NRES > 3 ? smem + 3 * CH : a.chunk[3];
+
+    for (TileWalk tw(a.ntiles, wave); tw.tile < tw.end; tw.tile += tw.stride) {
+        OPAQUE_LANE();
+        const int n = tw.tile * TILE + c;
+        const bool valid = n < a.n;
+        const int nn = valid ? n : 0;
+        const int64_t g = a.gid[nn];
+        f32x16 acc[NT], y[NT];
+        tab_frag<NT>(acc, tb + T_B1 * L, h);
+        const int Fn = a.wa + a.wb;
+        for (int k = 0; k < Fn; ++k) {
+            float xk = (k < a.wa) ? a.srcA[g * a.wa + k] : a.srcB[g * a.wb + (k - a.wa)];
+            if (a.scale) xk = fmaf(xk, a.scale[k], a.shift[k]);
+            first_layer<NT>(acc, a.w1f, k, xk, h);
+        }
+        relu_frag<NT>(acc);
+        tab_frag<NT>(y, tb + T_B2 * L, h);
+        mfma_chunk<NT, (NRES > 0)>(y, acc, w2, lane);
+        relu_frag<NT>(y);
+        tab_frag<NT>(acc, tb + T_B3 * L, h);
+        mfma_chunk<NT, (NRES > 1)>(acc, y, w3, lane);
+        layer_norm_frag<NT>(acc, tb + T_GAMMA * L, tb + T_BETA * L, h);
+        if (valid) store_frag<NT>(a.V + (int64_t)nn * L, acc, h);
+        zero_frag<NT>(y);
+        mfma_chunk<NT, (NRES > 2)>(y, acc, wp, lane);
+        if (valid) store_frag<NT>(a.P + (int64_t)nn * L, y, h);
+        tab_frag<NT>(y, tb + T_BQ * L, h);
+        mfma_chunk<NT, (NRES > 3)>(y, acc, wq, lane);
+        if (valid) store_frag<NT>(a.Q + (int64_t)nn * L, y, h);
+    }
+}
+
+// ================================================================================================
+// Encoder, edge side (K0b+K2).  chunk[0]=W2 [1]=W3
+// ================================================================================================
+template <int NT, int NRES>
+__global__ __launch_bounds__(512, 2) void k_enc_edge(const EncEdgeArgs a) {
+    constexpr int L = 32 * NT, CH = 16 * NT * 64 * NT;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+#pragma unroll
+    for (int r = 0; r < NRES; ++r) copy_to_lds(smem + r * CH, a.chunk[r], CH);
+    float* tb = smem + NRES * CH;
+    copy_to_lds(tb, a.tabs, T_COUNT * L);
+    __syncthreads();
+    const int lane0 = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const float* w2 = NRES > 0 ? smem : a.chunk[0];
+    const float* w3 = NRES > 1 ? smem + CH : a.chunk[1];
+
+    for (TileWalk tw(a.ntiles, wave); tw.tile < tw.end; tw.tile += tw.stride) {
+        OPAQUE_LANE();
+        const int64_t eid = (int64_t)tw.tile * TILE + c;
+        const bool valid = eid < a.E;
+        const int64_t ee = valid ? eid : 0;
+        const int64_t g = a.gid[ee];
+        f32x16 acc[NT], y[NT];
+        tab_frag<NT>(acc, tb + T_B1 * L, h);
+        for (int k = 0; k < a.Fe; ++k) {
+            float xk = a.ef[g * a.Fe + k];
+            if (a.scale) xk = fmaf(xk, a.scale[k], a.shift[k]);
+            first_layer<NT>(acc, a.w1f, k, xk, h);
+        }
+        relu_frag<NT>(acc);
+        tab_frag<NT>(y, tb + T_B2 * L, h);
+        mfma_chunk<NT, (NRES > 0)>(y, acc, w2, lane);
+        relu_frag<NT>(y);
+        tab_frag<NT>(acc, tb + T_B3 * L, h);
+        mfma_chunk<NT, (NRES > 1)>(acc, y, w3, lane);
+        layer_norm_frag<NT>(acc, tb + T_GAMMA * L, tb + T_BETA * L, h);
+        if (valid) store_frag<NT>(a.Elat + ee * L, acc, h);
+    }
+}
+
+// ================================================================================================
+// Decoder (K7) + inverse normaliser + val_mask epilogue (K8).  chunk[0]=W1 [1]=W2
+// ================================================================================================
+template <int NT, int NRES>
+__global__ __launch_bounds__(512, 2) void k_decode(const DecArgs a) {
+    constexpr int L = 32 * NT, CH = 16 * NT * 64 * NT;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+#pragma unroll
+    for (int r = 0; r < NRES; ++r) copy_to_lds(smem + r * CH, a.chunk[r], CH);
+    float* tb = smem + NRES * CH;
+    copy_to_lds(tb, a.tabs, T_COUNT * L);
+    __syncthreads();
+    const int lane0 = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const float* w1 = NRES > 0 ? smem : a.chunk[0];
+    const float* w2 = NRES > 1 ? smem + CH : a.chunk[1];
+
+    for (TileWalk tw(a.ntiles, wave); tw.tile < tw.end; tw.tile += tw.stride) {
+        OPAQUE_LANE();
+        const int n = tw.tile * TILE + c;
+        const bool valid = n < a.n;
+        const int nn = valid ? n : 0;
+        f32x16 v[NT], acc[NT];
+        load_frag<NT>(v, a.V + (int64_t)nn * L, h);
+        tab_frag<NT>(acc, tb + T_B1 * L, h);
+        mfma_chunk<NT, (NRES > 0)>(acc, v, w1, lane);
+        relu_frag<NT>(acc);
+        tab_frag<NT>(v, tb + T_B2 * L, h);
+        mfma_chunk<NT, (NRES > 1)>(v, acc, w2, lane);
+        relu_frag<NT>(v);
+        const float m = a.mask ? a.mask[a.gid[nn]] : 1.0f;
+        for (int o = 0; o < a.O; ++o) {
+            const f32x4* w4 = reinterpret_cast<const f32x4*>(a.w3f + (int64_t)o * L) + h;
+            float s = 0.f;
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 w = w4[2 * (4 * t + g)];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) s = fmaf(v[t][4 * g + i], w[i], s);
+                }
+            s += __shfl_xor(s, 32, 64);
+            s += a.b3[o];
+            if (a.oscale) s = fmaf(s, a.oscale[o], a.oshift[o]);
+            s *= m;
+            if (valid && h == 0) a.out[(int64_t)nn * a.O + o] = s;
+        }
+    }
+}
+
+// ================================================================================================
+// small utility kernels
+// ================================================================================================
+__global__ void k_gather_rows(const float* __restrict__ src, const int32_t* __restrict__ idx, float* __restrict__ dst,
+                              int64_t rows, int L4) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * L4) return;
+    const int64_t r = i / L4;
+    const int q = (int)(i - r * L4);
+    reinterpret_cast<f32x4*>(dst)[i] = reinterpret_cast<const f32x4*>(src)[(int64_t)idx[r] * L4 + q];
+}
+
+DEVINL uint64_t splitmix64(uint64_t x) {
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+
+// N(0,1) keyed by (seed, global row id, feature): identical whatever the partition (KAT-7 at scale)
+__global__ void k_randn_rows(float* __restrict__ dst, const int64_t* __restrict__ gid64, const int32_t* __restrict__ gid32,
+                             int64_t rows, int L, uint64_t seed) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * L) return;
+    const int64_t r = i / L;
+    const int f = (int)(i - r * L);
+    const uint64_t g = gid64 ? (uint64_t)gid64[r] : (gid32 ? (uint64_t)gid32[r] : (uint64_t)r);
+    const uint64_t bits = splitmix64(seed ^ splitmix64(g * (uint64_t)L + (uint64_t)f));
+    const float u1 = ((float)(uint32_t)(bits >> 40) + 1.0f) * (1.0f / 16777216.0f);  // (0,1]
+    const float u2 = (float)(uint32_t)((bits >> 8) & 0xFFFFFF) * (1.0f / 16777216.0f);
+    dst[i] = sqrtf(-2.0f * logf(u1)) * cosf(6.28318530717958647692f * u2);
+}
+
+__global__ void k_checksum(const float* __restrict__ src, int64_t n, double* __restrict__ out2) {
+    double s = 0.0, q = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const double v = (double)src[i];
+        s += v;
+        q += v * v;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        s += __shfl_xor(s, off, 64);
+        q += __shfl_xor(q, off, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(out2, s);
+        atomicAdd(out2 + 1, q);
+    }
+}
+
+// ================================================================================================
+// launch wrappers
+// ================================================================================================
+static int g_num_cu = 0;
+static int num_cus() {
+    if (g_num_cu == 0) {
+        int dev = 0;
+        hipDeviceProp_t p;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount > 0)
+            g_num_cu = p.multiProcessorCount;
+        else
+            g_num_cu = 256;
+    }
+    return g_num_cu;
+}
+
+constexpr size_t LDS_BYTES = 160 * 1024;
+
+// resident chunks for L: chunk bytes = L*L*4; tables T_COUNT*L*4
+static int resident_chunks(int L, int want) {
+    const size_t ch = (size_t)L * L * 4, tabs = (size_t)T_COUNT * L * 4;
+    int r = (int)((LDS_BYTES - tabs) / ch);
+    return r < want ? r : want;
+}
+
+static LaunchCfg tile_launch(int L, int ntiles, int nres) {
+    LaunchCfg lc;
+    const int cus = num_cus();
+    int wpb = 8;
+    if (ntiles <= cus) wpb = 1;
+    else if (ntiles <= 2 * cus) wpb = 2;
+    else if (ntiles <= 4 * cus) wpb = 4;
+    int blocks = (ntiles + wpb - 1) / wpb;
+    if (blocks > cus) blocks = cus;
+    blocks = ((blocks + NUM_XCD - 1) / NUM_XCD) * NUM_XCD;
+    lc.blocks = blocks;
+    lc.threads = wpb * 64;
+    lc.lds = (size_t)nres * L * L * 4 + (size_t)T_COUNT * L * 4;
+    return lc;
+}
+
+template <typename K, typename A>
+static hipError_t launch_k(K kern, const A& a, const LaunchCfg& lc, hipStream_t s) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lc.lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, dim3(lc.blocks), dim3(lc.threads), lc.lds, s, a);
+    return hipGetLastError();
+}
+
+#define DISPATCH_L(KERN, WANT, ARGS, NTILES)                                                   \
+    do {                                                                                       \
+        if ((NTILES) <= 0) return hipSuccess;                                                  \
+        const int nres = resident_chunks(L, WANT);                                             \
+        const LaunchCfg lc = tile_launch(L, NTILES, nres);                                     \
+        if (L == 128) return launch_k(KERN<4, (WANT < 2 ? WANT : 2)>, ARGS, lc, s);            \
+        if (L == 64) return launch_k(KERN<2, WANT>, ARGS, lc, s);                              \
+        if (L == 32) return launch_k(KERN<1, WANT>, ARGS, lc, s);                              \
+        return hipErrorInvalidValue;                                                           \
+    } while (0)
+
+hipError_t launch_edge_step(int L, const EdgeArgs& a, hipStream_t s) { DISPATCH_L(k_edge_step, 3, a, a.ntiles); }
+hipError_t launch_node_step(int L, const NodeArgs& a, hipStream_t s) { DISPATCH_L(k_node_step, 6, a, a.ntiles); }
+hipError_t launch_enc_node(int L, const EncNodeArgs& a, hipStream_t s) { DISPATCH_L(k_enc_node, 4, a, a.ntiles); }
+hipError_t launch_enc_edge(int L, const EncEdgeArgs& a, hipStream_t s) { DISPATCH_L(k_enc_edge, 2, a, a.ntiles); }
+hipError_t launch_decode(int L, const DecArgs& a, hipStream_t s) { DISPATCH_L(k_decode, 2, a, a.ntiles); }
+
+hipError_t launch_gather_rows(const float* src, const int32_t* idx, float* dst, int64_t rows, int L, hipStream_t s) {
+    if (rows <= 0) return hipSuccess;
+    const int64_t n = rows * (L / 4);
+    hipLaunchKernelGGL(k_gather_rows, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src, idx, dst, rows, L / 4);
+    return hipGetLastError();
+}
+
+hipError_t launch_randn_rows(float* dst, const int64_t* gid64, const int32_t* gid32, int64_t rows, int L, uint64_t seed,
+                             hipStream_t s) {
+    if (rows <= 0) return hipSuccess;
+    const int64_t n = rows * L;
+    hipLaunchKernelGGL(k_randn_rows, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, dst, gid64, gid32, rows, L, seed);
+    return hipGetLastError();
+}
+
+hipError_t launch_checksum(const float* src, int64_t n, double* out2, hipStream_t s) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_checksum, dim3(1024), dim3(256), 0, s, src, n, out2);
+    return hipGetLastError();
+}
+
+}  // namespace mgn

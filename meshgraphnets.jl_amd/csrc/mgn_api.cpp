@@ -1,0 +1,854 @@
+// C ABI of the engine (include/mgn_hip.h).  Host orchestration only: parameter repacking into MFMA
+// fragment order, device buffers, kernel sequencing.  All arithmetic is in kernels.hip; there is no
+// CPU compute path here.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/mgn_hip.h"
+#include "graph_host.h"
+#include "kernels.h"
+
+using namespace mgn;
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    ~DevBuf() { release(); }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+    }
+    hipError_t ensure(size_t n) {
+        if (n <= bytes && p) return hipSuccess;
+        release();
+        if (n == 0) n = 16;
+        hipError_t e = hipMalloc(&p, n);
+        if (e == hipSuccess) bytes = n;
+        return e;
+    }
+    template <typename T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+// offsets (in floats) of one MLP inside the packed parameter vector
+struct MlpOff {
+    size_t W[3], b[3], gamma = 0, beta = 0;
+    int in = 0, out = 0;
+    bool ln = false;
+};
+
+enum Family { F_EDGE = 0, F_NODE, F_ENC, F_DEC, F_HALO, F_NFAM };
+
+struct ProfRec {
+    int fam;
+    hipEvent_t a, b;
+};
+
+}  // namespace
+
+struct mgn_engine {
+    mgn_config cfg{};
+    std::string err;
+    hipStream_t stream = nullptr;
+    hipStream_t own_stream = nullptr;
+    bool host_only = false;
+
+    // parameters
+    bool have_params = false;
+    std::vector<float> params;  // packed, host
+    MlpOff enc_node, enc_edge, dec;
+    std::vector<MlpOff> pe, pn;
+    DevBuf wfrag;     // all chunks + tables + small tensors, fragment order
+    // offsets into wfrag (floats)
+    struct StepOff { size_t e_ch[3], e_tabs, n_ch[6], n_tabs; };
+    std::vector<StepOff> soff;
+    size_t en_ch[4] = {0, 0, 0, 0}, en_tabs = 0, en_w1f = 0;
+    size_t ee_ch[2] = {0, 0}, ee_tabs = 0, ee_w1f = 0;
+    size_t de_ch[2] = {0, 0}, de_tabs = 0, de_w3f = 0, de_b3 = 0;
+
+    // norms (device): node scale/shift [Fn], edge [Fe], out [O]; null = identity
+    DevBuf norms;
+    bool have_nnorm = false, have_enorm = false, have_onorm = false;
+
+    // graph
+    bool have_graph = false;
+    LocalGraph g;
+    int32_t ntiles_e = 0, ntiles_n = 0;
+    DevBuf d_snd, d_rcv, d_rowptr, d_own_gid, d_edge_gid, d_send_idx;
+
+    // latents and I/O
+    DevBuf V, P, Q, Elat, AGG, CARRY, d_nfA, d_nfB, d_ef, d_out, d_mask, d_sum;
+    int32_t in_wa = 0, in_wb = 0;
+    bool have_mask = false;
+
+    // profiling
+    bool prof = false;
+    std::vector<ProfRec> recs;
+};
+
+namespace {
+
+int fail(mgn_engine* h, int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (h) h->err = buf; else g_create_error = buf;
+    return code;
+}
+
+#define HIPCHK(h, expr)                                                                              \
+    do {                                                                                             \
+        hipError_t _e = (expr);                                                                      \
+        if (_e != hipSuccess)                                                                        \
+            return fail(h, _e == hipErrorOutOfMemory ? MGN_E_OOM : MGN_E_HIP, "%s failed: %s (%s:%d)", #expr, \
+                        hipGetErrorString(_e), __FILE__, __LINE__);                                  \
+    } while (0)
+
+bool cfg_ok(const mgn_config* c, std::string& why) {
+    if (!c) { why = "null config"; return false; }
+    if (c->Fn < 1 || c->Fe < 1 || c->O < 1) { why = "Fn, Fe, O must be >= 1"; return false; }
+    if (c->L != 32 && c->L != 64 && c->L != 128) { why = "L must be 32, 64 or 128 on the HIP path"; return false; }
+    if (c->hidden_layers != 2) { why = "hidden_layers must be 2 on the HIP path"; return false; }
+    if (c->mps < 1) { why = "mps must be >= 1"; return false; }
+    if (c->dtype != MGN_F32) { why = "only MGN_F32 is implemented"; return false; }
+    if (c->nranks < 1 || c->rank < 0 || c->rank >= c->nranks) { why = "bad rank/nranks"; return false; }
+    return true;
+}
+
+size_t mlp_layout(MlpOff& m, size_t off, int in, int L, int out, bool ln) {
+    const int dims[4] = {in, L, L, out};
+    m.in = in;
+    m.out = out;
+    m.ln = ln;
+    for (int i = 0; i < 3; ++i) {
+        m.W[i] = off;
+        off += (size_t)dims[i] * dims[i + 1];
+        m.b[i] = off;
+        off += dims[i + 1];
+    }
+    if (ln) {
+        m.gamma = off;
+        off += out;
+        m.beta = off;
+        off += out;
+    }
+    return off;
+}
+
+size_t layout_all(mgn_engine* h) {
+    const mgn_config& c = h->cfg;
+    size_t off = 0;
+    off = mlp_layout(h->enc_node, off, c.Fn, c.L, c.L, true);
+    off = mlp_layout(h->enc_edge, off, c.Fe, c.L, c.L, true);
+    h->pe.resize(c.mps);
+    h->pn.resize(c.mps);
+    for (int k = 0; k < c.mps; ++k) {
+        off = mlp_layout(h->pe[k], off, 3 * c.L, c.L, c.L, true);
+        off = mlp_layout(h->pn[k], off, 2 * c.L, c.L, c.L, true);
+    }
+    off = mlp_layout(h->dec, off, c.L, c.L, c.O, false);
+    return off;
+}
+
+inline int phi(int j, int hh) { return 32 * (j >> 4) + (j & 3) + 8 * ((j & 15) >> 2) + 4 * hh; }
+
+// L x L chunk of W (row-major [K][ldw], rows kbase.., all L output columns) -> fragment order
+void pack_chunk(float* dst, const float* W, int ldw, int kbase, int L) {
+    const int NT = L / 32, J = L / 2;
+    for (int j = 0; j < J; ++j)
+        for (int lane = 0; lane < 64; ++lane) {
+            const int hh = lane >> 5, i = lane & 31;
+            const float* wrow = W + (size_t)(kbase + phi(j, hh)) * ldw;
+            for (int t = 0; t < NT; ++t) dst[((size_t)j * 64 + lane) * NT + t] = wrow[32 * t + i];
+        }
+}
+
+// vector of L values (stride between consecutive features = stride) -> table fragment order
+void pack_tab(float* dst, const float* vec, int L, int stride = 1) {
+    for (int m = 0; m < L / 8; ++m)
+        for (int hh = 0; hh < 2; ++hh)
+            for (int i = 0; i < 4; ++i)
+                dst[(m * 2 + hh) * 4 + i] = vec ? vec[(size_t)(32 * (m >> 2) + 8 * (m & 3) + 4 * hh + i) * stride] : 0.f;
+}
+
+int need(mgn_engine* h, bool params, bool graph) {
+    if (!h) return MGN_E_ARG;
+    if (h->host_only) return fail(h, MGN_E_HIP, "host-only handle (MGN_DEVICE_NONE): no compute path; create the handle on a HIP device");
+    if (params && !h->have_params) return fail(h, MGN_E_STATE, "mgn_set_params has not been called");
+    if (graph && !h->have_graph) return fail(h, MGN_E_STATE, "mgn_set_graph has not been called");
+    return MGN_OK;
+}
+
+struct ProfScope {
+    mgn_engine* h;
+    int fam;
+    hipEvent_t a = nullptr, b = nullptr;
+    ProfScope(mgn_engine* h_, int fam_) : h(h_), fam(fam_) {
+        if (h->prof && hipEventCreate(&a) == hipSuccess && hipEventCreate(&b) == hipSuccess) (void)hipEventRecord(a, h->stream);
+    }
+    ~ProfScope() {
+        if (a && b) {
+            (void)hipEventRecord(b, h->stream);
+            h->recs.push_back({fam, a, b});
+        }
+    }
+};
+
+const float* W(const mgn_engine* h, size_t off) { return h->wfrag.as<float>() + off; }
+
+int alloc_latents(mgn_engine* h) {
+    const int L = h->cfg.L;
+    const LocalGraph& g = h->g;
+    HIPCHK(h, h->V.ensure((size_t)g.n_own * L * 4));
+    HIPCHK(h, h->P.ensure((size_t)(g.n_own + g.n_halo) * L * 4));
+    HIPCHK(h, h->Q.ensure((size_t)g.n_own * L * 4));
+    HIPCHK(h, h->Elat.ensure((size_t)g.e_local * L * 4));
+    HIPCHK(h, h->AGG.ensure((size_t)(g.n_own + 1) * L * 4));
+    HIPCHK(h, h->CARRY.ensure((size_t)2 * (h->ntiles_e > 0 ? h->ntiles_e : 1) * L * 4));
+    HIPCHK(h, h->d_out.ensure((size_t)g.n_own * h->cfg.O * 4));
+    HIPCHK(h, h->d_sum.ensure(4 * sizeof(double)));
+    // row n_own of AGG is the all-zero row read for receivers without incoming edges
+    HIPCHK(h, hipMemsetAsync(h->AGG.p, 0, (size_t)(g.n_own + 1) * L * 4, h->stream));
+    HIPCHK(h, hipMemsetAsync(h->P.p, 0, (size_t)(g.n_own + g.n_halo) * L * 4, h->stream));
+    return MGN_OK;
+}
+
+EdgeArgs edge_args(mgn_engine* h, int k) {
+    EdgeArgs a{};
+    a.snd = h->d_snd.as<int32_t>();
+    a.rcv = h->d_rcv.as<int32_t>();
+    a.E = h->g.e_local;
+    a.ntiles = h->ntiles_e;
+    a.P = h->P.as<float>();
+    a.Q = h->Q.as<float>();
+    a.Elat = h->Elat.as<float>();
+    a.AGG = h->AGG.as<float>();
+    a.CARRY = h->CARRY.as<float>();
+    for (int i = 0; i < 3; ++i) a.chunk[i] = W(h, h->soff[k].e_ch[i]);
+    a.tabs = W(h, h->soff[k].e_tabs);
+    return a;
+}
+
+NodeArgs node_args(mgn_engine* h, int k, int mode) {
+    NodeArgs a{};
+    a.n = h->g.n_own;
+    a.ntiles = h->ntiles_n;
+    a.rowptr = h->d_rowptr.as<int32_t>();
+    a.V = h->V.as<float>();
+    a.AGG = h->AGG.as<float>();
+    a.CARRY = h->CARRY.as<float>();
+    a.P = h->P.as<float>();
+    a.Q = h->Q.as<float>();
+    for (int i = 0; i < 6; ++i) a.chunk[i] = W(h, h->soff[k].n_ch[i]);
+    a.tabs = W(h, h->soff[k].n_tabs);
+    a.mode = mode;
+    return a;
+}
+
+}  // namespace
+
+// =================================================================================================
+extern "C" {
+
+int mgn_create(const mgn_config* cfg, mgn_handle** out) {
+    if (!out) return fail(nullptr, MGN_E_ARG, "null out pointer");
+    *out = nullptr;
+    std::string why;
+    if (!cfg_ok(cfg, why)) return fail(nullptr, MGN_E_ARG, "mgn_create: %s", why.c_str());
+    if (cfg->device == MGN_DEVICE_NONE) {
+        mgn_engine* ho = new (std::nothrow) mgn_engine();
+        if (!ho) return fail(nullptr, MGN_E_OOM, "host allocation failed");
+        ho->cfg = *cfg;
+        ho->host_only = true;
+        layout_all(ho);
+        *out = ho;
+        return MGN_OK;
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(nullptr, MGN_E_HIP, "mgn_create: no HIP device available (this engine has no CPU fallback)");
+    if (cfg->device >= 0) {
+        if (cfg->device >= ndev) return fail(nullptr, MGN_E_ARG, "mgn_create: device %d out of range (%d devices)", cfg->device, ndev);
+        if (hipSetDevice(cfg->device) != hipSuccess) return fail(nullptr, MGN_E_HIP, "mgn_create: hipSetDevice failed");
+    }
+    mgn_engine* h = new (std::nothrow) mgn_engine();
+    if (!h) return fail(nullptr, MGN_E_OOM, "host allocation failed");
+    h->cfg = *cfg;
+    if (hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking) != hipSuccess) {
+        delete h;
+        return fail(nullptr, MGN_E_HIP, "mgn_create: hipStreamCreate failed");
+    }
+    h->stream = h->own_stream;
+    layout_all(h);
+    *out = h;
+    return MGN_OK;
+}
+
+void mgn_destroy(mgn_handle* h) {
+    if (!h) return;
+    if (h->host_only) { delete h; return; }
+    (void)hipStreamSynchronize(h->stream);
+    for (auto& r : h->recs) {
+        (void)hipEventDestroy(r.a);
+        (void)hipEventDestroy(r.b);
+    }
+    if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
+    delete h;
+}
+
+const char* mgn_last_error(const mgn_handle* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+int mgn_set_stream(mgn_handle* h, void* hip_stream) {
+    if (int rc = need(h, false, false)) return rc;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    h->stream = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : h->own_stream;
+    return MGN_OK;
+}
+
+int mgn_synchronize(mgn_handle* h) {
+    if (int rc = need(h, false, false)) return rc;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return MGN_OK;
+}
+
+size_t mgn_param_count(const mgn_config* c) {
+    std::string why;
+    if (!c || c->Fn < 1 || c->Fe < 1 || c->O < 1 || c->L < 1 || c->hidden_layers != 2 || c->mps < 1) return 0;
+    mgn_engine tmp;
+    tmp.cfg = *c;
+    return layout_all(&tmp);
+}
+
+int mgn_set_params(mgn_handle* h, const float* packed, size_t n) {
+    if (!h || !packed) return fail(h, MGN_E_ARG, "mgn_set_params: null argument");
+    if (int rc = need(h, false, false)) return rc;
+    const size_t want = layout_all(h);
+    if (n != want) return fail(h, MGN_E_ARG, "mgn_set_params: got %zu floats, model needs %zu", n, want);
+    h->params.assign(packed, packed + n);
+    const float* p = h->params.data();
+    const mgn_config& c = h->cfg;
+    const int L = c.L;
+    const size_t CH = (size_t)L * L, TB = (size_t)T_COUNT * L;
+
+    std::vector<float> f;
+    auto add_chunk = [&](const float* Wm, int ldw, int kbase) {
+        const size_t off = f.size();
+        f.resize(off + CH);
+        pack_chunk(f.data() + off, Wm, ldw, kbase, L);
+        return off;
+    };
+    auto add_tabs = [&](const float* b1, const float* b2, const float* b3, const float* ga, const float* be, const float* bq) {
+        const size_t off = f.size();
+        f.resize(off + TB);
+        const float* src[T_COUNT] = {b1, b2, b3, ga, be, bq};
+        for (int t = 0; t < T_COUNT; ++t) pack_tab(f.data() + off + (size_t)t * L, src[t], L);
+        return off;
+    };
+    auto add_w1f = [&](const float* W1, int K) {  // [K][L] -> per-k fragment tables
+        const size_t off = f.size();
+        f.resize(off + (size_t)K * L);
+        for (int k = 0; k < K; ++k) pack_tab(f.data() + off + (size_t)k * L, W1 + (size_t)k * L, L);
+        return off;
+    };
+
+    const MlpOff& e0 = h->pe[0];
+    // encoder, node side (+ projection onto step-0 edge-MLP layer 1)
+    {
+        const MlpOff& m = h->enc_node;
+        h->en_ch[0] = add_chunk(p + m.W[1], L, 0);
+        h->en_ch[1] = add_chunk(p + m.W[2], L, 0);
+        h->en_ch[2] = add_chunk(p + e0.W[0], L, 0);
+        h->en_ch[3] = add_chunk(p + e0.W[0], L, L);
+        h->en_tabs = add_tabs(p + m.b[0], p + m.b[1], p + m.b[2], p + m.gamma, p + m.beta, p + e0.b[0]);
+        h->en_w1f = add_w1f(p + m.W[0], c.Fn);
+    }
+    {
+        const MlpOff& m = h->enc_edge;
+        h->ee_ch[0] = add_chunk(p + m.W[1], L, 0);
+        h->ee_ch[1] = add_chunk(p + m.W[2], L, 0);
+        h->ee_tabs = add_tabs(p + m.b[0], p + m.b[1], p + m.b[2], p + m.gamma, p + m.beta, nullptr);
+        h->ee_w1f = add_w1f(p + m.W[0], c.Fe);
+    }
+    h->soff.resize(c.mps);
+    for (int k = 0; k < c.mps; ++k) {
+        const MlpOff& me = h->pe[k];
+        const MlpOff& mn = h->pn[k];
+        const MlpOff& nx = h->pe[k + 1 < c.mps ? k + 1 : 0];  // projection target (mode 2 at k=0 uses step 0 itself)
+        auto& so = h->soff[k];
+        so.e_ch[0] = add_chunk(p + me.W[1], L, 0);
+        so.e_ch[1] = add_chunk(p + me.W[2], L, 0);
+        so.e_ch[2] = add_chunk(p + me.W[0], L, 2 * L);
+        so.e_tabs = add_tabs(nullptr, p + me.b[1], p + me.b[2], p + me.gamma, p + me.beta, nullptr);
+        so.n_ch[0] = add_chunk(p + mn.W[1], L, 0);
+        so.n_ch[1] = add_chunk(p + mn.W[2], L, 0);
+        so.n_ch[2] = add_chunk(p + mn.W[0], L, 0);
+        so.n_ch[3] = add_chunk(p + mn.W[0], L, L);
+        so.n_ch[4] = add_chunk(p + nx.W[0], L, 0);
+        so.n_ch[5] = add_chunk(p + nx.W[0], L, L);
+        so.n_tabs = add_tabs(p + mn.b[0], p + mn.b[1], p + mn.b[2], p + mn.gamma, p + mn.beta, p + nx.b[0]);
+    }
+    {
+        const MlpOff& m = h->dec;
+        h->de_ch[0] = add_chunk(p + m.W[0], L, 0);
+        h->de_ch[1] = add_chunk(p + m.W[1], L, 0);
+        h->de_tabs = add_tabs(p + m.b[0], p + m.b[1], nullptr, nullptr, nullptr, nullptr);
+        h->de_w3f = f.size();
+        f.resize(f.size() + (size_t)c.O * L);
+        for (int o = 0; o < c.O; ++o) pack_tab(f.data() + h->de_w3f + (size_t)o * L, p + m.W[2] + o, L, c.O);
+        h->de_b3 = f.size();
+        for (int o = 0; o < c.O; ++o) f.push_back(p[m.b[2] + o]);
+        while (f.size() % 4) f.push_back(0.f);
+    }
+    // "project only" (mgn_proc_begin) needs step 0's own first layer in slots 4,5 of some NodeArgs: add a
+    // dedicated pseudo-step at index mps (slots 0..3 alias step 0; tables carry bq = b1 of step 0).
+    {
+        mgn_engine::StepOff so = h->soff[0];
+        so.n_ch[4] = h->en_ch[2];
+        so.n_ch[5] = h->en_ch[3];
+        so.n_tabs = add_tabs(nullptr, nullptr, nullptr, nullptr, nullptr, p + e0.b[0]);
+        h->soff.push_back(so);
+    }
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, h->wfrag.ensure(f.size() * 4));
+    HIPCHK(h, hipMemcpy(h->wfrag.p, f.data(), f.size() * 4, hipMemcpyHostToDevice));
+    h->have_params = true;
+    return MGN_OK;
+}
+
+int mgn_get_params(mgn_handle* h, float* packed, size_t n) {
+    if (int rc = need(h, true, false)) return rc;
+    if (!packed || n != h->params.size()) return fail(h, MGN_E_ARG, "mgn_get_params: size mismatch");
+    memcpy(packed, h->params.data(), n * sizeof(float));
+    return MGN_OK;
+}
+
+int mgn_set_norms(mgn_handle* h, const float* ns, const float* nsh, const float* es, const float* esh, const float* os,
+                  const float* osh) {
+    if (int rc = need(h, false, false)) return rc;
+    const mgn_config& c = h->cfg;
+    if ((ns == nullptr) != (nsh == nullptr) || (es == nullptr) != (esh == nullptr) || (os == nullptr) != (osh == nullptr))
+        return fail(h, MGN_E_ARG, "mgn_set_norms: scale and shift must both be given or both be NULL");
+    std::vector<float> v((size_t)2 * (c.Fn + c.Fe + c.O), 0.f);
+    float* q = v.data();
+    auto put = [&](const float* a, const float* b, int n) {
+        for (int i = 0; i < n; ++i) { q[i] = a ? a[i] : 1.f; q[n + i] = b ? b[i] : 0.f; }
+        q += 2 * n;
+    };
+    put(ns, nsh, c.Fn);
+    put(es, esh, c.Fe);
+    put(os, osh, c.O);
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, h->norms.ensure(v.size() * 4));
+    HIPCHK(h, hipMemcpy(h->norms.p, v.data(), v.size() * 4, hipMemcpyHostToDevice));
+    h->have_nnorm = ns != nullptr;
+    h->have_enorm = es != nullptr;
+    h->have_onorm = os != nullptr;
+    return MGN_OK;
+}
+
+int mgn_set_graph(mgn_handle* h, int32_t N, int64_t E, const int32_t* senders, const int32_t* receivers, int32_t index_base,
+                  const float* mesh_pos, int32_t pos_dim) {
+    if (!h) return MGN_E_ARG;
+    if (index_base != 0 && index_base != 1) return fail(h, MGN_E_ARG, "mgn_set_graph: index_base must be 0 or 1");
+    h->have_graph = false;
+    const std::string why = build_local_graph(N, E, senders, receivers, index_base, mesh_pos, pos_dim, h->cfg.rank, h->cfg.nranks, h->g);
+    if (!why.empty()) return fail(h, MGN_E_ARG, "mgn_set_graph: %s", why.c_str());
+    const LocalGraph& g = h->g;
+    h->ntiles_e = (int32_t)((g.e_local + TILE - 1) / TILE);
+    h->ntiles_n = (g.n_own + TILE - 1) / TILE;
+    if (h->host_only) {
+        h->have_graph = true;
+        return MGN_OK;
+    }
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    auto up = [&](DevBuf& d, const void* src, size_t bytes) -> hipError_t {
+        hipError_t e = d.ensure(bytes);
+        if (e != hipSuccess || bytes == 0) return e;
+        return hipMemcpy(d.p, src, bytes, hipMemcpyHostToDevice);
+    };
+    HIPCHK(h, up(h->d_snd, g.snd.data(), g.snd.size() * 4));
+    HIPCHK(h, up(h->d_rcv, g.rcv.data(), g.rcv.size() * 4));
+    HIPCHK(h, up(h->d_rowptr, g.rowptr.data(), g.rowptr.size() * 4));
+    HIPCHK(h, up(h->d_own_gid, g.own_gid.data(), g.own_gid.size() * 4));
+    HIPCHK(h, up(h->d_edge_gid, g.edge_gid.data(), g.edge_gid.size() * 8));
+    HIPCHK(h, up(h->d_send_idx, g.send_idx.data(), g.send_idx.size() * 4));
+    if (int rc = alloc_latents(h)) return rc;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    h->have_graph = true;
+    return MGN_OK;
+}
+
+int mgn_partition_info(const mgn_handle* h, int32_t* n_own, int32_t* n_halo, int64_t* e_local) {
+    if (!h || !h->have_graph) return MGN_E_STATE;
+    if (n_own) *n_own = h->g.n_own;
+    if (n_halo) *n_halo = h->g.n_halo;
+    if (e_local) *e_local = h->g.e_local;
+    return MGN_OK;
+}
+
+int mgn_owned_nodes(const mgn_handle* h, int32_t* ids) {
+    if (!h || !h->have_graph || !ids) return MGN_E_STATE;
+    memcpy(ids, h->g.own_gid.data(), h->g.own_gid.size() * 4);
+    return MGN_OK;
+}
+
+int mgn_local_edges(const mgn_handle* h, int64_t* ids) {
+    if (!h || !h->have_graph || !ids) return MGN_E_STATE;
+    memcpy(ids, h->g.edge_gid.data(), h->g.edge_gid.size() * 8);
+    return MGN_OK;
+}
+
+int mgn_halo_counts(const mgn_handle* h, int32_t* send_rows, int32_t* recv_rows) {
+    if (!h || !h->have_graph) return MGN_E_STATE;
+    for (int q = 0; q < h->cfg.nranks; ++q) {
+        if (send_rows) send_rows[q] = h->g.send_rows[q];
+        if (recv_rows) recv_rows[q] = h->g.recv_rows[q];
+    }
+    return MGN_OK;
+}
+
+int mgn_halo_nodes(const mgn_handle* h, int32_t* ids) {
+    if (!h || !h->have_graph || !ids) return MGN_E_STATE;
+    memcpy(ids, h->g.halo_gid.data(), h->g.halo_gid.size() * 4);
+    return MGN_OK;
+}
+
+int mgn_halo_send_index(const mgn_handle* h, int32_t* rows) {
+    if (!h || !h->have_graph || !rows) return MGN_E_STATE;
+    memcpy(rows, h->g.send_idx.data(), h->g.send_idx.size() * 4);
+    return MGN_OK;
+}
+
+int mgn_local_graph(const mgn_handle* h, int32_t* snd, int32_t* rcv, int32_t* rowptr) {
+    if (!h || !h->have_graph) return MGN_E_STATE;
+    if (snd) memcpy(snd, h->g.snd.data(), h->g.snd.size() * 4);
+    if (rcv) memcpy(rcv, h->g.rcv.data(), h->g.rcv.size() * 4);
+    if (rowptr) memcpy(rowptr, h->g.rowptr.data(), h->g.rowptr.size() * 4);
+    return MGN_OK;
+}
+
+int mgn_node_owner(const mgn_handle* h, int32_t* owner) {
+    if (!h || !h->have_graph || !owner) return MGN_E_STATE;
+    memcpy(owner, h->g.owner.data(), h->g.owner.size() * 4);
+    return MGN_OK;
+}
+
+// ---- staged pipeline ----------------------------------------------------------------------------
+static int upload_inputs(mgn_handle* h, const float* a, int wa, const float* b, int wb, const float* ef) {
+    const LocalGraph& g = h->g;
+    h->in_wa = wa;
+    h->in_wb = wb;
+    HIPCHK(h, h->d_nfA.ensure((size_t)g.N * wa * 4));
+    HIPCHK(h, hipMemcpyAsync(h->d_nfA.p, a, (size_t)g.N * wa * 4, hipMemcpyHostToDevice, h->stream));
+    if (wb > 0) {
+        HIPCHK(h, h->d_nfB.ensure((size_t)g.N * wb * 4));
+        HIPCHK(h, hipMemcpyAsync(h->d_nfB.p, b, (size_t)g.N * wb * 4, hipMemcpyHostToDevice, h->stream));
+    }
+    HIPCHK(h, h->d_ef.ensure((size_t)g.E * h->cfg.Fe * 4));
+    HIPCHK(h, hipMemcpyAsync(h->d_ef.p, ef, (size_t)g.E * h->cfg.Fe * 4, hipMemcpyHostToDevice, h->stream));
+    return MGN_OK;
+}
+
+int mgn_fwd_upload(mgn_handle* h, const float* nf, const float* ef) {
+    if (int rc = need(h, false, true)) return rc;
+    if (!nf || (!ef && h->g.E > 0)) return fail(h, MGN_E_ARG, "mgn_fwd_upload: null input");
+    return upload_inputs(h, nf, h->cfg.Fn, nullptr, 0, ef);
+}
+
+static int encode_impl(mgn_handle* h, bool use_norms) {
+    const mgn_config& c = h->cfg;
+    const LocalGraph& g = h->g;
+    const float* nrm = h->norms.as<float>();
+    {
+        ProfScope ps(h, F_ENC);
+        EncNodeArgs a{};
+        a.n = g.n_own;
+        a.ntiles = h->ntiles_n;
+        a.gid = h->d_own_gid.as<int32_t>();
+        a.srcA = h->d_nfA.as<float>();
+        a.wa = h->in_wa;
+        a.srcB = h->d_nfB.as<float>();
+        a.wb = h->in_wb;
+        if (use_norms && h->have_nnorm) { a.scale = nrm; a.shift = nrm + c.Fn; }
+        a.w1f = W(h, h->en_w1f);
+        a.V = h->V.as<float>();
+        a.P = h->P.as<float>();
+        a.Q = h->Q.as<float>();
+        for (int i = 0; i < 4; ++i) a.chunk[i] = W(h, h->en_ch[i]);
+        a.tabs = W(h, h->en_tabs);
+        HIPCHK(h, launch_enc_node(c.L, a, h->stream));
+        EncEdgeArgs b{};
+        b.E = g.e_local;
+        b.ntiles = h->ntiles_e;
+        b.gid = h->d_edge_gid.as<int64_t>();
+        b.ef = h->d_ef.as<float>();
+        b.Fe = c.Fe;
+        if (use_norms && h->have_enorm) { b.scale = nrm + 2 * c.Fn; b.shift = nrm + 2 * c.Fn + c.Fe; }
+        b.w1f = W(h, h->ee_w1f);
+        b.Elat = h->Elat.as<float>();
+        for (int i = 0; i < 2; ++i) b.chunk[i] = W(h, h->ee_ch[i]);
+        b.tabs = W(h, h->ee_tabs);
+        HIPCHK(h, launch_enc_edge(c.L, b, h->stream));
+    }
+    return MGN_OK;
+}
+
+int mgn_fwd_encode(mgn_handle* h) {
+    if (int rc = need(h, true, true)) return rc;
+    if (!h->d_nfA.p) return fail(h, MGN_E_STATE, "mgn_fwd_encode before mgn_fwd_upload");
+    return encode_impl(h, false);
+}
+
+int mgn_proc_begin(mgn_handle* h) {
+    if (int rc = need(h, true, true)) return rc;
+    ProfScope ps(h, F_NODE);
+    const NodeArgs a = node_args(h, h->cfg.mps, 2);
+    HIPCHK(h, launch_node_step(h->cfg.L, a, h->stream));
+    return MGN_OK;
+}
+
+int mgn_proc_edge(mgn_handle* h, int32_t k) {
+    if (int rc = need(h, true, true)) return rc;
+    if (k < 0 || k >= h->cfg.mps) return fail(h, MGN_E_ARG, "mgn_proc_edge: step %d out of range", k);
+    ProfScope ps(h, F_EDGE);
+    const EdgeArgs a = edge_args(h, k);
+    HIPCHK(h, launch_edge_step(h->cfg.L, a, h->stream));
+    return MGN_OK;
+}
+
+int mgn_proc_node(mgn_handle* h, int32_t k, int32_t project_next) {
+    if (int rc = need(h, true, true)) return rc;
+    if (k < 0 || k >= h->cfg.mps) return fail(h, MGN_E_ARG, "mgn_proc_node: step %d out of range", k);
+    if (project_next && k + 1 >= h->cfg.mps) return fail(h, MGN_E_ARG, "mgn_proc_node: no step %d to project for", k + 1);
+    ProfScope ps(h, F_NODE);
+    const NodeArgs a = node_args(h, k, project_next ? 1 : 0);
+    HIPCHK(h, launch_node_step(h->cfg.L, a, h->stream));
+    return MGN_OK;
+}
+
+static int decode_impl(mgn_handle* h, bool use_norms) {
+    const mgn_config& c = h->cfg;
+    ProfScope ps(h, F_DEC);
+    DecArgs a{};
+    a.n = h->g.n_own;
+    a.ntiles = h->ntiles_n;
+    a.V = h->V.as<float>();
+    a.w3f = W(h, h->de_w3f);
+    a.b3 = W(h, h->de_b3);
+    a.O = c.O;
+    if (use_norms && h->have_onorm) {
+        const float* nrm = h->norms.as<float>() + 2 * c.Fn + 2 * c.Fe;
+        a.oscale = nrm;
+        a.oshift = nrm + c.O;
+    }
+    a.mask = (use_norms && h->have_mask) ? h->d_mask.as<float>() : nullptr;
+    a.gid = h->d_own_gid.as<int32_t>();
+    a.out = h->d_out.as<float>();
+    for (int i = 0; i < 2; ++i) a.chunk[i] = W(h, h->de_ch[i]);
+    a.tabs = W(h, h->de_tabs);
+    HIPCHK(h, launch_decode(c.L, a, h->stream));
+    return MGN_OK;
+}
+
+int mgn_fwd_decode(mgn_handle* h) {
+    if (int rc = need(h, true, true)) return rc;
+    return decode_impl(h, false);
+}
+
+int mgn_fwd_download(mgn_handle* h, float* out) {
+    if (int rc = need(h, false, true)) return rc;
+    if (!out) return fail(h, MGN_E_ARG, "mgn_fwd_download: null out");
+    const LocalGraph& g = h->g;
+    const int O = h->cfg.O;
+    std::vector<float> loc((size_t)g.n_own * O);
+    HIPCHK(h, hipMemcpyAsync(loc.data(), h->d_out.p, loc.size() * 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    for (int32_t i = 0; i < g.n_own; ++i) memcpy(out + (size_t)g.own_gid[i] * O, loc.data() + (size_t)i * O, (size_t)O * 4);
+    return MGN_OK;
+}
+
+static int run_processor(mgn_handle* h, int nsteps) {
+    for (int k = 0; k < nsteps; ++k) {
+        if (int rc = mgn_proc_edge(h, k)) return rc;
+        if (int rc = mgn_proc_node(h, k, k + 1 < nsteps ? 1 : 0)) return rc;
+    }
+    return MGN_OK;
+}
+
+int mgn_forward(mgn_handle* h, const float* nf, const float* ef, float* out) {
+    if (int rc = need(h, true, true)) return rc;
+    if (h->cfg.nranks != 1)
+        return fail(h, MGN_E_STATE, "mgn_forward drives one partition; with nranks > 1 use the staged mgn_fwd_*/mgn_halo_* calls");
+    if (int rc = mgn_fwd_upload(h, nf, ef)) return rc;
+    if (int rc = encode_impl(h, false)) return rc;
+    if (int rc = run_processor(h, h->cfg.mps)) return rc;
+    if (int rc = decode_impl(h, false)) return rc;
+    return mgn_fwd_download(h, out);
+}
+
+int mgn_ode_step(mgn_handle* h, const float* x, const float* onehot, const float* ef_raw, const float* val_mask, float* dxdt) {
+    if (int rc = need(h, true, true)) return rc;
+    const mgn_config& c = h->cfg;
+    if (h->cfg.nranks != 1) return fail(h, MGN_E_STATE, "mgn_ode_step drives one partition");
+    if (!x || !dxdt || (c.Fn > c.O && !onehot)) return fail(h, MGN_E_ARG, "mgn_ode_step: null argument");
+    if (c.Fn < c.O) return fail(h, MGN_E_ARG, "mgn_ode_step: Fn < O");
+    if (int rc = upload_inputs(h, x, c.O, onehot, c.Fn - c.O, ef_raw)) return rc;
+    h->have_mask = val_mask != nullptr;
+    if (val_mask) {
+        HIPCHK(h, h->d_mask.ensure((size_t)h->g.N * 4));
+        HIPCHK(h, hipMemcpyAsync(h->d_mask.p, val_mask, (size_t)h->g.N * 4, hipMemcpyHostToDevice, h->stream));
+    }
+    if (int rc = encode_impl(h, true)) return rc;
+    if (int rc = run_processor(h, c.mps)) return rc;
+    if (int rc = decode_impl(h, true)) return rc;
+    return mgn_fwd_download(h, dxdt);
+}
+
+// ---- latents -------------------------------------------------------------------------------------
+int mgn_latents_import(mgn_handle* h, const float* v, const float* e) {
+    if (int rc = need(h, false, true)) return rc;
+    if (!v || (!e && h->g.e_local > 0)) return fail(h, MGN_E_ARG, "mgn_latents_import: null input");
+    const LocalGraph& g = h->g;
+    const size_t L = h->cfg.L;
+    std::vector<float> tv((size_t)g.n_own * L), te((size_t)g.e_local * L);
+    for (int32_t i = 0; i < g.n_own; ++i) memcpy(&tv[(size_t)i * L], v + (size_t)g.own_gid[i] * L, L * 4);
+    for (int64_t i = 0; i < g.e_local; ++i) memcpy(&te[(size_t)i * L], e + (size_t)g.edge_gid[i] * L, L * 4);
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (!tv.empty()) HIPCHK(h, hipMemcpy(h->V.p, tv.data(), tv.size() * 4, hipMemcpyHostToDevice));
+    if (!te.empty()) HIPCHK(h, hipMemcpy(h->Elat.p, te.data(), te.size() * 4, hipMemcpyHostToDevice));
+    return MGN_OK;
+}
+
+int mgn_latents_export(mgn_handle* h, float* v, float* e) {
+    if (int rc = need(h, false, true)) return rc;
+    const LocalGraph& g = h->g;
+    const size_t L = h->cfg.L;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (v) {
+        std::vector<float> tv((size_t)g.n_own * L);
+        if (!tv.empty()) HIPCHK(h, hipMemcpy(tv.data(), h->V.p, tv.size() * 4, hipMemcpyDeviceToHost));
+        for (int32_t i = 0; i < g.n_own; ++i) memcpy(v + (size_t)g.own_gid[i] * L, &tv[(size_t)i * L], L * 4);
+    }
+    if (e) {
+        std::vector<float> te((size_t)g.e_local * L);
+        if (!te.empty()) HIPCHK(h, hipMemcpy(te.data(), h->Elat.p, te.size() * 4, hipMemcpyDeviceToHost));
+        for (int64_t i = 0; i < g.e_local; ++i) memcpy(e + (size_t)g.edge_gid[i] * L, &te[(size_t)i * L], L * 4);
+    }
+    return MGN_OK;
+}
+
+int mgn_latents_randn(mgn_handle* h, uint64_t seed) {
+    if (int rc = need(h, false, true)) return rc;
+    const LocalGraph& g = h->g;
+    HIPCHK(h, launch_randn_rows(h->V.as<float>(), nullptr, h->d_own_gid.as<int32_t>(), g.n_own, h->cfg.L, seed, h->stream));
+    HIPCHK(h, launch_randn_rows(h->Elat.as<float>(), h->d_edge_gid.as<int64_t>(), nullptr, g.e_local, h->cfg.L,
+                                seed ^ 0xE5E5E5E5E5E5E5E5ull, h->stream));
+    return MGN_OK;
+}
+
+int mgn_latents_checksum(mgn_handle* h, double* sv, double* se, double* qv, double* qe) {
+    if (int rc = need(h, false, true)) return rc;
+    const LocalGraph& g = h->g;
+    HIPCHK(h, hipMemsetAsync(h->d_sum.p, 0, 4 * sizeof(double), h->stream));
+    HIPCHK(h, launch_checksum(h->V.as<float>(), (int64_t)g.n_own * h->cfg.L, h->d_sum.as<double>(), h->stream));
+    HIPCHK(h, launch_checksum(h->Elat.as<float>(), g.e_local * h->cfg.L, h->d_sum.as<double>() + 2, h->stream));
+    double r[4];
+    HIPCHK(h, hipMemcpyAsync(r, h->d_sum.p, sizeof r, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (sv) *sv = r[0];
+    if (qv) *qv = r[1];
+    if (se) *se = r[2];
+    if (qe) *qe = r[3];
+    return MGN_OK;
+}
+
+int mgn_processor_steps_dev(mgn_handle* h, int32_t nsteps) {
+    if (int rc = need(h, true, true)) return rc;
+    if (h->cfg.nranks != 1) return fail(h, MGN_E_STATE, "mgn_processor_steps_dev drives one partition; use mgn_proc_* + mgn_halo_*");
+    if (nsteps < 0 || nsteps > h->cfg.mps) return fail(h, MGN_E_ARG, "nsteps must be in [0, mps]");
+    if (nsteps == 0) return MGN_OK;
+    if (int rc = mgn_proc_begin(h)) return rc;
+    return run_processor(h, nsteps);
+}
+
+int mgn_processor_steps(mgn_handle* h, float* v, float* e, int32_t nsteps) {
+    if (int rc = need(h, true, true)) return rc;
+    if (h->cfg.nranks != 1) return fail(h, MGN_E_STATE, "mgn_processor_steps drives one partition");
+    if (int rc = mgn_latents_import(h, v, e)) return rc;
+    if (int rc = mgn_processor_steps_dev(h, nsteps)) return rc;
+    return mgn_latents_export(h, v, e);
+}
+
+// ---- halo ------------------------------------------------------------------------------------------
+int mgn_halo_bytes_per_row(const mgn_handle* h) { return h ? h->cfg.L * 4 : MGN_E_ARG; }
+
+int mgn_halo_pack(mgn_handle* h, void* send_dev) {
+    if (int rc = need(h, false, true)) return rc;
+    const int64_t rows = (int64_t)h->g.send_idx.size();
+    if (rows == 0) return MGN_OK;
+    if (!send_dev) return fail(h, MGN_E_ARG, "mgn_halo_pack: null buffer");
+    ProfScope ps(h, F_HALO);
+    HIPCHK(h, launch_gather_rows(h->P.as<float>(), h->d_send_idx.as<int32_t>(), reinterpret_cast<float*>(send_dev), rows, h->cfg.L, h->stream));
+    return MGN_OK;
+}
+
+int mgn_halo_unpack(mgn_handle* h, const void* recv_dev) {
+    if (int rc = need(h, false, true)) return rc;
+    const LocalGraph& g = h->g;
+    if (g.n_halo == 0) return MGN_OK;
+    if (!recv_dev) return fail(h, MGN_E_ARG, "mgn_halo_unpack: null buffer");
+    ProfScope ps(h, F_HALO);
+    HIPCHK(h, hipMemcpyAsync(h->P.as<float>() + (size_t)g.n_own * h->cfg.L, recv_dev, (size_t)g.n_halo * h->cfg.L * 4,
+                             hipMemcpyDeviceToDevice, h->stream));
+    return MGN_OK;
+}
+
+// ---- profiling ---------------------------------------------------------------------------------------
+int mgn_profile_enable(mgn_handle* h, int32_t on) {
+    if (int rc = need(h, false, false)) return rc;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    for (auto& r : h->recs) {
+        (void)hipEventDestroy(r.a);
+        (void)hipEventDestroy(r.b);
+    }
+    h->recs.clear();
+    h->prof = on != 0;
+    return MGN_OK;
+}
+
+int mgn_profile_read(mgn_handle* h, double ms_avg[8], int64_t counts[8]) {
+    if (!h || !ms_avg || !counts) return MGN_E_ARG;
+    if (int rc = need(h, false, false)) return rc;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    double tot[8] = {0};
+    int64_t cnt[8] = {0};
+    for (auto& r : h->recs) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
+            tot[r.fam] += ms;
+            cnt[r.fam] += 1;
+        }
+        (void)hipEventDestroy(r.a);
+        (void)hipEventDestroy(r.b);
+    }
+    h->recs.clear();
+    for (int i = 0; i < 8; ++i) {
+        ms_avg[i] = cnt[i] ? tot[i] / (double)cnt[i] : 0.0;
+        counts[i] = cnt[i];
+    }
+    return MGN_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,347 @@
+"""Host-side mirror of the GraphNetCore surface the reference calls, over the C ABI.
+
+Names follow the reference so that the parity tests read like its call sites:
+    FeatureGraph(nf, ef, senders, receivers)              reference src/graph.jl:87-96
+    GraphNetwork{model, ps, st, e_norm, n_norm, o_norm}   fields used at src/solve.jl:200-208, src/graph.jl:80-93
+    mgn.model(graph, ps, st) -> (output, st)              src/solve.jl:200
+
+Array convention: NumPy C row-major [count][feat] == the bytes of Julia's (feat x count) arrays.
+There is no CPU compute path: constructing an Engine without the built HIP extension or without a
+GPU raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _capi
+from ._capi import MgnConfig, f32, i32, i64
+
+
+class MgnError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"{_capi.STATUS_NAMES.get(code, code)}: {msg}")
+        self.code = code
+
+
+def _c32(a, shape=None):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    if shape is not None and tuple(a.shape) != tuple(shape):
+        raise ValueError(f"DimensionMismatch: expected {tuple(shape)}, got {tuple(a.shape)}")
+    return a
+
+
+class Engine:
+    """One engine handle == one mesh partition on one GPU (rank/nranks select the partition)."""
+
+    def __init__(self, Fn, Fe, O, L=128, hidden_layers=2, mps=15, rank=0, nranks=1, device=-1):
+        self.lib = _capi.load()
+        self.cfg = MgnConfig(Fn, Fe, O, L, hidden_layers, mps, 0, rank, nranks, device)
+        self.h = C.c_void_p()
+        rc = self.lib.mgn_create(C.byref(self.cfg), C.byref(self.h))
+        if rc != 0:
+            raise MgnError(rc, self.lib.mgn_last_error(None).decode())
+        self.N = self.E = 0
+        self.n_own = self.n_halo = self.e_local = 0
+
+    # -- lifecycle -----------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "h", None) is not None and self.h.value:
+            self.lib.mgn_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise MgnError(rc, self.lib.mgn_last_error(self.h).decode())
+
+    @property
+    def host_only(self):
+        return self.cfg.device == _capi.MGN_DEVICE_NONE
+
+    def set_stream(self, stream_ptr):
+        self._chk(self.lib.mgn_set_stream(self.h, C.c_void_p(stream_ptr)))
+
+    def synchronize(self):
+        self._chk(self.lib.mgn_synchronize(self.h))
+
+    # -- parameters ----------------------------------------------------------------------------
+    @property
+    def param_count(self):
+        return int(self.lib.mgn_param_count(C.byref(self.cfg)))
+
+    def set_params(self, packed):
+        packed = _c32(packed).ravel()
+        self._chk(self.lib.mgn_set_params(self.h, f32(packed), packed.size))
+
+    def get_params(self):
+        out = np.empty(self.param_count, np.float32)
+        self._chk(self.lib.mgn_get_params(self.h, f32(out), out.size))
+        return out
+
+    def set_norms(self, node=None, edge=None, out=None):
+        """Each argument: None (identity) or (scale[F], shift[F]) with forward y = x*scale + shift;
+        `out` is the INVERSE map of o_norm (inverse_data)."""
+        def sp(p, n):
+            if p is None:
+                return None, None
+            return _c32(p[0], (n,)), _c32(p[1], (n,))
+        ns, nsh = sp(node, self.cfg.Fn)
+        es, esh = sp(edge, self.cfg.Fe)
+        os_, osh = sp(out, self.cfg.O)
+        self._keep_norms = (ns, nsh, es, esh, os_, osh)
+        self._chk(self.lib.mgn_set_norms(self.h, f32(ns), f32(nsh), f32(es), f32(esh), f32(os_), f32(osh)))
+
+    # -- graph ---------------------------------------------------------------------------------
+    def set_graph(self, senders, receivers, N, index_base=0, mesh_pos=None):
+        s = np.ascontiguousarray(senders, dtype=np.int32).ravel()
+        r = np.ascontiguousarray(receivers, dtype=np.int32).ravel()
+        if s.size != r.size:
+            raise ValueError("DimensionMismatch: senders and receivers differ in length")
+        pos, pd = None, 0
+        if mesh_pos is not None:
+            pos = _c32(mesh_pos)
+            if pos.ndim != 2 or pos.shape[0] != N:
+                raise ValueError("DimensionMismatch: mesh_pos must be [N][dim]")
+            pd = pos.shape[1]
+        self._chk(self.lib.mgn_set_graph(self.h, N, s.size, i32(s), i32(r), index_base, f32(pos), pd))
+        self.N, self.E = int(N), int(s.size)
+        a, b, c = C.c_int32(), C.c_int32(), C.c_int64()
+        self._chk(self.lib.mgn_partition_info(self.h, C.byref(a), C.byref(b), C.byref(c)))
+        self.n_own, self.n_halo, self.e_local = a.value, b.value, c.value
+
+    def owned_nodes(self):
+        out = np.empty(self.n_own, np.int32)
+        self._chk(self.lib.mgn_owned_nodes(self.h, i32(out)))
+        return out
+
+    def local_edges(self):
+        out = np.empty(self.e_local, np.int64)
+        self._chk(self.lib.mgn_local_edges(self.h, i64(out)))
+        return out
+
+    def halo_counts(self):
+        n = self.cfg.nranks
+        s, r = np.zeros(n, np.int32), np.zeros(n, np.int32)
+        self._chk(self.lib.mgn_halo_counts(self.h, i32(s), i32(r)))
+        return s, r
+
+    def halo_nodes(self):
+        out = np.empty(self.n_halo, np.int32)
+        self._chk(self.lib.mgn_halo_nodes(self.h, i32(out)))
+        return out
+
+    def halo_send_index(self):
+        s, _ = self.halo_counts()
+        out = np.empty(int(s.sum()), np.int32)
+        self._chk(self.lib.mgn_halo_send_index(self.h, i32(out)))
+        return out
+
+    def local_graph(self):
+        snd = np.empty(self.e_local, np.int32)
+        rcv = np.empty(self.e_local, np.int32)
+        rowptr = np.empty(self.n_own + 1, np.int32)
+        self._chk(self.lib.mgn_local_graph(self.h, i32(snd), i32(rcv), i32(rowptr)))
+        return snd, rcv, rowptr
+
+    def node_owner(self):
+        out = np.empty(self.N, np.int32)
+        self._chk(self.lib.mgn_node_owner(self.h, i32(out)))
+        return out
+
+    # -- model ---------------------------------------------------------------------------------
+    def forward(self, nf, ef):
+        nf = _c32(nf, (self.N, self.cfg.Fn))
+        ef = _c32(ef, (self.E, self.cfg.Fe))
+        out = np.zeros((self.N, self.cfg.O), np.float32)
+        self._chk(self.lib.mgn_forward(self.h, f32(nf), f32(ef), f32(out)))
+        return out
+
+    def ode_step(self, x, node_type_onehot, ef_raw, val_mask=None):
+        O, Fn = self.cfg.O, self.cfg.Fn
+        x = _c32(x, (self.N, O))
+        oh = _c32(node_type_onehot, (self.N, Fn - O)) if Fn > O else None
+        ef = _c32(ef_raw, (self.E, self.cfg.Fe))
+        vm = _c32(val_mask, (self.N,)) if val_mask is not None else None
+        out = np.zeros((self.N, O), np.float32)
+        self._chk(self.lib.mgn_ode_step(self.h, f32(x), f32(oh), f32(ef), f32(vm), f32(out)))
+        return out
+
+    def processor_steps(self, v, e, nsteps):
+        v = _c32(v, (self.N, self.cfg.L)).copy()
+        e = _c32(e, (self.E, self.cfg.L)).copy()
+        self._chk(self.lib.mgn_processor_steps(self.h, f32(v), f32(e), nsteps))
+        return v, e
+
+    # -- device-resident latents ---------------------------------------------------------------
+    def latents_import(self, v, e):
+        v = _c32(v, (self.N, self.cfg.L))
+        e = _c32(e, (self.E, self.cfg.L))
+        self._chk(self.lib.mgn_latents_import(self.h, f32(v), f32(e)))
+
+    def latents_export(self, v=None, e=None):
+        """Writes owned rows into GLOBAL-shaped arrays (allocated zero-filled when not given)."""
+        v = np.zeros((self.N, self.cfg.L), np.float32) if v is None else v
+        e = np.zeros((self.E, self.cfg.L), np.float32) if e is None else e
+        self._chk(self.lib.mgn_latents_export(self.h, f32(v), f32(e)))
+        return v, e
+
+    def latents_randn(self, seed):
+        self._chk(self.lib.mgn_latents_randn(self.h, C.c_uint64(seed)))
+
+    def latents_checksum(self):
+        a, b, c, d = (C.c_double() for _ in range(4))
+        self._chk(self.lib.mgn_latents_checksum(self.h, C.byref(a), C.byref(b), C.byref(c), C.byref(d)))
+        return dict(sum_v=a.value, sum_e=b.value, sumsq_v=c.value, sumsq_e=d.value)
+
+    def processor_steps_dev(self, nsteps):
+        self._chk(self.lib.mgn_processor_steps_dev(self.h, nsteps))
+
+    # -- staged pipeline (multi-partition driver) ------------------------------------------------
+    def fwd_upload(self, nf, ef):
+        nf = _c32(nf, (self.N, self.cfg.Fn))
+        ef = _c32(ef, (self.E, self.cfg.Fe))
+        self._keep_in = (nf, ef)
+        self._chk(self.lib.mgn_fwd_upload(self.h, f32(nf), f32(ef)))
+
+    def fwd_encode(self):
+        self._chk(self.lib.mgn_fwd_encode(self.h))
+
+    def proc_begin(self):
+        self._chk(self.lib.mgn_proc_begin(self.h))
+
+    def proc_edge(self, k):
+        self._chk(self.lib.mgn_proc_edge(self.h, k))
+
+    def proc_node(self, k, project_next):
+        self._chk(self.lib.mgn_proc_node(self.h, k, 1 if project_next else 0))
+
+    def fwd_decode(self):
+        self._chk(self.lib.mgn_fwd_decode(self.h))
+
+    def fwd_download(self, out=None):
+        out = np.zeros((self.N, self.cfg.O), np.float32) if out is None else out
+        self._chk(self.lib.mgn_fwd_download(self.h, f32(out)))
+        return out
+
+    @property
+    def halo_row_floats(self):
+        return self.cfg.L
+
+    def halo_pack(self, send_ptr):
+        self._chk(self.lib.mgn_halo_pack(self.h, C.c_void_p(send_ptr)))
+
+    def halo_unpack(self, recv_ptr):
+        self._chk(self.lib.mgn_halo_unpack(self.h, C.c_void_p(recv_ptr)))
+
+    # -- measurement ---------------------------------------------------------------------------
+    def profile_enable(self, on=True):
+        self._chk(self.lib.mgn_profile_enable(self.h, 1 if on else 0))
+
+    def profile_read(self):
+        ms = (C.c_double * 8)()
+        cnt = (C.c_int64 * 8)()
+        self._chk(self.lib.mgn_profile_read(self.h, ms, cnt))
+        names = ["edge_step", "node_step", "encode", "decode", "halo"]
+        return {n: dict(avg_ms=ms[i], count=cnt[i]) for i, n in enumerate(names)}
+
+
+# ==================================================================================================
+# GraphNetCore-shaped surface
+# ==================================================================================================
+class FeatureGraph:
+    """FeatureGraph(nf, ef, senders, receivers) -- reference src/graph.jl:87-96.  Single edge set."""
+
+    def __init__(self, nf, ef, senders, receivers):
+        self.nf, self.ef, self.senders, self.receivers = nf, ef, senders, receivers
+
+
+class _Model:
+    """Callable `mgn.model(graph, ps, st) -> (output, st)` (reference src/solve.jl:200)."""
+
+    def __init__(self, net):
+        self.net = net
+
+    def __call__(self, graph, ps, st):
+        net = self.net
+        net._sync_params(ps)
+        net._sync_graph(graph.senders, graph.receivers, np.asarray(graph.nf).shape[0])
+        return net.engine.forward(graph.nf, graph.ef), st
+
+
+class GraphNetwork:
+    """Mutable holder mirroring GraphNetCore.GraphNetwork: fields model, ps, st, e_norm, n_norm, o_norm
+    (reference reads/writes them at src/solve.jl:54,200-208, src/graph.jl:80-93,
+    src/MeshGraphNets.jl:288,376-377).  `ps` is the packed float32 parameter vector (MGN-spec order),
+    owned by the caller so an optimiser can update it in place; it is re-uploaded when it changes."""
+
+    def __init__(self, quantities, dims, e_norm, n_norm, o_norm, outputs, mps=15, layer_size=128,
+                 hidden_layers=2, ps=None, index_base=0, device=-1):
+        self.engine = Engine(quantities, dims + 1, outputs, layer_size, hidden_layers, mps, device=device)
+        self.e_norm, self.n_norm, self.o_norm = e_norm, n_norm, o_norm
+        self.st = None
+        self.index_base = index_base
+        if ps is None:
+            raise ValueError("ps (packed parameters) is required: use load_params or init_params")
+        self.ps = np.ascontiguousarray(ps, np.float32)
+        self._ps_token = None
+        self._graph_token = None
+        self.model = _Model(self)
+
+    def _sync_params(self, ps):
+        ps = np.ascontiguousarray(ps, np.float32)
+        tok = (ps.ctypes.data, ps.size, float(ps[:64].sum()), float(ps[-64:].sum()), float(ps[::4099].sum()))
+        if tok != self._ps_token:
+            self.engine.set_params(ps)
+            self._ps_token = tok
+
+    def _sync_graph(self, senders, receivers, N):
+        s = np.asarray(senders)
+        tok = (s.ctypes.data if s.flags.c_contiguous else id(senders), s.size, N, int(s[:16].sum()) if s.size else 0)
+        if tok != self._graph_token:
+            self.engine.set_graph(senders, receivers, N, index_base=self.index_base)
+            self._graph_token = tok
+
+    def set_graph(self, senders, receivers, N, mesh_pos=None):
+        """Explicit once-per-trajectory call (what create_base_graph amortises, src/MeshGraphNets.jl:360)."""
+        self.engine.set_graph(senders, receivers, N, index_base=self.index_base, mesh_pos=mesh_pos)
+        s = np.asarray(senders)
+        self._graph_token = (s.ctypes.data if s.flags.c_contiguous else id(senders), s.size, N,
+                             int(s[:16].sum()) if s.size else 0)
+
+
+# ==================================================================================================
+# staged driver shared by the single-GPU loopback test, the RCCL path and the gloo CPU test
+# ==================================================================================================
+def run_processor_staged(engines, exchange, nsteps, begin=True):
+    """engines: objects with proc_begin/proc_edge/proc_node (one per local partition);
+    exchange(): performs pack -> all-to-all-v -> unpack for all of them.
+    Mirrors mgn_processor_steps_dev for nranks > 1."""
+    if nsteps <= 0:
+        return
+    if begin:
+        for e in engines:
+            e.proc_begin()
+    exchange()
+    for k in range(nsteps):
+        for e in engines:
+            e.proc_edge(k)
+        more = k + 1 < nsteps
+        for e in engines:
+            e.proc_node(k, more)
+        if more:
+            exchange()
+
+
+def run_forward_staged(engines, exchange, mps):
+    for e in engines:
+        e.fwd_encode()
+    run_processor_staged(engines, exchange, mps, begin=False)
+    for e in engines:
+        e.fwd_decode()

@@ -1,0 +1,296 @@
+"""MGN-spec v1 float64 oracle  --  TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+PARITY UNPINNED: the reference (una-auxme/MeshGraphNets.jl @ 2024_08_07) delegates all
+arithmetic on this path to GraphNetCore.jl 0.3 / Lux 0.5, neither of which is vendored under
+/root/reference (Project.toml:11,15,36,40; Manifest git-ignored .gitignore:7-8), `julia` is not
+installed here, and the reference's own tests hold no numerical fixtures (test/runtests.jl:11-19
+is Aqua static QA only).  This file therefore restates the *published* algorithm (DeepMind
+MeshGraphNets, arXiv 2010.03409, which README.md:9-19 names as what GraphNetCore implements)
+under the constraints of every reference call site, each cited below.  Only tests/,
+__graft_entry__.smoke() and bench.py's cpu_baseline leg may import it.
+
+All arrays are C row-major [count][feat]  ==  the bytes of Julia's column-major (feat x count).
+Indices are 0-based here; the 1-based Julia boundary (src/graph.jl:31-34) is handled by callers.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+LN_EPS = 1e-5  # Lux 0.5 LayerNorm default epsilon [GNC-unverified], SURVEY.md section 8c
+
+
+# --------------------------------------------------------------------------------------------
+# Graph prologue  (src/graph.jl:25-55 create_base_graph)
+# --------------------------------------------------------------------------------------------
+def one_hot(types, depth, offset=0):
+    """one_hot(vec, depth, offset) as called at src/graph.jl:26-27:
+    depth = type_max - type_min + 1, offset = 1 - type_min (1-based Julia) => column type-type_min."""
+    types = np.asarray(types).reshape(-1)
+    out = np.zeros((types.size, depth), dtype=np.float64)
+    out[np.arange(types.size), types + offset] = 1.0
+    return out
+
+
+def triangles_to_edges(cells):
+    """triangles_to_edges(cells) called at src/graph.jl:30.  cells: [C][3] int.
+    Undirected unique edges of the triangulation in first-occurrence order, returned two-way:
+    senders=[a;b], receivers=[b;a] with a=max(i,j), b=min(i,j)  (DeepMind common.triangles_to_edges)."""
+    cells = np.asarray(cells, dtype=np.int64)
+    e = np.concatenate([cells[:, 0:2], cells[:, 1:3], np.stack([cells[:, 2], cells[:, 0]], 1)], 0)
+    hi = e.max(1)
+    lo = e.min(1)
+    key = hi * (int(e.max()) + 1) + lo
+    _, first = np.unique(key, return_index=True)
+    first.sort()
+    a, b = hi[first], lo[first]
+    return np.concatenate([a, b]), np.concatenate([b, a])
+
+
+def edge_features(mesh_pos, senders, receivers):
+    """edge_features = [pos[s]-pos[r]; ||pos[s]-pos[r]||]  (src/graph.jl:35-36,49-52)."""
+    rel = np.asarray(mesh_pos, np.float64)[senders] - np.asarray(mesh_pos, np.float64)[receivers]
+    return np.concatenate([rel, np.linalg.norm(rel, axis=1, keepdims=True)], 1)
+
+
+# --------------------------------------------------------------------------------------------
+# Normalisers  (constructed at src/MeshGraphNets.jl:79-203, applied at src/graph.jl:80-93,
+#               inverted at src/solve.jl:205-210)
+# --------------------------------------------------------------------------------------------
+class NormMinMax:
+    """NormaliserOfflineMinMax(dmin, dmax[, tmin, tmax]); defaults target (0,1)."""
+
+    def __init__(self, dmin, dmax, tmin=0.0, tmax=1.0):
+        self.dmin, self.dmax, self.tmin, self.tmax = map(float, (dmin, dmax, tmin, tmax))
+
+    def __call__(self, x):
+        return (x - self.dmin) / (self.dmax - self.dmin) * (self.tmax - self.tmin) + self.tmin
+
+    def inverse(self, y):
+        return (y - self.tmin) / (self.tmax - self.tmin) * (self.dmax - self.dmin) + self.dmin
+
+    def affine(self, dim):
+        """(scale, shift) per feature with forward y = x*scale + shift."""
+        s = (self.tmax - self.tmin) / (self.dmax - self.dmin)
+        return np.full(dim, s), np.full(dim, self.tmin - self.dmin * s)
+
+
+class NormMeanStd:
+    """NormaliserOfflineMeanStd(mean, std); also the frozen state of a NormaliserOnline
+    (mean, max(std, 1e-8)) once accumulation has stopped (max_acc reached / inference)."""
+
+    def __init__(self, mean, std):
+        self.mean = np.asarray(mean, np.float64)
+        self.std = np.maximum(np.asarray(std, np.float64), 1e-8)
+
+    def __call__(self, x):
+        return (x - self.mean) / self.std
+
+    def inverse(self, y):
+        return y * self.std + self.mean
+
+    def affine(self, dim):
+        s = np.broadcast_to(1.0 / self.std, (dim,)).copy()
+        return s, -np.broadcast_to(self.mean, (dim,)) * s
+
+
+class NormOnline:
+    """NormaliserOnline(dims; max_acc): running sum / sum-of-squares / count over rows while
+    count < max_acc, then (x-mean)/max(std,1e-8)  (src/MeshGraphNets.jl:92,193-199)."""
+
+    def __init__(self, dim, max_acc=1e6, eps=1e-8):
+        self.dim, self.max_acc, self.eps = dim, float(max_acc), eps
+        self.acc_sum = np.zeros(dim)
+        self.acc_sq = np.zeros(dim)
+        self.count = 0.0
+        self.n_acc = 0.0
+
+    def accumulate(self, x):
+        if self.n_acc < self.max_acc:
+            self.acc_sum += x.sum(0)
+            self.acc_sq += (x * x).sum(0)
+            self.count += x.shape[0]
+            self.n_acc += 1.0
+
+    def frozen(self):
+        c = max(self.count, 1.0)
+        mean = self.acc_sum / c
+        std = np.sqrt(np.maximum(self.acc_sq / c - mean * mean, 0.0))
+        return NormMeanStd(mean, np.maximum(std, self.eps))
+
+    def __call__(self, x):
+        self.accumulate(x)
+        return self.frozen()(x)
+
+    def inverse(self, y):
+        return self.frozen().inverse(y)
+
+
+# --------------------------------------------------------------------------------------------
+# Parameters (packing order fixed by SURVEY.md section 8b)
+# --------------------------------------------------------------------------------------------
+def mlp_shapes(n_in, L, n_out, hidden_layers, ln):
+    dims = [n_in] + [L] * hidden_layers + [n_out]
+    shapes = []
+    for i in range(len(dims) - 1):
+        shapes.append(("W%d" % (i + 1), (dims[i], dims[i + 1])))  # row-major [in][out]
+        shapes.append(("b%d" % (i + 1), (dims[i + 1],)))
+    if ln:
+        shapes.append(("ln_scale", (n_out,)))
+        shapes.append(("ln_bias", (n_out,)))
+    return shapes
+
+
+def model_layout(Fn, Fe, O, L, hidden_layers, mps):
+    """[(block_name, [(tensor_name, shape)...])...] in packed order:
+    encoder-node, encoder-edge, step1-edge, step1-node, ..., decoder."""
+    blocks = [("enc_node", mlp_shapes(Fn, L, L, hidden_layers, True)),
+              ("enc_edge", mlp_shapes(Fe, L, L, hidden_layers, True))]
+    for k in range(mps):
+        blocks.append(("proc%d_edge" % k, mlp_shapes(3 * L, L, L, hidden_layers, True)))
+        blocks.append(("proc%d_node" % k, mlp_shapes(2 * L, L, L, hidden_layers, True)))
+    blocks.append(("decoder", mlp_shapes(L, L, O, hidden_layers, False)))
+    return blocks
+
+
+def param_count(Fn, Fe, O, L, hidden_layers, mps):
+    return sum(int(np.prod(s)) for _, ts in model_layout(Fn, Fe, O, L, hidden_layers, mps) for _, s in ts)
+
+
+def unpack_params(packed, Fn, Fe, O, L, hidden_layers, mps):
+    packed = np.asarray(packed)
+    out, off = {}, 0
+    for bname, tensors in model_layout(Fn, Fe, O, L, hidden_layers, mps):
+        d = {}
+        for tname, shape in tensors:
+            n = int(np.prod(shape))
+            d[tname] = packed[off:off + n].reshape(shape)
+            off += n
+        out[bname] = d
+    assert off == packed.size, (off, packed.size)
+    return out
+
+
+def init_params(Fn, Fe, O, L, hidden_layers, mps, seed=1234, ln_jitter=0.0):
+    """Glorot-uniform W, zero b, gamma=1, beta=0 (SURVEY.md 8c 'Init').  ln_jitter/bias jitter > 0
+    perturbs b, gamma, beta so that tests exercise them."""
+    rng = np.random.default_rng(seed)
+    chunks = []
+    for _, tensors in model_layout(Fn, Fe, O, L, hidden_layers, mps):
+        for tname, shape in tensors:
+            if tname.startswith("W"):
+                lim = np.sqrt(6.0 / (shape[0] + shape[1]))
+                chunks.append(rng.uniform(-lim, lim, size=shape).ravel())
+            elif tname.startswith("b"):
+                chunks.append(ln_jitter * rng.standard_normal(shape).ravel())
+            elif tname == "ln_scale":
+                chunks.append(1.0 + ln_jitter * rng.standard_normal(shape).ravel())
+            else:
+                chunks.append(ln_jitter * rng.standard_normal(shape).ravel())
+    return np.concatenate(chunks).astype(np.float32)
+
+
+# --------------------------------------------------------------------------------------------
+# Encode - Process - Decode  (mgn.model(graph, ps, st) at src/solve.jl:200)
+# --------------------------------------------------------------------------------------------
+def layer_norm(x, gamma, beta):
+    mu = x.mean(-1, keepdims=True)
+    var = ((x - mu) ** 2).mean(-1, keepdims=True)  # biased variance
+    return (x - mu) / np.sqrt(var + LN_EPS) * gamma + beta
+
+
+def mlp(x, p, hidden_layers):
+    for i in range(1, hidden_layers + 2):
+        x = x @ p["W%d" % i] + p["b%d" % i]
+        if i <= hidden_layers:
+            x = np.maximum(x, 0.0)
+    if "ln_scale" in p:
+        x = layer_norm(x, p["ln_scale"], p["ln_bias"])
+    return x
+
+
+def scatter_add(rows, index, n):
+    out = np.zeros((n, rows.shape[1]), rows.dtype)
+    np.add.at(out, index, rows)
+    return out
+
+
+def encode(P, nf, ef, h):
+    return mlp(nf, P["enc_node"], h), mlp(ef, P["enc_edge"], h)
+
+
+def processor_step(P, k, v, e, senders, receivers, h):
+    """One message-passing step (DeepMind GraphNetBlock order): the node update consumes e'
+    BEFORE the residual is added; then v += v', e += e'."""
+    e_new = mlp(np.concatenate([v[senders], v[receivers], e], 1), P["proc%d_edge" % k], h)
+    agg = scatter_add(e_new, receivers, v.shape[0])
+    v_new = mlp(np.concatenate([v, agg], 1), P["proc%d_node" % k], h)
+    return v + v_new, e + e_new
+
+
+def decode(P, v, h):
+    return mlp(v, P["decoder"], h)
+
+
+def forward(packed, cfg, nf, ef, senders, receivers, return_latents=False, dtype=np.float64):
+    """cfg: dict(Fn, Fe, O, L, hidden_layers, mps).  nf [N][Fn], ef [E][Fe] (already normalised,
+    i.e. the FeatureGraph of src/graph.jl:87-96).  Returns out [N][O]."""
+    h = cfg["hidden_layers"]
+    P = unpack_params(np.asarray(packed, dtype), cfg["Fn"], cfg["Fe"], cfg["O"], cfg["L"], h, cfg["mps"])
+    v, e = encode(P, np.asarray(nf, dtype), np.asarray(ef, dtype), h)
+    lat = [(v.copy(), e.copy())]
+    for k in range(cfg["mps"]):
+        v, e = processor_step(P, k, v, e, senders, receivers, h)
+        if return_latents:
+            lat.append((v.copy(), e.copy()))
+    out = decode(P, v, h)
+    return (out, lat) if return_latents else out
+
+
+def processor_steps(packed, cfg, v, e, senders, receivers, nsteps, dtype=np.float64):
+    """The benchmarked unit (SURVEY.md 8b mgn_processor_steps): nsteps of A6 on given latents."""
+    h = cfg["hidden_layers"]
+    P = unpack_params(np.asarray(packed, dtype), cfg["Fn"], cfg["Fe"], cfg["O"], cfg["L"], h, cfg["mps"])
+    v, e = np.asarray(v, dtype), np.asarray(e, dtype)
+    for k in range(nsteps):
+        v, e = processor_step(P, k, v, e, senders, receivers, h)
+    return v, e
+
+
+# --------------------------------------------------------------------------------------------
+# ODE right-hand side wrapper  (src/solve.jl:147-158 ode_func_eval, :188-219 ode_step,
+#                               src/graph.jl:75-97 build_graph)
+# --------------------------------------------------------------------------------------------
+def ode_rhs(packed, cfg, x, node_type_onehot, ef_raw, senders, receivers, n_norm_fields, n_norm_type,
+            e_norm, o_norm, val_mask, inflow_mask=None, inflow_values=None):
+    """x: [N][O] state (target fields stacked).  Returns dx/dt [N][O].
+    - inflow overwrite x[inflow_mask] = gt[inflow_mask]          (src/solve.jl:151-152)
+    - nf = [n_norm[field](x) ..., n_norm['node_type'](onehot)]    (src/graph.jl:80-86)
+    - ef = e_norm(edge_features)                                 (src/graph.jl:93)
+    - out = model(graph); inverse_data(o_norm, out) .* val_mask  (src/solve.jl:200-218)"""
+    x = np.array(x, np.float64)
+    if inflow_mask is not None:
+        x[inflow_mask] = np.asarray(inflow_values, np.float64)[inflow_mask]
+    nf = np.concatenate([n_norm_fields(x), n_norm_type(node_type_onehot)], 1)
+    ef = e_norm(ef_raw)
+    out = forward(packed, cfg, nf, ef, senders, receivers)
+    return o_norm.inverse(out) * val_mask
+
+
+def euler_rollout(rhs, x0, dt, nsteps):
+    """Fixed-step Euler (solve(prob, Euler(); adaptive=false, dt) at src/solve.jl:60)."""
+    xs = [np.array(x0, np.float64)]
+    for i in range(nsteps):
+        xs.append(xs[-1] + dt * rhs(xs[-1], i * dt))
+    return np.stack(xs)
+
+
+# --------------------------------------------------------------------------------------------
+# Training-step forward part  (step!(mgn, graph, target, mask, mse_reduce), src/strategies.jl:421)
+# --------------------------------------------------------------------------------------------
+def mse_reduce(target, out):
+    return ((target - out) ** 2).sum(-1)
+
+
+def step_loss(packed, cfg, nf, ef, senders, receivers, target, mask_idx):
+    out = forward(packed, cfg, nf, ef, senders, receivers)
+    return mse_reduce(target, out)[mask_idx].mean()

@@ -1,0 +1,146 @@
+"""GPU parity tests proper: the HIP path (through the C ABI) against the float64 oracle on identical
+seeded inputs.  Run on the MI355X box with `-m gpu`."""
+import numpy as np
+import pytest
+
+import mgn_oracle as orc
+from util import (TOL_15, TOL_STEP, cfg_dict, engine_for, make_params, random_inputs, rel_max, small_mesh)
+
+from mgn_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("L", [128, 64, 32])
+def test_forward_small_mesh(L):
+    cfg = cfg_dict(L=L, mps=3)
+    pos, s, r = small_mesh()
+    N, E = pos.shape[0], s.size
+    ps = make_params(cfg)
+    nf, ef = random_inputs(N, E, cfg)
+    eng = engine_for(cfg)
+    eng.set_params(ps)
+    eng.set_graph(s, r, N)
+    out = eng.forward(nf, ef)
+    ref = orc.forward(ps, cfg, nf, ef, s, r)
+    assert rel_max(out, ref) <= TOL_15, rel_max(out, ref)
+
+
+def test_processor_one_step_latents():
+    cfg = cfg_dict(mps=1)
+    pos, s, r = small_mesh(11, 7)
+    N, E = pos.shape[0], s.size
+    ps = make_params(cfg)
+    rng = np.random.default_rng(5)
+    v = rng.standard_normal((N, 128)).astype(np.float32)
+    e = rng.standard_normal((E, 128)).astype(np.float32)
+    eng = engine_for(cfg)
+    eng.set_params(ps)
+    eng.set_graph(s, r, N)
+    v1, e1 = eng.processor_steps(v, e, 1)
+    rv, re = orc.processor_steps(ps, cfg, v, e, s, r, 1)
+    assert rel_max(e1, re) <= TOL_STEP, ("edge", rel_max(e1, re))
+    assert rel_max(v1, rv) <= TOL_STEP, ("node", rel_max(v1, rv))
+
+
+def test_processor_15_steps_cyl():
+    """cfg-2 shaped: M-cyl, L=128, 15 steps (GOLD-B shape at full size)."""
+    cfg = cfg_dict(mps=15)
+    pos, cells, node_type, vel = synth.mesh_cyl(1234, 600)
+    s, r = synth.cells_to_edges(cells)
+    N, E = pos.shape[0], s.size
+    ps = make_params(cfg, jitter=0.05)
+    rng = np.random.default_rng(7)
+    v = rng.standard_normal((N, 128)).astype(np.float32)
+    e = rng.standard_normal((E, 128)).astype(np.float32)
+    eng = engine_for(cfg)
+    eng.set_params(ps)
+    eng.set_graph(s, r, N)
+    v1, e1 = eng.processor_steps(v, e, 15)
+    rv, re = orc.processor_steps(ps, cfg, v, e, s, r, 15)
+    assert rel_max(e1, re) <= TOL_15, ("edge", rel_max(e1, re))
+    assert rel_max(v1, rv) <= TOL_15, ("node", rel_max(v1, rv))
+
+
+@pytest.mark.parametrize("N,E,seed", [(1, 0, 0), (5, 1, 1), (33, 31, 2), (40, 700, 3), (64, 64, 4), (70, 2049, 5)])
+def test_ragged_graphs(N, E, seed):
+    """Ragged inputs: isolated nodes, self loops, duplicate edges, receivers with > 32 and > 64
+    incoming edges (segments that straddle one and several 32-edge tiles), E not a multiple of 32."""
+    cfg = cfg_dict(mps=2)
+    s, r = synth.random_graph(N, E, seed)
+    if E >= 700:
+        r[: E // 2] = 3      # one hub receiver spanning many tiles
+        r[E // 2: E // 2 + 40] = 7
+    ps = make_params(cfg)
+    nf, ef = random_inputs(N, E, cfg, seed)
+    eng = engine_for(cfg)
+    eng.set_params(ps)
+    eng.set_graph(s, r, N)
+    out = eng.forward(nf, ef)
+    ref = orc.forward(ps, cfg, nf, ef, s, r)
+    assert rel_max(out, ref) <= TOL_15, rel_max(out, ref)
+
+
+def test_edge_order_permutation_invariance():
+    """KAT-6: the engine re-sorts edges by receiver, so any input edge order gives the same result
+    bit for bit (stable sort keeps the within-receiver order only up to the permutation; tolerance
+    is a few ulp of the aggregate)."""
+    cfg = cfg_dict(mps=2)
+    pos, s, r = small_mesh(9, 9)
+    N, E = pos.shape[0], s.size
+    ps = make_params(cfg)
+    nf, ef = random_inputs(N, E, cfg, 9)
+    perm = np.random.default_rng(0).permutation(E)
+    eng = engine_for(cfg)
+    eng.set_params(ps)
+    eng.set_graph(s, r, N)
+    a = eng.forward(nf, ef)
+    eng.set_graph(s[perm], r[perm], N)
+    b = eng.forward(nf, ef[perm])
+    assert rel_max(b, a) <= 2e-6
+
+
+def test_one_based_indices_and_determinism():
+    cfg = cfg_dict(mps=2)
+    pos, s, r = small_mesh()
+    N, E = pos.shape[0], s.size
+    ps = make_params(cfg)
+    nf, ef = random_inputs(N, E, cfg, 2)
+    eng = engine_for(cfg)
+    eng.set_params(ps)
+    eng.set_graph(s, r, N, index_base=0)
+    a = eng.forward(nf, ef)
+    eng.set_graph(s + 1, r + 1, N, index_base=1)   # Julia boundary, src/graph.jl:31-34
+    b = eng.forward(nf, ef)
+    c = eng.forward(nf, ef)
+    assert np.array_equal(a, b) and np.array_equal(b, c)   # no atomics: bitwise reproducible
+
+
+def test_kat4_zero_weights_give_decoder_bias():
+    cfg = cfg_dict(mps=2)
+    pos, s, r = small_mesh()
+    N, E = pos.shape[0], s.size
+    ps = np.zeros(orc.param_count(9, 3, 2, 128, 2, 2), np.float32)
+    P = orc.unpack_params(ps, 9, 3, 2, 128, 2, 2)
+    P["decoder"]["b3"][:] = [0.25, -1.5]
+    nf, ef = random_inputs(N, E, cfg)
+    eng = engine_for(cfg)
+    eng.set_params(ps)
+    eng.set_graph(s, r, N)
+    out = eng.forward(nf, ef)
+    assert np.allclose(out, np.array([0.25, -1.5], np.float32)[None, :], atol=0)
+
+
+def test_error_paths():
+    from mgn_amd import MgnError
+    cfg = cfg_dict(mps=1)
+    eng = engine_for(cfg)
+    with pytest.raises(MgnError):
+        eng.forward(np.zeros((0, 9), np.float32), np.zeros((0, 3), np.float32))   # before set_params/set_graph
+    with pytest.raises(MgnError):
+        eng.set_params(np.zeros(10, np.float32))
+    eng.set_params(make_params(cfg))
+    with pytest.raises(MgnError):
+        eng.set_graph(np.array([0, 5], np.int32), np.array([1, 1], np.int32), 3)  # index out of range
+    with pytest.raises(MgnError):
+        engine_for(dict(cfg, L=100))

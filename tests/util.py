@@ -1,0 +1,41 @@
+"""Shared helpers for the parity tests (test infrastructure; may import the oracle)."""
+import numpy as np
+
+import mgn_amd
+from mgn_amd import synth
+import mgn_oracle as orc
+
+# Stated tolerances: fp32 engine vs float64 oracle, max|d| / max|ref|
+TOL_STEP = 2e-5       # latents after one processor step
+TOL_15 = 1e-4         # latents / output after 15 steps
+TOL_ROLLOUT = 1e-3    # relative L2 after a 100-step Euler rollout
+
+
+def rel_max(a, ref):
+    ref = np.asarray(ref, np.float64)
+    return float(np.abs(np.asarray(a, np.float64) - ref).max() / max(np.abs(ref).max(), 1e-30))
+
+
+def cfg_dict(Fn=9, Fe=3, O=2, L=128, mps=15):
+    return dict(Fn=Fn, Fe=Fe, O=O, L=L, hidden_layers=2, mps=mps)
+
+
+def make_params(cfg, seed=1234, jitter=0.1):
+    return orc.init_params(cfg["Fn"], cfg["Fe"], cfg["O"], cfg["L"], cfg["hidden_layers"], cfg["mps"], seed, jitter)
+
+
+def small_mesh(nx=8, ny=6, seed=3):
+    pos, cells = synth.grid_mesh(nx, ny, seed)
+    s, r = synth.cells_to_edges(cells)
+    return pos, s, r
+
+
+def random_inputs(N, E, cfg, seed=0):
+    rng = np.random.default_rng(seed)
+    nf = rng.standard_normal((N, cfg["Fn"])).astype(np.float32)
+    ef = rng.standard_normal((E, cfg["Fe"])).astype(np.float32)
+    return nf, ef
+
+
+def engine_for(cfg, **kw):
+    return mgn_amd.Engine(cfg["Fn"], cfg["Fe"], cfg["O"], cfg["L"], cfg["hidden_layers"], cfg["mps"], **kw)
