@@ -1,0 +1,252 @@
+#!/usr/bin/env python3
+"""bench.py -- processor-step throughput of the MI355X-native MeshGraphNets engine.
+
+Contract (driver):  python bench.py --gpus N --steps K --warmup W
+  N > 1 is launched by torch.distributed.run, one rank per GPU (RCCL), RANK/LOCAL_RANK/WORLD_SIZE from env.
+  One "step" = one pass of the hot path over the mesh = `mps` (15) message-passing steps of the processor
+  (mgn_processor_steps_dev; at N > 1 the staged edge/node kernels + RCCL halo all-to-all-v between them).
+  W untimed warm-up steps, then EXACTLY K timed steps bracketed by barrier + device synchronise on both
+  sides; time = MAX over ranks; rank 0 prints ONE JSON line.
+
+Metric (BASELINE.json): processor-step edges/s (+ nodes/s) = E * mps * K / time  -- whole job, all GPUs.
+Workload at N = 1: M-1M, the 1000x1000 jittered-grid triangulation (N = 1 000 000 nodes, E = 5 992 002
+directed edges, L = 128, 15 steps, fp32) -- BASELINE.json configs[3], the config the multi-GPU metric is
+quoted on; it fits one GPU (5 GB).  configs[1] (cylinder_flow-sized M-cyl) is timed too and reported in the
+same line under "secondary" (it is latency-bound: ~12k edges).  At N > 1 the SAME mesh is edge-cut over
+the N GPUs ("scaling": "strong").  Latents are N(0,1) generated on device, weights Glorot-uniform
+(random init: no datasets/checkpoints exist offline) -- "data": "synthetic".
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_F32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: dense f32-input MFMA peak
+L, MPS, FN, FE, O = 128, 15, 9, 3, 2
+
+
+def glorot_params(seed=1234):
+    """Glorot-uniform W, zero b, gamma = 1, beta = 0 in MGN-spec packed order (include/mgn_hip.h)."""
+    import numpy as np
+    rng = np.random.default_rng(seed)
+    chunks = []
+
+    def mlp(n_in, n_out, ln):
+        dims = [n_in, L, L, n_out]
+        for i in range(3):
+            lim = (6.0 / (dims[i] + dims[i + 1])) ** 0.5
+            chunks.append(rng.uniform(-lim, lim, size=dims[i] * dims[i + 1]).astype(np.float32))
+            chunks.append(np.zeros(dims[i + 1], np.float32))
+        if ln:
+            chunks.append(np.ones(n_out, np.float32))
+            chunks.append(np.zeros(n_out, np.float32))
+
+    mlp(FN, L, True)
+    mlp(FE, L, True)
+    for _ in range(MPS):
+        mlp(3 * L, L, True)
+        mlp(2 * L, L, True)
+    mlp(L, O, False)
+    return np.concatenate(chunks)
+
+
+def flops_algorithmic(E, N):
+    """GEMM flops of the un-factored processor step."""
+    return 163840.0 * E + 131072.0 * N
+
+
+def flops_edge_kernel(E):
+    """MFMA flops the edge kernel executes: 3 chunks of L x L per edge (layer 1 is factored)."""
+    return 2.0 * 3 * L * L * E
+
+
+def flops_node_kernel(N, project):
+    return 2.0 * (4 + (2 if project else 0)) * L * L * N
+
+
+def cpu_baseline(ps, budget_s=20.0):
+    """oracle/mgn_ref.c (fp32 C restatement, OpenMP) timed on this box's host cores on a bounded
+    sample of the same workload: processor steps on a 300x300 slice of the M-1M generator."""
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import mgn_ref
+    import mgn_amd
+    pos, cells = mgn_amd.synth.grid_mesh(300, 300, 1234)
+    s, r = mgn_amd.synth.cells_to_edges(cells)
+    n, e = pos.shape[0], s.size
+    rng = np.random.default_rng(1234)
+    v = rng.standard_normal((n, L)).astype(np.float32)
+    el = rng.standard_normal((e, L)).astype(np.float32)
+    cfg = dict(Fn=FN, Fe=FE, O=O, L=L, mps=MPS)
+    t0 = time.time()
+    steps = 0
+    while steps < MPS and (time.time() - t0 < budget_s or steps == 0):
+        v, el = mgn_ref.processor_steps(ps, cfg, v, el, s, r, 1)
+        steps += 1
+    dt = time.time() - t0
+    return dict(value=e * steps / dt, unit="edges/s", nodes_per_s=n * steps / dt, cores=mgn_ref.num_threads(),
+                kind="port", sample=f"{steps} processor step(s), L=128 fp32, on a 300x300 slice of the M-1M "
+                f"generator (N={n}, E={e}); oracle/mgn_ref.c with OpenMP on all host cores; {dt:.1f} s",
+                host_cpus=os.cpu_count())
+
+
+def time_single(eng, steps, warmup, sync):
+    for _ in range(warmup):
+        eng.processor_steps_dev(MPS)
+    sync()
+    eng.profile_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        eng.processor_steps_dev(MPS)
+    sync()
+    dt = time.perf_counter() - t0
+    prof = eng.profile_read()
+    eng.profile_enable(False)
+    return dt, prof
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--nx", type=int, default=1000, help="M-1M grid side (default 1000 -> 1M nodes)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import mgn_amd
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the engine has no CPU path")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    def barrier_sync():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    ps = glorot_params()
+    pos, s, r = mgn_amd.synth.mesh_1m(1234, args.nx, args.nx)
+    N, E = pos.shape[0], int(s.size)
+
+    eng = mgn_amd.Engine(FN, FE, O, L, 2, MPS, rank=rank, nranks=world, device=local_rank)
+    eng.set_stream(torch.cuda.current_stream().cuda_stream)
+    eng.set_params(ps)
+    eng.set_graph(s, r, N, mesh_pos=pos)
+    eng.latents_randn(1234)
+
+    if world == 1:
+        barrier_sync()
+        dt, prof = time_single(eng, args.steps, args.warmup, barrier_sync)
+    else:
+        from importlib import import_module
+        halo = import_module("mgn_amd.halo")
+        ex = halo.DistExchange(eng, torch.device("cuda", local_rank))
+        for _ in range(args.warmup):
+            mgn_amd.run_processor_staged([eng], ex, MPS)
+        barrier_sync()
+        eng.profile_enable(True)
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            mgn_amd.run_processor_staged([eng], ex, MPS)
+        barrier_sync()
+        dt = time.perf_counter() - t0
+        prof = eng.profile_read()
+        eng.profile_enable(False)
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    chk = eng.latents_checksum()
+    finite = all(np.isfinite(v) for v in chk.values())
+
+    if rank == 0:
+        t_edge = prof["edge_step"]["avg_ms"] * 1e-3
+        t_node = prof["node_step"]["avg_ms"] * 1e-3
+        e_loc, n_loc = eng.e_local, eng.n_own
+        ach = flops_edge_kernel(e_loc) / t_edge / 1e12 if t_edge > 0 else 0.0
+        t_step = dt / (args.steps * MPS)
+        # node kernel average mixes 14 projecting launches, 1 without and 1 projection-only per pass
+        node_flops_pass = (MPS - 1) * flops_node_kernel(n_loc, True) + flops_node_kernel(n_loc, False) + 2.0 * 2 * L * L * n_loc
+        node_launches = MPS + 1
+        out = {
+            "metric": "processor-step edges/s",
+            "value": E * MPS * args.steps / dt,
+            "unit": "edges/s",
+            "nodes_per_s": N * MPS * args.steps / dt,
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "ms_per_processor_step": t_step * 1e3,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"M-1M jittered-grid triangulation {args.nx}x{args.nx}: N={N} nodes, E={E} directed edges, "
+                                   f"L=128, hidden_layers=2, {MPS} processor steps per bench step, fp32 (BASELINE.json configs[3])",
+                       "partition": f"edge-cut RCB over {world} GPU(s)" if world > 1 else "single partition",
+                       "edge_order": "engine re-sorts by receiver once per trajectory (mgn_set_graph)"},
+            "roofline": {
+                "bound": "mfma", "kernel": "k_edge_step<4,2> (fused gather + edge MLP + LayerNorm + residual + segmented scatter)",
+                "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS,
+                "flops_per_launch": flops_edge_kernel(e_loc), "flops_kind": "MFMA flops executed by this kernel (98 304 per edge; "
+                "layer 1 is factored so the v_s/v_r blocks run per node in k_node_step)",
+                "avg_launch_ms": t_edge * 1e3, "launches": prof["edge_step"]["count"], "traffic": None,
+                "node_kernel": {"avg_launch_ms": t_node * 1e3, "launches": prof["node_step"]["count"],
+                                "achieved": node_flops_pass / node_launches / t_node / 1e12 if t_node > 0 else 0.0},
+                "processor_step_algorithmic": {
+                    "flops_per_step": flops_algorithmic(e_loc, n_loc),
+                    "achieved": flops_algorithmic(E, N) / t_step / 1e12, "peak": PEAK_F32_MFMA_TFLOPS * world,
+                    "frac": flops_algorithmic(E, N) / t_step / 1e12 / (PEAK_F32_MFMA_TFLOPS * world),
+                    "note": "SURVEY.md 8(d) un-factored GEMM flops (163 840 E + 131 072 N) / wall time per step"},
+            },
+            "latents_finite": bool(finite),
+        }
+        if world == 1 and not args.no_secondary:
+            pos2, cells2, _, _ = mgn_amd.synth.mesh_cyl(1234, 2000)
+            s2, r2 = mgn_amd.synth.cells_to_edges(cells2)
+            eng2 = mgn_amd.Engine(FN, FE, O, L, 2, MPS, device=local_rank)
+            eng2.set_stream(torch.cuda.current_stream().cuda_stream)
+            eng2.set_params(ps)
+            eng2.set_graph(s2, r2, pos2.shape[0])
+            eng2.latents_randn(1234)
+            dt2, prof2 = time_single(eng2, max(args.steps, 20), max(args.warmup, 5), barrier_sync)
+            k2 = max(args.steps, 20)
+            out["secondary"] = {"workload": f"M-cyl Delaunay 2000 pts: N={pos2.shape[0]}, E={s2.size}, L=128, 15 steps, fp32 (BASELINE.json configs[1])",
+                                "edges_per_s": s2.size * MPS * k2 / dt2, "nodes_per_s": pos2.shape[0] * MPS * k2 / dt2,
+                                "us_per_processor_step": dt2 / (k2 * MPS) * 1e6,
+                                "edge_kernel_us": prof2["edge_step"]["avg_ms"] * 1e3, "node_kernel_us": prof2["node_step"]["avg_ms"] * 1e3}
+            eng2.close()
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(ps)
+        print(json.dumps(out), flush=True)
+
+    eng.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
