@@ -48,6 +48,7 @@ def build_hip(force=False, verbose=True):
     os.makedirs(objdir, exist_ok=True)
     hipcc = hipcc_path()
     common = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-I", os.path.join(ROOT, "include")]
+    common += os.environ.get("MGN_HIPCC_FLAGS", "").split()  # experiments only (e.g. -DMGN_EXP_...)
     objs = []
     for s in srcs:
         o = os.path.join(objdir, os.path.basename(s) + ".o")

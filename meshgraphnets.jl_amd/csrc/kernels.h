@@ -19,18 +19,20 @@ struct EdgeArgs {
     int32_t ntiles;
     const float* P;         // [n_own+n_halo][L]  v * W1[0:L]      (sender part of edge-MLP layer 1)
     const float* Q;         // [n_own][L]         v * W1[L:2L]+b1  (receiver part + bias)
-    float* Elat;            // [E][L] edge latents, updated in place
-    float* AGG;             // [n_own+1][L] per-receiver sums of e' (row n_own stays zero)
-    float* CARRY;           // [2*ntiles][L] partial sums of receiver segments that straddle tiles
+    float* Elat;            // tile-major [ntiles][16 pieces][64 lanes][4]: edge latents, updated in place
+    float* AGG;             // tile-major over NODE tiles: per-receiver sums of e'
+    float* CARRY;           // row-major [2*ntiles+1][L]: partial sums of receiver runs that straddle edge tiles; last row = 0
     const float* chunk[MAX_CHUNKS];  // 0:W2 1:W3 2:W1[2L:3L]   (fragment order)
     const float* tabs;      // T_COUNT * L floats (fragment order): b2,b3 in T_B2,T_B3; LN in T_GAMMA,T_BETA
+    int32_t stagger;        // s_sleep(127) units by which waves 4..7 of a block start late
+    unsigned long long* stamps;  // diagnostic builds only (MGN_DIAG_STAMPS), else null
 };
 
 struct NodeArgs {
     int32_t n;              // owned nodes
     int32_t ntiles;
     const int32_t* rowptr;  // [n+1] CSR by receiver over the local (receiver-sorted) edge list
-    float* V;               // [n][L] node latents, updated in place
+    float* V;               // tile-major node latents, updated in place
     const float* AGG;
     const float* CARRY;
     float* P;
@@ -38,6 +40,8 @@ struct NodeArgs {
     const float* chunk[MAX_CHUNKS];  // 0:W2 1:W3 2:W1[0:L] 3:W1[L:2L] 4:WP(next) 5:WQ(next)
     const float* tabs;      // b1,b2,b3,gamma,beta,bq
     int32_t mode;           // 0: MLP only (last step)  1: MLP + project P,Q  2: project only
+    int32_t stagger;
+    int64_t zero_row;       // CARRY row that is all zeros (read for receivers without incoming edges)
 };
 
 struct EncNodeArgs {

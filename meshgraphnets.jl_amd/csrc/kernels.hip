@@ -45,43 +45,56 @@ constexpr float LN_EPS = 1e-5f;
 constexpr int NUM_XCD = 8;
 
 // ------------------------------------------------------------------------------------------------
-// fragment <-> row helpers.  Row r of an [rows][L] array; lane half h owns float4 pieces 8t+2g+h.
+// fragment <-> memory helpers.  A lane (c,h) owns 4*NT pieces of 4 floats: piece m = 4t+g holds
+// features 32t + 8g + 4h + {0..3} of row c and lives in registers x[t][4g..4g+3].  Two memory layouts:
+//   row-major   [row][L]            piece m of lane (c,h) at  row*L + (2m+h)*4        -> stride 2 float4
+//   tile-major  [tile][m][lane][4]  piece m of lane l     at  tile*32L + m*256 + l*4  -> stride 64 float4
+// Tile-major ("fragment-major") arrays make every wave-instruction a contiguous 1 KiB: used for all
+// arrays that are only ever touched tile-wise (edge latents, node latents, AGG); arrays gathered by
+// index (P, Q, CARRY) stay row-major.  `p` already includes the lane's own offset.
 // ------------------------------------------------------------------------------------------------
-template <int NT>
-DEVINL void load_frag(f32x16 (&x)[NT], const float* __restrict__ row, int h) {
-    const f32x4* r4 = reinterpret_cast<const f32x4*>(row) + h;
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const f32x4 v = r4[8 * t + 2 * g];
-            x[t][4 * g + 0] = v[0]; x[t][4 * g + 1] = v[1]; x[t][4 * g + 2] = v[2]; x[t][4 * g + 3] = v[3];
-        }
+constexpr int STRIDE_ROW = 2, STRIDE_TILE = 64;
+
+DEVINL const f32x4* row_ptr(const float* base, int64_t row, int L, int h) {
+    return reinterpret_cast<const f32x4*>(base + row * L) + h;
+}
+DEVINL f32x4* row_ptr(float* base, int64_t row, int L, int h) { return reinterpret_cast<f32x4*>(base + row * L) + h; }
+DEVINL const f32x4* tile_ptr(const float* base, int64_t tile, int L, int lane) {
+    return reinterpret_cast<const f32x4*>(base + tile * (TILE * L)) + lane;
+}
+DEVINL f32x4* tile_ptr(float* base, int64_t tile, int L, int lane) {
+    return reinterpret_cast<f32x4*>(base + tile * (TILE * L)) + lane;
 }
 
 template <int NT>
-DEVINL void add_frag(f32x16 (&x)[NT], const float* __restrict__ row, int h) {
-    const f32x4* r4 = reinterpret_cast<const f32x4*>(row) + h;
+DEVINL void load_frag(f32x16 (&x)[NT], const f32x4* __restrict__ p, int stride) {
 #pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const f32x4 v = r4[8 * t + 2 * g];
-            x[t][4 * g + 0] += v[0]; x[t][4 * g + 1] += v[1]; x[t][4 * g + 2] += v[2]; x[t][4 * g + 3] += v[3];
-        }
+    for (int m = 0; m < 4 * NT; ++m) {
+        const f32x4 v = p[m * stride];
+        x[m >> 2][4 * (m & 3) + 0] = v[0]; x[m >> 2][4 * (m & 3) + 1] = v[1];
+        x[m >> 2][4 * (m & 3) + 2] = v[2]; x[m >> 2][4 * (m & 3) + 3] = v[3];
+    }
 }
 
 template <int NT>
-DEVINL void store_frag(float* __restrict__ row, const f32x16 (&x)[NT], int h) {
-    f32x4* r4 = reinterpret_cast<f32x4*>(row) + h;
+DEVINL void add_frag(f32x16 (&x)[NT], const f32x4* __restrict__ p, int stride) {
 #pragma unroll
-    for (int t = 0; t < NT; ++t)
+    for (int m = 0; m < 4 * NT; ++m) {
+        const f32x4 v = p[m * stride];
+        x[m >> 2][4 * (m & 3) + 0] += v[0]; x[m >> 2][4 * (m & 3) + 1] += v[1];
+        x[m >> 2][4 * (m & 3) + 2] += v[2]; x[m >> 2][4 * (m & 3) + 3] += v[3];
+    }
+}
+
+template <int NT>
+DEVINL void store_frag(f32x4* __restrict__ p, int stride, const f32x16 (&x)[NT]) {
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            f32x4 v;
-            v[0] = x[t][4 * g + 0]; v[1] = x[t][4 * g + 1]; v[2] = x[t][4 * g + 2]; v[3] = x[t][4 * g + 3];
-            r4[8 * t + 2 * g] = v;
-        }
+    for (int m = 0; m < 4 * NT; ++m) {
+        f32x4 v;
+        v[0] = x[m >> 2][4 * (m & 3) + 0]; v[1] = x[m >> 2][4 * (m & 3) + 1];
+        v[2] = x[m >> 2][4 * (m & 3) + 2]; v[3] = x[m >> 2][4 * (m & 3) + 3];
+        p[m * stride] = v;
+    }
 }
 
 // table (bias / gamma / beta) in fragment order: float4 tab[4*NT][2]
@@ -215,6 +228,30 @@ struct TileWalk {
     }
 };
 
+// Waves w and w+4 of a block share a SIMD and run the same program; started together they stay in
+// lockstep (both gather, then both want the MFMA pipe).  Delaying the second half once by about half a
+// tile period makes one wave's memory/VALU phase coincide with its partner's MFMA chain.
+DEVINL void stagger_second_half(int wave, int units) {
+    if (wave >= 4)
+        for (int i = 0; i < units; ++i) __builtin_amdgcn_s_sleep(127);
+}
+
+// Diagnostic build only (-DMGN_DIAG_STAMPS): s_memtime stamps per tile phase; no stamp executes in the
+// shipped kernel.  Values go to a buffer no other code reads.
+#ifdef MGN_DIAG_STAMPS
+#define STAMP(slot)                                                                              \
+    do {                                                                                         \
+        __builtin_amdgcn_sched_barrier(0);                                                       \
+        unsigned long long _t;                                                                   \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t)::"memory");              \
+        __builtin_amdgcn_sched_barrier(0);                                                       \
+        if (a.stamps && blockIdx.x < 4 && stamp_tile < 24 && lane0 == 0)                         \
+            a.stamps[(((size_t)blockIdx.x * 8 + wave) * 24 + stamp_tile) * 8 + (slot)] = _t;     \
+    } while (0)
+#else
+#define STAMP(slot) do {} while (0)
+#endif
+
 template <int CTRL, int ROWMASK>
 DEVINL float dpp_zero(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROWMASK, 0xF, true));
@@ -223,7 +260,24 @@ DEVINL float dpp_zero(float v) {
 // ================================================================================================
 // Processor edge step (K3+K4+K5): gather, edge MLP, LayerNorm, residual, segmented scatter.
 // chunk[0]=W2 chunk[1]=W3 chunk[2]=W1[2L:3L];  NRES leading chunks are LDS-resident.
+// Elat and AGG are tile-major; P, Q, CARRY row-major.
 // ================================================================================================
+struct EdgeIdx {
+    int s, r, r_before, r_after;
+};
+
+DEVINL EdgeIdx load_edge_idx(const EdgeArgs& a, int tile, int c) {
+    EdgeIdx ix;
+    const int64_t e0 = (int64_t)tile * TILE;
+    const int64_t eid = e0 + c;
+    const bool valid = eid < a.E;
+    ix.s = valid ? a.snd[eid] : 0;
+    ix.r = valid ? a.rcv[eid] : -1;                                   // -1 marks a padding lane
+    ix.r_before = (tile > 0) ? a.rcv[e0 - 1] : -2;                    // wave-uniform
+    ix.r_after = (e0 + TILE < a.E) ? a.rcv[e0 + TILE] : -3;           // wave-uniform
+    return ix;
+}
+
 template <int NT, int NRES>
 __global__ __launch_bounds__(512, 2) void k_edge_step(const EdgeArgs a) {
     constexpr int L = 32 * NT, CH = 16 * NT * 64 * NT;
@@ -239,37 +293,51 @@ __global__ __launch_bounds__(512, 2) void k_edge_step(const EdgeArgs a) {
     const float* w2 = NRES > 0 ? smem : a.chunk[0];
     const float* w3 = NRES > 1 ? smem + CH : a.chunk[1];
     const float* w1 = NRES > 2 ? smem + 2 * CH : a.chunk[2];
+    stagger_second_half(wave, a.stagger);
 
-    for (TileWalk tw(a.ntiles, wave); tw.tile < tw.end; tw.tile += tw.stride) {
+    TileWalk tw(a.ntiles, wave);
+    if (tw.tile >= tw.end) return;
+    EdgeIdx ix = load_edge_idx(a, tw.tile, lane0 & 31);
+    int stamp_tile = 0;
+    (void)stamp_tile;
+    for (;; ++stamp_tile) {
         OPAQUE_LANE();
         const int tile = tw.tile;
-        const int64_t e0 = (int64_t)tile * TILE;
-        const int64_t eid = e0 + c;
-        const bool valid = eid < a.E;
-        const int s = valid ? a.snd[eid] : 0;
-        const int r = valid ? a.rcv[eid] : 0;
-        float* erow = a.Elat + (valid ? eid : 0) * L;
+        const int next = tile + tw.stride;
+        const bool has_next = next < tw.end;
+        STAMP(0);
+        // indices of the NEXT tile are fetched now, ahead of this tile's stores: vmcnt retires in order, so
+        // an index load issued after the epilogue stores would wait for every one of them.
+        EdgeIdx ixn = ix;
+        if (has_next) ixn = load_edge_idx(a, next, c);
 
+        const bool valid = ix.r >= 0;
+        const int r = valid ? ix.r : 0;
+        f32x4* etile = tile_ptr(a.Elat, tile, L, lane);
         f32x16 x[NT], acc[NT], y[NT];
-        load_frag<NT>(acc, a.P + (int64_t)s * L, h);
-        add_frag<NT>(acc, a.Q + (int64_t)r * L, h);
-        load_frag<NT>(x, erow, h);
+        load_frag<NT>(acc, row_ptr(a.P, ix.s, L, h), STRIDE_ROW);
+        add_frag<NT>(acc, row_ptr(a.Q, r, L, h), STRIDE_ROW);
+        load_frag<NT>(x, etile, STRIDE_TILE);
+        STAMP(1);
 
         mfma_chunk<NT, (NRES > 2)>(acc, x, w1, lane);          // layer 1 (edge part; P,Q,b1 preloaded)
+        STAMP(2);
         relu_frag<NT>(acc);
         tab_frag<NT>(y, tb + T_B2 * L, h);
         mfma_chunk<NT, (NRES > 0)>(y, acc, w2, lane);          // layer 2
+        STAMP(3);
         relu_frag<NT>(y);
         tab_frag<NT>(acc, tb + T_B3 * L, h);
         mfma_chunk<NT, (NRES > 1)>(acc, y, w3, lane);          // layer 3
+        STAMP(4);
         layer_norm_frag<NT>(acc, tb + T_GAMMA * L, tb + T_BETA * L, h);   // acc = e'
 
 #pragma unroll
         for (int t = 0; t < NT; ++t) x[t] += acc[t];            // e <- e + e'
-        if (valid) store_frag<NT>(erow, x, h);
+        if (valid) store_frag<NT>(etile, STRIDE_TILE, x);       // padding rows of the last tile stay zero
 
         // ---- segmented sum of e' over runs of equal receiver (both halves see the same structure)
-        const int reff = valid ? r : (-1 - c);
+        const int reff = valid ? r : (-4 - c);
         const int rprev = __shfl_up(reff, 1, 32);
         const int rnext = __shfl_down(reff, 1, 32);
         const bool head = (c == 0) || (reff != rprev);
@@ -294,20 +362,24 @@ __global__ __launch_bounds__(512, 2) void k_edge_step(const EdgeArgs a) {
                 acc[t][k] = v;
             }
         const bool tail = valid && ((c == 31) || (reff != rnext));
-        const int r_before = (tile > 0) ? a.rcv[e0 - 1] : -1;                 // wave-uniform
-        const int r_after = (e0 + TILE < a.E) ? a.rcv[e0 + TILE] : -2;        // wave-uniform
         const int r_first = __builtin_amdgcn_readfirstlane(reff);
-        const bool sl = (start == 0) && (r_before == r_first);
-        const bool sr = (c == 31) && (r_after == reff);
-        float* dst = sl ? a.CARRY + (int64_t)(2 * tile) * L
-                        : (sr ? a.CARRY + (int64_t)(2 * tile + 1) * L : a.AGG + (int64_t)r * L);
-        if (tail) store_frag<NT>(dst, acc, h);
+        const bool sl = (start == 0) && (ix.r_before == r_first);   // run continues from the previous tile
+        const bool sr = (c == 31) && (ix.r_after == reff);          // run continues into the next tile
+        const bool to_carry = sl || sr;
+        f32x4* dst = to_carry ? row_ptr(a.CARRY, (int64_t)2 * tile + (sl ? 0 : 1), L, h)
+                              : tile_ptr(a.AGG, r >> 5, L, 32 * h + (r & 31));
+        if (tail) store_frag<NT>(dst, to_carry ? STRIDE_ROW : STRIDE_TILE, acc);
+        STAMP(5);
+        if (!has_next) break;
+        ix = ixn;
+        tw.tile = next;
     }
 }
 
 // ================================================================================================
 // Processor node step (K6) + projection of next step's P,Q.
 // chunk[0]=W2 chunk[1]=W3 chunk[2]=W1[0:L] chunk[3]=W1[L:2L] chunk[4]=WP chunk[5]=WQ
+// V and AGG tile-major; CARRY, P, Q row-major.  CARRY row 2*ntiles_e is the all-zero row.
 // ================================================================================================
 template <int NT, int NRES>
 __global__ __launch_bounds__(512, 2) void k_node_step(const NodeArgs a) {
@@ -333,26 +405,29 @@ __global__ __launch_bounds__(512, 2) void k_node_step(const NodeArgs a) {
     const float* w1a = NRES > 3 ? smem + 3 * CH : a.chunk[3];
     const float* wp = NRES > 4 ? smem + 4 * CH : a.chunk[4];
     const float* wq = NRES > 5 ? smem + 5 * CH : a.chunk[5];
+    stagger_second_half(wave, a.stagger);
 
     for (TileWalk tw(a.ntiles, wave); tw.tile < tw.end; tw.tile += tw.stride) {
         OPAQUE_LANE();
-        const int n = tw.tile * TILE + c;
+        const int tile = tw.tile;
+        const int n = tile * TILE + c;
         const bool valid = n < a.n;
         const int nn = valid ? n : 0;
-        float* vrow = a.V + (int64_t)nn * L;
+        f32x4* vtile = tile_ptr(a.V, tile, L, lane);
         f32x16 v[NT], acc[NT], y[NT];
-        load_frag<NT>(v, vrow, h);
+        load_frag<NT>(v, vtile, STRIDE_TILE);
 
         if (a.mode != 2) {
-            // aggregated messages: AGG row, or carry rows when the receiver's edge run straddles tiles
+            // aggregated messages: this node's AGG slot, or carry rows when its edge run straddles edge tiles
             const int a0 = valid ? a.rowptr[nn] : 0, a1 = valid ? a.rowptr[nn + 1] : 0;
             const int T1 = a0 >> 5, T2 = (a1 - 1) >> 5;
             const int extra = (a1 > a0 && T2 > T1) ? (T2 - T1) : 0;
-            const float* src0 = (a1 == a0) ? a.AGG + (int64_t)a.n * L
-                                           : (extra ? a.CARRY + (int64_t)(2 * T1 + 1) * L : a.AGG + (int64_t)nn * L);
-            load_frag<NT>(y, src0, h);
+            const bool from_agg = (a1 > a0) && !extra;
+            const f32x4* src0 = from_agg ? tile_ptr(a.AGG, tile, L, lane)
+                                         : row_ptr(a.CARRY, extra ? (int64_t)(2 * T1 + 1) : a.zero_row, L, h);
+            load_frag<NT>(y, src0, from_agg ? STRIDE_TILE : STRIDE_ROW);
             for (int q = 1; __any(q <= extra); ++q)
-                if (q <= extra) add_frag<NT>(y, a.CARRY + (int64_t)(2 * (T1 + q)) * L, h);
+                if (q <= extra) add_frag<NT>(y, row_ptr(a.CARRY, (int64_t)2 * (T1 + q), L, h), STRIDE_ROW);
 
             tab_frag<NT>(acc, tb + T_B1 * L, h);
             mfma_chunk<NT, (NRES > 2)>(acc, v, w1v, lane);     // layer 1, node part
@@ -366,15 +441,15 @@ __global__ __launch_bounds__(512, 2) void k_node_step(const NodeArgs a) {
             layer_norm_frag<NT>(acc, tb + T_GAMMA * L, tb + T_BETA * L, h);
 #pragma unroll
             for (int t = 0; t < NT; ++t) v[t] += acc[t];        // v <- v + v'
-            if (valid) store_frag<NT>(vrow, v, h);
+            if (valid) store_frag<NT>(vtile, STRIDE_TILE, v);
         }
         if (a.mode != 0) {
             zero_frag<NT>(acc);
             mfma_chunk<NT, (NRES > 4)>(acc, v, wp, lane);
-            if (valid) store_frag<NT>(a.P + (int64_t)nn * L, acc, h);
+            if (valid) store_frag<NT>(row_ptr(a.P, nn, L, h), STRIDE_ROW, acc);
             tab_frag<NT>(y, tb + T_BQ * L, h);
             mfma_chunk<NT, (NRES > 5)>(y, v, wq, lane);
-            if (valid) store_frag<NT>(a.Q + (int64_t)nn * L, y, h);
+            if (valid) store_frag<NT>(row_ptr(a.Q, nn, L, h), STRIDE_ROW, y);
         }
     }
 }
@@ -434,13 +509,14 @@ __global__ __launch_bounds__(512, 2) void k_enc_node(const EncNodeArgs a) {
         tab_frag<NT>(acc, tb + T_B3 * L, h);
         mfma_chunk<NT, (NRES > 1)>(acc, y, w3, lane);
         layer_norm_frag<NT>(acc, tb + T_GAMMA * L, tb + T_BETA * L, h);
-        if (valid) store_frag<NT>(a.V + (int64_t)nn * L, acc, h);
+        if (!valid) zero_frag<NT>(acc);                          // padding rows stay zero (checksums)
+        store_frag<NT>(tile_ptr(a.V, tw.tile, L, lane), STRIDE_TILE, acc);
         zero_frag<NT>(y);
         mfma_chunk<NT, (NRES > 2)>(y, acc, wp, lane);
-        if (valid) store_frag<NT>(a.P + (int64_t)nn * L, y, h);
+        if (valid) store_frag<NT>(row_ptr(a.P, nn, L, h), STRIDE_ROW, y);
         tab_frag<NT>(y, tb + T_BQ * L, h);
         mfma_chunk<NT, (NRES > 3)>(y, acc, wq, lane);
-        if (valid) store_frag<NT>(a.Q + (int64_t)nn * L, y, h);
+        if (valid) store_frag<NT>(row_ptr(a.Q, nn, L, h), STRIDE_ROW, y);
     }
 }
 
@@ -481,7 +557,8 @@ __global__ __launch_bounds__(512, 2) void k_enc_edge(const EncEdgeArgs a) {
         tab_frag<NT>(acc, tb + T_B3 * L, h);
         mfma_chunk<NT, (NRES > 1)>(acc, y, w3, lane);
         layer_norm_frag<NT>(acc, tb + T_GAMMA * L, tb + T_BETA * L, h);
-        if (valid) store_frag<NT>(a.Elat + ee * L, acc, h);
+        if (!valid) zero_frag<NT>(acc);
+        store_frag<NT>(tile_ptr(a.Elat, tw.tile, L, lane), STRIDE_TILE, acc);
     }
 }
 
@@ -508,7 +585,7 @@ __global__ __launch_bounds__(512, 2) void k_decode(const DecArgs a) {
         const bool valid = n < a.n;
         const int nn = valid ? n : 0;
         f32x16 v[NT], acc[NT];
-        load_frag<NT>(v, a.V + (int64_t)nn * L, h);
+        load_frag<NT>(v, tile_ptr(a.V, tw.tile, L, lane), STRIDE_TILE);
         tab_frag<NT>(acc, tb + T_B1 * L, h);
         mfma_chunk<NT, (NRES > 0)>(acc, v, w1, lane);
         relu_frag<NT>(acc);
@@ -555,13 +632,19 @@ DEVINL uint64_t splitmix64(uint64_t x) {
     return x ^ (x >> 31);
 }
 
-// N(0,1) keyed by (seed, global row id, feature): identical whatever the partition (KAT-7 at scale)
+// N(0,1) keyed by (seed, global row id, feature): identical whatever the partition (KAT-7 at scale).
+// dst is TILE-MAJOR storage of `rows` rows padded to whole 32-row tiles; padding rows are zeroed.
 __global__ void k_randn_rows(float* __restrict__ dst, const int64_t* __restrict__ gid64, const int32_t* __restrict__ gid32,
                              int64_t rows, int L, uint64_t seed) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= rows * L) return;
-    const int64_t r = i / L;
-    const int f = (int)(i - r * L);
+    const int64_t ntl = (rows + TILE - 1) / TILE;
+    if (i >= ntl * TILE * L) return;
+    const int64_t tile = i / (TILE * L);
+    const int rem = (int)(i - tile * (TILE * L));
+    const int m = rem >> 8, lane = (rem & 255) >> 2, q = rem & 3;
+    const int64_t r = tile * TILE + (lane & 31);
+    const int f = 32 * (m >> 2) + 8 * (m & 3) + 4 * (lane >> 5) + q;
+    if (r >= rows) { dst[i] = 0.f; return; }
     const uint64_t g = gid64 ? (uint64_t)gid64[r] : (gid32 ? (uint64_t)gid32[r] : (uint64_t)r);
     const uint64_t bits = splitmix64(seed ^ splitmix64(g * (uint64_t)L + (uint64_t)f));
     const float u1 = ((float)(uint32_t)(bits >> 40) + 1.0f) * (1.0f / 16777216.0f);  // (0,1]
@@ -663,7 +746,7 @@ hipError_t launch_gather_rows(const float* src, const int32_t* idx, float* dst, 
 hipError_t launch_randn_rows(float* dst, const int64_t* gid64, const int32_t* gid32, int64_t rows, int L, uint64_t seed,
                              hipStream_t s) {
     if (rows <= 0) return hipSuccess;
-    const int64_t n = rows * L;
+    const int64_t n = ((rows + TILE - 1) / TILE) * TILE * L;
     hipLaunchKernelGGL(k_randn_rows, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, dst, gid64, gid32, rows, L, seed);
     return hipGetLastError();
 }

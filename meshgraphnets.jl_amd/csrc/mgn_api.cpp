@@ -6,6 +6,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -62,6 +63,7 @@ struct mgn_engine {
     hipStream_t stream = nullptr;
     hipStream_t own_stream = nullptr;
     bool host_only = false;
+    int32_t stagger_edge = 8, stagger_node = 8;  // tunables (MGN_STAGGER_EDGE / MGN_STAGGER_NODE)
 
     // parameters
     bool have_params = false;
@@ -87,6 +89,7 @@ struct mgn_engine {
     DevBuf d_snd, d_rcv, d_rowptr, d_own_gid, d_edge_gid, d_send_idx;
 
     // latents and I/O
+    DevBuf d_stamps;  // diagnostic builds only
     DevBuf V, P, Q, Elat, AGG, CARRY, d_nfA, d_nfB, d_ef, d_out, d_mask, d_sum;
     int32_t in_wa = 0, in_wb = 0;
     bool have_mask = false;
@@ -208,20 +211,36 @@ struct ProfScope {
 
 const float* W(const mgn_engine* h, size_t off) { return h->wfrag.as<float>() + off; }
 
+// tile-major storage: rows padded to whole 32-row tiles
+size_t tile_floats(int64_t ntiles, int L) { return (size_t)ntiles * TILE * L; }
+
+// host <-> tile-major conversion of one row (see kernels.hip "fragment <-> memory helpers")
+inline size_t tile_index(int64_t row, int f, int L) {
+    const int64_t tile = row / TILE;
+    const int c = (int)(row % TILE);
+    const int m = 4 * (f >> 5) + ((f & 31) >> 3), hh = (f & 7) >> 2, i = f & 3;
+    return (size_t)tile * TILE * L + (size_t)m * 256 + (size_t)(32 * hh + c) * 4 + i;
+}
+
 int alloc_latents(mgn_engine* h) {
     const int L = h->cfg.L;
     const LocalGraph& g = h->g;
-    HIPCHK(h, h->V.ensure((size_t)g.n_own * L * 4));
-    HIPCHK(h, h->P.ensure((size_t)(g.n_own + g.n_halo) * L * 4));
-    HIPCHK(h, h->Q.ensure((size_t)g.n_own * L * 4));
-    HIPCHK(h, h->Elat.ensure((size_t)g.e_local * L * 4));
-    HIPCHK(h, h->AGG.ensure((size_t)(g.n_own + 1) * L * 4));
-    HIPCHK(h, h->CARRY.ensure((size_t)2 * (h->ntiles_e > 0 ? h->ntiles_e : 1) * L * 4));
-    HIPCHK(h, h->d_out.ensure((size_t)g.n_own * h->cfg.O * 4));
+    const int64_t nte = h->ntiles_e > 0 ? h->ntiles_e : 1, ntn = h->ntiles_n > 0 ? h->ntiles_n : 1;
+    HIPCHK(h, h->V.ensure(tile_floats(ntn, L) * 4));
+    HIPCHK(h, h->P.ensure((size_t)(g.n_own + g.n_halo + 1) * L * 4));
+    HIPCHK(h, h->Q.ensure((size_t)(g.n_own + 1) * L * 4));
+    HIPCHK(h, h->Elat.ensure(tile_floats(nte, L) * 4));
+    HIPCHK(h, h->AGG.ensure(tile_floats(ntn, L) * 4));
+    HIPCHK(h, h->CARRY.ensure((size_t)(2 * nte + 1) * L * 4));
+    HIPCHK(h, h->d_out.ensure((size_t)(g.n_own + 1) * h->cfg.O * 4));
     HIPCHK(h, h->d_sum.ensure(4 * sizeof(double)));
-    // row n_own of AGG is the all-zero row read for receivers without incoming edges
-    HIPCHK(h, hipMemsetAsync(h->AGG.p, 0, (size_t)(g.n_own + 1) * L * 4, h->stream));
-    HIPCHK(h, hipMemsetAsync(h->P.p, 0, (size_t)(g.n_own + g.n_halo) * L * 4, h->stream));
+    // padding rows of the tile-major arrays and the zero row of CARRY (its last row) must read as 0
+    HIPCHK(h, hipMemsetAsync(h->V.p, 0, tile_floats(ntn, L) * 4, h->stream));
+    HIPCHK(h, hipMemsetAsync(h->Elat.p, 0, tile_floats(nte, L) * 4, h->stream));
+    HIPCHK(h, hipMemsetAsync(h->AGG.p, 0, tile_floats(ntn, L) * 4, h->stream));
+    HIPCHK(h, hipMemsetAsync(h->CARRY.p, 0, (size_t)(2 * nte + 1) * L * 4, h->stream));
+    HIPCHK(h, hipMemsetAsync(h->P.p, 0, (size_t)(g.n_own + g.n_halo + 1) * L * 4, h->stream));
+    HIPCHK(h, hipMemsetAsync(h->Q.p, 0, (size_t)(g.n_own + 1) * L * 4, h->stream));
     return MGN_OK;
 }
 
@@ -238,6 +257,8 @@ EdgeArgs edge_args(mgn_engine* h, int k) {
     a.CARRY = h->CARRY.as<float>();
     for (int i = 0; i < 3; ++i) a.chunk[i] = W(h, h->soff[k].e_ch[i]);
     a.tabs = W(h, h->soff[k].e_tabs);
+    a.stagger = h->stagger_edge;
+    a.stamps = h->d_stamps.as<unsigned long long>();
     return a;
 }
 
@@ -254,6 +275,8 @@ NodeArgs node_args(mgn_engine* h, int k, int mode) {
     for (int i = 0; i < 6; ++i) a.chunk[i] = W(h, h->soff[k].n_ch[i]);
     a.tabs = W(h, h->soff[k].n_tabs);
     a.mode = mode;
+    a.stagger = h->stagger_node;
+    a.zero_row = 2 * (int64_t)(h->ntiles_e > 0 ? h->ntiles_e : 1);
     return a;
 }
 
@@ -291,6 +314,8 @@ int mgn_create(const mgn_config* cfg, mgn_handle** out) {
         return fail(nullptr, MGN_E_HIP, "mgn_create: hipStreamCreate failed");
     }
     h->stream = h->own_stream;
+    if (const char* e = getenv("MGN_STAGGER_EDGE")) h->stagger_edge = atoi(e);
+    if (const char* e = getenv("MGN_STAGGER_NODE")) h->stagger_node = atoi(e);
     layout_all(h);
     *out = h;
     return MGN_OK;
@@ -721,10 +746,16 @@ int mgn_latents_import(mgn_handle* h, const float* v, const float* e) {
     if (int rc = need(h, false, true)) return rc;
     if (!v || (!e && h->g.e_local > 0)) return fail(h, MGN_E_ARG, "mgn_latents_import: null input");
     const LocalGraph& g = h->g;
-    const size_t L = h->cfg.L;
-    std::vector<float> tv((size_t)g.n_own * L), te((size_t)g.e_local * L);
-    for (int32_t i = 0; i < g.n_own; ++i) memcpy(&tv[(size_t)i * L], v + (size_t)g.own_gid[i] * L, L * 4);
-    for (int64_t i = 0; i < g.e_local; ++i) memcpy(&te[(size_t)i * L], e + (size_t)g.edge_gid[i] * L, L * 4);
+    const int L = h->cfg.L;
+    std::vector<float> tv(tile_floats(h->ntiles_n, L), 0.f), te(tile_floats(h->ntiles_e, L), 0.f);
+    for (int32_t i = 0; i < g.n_own; ++i) {
+        const float* src = v + (size_t)g.own_gid[i] * L;
+        for (int f = 0; f < L; ++f) tv[tile_index(i, f, L)] = src[f];
+    }
+    for (int64_t i = 0; i < g.e_local; ++i) {
+        const float* src = e + (size_t)g.edge_gid[i] * L;
+        for (int f = 0; f < L; ++f) te[tile_index(i, f, L)] = src[f];
+    }
     HIPCHK(h, hipStreamSynchronize(h->stream));
     if (!tv.empty()) HIPCHK(h, hipMemcpy(h->V.p, tv.data(), tv.size() * 4, hipMemcpyHostToDevice));
     if (!te.empty()) HIPCHK(h, hipMemcpy(h->Elat.p, te.data(), te.size() * 4, hipMemcpyHostToDevice));
@@ -734,17 +765,23 @@ int mgn_latents_import(mgn_handle* h, const float* v, const float* e) {
 int mgn_latents_export(mgn_handle* h, float* v, float* e) {
     if (int rc = need(h, false, true)) return rc;
     const LocalGraph& g = h->g;
-    const size_t L = h->cfg.L;
+    const int L = h->cfg.L;
     HIPCHK(h, hipStreamSynchronize(h->stream));
     if (v) {
-        std::vector<float> tv((size_t)g.n_own * L);
+        std::vector<float> tv(tile_floats(h->ntiles_n, L));
         if (!tv.empty()) HIPCHK(h, hipMemcpy(tv.data(), h->V.p, tv.size() * 4, hipMemcpyDeviceToHost));
-        for (int32_t i = 0; i < g.n_own; ++i) memcpy(v + (size_t)g.own_gid[i] * L, &tv[(size_t)i * L], L * 4);
+        for (int32_t i = 0; i < g.n_own; ++i) {
+            float* dst = v + (size_t)g.own_gid[i] * L;
+            for (int f = 0; f < L; ++f) dst[f] = tv[tile_index(i, f, L)];
+        }
     }
     if (e) {
-        std::vector<float> te((size_t)g.e_local * L);
+        std::vector<float> te(tile_floats(h->ntiles_e, L));
         if (!te.empty()) HIPCHK(h, hipMemcpy(te.data(), h->Elat.p, te.size() * 4, hipMemcpyDeviceToHost));
-        for (int64_t i = 0; i < g.e_local; ++i) memcpy(e + (size_t)g.edge_gid[i] * L, &te[(size_t)i * L], L * 4);
+        for (int64_t i = 0; i < g.e_local; ++i) {
+            float* dst = e + (size_t)g.edge_gid[i] * L;
+            for (int f = 0; f < L; ++f) dst[f] = te[tile_index(i, f, L)];
+        }
     }
     return MGN_OK;
 }
@@ -762,8 +799,8 @@ int mgn_latents_checksum(mgn_handle* h, double* sv, double* se, double* qv, doub
     if (int rc = need(h, false, true)) return rc;
     const LocalGraph& g = h->g;
     HIPCHK(h, hipMemsetAsync(h->d_sum.p, 0, 4 * sizeof(double), h->stream));
-    HIPCHK(h, launch_checksum(h->V.as<float>(), (int64_t)g.n_own * h->cfg.L, h->d_sum.as<double>(), h->stream));
-    HIPCHK(h, launch_checksum(h->Elat.as<float>(), g.e_local * h->cfg.L, h->d_sum.as<double>() + 2, h->stream));
+    HIPCHK(h, launch_checksum(h->V.as<float>(), (int64_t)tile_floats(h->ntiles_n, h->cfg.L), h->d_sum.as<double>(), h->stream));
+    HIPCHK(h, launch_checksum(h->Elat.as<float>(), (int64_t)tile_floats(h->ntiles_e, h->cfg.L), h->d_sum.as<double>() + 2, h->stream));
     double r[4];
     HIPCHK(h, hipMemcpyAsync(r, h->d_sum.p, sizeof r, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -812,6 +849,19 @@ int mgn_halo_unpack(mgn_handle* h, const void* recv_dev) {
     ProfScope ps(h, F_HALO);
     HIPCHK(h, hipMemcpyAsync(h->P.as<float>() + (size_t)g.n_own * h->cfg.L, recv_dev, (size_t)g.n_halo * h->cfg.L * 4,
                              hipMemcpyDeviceToDevice, h->stream));
+    return MGN_OK;
+}
+
+// ---- diagnostics (not part of the public header; meaningful only with -DMGN_DIAG_STAMPS) -----------------
+int mgn_debug_edge_stamps(mgn_handle* h, int32_t k, unsigned long long* out /* [4*8*24*8] */) {
+    if (int rc = need(h, true, true)) return rc;
+    const size_t n = (size_t)4 * 8 * 24 * 8;
+    HIPCHK(h, h->d_stamps.ensure(n * 8));
+    HIPCHK(h, hipMemsetAsync(h->d_stamps.p, 0, n * 8, h->stream));
+    if (int rc = mgn_proc_edge(h, k)) return rc;
+    HIPCHK(h, hipMemcpyAsync(out, h->d_stamps.p, n * 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    h->d_stamps.release();
     return MGN_OK;
 }
 
