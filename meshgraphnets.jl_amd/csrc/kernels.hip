@@ -34,6 +34,10 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 #define DEVINL __device__ __forceinline__
+// Phase fence: values are SSA to the compiler, so "reuse array y for the reload" is only a hint; without a
+// fence hipcc hoists the next phase's loads above the current MFMA chain, a fourth 64-VGPR array becomes
+// live and the kernel spills.
+#define PHASE_FENCE() __builtin_amdgcn_sched_barrier(0)
 // Re-derive the lane id through an opaque asm once per tile: every address and table read that depends
 // on it then stays INSIDE the persistent tile loop.  Without this hipcc hoists ~250 loop-invariant LDS
 // table reads and 64-bit weight addresses out of the loop and spills them all to scratch.
@@ -278,6 +282,14 @@ DEVINL EdgeIdx load_edge_idx(const EdgeArgs& a, int tile, int c) {
     return ix;
 }
 
+// Register plan (L = 128: three 64-VGPR arrays, nothing else of that size may be live, the kernel must not
+// spill: vmcnt retires in order, so a scratch reload issued behind the epilogue stores waits for all of them):
+//   layer 1   acc (init P[s]+Q[r], accumulates)   x = e tile (B operand)          y  free
+//   layer 2   acc (B operand)                     x <- P[s'] of the NEXT tile      y  (accumulates)
+//   layer 3   acc (accumulates)                   x    in flight                   y  (B operand)
+//   epilogue  acc = e' (LN, scan, tail stores)    x    P[s']                       y <- e tile re-read (L2) for the
+//                                                                                       residual, then <- Q[r']
+//   turnover  acc <- x + y (= next tile's init)   x <- e tile of the next tile
 template <int NT, int NRES>
 __global__ __launch_bounds__(512, 2) void k_edge_step(const EdgeArgs a) {
     constexpr int L = 32 * NT, CH = 16 * NT * 64 * NT;
@@ -297,7 +309,14 @@ __global__ __launch_bounds__(512, 2) void k_edge_step(const EdgeArgs a) {
 
     TileWalk tw(a.ntiles, wave);
     if (tw.tile >= tw.end) return;
+    f32x16 x[NT], acc[NT], y[NT];
     EdgeIdx ix = load_edge_idx(a, tw.tile, lane0 & 31);
+    {
+        const int h0 = lane0 >> 5;
+        load_frag<NT>(acc, row_ptr(a.P, ix.s, L, h0), STRIDE_ROW);
+        add_frag<NT>(acc, row_ptr(a.Q, ix.r >= 0 ? ix.r : 0, L, h0), STRIDE_ROW);
+        load_frag<NT>(x, tile_ptr(a.Elat, tw.tile, L, lane0), STRIDE_TILE);
+    }
     int stamp_tile = 0;
     (void)stamp_tile;
     for (;; ++stamp_tile) {
@@ -306,18 +325,13 @@ __global__ __launch_bounds__(512, 2) void k_edge_step(const EdgeArgs a) {
         const int next = tile + tw.stride;
         const bool has_next = next < tw.end;
         STAMP(0);
-        // indices of the NEXT tile are fetched now, ahead of this tile's stores: vmcnt retires in order, so
-        // an index load issued after the epilogue stores would wait for every one of them.
-        EdgeIdx ixn = ix;
-        if (has_next) ixn = load_edge_idx(a, next, c);
-
+        // indices of the NEXT tile are fetched now, ahead of this tile's stores (in-order vmcnt)
+        // (the last tile of a wave harmlessly re-fetches itself: no divergent control flow around the loads)
+        const int nxt = has_next ? next : tile;
+        const EdgeIdx ixn = load_edge_idx(a, nxt, c);
         const bool valid = ix.r >= 0;
         const int r = valid ? ix.r : 0;
         f32x4* etile = tile_ptr(a.Elat, tile, L, lane);
-        f32x16 x[NT], acc[NT], y[NT];
-        load_frag<NT>(acc, row_ptr(a.P, ix.s, L, h), STRIDE_ROW);
-        add_frag<NT>(acc, row_ptr(a.Q, r, L, h), STRIDE_ROW);
-        load_frag<NT>(x, etile, STRIDE_TILE);
         STAMP(1);
 
         mfma_chunk<NT, (NRES > 2)>(acc, x, w1, lane);          // layer 1 (edge part; P,Q,b1 preloaded)
@@ -330,11 +344,14 @@ __global__ __launch_bounds__(512, 2) void k_edge_step(const EdgeArgs a) {
         tab_frag<NT>(acc, tb + T_B3 * L, h);
         mfma_chunk<NT, (NRES > 1)>(acc, y, w3, lane);          // layer 3
         STAMP(4);
+        PHASE_FENCE();
+        load_frag<NT>(y, etile, STRIDE_TILE);                   // e tile again (L2) for the residual
         layer_norm_frag<NT>(acc, tb + T_GAMMA * L, tb + T_BETA * L, h);   // acc = e'
-
+        STAMP(5);
 #pragma unroll
-        for (int t = 0; t < NT; ++t) x[t] += acc[t];            // e <- e + e'
-        if (valid) store_frag<NT>(etile, STRIDE_TILE, x);       // padding rows of the last tile stay zero
+        for (int t = 0; t < NT; ++t) y[t] += acc[t];            // e <- e + e'
+        if (valid) store_frag<NT>(etile, STRIDE_TILE, y);       // padding rows of the last tile stay zero
+        STAMP(6);
 
         // ---- segmented sum of e' over runs of equal receiver (both halves see the same structure)
         const int reff = valid ? r : (-4 - c);
@@ -347,7 +364,8 @@ __global__ __launch_bounds__(512, 2) void k_edge_step(const EdgeArgs a) {
         const bool c1 = (c - 1 >= st_in), c2 = (c - 2 >= st_in), c4 = (c - 4 >= st_in), c8 = (c - 8 >= st_in);
         const bool cx = (c >= 16) && (start <= 15);
 #pragma unroll
-        for (int t = 0; t < NT; ++t)
+        for (int t = 0; t < NT; ++t) {
+            PHASE_FENCE();   // bound the scan's temporaries to one 16-register group at a time
 #pragma unroll
             for (int k = 0; k < 16; ++k) {
                 // DPP reads must run with every lane active (an EXEC-masked source lane reads as 0), so the
@@ -361,6 +379,8 @@ __global__ __launch_bounds__(512, 2) void k_edge_step(const EdgeArgs a) {
                 u = v + dpp_zero<0x142, 0xA>(v); v = cx ? u : v;   // row_bcast:15 into rows 1 and 3
                 acc[t][k] = v;
             }
+        }
+        STAMP(7);
         const bool tail = valid && ((c == 31) || (reff != rnext));
         const int r_first = __builtin_amdgcn_readfirstlane(reff);
         const bool sl = (start == 0) && (ix.r_before == r_first);   // run continues from the previous tile
@@ -369,8 +389,12 @@ __global__ __launch_bounds__(512, 2) void k_edge_step(const EdgeArgs a) {
         f32x4* dst = to_carry ? row_ptr(a.CARRY, (int64_t)2 * tile + (sl ? 0 : 1), L, h)
                               : tile_ptr(a.AGG, r >> 5, L, 32 * h + (r & 31));
         if (tail) store_frag<NT>(dst, to_carry ? STRIDE_ROW : STRIDE_TILE, acc);
-        STAMP(5);
         if (!has_next) break;
+        PHASE_FENCE();
+        // turnover: next accumulator init = P[s'] + Q[r'];  x <- e tile of the next tile
+        load_frag<NT>(acc, row_ptr(a.P, ixn.s, L, h), STRIDE_ROW);
+        add_frag<NT>(acc, row_ptr(a.Q, ixn.r >= 0 ? ixn.r : 0, L, h), STRIDE_ROW);
+        load_frag<NT>(x, tile_ptr(a.Elat, nxt, L, lane), STRIDE_TILE);
         ix = ixn;
         tw.tile = next;
     }

@@ -13,12 +13,13 @@ out = np.zeros(4 * 8 * 24 * 8, np.uint64)
 f = eng.lib.mgn_debug_edge_stamps; f.restype = C.c_int; f.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
 assert f(eng.h, 1, out.ctypes.data_as(C.c_void_p)) == 0
 st = out.reshape(4, 8, 24, 8).astype(np.int64)
-names = ["issue_loads", "wait+L1", "L2", "L3", "LN+store+scan"]
+names = ["issue_loads", "wait+L1", "L2", "L3", "LN", "resid+store", "scan", "tailstore(to next start)"]
 for b in range(1):
     t0 = st[b, :, 0, 0].min()
     for w in range(8):
         print(f"block {b} wave {w}: start-of-tile offsets (kcyc):", np.round((st[b, w, :10, 0] - t0) / 1e3, 1))
-    d = np.diff(st[b, :, 2:20, :6], axis=-1)   # [wave][tile][phase]
+    ext = np.concatenate([st[b, :, 2:20, :8], st[b, :, 3:21, 0:1]], axis=-1)
+    d = np.diff(ext, axis=-1)   # [wave][tile][phase]
     print("mean cycles per phase (tiles 2..19), rows = waves:")
     for w in range(8):
         print("  wave", w, {n: int(d[w, :, i].mean()) for i, n in enumerate(names)}, "tile period", int(np.diff(st[b, w, 2:20, 0]).mean()))
