@@ -77,7 +77,7 @@ def load(path: str | None = None):
     global _lib
     if _lib is not None and path is None:
         return _lib
-    p = path or LIB_PATH
+    p = path or os.environ.get("MGN_LIB_PATH") or LIB_PATH   # MGN_LIB_PATH: A/B experiments only
     if not os.path.exists(p):
         raise RuntimeError(
             f"HIP extension {p} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "

@@ -38,6 +38,19 @@ def hipcc_path():
     raise RuntimeError("hipcc not found; the HIP extension cannot be built")
 
 
+def build_variant(name, flags, verbose=False):
+    """A/B experiments: compile the library with extra -D flags into lib/variants/<name>.so."""
+    vdir = os.path.join(LIBDIR, "variants")
+    os.makedirs(vdir, exist_ok=True)
+    out = os.path.join(vdir, name + ".so")
+    cmd = [hipcc_path(), "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-shared", "-I", os.path.join(ROOT, "include")]
+    cmd += list(flags) + [os.path.join(CSRC, s) for s in HIP_SOURCES] + ["-o", out]
+    if verbose:
+        print("[build]", " ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return out
+
+
 def build_hip(force=False, verbose=True):
     srcs = [os.path.join(CSRC, s) for s in HIP_SOURCES]
     deps = srcs + [h if os.path.isabs(h) else os.path.join(CSRC, h) for h in HIP_HEADERS]

@@ -38,6 +38,12 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // fence hipcc hoists the next phase's loads above the current MFMA chain, a fourth 64-VGPR array becomes
 // live and the kernel spills.
 #define PHASE_FENCE() __builtin_amdgcn_sched_barrier(0)
+// The two waves that share a SIMD arbitrate instruction issue by priority, then age: without help the older
+// wave's MFMA chain starves the younger wave's gather/LayerNorm/scan phase (measured 2-3x longer).  Every
+// wave therefore raises its priority while it is OUTSIDE its MFMA chains (-6 % kernel time, same-box A/B).
+#ifndef MGN_PRIO
+#define MGN_PRIO 1
+#endif
 // Re-derive the lane id through an opaque asm once per tile: every address and table read that depends
 // on it then stays INSIDE the persistent tile loop.  Without this hipcc hoists ~250 loop-invariant LDS
 // table reads and 64-bit weight addresses out of the loop and spills them all to scratch.
@@ -256,6 +262,31 @@ DEVINL void stagger_second_half(int wave, int units) {
 #define STAMP(slot) do {} while (0)
 #endif
 
+// MFMA-pipe token between the two waves of a SIMD (waves w and w+4 of an 8-wave block).  A wave takes the token
+// for its whole 3-layer MFMA chain and hands it over afterwards, so its partner's chain coincides with its own
+// gather / LayerNorm / scan / store phase (and the gather's latency is spent waiting for the token, not for
+// data).  The token orders no data: it is a scheduling hint with a bounded spin, any race is benign.
+struct PipeToken {
+    volatile int* tok;   // [pair]: which half (0: waves 0-3, 1: waves 4-7) may run its MFMA chain
+    volatile int* done;  // [pair]: set once by each wave when it leaves
+    int half;
+    bool paired;
+    DEVINL void acquire() const {
+        if (!paired) return;
+        for (int spins = 0; spins < 4096; ++spins) {
+            const int t = __builtin_amdgcn_readfirstlane(*tok), d = __builtin_amdgcn_readfirstlane(*done);
+            if (t == half || d) break;
+            __builtin_amdgcn_s_sleep(2);
+        }
+    }
+    DEVINL void release() const {
+        if (paired) *tok = half ^ 1;
+    }
+    DEVINL void leave() const {
+        if (paired) { *done = 1; *tok = half ^ 1; }
+    }
+};
+
 template <int CTRL, int ROWMASK>
 DEVINL float dpp_zero(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROWMASK, 0xF, true));
@@ -298,6 +329,8 @@ __global__ __launch_bounds__(512, 2) void k_edge_step(const EdgeArgs a) {
     for (int r = 0; r < NRES; ++r) copy_to_lds(smem + r * CH, a.chunk[r], CH);
     float* tb = smem + NRES * CH;
     copy_to_lds(tb, a.tabs, T_COUNT * L);
+    int* tokmem = reinterpret_cast<int*>(tb + T_COUNT * L);
+    if (threadIdx.x < 8) tokmem[threadIdx.x] = 0;
     __syncthreads();
 
     const int lane0 = threadIdx.x & 63;
@@ -306,9 +339,14 @@ __global__ __launch_bounds__(512, 2) void k_edge_step(const EdgeArgs a) {
     const float* w3 = NRES > 1 ? smem + CH : a.chunk[1];
     const float* w1 = NRES > 2 ? smem + 2 * CH : a.chunk[2];
     stagger_second_half(wave, a.stagger);
+#ifdef MGN_TOKEN
+    const PipeToken token{tokmem + (wave & 3), tokmem + 4 + (wave & 3), wave >> 2, blockDim.x == 512};
+#else
+    const PipeToken token{tokmem, tokmem, 0, false};
+#endif
 
     TileWalk tw(a.ntiles, wave);
-    if (tw.tile >= tw.end) return;
+    if (tw.tile >= tw.end) { token.leave(); return; }
     f32x16 x[NT], acc[NT], y[NT];
     EdgeIdx ix = load_edge_idx(a, tw.tile, lane0 & 31);
     {
@@ -334,6 +372,7 @@ __global__ __launch_bounds__(512, 2) void k_edge_step(const EdgeArgs a) {
         f32x4* etile = tile_ptr(a.Elat, tile, L, lane);
         STAMP(1);
 
+        token.acquire();
         mfma_chunk<NT, (NRES > 2)>(acc, x, w1, lane);          // layer 1 (edge part; P,Q,b1 preloaded)
         STAMP(2);
         relu_frag<NT>(acc);
@@ -345,6 +384,8 @@ __global__ __launch_bounds__(512, 2) void k_edge_step(const EdgeArgs a) {
         mfma_chunk<NT, (NRES > 1)>(acc, y, w3, lane);          // layer 3
         STAMP(4);
         PHASE_FENCE();
+        token.release();
+        __builtin_amdgcn_s_setprio(MGN_PRIO);                   // memory/VALU phase: win issue arbitration
         load_frag<NT>(y, etile, STRIDE_TILE);                   // e tile again (L2) for the residual
         layer_norm_frag<NT>(acc, tb + T_GAMMA * L, tb + T_BETA * L, h);   // acc = e'
         STAMP(5);
@@ -389,12 +430,13 @@ __global__ __launch_bounds__(512, 2) void k_edge_step(const EdgeArgs a) {
         f32x4* dst = to_carry ? row_ptr(a.CARRY, (int64_t)2 * tile + (sl ? 0 : 1), L, h)
                               : tile_ptr(a.AGG, r >> 5, L, 32 * h + (r & 31));
         if (tail) store_frag<NT>(dst, to_carry ? STRIDE_ROW : STRIDE_TILE, acc);
-        if (!has_next) break;
+        if (!has_next) { token.leave(); break; }
         PHASE_FENCE();
         // turnover: next accumulator init = P[s'] + Q[r'];  x <- e tile of the next tile
         load_frag<NT>(acc, row_ptr(a.P, ixn.s, L, h), STRIDE_ROW);
         add_frag<NT>(acc, row_ptr(a.Q, ixn.r >= 0 ? ixn.r : 0, L, h), STRIDE_ROW);
         load_frag<NT>(x, tile_ptr(a.Elat, nxt, L, lane), STRIDE_TILE);
+        __builtin_amdgcn_s_setprio(0);
         ix = ixn;
         tw.tile = next;
     }
@@ -462,10 +504,16 @@ __global__ __launch_bounds__(512, 2) void k_node_step(const NodeArgs a) {
             relu_frag<NT>(y);
             tab_frag<NT>(acc, tb + T_B3 * L, h);
             mfma_chunk<NT, (NRES > 1)>(acc, y, w3, lane);      // layer 3
+#ifdef MGN_PRIO_NODE
+            __builtin_amdgcn_s_setprio(MGN_PRIO_NODE);
+#endif
             layer_norm_frag<NT>(acc, tb + T_GAMMA * L, tb + T_BETA * L, h);
 #pragma unroll
             for (int t = 0; t < NT; ++t) v[t] += acc[t];        // v <- v + v'
             if (valid) store_frag<NT>(vtile, STRIDE_TILE, v);
+#ifdef MGN_PRIO_NODE
+            __builtin_amdgcn_s_setprio(0);
+#endif
         }
         if (a.mode != 0) {
             zero_frag<NT>(acc);
@@ -714,7 +762,7 @@ constexpr size_t LDS_BYTES = 160 * 1024;
 
 // resident chunks for L: chunk bytes = L*L*4; tables T_COUNT*L*4
 static int resident_chunks(int L, int want) {
-    const size_t ch = (size_t)L * L * 4, tabs = (size_t)T_COUNT * L * 4;
+    const size_t ch = (size_t)L * L * 4, tabs = (size_t)T_COUNT * L * 4 + 64;
     int r = (int)((LDS_BYTES - tabs) / ch);
     return r < want ? r : want;
 }
@@ -731,7 +779,7 @@ static LaunchCfg tile_launch(int L, int ntiles, int nres) {
     blocks = ((blocks + NUM_XCD - 1) / NUM_XCD) * NUM_XCD;
     lc.blocks = blocks;
     lc.threads = wpb * 64;
-    lc.lds = (size_t)nres * L * L * 4 + (size_t)T_COUNT * L * 4;
+    lc.lds = (size_t)nres * L * L * 4 + (size_t)T_COUNT * L * 4 + 64;  // + pipe-token words
     return lc;
 }
 
