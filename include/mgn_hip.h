@@ -66,7 +66,12 @@ typedef struct mgn_engine mgn_handle;
 int mgn_create(const mgn_config* cfg, mgn_handle** out);
 void mgn_destroy(mgn_handle* h);
 const char* mgn_last_error(const mgn_handle* h); /* h may be NULL: error of the last failed mgn_create */
-int mgn_set_stream(mgn_handle* h, void* hip_stream); /* NULL = engine's own stream (default)   */
+/* Stream all work of the handle is enqueued on.  hip_stream is a hipStream_t; NULL is HIP's default (null)
+ * stream -- what torch.cuda.current_stream().cuda_stream returns for torch's default stream -- and
+ * MGN_STREAM_OWN selects the engine's private non-blocking stream (the state after mgn_create).  Callers that
+ * mix engine calls with other GPU work (RCCL collectives, torch copies) must pass THEIR stream here. */
+#define MGN_STREAM_OWN ((void*)(intptr_t)-1)
+int mgn_set_stream(mgn_handle* h, void* hip_stream);
 int mgn_synchronize(mgn_handle* h);
 
 /* ---- parameters: mgn.ps (reference src/MeshGraphNets.jl:288,376-377) ------------------------- */

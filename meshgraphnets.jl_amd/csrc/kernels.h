@@ -93,6 +93,7 @@ hipError_t launch_decode(int L, const DecArgs& a, hipStream_t s);
 hipError_t launch_gather_rows(const float* src, const int32_t* idx, float* dst, int64_t rows, int L, hipStream_t s);
 hipError_t launch_randn_rows(float* dst, const int64_t* gid64, const int32_t* gid32, int64_t rows, int L,
                              uint64_t seed, hipStream_t s);
-hipError_t launch_checksum(const float* src, int64_t n, double* out2, hipStream_t s);
+int checksum_partials();  // doubles written by launch_checksum: (sum, sumsq) per block, to be added in order
+hipError_t launch_checksum(const float* src, int64_t n, double* partials, hipStream_t s);
 
 }  // namespace mgn

@@ -724,7 +724,11 @@ __global__ void k_randn_rows(float* __restrict__ dst, const int64_t* __restrict_
     dst[i] = sqrtf(-2.0f * logf(u1)) * cosf(6.28318530717958647692f * u2);
 }
 
-__global__ void k_checksum(const float* __restrict__ src, int64_t n, double* __restrict__ out2) {
+// deterministic: every block writes its own partial (fixed grid, fixed per-thread stride), the host adds
+// the partials in block order.  out[2*block] = sum, out[2*block+1] = sum of squares.
+constexpr int CHECKSUM_BLOCKS = 1024;
+__global__ void k_checksum(const float* __restrict__ src, int64_t n, double* __restrict__ out) {
+    __shared__ double sh[2][4];
     double s = 0.0, q = 0.0;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         const double v = (double)src[i];
@@ -736,9 +740,11 @@ __global__ void k_checksum(const float* __restrict__ src, int64_t n, double* __r
         s += __shfl_xor(s, off, 64);
         q += __shfl_xor(q, off, 64);
     }
-    if ((threadIdx.x & 63) == 0) {
-        atomicAdd(out2, s);
-        atomicAdd(out2 + 1, q);
+    if ((threadIdx.x & 63) == 0) { sh[0][threadIdx.x >> 6] = s; sh[1][threadIdx.x >> 6] = q; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        out[2 * blockIdx.x] = sh[0][0] + sh[0][1] + sh[0][2] + sh[0][3];
+        out[2 * blockIdx.x + 1] = sh[1][0] + sh[1][1] + sh[1][2] + sh[1][3];
     }
 }
 
@@ -823,9 +829,10 @@ hipError_t launch_randn_rows(float* dst, const int64_t* gid64, const int32_t* gi
     return hipGetLastError();
 }
 
-hipError_t launch_checksum(const float* src, int64_t n, double* out2, hipStream_t s) {
-    if (n <= 0) return hipSuccess;
-    hipLaunchKernelGGL(k_checksum, dim3(1024), dim3(256), 0, s, src, n, out2);
+int checksum_partials() { return 2 * CHECKSUM_BLOCKS; }
+
+hipError_t launch_checksum(const float* src, int64_t n, double* partials, hipStream_t s) {
+    hipLaunchKernelGGL(k_checksum, dim3(CHECKSUM_BLOCKS), dim3(256), 0, s, src, n < 0 ? 0 : n, partials);
     return hipGetLastError();
 }
 

@@ -338,7 +338,7 @@ const char* mgn_last_error(const mgn_handle* h) { return h ? h->err.c_str() : g_
 int mgn_set_stream(mgn_handle* h, void* hip_stream) {
     if (int rc = need(h, false, false)) return rc;
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    h->stream = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : h->own_stream;
+    h->stream = (hip_stream == MGN_STREAM_OWN) ? h->own_stream : reinterpret_cast<hipStream_t>(hip_stream);
     return MGN_OK;
 }
 
@@ -797,17 +797,24 @@ int mgn_latents_randn(mgn_handle* h, uint64_t seed) {
 
 int mgn_latents_checksum(mgn_handle* h, double* sv, double* se, double* qv, double* qe) {
     if (int rc = need(h, false, true)) return rc;
-    const LocalGraph& g = h->g;
-    HIPCHK(h, hipMemsetAsync(h->d_sum.p, 0, 4 * sizeof(double), h->stream));
+    const int np_ = checksum_partials();
+    HIPCHK(h, h->d_sum.ensure((size_t)2 * np_ * sizeof(double)));
     HIPCHK(h, launch_checksum(h->V.as<float>(), (int64_t)tile_floats(h->ntiles_n, h->cfg.L), h->d_sum.as<double>(), h->stream));
-    HIPCHK(h, launch_checksum(h->Elat.as<float>(), (int64_t)tile_floats(h->ntiles_e, h->cfg.L), h->d_sum.as<double>() + 2, h->stream));
-    double r[4];
-    HIPCHK(h, hipMemcpyAsync(r, h->d_sum.p, sizeof r, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, launch_checksum(h->Elat.as<float>(), (int64_t)tile_floats(h->ntiles_e, h->cfg.L), h->d_sum.as<double>() + np_, h->stream));
+    std::vector<double> r((size_t)2 * np_);
+    HIPCHK(h, hipMemcpyAsync(r.data(), h->d_sum.p, r.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    if (sv) *sv = r[0];
-    if (qv) *qv = r[1];
-    if (se) *se = r[2];
-    if (qe) *qe = r[3];
+    double acc[4] = {0, 0, 0, 0};   // bitwise reproducible: fixed partials, fixed order
+    for (int b = 0; b < np_ / 2; ++b) {
+        acc[0] += r[2 * b];
+        acc[1] += r[2 * b + 1];
+        acc[2] += r[np_ + 2 * b];
+        acc[3] += r[np_ + 2 * b + 1];
+    }
+    if (sv) *sv = acc[0];
+    if (qv) *qv = acc[1];
+    if (se) *se = acc[2];
+    if (qe) *qe = acc[3];
     return MGN_OK;
 }
 

@@ -66,7 +66,10 @@ class Engine:
         return self.cfg.device == _capi.MGN_DEVICE_NONE
 
     def set_stream(self, stream_ptr):
-        self._chk(self.lib.mgn_set_stream(self.h, C.c_void_p(stream_ptr)))
+        """stream_ptr: raw hipStream_t (0 = HIP default stream, e.g. torch.cuda.current_stream().cuda_stream);
+        None = the engine's own private stream (MGN_STREAM_OWN)."""
+        ptr = C.c_void_p(-1) if stream_ptr is None else C.c_void_p(stream_ptr)
+        self._chk(self.lib.mgn_set_stream(self.h, ptr))
 
     def synchronize(self):
         self._chk(self.lib.mgn_synchronize(self.h))

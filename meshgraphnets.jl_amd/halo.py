@@ -29,11 +29,18 @@ class DistExchange:
         self.n_send, self.n_recv = sum(self.send_rows), sum(self.recv_rows)
 
     def __call__(self):
-        self.engine.halo_pack(self.send.data_ptr())
+        tensor_api = hasattr(self.engine, "halo_pack_tensor")   # NumPy stand-in engines of the CPU tests
+        if tensor_api:
+            self.engine.halo_pack_tensor(self.send)
+        else:
+            self.engine.halo_pack(self.send.data_ptr())
         self.dist.all_to_all_single(self.recv[: self.n_recv], self.send[: self.n_send],
                                     output_split_sizes=self.recv_rows, input_split_sizes=self.send_rows,
                                     group=self.group)
-        self.engine.halo_unpack(self.recv.data_ptr())
+        if tensor_api:
+            self.engine.halo_unpack_tensor(self.recv)
+        else:
+            self.engine.halo_unpack(self.recv.data_ptr())
 
 
 class LoopbackExchange:
@@ -55,8 +62,9 @@ class LoopbackExchange:
 
     def __call__(self):
         P = len(self.engines)
+        tensor_api = hasattr(self.engines[0], "halo_pack_tensor")
         for p, e in enumerate(self.engines):
-            e.halo_pack(self.send[p].data_ptr())
+            e.halo_pack_tensor(self.send[p]) if tensor_api else e.halo_pack(self.send[p].data_ptr())
         for p in range(P):          # receiver
             for q in range(P):      # sender
                 n = int(self.counts[p][1][q])
@@ -64,4 +72,4 @@ class LoopbackExchange:
                     self.recv[p][self.roff[p][q]: self.roff[p][q] + n].copy_(
                         self.send[q][self.soff[q][p]: self.soff[q][p] + n])
         for p, e in enumerate(self.engines):
-            e.halo_unpack(self.recv[p].data_ptr())
+            e.halo_unpack_tensor(self.recv[p]) if tensor_api else e.halo_unpack(self.recv[p].data_ptr())

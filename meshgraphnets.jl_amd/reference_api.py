@@ -1,0 +1,245 @@
+"""Host-side mirror of the reference functions on either side of the hot path, with the reference's names.
+
+In the real drop-in these stay Julia and unchanged (reference src/graph.jl, src/solve.jl call into
+GraphNetCore; only GraphNetCore is replaced).  Julia is not available in this environment, so the same
+functions are written here in NumPy float32 to drive the engine exactly the way the reference does:
+
+    create_base_graph      reference src/graph.jl:25-55
+    build_graph            reference src/graph.jl:75-97
+    ode_func_eval          reference src/solve.jl:147-158
+    ode_step               reference src/solve.jl:188-219
+    rollout (Euler branch) reference src/solve.jl:42-68  (`solve(prob, solver; adaptive=false, dt, saveat)`)
+    GraphNetCore surface   one_hot, triangles_to_edges, parse_edges, mse_reduce, NormaliserOfflineMinMax,
+                           NormaliserOfflineMeanStd, NormaliserOnline, inverse_data (docs/src/graph_net_core.md)
+
+Arrays are [count][feat] (the bytes of Julia's feat x count).  Indices returned by triangles_to_edges /
+parse_edges are 0-based here; GraphNetwork(index_base=...) tells the engine which base the caller uses.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from .engine import FeatureGraph
+
+F32 = np.float32
+
+
+# ---- GraphNetCore utilities ---------------------------------------------------------------------
+def one_hot(v, depth, offset=0):
+    """one_hot(vec(node_type), type_max - type_min + 1, 1 - type_min) at src/graph.jl:26-27 (the Julia offset
+    is 1-based; here offset = -type_min)."""
+    v = np.asarray(v).reshape(-1).astype(np.int64) + offset
+    if v.size and (v.min() < 0 or v.max() >= depth):
+        raise ValueError("ArgumentError: one_hot index outside [0, depth)")
+    out = np.zeros((v.size, depth), F32)
+    out[np.arange(v.size), v] = 1.0
+    return out
+
+
+def triangles_to_edges(cells):
+    """Two-way unique edges of a triangulation in first-occurrence order (src/graph.jl:30)."""
+    cells = np.asarray(cells, dtype=np.int64)
+    if cells.ndim != 2 or cells.shape[1] != 3:
+        raise ValueError("DimensionMismatch: cells must be [C][3]")
+    e = np.concatenate([cells[:, 0:2], cells[:, 1:3], cells[:, [2, 0]]], 0)
+    hi, lo = e.max(1), e.min(1)
+    key = hi * (int(e.max()) + 1) + lo
+    _, first = np.unique(key, return_index=True)
+    first.sort()
+    a, b = hi[first].astype(np.int32), lo[first].astype(np.int32)
+    return np.concatenate([a, b]), np.concatenate([b, a])
+
+
+def parse_edges(edges):
+    """parse_edges(data["edges"]) at src/graph.jl:38: explicit [n][2] edge list -> two-way senders/receivers."""
+    e = np.asarray(edges, dtype=np.int32)
+    if e.ndim != 2 or e.shape[1] != 2:
+        raise ValueError("DimensionMismatch: edges must be [n][2]")
+    return np.concatenate([e[:, 0], e[:, 1]]), np.concatenate([e[:, 1], e[:, 0]])
+
+
+def mse_reduce(target, output):
+    """Sum of squared errors over the feature rows, per node (loss_fn of step!, src/strategies.jl:421)."""
+    return ((np.asarray(target, F32) - np.asarray(output, F32)) ** 2).sum(-1)
+
+
+# ---- normalisers (constructed at src/MeshGraphNets.jl:79-203) --------------------------------------
+class NormaliserOfflineMinMax:
+    def __init__(self, data_min, data_max, target_min=0.0, target_max=1.0):
+        self.data_min, self.data_max = F32(data_min), F32(data_max)
+        self.target_min, self.target_max = F32(target_min), F32(target_max)
+
+    def __call__(self, x):
+        x = np.asarray(x, F32)
+        return (x - self.data_min) / (self.data_max - self.data_min) * (self.target_max - self.target_min) + self.target_min
+
+    def inverse(self, y):
+        y = np.asarray(y, F32)
+        return (y - self.target_min) / (self.target_max - self.target_min) * (self.data_max - self.data_min) + self.data_min
+
+    def affine(self, dim):
+        s = (self.target_max - self.target_min) / (self.data_max - self.data_min)
+        return np.full(dim, s, F32), np.full(dim, self.target_min - self.data_min * s, F32)
+
+    def inverse_affine(self, dim):
+        s = (self.data_max - self.data_min) / (self.target_max - self.target_min)
+        return np.full(dim, s, F32), np.full(dim, self.data_min - self.target_min * s, F32)
+
+
+class NormaliserOfflineMeanStd:
+    def __init__(self, mean, std):
+        self.mean = np.asarray(mean, F32)
+        self.std = np.maximum(np.asarray(std, F32), F32(1e-8))
+
+    def __call__(self, x):
+        return (np.asarray(x, F32) - self.mean) / self.std
+
+    def inverse(self, y):
+        return np.asarray(y, F32) * self.std + self.mean
+
+    def affine(self, dim):
+        s = np.broadcast_to(F32(1.0) / self.std, (dim,)).astype(F32)
+        return s, (-np.broadcast_to(self.mean, (dim,)) * s).astype(F32)
+
+    def inverse_affine(self, dim):
+        return np.broadcast_to(self.std, (dim,)).astype(F32), np.broadcast_to(self.mean, (dim,)).astype(F32)
+
+
+class NormaliserOnline:
+    """NormaliserOnline(dims, device; max_acc): accumulates sum / sum of squares / count over the rows it is
+    called with until max_acc calls, then normalises with the running mean / max(std, 1e-8)."""
+
+    def __init__(self, dims, device=None, max_acc=1e6, std_epsilon=1e-8):
+        self.dims, self.max_acc, self.std_epsilon = int(dims), float(max_acc), F32(std_epsilon)
+        self.acc_sum = np.zeros(self.dims, np.float64)
+        self.acc_sum_squared = np.zeros(self.dims, np.float64)
+        self.acc_count = 0.0
+        self.num_accumulations = 0.0
+
+    def _accumulate(self, x):
+        if self.num_accumulations < self.max_acc:
+            self.acc_sum += x.sum(0, dtype=np.float64)
+            self.acc_sum_squared += (x.astype(np.float64) ** 2).sum(0)
+            self.acc_count += x.shape[0]
+            self.num_accumulations += 1.0
+
+    def frozen(self):
+        c = max(self.acc_count, 1.0)
+        mean = self.acc_sum / c
+        std = np.sqrt(np.maximum(self.acc_sum_squared / c - mean * mean, 0.0))
+        return NormaliserOfflineMeanStd(mean.astype(F32), np.maximum(std, self.std_epsilon).astype(F32))
+
+    def __call__(self, x, accumulate=True):
+        x = np.asarray(x, F32)
+        if x.shape[-1] != self.dims:
+            raise ValueError("DimensionMismatch: NormaliserOnline built for %d features, got %d" % (self.dims, x.shape[-1]))
+        if accumulate:
+            self._accumulate(x)
+        return self.frozen()(x)
+
+    def inverse(self, y):
+        return self.frozen().inverse(y)
+
+    def affine(self, dim):
+        return self.frozen().affine(dim)
+
+    def inverse_affine(self, dim):
+        return self.frozen().inverse_affine(dim)
+
+
+def inverse_data(norm, y):
+    """inverse_data(mgn.o_norm[field], output_rows) at src/solve.jl:207."""
+    return norm.inverse(y)
+
+
+# ---- src/graph.jl ------------------------------------------------------------------------------------
+def create_base_graph(data, type_size, type_min, device=None):
+    """Static part of the graph, once per trajectory.  data: dict with 'node_type' [N] (or [N][1]), 'mesh_pos'
+    [N][dims] and 'cells' [C][3] or 'edges' [n][2].  Returns (node_type_onehot, senders, receivers,
+    edge_features) like src/graph.jl:54 (0-based indices)."""
+    node_type = one_hot(np.asarray(data["node_type"]).reshape(-1), type_size - type_min + 1, -type_min)
+    if "cells" in data:
+        senders, receivers = triangles_to_edges(data["cells"])
+    elif "edges" in data:
+        senders, receivers = parse_edges(data["edges"])
+    else:
+        raise KeyError("Data does not contain cell or edge information!")
+    pos = np.asarray(data["mesh_pos"], F32)
+    rel = pos[senders] - pos[receivers]
+    edge_features = np.concatenate([rel, np.linalg.norm(rel, axis=1, keepdims=True).astype(F32)], 1).astype(F32)
+    return node_type, senders, receivers, edge_features
+
+
+def build_graph(mgn, data, fields, datapoint, node_type, edge_features, senders, receivers):
+    """nf = [n_norm[field](data[field]) for field in fields ..., n_norm['node_type'](node_type)]; ef = e_norm(...)
+    (src/graph.jl:80-96).  data[field]: [N][dim] or [T][N][dim] (then row min(T, datapoint) is used)."""
+    if np.asarray(edge_features).dtype != np.float32:
+        raise TypeError("MethodError: edge_features must be Float32 (src/graph.jl:76)")
+    cols = []
+    for field in fields:
+        d = np.asarray(data[field], F32)
+        if d.ndim == 3:
+            d = d[min(d.shape[0] - 1, datapoint)]
+        cols.append(mgn.n_norm[field](d))
+    cols.append(mgn.n_norm["node_type"](node_type))
+    return FeatureGraph(np.concatenate(cols, 1).astype(F32), mgn.e_norm(edge_features).astype(F32), senders, receivers)
+
+
+# ---- src/solve.jl ------------------------------------------------------------------------------------
+def ode_step(x, p, t):
+    """x: [N][sum(dims)] state; p = (mgn, ps, inputs, fields, meta, target_fields, target_dict, node_type,
+    edge_features, senders, receivers, val_mask, pr) exactly as src/solve.jl:188-191."""
+    (mgn, ps, inputs, fields, meta, target_fields, target_dict, node_type, edge_features, senders, receivers,
+     val_mask, pr) = p
+    offset = 0
+    for k in target_fields:
+        inputs[k] = x[:, offset:offset + target_dict[k]]
+        offset += target_dict[k]
+    graph = build_graph(mgn, inputs, fields, 0, node_type, edge_features, senders, receivers)
+    output, st = mgn.model(graph, ps, mgn.st)
+    mgn.st = st
+    indices = [meta["features"][tf]["dim"] for tf in target_fields]
+    buf = np.empty_like(output)
+    o = 0
+    for i, tf in enumerate(target_fields):
+        buf[:, o:o + indices[i]] = inverse_data(mgn.o_norm[tf], output[:, o:o + indices[i]])
+        o += indices[i]
+    return buf * val_mask
+
+
+def ode_func_eval(x, p, t):
+    """Inflow overwrite then ode_step (src/solve.jl:147-158).  p as in the reference plus (data, inflow_mask,
+    saves_dt): x[inflow_mask] = vcat(data[field][floor(t / saves_dt)] ...)[inflow_mask]."""
+    (mgn, ps, data, inputs, fields, meta, target_fields, target_dict, node_type, edge_features, senders, receivers,
+     val_mask, inflow_mask, saves_dt, pr) = p
+    k = int(np.floor(t / saves_dt + 1e-9))
+    gt = np.concatenate([np.asarray(data[f], F32)[k] for f in target_fields], 1)
+    x[inflow_mask] = gt[inflow_mask]   # IN PLACE, like the reference: the caller's (solver's) state is modified
+    return ode_step(x, (mgn, ps, inputs, fields, meta, target_fields, target_dict, node_type, edge_features,
+                        senders, receivers, val_mask, pr), t)
+
+
+def rollout(solver, mgn, initial_state, fields, meta, target_fields, target_dict, node_type, edge_features, senders,
+            receivers, val_mask, inflow_mask, data, start, stop, dt, saves, show_progress=False):
+    """Fixed-step branch of rollout (src/solve.jl:57-61, `adaptive = false, dt = dt`); solver must be "Euler".
+    Returns (sol_u [len(saves)][N][O], sol_t)."""
+    if solver != "Euler" or dt is None:
+        raise NotImplementedError("only the fixed-step Euler branch is mirrored; adaptive Tsit5 stays in DifferentialEquations.jl")
+    x = np.concatenate([np.asarray(initial_state[f], F32) for f in target_fields], 1)
+    inputs = {k: v for k, v in initial_state.items() if k not in target_dict}
+    p = (mgn, mgn.ps, data, inputs, fields, meta, target_fields, target_dict, node_type, edge_features, senders,
+         receivers, val_mask, inflow_mask, saves[1] - saves[0], None)
+    sol_u, sol_t = [], []
+    t = start
+    nsteps = int(round((stop - start) / dt))
+    save_set = {int(round((s - start) / dt)) for s in saves}
+    for i in range(nsteps + 1):
+        if i in save_set:
+            sol_u.append(x.copy())
+            sol_t.append(t)
+        if i == nsteps:
+            break
+        dx = ode_func_eval(x, p, t)   # mutates the inflow rows of x (reference quirk, src/solve.jl:151-152)
+        x = x + F32(dt) * dx
+        t = start + (i + 1) * dt
+    return np.stack(sol_u), np.array(sol_t)

@@ -276,11 +276,19 @@ def ode_rhs(packed, cfg, x, node_type_onehot, ef_raw, senders, receivers, n_norm
     return o_norm.inverse(out) * val_mask
 
 
-def euler_rollout(rhs, x0, dt, nsteps):
-    """Fixed-step Euler (solve(prob, Euler(); adaptive=false, dt) at src/solve.jl:60)."""
+def euler_rollout(rhs, x0, dt, nsteps, inflow_mask=None, inflow_values=None):
+    """Fixed-step Euler (solve(prob, Euler(); adaptive=false, dt) at src/solve.jl:60).
+    Reference quirk kept on purpose: ode_func_eval overwrites the inflow rows of the array the solver hands it
+    IN PLACE (`x[inflow_mask] = ...`, src/solve.jl:151-152), and for an out-of-place Euler step that array is
+    the integrator's own state, so the overwrite is part of the state the step starts from:
+        x_k' = overwrite(x_k);  x_{k+1} = x_k' + dt * f(x_k').   Saved values are the x_k BEFORE the overwrite
+    of step k (saveat stores u after the step)."""
     xs = [np.array(x0, np.float64)]
     for i in range(nsteps):
-        xs.append(xs[-1] + dt * rhs(xs[-1], i * dt))
+        xk = xs[-1].copy()
+        if inflow_mask is not None:
+            xk[inflow_mask] = np.asarray(inflow_values[i], np.float64)[inflow_mask]
+        xs.append(xk + dt * rhs(xk, i * dt))
     return np.stack(xs)
 
 

@@ -1,0 +1,107 @@
+#!/usr/bin/env python3
+"""Generates the committed golden vectors from the float64 oracle (oracle/mgn_oracle.py).
+
+The reference itself pins nothing (test/runtests.jl:11-19 is Aqua-only) and cannot be run here (no julia,
+GraphNetCore.jl not vendored), so these vectors pin the build's own MGN-spec v1: they are produced ONCE by the
+float64 NumPy oracle and every implementation (C restatement, HIP engine) is compared against them.
+Run from the repo root:  python tests/golden/gen_golden.py
+"""
+import hashlib
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import mgn_amd  # noqa: E402
+import mgn_oracle as orc  # noqa: E402
+
+SEED = 1234
+
+
+def mesh():
+    pos, cells = mgn_amd.synth.grid_mesh(8, 6, SEED)          # N = 48
+    s, r = orc.triangles_to_edges(cells)                       # reference order: first occurrence, two-way
+    return pos, cells, s.astype(np.int32), r.astype(np.int32)
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def gold(L, mps, name, snaps):
+    pos, cells, s, r = mesh()
+    N, E = pos.shape[0], s.size
+    cfg = dict(Fn=9, Fe=3, O=2, L=L, hidden_layers=2, mps=mps)
+    ps = orc.init_params(9, 3, 2, L, 2, mps, seed=SEED, ln_jitter=0.1)
+    rng = np.random.default_rng(SEED)
+    nf = rng.standard_normal((N, 9)).astype(np.float32)
+    ef = rng.standard_normal((E, 3)).astype(np.float32)
+    out, lat = orc.forward(ps, cfg, nf, ef, s, r, return_latents=True)
+    d = dict(L=L, mps=mps, seed=SEED, jitter=0.1, params_sha256=sha(ps), senders=s, receivers=r, nf=nf, ef=ef, out=out)
+    for k in snaps:
+        d[f"v_after_{k}"] = lat[k][0].astype(np.float32)
+        d[f"e_after_{k}"] = lat[k][1].astype(np.float32)
+    np.savez_compressed(os.path.join(HERE, name), **d)
+    print(name, "N", N, "E", E, "out[0]", out[0])
+
+
+def gold_rollout():
+    """GOLD-D: 10-step fixed-dt Euler rollout through the ode_func_eval -> ode_step wrapper
+    (reference src/solve.jl:147-158,188-219) on a cylinder_flow-shaped toy problem."""
+    pos, cells, s, r = mesh()
+    N, E = pos.shape[0], s.size
+    L, mps = 128, 3
+    cfg = dict(Fn=9, Fe=3, O=2, L=L, hidden_layers=2, mps=mps)
+    ps = orc.init_params(9, 3, 2, L, 2, mps, seed=SEED + 1, ln_jitter=0.1)
+    rng = np.random.default_rng(SEED + 1)
+    node_type = rng.choice([0, 0, 0, 1, 4, 5, 6], size=N).astype(np.int32)
+    onehot = orc.one_hot(node_type, 7, 0)
+    ef_raw = orc.edge_features(pos, s, r)
+    x0 = rng.standard_normal((N, 2)) * 0.3 + 1.0
+    gt = rng.standard_normal((11, N, 2)) * 0.3 + 1.0          # "data" used for the inflow overwrite
+    n_norm = orc.NormMeanStd(np.array([1.0, 0.9]), np.array([0.31, 0.27]))
+    t_norm = orc.NormMinMax(0.0, 1.0)
+    e_norm = orc.NormMeanStd(ef_raw.mean(0), ef_raw.std(0))
+    o_norm = orc.NormMeanStd(np.array([0.01, -0.02]), np.array([0.5, 0.4]))
+    val_mask = np.isin(node_type, [0, 5]).astype(np.float64)[:, None]     # types_updated = [0, 5]
+    inflow = np.repeat((node_type == 1)[:, None], 2, 1)                   # literal 1: src/MeshGraphNets.jl:593
+    dt = 0.01
+
+    def rhs(x, t):
+        k = int(np.floor(t / dt + 1e-9))
+        return orc.ode_rhs(ps, cfg, x, onehot, ef_raw, s, r, n_norm, t_norm, e_norm, o_norm, val_mask, inflow, gt[k])
+
+    xs = orc.euler_rollout(rhs, x0, dt, 10, inflow, gt)
+    ns, nsh = n_norm.affine(2)
+    ts, tsh = t_norm.affine(7)
+    es, esh = e_norm.affine(3)
+    np.savez_compressed(os.path.join(HERE, "gold_d_rollout.npz"), L=L, mps=mps, seed=SEED + 1, jitter=0.1,
+                        params_sha256=sha(ps), senders=s, receivers=r, mesh_pos=pos, node_type=node_type, x0=x0, gt=gt,
+                        ef_raw=ef_raw.astype(np.float32), node_scale=np.concatenate([ns, ts]), node_shift=np.concatenate([nsh, tsh]),
+                        edge_scale=es, edge_shift=esh, out_scale=o_norm.std, out_shift=o_norm.mean, val_mask=val_mask[:, 0],
+                        inflow_mask=inflow, dt=dt, xs=xs, dxdt0=rhs(x0, 0.0))
+    print("gold_d_rollout", xs.shape, xs[-1, 0])
+
+
+def kats():
+    """Known-answer tests stored as data so every implementation reads the same file."""
+    tri1 = np.array([[0, 1, 2]], np.int32)
+    tri2 = np.array([[0, 1, 2], [1, 3, 2]], np.int32)
+    s1, r1 = orc.triangles_to_edges(tri1)
+    s2, r2 = orc.triangles_to_edges(tri2)
+    pos345 = np.array([[0.0, 0.0], [3.0, 0.0], [3.0, 4.0]])
+    ef = orc.edge_features(pos345, np.array([1, 2, 2]), np.array([0, 1, 0]))
+    np.savez_compressed(os.path.join(HERE, "kats.npz"), tri1_s=s1, tri1_r=r1, tri2_s=s2, tri2_r=r2,
+                        onehot_types=np.array([0, 4, 5, 6]), onehot=orc.one_hot([0, 4, 5, 6], 7, 0), ef345=ef)
+    print("kats: tri1 directed", s1.size, "tri2 directed", s2.size, "norms", ef[:, 2])
+
+
+if __name__ == "__main__":
+    gold(32, 1, "gold_a_L32_mps1.npz", [0, 1])
+    gold(128, 15, "gold_b_L128_mps15.npz", [1, 8, 15])
+    gold_rollout()
+    kats()

@@ -1,0 +1,73 @@
+"""NumPy stand-in for one partition's engine (TEST INFRASTRUCTURE): same staged interface as mgn_amd.Engine
+(proc_begin / proc_edge / proc_node / halo_*), arithmetic from the float64 oracle's parameters, written in the
+FACTORED form the HIP kernels use (P = v W1s, Q = v W1r + b1, edge layer 1 = P[s] + Q[r] + e W1e), partition
+data from the C library's host-only handle.  Used by the gloo world_size-2 test and the loopback test."""
+import numpy as np
+
+import mgn_amd
+import mgn_oracle as orc
+
+
+class OracleRankEngine:
+    def __init__(self, cfg, ps, senders, receivers, N, mesh_pos, rank, nranks):
+        self.cfg = cfg
+        self.h = cfg["hidden_layers"]
+        self.P_ = orc.unpack_params(np.asarray(ps, np.float64), cfg["Fn"], cfg["Fe"], cfg["O"], cfg["L"], self.h, cfg["mps"])
+        self.part = mgn_amd.Engine(cfg["Fn"], cfg["Fe"], cfg["O"], cfg["L"], self.h, cfg["mps"], rank=rank, nranks=nranks,
+                                   device=mgn_amd.MGN_DEVICE_NONE)
+        self.part.set_graph(senders, receivers, N, mesh_pos=mesh_pos)
+        self.own = self.part.owned_nodes()
+        self.eid = self.part.local_edges()
+        self.snd, self.rcv, self.rowptr = self.part.local_graph()
+        self.send_idx = self.part.halo_send_index()
+        self.n_own, self.n_halo = self.part.n_own, self.part.n_halo
+        L = cfg["L"]
+        self.V = np.zeros((self.n_own, L))
+        self.E = np.zeros((self.eid.size, L))
+        self.P = np.zeros((self.n_own + self.n_halo, L))
+        self.Q = np.zeros((self.n_own, L))
+        self.halo_row_floats = L
+
+    def halo_counts(self):
+        return self.part.halo_counts()
+
+    def latents_import(self, v, e):
+        self.V = np.asarray(v, np.float64)[self.own].copy()
+        self.E = np.asarray(e, np.float64)[self.eid].copy()
+
+    def latents_export(self, v, e):
+        v[self.own] = self.V
+        e[self.eid] = self.E
+
+    def _project(self, k):
+        W1, b1 = self.P_["proc%d_edge" % k]["W1"], self.P_["proc%d_edge" % k]["b1"]
+        L = self.cfg["L"]
+        self.P[: self.n_own] = self.V @ W1[0:L]
+        self.Q = self.V @ W1[L:2 * L] + b1
+
+    def proc_begin(self):
+        self._project(0)
+
+    def proc_edge(self, k):
+        p = self.P_["proc%d_edge" % k]
+        L = self.cfg["L"]
+        h1 = np.maximum(self.P[self.snd] + self.Q[self.rcv] + self.E @ p["W1"][2 * L:], 0.0)
+        h2 = np.maximum(h1 @ p["W2"] + p["b2"], 0.0)
+        en = orc.layer_norm(h2 @ p["W3"] + p["b3"], p["ln_scale"], p["ln_bias"])
+        self.agg = orc.scatter_add(en, self.rcv, self.n_own)
+        self.E = self.E + en
+
+    def proc_node(self, k, project_next):
+        vn = orc.mlp(np.concatenate([self.V, self.agg], 1), self.P_["proc%d_node" % k], self.h)
+        self.V = self.V + vn
+        if project_next:
+            self._project(k + 1)
+
+    def halo_pack_tensor(self, t):
+        import torch
+        if self.send_idx.size:
+            t[: self.send_idx.size] = torch.from_numpy(self.P[self.send_idx].astype(np.float32))
+
+    def halo_unpack_tensor(self, t):
+        if self.n_halo:
+            self.P[self.n_own:] = t[: self.n_halo].cpu().numpy().astype(np.float64)

@@ -1,0 +1,132 @@
+"""CPU tests: the C-ABI library loads and exports every symbol include/mgn_hip.h declares; host logic
+(parameter layout, receiver sort, CSR, RCB partition, halo lists) through host-only handles.
+No compute call is made: there is no GPU here and the engine has no CPU path."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import mgn_oracle as orc
+
+import mgn_amd
+from mgn_amd import MGN_DEVICE_NONE, Engine, MgnError, synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_symbols():
+    hdr = open(os.path.join(ROOT, "include", "mgn_hip.h")).read()
+    return set(re.findall(r"\b(mgn_[a-z0-9_]+)\s*\(", hdr))
+
+
+def test_library_exports_every_declared_symbol(lib_built):
+    lib = C.CDLL(lib_built)
+    declared = header_symbols()
+    assert len(declared) >= 38
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in include/mgn_hip.h but not exported"
+    assert declared == set(mgn_amd.PROTOTYPES), "ctypes prototypes and header disagree"
+
+
+def test_param_count_and_config_validation(lib_built):
+    lib = mgn_amd.load()
+    for (Fn, Fe, O, L, mps) in [(9, 3, 2, 128, 15), (12, 7, 3, 64, 4), (9, 3, 2, 32, 1)]:
+        cfg = mgn_amd._capi.MgnConfig(Fn, Fe, O, L, 2, mps, 0, 0, 1, -1)
+        assert lib.mgn_param_count(C.byref(cfg)) == orc.param_count(Fn, Fe, O, L, 2, mps)
+    for bad in [dict(L=100), dict(hidden_layers=3), dict(mps=0), dict(Fn=0), dict(rank=2, nranks=2)]:
+        kw = dict(Fn=9, Fe=3, O=2, L=128, hidden_layers=2, mps=2, rank=0, nranks=1, device=MGN_DEVICE_NONE)
+        kw.update(bad)
+        with pytest.raises(MgnError) as ei:
+            Engine(**kw)
+        assert ei.value.code == -1        # MGN_E_ARG
+
+
+def test_no_gpu_means_no_compute(lib_built):
+    """The product path must fail loudly without a device: no CPU fallback anywhere."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(MgnError) as ei:
+        Engine(9, 3, 2)
+    assert ei.value.code == -2            # MGN_E_HIP
+    e = Engine(9, 3, 2, device=MGN_DEVICE_NONE)
+    s, r = synth.random_graph(10, 30, 0)
+    e.set_graph(s, r, 10)
+    for call in (lambda: e.set_params(np.zeros(e.param_count, np.float32)),
+                 lambda: e.forward(np.zeros((10, 9), np.float32), np.zeros((30, 3), np.float32)),
+                 lambda: e.processor_steps_dev(1), lambda: e.proc_edge(0), lambda: e.latents_randn(1)):
+        with pytest.raises(MgnError) as ei:
+            call()
+        assert ei.value.code == -2
+
+
+def test_set_graph_argument_errors(lib_built):
+    e = Engine(9, 3, 2, device=MGN_DEVICE_NONE)
+    with pytest.raises(MgnError):
+        e.set_graph(np.array([0, 9], np.int32), np.array([1, 1], np.int32), 3)            # out of range
+    with pytest.raises(MgnError):
+        e.set_graph(np.array([0], np.int32), np.array([1], np.int32), 3, index_base=2)
+    with pytest.raises(ValueError):
+        e.set_graph(np.array([0, 1], np.int32), np.array([1], np.int32), 3)
+    e.set_graph(np.array([1, 3], np.int32), np.array([3, 1], np.int32), 3, index_base=1)  # Julia 1-based ok
+    assert e.e_local == 2 and e.n_own == 3
+    e.set_graph(np.zeros(0, np.int32), np.zeros(0, np.int32), 4)                           # empty edge set
+    assert e.e_local == 0 and e.n_own == 4
+
+
+@pytest.mark.parametrize("P", [1, 2, 3, 4, 8])
+def test_partition_invariants(lib_built, P):
+    pos, cells = synth.grid_mesh(23, 17, 5)
+    s, r = synth.cells_to_edges(cells)
+    N, E = pos.shape[0], s.size
+    engs = []
+    for rk in range(P):
+        e = Engine(9, 3, 2, rank=rk, nranks=P, device=MGN_DEVICE_NONE)
+        e.set_graph(s, r, N, mesh_pos=pos)
+        engs.append(e)
+    owner = engs[0].node_owner()
+    counts = np.bincount(owner, minlength=P)
+    assert counts.max() - counts.min() <= 1                       # RCB balances node counts
+    seen_nodes, seen_edges = np.zeros(N, int), np.zeros(E, int)
+    for rk, e in enumerate(engs):
+        assert np.array_equal(e.node_owner(), owner)               # every rank computes the same partition
+        own = e.owned_nodes()
+        assert np.all(owner[own] == rk) and np.all(np.diff(own) > 0)
+        seen_nodes[own] += 1
+        eid = e.local_edges()
+        seen_edges[eid] += 1
+        snd, rcv, rowptr = e.local_graph()
+        assert np.all(np.diff(rcv) >= 0)                           # receiver-sorted
+        assert rowptr[0] == 0 and rowptr[-1] == eid.size
+        assert np.array_equal(np.bincount(rcv, minlength=e.n_own), np.diff(rowptr))
+        halo = e.halo_nodes()
+        l2g = np.concatenate([own, halo])
+        assert np.array_equal(l2g[snd], s[eid]) and np.array_equal(own[rcv], r[eid])   # local ids map back
+        assert np.all(owner[halo] != rk)
+        # stable: edges of one receiver keep their input order
+        for n in range(min(e.n_own, 50)):
+            seg = eid[rowptr[n]:rowptr[n + 1]]
+            assert np.all(np.diff(seg) > 0)
+        send, recv = e.halo_counts()
+        assert send[rk] == 0 and recv[rk] == 0 and recv.sum() == e.n_halo
+        assert np.array_equal(np.bincount(owner[halo], minlength=P), recv)
+    assert np.all(seen_nodes == 1) and np.all(seen_edges == 1)
+    for p in range(P):                                             # what p sends to q is what q expects from p
+        sp, _ = engs[p].halo_counts()
+        off = np.concatenate([[0], np.cumsum(sp)])
+        sidx = engs[p].halo_send_index()
+        own_p = engs[p].owned_nodes()
+        for q in range(P):
+            _, rq = engs[q].halo_counts()
+            assert sp[q] == rq[p]
+            roff = np.concatenate([[0], np.cumsum(rq)])
+            assert np.array_equal(own_p[sidx[off[q]:off[q + 1]]], engs[q].halo_nodes()[roff[p]:roff[p + 1]])
+
+
+def test_partition_without_positions_uses_index_blocks(lib_built):
+    s, r = synth.random_graph(100, 400, 1, allow_isolated=False)
+    e = Engine(9, 3, 2, rank=1, nranks=4, device=MGN_DEVICE_NONE)
+    e.set_graph(s, r, 100)
+    assert np.array_equal(e.owned_nodes(), np.arange(25, 50))

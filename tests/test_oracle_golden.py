@@ -1,0 +1,143 @@
+"""CPU tests: the float64 oracle against the committed golden vectors and known-answer tests; the fp32 C
+restatement (oracle/mgn_ref.c) against the oracle; the reference-named host functions against both."""
+import hashlib
+import os
+
+import numpy as np
+import pytest
+
+import mgn_oracle as orc
+from util import rel_max
+
+import mgn_amd
+from importlib import import_module
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load(name):
+    return np.load(os.path.join(GOLD, name))
+
+
+def params_for(g):
+    ps = orc.init_params(9, 3, 2, int(g["L"]), 2, int(g["mps"]), seed=int(g["seed"]), ln_jitter=float(g["jitter"]))
+    assert hashlib.sha256(ps.tobytes()).hexdigest() == str(g["params_sha256"]), "parameter generator drifted"
+    return ps
+
+
+@pytest.mark.parametrize("name,snaps", [("gold_a_L32_mps1.npz", [1]), ("gold_b_L128_mps15.npz", [1, 8, 15])])
+def test_oracle_reproduces_golden(name, snaps):
+    g = load(name)
+    ps = params_for(g)
+    cfg = dict(Fn=9, Fe=3, O=2, L=int(g["L"]), hidden_layers=2, mps=int(g["mps"]))
+    out, lat = orc.forward(ps, cfg, g["nf"], g["ef"], g["senders"], g["receivers"], return_latents=True)
+    assert rel_max(out, g["out"]) < 1e-12
+    for k in snaps:
+        assert rel_max(lat[k][0], g[f"v_after_{k}"]) < 1e-6
+        assert rel_max(lat[k][1], g[f"e_after_{k}"]) < 1e-6
+
+
+def test_param_count_matches_survey():
+    # enc-node 34,560; enc-edge 33,792; per step edge 82,560 + node 66,176; decoder 33,282
+    assert orc.param_count(9, 3, 2, 128, 2, 15) == 34560 + 33792 + 15 * (82560 + 66176) + 33282
+
+
+def test_kats():
+    k = load("kats.npz")
+    ref = import_module("mgn_amd.reference_api")
+    s1, r1 = ref.triangles_to_edges(np.array([[0, 1, 2]]))
+    assert s1.size == 6 and np.array_equal(s1, k["tri1_s"]) and np.array_equal(r1, k["tri1_r"])       # KAT-1
+    s2, r2 = ref.triangles_to_edges(np.array([[0, 1, 2], [1, 3, 2]]))
+    assert s2.size == 10 and np.array_equal(s2, k["tri2_s"]) and np.array_equal(r2, k["tri2_r"])
+    assert np.array_equal(ref.one_hot(k["onehot_types"], 7, 0), k["onehot"].astype(np.float32))      # KAT-2
+    data = dict(node_type=np.zeros(3, np.int32), mesh_pos=np.array([[0, 0], [3, 0], [3, 4]], np.float32),
+                edges=np.array([[1, 0], [2, 1], [2, 0]]))
+    _, s, r, ef = ref.create_base_graph(data, 6, 0)
+    assert sorted(ef[:3, 2].tolist()) == [3.0, 4.0, 5.0]                                             # KAT-3
+    assert np.allclose(ef[3:, :2], -ef[:3, :2])
+    # vectorised mesh helper gives the same edge SET as the reference-order function
+    pos, cells = mgn_amd.synth.grid_mesh(7, 5, 0)
+    a = set(zip(*[x.tolist() for x in mgn_amd.synth.cells_to_edges(cells)]))
+    b = set(zip(*[x.tolist() for x in ref.triangles_to_edges(cells)]))
+    assert a == b
+
+
+def test_kat5_scatter_star_and_ln_constant():
+    rows = np.arange(12.0).reshape(4, 3)
+    assert np.array_equal(orc.scatter_add(rows, np.zeros(4, int), 2)[0], rows.sum(0))                # KAT-5
+    x = np.full((2, 8), 3.5)
+    assert np.allclose(orc.layer_norm(x, np.ones(8), np.full(8, 0.25)), 0.25)                        # KAT-4 mechanism
+
+
+def test_c_restatement_matches_oracle_on_golden():
+    import mgn_ref
+    for name in ("gold_a_L32_mps1.npz", "gold_b_L128_mps15.npz"):
+        g = load(name)
+        ps = params_for(g)
+        cfg = dict(Fn=9, Fe=3, O=2, L=int(g["L"]), hidden_layers=2, mps=int(g["mps"]))
+        out = mgn_ref.forward(ps, cfg, g["nf"], g["ef"], g["senders"], g["receivers"])
+        assert rel_max(out, g["out"]) <= 1e-4, name
+    g = load("gold_b_L128_mps15.npz")
+    ps = params_for(g)
+    cfg = dict(Fn=9, Fe=3, O=2, L=128, hidden_layers=2, mps=15)
+    v, e = mgn_ref.processor_steps(ps, cfg, g["v_after_1"], g["e_after_1"], g["senders"], g["receivers"], 0)
+    assert np.array_equal(v, g["v_after_1"])
+
+
+def test_c_restatement_ragged():
+    import mgn_ref
+    cfg = dict(Fn=9, Fe=3, O=2, L=32, hidden_layers=2, mps=2)
+    ps = orc.init_params(9, 3, 2, 32, 2, 2, 7, 0.1)
+    for N, E, seed in [(1, 0, 0), (5, 1, 1), (70, 300, 2)]:
+        s, r = mgn_amd.synth.random_graph(N, E, seed)
+        rng = np.random.default_rng(seed)
+        nf, ef = rng.standard_normal((N, 9)).astype(np.float32), rng.standard_normal((E, 3)).astype(np.float32)
+        assert rel_max(mgn_ref.forward(ps, cfg, nf, ef, s, r), orc.forward(ps, cfg, nf, ef, s, r)) <= 1e-4
+
+
+def test_normalisers_and_rollout_wrapper_match_oracle():
+    """reference_api (float32 host mirror of src/graph.jl + src/solve.jl) against the oracle's ode_rhs on GOLD-D,
+    with the model call served by the oracle (no GPU here)."""
+    ref = import_module("mgn_amd.reference_api")
+    g = load("gold_d_rollout.npz")
+    ps = params_for(g)
+    cfg = dict(Fn=9, Fe=3, O=2, L=int(g["L"]), hidden_layers=2, mps=int(g["mps"]))
+
+    class FakeMgn:   # GraphNetwork-shaped holder whose model is the oracle
+        def __init__(self):
+            self.ps, self.st = ps, None
+            self.n_norm = {"velocity": ref.NormaliserOfflineMeanStd(-g["node_shift"][:2] / g["node_scale"][:2], 1 / g["node_scale"][:2]),
+                           "node_type": ref.NormaliserOfflineMinMax(0.0, 1.0)}
+            self.e_norm = ref.NormaliserOfflineMeanStd(-g["edge_shift"] / g["edge_scale"], 1 / g["edge_scale"])
+            self.o_norm = {"velocity": ref.NormaliserOfflineMeanStd(g["out_shift"], g["out_scale"])}
+
+        def model(self, graph, ps_, st):
+            return orc.forward(ps_, cfg, graph.nf, graph.ef, graph.senders, graph.receivers).astype(np.float32), st
+
+    mgn = FakeMgn()
+    data = dict(node_type=g["node_type"], mesh_pos=g["mesh_pos"], edges=np.stack([g["senders"], g["receivers"]], 1)[: g["senders"].size // 2])
+    onehot, s, r, ef = ref.create_base_graph(data, 6, 0)
+    assert np.array_equal(s, g["senders"]) and np.array_equal(r, g["receivers"])
+    assert np.allclose(ef, g["ef_raw"], atol=1e-6)
+    meta = {"features": {"velocity": {"dim": 2}}}
+    val_mask = g["val_mask"][:, None].astype(np.float32)
+    saves = np.arange(11) * float(g["dt"])
+    sol_u, sol_t = ref.rollout("Euler", mgn, {"velocity": g["x0"].astype(np.float32)}, ["velocity"], meta, ["velocity"],
+                               {"velocity": 2}, onehot, ef, s, r, val_mask, g["inflow_mask"], {"velocity": g["gt"]},
+                               0.0, 10 * float(g["dt"]), float(g["dt"]), saves)
+    assert sol_u.shape == g["xs"].shape
+    assert np.linalg.norm(sol_u - g["xs"]) / np.linalg.norm(g["xs"]) <= 1e-5
+
+
+def test_online_normaliser_accumulates_then_freezes():
+    ref = import_module("mgn_amd.reference_api")
+    rng = np.random.default_rng(0)
+    x = (rng.standard_normal((1000, 3)) * [1, 2, 3] + [5, 0, -1]).astype(np.float32)
+    n = ref.NormaliserOnline(3, max_acc=2)
+    n(x[:500]); n(x[500:])
+    frozen = n.frozen()
+    n(x[:10] * 100)   # third call: max_acc reached, statistics must not move
+    assert np.allclose(n.frozen().mean, frozen.mean) and np.allclose(frozen.mean, x.mean(0), atol=1e-3)
+    assert np.allclose(n.inverse(n(x, accumulate=False)), x, atol=1e-4)
+    with pytest.raises(ValueError):
+        n(x[:, :2])
