@@ -1,0 +1,123 @@
+# MGNHip.jl -- thin `ccall` shim that puts libmgn_hip.so behind the GraphNetCore surface
+# una-auxme/MeshGraphNets.jl uses, so that src/graph.jl and src/solve.jl keep working unchanged.
+#
+# NOT EXECUTED IN THIS REPOSITORY'S CI: julia is not available in the build environment.  The shim binds
+# exactly the symbols of include/mgn_hip.h and mirrors meshgraphnets.jl_amd/engine.py call for call; the
+# Python ctypes host is the tested twin.  See INTEGRATION.md.
+#
+# Usage inside MeshGraphNets.jl:   replace `using GraphNetCore` (src/MeshGraphNets.jl:8) by
+#     include("MGNHip.jl"); using .MGNHip
+# Normalisers, one_hot, triangles_to_edges, parse_edges, mse_reduce, save!/load stay GraphNetCore's (host
+# side, cheap); only GraphNetwork.model / FeatureGraph / step! are replaced.
+module MGNHip
+
+export FeatureGraph, GraphNetwork, set_trajectory_graph!, pack_params
+
+const LIB = get(ENV, "MGN_HIP_LIB", joinpath(@__DIR__, "..", "meshgraphnets.jl_amd", "lib", "libmgn_hip.so"))
+
+struct MgnConfig            # mirrors `mgn_config` (include/mgn_hip.h)
+    Fn::Int32; Fe::Int32; O::Int32; L::Int32; hidden_layers::Int32; mps::Int32
+    dtype::Int32; rank::Int32; nranks::Int32; device::Int32
+end
+
+function check(h::Ptr{Cvoid}, rc::Cint)
+    rc == 0 && return
+    msg = unsafe_string(ccall((:mgn_last_error, LIB), Cstring, (Ptr{Cvoid},), h))
+    rc == -1 ? throw(ArgumentError(msg)) : error("mgn_hip ($rc): $msg")
+end
+
+"FeatureGraph(nf, ef, senders, receivers) -- same fields as GraphNetCore's (reference src/graph.jl:87-96)."
+struct FeatureGraph{A <: AbstractMatrix{Float32}, I <: AbstractVector{<:Integer}}
+    nf::A          # (Fn x N)  == row-major [N][Fn]
+    ef::A          # (Fe x E)
+    senders::I     # 1-based
+    receivers::I
+end
+
+"""
+Mutable holder with the fields the reference reads and writes: `model`, `ps`, `st`, `e_norm`, `n_norm`, `o_norm`
+(src/solve.jl:54,200-208; src/graph.jl:80-93; src/MeshGraphNets.jl:288,376-377).  `ps` stays a Julia-owned
+array tree so `Optimisers.update(opt_state, mgn.ps, gs)` keeps working; it is flattened (pack_params) and
+uploaded only when it changed.
+"""
+mutable struct GraphNetwork
+    handle::Ptr{Cvoid}
+    cfg::MgnConfig
+    model::Function
+    ps
+    st
+    e_norm
+    n_norm
+    o_norm
+    ps_hash::UInt
+    graph_id::UInt
+end
+
+function GraphNetwork(quantities, dims, e_norm, n_norm, o_norm, outputs, mps, layer_size, hidden_layers, ps; device = -1)
+    cfg = MgnConfig(quantities, dims + 1, outputs, layer_size, hidden_layers, mps, 0, 0, 1, device)
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    rc = ccall((:mgn_create, LIB), Cint, (Ref{MgnConfig}, Ref{Ptr{Cvoid}}), cfg, h)
+    rc == 0 || error(unsafe_string(ccall((:mgn_last_error, LIB), Cstring, (Ptr{Cvoid},), C_NULL)))
+    mgn = GraphNetwork(h[], cfg, identity, ps, NamedTuple(), e_norm, n_norm, o_norm, UInt(0), UInt(0))
+    mgn.model = (graph, ps_, st) -> (forward(mgn, graph, ps_), st)      # mgn.model(graph, ps, st) -> (output, st)
+    finalizer(m -> ccall((:mgn_destroy, LIB), Cvoid, (Ptr{Cvoid},), m.handle), mgn)
+    return mgn
+end
+
+"""
+Flatten a Lux parameter tree into MGN-spec packed order (include/mgn_hip.h): enc-node, enc-edge, step1-edge,
+step1-node, ..., decoder; per MLP W1,b1,W2,b2,W3,b3,[ln_scale,ln_bias].  A Lux `Dense` weight is (out x in)
+column-major, i.e. the row-major [in][out] block the engine expects: `vec(W)` is already the right bytes.
+`leaves` must enumerate the (weight, bias, ...) arrays in that order for the concrete GraphNetCore model.
+"""
+pack_params(leaves) = reduce(vcat, (vec(Float32.(Array(x))) for x in leaves))
+
+"Once per trajectory, where the reference calls create_base_graph (src/MeshGraphNets.jl:360,418,596)."
+function set_trajectory_graph!(mgn::GraphNetwork, senders::Vector{Int32}, receivers::Vector{Int32}, N::Integer;
+        mesh_pos::Union{Nothing, Matrix{Float32}} = nothing)
+    pos = mesh_pos === nothing ? C_NULL : pointer(mesh_pos)
+    pd = mesh_pos === nothing ? 0 : size(mesh_pos, 1)
+    GC.@preserve senders receivers mesh_pos check(mgn.handle,
+        ccall((:mgn_set_graph, LIB), Cint,
+            (Ptr{Cvoid}, Int32, Int64, Ptr{Int32}, Ptr{Int32}, Int32, Ptr{Float32}, Int32),
+            mgn.handle, N, length(senders), senders, receivers, 1 #= Julia indices, src/graph.jl:31-34 =#, pos, pd))
+    mgn.graph_id = objectid(senders)
+    return mgn
+end
+
+function sync_params!(mgn::GraphNetwork, packed::Vector{Float32})
+    hsh = hash(packed)
+    hsh == mgn.ps_hash && return
+    check(mgn.handle, ccall((:mgn_set_params, LIB), Cint, (Ptr{Cvoid}, Ptr{Float32}, Csize_t), mgn.handle, packed, length(packed)))
+    mgn.ps_hash = hsh
+end
+
+"`mgn.model(graph, ps, st)` at src/solve.jl:200.  `ps` is the packed Vector{Float32} (see pack_params)."
+function forward(mgn::GraphNetwork, graph::FeatureGraph, ps::Vector{Float32})
+    sync_params!(mgn, ps)
+    N = size(graph.nf, 2)
+    objectid(graph.senders) == mgn.graph_id ||
+        set_trajectory_graph!(mgn, Vector{Int32}(graph.senders), Vector{Int32}(graph.receivers), N)
+    out = Matrix{Float32}(undef, mgn.cfg.O, N)
+    nf = Array(graph.nf); ef = Array(graph.ef)             # host arrays: the engine copies in (H2D) itself
+    GC.@preserve nf ef out check(mgn.handle,
+        ccall((:mgn_forward, LIB), Cint, (Ptr{Cvoid}, Ptr{Float32}, Ptr{Float32}, Ptr{Float32}), mgn.handle, nf, ef, out))
+    return out
+end
+
+"""
+Fused right-hand side: everything `ode_step` does after the state split (src/solve.jl:198-218) in one call --
+build_graph normalisation, model, inverse_data, `.* val_mask`.  Normalisers must have been frozen into affine
+maps with `mgn_set_norms` (a NormaliserOnline past `max_acc`, or any offline normaliser).
+"""
+function ode_step_fused(mgn::GraphNetwork, x::Matrix{Float32}, node_type_onehot::Matrix{Float32},
+        edge_features::Matrix{Float32}, val_mask_row::Vector{Float32})
+    out = similar(x)
+    GC.@preserve x node_type_onehot edge_features val_mask_row out check(mgn.handle,
+        ccall((:mgn_ode_step, LIB), Cint,
+            (Ptr{Cvoid}, Ptr{Float32}, Ptr{Float32}, Ptr{Float32}, Ptr{Float32}, Ptr{Float32}),
+            mgn.handle, x, node_type_onehot, edge_features, val_mask_row, out))
+    return out
+end
+
+end # module
