@@ -87,6 +87,7 @@ struct LaunchCfg { int blocks; int threads; size_t lds; };
 // L in {32,64,128}.  All return hipError_t of the launch.
 hipError_t launch_edge_step(int L, const EdgeArgs& a, hipStream_t s);
 hipError_t launch_node_step(int L, const NodeArgs& a, hipStream_t s);
+hipError_t launch_project(int L, const NodeArgs& a, hipStream_t s);   // mode-2 work with both chunks LDS-resident
 hipError_t launch_enc_node(int L, const EncNodeArgs& a, hipStream_t s);
 hipError_t launch_enc_edge(int L, const EncEdgeArgs& a, hipStream_t s);
 hipError_t launch_decode(int L, const DecArgs& a, hipStream_t s);

@@ -27,6 +27,9 @@
 //     no zero-fill pass, bitwise reproducible.
 #include "kernels.h"
 
+#include <mutex>
+#include <unordered_map>
+
 namespace mgn {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -178,6 +181,33 @@ DEVINL void mfma_chunk(f32x16 (&acc)[NT], const f32x16 (&in)[NT], const float* w
     }
 }
 
+// A chunk whose first JR k-steps are LDS-resident and whose tail streams from L2 (JR = 0: all streamed).  The
+// ring is primed before the resident steps, so the first streamed fragments have JR k-steps to arrive.
+template <int NT, int JR>
+DEVINL void mfma_chunk_split(f32x16 (&acc)[NT], const f32x16 (&in)[NT], const float* w_lds, const float* w_glb, int lane) {
+    typedef typename AVec<NT>::T AV;
+    constexpr int J = 16 * NT;
+    constexpr int PF = (J - JR) < 4 ? (J - JR) : 4;
+    const AV* wl = reinterpret_cast<const AV*>(w_lds) + lane;
+    const AV* wg = reinterpret_cast<const AV*>(w_glb) + lane;
+    AV ring[PF > 0 ? PF : 1];
+#pragma unroll
+    for (int p = 0; p < PF; ++p) ring[p] = wg[(JR + p) * 64];
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+        AV a;
+        if (j < JR) {
+            a = wl[j * 64];
+        } else {
+            a = ring[(j - JR) % PF];
+            if (j + PF < J) ring[(j - JR) % PF] = wg[(j + PF) * 64];
+        }
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(aget<NT>(a, t), in[j >> 4][j & 15], acc[t], 0, 0, 0);
+    }
+}
+
 // LayerNorm over the row's L features: 16*NT in this lane + 16*NT in lane^32.  Biased variance.
 template <int NT>
 DEVINL void layer_norm_frag(f32x16 (&x)[NT], const float* gamma, const float* beta, int h) {
@@ -321,13 +351,21 @@ DEVINL EdgeIdx load_edge_idx(const EdgeArgs& a, int tile, int c) {
 //   epilogue  acc = e' (LN, scan, tail stores)    x    P[s']                       y <- e tile re-read (L2) for the
 //                                                                                       residual, then <- Q[r']
 //   turnover  acc <- x + y (= next tile's init)   x <- e tile of the next tile
+// Steps of the third chunk kept in the LDS left over by two resident chunks at L = 128 (0 when it is fully
+// resident anyway): 160 KiB - 2 x 64 KiB - tables - token words = 29 632 B = 28 k-steps of 1 KiB.
+#ifndef MGN_EDGE_JR
+#define MGN_EDGE_JR 28
+#endif
 template <int NT, int NRES>
 __global__ __launch_bounds__(512, 2) void k_edge_step(const EdgeArgs a) {
     constexpr int L = 32 * NT, CH = 16 * NT * 64 * NT;
+    constexpr int JR = (NRES > 2) ? 0 : (NT == 4 ? MGN_EDGE_JR : 0);   // partial residency of chunk 2
+    constexpr int PART = JR * 64 * NT;
     extern __shared__ __attribute__((aligned(16))) float smem[];
 #pragma unroll
     for (int r = 0; r < NRES; ++r) copy_to_lds(smem + r * CH, a.chunk[r], CH);
-    float* tb = smem + NRES * CH;
+    if (PART > 0) copy_to_lds(smem + NRES * CH, a.chunk[2], PART);
+    float* tb = smem + NRES * CH + PART;
     copy_to_lds(tb, a.tabs, T_COUNT * L);
     int* tokmem = reinterpret_cast<int*>(tb + T_COUNT * L);
     if (threadIdx.x < 8) tokmem[threadIdx.x] = 0;
@@ -373,7 +411,10 @@ __global__ __launch_bounds__(512, 2) void k_edge_step(const EdgeArgs a) {
         STAMP(1);
 
         token.acquire();
-        mfma_chunk<NT, (NRES > 2)>(acc, x, w1, lane);          // layer 1 (edge part; P,Q,b1 preloaded)
+        if constexpr (NRES > 2)
+            mfma_chunk<NT, true>(acc, x, w1, lane);            // layer 1 (edge part; P,Q,b1 preloaded)
+        else
+            mfma_chunk_split<NT, JR>(acc, x, smem + NRES * CH, a.chunk[2], lane);
         STAMP(2);
         relu_frag<NT>(acc);
         tab_frag<NT>(y, tb + T_B2 * L, h);
@@ -447,15 +488,17 @@ __global__ __launch_bounds__(512, 2) void k_edge_step(const EdgeArgs a) {
 // chunk[0]=W2 chunk[1]=W3 chunk[2]=W1[0:L] chunk[3]=W1[L:2L] chunk[4]=WP chunk[5]=WQ
 // V and AGG tile-major; CARRY, P, Q row-major.  CARRY row 2*ntiles_e is the all-zero row.
 // ================================================================================================
-template <int NT, int NRES>
+// PROJECT: also emit P,Q of the next step in the same launch (fewer launches: used for small meshes; on large
+// meshes the projection runs as k_project, where both of its chunks are LDS-resident).
+template <int NT, int NRES, bool PROJECT>
 __global__ __launch_bounds__(512, 2) void k_node_step(const NodeArgs a) {
     constexpr int L = 32 * NT, CH = 16 * NT * 64 * NT;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    if (a.mode != 2) {
+    {
 #pragma unroll
         for (int r = 0; r < (NRES < 4 ? NRES : 4); ++r) copy_to_lds(smem + r * CH, a.chunk[r], CH);
     }
-    if (NRES > 4) {
+    if (PROJECT && NRES > 4) {
 #pragma unroll
         for (int r = 4; r < NRES; ++r) copy_to_lds(smem + r * CH, a.chunk[r], CH);
     }
@@ -483,7 +526,7 @@ __global__ __launch_bounds__(512, 2) void k_node_step(const NodeArgs a) {
         f32x16 v[NT], acc[NT], y[NT];
         load_frag<NT>(v, vtile, STRIDE_TILE);
 
-        if (a.mode != 2) {
+        {
             // aggregated messages: this node's AGG slot, or carry rows when its edge run straddles edge tiles
             const int a0 = valid ? a.rowptr[nn] : 0, a1 = valid ? a.rowptr[nn + 1] : 0;
             const int T1 = a0 >> 5, T2 = (a1 - 1) >> 5;
@@ -515,7 +558,7 @@ __global__ __launch_bounds__(512, 2) void k_node_step(const NodeArgs a) {
             __builtin_amdgcn_s_setprio(0);
 #endif
         }
-        if (a.mode != 0) {
+        if constexpr (PROJECT) {
             zero_frag<NT>(acc);
             mfma_chunk<NT, (NRES > 4)>(acc, v, wp, lane);
             if (valid) store_frag<NT>(row_ptr(a.P, nn, L, h), STRIDE_ROW, acc);
@@ -523,6 +566,36 @@ __global__ __launch_bounds__(512, 2) void k_node_step(const NodeArgs a) {
             mfma_chunk<NT, (NRES > 5)>(y, v, wq, lane);
             if (valid) store_frag<NT>(row_ptr(a.Q, nn, L, h), STRIDE_ROW, y);
         }
+    }
+}
+
+// ================================================================================================
+// P,Q projection alone (both of its chunks LDS-resident: no weight streaming).  chunk[4]=WP chunk[5]=WQ
+// ================================================================================================
+template <int NT>
+__global__ __launch_bounds__(512, 2) void k_project(const NodeArgs a) {
+    constexpr int L = 32 * NT, CH = 16 * NT * 64 * NT;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    copy_to_lds(smem, a.chunk[4], CH);
+    copy_to_lds(smem + CH, a.chunk[5], CH);
+    float* tb = smem + 2 * CH;
+    copy_to_lds(tb, a.tabs, T_COUNT * L);
+    __syncthreads();
+    const int lane0 = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    for (TileWalk tw(a.ntiles, wave); tw.tile < tw.end; tw.tile += tw.stride) {
+        OPAQUE_LANE();
+        const int n = tw.tile * TILE + c;
+        const bool valid = n < a.n;
+        const int nn = valid ? n : 0;
+        f32x16 v[NT], acc[NT], y[NT];
+        load_frag<NT>(v, tile_ptr(a.V, tw.tile, L, lane), STRIDE_TILE);
+        zero_frag<NT>(acc);
+        mfma_chunk<NT, true>(acc, v, smem, lane);
+        if (valid) store_frag<NT>(row_ptr(a.P, nn, L, h), STRIDE_ROW, acc);
+        tab_frag<NT>(y, tb + T_BQ * L, h);
+        mfma_chunk<NT, true>(y, v, smem + CH, lane);
+        if (valid) store_frag<NT>(row_ptr(a.Q, nn, L, h), STRIDE_ROW, y);
     }
 }
 
@@ -791,8 +864,19 @@ static LaunchCfg tile_launch(int L, int ntiles, int nres) {
 
 template <typename K, typename A>
 static hipError_t launch_k(K kern, const A& a, const LaunchCfg& lc, hipStream_t s) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lc.lds);
-    if (e != hipSuccess) return e;
+    // opt in to > 64 KiB dynamic LDS once per kernel and size (small meshes are launch-bound: keep this off the
+    // per-launch path)
+    {
+        static std::mutex mu;
+        static std::unordered_map<const void*, size_t> granted;   // keyed by kernel: K is only the signature type
+        std::lock_guard<std::mutex> lock(mu);
+        size_t& g = granted[reinterpret_cast<const void*>(kern)];
+        if (lc.lds > g) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lc.lds);
+            if (e != hipSuccess) return e;
+            g = lc.lds;
+        }
+    }
     hipLaunchKernelGGL(kern, dim3(lc.blocks), dim3(lc.threads), lc.lds, s, a);
     return hipGetLastError();
 }
@@ -808,8 +892,39 @@ static hipError_t launch_k(K kern, const A& a, const LaunchCfg& lc, hipStream_t 
         return hipErrorInvalidValue;                                                           \
     } while (0)
 
-hipError_t launch_edge_step(int L, const EdgeArgs& a, hipStream_t s) { DISPATCH_L(k_edge_step, 3, a, a.ntiles); }
-hipError_t launch_node_step(int L, const NodeArgs& a, hipStream_t s) { DISPATCH_L(k_node_step, 6, a, a.ntiles); }
+hipError_t launch_project(int L, const NodeArgs& a, hipStream_t s);
+
+hipError_t launch_edge_step(int L, const EdgeArgs& a, hipStream_t s) {
+    if (a.ntiles <= 0) return hipSuccess;
+    const int nres = resident_chunks(L, 3);
+    LaunchCfg lc = tile_launch(L, a.ntiles, nres);
+    if (L == 128) {
+        lc.lds += (size_t)MGN_EDGE_JR * 64 * 4 * 4;   // partially resident third chunk
+        return launch_k(k_edge_step<4, 2>, a, lc, s);
+    }
+    if (L == 64) return launch_k(k_edge_step<2, 3>, a, lc, s);
+    if (L == 32) return launch_k(k_edge_step<1, 3>, a, lc, s);
+    return hipErrorInvalidValue;
+}
+hipError_t launch_node_step(int L, const NodeArgs& a, hipStream_t s) {
+    if (a.ntiles <= 0) return hipSuccess;
+    if (a.mode == 2) return launch_project(L, a, s);
+    const bool proj = a.mode == 1;
+    const int nres = resident_chunks(L, proj ? 6 : 4);
+    const LaunchCfg lc = tile_launch(L, a.ntiles, nres);
+    if (L == 128) return proj ? launch_k(k_node_step<4, 2, true>, a, lc, s) : launch_k(k_node_step<4, 2, false>, a, lc, s);
+    if (L == 64) return proj ? launch_k(k_node_step<2, 6, true>, a, lc, s) : launch_k(k_node_step<2, 4, false>, a, lc, s);
+    if (L == 32) return proj ? launch_k(k_node_step<1, 6, true>, a, lc, s) : launch_k(k_node_step<1, 4, false>, a, lc, s);
+    return hipErrorInvalidValue;
+}
+hipError_t launch_project(int L, const NodeArgs& a, hipStream_t s) {
+    if (a.ntiles <= 0) return hipSuccess;
+    const LaunchCfg lc = tile_launch(L, a.ntiles, 2);
+    if (L == 128) return launch_k(k_project<4>, a, lc, s);
+    if (L == 64) return launch_k(k_project<2>, a, lc, s);
+    if (L == 32) return launch_k(k_project<1>, a, lc, s);
+    return hipErrorInvalidValue;
+}
 hipError_t launch_enc_node(int L, const EncNodeArgs& a, hipStream_t s) { DISPATCH_L(k_enc_node, 4, a, a.ntiles); }
 hipError_t launch_enc_edge(int L, const EncEdgeArgs& a, hipStream_t s) { DISPATCH_L(k_enc_edge, 2, a, a.ntiles); }
 hipError_t launch_decode(int L, const DecArgs& a, hipStream_t s) { DISPATCH_L(k_decode, 2, a, a.ntiles); }

@@ -63,6 +63,7 @@ struct mgn_engine {
     hipStream_t stream = nullptr;
     hipStream_t own_stream = nullptr;
     bool host_only = false;
+    int32_t node_split = 1;   // projection as its own launch (both chunks LDS-resident); MGN_NODE_SPLIT=0 fuses it
     int32_t stagger_edge = 8, stagger_node = 8;  // tunables (MGN_STAGGER_EDGE / MGN_STAGGER_NODE)
 
     // parameters
@@ -316,6 +317,7 @@ int mgn_create(const mgn_config* cfg, mgn_handle** out) {
     h->stream = h->own_stream;
     if (const char* e = getenv("MGN_STAGGER_EDGE")) h->stagger_edge = atoi(e);
     if (const char* e = getenv("MGN_STAGGER_NODE")) h->stagger_node = atoi(e);
+    if (const char* e = getenv("MGN_NODE_SPLIT")) h->node_split = atoi(e);
     layout_all(h);
     *out = h;
     return MGN_OK;
@@ -640,7 +642,7 @@ int mgn_proc_begin(mgn_handle* h) {
     if (int rc = need(h, true, true)) return rc;
     ProfScope ps(h, F_NODE);
     const NodeArgs a = node_args(h, h->cfg.mps, 2);
-    HIPCHK(h, launch_node_step(h->cfg.L, a, h->stream));
+    HIPCHK(h, launch_project(h->cfg.L, a, h->stream));
     return MGN_OK;
 }
 
@@ -658,6 +660,12 @@ int mgn_proc_node(mgn_handle* h, int32_t k, int32_t project_next) {
     if (k < 0 || k >= h->cfg.mps) return fail(h, MGN_E_ARG, "mgn_proc_node: step %d out of range", k);
     if (project_next && k + 1 >= h->cfg.mps) return fail(h, MGN_E_ARG, "mgn_proc_node: no step %d to project for", k + 1);
     ProfScope ps(h, F_NODE);
+    if (project_next && h->node_split) {
+        // two launches: MLP (2 of its 4 chunks stream from L2), then the projection with both chunks resident
+        HIPCHK(h, launch_node_step(h->cfg.L, node_args(h, k, 0), h->stream));
+        HIPCHK(h, launch_project(h->cfg.L, node_args(h, k, 2), h->stream));
+        return MGN_OK;
+    }
     const NodeArgs a = node_args(h, k, project_next ? 1 : 0);
     HIPCHK(h, launch_node_step(h->cfg.L, a, h->stream));
     return MGN_OK;
