@@ -117,6 +117,8 @@ def main():
     ap.add_argument("--nx", type=int, default=1000, help="M-1M grid side (default 1000 -> 1M nodes)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
+    ap.add_argument("--force-staged", action="store_true",
+                    help="drive the staged multi-partition path (RCCL all-to-all-v) even at world size 1 (self-test)")
     args = ap.parse_args()
 
     import numpy as np
@@ -133,9 +135,14 @@ def main():
         raise SystemExit("bench.py needs a GPU: the engine has no CPU path")
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    staged = world > 1 or args.force_staged
+    if staged:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     def barrier_sync():
@@ -149,12 +156,13 @@ def main():
     N, E = pos.shape[0], int(s.size)
 
     eng = mgn_amd.Engine(FN, FE, O, L, 2, MPS, rank=rank, nranks=world, device=local_rank)
-    eng.set_stream(torch.cuda.current_stream().cuda_stream)
+    if staged:   # RCCL collectives and the engine must share torch's stream; alone the engine keeps its own stream
+        eng.set_stream(torch.cuda.current_stream().cuda_stream)
     eng.set_params(ps)
     eng.set_graph(s, r, N, mesh_pos=pos)
     eng.latents_randn(1234)
 
-    if world == 1:
+    if not staged:
         barrier_sync()
         dt, prof = time_single(eng, args.steps, args.warmup, barrier_sync)
     else:
@@ -227,12 +235,19 @@ def main():
             pos2, cells2, _, _ = mgn_amd.synth.mesh_cyl(1234, 2000)
             s2, r2 = mgn_amd.synth.cells_to_edges(cells2)
             eng2 = mgn_amd.Engine(FN, FE, O, L, 2, MPS, device=local_rank)
-            eng2.set_stream(torch.cuda.current_stream().cuda_stream)
             eng2.set_params(ps)
             eng2.set_graph(s2, r2, pos2.shape[0])
             eng2.latents_randn(1234)
-            dt2, prof2 = time_single(eng2, max(args.steps, 20), max(args.warmup, 5), barrier_sync)
-            k2 = max(args.steps, 20)
+            k2 = max(args.steps, 50)
+            _, prof2 = time_single(eng2, 5, 3, barrier_sync)          # per-kernel times (event records on)
+            for _ in range(5):                                        # wall time: no events, hipGraph replay
+                eng2.processor_steps_dev(MPS)
+            barrier_sync()
+            t0 = time.perf_counter()
+            for _ in range(k2):
+                eng2.processor_steps_dev(MPS)
+            barrier_sync()
+            dt2 = time.perf_counter() - t0
             out["secondary"] = {"workload": f"M-cyl Delaunay 2000 pts: N={pos2.shape[0]}, E={s2.size}, L=128, 15 steps, fp32 (BASELINE.json configs[1])",
                                 "edges_per_s": s2.size * MPS * k2 / dt2, "nodes_per_s": pos2.shape[0] * MPS * k2 / dt2,
                                 "us_per_processor_step": dt2 / (k2 * MPS) * 1e6,

@@ -359,7 +359,7 @@ DEVINL EdgeIdx load_edge_idx(const EdgeArgs& a, int tile, int c) {
 template <int NT, int NRES>
 __global__ __launch_bounds__(512, 2) void k_edge_step(const EdgeArgs a) {
     constexpr int L = 32 * NT, CH = 16 * NT * 64 * NT;
-    constexpr int JR = (NRES > 2) ? 0 : (NT == 4 ? MGN_EDGE_JR : 0);   // partial residency of chunk 2
+    constexpr int JR = (NRES == 2 && NT == 4) ? MGN_EDGE_JR : 0;   // partial residency of chunk 2
     constexpr int PART = JR * 64 * NT;
     extern __shared__ __attribute__((aligned(16))) float smem[];
 #pragma unroll
@@ -572,13 +572,15 @@ __global__ __launch_bounds__(512, 2) void k_node_step(const NodeArgs a) {
 // ================================================================================================
 // P,Q projection alone (both of its chunks LDS-resident: no weight streaming).  chunk[4]=WP chunk[5]=WQ
 // ================================================================================================
-template <int NT>
+template <int NT, bool RES>
 __global__ __launch_bounds__(512, 2) void k_project(const NodeArgs a) {
     constexpr int L = 32 * NT, CH = 16 * NT * 64 * NT;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    copy_to_lds(smem, a.chunk[4], CH);
-    copy_to_lds(smem + CH, a.chunk[5], CH);
-    float* tb = smem + 2 * CH;
+    if (RES) {
+        copy_to_lds(smem, a.chunk[4], CH);
+        copy_to_lds(smem + CH, a.chunk[5], CH);
+    }
+    float* tb = smem + (RES ? 2 * CH : 0);
     copy_to_lds(tb, a.tabs, T_COUNT * L);
     __syncthreads();
     const int lane0 = threadIdx.x & 63;
@@ -591,10 +593,10 @@ __global__ __launch_bounds__(512, 2) void k_project(const NodeArgs a) {
         f32x16 v[NT], acc[NT], y[NT];
         load_frag<NT>(v, tile_ptr(a.V, tw.tile, L, lane), STRIDE_TILE);
         zero_frag<NT>(acc);
-        mfma_chunk<NT, true>(acc, v, smem, lane);
+        mfma_chunk<NT, RES>(acc, v, RES ? smem : a.chunk[4], lane);
         if (valid) store_frag<NT>(row_ptr(a.P, nn, L, h), STRIDE_ROW, acc);
         tab_frag<NT>(y, tb + T_BQ * L, h);
-        mfma_chunk<NT, true>(y, v, smem + CH, lane);
+        mfma_chunk<NT, RES>(y, v, RES ? smem + CH : a.chunk[5], lane);
         if (valid) store_frag<NT>(row_ptr(a.Q, nn, L, h), STRIDE_ROW, y);
     }
 }
@@ -846,6 +848,10 @@ static int resident_chunks(int L, int want) {
     return r < want ? r : want;
 }
 
+// Launches with at most one tile per SIMD cannot amortise a per-block LDS weight preload (up to 156 KB copied by
+// 64-128 threads = 10-17 us): such launches use the all-streaming instantiations (weights stay in L2).
+static bool small_launch(int ntiles) { return ntiles <= 4 * num_cus(); }
+
 static LaunchCfg tile_launch(int L, int ntiles, int nres) {
     LaunchCfg lc;
     const int cus = num_cus();
@@ -899,6 +905,10 @@ hipError_t launch_edge_step(int L, const EdgeArgs& a, hipStream_t s) {
     const int nres = resident_chunks(L, 3);
     LaunchCfg lc = tile_launch(L, a.ntiles, nres);
     if (L == 128) {
+        if (small_launch(a.ntiles)) {   // few tiles: the per-block LDS preload would dominate -> stream everything from L2
+            lc.lds = (size_t)T_COUNT * L * 4 + 64;
+            return launch_k(k_edge_step<4, 0>, a, lc, s);
+        }
         lc.lds += (size_t)MGN_EDGE_JR * 64 * 4 * 4;   // partially resident third chunk
         return launch_k(k_edge_step<4, 2>, a, lc, s);
     }
@@ -912,17 +922,28 @@ hipError_t launch_node_step(int L, const NodeArgs& a, hipStream_t s) {
     const bool proj = a.mode == 1;
     const int nres = resident_chunks(L, proj ? 6 : 4);
     const LaunchCfg lc = tile_launch(L, a.ntiles, nres);
-    if (L == 128) return proj ? launch_k(k_node_step<4, 2, true>, a, lc, s) : launch_k(k_node_step<4, 2, false>, a, lc, s);
+    if (L == 128) {
+        if (small_launch(a.ntiles)) {
+            LaunchCfg l0 = lc;
+            l0.lds = (size_t)T_COUNT * L * 4 + 64;
+            return proj ? launch_k(k_node_step<4, 0, true>, a, l0, s) : launch_k(k_node_step<4, 0, false>, a, l0, s);
+        }
+        return proj ? launch_k(k_node_step<4, 2, true>, a, lc, s) : launch_k(k_node_step<4, 2, false>, a, lc, s);
+    }
     if (L == 64) return proj ? launch_k(k_node_step<2, 6, true>, a, lc, s) : launch_k(k_node_step<2, 4, false>, a, lc, s);
     if (L == 32) return proj ? launch_k(k_node_step<1, 6, true>, a, lc, s) : launch_k(k_node_step<1, 4, false>, a, lc, s);
     return hipErrorInvalidValue;
 }
 hipError_t launch_project(int L, const NodeArgs& a, hipStream_t s) {
     if (a.ntiles <= 0) return hipSuccess;
-    const LaunchCfg lc = tile_launch(L, a.ntiles, 2);
-    if (L == 128) return launch_k(k_project<4>, a, lc, s);
-    if (L == 64) return launch_k(k_project<2>, a, lc, s);
-    if (L == 32) return launch_k(k_project<1>, a, lc, s);
+    LaunchCfg lc = tile_launch(L, a.ntiles, 2);
+    if (L == 128 && small_launch(a.ntiles)) {
+        lc.lds = (size_t)T_COUNT * L * 4 + 64;
+        return launch_k(k_project<4, false>, a, lc, s);
+    }
+    if (L == 128) return launch_k(k_project<4, true>, a, lc, s);
+    if (L == 64) return launch_k(k_project<2, true>, a, lc, s);
+    if (L == 32) return launch_k(k_project<1, true>, a, lc, s);
     return hipErrorInvalidValue;
 }
 hipError_t launch_enc_node(int L, const EncNodeArgs& a, hipStream_t s) { DISPATCH_L(k_enc_node, 4, a, a.ntiles); }

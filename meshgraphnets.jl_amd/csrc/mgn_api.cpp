@@ -95,6 +95,13 @@ struct mgn_engine {
     int32_t in_wa = 0, in_wb = 0;
     bool have_mask = false;
 
+    // hipGraph of one mgn_processor_steps_dev(nsteps) pass: small meshes are launch-bound (3 kernels per step).
+    // State machine per invalidation: first call runs eagerly (warms per-kernel attributes), second captures.
+    int32_t use_graph = 1;          // MGN_GRAPH=0 disables
+    int32_t graph_nsteps = -1;      // nsteps the cached graph was captured for
+    int32_t graph_warm = -1;        // nsteps of the last eager run since the last invalidation
+    hipGraphExec_t graph_exec = nullptr;
+
     // profiling
     bool prof = false;
     std::vector<ProfRec> recs;
@@ -245,6 +252,13 @@ int alloc_latents(mgn_engine* h) {
     return MGN_OK;
 }
 
+void drop_graph(mgn_engine* h) {
+    if (h->graph_exec) (void)hipGraphExecDestroy(h->graph_exec);
+    h->graph_exec = nullptr;
+    h->graph_nsteps = -1;
+    h->graph_warm = -1;
+}
+
 EdgeArgs edge_args(mgn_engine* h, int k) {
     EdgeArgs a{};
     a.snd = h->d_snd.as<int32_t>();
@@ -318,6 +332,7 @@ int mgn_create(const mgn_config* cfg, mgn_handle** out) {
     if (const char* e = getenv("MGN_STAGGER_EDGE")) h->stagger_edge = atoi(e);
     if (const char* e = getenv("MGN_STAGGER_NODE")) h->stagger_node = atoi(e);
     if (const char* e = getenv("MGN_NODE_SPLIT")) h->node_split = atoi(e);
+    if (const char* e = getenv("MGN_GRAPH")) h->use_graph = atoi(e);
     layout_all(h);
     *out = h;
     return MGN_OK;
@@ -327,6 +342,7 @@ void mgn_destroy(mgn_handle* h) {
     if (!h) return;
     if (h->host_only) { delete h; return; }
     (void)hipStreamSynchronize(h->stream);
+    drop_graph(h);
     for (auto& r : h->recs) {
         (void)hipEventDestroy(r.a);
         (void)hipEventDestroy(r.b);
@@ -340,6 +356,7 @@ const char* mgn_last_error(const mgn_handle* h) { return h ? h->err.c_str() : g_
 int mgn_set_stream(mgn_handle* h, void* hip_stream) {
     if (int rc = need(h, false, false)) return rc;
     HIPCHK(h, hipStreamSynchronize(h->stream));
+    drop_graph(h);
     h->stream = (hip_stream == MGN_STREAM_OWN) ? h->own_stream : reinterpret_cast<hipStream_t>(hip_stream);
     return MGN_OK;
 }
@@ -448,6 +465,7 @@ int mgn_set_params(mgn_handle* h, const float* packed, size_t n) {
         h->soff.push_back(so);
     }
     HIPCHK(h, hipStreamSynchronize(h->stream));
+    drop_graph(h);
     HIPCHK(h, h->wfrag.ensure(f.size() * 4));
     HIPCHK(h, hipMemcpy(h->wfrag.p, f.data(), f.size() * 4, hipMemcpyHostToDevice));
     h->have_params = true;
@@ -490,6 +508,7 @@ int mgn_set_graph(mgn_handle* h, int32_t N, int64_t E, const int32_t* senders, c
     if (!h) return MGN_E_ARG;
     if (index_base != 0 && index_base != 1) return fail(h, MGN_E_ARG, "mgn_set_graph: index_base must be 0 or 1");
     h->have_graph = false;
+    if (!h->host_only) { (void)hipStreamSynchronize(h->stream); drop_graph(h); }
     const std::string why = build_local_graph(N, E, senders, receivers, index_base, mesh_pos, pos_dim, h->cfg.rank, h->cfg.nranks, h->g);
     if (!why.empty()) return fail(h, MGN_E_ARG, "mgn_set_graph: %s", why.c_str());
     const LocalGraph& g = h->g;
@@ -826,13 +845,51 @@ int mgn_latents_checksum(mgn_handle* h, double* sv, double* se, double* qv, doub
     return MGN_OK;
 }
 
+static int processor_pass(mgn_handle* h, int32_t nsteps) {
+    if (int rc = mgn_proc_begin(h)) return rc;
+    return run_processor(h, nsteps);
+}
+
 int mgn_processor_steps_dev(mgn_handle* h, int32_t nsteps) {
     if (int rc = need(h, true, true)) return rc;
     if (h->cfg.nranks != 1) return fail(h, MGN_E_STATE, "mgn_processor_steps_dev drives one partition; use mgn_proc_* + mgn_halo_*");
     if (nsteps < 0 || nsteps > h->cfg.mps) return fail(h, MGN_E_ARG, "nsteps must be in [0, mps]");
     if (nsteps == 0) return MGN_OK;
-    if (int rc = mgn_proc_begin(h)) return rc;
-    return run_processor(h, nsteps);
+    // Graph replay only helps launch-bound (small) passes; it needs a capturable stream (not the null stream) and no
+    // per-launch event records.
+    const bool graphable = h->use_graph && !h->prof && h->stream != nullptr && h->ntiles_e <= 16384;
+    if (!graphable) return processor_pass(h, nsteps);
+    if (h->graph_exec && h->graph_nsteps == nsteps) {
+        HIPCHK(h, hipGraphLaunch(h->graph_exec, h->stream));
+        return MGN_OK;
+    }
+    if (h->graph_warm != nsteps) {   // eager first: sets the per-kernel LDS attributes outside of any capture
+        h->graph_warm = nsteps;
+        return processor_pass(h, nsteps);
+    }
+    if (h->graph_exec) (void)hipGraphExecDestroy(h->graph_exec);
+    h->graph_exec = nullptr;
+    h->graph_nsteps = -1;
+    hipGraph_t graph = nullptr;
+    HIPCHK(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
+    const int rc = processor_pass(h, nsteps);
+    const hipError_t ce = hipStreamEndCapture(h->stream, &graph);
+    if (rc != MGN_OK || ce != hipSuccess || !graph) {
+        if (graph) (void)hipGraphDestroy(graph);
+        h->use_graph = 0;                       // fall back to eager launches for good
+        if (rc != MGN_OK) return rc;
+        return processor_pass(h, nsteps);
+    }
+    const hipError_t ie = hipGraphInstantiate(&h->graph_exec, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    if (ie != hipSuccess) {
+        h->graph_exec = nullptr;
+        h->use_graph = 0;
+        return processor_pass(h, nsteps);
+    }
+    h->graph_nsteps = nsteps;
+    HIPCHK(h, hipGraphLaunch(h->graph_exec, h->stream));
+    return MGN_OK;
 }
 
 int mgn_processor_steps(mgn_handle* h, float* v, float* e, int32_t nsteps) {

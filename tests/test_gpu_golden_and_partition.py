@@ -229,3 +229,19 @@ def test_full_size_1m_properties():
     c = run(s, r, P=2)                                                     # (3)
     for k in a:
         assert abs(c[k] - a[k]) <= 2e-6 * max(abs(a[k]), 1.0) + 1e-3 * (k.startswith("sum_")), (k, a[k], c[k])
+
+
+def test_bench_staged_path_with_rccl_world1():
+    """The N > 1 code path of bench.py (torch.distributed nccl == RCCL, DistExchange, staged driver) driven at
+    world size 1 on a reduced mesh: catches API/stream mistakes that only the RCCL path would hit."""
+    import json
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
+                          "--nx", "200", "--force-staged", "--no-cpu-baseline", "--no-secondary"],
+                         env=env, capture_output=True, text=True, timeout=600)
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert lines, out.stdout[-2000:] + out.stderr[-2000:]
+    d = json.loads(lines[-1])
+    assert d["n_gpus"] == 1 and d["value"] > 0 and d["latents_finite"]
