@@ -94,6 +94,20 @@ def cpu_baseline(ps, budget_s=20.0):
                 host_cpus=os.cpu_count())
 
 
+def committed_traffic(kernel_substr):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this same command
+    (profiles/r01/pmc_summary_bench_1m.json; separate --pmc FETCH_SIZE / WRITE_SIZE passes, gfx950 x2 read
+    correction as prescribed by the guide's HBM section).  None when no profile is committed."""
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "r01", "pmc_summary_bench_1m.json")))
+        for k, v in d.items():
+            if kernel_substr in k and "derived" in v:
+                return v["derived"]["hbm_bytes_per_launch_corrected"]
+    except Exception:
+        pass
+    return None
+
+
 def time_single(eng, steps, warmup, sync):
     for _ in range(warmup):
         eng.processor_steps_dev(MPS)
@@ -220,7 +234,10 @@ def main():
                 "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS,
                 "flops_per_launch": flops_edge_kernel(e_loc), "flops_kind": "MFMA flops executed by this kernel (98 304 per edge; "
                 "layer 1 is factored so the v_s/v_r blocks run per node in k_node_step)",
-                "avg_launch_ms": t_edge * 1e3, "launches": prof["edge_step"]["count"], "traffic": None,
+                "avg_launch_ms": t_edge * 1e3, "launches": prof["edge_step"]["count"],
+                "traffic": committed_traffic("k_edge_step<4, 2>") if (world == 1 and args.nx == 1000) else None,
+                "traffic_unit": "bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/r01/); algorithmic = 1117 B/edge",
+                "algorithmic_bytes_per_launch": (1024.0 + 8.0 + 85.0) * e_loc,
                 "node_kernel": {"avg_launch_ms": t_node * 1e3, "launches": prof["node_step"]["count"],
                                 "achieved": node_flops_pass / node_launches / t_node / 1e12 if t_node > 0 else 0.0},
                 "processor_step_algorithmic": {
