@@ -107,6 +107,8 @@ int mgn_halo_send_index(const mgn_handle* h, int32_t* local_rows /* [sum(send_ro
 /* local (receiver-sorted) edge list: snd may index halo rows (>= n_own); rowptr is CSR by receiver */
 int mgn_local_graph(const mgn_handle* h, int32_t* snd /* [e_local] */, int32_t* rcv /* [e_local] */, int32_t* rowptr /* [n_own+1] */);
 int mgn_node_owner(const mgn_handle* h, int32_t* owner /* [N] rank owning each global node */);
+/* owned nodes are numbered boundary-first: local rows [0, n_boundary) are the nodes some peer lists as halo */
+int mgn_boundary_count(const mgn_handle* h, int32_t* n_boundary);
 
 /* ---- the model: mgn.model(graph, ps, st) -> output (reference src/solve.jl:200) ---------------
  * nf [N][Fn], ef [E][Fe] are the FeatureGraph fields (already normalised, src/graph.jl:87-96);
@@ -142,6 +144,12 @@ int mgn_fwd_encode(mgn_handle* h);
 int mgn_proc_begin(mgn_handle* h);                      /* project P,Q of step 0 from current v     */
 int mgn_proc_edge(mgn_handle* h, int32_t k);
 int mgn_proc_node(mgn_handle* h, int32_t k, int32_t project_next); /* project_next: also emit P,Q of step k+1 */
+/* Split form for overlapping the halo exchange (owned nodes are numbered boundary-first):
+ *   phase 1: node MLP of step k on all nodes + projection (P,Q of step k+1; k = -1: of step 0) of the BOUNDARY tiles
+ *   -> mgn_halo_pack + start the exchange ->
+ *   phase 2: projection of the interior tiles     -> finish the exchange, mgn_halo_unpack.
+ * phase 1 followed by phase 2 equals mgn_proc_node(h, k, 1) (k >= 0) or mgn_proc_begin (k = -1). */
+int mgn_proc_node_phase(mgn_handle* h, int32_t k, int32_t phase);
 int mgn_fwd_decode(mgn_handle* h);
 int mgn_fwd_download(mgn_handle* h, float* out);        /* host GLOBAL [N][O]; owned rows written   */
 int mgn_halo_bytes_per_row(const mgn_handle* h);

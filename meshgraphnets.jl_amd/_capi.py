@@ -47,6 +47,7 @@ PROTOTYPES = {
     "mgn_halo_send_index": (C.c_int, [_H, _i32p]),
     "mgn_local_graph": (C.c_int, [_H, _i32p, _i32p, _i32p]),
     "mgn_node_owner": (C.c_int, [_H, _i32p]),
+    "mgn_boundary_count": (C.c_int, [_H, _i32p]),
     "mgn_forward": (C.c_int, [_H, _f32p, _f32p, _f32p]),
     "mgn_ode_step": (C.c_int, [_H, _f32p, _f32p, _f32p, _f32p, _f32p]),
     "mgn_processor_steps": (C.c_int, [_H, _f32p, _f32p, C.c_int32]),
@@ -60,6 +61,7 @@ PROTOTYPES = {
     "mgn_proc_begin": (C.c_int, [_H]),
     "mgn_proc_edge": (C.c_int, [_H, C.c_int32]),
     "mgn_proc_node": (C.c_int, [_H, C.c_int32, C.c_int32]),
+    "mgn_proc_node_phase": (C.c_int, [_H, C.c_int32, C.c_int32]),
     "mgn_fwd_decode": (C.c_int, [_H]),
     "mgn_fwd_download": (C.c_int, [_H, _f32p]),
     "mgn_halo_bytes_per_row": (C.c_int, [_H]),

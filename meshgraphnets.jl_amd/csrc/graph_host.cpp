@@ -74,13 +74,26 @@ std::string build_local_graph(int32_t N, int64_t E, const int32_t* senders, cons
     g.nranks = nranks;
     rcb_partition(N, pos, pos_dim, nranks, g.owner);
 
-    // owned nodes, ascending global id
+    // owned nodes: boundary nodes (senders of an edge received on another rank) first, then interior, each in
+    // ascending global id.  Boundary-first lets the driver project the boundary tiles, start the halo exchange and
+    // overlap it with the projection of the interior tiles.
     std::vector<int32_t> g2l(N, -1);
-    for (int32_t i = 0; i < N; ++i)
-        if (g.owner[i] == rank) {
-            g2l[i] = (int32_t)g.own_gid.size();
-            g.own_gid.push_back(i);
+    {
+        std::vector<uint8_t> is_bnd(N, 0);
+        if (nranks > 1)
+            for (int64_t i = 0; i < E; ++i) {
+                const int32_t s = senders[i] - index_base, r = receivers[i] - index_base;
+                if (g.owner[s] == rank && g.owner[r] != rank) is_bnd[s] = 1;
+            }
+        for (int pass = 0; pass < 2; ++pass) {
+            for (int32_t i = 0; i < N; ++i)
+                if (g.owner[i] == rank && (is_bnd[i] != 0) == (pass == 0)) {
+                    g2l[i] = (int32_t)g.own_gid.size();
+                    g.own_gid.push_back(i);
+                }
+            if (pass == 0) g.n_boundary = (int32_t)g.own_gid.size();
         }
+    }
     g.n_own = (int32_t)g.own_gid.size();
 
     // local edges = edges whose receiver is owned; count per receiver for the stable counting sort

@@ -12,8 +12,9 @@ struct LocalGraph {
     int64_t E = 0;              // global edges
     int32_t rank = 0, nranks = 1;
     int32_t n_own = 0, n_halo = 0;
+    int32_t n_boundary = 0;          // owned nodes that some peer lists as halo; they are numbered FIRST
     int64_t e_local = 0;
-    std::vector<int32_t> own_gid;    // [n_own] global id of owned node i (ascending)
+    std::vector<int32_t> own_gid;    // [n_own] global id of owned node i: boundary nodes (ascending), then interior (ascending)
     std::vector<int32_t> halo_gid;   // [n_halo] grouped by owner rank, ascending gid inside a group
     std::vector<int64_t> edge_gid;   // [e_local] global edge id, engine (receiver-sorted, stable) order
     std::vector<int32_t> snd, rcv;   // [e_local] local indices; snd may be >= n_own (halo)

@@ -42,6 +42,7 @@ struct NodeArgs {
     int32_t mode;           // 0: MLP only (last step)  1: MLP + project P,Q  2: project only
     int32_t stagger;
     int64_t zero_row;       // CARRY row that is all zeros (read for receivers without incoming edges)
+    int32_t tile0;          // k_project only: first tile of the range [tile0, tile0 + ntiles)
 };
 
 struct EncNodeArgs {

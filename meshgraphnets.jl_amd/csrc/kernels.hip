@@ -587,11 +587,12 @@ __global__ __launch_bounds__(512, 2) void k_project(const NodeArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     for (TileWalk tw(a.ntiles, wave); tw.tile < tw.end; tw.tile += tw.stride) {
         OPAQUE_LANE();
-        const int n = tw.tile * TILE + c;
+        const int tile = a.tile0 + tw.tile;
+        const int n = tile * TILE + c;
         const bool valid = n < a.n;
         const int nn = valid ? n : 0;
         f32x16 v[NT], acc[NT], y[NT];
-        load_frag<NT>(v, tile_ptr(a.V, tw.tile, L, lane), STRIDE_TILE);
+        load_frag<NT>(v, tile_ptr(a.V, tile, L, lane), STRIDE_TILE);
         zero_frag<NT>(acc);
         mfma_chunk<NT, RES>(acc, v, RES ? smem : a.chunk[4], lane);
         if (valid) store_frag<NT>(row_ptr(a.P, nn, L, h), STRIDE_ROW, acc);

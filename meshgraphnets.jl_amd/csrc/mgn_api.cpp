@@ -292,6 +292,7 @@ NodeArgs node_args(mgn_engine* h, int k, int mode) {
     a.mode = mode;
     a.stagger = h->stagger_node;
     a.zero_row = 2 * (int64_t)(h->ntiles_e > 0 ? h->ntiles_e : 1);
+    a.tile0 = 0;
     return a;
 }
 
@@ -591,6 +592,12 @@ int mgn_node_owner(const mgn_handle* h, int32_t* owner) {
     return MGN_OK;
 }
 
+int mgn_boundary_count(const mgn_handle* h, int32_t* n_boundary) {
+    if (!h || !h->have_graph || !n_boundary) return MGN_E_STATE;
+    *n_boundary = h->g.n_boundary;
+    return MGN_OK;
+}
+
 // ---- staged pipeline ----------------------------------------------------------------------------
 static int upload_inputs(mgn_handle* h, const float* a, int wa, const float* b, int wb, const float* ef) {
     const LocalGraph& g = h->g;
@@ -687,6 +694,25 @@ int mgn_proc_node(mgn_handle* h, int32_t k, int32_t project_next) {
     }
     const NodeArgs a = node_args(h, k, project_next ? 1 : 0);
     HIPCHK(h, launch_node_step(h->cfg.L, a, h->stream));
+    return MGN_OK;
+}
+
+int mgn_proc_node_phase(mgn_handle* h, int32_t k, int32_t phase) {
+    if (int rc = need(h, true, true)) return rc;
+    if (k < -1 || k + 1 >= h->cfg.mps) return fail(h, MGN_E_ARG, "mgn_proc_node_phase: no step %d to project for", k + 1);
+    if (phase != 1 && phase != 2) return fail(h, MGN_E_ARG, "mgn_proc_node_phase: phase must be 1 or 2");
+    ProfScope ps(h, F_NODE);
+    const int ntb = (h->g.n_boundary + TILE - 1) / TILE;   // tiles that contain a boundary node
+    if (phase == 1 && k >= 0) HIPCHK(h, launch_node_step(h->cfg.L, node_args(h, k, 0), h->stream));
+    NodeArgs a = node_args(h, k >= 0 ? k : h->cfg.mps, 2);
+    if (phase == 1) {
+        a.tile0 = 0;
+        a.ntiles = ntb < h->ntiles_n ? ntb : h->ntiles_n;
+    } else {
+        a.tile0 = ntb < h->ntiles_n ? ntb : h->ntiles_n;
+        a.ntiles = h->ntiles_n - a.tile0;
+    }
+    HIPCHK(h, launch_project(h->cfg.L, a, h->stream));
     return MGN_OK;
 }
 

@@ -153,6 +153,11 @@ class Engine:
         self._chk(self.lib.mgn_local_graph(self.h, i32(snd), i32(rcv), i32(rowptr)))
         return snd, rcv, rowptr
 
+    def boundary_count(self):
+        n = C.c_int32()
+        self._chk(self.lib.mgn_boundary_count(self.h, C.byref(n)))
+        return n.value
+
     def node_owner(self):
         out = np.empty(self.N, np.int32)
         self._chk(self.lib.mgn_node_owner(self.h, i32(out)))
@@ -224,6 +229,10 @@ class Engine:
 
     def proc_node(self, k, project_next):
         self._chk(self.lib.mgn_proc_node(self.h, k, 1 if project_next else 0))
+
+    def proc_node_phase(self, k, phase):
+        """phase 1: node MLP of step k (k = -1: none) + projection of the boundary tiles; phase 2: interior tiles."""
+        self._chk(self.lib.mgn_proc_node_phase(self.h, k, phase))
 
     def fwd_decode(self):
         self._chk(self.lib.mgn_fwd_decode(self.h))
@@ -322,24 +331,44 @@ class GraphNetwork:
 # ==================================================================================================
 # staged driver shared by the single-GPU loopback test, the RCCL path and the gloo CPU test
 # ==================================================================================================
-def run_processor_staged(engines, exchange, nsteps, begin=True):
+def run_processor_staged(engines, exchange, nsteps, begin=True, overlap=None):
     """engines: objects with proc_begin/proc_edge/proc_node (one per local partition);
     exchange(): performs pack -> all-to-all-v -> unpack for all of them.
-    Mirrors mgn_processor_steps_dev for nranks > 1."""
+    Mirrors mgn_processor_steps_dev for nranks > 1.
+
+    overlap (default: on when the engines and the exchange support it): owned nodes are numbered boundary-first,
+    so the projection of the boundary tiles runs first, the exchange is started (exchange.start(): pack + async
+    all-to-all-v) and the interior tiles are projected while the rows are on the wire (exchange.finish())."""
     if nsteps <= 0:
         return
+    if overlap is None:
+        overlap = all(hasattr(e, "proc_node_phase") for e in engines) and hasattr(exchange, "start")
+
+    def project_and_exchange(k):        # k = -1: projection for step 0 (proc_begin)
+        if overlap:
+            for e in engines:
+                e.proc_node_phase(k, 1)
+            exchange.start()
+            for e in engines:
+                e.proc_node_phase(k, 2)
+            exchange.finish()
+        else:
+            for e in engines:
+                e.proc_begin() if k < 0 else e.proc_node(k, True)
+            exchange()
+
     if begin:
-        for e in engines:
-            e.proc_begin()
-    exchange()
+        project_and_exchange(-1)
+    else:
+        exchange()
     for k in range(nsteps):
         for e in engines:
             e.proc_edge(k)
-        more = k + 1 < nsteps
-        for e in engines:
-            e.proc_node(k, more)
-        if more:
-            exchange()
+        if k + 1 < nsteps:
+            project_and_exchange(k)
+        else:
+            for e in engines:
+                e.proc_node(k, False)
 
 
 def run_forward_staged(engines, exchange, mps):

@@ -27,20 +27,33 @@ class DistExchange:
         self.send = torch.empty((max(1, sum(self.send_rows)), L), dtype=torch.float32, device=device)
         self.recv = torch.empty((max(1, sum(self.recv_rows)), L), dtype=torch.float32, device=device)
         self.n_send, self.n_recv = sum(self.send_rows), sum(self.recv_rows)
+        self._work = None
 
-    def __call__(self):
+    def start(self):
+        """pack + launch the all-to-all-v asynchronously (RCCL runs it on its own stream, ordered after the pack
+        kernel on the current stream)."""
         tensor_api = hasattr(self.engine, "halo_pack_tensor")   # NumPy stand-in engines of the CPU tests
         if tensor_api:
             self.engine.halo_pack_tensor(self.send)
         else:
             self.engine.halo_pack(self.send.data_ptr())
-        self.dist.all_to_all_single(self.recv[: self.n_recv], self.send[: self.n_send],
-                                    output_split_sizes=self.recv_rows, input_split_sizes=self.send_rows,
-                                    group=self.group)
-        if tensor_api:
+        self._work = self.dist.all_to_all_single(self.recv[: self.n_recv], self.send[: self.n_send],
+                                                 output_split_sizes=self.recv_rows, input_split_sizes=self.send_rows,
+                                                 group=self.group, async_op=True)
+
+    def finish(self):
+        """make the current stream wait for the collective, then copy the rows into the halo block of P."""
+        if self._work is not None:
+            self._work.wait()
+            self._work = None
+        if hasattr(self.engine, "halo_pack_tensor"):
             self.engine.halo_unpack_tensor(self.recv)
         else:
             self.engine.halo_unpack(self.recv.data_ptr())
+
+    def __call__(self):
+        self.start()
+        self.finish()
 
 
 class LoopbackExchange:
@@ -60,11 +73,18 @@ class LoopbackExchange:
             for q in range(P):
                 assert self.counts[p][0][q] == self.counts[q][1][p], "send/recv halo counts disagree"
 
-    def __call__(self):
-        P = len(self.engines)
+    def start(self):
         tensor_api = hasattr(self.engines[0], "halo_pack_tensor")
         for p, e in enumerate(self.engines):
             e.halo_pack_tensor(self.send[p]) if tensor_api else e.halo_pack(self.send[p].data_ptr())
+
+    def __call__(self):
+        self.start()
+        self.finish()
+
+    def finish(self):
+        P = len(self.engines)
+        tensor_api = hasattr(self.engines[0], "halo_pack_tensor")
         for p in range(P):          # receiver
             for q in range(P):      # sender
                 n = int(self.counts[p][1][q])

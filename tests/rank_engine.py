@@ -21,6 +21,7 @@ class OracleRankEngine:
         self.snd, self.rcv, self.rowptr = self.part.local_graph()
         self.send_idx = self.part.halo_send_index()
         self.n_own, self.n_halo = self.part.n_own, self.part.n_halo
+        self.n_bnd_rows = min(self.n_own, -(-self.part.boundary_count() // 32) * 32)   # whole boundary tiles
         L = cfg["L"]
         self.V = np.zeros((self.n_own, L))
         self.E = np.zeros((self.eid.size, L))
@@ -39,11 +40,21 @@ class OracleRankEngine:
         v[self.own] = self.V
         e[self.eid] = self.E
 
-    def _project(self, k):
+    def _project(self, k, lo=0, hi=None):
         W1, b1 = self.P_["proc%d_edge" % k]["W1"], self.P_["proc%d_edge" % k]["b1"]
         L = self.cfg["L"]
-        self.P[: self.n_own] = self.V @ W1[0:L]
-        self.Q = self.V @ W1[L:2 * L] + b1
+        hi = self.n_own if hi is None else hi
+        self.P[lo:hi] = self.V[lo:hi] @ W1[0:L]
+        self.Q[lo:hi] = self.V[lo:hi] @ W1[L:2 * L] + b1
+
+    def proc_node_phase(self, k, phase):
+        """phase 1: node MLP of step k (k >= 0) + projection of the boundary tiles; phase 2: interior tiles."""
+        if phase == 1:
+            if k >= 0:
+                self.proc_node(k, False)
+            self._project(k + 1, 0, self.n_bnd_rows)
+        else:
+            self._project(k + 1, self.n_bnd_rows, self.n_own)
 
     def proc_begin(self):
         self._project(0)

@@ -93,7 +93,10 @@ def test_partition_invariants(lib_built, P):
     for rk, e in enumerate(engs):
         assert np.array_equal(e.node_owner(), owner)               # every rank computes the same partition
         own = e.owned_nodes()
-        assert np.all(owner[own] == rk) and np.all(np.diff(own) > 0)
+        nb = e.boundary_count()
+        assert np.all(owner[own] == rk) and np.all(np.diff(own[:nb]) > 0) and np.all(np.diff(own[nb:]) > 0)
+        sidx_all = e.halo_send_index()
+        assert set(sidx_all.tolist()) == set(range(nb))            # boundary nodes == send-listed nodes, numbered first
         seen_nodes[own] += 1
         eid = e.local_edges()
         seen_edges[eid] += 1
@@ -129,4 +132,4 @@ def test_partition_without_positions_uses_index_blocks(lib_built):
     s, r = synth.random_graph(100, 400, 1, allow_isolated=False)
     e = Engine(9, 3, 2, rank=1, nranks=4, device=MGN_DEVICE_NONE)
     e.set_graph(s, r, 100)
-    assert np.array_equal(e.owned_nodes(), np.arange(25, 50))
+    assert sorted(e.owned_nodes().tolist()) == list(range(25, 50))
