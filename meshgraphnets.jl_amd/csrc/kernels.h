@@ -23,6 +23,7 @@ struct EdgeArgs {
     float* AGG;             // tile-major over NODE tiles: per-receiver sums of e'
     float* CARRY;           // row-major [2*ntiles+1][L]: partial sums of receiver runs that straddle edge tiles; last row = 0
     const float* chunk[MAX_CHUNKS];  // 0:W2 1:W3 2:W1[2L:3L]   (fragment order)
+    const float* chunk_t[MAX_CHUNKS]; // same chunks in t-major fragment order (cooperative small-graph kernels); null if absent
     const float* tabs;      // T_COUNT * L floats (fragment order): b2,b3 in T_B2,T_B3; LN in T_GAMMA,T_BETA
     int32_t stagger;        // s_sleep(127) units by which waves 4..7 of a block start late
     unsigned long long* stamps;  // diagnostic builds only (MGN_DIAG_STAMPS), else null
@@ -38,6 +39,7 @@ struct NodeArgs {
     float* P;
     float* Q;
     const float* chunk[MAX_CHUNKS];  // 0:W2 1:W3 2:W1[0:L] 3:W1[L:2L] 4:WP(next) 5:WQ(next)
+    const float* chunk_t[MAX_CHUNKS];
     const float* tabs;      // b1,b2,b3,gamma,beta,bq
     int32_t mode;           // 0: MLP only (last step)  1: MLP + project P,Q  2: project only
     int32_t stagger;
@@ -86,6 +88,7 @@ struct DecArgs {
 struct LaunchCfg { int blocks; int threads; size_t lds; };
 
 // L in {32,64,128}.  All return hipError_t of the launch.
+int set_kernel_path(int p);   // debug/tests: 0 auto, 1 resident, 2 streaming, 3 cooperative; returns the old value
 hipError_t launch_edge_step(int L, const EdgeArgs& a, hipStream_t s);
 hipError_t launch_node_step(int L, const NodeArgs& a, hipStream_t s);
 hipError_t launch_project(int L, const NodeArgs& a, hipStream_t s);   // mode-2 work with both chunks LDS-resident

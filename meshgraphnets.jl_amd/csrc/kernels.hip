@@ -110,6 +110,23 @@ DEVINL void store_frag(f32x4* __restrict__ p, int stride, const f32x16 (&x)[NT])
     }
 }
 
+// one 16-register quarter (feature block t: pieces 4t..4t+3) of a fragment
+DEVINL void load_quarter(f32x16& q, const f32x4* __restrict__ p, int stride, int t) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const f32x4 v = p[(4 * t + g) * stride];
+        q[4 * g + 0] = v[0]; q[4 * g + 1] = v[1]; q[4 * g + 2] = v[2]; q[4 * g + 3] = v[3];
+    }
+}
+DEVINL void store_quarter(f32x4* __restrict__ p, int stride, int t, const f32x16& q) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        f32x4 v;
+        v[0] = q[4 * g + 0]; v[1] = q[4 * g + 1]; v[2] = q[4 * g + 2]; v[3] = q[4 * g + 3];
+        p[(4 * t + g) * stride] = v;
+    }
+}
+
 // table (bias / gamma / beta) in fragment order: float4 tab[4*NT][2]
 template <int NT>
 DEVINL void tab_frag(f32x16 (&x)[NT], const float* tab, int h) {
@@ -602,6 +619,212 @@ __global__ __launch_bounds__(512, 2) void k_project(const NodeArgs a) {
     }
 }
 
+// ================================================================================================
+// Cooperative-tile kernels for SMALL graphs (L = 128): one 32-row tile per 4-wave block, wave w owns the
+// 32-feature block t = w of every layer (64 dependent MFMAs = 4.1 k cycles instead of a 16.4 k-cycle chunk) and
+// the waves exchange their output slices through LDS between layers.  A cylinder_flow-sized mesh (374 edge
+// tiles, 63 node tiles) then spreads over ~1500 / 250 waves instead of 374 / 63.  Weights stream from L2 in
+// t-major fragment order (chunk_t[(t*64 + j)*64 + lane]), one coalesced 256-B load per k-step and wave.
+// ================================================================================================
+constexpr int COOP_PF = 8;
+
+DEVINL void coop_chain(f32x16& acc, const f32x16 (&in)[4], const float* wt, int lane) {
+    const float* wv = wt + lane;
+    float ring[COOP_PF];
+#pragma unroll
+    for (int p = 0; p < COOP_PF; ++p) ring[p] = wv[p * 64];
+#pragma unroll
+    for (int j = 0; j < 64; ++j) {
+        const float a = ring[j % COOP_PF];
+        if (j + COOP_PF < 64) ring[j % COOP_PF] = wv[(j + COOP_PF) * 64];
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, in[j >> 4][j & 15], acc, 0, 0, 0);
+    }
+}
+
+// every wave publishes its 16-register slice and reads back the full 64-register row fragment
+DEVINL void coop_exchange(f32x16 (&full)[4], const f32x16& mine, f32x4* xch, int wave, int lane) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        f32x4 v;
+        v[0] = mine[4 * g + 0]; v[1] = mine[4 * g + 1]; v[2] = mine[4 * g + 2]; v[3] = mine[4 * g + 3];
+        xch[(4 * wave + g) * 64 + lane] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int m = 0; m < 16; ++m) {
+        const f32x4 v = xch[m * 64 + lane];
+        full[m >> 2][4 * (m & 3) + 0] = v[0]; full[m >> 2][4 * (m & 3) + 1] = v[1];
+        full[m >> 2][4 * (m & 3) + 2] = v[2]; full[m >> 2][4 * (m & 3) + 3] = v[3];
+    }
+}
+
+DEVINL void tab_quarter(f32x16& q, const float* tab, int t, int h) { load_quarter(q, reinterpret_cast<const f32x4*>(tab) + h, 2, t); }
+
+DEVINL void relu_quarter(f32x16& q) {
+#pragma unroll
+    for (int k = 0; k < 16; ++k) q[k] = fmaxf(q[k], 0.f);
+}
+
+// LayerNorm statistics from the full row fragment, applied to this wave's quarter
+DEVINL void coop_layer_norm(f32x16& mine, const f32x16 (&full)[4], const float* gamma, const float* beta, int t, int h) {
+    float s = 0.f;
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int k = 0; k < 16; ++k) s += full[u][k];
+    s += __shfl_xor(s, 32, 64);
+    const float mean = s * (1.0f / 128);
+    float q = 0.f;
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const float d = full[u][k] - mean;
+            q += d * d;
+        }
+    q += __shfl_xor(q, 32, 64);
+    const float rstd = 1.0f / sqrtf(q * (1.0f / 128) + LN_EPS);
+    f32x16 gq, bq;
+    tab_quarter(gq, gamma, t, h);
+    tab_quarter(bq, beta, t, h);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) mine[k] = (mine[k] - mean) * rstd * gq[k] + bq[k];
+}
+
+// chunk_t[0]=W2 [1]=W3 [2]=W1e  (t-major)
+__global__ __launch_bounds__(256, 2) void k_edge_coop(const EdgeArgs a) {
+    constexpr int L = 128;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    f32x4* xch0 = reinterpret_cast<f32x4*>(smem);
+    f32x4* xch1 = xch0 + 16 * 64;
+    float* tb = smem + 2 * 16 * 64 * 4;
+    copy_to_lds(tb, a.tabs, T_COUNT * L);
+    __syncthreads();
+    const int lane0 = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int tq = wave;   // feature block owned by this wave
+    for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+        OPAQUE_LANE();     // keeps the (loop-invariant) weight and table loads inside the tile loop
+        const EdgeIdx ix = load_edge_idx(a, tile, c);
+        const bool valid = ix.r >= 0;
+        const int r = valid ? ix.r : 0;
+        f32x16 x[4], in[4], acc, xq;
+        f32x4* etile = tile_ptr(a.Elat, tile, L, lane);
+        load_frag<4>(x, etile, STRIDE_TILE);
+        load_quarter(xq, etile, STRIDE_TILE, tq);
+        load_quarter(acc, row_ptr(a.P, ix.s, L, h), STRIDE_ROW, tq);
+        {
+            f32x16 qq;
+            load_quarter(qq, row_ptr(a.Q, r, L, h), STRIDE_ROW, tq);
+            acc += qq;
+        }
+        coop_chain(acc, x, a.chunk_t[2] + tq * 4096, lane);                 // layer 1 (edge part)
+        relu_quarter(acc);
+        coop_exchange(in, acc, xch0, wave, lane);
+        tab_quarter(acc, tb + T_B2 * L, tq, h);
+        coop_chain(acc, in, a.chunk_t[0] + tq * 4096, lane);                // layer 2
+        relu_quarter(acc);
+        coop_exchange(in, acc, xch1, wave, lane);
+        tab_quarter(acc, tb + T_B3 * L, tq, h);
+        coop_chain(acc, in, a.chunk_t[1] + tq * 4096, lane);                // layer 3
+        coop_exchange(in, acc, xch0, wave, lane);                           // full pre-LN row (for the statistics)
+        coop_layer_norm(acc, in, tb + T_GAMMA * L, tb + T_BETA * L, tq, h); // acc = this wave's quarter of e'
+        xq += acc;
+        if (valid) store_quarter(etile, STRIDE_TILE, tq, xq);
+        // segmented sum over runs of equal receiver, this wave's 16 registers
+        const int reff = valid ? r : (-4 - c);
+        const int rprev = __shfl_up(reff, 1, 32);
+        const int rnext = __shfl_down(reff, 1, 32);
+        const bool head = (c == 0) || (reff != rprev);
+        const unsigned hm = (unsigned)__ballot(head);
+        const int start = 31 - __clz((int)(hm & (0xFFFFFFFFu >> (31 - c))));
+        const int st_in = max(start, c & 16);
+        const bool c1 = (c - 1 >= st_in), c2 = (c - 2 >= st_in), c4 = (c - 4 >= st_in), c8 = (c - 8 >= st_in);
+        const bool cx = (c >= 16) && (start <= 15);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            float v = acc[k];
+            float u;
+            u = v + dpp_zero<0x111, 0xF>(v); v = c1 ? u : v;
+            u = v + dpp_zero<0x112, 0xF>(v); v = c2 ? u : v;
+            u = v + dpp_zero<0x114, 0xF>(v); v = c4 ? u : v;
+            u = v + dpp_zero<0x118, 0xF>(v); v = c8 ? u : v;
+            u = v + dpp_zero<0x142, 0xA>(v); v = cx ? u : v;
+            acc[k] = v;
+        }
+        const bool tail = valid && ((c == 31) || (reff != rnext));
+        const int r_first = __builtin_amdgcn_readfirstlane(reff);
+        const bool sl = (start == 0) && (ix.r_before == r_first);
+        const bool sr = (c == 31) && (ix.r_after == reff);
+        const bool to_carry = sl || sr;
+        f32x4* dst = to_carry ? row_ptr(a.CARRY, (int64_t)2 * tile + (sl ? 0 : 1), L, h)
+                              : tile_ptr(a.AGG, r >> 5, L, 32 * h + (r & 31));
+        if (tail) store_quarter(dst, to_carry ? STRIDE_ROW : STRIDE_TILE, tq, acc);
+        __syncthreads();   // xch0 is rewritten by the next tile's first exchange
+    }
+}
+
+// chunk_t[0]=W2 [1]=W3 [2]=W1v [3]=W1a [4]=WP [5]=WQ (t-major).  mode as in NodeArgs.
+__global__ __launch_bounds__(256, 2) void k_node_coop(const NodeArgs a) {
+    constexpr int L = 128;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    f32x4* xch0 = reinterpret_cast<f32x4*>(smem);
+    f32x4* xch1 = xch0 + 16 * 64;
+    float* tb = smem + 2 * 16 * 64 * 4;
+    copy_to_lds(tb, a.tabs, T_COUNT * L);
+    __syncthreads();
+    const int lane0 = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int tq = wave;
+    for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+        OPAQUE_LANE();
+        const int n = tile * TILE + c;
+        const bool valid = n < a.n;
+        const int nn = valid ? n : 0;
+        f32x16 v[4], in[4], acc, vq;
+        f32x4* vtile = tile_ptr(a.V, tile, L, lane);
+        load_frag<4>(v, vtile, STRIDE_TILE);
+        load_quarter(vq, vtile, STRIDE_TILE, tq);
+        if (a.mode != 2) {
+            const int a0 = valid ? a.rowptr[nn] : 0, a1 = valid ? a.rowptr[nn + 1] : 0;
+            const int T1 = a0 >> 5, T2 = (a1 - 1) >> 5;
+            const int extra = (a1 > a0 && T2 > T1) ? (T2 - T1) : 0;
+            const bool from_agg = (a1 > a0) && !extra;
+            const f32x4* src0 = from_agg ? tile_ptr(a.AGG, tile, L, lane)
+                                         : row_ptr(a.CARRY, extra ? (int64_t)(2 * T1 + 1) : a.zero_row, L, h);
+            load_frag<4>(in, src0, from_agg ? STRIDE_TILE : STRIDE_ROW);
+            for (int q = 1; __any(q <= extra); ++q)
+                if (q <= extra) add_frag<4>(in, row_ptr(a.CARRY, (int64_t)2 * (T1 + q), L, h), STRIDE_ROW);
+            tab_quarter(acc, tb + T_B1 * L, tq, h);
+            coop_chain(acc, v, a.chunk_t[2] + tq * 4096, lane);             // layer 1, node part
+            coop_chain(acc, in, a.chunk_t[3] + tq * 4096, lane);            // layer 1, aggregate part
+            relu_quarter(acc);
+            coop_exchange(in, acc, xch0, wave, lane);
+            tab_quarter(acc, tb + T_B2 * L, tq, h);
+            coop_chain(acc, in, a.chunk_t[0] + tq * 4096, lane);            // layer 2
+            relu_quarter(acc);
+            coop_exchange(in, acc, xch1, wave, lane);
+            tab_quarter(acc, tb + T_B3 * L, tq, h);
+            coop_chain(acc, in, a.chunk_t[1] + tq * 4096, lane);            // layer 3
+            coop_exchange(in, acc, xch0, wave, lane);
+            coop_layer_norm(acc, in, tb + T_GAMMA * L, tb + T_BETA * L, tq, h);
+            vq += acc;                                                      // v <- v + v'  (this wave's quarter)
+            if (valid) store_quarter(vtile, STRIDE_TILE, tq, vq);
+            if (a.mode == 1) coop_exchange(v, vq, xch1, wave, lane);         // full updated row for the projection
+        }
+        if (a.mode != 0) {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) acc[k] = 0.f;
+            coop_chain(acc, v, a.chunk_t[4] + tq * 4096, lane);
+            if (valid) store_quarter(row_ptr(a.P, nn, L, h), STRIDE_ROW, tq, acc);
+            tab_quarter(acc, tb + T_BQ * L, tq, h);
+            coop_chain(acc, v, a.chunk_t[5] + tq * 4096, lane);
+            if (valid) store_quarter(row_ptr(a.Q, nn, L, h), STRIDE_ROW, tq, acc);
+        }
+        __syncthreads();
+    }
+}
+
 // first dense layer with a tiny input width: acc[feature] = b1 + sum_k x[k] * W1[k][feature]  (VALU)
 template <int NT>
 DEVINL void first_layer(f32x16 (&acc)[NT], const float* w1f, int k, float xk, int h) {
@@ -851,7 +1074,11 @@ static int resident_chunks(int L, int want) {
 
 // Launches with at most one tile per SIMD cannot amortise a per-block LDS weight preload (up to 156 KB copied by
 // 64-128 threads = 10-17 us): such launches use the all-streaming instantiations (weights stay in L2).
-static bool small_launch(int ntiles) { return ntiles <= 4 * num_cus(); }
+// g_path: 0 auto, 1 force the LDS-resident persistent kernels, 2 force all-streaming, 3 force cooperative
+// (tests exercise every path on small graphs through mgn_debug_kernel_path)
+static int g_path = 0;
+int set_kernel_path(int p) { const int old = g_path; g_path = p; return old; }
+static bool small_launch(int ntiles) { return g_path == 0 ? ntiles <= 4 * num_cus() : g_path >= 2; }
 
 static LaunchCfg tile_launch(int L, int ntiles, int nres) {
     LaunchCfg lc;
@@ -901,10 +1128,19 @@ static hipError_t launch_k(K kern, const A& a, const LaunchCfg& lc, hipStream_t 
 
 hipError_t launch_project(int L, const NodeArgs& a, hipStream_t s);
 
+static size_t coop_lds() { return (size_t)2 * 16 * 64 * 16 + (size_t)T_COUNT * 128 * 4; }
+static bool coop_ok(int L, int ntiles, const float* const* chunk_t) {
+    return L == 128 && chunk_t[0] != nullptr && (g_path == 0 ? small_launch(ntiles) : g_path == 3);
+}
+
 hipError_t launch_edge_step(int L, const EdgeArgs& a, hipStream_t s) {
     if (a.ntiles <= 0) return hipSuccess;
     const int nres = resident_chunks(L, 3);
     LaunchCfg lc = tile_launch(L, a.ntiles, nres);
+    if (coop_ok(L, a.ntiles, a.chunk_t)) {   // small graph: 4 waves per tile
+        LaunchCfg c4{a.ntiles, 256, coop_lds()};
+        return launch_k(k_edge_coop, a, c4, s);
+    }
     if (L == 128) {
         if (small_launch(a.ntiles)) {   // few tiles: the per-block LDS preload would dominate -> stream everything from L2
             lc.lds = (size_t)T_COUNT * L * 4 + 64;
@@ -919,6 +1155,10 @@ hipError_t launch_edge_step(int L, const EdgeArgs& a, hipStream_t s) {
 }
 hipError_t launch_node_step(int L, const NodeArgs& a, hipStream_t s) {
     if (a.ntiles <= 0) return hipSuccess;
+    if (coop_ok(L, a.ntiles, a.chunk_t)) {
+        LaunchCfg c4{a.ntiles, 256, coop_lds()};
+        return launch_k(k_node_coop, a, c4, s);
+    }
     if (a.mode == 2) return launch_project(L, a, s);
     const bool proj = a.mode == 1;
     const int nres = resident_chunks(L, proj ? 6 : 4);
@@ -938,6 +1178,10 @@ hipError_t launch_node_step(int L, const NodeArgs& a, hipStream_t s) {
 hipError_t launch_project(int L, const NodeArgs& a, hipStream_t s) {
     if (a.ntiles <= 0) return hipSuccess;
     LaunchCfg lc = tile_launch(L, a.ntiles, 2);
+    if (a.tile0 == 0 && a.mode == 2 && coop_ok(L, a.ntiles, a.chunk_t)) {
+        LaunchCfg c4{a.ntiles, 256, coop_lds()};
+        return launch_k(k_node_coop, a, c4, s);
+    }
     if (L == 128 && small_launch(a.ntiles)) {
         lc.lds = (size_t)T_COUNT * L * 4 + 64;
         return launch_k(k_project<4, false>, a, lc, s);

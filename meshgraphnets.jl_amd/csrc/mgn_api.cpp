@@ -270,7 +270,10 @@ EdgeArgs edge_args(mgn_engine* h, int k) {
     a.Elat = h->Elat.as<float>();
     a.AGG = h->AGG.as<float>();
     a.CARRY = h->CARRY.as<float>();
-    for (int i = 0; i < 3; ++i) a.chunk[i] = W(h, h->soff[k].e_ch[i]);
+    for (int i = 0; i < 3; ++i) {
+        a.chunk[i] = W(h, h->soff[k].e_ch[i]);
+        a.chunk_t[i] = a.chunk[i] + (size_t)h->cfg.L * h->cfg.L;
+    }
     a.tabs = W(h, h->soff[k].e_tabs);
     a.stagger = h->stagger_edge;
     a.stamps = h->d_stamps.as<unsigned long long>();
@@ -287,7 +290,10 @@ NodeArgs node_args(mgn_engine* h, int k, int mode) {
     a.CARRY = h->CARRY.as<float>();
     a.P = h->P.as<float>();
     a.Q = h->Q.as<float>();
-    for (int i = 0; i < 6; ++i) a.chunk[i] = W(h, h->soff[k].n_ch[i]);
+    for (int i = 0; i < 6; ++i) {
+        a.chunk[i] = W(h, h->soff[k].n_ch[i]);
+        a.chunk_t[i] = a.chunk[i] + (size_t)h->cfg.L * h->cfg.L;
+    }
     a.tabs = W(h, h->soff[k].n_tabs);
     a.mode = mode;
     a.stagger = h->stagger_node;
@@ -388,10 +394,17 @@ int mgn_set_params(mgn_handle* h, const float* packed, size_t n) {
     const size_t CH = (size_t)L * L, TB = (size_t)T_COUNT * L;
 
     std::vector<float> f;
+    // every chunk is stored twice: [lane-interleaved fragment order][t-major order] (the latter for the
+    // cooperative small-graph kernels), so the t-major copy of a chunk at offset `off` lives at `off + CH`
     auto add_chunk = [&](const float* Wm, int ldw, int kbase) {
         const size_t off = f.size();
-        f.resize(off + CH);
+        f.resize(off + 2 * CH);
         pack_chunk(f.data() + off, Wm, ldw, kbase, L);
+        const int NT = L / 32, J = L / 2;
+        for (int t = 0; t < NT; ++t)
+            for (int j = 0; j < J; ++j)
+                for (int lane = 0; lane < 64; ++lane)
+                    f[off + CH + ((size_t)t * J + j) * 64 + lane] = f[off + ((size_t)j * 64 + lane) * NT + t];
         return off;
     };
     auto add_tabs = [&](const float* b1, const float* b2, const float* b3, const float* ga, const float* be, const float* bq) {
@@ -949,6 +962,10 @@ int mgn_halo_unpack(mgn_handle* h, const void* recv_dev) {
                              hipMemcpyDeviceToDevice, h->stream));
     return MGN_OK;
 }
+
+// Process-wide kernel-path override for tests (not part of the public header): 0 auto, 1 LDS-resident persistent
+// kernels, 2 all-streaming, 3 cooperative 4-wave tiles.  Returns the previous value.
+int mgn_debug_kernel_path(int path) { return set_kernel_path(path); }
 
 // ---- diagnostics (not part of the public header; meaningful only with -DMGN_DIAG_STAMPS) -----------------
 int mgn_debug_edge_stamps(mgn_handle* h, int32_t k, unsigned long long* out /* [4*8*24*8] */) {

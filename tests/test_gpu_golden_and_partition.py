@@ -30,8 +30,18 @@ def params_for(g):
     return ps
 
 
+@pytest.mark.parametrize("path", [1, 2, 3], ids=["resident", "streaming", "cooperative"])
 @pytest.mark.parametrize("name", ["gold_a_L32_mps1.npz", "gold_b_L128_mps15.npz"])
-def test_forward_matches_golden(name):
+def test_forward_matches_golden(name, path):
+    from util import set_kernel_path
+    old_path = set_kernel_path(path)
+    try:
+        _forward_matches_golden(name)
+    finally:
+        set_kernel_path(old_path)
+
+
+def _forward_matches_golden(name):
     g = load(name)
     ps = params_for(g)
     cfg = cfg_dict(L=int(g["L"]), mps=int(g["mps"]))
@@ -123,11 +133,14 @@ def test_graphnetwork_surface_and_fused_rhs_and_rollout():
     assert np.linalg.norm(np.stack(xs) - g["xs"]) / np.linalg.norm(g["xs"]) <= TOL_ROLLOUT
 
 
+@pytest.mark.parametrize("path", [1, 3], ids=["resident", "cooperative"])
 @pytest.mark.parametrize("P", [2, 4, 8])
-def test_kat7_partitioned_equals_single(P):
+def test_kat7_partitioned_equals_single(P, path):
     """KAT-7: P edge-cut partitions driven in one process on one GPU (halo all-to-all-v by device copies) give the
     single-partition result up to fp32 summation order of the per-receiver aggregates."""
+    from util import set_kernel_path
     halo = import_module("mgn_amd.halo")
+    old_path = set_kernel_path(path)
     cfg = cfg_dict(mps=4)
     pos, cells = synth.grid_mesh(40, 33, 9)
     s, r = synth.cells_to_edges(cells)
@@ -157,6 +170,7 @@ def test_kat7_partitioned_equals_single(P):
         g.latents_export(v, e)
     assert rel_max(v, v1) <= 1e-5 and rel_max(e, e1) <= 1e-5
     rv, re = orc.processor_steps(ps, cfg, v0, e0, s, r, 4)
+    set_kernel_path(old_path)
     assert rel_max(v, rv) <= TOL_15 and rel_max(e, re) <= TOL_15
 
 

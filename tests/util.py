@@ -39,3 +39,11 @@ def random_inputs(N, E, cfg, seed=0):
 
 def engine_for(cfg, **kw):
     return mgn_amd.Engine(cfg["Fn"], cfg["Fe"], cfg["O"], cfg["L"], cfg["hidden_layers"], cfg["mps"], **kw)
+
+
+def set_kernel_path(path):
+    """Force a kernel family (tests only): 0 auto, 1 LDS-resident persistent, 2 all-streaming, 3 cooperative."""
+    lib = mgn_amd.load()
+    lib.mgn_debug_kernel_path.restype = __import__("ctypes").c_int
+    lib.mgn_debug_kernel_path.argtypes = [__import__("ctypes").c_int]
+    return lib.mgn_debug_kernel_path(path)
