@@ -269,6 +269,26 @@ def main():
                                 "edges_per_s": s2.size * MPS * k2 / dt2, "nodes_per_s": pos2.shape[0] * MPS * k2 / dt2,
                                 "us_per_processor_step": dt2 / (k2 * MPS) * 1e6,
                                 "edge_kernel_us": prof2["edge_step"]["avg_ms"] * 1e3, "node_kernel_us": prof2["node_step"]["avg_ms"] * 1e3}
+            # cfg-5: 100-step inference rollout on the same mesh through the native driver (mgn_rollout):
+            # full Encode-Process-Decode per right-hand side, Euler (100 RHS) and adaptive Tsit5 (6 RHS per step)
+            pos5, cells5, ntype5, vel5 = mgn_amd.synth.mesh_cyl(1234, 2000)
+            onehot5 = np.eye(7, dtype=np.float32)[ntype5]
+            rel5 = pos5[s2] - pos5[r2]
+            ef5 = np.concatenate([rel5, np.linalg.norm(rel5, axis=1, keepdims=True)], 1).astype(np.float32)
+            eng2.set_norms(node=(np.ones(FN, np.float32), np.zeros(FN, np.float32)),
+                           edge=(1.0 / np.maximum(ef5.std(0), 1e-8), -ef5.mean(0) / np.maximum(ef5.std(0), 1e-8)),
+                           out=(np.full(O, 0.05, np.float32), np.zeros(O, np.float32)))
+            vm5 = np.isin(ntype5, [0, 5]).astype(np.float32)
+            roll = {}
+            for name, kw in (("Euler", dict(dt=0.01)), ("Tsit5", dict())):
+                eng2.rollout(name, vel5, onehot5, ef5, 0.0, 0.1, 0.01, 11, val_mask=vm5, **kw)          # warm-up
+                t0 = time.perf_counter()
+                _, st5 = eng2.rollout(name, vel5, onehot5, ef5, 0.0, 1.0, 0.01, 101, val_mask=vm5, **kw)
+                dt5 = time.perf_counter() - t0
+                roll[name] = {"ms_per_rollout": dt5 * 1e3, "rhs_evals": st5["n_rhs"], "accepted_steps": st5["n_accept"],
+                              "rejected_steps": st5["n_reject"], "us_per_rhs": dt5 / max(st5["n_rhs"], 1) * 1e6}
+            out["secondary"]["rollout_100_saves"] = {"workload": "cfg-5 shaped: M-cyl, t in [0,1], saveat 0:0.01:1, random-init weights "
+                                                     "(BASELINE.json configs[4]); native driver, host in/out included", **roll}
             eng2.close()
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(ps)

@@ -123,6 +123,31 @@ int mgn_forward(mgn_handle* h, const float* nf, const float* ef, float* out);
 int mgn_ode_step(mgn_handle* h, const float* x, const float* node_type_onehot, const float* ef_raw,
                  const float* val_mask, float* dxdt);
 
+/* ---- native rollout driver: the whole `rollout` of reference src/solve.jl:42-68 on the device:
+ * ODEProblem(ode_func_eval, x0, (t0, t1), ...) solved with fixed-step Euler (`adaptive = false, dt = dt`) or an
+ * adaptive Tsit5 (own tableau + PI step controller, tstops = saveat = t0 + i*saves_dt), the right-hand side being
+ * ode_func_eval (inflow overwrite from `inflow_data[floor(t / saves_dt)]`, src/solve.jl:151-152, applied IN PLACE to
+ * the array the RHS is evaluated on, like the reference) -> ode_step (mgn_ode_step semantics).  No host round trip
+ * per RHS; one small D2H (error norm) per adaptive step.  Normalisers must be set with mgn_set_norms. */
+typedef struct mgn_rollout_desc {
+    int32_t solver;          /* 0 = Euler fixed step, 1 = Tsit5 adaptive                                     */
+    float t0, t1;            /* integration interval                                                         */
+    float dt;                /* Euler: step; Tsit5: initial step (0 = automatic)                             */
+    float saves_dt;          /* spacing of the save points AND of the inflow_data frames                     */
+    int32_t n_saves;         /* solution is stored at t0 + i*saves_dt, i = 0..n_saves-1                      */
+    float abstol, reltol;    /* Tsit5 only (OrdinaryDiffEq defaults: 1e-6, 1e-3)                             */
+    const float* x0;               /* [N][O]                                                                 */
+    const float* node_type_onehot; /* [N][Fn-O]                                                              */
+    const float* ef_raw;           /* [E][Fe]                                                                */
+    const float* val_mask;         /* [N] or NULL                                                            */
+    const uint8_t* inflow_mask;    /* [N] 0/1 or NULL: rows overwritten from inflow_data                      */
+    const float* inflow_data;      /* [n_frames][N][O] or NULL                                               */
+    int32_t n_frames;
+    float* out;                    /* [n_saves][N][O]                                                        */
+    int32_t n_accept, n_reject, n_rhs; /* filled on return                                                   */
+} mgn_rollout_desc;
+int mgn_rollout(mgn_handle* h, mgn_rollout_desc* d);
+
 /* ---- the benchmarked unit: nsteps processor steps on given latents -------------
  * v [N][L], e [E][L] in caller order, updated in place (host buffers).                          */
 int mgn_processor_steps(mgn_handle* h, float* v, float* e, int32_t nsteps);

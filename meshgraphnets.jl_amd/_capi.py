@@ -21,6 +21,15 @@ class MgnConfig(C.Structure):
                 ("Fn", "Fe", "O", "L", "hidden_layers", "mps", "dtype", "rank", "nranks", "device")]
 
 
+class MgnRolloutDesc(C.Structure):
+    _fields_ = [("solver", C.c_int32), ("t0", C.c_float), ("t1", C.c_float), ("dt", C.c_float), ("saves_dt", C.c_float),
+                ("n_saves", C.c_int32), ("abstol", C.c_float), ("reltol", C.c_float),
+                ("x0", C.POINTER(C.c_float)), ("node_type_onehot", C.POINTER(C.c_float)), ("ef_raw", C.POINTER(C.c_float)),
+                ("val_mask", C.POINTER(C.c_float)), ("inflow_mask", C.POINTER(C.c_uint8)), ("inflow_data", C.POINTER(C.c_float)),
+                ("n_frames", C.c_int32), ("out", C.POINTER(C.c_float)),
+                ("n_accept", C.c_int32), ("n_reject", C.c_int32), ("n_rhs", C.c_int32)]
+
+
 _f32p = C.POINTER(C.c_float)
 _i32p = C.POINTER(C.c_int32)
 _i64p = C.POINTER(C.c_int64)
@@ -50,6 +59,7 @@ PROTOTYPES = {
     "mgn_boundary_count": (C.c_int, [_H, _i32p]),
     "mgn_forward": (C.c_int, [_H, _f32p, _f32p, _f32p]),
     "mgn_ode_step": (C.c_int, [_H, _f32p, _f32p, _f32p, _f32p, _f32p]),
+    "mgn_rollout": (C.c_int, [_H, C.POINTER(MgnRolloutDesc)]),
     "mgn_processor_steps": (C.c_int, [_H, _f32p, _f32p, C.c_int32]),
     "mgn_latents_import": (C.c_int, [_H, _f32p, _f32p]),
     "mgn_latents_export": (C.c_int, [_H, _f32p, _f32p]),

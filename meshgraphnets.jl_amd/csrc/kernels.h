@@ -87,6 +87,17 @@ struct DecArgs {
 
 struct LaunchCfg { int blocks; int threads; size_t lds; };
 
+struct LinComb {            // sum_j c[j] * k[j]
+    int n;
+    float c[7];
+    const float* k[7];
+};
+hipError_t launch_lincomb(float* out, const float* u, const LinComb& lc, float dt, int64_t n, hipStream_t s);
+hipError_t launch_overwrite(float* x, const float* frame, const uint8_t* mask, int64_t N, int O, hipStream_t s);
+int errnorm_partials();
+hipError_t launch_errnorm(const float* u, const float* unew, const LinComb& lc, float dt, float atol, float rtol, int64_t n,
+                          double* partial, hipStream_t s);
+
 // L in {32,64,128}.  All return hipError_t of the launch.
 int set_kernel_path(int p);   // debug/tests: 0 auto, 1 resident, 2 streaming, 3 cooperative; returns the old value
 hipError_t launch_edge_step(int L, const EdgeArgs& a, hipStream_t s);

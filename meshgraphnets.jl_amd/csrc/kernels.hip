@@ -1047,6 +1047,63 @@ __global__ void k_checksum(const float* __restrict__ src, int64_t n, double* __r
     }
 }
 
+// ---- ODE-driver helpers (native rollout) ------------------------------------------------
+// out = u + dt * sum_j c[j] * k[j]   (n elements; up to 7 stages)
+__global__ void k_lincomb(float* __restrict__ out, const float* __restrict__ u, LinComb lc, float dt, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < 7; ++j)
+        if (j < lc.n) s = fmaf(lc.c[j], lc.k[j][i], s);
+    out[i] = fmaf(dt, s, u[i]);
+}
+
+// x[n][:] = frame[n][:] where mask[n]   (ode_func_eval's in-place inflow overwrite, reference src/solve.jl:151-152)
+__global__ void k_overwrite(float* __restrict__ x, const float* __restrict__ frame, const uint8_t* __restrict__ mask, int64_t N, int O) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N * O) return;
+    if (mask[i / O]) x[i] = frame[i];
+}
+
+// partial sums of ((dt * sum_j c[j] k[j]) / (atol + rtol * max(|u|, |unew|)))^2 : deterministic per-block partials
+__global__ void k_errnorm(const float* __restrict__ u, const float* __restrict__ unew, LinComb lc, float dt, float atol,
+                          float rtol, int64_t n, double* __restrict__ partial) {
+    __shared__ double sh[4];
+    double acc = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < 7; ++j)
+            if (j < lc.n) s = fmaf(lc.c[j], lc.k[j][i], s);
+        const float sc = atol + rtol * fmaxf(fabsf(u[i]), fabsf(unew[i]));
+        const double r = (double)(dt * s) / (double)sc;
+        acc += r * r;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
+}
+
+hipError_t launch_lincomb(float* out, const float* u, const LinComb& lc, float dt, int64_t n, hipStream_t s) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_lincomb, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, out, u, lc, dt, n);
+    return hipGetLastError();
+}
+hipError_t launch_overwrite(float* x, const float* frame, const uint8_t* mask, int64_t N, int O, hipStream_t s) {
+    if (N <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_overwrite, dim3((unsigned)((N * O + 255) / 256)), dim3(256), 0, s, x, frame, mask, N, O);
+    return hipGetLastError();
+}
+int errnorm_partials() { return 64; }
+hipError_t launch_errnorm(const float* u, const float* unew, const LinComb& lc, float dt, float atol, float rtol, int64_t n,
+                          double* partial, hipStream_t s) {
+    hipLaunchKernelGGL(k_errnorm, dim3(64), dim3(256), 0, s, u, unew, lc, dt, atol, rtol, n, partial);
+    return hipGetLastError();
+}
+
 // ================================================================================================
 // launch wrappers
 // ================================================================================================
@@ -1120,6 +1177,11 @@ static hipError_t launch_k(K kern, const A& a, const LaunchCfg& lc, hipStream_t 
         if ((NTILES) <= 0) return hipSuccess;                                                  \
         const int nres = resident_chunks(L, WANT);                                             \
         const LaunchCfg lc = tile_launch(L, NTILES, nres);                                     \
+        if (L == 128 && small_launch(NTILES)) {                                                \
+            LaunchCfg l0 = lc;                                                                 \
+            l0.lds = (size_t)T_COUNT * L * 4 + 64;                                             \
+            return launch_k(KERN<4, 0>, ARGS, l0, s);                                          \
+        }                                                                                      \
         if (L == 128) return launch_k(KERN<4, (WANT < 2 ? WANT : 2)>, ARGS, lc, s);            \
         if (L == 64) return launch_k(KERN<2, WANT>, ARGS, lc, s);                              \
         if (L == 32) return launch_k(KERN<1, WANT>, ARGS, lc, s);                              \

@@ -3,6 +3,7 @@
 // CPU compute path here.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -91,6 +92,9 @@ struct mgn_engine {
 
     // latents and I/O
     DevBuf d_stamps;  // diagnostic builds only
+    DevBuf ode;       // native rollout: state, stages, frames, saves, Elat0
+    const float* srcA_override = nullptr;  // rollout: encoder reads the node state from here instead of d_nfA
+    float* out_override = nullptr;         // rollout: decoder writes dx/dt here instead of d_out
     DevBuf V, P, Q, Elat, AGG, CARRY, d_nfA, d_nfB, d_ef, d_out, d_mask, d_sum;
     int32_t in_wa = 0, in_wb = 0;
     bool have_mask = false;
@@ -633,17 +637,17 @@ int mgn_fwd_upload(mgn_handle* h, const float* nf, const float* ef) {
     return upload_inputs(h, nf, h->cfg.Fn, nullptr, 0, ef);
 }
 
-static int encode_impl(mgn_handle* h, bool use_norms) {
+static int encode_impl(mgn_handle* h, bool use_norms, bool nodes = true, bool edges = true) {
     const mgn_config& c = h->cfg;
     const LocalGraph& g = h->g;
     const float* nrm = h->norms.as<float>();
-    {
-        ProfScope ps(h, F_ENC);
+    ProfScope ps(h, F_ENC);
+    if (nodes) {
         EncNodeArgs a{};
         a.n = g.n_own;
         a.ntiles = h->ntiles_n;
         a.gid = h->d_own_gid.as<int32_t>();
-        a.srcA = h->d_nfA.as<float>();
+        a.srcA = h->srcA_override ? h->srcA_override : h->d_nfA.as<float>();
         a.wa = h->in_wa;
         a.srcB = h->d_nfB.as<float>();
         a.wb = h->in_wb;
@@ -655,6 +659,8 @@ static int encode_impl(mgn_handle* h, bool use_norms) {
         for (int i = 0; i < 4; ++i) a.chunk[i] = W(h, h->en_ch[i]);
         a.tabs = W(h, h->en_tabs);
         HIPCHK(h, launch_enc_node(c.L, a, h->stream));
+    }
+    if (edges) {
         EncEdgeArgs b{};
         b.E = g.e_local;
         b.ntiles = h->ntiles_e;
@@ -746,7 +752,7 @@ static int decode_impl(mgn_handle* h, bool use_norms) {
     }
     a.mask = (use_norms && h->have_mask) ? h->d_mask.as<float>() : nullptr;
     a.gid = h->d_own_gid.as<int32_t>();
-    a.out = h->d_out.as<float>();
+    a.out = h->out_override ? h->out_override : h->d_out.as<float>();
     for (int i = 0; i < 2; ++i) a.chunk[i] = W(h, h->de_ch[i]);
     a.tabs = W(h, h->de_tabs);
     HIPCHK(h, launch_decode(c.L, a, h->stream));
@@ -805,6 +811,214 @@ int mgn_ode_step(mgn_handle* h, const float* x, const float* onehot, const float
     if (int rc = run_processor(h, c.mps)) return rc;
     if (int rc = decode_impl(h, true)) return rc;
     return mgn_fwd_download(h, dxdt);
+}
+
+// ---- native rollout driver (N1) -----------------------------------------------------------------------------
+namespace {
+
+// Tsitouras 5(4) tableau (the method OrdinaryDiffEq.jl calls Tsit5)
+const double TS_C[7] = {0.0, 0.161, 0.327, 0.9, 0.9800255409045097, 1.0, 1.0};
+const double TS_A[7][6] = {
+    {0, 0, 0, 0, 0, 0},
+    {0.161, 0, 0, 0, 0, 0},
+    {-0.008480655492356989, 0.335480655492357, 0, 0, 0, 0},
+    {2.8971530571054935, -6.359448489975075, 4.3622954328695815, 0, 0, 0},
+    {5.325864828439257, -11.748883564062828, 7.4955393428898365, -0.09249506636175525, 0, 0},
+    {5.86145544294642, -12.92096931784711, 8.159367898576159, -0.071584973281401, -0.028269050394068383, 0},
+    {0.09646076681806523, 0.01, 0.4798896504144996, 1.379008574103742, -3.290069515436081, 2.324710524099774}};
+const double TS_BT[7] = {-0.00178001105222577714, -0.0008164344596567469, 0.007880878010261995, -0.1447110071732629,
+                         0.5823571654525552, -0.45808210592918697, 0.015151515151515152};
+
+struct Rollout {
+    mgn_engine* h;
+    mgn_rollout_desc* d;
+    int64_t n;                 // N * O
+    float *u, *unew, *utmp, *k[7], *frames, *saves;
+    uint8_t* mask;
+    double* partial;
+    int n_rhs = 0;
+
+    // f(x, t): in-place inflow overwrite of x, then dx/dt -> kout    (ode_func_eval, reference src/solve.jl:147-158)
+    int rhs(float* x, double t, float* kout) {
+        const mgn_config& c = h->cfg;
+        if (mask && frames) {
+            int64_t fr = (int64_t)std::floor(t / d->saves_dt + 1e-6);
+            if (fr < 0) fr = 0;
+            if (fr >= d->n_frames) fr = d->n_frames - 1;
+            HIPCHK(h, launch_overwrite(x, frames + (size_t)fr * n, mask, h->g.N, c.O, h->stream));
+        }
+        h->srcA_override = x;
+        h->out_override = kout;
+        int rc = encode_impl(h, true, true, false);
+        if (!rc) {
+            // encoded edge latents are identical for every RHS of a trajectory (static edge features, frozen e_norm)
+            const size_t eb = tile_floats(h->ntiles_e, c.L) * 4;
+            hipError_t e = hipMemcpyAsync(h->Elat.p, h->ode.as<char>() + elat0_off, eb, hipMemcpyDeviceToDevice, h->stream);
+            if (e != hipSuccess) rc = fail(h, MGN_E_HIP, "rollout: Elat restore failed: %s", hipGetErrorString(e));
+        }
+        if (!rc) rc = run_processor(h, c.mps);
+        if (!rc) rc = decode_impl(h, true);
+        h->srcA_override = nullptr;
+        h->out_override = nullptr;
+        ++n_rhs;
+        return rc;
+    }
+    size_t elat0_off = 0;
+
+    int norm(const float* a, const float* b, const LinComb& lc, float dt, double* out) {
+        const int np_ = errnorm_partials();
+        HIPCHK(h, launch_errnorm(a, b, lc, dt, d->abstol, d->reltol, n, partial, h->stream));
+        std::vector<double> r(np_);
+        HIPCHK(h, hipMemcpyAsync(r.data(), partial, np_ * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        double s = 0;
+        for (double v : r) s += v;
+        *out = std::sqrt(s / (double)(n > 0 ? n : 1));
+        return MGN_OK;
+    }
+};
+
+}  // namespace
+
+int mgn_rollout(mgn_handle* h, mgn_rollout_desc* d) {
+    if (int rc = need(h, true, true)) return rc;
+    const mgn_config& c = h->cfg;
+    if (c.nranks != 1) return fail(h, MGN_E_STATE, "mgn_rollout drives one partition");
+    if (!d || !d->x0 || !d->out || !d->ef_raw || (c.Fn > c.O && !d->node_type_onehot)) return fail(h, MGN_E_ARG, "mgn_rollout: null argument");
+    if (c.Fn < c.O) return fail(h, MGN_E_ARG, "mgn_rollout: Fn < O");
+    if (d->n_saves < 1 || d->saves_dt <= 0.f || d->t1 < d->t0) return fail(h, MGN_E_ARG, "mgn_rollout: bad time grid");
+    if (d->solver == 0 && d->dt <= 0.f) return fail(h, MGN_E_ARG, "mgn_rollout: Euler needs dt > 0");
+    if (d->solver != 0 && d->solver != 1) return fail(h, MGN_E_ARG, "mgn_rollout: solver must be 0 (Euler) or 1 (Tsit5)");
+    if ((d->inflow_mask != nullptr) != (d->inflow_data != nullptr)) return fail(h, MGN_E_ARG, "mgn_rollout: inflow mask and data go together");
+    if (d->solver == 1 && (d->abstol <= 0.f || d->reltol <= 0.f)) return fail(h, MGN_E_ARG, "mgn_rollout: tolerances must be > 0");
+    const LocalGraph& g = h->g;
+    Rollout R;
+    R.h = h;
+    R.d = d;
+    R.n = (int64_t)g.N * c.O;
+    const size_t nb = (size_t)R.n * 4;
+    const size_t fb = d->inflow_data ? (size_t)d->n_frames * nb : 0, sb = (size_t)d->n_saves * nb;
+    const size_t eb = tile_floats(h->ntiles_e, c.L) * 4;
+    auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    size_t off = 0;
+    auto take = [&](size_t bytes) { const size_t o = off; off += al(bytes); return o; };
+    const size_t o_u = take(nb), o_un = take(nb), o_ut = take(nb);
+    size_t o_k[7];
+    for (auto& o : o_k) o = take(nb);
+    const size_t o_fr = take(fb), o_sv = take(sb), o_mask = take((size_t)g.N), o_part = take(errnorm_partials() * sizeof(double));
+    R.elat0_off = take(eb);
+    HIPCHK(h, h->ode.ensure(off));
+    char* base = h->ode.as<char>();
+    R.u = (float*)(base + o_u); R.unew = (float*)(base + o_un); R.utmp = (float*)(base + o_ut);
+    for (int j = 0; j < 7; ++j) R.k[j] = (float*)(base + o_k[j]);
+    R.frames = d->inflow_data ? (float*)(base + o_fr) : nullptr;
+    R.saves = (float*)(base + o_sv);
+    R.mask = d->inflow_mask ? (uint8_t*)(base + o_mask) : nullptr;
+    R.partial = (double*)(base + o_part);
+
+    HIPCHK(h, hipMemcpyAsync(R.u, d->x0, nb, hipMemcpyHostToDevice, h->stream));
+    if (R.frames) HIPCHK(h, hipMemcpyAsync(R.frames, d->inflow_data, fb, hipMemcpyHostToDevice, h->stream));
+    if (R.mask) HIPCHK(h, hipMemcpyAsync(R.mask, d->inflow_mask, (size_t)g.N, hipMemcpyHostToDevice, h->stream));
+    // static inputs: one-hot node types, raw edge features, val_mask; the edge encoder runs ONCE per trajectory
+    if (int rc = upload_inputs(h, d->x0, c.O, d->node_type_onehot, c.Fn - c.O, d->ef_raw)) return rc;
+    h->have_mask = d->val_mask != nullptr;
+    if (d->val_mask) {
+        HIPCHK(h, h->d_mask.ensure((size_t)g.N * 4));
+        HIPCHK(h, hipMemcpyAsync(h->d_mask.p, d->val_mask, (size_t)g.N * 4, hipMemcpyHostToDevice, h->stream));
+    }
+    if (int rc = encode_impl(h, true, false, true)) return rc;
+    HIPCHK(h, hipMemcpyAsync(base + R.elat0_off, h->Elat.p, eb, hipMemcpyDeviceToDevice, h->stream));
+
+    d->n_accept = d->n_reject = 0;
+    int saved = 0;
+    auto save = [&]() -> hipError_t {
+        if (saved >= d->n_saves) return hipSuccess;
+        return hipMemcpyAsync(R.saves + (size_t)saved++ * R.n, R.u, nb, hipMemcpyDeviceToDevice, h->stream);
+    };
+    auto stop_time = [&](int i) { return (double)d->t0 + (double)i * (double)d->saves_dt; };
+    double t = d->t0;
+    HIPCHK(h, save());   // solution at t0
+
+    if (d->solver == 0) {
+        const double dt = d->dt;
+        const int64_t nsteps = (int64_t)std::llround(((double)d->t1 - (double)d->t0) / dt);
+        for (int64_t i = 0; i < nsteps; ++i) {
+            if (int rc = R.rhs(R.u, t, R.k[0])) return rc;
+            LinComb lc{1, {1.f}, {R.k[0]}};
+            HIPCHK(h, launch_lincomb(R.u, R.u, lc, (float)dt, R.n, h->stream));
+            t = (double)d->t0 + (double)(i + 1) * dt;
+            ++d->n_accept;
+            while (saved < d->n_saves && stop_time(saved) <= t + 1e-9 * std::fabs(t) + 1e-12) HIPCHK(h, save());
+        }
+    } else {
+        // adaptive Tsit5, PI controller (beta1 = 7/50, beta2 = 2/25, gamma = 0.9, qmin = 0.2, qmax = 10), tstops = saves
+        const double beta1 = 7.0 / 50, beta2 = 2.0 / 25, gamma = 0.9, qmin = 0.2, qmax = 10.0;
+        double qold = 1e-4;
+        if (int rc = R.rhs(R.u, t, R.k[0])) return rc;     // k1 (FSAL afterwards)
+        double dt = d->dt;
+        if (dt <= 0) {   // Hairer-Wanner starting step
+            LinComb z{0, {}, {}};
+            double d0, d1, d2;
+            LinComb l1{1, {1.f}, {R.k[0]}};
+            // d0 = ||u||, d1 = ||f0|| in the scaled norm: errnorm(dt = 1) of u and k1 themselves
+            LinComb lu{1, {1.f}, {R.u}};
+            if (int rc = R.norm(R.u, R.u, lu, 1.f, &d0)) return rc;
+            if (int rc = R.norm(R.u, R.u, l1, 1.f, &d1)) return rc;
+            const double h0 = (d0 < 1e-5 || d1 < 1e-5) ? 1e-6 : 0.01 * d0 / d1;
+            HIPCHK(h, launch_lincomb(R.utmp, R.u, l1, (float)h0, R.n, h->stream));
+            if (int rc = R.rhs(R.utmp, t + h0, R.k[1])) return rc;
+            LinComb ld{2, {1.f, -1.f}, {R.k[1], R.k[0]}};
+            if (int rc = R.norm(R.u, R.u, ld, (float)(1.0 / h0), &d2)) return rc;
+            const double mx = d1 > d2 ? d1 : d2;
+            const double h1 = mx <= 1e-15 ? (h0 * 1e-3 > 1e-6 ? h0 * 1e-3 : 1e-6) : std::pow(0.01 / mx, 1.0 / 5);
+            dt = 100 * h0 < h1 ? 100 * h0 : h1;
+            (void)z;
+        }
+        const double tend = d->t1;
+        int guard = 0;
+        // float32 descriptors: t1 and n*saves_dt may differ in the last ulp; an interval shorter than 1e-5 save
+        // periods is not worth a step
+        while (t < tend - 1e-5 * (double)d->saves_dt && ++guard < 10000000) {
+            double tstop = saved < d->n_saves ? stop_time(saved) : tend;
+            if (tstop > tend) tstop = tend;
+            bool hit_stop = false;
+            double hstep = dt;
+            if (t + hstep >= tstop - 1e-9 * std::fabs(tstop)) { hstep = tstop - t; hit_stop = true; }
+            for (int sidx = 1; sidx < 7; ++sidx) {     // stages 2..7; stage 7 is evaluated on unew (FSAL)
+                LinComb lc{sidx, {}, {}};
+                for (int j = 0; j < sidx; ++j) { lc.c[j] = (float)TS_A[sidx][j]; lc.k[j] = R.k[j]; }
+                float* dst = (sidx == 6) ? R.unew : R.utmp;
+                HIPCHK(h, launch_lincomb(dst, R.u, lc, (float)hstep, R.n, h->stream));
+                if (int rc = R.rhs(dst, t + TS_C[sidx] * hstep, R.k[sidx])) return rc;
+            }
+            LinComb le{7, {}, {}};
+            for (int j = 0; j < 7; ++j) { le.c[j] = (float)TS_BT[j]; le.k[j] = R.k[j]; }
+            double EEst;
+            if (int rc = R.norm(R.u, R.unew, le, (float)hstep, &EEst)) return rc;
+            if (!(EEst == EEst)) return fail(h, MGN_E_STATE, "mgn_rollout: NaN in the error estimate at t = %g", t);
+            const double q11 = std::pow(EEst > 1e-30 ? EEst : 1e-30, beta1);
+            if (EEst <= 1.0) {
+                double q = q11 / std::pow(qold, beta2);
+                q = std::max(1.0 / qmax, std::min(1.0 / qmin, q / gamma));
+                qold = std::max(EEst, 1e-4);
+                std::swap(R.u, R.unew);
+                std::swap(R.k[0], R.k[6]);            // FSAL: k1 of the next step = f(unew)
+                t = hit_stop ? tstop : t + hstep;
+                ++d->n_accept;
+                if (!hit_stop || hstep >= dt * (1 - 1e-9)) dt = hstep / q;   // a step cut by a stop does not shrink dt
+                else dt = std::max(dt, hstep / q);
+                if (hit_stop && saved < d->n_saves && std::fabs(stop_time(saved) - t) <= 1e-9 * std::fabs(t) + 1e-12) HIPCHK(h, save());
+            } else {
+                ++d->n_reject;
+                dt = hstep / std::min(1.0 / qmin, q11 / gamma);
+            }
+        }
+    }
+    while (saved < d->n_saves) HIPCHK(h, save());      // (t1 short of the last stop: repeat the final state)
+    HIPCHK(h, hipMemcpyAsync(d->out, R.saves, sb, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    d->n_rhs = R.n_rhs;
+    return MGN_OK;
 }
 
 // ---- latents -------------------------------------------------------------------------------------

@@ -181,6 +181,31 @@ class Engine:
         self._chk(self.lib.mgn_ode_step(self.h, f32(x), f32(oh), f32(ef), f32(vm), f32(out)))
         return out
 
+    def rollout(self, solver, x0, node_type_onehot, ef_raw, t0, t1, saves_dt, n_saves, dt=0.0, val_mask=None,
+                inflow_mask=None, inflow_data=None, abstol=1e-6, reltol=1e-3):
+        """Native device-side `rollout` (reference src/solve.jl:42-68).  solver: "Euler" (fixed dt) or "Tsit5".
+        Returns (sol_u [n_saves][N][O], stats dict)."""
+        O, Fn = self.cfg.O, self.cfg.Fn
+        d = _capi.MgnRolloutDesc()
+        d.solver = {"Euler": 0, "Tsit5": 1}[solver]
+        d.t0, d.t1, d.dt, d.saves_dt, d.n_saves, d.abstol, d.reltol = t0, t1, dt, saves_dt, n_saves, abstol, reltol
+        x0 = _c32(x0, (self.N, O))
+        oh = _c32(node_type_onehot, (self.N, Fn - O)) if Fn > O else None
+        ef = _c32(ef_raw, (self.E, self.cfg.Fe))
+        vm = _c32(val_mask, (self.N,)) if val_mask is not None else None
+        im = np.ascontiguousarray(inflow_mask, dtype=np.uint8).reshape(self.N) if inflow_mask is not None else None
+        idata = _c32(inflow_data) if inflow_data is not None else None
+        if idata is not None and idata.shape[1:] != (self.N, O):
+            raise ValueError("DimensionMismatch: inflow_data must be [frames][N][O]")
+        out = np.zeros((n_saves, self.N, O), np.float32)
+        d.x0, d.node_type_onehot, d.ef_raw, d.val_mask = f32(x0), f32(oh), f32(ef), f32(vm)
+        d.inflow_mask = im.ctypes.data_as(C.POINTER(C.c_uint8)) if im is not None else None
+        d.inflow_data = f32(idata)
+        d.n_frames = idata.shape[0] if idata is not None else 0
+        d.out = f32(out)
+        self._chk(self.lib.mgn_rollout(self.h, C.byref(d)))
+        return out, dict(n_accept=d.n_accept, n_reject=d.n_reject, n_rhs=d.n_rhs)
+
     def processor_steps(self, v, e, nsteps):
         v = _c32(v, (self.N, self.cfg.L)).copy()
         e = _c32(e, (self.E, self.cfg.L)).copy()

@@ -302,3 +302,77 @@ def mse_reduce(target, out):
 def step_loss(packed, cfg, nf, ef, senders, receivers, target, mask_idx):
     out = forward(packed, cfg, nf, ef, senders, receivers)
     return mse_reduce(target, out)[mask_idx].mean()
+
+
+# --------------------------------------------------------------------------------------------
+# Tsit5 with PI step control and tstops = saveat (the adaptive branch of rollout, src/solve.jl:58-59).
+# DifferentialEquations.jl itself cannot be run here: this restates the published Tsitouras 5(4) pair and the
+# standard PI controller (beta1 = 7/50, beta2 = 2/25, gamma = 0.9, qmin = 0.2, qmax = 10) used as its default.
+# --------------------------------------------------------------------------------------------
+TS_C = np.array([0.0, 0.161, 0.327, 0.9, 0.9800255409045097, 1.0, 1.0])
+TS_A = np.zeros((7, 6))
+TS_A[1, :1] = [0.161]
+TS_A[2, :2] = [-0.008480655492356989, 0.335480655492357]
+TS_A[3, :3] = [2.8971530571054935, -6.359448489975075, 4.3622954328695815]
+TS_A[4, :4] = [5.325864828439257, -11.748883564062828, 7.4955393428898365, -0.09249506636175525]
+TS_A[5, :5] = [5.86145544294642, -12.92096931784711, 8.159367898576159, -0.071584973281401, -0.028269050394068383]
+TS_A[6, :6] = [0.09646076681806523, 0.01, 0.4798896504144996, 1.379008574103742, -3.290069515436081, 2.324710524099774]
+TS_BT = np.array([-0.00178001105222577714, -0.0008164344596567469, 0.007880878010261995, -0.1447110071732629,
+                  0.5823571654525552, -0.45808210592918697, 0.015151515151515152])
+
+
+def tsit5_rollout(f, x0, t0, t1, saves, abstol=1e-6, reltol=1e-3, dt0=0.0):
+    """f(x, t) may modify x in place (the inflow overwrite).  Returns (solution at `saves`, stats)."""
+    beta1, beta2, gamma, qmin, qmax = 7 / 50, 2 / 25, 0.9, 0.2, 10.0
+
+    def nrm(v, a, b):
+        return float(np.sqrt(np.mean((v / (abstol + reltol * np.maximum(np.abs(a), np.abs(b)))) ** 2)))
+
+    u = np.array(x0, np.float64)
+    t, qold = float(t0), 1e-4
+    out, si, nacc, nrej = [], 0, 0, 0
+    if abs(saves[0] - t0) < 1e-12:      # the initial value is saved BEFORE the first f call can overwrite inflow rows
+        out.append(u.copy())            # (OrdinaryDiffEq saves u0 in init, then initialises fsalfirst = f(u0))
+        si = 1
+    k = [None] * 7
+    k[0] = f(u, t)
+    nrhs = 1
+    dt = dt0
+    if dt <= 0:
+        d0, d1 = nrm(u, u, u), nrm(k[0], u, u)
+        h0 = 1e-6 if (d0 < 1e-5 or d1 < 1e-5) else 0.01 * d0 / d1
+        ut = u + h0 * k[0]
+        f1 = f(ut, t + h0)
+        nrhs += 1
+        d2 = nrm((f1 - k[0]) / h0, u, u)
+        mx = max(d1, d2)
+        h1 = max(1e-6, h0 * 1e-3) if mx <= 1e-15 else (0.01 / mx) ** 0.2
+        dt = min(100 * h0, h1)
+    while t < t1 - 1e-12 * abs(t1) - 1e-15:
+        tstop = min(saves[si] if si < len(saves) else t1, t1)
+        h, hit = dt, False
+        if t + h >= tstop - 1e-9 * abs(tstop):
+            h, hit = tstop - t, True
+        for s_ in range(1, 7):
+            us = u + h * sum(TS_A[s_, j] * k[j] for j in range(s_))
+            k[s_] = f(us, t + TS_C[s_] * h)
+            nrhs += 1
+        unew = us
+        est = nrm(h * sum(TS_BT[j] * k[j] for j in range(7)), u, unew)
+        q11 = max(est, 1e-30) ** beta1
+        if est <= 1.0:
+            q = max(1 / qmax, min(1 / qmin, q11 / qold ** beta2 / gamma))
+            qold = max(est, 1e-4)
+            u, k[0] = unew, k[6]
+            t = tstop if hit else t + h
+            nacc += 1
+            dt = h / q if (not hit or h >= dt * (1 - 1e-9)) else max(dt, h / q)
+            if hit and si < len(saves) and abs(saves[si] - t) <= 1e-9 * abs(t) + 1e-12:
+                out.append(u.copy())
+                si += 1
+        else:
+            nrej += 1
+            dt = h / min(1 / qmin, q11 / gamma)
+    while len(out) < len(saves):
+        out.append(u.copy())
+    return np.stack(out), dict(n_accept=nacc, n_reject=nrej, n_rhs=nrhs)

@@ -259,3 +259,51 @@ def test_bench_staged_path_with_rccl_world1():
     assert lines, out.stdout[-2000:] + out.stderr[-2000:]
     d = json.loads(lines[-1])
     assert d["n_gpus"] == 1 and d["value"] > 0 and d["latents_finite"]
+
+
+def _gold_d_problem():
+    g = load("gold_d_rollout.npz")
+    ps = params_for(g)
+    cfg = cfg_dict(L=int(g["L"]), mps=int(g["mps"]))
+    eng = engine_for(cfg)
+    eng.set_params(ps)
+    eng.set_graph(g["senders"], g["receivers"], g["x0"].shape[0])
+    eng.set_norms(node=(g["node_scale"], g["node_shift"]), edge=(g["edge_scale"], g["edge_shift"]),
+                  out=(g["out_scale"], g["out_shift"]))
+    onehot = orc.one_hot(g["node_type"], 7, 0).astype(np.float32)
+    return g, ps, cfg, eng, onehot
+
+
+def test_native_rollout_euler_matches_gold_d():
+    """N1: the device-side driver (mgn_rollout, Euler) against GOLD-D (float64 oracle through ode_func_eval)."""
+    g, ps, cfg, eng, onehot = _gold_d_problem()
+    dt = float(g["dt"])
+    sol, st = eng.rollout("Euler", g["x0"], onehot, g["ef_raw"], 0.0, 10 * dt, dt, 11, dt=dt, val_mask=g["val_mask"],
+                          inflow_mask=g["inflow_mask"][:, 0], inflow_data=g["gt"])
+    assert st["n_rhs"] == 10 and sol.shape == g["xs"].shape
+    assert np.linalg.norm(sol - g["xs"]) / np.linalg.norm(g["xs"]) <= TOL_ROLLOUT
+    assert rel_max(sol[1], g["xs"][1]) <= TOL_15
+
+
+def test_native_rollout_tsit5_matches_oracle_tsit5():
+    """Adaptive branch: same algorithm in float64 NumPy (oracle.tsit5_rollout) on the GOLD-D problem, compared at the
+    save points (accept/reject decisions may differ by a step between fp32 and float64)."""
+    g, ps, cfg, eng, onehot = _gold_d_problem()
+    dt = float(g["dt"])
+    saves = np.arange(11) * dt
+    n_norm = orc.NormMeanStd(-g["node_shift"][:2] / g["node_scale"][:2], 1 / g["node_scale"][:2])
+    e_norm = orc.NormMeanStd(-g["edge_shift"] / g["edge_scale"], 1 / g["edge_scale"])
+    o_norm = orc.NormMeanStd(g["out_shift"], g["out_scale"])
+    inflow = g["inflow_mask"]
+
+    def f(x, t):
+        k = min(int(np.floor(t / dt + 1e-6)), g["gt"].shape[0] - 1)
+        x[inflow] = g["gt"][k][inflow]          # in place, like the reference
+        return orc.ode_rhs(ps, cfg, x, onehot.astype(np.float64), g["ef_raw"].astype(np.float64), g["senders"], g["receivers"],
+                           n_norm, orc.NormMinMax(0.0, 1.0), e_norm, o_norm, g["val_mask"][:, None])
+
+    ref, rst = orc.tsit5_rollout(f, g["x0"], 0.0, 10 * dt, saves, abstol=1e-6, reltol=1e-3)
+    sol, st = eng.rollout("Tsit5", g["x0"], onehot, g["ef_raw"], 0.0, 10 * dt, dt, 11, val_mask=g["val_mask"],
+                          inflow_mask=inflow[:, 0], inflow_data=g["gt"], abstol=1e-6, reltol=1e-3)
+    assert st["n_accept"] >= 10 and abs(st["n_accept"] - rst["n_accept"]) <= 2
+    assert np.linalg.norm(sol - ref) / np.linalg.norm(ref) <= TOL_ROLLOUT

@@ -141,3 +141,20 @@ def test_online_normaliser_accumulates_then_freezes():
     assert np.allclose(n.inverse(n(x, accumulate=False)), x, atol=1e-4)
     with pytest.raises(ValueError):
         n(x[:, :2])
+
+
+def test_tsit5_tableau_and_convergence():
+    """KAT for the adaptive branch of rollout: Tsitouras 5(4) order conditions and convergence on y' = -y + sin t."""
+    A, c, bt = orc.TS_A, orc.TS_C, orc.TS_BT
+    b = np.append(A[6], 0.0)
+    assert np.allclose(A.sum(1), c, atol=1e-15) and abs(bt.sum()) < 1e-15
+    for p, want in [(0, 1.0), (1, 1 / 2), (2, 1 / 3), (3, 1 / 4), (4, 1 / 5)]:
+        assert abs(b @ c ** p - want) < 1e-14
+    f = lambda x, t: -x + np.sin(t)
+    exact = 1.5 * np.exp(-2.0) + 0.5 * (np.sin(2.0) - np.cos(2.0))
+    errs = []
+    for tol in (1e-4, 1e-6, 1e-8):
+        sol, st = orc.tsit5_rollout(f, np.array([1.0]), 0.0, 2.0, np.linspace(0, 2, 5), abstol=tol * 1e-3, reltol=tol)
+        errs.append(abs(sol[-1, 0] - exact))
+        assert st["n_rhs"] == 2 + 6 * (st["n_accept"] + st["n_reject"])      # FSAL: 6 evaluations per step
+    assert errs[0] > errs[1] > errs[2] and errs[2] < 1e-9
