@@ -27,6 +27,7 @@
 //     no zero-fill pass, bitwise reproducible.
 #include "kernels.h"
 
+#include <cstdlib>
 #include <mutex>
 #include <unordered_map>
 
@@ -204,7 +205,10 @@ template <int NT, int JR>
 DEVINL void mfma_chunk_split(f32x16 (&acc)[NT], const f32x16 (&in)[NT], const float* w_lds, const float* w_glb, int lane) {
     typedef typename AVec<NT>::T AV;
     constexpr int J = 16 * NT;
-    constexpr int PF = (J - JR) < 4 ? (J - JR) : 4;
+#ifndef MGN_PF
+#define MGN_PF 4
+#endif
+    constexpr int PF = (J - JR) < MGN_PF ? (J - JR) : MGN_PF;
     const AV* wl = reinterpret_cast<const AV*>(w_lds) + lane;
     const AV* wg = reinterpret_cast<const AV*>(w_glb) + lane;
     AV ring[PF > 0 ? PF : 1];
@@ -275,13 +279,29 @@ DEVINL void copy_to_lds(float* dst, const float* __restrict__ src, int nfloats) 
 struct TileWalk {
     int tile, end, stride;
     DEVINL TileWalk(int ntiles, int wave) {
-        const int xcd = blockIdx.x % NUM_XCD;
         const int wpb = blockDim.x >> 6;
+#if defined(MGN_WALK_PLAIN)      // experiment: no XCD awareness, global interleave
+        tile = blockIdx.x * wpb + wave;
+        end = ntiles;
+        stride = gridDim.x * wpb;
+#elif defined(MGN_WALK_CONTIG)   // experiment: every wave owns one contiguous run of tiles inside its XCD's range
+        const int xcd = blockIdx.x % NUM_XCD;
+        const int per = (ntiles + NUM_XCD - 1) / NUM_XCD;
+        const int nb = (gridDim.x - xcd + NUM_XCD - 1) / NUM_XCD;
+        const int nw = nb * wpb, w = (blockIdx.x / NUM_XCD) * wpb + wave;
+        const int lo = xcd * per, hi = min(lo + per, ntiles);
+        const int each = (hi - lo + nw - 1) / nw;
+        tile = lo + w * each;
+        end = min(tile + each, hi);
+        stride = 1;
+#else
+        const int xcd = blockIdx.x % NUM_XCD;
         const int per = (ntiles + NUM_XCD - 1) / NUM_XCD;
         const int nb = (gridDim.x - xcd + NUM_XCD - 1) / NUM_XCD;  // blocks on this XCD label
         tile = xcd * per + (blockIdx.x / NUM_XCD) * wpb + wave;
         end = min(xcd * per + per, ntiles);
         stride = nb * wpb;
+#endif
     }
 };
 
@@ -362,12 +382,14 @@ DEVINL EdgeIdx load_edge_idx(const EdgeArgs& a, int tile, int c) {
 
 // Register plan (L = 128: three 64-VGPR arrays, nothing else of that size may be live, the kernel must not
 // spill: vmcnt retires in order, so a scratch reload issued behind the epilogue stores waits for all of them):
-//   layer 1   acc (init P[s]+Q[r], accumulates)   x = e tile (B operand)          y  free
-//   layer 2   acc (B operand)                     x <- P[s'] of the NEXT tile      y  (accumulates)
-//   layer 3   acc (accumulates)                   x    in flight                   y  (B operand)
-//   epilogue  acc = e' (LN, scan, tail stores)    x    P[s']                       y <- e tile re-read (L2) for the
-//                                                                                       residual, then <- Q[r']
-//   turnover  acc <- x + y (= next tile's init)   x <- e tile of the next tile
+//   layer 1   acc (init P[s]+Q[r], accumulates)   x = e tile (B operand)           y  free
+//   layer 2   acc (B operand)                     x   kept for the residual         y  accumulates
+//   layer 3   acc accumulates                     x   kept                          y  (B operand)
+//   epilogue  acc = e' (LayerNorm, scan, tails)   x += e', stored                   y  free
+//   turnover  acc <- P[s'] + Q[r']                x <- e tile of the next tile
+// Rejected by same-box A/B: re-reading the e tile instead of keeping x (+2 %, +3 GB fetch per
+// launch), prefetching the next tile's P rows or e tile into the free array during the epilogue (spills, or +-0),
+// a deeper weight ring, start stagger, strict MFMA-pipe token between partner waves.
 // Steps of the third chunk kept in the LDS left over by two resident chunks at L = 128 (0 when it is fully
 // resident anyway): 160 KiB - 2 x 64 KiB - tables - token words = 29 632 B = 28 k-steps of 1 KiB.
 #ifndef MGN_EDGE_JR
@@ -444,12 +466,13 @@ __global__ __launch_bounds__(512, 2) void k_edge_step(const EdgeArgs a) {
         PHASE_FENCE();
         token.release();
         __builtin_amdgcn_s_setprio(MGN_PRIO);                   // memory/VALU phase: win issue arbitration
-        load_frag<NT>(y, etile, STRIDE_TILE);                   // e tile again (L2) for the residual
+        // the e tile stays in registers across the three chains (x): re-reading it for the residual cost 3 GB of
+        // extra fetch per launch on M-1M and 2 % of kernel time (same-box A/B)
         layer_norm_frag<NT>(acc, tb + T_GAMMA * L, tb + T_BETA * L, h);   // acc = e'
         STAMP(5);
 #pragma unroll
-        for (int t = 0; t < NT; ++t) y[t] += acc[t];            // e <- e + e'
-        if (valid) store_frag<NT>(etile, STRIDE_TILE, y);       // padding rows of the last tile stay zero
+        for (int t = 0; t < NT; ++t) x[t] += acc[t];            // e <- e + e'
+        if (valid) store_frag<NT>(etile, STRIDE_TILE, x);       // padding rows of the last tile stay zero
         STAMP(6);
 
         // ---- segmented sum of e' over runs of equal receiver (both halves see the same structure)
@@ -1133,7 +1156,7 @@ static int resident_chunks(int L, int want) {
 // 64-128 threads = 10-17 us): such launches use the all-streaming instantiations (weights stay in L2).
 // g_path: 0 auto, 1 force the LDS-resident persistent kernels, 2 force all-streaming, 3 force cooperative
 // (tests exercise every path on small graphs through mgn_debug_kernel_path)
-static int g_path = 0;
+static int g_path = [] { const char* e = getenv("MGN_KERNEL_PATH"); return e ? atoi(e) : 0; }();   // experiments
 int set_kernel_path(int p) { const int old = g_path; g_path = p; return old; }
 static bool small_launch(int ntiles) { return g_path == 0 ? ntiles <= 4 * num_cus() : g_path >= 2; }
 
