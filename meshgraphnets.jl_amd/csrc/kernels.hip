@@ -649,18 +649,21 @@ __global__ __launch_bounds__(512, 2) void k_project(const NodeArgs a) {
 // tiles, 63 node tiles) then spreads over ~1500 / 250 waves instead of 374 / 63.  Weights stream from L2 in
 // t-major fragment order (chunk_t[(t*64 + j)*64 + lane]), one coalesced 256-B load per k-step and wave.
 // ================================================================================================
-constexpr int COOP_PF = 8;
+constexpr int COOP_PF = 4;   // 16-byte fragments: 4 k-steps each
 
+// wt: this wave's t-slice of a chunk in t-major order [j/4][lane][4]
 DEVINL void coop_chain(f32x16& acc, const f32x16 (&in)[4], const float* wt, int lane) {
-    const float* wv = wt + lane;
-    float ring[COOP_PF];
+    const f32x4* wv = reinterpret_cast<const f32x4*>(wt) + lane;
+    f32x4 ring[COOP_PF];
 #pragma unroll
     for (int p = 0; p < COOP_PF; ++p) ring[p] = wv[p * 64];
 #pragma unroll
-    for (int j = 0; j < 64; ++j) {
-        const float a = ring[j % COOP_PF];
-        if (j + COOP_PF < 64) ring[j % COOP_PF] = wv[(j + COOP_PF) * 64];
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, in[j >> 4][j & 15], acc, 0, 0, 0);
+    for (int m = 0; m < 16; ++m) {
+        const f32x4 a = ring[m % COOP_PF];
+        if (m + COOP_PF < 16) ring[m % COOP_PF] = wv[(m + COOP_PF) * 64];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], in[m >> 2][4 * (m & 3) + i], acc, 0, 0, 0);
     }
 }
 

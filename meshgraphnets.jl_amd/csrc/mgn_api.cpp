@@ -408,7 +408,8 @@ int mgn_set_params(mgn_handle* h, const float* packed, size_t n) {
         for (int t = 0; t < NT; ++t)
             for (int j = 0; j < J; ++j)
                 for (int lane = 0; lane < 64; ++lane)
-                    f[off + CH + ((size_t)t * J + j) * 64 + lane] = f[off + ((size_t)j * 64 + lane) * NT + t];
+                    // t-major, four consecutive k-steps per lane contiguous: [t][j/4][lane][j%4]
+                    f[off + CH + (((size_t)t * (J / 4) + j / 4) * 64 + lane) * 4 + (j & 3)] = f[off + ((size_t)j * 64 + lane) * NT + t];
         return off;
     };
     auto add_tabs = [&](const float* b1, const float* b2, const float* b3, const float* ga, const float* be, const float* bq) {
