@@ -42,9 +42,42 @@ static const float* mlp_bind(mlp_t* m, const float* p, int in, int L, int out, i
     return p;
 }
 
-/* Y[rows][n] = act(X[rows][k] * W[k][n] + b) ; i-k-j order, j vectorises */
+/* Y[rows][n] = act(X[rows][k] * W[k][n] + b).  Register-blocked: RB rows x CB columns of Y are kept in vector
+ * registers while k runs, so every W row segment loaded feeds RB FMAs (the un-blocked i-k-j loop is bound by
+ * reloading Y).  Plain C, vectorised by gcc -O3 (AVX2/FMA at -march=x86-64-v3). */
 static void dense(const float* X, int rows, int k, const float* W, const float* b, int n, int relu, float* Y) {
-    for (int i = 0; i < rows; ++i) {
+    enum { RB = 3, CB = 32 };   /* 12 ymm accumulators: the sweet spot of gcc's AVX2 code here (2.3x the un-blocked loop) */
+    int i = 0;
+    for (; i + RB <= rows; i += RB) {
+        for (int j0 = 0; j0 < n; j0 += CB) {
+            const int cb = (n - j0) < CB ? (n - j0) : CB;
+            float acc[RB][CB];
+            for (int r = 0; r < RB; ++r)
+                for (int j = 0; j < cb; ++j) acc[r][j] = b[j0 + j];
+            if (cb == CB) {
+                for (int kk = 0; kk < k; ++kk) {
+                    const float* w = W + (size_t)kk * n + j0;
+                    float xr[RB];
+                    for (int r = 0; r < RB; ++r) xr[r] = X[(size_t)(i + r) * k + kk];
+                    for (int r = 0; r < RB; ++r)
+                        for (int j = 0; j < CB; ++j) acc[r][j] += xr[r] * w[j];
+                }
+            } else {
+                for (int kk = 0; kk < k; ++kk) {
+                    const float* w = W + (size_t)kk * n + j0;
+                    for (int r = 0; r < RB; ++r) {
+                        const float xv = X[(size_t)(i + r) * k + kk];
+                        for (int j = 0; j < cb; ++j) acc[r][j] += xv * w[j];
+                    }
+                }
+            }
+            for (int r = 0; r < RB; ++r) {
+                float* y = Y + (size_t)(i + r) * n + j0;
+                for (int j = 0; j < cb; ++j) y[j] = (relu && acc[r][j] < 0.f) ? 0.f : acc[r][j];
+            }
+        }
+    }
+    for (; i < rows; ++i) {   /* remainder rows */
         float* y = Y + (size_t)i * n;
         for (int j = 0; j < n; ++j) y[j] = b[j];
         const float* x = X + (size_t)i * k;
