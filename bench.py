@@ -131,6 +131,8 @@ def main():
     ap.add_argument("--nx", type=int, default=1000, help="M-1M grid side (default 1000 -> 1M nodes)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
+    ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
+                    help="f32 = the reference's precision (headline); bf16 = BASELINE.json configs[2] precision")
     ap.add_argument("--force-staged", action="store_true",
                     help="drive the staged multi-partition path (RCCL all-to-all-v) even at world size 1 (self-test)")
     args = ap.parse_args()
@@ -169,7 +171,7 @@ def main():
     pos, s, r = mgn_amd.synth.mesh_1m(1234, args.nx, args.nx)
     N, E = pos.shape[0], int(s.size)
 
-    eng = mgn_amd.Engine(FN, FE, O, L, 2, MPS, rank=rank, nranks=world, device=local_rank)
+    eng = mgn_amd.Engine(FN, FE, O, L, 2, MPS, rank=rank, nranks=world, device=local_rank, dtype=args.dtype)
     if staged:   # RCCL collectives and the engine must share torch's stream; alone the engine keeps its own stream
         eng.set_stream(torch.cuda.current_stream().cuda_stream)
     eng.set_params(ps)
@@ -223,7 +225,7 @@ def main():
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": args.dtype,
             "data": "synthetic",
             "config": {"workload": f"M-1M jittered-grid triangulation {args.nx}x{args.nx}: N={N} nodes, E={E} directed edges, "
                                    f"L=128, hidden_layers=2, {MPS} processor steps per bench step, fp32 (BASELINE.json configs[3])",
@@ -248,7 +250,27 @@ def main():
             },
             "latents_finite": bool(finite),
         }
-        if world == 1 and not args.no_secondary:
+        if args.dtype == "bf16":
+            # bf16: MFMA is 16x faster, the step sits at the HBM/MFMA ridge: report the HBM fraction too
+            bytes_step = 2.0 * L * (2 * e_loc + 2 * n_loc) + 8.0 * e_loc
+            out["roofline"]["bf16_note"] = "peak/frac above are quoted against the fp32 MFMA peak for comparability; bf16 dense MFMA peak is ~2500 TFLOP/s"
+            out["roofline"]["hbm"] = {"bound": "hbm", "algorithmic_bytes_per_step": bytes_step, "achieved": bytes_step / t_step / 1e9,
+                                      "peak": 8000.0, "unit": "GB/s", "frac": bytes_step / t_step / 1e9 / 8000.0}
+        if world == 1 and not args.no_secondary and args.dtype == "f32":
+            engb = mgn_amd.Engine(FN, FE, O, L, 2, MPS, device=local_rank, dtype="bf16")
+            engb.set_params(ps)
+            engb.set_graph(s, r, N)
+            engb.latents_randn(1234)
+            dtb, profb = time_single(engb, 3, 1, barrier_sync)
+            tb = dtb / (3 * MPS)
+            bytes_b = 2.0 * L * (2 * E + 2 * N) + 8.0 * E
+            out["bf16"] = {"workload": "same M-1M mesh, bf16 storage + bf16 MFMA (BASELINE.json configs[2] precision; single edge set)",
+                           "ms_per_processor_step": tb * 1e3, "edges_per_s": E / tb, "edge_kernel_ms": profb["edge_step"]["avg_ms"],
+                           "node_side_ms": profb["node_step"]["avg_ms"], "algorithmic_GBps": bytes_b / tb / 1e9,
+                           "hbm_frac_of_8TBps": bytes_b / tb / 1e9 / 8000.0,
+                           "mfma_TFLOPs_algorithmic": flops_algorithmic(E, N) / tb / 1e12}
+            engb.close()
+        if world == 1 and not args.no_secondary and args.dtype == "f32":
             pos2, cells2, _, _ = mgn_amd.synth.mesh_cyl(1234, 2000)
             s2, r2 = mgn_amd.synth.cells_to_edges(cells2)
             eng2 = mgn_amd.Engine(FN, FE, O, L, 2, MPS, device=local_rank)

@@ -48,7 +48,8 @@ typedef struct mgn_config {
     int32_t L;             /* latent width `layer_size`; HIP path supports 32, 64, 128            */
     int32_t hidden_layers; /* hidden layers per MLP; HIP path supports 2 (3 Dense), the default   */
     int32_t mps;           /* message passing steps                                               */
-    int32_t dtype;         /* mgn_dtype; MGN_F32 implemented                                      */
+    int32_t dtype;         /* mgn_dtype: MGN_F32, or MGN_BF16 (L = 128: bf16 storage + bf16 MFMA in the processor, */
+                           /* fp32 accumulate / LayerNorm / residual / aggregation; encoder, decoder in fp32)      */
     int32_t rank;          /* this process's partition, 0 <= rank < nranks                        */
     int32_t nranks;        /* number of edge-cut partitions (1 = whole mesh on this GPU)          */
     int32_t device;        /* HIP device ordinal, -1 = current device, MGN_DEVICE_NONE = host-only handle */

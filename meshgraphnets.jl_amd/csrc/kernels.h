@@ -85,6 +85,31 @@ struct DecArgs {
     const float* tabs;      // b1,b2
 };
 
+// ---- bf16 processor (BASELINE cfg-3 precision): bf16 storage + bf16 MFMA, fp32 accumulate / LayerNorm / residual /
+// aggregation.  All pointers are bf16 (uint16_t) arrays; chunks are bf16 fragment order [s(8)][t(4)][lane(64)][8].
+struct BfEdgeArgs {
+    const int32_t* snd; const int32_t* rcv; int64_t E; int32_t ntiles;
+    const uint16_t* P; const uint16_t* Q;      // row-major [row][16 pieces][8], fragment feature order
+    uint16_t* Elat; uint16_t* AGG;             // tile-major [tile][8][64][8]
+    uint16_t* CARRY;                           // row-major
+    const uint16_t* chunk[3];                  // 0:W2 1:W3 2:W1e
+    const float* tabs;                         // fp32 tables (same as the fp32 kernels)
+};
+struct BfNodeArgs {
+    int32_t n, ntiles; const int32_t* rowptr;
+    uint16_t* V; const uint16_t* AGG; const uint16_t* CARRY; uint16_t* P; uint16_t* Q;
+    const uint16_t* chunk[6];                  // 0:W2 1:W3 2:W1v 3:W1a 4:WP 5:WQ
+    const float* tabs;
+    int64_t zero_row; int32_t tile0;
+};
+hipError_t launch_edge_bf16(const BfEdgeArgs& a, hipStream_t s);
+hipError_t launch_node_bf16(const BfNodeArgs& a, hipStream_t s);      // node MLP
+hipError_t launch_project_bf16(const BfNodeArgs& a, hipStream_t s);   // P,Q projection
+// layout converters between the fp32 and bf16 tile-major forms (encoder output / decoder input in bf16 mode)
+hipError_t launch_tile_f32_to_bf16(const float* src, uint16_t* dst, int64_t ntiles, hipStream_t s);
+hipError_t launch_tile_bf16_to_f32(const uint16_t* src, float* dst, int64_t ntiles, hipStream_t s);
+hipError_t launch_gather_rows16(const uint16_t* src, const int32_t* idx, uint16_t* dst, int64_t rows, hipStream_t s);
+
 struct LaunchCfg { int blocks; int threads; size_t lds; };
 
 struct LinComb {            // sum_j c[j] * k[j]

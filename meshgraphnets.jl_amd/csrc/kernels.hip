@@ -1011,6 +1011,274 @@ __global__ __launch_bounds__(512, 2) void k_decode(const DecArgs a) {
 }
 
 // ================================================================================================
+// bf16 processor kernels (L = 128): bf16 storage, v_mfma_f32_32x32x16_bf16, fp32 accumulate / LayerNorm / residual /
+// aggregation.  Same lane-per-row design: lane (c,h) owns row c; a k-step s covers 16 features and each half supplies
+// 8 of them, element j of half h being feature  f(s,h,j) = 32(s>>1) + 16(s&1) + 8(j>>2) + 4h + (j&3)  -- exactly the
+// features this lane's accumulator registers 8(s&1)..8(s&1)+7 of block t = s>>1 hold, so an accumulator becomes the
+// next layer's B operand by eight v_cvt_pk_bf16_f32 per k-step and no data movement.  A row is stored as 16 pieces
+// of 8 bf16 in that order (piece 2s+h); weights are 32 KiB per chunk, so every chunk of a kernel is LDS-resident.
+// ================================================================================================
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+constexpr int BF_STRIDE_ROW = 2, BF_STRIDE_TILE = 64;   // in 16-byte pieces
+
+DEVINL const bf16x8* bf_row_ptr(const uint16_t* base, int64_t row, int h) { return reinterpret_cast<const bf16x8*>(base + row * 128) + h; }
+DEVINL bf16x8* bf_row_ptr(uint16_t* base, int64_t row, int h) { return reinterpret_cast<bf16x8*>(base + row * 128) + h; }
+DEVINL const bf16x8* bf_tile_ptr(const uint16_t* base, int64_t tile, int lane) { return reinterpret_cast<const bf16x8*>(base + tile * (TILE * 128)) + lane; }
+DEVINL bf16x8* bf_tile_ptr(uint16_t* base, int64_t tile, int lane) { return reinterpret_cast<bf16x8*>(base + tile * (TILE * 128)) + lane; }
+
+DEVINL void bf_load(bf16x8 (&x)[8], const bf16x8* __restrict__ p, int stride) {
+#pragma unroll
+    for (int s = 0; s < 8; ++s) x[s] = p[s * stride];
+}
+DEVINL void bf_store(bf16x8* __restrict__ p, int stride, const bf16x8 (&x)[8]) {
+#pragma unroll
+    for (int s = 0; s < 8; ++s) p[s * stride] = x[s];
+}
+DEVINL void bf_pack(bf16x8 (&x)[8], const f32x16 (&acc)[4]) {          // accumulator -> B operand / storage
+#pragma unroll
+    for (int s = 0; s < 8; ++s)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) x[s][j] = (__bf16)acc[s >> 1][8 * (s & 1) + j];
+}
+DEVINL void bf_unpack_add(f32x16 (&acc)[4], const bf16x8 (&x)[8]) {    // acc += float(x)
+#pragma unroll
+    for (int s = 0; s < 8; ++s)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[s >> 1][8 * (s & 1) + j] += (float)x[s][j];
+}
+
+// one 128 x 128 chunk from LDS: w[(s*4 + t)*64 + lane] is the A fragment of k-step s, feature block t
+DEVINL void bf_chunk(f32x16 (&acc)[4], const bf16x8 (&in)[8], const bf16x8* w, int lane) {
+#pragma unroll
+    for (int s = 0; s < 8; ++s)
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[(s * 4 + t) * 64 + lane], in[s], acc[t], 0, 0, 0);
+}
+
+constexpr int BF_CH = 128 * 128;   // bf16 elements per chunk (32 KiB)
+
+DEVINL void copy_to_lds16(uint16_t* dst, const uint16_t* __restrict__ src, int n) {
+    const f32x4* s4 = reinterpret_cast<const f32x4*>(src);
+    f32x4* d4 = reinterpret_cast<f32x4*>(dst);
+    for (int i = threadIdx.x; i < n / 8; i += blockDim.x) d4[i] = s4[i];
+}
+
+__global__ __launch_bounds__(512, 2) void k_edge_bf16(const BfEdgeArgs a) {
+    constexpr int L = 128;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    uint16_t* wl = reinterpret_cast<uint16_t*>(smem);
+#pragma unroll
+    for (int r = 0; r < 3; ++r) copy_to_lds16(wl + r * BF_CH, a.chunk[r], BF_CH);
+    float* tb = smem + 3 * BF_CH / 2;
+    copy_to_lds(tb, a.tabs, T_COUNT * L);
+    __syncthreads();
+    const bf16x8* w2 = reinterpret_cast<const bf16x8*>(wl);
+    const bf16x8* w3 = reinterpret_cast<const bf16x8*>(wl + BF_CH);
+    const bf16x8* w1 = reinterpret_cast<const bf16x8*>(wl + 2 * BF_CH);
+    const int lane0 = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    EdgeArgs ia{};   // load_edge_idx only needs the index arrays
+    ia.snd = a.snd; ia.rcv = a.rcv; ia.E = a.E;
+    for (TileWalk tw(a.ntiles, wave); tw.tile < tw.end; tw.tile += tw.stride) {
+        OPAQUE_LANE();
+        const int tile = tw.tile;
+        const EdgeIdx ix = load_edge_idx(ia, tile, c);
+        const bool valid = ix.r >= 0;
+        const int r = valid ? ix.r : 0;
+        bf16x8 x[8], in[8];
+        f32x16 acc[4], y[4];
+        bf16x8* etile = bf_tile_ptr(a.Elat, tile, lane);
+        bf_load(x, etile, BF_STRIDE_TILE);
+        zero_frag<4>(acc);
+        bf_load(in, bf_row_ptr(a.P, ix.s, h), BF_STRIDE_ROW);
+        bf_unpack_add(acc, in);
+        bf_load(in, bf_row_ptr(a.Q, r, h), BF_STRIDE_ROW);
+        bf_unpack_add(acc, in);
+        bf_chunk(acc, x, w1, lane);                              // layer 1 (edge part; P, Q, b1 preloaded)
+        relu_frag<4>(acc);
+        bf_pack(in, acc);
+        tab_frag<4>(y, tb + T_B2 * L, h);
+        bf_chunk(y, in, w2, lane);                               // layer 2
+        relu_frag<4>(y);
+        bf_pack(in, y);
+        tab_frag<4>(acc, tb + T_B3 * L, h);
+        bf_chunk(acc, in, w3, lane);                             // layer 3
+        layer_norm_frag<4>(acc, tb + T_GAMMA * L, tb + T_BETA * L, h);   // acc = e' (fp32)
+        // residual in fp32, stored as bf16
+        zero_frag<4>(y);
+        bf_unpack_add(y, x);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) y[t] += acc[t];
+        bf_pack(in, y);
+        if (valid) bf_store(etile, BF_STRIDE_TILE, in);
+        // segmented sum of e' (fp32) over runs of equal receiver
+        const int reff = valid ? r : (-4 - c);
+        const int rprev = __shfl_up(reff, 1, 32);
+        const int rnext = __shfl_down(reff, 1, 32);
+        const bool head = (c == 0) || (reff != rprev);
+        const unsigned hm = (unsigned)__ballot(head);
+        const int start = 31 - __clz((int)(hm & (0xFFFFFFFFu >> (31 - c))));
+        const int st_in = max(start, c & 16);
+        const bool c1 = (c - 1 >= st_in), c2 = (c - 2 >= st_in), c4 = (c - 4 >= st_in), c8 = (c - 8 >= st_in);
+        const bool cx = (c >= 16) && (start <= 15);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            PHASE_FENCE();
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                float v = acc[t][k];
+                float u;
+                u = v + dpp_zero<0x111, 0xF>(v); v = c1 ? u : v;
+                u = v + dpp_zero<0x112, 0xF>(v); v = c2 ? u : v;
+                u = v + dpp_zero<0x114, 0xF>(v); v = c4 ? u : v;
+                u = v + dpp_zero<0x118, 0xF>(v); v = c8 ? u : v;
+                u = v + dpp_zero<0x142, 0xA>(v); v = cx ? u : v;
+                acc[t][k] = v;
+            }
+        }
+        const bool tail = valid && ((c == 31) || (reff != rnext));
+        const int r_first = __builtin_amdgcn_readfirstlane(reff);
+        const bool sl = (start == 0) && (ix.r_before == r_first);
+        const bool sr = (c == 31) && (ix.r_after == reff);
+        const bool to_carry = sl || sr;
+        bf16x8* dst = to_carry ? bf_row_ptr(a.CARRY, (int64_t)2 * tile + (sl ? 0 : 1), h)
+                               : bf_tile_ptr(a.AGG, r >> 5, 32 * h + (r & 31));
+        bf_pack(in, acc);
+        if (tail) bf_store(dst, to_carry ? BF_STRIDE_ROW : BF_STRIDE_TILE, in);
+    }
+}
+
+// node MLP: chunk[0]=W2 [1]=W3 [2]=W1v [3]=W1a, all resident (128 KiB)
+__global__ __launch_bounds__(512, 2) void k_node_bf16(const BfNodeArgs a) {
+    constexpr int L = 128;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    uint16_t* wl = reinterpret_cast<uint16_t*>(smem);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) copy_to_lds16(wl + r * BF_CH, a.chunk[r], BF_CH);
+    float* tb = smem + 4 * BF_CH / 2;
+    copy_to_lds(tb, a.tabs, T_COUNT * L);
+    __syncthreads();
+    const bf16x8* w2 = reinterpret_cast<const bf16x8*>(wl);
+    const bf16x8* w3 = reinterpret_cast<const bf16x8*>(wl + BF_CH);
+    const bf16x8* w1v = reinterpret_cast<const bf16x8*>(wl + 2 * BF_CH);
+    const bf16x8* w1a = reinterpret_cast<const bf16x8*>(wl + 3 * BF_CH);
+    const int lane0 = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    for (TileWalk tw(a.ntiles, wave); tw.tile < tw.end; tw.tile += tw.stride) {
+        OPAQUE_LANE();
+        const int tile = tw.tile;
+        const int n = tile * TILE + c;
+        const bool valid = n < a.n;
+        const int nn = valid ? n : 0;
+        bf16x8 v[8], in[8];
+        f32x16 acc[4], y[4];
+        bf16x8* vtile = bf_tile_ptr(a.V, tile, lane);
+        bf_load(v, vtile, BF_STRIDE_TILE);
+        const int a0 = valid ? a.rowptr[nn] : 0, a1 = valid ? a.rowptr[nn + 1] : 0;
+        const int T1 = a0 >> 5, T2 = (a1 - 1) >> 5;
+        const int extra = (a1 > a0 && T2 > T1) ? (T2 - T1) : 0;
+        const bool from_agg = (a1 > a0) && !extra;
+        const bf16x8* src0 = from_agg ? bf_tile_ptr(a.AGG, tile, lane) : bf_row_ptr(a.CARRY, extra ? (int64_t)(2 * T1 + 1) : a.zero_row, h);
+        bf_load(in, src0, from_agg ? BF_STRIDE_TILE : BF_STRIDE_ROW);
+        if (__any(extra > 0)) {                                  // carry rows are summed in fp32, rounded once
+            zero_frag<4>(y);
+            bf_unpack_add(y, in);
+            for (int q = 1; __any(q <= extra); ++q)
+                if (q <= extra) {
+                    bf16x8 cr[8];
+                    bf_load(cr, bf_row_ptr(a.CARRY, (int64_t)2 * (T1 + q), h), BF_STRIDE_ROW);
+                    bf_unpack_add(y, cr);
+                }
+            bf_pack(in, y);
+        }
+        tab_frag<4>(acc, tb + T_B1 * L, h);
+        bf_chunk(acc, v, w1v, lane);                             // layer 1, node part
+        bf_chunk(acc, in, w1a, lane);                            // layer 1, aggregate part
+        relu_frag<4>(acc);
+        bf_pack(in, acc);
+        tab_frag<4>(y, tb + T_B2 * L, h);
+        bf_chunk(y, in, w2, lane);
+        relu_frag<4>(y);
+        bf_pack(in, y);
+        tab_frag<4>(acc, tb + T_B3 * L, h);
+        bf_chunk(acc, in, w3, lane);
+        layer_norm_frag<4>(acc, tb + T_GAMMA * L, tb + T_BETA * L, h);
+        bf_unpack_add(acc, v);                                   // v <- v + v'  (fp32 add, one rounding)
+        bf_pack(in, acc);
+        if (valid) bf_store(vtile, BF_STRIDE_TILE, in);
+    }
+}
+
+// P,Q projection: chunk[4]=WP chunk[5]=WQ resident
+__global__ __launch_bounds__(512, 2) void k_project_bf16(const BfNodeArgs a) {
+    constexpr int L = 128;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    uint16_t* wl = reinterpret_cast<uint16_t*>(smem);
+    copy_to_lds16(wl, a.chunk[4], BF_CH);
+    copy_to_lds16(wl + BF_CH, a.chunk[5], BF_CH);
+    float* tb = smem + 2 * BF_CH / 2;
+    copy_to_lds(tb, a.tabs, T_COUNT * L);
+    __syncthreads();
+    const bf16x8* wp = reinterpret_cast<const bf16x8*>(wl);
+    const bf16x8* wq = reinterpret_cast<const bf16x8*>(wl + BF_CH);
+    const int lane0 = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    for (TileWalk tw(a.ntiles, wave); tw.tile < tw.end; tw.tile += tw.stride) {
+        OPAQUE_LANE();
+        const int tile = a.tile0 + tw.tile;
+        const int n = tile * TILE + c;
+        const bool valid = n < a.n;
+        const int nn = valid ? n : 0;
+        bf16x8 v[8], out[8];
+        f32x16 acc[4];
+        bf_load(v, bf_tile_ptr(a.V, tile, lane), BF_STRIDE_TILE);
+        zero_frag<4>(acc);
+        bf_chunk(acc, v, wp, lane);
+        bf_pack(out, acc);
+        if (valid) bf_store(bf_row_ptr(a.P, nn, h), BF_STRIDE_ROW, out);
+        tab_frag<4>(acc, tb + T_BQ * L, h);
+        bf_chunk(acc, v, wq, lane);
+        bf_pack(out, acc);
+        if (valid) bf_store(bf_row_ptr(a.Q, nn, h), BF_STRIDE_ROW, out);
+    }
+}
+
+// fp32 tile-major piece m = 4t+g (features 32t+8g+4h+i)  <->  bf16 piece s (features f(s,h,j)): bf16 piece s of a
+// lane is the concatenation of its fp32 pieces 2s and 2s+1.
+__global__ void k_tile_f32_to_bf16(const float* __restrict__ src, uint16_t* __restrict__ dst, int64_t n_pieces) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // one bf16 piece (tile, s, lane)
+    if (i >= n_pieces) return;
+    const int64_t tile = i / 512;
+    const int rem = (int)(i - tile * 512), sidx = rem >> 6, lane = rem & 63;
+    const f32x4* s4 = reinterpret_cast<const f32x4*>(src) + tile * 1024 + lane;
+    const f32x4 lo = s4[(2 * sidx) * 64], hi = s4[(2 * sidx + 1) * 64];
+    bf16x8 o;
+    o[0] = (__bf16)lo[0]; o[1] = (__bf16)lo[1]; o[2] = (__bf16)lo[2]; o[3] = (__bf16)lo[3];
+    o[4] = (__bf16)hi[0]; o[5] = (__bf16)hi[1]; o[6] = (__bf16)hi[2]; o[7] = (__bf16)hi[3];
+    reinterpret_cast<bf16x8*>(dst)[i] = o;
+}
+__global__ void k_tile_bf16_to_f32(const uint16_t* __restrict__ src, float* __restrict__ dst, int64_t n_pieces) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_pieces) return;
+    const int64_t tile = i / 512;
+    const int rem = (int)(i - tile * 512), sidx = rem >> 6, lane = rem & 63;
+    const bf16x8 v = reinterpret_cast<const bf16x8*>(src)[i];
+    f32x4* d4 = reinterpret_cast<f32x4*>(dst) + tile * 1024 + lane;
+    f32x4 lo, hi;
+    lo[0] = (float)v[0]; lo[1] = (float)v[1]; lo[2] = (float)v[2]; lo[3] = (float)v[3];
+    hi[0] = (float)v[4]; hi[1] = (float)v[5]; hi[2] = (float)v[6]; hi[3] = (float)v[7];
+    d4[(2 * sidx) * 64] = lo;
+    d4[(2 * sidx + 1) * 64] = hi;
+}
+__global__ void k_gather_rows16(const uint16_t* __restrict__ src, const int32_t* __restrict__ idx, uint16_t* __restrict__ dst, int64_t rows) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // one 16-byte piece; 16 per row
+    if (i >= rows * 16) return;
+    const int64_t r = i >> 4;
+    reinterpret_cast<f32x4*>(dst)[i] = reinterpret_cast<const f32x4*>(src)[(int64_t)idx[r] * 16 + (i & 15)];
+}
+
+// ================================================================================================
 // small utility kernels
 // ================================================================================================
 __global__ void k_gather_rows(const float* __restrict__ src, const int32_t* __restrict__ idx, float* __restrict__ dst,
@@ -1282,6 +1550,42 @@ hipError_t launch_project(int L, const NodeArgs& a, hipStream_t s) {
 hipError_t launch_enc_node(int L, const EncNodeArgs& a, hipStream_t s) { DISPATCH_L(k_enc_node, 4, a, a.ntiles); }
 hipError_t launch_enc_edge(int L, const EncEdgeArgs& a, hipStream_t s) { DISPATCH_L(k_enc_edge, 2, a, a.ntiles); }
 hipError_t launch_decode(int L, const DecArgs& a, hipStream_t s) { DISPATCH_L(k_decode, 2, a, a.ntiles); }
+
+static LaunchCfg bf_launch(int ntiles, int nchunks) {
+    LaunchCfg lc = tile_launch(128, ntiles, 0);
+    lc.lds = (size_t)nchunks * BF_CH * 2 + (size_t)T_COUNT * 128 * 4;
+    return lc;
+}
+hipError_t launch_edge_bf16(const BfEdgeArgs& a, hipStream_t s) {
+    if (a.ntiles <= 0) return hipSuccess;
+    return launch_k(k_edge_bf16, a, bf_launch(a.ntiles, 3), s);
+}
+hipError_t launch_node_bf16(const BfNodeArgs& a, hipStream_t s) {
+    if (a.ntiles <= 0) return hipSuccess;
+    return launch_k(k_node_bf16, a, bf_launch(a.ntiles, 4), s);
+}
+hipError_t launch_project_bf16(const BfNodeArgs& a, hipStream_t s) {
+    if (a.ntiles <= 0) return hipSuccess;
+    return launch_k(k_project_bf16, a, bf_launch(a.ntiles, 2), s);
+}
+hipError_t launch_tile_f32_to_bf16(const float* src, uint16_t* dst, int64_t ntiles, hipStream_t s) {
+    const int64_t n = ntiles * 512;
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_tile_f32_to_bf16, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src, dst, n);
+    return hipGetLastError();
+}
+hipError_t launch_tile_bf16_to_f32(const uint16_t* src, float* dst, int64_t ntiles, hipStream_t s) {
+    const int64_t n = ntiles * 512;
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_tile_bf16_to_f32, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src, dst, n);
+    return hipGetLastError();
+}
+hipError_t launch_gather_rows16(const uint16_t* src, const int32_t* idx, uint16_t* dst, int64_t rows, hipStream_t s) {
+    if (rows <= 0) return hipSuccess;
+    const int64_t n = rows * 16;
+    hipLaunchKernelGGL(k_gather_rows16, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src, idx, dst, rows);
+    return hipGetLastError();
+}
 
 hipError_t launch_gather_rows(const float* src, const int32_t* idx, float* dst, int64_t rows, int L, hipStream_t s) {
     if (rows <= 0) return hipSuccess;

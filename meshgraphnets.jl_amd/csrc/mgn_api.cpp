@@ -91,6 +91,11 @@ struct mgn_engine {
     DevBuf d_snd, d_rcv, d_rowptr, d_own_gid, d_edge_gid, d_send_idx;
 
     // latents and I/O
+    // bf16 mode (cfg.dtype == MGN_BF16): bf16 copies of the processor state and weights; the fp32 V / Elat buffers
+    // then only carry encoder output / decoder input
+    DevBuf wbf, bV, bP, bQ, bElat, bAGG, bCARRY;
+    struct BfStepOff { size_t e_ch[3], n_ch[6]; };
+    std::vector<BfStepOff> bsoff;
     DevBuf d_stamps;  // diagnostic builds only
     DevBuf ode;       // native rollout: state, stages, frames, saves, Elat0
     const float* srcA_override = nullptr;  // rollout: encoder reads the node state from here instead of d_nfA
@@ -137,7 +142,8 @@ bool cfg_ok(const mgn_config* c, std::string& why) {
     if (c->L != 32 && c->L != 64 && c->L != 128) { why = "L must be 32, 64 or 128 on the HIP path"; return false; }
     if (c->hidden_layers != 2) { why = "hidden_layers must be 2 on the HIP path"; return false; }
     if (c->mps < 1) { why = "mps must be >= 1"; return false; }
-    if (c->dtype != MGN_F32) { why = "only MGN_F32 is implemented"; return false; }
+    if (c->dtype != MGN_F32 && c->dtype != MGN_BF16) { why = "dtype must be MGN_F32 or MGN_BF16"; return false; }
+    if (c->dtype == MGN_BF16 && c->L != 128) { why = "MGN_BF16 is implemented for L = 128"; return false; }
     if (c->nranks < 1 || c->rank < 0 || c->rank >= c->nranks) { why = "bad rank/nranks"; return false; }
     return true;
 }
@@ -198,6 +204,41 @@ void pack_tab(float* dst, const float* vec, int L, int stride = 1) {
                 dst[(m * 2 + hh) * 4 + i] = vec ? vec[(size_t)(32 * (m >> 2) + 8 * (m & 3) + 4 * hh + i) * stride] : 0.f;
 }
 
+inline uint16_t f32_to_bf16(float f) {   // round to nearest even (inputs are finite weights / latents)
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+inline float bf16_to_f32(uint16_t b) {
+    const uint32_t u = (uint32_t)b << 16;
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+// feature held by element j of piece (s, hh) of a bf16 row fragment (see kernels.hip, bf16 section)
+inline int bf_feature(int sidx, int hh, int j) { return 32 * (sidx >> 1) + 16 * (sidx & 1) + 8 * (j >> 2) + 4 * hh + (j & 3); }
+// inverse: position of feature f inside a 128-wide bf16 row (piece 2s+hh, element j)
+inline int bf_row_pos(int f) {
+    const int t = f >> 5, rem = f & 31, sidx = 2 * t + (rem >> 4), r2 = rem & 15, hh = (r2 >> 2) & 1, j = 4 * (r2 >> 3) + (r2 & 3);
+    return (2 * sidx + hh) * 8 + j;
+}
+inline size_t bf_tile_index(int64_t row, int f) {
+    const int64_t tile = row / TILE;
+    const int c = (int)(row % TILE), pos = bf_row_pos(f), piece = pos >> 3, j = pos & 7, sidx = piece >> 1, hh = piece & 1;
+    return (size_t)tile * TILE * 128 + ((size_t)sidx * 64 + 32 * hh + c) * 8 + j;
+}
+// 128 x 128 chunk of W (row-major [K][ldw], rows kbase..) -> bf16 fragment order [s][t][lane][8]
+void pack_chunk_bf16(uint16_t* dst, const float* W, int ldw, int kbase) {
+    for (int sidx = 0; sidx < 8; ++sidx)
+        for (int t = 0; t < 4; ++t)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int j = 0; j < 8; ++j) {
+                    const int hh = lane >> 5, i = lane & 31;
+                    dst[(((size_t)sidx * 4 + t) * 64 + lane) * 8 + j] = f32_to_bf16(W[(size_t)(kbase + bf_feature(sidx, hh, j)) * ldw + 32 * t + i]);
+                }
+}
+
 int need(mgn_engine* h, bool params, bool graph) {
     if (!h) return MGN_E_ARG;
     if (h->host_only) return fail(h, MGN_E_HIP, "host-only handle (MGN_DEVICE_NONE): no compute path; create the handle on a HIP device");
@@ -253,6 +294,16 @@ int alloc_latents(mgn_engine* h) {
     HIPCHK(h, hipMemsetAsync(h->CARRY.p, 0, (size_t)(2 * nte + 1) * L * 4, h->stream));
     HIPCHK(h, hipMemsetAsync(h->P.p, 0, (size_t)(g.n_own + g.n_halo + 1) * L * 4, h->stream));
     HIPCHK(h, hipMemsetAsync(h->Q.p, 0, (size_t)(g.n_own + 1) * L * 4, h->stream));
+    if (h->cfg.dtype == MGN_BF16) {
+        struct { DevBuf* b; size_t bytes; } bufs[6] = {
+            {&h->bV, tile_floats(ntn, L) * 2}, {&h->bElat, tile_floats(nte, L) * 2}, {&h->bAGG, tile_floats(ntn, L) * 2},
+            {&h->bP, (size_t)(g.n_own + g.n_halo + 1) * L * 2}, {&h->bQ, (size_t)(g.n_own + 1) * L * 2},
+            {&h->bCARRY, (size_t)(2 * nte + 1) * L * 2}};
+        for (auto& b : bufs) {
+            HIPCHK(h, b.b->ensure(b.bytes));
+            HIPCHK(h, hipMemsetAsync(b.b->p, 0, b.bytes, h->stream));
+        }
+    }
     return MGN_OK;
 }
 
@@ -305,6 +356,43 @@ NodeArgs node_args(mgn_engine* h, int k, int mode) {
     a.tile0 = 0;
     return a;
 }
+
+const uint16_t* WB(const mgn_engine* h, size_t off) { return h->wbf.as<uint16_t>() + off; }
+
+BfEdgeArgs bf_edge_args(mgn_engine* h, int k) {
+    BfEdgeArgs a{};
+    a.snd = h->d_snd.as<int32_t>();
+    a.rcv = h->d_rcv.as<int32_t>();
+    a.E = h->g.e_local;
+    a.ntiles = h->ntiles_e;
+    a.P = h->bP.as<uint16_t>();
+    a.Q = h->bQ.as<uint16_t>();
+    a.Elat = h->bElat.as<uint16_t>();
+    a.AGG = h->bAGG.as<uint16_t>();
+    a.CARRY = h->bCARRY.as<uint16_t>();
+    for (int i = 0; i < 3; ++i) a.chunk[i] = WB(h, h->bsoff[k].e_ch[i]);
+    a.tabs = W(h, h->soff[k].e_tabs);
+    return a;
+}
+
+BfNodeArgs bf_node_args(mgn_engine* h, int k) {
+    BfNodeArgs a{};
+    a.n = h->g.n_own;
+    a.ntiles = h->ntiles_n;
+    a.rowptr = h->d_rowptr.as<int32_t>();
+    a.V = h->bV.as<uint16_t>();
+    a.AGG = h->bAGG.as<uint16_t>();
+    a.CARRY = h->bCARRY.as<uint16_t>();
+    a.P = h->bP.as<uint16_t>();
+    a.Q = h->bQ.as<uint16_t>();
+    for (int i = 0; i < 6; ++i) a.chunk[i] = WB(h, h->bsoff[k].n_ch[i]);
+    a.tabs = W(h, h->soff[k].n_tabs);
+    a.zero_row = 2 * (int64_t)(h->ntiles_e > 0 ? h->ntiles_e : 1);
+    a.tile0 = 0;
+    return a;
+}
+
+inline bool is_bf16(const mgn_engine* h) { return h->cfg.dtype == MGN_BF16; }
 
 }  // namespace
 
@@ -483,6 +571,37 @@ int mgn_set_params(mgn_handle* h, const float* packed, size_t n) {
         so.n_tabs = add_tabs(nullptr, nullptr, nullptr, nullptr, nullptr, p + e0.b[0]);
         h->soff.push_back(so);
     }
+    if (c.dtype == MGN_BF16) {
+        std::vector<uint16_t> wb;
+        auto addb = [&](const float* Wm, int kbase) {
+            const size_t off = wb.size();
+            wb.resize(off + (size_t)L * L);
+            pack_chunk_bf16(wb.data() + off, Wm, L, kbase);
+            return off;
+        };
+        h->bsoff.assign(c.mps + 1, {});
+        for (int k = 0; k < c.mps; ++k) {
+            const MlpOff& me = h->pe[k];
+            const MlpOff& mn = h->pn[k];
+            const MlpOff& nx = h->pe[k + 1 < c.mps ? k + 1 : 0];
+            auto& so = h->bsoff[k];
+            so.e_ch[0] = addb(p + me.W[1], 0);
+            so.e_ch[1] = addb(p + me.W[2], 0);
+            so.e_ch[2] = addb(p + me.W[0], 2 * L);
+            so.n_ch[0] = addb(p + mn.W[1], 0);
+            so.n_ch[1] = addb(p + mn.W[2], 0);
+            so.n_ch[2] = addb(p + mn.W[0], 0);
+            so.n_ch[3] = addb(p + mn.W[0], L);
+            so.n_ch[4] = addb(p + nx.W[0], 0);
+            so.n_ch[5] = addb(p + nx.W[0], L);
+        }
+        h->bsoff[c.mps] = h->bsoff[0];                       // projection for step 0 (mgn_proc_begin)
+        h->bsoff[c.mps].n_ch[4] = addb(p + e0.W[0], 0);
+        h->bsoff[c.mps].n_ch[5] = addb(p + e0.W[0], L);
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        HIPCHK(h, h->wbf.ensure(wb.size() * 2));
+        HIPCHK(h, hipMemcpy(h->wbf.p, wb.data(), wb.size() * 2, hipMemcpyHostToDevice));
+    }
     HIPCHK(h, hipStreamSynchronize(h->stream));
     drop_graph(h);
     HIPCHK(h, h->wfrag.ensure(f.size() * 4));
@@ -660,6 +779,10 @@ static int encode_impl(mgn_handle* h, bool use_norms, bool nodes = true, bool ed
         for (int i = 0; i < 4; ++i) a.chunk[i] = W(h, h->en_ch[i]);
         a.tabs = W(h, h->en_tabs);
         HIPCHK(h, launch_enc_node(c.L, a, h->stream));
+        if (is_bf16(h)) {   // fp32 encoder output -> bf16 state; P,Q of step 0 from the bf16 latents
+            HIPCHK(h, launch_tile_f32_to_bf16(h->V.as<float>(), h->bV.as<uint16_t>(), h->ntiles_n, h->stream));
+            HIPCHK(h, launch_project_bf16(bf_node_args(h, c.mps), h->stream));
+        }
     }
     if (edges) {
         EncEdgeArgs b{};
@@ -674,6 +797,7 @@ static int encode_impl(mgn_handle* h, bool use_norms, bool nodes = true, bool ed
         for (int i = 0; i < 2; ++i) b.chunk[i] = W(h, h->ee_ch[i]);
         b.tabs = W(h, h->ee_tabs);
         HIPCHK(h, launch_enc_edge(c.L, b, h->stream));
+        if (is_bf16(h)) HIPCHK(h, launch_tile_f32_to_bf16(h->Elat.as<float>(), h->bElat.as<uint16_t>(), h->ntiles_e, h->stream));
     }
     return MGN_OK;
 }
@@ -687,6 +811,10 @@ int mgn_fwd_encode(mgn_handle* h) {
 int mgn_proc_begin(mgn_handle* h) {
     if (int rc = need(h, true, true)) return rc;
     ProfScope ps(h, F_NODE);
+    if (is_bf16(h)) {
+        HIPCHK(h, launch_project_bf16(bf_node_args(h, h->cfg.mps), h->stream));
+        return MGN_OK;
+    }
     const NodeArgs a = node_args(h, h->cfg.mps, 2);
     HIPCHK(h, launch_project(h->cfg.L, a, h->stream));
     return MGN_OK;
@@ -696,6 +824,10 @@ int mgn_proc_edge(mgn_handle* h, int32_t k) {
     if (int rc = need(h, true, true)) return rc;
     if (k < 0 || k >= h->cfg.mps) return fail(h, MGN_E_ARG, "mgn_proc_edge: step %d out of range", k);
     ProfScope ps(h, F_EDGE);
+    if (is_bf16(h)) {
+        HIPCHK(h, launch_edge_bf16(bf_edge_args(h, k), h->stream));
+        return MGN_OK;
+    }
     const EdgeArgs a = edge_args(h, k);
     HIPCHK(h, launch_edge_step(h->cfg.L, a, h->stream));
     return MGN_OK;
@@ -706,6 +838,11 @@ int mgn_proc_node(mgn_handle* h, int32_t k, int32_t project_next) {
     if (k < 0 || k >= h->cfg.mps) return fail(h, MGN_E_ARG, "mgn_proc_node: step %d out of range", k);
     if (project_next && k + 1 >= h->cfg.mps) return fail(h, MGN_E_ARG, "mgn_proc_node: no step %d to project for", k + 1);
     ProfScope ps(h, F_NODE);
+    if (is_bf16(h)) {
+        HIPCHK(h, launch_node_bf16(bf_node_args(h, k), h->stream));
+        if (project_next) HIPCHK(h, launch_project_bf16(bf_node_args(h, k), h->stream));
+        return MGN_OK;
+    }
     if (project_next && h->node_split) {
         // two launches: MLP (2 of its 4 chunks stream from L2), then the projection with both chunks resident
         HIPCHK(h, launch_node_step(h->cfg.L, node_args(h, k, 0), h->stream));
@@ -723,6 +860,14 @@ int mgn_proc_node_phase(mgn_handle* h, int32_t k, int32_t phase) {
     if (phase != 1 && phase != 2) return fail(h, MGN_E_ARG, "mgn_proc_node_phase: phase must be 1 or 2");
     ProfScope ps(h, F_NODE);
     const int ntb = (h->g.n_boundary + TILE - 1) / TILE;   // tiles that contain a boundary node
+    if (is_bf16(h)) {
+        if (phase == 1 && k >= 0) HIPCHK(h, launch_node_bf16(bf_node_args(h, k), h->stream));
+        BfNodeArgs b = bf_node_args(h, k >= 0 ? k : h->cfg.mps);
+        b.tile0 = phase == 1 ? 0 : (ntb < h->ntiles_n ? ntb : h->ntiles_n);
+        b.ntiles = phase == 1 ? (ntb < h->ntiles_n ? ntb : h->ntiles_n) : h->ntiles_n - b.tile0;
+        HIPCHK(h, launch_project_bf16(b, h->stream));
+        return MGN_OK;
+    }
     if (phase == 1 && k >= 0) HIPCHK(h, launch_node_step(h->cfg.L, node_args(h, k, 0), h->stream));
     NodeArgs a = node_args(h, k >= 0 ? k : h->cfg.mps, 2);
     if (phase == 1) {
@@ -739,6 +884,7 @@ int mgn_proc_node_phase(mgn_handle* h, int32_t k, int32_t phase) {
 static int decode_impl(mgn_handle* h, bool use_norms) {
     const mgn_config& c = h->cfg;
     ProfScope ps(h, F_DEC);
+    if (is_bf16(h)) HIPCHK(h, launch_tile_bf16_to_f32(h->bV.as<uint16_t>(), h->V.as<float>(), h->ntiles_n, h->stream));
     DecArgs a{};
     a.n = h->g.n_own;
     a.ntiles = h->ntiles_n;
@@ -853,8 +999,9 @@ struct Rollout {
         int rc = encode_impl(h, true, true, false);
         if (!rc) {
             // encoded edge latents are identical for every RHS of a trajectory (static edge features, frozen e_norm)
-            const size_t eb = tile_floats(h->ntiles_e, c.L) * 4;
-            hipError_t e = hipMemcpyAsync(h->Elat.p, h->ode.as<char>() + elat0_off, eb, hipMemcpyDeviceToDevice, h->stream);
+            const bool bf = c.dtype == MGN_BF16;
+            const size_t eb = tile_floats(h->ntiles_e, c.L) * (bf ? 2 : 4);
+            hipError_t e = hipMemcpyAsync(bf ? h->bElat.p : h->Elat.p, h->ode.as<char>() + elat0_off, eb, hipMemcpyDeviceToDevice, h->stream);
             if (e != hipSuccess) rc = fail(h, MGN_E_HIP, "rollout: Elat restore failed: %s", hipGetErrorString(e));
         }
         if (!rc) rc = run_processor(h, c.mps);
@@ -928,7 +1075,7 @@ int mgn_rollout(mgn_handle* h, mgn_rollout_desc* d) {
         HIPCHK(h, hipMemcpyAsync(h->d_mask.p, d->val_mask, (size_t)g.N * 4, hipMemcpyHostToDevice, h->stream));
     }
     if (int rc = encode_impl(h, true, false, true)) return rc;
-    HIPCHK(h, hipMemcpyAsync(base + R.elat0_off, h->Elat.p, eb, hipMemcpyDeviceToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(base + R.elat0_off, is_bf16(h) ? h->bElat.p : h->Elat.p, is_bf16(h) ? eb / 2 : eb, hipMemcpyDeviceToDevice, h->stream));
 
     d->n_accept = d->n_reject = 0;
     int saved = 0;
@@ -1040,6 +1187,11 @@ int mgn_latents_import(mgn_handle* h, const float* v, const float* e) {
     HIPCHK(h, hipStreamSynchronize(h->stream));
     if (!tv.empty()) HIPCHK(h, hipMemcpy(h->V.p, tv.data(), tv.size() * 4, hipMemcpyHostToDevice));
     if (!te.empty()) HIPCHK(h, hipMemcpy(h->Elat.p, te.data(), te.size() * 4, hipMemcpyHostToDevice));
+    if (is_bf16(h)) {   // the processor state proper is the bf16 copy (rounded once, on the device)
+        HIPCHK(h, launch_tile_f32_to_bf16(h->V.as<float>(), h->bV.as<uint16_t>(), h->ntiles_n, h->stream));
+        HIPCHK(h, launch_tile_f32_to_bf16(h->Elat.as<float>(), h->bElat.as<uint16_t>(), h->ntiles_e, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+    }
     return MGN_OK;
 }
 
@@ -1047,6 +1199,10 @@ int mgn_latents_export(mgn_handle* h, float* v, float* e) {
     if (int rc = need(h, false, true)) return rc;
     const LocalGraph& g = h->g;
     const int L = h->cfg.L;
+    if (is_bf16(h)) {
+        HIPCHK(h, launch_tile_bf16_to_f32(h->bV.as<uint16_t>(), h->V.as<float>(), h->ntiles_n, h->stream));
+        HIPCHK(h, launch_tile_bf16_to_f32(h->bElat.as<uint16_t>(), h->Elat.as<float>(), h->ntiles_e, h->stream));
+    }
     HIPCHK(h, hipStreamSynchronize(h->stream));
     if (v) {
         std::vector<float> tv(tile_floats(h->ntiles_n, L));
@@ -1073,12 +1229,20 @@ int mgn_latents_randn(mgn_handle* h, uint64_t seed) {
     HIPCHK(h, launch_randn_rows(h->V.as<float>(), nullptr, h->d_own_gid.as<int32_t>(), g.n_own, h->cfg.L, seed, h->stream));
     HIPCHK(h, launch_randn_rows(h->Elat.as<float>(), h->d_edge_gid.as<int64_t>(), nullptr, g.e_local, h->cfg.L,
                                 seed ^ 0xE5E5E5E5E5E5E5E5ull, h->stream));
+    if (is_bf16(h)) {
+        HIPCHK(h, launch_tile_f32_to_bf16(h->V.as<float>(), h->bV.as<uint16_t>(), h->ntiles_n, h->stream));
+        HIPCHK(h, launch_tile_f32_to_bf16(h->Elat.as<float>(), h->bElat.as<uint16_t>(), h->ntiles_e, h->stream));
+    }
     return MGN_OK;
 }
 
 int mgn_latents_checksum(mgn_handle* h, double* sv, double* se, double* qv, double* qe) {
     if (int rc = need(h, false, true)) return rc;
     const int np_ = checksum_partials();
+    if (is_bf16(h)) {
+        HIPCHK(h, launch_tile_bf16_to_f32(h->bV.as<uint16_t>(), h->V.as<float>(), h->ntiles_n, h->stream));
+        HIPCHK(h, launch_tile_bf16_to_f32(h->bElat.as<uint16_t>(), h->Elat.as<float>(), h->ntiles_e, h->stream));
+    }
     HIPCHK(h, h->d_sum.ensure((size_t)2 * np_ * sizeof(double)));
     HIPCHK(h, launch_checksum(h->V.as<float>(), (int64_t)tile_floats(h->ntiles_n, h->cfg.L), h->d_sum.as<double>(), h->stream));
     HIPCHK(h, launch_checksum(h->Elat.as<float>(), (int64_t)tile_floats(h->ntiles_e, h->cfg.L), h->d_sum.as<double>() + np_, h->stream));
@@ -1155,7 +1319,7 @@ int mgn_processor_steps(mgn_handle* h, float* v, float* e, int32_t nsteps) {
 }
 
 // ---- halo ------------------------------------------------------------------------------------------
-int mgn_halo_bytes_per_row(const mgn_handle* h) { return h ? h->cfg.L * 4 : MGN_E_ARG; }
+int mgn_halo_bytes_per_row(const mgn_handle* h) { return h ? h->cfg.L * (h->cfg.dtype == MGN_BF16 ? 2 : 4) : MGN_E_ARG; }
 
 int mgn_halo_pack(mgn_handle* h, void* send_dev) {
     if (int rc = need(h, false, true)) return rc;
@@ -1163,6 +1327,10 @@ int mgn_halo_pack(mgn_handle* h, void* send_dev) {
     if (rows == 0) return MGN_OK;
     if (!send_dev) return fail(h, MGN_E_ARG, "mgn_halo_pack: null buffer");
     ProfScope ps(h, F_HALO);
+    if (is_bf16(h)) {
+        HIPCHK(h, launch_gather_rows16(h->bP.as<uint16_t>(), h->d_send_idx.as<int32_t>(), reinterpret_cast<uint16_t*>(send_dev), rows, h->stream));
+        return MGN_OK;
+    }
     HIPCHK(h, launch_gather_rows(h->P.as<float>(), h->d_send_idx.as<int32_t>(), reinterpret_cast<float*>(send_dev), rows, h->cfg.L, h->stream));
     return MGN_OK;
 }
@@ -1173,6 +1341,11 @@ int mgn_halo_unpack(mgn_handle* h, const void* recv_dev) {
     if (g.n_halo == 0) return MGN_OK;
     if (!recv_dev) return fail(h, MGN_E_ARG, "mgn_halo_unpack: null buffer");
     ProfScope ps(h, F_HALO);
+    if (is_bf16(h)) {
+        HIPCHK(h, hipMemcpyAsync(h->bP.as<uint16_t>() + (size_t)g.n_own * h->cfg.L, recv_dev, (size_t)g.n_halo * h->cfg.L * 2,
+                                 hipMemcpyDeviceToDevice, h->stream));
+        return MGN_OK;
+    }
     HIPCHK(h, hipMemcpyAsync(h->P.as<float>() + (size_t)g.n_own * h->cfg.L, recv_dev, (size_t)g.n_halo * h->cfg.L * 4,
                              hipMemcpyDeviceToDevice, h->stream));
     return MGN_OK;

@@ -35,9 +35,9 @@ def _c32(a, shape=None):
 class Engine:
     """One engine handle == one mesh partition on one GPU (rank/nranks select the partition)."""
 
-    def __init__(self, Fn, Fe, O, L=128, hidden_layers=2, mps=15, rank=0, nranks=1, device=-1):
+    def __init__(self, Fn, Fe, O, L=128, hidden_layers=2, mps=15, rank=0, nranks=1, device=-1, dtype="f32"):
         self.lib = _capi.load()
-        self.cfg = MgnConfig(Fn, Fe, O, L, hidden_layers, mps, 0, rank, nranks, device)
+        self.cfg = MgnConfig(Fn, Fe, O, L, hidden_layers, mps, {"f32": 0, "bf16": 1}[dtype], rank, nranks, device)
         self.h = C.c_void_p()
         rc = self.lib.mgn_create(C.byref(self.cfg), C.byref(self.h))
         if rc != 0:
@@ -269,7 +269,8 @@ class Engine:
 
     @property
     def halo_row_floats(self):
-        return self.cfg.L
+        """width of one halo row in 4-byte units (exchange buffers are float32 tensors; bf16 rows are 64 wide)"""
+        return int(self.lib.mgn_halo_bytes_per_row(self.h)) // 4
 
     def halo_pack(self, send_ptr):
         self._chk(self.lib.mgn_halo_pack(self.h, C.c_void_p(send_ptr)))
