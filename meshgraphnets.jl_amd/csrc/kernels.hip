@@ -1064,7 +1064,10 @@ DEVINL void copy_to_lds16(uint16_t* dst, const uint16_t* __restrict__ src, int n
     for (int i = threadIdx.x; i < n / 8; i += blockDim.x) d4[i] = s4[i];
 }
 
-__global__ __launch_bounds__(512, 2) void k_edge_bf16(const BfEdgeArgs a) {
+#ifndef MGN_BF_WAVES
+#define MGN_BF_WAVES 12   // waves per block of the bf16 edge kernel: 3 per SIMD (<= 168 VGPRs)
+#endif
+__global__ __launch_bounds__(MGN_BF_WAVES * 64, MGN_BF_WAVES / 4) void k_edge_bf16(const BfEdgeArgs a) {
     constexpr int L = 128;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     uint16_t* wl = reinterpret_cast<uint16_t*>(smem);
@@ -1087,7 +1090,7 @@ __global__ __launch_bounds__(512, 2) void k_edge_bf16(const BfEdgeArgs a) {
         const bool valid = ix.r >= 0;
         const int r = valid ? ix.r : 0;
         bf16x8 x[8], in[8];
-        f32x16 acc[4], y[4];
+        f32x16 acc[4];   // ONE fp32 accumulator array: the packed copy `in` is the next layer's operand
         bf16x8* etile = bf_tile_ptr(a.Elat, tile, lane);
         bf_load(x, etile, BF_STRIDE_TILE);
         zero_frag<4>(acc);
@@ -1098,19 +1101,18 @@ __global__ __launch_bounds__(512, 2) void k_edge_bf16(const BfEdgeArgs a) {
         bf_chunk(acc, x, w1, lane);                              // layer 1 (edge part; P, Q, b1 preloaded)
         relu_frag<4>(acc);
         bf_pack(in, acc);
-        tab_frag<4>(y, tb + T_B2 * L, h);
-        bf_chunk(y, in, w2, lane);                               // layer 2
-        relu_frag<4>(y);
-        bf_pack(in, y);
+        tab_frag<4>(acc, tb + T_B2 * L, h);
+        bf_chunk(acc, in, w2, lane);                             // layer 2
+        relu_frag<4>(acc);
+        bf_pack(in, acc);
         tab_frag<4>(acc, tb + T_B3 * L, h);
         bf_chunk(acc, in, w3, lane);                             // layer 3
         layer_norm_frag<4>(acc, tb + T_GAMMA * L, tb + T_BETA * L, h);   // acc = e' (fp32)
         // residual in fp32, stored as bf16
-        zero_frag<4>(y);
-        bf_unpack_add(y, x);
 #pragma unroll
-        for (int t = 0; t < 4; ++t) y[t] += acc[t];
-        bf_pack(in, y);
+        for (int s = 0; s < 8; ++s)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) in[s][j] = (__bf16)((float)x[s][j] + acc[s >> 1][8 * (s & 1) + j]);
         if (valid) bf_store(etile, BF_STRIDE_TILE, in);
         // segmented sum of e' (fp32) over runs of equal receiver
         const int reff = valid ? r : (-4 - c);
@@ -1558,7 +1560,9 @@ static LaunchCfg bf_launch(int ntiles, int nchunks) {
 }
 hipError_t launch_edge_bf16(const BfEdgeArgs& a, hipStream_t s) {
     if (a.ntiles <= 0) return hipSuccess;
-    return launch_k(k_edge_bf16, a, bf_launch(a.ntiles, 3), s);
+    LaunchCfg lc = bf_launch(a.ntiles, 3);
+    if (lc.threads == 512) lc.threads = MGN_BF_WAVES * 64;   // large launch: more waves per SIMD hide the memory phases
+    return launch_k(k_edge_bf16, a, lc, s);
 }
 hipError_t launch_node_bf16(const BfNodeArgs& a, hipStream_t s) {
     if (a.ntiles <= 0) return hipSuccess;

@@ -6,9 +6,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 names = [a for a in sys.argv[1:] if not a.startswith("--")]
 rounds = 3
 nx = 1000
+dtype = "f32"
 for i, a in enumerate(sys.argv):
     if a == "--rounds": rounds = int(sys.argv[i + 1]); names.remove(sys.argv[i + 1])
     if a == "--nx": nx = int(sys.argv[i + 1]); names.remove(sys.argv[i + 1])
+    if a == "--dtype": dtype = sys.argv[i + 1]; names.remove(sys.argv[i + 1])
 res = {n: [] for n in names}
 for r in range(rounds):
     for n in names:
@@ -16,7 +18,7 @@ for r in range(rounds):
         if n != "default":
             env["MGN_LIB_PATH"] = os.path.join(ROOT, "meshgraphnets.jl_amd", "lib", "variants", n + ".so")
         out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--nx", str(nx),
-                              "--no-cpu-baseline", "--no-secondary"], env=env, capture_output=True, text=True).stdout
+                              "--no-cpu-baseline", "--no-secondary", "--dtype", dtype], env=env, capture_output=True, text=True).stdout
         line = [l for l in out.splitlines() if l.startswith("{")]
         if not line:
             print(n, "FAILED", out[-300:]); continue
