@@ -124,6 +124,23 @@ int mgn_forward(mgn_handle* h, const float* nf, const float* ef, float* out);
 int mgn_ode_step(mgn_handle* h, const float* x, const float* node_type_onehot, const float* ef_raw,
                  const float* val_mask, float* dxdt);
 
+/* Static per-trajectory inputs of the RHS, set ONCE (like create_base_graph's outputs, reference src/graph.jl:54):
+ * node_type_onehot [N][Fn-O], ef_raw [E][Fe], val_mask [N] or NULL.  They are uploaded once, the edge encoder runs
+ * once and its output is cached; afterwards mgn_ode_step may be called with node_type_onehot = ef_raw = val_mask =
+ * NULL and only moves the O x N state per call.  Invalidated by mgn_set_params / mgn_set_norms / mgn_set_graph. */
+int mgn_set_static(mgn_handle* h, const float* node_type_onehot, const float* ef_raw, const float* val_mask);
+
+/* ---- graph prologue helpers (GraphNetCore utilities used at reference src/graph.jl:26-52) -------
+ * Scalable replacements for the reference's per-edge host loops (which cannot build a 6 M-edge graph).
+ * No handle, no GPU needed.
+ * mgn_triangles_to_edges: cells [C][3] (any index base) -> unique undirected edges, returned two-way
+ *   (senders = [a;b], receivers = [b;a], a = max, b = min) in first-occurrence order like the reference.
+ *   Call with senders = receivers = NULL to get the count; *n_directed receives 2 x (unique undirected edges).
+ * mgn_edge_features: ef[e] = [pos[s]-pos[r] ; ||pos[s]-pos[r]||]  (src/graph.jl:35-36,49-52), ef is [E][dim+1]. */
+int mgn_triangles_to_edges(const int32_t* cells, int64_t n_cells, int32_t* senders, int32_t* receivers, int64_t* n_directed);
+int mgn_edge_features(const float* mesh_pos, int32_t pos_dim, const int32_t* senders, const int32_t* receivers,
+                      int64_t E, int32_t index_base, float* ef);
+
 /* ---- native rollout driver: the whole `rollout` of reference src/solve.jl:42-68 on the device:
  * ODEProblem(ode_func_eval, x0, (t0, t1), ...) solved with fixed-step Euler (`adaptive = false, dt = dt`) or an
  * adaptive Tsit5 (own tableau + PI step controller, tstops = saveat = t0 + i*saves_dt), the right-hand side being

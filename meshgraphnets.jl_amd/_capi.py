@@ -59,6 +59,9 @@ PROTOTYPES = {
     "mgn_boundary_count": (C.c_int, [_H, _i32p]),
     "mgn_forward": (C.c_int, [_H, _f32p, _f32p, _f32p]),
     "mgn_ode_step": (C.c_int, [_H, _f32p, _f32p, _f32p, _f32p, _f32p]),
+    "mgn_set_static": (C.c_int, [_H, _f32p, _f32p, _f32p]),
+    "mgn_triangles_to_edges": (C.c_int, [_i32p, C.c_int64, _i32p, _i32p, _i64p]),
+    "mgn_edge_features": (C.c_int, [_f32p, C.c_int32, _i32p, _i32p, C.c_int64, C.c_int32, _f32p]),
     "mgn_rollout": (C.c_int, [_H, C.POINTER(MgnRolloutDesc)]),
     "mgn_processor_steps": (C.c_int, [_H, _f32p, _f32p, C.c_int32]),
     "mgn_latents_import": (C.c_int, [_H, _f32p, _f32p]),

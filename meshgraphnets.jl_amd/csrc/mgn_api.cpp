@@ -96,6 +96,9 @@ struct mgn_engine {
     DevBuf wbf, bV, bP, bQ, bElat, bAGG, bCARRY;
     struct BfStepOff { size_t e_ch[3], n_ch[6]; };
     std::vector<BfStepOff> bsoff;
+    // static per-trajectory RHS inputs (mgn_set_static): cached encoded edge latents
+    bool have_static = false;
+    DevBuf elat0;
     DevBuf d_stamps;  // diagnostic builds only
     DevBuf ode;       // native rollout: state, stages, frames, saves, Elat0
     const float* srcA_override = nullptr;  // rollout: encoder reads the node state from here instead of d_nfA
@@ -604,6 +607,7 @@ int mgn_set_params(mgn_handle* h, const float* packed, size_t n) {
     }
     HIPCHK(h, hipStreamSynchronize(h->stream));
     drop_graph(h);
+    h->have_static = false;
     HIPCHK(h, h->wfrag.ensure(f.size() * 4));
     HIPCHK(h, hipMemcpy(h->wfrag.p, f.data(), f.size() * 4, hipMemcpyHostToDevice));
     h->have_params = true;
@@ -635,6 +639,7 @@ int mgn_set_norms(mgn_handle* h, const float* ns, const float* nsh, const float*
     HIPCHK(h, hipStreamSynchronize(h->stream));
     HIPCHK(h, h->norms.ensure(v.size() * 4));
     HIPCHK(h, hipMemcpy(h->norms.p, v.data(), v.size() * 4, hipMemcpyHostToDevice));
+    h->have_static = false;
     h->have_nnorm = ns != nullptr;
     h->have_enorm = es != nullptr;
     h->have_onorm = os != nullptr;
@@ -646,6 +651,7 @@ int mgn_set_graph(mgn_handle* h, int32_t N, int64_t E, const int32_t* senders, c
     if (!h) return MGN_E_ARG;
     if (index_base != 0 && index_base != 1) return fail(h, MGN_E_ARG, "mgn_set_graph: index_base must be 0 or 1");
     h->have_graph = false;
+    h->have_static = false;
     if (!h->host_only) { (void)hipStreamSynchronize(h->stream); drop_graph(h); }
     const std::string why = build_local_graph(N, E, senders, receivers, index_base, mesh_pos, pos_dim, h->cfg.rank, h->cfg.nranks, h->g);
     if (!why.empty()) return fail(h, MGN_E_ARG, "mgn_set_graph: %s", why.c_str());
@@ -753,6 +759,7 @@ static int upload_inputs(mgn_handle* h, const float* a, int wa, const float* b, 
 
 int mgn_fwd_upload(mgn_handle* h, const float* nf, const float* ef) {
     if (int rc = need(h, false, true)) return rc;
+    h->have_static = false;
     if (!nf || (!ef && h->g.E > 0)) return fail(h, MGN_E_ARG, "mgn_fwd_upload: null input");
     return upload_inputs(h, nf, h->cfg.Fn, nullptr, 0, ef);
 }
@@ -942,12 +949,58 @@ int mgn_forward(mgn_handle* h, const float* nf, const float* ef, float* out) {
     return mgn_fwd_download(h, out);
 }
 
+int mgn_set_static(mgn_handle* h, const float* onehot, const float* ef_raw, const float* val_mask) {
+    if (int rc = need(h, true, true)) return rc;
+    const mgn_config& c = h->cfg;
+    if (c.nranks != 1) return fail(h, MGN_E_STATE, "mgn_set_static drives one partition");
+    if (!ef_raw || (c.Fn > c.O && !onehot)) return fail(h, MGN_E_ARG, "mgn_set_static: null argument");
+    if (c.Fn < c.O) return fail(h, MGN_E_ARG, "mgn_set_static: Fn < O");
+    const LocalGraph& g = h->g;
+    h->have_static = false;
+    h->in_wa = c.O;
+    h->in_wb = c.Fn - c.O;
+    HIPCHK(h, h->d_nfA.ensure((size_t)g.N * c.O * 4));
+    if (h->in_wb > 0) {
+        HIPCHK(h, h->d_nfB.ensure((size_t)g.N * h->in_wb * 4));
+        HIPCHK(h, hipMemcpyAsync(h->d_nfB.p, onehot, (size_t)g.N * h->in_wb * 4, hipMemcpyHostToDevice, h->stream));
+    }
+    HIPCHK(h, h->d_ef.ensure((size_t)g.E * c.Fe * 4));
+    HIPCHK(h, hipMemcpyAsync(h->d_ef.p, ef_raw, (size_t)g.E * c.Fe * 4, hipMemcpyHostToDevice, h->stream));
+    h->have_mask = val_mask != nullptr;
+    if (val_mask) {
+        HIPCHK(h, h->d_mask.ensure((size_t)g.N * 4));
+        HIPCHK(h, hipMemcpyAsync(h->d_mask.p, val_mask, (size_t)g.N * 4, hipMemcpyHostToDevice, h->stream));
+    }
+    if (int rc = encode_impl(h, true, false, true)) return rc;       // edge encoder: once per trajectory
+    const bool bf = is_bf16(h);
+    const size_t eb = tile_floats(h->ntiles_e, c.L) * (bf ? 2 : 4);
+    HIPCHK(h, h->elat0.ensure(eb));
+    HIPCHK(h, hipMemcpyAsync(h->elat0.p, bf ? h->bElat.p : h->Elat.p, eb, hipMemcpyDeviceToDevice, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    h->have_static = true;
+    return MGN_OK;
+}
+
 int mgn_ode_step(mgn_handle* h, const float* x, const float* onehot, const float* ef_raw, const float* val_mask, float* dxdt) {
     if (int rc = need(h, true, true)) return rc;
     const mgn_config& c = h->cfg;
     if (h->cfg.nranks != 1) return fail(h, MGN_E_STATE, "mgn_ode_step drives one partition");
-    if (!x || !dxdt || (c.Fn > c.O && !onehot)) return fail(h, MGN_E_ARG, "mgn_ode_step: null argument");
+    if (!x || !dxdt) return fail(h, MGN_E_ARG, "mgn_ode_step: null argument");
     if (c.Fn < c.O) return fail(h, MGN_E_ARG, "mgn_ode_step: Fn < O");
+    if (!onehot && !ef_raw && !val_mask) {
+        // fast path: static inputs and encoded edges are resident (mgn_set_static); only the state moves
+        if (!h->have_static) return fail(h, MGN_E_STATE, "mgn_ode_step without static inputs: call mgn_set_static first or pass them");
+        HIPCHK(h, hipMemcpyAsync(h->d_nfA.p, x, (size_t)h->g.N * c.O * 4, hipMemcpyHostToDevice, h->stream));
+        if (int rc = encode_impl(h, true, true, false)) return rc;
+        const bool bf = is_bf16(h);
+        const size_t eb = tile_floats(h->ntiles_e, c.L) * (bf ? 2 : 4);
+        HIPCHK(h, hipMemcpyAsync(bf ? h->bElat.p : h->Elat.p, h->elat0.p, eb, hipMemcpyDeviceToDevice, h->stream));
+        if (int rc = run_processor(h, c.mps)) return rc;
+        if (int rc = decode_impl(h, true)) return rc;
+        return mgn_fwd_download(h, dxdt);
+    }
+    if (!ef_raw || (c.Fn > c.O && !onehot)) return fail(h, MGN_E_ARG, "mgn_ode_step: null argument");
+    h->have_static = false;   // the one-shot path overwrites the resident inputs
     if (int rc = upload_inputs(h, x, c.O, onehot, c.Fn - c.O, ef_raw)) return rc;
     h->have_mask = val_mask != nullptr;
     if (val_mask) {
@@ -1040,6 +1093,7 @@ int mgn_rollout(mgn_handle* h, mgn_rollout_desc* d) {
     if ((d->inflow_mask != nullptr) != (d->inflow_data != nullptr)) return fail(h, MGN_E_ARG, "mgn_rollout: inflow mask and data go together");
     if (d->solver == 1 && (d->abstol <= 0.f || d->reltol <= 0.f)) return fail(h, MGN_E_ARG, "mgn_rollout: tolerances must be > 0");
     const LocalGraph& g = h->g;
+    h->have_static = false;
     Rollout R;
     R.h = h;
     R.d = d;
@@ -1354,6 +1408,53 @@ int mgn_halo_unpack(mgn_handle* h, const void* recv_dev) {
 // Process-wide kernel-path override for tests (not part of the public header): 0 auto, 1 LDS-resident persistent
 // kernels, 2 all-streaming, 3 cooperative 4-wave tiles.  Returns the previous value.
 int mgn_debug_kernel_path(int path) { return set_kernel_path(path); }
+
+// ---- graph prologue helpers (N3): host code, no handle ------------------------------------------------------
+int mgn_triangles_to_edges(const int32_t* cells, int64_t n_cells, int32_t* senders, int32_t* receivers, int64_t* n_directed) {
+    if (!cells || n_cells < 0 || !n_directed) return MGN_E_ARG;
+    // packed (max, min) key with the first-occurrence position, sort, unique, restore first-occurrence order
+    struct K { uint64_t key; int64_t first; };
+    std::vector<K> v((size_t)3 * n_cells);
+    for (int64_t cidx = 0; cidx < n_cells; ++cidx) {
+        const int32_t* t = cells + 3 * cidx;
+        const int32_t pa[3] = {t[0], t[1], t[2]}, pb[3] = {t[1], t[2], t[0]};
+        for (int e = 0; e < 3; ++e) {     // reference order: all (0,1) edges, then (1,2), then (2,0)
+            const uint32_t hi = (uint32_t)(pa[e] > pb[e] ? pa[e] : pb[e]), lo = (uint32_t)(pa[e] > pb[e] ? pb[e] : pa[e]);
+            v[(size_t)e * n_cells + cidx] = {((uint64_t)hi << 32) | lo, (int64_t)e * n_cells + cidx};
+        }
+    }
+    std::sort(v.begin(), v.end(), [](const K& x, const K& y) { return x.key < y.key || (x.key == y.key && x.first < y.first); });
+    size_t m = 0;
+    for (size_t i = 0; i < v.size(); ++i)
+        if (i == 0 || v[i].key != v[i - 1].key) v[m++] = v[i];
+    v.resize(m);
+    *n_directed = (int64_t)(2 * m);
+    if (!senders || !receivers) return MGN_OK;
+    std::sort(v.begin(), v.end(), [](const K& x, const K& y) { return x.first < y.first; });
+    for (size_t i = 0; i < m; ++i) {
+        const int32_t hi = (int32_t)(v[i].key >> 32), lo = (int32_t)(v[i].key & 0xFFFFFFFFu);
+        senders[i] = hi; receivers[i] = lo;
+        senders[m + i] = lo; receivers[m + i] = hi;
+    }
+    return MGN_OK;
+}
+
+int mgn_edge_features(const float* pos, int32_t dim, const int32_t* senders, const int32_t* receivers, int64_t E,
+                      int32_t index_base, float* ef) {
+    if (!pos || dim < 1 || dim > 8 || (E > 0 && (!senders || !receivers || !ef)) || E < 0) return MGN_E_ARG;
+    for (int64_t i = 0; i < E; ++i) {
+        const float* ps = pos + (size_t)(senders[i] - index_base) * dim;
+        const float* pr = pos + (size_t)(receivers[i] - index_base) * dim;
+        float* o = ef + (size_t)i * (dim + 1);
+        float n2 = 0.f;
+        for (int d = 0; d < dim; ++d) {
+            o[d] = ps[d] - pr[d];
+            n2 += o[d] * o[d];
+        }
+        o[dim] = std::sqrt(n2);
+    }
+    return MGN_OK;
+}
 
 // ---- diagnostics (not part of the public header; meaningful only with -DMGN_DIAG_STAMPS) -----------------
 int mgn_debug_edge_stamps(mgn_handle* h, int32_t k, unsigned long long* out /* [4*8*24*8] */) {

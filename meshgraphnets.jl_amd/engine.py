@@ -171,9 +171,22 @@ class Engine:
         self._chk(self.lib.mgn_forward(self.h, f32(nf), f32(ef), f32(out)))
         return out
 
-    def ode_step(self, x, node_type_onehot, ef_raw, val_mask=None):
+    def set_static(self, node_type_onehot, ef_raw, val_mask=None):
+        """Once per trajectory: static RHS inputs become device-resident and the edge encoder runs once; afterwards
+        ode_step(x) only moves the state."""
+        O, Fn = self.cfg.O, self.cfg.Fn
+        oh = _c32(node_type_onehot, (self.N, Fn - O)) if Fn > O else None
+        ef = _c32(ef_raw, (self.E, self.cfg.Fe))
+        vm = _c32(val_mask, (self.N,)) if val_mask is not None else None
+        self._chk(self.lib.mgn_set_static(self.h, f32(oh), f32(ef), f32(vm)))
+
+    def ode_step(self, x, node_type_onehot=None, ef_raw=None, val_mask=None):
         O, Fn = self.cfg.O, self.cfg.Fn
         x = _c32(x, (self.N, O))
+        if node_type_onehot is None and ef_raw is None and val_mask is None:
+            out = np.zeros((self.N, O), np.float32)
+            self._chk(self.lib.mgn_ode_step(self.h, f32(x), None, None, None, f32(out)))
+            return out
         oh = _c32(node_type_onehot, (self.N, Fn - O)) if Fn > O else None
         ef = _c32(ef_raw, (self.E, self.cfg.Fe))
         vm = _c32(val_mask, (self.N,)) if val_mask is not None else None
@@ -288,6 +301,35 @@ class Engine:
         self._chk(self.lib.mgn_profile_read(self.h, ms, cnt))
         names = ["edge_step", "node_step", "encode", "decode", "halo"]
         return {n: dict(avg_ms=ms[i], count=cnt[i]) for i, n in enumerate(names)}
+
+
+def triangles_to_edges_native(cells):
+    """GraphNetCore.triangles_to_edges at scale (C++ sort/unique on packed keys): returns (senders, receivers)."""
+    lib = _capi.load()
+    cells = np.ascontiguousarray(cells, dtype=np.int32)
+    if cells.ndim != 2 or cells.shape[1] != 3:
+        raise ValueError("DimensionMismatch: cells must be [C][3]")
+    n = C.c_int64()
+    rc = lib.mgn_triangles_to_edges(i32(cells), cells.shape[0], None, None, C.byref(n))
+    if rc != 0:
+        raise MgnError(rc, "mgn_triangles_to_edges")
+    s, r = np.empty(n.value, np.int32), np.empty(n.value, np.int32)
+    rc = lib.mgn_triangles_to_edges(i32(cells), cells.shape[0], i32(s), i32(r), C.byref(n))
+    if rc != 0:
+        raise MgnError(rc, "mgn_triangles_to_edges")
+    return s, r
+
+
+def edge_features_native(mesh_pos, senders, receivers, index_base=0):
+    lib = _capi.load()
+    pos = _c32(mesh_pos)
+    s = np.ascontiguousarray(senders, dtype=np.int32)
+    r = np.ascontiguousarray(receivers, dtype=np.int32)
+    ef = np.empty((s.size, pos.shape[1] + 1), np.float32)
+    rc = lib.mgn_edge_features(f32(pos), pos.shape[1], i32(s), i32(r), s.size, index_base, f32(ef))
+    if rc != 0:
+        raise MgnError(rc, "mgn_edge_features")
+    return ef
 
 
 # ==================================================================================================

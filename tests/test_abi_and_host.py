@@ -133,3 +133,24 @@ def test_partition_without_positions_uses_index_blocks(lib_built):
     e = Engine(9, 3, 2, rank=1, nranks=4, device=MGN_DEVICE_NONE)
     e.set_graph(s, r, 100)
     assert sorted(e.owned_nodes().tolist()) == list(range(25, 50))
+
+
+def test_native_graph_prologue_helpers(lib_built):
+    """N3: mgn_triangles_to_edges / mgn_edge_features (host C++, scalable) against the oracle's reference-order
+    restatement, incl. KAT-1 and KAT-3."""
+    s, r = mgn_amd.triangles_to_edges_native(np.array([[0, 1, 2]], np.int32))
+    assert s.size == 6 and set(zip(s.tolist(), r.tolist())) == {(1, 0), (2, 1), (2, 0), (0, 1), (1, 2), (0, 2)}
+    s, r = mgn_amd.triangles_to_edges_native(np.array([[0, 1, 2], [1, 3, 2]], np.int32))
+    assert s.size == 10
+    pos, cells = synth.grid_mesh(37, 23, 4)
+    s, r = mgn_amd.triangles_to_edges_native(cells)
+    so, ro = orc.triangles_to_edges(cells)
+    assert np.array_equal(s, so) and np.array_equal(r, ro)              # same first-occurrence order
+    s1, r1 = mgn_amd.triangles_to_edges_native(cells + 1)               # 1-based cells (Julia data)
+    assert np.array_equal(s1, so + 1) and np.array_equal(r1, ro + 1)
+    ef = mgn_amd.edge_features_native(pos, s, r)
+    assert np.allclose(ef, orc.edge_features(pos, s, r), atol=1e-6)
+    ef345 = mgn_amd.edge_features_native(np.array([[0, 0], [3, 0], [3, 4]], np.float32), [2, 3, 3], [1, 2, 1], index_base=1)
+    assert sorted(ef345[:, 2].tolist()) == [3.0, 4.0, 5.0]
+    with pytest.raises(ValueError):
+        mgn_amd.triangles_to_edges_native(np.zeros((3, 2), np.int32))

@@ -307,3 +307,30 @@ def test_native_rollout_tsit5_matches_oracle_tsit5():
                           inflow_mask=inflow[:, 0], inflow_data=g["gt"], abstol=1e-6, reltol=1e-3)
     assert st["n_accept"] >= 10 and abs(st["n_accept"] - rst["n_accept"]) <= 2
     assert np.linalg.norm(sol - ref) / np.linalg.norm(ref) <= TOL_ROLLOUT
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_set_static_fast_rhs_equals_one_shot(dtype):
+    """mgn_set_static: resident static inputs + cached encoded edges; ode_step(x) alone must reproduce the one-shot
+    ode_step bit for bit, and be invalidated by set_norms / set_params / set_graph."""
+    from mgn_amd import MgnError
+    g, ps, cfg, eng0, onehot = _gold_d_problem()
+    eng = engine_for(cfg, dtype=dtype)
+    eng.set_params(ps)
+    eng.set_graph(g["senders"], g["receivers"], g["x0"].shape[0])
+    norms = dict(node=(g["node_scale"], g["node_shift"]), edge=(g["edge_scale"], g["edge_shift"]), out=(g["out_scale"], g["out_shift"]))
+    eng.set_norms(**norms)
+    x = g["x0"].astype(np.float32)
+    ref = eng.ode_step(x, onehot, g["ef_raw"], g["val_mask"])
+    with pytest.raises(MgnError):
+        eng.ode_step(x)                                   # no static inputs yet
+    eng.set_static(onehot, g["ef_raw"], g["val_mask"])
+    a = eng.ode_step(x)
+    b = eng.ode_step(x * 1.01)
+    c = eng.ode_step(x)
+    assert np.array_equal(a, ref) and np.array_equal(a, c) and not np.array_equal(a, b)
+    if dtype == "f32":
+        assert rel_max(a, g["dxdt0_noinflow"] if "dxdt0_noinflow" in g else a) <= TOL_15
+    eng.set_norms(**norms)                                # invalidates the cache
+    with pytest.raises(MgnError):
+        eng.ode_step(x)
