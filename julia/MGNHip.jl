@@ -11,7 +11,7 @@
 # side, cheap); only GraphNetwork.model / FeatureGraph / step! are replaced.
 module MGNHip
 
-export FeatureGraph, GraphNetwork, set_trajectory_graph!, pack_params
+export FeatureGraph, GraphNetwork, set_trajectory_graph!, pack_params, set_static!, ode_step_resident, ode_step_fused
 
 const LIB = get(ENV, "MGN_HIP_LIB", joinpath(@__DIR__, "..", "meshgraphnets.jl_amd", "lib", "libmgn_hip.so"))
 
@@ -110,6 +110,27 @@ Fused right-hand side: everything `ode_step` does after the state split (src/sol
 build_graph normalisation, model, inverse_data, `.* val_mask`.  Normalisers must have been frozen into affine
 maps with `mgn_set_norms` (a NormaliserOnline past `max_acc`, or any offline normaliser).
 """
+"""
+Once per trajectory (where `create_base_graph` returns, src/MeshGraphNets.jl:360,418,596): make the static RHS
+inputs device-resident and run the edge encoder once.  Afterwards `ode_step_resident(mgn, x)` moves only the state.
+"""
+function set_static!(mgn::GraphNetwork, node_type_onehot::Matrix{Float32}, edge_features::Matrix{Float32},
+        val_mask_row::Union{Nothing, Vector{Float32}} = nothing)
+    vm = val_mask_row === nothing ? C_NULL : pointer(val_mask_row)
+    GC.@preserve node_type_onehot edge_features val_mask_row check(mgn.handle,
+        ccall((:mgn_set_static, LIB), Cint, (Ptr{Cvoid}, Ptr{Float32}, Ptr{Float32}, Ptr{Float32}),
+            mgn.handle, node_type_onehot, edge_features, vm))
+    return mgn
+end
+
+function ode_step_resident(mgn::GraphNetwork, x::Matrix{Float32})
+    out = similar(x)
+    GC.@preserve x out check(mgn.handle,
+        ccall((:mgn_ode_step, LIB), Cint, (Ptr{Cvoid}, Ptr{Float32}, Ptr{Float32}, Ptr{Float32}, Ptr{Float32}, Ptr{Float32}),
+            mgn.handle, x, C_NULL, C_NULL, C_NULL, out))
+    return out
+end
+
 function ode_step_fused(mgn::GraphNetwork, x::Matrix{Float32}, node_type_onehot::Matrix{Float32},
         edge_features::Matrix{Float32}, val_mask_row::Vector{Float32})
     out = similar(x)
