@@ -106,11 +106,6 @@ function forward(mgn::GraphNetwork, graph::FeatureGraph, ps::Vector{Float32})
 end
 
 """
-Fused right-hand side: everything `ode_step` does after the state split (src/solve.jl:198-218) in one call --
-build_graph normalisation, model, inverse_data, `.* val_mask`.  Normalisers must have been frozen into affine
-maps with `mgn_set_norms` (a NormaliserOnline past `max_acc`, or any offline normaliser).
-"""
-"""
 Once per trajectory (where `create_base_graph` returns, src/MeshGraphNets.jl:360,418,596): make the static RHS
 inputs device-resident and run the edge encoder once.  Afterwards `ode_step_resident(mgn, x)` moves only the state.
 """
@@ -131,6 +126,11 @@ function ode_step_resident(mgn::GraphNetwork, x::Matrix{Float32})
     return out
 end
 
+"""
+Fused right-hand side: everything `ode_step` does after the state split (src/solve.jl:198-218) in one call --
+build_graph normalisation, model, inverse_data, `.* val_mask`.  Normalisers must have been frozen into affine
+maps with `mgn_set_norms` (a NormaliserOnline past `max_acc`, or any offline normaliser).
+"""
 function ode_step_fused(mgn::GraphNetwork, x::Matrix{Float32}, node_type_onehot::Matrix{Float32},
         edge_features::Matrix{Float32}, val_mask_row::Vector{Float32})
     out = similar(x)
