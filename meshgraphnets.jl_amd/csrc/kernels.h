@@ -132,6 +132,8 @@ hipError_t launch_enc_node(int L, const EncNodeArgs& a, hipStream_t s);
 hipError_t launch_enc_edge(int L, const EncEdgeArgs& a, hipStream_t s);
 hipError_t launch_decode(int L, const DecArgs& a, hipStream_t s);
 hipError_t launch_gather_rows(const float* src, const int32_t* idx, float* dst, int64_t rows, int L, hipStream_t s);
+hipError_t launch_rows_to_tiles(const float* src, const int64_t* gid64, const int32_t* gid32, float* dst, int64_t rows, int L, hipStream_t s);
+hipError_t launch_tiles_to_rows(const float* src, const int64_t* gid64, const int32_t* gid32, float* dst, int64_t rows, int L, hipStream_t s);
 hipError_t launch_randn_rows(float* dst, const int64_t* gid64, const int32_t* gid32, int64_t rows, int L,
                              uint64_t seed, hipStream_t s);
 int checksum_partials();  // doubles written by launch_checksum: (sum, sumsq) per block, to be added in order

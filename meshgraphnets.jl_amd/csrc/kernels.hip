@@ -612,8 +612,11 @@ __global__ __launch_bounds__(512, 2) void k_node_step(const NodeArgs a) {
 // ================================================================================================
 // P,Q projection alone (both of its chunks LDS-resident: no weight streaming).  chunk[4]=WP chunk[5]=WQ
 // ================================================================================================
+#ifndef MGN_PROJ_WAVES
+#define MGN_PROJ_WAVES 8
+#endif
 template <int NT, bool RES>
-__global__ __launch_bounds__(512, 2) void k_project(const NodeArgs a) {
+__global__ __launch_bounds__(MGN_PROJ_WAVES * 64, MGN_PROJ_WAVES / 4) void k_project(const NodeArgs a) {
     constexpr int L = 32 * NT, CH = 16 * NT * 64 * NT;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     if (RES) {
@@ -1292,6 +1295,31 @@ __global__ void k_gather_rows(const float* __restrict__ src, const int32_t* __re
     reinterpret_cast<f32x4*>(dst)[i] = reinterpret_cast<const f32x4*>(src)[(int64_t)idx[r] * L4 + q];
 }
 
+// caller-order row-major rows  <->  engine order, tile-major storage (mgn_latents_import / export on the device)
+// one thread per 16-byte piece of a local row: tile-major piece m of lane (c,h) <- row-major float4 index 2m+h
+__global__ void k_rows_to_tiles(const float* __restrict__ src, const int64_t* __restrict__ gid64, const int32_t* __restrict__ gid32,
+                                float* __restrict__ dst, int64_t rows, int L) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int pieces = L / 4;
+    if (i >= rows * pieces) return;
+    const int64_t r = i / pieces;
+    const int q = (int)(i - r * pieces), m = q >> 1, hh = q & 1;
+    const int64_t g = gid64 ? gid64[r] : (int64_t)gid32[r];
+    const f32x4 v = reinterpret_cast<const f32x4*>(src)[g * pieces + q];
+    reinterpret_cast<f32x4*>(dst)[(r / TILE) * (TILE * pieces) + (int64_t)m * 64 + 32 * hh + (r % TILE)] = v;
+}
+__global__ void k_tiles_to_rows(const float* __restrict__ src, const int64_t* __restrict__ gid64, const int32_t* __restrict__ gid32,
+                                float* __restrict__ dst, int64_t rows, int L) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int pieces = L / 4;
+    if (i >= rows * pieces) return;
+    const int64_t r = i / pieces;
+    const int q = (int)(i - r * pieces), m = q >> 1, hh = q & 1;
+    const int64_t g = gid64 ? gid64[r] : (int64_t)gid32[r];
+    reinterpret_cast<f32x4*>(dst)[g * pieces + q] =
+        reinterpret_cast<const f32x4*>(src)[(r / TILE) * (TILE * pieces) + (int64_t)m * 64 + 32 * hh + (r % TILE)];
+}
+
 DEVINL uint64_t splitmix64(uint64_t x) {
     x += 0x9E3779B97F4A7C15ull;
     x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
@@ -1544,7 +1572,10 @@ hipError_t launch_project(int L, const NodeArgs& a, hipStream_t s) {
         lc.lds = (size_t)T_COUNT * L * 4 + 64;
         return launch_k(k_project<4, false>, a, lc, s);
     }
-    if (L == 128) return launch_k(k_project<4, true>, a, lc, s);
+    if (L == 128) {
+        if (lc.threads == 512) lc.threads = MGN_PROJ_WAVES * 64;
+        return launch_k(k_project<4, true>, a, lc, s);
+    }
     if (L == 64) return launch_k(k_project<2, true>, a, lc, s);
     if (L == 32) return launch_k(k_project<1, true>, a, lc, s);
     return hipErrorInvalidValue;
@@ -1595,6 +1626,19 @@ hipError_t launch_gather_rows(const float* src, const int32_t* idx, float* dst, 
     if (rows <= 0) return hipSuccess;
     const int64_t n = rows * (L / 4);
     hipLaunchKernelGGL(k_gather_rows, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src, idx, dst, rows, L / 4);
+    return hipGetLastError();
+}
+
+hipError_t launch_rows_to_tiles(const float* src, const int64_t* gid64, const int32_t* gid32, float* dst, int64_t rows, int L, hipStream_t s) {
+    if (rows <= 0) return hipSuccess;
+    const int64_t n = rows * (L / 4);
+    hipLaunchKernelGGL(k_rows_to_tiles, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src, gid64, gid32, dst, rows, L);
+    return hipGetLastError();
+}
+hipError_t launch_tiles_to_rows(const float* src, const int64_t* gid64, const int32_t* gid32, float* dst, int64_t rows, int L, hipStream_t s) {
+    if (rows <= 0) return hipSuccess;
+    const int64_t n = rows * (L / 4);
+    hipLaunchKernelGGL(k_tiles_to_rows, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src, gid64, gid32, dst, rows, L);
     return hipGetLastError();
 }
 

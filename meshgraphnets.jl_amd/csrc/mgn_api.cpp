@@ -99,6 +99,7 @@ struct mgn_engine {
     // static per-trajectory RHS inputs (mgn_set_static): cached encoded edge latents
     bool have_static = false;
     DevBuf elat0;
+    DevBuf stage;     // device staging image of caller-order latents (import / export)
     DevBuf d_stamps;  // diagnostic builds only
     DevBuf ode;       // native rollout: state, stages, frames, saves, Elat0
     const float* srcA_override = nullptr;  // rollout: encoder reads the node state from here instead of d_nfA
@@ -1224,31 +1225,30 @@ int mgn_rollout(mgn_handle* h, mgn_rollout_desc* d) {
 }
 
 // ---- latents -------------------------------------------------------------------------------------
+// Host boundary of the latents: the caller's arrays travel over PCIe as they are (one contiguous copy each) and
+// the gather into engine order / tile-major storage runs on the device.
 int mgn_latents_import(mgn_handle* h, const float* v, const float* e) {
     if (int rc = need(h, false, true)) return rc;
     if (!v || (!e && h->g.e_local > 0)) return fail(h, MGN_E_ARG, "mgn_latents_import: null input");
     const LocalGraph& g = h->g;
     const int L = h->cfg.L;
-    std::vector<float> tv(tile_floats(h->ntiles_n, L), 0.f), te(tile_floats(h->ntiles_e, L), 0.f);
-    for (int32_t i = 0; i < g.n_own; ++i) {
-        const float* src = v + (size_t)g.own_gid[i] * L;
-        for (int f = 0; f < L; ++f) tv[tile_index(i, f, L)] = src[f];
+    const size_t vb = (size_t)g.N * L * 4, ebytes = (size_t)g.E * L * 4;
+    HIPCHK(h, h->stage.ensure(vb > ebytes ? vb : ebytes));
+    HIPCHK(h, hipMemcpyAsync(h->stage.p, v, vb, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, launch_rows_to_tiles(h->stage.as<float>(), nullptr, h->d_own_gid.as<int32_t>(), h->V.as<float>(), g.n_own, L, h->stream));
+    if (g.e_local > 0) {
+        HIPCHK(h, hipMemcpyAsync(h->stage.p, e, ebytes, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(h, launch_rows_to_tiles(h->stage.as<float>(), h->d_edge_gid.as<int64_t>(), nullptr, h->Elat.as<float>(), g.e_local, L, h->stream));
     }
-    for (int64_t i = 0; i < g.e_local; ++i) {
-        const float* src = e + (size_t)g.edge_gid[i] * L;
-        for (int f = 0; f < L; ++f) te[tile_index(i, f, L)] = src[f];
-    }
-    HIPCHK(h, hipStreamSynchronize(h->stream));
-    if (!tv.empty()) HIPCHK(h, hipMemcpy(h->V.p, tv.data(), tv.size() * 4, hipMemcpyHostToDevice));
-    if (!te.empty()) HIPCHK(h, hipMemcpy(h->Elat.p, te.data(), te.size() * 4, hipMemcpyHostToDevice));
     if (is_bf16(h)) {   // the processor state proper is the bf16 copy (rounded once, on the device)
         HIPCHK(h, launch_tile_f32_to_bf16(h->V.as<float>(), h->bV.as<uint16_t>(), h->ntiles_n, h->stream));
         HIPCHK(h, launch_tile_f32_to_bf16(h->Elat.as<float>(), h->bElat.as<uint16_t>(), h->ntiles_e, h->stream));
-        HIPCHK(h, hipStreamSynchronize(h->stream));
     }
+    HIPCHK(h, hipStreamSynchronize(h->stream));
     return MGN_OK;
 }
 
+// Writes the owned rows into the caller's GLOBAL-shaped arrays (other rows are left untouched).
 int mgn_latents_export(mgn_handle* h, float* v, float* e) {
     if (int rc = need(h, false, true)) return rc;
     const LocalGraph& g = h->g;
@@ -1257,22 +1257,20 @@ int mgn_latents_export(mgn_handle* h, float* v, float* e) {
         HIPCHK(h, launch_tile_bf16_to_f32(h->bV.as<uint16_t>(), h->V.as<float>(), h->ntiles_n, h->stream));
         HIPCHK(h, launch_tile_bf16_to_f32(h->bElat.as<uint16_t>(), h->Elat.as<float>(), h->ntiles_e, h->stream));
     }
-    HIPCHK(h, hipStreamSynchronize(h->stream));
+    const size_t vb = (size_t)g.N * L * 4, ebytes = (size_t)g.E * L * 4;
+    HIPCHK(h, h->stage.ensure(vb > ebytes ? vb : ebytes));
+    const bool whole = h->cfg.nranks == 1;   // single partition: every row is owned, the staging image is complete
     if (v) {
-        std::vector<float> tv(tile_floats(h->ntiles_n, L));
-        if (!tv.empty()) HIPCHK(h, hipMemcpy(tv.data(), h->V.p, tv.size() * 4, hipMemcpyDeviceToHost));
-        for (int32_t i = 0; i < g.n_own; ++i) {
-            float* dst = v + (size_t)g.own_gid[i] * L;
-            for (int f = 0; f < L; ++f) dst[f] = tv[tile_index(i, f, L)];
-        }
+        if (!whole) HIPCHK(h, hipMemcpyAsync(h->stage.p, v, vb, hipMemcpyHostToDevice, h->stream));   // keep foreign rows
+        HIPCHK(h, launch_tiles_to_rows(h->V.as<float>(), nullptr, h->d_own_gid.as<int32_t>(), h->stage.as<float>(), g.n_own, L, h->stream));
+        HIPCHK(h, hipMemcpyAsync(v, h->stage.p, vb, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
     }
-    if (e) {
-        std::vector<float> te(tile_floats(h->ntiles_e, L));
-        if (!te.empty()) HIPCHK(h, hipMemcpy(te.data(), h->Elat.p, te.size() * 4, hipMemcpyDeviceToHost));
-        for (int64_t i = 0; i < g.e_local; ++i) {
-            float* dst = e + (size_t)g.edge_gid[i] * L;
-            for (int f = 0; f < L; ++f) dst[f] = te[tile_index(i, f, L)];
-        }
+    if (e && g.E > 0) {
+        if (!whole) HIPCHK(h, hipMemcpyAsync(h->stage.p, e, ebytes, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(h, launch_tiles_to_rows(h->Elat.as<float>(), h->d_edge_gid.as<int64_t>(), nullptr, h->stage.as<float>(), g.e_local, L, h->stream));
+        HIPCHK(h, hipMemcpyAsync(e, h->stage.p, ebytes, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
     }
     return MGN_OK;
 }
