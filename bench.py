@@ -29,8 +29,9 @@ PEAK_F32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: dense f
 L, MPS, FN, FE, O = 128, 15, 9, 3, 2
 
 
-def glorot_params(seed=1234):
-    """Glorot-uniform W, zero b, gamma = 1, beta = 0 in MGN-spec packed order (include/mgn_hip.h)."""
+def glorot_params(seed=1234, Fn=None, Fe=None, O_=None, Fe2=None):
+    """Glorot-uniform W, zero b, gamma = 1, beta = 0 in MGN-spec packed order (include/mgn_hip.h).
+    Fe2: a second edge set (its encoder and per-step edge MLP; node MLP input 3L)."""
     import numpy as np
     rng = np.random.default_rng(seed)
     chunks = []
@@ -45,12 +46,16 @@ def glorot_params(seed=1234):
             chunks.append(np.ones(n_out, np.float32))
             chunks.append(np.zeros(n_out, np.float32))
 
-    mlp(FN, L, True)
-    mlp(FE, L, True)
+    mlp(Fn or FN, L, True)
+    mlp(Fe or FE, L, True)
+    if Fe2:
+        mlp(Fe2, L, True)
     for _ in range(MPS):
         mlp(3 * L, L, True)
-        mlp(2 * L, L, True)
-    mlp(L, O, False)
+        if Fe2:
+            mlp(3 * L, L, True)
+        mlp((3 if Fe2 else 2) * L, L, True)
+    mlp(L, O_ or O, False)
     return np.concatenate(chunks)
 
 
@@ -312,6 +317,31 @@ def main():
             out["secondary"]["rollout_100_saves"] = {"workload": "cfg-5 shaped: M-cyl, t in [0,1], saveat 0:0.01:1, random-init weights "
                                                      "(BASELINE.json configs[4]); native driver, host in/out included", **roll}
             eng2.close()
+            # cfg-3: flag_simple-shaped cloth, mesh + world edges (two edge sets), 15 steps, bf16 (and fp32 beside it)
+            mf = mgn_amd.synth.mesh_flag()
+            Nf, Ef, Ef2 = mf["mesh_pos"].shape[0], mf["s"].size, mf["s2"].size
+            psf = glorot_params(1234, 12, 7, 3, Fe2=4)
+            flag = {"workload": f"M-flag 40x40 folded cloth: N={Nf}, mesh E={Ef} (Fe=7), world E={Ef2} (Fe=4), L=128, 15 steps "
+                                "(BASELINE.json configs[2]); hipGraph replay, latents resident"}
+            for dt_name in ("bf16", "f32"):
+                eng3 = mgn_amd.Engine(12, 7, 3, L, 2, MPS, device=local_rank, dtype=dt_name, Fe2=4)
+                eng3.set_params(psf)
+                eng3.set_graph(mf["s"], mf["r"], Nf)
+                eng3.set_edge_set(1, mf["s2"], mf["r2"])
+                eng3.latents_randn(1234)
+                for _ in range(5):
+                    eng3.processor_steps_dev(MPS)
+                barrier_sync()
+                k3 = max(args.steps, 50)
+                t0 = time.perf_counter()
+                for _ in range(k3):
+                    eng3.processor_steps_dev(MPS)
+                barrier_sync()
+                dt3 = time.perf_counter() - t0
+                flag[dt_name] = {"us_per_processor_step": dt3 / (k3 * MPS) * 1e6, "edges_per_s": (Ef + Ef2) * MPS * k3 / dt3,
+                                 "nodes_per_s": Nf * MPS * k3 / dt3}
+                eng3.close()
+            out["secondary"]["flag_two_edge_sets"] = flag
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(ps)
         print(json.dumps(out), flush=True)

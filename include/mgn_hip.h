@@ -53,7 +53,12 @@ typedef struct mgn_config {
     int32_t rank;          /* this process's partition, 0 <= rank < nranks                        */
     int32_t nranks;        /* number of edge-cut partitions (1 = whole mesh on this GPU)          */
     int32_t device;        /* HIP device ordinal, -1 = current device, MGN_DEVICE_NONE = host-only handle */
+    int32_t n_edge_sets;   /* 0 or 1: the reference's single edge set (FeatureGraph, src/graph.jl:87-96);          */
+                           /* 2: mesh edges + world edges (MGN-spec "per edge set"; flag_simple-shaped, BASELINE cfg-3) */
+    int32_t Fe2;           /* edge input width of the second set (used when n_edge_sets == 2)                      */
 } mgn_config;
+
+#define MGN_MAX_EDGE_SETS 2
 
 /* A handle created with device == MGN_DEVICE_NONE owns no GPU state: only mgn_set_graph and the partition
  * introspection calls work on it (host logic: receiver sort, CSR, edge-cut partition, halo lists); every
@@ -97,6 +102,21 @@ int mgn_set_norms(mgn_handle* h, const float* node_scale, const float* node_shif
  * mesh_pos [N][pos_dim] is optional; it drives the geometric partition when nranks > 1.         */
 int mgn_set_graph(mgn_handle* h, int32_t N, int64_t E, const int32_t* senders, const int32_t* receivers,
                   int32_t index_base, const float* mesh_pos, int32_t pos_dim);
+
+/* Second edge set (n_edge_sets == 2): topology of set `set` (>= 1) over the same N nodes, after mgn_set_graph and
+ * as often as it changes (world edges are re-searched every step of a cloth rollout; the mesh set, the node
+ * partition and the node order stay).  Edges live with their receiver's owner like mesh edges; with nranks > 1
+ * the halo / send lists become the union over the sets, so query mgn_halo_* again afterwards.  E may be 0.
+ * The reference has one edge set; this is the MGN-spec extension SURVEY.md 8c defines (GOLD-C).                */
+int mgn_set_edge_set(mgn_handle* h, int32_t set, int64_t E, const int32_t* senders, const int32_t* receivers,
+                     int32_t index_base);
+/* Raw features [E_set][Fe2] of set >= 1 for the next mgn_forward / mgn_fwd_upload (which carry set 0's `ef`).
+ * No normaliser is applied to them (normalise on the host, or fold the affine map into the first layer).       */
+int mgn_set_edge_features(mgn_handle* h, int32_t set, const float* ef);
+int mgn_edge_set_info(const mgn_handle* h, int32_t set, int64_t* E, int64_t* e_local);
+/* Latents of edge set `set` (0 included), host GLOBAL arrays [E_set][L]; mgn_latents_import/export cover v and set 0. */
+int mgn_edge_latents_import(mgn_handle* h, int32_t set, const float* e);
+int mgn_edge_latents_export(mgn_handle* h, int32_t set, float* e);
 
 /* Partition introspection (nranks == 1: n_own = N, n_halo = 0, e_local = E). */
 int mgn_partition_info(const mgn_handle* h, int32_t* n_own, int32_t* n_halo, int64_t* e_local);

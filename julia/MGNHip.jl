@@ -18,6 +18,7 @@ const LIB = get(ENV, "MGN_HIP_LIB", joinpath(@__DIR__, "..", "meshgraphnets.jl_a
 struct MgnConfig            # mirrors `mgn_config` (include/mgn_hip.h)
     Fn::Int32; Fe::Int32; O::Int32; L::Int32; hidden_layers::Int32; mps::Int32
     dtype::Int32; rank::Int32; nranks::Int32; device::Int32
+    n_edge_sets::Int32; Fe2::Int32      # 1, 0: the reference's single edge set (src/graph.jl:87-96)
 end
 
 function check(h::Ptr{Cvoid}, rc::Cint)
@@ -54,7 +55,7 @@ mutable struct GraphNetwork
 end
 
 function GraphNetwork(quantities, dims, e_norm, n_norm, o_norm, outputs, mps, layer_size, hidden_layers, ps; device = -1)
-    cfg = MgnConfig(quantities, dims + 1, outputs, layer_size, hidden_layers, mps, 0, 0, 1, device)
+    cfg = MgnConfig(quantities, dims + 1, outputs, layer_size, hidden_layers, mps, 0, 0, 1, device, 1, 0)
     h = Ref{Ptr{Cvoid}}(C_NULL)
     rc = ccall((:mgn_create, LIB), Cint, (Ref{MgnConfig}, Ref{Ptr{Cvoid}}), cfg, h)
     rc == 0 || error(unsafe_string(ccall((:mgn_last_error, LIB), Cstring, (Ptr{Cvoid},), C_NULL)))

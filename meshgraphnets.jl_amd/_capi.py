@@ -18,7 +18,7 @@ STATUS_NAMES = {0: "MGN_OK", -1: "MGN_E_ARG", -2: "MGN_E_HIP", -3: "MGN_E_STATE"
 
 class MgnConfig(C.Structure):
     _fields_ = [(n, C.c_int32) for n in
-                ("Fn", "Fe", "O", "L", "hidden_layers", "mps", "dtype", "rank", "nranks", "device")]
+                ("Fn", "Fe", "O", "L", "hidden_layers", "mps", "dtype", "rank", "nranks", "device", "n_edge_sets", "Fe2")]
 
 
 class MgnRolloutDesc(C.Structure):
@@ -48,6 +48,11 @@ PROTOTYPES = {
     "mgn_get_params": (C.c_int, [_H, _f32p, C.c_size_t]),
     "mgn_set_norms": (C.c_int, [_H, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p]),
     "mgn_set_graph": (C.c_int, [_H, C.c_int32, C.c_int64, _i32p, _i32p, C.c_int32, _f32p, C.c_int32]),
+    "mgn_set_edge_set": (C.c_int, [_H, C.c_int32, C.c_int64, _i32p, _i32p, C.c_int32]),
+    "mgn_set_edge_features": (C.c_int, [_H, C.c_int32, _f32p]),
+    "mgn_edge_set_info": (C.c_int, [_H, C.c_int32, _i64p, _i64p]),
+    "mgn_edge_latents_import": (C.c_int, [_H, C.c_int32, _f32p]),
+    "mgn_edge_latents_export": (C.c_int, [_H, C.c_int32, _f32p]),
     "mgn_partition_info": (C.c_int, [_H, _i32p, _i32p, _i64p]),
     "mgn_owned_nodes": (C.c_int, [_H, _i32p]),
     "mgn_local_edges": (C.c_int, [_H, _i64p]),

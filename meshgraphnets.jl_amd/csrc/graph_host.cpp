@@ -57,22 +57,31 @@ void rcb_partition(int32_t N, const float* pos, int32_t pos_dim, int32_t parts, 
     rcb_rec(idx, 0, N, 0, parts, pos, pos_dim, owner);
 }
 
-std::string build_local_graph(int32_t N, int64_t E, const int32_t* senders, const int32_t* receivers, int32_t index_base,
-                              const float* pos, int32_t pos_dim, int32_t rank, int32_t nranks, LocalGraph& g) {
-    if (N < 0 || E < 0) return "negative N or E";
-    if (E > 0 && (!senders || !receivers)) return "null senders/receivers";
+std::string build_local_graph(int32_t N, int nsets, const EdgeList* sets, const float* pos, int32_t pos_dim,
+                              const int32_t* owner_in, int32_t rank, int32_t nranks, LocalGraph& g) {
+    if (N < 0) return "negative N";
+    if (nsets < 1 || nsets > MAX_EDGE_SETS) return "bad number of edge sets";
     if (nranks < 1 || rank < 0 || rank >= nranks) return "bad rank/nranks";
-    if (E >= ((int64_t)1 << 31)) return "E >= 2^31 not supported";
-    for (int64_t i = 0; i < E; ++i) {
-        const int64_t s = (int64_t)senders[i] - index_base, r = (int64_t)receivers[i] - index_base;
-        if (s < 0 || s >= N || r < 0 || r >= N) return "edge index out of range at edge " + std::to_string(i);
+    for (int k = 0; k < nsets; ++k) {
+        const EdgeList& es = sets[k];
+        if (es.E < 0) return "negative E";
+        if (es.E > 0 && (!es.senders || !es.receivers)) return "null senders/receivers";
+        if (es.E >= ((int64_t)1 << 31)) return "E >= 2^31 not supported";
+        for (int64_t i = 0; i < es.E; ++i) {
+            const int64_t s = (int64_t)es.senders[i] - es.index_base, r = (int64_t)es.receivers[i] - es.index_base;
+            if (s < 0 || s >= N || r < 0 || r >= N)
+                return "edge index out of range at edge " + std::to_string(i) + " of set " + std::to_string(k);
+        }
     }
+    std::vector<int32_t> owner_keep;
+    if (owner_in) owner_keep.assign(owner_in, owner_in + N);   // owner_in may alias g.owner
     g = LocalGraph();
     g.N = N;
-    g.E = E;
     g.rank = rank;
     g.nranks = nranks;
-    rcb_partition(N, pos, pos_dim, nranks, g.owner);
+    g.nsets = nsets;
+    if (owner_in) g.owner.swap(owner_keep);
+    else rcb_partition(N, pos, pos_dim, nranks, g.owner);
 
     // owned nodes: boundary nodes (senders of an edge received on another rank) first, then interior, each in
     // ascending global id.  Boundary-first lets the driver project the boundary tiles, start the halo exchange and
@@ -81,10 +90,11 @@ std::string build_local_graph(int32_t N, int64_t E, const int32_t* senders, cons
     {
         std::vector<uint8_t> is_bnd(N, 0);
         if (nranks > 1)
-            for (int64_t i = 0; i < E; ++i) {
-                const int32_t s = senders[i] - index_base, r = receivers[i] - index_base;
-                if (g.owner[s] == rank && g.owner[r] != rank) is_bnd[s] = 1;
-            }
+            for (int k = 0; k < nsets; ++k)
+                for (int64_t i = 0; i < sets[k].E; ++i) {
+                    const int32_t s = sets[k].senders[i] - sets[k].index_base, r = sets[k].receivers[i] - sets[k].index_base;
+                    if (g.owner[s] == rank && g.owner[r] != rank) is_bnd[s] = 1;
+                }
         for (int pass = 0; pass < 2; ++pass) {
             for (int32_t i = 0; i < N; ++i)
                 if (g.owner[i] == rank && (is_bnd[i] != 0) == (pass == 0)) {
@@ -96,26 +106,14 @@ std::string build_local_graph(int32_t N, int64_t E, const int32_t* senders, cons
     }
     g.n_own = (int32_t)g.own_gid.size();
 
-    // local edges = edges whose receiver is owned; count per receiver for the stable counting sort
-    g.rowptr.assign((size_t)g.n_own + 1, 0);
-    int64_t el = 0;
-    for (int64_t i = 0; i < E; ++i) {
-        const int32_t r = receivers[i] - index_base;
-        if (g.owner[r] == rank) {
-            ++g.rowptr[(size_t)g2l[r] + 1];
-            ++el;
-        }
-    }
-    g.e_local = el;
-    for (int32_t i = 0; i < g.n_own; ++i) g.rowptr[(size_t)i + 1] += g.rowptr[i];
-
-    // halo nodes: remote senders of local edges, grouped by owner rank then ascending gid
+    // halo nodes: remote senders of local edges (any set), grouped by owner rank then ascending gid
     {
         std::vector<uint8_t> is_halo(N, 0);
-        for (int64_t i = 0; i < E; ++i) {
-            const int32_t s = senders[i] - index_base, r = receivers[i] - index_base;
-            if (g.owner[r] == rank && g.owner[s] != rank) is_halo[s] = 1;
-        }
+        for (int k = 0; k < nsets; ++k)
+            for (int64_t i = 0; i < sets[k].E; ++i) {
+                const int32_t s = sets[k].senders[i] - sets[k].index_base, r = sets[k].receivers[i] - sets[k].index_base;
+                if (g.owner[r] == rank && g.owner[s] != rank) is_halo[s] = 1;
+            }
         g.recv_rows.assign(nranks, 0);
         for (int32_t i = 0; i < N; ++i)
             if (is_halo[i]) ++g.recv_rows[g.owner[i]];
@@ -132,20 +130,34 @@ std::string build_local_graph(int32_t N, int64_t E, const int32_t* senders, cons
             }
     }
 
-    // fill local edges in receiver-sorted, input-stable order
-    g.snd.assign(el, 0);
-    g.rcv.assign(el, 0);
-    g.edge_gid.assign(el, 0);
-    {
-        std::vector<int32_t> cur(g.rowptr.begin(), g.rowptr.end() - 1);
-        for (int64_t i = 0; i < E; ++i) {
-            const int32_t s = senders[i] - index_base, r = receivers[i] - index_base;
+    // per set: local edges = edges whose receiver is owned, in receiver-sorted, input-stable order (counting sort)
+    for (int k = 0; k < nsets; ++k) {
+        const EdgeList& es = sets[k];
+        EdgeTopo& t = g.set[k];
+        t.E = es.E;
+        t.rowptr.assign((size_t)g.n_own + 1, 0);
+        int64_t el = 0;
+        for (int64_t i = 0; i < es.E; ++i) {
+            const int32_t r = es.receivers[i] - es.index_base;
+            if (g.owner[r] == rank) {
+                ++t.rowptr[(size_t)g2l[r] + 1];
+                ++el;
+            }
+        }
+        t.e_local = el;
+        for (int32_t i = 0; i < g.n_own; ++i) t.rowptr[(size_t)i + 1] += t.rowptr[i];
+        t.snd.assign(el, 0);
+        t.rcv.assign(el, 0);
+        t.edge_gid.assign(el, 0);
+        std::vector<int32_t> cur(t.rowptr.begin(), t.rowptr.end() - 1);
+        for (int64_t i = 0; i < es.E; ++i) {
+            const int32_t s = es.senders[i] - es.index_base, r = es.receivers[i] - es.index_base;
             if (g.owner[r] != rank) continue;
             const int32_t lr = g2l[r];
             const int32_t p = cur[lr]++;
-            g.snd[p] = g2l[s];
-            g.rcv[p] = lr;
-            g.edge_gid[p] = i;
+            t.snd[p] = g2l[s];
+            t.rcv[p] = lr;
+            t.edge_gid[p] = i;
         }
     }
 
@@ -154,11 +166,12 @@ std::string build_local_graph(int32_t N, int64_t E, const int32_t* senders, cons
     g.send_idx.clear();
     if (nranks > 1) {
         std::vector<std::vector<int32_t>> lists(nranks);
-        for (int64_t i = 0; i < E; ++i) {
-            const int32_t s = senders[i] - index_base, r = receivers[i] - index_base;
-            const int32_t q = g.owner[r];
-            if (g.owner[s] == rank && q != rank) lists[q].push_back(s);
-        }
+        for (int k = 0; k < nsets; ++k)
+            for (int64_t i = 0; i < sets[k].E; ++i) {
+                const int32_t s = sets[k].senders[i] - sets[k].index_base, r = sets[k].receivers[i] - sets[k].index_base;
+                const int32_t q = g.owner[r];
+                if (g.owner[s] == rank && q != rank) lists[q].push_back(s);
+            }
         for (int32_t q = 0; q < nranks; ++q) {
             auto& l = lists[q];
             std::sort(l.begin(), l.end());

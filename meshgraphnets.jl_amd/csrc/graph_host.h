@@ -7,18 +7,26 @@
 
 namespace mgn {
 
-struct LocalGraph {
-    int32_t N = 0;              // global nodes
-    int64_t E = 0;              // global edges
-    int32_t rank = 0, nranks = 1;
-    int32_t n_own = 0, n_halo = 0;
-    int32_t n_boundary = 0;          // owned nodes that some peer lists as halo; they are numbered FIRST
+constexpr int MAX_EDGE_SETS = 2;  // mesh edges (+ world edges, MGN-spec "per edge set")
+
+// One edge set of this rank: the edges whose receiver is owned, receiver-sorted (input-stable).
+struct EdgeTopo {
+    int64_t E = 0;                   // global edges of the set
     int64_t e_local = 0;
-    std::vector<int32_t> own_gid;    // [n_own] global id of owned node i: boundary nodes (ascending), then interior (ascending)
-    std::vector<int32_t> halo_gid;   // [n_halo] grouped by owner rank, ascending gid inside a group
     std::vector<int64_t> edge_gid;   // [e_local] global edge id, engine (receiver-sorted, stable) order
     std::vector<int32_t> snd, rcv;   // [e_local] local indices; snd may be >= n_own (halo)
     std::vector<int32_t> rowptr;     // [n_own+1] CSR by receiver
+};
+
+struct LocalGraph {
+    int32_t N = 0;              // global nodes
+    int32_t rank = 0, nranks = 1;
+    int32_t nsets = 1;
+    int32_t n_own = 0, n_halo = 0;
+    int32_t n_boundary = 0;          // owned nodes that some peer lists as halo; they are numbered FIRST
+    EdgeTopo set[MAX_EDGE_SETS];
+    std::vector<int32_t> own_gid;    // [n_own] global id of owned node i: boundary nodes (ascending), then interior (ascending)
+    std::vector<int32_t> halo_gid;   // [n_halo] grouped by owner rank, ascending gid inside a group (union over the edge sets)
     std::vector<int32_t> send_rows;  // [nranks] rows this rank sends to each peer per exchange
     std::vector<int32_t> recv_rows;  // [nranks] rows received from each peer (== halo group sizes)
     std::vector<int32_t> send_idx;   // [sum(send_rows)] local (owned) row of each sent row, peer-major
@@ -30,9 +38,18 @@ struct LocalGraph {
 // contiguous index blocks.  Every rank computes the same answer from the same inputs.
 void rcb_partition(int32_t N, const float* pos, int32_t pos_dim, int32_t parts, std::vector<int32_t>& owner);
 
-// Build rank `rank`'s local graph.  senders/receivers are global ids with the given index base.
-// Returns empty string on success, else an error message.
-std::string build_local_graph(int32_t N, int64_t E, const int32_t* senders, const int32_t* receivers, int32_t index_base,
-                              const float* pos, int32_t pos_dim, int32_t rank, int32_t nranks, LocalGraph& g);
+// Global description of one edge set as the caller hands it over.
+struct EdgeList {
+    int64_t E = 0;
+    const int32_t* senders = nullptr;
+    const int32_t* receivers = nullptr;
+    int32_t index_base = 0;
+};
+
+// Build rank `rank`'s local graph from `nsets` edge sets over the same nodes.  Node ownership comes from
+// `owner` when given ([N], e.g. kept from an earlier call), else from rcb_partition(pos).  Halo / boundary /
+// send lists are the union over the sets.  Returns empty string on success, else an error message.
+std::string build_local_graph(int32_t N, int nsets, const EdgeList* sets, const float* pos, int32_t pos_dim,
+                              const int32_t* owner, int32_t rank, int32_t nranks, LocalGraph& g);
 
 }  // namespace mgn

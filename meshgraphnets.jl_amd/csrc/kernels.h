@@ -7,7 +7,7 @@
 namespace mgn {
 
 constexpr int TILE = 32;        // rows (edges or nodes) per wave tile == MFMA 32x32 N dimension
-constexpr int MAX_CHUNKS = 6;   // weight chunks (L x L, fragment order) a fused kernel may chain
+constexpr int MAX_CHUNKS = 7;   // weight chunks (L x L, fragment order) a fused kernel may chain
 
 // Table slots (each L floats, fragment order) inside a kernel's `tabs` block.
 enum { T_B1 = 0, T_B2, T_B3, T_GAMMA, T_BETA, T_BQ, T_COUNT };
@@ -38,8 +38,10 @@ struct NodeArgs {
     const float* CARRY;
     float* P;
     float* Q;
-    const float* chunk[MAX_CHUNKS];  // 0:W2 1:W3 2:W1[0:L] 3:W1[L:2L] 4:WP(next) 5:WQ(next)
+    const float* chunk[MAX_CHUNKS];  // 0:W2 1:W3 2:W1[0:L] 3:W1[L:2L] 4:WP(next) 5:WQ(next) 6:W1[2L:3L] (second edge set)
     const float* chunk_t[MAX_CHUNKS];
+    // second edge set (world edges): its aggregate is one more layer-1 input block; AGG2 == null with one set
+    const int32_t* rowptr2; const float* AGG2; const float* CARRY2; int64_t zero_row2;
     const float* tabs;      // b1,b2,b3,gamma,beta,bq
     int32_t mode;           // 0: MLP only (last step)  1: MLP + project P,Q  2: project only
     int32_t stagger;
@@ -98,9 +100,10 @@ struct BfEdgeArgs {
 struct BfNodeArgs {
     int32_t n, ntiles; const int32_t* rowptr;
     uint16_t* V; const uint16_t* AGG; const uint16_t* CARRY; uint16_t* P; uint16_t* Q;
-    const uint16_t* chunk[6];                  // 0:W2 1:W3 2:W1v 3:W1a 4:WP 5:WQ
+    const uint16_t* chunk[7];                  // 0:W2 1:W3 2:W1v 3:W1a 4:WP 5:WQ 6:W1a of the second edge set
     const float* tabs;
     int64_t zero_row; int32_t tile0;
+    const int32_t* rowptr2; const uint16_t* AGG2; const uint16_t* CARRY2; int64_t zero_row2;   // second edge set or null
 };
 hipError_t launch_edge_bf16(const BfEdgeArgs& a, hipStream_t s);
 hipError_t launch_node_bf16(const BfNodeArgs& a, hipStream_t s);      // node MLP
@@ -108,7 +111,7 @@ hipError_t launch_project_bf16(const BfNodeArgs& a, hipStream_t s);   // P,Q pro
 // layout converters between the fp32 and bf16 tile-major forms (encoder output / decoder input in bf16 mode)
 hipError_t launch_tile_f32_to_bf16(const float* src, uint16_t* dst, int64_t ntiles, hipStream_t s);
 hipError_t launch_tile_bf16_to_f32(const uint16_t* src, float* dst, int64_t ntiles, hipStream_t s);
-hipError_t launch_gather_rows16(const uint16_t* src, const int32_t* idx, uint16_t* dst, int64_t rows, hipStream_t s);
+hipError_t launch_gather_rows16(const uint16_t* src, const int32_t* idx, uint16_t* dst, int64_t rows, int dst_stride /* elements */, hipStream_t s);
 
 struct LaunchCfg { int blocks; int threads; size_t lds; };
 
@@ -131,7 +134,7 @@ hipError_t launch_project(int L, const NodeArgs& a, hipStream_t s);   // mode-2 
 hipError_t launch_enc_node(int L, const EncNodeArgs& a, hipStream_t s);
 hipError_t launch_enc_edge(int L, const EncEdgeArgs& a, hipStream_t s);
 hipError_t launch_decode(int L, const DecArgs& a, hipStream_t s);
-hipError_t launch_gather_rows(const float* src, const int32_t* idx, float* dst, int64_t rows, int L, hipStream_t s);
+hipError_t launch_gather_rows(const float* src, const int32_t* idx, float* dst, int64_t rows, int L, int dst_stride /* elements */, hipStream_t s);
 hipError_t launch_rows_to_tiles(const float* src, const int64_t* gid64, const int32_t* gid32, float* dst, int64_t rows, int L, hipStream_t s);
 hipError_t launch_tiles_to_rows(const float* src, const int64_t* gid64, const int32_t* gid32, float* dst, int64_t rows, int L, hipStream_t s);
 hipError_t launch_randn_rows(float* dst, const int64_t* gid64, const int32_t* gid32, int64_t rows, int L,

@@ -530,7 +530,24 @@ __global__ __launch_bounds__(512, 2) void k_edge_step(const EdgeArgs a) {
 // ================================================================================================
 // PROJECT: also emit P,Q of the next step in the same launch (fewer launches: used for small meshes; on large
 // meshes the projection runs as k_project, where both of its chunks are LDS-resident).
-template <int NT, int NRES, bool PROJECT>
+// aggregated messages of the tile's nodes: the node's AGG slot, or carry rows when its edge run straddles edge tiles.
+// A macro on purpose: as a (force-inlined) function the same code costs k_node_step<4,*> 37 spilled VGPRs.
+// Uses tile, nn, valid, lane, h, L of the enclosing tile loop.
+#define LOAD_AGGREGATE(NT_, y_, rowptr_, AGG_, CARRY_, zero_row_)                                                        \
+    do {                                                                                                                 \
+        const int a0 = valid ? (rowptr_)[nn] : 0, a1 = valid ? (rowptr_)[nn + 1] : 0;                                     \
+        const int T1 = a0 >> 5, T2 = (a1 - 1) >> 5;                                                                      \
+        const int extra = (a1 > a0 && T2 > T1) ? (T2 - T1) : 0;                                                          \
+        const bool from_agg = (a1 > a0) && !extra;                                                                       \
+        const f32x4* src0 = from_agg ? tile_ptr((AGG_), tile, L, lane)                                                   \
+                                     : row_ptr((CARRY_), extra ? (int64_t)(2 * T1 + 1) : (zero_row_), L, h);            \
+        load_frag<NT_>(y_, src0, from_agg ? STRIDE_TILE : STRIDE_ROW);                                                   \
+        for (int q = 1; __any(q <= extra); ++q)                                                                          \
+            if (q <= extra) add_frag<NT_>(y_, row_ptr((CARRY_), (int64_t)2 * (T1 + q), L, h), STRIDE_ROW);              \
+    } while (0)
+
+// NAGG = 2: a second edge set's aggregate (AGG2 / CARRY2 / rowptr2) is a further layer-1 input, chunk[6] streamed.
+template <int NT, int NRES, bool PROJECT, int NAGG = 1>
 __global__ __launch_bounds__(512, 2) void k_node_step(const NodeArgs a) {
     constexpr int L = 32 * NT, CH = 16 * NT * 64 * NT;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -567,20 +584,15 @@ __global__ __launch_bounds__(512, 2) void k_node_step(const NodeArgs a) {
         load_frag<NT>(v, vtile, STRIDE_TILE);
 
         {
-            // aggregated messages: this node's AGG slot, or carry rows when its edge run straddles edge tiles
-            const int a0 = valid ? a.rowptr[nn] : 0, a1 = valid ? a.rowptr[nn + 1] : 0;
-            const int T1 = a0 >> 5, T2 = (a1 - 1) >> 5;
-            const int extra = (a1 > a0 && T2 > T1) ? (T2 - T1) : 0;
-            const bool from_agg = (a1 > a0) && !extra;
-            const f32x4* src0 = from_agg ? tile_ptr(a.AGG, tile, L, lane)
-                                         : row_ptr(a.CARRY, extra ? (int64_t)(2 * T1 + 1) : a.zero_row, L, h);
-            load_frag<NT>(y, src0, from_agg ? STRIDE_TILE : STRIDE_ROW);
-            for (int q = 1; __any(q <= extra); ++q)
-                if (q <= extra) add_frag<NT>(y, row_ptr(a.CARRY, (int64_t)2 * (T1 + q), L, h), STRIDE_ROW);
+            LOAD_AGGREGATE(NT, y, a.rowptr, a.AGG, a.CARRY, a.zero_row);
 
             tab_frag<NT>(acc, tb + T_B1 * L, h);
             mfma_chunk<NT, (NRES > 2)>(acc, v, w1v, lane);     // layer 1, node part
             mfma_chunk<NT, (NRES > 3)>(acc, y, w1a, lane);     // layer 1, aggregate part
+            if constexpr (NAGG > 1) {
+                LOAD_AGGREGATE(NT, y, a.rowptr2, a.AGG2, a.CARRY2, a.zero_row2);
+                mfma_chunk<NT, false>(acc, y, a.chunk[6], lane);   // layer 1, second edge set's aggregate
+            }
             relu_frag<NT>(acc);
             tab_frag<NT>(y, tb + T_B2 * L, h);
             mfma_chunk<NT, (NRES > 0)>(y, acc, w2, lane);      // layer 2
@@ -794,6 +806,7 @@ __global__ __launch_bounds__(256, 2) void k_edge_coop(const EdgeArgs a) {
 }
 
 // chunk_t[0]=W2 [1]=W3 [2]=W1v [3]=W1a [4]=WP [5]=WQ (t-major).  mode as in NodeArgs.
+template <bool TWO_SETS>
 __global__ __launch_bounds__(256, 2) void k_node_coop(const NodeArgs a) {
     constexpr int L = 128;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -815,18 +828,14 @@ __global__ __launch_bounds__(256, 2) void k_node_coop(const NodeArgs a) {
         load_frag<4>(v, vtile, STRIDE_TILE);
         load_quarter(vq, vtile, STRIDE_TILE, tq);
         if (a.mode != 2) {
-            const int a0 = valid ? a.rowptr[nn] : 0, a1 = valid ? a.rowptr[nn + 1] : 0;
-            const int T1 = a0 >> 5, T2 = (a1 - 1) >> 5;
-            const int extra = (a1 > a0 && T2 > T1) ? (T2 - T1) : 0;
-            const bool from_agg = (a1 > a0) && !extra;
-            const f32x4* src0 = from_agg ? tile_ptr(a.AGG, tile, L, lane)
-                                         : row_ptr(a.CARRY, extra ? (int64_t)(2 * T1 + 1) : a.zero_row, L, h);
-            load_frag<4>(in, src0, from_agg ? STRIDE_TILE : STRIDE_ROW);
-            for (int q = 1; __any(q <= extra); ++q)
-                if (q <= extra) add_frag<4>(in, row_ptr(a.CARRY, (int64_t)2 * (T1 + q), L, h), STRIDE_ROW);
+            LOAD_AGGREGATE(4, in, a.rowptr, a.AGG, a.CARRY, a.zero_row);
             tab_quarter(acc, tb + T_B1 * L, tq, h);
             coop_chain(acc, v, a.chunk_t[2] + tq * 4096, lane);             // layer 1, node part
             coop_chain(acc, in, a.chunk_t[3] + tq * 4096, lane);            // layer 1, aggregate part
+            if constexpr (TWO_SETS) {                                       // second edge set's aggregate
+                LOAD_AGGREGATE(4, in, a.rowptr2, a.AGG2, a.CARRY2, a.zero_row2);
+                coop_chain(acc, in, a.chunk_t[6] + tq * 4096, lane);
+            }
             relu_quarter(acc);
             coop_exchange(in, acc, xch0, wave, lane);
             tab_quarter(acc, tb + T_B2 * L, tq, h);
@@ -1154,6 +1163,28 @@ __global__ __launch_bounds__(MGN_BF_WAVES * 64, MGN_BF_WAVES / 4) void k_edge_bf
     }
 }
 
+// bf16 twin of load_aggregate; `y` is scratch (carry rows are summed in fp32 and rounded once)
+DEVINL void bf_load_aggregate(bf16x8 (&in)[8], f32x16 (&y)[4], const int32_t* __restrict__ rowptr, const uint16_t* AGG, const uint16_t* CARRY,
+                              int64_t zero_row, int tile, int nn, bool valid, int lane, int h) {
+    const int a0 = valid ? rowptr[nn] : 0, a1 = valid ? rowptr[nn + 1] : 0;
+    const int T1 = a0 >> 5, T2 = (a1 - 1) >> 5;
+    const int extra = (a1 > a0 && T2 > T1) ? (T2 - T1) : 0;
+    const bool from_agg = (a1 > a0) && !extra;
+    const bf16x8* src0 = from_agg ? bf_tile_ptr(AGG, tile, lane) : bf_row_ptr(CARRY, extra ? (int64_t)(2 * T1 + 1) : zero_row, h);
+    bf_load(in, src0, from_agg ? BF_STRIDE_TILE : BF_STRIDE_ROW);
+    if (__any(extra > 0)) {
+        zero_frag<4>(y);
+        bf_unpack_add(y, in);
+        for (int q = 1; __any(q <= extra); ++q)
+            if (q <= extra) {
+                bf16x8 cr[8];
+                bf_load(cr, bf_row_ptr(CARRY, (int64_t)2 * (T1 + q), h), BF_STRIDE_ROW);
+                bf_unpack_add(y, cr);
+            }
+        bf_pack(in, y);
+    }
+}
+
 // node MLP: chunk[0]=W2 [1]=W3 [2]=W1v [3]=W1a, all resident (128 KiB)
 __global__ __launch_bounds__(512, 2) void k_node_bf16(const BfNodeArgs a) {
     constexpr int L = 128;
@@ -1180,26 +1211,14 @@ __global__ __launch_bounds__(512, 2) void k_node_bf16(const BfNodeArgs a) {
         f32x16 acc[4], y[4];
         bf16x8* vtile = bf_tile_ptr(a.V, tile, lane);
         bf_load(v, vtile, BF_STRIDE_TILE);
-        const int a0 = valid ? a.rowptr[nn] : 0, a1 = valid ? a.rowptr[nn + 1] : 0;
-        const int T1 = a0 >> 5, T2 = (a1 - 1) >> 5;
-        const int extra = (a1 > a0 && T2 > T1) ? (T2 - T1) : 0;
-        const bool from_agg = (a1 > a0) && !extra;
-        const bf16x8* src0 = from_agg ? bf_tile_ptr(a.AGG, tile, lane) : bf_row_ptr(a.CARRY, extra ? (int64_t)(2 * T1 + 1) : a.zero_row, h);
-        bf_load(in, src0, from_agg ? BF_STRIDE_TILE : BF_STRIDE_ROW);
-        if (__any(extra > 0)) {                                  // carry rows are summed in fp32, rounded once
-            zero_frag<4>(y);
-            bf_unpack_add(y, in);
-            for (int q = 1; __any(q <= extra); ++q)
-                if (q <= extra) {
-                    bf16x8 cr[8];
-                    bf_load(cr, bf_row_ptr(a.CARRY, (int64_t)2 * (T1 + q), h), BF_STRIDE_ROW);
-                    bf_unpack_add(y, cr);
-                }
-            bf_pack(in, y);
-        }
+        bf_load_aggregate(in, y, a.rowptr, a.AGG, a.CARRY, a.zero_row, tile, nn, valid, lane, h);
         tab_frag<4>(acc, tb + T_B1 * L, h);
         bf_chunk(acc, v, w1v, lane);                             // layer 1, node part
         bf_chunk(acc, in, w1a, lane);                            // layer 1, aggregate part
+        if (a.AGG2) {                                            // second edge set's aggregate (its chunk streams from L2)
+            bf_load_aggregate(in, y, a.rowptr2, a.AGG2, a.CARRY2, a.zero_row2, tile, nn, valid, lane, h);
+            bf_chunk(acc, in, reinterpret_cast<const bf16x8*>(a.chunk[6]), lane);
+        }
         relu_frag<4>(acc);
         bf_pack(in, acc);
         tab_frag<4>(y, tb + T_B2 * L, h);
@@ -1276,23 +1295,25 @@ __global__ void k_tile_bf16_to_f32(const uint16_t* __restrict__ src, float* __re
     d4[(2 * sidx) * 64] = lo;
     d4[(2 * sidx + 1) * 64] = hi;
 }
-__global__ void k_gather_rows16(const uint16_t* __restrict__ src, const int32_t* __restrict__ idx, uint16_t* __restrict__ dst, int64_t rows) {
+// dst row stride `dst4` in 16-byte pieces (> row width when the rows of several edge sets interleave in a halo message)
+__global__ void k_gather_rows16(const uint16_t* __restrict__ src, const int32_t* __restrict__ idx, uint16_t* __restrict__ dst, int64_t rows,
+                                int dst4) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // one 16-byte piece; 16 per row
     if (i >= rows * 16) return;
     const int64_t r = i >> 4;
-    reinterpret_cast<f32x4*>(dst)[i] = reinterpret_cast<const f32x4*>(src)[(int64_t)idx[r] * 16 + (i & 15)];
+    reinterpret_cast<f32x4*>(dst)[r * dst4 + (i & 15)] = reinterpret_cast<const f32x4*>(src)[(int64_t)idx[r] * 16 + (i & 15)];
 }
 
 // ================================================================================================
 // small utility kernels
 // ================================================================================================
 __global__ void k_gather_rows(const float* __restrict__ src, const int32_t* __restrict__ idx, float* __restrict__ dst,
-                              int64_t rows, int L4) {
+                              int64_t rows, int L4, int dst4) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= rows * L4) return;
     const int64_t r = i / L4;
     const int q = (int)(i - r * L4);
-    reinterpret_cast<f32x4*>(dst)[i] = reinterpret_cast<const f32x4*>(src)[(int64_t)idx[r] * L4 + q];
+    reinterpret_cast<f32x4*>(dst)[r * dst4 + q] = reinterpret_cast<const f32x4*>(src)[(int64_t)idx[r] * L4 + q];
 }
 
 // caller-order row-major rows  <->  engine order, tile-major storage (mgn_latents_import / export on the device)
@@ -1543,12 +1564,26 @@ hipError_t launch_node_step(int L, const NodeArgs& a, hipStream_t s) {
     if (a.ntiles <= 0) return hipSuccess;
     if (coop_ok(L, a.ntiles, a.chunk_t)) {
         LaunchCfg c4{a.ntiles, 256, coop_lds()};
-        return launch_k(k_node_coop, a, c4, s);
+        return a.AGG2 ? launch_k(k_node_coop<true>, a, c4, s) : launch_k(k_node_coop<false>, a, c4, s);
     }
     if (a.mode == 2) return launch_project(L, a, s);
     const bool proj = a.mode == 1;
     const int nres = resident_chunks(L, proj ? 6 : 4);
     const LaunchCfg lc = tile_launch(L, a.ntiles, nres);
+    if (a.AGG2) {   // two edge sets: MLP only here, the host projects per set in separate launches
+        if (proj) return hipErrorInvalidValue;
+        if (L == 128) {
+            if (small_launch(a.ntiles)) {
+                LaunchCfg l0 = lc;
+                l0.lds = (size_t)T_COUNT * L * 4 + 64;
+                return launch_k(k_node_step<4, 0, false, 2>, a, l0, s);
+            }
+            return launch_k(k_node_step<4, 2, false, 2>, a, lc, s);
+        }
+        if (L == 64) return launch_k(k_node_step<2, 4, false, 2>, a, lc, s);
+        if (L == 32) return launch_k(k_node_step<1, 4, false, 2>, a, lc, s);
+        return hipErrorInvalidValue;
+    }
     if (L == 128) {
         if (small_launch(a.ntiles)) {
             LaunchCfg l0 = lc;
@@ -1566,7 +1601,7 @@ hipError_t launch_project(int L, const NodeArgs& a, hipStream_t s) {
     LaunchCfg lc = tile_launch(L, a.ntiles, 2);
     if (a.tile0 == 0 && a.mode == 2 && coop_ok(L, a.ntiles, a.chunk_t)) {
         LaunchCfg c4{a.ntiles, 256, coop_lds()};
-        return launch_k(k_node_coop, a, c4, s);
+        return a.AGG2 ? launch_k(k_node_coop<true>, a, c4, s) : launch_k(k_node_coop<false>, a, c4, s);
     }
     if (L == 128 && small_launch(a.ntiles)) {
         lc.lds = (size_t)T_COUNT * L * 4 + 64;
@@ -1615,17 +1650,17 @@ hipError_t launch_tile_bf16_to_f32(const uint16_t* src, float* dst, int64_t ntil
     hipLaunchKernelGGL(k_tile_bf16_to_f32, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src, dst, n);
     return hipGetLastError();
 }
-hipError_t launch_gather_rows16(const uint16_t* src, const int32_t* idx, uint16_t* dst, int64_t rows, hipStream_t s) {
+hipError_t launch_gather_rows16(const uint16_t* src, const int32_t* idx, uint16_t* dst, int64_t rows, int dst_stride, hipStream_t s) {
     if (rows <= 0) return hipSuccess;
     const int64_t n = rows * 16;
-    hipLaunchKernelGGL(k_gather_rows16, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src, idx, dst, rows);
+    hipLaunchKernelGGL(k_gather_rows16, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src, idx, dst, rows, dst_stride / 8);
     return hipGetLastError();
 }
 
-hipError_t launch_gather_rows(const float* src, const int32_t* idx, float* dst, int64_t rows, int L, hipStream_t s) {
+hipError_t launch_gather_rows(const float* src, const int32_t* idx, float* dst, int64_t rows, int L, int dst_stride, hipStream_t s) {
     if (rows <= 0) return hipSuccess;
     const int64_t n = rows * (L / 4);
-    hipLaunchKernelGGL(k_gather_rows, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src, idx, dst, rows, L / 4);
+    hipLaunchKernelGGL(k_gather_rows, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src, idx, dst, rows, L / 4, dst_stride / 4);
     return hipGetLastError();
 }
 

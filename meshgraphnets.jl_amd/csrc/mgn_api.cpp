@@ -70,14 +70,15 @@ struct mgn_engine {
     // parameters
     bool have_params = false;
     std::vector<float> params;  // packed, host
-    MlpOff enc_node, enc_edge, dec;
-    std::vector<MlpOff> pe, pn;
+    MlpOff enc_node, dec;
+    std::vector<MlpOff> pn;
     DevBuf wfrag;     // all chunks + tables + small tensors, fragment order
-    // offsets into wfrag (floats)
-    struct StepOff { size_t e_ch[3], e_tabs, n_ch[6], n_tabs; };
+    // offsets into wfrag (floats).  e_ch / e_tabs: edge MLP of each set; n_ch: node MLP (0:W2 1:W3 2:W1v 3:W1a 6:W1a of
+    // set 1) and the projection onto the NEXT step's set-0 edge MLP (4:WP 5:WQ, bias in n_tabs[T_BQ]); p1_ch / p1_tabs:
+    // the same projection for set 1
+    struct StepOff { size_t e_ch[MAX_EDGE_SETS][3], e_tabs[MAX_EDGE_SETS], n_ch[7], n_tabs, p1_ch[2], p1_tabs; };
     std::vector<StepOff> soff;
     size_t en_ch[4] = {0, 0, 0, 0}, en_tabs = 0, en_w1f = 0;
-    size_t ee_ch[2] = {0, 0}, ee_tabs = 0, ee_w1f = 0;
     size_t de_ch[2] = {0, 0}, de_tabs = 0, de_w3f = 0, de_b3 = 0;
 
     // norms (device): node scale/shift [Fn], edge [Fe], out [O]; null = identity
@@ -87,24 +88,38 @@ struct mgn_engine {
     // graph
     bool have_graph = false;
     LocalGraph g;
-    int32_t ntiles_e = 0, ntiles_n = 0;
-    DevBuf d_snd, d_rcv, d_rowptr, d_own_gid, d_edge_gid, d_send_idx;
+    int32_t nsets = 1;
+    int32_t ntiles_n = 0;
+    DevBuf d_own_gid, d_send_idx;
+    // per edge set: parameters, topology, latents (set 0 = the reference's mesh edges; set 1 = world edges)
+    struct EdgeSetState {
+        int32_t Fe = 0;
+        MlpOff enc;
+        std::vector<MlpOff> pe;
+        size_t ee_ch[2] = {0, 0}, ee_tabs = 0, ee_w1f = 0;
+        int32_t ntiles_e = 0;
+        bool have_ef = false;
+        DevBuf d_snd, d_rcv, d_rowptr, d_edge_gid, d_ef;
+        DevBuf Elat, AGG, CARRY, P, Q, elat0;
+        DevBuf bP, bQ, bElat, bAGG, bCARRY;   // bf16 mode
+        std::vector<int32_t> gs, gr;          // host copy of the global edge list (kept only with two sets: rebuilds)
+        int32_t gbase = 0;
+    } es[MAX_EDGE_SETS];
 
     // latents and I/O
     // bf16 mode (cfg.dtype == MGN_BF16): bf16 copies of the processor state and weights; the fp32 V / Elat buffers
     // then only carry encoder output / decoder input
-    DevBuf wbf, bV, bP, bQ, bElat, bAGG, bCARRY;
-    struct BfStepOff { size_t e_ch[3], n_ch[6]; };
+    DevBuf wbf, bV;
+    struct BfStepOff { size_t e_ch[MAX_EDGE_SETS][3], n_ch[7], p1_ch[2]; };
     std::vector<BfStepOff> bsoff;
     // static per-trajectory RHS inputs (mgn_set_static): cached encoded edge latents
     bool have_static = false;
-    DevBuf elat0;
     DevBuf stage;     // device staging image of caller-order latents (import / export)
     DevBuf d_stamps;  // diagnostic builds only
     DevBuf ode;       // native rollout: state, stages, frames, saves, Elat0
     const float* srcA_override = nullptr;  // rollout: encoder reads the node state from here instead of d_nfA
     float* out_override = nullptr;         // rollout: decoder writes dx/dt here instead of d_out
-    DevBuf V, P, Q, Elat, AGG, CARRY, d_nfA, d_nfB, d_ef, d_out, d_mask, d_sum;
+    DevBuf V, d_nfA, d_nfB, d_out, d_mask, d_sum;
     int32_t in_wa = 0, in_wb = 0;
     bool have_mask = false;
 
@@ -149,6 +164,8 @@ bool cfg_ok(const mgn_config* c, std::string& why) {
     if (c->dtype != MGN_F32 && c->dtype != MGN_BF16) { why = "dtype must be MGN_F32 or MGN_BF16"; return false; }
     if (c->dtype == MGN_BF16 && c->L != 128) { why = "MGN_BF16 is implemented for L = 128"; return false; }
     if (c->nranks < 1 || c->rank < 0 || c->rank >= c->nranks) { why = "bad rank/nranks"; return false; }
+    if (c->n_edge_sets < 0 || c->n_edge_sets > MAX_EDGE_SETS) { why = "n_edge_sets must be 0, 1 or 2"; return false; }
+    if (c->n_edge_sets == 2 && c->Fe2 < 1) { why = "Fe2 must be >= 1 with two edge sets"; return false; }
     return true;
 }
 
@@ -176,12 +193,18 @@ size_t layout_all(mgn_engine* h) {
     const mgn_config& c = h->cfg;
     size_t off = 0;
     off = mlp_layout(h->enc_node, off, c.Fn, c.L, c.L, true);
-    off = mlp_layout(h->enc_edge, off, c.Fe, c.L, c.L, true);
-    h->pe.resize(c.mps);
+    // MGN-spec order: encoder-node, encoder-edge per set, (edge MLP per set, node MLP) x mps, decoder
+    h->nsets = c.n_edge_sets == 2 ? 2 : 1;
+    h->es[0].Fe = c.Fe;
+    h->es[1].Fe = c.Fe2;
+    for (int q = 0; q < h->nsets; ++q) {
+        off = mlp_layout(h->es[q].enc, off, h->es[q].Fe, c.L, c.L, true);
+        h->es[q].pe.resize(c.mps);
+    }
     h->pn.resize(c.mps);
     for (int k = 0; k < c.mps; ++k) {
-        off = mlp_layout(h->pe[k], off, 3 * c.L, c.L, c.L, true);
-        off = mlp_layout(h->pn[k], off, 2 * c.L, c.L, c.L, true);
+        for (int q = 0; q < h->nsets; ++q) off = mlp_layout(h->es[q].pe[k], off, 3 * c.L, c.L, c.L, true);
+        off = mlp_layout(h->pn[k], off, (1 + h->nsets) * c.L, c.L, c.L, true);
     }
     off = mlp_layout(h->dec, off, c.L, c.L, c.O, false);
     return off;
@@ -279,35 +302,49 @@ inline size_t tile_index(int64_t row, int f, int L) {
     return (size_t)tile * TILE * L + (size_t)m * 256 + (size_t)(32 * hh + c) * 4 + i;
 }
 
-int alloc_latents(mgn_engine* h) {
+inline int64_t tiles_or_one(int32_t nt) { return nt > 0 ? nt : 1; }
+
+// per-set buffers (sized by that set's local edges and by the owned + halo nodes)
+int alloc_edge_set(mgn_engine* h, int q) {
     const int L = h->cfg.L;
     const LocalGraph& g = h->g;
-    const int64_t nte = h->ntiles_e > 0 ? h->ntiles_e : 1, ntn = h->ntiles_n > 0 ? h->ntiles_n : 1;
-    HIPCHK(h, h->V.ensure(tile_floats(ntn, L) * 4));
-    HIPCHK(h, h->P.ensure((size_t)(g.n_own + g.n_halo + 1) * L * 4));
-    HIPCHK(h, h->Q.ensure((size_t)(g.n_own + 1) * L * 4));
-    HIPCHK(h, h->Elat.ensure(tile_floats(nte, L) * 4));
-    HIPCHK(h, h->AGG.ensure(tile_floats(ntn, L) * 4));
-    HIPCHK(h, h->CARRY.ensure((size_t)(2 * nte + 1) * L * 4));
-    HIPCHK(h, h->d_out.ensure((size_t)(g.n_own + 1) * h->cfg.O * 4));
-    HIPCHK(h, h->d_sum.ensure(4 * sizeof(double)));
+    auto& es = h->es[q];
+    const int64_t nte = tiles_or_one(es.ntiles_e), ntn = tiles_or_one(h->ntiles_n);
+    struct { DevBuf* b; size_t bytes; } bufs[5] = {
+        {&es.P, (size_t)(g.n_own + g.n_halo + 1) * L * 4}, {&es.Q, (size_t)(g.n_own + 1) * L * 4},
+        {&es.Elat, tile_floats(nte, L) * 4}, {&es.AGG, tile_floats(ntn, L) * 4}, {&es.CARRY, (size_t)(2 * nte + 1) * L * 4}};
     // padding rows of the tile-major arrays and the zero row of CARRY (its last row) must read as 0
-    HIPCHK(h, hipMemsetAsync(h->V.p, 0, tile_floats(ntn, L) * 4, h->stream));
-    HIPCHK(h, hipMemsetAsync(h->Elat.p, 0, tile_floats(nte, L) * 4, h->stream));
-    HIPCHK(h, hipMemsetAsync(h->AGG.p, 0, tile_floats(ntn, L) * 4, h->stream));
-    HIPCHK(h, hipMemsetAsync(h->CARRY.p, 0, (size_t)(2 * nte + 1) * L * 4, h->stream));
-    HIPCHK(h, hipMemsetAsync(h->P.p, 0, (size_t)(g.n_own + g.n_halo + 1) * L * 4, h->stream));
-    HIPCHK(h, hipMemsetAsync(h->Q.p, 0, (size_t)(g.n_own + 1) * L * 4, h->stream));
+    for (auto& b : bufs) {
+        HIPCHK(h, b.b->ensure(b.bytes));
+        HIPCHK(h, hipMemsetAsync(b.b->p, 0, b.bytes, h->stream));
+    }
     if (h->cfg.dtype == MGN_BF16) {
-        struct { DevBuf* b; size_t bytes; } bufs[6] = {
-            {&h->bV, tile_floats(ntn, L) * 2}, {&h->bElat, tile_floats(nte, L) * 2}, {&h->bAGG, tile_floats(ntn, L) * 2},
-            {&h->bP, (size_t)(g.n_own + g.n_halo + 1) * L * 2}, {&h->bQ, (size_t)(g.n_own + 1) * L * 2},
-            {&h->bCARRY, (size_t)(2 * nte + 1) * L * 2}};
-        for (auto& b : bufs) {
+        struct { DevBuf* b; size_t bytes; } bb[5] = {
+            {&es.bElat, tile_floats(nte, L) * 2}, {&es.bAGG, tile_floats(ntn, L) * 2},
+            {&es.bP, (size_t)(g.n_own + g.n_halo + 1) * L * 2}, {&es.bQ, (size_t)(g.n_own + 1) * L * 2},
+            {&es.bCARRY, (size_t)(2 * nte + 1) * L * 2}};
+        for (auto& b : bb) {
             HIPCHK(h, b.b->ensure(b.bytes));
             HIPCHK(h, hipMemsetAsync(b.b->p, 0, b.bytes, h->stream));
         }
     }
+    return MGN_OK;
+}
+
+int alloc_latents(mgn_engine* h) {
+    const int L = h->cfg.L;
+    const LocalGraph& g = h->g;
+    const int64_t ntn = tiles_or_one(h->ntiles_n);
+    HIPCHK(h, h->V.ensure(tile_floats(ntn, L) * 4));
+    HIPCHK(h, h->d_out.ensure((size_t)(g.n_own + 1) * h->cfg.O * 4));
+    HIPCHK(h, h->d_sum.ensure(4 * sizeof(double)));
+    HIPCHK(h, hipMemsetAsync(h->V.p, 0, tile_floats(ntn, L) * 4, h->stream));
+    if (h->cfg.dtype == MGN_BF16) {
+        HIPCHK(h, h->bV.ensure(tile_floats(ntn, L) * 2));
+        HIPCHK(h, hipMemsetAsync(h->bV.p, 0, tile_floats(ntn, L) * 2, h->stream));
+    }
+    for (int q = 0; q < h->nsets; ++q)
+        if (int rc = alloc_edge_set(h, q)) return rc;
     return MGN_OK;
 }
 
@@ -318,80 +355,114 @@ void drop_graph(mgn_engine* h) {
     h->graph_warm = -1;
 }
 
-EdgeArgs edge_args(mgn_engine* h, int k) {
+EdgeArgs edge_args(mgn_engine* h, int k, int q = 0) {
     EdgeArgs a{};
-    a.snd = h->d_snd.as<int32_t>();
-    a.rcv = h->d_rcv.as<int32_t>();
-    a.E = h->g.e_local;
-    a.ntiles = h->ntiles_e;
-    a.P = h->P.as<float>();
-    a.Q = h->Q.as<float>();
-    a.Elat = h->Elat.as<float>();
-    a.AGG = h->AGG.as<float>();
-    a.CARRY = h->CARRY.as<float>();
+    auto& es = h->es[q];
+    a.snd = es.d_snd.as<int32_t>();
+    a.rcv = es.d_rcv.as<int32_t>();
+    a.E = h->g.set[q].e_local;
+    a.ntiles = es.ntiles_e;
+    a.P = es.P.as<float>();
+    a.Q = es.Q.as<float>();
+    a.Elat = es.Elat.as<float>();
+    a.AGG = es.AGG.as<float>();
+    a.CARRY = es.CARRY.as<float>();
     for (int i = 0; i < 3; ++i) {
-        a.chunk[i] = W(h, h->soff[k].e_ch[i]);
+        a.chunk[i] = W(h, h->soff[k].e_ch[q][i]);
         a.chunk_t[i] = a.chunk[i] + (size_t)h->cfg.L * h->cfg.L;
     }
-    a.tabs = W(h, h->soff[k].e_tabs);
+    a.tabs = W(h, h->soff[k].e_tabs[q]);
     a.stagger = h->stagger_edge;
     a.stamps = h->d_stamps.as<unsigned long long>();
     return a;
 }
 
-NodeArgs node_args(mgn_engine* h, int k, int mode) {
+// q: the edge set whose P,Q the projection part (modes 1, 2) writes
+NodeArgs node_args(mgn_engine* h, int k, int mode, int q = 0) {
     NodeArgs a{};
+    const size_t CH = (size_t)h->cfg.L * h->cfg.L;
+    const auto& so = h->soff[k];
     a.n = h->g.n_own;
     a.ntiles = h->ntiles_n;
-    a.rowptr = h->d_rowptr.as<int32_t>();
+    a.rowptr = h->es[0].d_rowptr.as<int32_t>();
     a.V = h->V.as<float>();
-    a.AGG = h->AGG.as<float>();
-    a.CARRY = h->CARRY.as<float>();
-    a.P = h->P.as<float>();
-    a.Q = h->Q.as<float>();
+    a.AGG = h->es[0].AGG.as<float>();
+    a.CARRY = h->es[0].CARRY.as<float>();
+    a.P = h->es[q].P.as<float>();
+    a.Q = h->es[q].Q.as<float>();
     for (int i = 0; i < 6; ++i) {
-        a.chunk[i] = W(h, h->soff[k].n_ch[i]);
-        a.chunk_t[i] = a.chunk[i] + (size_t)h->cfg.L * h->cfg.L;
+        a.chunk[i] = W(h, so.n_ch[i]);
+        a.chunk_t[i] = a.chunk[i] + CH;
     }
-    a.tabs = W(h, h->soff[k].n_tabs);
+    a.tabs = W(h, so.n_tabs);
+    if (q == 1) {
+        for (int i = 0; i < 2; ++i) {
+            a.chunk[4 + i] = W(h, so.p1_ch[i]);
+            a.chunk_t[4 + i] = a.chunk[4 + i] + CH;
+        }
+        a.tabs = W(h, so.p1_tabs);
+    }
+    if (h->nsets > 1 && mode != 2) {
+        a.rowptr2 = h->es[1].d_rowptr.as<int32_t>();
+        a.AGG2 = h->es[1].AGG.as<float>();
+        a.CARRY2 = h->es[1].CARRY.as<float>();
+        a.zero_row2 = 2 * tiles_or_one(h->es[1].ntiles_e);
+        a.chunk[6] = W(h, so.n_ch[6]);
+        a.chunk_t[6] = a.chunk[6] + CH;
+    }
     a.mode = mode;
     a.stagger = h->stagger_node;
-    a.zero_row = 2 * (int64_t)(h->ntiles_e > 0 ? h->ntiles_e : 1);
+    a.zero_row = 2 * tiles_or_one(h->es[0].ntiles_e);
     a.tile0 = 0;
     return a;
 }
 
 const uint16_t* WB(const mgn_engine* h, size_t off) { return h->wbf.as<uint16_t>() + off; }
 
-BfEdgeArgs bf_edge_args(mgn_engine* h, int k) {
+BfEdgeArgs bf_edge_args(mgn_engine* h, int k, int q = 0) {
     BfEdgeArgs a{};
-    a.snd = h->d_snd.as<int32_t>();
-    a.rcv = h->d_rcv.as<int32_t>();
-    a.E = h->g.e_local;
-    a.ntiles = h->ntiles_e;
-    a.P = h->bP.as<uint16_t>();
-    a.Q = h->bQ.as<uint16_t>();
-    a.Elat = h->bElat.as<uint16_t>();
-    a.AGG = h->bAGG.as<uint16_t>();
-    a.CARRY = h->bCARRY.as<uint16_t>();
-    for (int i = 0; i < 3; ++i) a.chunk[i] = WB(h, h->bsoff[k].e_ch[i]);
-    a.tabs = W(h, h->soff[k].e_tabs);
+    auto& es = h->es[q];
+    a.snd = es.d_snd.as<int32_t>();
+    a.rcv = es.d_rcv.as<int32_t>();
+    a.E = h->g.set[q].e_local;
+    a.ntiles = es.ntiles_e;
+    a.P = es.bP.as<uint16_t>();
+    a.Q = es.bQ.as<uint16_t>();
+    a.Elat = es.bElat.as<uint16_t>();
+    a.AGG = es.bAGG.as<uint16_t>();
+    a.CARRY = es.bCARRY.as<uint16_t>();
+    for (int i = 0; i < 3; ++i) a.chunk[i] = WB(h, h->bsoff[k].e_ch[q][i]);
+    a.tabs = W(h, h->soff[k].e_tabs[q]);
     return a;
 }
 
-BfNodeArgs bf_node_args(mgn_engine* h, int k) {
+// project: the args feed k_project_bf16 (P,Q of set q); else k_node_bf16 (node MLP over all sets' aggregates)
+BfNodeArgs bf_node_args(mgn_engine* h, int k, int q = 0, bool project = false) {
     BfNodeArgs a{};
+    const auto& so = h->bsoff[k];
     a.n = h->g.n_own;
     a.ntiles = h->ntiles_n;
-    a.rowptr = h->d_rowptr.as<int32_t>();
+    a.rowptr = h->es[0].d_rowptr.as<int32_t>();
     a.V = h->bV.as<uint16_t>();
-    a.AGG = h->bAGG.as<uint16_t>();
-    a.CARRY = h->bCARRY.as<uint16_t>();
-    a.P = h->bP.as<uint16_t>();
-    a.Q = h->bQ.as<uint16_t>();
-    for (int i = 0; i < 6; ++i) a.chunk[i] = WB(h, h->bsoff[k].n_ch[i]);
+    a.AGG = h->es[0].bAGG.as<uint16_t>();
+    a.CARRY = h->es[0].bCARRY.as<uint16_t>();
+    a.P = h->es[q].bP.as<uint16_t>();
+    a.Q = h->es[q].bQ.as<uint16_t>();
+    for (int i = 0; i < 6; ++i) a.chunk[i] = WB(h, so.n_ch[i]);
     a.tabs = W(h, h->soff[k].n_tabs);
-    a.zero_row = 2 * (int64_t)(h->ntiles_e > 0 ? h->ntiles_e : 1);
+    if (q == 1) {
+        a.chunk[4] = WB(h, so.p1_ch[0]);
+        a.chunk[5] = WB(h, so.p1_ch[1]);
+        a.tabs = W(h, h->soff[k].p1_tabs);
+    }
+    if (h->nsets > 1 && !project) {
+        a.rowptr2 = h->es[1].d_rowptr.as<int32_t>();
+        a.AGG2 = h->es[1].bAGG.as<uint16_t>();
+        a.CARRY2 = h->es[1].bCARRY.as<uint16_t>();
+        a.zero_row2 = 2 * tiles_or_one(h->es[1].ntiles_e);
+        a.chunk[6] = WB(h, so.n_ch[6]);
+    }
+    a.zero_row = 2 * tiles_or_one(h->es[0].ntiles_e);
     a.tile0 = 0;
     return a;
 }
@@ -518,8 +589,9 @@ int mgn_set_params(mgn_handle* h, const float* packed, size_t n) {
         return off;
     };
 
-    const MlpOff& e0 = h->pe[0];
-    // encoder, node side (+ projection onto step-0 edge-MLP layer 1)
+    const int S = h->nsets;
+    const MlpOff& e0 = h->es[0].pe[0];
+    // encoder, node side (+ projection onto step-0 edge-MLP layer 1 of set 0)
     {
         const MlpOff& m = h->enc_node;
         h->en_ch[0] = add_chunk(p + m.W[1], L, 0);
@@ -529,23 +601,27 @@ int mgn_set_params(mgn_handle* h, const float* packed, size_t n) {
         h->en_tabs = add_tabs(p + m.b[0], p + m.b[1], p + m.b[2], p + m.gamma, p + m.beta, p + e0.b[0]);
         h->en_w1f = add_w1f(p + m.W[0], c.Fn);
     }
-    {
-        const MlpOff& m = h->enc_edge;
-        h->ee_ch[0] = add_chunk(p + m.W[1], L, 0);
-        h->ee_ch[1] = add_chunk(p + m.W[2], L, 0);
-        h->ee_tabs = add_tabs(p + m.b[0], p + m.b[1], p + m.b[2], p + m.gamma, p + m.beta, nullptr);
-        h->ee_w1f = add_w1f(p + m.W[0], c.Fe);
+    for (int q = 0; q < S; ++q) {
+        auto& es = h->es[q];
+        const MlpOff& m = es.enc;
+        es.ee_ch[0] = add_chunk(p + m.W[1], L, 0);
+        es.ee_ch[1] = add_chunk(p + m.W[2], L, 0);
+        es.ee_tabs = add_tabs(p + m.b[0], p + m.b[1], p + m.b[2], p + m.gamma, p + m.beta, nullptr);
+        es.ee_w1f = add_w1f(p + m.W[0], es.Fe);
     }
-    h->soff.resize(c.mps);
+    h->soff.assign(c.mps, {});
     for (int k = 0; k < c.mps; ++k) {
-        const MlpOff& me = h->pe[k];
         const MlpOff& mn = h->pn[k];
-        const MlpOff& nx = h->pe[k + 1 < c.mps ? k + 1 : 0];  // projection target (mode 2 at k=0 uses step 0 itself)
+        const int kn = k + 1 < c.mps ? k + 1 : 0;                  // projection target (mode 2 at k=0 uses step 0 itself)
         auto& so = h->soff[k];
-        so.e_ch[0] = add_chunk(p + me.W[1], L, 0);
-        so.e_ch[1] = add_chunk(p + me.W[2], L, 0);
-        so.e_ch[2] = add_chunk(p + me.W[0], L, 2 * L);
-        so.e_tabs = add_tabs(nullptr, p + me.b[1], p + me.b[2], p + me.gamma, p + me.beta, nullptr);
+        for (int q = 0; q < S; ++q) {
+            const MlpOff& me = h->es[q].pe[k];
+            so.e_ch[q][0] = add_chunk(p + me.W[1], L, 0);
+            so.e_ch[q][1] = add_chunk(p + me.W[2], L, 0);
+            so.e_ch[q][2] = add_chunk(p + me.W[0], L, 2 * L);
+            so.e_tabs[q] = add_tabs(nullptr, p + me.b[1], p + me.b[2], p + me.gamma, p + me.beta, nullptr);
+        }
+        const MlpOff& nx = h->es[0].pe[kn];
         so.n_ch[0] = add_chunk(p + mn.W[1], L, 0);
         so.n_ch[1] = add_chunk(p + mn.W[2], L, 0);
         so.n_ch[2] = add_chunk(p + mn.W[0], L, 0);
@@ -553,6 +629,13 @@ int mgn_set_params(mgn_handle* h, const float* packed, size_t n) {
         so.n_ch[4] = add_chunk(p + nx.W[0], L, 0);
         so.n_ch[5] = add_chunk(p + nx.W[0], L, L);
         so.n_tabs = add_tabs(p + mn.b[0], p + mn.b[1], p + mn.b[2], p + mn.gamma, p + mn.beta, p + nx.b[0]);
+        if (S > 1) {
+            const MlpOff& nx1 = h->es[1].pe[kn];
+            so.n_ch[6] = add_chunk(p + mn.W[0], L, 2 * L);
+            so.p1_ch[0] = add_chunk(p + nx1.W[0], L, 0);
+            so.p1_ch[1] = add_chunk(p + nx1.W[0], L, L);
+            so.p1_tabs = add_tabs(nullptr, nullptr, nullptr, nullptr, nullptr, p + nx1.b[0]);
+        }
     }
     {
         const MlpOff& m = h->dec;
@@ -566,13 +649,19 @@ int mgn_set_params(mgn_handle* h, const float* packed, size_t n) {
         for (int o = 0; o < c.O; ++o) f.push_back(p[m.b[2] + o]);
         while (f.size() % 4) f.push_back(0.f);
     }
-    // "project only" (mgn_proc_begin) needs step 0's own first layer in slots 4,5 of some NodeArgs: add a
+    // "project only" (mgn_proc_begin) needs step 0's own first layer in the projection slots of some NodeArgs: add a
     // dedicated pseudo-step at index mps (slots 0..3 alias step 0; tables carry bq = b1 of step 0).
     {
         mgn_engine::StepOff so = h->soff[0];
         so.n_ch[4] = h->en_ch[2];
         so.n_ch[5] = h->en_ch[3];
         so.n_tabs = add_tabs(nullptr, nullptr, nullptr, nullptr, nullptr, p + e0.b[0]);
+        if (S > 1) {
+            const MlpOff& e1 = h->es[1].pe[0];
+            so.p1_ch[0] = add_chunk(p + e1.W[0], L, 0);
+            so.p1_ch[1] = add_chunk(p + e1.W[0], L, L);
+            so.p1_tabs = add_tabs(nullptr, nullptr, nullptr, nullptr, nullptr, p + e1.b[0]);
+        }
         h->soff.push_back(so);
     }
     if (c.dtype == MGN_BF16) {
@@ -585,23 +674,37 @@ int mgn_set_params(mgn_handle* h, const float* packed, size_t n) {
         };
         h->bsoff.assign(c.mps + 1, {});
         for (int k = 0; k < c.mps; ++k) {
-            const MlpOff& me = h->pe[k];
             const MlpOff& mn = h->pn[k];
-            const MlpOff& nx = h->pe[k + 1 < c.mps ? k + 1 : 0];
+            const int kn = k + 1 < c.mps ? k + 1 : 0;
+            const MlpOff& nx = h->es[0].pe[kn];
             auto& so = h->bsoff[k];
-            so.e_ch[0] = addb(p + me.W[1], 0);
-            so.e_ch[1] = addb(p + me.W[2], 0);
-            so.e_ch[2] = addb(p + me.W[0], 2 * L);
+            for (int q = 0; q < S; ++q) {
+                const MlpOff& me = h->es[q].pe[k];
+                so.e_ch[q][0] = addb(p + me.W[1], 0);
+                so.e_ch[q][1] = addb(p + me.W[2], 0);
+                so.e_ch[q][2] = addb(p + me.W[0], 2 * L);
+            }
             so.n_ch[0] = addb(p + mn.W[1], 0);
             so.n_ch[1] = addb(p + mn.W[2], 0);
             so.n_ch[2] = addb(p + mn.W[0], 0);
             so.n_ch[3] = addb(p + mn.W[0], L);
             so.n_ch[4] = addb(p + nx.W[0], 0);
             so.n_ch[5] = addb(p + nx.W[0], L);
+            if (S > 1) {
+                const MlpOff& nx1 = h->es[1].pe[kn];
+                so.n_ch[6] = addb(p + mn.W[0], 2 * L);
+                so.p1_ch[0] = addb(p + nx1.W[0], 0);
+                so.p1_ch[1] = addb(p + nx1.W[0], L);
+            }
         }
         h->bsoff[c.mps] = h->bsoff[0];                       // projection for step 0 (mgn_proc_begin)
         h->bsoff[c.mps].n_ch[4] = addb(p + e0.W[0], 0);
         h->bsoff[c.mps].n_ch[5] = addb(p + e0.W[0], L);
+        if (S > 1) {
+            const MlpOff& e1 = h->es[1].pe[0];
+            h->bsoff[c.mps].p1_ch[0] = addb(p + e1.W[0], 0);
+            h->bsoff[c.mps].p1_ch[1] = addb(p + e1.W[0], L);
+        }
         HIPCHK(h, hipStreamSynchronize(h->stream));
         HIPCHK(h, h->wbf.ensure(wb.size() * 2));
         HIPCHK(h, hipMemcpy(h->wbf.p, wb.data(), wb.size() * 2, hipMemcpyHostToDevice));
@@ -647,17 +750,17 @@ int mgn_set_norms(mgn_handle* h, const float* ns, const float* nsh, const float*
     return MGN_OK;
 }
 
-int mgn_set_graph(mgn_handle* h, int32_t N, int64_t E, const int32_t* senders, const int32_t* receivers, int32_t index_base,
-                  const float* mesh_pos, int32_t pos_dim) {
-    if (!h) return MGN_E_ARG;
-    if (index_base != 0 && index_base != 1) return fail(h, MGN_E_ARG, "mgn_set_graph: index_base must be 0 or 1");
+// (re)build the local graph from the kept global edge lists and upload it.  keep_owner: node partition unchanged
+static int rebuild_graph(mgn_handle* h, int32_t N, const EdgeList* sets, const float* mesh_pos, int32_t pos_dim, bool keep_owner,
+                         const char* who) {
     h->have_graph = false;
     h->have_static = false;
     if (!h->host_only) { (void)hipStreamSynchronize(h->stream); drop_graph(h); }
-    const std::string why = build_local_graph(N, E, senders, receivers, index_base, mesh_pos, pos_dim, h->cfg.rank, h->cfg.nranks, h->g);
-    if (!why.empty()) return fail(h, MGN_E_ARG, "mgn_set_graph: %s", why.c_str());
+    const std::string why = build_local_graph(N, h->nsets, sets, mesh_pos, pos_dim, keep_owner ? h->g.owner.data() : nullptr,
+                                              h->cfg.rank, h->cfg.nranks, h->g);
+    if (!why.empty()) return fail(h, MGN_E_ARG, "%s: %s", who, why.c_str());
     const LocalGraph& g = h->g;
-    h->ntiles_e = (int32_t)((g.e_local + TILE - 1) / TILE);
+    for (int q = 0; q < h->nsets; ++q) h->es[q].ntiles_e = (int32_t)((g.set[q].e_local + TILE - 1) / TILE);
     h->ntiles_n = (g.n_own + TILE - 1) / TILE;
     if (h->host_only) {
         h->have_graph = true;
@@ -669,15 +772,86 @@ int mgn_set_graph(mgn_handle* h, int32_t N, int64_t E, const int32_t* senders, c
         if (e != hipSuccess || bytes == 0) return e;
         return hipMemcpy(d.p, src, bytes, hipMemcpyHostToDevice);
     };
-    HIPCHK(h, up(h->d_snd, g.snd.data(), g.snd.size() * 4));
-    HIPCHK(h, up(h->d_rcv, g.rcv.data(), g.rcv.size() * 4));
-    HIPCHK(h, up(h->d_rowptr, g.rowptr.data(), g.rowptr.size() * 4));
+    for (int q = 0; q < h->nsets; ++q) {
+        const EdgeTopo& t = g.set[q];
+        auto& es = h->es[q];
+        HIPCHK(h, up(es.d_snd, t.snd.data(), t.snd.size() * 4));
+        HIPCHK(h, up(es.d_rcv, t.rcv.data(), t.rcv.size() * 4));
+        HIPCHK(h, up(es.d_rowptr, t.rowptr.data(), t.rowptr.size() * 4));
+        HIPCHK(h, up(es.d_edge_gid, t.edge_gid.data(), t.edge_gid.size() * 8));
+    }
     HIPCHK(h, up(h->d_own_gid, g.own_gid.data(), g.own_gid.size() * 4));
-    HIPCHK(h, up(h->d_edge_gid, g.edge_gid.data(), g.edge_gid.size() * 8));
     HIPCHK(h, up(h->d_send_idx, g.send_idx.data(), g.send_idx.size() * 4));
+    return MGN_OK;
+}
+
+int mgn_set_graph(mgn_handle* h, int32_t N, int64_t E, const int32_t* senders, const int32_t* receivers, int32_t index_base,
+                  const float* mesh_pos, int32_t pos_dim) {
+    if (!h) return MGN_E_ARG;
+    if (index_base != 0 && index_base != 1) return fail(h, MGN_E_ARG, "mgn_set_graph: index_base must be 0 or 1");
+    if (E < 0 || (E > 0 && (!senders || !receivers))) return fail(h, MGN_E_ARG, "mgn_set_graph: null senders/receivers");
+    EdgeList sets[MAX_EDGE_SETS];
+    sets[0] = {E, senders, receivers, index_base};
+    if (h->nsets > 1) {   // the second set starts empty; keep set 0's global list for the rebuild in mgn_set_edge_set
+        h->es[0].gs.assign(senders, senders + E);
+        h->es[0].gr.assign(receivers, receivers + E);
+        h->es[0].gbase = index_base;
+        h->es[1].gs.clear();
+        h->es[1].gr.clear();
+        h->es[1].have_ef = false;
+    }
+    if (int rc = rebuild_graph(h, N, sets, mesh_pos, pos_dim, false, "mgn_set_graph")) return rc;
+    if (h->host_only) return MGN_OK;
     if (int rc = alloc_latents(h)) return rc;
     HIPCHK(h, hipStreamSynchronize(h->stream));
     h->have_graph = true;
+    return MGN_OK;
+}
+
+int mgn_set_edge_set(mgn_handle* h, int32_t set, int64_t E, const int32_t* senders, const int32_t* receivers, int32_t index_base) {
+    if (!h) return MGN_E_ARG;
+    if (!h->have_graph) return fail(h, MGN_E_STATE, "mgn_set_edge_set before mgn_set_graph");
+    if (set < 1 || set >= h->nsets) return fail(h, MGN_E_ARG, "mgn_set_edge_set: set %d out of range (handle has %d edge sets; set 0 is mgn_set_graph's)", set, h->nsets);
+    if (index_base != 0 && index_base != 1) return fail(h, MGN_E_ARG, "mgn_set_edge_set: index_base must be 0 or 1");
+    if (E < 0 || (E > 0 && (!senders || !receivers))) return fail(h, MGN_E_ARG, "mgn_set_edge_set: null senders/receivers");
+    auto& e1 = h->es[set];
+    e1.gs.assign(senders, senders + E);
+    e1.gr.assign(receivers, receivers + E);
+    e1.gbase = index_base;
+    e1.have_ef = false;
+    EdgeList sets[MAX_EDGE_SETS];
+    for (int q = 0; q < h->nsets; ++q) sets[q] = {(int64_t)h->es[q].gs.size(), h->es[q].gs.data(), h->es[q].gr.data(), h->es[q].gbase};
+    const int32_t n_halo_before = h->g.n_halo;
+    if (int rc = rebuild_graph(h, h->g.N, sets, nullptr, 0, true, "mgn_set_edge_set")) return rc;
+    if (h->host_only) return MGN_OK;
+    // node numbering is unchanged with one partition (no boundary / halo): V and set 0's latents stay valid and only the
+    // new set's buffers are (re)sized; a changed halo re-sizes everything that is indexed by owned + halo rows
+    if (h->cfg.nranks == 1 && n_halo_before == 0) {
+        if (int rc = alloc_edge_set(h, set)) return rc;
+    } else if (int rc = alloc_latents(h)) return rc;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    h->have_graph = true;
+    return MGN_OK;
+}
+
+int mgn_edge_set_info(const mgn_handle* h, int32_t set, int64_t* E, int64_t* e_local) {
+    if (!h || !h->have_graph) return MGN_E_STATE;
+    if (set < 0 || set >= h->nsets) return MGN_E_ARG;
+    if (E) *E = h->g.set[set].E;
+    if (e_local) *e_local = h->g.set[set].e_local;
+    return MGN_OK;
+}
+
+int mgn_set_edge_features(mgn_handle* h, int32_t set, const float* ef) {
+    if (int rc = need(h, false, true)) return rc;
+    if (set < 1 || set >= h->nsets) return fail(h, MGN_E_ARG, "mgn_set_edge_features: set %d out of range", set);
+    auto& es = h->es[set];
+    const size_t bytes = (size_t)h->g.set[set].E * es.Fe * 4;
+    if (bytes && !ef) return fail(h, MGN_E_ARG, "mgn_set_edge_features: null input");
+    HIPCHK(h, es.d_ef.ensure(bytes));
+    if (bytes) HIPCHK(h, hipMemcpyAsync(es.d_ef.p, ef, bytes, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    es.have_ef = true;
     return MGN_OK;
 }
 
@@ -685,7 +859,7 @@ int mgn_partition_info(const mgn_handle* h, int32_t* n_own, int32_t* n_halo, int
     if (!h || !h->have_graph) return MGN_E_STATE;
     if (n_own) *n_own = h->g.n_own;
     if (n_halo) *n_halo = h->g.n_halo;
-    if (e_local) *e_local = h->g.e_local;
+    if (e_local) *e_local = h->g.set[0].e_local;
     return MGN_OK;
 }
 
@@ -697,7 +871,7 @@ int mgn_owned_nodes(const mgn_handle* h, int32_t* ids) {
 
 int mgn_local_edges(const mgn_handle* h, int64_t* ids) {
     if (!h || !h->have_graph || !ids) return MGN_E_STATE;
-    memcpy(ids, h->g.edge_gid.data(), h->g.edge_gid.size() * 8);
+    memcpy(ids, h->g.set[0].edge_gid.data(), h->g.set[0].edge_gid.size() * 8);
     return MGN_OK;
 }
 
@@ -724,9 +898,9 @@ int mgn_halo_send_index(const mgn_handle* h, int32_t* rows) {
 
 int mgn_local_graph(const mgn_handle* h, int32_t* snd, int32_t* rcv, int32_t* rowptr) {
     if (!h || !h->have_graph) return MGN_E_STATE;
-    if (snd) memcpy(snd, h->g.snd.data(), h->g.snd.size() * 4);
-    if (rcv) memcpy(rcv, h->g.rcv.data(), h->g.rcv.size() * 4);
-    if (rowptr) memcpy(rowptr, h->g.rowptr.data(), h->g.rowptr.size() * 4);
+    if (snd) memcpy(snd, h->g.set[0].snd.data(), h->g.set[0].snd.size() * 4);
+    if (rcv) memcpy(rcv, h->g.set[0].rcv.data(), h->g.set[0].rcv.size() * 4);
+    if (rowptr) memcpy(rowptr, h->g.set[0].rowptr.data(), h->g.set[0].rowptr.size() * 4);
     return MGN_OK;
 }
 
@@ -753,16 +927,32 @@ static int upload_inputs(mgn_handle* h, const float* a, int wa, const float* b, 
         HIPCHK(h, h->d_nfB.ensure((size_t)g.N * wb * 4));
         HIPCHK(h, hipMemcpyAsync(h->d_nfB.p, b, (size_t)g.N * wb * 4, hipMemcpyHostToDevice, h->stream));
     }
-    HIPCHK(h, h->d_ef.ensure((size_t)g.E * h->cfg.Fe * 4));
-    HIPCHK(h, hipMemcpyAsync(h->d_ef.p, ef, (size_t)g.E * h->cfg.Fe * 4, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, h->es[0].d_ef.ensure((size_t)g.set[0].E * h->cfg.Fe * 4));
+    HIPCHK(h, hipMemcpyAsync(h->es[0].d_ef.p, ef, (size_t)g.set[0].E * h->cfg.Fe * 4, hipMemcpyHostToDevice, h->stream));
     return MGN_OK;
 }
 
 int mgn_fwd_upload(mgn_handle* h, const float* nf, const float* ef) {
     if (int rc = need(h, false, true)) return rc;
     h->have_static = false;
-    if (!nf || (!ef && h->g.E > 0)) return fail(h, MGN_E_ARG, "mgn_fwd_upload: null input");
+    if (!nf || (!ef && h->g.set[0].E > 0)) return fail(h, MGN_E_ARG, "mgn_fwd_upload: null input");
     return upload_inputs(h, nf, h->cfg.Fn, nullptr, 0, ef);
+}
+
+static int project_set(mgn_handle* h, int k, int q, int32_t tile0 = 0, int32_t ntiles = -1) {   // P,Q of set q for step k (k = mps: step 0)
+    if (ntiles < 0) ntiles = h->ntiles_n;
+    if (is_bf16(h)) {
+        BfNodeArgs b = bf_node_args(h, k, q, true);
+        b.tile0 = tile0;
+        b.ntiles = ntiles;
+        HIPCHK(h, launch_project_bf16(b, h->stream));
+        return MGN_OK;
+    }
+    NodeArgs a = node_args(h, k, 2, q);
+    a.tile0 = tile0;
+    a.ntiles = ntiles;
+    HIPCHK(h, launch_project(h->cfg.L, a, h->stream));
+    return MGN_OK;
 }
 
 static int encode_impl(mgn_handle* h, bool use_norms, bool nodes = true, bool edges = true) {
@@ -782,49 +972,58 @@ static int encode_impl(mgn_handle* h, bool use_norms, bool nodes = true, bool ed
         if (use_norms && h->have_nnorm) { a.scale = nrm; a.shift = nrm + c.Fn; }
         a.w1f = W(h, h->en_w1f);
         a.V = h->V.as<float>();
-        a.P = h->P.as<float>();
-        a.Q = h->Q.as<float>();
+        a.P = h->es[0].P.as<float>();
+        a.Q = h->es[0].Q.as<float>();
         for (int i = 0; i < 4; ++i) a.chunk[i] = W(h, h->en_ch[i]);
         a.tabs = W(h, h->en_tabs);
         HIPCHK(h, launch_enc_node(c.L, a, h->stream));
         if (is_bf16(h)) {   // fp32 encoder output -> bf16 state; P,Q of step 0 from the bf16 latents
             HIPCHK(h, launch_tile_f32_to_bf16(h->V.as<float>(), h->bV.as<uint16_t>(), h->ntiles_n, h->stream));
-            HIPCHK(h, launch_project_bf16(bf_node_args(h, c.mps), h->stream));
+            if (int rc = project_set(h, c.mps, 0)) return rc;
         }
+        for (int q = 1; q < h->nsets; ++q)
+            if (int rc = project_set(h, c.mps, q)) return rc;
     }
     if (edges) {
-        EncEdgeArgs b{};
-        b.E = g.e_local;
-        b.ntiles = h->ntiles_e;
-        b.gid = h->d_edge_gid.as<int64_t>();
-        b.ef = h->d_ef.as<float>();
-        b.Fe = c.Fe;
-        if (use_norms && h->have_enorm) { b.scale = nrm + 2 * c.Fn; b.shift = nrm + 2 * c.Fn + c.Fe; }
-        b.w1f = W(h, h->ee_w1f);
-        b.Elat = h->Elat.as<float>();
-        for (int i = 0; i < 2; ++i) b.chunk[i] = W(h, h->ee_ch[i]);
-        b.tabs = W(h, h->ee_tabs);
-        HIPCHK(h, launch_enc_edge(c.L, b, h->stream));
-        if (is_bf16(h)) HIPCHK(h, launch_tile_f32_to_bf16(h->Elat.as<float>(), h->bElat.as<uint16_t>(), h->ntiles_e, h->stream));
+        for (int q = 0; q < h->nsets; ++q) {
+            auto& es = h->es[q];
+            EncEdgeArgs b{};
+            b.E = g.set[q].e_local;
+            b.ntiles = es.ntiles_e;
+            b.gid = es.d_edge_gid.as<int64_t>();
+            b.ef = es.d_ef.as<float>();
+            b.Fe = es.Fe;
+            if (q == 0 && use_norms && h->have_enorm) { b.scale = nrm + 2 * c.Fn; b.shift = nrm + 2 * c.Fn + c.Fe; }
+            b.w1f = W(h, es.ee_w1f);
+            b.Elat = es.Elat.as<float>();
+            for (int i = 0; i < 2; ++i) b.chunk[i] = W(h, es.ee_ch[i]);
+            b.tabs = W(h, es.ee_tabs);
+            HIPCHK(h, launch_enc_edge(c.L, b, h->stream));
+            if (is_bf16(h)) HIPCHK(h, launch_tile_f32_to_bf16(es.Elat.as<float>(), es.bElat.as<uint16_t>(), es.ntiles_e, h->stream));
+        }
     }
+    return MGN_OK;
+}
+
+static int need_set_features(mgn_handle* h) {
+    for (int q = 1; q < h->nsets; ++q)
+        if (h->g.set[q].E > 0 && !h->es[q].have_ef)
+            return fail(h, MGN_E_STATE, "edge set %d has edges but no features: call mgn_set_edge_features after mgn_set_edge_set", q);
     return MGN_OK;
 }
 
 int mgn_fwd_encode(mgn_handle* h) {
     if (int rc = need(h, true, true)) return rc;
     if (!h->d_nfA.p) return fail(h, MGN_E_STATE, "mgn_fwd_encode before mgn_fwd_upload");
+    if (int rc = need_set_features(h)) return rc;
     return encode_impl(h, false);
 }
 
 int mgn_proc_begin(mgn_handle* h) {
     if (int rc = need(h, true, true)) return rc;
     ProfScope ps(h, F_NODE);
-    if (is_bf16(h)) {
-        HIPCHK(h, launch_project_bf16(bf_node_args(h, h->cfg.mps), h->stream));
-        return MGN_OK;
-    }
-    const NodeArgs a = node_args(h, h->cfg.mps, 2);
-    HIPCHK(h, launch_project(h->cfg.L, a, h->stream));
+    for (int q = 0; q < h->nsets; ++q)
+        if (int rc = project_set(h, h->cfg.mps, q)) return rc;
     return MGN_OK;
 }
 
@@ -832,12 +1031,10 @@ int mgn_proc_edge(mgn_handle* h, int32_t k) {
     if (int rc = need(h, true, true)) return rc;
     if (k < 0 || k >= h->cfg.mps) return fail(h, MGN_E_ARG, "mgn_proc_edge: step %d out of range", k);
     ProfScope ps(h, F_EDGE);
-    if (is_bf16(h)) {
-        HIPCHK(h, launch_edge_bf16(bf_edge_args(h, k), h->stream));
-        return MGN_OK;
+    for (int q = 0; q < h->nsets; ++q) {
+        if (is_bf16(h)) HIPCHK(h, launch_edge_bf16(bf_edge_args(h, k, q), h->stream));
+        else HIPCHK(h, launch_edge_step(h->cfg.L, edge_args(h, k, q), h->stream));
     }
-    const EdgeArgs a = edge_args(h, k);
-    HIPCHK(h, launch_edge_step(h->cfg.L, a, h->stream));
     return MGN_OK;
 }
 
@@ -848,13 +1045,16 @@ int mgn_proc_node(mgn_handle* h, int32_t k, int32_t project_next) {
     ProfScope ps(h, F_NODE);
     if (is_bf16(h)) {
         HIPCHK(h, launch_node_bf16(bf_node_args(h, k), h->stream));
-        if (project_next) HIPCHK(h, launch_project_bf16(bf_node_args(h, k), h->stream));
+        for (int q = 0; project_next && q < h->nsets; ++q)
+            if (int rc = project_set(h, k, q)) return rc;
         return MGN_OK;
     }
-    if (project_next && h->node_split) {
-        // two launches: MLP (2 of its 4 chunks stream from L2), then the projection with both chunks resident
+    if (project_next && (h->node_split || h->nsets > 1)) {
+        // MLP (2 of its chunks LDS-resident, the others stream from L2), then per edge set the projection with both of
+        // its chunks resident
         HIPCHK(h, launch_node_step(h->cfg.L, node_args(h, k, 0), h->stream));
-        HIPCHK(h, launch_project(h->cfg.L, node_args(h, k, 2), h->stream));
+        for (int q = 0; q < h->nsets; ++q)
+            if (int rc = project_set(h, k, q)) return rc;
         return MGN_OK;
     }
     const NodeArgs a = node_args(h, k, project_next ? 1 : 0);
@@ -867,25 +1067,15 @@ int mgn_proc_node_phase(mgn_handle* h, int32_t k, int32_t phase) {
     if (k < -1 || k + 1 >= h->cfg.mps) return fail(h, MGN_E_ARG, "mgn_proc_node_phase: no step %d to project for", k + 1);
     if (phase != 1 && phase != 2) return fail(h, MGN_E_ARG, "mgn_proc_node_phase: phase must be 1 or 2");
     ProfScope ps(h, F_NODE);
-    const int ntb = (h->g.n_boundary + TILE - 1) / TILE;   // tiles that contain a boundary node
-    if (is_bf16(h)) {
-        if (phase == 1 && k >= 0) HIPCHK(h, launch_node_bf16(bf_node_args(h, k), h->stream));
-        BfNodeArgs b = bf_node_args(h, k >= 0 ? k : h->cfg.mps);
-        b.tile0 = phase == 1 ? 0 : (ntb < h->ntiles_n ? ntb : h->ntiles_n);
-        b.ntiles = phase == 1 ? (ntb < h->ntiles_n ? ntb : h->ntiles_n) : h->ntiles_n - b.tile0;
-        HIPCHK(h, launch_project_bf16(b, h->stream));
-        return MGN_OK;
+    const int ntb_all = (h->g.n_boundary + TILE - 1) / TILE;   // tiles that contain a boundary node
+    const int ntb = ntb_all < h->ntiles_n ? ntb_all : h->ntiles_n;
+    if (phase == 1 && k >= 0) {
+        if (is_bf16(h)) HIPCHK(h, launch_node_bf16(bf_node_args(h, k), h->stream));
+        else HIPCHK(h, launch_node_step(h->cfg.L, node_args(h, k, 0), h->stream));
     }
-    if (phase == 1 && k >= 0) HIPCHK(h, launch_node_step(h->cfg.L, node_args(h, k, 0), h->stream));
-    NodeArgs a = node_args(h, k >= 0 ? k : h->cfg.mps, 2);
-    if (phase == 1) {
-        a.tile0 = 0;
-        a.ntiles = ntb < h->ntiles_n ? ntb : h->ntiles_n;
-    } else {
-        a.tile0 = ntb < h->ntiles_n ? ntb : h->ntiles_n;
-        a.ntiles = h->ntiles_n - a.tile0;
-    }
-    HIPCHK(h, launch_project(h->cfg.L, a, h->stream));
+    const int32_t tile0 = phase == 1 ? 0 : ntb, nt = phase == 1 ? ntb : h->ntiles_n - ntb;
+    for (int q = 0; q < h->nsets; ++q)
+        if (int rc = project_set(h, k >= 0 ? k : h->cfg.mps, q, tile0, nt)) return rc;
     return MGN_OK;
 }
 
@@ -943,6 +1133,7 @@ int mgn_forward(mgn_handle* h, const float* nf, const float* ef, float* out) {
     if (int rc = need(h, true, true)) return rc;
     if (h->cfg.nranks != 1)
         return fail(h, MGN_E_STATE, "mgn_forward drives one partition; with nranks > 1 use the staged mgn_fwd_*/mgn_halo_* calls");
+    if (int rc = need_set_features(h)) return rc;
     if (int rc = mgn_fwd_upload(h, nf, ef)) return rc;
     if (int rc = encode_impl(h, false)) return rc;
     if (int rc = run_processor(h, h->cfg.mps)) return rc;
@@ -954,6 +1145,7 @@ int mgn_set_static(mgn_handle* h, const float* onehot, const float* ef_raw, cons
     if (int rc = need(h, true, true)) return rc;
     const mgn_config& c = h->cfg;
     if (c.nranks != 1) return fail(h, MGN_E_STATE, "mgn_set_static drives one partition");
+    if (h->nsets != 1) return fail(h, MGN_E_STATE, "mgn_set_static / mgn_ode_step / mgn_rollout mirror the reference's single-edge-set RHS (src/solve.jl:188-219)");
     if (!ef_raw || (c.Fn > c.O && !onehot)) return fail(h, MGN_E_ARG, "mgn_set_static: null argument");
     if (c.Fn < c.O) return fail(h, MGN_E_ARG, "mgn_set_static: Fn < O");
     const LocalGraph& g = h->g;
@@ -965,8 +1157,8 @@ int mgn_set_static(mgn_handle* h, const float* onehot, const float* ef_raw, cons
         HIPCHK(h, h->d_nfB.ensure((size_t)g.N * h->in_wb * 4));
         HIPCHK(h, hipMemcpyAsync(h->d_nfB.p, onehot, (size_t)g.N * h->in_wb * 4, hipMemcpyHostToDevice, h->stream));
     }
-    HIPCHK(h, h->d_ef.ensure((size_t)g.E * c.Fe * 4));
-    HIPCHK(h, hipMemcpyAsync(h->d_ef.p, ef_raw, (size_t)g.E * c.Fe * 4, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, h->es[0].d_ef.ensure((size_t)g.set[0].E * c.Fe * 4));
+    HIPCHK(h, hipMemcpyAsync(h->es[0].d_ef.p, ef_raw, (size_t)g.set[0].E * c.Fe * 4, hipMemcpyHostToDevice, h->stream));
     h->have_mask = val_mask != nullptr;
     if (val_mask) {
         HIPCHK(h, h->d_mask.ensure((size_t)g.N * 4));
@@ -974,9 +1166,9 @@ int mgn_set_static(mgn_handle* h, const float* onehot, const float* ef_raw, cons
     }
     if (int rc = encode_impl(h, true, false, true)) return rc;       // edge encoder: once per trajectory
     const bool bf = is_bf16(h);
-    const size_t eb = tile_floats(h->ntiles_e, c.L) * (bf ? 2 : 4);
-    HIPCHK(h, h->elat0.ensure(eb));
-    HIPCHK(h, hipMemcpyAsync(h->elat0.p, bf ? h->bElat.p : h->Elat.p, eb, hipMemcpyDeviceToDevice, h->stream));
+    const size_t eb = tile_floats(h->es[0].ntiles_e, c.L) * (bf ? 2 : 4);
+    HIPCHK(h, h->es[0].elat0.ensure(eb));
+    HIPCHK(h, hipMemcpyAsync(h->es[0].elat0.p, bf ? h->es[0].bElat.p : h->es[0].Elat.p, eb, hipMemcpyDeviceToDevice, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     h->have_static = true;
     return MGN_OK;
@@ -986,6 +1178,7 @@ int mgn_ode_step(mgn_handle* h, const float* x, const float* onehot, const float
     if (int rc = need(h, true, true)) return rc;
     const mgn_config& c = h->cfg;
     if (h->cfg.nranks != 1) return fail(h, MGN_E_STATE, "mgn_ode_step drives one partition");
+    if (h->nsets != 1) return fail(h, MGN_E_STATE, "%s mirrors the reference's single-edge-set RHS (src/solve.jl:188-219); this handle has two edge sets", "mgn_ode_step");
     if (!x || !dxdt) return fail(h, MGN_E_ARG, "mgn_ode_step: null argument");
     if (c.Fn < c.O) return fail(h, MGN_E_ARG, "mgn_ode_step: Fn < O");
     if (!onehot && !ef_raw && !val_mask) {
@@ -994,8 +1187,8 @@ int mgn_ode_step(mgn_handle* h, const float* x, const float* onehot, const float
         HIPCHK(h, hipMemcpyAsync(h->d_nfA.p, x, (size_t)h->g.N * c.O * 4, hipMemcpyHostToDevice, h->stream));
         if (int rc = encode_impl(h, true, true, false)) return rc;
         const bool bf = is_bf16(h);
-        const size_t eb = tile_floats(h->ntiles_e, c.L) * (bf ? 2 : 4);
-        HIPCHK(h, hipMemcpyAsync(bf ? h->bElat.p : h->Elat.p, h->elat0.p, eb, hipMemcpyDeviceToDevice, h->stream));
+        const size_t eb = tile_floats(h->es[0].ntiles_e, c.L) * (bf ? 2 : 4);
+        HIPCHK(h, hipMemcpyAsync(bf ? h->es[0].bElat.p : h->es[0].Elat.p, h->es[0].elat0.p, eb, hipMemcpyDeviceToDevice, h->stream));
         if (int rc = run_processor(h, c.mps)) return rc;
         if (int rc = decode_impl(h, true)) return rc;
         return mgn_fwd_download(h, dxdt);
@@ -1054,8 +1247,8 @@ struct Rollout {
         if (!rc) {
             // encoded edge latents are identical for every RHS of a trajectory (static edge features, frozen e_norm)
             const bool bf = c.dtype == MGN_BF16;
-            const size_t eb = tile_floats(h->ntiles_e, c.L) * (bf ? 2 : 4);
-            hipError_t e = hipMemcpyAsync(bf ? h->bElat.p : h->Elat.p, h->ode.as<char>() + elat0_off, eb, hipMemcpyDeviceToDevice, h->stream);
+            const size_t eb = tile_floats(h->es[0].ntiles_e, c.L) * (bf ? 2 : 4);
+            hipError_t e = hipMemcpyAsync(bf ? h->es[0].bElat.p : h->es[0].Elat.p, h->ode.as<char>() + elat0_off, eb, hipMemcpyDeviceToDevice, h->stream);
             if (e != hipSuccess) rc = fail(h, MGN_E_HIP, "rollout: Elat restore failed: %s", hipGetErrorString(e));
         }
         if (!rc) rc = run_processor(h, c.mps);
@@ -1086,6 +1279,7 @@ int mgn_rollout(mgn_handle* h, mgn_rollout_desc* d) {
     if (int rc = need(h, true, true)) return rc;
     const mgn_config& c = h->cfg;
     if (c.nranks != 1) return fail(h, MGN_E_STATE, "mgn_rollout drives one partition");
+    if (h->nsets != 1) return fail(h, MGN_E_STATE, "%s mirrors the reference's single-edge-set RHS (src/solve.jl:188-219); this handle has two edge sets", "mgn_rollout");
     if (!d || !d->x0 || !d->out || !d->ef_raw || (c.Fn > c.O && !d->node_type_onehot)) return fail(h, MGN_E_ARG, "mgn_rollout: null argument");
     if (c.Fn < c.O) return fail(h, MGN_E_ARG, "mgn_rollout: Fn < O");
     if (d->n_saves < 1 || d->saves_dt <= 0.f || d->t1 < d->t0) return fail(h, MGN_E_ARG, "mgn_rollout: bad time grid");
@@ -1101,7 +1295,7 @@ int mgn_rollout(mgn_handle* h, mgn_rollout_desc* d) {
     R.n = (int64_t)g.N * c.O;
     const size_t nb = (size_t)R.n * 4;
     const size_t fb = d->inflow_data ? (size_t)d->n_frames * nb : 0, sb = (size_t)d->n_saves * nb;
-    const size_t eb = tile_floats(h->ntiles_e, c.L) * 4;
+    const size_t eb = tile_floats(h->es[0].ntiles_e, c.L) * 4;
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
     size_t off = 0;
     auto take = [&](size_t bytes) { const size_t o = off; off += al(bytes); return o; };
@@ -1130,7 +1324,7 @@ int mgn_rollout(mgn_handle* h, mgn_rollout_desc* d) {
         HIPCHK(h, hipMemcpyAsync(h->d_mask.p, d->val_mask, (size_t)g.N * 4, hipMemcpyHostToDevice, h->stream));
     }
     if (int rc = encode_impl(h, true, false, true)) return rc;
-    HIPCHK(h, hipMemcpyAsync(base + R.elat0_off, is_bf16(h) ? h->bElat.p : h->Elat.p, is_bf16(h) ? eb / 2 : eb, hipMemcpyDeviceToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(base + R.elat0_off, is_bf16(h) ? h->es[0].bElat.p : h->es[0].Elat.p, is_bf16(h) ? eb / 2 : eb, hipMemcpyDeviceToDevice, h->stream));
 
     d->n_accept = d->n_reject = 0;
     int saved = 0;
@@ -1227,25 +1421,50 @@ int mgn_rollout(mgn_handle* h, mgn_rollout_desc* d) {
 // ---- latents -------------------------------------------------------------------------------------
 // Host boundary of the latents: the caller's arrays travel over PCIe as they are (one contiguous copy each) and
 // the gather into engine order / tile-major storage runs on the device.
-int mgn_latents_import(mgn_handle* h, const float* v, const float* e) {
-    if (int rc = need(h, false, true)) return rc;
-    if (!v || (!e && h->g.e_local > 0)) return fail(h, MGN_E_ARG, "mgn_latents_import: null input");
-    const LocalGraph& g = h->g;
+static int import_edges(mgn_handle* h, int q, const float* e) {
+    const EdgeTopo& t = h->g.set[q];
+    auto& es = h->es[q];
     const int L = h->cfg.L;
-    const size_t vb = (size_t)g.N * L * 4, ebytes = (size_t)g.E * L * 4;
-    HIPCHK(h, h->stage.ensure(vb > ebytes ? vb : ebytes));
-    HIPCHK(h, hipMemcpyAsync(h->stage.p, v, vb, hipMemcpyHostToDevice, h->stream));
-    HIPCHK(h, launch_rows_to_tiles(h->stage.as<float>(), nullptr, h->d_own_gid.as<int32_t>(), h->V.as<float>(), g.n_own, L, h->stream));
-    if (g.e_local > 0) {
+    if (t.e_local > 0) {
+        if (!e) return fail(h, MGN_E_ARG, "latents import: null edge input");
+        const size_t ebytes = (size_t)t.E * L * 4;
+        HIPCHK(h, h->stage.ensure(ebytes));
         HIPCHK(h, hipMemcpyAsync(h->stage.p, e, ebytes, hipMemcpyHostToDevice, h->stream));
-        HIPCHK(h, launch_rows_to_tiles(h->stage.as<float>(), h->d_edge_gid.as<int64_t>(), nullptr, h->Elat.as<float>(), g.e_local, L, h->stream));
+        HIPCHK(h, launch_rows_to_tiles(h->stage.as<float>(), es.d_edge_gid.as<int64_t>(), nullptr, es.Elat.as<float>(), t.e_local, L, h->stream));
     }
-    if (is_bf16(h)) {   // the processor state proper is the bf16 copy (rounded once, on the device)
-        HIPCHK(h, launch_tile_f32_to_bf16(h->V.as<float>(), h->bV.as<uint16_t>(), h->ntiles_n, h->stream));
-        HIPCHK(h, launch_tile_f32_to_bf16(h->Elat.as<float>(), h->bElat.as<uint16_t>(), h->ntiles_e, h->stream));
-    }
+    // bf16 mode: the processor state proper is the bf16 copy (rounded once, on the device)
+    if (is_bf16(h)) HIPCHK(h, launch_tile_f32_to_bf16(es.Elat.as<float>(), es.bElat.as<uint16_t>(), es.ntiles_e, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     return MGN_OK;
+}
+
+static int export_edges(mgn_handle* h, int q, float* e) {
+    const EdgeTopo& t = h->g.set[q];
+    auto& es = h->es[q];
+    const int L = h->cfg.L;
+    if (!e || t.E == 0) return MGN_OK;
+    if (is_bf16(h)) HIPCHK(h, launch_tile_bf16_to_f32(es.bElat.as<uint16_t>(), es.Elat.as<float>(), es.ntiles_e, h->stream));
+    const size_t ebytes = (size_t)t.E * L * 4;
+    HIPCHK(h, h->stage.ensure(ebytes));
+    // single partition: every row is owned, the staging image is complete; else keep the caller's foreign rows
+    if (h->cfg.nranks != 1) HIPCHK(h, hipMemcpyAsync(h->stage.p, e, ebytes, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, launch_tiles_to_rows(es.Elat.as<float>(), es.d_edge_gid.as<int64_t>(), nullptr, h->stage.as<float>(), t.e_local, L, h->stream));
+    HIPCHK(h, hipMemcpyAsync(e, h->stage.p, ebytes, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return MGN_OK;
+}
+
+int mgn_latents_import(mgn_handle* h, const float* v, const float* e) {
+    if (int rc = need(h, false, true)) return rc;
+    if (!v) return fail(h, MGN_E_ARG, "mgn_latents_import: null input");
+    const LocalGraph& g = h->g;
+    const int L = h->cfg.L;
+    const size_t vb = (size_t)g.N * L * 4;
+    HIPCHK(h, h->stage.ensure(vb));
+    HIPCHK(h, hipMemcpyAsync(h->stage.p, v, vb, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, launch_rows_to_tiles(h->stage.as<float>(), nullptr, h->d_own_gid.as<int32_t>(), h->V.as<float>(), g.n_own, L, h->stream));
+    if (is_bf16(h)) HIPCHK(h, launch_tile_f32_to_bf16(h->V.as<float>(), h->bV.as<uint16_t>(), h->ntiles_n, h->stream));
+    return import_edges(h, 0, e);
 }
 
 // Writes the owned rows into the caller's GLOBAL-shaped arrays (other rows are left untouched).
@@ -1253,61 +1472,73 @@ int mgn_latents_export(mgn_handle* h, float* v, float* e) {
     if (int rc = need(h, false, true)) return rc;
     const LocalGraph& g = h->g;
     const int L = h->cfg.L;
-    if (is_bf16(h)) {
-        HIPCHK(h, launch_tile_bf16_to_f32(h->bV.as<uint16_t>(), h->V.as<float>(), h->ntiles_n, h->stream));
-        HIPCHK(h, launch_tile_bf16_to_f32(h->bElat.as<uint16_t>(), h->Elat.as<float>(), h->ntiles_e, h->stream));
-    }
-    const size_t vb = (size_t)g.N * L * 4, ebytes = (size_t)g.E * L * 4;
-    HIPCHK(h, h->stage.ensure(vb > ebytes ? vb : ebytes));
-    const bool whole = h->cfg.nranks == 1;   // single partition: every row is owned, the staging image is complete
     if (v) {
-        if (!whole) HIPCHK(h, hipMemcpyAsync(h->stage.p, v, vb, hipMemcpyHostToDevice, h->stream));   // keep foreign rows
+        if (is_bf16(h)) HIPCHK(h, launch_tile_bf16_to_f32(h->bV.as<uint16_t>(), h->V.as<float>(), h->ntiles_n, h->stream));
+        const size_t vb = (size_t)g.N * L * 4;
+        HIPCHK(h, h->stage.ensure(vb));
+        if (h->cfg.nranks != 1) HIPCHK(h, hipMemcpyAsync(h->stage.p, v, vb, hipMemcpyHostToDevice, h->stream));   // keep foreign rows
         HIPCHK(h, launch_tiles_to_rows(h->V.as<float>(), nullptr, h->d_own_gid.as<int32_t>(), h->stage.as<float>(), g.n_own, L, h->stream));
         HIPCHK(h, hipMemcpyAsync(v, h->stage.p, vb, hipMemcpyDeviceToHost, h->stream));
         HIPCHK(h, hipStreamSynchronize(h->stream));
     }
-    if (e && g.E > 0) {
-        if (!whole) HIPCHK(h, hipMemcpyAsync(h->stage.p, e, ebytes, hipMemcpyHostToDevice, h->stream));
-        HIPCHK(h, launch_tiles_to_rows(h->Elat.as<float>(), h->d_edge_gid.as<int64_t>(), nullptr, h->stage.as<float>(), g.e_local, L, h->stream));
-        HIPCHK(h, hipMemcpyAsync(e, h->stage.p, ebytes, hipMemcpyDeviceToHost, h->stream));
-        HIPCHK(h, hipStreamSynchronize(h->stream));
-    }
-    return MGN_OK;
+    return export_edges(h, 0, e);
+}
+
+int mgn_edge_latents_import(mgn_handle* h, int32_t set, const float* e) {
+    if (int rc = need(h, false, true)) return rc;
+    if (set < 0 || set >= h->nsets) return fail(h, MGN_E_ARG, "mgn_edge_latents_import: set %d out of range", set);
+    return import_edges(h, set, e);
+}
+
+int mgn_edge_latents_export(mgn_handle* h, int32_t set, float* e) {
+    if (int rc = need(h, false, true)) return rc;
+    if (set < 0 || set >= h->nsets) return fail(h, MGN_E_ARG, "mgn_edge_latents_export: set %d out of range", set);
+    return export_edges(h, set, e);
 }
 
 int mgn_latents_randn(mgn_handle* h, uint64_t seed) {
     if (int rc = need(h, false, true)) return rc;
     const LocalGraph& g = h->g;
     HIPCHK(h, launch_randn_rows(h->V.as<float>(), nullptr, h->d_own_gid.as<int32_t>(), g.n_own, h->cfg.L, seed, h->stream));
-    HIPCHK(h, launch_randn_rows(h->Elat.as<float>(), h->d_edge_gid.as<int64_t>(), nullptr, g.e_local, h->cfg.L,
-                                seed ^ 0xE5E5E5E5E5E5E5E5ull, h->stream));
+    for (int q = 0; q < h->nsets; ++q)
+        HIPCHK(h, launch_randn_rows(h->es[q].Elat.as<float>(), h->es[q].d_edge_gid.as<int64_t>(), nullptr, g.set[q].e_local, h->cfg.L,
+                                    seed ^ (0xE5E5E5E5E5E5E5E5ull + (uint64_t)q * 0x9E3779B97F4A7C15ull), h->stream));
     if (is_bf16(h)) {
         HIPCHK(h, launch_tile_f32_to_bf16(h->V.as<float>(), h->bV.as<uint16_t>(), h->ntiles_n, h->stream));
-        HIPCHK(h, launch_tile_f32_to_bf16(h->Elat.as<float>(), h->bElat.as<uint16_t>(), h->ntiles_e, h->stream));
+        for (int q = 0; q < h->nsets; ++q)
+            HIPCHK(h, launch_tile_f32_to_bf16(h->es[q].Elat.as<float>(), h->es[q].bElat.as<uint16_t>(), h->es[q].ntiles_e, h->stream));
     }
     return MGN_OK;
 }
 
+// (sum, sum of squares) of the node latents and of the edge latents (all sets)
 int mgn_latents_checksum(mgn_handle* h, double* sv, double* se, double* qv, double* qe) {
     if (int rc = need(h, false, true)) return rc;
     const int np_ = checksum_partials();
+    const int nb = 1 + h->nsets;
     if (is_bf16(h)) {
         HIPCHK(h, launch_tile_bf16_to_f32(h->bV.as<uint16_t>(), h->V.as<float>(), h->ntiles_n, h->stream));
-        HIPCHK(h, launch_tile_bf16_to_f32(h->bElat.as<uint16_t>(), h->Elat.as<float>(), h->ntiles_e, h->stream));
+        for (int q = 0; q < h->nsets; ++q)
+            HIPCHK(h, launch_tile_bf16_to_f32(h->es[q].bElat.as<uint16_t>(), h->es[q].Elat.as<float>(), h->es[q].ntiles_e, h->stream));
     }
-    HIPCHK(h, h->d_sum.ensure((size_t)2 * np_ * sizeof(double)));
+    HIPCHK(h, h->d_sum.ensure((size_t)nb * np_ * sizeof(double)));
     HIPCHK(h, launch_checksum(h->V.as<float>(), (int64_t)tile_floats(h->ntiles_n, h->cfg.L), h->d_sum.as<double>(), h->stream));
-    HIPCHK(h, launch_checksum(h->Elat.as<float>(), (int64_t)tile_floats(h->ntiles_e, h->cfg.L), h->d_sum.as<double>() + np_, h->stream));
-    std::vector<double> r((size_t)2 * np_);
+    for (int q = 0; q < h->nsets; ++q)
+        HIPCHK(h, launch_checksum(h->es[q].Elat.as<float>(), (int64_t)tile_floats(h->es[q].ntiles_e, h->cfg.L),
+                                  h->d_sum.as<double>() + (size_t)(1 + q) * np_, h->stream));
+    std::vector<double> r((size_t)nb * np_);
     HIPCHK(h, hipMemcpyAsync(r.data(), h->d_sum.p, r.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     double acc[4] = {0, 0, 0, 0};   // bitwise reproducible: fixed partials, fixed order
     for (int b = 0; b < np_ / 2; ++b) {
         acc[0] += r[2 * b];
         acc[1] += r[2 * b + 1];
-        acc[2] += r[np_ + 2 * b];
-        acc[3] += r[np_ + 2 * b + 1];
     }
+    for (int q = 0; q < h->nsets; ++q)
+        for (int b = 0; b < np_ / 2; ++b) {
+            acc[2] += r[(size_t)(1 + q) * np_ + 2 * b];
+            acc[3] += r[(size_t)(1 + q) * np_ + 2 * b + 1];
+        }
     if (sv) *sv = acc[0];
     if (qv) *qv = acc[1];
     if (se) *se = acc[2];
@@ -1327,7 +1558,7 @@ int mgn_processor_steps_dev(mgn_handle* h, int32_t nsteps) {
     if (nsteps == 0) return MGN_OK;
     // Graph replay only helps launch-bound (small) passes; it needs a capturable stream (not the null stream) and no
     // per-launch event records.
-    const bool graphable = h->use_graph && !h->prof && h->stream != nullptr && h->ntiles_e <= 16384;
+    const bool graphable = h->use_graph && !h->prof && h->stream != nullptr && h->es[0].ntiles_e <= 16384;
     if (!graphable) return processor_pass(h, nsteps);
     if (h->graph_exec && h->graph_nsteps == nsteps) {
         HIPCHK(h, hipGraphLaunch(h->graph_exec, h->stream));
@@ -1371,7 +1602,8 @@ int mgn_processor_steps(mgn_handle* h, float* v, float* e, int32_t nsteps) {
 }
 
 // ---- halo ------------------------------------------------------------------------------------------
-int mgn_halo_bytes_per_row(const mgn_handle* h) { return h ? h->cfg.L * (h->cfg.dtype == MGN_BF16 ? 2 : 4) : MGN_E_ARG; }
+// one halo row carries the P row of every edge set: [set 0: L][set 1: L]
+int mgn_halo_bytes_per_row(const mgn_handle* h) { return h ? h->nsets * h->cfg.L * (h->cfg.dtype == MGN_BF16 ? 2 : 4) : MGN_E_ARG; }
 
 int mgn_halo_pack(mgn_handle* h, void* send_dev) {
     if (int rc = need(h, false, true)) return rc;
@@ -1379,11 +1611,15 @@ int mgn_halo_pack(mgn_handle* h, void* send_dev) {
     if (rows == 0) return MGN_OK;
     if (!send_dev) return fail(h, MGN_E_ARG, "mgn_halo_pack: null buffer");
     ProfScope ps(h, F_HALO);
-    if (is_bf16(h)) {
-        HIPCHK(h, launch_gather_rows16(h->bP.as<uint16_t>(), h->d_send_idx.as<int32_t>(), reinterpret_cast<uint16_t*>(send_dev), rows, h->stream));
-        return MGN_OK;
+    const int L = h->cfg.L, stride = h->nsets * L;
+    for (int q = 0; q < h->nsets; ++q) {
+        if (is_bf16(h))
+            HIPCHK(h, launch_gather_rows16(h->es[q].bP.as<uint16_t>(), h->d_send_idx.as<int32_t>(),
+                                           reinterpret_cast<uint16_t*>(send_dev) + (size_t)q * L, rows, stride, h->stream));
+        else
+            HIPCHK(h, launch_gather_rows(h->es[q].P.as<float>(), h->d_send_idx.as<int32_t>(), reinterpret_cast<float*>(send_dev) + (size_t)q * L,
+                                         rows, L, stride, h->stream));
     }
-    HIPCHK(h, launch_gather_rows(h->P.as<float>(), h->d_send_idx.as<int32_t>(), reinterpret_cast<float*>(send_dev), rows, h->cfg.L, h->stream));
     return MGN_OK;
 }
 
@@ -1393,13 +1629,12 @@ int mgn_halo_unpack(mgn_handle* h, const void* recv_dev) {
     if (g.n_halo == 0) return MGN_OK;
     if (!recv_dev) return fail(h, MGN_E_ARG, "mgn_halo_unpack: null buffer");
     ProfScope ps(h, F_HALO);
-    if (is_bf16(h)) {
-        HIPCHK(h, hipMemcpyAsync(h->bP.as<uint16_t>() + (size_t)g.n_own * h->cfg.L, recv_dev, (size_t)g.n_halo * h->cfg.L * 2,
-                                 hipMemcpyDeviceToDevice, h->stream));
-        return MGN_OK;
+    const size_t b = is_bf16(h) ? 2 : 4, rowb = (size_t)h->cfg.L * b;
+    for (int q = 0; q < h->nsets; ++q) {
+        char* dst = reinterpret_cast<char*>(is_bf16(h) ? h->es[q].bP.p : h->es[q].P.p) + (size_t)g.n_own * rowb;
+        HIPCHK(h, hipMemcpy2DAsync(dst, rowb, reinterpret_cast<const char*>(recv_dev) + (size_t)q * rowb, (size_t)h->nsets * rowb, rowb,
+                                   (size_t)g.n_halo, hipMemcpyDeviceToDevice, h->stream));
     }
-    HIPCHK(h, hipMemcpyAsync(h->P.as<float>() + (size_t)g.n_own * h->cfg.L, recv_dev, (size_t)g.n_halo * h->cfg.L * 4,
-                             hipMemcpyDeviceToDevice, h->stream));
     return MGN_OK;
 }
 

@@ -35,9 +35,12 @@ def _c32(a, shape=None):
 class Engine:
     """One engine handle == one mesh partition on one GPU (rank/nranks select the partition)."""
 
-    def __init__(self, Fn, Fe, O, L=128, hidden_layers=2, mps=15, rank=0, nranks=1, device=-1, dtype="f32"):
+    def __init__(self, Fn, Fe, O, L=128, hidden_layers=2, mps=15, rank=0, nranks=1, device=-1, dtype="f32", Fe2=None):
+        """Fe2: input width of a second edge set (world edges, MGN-spec "per edge set"); None = the reference's one set."""
         self.lib = _capi.load()
-        self.cfg = MgnConfig(Fn, Fe, O, L, hidden_layers, mps, {"f32": 0, "bf16": 1}[dtype], rank, nranks, device)
+        self.cfg = MgnConfig(Fn, Fe, O, L, hidden_layers, mps, {"f32": 0, "bf16": 1}[dtype], rank, nranks, device,
+                             2 if Fe2 else 1, Fe2 or 0)
+        self.E2 = 0
         self.h = C.c_void_p()
         rc = self.lib.mgn_create(C.byref(self.cfg), C.byref(self.h))
         if rc != 0:
@@ -114,10 +117,41 @@ class Engine:
                 raise ValueError("DimensionMismatch: mesh_pos must be [N][dim]")
             pd = pos.shape[1]
         self._chk(self.lib.mgn_set_graph(self.h, N, s.size, i32(s), i32(r), index_base, f32(pos), pd))
-        self.N, self.E = int(N), int(s.size)
+        self.N, self.E, self.E2 = int(N), int(s.size), 0
+        self._refresh_partition()
+
+    def _refresh_partition(self):
         a, b, c = C.c_int32(), C.c_int32(), C.c_int64()
         self._chk(self.lib.mgn_partition_info(self.h, C.byref(a), C.byref(b), C.byref(c)))
         self.n_own, self.n_halo, self.e_local = a.value, b.value, c.value
+
+    def set_edge_set(self, set_index, senders, receivers, index_base=0):
+        """Topology of the second edge set (after set_graph; as often as it changes)."""
+        s = np.ascontiguousarray(senders, dtype=np.int32).ravel()
+        r = np.ascontiguousarray(receivers, dtype=np.int32).ravel()
+        if s.size != r.size:
+            raise ValueError("DimensionMismatch: senders and receivers differ in length")
+        self._chk(self.lib.mgn_set_edge_set(self.h, set_index, s.size, i32(s), i32(r), index_base))
+        self.E2 = int(s.size)
+        self._refresh_partition()
+
+    def set_edge_features(self, set_index, ef):
+        ef = _c32(ef, (self.E2, self.cfg.Fe2))
+        self._chk(self.lib.mgn_set_edge_features(self.h, set_index, f32(ef)))
+
+    def edge_set_info(self, set_index):
+        a, b = C.c_int64(), C.c_int64()
+        self._chk(self.lib.mgn_edge_set_info(self.h, set_index, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def edge_latents_import(self, set_index, e):
+        e = _c32(e, ((self.E, self.E2)[set_index], self.cfg.L))
+        self._chk(self.lib.mgn_edge_latents_import(self.h, set_index, f32(e)))
+
+    def edge_latents_export(self, set_index, e=None):
+        e = np.zeros(((self.E, self.E2)[set_index], self.cfg.L), np.float32) if e is None else e
+        self._chk(self.lib.mgn_edge_latents_export(self.h, set_index, f32(e)))
+        return e
 
     def owned_nodes(self):
         out = np.empty(self.n_own, np.int32)

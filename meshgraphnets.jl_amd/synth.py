@@ -3,6 +3,7 @@ reference, .gitignore:1-2).  NumPy only; deterministic for a given seed.
 
 M-cyl : cylinder_flow-like planar triangulation, ~2k nodes / ~12k directed edges   (cfg-1/2/5)
 M-1M  : nx x ny jittered grid, random diagonal per quad; 1000x1000 -> N=1 000 000, E=5 992 002 (cfg-4)
+M-flag: 40 x 40 cloth grid folded in world space, mesh edges + world (radius) edges          (cfg-3)
 """
 from __future__ import annotations
 
@@ -71,6 +72,44 @@ def mesh_cyl(seed: int = 1234, n_points: int = 2000):
     vel = np.stack([prof * (1.0 + 0.1 * rng.standard_normal(pos.shape[0])),
                     0.05 * rng.standard_normal(pos.shape[0])], 1).astype(np.float32)
     return pos, cells, node_type, vel
+
+
+def world_edges(world_pos: np.ndarray, radius: float, mesh_senders: np.ndarray, mesh_receivers: np.ndarray):
+    """Radius graph in world space without self loops and without pairs already joined by a mesh edge (DeepMind
+    flag/cloth world edges).  Dense O(N^2) distances: meant for cloth-sized meshes (N ~ 1.6k)."""
+    wp = np.asarray(world_pos, np.float64)
+    n = wp.shape[0]
+    d2 = ((wp[:, None, :] - wp[None, :, :]) ** 2).sum(-1)
+    close = d2 < radius * radius
+    np.fill_diagonal(close, False)
+    close[np.asarray(mesh_senders), np.asarray(mesh_receivers)] = False
+    s, r = np.nonzero(close)
+    return s.astype(np.int32), r.astype(np.int32)
+
+
+def mesh_flag(seed: int = 1234, nx: int = 40, ny: int = 40, radius: float = 0.045):
+    """M-flag (BASELINE cfg-3): nx x ny cloth grid, folded in half in world space so that the two
+    layers (0.03 apart) see each other through world edges.  Returns a dict with mesh_pos [N][2], world_pos [N][3],
+    mesh edges (s, r), world edges (s2, r2), edge features ef [E][7] = (rel world 3, norm, rel mesh 2, norm),
+    ef2 [E2][4] = (rel world 3, norm), node_type [N] (0 normal, 3 handle on the x = 0 column) and velocity [N][3]."""
+    rng = np.random.default_rng(seed)
+    pos, cells = grid_mesh(nx, ny, seed)
+    s, r = cells_to_edges(cells)
+    u, v = pos[:, 0].astype(np.float64), pos[:, 1].astype(np.float64)
+    fold = np.abs(u - 0.5)
+    world = np.stack([fold, v, 0.015 * np.sign(u - 0.5) + 0.01 * np.sin(6.0 * v) * fold], 1)
+    world += 0.002 * rng.standard_normal(world.shape)
+    s2, r2 = world_edges(world, radius, s, r)
+    relw = world[s] - world[r]
+    relm = pos[s].astype(np.float64) - pos[r].astype(np.float64)
+    ef = np.concatenate([relw, np.linalg.norm(relw, axis=1, keepdims=True), relm, np.linalg.norm(relm, axis=1, keepdims=True)], 1)
+    relw2 = world[s2] - world[r2]
+    ef2 = np.concatenate([relw2, np.linalg.norm(relw2, axis=1, keepdims=True)], 1)
+    node_type = np.zeros(pos.shape[0], np.int32)
+    node_type[pos[:, 0] < 1e-6] = 3
+    vel = (0.1 * rng.standard_normal((pos.shape[0], 3))).astype(np.float32)
+    return dict(mesh_pos=pos, world_pos=world.astype(np.float32), cells=cells, s=s, r=r, s2=s2, r2=r2,
+                ef=ef.astype(np.float32), ef2=ef2.astype(np.float32), node_type=node_type, velocity=vel)
 
 
 def random_graph(n: int, e: int, seed: int = 0, allow_isolated: bool = True):

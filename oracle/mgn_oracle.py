@@ -140,26 +140,33 @@ def mlp_shapes(n_in, L, n_out, hidden_layers, ln):
     return shapes
 
 
-def model_layout(Fn, Fe, O, L, hidden_layers, mps):
+def model_layout(Fn, Fe, O, L, hidden_layers, mps, Fe2=None):
     """[(block_name, [(tensor_name, shape)...])...] in packed order:
-    encoder-node, encoder-edge, step1-edge, step1-node, ..., decoder."""
+    encoder-node, encoder-edge (per edge set), step1-edge (per edge set), step1-node, ..., decoder.
+    Fe2: input width of a second edge set (MGN-spec "per edge set": world edges of flag_simple; the reference's
+    FeatureGraph has one set, src/graph.jl:87-96).  The node MLP then takes [v; agg_1; agg_2]."""
+    K = 2 if Fe2 else 1
     blocks = [("enc_node", mlp_shapes(Fn, L, L, hidden_layers, True)),
               ("enc_edge", mlp_shapes(Fe, L, L, hidden_layers, True))]
+    if K == 2:
+        blocks.append(("enc_edge2", mlp_shapes(Fe2, L, L, hidden_layers, True)))
     for k in range(mps):
         blocks.append(("proc%d_edge" % k, mlp_shapes(3 * L, L, L, hidden_layers, True)))
-        blocks.append(("proc%d_node" % k, mlp_shapes(2 * L, L, L, hidden_layers, True)))
+        if K == 2:
+            blocks.append(("proc%d_edge2" % k, mlp_shapes(3 * L, L, L, hidden_layers, True)))
+        blocks.append(("proc%d_node" % k, mlp_shapes((1 + K) * L, L, L, hidden_layers, True)))
     blocks.append(("decoder", mlp_shapes(L, L, O, hidden_layers, False)))
     return blocks
 
 
-def param_count(Fn, Fe, O, L, hidden_layers, mps):
-    return sum(int(np.prod(s)) for _, ts in model_layout(Fn, Fe, O, L, hidden_layers, mps) for _, s in ts)
+def param_count(Fn, Fe, O, L, hidden_layers, mps, Fe2=None):
+    return sum(int(np.prod(s)) for _, ts in model_layout(Fn, Fe, O, L, hidden_layers, mps, Fe2) for _, s in ts)
 
 
-def unpack_params(packed, Fn, Fe, O, L, hidden_layers, mps):
+def unpack_params(packed, Fn, Fe, O, L, hidden_layers, mps, Fe2=None):
     packed = np.asarray(packed)
     out, off = {}, 0
-    for bname, tensors in model_layout(Fn, Fe, O, L, hidden_layers, mps):
+    for bname, tensors in model_layout(Fn, Fe, O, L, hidden_layers, mps, Fe2):
         d = {}
         for tname, shape in tensors:
             n = int(np.prod(shape))
@@ -170,12 +177,12 @@ def unpack_params(packed, Fn, Fe, O, L, hidden_layers, mps):
     return out
 
 
-def init_params(Fn, Fe, O, L, hidden_layers, mps, seed=1234, ln_jitter=0.0):
+def init_params(Fn, Fe, O, L, hidden_layers, mps, seed=1234, ln_jitter=0.0, Fe2=None):
     """Glorot-uniform W, zero b, gamma=1, beta=0 (SURVEY.md 8c 'Init').  ln_jitter/bias jitter > 0
     perturbs b, gamma, beta so that tests exercise them."""
     rng = np.random.default_rng(seed)
     chunks = []
-    for _, tensors in model_layout(Fn, Fe, O, L, hidden_layers, mps):
+    for _, tensors in model_layout(Fn, Fe, O, L, hidden_layers, mps, Fe2):
         for tname, shape in tensors:
             if tname.startswith("W"):
                 lim = np.sqrt(6.0 / (shape[0] + shape[1]))
@@ -218,12 +225,19 @@ def encode(P, nf, ef, h):
     return mlp(nf, P["enc_node"], h), mlp(ef, P["enc_edge"], h)
 
 
-def processor_step(P, k, v, e, senders, receivers, h):
+def processor_step(P, k, v, e, senders, receivers, h, set2=None):
     """One message-passing step (DeepMind GraphNetBlock order): the node update consumes e'
-    BEFORE the residual is added; then v += v', e += e'."""
+    BEFORE the residual is added; then v += v', e += e'.
+    set2 = (e2, senders2, receivers2): second edge set with its own edge MLP; v' = MLP_v([v; agg_1; agg_2])."""
     e_new = mlp(np.concatenate([v[senders], v[receivers], e], 1), P["proc%d_edge" % k], h)
-    agg = scatter_add(e_new, receivers, v.shape[0])
-    v_new = mlp(np.concatenate([v, agg], 1), P["proc%d_node" % k], h)
+    aggs = [scatter_add(e_new, receivers, v.shape[0])]
+    if set2 is not None:
+        e2, s2, r2 = set2
+        e2_new = mlp(np.concatenate([v[s2], v[r2], e2], 1), P["proc%d_edge2" % k], h)
+        aggs.append(scatter_add(e2_new, r2, v.shape[0]))
+    v_new = mlp(np.concatenate([v] + aggs, 1), P["proc%d_node" % k], h)
+    if set2 is not None:
+        return v + v_new, e + e_new, e2 + e2_new
     return v + v_new, e + e_new
 
 
@@ -231,26 +245,42 @@ def decode(P, v, h):
     return mlp(v, P["decoder"], h)
 
 
-def forward(packed, cfg, nf, ef, senders, receivers, return_latents=False, dtype=np.float64):
-    """cfg: dict(Fn, Fe, O, L, hidden_layers, mps).  nf [N][Fn], ef [E][Fe] (already normalised,
-    i.e. the FeatureGraph of src/graph.jl:87-96).  Returns out [N][O]."""
+def _unpack(packed, cfg, dtype):
+    return unpack_params(np.asarray(packed, dtype), cfg["Fn"], cfg["Fe"], cfg["O"], cfg["L"], cfg["hidden_layers"], cfg["mps"],
+                         cfg.get("Fe2"))
+
+
+def forward(packed, cfg, nf, ef, senders, receivers, return_latents=False, dtype=np.float64, set2=None):
+    """cfg: dict(Fn, Fe, O, L, hidden_layers, mps[, Fe2]).  nf [N][Fn], ef [E][Fe] (already normalised,
+    i.e. the FeatureGraph of src/graph.jl:87-96).  set2 = (ef2 [E2][Fe2], senders2, receivers2).  Returns out [N][O]."""
     h = cfg["hidden_layers"]
-    P = unpack_params(np.asarray(packed, dtype), cfg["Fn"], cfg["Fe"], cfg["O"], cfg["L"], h, cfg["mps"])
+    P = _unpack(packed, cfg, dtype)
     v, e = encode(P, np.asarray(nf, dtype), np.asarray(ef, dtype), h)
+    if set2 is not None:
+        e2, s2, r2 = mlp(np.asarray(set2[0], dtype), P["enc_edge2"], h), set2[1], set2[2]
     lat = [(v.copy(), e.copy())]
     for k in range(cfg["mps"]):
-        v, e = processor_step(P, k, v, e, senders, receivers, h)
+        if set2 is not None:
+            v, e, e2 = processor_step(P, k, v, e, senders, receivers, h, (e2, s2, r2))
+        else:
+            v, e = processor_step(P, k, v, e, senders, receivers, h)
         if return_latents:
-            lat.append((v.copy(), e.copy()))
+            lat.append((v.copy(), e.copy()) if set2 is None else (v.copy(), e.copy(), e2.copy()))
     out = decode(P, v, h)
     return (out, lat) if return_latents else out
 
 
-def processor_steps(packed, cfg, v, e, senders, receivers, nsteps, dtype=np.float64):
-    """The benchmarked unit (SURVEY.md 8b mgn_processor_steps): nsteps of A6 on given latents."""
+def processor_steps(packed, cfg, v, e, senders, receivers, nsteps, dtype=np.float64, set2=None):
+    """The benchmarked unit (SURVEY.md 8b mgn_processor_steps): nsteps of A6 on given latents.
+    set2 = (e2 [E2][L], senders2, receivers2): returns (v, e, e2)."""
     h = cfg["hidden_layers"]
-    P = unpack_params(np.asarray(packed, dtype), cfg["Fn"], cfg["Fe"], cfg["O"], cfg["L"], h, cfg["mps"])
+    P = _unpack(packed, cfg, dtype)
     v, e = np.asarray(v, dtype), np.asarray(e, dtype)
+    if set2 is not None:
+        e2, s2, r2 = np.asarray(set2[0], dtype), set2[1], set2[2]
+        for k in range(nsteps):
+            v, e, e2 = processor_step(P, k, v, e, senders, receivers, h, (e2, s2, r2))
+        return v, e, e2
     for k in range(nsteps):
         v, e = processor_step(P, k, v, e, senders, receivers, h)
     return v, e

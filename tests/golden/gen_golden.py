@@ -87,6 +87,33 @@ def gold_rollout():
     print("gold_d_rollout", xs.shape, xs[-1, 0])
 
 
+def gold_two_sets():
+    """GOLD-C: two edge sets, flag_simple-shaped widths (Fn = 3 velocity + 9 one-hot, mesh Fe = 7,
+    world Fe2 = 4, O = 3), L = 128, mps = 15, on a 12 x 10 folded cloth patch.  fp32 engines are held to the fp32
+    tolerance, the bf16 mode to its band."""
+    m = mgn_amd.synth.mesh_flag(SEED + 2, 12, 10, radius=0.13)
+    N, E, E2 = m["mesh_pos"].shape[0], m["s"].size, m["s2"].size
+    L, mps = 128, 15
+    cfg = dict(Fn=12, Fe=7, O=3, L=L, hidden_layers=2, mps=mps, Fe2=4)
+    ps = orc.init_params(12, 7, 3, L, 2, mps, seed=SEED + 2, ln_jitter=0.1, Fe2=4)
+    rng = np.random.default_rng(SEED + 2)
+    onehot = orc.one_hot(m["node_type"], 9, 0)
+    nf = np.concatenate([m["velocity"], onehot], 1).astype(np.float32)
+    # features as the normalisers would hand them over (unit scale), from the synthetic geometry
+    ef = ((m["ef"] - m["ef"].mean(0)) / m["ef"].std(0)).astype(np.float32)
+    ef2 = ((m["ef2"] - m["ef2"].mean(0)) / m["ef2"].std(0)).astype(np.float32)
+    out, lat = orc.forward(ps, cfg, nf, ef, m["s"], m["r"], return_latents=True, set2=(ef2, m["s2"], m["r2"]))
+    d = dict(L=L, mps=mps, seed=SEED + 2, jitter=0.1, params_sha256=sha(ps), senders=m["s"], receivers=m["r"],
+             senders2=m["s2"], receivers2=m["r2"], nf=nf, ef=ef, ef2=ef2, out=out)
+    for k in (1,):
+        d[f"v_after_{k}"] = lat[k][0].astype(np.float32)
+        d[f"e_after_{k}"] = lat[k][1].astype(np.float32)
+        d[f"e2_after_{k}"] = lat[k][2].astype(np.float32)
+    d["v_after_15"] = lat[15][0].astype(np.float32)
+    np.savez_compressed(os.path.join(HERE, "gold_c_two_sets.npz"), **d)
+    print("gold_c_two_sets N", N, "E", E, "E2", E2, "out[0]", out[0], "rng", rng.integers(10))
+
+
 def kats():
     """Known-answer tests stored as data so every implementation reads the same file."""
     tri1 = np.array([[0, 1, 2]], np.int32)
@@ -104,4 +131,5 @@ if __name__ == "__main__":
     gold(32, 1, "gold_a_L32_mps1.npz", [0, 1])
     gold(128, 15, "gold_b_L128_mps15.npz", [1, 8, 15])
     gold_rollout()
+    gold_two_sets()
     kats()

@@ -35,6 +35,8 @@ def test_param_count_and_config_validation(lib_built):
     for (Fn, Fe, O, L, mps) in [(9, 3, 2, 128, 15), (12, 7, 3, 64, 4), (9, 3, 2, 32, 1)]:
         cfg = mgn_amd._capi.MgnConfig(Fn, Fe, O, L, 2, mps, 0, 0, 1, -1)
         assert lib.mgn_param_count(C.byref(cfg)) == orc.param_count(Fn, Fe, O, L, 2, mps)
+        cfg2 = mgn_amd._capi.MgnConfig(Fn, Fe, O, L, 2, mps, 0, 0, 1, -1, 2, 4)      # + world-edge set
+        assert lib.mgn_param_count(C.byref(cfg2)) == orc.param_count(Fn, Fe, O, L, 2, mps, Fe2=4)
     for bad in [dict(L=100), dict(hidden_layers=3), dict(mps=0), dict(Fn=0), dict(rank=2, nranks=2)]:
         kw = dict(Fn=9, Fe=3, O=2, L=128, hidden_layers=2, mps=2, rank=0, nranks=1, device=MGN_DEVICE_NONE)
         kw.update(bad)
@@ -126,6 +128,50 @@ def test_partition_invariants(lib_built, P):
             assert sp[q] == rq[p]
             roff = np.concatenate([[0], np.cumsum(rq)])
             assert np.array_equal(own_p[sidx[off[q]:off[q + 1]]], engs[q].halo_nodes()[roff[p]:roff[p + 1]])
+
+
+@pytest.mark.parametrize("P", [1, 3])
+def test_two_edge_sets_partition_union_halo(lib_built, P):
+    """Second edge set (world edges): same node partition and order as with the mesh set alone when no halo changes;
+    halo / send lists are the union over both sets; the set can be replaced and emptied."""
+    m = synth.mesh_flag(3, 16, 12, radius=0.11)
+    N, s, r, s2, r2 = m["mesh_pos"].shape[0], m["s"], m["r"], m["s2"], m["r2"]
+    assert s2.size > 50
+    engs = []
+    for rk in range(P):
+        e = Engine(12, 7, 3, rank=rk, nranks=P, device=MGN_DEVICE_NONE, Fe2=4)
+        e.set_graph(s, r, N, mesh_pos=m["mesh_pos"])
+        assert e.edge_set_info(1) == (0, 0)
+        engs.append(e)
+    owner = engs[0].node_owner()
+    own_before = [e.owned_nodes() for e in engs]
+    for e in engs:
+        e.set_edge_set(1, s2, r2)
+    assert sum(e.e_local for e in engs) == s.size and sum(e.edge_set_info(1)[1] for e in engs) == s2.size
+    for rk, e in enumerate(engs):
+        assert np.array_equal(e.node_owner(), owner)                        # partition kept
+        assert e.edge_set_info(1)[0] == s2.size
+        assert e.edge_set_info(1)[1] == int(np.sum(owner[r2] == rk))        # edges live with their receiver's owner
+        assert sorted(e.owned_nodes().tolist()) == sorted(own_before[rk].tolist())
+        both_s, both_r = np.concatenate([s, s2]), np.concatenate([r, r2])
+        want_halo = np.unique(both_s[(owner[both_r] == rk) & (owner[both_s] != rk)])
+        assert np.array_equal(np.sort(e.halo_nodes()), want_halo)            # union over the sets
+        if P == 1:
+            assert np.array_equal(e.owned_nodes(), own_before[rk]) and e.n_halo == 0
+    for p in range(P):
+        sp, _ = engs[p].halo_counts()
+        for q in range(P):
+            assert sp[q] == engs[q].halo_counts()[1][p]
+    for e in engs:                                                           # empty it again: back to the mesh-only halo
+        e.set_edge_set(1, s2[:0], r2[:0])
+        assert e.edge_set_info(1) == (0, 0)
+    for rk, e in enumerate(engs):
+        want = np.unique(s[(owner[r] == rk) & (owner[s] != rk)])
+        assert np.array_equal(np.sort(e.halo_nodes()), want)
+    one = Engine(9, 3, 2, device=MGN_DEVICE_NONE)
+    one.set_graph(s, r, N)
+    with pytest.raises(MgnError):
+        one.set_edge_set(1, s2, r2)                                          # single-edge-set handle
 
 
 def test_partition_without_positions_uses_index_blocks(lib_built):

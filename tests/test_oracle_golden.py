@@ -37,6 +37,25 @@ def test_oracle_reproduces_golden(name, snaps):
         assert rel_max(lat[k][1], g[f"e_after_{k}"]) < 1e-6
 
 
+def test_oracle_reproduces_gold_c_two_edge_sets():
+    """GOLD-C: two edge sets (flag_simple-shaped widths).  Also pins that an EMPTY second set only contributes its
+    zero aggregate (the node MLP still has the wider first layer)."""
+    g = load("gold_c_two_sets.npz")
+    cfg = dict(Fn=12, Fe=7, O=3, L=int(g["L"]), hidden_layers=2, mps=int(g["mps"]), Fe2=4)
+    ps = orc.init_params(12, 7, 3, cfg["L"], 2, cfg["mps"], seed=int(g["seed"]), ln_jitter=float(g["jitter"]), Fe2=4)
+    assert hashlib.sha256(ps.tobytes()).hexdigest() == str(g["params_sha256"]), "parameter generator drifted"
+    assert ps.size == orc.param_count(12, 7, 3, cfg["L"], 2, cfg["mps"], Fe2=4)
+    set2 = (g["ef2"], g["senders2"], g["receivers2"])
+    out, lat = orc.forward(ps, cfg, g["nf"], g["ef"], g["senders"], g["receivers"], return_latents=True, set2=set2)
+    assert rel_max(out, g["out"]) < 1e-12
+    assert rel_max(lat[1][0], g["v_after_1"]) < 1e-6 and rel_max(lat[1][1], g["e_after_1"]) < 1e-6
+    assert rel_max(lat[1][2], g["e2_after_1"]) < 1e-6 and rel_max(lat[15][0], g["v_after_15"]) < 1e-6
+    # world edges matter: dropping them changes the answer
+    empty = (g["ef2"][:0], g["senders2"][:0], g["receivers2"][:0])
+    out0 = orc.forward(ps, cfg, g["nf"], g["ef"], g["senders"], g["receivers"], set2=empty)
+    assert rel_max(out0, g["out"]) > 1e-3
+
+
 def test_param_count_matches_survey():
     # SURVEY.md A4: enc-node 34,560; enc-edge 33,792; per step edge 82,560 + node 66,176; decoder 33,282
     assert orc.param_count(9, 3, 2, 128, 2, 15) == 34560 + 33792 + 15 * (82560 + 66176) + 33282
