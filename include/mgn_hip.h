@@ -186,6 +186,18 @@ typedef struct mgn_rollout_desc {
 } mgn_rollout_desc;
 int mgn_rollout(mgn_handle* h, mgn_rollout_desc* d);
 
+/* ---- training step -------------------------------------------------------
+ * GraphNetCore.step!(mgn, graph, target, mask, mse_reduce) as called at reference src/strategies.jl:418-422 and
+ * consumed at src/MeshGraphNets.jl:370-378:  out = model(graph);  loss = mean(mse_reduce(target, out)[mask]) with
+ * mse_reduce = sum of squared differences over the O rows per node;  gs = d loss / d ps.
+ *   nf [N][Fn], ef [E][Fe]: the FeatureGraph (already normalised, as build_graph hands it over, src/graph.jl:75-97)
+ *   target [N][O];  mask [nmask]: node indices (Int32, 1-based at the Julia boundary: mask_index_base = 1,
+ *   src/MeshGraphNets.jl:352);  grads [n_grads = mgn_param_count]: packed order of mgn_set_params, so that
+ *   Optimisers.update(opt_state, ps, gs) keeps working on the Julia side;  *loss: the scalar.
+ * fp32, one partition, one edge set.  Deterministic (no atomics on the gradient path).                          */
+int mgn_step(mgn_handle* h, const float* nf, const float* ef, const float* target, const int32_t* mask, int64_t nmask,
+             int32_t mask_index_base, float* grads, size_t n_grads, float* loss);
+
 /* ---- the benchmarked unit: nsteps processor steps on given latents -------------
  * v [N][L], e [E][L] in caller order, updated in place (host buffers).                          */
 int mgn_processor_steps(mgn_handle* h, float* v, float* e, int32_t nsteps);

@@ -11,7 +11,7 @@
 # side, cheap); only GraphNetwork.model / FeatureGraph / step! are replaced.
 module MGNHip
 
-export FeatureGraph, GraphNetwork, set_trajectory_graph!, pack_params, set_static!, ode_step_resident, ode_step_fused
+export FeatureGraph, GraphNetwork, set_trajectory_graph!, pack_params, set_static!, ode_step_resident, ode_step_fused, step!
 
 const LIB = get(ENV, "MGN_HIP_LIB", joinpath(@__DIR__, "..", "meshgraphnets.jl_amd", "lib", "libmgn_hip.so"))
 
@@ -104,6 +104,29 @@ function forward(mgn::GraphNetwork, graph::FeatureGraph, ps::Vector{Float32})
     GC.@preserve nf ef out check(mgn.handle,
         ccall((:mgn_forward, LIB), Cint, (Ptr{Cvoid}, Ptr{Float32}, Ptr{Float32}, Ptr{Float32}), mgn.handle, nf, ef, out))
     return out
+end
+
+"""
+`step!(mgn, graph, target, mask, loss_function)` as called at src/strategies.jl:418-422: returns `(gs, loss)` with
+`loss = mean(mse_reduce(target, output)[mask])`.  `gs` is ONE packed Vector{Float32} in the order of `pack_params`, so
+the caller's loop `for i in eachindex(gs); opt_state, ps = Optimisers.update(opt_state, ps, gs[i]); end`
+(src/MeshGraphNets.jl:375-377) becomes a single `Optimisers.update(opt_state, mgn.ps, gs)` on the packed vector.
+`mask` are the Int32 node indices built at src/MeshGraphNets.jl:352 (1-based).  Only `mse_reduce` runs on the device.
+"""
+function step!(mgn::GraphNetwork, graph::FeatureGraph, target::Matrix{Float32}, mask::Vector{Int32}, loss_function = nothing)
+    ps = mgn.ps::Vector{Float32}
+    sync_params!(mgn, ps)
+    N = size(graph.nf, 2)
+    objectid(graph.senders) == mgn.graph_id ||
+        set_trajectory_graph!(mgn, Vector{Int32}(graph.senders), Vector{Int32}(graph.receivers), N)
+    gs = Vector{Float32}(undef, length(ps))
+    loss = Ref{Float32}(0)
+    nf = Array(graph.nf); ef = Array(graph.ef)
+    GC.@preserve nf ef target mask gs check(mgn.handle,
+        ccall((:mgn_step, LIB), Cint,
+            (Ptr{Cvoid}, Ptr{Float32}, Ptr{Float32}, Ptr{Float32}, Ptr{Int32}, Int64, Int32, Ptr{Float32}, Csize_t, Ref{Float32}),
+            mgn.handle, nf, ef, target, mask, length(mask), 1, gs, length(gs), loss))
+    return gs, loss[]
 end
 
 """

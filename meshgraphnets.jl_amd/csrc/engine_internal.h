@@ -1,0 +1,162 @@
+// Engine state shared by the C-ABI translation units (mgn_api.cpp: inference path, mgn_train.cpp: step!).
+// Internal; the public boundary is include/mgn_hip.h.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/mgn_hip.h"
+#include "graph_host.h"
+#include "kernels.h"
+
+namespace mgn {
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    ~DevBuf() { release(); }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+    }
+    hipError_t ensure(size_t n) {
+        if (n <= bytes && p) return hipSuccess;
+        release();
+        if (n == 0) n = 16;
+        hipError_t e = hipMalloc(&p, n);
+        if (e == hipSuccess) bytes = n;
+        return e;
+    }
+    template <typename T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+// offsets (in floats) of one MLP inside the packed parameter vector
+struct MlpOff {
+    size_t W[3], b[3], gamma = 0, beta = 0;
+    int in = 0, out = 0;
+    bool ln = false;
+};
+
+enum Family { F_EDGE = 0, F_NODE, F_ENC, F_DEC, F_HALO, F_NFAM };
+
+struct ProfRec {
+    int fam;
+    hipEvent_t a, b;
+};
+
+}  // namespace mgn
+
+namespace mgn { struct TrainState; }
+using mgn::DevBuf;
+using mgn::MlpOff;
+using mgn::ProfRec;
+using mgn::LocalGraph;
+using mgn::MAX_EDGE_SETS;
+
+struct mgn_engine {
+    // (fields use mgn:: types)
+
+    mgn_config cfg{};
+    std::string err;
+    hipStream_t stream = nullptr;
+    hipStream_t own_stream = nullptr;
+    bool host_only = false;
+    int32_t node_split = 1;   // projection as its own launch (both chunks LDS-resident); MGN_NODE_SPLIT=0 fuses it
+    int32_t stagger_edge = 8, stagger_node = 8;  // tunables (MGN_STAGGER_EDGE / MGN_STAGGER_NODE)
+
+    // parameters
+    bool have_params = false;
+    std::vector<float> params;  // packed, host
+    MlpOff enc_node, dec;
+    std::vector<MlpOff> pn;
+    DevBuf wfrag;     // all chunks + tables + small tensors, fragment order
+    // offsets into wfrag (floats).  e_ch / e_tabs: edge MLP of each set; n_ch: node MLP (0:W2 1:W3 2:W1v 3:W1a 6:W1a of
+    // set 1) and the projection onto the NEXT step's set-0 edge MLP (4:WP 5:WQ, bias in n_tabs[T_BQ]); p1_ch / p1_tabs:
+    // the same projection for set 1
+    struct StepOff { size_t e_ch[MAX_EDGE_SETS][3], e_tabs[MAX_EDGE_SETS], n_ch[7], n_tabs, p1_ch[2], p1_tabs; };
+    std::vector<StepOff> soff;
+    size_t en_ch[4] = {0, 0, 0, 0}, en_tabs = 0, en_w1f = 0;
+    size_t de_ch[2] = {0, 0}, de_tabs = 0, de_w3f = 0, de_b3 = 0;
+
+    // norms (device): node scale/shift [Fn], edge [Fe], out [O]; null = identity
+    DevBuf norms;
+    bool have_nnorm = false, have_enorm = false, have_onorm = false;
+
+    // graph
+    bool have_graph = false;
+    LocalGraph g;
+    int32_t nsets = 1;
+    int32_t ntiles_n = 0;
+    DevBuf d_own_gid, d_send_idx;
+    // per edge set: parameters, topology, latents (set 0 = the reference's mesh edges; set 1 = world edges)
+    struct EdgeSetState {
+        int32_t Fe = 0;
+        MlpOff enc;
+        std::vector<MlpOff> pe;
+        size_t ee_ch[2] = {0, 0}, ee_tabs = 0, ee_w1f = 0;
+        int32_t ntiles_e = 0;
+        bool have_ef = false;
+        DevBuf d_snd, d_rcv, d_rowptr, d_edge_gid, d_ef;
+        DevBuf Elat, AGG, CARRY, P, Q, elat0;
+        DevBuf bP, bQ, bElat, bAGG, bCARRY;   // bf16 mode
+        std::vector<int32_t> gs, gr;          // host copy of the global edge list (kept only with two sets: rebuilds)
+        int32_t gbase = 0;
+    } es[MAX_EDGE_SETS];
+
+    // latents and I/O
+    // bf16 mode (cfg.dtype == MGN_BF16): bf16 copies of the processor state and weights; the fp32 V / Elat buffers
+    // then only carry encoder output / decoder input
+    DevBuf wbf, bV;
+    struct BfStepOff { size_t e_ch[MAX_EDGE_SETS][3], n_ch[7], p1_ch[2]; };
+    std::vector<BfStepOff> bsoff;
+    // static per-trajectory RHS inputs (mgn_set_static): cached encoded edge latents
+    bool have_static = false;
+    DevBuf stage;     // device staging image of caller-order latents (import / export)
+    DevBuf d_stamps;  // diagnostic builds only
+    DevBuf ode;       // native rollout: state, stages, frames, saves, Elat0
+    const float* srcA_override = nullptr;  // rollout: encoder reads the node state from here instead of d_nfA
+    float* out_override = nullptr;         // rollout: decoder writes dx/dt here instead of d_out
+    DevBuf V, d_nfA, d_nfB, d_out, d_mask, d_sum;
+    int32_t in_wa = 0, in_wb = 0;
+    bool have_mask = false;
+
+    // hipGraph of one mgn_processor_steps_dev(nsteps) pass: small meshes are launch-bound (3 kernels per step).
+    // State machine per invalidation: first call runs eagerly (warms per-kernel attributes), second captures.
+    int32_t use_graph = 1;          // MGN_GRAPH=0 disables
+    int32_t graph_nsteps = -1;      // nsteps the cached graph was captured for
+    int32_t graph_warm = -1;        // nsteps of the last eager run since the last invalidation
+    hipGraphExec_t graph_exec = nullptr;
+
+    // training step (mgn_step): weights in training order, kept activations, scratch -- created on first use
+    mgn::TrainState* train = nullptr;
+
+    // profiling
+    bool prof = false;
+    std::vector<ProfRec> recs;
+};
+
+
+namespace mgn {
+
+int fail(mgn_engine* h, int code, const char* fmt, ...);
+int need(mgn_engine* h, bool params, bool graph);
+// L x L chunk of W (row-major [K][ldw], rows kbase.., all L output columns) -> MFMA fragment order
+void pack_chunk(float* dst, const float* W, int ldw, int kbase, int L);
+// vector of L values (stride between consecutive features = stride) -> table fragment order
+void pack_tab(float* dst, const float* vec, int L, int stride = 1);
+// mgn_train.cpp: drop training-side state that depends on the parameters (what & 1) or the graph (what & 2); free it all
+void train_invalidate(mgn_engine* h, int what);
+void train_free(mgn_engine* h);
+
+#define HIPCHK(h, expr)                                                                              \
+    do {                                                                                             \
+        hipError_t _e = (expr);                                                                      \
+        if (_e != hipSuccess)                                                                        \
+            return mgn::fail(h, _e == hipErrorOutOfMemory ? MGN_E_OOM : MGN_E_HIP, "%s failed: %s (%s:%d)", #expr, \
+                             hipGetErrorString(_e), __FILE__, __LINE__);                             \
+    } while (0)
+
+}  // namespace mgn

@@ -25,6 +25,7 @@
 //     scan across its 32 lanes (DPP row shifts), segment tails store whole rows with plain stores;
 //     segments that straddle tiles go to per-tile carry rows that the node kernel adds.  No atomics,
 //     no zero-fill pass, bitwise reproducible.
+#include "frag.hpp"
 #include "kernels.h"
 
 #include <cstdlib>
@@ -32,246 +33,6 @@
 #include <unordered_map>
 
 namespace mgn {
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-
-#define DEVINL __device__ __forceinline__
-// Phase fence: values are SSA to the compiler, so "reuse array y for the reload" is only a hint; without a
-// fence hipcc hoists the next phase's loads above the current MFMA chain, a fourth 64-VGPR array becomes
-// live and the kernel spills.
-#define PHASE_FENCE() __builtin_amdgcn_sched_barrier(0)
-// The two waves that share a SIMD arbitrate instruction issue by priority, then age: without help the older
-// wave's MFMA chain starves the younger wave's gather/LayerNorm/scan phase (measured 2-3x longer).  Every
-// wave therefore raises its priority while it is OUTSIDE its MFMA chains (-6 % kernel time, same-box A/B).
-#ifndef MGN_PRIO
-#define MGN_PRIO 1
-#endif
-// Re-derive the lane id through an opaque asm once per tile: every address and table read that depends
-// on it then stays INSIDE the persistent tile loop.  Without this hipcc hoists ~250 loop-invariant LDS
-// table reads and 64-bit weight addresses out of the loop and spills them all to scratch.
-#define OPAQUE_LANE()                          \
-    int lane = lane0;                          \
-    asm volatile("" : "+v"(lane));             \
-    const int c = lane & 31, h = lane >> 5
-constexpr float LN_EPS = 1e-5f;
-constexpr int NUM_XCD = 8;
-
-// ------------------------------------------------------------------------------------------------
-// fragment <-> memory helpers.  A lane (c,h) owns 4*NT pieces of 4 floats: piece m = 4t+g holds
-// features 32t + 8g + 4h + {0..3} of row c and lives in registers x[t][4g..4g+3].  Two memory layouts:
-//   row-major   [row][L]            piece m of lane (c,h) at  row*L + (2m+h)*4        -> stride 2 float4
-//   tile-major  [tile][m][lane][4]  piece m of lane l     at  tile*32L + m*256 + l*4  -> stride 64 float4
-// Tile-major ("fragment-major") arrays make every wave-instruction a contiguous 1 KiB: used for all
-// arrays that are only ever touched tile-wise (edge latents, node latents, AGG); arrays gathered by
-// index (P, Q, CARRY) stay row-major.  `p` already includes the lane's own offset.
-// ------------------------------------------------------------------------------------------------
-constexpr int STRIDE_ROW = 2, STRIDE_TILE = 64;
-
-DEVINL const f32x4* row_ptr(const float* base, int64_t row, int L, int h) {
-    return reinterpret_cast<const f32x4*>(base + row * L) + h;
-}
-DEVINL f32x4* row_ptr(float* base, int64_t row, int L, int h) { return reinterpret_cast<f32x4*>(base + row * L) + h; }
-DEVINL const f32x4* tile_ptr(const float* base, int64_t tile, int L, int lane) {
-    return reinterpret_cast<const f32x4*>(base + tile * (TILE * L)) + lane;
-}
-DEVINL f32x4* tile_ptr(float* base, int64_t tile, int L, int lane) {
-    return reinterpret_cast<f32x4*>(base + tile * (TILE * L)) + lane;
-}
-
-template <int NT>
-DEVINL void load_frag(f32x16 (&x)[NT], const f32x4* __restrict__ p, int stride) {
-#pragma unroll
-    for (int m = 0; m < 4 * NT; ++m) {
-        const f32x4 v = p[m * stride];
-        x[m >> 2][4 * (m & 3) + 0] = v[0]; x[m >> 2][4 * (m & 3) + 1] = v[1];
-        x[m >> 2][4 * (m & 3) + 2] = v[2]; x[m >> 2][4 * (m & 3) + 3] = v[3];
-    }
-}
-
-template <int NT>
-DEVINL void add_frag(f32x16 (&x)[NT], const f32x4* __restrict__ p, int stride) {
-#pragma unroll
-    for (int m = 0; m < 4 * NT; ++m) {
-        const f32x4 v = p[m * stride];
-        x[m >> 2][4 * (m & 3) + 0] += v[0]; x[m >> 2][4 * (m & 3) + 1] += v[1];
-        x[m >> 2][4 * (m & 3) + 2] += v[2]; x[m >> 2][4 * (m & 3) + 3] += v[3];
-    }
-}
-
-template <int NT>
-DEVINL void store_frag(f32x4* __restrict__ p, int stride, const f32x16 (&x)[NT]) {
-#pragma unroll
-    for (int m = 0; m < 4 * NT; ++m) {
-        f32x4 v;
-        v[0] = x[m >> 2][4 * (m & 3) + 0]; v[1] = x[m >> 2][4 * (m & 3) + 1];
-        v[2] = x[m >> 2][4 * (m & 3) + 2]; v[3] = x[m >> 2][4 * (m & 3) + 3];
-        p[m * stride] = v;
-    }
-}
-
-// one 16-register quarter (feature block t: pieces 4t..4t+3) of a fragment
-DEVINL void load_quarter(f32x16& q, const f32x4* __restrict__ p, int stride, int t) {
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        const f32x4 v = p[(4 * t + g) * stride];
-        q[4 * g + 0] = v[0]; q[4 * g + 1] = v[1]; q[4 * g + 2] = v[2]; q[4 * g + 3] = v[3];
-    }
-}
-DEVINL void store_quarter(f32x4* __restrict__ p, int stride, int t, const f32x16& q) {
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        f32x4 v;
-        v[0] = q[4 * g + 0]; v[1] = q[4 * g + 1]; v[2] = q[4 * g + 2]; v[3] = q[4 * g + 3];
-        p[(4 * t + g) * stride] = v;
-    }
-}
-
-// table (bias / gamma / beta) in fragment order: float4 tab[4*NT][2]
-template <int NT>
-DEVINL void tab_frag(f32x16 (&x)[NT], const float* tab, int h) {
-    const f32x4* t4 = reinterpret_cast<const f32x4*>(tab) + h;
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const f32x4 v = t4[2 * (4 * t + g)];
-            x[t][4 * g + 0] = v[0]; x[t][4 * g + 1] = v[1]; x[t][4 * g + 2] = v[2]; x[t][4 * g + 3] = v[3];
-        }
-}
-
-template <int NT>
-DEVINL void zero_frag(f32x16 (&x)[NT]) {
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int k = 0; k < 16; ++k) x[t][k] = 0.f;
-}
-
-template <int NT>
-DEVINL void relu_frag(f32x16 (&x)[NT]) {
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int k = 0; k < 16; ++k) x[t][k] = fmaxf(x[t][k], 0.f);
-}
-
-// ------------------------------------------------------------------------------------------------
-// One L x L weight chunk:  acc[feature][row] += W^T * in   (16*NT k-steps x NT MFMA 32x32x2 f32)
-// Weight fragment layout (host: pack_chunk): w[(j*64 + lane)*NT + t] = W[kbase + phi(j,h)][32t + i],
-// lane = 32h + i.  RES: w is in LDS; else global (L2-resident), streamed through a register ring.
-// ------------------------------------------------------------------------------------------------
-template <int NT> struct AVec;
-template <> struct AVec<4> { typedef f32x4 T; };
-template <> struct AVec<2> { typedef f32x2 T; };
-template <> struct AVec<1> { typedef float T; };
-
-template <int NT> DEVINL float aget(const typename AVec<NT>::T& a, int t) { return a[t]; }
-template <> DEVINL float aget<1>(const float& a, int) { return a; }
-
-template <int NT, bool RES>
-DEVINL void mfma_chunk(f32x16 (&acc)[NT], const f32x16 (&in)[NT], const float* w, int lane) {
-    typedef typename AVec<NT>::T AV;
-    constexpr int J = 16 * NT;
-    const AV* wv = reinterpret_cast<const AV*>(w) + lane;
-    if constexpr (RES) {
-#pragma unroll
-        for (int j = 0; j < J; ++j) {
-            const AV a = wv[j * 64];
-#pragma unroll
-            for (int t = 0; t < NT; ++t)
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(aget<NT>(a, t), in[j >> 4][j & 15], acc[t], 0, 0, 0);
-        }
-    } else {
-        constexpr int PF = 4;  // k-steps in flight: 4 x (NT MFMA x 64 cyc) of cover for an L2 hit
-        AV ring[PF];
-#pragma unroll
-        for (int p = 0; p < PF; ++p) ring[p] = wv[p * 64];
-#pragma unroll
-        for (int j = 0; j < J; ++j) {
-            const AV a = ring[j % PF];
-            if (j + PF < J) ring[j % PF] = wv[(j + PF) * 64];
-#pragma unroll
-            for (int t = 0; t < NT; ++t)
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(aget<NT>(a, t), in[j >> 4][j & 15], acc[t], 0, 0, 0);
-        }
-    }
-}
-
-// A chunk whose first JR k-steps are LDS-resident and whose tail streams from L2 (JR = 0: all streamed).  The
-// ring is primed before the resident steps, so the first streamed fragments have JR k-steps to arrive.
-template <int NT, int JR>
-DEVINL void mfma_chunk_split(f32x16 (&acc)[NT], const f32x16 (&in)[NT], const float* w_lds, const float* w_glb, int lane) {
-    typedef typename AVec<NT>::T AV;
-    constexpr int J = 16 * NT;
-#ifndef MGN_PF
-#define MGN_PF 4
-#endif
-    constexpr int PF = (J - JR) < MGN_PF ? (J - JR) : MGN_PF;
-    const AV* wl = reinterpret_cast<const AV*>(w_lds) + lane;
-    const AV* wg = reinterpret_cast<const AV*>(w_glb) + lane;
-    AV ring[PF > 0 ? PF : 1];
-#pragma unroll
-    for (int p = 0; p < PF; ++p) ring[p] = wg[(JR + p) * 64];
-#pragma unroll
-    for (int j = 0; j < J; ++j) {
-        AV a;
-        if (j < JR) {
-            a = wl[j * 64];
-        } else {
-            a = ring[(j - JR) % PF];
-            if (j + PF < J) ring[(j - JR) % PF] = wg[(j + PF) * 64];
-        }
-#pragma unroll
-        for (int t = 0; t < NT; ++t)
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(aget<NT>(a, t), in[j >> 4][j & 15], acc[t], 0, 0, 0);
-    }
-}
-
-// LayerNorm over the row's L features: 16*NT in this lane + 16*NT in lane^32.  Biased variance.
-template <int NT>
-DEVINL void layer_norm_frag(f32x16 (&x)[NT], const float* gamma, const float* beta, int h) {
-    constexpr float invL = 1.0f / (32 * NT);
-    float s = 0.f;
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int k = 0; k < 16; ++k) s += x[t][k];
-    s += __shfl_xor(s, 32, 64);
-    const float mean = s * invL;
-    float q = 0.f;
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            const float d = x[t][k] - mean;
-            x[t][k] = d;
-            q += d * d;
-        }
-    q += __shfl_xor(q, 32, 64);
-    const float rstd = 1.0f / sqrtf(q * invL + LN_EPS);
-    const f32x4* g4 = reinterpret_cast<const f32x4*>(gamma) + h;
-    const f32x4* b4 = reinterpret_cast<const f32x4*>(beta) + h;
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const f32x4 gv = g4[2 * (4 * t + g)];
-            const f32x4 bv = b4[2 * (4 * t + g)];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) x[t][4 * g + i] = x[t][4 * g + i] * rstd * gv[i] + bv[i];
-        }
-}
-
-// ------------------------------------------------------------------------------------------------
-// cooperative global -> LDS copy of resident weight chunks + tables (once per block; persistent grid)
-// ------------------------------------------------------------------------------------------------
-DEVINL void copy_to_lds(float* dst, const float* __restrict__ src, int nfloats) {
-    const f32x4* s4 = reinterpret_cast<const f32x4*>(src);
-    f32x4* d4 = reinterpret_cast<f32x4*>(dst);
-    for (int i = threadIdx.x; i < nfloats / 4; i += blockDim.x) d4[i] = s4[i];
-}
 
 // XCD-aware persistent tile walk: blocks b and b+8 share an XCD (round-robin dispatch), so every XCD
 // gets one contiguous range of tiles and its waves sweep it interleaved -> gathered P/Q rows of

@@ -12,9 +12,7 @@
 #include <string>
 #include <vector>
 
-#include "../../include/mgn_hip.h"
-#include "graph_host.h"
-#include "kernels.h"
+#include "engine_internal.h"
 
 using namespace mgn;
 
@@ -22,120 +20,9 @@ namespace {
 
 thread_local std::string g_create_error;
 
-struct DevBuf {
-    void* p = nullptr;
-    size_t bytes = 0;
-    ~DevBuf() { release(); }
-    void release() {
-        if (p) (void)hipFree(p);
-        p = nullptr;
-        bytes = 0;
-    }
-    hipError_t ensure(size_t n) {
-        if (n <= bytes && p) return hipSuccess;
-        release();
-        if (n == 0) n = 16;
-        hipError_t e = hipMalloc(&p, n);
-        if (e == hipSuccess) bytes = n;
-        return e;
-    }
-    template <typename T> T* as() const { return reinterpret_cast<T*>(p); }
-};
-
-// offsets (in floats) of one MLP inside the packed parameter vector
-struct MlpOff {
-    size_t W[3], b[3], gamma = 0, beta = 0;
-    int in = 0, out = 0;
-    bool ln = false;
-};
-
-enum Family { F_EDGE = 0, F_NODE, F_ENC, F_DEC, F_HALO, F_NFAM };
-
-struct ProfRec {
-    int fam;
-    hipEvent_t a, b;
-};
-
 }  // namespace
 
-struct mgn_engine {
-    mgn_config cfg{};
-    std::string err;
-    hipStream_t stream = nullptr;
-    hipStream_t own_stream = nullptr;
-    bool host_only = false;
-    int32_t node_split = 1;   // projection as its own launch (both chunks LDS-resident); MGN_NODE_SPLIT=0 fuses it
-    int32_t stagger_edge = 8, stagger_node = 8;  // tunables (MGN_STAGGER_EDGE / MGN_STAGGER_NODE)
-
-    // parameters
-    bool have_params = false;
-    std::vector<float> params;  // packed, host
-    MlpOff enc_node, dec;
-    std::vector<MlpOff> pn;
-    DevBuf wfrag;     // all chunks + tables + small tensors, fragment order
-    // offsets into wfrag (floats).  e_ch / e_tabs: edge MLP of each set; n_ch: node MLP (0:W2 1:W3 2:W1v 3:W1a 6:W1a of
-    // set 1) and the projection onto the NEXT step's set-0 edge MLP (4:WP 5:WQ, bias in n_tabs[T_BQ]); p1_ch / p1_tabs:
-    // the same projection for set 1
-    struct StepOff { size_t e_ch[MAX_EDGE_SETS][3], e_tabs[MAX_EDGE_SETS], n_ch[7], n_tabs, p1_ch[2], p1_tabs; };
-    std::vector<StepOff> soff;
-    size_t en_ch[4] = {0, 0, 0, 0}, en_tabs = 0, en_w1f = 0;
-    size_t de_ch[2] = {0, 0}, de_tabs = 0, de_w3f = 0, de_b3 = 0;
-
-    // norms (device): node scale/shift [Fn], edge [Fe], out [O]; null = identity
-    DevBuf norms;
-    bool have_nnorm = false, have_enorm = false, have_onorm = false;
-
-    // graph
-    bool have_graph = false;
-    LocalGraph g;
-    int32_t nsets = 1;
-    int32_t ntiles_n = 0;
-    DevBuf d_own_gid, d_send_idx;
-    // per edge set: parameters, topology, latents (set 0 = the reference's mesh edges; set 1 = world edges)
-    struct EdgeSetState {
-        int32_t Fe = 0;
-        MlpOff enc;
-        std::vector<MlpOff> pe;
-        size_t ee_ch[2] = {0, 0}, ee_tabs = 0, ee_w1f = 0;
-        int32_t ntiles_e = 0;
-        bool have_ef = false;
-        DevBuf d_snd, d_rcv, d_rowptr, d_edge_gid, d_ef;
-        DevBuf Elat, AGG, CARRY, P, Q, elat0;
-        DevBuf bP, bQ, bElat, bAGG, bCARRY;   // bf16 mode
-        std::vector<int32_t> gs, gr;          // host copy of the global edge list (kept only with two sets: rebuilds)
-        int32_t gbase = 0;
-    } es[MAX_EDGE_SETS];
-
-    // latents and I/O
-    // bf16 mode (cfg.dtype == MGN_BF16): bf16 copies of the processor state and weights; the fp32 V / Elat buffers
-    // then only carry encoder output / decoder input
-    DevBuf wbf, bV;
-    struct BfStepOff { size_t e_ch[MAX_EDGE_SETS][3], n_ch[7], p1_ch[2]; };
-    std::vector<BfStepOff> bsoff;
-    // static per-trajectory RHS inputs (mgn_set_static): cached encoded edge latents
-    bool have_static = false;
-    DevBuf stage;     // device staging image of caller-order latents (import / export)
-    DevBuf d_stamps;  // diagnostic builds only
-    DevBuf ode;       // native rollout: state, stages, frames, saves, Elat0
-    const float* srcA_override = nullptr;  // rollout: encoder reads the node state from here instead of d_nfA
-    float* out_override = nullptr;         // rollout: decoder writes dx/dt here instead of d_out
-    DevBuf V, d_nfA, d_nfB, d_out, d_mask, d_sum;
-    int32_t in_wa = 0, in_wb = 0;
-    bool have_mask = false;
-
-    // hipGraph of one mgn_processor_steps_dev(nsteps) pass: small meshes are launch-bound (3 kernels per step).
-    // State machine per invalidation: first call runs eagerly (warms per-kernel attributes), second captures.
-    int32_t use_graph = 1;          // MGN_GRAPH=0 disables
-    int32_t graph_nsteps = -1;      // nsteps the cached graph was captured for
-    int32_t graph_warm = -1;        // nsteps of the last eager run since the last invalidation
-    hipGraphExec_t graph_exec = nullptr;
-
-    // profiling
-    bool prof = false;
-    std::vector<ProfRec> recs;
-};
-
-namespace {
+namespace mgn {
 
 int fail(mgn_engine* h, int code, const char* fmt, ...) {
     char buf[512];
@@ -147,13 +34,9 @@ int fail(mgn_engine* h, int code, const char* fmt, ...) {
     return code;
 }
 
-#define HIPCHK(h, expr)                                                                              \
-    do {                                                                                             \
-        hipError_t _e = (expr);                                                                      \
-        if (_e != hipSuccess)                                                                        \
-            return fail(h, _e == hipErrorOutOfMemory ? MGN_E_OOM : MGN_E_HIP, "%s failed: %s (%s:%d)", #expr, \
-                        hipGetErrorString(_e), __FILE__, __LINE__);                                  \
-    } while (0)
+}  // namespace mgn
+
+namespace {
 
 bool cfg_ok(const mgn_config* c, std::string& why) {
     if (!c) { why = "null config"; return false; }
@@ -212,6 +95,8 @@ size_t layout_all(mgn_engine* h) {
 
 inline int phi(int j, int hh) { return 32 * (j >> 4) + (j & 3) + 8 * ((j & 15) >> 2) + 4 * hh; }
 
+}  // namespace
+namespace mgn {
 // L x L chunk of W (row-major [K][ldw], rows kbase.., all L output columns) -> fragment order
 void pack_chunk(float* dst, const float* W, int ldw, int kbase, int L) {
     const int NT = L / 32, J = L / 2;
@@ -222,14 +107,20 @@ void pack_chunk(float* dst, const float* W, int ldw, int kbase, int L) {
             for (int t = 0; t < NT; ++t) dst[((size_t)j * 64 + lane) * NT + t] = wrow[32 * t + i];
         }
 }
+}  // namespace mgn
+namespace {
 
+}  // namespace
+namespace mgn {
 // vector of L values (stride between consecutive features = stride) -> table fragment order
-void pack_tab(float* dst, const float* vec, int L, int stride = 1) {
+void pack_tab(float* dst, const float* vec, int L, int stride) {
     for (int m = 0; m < L / 8; ++m)
         for (int hh = 0; hh < 2; ++hh)
             for (int i = 0; i < 4; ++i)
                 dst[(m * 2 + hh) * 4 + i] = vec ? vec[(size_t)(32 * (m >> 2) + 8 * (m & 3) + 4 * hh + i) * stride] : 0.f;
 }
+}  // namespace mgn
+namespace {
 
 inline uint16_t f32_to_bf16(float f) {   // round to nearest even (inputs are finite weights / latents)
     uint32_t u;
@@ -266,6 +157,8 @@ void pack_chunk_bf16(uint16_t* dst, const float* W, int ldw, int kbase) {
                 }
 }
 
+}  // namespace
+namespace mgn {
 int need(mgn_engine* h, bool params, bool graph) {
     if (!h) return MGN_E_ARG;
     if (h->host_only) return fail(h, MGN_E_HIP, "host-only handle (MGN_DEVICE_NONE): no compute path; create the handle on a HIP device");
@@ -273,6 +166,8 @@ int need(mgn_engine* h, bool params, bool graph) {
     if (graph && !h->have_graph) return fail(h, MGN_E_STATE, "mgn_set_graph has not been called");
     return MGN_OK;
 }
+}  // namespace mgn
+namespace {
 
 struct ProfScope {
     mgn_engine* h;
@@ -521,6 +416,7 @@ void mgn_destroy(mgn_handle* h) {
         (void)hipEventDestroy(r.a);
         (void)hipEventDestroy(r.b);
     }
+    train_free(h);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
     delete h;
 }
@@ -555,6 +451,7 @@ int mgn_set_params(mgn_handle* h, const float* packed, size_t n) {
     const size_t want = layout_all(h);
     if (n != want) return fail(h, MGN_E_ARG, "mgn_set_params: got %zu floats, model needs %zu", n, want);
     h->params.assign(packed, packed + n);
+    train_invalidate(h, 1);
     const float* p = h->params.data();
     const mgn_config& c = h->cfg;
     const int L = c.L;
@@ -755,6 +652,7 @@ static int rebuild_graph(mgn_handle* h, int32_t N, const EdgeList* sets, const f
                          const char* who) {
     h->have_graph = false;
     h->have_static = false;
+    train_invalidate(h, 2);
     if (!h->host_only) { (void)hipStreamSynchronize(h->stream); drop_graph(h); }
     const std::string why = build_local_graph(N, h->nsets, sets, mesh_pos, pos_dim, keep_owner ? h->g.owner.data() : nullptr,
                                               h->cfg.rank, h->cfg.nranks, h->g);

@@ -1,0 +1,386 @@
+// mgn_step: the training step GraphNetCore.step!(mgn, graph, target, mask, mse_reduce) of the reference
+// (src/strategies.jl:418-422; gradients applied at src/MeshGraphNets.jl:370-378) behind the C ABI.
+// Host orchestration only -- weights repacked into training order (forward and transposed chunks), an arena of kept
+// activations, kernel sequencing; all arithmetic is in train.hip.  No CPU compute path.
+#include <algorithm>
+#include <cstring>
+#include <numeric>
+
+#include "engine_internal.h"
+#include "train.h"
+
+namespace mgn {
+
+namespace {
+
+// device offsets (floats into TrainState::w) of one MLP in training order
+struct TrainMlp {
+    const MlpOff* off = nullptr;
+    int nin = 1;                 // L-wide layer-1 input blocks
+    int in_rows = 0;             // rows of W1 that exist (< L for the encoders: zero-padded chunk)
+    size_t W1[3] = {0, 0, 0}, W2 = 0, W3 = 0, W2T = 0, W3T = 0, tabs = 0;
+    size_t W1T[3] = {0, 0, 0};
+    bool has_w1t = false;
+};
+
+}  // namespace
+
+struct TrainState {
+    bool packed = false, graph_ready = false;
+    DevBuf w;                    // training-order weights
+    std::vector<TrainMlp> mlp;   // 0 enc-node, 1 enc-edge, 2+2k edge k, 3+2k node k, last decoder
+    DevBuf arena, idx, grads, target, mask, loss;
+    size_t arena_floats = 0;
+    int64_t cap_n = 0, cap_e = 0;
+    // arena offsets (floats)
+    size_t nf_raw, ef_raw, nf_pad, ef_pad, enH[3], V0, eeH[3], E0, Enew, dH[3];
+    std::vector<size_t> eH[3], nH[3], Ek, Vk, agg;
+    size_t GT, GXH, GY, GZ2, GZ1, GXs, GXr, gV[2], gE[2], gAgg, Gout, pw, pb;
+    // idx buffer (int32): egid32 [E], perm_s [E], rowptr_s [N+1]
+    size_t i_egid = 0, i_perm = 0, i_rowptr_s = 0;
+};
+
+void train_invalidate(mgn_engine* h, int what) {
+    if (!h || !h->train) return;
+    if (what & 1) h->train->packed = false;
+    if (what & 2) h->train->graph_ready = false;
+}
+
+void train_free(mgn_engine* h) {
+    if (!h) return;
+    delete h->train;
+    h->train = nullptr;
+}
+
+namespace {
+
+int pack_training_weights(mgn_engine* h) {
+    TrainState& T = *h->train;
+    const mgn_config& c = h->cfg;
+    const int L = c.L;
+    const size_t CH = (size_t)L * L;
+    const float* p = h->params.data();
+    std::vector<float> f, tmp(CH);
+    auto add_chunk_from = [&](const float* M /* L x L row-major */) {
+        const size_t off = f.size();
+        f.resize(off + CH);
+        pack_chunk(f.data() + off, M, L, 0, L);
+        return off;
+    };
+    // rows [r0, r0 + nr) x cols [0, nc) of W (leading dimension ldw), zero-padded to L x L; transposed on request
+    auto block = [&](const float* Wm, int ldw, int r0, int nr, int nc, bool transpose) {
+        std::fill(tmp.begin(), tmp.end(), 0.f);
+        for (int r = 0; r < nr; ++r)
+            for (int cc = 0; cc < nc; ++cc) {
+                const float v = Wm[(size_t)(r0 + r) * ldw + cc];
+                if (transpose) tmp[(size_t)cc * L + r] = v; else tmp[(size_t)r * L + cc] = v;
+            }
+        return add_chunk_from(tmp.data());
+    };
+    auto add_tabs = [&](const MlpOff& m) {
+        const size_t off = f.size();
+        f.resize(off + (size_t)T_COUNT * L, 0.f);
+        std::vector<float> b3(L, 0.f);
+        for (int i = 0; i < m.out; ++i) b3[i] = p[m.b[2] + i];
+        pack_tab(f.data() + off + (size_t)T_B1 * L, p + m.b[0], L);
+        pack_tab(f.data() + off + (size_t)T_B2 * L, p + m.b[1], L);
+        pack_tab(f.data() + off + (size_t)T_B3 * L, b3.data(), L);
+        if (m.ln) {
+            pack_tab(f.data() + off + (size_t)T_GAMMA * L, p + m.gamma, L);
+            pack_tab(f.data() + off + (size_t)T_BETA * L, p + m.beta, L);
+        }
+        return off;
+    };
+    auto build = [&](const MlpOff& m, bool need_input_grad) {
+        TrainMlp t;
+        t.off = &m;
+        t.nin = m.in >= L ? m.in / L : 1;
+        t.in_rows = m.in >= L ? L : m.in;
+        for (int j = 0; j < t.nin; ++j) t.W1[j] = block(p + m.W[0], L, j * L, t.in_rows, L, false);
+        t.W2 = block(p + m.W[1], L, 0, L, L, false);
+        t.W3 = block(p + m.W[2], m.out, 0, L, m.out, false);
+        t.W2T = block(p + m.W[1], L, 0, L, L, true);
+        t.W3T = block(p + m.W[2], m.out, 0, L, m.out, true);
+        t.has_w1t = need_input_grad;
+        if (need_input_grad)
+            for (int j = 0; j < t.nin; ++j) t.W1T[j] = block(p + m.W[0], L, j * L, L, L, true);
+        t.tabs = add_tabs(m);
+        return t;
+    };
+    T.mlp.clear();
+    T.mlp.push_back(build(h->enc_node, false));
+    T.mlp.push_back(build(h->es[0].enc, false));
+    for (int k = 0; k < c.mps; ++k) {
+        T.mlp.push_back(build(h->es[0].pe[k], true));
+        T.mlp.push_back(build(h->pn[k], true));
+    }
+    T.mlp.push_back(build(h->dec, true));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, T.w.ensure(f.size() * 4));
+    HIPCHK(h, hipMemcpy(T.w.p, f.data(), f.size() * 4, hipMemcpyHostToDevice));
+    HIPCHK(h, T.grads.ensure(h->params.size() * 4));
+    T.packed = true;
+    return MGN_OK;
+}
+
+int prepare_graph(mgn_engine* h) {
+    TrainState& T = *h->train;
+    const LocalGraph& g = h->g;
+    const EdgeTopo& t = g.set[0];
+    const int L = h->cfg.L, mps = h->cfg.mps;
+    const int64_t N = g.n_own, E = t.e_local;
+    const size_t NL = (size_t)(N > 0 ? N : 1) * L, EL = (size_t)(E > 0 ? E : 1) * L;
+    // index arrays: edge_gid as int32, sender CSR over the receiver-sorted edge list
+    std::vector<int32_t> ix((size_t)2 * E + N + 1, 0);
+    T.i_egid = 0;
+    T.i_perm = E;
+    T.i_rowptr_s = 2 * E;
+    for (int64_t i = 0; i < E; ++i) ix[T.i_egid + i] = (int32_t)t.edge_gid[i];
+    {
+        int32_t* rp = ix.data() + T.i_rowptr_s;
+        for (int64_t i = 0; i < E; ++i) ++rp[t.snd[i] + 1];
+        for (int64_t n = 0; n < N; ++n) rp[n + 1] += rp[n];
+        std::vector<int32_t> cur(rp, rp + N);
+        for (int64_t i = 0; i < E; ++i) ix[T.i_perm + cur[t.snd[i]]++] = (int32_t)i;   // stable: ascending edge position
+    }
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, T.idx.ensure(ix.size() * 4));
+    HIPCHK(h, hipMemcpy(T.idx.p, ix.data(), ix.size() * 4, hipMemcpyHostToDevice));
+
+    size_t off = 0;
+    auto take = [&](size_t n) { const size_t o = off; off += (n + 63) / 64 * 64; return o; };
+    T.nf_raw = take((size_t)N * h->cfg.Fn);
+    T.ef_raw = take((size_t)E * h->cfg.Fe);
+    T.nf_pad = take(NL);
+    T.ef_pad = take(EL);
+    for (int i = 0; i < 3; ++i) T.enH[i] = take(NL);
+    for (int i = 0; i < 3; ++i) T.eeH[i] = take(EL);
+    for (int i = 0; i < 3; ++i) T.dH[i] = take(NL);
+    T.Enew = take(EL);
+    for (int i = 0; i < 3; ++i) { T.eH[i].assign(mps, 0); T.nH[i].assign(mps, 0); }
+    T.Ek.assign(mps + 1, 0);
+    T.Vk.assign(mps + 1, 0);
+    T.agg.assign(mps, 0);
+    T.Vk[0] = take(NL);
+    T.Ek[0] = take(EL);
+    for (int k = 0; k < mps; ++k) {
+        for (int i = 0; i < 3; ++i) { T.eH[i][k] = take(EL); T.nH[i][k] = take(NL); }
+        T.agg[k] = take(NL);
+        T.Ek[k + 1] = take(EL);
+        T.Vk[k + 1] = take(NL);
+    }
+    const size_t ML = NL > EL ? NL : EL;
+    T.GT = take(ML); T.GXH = take(ML); T.GY = take(ML); T.GZ2 = take(ML); T.GZ1 = take(ML);
+    T.GXs = take(EL); T.GXr = take(EL);
+    T.gV[0] = take(NL); T.gV[1] = take(NL);
+    T.gE[0] = take(EL); T.gE[1] = take(EL);
+    T.gAgg = take(NL);
+    T.Gout = take(NL);
+    const int nb = std::max(wgrad_blocks(N), wgrad_blocks(E));
+    T.pw = take((size_t)5 * (nb > 0 ? nb : 1) * L * L);             // one partial-dW region per weight-gradient job of an MLP
+    T.pb = take((size_t)WGRAD_MAX_JOBS * (nb > 0 ? nb : 1) * L);
+    T.arena_floats = off;
+    HIPCHK(h, T.arena.ensure(off * 4));
+    HIPCHK(h, T.target.ensure((size_t)(N > 0 ? N : 1) * h->cfg.O * 4));
+    T.graph_ready = true;
+    return MGN_OK;
+}
+
+}  // namespace
+}  // namespace mgn
+
+using namespace mgn;
+
+extern "C" int mgn_step(mgn_handle* h, const float* nf, const float* ef, const float* target, const int32_t* mask, int64_t nmask,
+                        int32_t mask_index_base, float* grads, size_t n_grads, float* loss) {
+    if (int rc = need(h, true, true)) return rc;
+    const mgn_config& c = h->cfg;
+    if (c.nranks != 1) return fail(h, MGN_E_STATE, "mgn_step drives one partition");
+    if (h->nsets != 1) return fail(h, MGN_E_STATE, "mgn_step mirrors the reference's single-edge-set step! (src/strategies.jl:418-422)");
+    if (c.dtype != MGN_F32) return fail(h, MGN_E_STATE, "mgn_step computes in fp32: create the handle with dtype MGN_F32");
+    if (!nf || !target || !mask || !grads || !loss || (!ef && h->g.set[0].E > 0)) return fail(h, MGN_E_ARG, "mgn_step: null argument");
+    if (nmask < 1) return fail(h, MGN_E_ARG, "mgn_step: empty mask");
+    if (n_grads != h->params.size()) return fail(h, MGN_E_ARG, "mgn_step: grads has %zu floats, model has %zu", n_grads, h->params.size());
+    if (mask_index_base != 0 && mask_index_base != 1) return fail(h, MGN_E_ARG, "mgn_step: mask_index_base must be 0 or 1");
+    const LocalGraph& g = h->g;
+    const int64_t N = g.n_own, E = g.set[0].e_local;
+    for (int64_t i = 0; i < nmask; ++i) {
+        const int64_t n = (int64_t)mask[i] - mask_index_base;
+        if (n < 0 || n >= N) return fail(h, MGN_E_ARG, "mgn_step: mask entry %lld out of range", (long long)i);
+    }
+    if (!h->train) h->train = new (std::nothrow) TrainState();
+    if (!h->train) return fail(h, MGN_E_OOM, "host allocation failed");
+    TrainState& T = *h->train;
+    if (!T.packed)
+        if (int rc = pack_training_weights(h)) return rc;
+    if (!T.graph_ready)
+        if (int rc = prepare_graph(h)) return rc;
+
+    const int L = c.L, mps = c.mps, O = c.O;
+    hipStream_t st = h->stream;
+    float* A = T.arena.as<float>();
+    const float* Wt = T.w.as<float>();
+    const int32_t* egid = T.idx.as<int32_t>() + T.i_egid;
+    const int32_t* perm_s = T.idx.as<int32_t>() + T.i_perm;
+    const int32_t* rowptr_s = T.idx.as<int32_t>() + T.i_rowptr_s;
+    const int32_t* snd = h->es[0].d_snd.as<int32_t>();
+    const int32_t* rcv = h->es[0].d_rcv.as<int32_t>();
+    const int32_t* rowptr = h->es[0].d_rowptr.as<int32_t>();
+    const int32_t nt_n = (int32_t)((N + TILE - 1) / TILE), nt_e = (int32_t)((E + TILE - 1) / TILE);
+    float* G = T.grads.as<float>();
+
+    // ---- inputs
+    HIPCHK(h, hipMemsetAsync(G, 0, h->params.size() * 4, st));
+    HIPCHK(h, hipMemcpyAsync(A + T.nf_raw, nf, (size_t)N * c.Fn * 4, hipMemcpyHostToDevice, st));
+    HIPCHK(h, launch_pad_rows(A + T.nf_raw, c.Fn, A + T.nf_pad, L, N, st));
+    if (E > 0) {
+        HIPCHK(h, hipMemcpyAsync(A + T.ef_raw, ef, (size_t)E * c.Fe * 4, hipMemcpyHostToDevice, st));
+        HIPCHK(h, launch_pad_rows(A + T.ef_raw, c.Fe, A + T.ef_pad, L, E, st));
+    }
+    HIPCHK(h, hipMemcpyAsync(T.target.p, target, (size_t)N * O * 4, hipMemcpyHostToDevice, st));
+    HIPCHK(h, T.mask.ensure((size_t)nmask * 4));
+    HIPCHK(h, hipMemcpyAsync(T.mask.p, mask, (size_t)nmask * 4, hipMemcpyHostToDevice, st));
+
+    auto fwd = [&](const TrainMlp& m, int64_t rows, int32_t ntiles, const float* x0, const int32_t* i0, const float* x1, const int32_t* i1,
+                   const float* x2, const int32_t* i2, size_t h1, size_t h2, size_t y, const float* resid, float* out, float* lnout) {
+        TrainFwdArgs a{};
+        a.rows = rows; a.ntiles = ntiles;
+        a.X[0] = x0; a.X[1] = x1; a.X[2] = x2;
+        a.xidx[0] = i0; a.xidx[1] = i1; a.xidx[2] = i2;
+        for (int j = 0; j < m.nin; ++j) a.W1[j] = Wt + m.W1[j];
+        a.W2 = Wt + m.W2; a.W3 = Wt + m.W3; a.tabs = Wt + m.tabs;
+        a.H1 = A + h1; a.H2 = A + h2; a.Y = A + y;
+        a.resid = resid; a.OUT = out; a.LNOUT = lnout;
+        a.ln = m.off->ln ? 1 : 0;
+        return launch_mlp_fwd(L, m.nin, a, st);
+    };
+
+    // ---- forward, keeping activations
+    const TrainMlp& m_en = T.mlp[0];
+    const TrainMlp& m_ee = T.mlp[1];
+    const TrainMlp& m_de = T.mlp.back();
+    HIPCHK(h, fwd(m_en, N, nt_n, A + T.nf_pad, nullptr, nullptr, nullptr, nullptr, nullptr, T.enH[0], T.enH[1], T.enH[2], nullptr, A + T.Vk[0], nullptr));
+    HIPCHK(h, fwd(m_ee, E, nt_e, A + T.ef_pad, egid, nullptr, nullptr, nullptr, nullptr, T.eeH[0], T.eeH[1], T.eeH[2], nullptr, A + T.Ek[0], nullptr));
+    for (int k = 0; k < mps; ++k) {
+        const TrainMlp& me = T.mlp[2 + 2 * k];
+        const TrainMlp& mn = T.mlp[3 + 2 * k];
+        HIPCHK(h, fwd(me, E, nt_e, A + T.Vk[k], snd, A + T.Vk[k], rcv, A + T.Ek[k], nullptr, T.eH[0][k], T.eH[1][k], T.eH[2][k], A + T.Ek[k],
+                      A + T.Ek[k + 1], A + T.Enew));
+        HIPCHK(h, launch_segment_sum(L, A + T.Enew, rowptr, nullptr, nullptr, A + T.agg[k], (int32_t)N, st));
+        HIPCHK(h, fwd(mn, N, nt_n, A + T.Vk[k], nullptr, A + T.agg[k], nullptr, nullptr, nullptr, T.nH[0][k], T.nH[1][k], T.nH[2][k], A + T.Vk[k],
+                      A + T.Vk[k + 1], nullptr));
+    }
+    HIPCHK(h, fwd(m_de, N, nt_n, A + T.Vk[mps], nullptr, nullptr, nullptr, nullptr, nullptr, T.dH[0], T.dH[1], T.dH[2], nullptr, nullptr, nullptr));
+
+    // ---- loss = mean(mse_reduce(target, out)[mask]) and its gradient w.r.t. out
+    const int nlb = loss_blocks(nmask);
+    HIPCHK(h, T.loss.ensure((size_t)nlb * sizeof(double)));
+    HIPCHK(h, hipMemsetAsync(A + T.Gout, 0, (size_t)N * L * 4, st));
+    HIPCHK(h, launch_loss(A + T.dH[2], L, T.target.as<float>(), O, T.mask.as<int32_t>(), nmask, mask_index_base, A + T.Gout, T.loss.as<double>(), st));
+
+    // ---- backward
+    // activation backward of one MLP + all of its parameter gradients
+    auto bwd = [&](const TrainMlp& m, int64_t rows, int32_t ntiles, const float* g0, const float* g1, const int32_t* g1i, size_t h1, size_t h2, size_t y,
+                   float* const gx[3], const float* const gxadd[3], const float* const xin[3], const int32_t* const xi[3]) -> int {
+        TrainBwdArgs a{};
+        a.rows = rows; a.ntiles = ntiles;
+        a.G0 = g0; a.G1 = g1; a.g1idx = g1i;
+        a.Y = A + y; a.H2 = A + h2; a.H1 = A + h1;
+        a.W3T = Wt + m.W3T; a.W2T = Wt + m.W2T;
+        for (int j = 0; j < m.nin; ++j) {
+            a.W1T[j] = (m.has_w1t && gx[j]) ? Wt + m.W1T[j] : nullptr;
+            a.GX[j] = gx[j];
+            a.GXadd[j] = gxadd[j];
+        }
+        a.tabs = Wt + m.tabs;
+        a.ln = m.off->ln ? 1 : 0;
+        a.GT = A + T.GT; a.GXH = A + T.GXH; a.GY = A + T.GY; a.GZ2 = A + T.GZ2; a.GZ1 = A + T.GZ1;
+        HIPCHK(h, launch_mlp_bwd(L, m.nin, a, st));
+        // every parameter gradient of this MLP: one batched weight-gradient launch + one batched (ordered) reduction
+        const MlpOff& o = *m.off;
+        const int nb = wgrad_blocks(rows);
+        if (nb == 0) return MGN_OK;
+        WgradBatch wb{};
+        ReduceBatch rb{};
+        int nw = 0;
+        auto job = [&](const float* X, const int32_t* xi_, const float* Gm, long woff, int nrows, int cols, long boff, int bcols) {
+            WgradJob& j = wb.job[wb.njobs];
+            j.X = X; j.xidx = xi_; j.G = Gm; j.rows = rows;
+            j.pw = woff >= 0 ? A + T.pw + (size_t)nw * nb * L * L : nullptr;
+            j.pb = boff >= 0 ? A + T.pb + (size_t)wb.njobs * nb * L : nullptr;
+            if (woff >= 0) {
+                rb.job[rb.njobs++] = ReduceJob{j.pw, nb, (int64_t)L * L, nrows, cols, L, G + woff};
+                ++nw;
+            }
+            if (boff >= 0) rb.job[rb.njobs++] = ReduceJob{j.pb, nb, (int64_t)L, 1, bcols, L, G + boff};
+            ++wb.njobs;
+        };
+        job(A + h2, nullptr, A + T.GY, (long)o.W[2], L, o.out, (long)o.b[2], o.out);
+        job(A + h1, nullptr, A + T.GZ2, (long)o.W[1], L, L, (long)o.b[1], L);
+        for (int j = 0; j < m.nin; ++j)
+            job(xin[j], xi[j], A + T.GZ1, (long)(o.W[0] + (size_t)j * L * L), m.in_rows, L, j == 0 ? (long)o.b[0] : -1, L);
+        if (o.ln) {
+            job(nullptr, nullptr, A + T.GXH, -1, 0, 0, (long)o.gamma, L);
+            job(nullptr, nullptr, A + T.GT, -1, 0, 0, (long)o.beta, L);
+        }
+        HIPCHK(h, launch_wgrad(L, wb, rows, st));
+        HIPCHK(h, launch_reduce_partials(rb, st));
+        return MGN_OK;
+    };
+
+    int cur = 0;   // gV[cur], gE[cur] hold the gradients w.r.t. the latents entering the part of the model already unwound
+    {
+        float* gx[3] = {A + T.gV[cur], nullptr, nullptr};
+        const float* gxadd[3] = {nullptr, nullptr, nullptr};
+        const float* xin[3] = {A + T.Vk[mps], nullptr, nullptr};
+        const int32_t* xi[3] = {nullptr, nullptr, nullptr};
+        if (int rc = bwd(m_de, N, nt_n, A + T.Gout, nullptr, nullptr, T.dH[0], T.dH[1], T.dH[2], gx, gxadd, xin, xi)) return rc;
+    }
+    HIPCHK(h, hipMemsetAsync(A + T.gE[cur], 0, (size_t)(E > 0 ? E : 1) * L * 4, st));
+    int ecur = 0;
+    for (int k = mps - 1; k >= 0; --k) {
+        const TrainMlp& me = T.mlp[2 + 2 * k];
+        const TrainMlp& mn = T.mlp[3 + 2 * k];
+        const int nxt = cur ^ 1, enxt = ecur ^ 1;
+        {   // node MLP: v_{k+1} = v_k + MLP_v([v_k; agg_k])
+            float* gx[3] = {A + T.gV[nxt], A + T.gAgg, nullptr};
+            const float* gxadd[3] = {A + T.gV[cur], nullptr, nullptr};
+            const float* xin[3] = {A + T.Vk[k], A + T.agg[k], nullptr};
+            const int32_t* xi[3] = {nullptr, nullptr, nullptr};
+            if (int rc = bwd(mn, N, nt_n, A + T.gV[cur], nullptr, nullptr, T.nH[0][k], T.nH[1][k], T.nH[2][k], gx, gxadd, xin, xi)) return rc;
+        }
+        {   // edge MLP: e' feeds e_{k+1} = e_k + e' and agg_k[receiver]
+            float* gx[3] = {A + T.GXs, A + T.GXr, A + T.gE[enxt]};
+            const float* gxadd[3] = {nullptr, nullptr, A + T.gE[ecur]};
+            const float* xin[3] = {A + T.Vk[k], A + T.Vk[k], A + T.Ek[k]};
+            const int32_t* xi[3] = {snd, rcv, nullptr};
+            if (int rc = bwd(me, E, nt_e, A + T.gE[ecur], A + T.gAgg, rcv, T.eH[0][k], T.eH[1][k], T.eH[2][k], gx, gxadd, xin, xi)) return rc;
+        }
+        // gather duality: the gradients of v[receivers] / v[senders] are segmented sums over the receiver / sender CSR
+        HIPCHK(h, launch_segment_sum(L, A + T.GXr, rowptr, nullptr, A + T.gV[nxt], A + T.gV[cur], (int32_t)N, st));
+        HIPCHK(h, launch_segment_sum(L, A + T.GXs, rowptr_s, perm_s, A + T.gV[cur], A + T.gV[nxt], (int32_t)N, st));
+        if (E == 0) HIPCHK(h, hipMemsetAsync(A + T.gE[enxt], 0, (size_t)L * 4, st));
+        cur = nxt;
+        ecur = enxt;
+    }
+    {
+        float* gx[3] = {nullptr, nullptr, nullptr};
+        const float* gxadd[3] = {nullptr, nullptr, nullptr};
+        const float* xin[3] = {A + T.nf_pad, nullptr, nullptr};
+        const int32_t* xi[3] = {nullptr, nullptr, nullptr};
+        if (int rc = bwd(m_en, N, nt_n, A + T.gV[cur], nullptr, nullptr, T.enH[0], T.enH[1], T.enH[2], gx, gxadd, xin, xi)) return rc;
+        const float* xin_e[3] = {A + T.ef_pad, nullptr, nullptr};
+        const int32_t* xi_e[3] = {egid, nullptr, nullptr};
+        if (int rc = bwd(m_ee, E, nt_e, A + T.gE[ecur], nullptr, nullptr, T.eeH[0], T.eeH[1], T.eeH[2], gx, gxadd, xin_e, xi_e)) return rc;
+    }
+
+    // ---- results
+    std::vector<double> lp((size_t)nlb);
+    HIPCHK(h, hipMemcpyAsync(grads, G, h->params.size() * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(h, hipMemcpyAsync(lp.data(), T.loss.p, lp.size() * sizeof(double), hipMemcpyDeviceToHost, st));
+    HIPCHK(h, hipStreamSynchronize(st));
+    double s = 0.0;
+    for (double v : lp) s += v;
+    *loss = (float)(s / (double)nmask);
+    return MGN_OK;
+}

@@ -1,0 +1,67 @@
+// Kernel argument blocks and launch wrappers of the training step (mgn_step == GraphNetCore.step!, reference
+// src/strategies.jl:418-422).  Internal; the public boundary is include/mgn_hip.h.
+//
+// All training tensors are ROW-MAJOR [rows][L] fp32 (rows padded to whole 32-row tiles by the allocator); inputs
+// narrower than L (node / edge features, decoder output) are zero-padded to L so that every MLP of the model --
+// encoders, processor MLPs, decoder -- runs through the same three MFMA kernels:
+//   k_mlp_fwd   forward, keeps the post-ReLU hidden activations H1, H2 and the pre-LayerNorm output Y
+//   k_mlp_bwd   LayerNorm / ReLU / Dense backward w.r.t. the activations (transposed weight chunks)
+//   k_wgrad     dW = X^T G  (reduction over rows on the MFMA, deterministic per-block partials) + column sums of G
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace mgn {
+
+struct TrainFwdArgs {
+    int64_t rows; int32_t ntiles;
+    const float* X[3]; const int32_t* xidx[3];   // layer-1 input blocks; xidx[j] != null: row gather
+    const float* W1[3]; const float* W2; const float* W3;   // L x L chunks, fragment order (streamed from L2)
+    const float* tabs;                           // T_B1, T_B2, T_B3, T_GAMMA, T_BETA (fragment order)
+    float* H1; float* H2; float* Y;              // kept for the backward
+    const float* resid; float* OUT;              // OUT = (resid ? resid : 0) + (ln ? LayerNorm(Y) : Y)
+    float* LNOUT;                                // optional: LayerNorm(Y) alone (the message e' that is aggregated)
+    int32_t ln;
+};
+
+struct TrainBwdArgs {
+    int64_t rows; int32_t ntiles;
+    const float* G0; const float* G1; const int32_t* g1idx;   // upstream gradient = G0[row] (+ G1[g1idx[row]])
+    const float* Y; const float* H2; const float* H1;
+    const float* W3T; const float* W2T; const float* W1T[3];  // transposed chunks, fragment order; W1T[j] null: skip
+    const float* tabs;                           // gamma in T_GAMMA
+    int32_t ln;
+    float* GT; float* GXH;                       // ln: total upstream gradient and G * xhat (-> dbeta, dgamma by column sums)
+    float* GY; float* GZ2; float* GZ1;           // gradients at the three Dense outputs (-> weight / bias gradients)
+    float* GX[3]; const float* GXadd[3];         // GX[j][row] = (GXadd[j] ? GXadd[j][row] : 0) + GZ1[row] * W1T[j]
+};
+
+hipError_t launch_mlp_fwd(int L, int nin, const TrainFwdArgs& a, hipStream_t s);
+hipError_t launch_mlp_bwd(int L, int nin, const TrainBwdArgs& a, hipStream_t s);
+
+// Weight gradients of one MLP in ONE launch (blockIdx.y = job):
+//   dW[in][out] = sum_rows X[xidx ? xidx[row] : row][in] * G[row][out];   db[out] = sum_rows G[row][out]
+// The row range is split over wgrad_blocks(rows) blocks: pw [nblocks][L][L], pb [nblocks][L] hold per-block partials.
+// pw == null: column sums only (LayerNorm parameter gradients); pb == null: no column sums.
+constexpr int WGRAD_MAX_JOBS = 8;
+struct WgradJob { const float* X; const int32_t* xidx; const float* G; int64_t rows; float* pw; float* pb; };
+struct WgradBatch { int32_t njobs; int64_t rows_per_block; WgradJob job[WGRAD_MAX_JOBS]; };
+int wgrad_blocks(int64_t rows);
+hipError_t launch_wgrad(int L, WgradBatch wb, int64_t rows, hipStream_t s);
+// out[r * cols + c] = sum_b partial[b * block_stride + r * ld + c]   (fixed order: bitwise reproducible), one job per blockIdx.y
+constexpr int REDUCE_MAX_JOBS = 16;
+struct ReduceJob { const float* partial; int32_t nblocks; int64_t block_stride; int32_t nrows, cols, ld; float* out; };
+struct ReduceBatch { int32_t njobs; ReduceJob job[REDUCE_MAX_JOBS]; };
+hipError_t launch_reduce_partials(const ReduceBatch& rb, hipStream_t s);
+// out[n] = (add ? add[n] : 0) + sum_{p in [rowptr[n], rowptr[n+1])} src[perm ? perm[p] : p]   (rows of L floats)
+hipError_t launch_segment_sum(int L, const float* src, const int32_t* rowptr, const int32_t* perm, const float* add, float* out,
+                              int32_t n, hipStream_t s);
+// dst [rows][L] = [src[rows][F] | 0]
+hipError_t launch_pad_rows(const float* src, int F, float* dst, int L, int64_t rows, hipStream_t s);
+// masked MSE: loss_partial[b] = sum over this block's mask entries of sum_o (out - target)^2;
+// G[n][o] += 2 (out[n][o] - target[n][o]) / nmask   (G [N][L] zeroed by the caller; out = first O columns of Y)
+int loss_blocks(int64_t nmask);
+hipError_t launch_loss(const float* Y, int L, const float* target, int O, const int32_t* mask, int64_t nmask, int32_t index_base,
+                       float* G, double* loss_partial, hipStream_t s);
+
+}  // namespace mgn

@@ -1,0 +1,377 @@
+// CDNA4 (gfx950) kernels of the training step: forward with kept activations, backward, weight gradients.
+//
+// Replaces what Zygote + Lux + NNlib execute for GraphNetCore.step!(mgn, graph, target, mask, mse_reduce)
+// (reference src/strategies.jl:418-422; gradients consumed at src/MeshGraphNets.jl:370-378).  First correct HIP
+// version of SURVEY.md N2: the same lane-per-row MFMA building blocks as the inference kernels (frag.hpp), one
+// MLP per launch, row-major activations, weights streamed from L2.  See train.h for the kernel inventory.
+#include "train.h"
+
+#include "frag.hpp"
+
+namespace mgn {
+
+namespace {
+
+struct RowRef {
+    int64_t row, rr;
+    bool valid;
+};
+
+DEVINL RowRef row_of(int tile, int c, int64_t rows) {
+    RowRef r;
+    r.row = (int64_t)tile * TILE + c;
+    r.valid = r.row < rows;
+    r.rr = r.valid ? r.row : rows - 1;
+    return r;
+}
+
+}  // namespace
+
+// ================================================================================================
+// forward of one 3-Dense MLP (+ LayerNorm, + residual), keeping H1, H2, Y
+// ================================================================================================
+template <int NT, int NIN>
+__global__ __launch_bounds__(256) void k_mlp_fwd(const TrainFwdArgs a) {
+    constexpr int L = 32 * NT;
+    const int lane0 = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int tile = blockIdx.x * 4 + wave;
+    if (tile >= a.ntiles) return;
+    OPAQUE_LANE();
+    const RowRef rw = row_of(tile, c, a.rows);
+    f32x16 x[NT], acc[NT], y[NT];
+    tab_frag<NT>(acc, a.tabs + T_B1 * L, h);
+#pragma unroll
+    for (int j = 0; j < NIN; ++j) {
+        const int64_t src = a.xidx[j] ? (int64_t)a.xidx[j][rw.rr] : rw.rr;
+        load_frag<NT>(x, row_ptr(a.X[j], src, L, h), STRIDE_ROW);
+        mfma_chunk<NT, false>(acc, x, a.W1[j], lane);
+    }
+    relu_frag<NT>(acc);
+    if (rw.valid) store_frag<NT>(row_ptr(a.H1, rw.row, L, h), STRIDE_ROW, acc);
+    tab_frag<NT>(y, a.tabs + T_B2 * L, h);
+    mfma_chunk<NT, false>(y, acc, a.W2, lane);
+    relu_frag<NT>(y);
+    if (rw.valid) store_frag<NT>(row_ptr(a.H2, rw.row, L, h), STRIDE_ROW, y);
+    tab_frag<NT>(acc, a.tabs + T_B3 * L, h);
+    mfma_chunk<NT, false>(acc, y, a.W3, lane);
+    if (rw.valid) store_frag<NT>(row_ptr(a.Y, rw.row, L, h), STRIDE_ROW, acc);
+    if (a.ln) layer_norm_frag<NT>(acc, a.tabs + T_GAMMA * L, a.tabs + T_BETA * L, h);
+    if (a.LNOUT && rw.valid) store_frag<NT>(row_ptr(a.LNOUT, rw.row, L, h), STRIDE_ROW, acc);
+    if (a.resid) add_frag<NT>(acc, row_ptr(a.resid, rw.rr, L, h), STRIDE_ROW);
+    if (a.OUT && rw.valid) store_frag<NT>(row_ptr(a.OUT, rw.row, L, h), STRIDE_ROW, acc);
+}
+
+// ================================================================================================
+// backward of the same MLP w.r.t. its activations
+//   LayerNorm:  gy = rstd * (g*gamma - mean(g*gamma) - xhat * mean(g*gamma*xhat))
+//   Dense i:    g_in = g_out * W_i^T (transposed chunk through the same MFMA path), masked by the kept ReLU output
+// ================================================================================================
+template <int NT>
+DEVINL void mask_by_relu(f32x16 (&g)[NT], const f32x16 (&act)[NT]) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int k = 0; k < 16; ++k) g[t][k] = act[t][k] > 0.f ? g[t][k] : 0.f;
+}
+
+template <int NT, int NIN>
+__global__ __launch_bounds__(256) void k_mlp_bwd(const TrainBwdArgs a) {
+    constexpr int L = 32 * NT;
+    constexpr float invL = 1.0f / L;
+    const int lane0 = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int tile = blockIdx.x * 4 + wave;
+    if (tile >= a.ntiles) return;
+    OPAQUE_LANE();
+    const RowRef rw = row_of(tile, c, a.rows);
+    f32x16 g[NT], y[NT], acc[NT];
+    load_frag<NT>(g, row_ptr(a.G0, rw.rr, L, h), STRIDE_ROW);
+    if (a.G1) add_frag<NT>(g, row_ptr(a.G1, a.g1idx ? (int64_t)a.g1idx[rw.rr] : rw.rr, L, h), STRIDE_ROW);
+    if (!rw.valid) zero_frag<NT>(g);
+    if (a.ln) {
+        if (rw.valid) store_frag<NT>(row_ptr(a.GT, rw.row, L, h), STRIDE_ROW, g);
+        load_frag<NT>(y, row_ptr(a.Y, rw.rr, L, h), STRIDE_ROW);
+        float s = 0.f;
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int k = 0; k < 16; ++k) s += y[t][k];
+        s += __shfl_xor(s, 32, 64);
+        const float mean = s * invL;
+        float q = 0.f;
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const float d = y[t][k] - mean;
+                y[t][k] = d;
+                q += d * d;
+            }
+        q += __shfl_xor(q, 32, 64);
+        const float rstd = 1.0f / sqrtf(q * invL + LN_EPS);
+        tab_frag<NT>(acc, a.tabs + T_GAMMA * L, h);           // acc = gamma
+        float m1 = 0.f, m2 = 0.f;
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const float xh = y[t][k] * rstd;
+                const float gg = g[t][k] * acc[t][k];
+                acc[t][k] = g[t][k] * xh;                     // G * xhat  (-> dgamma)
+                y[t][k] = xh;
+                g[t][k] = gg;
+                m1 += gg;
+                m2 += gg * xh;
+            }
+        m1 += __shfl_xor(m1, 32, 64);
+        m2 += __shfl_xor(m2, 32, 64);
+        m1 *= invL;
+        m2 *= invL;
+        if (rw.valid) store_frag<NT>(row_ptr(a.GXH, rw.row, L, h), STRIDE_ROW, acc);
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int k = 0; k < 16; ++k) g[t][k] = rstd * (g[t][k] - m1 - y[t][k] * m2);
+    }
+    if (rw.valid) store_frag<NT>(row_ptr(a.GY, rw.row, L, h), STRIDE_ROW, g);
+    zero_frag<NT>(acc);
+    mfma_chunk<NT, false>(acc, g, a.W3T, lane);               // gradient at H2
+    load_frag<NT>(y, row_ptr(a.H2, rw.rr, L, h), STRIDE_ROW);
+    mask_by_relu<NT>(acc, y);
+    if (rw.valid) store_frag<NT>(row_ptr(a.GZ2, rw.row, L, h), STRIDE_ROW, acc);
+    zero_frag<NT>(g);
+    mfma_chunk<NT, false>(g, acc, a.W2T, lane);               // gradient at H1
+    load_frag<NT>(y, row_ptr(a.H1, rw.rr, L, h), STRIDE_ROW);
+    mask_by_relu<NT>(g, y);
+    if (rw.valid) store_frag<NT>(row_ptr(a.GZ1, rw.row, L, h), STRIDE_ROW, g);
+#pragma unroll
+    for (int j = 0; j < NIN; ++j) {
+        if (!a.W1T[j]) continue;
+        if (a.GXadd[j]) load_frag<NT>(acc, row_ptr(a.GXadd[j], rw.rr, L, h), STRIDE_ROW);
+        else zero_frag<NT>(acc);
+        mfma_chunk<NT, false>(acc, g, a.W1T[j], lane);
+        if (rw.valid) store_frag<NT>(row_ptr(a.GX[j], rw.row, L, h), STRIDE_ROW, acc);
+    }
+}
+
+// ================================================================================================
+// weight gradient: dW[in][out] = sum_rows X[row][in] * G[row][out] on v_mfma_f32_32x32x2_f32 with the ROW index as the
+// reduction dimension: A operand = X^T (lane (m = l&31, k = l>>5) reads X[row 2q+k][32 ti + m], 128 contiguous bytes per
+// half wave), B operand = G (lane (n, k) reads G[row 2q+k][32 tj + n]).  Wave ti of a block owns input-feature block ti
+// and all NT output blocks; a block owns a contiguous row range and writes its partial dW (and the column sums of G).
+// ================================================================================================
+constexpr int WG_ROWS = 32;    // rows per block at least (small meshes: many short blocks, the loads are latency-bound)
+constexpr int WG_UNROLL = 8;   // k-steps (2 rows each) whose loads are issued together
+
+template <int NT>
+__global__ __launch_bounds__(64 * NT) void k_wgrad(const WgradBatch wb) {
+    constexpr int L = 32 * NT;
+    const WgradJob& jb = wb.job[blockIdx.y];
+    const int64_t r0 = (int64_t)blockIdx.x * wb.rows_per_block;
+    if (r0 >= jb.rows) return;
+    const int64_t r1 = r0 + wb.rows_per_block < jb.rows ? r0 + wb.rows_per_block : jb.rows;
+    const int lane = threadIdx.x & 63, m = lane & 31, kk = lane >> 5;
+    const int ti = threadIdx.x >> 6;
+    const float* __restrict__ X = jb.X;
+    const float* __restrict__ G = jb.G;
+    const int32_t* __restrict__ xidx = jb.xidx;
+    const bool with_w = jb.pw != nullptr;
+    if (!with_w && ti != 0) return;              // column sums only: one wave
+    f32x16 acc[NT];
+    float bs[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        bs[t] = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) acc[t][k] = 0.f;
+    }
+    for (int64_t q = r0; q < r1; q += 2 * WG_UNROLL) {
+        float av[WG_UNROLL], bv[WG_UNROLL][NT];
+#pragma unroll
+        for (int u = 0; u < WG_UNROLL; ++u) {
+            const int64_t row = q + 2 * u + kk;
+            const bool ok = row < r1;
+            const int64_t rr = ok ? row : r0;
+            float xa = 0.f;
+            if (with_w) {
+                const int64_t src = xidx ? (int64_t)xidx[rr] : rr;
+                xa = X[src * L + 32 * ti + m];
+            }
+            av[u] = ok ? xa : 0.f;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const float gb = G[rr * L + 32 * t + m];
+                bv[u][t] = ok ? gb : 0.f;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < WG_UNROLL; ++u)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                if (with_w) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bv[u][t], acc[t], 0, 0, 0);
+                bs[t] += bv[u][t];
+            }
+    }
+    // D layout of the 32x32 MFMA: register r of lane l holds D[(r&3) + 8(r>>2) + 4(l>>5)][l&31]
+    if (with_w) {
+        float* pw = jb.pw + (size_t)blockIdx.x * L * L;
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) pw[(size_t)(32 * ti + (r & 3) + 8 * (r >> 2) + 4 * kk) * L + 32 * t + m] = acc[t][r];
+    }
+    if (ti == 0 && jb.pb) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const float sb = bs[t] + __shfl_xor(bs[t], 32, 64);
+            if (kk == 0) jb.pb[(size_t)blockIdx.x * L + 32 * t + m] = sb;
+        }
+    }
+}
+
+// out[r * cols + c] = sum_b partial[b][r * ld + c], fixed order (bitwise reproducible); one job per blockIdx.y
+__global__ void k_reduce_partials(const ReduceBatch rb) {
+    const ReduceJob& jb = rb.job[blockIdx.y];
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= jb.nrows * jb.cols) return;
+    const int r = i / jb.cols, cidx = i - r * jb.cols;
+    const float* __restrict__ p = jb.partial + (size_t)r * jb.ld + cidx;
+    float s = 0.f;
+    int b = 0;
+    for (; b + 4 <= jb.nblocks; b += 4) {        // independent loads, same summation order
+        const float v0 = p[(size_t)b * jb.block_stride], v1 = p[(size_t)(b + 1) * jb.block_stride];
+        const float v2 = p[(size_t)(b + 2) * jb.block_stride], v3 = p[(size_t)(b + 3) * jb.block_stride];
+        s += v0; s += v1; s += v2; s += v3;
+    }
+    for (; b < jb.nblocks; ++b) s += p[(size_t)b * jb.block_stride];
+    jb.out[i] = s;
+}
+
+__global__ void k_segment_sum(const float* __restrict__ src, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ perm,
+                              const float* __restrict__ add, float* __restrict__ out, int32_t n, int L4) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)n * L4) return;
+    const int node = (int)(i / L4), q = (int)(i - (int64_t)node * L4);
+    f32x4 s = add ? reinterpret_cast<const f32x4*>(add)[i] : f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int p = rowptr[node]; p < rowptr[node + 1]; ++p) {
+        const int64_t row = perm ? perm[p] : p;
+        s += reinterpret_cast<const f32x4*>(src)[row * L4 + q];
+    }
+    reinterpret_cast<f32x4*>(out)[i] = s;
+}
+
+__global__ void k_pad_rows(const float* __restrict__ src, int F, float* __restrict__ dst, int L, int64_t rows) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * L) return;
+    const int64_t r = i / L;
+    const int f = (int)(i - r * L);
+    dst[i] = f < F ? src[r * F + f] : 0.f;
+}
+
+__global__ void k_loss(const float* __restrict__ Y, int L, const float* __restrict__ target, int O, const int32_t* __restrict__ mask,
+                       int64_t nmask, int32_t index_base, float* __restrict__ G, double* __restrict__ loss_partial) {
+    __shared__ double sh[4];
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    double e = 0.0;
+    if (i < nmask) {
+        const int64_t n = (int64_t)mask[i] - index_base;
+        const float scale = 2.0f / (float)nmask;
+        for (int o = 0; o < O; ++o) {
+            const float d = Y[n * L + o] - target[n * O + o];
+            e += (double)d * (double)d;
+            atomicAdd(&G[n * L + o], scale * d);     // a node listed twice contributes twice, like err[mask]
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) e += __shfl_xor(e, off, 64);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = e;
+    __syncthreads();
+    if (threadIdx.x == 0) loss_partial[blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
+}
+
+// ================================================================================================
+// launch wrappers
+// ================================================================================================
+template <typename K, typename A>
+static hipError_t launch_tiles(K kern, const A& a, int ntiles, hipStream_t s) {
+    if (ntiles <= 0) return hipSuccess;
+    hipLaunchKernelGGL(kern, dim3((unsigned)((ntiles + 3) / 4)), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_mlp_fwd(int L, int nin, const TrainFwdArgs& a, hipStream_t s) {
+#define FWD_CASE(NT_, NIN_) if (L == 32 * NT_ && nin == NIN_) return launch_tiles(k_mlp_fwd<NT_, NIN_>, a, a.ntiles, s)
+    FWD_CASE(4, 1); FWD_CASE(4, 2); FWD_CASE(4, 3);
+    FWD_CASE(2, 1); FWD_CASE(2, 2); FWD_CASE(2, 3);
+    FWD_CASE(1, 1); FWD_CASE(1, 2); FWD_CASE(1, 3);
+#undef FWD_CASE
+    return hipErrorInvalidValue;
+}
+
+hipError_t launch_mlp_bwd(int L, int nin, const TrainBwdArgs& a, hipStream_t s) {
+#define BWD_CASE(NT_, NIN_) if (L == 32 * NT_ && nin == NIN_) return launch_tiles(k_mlp_bwd<NT_, NIN_>, a, a.ntiles, s)
+    BWD_CASE(4, 1); BWD_CASE(4, 2); BWD_CASE(4, 3);
+    BWD_CASE(2, 1); BWD_CASE(2, 2); BWD_CASE(2, 3);
+    BWD_CASE(1, 1); BWD_CASE(1, 2); BWD_CASE(1, 3);
+#undef BWD_CASE
+    return hipErrorInvalidValue;
+}
+
+static int64_t wgrad_rows_per_block(int64_t rows) {
+    int64_t rpb = (rows + 1023) / 1024;              // at most 1024 blocks
+    if (rpb < WG_ROWS) rpb = WG_ROWS;
+    return (rpb + 2 * WG_UNROLL - 1) / (2 * WG_UNROLL) * (2 * WG_UNROLL);
+}
+int wgrad_blocks(int64_t rows) {
+    if (rows <= 0) return 0;
+    const int64_t rpb = wgrad_rows_per_block(rows);
+    return (int)((rows + rpb - 1) / rpb);
+}
+
+hipError_t launch_wgrad(int L, WgradBatch wb, int64_t rows, hipStream_t s) {
+    const int nb = wgrad_blocks(rows);
+    if (nb == 0 || wb.njobs <= 0) return hipSuccess;
+    wb.rows_per_block = wgrad_rows_per_block(rows);
+    const dim3 grid(nb, wb.njobs);
+    if (L == 128) hipLaunchKernelGGL(k_wgrad<4>, grid, dim3(256), 0, s, wb);
+    else if (L == 64) hipLaunchKernelGGL(k_wgrad<2>, grid, dim3(128), 0, s, wb);
+    else if (L == 32) hipLaunchKernelGGL(k_wgrad<1>, grid, dim3(64), 0, s, wb);
+    else return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
+hipError_t launch_reduce_partials(const ReduceBatch& rb, hipStream_t s) {
+    int n = 0;
+    for (int j = 0; j < rb.njobs; ++j) n = rb.job[j].nrows * rb.job[j].cols > n ? rb.job[j].nrows * rb.job[j].cols : n;
+    if (n <= 0 || rb.njobs <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_reduce_partials, dim3((n + 255) / 256, rb.njobs), dim3(256), 0, s, rb);
+    return hipGetLastError();
+}
+
+hipError_t launch_segment_sum(int L, const float* src, const int32_t* rowptr, const int32_t* perm, const float* add, float* out,
+                              int32_t n, hipStream_t s) {
+    const int64_t tot = (int64_t)n * (L / 4);
+    if (tot <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_segment_sum, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, src, rowptr, perm, add, out, n, L / 4);
+    return hipGetLastError();
+}
+
+hipError_t launch_pad_rows(const float* src, int F, float* dst, int L, int64_t rows, hipStream_t s) {
+    const int64_t tot = rows * L;
+    if (tot <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_pad_rows, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, src, F, dst, L, rows);
+    return hipGetLastError();
+}
+
+int loss_blocks(int64_t nmask) { return nmask > 0 ? (int)((nmask + 255) / 256) : 0; }
+
+hipError_t launch_loss(const float* Y, int L, const float* target, int O, const int32_t* mask, int64_t nmask, int32_t index_base,
+                       float* G, double* loss_partial, hipStream_t s) {
+    const int nb = loss_blocks(nmask);
+    if (nb == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_loss, dim3(nb), dim3(256), 0, s, Y, L, target, O, mask, nmask, index_base, G, loss_partial);
+    return hipGetLastError();
+}
+
+}  // namespace mgn

@@ -253,6 +253,19 @@ class Engine:
         self._chk(self.lib.mgn_rollout(self.h, C.byref(d)))
         return out, dict(n_accept=d.n_accept, n_reject=d.n_reject, n_rhs=d.n_rhs)
 
+    def step(self, nf, ef, target, mask, mask_index_base=0):
+        """step!(mgn, graph, target, mask, mse_reduce) (reference src/strategies.jl:418-422): returns (gs, loss) with gs
+        in the packed order of set_params."""
+        nf = _c32(nf, (self.N, self.cfg.Fn))
+        ef = _c32(ef, (self.E, self.cfg.Fe))
+        target = _c32(target, (self.N, self.cfg.O))
+        mask = np.ascontiguousarray(mask, dtype=np.int32).ravel()
+        gs = np.zeros(self.param_count, np.float32)
+        loss = C.c_float()
+        self._chk(self.lib.mgn_step(self.h, f32(nf), f32(ef), f32(target), i32(mask), mask.size, mask_index_base, f32(gs), gs.size,
+                                    C.byref(loss)))
+        return gs, loss.value
+
     def processor_steps(self, v, e, nsteps):
         v = _c32(v, (self.N, self.cfg.L)).copy()
         e = _c32(e, (self.E, self.cfg.L)).copy()
@@ -428,6 +441,19 @@ class GraphNetwork:
         s = np.asarray(senders)
         self._graph_token = (s.ctypes.data if s.flags.c_contiguous else id(senders), s.size, N,
                              int(s[:16].sum()) if s.size else 0)
+
+
+def step(mgn, graph, target, mask, loss_function=None):
+    """GraphNetCore.step!(mgn, graph, target, mask, loss_function) as the reference calls it (src/strategies.jl:418-422):
+    returns (gs, loss) with loss = mean(mse_reduce(target, mgn.model(graph))[mask]) and gs = d loss / d mgn.ps in packed
+    order, ready for the optimiser update at src/MeshGraphNets.jl:375-377.  `mask` follows mgn.index_base (1-based Int32 node
+    indices at the Julia boundary).  Only the reference's loss (mse_reduce) exists on the device: any other callable
+    is refused rather than silently replaced."""
+    if loss_function is not None and getattr(loss_function, "__name__", "") != "mse_reduce":
+        raise ValueError("step: only mse_reduce is implemented on the device (reference src/strategies.jl:421)")
+    mgn._sync_params(mgn.ps)
+    mgn._sync_graph(graph.senders, graph.receivers, graph.nf.shape[0])
+    return mgn.engine.step(graph.nf, graph.ef, target, mask, mask_index_base=mgn.index_base)
 
 
 # ==================================================================================================

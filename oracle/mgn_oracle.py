@@ -287,6 +287,106 @@ def processor_steps(packed, cfg, v, e, senders, receivers, nsteps, dtype=np.floa
 
 
 # --------------------------------------------------------------------------------------------
+# Training step  (GraphNetCore.step!(mgn, graph, target, mask, mse_reduce) as called at
+#                 src/strategies.jl:418-422 and consumed at src/MeshGraphNets.jl:370-378)
+# Reverse-mode differentiation written out by hand (the reference uses Zygote); float64.
+# --------------------------------------------------------------------------------------------
+def mse_reduce(target, out):
+    """mse_reduce(target, output): sum of squared differences over the O rows per node (src/strategies.jl:421)."""
+    return ((np.asarray(target) - np.asarray(out)) ** 2).sum(1)
+
+
+def _mlp_fwd(x, p, h):
+    """MLP forward keeping what the backward needs."""
+    acts, a = [x], x
+    for i in range(1, h + 2):
+        z = a @ p["W%d" % i] + p["b%d" % i]
+        a = np.maximum(z, 0.0) if i <= h else z
+        acts.append(a)
+    cache = dict(acts=acts)
+    if "ln_scale" in p:
+        mu = a.mean(-1, keepdims=True)
+        var = ((a - mu) ** 2).mean(-1, keepdims=True)
+        rstd = 1.0 / np.sqrt(var + LN_EPS)
+        xhat = (a - mu) * rstd
+        cache.update(xhat=xhat, rstd=rstd)
+        a = xhat * p["ln_scale"] + p["ln_bias"]
+    return a, cache
+
+
+def _mlp_bwd(g, cache, p, h):
+    """g: gradient wrt the MLP output.  Returns (gradient wrt the input, {tensor name: gradient})."""
+    gp = {}
+    if "ln_scale" in p:
+        xhat, rstd = cache["xhat"], cache["rstd"]
+        gp["ln_scale"] = (g * xhat).sum(0)
+        gp["ln_bias"] = g.sum(0)
+        gg = g * p["ln_scale"]
+        g = rstd * (gg - gg.mean(-1, keepdims=True) - xhat * (gg * xhat).mean(-1, keepdims=True))
+    acts = cache["acts"]
+    for i in range(h + 1, 0, -1):
+        if i <= h:
+            g = g * (acts[i] > 0.0)
+        gp["W%d" % i] = acts[i - 1].T @ g
+        gp["b%d" % i] = g.sum(0)
+        g = g @ p["W%d" % i].T
+    return g, gp
+
+
+def step_grads(packed, cfg, nf, ef, senders, receivers, target, mask):
+    """(gs, loss) of step!: loss = mean(mse_reduce(target, model(graph))[mask]); gs = d loss / d ps in packed order.
+    mask: integer node indices (0-based here; Int32 1-based at the Julia boundary, src/MeshGraphNets.jl:352)."""
+    h = cfg["hidden_layers"]
+    P = _unpack(packed, cfg, np.float64)
+    if cfg.get("Fe2"):
+        raise NotImplementedError("step_grads: single edge set (the reference's FeatureGraph)")
+    nf, ef, target = np.asarray(nf, np.float64), np.asarray(ef, np.float64), np.asarray(target, np.float64)
+    mask = np.asarray(mask).reshape(-1)
+    N = nf.shape[0]
+    v, c_en = _mlp_fwd(nf, P["enc_node"], h)
+    e, c_ee = _mlp_fwd(ef, P["enc_edge"], h)
+    caches = []
+    for k in range(cfg["mps"]):
+        e_new, c_e = _mlp_fwd(np.concatenate([v[senders], v[receivers], e], 1), P["proc%d_edge" % k], h)
+        agg = scatter_add(e_new, receivers, N)
+        v_new, c_v = _mlp_fwd(np.concatenate([v, agg], 1), P["proc%d_node" % k], h)
+        caches.append((c_e, c_v))
+        v, e = v + v_new, e + e_new
+    out, c_d = _mlp_fwd(v, P["decoder"], h)
+    err = mse_reduce(target, out)
+    loss = err[mask].mean()
+
+    G = {}
+    g_out = np.zeros_like(out)
+    np.add.at(g_out, mask, 2.0 * (out[mask] - target[mask]) / mask.size)
+    gv, G["decoder"] = _mlp_bwd(g_out, c_d, P["decoder"], h)
+    ge = np.zeros_like(e)
+    L = cfg["L"]
+    for k in range(cfg["mps"] - 1, -1, -1):
+        c_e, c_v = caches[k]
+        g_in, G["proc%d_node" % k] = _mlp_bwd(gv, c_v, P["proc%d_node" % k], h)     # v_{k+1} = v_k + MLP_v([v_k; agg])
+        g_enew = ge + g_in[:, L:][receivers]                                        # e' feeds e_{k+1} and agg[receiver]
+        g_cat, G["proc%d_edge" % k] = _mlp_bwd(g_enew, c_e, P["proc%d_edge" % k], h)
+        gv = gv + g_in[:, :L]
+        np.add.at(gv, senders, g_cat[:, :L])
+        np.add.at(gv, receivers, g_cat[:, L:2 * L])
+        ge = ge + g_cat[:, 2 * L:]
+    _, G["enc_node"] = _mlp_bwd(gv, c_en, P["enc_node"], h)
+    _, G["enc_edge"] = _mlp_bwd(ge, c_ee, P["enc_edge"], h)
+    chunks = []
+    for bname, tensors in model_layout(cfg["Fn"], cfg["Fe"], cfg["O"], cfg["L"], h, cfg["mps"]):
+        for tname, shape in tensors:
+            assert G[bname][tname].shape == tuple(shape)
+            chunks.append(G[bname][tname].ravel())
+    return np.concatenate(chunks), float(loss)
+
+
+def loss_only(packed, cfg, nf, ef, senders, receivers, target, mask):
+    out = forward(packed, cfg, nf, ef, senders, receivers)
+    return float(mse_reduce(target, out)[np.asarray(mask).reshape(-1)].mean())
+
+
+# --------------------------------------------------------------------------------------------
 # ODE right-hand side wrapper  (src/solve.jl:147-158 ode_func_eval, :188-219 ode_step,
 #                               src/graph.jl:75-97 build_graph)
 # --------------------------------------------------------------------------------------------

@@ -1,0 +1,145 @@
+"""Training step (mgn_step == GraphNetCore.step!, reference src/strategies.jl:418-422) against the float64 hand-written
+reverse-mode oracle (oracle/mgn_oracle.py step_grads, itself checked against finite differences on the CPU).
+Run on the MI355X box with `-m gpu`."""
+import numpy as np
+import pytest
+
+import mgn_oracle as orc
+from mgn_amd import synth
+from util import cfg_dict, engine_for, make_params, rel_max, small_mesh
+
+pytestmark = pytest.mark.gpu
+
+TOL_LOSS = 1e-5      # relative
+TOL_GRAD = 2e-4      # max|d| / max|ref| per parameter tensor (fp32 reductions over up to ~12k rows, 15 steps deep)
+
+
+def check_grads(gs, ref, cfg, tol=TOL_GRAD):
+    off, worst = 0, ("", 0.0)
+    for bname, tensors in orc.model_layout(cfg["Fn"], cfg["Fe"], cfg["O"], cfg["L"], 2, cfg["mps"]):
+        for tname, shape in tensors:
+            n = int(np.prod(shape))
+            a, b = gs[off:off + n], ref[off:off + n]
+            scale = max(np.abs(b).max(), 1e-3 * np.abs(ref).max())
+            err = float(np.abs(a - b).max() / scale)
+            if err > worst[1]:
+                worst = (f"{bname}.{tname}", err)
+            off += n
+    assert off == ref.size
+    assert worst[1] <= tol, worst
+    return worst
+
+
+def problem(cfg, pos, s, r, seed=0, frac=0.6):
+    N, E = pos.shape[0], s.size
+    rng = np.random.default_rng(seed)
+    nf = rng.standard_normal((N, cfg["Fn"])).astype(np.float32)
+    ef = rng.standard_normal((E, cfg["Fe"])).astype(np.float32)
+    target = rng.standard_normal((N, cfg["O"])).astype(np.float32)
+    mask = np.sort(rng.choice(N, max(1, int(frac * N)), replace=False)).astype(np.int32)
+    return nf, ef, target, mask
+
+
+@pytest.mark.parametrize("L,mps", [(32, 1), (64, 2), (128, 3)])
+def test_step_matches_oracle_small_mesh(L, mps):
+    cfg = cfg_dict(L=L, mps=mps)
+    pos, s, r = small_mesh(9, 7)
+    ps = make_params(cfg)
+    nf, ef, target, mask = problem(cfg, pos, s, r)
+    eng = engine_for(cfg)
+    eng.set_params(ps)
+    eng.set_graph(s, r, pos.shape[0])
+    gs, loss = eng.step(nf, ef, target, mask)
+    ref, ref_loss = orc.step_grads(ps, cfg, nf, ef, s, r, target, mask)
+    assert abs(loss - ref_loss) <= TOL_LOSS * abs(ref_loss), (loss, ref_loss)
+    check_grads(gs, ref, cfg)
+    gs2, loss2 = eng.step(nf, ef, target, mask)                     # deterministic: bitwise repeatable
+    assert loss2 == loss and np.array_equal(gs, gs2)
+
+
+def test_step_cyl_15_steps_one_based_mask():
+    """cylinder_flow-shaped training datapoint (cfg-2 sized mesh, L = 128, 15 steps), mask 1-based as at the Julia
+    boundary (src/MeshGraphNets.jl:352)."""
+    cfg = cfg_dict(mps=15)
+    pos, cells, node_type, vel = synth.mesh_cyl(1234, 700)
+    s, r = synth.cells_to_edges(cells)
+    ps = make_params(cfg, jitter=0.05)
+    nf, ef, target, _ = problem(cfg, pos, s, r, seed=3)
+    mask0 = np.nonzero(np.isin(node_type, [0, 5]))[0].astype(np.int32)      # types_updated, like val_mask
+    eng = engine_for(cfg)
+    eng.set_params(ps)
+    eng.set_graph(s, r, pos.shape[0])
+    gs, loss = eng.step(nf, ef, target, mask0 + 1, mask_index_base=1)
+    ref, ref_loss = orc.step_grads(ps, cfg, nf, ef, s, r, target, mask0)
+    assert abs(loss - ref_loss) <= TOL_LOSS * abs(ref_loss), (loss, ref_loss)
+    check_grads(gs, ref, cfg)
+    # the forward inside step! is the model: same output as mgn_forward
+    out = eng.forward(nf, ef)
+    assert abs(float(orc.mse_reduce(target, out)[mask0].mean()) - loss) <= 1e-4 * abs(loss)
+
+
+@pytest.mark.parametrize("N,E,seed", [(1, 0, 0), (33, 31, 2), (40, 700, 3), (70, 2049, 5)])
+def test_step_ragged_graphs(N, E, seed):
+    """isolated nodes, self loops, duplicate edges, heavy receivers, no edges at all"""
+    cfg = cfg_dict(mps=2)
+    s, r = synth.random_graph(N, E, seed)
+    ps = make_params(cfg)
+    rng = np.random.default_rng(seed)
+    nf = rng.standard_normal((N, 9)).astype(np.float32)
+    ef = rng.standard_normal((E, 3)).astype(np.float32)
+    target = rng.standard_normal((N, 2)).astype(np.float32)
+    mask = np.arange(0, N, 2, dtype=np.int32)
+    eng = engine_for(cfg)
+    eng.set_params(ps)
+    eng.set_graph(s, r, N)
+    gs, loss = eng.step(nf, ef, target, mask)
+    ref, ref_loss = orc.step_grads(ps, cfg, nf, ef, s, r, target, mask)
+    assert abs(loss - ref_loss) <= TOL_LOSS * max(abs(ref_loss), 1e-6)
+    check_grads(gs, ref, cfg)
+
+
+def test_step_descends_and_tracks_new_params():
+    """A few plain gradient-descent updates through set_params / step: the loss falls, and the gradients follow the
+    parameters that were uploaded last (the training-order weight copy is rebuilt)."""
+    cfg = cfg_dict(L=64, mps=2)
+    pos, s, r = small_mesh(8, 6)
+    ps = make_params(cfg).astype(np.float32)
+    nf, ef, target, mask = problem(cfg, pos, s, r, seed=9)
+    eng = engine_for(cfg)
+    eng.set_graph(s, r, pos.shape[0])
+    losses = []
+    for it in range(6):
+        eng.set_params(ps)
+        gs, loss = eng.step(nf, ef, target, mask)
+        losses.append(loss)
+        if it == 3:
+            ref, _ = orc.step_grads(ps, cfg, nf, ef, s, r, target, mask)
+            check_grads(gs, ref, cfg)
+        ps = ps - 0.01 * gs
+    assert losses[-1] < losses[0], losses
+
+
+def test_step_argument_errors():
+    import mgn_amd
+    cfg = cfg_dict(L=32, mps=1)
+    pos, s, r = small_mesh(5, 4)
+    N = pos.shape[0]
+    eng = engine_for(cfg)
+    eng.set_params(make_params(cfg))
+    eng.set_graph(s, r, N)
+    nf, ef, target, mask = problem(cfg, pos, s, r)
+    with pytest.raises(mgn_amd.MgnError) as ei:
+        eng.step(nf, ef, target, np.array([N], np.int32))            # out of range (0-based)
+    assert ei.value.code == -1
+    with pytest.raises(mgn_amd.MgnError) as ei:
+        eng.step(nf, ef, target, np.array([0], np.int32), mask_index_base=1)
+    assert ei.value.code == -1
+    with pytest.raises(mgn_amd.MgnError) as ei:
+        eng.step(nf, ef, target, np.zeros(0, np.int32))
+    assert ei.value.code == -1
+    bf = mgn_amd.Engine(9, 3, 2, 128, 2, 1, dtype="bf16")
+    bf.set_params(make_params(cfg_dict(mps=1)))
+    bf.set_graph(s, r, N)
+    with pytest.raises(mgn_amd.MgnError) as ei:
+        bf.step(nf, ef, target, mask)
+    assert ei.value.code == -3

@@ -56,6 +56,35 @@ def test_oracle_reproduces_gold_c_two_edge_sets():
     assert rel_max(out0, g["out"]) > 1e-3
 
 
+def test_step_grads_match_finite_differences():
+    """The hand-written reverse mode of the oracle (the checker of mgn_step) against central differences of its own
+    float64 forward: loss = mean(mse_reduce(target, model(graph))[mask]) (reference src/strategies.jl:418-422)."""
+    cfg = dict(Fn=9, Fe=3, O=2, L=32, hidden_layers=2, mps=2)
+    ps = orc.init_params(9, 3, 2, 32, 2, 2, seed=1, ln_jitter=0.1).astype(np.float64)
+    pos, cells = mgn_amd.synth.grid_mesh(5, 4, 3)
+    s, r = mgn_amd.synth.cells_to_edges(cells)
+    N, E = pos.shape[0], s.size
+    rng = np.random.default_rng(0)
+    nf, ef, tgt = rng.standard_normal((N, 9)), rng.standard_normal((E, 3)), rng.standard_normal((N, 2))
+    mask = np.array([0, 3, 4, 7, 11, 12, 12])                     # a node listed twice counts twice, like err[mask]
+    g, loss = orc.step_grads(ps, cfg, nf, ef, s, r, tgt, mask)
+    assert abs(loss - orc.loss_only(ps, cfg, nf, ef, s, r, tgt, mask)) < 1e-12
+    assert g.size == ps.size
+    # one probe in every parameter tensor
+    off = 0
+    for bname, tensors in orc.model_layout(9, 3, 2, 32, 2, 2):
+        for tname, shape in tensors:
+            n = int(np.prod(shape))
+            i = off + int(rng.integers(n))
+            hh = 1e-6
+            p1, p2 = ps.copy(), ps.copy()
+            p1[i] += hh
+            p2[i] -= hh
+            fd = (orc.loss_only(p1, cfg, nf, ef, s, r, tgt, mask) - orc.loss_only(p2, cfg, nf, ef, s, r, tgt, mask)) / (2 * hh)
+            assert abs(fd - g[i]) <= 1e-6 * max(abs(fd), 1.0), (bname, tname, fd, g[i])
+            off += n
+
+
 def test_param_count_matches_survey():
     # SURVEY.md A4: enc-node 34,560; enc-edge 33,792; per step edge 82,560 + node 66,176; decoder 33,282
     assert orc.param_count(9, 3, 2, 128, 2, 15) == 34560 + 33792 + 15 * (82560 + 66176) + 33282
