@@ -198,6 +198,14 @@ int mgn_rollout(mgn_handle* h, mgn_rollout_desc* d);
 int mgn_step(mgn_handle* h, const float* nf, const float* ef, const float* target, const int32_t* mask, int64_t nmask,
              int32_t mask_index_base, float* grads, size_t n_grads, float* loss);
 
+/* Vector-Jacobian product of the right-hand side f = mgn_ode_step (reference ode_step, src/solve.jl:188-219) for the
+ * solver-based training strategies, where the adjoint of `solve` needs lambda^T df/dx and lambda^T df/dps per RHS
+ * evaluation (ZygoteVJP inside the sensitivity algorithm, src/strategies.jl:175-196).  Inputs as mgn_ode_step (raw edge
+ * features, frozen normalisers of mgn_set_norms); lambda [N][O]; outputs xbar [N][O], grads [n_grads] (packed order) and,
+ * when dxdt != NULL, f(x) itself.                                                                                   */
+int mgn_ode_vjp(mgn_handle* h, const float* x, const float* node_type_onehot, const float* ef_raw, const float* val_mask,
+                const float* lambda, float* dxdt, float* xbar, float* grads, size_t n_grads);
+
 /* ---- the benchmarked unit: nsteps processor steps on given latents -------------
  * v [N][L], e [E][L] in caller order, updated in place (host buffers).                          */
 int mgn_processor_steps(mgn_handle* h, float* v, float* e, int32_t nsteps);

@@ -69,6 +69,7 @@ PROTOTYPES = {
     "mgn_edge_features": (C.c_int, [_f32p, C.c_int32, _i32p, _i32p, C.c_int64, C.c_int32, _f32p]),
     "mgn_rollout": (C.c_int, [_H, C.POINTER(MgnRolloutDesc)]),
     "mgn_step": (C.c_int, [_H, _f32p, _f32p, _f32p, _i32p, C.c_int64, C.c_int32, _f32p, C.c_size_t, _f32p]),
+    "mgn_ode_vjp": (C.c_int, [_H, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, C.c_size_t]),
     "mgn_processor_steps": (C.c_int, [_H, _f32p, _f32p, C.c_int32]),
     "mgn_latents_import": (C.c_int, [_H, _f32p, _f32p]),
     "mgn_latents_export": (C.c_int, [_H, _f32p, _f32p]),

@@ -35,7 +35,7 @@ struct TrainState {
     // arena offsets (floats)
     size_t nf_raw, ef_raw, nf_pad, ef_pad, enH[3], V0, eeH[3], E0, Enew, dH[3];
     std::vector<size_t> eH[3], nH[3], Ek, Vk, agg;
-    size_t GT, GXH, GY, GZ2, GZ1, GXs, GXr, gV[2], gE[2], gAgg, Gout, pw, pb;
+    size_t GT, GXH, GY, GZ2, GZ1, GXs, GXr, gV[2], gE[2], gAgg, Gout, gNF, io, pw, pb;
     // idx buffer (int32): egid32 [E], perm_s [E], rowptr_s [N+1]
     size_t i_egid = 0, i_perm = 0, i_rowptr_s = 0;
 };
@@ -103,12 +103,12 @@ int pack_training_weights(mgn_engine* h) {
         t.W3T = block(p + m.W[2], m.out, 0, L, m.out, true);
         t.has_w1t = need_input_grad;
         if (need_input_grad)
-            for (int j = 0; j < t.nin; ++j) t.W1T[j] = block(p + m.W[0], L, j * L, L, L, true);
+            for (int j = 0; j < t.nin; ++j) t.W1T[j] = block(p + m.W[0], L, j * L, t.in_rows, L, true);
         t.tabs = add_tabs(m);
         return t;
     };
     T.mlp.clear();
-    T.mlp.push_back(build(h->enc_node, false));
+    T.mlp.push_back(build(h->enc_node, true));    // input gradient: mgn_ode_vjp (d f / d x)
     T.mlp.push_back(build(h->es[0].enc, false));
     for (int k = 0; k < c.mps; ++k) {
         T.mlp.push_back(build(h->es[0].pe[k], true));
@@ -176,6 +176,8 @@ int prepare_graph(mgn_engine* h) {
     T.gE[0] = take(EL); T.gE[1] = take(EL);
     T.gAgg = take(NL);
     T.Gout = take(NL);
+    T.gNF = take(NL);
+    T.io = take((size_t)(N > 0 ? N : 1) * (2 * h->cfg.O + h->cfg.Fn + 1));
     const int nb = std::max(wgrad_blocks(N), wgrad_blocks(E));
     T.pw = take((size_t)5 * (nb > 0 ? nb : 1) * L * L);             // one partial-dW region per weight-gradient job of an MLP
     T.pb = take((size_t)WGRAD_MAX_JOBS * (nb > 0 ? nb : 1) * L);
@@ -191,31 +193,42 @@ int prepare_graph(mgn_engine* h) {
 
 using namespace mgn;
 
-extern "C" int mgn_step(mgn_handle* h, const float* nf, const float* ef, const float* target, const int32_t* mask, int64_t nmask,
-                        int32_t mask_index_base, float* grads, size_t n_grads, float* loss) {
+namespace {
+
+struct TrainJob {
+    bool vjp = false;
+    // step!: the FeatureGraph as given, target, mask
+    const float* nf = nullptr; const float* ef = nullptr; const float* target = nullptr;
+    const int32_t* mask = nullptr; int64_t nmask = 0; int32_t mask_index_base = 0;
+    float* loss = nullptr;
+    // vjp of the RHS: raw inputs of mgn_ode_step (ef = raw edge features), cotangent lambda
+    const float* x = nullptr; const float* onehot = nullptr; const float* val_mask = nullptr; const float* lambda = nullptr;
+    float* dxdt = nullptr; float* xbar = nullptr;
+    float* grads = nullptr;
+};
+
+int train_prepare(mgn_handle* h, const char* who, size_t n_grads) {
     if (int rc = need(h, true, true)) return rc;
     const mgn_config& c = h->cfg;
-    if (c.nranks != 1) return fail(h, MGN_E_STATE, "mgn_step drives one partition");
-    if (h->nsets != 1) return fail(h, MGN_E_STATE, "mgn_step mirrors the reference's single-edge-set step! (src/strategies.jl:418-422)");
-    if (c.dtype != MGN_F32) return fail(h, MGN_E_STATE, "mgn_step computes in fp32: create the handle with dtype MGN_F32");
-    if (!nf || !target || !mask || !grads || !loss || (!ef && h->g.set[0].E > 0)) return fail(h, MGN_E_ARG, "mgn_step: null argument");
-    if (nmask < 1) return fail(h, MGN_E_ARG, "mgn_step: empty mask");
-    if (n_grads != h->params.size()) return fail(h, MGN_E_ARG, "mgn_step: grads has %zu floats, model has %zu", n_grads, h->params.size());
-    if (mask_index_base != 0 && mask_index_base != 1) return fail(h, MGN_E_ARG, "mgn_step: mask_index_base must be 0 or 1");
-    const LocalGraph& g = h->g;
-    const int64_t N = g.n_own, E = g.set[0].e_local;
-    for (int64_t i = 0; i < nmask; ++i) {
-        const int64_t n = (int64_t)mask[i] - mask_index_base;
-        if (n < 0 || n >= N) return fail(h, MGN_E_ARG, "mgn_step: mask entry %lld out of range", (long long)i);
-    }
+    if (c.nranks != 1) return fail(h, MGN_E_STATE, "%s drives one partition", who);
+    if (h->nsets != 1) return fail(h, MGN_E_STATE, "%s mirrors the reference's single-edge-set model (src/strategies.jl:418-422)", who);
+    if (c.dtype != MGN_F32) return fail(h, MGN_E_STATE, "%s computes in fp32: create the handle with dtype MGN_F32", who);
+    if (n_grads != h->params.size()) return fail(h, MGN_E_ARG, "%s: grads has %zu floats, model has %zu", who, n_grads, h->params.size());
     if (!h->train) h->train = new (std::nothrow) TrainState();
     if (!h->train) return fail(h, MGN_E_OOM, "host allocation failed");
-    TrainState& T = *h->train;
-    if (!T.packed)
+    if (!h->train->packed)
         if (int rc = pack_training_weights(h)) return rc;
-    if (!T.graph_ready)
+    if (!h->train->graph_ready)
         if (int rc = prepare_graph(h)) return rc;
+    return MGN_OK;
+}
 
+// forward with kept activations, seed, reverse pass, all parameter gradients (+ the input gradient for the VJP)
+int train_run(mgn_handle* h, const TrainJob& J) {
+    const mgn_config& c = h->cfg;
+    TrainState& T = *h->train;
+    const LocalGraph& g = h->g;
+    const int64_t N = g.n_own, E = g.set[0].e_local;
     const int L = c.L, mps = c.mps, O = c.O;
     hipStream_t st = h->stream;
     float* A = T.arena.as<float>();
@@ -230,16 +243,33 @@ extern "C" int mgn_step(mgn_handle* h, const float* nf, const float* ef, const f
     float* G = T.grads.as<float>();
 
     // ---- inputs
+    const float* nrm = h->norms.as<float>();   // [node scale, shift (Fn) | edge scale, shift (Fe) | out scale, shift (O)]
     HIPCHK(h, hipMemsetAsync(G, 0, h->params.size() * 4, st));
-    HIPCHK(h, hipMemcpyAsync(A + T.nf_raw, nf, (size_t)N * c.Fn * 4, hipMemcpyHostToDevice, st));
-    HIPCHK(h, launch_pad_rows(A + T.nf_raw, c.Fn, A + T.nf_pad, L, N, st));
-    if (E > 0) {
-        HIPCHK(h, hipMemcpyAsync(A + T.ef_raw, ef, (size_t)E * c.Fe * 4, hipMemcpyHostToDevice, st));
-        HIPCHK(h, launch_pad_rows(A + T.ef_raw, c.Fe, A + T.ef_pad, L, E, st));
+    if (!J.vjp) {
+        HIPCHK(h, hipMemcpyAsync(A + T.nf_raw, J.nf, (size_t)N * c.Fn * 4, hipMemcpyHostToDevice, st));
+        HIPCHK(h, launch_affine_pad(A + T.nf_raw, c.Fn, nullptr, 0, nullptr, nullptr, A + T.nf_pad, L, N, st));
+        if (E > 0) {
+            HIPCHK(h, hipMemcpyAsync(A + T.ef_raw, J.ef, (size_t)E * c.Fe * 4, hipMemcpyHostToDevice, st));
+            HIPCHK(h, launch_affine_pad(A + T.ef_raw, c.Fe, nullptr, 0, nullptr, nullptr, A + T.ef_pad, L, E, st));
+        }
+        HIPCHK(h, hipMemcpyAsync(T.target.p, J.target, (size_t)N * O * 4, hipMemcpyHostToDevice, st));
+        HIPCHK(h, T.mask.ensure((size_t)J.nmask * 4));
+        HIPCHK(h, hipMemcpyAsync(T.mask.p, J.mask, (size_t)J.nmask * 4, hipMemcpyHostToDevice, st));
+    } else {
+        // RHS inputs exactly as mgn_ode_step takes them: nf = [n_norm(x); n_norm(onehot)], ef = e_norm(ef_raw)
+        float* io = A + T.io;                  // x [N][O] | lambda [N][O] | onehot [N][Fn-O] | val_mask [N]
+        HIPCHK(h, hipMemcpyAsync(io, J.x, (size_t)N * O * 4, hipMemcpyHostToDevice, st));
+        HIPCHK(h, hipMemcpyAsync(io + (size_t)N * O, J.lambda, (size_t)N * O * 4, hipMemcpyHostToDevice, st));
+        if (c.Fn > O) HIPCHK(h, hipMemcpyAsync(io + (size_t)2 * N * O, J.onehot, (size_t)N * (c.Fn - O) * 4, hipMemcpyHostToDevice, st));
+        if (J.val_mask) HIPCHK(h, hipMemcpyAsync(io + (size_t)N * (O + c.Fn), J.val_mask, (size_t)N * 4, hipMemcpyHostToDevice, st));
+        HIPCHK(h, launch_affine_pad(io, O, io + (size_t)2 * N * O, c.Fn - O, h->have_nnorm ? nrm : nullptr, h->have_nnorm ? nrm + c.Fn : nullptr,
+                                    A + T.nf_pad, L, N, st));
+        if (E > 0) {
+            HIPCHK(h, hipMemcpyAsync(A + T.ef_raw, J.ef, (size_t)E * c.Fe * 4, hipMemcpyHostToDevice, st));
+            HIPCHK(h, launch_affine_pad(A + T.ef_raw, c.Fe, nullptr, 0, h->have_enorm ? nrm + 2 * c.Fn : nullptr,
+                                        h->have_enorm ? nrm + 2 * c.Fn + c.Fe : nullptr, A + T.ef_pad, L, E, st));
+        }
     }
-    HIPCHK(h, hipMemcpyAsync(T.target.p, target, (size_t)N * O * 4, hipMemcpyHostToDevice, st));
-    HIPCHK(h, T.mask.ensure((size_t)nmask * 4));
-    HIPCHK(h, hipMemcpyAsync(T.mask.p, mask, (size_t)nmask * 4, hipMemcpyHostToDevice, st));
 
     auto fwd = [&](const TrainMlp& m, int64_t rows, int32_t ntiles, const float* x0, const int32_t* i0, const float* x1, const int32_t* i1,
                    const float* x2, const int32_t* i2, size_t h1, size_t h2, size_t y, const float* resid, float* out, float* lnout) {
@@ -272,11 +302,19 @@ extern "C" int mgn_step(mgn_handle* h, const float* nf, const float* ef, const f
     }
     HIPCHK(h, fwd(m_de, N, nt_n, A + T.Vk[mps], nullptr, nullptr, nullptr, nullptr, nullptr, T.dH[0], T.dH[1], T.dH[2], nullptr, nullptr, nullptr));
 
-    // ---- loss = mean(mse_reduce(target, out)[mask]) and its gradient w.r.t. out
-    const int nlb = loss_blocks(nmask);
-    HIPCHK(h, T.loss.ensure((size_t)nlb * sizeof(double)));
+    // ---- seed of the reverse pass
+    const int nlb = J.vjp ? 0 : loss_blocks(J.nmask);
     HIPCHK(h, hipMemsetAsync(A + T.Gout, 0, (size_t)N * L * 4, st));
-    HIPCHK(h, launch_loss(A + T.dH[2], L, T.target.as<float>(), O, T.mask.as<int32_t>(), nmask, mask_index_base, A + T.Gout, T.loss.as<double>(), st));
+    if (!J.vjp) {   // loss = mean(mse_reduce(target, out)[mask]) and its gradient w.r.t. out
+        HIPCHK(h, T.loss.ensure((size_t)nlb * sizeof(double)));
+        HIPCHK(h, launch_loss(A + T.dH[2], L, T.target.as<float>(), O, T.mask.as<int32_t>(), J.nmask, J.mask_index_base, A + T.Gout,
+                              T.loss.as<double>(), st));
+    } else {        // dx/dt = inverse_data(o_norm, out) .* val_mask  =>  d/d out = lambda .* val_mask .* out_scale
+        const float* os = h->have_onorm ? nrm + 2 * c.Fn + 2 * c.Fe : nullptr;
+        const float* vm = J.val_mask ? A + T.io + (size_t)N * (O + c.Fn) : nullptr;
+        HIPCHK(h, launch_vjp_seed(A + T.dH[2], L, O, A + T.io + (size_t)N * O, vm, os, os ? os + O : nullptr, A + T.Gout,
+                                  J.dxdt ? T.target.as<float>() : nullptr, N, st));
+    }
 
     // ---- backward
     // activation backward of one MLP + all of its parameter gradients
@@ -364,11 +402,12 @@ extern "C" int mgn_step(mgn_handle* h, const float* nf, const float* ef, const f
         ecur = enxt;
     }
     {
+        float* gx_n[3] = {J.vjp ? A + T.gNF : nullptr, nullptr, nullptr};
         float* gx[3] = {nullptr, nullptr, nullptr};
         const float* gxadd[3] = {nullptr, nullptr, nullptr};
         const float* xin[3] = {A + T.nf_pad, nullptr, nullptr};
         const int32_t* xi[3] = {nullptr, nullptr, nullptr};
-        if (int rc = bwd(m_en, N, nt_n, A + T.gV[cur], nullptr, nullptr, T.enH[0], T.enH[1], T.enH[2], gx, gxadd, xin, xi)) return rc;
+        if (int rc = bwd(m_en, N, nt_n, A + T.gV[cur], nullptr, nullptr, T.enH[0], T.enH[1], T.enH[2], gx_n, gxadd, xin, xi)) return rc;
         const float* xin_e[3] = {A + T.ef_pad, nullptr, nullptr};
         const int32_t* xi_e[3] = {egid, nullptr, nullptr};
         if (int rc = bwd(m_ee, E, nt_e, A + T.gE[ecur], nullptr, nullptr, T.eeH[0], T.eeH[1], T.eeH[2], gx, gxadd, xin_e, xi_e)) return rc;
@@ -376,11 +415,56 @@ extern "C" int mgn_step(mgn_handle* h, const float* nf, const float* ef, const f
 
     // ---- results
     std::vector<double> lp((size_t)nlb);
-    HIPCHK(h, hipMemcpyAsync(grads, G, h->params.size() * 4, hipMemcpyDeviceToHost, st));
-    HIPCHK(h, hipMemcpyAsync(lp.data(), T.loss.p, lp.size() * sizeof(double), hipMemcpyDeviceToHost, st));
+    HIPCHK(h, hipMemcpyAsync(J.grads, G, h->params.size() * 4, hipMemcpyDeviceToHost, st));
+    if (!J.vjp) {
+        HIPCHK(h, hipMemcpyAsync(lp.data(), T.loss.p, lp.size() * sizeof(double), hipMemcpyDeviceToHost, st));
+    } else {
+        // x enters through the node normaliser: xbar = (d / d nf)[:, 0:O] .* node_scale[0:O]
+        HIPCHK(h, launch_extract_cols(A + T.gNF, L, O, h->have_nnorm ? nrm : nullptr, A + T.io, N, st));
+        HIPCHK(h, hipMemcpyAsync(J.xbar, A + T.io, (size_t)N * O * 4, hipMemcpyDeviceToHost, st));
+        if (J.dxdt) HIPCHK(h, hipMemcpyAsync(J.dxdt, T.target.p, (size_t)N * O * 4, hipMemcpyDeviceToHost, st));
+    }
     HIPCHK(h, hipStreamSynchronize(st));
-    double s = 0.0;
-    for (double v : lp) s += v;
-    *loss = (float)(s / (double)nmask);
+    if (!J.vjp) {
+        double s = 0.0;
+        for (double v : lp) s += v;
+        *J.loss = (float)(s / (double)J.nmask);
+    }
     return MGN_OK;
+}
+
+
+}  // namespace
+
+extern "C" int mgn_step(mgn_handle* h, const float* nf, const float* ef, const float* target, const int32_t* mask, int64_t nmask,
+                        int32_t mask_index_base, float* grads, size_t n_grads, float* loss) {
+    if (!h) return MGN_E_ARG;
+    if (!nf || !target || !mask || !grads || !loss) return fail(h, MGN_E_ARG, "mgn_step: null argument");
+    if (int rc = train_prepare(h, "mgn_step", n_grads)) return rc;
+    if (!ef && h->g.set[0].E > 0) return fail(h, MGN_E_ARG, "mgn_step: null argument");
+    if (nmask < 1) return fail(h, MGN_E_ARG, "mgn_step: empty mask");
+    if (mask_index_base != 0 && mask_index_base != 1) return fail(h, MGN_E_ARG, "mgn_step: mask_index_base must be 0 or 1");
+    for (int64_t i = 0; i < nmask; ++i) {
+        const int64_t n = (int64_t)mask[i] - mask_index_base;
+        if (n < 0 || n >= h->g.n_own) return fail(h, MGN_E_ARG, "mgn_step: mask entry %lld out of range", (long long)i);
+    }
+    TrainJob J;
+    J.nf = nf; J.ef = ef; J.target = target; J.mask = mask; J.nmask = nmask; J.mask_index_base = mask_index_base;
+    J.loss = loss; J.grads = grads;
+    return train_run(h, J);
+}
+
+extern "C" int mgn_ode_vjp(mgn_handle* h, const float* x, const float* node_type_onehot, const float* ef_raw, const float* val_mask,
+                           const float* lambda, float* dxdt, float* xbar, float* grads, size_t n_grads) {
+    if (!h) return MGN_E_ARG;
+    if (!x || !lambda || !xbar || !grads) return fail(h, MGN_E_ARG, "mgn_ode_vjp: null argument");
+    if (int rc = train_prepare(h, "mgn_ode_vjp", n_grads)) return rc;
+    const mgn_config& c = h->cfg;
+    if (c.Fn < c.O) return fail(h, MGN_E_ARG, "mgn_ode_vjp: Fn < O");
+    if ((c.Fn > c.O && !node_type_onehot) || (!ef_raw && h->g.set[0].E > 0)) return fail(h, MGN_E_ARG, "mgn_ode_vjp: null argument");
+    TrainJob J;
+    J.vjp = true;
+    J.x = x; J.onehot = node_type_onehot; J.ef = ef_raw; J.val_mask = val_mask; J.lambda = lambda;
+    J.dxdt = dxdt; J.xbar = xbar; J.grads = grads;
+    return train_run(h, J);
 }

@@ -56,8 +56,14 @@ hipError_t launch_reduce_partials(const ReduceBatch& rb, hipStream_t s);
 // out[n] = (add ? add[n] : 0) + sum_{p in [rowptr[n], rowptr[n+1])} src[perm ? perm[p] : p]   (rows of L floats)
 hipError_t launch_segment_sum(int L, const float* src, const int32_t* rowptr, const int32_t* perm, const float* add, float* out,
                               int32_t n, hipStream_t s);
-// dst [rows][L] = [src[rows][F] | 0]
-hipError_t launch_pad_rows(const float* src, int F, float* dst, int L, int64_t rows, hipStream_t s);
+// dst [rows][L] = [ (srcA | srcB)[rows][wa + wb] * scale + shift | 0 ]   (srcB may be null with wb = 0; scale null: identity)
+hipError_t launch_affine_pad(const float* srcA, int wa, const float* srcB, int wb, const float* scale, const float* shift, float* dst, int L,
+                             int64_t rows, hipStream_t s);
+// seed of the RHS VJP (mgn_ode_vjp): G[n][o] = lambda[n][o] * val_mask[n] * os[o]; optionally dxdt = (Y * os + osh) .* val_mask
+hipError_t launch_vjp_seed(const float* Y, int L, int O, const float* lambda, const float* vm, const float* os, const float* osh, float* G,
+                           float* dxdt, int64_t N, hipStream_t s);
+// dst [N][O] = src[N][L][:, 0:O] .* scale
+hipError_t launch_extract_cols(const float* src, int L, int O, const float* scale, float* dst, int64_t N, hipStream_t s);
 // masked MSE: loss_partial[b] = sum over this block's mask entries of sum_o (out - target)^2;
 // G[n][o] += 2 (out[n][o] - target[n][o]) / nmask   (G [N][L] zeroed by the caller; out = first O columns of Y)
 int loss_blocks(int64_t nmask);

@@ -261,12 +261,40 @@ __global__ void k_segment_sum(const float* __restrict__ src, const int32_t* __re
     reinterpret_cast<f32x4*>(out)[i] = s;
 }
 
-__global__ void k_pad_rows(const float* __restrict__ src, int F, float* __restrict__ dst, int L, int64_t rows) {
+// dst [rows][L] = [ (srcA | srcB)[rows][wa + wb] * scale + shift | 0 ]   (scale == null: identity)
+__global__ void k_affine_pad(const float* __restrict__ srcA, int wa, const float* __restrict__ srcB, int wb, const float* __restrict__ scale,
+                             const float* __restrict__ shift, float* __restrict__ dst, int L, int64_t rows) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= rows * L) return;
     const int64_t r = i / L;
     const int f = (int)(i - r * L);
-    dst[i] = f < F ? src[r * F + f] : 0.f;
+    float v = 0.f;
+    if (f < wa + wb) {
+        v = f < wa ? srcA[r * wa + f] : srcB[r * wb + (f - wa)];
+        if (scale) v = v * scale[f] + shift[f];
+    }
+    dst[i] = v;
+}
+
+// seed of the RHS VJP: dx/dt = (out * os + osh) .* val_mask  =>  G[n][o] = lambda[n][o] * val_mask[n] * os[o]
+__global__ void k_vjp_seed(const float* __restrict__ Y, int L, int O, const float* __restrict__ lambda, const float* __restrict__ vm,
+                           const float* __restrict__ os, const float* __restrict__ osh, float* __restrict__ G, float* __restrict__ dxdt,
+                           int64_t N) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N * O) return;
+    const int64_t n = i / O;
+    const int o = (int)(i - n * O);
+    const float m = vm ? vm[n] : 1.f, sc = os ? os[o] : 1.f, sh = osh ? osh[o] : 0.f;
+    G[n * L + o] = lambda[i] * m * sc;
+    if (dxdt) dxdt[i] = (Y[n * L + o] * sc + sh) * m;
+}
+
+__global__ void k_extract_cols(const float* __restrict__ src, int L, int O, const float* __restrict__ scale, float* __restrict__ dst, int64_t N) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N * O) return;
+    const int64_t n = i / O;
+    const int o = (int)(i - n * O);
+    dst[i] = src[n * L + o] * (scale ? scale[o] : 1.f);
 }
 
 __global__ void k_loss(const float* __restrict__ Y, int L, const float* __restrict__ target, int O, const int32_t* __restrict__ mask,
@@ -357,10 +385,26 @@ hipError_t launch_segment_sum(int L, const float* src, const int32_t* rowptr, co
     return hipGetLastError();
 }
 
-hipError_t launch_pad_rows(const float* src, int F, float* dst, int L, int64_t rows, hipStream_t s) {
+hipError_t launch_affine_pad(const float* srcA, int wa, const float* srcB, int wb, const float* scale, const float* shift, float* dst, int L,
+                             int64_t rows, hipStream_t s) {
     const int64_t tot = rows * L;
     if (tot <= 0) return hipSuccess;
-    hipLaunchKernelGGL(k_pad_rows, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, src, F, dst, L, rows);
+    hipLaunchKernelGGL(k_affine_pad, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, srcA, wa, srcB, wb, scale, shift, dst, L, rows);
+    return hipGetLastError();
+}
+
+hipError_t launch_vjp_seed(const float* Y, int L, int O, const float* lambda, const float* vm, const float* os, const float* osh, float* G,
+                           float* dxdt, int64_t N, hipStream_t s) {
+    const int64_t tot = N * O;
+    if (tot <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_vjp_seed, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, Y, L, O, lambda, vm, os, osh, G, dxdt, N);
+    return hipGetLastError();
+}
+
+hipError_t launch_extract_cols(const float* src, int L, int O, const float* scale, float* dst, int64_t N, hipStream_t s) {
+    const int64_t tot = N * O;
+    if (tot <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_extract_cols, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, src, L, O, scale, dst, N);
     return hipGetLastError();
 }
 

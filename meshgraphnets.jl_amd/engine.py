@@ -266,6 +266,21 @@ class Engine:
                                     C.byref(loss)))
         return gs, loss.value
 
+    def ode_vjp(self, x, node_type_onehot, ef_raw, lam, val_mask=None, want_dxdt=False):
+        """lambda^T df/dx and lambda^T df/dps of the RHS f = ode_step (solver-based training, src/strategies.jl:175-196).
+        Returns (xbar [N][O], gs [packed], dxdt or None)."""
+        O, Fn = self.cfg.O, self.cfg.Fn
+        x = _c32(x, (self.N, O))
+        lam = _c32(lam, (self.N, O))
+        oh = _c32(node_type_onehot, (self.N, Fn - O)) if Fn > O else None
+        ef = _c32(ef_raw, (self.E, self.cfg.Fe))
+        vm = _c32(val_mask, (self.N,)) if val_mask is not None else None
+        xbar = np.zeros((self.N, O), np.float32)
+        gs = np.zeros(self.param_count, np.float32)
+        dxdt = np.zeros((self.N, O), np.float32) if want_dxdt else None
+        self._chk(self.lib.mgn_ode_vjp(self.h, f32(x), f32(oh), f32(ef), f32(vm), f32(lam), f32(dxdt), f32(xbar), f32(gs), gs.size))
+        return xbar, gs, dxdt
+
     def processor_steps(self, v, e, nsteps):
         v = _c32(v, (self.N, self.cfg.L)).copy()
         e = _c32(e, (self.E, self.cfg.L)).copy()

@@ -333,15 +333,14 @@ def _mlp_bwd(g, cache, p, h):
     return g, gp
 
 
-def step_grads(packed, cfg, nf, ef, senders, receivers, target, mask):
-    """(gs, loss) of step!: loss = mean(mse_reduce(target, model(graph))[mask]); gs = d loss / d ps in packed order.
-    mask: integer node indices (0-based here; Int32 1-based at the Julia boundary, src/MeshGraphNets.jl:352)."""
+def model_vjp(packed, cfg, nf, ef, senders, receivers, seed, dtype=np.float64):
+    """Reverse pass through model(graph): seed(out) -> cotangent of out.  Returns (out, packed parameter gradient,
+    cotangent of nf)."""
     h = cfg["hidden_layers"]
-    P = _unpack(packed, cfg, np.float64)
+    P = _unpack(packed, cfg, dtype)
     if cfg.get("Fe2"):
-        raise NotImplementedError("step_grads: single edge set (the reference's FeatureGraph)")
-    nf, ef, target = np.asarray(nf, np.float64), np.asarray(ef, np.float64), np.asarray(target, np.float64)
-    mask = np.asarray(mask).reshape(-1)
+        raise NotImplementedError("model_vjp: single edge set (the reference's FeatureGraph)")
+    nf, ef = np.asarray(nf, dtype), np.asarray(ef, dtype)
     N = nf.shape[0]
     v, c_en = _mlp_fwd(nf, P["enc_node"], h)
     e, c_ee = _mlp_fwd(ef, P["enc_edge"], h)
@@ -353,13 +352,9 @@ def step_grads(packed, cfg, nf, ef, senders, receivers, target, mask):
         caches.append((c_e, c_v))
         v, e = v + v_new, e + e_new
     out, c_d = _mlp_fwd(v, P["decoder"], h)
-    err = mse_reduce(target, out)
-    loss = err[mask].mean()
 
     G = {}
-    g_out = np.zeros_like(out)
-    np.add.at(g_out, mask, 2.0 * (out[mask] - target[mask]) / mask.size)
-    gv, G["decoder"] = _mlp_bwd(g_out, c_d, P["decoder"], h)
+    gv, G["decoder"] = _mlp_bwd(seed(out), c_d, P["decoder"], h)
     ge = np.zeros_like(e)
     L = cfg["L"]
     for k in range(cfg["mps"] - 1, -1, -1):
@@ -371,14 +366,44 @@ def step_grads(packed, cfg, nf, ef, senders, receivers, target, mask):
         np.add.at(gv, senders, g_cat[:, :L])
         np.add.at(gv, receivers, g_cat[:, L:2 * L])
         ge = ge + g_cat[:, 2 * L:]
-    _, G["enc_node"] = _mlp_bwd(gv, c_en, P["enc_node"], h)
+    g_nf, G["enc_node"] = _mlp_bwd(gv, c_en, P["enc_node"], h)
     _, G["enc_edge"] = _mlp_bwd(ge, c_ee, P["enc_edge"], h)
     chunks = []
     for bname, tensors in model_layout(cfg["Fn"], cfg["Fe"], cfg["O"], cfg["L"], h, cfg["mps"]):
         for tname, shape in tensors:
             assert G[bname][tname].shape == tuple(shape)
             chunks.append(G[bname][tname].ravel())
-    return np.concatenate(chunks), float(loss)
+    return out, np.concatenate(chunks), g_nf
+
+
+def step_grads(packed, cfg, nf, ef, senders, receivers, target, mask):
+    """(gs, loss) of step!: loss = mean(mse_reduce(target, model(graph))[mask]); gs = d loss / d ps in packed order.
+    mask: integer node indices (0-based here; Int32 1-based at the Julia boundary, src/MeshGraphNets.jl:352)."""
+    target = np.asarray(target, np.float64)
+    mask = np.asarray(mask).reshape(-1)
+
+    def seed(out):
+        g_out = np.zeros_like(out)
+        np.add.at(g_out, mask, 2.0 * (out[mask] - target[mask]) / mask.size)
+        return g_out
+
+    out, gs, _ = model_vjp(packed, cfg, nf, ef, senders, receivers, seed)
+    return gs, float(mse_reduce(target, out)[mask].mean())
+
+
+def ode_vjp(packed, cfg, x, node_type_onehot, ef_raw, senders, receivers, n_norm_fields, n_norm_type, e_norm, o_norm, val_mask, lam):
+    """Vector-Jacobian product of the RHS f = ode_rhs (no inflow overwrite) for solver-based training
+    (src/strategies.jl:175-196): returns (lambda^T df/dx, lambda^T df/dps, f(x)).  Normalisers must be affine
+    (frozen), given as objects with .affine(dim) -> (scale, shift)."""
+    x = np.asarray(x, np.float64)
+    O = x.shape[1]
+    nf = np.concatenate([n_norm_fields(x), n_norm_type(node_type_onehot)], 1)
+    ef = e_norm(ef_raw)
+    vm = np.asarray(val_mask, np.float64).reshape(-1, 1)
+    o_scale = np.broadcast_to(o_norm.std, (O,))            # inverse_data: out * std + mean
+    out, gs, g_nf = model_vjp(packed, cfg, nf, ef, senders, receivers, lambda out: np.asarray(lam, np.float64) * vm * o_scale)
+    n_scale, _ = n_norm_fields.affine(O)
+    return g_nf[:, :O] * n_scale, gs, o_norm.inverse(out) * vm
 
 
 def loss_only(packed, cfg, nf, ef, senders, receivers, target, mask):

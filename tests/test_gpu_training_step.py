@@ -143,3 +143,51 @@ def test_step_argument_errors():
     with pytest.raises(mgn_amd.MgnError) as ei:
         bf.step(nf, ef, target, mask)
     assert ei.value.code == -3
+
+
+def test_ode_vjp_matches_oracle_and_ode_step():
+    """mgn_ode_vjp: lambda^T df/dx, lambda^T df/dps of the RHS the solver-based strategies differentiate
+    (src/strategies.jl:175-196), with frozen normalisers and val_mask like mgn_ode_step."""
+    cfg = cfg_dict(mps=3)
+    pos, cells, node_type, vel = synth.mesh_cyl(1234, 300)
+    s, r = synth.cells_to_edges(cells)
+    N, E = pos.shape[0], s.size
+    ps = make_params(cfg)
+    rng = np.random.default_rng(4)
+    onehot = orc.one_hot(node_type, 7, 0).astype(np.float32)
+    ef_raw = orc.edge_features(pos, s, r).astype(np.float32)
+    x = vel.astype(np.float32)
+    lam = rng.standard_normal((N, 2)).astype(np.float32)
+    n_norm = orc.NormMeanStd(np.array([1.0, 0.1]), np.array([0.4, 0.2]))
+    t_norm = orc.NormMinMax(0.0, 1.0)
+    e_norm = orc.NormMeanStd(ef_raw.mean(0), ef_raw.std(0))
+    o_norm = orc.NormMeanStd(np.array([0.01, -0.02]), np.array([0.5, 0.4]))
+    vm = np.isin(node_type, [0, 5]).astype(np.float32)
+    ns, nsh = n_norm.affine(2)
+    ts, tsh = t_norm.affine(7)
+    es, esh = e_norm.affine(3)
+    eng = engine_for(cfg)
+    eng.set_params(ps)
+    eng.set_graph(s, r, N)
+    eng.set_norms(node=(np.concatenate([ns, ts]), np.concatenate([nsh, tsh])), edge=(es, esh), out=(o_norm.std, o_norm.mean))
+    xbar, gs, dxdt = eng.ode_vjp(x, onehot, ef_raw, lam, val_mask=vm, want_dxdt=True)
+    rx, rg, rf = orc.ode_vjp(ps, cfg, x, onehot, ef_raw, s, r, n_norm, t_norm, e_norm, o_norm, vm, lam)
+    assert rel_max(dxdt, rf) <= 1e-4
+    assert np.array_equal(dxdt, eng.ode_step(x, onehot, ef_raw, vm)) or rel_max(dxdt, eng.ode_step(x, onehot, ef_raw, vm)) <= 1e-5
+    # ReLU kinks: with ~1e6 hidden units per evaluation about one pre-activation lies within fp32 rounding of zero, and
+    # the engine's summation order may put it on the other side than the oracle's -- the derivative through that ONE
+    # unit then differs (seen here: one edge-MLP unit, both end nodes of that edge off by 3 %, everything else 1e-6).
+    # Hence a robust criterion: all but 2 % of the rows within TOL_GRAD, and a small relative L2 error overall.
+    row_err = np.abs(xbar - rx).max(1) / np.abs(rx).max()
+    assert np.quantile(row_err, 0.98) <= TOL_GRAD, np.quantile(row_err, 0.98)
+    assert np.linalg.norm(xbar - rx) <= 5e-3 * np.linalg.norm(rx)
+    assert np.linalg.norm(gs - rg) <= 5e-3 * np.linalg.norm(rg)
+    check_grads(gs, rg, cfg, tol=2e-2)
+    # coarse self-consistency with the engine's own RHS (sign and scale): <lambda, f(x + eps d) - f(x - eps d)> / 2 eps vs
+    # <xbar, d>.  f is strongly nonlinear (the float64 oracle needs eps <= 1e-4 for 1 %) and fp32 forbids a smaller eps.
+    d = rng.standard_normal((N, 2)).astype(np.float32)
+    eps = 1e-3
+    fd = float((lam.astype(np.float64) * (eng.ode_step(x + eps * d, onehot, ef_raw, vm).astype(np.float64)
+                                          - eng.ode_step(x - eps * d, onehot, ef_raw, vm))).sum() / (2 * eps))
+    an = float((xbar.astype(np.float64) * d).sum())
+    assert abs(fd - an) <= 0.2 * abs(an), (fd, an)
