@@ -131,8 +131,8 @@ def time_single(eng, steps, warmup, sync):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)   # >= 20 timed runs after >= 5 warm-ups
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--nx", type=int, default=1000, help="M-1M grid side (default 1000 -> 1M nodes)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
@@ -180,7 +180,9 @@ def main():
     if staged:   # RCCL collectives and the engine must share torch's stream; alone the engine keeps its own stream
         eng.set_stream(torch.cuda.current_stream().cuda_stream)
     eng.set_params(ps)
-    eng.set_graph(s, r, N, mesh_pos=pos)
+    t_setup = time.perf_counter()
+    eng.set_graph(s, r, N, mesh_pos=pos)     # unsorted COO in: receiver sort / CSR / partition / halo lists are amortised here
+    t_setup = time.perf_counter() - t_setup
     eng.latents_randn(1234)
 
     if not staged:
@@ -254,6 +256,7 @@ def main():
                     "note": "SURVEY.md 8(d) un-factored GEMM flops (163 840 E + 131 072 N) / wall time per step"},
             },
             "latents_finite": bool(finite),
+            "graph_setup_s": t_setup,   # once per trajectory (mgn_set_graph: sort by receiver, CSR, partition, upload), not in `value`
         }
         if args.dtype == "bf16":
             # bf16: MFMA is 16x faster, the step sits at the HBM/MFMA ridge: report the HBM fraction too
@@ -317,6 +320,23 @@ def main():
             out["secondary"]["rollout_100_saves"] = {"workload": "cfg-5 shaped: M-cyl, t in [0,1], saveat 0:0.01:1, random-init weights "
                                                      "(BASELINE.json configs[4]); native driver, host in/out included", **roll}
             eng2.close()
+            # N2: one training step (step!: forward with kept activations, backward, all gradients) on the same datapoint
+            engt = mgn_amd.Engine(FN, FE, O, L, 2, MPS, device=local_rank)
+            engt.set_params(ps)
+            engt.set_graph(s2, r2, pos2.shape[0])
+            rngt = np.random.default_rng(0)
+            nft = rngt.standard_normal((pos2.shape[0], FN)).astype(np.float32)
+            eft = rngt.standard_normal((s2.size, FE)).astype(np.float32)
+            tgt = rngt.standard_normal((pos2.shape[0], O)).astype(np.float32)
+            maskt = np.nonzero(np.isin(ntype5, [0, 5]))[0].astype(np.int32)
+            engt.step(nft, eft, tgt, maskt)
+            t0 = time.perf_counter()
+            for _ in range(10):
+                _, loss_t = engt.step(nft, eft, tgt, maskt)
+            dtt = (time.perf_counter() - t0) / 10
+            out["secondary"]["train_step"] = {"workload": "mgn_step == step! (src/strategies.jl:418-422) on the M-cyl datapoint, L=128, 15 steps, fp32; "
+                                                          "host in/out included", "ms_per_step": dtt * 1e3, "loss_finite": bool(np.isfinite(loss_t))}
+            engt.close()
             # cfg-3: flag_simple-shaped cloth, mesh + world edges (two edge sets), 15 steps, bf16 (and fp32 beside it)
             mf = mgn_amd.synth.mesh_flag()
             Nf, Ef, Ef2 = mf["mesh_pos"].shape[0], mf["s"].size, mf["s2"].size
