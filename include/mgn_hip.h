@@ -245,6 +245,24 @@ int mgn_halo_unpack(mgn_handle* h, const void* recv_dev); /* device buffer, sum(
 int mgn_profile_enable(mgn_handle* h, int32_t on);
 int mgn_profile_read(mgn_handle* h, double ms_avg[8], int64_t counts[8]);
 
+/* ---- data formats: host code, no handle -------------------------------------------
+ * TFRecord framing + tf.train.Example decoding of the DeepMind MeshGraphNets datasets, as the reference reads them
+ * through TFRecord.jl (read(path; channel_size) at src/dataset.jl:107-112; one Example per trajectory, consumed by
+ * parse_data src/dataset.jl:61-75).  mgn_tfrecord_next: 1 = a record is loaded, 0 = end of file, < 0 = error
+ * (CRC mismatch, truncation, malformed protobuf; text from mgn_tfrecord_error).  mgn_tfrecord_feature hands out the
+ * payload of feature `key` of the current record: kind 1 = bytes_list (first value, what parse_data reinterprets by
+ * meta.json's dtype), 2 = float_list (float32 array), 3 = int64_list (int64 array); the pointer stays valid until the
+ * next mgn_tfrecord_next / close.  Unknown key -> MGN_E_ARG (KeyError on the Julia side).                        */
+typedef struct mgn_tfrecord mgn_tfrecord;
+int mgn_tfrecord_open(const char* path, int32_t verify_crc, mgn_tfrecord** out);
+int mgn_tfrecord_next(mgn_tfrecord* r);
+int mgn_tfrecord_feature_count(const mgn_tfrecord* r);
+const char* mgn_tfrecord_feature_name(const mgn_tfrecord* r, int32_t i);
+int mgn_tfrecord_feature(const mgn_tfrecord* r, const char* key, int32_t* kind, const void** data, int64_t* nbytes);
+const char* mgn_tfrecord_error(const mgn_tfrecord* r);
+void mgn_tfrecord_close(mgn_tfrecord* r);
+uint32_t mgn_crc32c(const void* data, size_t n);   /* CRC-32C (Castagnoli) as used by the record framing */
+
 #ifdef __cplusplus
 }
 #endif

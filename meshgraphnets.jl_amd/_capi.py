@@ -87,6 +87,14 @@ PROTOTYPES = {
     "mgn_halo_bytes_per_row": (C.c_int, [_H]),
     "mgn_halo_pack": (C.c_int, [_H, C.c_void_p]),
     "mgn_halo_unpack": (C.c_int, [_H, C.c_void_p]),
+    "mgn_tfrecord_open": (C.c_int, [C.c_char_p, C.c_int32, C.POINTER(_H)]),
+    "mgn_tfrecord_next": (C.c_int, [_H]),
+    "mgn_tfrecord_feature_count": (C.c_int, [_H]),
+    "mgn_tfrecord_feature_name": (C.c_char_p, [_H, C.c_int32]),
+    "mgn_tfrecord_feature": (C.c_int, [_H, C.c_char_p, _i32p, C.POINTER(C.c_void_p), _i64p]),
+    "mgn_tfrecord_error": (C.c_char_p, [_H]),
+    "mgn_tfrecord_close": (None, [_H]),
+    "mgn_crc32c": (C.c_uint32, [C.c_void_p, C.c_size_t]),
     "mgn_profile_enable": (C.c_int, [_H, C.c_int32]),
     "mgn_profile_read": (C.c_int, [_H, _f64p, _i64p]),
 }

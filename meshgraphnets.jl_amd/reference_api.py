@@ -243,3 +243,82 @@ def rollout(solver, mgn, initial_state, fields, meta, target_fields, target_dict
         x = x + F32(dt) * dx
         t = start + (i + 1) * dt
     return np.stack(sol_u), np.array(sol_t)
+
+
+# ---- dataset formats -------------------------------------------------------------------------------
+class TFRecordReader:
+    """Iterator over the tf.train.Example records of a .tfrecord file (native reader: mgn_tfrecord_*), the stand-in for
+    TFRecord.jl's `read(path; channel_size)` (reference src/dataset.jl:107-112).  Yields {feature name: (kind, bytes)}
+    with kind 1 = bytes_list (first value), 2 = float_list, 3 = int64_list."""
+
+    def __init__(self, path, verify_crc=True):
+        import ctypes as C
+        from . import _capi
+        self._C, self.lib = C, _capi.load()
+        self.h = C.c_void_p()
+        if self.lib.mgn_tfrecord_open(str(path).encode(), 1 if verify_crc else 0, C.byref(self.h)) != 0:
+            raise FileNotFoundError(path)
+
+    def __iter__(self):
+        return self
+
+    def __next__(self):
+        C = self._C
+        rc = self.lib.mgn_tfrecord_next(self.h)
+        if rc == 0:
+            raise StopIteration
+        if rc < 0:
+            raise ValueError("ArgumentError: " + self.lib.mgn_tfrecord_error(self.h).decode())
+        out = {}
+        for i in range(self.lib.mgn_tfrecord_feature_count(self.h)):
+            name = self.lib.mgn_tfrecord_feature_name(self.h, i)
+            kind, ptr, nb = C.c_int32(), C.c_void_p(), C.c_int64()
+            self.lib.mgn_tfrecord_feature(self.h, name, C.byref(kind), C.byref(ptr), C.byref(nb))
+            out[name.decode()] = (kind.value, C.string_at(ptr, nb.value) if nb.value else b"")
+        return out
+
+    def close(self):
+        if self.h:
+            self.lib.mgn_tfrecord_close(self.h)
+            self.h = self._C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def parse_data(example, meta):
+    """parse_data(data::Example, meta) (reference src/dataset.jl:61-75): every feature listed in meta["features"] is
+    reinterpreted by its dtype and reshaped to reverse(shape) (a -1 entry resolved from the payload length); static
+    features are repeated over the trajectory.  Arrays come back as [T][count][dim] (the bytes of Julia's dim x count x T).
+    A feature missing from the record raises KeyError, like `data.features.feature[key]`."""
+    out = {}
+    for key, value in meta["features"].items():
+        kind, payload = example[key]
+        d = np.frombuffer(payload, dtype=np.dtype(value["dtype"]))
+        shape = list(value["shape"])
+        if -1 in shape:
+            q = d.size
+            for sdim in shape:                      # abs(reduce(div, shape; init = length(d)))
+                q = int(q / sdim) if sdim else q    # Julia `div` truncates toward zero
+            shape[shape.index(-1)] = abs(q)
+        d = d.reshape(shape)
+        if value["type"] == "static":
+            d = np.repeat(d, meta["trajectory_length"], axis=0)
+        out[key] = d
+    return out
+
+
+def load_dataset(path, is_training):
+    """load_dataset(path, is_training) (reference src/dataset.jl:89-117), TFRecord branch: returns (meta, iterator over
+    parsed trajectories).  The .jld2 / .h5 branches need HDF5 and stay on the Julia side."""
+    import json
+    import os
+    with open(os.path.join(path, "meta.json")) as f:
+        meta = json.load(f)
+    file = os.path.join(path, ("train" if is_training else "test") + ".tfrecord")
+    if not os.path.isfile(file):
+        raise FileNotFoundError(file)
+    return meta, (parse_data(ex, meta) for ex in TFRecordReader(file))
