@@ -41,28 +41,12 @@ struct TileWalk {
     int tile, end, stride;
     DEVINL TileWalk(int ntiles, int wave) {
         const int wpb = blockDim.x >> 6;
-#if defined(MGN_WALK_PLAIN)      // experiment: no XCD awareness, global interleave
-        tile = blockIdx.x * wpb + wave;
-        end = ntiles;
-        stride = gridDim.x * wpb;
-#elif defined(MGN_WALK_CONTIG)   // experiment: every wave owns one contiguous run of tiles inside its XCD's range
-        const int xcd = blockIdx.x % NUM_XCD;
-        const int per = (ntiles + NUM_XCD - 1) / NUM_XCD;
-        const int nb = (gridDim.x - xcd + NUM_XCD - 1) / NUM_XCD;
-        const int nw = nb * wpb, w = (blockIdx.x / NUM_XCD) * wpb + wave;
-        const int lo = xcd * per, hi = min(lo + per, ntiles);
-        const int each = (hi - lo + nw - 1) / nw;
-        tile = lo + w * each;
-        end = min(tile + each, hi);
-        stride = 1;
-#else
         const int xcd = blockIdx.x % NUM_XCD;
         const int per = (ntiles + NUM_XCD - 1) / NUM_XCD;
         const int nb = (gridDim.x - xcd + NUM_XCD - 1) / NUM_XCD;  // blocks on this XCD label
         tile = xcd * per + (blockIdx.x / NUM_XCD) * wpb + wave;
         end = min(xcd * per + per, ntiles);
         stride = nb * wpb;
-#endif
     }
 };
 
@@ -89,31 +73,6 @@ DEVINL void stagger_second_half(int wave, int units) {
 #else
 #define STAMP(slot) do {} while (0)
 #endif
-
-// MFMA-pipe token between the two waves of a SIMD (waves w and w+4 of an 8-wave block).  A wave takes the token
-// for its whole 3-layer MFMA chain and hands it over afterwards, so its partner's chain coincides with its own
-// gather / LayerNorm / scan / store phase (and the gather's latency is spent waiting for the token, not for
-// data).  The token orders no data: it is a scheduling hint with a bounded spin, any race is benign.
-struct PipeToken {
-    volatile int* tok;   // [pair]: which half (0: waves 0-3, 1: waves 4-7) may run its MFMA chain
-    volatile int* done;  // [pair]: set once by each wave when it leaves
-    int half;
-    bool paired;
-    DEVINL void acquire() const {
-        if (!paired) return;
-        for (int spins = 0; spins < 4096; ++spins) {
-            const int t = __builtin_amdgcn_readfirstlane(*tok), d = __builtin_amdgcn_readfirstlane(*done);
-            if (t == half || d) break;
-            __builtin_amdgcn_s_sleep(2);
-        }
-    }
-    DEVINL void release() const {
-        if (paired) *tok = half ^ 1;
-    }
-    DEVINL void leave() const {
-        if (paired) { *done = 1; *tok = half ^ 1; }
-    }
-};
 
 template <int CTRL, int ROWMASK>
 DEVINL float dpp_zero(float v) {
@@ -150,9 +109,9 @@ DEVINL EdgeIdx load_edge_idx(const EdgeArgs& a, int tile, int c) {
 //   turnover  acc <- P[s'] + Q[r']                x <- e tile of the next tile
 // Rejected by same-box A/B: re-reading the e tile instead of keeping x (+2 %, +3 GB fetch per
 // launch), prefetching the next tile's P rows or e tile into the free array during the epilogue (spills, or +-0),
-// a deeper weight ring, start stagger, strict MFMA-pipe token between partner waves.
+// a deeper weight ring, start stagger, a strict MFMA-pipe token between partner waves (all removed again).
 // Steps of the third chunk kept in the LDS left over by two resident chunks at L = 128 (0 when it is fully
-// resident anyway): 160 KiB - 2 x 64 KiB - tables - token words = 29 632 B = 28 k-steps of 1 KiB.
+// resident anyway): 160 KiB - 2 x 64 KiB - tables - 64 spare bytes = 29 632 B = 28 k-steps of 1 KiB.
 #ifndef MGN_EDGE_JR
 #define MGN_EDGE_JR 28
 #endif
@@ -167,8 +126,6 @@ __global__ __launch_bounds__(512, 2) void k_edge_step(const EdgeArgs a) {
     if (PART > 0) copy_to_lds(smem + NRES * CH, a.chunk[2], PART);
     float* tb = smem + NRES * CH + PART;
     copy_to_lds(tb, a.tabs, T_COUNT * L);
-    int* tokmem = reinterpret_cast<int*>(tb + T_COUNT * L);
-    if (threadIdx.x < 8) tokmem[threadIdx.x] = 0;
     __syncthreads();
 
     const int lane0 = threadIdx.x & 63;
@@ -177,14 +134,9 @@ __global__ __launch_bounds__(512, 2) void k_edge_step(const EdgeArgs a) {
     const float* w3 = NRES > 1 ? smem + CH : a.chunk[1];
     const float* w1 = NRES > 2 ? smem + 2 * CH : a.chunk[2];
     stagger_second_half(wave, a.stagger);
-#ifdef MGN_TOKEN
-    const PipeToken token{tokmem + (wave & 3), tokmem + 4 + (wave & 3), wave >> 2, blockDim.x == 512};
-#else
-    const PipeToken token{tokmem, tokmem, 0, false};
-#endif
 
     TileWalk tw(a.ntiles, wave);
-    if (tw.tile >= tw.end) { token.leave(); return; }
+    if (tw.tile >= tw.end) return;
     f32x16 x[NT], acc[NT], y[NT];
     EdgeIdx ix = load_edge_idx(a, tw.tile, lane0 & 31);
     {
@@ -210,7 +162,6 @@ __global__ __launch_bounds__(512, 2) void k_edge_step(const EdgeArgs a) {
         f32x4* etile = tile_ptr(a.Elat, tile, L, lane);
         STAMP(1);
 
-        token.acquire();
         if constexpr (NRES > 2)
             mfma_chunk<NT, true>(acc, x, w1, lane);            // layer 1 (edge part; P,Q,b1 preloaded)
         else
@@ -225,7 +176,6 @@ __global__ __launch_bounds__(512, 2) void k_edge_step(const EdgeArgs a) {
         mfma_chunk<NT, (NRES > 1)>(acc, y, w3, lane);          // layer 3
         STAMP(4);
         PHASE_FENCE();
-        token.release();
         __builtin_amdgcn_s_setprio(MGN_PRIO);                   // memory/VALU phase: win issue arbitration
         // the e tile stays in registers across the three chains (x): re-reading it for the residual cost 3 GB of
         // extra fetch per launch on M-1M and 2 % of kernel time (same-box A/B)
@@ -272,7 +222,7 @@ __global__ __launch_bounds__(512, 2) void k_edge_step(const EdgeArgs a) {
         f32x4* dst = to_carry ? row_ptr(a.CARRY, (int64_t)2 * tile + (sl ? 0 : 1), L, h)
                               : tile_ptr(a.AGG, r >> 5, L, 32 * h + (r & 31));
         if (tail) store_frag<NT>(dst, to_carry ? STRIDE_ROW : STRIDE_TILE, acc);
-        if (!has_next) { token.leave(); break; }
+        if (!has_next) break;
         PHASE_FENCE();
         // turnover: next accumulator init = P[s'] + Q[r'];  x <- e tile of the next tile
         load_frag<NT>(acc, row_ptr(a.P, ixn.s, L, h), STRIDE_ROW);
@@ -1255,7 +1205,7 @@ static LaunchCfg tile_launch(int L, int ntiles, int nres) {
     blocks = ((blocks + NUM_XCD - 1) / NUM_XCD) * NUM_XCD;
     lc.blocks = blocks;
     lc.threads = wpb * 64;
-    lc.lds = (size_t)nres * L * L * 4 + (size_t)T_COUNT * L * 4 + 64;  // + pipe-token words
+    lc.lds = (size_t)nres * L * L * 4 + (size_t)T_COUNT * L * 4 + 64;  // + spare
     return lc;
 }
 

@@ -6,6 +6,9 @@
 // MLP per launch, row-major activations, weights streamed from L2.  See train.h for the kernel inventory.
 #include "train.h"
 
+#include <mutex>
+#include <unordered_map>
+
 #include "frag.hpp"
 
 namespace mgn {
@@ -30,31 +33,77 @@ DEVINL RowRef row_of(int tile, int c, int64_t rows) {
 // ================================================================================================
 // forward of one 3-Dense MLP (+ LayerNorm, + residual), keeping H1, H2, Y
 // ================================================================================================
+// Weight chunks are staged through a double-buffered LDS area by the whole block (4 waves = 4 tiles): chunk i+1 is
+// copied while chunk i feeds the MFMA chain.  (Per-wave streaming from L2 through the 4-deep register ring of the
+// persistent inference kernels is latency-bound here: one wave per SIMD, 5 chunks per tile.)
+// Block-wide copy of one L x L chunk global -> LDS with all of a thread's loads in flight at once (copy_to_lds' runtime
+// loop serialises load -> ds_write per iteration: ~11 us per 64 KiB chunk, which dominated these kernels).
+template <int CH>
+DEVINL void stage_chunk(float* dst, const float* __restrict__ src) {
+    constexpr int PER = CH / 4 / 256 > 0 ? CH / 4 / 256 : 1;   // float4 per thread: 16 (L = 128), 4 (L = 64), 1 (L = 32)
+    constexpr int B = PER < 16 ? PER : 16;
+    const f32x4* s4 = reinterpret_cast<const f32x4*>(src);
+    f32x4* d4 = reinterpret_cast<f32x4*>(dst);
+#pragma unroll
+    for (int base = 0; base < PER; base += B) {
+        f32x4 v[B];
+#pragma unroll
+        for (int u = 0; u < B; ++u) v[u] = s4[(base + u) * 256 + threadIdx.x];
+#pragma unroll
+        for (int u = 0; u < B; ++u) d4[(base + u) * 256 + threadIdx.x] = v[u];
+    }
+}
+
+// `cur` is a compile-time constant at every use (the chunk sequence is fully unrolled), so the LDS addresses are too.
+#define CP_PRIME(first)                   \
+    int cur = 0;                          \
+    stage_chunk<CH>(smem, (first));       \
+    __syncthreads()
+#define CP_PREFETCH(next)                                                        \
+    do {                                                                         \
+        const float* nx_ = (next);                                               \
+        if (nx_) stage_chunk<CH>(smem + (cur ^ 1) * CH, nx_);                    \
+    } while (0)
+#define CP_W() (smem + cur * CH)
+#define CP_ADVANCE()     \
+    do {                 \
+        __syncthreads(); \
+        cur ^= 1;        \
+    } while (0)
+
 template <int NT, int NIN>
 __global__ __launch_bounds__(256) void k_mlp_fwd(const TrainFwdArgs a) {
-    constexpr int L = 32 * NT;
+    constexpr int L = 32 * NT, CH = L * L;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane0 = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int tile = blockIdx.x * 4 + wave;
-    if (tile >= a.ntiles) return;
+    const int tile_raw = blockIdx.x * 4 + wave;
+    const bool active = tile_raw < a.ntiles;
+    const int tile = active ? tile_raw : a.ntiles - 1;       // idle waves shadow the last tile (no stores): they share the barriers
     OPAQUE_LANE();
-    const RowRef rw = row_of(tile, c, a.rows);
+    RowRef rw = row_of(tile, c, a.rows);
+    rw.valid = rw.valid && active;
+    CP_PRIME(a.W1[0]);
     f32x16 x[NT], acc[NT], y[NT];
     tab_frag<NT>(acc, a.tabs + T_B1 * L, h);
 #pragma unroll
     for (int j = 0; j < NIN; ++j) {
+        CP_PREFETCH(j + 1 < NIN ? a.W1[j + 1] : a.W2);
         const int64_t src = a.xidx[j] ? (int64_t)a.xidx[j][rw.rr] : rw.rr;
         load_frag<NT>(x, row_ptr(a.X[j], src, L, h), STRIDE_ROW);
-        mfma_chunk<NT, false>(acc, x, a.W1[j], lane);
+        mfma_chunk<NT, true>(acc, x, CP_W(), lane);
+        CP_ADVANCE();
     }
     relu_frag<NT>(acc);
     if (rw.valid) store_frag<NT>(row_ptr(a.H1, rw.row, L, h), STRIDE_ROW, acc);
+    CP_PREFETCH(a.W3);
     tab_frag<NT>(y, a.tabs + T_B2 * L, h);
-    mfma_chunk<NT, false>(y, acc, a.W2, lane);
+    mfma_chunk<NT, true>(y, acc, CP_W(), lane);
+    CP_ADVANCE();
     relu_frag<NT>(y);
     if (rw.valid) store_frag<NT>(row_ptr(a.H2, rw.row, L, h), STRIDE_ROW, y);
     tab_frag<NT>(acc, a.tabs + T_B3 * L, h);
-    mfma_chunk<NT, false>(acc, y, a.W3, lane);
+    mfma_chunk<NT, true>(acc, y, CP_W(), lane);
     if (rw.valid) store_frag<NT>(row_ptr(a.Y, rw.row, L, h), STRIDE_ROW, acc);
     if (a.ln) layer_norm_frag<NT>(acc, a.tabs + T_GAMMA * L, a.tabs + T_BETA * L, h);
     if (a.LNOUT && rw.valid) store_frag<NT>(row_ptr(a.LNOUT, rw.row, L, h), STRIDE_ROW, acc);
@@ -77,14 +126,18 @@ DEVINL void mask_by_relu(f32x16 (&g)[NT], const f32x16 (&act)[NT]) {
 
 template <int NT, int NIN>
 __global__ __launch_bounds__(256) void k_mlp_bwd(const TrainBwdArgs a) {
-    constexpr int L = 32 * NT;
+    constexpr int L = 32 * NT, CH = L * L;
     constexpr float invL = 1.0f / L;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane0 = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int tile = blockIdx.x * 4 + wave;
-    if (tile >= a.ntiles) return;
+    const int tile_raw = blockIdx.x * 4 + wave;
+    const bool active = tile_raw < a.ntiles;
+    const int tile = active ? tile_raw : a.ntiles - 1;
     OPAQUE_LANE();
-    const RowRef rw = row_of(tile, c, a.rows);
+    RowRef rw = row_of(tile, c, a.rows);
+    rw.valid = rw.valid && active;
+    CP_PRIME(a.W3T);
     f32x16 g[NT], y[NT], acc[NT];
     load_frag<NT>(g, row_ptr(a.G0, rw.rr, L, h), STRIDE_ROW);
     if (a.G1) add_frag<NT>(g, row_ptr(a.G1, a.g1idx ? (int64_t)a.g1idx[rw.rr] : rw.rr, L, h), STRIDE_ROW);
@@ -135,22 +188,34 @@ __global__ __launch_bounds__(256) void k_mlp_bwd(const TrainBwdArgs a) {
             for (int k = 0; k < 16; ++k) g[t][k] = rstd * (g[t][k] - m1 - y[t][k] * m2);
     }
     if (rw.valid) store_frag<NT>(row_ptr(a.GY, rw.row, L, h), STRIDE_ROW, g);
+    CP_PREFETCH(a.W2T);
     zero_frag<NT>(acc);
-    mfma_chunk<NT, false>(acc, g, a.W3T, lane);               // gradient at H2
+    mfma_chunk<NT, true>(acc, g, CP_W(), lane);               // gradient at H2
+    CP_ADVANCE();
     load_frag<NT>(y, row_ptr(a.H2, rw.rr, L, h), STRIDE_ROW);
     mask_by_relu<NT>(acc, y);
     if (rw.valid) store_frag<NT>(row_ptr(a.GZ2, rw.row, L, h), STRIDE_ROW, acc);
+    // the input-gradient chunks that exist, in order (kernel-uniform)
+    const float* nxt[3] = {nullptr, nullptr, nullptr};
+    int first = -1;
+#pragma unroll
+    for (int j = NIN - 1; j >= 0; --j)
+        if (a.W1T[j]) { nxt[j] = first >= 0 ? a.W1T[first] : nullptr; first = j; }
+    CP_PREFETCH(first >= 0 ? a.W1T[first] : nullptr);
     zero_frag<NT>(g);
-    mfma_chunk<NT, false>(g, acc, a.W2T, lane);               // gradient at H1
+    mfma_chunk<NT, true>(g, acc, CP_W(), lane);               // gradient at H1
+    CP_ADVANCE();
     load_frag<NT>(y, row_ptr(a.H1, rw.rr, L, h), STRIDE_ROW);
     mask_by_relu<NT>(g, y);
     if (rw.valid) store_frag<NT>(row_ptr(a.GZ1, rw.row, L, h), STRIDE_ROW, g);
 #pragma unroll
     for (int j = 0; j < NIN; ++j) {
         if (!a.W1T[j]) continue;
+        CP_PREFETCH(nxt[j]);
         if (a.GXadd[j]) load_frag<NT>(acc, row_ptr(a.GXadd[j], rw.rr, L, h), STRIDE_ROW);
         else zero_frag<NT>(acc);
-        mfma_chunk<NT, false>(acc, g, a.W1T[j], lane);
+        mfma_chunk<NT, true>(acc, g, CP_W(), lane);
+        CP_ADVANCE();
         if (rw.valid) store_frag<NT>(row_ptr(a.GX[j], rw.row, L, h), STRIDE_ROW, acc);
     }
 }
@@ -321,15 +386,28 @@ __global__ void k_loss(const float* __restrict__ Y, int L, const float* __restri
 // ================================================================================================
 // launch wrappers
 // ================================================================================================
+// 4 tiles per block; two L x L chunk buffers of dynamic LDS (128 KiB at L = 128: the attribute is raised once per kernel)
 template <typename K, typename A>
-static hipError_t launch_tiles(K kern, const A& a, int ntiles, hipStream_t s) {
+static hipError_t launch_tiles(K kern, const A& a, int ntiles, int L, hipStream_t s) {
     if (ntiles <= 0) return hipSuccess;
-    hipLaunchKernelGGL(kern, dim3((unsigned)((ntiles + 3) / 4)), dim3(256), 0, s, a);
+    const size_t lds = (size_t)2 * L * L * sizeof(float);
+    static std::mutex mu;
+    static std::unordered_map<const void*, size_t> granted;
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        size_t& g = granted[reinterpret_cast<const void*>(kern)];
+        if (lds > 48 * 1024 && g < lds) {
+            const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
+            g = lds;
+        }
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)((ntiles + 3) / 4)), dim3(256), lds, s, a);
     return hipGetLastError();
 }
 
 hipError_t launch_mlp_fwd(int L, int nin, const TrainFwdArgs& a, hipStream_t s) {
-#define FWD_CASE(NT_, NIN_) if (L == 32 * NT_ && nin == NIN_) return launch_tiles(k_mlp_fwd<NT_, NIN_>, a, a.ntiles, s)
+#define FWD_CASE(NT_, NIN_) if (L == 32 * NT_ && nin == NIN_) return launch_tiles(k_mlp_fwd<NT_, NIN_>, a, a.ntiles, L, s)
     FWD_CASE(4, 1); FWD_CASE(4, 2); FWD_CASE(4, 3);
     FWD_CASE(2, 1); FWD_CASE(2, 2); FWD_CASE(2, 3);
     FWD_CASE(1, 1); FWD_CASE(1, 2); FWD_CASE(1, 3);
@@ -338,7 +416,7 @@ hipError_t launch_mlp_fwd(int L, int nin, const TrainFwdArgs& a, hipStream_t s) 
 }
 
 hipError_t launch_mlp_bwd(int L, int nin, const TrainBwdArgs& a, hipStream_t s) {
-#define BWD_CASE(NT_, NIN_) if (L == 32 * NT_ && nin == NIN_) return launch_tiles(k_mlp_bwd<NT_, NIN_>, a, a.ntiles, s)
+#define BWD_CASE(NT_, NIN_) if (L == 32 * NT_ && nin == NIN_) return launch_tiles(k_mlp_bwd<NT_, NIN_>, a, a.ntiles, L, s)
     BWD_CASE(4, 1); BWD_CASE(4, 2); BWD_CASE(4, 3);
     BWD_CASE(2, 1); BWD_CASE(2, 2); BWD_CASE(2, 3);
     BWD_CASE(1, 1); BWD_CASE(1, 2); BWD_CASE(1, 3);
