@@ -1,0 +1,71 @@
+"""Randomised parity sweep (seeded, reproducible): widths, depths and ragged graphs the fixed tests do not name --
+forward, device-resident processor steps, fused RHS and the training step against the float64 oracle.
+Run on the MI355X box with `-m gpu`."""
+import numpy as np
+import pytest
+
+import mgn_amd
+import mgn_oracle as orc
+from mgn_amd import synth
+from util import TOL_15, rel_max, set_kernel_path
+
+pytestmark = pytest.mark.gpu
+
+
+def draw(seed):
+    rng = np.random.default_rng(1000 + seed)
+    L = int(rng.choice([32, 64, 128]))
+    cfg = dict(Fn=int(rng.integers(1, 17)), Fe=int(rng.integers(1, 9)), O=int(rng.integers(1, 5)), L=L, hidden_layers=2,
+               mps=int(rng.integers(1, 5)))
+    cfg["Fn"] = max(cfg["Fn"], cfg["O"])
+    N = int(rng.integers(1, 400))
+    E = int(rng.integers(0, 3500))
+    s, r = synth.random_graph(N, E, seed, allow_isolated=bool(rng.integers(2)))
+    if rng.integers(3) == 0 and E > 0:          # a hub: one receiver with hundreds of incoming edges
+        r[: E // 3] = int(rng.integers(N))
+    ps = orc.init_params(cfg["Fn"], cfg["Fe"], cfg["O"], L, 2, cfg["mps"], seed=seed, ln_jitter=0.1)
+    return rng, cfg, N, E, s, r, ps
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_forward_and_processor(seed):
+    rng, cfg, N, E, s, r, ps = draw(seed)
+    path = int(rng.integers(0, 4)) if cfg["L"] == 128 else 0
+    old = set_kernel_path(path)
+    try:
+        base = int(rng.integers(2))
+        eng = mgn_amd.Engine(cfg["Fn"], cfg["Fe"], cfg["O"], cfg["L"], 2, cfg["mps"])
+        eng.set_params(ps)
+        eng.set_graph(s + base, r + base, N, index_base=base)
+        nf = rng.standard_normal((N, cfg["Fn"])).astype(np.float32)
+        ef = rng.standard_normal((E, cfg["Fe"])).astype(np.float32)
+        out = eng.forward(nf, ef)
+        ref = orc.forward(ps, cfg, nf, ef, s, r)
+        assert rel_max(out, ref) <= TOL_15, (cfg, N, E, path, rel_max(out, ref))
+        v = rng.standard_normal((N, cfg["L"])).astype(np.float32)
+        e = rng.standard_normal((E, cfg["L"])).astype(np.float32)
+        k = int(rng.integers(1, cfg["mps"] + 1))
+        eng.latents_import(v, e)
+        eng.processor_steps_dev(k)
+        v1, e1 = eng.latents_export()
+        rv, re = orc.processor_steps(ps, cfg, v, e, s, r, k)
+        assert rel_max(v1, rv) <= TOL_15 and (E == 0 or rel_max(e1, re) <= TOL_15), (cfg, N, E, path, k)
+    finally:
+        set_kernel_path(old)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_random_training_step(seed):
+    rng, cfg, N, E, s, r, ps = draw(100 + seed)
+    eng = mgn_amd.Engine(cfg["Fn"], cfg["Fe"], cfg["O"], cfg["L"], 2, cfg["mps"])
+    eng.set_params(ps)
+    eng.set_graph(s, r, N)
+    nf = rng.standard_normal((N, cfg["Fn"])).astype(np.float32)
+    ef = rng.standard_normal((E, cfg["Fe"])).astype(np.float32)
+    target = rng.standard_normal((N, cfg["O"])).astype(np.float32)
+    mask = rng.choice(N, max(1, N // 2), replace=False).astype(np.int32)
+    gs, loss = eng.step(nf, ef, target, mask)
+    ref, ref_loss = orc.step_grads(ps, cfg, nf, ef, s, r, target, mask)
+    assert abs(loss - ref_loss) <= 1e-5 * max(abs(ref_loss), 1e-6), (cfg, N, E)
+    # robust to a ReLU unit sitting on its kink (see test_gpu_training_step.py): relative L2 over the whole gradient
+    assert np.linalg.norm(gs - ref) <= 2e-3 * np.linalg.norm(ref), (cfg, N, E, np.linalg.norm(gs - ref) / np.linalg.norm(ref))
