@@ -158,6 +158,13 @@ int mgn_set_static(mgn_handle* h, const float* node_type_onehot, const float* ef
  *   Call with senders = receivers = NULL to get the count; *n_directed receives 2 x (unique undirected edges).
  * mgn_edge_features: ef[e] = [pos[s]-pos[r] ; ||pos[s]-pos[r]||]  (src/graph.jl:35-36,49-52), ef is [E][dim+1]. */
 int mgn_triangles_to_edges(const int32_t* cells, int64_t n_cells, int32_t* senders, int32_t* receivers, int64_t* n_directed);
+/* World edges of a cloth-like mesh (second edge set of MGN-spec; no reference symbol, the reference has one edge set):
+ * every ordered pair (s, r), s != r, closer than `radius` in world space and not already joined by a mesh edge; uniform
+ * grid search, receiver-major output with ascending senders.  Call with senders = receivers = NULL to get the count in
+ * *n_edges; with buffers, *n_edges holds their capacity on entry and the number written on return.               */
+int mgn_world_edges(const float* world_pos, int32_t dim, int32_t N, float radius, const int32_t* mesh_senders,
+                    const int32_t* mesh_receivers, int64_t n_mesh, int32_t index_base, int32_t* senders, int32_t* receivers,
+                    int64_t* n_edges);
 int mgn_edge_features(const float* mesh_pos, int32_t pos_dim, const int32_t* senders, const int32_t* receivers,
                       int64_t E, int32_t index_base, float* ef);
 

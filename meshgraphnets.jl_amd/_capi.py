@@ -66,6 +66,7 @@ PROTOTYPES = {
     "mgn_ode_step": (C.c_int, [_H, _f32p, _f32p, _f32p, _f32p, _f32p]),
     "mgn_set_static": (C.c_int, [_H, _f32p, _f32p, _f32p]),
     "mgn_triangles_to_edges": (C.c_int, [_i32p, C.c_int64, _i32p, _i32p, _i64p]),
+    "mgn_world_edges": (C.c_int, [_f32p, C.c_int32, C.c_int32, C.c_float, _i32p, _i32p, C.c_int64, C.c_int32, _i32p, _i32p, _i64p]),
     "mgn_edge_features": (C.c_int, [_f32p, C.c_int32, _i32p, _i32p, C.c_int64, C.c_int32, _f32p]),
     "mgn_rollout": (C.c_int, [_H, C.POINTER(MgnRolloutDesc)]),
     "mgn_step": (C.c_int, [_H, _f32p, _f32p, _f32p, _i32p, C.c_int64, C.c_int32, _f32p, C.c_size_t, _f32p]),

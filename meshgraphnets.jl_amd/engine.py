@@ -382,6 +382,24 @@ def triangles_to_edges_native(cells):
     return s, r
 
 
+def world_edges_native(world_pos, radius, mesh_senders, mesh_receivers, index_base=0):
+    """Radius graph in world space minus self loops and mesh-edge pairs (world edges of cloth models): (senders, receivers)."""
+    lib = _capi.load()
+    wp = _c32(world_pos)
+    ms = np.ascontiguousarray(mesh_senders, dtype=np.int32)
+    mr = np.ascontiguousarray(mesh_receivers, dtype=np.int32)
+    n = C.c_int64()
+    args = (f32(wp), wp.shape[1], wp.shape[0], C.c_float(radius), i32(ms), i32(mr), ms.size, index_base)
+    rc = lib.mgn_world_edges(*args, None, None, C.byref(n))
+    if rc != 0:
+        raise MgnError(rc, "mgn_world_edges")
+    s, r = np.empty(n.value, np.int32), np.empty(n.value, np.int32)
+    rc = lib.mgn_world_edges(*args, i32(s), i32(r), C.byref(n))
+    if rc != 0:
+        raise MgnError(rc, "mgn_world_edges")
+    return s, r
+
+
 def edge_features_native(mesh_pos, senders, receivers, index_base=0):
     lib = _capi.load()
     pos = _c32(mesh_pos)

@@ -200,3 +200,26 @@ def test_native_graph_prologue_helpers(lib_built):
     assert sorted(ef345[:, 2].tolist()) == [3.0, 4.0, 5.0]
     with pytest.raises(ValueError):
         mgn_amd.triangles_to_edges_native(np.zeros((3, 2), np.int32))
+
+
+def test_world_edges_native_matches_dense_search(lib_built):
+    """mgn_world_edges (uniform-grid search) against the dense O(N^2) NumPy search on the folded cloth, 2-D and 3-D, both
+    index bases; and at a size the dense search cannot do (200 k nodes) by its invariants."""
+    m = synth.mesh_flag(3, 30, 24, radius=0.06)
+    for pos in (m["world_pos"], m["world_pos"][:, :2].copy()):
+        for rad in (0.03, 0.06, 0.2):
+            s0, r0 = synth.world_edges(pos, rad, m["s"], m["r"])
+            s1, r1 = mgn_amd.world_edges_native(pos, rad, m["s"], m["r"])
+            k0 = np.sort(r0.astype(np.int64) * 100000 + s0)
+            assert np.array_equal(r1.astype(np.int64) * 100000 + s1, k0)          # receiver-major, senders ascending
+            s2, r2 = mgn_amd.world_edges_native(pos, rad, m["s"] + 1, m["r"] + 1, index_base=1)
+            assert np.array_equal(s2, s1 + 1) and np.array_equal(r2, r1 + 1)
+    rng = np.random.default_rng(0)
+    big = rng.random((200000, 3)).astype(np.float32)
+    s3, r3 = mgn_amd.world_edges_native(big, 0.012, np.zeros(0, np.int32), np.zeros(0, np.int32))
+    d = np.linalg.norm(big[s3] - big[r3], axis=1)
+    assert s3.size > 100000 and d.max() < 0.012 and np.all(s3 != r3)
+    key = r3.astype(np.int64) * 200000 + s3
+    assert np.all(np.diff(key) > 0)                                               # sorted, no duplicates
+    rev = np.isin(s3.astype(np.int64) * 200000 + r3, key)
+    assert rev.all()                                                              # symmetric
