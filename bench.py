@@ -211,7 +211,8 @@ def main():
     finite = all(np.isfinite(v) for v in chk.values())
 
     if rank == 0:
-        t_edge = prof["edge_step"]["avg_ms"] * 1e-3
+        # a split edge step (N > 1: interior tiles while the halo is in flight, boundary tiles after) is two launches
+        t_edge = (prof["edge_step"]["avg_ms"] + (prof["edge_boundary"]["avg_ms"] if prof["edge_boundary"]["count"] else 0.0)) * 1e-3
         t_node = prof["node_step"]["avg_ms"] * 1e-3
         e_loc, n_loc = eng.e_local, eng.n_own
         ach = flops_edge_kernel(e_loc) / t_edge / 1e12 if t_edge > 0 else 0.0

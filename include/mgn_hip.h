@@ -240,6 +240,12 @@ int mgn_proc_node(mgn_handle* h, int32_t k, int32_t project_next); /* project_ne
  *   phase 2: projection of the interior tiles     -> finish the exchange, mgn_halo_unpack.
  * phase 1 followed by phase 2 equals mgn_proc_node(h, k, 1) (k >= 0) or mgn_proc_begin (k = -1). */
 int mgn_proc_node_phase(mgn_handle* h, int32_t k, int32_t phase);
+/* The edge step split the same way (SURVEY.md 8e "interior edges while the halo is in flight, boundary edges after"):
+ * edges whose sender is a halo node all lie in the first `boundary` 32-edge tiles of the receiver-sorted list (mesh edges
+ * are two-way, so they end at boundary nodes, which are numbered first).  phase 1: tiles [boundary, total) -- needs no
+ * exchanged row, may run before mgn_halo_unpack; phase 2: tiles [0, boundary).  phase 1 + phase 2 == mgn_proc_edge.   */
+int mgn_proc_edge_phase(mgn_handle* h, int32_t k, int32_t phase);
+int mgn_edge_boundary_tiles(const mgn_handle* h, int32_t set, int32_t* boundary, int32_t* total);
 int mgn_fwd_decode(mgn_handle* h);
 int mgn_fwd_download(mgn_handle* h, float* out);        /* host GLOBAL [N][O]; owned rows written   */
 int mgn_halo_bytes_per_row(const mgn_handle* h);
@@ -250,7 +256,7 @@ int mgn_halo_unpack(mgn_handle* h, const void* recv_dev); /* device buffer, sum(
 /* Average device time (HIP events on the launch stream) of each kernel family since the last reset:
  * ms[0]=edge step, ms[1]=node step, ms[2]=encode, ms[3]=decode, ms[4]=halo pack/unpack; counts alike. */
 int mgn_profile_enable(mgn_handle* h, int32_t on);
-int mgn_profile_read(mgn_handle* h, double ms_avg[8], int64_t counts[8]);
+int mgn_profile_read(mgn_handle* h, double ms_avg[8], int64_t counts[8]);   /* slots: edge, node, encode, decode, halo, boundary edge tiles */
 
 /* ---- data formats: host code, no handle -------------------------------------------
  * TFRecord framing + tf.train.Example decoding of the DeepMind MeshGraphNets datasets, as the reference reads them

@@ -83,6 +83,8 @@ PROTOTYPES = {
     "mgn_proc_edge": (C.c_int, [_H, C.c_int32]),
     "mgn_proc_node": (C.c_int, [_H, C.c_int32, C.c_int32]),
     "mgn_proc_node_phase": (C.c_int, [_H, C.c_int32, C.c_int32]),
+    "mgn_proc_edge_phase": (C.c_int, [_H, C.c_int32, C.c_int32]),
+    "mgn_edge_boundary_tiles": (C.c_int, [_H, C.c_int32, _i32p, _i32p]),
     "mgn_fwd_decode": (C.c_int, [_H]),
     "mgn_fwd_download": (C.c_int, [_H, _f32p]),
     "mgn_halo_bytes_per_row": (C.c_int, [_H]),

@@ -40,7 +40,7 @@ struct MlpOff {
     bool ln = false;
 };
 
-enum Family { F_EDGE = 0, F_NODE, F_ENC, F_DEC, F_HALO, F_NFAM };
+enum Family { F_EDGE = 0, F_NODE, F_ENC, F_DEC, F_HALO, F_EDGE_BND, F_NFAM };   // F_EDGE_BND: boundary tiles of a split edge step
 
 struct ProfRec {
     int fam;

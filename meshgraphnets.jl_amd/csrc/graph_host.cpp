@@ -159,6 +159,9 @@ std::string build_local_graph(int32_t N, int nsets, const EdgeList* sets, const 
             t.rcv[p] = lr;
             t.edge_gid[p] = i;
         }
+        t.halo_span = 0;
+        for (int64_t p = el - 1; p >= 0; --p)
+            if (t.snd[p] >= g.n_own) { t.halo_span = p + 1; break; }
     }
 
     // send lists: my owned nodes that are senders of edges received on peer q (unique, ascending gid)

@@ -16,6 +16,8 @@ struct EdgeTopo {
     std::vector<int64_t> edge_gid;   // [e_local] global edge id, engine (receiver-sorted, stable) order
     std::vector<int32_t> snd, rcv;   // [e_local] local indices; snd may be >= n_own (halo)
     std::vector<int32_t> rowptr;     // [n_own+1] CSR by receiver
+    int64_t halo_span = 0;           // 1 + position of the last edge whose sender is a halo node (0: none).  Mesh edges are
+                                     // two-way, so such edges end at boundary nodes, which are numbered first: the span is short
 };
 
 struct LocalGraph {

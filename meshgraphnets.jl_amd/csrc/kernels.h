@@ -26,6 +26,7 @@ struct EdgeArgs {
     const float* chunk_t[MAX_CHUNKS]; // same chunks in t-major fragment order (cooperative small-graph kernels); null if absent
     const float* tabs;      // T_COUNT * L floats (fragment order): b2,b3 in T_B2,T_B3; LN in T_GAMMA,T_BETA
     int32_t stagger;        // s_sleep(127) units by which waves 4..7 of a block start late
+    int32_t tile0;          // the launch covers edge tiles [tile0, tile0 + ntiles) (interior / boundary split)
     unsigned long long* stamps;  // diagnostic builds only (MGN_DIAG_STAMPS), else null
 };
 
@@ -90,7 +91,7 @@ struct DecArgs {
 // ---- bf16 processor (BASELINE cfg-3 precision): bf16 storage + bf16 MFMA, fp32 accumulate / LayerNorm / residual /
 // aggregation.  All pointers are bf16 (uint16_t) arrays; chunks are bf16 fragment order [s(8)][t(4)][lane(64)][8].
 struct BfEdgeArgs {
-    const int32_t* snd; const int32_t* rcv; int64_t E; int32_t ntiles;
+    const int32_t* snd; const int32_t* rcv; int64_t E; int32_t ntiles; int32_t tile0;
     const uint16_t* P; const uint16_t* Q;      // row-major [row][16 pieces][8], fragment feature order
     uint16_t* Elat; uint16_t* AGG;             // tile-major [tile][8][64][8]
     uint16_t* CARRY;                           // row-major

@@ -135,7 +135,9 @@ __global__ __launch_bounds__(512, 2) void k_edge_step(const EdgeArgs a) {
     const float* w1 = NRES > 2 ? smem + 2 * CH : a.chunk[2];
     stagger_second_half(wave, a.stagger);
 
-    TileWalk tw(a.ntiles, wave);
+    TileWalk tw(a.ntiles, wave);           // walks the launch's tile range [tile0, tile0 + ntiles)
+    tw.tile += a.tile0;
+    tw.end += a.tile0;
     if (tw.tile >= tw.end) return;
     f32x16 x[NT], acc[NT], y[NT];
     EdgeIdx ix = load_edge_idx(a, tw.tile, lane0 & 31);
@@ -375,7 +377,10 @@ __global__ __launch_bounds__(MGN_PROJ_WAVES * 64, MGN_PROJ_WAVES / 4) void k_pro
 // tiles, 63 node tiles) then spreads over ~1500 / 250 waves instead of 374 / 63.  Weights stream from L2 in
 // t-major fragment order (chunk_t[(t*64 + j)*64 + lane]), one coalesced 256-B load per k-step and wave.
 // ================================================================================================
-constexpr int COOP_PF = 4;   // 16-byte fragments: 4 k-steps each
+#ifndef MGN_COOP_PF
+#define MGN_COOP_PF 4
+#endif
+constexpr int COOP_PF = MGN_COOP_PF;   // weight ring depth in 16-byte fragments (4 k-steps each)
 
 // wt: this wave's t-slice of a chunk in t-major order [j/4][lane][4]
 DEVINL void coop_chain(f32x16& acc, const f32x16 (&in)[4], const float* wt, int lane) {
@@ -455,7 +460,7 @@ __global__ __launch_bounds__(256, 2) void k_edge_coop(const EdgeArgs a) {
     const int lane0 = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int tq = wave;   // feature block owned by this wave
-    for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+    for (int tile = a.tile0 + blockIdx.x; tile < a.tile0 + a.ntiles; tile += gridDim.x) {
         OPAQUE_LANE();     // keeps the (loop-invariant) weight and table loads inside the tile loop
         const EdgeIdx ix = load_edge_idx(a, tile, c);
         const bool valid = ix.r >= 0;
@@ -808,7 +813,7 @@ __global__ __launch_bounds__(MGN_BF_WAVES * 64, MGN_BF_WAVES / 4) void k_edge_bf
     ia.snd = a.snd; ia.rcv = a.rcv; ia.E = a.E;
     for (TileWalk tw(a.ntiles, wave); tw.tile < tw.end; tw.tile += tw.stride) {
         OPAQUE_LANE();
-        const int tile = tw.tile;
+        const int tile = a.tile0 + tw.tile;
         const EdgeIdx ix = load_edge_idx(ia, tile, c);
         const bool valid = ix.r >= 0;
         const int r = valid ? ix.r : 0;

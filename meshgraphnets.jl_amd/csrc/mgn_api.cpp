@@ -268,8 +268,15 @@ EdgeArgs edge_args(mgn_engine* h, int k, int q = 0) {
     }
     a.tabs = W(h, h->soff[k].e_tabs[q]);
     a.stagger = h->stagger_edge;
+    a.tile0 = 0;
     a.stamps = h->d_stamps.as<unsigned long long>();
     return a;
+}
+
+// tiles [0, tb) of set q hold every edge with a halo sender (they need the exchanged P rows); tiles [tb, ntiles) do not
+inline int32_t boundary_tiles(const mgn_engine* h, int q) {
+    const int64_t tb = (h->g.set[q].halo_span + TILE - 1) / TILE;
+    return (int32_t)(tb < h->es[q].ntiles_e ? tb : h->es[q].ntiles_e);
 }
 
 // q: the edge set whose P,Q the projection part (modes 1, 2) writes
@@ -925,14 +932,51 @@ int mgn_proc_begin(mgn_handle* h) {
     return MGN_OK;
 }
 
+static int proc_edge_range(mgn_handle* h, int32_t k, int32_t phase) {   // phase 0: all tiles, 1: interior tiles, 2: boundary tiles
+    bool work = false;
+    for (int q = 0; q < h->nsets; ++q) {
+        const int32_t tb = boundary_tiles(h, q), nt = h->es[q].ntiles_e;
+        work = work || (phase == 0 ? nt : (phase == 1 ? nt - tb : tb)) > 0;
+    }
+    if (!work) return MGN_OK;
+    ProfScope ps(h, phase == 2 ? F_EDGE_BND : F_EDGE);
+    for (int q = 0; q < h->nsets; ++q) {
+        const int32_t tb = boundary_tiles(h, q), nt = h->es[q].ntiles_e;
+        const int32_t t0 = phase == 1 ? tb : 0, n = phase == 0 ? nt : (phase == 1 ? nt - tb : tb);
+        if (n <= 0) continue;
+        if (is_bf16(h)) {
+            BfEdgeArgs a = bf_edge_args(h, k, q);
+            a.tile0 = t0;
+            a.ntiles = n;
+            HIPCHK(h, launch_edge_bf16(a, h->stream));
+        } else {
+            EdgeArgs a = edge_args(h, k, q);
+            a.tile0 = t0;
+            a.ntiles = n;
+            HIPCHK(h, launch_edge_step(h->cfg.L, a, h->stream));
+        }
+    }
+    return MGN_OK;
+}
+
 int mgn_proc_edge(mgn_handle* h, int32_t k) {
     if (int rc = need(h, true, true)) return rc;
     if (k < 0 || k >= h->cfg.mps) return fail(h, MGN_E_ARG, "mgn_proc_edge: step %d out of range", k);
-    ProfScope ps(h, F_EDGE);
-    for (int q = 0; q < h->nsets; ++q) {
-        if (is_bf16(h)) HIPCHK(h, launch_edge_bf16(bf_edge_args(h, k, q), h->stream));
-        else HIPCHK(h, launch_edge_step(h->cfg.L, edge_args(h, k, q), h->stream));
-    }
+    return proc_edge_range(h, k, 0);
+}
+
+int mgn_proc_edge_phase(mgn_handle* h, int32_t k, int32_t phase) {
+    if (int rc = need(h, true, true)) return rc;
+    if (k < 0 || k >= h->cfg.mps) return fail(h, MGN_E_ARG, "mgn_proc_edge_phase: step %d out of range", k);
+    if (phase != 1 && phase != 2) return fail(h, MGN_E_ARG, "mgn_proc_edge_phase: phase must be 1 or 2");
+    return proc_edge_range(h, k, phase);
+}
+
+int mgn_edge_boundary_tiles(const mgn_handle* h, int32_t set, int32_t* boundary, int32_t* total) {
+    if (!h || !h->have_graph) return MGN_E_STATE;
+    if (set < 0 || set >= h->nsets) return MGN_E_ARG;
+    if (boundary) *boundary = boundary_tiles(h, set);
+    if (total) *total = h->es[set].ntiles_e;
     return MGN_OK;
 }
 

@@ -334,6 +334,15 @@ class Engine:
         """phase 1: node MLP of step k (k = -1: none) + projection of the boundary tiles; phase 2: interior tiles."""
         self._chk(self.lib.mgn_proc_node_phase(self.h, k, phase))
 
+    def proc_edge_phase(self, k, phase):
+        """phase 1: edge tiles without halo senders (may run while the halo exchange is in flight); phase 2: the rest."""
+        self._chk(self.lib.mgn_proc_edge_phase(self.h, k, phase))
+
+    def edge_boundary_tiles(self, set_index=0):
+        a, b = C.c_int32(), C.c_int32()
+        self._chk(self.lib.mgn_edge_boundary_tiles(self.h, set_index, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
     def fwd_decode(self):
         self._chk(self.lib.mgn_fwd_decode(self.h))
 
@@ -361,7 +370,7 @@ class Engine:
         ms = (C.c_double * 8)()
         cnt = (C.c_int64 * 8)()
         self._chk(self.lib.mgn_profile_read(self.h, ms, cnt))
-        names = ["edge_step", "node_step", "encode", "decode", "halo"]
+        names = ["edge_step", "node_step", "encode", "decode", "halo", "edge_boundary"]
         return {n: dict(avg_ms=ms[i], count=cnt[i]) for i, n in enumerate(names)}
 
 
@@ -499,34 +508,49 @@ def run_processor_staged(engines, exchange, nsteps, begin=True, overlap=None):
 
     overlap (default: on when the engines and the exchange support it): owned nodes are numbered boundary-first,
     so the projection of the boundary tiles runs first, the exchange is started (exchange.start(): pack + async
-    all-to-all-v) and the interior tiles are projected while the rows are on the wire (exchange.finish())."""
+    all-to-all-v) and the interior tiles are projected while the rows are on the wire; the next edge step then runs
+    its interior tiles (no halo sender) first and only its few boundary tiles after exchange.finish()."""
     if nsteps <= 0:
         return
     if overlap is None:
         overlap = all(hasattr(e, "proc_node_phase") for e in engines) and hasattr(exchange, "start")
 
-    def project_and_exchange(k):        # k = -1: projection for step 0 (proc_begin)
+    edge_split = overlap and all(hasattr(e, "proc_edge_phase") for e in engines)
+
+    def project_and_start(k):           # k = -1: projection for step 0 (proc_begin); leaves the exchange in flight
         if overlap:
             for e in engines:
                 e.proc_node_phase(k, 1)
             exchange.start()
             for e in engines:
                 e.proc_node_phase(k, 2)
-            exchange.finish()
         else:
             for e in engines:
                 e.proc_begin() if k < 0 else e.proc_node(k, True)
-            exchange()
+            exchange.start() if hasattr(exchange, "start") else exchange()
+
+    def finish():
+        if hasattr(exchange, "finish"):
+            exchange.finish()
 
     if begin:
-        project_and_exchange(-1)
+        project_and_start(-1)
     else:
-        exchange()
+        exchange.start() if hasattr(exchange, "start") else exchange()
     for k in range(nsteps):
-        for e in engines:
-            e.proc_edge(k)
+        if edge_split:
+            # edges whose sender is owned run while the halo rows are on the wire; the few boundary tiles after them
+            for e in engines:
+                e.proc_edge_phase(k, 1)
+            finish()
+            for e in engines:
+                e.proc_edge_phase(k, 2)
+        else:
+            finish()
+            for e in engines:
+                e.proc_edge(k)
         if k + 1 < nsteps:
-            project_and_exchange(k)
+            project_and_start(k)
         else:
             for e in engines:
                 e.proc_node(k, False)

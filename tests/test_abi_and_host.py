@@ -223,3 +223,25 @@ def test_world_edges_native_matches_dense_search(lib_built):
     assert np.all(np.diff(key) > 0)                                               # sorted, no duplicates
     rev = np.isin(s3.astype(np.int64) * 200000 + r3, key)
     assert rev.all()                                                              # symmetric
+
+
+@pytest.mark.parametrize("P", [2, 4, 8])
+def test_edge_tiles_without_halo_senders(lib_built, P):
+    """Interior / boundary split of the edge step: every edge with a halo sender lies in the first
+    `boundary` 32-edge tiles; for a two-way mesh that is a small share of the tiles."""
+    pos, cells = synth.grid_mesh(60, 50, 7)
+    s, r = synth.cells_to_edges(cells)
+    N = pos.shape[0]
+    for rk in range(P):
+        e = Engine(9, 3, 2, rank=rk, nranks=P, device=MGN_DEVICE_NONE)
+        e.set_graph(s, r, N, mesh_pos=pos)
+        tb, nt = e.edge_boundary_tiles()
+        snd, rcv, rowptr = e.local_graph()
+        assert nt == (snd.size + 31) // 32 and 0 < tb <= nt
+        assert np.all(snd[tb * 32:] < e.n_own)                        # no halo sender beyond the boundary tiles
+        assert np.any(snd[max(0, (tb - 1) * 32): tb * 32] >= e.n_own)  # and the last boundary tile has one
+        assert np.all(rcv[snd >= e.n_own] < e.boundary_count())       # such edges end at boundary nodes (numbered first)
+        assert tb <= max(4, nt // 3)
+    one = Engine(9, 3, 2, device=MGN_DEVICE_NONE)
+    one.set_graph(s, r, N)
+    assert one.edge_boundary_tiles() == (0, (s.size + 31) // 32)

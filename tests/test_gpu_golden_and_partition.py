@@ -334,3 +334,50 @@ def test_set_static_fast_rhs_equals_one_shot(dtype):
     eng.set_norms(**norms)                                # invalidates the cache
     with pytest.raises(MgnError):
         eng.ode_step(x)
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_edge_phases_equal_whole_edge_step(dtype):
+    """mgn_proc_edge_phase(k, 1) + (k, 2) == mgn_proc_edge(k), bitwise, on a partition with halo senders (a receiver run
+    may straddle the boundary between the two tile ranges: the carry rows take care of it)."""
+    halo = import_module("mgn_amd.halo")
+    cfg = cfg_dict(mps=2)
+    pos, cells = synth.grid_mesh(40, 36, 5)
+    s, r = synth.cells_to_edges(cells)
+    N, E = pos.shape[0], s.size
+    ps = make_params(cfg)
+    rng = np.random.default_rng(8)
+    v0, e0 = rng.standard_normal((N, 128)).astype(np.float32), rng.standard_normal((E, 128)).astype(np.float32)
+    stream = torch.cuda.current_stream().cuda_stream
+    results = []
+    for split in (False, True):
+        engs = []
+        for k in range(3):
+            g = engine_for(cfg, rank=k, nranks=3, dtype=dtype)
+            g.set_stream(stream)
+            g.set_params(ps)
+            g.set_graph(s, r, N, mesh_pos=pos)
+            g.latents_import(v0, e0)
+            engs.append(g)
+        tb, nt = engs[1].edge_boundary_tiles()
+        assert 0 < tb < nt
+        ex = halo.LoopbackExchange(engs, torch.device("cuda"))
+        for g in engs:
+            g.proc_begin()
+        ex()
+        for g in engs:
+            if split:
+                g.proc_edge_phase(0, 1)
+                g.proc_edge_phase(0, 2)
+            else:
+                g.proc_edge(0)
+            g.proc_node(0, False)
+        torch.cuda.synchronize()
+        v, e = np.zeros((N, 128), np.float32), np.zeros((E, 128), np.float32)
+        for g in engs:
+            g.latents_export(v, e)
+        results.append((v, e))
+    assert np.array_equal(results[0][0], results[1][0]) and np.array_equal(results[0][1], results[1][1])
+    if dtype == "f32":
+        rv, re = orc.processor_steps(ps, cfg, v0, e0, s, r, 1)
+        assert rel_max(results[1][0], rv) <= TOL_STEP and rel_max(results[1][1], re) <= TOL_STEP
