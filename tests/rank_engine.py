@@ -59,14 +59,30 @@ class OracleRankEngine:
     def proc_begin(self):
         self._project(0)
 
-    def proc_edge(self, k):
+    def _edge_range(self, k, lo, hi):
         p = self.P_["proc%d_edge" % k]
         L = self.cfg["L"]
-        h1 = np.maximum(self.P[self.snd] + self.Q[self.rcv] + self.E @ p["W1"][2 * L:], 0.0)
+        sl = slice(lo, hi)
+        h1 = np.maximum(self.P[self.snd[sl]] + self.Q[self.rcv[sl]] + self.E[sl] @ p["W1"][2 * L:], 0.0)
         h2 = np.maximum(h1 @ p["W2"] + p["b2"], 0.0)
         en = orc.layer_norm(h2 @ p["W3"] + p["b3"], p["ln_scale"], p["ln_bias"])
-        self.agg = orc.scatter_add(en, self.rcv, self.n_own)
-        self.E = self.E + en
+        self.agg += orc.scatter_add(en, self.rcv[sl], self.n_own)
+        self.E[sl] = self.E[sl] + en
+
+    def proc_edge(self, k):
+        self.agg = np.zeros((self.n_own, self.cfg["L"]))
+        self._edge_range(k, 0, self.eid.size)
+
+    def proc_edge_phase(self, k, phase):
+        """phase 1: the edge tiles without halo senders (runs BEFORE the halo rows have arrived: they are poisoned with
+        NaN until halo_unpack_tensor, so a misplaced edge would show); phase 2: the boundary tiles."""
+        tb, _ = self.part.edge_boundary_tiles()
+        cut = min(tb * 32, self.eid.size)
+        if phase == 1:
+            self.agg = np.zeros((self.n_own, self.cfg["L"]))
+            self._edge_range(k, cut, self.eid.size)
+        else:
+            self._edge_range(k, 0, cut)
 
     def proc_node(self, k, project_next):
         vn = orc.mlp(np.concatenate([self.V, self.agg], 1), self.P_["proc%d_node" % k], self.h)
@@ -78,6 +94,7 @@ class OracleRankEngine:
         import torch
         if self.send_idx.size:
             t[: self.send_idx.size] = torch.from_numpy(self.P[self.send_idx].astype(np.float32))
+        self.P[self.n_own:] = np.nan          # stale halo rows must not be read before the exchange has finished
 
     def halo_unpack_tensor(self, t):
         if self.n_halo:
