@@ -242,6 +242,8 @@ def main():
             "roofline": {
                 "bound": "mfma", "kernel": "k_edge_step<4,2> (fused gather + edge MLP + LayerNorm + residual + segmented scatter)",
                 "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS,
+                "sustained_peak_measured": 138.7, "frac_of_sustained": ach / 138.7,
+                "sustained_note": "tools/mfma_probe.hip: back-to-back v_mfma_f32_32x32x2_f32 chains alone reach 138.7 TFLOP/s on this part (DESIGN.md section 4)",
                 "flops_per_launch": flops_edge_kernel(e_loc), "flops_kind": "MFMA flops executed by this kernel (98 304 per edge; "
                 "layer 1 is factored so the v_s/v_r blocks run per node in k_node_step)",
                 "avg_launch_ms": t_edge * 1e3, "launches": prof["edge_step"]["count"],
