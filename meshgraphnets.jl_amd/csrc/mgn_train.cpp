@@ -3,6 +3,7 @@
 // Host orchestration only -- weights repacked into training order (forward and transposed chunks), an arena of kept
 // activations, kernel sequencing; all arithmetic is in train.hip.  No CPU compute path.
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <numeric>
 
@@ -27,6 +28,7 @@ struct TrainMlp {
 
 struct TrainState {
     bool packed = false, graph_ready = false;
+    bool recompute = false;      // processor MLPs keep only their inputs; H1 / H2 / Y are recomputed in the reverse pass
     DevBuf w;                    // training-order weights
     std::vector<TrainMlp> mlp;   // 0 enc-node, 1 enc-edge, 2+2k edge k, 3+2k node k, last decoder
     DevBuf arena, idx, grads, target, mask, loss;
@@ -163,8 +165,22 @@ int prepare_graph(mgn_engine* h) {
     T.agg.assign(mps, 0);
     T.Vk[0] = take(NL);
     T.Ek[0] = take(EL);
+    // Kept activations of the processor: 3 (E + N) L floats per step when H1 / H2 / Y are stored.  Large meshes switch to
+    // recomputation (one more forward per MLP in the reverse pass, (E + 2 N) L floats per step kept): 15 steps of M-1M
+    // then need 61 GB instead of 270 GB.  MGN_TRAIN_RECOMPUTE = 0 / 1 overrides the size rule.
+    {
+        const double stored = (double)mps * 3.0 * ((double)EL + (double)NL) * 4.0;
+        T.recompute = stored > 48e9;
+        if (const char* e = getenv("MGN_TRAIN_RECOMPUTE")) T.recompute = atoi(e) != 0;
+    }
+    size_t shared_e[3] = {0, 0, 0}, shared_n[3] = {0, 0, 0};
+    if (T.recompute)
+        for (int i = 0; i < 3; ++i) { shared_e[i] = take(EL); shared_n[i] = take(NL); }
     for (int k = 0; k < mps; ++k) {
-        for (int i = 0; i < 3; ++i) { T.eH[i][k] = take(EL); T.nH[i][k] = take(NL); }
+        for (int i = 0; i < 3; ++i) {
+            T.eH[i][k] = T.recompute ? shared_e[i] : take(EL);
+            T.nH[i][k] = T.recompute ? shared_n[i] : take(NL);
+        }
         T.agg[k] = take(NL);
         T.Ek[k + 1] = take(EL);
         T.Vk[k + 1] = take(NL);
@@ -380,6 +396,12 @@ int train_run(mgn_handle* h, const TrainJob& J) {
         const TrainMlp& me = T.mlp[2 + 2 * k];
         const TrainMlp& mn = T.mlp[3 + 2 * k];
         const int nxt = cur ^ 1, enxt = ecur ^ 1;
+        if (T.recompute) {   // regenerate H1, H2, Y of both MLPs of this step from their kept inputs
+            HIPCHK(h, fwd(mn, N, nt_n, A + T.Vk[k], nullptr, A + T.agg[k], nullptr, nullptr, nullptr, T.nH[0][k], T.nH[1][k], T.nH[2][k], nullptr,
+                          nullptr, nullptr));
+            HIPCHK(h, fwd(me, E, nt_e, A + T.Vk[k], snd, A + T.Vk[k], rcv, A + T.Ek[k], nullptr, T.eH[0][k], T.eH[1][k], T.eH[2][k], nullptr,
+                          nullptr, nullptr));
+        }
         {   // node MLP: v_{k+1} = v_k + MLP_v([v_k; agg_k])
             float* gx[3] = {A + T.gV[nxt], A + T.gAgg, nullptr};
             const float* gxadd[3] = {A + T.gV[cur], nullptr, nullptr};

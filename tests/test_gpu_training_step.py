@@ -191,3 +191,22 @@ def test_ode_vjp_matches_oracle_and_ode_step():
                                           - eng.ode_step(x - eps * d, onehot, ef_raw, vm))).sum() / (2 * eps))
     an = float((xbar.astype(np.float64) * d).sum())
     assert abs(fd - an) <= 0.2 * abs(an), (fd, an)
+
+
+def test_recompute_mode_gives_the_same_gradients(monkeypatch):
+    """Large meshes keep only the inputs of the processor MLPs and recompute H1 / H2 / Y in the reverse pass
+    (MGN_TRAIN_RECOMPUTE forces the mode): same forward arithmetic, so loss and gradients are bitwise equal."""
+    cfg = cfg_dict(L=128, mps=3)
+    pos, s, r = small_mesh(12, 9)
+    ps = make_params(cfg)
+    nf, ef, target, mask = problem(cfg, pos, s, r, seed=21)
+    res = []
+    for mode in ("0", "1"):
+        monkeypatch.setenv("MGN_TRAIN_RECOMPUTE", mode)
+        eng = engine_for(cfg)
+        eng.set_params(ps)
+        eng.set_graph(s, r, pos.shape[0])
+        res.append(eng.step(nf, ef, target, mask))
+    assert res[0][1] == res[1][1] and np.array_equal(res[0][0], res[1][0])
+    ref, _ = orc.step_grads(ps, cfg, nf, ef, s, r, target, mask)
+    check_grads(res[1][0], ref, cfg)
