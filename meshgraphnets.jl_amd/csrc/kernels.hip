@@ -1197,6 +1197,7 @@ static int resident_chunks(int L, int want) {
 static int g_path = [] { const char* e = getenv("MGN_KERNEL_PATH"); return e ? atoi(e) : 0; }();   // experiments
 int set_kernel_path(int p) { const int old = g_path; g_path = p; return old; }
 static bool small_launch(int ntiles) { return g_path == 0 ? ntiles <= 4 * num_cus() : g_path >= 2; }
+bool launch_is_small(int ntiles) { return small_launch(ntiles); }
 
 static LaunchCfg tile_launch(int L, int ntiles, int nres) {
     LaunchCfg lc;

@@ -991,7 +991,9 @@ int mgn_proc_node(mgn_handle* h, int32_t k, int32_t project_next) {
             if (int rc = project_set(h, k, q)) return rc;
         return MGN_OK;
     }
-    if (project_next && (h->node_split || h->nsets > 1)) {
+    // large meshes: MLP and projection as two launches (the projection then has both of its chunks LDS-resident);
+    // small meshes are launch-latency-bound: one fused launch (M-cyl: 53.0 -> 50.8 us per step)
+    if (project_next && (h->nsets > 1 || (h->node_split && !launch_is_small(h->ntiles_n)))) {
         // MLP (2 of its chunks LDS-resident, the others stream from L2), then per edge set the projection with both of
         // its chunks resident
         HIPCHK(h, launch_node_step(h->cfg.L, node_args(h, k, 0), h->stream));
