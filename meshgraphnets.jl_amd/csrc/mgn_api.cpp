@@ -128,24 +128,8 @@ inline uint16_t f32_to_bf16(float f) {   // round to nearest even (inputs are fi
     u += 0x7FFFu + ((u >> 16) & 1u);
     return (uint16_t)(u >> 16);
 }
-inline float bf16_to_f32(uint16_t b) {
-    const uint32_t u = (uint32_t)b << 16;
-    float f;
-    memcpy(&f, &u, 4);
-    return f;
-}
 // feature held by element j of piece (s, hh) of a bf16 row fragment (see kernels.hip, bf16 section)
 inline int bf_feature(int sidx, int hh, int j) { return 32 * (sidx >> 1) + 16 * (sidx & 1) + 8 * (j >> 2) + 4 * hh + (j & 3); }
-// inverse: position of feature f inside a 128-wide bf16 row (piece 2s+hh, element j)
-inline int bf_row_pos(int f) {
-    const int t = f >> 5, rem = f & 31, sidx = 2 * t + (rem >> 4), r2 = rem & 15, hh = (r2 >> 2) & 1, j = 4 * (r2 >> 3) + (r2 & 3);
-    return (2 * sidx + hh) * 8 + j;
-}
-inline size_t bf_tile_index(int64_t row, int f) {
-    const int64_t tile = row / TILE;
-    const int c = (int)(row % TILE), pos = bf_row_pos(f), piece = pos >> 3, j = pos & 7, sidx = piece >> 1, hh = piece & 1;
-    return (size_t)tile * TILE * 128 + ((size_t)sidx * 64 + 32 * hh + c) * 8 + j;
-}
 // 128 x 128 chunk of W (row-major [K][ldw], rows kbase..) -> bf16 fragment order [s][t][lane][8]
 void pack_chunk_bf16(uint16_t* dst, const float* W, int ldw, int kbase) {
     for (int sidx = 0; sidx < 8; ++sidx)
@@ -189,13 +173,6 @@ const float* W(const mgn_engine* h, size_t off) { return h->wfrag.as<float>() + 
 // tile-major storage: rows padded to whole 32-row tiles
 size_t tile_floats(int64_t ntiles, int L) { return (size_t)ntiles * TILE * L; }
 
-// host <-> tile-major conversion of one row (see kernels.hip "fragment <-> memory helpers")
-inline size_t tile_index(int64_t row, int f, int L) {
-    const int64_t tile = row / TILE;
-    const int c = (int)(row % TILE);
-    const int m = 4 * (f >> 5) + ((f & 31) >> 3), hh = (f & 7) >> 2, i = f & 3;
-    return (size_t)tile * TILE * L + (size_t)m * 256 + (size_t)(32 * hh + c) * 4 + i;
-}
 
 inline int64_t tiles_or_one(int32_t nt) { return nt > 0 ? nt : 1; }
 
