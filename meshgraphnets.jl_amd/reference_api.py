@@ -322,3 +322,35 @@ def load_dataset(path, is_training):
     if not os.path.isfile(file):
         raise FileNotFoundError(file)
     return meta, (parse_data(ex, meta) for ex in TFRecordReader(file))
+
+
+# ---- solver-based training (second half) --------------------------------------------------------------
+def solver_training_euler(rhs, vjp, x0, gt, dt, val_mask, n_scale):
+    """What train_step(::SolverStrategy) computes for SolverTraining with a fixed-step Euler solver (reference
+    src/strategies.jl:175-196, 257-292), written as the discrete adjoint the sensitivity algorithm evaluates through VJPs of
+    the right-hand side:
+        x_{k+1} = x_k + dt f(x_k),   loss = mean(((n_norm(gt_k) - n_norm(x_k)) ^ 2) .* val_mask)  over k = 0..K, nodes, fields
+        a_K = dL/dx_K;   a_k = dL/dx_k + a_{k+1} + dt J_x(x_k)^T a_{k+1};   gs = sum_k dt J_p(x_k)^T a_{k+1}
+    rhs(x) -> f(x) [N][O];  vjp(x, lam) -> (lam^T df/dx, lam^T df/dps)  (Engine.ode_step / Engine.ode_vjp with the static
+    inputs bound);  gt [K+1][N][O];  n_scale [O]: scale of the field normaliser (its shift cancels in the difference).
+    Returns (gs, loss, xs)."""
+    gt = np.asarray(gt, np.float64)
+    K = gt.shape[0] - 1
+    vm = np.asarray(val_mask, np.float64).reshape(-1, 1)
+    sc = np.asarray(n_scale, np.float64).reshape(1, -1)
+    xs = [np.asarray(x0, np.float64)]
+    for _ in range(K):
+        xs.append(xs[-1] + dt * np.asarray(rhs(xs[-1].astype(F32)), np.float64))
+    count = float((K + 1) * gt.shape[1] * gt.shape[2])
+    loss = float(sum((((gt[k] - xs[k]) * sc) ** 2 * vm).sum() for k in range(K + 1)) / count)
+
+    def dl_dx(k):
+        return -2.0 * sc * sc * (gt[k] - xs[k]) * vm / count
+
+    a = dl_dx(K)
+    gs = None
+    for k in range(K - 1, -1, -1):
+        xbar, g = vjp(xs[k].astype(F32), (dt * a).astype(F32))
+        gs = np.asarray(g, np.float64) if gs is None else gs + g
+        a = dl_dx(k) + a + np.asarray(xbar, np.float64)
+    return gs, loss, xs

@@ -210,3 +210,56 @@ def test_recompute_mode_gives_the_same_gradients(monkeypatch):
     assert res[0][1] == res[1][1] and np.array_equal(res[0][0], res[1][0])
     ref, _ = orc.step_grads(ps, cfg, nf, ef, s, r, target, mask)
     check_grads(res[1][0], ref, cfg)
+
+
+def test_solver_training_euler_discrete_adjoint():
+    """train_step(::SolverTraining) with fixed-step Euler (reference src/strategies.jl:175-196, 257-292) through
+    mgn_ode_step + mgn_ode_vjp, against the same discrete adjoint driven by the float64 oracle, and against a central
+    difference of the oracle's own loss in one parameter direction."""
+    from mgn_amd import reference_api as ra
+    cfg = cfg_dict(L=64, mps=2)
+    pos, cells, node_type, vel = synth.mesh_cyl(1234, 150)
+    s, r = synth.cells_to_edges(cells)
+    N = pos.shape[0]
+    ps = make_params(cfg).astype(np.float32)
+    rng = np.random.default_rng(6)
+    onehot = orc.one_hot(node_type, 7, 0).astype(np.float32)
+    ef_raw = orc.edge_features(pos, s, r).astype(np.float32)
+    K, dt = 4, 0.01
+    gt = (vel[None] * (1.0 + 0.05 * rng.standard_normal((K + 1, N, 2)))).astype(np.float32)
+    n_norm = orc.NormMeanStd(np.array([1.0, 0.1]), np.array([0.4, 0.2]))
+    t_norm = orc.NormMinMax(0.0, 1.0)
+    e_norm = orc.NormMeanStd(ef_raw.mean(0), ef_raw.std(0))
+    o_norm = orc.NormMeanStd(np.array([0.01, -0.02]), np.array([5.0, 4.0]))
+    vm = np.isin(node_type, [0, 5]).astype(np.float32)
+    ns, nsh = n_norm.affine(2)
+    ts, tsh = t_norm.affine(7)
+    es, esh = e_norm.affine(3)
+    eng = engine_for(cfg)
+    eng.set_params(ps)
+    eng.set_graph(s, r, N)
+    eng.set_norms(node=(np.concatenate([ns, ts]), np.concatenate([nsh, tsh])), edge=(es, esh), out=(o_norm.std, o_norm.mean))
+
+    gs, loss, xs = ra.solver_training_euler(lambda x: eng.ode_step(x, onehot, ef_raw, vm),
+                                            lambda x, lam: eng.ode_vjp(x, onehot, ef_raw, lam, val_mask=vm)[:2], gt[0], gt, dt, vm, ns)
+
+    def o_rhs(p):
+        return lambda x: orc.ode_rhs(p, cfg, x, onehot, ef_raw, s, r, n_norm, t_norm, e_norm, o_norm, vm[:, None].astype(np.float64))
+
+    def o_vjp(x, lam):
+        return orc.ode_vjp(ps, cfg, x, onehot, ef_raw, s, r, n_norm, t_norm, e_norm, o_norm, vm, lam)[:2]
+
+    gs_o, loss_o, xs_o = ra.solver_training_euler(o_rhs(ps), o_vjp, gt[0], gt, dt, vm, ns)
+    assert abs(loss - loss_o) <= 1e-4 * abs(loss_o), (loss, loss_o)
+    assert rel_max(xs[-1], xs_o[-1]) <= 1e-4
+    assert np.linalg.norm(gs - gs_o) <= 5e-3 * np.linalg.norm(gs_o), np.linalg.norm(gs - gs_o) / np.linalg.norm(gs_o)
+    # the adjoint really is the gradient of that loss: directional central difference on the float64 oracle
+    d = rng.standard_normal(ps.size)
+    d /= np.linalg.norm(d)
+    eps = 1e-4
+
+    def loss_at(p):
+        return ra.solver_training_euler(o_rhs(p), lambda x, lam: (np.zeros_like(x), np.zeros(ps.size)), gt[0], gt, dt, vm, ns)[1]
+
+    fd = (loss_at(ps.astype(np.float64) + eps * d) - loss_at(ps.astype(np.float64) - eps * d)) / (2 * eps)
+    assert abs(fd - float(gs_o @ d)) <= 1e-3 * max(abs(fd), 1e-9), (fd, float(gs_o @ d))
