@@ -1,8 +1,11 @@
 """Randomised parity sweep (seeded, reproducible): widths, depths and ragged graphs the fixed tests do not name --
 forward, device-resident processor steps, fused RHS and the training step against the float64 oracle.
 Run on the MI355X box with `-m gpu`."""
+import os
+
 import numpy as np
 import pytest
+import torch   # before the engine's first HIP call (the fp32 cross-check below runs on cuda)
 
 import mgn_amd
 import mgn_oracle as orc
@@ -10,6 +13,7 @@ from mgn_amd import synth
 from util import TOL_15, rel_max, set_kernel_path
 
 pytestmark = pytest.mark.gpu
+SWEEP = int(os.environ.get("MGN_SWEEP", "12"))   # more seeds for an occasional soak: MGN_SWEEP=200 pytest ...
 
 
 def draw(seed):
@@ -27,7 +31,7 @@ def draw(seed):
     return rng, cfg, N, E, s, r, ps
 
 
-@pytest.mark.parametrize("seed", range(12))
+@pytest.mark.parametrize("seed", range(SWEEP))
 def test_random_forward_and_processor(seed):
     rng, cfg, N, E, s, r, ps = draw(seed)
     path = int(rng.integers(0, 4)) if cfg["L"] == 128 else 0
@@ -54,7 +58,7 @@ def test_random_forward_and_processor(seed):
         set_kernel_path(old)
 
 
-@pytest.mark.parametrize("seed", range(6))
+@pytest.mark.parametrize("seed", range(max(6, SWEEP // 2)))
 def test_random_training_step(seed):
     rng, cfg, N, E, s, r, ps = draw(100 + seed)
     eng = mgn_amd.Engine(cfg["Fn"], cfg["Fe"], cfg["O"], cfg["L"], 2, cfg["mps"])
@@ -67,5 +71,13 @@ def test_random_training_step(seed):
     gs, loss = eng.step(nf, ef, target, mask)
     ref, ref_loss = orc.step_grads(ps, cfg, nf, ef, s, r, target, mask)
     assert abs(loss - ref_loss) <= 1e-5 * max(abs(ref_loss), 1e-6), (cfg, N, E)
-    # robust to a ReLU unit sitting on its kink (see test_gpu_training_step.py): relative L2 over the whole gradient
-    assert np.linalg.norm(gs - ref) <= 2e-3 * np.linalg.norm(ref), (cfg, N, E, np.linalg.norm(gs - ref) / np.linalg.norm(ref))
+    # fp32 against float64: a ReLU pre-activation within fp32 rounding of zero, or a hub with a thousand incoming edges,
+    # can move the whole gradient by a few 1e-3 -- in EVERY fp32 implementation alike (seen: engine, PyTorch fp32 on GPU
+    # and on CPU all 3.4e-3 from float64 and 3e-7 from each other).  So: close to float64, or else indistinguishable from
+    # the independent PyTorch fp32 restatement.
+    err64 = np.linalg.norm(gs - ref) / np.linalg.norm(ref)
+    if err64 > 2e-3:
+        import torch_reference as tr
+        g32, _ = tr.step(ps, cfg, nf, ef, s, r, target, mask, dtype=torch.float32, device="cuda")
+        err32 = np.linalg.norm(gs - g32) / np.linalg.norm(ref)
+        assert err32 <= 1e-4 and err64 <= 5e-2, (cfg, N, E, err64, err32)
