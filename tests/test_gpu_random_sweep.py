@@ -81,3 +81,27 @@ def test_random_training_step(seed):
         g32, _ = tr.step(ps, cfg, nf, ef, s, r, target, mask, dtype=torch.float32, device="cuda")
         err32 = np.linalg.norm(gs - g32) / np.linalg.norm(ref)
         assert err32 <= 1e-4 and err64 <= 5e-2, (cfg, N, E, err64, err32)
+
+
+@pytest.mark.parametrize("seed", range(max(6, SWEEP // 4)))
+def test_random_bf16_band(seed):
+    """bf16 mode (L = 128) on the same random family: relative L2 of the latents within the stated 3e-2 band after up to 4
+    steps."""
+    rng = np.random.default_rng(5000 + seed)
+    cfg = dict(Fn=int(rng.integers(2, 13)), Fe=int(rng.integers(1, 8)), O=int(rng.integers(1, 4)), L=128, hidden_layers=2,
+               mps=int(rng.integers(1, 5)))
+    N = int(rng.integers(2, 500))
+    E = int(rng.integers(1, 4000))
+    s, r = synth.random_graph(N, E, seed)
+    ps = orc.init_params(cfg["Fn"], cfg["Fe"], cfg["O"], 128, 2, cfg["mps"], seed=seed, ln_jitter=0.05)
+    v = rng.standard_normal((N, 128)).astype(np.float32)
+    e = rng.standard_normal((E, 128)).astype(np.float32)
+    eng = mgn_amd.Engine(cfg["Fn"], cfg["Fe"], cfg["O"], 128, 2, cfg["mps"], dtype="bf16")
+    eng.set_params(ps)
+    eng.set_graph(s, r, N)
+    eng.latents_import(v, e)
+    eng.processor_steps_dev(cfg["mps"])
+    v1, e1 = eng.latents_export()
+    rv, re = orc.processor_steps(ps, cfg, v, e, s, r, cfg["mps"])
+    l2 = lambda a, b: float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
+    assert l2(v1, rv) <= 3e-2 and l2(e1, re) <= 3e-2, (cfg, N, E, l2(v1, rv), l2(e1, re))
