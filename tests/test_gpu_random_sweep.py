@@ -105,3 +105,37 @@ def test_random_bf16_band(seed):
     rv, re = orc.processor_steps(ps, cfg, v, e, s, r, cfg["mps"])
     l2 = lambda a, b: float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
     assert l2(v1, rv) <= 3e-2 and l2(e1, re) <= 3e-2, (cfg, N, E, l2(v1, rv), l2(e1, re))
+
+
+@pytest.mark.parametrize("seed", range(max(8, SWEEP // 4)))
+def test_random_partitions_loopback(seed):
+    """Random graphs cut into 2..5 index-block partitions (no positions; some parts may have no halo, no edges, or fewer
+    than 32 nodes), driven by the staged driver with the split edge step: the merged result equals the single-domain oracle."""
+    from importlib import import_module
+    halo = import_module("mgn_amd.halo")
+    rng = np.random.default_rng(9000 + seed)
+    L = int(rng.choice([32, 64, 128]))
+    cfg = dict(Fn=9, Fe=3, O=2, L=L, hidden_layers=2, mps=int(rng.integers(1, 4)))
+    N = int(rng.integers(6, 300))
+    E = int(rng.integers(0, 2500))
+    P = int(rng.integers(2, 6))
+    s, r = synth.random_graph(N, E, seed)
+    ps = orc.init_params(9, 3, 2, L, 2, cfg["mps"], seed=seed, ln_jitter=0.1)
+    v0 = rng.standard_normal((N, L)).astype(np.float32)
+    e0 = rng.standard_normal((E, L)).astype(np.float32)
+    stream = torch.cuda.current_stream().cuda_stream
+    engs = []
+    for k in range(P):
+        g = mgn_amd.Engine(9, 3, 2, L, 2, cfg["mps"], rank=k, nranks=P)
+        g.set_stream(stream)
+        g.set_params(ps)
+        g.set_graph(s, r, N)
+        g.latents_import(v0, e0)
+        engs.append(g)
+    mgn_amd.run_processor_staged(engs, halo.LoopbackExchange(engs, torch.device("cuda")), cfg["mps"])
+    torch.cuda.synchronize()
+    v, e = np.zeros((N, L), np.float32), np.zeros((E, L), np.float32)
+    for g in engs:
+        g.latents_export(v, e)
+    rv, re = orc.processor_steps(ps, cfg, v0, e0, s, r, cfg["mps"])
+    assert rel_max(v, rv) <= TOL_15 and (E == 0 or rel_max(e, re) <= TOL_15), (cfg, N, E, P)
