@@ -226,7 +226,10 @@ __global__ __launch_bounds__(256) void k_mlp_bwd(const TrainBwdArgs a) {
 // half wave), B operand = G (lane (n, k) reads G[row 2q+k][32 tj + n]).  Wave ti of a block owns input-feature block ti
 // and all NT output blocks; a block owns a contiguous row range and writes its partial dW (and the column sums of G).
 // ================================================================================================
-constexpr int WG_ROWS = 32;    // rows per block at least (small meshes: many short blocks, the loads are latency-bound)
+#ifndef MGN_WG_ROWS
+#define MGN_WG_ROWS 64
+#endif
+constexpr int WG_ROWS = MGN_WG_ROWS;    // rows per block at least (small meshes: many short blocks, the loads are latency-bound)
 constexpr int WG_UNROLL = 8;   // k-steps (2 rows each) whose loads are issued together
 
 template <int NT>
