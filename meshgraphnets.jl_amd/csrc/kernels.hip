@@ -382,20 +382,32 @@ __global__ __launch_bounds__(MGN_PROJ_WAVES * 64, MGN_PROJ_WAVES / 4) void k_pro
 #endif
 constexpr int COOP_PF = MGN_COOP_PF;   // weight ring depth in 16-byte fragments (4 k-steps each)
 
-// wt: this wave's t-slice of a chunk in t-major order [j/4][lane][4]
-DEVINL void coop_chain(f32x16& acc, const f32x16 (&in)[4], const float* wt, int lane) {
+// wt: this wave's t-slice of a chunk in t-major order [j/4][lane][4].  The weight ring of a chain can be primed ahead of
+// time (coop_prime) -- before the previous chain or the exchange barrier -- so that the first fragments' L2 latency
+// (~1.5 k cycles per chain on a small mesh, where nothing else hides it) is off the critical path.
+struct CoopRing {
+    f32x4 r[COOP_PF];
+};
+DEVINL void coop_prime(CoopRing& ring, const float* wt, int lane) {
     const f32x4* wv = reinterpret_cast<const f32x4*>(wt) + lane;
-    f32x4 ring[COOP_PF];
 #pragma unroll
-    for (int p = 0; p < COOP_PF; ++p) ring[p] = wv[p * 64];
+    for (int p = 0; p < COOP_PF; ++p) ring.r[p] = wv[p * 64];
+}
+DEVINL void coop_chain_primed(f32x16& acc, const f32x16 (&in)[4], const float* wt, int lane, CoopRing& ring) {
+    const f32x4* wv = reinterpret_cast<const f32x4*>(wt) + lane;
 #pragma unroll
     for (int m = 0; m < 16; ++m) {
-        const f32x4 a = ring[m % COOP_PF];
-        if (m + COOP_PF < 16) ring[m % COOP_PF] = wv[(m + COOP_PF) * 64];
+        const f32x4 a = ring.r[m % COOP_PF];
+        if (m + COOP_PF < 16) ring.r[m % COOP_PF] = wv[(m + COOP_PF) * 64];
 #pragma unroll
         for (int i = 0; i < 4; ++i)
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], in[m >> 2][4 * (m & 3) + i], acc, 0, 0, 0);
     }
+}
+DEVINL void coop_chain(f32x16& acc, const f32x16 (&in)[4], const float* wt, int lane) {
+    CoopRing ring;
+    coop_prime(ring, wt, lane);
+    coop_chain_primed(acc, in, wt, lane, ring);
 }
 
 // every wave publishes its 16-register slice and reads back the full 64-register row fragment
@@ -451,18 +463,23 @@ DEVINL void coop_layer_norm(f32x16& mine, const f32x16 (&full)[4], const float* 
 // chunk_t[0]=W2 [1]=W3 [2]=W1e  (t-major)
 __global__ __launch_bounds__(256, 2) void k_edge_coop(const EdgeArgs a) {
     constexpr int L = 128;
+    const int stamp_tile = 0;
+    (void)stamp_tile;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     f32x4* xch0 = reinterpret_cast<f32x4*>(smem);
     f32x4* xch1 = xch0 + 16 * 64;
     float* tb = smem + 2 * 16 * 64 * 4;
-    copy_to_lds(tb, a.tabs, T_COUNT * L);
-    __syncthreads();
     const int lane0 = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int tq = wave;   // feature block owned by this wave
+    // the first tile's indices travel while the tables are copied (the gathers depend on them: a serial ~2 us otherwise)
+    EdgeIdx ix_first = load_edge_idx(a, a.tile0 + blockIdx.x < a.tile0 + a.ntiles ? a.tile0 + (int)blockIdx.x : a.tile0, lane0 & 31);
+    copy_to_lds(tb, a.tabs, T_COUNT * L);
+    __syncthreads();
+    STAMP(0);
     for (int tile = a.tile0 + blockIdx.x; tile < a.tile0 + a.ntiles; tile += gridDim.x) {
         OPAQUE_LANE();     // keeps the (loop-invariant) weight and table loads inside the tile loop
-        const EdgeIdx ix = load_edge_idx(a, tile, c);
+        const EdgeIdx ix = (tile == a.tile0 + (int)blockIdx.x) ? ix_first : load_edge_idx(a, tile, c);
         const bool valid = ix.r >= 0;
         const int r = valid ? ix.r : 0;
         f32x16 x[4], in[4], acc, xq;
@@ -475,19 +492,28 @@ __global__ __launch_bounds__(256, 2) void k_edge_coop(const EdgeArgs a) {
             load_quarter(qq, row_ptr(a.Q, r, L, h), STRIDE_ROW, tq);
             acc += qq;
         }
+        STAMP(1);
+        CoopRing ring2, ring3;
+        coop_prime(ring2, a.chunk_t[0] + tq * 4096, lane);                  // layer 2's first fragments, ahead of time
         coop_chain(acc, x, a.chunk_t[2] + tq * 4096, lane);                 // layer 1 (edge part)
+        STAMP(2);
         relu_quarter(acc);
+        coop_prime(ring3, a.chunk_t[1] + tq * 4096, lane);
         coop_exchange(in, acc, xch0, wave, lane);
+        STAMP(3);
         tab_quarter(acc, tb + T_B2 * L, tq, h);
-        coop_chain(acc, in, a.chunk_t[0] + tq * 4096, lane);                // layer 2
+        coop_chain_primed(acc, in, a.chunk_t[0] + tq * 4096, lane, ring2);  // layer 2
         relu_quarter(acc);
         coop_exchange(in, acc, xch1, wave, lane);
+        STAMP(4);
         tab_quarter(acc, tb + T_B3 * L, tq, h);
-        coop_chain(acc, in, a.chunk_t[1] + tq * 4096, lane);                // layer 3
+        coop_chain_primed(acc, in, a.chunk_t[1] + tq * 4096, lane, ring3);  // layer 3
         coop_exchange(in, acc, xch0, wave, lane);                           // full pre-LN row (for the statistics)
+        STAMP(5);
         coop_layer_norm(acc, in, tb + T_GAMMA * L, tb + T_BETA * L, tq, h); // acc = this wave's quarter of e'
         xq += acc;
         if (valid) store_quarter(etile, STRIDE_TILE, tq, xq);
+        STAMP(6);
         // segmented sum over runs of equal receiver, this wave's 16 registers
         const int reff = valid ? r : (-4 - c);
         const int rprev = __shfl_up(reff, 1, 32);
@@ -517,6 +543,7 @@ __global__ __launch_bounds__(256, 2) void k_edge_coop(const EdgeArgs a) {
         f32x4* dst = to_carry ? row_ptr(a.CARRY, (int64_t)2 * tile + (sl ? 0 : 1), L, h)
                               : tile_ptr(a.AGG, r >> 5, L, 32 * h + (r & 31));
         if (tail) store_quarter(dst, to_carry ? STRIDE_ROW : STRIDE_TILE, tq, acc);
+        STAMP(7);
         __syncthreads();   // xch0 is rewritten by the next tile's first exchange
     }
 }
@@ -545,34 +572,52 @@ __global__ __launch_bounds__(256, 2) void k_node_coop(const NodeArgs a) {
         load_quarter(vq, vtile, STRIDE_TILE, tq);
         if (a.mode != 2) {
             LOAD_AGGREGATE(4, in, a.rowptr, a.AGG, a.CARRY, a.zero_row);
+            // every chain's first weight fragments are requested one chain ahead (coop_prime)
+            CoopRing ra, rb;
             tab_quarter(acc, tb + T_B1 * L, tq, h);
+            coop_prime(ra, a.chunk_t[3] + tq * 4096, lane);
             coop_chain(acc, v, a.chunk_t[2] + tq * 4096, lane);             // layer 1, node part
-            coop_chain(acc, in, a.chunk_t[3] + tq * 4096, lane);            // layer 1, aggregate part
+            coop_prime(rb, a.chunk_t[0] + tq * 4096, lane);
+            coop_chain_primed(acc, in, a.chunk_t[3] + tq * 4096, lane, ra); // layer 1, aggregate part
             if constexpr (TWO_SETS) {                                       // second edge set's aggregate
                 LOAD_AGGREGATE(4, in, a.rowptr2, a.AGG2, a.CARRY2, a.zero_row2);
                 coop_chain(acc, in, a.chunk_t[6] + tq * 4096, lane);
             }
             relu_quarter(acc);
+            coop_prime(ra, a.chunk_t[1] + tq * 4096, lane);
             coop_exchange(in, acc, xch0, wave, lane);
             tab_quarter(acc, tb + T_B2 * L, tq, h);
-            coop_chain(acc, in, a.chunk_t[0] + tq * 4096, lane);            // layer 2
+            coop_chain_primed(acc, in, a.chunk_t[0] + tq * 4096, lane, rb); // layer 2
             relu_quarter(acc);
             coop_exchange(in, acc, xch1, wave, lane);
             tab_quarter(acc, tb + T_B3 * L, tq, h);
-            coop_chain(acc, in, a.chunk_t[1] + tq * 4096, lane);            // layer 3
+            if (a.mode == 1) coop_prime(rb, a.chunk_t[4] + tq * 4096, lane);
+            coop_chain_primed(acc, in, a.chunk_t[1] + tq * 4096, lane, ra); // layer 3
             coop_exchange(in, acc, xch0, wave, lane);
             coop_layer_norm(acc, in, tb + T_GAMMA * L, tb + T_BETA * L, tq, h);
             vq += acc;                                                      // v <- v + v'  (this wave's quarter)
             if (valid) store_quarter(vtile, STRIDE_TILE, tq, vq);
-            if (a.mode == 1) coop_exchange(v, vq, xch1, wave, lane);         // full updated row for the projection
+            if (a.mode == 1) {
+                coop_prime(ra, a.chunk_t[5] + tq * 4096, lane);
+                coop_exchange(v, vq, xch1, wave, lane);                      // full updated row for the projection
+#pragma unroll
+                for (int k = 0; k < 16; ++k) acc[k] = 0.f;
+                coop_chain_primed(acc, v, a.chunk_t[4] + tq * 4096, lane, rb);
+                if (valid) store_quarter(row_ptr(a.P, nn, L, h), STRIDE_ROW, tq, acc);
+                tab_quarter(acc, tb + T_BQ * L, tq, h);
+                coop_chain_primed(acc, v, a.chunk_t[5] + tq * 4096, lane, ra);
+                if (valid) store_quarter(row_ptr(a.Q, nn, L, h), STRIDE_ROW, tq, acc);
+            }
         }
-        if (a.mode != 0) {
+        if (a.mode == 2) {
+            CoopRing rq;
+            coop_prime(rq, a.chunk_t[5] + tq * 4096, lane);
 #pragma unroll
             for (int k = 0; k < 16; ++k) acc[k] = 0.f;
             coop_chain(acc, v, a.chunk_t[4] + tq * 4096, lane);
             if (valid) store_quarter(row_ptr(a.P, nn, L, h), STRIDE_ROW, tq, acc);
             tab_quarter(acc, tb + T_BQ * L, tq, h);
-            coop_chain(acc, v, a.chunk_t[5] + tq * 4096, lane);
+            coop_chain_primed(acc, v, a.chunk_t[5] + tq * 4096, lane, rq);
             if (valid) store_quarter(row_ptr(a.Q, nn, L, h), STRIDE_ROW, tq, acc);
         }
         __syncthreads();
