@@ -460,6 +460,29 @@ DEVINL void coop_layer_norm(f32x16& mine, const f32x16 (&full)[4], const float* 
     for (int k = 0; k < 16; ++k) mine[k] = (mine[k] - mean) * rstd * gq[k] + bq[k];
 }
 
+// same with gamma / beta quarters already in registers
+DEVINL void coop_layer_norm_reg(f32x16& mine, const f32x16 (&full)[4], const f32x16& gq, const f32x16& bq) {
+    float s = 0.f;
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int k = 0; k < 16; ++k) s += full[u][k];
+    s += __shfl_xor(s, 32, 64);
+    const float mean = s * (1.0f / 128);
+    float q = 0.f;
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const float d = full[u][k] - mean;
+            q += d * d;
+        }
+    q += __shfl_xor(q, 32, 64);
+    const float rstd = 1.0f / sqrtf(q * (1.0f / 128) + LN_EPS);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) mine[k] = (mine[k] - mean) * rstd * gq[k] + bq[k];
+}
+
 // chunk_t[0]=W2 [1]=W3 [2]=W1e  (t-major)
 __global__ __launch_bounds__(256, 2) void k_edge_coop(const EdgeArgs a) {
     constexpr int L = 128;
@@ -468,14 +491,21 @@ __global__ __launch_bounds__(256, 2) void k_edge_coop(const EdgeArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     f32x4* xch0 = reinterpret_cast<f32x4*>(smem);
     f32x4* xch1 = xch0 + 16 * 64;
-    float* tb = smem + 2 * 16 * 64 * 4;
     const int lane0 = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int tq = wave;   // feature block owned by this wave
     // the first tile's indices travel while the tables are copied (the gathers depend on them: a serial ~2 us otherwise)
     EdgeIdx ix_first = load_edge_idx(a, a.tile0 + blockIdx.x < a.tile0 + a.ntiles ? a.tile0 + (int)blockIdx.x : a.tile0, lane0 & 31);
-    copy_to_lds(tb, a.tabs, T_COUNT * L);
-    __syncthreads();
+    // this wave's quarters of the four tables it needs, straight from L2 into registers: no LDS copy, no barrier before the
+    // first tile (one tile per block on a small mesh: the prologue is on the critical path)
+    f32x16 b2q, b3q, gq, bq;
+    {
+        const int h0 = lane0 >> 5;
+        tab_quarter(b2q, a.tabs + T_B2 * L, tq, h0);
+        tab_quarter(b3q, a.tabs + T_B3 * L, tq, h0);
+        tab_quarter(gq, a.tabs + T_GAMMA * L, tq, h0);
+        tab_quarter(bq, a.tabs + T_BETA * L, tq, h0);
+    }
     STAMP(0);
     for (int tile = a.tile0 + blockIdx.x; tile < a.tile0 + a.ntiles; tile += gridDim.x) {
         OPAQUE_LANE();     // keeps the (loop-invariant) weight and table loads inside the tile loop
@@ -501,16 +531,16 @@ __global__ __launch_bounds__(256, 2) void k_edge_coop(const EdgeArgs a) {
         coop_prime(ring3, a.chunk_t[1] + tq * 4096, lane);
         coop_exchange(in, acc, xch0, wave, lane);
         STAMP(3);
-        tab_quarter(acc, tb + T_B2 * L, tq, h);
+        acc = b2q;
         coop_chain_primed(acc, in, a.chunk_t[0] + tq * 4096, lane, ring2);  // layer 2
         relu_quarter(acc);
         coop_exchange(in, acc, xch1, wave, lane);
         STAMP(4);
-        tab_quarter(acc, tb + T_B3 * L, tq, h);
+        acc = b3q;
         coop_chain_primed(acc, in, a.chunk_t[1] + tq * 4096, lane, ring3);  // layer 3
         coop_exchange(in, acc, xch0, wave, lane);                           // full pre-LN row (for the statistics)
         STAMP(5);
-        coop_layer_norm(acc, in, tb + T_GAMMA * L, tb + T_BETA * L, tq, h); // acc = this wave's quarter of e'
+        coop_layer_norm_reg(acc, in, gq, bq);                               // acc = this wave's quarter of e'
         xq += acc;
         if (valid) store_quarter(etile, STRIDE_TILE, tq, xq);
         STAMP(6);
