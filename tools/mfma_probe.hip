@@ -78,5 +78,10 @@ int main() {
     run("1 wave/SIMD, MFMA + 10 VALU each", probe<10, false>, 256, out, src);
     run("1 wave/SIMD, MFMA + 3 VALU + VMEM", probe<3, true>, 256, out, src);
     run("2 waves/SIMD, MFMA + 3 VALU each", probe<3, false>, 512, out, src);
+    run("3 waves/SIMD, MFMA + 3 VALU each", probe<3, false>, 768, out, src);
+    run("4 waves/SIMD, MFMA + 3 VALU each", probe<3, false>, 1024, out, src);
+    run("3 waves/SIMD, MFMA + 6 VALU each", probe<6, false>, 768, out, src);
+    run("2 waves/SIMD, MFMA + 3 VALU + VMEM", probe<3, true>, 512, out, src);
+    run("3 waves/SIMD, MFMA + 3 VALU + VMEM", probe<3, true>, 768, out, src);
     return 0;
 }
