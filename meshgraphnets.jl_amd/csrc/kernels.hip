@@ -516,16 +516,19 @@ __global__ __launch_bounds__(256, 2) void k_edge_coop(const EdgeArgs a) {
         f32x4* etile = tile_ptr(a.Elat, tile, L, lane);
         load_frag<4>(x, etile, STRIDE_TILE);
         load_quarter(xq, etile, STRIDE_TILE, tq);
-        load_quarter(acc, row_ptr(a.P, ix.s, L, h), STRIDE_ROW, tq);
-        {
-            f32x16 qq;
-            load_quarter(qq, row_ptr(a.Q, r, L, h), STRIDE_ROW, tq);
-            acc += qq;
-        }
+        // the gathered rows depend on the indices (a serial ~2 us); the e tile does not: the layer-1 chain starts from zero on
+        // the e tile alone and P[s] + Q[r] (which carry b1) are added when it is done
+        f32x16 pq, qq;
+        load_quarter(pq, row_ptr(a.P, ix.s, L, h), STRIDE_ROW, tq);
+        load_quarter(qq, row_ptr(a.Q, r, L, h), STRIDE_ROW, tq);
         STAMP(1);
         CoopRing ring2, ring3;
         coop_prime(ring2, a.chunk_t[0] + tq * 4096, lane);                  // layer 2's first fragments, ahead of time
+#pragma unroll
+        for (int k = 0; k < 16; ++k) acc[k] = 0.f;
         coop_chain(acc, x, a.chunk_t[2] + tq * 4096, lane);                 // layer 1 (edge part)
+        acc += pq;
+        acc += qq;
         STAMP(2);
         relu_quarter(acc);
         coop_prime(ring3, a.chunk_t[1] + tq * 4096, lane);

@@ -16,7 +16,7 @@ for rep in range(2):
 st = out.reshape(4, 8, 24, 8).astype(np.int64)[:, :4, 0, :]       # [block][wave][slot]
 names = ["loads issued", "L1 (wait+chain)", "xch1", "L2+xch2", "L3+xch3", "LN+store", "scan+tails"]
 t0 = st[:, :, 0].min()
-print("s_memtime ticks are 10 ns (100 MHz): values in us")
+print("values in units of 100 s_memtime ticks (core clock, ~2.4 GHz: 100 ticks = 0.042 us)")
 for b in range(4):
     for w in range(4):
         d = np.diff(st[b, w]) / 100.0
