@@ -242,10 +242,35 @@ DEVINL void layer_norm_frag(f32x16 (&x)[NT], const float* gamma, const float* be
 // ------------------------------------------------------------------------------------------------
 // cooperative global -> LDS copy of resident weight chunks + tables (once per block; persistent grid)
 // ------------------------------------------------------------------------------------------------
+// global -> LDS copy of resident weight chunks + tables (once per block; persistent grid).  Deliberately the plain loop: a
+// copy with eight loads in flight (copy_to_lds_vec) shortens the prologue from ~20 us to a few, but the persistent fp32
+// kernels then run 4 % SLOWER in steady state (same-box A/B, M-1M and a 90 k-node mesh) -- once more the alternation of the
+// two waves of a SIMD, which the staggered end of the slow prologue happens to help.
 DEVINL void copy_to_lds(float* dst, const float* __restrict__ src, int nfloats) {
     const f32x4* s4 = reinterpret_cast<const f32x4*>(src);
     f32x4* d4 = reinterpret_cast<f32x4*>(dst);
     for (int i = threadIdx.x; i < nfloats / 4; i += blockDim.x) d4[i] = s4[i];
+}
+
+// Eight 16-byte loads of a thread in flight before the first LDS write (a plain `d4[i] = s4[i]` loop waits for every load
+// before issuing the next one, ~1 us per iteration).  Used by the bf16 kernels, whose 96 KiB preload is paid per launch
+// and dominated a cylinder-sized mesh (M-flag, two edge sets: 132 -> 78 us per step).
+DEVINL void copy_to_lds_vec(f32x4* d4, const f32x4* __restrict__ s4, int n4) {
+    constexpr int B = 8;
+    const int bd = blockDim.x;
+    for (int i = threadIdx.x; i < n4; i += B * bd) {
+        f32x4 v[B];
+#pragma unroll
+        for (int u = 0; u < B; ++u) {
+            const int k = i + u * bd;
+            v[u] = s4[k < n4 ? k : i];
+        }
+#pragma unroll
+        for (int u = 0; u < B; ++u) {
+            const int k = i + u * bd;
+            if (k < n4) d4[k] = v[u];
+        }
+    }
 }
 
 }  // namespace mgn

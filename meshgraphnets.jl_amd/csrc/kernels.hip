@@ -864,10 +864,14 @@ DEVINL void bf_chunk(f32x16 (&acc)[4], const bf16x8 (&in)[8], const bf16x8* w, i
 
 constexpr int BF_CH = 128 * 128;   // bf16 elements per chunk (32 KiB)
 
-DEVINL void copy_to_lds16(uint16_t* dst, const uint16_t* __restrict__ src, int n) {
+// `fast`: launches of a few tiles per wave, where the preload is a large share of the kernel (see copy_to_lds_vec); long
+// persistent launches keep the plain loop (the batched copy costs them ~1 % in steady state, same-box A/B on M-1M)
+DEVINL void copy_to_lds16(uint16_t* dst, const uint16_t* __restrict__ src, int n, bool fast) {
     const f32x4* s4 = reinterpret_cast<const f32x4*>(src);
     f32x4* d4 = reinterpret_cast<f32x4*>(dst);
-    for (int i = threadIdx.x; i < n / 8; i += blockDim.x) d4[i] = s4[i];
+    if (fast) copy_to_lds_vec(d4, s4, n / 8);
+    else
+        for (int i = threadIdx.x; i < n / 8; i += blockDim.x) d4[i] = s4[i];
 }
 
 #ifndef MGN_BF_WAVES
@@ -878,7 +882,7 @@ __global__ __launch_bounds__(MGN_BF_WAVES * 64, MGN_BF_WAVES / 4) void k_edge_bf
     extern __shared__ __attribute__((aligned(16))) float smem[];
     uint16_t* wl = reinterpret_cast<uint16_t*>(smem);
 #pragma unroll
-    for (int r = 0; r < 3; ++r) copy_to_lds16(wl + r * BF_CH, a.chunk[r], BF_CH);
+    for (int r = 0; r < 3; ++r) copy_to_lds16(wl + r * BF_CH, a.chunk[r], BF_CH, a.ntiles <= 16 * 1024);
     float* tb = smem + 3 * BF_CH / 2;
     copy_to_lds(tb, a.tabs, T_COUNT * L);
     __syncthreads();
@@ -985,7 +989,7 @@ __global__ __launch_bounds__(512, 2) void k_node_bf16(const BfNodeArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     uint16_t* wl = reinterpret_cast<uint16_t*>(smem);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) copy_to_lds16(wl + r * BF_CH, a.chunk[r], BF_CH);
+    for (int r = 0; r < 4; ++r) copy_to_lds16(wl + r * BF_CH, a.chunk[r], BF_CH, a.ntiles <= 16 * 1024);
     float* tb = smem + 4 * BF_CH / 2;
     copy_to_lds(tb, a.tabs, T_COUNT * L);
     __syncthreads();
@@ -1033,8 +1037,8 @@ __global__ __launch_bounds__(512, 2) void k_project_bf16(const BfNodeArgs a) {
     constexpr int L = 128;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     uint16_t* wl = reinterpret_cast<uint16_t*>(smem);
-    copy_to_lds16(wl, a.chunk[4], BF_CH);
-    copy_to_lds16(wl + BF_CH, a.chunk[5], BF_CH);
+    copy_to_lds16(wl, a.chunk[4], BF_CH, a.ntiles <= 16 * 1024);
+    copy_to_lds16(wl + BF_CH, a.chunk[5], BF_CH, a.ntiles <= 16 * 1024);
     float* tb = smem + 2 * BF_CH / 2;
     copy_to_lds(tb, a.tabs, T_COUNT * L);
     __syncthreads();
