@@ -1279,7 +1279,11 @@ static int resident_chunks(int L, int want) {
 static int g_path = [] { const char* e = getenv("MGN_KERNEL_PATH"); return e ? atoi(e) : 0; }();   // experiments
 int set_kernel_path(int p) { const int old = g_path; g_path = p; return old; }
 static bool small_launch(int ntiles) { return g_path == 0 ? ntiles <= 4 * num_cus() : g_path >= 2; }
-bool launch_is_small(int ntiles) { return small_launch(ntiles); }
+// cooperative (4 waves per tile) kernels: up to this many tiles per CU for the edge / node kernels (size sweep)
+static int g_coop_edge = [] { const char* e = getenv("MGN_COOP_EDGE_TILES_PER_CU"); return e ? atoi(e) : 16; }();
+static int g_coop_node = [] { const char* e = getenv("MGN_COOP_NODE_TILES_PER_CU"); return e ? atoi(e) : 8; }();
+static bool coop_size(int ntiles, bool edge) { return g_path == 0 ? ntiles <= (edge ? g_coop_edge : g_coop_node) * num_cus() : g_path == 3; }
+bool launch_is_small(int ntiles) { return coop_size(ntiles, false); }
 
 static LaunchCfg tile_launch(int L, int ntiles, int nres) {
     LaunchCfg lc;
@@ -1335,15 +1339,15 @@ static hipError_t launch_k(K kern, const A& a, const LaunchCfg& lc, hipStream_t 
 hipError_t launch_project(int L, const NodeArgs& a, hipStream_t s);
 
 static size_t coop_lds() { return (size_t)2 * 16 * 64 * 16 + (size_t)T_COUNT * 128 * 4; }
-static bool coop_ok(int L, int ntiles, const float* const* chunk_t) {
-    return L == 128 && chunk_t[0] != nullptr && (g_path == 0 ? small_launch(ntiles) : g_path == 3);
+static bool coop_ok(int L, int ntiles, const float* const* chunk_t, bool edge = false) {
+    return L == 128 && chunk_t[0] != nullptr && coop_size(ntiles, edge);
 }
 
 hipError_t launch_edge_step(int L, const EdgeArgs& a, hipStream_t s) {
     if (a.ntiles <= 0) return hipSuccess;
     const int nres = resident_chunks(L, 3);
     LaunchCfg lc = tile_launch(L, a.ntiles, nres);
-    if (coop_ok(L, a.ntiles, a.chunk_t)) {   // small graph: 4 waves per tile
+    if (coop_ok(L, a.ntiles, a.chunk_t, true)) {   // small graph: 4 waves per tile
         LaunchCfg c4{a.ntiles, 256, coop_lds()};
         return launch_k(k_edge_coop, a, c4, s);
     }
