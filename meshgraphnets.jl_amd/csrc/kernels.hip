@@ -724,6 +724,174 @@ __global__ __launch_bounds__(512, 2) void k_enc_node(const EncNodeArgs a) {
 }
 
 // ================================================================================================
+// Cooperative node encoder and decoder for small meshes (L = 128): 4 waves per tile like k_node_coop.  On a cylinder-sized
+// mesh the one-wave-per-tile encoder / decoder cost 60 + 32 us of every 840 us right-hand side of a rollout.
+// ================================================================================================
+// chunk[0]=W2 [1]=W3 [2]=WP [3]=WQ; the t-major copy of a chunk follows its fragment-major copy (mgn_set_params)
+__global__ __launch_bounds__(256, 2) void k_enc_node_coop(const EncNodeArgs a) {
+    constexpr int L = 128, CH = L * L;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    f32x4* xch0 = reinterpret_cast<f32x4*>(smem);
+    f32x4* xch1 = xch0 + 16 * 64;
+    float* tb = smem + 2 * 16 * 64 * 4;
+    copy_to_lds(tb, a.tabs, T_COUNT * L);
+    __syncthreads();
+    const int lane0 = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int tq = wave;
+    const float* w2 = a.chunk[0] + CH + tq * 4096;
+    const float* w3 = a.chunk[1] + CH + tq * 4096;
+    const float* wp = a.chunk[2] + CH + tq * 4096;
+    const float* wq = a.chunk[3] + CH + tq * 4096;
+    for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+        OPAQUE_LANE();
+        const int n = tile * TILE + c;
+        const bool valid = n < a.n;
+        const int nn = valid ? n : 0;
+        const int64_t g = a.gid[nn];
+        f32x16 in[4], acc;
+        CoopRing r2, r3;
+        coop_prime(r2, w2, lane);
+        // layer 1 (a handful of input features: VALU), every wave the full row
+        tab_frag<4>(in, tb + T_B1 * L, h);
+        const int Fn = a.wa + a.wb;
+        for (int k = 0; k < Fn; ++k) {
+            float xk = (k < a.wa) ? a.srcA[g * a.wa + k] : a.srcB[g * a.wb + (k - a.wa)];
+            if (a.scale) xk = fmaf(xk, a.scale[k], a.shift[k]);
+            first_layer<4>(in, a.w1f, k, xk, h);
+        }
+        relu_frag<4>(in);
+        tab_quarter(acc, tb + T_B2 * L, tq, h);
+        coop_prime(r3, w3, lane);
+        coop_chain_primed(acc, in, w2, lane, r2);                            // layer 2
+        relu_quarter(acc);
+        coop_exchange(in, acc, xch0, wave, lane);
+        tab_quarter(acc, tb + T_B3 * L, tq, h);
+        coop_prime(r2, wp, lane);
+        coop_chain_primed(acc, in, w3, lane, r3);                            // layer 3
+        coop_exchange(in, acc, xch1, wave, lane);
+        coop_layer_norm(acc, in, tb + T_GAMMA * L, tb + T_BETA * L, tq, h);
+        if (!valid) {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) acc[k] = 0.f;                        // padding rows stay zero (checksums)
+        }
+        store_quarter(tile_ptr(a.V, tile, L, lane), STRIDE_TILE, tq, acc);
+        coop_prime(r3, wq, lane);
+        coop_exchange(in, acc, xch0, wave, lane);                            // full latent row for the projection
+#pragma unroll
+        for (int k = 0; k < 16; ++k) acc[k] = 0.f;
+        coop_chain_primed(acc, in, wp, lane, r2);
+        if (valid) store_quarter(row_ptr(a.P, nn, L, h), STRIDE_ROW, tq, acc);
+        tab_quarter(acc, tb + T_BQ * L, tq, h);
+        coop_chain_primed(acc, in, wq, lane, r3);
+        if (valid) store_quarter(row_ptr(a.Q, nn, L, h), STRIDE_ROW, tq, acc);
+        __syncthreads();
+    }
+}
+
+// edge encoder: chunk[0]=W2 [1]=W3
+__global__ __launch_bounds__(256, 2) void k_enc_edge_coop(const EncEdgeArgs a) {
+    constexpr int L = 128, CH = L * L;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    f32x4* xch0 = reinterpret_cast<f32x4*>(smem);
+    f32x4* xch1 = xch0 + 16 * 64;
+    float* tb = smem + 2 * 16 * 64 * 4;
+    copy_to_lds(tb, a.tabs, T_COUNT * L);
+    __syncthreads();
+    const int lane0 = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int tq = wave;
+    const float* w2 = a.chunk[0] + CH + tq * 4096;
+    const float* w3 = a.chunk[1] + CH + tq * 4096;
+    for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+        OPAQUE_LANE();
+        const int64_t eid = (int64_t)tile * TILE + c;
+        const bool valid = eid < a.E;
+        const int64_t g = a.gid[valid ? eid : 0];
+        f32x16 in[4], acc;
+        CoopRing r2, r3;
+        coop_prime(r2, w2, lane);
+        tab_frag<4>(in, tb + T_B1 * L, h);
+        for (int k = 0; k < a.Fe; ++k) {
+            float xk = a.ef[g * a.Fe + k];
+            if (a.scale) xk = fmaf(xk, a.scale[k], a.shift[k]);
+            first_layer<4>(in, a.w1f, k, xk, h);
+        }
+        relu_frag<4>(in);
+        tab_quarter(acc, tb + T_B2 * L, tq, h);
+        coop_prime(r3, w3, lane);
+        coop_chain_primed(acc, in, w2, lane, r2);
+        relu_quarter(acc);
+        coop_exchange(in, acc, xch0, wave, lane);
+        tab_quarter(acc, tb + T_B3 * L, tq, h);
+        coop_chain_primed(acc, in, w3, lane, r3);
+        coop_exchange(in, acc, xch1, wave, lane);
+        coop_layer_norm(acc, in, tb + T_GAMMA * L, tb + T_BETA * L, tq, h);
+        if (!valid) {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) acc[k] = 0.f;
+        }
+        store_quarter(tile_ptr(a.Elat, tile, L, lane), STRIDE_TILE, tq, acc);
+        __syncthreads();
+    }
+}
+
+// chunk[0]=W1 [1]=W2; last layer (L -> O) by wave 0 from the exchanged row
+__global__ __launch_bounds__(256, 2) void k_decode_coop(const DecArgs a) {
+    constexpr int L = 128, CH = L * L;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    f32x4* xch0 = reinterpret_cast<f32x4*>(smem);
+    f32x4* xch1 = xch0 + 16 * 64;
+    float* tb = smem + 2 * 16 * 64 * 4;
+    copy_to_lds(tb, a.tabs, T_COUNT * L);
+    __syncthreads();
+    const int lane0 = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int tq = wave;
+    const float* w1 = a.chunk[0] + CH + tq * 4096;
+    const float* w2 = a.chunk[1] + CH + tq * 4096;
+    for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+        OPAQUE_LANE();
+        const int n = tile * TILE + c;
+        const bool valid = n < a.n;
+        const int nn = valid ? n : 0;
+        f32x16 in[4], acc;
+        CoopRing r2;
+        coop_prime(r2, w2, lane);
+        load_frag<4>(in, tile_ptr(a.V, tile, L, lane), STRIDE_TILE);
+        tab_quarter(acc, tb + T_B1 * L, tq, h);
+        coop_chain(acc, in, w1, lane);
+        relu_quarter(acc);
+        coop_exchange(in, acc, xch0, wave, lane);
+        tab_quarter(acc, tb + T_B2 * L, tq, h);
+        coop_chain_primed(acc, in, w2, lane, r2);
+        relu_quarter(acc);
+        coop_exchange(in, acc, xch1, wave, lane);
+        if (wave == 0) {
+            const float m = a.mask ? a.mask[a.gid[nn]] : 1.0f;
+            for (int o = 0; o < a.O; ++o) {
+                const f32x4* w4 = reinterpret_cast<const f32x4*>(a.w3f + (int64_t)o * L) + h;
+                float sacc = 0.f;
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const f32x4 w = w4[2 * (4 * t + g)];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) sacc = fmaf(in[t][4 * g + i], w[i], sacc);
+                    }
+                sacc += __shfl_xor(sacc, 32, 64);
+                sacc += a.b3[o];
+                if (a.oscale) sacc = fmaf(sacc, a.oscale[o], a.oshift[o]);
+                sacc *= m;
+                if (valid && h == 0) a.out[(int64_t)nn * a.O + o] = sacc;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ================================================================================================
 // Encoder, edge side (K0b+K2).  chunk[0]=W2 [1]=W3
 // ================================================================================================
 template <int NT, int NRES>
@@ -1418,9 +1586,27 @@ hipError_t launch_project(int L, const NodeArgs& a, hipStream_t s) {
     if (L == 32) return launch_k(k_project<1, true>, a, lc, s);
     return hipErrorInvalidValue;
 }
-hipError_t launch_enc_node(int L, const EncNodeArgs& a, hipStream_t s) { DISPATCH_L(k_enc_node, 4, a, a.ntiles); }
-hipError_t launch_enc_edge(int L, const EncEdgeArgs& a, hipStream_t s) { DISPATCH_L(k_enc_edge, 2, a, a.ntiles); }
-hipError_t launch_decode(int L, const DecArgs& a, hipStream_t s) { DISPATCH_L(k_decode, 2, a, a.ntiles); }
+hipError_t launch_enc_node(int L, const EncNodeArgs& a, hipStream_t s) {
+    if (a.ntiles > 0 && L == 128 && coop_size(a.ntiles, false)) {
+        LaunchCfg c4{a.ntiles, 256, coop_lds()};
+        return launch_k(k_enc_node_coop, a, c4, s);
+    }
+    DISPATCH_L(k_enc_node, 4, a, a.ntiles);
+}
+hipError_t launch_enc_edge(int L, const EncEdgeArgs& a, hipStream_t s) {
+    if (a.ntiles > 0 && L == 128 && coop_size(a.ntiles, true)) {
+        LaunchCfg c4{a.ntiles, 256, coop_lds()};
+        return launch_k(k_enc_edge_coop, a, c4, s);
+    }
+    DISPATCH_L(k_enc_edge, 2, a, a.ntiles);
+}
+hipError_t launch_decode(int L, const DecArgs& a, hipStream_t s) {
+    if (a.ntiles > 0 && L == 128 && coop_size(a.ntiles, false)) {
+        LaunchCfg c4{a.ntiles, 256, coop_lds()};
+        return launch_k(k_decode_coop, a, c4, s);
+    }
+    DISPATCH_L(k_decode, 2, a, a.ntiles);
+}
 
 static LaunchCfg bf_launch(int ntiles, int nchunks) {
     LaunchCfg lc = tile_launch(128, ntiles, 0);
