@@ -128,7 +128,7 @@ hipError_t launch_errnorm(const float* u, const float* unew, const LinComb& lc, 
                           double* partial, hipStream_t s);
 
 // L in {32,64,128}.  All return hipError_t of the launch.
-bool launch_is_small(int ntiles);   // the launch wrappers' rule for the small-graph kernel families (<= 4 tiles per CU)
+bool launch_is_small(int ntiles);   // the launch wrappers' rule for the cooperative node kernels (<= 8 tiles per CU)
 int set_kernel_path(int p);   // debug/tests: 0 auto, 1 resident, 2 streaming, 3 cooperative; returns the old value
 hipError_t launch_edge_step(int L, const EdgeArgs& a, hipStream_t s);
 hipError_t launch_node_step(int L, const NodeArgs& a, hipStream_t s);
