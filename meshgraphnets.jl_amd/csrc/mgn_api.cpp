@@ -1153,15 +1153,14 @@ struct Rollout {
     double* partial;
     int n_rhs = 0;
 
-    // f(x, t): in-place inflow overwrite of x, then dx/dt -> kout    (ode_func_eval, reference src/solve.jl:147-158)
-    int rhs(float* x, double t, float* kout) {
+    // One right-hand side is ~35 launches; on a small mesh they are latency-bound, so each distinct (x, kout) pair of the
+    // solver (1 for Euler, 7 for Tsit5) gets its launch sequence captured once and replayed (hipGraph).
+    struct RhsGraph { float* x; float* kout; hipGraphExec_t exec; };
+    std::vector<RhsGraph> graphs;
+    bool warmed = false;
+
+    int rhs_launches(float* x, float* kout) {
         const mgn_config& c = h->cfg;
-        if (mask && frames) {
-            int64_t fr = (int64_t)std::floor(t / d->saves_dt + 1e-6);
-            if (fr < 0) fr = 0;
-            if (fr >= d->n_frames) fr = d->n_frames - 1;
-            HIPCHK(h, launch_overwrite(x, frames + (size_t)fr * n, mask, h->g.N, c.O, h->stream));
-        }
         h->srcA_override = x;
         h->out_override = kout;
         int rc = encode_impl(h, true, true, false);
@@ -1176,8 +1175,47 @@ struct Rollout {
         if (!rc) rc = decode_impl(h, true);
         h->srcA_override = nullptr;
         h->out_override = nullptr;
-        ++n_rhs;
         return rc;
+    }
+
+    // f(x, t): in-place inflow overwrite of x, then dx/dt -> kout    (ode_func_eval, reference src/solve.jl:147-158)
+    int rhs(float* x, double t, float* kout) {
+        const mgn_config& c = h->cfg;
+        if (mask && frames) {
+            int64_t fr = (int64_t)std::floor(t / d->saves_dt + 1e-6);
+            if (fr < 0) fr = 0;
+            if (fr >= d->n_frames) fr = d->n_frames - 1;
+            HIPCHK(h, launch_overwrite(x, frames + (size_t)fr * n, mask, h->g.N, c.O, h->stream));
+        }
+        ++n_rhs;
+        const bool graphable = h->use_graph && !h->prof && launch_is_small(h->ntiles_n);
+        if (!graphable || !warmed) {       // the first RHS runs eagerly: it sets the per-kernel attributes outside of any capture
+            warmed = true;
+            return rhs_launches(x, kout);
+        }
+        for (const RhsGraph& g : graphs)
+            if (g.x == x && g.kout == kout) {
+                HIPCHK(h, hipGraphLaunch(g.exec, h->stream));
+                return MGN_OK;
+            }
+        hipGraph_t graph = nullptr;
+        HIPCHK(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
+        const int rc = rhs_launches(x, kout);
+        const hipError_t ce = hipStreamEndCapture(h->stream, &graph);
+        hipGraphExec_t exec = nullptr;
+        if (rc != MGN_OK || ce != hipSuccess || !graph || hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess) {
+            if (graph) (void)hipGraphDestroy(graph);
+            h->use_graph = 0;              // eager from here on
+            if (rc != MGN_OK) return rc;
+            return rhs_launches(x, kout);
+        }
+        (void)hipGraphDestroy(graph);
+        graphs.push_back({x, kout, exec});
+        HIPCHK(h, hipGraphLaunch(exec, h->stream));
+        return MGN_OK;
+    }
+    ~Rollout() {
+        for (RhsGraph& g : graphs) (void)hipGraphExecDestroy(g.exec);
     }
     size_t elat0_off = 0;
 
