@@ -147,7 +147,8 @@ int mgn_ode_step(mgn_handle* h, const float* x, const float* node_type_onehot, c
 /* Static per-trajectory inputs of the RHS, set ONCE (like create_base_graph's outputs, reference src/graph.jl:54):
  * node_type_onehot [N][Fn-O], ef_raw [E][Fe], val_mask [N] or NULL.  They are uploaded once, the edge encoder runs
  * once and its output is cached; afterwards mgn_ode_step may be called with node_type_onehot = ef_raw = val_mask =
- * NULL and only moves the O x N state per call.  Invalidated by mgn_set_params / mgn_set_norms / mgn_set_graph. */
+ * NULL and only moves the O x N state per call (on small meshes it replays a hipGraph of the launch sequence).
+ * Invalidated by mgn_set_params / mgn_set_norms / mgn_set_graph. */
 int mgn_set_static(mgn_handle* h, const float* node_type_onehot, const float* ef_raw, const float* val_mask);
 
 /* ---- graph prologue helpers (GraphNetCore utilities used at reference src/graph.jl:26-52) -------

@@ -129,6 +129,9 @@ struct mgn_engine {
     int32_t graph_nsteps = -1;      // nsteps the cached graph was captured for
     int32_t graph_warm = -1;        // nsteps of the last eager run since the last invalidation
     hipGraphExec_t graph_exec = nullptr;
+    // hipGraph of the resident right-hand side (mgn_ode_step after mgn_set_static) on small meshes; same life cycle
+    hipGraphExec_t rhs_exec = nullptr;
+    bool rhs_warm = false;
 
     // training step (mgn_step): weights in training order, kept activations, scratch -- created on first use
     mgn::TrainState* train = nullptr;

@@ -221,10 +221,24 @@ int alloc_latents(mgn_engine* h) {
 }
 
 void drop_graph(mgn_engine* h) {
+    if (h->rhs_exec) (void)hipGraphExecDestroy(h->rhs_exec);
+    h->rhs_exec = nullptr;
+    h->rhs_warm = false;
     if (h->graph_exec) (void)hipGraphExecDestroy(h->graph_exec);
     h->graph_exec = nullptr;
     h->graph_nsteps = -1;
     h->graph_warm = -1;
+}
+
+// the resident right-hand side (mgn_set_static) and the hipGraph captured over its buffers go together
+void invalidate_static(mgn_engine* h) {
+    h->have_static = false;
+    if (h->rhs_exec) {
+        if (!h->host_only) (void)hipStreamSynchronize(h->stream);
+        (void)hipGraphExecDestroy(h->rhs_exec);
+    }
+    h->rhs_exec = nullptr;
+    h->rhs_warm = false;
 }
 
 EdgeArgs edge_args(mgn_engine* h, int k, int q = 0) {
@@ -592,7 +606,7 @@ int mgn_set_params(mgn_handle* h, const float* packed, size_t n) {
     }
     HIPCHK(h, hipStreamSynchronize(h->stream));
     drop_graph(h);
-    h->have_static = false;
+    invalidate_static(h);
     HIPCHK(h, h->wfrag.ensure(f.size() * 4));
     HIPCHK(h, hipMemcpy(h->wfrag.p, f.data(), f.size() * 4, hipMemcpyHostToDevice));
     h->have_params = true;
@@ -624,7 +638,7 @@ int mgn_set_norms(mgn_handle* h, const float* ns, const float* nsh, const float*
     HIPCHK(h, hipStreamSynchronize(h->stream));
     HIPCHK(h, h->norms.ensure(v.size() * 4));
     HIPCHK(h, hipMemcpy(h->norms.p, v.data(), v.size() * 4, hipMemcpyHostToDevice));
-    h->have_static = false;
+    invalidate_static(h);
     h->have_nnorm = ns != nullptr;
     h->have_enorm = es != nullptr;
     h->have_onorm = os != nullptr;
@@ -635,7 +649,7 @@ int mgn_set_norms(mgn_handle* h, const float* ns, const float* nsh, const float*
 static int rebuild_graph(mgn_handle* h, int32_t N, const EdgeList* sets, const float* mesh_pos, int32_t pos_dim, bool keep_owner,
                          const char* who) {
     h->have_graph = false;
-    h->have_static = false;
+    invalidate_static(h);
     train_invalidate(h, 2);
     if (!h->host_only) { (void)hipStreamSynchronize(h->stream); drop_graph(h); }
     const std::string why = build_local_graph(N, h->nsets, sets, mesh_pos, pos_dim, keep_owner ? h->g.owner.data() : nullptr,
@@ -816,7 +830,7 @@ static int upload_inputs(mgn_handle* h, const float* a, int wa, const float* b, 
 
 int mgn_fwd_upload(mgn_handle* h, const float* nf, const float* ef) {
     if (int rc = need(h, false, true)) return rc;
-    h->have_static = false;
+    invalidate_static(h);
     if (!nf || (!ef && h->g.set[0].E > 0)) return fail(h, MGN_E_ARG, "mgn_fwd_upload: null input");
     return upload_inputs(h, nf, h->cfg.Fn, nullptr, 0, ef);
 }
@@ -1070,7 +1084,7 @@ int mgn_set_static(mgn_handle* h, const float* onehot, const float* ef_raw, cons
     if (!ef_raw || (c.Fn > c.O && !onehot)) return fail(h, MGN_E_ARG, "mgn_set_static: null argument");
     if (c.Fn < c.O) return fail(h, MGN_E_ARG, "mgn_set_static: Fn < O");
     const LocalGraph& g = h->g;
-    h->have_static = false;
+    invalidate_static(h);
     h->in_wa = c.O;
     h->in_wb = c.Fn - c.O;
     HIPCHK(h, h->d_nfA.ensure((size_t)g.N * c.O * 4));
@@ -1106,16 +1120,42 @@ int mgn_ode_step(mgn_handle* h, const float* x, const float* onehot, const float
         // fast path: static inputs and encoded edges are resident (mgn_set_static); only the state moves
         if (!h->have_static) return fail(h, MGN_E_STATE, "mgn_ode_step without static inputs: call mgn_set_static first or pass them");
         HIPCHK(h, hipMemcpyAsync(h->d_nfA.p, x, (size_t)h->g.N * c.O * 4, hipMemcpyHostToDevice, h->stream));
-        if (int rc = encode_impl(h, true, true, false)) return rc;
-        const bool bf = is_bf16(h);
-        const size_t eb = tile_floats(h->es[0].ntiles_e, c.L) * (bf ? 2 : 4);
-        HIPCHK(h, hipMemcpyAsync(bf ? h->es[0].bElat.p : h->es[0].Elat.p, h->es[0].elat0.p, eb, hipMemcpyDeviceToDevice, h->stream));
-        if (int rc = run_processor(h, c.mps)) return rc;
-        if (int rc = decode_impl(h, true)) return rc;
+        auto launches = [&]() -> int {
+            if (int rc = encode_impl(h, true, true, false)) return rc;
+            const bool bf = is_bf16(h);
+            const size_t eb = tile_floats(h->es[0].ntiles_e, c.L) * (bf ? 2 : 4);
+            HIPCHK(h, hipMemcpyAsync(bf ? h->es[0].bElat.p : h->es[0].Elat.p, h->es[0].elat0.p, eb, hipMemcpyDeviceToDevice, h->stream));
+            if (int rc = run_processor(h, c.mps)) return rc;
+            return decode_impl(h, true);
+        };
+        // small meshes: the ~35 launches of a right-hand side are latency-bound and every buffer of this path is resident
+        // at a fixed address -> captured on the second call, replayed afterwards (a Julia-driven solve calls this per RHS)
+        const bool graphable = h->use_graph && !h->prof && launch_is_small(h->ntiles_n);
+        if (graphable && h->rhs_exec) {
+            HIPCHK(h, hipGraphLaunch(h->rhs_exec, h->stream));
+        } else if (graphable && h->rhs_warm) {
+            hipGraph_t graph = nullptr;
+            HIPCHK(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
+            const int rc = launches();
+            const hipError_t ce = hipStreamEndCapture(h->stream, &graph);
+            if (rc != MGN_OK || ce != hipSuccess || !graph || hipGraphInstantiate(&h->rhs_exec, graph, nullptr, nullptr, 0) != hipSuccess) {
+                if (graph) (void)hipGraphDestroy(graph);
+                h->rhs_exec = nullptr;
+                h->use_graph = 0;
+                if (rc != MGN_OK) return rc;
+                if (int rc2 = launches()) return rc2;
+            } else {
+                (void)hipGraphDestroy(graph);
+                HIPCHK(h, hipGraphLaunch(h->rhs_exec, h->stream));
+            }
+        } else {
+            h->rhs_warm = true;
+            if (int rc = launches()) return rc;
+        }
         return mgn_fwd_download(h, dxdt);
     }
     if (!ef_raw || (c.Fn > c.O && !onehot)) return fail(h, MGN_E_ARG, "mgn_ode_step: null argument");
-    h->have_static = false;   // the one-shot path overwrites the resident inputs
+    invalidate_static(h);   // the one-shot path overwrites the resident inputs
     if (int rc = upload_inputs(h, x, c.O, onehot, c.Fn - c.O, ef_raw)) return rc;
     h->have_mask = val_mask != nullptr;
     if (val_mask) {
@@ -1247,7 +1287,7 @@ int mgn_rollout(mgn_handle* h, mgn_rollout_desc* d) {
     if ((d->inflow_mask != nullptr) != (d->inflow_data != nullptr)) return fail(h, MGN_E_ARG, "mgn_rollout: inflow mask and data go together");
     if (d->solver == 1 && (d->abstol <= 0.f || d->reltol <= 0.f)) return fail(h, MGN_E_ARG, "mgn_rollout: tolerances must be > 0");
     const LocalGraph& g = h->g;
-    h->have_static = false;
+    invalidate_static(h);
     Rollout R;
     R.h = h;
     R.d = d;

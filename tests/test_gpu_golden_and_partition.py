@@ -334,6 +334,20 @@ def test_set_static_fast_rhs_equals_one_shot(dtype):
     eng.set_norms(**norms)                                # invalidates the cache
     with pytest.raises(MgnError):
         eng.ode_step(x)
+    # second life: other parameters; the eager call, the capturing call and the hipGraph replays must all see them
+    ps2 = (ps * 1.01).astype(np.float32)
+    eng.set_params(ps2)
+    ref2 = eng.ode_step(x, onehot, g["ef_raw"], g["val_mask"])
+    assert not np.array_equal(ref2, ref)
+    eng.set_static(onehot, g["ef_raw"], g["val_mask"])
+    for _ in range(4):
+        assert np.array_equal(eng.ode_step(x), ref2)
+    eng.set_params(ps)                                    # parameters changed under a captured graph: static inputs are dropped
+    with pytest.raises(MgnError):
+        eng.ode_step(x)
+    eng.set_static(onehot, g["ef_raw"], g["val_mask"])
+    for _ in range(3):
+        assert np.array_equal(eng.ode_step(x), ref)
 
 
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
