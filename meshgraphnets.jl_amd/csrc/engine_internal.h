@@ -132,6 +132,9 @@ struct mgn_engine {
     // hipGraph of the resident right-hand side (mgn_ode_step after mgn_set_static) on small meshes; same life cycle
     hipGraphExec_t rhs_exec = nullptr;
     bool rhs_warm = false;
+    // the same for mgn_forward (its device buffers keep their addresses between calls)
+    hipGraphExec_t fwd_exec = nullptr;
+    bool fwd_warm = false;
 
     // training step (mgn_step): weights in training order, kept activations, scratch -- created on first use
     mgn::TrainState* train = nullptr;

@@ -224,10 +224,42 @@ void drop_graph(mgn_engine* h) {
     if (h->rhs_exec) (void)hipGraphExecDestroy(h->rhs_exec);
     h->rhs_exec = nullptr;
     h->rhs_warm = false;
+    if (h->fwd_exec) (void)hipGraphExecDestroy(h->fwd_exec);
+    h->fwd_exec = nullptr;
+    h->fwd_warm = false;
     if (h->graph_exec) (void)hipGraphExecDestroy(h->graph_exec);
     h->graph_exec = nullptr;
     h->graph_nsteps = -1;
     h->graph_warm = -1;
+}
+
+// Small meshes: a launch sequence over buffers with fixed addresses runs eagerly once (per-kernel attributes are set outside
+// of any capture), is captured on the next call and replayed afterwards.
+template <typename F>
+int run_graphed(mgn_engine* h, hipGraphExec_t& exec, bool& warm, F&& launches) {
+    const bool graphable = h->use_graph && !h->prof && launch_is_small(h->ntiles_n);
+    if (graphable && exec) {
+        HIPCHK(h, hipGraphLaunch(exec, h->stream));
+        return MGN_OK;
+    }
+    if (!graphable || !warm) {
+        warm = true;
+        return launches();
+    }
+    hipGraph_t graph = nullptr;
+    HIPCHK(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
+    const int rc = launches();
+    const hipError_t ce = hipStreamEndCapture(h->stream, &graph);
+    if (rc != MGN_OK || ce != hipSuccess || !graph || hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess) {
+        if (graph) (void)hipGraphDestroy(graph);
+        exec = nullptr;
+        h->use_graph = 0;               // eager from here on
+        if (rc != MGN_OK) return rc;
+        return launches();
+    }
+    (void)hipGraphDestroy(graph);
+    HIPCHK(h, hipGraphLaunch(exec, h->stream));
+    return MGN_OK;
 }
 
 // the resident right-hand side (mgn_set_static) and the hipGraph captured over its buffers go together
@@ -744,7 +776,14 @@ int mgn_set_edge_features(mgn_handle* h, int32_t set, const float* ef) {
     auto& es = h->es[set];
     const size_t bytes = (size_t)h->g.set[set].E * es.Fe * 4;
     if (bytes && !ef) return fail(h, MGN_E_ARG, "mgn_set_edge_features: null input");
+    const void* before = es.d_ef.p;
     HIPCHK(h, es.d_ef.ensure(bytes));
+    if (es.d_ef.p != before && h->fwd_exec) {   // the captured forward reads this buffer
+        (void)hipStreamSynchronize(h->stream);
+        (void)hipGraphExecDestroy(h->fwd_exec);
+        h->fwd_exec = nullptr;
+        h->fwd_warm = false;
+    }
     if (bytes) HIPCHK(h, hipMemcpyAsync(es.d_ef.p, ef, bytes, hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     es.have_ef = true;
@@ -1069,10 +1108,21 @@ int mgn_forward(mgn_handle* h, const float* nf, const float* ef, float* out) {
     if (h->cfg.nranks != 1)
         return fail(h, MGN_E_STATE, "mgn_forward drives one partition; with nranks > 1 use the staged mgn_fwd_*/mgn_halo_* calls");
     if (int rc = need_set_features(h)) return rc;
+    const float* nfA_before = h->d_nfA.as<float>();
+    const float* ef_before = h->es[0].d_ef.as<float>();
+    const int wa_before = h->in_wa, wb_before = h->in_wb;
     if (int rc = mgn_fwd_upload(h, nf, ef)) return rc;
-    if (int rc = encode_impl(h, false)) return rc;
-    if (int rc = run_processor(h, h->cfg.mps)) return rc;
-    if (int rc = decode_impl(h, false)) return rc;
+    if (h->fwd_exec && (nfA_before != h->d_nfA.as<float>() || ef_before != h->es[0].d_ef.as<float>() || wa_before != h->in_wa || wb_before != h->in_wb)) {
+        (void)hipGraphExecDestroy(h->fwd_exec);   // an input buffer moved or changed its layout since the capture
+        h->fwd_exec = nullptr;
+        h->fwd_warm = false;
+    }
+    auto launches = [&]() -> int {
+        if (int rc = encode_impl(h, false)) return rc;
+        if (int rc = run_processor(h, h->cfg.mps)) return rc;
+        return decode_impl(h, false);
+    };
+    if (int rc = run_graphed(h, h->fwd_exec, h->fwd_warm, launches)) return rc;
     return mgn_fwd_download(h, out);
 }
 
@@ -1128,30 +1178,8 @@ int mgn_ode_step(mgn_handle* h, const float* x, const float* onehot, const float
             if (int rc = run_processor(h, c.mps)) return rc;
             return decode_impl(h, true);
         };
-        // small meshes: the ~35 launches of a right-hand side are latency-bound and every buffer of this path is resident
-        // at a fixed address -> captured on the second call, replayed afterwards (a Julia-driven solve calls this per RHS)
-        const bool graphable = h->use_graph && !h->prof && launch_is_small(h->ntiles_n);
-        if (graphable && h->rhs_exec) {
-            HIPCHK(h, hipGraphLaunch(h->rhs_exec, h->stream));
-        } else if (graphable && h->rhs_warm) {
-            hipGraph_t graph = nullptr;
-            HIPCHK(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
-            const int rc = launches();
-            const hipError_t ce = hipStreamEndCapture(h->stream, &graph);
-            if (rc != MGN_OK || ce != hipSuccess || !graph || hipGraphInstantiate(&h->rhs_exec, graph, nullptr, nullptr, 0) != hipSuccess) {
-                if (graph) (void)hipGraphDestroy(graph);
-                h->rhs_exec = nullptr;
-                h->use_graph = 0;
-                if (rc != MGN_OK) return rc;
-                if (int rc2 = launches()) return rc2;
-            } else {
-                (void)hipGraphDestroy(graph);
-                HIPCHK(h, hipGraphLaunch(h->rhs_exec, h->stream));
-            }
-        } else {
-            h->rhs_warm = true;
-            if (int rc = launches()) return rc;
-        }
+        // a Julia-driven solve calls this once per right-hand side
+        if (int rc = run_graphed(h, h->rhs_exec, h->rhs_warm, launches)) return rc;
         return mgn_fwd_download(h, dxdt);
     }
     if (!ef_raw || (c.Fn > c.O && !onehot)) return fail(h, MGN_E_ARG, "mgn_ode_step: null argument");

@@ -10,11 +10,14 @@ eng.set_params(bench.glorot_params()); eng.set_graph(s, r, N)
 rng = np.random.default_rng(0)
 nf = rng.standard_normal((N, 9)).astype(np.float32); ef = rng.standard_normal((E, 3)).astype(np.float32)
 for _ in range(3): eng.forward(nf, ef)
+t = time.perf_counter()
+for _ in range(50): eng.forward(nf, ef)
+print("mgn_forward wall, hipGraph replay: %.0f us" % ((time.perf_counter() - t) / 50 * 1e6))
 eng.profile_enable(True)
 t = time.perf_counter()
 for _ in range(20): eng.forward(nf, ef)
 dt = (time.perf_counter() - t) / 20
 p = eng.profile_read()
-print("mgn_forward wall %.0f us" % (dt * 1e6))
+print("mgn_forward wall with per-kernel events (eager): %.0f us" % (dt * 1e6))
 for k, v in p.items():
     if v["count"]: print("  %-14s %6.1f us x %d" % (k, v["avg_ms"] * 1e3, v["count"] // 20))
