@@ -245,3 +245,15 @@ def test_edge_tiles_without_halo_senders(lib_built, P):
     one = Engine(9, 3, 2, device=MGN_DEVICE_NONE)
     one.set_graph(s, r, N)
     assert one.edge_boundary_tiles() == (0, (s.size + 31) // 32)
+
+
+def test_c_abi_from_plain_c(lib_built, tmp_path):
+    """include/mgn_hip.h compiles as pedantic C99 and the library is driven from a C program (no Python, no C++)."""
+    import subprocess
+    src = os.path.join(ROOT, "tests", "c_abi", "abi_check.c")
+    exe = str(tmp_path / "abi_check")
+    libdir = os.path.dirname(lib_built)
+    subprocess.check_call(["gcc", "-std=c99", "-pedantic", "-Wall", "-Wextra", "-Werror", src, "-o", exe, "-L", libdir, "-lmgn_hip",
+                           "-Wl,-rpath," + libdir])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and "abi_check OK" in out.stdout, out.stdout + out.stderr
