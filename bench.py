@@ -250,6 +250,9 @@ def main():
                 "traffic": committed_traffic("k_edge_step<4, 2>") if (world == 1 and args.nx == 1000) else None,
                 "traffic_unit": "bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/r01/); algorithmic = 1117 B/edge",
                 "algorithmic_bytes_per_launch": (1024.0 + 8.0 + 85.0) * e_loc,
+                # what THIS kernel has to move at least, given the factored design: e latents R + W, index streams, and one
+                # pass over the P, Q rows it gathers and the AGG rows it writes (3 x N x 512 B); gather re-reads come on top
+                "kernel_compulsory_bytes_per_launch": (1024.0 + 8.0) * e_loc + 3.0 * 512.0 * n_loc,
                 "node_kernel": {"avg_launch_ms": t_node * 1e3, "launches": prof["node_step"]["count"],
                                 "achieved": node_flops_pass / node_launches / t_node / 1e12 if t_node > 0 else 0.0},
                 "processor_step_algorithmic": {
