@@ -1448,6 +1448,7 @@ static int g_path = [] { const char* e = getenv("MGN_KERNEL_PATH"); return e ? a
 int set_kernel_path(int p) { const int old = g_path; g_path = p; return old; }
 static bool small_launch(int ntiles) { return g_path == 0 ? ntiles <= 4 * num_cus() : g_path >= 2; }
 // cooperative (4 waves per tile) kernels: up to this many tiles per CU for the edge / node kernels (size sweep)
+static int g_tail_coop = [] { const char* e = getenv("MGN_TAIL_COOP"); return e ? atoi(e) : 1; }();   // 0: whole launch persistent
 static int g_coop_edge = [] { const char* e = getenv("MGN_COOP_EDGE_TILES_PER_CU"); return e ? atoi(e) : 16; }();
 static int g_coop_node = [] { const char* e = getenv("MGN_COOP_NODE_TILES_PER_CU"); return e ? atoi(e) : 8; }();
 static bool coop_size(int ntiles, bool edge) { return g_path == 0 ? ntiles <= (edge ? g_coop_edge : g_coop_node) * num_cus() : g_path == 3; }
@@ -1525,6 +1526,21 @@ hipError_t launch_edge_step(int L, const EdgeArgs& a, hipStream_t s) {
             return launch_k(k_edge_step<4, 0>, a, lc, s);
         }
         lc.lds += (size_t)MGN_EDGE_JR * 64 * 4 * 4;   // partially resident third chunk
+        // Tail of the persistent walk: with r = ntiles / (8 waves x 256 blocks) rounds, a last round that is less than
+        // ~60 % full costs a whole tile-time (11.4 tiles per wave on an 8-GPU partition of M-1M: 5 %).  Those tiles go to
+        // the cooperative kernel instead (4 waves per tile: a third of the latency), launched behind the persistent one.
+        const int nw = lc.blocks * (lc.threads / 64);
+        const int rem = a.ntiles % nw, rounds = a.ntiles / nw;
+        if (g_tail_coop && g_path == 0 && a.chunk_t[0] && rounds >= 4 && rem > 0 && rem * 10 < nw * 6) {
+            EdgeArgs body = a, tail = a;
+            body.ntiles = a.ntiles - rem;
+            tail.tile0 = a.tile0 + body.ntiles;
+            tail.ntiles = rem;
+            const hipError_t e = launch_k(k_edge_step<4, 2>, body, lc, s);
+            if (e != hipSuccess) return e;
+            LaunchCfg c4{rem, 256, coop_lds()};
+            return launch_k(k_edge_coop, tail, c4, s);
+        }
         return launch_k(k_edge_step<4, 2>, a, lc, s);
     }
     if (L == 64) return launch_k(k_edge_step<2, 3>, a, lc, s);

@@ -154,3 +154,22 @@ def test_error_paths():
         eng.set_graph(np.array([0, 5], np.int32), np.array([1, 1], np.int32), 3)  # index out of range
     with pytest.raises(MgnError):
         engine_for(dict(cfg, L=100))
+
+
+def test_mid_size_mesh_with_tail_split():
+    """90 000 nodes / 537 602 edges (16.8 k edge tiles): the LDS-resident persistent kernels with the last partial round of
+    the edge walk handed to the cooperative kernel -- two kernel families inside one edge step, against the oracle."""
+    from mgn_amd import synth as sy
+    pos, s, r = sy.mesh_1m(7, 300, 300)
+    N, E = pos.shape[0], s.size
+    cfg = cfg_dict(mps=2)
+    ps = make_params(cfg, seed=3, jitter=0.05)
+    rng = np.random.default_rng(0)
+    v = rng.standard_normal((N, 128)).astype(np.float32)
+    e = rng.standard_normal((E, 128)).astype(np.float32)
+    eng = engine_for(cfg)
+    eng.set_params(ps)
+    eng.set_graph(s, r, N)
+    v1, e1 = eng.processor_steps(v, e, 2)
+    rv, re = orc.processor_steps(ps, cfg, v, e, s, r, 2)
+    assert rel_max(v1, rv) <= TOL_15 and rel_max(e1, re) <= TOL_15
