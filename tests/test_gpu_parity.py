@@ -173,3 +173,37 @@ def test_mid_size_mesh_with_tail_split():
     v1, e1 = eng.processor_steps(v, e, 2)
     rv, re = orc.processor_steps(ps, cfg, v, e, s, r, 2)
     assert rel_max(v1, rv) <= TOL_15 and rel_max(e1, re) <= TOL_15
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_degenerate_graphs_both_precisions(dtype):
+    """One node, no edges, fewer edges than a tile, more edges than nodes -- and a two-edge-set model whose mesh set is
+    empty while the world set is not."""
+    import mgn_amd
+    tol = 3e-2 if dtype == "bf16" else 1e-4
+    l2 = lambda a, b: float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
+    cfg = cfg_dict(mps=2)
+    ps = make_params(cfg, seed=1, jitter=0.05)
+    for N, E in ((1, 0), (2, 0), (33, 1), (5, 40)):
+        rng = np.random.default_rng(N * 7 + E)
+        s, r = rng.integers(0, N, E).astype(np.int32), rng.integers(0, N, E).astype(np.int32)
+        nf, ef = rng.standard_normal((N, 9)).astype(np.float32), rng.standard_normal((E, 3)).astype(np.float32)
+        eng = engine_for(cfg, dtype=dtype)
+        eng.set_params(ps)
+        eng.set_graph(s, r, N)
+        assert l2(eng.forward(nf, ef), orc.forward(ps, cfg, nf, ef, s, r)) <= tol, (N, E)
+    cfg2 = dict(Fn=12, Fe=7, O=3, L=128, hidden_layers=2, mps=2, Fe2=4)
+    ps2 = orc.init_params(12, 7, 3, 128, 2, 2, seed=2, ln_jitter=0.05, Fe2=4)
+    rng = np.random.default_rng(5)
+    N = 40
+    s2, r2 = rng.integers(0, N, 70).astype(np.int32), rng.integers(0, N, 70).astype(np.int32)
+    nf, ef2 = rng.standard_normal((N, 12)).astype(np.float32), rng.standard_normal((70, 4)).astype(np.float32)
+    eng = mgn_amd.Engine(12, 7, 3, 128, 2, 2, dtype=dtype, Fe2=4)
+    eng.set_params(ps2)
+    none = np.zeros(0, np.int32)
+    eng.set_graph(none, none, N)
+    eng.set_edge_set(1, s2, r2)
+    eng.set_edge_features(1, ef2)
+    out = eng.forward(nf, np.zeros((0, 7), np.float32))
+    ref = orc.forward(ps2, cfg2, nf, np.zeros((0, 7)), np.zeros(0, int), np.zeros(0, int), set2=(ef2, s2, r2))
+    assert l2(out, ref) <= tol
