@@ -257,3 +257,18 @@ def test_c_abi_from_plain_c(lib_built, tmp_path):
                            "-Wl,-rpath," + libdir])
     out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0 and "abi_check OK" in out.stdout, out.stdout + out.stderr
+
+
+def test_integration_doc_names_every_symbol(lib_built):
+    """INTEGRATION.md maps every entry point of include/mgn_hip.h to the reference interface it replaces: no symbol may be
+    missing from it (a slash list such as `mgn_fwd_upload/encode/decode` counts)."""
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    missing = []
+    for sym in sorted(header_symbols()):
+        if sym in doc:
+            continue
+        tail = sym.split("_")[-1]
+        if re.search(r"mgn_[a-z0-9_/]*/" + re.escape(tail) + r"\b", doc) or (sym.rsplit("_", 1)[0] + "_*") in doc:
+            continue
+        missing.append(sym)
+    assert not missing, missing
