@@ -93,3 +93,40 @@ class LoopbackExchange:
                         self.send[q][self.soff[q][p]: self.soff[q][p] + n])
         for p, e in enumerate(self.engines):
             e.halo_unpack_tensor(self.recv[p]) if tensor_api else e.halo_unpack(self.recv[p].data_ptr())
+
+
+class HostStagedExchange:
+    """The same all-to-all-v over a CPU backend (gloo): rows are packed on the device, staged through pinned host buffers
+    and exchanged by the process group.  Not the production wire (that is DistExchange over RCCL / xGMI) -- it exists so that
+    the REAL engine can be driven by several processes on a box with a single GPU (tests), and as a fallback transport."""
+
+    def __init__(self, engine, device, group=None):
+        import torch.distributed as dist
+        self.dist, self.engine, self.group = dist, engine, group
+        s, r = engine.halo_counts()
+        self.send_rows, self.recv_rows = [int(x) for x in s], [int(x) for x in r]
+        self.n_send, self.n_recv = sum(self.send_rows), sum(self.recv_rows)
+        L = engine.halo_row_floats
+        self.send_dev = torch.empty((max(1, self.n_send), L), dtype=torch.float32, device=device)
+        self.recv_dev = torch.empty((max(1, self.n_recv), L), dtype=torch.float32, device=device)
+        self.send_host = torch.empty((max(1, self.n_send), L), dtype=torch.float32).pin_memory()
+        self.recv_host = torch.empty((max(1, self.n_recv), L), dtype=torch.float32).pin_memory()
+        self._work = None
+
+    def start(self):
+        self.engine.halo_pack(self.send_dev.data_ptr())
+        self.send_host.copy_(self.send_dev)                    # synchronous: the rows are on the host when it returns
+        self._work = self.dist.all_to_all_single(self.recv_host[: self.n_recv], self.send_host[: self.n_send],
+                                                 output_split_sizes=self.recv_rows, input_split_sizes=self.send_rows,
+                                                 group=self.group, async_op=True)
+
+    def finish(self):
+        if self._work is not None:
+            self._work.wait()
+            self._work = None
+        self.recv_dev.copy_(self.recv_host)                    # synchronous: recv_host is free for the next exchange
+        self.engine.halo_unpack(self.recv_dev.data_ptr())
+
+    def __call__(self):
+        self.start()
+        self.finish()
