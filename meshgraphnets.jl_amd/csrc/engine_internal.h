@@ -142,6 +142,7 @@ struct mgn_engine {
     // profiling
     bool prof = false;
     std::vector<ProfRec> recs;
+    std::vector<hipEvent_t> event_pool;   // recycled by mgn_profile_read: creating events inside the timed region costs microseconds each
 };
 
 

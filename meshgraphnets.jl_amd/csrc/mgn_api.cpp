@@ -157,8 +157,21 @@ struct ProfScope {
     mgn_engine* h;
     int fam;
     hipEvent_t a = nullptr, b = nullptr;
+    static hipEvent_t take(mgn_engine* h) {
+        hipEvent_t e = nullptr;
+        if (!h->event_pool.empty()) {
+            e = h->event_pool.back();
+            h->event_pool.pop_back();
+        } else if (hipEventCreate(&e) != hipSuccess) {
+            e = nullptr;
+        }
+        return e;
+    }
     ProfScope(mgn_engine* h_, int fam_) : h(h_), fam(fam_) {
-        if (h->prof && hipEventCreate(&a) == hipSuccess && hipEventCreate(&b) == hipSuccess) (void)hipEventRecord(a, h->stream);
+        if (!h->prof) return;
+        a = take(h);
+        b = take(h);
+        if (a && b) (void)hipEventRecord(a, h->stream);
     }
     ~ProfScope() {
         if (a && b) {
@@ -446,6 +459,7 @@ void mgn_destroy(mgn_handle* h) {
         (void)hipEventDestroy(r.a);
         (void)hipEventDestroy(r.b);
     }
+    for (hipEvent_t e : h->event_pool) (void)hipEventDestroy(e);
     train_free(h);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
     delete h;
@@ -1686,11 +1700,18 @@ int mgn_profile_enable(mgn_handle* h, int32_t on) {
     if (int rc = need(h, false, false)) return rc;
     HIPCHK(h, hipStreamSynchronize(h->stream));
     for (auto& r : h->recs) {
-        (void)hipEventDestroy(r.a);
-        (void)hipEventDestroy(r.b);
+        h->event_pool.push_back(r.a);
+        h->event_pool.push_back(r.b);
     }
     h->recs.clear();
     h->prof = on != 0;
+    // events are created here, outside of whatever the caller is about to time (one per scope boundary; the pool grows on
+    // demand beyond this)
+    while (h->prof && h->event_pool.size() < 4096) {
+        hipEvent_t e = nullptr;
+        if (hipEventCreate(&e) != hipSuccess) break;
+        h->event_pool.push_back(e);
+    }
     return MGN_OK;
 }
 
@@ -1706,8 +1727,8 @@ int mgn_profile_read(mgn_handle* h, double ms_avg[8], int64_t counts[8]) {
             tot[r.fam] += ms;
             cnt[r.fam] += 1;
         }
-        (void)hipEventDestroy(r.a);
-        (void)hipEventDestroy(r.b);
+        h->event_pool.push_back(r.a);
+        h->event_pool.push_back(r.b);
     }
     h->recs.clear();
     for (int i = 0; i < 8; ++i) {
