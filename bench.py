@@ -343,6 +343,26 @@ def main():
             out["secondary"]["train_step"] = {"workload": "mgn_step == step! (src/strategies.jl:418-422) on the M-cyl datapoint, L=128, 15 steps, fp32; "
                                                           "host in/out included", "ms_per_step": dtt * 1e3, "loss_finite": bool(np.isfinite(loss_t))}
             engt.close()
+            # mid-size meshes (real CFD meshes, and the per-GPU share of M-1M on 8 GPUs): where the kernel families meet
+            mids = {}
+            for nxm in (128, 300):
+                posm, sm, rm = mgn_amd.synth.mesh_1m(1234, nxm, nxm)
+                engm = mgn_amd.Engine(FN, FE, O, L, 2, MPS, device=local_rank)
+                engm.set_params(ps)
+                engm.set_graph(sm, rm, posm.shape[0])
+                engm.latents_randn(1234)
+                for _ in range(3):
+                    engm.processor_steps_dev(MPS)
+                barrier_sync()
+                km = 10
+                t0 = time.perf_counter()
+                for _ in range(km):
+                    engm.processor_steps_dev(MPS)
+                barrier_sync()
+                dtm = time.perf_counter() - t0
+                mids[f"N={posm.shape[0]},E={sm.size}"] = {"us_per_processor_step": dtm / (km * MPS) * 1e6, "edges_per_s": sm.size * MPS * km / dtm}
+                engm.close()
+            out["secondary"]["mid_size_meshes"] = mids
             # cfg-3: flag_simple-shaped cloth, mesh + world edges (two edge sets), 15 steps, bf16 (and fp32 beside it)
             mf = mgn_amd.synth.mesh_flag()
             Nf, Ef, Ef2 = mf["mesh_pos"].shape[0], mf["s"].size, mf["s2"].size
