@@ -202,7 +202,10 @@ int mgn_rollout(mgn_handle* h, mgn_rollout_desc* d);
  *   target [N][O];  mask [nmask]: node indices (Int32, 1-based at the Julia boundary: mask_index_base = 1,
  *   src/MeshGraphNets.jl:352);  grads [n_grads = mgn_param_count]: packed order of mgn_set_params, so that
  *   Optimisers.update(opt_state, ps, gs) keeps working on the Julia side;  *loss: the scalar.
- * fp32, one partition, one edge set.  Deterministic (no atomics on the gradient path).                          */
+ * fp32, one partition, one edge set.  Deterministic (no atomics on the gradient path).
+ * nf, ef, target and grads may be HOST or DEVICE pointers (copied with hipMemcpyDefault on the handle's stream): with
+ * device arrays -- the reference keeps graph, ps and gs on the GPU, src/MeshGraphNets.jl:255-263 -- the optimiser update
+ * runs where the gradients are and no 4 x param_count bytes cross PCIe per step.  mask is read on the host.        */
 int mgn_step(mgn_handle* h, const float* nf, const float* ef, const float* target, const int32_t* mask, int64_t nmask,
              int32_t mask_index_base, float* grads, size_t n_grads, float* loss);
 
@@ -210,7 +213,7 @@ int mgn_step(mgn_handle* h, const float* nf, const float* ef, const float* targe
  * solver-based training strategies, where the adjoint of `solve` needs lambda^T df/dx and lambda^T df/dps per RHS
  * evaluation (ZygoteVJP inside the sensitivity algorithm, src/strategies.jl:175-196).  Inputs as mgn_ode_step (raw edge
  * features, frozen normalisers of mgn_set_norms); lambda [N][O]; outputs xbar [N][O], grads [n_grads] (packed order) and,
- * when dxdt != NULL, f(x) itself.                                                                                   */
+ * when dxdt != NULL, f(x) itself.  Every array argument may be a host or a device pointer (hipMemcpyDefault).       */
 int mgn_ode_vjp(mgn_handle* h, const float* x, const float* node_type_onehot, const float* ef_raw, const float* val_mask,
                 const float* lambda, float* dxdt, float* xbar, float* grads, size_t n_grads);
 

@@ -377,111 +377,7 @@ __global__ __launch_bounds__(MGN_PROJ_WAVES * 64, MGN_PROJ_WAVES / 4) void k_pro
 // tiles, 63 node tiles) then spreads over ~1500 / 250 waves instead of 374 / 63.  Weights stream from L2 in
 // t-major fragment order (chunk_t[(t*64 + j)*64 + lane]), one coalesced 256-B load per k-step and wave.
 // ================================================================================================
-#ifndef MGN_COOP_PF
-#define MGN_COOP_PF 4
-#endif
-constexpr int COOP_PF = MGN_COOP_PF;   // weight ring depth in 16-byte fragments (4 k-steps each)
-
-// wt: this wave's t-slice of a chunk in t-major order [j/4][lane][4].  The weight ring of a chain can be primed ahead of
-// time (coop_prime) -- before the previous chain or the exchange barrier -- so that the first fragments' L2 latency
-// (~1.5 k cycles per chain on a small mesh, where nothing else hides it) is off the critical path.
-struct CoopRing {
-    f32x4 r[COOP_PF];
-};
-DEVINL void coop_prime(CoopRing& ring, const float* wt, int lane) {
-    const f32x4* wv = reinterpret_cast<const f32x4*>(wt) + lane;
-#pragma unroll
-    for (int p = 0; p < COOP_PF; ++p) ring.r[p] = wv[p * 64];
-}
-DEVINL void coop_chain_primed(f32x16& acc, const f32x16 (&in)[4], const float* wt, int lane, CoopRing& ring) {
-    const f32x4* wv = reinterpret_cast<const f32x4*>(wt) + lane;
-#pragma unroll
-    for (int m = 0; m < 16; ++m) {
-        const f32x4 a = ring.r[m % COOP_PF];
-        if (m + COOP_PF < 16) ring.r[m % COOP_PF] = wv[(m + COOP_PF) * 64];
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], in[m >> 2][4 * (m & 3) + i], acc, 0, 0, 0);
-    }
-}
-DEVINL void coop_chain(f32x16& acc, const f32x16 (&in)[4], const float* wt, int lane) {
-    CoopRing ring;
-    coop_prime(ring, wt, lane);
-    coop_chain_primed(acc, in, wt, lane, ring);
-}
-
-// every wave publishes its 16-register slice and reads back the full 64-register row fragment
-DEVINL void coop_exchange(f32x16 (&full)[4], const f32x16& mine, f32x4* xch, int wave, int lane) {
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        f32x4 v;
-        v[0] = mine[4 * g + 0]; v[1] = mine[4 * g + 1]; v[2] = mine[4 * g + 2]; v[3] = mine[4 * g + 3];
-        xch[(4 * wave + g) * 64 + lane] = v;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int m = 0; m < 16; ++m) {
-        const f32x4 v = xch[m * 64 + lane];
-        full[m >> 2][4 * (m & 3) + 0] = v[0]; full[m >> 2][4 * (m & 3) + 1] = v[1];
-        full[m >> 2][4 * (m & 3) + 2] = v[2]; full[m >> 2][4 * (m & 3) + 3] = v[3];
-    }
-}
-
-DEVINL void tab_quarter(f32x16& q, const float* tab, int t, int h) { load_quarter(q, reinterpret_cast<const f32x4*>(tab) + h, 2, t); }
-
-DEVINL void relu_quarter(f32x16& q) {
-#pragma unroll
-    for (int k = 0; k < 16; ++k) q[k] = fmaxf(q[k], 0.f);
-}
-
-// LayerNorm statistics from the full row fragment, applied to this wave's quarter
-DEVINL void coop_layer_norm(f32x16& mine, const f32x16 (&full)[4], const float* gamma, const float* beta, int t, int h) {
-    float s = 0.f;
-#pragma unroll
-    for (int u = 0; u < 4; ++u)
-#pragma unroll
-        for (int k = 0; k < 16; ++k) s += full[u][k];
-    s += __shfl_xor(s, 32, 64);
-    const float mean = s * (1.0f / 128);
-    float q = 0.f;
-#pragma unroll
-    for (int u = 0; u < 4; ++u)
-#pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            const float d = full[u][k] - mean;
-            q += d * d;
-        }
-    q += __shfl_xor(q, 32, 64);
-    const float rstd = 1.0f / sqrtf(q * (1.0f / 128) + LN_EPS);
-    f32x16 gq, bq;
-    tab_quarter(gq, gamma, t, h);
-    tab_quarter(bq, beta, t, h);
-#pragma unroll
-    for (int k = 0; k < 16; ++k) mine[k] = (mine[k] - mean) * rstd * gq[k] + bq[k];
-}
-
-// same with gamma / beta quarters already in registers
-DEVINL void coop_layer_norm_reg(f32x16& mine, const f32x16 (&full)[4], const f32x16& gq, const f32x16& bq) {
-    float s = 0.f;
-#pragma unroll
-    for (int u = 0; u < 4; ++u)
-#pragma unroll
-        for (int k = 0; k < 16; ++k) s += full[u][k];
-    s += __shfl_xor(s, 32, 64);
-    const float mean = s * (1.0f / 128);
-    float q = 0.f;
-#pragma unroll
-    for (int u = 0; u < 4; ++u)
-#pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            const float d = full[u][k] - mean;
-            q += d * d;
-        }
-    q += __shfl_xor(q, 32, 64);
-    const float rstd = 1.0f / sqrtf(q * (1.0f / 128) + LN_EPS);
-#pragma unroll
-    for (int k = 0; k < 16; ++k) mine[k] = (mine[k] - mean) * rstd * gq[k] + bq[k];
-}
+// (CoopRing, coop_prime / coop_chain*, coop_exchange, coop_layer_norm*: frag.hpp -- shared with the training kernels)
 
 // chunk_t[0]=W2 [1]=W3 [2]=W1e  (t-major)
 __global__ __launch_bounds__(256, 2) void k_edge_coop(const EdgeArgs a) {

@@ -107,11 +107,14 @@ void pack_chunk(float* dst, const float* W, int ldw, int kbase, int L) {
             for (int t = 0; t < NT; ++t) dst[((size_t)j * 64 + lane) * NT + t] = wrow[32 * t + i];
         }
 }
-}  // namespace mgn
-namespace {
-
-}  // namespace
-namespace mgn {
+// t-major copy of a packed chunk, four consecutive k-steps per lane contiguous: [t][j/4][lane][j%4] (cooperative kernels)
+void pack_chunk_tmajor(float* dst, const float* frag, int L) {
+    const int NT = L / 32, J = L / 2;
+    for (int t = 0; t < NT; ++t)
+        for (int j = 0; j < J; ++j)
+            for (int lane = 0; lane < 64; ++lane)
+                dst[(((size_t)t * (J / 4) + j / 4) * 64 + lane) * 4 + (j & 3)] = frag[((size_t)j * 64 + lane) * NT + t];
+}
 // vector of L values (stride between consecutive features = stride) -> table fragment order
 void pack_tab(float* dst, const float* vec, int L, int stride) {
     for (int m = 0; m < L / 8; ++m)
@@ -508,12 +511,7 @@ int mgn_set_params(mgn_handle* h, const float* packed, size_t n) {
         const size_t off = f.size();
         f.resize(off + 2 * CH);
         pack_chunk(f.data() + off, Wm, ldw, kbase, L);
-        const int NT = L / 32, J = L / 2;
-        for (int t = 0; t < NT; ++t)
-            for (int j = 0; j < J; ++j)
-                for (int lane = 0; lane < 64; ++lane)
-                    // t-major, four consecutive k-steps per lane contiguous: [t][j/4][lane][j%4]
-                    f[off + CH + (((size_t)t * (J / 4) + j / 4) * 64 + lane) * 4 + (j & 3)] = f[off + ((size_t)j * 64 + lane) * NT + t];
+        pack_chunk_tmajor(f.data() + off + CH, f.data() + off, L);
         return off;
     };
     auto add_tabs = [&](const float* b1, const float* b2, const float* b3, const float* ga, const float* be, const float* bq) {

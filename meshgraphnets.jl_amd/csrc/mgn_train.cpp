@@ -37,7 +37,18 @@ struct TrainState {
     // arena offsets (floats)
     size_t nf_raw, ef_raw, nf_pad, ef_pad, enH[3], V0, eeH[3], E0, Enew, dH[3];
     std::vector<size_t> eH[3], nH[3], Ek, Vk, agg;
-    size_t GT, GXH, GY, GZ2, GZ1, GXs, GXr, gV[2], gE[2], gAgg, Gout, gNF, io, pw, pb;
+    static constexpr int GSETS = 4;   // gradient-buffer sets: the weight gradients of MLP i run beside the backward of MLPs i+1 .. i+3
+    int gsets = 1;                    // sets allocated for the current graph (GSETS on small meshes, else 1: no overlap)
+    size_t GT[GSETS], GXH[GSETS], GY[GSETS], GZ2[GSETS], GZ1[GSETS];
+    size_t GXs, GXr, gV[2], gE[2], gAgg, Gout, gNF, io, pw, pb;
+    // weight gradients + their reductions go to a second stream (small meshes leave most of the chip idle during k_mlp_bwd)
+    hipStream_t aux = nullptr;
+    hipEvent_t ev_bwd = nullptr, ev_wg[GSETS] = {};
+    ~TrainState() {
+        if (ev_bwd) (void)hipEventDestroy(ev_bwd);
+        for (hipEvent_t e : ev_wg) if (e) (void)hipEventDestroy(e);
+        if (aux) (void)hipStreamDestroy(aux);
+    }
     // idx buffer (int32): egid32 [E], perm_s [E], rowptr_s [N+1]
     size_t i_egid = 0, i_perm = 0, i_rowptr_s = 0;
 };
@@ -65,8 +76,9 @@ int pack_training_weights(mgn_engine* h) {
     std::vector<float> f, tmp(CH);
     auto add_chunk_from = [&](const float* M /* L x L row-major */) {
         const size_t off = f.size();
-        f.resize(off + CH);
+        f.resize(off + 2 * CH);                       // fragment order, then the t-major copy (cooperative kernels) at + CH
         pack_chunk(f.data() + off, M, L, 0, L);
+        pack_chunk_tmajor(f.data() + off + CH, f.data() + off, L);
         return off;
     };
     // rows [r0, r0 + nr) x cols [0, nc) of W (leading dimension ldw), zero-padded to L x L; transposed on request
@@ -186,7 +198,14 @@ int prepare_graph(mgn_engine* h) {
         T.Vk[k + 1] = take(NL);
     }
     const size_t ML = NL > EL ? NL : EL;
-    T.GT = take(ML); T.GXH = take(ML); T.GY = take(ML); T.GZ2 = take(ML); T.GZ1 = take(ML);
+    // Small meshes (the cooperative-tile regime: a launch leaves most of the chip idle) get GSETS sets of gradient buffers so
+    // that the parameter gradients can run on a second stream; larger ones fill the chip on their own and keep one set.
+    {
+        static const bool overlap_env = [] { const char* e = getenv("MGN_TRAIN_OVERLAP"); return !e || atoi(e) != 0; }();
+        const int64_t big = E > N ? E : N;
+        T.gsets = (overlap_env && !T.recompute && L == 128 && big <= 2048 * TILE) ? TrainState::GSETS : 1;
+    }
+    for (int i = 0; i < T.gsets; ++i) { T.GT[i] = take(ML); T.GXH[i] = take(ML); T.GY[i] = take(ML); T.GZ2[i] = take(ML); T.GZ1[i] = take(ML); }
     T.GXs = take(EL); T.GXr = take(EL);
     T.gV[0] = take(NL); T.gV[1] = take(NL);
     T.gE[0] = take(EL); T.gE[1] = take(EL);
@@ -262,26 +281,26 @@ int train_run(mgn_handle* h, const TrainJob& J) {
     const float* nrm = h->norms.as<float>();   // [node scale, shift (Fn) | edge scale, shift (Fe) | out scale, shift (O)]
     HIPCHK(h, hipMemsetAsync(G, 0, h->params.size() * 4, st));
     if (!J.vjp) {
-        HIPCHK(h, hipMemcpyAsync(A + T.nf_raw, J.nf, (size_t)N * c.Fn * 4, hipMemcpyHostToDevice, st));
+        HIPCHK(h, hipMemcpyAsync(A + T.nf_raw, J.nf, (size_t)N * c.Fn * 4, hipMemcpyDefault, st));
         HIPCHK(h, launch_affine_pad(A + T.nf_raw, c.Fn, nullptr, 0, nullptr, nullptr, A + T.nf_pad, L, N, st));
         if (E > 0) {
-            HIPCHK(h, hipMemcpyAsync(A + T.ef_raw, J.ef, (size_t)E * c.Fe * 4, hipMemcpyHostToDevice, st));
+            HIPCHK(h, hipMemcpyAsync(A + T.ef_raw, J.ef, (size_t)E * c.Fe * 4, hipMemcpyDefault, st));
             HIPCHK(h, launch_affine_pad(A + T.ef_raw, c.Fe, nullptr, 0, nullptr, nullptr, A + T.ef_pad, L, E, st));
         }
-        HIPCHK(h, hipMemcpyAsync(T.target.p, J.target, (size_t)N * O * 4, hipMemcpyHostToDevice, st));
+        HIPCHK(h, hipMemcpyAsync(T.target.p, J.target, (size_t)N * O * 4, hipMemcpyDefault, st));
         HIPCHK(h, T.mask.ensure((size_t)J.nmask * 4));
-        HIPCHK(h, hipMemcpyAsync(T.mask.p, J.mask, (size_t)J.nmask * 4, hipMemcpyHostToDevice, st));
+        HIPCHK(h, hipMemcpyAsync(T.mask.p, J.mask, (size_t)J.nmask * 4, hipMemcpyDefault, st));
     } else {
         // RHS inputs exactly as mgn_ode_step takes them: nf = [n_norm(x); n_norm(onehot)], ef = e_norm(ef_raw)
         float* io = A + T.io;                  // x [N][O] | lambda [N][O] | onehot [N][Fn-O] | val_mask [N]
-        HIPCHK(h, hipMemcpyAsync(io, J.x, (size_t)N * O * 4, hipMemcpyHostToDevice, st));
-        HIPCHK(h, hipMemcpyAsync(io + (size_t)N * O, J.lambda, (size_t)N * O * 4, hipMemcpyHostToDevice, st));
-        if (c.Fn > O) HIPCHK(h, hipMemcpyAsync(io + (size_t)2 * N * O, J.onehot, (size_t)N * (c.Fn - O) * 4, hipMemcpyHostToDevice, st));
-        if (J.val_mask) HIPCHK(h, hipMemcpyAsync(io + (size_t)N * (O + c.Fn), J.val_mask, (size_t)N * 4, hipMemcpyHostToDevice, st));
+        HIPCHK(h, hipMemcpyAsync(io, J.x, (size_t)N * O * 4, hipMemcpyDefault, st));
+        HIPCHK(h, hipMemcpyAsync(io + (size_t)N * O, J.lambda, (size_t)N * O * 4, hipMemcpyDefault, st));
+        if (c.Fn > O) HIPCHK(h, hipMemcpyAsync(io + (size_t)2 * N * O, J.onehot, (size_t)N * (c.Fn - O) * 4, hipMemcpyDefault, st));
+        if (J.val_mask) HIPCHK(h, hipMemcpyAsync(io + (size_t)N * (O + c.Fn), J.val_mask, (size_t)N * 4, hipMemcpyDefault, st));
         HIPCHK(h, launch_affine_pad(io, O, io + (size_t)2 * N * O, c.Fn - O, h->have_nnorm ? nrm : nullptr, h->have_nnorm ? nrm + c.Fn : nullptr,
                                     A + T.nf_pad, L, N, st));
         if (E > 0) {
-            HIPCHK(h, hipMemcpyAsync(A + T.ef_raw, J.ef, (size_t)E * c.Fe * 4, hipMemcpyHostToDevice, st));
+            HIPCHK(h, hipMemcpyAsync(A + T.ef_raw, J.ef, (size_t)E * c.Fe * 4, hipMemcpyDefault, st));
             HIPCHK(h, launch_affine_pad(A + T.ef_raw, c.Fe, nullptr, 0, h->have_enorm ? nrm + 2 * c.Fn : nullptr,
                                         h->have_enorm ? nrm + 2 * c.Fn + c.Fe : nullptr, A + T.ef_pad, L, E, st));
         }
@@ -334,8 +353,23 @@ int train_run(mgn_handle* h, const TrainJob& J) {
 
     // ---- backward
     // activation backward of one MLP + all of its parameter gradients
+    // The parameter gradients of MLP i (k_wgrad + k_reduce_partials: they only read what k_mlp_bwd left in gradient-buffer
+    // set i & 1 and the kept activations) run on a second stream beside the activation backward of MLP i + 1.  Not in
+    // recompute mode (there the kept activations are shared buffers which the next step's recomputation overwrites) and not
+    // on large meshes, which fill the chip on their own (prepare_graph).  MGN_TRAIN_OVERLAP = 0 keeps everything on one stream.
+    const bool overlap = T.gsets > 1;
+    if (overlap && !T.aux) {
+        HIPCHK(h, hipStreamCreateWithFlags(&T.aux, hipStreamNonBlocking));
+        HIPCHK(h, hipEventCreateWithFlags(&T.ev_bwd, hipEventDisableTiming));
+        for (hipEvent_t& e : T.ev_wg) HIPCHK(h, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    }
+    int n_bwd = 0;
     auto bwd = [&](const TrainMlp& m, int64_t rows, int32_t ntiles, const float* g0, const float* g1, const int32_t* g1i, size_t h1, size_t h2, size_t y,
                    float* const gx[3], const float* const gxadd[3], const float* const xin[3], const int32_t* const xi[3]) -> int {
+        const int gs = overlap ? n_bwd % T.gsets : 0;
+        hipStream_t wst = overlap ? T.aux : st;
+        if (overlap && n_bwd >= T.gsets) HIPCHK(h, hipStreamWaitEvent(st, T.ev_wg[gs], 0));   // set gs is free again
+        ++n_bwd;
         TrainBwdArgs a{};
         a.rows = rows; a.ntiles = ntiles;
         a.G0 = g0; a.G1 = g1; a.g1idx = g1i;
@@ -348,8 +382,12 @@ int train_run(mgn_handle* h, const TrainJob& J) {
         }
         a.tabs = Wt + m.tabs;
         a.ln = m.off->ln ? 1 : 0;
-        a.GT = A + T.GT; a.GXH = A + T.GXH; a.GY = A + T.GY; a.GZ2 = A + T.GZ2; a.GZ1 = A + T.GZ1;
+        a.GT = A + T.GT[gs]; a.GXH = A + T.GXH[gs]; a.GY = A + T.GY[gs]; a.GZ2 = A + T.GZ2[gs]; a.GZ1 = A + T.GZ1[gs];
         HIPCHK(h, launch_mlp_bwd(L, m.nin, a, st));
+        if (overlap) {
+            HIPCHK(h, hipEventRecord(T.ev_bwd, st));
+            HIPCHK(h, hipStreamWaitEvent(wst, T.ev_bwd, 0));
+        }
         // every parameter gradient of this MLP: one batched weight-gradient launch + one batched (ordered) reduction
         const MlpOff& o = *m.off;
         const int nb = wgrad_blocks(rows);
@@ -369,16 +407,17 @@ int train_run(mgn_handle* h, const TrainJob& J) {
             if (boff >= 0) rb.job[rb.njobs++] = ReduceJob{j.pb, nb, (int64_t)L, 1, bcols, L, G + boff};
             ++wb.njobs;
         };
-        job(A + h2, nullptr, A + T.GY, (long)o.W[2], L, o.out, (long)o.b[2], o.out);
-        job(A + h1, nullptr, A + T.GZ2, (long)o.W[1], L, L, (long)o.b[1], L);
+        job(A + h2, nullptr, A + T.GY[gs], (long)o.W[2], L, o.out, (long)o.b[2], o.out);
+        job(A + h1, nullptr, A + T.GZ2[gs], (long)o.W[1], L, L, (long)o.b[1], L);
         for (int j = 0; j < m.nin; ++j)
-            job(xin[j], xi[j], A + T.GZ1, (long)(o.W[0] + (size_t)j * L * L), m.in_rows, L, j == 0 ? (long)o.b[0] : -1, L);
+            job(xin[j], xi[j], A + T.GZ1[gs], (long)(o.W[0] + (size_t)j * L * L), m.in_rows, L, j == 0 ? (long)o.b[0] : -1, L);
         if (o.ln) {
-            job(nullptr, nullptr, A + T.GXH, -1, 0, 0, (long)o.gamma, L);
-            job(nullptr, nullptr, A + T.GT, -1, 0, 0, (long)o.beta, L);
+            job(nullptr, nullptr, A + T.GXH[gs], -1, 0, 0, (long)o.gamma, L);
+            job(nullptr, nullptr, A + T.GT[gs], -1, 0, 0, (long)o.beta, L);
         }
-        HIPCHK(h, launch_wgrad(L, wb, rows, st));
-        HIPCHK(h, launch_reduce_partials(rb, st));
+        HIPCHK(h, launch_wgrad(L, wb, rows, wst));
+        HIPCHK(h, launch_reduce_partials(rb, wst));
+        if (overlap) HIPCHK(h, hipEventRecord(T.ev_wg[gs], wst));
         return MGN_OK;
     };
 
@@ -417,8 +456,7 @@ int train_run(mgn_handle* h, const TrainJob& J) {
             if (int rc = bwd(me, E, nt_e, A + T.gE[ecur], A + T.gAgg, rcv, T.eH[0][k], T.eH[1][k], T.eH[2][k], gx, gxadd, xin, xi)) return rc;
         }
         // gather duality: the gradients of v[receivers] / v[senders] are segmented sums over the receiver / sender CSR
-        HIPCHK(h, launch_segment_sum(L, A + T.GXr, rowptr, nullptr, A + T.gV[nxt], A + T.gV[cur], (int32_t)N, st));
-        HIPCHK(h, launch_segment_sum(L, A + T.GXs, rowptr_s, perm_s, A + T.gV[cur], A + T.gV[nxt], (int32_t)N, st));
+        HIPCHK(h, launch_segment_sum2(L, A + T.GXr, rowptr, A + T.GXs, rowptr_s, perm_s, A + T.gV[nxt], A + T.gV[nxt], (int32_t)N, st));
         if (E == 0) HIPCHK(h, hipMemsetAsync(A + T.gE[enxt], 0, (size_t)L * 4, st));
         cur = nxt;
         ecur = enxt;
@@ -436,15 +474,17 @@ int train_run(mgn_handle* h, const TrainJob& J) {
     }
 
     // ---- results
+    if (overlap)                                         // the second stream is in order: its last event covers all of it
+        for (int i = 0; i < T.gsets && i < n_bwd; ++i) HIPCHK(h, hipStreamWaitEvent(st, T.ev_wg[i], 0));
     std::vector<double> lp((size_t)nlb);
-    HIPCHK(h, hipMemcpyAsync(J.grads, G, h->params.size() * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(h, hipMemcpyAsync(J.grads, G, h->params.size() * 4, hipMemcpyDefault, st));
     if (!J.vjp) {
         HIPCHK(h, hipMemcpyAsync(lp.data(), T.loss.p, lp.size() * sizeof(double), hipMemcpyDeviceToHost, st));
     } else {
         // x enters through the node normaliser: xbar = (d / d nf)[:, 0:O] .* node_scale[0:O]
         HIPCHK(h, launch_extract_cols(A + T.gNF, L, O, h->have_nnorm ? nrm : nullptr, A + T.io, N, st));
-        HIPCHK(h, hipMemcpyAsync(J.xbar, A + T.io, (size_t)N * O * 4, hipMemcpyDeviceToHost, st));
-        if (J.dxdt) HIPCHK(h, hipMemcpyAsync(J.dxdt, T.target.p, (size_t)N * O * 4, hipMemcpyDeviceToHost, st));
+        HIPCHK(h, hipMemcpyAsync(J.xbar, A + T.io, (size_t)N * O * 4, hipMemcpyDefault, st));
+        if (J.dxdt) HIPCHK(h, hipMemcpyAsync(J.dxdt, T.target.p, (size_t)N * O * 4, hipMemcpyDefault, st));
     }
     HIPCHK(h, hipStreamSynchronize(st));
     if (!J.vjp) {

@@ -56,6 +56,9 @@ hipError_t launch_reduce_partials(const ReduceBatch& rb, hipStream_t s);
 // out[n] = (add ? add[n] : 0) + sum_{p in [rowptr[n], rowptr[n+1])} src[perm ? perm[p] : p]   (rows of L floats)
 hipError_t launch_segment_sum(int L, const float* src, const int32_t* rowptr, const int32_t* perm, const float* add, float* out,
                               int32_t n, hipStream_t s);
+// out[n] = add[n] + sum_{p in A-range(n)} srcA[p] + sum_{p in B-range(n)} srcB[permB[p]]   (add may alias out)
+hipError_t launch_segment_sum2(int L, const float* srcA, const int32_t* rowptrA, const float* srcB, const int32_t* rowptrB, const int32_t* permB,
+                               const float* add, float* out, int32_t n, hipStream_t s);
 // dst [rows][L] = [ (srcA | srcB)[rows][wa + wb] * scale + shift | 0 ]   (srcB may be null with wb = 0; scale null: identity)
 hipError_t launch_affine_pad(const float* srcA, int wa, const float* srcB, int wb, const float* scale, const float* shift, float* dst, int L,
                              int64_t rows, hipStream_t s);

@@ -6,6 +6,7 @@
 // MLP per launch, row-major activations, weights streamed from L2.  See train.h for the kernel inventory.
 #include "train.h"
 
+#include <cstdlib>
 #include <mutex>
 #include <unordered_map>
 
@@ -221,6 +222,174 @@ __global__ __launch_bounds__(256) void k_mlp_bwd(const TrainBwdArgs a) {
 }
 
 // ================================================================================================
+// Cooperative 4-wave variants for SMALL meshes (L = 128): one 32-row tile per block, wave t owns feature block t of every
+// Dense output (chains of 64 MFMAs instead of 256), the waves exchange their slices through LDS between layers and read
+// their slice of every weight chunk from its t-major copy (at + L*L of the fragment-order chunk) through a register ring.
+// A cylinder_flow-sized datapoint (374 edge tiles) then occupies ~1500 waves instead of 374 on 94 CUs.  Same arithmetic in
+// the same order as k_mlp_fwd / k_mlp_bwd.
+// ================================================================================================
+DEVINL void add_quarter(f32x16& q, const f32x4* __restrict__ p, int stride, int t) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const f32x4 v = p[(4 * t + g) * stride];
+        q[4 * g + 0] += v[0]; q[4 * g + 1] += v[1]; q[4 * g + 2] += v[2]; q[4 * g + 3] += v[3];
+    }
+}
+
+template <int NIN>
+__global__ __launch_bounds__(256, 2) void k_mlp_fwd_coop(const TrainFwdArgs a) {
+    constexpr int L = 128, CH = L * L, QS = 4096;     // QS: one wave's t-slice of a chunk
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    f32x4* xch0 = reinterpret_cast<f32x4*>(smem);
+    f32x4* xch1 = xch0 + 16 * 64;
+    const int lane0 = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int tq = wave;
+    for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+        OPAQUE_LANE();
+        const RowRef rw = row_of(tile, c, a.rows);
+        int64_t src[NIN];
+#pragma unroll
+        for (int j = 0; j < NIN; ++j) src[j] = a.xidx[j] ? (int64_t)a.xidx[j][rw.rr] : rw.rr;
+        f32x16 xa[4], xb[4], acc;
+        CoopRing r2, r3;
+        load_frag<4>(xa, row_ptr(a.X[0], src[0], L, h), STRIDE_ROW);
+        if constexpr (NIN > 1) load_frag<4>(xb, row_ptr(a.X[1], src[1], L, h), STRIDE_ROW);
+        tab_quarter(acc, a.tabs + T_B1 * L, tq, h);
+        coop_chain(acc, xa, a.W1[0] + CH + tq * QS, lane);
+        if constexpr (NIN > 2) load_frag<4>(xa, row_ptr(a.X[2], src[2], L, h), STRIDE_ROW);
+        if constexpr (NIN > 1) coop_chain(acc, xb, a.W1[1] + CH + tq * QS, lane);
+        coop_prime(r2, a.W2 + CH + tq * QS, lane);
+        if constexpr (NIN > 2) coop_chain(acc, xa, a.W1[2] + CH + tq * QS, lane);
+        relu_quarter(acc);
+        if (rw.valid) store_quarter(row_ptr(a.H1, rw.row, L, h), STRIDE_ROW, tq, acc);
+        coop_exchange(xa, acc, xch0, wave, lane);
+        coop_prime(r3, a.W3 + CH + tq * QS, lane);
+        tab_quarter(acc, a.tabs + T_B2 * L, tq, h);
+        coop_chain_primed(acc, xa, a.W2 + CH + tq * QS, lane, r2);
+        relu_quarter(acc);
+        if (rw.valid) store_quarter(row_ptr(a.H2, rw.row, L, h), STRIDE_ROW, tq, acc);
+        coop_exchange(xb, acc, xch1, wave, lane);
+        tab_quarter(acc, a.tabs + T_B3 * L, tq, h);
+        coop_chain_primed(acc, xb, a.W3 + CH + tq * QS, lane, r3);
+        if (rw.valid) store_quarter(row_ptr(a.Y, rw.row, L, h), STRIDE_ROW, tq, acc);
+        if (a.ln) {
+            coop_exchange(xa, acc, xch0, wave, lane);                  // full pre-LN row for the statistics
+            coop_layer_norm(acc, xa, a.tabs + T_GAMMA * L, a.tabs + T_BETA * L, tq, h);
+        }
+        if (a.LNOUT && rw.valid) store_quarter(row_ptr(a.LNOUT, rw.row, L, h), STRIDE_ROW, tq, acc);
+        if (a.resid) add_quarter(acc, row_ptr(a.resid, rw.rr, L, h), STRIDE_ROW, tq);
+        if (a.OUT && rw.valid) store_quarter(row_ptr(a.OUT, rw.row, L, h), STRIDE_ROW, tq, acc);
+        __syncthreads();                                               // the exchange buffers are rewritten by the next tile
+    }
+}
+
+// feature block t (wave-uniform) of a full row fragment, without dynamic register indexing
+DEVINL f32x16 pick_quarter(const f32x16 (&x)[4], int t) { return t == 0 ? x[0] : t == 1 ? x[1] : t == 2 ? x[2] : x[3]; }
+
+DEVINL void mask_quarter(f32x16& g, const f32x16& act) {
+#pragma unroll
+    for (int k = 0; k < 16; ++k) g[k] = act[k] > 0.f ? g[k] : 0.f;
+}
+
+template <int NIN>
+__global__ __launch_bounds__(256, 2) void k_mlp_bwd_coop(const TrainBwdArgs a) {
+    constexpr int L = 128, CH = L * L, QS = 4096;
+    constexpr float invL = 1.0f / L;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    f32x4* xch0 = reinterpret_cast<f32x4*>(smem);
+    f32x4* xch1 = xch0 + 16 * 64;
+    const int lane0 = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int tq = wave;
+    for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+        OPAQUE_LANE();
+        const RowRef rw = row_of(tile, c, a.rows);
+        f32x16 g[4], y[4], acc, q;
+        CoopRing r3, r2;
+        coop_prime(r3, a.W3T + CH + tq * QS, lane);
+        // every wave holds the full upstream row (it is the B operand of the first chain) and repeats the row statistics
+        load_frag<4>(g, row_ptr(a.G0, rw.rr, L, h), STRIDE_ROW);
+        if (a.G1) add_frag<4>(g, row_ptr(a.G1, a.g1idx ? (int64_t)a.g1idx[rw.rr] : rw.rr, L, h), STRIDE_ROW);
+        if (!rw.valid) zero_frag<4>(g);
+        if (a.ln) {
+            if (rw.valid) store_quarter(row_ptr(a.GT, rw.row, L, h), STRIDE_ROW, tq, pick_quarter(g, tq));
+            load_frag<4>(y, row_ptr(a.Y, rw.rr, L, h), STRIDE_ROW);
+            float s = 0.f;
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int k = 0; k < 16; ++k) s += y[t][k];
+            s += __shfl_xor(s, 32, 64);
+            const float mean = s * invL;
+            float v = 0.f;
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    const float d = y[t][k] - mean;
+                    y[t][k] = d;
+                    v += d * d;
+                }
+            v += __shfl_xor(v, 32, 64);
+            const float rstd = 1.0f / sqrtf(v * invL + LN_EPS);
+            float m1 = 0.f, m2 = 0.f;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                tab_quarter(q, a.tabs + T_GAMMA * L, t, h);            // gamma, feature block t
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    const float xh = y[t][k] * rstd;
+                    const float gg = g[t][k] * q[k];
+                    q[k] = g[t][k] * xh;                               // G * xhat  (-> dgamma)
+                    y[t][k] = xh;
+                    g[t][k] = gg;
+                    m1 += gg;
+                    m2 += gg * xh;
+                }
+                if (t == tq && rw.valid) store_quarter(row_ptr(a.GXH, rw.row, L, h), STRIDE_ROW, tq, q);
+            }
+            m1 += __shfl_xor(m1, 32, 64);
+            m2 += __shfl_xor(m2, 32, 64);
+            m1 *= invL;
+            m2 *= invL;
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int k = 0; k < 16; ++k) g[t][k] = rstd * (g[t][k] - m1 - y[t][k] * m2);
+        }
+        if (rw.valid) store_quarter(row_ptr(a.GY, rw.row, L, h), STRIDE_ROW, tq, pick_quarter(g, tq));
+        coop_prime(r2, a.W2T + CH + tq * QS, lane);
+        load_quarter(q, row_ptr(a.H2, rw.rr, L, h), STRIDE_ROW, tq);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) acc[k] = 0.f;
+        coop_chain_primed(acc, g, a.W3T + CH + tq * QS, lane, r3);     // gradient at H2
+        mask_quarter(acc, q);
+        if (rw.valid) store_quarter(row_ptr(a.GZ2, rw.row, L, h), STRIDE_ROW, tq, acc);
+        coop_exchange(y, acc, xch0, wave, lane);
+        load_quarter(q, row_ptr(a.H1, rw.rr, L, h), STRIDE_ROW, tq);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) acc[k] = 0.f;
+        coop_chain_primed(acc, y, a.W2T + CH + tq * QS, lane, r2);     // gradient at H1
+        mask_quarter(acc, q);
+        if (rw.valid) store_quarter(row_ptr(a.GZ1, rw.row, L, h), STRIDE_ROW, tq, acc);
+        coop_exchange(g, acc, xch1, wave, lane);
+#pragma unroll
+        for (int j = 0; j < NIN; ++j) {
+            if (!a.W1T[j]) continue;
+            if (a.GXadd[j]) load_quarter(acc, row_ptr(a.GXadd[j], rw.rr, L, h), STRIDE_ROW, tq);
+            else {
+#pragma unroll
+                for (int k = 0; k < 16; ++k) acc[k] = 0.f;
+            }
+            coop_chain(acc, g, a.W1T[j] + CH + tq * QS, lane);
+            if (rw.valid) store_quarter(row_ptr(a.GX[j], rw.row, L, h), STRIDE_ROW, tq, acc);
+        }
+        __syncthreads();
+    }
+}
+
+// ================================================================================================
 // weight gradient: dW[in][out] = sum_rows X[row][in] * G[row][out] on v_mfma_f32_32x32x2_f32 with the ROW index as the
 // reduction dimension: A operand = X^T (lane (m = l&31, k = l>>5) reads X[row 2q+k][32 ti + m], 128 contiguous bytes per
 // half wave), B operand = G (lane (n, k) reads G[row 2q+k][32 tj + n]).  Wave ti of a block owns input-feature block ti
@@ -329,6 +498,20 @@ __global__ void k_segment_sum(const float* __restrict__ src, const int32_t* __re
     reinterpret_cast<f32x4*>(out)[i] = s;
 }
 
+// out[n] = add[n] + sum over the receiver range of srcA + sum over the (permuted) sender range of srcB, in that order: the
+// two segmented sums of a processor step's backward in one launch (same summation order as two k_segment_sum passes)
+__global__ void k_segment_sum2(const float* __restrict__ srcA, const int32_t* __restrict__ rowptrA, const float* __restrict__ srcB,
+                               const int32_t* __restrict__ rowptrB, const int32_t* __restrict__ permB, const float* add, float* out, int32_t n,
+                               int L4) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)n * L4) return;
+    const int node = (int)(i / L4), q = (int)(i - (int64_t)node * L4);
+    f32x4 s = reinterpret_cast<const f32x4*>(add)[i];
+    for (int p = rowptrA[node]; p < rowptrA[node + 1]; ++p) s += reinterpret_cast<const f32x4*>(srcA)[(int64_t)p * L4 + q];
+    for (int p = rowptrB[node]; p < rowptrB[node + 1]; ++p) s += reinterpret_cast<const f32x4*>(srcB)[(int64_t)permB[p] * L4 + q];
+    reinterpret_cast<f32x4*>(out)[i] = s;
+}
+
 // dst [rows][L] = [ (srcA | srcB)[rows][wa + wb] * scale + shift | 0 ]   (scale == null: identity)
 __global__ void k_affine_pad(const float* __restrict__ srcA, int wa, const float* __restrict__ srcB, int wb, const float* __restrict__ scale,
                              const float* __restrict__ shift, float* __restrict__ dst, int L, int64_t rows) {
@@ -409,7 +592,23 @@ static hipError_t launch_tiles(K kern, const A& a, int ntiles, int L, hipStream_
     return hipGetLastError();
 }
 
+// Cooperative tiles while a launch has fewer than MGN_TRAIN_COOP_TILES_PER_CU tiles per CU (default 8), L = 128.
+static bool train_coop(int L, int ntiles) {
+    static const int per_cu = [] { const char* e = getenv("MGN_TRAIN_COOP_TILES_PER_CU"); return e ? atoi(e) : 8; }();
+    return L == 128 && ntiles > 0 && ntiles <= per_cu * 256;
+}
+template <typename K, typename A>
+static hipError_t launch_coop(K kern, const A& a, int ntiles, hipStream_t s) {
+    hipLaunchKernelGGL(kern, dim3((unsigned)ntiles), dim3(256), 2 * 16 * 64 * sizeof(f32x4), s, a);
+    return hipGetLastError();
+}
+
 hipError_t launch_mlp_fwd(int L, int nin, const TrainFwdArgs& a, hipStream_t s) {
+    if (train_coop(L, a.ntiles)) {
+        if (nin == 1) return launch_coop(k_mlp_fwd_coop<1>, a, a.ntiles, s);
+        if (nin == 2) return launch_coop(k_mlp_fwd_coop<2>, a, a.ntiles, s);
+        if (nin == 3) return launch_coop(k_mlp_fwd_coop<3>, a, a.ntiles, s);
+    }
 #define FWD_CASE(NT_, NIN_) if (L == 32 * NT_ && nin == NIN_) return launch_tiles(k_mlp_fwd<NT_, NIN_>, a, a.ntiles, L, s)
     FWD_CASE(4, 1); FWD_CASE(4, 2); FWD_CASE(4, 3);
     FWD_CASE(2, 1); FWD_CASE(2, 2); FWD_CASE(2, 3);
@@ -419,6 +618,11 @@ hipError_t launch_mlp_fwd(int L, int nin, const TrainFwdArgs& a, hipStream_t s) 
 }
 
 hipError_t launch_mlp_bwd(int L, int nin, const TrainBwdArgs& a, hipStream_t s) {
+    if (train_coop(L, a.ntiles)) {
+        if (nin == 1) return launch_coop(k_mlp_bwd_coop<1>, a, a.ntiles, s);
+        if (nin == 2) return launch_coop(k_mlp_bwd_coop<2>, a, a.ntiles, s);
+        if (nin == 3) return launch_coop(k_mlp_bwd_coop<3>, a, a.ntiles, s);
+    }
 #define BWD_CASE(NT_, NIN_) if (L == 32 * NT_ && nin == NIN_) return launch_tiles(k_mlp_bwd<NT_, NIN_>, a, a.ntiles, L, s)
     BWD_CASE(4, 1); BWD_CASE(4, 2); BWD_CASE(4, 3);
     BWD_CASE(2, 1); BWD_CASE(2, 2); BWD_CASE(2, 3);
@@ -463,6 +667,14 @@ hipError_t launch_segment_sum(int L, const float* src, const int32_t* rowptr, co
     const int64_t tot = (int64_t)n * (L / 4);
     if (tot <= 0) return hipSuccess;
     hipLaunchKernelGGL(k_segment_sum, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, src, rowptr, perm, add, out, n, L / 4);
+    return hipGetLastError();
+}
+
+hipError_t launch_segment_sum2(int L, const float* srcA, const int32_t* rowptrA, const float* srcB, const int32_t* rowptrB, const int32_t* permB,
+                               const float* add, float* out, int32_t n, hipStream_t s) {
+    const int64_t tot = (int64_t)n * (L / 4);
+    if (tot <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_segment_sum2, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, srcA, rowptrA, srcB, rowptrB, permB, add, out, n, L / 4);
     return hipGetLastError();
 }
 

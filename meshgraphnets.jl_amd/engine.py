@@ -32,6 +32,26 @@ def _c32(a, shape=None):
     return a
 
 
+def _host_or_device(a, shape, writable=False):
+    """(object kept alive, float* for the C ABI) of a NumPy array or a contiguous fp32 torch tensor (host or device: the
+    entry points that document it copy with hipMemcpyDefault)."""
+    if hasattr(a, "data_ptr"):                       # torch tensor
+        import torch
+        if a.dtype != torch.float32 or not a.is_contiguous():
+            raise ValueError("tensor arguments must be contiguous float32")
+        if tuple(a.shape) != tuple(shape):
+            raise ValueError(f"DimensionMismatch: expected {tuple(shape)}, got {tuple(a.shape)}")
+        return a, C.cast(C.c_void_p(a.data_ptr()), C.POINTER(C.c_float))
+    if writable:
+        if not (isinstance(a, np.ndarray) and a.dtype == np.float32 and a.flags.c_contiguous and a.flags.writeable):
+            raise ValueError("out must be a writable contiguous float32 array")
+        if tuple(a.shape) != tuple(shape):
+            raise ValueError(f"DimensionMismatch: expected {tuple(shape)}, got {tuple(a.shape)}")
+        return a, f32(a)
+    a = _c32(a, shape)
+    return a, f32(a)
+
+
 class Engine:
     """One engine handle == one mesh partition on one GPU (rank/nranks select the partition)."""
 
@@ -253,16 +273,20 @@ class Engine:
         self._chk(self.lib.mgn_rollout(self.h, C.byref(d)))
         return out, dict(n_accept=d.n_accept, n_reject=d.n_reject, n_rhs=d.n_rhs)
 
-    def step(self, nf, ef, target, mask, mask_index_base=0):
+    def step(self, nf, ef, target, mask, mask_index_base=0, out=None):
         """step!(mgn, graph, target, mask, mse_reduce) (reference src/strategies.jl:418-422): returns (gs, loss) with gs
-        in the packed order of set_params."""
-        nf = _c32(nf, (self.N, self.cfg.Fn))
-        ef = _c32(ef, (self.E, self.cfg.Fe))
-        target = _c32(target, (self.N, self.cfg.O))
+        in the packed order of set_params.  nf / ef / target may be NumPy arrays or contiguous fp32 torch tensors on
+        the engine's GPU (the reference keeps the graph on the device); `out`: a NumPy array or device tensor of
+        param_count floats that receives the gradients (device: no PCIe transfer, the optimiser runs where they are)."""
+        nf, p_nf = _host_or_device(nf, (self.N, self.cfg.Fn))
+        ef, p_ef = _host_or_device(ef, (self.E, self.cfg.Fe))
+        target, p_t = _host_or_device(target, (self.N, self.cfg.O))
         mask = np.ascontiguousarray(mask, dtype=np.int32).ravel()
-        gs = np.zeros(self.param_count, np.float32)
+        if out is None:
+            out = np.zeros(self.param_count, np.float32)
+        gs, p_gs = _host_or_device(out, (self.param_count,), writable=True)
         loss = C.c_float()
-        self._chk(self.lib.mgn_step(self.h, f32(nf), f32(ef), f32(target), i32(mask), mask.size, mask_index_base, f32(gs), gs.size,
+        self._chk(self.lib.mgn_step(self.h, p_nf, p_ef, p_t, i32(mask), mask.size, mask_index_base, p_gs, self.param_count,
                                     C.byref(loss)))
         return gs, loss.value
 
