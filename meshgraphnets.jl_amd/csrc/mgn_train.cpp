@@ -44,7 +44,20 @@ struct TrainState {
     // weight gradients + their reductions go to a second stream (small meshes leave most of the chip idle during k_mlp_bwd)
     hipStream_t aux = nullptr;
     hipEvent_t ev_bwd = nullptr, ev_wg[GSETS] = {};
+    // hipGraph replay of the two launch sequences over fixed buffers (small meshes): [0] forward, [1] backward of mgn_step,
+    // [2] backward of mgn_ode_vjp (it also produces the input gradient).  Eager once, captured on the next call.
+    hipGraphExec_t exec[3] = {nullptr, nullptr, nullptr};
+    bool warm[3] = {false, false, false};
+    const void* exec_arena = nullptr; const void* exec_w = nullptr;
+    void drop_graphs() {
+        for (int i = 0; i < 3; ++i) {
+            if (exec[i]) (void)hipGraphExecDestroy(exec[i]);
+            exec[i] = nullptr;
+            warm[i] = false;
+        }
+    }
     ~TrainState() {
+        drop_graphs();
         if (ev_bwd) (void)hipEventDestroy(ev_bwd);
         for (hipEvent_t e : ev_wg) if (e) (void)hipEventDestroy(e);
         if (aux) (void)hipStreamDestroy(aux);
@@ -217,6 +230,7 @@ int prepare_graph(mgn_engine* h) {
     T.pw = take((size_t)5 * (nb > 0 ? nb : 1) * L * L);             // one partial-dW region per weight-gradient job of an MLP
     T.pb = take((size_t)WGRAD_MAX_JOBS * (nb > 0 ? nb : 1) * L);
     T.arena_floats = off;
+    T.drop_graphs();
     HIPCHK(h, T.arena.ensure(off * 4));
     HIPCHK(h, T.target.ensure((size_t)(N > 0 ? N : 1) * h->cfg.O * 4));
     T.graph_ready = true;
@@ -320,10 +334,44 @@ int train_run(mgn_handle* h, const TrainJob& J) {
         return launch_mlp_fwd(L, m.nin, a, st);
     };
 
+    // Small meshes replay both launch sequences from hipGraphs (everything they touch lives at fixed addresses in the arena;
+    // the inputs, the seed of the reverse pass and the results stay outside).  The captured pointers are checked per call.
+    const bool graphable = h->use_graph && !h->prof && T.gsets > 1;
+    if (T.exec_arena != T.arena.p || T.exec_w != T.w.p) {
+        T.drop_graphs();
+        T.exec_arena = T.arena.p;
+        T.exec_w = T.w.p;
+    }
+    auto graphed = [&](int slot, auto&& launches) -> int {
+        if (graphable && T.exec[slot]) {
+            HIPCHK(h, hipGraphLaunch(T.exec[slot], st));
+            return MGN_OK;
+        }
+        if (!graphable || !T.warm[slot]) {
+            T.warm[slot] = true;
+            return launches();
+        }
+        hipGraph_t graph = nullptr;
+        HIPCHK(h, hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+        const int rc = launches();
+        const hipError_t ce = hipStreamEndCapture(st, &graph);
+        if (rc != MGN_OK || ce != hipSuccess || !graph || hipGraphInstantiate(&T.exec[slot], graph, nullptr, nullptr, 0) != hipSuccess) {
+            if (graph) (void)hipGraphDestroy(graph);
+            T.exec[slot] = nullptr;
+            h->use_graph = 0;             // eager from here on
+            if (rc != MGN_OK) return rc;
+            return launches();
+        }
+        (void)hipGraphDestroy(graph);
+        HIPCHK(h, hipGraphLaunch(T.exec[slot], st));
+        return MGN_OK;
+    };
+
     // ---- forward, keeping activations
     const TrainMlp& m_en = T.mlp[0];
     const TrainMlp& m_ee = T.mlp[1];
     const TrainMlp& m_de = T.mlp.back();
+    auto forward_launches = [&]() -> int {
     HIPCHK(h, fwd(m_en, N, nt_n, A + T.nf_pad, nullptr, nullptr, nullptr, nullptr, nullptr, T.enH[0], T.enH[1], T.enH[2], nullptr, A + T.Vk[0], nullptr));
     HIPCHK(h, fwd(m_ee, E, nt_e, A + T.ef_pad, egid, nullptr, nullptr, nullptr, nullptr, T.eeH[0], T.eeH[1], T.eeH[2], nullptr, A + T.Ek[0], nullptr));
     for (int k = 0; k < mps; ++k) {
@@ -336,6 +384,9 @@ int train_run(mgn_handle* h, const TrainJob& J) {
                       A + T.Vk[k + 1], nullptr));
     }
     HIPCHK(h, fwd(m_de, N, nt_n, A + T.Vk[mps], nullptr, nullptr, nullptr, nullptr, nullptr, T.dH[0], T.dH[1], T.dH[2], nullptr, nullptr, nullptr));
+    return MGN_OK;
+    };
+    if (int rc = graphed(0, forward_launches)) return rc;
 
     // ---- seed of the reverse pass
     const int nlb = J.vjp ? 0 : loss_blocks(J.nmask);
@@ -421,6 +472,8 @@ int train_run(mgn_handle* h, const TrainJob& J) {
         return MGN_OK;
     };
 
+    auto backward_launches = [&]() -> int {
+    n_bwd = 0;
     int cur = 0;   // gV[cur], gE[cur] hold the gradients w.r.t. the latents entering the part of the model already unwound
     {
         float* gx[3] = {A + T.gV[cur], nullptr, nullptr};
@@ -473,9 +526,13 @@ int train_run(mgn_handle* h, const TrainJob& J) {
         if (int rc = bwd(m_ee, E, nt_e, A + T.gE[ecur], nullptr, nullptr, T.eeH[0], T.eeH[1], T.eeH[2], gx, gxadd, xin_e, xi_e)) return rc;
     }
 
-    // ---- results
-    if (overlap)                                         // the second stream is in order: its last event covers all of it
+    if (overlap)                                         // join: the second stream is in order, its last events cover all of it
         for (int i = 0; i < T.gsets && i < n_bwd; ++i) HIPCHK(h, hipStreamWaitEvent(st, T.ev_wg[i], 0));
+    return MGN_OK;
+    };
+    if (int rc = graphed(J.vjp ? 2 : 1, backward_launches)) return rc;
+
+    // ---- results
     std::vector<double> lp((size_t)nlb);
     HIPCHK(h, hipMemcpyAsync(J.grads, G, h->params.size() * 4, hipMemcpyDefault, st));
     if (!J.vjp) {

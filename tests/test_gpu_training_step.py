@@ -212,6 +212,37 @@ def test_recompute_mode_gives_the_same_gradients(monkeypatch):
     check_grads(res[1][0], ref, cfg)
 
 
+def test_step_device_arrays_and_graph_replay():
+    """nf / ef / target / grads may live on the device (hipMemcpyDefault, include/mgn_hip.h): same bits as the host call.  Four
+    calls in a row take the small-mesh path through its three stages -- eager, hipGraph capture, replay (forward and backward
+    sequences, the weight gradients on the second stream) -- and have to agree bitwise; new inputs must show through a replay."""
+    import torch
+    cfg = cfg_dict(L=128, mps=3)
+    pos, s, r = small_mesh(14, 11)
+    ps = make_params(cfg)
+    nf, ef, target, mask = problem(cfg, pos, s, r, seed=33)
+    eng = engine_for(cfg)
+    eng.set_params(ps)
+    eng.set_graph(s, r, pos.shape[0])
+    host = [eng.step(nf, ef, target, mask) for _ in range(4)]
+    for g, l in host[1:]:
+        assert l == host[0][1] and np.array_equal(g, host[0][0])
+    d = lambda a: torch.from_numpy(a).cuda()
+    out = torch.zeros(eng.param_count, device="cuda")
+    g_dev, l_dev = eng.step(d(nf), d(ef), d(target), mask, out=out)
+    assert g_dev is out and l_dev == host[0][1] and np.array_equal(out.cpu().numpy(), host[0][0])
+    buf = np.full(eng.param_count, np.nan, np.float32)
+    eng.step(nf, ef, target, mask, out=buf)
+    assert np.array_equal(buf, host[0][0])
+    nf2 = nf + 0.25
+    g2, l2 = eng.step(nf2, ef, target, mask)                 # replayed graphs, new inputs
+    ref, rl = orc.step_grads(ps, cfg, nf2, ef, s, r, target, mask)
+    assert abs(l2 - rl) <= TOL_LOSS * abs(rl)
+    check_grads(g2, ref, cfg)
+    with pytest.raises(ValueError):
+        eng.step(nf, ef, target, mask, out=np.zeros(eng.param_count + 1, np.float32))
+
+
 def test_solver_training_euler_discrete_adjoint():
     """train_step(::SolverTraining) with fixed-step Euler (reference src/strategies.jl:175-196, 257-292) through
     mgn_ode_step + mgn_ode_vjp, against the same discrete adjoint driven by the float64 oracle, and against a central
