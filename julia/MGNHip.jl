@@ -112,6 +112,9 @@ end
 the caller's loop `for i in eachindex(gs); opt_state, ps = Optimisers.update(opt_state, ps, gs[i]); end`
 (src/MeshGraphNets.jl:375-377) becomes a single `Optimisers.update(opt_state, mgn.ps, gs)` on the packed vector.
 `mask` are the Int32 node indices built at src/MeshGraphNets.jl:352 (1-based).  Only `mse_reduce` runs on the device.
+`mgn_step` copies with hipMemcpyDefault: with AMDGPU.jl arrays pass `pointer(graph.nf)` etc. of the ROCArrays and a
+`ROCVector{Float32}` for `gs` instead of the host copies made below, and the gradients never cross PCIe (the
+reference keeps graph, ps and gs on the GPU, src/MeshGraphNets.jl:255-263); `mask` stays a host vector.
 """
 function step!(mgn::GraphNetwork, graph::FeatureGraph, target::Matrix{Float32}, mask::Vector{Int32}, loss_function = nothing)
     ps = mgn.ps::Vector{Float32}
