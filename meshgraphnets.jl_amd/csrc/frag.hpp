@@ -159,17 +159,29 @@ DEVINL void mfma_chunk(f32x16 (&acc)[NT], const f32x16 (&in)[NT], const float* w
                 acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(aget<NT>(a, t), in[j >> 4][j & 15], acc[t], 0, 0, 0);
         }
     } else {
-        constexpr int PF = 4;  // k-steps in flight: 4 x (NT MFMA x 64 cyc) of cover for an L2 hit
+#ifndef MGN_CHUNK_PF
+#define MGN_CHUNK_PF 4
+#endif
+        constexpr int PF = MGN_CHUNK_PF;  // k-steps in flight: PF x (NT MFMA x 64 cyc) of cover for an L2 hit
         AV ring[PF];
 #pragma unroll
         for (int p = 0; p < PF; ++p) ring[p] = wv[p * 64];
+#ifdef MGN_CHUNK_FENCE
+        __builtin_amdgcn_sched_barrier(0);
+#endif
 #pragma unroll
         for (int j = 0; j < J; ++j) {
             const AV a = ring[j % PF];
             if (j + PF < J) ring[j % PF] = wv[(j + PF) * 64];
+#ifdef MGN_CHUNK_FENCE
+            __builtin_amdgcn_sched_barrier(0);
+#endif
 #pragma unroll
             for (int t = 0; t < NT; ++t)
                 acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(aget<NT>(a, t), in[j >> 4][j & 15], acc[t], 0, 0, 0);
+#ifdef MGN_CHUNK_FENCE
+            __builtin_amdgcn_sched_barrier(0);
+#endif
         }
     }
 }
@@ -189,6 +201,9 @@ DEVINL void mfma_chunk_split(f32x16 (&acc)[NT], const f32x16 (&in)[NT], const fl
     AV ring[PF > 0 ? PF : 1];
 #pragma unroll
     for (int p = 0; p < PF; ++p) ring[p] = wg[(JR + p) * 64];
+#ifdef MGN_SPLIT_FENCE
+    __builtin_amdgcn_sched_barrier(0);      // the requests go out HERE, not where hipcc would sink them (just before their use)
+#endif
 #pragma unroll
     for (int j = 0; j < J; ++j) {
         AV a;
@@ -197,10 +212,16 @@ DEVINL void mfma_chunk_split(f32x16 (&acc)[NT], const f32x16 (&in)[NT], const fl
         } else {
             a = ring[(j - JR) % PF];
             if (j + PF < J) ring[(j - JR) % PF] = wg[(j + PF) * 64];
+#ifdef MGN_SPLIT_FENCE
+            __builtin_amdgcn_sched_barrier(0);
+#endif
         }
 #pragma unroll
         for (int t = 0; t < NT; ++t)
             acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(aget<NT>(a, t), in[j >> 4][j & 15], acc[t], 0, 0, 0);
+#ifdef MGN_SPLIT_FENCE
+        if (j >= JR) __builtin_amdgcn_sched_barrier(0);
+#endif
     }
 }
 
@@ -293,21 +314,30 @@ DEVINL void coop_prime(CoopRing& ring, const float* wt, int lane) {
 #pragma unroll
     for (int p = 0; p < COOP_PF; ++p) ring.r[p] = wv[p * 64];
 }
+// FENCE pins the ring with scheduling fences: group m consumes slot m % COOP_PF and requests group m + COOP_PF before its
+// four MFMAs.  Left alone hipcc sinks every request to just before its use (an effective depth of 1-2), which costs a launch
+// with one or two tiles per CU 2-3 % (nothing else hides the L2 round trips) -- but the fences take away the freedom the
+// scheduler needs when several tiles per SIMD alternate (+4 % at 6 tiles per CU, +11 % at 12): the launch wrappers pick.
+template <bool FENCE>
 DEVINL void coop_chain_primed(f32x16& acc, const f32x16 (&in)[4], const float* wt, int lane, CoopRing& ring) {
     const f32x4* wv = reinterpret_cast<const f32x4*>(wt) + lane;
 #pragma unroll
     for (int m = 0; m < 16; ++m) {
         const f32x4 a = ring.r[m % COOP_PF];
         if (m + COOP_PF < 16) ring.r[m % COOP_PF] = wv[(m + COOP_PF) * 64];
+        if constexpr (FENCE) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int i = 0; i < 4; ++i)
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], in[m >> 2][4 * (m & 3) + i], acc, 0, 0, 0);
+        if constexpr (FENCE) __builtin_amdgcn_sched_barrier(0);
     }
 }
+template <bool FENCE>
 DEVINL void coop_chain(f32x16& acc, const f32x16 (&in)[4], const float* wt, int lane) {
     CoopRing ring;
     coop_prime(ring, wt, lane);
-    coop_chain_primed(acc, in, wt, lane, ring);
+    if constexpr (FENCE) __builtin_amdgcn_sched_barrier(0);
+    coop_chain_primed<FENCE>(acc, in, wt, lane, ring);
 }
 
 // every wave publishes its 16-register slice and reads back the full 64-register row fragment

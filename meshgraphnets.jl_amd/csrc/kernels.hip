@@ -380,6 +380,7 @@ __global__ __launch_bounds__(MGN_PROJ_WAVES * 64, MGN_PROJ_WAVES / 4) void k_pro
 // (CoopRing, coop_prime / coop_chain*, coop_exchange, coop_layer_norm*: frag.hpp -- shared with the training kernels)
 
 // chunk_t[0]=W2 [1]=W3 [2]=W1e  (t-major)
+template <bool FENCE>
 __global__ __launch_bounds__(256, 2) void k_edge_coop(const EdgeArgs a) {
     constexpr int L = 128;
     const int stamp_tile = 0;
@@ -422,7 +423,7 @@ __global__ __launch_bounds__(256, 2) void k_edge_coop(const EdgeArgs a) {
         coop_prime(ring2, a.chunk_t[0] + tq * 4096, lane);                  // layer 2's first fragments, ahead of time
 #pragma unroll
         for (int k = 0; k < 16; ++k) acc[k] = 0.f;
-        coop_chain(acc, x, a.chunk_t[2] + tq * 4096, lane);                 // layer 1 (edge part)
+        coop_chain<FENCE>(acc, x, a.chunk_t[2] + tq * 4096, lane);                 // layer 1 (edge part)
         acc += pq;
         acc += qq;
         STAMP(2);
@@ -431,12 +432,12 @@ __global__ __launch_bounds__(256, 2) void k_edge_coop(const EdgeArgs a) {
         coop_exchange(in, acc, xch0, wave, lane);
         STAMP(3);
         acc = b2q;
-        coop_chain_primed(acc, in, a.chunk_t[0] + tq * 4096, lane, ring2);  // layer 2
+        coop_chain_primed<FENCE>(acc, in, a.chunk_t[0] + tq * 4096, lane, ring2);  // layer 2
         relu_quarter(acc);
         coop_exchange(in, acc, xch1, wave, lane);
         STAMP(4);
         acc = b3q;
-        coop_chain_primed(acc, in, a.chunk_t[1] + tq * 4096, lane, ring3);  // layer 3
+        coop_chain_primed<FENCE>(acc, in, a.chunk_t[1] + tq * 4096, lane, ring3);  // layer 3
         coop_exchange(in, acc, xch0, wave, lane);                           // full pre-LN row (for the statistics)
         STAMP(5);
         coop_layer_norm_reg(acc, in, gq, bq);                               // acc = this wave's quarter of e'
@@ -478,7 +479,7 @@ __global__ __launch_bounds__(256, 2) void k_edge_coop(const EdgeArgs a) {
 }
 
 // chunk_t[0]=W2 [1]=W3 [2]=W1v [3]=W1a [4]=WP [5]=WQ (t-major).  mode as in NodeArgs.
-template <bool TWO_SETS>
+template <bool TWO_SETS, bool FENCE>
 __global__ __launch_bounds__(256, 2) void k_node_coop(const NodeArgs a) {
     constexpr int L = 128;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -505,23 +506,23 @@ __global__ __launch_bounds__(256, 2) void k_node_coop(const NodeArgs a) {
             CoopRing ra, rb;
             tab_quarter(acc, tb + T_B1 * L, tq, h);
             coop_prime(ra, a.chunk_t[3] + tq * 4096, lane);
-            coop_chain(acc, v, a.chunk_t[2] + tq * 4096, lane);             // layer 1, node part
+            coop_chain<FENCE>(acc, v, a.chunk_t[2] + tq * 4096, lane);             // layer 1, node part
             coop_prime(rb, a.chunk_t[0] + tq * 4096, lane);
-            coop_chain_primed(acc, in, a.chunk_t[3] + tq * 4096, lane, ra); // layer 1, aggregate part
+            coop_chain_primed<FENCE>(acc, in, a.chunk_t[3] + tq * 4096, lane, ra); // layer 1, aggregate part
             if constexpr (TWO_SETS) {                                       // second edge set's aggregate
                 LOAD_AGGREGATE(4, in, a.rowptr2, a.AGG2, a.CARRY2, a.zero_row2);
-                coop_chain(acc, in, a.chunk_t[6] + tq * 4096, lane);
+                coop_chain<FENCE>(acc, in, a.chunk_t[6] + tq * 4096, lane);
             }
             relu_quarter(acc);
             coop_prime(ra, a.chunk_t[1] + tq * 4096, lane);
             coop_exchange(in, acc, xch0, wave, lane);
             tab_quarter(acc, tb + T_B2 * L, tq, h);
-            coop_chain_primed(acc, in, a.chunk_t[0] + tq * 4096, lane, rb); // layer 2
+            coop_chain_primed<FENCE>(acc, in, a.chunk_t[0] + tq * 4096, lane, rb); // layer 2
             relu_quarter(acc);
             coop_exchange(in, acc, xch1, wave, lane);
             tab_quarter(acc, tb + T_B3 * L, tq, h);
             if (a.mode == 1) coop_prime(rb, a.chunk_t[4] + tq * 4096, lane);
-            coop_chain_primed(acc, in, a.chunk_t[1] + tq * 4096, lane, ra); // layer 3
+            coop_chain_primed<FENCE>(acc, in, a.chunk_t[1] + tq * 4096, lane, ra); // layer 3
             coop_exchange(in, acc, xch0, wave, lane);
             coop_layer_norm(acc, in, tb + T_GAMMA * L, tb + T_BETA * L, tq, h);
             vq += acc;                                                      // v <- v + v'  (this wave's quarter)
@@ -531,10 +532,10 @@ __global__ __launch_bounds__(256, 2) void k_node_coop(const NodeArgs a) {
                 coop_exchange(v, vq, xch1, wave, lane);                      // full updated row for the projection
 #pragma unroll
                 for (int k = 0; k < 16; ++k) acc[k] = 0.f;
-                coop_chain_primed(acc, v, a.chunk_t[4] + tq * 4096, lane, rb);
+                coop_chain_primed<FENCE>(acc, v, a.chunk_t[4] + tq * 4096, lane, rb);
                 if (valid) store_quarter(row_ptr(a.P, nn, L, h), STRIDE_ROW, tq, acc);
                 tab_quarter(acc, tb + T_BQ * L, tq, h);
-                coop_chain_primed(acc, v, a.chunk_t[5] + tq * 4096, lane, ra);
+                coop_chain_primed<FENCE>(acc, v, a.chunk_t[5] + tq * 4096, lane, ra);
                 if (valid) store_quarter(row_ptr(a.Q, nn, L, h), STRIDE_ROW, tq, acc);
             }
         }
@@ -543,10 +544,10 @@ __global__ __launch_bounds__(256, 2) void k_node_coop(const NodeArgs a) {
             coop_prime(rq, a.chunk_t[5] + tq * 4096, lane);
 #pragma unroll
             for (int k = 0; k < 16; ++k) acc[k] = 0.f;
-            coop_chain(acc, v, a.chunk_t[4] + tq * 4096, lane);
+            coop_chain<FENCE>(acc, v, a.chunk_t[4] + tq * 4096, lane);
             if (valid) store_quarter(row_ptr(a.P, nn, L, h), STRIDE_ROW, tq, acc);
             tab_quarter(acc, tb + T_BQ * L, tq, h);
-            coop_chain_primed(acc, v, a.chunk_t[5] + tq * 4096, lane, rq);
+            coop_chain_primed<FENCE>(acc, v, a.chunk_t[5] + tq * 4096, lane, rq);
             if (valid) store_quarter(row_ptr(a.Q, nn, L, h), STRIDE_ROW, tq, acc);
         }
         __syncthreads();
@@ -624,6 +625,7 @@ __global__ __launch_bounds__(512, 2) void k_enc_node(const EncNodeArgs a) {
 // mesh the one-wave-per-tile encoder / decoder cost 60 + 32 us of every 840 us right-hand side of a rollout.
 // ================================================================================================
 // chunk[0]=W2 [1]=W3 [2]=WP [3]=WQ; the t-major copy of a chunk follows its fragment-major copy (mgn_set_params)
+template <bool FENCE>
 __global__ __launch_bounds__(256, 2) void k_enc_node_coop(const EncNodeArgs a) {
     constexpr int L = 128, CH = L * L;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -659,12 +661,12 @@ __global__ __launch_bounds__(256, 2) void k_enc_node_coop(const EncNodeArgs a) {
         relu_frag<4>(in);
         tab_quarter(acc, tb + T_B2 * L, tq, h);
         coop_prime(r3, w3, lane);
-        coop_chain_primed(acc, in, w2, lane, r2);                            // layer 2
+        coop_chain_primed<FENCE>(acc, in, w2, lane, r2);                            // layer 2
         relu_quarter(acc);
         coop_exchange(in, acc, xch0, wave, lane);
         tab_quarter(acc, tb + T_B3 * L, tq, h);
         coop_prime(r2, wp, lane);
-        coop_chain_primed(acc, in, w3, lane, r3);                            // layer 3
+        coop_chain_primed<FENCE>(acc, in, w3, lane, r3);                            // layer 3
         coop_exchange(in, acc, xch1, wave, lane);
         coop_layer_norm(acc, in, tb + T_GAMMA * L, tb + T_BETA * L, tq, h);
         if (!valid) {
@@ -676,16 +678,17 @@ __global__ __launch_bounds__(256, 2) void k_enc_node_coop(const EncNodeArgs a) {
         coop_exchange(in, acc, xch0, wave, lane);                            // full latent row for the projection
 #pragma unroll
         for (int k = 0; k < 16; ++k) acc[k] = 0.f;
-        coop_chain_primed(acc, in, wp, lane, r2);
+        coop_chain_primed<FENCE>(acc, in, wp, lane, r2);
         if (valid) store_quarter(row_ptr(a.P, nn, L, h), STRIDE_ROW, tq, acc);
         tab_quarter(acc, tb + T_BQ * L, tq, h);
-        coop_chain_primed(acc, in, wq, lane, r3);
+        coop_chain_primed<FENCE>(acc, in, wq, lane, r3);
         if (valid) store_quarter(row_ptr(a.Q, nn, L, h), STRIDE_ROW, tq, acc);
         __syncthreads();
     }
 }
 
 // edge encoder: chunk[0]=W2 [1]=W3
+template <bool FENCE>
 __global__ __launch_bounds__(256, 2) void k_enc_edge_coop(const EncEdgeArgs a) {
     constexpr int L = 128, CH = L * L;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -716,11 +719,11 @@ __global__ __launch_bounds__(256, 2) void k_enc_edge_coop(const EncEdgeArgs a) {
         relu_frag<4>(in);
         tab_quarter(acc, tb + T_B2 * L, tq, h);
         coop_prime(r3, w3, lane);
-        coop_chain_primed(acc, in, w2, lane, r2);
+        coop_chain_primed<FENCE>(acc, in, w2, lane, r2);
         relu_quarter(acc);
         coop_exchange(in, acc, xch0, wave, lane);
         tab_quarter(acc, tb + T_B3 * L, tq, h);
-        coop_chain_primed(acc, in, w3, lane, r3);
+        coop_chain_primed<FENCE>(acc, in, w3, lane, r3);
         coop_exchange(in, acc, xch1, wave, lane);
         coop_layer_norm(acc, in, tb + T_GAMMA * L, tb + T_BETA * L, tq, h);
         if (!valid) {
@@ -733,6 +736,7 @@ __global__ __launch_bounds__(256, 2) void k_enc_edge_coop(const EncEdgeArgs a) {
 }
 
 // chunk[0]=W1 [1]=W2; last layer (L -> O) by wave 0 from the exchanged row
+template <bool FENCE>
 __global__ __launch_bounds__(256, 2) void k_decode_coop(const DecArgs a) {
     constexpr int L = 128, CH = L * L;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -756,11 +760,11 @@ __global__ __launch_bounds__(256, 2) void k_decode_coop(const DecArgs a) {
         coop_prime(r2, w2, lane);
         load_frag<4>(in, tile_ptr(a.V, tile, L, lane), STRIDE_TILE);
         tab_quarter(acc, tb + T_B1 * L, tq, h);
-        coop_chain(acc, in, w1, lane);
+        coop_chain<FENCE>(acc, in, w1, lane);
         relu_quarter(acc);
         coop_exchange(in, acc, xch0, wave, lane);
         tab_quarter(acc, tb + T_B2 * L, tq, h);
-        coop_chain_primed(acc, in, w2, lane, r2);
+        coop_chain_primed<FENCE>(acc, in, w2, lane, r2);
         relu_quarter(acc);
         coop_exchange(in, acc, xch1, wave, lane);
         if (wave == 0) {
@@ -1403,6 +1407,11 @@ static hipError_t launch_k(K kern, const A& a, const LaunchCfg& lc, hipStream_t 
 
 hipError_t launch_project(int L, const NodeArgs& a, hipStream_t s);
 
+// pinned weight rings (coop_chain_primed<true>) while a launch has at most MGN_COOP_FENCE_TILES_PER_CU (default 4) tiles per CU
+static bool coop_fence(int ntiles) {
+    static const int per_cu = [] { const char* e = getenv("MGN_COOP_FENCE_TILES_PER_CU"); return e ? atoi(e) : 4; }();
+    return ntiles <= per_cu * 256;
+}
 static size_t coop_lds() { return (size_t)2 * 16 * 64 * 16 + (size_t)T_COUNT * 128 * 4; }
 static bool coop_ok(int L, int ntiles, const float* const* chunk_t, bool edge = false) {
     return L == 128 && chunk_t[0] != nullptr && coop_size(ntiles, edge);
@@ -1414,7 +1423,7 @@ hipError_t launch_edge_step(int L, const EdgeArgs& a, hipStream_t s) {
     LaunchCfg lc = tile_launch(L, a.ntiles, nres);
     if (coop_ok(L, a.ntiles, a.chunk_t, true)) {   // small graph: 4 waves per tile
         LaunchCfg c4{a.ntiles, 256, coop_lds()};
-        return launch_k(k_edge_coop, a, c4, s);
+        return coop_fence(a.ntiles) ? launch_k(k_edge_coop<true>, a, c4, s) : launch_k(k_edge_coop<false>, a, c4, s);
     }
     if (L == 128) {
         if (small_launch(a.ntiles)) {   // few tiles: the per-block LDS preload would dominate -> stream everything from L2
@@ -1435,7 +1444,7 @@ hipError_t launch_edge_step(int L, const EdgeArgs& a, hipStream_t s) {
             const hipError_t e = launch_k(k_edge_step<4, 2>, body, lc, s);
             if (e != hipSuccess) return e;
             LaunchCfg c4{rem, 256, coop_lds()};
-            return launch_k(k_edge_coop, tail, c4, s);
+            return launch_k(k_edge_coop<false>, tail, c4, s);
         }
         return launch_k(k_edge_step<4, 2>, a, lc, s);
     }
@@ -1447,7 +1456,8 @@ hipError_t launch_node_step(int L, const NodeArgs& a, hipStream_t s) {
     if (a.ntiles <= 0) return hipSuccess;
     if (coop_ok(L, a.ntiles, a.chunk_t)) {
         LaunchCfg c4{a.ntiles, 256, coop_lds()};
-        return a.AGG2 ? launch_k(k_node_coop<true>, a, c4, s) : launch_k(k_node_coop<false>, a, c4, s);
+        if (coop_fence(a.ntiles)) return a.AGG2 ? launch_k(k_node_coop<true, true>, a, c4, s) : launch_k(k_node_coop<false, true>, a, c4, s);
+        return a.AGG2 ? launch_k(k_node_coop<true, false>, a, c4, s) : launch_k(k_node_coop<false, false>, a, c4, s);
     }
     if (a.mode == 2) return launch_project(L, a, s);
     const bool proj = a.mode == 1;
@@ -1484,7 +1494,8 @@ hipError_t launch_project(int L, const NodeArgs& a, hipStream_t s) {
     LaunchCfg lc = tile_launch(L, a.ntiles, 2);
     if (a.tile0 == 0 && a.mode == 2 && coop_ok(L, a.ntiles, a.chunk_t)) {
         LaunchCfg c4{a.ntiles, 256, coop_lds()};
-        return a.AGG2 ? launch_k(k_node_coop<true>, a, c4, s) : launch_k(k_node_coop<false>, a, c4, s);
+        if (coop_fence(a.ntiles)) return a.AGG2 ? launch_k(k_node_coop<true, true>, a, c4, s) : launch_k(k_node_coop<false, true>, a, c4, s);
+        return a.AGG2 ? launch_k(k_node_coop<true, false>, a, c4, s) : launch_k(k_node_coop<false, false>, a, c4, s);
     }
     if (L == 128 && small_launch(a.ntiles)) {
         lc.lds = (size_t)T_COUNT * L * 4 + 64;
@@ -1501,21 +1512,21 @@ hipError_t launch_project(int L, const NodeArgs& a, hipStream_t s) {
 hipError_t launch_enc_node(int L, const EncNodeArgs& a, hipStream_t s) {
     if (a.ntiles > 0 && L == 128 && coop_size(a.ntiles, false)) {
         LaunchCfg c4{a.ntiles, 256, coop_lds()};
-        return launch_k(k_enc_node_coop, a, c4, s);
+        return coop_fence(a.ntiles) ? launch_k(k_enc_node_coop<true>, a, c4, s) : launch_k(k_enc_node_coop<false>, a, c4, s);
     }
     DISPATCH_L(k_enc_node, 4, a, a.ntiles);
 }
 hipError_t launch_enc_edge(int L, const EncEdgeArgs& a, hipStream_t s) {
     if (a.ntiles > 0 && L == 128 && coop_size(a.ntiles, true)) {
         LaunchCfg c4{a.ntiles, 256, coop_lds()};
-        return launch_k(k_enc_edge_coop, a, c4, s);
+        return coop_fence(a.ntiles) ? launch_k(k_enc_edge_coop<true>, a, c4, s) : launch_k(k_enc_edge_coop<false>, a, c4, s);
     }
     DISPATCH_L(k_enc_edge, 2, a, a.ntiles);
 }
 hipError_t launch_decode(int L, const DecArgs& a, hipStream_t s) {
     if (a.ntiles > 0 && L == 128 && coop_size(a.ntiles, false)) {
         LaunchCfg c4{a.ntiles, 256, coop_lds()};
-        return launch_k(k_decode_coop, a, c4, s);
+        return coop_fence(a.ntiles) ? launch_k(k_decode_coop<true>, a, c4, s) : launch_k(k_decode_coop<false>, a, c4, s);
     }
     DISPATCH_L(k_decode, 2, a, a.ntiles);
 }

@@ -236,29 +236,9 @@ DEVINL void add_quarter(f32x16& q, const f32x4* __restrict__ p, int stride, int 
     }
 }
 
-// The chains of these kernels pin their weight ring with scheduling fences: k-step group m consumes ring slot m % COOP_PF and
-// requests group m + COOP_PF BEFORE its four MFMAs.  (Left to itself hipcc sinks each request to just before its use when
-// many row-fragment registers are live, and every group then waits a full L2 round trip: 3-4 x the chain's MFMA time.)
-DEVINL void tchain_primed(f32x16& acc, const f32x16 (&in)[4], const float* wt, int lane, CoopRing& ring) {
-    const f32x4* wv = reinterpret_cast<const f32x4*>(wt) + lane;
-#pragma unroll
-    for (int m = 0; m < 16; ++m) {
-        const f32x4 a = ring.r[m % COOP_PF];
-        if (m + COOP_PF < 16) ring.r[m % COOP_PF] = wv[(m + COOP_PF) * 64];
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], in[m >> 2][4 * (m & 3) + i], acc, 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-    }
-}
-DEVINL void tchain(f32x16& acc, const f32x16 (&in)[4], const float* wt, int lane) {
-    CoopRing ring;
-    coop_prime(ring, wt, lane);
-    __builtin_amdgcn_sched_barrier(0);
-    tchain_primed(acc, in, wt, lane, ring);
-}
-
+// The chains of these kernels pin their weight ring with scheduling fences (coop_chain_primed<true>, frag.hpp): with many
+// row-fragment registers live hipcc otherwise sinks each request to just before its use and every k-step group waits a full
+// L2 round trip (3-4 x the chain's MFMA time).
 template <int NIN>
 __global__ __launch_bounds__(256, 2) void k_mlp_fwd_coop(const TrainFwdArgs a) {
     constexpr int L = 128, CH = L * L, QS = 4096;     // QS: one wave's t-slice of a chunk
@@ -282,29 +262,29 @@ __global__ __launch_bounds__(256, 2) void k_mlp_fwd_coop(const TrainFwdArgs a) {
         // Fences: without them hipcc sinks the (gathered, slow) row loads INTO the MFMA chains, a few pieces ahead of their use,
         // where they queue in front of the weight ring's loads (vmcnt retires in order) and every k-step waits for memory.
         PHASE_FENCE();
-        tchain(acc, xa, a.W1[0] + CH + tq * QS, lane);
+        coop_chain<true>(acc, xa, a.W1[0] + CH + tq * QS, lane);
         PHASE_FENCE();
         if constexpr (NIN > 2) load_frag<4>(xa, row_ptr(a.X[2], src[2], L, h), STRIDE_ROW);
         if constexpr (NIN <= 2) coop_prime(r2, a.W2 + CH + tq * QS, lane);
         PHASE_FENCE();
-        if constexpr (NIN > 1) tchain(acc, xb, a.W1[1] + CH + tq * QS, lane);
+        if constexpr (NIN > 1) coop_chain<true>(acc, xb, a.W1[1] + CH + tq * QS, lane);
         PHASE_FENCE();
         if constexpr (NIN > 2) {
             coop_prime(r2, a.W2 + CH + tq * QS, lane);
             PHASE_FENCE();
-            tchain(acc, xa, a.W1[2] + CH + tq * QS, lane);
+            coop_chain<true>(acc, xa, a.W1[2] + CH + tq * QS, lane);
         }
         relu_quarter(acc);
         if (rw.valid) store_quarter(row_ptr(a.H1, rw.row, L, h), STRIDE_ROW, tq, acc);
         coop_exchange(xa, acc, xch0, wave, lane);
         coop_prime(r3, a.W3 + CH + tq * QS, lane);
         tab_quarter(acc, a.tabs + T_B2 * L, tq, h);
-        tchain_primed(acc, xa, a.W2 + CH + tq * QS, lane, r2);
+        coop_chain_primed<true>(acc, xa, a.W2 + CH + tq * QS, lane, r2);
         relu_quarter(acc);
         if (rw.valid) store_quarter(row_ptr(a.H2, rw.row, L, h), STRIDE_ROW, tq, acc);
         coop_exchange(xb, acc, xch1, wave, lane);
         tab_quarter(acc, a.tabs + T_B3 * L, tq, h);
-        tchain_primed(acc, xb, a.W3 + CH + tq * QS, lane, r3);
+        coop_chain_primed<true>(acc, xb, a.W3 + CH + tq * QS, lane, r3);
         if (rw.valid) store_quarter(row_ptr(a.Y, rw.row, L, h), STRIDE_ROW, tq, acc);
         if (a.ln) {
             coop_exchange(xa, acc, xch0, wave, lane);                  // full pre-LN row for the statistics
@@ -397,7 +377,7 @@ __global__ __launch_bounds__(256, 2) void k_mlp_bwd_coop(const TrainBwdArgs a) {
         PHASE_FENCE();                                                 // (see k_mlp_fwd_coop: loads stay outside the chains)
 #pragma unroll
         for (int k = 0; k < 16; ++k) acc[k] = 0.f;
-        tchain_primed(acc, g, a.W3T + CH + tq * QS, lane, r3);     // gradient at H2
+        coop_chain_primed<true>(acc, g, a.W3T + CH + tq * QS, lane, r3);     // gradient at H2
         mask_quarter(acc, q);
         if (rw.valid) store_quarter(row_ptr(a.GZ2, rw.row, L, h), STRIDE_ROW, tq, acc);
         coop_exchange(y, acc, xch0, wave, lane);
@@ -405,7 +385,7 @@ __global__ __launch_bounds__(256, 2) void k_mlp_bwd_coop(const TrainBwdArgs a) {
         PHASE_FENCE();
 #pragma unroll
         for (int k = 0; k < 16; ++k) acc[k] = 0.f;
-        tchain_primed(acc, y, a.W2T + CH + tq * QS, lane, r2);     // gradient at H1
+        coop_chain_primed<true>(acc, y, a.W2T + CH + tq * QS, lane, r2);     // gradient at H1
         mask_quarter(acc, q);
         if (rw.valid) store_quarter(row_ptr(a.GZ1, rw.row, L, h), STRIDE_ROW, tq, acc);
         coop_exchange(g, acc, xch1, wave, lane);
@@ -417,7 +397,7 @@ __global__ __launch_bounds__(256, 2) void k_mlp_bwd_coop(const TrainBwdArgs a) {
 #pragma unroll
                 for (int k = 0; k < 16; ++k) acc[k] = 0.f;
             }
-            tchain(acc, g, a.W1T[j] + CH + tq * QS, lane);
+            coop_chain<true>(acc, g, a.W1T[j] + CH + tq * QS, lane);
             if (rw.valid) store_quarter(row_ptr(a.GX[j], rw.row, L, h), STRIDE_ROW, tq, acc);
         }
         __syncthreads();
