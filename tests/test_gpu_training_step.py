@@ -3,6 +3,7 @@ reverse-mode oracle (oracle/mgn_oracle.py step_grads, itself checked against fin
 Run on the MI355X box with `-m gpu`."""
 import numpy as np
 import pytest
+import torch   # before the engine's first HIP call (device-array test), or torch finds no GPU afterwards
 
 import mgn_oracle as orc
 from mgn_amd import synth

@@ -33,7 +33,9 @@ for it in range(int(sys.argv[1]) if len(sys.argv) > 1 else 120):
     eng.set_static(onehot, ef, np.ones(N, np.float32))
     for _ in range(3): eng.ode_step(vel)
     mask = np.nonzero(np.isin(ntype, [0, 5]))[0].astype(np.int32)
-    eng.step(nf, ef, rng.standard_normal((N, 2)).astype(np.float32), mask)
+    tgt = rng.standard_normal((N, 2)).astype(np.float32)
+    for _ in range(4):          # eager, hipGraph capture (forward + backward sequences), two replays; dropped by the next set_graph
+        eng.step(nf, ef, tgt, mask)
     eng.rollout("Euler", vel, onehot, ef, 0.0, 0.03, 0.01, 4, dt=0.01)
     eng.rollout("Tsit5", vel, onehot, ef, 0.0, 0.02, 0.01, 3)
     eng.latents_randn(it); eng.processor_steps_dev(15); eng.processor_steps_dev(15); eng.processor_steps_dev(15)
