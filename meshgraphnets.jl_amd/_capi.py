@@ -7,6 +7,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "lib", "libmgn_hip.so")
@@ -115,6 +116,14 @@ def load(path: str | None = None):
         raise RuntimeError(
             f"HIP extension {p} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950).  This package has no CPU fallback.")
+    # PyTorch-ROCm wheels bundle their own libamdhip64; two HIP runtimes in one process fight over the device and the one
+    # that initialises second reports "No HIP GPUs are available".  Importing torch first makes this library resolve to
+    # the runtime that is already loaded (device tensors at the boundary, torch.distributed for the halo exchange).
+    if os.environ.get("MGN_TORCH_PRELOAD", "1") != "0" and "torch" not in sys.modules:
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
     lib = C.CDLL(p, mode=C.RTLD_LOCAL)
     for name, (res, args) in PROTOTYPES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported

@@ -69,3 +69,22 @@ def test_real_engines_in_separate_processes(world, dtype):
             assert res["dv"] <= 1e-4 and res["de"] <= 1e-4, (res["dv"], res["de"])
         else:
             assert res["lv"] <= 3e-2 and res["le"] <= 3e-2, (res["lv"], res["le"])
+
+
+def test_engine_first_then_torch_in_one_process():
+    """The loader imports torch before it dlopens the library (PyTorch-ROCm bundles its own HIP runtime; whichever copy
+    initialises second finds no GPU): a program that uses the engine FIRST and a device tensor afterwards has to work."""
+    import subprocess
+    code = (
+        "import sys; sys.path.insert(0, %r)\n"
+        "import numpy as np, mgn_amd\n"
+        "pos, cells = mgn_amd.synth.grid_mesh(9, 7, 1); s, r = mgn_amd.synth.cells_to_edges(cells)\n"
+        "eng = mgn_amd.Engine(9, 3, 2, 32, 2, 1); eng.set_params(np.zeros(eng.param_count, np.float32)); eng.set_graph(s, r, pos.shape[0])\n"
+        "assert 'torch' in sys.modules          # the loader did it\n"
+        "out = eng.forward(np.zeros((pos.shape[0], 9), np.float32), np.zeros((s.size, 3), np.float32))\n"
+        "import torch\n"
+        "t = torch.ones(4, device='cuda') * 2\n"
+        "assert float(t.sum()) == 8.0 and np.isfinite(out).all()\n"
+        "print('OK')\n" % ROOT)
+    res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0 and "OK" in res.stdout, res.stderr[-2000:]
