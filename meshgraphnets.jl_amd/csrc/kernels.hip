@@ -1446,7 +1446,9 @@ hipError_t launch_edge_step(int L, const EdgeArgs& a, hipStream_t s) {
         // the cooperative kernel instead (4 waves per tile: a third of the latency), launched behind the persistent one.
         const int nw = lc.blocks * (lc.threads / 64);
         const int rem = a.ntiles % nw, rounds = a.ntiles / nw;
-        if (g_tail_coop && g_path == 0 && a.chunk_t[0] && rounds >= 4 && rem > 0 && rem * 10 < nw * 6) {
+        // (Launches with fewer than MGN_SPREAD_ROUNDS rounds spread their last round over all CUs instead -- TileWalk -- and
+        // are faster without the split: -2.7 % at 125 k nodes, the per-GPU share of M-1M on 8 GPUs.)
+        if (g_tail_coop && g_path == 0 && a.chunk_t[0] && rounds >= MGN_SPREAD_ROUNDS && rem > 0 && rem * 10 < nw * 6) {
             EdgeArgs body = a, tail = a;
             body.ntiles = a.ntiles - rem;
             tail.tile0 = a.tile0 + body.ntiles;
