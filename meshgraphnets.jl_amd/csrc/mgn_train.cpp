@@ -28,6 +28,7 @@ struct TrainMlp {
 
 struct TrainState {
     bool packed = false, graph_ready = false;
+    bool factored = false;       // edge MLPs with a factored first layer (P = v W1s, Q = v W1r per node): large meshes
     bool recompute = false;      // processor MLPs keep only their inputs; H1 / H2 / Y are recomputed in the reverse pass
     DevBuf w;                    // training-order weights
     std::vector<TrainMlp> mlp;   // 0 enc-node, 1 enc-edge, 2+2k edge k, 3+2k node k, last decoder
@@ -41,6 +42,7 @@ struct TrainState {
     int gsets = 1;                    // sets allocated for the current graph (GSETS on small meshes, else 1: no overlap)
     size_t GT[GSETS], GXH[GSETS], GY[GSETS], GZ2[GSETS], GZ1[GSETS];
     size_t GXs, GXr, gV[2], gE[2], gAgg, Gout, gNF, io, pw, pb;
+    size_t Pn, Qn, SGs, SGr;     // factored first layer: per-node projections (forward) and summed GZ1 rows (backward)
     // weight gradients + their reductions go to a second stream (small meshes leave most of the chip idle during k_mlp_bwd)
     hipStream_t aux = nullptr;
     hipEvent_t ev_bwd = nullptr, ev_wg[GSETS] = {};
@@ -211,15 +213,22 @@ int prepare_graph(mgn_engine* h) {
         T.Vk[k + 1] = take(NL);
     }
     const size_t ML = NL > EL ? NL : EL;
+    // Above the cooperative range the first layer of the edge MLPs is factored as in the inference kernels: per NODE
+    // P = v W1_sender, Q = v W1_receiver (2 chunk passes over N rows instead of 2 over E rows), backward and weight gradients
+    // through the summed rows of GZ1 (gather <-> segmented-sum duality).  MGN_TRAIN_FACTORED = 0 / 1 overrides the size rule.
+    T.factored = !train_uses_coop(L, (int)((E + TILE - 1) / TILE));
+    if (const char* e = getenv("MGN_TRAIN_FACTORED")) T.factored = atoi(e) != 0;
+    if (E == 0) T.factored = false;
     // Small meshes (the cooperative-tile regime: a launch leaves most of the chip idle) get GSETS sets of gradient buffers so
     // that the parameter gradients can run on a second stream; larger ones fill the chip on their own and keep one set.
     {
         static const bool overlap_env = [] { const char* e = getenv("MGN_TRAIN_OVERLAP"); return !e || atoi(e) != 0; }();
         const int64_t big = E > N ? E : N;
-        T.gsets = (overlap_env && !T.recompute && L == 128 && big <= 2048 * TILE) ? TrainState::GSETS : 1;
+        T.gsets = (overlap_env && !T.recompute && !T.factored && L == 128 && big <= 2048 * TILE) ? TrainState::GSETS : 1;   // (SGs / SGr are single buffers)
     }
     for (int i = 0; i < T.gsets; ++i) { T.GT[i] = take(ML); T.GXH[i] = take(ML); T.GY[i] = take(ML); T.GZ2[i] = take(ML); T.GZ1[i] = take(ML); }
-    T.GXs = take(EL); T.GXr = take(EL);
+    if (T.factored) { T.GXs = T.GXr = 0; T.Pn = take(NL); T.Qn = take(NL); T.SGs = take(NL); T.SGr = take(NL); }
+    else { T.GXs = take(EL); T.GXr = take(EL); T.Pn = T.Qn = T.SGs = T.SGr = 0; }
     T.gV[0] = take(NL); T.gV[1] = take(NL);
     T.gE[0] = take(EL); T.gE[1] = take(EL);
     T.gAgg = take(NL);
@@ -334,6 +343,26 @@ int train_run(mgn_handle* h, const TrainJob& J) {
         return launch_mlp_fwd(L, m.nin, a, st);
     };
 
+    // edge MLP of step k: [v_s; v_r; e] -> 3 Dense + LayerNorm; with the factored first layer P[s] + Q[r] + e W1e
+    auto fwd_edge = [&](const TrainMlp& m, int k, const float* resid, float* out, float* lnout) -> hipError_t {
+        if (!T.factored)
+            return fwd(m, E, nt_e, A + T.Vk[k], snd, A + T.Vk[k], rcv, A + T.Ek[k], nullptr, T.eH[0][k], T.eH[1][k], T.eH[2][k], resid, out, lnout);
+        Lin2Args p{};
+        p.rows = N; p.ntiles = nt_n;
+        p.X0 = A + T.Vk[k]; p.W0 = Wt + m.W1[0]; p.W1 = Wt + m.W1[1];
+        p.OUT0 = A + T.Pn; p.OUT1 = A + T.Qn;
+        if (hipError_t e = launch_lin2(L, p, st)) return e;
+        TrainFwdArgs a{};
+        a.rows = E; a.ntiles = nt_e;
+        a.X[0] = A + T.Ek[k];
+        a.W1[0] = Wt + m.W1[2]; a.W2 = Wt + m.W2; a.W3 = Wt + m.W3; a.tabs = Wt + m.tabs;
+        a.PRE[0] = A + T.Pn; a.preidx[0] = snd; a.PRE[1] = A + T.Qn; a.preidx[1] = rcv;
+        a.H1 = A + T.eH[0][k]; a.H2 = A + T.eH[1][k]; a.Y = A + T.eH[2][k];
+        a.resid = resid; a.OUT = out; a.LNOUT = lnout;
+        a.ln = m.off->ln ? 1 : 0;
+        return launch_mlp_fwd(L, 1, a, st);
+    };
+
     // Small meshes replay both launch sequences from hipGraphs (everything they touch lives at fixed addresses in the arena;
     // the inputs, the seed of the reverse pass and the results stay outside).  The captured pointers are checked per call.
     const bool graphable = h->use_graph && !h->prof && T.gsets > 1;
@@ -377,8 +406,7 @@ int train_run(mgn_handle* h, const TrainJob& J) {
     for (int k = 0; k < mps; ++k) {
         const TrainMlp& me = T.mlp[2 + 2 * k];
         const TrainMlp& mn = T.mlp[3 + 2 * k];
-        HIPCHK(h, fwd(me, E, nt_e, A + T.Vk[k], snd, A + T.Vk[k], rcv, A + T.Ek[k], nullptr, T.eH[0][k], T.eH[1][k], T.eH[2][k], A + T.Ek[k],
-                      A + T.Ek[k + 1], A + T.Enew));
+        HIPCHK(h, fwd_edge(me, k, A + T.Ek[k], A + T.Ek[k + 1], A + T.Enew));
         HIPCHK(h, launch_segment_sum(L, A + T.Enew, rowptr, nullptr, nullptr, A + T.agg[k], (int32_t)N, st));
         HIPCHK(h, fwd(mn, N, nt_n, A + T.Vk[k], nullptr, A + T.agg[k], nullptr, nullptr, nullptr, T.nH[0][k], T.nH[1][k], T.nH[2][k], A + T.Vk[k],
                       A + T.Vk[k + 1], nullptr));
@@ -415,8 +443,13 @@ int train_run(mgn_handle* h, const TrainJob& J) {
         for (hipEvent_t& e : T.ev_wg) HIPCHK(h, hipEventCreateWithFlags(&e, hipEventDisableTiming));
     }
     int n_bwd = 0;
+    // `node_rows` > 0: the edge MLP with the factored first layer -- only the e block of W1 is unwound per edge (gx[0] /
+    // gxadd[0] / xin[0] describe it); the v blocks follow per node from the summed rows of GZ1 (SGs, SGr) after this call.
     auto bwd = [&](const TrainMlp& m, int64_t rows, int32_t ntiles, const float* g0, const float* g1, const int32_t* g1i, size_t h1, size_t h2, size_t y,
-                   float* const gx[3], const float* const gxadd[3], const float* const xin[3], const int32_t* const xi[3]) -> int {
+                   float* const gx[3], const float* const gxadd[3], const float* const xin[3], const int32_t* const xi[3],
+                   int64_t node_rows = 0, const float* vin = nullptr) -> int {
+        const bool fact = node_rows > 0;
+        const int nin_k = fact ? 1 : m.nin;               // input blocks the kernel unwinds
         const int gs = overlap ? n_bwd % T.gsets : 0;
         hipStream_t wst = overlap ? T.aux : st;
         if (overlap && n_bwd >= T.gsets) HIPCHK(h, hipStreamWaitEvent(st, T.ev_wg[gs], 0));   // set gs is free again
@@ -426,15 +459,19 @@ int train_run(mgn_handle* h, const TrainJob& J) {
         a.G0 = g0; a.G1 = g1; a.g1idx = g1i;
         a.Y = A + y; a.H2 = A + h2; a.H1 = A + h1;
         a.W3T = Wt + m.W3T; a.W2T = Wt + m.W2T;
-        for (int j = 0; j < m.nin; ++j) {
-            a.W1T[j] = (m.has_w1t && gx[j]) ? Wt + m.W1T[j] : nullptr;
+        for (int j = 0; j < nin_k; ++j) {
+            const int jw = fact ? 2 : j;                   // factored: block 2 (e) of W1
+            a.W1T[j] = (m.has_w1t && gx[j]) ? Wt + m.W1T[jw] : nullptr;
             a.GX[j] = gx[j];
             a.GXadd[j] = gxadd[j];
         }
         a.tabs = Wt + m.tabs;
         a.ln = m.off->ln ? 1 : 0;
         a.GT = A + T.GT[gs]; a.GXH = A + T.GXH[gs]; a.GY = A + T.GY[gs]; a.GZ2 = A + T.GZ2[gs]; a.GZ1 = A + T.GZ1[gs];
-        HIPCHK(h, launch_mlp_bwd(L, m.nin, a, st));
+        HIPCHK(h, launch_mlp_bwd(L, nin_k, a, st));
+        if (fact) {   // gather <-> segmented-sum duality on GZ1 itself: SGr[n] = sum of GZ1 over edges received by n, SGs: sent by n
+            HIPCHK(h, launch_segment_sum_pair(L, A + T.GZ1[gs], rowptr, rowptr_s, perm_s, A + T.SGr, A + T.SGs, (int32_t)node_rows, st));
+        }
         if (overlap) {
             HIPCHK(h, hipEventRecord(T.ev_bwd, st));
             HIPCHK(h, hipStreamWaitEvent(wst, T.ev_bwd, 0));
@@ -446,22 +483,31 @@ int train_run(mgn_handle* h, const TrainJob& J) {
         WgradBatch wb{};
         ReduceBatch rb{};
         int nw = 0;
-        auto job = [&](const float* X, const int32_t* xi_, const float* Gm, long woff, int nrows, int cols, long boff, int bcols) {
+        auto job = [&](const float* X, const int32_t* xi_, const float* Gm, long woff, int nrows, int cols, long boff, int bcols,
+                       int64_t jrows = -1) {
             WgradJob& j = wb.job[wb.njobs];
-            j.X = X; j.xidx = xi_; j.G = Gm; j.rows = rows;
+            if (jrows < 0) jrows = rows;
+            const int nbj = wgrad_blocks_of_job(rows, jrows);      // blocks of this launch that hold rows of the job
+            j.X = X; j.xidx = xi_; j.G = Gm; j.rows = jrows;
             j.pw = woff >= 0 ? A + T.pw + (size_t)nw * nb * L * L : nullptr;
             j.pb = boff >= 0 ? A + T.pb + (size_t)wb.njobs * nb * L : nullptr;
             if (woff >= 0) {
-                rb.job[rb.njobs++] = ReduceJob{j.pw, nb, (int64_t)L * L, nrows, cols, L, G + woff};
+                rb.job[rb.njobs++] = ReduceJob{j.pw, nbj, (int64_t)L * L, nrows, cols, L, G + woff};
                 ++nw;
             }
-            if (boff >= 0) rb.job[rb.njobs++] = ReduceJob{j.pb, nb, (int64_t)L, 1, bcols, L, G + boff};
+            if (boff >= 0) rb.job[rb.njobs++] = ReduceJob{j.pb, nbj, (int64_t)L, 1, bcols, L, G + boff};
             ++wb.njobs;
         };
         job(A + h2, nullptr, A + T.GY[gs], (long)o.W[2], L, o.out, (long)o.b[2], o.out);
         job(A + h1, nullptr, A + T.GZ2[gs], (long)o.W[1], L, L, (long)o.b[1], L);
-        for (int j = 0; j < m.nin; ++j)
-            job(xin[j], xi[j], A + T.GZ1[gs], (long)(o.W[0] + (size_t)j * L * L), m.in_rows, L, j == 0 ? (long)o.b[0] : -1, L);
+        if (!fact) {
+            for (int j = 0; j < m.nin; ++j)
+                job(xin[j], xi[j], A + T.GZ1[gs], (long)(o.W[0] + (size_t)j * L * L), m.in_rows, L, j == 0 ? (long)o.b[0] : -1, L);
+        } else {   // dW1e = e^T GZ1 (+ db1) over the edges; dW1s = v^T SGs, dW1r = v^T SGr over the nodes
+            job(xin[0], xi[0], A + T.GZ1[gs], (long)(o.W[0] + (size_t)2 * L * L), L, L, (long)o.b[0], L);
+            job(vin, nullptr, A + T.SGs, (long)(o.W[0]), L, L, -1, L, node_rows);
+            job(vin, nullptr, A + T.SGr, (long)(o.W[0] + (size_t)L * L), L, L, -1, L, node_rows);
+        }
         if (o.ln) {
             job(nullptr, nullptr, A + T.GXH[gs], -1, 0, 0, (long)o.gamma, L);
             job(nullptr, nullptr, A + T.GT[gs], -1, 0, 0, (long)o.beta, L);
@@ -491,8 +537,7 @@ int train_run(mgn_handle* h, const TrainJob& J) {
         if (T.recompute) {   // regenerate H1, H2, Y of both MLPs of this step from their kept inputs
             HIPCHK(h, fwd(mn, N, nt_n, A + T.Vk[k], nullptr, A + T.agg[k], nullptr, nullptr, nullptr, T.nH[0][k], T.nH[1][k], T.nH[2][k], nullptr,
                           nullptr, nullptr));
-            HIPCHK(h, fwd(me, E, nt_e, A + T.Vk[k], snd, A + T.Vk[k], rcv, A + T.Ek[k], nullptr, T.eH[0][k], T.eH[1][k], T.eH[2][k], nullptr,
-                          nullptr, nullptr));
+            HIPCHK(h, fwd_edge(me, k, nullptr, nullptr, nullptr));
         }
         {   // node MLP: v_{k+1} = v_k + MLP_v([v_k; agg_k])
             float* gx[3] = {A + T.gV[nxt], A + T.gAgg, nullptr};
@@ -501,15 +546,27 @@ int train_run(mgn_handle* h, const TrainJob& J) {
             const int32_t* xi[3] = {nullptr, nullptr, nullptr};
             if (int rc = bwd(mn, N, nt_n, A + T.gV[cur], nullptr, nullptr, T.nH[0][k], T.nH[1][k], T.nH[2][k], gx, gxadd, xin, xi)) return rc;
         }
-        {   // edge MLP: e' feeds e_{k+1} = e_k + e' and agg_k[receiver]
+        if (!T.factored) {   // edge MLP: e' feeds e_{k+1} = e_k + e' and agg_k[receiver]
             float* gx[3] = {A + T.GXs, A + T.GXr, A + T.gE[enxt]};
             const float* gxadd[3] = {nullptr, nullptr, A + T.gE[ecur]};
             const float* xin[3] = {A + T.Vk[k], A + T.Vk[k], A + T.Ek[k]};
             const int32_t* xi[3] = {snd, rcv, nullptr};
             if (int rc = bwd(me, E, nt_e, A + T.gE[ecur], A + T.gAgg, rcv, T.eH[0][k], T.eH[1][k], T.eH[2][k], gx, gxadd, xin, xi)) return rc;
+            // gather duality: the gradients of v[receivers] / v[senders] are segmented sums over the receiver / sender CSR
+            HIPCHK(h, launch_segment_sum2(L, A + T.GXr, rowptr, A + T.GXs, rowptr_s, perm_s, A + T.gV[nxt], A + T.gV[nxt], (int32_t)N, st));
+        } else {             // factored first layer: per edge only the e block; the v blocks per node from SGs / SGr
+            float* gx[3] = {A + T.gE[enxt], nullptr, nullptr};
+            const float* gxadd[3] = {A + T.gE[ecur], nullptr, nullptr};
+            const float* xin[3] = {A + T.Ek[k], nullptr, nullptr};
+            const int32_t* xi[3] = {nullptr, nullptr, nullptr};
+            if (int rc = bwd(me, E, nt_e, A + T.gE[ecur], A + T.gAgg, rcv, T.eH[0][k], T.eH[1][k], T.eH[2][k], gx, gxadd, xin, xi, N, A + T.Vk[k]))
+                return rc;
+            Lin2Args q{};     // gV += SGs W1s^T + SGr W1r^T
+            q.rows = N; q.ntiles = nt_n;
+            q.X0 = A + T.SGs; q.X1 = A + T.SGr; q.W0 = Wt + me.W1T[0]; q.W1 = Wt + me.W1T[1];
+            q.ADD = A + T.gV[nxt]; q.OUT0 = A + T.gV[nxt];
+            HIPCHK(h, launch_lin2(L, q, st));
         }
-        // gather duality: the gradients of v[receivers] / v[senders] are segmented sums over the receiver / sender CSR
-        HIPCHK(h, launch_segment_sum2(L, A + T.GXr, rowptr, A + T.GXs, rowptr_s, perm_s, A + T.gV[nxt], A + T.gV[nxt], (int32_t)N, st));
         if (E == 0) HIPCHK(h, hipMemsetAsync(A + T.gE[enxt], 0, (size_t)L * 4, st));
         cur = nxt;
         ecur = enxt;

@@ -22,6 +22,9 @@ struct TrainFwdArgs {
     const float* resid; float* OUT;              // OUT = (resid ? resid : 0) + (ln ? LayerNorm(Y) : Y)
     float* LNOUT;                                // optional: LayerNorm(Y) alone (the message e' that is aggregated)
     int32_t ln;
+    // factored first layer (edge MLP on large meshes): layer-1 pre-activation += PRE[i][preidx[i] ? preidx[i][row] : row]
+    // (P = v W1_sender and Q = v W1_receiver, computed once per NODE by launch_lin2)
+    const float* PRE[2]; const int32_t* preidx[2];
 };
 
 struct TrainBwdArgs {
@@ -38,6 +41,21 @@ struct TrainBwdArgs {
 
 hipError_t launch_mlp_fwd(int L, int nin, const TrainFwdArgs& a, hipStream_t s);
 hipError_t launch_mlp_bwd(int L, int nin, const TrainBwdArgs& a, hipStream_t s);
+bool train_uses_coop(int L, int ntiles);     // the cooperative 4-wave MLP kernels serve this launch size
+
+// Two L x L products per row tile (the per-node halves of the factored first edge layer):
+//   split  (X1 == null):  OUT0 = X0 W0,  OUT1 = X0 W1                     (P, Q of the forward)
+//   merge  (X1 != null):  OUT0 = (ADD ? ADD : 0) + X0 W0 + X1 W1          (gradient w.r.t. v from the summed GZ1 rows)
+struct Lin2Args {
+    int64_t rows; int32_t ntiles;
+    const float* X0; const float* X1;
+    const float* W0; const float* W1;            // chunks in fragment order
+    const float* ADD; float* OUT0; float* OUT1;
+};
+hipError_t launch_lin2(int L, const Lin2Args& a, hipStream_t s);
+// out_r[n] = sum over the receiver range of src (rows contiguous), out_s[n] = sum over the sender range of src[perm[p]]
+hipError_t launch_segment_sum_pair(int L, const float* src, const int32_t* rowptr_r, const int32_t* rowptr_s, const int32_t* perm_s,
+                                   float* out_r, float* out_s, int32_t n, hipStream_t s);
 
 // Weight gradients of one MLP in ONE launch (blockIdx.y = job):
 //   dW[in][out] = sum_rows X[xidx ? xidx[row] : row][in] * G[row][out];   db[out] = sum_rows G[row][out]
@@ -47,6 +65,7 @@ constexpr int WGRAD_MAX_JOBS = 8;
 struct WgradJob { const float* X; const int32_t* xidx; const float* G; int64_t rows; float* pw; float* pb; };
 struct WgradBatch { int32_t njobs; int64_t rows_per_block; WgradJob job[WGRAD_MAX_JOBS]; };
 int wgrad_blocks(int64_t rows);
+int wgrad_blocks_of_job(int64_t launch_rows, int64_t job_rows);   // blocks of a launch sized for launch_rows that touch a job with fewer rows
 hipError_t launch_wgrad(int L, WgradBatch wb, int64_t rows, hipStream_t s);
 // out[r * cols + c] = sum_b partial[b * block_stride + r * ld + c]   (fixed order: bitwise reproducible), one job per blockIdx.y
 constexpr int REDUCE_MAX_JOBS = 16;

@@ -88,6 +88,9 @@ __global__ __launch_bounds__(256) void k_mlp_fwd(const TrainFwdArgs a) {
     f32x16 x[NT], acc[NT], y[NT];
     tab_frag<NT>(acc, a.tabs + T_B1 * L, h);
 #pragma unroll
+    for (int i = 0; i < 2; ++i)
+        if (a.PRE[i]) add_frag<NT>(acc, row_ptr(a.PRE[i], a.preidx[i] ? (int64_t)a.preidx[i][rw.rr] : rw.rr, L, h), STRIDE_ROW);
+#pragma unroll
     for (int j = 0; j < NIN; ++j) {
         CP_PREFETCH(j + 1 < NIN ? a.W1[j + 1] : a.W2);
         const int64_t src = a.xidx[j] ? (int64_t)a.xidx[j][rw.rr] : rw.rr;
@@ -259,6 +262,9 @@ __global__ __launch_bounds__(256, 2) void k_mlp_fwd_coop(const TrainFwdArgs a) {
         load_frag<4>(xa, row_ptr(a.X[0], src[0], L, h), STRIDE_ROW);
         if constexpr (NIN > 1) load_frag<4>(xb, row_ptr(a.X[1], src[1], L, h), STRIDE_ROW);
         tab_quarter(acc, a.tabs + T_B1 * L, tq, h);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            if (a.PRE[i]) add_quarter(acc, row_ptr(a.PRE[i], a.preidx[i] ? (int64_t)a.preidx[i][rw.rr] : rw.rr, L, h), STRIDE_ROW, tq);
         // Fences: without them hipcc sinks the (gathered, slow) row loads INTO the MFMA chains, a few pieces ahead of their use,
         // where they queue in front of the weight ring's loads (vmcnt retires in order) and every k-step waits for memory.
         PHASE_FENCE();
@@ -405,6 +411,44 @@ __global__ __launch_bounds__(256, 2) void k_mlp_bwd_coop(const TrainBwdArgs a) {
 }
 
 // ================================================================================================
+// two L x L products per row tile: the per-node halves of the factored first edge layer (see train.h, Lin2Args)
+// ================================================================================================
+template <int NT>
+__global__ __launch_bounds__(256) void k_lin2(const Lin2Args a) {
+    constexpr int L = 32 * NT, CH = L * L;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lane0 = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int tile_raw = blockIdx.x * 4 + wave;
+    const bool active = tile_raw < a.ntiles;
+    const int tile = active ? tile_raw : a.ntiles - 1;
+    OPAQUE_LANE();
+    RowRef rw = row_of(tile, c, a.rows);
+    rw.valid = rw.valid && active;
+    CP_PRIME(a.W0);
+    f32x16 x[NT], acc[NT];
+    load_frag<NT>(x, row_ptr(a.X0, rw.rr, L, h), STRIDE_ROW);
+    CP_PREFETCH(a.W1);
+    if (a.X1) {      // merge
+        if (a.ADD) load_frag<NT>(acc, row_ptr(a.ADD, rw.rr, L, h), STRIDE_ROW);
+        else zero_frag<NT>(acc);
+        mfma_chunk<NT, true>(acc, x, CP_W(), lane);
+        CP_ADVANCE();
+        load_frag<NT>(x, row_ptr(a.X1, rw.rr, L, h), STRIDE_ROW);
+        mfma_chunk<NT, true>(acc, x, CP_W(), lane);
+        if (rw.valid) store_frag<NT>(row_ptr(a.OUT0, rw.row, L, h), STRIDE_ROW, acc);
+    } else {         // split
+        zero_frag<NT>(acc);
+        mfma_chunk<NT, true>(acc, x, CP_W(), lane);
+        CP_ADVANCE();
+        if (rw.valid) store_frag<NT>(row_ptr(a.OUT0, rw.row, L, h), STRIDE_ROW, acc);
+        zero_frag<NT>(acc);
+        mfma_chunk<NT, true>(acc, x, CP_W(), lane);
+        if (rw.valid) store_frag<NT>(row_ptr(a.OUT1, rw.row, L, h), STRIDE_ROW, acc);
+    }
+}
+
+// ================================================================================================
 // weight gradient: dW[in][out] = sum_rows X[row][in] * G[row][out] on v_mfma_f32_32x32x2_f32 with the ROW index as the
 // reduction dimension: A operand = X^T (lane (m = l&31, k = l>>5) reads X[row 2q+k][32 ti + m], 128 contiguous bytes per
 // half wave), B operand = G (lane (n, k) reads G[row 2q+k][32 tj + n]).  Wave ti of a block owns input-feature block ti
@@ -527,6 +571,19 @@ __global__ void k_segment_sum2(const float* __restrict__ srcA, const int32_t* __
     reinterpret_cast<f32x4*>(out)[i] = s;
 }
 
+__global__ void k_segment_sum_pair(const float* __restrict__ src, const int32_t* __restrict__ rowptr_r, const int32_t* __restrict__ rowptr_s,
+                                   const int32_t* __restrict__ perm_s, float* __restrict__ out_r, float* __restrict__ out_s, int32_t n, int L4) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)n * L4) return;
+    const int node = (int)(i / L4), q = (int)(i - (int64_t)node * L4);
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    for (int p = rowptr_r[node]; p < rowptr_r[node + 1]; ++p) s += reinterpret_cast<const f32x4*>(src)[(int64_t)p * L4 + q];
+    reinterpret_cast<f32x4*>(out_r)[i] = s;
+    s = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int p = rowptr_s[node]; p < rowptr_s[node + 1]; ++p) s += reinterpret_cast<const f32x4*>(src)[(int64_t)perm_s[p] * L4 + q];
+    reinterpret_cast<f32x4*>(out_s)[i] = s;
+}
+
 // dst [rows][L] = [ (srcA | srcB)[rows][wa + wb] * scale + shift | 0 ]   (scale == null: identity)
 __global__ void k_affine_pad(const float* __restrict__ srcA, int wa, const float* __restrict__ srcB, int wb, const float* __restrict__ scale,
                              const float* __restrict__ shift, float* __restrict__ dst, int L, int64_t rows) {
@@ -618,6 +675,15 @@ static hipError_t launch_coop(K kern, const A& a, int ntiles, hipStream_t s) {
     return hipGetLastError();
 }
 
+bool train_uses_coop(int L, int ntiles) { return train_coop(L, ntiles); }
+
+hipError_t launch_lin2(int L, const Lin2Args& a, hipStream_t s) {
+    if (L == 128) return launch_tiles(k_lin2<4>, a, a.ntiles, L, s);
+    if (L == 64) return launch_tiles(k_lin2<2>, a, a.ntiles, L, s);
+    if (L == 32) return launch_tiles(k_lin2<1>, a, a.ntiles, L, s);
+    return hipErrorInvalidValue;
+}
+
 hipError_t launch_mlp_fwd(int L, int nin, const TrainFwdArgs& a, hipStream_t s) {
     if (train_coop(L, a.ntiles)) {
         if (nin == 1) return launch_coop(k_mlp_fwd_coop<1>, a, a.ntiles, s);
@@ -650,6 +716,11 @@ static int64_t wgrad_rows_per_block(int64_t rows) {
     int64_t rpb = (rows + 1023) / 1024;              // at most 1024 blocks
     if (rpb < WG_ROWS) rpb = WG_ROWS;
     return (rpb + 2 * WG_UNROLL - 1) / (2 * WG_UNROLL) * (2 * WG_UNROLL);
+}
+int wgrad_blocks_of_job(int64_t launch_rows, int64_t job_rows) {
+    if (launch_rows <= 0 || job_rows <= 0) return 0;
+    const int64_t rpb = wgrad_rows_per_block(launch_rows);
+    return (int)((job_rows + rpb - 1) / rpb);
 }
 int wgrad_blocks(int64_t rows) {
     if (rows <= 0) return 0;
@@ -690,6 +761,15 @@ hipError_t launch_segment_sum2(int L, const float* srcA, const int32_t* rowptrA,
     const int64_t tot = (int64_t)n * (L / 4);
     if (tot <= 0) return hipSuccess;
     hipLaunchKernelGGL(k_segment_sum2, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, srcA, rowptrA, srcB, rowptrB, permB, add, out, n, L / 4);
+    return hipGetLastError();
+}
+
+hipError_t launch_segment_sum_pair(int L, const float* src, const int32_t* rowptr_r, const int32_t* rowptr_s, const int32_t* perm_s,
+                                   float* out_r, float* out_s, int32_t n, hipStream_t s) {
+    const int64_t tot = (int64_t)n * (L / 4);
+    if (tot <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_segment_sum_pair, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, src, rowptr_r, rowptr_s, perm_s, out_r, out_s, n,
+                       L / 4);
     return hipGetLastError();
 }
 
