@@ -39,31 +39,33 @@ DEVINL RowRef row_of(int tile, int c, int64_t rows) {
 // persistent inference kernels is latency-bound here: one wave per SIMD, 5 chunks per tile.)
 // Block-wide copy of one L x L chunk global -> LDS with all of a thread's loads in flight at once (copy_to_lds' runtime
 // loop serialises load -> ds_write per iteration: ~11 us per 64 KiB chunk, which dominated these kernels).
-template <int CH>
+template <int CH, int NTHR>
 DEVINL void stage_chunk(float* dst, const float* __restrict__ src) {
-    constexpr int PER = CH / 4 / 256 > 0 ? CH / 4 / 256 : 1;   // float4 per thread: 16 (L = 128), 4 (L = 64), 1 (L = 32)
+    static_assert(CH / 4 >= NTHR || CH / 4 == 256, "chunk smaller than the block");
+    constexpr int PER = CH / 4 / NTHR > 0 ? CH / 4 / NTHR : 1;   // float4 per thread: 16 (L = 128, 256 threads), 4 (L = 64), 1 (L = 32)
     constexpr int B = PER < 16 ? PER : 16;
     const f32x4* s4 = reinterpret_cast<const f32x4*>(src);
     f32x4* d4 = reinterpret_cast<f32x4*>(dst);
+    if (CH / 4 < NTHR && (int)threadIdx.x >= CH / 4) return;      // (L = 32 chunk under a 512-thread block: not instantiated)
 #pragma unroll
     for (int base = 0; base < PER; base += B) {
         f32x4 v[B];
 #pragma unroll
-        for (int u = 0; u < B; ++u) v[u] = s4[(base + u) * 256 + threadIdx.x];
+        for (int u = 0; u < B; ++u) v[u] = s4[(base + u) * NTHR + threadIdx.x];
 #pragma unroll
-        for (int u = 0; u < B; ++u) d4[(base + u) * 256 + threadIdx.x] = v[u];
+        for (int u = 0; u < B; ++u) d4[(base + u) * NTHR + threadIdx.x] = v[u];
     }
 }
 
 // `cur` is a compile-time constant at every use (the chunk sequence is fully unrolled), so the LDS addresses are too.
 #define CP_PRIME(first)                   \
     int cur = 0;                          \
-    stage_chunk<CH>(smem, (first));       \
+    stage_chunk<CH, 64 * WPB>(smem, (first));       \
     __syncthreads()
 #define CP_PREFETCH(next)                                                        \
     do {                                                                         \
         const float* nx_ = (next);                                               \
-        if (nx_) stage_chunk<CH>(smem + (cur ^ 1) * CH, nx_);                    \
+        if (nx_) stage_chunk<CH, 64 * WPB>(smem + (cur ^ 1) * CH, nx_);                    \
     } while (0)
 #define CP_W() (smem + cur * CH)
 #define CP_ADVANCE()     \
@@ -72,13 +74,15 @@ DEVINL void stage_chunk(float* dst, const float* __restrict__ src) {
         cur ^= 1;        \
     } while (0)
 
-template <int NT, int NIN>
-__global__ __launch_bounds__(256) void k_mlp_fwd(const TrainFwdArgs a) {
+// WPB waves (= tiles) per block share the staged chunks: 4, or 8 on large launches (two waves per SIMD: one's loads and stores
+// overlap the other's MFMA chain; 128 KiB of LDS allow one block per CU either way)
+template <int NT, int NIN, int WPB>
+__global__ __launch_bounds__(64 * WPB) void k_mlp_fwd(const TrainFwdArgs a) {
     constexpr int L = 32 * NT, CH = L * L;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane0 = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int tile_raw = blockIdx.x * 4 + wave;
+    const int tile_raw = blockIdx.x * WPB + wave;
     const bool active = tile_raw < a.ntiles;
     const int tile = active ? tile_raw : a.ntiles - 1;       // idle waves shadow the last tile (no stores): they share the barriers
     OPAQUE_LANE();
@@ -128,14 +132,14 @@ DEVINL void mask_by_relu(f32x16 (&g)[NT], const f32x16 (&act)[NT]) {
         for (int k = 0; k < 16; ++k) g[t][k] = act[t][k] > 0.f ? g[t][k] : 0.f;
 }
 
-template <int NT, int NIN>
-__global__ __launch_bounds__(256) void k_mlp_bwd(const TrainBwdArgs a) {
+template <int NT, int NIN, int WPB>
+__global__ __launch_bounds__(64 * WPB) void k_mlp_bwd(const TrainBwdArgs a) {
     constexpr int L = 32 * NT, CH = L * L;
     constexpr float invL = 1.0f / L;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane0 = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int tile_raw = blockIdx.x * 4 + wave;
+    const int tile_raw = blockIdx.x * WPB + wave;
     const bool active = tile_raw < a.ntiles;
     const int tile = active ? tile_raw : a.ntiles - 1;
     OPAQUE_LANE();
@@ -413,13 +417,13 @@ __global__ __launch_bounds__(256, 2) void k_mlp_bwd_coop(const TrainBwdArgs a) {
 // ================================================================================================
 // two L x L products per row tile: the per-node halves of the factored first edge layer (see train.h, Lin2Args)
 // ================================================================================================
-template <int NT>
-__global__ __launch_bounds__(256) void k_lin2(const Lin2Args a) {
+template <int NT, int WPB>
+__global__ __launch_bounds__(64 * WPB) void k_lin2(const Lin2Args a) {
     constexpr int L = 32 * NT, CH = L * L;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane0 = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int tile_raw = blockIdx.x * 4 + wave;
+    const int tile_raw = blockIdx.x * WPB + wave;
     const bool active = tile_raw < a.ntiles;
     const int tile = active ? tile_raw : a.ntiles - 1;
     OPAQUE_LANE();
@@ -646,7 +650,7 @@ __global__ void k_loss(const float* __restrict__ Y, int L, const float* __restri
 // ================================================================================================
 // 4 tiles per block; two L x L chunk buffers of dynamic LDS (128 KiB at L = 128: the attribute is raised once per kernel)
 template <typename K, typename A>
-static hipError_t launch_tiles(K kern, const A& a, int ntiles, int L, hipStream_t s) {
+static hipError_t launch_tiles(K kern, const A& a, int ntiles, int L, hipStream_t s, int wpb = 4) {
     if (ntiles <= 0) return hipSuccess;
     const size_t lds = (size_t)2 * L * L * sizeof(float);
     static std::mutex mu;
@@ -660,8 +664,16 @@ static hipError_t launch_tiles(K kern, const A& a, int ntiles, int L, hipStream_
             g = lds;
         }
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)((ntiles + 3) / 4)), dim3(256), lds, s, a);
+    hipLaunchKernelGGL(kern, dim3((unsigned)((ntiles + wpb - 1) / wpb)), dim3(64 * wpb), lds, s, a);
     return hipGetLastError();
+}
+
+// eight tiles per block once a launch fills the chip twice over with four (L = 128; MGN_TRAIN_WPB = 4 / 8 forces)
+static bool train_wpb8(int L, int ntiles) {
+    static const int forced = [] { const char* e = getenv("MGN_TRAIN_WPB"); return e ? atoi(e) : 0; }();
+    if (L != 128) return false;
+    if (forced) return forced == 8;
+    return ntiles > 2048;
 }
 
 // Cooperative tiles while a launch has fewer than MGN_TRAIN_COOP_TILES_PER_CU tiles per CU (default 8), L = 128.
@@ -678,9 +690,10 @@ static hipError_t launch_coop(K kern, const A& a, int ntiles, hipStream_t s) {
 bool train_uses_coop(int L, int ntiles) { return train_coop(L, ntiles); }
 
 hipError_t launch_lin2(int L, const Lin2Args& a, hipStream_t s) {
-    if (L == 128) return launch_tiles(k_lin2<4>, a, a.ntiles, L, s);
-    if (L == 64) return launch_tiles(k_lin2<2>, a, a.ntiles, L, s);
-    if (L == 32) return launch_tiles(k_lin2<1>, a, a.ntiles, L, s);
+    if (train_wpb8(L, a.ntiles)) return launch_tiles(k_lin2<4, 8>, a, a.ntiles, L, s, 8);
+    if (L == 128) return launch_tiles(k_lin2<4, 4>, a, a.ntiles, L, s);
+    if (L == 64) return launch_tiles(k_lin2<2, 4>, a, a.ntiles, L, s);
+    if (L == 32) return launch_tiles(k_lin2<1, 4>, a, a.ntiles, L, s);
     return hipErrorInvalidValue;
 }
 
@@ -690,7 +703,12 @@ hipError_t launch_mlp_fwd(int L, int nin, const TrainFwdArgs& a, hipStream_t s) 
         if (nin == 2) return launch_coop(k_mlp_fwd_coop<2>, a, a.ntiles, s);
         if (nin == 3) return launch_coop(k_mlp_fwd_coop<3>, a, a.ntiles, s);
     }
-#define FWD_CASE(NT_, NIN_) if (L == 32 * NT_ && nin == NIN_) return launch_tiles(k_mlp_fwd<NT_, NIN_>, a, a.ntiles, L, s)
+#define FWD_CASE(NT_, NIN_) if (L == 32 * NT_ && nin == NIN_) return launch_tiles(k_mlp_fwd<NT_, NIN_, 4>, a, a.ntiles, L, s)
+    if (train_wpb8(L, a.ntiles)) {
+        if (nin == 1) return launch_tiles(k_mlp_fwd<4, 1, 8>, a, a.ntiles, L, s, 8);
+        if (nin == 2) return launch_tiles(k_mlp_fwd<4, 2, 8>, a, a.ntiles, L, s, 8);
+        if (nin == 3) return launch_tiles(k_mlp_fwd<4, 3, 8>, a, a.ntiles, L, s, 8);
+    }
     FWD_CASE(4, 1); FWD_CASE(4, 2); FWD_CASE(4, 3);
     FWD_CASE(2, 1); FWD_CASE(2, 2); FWD_CASE(2, 3);
     FWD_CASE(1, 1); FWD_CASE(1, 2); FWD_CASE(1, 3);
@@ -704,7 +722,12 @@ hipError_t launch_mlp_bwd(int L, int nin, const TrainBwdArgs& a, hipStream_t s) 
         if (nin == 2) return launch_coop(k_mlp_bwd_coop<2>, a, a.ntiles, s);
         if (nin == 3) return launch_coop(k_mlp_bwd_coop<3>, a, a.ntiles, s);
     }
-#define BWD_CASE(NT_, NIN_) if (L == 32 * NT_ && nin == NIN_) return launch_tiles(k_mlp_bwd<NT_, NIN_>, a, a.ntiles, L, s)
+#define BWD_CASE(NT_, NIN_) if (L == 32 * NT_ && nin == NIN_) return launch_tiles(k_mlp_bwd<NT_, NIN_, 4>, a, a.ntiles, L, s)
+    if (train_wpb8(L, a.ntiles)) {
+        if (nin == 1) return launch_tiles(k_mlp_bwd<4, 1, 8>, a, a.ntiles, L, s, 8);
+        if (nin == 2) return launch_tiles(k_mlp_bwd<4, 2, 8>, a, a.ntiles, L, s, 8);
+        if (nin == 3) return launch_tiles(k_mlp_bwd<4, 3, 8>, a, a.ntiles, L, s, 8);
+    }
     BWD_CASE(4, 1); BWD_CASE(4, 2); BWD_CASE(4, 3);
     BWD_CASE(2, 1); BWD_CASE(2, 2); BWD_CASE(2, 3);
     BWD_CASE(1, 1); BWD_CASE(1, 2); BWD_CASE(1, 3);
