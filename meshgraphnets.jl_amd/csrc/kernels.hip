@@ -34,31 +34,7 @@
 
 namespace mgn {
 
-// XCD-aware persistent tile walk: blocks b and b+8 share an XCD (round-robin dispatch), so every XCD
-// gets one contiguous range of tiles and its waves sweep it interleaved -> gathered P/Q rows of
-// neighbouring tiles are served by that XCD's L2.  Speed only; any placement is correct.
-#ifndef MGN_SPREAD_ROUNDS
-#define MGN_SPREAD_ROUNDS 24
-#endif
-#ifndef MGN_SPREAD_ROUNDS_NODE
-#define MGN_SPREAD_ROUNDS_NODE MGN_SPREAD_ROUNDS
-#endif
-struct TileWalk {
-    int tile, end, stride;
-    DEVINL TileWalk(int ntiles, int wave, int spread_rounds = MGN_SPREAD_ROUNDS) {
-        const int wpb = blockDim.x >> 6;
-        const int xcd = blockIdx.x % NUM_XCD;
-        const int per = (ntiles + NUM_XCD - 1) / NUM_XCD;
-        const int nb = (gridDim.x - xcd + NUM_XCD - 1) / NUM_XCD;  // blocks on this XCD label
-        end = min(xcd * per + per, ntiles);
-        stride = nb * wpb;
-        // Few rounds (mid-size meshes, per-GPU partitions): the last, partly filled round must not land on the first blocks of
-        // the XCD alone -- with positions numbered block-major, 2 813 node tiles gave 12 CUs per XCD 16 tiles and the other
-        // 20 CUs 8.  Wave-major positions hand one extra tile to wave 0 (1, 2 ..) of EVERY block instead: 11 per CU.
-        const bool spread = per < spread_rounds * stride;
-        tile = xcd * per + (spread ? wave * nb + (int)(blockIdx.x / NUM_XCD) : (int)(blockIdx.x / NUM_XCD) * wpb + wave);
-    }
-};
+// (TileWalk: frag.hpp -- shared with the persistent training kernels)
 
 // Waves w and w+4 of a block share a SIMD and run the same program; started together they stay in
 // lockstep (both gather, then both want the MFMA pipe).  Delaying the second half once by about half a

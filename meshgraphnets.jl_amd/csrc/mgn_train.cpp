@@ -216,7 +216,7 @@ int prepare_graph(mgn_engine* h) {
     // Above the cooperative range the first layer of the edge MLPs is factored as in the inference kernels: per NODE
     // P = v W1_sender, Q = v W1_receiver (2 chunk passes over N rows instead of 2 over E rows), backward and weight gradients
     // through the summed rows of GZ1 (gather <-> segmented-sum duality).  MGN_TRAIN_FACTORED = 0 / 1 overrides the size rule.
-    T.factored = !train_uses_coop(L, (int)((E + TILE - 1) / TILE));
+    T.factored = !train_uses_coop(128, (int)((E + TILE - 1) / TILE));   // the size rule of the cooperative kernels, for every L
     if (const char* e = getenv("MGN_TRAIN_FACTORED")) T.factored = atoi(e) != 0;
     if (E == 0) T.factored = false;
     // Small meshes (the cooperative-tile regime: a launch leaves most of the chip idle) get GSETS sets of gradient buffers so
@@ -330,23 +330,26 @@ int train_run(mgn_handle* h, const TrainJob& J) {
     }
 
     auto fwd = [&](const TrainMlp& m, int64_t rows, int32_t ntiles, const float* x0, const int32_t* i0, const float* x1, const int32_t* i1,
-                   const float* x2, const int32_t* i2, size_t h1, size_t h2, size_t y, const float* resid, float* out, float* lnout) {
+                   const float* x2, const int32_t* i2, size_t h1, size_t h2, size_t y, const float* resid, float* out, float* lnout,
+                   bool keep = true) {
         TrainFwdArgs a{};
         a.rows = rows; a.ntiles = ntiles;
         a.X[0] = x0; a.X[1] = x1; a.X[2] = x2;
         a.xidx[0] = i0; a.xidx[1] = i1; a.xidx[2] = i2;
         for (int j = 0; j < m.nin; ++j) a.W1[j] = Wt + m.W1[j];
         a.W2 = Wt + m.W2; a.W3 = Wt + m.W3; a.tabs = Wt + m.tabs;
-        a.H1 = A + h1; a.H2 = A + h2; a.Y = A + y;
+        if (keep) { a.H1 = A + h1; a.H2 = A + h2; a.Y = A + y; }
         a.resid = resid; a.OUT = out; a.LNOUT = lnout;
         a.ln = m.off->ln ? 1 : 0;
         return launch_mlp_fwd(L, m.nin, a, st);
     };
 
     // edge MLP of step k: [v_s; v_r; e] -> 3 Dense + LayerNorm; with the factored first layer P[s] + Q[r] + e W1e
-    auto fwd_edge = [&](const TrainMlp& m, int k, const float* resid, float* out, float* lnout) -> hipError_t {
+    // keep = false: first pass of recompute mode -- H1 / H2 / Y are regenerated right before the backward, not stored here
+    auto fwd_edge = [&](const TrainMlp& m, int k, const float* resid, float* out, float* lnout, bool keep = true) -> hipError_t {
         if (!T.factored)
-            return fwd(m, E, nt_e, A + T.Vk[k], snd, A + T.Vk[k], rcv, A + T.Ek[k], nullptr, T.eH[0][k], T.eH[1][k], T.eH[2][k], resid, out, lnout);
+            return fwd(m, E, nt_e, A + T.Vk[k], snd, A + T.Vk[k], rcv, A + T.Ek[k], nullptr, T.eH[0][k], T.eH[1][k], T.eH[2][k], resid, out, lnout,
+                       keep);
         Lin2Args p{};
         p.rows = N; p.ntiles = nt_n;
         p.X0 = A + T.Vk[k]; p.W0 = Wt + m.W1[0]; p.W1 = Wt + m.W1[1];
@@ -357,7 +360,7 @@ int train_run(mgn_handle* h, const TrainJob& J) {
         a.X[0] = A + T.Ek[k];
         a.W1[0] = Wt + m.W1[2]; a.W2 = Wt + m.W2; a.W3 = Wt + m.W3; a.tabs = Wt + m.tabs;
         a.PRE[0] = A + T.Pn; a.preidx[0] = snd; a.PRE[1] = A + T.Qn; a.preidx[1] = rcv;
-        a.H1 = A + T.eH[0][k]; a.H2 = A + T.eH[1][k]; a.Y = A + T.eH[2][k];
+        if (keep) { a.H1 = A + T.eH[0][k]; a.H2 = A + T.eH[1][k]; a.Y = A + T.eH[2][k]; }
         a.resid = resid; a.OUT = out; a.LNOUT = lnout;
         a.ln = m.off->ln ? 1 : 0;
         return launch_mlp_fwd(L, 1, a, st);
@@ -406,10 +409,10 @@ int train_run(mgn_handle* h, const TrainJob& J) {
     for (int k = 0; k < mps; ++k) {
         const TrainMlp& me = T.mlp[2 + 2 * k];
         const TrainMlp& mn = T.mlp[3 + 2 * k];
-        HIPCHK(h, fwd_edge(me, k, A + T.Ek[k], A + T.Ek[k + 1], A + T.Enew));
+        HIPCHK(h, fwd_edge(me, k, A + T.Ek[k], A + T.Ek[k + 1], A + T.Enew, !T.recompute));
         HIPCHK(h, launch_segment_sum(L, A + T.Enew, rowptr, nullptr, nullptr, A + T.agg[k], (int32_t)N, st));
         HIPCHK(h, fwd(mn, N, nt_n, A + T.Vk[k], nullptr, A + T.agg[k], nullptr, nullptr, nullptr, T.nH[0][k], T.nH[1][k], T.nH[2][k], A + T.Vk[k],
-                      A + T.Vk[k + 1], nullptr));
+                      A + T.Vk[k + 1], nullptr, !T.recompute));
     }
     HIPCHK(h, fwd(m_de, N, nt_n, A + T.Vk[mps], nullptr, nullptr, nullptr, nullptr, nullptr, T.dH[0], T.dH[1], T.dH[2], nullptr, nullptr, nullptr));
     return MGN_OK;
@@ -478,7 +481,8 @@ int train_run(mgn_handle* h, const TrainJob& J) {
         }
         // every parameter gradient of this MLP: one batched weight-gradient launch + one batched (ordered) reduction
         const MlpOff& o = *m.off;
-        const int nb = wgrad_blocks(rows);
+        const int64_t lrows = rows > node_rows ? rows : node_rows;   // the launch covers its longest job (node jobs of a factored edge MLP)
+        const int nb = wgrad_blocks(lrows);
         if (nb == 0) return MGN_OK;
         WgradBatch wb{};
         ReduceBatch rb{};
@@ -487,7 +491,7 @@ int train_run(mgn_handle* h, const TrainJob& J) {
                        int64_t jrows = -1) {
             WgradJob& j = wb.job[wb.njobs];
             if (jrows < 0) jrows = rows;
-            const int nbj = wgrad_blocks_of_job(rows, jrows);      // blocks of this launch that hold rows of the job
+            const int nbj = wgrad_blocks_of_job(lrows, jrows);     // blocks of this launch that hold rows of the job
             j.X = X; j.xidx = xi_; j.G = Gm; j.rows = jrows;
             j.pw = woff >= 0 ? A + T.pw + (size_t)nw * nb * L * L : nullptr;
             j.pb = boff >= 0 ? A + T.pb + (size_t)wb.njobs * nb * L : nullptr;
@@ -512,7 +516,7 @@ int train_run(mgn_handle* h, const TrainJob& J) {
             job(nullptr, nullptr, A + T.GXH[gs], -1, 0, 0, (long)o.gamma, L);
             job(nullptr, nullptr, A + T.GT[gs], -1, 0, 0, (long)o.beta, L);
         }
-        HIPCHK(h, launch_wgrad(L, wb, rows, wst));
+        HIPCHK(h, launch_wgrad(L, wb, lrows, wst));
         HIPCHK(h, launch_reduce_partials(rb, wst));
         if (overlap) HIPCHK(h, hipEventRecord(T.ev_wg[gs], wst));
         return MGN_OK;

@@ -18,7 +18,7 @@ struct TrainFwdArgs {
     const float* X[3]; const int32_t* xidx[3];   // layer-1 input blocks; xidx[j] != null: row gather
     const float* W1[3]; const float* W2; const float* W3;   // L x L chunks, fragment order (streamed from L2)
     const float* tabs;                           // T_B1, T_B2, T_B3, T_GAMMA, T_BETA (fragment order)
-    float* H1; float* H2; float* Y;              // kept for the backward
+    float* H1; float* H2; float* Y;              // kept for the backward (null: not stored -- first pass of recompute mode)
     const float* resid; float* OUT;              // OUT = (resid ? resid : 0) + (ln ? LayerNorm(Y) : Y)
     float* LNOUT;                                // optional: LayerNorm(Y) alone (the message e' that is aggregated)
     int32_t ln;

@@ -103,16 +103,16 @@ __global__ __launch_bounds__(64 * WPB) void k_mlp_fwd(const TrainFwdArgs a) {
         CP_ADVANCE();
     }
     relu_frag<NT>(acc);
-    if (rw.valid) store_frag<NT>(row_ptr(a.H1, rw.row, L, h), STRIDE_ROW, acc);
+    if (a.H1 && rw.valid) store_frag<NT>(row_ptr(a.H1, rw.row, L, h), STRIDE_ROW, acc);
     CP_PREFETCH(a.W3);
     tab_frag<NT>(y, a.tabs + T_B2 * L, h);
     mfma_chunk<NT, true>(y, acc, CP_W(), lane);
     CP_ADVANCE();
     relu_frag<NT>(y);
-    if (rw.valid) store_frag<NT>(row_ptr(a.H2, rw.row, L, h), STRIDE_ROW, y);
+    if (a.H2 && rw.valid) store_frag<NT>(row_ptr(a.H2, rw.row, L, h), STRIDE_ROW, y);
     tab_frag<NT>(acc, a.tabs + T_B3 * L, h);
     mfma_chunk<NT, true>(acc, y, CP_W(), lane);
-    if (rw.valid) store_frag<NT>(row_ptr(a.Y, rw.row, L, h), STRIDE_ROW, acc);
+    if (a.Y && rw.valid) store_frag<NT>(row_ptr(a.Y, rw.row, L, h), STRIDE_ROW, acc);
     if (a.ln) layer_norm_frag<NT>(acc, a.tabs + T_GAMMA * L, a.tabs + T_BETA * L, h);
     if (a.LNOUT && rw.valid) store_frag<NT>(row_ptr(a.LNOUT, rw.row, L, h), STRIDE_ROW, acc);
     if (a.resid) add_frag<NT>(acc, row_ptr(a.resid, rw.rr, L, h), STRIDE_ROW);
@@ -285,17 +285,17 @@ __global__ __launch_bounds__(256, 2) void k_mlp_fwd_coop(const TrainFwdArgs a) {
             coop_chain<true>(acc, xa, a.W1[2] + CH + tq * QS, lane);
         }
         relu_quarter(acc);
-        if (rw.valid) store_quarter(row_ptr(a.H1, rw.row, L, h), STRIDE_ROW, tq, acc);
+        if (a.H1 && rw.valid) store_quarter(row_ptr(a.H1, rw.row, L, h), STRIDE_ROW, tq, acc);
         coop_exchange(xa, acc, xch0, wave, lane);
         coop_prime(r3, a.W3 + CH + tq * QS, lane);
         tab_quarter(acc, a.tabs + T_B2 * L, tq, h);
         coop_chain_primed<true>(acc, xa, a.W2 + CH + tq * QS, lane, r2);
         relu_quarter(acc);
-        if (rw.valid) store_quarter(row_ptr(a.H2, rw.row, L, h), STRIDE_ROW, tq, acc);
+        if (a.H2 && rw.valid) store_quarter(row_ptr(a.H2, rw.row, L, h), STRIDE_ROW, tq, acc);
         coop_exchange(xb, acc, xch1, wave, lane);
         tab_quarter(acc, a.tabs + T_B3 * L, tq, h);
         coop_chain_primed<true>(acc, xb, a.W3 + CH + tq * QS, lane, r3);
-        if (rw.valid) store_quarter(row_ptr(a.Y, rw.row, L, h), STRIDE_ROW, tq, acc);
+        if (a.Y && rw.valid) store_quarter(row_ptr(a.Y, rw.row, L, h), STRIDE_ROW, tq, acc);
         if (a.ln) {
             coop_exchange(xa, acc, xch0, wave, lane);                  // full pre-LN row for the statistics
             coop_layer_norm(acc, xa, a.tabs + T_GAMMA * L, a.tabs + T_BETA * L, tq, h);
