@@ -169,6 +169,12 @@ int mgn_world_edges(const float* world_pos, int32_t dim, int32_t N, float radius
 int mgn_edge_features(const float* mesh_pos, int32_t pos_dim, const int32_t* senders, const int32_t* receivers,
                       int64_t E, int32_t index_base, float* ef);
 
+/* Online-normaliser accumulation as a device reduction: what GraphNetCore's NormaliserOnline adds up per call
+ * (normalisers built at reference src/MeshGraphNets.jl:92,193-199, applied in build_graph src/graph.jl:75-97):
+ * sum[f] = sum_r x[r][f], sum_squares[f] = sum_r x[r][f]^2 over x [rows][dim] (host or device pointer), accumulated in double
+ * in a fixed order (bitwise repeatable).  The caller keeps the running totals, count and max_accumulations logic.          */
+int mgn_feature_stats(mgn_handle* h, const float* x, int64_t rows, int32_t dim, double* sum, double* sum_squares);
+
 /* ---- native rollout driver: the whole `rollout` of reference src/solve.jl:42-68 on the device:
  * ODEProblem(ode_func_eval, x0, (t0, t1), ...) solved with fixed-step Euler (`adaptive = false, dt = dt`) or an
  * adaptive Tsit5 (own tableau + PI step controller, tstops = saveat = t0 + i*saves_dt), the right-hand side being

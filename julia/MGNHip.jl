@@ -11,7 +11,7 @@
 # side, cheap); only GraphNetwork.model / FeatureGraph / step! are replaced.
 module MGNHip
 
-export FeatureGraph, GraphNetwork, set_trajectory_graph!, pack_params, set_static!, ode_step_resident, ode_step_fused, step!
+export FeatureGraph, GraphNetwork, set_trajectory_graph!, pack_params, set_static!, ode_step_resident, ode_step_fused, step!, feature_stats
 
 const LIB = get(ENV, "MGN_HIP_LIB", joinpath(@__DIR__, "..", "meshgraphnets.jl_amd", "lib", "libmgn_hip.so"))
 
@@ -130,6 +130,16 @@ function step!(mgn::GraphNetwork, graph::FeatureGraph, target::Matrix{Float32}, 
             (Ptr{Cvoid}, Ptr{Float32}, Ptr{Float32}, Ptr{Float32}, Ptr{Int32}, Int64, Int32, Ptr{Float32}, Csize_t, Ref{Float32}),
             mgn.handle, nf, ef, target, mask, length(mask), 1, gs, length(gs), loss))
     return gs, loss[]
+end
+
+"Per-feature (sum, sum of squares) in Float64 of `x` (dim x rows): one accumulation step of a `NormaliserOnline`, on the device."
+function feature_stats(mgn::GraphNetwork, x::Matrix{Float32})
+    dim, rows = size(x)
+    s = zeros(Float64, dim); q = zeros(Float64, dim)
+    GC.@preserve x s q check(mgn.handle,
+        ccall((:mgn_feature_stats, LIB), Cint, (Ptr{Cvoid}, Ptr{Float32}, Int64, Int32, Ptr{Float64}, Ptr{Float64}),
+            mgn.handle, x, rows, dim, s, q))
+    return s, q
 end
 
 """

@@ -99,6 +99,7 @@ PROTOTYPES = {
     "mgn_tfrecord_error": (C.c_char_p, [_H]),
     "mgn_tfrecord_close": (None, [_H]),
     "mgn_crc32c": (C.c_uint32, [C.c_void_p, C.c_size_t]),
+    "mgn_feature_stats": (C.c_int, [_H, _f32p, C.c_int64, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "mgn_profile_enable": (C.c_int, [_H, C.c_int32]),
     "mgn_profile_read": (C.c_int, [_H, _f64p, _i64p]),
 }

@@ -648,3 +648,29 @@ extern "C" int mgn_ode_vjp(mgn_handle* h, const float* x, const float* node_type
     J.dxdt = dxdt; J.xbar = xbar; J.grads = grads;
     return train_run(h, J);
 }
+
+// Online-normaliser accumulation (GraphNetCore NormaliserOnline, used at reference src/MeshGraphNets.jl:92,193-199 and inside
+// build_graph): per-feature sum and sum of squares of x [rows][dim], in double.
+extern "C" int mgn_feature_stats(mgn_handle* h, const float* x, int64_t rows, int32_t dim, double* sum, double* sum_squares) {
+    if (!h) return MGN_E_ARG;
+    if (int rc = need(h, false, false)) return rc;
+    if (!x || !sum || !sum_squares || rows < 0 || dim < 1) return fail(h, MGN_E_ARG, "mgn_feature_stats: bad argument");
+    for (int f = 0; f < dim; ++f) sum[f] = sum_squares[f] = 0.0;
+    const int nb = stats_blocks(rows);
+    if (nb == 0) return MGN_OK;
+    const size_t xbytes = (size_t)rows * dim * 4, pbytes = (size_t)nb * 2 * dim * sizeof(double);
+    HIPCHK(h, h->stage.ensure(xbytes + pbytes + 64));
+    float* dx = h->stage.as<float>();
+    double* dp = reinterpret_cast<double*>(reinterpret_cast<char*>(h->stage.p) + (xbytes + 63) / 64 * 64);
+    HIPCHK(h, hipMemcpyAsync(dx, x, xbytes, hipMemcpyDefault, h->stream));       // host or device source
+    HIPCHK(h, launch_col_stats(dx, rows, dim, dp, h->stream));
+    std::vector<double> part((size_t)nb * 2 * dim);
+    HIPCHK(h, hipMemcpyAsync(part.data(), dp, pbytes, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    for (int b = 0; b < nb; ++b)
+        for (int f = 0; f < dim; ++f) {
+            sum[f] += part[((size_t)b * 2 + 0) * dim + f];
+            sum_squares[f] += part[((size_t)b * 2 + 1) * dim + f];
+        }
+    return MGN_OK;
+}

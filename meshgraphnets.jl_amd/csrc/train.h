@@ -86,6 +86,11 @@ hipError_t launch_vjp_seed(const float* Y, int L, int O, const float* lambda, co
                            float* dxdt, int64_t N, hipStream_t s);
 // dst [N][O] = src[N][L][:, 0:O] .* scale
 hipError_t launch_extract_cols(const float* src, int L, int O, const float* scale, float* dst, int64_t N, hipStream_t s);
+// column statistics for the online normalisers: partial[b][0][f] = sum over block b's rows of x[r][f], partial[b][1][f] = sum of
+// squares, in double, fixed order inside a block (stats_blocks(rows) blocks of STATS_ROWS rows; the caller adds the blocks in order)
+constexpr int STATS_ROWS = 2048;
+int stats_blocks(int64_t rows);
+hipError_t launch_col_stats(const float* x, int64_t rows, int dim, double* partial, hipStream_t s);
 // masked MSE: loss_partial[b] = sum over this block's mask entries of sum_o (out - target)^2;
 // G[n][o] += 2 (out[n][o] - target[n][o]) / nmask   (G [N][L] zeroed by the caller; out = first O columns of Y)
 int loss_blocks(int64_t nmask);

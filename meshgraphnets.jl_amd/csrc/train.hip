@@ -645,6 +645,35 @@ __global__ void k_loss(const float* __restrict__ Y, int L, const float* __restri
     if (threadIdx.x == 0) loss_partial[blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
 }
 
+// column sums and sums of squares of a [rows][dim] array (online-normaliser accumulation): 8 row groups x 32 columns per pass,
+// double accumulators, the row groups are added in fixed order
+__global__ __launch_bounds__(256) void k_col_stats(const float* __restrict__ x, int64_t rows, int dim, double* __restrict__ partial) {
+    __shared__ double sh[2][8][32];
+    const int cidx = threadIdx.x & 31, rg = threadIdx.x >> 5;
+    const int64_t r0 = (int64_t)blockIdx.x * STATS_ROWS;
+    const int64_t r1 = r0 + STATS_ROWS < rows ? r0 + STATS_ROWS : rows;
+    for (int c0 = 0; c0 < dim; c0 += 32) {
+        const int col = c0 + cidx;
+        double s = 0.0, q = 0.0;
+        if (col < dim)
+            for (int64_t r = r0 + rg; r < r1; r += 8) {
+                const double v = (double)x[r * dim + col];
+                s += v;
+                q += v * v;
+            }
+        sh[0][rg][cidx] = s;
+        sh[1][rg][cidx] = q;
+        __syncthreads();
+        if (rg < 2 && col < dim) {
+            double t = 0.0;
+#pragma unroll
+            for (int g = 0; g < 8; ++g) t += sh[rg][g][cidx];
+            partial[((size_t)blockIdx.x * 2 + rg) * dim + col] = t;
+        }
+        __syncthreads();
+    }
+}
+
 // ================================================================================================
 // launch wrappers
 // ================================================================================================
@@ -816,6 +845,15 @@ hipError_t launch_extract_cols(const float* src, int L, int O, const float* scal
     const int64_t tot = N * O;
     if (tot <= 0) return hipSuccess;
     hipLaunchKernelGGL(k_extract_cols, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, src, L, O, scale, dst, N);
+    return hipGetLastError();
+}
+
+int stats_blocks(int64_t rows) { return rows > 0 ? (int)((rows + STATS_ROWS - 1) / STATS_ROWS) : 0; }
+
+hipError_t launch_col_stats(const float* x, int64_t rows, int dim, double* partial, hipStream_t s) {
+    const int nb = stats_blocks(rows);
+    if (nb == 0 || dim <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_col_stats, dim3(nb), dim3(256), 0, s, x, rows, dim, partial);
     return hipGetLastError();
 }
 

@@ -290,6 +290,19 @@ class Engine:
                                     C.byref(loss)))
         return gs, loss.value
 
+    def feature_stats(self, x):
+        """Per-feature (sum, sum of squares) of x [rows][dim] in float64 on the device: one NormaliserOnline accumulation
+        (GraphNetCore; normalisers of reference src/MeshGraphNets.jl:92,193-199).  x: NumPy array or device tensor."""
+        shape = tuple(x.shape)
+        if len(shape) != 2:
+            raise ValueError("DimensionMismatch: x must be [rows][dim]")
+        x, px = _host_or_device(x, shape)
+        s = np.zeros(shape[1], np.float64)
+        q = np.zeros(shape[1], np.float64)
+        dp = C.POINTER(C.c_double)
+        self._chk(self.lib.mgn_feature_stats(self.h, px, shape[0], shape[1], s.ctypes.data_as(dp), q.ctypes.data_as(dp)))
+        return s, q
+
     def ode_vjp(self, x, node_type_onehot, ef_raw, lam, val_mask=None, want_dxdt=False):
         """lambda^T df/dx and lambda^T df/dps of the RHS f = ode_step (solver-based training, src/strategies.jl:175-196).
         Returns (xbar [N][O], gs [packed], dxdt or None)."""

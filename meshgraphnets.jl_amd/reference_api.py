@@ -115,11 +115,17 @@ class NormaliserOnline:
         self.acc_sum_squared = np.zeros(self.dims, np.float64)
         self.acc_count = 0.0
         self.num_accumulations = 0.0
+        self.engine = None               # set to an Engine to accumulate on the device
 
     def _accumulate(self, x):
         if self.num_accumulations < self.max_acc:
-            self.acc_sum += x.sum(0, dtype=np.float64)
-            self.acc_sum_squared += (x.astype(np.float64) ** 2).sum(0)
+            if self.engine is not None:          # device reduction (mgn_feature_stats), same float64 totals
+                s, q = self.engine.feature_stats(np.ascontiguousarray(x, dtype=np.float32))
+                self.acc_sum += s
+                self.acc_sum_squared += q
+            else:
+                self.acc_sum += x.sum(0, dtype=np.float64)
+                self.acc_sum_squared += (x.astype(np.float64) ** 2).sum(0)
             self.acc_count += x.shape[0]
             self.num_accumulations += 1.0
 

@@ -2,6 +2,7 @@
 seeded inputs.  Run on the MI355X box with `-m gpu`."""
 import numpy as np
 import pytest
+import torch   # before the engine's first HIP call (device-array tests)
 
 import mgn_oracle as orc
 from util import (TOL_15, TOL_STEP, cfg_dict, engine_for, make_params, random_inputs, rel_max, small_mesh)
@@ -207,3 +208,28 @@ def test_degenerate_graphs_both_precisions(dtype):
     out = eng.forward(nf, np.zeros((0, 7), np.float32))
     ref = orc.forward(ps2, cfg2, nf, np.zeros((0, 7)), np.zeros(0, int), np.zeros(0, int), set2=(ef2, s2, r2))
     assert l2(out, ref) <= tol
+
+
+def test_feature_stats_online_normaliser_accumulation():
+    """mgn_feature_stats == one accumulation of GraphNetCore's NormaliserOnline: float64 column sums / sums of squares,
+    host or device source, ragged row counts (block edges), bitwise repeatable; the Python mirror gives the same
+    normalised output with the engine-backed accumulation."""
+    import torch
+    from mgn_amd import reference_api as ra
+    eng = engine_for(cfg_dict(L=32, mps=1))
+    rng = np.random.default_rng(5)
+    for rows, dim in ((1, 3), (2047, 9), (2049, 12), (50000, 128), (7, 33)):
+        x = (rng.standard_normal((rows, dim)) * 3 + 1).astype(np.float32)
+        s, q = eng.feature_stats(x)
+        x64 = x.astype(np.float64)
+        assert np.allclose(s, x64.sum(0), rtol=1e-12, atol=1e-9) and np.allclose(q, (x64 ** 2).sum(0), rtol=1e-12, atol=1e-9)
+        s2, q2 = eng.feature_stats(torch.from_numpy(x).cuda())
+        assert np.array_equal(s, s2) and np.array_equal(q, q2)
+    with pytest.raises(ValueError):
+        eng.feature_stats(np.zeros(5, np.float32))
+    a, b = ra.NormaliserOnline(9), ra.NormaliserOnline(9)
+    b.engine = eng
+    for _ in range(3):
+        x = rng.standard_normal((4000, 9)).astype(np.float32) * 2 - 0.5
+        ya, yb = a(x), b(x)
+    assert np.allclose(ya, yb, rtol=1e-6, atol=1e-6)
