@@ -65,6 +65,55 @@ DEVINL float dpp_zero(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROWMASK, 0xF, true));
 }
 
+// Segmented inclusive sum over runs of equal receiver inside a 32-row tile (lanes c = 0..31 of each half wave), in place on
+// NG groups of 16 registers.  c1 .. c8: "my run reaches back at least 1 / 2 / 4 / 8 rows inside my 16-lane DPP row",
+// cx: "my run continues from the previous DPP row".  One v_fmac_f32_dpp per register and level:
+//     v += dpp(v) * (condition ? 1 : 0)          (a single rounding: bitwise the sum v + dpp(v))
+// instead of v_add_f32_dpp + v_cndmask: 320 fewer VALU instructions per fp32 edge tile, and VALU issue time adds to MFMA time
+// on this part: edge kernel -2.4 % on M-1M.  DPP reads run with every lane active (a masked-out source
+// lane would read as 0 on gfx9), hence the multiplicative mask; invalid source lanes (row boundaries) read 0 (bound_ctrl).
+// Inline asm: hipcc has no builtin that yields the DPP form of fmac.  Hazards: a DPP read needs 2 wait states after a VALU
+// write of the same VGPR -- consecutive levels touch a register NG * 16 >= 16 instructions apart, and an s_nop covers the
+// first level.  MGN_SCAN_FMAC = 0 restores the two-instruction form (also the reference for tests of this helper).
+#ifndef MGN_SCAN_FMAC
+#define MGN_SCAN_FMAC 1
+#endif
+template <int NG>
+DEVINL void segmented_scan(f32x16 (&acc)[NG], bool c1, bool c2, bool c4, bool c8, bool cx) {
+#if MGN_SCAN_FMAC
+    const float m1 = c1 ? 1.f : 0.f, m2 = c2 ? 1.f : 0.f, m4 = c4 ? 1.f : 0.f, m8 = c8 ? 1.f : 0.f, mx = cx ? 1.f : 0.f;
+#define MGN_SCAN_LEVEL(M, CTRL)                                                                                  \
+    _Pragma("unroll") for (int t = 0; t < NG; ++t)                                                               \
+        _Pragma("unroll") for (int k = 0; k < 16; ++k)                                                           \
+            asm volatile("v_fmac_f32_dpp %0, %0, %1 " CTRL " bound_ctrl:0" : "+v"(acc[t][k]) : "v"(M));
+    PHASE_FENCE();
+    asm volatile("s_nop 1");
+    MGN_SCAN_LEVEL(m1, "row_shr:1 row_mask:0xf bank_mask:0xf")
+    MGN_SCAN_LEVEL(m2, "row_shr:2 row_mask:0xf bank_mask:0xf")
+    MGN_SCAN_LEVEL(m4, "row_shr:4 row_mask:0xf bank_mask:0xf")
+    MGN_SCAN_LEVEL(m8, "row_shr:8 row_mask:0xf bank_mask:0xf")
+    MGN_SCAN_LEVEL(mx, "row_bcast:15 row_mask:0xa bank_mask:0xf")
+#undef MGN_SCAN_LEVEL
+    PHASE_FENCE();
+#else
+#pragma unroll
+    for (int t = 0; t < NG; ++t) {
+        PHASE_FENCE();   // bound the scan's temporaries to one 16-register group at a time
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            float v = acc[t][k];
+            float u;
+            u = v + dpp_zero<0x111, 0xF>(v); v = c1 ? u : v;   // row_shr:1
+            u = v + dpp_zero<0x112, 0xF>(v); v = c2 ? u : v;   // row_shr:2
+            u = v + dpp_zero<0x114, 0xF>(v); v = c4 ? u : v;   // row_shr:4
+            u = v + dpp_zero<0x118, 0xF>(v); v = c8 ? u : v;   // row_shr:8
+            u = v + dpp_zero<0x142, 0xA>(v); v = cx ? u : v;   // row_bcast:15 into rows 1 and 3
+            acc[t][k] = v;
+        }
+    }
+#endif
+}
+
 // ================================================================================================
 // Processor edge step (K3+K4+K5): gather, edge MLP, LayerNorm, residual, segmented scatter.
 // chunk[0]=W2 chunk[1]=W3 chunk[2]=W1[2L:3L];  NRES leading chunks are LDS-resident.
@@ -184,23 +233,7 @@ __global__ __launch_bounds__(512, 2) void k_edge_step(const EdgeArgs a) {
         const int st_in = max(start, c & 16);
         const bool c1 = (c - 1 >= st_in), c2 = (c - 2 >= st_in), c4 = (c - 4 >= st_in), c8 = (c - 8 >= st_in);
         const bool cx = (c >= 16) && (start <= 15);
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            PHASE_FENCE();   // bound the scan's temporaries to one 16-register group at a time
-#pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                // DPP reads must run with every lane active (an EXEC-masked source lane reads as 0), so the
-                // shifted value is formed unconditionally and selected afterwards (v_add_dpp + v_cndmask).
-                float v = acc[t][k];
-                float u;
-                u = v + dpp_zero<0x111, 0xF>(v); v = c1 ? u : v;   // row_shr:1
-                u = v + dpp_zero<0x112, 0xF>(v); v = c2 ? u : v;   // row_shr:2
-                u = v + dpp_zero<0x114, 0xF>(v); v = c4 ? u : v;   // row_shr:4
-                u = v + dpp_zero<0x118, 0xF>(v); v = c8 ? u : v;   // row_shr:8
-                u = v + dpp_zero<0x142, 0xA>(v); v = cx ? u : v;   // row_bcast:15 into rows 1 and 3
-                acc[t][k] = v;
-            }
-        }
+        segmented_scan<NT>(acc, c1, c2, c4, c8, cx);
         STAMP(7);
         const bool tail = valid && ((c == 31) || (reff != rnext));
         const int r_first = __builtin_amdgcn_readfirstlane(reff);
@@ -440,16 +473,10 @@ __global__ __launch_bounds__(256, 2) void k_edge_coop(const EdgeArgs a) {
         const int st_in = max(start, c & 16);
         const bool c1 = (c - 1 >= st_in), c2 = (c - 2 >= st_in), c4 = (c - 4 >= st_in), c8 = (c - 8 >= st_in);
         const bool cx = (c >= 16) && (start <= 15);
-#pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            float v = acc[k];
-            float u;
-            u = v + dpp_zero<0x111, 0xF>(v); v = c1 ? u : v;
-            u = v + dpp_zero<0x112, 0xF>(v); v = c2 ? u : v;
-            u = v + dpp_zero<0x114, 0xF>(v); v = c4 ? u : v;
-            u = v + dpp_zero<0x118, 0xF>(v); v = c8 ? u : v;
-            u = v + dpp_zero<0x142, 0xA>(v); v = cx ? u : v;
-            acc[k] = v;
+        {
+            f32x16 grp[1] = {acc};
+            segmented_scan<1>(grp, c1, c2, c4, c8, cx);
+            acc = grp[0];
         }
         const bool tail = valid && ((c == 31) || (reff != rnext));
         const int r_first = __builtin_amdgcn_readfirstlane(reff);
@@ -988,21 +1015,7 @@ __global__ __launch_bounds__(MGN_BF_WAVES * 64, MGN_BF_WAVES / 4) void k_edge_bf
         const int st_in = max(start, c & 16);
         const bool c1 = (c - 1 >= st_in), c2 = (c - 2 >= st_in), c4 = (c - 4 >= st_in), c8 = (c - 8 >= st_in);
         const bool cx = (c >= 16) && (start <= 15);
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            PHASE_FENCE();
-#pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                float v = acc[t][k];
-                float u;
-                u = v + dpp_zero<0x111, 0xF>(v); v = c1 ? u : v;
-                u = v + dpp_zero<0x112, 0xF>(v); v = c2 ? u : v;
-                u = v + dpp_zero<0x114, 0xF>(v); v = c4 ? u : v;
-                u = v + dpp_zero<0x118, 0xF>(v); v = c8 ? u : v;
-                u = v + dpp_zero<0x142, 0xA>(v); v = cx ? u : v;
-                acc[t][k] = v;
-            }
-        }
+        segmented_scan<4>(acc, c1, c2, c4, c8, cx);
         const bool tail = valid && ((c == 31) || (reff != rnext));
         const int r_first = __builtin_amdgcn_readfirstlane(reff);
         const bool sl = (start == 0) && (ix.r_before == r_first);
