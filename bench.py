@@ -26,6 +26,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: dense f32-input MFMA peak
+PEAK_HBM_GBPS = 8000.0         # same guide: HBM3E ~8 TB/s
 L, MPS, FN, FE, O = 128, 15, 9, 3, 2
 
 
@@ -99,33 +100,74 @@ def cpu_baseline(ps, budget_s=20.0):
                 host_cpus=os.cpu_count())
 
 
-def committed_traffic(kernel_substr):
+def committed_traffic(kernel_substr, dtype="f32"):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this same command
-    (profiles/r01/pmc_summary_bench_1m.json; separate --pmc FETCH_SIZE / WRITE_SIZE passes, gfx950 x2 read
-    correction as prescribed by the guide's HBM section).  None when no profile is committed."""
+    (profiles/rNN/pmc_summary_bench_1m[_bf16].json, newest round first; separate --pmc FETCH_SIZE / WRITE_SIZE passes,
+    gfx950 x2 read correction as prescribed by the guide's HBM section).  None when no profile is committed."""
+    name = "pmc_summary_bench_1m.json" if dtype == "f32" else "pmc_summary_bench_1m_bf16.json"
+    pdir = os.path.join(ROOT, "profiles")
     try:
-        d = json.load(open(os.path.join(ROOT, "profiles", "r01", "pmc_summary_bench_1m.json")))
+        rounds = sorted((d for d in os.listdir(pdir) if d.startswith("r") and d[1:].isdigit()), reverse=True)
+    except OSError:
+        return None, None
+    for rd in rounds:
+        try:
+            d = json.load(open(os.path.join(pdir, rd, name)))
+        except Exception:
+            continue
         for k, v in d.items():
             if kernel_substr in k and "derived" in v:
-                return v["derived"]["hbm_bytes_per_launch_corrected"]
-    except Exception:
-        pass
-    return None
+                return v["derived"]["hbm_bytes_per_launch_corrected"], f"profiles/{rd}/{name}"
+    return None, None
 
 
-def time_single(eng, steps, warmup, sync):
+def time_clean(eng, steps, warmup, sync):
+    """the timed region: nothing but mgn_processor_steps_dev calls between two barrier + synchronise brackets"""
     for _ in range(warmup):
         eng.processor_steps_dev(MPS)
     sync()
-    eng.profile_enable(True)
     t0 = time.perf_counter()
     for _ in range(steps):
         eng.processor_steps_dev(MPS)
     sync()
-    dt = time.perf_counter() - t0
+    return time.perf_counter() - t0
+
+
+def kernel_split(eng, steps, sync):
+    """per-kernel average launch durations: a SEPARATE pass over the same workload with HIP event pairs around every launch
+    group, recorded on the stream the kernels are launched on (mgn_profile_enable); not part of the timed region"""
+    sync()
+    eng.profile_enable(True)
+    for _ in range(steps):
+        eng.processor_steps_dev(MPS)
+    sync()
     prof = eng.profile_read()
     eng.profile_enable(False)
-    return dt, prof
+    return prof
+
+
+def time_single(eng, steps, warmup, sync):
+    dt = time_clean(eng, steps, warmup, sync)
+    return dt, kernel_split(eng, max(1, min(steps, 3)), sync)
+
+
+def comm_bootstrap(eng, rank, world):
+    """One communicator id for all ranks of the job: rank 0 makes it (mgn_comm_unique_id), the launcher's rendezvous store
+    (torch.distributed env:// -- plumbing only) hands it to the others; without a store, a file on this node."""
+    try:
+        from torch.distributed import rendezvous
+        store, _, _ = next(rendezvous("env://", rank, world))
+        if rank == 0:
+            store.set("mgn_comm_id", eng.comm_unique_id("rccl"))
+        eng.comm_init(bytes(store.get("mgn_comm_id")), "rccl")
+        return store
+    except Exception as ex:   # noqa: BLE001
+        if world > 1 and "MASTER_PORT" not in os.environ:
+            raise
+        path = f"/tmp/mgn_comm_{os.environ.get('MASTER_PORT', '0')}_{os.getppid()}_{os.environ.get('TORCHELASTIC_RUN_ID', 'x')}.id"
+        sys.stderr.write(f"[bench] store rendezvous failed ({ex!r}); file bootstrap {path}\n")
+        eng.comm_init_file(path, "rccl")
+        return None
 
 
 def main():
@@ -139,9 +181,12 @@ def main():
     ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
                     help="f32 = the reference's precision (headline); bf16 = BASELINE.json configs[2] precision")
     ap.add_argument("--force-staged", action="store_true",
-                    help="drive the staged multi-partition path (RCCL all-to-all-v) even at world size 1 (self-test)")
+                    help="drive the staged multi-partition path (RCCL communicator, in-library schedule) even at world size 1 (self-test)")
     args = ap.parse_args()
 
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL across processes needs it on this driver
+    if args.force_staged:
+        os.environ["MGN_FORCE_STAGED"] = "1"
     import numpy as np
     import torch
     import mgn_amd
@@ -155,71 +200,93 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the engine has no CPU path")
     torch.cuda.set_device(local_rank)
-    dist = None
     staged = world > 1 or args.force_staged
-    if staged:
-        import torch.distributed as dist
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29511")
-        os.environ.setdefault("RANK", "0")
-        os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-
-    def barrier_sync():
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-            torch.cuda.synchronize()
 
     ps = glorot_params()
     pos, s, r = mgn_amd.synth.mesh_1m(1234, args.nx, args.nx)
     N, E = pos.shape[0], int(s.size)
 
+    # one handle == one partition on one GPU.  The halo exchange (RCCL grouped send / recv over xGMI) and the overlap schedule
+    # run inside mgn_processor_steps_dev: the timed loop below is the same at every N.
     eng = mgn_amd.Engine(FN, FE, O, L, 2, MPS, rank=rank, nranks=world, device=local_rank, dtype=args.dtype)
-    if staged:   # RCCL collectives and the engine must share torch's stream; alone the engine keeps its own stream
-        eng.set_stream(torch.cuda.current_stream().cuda_stream)
     eng.set_params(ps)
     t_setup = time.perf_counter()
     eng.set_graph(s, r, N, mesh_pos=pos)     # unsorted COO in: receiver sort / CSR / partition / halo lists are amortised here
     t_setup = time.perf_counter() - t_setup
+    store = comm_bootstrap(eng, rank, world) if staged else None
     eng.latents_randn(1234)
 
-    if not staged:
-        barrier_sync()
-        dt, prof = time_single(eng, args.steps, args.warmup, barrier_sync)
-    else:
-        from importlib import import_module
-        halo = import_module("mgn_amd.halo")
-        ex = halo.DistExchange(eng, torch.device("cuda", local_rank))
-        for _ in range(args.warmup):
-            mgn_amd.run_processor_staged([eng], ex, MPS)
-        barrier_sync()
-        eng.profile_enable(True)
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            mgn_amd.run_processor_staged([eng], ex, MPS)
-        barrier_sync()
-        dt = time.perf_counter() - t0
-        prof = eng.profile_read()
-        eng.profile_enable(False)
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    def barrier_sync():
+        eng.synchronize()
+        torch.cuda.synchronize()
+        if staged:
+            eng.comm_barrier()
+
+    barrier_sync()
+    dt = time_clean(eng, args.steps, args.warmup, barrier_sync)
+    if staged:
+        dt = float(eng.comm_allreduce([dt], "max")[0])      # MAX over ranks
+    prof = kernel_split(eng, max(1, min(args.steps, 5)), barrier_sync)
 
     chk = eng.latents_checksum()
     finite = all(np.isfinite(v) for v in chk.values())
+    if staged:
+        finite = bool(eng.comm_allreduce([0.0 if finite else 1.0], "max")[0] == 0.0)
 
     if rank == 0:
+        bf = args.dtype == "bf16"
         # a split edge step (N > 1: interior tiles while the halo is in flight, boundary tiles after) is two launches
         t_edge = (prof["edge_step"]["avg_ms"] + (prof["edge_boundary"]["avg_ms"] if prof["edge_boundary"]["count"] else 0.0)) * 1e-3
         t_node = prof["node_step"]["avg_ms"] * 1e-3
         e_loc, n_loc = eng.e_local, eng.n_own
-        ach = flops_edge_kernel(e_loc) / t_edge / 1e12 if t_edge > 0 else 0.0
         t_step = dt / (args.steps * MPS)
-        # node kernel average mixes 14 projecting launches, 1 without and 1 projection-only per pass
-        node_flops_pass = (MPS - 1) * flops_node_kernel(n_loc, True) + flops_node_kernel(n_loc, False) + 2.0 * 2 * L * L * n_loc
-        node_launches = MPS + 1
+        # MFMA flops the kernels EXECUTE per pass (layer 1 of the edge MLP is factored into per-node P / Q): edge kernel 3 chunks
+        # per edge; node side 4 chunks per node per step + 2 for every projection (15 per pass: 14 next-step + the initial one)
+        exec_flops_pass = MPS * flops_edge_kernel(E) + (MPS * 4 + MPS * 2) * 2.0 * L * L * N
+        node_flops_pass = (MPS * 4 + MPS * 2) * 2.0 * L * L * n_loc
+        node_launches = max(prof["node_step"]["count"], 1) / max(1, min(args.steps, 5))
+        edge_kernel = "k_edge_bf16" if bf else "k_edge_step<4,2>"
+        if bf:
+            # bf16 storage: the step is HBM-bound.  Algorithmic bytes of the edge kernel: e latents R + W,
+            # two index streams, one pass over the P, Q rows it gathers and the AGG rows it writes
+            edge_bytes = 2.0 * L * 2 * e_loc + 8.0 * e_loc + 3.0 * 2.0 * L * n_loc
+            ach = edge_bytes / t_edge / 1e9 if t_edge > 0 else 0.0
+            traffic, tsrc = committed_traffic("k_edge_bf16", "bf16") if (world == 1 and args.nx == 1000) else (None, None)
+            roof = {"bound": "hbm", "kernel": "k_edge_bf16 (fused gather + edge MLP + LayerNorm + residual + segmented scatter, bf16 storage)",
+                    "achieved": ach, "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": ach / PEAK_HBM_GBPS,
+                    "bytes_per_launch": edge_bytes, "bytes_kind": "algorithmic: 2 L (2 E) latents R+W + 8 E indices + 3 x 2 L N (P, Q rows read once, AGG rows written)",
+                    "avg_launch_ms": t_edge * 1e3, "launches": prof["edge_step"]["count"], "traffic": traffic, "traffic_source": tsrc}
+            bytes_step = 2.0 * L * (2 * E + 2 * N) + 8.0 * E
+            roof["processor_step"] = {"bound": "hbm", "algorithmic_bytes_per_step": bytes_step, "achieved": bytes_step / t_step / 1e9,
+                                      "peak": PEAK_HBM_GBPS * world, "unit": "GB/s", "frac": bytes_step / t_step / 1e9 / (PEAK_HBM_GBPS * world),
+                                      "note": "SURVEY.md 8(d) compulsory bytes at 2-byte storage / wall time per step",
+                                      "mfma_TFLOPs_executed": exec_flops_pass / MPS / t_step / 1e12, "mfma_peak_bf16_dense": 2500.0}
+        else:
+            ach = flops_edge_kernel(e_loc) / t_edge / 1e12 if t_edge > 0 else 0.0
+            traffic, tsrc = committed_traffic("k_edge_step<4, 2>") if (world == 1 and args.nx == 1000) else (None, None)
+            roof = {"bound": "mfma", "kernel": "k_edge_step<4,2> (fused gather + edge MLP + LayerNorm + residual + segmented scatter)",
+                    "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS,
+                    "flops_per_launch": flops_edge_kernel(e_loc), "flops_kind": "MFMA flops executed by this kernel (98 304 per edge; "
+                    "layer 1 is factored so the v_s/v_r blocks run per node in k_node_step)",
+                    "avg_launch_ms": t_edge * 1e3, "launches": prof["edge_step"]["count"],
+                    "traffic": traffic, "traffic_source": tsrc,
+                    "traffic_unit": "bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE); algorithmic = 1117 B/edge",
+                    "algorithmic_bytes_per_launch": (1024.0 + 8.0 + 85.0) * e_loc,
+                    # what THIS kernel has to move at least, given the factored design: e latents R + W, index streams, and one
+                    # pass over the P, Q rows it gathers and the AGG rows it writes (3 x N x 512 B); gather re-reads come on top
+                    "kernel_compulsory_bytes_per_launch": (1024.0 + 8.0) * e_loc + 3.0 * 512.0 * n_loc}
+            roof["processor_step"] = {
+                "bound": "mfma", "executed_flops_per_step": exec_flops_pass / MPS, "achieved": exec_flops_pass / MPS / t_step / 1e12,
+                "peak": PEAK_F32_MFMA_TFLOPS * world, "unit": "TFLOP/s", "frac": exec_flops_pass / MPS / t_step / 1e12 / (PEAK_F32_MFMA_TFLOPS * world),
+                "note": "MFMA flops the kernels execute (edge 98 304 E; node side 196 608 N incl. the P / Q projection) / wall time per step",
+                "algorithmic_equivalent_TFLOPs": flops_algorithmic(E, N) / t_step / 1e12,
+                "algorithmic_equivalent_note": "SURVEY.md 8(d) flops of the UN-factored algorithm (163 840 E + 131 072 N) over the same time: "
+                                               "a speed-up of the factored design, not a fraction of any peak"}
+        roof["kernel_timing"] = "separate pass after the timed region: HIP event pairs per launch on the launch stream (mgn_profile_enable)"
+        roof["node_side"] = {"avg_launch_ms": t_node * 1e3, "launches": prof["node_step"]["count"],
+                             "achieved_TFLOPs": node_flops_pass / max(node_launches, 1) / t_node / 1e12 if t_node > 0 else 0.0}
+        if prof["halo"]["count"]:
+            roof["halo_pack_ms"] = prof["halo"]["avg_ms"]
         out = {
             "metric": "processor-step edges/s",
             "value": E * MPS * args.steps / dt,
@@ -236,40 +303,17 @@ def main():
             "dtype": args.dtype,
             "data": "synthetic",
             "config": {"workload": f"M-1M jittered-grid triangulation {args.nx}x{args.nx}: N={N} nodes, E={E} directed edges, "
-                                   f"L=128, hidden_layers=2, {MPS} processor steps per bench step, fp32 (BASELINE.json configs[3])",
-                       "partition": f"edge-cut RCB over {world} GPU(s)" if world > 1 else "single partition",
+                                   f"L=128, hidden_layers=2, {MPS} processor steps per bench step, {'bf16 storage + bf16 MFMA' if bf else 'fp32'} "
+                                   f"(BASELINE.json configs[3]{' mesh at configs[2] precision' if bf else ''})",
+                       "partition": (f"edge-cut RCB over {world} GPU(s), halo exchange = RCCL grouped send/recv inside mgn_processor_steps_dev"
+                                     if world > 1 else "single partition"),
                        "edge_order": "engine re-sorts by receiver once per trajectory (mgn_set_graph)"},
-            "roofline": {
-                "bound": "mfma", "kernel": "k_edge_step<4,2> (fused gather + edge MLP + LayerNorm + residual + segmented scatter)",
-                "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS,
-                "sustained_peak_measured": 138.7, "frac_of_sustained": ach / 138.7,
-                "sustained_note": "tools/mfma_probe.hip: back-to-back v_mfma_f32_32x32x2_f32 chains alone reach 138.7 TFLOP/s on this part (DESIGN.md section 4)",
-                "flops_per_launch": flops_edge_kernel(e_loc), "flops_kind": "MFMA flops executed by this kernel (98 304 per edge; "
-                "layer 1 is factored so the v_s/v_r blocks run per node in k_node_step)",
-                "avg_launch_ms": t_edge * 1e3, "launches": prof["edge_step"]["count"],
-                "traffic": committed_traffic("k_edge_step<4, 2>") if (world == 1 and args.nx == 1000) else None,
-                "traffic_unit": "bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/r01/); algorithmic = 1117 B/edge",
-                "algorithmic_bytes_per_launch": (1024.0 + 8.0 + 85.0) * e_loc,
-                # what THIS kernel has to move at least, given the factored design: e latents R + W, index streams, and one
-                # pass over the P, Q rows it gathers and the AGG rows it writes (3 x N x 512 B); gather re-reads come on top
-                "kernel_compulsory_bytes_per_launch": (1024.0 + 8.0) * e_loc + 3.0 * 512.0 * n_loc,
-                "node_kernel": {"avg_launch_ms": t_node * 1e3, "launches": prof["node_step"]["count"],
-                                "achieved": node_flops_pass / node_launches / t_node / 1e12 if t_node > 0 else 0.0},
-                "processor_step_algorithmic": {
-                    "flops_per_step": flops_algorithmic(e_loc, n_loc),
-                    "achieved": flops_algorithmic(E, N) / t_step / 1e12, "peak": PEAK_F32_MFMA_TFLOPS * world,
-                    "frac": flops_algorithmic(E, N) / t_step / 1e12 / (PEAK_F32_MFMA_TFLOPS * world),
-                    "note": "SURVEY.md 8(d) un-factored GEMM flops (163 840 E + 131 072 N) / wall time per step"},
-            },
+            "roofline": roof,
             "latents_finite": bool(finite),
             "graph_setup_s": t_setup,   # once per trajectory (mgn_set_graph: sort by receiver, CSR, partition, upload), not in `value`
         }
-        if args.dtype == "bf16":
-            # bf16: MFMA is 16x faster, the step sits at the HBM/MFMA ridge: report the HBM fraction too
-            bytes_step = 2.0 * L * (2 * e_loc + 2 * n_loc) + 8.0 * e_loc
-            out["roofline"]["bf16_note"] = "peak/frac above are quoted against the fp32 MFMA peak for comparability; bf16 dense MFMA peak is ~2500 TFLOP/s"
-            out["roofline"]["hbm"] = {"bound": "hbm", "algorithmic_bytes_per_step": bytes_step, "achieved": bytes_step / t_step / 1e9,
-                                      "peak": 8000.0, "unit": "GB/s", "frac": bytes_step / t_step / 1e9 / 8000.0}
+        if world > 1:
+            out["per_rank"] = {"n_own": n_loc, "e_local": e_loc, "n_halo": eng.n_halo}
         if world == 1 and not args.no_secondary and args.dtype == "f32":
             engb = mgn_amd.Engine(FN, FE, O, L, 2, MPS, device=local_rank, dtype="bf16")
             engb.set_params(ps)
@@ -283,6 +327,13 @@ def main():
                            "node_side_ms": profb["node_step"]["avg_ms"], "algorithmic_GBps": bytes_b / tb / 1e9,
                            "hbm_frac_of_8TBps": bytes_b / tb / 1e9 / 8000.0,
                            "mfma_TFLOPs_algorithmic": flops_algorithmic(E, N) / tb / 1e12}
+            eb_b = 2.0 * L * 2 * E + 8.0 * E + 3.0 * 2.0 * L * N
+            te_b = profb["edge_step"]["avg_ms"] * 1e-3
+            trb, srcb = committed_traffic("k_edge_bf16", "bf16") if args.nx == 1000 else (None, None)
+            out["bf16"]["roofline"] = {"bound": "hbm", "kernel": "k_edge_bf16", "achieved": eb_b / te_b / 1e9 if te_b > 0 else 0.0,
+                                       "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": eb_b / te_b / 1e9 / PEAK_HBM_GBPS if te_b > 0 else 0.0,
+                                       "bytes_per_launch": eb_b, "traffic": trb, "traffic_source": srcb,
+                                       "processor_step_frac": bytes_b / tb / 1e9 / PEAK_HBM_GBPS}
             engb.close()
         if world == 1 and not args.no_secondary and args.dtype == "f32":
             pos2, cells2, _, _ = mgn_amd.synth.mesh_cyl(1234, 2000)
@@ -409,10 +460,10 @@ def main():
             out["cpu_baseline"] = cpu_baseline(ps)
         print(json.dumps(out), flush=True)
 
+    if staged:
+        eng.comm_barrier()
     eng.close()
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    del store
 
 
 if __name__ == "__main__":

@@ -33,7 +33,8 @@ typedef enum mgn_status {
     MGN_E_HIP = -2,   /* HIP runtime error / no device                                          */
     MGN_E_STATE = -3, /* call order violated (e.g. forward before set_params / set_graph)       */
     MGN_E_OOM = -4,   /* device or host allocation failed                                       */
-    MGN_E_UNSUPPORTED = -5
+    MGN_E_UNSUPPORTED = -5,
+    MGN_E_RCCL = -6   /* communicator: RCCL error, peer time-out, exchange before mgn_comm_init              */
 } mgn_status;
 
 typedef enum mgn_dtype { MGN_F32 = 0, MGN_BF16 = 1 } mgn_dtype;
@@ -133,8 +134,8 @@ int mgn_boundary_count(const mgn_handle* h, int32_t* n_boundary);
 
 /* ---- the model: mgn.model(graph, ps, st) -> output (reference src/solve.jl:200) ---------------
  * nf [N][Fn], ef [E][Fe] are the FeatureGraph fields (already normalised, src/graph.jl:87-96);
- * out [N][O].  With nranks > 1 pass the GLOBAL arrays; only owned rows of `out` are written and the
- * caller drives the halo exchange through mgn_fwd_* below (see engine.py).                      */
+ * out [N][O].  With nranks > 1 every rank passes the GLOBAL arrays (each uploads only the rows it owns) and, after
+ * mgn_comm_init, receives the complete GLOBAL output (owned rows are gathered over the communicator).           */
 int mgn_forward(mgn_handle* h, const float* nf, const float* ef, float* out);
 
 /* ---- the fused RHS: ode_step (reference src/solve.jl:188-219) incl. build_graph (src/graph.jl:75-97)
@@ -223,12 +224,43 @@ int mgn_step(mgn_handle* h, const float* nf, const float* ef, const float* targe
 int mgn_ode_vjp(mgn_handle* h, const float* x, const float* node_type_onehot, const float* ef_raw, const float* val_mask,
                 const float* lambda, float* dxdt, float* xbar, float* grads, size_t n_grads);
 
+/* ---- multi-GPU: the halo exchange lives INSIDE the library (SURVEY.md 8b "the engine owns ... RCCL communicators", 8e) ----
+ * One process (or thread) per partition, one handle each (mgn_config.rank / nranks).  After mgn_comm_init every compute
+ * entry point that documents it runs at nranks > 1 with no host involvement per step: mgn_processor_steps_dev drives, per
+ * processor step, boundary projection -> pack -> sparse all-to-all-v (one grouped ncclSend / ncclRecv pair per neighbour, each
+ * pair over its own xGMI link, on the communicator's stream) -> interior projection and interior edge tiles while the rows
+ * are on the wire -> wait -> boundary edge tiles.  There is no precedent in the reference (single device,
+ * src/MeshGraphNets.jl:255-263).
+ *   transport MGN_COMM_RCCL: RCCL (needs one GPU per rank).
+ *   transport MGN_COMM_HOST: POSIX shared memory on one node, rows staged through the host.  Lets several ranks share one GPU
+ *     (tests), serves host-only handles, and is a fallback where RCCL cannot initialise; not the production wire.
+ * Bootstrap: ONE rank calls mgn_comm_unique_id and the host distributes the MGN_COMM_ID_BYTES bytes (MPI.bcast, a
+ * torch.distributed store, a file), then every rank calls mgn_comm_init with them (collective: returns when all ranks have
+ * joined).  mgn_comm_init_file does the distribution through a file on a shared filesystem: rank 0 writes it, the others wait
+ * for it.  Errors of this group: MGN_E_RCCL.                                                                          */
+#define MGN_COMM_ID_BYTES 128
+typedef enum mgn_comm_transport { MGN_COMM_RCCL = 0, MGN_COMM_HOST = 1 } mgn_comm_transport;
+int mgn_comm_unique_id(void* id /* [MGN_COMM_ID_BYTES] */, int32_t transport);
+int mgn_comm_init(mgn_handle* h, const void* id, size_t id_bytes, int32_t transport);
+int mgn_comm_init_file(mgn_handle* h, const char* path, int32_t transport);
+int mgn_comm_destroy(mgn_handle* h);            /* also done by mgn_destroy */
+int mgn_comm_barrier(mgn_handle* h);            /* drains the handle's stream, then meets the peers */
+/* x[n] (host) reduced over the ranks in place, op 0 = sum, 1 = max; the same bits on every rank (timing brackets, checksums) */
+int mgn_comm_allreduce(mgn_handle* h, double* x, int32_t n, int32_t op);
+/* One blocking halo exchange of the CURRENT P rows (what the staged driver does between steps); for hosts that drive the
+ * fine-grained mgn_fwd_* / mgn_proc_* stages themselves. */
+int mgn_halo_exchange(mgn_handle* h);
+/* Any per-node rows on the HOST: own_rows [n_own][width] -> halo_rows [n_halo][width] (order of mgn_halo_nodes) through the
+ * communicator; works on host-only handles (MGN_COMM_HOST transport).  E.g. positions of halo nodes. */
+int mgn_halo_exchange_host(mgn_handle* h, const float* own_rows, float* halo_rows, int32_t width);
+
 /* ---- the benchmarked unit: nsteps processor steps on given latents -------------
  * v [N][L], e [E][L] in caller order, updated in place (host buffers).                          */
 int mgn_processor_steps(mgn_handle* h, float* v, float* e, int32_t nsteps);
 
 /* Device-resident variant: latents live in the engine (import/randn them first); nothing crosses
- * PCIe.  Single partition only; enqueues 2*nsteps kernels (+1 projection) on the stream.        */
+ * PCIe.  Enqueues 2*nsteps kernels (+1 projection) on the stream; with nranks > 1 (after mgn_comm_init) every rank calls
+ * it and the halo exchange between the steps runs inside (see the multi-GPU section).          */
 int mgn_latents_import(mgn_handle* h, const float* v, const float* e);   /* host, GLOBAL arrays   */
 int mgn_latents_export(mgn_handle* h, float* v, float* e);               /* host, owned rows only */
 int mgn_latents_randn(mgn_handle* h, uint64_t seed); /* N(0,1) keyed by GLOBAL node/edge id      */

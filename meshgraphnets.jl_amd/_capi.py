@@ -13,8 +13,11 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "lib", "libmgn_hip.so")
 
 MGN_DEVICE_NONE = -2
-MGN_OK, MGN_E_ARG, MGN_E_HIP, MGN_E_STATE, MGN_E_OOM, MGN_E_UNSUPPORTED = 0, -1, -2, -3, -4, -5
-STATUS_NAMES = {0: "MGN_OK", -1: "MGN_E_ARG", -2: "MGN_E_HIP", -3: "MGN_E_STATE", -4: "MGN_E_OOM", -5: "MGN_E_UNSUPPORTED"}
+MGN_OK, MGN_E_ARG, MGN_E_HIP, MGN_E_STATE, MGN_E_OOM, MGN_E_UNSUPPORTED, MGN_E_RCCL = 0, -1, -2, -3, -4, -5, -6
+STATUS_NAMES = {0: "MGN_OK", -1: "MGN_E_ARG", -2: "MGN_E_HIP", -3: "MGN_E_STATE", -4: "MGN_E_OOM", -5: "MGN_E_UNSUPPORTED",
+                -6: "MGN_E_RCCL"}
+MGN_COMM_ID_BYTES = 128
+MGN_COMM_RCCL, MGN_COMM_HOST = 0, 1
 
 
 class MgnConfig(C.Structure):
@@ -91,6 +94,14 @@ PROTOTYPES = {
     "mgn_halo_bytes_per_row": (C.c_int, [_H]),
     "mgn_halo_pack": (C.c_int, [_H, C.c_void_p]),
     "mgn_halo_unpack": (C.c_int, [_H, C.c_void_p]),
+    "mgn_comm_unique_id": (C.c_int, [C.c_void_p, C.c_int32]),
+    "mgn_comm_init": (C.c_int, [_H, C.c_void_p, C.c_size_t, C.c_int32]),
+    "mgn_comm_init_file": (C.c_int, [_H, C.c_char_p, C.c_int32]),
+    "mgn_comm_destroy": (C.c_int, [_H]),
+    "mgn_comm_barrier": (C.c_int, [_H]),
+    "mgn_comm_allreduce": (C.c_int, [_H, _f64p, C.c_int32, C.c_int32]),
+    "mgn_halo_exchange": (C.c_int, [_H]),
+    "mgn_halo_exchange_host": (C.c_int, [_H, _f32p, _f32p, C.c_int32]),
     "mgn_tfrecord_open": (C.c_int, [C.c_char_p, C.c_int32, C.POINTER(_H)]),
     "mgn_tfrecord_next": (C.c_int, [_H]),
     "mgn_tfrecord_feature_count": (C.c_int, [_H]),

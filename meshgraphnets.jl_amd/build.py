@@ -20,8 +20,8 @@ LIB = os.path.join(LIBDIR, "libmgn_hip.so")
 ORACLE_DIR = os.path.join(ROOT, "oracle")
 REF_LIB = os.path.join(ORACLE_DIR, "_build", "libmgn_ref.so")
 
-HIP_SOURCES = ["kernels.hip", "train.hip", "mgn_api.cpp", "mgn_train.cpp", "graph_host.cpp", "graph_prologue.cpp", "tfrecord.cpp"]
-HIP_HEADERS = ["kernels.h", "graph_host.h", "frag.hpp", "engine_internal.h", "train.h", os.path.join(ROOT, "include", "mgn_hip.h")]
+HIP_SOURCES = ["kernels.hip", "train.hip", "mgn_api.cpp", "mgn_train.cpp", "graph_host.cpp", "graph_prologue.cpp", "tfrecord.cpp", "comm.cpp"]
+HIP_HEADERS = ["kernels.h", "graph_host.h", "frag.hpp", "engine_internal.h", "train.h", "comm.h", os.path.join(ROOT, "include", "mgn_hip.h")]
 
 
 def _newer(target, deps):
@@ -44,7 +44,7 @@ def build_variant(name, flags, verbose=False):
     os.makedirs(vdir, exist_ok=True)
     out = os.path.join(vdir, name + ".so")
     cmd = [hipcc_path(), "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-shared", "-I", os.path.join(ROOT, "include")]
-    cmd += list(flags) + [os.path.join(CSRC, s) for s in HIP_SOURCES] + ["-o", out]
+    cmd += list(flags) + [os.path.join(CSRC, s) for s in HIP_SOURCES] + ["-o", out, "-ldl", "-lrt", "-lpthread"]
     if verbose:
         print("[build]", " ".join(cmd), flush=True)
     subprocess.check_call(cmd)
@@ -71,7 +71,7 @@ def build_hip(force=False, verbose=True):
                 print("[build]", " ".join(cmd), flush=True)
             subprocess.check_call(cmd)
         objs.append(o)
-    cmd = [hipcc, "-shared", "-fPIC", "--offload-arch=gfx950", "-o", LIB] + objs
+    cmd = [hipcc, "-shared", "-fPIC", "--offload-arch=gfx950", "-o", LIB] + objs + ["-ldl", "-lrt", "-lpthread"]
     if verbose:
         print("[build]", " ".join(cmd), flush=True)
     subprocess.check_call(cmd)

@@ -8,6 +8,7 @@
 #include <vector>
 
 #include "../../include/mgn_hip.h"
+#include "comm.h"
 #include "graph_host.h"
 #include "kernels.h"
 
@@ -135,6 +136,17 @@ struct mgn_engine {
     // the same for mgn_forward (its device buffers keep their addresses between calls)
     hipGraphExec_t fwd_exec = nullptr;
     bool fwd_warm = false;
+
+    // communicator (mgn_comm_init): the halo exchange and the staged schedule run inside the library
+    mgn::Comm* comm = nullptr;
+    int32_t force_staged = 0;                 // MGN_FORCE_STAGED=1: staged schedule even at nranks == 1 (self-test)
+    DevBuf halo_send, halo_recv, gath_s, gath_r;
+    std::vector<size_t> hx_sb, hx_so, hx_rb, hx_ro;   // per-peer byte counts / offsets of one exchange (rebuilt per graph)
+    bool hx_ready = false;
+    bool hx_direct = false;                   // rows are received straight into the halo block of P (one edge set)
+    std::vector<int32_t> all_gid;             // [nranks][1 + max_own]: every rank's (n_own, own_gid...) for output gathers
+    int32_t max_own = 0;
+    bool in_local = false;                    // d_nfA / d_nfB / d_ef hold LOCAL rows (nranks > 1 uploads only what it owns)
 
     // training step (mgn_step): weights in training order, kept activations, scratch -- created on first use
     mgn::TrainState* train = nullptr;

@@ -606,7 +606,7 @@ __global__ __launch_bounds__(512, 2) void k_enc_node(const EncNodeArgs a) {
         const int n = tw.tile * TILE + c;
         const bool valid = n < a.n;
         const int nn = valid ? n : 0;
-        const int64_t g = a.gid[nn];
+        const int64_t g = a.gid ? a.gid[nn] : nn;     // null gid: the source rows are already in local order
         f32x16 acc[NT], y[NT];
         tab_frag<NT>(acc, tb + T_B1 * L, h);
         const int Fn = a.wa + a.wb;
@@ -659,7 +659,7 @@ __global__ __launch_bounds__(256, 2) void k_enc_node_coop(const EncNodeArgs a) {
         const int n = tile * TILE + c;
         const bool valid = n < a.n;
         const int nn = valid ? n : 0;
-        const int64_t g = a.gid[nn];
+        const int64_t g = a.gid ? a.gid[nn] : nn;     // null gid: the source rows are already in local order
         f32x16 in[4], acc;
         CoopRing r2, r3;
         coop_prime(r2, w2, lane);
@@ -719,7 +719,7 @@ __global__ __launch_bounds__(256, 2) void k_enc_edge_coop(const EncEdgeArgs a) {
         OPAQUE_LANE();
         const int64_t eid = (int64_t)tile * TILE + c;
         const bool valid = eid < a.E;
-        const int64_t g = a.gid[valid ? eid : 0];
+        const int64_t g = a.gid ? a.gid[valid ? eid : 0] : (valid ? eid : 0);
         f32x16 in[4], acc;
         CoopRing r2, r3;
         coop_prime(r2, w2, lane);
@@ -781,7 +781,7 @@ __global__ __launch_bounds__(256, 2) void k_decode_coop(const DecArgs a) {
         relu_quarter(acc);
         coop_exchange(in, acc, xch1, wave, lane);
         if (wave == 0) {
-            const float m = a.mask ? a.mask[a.gid[nn]] : 1.0f;
+            const float m = a.mask ? a.mask[a.gid ? a.gid[nn] : nn] : 1.0f;
             for (int o = 0; o < a.O; ++o) {
                 const f32x4* w4 = reinterpret_cast<const f32x4*>(a.w3f + (int64_t)o * L) + h;
                 float sacc = 0.f;
@@ -826,7 +826,7 @@ __global__ __launch_bounds__(512, 2) void k_enc_edge(const EncEdgeArgs a) {
         const int64_t eid = (int64_t)tw.tile * TILE + c;
         const bool valid = eid < a.E;
         const int64_t ee = valid ? eid : 0;
-        const int64_t g = a.gid[ee];
+        const int64_t g = a.gid ? a.gid[ee] : ee;
         f32x16 acc[NT], y[NT];
         tab_frag<NT>(acc, tb + T_B1 * L, h);
         for (int k = 0; k < a.Fe; ++k) {
@@ -876,7 +876,7 @@ __global__ __launch_bounds__(512, 2) void k_decode(const DecArgs a) {
         tab_frag<NT>(v, tb + T_B2 * L, h);
         mfma_chunk<NT, (NRES > 1)>(v, acc, w2, lane);
         relu_frag<NT>(v);
-        const float m = a.mask ? a.mask[a.gid[nn]] : 1.0f;
+        const float m = a.mask ? a.mask[a.gid ? a.gid[nn] : nn] : 1.0f;
         for (int o = 0; o < a.O; ++o) {
             const f32x4* w4 = reinterpret_cast<const f32x4*>(a.w3f + (int64_t)o * L) + h;
             float s = 0.f;

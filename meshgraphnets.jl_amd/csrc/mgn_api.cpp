@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <ctime>
 #include <string>
 #include <vector>
 
@@ -455,7 +456,7 @@ int mgn_create(const mgn_config* cfg, mgn_handle** out) {
 
 void mgn_destroy(mgn_handle* h) {
     if (!h) return;
-    if (h->host_only) { delete h; return; }
+    if (h->host_only) { delete h->comm; delete h; return; }
     (void)hipStreamSynchronize(h->stream);
     drop_graph(h);
     for (auto& r : h->recs) {
@@ -463,6 +464,8 @@ void mgn_destroy(mgn_handle* h) {
         (void)hipEventDestroy(r.b);
     }
     for (hipEvent_t e : h->event_pool) (void)hipEventDestroy(e);
+    delete h->comm;
+    h->comm = nullptr;
     train_free(h);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
     delete h;
@@ -693,6 +696,8 @@ int mgn_set_norms(mgn_handle* h, const float* ns, const float* nsh, const float*
 static int rebuild_graph(mgn_handle* h, int32_t N, const EdgeList* sets, const float* mesh_pos, int32_t pos_dim, bool keep_owner,
                          const char* who) {
     h->have_graph = false;
+    h->hx_ready = false;
+    h->all_gid.clear();
     invalidate_static(h);
     train_invalidate(h, 2);
     if (!h->host_only) { (void)hipStreamSynchronize(h->stream); drop_graph(h); }
@@ -868,6 +873,32 @@ static int upload_inputs(mgn_handle* h, const float* a, int wa, const float* b, 
     const LocalGraph& g = h->g;
     h->in_wa = wa;
     h->in_wb = wb;
+    if (h->cfg.nranks > 1) {
+        // a partition needs 1 / nranks of the inputs: gather the owned node rows and the local edge rows on the host and
+        // upload those (M-1M on 8 GPUs: 13 MB instead of 108 MB per rank and forward); the encoders then read them in
+        // local order (null gid)
+        h->in_local = true;
+        const EdgeTopo& t = g.set[0];
+        const int Fe = h->cfg.Fe;
+        std::vector<float> loc((size_t)g.n_own * (wa + wb) + (size_t)t.e_local * Fe);
+        float* la = loc.data();
+        float* lb = la + (size_t)g.n_own * wa;
+        float* le = lb + (size_t)g.n_own * wb;
+        for (int32_t i = 0; i < g.n_own; ++i) {
+            memcpy(la + (size_t)i * wa, a + (size_t)g.own_gid[i] * wa, (size_t)wa * 4);
+            if (wb > 0) memcpy(lb + (size_t)i * wb, b + (size_t)g.own_gid[i] * wb, (size_t)wb * 4);
+        }
+        for (int64_t j = 0; j < t.e_local; ++j) memcpy(le + (size_t)j * Fe, ef + (size_t)t.edge_gid[j] * Fe, (size_t)Fe * 4);
+        HIPCHK(h, h->d_nfA.ensure((size_t)g.n_own * wa * 4));
+        HIPCHK(h, h->d_nfB.ensure((size_t)g.n_own * (wb > 0 ? wb : 1) * 4));
+        HIPCHK(h, h->es[0].d_ef.ensure((size_t)t.e_local * Fe * 4));
+        HIPCHK(h, hipMemcpyAsync(h->d_nfA.p, la, (size_t)g.n_own * wa * 4, hipMemcpyHostToDevice, h->stream));
+        if (wb > 0) HIPCHK(h, hipMemcpyAsync(h->d_nfB.p, lb, (size_t)g.n_own * wb * 4, hipMemcpyHostToDevice, h->stream));
+        if (t.e_local > 0) HIPCHK(h, hipMemcpyAsync(h->es[0].d_ef.p, le, (size_t)t.e_local * Fe * 4, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));   // `loc` goes out of scope
+        return MGN_OK;
+    }
+    h->in_local = false;
     HIPCHK(h, h->d_nfA.ensure((size_t)g.N * wa * 4));
     HIPCHK(h, hipMemcpyAsync(h->d_nfA.p, a, (size_t)g.N * wa * 4, hipMemcpyHostToDevice, h->stream));
     if (wb > 0) {
@@ -911,7 +942,7 @@ static int encode_impl(mgn_handle* h, bool use_norms, bool nodes = true, bool ed
         EncNodeArgs a{};
         a.n = g.n_own;
         a.ntiles = h->ntiles_n;
-        a.gid = h->d_own_gid.as<int32_t>();
+        a.gid = h->in_local ? nullptr : h->d_own_gid.as<int32_t>();
         a.srcA = h->srcA_override ? h->srcA_override : h->d_nfA.as<float>();
         a.wa = h->in_wa;
         a.srcB = h->d_nfB.as<float>();
@@ -937,7 +968,7 @@ static int encode_impl(mgn_handle* h, bool use_norms, bool nodes = true, bool ed
             EncEdgeArgs b{};
             b.E = g.set[q].e_local;
             b.ntiles = es.ntiles_e;
-            b.gid = es.d_edge_gid.as<int64_t>();
+            b.gid = (q == 0 && h->in_local) ? nullptr : es.d_edge_gid.as<int64_t>();
             b.ef = es.d_ef.as<float>();
             b.Fe = es.Fe;
             if (q == 0 && use_norms && h->have_enorm) { b.scale = nrm + 2 * c.Fn; b.shift = nrm + 2 * c.Fn + c.Fe; }
@@ -1107,6 +1138,10 @@ int mgn_fwd_download(mgn_handle* h, float* out) {
     return MGN_OK;
 }
 
+static int forward_partitioned(mgn_handle* h, const float* nf, const float* ef, float* out);
+static int processor_pass_staged(mgn_handle* h, int32_t nsteps, bool begin);
+static int need_comm(mgn_handle* h, const char* who);
+
 static int run_processor(mgn_handle* h, int nsteps) {
     for (int k = 0; k < nsteps; ++k) {
         if (int rc = mgn_proc_edge(h, k)) return rc;
@@ -1117,8 +1152,7 @@ static int run_processor(mgn_handle* h, int nsteps) {
 
 int mgn_forward(mgn_handle* h, const float* nf, const float* ef, float* out) {
     if (int rc = need(h, true, true)) return rc;
-    if (h->cfg.nranks != 1)
-        return fail(h, MGN_E_STATE, "mgn_forward drives one partition; with nranks > 1 use the staged mgn_fwd_*/mgn_halo_* calls");
+    if (h->cfg.nranks != 1) return forward_partitioned(h, nf, ef, out);
     if (int rc = need_set_features(h)) return rc;
     const float* nfA_before = h->d_nfA.as<float>();
     const float* ef_before = h->es[0].d_ef.as<float>();
@@ -1149,6 +1183,7 @@ int mgn_set_static(mgn_handle* h, const float* onehot, const float* ef_raw, cons
     invalidate_static(h);
     h->in_wa = c.O;
     h->in_wb = c.Fn - c.O;
+    h->in_local = false;
     HIPCHK(h, h->d_nfA.ensure((size_t)g.N * c.O * 4));
     if (h->in_wb > 0) {
         HIPCHK(h, h->d_nfB.ensure((size_t)g.N * h->in_wb * 4));
@@ -1585,6 +1620,140 @@ int mgn_latents_checksum(mgn_handle* h, double* sv, double* se, double* qv, doub
     return MGN_OK;
 }
 
+
+// ---- communicator and the staged multi-partition schedule -------------------------------------------
+#define COMMCHK(h, expr)                                                                                   \
+    do {                                                                                                   \
+        if ((expr) != 0) return fail(h, MGN_E_RCCL, "%s: %s", #expr, (h)->comm ? (h)->comm->err.c_str() : "no communicator"); \
+    } while (0)
+
+static int need_comm(mgn_handle* h, const char* who) {
+    if (!h->comm) return fail(h, MGN_E_RCCL, "%s with nranks = %d needs a communicator: call mgn_comm_init on every rank first", who, h->cfg.nranks);
+    return MGN_OK;
+}
+
+// per-peer byte layout of one exchange; rebuilt after every mgn_set_graph / mgn_set_edge_set
+static int halo_plan(mgn_handle* h) {
+    if (h->hx_ready) return MGN_OK;
+    const LocalGraph& g = h->g;
+    const int P = h->cfg.nranks;
+    const size_t rowb = (size_t)mgn_halo_bytes_per_row(h);
+    h->hx_sb.assign(P, 0); h->hx_so.assign(P, 0); h->hx_rb.assign(P, 0); h->hx_ro.assign(P, 0);
+    size_t so = 0, ro = 0;
+    for (int q = 0; q < P; ++q) {
+        h->hx_sb[q] = (size_t)g.send_rows[q] * rowb; h->hx_so[q] = so; so += h->hx_sb[q];
+        h->hx_rb[q] = (size_t)g.recv_rows[q] * rowb; h->hx_ro[q] = ro; ro += h->hx_rb[q];
+    }
+    // one edge set: the halo rows of P are one contiguous block in owner-rank order -- the layout of the receive buffer --
+    // so the rows land there directly and no unpack copy runs
+    h->hx_direct = h->nsets == 1;
+    if (!h->host_only) {
+        HIPCHK(h, h->halo_send.ensure(so ? so : 16));
+        if (!h->hx_direct) HIPCHK(h, h->halo_recv.ensure(ro ? ro : 16));
+    }
+    h->hx_ready = true;
+    return MGN_OK;
+}
+
+static int exchange_start(mgn_handle* h) {
+    if (int rc = halo_plan(h)) return rc;
+    if (int rc = mgn_halo_pack(h, h->halo_send.p)) return rc;
+    void* recv = h->halo_recv.p;
+    if (h->hx_direct) {
+        const size_t b = is_bf16(h) ? 2 : 4;
+        recv = reinterpret_cast<char*>(is_bf16(h) ? h->es[0].bP.p : h->es[0].P.p) + (size_t)h->g.n_own * h->cfg.L * b;
+    }
+    COMMCHK(h, h->comm->a2a_start(h->halo_send.p, h->hx_sb.data(), h->hx_so.data(), recv, h->hx_rb.data(), h->hx_ro.data(), h->stream));
+    return MGN_OK;
+}
+
+static int exchange_finish(mgn_handle* h) {
+    COMMCHK(h, h->comm->a2a_finish(h->stream));
+    if (!h->hx_direct) return mgn_halo_unpack(h, h->halo_recv.p);
+    return MGN_OK;
+}
+
+// The schedule of one pass (the tested Python twin is engine.run_processor_staged): owned nodes are numbered boundary-first,
+// so the boundary tiles are projected first, their P rows leave, and the interior projection plus the interior edge tiles of
+// the next step run while the rows are on the wire; only the few boundary edge tiles wait for them.
+static int project_and_start(mgn_handle* h, int k) {      // k = -1: projection for step 0
+    if (int rc = mgn_proc_node_phase(h, k, 1)) return rc;
+    if (int rc = exchange_start(h)) return rc;
+    return mgn_proc_node_phase(h, k, 2);
+}
+
+static int processor_pass_staged(mgn_handle* h, int32_t nsteps, bool begin) {
+    if (begin) {
+        if (int rc = project_and_start(h, -1)) return rc;
+    } else if (int rc = exchange_start(h)) return rc;      // P, Q of step 0 came from the encoder
+    for (int k = 0; k < nsteps; ++k) {
+        if (int rc = proc_edge_range(h, k, 1)) return rc;
+        if (int rc = exchange_finish(h)) return rc;
+        if (int rc = proc_edge_range(h, k, 2)) return rc;
+        if (k + 1 < nsteps) {
+            if (int rc = project_and_start(h, k)) return rc;
+        } else if (int rc = mgn_proc_node(h, k, 0)) return rc;
+    }
+    return MGN_OK;
+}
+
+// every rank's (n_own, own_gid...) once per graph: output rows are gathered over the communicator
+static int gather_plan(mgn_handle* h) {
+    if (!h->all_gid.empty()) return MGN_OK;
+    const LocalGraph& g = h->g;
+    const int P = h->cfg.nranks;
+    double mx = (double)g.n_own;
+    COMMCHK(h, h->comm->allreduce_f64(&mx, 1, 1, h->stream));
+    h->max_own = (int32_t)mx;
+    const size_t per = (size_t)1 + h->max_own;
+    std::vector<int32_t> mine(per, 0);
+    mine[0] = g.n_own;
+    memcpy(mine.data() + 1, g.own_gid.data(), (size_t)g.n_own * 4);
+    HIPCHK(h, h->gath_s.ensure(per * 4));
+    HIPCHK(h, h->gath_r.ensure(per * 4 * P));
+    HIPCHK(h, hipMemcpyAsync(h->gath_s.p, mine.data(), per * 4, hipMemcpyHostToDevice, h->stream));
+    COMMCHK(h, h->comm->allgather(h->gath_s.p, per * 4, h->gath_r.p, h->stream));
+    std::vector<int32_t> all(per * P);
+    HIPCHK(h, hipMemcpyAsync(all.data(), h->gath_r.p, per * 4 * P, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    h->all_gid.swap(all);
+    return MGN_OK;
+}
+
+// local_dev [n_own][W] of every rank -> out [N][W] on the host, complete on every rank
+static int gather_rows_global(mgn_handle* h, const float* local_dev, int W, float* out) {
+    if (int rc = gather_plan(h)) return rc;
+    const LocalGraph& g = h->g;
+    const int P = h->cfg.nranks;
+    const size_t per = (size_t)h->max_own * W * 4;
+    HIPCHK(h, h->gath_s.ensure(per ? per : 16));
+    HIPCHK(h, h->gath_r.ensure(per ? per * P : 16));
+    HIPCHK(h, hipMemcpyAsync(h->gath_s.p, local_dev, (size_t)g.n_own * W * 4, hipMemcpyDeviceToDevice, h->stream));
+    COMMCHK(h, h->comm->allgather(h->gath_s.p, per, h->gath_r.p, h->stream));
+    std::vector<float> all((size_t)h->max_own * W * P);
+    HIPCHK(h, hipMemcpyAsync(all.data(), h->gath_r.p, per * P, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    const size_t gper = (size_t)1 + h->max_own;
+    for (int q = 0; q < P; ++q) {
+        const int32_t* gq = h->all_gid.data() + (size_t)q * gper;
+        const float* rows = all.data() + (size_t)q * h->max_own * W;
+        for (int32_t i = 0; i < gq[0]; ++i) memcpy(out + (size_t)gq[1 + i] * W, rows + (size_t)i * W, (size_t)W * 4);
+    }
+    return MGN_OK;
+}
+
+// mgn.model(graph, ps, st) on a partitioned mesh: every rank encodes what it owns, the processor runs the staged schedule,
+// the decoded rows are gathered so that every rank returns the complete output
+static int forward_partitioned(mgn_handle* h, const float* nf, const float* ef, float* out) {
+    if (int rc = need_comm(h, "mgn_forward")) return rc;
+    if (h->nsets != 1) return fail(h, MGN_E_UNSUPPORTED, "mgn_forward with nranks > 1 drives one edge set; use the staged mgn_fwd_* calls for two");
+    if (int rc = mgn_fwd_upload(h, nf, ef)) return rc;
+    if (int rc = encode_impl(h, false)) return rc;
+    if (int rc = processor_pass_staged(h, h->cfg.mps, false)) return rc;
+    if (int rc = decode_impl(h, false)) return rc;
+    return gather_rows_global(h, h->d_out.as<float>(), h->cfg.O, out);
+}
+
 static int processor_pass(mgn_handle* h, int32_t nsteps) {
     if (int rc = mgn_proc_begin(h)) return rc;
     return run_processor(h, nsteps);
@@ -1592,9 +1761,12 @@ static int processor_pass(mgn_handle* h, int32_t nsteps) {
 
 int mgn_processor_steps_dev(mgn_handle* h, int32_t nsteps) {
     if (int rc = need(h, true, true)) return rc;
-    if (h->cfg.nranks != 1) return fail(h, MGN_E_STATE, "mgn_processor_steps_dev drives one partition; use mgn_proc_* + mgn_halo_*");
     if (nsteps < 0 || nsteps > h->cfg.mps) return fail(h, MGN_E_ARG, "nsteps must be in [0, mps]");
     if (nsteps == 0) return MGN_OK;
+    if (h->cfg.nranks != 1 || (h->comm && h->force_staged)) {
+        if (int rc = need_comm(h, "mgn_processor_steps_dev")) return rc;
+        return processor_pass_staged(h, nsteps, true);
+    }
     // Graph replay only helps launch-bound (small) passes; it needs a capturable stream (not the null stream) and no
     // per-launch event records.
     const bool graphable = h->use_graph && !h->prof && h->stream != nullptr && h->es[0].ntiles_e <= 16384;
@@ -1674,6 +1846,111 @@ int mgn_halo_unpack(mgn_handle* h, const void* recv_dev) {
         HIPCHK(h, hipMemcpy2DAsync(dst, rowb, reinterpret_cast<const char*>(recv_dev) + (size_t)q * rowb, (size_t)h->nsets * rowb, rowb,
                                    (size_t)g.n_halo, hipMemcpyDeviceToDevice, h->stream));
     }
+    return MGN_OK;
+}
+
+
+// ---- communicator entry points ---------------------------------------------------------------------------------------
+int mgn_comm_unique_id(void* id, int32_t transport) {
+    if (!id) return fail(nullptr, MGN_E_ARG, "mgn_comm_unique_id: null id");
+    std::string why;
+    if (comm_unique_id(id, transport, why) != 0) return fail(nullptr, MGN_E_RCCL, "mgn_comm_unique_id: %s", why.c_str());
+    return MGN_OK;
+}
+
+int mgn_comm_init(mgn_handle* h, const void* id, size_t id_bytes, int32_t transport) {
+    if (!h) return MGN_E_ARG;
+    if (!id || id_bytes != MGN_COMM_ID_BYTES) return fail(h, MGN_E_ARG, "mgn_comm_init: id must be MGN_COMM_ID_BYTES (%d) bytes", MGN_COMM_ID_BYTES);
+    if (transport != MGN_COMM_RCCL && transport != MGN_COMM_HOST) return fail(h, MGN_E_ARG, "mgn_comm_init: unknown transport %d", transport);
+    if (h->comm) return fail(h, MGN_E_STATE, "mgn_comm_init: the handle already has a communicator (mgn_comm_destroy first)");
+    if (!h->host_only) HIPCHK(h, hipStreamSynchronize(h->stream));
+    std::string why;
+    h->comm = comm_create(id, transport, h->cfg.rank, h->cfg.nranks, !h->host_only, why);
+    if (!h->comm) return fail(h, MGN_E_RCCL, "mgn_comm_init: %s", why.c_str());
+    if (const char* e = getenv("MGN_FORCE_STAGED")) h->force_staged = atoi(e);
+    h->hx_ready = false;
+    h->all_gid.clear();
+    if (!h->host_only) drop_graph(h);
+    return MGN_OK;
+}
+
+int mgn_comm_init_file(mgn_handle* h, const char* path, int32_t transport) {
+    if (!h || !path) return fail(h, MGN_E_ARG, "mgn_comm_init_file: null argument");
+    unsigned char id[MGN_COMM_ID_BYTES];
+    if (h->cfg.rank == 0) {
+        if (int rc = mgn_comm_unique_id(id, transport)) return fail(h, rc, "%s", mgn_last_error(nullptr));
+        const std::string tmp = std::string(path) + ".tmp";
+        FILE* f = fopen(tmp.c_str(), "wb");
+        if (!f || fwrite(id, 1, sizeof id, f) != sizeof id) { if (f) fclose(f); return fail(h, MGN_E_RCCL, "mgn_comm_init_file: cannot write %s", tmp.c_str()); }
+        fclose(f);
+        if (rename(tmp.c_str(), path) != 0) return fail(h, MGN_E_RCCL, "mgn_comm_init_file: cannot publish %s", path);
+    } else {
+        double waited = 0;
+        const double limit = getenv("MGN_COMM_TIMEOUT_S") ? atof(getenv("MGN_COMM_TIMEOUT_S")) : 120.0;
+        for (;;) {
+            FILE* f = fopen(path, "rb");
+            if (f) {
+                const size_t n = fread(id, 1, sizeof id, f);
+                fclose(f);
+                if (n == sizeof id) break;
+            }
+            if (waited > limit) return fail(h, MGN_E_RCCL, "mgn_comm_init_file: timed out waiting for rank 0 to write %s", path);
+            struct timespec ts = {0, 20 * 1000 * 1000};
+            nanosleep(&ts, nullptr);
+            waited += 0.02;
+        }
+    }
+    return mgn_comm_init(h, id, sizeof id, transport);
+}
+
+int mgn_comm_destroy(mgn_handle* h) {
+    if (!h) return MGN_E_ARG;
+    if (!h->host_only) (void)hipStreamSynchronize(h->stream);
+    delete h->comm;
+    h->comm = nullptr;
+    h->hx_ready = false;
+    h->all_gid.clear();
+    return MGN_OK;
+}
+
+int mgn_comm_barrier(mgn_handle* h) {
+    if (!h) return MGN_E_ARG;
+    if (int rc = need_comm(h, "mgn_comm_barrier")) return rc;
+    COMMCHK(h, h->comm->barrier(h->stream));
+    return MGN_OK;
+}
+
+int mgn_comm_allreduce(mgn_handle* h, double* x, int32_t n, int32_t op) {
+    if (!h) return MGN_E_ARG;
+    if (int rc = need_comm(h, "mgn_comm_allreduce")) return rc;
+    if (!x || n < 0 || (op != 0 && op != 1)) return fail(h, MGN_E_ARG, "mgn_comm_allreduce: bad argument");
+    COMMCHK(h, h->comm->allreduce_f64(x, n, op, h->stream));
+    return MGN_OK;
+}
+
+int mgn_halo_exchange(mgn_handle* h) {
+    if (int rc = need(h, false, true)) return rc;
+    if (int rc = need_comm(h, "mgn_halo_exchange")) return rc;
+    if (int rc = exchange_start(h)) return rc;
+    return exchange_finish(h);
+}
+
+int mgn_halo_exchange_host(mgn_handle* h, const float* own_rows, float* halo_rows, int32_t width) {
+    if (!h || !h->have_graph) return fail(h, MGN_E_STATE, "mgn_halo_exchange_host before mgn_set_graph");
+    if (int rc = need_comm(h, "mgn_halo_exchange_host")) return rc;
+    if (width < 1 || (!own_rows && h->g.n_own) || (!halo_rows && h->g.n_halo)) return fail(h, MGN_E_ARG, "mgn_halo_exchange_host: bad argument");
+    const LocalGraph& g = h->g;
+    const int P = h->cfg.nranks;
+    const size_t rowb = (size_t)width * 4;
+    std::vector<float> send(g.send_idx.size() * (size_t)width);
+    for (size_t i = 0; i < g.send_idx.size(); ++i) memcpy(send.data() + i * width, own_rows + (size_t)g.send_idx[i] * width, rowb);
+    std::vector<size_t> sb(P), so(P), rb(P), ro(P);
+    size_t s0 = 0, r0 = 0;
+    for (int q = 0; q < P; ++q) {
+        sb[q] = (size_t)g.send_rows[q] * rowb; so[q] = s0; s0 += sb[q];
+        rb[q] = (size_t)g.recv_rows[q] * rowb; ro[q] = r0; r0 += rb[q];
+    }
+    COMMCHK(h, h->comm->a2a_host(send.data(), sb.data(), so.data(), halo_rows, rb.data(), ro.data()));
     return MGN_OK;
 }
 

@@ -399,6 +399,51 @@ class Engine:
     def halo_unpack(self, recv_ptr):
         self._chk(self.lib.mgn_halo_unpack(self.h, C.c_void_p(recv_ptr)))
 
+    # -- communicator: the halo exchange inside the library ---------------------
+    @staticmethod
+    def comm_unique_id(transport="rccl"):
+        """MGN_COMM_ID_BYTES bytes made on ONE rank; the host distributes them (a torch.distributed store, MPI, a file)."""
+        lib = _capi.load()
+        buf = C.create_string_buffer(_capi.MGN_COMM_ID_BYTES)
+        rc = lib.mgn_comm_unique_id(buf, {"rccl": 0, "host": 1}[transport])
+        if rc != 0:
+            raise MgnError(rc, lib.mgn_last_error(None).decode())
+        return buf.raw
+
+    def comm_init(self, comm_id, transport="rccl"):
+        """Collective over the nranks handles of the partitioned mesh; afterwards processor_steps_dev / forward run at
+        nranks > 1 with the halo exchange inside the library.  transport "rccl" (one GPU per rank) or "host" (shared memory)."""
+        if len(comm_id) != _capi.MGN_COMM_ID_BYTES:
+            raise ValueError("comm_id must be MGN_COMM_ID_BYTES bytes")
+        buf = C.create_string_buffer(bytes(comm_id), _capi.MGN_COMM_ID_BYTES)
+        self._chk(self.lib.mgn_comm_init(self.h, buf, _capi.MGN_COMM_ID_BYTES, {"rccl": 0, "host": 1}[transport]))
+
+    def comm_init_file(self, path, transport="rccl"):
+        self._chk(self.lib.mgn_comm_init_file(self.h, str(path).encode(), {"rccl": 0, "host": 1}[transport]))
+
+    def comm_destroy(self):
+        self._chk(self.lib.mgn_comm_destroy(self.h))
+
+    def comm_barrier(self):
+        self._chk(self.lib.mgn_comm_barrier(self.h))
+
+    def comm_allreduce(self, x, op="sum"):
+        x = np.ascontiguousarray(x, dtype=np.float64).copy()
+        self._chk(self.lib.mgn_comm_allreduce(self.h, x.ctypes.data_as(C.POINTER(C.c_double)), x.size, {"sum": 0, "max": 1}[op]))
+        return x
+
+    def halo_exchange(self):
+        self._chk(self.lib.mgn_halo_exchange(self.h))
+
+    def halo_exchange_host(self, own_rows):
+        """per-node host rows [n_own][W] -> rows of this partition's halo nodes [n_halo][W] (order of halo_nodes())"""
+        own_rows = _c32(own_rows)
+        if own_rows.ndim != 2 or own_rows.shape[0] != self.n_own:
+            raise ValueError("DimensionMismatch: own_rows must be [n_own][W]")
+        out = np.zeros((self.n_halo, own_rows.shape[1]), np.float32)
+        self._chk(self.lib.mgn_halo_exchange_host(self.h, f32(own_rows), f32(out), own_rows.shape[1]))
+        return out
+
     # -- measurement ---------------------------------------------------------------------------
     def profile_enable(self, on=True):
         self._chk(self.lib.mgn_profile_enable(self.h, 1 if on else 0))
