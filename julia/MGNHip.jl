@@ -12,6 +12,7 @@
 module MGNHip
 
 export FeatureGraph, GraphNetwork, set_trajectory_graph!, pack_params, set_static!, ode_step_resident, ode_step_fused, step!, feature_stats
+export comm_unique_id, comm_init!, comm_init_file!, comm_barrier, processor_steps_dev!
 
 const LIB = get(ENV, "MGN_HIP_LIB", joinpath(@__DIR__, "..", "meshgraphnets.jl_amd", "lib", "libmgn_hip.so"))
 
@@ -51,15 +52,18 @@ mutable struct GraphNetwork
     n_norm
     o_norm
     ps_hash::UInt
-    graph_id::UInt
+    graph_key::Tuple{Int, Int, UInt, UInt}     # (E, N, hash(senders), hash(receivers)) of the graph the engine holds
 end
 
-function GraphNetwork(quantities, dims, e_norm, n_norm, o_norm, outputs, mps, layer_size, hidden_layers, ps; device = -1)
-    cfg = MgnConfig(quantities, dims + 1, outputs, layer_size, hidden_layers, mps, 0, 0, 1, device, 1, 0)
+# `rank` / `nranks`: this process's partition of an edge-cut mesh (one process per GPU; see comm_init!).  The reference
+# itself is single-device (src/MeshGraphNets.jl:255-263).
+function GraphNetwork(quantities, dims, e_norm, n_norm, o_norm, outputs, mps, layer_size, hidden_layers, ps; device = -1,
+        rank = 0, nranks = 1)
+    cfg = MgnConfig(quantities, dims + 1, outputs, layer_size, hidden_layers, mps, 0, rank, nranks, device, 1, 0)
     h = Ref{Ptr{Cvoid}}(C_NULL)
     rc = ccall((:mgn_create, LIB), Cint, (Ref{MgnConfig}, Ref{Ptr{Cvoid}}), cfg, h)
     rc == 0 || error(unsafe_string(ccall((:mgn_last_error, LIB), Cstring, (Ptr{Cvoid},), C_NULL)))
-    mgn = GraphNetwork(h[], cfg, identity, ps, NamedTuple(), e_norm, n_norm, o_norm, UInt(0), UInt(0))
+    mgn = GraphNetwork(h[], cfg, identity, ps, NamedTuple(), e_norm, n_norm, o_norm, UInt(0), (-1, -1, UInt(0), UInt(0)))
     mgn.model = (graph, ps_, st) -> (forward(mgn, graph, ps_), st)      # mgn.model(graph, ps, st) -> (output, st)
     finalizer(m -> ccall((:mgn_destroy, LIB), Cvoid, (Ptr{Cvoid},), m.handle), mgn)
     return mgn
@@ -74,17 +78,29 @@ column-major, i.e. the row-major [in][out] block the engine expects: `vec(W)` is
 pack_params(leaves) = reduce(vcat, (vec(Float32.(Array(x))) for x in leaves))
 
 "Once per trajectory, where the reference calls create_base_graph (src/MeshGraphNets.jl:360,418,596)."
-function set_trajectory_graph!(mgn::GraphNetwork, senders::Vector{Int32}, receivers::Vector{Int32}, N::Integer;
+# Content key of a topology.  The key is taken from the CALLER's arrays (whatever their element type) and by content: an
+# `objectid` would name the Int32 copy made below -- a cache that never hits and re-runs mgn_set_graph (receiver sort, CSR,
+# buffer reallocation) for every ODE right-hand side -- and, being address based, can match a different array after GC.  The
+# reference also mutates `senders` in place while it builds the graph (`senders .+= 1`, src/graph.jl:32): a content hash sees that.
+graph_key(senders, receivers, N) = (length(senders), Int(N), hash(senders), hash(receivers))
+
+function set_trajectory_graph!(mgn::GraphNetwork, senders::AbstractVector{<:Integer}, receivers::AbstractVector{<:Integer}, N::Integer;
         mesh_pos::Union{Nothing, Matrix{Float32}} = nothing)
+    key = graph_key(senders, receivers, N)
+    senders = senders isa Vector{Int32} ? senders : Vector{Int32}(senders)        # convert only when needed
+    receivers = receivers isa Vector{Int32} ? receivers : Vector{Int32}(receivers)
     pos = mesh_pos === nothing ? C_NULL : pointer(mesh_pos)
     pd = mesh_pos === nothing ? 0 : size(mesh_pos, 1)
     GC.@preserve senders receivers mesh_pos check(mgn.handle,
         ccall((:mgn_set_graph, LIB), Cint,
             (Ptr{Cvoid}, Int32, Int64, Ptr{Int32}, Ptr{Int32}, Int32, Ptr{Float32}, Int32),
             mgn.handle, N, length(senders), senders, receivers, 1 #= Julia indices, src/graph.jl:31-34 =#, pos, pd))
-    mgn.graph_id = objectid(senders)
+    mgn.graph_key = key
     return mgn
 end
+
+sync_graph!(mgn::GraphNetwork, graph, N) =
+    graph_key(graph.senders, graph.receivers, N) == mgn.graph_key || set_trajectory_graph!(mgn, graph.senders, graph.receivers, N)
 
 function sync_params!(mgn::GraphNetwork, packed::Vector{Float32})
     hsh = hash(packed)
@@ -97,8 +113,7 @@ end
 function forward(mgn::GraphNetwork, graph::FeatureGraph, ps::Vector{Float32})
     sync_params!(mgn, ps)
     N = size(graph.nf, 2)
-    objectid(graph.senders) == mgn.graph_id ||
-        set_trajectory_graph!(mgn, Vector{Int32}(graph.senders), Vector{Int32}(graph.receivers), N)
+    sync_graph!(mgn, graph, N)
     out = Matrix{Float32}(undef, mgn.cfg.O, N)
     nf = Array(graph.nf); ef = Array(graph.ef)             # host arrays: the engine copies in (H2D) itself
     GC.@preserve nf ef out check(mgn.handle,
@@ -120,8 +135,7 @@ function step!(mgn::GraphNetwork, graph::FeatureGraph, target::Matrix{Float32}, 
     ps = mgn.ps::Vector{Float32}
     sync_params!(mgn, ps)
     N = size(graph.nf, 2)
-    objectid(graph.senders) == mgn.graph_id ||
-        set_trajectory_graph!(mgn, Vector{Int32}(graph.senders), Vector{Int32}(graph.receivers), N)
+    sync_graph!(mgn, graph, N)
     gs = Vector{Float32}(undef, length(ps))
     loss = Ref{Float32}(0)
     nf = Array(graph.nf); ef = Array(graph.ef)
@@ -177,5 +191,36 @@ function ode_step_fused(mgn::GraphNetwork, x::Matrix{Float32}, node_type_onehot:
             mgn.handle, x, node_type_onehot, edge_features, val_mask_row, out))
     return out
 end
+
+# ---- multi-GPU: one Julia process per GPU (e.g. under MPI.jl or Distributed), one handle each; the halo exchange (RCCL grouped
+# send / recv over xGMI) and the overlap schedule run inside the library.  With `nranks > 1` and a communicator,
+# `mgn.model(graph, ps, st)` takes the GLOBAL FeatureGraph on every rank and returns the complete output on every rank.
+const COMM_ID_BYTES = 128
+const COMM_RCCL = Int32(0)
+const COMM_HOST = Int32(1)      # shared memory on one node (several ranks on one GPU; tests)
+
+"Made on ONE rank; distribute the bytes to the others (`MPI.Bcast!(id, 0, comm)`), then every rank calls `comm_init!`."
+function comm_unique_id(transport::Int32 = COMM_RCCL)
+    id = Vector{UInt8}(undef, COMM_ID_BYTES)
+    rc = ccall((:mgn_comm_unique_id, LIB), Cint, (Ptr{UInt8}, Int32), id, transport)
+    rc == 0 || error(unsafe_string(ccall((:mgn_last_error, LIB), Cstring, (Ptr{Cvoid},), C_NULL)))
+    return id
+end
+
+function comm_init!(mgn::GraphNetwork, id::Vector{UInt8}, transport::Int32 = COMM_RCCL)
+    GC.@preserve id check(mgn.handle,
+        ccall((:mgn_comm_init, LIB), Cint, (Ptr{Cvoid}, Ptr{UInt8}, Csize_t, Int32), mgn.handle, id, length(id), transport))
+    return mgn
+end
+
+"Bootstrap without MPI: rank 0 writes the id to `path` (a filesystem every rank sees), the others wait for it."
+comm_init_file!(mgn::GraphNetwork, path::AbstractString, transport::Int32 = COMM_RCCL) =
+    (check(mgn.handle, ccall((:mgn_comm_init_file, LIB), Cint, (Ptr{Cvoid}, Cstring, Int32), mgn.handle, path, transport)); mgn)
+
+comm_barrier(mgn::GraphNetwork) = check(mgn.handle, ccall((:mgn_comm_barrier, LIB), Cint, (Ptr{Cvoid},), mgn.handle))
+
+"`nsteps` processor steps on the engine-resident latents (the benchmarked unit); every rank calls it."
+processor_steps_dev!(mgn::GraphNetwork, nsteps::Integer) =
+    check(mgn.handle, ccall((:mgn_processor_steps_dev, LIB), Cint, (Ptr{Cvoid}, Int32), mgn.handle, nsteps))
 
 end # module

@@ -4,6 +4,8 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <exception>
+#include <new>
 #include <string>
 #include <vector>
 
@@ -180,3 +182,10 @@ void train_free(mgn_engine* h);
     } while (0)
 
 }  // namespace mgn
+
+// No C++ exception crosses the C ABI (a Julia or C host would see std::terminate): every entry point is a function-try-block.
+#define MGN_CATCH(h)                                                                                              \
+    catch (const std::bad_alloc&) { return mgn::fail(h, MGN_E_OOM, "%s: host allocation failed", __func__); }     \
+    catch (const std::exception& mgn_ex_) { return mgn::fail(h, MGN_E_ARG, "%s: %s", __func__, mgn_ex_.what()); }             \
+    catch (...) { return mgn::fail(h, MGN_E_ARG, "%s: unknown C++ exception", __func__); }
+#define MGN_CATCH_SIZE catch (...) { return 0; }

@@ -4,14 +4,23 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
+#include <new>
 #include <vector>
 
 #include "../../include/mgn_hip.h"
+
+// no C++ exception crosses the C ABI: allocation failures become MGN_E_OOM
+#define MGN_NOEXCEPT_BEGIN try {
+#define MGN_NOEXCEPT_END                              \
+    }                                                 \
+    catch (const std::bad_alloc&) { return MGN_E_OOM; } \
+    catch (...) { return MGN_E_ARG; }
 
 extern "C" {
 
 int mgn_triangles_to_edges(const int32_t* cells, int64_t n_cells, int32_t* senders, int32_t* receivers, int64_t* n_directed) {
     if (!cells || n_cells < 0 || !n_directed) return MGN_E_ARG;
+    MGN_NOEXCEPT_BEGIN
     // packed (max, min) key with the first-occurrence position, sort, unique, restore first-occurrence order
     struct K { uint64_t key; int64_t first; };
     std::vector<K> v((size_t)3 * n_cells);
@@ -37,6 +46,7 @@ int mgn_triangles_to_edges(const int32_t* cells, int64_t n_cells, int32_t* sende
         senders[m + i] = lo; receivers[m + i] = hi;
     }
     return MGN_OK;
+    MGN_NOEXCEPT_END
 }
 
 // World edges of a cloth-like mesh: all ordered pairs (s, r), s != r, with |world_pos[s] - world_pos[r]| < radius that are
@@ -46,19 +56,34 @@ int mgn_world_edges(const float* world_pos, int32_t dim, int32_t N, float radius
                     int64_t n_mesh, int32_t index_base, int32_t* senders, int32_t* receivers, int64_t* n_edges) {
     if (!world_pos || dim < 1 || dim > 3 || N < 0 || !(radius > 0.f) || !n_edges || n_mesh < 0 || (n_mesh > 0 && (!mesh_senders || !mesh_receivers)))
         return MGN_E_ARG;
+    MGN_NOEXCEPT_BEGIN
     float lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
     for (int d = 0; d < dim; ++d) { lo[d] = 1e30f; hi[d] = -1e30f; }
     for (int64_t i = 0; i < N; ++i)
         for (int d = 0; d < dim; ++d) {
             const float v = world_pos[i * dim + d];
+            if (!std::isfinite(v)) return MGN_E_ARG;       // a NaN / Inf position has no cell
             lo[d] = std::min(lo[d], v);
             hi[d] = std::max(hi[d], v);
         }
+    // cell size >= radius (the 3^dim neighbourhood then covers the search radius), enlarged until the grid has O(N) cells: a
+    // small radius in a large box must not allocate (extent / radius)^dim cells
     int64_t nc[3] = {1, 1, 1};
-    for (int d = 0; d < dim; ++d) nc[d] = N > 0 ? std::min<int64_t>(std::max<int64_t>((int64_t)((hi[d] - lo[d]) / radius) + 1, 1), 2048) : 1;
+    double cell = radius;
+    const double cap = 4.0 * (double)(N > 16 ? N : 16);
+    for (int it = 0; it < 64; ++it) {
+        double prod = 1.0;
+        for (int d = 0; d < dim; ++d) {
+            nc[d] = N > 0 ? std::max<int64_t>((int64_t)(((double)hi[d] - (double)lo[d]) / cell) + 1, 1) : 1;
+            prod *= (double)nc[d];
+        }
+        if (prod <= cap) break;
+        cell *= std::max(1.05, std::pow(prod / cap, 1.0 / dim));
+    }
     auto cell_of = [&](int64_t i, int64_t cc[3]) {
         for (int d = 0; d < 3; ++d) cc[d] = 0;
-        for (int d = 0; d < dim; ++d) cc[d] = std::min<int64_t>((int64_t)((world_pos[i * dim + d] - lo[d]) / radius), nc[d] - 1);
+        for (int d = 0; d < dim; ++d)
+            cc[d] = std::min<int64_t>(std::max<int64_t>((int64_t)(((double)world_pos[i * dim + d] - (double)lo[d]) / cell), 0), nc[d] - 1);
     };
     const int64_t ncell = nc[0] * nc[1] * nc[2];
     std::vector<int32_t> start((size_t)ncell + 1, 0), order((size_t)N);
@@ -121,6 +146,7 @@ int mgn_world_edges(const float* world_pos, int32_t dim, int32_t N, float radius
     }
     *n_edges = count;
     return MGN_OK;
+    MGN_NOEXCEPT_END
 }
 
 int mgn_edge_features(const float* pos, int32_t dim, const int32_t* senders, const int32_t* receivers, int64_t E,

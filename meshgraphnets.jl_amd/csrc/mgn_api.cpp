@@ -17,6 +17,7 @@
 
 using namespace mgn;
 
+
 namespace {
 
 thread_local std::string g_create_error;
@@ -254,7 +255,8 @@ void drop_graph(mgn_engine* h) {
 // of any capture), is captured on the next call and replayed afterwards.
 template <typename F>
 int run_graphed(mgn_engine* h, hipGraphExec_t& exec, bool& warm, F&& launches) {
-    const bool graphable = h->use_graph && !h->prof && launch_is_small(h->ntiles_n);
+    // (the legacy NULL stream -- mgn_set_stream(h, NULL) -- cannot be captured: eager there)
+    const bool graphable = h->use_graph && !h->prof && h->stream != nullptr && launch_is_small(h->ntiles_n);
     if (graphable && exec) {
         HIPCHK(h, hipGraphLaunch(exec, h->stream));
         return MGN_OK;
@@ -264,7 +266,11 @@ int run_graphed(mgn_engine* h, hipGraphExec_t& exec, bool& warm, F&& launches) {
         return launches();
     }
     hipGraph_t graph = nullptr;
-    HIPCHK(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
+    if (hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) {
+        (void)hipGetLastError();
+        h->use_graph = 0;               // a stream that cannot be captured: eager from here on
+        return launches();
+    }
     const int rc = launches();
     const hipError_t ce = hipStreamEndCapture(h->stream, &graph);
     if (rc != MGN_OK || ce != hipSuccess || !graph || hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess) {
@@ -416,7 +422,7 @@ inline bool is_bf16(const mgn_engine* h) { return h->cfg.dtype == MGN_BF16; }
 // =================================================================================================
 extern "C" {
 
-int mgn_create(const mgn_config* cfg, mgn_handle** out) {
+int mgn_create(const mgn_config* cfg, mgn_handle** out) try {
     if (!out) return fail(nullptr, MGN_E_ARG, "null out pointer");
     *out = nullptr;
     std::string why;
@@ -452,7 +458,7 @@ int mgn_create(const mgn_config* cfg, mgn_handle** out) {
     layout_all(h);
     *out = h;
     return MGN_OK;
-}
+} MGN_CATCH(nullptr)
 
 void mgn_destroy(mgn_handle* h) {
     if (!h) return;
@@ -473,29 +479,29 @@ void mgn_destroy(mgn_handle* h) {
 
 const char* mgn_last_error(const mgn_handle* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
 
-int mgn_set_stream(mgn_handle* h, void* hip_stream) {
+int mgn_set_stream(mgn_handle* h, void* hip_stream) try {
     if (int rc = need(h, false, false)) return rc;
     HIPCHK(h, hipStreamSynchronize(h->stream));
     drop_graph(h);
     h->stream = (hip_stream == MGN_STREAM_OWN) ? h->own_stream : reinterpret_cast<hipStream_t>(hip_stream);
     return MGN_OK;
-}
+} MGN_CATCH(h)
 
-int mgn_synchronize(mgn_handle* h) {
+int mgn_synchronize(mgn_handle* h) try {
     if (int rc = need(h, false, false)) return rc;
     HIPCHK(h, hipStreamSynchronize(h->stream));
     return MGN_OK;
-}
+} MGN_CATCH(h)
 
-size_t mgn_param_count(const mgn_config* c) {
+size_t mgn_param_count(const mgn_config* c) try {
     std::string why;
     if (!c || c->Fn < 1 || c->Fe < 1 || c->O < 1 || c->L < 1 || c->hidden_layers != 2 || c->mps < 1) return 0;
     mgn_engine tmp;
     tmp.cfg = *c;
     return layout_all(&tmp);
-}
+} MGN_CATCH_SIZE
 
-int mgn_set_params(mgn_handle* h, const float* packed, size_t n) {
+int mgn_set_params(mgn_handle* h, const float* packed, size_t n) try {
     if (!h || !packed) return fail(h, MGN_E_ARG, "mgn_set_params: null argument");
     if (int rc = need(h, false, false)) return rc;
     const size_t want = layout_all(h);
@@ -658,17 +664,17 @@ int mgn_set_params(mgn_handle* h, const float* packed, size_t n) {
     HIPCHK(h, hipMemcpy(h->wfrag.p, f.data(), f.size() * 4, hipMemcpyHostToDevice));
     h->have_params = true;
     return MGN_OK;
-}
+} MGN_CATCH(h)
 
-int mgn_get_params(mgn_handle* h, float* packed, size_t n) {
+int mgn_get_params(mgn_handle* h, float* packed, size_t n) try {
     if (int rc = need(h, true, false)) return rc;
     if (!packed || n != h->params.size()) return fail(h, MGN_E_ARG, "mgn_get_params: size mismatch");
     memcpy(packed, h->params.data(), n * sizeof(float));
     return MGN_OK;
-}
+} MGN_CATCH(h)
 
 int mgn_set_norms(mgn_handle* h, const float* ns, const float* nsh, const float* es, const float* esh, const float* os,
-                  const float* osh) {
+                  const float* osh) try {
     if (int rc = need(h, false, false)) return rc;
     const mgn_config& c = h->cfg;
     if ((ns == nullptr) != (nsh == nullptr) || (es == nullptr) != (esh == nullptr) || (os == nullptr) != (osh == nullptr))
@@ -690,7 +696,7 @@ int mgn_set_norms(mgn_handle* h, const float* ns, const float* nsh, const float*
     h->have_enorm = es != nullptr;
     h->have_onorm = os != nullptr;
     return MGN_OK;
-}
+} MGN_CATCH(h)
 
 // (re)build the local graph from the kept global edge lists and upload it.  keep_owner: node partition unchanged
 static int rebuild_graph(mgn_handle* h, int32_t N, const EdgeList* sets, const float* mesh_pos, int32_t pos_dim, bool keep_owner,
@@ -731,7 +737,7 @@ static int rebuild_graph(mgn_handle* h, int32_t N, const EdgeList* sets, const f
 }
 
 int mgn_set_graph(mgn_handle* h, int32_t N, int64_t E, const int32_t* senders, const int32_t* receivers, int32_t index_base,
-                  const float* mesh_pos, int32_t pos_dim) {
+                  const float* mesh_pos, int32_t pos_dim) try {
     if (!h) return MGN_E_ARG;
     if (index_base != 0 && index_base != 1) return fail(h, MGN_E_ARG, "mgn_set_graph: index_base must be 0 or 1");
     if (E < 0 || (E > 0 && (!senders || !receivers))) return fail(h, MGN_E_ARG, "mgn_set_graph: null senders/receivers");
@@ -751,9 +757,9 @@ int mgn_set_graph(mgn_handle* h, int32_t N, int64_t E, const int32_t* senders, c
     HIPCHK(h, hipStreamSynchronize(h->stream));
     h->have_graph = true;
     return MGN_OK;
-}
+} MGN_CATCH(h)
 
-int mgn_set_edge_set(mgn_handle* h, int32_t set, int64_t E, const int32_t* senders, const int32_t* receivers, int32_t index_base) {
+int mgn_set_edge_set(mgn_handle* h, int32_t set, int64_t E, const int32_t* senders, const int32_t* receivers, int32_t index_base) try {
     if (!h) return MGN_E_ARG;
     if (!h->have_graph) return fail(h, MGN_E_STATE, "mgn_set_edge_set before mgn_set_graph");
     if (set < 1 || set >= h->nsets) return fail(h, MGN_E_ARG, "mgn_set_edge_set: set %d out of range (handle has %d edge sets; set 0 is mgn_set_graph's)", set, h->nsets);
@@ -777,17 +783,17 @@ int mgn_set_edge_set(mgn_handle* h, int32_t set, int64_t E, const int32_t* sende
     HIPCHK(h, hipStreamSynchronize(h->stream));
     h->have_graph = true;
     return MGN_OK;
-}
+} MGN_CATCH(h)
 
-int mgn_edge_set_info(const mgn_handle* h, int32_t set, int64_t* E, int64_t* e_local) {
+int mgn_edge_set_info(const mgn_handle* h, int32_t set, int64_t* E, int64_t* e_local) try {
     if (!h || !h->have_graph) return MGN_E_STATE;
     if (set < 0 || set >= h->nsets) return MGN_E_ARG;
     if (E) *E = h->g.set[set].E;
     if (e_local) *e_local = h->g.set[set].e_local;
     return MGN_OK;
-}
+} MGN_CATCH(nullptr)
 
-int mgn_set_edge_features(mgn_handle* h, int32_t set, const float* ef) {
+int mgn_set_edge_features(mgn_handle* h, int32_t set, const float* ef) try {
     if (int rc = need(h, false, true)) return rc;
     if (set < 1 || set >= h->nsets) return fail(h, MGN_E_ARG, "mgn_set_edge_features: set %d out of range", set);
     auto& es = h->es[set];
@@ -805,68 +811,68 @@ int mgn_set_edge_features(mgn_handle* h, int32_t set, const float* ef) {
     HIPCHK(h, hipStreamSynchronize(h->stream));
     es.have_ef = true;
     return MGN_OK;
-}
+} MGN_CATCH(h)
 
-int mgn_partition_info(const mgn_handle* h, int32_t* n_own, int32_t* n_halo, int64_t* e_local) {
+int mgn_partition_info(const mgn_handle* h, int32_t* n_own, int32_t* n_halo, int64_t* e_local) try {
     if (!h || !h->have_graph) return MGN_E_STATE;
     if (n_own) *n_own = h->g.n_own;
     if (n_halo) *n_halo = h->g.n_halo;
     if (e_local) *e_local = h->g.set[0].e_local;
     return MGN_OK;
-}
+} MGN_CATCH(nullptr)
 
-int mgn_owned_nodes(const mgn_handle* h, int32_t* ids) {
+int mgn_owned_nodes(const mgn_handle* h, int32_t* ids) try {
     if (!h || !h->have_graph || !ids) return MGN_E_STATE;
     memcpy(ids, h->g.own_gid.data(), h->g.own_gid.size() * 4);
     return MGN_OK;
-}
+} MGN_CATCH(nullptr)
 
-int mgn_local_edges(const mgn_handle* h, int64_t* ids) {
+int mgn_local_edges(const mgn_handle* h, int64_t* ids) try {
     if (!h || !h->have_graph || !ids) return MGN_E_STATE;
     memcpy(ids, h->g.set[0].edge_gid.data(), h->g.set[0].edge_gid.size() * 8);
     return MGN_OK;
-}
+} MGN_CATCH(nullptr)
 
-int mgn_halo_counts(const mgn_handle* h, int32_t* send_rows, int32_t* recv_rows) {
+int mgn_halo_counts(const mgn_handle* h, int32_t* send_rows, int32_t* recv_rows) try {
     if (!h || !h->have_graph) return MGN_E_STATE;
     for (int q = 0; q < h->cfg.nranks; ++q) {
         if (send_rows) send_rows[q] = h->g.send_rows[q];
         if (recv_rows) recv_rows[q] = h->g.recv_rows[q];
     }
     return MGN_OK;
-}
+} MGN_CATCH(nullptr)
 
-int mgn_halo_nodes(const mgn_handle* h, int32_t* ids) {
+int mgn_halo_nodes(const mgn_handle* h, int32_t* ids) try {
     if (!h || !h->have_graph || !ids) return MGN_E_STATE;
     memcpy(ids, h->g.halo_gid.data(), h->g.halo_gid.size() * 4);
     return MGN_OK;
-}
+} MGN_CATCH(nullptr)
 
-int mgn_halo_send_index(const mgn_handle* h, int32_t* rows) {
+int mgn_halo_send_index(const mgn_handle* h, int32_t* rows) try {
     if (!h || !h->have_graph || !rows) return MGN_E_STATE;
     memcpy(rows, h->g.send_idx.data(), h->g.send_idx.size() * 4);
     return MGN_OK;
-}
+} MGN_CATCH(nullptr)
 
-int mgn_local_graph(const mgn_handle* h, int32_t* snd, int32_t* rcv, int32_t* rowptr) {
+int mgn_local_graph(const mgn_handle* h, int32_t* snd, int32_t* rcv, int32_t* rowptr) try {
     if (!h || !h->have_graph) return MGN_E_STATE;
     if (snd) memcpy(snd, h->g.set[0].snd.data(), h->g.set[0].snd.size() * 4);
     if (rcv) memcpy(rcv, h->g.set[0].rcv.data(), h->g.set[0].rcv.size() * 4);
     if (rowptr) memcpy(rowptr, h->g.set[0].rowptr.data(), h->g.set[0].rowptr.size() * 4);
     return MGN_OK;
-}
+} MGN_CATCH(nullptr)
 
-int mgn_node_owner(const mgn_handle* h, int32_t* owner) {
+int mgn_node_owner(const mgn_handle* h, int32_t* owner) try {
     if (!h || !h->have_graph || !owner) return MGN_E_STATE;
     memcpy(owner, h->g.owner.data(), h->g.owner.size() * 4);
     return MGN_OK;
-}
+} MGN_CATCH(nullptr)
 
-int mgn_boundary_count(const mgn_handle* h, int32_t* n_boundary) {
+int mgn_boundary_count(const mgn_handle* h, int32_t* n_boundary) try {
     if (!h || !h->have_graph || !n_boundary) return MGN_E_STATE;
     *n_boundary = h->g.n_boundary;
     return MGN_OK;
-}
+} MGN_CATCH(nullptr)
 
 // ---- staged pipeline ----------------------------------------------------------------------------
 static int upload_inputs(mgn_handle* h, const float* a, int wa, const float* b, int wb, const float* ef) {
@@ -910,12 +916,12 @@ static int upload_inputs(mgn_handle* h, const float* a, int wa, const float* b, 
     return MGN_OK;
 }
 
-int mgn_fwd_upload(mgn_handle* h, const float* nf, const float* ef) {
+int mgn_fwd_upload(mgn_handle* h, const float* nf, const float* ef) try {
     if (int rc = need(h, false, true)) return rc;
     invalidate_static(h);
     if (!nf || (!ef && h->g.set[0].E > 0)) return fail(h, MGN_E_ARG, "mgn_fwd_upload: null input");
     return upload_inputs(h, nf, h->cfg.Fn, nullptr, 0, ef);
-}
+} MGN_CATCH(h)
 
 static int project_set(mgn_handle* h, int k, int q, int32_t tile0 = 0, int32_t ntiles = -1) {   // P,Q of set q for step k (k = mps: step 0)
     if (ntiles < 0) ntiles = h->ntiles_n;
@@ -990,20 +996,20 @@ static int need_set_features(mgn_handle* h) {
     return MGN_OK;
 }
 
-int mgn_fwd_encode(mgn_handle* h) {
+int mgn_fwd_encode(mgn_handle* h) try {
     if (int rc = need(h, true, true)) return rc;
     if (!h->d_nfA.p) return fail(h, MGN_E_STATE, "mgn_fwd_encode before mgn_fwd_upload");
     if (int rc = need_set_features(h)) return rc;
     return encode_impl(h, false);
-}
+} MGN_CATCH(h)
 
-int mgn_proc_begin(mgn_handle* h) {
+int mgn_proc_begin(mgn_handle* h) try {
     if (int rc = need(h, true, true)) return rc;
     ProfScope ps(h, F_NODE);
     for (int q = 0; q < h->nsets; ++q)
         if (int rc = project_set(h, h->cfg.mps, q)) return rc;
     return MGN_OK;
-}
+} MGN_CATCH(h)
 
 static int proc_edge_range(mgn_handle* h, int32_t k, int32_t phase) {   // phase 0: all tiles, 1: interior tiles, 2: boundary tiles
     bool work = false;
@@ -1032,28 +1038,28 @@ static int proc_edge_range(mgn_handle* h, int32_t k, int32_t phase) {   // phase
     return MGN_OK;
 }
 
-int mgn_proc_edge(mgn_handle* h, int32_t k) {
+int mgn_proc_edge(mgn_handle* h, int32_t k) try {
     if (int rc = need(h, true, true)) return rc;
     if (k < 0 || k >= h->cfg.mps) return fail(h, MGN_E_ARG, "mgn_proc_edge: step %d out of range", k);
     return proc_edge_range(h, k, 0);
-}
+} MGN_CATCH(h)
 
-int mgn_proc_edge_phase(mgn_handle* h, int32_t k, int32_t phase) {
+int mgn_proc_edge_phase(mgn_handle* h, int32_t k, int32_t phase) try {
     if (int rc = need(h, true, true)) return rc;
     if (k < 0 || k >= h->cfg.mps) return fail(h, MGN_E_ARG, "mgn_proc_edge_phase: step %d out of range", k);
     if (phase != 1 && phase != 2) return fail(h, MGN_E_ARG, "mgn_proc_edge_phase: phase must be 1 or 2");
     return proc_edge_range(h, k, phase);
-}
+} MGN_CATCH(h)
 
-int mgn_edge_boundary_tiles(const mgn_handle* h, int32_t set, int32_t* boundary, int32_t* total) {
+int mgn_edge_boundary_tiles(const mgn_handle* h, int32_t set, int32_t* boundary, int32_t* total) try {
     if (!h || !h->have_graph) return MGN_E_STATE;
     if (set < 0 || set >= h->nsets) return MGN_E_ARG;
     if (boundary) *boundary = boundary_tiles(h, set);
     if (total) *total = h->es[set].ntiles_e;
     return MGN_OK;
-}
+} MGN_CATCH(nullptr)
 
-int mgn_proc_node(mgn_handle* h, int32_t k, int32_t project_next) {
+int mgn_proc_node(mgn_handle* h, int32_t k, int32_t project_next) try {
     if (int rc = need(h, true, true)) return rc;
     if (k < 0 || k >= h->cfg.mps) return fail(h, MGN_E_ARG, "mgn_proc_node: step %d out of range", k);
     if (project_next && k + 1 >= h->cfg.mps) return fail(h, MGN_E_ARG, "mgn_proc_node: no step %d to project for", k + 1);
@@ -1077,9 +1083,9 @@ int mgn_proc_node(mgn_handle* h, int32_t k, int32_t project_next) {
     const NodeArgs a = node_args(h, k, project_next ? 1 : 0);
     HIPCHK(h, launch_node_step(h->cfg.L, a, h->stream));
     return MGN_OK;
-}
+} MGN_CATCH(h)
 
-int mgn_proc_node_phase(mgn_handle* h, int32_t k, int32_t phase) {
+int mgn_proc_node_phase(mgn_handle* h, int32_t k, int32_t phase) try {
     if (int rc = need(h, true, true)) return rc;
     if (k < -1 || k + 1 >= h->cfg.mps) return fail(h, MGN_E_ARG, "mgn_proc_node_phase: no step %d to project for", k + 1);
     if (phase != 1 && phase != 2) return fail(h, MGN_E_ARG, "mgn_proc_node_phase: phase must be 1 or 2");
@@ -1094,7 +1100,7 @@ int mgn_proc_node_phase(mgn_handle* h, int32_t k, int32_t phase) {
     for (int q = 0; q < h->nsets; ++q)
         if (int rc = project_set(h, k >= 0 ? k : h->cfg.mps, q, tile0, nt)) return rc;
     return MGN_OK;
-}
+} MGN_CATCH(h)
 
 static int decode_impl(mgn_handle* h, bool use_norms) {
     const mgn_config& c = h->cfg;
@@ -1121,12 +1127,12 @@ static int decode_impl(mgn_handle* h, bool use_norms) {
     return MGN_OK;
 }
 
-int mgn_fwd_decode(mgn_handle* h) {
+int mgn_fwd_decode(mgn_handle* h) try {
     if (int rc = need(h, true, true)) return rc;
     return decode_impl(h, false);
-}
+} MGN_CATCH(h)
 
-int mgn_fwd_download(mgn_handle* h, float* out) {
+int mgn_fwd_download(mgn_handle* h, float* out) try {
     if (int rc = need(h, false, true)) return rc;
     if (!out) return fail(h, MGN_E_ARG, "mgn_fwd_download: null out");
     const LocalGraph& g = h->g;
@@ -1136,7 +1142,7 @@ int mgn_fwd_download(mgn_handle* h, float* out) {
     HIPCHK(h, hipStreamSynchronize(h->stream));
     for (int32_t i = 0; i < g.n_own; ++i) memcpy(out + (size_t)g.own_gid[i] * O, loc.data() + (size_t)i * O, (size_t)O * 4);
     return MGN_OK;
-}
+} MGN_CATCH(h)
 
 static int forward_partitioned(mgn_handle* h, const float* nf, const float* ef, float* out);
 static int processor_pass_staged(mgn_handle* h, int32_t nsteps, bool begin);
@@ -1150,7 +1156,7 @@ static int run_processor(mgn_handle* h, int nsteps) {
     return MGN_OK;
 }
 
-int mgn_forward(mgn_handle* h, const float* nf, const float* ef, float* out) {
+int mgn_forward(mgn_handle* h, const float* nf, const float* ef, float* out) try {
     if (int rc = need(h, true, true)) return rc;
     if (h->cfg.nranks != 1) return forward_partitioned(h, nf, ef, out);
     if (int rc = need_set_features(h)) return rc;
@@ -1170,9 +1176,9 @@ int mgn_forward(mgn_handle* h, const float* nf, const float* ef, float* out) {
     };
     if (int rc = run_graphed(h, h->fwd_exec, h->fwd_warm, launches)) return rc;
     return mgn_fwd_download(h, out);
-}
+} MGN_CATCH(h)
 
-int mgn_set_static(mgn_handle* h, const float* onehot, const float* ef_raw, const float* val_mask) {
+int mgn_set_static(mgn_handle* h, const float* onehot, const float* ef_raw, const float* val_mask) try {
     if (int rc = need(h, true, true)) return rc;
     const mgn_config& c = h->cfg;
     if (c.nranks != 1) return fail(h, MGN_E_STATE, "mgn_set_static drives one partition");
@@ -1204,9 +1210,9 @@ int mgn_set_static(mgn_handle* h, const float* onehot, const float* ef_raw, cons
     HIPCHK(h, hipStreamSynchronize(h->stream));
     h->have_static = true;
     return MGN_OK;
-}
+} MGN_CATCH(h)
 
-int mgn_ode_step(mgn_handle* h, const float* x, const float* onehot, const float* ef_raw, const float* val_mask, float* dxdt) {
+int mgn_ode_step(mgn_handle* h, const float* x, const float* onehot, const float* ef_raw, const float* val_mask, float* dxdt) try {
     if (int rc = need(h, true, true)) return rc;
     const mgn_config& c = h->cfg;
     if (h->cfg.nranks != 1) return fail(h, MGN_E_STATE, "mgn_ode_step drives one partition");
@@ -1241,7 +1247,7 @@ int mgn_ode_step(mgn_handle* h, const float* x, const float* onehot, const float
     if (int rc = run_processor(h, c.mps)) return rc;
     if (int rc = decode_impl(h, true)) return rc;
     return mgn_fwd_download(h, dxdt);
-}
+} MGN_CATCH(h)
 
 // ---- native rollout driver (N1) -----------------------------------------------------------------------------
 namespace {
@@ -1303,7 +1309,7 @@ struct Rollout {
             HIPCHK(h, launch_overwrite(x, frames + (size_t)fr * n, mask, h->g.N, c.O, h->stream));
         }
         ++n_rhs;
-        const bool graphable = h->use_graph && !h->prof && launch_is_small(h->ntiles_n);
+        const bool graphable = h->use_graph && !h->prof && h->stream != nullptr && launch_is_small(h->ntiles_n);
         if (!graphable || !warmed) {       // the first RHS runs eagerly: it sets the per-kernel attributes outside of any capture
             warmed = true;
             return rhs_launches(x, kout);
@@ -1314,7 +1320,11 @@ struct Rollout {
                 return MGN_OK;
             }
         hipGraph_t graph = nullptr;
-        HIPCHK(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
+        if (hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) {
+            (void)hipGetLastError();
+            h->use_graph = 0;
+            return rhs_launches(x, kout);
+        }
         const int rc = rhs_launches(x, kout);
         const hipError_t ce = hipStreamEndCapture(h->stream, &graph);
         hipGraphExec_t exec = nullptr;
@@ -1349,7 +1359,7 @@ struct Rollout {
 
 }  // namespace
 
-int mgn_rollout(mgn_handle* h, mgn_rollout_desc* d) {
+int mgn_rollout(mgn_handle* h, mgn_rollout_desc* d) try {
     if (int rc = need(h, true, true)) return rc;
     const mgn_config& c = h->cfg;
     if (c.nranks != 1) return fail(h, MGN_E_STATE, "mgn_rollout drives one partition");
@@ -1490,7 +1500,7 @@ int mgn_rollout(mgn_handle* h, mgn_rollout_desc* d) {
     HIPCHK(h, hipStreamSynchronize(h->stream));
     d->n_rhs = R.n_rhs;
     return MGN_OK;
-}
+} MGN_CATCH(h)
 
 // ---- latents -------------------------------------------------------------------------------------
 // Host boundary of the latents: the caller's arrays travel over PCIe as they are (one contiguous copy each) and
@@ -1528,7 +1538,7 @@ static int export_edges(mgn_handle* h, int q, float* e) {
     return MGN_OK;
 }
 
-int mgn_latents_import(mgn_handle* h, const float* v, const float* e) {
+int mgn_latents_import(mgn_handle* h, const float* v, const float* e) try {
     if (int rc = need(h, false, true)) return rc;
     if (!v) return fail(h, MGN_E_ARG, "mgn_latents_import: null input");
     const LocalGraph& g = h->g;
@@ -1539,10 +1549,10 @@ int mgn_latents_import(mgn_handle* h, const float* v, const float* e) {
     HIPCHK(h, launch_rows_to_tiles(h->stage.as<float>(), nullptr, h->d_own_gid.as<int32_t>(), h->V.as<float>(), g.n_own, L, h->stream));
     if (is_bf16(h)) HIPCHK(h, launch_tile_f32_to_bf16(h->V.as<float>(), h->bV.as<uint16_t>(), h->ntiles_n, h->stream));
     return import_edges(h, 0, e);
-}
+} MGN_CATCH(h)
 
 // Writes the owned rows into the caller's GLOBAL-shaped arrays (other rows are left untouched).
-int mgn_latents_export(mgn_handle* h, float* v, float* e) {
+int mgn_latents_export(mgn_handle* h, float* v, float* e) try {
     if (int rc = need(h, false, true)) return rc;
     const LocalGraph& g = h->g;
     const int L = h->cfg.L;
@@ -1556,21 +1566,21 @@ int mgn_latents_export(mgn_handle* h, float* v, float* e) {
         HIPCHK(h, hipStreamSynchronize(h->stream));
     }
     return export_edges(h, 0, e);
-}
+} MGN_CATCH(h)
 
-int mgn_edge_latents_import(mgn_handle* h, int32_t set, const float* e) {
+int mgn_edge_latents_import(mgn_handle* h, int32_t set, const float* e) try {
     if (int rc = need(h, false, true)) return rc;
     if (set < 0 || set >= h->nsets) return fail(h, MGN_E_ARG, "mgn_edge_latents_import: set %d out of range", set);
     return import_edges(h, set, e);
-}
+} MGN_CATCH(h)
 
-int mgn_edge_latents_export(mgn_handle* h, int32_t set, float* e) {
+int mgn_edge_latents_export(mgn_handle* h, int32_t set, float* e) try {
     if (int rc = need(h, false, true)) return rc;
     if (set < 0 || set >= h->nsets) return fail(h, MGN_E_ARG, "mgn_edge_latents_export: set %d out of range", set);
     return export_edges(h, set, e);
-}
+} MGN_CATCH(h)
 
-int mgn_latents_randn(mgn_handle* h, uint64_t seed) {
+int mgn_latents_randn(mgn_handle* h, uint64_t seed) try {
     if (int rc = need(h, false, true)) return rc;
     const LocalGraph& g = h->g;
     HIPCHK(h, launch_randn_rows(h->V.as<float>(), nullptr, h->d_own_gid.as<int32_t>(), g.n_own, h->cfg.L, seed, h->stream));
@@ -1583,10 +1593,10 @@ int mgn_latents_randn(mgn_handle* h, uint64_t seed) {
             HIPCHK(h, launch_tile_f32_to_bf16(h->es[q].Elat.as<float>(), h->es[q].bElat.as<uint16_t>(), h->es[q].ntiles_e, h->stream));
     }
     return MGN_OK;
-}
+} MGN_CATCH(h)
 
 // (sum, sum of squares) of the node latents and of the edge latents (all sets)
-int mgn_latents_checksum(mgn_handle* h, double* sv, double* se, double* qv, double* qe) {
+int mgn_latents_checksum(mgn_handle* h, double* sv, double* se, double* qv, double* qe) try {
     if (int rc = need(h, false, true)) return rc;
     const int np_ = checksum_partials();
     const int nb = 1 + h->nsets;
@@ -1618,7 +1628,7 @@ int mgn_latents_checksum(mgn_handle* h, double* sv, double* se, double* qv, doub
     if (se) *se = acc[2];
     if (qe) *qe = acc[3];
     return MGN_OK;
-}
+} MGN_CATCH(h)
 
 
 // ---- communicator and the staged multi-partition schedule -------------------------------------------
@@ -1759,7 +1769,7 @@ static int processor_pass(mgn_handle* h, int32_t nsteps) {
     return run_processor(h, nsteps);
 }
 
-int mgn_processor_steps_dev(mgn_handle* h, int32_t nsteps) {
+int mgn_processor_steps_dev(mgn_handle* h, int32_t nsteps) try {
     if (int rc = need(h, true, true)) return rc;
     if (nsteps < 0 || nsteps > h->cfg.mps) return fail(h, MGN_E_ARG, "nsteps must be in [0, mps]");
     if (nsteps == 0) return MGN_OK;
@@ -1783,7 +1793,11 @@ int mgn_processor_steps_dev(mgn_handle* h, int32_t nsteps) {
     h->graph_exec = nullptr;
     h->graph_nsteps = -1;
     hipGraph_t graph = nullptr;
-    HIPCHK(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
+    if (hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) {
+        (void)hipGetLastError();
+        h->use_graph = 0;
+        return processor_pass(h, nsteps);
+    }
     const int rc = processor_pass(h, nsteps);
     const hipError_t ce = hipStreamEndCapture(h->stream, &graph);
     if (rc != MGN_OK || ce != hipSuccess || !graph) {
@@ -1802,21 +1816,21 @@ int mgn_processor_steps_dev(mgn_handle* h, int32_t nsteps) {
     h->graph_nsteps = nsteps;
     HIPCHK(h, hipGraphLaunch(h->graph_exec, h->stream));
     return MGN_OK;
-}
+} MGN_CATCH(h)
 
-int mgn_processor_steps(mgn_handle* h, float* v, float* e, int32_t nsteps) {
+int mgn_processor_steps(mgn_handle* h, float* v, float* e, int32_t nsteps) try {
     if (int rc = need(h, true, true)) return rc;
     if (h->cfg.nranks != 1) return fail(h, MGN_E_STATE, "mgn_processor_steps drives one partition");
     if (int rc = mgn_latents_import(h, v, e)) return rc;
     if (int rc = mgn_processor_steps_dev(h, nsteps)) return rc;
     return mgn_latents_export(h, v, e);
-}
+} MGN_CATCH(h)
 
 // ---- halo ------------------------------------------------------------------------------------------
 // one halo row carries the P row of every edge set: [set 0: L][set 1: L]
 int mgn_halo_bytes_per_row(const mgn_handle* h) { return h ? h->nsets * h->cfg.L * (h->cfg.dtype == MGN_BF16 ? 2 : 4) : MGN_E_ARG; }
 
-int mgn_halo_pack(mgn_handle* h, void* send_dev) {
+int mgn_halo_pack(mgn_handle* h, void* send_dev) try {
     if (int rc = need(h, false, true)) return rc;
     const int64_t rows = (int64_t)h->g.send_idx.size();
     if (rows == 0) return MGN_OK;
@@ -1832,9 +1846,9 @@ int mgn_halo_pack(mgn_handle* h, void* send_dev) {
                                          rows, L, stride, h->stream));
     }
     return MGN_OK;
-}
+} MGN_CATCH(nullptr)
 
-int mgn_halo_unpack(mgn_handle* h, const void* recv_dev) {
+int mgn_halo_unpack(mgn_handle* h, const void* recv_dev) try {
     if (int rc = need(h, false, true)) return rc;
     const LocalGraph& g = h->g;
     if (g.n_halo == 0) return MGN_OK;
@@ -1847,18 +1861,18 @@ int mgn_halo_unpack(mgn_handle* h, const void* recv_dev) {
                                    (size_t)g.n_halo, hipMemcpyDeviceToDevice, h->stream));
     }
     return MGN_OK;
-}
+} MGN_CATCH(h)
 
 
 // ---- communicator entry points ---------------------------------------------------------------------------------------
-int mgn_comm_unique_id(void* id, int32_t transport) {
+int mgn_comm_unique_id(void* id, int32_t transport) try {
     if (!id) return fail(nullptr, MGN_E_ARG, "mgn_comm_unique_id: null id");
     std::string why;
     if (comm_unique_id(id, transport, why) != 0) return fail(nullptr, MGN_E_RCCL, "mgn_comm_unique_id: %s", why.c_str());
     return MGN_OK;
-}
+} MGN_CATCH(nullptr)
 
-int mgn_comm_init(mgn_handle* h, const void* id, size_t id_bytes, int32_t transport) {
+int mgn_comm_init(mgn_handle* h, const void* id, size_t id_bytes, int32_t transport) try {
     if (!h) return MGN_E_ARG;
     if (!id || id_bytes != MGN_COMM_ID_BYTES) return fail(h, MGN_E_ARG, "mgn_comm_init: id must be MGN_COMM_ID_BYTES (%d) bytes", MGN_COMM_ID_BYTES);
     if (transport != MGN_COMM_RCCL && transport != MGN_COMM_HOST) return fail(h, MGN_E_ARG, "mgn_comm_init: unknown transport %d", transport);
@@ -1872,9 +1886,9 @@ int mgn_comm_init(mgn_handle* h, const void* id, size_t id_bytes, int32_t transp
     h->all_gid.clear();
     if (!h->host_only) drop_graph(h);
     return MGN_OK;
-}
+} MGN_CATCH(h)
 
-int mgn_comm_init_file(mgn_handle* h, const char* path, int32_t transport) {
+int mgn_comm_init_file(mgn_handle* h, const char* path, int32_t transport) try {
     if (!h || !path) return fail(h, MGN_E_ARG, "mgn_comm_init_file: null argument");
     unsigned char id[MGN_COMM_ID_BYTES];
     if (h->cfg.rank == 0) {
@@ -1901,9 +1915,9 @@ int mgn_comm_init_file(mgn_handle* h, const char* path, int32_t transport) {
         }
     }
     return mgn_comm_init(h, id, sizeof id, transport);
-}
+} MGN_CATCH(h)
 
-int mgn_comm_destroy(mgn_handle* h) {
+int mgn_comm_destroy(mgn_handle* h) try {
     if (!h) return MGN_E_ARG;
     if (!h->host_only) (void)hipStreamSynchronize(h->stream);
     delete h->comm;
@@ -1911,31 +1925,31 @@ int mgn_comm_destroy(mgn_handle* h) {
     h->hx_ready = false;
     h->all_gid.clear();
     return MGN_OK;
-}
+} MGN_CATCH(h)
 
-int mgn_comm_barrier(mgn_handle* h) {
+int mgn_comm_barrier(mgn_handle* h) try {
     if (!h) return MGN_E_ARG;
     if (int rc = need_comm(h, "mgn_comm_barrier")) return rc;
     COMMCHK(h, h->comm->barrier(h->stream));
     return MGN_OK;
-}
+} MGN_CATCH(h)
 
-int mgn_comm_allreduce(mgn_handle* h, double* x, int32_t n, int32_t op) {
+int mgn_comm_allreduce(mgn_handle* h, double* x, int32_t n, int32_t op) try {
     if (!h) return MGN_E_ARG;
     if (int rc = need_comm(h, "mgn_comm_allreduce")) return rc;
     if (!x || n < 0 || (op != 0 && op != 1)) return fail(h, MGN_E_ARG, "mgn_comm_allreduce: bad argument");
     COMMCHK(h, h->comm->allreduce_f64(x, n, op, h->stream));
     return MGN_OK;
-}
+} MGN_CATCH(h)
 
-int mgn_halo_exchange(mgn_handle* h) {
+int mgn_halo_exchange(mgn_handle* h) try {
     if (int rc = need(h, false, true)) return rc;
     if (int rc = need_comm(h, "mgn_halo_exchange")) return rc;
     if (int rc = exchange_start(h)) return rc;
     return exchange_finish(h);
-}
+} MGN_CATCH(h)
 
-int mgn_halo_exchange_host(mgn_handle* h, const float* own_rows, float* halo_rows, int32_t width) {
+int mgn_halo_exchange_host(mgn_handle* h, const float* own_rows, float* halo_rows, int32_t width) try {
     if (!h || !h->have_graph) return fail(h, MGN_E_STATE, "mgn_halo_exchange_host before mgn_set_graph");
     if (int rc = need_comm(h, "mgn_halo_exchange_host")) return rc;
     if (width < 1 || (!own_rows && h->g.n_own) || (!halo_rows && h->g.n_halo)) return fail(h, MGN_E_ARG, "mgn_halo_exchange_host: bad argument");
@@ -1952,13 +1966,13 @@ int mgn_halo_exchange_host(mgn_handle* h, const float* own_rows, float* halo_row
     }
     COMMCHK(h, h->comm->a2a_host(send.data(), sb.data(), so.data(), halo_rows, rb.data(), ro.data()));
     return MGN_OK;
-}
+} MGN_CATCH(h)
 
 // Process-wide kernel-path override for tests (not part of the public header): 0 auto, 1 LDS-resident persistent
 // kernels, 2 all-streaming, 3 cooperative 4-wave tiles.  Returns the previous value.
 int mgn_debug_kernel_path(int path) { return set_kernel_path(path); }
 
-int mgn_debug_edge_stamps(mgn_handle* h, int32_t k, unsigned long long* out /* [4*8*24*8] */) {
+int mgn_debug_edge_stamps(mgn_handle* h, int32_t k, unsigned long long* out /* [4*8*24*8] */) try {
     if (int rc = need(h, true, true)) return rc;
     const size_t n = (size_t)4 * 8 * 24 * 8;
     HIPCHK(h, h->d_stamps.ensure(n * 8));
@@ -1968,10 +1982,10 @@ int mgn_debug_edge_stamps(mgn_handle* h, int32_t k, unsigned long long* out /* [
     HIPCHK(h, hipStreamSynchronize(h->stream));
     h->d_stamps.release();
     return MGN_OK;
-}
+} MGN_CATCH(h)
 
 // ---- profiling ---------------------------------------------------------------------------------------
-int mgn_profile_enable(mgn_handle* h, int32_t on) {
+int mgn_profile_enable(mgn_handle* h, int32_t on) try {
     if (int rc = need(h, false, false)) return rc;
     HIPCHK(h, hipStreamSynchronize(h->stream));
     for (auto& r : h->recs) {
@@ -1988,9 +2002,9 @@ int mgn_profile_enable(mgn_handle* h, int32_t on) {
         h->event_pool.push_back(e);
     }
     return MGN_OK;
-}
+} MGN_CATCH(h)
 
-int mgn_profile_read(mgn_handle* h, double ms_avg[8], int64_t counts[8]) {
+int mgn_profile_read(mgn_handle* h, double ms_avg[8], int64_t counts[8]) try {
     if (!h || !ms_avg || !counts) return MGN_E_ARG;
     if (int rc = need(h, false, false)) return rc;
     HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -2011,6 +2025,6 @@ int mgn_profile_read(mgn_handle* h, double ms_avg[8], int64_t counts[8]) {
         counts[i] = cnt[i];
     }
     return MGN_OK;
-}
+} MGN_CATCH(h)
 
 }  // extern "C"

@@ -368,7 +368,7 @@ int train_run(mgn_handle* h, const TrainJob& J) {
 
     // Small meshes replay both launch sequences from hipGraphs (everything they touch lives at fixed addresses in the arena;
     // the inputs, the seed of the reverse pass and the results stay outside).  The captured pointers are checked per call.
-    const bool graphable = h->use_graph && !h->prof && T.gsets > 1;
+    const bool graphable = h->use_graph && !h->prof && st != nullptr && T.gsets > 1;   // the NULL stream cannot be captured
     if (T.exec_arena != T.arena.p || T.exec_w != T.w.p) {
         T.drop_graphs();
         T.exec_arena = T.arena.p;
@@ -384,7 +384,11 @@ int train_run(mgn_handle* h, const TrainJob& J) {
             return launches();
         }
         hipGraph_t graph = nullptr;
-        HIPCHK(h, hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+        if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) != hipSuccess) {
+            (void)hipGetLastError();
+            h->use_graph = 0;
+            return launches();
+        }
         const int rc = launches();
         const hipError_t ce = hipStreamEndCapture(st, &graph);
         if (rc != MGN_OK || ce != hipSuccess || !graph || hipGraphInstantiate(&T.exec[slot], graph, nullptr, nullptr, 0) != hipSuccess) {
@@ -617,7 +621,7 @@ int train_run(mgn_handle* h, const TrainJob& J) {
 }  // namespace
 
 extern "C" int mgn_step(mgn_handle* h, const float* nf, const float* ef, const float* target, const int32_t* mask, int64_t nmask,
-                        int32_t mask_index_base, float* grads, size_t n_grads, float* loss) {
+                        int32_t mask_index_base, float* grads, size_t n_grads, float* loss) try {
     if (!h) return MGN_E_ARG;
     if (!nf || !target || !mask || !grads || !loss) return fail(h, MGN_E_ARG, "mgn_step: null argument");
     if (int rc = train_prepare(h, "mgn_step", n_grads)) return rc;
@@ -632,10 +636,10 @@ extern "C" int mgn_step(mgn_handle* h, const float* nf, const float* ef, const f
     J.nf = nf; J.ef = ef; J.target = target; J.mask = mask; J.nmask = nmask; J.mask_index_base = mask_index_base;
     J.loss = loss; J.grads = grads;
     return train_run(h, J);
-}
+} MGN_CATCH(h)
 
 extern "C" int mgn_ode_vjp(mgn_handle* h, const float* x, const float* node_type_onehot, const float* ef_raw, const float* val_mask,
-                           const float* lambda, float* dxdt, float* xbar, float* grads, size_t n_grads) {
+                           const float* lambda, float* dxdt, float* xbar, float* grads, size_t n_grads) try {
     if (!h) return MGN_E_ARG;
     if (!x || !lambda || !xbar || !grads) return fail(h, MGN_E_ARG, "mgn_ode_vjp: null argument");
     if (int rc = train_prepare(h, "mgn_ode_vjp", n_grads)) return rc;
@@ -647,11 +651,11 @@ extern "C" int mgn_ode_vjp(mgn_handle* h, const float* x, const float* node_type
     J.x = x; J.onehot = node_type_onehot; J.ef = ef_raw; J.val_mask = val_mask; J.lambda = lambda;
     J.dxdt = dxdt; J.xbar = xbar; J.grads = grads;
     return train_run(h, J);
-}
+} MGN_CATCH(h)
 
 // Online-normaliser accumulation (GraphNetCore NormaliserOnline, used at reference src/MeshGraphNets.jl:92,193-199 and inside
 // build_graph): per-feature sum and sum of squares of x [rows][dim], in double.
-extern "C" int mgn_feature_stats(mgn_handle* h, const float* x, int64_t rows, int32_t dim, double* sum, double* sum_squares) {
+extern "C" int mgn_feature_stats(mgn_handle* h, const float* x, int64_t rows, int32_t dim, double* sum, double* sum_squares) try {
     if (!h) return MGN_E_ARG;
     if (int rc = need(h, false, false)) return rc;
     if (!x || !sum || !sum_squares || rows < 0 || dim < 1) return fail(h, MGN_E_ARG, "mgn_feature_stats: bad argument");
@@ -673,4 +677,4 @@ extern "C" int mgn_feature_stats(mgn_handle* h, const float* x, int64_t rows, in
             sum_squares[f] += part[((size_t)b * 2 + 1) * dim + f];
         }
     return MGN_OK;
-}
+} MGN_CATCH(h)

@@ -114,6 +114,57 @@ def gold_two_sets():
     print("gold_c_two_sets N", N, "E", E, "E2", E2, "out[0]", out[0], "rng", rng.integers(10))
 
 
+def cyl_rollout_problem():
+    """The cfg-5 problem (BASELINE.json configs[4]: cylinder_flow 100-step rollout) on M-cyl, rebuilt from seeds by the
+    generator and by the GPU test alike; nothing but the reference solution is stored."""
+    pos, cells, ntype, vel = mgn_amd.synth.mesh_cyl(SEED, 2000)
+    s, r = mgn_amd.synth.cells_to_edges(cells)
+    N = pos.shape[0]
+    cfg = dict(Fn=9, Fe=3, O=2, L=128, hidden_layers=2, mps=15)
+    ps = orc.init_params(9, 3, 2, 128, 2, 15, seed=SEED + 5, ln_jitter=0.05)
+    onehot = orc.one_hot(ntype, 7, 0)
+    ef_raw = orc.edge_features(pos, s, r)
+    x0 = vel.astype(np.float64)
+    dt, nsteps = 0.01, 100
+    tt = np.arange(nsteps + 1)[:, None, None] * dt
+    gt = x0[None] * (1.0 + 0.05 * np.sin(2 * np.pi * tt))                 # inflow "data" frames, one per save point
+    n_norm = orc.NormMeanStd(x0.mean(0), x0.std(0))
+    t_norm = orc.NormMinMax(0.0, 1.0)
+    e_norm = orc.NormMeanStd(ef_raw.mean(0), ef_raw.std(0))
+    o_norm = orc.NormMeanStd(np.array([0.0, 0.0]), np.array([0.5, 0.5]))
+    val_mask = np.isin(ntype, [0, 5]).astype(np.float64)[:, None]         # types_updated = [0, 5]
+    inflow = np.repeat((ntype == 1)[:, None], 2, 1)                       # literal 1: src/MeshGraphNets.jl:593
+    return dict(pos=pos, s=s, r=r, N=N, cfg=cfg, ps=ps, onehot=onehot, ef_raw=ef_raw, x0=x0, dt=dt, nsteps=nsteps, gt=gt,
+                n_norm=n_norm, t_norm=t_norm, e_norm=e_norm, o_norm=o_norm, val_mask=val_mask, inflow=inflow, ntype=ntype)
+
+
+def gold_cyl_rollout(tsit5=True):
+    """GOLD-E: the 100-step rollout of BASELINE.json configs[4] at its real size (M-cyl: N = 2000, E = 11 954, L = 128, 15
+    steps): fixed-step Euler and adaptive Tsit5 with 101 saves, float64 oracle; every 10th save point is stored."""
+    p = cyl_rollout_problem()
+    dt, ns = p["dt"], p["nsteps"]
+
+    def rhs(x, t):
+        k = min(int(np.floor(t / dt + 1e-6)), ns)
+        return orc.ode_rhs(p["ps"], p["cfg"], x, p["onehot"], p["ef_raw"], p["s"], p["r"], p["n_norm"], p["t_norm"], p["e_norm"],
+                           p["o_norm"], p["val_mask"], p["inflow"], p["gt"][k])
+
+    xs = orc.euler_rollout(rhs, p["x0"], dt, ns, p["inflow"], p["gt"])
+    d = dict(seed=SEED, params_sha256=sha(p["ps"]), senders_sha256=sha(p["s"]), receivers_sha256=sha(p["r"]), N=p["N"], E=p["s"].size,
+             dt=dt, nsteps=ns, every=10, euler=xs[::10].astype(np.float32), euler_first=xs[1].astype(np.float32))
+    print("gold_e euler", xs.shape, xs[-1, 0], flush=True)
+    if tsit5:
+        def f(x, t):
+            k = min(int(np.floor(t / dt + 1e-6)), ns)
+            x[p["inflow"]] = p["gt"][k][p["inflow"]]          # in place, like the reference
+            return orc.ode_rhs(p["ps"], p["cfg"], x, p["onehot"], p["ef_raw"], p["s"], p["r"], p["n_norm"], p["t_norm"], p["e_norm"],
+                               p["o_norm"], p["val_mask"])
+        sol, st = orc.tsit5_rollout(f, p["x0"], 0.0, ns * dt, np.arange(ns + 1) * dt, abstol=1e-6, reltol=1e-3)
+        d.update(tsit5=sol[::10].astype(np.float32), tsit5_accept=st["n_accept"], tsit5_reject=st["n_reject"], tsit5_rhs=st["n_rhs"])
+        print("gold_e tsit5", st, sol[-1, 0], flush=True)
+    np.savez_compressed(os.path.join(HERE, "gold_e_cyl_rollout.npz"), **d)
+
+
 def kats():
     """Known-answer tests stored as data so every implementation reads the same file."""
     tri1 = np.array([[0, 1, 2]], np.int32)
@@ -128,6 +179,9 @@ def kats():
 
 
 if __name__ == "__main__":
+    if "--cyl-rollout" in sys.argv:       # ~40 minutes of float64 NumPy on 8 cores: generated separately
+        gold_cyl_rollout()
+        sys.exit(0)
     gold(32, 1, "gold_a_L32_mps1.npz", [0, 1])
     gold(128, 15, "gold_b_L128_mps15.npz", [1, 8, 15])
     gold_rollout()
