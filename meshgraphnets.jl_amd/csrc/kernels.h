@@ -97,6 +97,7 @@ struct BfEdgeArgs {
     uint16_t* CARRY;                           // row-major
     const uint16_t* chunk[3];                  // 0:W2 1:W3 2:W1e
     const float* tabs;                         // fp32 tables (same as the fp32 kernels)
+    unsigned long long* stamps;                // diagnostic builds only (MGN_DIAG_STAMPS), else null
 };
 struct BfNodeArgs {
     int32_t n, ntiles; const int32_t* rowptr;

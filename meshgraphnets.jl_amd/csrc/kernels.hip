@@ -135,6 +135,27 @@ DEVINL EdgeIdx load_edge_idx(const EdgeArgs& a, int tile, int c) {
     return ix;
 }
 
+// Branch-free form for the software-pipelined kernels: every load is unconditional (addresses clamped into the arrays), the
+// padding / boundary cases are selects on the loaded values.  With the conditional form hipcc puts `valid ? snd[eid] : 0` into an
+// EXEC-masked block together with everything that depends on it (the 64-bit row address of the later gather), and that block
+// starts with s_waitcnt vmcnt(0): the index load requested "ahead of time" is waited for on the spot, with every prefetch in
+// flight behind it.  Needs E >= 1 (a launch has at least one tile).
+DEVINL EdgeIdx load_edge_idx_nb(const int32_t* __restrict__ snd, const int32_t* __restrict__ rcv, int64_t E, int tile, int c) {
+    EdgeIdx ix;
+    const int64_t e0 = (int64_t)tile * TILE;
+    const int64_t eid = e0 + c;
+    const bool valid = eid < E;
+    const int64_t ec = valid ? eid : E - 1;
+    const int s_ = snd[ec], r_ = rcv[ec];
+    const int rb = rcv[e0 > 0 ? e0 - 1 : 0];                           // wave-uniform
+    const int ra = rcv[e0 + TILE < E ? e0 + TILE : E - 1];             // wave-uniform
+    ix.s = valid ? s_ : 0;
+    ix.r = valid ? r_ : -1;                                            // -1 marks a padding lane
+    ix.r_before = (tile > 0) ? rb : -2;
+    ix.r_after = (e0 + TILE < E) ? ra : -3;
+    return ix;
+}
+
 // Register plan (L = 128: three 64-VGPR arrays, nothing else of that size may be live, the kernel must not
 // spill: vmcnt retires in order, so a scratch reload issued behind the epilogue stores waits for all of them):
 //   layer 1   acc (init P[s]+Q[r], accumulates)   x = e tile (B operand)           y  free
@@ -1028,6 +1049,270 @@ __global__ __launch_bounds__(MGN_BF_WAVES * 64, MGN_BF_WAVES / 4) void k_edge_bf
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// bf16 processor, second generation (round 2).  What the rocprofv3 passes of the first version showed (profiles/r02/
+// pmc_summary_bench_1m_bf16.json): 1 500 VALU instructions per 32-edge tile against 96 MFMAs, waves waiting on memory for 68 % of
+// their cycles (index -> gathered P / Q rows is a serial chain per tile, nothing is requested ahead), 5.2 GB moved per launch
+// against 3.9 GB algorithmic.  Changes:
+//   * software pipeline: the operands of tile t+1 (e tile, P[s], Q[r]) are requested at the top of tile t and the indices of
+//     tile t+2 with them, so a wave never waits for an index -> gather chain (two waves per SIMD, 256 registers each);
+//   * unpack-and-accumulate in ONE instruction: v_dot2c_f32_bf16 with a (1, 0) / (0, 1) selector is float(x.lo / x.hi) + c
+//     (exact product, sum within 1 fp32 ulp of IEEE: tools/dot2_probe.hip) -- replaces shift / mask + add for P + Q and the residual;
+//   * ReLU on the PACKED row: max(x, 0) of a bf16 is a signed 16-bit integer max with 0 (v_pk_max_i16: one instruction per pair,
+//     after the conversion; commutes with the rounding, -0 -> +0);
+//   * the edge latents, touched once per step, are read and written non-temporally (they do not displace the gathered P / Q
+//     rows from L2).
+// ------------------------------------------------------------------------------------------------------------------------
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+
+struct BfSel { bf16x2 lo, hi; };
+// the selectors go through opaque registers: as compile-time constants hipcc (ROCm 7.2) folds the pair (1.0, 0.0) into the inline
+// constant `1.0`, which the instruction reads as the 32-bit pattern 0x3F800000 = the pair (0.0, 1.0) (tools/dot2_probe.hip)
+DEVINL BfSel bf_selectors() {
+    unsigned u0 = 0x00003F80u, u1 = 0x3F800000u;
+    asm volatile("" : "+s"(u0), "+s"(u1));
+    BfSel s;
+    s.lo = __builtin_bit_cast(bf16x2, u0);
+    s.hi = __builtin_bit_cast(bf16x2, u1);
+    return s;
+}
+DEVINL const u32x4* bfq_row_ptr(const uint16_t* base, int64_t row, int h) { return reinterpret_cast<const u32x4*>(base + row * 128) + h; }
+DEVINL u32x4* bfq_row_ptr(uint16_t* base, int64_t row, int h) { return reinterpret_cast<u32x4*>(base + row * 128) + h; }
+DEVINL const u32x4* bfq_tile_ptr(const uint16_t* base, int64_t tile, int lane) { return reinterpret_cast<const u32x4*>(base + tile * (TILE * 128)) + lane; }
+DEVINL u32x4* bfq_tile_ptr(uint16_t* base, int64_t tile, int lane) { return reinterpret_cast<u32x4*>(base + tile * (TILE * 128)) + lane; }
+
+template <bool NT>
+DEVINL void bfq_load(u32x4 (&x)[8], const u32x4* __restrict__ p, int stride) {
+#pragma unroll
+    for (int s = 0; s < 8; ++s) x[s] = NT ? __builtin_nontemporal_load(p + s * stride) : p[s * stride];
+}
+template <bool NT>
+DEVINL void bfq_store(u32x4* __restrict__ p, int stride, const u32x4 (&x)[8]) {
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+        if (NT) __builtin_nontemporal_store(x[s], p + s * stride);
+        else p[s * stride] = x[s];
+    }
+}
+// acc (+)= float(x): element j of piece s is register 8(s&1) + j of block s>>1
+template <bool INIT>
+DEVINL void bfq_acc_add(f32x16 (&acc)[4], const u32x4 (&x)[8], const BfSel& sel) {
+#pragma unroll
+    for (int s = 0; s < 8; ++s)
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            // through a scalar: clang's __builtin_bit_cast of a vector ELEMENT lvalue copies from the vector's base address, i.e.
+            // always element 0 (every pair came out as a copy of the first -- the "80 % off" of round 1's packed-ReLU attempts)
+            const unsigned w = x[s][d];
+            const bf16x2 v = __builtin_bit_cast(bf16x2, w);
+            const int k = 8 * (s & 1) + 2 * d;
+            acc[s >> 1][k] = __builtin_amdgcn_fdot2_f32_bf16(v, sel.lo, INIT ? 0.f : acc[s >> 1][k], false);
+            acc[s >> 1][k + 1] = __builtin_amdgcn_fdot2_f32_bf16(v, sel.hi, INIT ? 0.f : acc[s >> 1][k + 1], false);
+        }
+}
+DEVINL unsigned bf_pk2(float a, float b) {
+    bf16x2 v;
+    v[0] = (__bf16)a;
+    v[1] = (__bf16)b;
+    return __builtin_bit_cast(unsigned, v);
+}
+// accumulator -> packed row (next B operand / storage); RELU: max(., 0) on the packed pairs
+template <bool RELU>
+DEVINL void bfq_pack(u32x4 (&x)[8], const f32x16 (&acc)[4]) {
+#pragma unroll
+    for (int s = 0; s < 8; ++s)
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            unsigned w = bf_pk2(acc[s >> 1][8 * (s & 1) + 2 * d], acc[s >> 1][8 * (s & 1) + 2 * d + 1]);
+            if (RELU) asm("v_pk_max_i16 %0, %1, 0" : "=v"(w) : "v"(w));   // reads a VALU result (the conversion), never an MFMA one
+            x[s][d] = w;
+        }
+}
+DEVINL void bfq_chunk(f32x16 (&acc)[4], const u32x4 (&in)[8], const bf16x8* w, int lane) {
+#pragma unroll
+    for (int s = 0; s < 8; ++s)
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[(s * 4 + t) * 64 + lane], __builtin_bit_cast(bf16x8, in[s]), acc[t], 0, 0, 0);
+}
+
+// acc = float(x) (no accumulate): the two bf16 of a dword are the high halves of two fp32 patterns
+DEVINL void bfq_unpack(f32x16 (&acc)[4], const u32x4 (&x)[8]) {
+#pragma unroll
+    for (int s = 0; s < 8; ++s)
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            const unsigned w = x[s][d];
+            const unsigned lo = w << 16, hi = w & 0xFFFF0000u;
+            acc[s >> 1][8 * (s & 1) + 2 * d] = __builtin_bit_cast(float, lo);
+            acc[s >> 1][8 * (s & 1) + 2 * d + 1] = __builtin_bit_cast(float, hi);
+        }
+}
+
+// LayerNorm with packed fp32 arithmetic (v_pk_add / v_pk_mul / v_pk_fma_f32 on register pairs): the bf16 kernels are bound by
+// VALU issue, not by the MFMA pipe (where packing the fp32 kernel's LayerNorm cost time), so half the instructions pay.
+DEVINL void layer_norm_frag_pk(f32x16 (&x)[4], const float* gamma, const float* beta, int h) {
+    constexpr float invL = 1.0f / 128;
+    f32x2 s2 = {0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int k = 0; k < 16; k += 2) {
+            f32x2 v = {x[t][k], x[t][k + 1]};
+            s2 += v;
+        }
+    float s = s2[0] + s2[1];
+    s += __shfl_xor(s, 32, 64);
+    const float mean = s * invL;
+    const f32x2 m2 = {mean, mean};
+    f32x2 q2 = {0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int k = 0; k < 16; k += 2) {
+            f32x2 v = {x[t][k], x[t][k + 1]};
+            v -= m2;
+            q2 = __builtin_elementwise_fma(v, v, q2);
+            x[t][k] = v[0];
+            x[t][k + 1] = v[1];
+        }
+    float q = q2[0] + q2[1];
+    q += __shfl_xor(q, 32, 64);
+    const float rstd = 1.0f / sqrtf(q * invL + LN_EPS);
+    const f32x2 r2 = {rstd, rstd};
+    const f32x4* g4 = reinterpret_cast<const f32x4*>(gamma) + h;
+    const f32x4* b4 = reinterpret_cast<const f32x4*>(beta) + h;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 gv = g4[2 * (4 * t + g)];
+            const f32x4 bv = b4[2 * (4 * t + g)];
+#pragma unroll
+            for (int i = 0; i < 4; i += 2) {
+                f32x2 v = {x[t][4 * g + i], x[t][4 * g + i + 1]};
+                const f32x2 gg = {gv[i], gv[i + 1]}, bb = {bv[i], bv[i + 1]};
+                v = __builtin_elementwise_fma(v * r2, gg, bb);
+                x[t][4 * g + i] = v[0];
+                x[t][4 * g + i + 1] = v[1];
+            }
+        }
+}
+
+// Pipelined bf16 edge kernel.  Per tile t (one wave, 32 edges; `acc` enters holding P[s] + Q[r] of this tile, `x` its e tile):
+//   top     request P[s(t+1)] (gathered by sender: the long, index-dependent latency) and the indices of tile t+2
+//   middle  three MFMA chains, LayerNorm, residual store                      -> x is dead
+//           request the e tile of t+1 into x (streams from HBM) and Q[r(t+1)] (receiver-sorted edges share it: mostly hits)
+//   bottom  segmented scan, aggregate stores, then acc = float(P[s(t+1)]) + Q[r(t+1)] for the next tile
+// so no request is waited for where it is issued.  Register budget at two waves per SIMD (256): acc 64 + x 32 + in 32 + p 32
+// + q 32 = 192 plus addresses and tables; a full (x, p, q) double buffer (224) spilled freshly loaded rows, each spill behind
+// an s_waitcnt vmcnt(0).
+__global__ __launch_bounds__(512, 2) void k_edge_bf16_pipe(const BfEdgeArgs a) {
+    constexpr int L = 128;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    uint16_t* wl = reinterpret_cast<uint16_t*>(smem);
+#pragma unroll
+    for (int r = 0; r < 3; ++r) copy_to_lds16(wl + r * BF_CH, a.chunk[r], BF_CH, a.ntiles <= 16 * 1024);
+    float* tb = smem + 3 * BF_CH / 2;
+    copy_to_lds(tb, a.tabs, T_COUNT * L);
+    __syncthreads();
+    const bf16x8* w2 = reinterpret_cast<const bf16x8*>(wl);
+    const bf16x8* w3 = reinterpret_cast<const bf16x8*>(wl + BF_CH);
+    const bf16x8* w1 = reinterpret_cast<const bf16x8*>(wl + 2 * BF_CH);
+    const int lane0 = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    TileWalk tw(a.ntiles, wave);
+    if (tw.tile >= tw.end) return;
+    const BfSel sel = bf_selectors();
+    const int last = tw.tile + ((tw.end - 1 - tw.tile) / tw.stride) * tw.stride;   // this wave's last tile
+    // (a request past the wave's last tile harmlessly repeats the last one: no divergent control flow around the loads)
+    auto clampt = [&](int t) { return a.tile0 + (t <= last ? t : last); };
+    // pipeline prologue: operands of the first tile, indices of the second
+    EdgeIdx ix = load_edge_idx_nb(a.snd, a.rcv, a.E, clampt(tw.tile), lane0 & 31);
+    EdgeIdx ixn = load_edge_idx_nb(a.snd, a.rcv, a.E, clampt(tw.tile + tw.stride), lane0 & 31);
+    u32x4 x[8];
+    f32x16 acc[4];
+    {
+        u32x4 p0[8], q0[8];
+        bfq_load<true>(x, bfq_tile_ptr(a.Elat, clampt(tw.tile), lane0), BF_STRIDE_TILE);
+        bfq_load<false>(p0, bfq_row_ptr(a.P, ix.s, lane0 >> 5), BF_STRIDE_ROW);
+        bfq_load<false>(q0, bfq_row_ptr(a.Q, ix.r >= 0 ? ix.r : 0, lane0 >> 5), BF_STRIDE_ROW);
+        bfq_unpack(acc, p0);
+        bfq_acc_add<false>(acc, q0, sel);
+    }
+    int stamp_tile = 0;
+    (void)stamp_tile;
+    for (int t = tw.tile;; t += tw.stride, ++stamp_tile) {
+        OPAQUE_LANE();
+        STAMP(0);
+        const int tile = a.tile0 + t;
+        const bool valid = ix.r >= 0;
+        const int r = valid ? ix.r : 0;
+        u32x4 in[8], pn[8], qn[8];
+        bfq_load<false>(pn, bfq_row_ptr(a.P, ixn.s, h), BF_STRIDE_ROW);
+        const EdgeIdx ixnn = load_edge_idx_nb(a.snd, a.rcv, a.E, clampt(t + 2 * tw.stride), c);
+        PHASE_FENCE();
+        STAMP(1);
+        bfq_chunk(acc, x, w1, lane);                              // layer 1 (edge part; P, Q, b1 are in acc)
+        STAMP(2);
+        bfq_pack<true>(in, acc);
+        PHASE_FENCE();      // the bias table must not be read into 64 NEW registers while the old accumulator is still being packed
+        tab_frag<4>(acc, tb + T_B2 * L, h);
+        bfq_chunk(acc, in, w2, lane);                             // layer 2
+        STAMP(3);
+        bfq_pack<true>(in, acc);
+        PHASE_FENCE();
+        tab_frag<4>(acc, tb + T_B3 * L, h);
+        bfq_chunk(acc, in, w3, lane);                             // layer 3
+        STAMP(4);
+        layer_norm_frag_pk(acc, tb + T_GAMMA * L, tb + T_BETA * L, h);   // acc = e' (fp32)
+        // residual in fp32 (x + e', one rounding to bf16), stored non-temporally
+#pragma unroll
+        for (int s = 0; s < 8; ++s)
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                const unsigned w = x[s][d];
+                const bf16x2 v = __builtin_bit_cast(bf16x2, w);
+                const int k = 8 * (s & 1) + 2 * d;
+                in[s][d] = bf_pk2(__builtin_amdgcn_fdot2_f32_bf16(v, sel.lo, acc[s >> 1][k], false),
+                                  __builtin_amdgcn_fdot2_f32_bf16(v, sel.hi, acc[s >> 1][k + 1], false));
+            }
+        if (valid) bfq_store<true>(bfq_tile_ptr(a.Elat, tile, lane), BF_STRIDE_TILE, in);
+        PHASE_FENCE();
+        STAMP(5);
+        bfq_load<true>(x, bfq_tile_ptr(a.Elat, clampt(t + tw.stride), lane), BF_STRIDE_TILE);      // next tile's e rows
+        bfq_load<false>(qn, bfq_row_ptr(a.Q, ixn.r >= 0 ? ixn.r : 0, h), BF_STRIDE_ROW);           // next tile's Q rows
+        // segmented sum of e' (fp32) over runs of equal receiver
+        const int reff = valid ? r : (-4 - c);
+        const int rprev = __shfl_up(reff, 1, 32);
+        const int rnext = __shfl_down(reff, 1, 32);
+        const bool head = (c == 0) || (reff != rprev);
+        const unsigned hm = (unsigned)__ballot(head);
+        const int start = 31 - __clz((int)(hm & (0xFFFFFFFFu >> (31 - c))));
+        const int st_in = max(start, c & 16);
+        const bool c1 = (c - 1 >= st_in), c2 = (c - 2 >= st_in), c4 = (c - 4 >= st_in), c8 = (c - 8 >= st_in);
+        const bool cxr = (c >= 16) && (start <= 15);
+        segmented_scan<4>(acc, c1, c2, c4, c8, cxr);
+        STAMP(6);
+        const bool tail = valid && ((c == 31) || (reff != rnext));
+        const int r_first = __builtin_amdgcn_readfirstlane(reff);
+        const bool sl = (start == 0) && (ix.r_before == r_first);
+        const bool sr = (c == 31) && (ix.r_after == reff);
+        const bool to_carry = sl || sr;
+        u32x4* dst = to_carry ? bfq_row_ptr(a.CARRY, (int64_t)2 * tile + (sl ? 0 : 1), h) : bfq_tile_ptr(a.AGG, r >> 5, 32 * h + (r & 31));
+        bfq_pack<false>(in, acc);
+        if (tail) bfq_store<false>(dst, to_carry ? BF_STRIDE_ROW : BF_STRIDE_TILE, in);
+        if (t + tw.stride > last) break;
+        PHASE_FENCE();
+        STAMP(7);
+        bfq_unpack(acc, pn);                                      // next tile: acc = P[s] + Q[r]
+        bfq_acc_add<false>(acc, qn, sel);
+        ix = ixn;
+        ixn = ixnn;
+    }
+}
+
 // bf16 twin of load_aggregate; `y` is scratch (carry rows are summed in fp32 and rounded once)
 DEVINL void bf_load_aggregate(bf16x8 (&in)[8], f32x16 (&y)[4], const int32_t* __restrict__ rowptr, const uint16_t* AGG, const uint16_t* CARRY,
                               int64_t zero_row, int tile, int nn, bool valid, int lane, int h) {
@@ -1537,9 +1822,11 @@ static LaunchCfg bf_launch(int ntiles, int nchunks) {
     lc.lds = (size_t)nchunks * BF_CH * 2 + (size_t)T_COUNT * 128 * 4;
     return lc;
 }
+static int g_bf_edge = [] { const char* e = getenv("MGN_BF_EDGE"); return e ? atoi(e) : 1; }();   // 0: first-generation kernel (A/B)
 hipError_t launch_edge_bf16(const BfEdgeArgs& a, hipStream_t s) {
     if (a.ntiles <= 0) return hipSuccess;
     LaunchCfg lc = bf_launch(a.ntiles, 3);
+    if (g_bf_edge) return launch_k(k_edge_bf16_pipe, a, lc, s);   // software-pipelined: two waves per SIMD, 256 registers
     if (lc.threads == 512) lc.threads = MGN_BF_WAVES * 64;   // large launch: more waves per SIMD hide the memory phases
     return launch_k(k_edge_bf16, a, lc, s);
 }

@@ -381,6 +381,7 @@ BfEdgeArgs bf_edge_args(mgn_engine* h, int k, int q = 0) {
     a.CARRY = es.bCARRY.as<uint16_t>();
     for (int i = 0; i < 3; ++i) a.chunk[i] = WB(h, h->bsoff[k].e_ch[q][i]);
     a.tabs = W(h, h->soff[k].e_tabs[q]);
+    a.stamps = h->d_stamps.as<unsigned long long>();
     return a;
 }
 

@@ -1,0 +1,23 @@
+"""Diagnostic: per-tile phase durations of k_edge_bf16_pipe from s_memtime stamps (a library built with
+MGN_HIPCC_FLAGS=-DMGN_DIAG_STAMPS, e.g. build.build_variant("stamps", ["-DMGN_DIAG_STAMPS"]) and MGN_LIB_PATH).
+Prints cycles per phase for the waves of block 0 (s_memtime counts at 100 MHz x ... -> relative numbers matter)."""
+import ctypes as C, os, sys
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import mgn_amd, bench
+nx = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
+pos, s, r = mgn_amd.synth.mesh_1m(1234, nx, nx)
+eng = mgn_amd.Engine(9, 3, 2, 128, 2, 15, dtype="bf16")
+eng.set_params(bench.glorot_params()); eng.set_graph(s, r, pos.shape[0]); eng.latents_randn(1)
+eng.processor_steps_dev(2)
+out = np.zeros(4 * 8 * 24 * 8, np.uint64)
+f = eng.lib.mgn_debug_edge_stamps; f.restype = C.c_int; f.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
+assert f(eng.h, 1, out.ctypes.data_as(C.c_void_p)) == 0
+st = out.reshape(4, 8, 24, 8).astype(np.int64)
+names = ["top: issue P,idx", "L1 (waits x)", "pack+L2", "pack+L3", "LN+resid+store", "issue x,q + scan", "pack+tailstore", "unpack (waits P,Q)"]
+for b in range(1):
+    ext = np.concatenate([st[b, :, 2:20, :8], st[b, :, 3:21, 0:1]], axis=-1)
+    d = np.diff(ext, axis=-1)   # [wave][tile][phase]
+    print("mean s_memtime ticks per phase (tiles 2..19), rows = waves:")
+    for w in range(8):
+        print("  wave", w, {n: int(d[w, :, i].mean()) for i, n in enumerate(names)}, "tile period", int(np.diff(st[b, w, 2:20, 0]).mean()))
