@@ -47,7 +47,9 @@ typedef struct mgn_config {
     int32_t Fe;            /* edge input width  (2-D mesh: 3 = rel pos 2 + norm)                  */
     int32_t O;             /* output width      (cylinder_flow: 2)                                */
     int32_t L;             /* latent width `layer_size`; HIP path supports 32, 64, 128            */
-    int32_t hidden_layers; /* hidden layers per MLP; HIP path supports 2 (3 Dense), the default   */
+    int32_t hidden_layers; /* hidden layers per MLP (h + 1 Dense): 1 .. 4.  2 (the example's value) runs the tuned kernel */
+                           /* families; other counts run the general instantiations (forward path only: mgn_step / */
+                           /* mgn_ode_vjp and MGN_BF16 are specialised for 2 and refuse others)                    */
     int32_t mps;           /* message passing steps                                               */
     int32_t dtype;         /* mgn_dtype: MGN_F32, or MGN_BF16 (L = 128: bf16 storage + bf16 MFMA in the processor, */
                            /* fp32 accumulate / LayerNorm / residual / aggregation; encoder, decoder in fp32)      */

@@ -36,11 +36,16 @@ struct DevBuf {
     template <typename T> T* as() const { return reinterpret_cast<T*>(p); }
 };
 
-// offsets (in floats) of one MLP inside the packed parameter vector
+// offsets (in floats) of one MLP inside the packed parameter vector: nl = hidden_layers + 1 Dense layers
+constexpr int MAX_DENSE = 5;        // hidden_layers <= 4
 struct MlpOff {
-    size_t W[3], b[3], gamma = 0, beta = 0;
-    int in = 0, out = 0;
+    size_t W[MAX_DENSE], b[MAX_DENSE], gamma = 0, beta = 0;
+    int in = 0, out = 0, nl = 3;
     bool ln = false;
+};
+// offsets (floats, into wfrag) of the Dense layers after the first one of an MLP, for the GEN kernels (kernels.h GenMlp)
+struct GenOff {
+    size_t ch[4] = {0, 0, 0, 0}, tabs = 0;
 };
 
 enum Family { F_EDGE = 0, F_NODE, F_ENC, F_DEC, F_HALO, F_EDGE_BND, F_NFAM };   // F_EDGE_BND: boundary tiles of a split edge step
@@ -55,6 +60,7 @@ struct ProfRec {
 namespace mgn { struct TrainState; }
 using mgn::DevBuf;
 using mgn::MlpOff;
+using mgn::GenOff;
 using mgn::ProfRec;
 using mgn::LocalGraph;
 using mgn::MAX_EDGE_SETS;
@@ -79,10 +85,11 @@ struct mgn_engine {
     // offsets into wfrag (floats).  e_ch / e_tabs: edge MLP of each set; n_ch: node MLP (0:W2 1:W3 2:W1v 3:W1a 6:W1a of
     // set 1) and the projection onto the NEXT step's set-0 edge MLP (4:WP 5:WQ, bias in n_tabs[T_BQ]); p1_ch / p1_tabs:
     // the same projection for set 1
-    struct StepOff { size_t e_ch[MAX_EDGE_SETS][3], e_tabs[MAX_EDGE_SETS], n_ch[7], n_tabs, p1_ch[2], p1_tabs; };
+    struct StepOff { size_t e_ch[MAX_EDGE_SETS][3], e_tabs[MAX_EDGE_SETS], n_ch[7], n_tabs, p1_ch[2], p1_tabs; GenOff e_gen[MAX_EDGE_SETS], n_gen; };
     std::vector<StepOff> soff;
     size_t en_ch[4] = {0, 0, 0, 0}, en_tabs = 0, en_w1f = 0;
     size_t de_ch[2] = {0, 0}, de_tabs = 0, de_w3f = 0, de_b3 = 0;
+    GenOff en_gen, de_gen;
 
     // norms (device): node scale/shift [Fn], edge [Fe], out [O]; null = identity
     DevBuf norms;
@@ -100,6 +107,7 @@ struct mgn_engine {
         MlpOff enc;
         std::vector<MlpOff> pe;
         size_t ee_ch[2] = {0, 0}, ee_tabs = 0, ee_w1f = 0;
+        GenOff ee_gen;
         int32_t ntiles_e = 0;
         bool have_ef = false;
         DevBuf d_snd, d_rcv, d_rowptr, d_edge_gid, d_ef;

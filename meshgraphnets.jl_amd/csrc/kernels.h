@@ -12,6 +12,18 @@ constexpr int MAX_CHUNKS = 7;   // weight chunks (L x L, fragment order) a fused
 // Table slots (each L floats, fragment order) inside a kernel's `tabs` block.
 enum { T_B1 = 0, T_B2, T_B3, T_GAMMA, T_BETA, T_BQ, T_COUNT };
 
+// General hidden-layer count (reference Args.hidden_layers, src/MeshGraphNets.jl:35-38; MGN-spec: h hidden layers = h + 1 Dense).
+// The Dense layers AFTER the first one of an MLP: chunk[0 .. nmid-1] = the L x L middle layers (each followed by ReLU),
+// chunk[nmid] = the last layer (absent for the decoder, whose last layer is L -> O on the VALU); tabs = their bias tables, L floats
+// each, fragment order.  hidden_layers = 2 is nmid = 1.  Used by the GEN instantiations of the kernels (weights streamed from L2);
+// the tuned kernel families are specialised for nmid = 1.
+struct GenMlp {
+    const float* chunk[4];
+    const float* tabs;
+    int32_t nmid;
+    int32_t use;            // 1: launch the GEN instantiation
+};
+
 struct EdgeArgs {
     const int32_t* snd;     // [E] local sender index (may point into halo rows of P)
     const int32_t* rcv;     // [E] local receiver index, non-decreasing
@@ -28,6 +40,7 @@ struct EdgeArgs {
     int32_t stagger;        // s_sleep(127) units by which waves 4..7 of a block start late
     int32_t tile0;          // the launch covers edge tiles [tile0, tile0 + ntiles) (interior / boundary split)
     unsigned long long* stamps;  // diagnostic builds only (MGN_DIAG_STAMPS), else null
+    GenMlp gen;
 };
 
 struct NodeArgs {
@@ -48,6 +61,7 @@ struct NodeArgs {
     int32_t stagger;
     int64_t zero_row;       // CARRY row that is all zeros (read for receivers without incoming edges)
     int32_t tile0;          // k_project only: first tile of the range [tile0, tile0 + ntiles)
+    GenMlp gen;
 };
 
 struct EncNodeArgs {
@@ -61,6 +75,7 @@ struct EncNodeArgs {
     float* V; float* P; float* Q;
     const float* chunk[MAX_CHUNKS];  // 0:W2 1:W3 2:WP 3:WQ
     const float* tabs;
+    GenMlp gen;
 };
 
 struct EncEdgeArgs {
@@ -72,6 +87,7 @@ struct EncEdgeArgs {
     float* Elat;
     const float* chunk[MAX_CHUNKS];  // 0:W2 1:W3
     const float* tabs;
+    GenMlp gen;
 };
 
 struct DecArgs {
@@ -86,6 +102,7 @@ struct DecArgs {
     float* out;             // [n][O] local order
     const float* chunk[MAX_CHUNKS];  // 0:W1 1:W2
     const float* tabs;      // b1,b2
+    GenMlp gen;             // decoder: chunk[0 .. nmid-1] = W2 .. W_h, no last chunk (L -> O runs on the VALU)
 };
 
 // ---- bf16 processor (BASELINE cfg-3 precision): bf16 storage + bf16 MFMA, fp32 accumulate / LayerNorm / residual /
@@ -130,7 +147,8 @@ hipError_t launch_errnorm(const float* u, const float* unew, const LinComb& lc, 
 
 // L in {32,64,128}.  All return hipError_t of the launch.
 bool launch_is_small(int ntiles);   // the launch wrappers' rule for the cooperative node kernels (<= 8 tiles per CU)
-int set_kernel_path(int p);   // debug/tests: 0 auto, 1 resident, 2 streaming, 3 cooperative; returns the old value
+int set_kernel_path(int p);   // debug/tests: 0 auto, 1 resident, 2 streaming, 3 cooperative, 4 GEN (general hidden_layers) kernels; returns the old value
+int get_kernel_path();
 hipError_t launch_edge_step(int L, const EdgeArgs& a, hipStream_t s);
 hipError_t launch_node_step(int L, const NodeArgs& a, hipStream_t s);
 hipError_t launch_project(int L, const NodeArgs& a, hipStream_t s);   // mode-2 work with both chunks LDS-resident

@@ -114,6 +114,33 @@ DEVINL void segmented_scan(f32x16 (&acc)[NG], bool c1, bool c2, bool c4, bool c8
 #endif
 }
 
+// ------------------------------------------------------------------------------------------------
+// General hidden-layer count (GenMlp, kernels.h).  acc enters with the pre-activation of the MLP's first layer.
+//   gen_hidden: ReLU, then every middle layer (Dense + ReLU): acc leaves as the last hidden activation
+//   gen_final : acc <- b + W acc for the last Dense (no activation)
+// Weights stream from L2 (mfma_chunk<NT, false>); one register copy per layer (64 moves against 16 NT^2 MFMAs).
+// ------------------------------------------------------------------------------------------------
+template <int NT>
+DEVINL void gen_hidden(f32x16 (&acc)[NT], f32x16 (&y)[NT], const GenMlp& g, int lane, int h) {
+    constexpr int L = 32 * NT;
+    relu_frag<NT>(acc);
+    for (int m = 0; m < g.nmid; ++m) {
+        tab_frag<NT>(y, g.tabs + m * L, h);
+        mfma_chunk<NT, false>(y, acc, g.chunk[m], lane);
+        relu_frag<NT>(y);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] = y[t];
+    }
+}
+template <int NT>
+DEVINL void gen_final(f32x16 (&acc)[NT], f32x16 (&y)[NT], const GenMlp& g, int lane, int h) {
+    constexpr int L = 32 * NT;
+    tab_frag<NT>(y, g.tabs + g.nmid * L, h);
+    mfma_chunk<NT, false>(y, acc, g.chunk[g.nmid], lane);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = y[t];
+}
+
 // ================================================================================================
 // Processor edge step (K3+K4+K5): gather, edge MLP, LayerNorm, residual, segmented scatter.
 // chunk[0]=W2 chunk[1]=W3 chunk[2]=W1[2L:3L];  NRES leading chunks are LDS-resident.
@@ -171,7 +198,7 @@ DEVINL EdgeIdx load_edge_idx_nb(const int32_t* __restrict__ snd, const int32_t* 
 #ifndef MGN_EDGE_JR
 #define MGN_EDGE_JR 28
 #endif
-template <int NT, int NRES>
+template <int NT, int NRES, bool GEN = false>
 __global__ __launch_bounds__(512, 2) void k_edge_step(const EdgeArgs a) {
     constexpr int L = 32 * NT, CH = 16 * NT * 64 * NT;
     constexpr int JR = (NRES == 2 && NT == 4) ? MGN_EDGE_JR : 0;   // partial residency of chunk 2
@@ -225,13 +252,18 @@ __global__ __launch_bounds__(512, 2) void k_edge_step(const EdgeArgs a) {
         else
             mfma_chunk_split<NT, JR>(acc, x, smem + NRES * CH, a.chunk[2], lane);
         STAMP(2);
-        relu_frag<NT>(acc);
-        tab_frag<NT>(y, tb + T_B2 * L, h);
-        mfma_chunk<NT, (NRES > 0)>(y, acc, w2, lane);          // layer 2
-        STAMP(3);
-        relu_frag<NT>(y);
-        tab_frag<NT>(acc, tb + T_B3 * L, h);
-        mfma_chunk<NT, (NRES > 1)>(acc, y, w3, lane);          // layer 3
+        if constexpr (GEN) {                                    // hidden_layers != 2: h - 1 middle layers, then the last one
+            gen_hidden<NT>(acc, y, a.gen, lane, h);
+            gen_final<NT>(acc, y, a.gen, lane, h);
+        } else {
+            relu_frag<NT>(acc);
+            tab_frag<NT>(y, tb + T_B2 * L, h);
+            mfma_chunk<NT, (NRES > 0)>(y, acc, w2, lane);          // layer 2
+            STAMP(3);
+            relu_frag<NT>(y);
+            tab_frag<NT>(acc, tb + T_B3 * L, h);
+            mfma_chunk<NT, (NRES > 1)>(acc, y, w3, lane);          // layer 3
+        }
         STAMP(4);
         PHASE_FENCE();
         __builtin_amdgcn_s_setprio(MGN_PRIO);                   // memory/VALU phase: win issue arbitration
@@ -300,7 +332,7 @@ __global__ __launch_bounds__(512, 2) void k_edge_step(const EdgeArgs a) {
     } while (0)
 
 // NAGG = 2: a second edge set's aggregate (AGG2 / CARRY2 / rowptr2) is a further layer-1 input, chunk[6] streamed.
-template <int NT, int NRES, bool PROJECT, int NAGG = 1>
+template <int NT, int NRES, bool PROJECT, int NAGG = 1, bool GEN = false>
 __global__ __launch_bounds__(512, 2) void k_node_step(const NodeArgs a) {
     constexpr int L = 32 * NT, CH = 16 * NT * 64 * NT;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -346,12 +378,17 @@ __global__ __launch_bounds__(512, 2) void k_node_step(const NodeArgs a) {
                 LOAD_AGGREGATE(NT, y, a.rowptr2, a.AGG2, a.CARRY2, a.zero_row2);
                 mfma_chunk<NT, false>(acc, y, a.chunk[6], lane);   // layer 1, second edge set's aggregate
             }
-            relu_frag<NT>(acc);
-            tab_frag<NT>(y, tb + T_B2 * L, h);
-            mfma_chunk<NT, (NRES > 0)>(y, acc, w2, lane);      // layer 2
-            relu_frag<NT>(y);
-            tab_frag<NT>(acc, tb + T_B3 * L, h);
-            mfma_chunk<NT, (NRES > 1)>(acc, y, w3, lane);      // layer 3
+            if constexpr (GEN) {
+                gen_hidden<NT>(acc, y, a.gen, lane, h);
+                gen_final<NT>(acc, y, a.gen, lane, h);
+            } else {
+                relu_frag<NT>(acc);
+                tab_frag<NT>(y, tb + T_B2 * L, h);
+                mfma_chunk<NT, (NRES > 0)>(y, acc, w2, lane);      // layer 2
+                relu_frag<NT>(y);
+                tab_frag<NT>(acc, tb + T_B3 * L, h);
+                mfma_chunk<NT, (NRES > 1)>(acc, y, w3, lane);      // layer 3
+            }
 #ifdef MGN_PRIO_NODE
             __builtin_amdgcn_s_setprio(MGN_PRIO_NODE);
 #endif
@@ -606,7 +643,7 @@ DEVINL void first_layer(f32x16 (&acc)[NT], const float* w1f, int k, float xk, in
 // ================================================================================================
 // Encoder, node side (K0a+K1) + projection of step-0 P,Q.  chunk[0]=W2 [1]=W3 [2]=WP [3]=WQ
 // ================================================================================================
-template <int NT, int NRES>
+template <int NT, int NRES, bool GEN = false>
 __global__ __launch_bounds__(512, 2) void k_enc_node(const EncNodeArgs a) {
     constexpr int L = 32 * NT, CH = 16 * NT * 64 * NT;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -636,12 +673,17 @@ __global__ __launch_bounds__(512, 2) void k_enc_node(const EncNodeArgs a) {
             if (a.scale) xk = fmaf(xk, a.scale[k], a.shift[k]);
             first_layer<NT>(acc, a.w1f, k, xk, h);
         }
-        relu_frag<NT>(acc);
-        tab_frag<NT>(y, tb + T_B2 * L, h);
-        mfma_chunk<NT, (NRES > 0)>(y, acc, w2, lane);
-        relu_frag<NT>(y);
-        tab_frag<NT>(acc, tb + T_B3 * L, h);
-        mfma_chunk<NT, (NRES > 1)>(acc, y, w3, lane);
+        if constexpr (GEN) {
+            gen_hidden<NT>(acc, y, a.gen, lane, h);
+            gen_final<NT>(acc, y, a.gen, lane, h);
+        } else {
+            relu_frag<NT>(acc);
+            tab_frag<NT>(y, tb + T_B2 * L, h);
+            mfma_chunk<NT, (NRES > 0)>(y, acc, w2, lane);
+            relu_frag<NT>(y);
+            tab_frag<NT>(acc, tb + T_B3 * L, h);
+            mfma_chunk<NT, (NRES > 1)>(acc, y, w3, lane);
+        }
         layer_norm_frag<NT>(acc, tb + T_GAMMA * L, tb + T_BETA * L, h);
         if (!valid) zero_frag<NT>(acc);                          // padding rows stay zero (checksums)
         store_frag<NT>(tile_ptr(a.V, tw.tile, L, lane), STRIDE_TILE, acc);
@@ -828,7 +870,7 @@ __global__ __launch_bounds__(256, 2) void k_decode_coop(const DecArgs a) {
 // ================================================================================================
 // Encoder, edge side (K0b+K2).  chunk[0]=W2 [1]=W3
 // ================================================================================================
-template <int NT, int NRES>
+template <int NT, int NRES, bool GEN = false>
 __global__ __launch_bounds__(512, 2) void k_enc_edge(const EncEdgeArgs a) {
     constexpr int L = 32 * NT, CH = 16 * NT * 64 * NT;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -855,12 +897,17 @@ __global__ __launch_bounds__(512, 2) void k_enc_edge(const EncEdgeArgs a) {
             if (a.scale) xk = fmaf(xk, a.scale[k], a.shift[k]);
             first_layer<NT>(acc, a.w1f, k, xk, h);
         }
-        relu_frag<NT>(acc);
-        tab_frag<NT>(y, tb + T_B2 * L, h);
-        mfma_chunk<NT, (NRES > 0)>(y, acc, w2, lane);
-        relu_frag<NT>(y);
-        tab_frag<NT>(acc, tb + T_B3 * L, h);
-        mfma_chunk<NT, (NRES > 1)>(acc, y, w3, lane);
+        if constexpr (GEN) {
+            gen_hidden<NT>(acc, y, a.gen, lane, h);
+            gen_final<NT>(acc, y, a.gen, lane, h);
+        } else {
+            relu_frag<NT>(acc);
+            tab_frag<NT>(y, tb + T_B2 * L, h);
+            mfma_chunk<NT, (NRES > 0)>(y, acc, w2, lane);
+            relu_frag<NT>(y);
+            tab_frag<NT>(acc, tb + T_B3 * L, h);
+            mfma_chunk<NT, (NRES > 1)>(acc, y, w3, lane);
+        }
         layer_norm_frag<NT>(acc, tb + T_GAMMA * L, tb + T_BETA * L, h);
         if (!valid) zero_frag<NT>(acc);
         store_frag<NT>(tile_ptr(a.Elat, tw.tile, L, lane), STRIDE_TILE, acc);
@@ -870,7 +917,7 @@ __global__ __launch_bounds__(512, 2) void k_enc_edge(const EncEdgeArgs a) {
 // ================================================================================================
 // Decoder (K7) + inverse normaliser + val_mask epilogue (K8).  chunk[0]=W1 [1]=W2
 // ================================================================================================
-template <int NT, int NRES>
+template <int NT, int NRES, bool GEN = false>
 __global__ __launch_bounds__(512, 2) void k_decode(const DecArgs a) {
     constexpr int L = 32 * NT, CH = 16 * NT * 64 * NT;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -893,10 +940,16 @@ __global__ __launch_bounds__(512, 2) void k_decode(const DecArgs a) {
         load_frag<NT>(v, tile_ptr(a.V, tw.tile, L, lane), STRIDE_TILE);
         tab_frag<NT>(acc, tb + T_B1 * L, h);
         mfma_chunk<NT, (NRES > 0)>(acc, v, w1, lane);
-        relu_frag<NT>(acc);
-        tab_frag<NT>(v, tb + T_B2 * L, h);
-        mfma_chunk<NT, (NRES > 1)>(v, acc, w2, lane);
-        relu_frag<NT>(v);
+        if constexpr (GEN) {                                    // middle layers, then the L -> O layer below reads v
+            gen_hidden<NT>(acc, v, a.gen, lane, h);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) v[t] = acc[t];
+        } else {
+            relu_frag<NT>(acc);
+            tab_frag<NT>(v, tb + T_B2 * L, h);
+            mfma_chunk<NT, (NRES > 1)>(v, acc, w2, lane);
+            relu_frag<NT>(v);
+        }
         const float m = a.mask ? a.mask[a.gid ? a.gid[nn] : nn] : 1.0f;
         for (int o = 0; o < a.O; ++o) {
             const f32x4* w4 = reinterpret_cast<const f32x4*>(a.w3f + (int64_t)o * L) + h;
@@ -1208,6 +1261,92 @@ DEVINL void layer_norm_frag_pk(f32x16 (&x)[4], const float* gamma, const float* 
 // so no request is waited for where it is issued.  Register budget at two waves per SIMD (256): acc 64 + x 32 + in 32 + p 32
 // + q 32 = 192 plus addresses and tables; a full (x, p, q) double buffer (224) spilled freshly loaded rows, each spill behind
 // an s_waitcnt vmcnt(0).
+struct BfEdgeCtx {
+    const bf16x8 *w1, *w2, *w3;
+    const float* tb;
+    BfSel sel;
+    int lane0;
+};
+// one tile; xc: this tile's e rows (requested one tile ago), xn: the buffer the next tile's are requested into (at the TOP: a
+// full tile of lead time for the HBM stream); the caller alternates the two buffers, so nothing is copied
+DEVINL void bf_edge_tile(const BfEdgeArgs& a, const BfEdgeCtx& cx, int tile, int tile_next, int tile_next2, bool more, f32x16 (&acc)[4],
+                         EdgeIdx& ix, EdgeIdx& ixn, u32x4 (&xc)[8], u32x4 (&xn)[8], int stamp_tile, int wave) {
+    constexpr int L = 128;
+    const int lane0 = cx.lane0;
+    OPAQUE_LANE();
+    STAMP(0);
+    const bool valid = ix.r >= 0;
+    const int r = valid ? ix.r : 0;
+    u32x4 in[8], pn[8], qn[8];
+    bfq_load<false>(pn, bfq_row_ptr(a.P, ixn.s, h), BF_STRIDE_ROW);
+    bfq_load<true>(xn, bfq_tile_ptr(a.Elat, tile_next, lane), BF_STRIDE_TILE);
+    const EdgeIdx ixnn = load_edge_idx_nb(a.snd, a.rcv, a.E, tile_next2, c);
+    PHASE_FENCE();
+    STAMP(1);
+    bfq_chunk(acc, xc, cx.w1, lane);                             // layer 1 (edge part; P, Q, b1 are in acc)
+    STAMP(2);
+    bfq_pack<true>(in, acc);
+    PHASE_FENCE();      // the bias table must not be read into 64 NEW registers while the old accumulator is still being packed
+    tab_frag<4>(acc, cx.tb + T_B2 * L, h);
+    bfq_chunk(acc, in, cx.w2, lane);                             // layer 2
+    STAMP(3);
+    bfq_pack<true>(in, acc);
+    PHASE_FENCE();
+    tab_frag<4>(acc, cx.tb + T_B3 * L, h);
+    bfq_chunk(acc, in, cx.w3, lane);                             // layer 3
+    STAMP(4);
+    layer_norm_frag_pk(acc, cx.tb + T_GAMMA * L, cx.tb + T_BETA * L, h);   // acc = e' (fp32)
+    // residual in fp32 (x + e', one rounding to bf16), stored non-temporally
+#pragma unroll
+    for (int s = 0; s < 8; ++s)
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            const unsigned w = xc[s][d];
+            const bf16x2 v = __builtin_bit_cast(bf16x2, w);
+            const int k = 8 * (s & 1) + 2 * d;
+            in[s][d] = bf_pk2(__builtin_amdgcn_fdot2_f32_bf16(v, cx.sel.lo, acc[s >> 1][k], false),
+                              __builtin_amdgcn_fdot2_f32_bf16(v, cx.sel.hi, acc[s >> 1][k + 1], false));
+        }
+    if (valid) bfq_store<true>(bfq_tile_ptr(a.Elat, tile, lane), BF_STRIDE_TILE, in);
+    PHASE_FENCE();
+    STAMP(5);
+    bfq_load<false>(qn, bfq_row_ptr(a.Q, ixn.r >= 0 ? ixn.r : 0, h), BF_STRIDE_ROW);           // next tile's Q rows
+    // segmented sum of e' (fp32) over runs of equal receiver
+    const int reff = valid ? r : (-4 - c);
+    const int rprev = __shfl_up(reff, 1, 32);
+    const int rnext = __shfl_down(reff, 1, 32);
+    const bool head = (c == 0) || (reff != rprev);
+    const unsigned hm = (unsigned)__ballot(head);
+    const int start = 31 - __clz((int)(hm & (0xFFFFFFFFu >> (31 - c))));
+    const int st_in = max(start, c & 16);
+    const bool c1 = (c - 1 >= st_in), c2 = (c - 2 >= st_in), c4 = (c - 4 >= st_in), c8 = (c - 8 >= st_in);
+    const bool cxr = (c >= 16) && (start <= 15);
+    segmented_scan<4>(acc, c1, c2, c4, c8, cxr);
+    STAMP(6);
+    const bool tail = valid && ((c == 31) || (reff != rnext));
+    const int r_first = __builtin_amdgcn_readfirstlane(reff);
+    const bool sl = (start == 0) && (ix.r_before == r_first);
+    const bool sr = (c == 31) && (ix.r_after == reff);
+    const bool to_carry = sl || sr;
+    u32x4* dst = to_carry ? bfq_row_ptr(a.CARRY, (int64_t)2 * tile + (sl ? 0 : 1), h) : bfq_tile_ptr(a.AGG, r >> 5, 32 * h + (r & 31));
+    bfq_pack<false>(in, acc);
+    if (tail) bfq_store<false>(dst, to_carry ? BF_STRIDE_ROW : BF_STRIDE_TILE, in);
+    if (!more) return;
+    PHASE_FENCE();
+    STAMP(7);
+    bfq_unpack(acc, pn);                                         // next tile: acc = P[s] + Q[r]
+    bfq_acc_add<false>(acc, qn, cx.sel);
+    ix = ixn;
+    ixn = ixnn;
+}
+
+// Pipelined bf16 edge kernel.  Per tile t (one wave, 32 edges; `acc` enters holding P[s] + Q[r] of this tile, `xc` its e tile):
+//   top     request P[s(t+1)] (gathered by sender), the e tile of t+1 (streams from HBM) and the indices of tile t+2
+//   middle  three MFMA chains, LayerNorm, residual store
+//           request Q[r(t+1)] (receiver-sorted edges share it: mostly cache hits)
+//   bottom  segmented scan, aggregate stores, then acc = float(P[s(t+1)]) + Q[r(t+1)] for the next tile
+// so no request is waited for where it is issued.  Two waves per SIMD (256 registers): acc 64 + e tile x 2 (64) + in 32 + p 32
+// + q 32.
 __global__ __launch_bounds__(512, 2) void k_edge_bf16_pipe(const BfEdgeArgs a) {
     constexpr int L = 128;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -1217,99 +1356,42 @@ __global__ __launch_bounds__(512, 2) void k_edge_bf16_pipe(const BfEdgeArgs a) {
     float* tb = smem + 3 * BF_CH / 2;
     copy_to_lds(tb, a.tabs, T_COUNT * L);
     __syncthreads();
-    const bf16x8* w2 = reinterpret_cast<const bf16x8*>(wl);
-    const bf16x8* w3 = reinterpret_cast<const bf16x8*>(wl + BF_CH);
-    const bf16x8* w1 = reinterpret_cast<const bf16x8*>(wl + 2 * BF_CH);
+    BfEdgeCtx cx;
+    cx.w2 = reinterpret_cast<const bf16x8*>(wl);
+    cx.w3 = reinterpret_cast<const bf16x8*>(wl + BF_CH);
+    cx.w1 = reinterpret_cast<const bf16x8*>(wl + 2 * BF_CH);
+    cx.tb = tb;
     const int lane0 = threadIdx.x & 63;
+    cx.lane0 = lane0;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     TileWalk tw(a.ntiles, wave);
     if (tw.tile >= tw.end) return;
-    const BfSel sel = bf_selectors();
+    cx.sel = bf_selectors();
     const int last = tw.tile + ((tw.end - 1 - tw.tile) / tw.stride) * tw.stride;   // this wave's last tile
     // (a request past the wave's last tile harmlessly repeats the last one: no divergent control flow around the loads)
     auto clampt = [&](int t) { return a.tile0 + (t <= last ? t : last); };
     // pipeline prologue: operands of the first tile, indices of the second
     EdgeIdx ix = load_edge_idx_nb(a.snd, a.rcv, a.E, clampt(tw.tile), lane0 & 31);
     EdgeIdx ixn = load_edge_idx_nb(a.snd, a.rcv, a.E, clampt(tw.tile + tw.stride), lane0 & 31);
-    u32x4 x[8];
+    u32x4 xa[8], xb[8];
     f32x16 acc[4];
     {
         u32x4 p0[8], q0[8];
-        bfq_load<true>(x, bfq_tile_ptr(a.Elat, clampt(tw.tile), lane0), BF_STRIDE_TILE);
+        bfq_load<true>(xa, bfq_tile_ptr(a.Elat, clampt(tw.tile), lane0), BF_STRIDE_TILE);
         bfq_load<false>(p0, bfq_row_ptr(a.P, ix.s, lane0 >> 5), BF_STRIDE_ROW);
         bfq_load<false>(q0, bfq_row_ptr(a.Q, ix.r >= 0 ? ix.r : 0, lane0 >> 5), BF_STRIDE_ROW);
         bfq_unpack(acc, p0);
-        bfq_acc_add<false>(acc, q0, sel);
+        bfq_acc_add<false>(acc, q0, cx.sel);
     }
     int stamp_tile = 0;
-    (void)stamp_tile;
-    for (int t = tw.tile;; t += tw.stride, ++stamp_tile) {
-        OPAQUE_LANE();
-        STAMP(0);
-        const int tile = a.tile0 + t;
-        const bool valid = ix.r >= 0;
-        const int r = valid ? ix.r : 0;
-        u32x4 in[8], pn[8], qn[8];
-        bfq_load<false>(pn, bfq_row_ptr(a.P, ixn.s, h), BF_STRIDE_ROW);
-        const EdgeIdx ixnn = load_edge_idx_nb(a.snd, a.rcv, a.E, clampt(t + 2 * tw.stride), c);
-        PHASE_FENCE();
-        STAMP(1);
-        bfq_chunk(acc, x, w1, lane);                              // layer 1 (edge part; P, Q, b1 are in acc)
-        STAMP(2);
-        bfq_pack<true>(in, acc);
-        PHASE_FENCE();      // the bias table must not be read into 64 NEW registers while the old accumulator is still being packed
-        tab_frag<4>(acc, tb + T_B2 * L, h);
-        bfq_chunk(acc, in, w2, lane);                             // layer 2
-        STAMP(3);
-        bfq_pack<true>(in, acc);
-        PHASE_FENCE();
-        tab_frag<4>(acc, tb + T_B3 * L, h);
-        bfq_chunk(acc, in, w3, lane);                             // layer 3
-        STAMP(4);
-        layer_norm_frag_pk(acc, tb + T_GAMMA * L, tb + T_BETA * L, h);   // acc = e' (fp32)
-        // residual in fp32 (x + e', one rounding to bf16), stored non-temporally
-#pragma unroll
-        for (int s = 0; s < 8; ++s)
-#pragma unroll
-            for (int d = 0; d < 4; ++d) {
-                const unsigned w = x[s][d];
-                const bf16x2 v = __builtin_bit_cast(bf16x2, w);
-                const int k = 8 * (s & 1) + 2 * d;
-                in[s][d] = bf_pk2(__builtin_amdgcn_fdot2_f32_bf16(v, sel.lo, acc[s >> 1][k], false),
-                                  __builtin_amdgcn_fdot2_f32_bf16(v, sel.hi, acc[s >> 1][k + 1], false));
-            }
-        if (valid) bfq_store<true>(bfq_tile_ptr(a.Elat, tile, lane), BF_STRIDE_TILE, in);
-        PHASE_FENCE();
-        STAMP(5);
-        bfq_load<true>(x, bfq_tile_ptr(a.Elat, clampt(t + tw.stride), lane), BF_STRIDE_TILE);      // next tile's e rows
-        bfq_load<false>(qn, bfq_row_ptr(a.Q, ixn.r >= 0 ? ixn.r : 0, h), BF_STRIDE_ROW);           // next tile's Q rows
-        // segmented sum of e' (fp32) over runs of equal receiver
-        const int reff = valid ? r : (-4 - c);
-        const int rprev = __shfl_up(reff, 1, 32);
-        const int rnext = __shfl_down(reff, 1, 32);
-        const bool head = (c == 0) || (reff != rprev);
-        const unsigned hm = (unsigned)__ballot(head);
-        const int start = 31 - __clz((int)(hm & (0xFFFFFFFFu >> (31 - c))));
-        const int st_in = max(start, c & 16);
-        const bool c1 = (c - 1 >= st_in), c2 = (c - 2 >= st_in), c4 = (c - 4 >= st_in), c8 = (c - 8 >= st_in);
-        const bool cxr = (c >= 16) && (start <= 15);
-        segmented_scan<4>(acc, c1, c2, c4, c8, cxr);
-        STAMP(6);
-        const bool tail = valid && ((c == 31) || (reff != rnext));
-        const int r_first = __builtin_amdgcn_readfirstlane(reff);
-        const bool sl = (start == 0) && (ix.r_before == r_first);
-        const bool sr = (c == 31) && (ix.r_after == reff);
-        const bool to_carry = sl || sr;
-        u32x4* dst = to_carry ? bfq_row_ptr(a.CARRY, (int64_t)2 * tile + (sl ? 0 : 1), h) : bfq_tile_ptr(a.AGG, r >> 5, 32 * h + (r & 31));
-        bfq_pack<false>(in, acc);
-        if (tail) bfq_store<false>(dst, to_carry ? BF_STRIDE_ROW : BF_STRIDE_TILE, in);
-        if (t + tw.stride > last) break;
-        PHASE_FENCE();
-        STAMP(7);
-        bfq_unpack(acc, pn);                                      // next tile: acc = P[s] + Q[r]
-        bfq_acc_add<false>(acc, qn, sel);
-        ix = ixn;
-        ixn = ixnn;
+    for (int t = tw.tile;; t += 2 * tw.stride, stamp_tile += 2) {
+        const bool more1 = t + tw.stride <= last;
+        bf_edge_tile(a, cx, a.tile0 + t, clampt(t + tw.stride), clampt(t + 2 * tw.stride), more1, acc, ix, ixn, xa, xb, stamp_tile, wave);
+        if (!more1) break;
+        const bool more2 = t + 2 * tw.stride <= last;
+        bf_edge_tile(a, cx, a.tile0 + t + tw.stride, clampt(t + 2 * tw.stride), clampt(t + 3 * tw.stride), more2, acc, ix, ixn, xb, xa,
+                     stamp_tile + 1, wave);
+        if (!more2) break;
     }
 }
 
@@ -1630,6 +1712,7 @@ static int resident_chunks(int L, int want) {
 // (tests exercise every path on small graphs through mgn_debug_kernel_path)
 static int g_path = [] { const char* e = getenv("MGN_KERNEL_PATH"); return e ? atoi(e) : 0; }();   // experiments
 int set_kernel_path(int p) { const int old = g_path; g_path = p; return old; }
+int get_kernel_path() { return g_path; }
 static bool small_launch(int ntiles) { return g_path == 0 ? ntiles <= 4 * num_cus() : g_path >= 2; }
 // cooperative (4 waves per tile) kernels: up to this many tiles per CU for the edge / node kernels (size sweep)
 static int g_tail_coop = [] { const char* e = getenv("MGN_TAIL_COOP"); return e ? atoi(e) : 1; }();   // 0: whole launch persistent
@@ -1691,6 +1774,22 @@ static hipError_t launch_k(K kern, const A& a, const LaunchCfg& lc, hipStream_t 
 
 hipError_t launch_project(int L, const NodeArgs& a, hipStream_t s);
 
+// hidden_layers != 2 (GenMlp): the GEN instantiations, every weight chunk streamed from L2, tables only in LDS
+static LaunchCfg gen_launch(int L, int ntiles) {
+    LaunchCfg lc = tile_launch(L, ntiles, 0);
+    lc.lds = (size_t)T_COUNT * L * 4 + 64;
+    return lc;
+}
+#define DISPATCH_GEN(L_, KERN4, KERN2, KERN1, ARGS, NTILES)                          \
+    do {                                                                             \
+        if ((NTILES) <= 0) return hipSuccess;                                        \
+        const LaunchCfg lg = gen_launch(L_, NTILES);                                 \
+        if ((L_) == 128) return launch_k(KERN4, ARGS, lg, s);                        \
+        if ((L_) == 64) return launch_k(KERN2, ARGS, lg, s);                         \
+        if ((L_) == 32) return launch_k(KERN1, ARGS, lg, s);                         \
+        return hipErrorInvalidValue;                                                 \
+    } while (0)
+
 // pinned weight rings (coop_chain_primed<true>) while a launch has at most MGN_COOP_FENCE_TILES_PER_CU (default 4) tiles per CU
 static bool coop_fence(int ntiles) {
     static const int per_cu = [] { const char* e = getenv("MGN_COOP_FENCE_TILES_PER_CU"); return e ? atoi(e) : 4; }();
@@ -1703,6 +1802,7 @@ static bool coop_ok(int L, int ntiles, const float* const* chunk_t, bool edge = 
 
 hipError_t launch_edge_step(int L, const EdgeArgs& a, hipStream_t s) {
     if (a.ntiles <= 0) return hipSuccess;
+    if (a.gen.use) DISPATCH_GEN(L, (k_edge_step<4, 0, true>), (k_edge_step<2, 0, true>), (k_edge_step<1, 0, true>), a, a.ntiles);
     const int nres = resident_chunks(L, 3);
     LaunchCfg lc = tile_launch(L, a.ntiles, nres);
     if (coop_ok(L, a.ntiles, a.chunk_t, true)) {   // small graph: 4 waves per tile
@@ -1740,6 +1840,15 @@ hipError_t launch_edge_step(int L, const EdgeArgs& a, hipStream_t s) {
 }
 hipError_t launch_node_step(int L, const NodeArgs& a, hipStream_t s) {
     if (a.ntiles <= 0) return hipSuccess;
+    if (a.gen.use) {
+        if (a.mode == 2) return launch_project(L, a, s);
+        if (a.AGG2) {
+            if (a.mode == 1) return hipErrorInvalidValue;      // two edge sets: the host projects per set
+            DISPATCH_GEN(L, (k_node_step<4, 0, false, 2, true>), (k_node_step<2, 0, false, 2, true>), (k_node_step<1, 0, false, 2, true>), a, a.ntiles);
+        }
+        if (a.mode == 1) DISPATCH_GEN(L, (k_node_step<4, 0, true, 1, true>), (k_node_step<2, 0, true, 1, true>), (k_node_step<1, 0, true, 1, true>), a, a.ntiles);
+        DISPATCH_GEN(L, (k_node_step<4, 0, false, 1, true>), (k_node_step<2, 0, false, 1, true>), (k_node_step<1, 0, false, 1, true>), a, a.ntiles);
+    }
     if (coop_ok(L, a.ntiles, a.chunk_t)) {
         LaunchCfg c4{a.ntiles, 256, coop_lds()};
         if (coop_fence(a.ntiles)) return a.AGG2 ? launch_k(k_node_coop<true, true>, a, c4, s) : launch_k(k_node_coop<false, true>, a, c4, s);
@@ -1778,7 +1887,7 @@ hipError_t launch_node_step(int L, const NodeArgs& a, hipStream_t s) {
 hipError_t launch_project(int L, const NodeArgs& a, hipStream_t s) {
     if (a.ntiles <= 0) return hipSuccess;
     LaunchCfg lc = tile_launch(L, a.ntiles, 2);
-    if (a.tile0 == 0 && a.mode == 2 && coop_ok(L, a.ntiles, a.chunk_t)) {
+    if (!a.gen.use && a.tile0 == 0 && a.mode == 2 && coop_ok(L, a.ntiles, a.chunk_t)) {
         LaunchCfg c4{a.ntiles, 256, coop_lds()};
         if (coop_fence(a.ntiles)) return a.AGG2 ? launch_k(k_node_coop<true, true>, a, c4, s) : launch_k(k_node_coop<false, true>, a, c4, s);
         return a.AGG2 ? launch_k(k_node_coop<true, false>, a, c4, s) : launch_k(k_node_coop<false, false>, a, c4, s);
@@ -1796,6 +1905,7 @@ hipError_t launch_project(int L, const NodeArgs& a, hipStream_t s) {
     return hipErrorInvalidValue;
 }
 hipError_t launch_enc_node(int L, const EncNodeArgs& a, hipStream_t s) {
+    if (a.gen.use) DISPATCH_GEN(L, (k_enc_node<4, 0, true>), (k_enc_node<2, 0, true>), (k_enc_node<1, 0, true>), a, a.ntiles);
     if (a.ntiles > 0 && L == 128 && coop_size(a.ntiles, false)) {
         LaunchCfg c4{a.ntiles, 256, coop_lds()};
         return coop_fence(a.ntiles) ? launch_k(k_enc_node_coop<true>, a, c4, s) : launch_k(k_enc_node_coop<false>, a, c4, s);
@@ -1803,6 +1913,7 @@ hipError_t launch_enc_node(int L, const EncNodeArgs& a, hipStream_t s) {
     DISPATCH_L(k_enc_node, 4, a, a.ntiles);
 }
 hipError_t launch_enc_edge(int L, const EncEdgeArgs& a, hipStream_t s) {
+    if (a.gen.use) DISPATCH_GEN(L, (k_enc_edge<4, 0, true>), (k_enc_edge<2, 0, true>), (k_enc_edge<1, 0, true>), a, a.ntiles);
     if (a.ntiles > 0 && L == 128 && coop_size(a.ntiles, true)) {
         LaunchCfg c4{a.ntiles, 256, coop_lds()};
         return coop_fence(a.ntiles) ? launch_k(k_enc_edge_coop<true>, a, c4, s) : launch_k(k_enc_edge_coop<false>, a, c4, s);
@@ -1810,6 +1921,7 @@ hipError_t launch_enc_edge(int L, const EncEdgeArgs& a, hipStream_t s) {
     DISPATCH_L(k_enc_edge, 2, a, a.ntiles);
 }
 hipError_t launch_decode(int L, const DecArgs& a, hipStream_t s) {
+    if (a.gen.use) DISPATCH_GEN(L, (k_decode<4, 0, true>), (k_decode<2, 0, true>), (k_decode<1, 0, true>), a, a.ntiles);
     if (a.ntiles > 0 && L == 128 && coop_size(a.ntiles, false)) {
         LaunchCfg c4{a.ntiles, 256, coop_lds()};
         return coop_fence(a.ntiles) ? launch_k(k_decode_coop<true>, a, c4, s) : launch_k(k_decode_coop<false>, a, c4, s);

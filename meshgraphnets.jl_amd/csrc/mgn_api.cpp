@@ -44,22 +44,28 @@ bool cfg_ok(const mgn_config* c, std::string& why) {
     if (!c) { why = "null config"; return false; }
     if (c->Fn < 1 || c->Fe < 1 || c->O < 1) { why = "Fn, Fe, O must be >= 1"; return false; }
     if (c->L != 32 && c->L != 64 && c->L != 128) { why = "L must be 32, 64 or 128 on the HIP path"; return false; }
-    if (c->hidden_layers != 2) { why = "hidden_layers must be 2 on the HIP path"; return false; }
+    if (c->hidden_layers < 1 || c->hidden_layers > 4) { why = "hidden_layers must be 1 .. 4 on the HIP path"; return false; }
     if (c->mps < 1) { why = "mps must be >= 1"; return false; }
     if (c->dtype != MGN_F32 && c->dtype != MGN_BF16) { why = "dtype must be MGN_F32 or MGN_BF16"; return false; }
-    if (c->dtype == MGN_BF16 && c->L != 128) { why = "MGN_BF16 is implemented for L = 128"; return false; }
+    if (c->dtype == MGN_BF16 && (c->L != 128 || c->hidden_layers != 2)) { why = "MGN_BF16 is implemented for L = 128, hidden_layers = 2"; return false; }
     if (c->nranks < 1 || c->rank < 0 || c->rank >= c->nranks) { why = "bad rank/nranks"; return false; }
     if (c->n_edge_sets < 0 || c->n_edge_sets > MAX_EDGE_SETS) { why = "n_edge_sets must be 0, 1 or 2"; return false; }
     if (c->n_edge_sets == 2 && c->Fe2 < 1) { why = "Fe2 must be >= 1 with two edge sets"; return false; }
     return true;
 }
 
-size_t mlp_layout(MlpOff& m, size_t off, int in, int L, int out, bool ln) {
-    const int dims[4] = {in, L, L, out};
+// MGN-spec MLP: Dense(in -> L) . ReLU -> [Dense(L -> L) . ReLU] x (hidden_layers - 1) -> Dense(L -> out) [+ LayerNorm]
+size_t mlp_layout(MlpOff& m, size_t off, int in, int L, int out, bool ln, int hidden_layers) {
+    int dims[MAX_DENSE + 1];
+    const int nl = hidden_layers + 1;
+    dims[0] = in;
+    for (int i = 1; i < nl; ++i) dims[i] = L;
+    dims[nl] = out;
     m.in = in;
     m.out = out;
     m.ln = ln;
-    for (int i = 0; i < 3; ++i) {
+    m.nl = nl;
+    for (int i = 0; i < nl; ++i) {
         m.W[i] = off;
         off += (size_t)dims[i] * dims[i + 1];
         m.b[i] = off;
@@ -77,21 +83,21 @@ size_t mlp_layout(MlpOff& m, size_t off, int in, int L, int out, bool ln) {
 size_t layout_all(mgn_engine* h) {
     const mgn_config& c = h->cfg;
     size_t off = 0;
-    off = mlp_layout(h->enc_node, off, c.Fn, c.L, c.L, true);
+    off = mlp_layout(h->enc_node, off, c.Fn, c.L, c.L, true, c.hidden_layers);
     // MGN-spec order: encoder-node, encoder-edge per set, (edge MLP per set, node MLP) x mps, decoder
     h->nsets = c.n_edge_sets == 2 ? 2 : 1;
     h->es[0].Fe = c.Fe;
     h->es[1].Fe = c.Fe2;
     for (int q = 0; q < h->nsets; ++q) {
-        off = mlp_layout(h->es[q].enc, off, h->es[q].Fe, c.L, c.L, true);
+        off = mlp_layout(h->es[q].enc, off, h->es[q].Fe, c.L, c.L, true, c.hidden_layers);
         h->es[q].pe.resize(c.mps);
     }
     h->pn.resize(c.mps);
     for (int k = 0; k < c.mps; ++k) {
-        for (int q = 0; q < h->nsets; ++q) off = mlp_layout(h->es[q].pe[k], off, 3 * c.L, c.L, c.L, true);
-        off = mlp_layout(h->pn[k], off, (1 + h->nsets) * c.L, c.L, c.L, true);
+        for (int q = 0; q < h->nsets; ++q) off = mlp_layout(h->es[q].pe[k], off, 3 * c.L, c.L, c.L, true, c.hidden_layers);
+        off = mlp_layout(h->pn[k], off, (1 + h->nsets) * c.L, c.L, c.L, true, c.hidden_layers);
     }
-    off = mlp_layout(h->dec, off, c.L, c.L, c.O, false);
+    off = mlp_layout(h->dec, off, c.L, c.L, c.O, false, c.hidden_layers);
     return off;
 }
 
@@ -296,6 +302,17 @@ void invalidate_static(mgn_engine* h) {
     h->rhs_warm = false;
 }
 
+// GenMlp of an MLP: used when hidden_layers != 2 (or when tests force the GEN kernels, kernel path 4)
+GenMlp gen_of(const mgn_engine* h, const GenOff& g, bool has_last) {
+    GenMlp m{};
+    const int nmid = h->cfg.hidden_layers - 1;
+    for (int i = 0; i < nmid + (has_last ? 1 : 0); ++i) m.chunk[i] = W(h, g.ch[i]);
+    m.tabs = W(h, g.tabs);
+    m.nmid = nmid;
+    m.use = (h->cfg.hidden_layers != 2 || get_kernel_path() == 4) ? 1 : 0;
+    return m;
+}
+
 EdgeArgs edge_args(mgn_engine* h, int k, int q = 0) {
     EdgeArgs a{};
     auto& es = h->es[q];
@@ -313,6 +330,7 @@ EdgeArgs edge_args(mgn_engine* h, int k, int q = 0) {
         a.chunk_t[i] = a.chunk[i] + (size_t)h->cfg.L * h->cfg.L;
     }
     a.tabs = W(h, h->soff[k].e_tabs[q]);
+    a.gen = gen_of(h, h->soff[k].e_gen[q], true);
     a.stagger = h->stagger_edge;
     a.tile0 = 0;
     a.stamps = h->d_stamps.as<unsigned long long>();
@@ -359,6 +377,7 @@ NodeArgs node_args(mgn_engine* h, int k, int mode, int q = 0) {
         a.chunk_t[6] = a.chunk[6] + CH;
     }
     a.mode = mode;
+    a.gen = gen_of(h, so.n_gen, true);
     a.stagger = h->stagger_node;
     a.zero_row = 2 * tiles_or_one(h->es[0].ntiles_e);
     a.tile0 = 0;
@@ -496,7 +515,7 @@ int mgn_synchronize(mgn_handle* h) try {
 
 size_t mgn_param_count(const mgn_config* c) try {
     std::string why;
-    if (!c || c->Fn < 1 || c->Fe < 1 || c->O < 1 || c->L < 1 || c->hidden_layers != 2 || c->mps < 1) return 0;
+    if (!c || c->Fn < 1 || c->Fe < 1 || c->O < 1 || c->L < 1 || c->hidden_layers < 1 || c->hidden_layers > 4 || c->mps < 1) return 0;
     mgn_engine tmp;
     tmp.cfg = *c;
     return layout_all(&tmp);
@@ -540,22 +559,39 @@ int mgn_set_params(mgn_handle* h, const float* packed, size_t n) try {
 
     const int S = h->nsets;
     const MlpOff& e0 = h->es[0].pe[0];
+    const int nl = c.hidden_layers + 1, nmid = nl - 2;      // Dense layers per MLP; L x L middle layers
+    const bool h2 = c.hidden_layers == 2;                   // the tuned kernel families are specialised for this
+    // the Dense layers after the first one of MLP m (GenOff): middle layers W[1 .. nmid], then the last one when it is L x L
+    // (has_last: every MLP but the decoder), and their biases as tables.  Returns through g; ch[0] / ch[nmid] double as the
+    // classic "W2" / "W3" slots of the tuned kernels at hidden_layers = 2.
+    auto add_gen = [&](const MlpOff& m, bool has_last, GenOff& g) {
+        for (int i = 0; i < nmid; ++i) g.ch[i] = add_chunk(p + m.W[1 + i], L, 0);
+        if (has_last) g.ch[nmid] = add_chunk(p + m.W[nl - 1], L, 0);
+        g.tabs = f.size();
+        f.resize(f.size() + (size_t)(nmid + 1) * L);
+        for (int i = 0; i < nmid; ++i) pack_tab(f.data() + g.tabs + (size_t)i * L, p + m.b[1 + i], L);
+        pack_tab(f.data() + g.tabs + (size_t)nmid * L, has_last ? p + m.b[nl - 1] : nullptr, L);
+    };
+    auto b2 = [&](const MlpOff& m) { return h2 ? p + m.b[1] : nullptr; };
+    auto b3 = [&](const MlpOff& m) { return h2 ? p + m.b[2] : nullptr; };
     // encoder, node side (+ projection onto step-0 edge-MLP layer 1 of set 0)
     {
         const MlpOff& m = h->enc_node;
-        h->en_ch[0] = add_chunk(p + m.W[1], L, 0);
-        h->en_ch[1] = add_chunk(p + m.W[2], L, 0);
+        add_gen(m, true, h->en_gen);
+        h->en_ch[0] = h->en_gen.ch[0];
+        h->en_ch[1] = h->en_gen.ch[nmid];
         h->en_ch[2] = add_chunk(p + e0.W[0], L, 0);
         h->en_ch[3] = add_chunk(p + e0.W[0], L, L);
-        h->en_tabs = add_tabs(p + m.b[0], p + m.b[1], p + m.b[2], p + m.gamma, p + m.beta, p + e0.b[0]);
+        h->en_tabs = add_tabs(p + m.b[0], b2(m), b3(m), p + m.gamma, p + m.beta, p + e0.b[0]);
         h->en_w1f = add_w1f(p + m.W[0], c.Fn);
     }
     for (int q = 0; q < S; ++q) {
         auto& es = h->es[q];
         const MlpOff& m = es.enc;
-        es.ee_ch[0] = add_chunk(p + m.W[1], L, 0);
-        es.ee_ch[1] = add_chunk(p + m.W[2], L, 0);
-        es.ee_tabs = add_tabs(p + m.b[0], p + m.b[1], p + m.b[2], p + m.gamma, p + m.beta, nullptr);
+        add_gen(m, true, es.ee_gen);
+        es.ee_ch[0] = es.ee_gen.ch[0];
+        es.ee_ch[1] = es.ee_gen.ch[nmid];
+        es.ee_tabs = add_tabs(p + m.b[0], b2(m), b3(m), p + m.gamma, p + m.beta, nullptr);
         es.ee_w1f = add_w1f(p + m.W[0], es.Fe);
     }
     h->soff.assign(c.mps, {});
@@ -565,19 +601,21 @@ int mgn_set_params(mgn_handle* h, const float* packed, size_t n) try {
         auto& so = h->soff[k];
         for (int q = 0; q < S; ++q) {
             const MlpOff& me = h->es[q].pe[k];
-            so.e_ch[q][0] = add_chunk(p + me.W[1], L, 0);
-            so.e_ch[q][1] = add_chunk(p + me.W[2], L, 0);
+            add_gen(me, true, so.e_gen[q]);
+            so.e_ch[q][0] = so.e_gen[q].ch[0];
+            so.e_ch[q][1] = so.e_gen[q].ch[nmid];
             so.e_ch[q][2] = add_chunk(p + me.W[0], L, 2 * L);
-            so.e_tabs[q] = add_tabs(nullptr, p + me.b[1], p + me.b[2], p + me.gamma, p + me.beta, nullptr);
+            so.e_tabs[q] = add_tabs(nullptr, b2(me), b3(me), p + me.gamma, p + me.beta, nullptr);
         }
         const MlpOff& nx = h->es[0].pe[kn];
-        so.n_ch[0] = add_chunk(p + mn.W[1], L, 0);
-        so.n_ch[1] = add_chunk(p + mn.W[2], L, 0);
+        add_gen(mn, true, so.n_gen);
+        so.n_ch[0] = so.n_gen.ch[0];
+        so.n_ch[1] = so.n_gen.ch[nmid];
         so.n_ch[2] = add_chunk(p + mn.W[0], L, 0);
         so.n_ch[3] = add_chunk(p + mn.W[0], L, L);
         so.n_ch[4] = add_chunk(p + nx.W[0], L, 0);
         so.n_ch[5] = add_chunk(p + nx.W[0], L, L);
-        so.n_tabs = add_tabs(p + mn.b[0], p + mn.b[1], p + mn.b[2], p + mn.gamma, p + mn.beta, p + nx.b[0]);
+        so.n_tabs = add_tabs(p + mn.b[0], b2(mn), b3(mn), p + mn.gamma, p + mn.beta, p + nx.b[0]);
         if (S > 1) {
             const MlpOff& nx1 = h->es[1].pe[kn];
             so.n_ch[6] = add_chunk(p + mn.W[0], L, 2 * L);
@@ -589,13 +627,14 @@ int mgn_set_params(mgn_handle* h, const float* packed, size_t n) try {
     {
         const MlpOff& m = h->dec;
         h->de_ch[0] = add_chunk(p + m.W[0], L, 0);
-        h->de_ch[1] = add_chunk(p + m.W[1], L, 0);
-        h->de_tabs = add_tabs(p + m.b[0], p + m.b[1], nullptr, nullptr, nullptr, nullptr);
+        add_gen(m, false, h->de_gen);                                  // middle layers only: the last one (L -> O) runs on the VALU
+        h->de_ch[1] = nmid > 0 ? h->de_gen.ch[0] : h->de_ch[0];
+        h->de_tabs = add_tabs(p + m.b[0], b2(m), nullptr, nullptr, nullptr, nullptr);
         h->de_w3f = f.size();
         f.resize(f.size() + (size_t)c.O * L);
-        for (int o = 0; o < c.O; ++o) pack_tab(f.data() + h->de_w3f + (size_t)o * L, p + m.W[2] + o, L, c.O);
+        for (int o = 0; o < c.O; ++o) pack_tab(f.data() + h->de_w3f + (size_t)o * L, p + m.W[nl - 1] + o, L, c.O);
         h->de_b3 = f.size();
-        for (int o = 0; o < c.O; ++o) f.push_back(p[m.b[2] + o]);
+        for (int o = 0; o < c.O; ++o) f.push_back(p[m.b[nl - 1] + o]);
         while (f.size() % 4) f.push_back(0.f);
     }
     // "project only" (mgn_proc_begin) needs step 0's own first layer in the projection slots of some NodeArgs: add a
@@ -961,6 +1000,7 @@ static int encode_impl(mgn_handle* h, bool use_norms, bool nodes = true, bool ed
         a.Q = h->es[0].Q.as<float>();
         for (int i = 0; i < 4; ++i) a.chunk[i] = W(h, h->en_ch[i]);
         a.tabs = W(h, h->en_tabs);
+        a.gen = gen_of(h, h->en_gen, true);
         HIPCHK(h, launch_enc_node(c.L, a, h->stream));
         if (is_bf16(h)) {   // fp32 encoder output -> bf16 state; P,Q of step 0 from the bf16 latents
             HIPCHK(h, launch_tile_f32_to_bf16(h->V.as<float>(), h->bV.as<uint16_t>(), h->ntiles_n, h->stream));
@@ -983,6 +1023,7 @@ static int encode_impl(mgn_handle* h, bool use_norms, bool nodes = true, bool ed
             b.Elat = es.Elat.as<float>();
             for (int i = 0; i < 2; ++i) b.chunk[i] = W(h, es.ee_ch[i]);
             b.tabs = W(h, es.ee_tabs);
+            b.gen = gen_of(h, es.ee_gen, true);
             HIPCHK(h, launch_enc_edge(c.L, b, h->stream));
             if (is_bf16(h)) HIPCHK(h, launch_tile_f32_to_bf16(es.Elat.as<float>(), es.bElat.as<uint16_t>(), es.ntiles_e, h->stream));
         }
@@ -1124,6 +1165,7 @@ static int decode_impl(mgn_handle* h, bool use_norms) {
     a.out = h->out_override ? h->out_override : h->d_out.as<float>();
     for (int i = 0; i < 2; ++i) a.chunk[i] = W(h, h->de_ch[i]);
     a.tabs = W(h, h->de_tabs);
+    a.gen = gen_of(h, h->de_gen, false);
     HIPCHK(h, launch_decode(c.L, a, h->stream));
     return MGN_OK;
 }

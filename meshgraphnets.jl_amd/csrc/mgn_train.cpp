@@ -271,6 +271,9 @@ int train_prepare(mgn_handle* h, const char* who, size_t n_grads) {
     if (c.nranks != 1) return fail(h, MGN_E_STATE, "%s drives one partition", who);
     if (h->nsets != 1) return fail(h, MGN_E_STATE, "%s mirrors the reference's single-edge-set model (src/strategies.jl:418-422)", who);
     if (c.dtype != MGN_F32) return fail(h, MGN_E_STATE, "%s computes in fp32: create the handle with dtype MGN_F32", who);
+    if (c.hidden_layers != 2)
+        return fail(h, MGN_E_UNSUPPORTED, "%s is implemented for hidden_layers = 2 (the reference's default, examples/cylinder_flow/cylinder_flow.jl:17); "
+                                          "the forward path supports 1 .. 4", who);
     if (n_grads != h->params.size()) return fail(h, MGN_E_ARG, "%s: grads has %zu floats, model has %zu", who, n_grads, h->params.size());
     if (!h->train) h->train = new (std::nothrow) TrainState();
     if (!h->train) return fail(h, MGN_E_OOM, "host allocation failed");

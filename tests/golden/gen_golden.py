@@ -165,6 +165,27 @@ def gold_cyl_rollout(tsit5=True):
     np.savez_compressed(os.path.join(HERE, "gold_e_cyl_rollout.npz"), **d)
 
 
+def gold_hidden_layers():
+    """GOLD-F: `hidden_layers` other than the example's 2 (reference Args.hidden_layers, src/MeshGraphNets.jl:35-38): h = 1 and h = 3
+    on the GOLD-A mesh, L = 32, two processor steps; outputs and the node latents after the last step."""
+    pos, cells, s, r = mesh()
+    N, E = pos.shape[0], s.size
+    rng = np.random.default_rng(SEED + 7)
+    nf = rng.standard_normal((N, 9)).astype(np.float32)
+    ef = rng.standard_normal((E, 3)).astype(np.float32)
+    d = dict(L=32, mps=2, seed=SEED + 7, jitter=0.1, senders=s, receivers=r, nf=nf, ef=ef)
+    for hl in (1, 3):
+        cfg = dict(Fn=9, Fe=3, O=2, L=32, hidden_layers=hl, mps=2)
+        ps = orc.init_params(9, 3, 2, 32, hl, 2, seed=SEED + 7 + hl, ln_jitter=0.1)
+        out, lat = orc.forward(ps, cfg, nf, ef, s, r, return_latents=True)
+        d[f"h{hl}_params_sha256"] = sha(ps)
+        d[f"h{hl}_param_count"] = ps.size
+        d[f"h{hl}_out"] = out
+        d[f"h{hl}_v_after_2"] = lat[2][0].astype(np.float32)
+        print("gold_f h", hl, "params", ps.size, "out[0]", out[0])
+    np.savez_compressed(os.path.join(HERE, "gold_f_hidden_layers.npz"), **d)
+
+
 def kats():
     """Known-answer tests stored as data so every implementation reads the same file."""
     tri1 = np.array([[0, 1, 2]], np.int32)
@@ -179,6 +200,9 @@ def kats():
 
 
 if __name__ == "__main__":
+    if "--hidden-layers" in sys.argv:
+        gold_hidden_layers()
+        sys.exit(0)
     if "--cyl-rollout" in sys.argv:       # ~40 minutes of float64 NumPy on 8 cores: generated separately
         gold_cyl_rollout()
         sys.exit(0)
@@ -186,4 +210,5 @@ if __name__ == "__main__":
     gold(128, 15, "gold_b_L128_mps15.npz", [1, 8, 15])
     gold_rollout()
     gold_two_sets()
+    gold_hidden_layers()
     kats()

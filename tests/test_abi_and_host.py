@@ -37,7 +37,10 @@ def test_param_count_and_config_validation(lib_built):
         assert lib.mgn_param_count(C.byref(cfg)) == orc.param_count(Fn, Fe, O, L, 2, mps)
         cfg2 = mgn_amd._capi.MgnConfig(Fn, Fe, O, L, 2, mps, 0, 0, 1, -1, 2, 4)      # + world-edge set
         assert lib.mgn_param_count(C.byref(cfg2)) == orc.param_count(Fn, Fe, O, L, 2, mps, Fe2=4)
-    for bad in [dict(L=100), dict(hidden_layers=3), dict(mps=0), dict(Fn=0), dict(rank=2, nranks=2)]:
+    for hl in (1, 3, 4):                  # reference Args.hidden_layers is any integer (src/MeshGraphNets.jl:35-38): 1 .. 4 here
+        cfg = mgn_amd._capi.MgnConfig(9, 3, 2, 64, hl, 3, 0, 0, 1, -1)
+        assert lib.mgn_param_count(C.byref(cfg)) == orc.param_count(9, 3, 2, 64, hl, 3)
+    for bad in [dict(L=100), dict(hidden_layers=0), dict(hidden_layers=5), dict(mps=0), dict(Fn=0), dict(rank=2, nranks=2)]:
         kw = dict(Fn=9, Fe=3, O=2, L=128, hidden_layers=2, mps=2, rank=0, nranks=1, device=MGN_DEVICE_NONE)
         kw.update(bad)
         with pytest.raises(MgnError) as ei:
