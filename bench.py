@@ -456,6 +456,34 @@ def main():
                                  "nodes_per_s": Nf * MPS * k3 / dt3}
                 eng3.close()
             out["secondary"]["flag_two_edge_sets"] = flag
+            # N3: the graph prologue (create_base_graph, src/graph.jl:25-55) at the M-1M size, host loops vs device kernels
+            _, cells1m = mgn_amd.synth.grid_mesh(args.nx, args.nx, 1234)
+            engp = mgn_amd.Engine(12, 7, 3, L, 2, MPS, device=local_rank, Fe2=4)
+            t0 = time.perf_counter()
+            sh, rh = mgn_amd.triangles_to_edges_native(cells1m)
+            t_th = time.perf_counter() - t0
+            engp.triangles_to_edges_dev(cells1m[:1024])
+            t0 = time.perf_counter()
+            sd, rd = engp.triangles_to_edges_dev(cells1m)
+            t_td = time.perf_counter() - t0
+            big = np.random.default_rng(0).random((200000, 3)).astype(np.float32)
+            none = np.zeros(0, np.int32)
+            t0 = time.perf_counter()
+            swh, rwh = mgn_amd.world_edges_native(big, 0.012, none, none)
+            t_wh = time.perf_counter() - t0
+            engp.set_graph(none, none, 200000)
+            engp.world_edges_dev(1, big, 0.012)
+            t0 = time.perf_counter()
+            n_w = engp.world_edges_dev(1, big, 0.012)
+            t_wd = time.perf_counter() - t0
+            out["secondary"]["graph_prologue"] = {
+                "triangles_to_edges": {"cells": int(cells1m.shape[0]), "directed_edges": int(sd.size), "host_s": t_th, "device_s": t_td,
+                                       "identical": bool(np.array_equal(sd, sh) and np.array_equal(rd, rh)),
+                                       "note": "device: radix sort / unique of packed 64-bit keys, PCIe in and out included"},
+                "world_edges_200k_nodes": {"edges": int(n_w), "host_search_s": t_wh, "device_search_and_install_s": t_wd,
+                                           "identical_count": bool(n_w == swh.size)},
+                "set_graph_s": t_setup}
+            engp.close()
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(ps)
         print(json.dumps(out), flush=True)

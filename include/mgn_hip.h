@@ -172,6 +172,26 @@ int mgn_world_edges(const float* world_pos, int32_t dim, int32_t N, float radius
 int mgn_edge_features(const float* mesh_pos, int32_t pos_dim, const int32_t* senders, const int32_t* receivers,
                       int64_t E, int32_t index_base, float* ef);
 
+/* The same prologue ON THE DEVICE: the reference's per-edge host loops cannot build a 6 M-edge graph.
+ * Integer results are bit-identical to the host versions above (same packed (max, min) keys, stable radix sort, first-occurrence
+ * order restored by a second sort).  Pointers may be host or device memory (hipMemcpyDefault).
+ * mgn_triangles_to_edges_dev: as mgn_triangles_to_edges; `capacity` = entries of each output buffer (6 x n_cells always suffices);
+ *   MGN_E_ARG with *n_directed set when they are too small.
+ * mgn_set_static_mesh: create_base_graph's FEATURE half (src/graph.jl:26-27,35-36,49-52) into the engine's resident static inputs:
+ *   one_hot(node_type, depth = type_max - type_min + 1, offset = 1 - type_min) and edge_features = [mesh_pos[s] - mesh_pos[r]; norm]
+ *   are computed by kernels in engine order -- no [E][Fe] host array, no PCIe transfer of it -- then the edge encoder runs once, as
+ *   in mgn_set_static; afterwards mgn_ode_step(x, NULL, NULL, NULL) / the resident fast path apply.  Needs Fn - O == depth, Fe == pos_dim + 1.
+ * mgn_world_edges_dev: the world-edge set `set` (>= 1) of a cloth-like mesh searched on the device (uniform grid, radix sort by cell)
+ *   and installed WITHOUT a host round trip (what mgn_world_edges + mgn_set_edge_set do on the host; cloth rollouts re-search every
+ *   step); with Fe2 == dim + 1 its features [rel world pos; norm] are written too.  One partition.  The same edges in the same
+ *   order as mgn_world_edges (receiver-major, ascending senders).  mgn_edge_set_export hands the installed lists back (0-based). */
+int mgn_triangles_to_edges_dev(mgn_handle* h, const int32_t* cells, int64_t n_cells, int32_t* senders, int32_t* receivers, int64_t capacity,
+                               int64_t* n_directed);
+int mgn_set_static_mesh(mgn_handle* h, const int32_t* node_type /* [N] */, int32_t type_min, int32_t type_max, const float* mesh_pos /* [N][pos_dim] */,
+                        int32_t pos_dim, const float* val_mask /* [N] or NULL */);
+int mgn_world_edges_dev(mgn_handle* h, int32_t set, const float* world_pos /* [N][dim] */, int32_t dim, float radius, int64_t* n_edges);
+int mgn_edge_set_export(mgn_handle* h, int32_t set, int32_t* senders, int32_t* receivers);
+
 /* Online-normaliser accumulation as a device reduction: what GraphNetCore's NormaliserOnline adds up per call
  * (normalisers built at reference src/MeshGraphNets.jl:92,193-199, applied in build_graph src/graph.jl:75-97):
  * sum[f] = sum_r x[r][f], sum_squares[f] = sum_r x[r][f]^2 over x [rows][dim] (host or device pointer), accumulated in double

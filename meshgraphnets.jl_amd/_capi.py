@@ -72,6 +72,10 @@ PROTOTYPES = {
     "mgn_triangles_to_edges": (C.c_int, [_i32p, C.c_int64, _i32p, _i32p, _i64p]),
     "mgn_world_edges": (C.c_int, [_f32p, C.c_int32, C.c_int32, C.c_float, _i32p, _i32p, C.c_int64, C.c_int32, _i32p, _i32p, _i64p]),
     "mgn_edge_features": (C.c_int, [_f32p, C.c_int32, _i32p, _i32p, C.c_int64, C.c_int32, _f32p]),
+    "mgn_triangles_to_edges_dev": (C.c_int, [_H, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, _i64p]),
+    "mgn_set_static_mesh": (C.c_int, [_H, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]),
+    "mgn_world_edges_dev": (C.c_int, [_H, C.c_int32, C.c_void_p, C.c_int32, C.c_float, _i64p]),
+    "mgn_edge_set_export": (C.c_int, [_H, C.c_int32, _i32p, _i32p]),
     "mgn_rollout": (C.c_int, [_H, C.POINTER(MgnRolloutDesc)]),
     "mgn_step": (C.c_int, [_H, _f32p, _f32p, _f32p, _i32p, C.c_int64, C.c_int32, _f32p, C.c_size_t, _f32p]),
     "mgn_ode_vjp": (C.c_int, [_H, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, C.c_size_t]),

@@ -20,8 +20,8 @@ LIB = os.path.join(LIBDIR, "libmgn_hip.so")
 ORACLE_DIR = os.path.join(ROOT, "oracle")
 REF_LIB = os.path.join(ORACLE_DIR, "_build", "libmgn_ref.so")
 
-HIP_SOURCES = ["kernels.hip", "train.hip", "mgn_api.cpp", "mgn_train.cpp", "graph_host.cpp", "graph_prologue.cpp", "tfrecord.cpp", "comm.cpp"]
-HIP_HEADERS = ["kernels.h", "graph_host.h", "frag.hpp", "engine_internal.h", "train.h", "comm.h", os.path.join(ROOT, "include", "mgn_hip.h")]
+HIP_SOURCES = ["kernels.hip", "train.hip", "mgn_api.cpp", "mgn_train.cpp", "graph_host.cpp", "graph_prologue.cpp", "tfrecord.cpp", "comm.cpp", "graph_dev.hip"]
+HIP_HEADERS = ["kernels.h", "graph_host.h", "frag.hpp", "engine_internal.h", "train.h", "comm.h", "graph_dev.h", os.path.join(ROOT, "include", "mgn_hip.h")]
 
 
 def _newer(target, deps):

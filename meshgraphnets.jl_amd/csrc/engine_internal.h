@@ -126,6 +126,7 @@ struct mgn_engine {
     // static per-trajectory RHS inputs (mgn_set_static): cached encoded edge latents
     bool have_static = false;
     DevBuf stage;     // device staging image of caller-order latents (import / export)
+    DevBuf gwork, gout, gpos, gtype;   // device-side graph prologue (csrc/graph_dev.hip): scratch, outputs, positions, node types
     DevBuf d_stamps;  // diagnostic builds only
     DevBuf ode;       // native rollout: state, stages, frames, saves, Elat0
     const float* srcA_override = nullptr;  // rollout: encoder reads the node state from here instead of d_nfA

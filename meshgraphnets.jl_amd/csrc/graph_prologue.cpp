@@ -105,7 +105,9 @@ int mgn_world_edges(const float* world_pos, int32_t dim, int32_t N, float radius
         std::vector<int32_t> cur(mrp.begin(), mrp.end() - 1);
         for (int64_t e = 0; e < n_mesh; ++e) msnd[cur[mesh_receivers[e] - index_base]++] = mesh_senders[e] - index_base;
     }
-    const float r2 = radius * radius;
+    // distances in double: differences and products of floats are exact there, so the decision d2 < r2 does not depend on how a
+    // compiler contracts the sum (the device version, csrc/graph_dev.hip, takes the same decisions bit for bit)
+    const double r2 = (double)radius * (double)radius;
     int64_t count = 0;
     std::vector<int32_t> cand;
     for (int pass = 0; pass < ((senders && receivers) ? 2 : 1); ++pass) {
@@ -123,9 +125,9 @@ int mgn_world_edges(const float* world_pos, int32_t dim, int32_t N, float radius
                         for (int32_t p = start[q]; p < start[q + 1]; ++p) {
                             const int32_t s_ = order[p];
                             if (s_ == r_) continue;
-                            float d2 = 0.f;
+                            double d2 = 0.0;
                             for (int d = 0; d < dim; ++d) {
-                                const float dd = world_pos[(int64_t)s_ * dim + d] - world_pos[r_ * dim + d];
+                                const double dd = (double)world_pos[(int64_t)s_ * dim + d] - (double)world_pos[r_ * dim + d];
                                 d2 += dd * dd;
                             }
                             if (d2 < r2) cand.push_back(s_);

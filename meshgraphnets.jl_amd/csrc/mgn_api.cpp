@@ -14,6 +14,7 @@
 #include <vector>
 
 #include "engine_internal.h"
+#include "graph_dev.h"
 
 using namespace mgn;
 
@@ -1906,6 +1907,130 @@ int mgn_halo_unpack(mgn_handle* h, const void* recv_dev) try {
     return MGN_OK;
 } MGN_CATCH(h)
 
+
+
+// ---- device-side graph prologue (reference create_base_graph, src/graph.jl:25-55) ----------------------------
+int mgn_triangles_to_edges_dev(mgn_handle* h, const int32_t* cells, int64_t n_cells, int32_t* senders, int32_t* receivers, int64_t capacity,
+                               int64_t* n_directed) try {
+    if (int rc = need(h, false, false)) return rc;
+    if (!cells || n_cells < 0 || !n_directed || capacity < 0 || (capacity > 0 && (!senders || !receivers)))
+        return fail(h, MGN_E_ARG, "mgn_triangles_to_edges_dev: bad argument");
+    *n_directed = 0;
+    if (n_cells == 0) return MGN_OK;
+    const size_t cb = (size_t)n_cells * 3 * 4;
+    HIPCHK(h, h->gpos.ensure(cb));
+    HIPCHK(h, hipMemcpyAsync(h->gpos.p, cells, cb, hipMemcpyDefault, h->stream));      // host or device source
+    HIPCHK(h, h->gout.ensure((size_t)(capacity > 0 ? capacity : 1) * 8));
+    int32_t* ds = h->gout.as<int32_t>();
+    int32_t* dr = ds + (capacity > 0 ? capacity : 1);
+    int64_t m = 0;
+    const hipError_t e = dev_triangles_to_edges(h->gpos.as<int32_t>(), n_cells, h->gwork, ds, dr, capacity, &m, h->stream);
+    *n_directed = 2 * m;
+    if (e == hipErrorInvalidValue && 2 * m > capacity)
+        return fail(h, MGN_E_ARG, "mgn_triangles_to_edges_dev: %lld directed edges do not fit the buffers (capacity %lld; 6 x n_cells always does)",
+                    (long long)(2 * m), (long long)capacity);
+    HIPCHK(h, e);
+    HIPCHK(h, hipMemcpyAsync(senders, ds, (size_t)(2 * m) * 4, hipMemcpyDefault, h->stream));
+    HIPCHK(h, hipMemcpyAsync(receivers, dr, (size_t)(2 * m) * 4, hipMemcpyDefault, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return MGN_OK;
+} MGN_CATCH(h)
+
+int mgn_set_static_mesh(mgn_handle* h, const int32_t* node_type, int32_t type_min, int32_t type_max, const float* mesh_pos, int32_t pos_dim,
+                        const float* val_mask) try {
+    if (int rc = need(h, true, true)) return rc;
+    const mgn_config& c = h->cfg;
+    if (c.nranks != 1) return fail(h, MGN_E_STATE, "mgn_set_static_mesh drives one partition");
+    if (h->nsets != 1) return fail(h, MGN_E_STATE, "mgn_set_static_mesh mirrors the reference's single-edge-set create_base_graph (src/graph.jl:25-55)");
+    if (!node_type || !mesh_pos || type_max < type_min) return fail(h, MGN_E_ARG, "mgn_set_static_mesh: bad argument");
+    const int depth = type_max - type_min + 1;
+    if (c.Fn - c.O != depth) return fail(h, MGN_E_ARG, "mgn_set_static_mesh: Fn - O = %d but the one-hot depth is %d", c.Fn - c.O, depth);
+    if (c.Fe != pos_dim + 1) return fail(h, MGN_E_ARG, "mgn_set_static_mesh: Fe = %d but mesh_pos has %d columns (Fe = dims + 1, src/graph.jl:49-52)", c.Fe, pos_dim);
+    const LocalGraph& g = h->g;
+    invalidate_static(h);
+    h->in_wa = c.O;
+    h->in_wb = depth;
+    h->in_local = true;          // the static inputs are produced in ENGINE order (owned nodes, receiver-sorted local edges)
+    HIPCHK(h, h->d_nfA.ensure((size_t)g.N * c.O * 4));
+    HIPCHK(h, h->d_nfB.ensure((size_t)g.n_own * depth * 4));
+    HIPCHK(h, h->es[0].d_ef.ensure((size_t)(g.set[0].e_local > 0 ? g.set[0].e_local : 1) * c.Fe * 4));
+    HIPCHK(h, h->gtype.ensure((size_t)g.N * 4));
+    HIPCHK(h, h->gpos.ensure((size_t)g.N * pos_dim * 4));
+    HIPCHK(h, hipMemcpyAsync(h->gtype.p, node_type, (size_t)g.N * 4, hipMemcpyDefault, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->gpos.p, mesh_pos, (size_t)g.N * pos_dim * 4, hipMemcpyDefault, h->stream));
+    // one partition: owned nodes are numbered 0 .. N-1 in global order (no boundary block), local ids are global ids
+    HIPCHK(h, launch_one_hot(h->gtype.as<int32_t>(), nullptr, g.n_own, type_min, depth, h->d_nfB.as<float>(), h->stream));
+    HIPCHK(h, launch_edge_features_local(h->gpos.as<float>(), pos_dim, h->es[0].d_snd.as<int32_t>(), h->es[0].d_rcv.as<int32_t>(), nullptr,
+                                         g.set[0].e_local, h->es[0].d_ef.as<float>(), h->stream));
+    h->have_mask = val_mask != nullptr;
+    if (val_mask) {
+        HIPCHK(h, h->d_mask.ensure((size_t)g.N * 4));
+        HIPCHK(h, hipMemcpyAsync(h->d_mask.p, val_mask, (size_t)g.N * 4, hipMemcpyDefault, h->stream));
+    }
+    if (int rc = encode_impl(h, true, false, true)) return rc;       // edge encoder: once per trajectory
+    const bool bf = is_bf16(h);
+    const size_t eb = tile_floats(h->es[0].ntiles_e, c.L) * (bf ? 2 : 4);
+    HIPCHK(h, h->es[0].elat0.ensure(eb));
+    HIPCHK(h, hipMemcpyAsync(h->es[0].elat0.p, bf ? h->es[0].bElat.p : h->es[0].Elat.p, eb, hipMemcpyDeviceToDevice, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    h->have_static = true;
+    return MGN_OK;
+} MGN_CATCH(h)
+
+int mgn_world_edges_dev(mgn_handle* h, int32_t set, const float* world_pos, int32_t dim, float radius, int64_t* n_edges) try {
+    if (int rc = need(h, false, true)) return rc;
+    if (h->cfg.nranks != 1) return fail(h, MGN_E_STATE, "mgn_world_edges_dev drives one partition (with nranks > 1 search on the host: mgn_world_edges + mgn_set_edge_set)");
+    if (set < 1 || set >= h->nsets) return fail(h, MGN_E_ARG, "mgn_world_edges_dev: set %d out of range (handle has %d edge sets)", set, h->nsets);
+    if (!world_pos || dim < 1 || dim > 3 || !(radius > 0.f)) return fail(h, MGN_E_ARG, "mgn_world_edges_dev: bad argument");
+    LocalGraph& g = h->g;
+    auto& es = h->es[set];
+    h->hx_ready = false;
+    invalidate_static(h);
+    train_invalidate(h, 2);
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    drop_graph(h);
+    HIPCHK(h, h->gpos.ensure((size_t)g.N * dim * 4));
+    HIPCHK(h, hipMemcpyAsync(h->gpos.p, world_pos, (size_t)g.N * dim * 4, hipMemcpyDefault, h->stream));
+    int64_t E = 0;
+    const hipError_t e = dev_world_edges(h->gpos.as<float>(), dim, g.N, radius, h->es[0].d_rowptr.as<int32_t>(), h->es[0].d_snd.as<int32_t>(), h->gwork,
+                                         es.d_snd, es.d_rcv, es.d_rowptr, &E, h->stream);
+    if (e == hipErrorInvalidValue) return fail(h, MGN_E_ARG, "mgn_world_edges_dev: non-finite position");
+    HIPCHK(h, e);
+    // the set lives on the device only (receiver-major == engine order, global edge id == position): no host lists are kept
+    EdgeTopo& t = g.set[set];
+    t.E = t.e_local = E;
+    t.halo_span = 0;
+    t.snd.clear(); t.rcv.clear(); t.rowptr.clear(); t.edge_gid.clear();
+    es.gs.clear(); es.gr.clear();
+    es.ntiles_e = (int32_t)((E + TILE - 1) / TILE);
+    HIPCHK(h, es.d_edge_gid.ensure((size_t)(E > 0 ? E : 1) * 8));
+    HIPCHK(h, launch_iota64(es.d_edge_gid.as<int64_t>(), E, h->stream));
+    if (int rc = alloc_edge_set(h, set)) return rc;
+    es.have_ef = false;
+    if (es.Fe == dim + 1) {      // [rel world pos ; norm]: the world-edge features of the cloth models, straight into the encoder's input
+        HIPCHK(h, es.d_ef.ensure((size_t)(E > 0 ? E : 1) * es.Fe * 4));
+        HIPCHK(h, launch_edge_features_local(h->gpos.as<float>(), dim, es.d_snd.as<int32_t>(), es.d_rcv.as<int32_t>(), nullptr, E, es.d_ef.as<float>(), h->stream));
+        es.have_ef = true;
+    }
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (n_edges) *n_edges = E;
+    return MGN_OK;
+} MGN_CATCH(h)
+
+/* the device-built set's topology, for hosts that want it (tests): senders / receivers [E] 0-based, receiver-major */
+int mgn_edge_set_export(mgn_handle* h, int32_t set, int32_t* senders, int32_t* receivers) try {
+    if (int rc = need(h, false, true)) return rc;
+    if (set < 0 || set >= h->nsets) return fail(h, MGN_E_ARG, "mgn_edge_set_export: set %d out of range", set);
+    if (h->cfg.nranks != 1) return fail(h, MGN_E_STATE, "mgn_edge_set_export drives one partition");
+    const int64_t E = h->g.set[set].e_local;
+    if (E > 0 && (!senders || !receivers)) return fail(h, MGN_E_ARG, "mgn_edge_set_export: null output");
+    if (E > 0) {
+        HIPCHK(h, hipMemcpyAsync(senders, h->es[set].d_snd.p, (size_t)E * 4, hipMemcpyDefault, h->stream));
+        HIPCHK(h, hipMemcpyAsync(receivers, h->es[set].d_rcv.p, (size_t)E * 4, hipMemcpyDefault, h->stream));
+    }
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return MGN_OK;
+} MGN_CATCH(h)
 
 // ---- communicator entry points ---------------------------------------------------------------------------------------
 int mgn_comm_unique_id(void* id, int32_t transport) try {

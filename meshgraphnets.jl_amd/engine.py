@@ -234,6 +234,46 @@ class Engine:
         vm = _c32(val_mask, (self.N,)) if val_mask is not None else None
         self._chk(self.lib.mgn_set_static(self.h, f32(oh), f32(ef), f32(vm)))
 
+    # -- graph prologue on the device ----------------------------------------------
+    def triangles_to_edges_dev(self, cells):
+        """GraphNetCore.triangles_to_edges (reference src/graph.jl:30) on the device: (senders, receivers), two-way, first-occurrence
+        order -- the same bits as triangles_to_edges_native."""
+        cells = np.ascontiguousarray(cells, dtype=np.int32)
+        if cells.ndim != 2 or cells.shape[1] != 3:
+            raise ValueError("DimensionMismatch: cells must be [C][3]")
+        cap = 6 * cells.shape[0]
+        s, r = np.empty(max(cap, 1), np.int32), np.empty(max(cap, 1), np.int32)
+        n = C.c_int64()
+        self._chk(self.lib.mgn_triangles_to_edges_dev(self.h, cells.ctypes.data, cells.shape[0], s.ctypes.data, r.ctypes.data, cap, C.byref(n)))
+        return s[: n.value].copy(), r[: n.value].copy()
+
+    def set_static_mesh(self, node_type, type_min, type_max, mesh_pos, val_mask=None):
+        """create_base_graph's feature half on the device (one-hot node types, edge features) + the once-per-trajectory edge encoder."""
+        nt = np.ascontiguousarray(node_type, dtype=np.int32).ravel()
+        pos = _c32(mesh_pos)
+        if nt.size != self.N or pos.shape[0] != self.N:
+            raise ValueError("DimensionMismatch: node_type / mesh_pos must have N rows")
+        vm = _c32(val_mask, (self.N,)) if val_mask is not None else None
+        self._keep_static = (nt, pos, vm)
+        self._chk(self.lib.mgn_set_static_mesh(self.h, nt.ctypes.data, type_min, type_max, pos.ctypes.data, pos.shape[1],
+                                               vm.ctypes.data if vm is not None else None))
+
+    def world_edges_dev(self, set_index, world_pos, radius):
+        """Search the world-edge set on the device and install it (no host round trip).  Returns the number of edges."""
+        wp = _c32(world_pos)
+        if wp.ndim != 2 or wp.shape[0] != self.N:
+            raise ValueError("DimensionMismatch: world_pos must be [N][dim]")
+        n = C.c_int64()
+        self._chk(self.lib.mgn_world_edges_dev(self.h, set_index, wp.ctypes.data, wp.shape[1], C.c_float(radius), C.byref(n)))
+        self.E2 = int(n.value)
+        return self.E2
+
+    def edge_set_export(self, set_index):
+        E, _ = self.edge_set_info(set_index)
+        s, r = np.empty(E, np.int32), np.empty(E, np.int32)
+        self._chk(self.lib.mgn_edge_set_export(self.h, set_index, i32(s), i32(r)))
+        return s, r
+
     def ode_step(self, x, node_type_onehot=None, ef_raw=None, val_mask=None):
         O, Fn = self.cfg.O, self.cfg.Fn
         x = _c32(x, (self.N, O))
