@@ -1182,12 +1182,29 @@ DEVINL void bfq_pack(u32x4 (&x)[8], const f32x16 (&acc)[4]) {
             x[s][d] = w;
         }
 }
+// One 128 x 128 chunk from LDS.  Every MFMA (32 cycles on the matrix pipe) needs its own 1 KiB weight fragment, i.e. one
+// ds_read_b128 per 32 cycles: left to hipcc this came out as read -> s_waitcnt lgkmcnt(0..1) -> MFMA with one or two reads in
+// flight, and the chains ran at LDS LATENCY, ~3 x the pipe's pace (deleting one of the three chains of the edge kernel took a
+// third off the whole kernel: 0.92 -> 0.61 ms).  Here the fragments go through a register ring MGN_BF_RING deep, pinned by
+// scheduling fences: MGN_BF_RING reads are in flight ahead of every MFMA.
+#ifndef MGN_BF_RING
+#define MGN_BF_RING 6
+#endif
 DEVINL void bfq_chunk(f32x16 (&acc)[4], const u32x4 (&in)[8], const bf16x8* w, int lane) {
+    constexpr int D = MGN_BF_RING;
+    const bf16x8* wl = w + lane;
+    bf16x8 ring[D];
 #pragma unroll
-    for (int s = 0; s < 8; ++s)
+    for (int p = 0; p < D; ++p) ring[p] = wl[p * 64];
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int t = 0; t < 4; ++t)
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[(s * 4 + t) * 64 + lane], __builtin_bit_cast(bf16x8, in[s]), acc[t], 0, 0, 0);
+    for (int i = 0; i < 32; ++i) {
+        const bf16x8 a = ring[i % D];
+        if (i + D < 32) ring[i % D] = wl[(i + D) * 64];
+        __builtin_amdgcn_sched_barrier(0);
+        acc[i & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, __builtin_bit_cast(bf16x8, in[i >> 2]), acc[i & 3], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    }
 }
 
 // acc = float(x) (no accumulate): the two bf16 of a dword are the high halves of two fp32 patterns
@@ -1253,14 +1270,6 @@ DEVINL void layer_norm_frag_pk(f32x16 (&x)[4], const float* gamma, const float* 
         }
 }
 
-// Pipelined bf16 edge kernel.  Per tile t (one wave, 32 edges; `acc` enters holding P[s] + Q[r] of this tile, `x` its e tile):
-//   top     request P[s(t+1)] (gathered by sender: the long, index-dependent latency) and the indices of tile t+2
-//   middle  three MFMA chains, LayerNorm, residual store                      -> x is dead
-//           request the e tile of t+1 into x (streams from HBM) and Q[r(t+1)] (receiver-sorted edges share it: mostly hits)
-//   bottom  segmented scan, aggregate stores, then acc = float(P[s(t+1)]) + Q[r(t+1)] for the next tile
-// so no request is waited for where it is issued.  Register budget at two waves per SIMD (256): acc 64 + x 32 + in 32 + p 32
-// + q 32 = 192 plus addresses and tables; a full (x, p, q) double buffer (224) spilled freshly loaded rows, each spill behind
-// an s_waitcnt vmcnt(0).
 struct BfEdgeCtx {
     const bf16x8 *w1, *w2, *w3;
     const float* tb;
@@ -1278,7 +1287,11 @@ DEVINL void bf_edge_tile(const BfEdgeArgs& a, const BfEdgeCtx& cx, int tile, int
     const bool valid = ix.r >= 0;
     const int r = valid ? ix.r : 0;
     u32x4 in[8], pn[8], qn[8];
+#ifdef MGN_EXP_NOGATHER
+    bfq_load<false>(pn, bfq_row_ptr(a.P, c, h), BF_STRIDE_ROW);
+#else
     bfq_load<false>(pn, bfq_row_ptr(a.P, ixn.s, h), BF_STRIDE_ROW);
+#endif
     bfq_load<true>(xn, bfq_tile_ptr(a.Elat, tile_next, lane), BF_STRIDE_TILE);
     const EdgeIdx ixnn = load_edge_idx_nb(a.snd, a.rcv, a.E, tile_next2, c);
     PHASE_FENCE();
@@ -1288,7 +1301,9 @@ DEVINL void bf_edge_tile(const BfEdgeArgs& a, const BfEdgeCtx& cx, int tile, int
     bfq_pack<true>(in, acc);
     PHASE_FENCE();      // the bias table must not be read into 64 NEW registers while the old accumulator is still being packed
     tab_frag<4>(acc, cx.tb + T_B2 * L, h);
+#ifndef MGN_EXP_NOL2
     bfq_chunk(acc, in, cx.w2, lane);                             // layer 2
+#endif
     STAMP(3);
     bfq_pack<true>(in, acc);
     PHASE_FENCE();
@@ -1310,7 +1325,11 @@ DEVINL void bf_edge_tile(const BfEdgeArgs& a, const BfEdgeCtx& cx, int tile, int
     if (valid) bfq_store<true>(bfq_tile_ptr(a.Elat, tile, lane), BF_STRIDE_TILE, in);
     PHASE_FENCE();
     STAMP(5);
+#ifdef MGN_EXP_NOGATHER
+    bfq_load<false>(qn, bfq_row_ptr(a.Q, c, h), BF_STRIDE_ROW);
+#else
     bfq_load<false>(qn, bfq_row_ptr(a.Q, ixn.r >= 0 ? ixn.r : 0, h), BF_STRIDE_ROW);           // next tile's Q rows
+#endif
     // segmented sum of e' (fp32) over runs of equal receiver
     const int reff = valid ? r : (-4 - c);
     const int rprev = __shfl_up(reff, 1, 32);
@@ -1321,7 +1340,9 @@ DEVINL void bf_edge_tile(const BfEdgeArgs& a, const BfEdgeCtx& cx, int tile, int
     const int st_in = max(start, c & 16);
     const bool c1 = (c - 1 >= st_in), c2 = (c - 2 >= st_in), c4 = (c - 4 >= st_in), c8 = (c - 8 >= st_in);
     const bool cxr = (c >= 16) && (start <= 15);
+#ifndef MGN_EXP_NOSCAN
     segmented_scan<4>(acc, c1, c2, c4, c8, cxr);
+#endif
     STAMP(6);
     const bool tail = valid && ((c == 31) || (reff != rnext));
     const int r_first = __builtin_amdgcn_readfirstlane(reff);
@@ -1463,6 +1484,191 @@ __global__ __launch_bounds__(512, 2) void k_node_bf16(const BfNodeArgs a) {
         bf_unpack_add(acc, v);                                   // v <- v + v'  (fp32 add, one rounding)
         bf_pack(in, acc);
         if (valid) bf_store(vtile, BF_STRIDE_TILE, in);
+    }
+}
+
+// ---- second-generation bf16 node kernels: the treatment of k_edge_bf16_pipe (requests ahead of use, weight-fragment ring,
+// packed ReLU, ONE fp32 accumulator array).  V is read and written once per step -> non-temporal.
+struct BfAggReq {       // where a node's aggregate comes from (bf_load_aggregate's address logic)
+    const u32x4* src0;
+    int stride0, T1, extra;
+};
+DEVINL BfAggReq bf_agg_req(int a0, int a1, bool valid, const uint16_t* AGG, const uint16_t* CARRY, int64_t zero_row, int tile, int lane, int h) {
+    BfAggReq q;
+    q.T1 = a0 >> 5;
+    const int T2 = (a1 - 1) >> 5;
+    q.extra = (valid && a1 > a0 && T2 > q.T1) ? (T2 - q.T1) : 0;
+    const bool from_agg = valid && (a1 > a0) && !q.extra;
+    q.src0 = from_agg ? bfq_tile_ptr(AGG, tile, lane) : bfq_row_ptr(CARRY, q.extra ? (int64_t)(2 * q.T1 + 1) : zero_row, h);
+    q.stride0 = from_agg ? BF_STRIDE_TILE : BF_STRIDE_ROW;
+    return q;
+}
+// in <- the node's aggregate as a packed row: g0 = the AGG slot or the first carry row, g1 = the second carry row of a run that
+// straddles two edge tiles (one node in five on a triangle mesh; zero row otherwise), further carry rows (a receiver with more
+// than 32 incoming edges) are fetched here.  Summed in fp32, rounded once.
+DEVINL void bf_agg_sum(u32x4 (&in)[8], const u32x4 (&g0)[8], const u32x4 (&g1)[8], const BfAggReq& q, const uint16_t* CARRY, const BfSel& sel, int h) {
+    (void)sel;
+    if (!__any(q.extra > 0)) {
+#pragma unroll
+        for (int s = 0; s < 8; ++s) in[s] = g0[s];
+        return;
+    }
+    const bool more = __any(q.extra > 1);
+    // piece by piece (eight values at a time): no 64-register fp32 copy of the row is ever live beside the accumulator
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+        float t[8];
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            const unsigned w0 = g0[s][d], w1 = g1[s][d];
+            t[2 * d] = __builtin_bit_cast(float, w0 << 16) + __builtin_bit_cast(float, w1 << 16);
+            t[2 * d + 1] = __builtin_bit_cast(float, w0 & 0xFFFF0000u) + __builtin_bit_cast(float, w1 & 0xFFFF0000u);
+        }
+        if (more)
+            for (int k = 2; __any(k <= q.extra); ++k)
+                if (k <= q.extra) {
+                    const u32x4 cr = bfq_row_ptr(CARRY, (int64_t)2 * (q.T1 + k), h)[s * BF_STRIDE_ROW];
+#pragma unroll
+                    for (int d = 0; d < 4; ++d) {
+                        const unsigned w = cr[d];
+                        t[2 * d] += __builtin_bit_cast(float, w << 16);
+                        t[2 * d + 1] += __builtin_bit_cast(float, w & 0xFFFF0000u);
+                    }
+                }
+#pragma unroll
+        for (int d = 0; d < 4; ++d) in[s][d] = bf_pk2(t[2 * d], t[2 * d + 1]);
+    }
+}
+
+// node MLP: chunk[0]=W2 [1]=W3 [2]=W1v [3]=W1a, all resident (128 KiB)
+__global__ __launch_bounds__(512, 2) void k_node_bf16_pipe(const BfNodeArgs a) {
+    constexpr int L = 128;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    uint16_t* wl = reinterpret_cast<uint16_t*>(smem);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) copy_to_lds16(wl + r * BF_CH, a.chunk[r], BF_CH, a.ntiles <= 16 * 1024);
+    float* tb = smem + 4 * BF_CH / 2;
+    copy_to_lds(tb, a.tabs, T_COUNT * L);
+    __syncthreads();
+    const bf16x8* w2 = reinterpret_cast<const bf16x8*>(wl);
+    const bf16x8* w3 = reinterpret_cast<const bf16x8*>(wl + BF_CH);
+    const bf16x8* w1v = reinterpret_cast<const bf16x8*>(wl + 2 * BF_CH);
+    const bf16x8* w1a = reinterpret_cast<const bf16x8*>(wl + 3 * BF_CH);
+    const int lane0 = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    TileWalk tw(a.ntiles, wave);
+    if (tw.tile >= tw.end) return;
+    const BfSel sel = bf_selectors();
+    const int last = tw.tile + ((tw.end - 1 - tw.tile) / tw.stride) * tw.stride;
+    auto clampt = [&](int t) { return t <= last ? t : last; };
+    auto rp = [&](int t, int c, int& a0, int& a1) {          // CSR bounds of node (t, c); branch-free (clamped address)
+        const int n = t * TILE + c;
+        const int nn = n < a.n ? n : a.n - 1;
+        a0 = a.rowptr[nn];
+        a1 = a.rowptr[nn + 1];
+    };
+    u32x4 v[8];
+    bfq_load<true>(v, bfq_tile_ptr(a.V, tw.tile, lane0), BF_STRIDE_TILE);
+    int a0, a1;
+    rp(tw.tile, lane0 & 31, a0, a1);
+    for (int t = tw.tile;; t += tw.stride) {
+        OPAQUE_LANE();
+        const int n = t * TILE + c;
+        const bool valid = n < a.n;
+        // this tile's aggregate rows (the CSR bounds came a tile ahead), the next tile's CSR bounds
+        const BfAggReq q = bf_agg_req(a0, a1, valid, a.AGG, a.CARRY, a.zero_row, t, lane, h);
+        u32x4 g0[8], g1[8], in[8];
+        bfq_load<false>(g0, q.src0, q.stride0);
+        bfq_load<false>(g1, bfq_row_ptr(a.CARRY, q.extra ? (int64_t)2 * (q.T1 + 1) : a.zero_row, h), BF_STRIDE_ROW);
+        int b0, b1;
+        rp(clampt(t + tw.stride), c, b0, b1);
+        PHASE_FENCE();
+        f32x16 acc[4];
+        tab_frag<4>(acc, tb + T_B1 * L, h);
+        bfq_chunk(acc, v, w1v, lane);                            // layer 1, node part (the aggregate rows arrive meanwhile)
+        bf_agg_sum(in, g0, g1, q, a.CARRY, sel, h);
+        PHASE_FENCE();
+        bfq_chunk(acc, in, w1a, lane);                           // layer 1, aggregate part
+        if (a.AGG2) {                                            // second edge set's aggregate (its chunk streams from L2)
+            int c0, c1;
+            const int nn = valid ? n : 0;
+            c0 = a.rowptr2[nn];
+            c1 = a.rowptr2[nn + 1];
+            const BfAggReq q2 = bf_agg_req(c0, c1, valid, a.AGG2, a.CARRY2, a.zero_row2, t, lane, h);
+            bfq_load<false>(g0, q2.src0, q2.stride0);
+            bfq_load<false>(g1, bfq_row_ptr(a.CARRY2, q2.extra ? (int64_t)2 * (q2.T1 + 1) : a.zero_row2, h), BF_STRIDE_ROW);
+            bf_agg_sum(in, g0, g1, q2, a.CARRY2, sel, h);
+            const bf16x8* w6 = reinterpret_cast<const bf16x8*>(a.chunk[6]);
+#pragma unroll
+            for (int s = 0; s < 8; ++s)
+#pragma unroll
+                for (int tt = 0; tt < 4; ++tt)
+                    acc[tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w6[(s * 4 + tt) * 64 + lane], __builtin_bit_cast(bf16x8, in[s]), acc[tt], 0, 0, 0);
+        }
+        bfq_pack<true>(in, acc);
+        PHASE_FENCE();
+        tab_frag<4>(acc, tb + T_B2 * L, h);
+        bfq_chunk(acc, in, w2, lane);                            // layer 2
+        bfq_pack<true>(in, acc);
+        PHASE_FENCE();
+        tab_frag<4>(acc, tb + T_B3 * L, h);
+        bfq_chunk(acc, in, w3, lane);                            // layer 3
+        layer_norm_frag<4>(acc, tb + T_GAMMA * L, tb + T_BETA * L, h);
+        bfq_acc_add<false>(acc, v, sel);                         // v <- v + v'  (fp32 add, one rounding)
+        bfq_pack<false>(in, acc);
+        if (valid) bfq_store<true>(bfq_tile_ptr(a.V, t, lane), BF_STRIDE_TILE, in);
+        if (t + tw.stride > last) break;
+        PHASE_FENCE();
+        bfq_load<true>(v, bfq_tile_ptr(a.V, t + tw.stride, lane), BF_STRIDE_TILE);     // next tile's rows (v is dead)
+        a0 = b0;
+        a1 = b1;
+    }
+}
+
+// P,Q projection, pipelined: chunk[4]=WP chunk[5]=WQ resident; the next tile's V rows are requested before this tile's chains
+__global__ __launch_bounds__(512, 2) void k_project_bf16_pipe(const BfNodeArgs a) {
+    constexpr int L = 128;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    uint16_t* wl = reinterpret_cast<uint16_t*>(smem);
+    copy_to_lds16(wl, a.chunk[4], BF_CH, a.ntiles <= 16 * 1024);
+    copy_to_lds16(wl + BF_CH, a.chunk[5], BF_CH, a.ntiles <= 16 * 1024);
+    float* tb = smem + 2 * BF_CH / 2;
+    copy_to_lds(tb, a.tabs, T_COUNT * L);
+    __syncthreads();
+    const bf16x8* wp = reinterpret_cast<const bf16x8*>(wl);
+    const bf16x8* wq = reinterpret_cast<const bf16x8*>(wl + BF_CH);
+    const int lane0 = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    TileWalk tw(a.ntiles, wave);
+    if (tw.tile >= tw.end) return;
+    const int last = tw.tile + ((tw.end - 1 - tw.tile) / tw.stride) * tw.stride;
+    u32x4 va[8], vb[8];
+    bfq_load<false>(va, bfq_tile_ptr(a.V, a.tile0 + tw.tile, lane0), BF_STRIDE_TILE);
+    auto body = [&](int t, u32x4 (&v)[8], u32x4 (&vn)[8]) {
+        OPAQUE_LANE();
+        const int tile = a.tile0 + t;
+        const int n = tile * TILE + c;
+        const bool valid = n < a.n;
+        const int nn = valid ? n : 0;
+        bfq_load<false>(vn, bfq_tile_ptr(a.V, a.tile0 + (t + tw.stride <= last ? t + tw.stride : last), lane), BF_STRIDE_TILE);
+        PHASE_FENCE();
+        u32x4 out[8];
+        f32x16 acc[4];
+        zero_frag<4>(acc);
+        bfq_chunk(acc, v, wp, lane);
+        bfq_pack<false>(out, acc);
+        if (valid) bfq_store<false>(bfq_row_ptr(a.P, nn, h), BF_STRIDE_ROW, out);
+        PHASE_FENCE();
+        tab_frag<4>(acc, tb + T_BQ * L, h);
+        bfq_chunk(acc, v, wq, lane);
+        bfq_pack<false>(out, acc);
+        if (valid) bfq_store<false>(bfq_row_ptr(a.Q, nn, h), BF_STRIDE_ROW, out);
+    };
+    for (int t = tw.tile;; t += 2 * tw.stride) {
+        body(t, va, vb);
+        if (t + tw.stride > last) break;
+        body(t + tw.stride, vb, va);
+        if (t + 2 * tw.stride > last) break;
     }
 }
 
@@ -1942,13 +2148,14 @@ hipError_t launch_edge_bf16(const BfEdgeArgs& a, hipStream_t s) {
     if (lc.threads == 512) lc.threads = MGN_BF_WAVES * 64;   // large launch: more waves per SIMD hide the memory phases
     return launch_k(k_edge_bf16, a, lc, s);
 }
+static int g_bf_node = [] { const char* e = getenv("MGN_BF_NODE"); return e ? atoi(e) : 1; }();   // 0: first-generation node kernels (A/B)
 hipError_t launch_node_bf16(const BfNodeArgs& a, hipStream_t s) {
     if (a.ntiles <= 0) return hipSuccess;
-    return launch_k(k_node_bf16, a, bf_launch(a.ntiles, 4), s);
+    return g_bf_node ? launch_k(k_node_bf16_pipe, a, bf_launch(a.ntiles, 4), s) : launch_k(k_node_bf16, a, bf_launch(a.ntiles, 4), s);
 }
 hipError_t launch_project_bf16(const BfNodeArgs& a, hipStream_t s) {
     if (a.ntiles <= 0) return hipSuccess;
-    return launch_k(k_project_bf16, a, bf_launch(a.ntiles, 2), s);
+    return g_bf_node ? launch_k(k_project_bf16_pipe, a, bf_launch(a.ntiles, 2), s) : launch_k(k_project_bf16, a, bf_launch(a.ntiles, 2), s);
 }
 hipError_t launch_tile_f32_to_bf16(const float* src, uint16_t* dst, int64_t ntiles, hipStream_t s) {
     const int64_t n = ntiles * 512;
