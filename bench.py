@@ -153,21 +153,37 @@ def time_single(eng, steps, warmup, sync):
 
 def comm_bootstrap(eng, rank, world):
     """One communicator id for all ranks of the job: rank 0 makes it (mgn_comm_unique_id), the launcher's rendezvous store
-    (torch.distributed env:// -- plumbing only) hands it to the others; without a store, a file on this node."""
+    (torch.distributed env:// -- plumbing only) hands it to the others; without a store, a file on this node.  Should RCCL fail to
+    initialise on ANY rank, all ranks agree (through the store) to fall back to the library's shared-memory transport, so that the
+    run still measures the in-library schedule; the JSON line names the transport that was used."""
     try:
         from torch.distributed import rendezvous
         store, _, _ = next(rendezvous("env://", rank, world))
-        if rank == 0:
-            store.set("mgn_comm_id", eng.comm_unique_id("rccl"))
-        eng.comm_init(bytes(store.get("mgn_comm_id")), "rccl")
-        return store
     except Exception as ex:   # noqa: BLE001
         if world > 1 and "MASTER_PORT" not in os.environ:
             raise
         path = f"/tmp/mgn_comm_{os.environ.get('MASTER_PORT', '0')}_{os.getppid()}_{os.environ.get('TORCHELASTIC_RUN_ID', 'x')}.id"
         sys.stderr.write(f"[bench] store rendezvous failed ({ex!r}); file bootstrap {path}\n")
         eng.comm_init_file(path, "rccl")
-        return None
+        return None, "rccl"
+    ok = True
+    try:
+        if rank == 0:
+            store.set("mgn_comm_id", eng.comm_unique_id("rccl"))
+        eng.comm_init(bytes(store.get("mgn_comm_id")), "rccl")
+    except Exception as ex:   # noqa: BLE001
+        sys.stderr.write(f"[bench] rank {rank}: RCCL communicator failed: {ex}\n")
+        ok = False
+    store.set(f"mgn_comm_ok_{rank}", b"1" if ok else b"0")
+    all_ok = all(bytes(store.get(f"mgn_comm_ok_{q}")) == b"1" for q in range(world))
+    if all_ok:
+        return store, "rccl"
+    if ok:
+        eng.comm_destroy()
+    if rank == 0:
+        store.set("mgn_comm_id_host", eng.comm_unique_id("host"))
+    eng.comm_init(bytes(store.get("mgn_comm_id_host")), "host")
+    return store, "host (shared memory: RCCL did not initialise on every rank)"
 
 
 def main():
@@ -199,6 +215,8 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the engine has no CPU path")
+    if os.environ.get("MGN_BENCH_ONE_GPU") == "1":   # tests on a one-GPU box: every rank on device 0 (RCCL refuses that: the
+        local_rank = 0                                #   agreed fallback to the shared-memory transport is what gets exercised)
     torch.cuda.set_device(local_rank)
     staged = world > 1 or args.force_staged
 
@@ -213,7 +231,7 @@ def main():
     t_setup = time.perf_counter()
     eng.set_graph(s, r, N, mesh_pos=pos)     # unsorted COO in: receiver sort / CSR / partition / halo lists are amortised here
     t_setup = time.perf_counter() - t_setup
-    store = comm_bootstrap(eng, rank, world) if staged else None
+    store, transport = comm_bootstrap(eng, rank, world) if staged else (None, None)
     eng.latents_randn(1234)
 
     def barrier_sync():
@@ -305,7 +323,7 @@ def main():
             "config": {"workload": f"M-1M jittered-grid triangulation {args.nx}x{args.nx}: N={N} nodes, E={E} directed edges, "
                                    f"L=128, hidden_layers=2, {MPS} processor steps per bench step, {'bf16 storage + bf16 MFMA' if bf else 'fp32'} "
                                    f"(BASELINE.json configs[3]{' mesh at configs[2] precision' if bf else ''})",
-                       "partition": (f"edge-cut RCB over {world} GPU(s), halo exchange = RCCL grouped send/recv inside mgn_processor_steps_dev"
+                       "partition": (f"edge-cut RCB over {world} GPU(s), halo exchange inside mgn_processor_steps_dev, transport {transport}"
                                      if world > 1 else "single partition"),
                        "edge_order": "engine re-sorts by receiver once per trajectory (mgn_set_graph)"},
             "roofline": roof,

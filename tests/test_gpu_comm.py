@@ -323,3 +323,21 @@ def test_full_size_1m_eight_partitions_in_library():
     assert c[4] == N and c[5] == E
     for k, v in zip(("sum_v", "sum_e", "sumsq_v", "sumsq_e"), c):
         assert abs(v - a[k]) <= 2e-6 * max(abs(a[k]), 1.0) + 1e-3 * (k.startswith("sum_")), (k, a[k], v)
+
+
+def test_bench_two_ranks_under_torchrun_on_one_gpu(tmp_path):
+    """`bench.py --gpus 2` exactly as the driver launches it (torch.distributed.run, rendezvous store for the communicator id),
+    with both ranks on device 0 of this one-GPU box: RCCL refuses two ranks on one device, every rank reports that through the
+    store and all fall back to the library's shared-memory transport -- the timed loop (mgn_processor_steps_dev at nranks = 2)
+    and the JSON contract are what a real 2-GPU run executes."""
+    import json
+    env = dict(os.environ, MGN_BENCH_ONE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    port = 29600 + (os.getpid() % 300)
+    res = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--nx", "200"],
+                         env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    assert res.returncode == 0 and len(lines) == 1, res.stdout[-1500:] + res.stderr[-3000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["latents_finite"] and d["scaling"] == "strong"
+    assert d["per_rank"]["n_halo"] > 0 and "transport" in d["config"]["partition"]
