@@ -203,7 +203,11 @@ int mgn_feature_stats(mgn_handle* h, const float* x, int64_t rows, int32_t dim, 
  * adaptive Tsit5 (own tableau + PI step controller, tstops = saveat = t0 + i*saves_dt), the right-hand side being
  * ode_func_eval (inflow overwrite from `inflow_data[floor(t / saves_dt)]`, src/solve.jl:151-152, applied IN PLACE to
  * the array the RHS is evaluated on, like the reference) -> ode_step (mgn_ode_step semantics).  No host round trip
- * per RHS; one small D2H (error norm) per adaptive step.  Normalisers must be set with mgn_set_norms. */
+ * per RHS; one small D2H (error norm) per adaptive step.  Normalisers must be set with mgn_set_norms.
+ * With nranks > 1 (after mgn_comm_init) every rank passes the GLOBAL arrays and integrates the rows it owns; the error norm of
+ * the step controller is reduced over the ranks (the same bits everywhere: the same accept / reject decisions), the halo exchange
+ * runs inside every right-hand side, and every rank returns the complete solution.  mgn_ode_step and mgn_set_static likewise
+ * (global arrays in, complete dx/dt out on every rank). */
 typedef struct mgn_rollout_desc {
     int32_t solver;          /* 0 = Euler fixed step, 1 = Tsit5 adaptive                                     */
     float t0, t1;            /* integration interval                                                         */

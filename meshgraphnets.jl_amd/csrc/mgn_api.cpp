@@ -1189,10 +1189,28 @@ int mgn_fwd_download(mgn_handle* h, float* out) try {
 } MGN_CATCH(h)
 
 static int forward_partitioned(mgn_handle* h, const float* nf, const float* ef, float* out);
+static int gather_rows_global(mgn_handle* h, const float* local_dev, int W, float* out);
 static int processor_pass_staged(mgn_handle* h, int32_t nsteps, bool begin);
 static int need_comm(mgn_handle* h, const char* who);
 
+// the O x N state of a right-hand side: one partition takes it as it is, a partitioned handle the rows it owns
+static int upload_state(mgn_handle* h, const float* x) {
+    const LocalGraph& g = h->g;
+    const int O = h->cfg.O;
+    if (h->cfg.nranks == 1) {
+        HIPCHK(h, hipMemcpyAsync(h->d_nfA.p, x, (size_t)g.N * O * 4, hipMemcpyHostToDevice, h->stream));
+        return MGN_OK;
+    }
+    std::vector<float> loc((size_t)g.n_own * O);
+    for (int32_t i = 0; i < g.n_own; ++i) memcpy(loc.data() + (size_t)i * O, x + (size_t)g.own_gid[i] * O, (size_t)O * 4);
+    HIPCHK(h, hipMemcpyAsync(h->d_nfA.p, loc.data(), loc.size() * 4, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return MGN_OK;
+}
+
 static int run_processor(mgn_handle* h, int nsteps) {
+    // partitioned: the staged schedule; P, Q of step 0 came from the encoder, so the pass starts with their exchange
+    if (h->cfg.nranks != 1) return processor_pass_staged(h, nsteps, false);
     for (int k = 0; k < nsteps; ++k) {
         if (int rc = mgn_proc_edge(h, k)) return rc;
         if (int rc = mgn_proc_node(h, k, k + 1 < nsteps ? 1 : 0)) return rc;
@@ -1225,22 +1243,17 @@ int mgn_forward(mgn_handle* h, const float* nf, const float* ef, float* out) try
 int mgn_set_static(mgn_handle* h, const float* onehot, const float* ef_raw, const float* val_mask) try {
     if (int rc = need(h, true, true)) return rc;
     const mgn_config& c = h->cfg;
-    if (c.nranks != 1) return fail(h, MGN_E_STATE, "mgn_set_static drives one partition");
+    if (c.nranks != 1) if (int rc = need_comm(h, "mgn_set_static")) return rc;
     if (h->nsets != 1) return fail(h, MGN_E_STATE, "mgn_set_static / mgn_ode_step / mgn_rollout mirror the reference's single-edge-set RHS (src/solve.jl:188-219)");
     if (!ef_raw || (c.Fn > c.O && !onehot)) return fail(h, MGN_E_ARG, "mgn_set_static: null argument");
     if (c.Fn < c.O) return fail(h, MGN_E_ARG, "mgn_set_static: Fn < O");
     const LocalGraph& g = h->g;
     invalidate_static(h);
-    h->in_wa = c.O;
-    h->in_wb = c.Fn - c.O;
-    h->in_local = false;
-    HIPCHK(h, h->d_nfA.ensure((size_t)g.N * c.O * 4));
-    if (h->in_wb > 0) {
-        HIPCHK(h, h->d_nfB.ensure((size_t)g.N * h->in_wb * 4));
-        HIPCHK(h, hipMemcpyAsync(h->d_nfB.p, onehot, (size_t)g.N * h->in_wb * 4, hipMemcpyHostToDevice, h->stream));
+    {   // static inputs through the common upload (a partitioned handle keeps the rows it owns); the state slot is a placeholder
+        std::vector<float> x0((size_t)g.N * c.O, 0.f);
+        if (int rc = upload_inputs(h, x0.data(), c.O, onehot, c.Fn - c.O, ef_raw)) return rc;
+        HIPCHK(h, hipStreamSynchronize(h->stream));
     }
-    HIPCHK(h, h->es[0].d_ef.ensure((size_t)g.set[0].E * c.Fe * 4));
-    HIPCHK(h, hipMemcpyAsync(h->es[0].d_ef.p, ef_raw, (size_t)g.set[0].E * c.Fe * 4, hipMemcpyHostToDevice, h->stream));
     h->have_mask = val_mask != nullptr;
     if (val_mask) {
         HIPCHK(h, h->d_mask.ensure((size_t)g.N * 4));
@@ -1259,14 +1272,14 @@ int mgn_set_static(mgn_handle* h, const float* onehot, const float* ef_raw, cons
 int mgn_ode_step(mgn_handle* h, const float* x, const float* onehot, const float* ef_raw, const float* val_mask, float* dxdt) try {
     if (int rc = need(h, true, true)) return rc;
     const mgn_config& c = h->cfg;
-    if (h->cfg.nranks != 1) return fail(h, MGN_E_STATE, "mgn_ode_step drives one partition");
+    if (h->cfg.nranks != 1) if (int rc = need_comm(h, "mgn_ode_step")) return rc;
     if (h->nsets != 1) return fail(h, MGN_E_STATE, "%s mirrors the reference's single-edge-set RHS (src/solve.jl:188-219); this handle has two edge sets", "mgn_ode_step");
     if (!x || !dxdt) return fail(h, MGN_E_ARG, "mgn_ode_step: null argument");
     if (c.Fn < c.O) return fail(h, MGN_E_ARG, "mgn_ode_step: Fn < O");
     if (!onehot && !ef_raw && !val_mask) {
         // fast path: static inputs and encoded edges are resident (mgn_set_static); only the state moves
         if (!h->have_static) return fail(h, MGN_E_STATE, "mgn_ode_step without static inputs: call mgn_set_static first or pass them");
-        HIPCHK(h, hipMemcpyAsync(h->d_nfA.p, x, (size_t)h->g.N * c.O * 4, hipMemcpyHostToDevice, h->stream));
+        if (int rc = upload_state(h, x)) return rc;
         auto launches = [&]() -> int {
             if (int rc = encode_impl(h, true, true, false)) return rc;
             const bool bf = is_bf16(h);
@@ -1276,6 +1289,10 @@ int mgn_ode_step(mgn_handle* h, const float* x, const float* onehot, const float
             return decode_impl(h, true);
         };
         // a Julia-driven solve calls this once per right-hand side
+        if (c.nranks != 1) {        // (no hipGraph around communicator calls)
+            if (int rc = launches()) return rc;
+            return gather_rows_global(h, h->d_out.as<float>(), c.O, dxdt);
+        }
         if (int rc = run_graphed(h, h->rhs_exec, h->rhs_warm, launches)) return rc;
         return mgn_fwd_download(h, dxdt);
     }
@@ -1290,6 +1307,7 @@ int mgn_ode_step(mgn_handle* h, const float* x, const float* onehot, const float
     if (int rc = encode_impl(h, true)) return rc;
     if (int rc = run_processor(h, c.mps)) return rc;
     if (int rc = decode_impl(h, true)) return rc;
+    if (c.nranks != 1) return gather_rows_global(h, h->d_out.as<float>(), c.O, dxdt);    // the complete dx/dt on every rank
     return mgn_fwd_download(h, dxdt);
 } MGN_CATCH(h)
 
@@ -1312,7 +1330,9 @@ const double TS_BT[7] = {-0.00178001105222577714, -0.0008164344596567469, 0.0078
 struct Rollout {
     mgn_engine* h;
     mgn_rollout_desc* d;
-    int64_t n;                 // N * O
+    int64_t n;                 // rows * O of the state this handle integrates (all N rows, or the owned rows of a partition)
+    int64_t n_global = 0;      // N * O
+    int32_t nrows = 0;
     float *u, *unew, *utmp, *k[7], *frames, *saves;
     uint8_t* mask;
     double* partial;
@@ -1350,10 +1370,10 @@ struct Rollout {
             int64_t fr = (int64_t)std::floor(t / d->saves_dt + 1e-6);
             if (fr < 0) fr = 0;
             if (fr >= d->n_frames) fr = d->n_frames - 1;
-            HIPCHK(h, launch_overwrite(x, frames + (size_t)fr * n, mask, h->g.N, c.O, h->stream));
+            HIPCHK(h, launch_overwrite(x, frames + (size_t)fr * n, mask, nrows, c.O, h->stream));
         }
         ++n_rhs;
-        const bool graphable = h->use_graph && !h->prof && h->stream != nullptr && launch_is_small(h->ntiles_n);
+        const bool graphable = h->use_graph && !h->prof && h->stream != nullptr && h->cfg.nranks == 1 && launch_is_small(h->ntiles_n);
         if (!graphable || !warmed) {       // the first RHS runs eagerly: it sets the per-kernel attributes outside of any capture
             warmed = true;
             return rhs_launches(x, kout);
@@ -1396,7 +1416,11 @@ struct Rollout {
         HIPCHK(h, hipStreamSynchronize(h->stream));
         double s = 0;
         for (double v : r) s += v;
-        *out = std::sqrt(s / (double)(n > 0 ? n : 1));
+        if (h->cfg.nranks != 1) {      // the same bits on every rank -> the same accept / reject decisions
+            if (h->comm->allreduce_f64(&s, 1, 0, h->stream) != 0) return fail(h, MGN_E_RCCL, "rollout: error-norm reduction failed: %s", h->comm->err.c_str());
+        }
+        const int64_t ng = n_global > 0 ? n_global : n;
+        *out = std::sqrt(s / (double)(ng > 0 ? ng : 1));
         return MGN_OK;
     }
 };
@@ -1406,7 +1430,8 @@ struct Rollout {
 int mgn_rollout(mgn_handle* h, mgn_rollout_desc* d) try {
     if (int rc = need(h, true, true)) return rc;
     const mgn_config& c = h->cfg;
-    if (c.nranks != 1) return fail(h, MGN_E_STATE, "mgn_rollout drives one partition");
+    const bool part = c.nranks != 1;      // partitioned: every rank integrates the rows it owns; error norms are reduced over the ranks
+    if (part) if (int rc = need_comm(h, "mgn_rollout")) return rc;
     if (h->nsets != 1) return fail(h, MGN_E_STATE, "%s mirrors the reference's single-edge-set RHS (src/solve.jl:188-219); this handle has two edge sets", "mgn_rollout");
     if (!d || !d->x0 || !d->out || !d->ef_raw || (c.Fn > c.O && !d->node_type_onehot)) return fail(h, MGN_E_ARG, "mgn_rollout: null argument");
     if (c.Fn < c.O) return fail(h, MGN_E_ARG, "mgn_rollout: Fn < O");
@@ -1420,7 +1445,10 @@ int mgn_rollout(mgn_handle* h, mgn_rollout_desc* d) try {
     Rollout R;
     R.h = h;
     R.d = d;
-    R.n = (int64_t)g.N * c.O;
+    const int32_t nloc = part ? g.n_own : g.N;        // rows of the state this handle integrates
+    R.n = (int64_t)nloc * c.O;
+    R.n_global = (int64_t)g.N * c.O;
+    R.nrows = nloc;
     const size_t nb = (size_t)R.n * 4;
     const size_t fb = d->inflow_data ? (size_t)d->n_frames * nb : 0, sb = (size_t)d->n_saves * nb;
     const size_t eb = tile_floats(h->es[0].ntiles_e, c.L) * 4;
@@ -1430,7 +1458,7 @@ int mgn_rollout(mgn_handle* h, mgn_rollout_desc* d) try {
     const size_t o_u = take(nb), o_un = take(nb), o_ut = take(nb);
     size_t o_k[7];
     for (auto& o : o_k) o = take(nb);
-    const size_t o_fr = take(fb), o_sv = take(sb), o_mask = take((size_t)g.N), o_part = take(errnorm_partials() * sizeof(double));
+    const size_t o_fr = take(fb), o_sv = take(sb), o_mask = take((size_t)nloc), o_part = take(errnorm_partials() * sizeof(double));
     R.elat0_off = take(eb);
     HIPCHK(h, h->ode.ensure(off));
     char* base = h->ode.as<char>();
@@ -1441,9 +1469,26 @@ int mgn_rollout(mgn_handle* h, mgn_rollout_desc* d) try {
     R.mask = d->inflow_mask ? (uint8_t*)(base + o_mask) : nullptr;
     R.partial = (double*)(base + o_part);
 
-    HIPCHK(h, hipMemcpyAsync(R.u, d->x0, nb, hipMemcpyHostToDevice, h->stream));
-    if (R.frames) HIPCHK(h, hipMemcpyAsync(R.frames, d->inflow_data, fb, hipMemcpyHostToDevice, h->stream));
-    if (R.mask) HIPCHK(h, hipMemcpyAsync(R.mask, d->inflow_mask, (size_t)g.N, hipMemcpyHostToDevice, h->stream));
+    if (!part) {
+        HIPCHK(h, hipMemcpyAsync(R.u, d->x0, nb, hipMemcpyHostToDevice, h->stream));
+        if (R.frames) HIPCHK(h, hipMemcpyAsync(R.frames, d->inflow_data, fb, hipMemcpyHostToDevice, h->stream));
+        if (R.mask) HIPCHK(h, hipMemcpyAsync(R.mask, d->inflow_mask, (size_t)g.N, hipMemcpyHostToDevice, h->stream));
+    } else {        // the owned rows of the state, of every inflow frame and of the inflow mask
+        const int O = c.O;
+        std::vector<float> loc((size_t)nloc * O * (1 + (d->inflow_data ? d->n_frames : 0)));
+        std::vector<uint8_t> lm(d->inflow_mask ? (size_t)nloc : 0);
+        for (int32_t i = 0; i < nloc; ++i) {
+            const size_t gi = (size_t)g.own_gid[i];
+            memcpy(loc.data() + (size_t)i * O, d->x0 + gi * O, (size_t)O * 4);
+            for (int f = 0; d->inflow_data && f < d->n_frames; ++f)
+                memcpy(loc.data() + ((size_t)(1 + f) * nloc + i) * O, d->inflow_data + ((size_t)f * g.N + gi) * O, (size_t)O * 4);
+            if (d->inflow_mask) lm[i] = d->inflow_mask[gi];
+        }
+        HIPCHK(h, hipMemcpyAsync(R.u, loc.data(), nb, hipMemcpyHostToDevice, h->stream));
+        if (R.frames) HIPCHK(h, hipMemcpyAsync(R.frames, loc.data() + (size_t)nloc * O, fb, hipMemcpyHostToDevice, h->stream));
+        if (R.mask) HIPCHK(h, hipMemcpyAsync(R.mask, lm.data(), (size_t)nloc, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+    }
     // static inputs: one-hot node types, raw edge features, val_mask; the edge encoder runs ONCE per trajectory
     if (int rc = upload_inputs(h, d->x0, c.O, d->node_type_onehot, c.Fn - c.O, d->ef_raw)) return rc;
     h->have_mask = d->val_mask != nullptr;
@@ -1540,7 +1585,12 @@ int mgn_rollout(mgn_handle* h, mgn_rollout_desc* d) try {
         }
     }
     while (saved < d->n_saves) HIPCHK(h, save());      // (t1 short of the last stop: repeat the final state)
-    HIPCHK(h, hipMemcpyAsync(d->out, R.saves, sb, hipMemcpyDeviceToHost, h->stream));
+    if (part) {     // every rank returns the complete solution
+        for (int i = 0; i < d->n_saves; ++i)
+            if (int rc = gather_rows_global(h, R.saves + (size_t)i * R.n, c.O, d->out + (size_t)i * g.N * c.O)) return rc;
+    } else {
+        HIPCHK(h, hipMemcpyAsync(d->out, R.saves, sb, hipMemcpyDeviceToHost, h->stream));
+    }
     HIPCHK(h, hipStreamSynchronize(h->stream));
     d->n_rhs = R.n_rhs;
     return MGN_OK;
