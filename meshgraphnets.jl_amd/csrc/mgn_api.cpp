@@ -1850,7 +1850,7 @@ static int gather_rows_global(mgn_handle* h, const float* local_dev, int W, floa
 // the decoded rows are gathered so that every rank returns the complete output
 static int forward_partitioned(mgn_handle* h, const float* nf, const float* ef, float* out) {
     if (int rc = need_comm(h, "mgn_forward")) return rc;
-    if (h->nsets != 1) return fail(h, MGN_E_UNSUPPORTED, "mgn_forward with nranks > 1 drives one edge set; use the staged mgn_fwd_* calls for two");
+    if (int rc = need_set_features(h)) return rc;
     if (int rc = mgn_fwd_upload(h, nf, ef)) return rc;
     if (int rc = encode_impl(h, false)) return rc;
     if (int rc = processor_pass_staged(h, h->cfg.mps, false)) return rc;

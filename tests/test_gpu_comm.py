@@ -189,6 +189,23 @@ def test_two_edge_sets_partitioned_in_library():
 
     run_ranks(2, body)
     assert rel_max(vc, v1) <= 1e-5 and rel_max(ec, e1) <= 1e-5 and rel_max(wc, w1) <= 1e-5
+    # ... and the whole model: mgn_forward with both edge sets on the partitioned mesh against the oracle
+    rng = np.random.default_rng(8)
+    nf = rng.standard_normal((N, 12)).astype(np.float32)
+    ref = orc.forward(ps, dict(cfg, Fe2=4), nf, mf["ef"], mf["s"], mf["r"], set2=(mf["ef2"], mf["s2"], mf["r2"]))
+    cid2 = mgn_amd.Engine.comm_unique_id("host")
+
+    def fwd(k):
+        e = make(rank=k, nranks=2, device=0)
+        e.set_edge_features(1, mf["ef2"])
+        e.comm_init(cid2, "host")
+        out = e.forward(nf, mf["ef"])
+        e.comm_barrier()
+        e.close()
+        return out
+
+    o = run_ranks(2, fwd)
+    assert np.array_equal(o[0], o[1]) and rel_max(o[0], ref) <= TOL_15
 
 
 _RCCL_SELFTEST = r"""
