@@ -176,6 +176,7 @@ int need(mgn_engine* h, bool params, bool graph);
 // L x L chunk of W (row-major [K][ldw], rows kbase.., all L output columns) -> MFMA fragment order
 void pack_chunk(float* dst, const float* W, int ldw, int kbase, int L);
 void pack_chunk_tmajor(float* dst, const float* frag, int L);
+void pack_chunk16(float* dst, const float* W, int ldw, int kbase);
 // vector of L values (stride between consecutive features = stride) -> table fragment order
 void pack_tab(float* dst, const float* vec, int L, int stride = 1);
 // mgn_train.cpp: drop training-side state that depends on the parameters (what & 1) or the graph (what & 2); free it all

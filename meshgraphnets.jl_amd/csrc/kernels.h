@@ -41,6 +41,8 @@ struct EdgeArgs {
     int32_t tile0;          // the launch covers edge tiles [tile0, tile0 + ntiles) (interior / boundary split)
     unsigned long long* stamps;  // diagnostic builds only (MGN_DIAG_STAMPS), else null
     GenMlp gen;
+    int32_t c16;            // 1: small graph, 16-row cooperative tiles on v_mfma_f32_16x16x4_f32 (both kernels of a step must agree:
+                            //    the carry rows are then per 16-edge tile)
 };
 
 struct NodeArgs {
@@ -62,6 +64,7 @@ struct NodeArgs {
     int64_t zero_row;       // CARRY row that is all zeros (read for receivers without incoming edges)
     int32_t tile0;          // k_project only: first tile of the range [tile0, tile0 + ntiles)
     GenMlp gen;
+    int32_t c16;            // see EdgeArgs
 };
 
 struct EncNodeArgs {
@@ -146,7 +149,10 @@ hipError_t launch_errnorm(const float* u, const float* unew, const LinComb& lc, 
                           double* partial, hipStream_t s);
 
 // L in {32,64,128}.  All return hipError_t of the launch.
-bool launch_is_small(int ntiles);   // the launch wrappers' rule for the cooperative node kernels (<= 8 tiles per CU)
+bool launch_is_small(int ntiles);
+bool launch_is_small_edge(int ntiles_e);   // the same rule for edge launches (<= 16 tiles per CU)
+int coop16_enabled();
+bool coop16_size(int ntiles_e, int ntiles_n);   // the launch wrappers' rule for the cooperative node kernels (<= 8 tiles per CU)
 int set_kernel_path(int p);   // debug/tests: 0 auto, 1 resident, 2 streaming, 3 cooperative, 4 GEN (general hidden_layers) kernels; returns the old value
 int get_kernel_path();
 hipError_t launch_edge_step(int L, const EdgeArgs& a, hipStream_t s);

@@ -625,6 +625,324 @@ __global__ __launch_bounds__(256, 2) void k_node_coop(const NodeArgs a) {
     }
 }
 
+// ================================================================================================
+// 16-row cooperative tiles for SMALL graphs (L = 128, fp32, hidden_layers = 2, one edge set): v_mfma_f32_16x16x4_f32.
+// A 32-row tile on v_mfma_f32_32x32x2_f32 is, per wave, a chain of 64 MFMAs of 64 cycles per layer (4.1 k cycles of matrix pipe
+// whatever the number of rows), and a cylinder_flow-sized mesh has 63 node tiles for 256 CUs: the step is bound by those serial
+// chains (six per node tile).  Half the rows per tile on the 16x16x4 shape (32 cycles per MFMA, 64 per chain) halve the chain time
+// and double the number of tiles.  Layout: lane l = (n = l & 15: the row, q = l >> 4); a ROW FRAGMENT is 8 float4: x[bb][i] =
+// X[row n][16 bb + 4 q + i]; wave w owns the output blocks 2w, 2w+1: acc[j][i] = feature 16 (2w + j) + 4 q + i of row n -- the
+// accumulator layout of the instruction -- so an all-gather of the four waves' slices through LDS is the next layer's operand, and
+// k-step (bb, i) contracts register (bb, i) of every lane (weights in that order: pack_chunk16).  HBM storage is unchanged
+// (32-row tile-major): a half tile addresses rows 16 (ht & 1) + n of tile ht >> 1.  Carry rows are per 16-edge tile here
+// (EdgeArgs.c16: the edge and the node kernel of a step agree).
+// ================================================================================================
+constexpr int C16_CH = 128 * 128;          // floats per chunk copy
+DEVINL f32x4 c16_mfma(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+// float4 index of (feature block bb, lane group q) of row `row` of tile `tile` in 32-row tile-major storage
+DEVINL int64_t c16_tile_idx(int64_t tile, int row, int bb, int q) {
+    const int o = 16 * (bb & 1) + 4 * q;
+    return tile * 1024 + (int64_t)(4 * (bb >> 1) + (o >> 3)) * 64 + 32 * ((o >> 2) & 1) + row;
+}
+DEVINL void c16_load_tile_row(f32x4 (&x)[8], const float* base, int64_t tile, int row, int q) {
+    const f32x4* p = reinterpret_cast<const f32x4*>(base);
+#pragma unroll
+    for (int bb = 0; bb < 8; ++bb) x[bb] = p[c16_tile_idx(tile, row, bb, q)];
+}
+DEVINL void c16_load_row(f32x4 (&x)[8], const float* base, int64_t row, int q) {       // row-major [row][128]
+    const f32x4* p = reinterpret_cast<const f32x4*>(base) + row * 32 + q;
+#pragma unroll
+    for (int bb = 0; bb < 8; ++bb) x[bb] = p[4 * bb];
+}
+// one L x L chunk: this wave's two output blocks; wt = chunk16 + w * 4096 floats ([bb][j][lane][4]).  The weight fragments come
+// from L2 (a launch of one or two tiles per CU cannot amortise an LDS preload) through a register ring C16_PF k-groups deep, pinned
+// by scheduling fences (hipcc otherwise sinks every request to just before its use), and a chain's first fragments can be requested
+// ahead of time (c16_prime) -- before the previous chain or the exchange barrier.
+#ifndef C16_PF
+#define C16_PF 3
+#endif
+struct C16Ring { f32x4 r[2 * C16_PF]; };
+DEVINL void c16_prime(C16Ring& g, const float* wt, int lane) {
+    const f32x4* wv = reinterpret_cast<const f32x4*>(wt) + lane;
+#pragma unroll
+    for (int p = 0; p < 2 * C16_PF; ++p) g.r[p] = wv[p * 64];
+}
+DEVINL void c16_chain_primed(f32x4 (&acc)[2], const f32x4 (&x)[8], const float* wt, int lane, C16Ring& g) {
+    const f32x4* wv = reinterpret_cast<const f32x4*>(wt) + lane;
+#pragma unroll
+    for (int bb = 0; bb < 8; ++bb) {
+        const f32x4 c0 = g.r[(2 * bb) % (2 * C16_PF)], c1 = g.r[(2 * bb + 1) % (2 * C16_PF)];
+        if (bb + C16_PF < 8) {
+            g.r[(2 * bb) % (2 * C16_PF)] = wv[(2 * (bb + C16_PF)) * 64];
+            g.r[(2 * bb + 1) % (2 * C16_PF)] = wv[(2 * (bb + C16_PF) + 1) * 64];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            acc[0] = c16_mfma(c0[i], x[bb][i], acc[0]);
+            acc[1] = c16_mfma(c1[i], x[bb][i], acc[1]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+DEVINL void c16_chain(f32x4 (&acc)[2], const f32x4 (&x)[8], const float* wt, int lane) {
+    C16Ring g;
+    c16_prime(g, wt, lane);
+    __builtin_amdgcn_sched_barrier(0);
+    c16_chain_primed(acc, x, wt, lane, g);
+}
+// every wave publishes its two blocks and reads back the full row fragment
+DEVINL void c16_exchange(f32x4 (&full)[8], const f32x4 (&mine)[2], f32x4* xch, int wave, int lane) {
+    xch[(2 * wave) * 64 + lane] = mine[0];
+    xch[(2 * wave + 1) * 64 + lane] = mine[1];
+    __syncthreads();
+#pragma unroll
+    for (int bb = 0; bb < 8; ++bb) full[bb] = xch[bb * 64 + lane];
+}
+// this wave's two blocks of a full row fragment (a switch on the uniform wave id: a runtime index into a register array would
+// send the array to scratch)
+DEVINL void c16_pick(f32x4 (&out)[2], const f32x4 (&x)[8], int wave) {
+    switch (wave) {
+        case 0: out[0] = x[0]; out[1] = x[1]; break;
+        case 1: out[0] = x[2]; out[1] = x[3]; break;
+        case 2: out[0] = x[4]; out[1] = x[5]; break;
+        default: out[0] = x[6]; out[1] = x[7]; break;
+    }
+}
+DEVINL void c16_tab(f32x4 (&acc)[2], const float* tab, int wave, int q) {      // natural-order table -> this wave's slice
+    const f32x4* t4 = reinterpret_cast<const f32x4*>(tab) + q;
+    acc[0] = t4[4 * (2 * wave)];
+    acc[1] = t4[4 * (2 * wave + 1)];
+}
+DEVINL void c16_relu(f32x4 (&acc)[2]) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[j][i] = fmaxf(acc[j][i], 0.f);
+}
+// LayerNorm statistics from the full pre-LN row (32 values in this lane, the rest in the lanes n + 16 q'), applied to the slice
+DEVINL void c16_layer_norm(f32x4 (&mine)[2], const f32x4 (&full)[8], const float* gamma, const float* beta, int wave, int q) {
+    float s = 0.f;
+#pragma unroll
+    for (int bb = 0; bb < 8; ++bb)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) s += full[bb][i];
+    s += __shfl_xor(s, 16, 64);
+    s += __shfl_xor(s, 32, 64);
+    const float mean = s * (1.0f / 128);
+    float v = 0.f;
+#pragma unroll
+    for (int bb = 0; bb < 8; ++bb)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float d = full[bb][i] - mean;
+            v += d * d;
+        }
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+    const float rstd = 1.0f / sqrtf(v * (1.0f / 128) + LN_EPS);
+    f32x4 g[2], b[2];
+    c16_tab(g, gamma, wave, q);
+    c16_tab(b, beta, wave, q);
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) mine[j][i] = (mine[j][i] - mean) * rstd * g[j][i] + b[j][i];
+}
+
+// chunk[0]=W2 [1]=W3 [2]=W1e; the 16x16x4 copy of a chunk follows its two other copies (mgn_set_params)
+__global__ __launch_bounds__(256, 2) void k_edge_coop16(const EdgeArgs a) {
+    constexpr int L = 128;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    f32x4* xch0 = reinterpret_cast<f32x4*>(smem);
+    f32x4* xch1 = xch0 + 8 * 64;
+    const int lane0 = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const float* tabs = a.tabs + T_COUNT * L;                       // natural feature order
+    const float* w1 = a.chunk[2] + 2 * C16_CH + wave * 4096;
+    const float* w2 = a.chunk[0] + 2 * C16_CH + wave * 4096;
+    const float* w3 = a.chunk[1] + 2 * C16_CH + wave * 4096;
+    const int ht0 = 2 * a.tile0, nht = 2 * a.ntiles;
+    for (int hi = blockIdx.x; hi < nht; hi += gridDim.x) {
+        int lane = lane0;
+        asm volatile("" : "+v"(lane));      // keeps the (loop-invariant) weight and table loads inside the loop: hoisted, they spill
+        const int n = lane & 15, q = lane >> 4;
+        const int ht = ht0 + hi;
+        const int64_t e0 = (int64_t)ht * 16;
+        if (e0 >= a.E) break;                                       // the empty second half of the last tile (block-uniform)
+        const int64_t eid = e0 + n;
+        const bool valid = eid < a.E;
+        const int64_t ec = valid ? eid : a.E - 1;
+        const int s_ = a.snd[ec], r_ = a.rcv[ec];
+        const int r_before = ht > 0 ? a.rcv[e0 - 1] : -2;
+        const int r_after = (e0 + 16 < a.E) ? a.rcv[e0 + 16] : -3;
+        const int64_t tile = ht >> 1;
+        const int row = 16 * (ht & 1) + n;
+        f32x4 x[8], full[8], acc[2];
+        c16_load_tile_row(x, a.Elat, tile, row, q);
+        {   // layer-1 accumulator: P[s] + Q[r] (carry b1), this wave's blocks
+            const f32x4* P4 = reinterpret_cast<const f32x4*>(a.P) + (int64_t)s_ * 32 + q;
+            const f32x4* Q4 = reinterpret_cast<const f32x4*>(a.Q) + (int64_t)r_ * 32 + q;
+            acc[0] = P4[4 * (2 * wave)] + Q4[4 * (2 * wave)];
+            acc[1] = P4[4 * (2 * wave + 1)] + Q4[4 * (2 * wave + 1)];
+        }
+        C16Ring g1, g2;
+        c16_prime(g1, w1, lane);
+        c16_prime(g2, w2, lane);                                     // layer 2's first fragments, a chain ahead
+        __builtin_amdgcn_sched_barrier(0);
+        c16_chain_primed(acc, x, w1, lane, g1);                      // layer 1 (edge part)
+        c16_relu(acc);
+        c16_prime(g1, w3, lane);
+        c16_exchange(full, acc, xch0, wave, lane);
+        c16_tab(acc, tabs + T_B2 * L, wave, q);
+        c16_chain_primed(acc, full, w2, lane, g2);                   // layer 2
+        c16_relu(acc);
+        c16_exchange(full, acc, xch1, wave, lane);
+        c16_tab(acc, tabs + T_B3 * L, wave, q);
+        c16_chain_primed(acc, full, w3, lane, g1);                   // layer 3
+        c16_exchange(full, acc, xch0, wave, lane);                   // full pre-LN row (for the statistics)
+        c16_layer_norm(acc, full, tabs + T_GAMMA * L, tabs + T_BETA * L, wave, q);   // acc = this wave's slice of e'
+        if (valid) {                                                 // e <- e + e'
+            f32x4* E4 = reinterpret_cast<f32x4*>(a.Elat);
+            f32x4 xs[2];
+            c16_pick(xs, x, wave);
+            E4[c16_tile_idx(tile, row, 2 * wave, q)] = xs[0] + acc[0];
+            E4[c16_tile_idx(tile, row, 2 * wave + 1, q)] = xs[1] + acc[1];
+        }
+        // segmented sum over runs of equal receiver: the 16 rows of a half tile are one DPP row (the same in all four lane groups)
+        const int reff = valid ? r_ : (-4 - n);
+        const int rprev = __shfl_up(reff, 1, 16);
+        const int rnext = __shfl_down(reff, 1, 16);
+        const bool head = (n == 0) || (reff != rprev);
+        const unsigned hm = (unsigned)(__ballot(head) & 0xFFFFull);          // lane group 0's 16 rows
+        const int start = 31 - __clz((int)(hm & (0xFFFFu >> (15 - n))));
+        const float m1 = (n - 1 >= start) ? 1.f : 0.f, m2 = (n - 2 >= start) ? 1.f : 0.f, m4 = (n - 4 >= start) ? 1.f : 0.f,
+                    m8 = (n - 8 >= start) ? 1.f : 0.f;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float v = acc[j][i];
+                v = __builtin_fmaf(dpp_zero<0x111, 0xF>(v), m1, v);
+                v = __builtin_fmaf(dpp_zero<0x112, 0xF>(v), m2, v);
+                v = __builtin_fmaf(dpp_zero<0x114, 0xF>(v), m4, v);
+                v = __builtin_fmaf(dpp_zero<0x118, 0xF>(v), m8, v);
+                acc[j][i] = v;
+            }
+        const bool tail = valid && ((n == 15) || (reff != rnext));
+        const int r_first = __builtin_amdgcn_readfirstlane(reff);
+        const bool sl = (start == 0) && (r_before == r_first);       // run continues from the previous 16-edge tile
+        const bool sr = (n == 15) && (r_after == reff);              // run continues into the next one
+        if (tail) {
+            if (sl || sr) {
+                f32x4* C4 = reinterpret_cast<f32x4*>(a.CARRY) + ((int64_t)2 * ht + (sl ? 0 : 1)) * 32 + q;
+                C4[4 * (2 * wave)] = acc[0];
+                C4[4 * (2 * wave + 1)] = acc[1];
+            } else {
+                f32x4* A4 = reinterpret_cast<f32x4*>(a.AGG);
+                A4[c16_tile_idx(r_ >> 5, r_ & 31, 2 * wave, q)] = acc[0];
+                A4[c16_tile_idx(r_ >> 5, r_ & 31, 2 * wave + 1, q)] = acc[1];
+            }
+        }
+        __syncthreads();   // xch0 is rewritten by the next half tile's first exchange
+    }
+}
+
+// chunk[0]=W2 [1]=W3 [2]=W1v [3]=W1a [4]=WP [5]=WQ.  mode as in NodeArgs.  One edge set.
+__global__ __launch_bounds__(256, 2) void k_node_coop16(const NodeArgs a) {
+    constexpr int L = 128;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    f32x4* xch0 = reinterpret_cast<f32x4*>(smem);
+    f32x4* xch1 = xch0 + 8 * 64;
+    const int lane0 = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const float* tabs = a.tabs + T_COUNT * L;
+    auto wt = [&](int ch) { return a.chunk[ch] + 2 * C16_CH + wave * 4096; };
+    const int ht0 = 2 * a.tile0, nht = 2 * a.ntiles;
+    for (int hi = blockIdx.x; hi < nht; hi += gridDim.x) {
+        int lane = lane0;
+        asm volatile("" : "+v"(lane));
+        const int n = lane & 15, q = lane >> 4;
+        const int ht = ht0 + hi;
+        const int node = ht * 16 + n;
+        if (ht * 16 >= a.n) break;
+        const bool valid = node < a.n;
+        const int nn = valid ? node : a.n - 1;
+        const int64_t tile = ht >> 1;
+        const int row = 16 * (ht & 1) + n;
+        f32x4 v[8], full[8], acc[2];
+        c16_load_tile_row(v, a.V, tile, row, q);
+        if (a.mode != 2) {
+            // aggregated messages: the node's AGG slot, or carry rows when its run of edges straddles 16-edge tiles
+            const int a0 = a.rowptr[nn], a1 = a.rowptr[nn + 1];
+            const int T1 = a0 >> 4, T2 = (a1 - 1) >> 4;
+            const int extra = (valid && a1 > a0 && T2 > T1) ? (T2 - T1) : 0;
+            const bool from_agg = valid && (a1 > a0) && !extra;
+            if (from_agg) c16_load_tile_row(full, a.AGG, tile, row, q);
+            else c16_load_row(full, a.CARRY, extra ? (int64_t)(2 * T1 + 1) : a.zero_row, q);
+            for (int k = 1; __any(k <= extra); ++k)
+                if (k <= extra) {
+                    f32x4 cr[8];
+                    c16_load_row(cr, a.CARRY, (int64_t)2 * (T1 + k), q);
+#pragma unroll
+                    for (int bb = 0; bb < 8; ++bb) full[bb] += cr[bb];
+                }
+            C16Ring ga, gb;
+            c16_prime(ga, wt(2), lane);
+            c16_prime(gb, wt(3), lane);
+            c16_tab(acc, tabs + T_B1 * L, wave, q);
+            __builtin_amdgcn_sched_barrier(0);
+            c16_chain_primed(acc, v, wt(2), lane, ga);               // layer 1, node part
+            c16_prime(ga, wt(0), lane);
+            c16_chain_primed(acc, full, wt(3), lane, gb);            // layer 1, aggregate part
+            c16_relu(acc);
+            c16_prime(gb, wt(1), lane);
+            c16_exchange(full, acc, xch0, wave, lane);
+            c16_tab(acc, tabs + T_B2 * L, wave, q);
+            c16_chain_primed(acc, full, wt(0), lane, ga);            // layer 2
+            c16_relu(acc);
+            c16_exchange(full, acc, xch1, wave, lane);
+            c16_tab(acc, tabs + T_B3 * L, wave, q);
+            c16_chain_primed(acc, full, wt(1), lane, gb);            // layer 3
+            c16_exchange(full, acc, xch0, wave, lane);
+            c16_layer_norm(acc, full, tabs + T_GAMMA * L, tabs + T_BETA * L, wave, q);
+            {
+                f32x4 vs[2];
+                c16_pick(vs, v, wave);
+                acc[0] += vs[0];                                     // v <- v + v'  (this wave's slice)
+                acc[1] += vs[1];
+            }
+            if (valid) {
+                f32x4* V4 = reinterpret_cast<f32x4*>(a.V);
+                V4[c16_tile_idx(tile, row, 2 * wave, q)] = acc[0];
+                V4[c16_tile_idx(tile, row, 2 * wave + 1, q)] = acc[1];
+            }
+            if (a.mode == 1) c16_exchange(v, acc, xch1, wave, lane); // full updated row for the projection
+        }
+        if (a.mode != 0) {                                           // P = v W1s, Q = v W1r + b1 of the next step
+            f32x4 o[2];
+            o[0] = f32x4{0.f, 0.f, 0.f, 0.f};
+            o[1] = o[0];
+            C16Ring gq;
+            c16_prime(gq, wt(5), lane);
+            c16_chain(o, v, wt(4), lane);
+            if (valid) {
+                f32x4* P4 = reinterpret_cast<f32x4*>(a.P) + (int64_t)nn * 32 + q;
+                P4[4 * (2 * wave)] = o[0];
+                P4[4 * (2 * wave + 1)] = o[1];
+            }
+            c16_tab(o, tabs + T_BQ * L, wave, q);
+            c16_chain_primed(o, v, wt(5), lane, gq);
+            if (valid) {
+                f32x4* Q4 = reinterpret_cast<f32x4*>(a.Q) + (int64_t)nn * 32 + q;
+                Q4[4 * (2 * wave)] = o[0];
+                Q4[4 * (2 * wave + 1)] = o[1];
+            }
+        }
+        __syncthreads();
+    }
+}
+
 // first dense layer with a tiny input width: acc[feature] = b1 + sum_k x[k] * W1[k][feature]  (VALU)
 template <int NT>
 DEVINL void first_layer(f32x16 (&acc)[NT], const float* w1f, int k, float xk, int h) {
@@ -1924,8 +2242,18 @@ static bool small_launch(int ntiles) { return g_path == 0 ? ntiles <= 4 * num_cu
 static int g_tail_coop = [] { const char* e = getenv("MGN_TAIL_COOP"); return e ? atoi(e) : 1; }();   // 0: whole launch persistent
 static int g_coop_edge = [] { const char* e = getenv("MGN_COOP_EDGE_TILES_PER_CU"); return e ? atoi(e) : 16; }();
 static int g_coop_node = [] { const char* e = getenv("MGN_COOP_NODE_TILES_PER_CU"); return e ? atoi(e) : 8; }();
-static bool coop_size(int ntiles, bool edge) { return g_path == 0 ? ntiles <= (edge ? g_coop_edge : g_coop_node) * num_cus() : g_path == 3; }
+static int g_coop16 = [] { const char* e = getenv("MGN_COOP16"); return e ? atoi(e) : 1; }();   // 16-row cooperative tiles on small graphs
+int coop16_enabled() { return (g_coop16 && (g_path == 0 || g_path == 5)) ? 1 : 0; }
+// the 16-row tiles pay while the launches are latency-bound: up to this many 32-row tiles per CU (size sweep, docs/experiments.md)
+static int g_c16_edge = [] { const char* e = getenv("MGN_C16_EDGE_TILES_PER_CU"); return e ? atoi(e) : 3; }();
+static int g_c16_node = [] { const char* e = getenv("MGN_C16_NODE_TILES_PER_CU"); return e ? atoi(e) : 1; }();
+bool coop16_size(int ntiles_e, int ntiles_n) {
+    if (g_path == 5) return true;
+    return ntiles_e <= g_c16_edge * num_cus() && ntiles_n <= g_c16_node * num_cus();
+}
+static bool coop_size(int ntiles, bool edge) { return g_path == 0 ? ntiles <= (edge ? g_coop_edge : g_coop_node) * num_cus() : (g_path == 3 || g_path == 5); }
 bool launch_is_small(int ntiles) { return coop_size(ntiles, false); }
+bool launch_is_small_edge(int ntiles_e) { return coop_size(ntiles_e, true); }
 
 static LaunchCfg tile_launch(int L, int ntiles, int nres) {
     LaunchCfg lc;
@@ -2011,6 +2339,10 @@ hipError_t launch_edge_step(int L, const EdgeArgs& a, hipStream_t s) {
     if (a.gen.use) DISPATCH_GEN(L, (k_edge_step<4, 0, true>), (k_edge_step<2, 0, true>), (k_edge_step<1, 0, true>), a, a.ntiles);
     const int nres = resident_chunks(L, 3);
     LaunchCfg lc = tile_launch(L, a.ntiles, nres);
+    if (a.c16 && L == 128 && a.chunk_t[0]) {        // small graph: 16-row tiles, 4 waves each (the handle decided for both kernels)
+        LaunchCfg c16{2 * a.ntiles, 256, (size_t)2 * 8 * 64 * 16};
+        return launch_k(k_edge_coop16, a, c16, s);
+    }
     if (coop_ok(L, a.ntiles, a.chunk_t, true)) {   // small graph: 4 waves per tile
         LaunchCfg c4{a.ntiles, 256, coop_lds()};
         return coop_fence(a.ntiles) ? launch_k(k_edge_coop<true>, a, c4, s) : launch_k(k_edge_coop<false>, a, c4, s);
@@ -2055,6 +2387,10 @@ hipError_t launch_node_step(int L, const NodeArgs& a, hipStream_t s) {
         if (a.mode == 1) DISPATCH_GEN(L, (k_node_step<4, 0, true, 1, true>), (k_node_step<2, 0, true, 1, true>), (k_node_step<1, 0, true, 1, true>), a, a.ntiles);
         DISPATCH_GEN(L, (k_node_step<4, 0, false, 1, true>), (k_node_step<2, 0, false, 1, true>), (k_node_step<1, 0, false, 1, true>), a, a.ntiles);
     }
+    if (a.c16 && L == 128 && a.chunk_t[0] && !a.AGG2) {
+        LaunchCfg c16{2 * a.ntiles, 256, (size_t)2 * 8 * 64 * 16};
+        return launch_k(k_node_coop16, a, c16, s);
+    }
     if (coop_ok(L, a.ntiles, a.chunk_t)) {
         LaunchCfg c4{a.ntiles, 256, coop_lds()};
         if (coop_fence(a.ntiles)) return a.AGG2 ? launch_k(k_node_coop<true, true>, a, c4, s) : launch_k(k_node_coop<false, true>, a, c4, s);
@@ -2093,6 +2429,10 @@ hipError_t launch_node_step(int L, const NodeArgs& a, hipStream_t s) {
 hipError_t launch_project(int L, const NodeArgs& a, hipStream_t s) {
     if (a.ntiles <= 0) return hipSuccess;
     LaunchCfg lc = tile_launch(L, a.ntiles, 2);
+    if (!a.gen.use && a.c16 && L == 128 && a.chunk_t[0] && !a.AGG2 && a.mode == 2) {
+        LaunchCfg c16{2 * a.ntiles, 256, (size_t)2 * 8 * 64 * 16};
+        return launch_k(k_node_coop16, a, c16, s);
+    }
     if (!a.gen.use && a.tile0 == 0 && a.mode == 2 && coop_ok(L, a.ntiles, a.chunk_t)) {
         LaunchCfg c4{a.ntiles, 256, coop_lds()};
         if (coop_fence(a.ntiles)) return a.AGG2 ? launch_k(k_node_coop<true, true>, a, c4, s) : launch_k(k_node_coop<false, true>, a, c4, s);

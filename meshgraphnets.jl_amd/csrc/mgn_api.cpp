@@ -124,6 +124,19 @@ void pack_chunk_tmajor(float* dst, const float* frag, int L) {
             for (int lane = 0; lane < 64; ++lane)
                 dst[(((size_t)t * (J / 4) + j / 4) * 64 + lane) * 4 + (j & 3)] = frag[((size_t)j * 64 + lane) * NT + t];
 }
+// 128 x 128 chunk of W (row-major [K][ldw], rows kbase..) -> v_mfma_f32_16x16x4_f32 fragment order of the 16-row cooperative
+// kernels: wave w owns output blocks 2w, 2w+1 (16 features each); k-step (bb, i) contracts the four input features
+// 16 bb + 4 q + i (q = lane >> 4), i.e. register (bb, i) of every lane's row fragment:
+//   dst[(((w*8 + bb)*2 + j)*64 + lane)*4 + i] = W[kbase + 16 bb + 4 (lane>>4) + i][16 (2w + j) + (lane & 15)]
+void pack_chunk16(float* dst, const float* W, int ldw, int kbase) {
+    for (int w = 0; w < 4; ++w)
+        for (int bb = 0; bb < 8; ++bb)
+            for (int j = 0; j < 2; ++j)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int i = 0; i < 4; ++i)
+                        dst[((((size_t)w * 8 + bb) * 2 + j) * 64 + lane) * 4 + i] =
+                            W[(size_t)(kbase + 16 * bb + 4 * (lane >> 4) + i) * ldw + 16 * (2 * w + j) + (lane & 15)];
+}
 // vector of L values (stride between consecutive features = stride) -> table fragment order
 void pack_tab(float* dst, const float* vec, int L, int stride) {
     for (int m = 0; m < L / 8; ++m)
@@ -209,7 +222,8 @@ int alloc_edge_set(mgn_engine* h, int q) {
     const int64_t nte = tiles_or_one(es.ntiles_e), ntn = tiles_or_one(h->ntiles_n);
     struct { DevBuf* b; size_t bytes; } bufs[5] = {
         {&es.P, (size_t)(g.n_own + g.n_halo + 1) * L * 4}, {&es.Q, (size_t)(g.n_own + 1) * L * 4},
-        {&es.Elat, tile_floats(nte, L) * 4}, {&es.AGG, tile_floats(ntn, L) * 4}, {&es.CARRY, (size_t)(2 * nte + 1) * L * 4}};
+        {&es.Elat, tile_floats(nte, L) * 4}, {&es.AGG, tile_floats(ntn, L) * 4}, {&es.CARRY, (size_t)(4 * nte + 1) * L * 4}};
+    // (CARRY: two rows per 32-edge tile, or per 16-edge tile with the 16-row cooperative kernels; its last row stays zero)
     // padding rows of the tile-major arrays and the zero row of CARRY (its last row) must read as 0
     for (auto& b : bufs) {
         HIPCHK(h, b.b->ensure(b.bytes));
@@ -219,7 +233,7 @@ int alloc_edge_set(mgn_engine* h, int q) {
         struct { DevBuf* b; size_t bytes; } bb[5] = {
             {&es.bElat, tile_floats(nte, L) * 2}, {&es.bAGG, tile_floats(ntn, L) * 2},
             {&es.bP, (size_t)(g.n_own + g.n_halo + 1) * L * 2}, {&es.bQ, (size_t)(g.n_own + 1) * L * 2},
-            {&es.bCARRY, (size_t)(2 * nte + 1) * L * 2}};
+            {&es.bCARRY, (size_t)(4 * nte + 1) * L * 2}};
         for (auto& b : bb) {
             HIPCHK(h, b.b->ensure(b.bytes));
             HIPCHK(h, hipMemsetAsync(b.b->p, 0, b.bytes, h->stream));
@@ -303,6 +317,15 @@ void invalidate_static(mgn_engine* h) {
     h->rhs_warm = false;
 }
 
+// 16-row cooperative tiles (v_mfma_f32_16x16x4_f32): both kernels of a processor step must agree (the carry rows are per 16-edge
+// tile then), so the choice is made per handle and graph: fp32, L = 128, hidden_layers = 2, one edge set, and BOTH the edge and the
+// node launches in the cooperative size range
+int32_t use_c16(const mgn_engine* h) {
+    return (coop16_enabled() && h->cfg.dtype == MGN_F32 && h->cfg.L == 128 && h->cfg.hidden_layers == 2 && h->nsets == 1 &&
+            get_kernel_path() != 4 && launch_is_small_edge(h->es[0].ntiles_e) && launch_is_small(h->ntiles_n) &&
+            coop16_size(h->es[0].ntiles_e, h->ntiles_n)) ? 1 : 0;
+}
+
 // GenMlp of an MLP: used when hidden_layers != 2 (or when tests force the GEN kernels, kernel path 4)
 GenMlp gen_of(const mgn_engine* h, const GenOff& g, bool has_last) {
     GenMlp m{};
@@ -332,6 +355,7 @@ EdgeArgs edge_args(mgn_engine* h, int k, int q = 0) {
     }
     a.tabs = W(h, h->soff[k].e_tabs[q]);
     a.gen = gen_of(h, h->soff[k].e_gen[q], true);
+    a.c16 = use_c16(h);
     a.stagger = h->stagger_edge;
     a.tile0 = 0;
     a.stamps = h->d_stamps.as<unsigned long long>();
@@ -373,14 +397,15 @@ NodeArgs node_args(mgn_engine* h, int k, int mode, int q = 0) {
         a.rowptr2 = h->es[1].d_rowptr.as<int32_t>();
         a.AGG2 = h->es[1].AGG.as<float>();
         a.CARRY2 = h->es[1].CARRY.as<float>();
-        a.zero_row2 = 2 * tiles_or_one(h->es[1].ntiles_e);
+        a.zero_row2 = 4 * tiles_or_one(h->es[1].ntiles_e);
         a.chunk[6] = W(h, so.n_ch[6]);
         a.chunk_t[6] = a.chunk[6] + CH;
     }
     a.mode = mode;
     a.gen = gen_of(h, so.n_gen, true);
     a.stagger = h->stagger_node;
-    a.zero_row = 2 * tiles_or_one(h->es[0].ntiles_e);
+    a.zero_row = 4 * tiles_or_one(h->es[0].ntiles_e);
+    a.c16 = use_c16(h);
     a.tile0 = 0;
     return a;
 }
@@ -428,10 +453,10 @@ BfNodeArgs bf_node_args(mgn_engine* h, int k, int q = 0, bool project = false) {
         a.rowptr2 = h->es[1].d_rowptr.as<int32_t>();
         a.AGG2 = h->es[1].bAGG.as<uint16_t>();
         a.CARRY2 = h->es[1].bCARRY.as<uint16_t>();
-        a.zero_row2 = 2 * tiles_or_one(h->es[1].ntiles_e);
+        a.zero_row2 = 4 * tiles_or_one(h->es[1].ntiles_e);
         a.chunk[6] = WB(h, so.n_ch[6]);
     }
-    a.zero_row = 2 * tiles_or_one(h->es[0].ntiles_e);
+    a.zero_row = 4 * tiles_or_one(h->es[0].ntiles_e);
     a.tile0 = 0;
     return a;
 }
@@ -535,20 +560,24 @@ int mgn_set_params(mgn_handle* h, const float* packed, size_t n) try {
     const size_t CH = (size_t)L * L, TB = (size_t)T_COUNT * L;
 
     std::vector<float> f;
-    // every chunk is stored twice: [lane-interleaved fragment order][t-major order] (the latter for the
-    // cooperative small-graph kernels), so the t-major copy of a chunk at offset `off` lives at `off + CH`
+    // every chunk is stored three times: [lane-interleaved fragment order][t-major order (cooperative 32-row kernels)]
+    // [16x16x4 fragment order (cooperative 16-row kernels, L = 128)]: copies of the chunk at offset `off` live at off + CH, off + 2 CH
     auto add_chunk = [&](const float* Wm, int ldw, int kbase) {
         const size_t off = f.size();
-        f.resize(off + 2 * CH);
+        f.resize(off + 3 * CH);
         pack_chunk(f.data() + off, Wm, ldw, kbase, L);
         pack_chunk_tmajor(f.data() + off + CH, f.data() + off, L);
+        if (L == 128) pack_chunk16(f.data() + off + 2 * CH, Wm, ldw, kbase);
         return off;
     };
     auto add_tabs = [&](const float* b1, const float* b2, const float* b3, const float* ga, const float* be, const float* bq) {
         const size_t off = f.size();
-        f.resize(off + TB);
+        f.resize(off + 2 * TB);          // fragment order, then natural feature order (16-row kernels)
         const float* src[T_COUNT] = {b1, b2, b3, ga, be, bq};
-        for (int t = 0; t < T_COUNT; ++t) pack_tab(f.data() + off + (size_t)t * L, src[t], L);
+        for (int t = 0; t < T_COUNT; ++t) {
+            pack_tab(f.data() + off + (size_t)t * L, src[t], L);
+            for (int i = 0; i < L; ++i) f[off + TB + (size_t)t * L + i] = src[t] ? src[t][i] : 0.f;
+        }
         return off;
     };
     auto add_w1f = [&](const float* W1, int K) {  // [K][L] -> per-k fragment tables

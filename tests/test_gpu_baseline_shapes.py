@@ -39,7 +39,7 @@ def mcyl():
     return dict(pos=pos, s=s, r=r, ntype=ntype, vel=vel, cfg=cfg, ps=ps, v=v, e=e, rv=rv, re=re)
 
 
-@pytest.mark.parametrize("path", [0, 1, 2, 3], ids=["auto", "resident", "streaming", "cooperative"])
+@pytest.mark.parametrize("path", [0, 1, 2, 3, 5], ids=["auto", "resident", "streaming", "cooperative", "cooperative16"])
 def test_mcyl_15_steps_fp32_every_kernel_family(mcyl, path):
     old = set_kernel_path(path)
     try:

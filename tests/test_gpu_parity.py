@@ -12,7 +12,7 @@ from mgn_amd import synth
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(params=[1, 2, 3], ids=["resident", "streaming", "cooperative"])
+@pytest.fixture(params=[1, 2, 3, 5], ids=["resident", "streaming", "cooperative", "cooperative16"])
 def kernel_path(request):
     """Every L = 128 kernel family must meet the same tolerance on the same inputs (auto-selection would send all
     of these small graphs to the cooperative kernels only)."""
