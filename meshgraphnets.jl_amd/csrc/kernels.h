@@ -65,6 +65,7 @@ struct NodeArgs {
     int32_t tile0;          // k_project only: first tile of the range [tile0, tile0 + ntiles)
     GenMlp gen;
     int32_t c16;            // see EdgeArgs
+    unsigned long long* stamps;  // diagnostic builds only (MGN_DIAG_STAMPS), else null
 };
 
 struct EncNodeArgs {
@@ -153,6 +154,7 @@ bool launch_is_small(int ntiles);
 bool launch_is_small_edge(int ntiles_e);   // the same rule for edge launches (<= 16 tiles per CU)
 int coop16_enabled();
 bool coop16_size(int ntiles_e, int ntiles_n);   // the launch wrappers' rule for the cooperative node kernels (<= 8 tiles per CU)
+int set_c16_row_tiles(int rt);  // debug/tests: 16-edge tiles per block of the small-graph edge kernel (0: chosen by size); returns the old value
 int set_kernel_path(int p);   // debug/tests: 0 auto, 1 resident, 2 streaming, 3 cooperative, 4 GEN (general hidden_layers) kernels; returns the old value
 int get_kernel_path();
 hipError_t launch_edge_step(int L, const EdgeArgs& a, hipStream_t s);

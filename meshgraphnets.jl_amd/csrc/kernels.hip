@@ -56,8 +56,19 @@ DEVINL void stagger_second_half(int wave, int units) {
         if (a.stamps && blockIdx.x < 4 && stamp_tile < 24 && lane0 == 0)                         \
             a.stamps[(((size_t)blockIdx.x * 8 + wave) * 24 + stamp_tile) * 8 + (slot)] = _t;     \
     } while (0)
+// 16-row cooperative kernels: one half tile per block, 1024 blocks x 4 waves x 8 slots
+#define STAMP16(slot)                                                                            \
+    do {                                                                                         \
+        __builtin_amdgcn_sched_barrier(0);                                                       \
+        unsigned long long _t;                                                                   \
+        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t)::"memory");              \
+        __builtin_amdgcn_sched_barrier(0);                                                       \
+        if (a.stamps && blockIdx.x < 1024 && lane0 == 0)                                         \
+            a.stamps[((size_t)blockIdx.x * 4 + wave) * 8 + (slot)] = _t;                         \
+    } while (0)
 #else
 #define STAMP(slot) do {} while (0)
+#define STAMP16(slot) do {} while (0)
 #endif
 
 template <int CTRL, int ROWMASK>
@@ -638,7 +649,11 @@ __global__ __launch_bounds__(256, 2) void k_node_coop(const NodeArgs a) {
 // (EdgeArgs.c16: the edge and the node kernel of a step agree).
 // ================================================================================================
 constexpr int C16_CH = 128 * 128;          // floats per chunk copy
+#ifdef MGN_EXP_C16_NOMFMA       // experiment: one VALU op in place of each MFMA (wrong results; the non-MFMA floor of the kernels)
+DEVINL f32x4 c16_mfma(float a, float b, f32x4 c) { c[0] = __builtin_fmaf(a, b, c[0]); return c; }
+#else
 DEVINL f32x4 c16_mfma(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+#endif
 // float4 index of (feature block bb, lane group q) of row `row` of tile `tile` in 32-row tile-major storage
 DEVINL int64_t c16_tile_idx(int64_t tile, int row, int bb, int q) {
     const int o = 16 * (bb & 1) + 4 * q;
@@ -667,12 +682,34 @@ DEVINL void c16_prime(C16Ring& g, const float* wt, int lane) {
 #pragma unroll
     for (int p = 0; p < 2 * C16_PF; ++p) g.r[p] = wv[p * 64];
 }
+#ifdef MGN_EXP_C16_NOPS     // experiment: idle cycles after each MFMA, so that the next one does not wait in the issue stage
+#define C16_YIELD                                          \
+    do {                                                   \
+        __builtin_amdgcn_sched_barrier(0);                 \
+        asm volatile("s_nop %0" ::"n"(MGN_EXP_C16_NOPS));  \
+        __builtin_amdgcn_sched_barrier(0);                 \
+    } while (0)
+#else
+#define C16_YIELD do {} while (0)
+#endif
+#ifdef MGN_EXP_C16_PRIO     // experiment: waves outside their MFMA chains win issue arbitration
+#define C16_PRIO_HI __builtin_amdgcn_s_setprio(3)
+#define C16_PRIO_LO __builtin_amdgcn_s_setprio(0)
+#else
+#define C16_PRIO_HI do {} while (0)
+#define C16_PRIO_LO do {} while (0)
+#endif
 DEVINL void c16_chain_primed(f32x4 (&acc)[2], const f32x4 (&x)[8], const float* wt, int lane, C16Ring& g) {
     const f32x4* wv = reinterpret_cast<const f32x4*>(wt) + lane;
+    C16_PRIO_LO;
 #pragma unroll
     for (int bb = 0; bb < 8; ++bb) {
         const f32x4 c0 = g.r[(2 * bb) % (2 * C16_PF)], c1 = g.r[(2 * bb + 1) % (2 * C16_PF)];
+#ifdef MGN_EXP_C16_NOW          // experiment: no weight refills (wrong results; bounds what the weight traffic costs)
+        if (false) {
+#else
         if (bb + C16_PF < 8) {
+#endif
             g.r[(2 * bb) % (2 * C16_PF)] = wv[(2 * (bb + C16_PF)) * 64];
             g.r[(2 * bb + 1) % (2 * C16_PF)] = wv[(2 * (bb + C16_PF) + 1) * 64];
         }
@@ -680,10 +717,13 @@ DEVINL void c16_chain_primed(f32x4 (&acc)[2], const f32x4 (&x)[8], const float* 
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             acc[0] = c16_mfma(c0[i], x[bb][i], acc[0]);
+            C16_YIELD;
             acc[1] = c16_mfma(c1[i], x[bb][i], acc[1]);
+            C16_YIELD;
         }
         __builtin_amdgcn_sched_barrier(0);
     }
+    C16_PRIO_HI;
 }
 DEVINL void c16_chain(f32x4 (&acc)[2], const f32x4 (&x)[8], const float* wt, int lane) {
     C16Ring g;
@@ -764,6 +804,8 @@ __global__ __launch_bounds__(256, 2) void k_edge_coop16(const EdgeArgs a) {
     const float* w3 = a.chunk[1] + 2 * C16_CH + wave * 4096;
     const int ht0 = 2 * a.tile0, nht = 2 * a.ntiles;
     for (int hi = blockIdx.x; hi < nht; hi += gridDim.x) {
+        STAMP16(0);
+        C16_PRIO_HI;
         int lane = lane0;
         asm volatile("" : "+v"(lane));      // keeps the (loop-invariant) weight and table loads inside the loop: hoisted, they spill
         const int n = lane & 15, q = lane >> 4;
@@ -773,16 +815,24 @@ __global__ __launch_bounds__(256, 2) void k_edge_coop16(const EdgeArgs a) {
         const int64_t eid = e0 + n;
         const bool valid = eid < a.E;
         const int64_t ec = valid ? eid : a.E - 1;
+#ifdef MGN_EXP_C16_NOGATHER     // experiment: P / Q rows that do not depend on the index loads (wrong results)
+        const int r_ = a.rcv[ec];
+        const int s_ = (int)(ec & 1023);
+#define C16_QROW (int)((ec + 7) & 1023)
+#else
         const int s_ = a.snd[ec], r_ = a.rcv[ec];
+#define C16_QROW r_
+#endif
         const int r_before = ht > 0 ? a.rcv[e0 - 1] : -2;
         const int r_after = (e0 + 16 < a.E) ? a.rcv[e0 + 16] : -3;
         const int64_t tile = ht >> 1;
         const int row = 16 * (ht & 1) + n;
         f32x4 x[8], full[8], acc[2];
         c16_load_tile_row(x, a.Elat, tile, row, q);
+        STAMP16(1);
         {   // layer-1 accumulator: P[s] + Q[r] (carry b1), this wave's blocks
             const f32x4* P4 = reinterpret_cast<const f32x4*>(a.P) + (int64_t)s_ * 32 + q;
-            const f32x4* Q4 = reinterpret_cast<const f32x4*>(a.Q) + (int64_t)r_ * 32 + q;
+            const f32x4* Q4 = reinterpret_cast<const f32x4*>(a.Q) + (int64_t)C16_QROW * 32 + q;
             acc[0] = P4[4 * (2 * wave)] + Q4[4 * (2 * wave)];
             acc[1] = P4[4 * (2 * wave + 1)] + Q4[4 * (2 * wave + 1)];
         }
@@ -790,18 +840,23 @@ __global__ __launch_bounds__(256, 2) void k_edge_coop16(const EdgeArgs a) {
         c16_prime(g1, w1, lane);
         c16_prime(g2, w2, lane);                                     // layer 2's first fragments, a chain ahead
         __builtin_amdgcn_sched_barrier(0);
+        STAMP16(2);
         c16_chain_primed(acc, x, w1, lane, g1);                      // layer 1 (edge part)
+        STAMP16(3);
         c16_relu(acc);
         c16_prime(g1, w3, lane);
         c16_exchange(full, acc, xch0, wave, lane);
+        STAMP16(4);
         c16_tab(acc, tabs + T_B2 * L, wave, q);
         c16_chain_primed(acc, full, w2, lane, g2);                   // layer 2
         c16_relu(acc);
         c16_exchange(full, acc, xch1, wave, lane);
         c16_tab(acc, tabs + T_B3 * L, wave, q);
         c16_chain_primed(acc, full, w3, lane, g1);                   // layer 3
+        STAMP16(5);
         c16_exchange(full, acc, xch0, wave, lane);                   // full pre-LN row (for the statistics)
         c16_layer_norm(acc, full, tabs + T_GAMMA * L, tabs + T_BETA * L, wave, q);   // acc = this wave's slice of e'
+        STAMP16(6);
         if (valid) {                                                 // e <- e + e'
             f32x4* E4 = reinterpret_cast<f32x4*>(a.Elat);
             f32x4 xs[2];
@@ -844,7 +899,201 @@ __global__ __launch_bounds__(256, 2) void k_edge_coop16(const EdgeArgs a) {
                 A4[c16_tile_idx(r_ >> 5, r_ & 31, 2 * wave + 1, q)] = acc[1];
             }
         }
+        STAMP16(7);
         __syncthreads();   // xch0 is rewritten by the next half tile's first exchange
+    }
+}
+
+// ---- RT consecutive 16-edge tiles per block -----------------------------------------------------------------------------------
+// Stamps of k_edge_coop16 on the cylinder mesh (tools/diag_stamps16.py): with three one-tile blocks on a CU the second and third
+// cannot even issue their first loads before 2-3 / 6-9 us -- every wave streams its own copy of the weights (48 KB per wave and
+// tile, 0.94 MB per CU and launch through a 64 B / clk texture path), and without its MFMAs the kernel still takes 12 us.  Here a
+// wave keeps RT row tiles: every weight fragment it fetches feeds 2 RT independent MFMAs (a third of the weight traffic at RT = 3,
+// no dependent MFMA pairs), one block per CU, and the exchange barriers are shared by the RT tiles.
+template <int RT>
+DEVINL void c16m_chain(f32x4 (&acc)[RT][2], const f32x4 (&x)[RT][8], const float* wt, int lane, C16Ring& g) {
+    const f32x4* wv = reinterpret_cast<const f32x4*>(wt) + lane;
+#pragma unroll
+    for (int bb = 0; bb < 8; ++bb) {
+        const f32x4 c0 = g.r[(2 * bb) % (2 * C16_PF)], c1 = g.r[(2 * bb + 1) % (2 * C16_PF)];
+        if (bb + C16_PF < 8) {
+            g.r[(2 * bb) % (2 * C16_PF)] = wv[(2 * (bb + C16_PF)) * 64];
+            g.r[(2 * bb + 1) % (2 * C16_PF)] = wv[(2 * (bb + C16_PF) + 1) * 64];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int t = 0; t < RT; ++t) {
+                acc[t][0] = c16_mfma(c0[i], x[t][bb][i], acc[t][0]);
+                acc[t][1] = c16_mfma(c1[i], x[t][bb][i], acc[t][1]);
+            }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+template <int RT>
+DEVINL void c16m_exchange(f32x4 (&full)[RT][8], const f32x4 (&mine)[RT][2], f32x4* xch, int wave, int lane) {
+#pragma unroll
+    for (int t = 0; t < RT; ++t) {
+        xch[(t * 8 + 2 * wave) * 64 + lane] = mine[t][0];
+        xch[(t * 8 + 2 * wave + 1) * 64 + lane] = mine[t][1];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < RT; ++t)
+#pragma unroll
+        for (int bb = 0; bb < 8; ++bb) full[t][bb] = xch[(t * 8 + bb) * 64 + lane];
+}
+// LayerNorm with the wave's gamma / beta slices already in registers
+DEVINL void c16_layer_norm_tab(f32x4 (&mine)[2], const f32x4 (&full)[8], const f32x4 (&g)[2], const f32x4 (&b)[2]) {
+    float s = 0.f;
+#pragma unroll
+    for (int bb = 0; bb < 8; ++bb)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) s += full[bb][i];
+    s += __shfl_xor(s, 16, 64);
+    s += __shfl_xor(s, 32, 64);
+    const float mean = s * (1.0f / 128);
+    float v = 0.f;
+#pragma unroll
+    for (int bb = 0; bb < 8; ++bb)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float d = full[bb][i] - mean;
+            v += d * d;
+        }
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+    const float rstd = 1.0f / sqrtf(v * (1.0f / 128) + LN_EPS);
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) mine[j][i] = (mine[j][i] - mean) * rstd * g[j][i] + b[j][i];
+}
+
+template <int RT>
+__global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_edge_coop16m(const EdgeArgs a) {
+    constexpr int L = 128;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    f32x4* xch0 = reinterpret_cast<f32x4*>(smem);
+    f32x4* xch1 = xch0 + RT * 8 * 64;
+    const int lane0 = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const float* tabs = a.tabs + T_COUNT * L;                       // natural feature order
+    const float* w1 = a.chunk[2] + 2 * C16_CH + wave * 4096;
+    const float* w2 = a.chunk[0] + 2 * C16_CH + wave * 4096;
+    const float* w3 = a.chunk[1] + 2 * C16_CH + wave * 4096;
+    const int ht0 = 2 * a.tile0, nht = 2 * a.ntiles;
+    const int ngroups = (nht + RT - 1) / RT;
+    for (int gi = blockIdx.x; gi < ngroups; gi += gridDim.x) {
+        int lane = lane0;
+        asm volatile("" : "+v"(lane));      // keeps the (loop-invariant) weight and table loads inside the loop: hoisted, they spill
+        const int n = lane & 15, q = lane >> 4;
+        if ((int64_t)(ht0 + gi * RT) * 16 >= a.E) break;            // nothing but the empty tail of the last 32-row tile
+        int ht[RT], s_[RT], r_[RT], r_before[RT], r_after[RT], row[RT];
+        int64_t tile[RT];
+        bool valid[RT];
+#pragma unroll
+        for (int t = 0; t < RT; ++t) {
+            ht[t] = ht0 + gi * RT + t;
+            const int64_t e0 = (int64_t)ht[t] * 16;
+            const bool live = (gi * RT + t < nht) && e0 < a.E;      // block-uniform; a dead tile computes on clamped rows, stores nothing
+            const int64_t eid = e0 + n;
+            valid[t] = live && eid < a.E;
+            const int64_t ec = valid[t] ? eid : a.E - 1;
+            s_[t] = a.snd[ec];
+            r_[t] = a.rcv[ec];
+            r_before[t] = (live && ht[t] > 0) ? a.rcv[e0 - 1] : -2;
+            r_after[t] = (e0 + 16 < a.E) ? a.rcv[e0 + 16] : -3;
+            const int htc = live ? ht[t] : ht0 + gi * RT;
+            tile[t] = htc >> 1;
+            row[t] = 16 * (htc & 1) + n;
+        }
+        f32x4 x[RT][8], acc[RT][2], xs[RT][2];
+#pragma unroll
+        for (int t = 0; t < RT; ++t) {
+            c16_load_tile_row(x[t], a.Elat, tile[t], row[t], q);
+            // the residual's slice, as loads of its own (a pick out of x by the wave id becomes a scratch array)
+            const f32x4* E4 = reinterpret_cast<const f32x4*>(a.Elat);
+            xs[t][0] = E4[c16_tile_idx(tile[t], row[t], 2 * wave, q)];
+            xs[t][1] = E4[c16_tile_idx(tile[t], row[t], 2 * wave + 1, q)];
+        }
+#pragma unroll
+        for (int t = 0; t < RT; ++t) {      // layer-1 accumulator: P[s] + Q[r] (carry b1), this wave's blocks
+            const f32x4* P4 = reinterpret_cast<const f32x4*>(a.P) + (int64_t)s_[t] * 32 + q;
+            const f32x4* Q4 = reinterpret_cast<const f32x4*>(a.Q) + (int64_t)r_[t] * 32 + q;
+            acc[t][0] = P4[4 * (2 * wave)] + Q4[4 * (2 * wave)];
+            acc[t][1] = P4[4 * (2 * wave + 1)] + Q4[4 * (2 * wave + 1)];
+        }
+        f32x4 tb2[2], tb3[2], tg[2], tb[2];                          // one wave per SIMD: no table request behind a barrier
+        c16_tab(tb2, tabs + T_B2 * L, wave, q);
+        c16_tab(tb3, tabs + T_B3 * L, wave, q);
+        c16_tab(tg, tabs + T_GAMMA * L, wave, q);
+        c16_tab(tb, tabs + T_BETA * L, wave, q);
+        C16Ring g1, g2;
+        c16_prime(g1, w1, lane);
+        c16_prime(g2, w2, lane);                                     // layer 2's first fragments, a chain ahead
+        __builtin_amdgcn_sched_barrier(0);
+        c16m_chain<RT>(acc, x, w1, lane, g1);                        // layer 1 (edge part)
+#pragma unroll
+        for (int t = 0; t < RT; ++t) c16_relu(acc[t]);
+        c16_prime(g1, w3, lane);
+        c16m_exchange<RT>(x, acc, xch0, wave, lane);                 // x becomes the exchange result from here on
+#pragma unroll
+        for (int t = 0; t < RT; ++t) { acc[t][0] = tb2[0]; acc[t][1] = tb2[1]; }
+        c16m_chain<RT>(acc, x, w2, lane, g2);                        // layer 2
+#pragma unroll
+        for (int t = 0; t < RT; ++t) c16_relu(acc[t]);
+        c16m_exchange<RT>(x, acc, xch1, wave, lane);
+#pragma unroll
+        for (int t = 0; t < RT; ++t) { acc[t][0] = tb3[0]; acc[t][1] = tb3[1]; }
+        c16m_chain<RT>(acc, x, w3, lane, g1);                        // layer 3
+        c16m_exchange<RT>(x, acc, xch0, wave, lane);                 // full pre-LN rows (for the statistics)
+#pragma unroll
+        for (int t = 0; t < RT; ++t) {
+            c16_layer_norm_tab(acc[t], x[t], tg, tb);                // acc = this wave's slice of e'
+            if (valid[t]) {                                          // e <- e + e'
+                f32x4* E4 = reinterpret_cast<f32x4*>(a.Elat);
+                E4[c16_tile_idx(tile[t], row[t], 2 * wave, q)] = xs[t][0] + acc[t][0];
+                E4[c16_tile_idx(tile[t], row[t], 2 * wave + 1, q)] = xs[t][1] + acc[t][1];
+            }
+            // segmented sum over runs of equal receiver within the 16-edge tile (as in k_edge_coop16)
+            const int reff = valid[t] ? r_[t] : (-4 - n);
+            const int rprev = __shfl_up(reff, 1, 16);
+            const int rnext = __shfl_down(reff, 1, 16);
+            const bool head = (n == 0) || (reff != rprev);
+            const unsigned hm = (unsigned)(__ballot(head) & 0xFFFFull);
+            const int start = 31 - __clz((int)(hm & (0xFFFFu >> (15 - n))));
+            const float m1 = (n - 1 >= start) ? 1.f : 0.f, m2 = (n - 2 >= start) ? 1.f : 0.f, m4 = (n - 4 >= start) ? 1.f : 0.f,
+                        m8 = (n - 8 >= start) ? 1.f : 0.f;
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    float v = acc[t][j][i];
+                    v = __builtin_fmaf(dpp_zero<0x111, 0xF>(v), m1, v);
+                    v = __builtin_fmaf(dpp_zero<0x112, 0xF>(v), m2, v);
+                    v = __builtin_fmaf(dpp_zero<0x114, 0xF>(v), m4, v);
+                    v = __builtin_fmaf(dpp_zero<0x118, 0xF>(v), m8, v);
+                    acc[t][j][i] = v;
+                }
+            const bool tail = valid[t] && ((n == 15) || (reff != rnext));
+            const int r_first = __builtin_amdgcn_readfirstlane(reff);
+            const bool sl = (start == 0) && (r_before[t] == r_first);   // run continues from the previous 16-edge tile
+            const bool sr = (n == 15) && (r_after[t] == reff);          // run continues into the next one
+            if (tail) {
+                if (sl || sr) {
+                    f32x4* C4 = reinterpret_cast<f32x4*>(a.CARRY) + ((int64_t)2 * ht[t] + (sl ? 0 : 1)) * 32 + q;
+                    C4[4 * (2 * wave)] = acc[t][0];
+                    C4[4 * (2 * wave + 1)] = acc[t][1];
+                } else {
+                    f32x4* A4 = reinterpret_cast<f32x4*>(a.AGG);
+                    A4[c16_tile_idx(r_[t] >> 5, r_[t] & 31, 2 * wave, q)] = acc[t][0];
+                    A4[c16_tile_idx(r_[t] >> 5, r_[t] & 31, 2 * wave + 1, q)] = acc[t][1];
+                }
+            }
+        }
+        __syncthreads();   // xch0 is rewritten by the next group's first exchange
     }
 }
 
@@ -860,6 +1109,7 @@ __global__ __launch_bounds__(256, 2) void k_node_coop16(const NodeArgs a) {
     auto wt = [&](int ch) { return a.chunk[ch] + 2 * C16_CH + wave * 4096; };
     const int ht0 = 2 * a.tile0, nht = 2 * a.ntiles;
     for (int hi = blockIdx.x; hi < nht; hi += gridDim.x) {
+        STAMP16(0);
         int lane = lane0;
         asm volatile("" : "+v"(lane));
         const int n = lane & 15, q = lane >> 4;
@@ -892,20 +1142,25 @@ __global__ __launch_bounds__(256, 2) void k_node_coop16(const NodeArgs a) {
             c16_prime(gb, wt(3), lane);
             c16_tab(acc, tabs + T_B1 * L, wave, q);
             __builtin_amdgcn_sched_barrier(0);
+            STAMP16(1);
             c16_chain_primed(acc, v, wt(2), lane, ga);               // layer 1, node part
+            STAMP16(2);
             c16_prime(ga, wt(0), lane);
             c16_chain_primed(acc, full, wt(3), lane, gb);            // layer 1, aggregate part
+            STAMP16(3);
             c16_relu(acc);
             c16_prime(gb, wt(1), lane);
             c16_exchange(full, acc, xch0, wave, lane);
             c16_tab(acc, tabs + T_B2 * L, wave, q);
             c16_chain_primed(acc, full, wt(0), lane, ga);            // layer 2
+            STAMP16(4);
             c16_relu(acc);
             c16_exchange(full, acc, xch1, wave, lane);
             c16_tab(acc, tabs + T_B3 * L, wave, q);
             c16_chain_primed(acc, full, wt(1), lane, gb);            // layer 3
             c16_exchange(full, acc, xch0, wave, lane);
             c16_layer_norm(acc, full, tabs + T_GAMMA * L, tabs + T_BETA * L, wave, q);
+            STAMP16(5);
             {
                 f32x4 vs[2];
                 c16_pick(vs, v, wave);
@@ -918,6 +1173,7 @@ __global__ __launch_bounds__(256, 2) void k_node_coop16(const NodeArgs a) {
                 V4[c16_tile_idx(tile, row, 2 * wave + 1, q)] = acc[1];
             }
             if (a.mode == 1) c16_exchange(v, acc, xch1, wave, lane); // full updated row for the projection
+            STAMP16(6);
         }
         if (a.mode != 0) {                                           // P = v W1s, Q = v W1r + b1 of the next step
             f32x4 o[2];
@@ -939,6 +1195,7 @@ __global__ __launch_bounds__(256, 2) void k_node_coop16(const NodeArgs a) {
                 Q4[4 * (2 * wave + 1)] = o[1];
             }
         }
+        STAMP16(7);
         __syncthreads();
     }
 }
@@ -2236,6 +2493,8 @@ static int resident_chunks(int L, int want) {
 // (tests exercise every path on small graphs through mgn_debug_kernel_path)
 static int g_path = [] { const char* e = getenv("MGN_KERNEL_PATH"); return e ? atoi(e) : 0; }();   // experiments
 int set_kernel_path(int p) { const int old = g_path; g_path = p; return old; }
+static int g_c16_rt = [] { const char* e = getenv("MGN_C16_RT"); return e ? atoi(e) : 0; }();   // 0: by size; 1..3: 16-edge tiles per block
+int set_c16_row_tiles(int rt) { const int old = g_c16_rt; g_c16_rt = rt; return old; }
 int get_kernel_path() { return g_path; }
 static bool small_launch(int ntiles) { return g_path == 0 ? ntiles <= 4 * num_cus() : g_path >= 2; }
 // cooperative (4 waves per tile) kernels: up to this many tiles per CU for the edge / node kernels (size sweep)
@@ -2340,7 +2599,13 @@ hipError_t launch_edge_step(int L, const EdgeArgs& a, hipStream_t s) {
     const int nres = resident_chunks(L, 3);
     LaunchCfg lc = tile_launch(L, a.ntiles, nres);
     if (a.c16 && L == 128 && a.chunk_t[0]) {        // small graph: 16-row tiles, 4 waves each (the handle decided for both kernels)
-        LaunchCfg c16{2 * a.ntiles, 256, (size_t)2 * 8 * 64 * 16};
+        // RT 16-edge tiles per block: about one block per CU (MGN_C16_RT = 1..3 pins it)
+        const int nht = 2 * a.ntiles;
+        int rt = g_c16_rt ? g_c16_rt : (nht + num_cus() - 1) / num_cus();
+        rt = rt < 1 ? 1 : (rt > 3 ? 3 : rt);
+        LaunchCfg c16{(nht + rt - 1) / rt, 256, (size_t)rt * 2 * 8 * 64 * 16};
+        if (rt == 3) return launch_k(k_edge_coop16m<3>, a, c16, s);
+        if (rt == 2) return launch_k(k_edge_coop16m<2>, a, c16, s);
         return launch_k(k_edge_coop16, a, c16, s);
     }
     if (coop_ok(L, a.ntiles, a.chunk_t, true)) {   // small graph: 4 waves per tile

@@ -406,6 +406,7 @@ NodeArgs node_args(mgn_engine* h, int k, int mode, int q = 0) {
     a.stagger = h->stagger_node;
     a.zero_row = 4 * tiles_or_one(h->es[0].ntiles_e);
     a.c16 = use_c16(h);
+    a.stamps = h->d_stamps.as<unsigned long long>();
     a.tile0 = 0;
     return a;
 }
@@ -2218,13 +2219,26 @@ int mgn_halo_exchange_host(mgn_handle* h, const float* own_rows, float* halo_row
 // Process-wide kernel-path override for tests (not part of the public header): 0 auto, 1 LDS-resident persistent
 // kernels, 2 all-streaming, 3 cooperative 4-wave tiles.  Returns the previous value.
 int mgn_debug_kernel_path(int path) { return set_kernel_path(path); }
+int mgn_debug_c16_row_tiles(int rt) { return set_c16_row_tiles(rt); }
 
-int mgn_debug_edge_stamps(mgn_handle* h, int32_t k, unsigned long long* out /* [4*8*24*8] */) try {
+int mgn_debug_edge_stamps(mgn_handle* h, int32_t k, unsigned long long* out /* [32768] */) try {
     if (int rc = need(h, true, true)) return rc;
-    const size_t n = (size_t)4 * 8 * 24 * 8;
+    const size_t n = 32768;
     HIPCHK(h, h->d_stamps.ensure(n * 8));
     HIPCHK(h, hipMemsetAsync(h->d_stamps.p, 0, n * 8, h->stream));
     if (int rc = mgn_proc_edge(h, k)) return rc;
+    HIPCHK(h, hipMemcpyAsync(out, h->d_stamps.p, n * 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    h->d_stamps.release();
+    return MGN_OK;
+} MGN_CATCH(h)
+
+int mgn_debug_node_stamps(mgn_handle* h, int32_t k, unsigned long long* out /* [32768] */) try {
+    if (int rc = need(h, true, true)) return rc;
+    const size_t n = 32768;
+    HIPCHK(h, h->d_stamps.ensure(n * 8));
+    HIPCHK(h, hipMemsetAsync(h->d_stamps.p, 0, n * 8, h->stream));
+    if (int rc = mgn_proc_node(h, k, 1)) return rc;
     HIPCHK(h, hipMemcpyAsync(out, h->d_stamps.p, n * 8, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     h->d_stamps.release();

@@ -15,7 +15,7 @@ import torch   # noqa: F401  (before the engine's first HIP call)
 
 import mgn_oracle as orc
 from mgn_amd import synth
-from util import TOL_15, TOL_ROLLOUT, cfg_dict, engine_for, make_params, rel_max, set_kernel_path
+from util import TOL_15, TOL_ROLLOUT, cfg_dict, engine_for, make_params, rel_max, set_c16_row_tiles, set_kernel_path
 
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
@@ -39,9 +39,11 @@ def mcyl():
     return dict(pos=pos, s=s, r=r, ntype=ntype, vel=vel, cfg=cfg, ps=ps, v=v, e=e, rv=rv, re=re)
 
 
-@pytest.mark.parametrize("path", [0, 1, 2, 3, 5], ids=["auto", "resident", "streaming", "cooperative", "cooperative16"])
+@pytest.mark.parametrize("path", [0, 1, 2, 3, 5, (5, 1), (5, 2), (5, 3)],
+                         ids=["auto", "resident", "streaming", "cooperative", "cooperative16", "cooperative16x1", "cooperative16x2", "cooperative16x3"])
 def test_mcyl_15_steps_fp32_every_kernel_family(mcyl, path):
-    old = set_kernel_path(path)
+    path, rt = path if isinstance(path, tuple) else (path, 0)
+    old, old_rt = set_kernel_path(path), set_c16_row_tiles(rt)
     try:
         m = mcyl
         eng = engine_for(m["cfg"])
@@ -61,6 +63,7 @@ def test_mcyl_15_steps_fp32_every_kernel_family(mcyl, path):
         assert np.array_equal(v2, v1) and np.array_equal(e2, e1) and np.array_equal(v3, v1) and np.array_equal(e3, e1)
     finally:
         set_kernel_path(old)
+        set_c16_row_tiles(old_rt)
 
 
 def test_mcyl_15_steps_bf16_band(mcyl):

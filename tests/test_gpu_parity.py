@@ -12,14 +12,15 @@ from mgn_amd import synth
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(params=[1, 2, 3, 5], ids=["resident", "streaming", "cooperative", "cooperative16"])
+@pytest.fixture(params=[1, 2, 3, 5, (5, 2), (5, 3)], ids=["resident", "streaming", "cooperative", "cooperative16", "cooperative16x2", "cooperative16x3"])
 def kernel_path(request):
-    """Every L = 128 kernel family must meet the same tolerance on the same inputs (auto-selection would send all
-    of these small graphs to the cooperative kernels only)."""
-    from util import set_kernel_path
-    old = set_kernel_path(request.param)
+    """every kernel family; (5, rt): the 16-row cooperative kernels with rt 16-edge tiles per block of the edge kernel"""
+    from util import set_c16_row_tiles, set_kernel_path
+    path, rt = request.param if isinstance(request.param, tuple) else (request.param, 0)
+    old, old_rt = set_kernel_path(path), set_c16_row_tiles(rt)
     yield request.param
     set_kernel_path(old)
+    set_c16_row_tiles(old_rt)
 
 
 @pytest.mark.parametrize("L", [128, 64, 32])

@@ -47,3 +47,11 @@ def set_kernel_path(path):
     lib.mgn_debug_kernel_path.restype = __import__("ctypes").c_int
     lib.mgn_debug_kernel_path.argtypes = [__import__("ctypes").c_int]
     return lib.mgn_debug_kernel_path(path)
+
+
+def set_c16_row_tiles(rt):
+    """16-edge tiles per block of the small-graph edge kernel (tests only): 0 chosen by size, 1..3 pinned.  Returns the old value."""
+    lib = mgn_amd.load()
+    lib.mgn_debug_c16_row_tiles.restype = __import__("ctypes").c_int
+    lib.mgn_debug_c16_row_tiles.argtypes = [__import__("ctypes").c_int]
+    return lib.mgn_debug_c16_row_tiles(rt)

@@ -23,7 +23,7 @@ for r in range(rounds):
         if not line:
             print(n, "FAILED", out[-300:]); continue
         d = json.loads(line[-1]); rf = d["roofline"]
-        res[n].append((rf["avg_launch_ms"], rf["node_kernel"]["avg_launch_ms"], d["ms_per_processor_step"]))
+        res[n].append((rf["avg_launch_ms"], (rf.get("node_side") or rf.get("node_kernel"))["avg_launch_ms"], d["ms_per_processor_step"]))
 for n in names:
     if res[n]:
         e = sorted(x[0] for x in res[n]); nd = sorted(x[1] for x in res[n]); st = sorted(x[2] for x in res[n])

@@ -1,6 +1,6 @@
 #!/bin/bash
 # same-box A/B of library variants on the cylinder-sized mesh (N = 2000 Delaunay, fp32):  bash tools/ab_small.sh <variant.so|main> ...
-for rep in 1 2; do
+for rep in 1; do
 for v in "$@"; do
   if [ "$v" = main ]; then unset MGN_LIB_PATH; else export MGN_LIB_PATH=$v; fi
   python - <<PY
