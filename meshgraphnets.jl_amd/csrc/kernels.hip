@@ -655,9 +655,9 @@ DEVINL f32x4 c16_mfma(float a, float b, f32x4 c) { c[0] = __builtin_fmaf(a, b, c
 DEVINL f32x4 c16_mfma(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 #endif
 // float4 index of (feature block bb, lane group q) of row `row` of tile `tile` in 32-row tile-major storage
+// (feature o = 16 bb + 4 q sits in piece o >> 3, half (o >> 2) & 1 of the 32-row tile: written so that bb is a constant offset)
 DEVINL int64_t c16_tile_idx(int64_t tile, int row, int bb, int q) {
-    const int o = 16 * (bb & 1) + 4 * q;
-    return tile * 1024 + (int64_t)(4 * (bb >> 1) + (o >> 3)) * 64 + 32 * ((o >> 2) & 1) + row;
+    return (tile * 1024 + (q >> 1) * 64 + 32 * (q & 1) + row) + 128 * bb;
 }
 DEVINL void c16_load_tile_row(f32x4 (&x)[8], const float* base, int64_t tile, int row, int q) {
     const f32x4* p = reinterpret_cast<const f32x4*>(base);
@@ -910,11 +910,11 @@ __global__ __launch_bounds__(256, 2) void k_edge_coop16(const EdgeArgs a) {
 // tile, 0.94 MB per CU and launch through a 64 B / clk texture path), and without its MFMAs the kernel still takes 12 us.  Here a
 // wave keeps RT row tiles: every weight fragment it fetches feeds 2 RT independent MFMAs (a third of the weight traffic at RT = 3,
 // no dependent MFMA pairs), one block per CU, and the exchange barriers are shared by the RT tiles.
-template <int RT>
+template <int RT, int B0 = 0, int B1 = 8>          // k-groups [B0, B1) of the chunk (the ring carries over between the parts)
 DEVINL void c16m_chain(f32x4 (&acc)[RT][2], const f32x4 (&x)[RT][8], const float* wt, int lane, C16Ring& g) {
     const f32x4* wv = reinterpret_cast<const f32x4*>(wt) + lane;
 #pragma unroll
-    for (int bb = 0; bb < 8; ++bb) {
+    for (int bb = B0; bb < B1; ++bb) {
         const f32x4 c0 = g.r[(2 * bb) % (2 * C16_PF)], c1 = g.r[(2 * bb + 1) % (2 * C16_PF)];
         if (bb + C16_PF < 8) {
             g.r[(2 * bb) % (2 * C16_PF)] = wv[(2 * (bb + C16_PF)) * 64];
@@ -971,12 +971,61 @@ DEVINL void c16_layer_norm_tab(f32x4 (&mine)[2], const f32x4 (&full)[8], const f
         for (int i = 0; i < 4; ++i) mine[j][i] = (mine[j][i] - mean) * rstd * g[j][i] + b[j][i];
 }
 
+// LayerNorm of RT tiles whose rows are spread over the four waves (each holds 32 of a row's 128 features: mine[t][j][i]): two passes
+// (sum, then sum of squared deviations), each a 32-feature partial per wave combined through red[t][wave][row] in LDS -- instead of
+// a third all-gather of the full rows and 4 x redundant statistics.
+template <int RT>
+DEVINL void c16m_layer_norm(f32x4 (&mine)[RT][2], float* red, const f32x4 (&g)[2], const f32x4 (&b)[2], int wave, int n) {
+    float mean[RT], rstd[RT];
+#pragma unroll
+    for (int t = 0; t < RT; ++t) {
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) s += mine[t][j][i];
+        s += __shfl_xor(s, 16, 64);
+        s += __shfl_xor(s, 32, 64);
+        red[(t * 4 + wave) * 16 + n] = s;           // the four lane groups write the same value
+    }
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < RT; ++t)
+        mean[t] = ((red[(t * 4 + 0) * 16 + n] + red[(t * 4 + 1) * 16 + n]) + (red[(t * 4 + 2) * 16 + n] + red[(t * 4 + 3) * 16 + n])) * (1.0f / 128);
+    float* red2 = red + RT * 64;
+#pragma unroll
+    for (int t = 0; t < RT; ++t) {
+        float v = 0.f;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float d = mine[t][j][i] - mean[t];
+                v += d * d;
+            }
+        v += __shfl_xor(v, 16, 64);
+        v += __shfl_xor(v, 32, 64);
+        red2[(t * 4 + wave) * 16 + n] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < RT; ++t) {
+        const float v = (red2[(t * 4 + 0) * 16 + n] + red2[(t * 4 + 1) * 16 + n]) + (red2[(t * 4 + 2) * 16 + n] + red2[(t * 4 + 3) * 16 + n]);
+        rstd[t] = 1.0f / sqrtf(v * (1.0f / 128) + LN_EPS);
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) mine[t][j][i] = (mine[t][j][i] - mean[t]) * rstd[t] * g[j][i] + b[j][i];
+    }
+}
+
 template <int RT>
 __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_edge_coop16m(const EdgeArgs a) {
     constexpr int L = 128;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     f32x4* xch0 = reinterpret_cast<f32x4*>(smem);
     f32x4* xch1 = xch0 + RT * 8 * 64;
+    float* red = reinterpret_cast<float*>(xch1 + RT * 8 * 64);      // LayerNorm partials: 2 x [RT][4 waves][16 rows]
     const int lane0 = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const float* tabs = a.tabs + T_COUNT * L;                       // natural feature order
@@ -986,13 +1035,14 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
     const int ht0 = 2 * a.tile0, nht = 2 * a.ntiles;
     const int ngroups = (nht + RT - 1) / RT;
     for (int gi = blockIdx.x; gi < ngroups; gi += gridDim.x) {
+        STAMP16(0);
         int lane = lane0;
         asm volatile("" : "+v"(lane));      // keeps the (loop-invariant) weight and table loads inside the loop: hoisted, they spill
         const int n = lane & 15, q = lane >> 4;
         if ((int64_t)(ht0 + gi * RT) * 16 >= a.E) break;            // nothing but the empty tail of the last 32-row tile
         int ht[RT], s_[RT], r_[RT], r_before[RT], r_after[RT], row[RT];
         int64_t tile[RT];
-        bool valid[RT];
+        bool valid[RT], hb[RT], ha[RT];
 #pragma unroll
         for (int t = 0; t < RT; ++t) {
             ht[t] = ht0 + gi * RT + t;
@@ -1003,55 +1053,79 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
             const int64_t ec = valid[t] ? eid : a.E - 1;
             s_[t] = a.snd[ec];
             r_[t] = a.rcv[ec];
-            r_before[t] = (live && ht[t] > 0) ? a.rcv[e0 - 1] : -2;
-            r_after[t] = (e0 + 16 < a.E) ? a.rcv[e0 + 16] : -3;
+            // branch-free (clamped address, select on the value): a conditional load is a branch with a full wait behind it
+            // (the selects happen at the use site, behind the chains: placed here they would wait for the loads before layer 1)
+            hb[t] = live && ht[t] > 0;
+            ha[t] = e0 + 16 < a.E;
+            r_before[t] = a.rcv[hb[t] ? e0 - 1 : 0];
+            r_after[t] = a.rcv[ha[t] ? e0 + 16 : 0];
             const int htc = live ? ht[t] : ht0 + gi * RT;
             tile[t] = htc >> 1;
             row[t] = 16 * (htc & 1) + n;
         }
         f32x4 x[RT][8], acc[RT][2], xs[RT][2];
+        // Few requests before layer 1 (a wave cannot keep sixty cold loads in flight: its first MFMA then waits ~2 us): every wave
+        // fetches only its own two blocks of the e rows -- the residual's slice -- and the four waves assemble the full rows through
+        // LDS; tables, the next layer's weights and the gathered rows are requested inside the layer-1 chain.
 #pragma unroll
         for (int t = 0; t < RT; ++t) {
-            c16_load_tile_row(x[t], a.Elat, tile[t], row[t], q);
-            // the residual's slice, as loads of its own (a pick out of x by the wave id becomes a scratch array)
             const f32x4* E4 = reinterpret_cast<const f32x4*>(a.Elat);
             xs[t][0] = E4[c16_tile_idx(tile[t], row[t], 2 * wave, q)];
             xs[t][1] = E4[c16_tile_idx(tile[t], row[t], 2 * wave + 1, q)];
         }
+        C16Ring g1, g2;
+        c16_prime(g1, w1, lane);
 #pragma unroll
-        for (int t = 0; t < RT; ++t) {      // layer-1 accumulator: P[s] + Q[r] (carry b1), this wave's blocks
-            const f32x4* P4 = reinterpret_cast<const f32x4*>(a.P) + (int64_t)s_[t] * 32 + q;
-            const f32x4* Q4 = reinterpret_cast<const f32x4*>(a.Q) + (int64_t)r_[t] * 32 + q;
-            acc[t][0] = P4[4 * (2 * wave)] + Q4[4 * (2 * wave)];
-            acc[t][1] = P4[4 * (2 * wave + 1)] + Q4[4 * (2 * wave + 1)];
-        }
-        f32x4 tb2[2], tb3[2], tg[2], tb[2];                          // one wave per SIMD: no table request behind a barrier
+        for (int t = 0; t < RT; ++t) acc[t][0] = acc[t][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+        c16m_exchange<RT>(x, xs, xch0, wave, lane);
+        __builtin_amdgcn_sched_barrier(0);
+        STAMP16(1);
+        // layer 1: the e tile's part starts as soon as the tile and the first weights are here; the gathered P[s] + Q[r] (which
+        // carry b1) are requested half way -- their addresses wait for the index loads, a serial round trip -- and added at the end
+        c16m_chain<RT, 0, 4>(acc, x, w1, lane, g1);
+        f32x4 tb2[2], tb3[2], tg[2], tb[2];
         c16_tab(tb2, tabs + T_B2 * L, wave, q);
         c16_tab(tb3, tabs + T_B3 * L, wave, q);
         c16_tab(tg, tabs + T_GAMMA * L, wave, q);
         c16_tab(tb, tabs + T_BETA * L, wave, q);
-        C16Ring g1, g2;
-        c16_prime(g1, w1, lane);
-        c16_prime(g2, w2, lane);                                     // layer 2's first fragments, a chain ahead
-        __builtin_amdgcn_sched_barrier(0);
-        c16m_chain<RT>(acc, x, w1, lane, g1);                        // layer 1 (edge part)
+        c16_prime(g2, w2, lane);                                     // layer 2's first fragments
+        f32x4 pq[RT][2][2];
+#pragma unroll
+        for (int t = 0; t < RT; ++t) {
+            const f32x4* P4 = reinterpret_cast<const f32x4*>(a.P) + (int64_t)s_[t] * 32 + q;
+            const f32x4* Q4 = reinterpret_cast<const f32x4*>(a.Q) + (int64_t)r_[t] * 32 + q;
+            pq[t][0][0] = P4[4 * (2 * wave)];
+            pq[t][0][1] = P4[4 * (2 * wave + 1)];
+            pq[t][1][0] = Q4[4 * (2 * wave)];
+            pq[t][1][1] = Q4[4 * (2 * wave + 1)];
+        }
+        c16m_chain<RT, 4, 8>(acc, x, w1, lane, g1);
+#pragma unroll
+        for (int t = 0; t < RT; ++t) {
+            acc[t][0] += pq[t][0][0] + pq[t][1][0];
+            acc[t][1] += pq[t][0][1] + pq[t][1][1];
+        }
+        STAMP16(2);
 #pragma unroll
         for (int t = 0; t < RT; ++t) c16_relu(acc[t]);
         c16_prime(g1, w3, lane);
-        c16m_exchange<RT>(x, acc, xch0, wave, lane);                 // x becomes the exchange result from here on
+        c16m_exchange<RT>(x, acc, xch1, wave, lane);                 // x becomes the exchange result from here on
+        STAMP16(3);
 #pragma unroll
         for (int t = 0; t < RT; ++t) { acc[t][0] = tb2[0]; acc[t][1] = tb2[1]; }
         c16m_chain<RT>(acc, x, w2, lane, g2);                        // layer 2
+        STAMP16(4);
 #pragma unroll
         for (int t = 0; t < RT; ++t) c16_relu(acc[t]);
-        c16m_exchange<RT>(x, acc, xch1, wave, lane);
+        c16m_exchange<RT>(x, acc, xch0, wave, lane);
 #pragma unroll
         for (int t = 0; t < RT; ++t) { acc[t][0] = tb3[0]; acc[t][1] = tb3[1]; }
         c16m_chain<RT>(acc, x, w3, lane, g1);                        // layer 3
-        c16m_exchange<RT>(x, acc, xch0, wave, lane);                 // full pre-LN rows (for the statistics)
+        STAMP16(5);
+        c16m_layer_norm<RT>(acc, red, tg, tb, wave, n);              // acc = this wave's slice of e'
+        STAMP16(6);
 #pragma unroll
         for (int t = 0; t < RT; ++t) {
-            c16_layer_norm_tab(acc[t], x[t], tg, tb);                // acc = this wave's slice of e'
             if (valid[t]) {                                          // e <- e + e'
                 f32x4* E4 = reinterpret_cast<f32x4*>(a.Elat);
                 E4[c16_tile_idx(tile[t], row[t], 2 * wave, q)] = xs[t][0] + acc[t][0];
@@ -1079,8 +1153,8 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
                 }
             const bool tail = valid[t] && ((n == 15) || (reff != rnext));
             const int r_first = __builtin_amdgcn_readfirstlane(reff);
-            const bool sl = (start == 0) && (r_before[t] == r_first);   // run continues from the previous 16-edge tile
-            const bool sr = (n == 15) && (r_after[t] == reff);          // run continues into the next one
+            const bool sl = (start == 0) && hb[t] && (r_before[t] == r_first);   // run continues from the previous 16-edge tile
+            const bool sr = (n == 15) && ha[t] && (r_after[t] == reff);          // run continues into the next one
             if (tail) {
                 if (sl || sr) {
                     f32x4* C4 = reinterpret_cast<f32x4*>(a.CARRY) + ((int64_t)2 * ht[t] + (sl ? 0 : 1)) * 32 + q;
@@ -1093,16 +1167,22 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
                 }
             }
         }
+        STAMP16(7);
         __syncthreads();   // xch0 is rewritten by the next group's first exchange
     }
 }
 
 // chunk[0]=W2 [1]=W3 [2]=W1v [3]=W1a [4]=WP [5]=WQ.  mode as in NodeArgs.  One edge set.
+// Every wave requests only its own two blocks of the v rows and of the aggregate rows (the residual's slice; a launch starts with
+// cold caches and a wave cannot keep dozens of cold loads in flight) and the four waves assemble the full rows through LDS; the
+// LayerNorm statistics are per-wave partials combined through LDS (c16m_layer_norm).
 __global__ __launch_bounds__(256, 2) void k_node_coop16(const NodeArgs a) {
     constexpr int L = 128;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     f32x4* xch0 = reinterpret_cast<f32x4*>(smem);
     f32x4* xch1 = xch0 + 8 * 64;
+    f32x4* xch2 = xch1 + 8 * 64;
+    float* red = reinterpret_cast<float*>(xch2 + 8 * 64);
     const int lane0 = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const float* tabs = a.tabs + T_COUNT * L;
@@ -1120,79 +1200,119 @@ __global__ __launch_bounds__(256, 2) void k_node_coop16(const NodeArgs a) {
         const int nn = valid ? node : a.n - 1;
         const int64_t tile = ht >> 1;
         const int row = 16 * (ht & 1) + n;
-        f32x4 v[8], full[8], acc[2];
-        c16_load_tile_row(v, a.V, tile, row, q);
+        f32x4 v[1][8], full[1][8], acc[1][2], vs[1][2];
+        {
+            const f32x4* V4 = reinterpret_cast<const f32x4*>(a.V);
+            vs[0][0] = V4[c16_tile_idx(tile, row, 2 * wave, q)];
+            vs[0][1] = V4[c16_tile_idx(tile, row, 2 * wave + 1, q)];
+        }
         if (a.mode != 2) {
             // aggregated messages: the node's AGG slot, or carry rows when its run of edges straddles 16-edge tiles
             const int a0 = a.rowptr[nn], a1 = a.rowptr[nn + 1];
             const int T1 = a0 >> 4, T2 = (a1 - 1) >> 4;
             const int extra = (valid && a1 > a0 && T2 > T1) ? (T2 - T1) : 0;
             const bool from_agg = valid && (a1 > a0) && !extra;
-            if (from_agg) c16_load_tile_row(full, a.AGG, tile, row, q);
-            else c16_load_row(full, a.CARRY, extra ? (int64_t)(2 * T1 + 1) : a.zero_row, q);
+            f32x4 as[1][2];
+            {
+                const f32x4* A4 = reinterpret_cast<const f32x4*>(a.AGG) + c16_tile_idx(tile, row, 2 * wave, q);
+                const f32x4* C4 = reinterpret_cast<const f32x4*>(a.CARRY) + (extra ? (int64_t)(2 * T1 + 1) : a.zero_row) * 32 + q + 4 * (2 * wave);
+                const f32x4* src = from_agg ? A4 : C4;
+                as[0][0] = src[0];
+                as[0][1] = src[from_agg ? 128 : 4];
+            }
             for (int k = 1; __any(k <= extra); ++k)
                 if (k <= extra) {
-                    f32x4 cr[8];
-                    c16_load_row(cr, a.CARRY, (int64_t)2 * (T1 + k), q);
-#pragma unroll
-                    for (int bb = 0; bb < 8; ++bb) full[bb] += cr[bb];
+                    const f32x4* C4 = reinterpret_cast<const f32x4*>(a.CARRY) + (int64_t)2 * (T1 + k) * 32 + q + 4 * (2 * wave);
+                    as[0][0] += C4[0];
+                    as[0][1] += C4[4];
                 }
             C16Ring ga, gb;
             c16_prime(ga, wt(2), lane);
-            c16_prime(gb, wt(3), lane);
-            c16_tab(acc, tabs + T_B1 * L, wave, q);
+            c16_tab(acc[0], tabs + T_B1 * L, wave, q);
+            xch0[(2 * wave) * 64 + lane] = vs[0][0];
+            xch0[(2 * wave + 1) * 64 + lane] = vs[0][1];
+            xch1[(2 * wave) * 64 + lane] = as[0][0];
+            xch1[(2 * wave + 1) * 64 + lane] = as[0][1];
+            __syncthreads();
+#pragma unroll
+            for (int bb = 0; bb < 8; ++bb) v[0][bb] = xch0[bb * 64 + lane];
+#pragma unroll
+            for (int bb = 0; bb < 8; ++bb) full[0][bb] = xch1[bb * 64 + lane];
             __builtin_amdgcn_sched_barrier(0);
             STAMP16(1);
-            c16_chain_primed(acc, v, wt(2), lane, ga);               // layer 1, node part
+            c16m_chain<1, 0, 4>(acc, v, wt(2), lane, ga);            // layer 1, node part
+            f32x4 tb2[2], tb3[2], tg[2], tb[2];
+            c16_tab(tb2, tabs + T_B2 * L, wave, q);
+            c16_tab(tb3, tabs + T_B3 * L, wave, q);
+            c16_tab(tg, tabs + T_GAMMA * L, wave, q);
+            c16_tab(tb, tabs + T_BETA * L, wave, q);
+            c16_prime(gb, wt(3), lane);
+            c16m_chain<1, 4, 8>(acc, v, wt(2), lane, ga);
             STAMP16(2);
             c16_prime(ga, wt(0), lane);
-            c16_chain_primed(acc, full, wt(3), lane, gb);            // layer 1, aggregate part
+            c16m_chain<1>(acc, full, wt(3), lane, gb);               // layer 1, aggregate part
             STAMP16(3);
-            c16_relu(acc);
+            c16_relu(acc[0]);
             c16_prime(gb, wt(1), lane);
-            c16_exchange(full, acc, xch0, wave, lane);
-            c16_tab(acc, tabs + T_B2 * L, wave, q);
-            c16_chain_primed(acc, full, wt(0), lane, ga);            // layer 2
+            c16m_exchange<1>(full, acc, xch2, wave, lane);
+            acc[0][0] = tb2[0];
+            acc[0][1] = tb2[1];
+            c16m_chain<1>(acc, full, wt(0), lane, ga);               // layer 2
             STAMP16(4);
-            c16_relu(acc);
-            c16_exchange(full, acc, xch1, wave, lane);
-            c16_tab(acc, tabs + T_B3 * L, wave, q);
-            c16_chain_primed(acc, full, wt(1), lane, gb);            // layer 3
-            c16_exchange(full, acc, xch0, wave, lane);
-            c16_layer_norm(acc, full, tabs + T_GAMMA * L, tabs + T_BETA * L, wave, q);
+            c16_relu(acc[0]);
+            if (a.mode == 1) c16_prime(ga, wt(4), lane);             // the projection's first fragments
+            c16m_exchange<1>(full, acc, xch0, wave, lane);
+            acc[0][0] = tb3[0];
+            acc[0][1] = tb3[1];
+            c16m_chain<1>(acc, full, wt(1), lane, gb);               // layer 3
+            if (a.mode == 1) c16_prime(gb, wt(5), lane);
+            c16m_layer_norm<1>(acc, red, tg, tb, wave, n);
             STAMP16(5);
-            {
-                f32x4 vs[2];
-                c16_pick(vs, v, wave);
-                acc[0] += vs[0];                                     // v <- v + v'  (this wave's slice)
-                acc[1] += vs[1];
-            }
+            acc[0][0] += vs[0][0];                                   // v <- v + v'  (this wave's slice)
+            acc[0][1] += vs[0][1];
             if (valid) {
                 f32x4* V4 = reinterpret_cast<f32x4*>(a.V);
-                V4[c16_tile_idx(tile, row, 2 * wave, q)] = acc[0];
-                V4[c16_tile_idx(tile, row, 2 * wave + 1, q)] = acc[1];
+                V4[c16_tile_idx(tile, row, 2 * wave, q)] = acc[0][0];
+                V4[c16_tile_idx(tile, row, 2 * wave + 1, q)] = acc[0][1];
             }
-            if (a.mode == 1) c16_exchange(v, acc, xch1, wave, lane); // full updated row for the projection
-            STAMP16(6);
-        }
-        if (a.mode != 0) {                                           // P = v W1s, Q = v W1r + b1 of the next step
-            f32x4 o[2];
-            o[0] = f32x4{0.f, 0.f, 0.f, 0.f};
-            o[1] = o[0];
-            C16Ring gq;
-            c16_prime(gq, wt(5), lane);
-            c16_chain(o, v, wt(4), lane);
+            if (a.mode == 1) {                                       // P = v W1s, Q = v W1r + b1 of the next step, on the updated rows
+                c16m_exchange<1>(v, acc, xch1, wave, lane);
+                STAMP16(6);
+                f32x4 o[1][2];
+                o[0][0] = o[0][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+                c16m_chain<1>(o, v, wt(4), lane, ga);
+                if (valid) {
+                    f32x4* P4 = reinterpret_cast<f32x4*>(a.P) + (int64_t)nn * 32 + q;
+                    P4[4 * (2 * wave)] = o[0][0];
+                    P4[4 * (2 * wave + 1)] = o[0][1];
+                }
+                c16_tab(o[0], tabs + T_BQ * L, wave, q);
+                c16m_chain<1>(o, v, wt(5), lane, gb);
+                if (valid) {
+                    f32x4* Q4 = reinterpret_cast<f32x4*>(a.Q) + (int64_t)nn * 32 + q;
+                    Q4[4 * (2 * wave)] = o[0][0];
+                    Q4[4 * (2 * wave + 1)] = o[0][1];
+                }
+            }
+        } else {                                                     // projection only (before the first step)
+            C16Ring ga, gb;
+            c16_prime(ga, wt(4), lane);
+            c16_prime(gb, wt(5), lane);
+            c16m_exchange<1>(v, vs, xch0, wave, lane);
+            f32x4 o[1][2];
+            o[0][0] = o[0][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+            c16m_chain<1>(o, v, wt(4), lane, ga);
             if (valid) {
                 f32x4* P4 = reinterpret_cast<f32x4*>(a.P) + (int64_t)nn * 32 + q;
-                P4[4 * (2 * wave)] = o[0];
-                P4[4 * (2 * wave + 1)] = o[1];
+                P4[4 * (2 * wave)] = o[0][0];
+                P4[4 * (2 * wave + 1)] = o[0][1];
             }
-            c16_tab(o, tabs + T_BQ * L, wave, q);
-            c16_chain_primed(o, v, wt(5), lane, gq);
+            c16_tab(o[0], tabs + T_BQ * L, wave, q);
+            c16m_chain<1>(o, v, wt(5), lane, gb);
             if (valid) {
                 f32x4* Q4 = reinterpret_cast<f32x4*>(a.Q) + (int64_t)nn * 32 + q;
-                Q4[4 * (2 * wave)] = o[0];
-                Q4[4 * (2 * wave + 1)] = o[1];
+                Q4[4 * (2 * wave)] = o[0][0];
+                Q4[4 * (2 * wave + 1)] = o[0][1];
             }
         }
         STAMP16(7);
@@ -2603,7 +2723,7 @@ hipError_t launch_edge_step(int L, const EdgeArgs& a, hipStream_t s) {
         const int nht = 2 * a.ntiles;
         int rt = g_c16_rt ? g_c16_rt : (nht + num_cus() - 1) / num_cus();
         rt = rt < 1 ? 1 : (rt > 3 ? 3 : rt);
-        LaunchCfg c16{(nht + rt - 1) / rt, 256, (size_t)rt * 2 * 8 * 64 * 16};
+        LaunchCfg c16{(nht + rt - 1) / rt, 256, (size_t)rt * 2 * 8 * 64 * 16 + (size_t)rt * 2 * 64 * 4};
         if (rt == 3) return launch_k(k_edge_coop16m<3>, a, c16, s);
         if (rt == 2) return launch_k(k_edge_coop16m<2>, a, c16, s);
         return launch_k(k_edge_coop16, a, c16, s);
@@ -2653,7 +2773,7 @@ hipError_t launch_node_step(int L, const NodeArgs& a, hipStream_t s) {
         DISPATCH_GEN(L, (k_node_step<4, 0, false, 1, true>), (k_node_step<2, 0, false, 1, true>), (k_node_step<1, 0, false, 1, true>), a, a.ntiles);
     }
     if (a.c16 && L == 128 && a.chunk_t[0] && !a.AGG2) {
-        LaunchCfg c16{2 * a.ntiles, 256, (size_t)2 * 8 * 64 * 16};
+        LaunchCfg c16{2 * a.ntiles, 256, (size_t)3 * 8 * 64 * 16 + 2 * 64 * 4};
         return launch_k(k_node_coop16, a, c16, s);
     }
     if (coop_ok(L, a.ntiles, a.chunk_t)) {
@@ -2695,7 +2815,7 @@ hipError_t launch_project(int L, const NodeArgs& a, hipStream_t s) {
     if (a.ntiles <= 0) return hipSuccess;
     LaunchCfg lc = tile_launch(L, a.ntiles, 2);
     if (!a.gen.use && a.c16 && L == 128 && a.chunk_t[0] && !a.AGG2 && a.mode == 2) {
-        LaunchCfg c16{2 * a.ntiles, 256, (size_t)2 * 8 * 64 * 16};
+        LaunchCfg c16{2 * a.ntiles, 256, (size_t)3 * 8 * 64 * 16 + 2 * 64 * 4};
         return launch_k(k_node_coop16, a, c16, s);
     }
     if (!a.gen.use && a.tile0 == 0 && a.mode == 2 && coop_ok(L, a.ntiles, a.chunk_t)) {

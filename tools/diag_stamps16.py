@@ -13,7 +13,7 @@ eng.set_params(bench.glorot_params()); eng.set_graph(s, r, pos.shape[0]); eng.la
 for _ in range(5): eng.processor_steps_dev(15)
 eng.synchronize()
 TICK = float(os.environ.get("MGN_TICK_US", "0.01"))
-for which, names in (("edge", ["issue idx+x loads", "idx wait, issue gathers+weights", "chain1(+gather wait)", "relu+xch1", "chain2+xch2+chain3", "xch3+LN", "store+scan"]),
+for which, names in (("edge", ["idx, issue loads", "chain1(+gather wait)", "relu+xch1", "chain2", "xch2+chain3", "xch3", "LN+store+scan"]),
                      ("node", ["agg+issue", "chain1v", "chain1a", "xch+chain2", "xch+chain3+xch+LN", "store+xch", "P,Q chains"])):
     f = getattr(eng.lib, f"mgn_debug_{which}_stamps"); f.restype = C.c_int; f.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
     for rep in range(2):
