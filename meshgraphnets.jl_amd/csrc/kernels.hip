@@ -649,25 +649,11 @@ __global__ __launch_bounds__(256, 2) void k_node_coop(const NodeArgs a) {
 // (EdgeArgs.c16: the edge and the node kernel of a step agree).
 // ================================================================================================
 constexpr int C16_CH = 128 * 128;          // floats per chunk copy
-#ifdef MGN_EXP_C16_NOMFMA       // experiment: one VALU op in place of each MFMA (wrong results; the non-MFMA floor of the kernels)
-DEVINL f32x4 c16_mfma(float a, float b, f32x4 c) { c[0] = __builtin_fmaf(a, b, c[0]); return c; }
-#else
 DEVINL f32x4 c16_mfma(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
-#endif
 // float4 index of (feature block bb, lane group q) of row `row` of tile `tile` in 32-row tile-major storage
 // (feature o = 16 bb + 4 q sits in piece o >> 3, half (o >> 2) & 1 of the 32-row tile: written so that bb is a constant offset)
 DEVINL int64_t c16_tile_idx(int64_t tile, int row, int bb, int q) {
     return (tile * 1024 + (q >> 1) * 64 + 32 * (q & 1) + row) + 128 * bb;
-}
-DEVINL void c16_load_tile_row(f32x4 (&x)[8], const float* base, int64_t tile, int row, int q) {
-    const f32x4* p = reinterpret_cast<const f32x4*>(base);
-#pragma unroll
-    for (int bb = 0; bb < 8; ++bb) x[bb] = p[c16_tile_idx(tile, row, bb, q)];
-}
-DEVINL void c16_load_row(f32x4 (&x)[8], const float* base, int64_t row, int q) {       // row-major [row][128]
-    const f32x4* p = reinterpret_cast<const f32x4*>(base) + row * 32 + q;
-#pragma unroll
-    for (int bb = 0; bb < 8; ++bb) x[bb] = p[4 * bb];
 }
 // one L x L chunk: this wave's two output blocks; wt = chunk16 + w * 4096 floats ([bb][j][lane][4]).  The weight fragments come
 // from L2 (a launch of one or two tiles per CU cannot amortise an LDS preload) through a register ring C16_PF k-groups deep, pinned
@@ -682,73 +668,6 @@ DEVINL void c16_prime(C16Ring& g, const float* wt, int lane) {
 #pragma unroll
     for (int p = 0; p < 2 * C16_PF; ++p) g.r[p] = wv[p * 64];
 }
-#ifdef MGN_EXP_C16_NOPS     // experiment: idle cycles after each MFMA, so that the next one does not wait in the issue stage
-#define C16_YIELD                                          \
-    do {                                                   \
-        __builtin_amdgcn_sched_barrier(0);                 \
-        asm volatile("s_nop %0" ::"n"(MGN_EXP_C16_NOPS));  \
-        __builtin_amdgcn_sched_barrier(0);                 \
-    } while (0)
-#else
-#define C16_YIELD do {} while (0)
-#endif
-#ifdef MGN_EXP_C16_PRIO     // experiment: waves outside their MFMA chains win issue arbitration
-#define C16_PRIO_HI __builtin_amdgcn_s_setprio(3)
-#define C16_PRIO_LO __builtin_amdgcn_s_setprio(0)
-#else
-#define C16_PRIO_HI do {} while (0)
-#define C16_PRIO_LO do {} while (0)
-#endif
-DEVINL void c16_chain_primed(f32x4 (&acc)[2], const f32x4 (&x)[8], const float* wt, int lane, C16Ring& g) {
-    const f32x4* wv = reinterpret_cast<const f32x4*>(wt) + lane;
-    C16_PRIO_LO;
-#pragma unroll
-    for (int bb = 0; bb < 8; ++bb) {
-        const f32x4 c0 = g.r[(2 * bb) % (2 * C16_PF)], c1 = g.r[(2 * bb + 1) % (2 * C16_PF)];
-#ifdef MGN_EXP_C16_NOW          // experiment: no weight refills (wrong results; bounds what the weight traffic costs)
-        if (false) {
-#else
-        if (bb + C16_PF < 8) {
-#endif
-            g.r[(2 * bb) % (2 * C16_PF)] = wv[(2 * (bb + C16_PF)) * 64];
-            g.r[(2 * bb + 1) % (2 * C16_PF)] = wv[(2 * (bb + C16_PF) + 1) * 64];
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            acc[0] = c16_mfma(c0[i], x[bb][i], acc[0]);
-            C16_YIELD;
-            acc[1] = c16_mfma(c1[i], x[bb][i], acc[1]);
-            C16_YIELD;
-        }
-        __builtin_amdgcn_sched_barrier(0);
-    }
-    C16_PRIO_HI;
-}
-DEVINL void c16_chain(f32x4 (&acc)[2], const f32x4 (&x)[8], const float* wt, int lane) {
-    C16Ring g;
-    c16_prime(g, wt, lane);
-    __builtin_amdgcn_sched_barrier(0);
-    c16_chain_primed(acc, x, wt, lane, g);
-}
-// every wave publishes its two blocks and reads back the full row fragment
-DEVINL void c16_exchange(f32x4 (&full)[8], const f32x4 (&mine)[2], f32x4* xch, int wave, int lane) {
-    xch[(2 * wave) * 64 + lane] = mine[0];
-    xch[(2 * wave + 1) * 64 + lane] = mine[1];
-    __syncthreads();
-#pragma unroll
-    for (int bb = 0; bb < 8; ++bb) full[bb] = xch[bb * 64 + lane];
-}
-// this wave's two blocks of a full row fragment (a switch on the uniform wave id: a runtime index into a register array would
-// send the array to scratch)
-DEVINL void c16_pick(f32x4 (&out)[2], const f32x4 (&x)[8], int wave) {
-    switch (wave) {
-        case 0: out[0] = x[0]; out[1] = x[1]; break;
-        case 1: out[0] = x[2]; out[1] = x[3]; break;
-        case 2: out[0] = x[4]; out[1] = x[5]; break;
-        default: out[0] = x[6]; out[1] = x[7]; break;
-    }
-}
 DEVINL void c16_tab(f32x4 (&acc)[2], const float* tab, int wave, int q) {      // natural-order table -> this wave's slice
     const f32x4* t4 = reinterpret_cast<const f32x4*>(tab) + q;
     acc[0] = t4[4 * (2 * wave)];
@@ -760,156 +679,13 @@ DEVINL void c16_relu(f32x4 (&acc)[2]) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) acc[j][i] = fmaxf(acc[j][i], 0.f);
 }
-// LayerNorm statistics from the full pre-LN row (32 values in this lane, the rest in the lanes n + 16 q'), applied to the slice
-DEVINL void c16_layer_norm(f32x4 (&mine)[2], const f32x4 (&full)[8], const float* gamma, const float* beta, int wave, int q) {
-    float s = 0.f;
-#pragma unroll
-    for (int bb = 0; bb < 8; ++bb)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) s += full[bb][i];
-    s += __shfl_xor(s, 16, 64);
-    s += __shfl_xor(s, 32, 64);
-    const float mean = s * (1.0f / 128);
-    float v = 0.f;
-#pragma unroll
-    for (int bb = 0; bb < 8; ++bb)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const float d = full[bb][i] - mean;
-            v += d * d;
-        }
-    v += __shfl_xor(v, 16, 64);
-    v += __shfl_xor(v, 32, 64);
-    const float rstd = 1.0f / sqrtf(v * (1.0f / 128) + LN_EPS);
-    f32x4 g[2], b[2];
-    c16_tab(g, gamma, wave, q);
-    c16_tab(b, beta, wave, q);
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) mine[j][i] = (mine[j][i] - mean) * rstd * g[j][i] + b[j][i];
-}
-
-// chunk[0]=W2 [1]=W3 [2]=W1e; the 16x16x4 copy of a chunk follows its two other copies (mgn_set_params)
-__global__ __launch_bounds__(256, 2) void k_edge_coop16(const EdgeArgs a) {
-    constexpr int L = 128;
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    f32x4* xch0 = reinterpret_cast<f32x4*>(smem);
-    f32x4* xch1 = xch0 + 8 * 64;
-    const int lane0 = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const float* tabs = a.tabs + T_COUNT * L;                       // natural feature order
-    const float* w1 = a.chunk[2] + 2 * C16_CH + wave * 4096;
-    const float* w2 = a.chunk[0] + 2 * C16_CH + wave * 4096;
-    const float* w3 = a.chunk[1] + 2 * C16_CH + wave * 4096;
-    const int ht0 = 2 * a.tile0, nht = 2 * a.ntiles;
-    for (int hi = blockIdx.x; hi < nht; hi += gridDim.x) {
-        STAMP16(0);
-        C16_PRIO_HI;
-        int lane = lane0;
-        asm volatile("" : "+v"(lane));      // keeps the (loop-invariant) weight and table loads inside the loop: hoisted, they spill
-        const int n = lane & 15, q = lane >> 4;
-        const int ht = ht0 + hi;
-        const int64_t e0 = (int64_t)ht * 16;
-        if (e0 >= a.E) break;                                       // the empty second half of the last tile (block-uniform)
-        const int64_t eid = e0 + n;
-        const bool valid = eid < a.E;
-        const int64_t ec = valid ? eid : a.E - 1;
-#ifdef MGN_EXP_C16_NOGATHER     // experiment: P / Q rows that do not depend on the index loads (wrong results)
-        const int r_ = a.rcv[ec];
-        const int s_ = (int)(ec & 1023);
-#define C16_QROW (int)((ec + 7) & 1023)
-#else
-        const int s_ = a.snd[ec], r_ = a.rcv[ec];
-#define C16_QROW r_
-#endif
-        const int r_before = ht > 0 ? a.rcv[e0 - 1] : -2;
-        const int r_after = (e0 + 16 < a.E) ? a.rcv[e0 + 16] : -3;
-        const int64_t tile = ht >> 1;
-        const int row = 16 * (ht & 1) + n;
-        f32x4 x[8], full[8], acc[2];
-        c16_load_tile_row(x, a.Elat, tile, row, q);
-        STAMP16(1);
-        {   // layer-1 accumulator: P[s] + Q[r] (carry b1), this wave's blocks
-            const f32x4* P4 = reinterpret_cast<const f32x4*>(a.P) + (int64_t)s_ * 32 + q;
-            const f32x4* Q4 = reinterpret_cast<const f32x4*>(a.Q) + (int64_t)C16_QROW * 32 + q;
-            acc[0] = P4[4 * (2 * wave)] + Q4[4 * (2 * wave)];
-            acc[1] = P4[4 * (2 * wave + 1)] + Q4[4 * (2 * wave + 1)];
-        }
-        C16Ring g1, g2;
-        c16_prime(g1, w1, lane);
-        c16_prime(g2, w2, lane);                                     // layer 2's first fragments, a chain ahead
-        __builtin_amdgcn_sched_barrier(0);
-        STAMP16(2);
-        c16_chain_primed(acc, x, w1, lane, g1);                      // layer 1 (edge part)
-        STAMP16(3);
-        c16_relu(acc);
-        c16_prime(g1, w3, lane);
-        c16_exchange(full, acc, xch0, wave, lane);
-        STAMP16(4);
-        c16_tab(acc, tabs + T_B2 * L, wave, q);
-        c16_chain_primed(acc, full, w2, lane, g2);                   // layer 2
-        c16_relu(acc);
-        c16_exchange(full, acc, xch1, wave, lane);
-        c16_tab(acc, tabs + T_B3 * L, wave, q);
-        c16_chain_primed(acc, full, w3, lane, g1);                   // layer 3
-        STAMP16(5);
-        c16_exchange(full, acc, xch0, wave, lane);                   // full pre-LN row (for the statistics)
-        c16_layer_norm(acc, full, tabs + T_GAMMA * L, tabs + T_BETA * L, wave, q);   // acc = this wave's slice of e'
-        STAMP16(6);
-        if (valid) {                                                 // e <- e + e'
-            f32x4* E4 = reinterpret_cast<f32x4*>(a.Elat);
-            f32x4 xs[2];
-            c16_pick(xs, x, wave);
-            E4[c16_tile_idx(tile, row, 2 * wave, q)] = xs[0] + acc[0];
-            E4[c16_tile_idx(tile, row, 2 * wave + 1, q)] = xs[1] + acc[1];
-        }
-        // segmented sum over runs of equal receiver: the 16 rows of a half tile are one DPP row (the same in all four lane groups)
-        const int reff = valid ? r_ : (-4 - n);
-        const int rprev = __shfl_up(reff, 1, 16);
-        const int rnext = __shfl_down(reff, 1, 16);
-        const bool head = (n == 0) || (reff != rprev);
-        const unsigned hm = (unsigned)(__ballot(head) & 0xFFFFull);          // lane group 0's 16 rows
-        const int start = 31 - __clz((int)(hm & (0xFFFFu >> (15 - n))));
-        const float m1 = (n - 1 >= start) ? 1.f : 0.f, m2 = (n - 2 >= start) ? 1.f : 0.f, m4 = (n - 4 >= start) ? 1.f : 0.f,
-                    m8 = (n - 8 >= start) ? 1.f : 0.f;
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                float v = acc[j][i];
-                v = __builtin_fmaf(dpp_zero<0x111, 0xF>(v), m1, v);
-                v = __builtin_fmaf(dpp_zero<0x112, 0xF>(v), m2, v);
-                v = __builtin_fmaf(dpp_zero<0x114, 0xF>(v), m4, v);
-                v = __builtin_fmaf(dpp_zero<0x118, 0xF>(v), m8, v);
-                acc[j][i] = v;
-            }
-        const bool tail = valid && ((n == 15) || (reff != rnext));
-        const int r_first = __builtin_amdgcn_readfirstlane(reff);
-        const bool sl = (start == 0) && (r_before == r_first);       // run continues from the previous 16-edge tile
-        const bool sr = (n == 15) && (r_after == reff);              // run continues into the next one
-        if (tail) {
-            if (sl || sr) {
-                f32x4* C4 = reinterpret_cast<f32x4*>(a.CARRY) + ((int64_t)2 * ht + (sl ? 0 : 1)) * 32 + q;
-                C4[4 * (2 * wave)] = acc[0];
-                C4[4 * (2 * wave + 1)] = acc[1];
-            } else {
-                f32x4* A4 = reinterpret_cast<f32x4*>(a.AGG);
-                A4[c16_tile_idx(r_ >> 5, r_ & 31, 2 * wave, q)] = acc[0];
-                A4[c16_tile_idx(r_ >> 5, r_ & 31, 2 * wave + 1, q)] = acc[1];
-            }
-        }
-        STAMP16(7);
-        __syncthreads();   // xch0 is rewritten by the next half tile's first exchange
-    }
-}
-
-// ---- RT consecutive 16-edge tiles per block -----------------------------------------------------------------------------------
-// Stamps of k_edge_coop16 on the cylinder mesh (tools/diag_stamps16.py): with three one-tile blocks on a CU the second and third
-// cannot even issue their first loads before 2-3 / 6-9 us -- every wave streams its own copy of the weights (48 KB per wave and
-// tile, 0.94 MB per CU and launch through a 64 B / clk texture path), and without its MFMAs the kernel still takes 12 us.  Here a
-// wave keeps RT row tiles: every weight fragment it fetches feeds 2 RT independent MFMAs (a third of the weight traffic at RT = 3,
-// no dependent MFMA pairs), one block per CU, and the exchange barriers are shared by the RT tiles.
+// ---- RT consecutive 16-row tiles per block -----------------------------------------------------------------------------------
+// A wave keeps RT row tiles, so every weight fragment it fetches feeds 2 RT independent MFMAs.  Why not one tile per block and RT
+// blocks per CU (the first version of these kernels; docs/experiments.md, tools/diag_stamps16.py): the second and third block of a
+// CU could not even issue their first loads before 2-3 / 6-9 us (each wave streams its own copy of the weights, 48 KB per wave
+// and tile through a 64 B / clk texture path), and the co-resident tiles' MFMA and non-MFMA phases did not overlap (12 us without
+// any MFMA + 8 us of MFMAs = the 20 us measured).  One block per CU, a third of the weight traffic at RT = 3, no dependent MFMA
+// pairs, and the exchange barriers are shared by the RT tiles.
 template <int RT, int B0 = 0, int B1 = 8>          // k-groups [B0, B1) of the chunk (the ring carries over between the parts)
 DEVINL void c16m_chain(f32x4 (&acc)[RT][2], const f32x4 (&x)[RT][8], const float* wt, int lane, C16Ring& g) {
     const f32x4* wv = reinterpret_cast<const f32x4*>(wt) + lane;
@@ -944,33 +720,6 @@ DEVINL void c16m_exchange(f32x4 (&full)[RT][8], const f32x4 (&mine)[RT][2], f32x
 #pragma unroll
         for (int bb = 0; bb < 8; ++bb) full[t][bb] = xch[(t * 8 + bb) * 64 + lane];
 }
-// LayerNorm with the wave's gamma / beta slices already in registers
-DEVINL void c16_layer_norm_tab(f32x4 (&mine)[2], const f32x4 (&full)[8], const f32x4 (&g)[2], const f32x4 (&b)[2]) {
-    float s = 0.f;
-#pragma unroll
-    for (int bb = 0; bb < 8; ++bb)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) s += full[bb][i];
-    s += __shfl_xor(s, 16, 64);
-    s += __shfl_xor(s, 32, 64);
-    const float mean = s * (1.0f / 128);
-    float v = 0.f;
-#pragma unroll
-    for (int bb = 0; bb < 8; ++bb)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const float d = full[bb][i] - mean;
-            v += d * d;
-        }
-    v += __shfl_xor(v, 16, 64);
-    v += __shfl_xor(v, 32, 64);
-    const float rstd = 1.0f / sqrtf(v * (1.0f / 128) + LN_EPS);
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) mine[j][i] = (mine[j][i] - mean) * rstd * g[j][i] + b[j][i];
-}
-
 // LayerNorm of RT tiles whose rows are spread over the four waves (each holds 32 of a row's 128 features: mine[t][j][i]): two passes
 // (sum, then sum of squared deviations), each a 32-feature partial per wave combined through red[t][wave][row] in LDS -- instead of
 // a third all-gather of the full rows and 4 x redundant statistics.
@@ -1131,7 +880,7 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
                 E4[c16_tile_idx(tile[t], row[t], 2 * wave, q)] = xs[t][0] + acc[t][0];
                 E4[c16_tile_idx(tile[t], row[t], 2 * wave + 1, q)] = xs[t][1] + acc[t][1];
             }
-            // segmented sum over runs of equal receiver within the 16-edge tile (as in k_edge_coop16)
+            // segmented sum over runs of equal receiver within the 16-edge tile: the 16 rows of a tile are one DPP row (the same in all four lane groups)
             const int reff = valid[t] ? r_[t] : (-4 - n);
             const int rprev = __shfl_up(reff, 1, 16);
             const int rnext = __shfl_down(reff, 1, 16);
@@ -2726,7 +2475,7 @@ hipError_t launch_edge_step(int L, const EdgeArgs& a, hipStream_t s) {
         LaunchCfg c16{(nht + rt - 1) / rt, 256, (size_t)rt * 2 * 8 * 64 * 16 + (size_t)rt * 2 * 64 * 4};
         if (rt == 3) return launch_k(k_edge_coop16m<3>, a, c16, s);
         if (rt == 2) return launch_k(k_edge_coop16m<2>, a, c16, s);
-        return launch_k(k_edge_coop16, a, c16, s);
+        return launch_k(k_edge_coop16m<1>, a, c16, s);
     }
     if (coop_ok(L, a.ntiles, a.chunk_t, true)) {   // small graph: 4 waves per tile
         LaunchCfg c4{a.ntiles, 256, coop_lds()};

@@ -6,7 +6,7 @@ sys.path.insert(0, %r)
 import torch, mgn_amd, bench
 ps = bench.glorot_params()
 out = {}
-for nx in (32, 45, 64, 90, 128):
+for nx in (24, 32, 45, 64, 90, 128):
     pos, s, r = mgn_amd.synth.mesh_1m(1234, nx, nx)
     eng = mgn_amd.Engine(9, 3, 2, 128, 2, 15)
     eng.set_params(ps); eng.set_graph(s, r, pos.shape[0]); eng.latents_randn(1)
@@ -20,6 +20,8 @@ for nx in (32, 45, 64, 90, 128):
     eng.close()
 print(out)
 ''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-for v in ("0", "1", "0", "1"):
-    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, MGN_COOP16=v, MGN_C16_EDGE_TILES_PER_CU="99", MGN_C16_NODE_TILES_PER_CU="99"), capture_output=True, text=True)
-    print("MGN_COOP16=" + v, r.stdout.strip().splitlines()[-1] if r.stdout.strip() else r.stderr[-500:])
+ALL = {"MGN_C16_EDGE_TILES_PER_CU": "99", "MGN_C16_NODE_TILES_PER_CU": "99"}
+for name, env in (("32-row cooperative (MGN_COOP16=0)", {"MGN_COOP16": "0"}), ("default thresholds", {}), ("16-row at every size", ALL),
+                  ("16-row at every size, RT=1 through the RT kernel", dict(ALL, MGN_C16_M1="1"))) * 2:
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True)
+    print("%-50s" % name, r.stdout.strip().splitlines()[-1] if r.stdout.strip() else r.stderr[-500:])
