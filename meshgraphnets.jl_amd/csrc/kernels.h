@@ -7,7 +7,7 @@
 namespace mgn {
 
 constexpr int TILE = 32;        // rows (edges or nodes) per wave tile == MFMA 32x32 N dimension
-constexpr int MAX_CHUNKS = 7;   // weight chunks (L x L, fragment order) a fused kernel may chain
+constexpr int MAX_CHUNKS = 9;   // weight chunks (L x L, fragment order) a fused kernel may chain
 
 // Table slots (each L floats, fragment order) inside a kernel's `tabs` block.
 enum { T_B1 = 0, T_B2, T_B3, T_GAMMA, T_BETA, T_BQ, T_COUNT };
@@ -65,6 +65,9 @@ struct NodeArgs {
     int32_t tile0;          // k_project only: first tile of the range [tile0, tile0 + ntiles)
     GenMlp gen;
     int32_t c16;            // see EdgeArgs
+    // 16-row kernels with two edge sets, mode 1: the second set's projection in the same launch (chunk[7] = WP, chunk[8] = WQ of
+    // set 1, tabs2 = its tables: T_BQ holds b1 of set 1's edge MLP)
+    float* P2; float* Q2; const float* tabs2;
     unsigned long long* stamps;  // diagnostic builds only (MGN_DIAG_STAMPS), else null
 };
 

@@ -921,17 +921,60 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
     }
 }
 
-// chunk[0]=W2 [1]=W3 [2]=W1v [3]=W1a [4]=WP [5]=WQ.  mode as in NodeArgs.  One edge set.
+// chunk[0]=W2 [1]=W3 [2]=W1v [3]=W1a [4]=WP [5]=WQ, with two edge sets [6]=W1a2 [7]=WP2 [8]=WQ2.  mode as in NodeArgs.
 // Every wave requests only its own two blocks of the v rows and of the aggregate rows (the residual's slice; a launch starts with
 // cold caches and a wave cannot keep dozens of cold loads in flight) and the four waves assemble the full rows through LDS; the
-// LayerNorm statistics are per-wave partials combined through LDS (c16m_layer_norm).
+// LayerNorm statistics are per-wave partials combined through LDS (c16m_layer_norm).  SETS = 2: the second set's aggregate is one
+// more layer-1 chain, and mode 1 projects P, Q of both sets.
+// this wave's slice of a node's aggregated messages: the node's AGG slot, or carry rows when its run of edges straddles tiles
+DEVINL void c16_agg_slice(f32x4 (&as)[2], const int32_t* rowptr, const float* AGG, const float* CARRY, int64_t zero_row, bool valid, int nn,
+                          int64_t tile, int row, int wave, int q) {
+    const int a0 = rowptr[nn], a1 = rowptr[nn + 1];
+    const int T1 = a0 >> 4, T2 = (a1 - 1) >> 4;
+    const int extra = (valid && a1 > a0 && T2 > T1) ? (T2 - T1) : 0;
+    const bool from_agg = valid && (a1 > a0) && !extra;
+    const f32x4* A4 = reinterpret_cast<const f32x4*>(AGG) + c16_tile_idx(tile, row, 2 * wave, q);
+    const f32x4* C4 = reinterpret_cast<const f32x4*>(CARRY) + (extra ? (int64_t)(2 * T1 + 1) : zero_row) * 32 + q + 4 * (2 * wave);
+    const f32x4* src = from_agg ? A4 : C4;
+    as[0] = src[0];
+    as[1] = src[from_agg ? 128 : 4];
+    for (int k = 1; __any(k <= extra); ++k)
+        if (k <= extra) {
+            const f32x4* K4 = reinterpret_cast<const f32x4*>(CARRY) + (int64_t)2 * (T1 + k) * 32 + q + 4 * (2 * wave);
+            as[0] += K4[0];
+            as[1] += K4[4];
+        }
+}
+// P = v W_P, Q = v W_Q + bq for this wave's blocks of one edge set (ga primed with wp's first fragments; gb is primed here)
+DEVINL void c16_project(const f32x4 (&v)[1][8], const float* wp, const float* wq, const float* bq, float* P, float* Q, bool valid, int nn,
+                        int wave, int lane, int q, C16Ring& ga, C16Ring& gb, const float* next_wp) {
+    f32x4 o[1][2];
+    o[0][0] = o[0][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    c16_prime(gb, wq, lane);
+    c16m_chain<1>(o, v, wp, lane, ga);
+    if (valid) {
+        f32x4* P4 = reinterpret_cast<f32x4*>(P) + (int64_t)nn * 32 + q;
+        P4[4 * (2 * wave)] = o[0][0];
+        P4[4 * (2 * wave + 1)] = o[0][1];
+    }
+    c16_tab(o[0], bq, wave, q);
+    if (next_wp) c16_prime(ga, next_wp, lane);
+    c16m_chain<1>(o, v, wq, lane, gb);
+    if (valid) {
+        f32x4* Q4 = reinterpret_cast<f32x4*>(Q) + (int64_t)nn * 32 + q;
+        Q4[4 * (2 * wave)] = o[0][0];
+        Q4[4 * (2 * wave + 1)] = o[0][1];
+    }
+}
+template <int SETS>
 __global__ __launch_bounds__(256, 2) void k_node_coop16(const NodeArgs a) {
     constexpr int L = 128;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     f32x4* xch0 = reinterpret_cast<f32x4*>(smem);
     f32x4* xch1 = xch0 + 8 * 64;
     f32x4* xch2 = xch1 + 8 * 64;
-    float* red = reinterpret_cast<float*>(xch2 + 8 * 64);
+    f32x4* xch3 = xch2 + 8 * 64;                                     // (SETS == 2 only)
+    float* red = reinterpret_cast<float*>(xch2 + (SETS == 2 ? 2 : 1) * 8 * 64);
     const int lane0 = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const float* tabs = a.tabs + T_COUNT * L;
@@ -955,33 +998,21 @@ __global__ __launch_bounds__(256, 2) void k_node_coop16(const NodeArgs a) {
             vs[0][0] = V4[c16_tile_idx(tile, row, 2 * wave, q)];
             vs[0][1] = V4[c16_tile_idx(tile, row, 2 * wave + 1, q)];
         }
+        C16Ring ga, gb;
         if (a.mode != 2) {
-            // aggregated messages: the node's AGG slot, or carry rows when its run of edges straddles 16-edge tiles
-            const int a0 = a.rowptr[nn], a1 = a.rowptr[nn + 1];
-            const int T1 = a0 >> 4, T2 = (a1 - 1) >> 4;
-            const int extra = (valid && a1 > a0 && T2 > T1) ? (T2 - T1) : 0;
-            const bool from_agg = valid && (a1 > a0) && !extra;
-            f32x4 as[1][2];
-            {
-                const f32x4* A4 = reinterpret_cast<const f32x4*>(a.AGG) + c16_tile_idx(tile, row, 2 * wave, q);
-                const f32x4* C4 = reinterpret_cast<const f32x4*>(a.CARRY) + (extra ? (int64_t)(2 * T1 + 1) : a.zero_row) * 32 + q + 4 * (2 * wave);
-                const f32x4* src = from_agg ? A4 : C4;
-                as[0][0] = src[0];
-                as[0][1] = src[from_agg ? 128 : 4];
-            }
-            for (int k = 1; __any(k <= extra); ++k)
-                if (k <= extra) {
-                    const f32x4* C4 = reinterpret_cast<const f32x4*>(a.CARRY) + (int64_t)2 * (T1 + k) * 32 + q + 4 * (2 * wave);
-                    as[0][0] += C4[0];
-                    as[0][1] += C4[4];
-                }
-            C16Ring ga, gb;
+            f32x4 as[2], as2[2];
+            c16_agg_slice(as, a.rowptr, a.AGG, a.CARRY, a.zero_row, valid, nn, tile, row, wave, q);
+            if constexpr (SETS == 2) c16_agg_slice(as2, a.rowptr2, a.AGG2, a.CARRY2, a.zero_row2, valid, nn, tile, row, wave, q);
             c16_prime(ga, wt(2), lane);
             c16_tab(acc[0], tabs + T_B1 * L, wave, q);
             xch0[(2 * wave) * 64 + lane] = vs[0][0];
             xch0[(2 * wave + 1) * 64 + lane] = vs[0][1];
-            xch1[(2 * wave) * 64 + lane] = as[0][0];
-            xch1[(2 * wave + 1) * 64 + lane] = as[0][1];
+            xch1[(2 * wave) * 64 + lane] = as[0];
+            xch1[(2 * wave + 1) * 64 + lane] = as[1];
+            if constexpr (SETS == 2) {
+                xch2[(2 * wave) * 64 + lane] = as2[0];
+                xch2[(2 * wave + 1) * 64 + lane] = as2[1];
+            }
             __syncthreads();
 #pragma unroll
             for (int bb = 0; bb < 8; ++bb) v[0][bb] = xch0[bb * 64 + lane];
@@ -998,23 +1029,30 @@ __global__ __launch_bounds__(256, 2) void k_node_coop16(const NodeArgs a) {
             c16_prime(gb, wt(3), lane);
             c16m_chain<1, 4, 8>(acc, v, wt(2), lane, ga);
             STAMP16(2);
-            c16_prime(ga, wt(0), lane);
+            c16_prime(ga, wt(SETS == 2 ? 6 : 0), lane);
             c16m_chain<1>(acc, full, wt(3), lane, gb);               // layer 1, aggregate part
+            if constexpr (SETS == 2) {
+#pragma unroll
+                for (int bb = 0; bb < 8; ++bb) full[0][bb] = xch2[bb * 64 + lane];
+                c16_prime(gb, wt(0), lane);
+                c16m_chain<1>(acc, full, wt(6), lane, ga);           // layer 1, the second set's aggregate
+            }
+            C16Ring& r2 = SETS == 2 ? gb : ga;                       // the ring that holds layer 2's first fragments
+            C16Ring& r3 = SETS == 2 ? ga : gb;
             STAMP16(3);
             c16_relu(acc[0]);
-            c16_prime(gb, wt(1), lane);
-            c16m_exchange<1>(full, acc, xch2, wave, lane);
+            c16_prime(r3, wt(1), lane);
+            c16m_exchange<1>(full, acc, SETS == 2 ? xch3 : xch2, wave, lane);
             acc[0][0] = tb2[0];
             acc[0][1] = tb2[1];
-            c16m_chain<1>(acc, full, wt(0), lane, ga);               // layer 2
+            c16m_chain<1>(acc, full, wt(0), lane, r2);               // layer 2
             STAMP16(4);
             c16_relu(acc[0]);
-            if (a.mode == 1) c16_prime(ga, wt(4), lane);             // the projection's first fragments
+            if (a.mode == 1) c16_prime(r2, wt(4), lane);             // the projection's first fragments
             c16m_exchange<1>(full, acc, xch0, wave, lane);
             acc[0][0] = tb3[0];
             acc[0][1] = tb3[1];
-            c16m_chain<1>(acc, full, wt(1), lane, gb);               // layer 3
-            if (a.mode == 1) c16_prime(gb, wt(5), lane);
+            c16m_chain<1>(acc, full, wt(1), lane, r3);               // layer 3
             c16m_layer_norm<1>(acc, red, tg, tb, wave, n);
             STAMP16(5);
             acc[0][0] += vs[0][0];                                   // v <- v + v'  (this wave's slice)
@@ -1024,45 +1062,17 @@ __global__ __launch_bounds__(256, 2) void k_node_coop16(const NodeArgs a) {
                 V4[c16_tile_idx(tile, row, 2 * wave, q)] = acc[0][0];
                 V4[c16_tile_idx(tile, row, 2 * wave + 1, q)] = acc[0][1];
             }
-            if (a.mode == 1) {                                       // P = v W1s, Q = v W1r + b1 of the next step, on the updated rows
+            if (a.mode == 1) {                                       // P, Q of the next step, on the updated rows
                 c16m_exchange<1>(v, acc, xch1, wave, lane);
                 STAMP16(6);
-                f32x4 o[1][2];
-                o[0][0] = o[0][1] = f32x4{0.f, 0.f, 0.f, 0.f};
-                c16m_chain<1>(o, v, wt(4), lane, ga);
-                if (valid) {
-                    f32x4* P4 = reinterpret_cast<f32x4*>(a.P) + (int64_t)nn * 32 + q;
-                    P4[4 * (2 * wave)] = o[0][0];
-                    P4[4 * (2 * wave + 1)] = o[0][1];
-                }
-                c16_tab(o[0], tabs + T_BQ * L, wave, q);
-                c16m_chain<1>(o, v, wt(5), lane, gb);
-                if (valid) {
-                    f32x4* Q4 = reinterpret_cast<f32x4*>(a.Q) + (int64_t)nn * 32 + q;
-                    Q4[4 * (2 * wave)] = o[0][0];
-                    Q4[4 * (2 * wave + 1)] = o[0][1];
-                }
+                c16_project(v, wt(4), wt(5), tabs + T_BQ * L, a.P, a.Q, valid, nn, wave, lane, q, r2, r3, SETS == 2 ? wt(7) : nullptr);
+                if constexpr (SETS == 2)
+                    c16_project(v, wt(7), wt(8), a.tabs2 + (T_COUNT + T_BQ) * L, a.P2, a.Q2, valid, nn, wave, lane, q, r2, r3, nullptr);
             }
-        } else {                                                     // projection only (before the first step)
-            C16Ring ga, gb;
+        } else {                                                     // projection only (before the first step; one set per launch)
             c16_prime(ga, wt(4), lane);
-            c16_prime(gb, wt(5), lane);
             c16m_exchange<1>(v, vs, xch0, wave, lane);
-            f32x4 o[1][2];
-            o[0][0] = o[0][1] = f32x4{0.f, 0.f, 0.f, 0.f};
-            c16m_chain<1>(o, v, wt(4), lane, ga);
-            if (valid) {
-                f32x4* P4 = reinterpret_cast<f32x4*>(a.P) + (int64_t)nn * 32 + q;
-                P4[4 * (2 * wave)] = o[0][0];
-                P4[4 * (2 * wave + 1)] = o[0][1];
-            }
-            c16_tab(o[0], tabs + T_BQ * L, wave, q);
-            c16m_chain<1>(o, v, wt(5), lane, gb);
-            if (valid) {
-                f32x4* Q4 = reinterpret_cast<f32x4*>(a.Q) + (int64_t)nn * 32 + q;
-                Q4[4 * (2 * wave)] = o[0][0];
-                Q4[4 * (2 * wave + 1)] = o[0][1];
-            }
+            c16_project(v, wt(4), wt(5), tabs + T_BQ * L, a.P, a.Q, valid, nn, wave, lane, q, ga, gb, nullptr);
         }
         STAMP16(7);
         __syncthreads();
@@ -2521,9 +2531,9 @@ hipError_t launch_node_step(int L, const NodeArgs& a, hipStream_t s) {
         if (a.mode == 1) DISPATCH_GEN(L, (k_node_step<4, 0, true, 1, true>), (k_node_step<2, 0, true, 1, true>), (k_node_step<1, 0, true, 1, true>), a, a.ntiles);
         DISPATCH_GEN(L, (k_node_step<4, 0, false, 1, true>), (k_node_step<2, 0, false, 1, true>), (k_node_step<1, 0, false, 1, true>), a, a.ntiles);
     }
-    if (a.c16 && L == 128 && a.chunk_t[0] && !a.AGG2) {
-        LaunchCfg c16{2 * a.ntiles, 256, (size_t)3 * 8 * 64 * 16 + 2 * 64 * 4};
-        return launch_k(k_node_coop16, a, c16, s);
+    if (a.c16 && L == 128 && a.chunk_t[0]) {
+        LaunchCfg c16{2 * a.ntiles, 256, (size_t)4 * 8 * 64 * 16 + 2 * 64 * 4};
+        return a.AGG2 ? launch_k(k_node_coop16<2>, a, c16, s) : launch_k(k_node_coop16<1>, a, c16, s);
     }
     if (coop_ok(L, a.ntiles, a.chunk_t)) {
         LaunchCfg c4{a.ntiles, 256, coop_lds()};
@@ -2564,8 +2574,8 @@ hipError_t launch_project(int L, const NodeArgs& a, hipStream_t s) {
     if (a.ntiles <= 0) return hipSuccess;
     LaunchCfg lc = tile_launch(L, a.ntiles, 2);
     if (!a.gen.use && a.c16 && L == 128 && a.chunk_t[0] && !a.AGG2 && a.mode == 2) {
-        LaunchCfg c16{2 * a.ntiles, 256, (size_t)3 * 8 * 64 * 16 + 2 * 64 * 4};
-        return launch_k(k_node_coop16, a, c16, s);
+        LaunchCfg c16{2 * a.ntiles, 256, (size_t)4 * 8 * 64 * 16 + 2 * 64 * 4};
+        return launch_k(k_node_coop16<1>, a, c16, s);
     }
     if (!a.gen.use && a.tile0 == 0 && a.mode == 2 && coop_ok(L, a.ntiles, a.chunk_t)) {
         LaunchCfg c4{a.ntiles, 256, coop_lds()};

@@ -318,12 +318,15 @@ void invalidate_static(mgn_engine* h) {
 }
 
 // 16-row cooperative tiles (v_mfma_f32_16x16x4_f32): both kernels of a processor step must agree (the carry rows are per 16-edge
-// tile then), so the choice is made per handle and graph: fp32, L = 128, hidden_layers = 2, one edge set, and BOTH the edge and the
-// node launches in the cooperative size range
+// tile then), so the choice is made per handle and graph: fp32, L = 128, hidden_layers = 2, and the node launch and EVERY edge
+// set's launch in the cooperative size range
 int32_t use_c16(const mgn_engine* h) {
-    return (coop16_enabled() && h->cfg.dtype == MGN_F32 && h->cfg.L == 128 && h->cfg.hidden_layers == 2 && h->nsets == 1 &&
-            get_kernel_path() != 4 && launch_is_small_edge(h->es[0].ntiles_e) && launch_is_small(h->ntiles_n) &&
-            coop16_size(h->es[0].ntiles_e, h->ntiles_n)) ? 1 : 0;
+    if (!(coop16_enabled() && h->cfg.dtype == MGN_F32 && h->cfg.L == 128 && h->cfg.hidden_layers == 2 && get_kernel_path() != 4 &&
+          launch_is_small(h->ntiles_n)))
+        return 0;
+    for (int q = 0; q < h->nsets; ++q)
+        if (!(launch_is_small_edge(h->es[q].ntiles_e) && coop16_size(h->es[q].ntiles_e, h->ntiles_n))) return 0;
+    return 1;
 }
 
 // GenMlp of an MLP: used when hidden_layers != 2 (or when tests force the GEN kernels, kernel path 4)
@@ -400,6 +403,15 @@ NodeArgs node_args(mgn_engine* h, int k, int mode, int q = 0) {
         a.zero_row2 = 4 * tiles_or_one(h->es[1].ntiles_e);
         a.chunk[6] = W(h, so.n_ch[6]);
         a.chunk_t[6] = a.chunk[6] + CH;
+        if (q == 0) {                                   // the 16-row kernels project both sets in one launch (mode 1)
+            a.P2 = h->es[1].P.as<float>();
+            a.Q2 = h->es[1].Q.as<float>();
+            a.tabs2 = W(h, so.p1_tabs);
+            for (int i = 0; i < 2; ++i) {
+                a.chunk[7 + i] = W(h, so.p1_ch[i]);
+                a.chunk_t[7 + i] = a.chunk[7 + i] + CH;
+            }
+        }
     }
     a.mode = mode;
     a.gen = gen_of(h, so.n_gen, true);
@@ -1145,7 +1157,7 @@ int mgn_proc_node(mgn_handle* h, int32_t k, int32_t project_next) try {
     }
     // large meshes: MLP and projection as two launches (the projection then has both of its chunks LDS-resident);
     // small meshes are launch-latency-bound: one fused launch (M-cyl: 53.0 -> 50.8 us per step)
-    if (project_next && (h->nsets > 1 || (h->node_split && !launch_is_small(h->ntiles_n)))) {
+    if (project_next && !(h->nsets == 2 && use_c16(h)) && (h->nsets > 1 || (h->node_split && !launch_is_small(h->ntiles_n)))) {
         // MLP (2 of its chunks LDS-resident, the others stream from L2), then per edge set the projection with both of
         // its chunks resident
         HIPCHK(h, launch_node_step(h->cfg.L, node_args(h, k, 0), h->stream));

@@ -35,7 +35,7 @@ def engine2(cfg, **kw):
     return mgn_amd.Engine(cfg["Fn"], cfg["Fe"], cfg["O"], cfg["L"], 2, cfg["mps"], Fe2=cfg["Fe2"], **kw)
 
 
-@pytest.fixture(params=[1, 2, 3], ids=["resident", "streaming", "cooperative"])
+@pytest.fixture(params=[1, 2, 3, 5], ids=["resident", "streaming", "cooperative", "cooperative16"])
 def kernel_path(request):
     old = set_kernel_path(request.param)
     yield request.param
