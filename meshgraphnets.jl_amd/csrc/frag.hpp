@@ -129,7 +129,15 @@ DEVINL void relu_frag(f32x16 (&x)[NT]) {
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
-        for (int k = 0; k < 16; ++k) x[t][k] = fmaxf(x[t][k], 0.f);
+        for (int k = 0; k < 16; ++k) {
+#ifdef MGN_RELU_FMAXF
+            x[t][k] = fmaxf(x[t][k], 0.f);          // two instructions: hipcc canonicalises the operand first
+#else
+            float r;                                // one v_max_f32 (maxNum: NaN -> 0, like fmaxf); non-volatile: free to be scheduled
+            asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(x[t][k]));
+            x[t][k] = r;
+#endif
+        }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -145,18 +153,59 @@ template <> struct AVec<1> { typedef float T; };
 template <int NT> DEVINL float aget(const typename AVec<NT>::T& a, int t) { return a[t]; }
 template <> DEVINL float aget<1>(const float& a, int) { return a; }
 
+// tools/issue_probe.hip: independent v_mfma_f32_32x32x2_f32 issued back to back run at 144 TFLOP/s; with >= 16 idle clocks
+// (`s_nop 3`) behind each they reach 156.  MGN_MFMA_NOP = N appends `s_nop N` to every MFMA of the chunk chains (non-volatile
+// inline asm: hipcc may still move the LDS / global weight reads across it).  The assembler-level MFMA is invisible to hipcc's
+// hazard recogniser: MFMA_CHAIN_BEGIN / _END supply the wait states around a chain.
+#ifndef MGN_MFMA_NOP
+#define MGN_MFMA_NOP 3          // -1: the compiler builtin, no padding (A/B)
+#endif
+#if MGN_MFMA_NOP >= 0
+DEVINL f32x16 mfma32(float a, float b, f32x16 c) {
+    asm("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0\n\ts_nop %3" : "+v"(c) : "v"(a), "v"(b), "n"(MGN_MFMA_NOP));
+    return c;
+}
+// wait states tied to the registers they protect (an untied `s_nop` statement is free to move away from them):
+// VALU writes of the operands -> first MFMA; last MFMAs -> VALU reads of the accumulators (16 passes: 18 wait states)
+template <int NT>
+DEVINL void mfma_chain_begin(f32x16 (&acc)[NT], const f32x16 (&in)[NT]) {
+    if constexpr (NT == 4)
+        asm volatile("s_nop 1" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]) : "v"(in[0]), "v"(in[1]), "v"(in[2]), "v"(in[3]));
+    else if constexpr (NT == 2)
+        asm volatile("s_nop 1" : "+v"(acc[0]), "+v"(acc[1]) : "v"(in[0]), "v"(in[1]));
+    else
+        asm volatile("s_nop 1" : "+v"(acc[0]) : "v"(in[0]));
+}
+template <int NT>
+DEVINL void mfma_chain_end(f32x16 (&acc)[NT]) {
+    if constexpr (NT == 4)
+        asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]));
+    else if constexpr (NT == 2)
+        asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" : "+v"(acc[0]), "+v"(acc[1]));
+    else
+        asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" : "+v"(acc[0]));
+}
+#define MFMA_CHAIN_BEGIN(ACC, IN) mfma_chain_begin(ACC, IN)
+#define MFMA_CHAIN_END(ACC, NT_) mfma_chain_end(ACC)
+#else
+DEVINL f32x16 mfma32(float a, float b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
+#define MFMA_CHAIN_BEGIN(ACC, IN) do {} while (0)
+#define MFMA_CHAIN_END(ACC, NT_) do {} while (0)
+#endif
+
 template <int NT, bool RES>
 DEVINL void mfma_chunk(f32x16 (&acc)[NT], const f32x16 (&in)[NT], const float* w, int lane) {
     typedef typename AVec<NT>::T AV;
     constexpr int J = 16 * NT;
     const AV* wv = reinterpret_cast<const AV*>(w) + lane;
+    MFMA_CHAIN_BEGIN(acc, in);
     if constexpr (RES) {
 #pragma unroll
         for (int j = 0; j < J; ++j) {
             const AV a = wv[j * 64];
 #pragma unroll
             for (int t = 0; t < NT; ++t)
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(aget<NT>(a, t), in[j >> 4][j & 15], acc[t], 0, 0, 0);
+                acc[t] = mfma32(aget<NT>(a, t), in[j >> 4][j & 15], acc[t]);
         }
     } else {
 #ifndef MGN_CHUNK_PF
@@ -178,12 +227,13 @@ DEVINL void mfma_chunk(f32x16 (&acc)[NT], const f32x16 (&in)[NT], const float* w
 #endif
 #pragma unroll
             for (int t = 0; t < NT; ++t)
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(aget<NT>(a, t), in[j >> 4][j & 15], acc[t], 0, 0, 0);
+                acc[t] = mfma32(aget<NT>(a, t), in[j >> 4][j & 15], acc[t]);
 #ifdef MGN_CHUNK_FENCE
             __builtin_amdgcn_sched_barrier(0);
 #endif
         }
     }
+    MFMA_CHAIN_END(acc, NT);
 }
 
 // A chunk whose first JR k-steps are LDS-resident and whose tail streams from L2 (JR = 0: all streamed).  The
@@ -199,6 +249,7 @@ DEVINL void mfma_chunk_split(f32x16 (&acc)[NT], const f32x16 (&in)[NT], const fl
     const AV* wl = reinterpret_cast<const AV*>(w_lds) + lane;
     const AV* wg = reinterpret_cast<const AV*>(w_glb) + lane;
     AV ring[PF > 0 ? PF : 1];
+    MFMA_CHAIN_BEGIN(acc, in);
 #pragma unroll
     for (int p = 0; p < PF; ++p) ring[p] = wg[(JR + p) * 64];
 #ifdef MGN_SPLIT_FENCE
@@ -218,11 +269,12 @@ DEVINL void mfma_chunk_split(f32x16 (&acc)[NT], const f32x16 (&in)[NT], const fl
         }
 #pragma unroll
         for (int t = 0; t < NT; ++t)
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(aget<NT>(a, t), in[j >> 4][j & 15], acc[t], 0, 0, 0);
+            acc[t] = mfma32(aget<NT>(a, t), in[j >> 4][j & 15], acc[t]);
 #ifdef MGN_SPLIT_FENCE
         if (j >= JR) __builtin_amdgcn_sched_barrier(0);
 #endif
     }
+    MFMA_CHAIN_END(acc, NT);
 }
 
 // LayerNorm over the row's L features: 16*NT in this lane + 16*NT in lane^32.  Biased variance.

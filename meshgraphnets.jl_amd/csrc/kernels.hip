@@ -234,7 +234,7 @@ __global__ __launch_bounds__(512, 2) void k_edge_step(const EdgeArgs a) {
     tw.end += a.tile0;
     if (tw.tile >= tw.end) return;
     f32x16 x[NT], acc[NT], y[NT];
-    EdgeIdx ix = load_edge_idx(a, tw.tile, lane0 & 31);
+    EdgeIdx ix = load_edge_idx_nb(a.snd, a.rcv, a.E, tw.tile, lane0 & 31);
     {
         const int h0 = lane0 >> 5;
         load_frag<NT>(acc, row_ptr(a.P, ix.s, L, h0), STRIDE_ROW);
@@ -252,7 +252,7 @@ __global__ __launch_bounds__(512, 2) void k_edge_step(const EdgeArgs a) {
         // indices of the NEXT tile are fetched now, ahead of this tile's stores (in-order vmcnt)
         // (the last tile of a wave harmlessly re-fetches itself: no divergent control flow around the loads)
         const int nxt = has_next ? next : tile;
-        const EdgeIdx ixn = load_edge_idx(a, nxt, c);
+        const EdgeIdx ixn = load_edge_idx_nb(a.snd, a.rcv, a.E, nxt, c);   // branch-free: no wait behind the request
         const bool valid = ix.r >= 0;
         const int r = valid ? ix.r : 0;
         f32x4* etile = tile_ptr(a.Elat, tile, L, lane);
