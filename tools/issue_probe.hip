@@ -27,6 +27,51 @@ __device__ __forceinline__ void mfma_role(int iters, float* sink, int lane) {
     asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");
     sink[threadIdx.x] = a0[0] + a1[1] + a2[2] + a3[3];
 }
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+template <int NOP>
+__device__ __forceinline__ void mfma16_role(int iters, float* sink, int lane) {   // 6 independent 16x16x4 accumulators
+    f32x4 a[6] = {};
+    float x = 1.0f + lane * 1e-3f, y = 0.5f;
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {
+                asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(a[k]) : "v"(x), "v"(y));
+                if (NOP >= 0) asm volatile("s_nop %0" ::"n"(NOP >= 0 ? NOP : 0));
+            }
+    }
+    asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");
+    sink[threadIdx.x] = a[0][0] + a[1][1] + a[2][2] + a[3][3] + a[4][0] + a[5][1];
+}
+template <int NOP>
+__global__ __launch_bounds__(256, 1) void k_probe16(int mi, float* sink, unsigned long long* t) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    unsigned long long t0, t1;
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0)::"memory");
+    mfma16_role<NOP>(mi, sink + blockIdx.x * 256, lane);
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1)::"memory");
+    if (lane == 0) t[blockIdx.x * 4 + wave] = t1 - t0;
+}
+template <int NOP>
+void run16(const char* name, int mi) {
+    float* sink;
+    unsigned long long* t;
+    hipMalloc(&sink, 256 * 256 * 4);
+    hipMalloc(&t, 256 * 4 * 8);
+    unsigned long long h[256 * 4];
+    for (int rep = 0; rep < 2; ++rep) {
+        hipLaunchKernelGGL(k_probe16<NOP>, dim3(256), dim3(256), 0, 0, mi, sink, t);
+        hipDeviceSynchronize();
+    }
+    hipMemcpy(h, t, sizeof(h), hipMemcpyDeviceToHost);
+    double m = 0;
+    for (int i = 0; i < 256 * 4; ++i) m += h[i] * 0.01 / (256 * 4);
+    printf("16x16x4 %-8s %.1f us for %d MFMAs per wave = %.1f clocks each at 2.4 GHz (%.1f TFLOP/s on 1024 SIMDs)\n", name, m, 24 * mi,
+           m * 2400.0 / (24 * mi), 24.0 * mi * 2048 * 1024 / m * 1e-6);
+    hipFree(sink);
+    hipFree(t);
+}
 __device__ __forceinline__ void valu_role(int iters, float* sink, int lane) {
     float v[8];
 #pragma unroll
@@ -93,5 +138,10 @@ int main() {
     run<11>("s_nop 11", mi, vi);
     run<13>("s_nop 13", mi, vi);
     run<15>("s_nop 15", mi, vi);
+    run16<-1>("no nop", 1500);
+    run16<0>("s_nop 0", 1500);
+    run16<1>("s_nop 1", 1500);
+    run16<3>("s_nop 3", 1500);
+    run16<5>("s_nop 5", 1500);
     return 0;
 }
