@@ -9,10 +9,10 @@ pos, s, r = mgn_amd.synth.mesh_1m(1234, nx, nx)
 eng = mgn_amd.Engine(9, 3, 2, 128, 2, 15)
 eng.set_params(bench.glorot_params()); eng.set_graph(s, r, pos.shape[0]); eng.latents_randn(1)
 eng.processor_steps_dev(2)
-out = np.zeros(4 * 8 * 24 * 8, np.uint64)
+out = np.zeros(32768, np.uint64)
 f = eng.lib.mgn_debug_edge_stamps; f.restype = C.c_int; f.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
 assert f(eng.h, 1, out.ctypes.data_as(C.c_void_p)) == 0
-st = out.reshape(4, 8, 24, 8).astype(np.int64)
+st = out[:4 * 8 * 24 * 8].reshape(4, 8, 24, 8).astype(np.int64)
 names = ["issue_loads", "wait+L1", "L2", "L3", "LN", "resid+store", "scan", "tailstore(to next start)"]
 for b in range(1):
     t0 = st[b, :, 0, 0].min()
