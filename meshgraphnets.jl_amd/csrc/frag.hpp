@@ -161,9 +161,14 @@ template <> DEVINL float aget<1>(const float& a, int) { return a; }
 #define MGN_MFMA_NOP 3          // -1: the compiler builtin, no padding (A/B)
 #endif
 #if MGN_MFMA_NOP >= 0
+template <bool PAD>
 DEVINL f32x16 mfma32(float a, float b, f32x16 c) {
-    asm("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0\n\ts_nop %3" : "+v"(c) : "v"(a), "v"(b), "n"(MGN_MFMA_NOP));
-    return c;
+    if constexpr (PAD) {
+        asm("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0\n\ts_nop %3" : "+v"(c) : "v"(a), "v"(b), "n"(MGN_MFMA_NOP));
+        return c;
+    } else {
+        return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+    }
 }
 // wait states tied to the registers they protect (an untied `s_nop` statement is free to move away from them):
 // VALU writes of the operands -> first MFMA; last MFMAs -> VALU reads of the accumulators (16 passes: 18 wait states)
@@ -185,15 +190,16 @@ DEVINL void mfma_chain_end(f32x16 (&acc)[NT]) {
     else
         asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" : "+v"(acc[0]));
 }
-#define MFMA_CHAIN_BEGIN(ACC, IN) mfma_chain_begin(ACC, IN)
-#define MFMA_CHAIN_END(ACC, NT_) mfma_chain_end(ACC)
+#define MFMA_CHAIN_BEGIN(ACC, IN) do { if constexpr (PAD) mfma_chain_begin(ACC, IN); } while (0)
+#define MFMA_CHAIN_END(ACC, NT_) do { if constexpr (PAD) mfma_chain_end(ACC); } while (0)
 #else
-DEVINL f32x16 mfma32(float a, float b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
+template <bool PAD> DEVINL f32x16 mfma32(float a, float b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
 #define MFMA_CHAIN_BEGIN(ACC, IN) do {} while (0)
 #define MFMA_CHAIN_END(ACC, NT_) do {} while (0)
 #endif
 
-template <int NT, bool RES>
+// PAD = false: the compiler builtin (k_node_step is 6 % slower with the padded form; k_edge_step and k_project are faster)
+template <int NT, bool RES, bool PAD = true>
 DEVINL void mfma_chunk(f32x16 (&acc)[NT], const f32x16 (&in)[NT], const float* w, int lane) {
     typedef typename AVec<NT>::T AV;
     constexpr int J = 16 * NT;
@@ -205,7 +211,7 @@ DEVINL void mfma_chunk(f32x16 (&acc)[NT], const f32x16 (&in)[NT], const float* w
             const AV a = wv[j * 64];
 #pragma unroll
             for (int t = 0; t < NT; ++t)
-                acc[t] = mfma32(aget<NT>(a, t), in[j >> 4][j & 15], acc[t]);
+                acc[t] = mfma32<PAD>(aget<NT>(a, t), in[j >> 4][j & 15], acc[t]);
         }
     } else {
 #ifndef MGN_CHUNK_PF
@@ -227,7 +233,7 @@ DEVINL void mfma_chunk(f32x16 (&acc)[NT], const f32x16 (&in)[NT], const float* w
 #endif
 #pragma unroll
             for (int t = 0; t < NT; ++t)
-                acc[t] = mfma32(aget<NT>(a, t), in[j >> 4][j & 15], acc[t]);
+                acc[t] = mfma32<PAD>(aget<NT>(a, t), in[j >> 4][j & 15], acc[t]);
 #ifdef MGN_CHUNK_FENCE
             __builtin_amdgcn_sched_barrier(0);
 #endif
@@ -238,7 +244,7 @@ DEVINL void mfma_chunk(f32x16 (&acc)[NT], const f32x16 (&in)[NT], const float* w
 
 // A chunk whose first JR k-steps are LDS-resident and whose tail streams from L2 (JR = 0: all streamed).  The
 // ring is primed before the resident steps, so the first streamed fragments have JR k-steps to arrive.
-template <int NT, int JR>
+template <int NT, int JR, bool PAD = true>
 DEVINL void mfma_chunk_split(f32x16 (&acc)[NT], const f32x16 (&in)[NT], const float* w_lds, const float* w_glb, int lane) {
     typedef typename AVec<NT>::T AV;
     constexpr int J = 16 * NT;
@@ -269,7 +275,7 @@ DEVINL void mfma_chunk_split(f32x16 (&acc)[NT], const f32x16 (&in)[NT], const fl
         }
 #pragma unroll
         for (int t = 0; t < NT; ++t)
-            acc[t] = mfma32(aget<NT>(a, t), in[j >> 4][j & 15], acc[t]);
+            acc[t] = mfma32<PAD>(aget<NT>(a, t), in[j >> 4][j & 15], acc[t]);
 #ifdef MGN_SPLIT_FENCE
         if (j >= JR) __builtin_amdgcn_sched_barrier(0);
 #endif

@@ -343,6 +343,10 @@ __global__ __launch_bounds__(512, 2) void k_edge_step(const EdgeArgs a) {
     } while (0)
 
 // NAGG = 2: a second edge set's aggregate (AGG2 / CARRY2 / rowptr2) is a further layer-1 input, chunk[6] streamed.
+#ifndef MGN_NODE_PAD
+#define MGN_NODE_PAD 0
+#endif
+constexpr bool NODE_PAD = MGN_NODE_PAD != 0;
 template <int NT, int NRES, bool PROJECT, int NAGG = 1, bool GEN = false>
 __global__ __launch_bounds__(512, 2) void k_node_step(const NodeArgs a) {
     constexpr int L = 32 * NT, CH = 16 * NT * 64 * NT;
@@ -383,11 +387,11 @@ __global__ __launch_bounds__(512, 2) void k_node_step(const NodeArgs a) {
             LOAD_AGGREGATE(NT, y, a.rowptr, a.AGG, a.CARRY, a.zero_row);
 
             tab_frag<NT>(acc, tb + T_B1 * L, h);
-            mfma_chunk<NT, (NRES > 2)>(acc, v, w1v, lane);     // layer 1, node part
-            mfma_chunk<NT, (NRES > 3)>(acc, y, w1a, lane);     // layer 1, aggregate part
+            mfma_chunk<NT, (NRES > 2), NODE_PAD>(acc, v, w1v, lane);     // layer 1, node part
+            mfma_chunk<NT, (NRES > 3), NODE_PAD>(acc, y, w1a, lane);     // layer 1, aggregate part
             if constexpr (NAGG > 1) {
                 LOAD_AGGREGATE(NT, y, a.rowptr2, a.AGG2, a.CARRY2, a.zero_row2);
-                mfma_chunk<NT, false>(acc, y, a.chunk[6], lane);   // layer 1, second edge set's aggregate
+                mfma_chunk<NT, false, NODE_PAD>(acc, y, a.chunk[6], lane);   // layer 1, second edge set's aggregate
             }
             if constexpr (GEN) {
                 gen_hidden<NT>(acc, y, a.gen, lane, h);
@@ -395,10 +399,10 @@ __global__ __launch_bounds__(512, 2) void k_node_step(const NodeArgs a) {
             } else {
                 relu_frag<NT>(acc);
                 tab_frag<NT>(y, tb + T_B2 * L, h);
-                mfma_chunk<NT, (NRES > 0)>(y, acc, w2, lane);      // layer 2
+                mfma_chunk<NT, (NRES > 0), NODE_PAD>(y, acc, w2, lane);      // layer 2
                 relu_frag<NT>(y);
                 tab_frag<NT>(acc, tb + T_B3 * L, h);
-                mfma_chunk<NT, (NRES > 1)>(acc, y, w3, lane);      // layer 3
+                mfma_chunk<NT, (NRES > 1), NODE_PAD>(acc, y, w3, lane);      // layer 3
             }
 #ifdef MGN_PRIO_NODE
             __builtin_amdgcn_s_setprio(MGN_PRIO_NODE);
@@ -413,10 +417,10 @@ __global__ __launch_bounds__(512, 2) void k_node_step(const NodeArgs a) {
         }
         if constexpr (PROJECT) {
             zero_frag<NT>(acc);
-            mfma_chunk<NT, (NRES > 4)>(acc, v, wp, lane);
+            mfma_chunk<NT, (NRES > 4), NODE_PAD>(acc, v, wp, lane);
             if (valid) store_frag<NT>(row_ptr(a.P, nn, L, h), STRIDE_ROW, acc);
             tab_frag<NT>(y, tb + T_BQ * L, h);
-            mfma_chunk<NT, (NRES > 5)>(y, v, wq, lane);
+            mfma_chunk<NT, (NRES > 5), NODE_PAD>(y, v, wq, lane);
             if (valid) store_frag<NT>(row_ptr(a.Q, nn, L, h), STRIDE_ROW, y);
         }
     }
