@@ -352,6 +352,13 @@ DEVINL void copy_to_lds_vec(f32x4* d4, const f32x4* __restrict__ s4, int n4) {
     }
 }
 
+// weight preload of a persistent launch: the plain loop for long launches, eight loads in flight when the launch has only a few
+// tiles per wave (the ~20 us prologue of the plain loop is then a large share of the kernel: node side of a 125 k-node mesh)
+DEVINL void copy_to_lds_sel(float* dst, const float* __restrict__ src, int nfloats, bool fast) {
+    if (fast) copy_to_lds_vec(reinterpret_cast<f32x4*>(dst), reinterpret_cast<const f32x4*>(src), nfloats / 4);
+    else copy_to_lds(dst, src, nfloats);
+}
+
 // ------------------------------------------------------------------------------------------------
 // Cooperative 4-wave tiles (L = 128): wave t owns feature block t of every layer's output; see kernels.hip
 // ("Cooperative-tile kernels for SMALL graphs") for the design.  Shared by kernels.hip and train.hip.

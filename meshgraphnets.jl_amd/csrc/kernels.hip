@@ -346,18 +346,22 @@ __global__ __launch_bounds__(512, 2) void k_edge_step(const EdgeArgs a) {
 #ifndef MGN_NODE_PAD
 #define MGN_NODE_PAD 0
 #endif
+#ifndef MGN_FAST_PRELOAD_TILES
+#define MGN_FAST_PRELOAD_TILES 8192     // node-side launches of up to 4 tiles per wave copy their weights with eight loads in flight
+#endif
 constexpr bool NODE_PAD = MGN_NODE_PAD != 0;
 template <int NT, int NRES, bool PROJECT, int NAGG = 1, bool GEN = false>
 __global__ __launch_bounds__(512, 2) void k_node_step(const NodeArgs a) {
     constexpr int L = 32 * NT, CH = 16 * NT * 64 * NT;
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    const bool fast = a.ntiles <= MGN_FAST_PRELOAD_TILES;             // few tiles per wave: see copy_to_lds_sel
     {
 #pragma unroll
-        for (int r = 0; r < (NRES < 4 ? NRES : 4); ++r) copy_to_lds(smem + r * CH, a.chunk[r], CH);
+        for (int r = 0; r < (NRES < 4 ? NRES : 4); ++r) copy_to_lds_sel(smem + r * CH, a.chunk[r], CH, fast);
     }
     if (PROJECT && NRES > 4) {
 #pragma unroll
-        for (int r = 4; r < NRES; ++r) copy_to_lds(smem + r * CH, a.chunk[r], CH);
+        for (int r = 4; r < NRES; ++r) copy_to_lds_sel(smem + r * CH, a.chunk[r], CH, fast);
     }
     float* tb = smem + NRES * CH;
     copy_to_lds(tb, a.tabs, T_COUNT * L);
@@ -437,8 +441,9 @@ __global__ __launch_bounds__(MGN_PROJ_WAVES * 64, MGN_PROJ_WAVES / 4) void k_pro
     constexpr int L = 32 * NT, CH = 16 * NT * 64 * NT;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     if (RES) {
-        copy_to_lds(smem, a.chunk[4], CH);
-        copy_to_lds(smem + CH, a.chunk[5], CH);
+        const bool fast = a.ntiles <= MGN_FAST_PRELOAD_TILES;
+        copy_to_lds_sel(smem, a.chunk[4], CH, fast);
+        copy_to_lds_sel(smem + CH, a.chunk[5], CH, fast);
     }
     float* tb = smem + (RES ? 2 * CH : 0);
     copy_to_lds(tb, a.tabs, T_COUNT * L);
