@@ -126,6 +126,13 @@ DEVINL void zero_frag(f32x16 (&x)[NT]) {
 
 template <int NT>
 DEVINL void relu_frag(f32x16 (&x)[NT]) {
+#ifndef MGN_RELU_FMAXF
+    // x usually comes straight out of an MFMA chain, and hipcc's hazard recogniser does not cover an inline-asm reader of an MFMA
+    // result (16 passes: 18 wait states before a VALU read): the wait states, tied to the registers
+    if constexpr (NT == 4) asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]));
+    else if constexpr (NT == 2) asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" : "+v"(x[0]), "+v"(x[1]));
+    else asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" : "+v"(x[0]));
+#endif
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
@@ -138,6 +145,13 @@ DEVINL void relu_frag(f32x16 (&x)[NT]) {
             x[t][k] = r;
 #endif
         }
+#ifndef MGN_RELU_FMAXF
+    // ... and the other way round: an inline-asm VALU write followed by a compiler-issued MFMA that reads the register gets no
+    // wait states either (k_node_step, builtin MFMAs: wrong results in the streaming and L = 64 / 32 instantiations)
+    if constexpr (NT == 4) asm volatile("s_nop 3" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]));
+    else if constexpr (NT == 2) asm volatile("s_nop 3" : "+v"(x[0]), "+v"(x[1]));
+    else asm volatile("s_nop 3" : "+v"(x[0]));
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -175,11 +189,11 @@ DEVINL f32x16 mfma32(float a, float b, f32x16 c) {
 template <int NT>
 DEVINL void mfma_chain_begin(f32x16 (&acc)[NT], const f32x16 (&in)[NT]) {
     if constexpr (NT == 4)
-        asm volatile("s_nop 1" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]) : "v"(in[0]), "v"(in[1]), "v"(in[2]), "v"(in[3]));
+        asm volatile("s_nop 3" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]) : "v"(in[0]), "v"(in[1]), "v"(in[2]), "v"(in[3]));
     else if constexpr (NT == 2)
-        asm volatile("s_nop 1" : "+v"(acc[0]), "+v"(acc[1]) : "v"(in[0]), "v"(in[1]));
+        asm volatile("s_nop 3" : "+v"(acc[0]), "+v"(acc[1]) : "v"(in[0]), "v"(in[1]));
     else
-        asm volatile("s_nop 1" : "+v"(acc[0]) : "v"(in[0]));
+        asm volatile("s_nop 3" : "+v"(acc[0]) : "v"(in[0]));
 }
 template <int NT>
 DEVINL void mfma_chain_end(f32x16 (&acc)[NT]) {

@@ -89,7 +89,9 @@ DEVINL float dpp_zero(float v) {
 #ifndef MGN_SCAN_FMAC
 #define MGN_SCAN_FMAC 1
 #endif
-template <int NG>
+// SKIP8: the reach-8 level runs only when some run of the tile reaches back 8 rows (in-degree >= 9; a wave-uniform branch).
+// bf16 edge kernel 0.918 -> 0.907 ms on M-1M; the fp32 kernel gets 3 % SLOWER with the branch (same-box A/B), so only bf16 uses it.
+template <int NG, bool SKIP8 = false>
 DEVINL void segmented_scan(f32x16 (&acc)[NG], bool c1, bool c2, bool c4, bool c8, bool cx) {
 #if MGN_SCAN_FMAC
     const float m1 = c1 ? 1.f : 0.f, m2 = c2 ? 1.f : 0.f, m4 = c4 ? 1.f : 0.f, m8 = c8 ? 1.f : 0.f, mx = cx ? 1.f : 0.f;
@@ -102,7 +104,9 @@ DEVINL void segmented_scan(f32x16 (&acc)[NG], bool c1, bool c2, bool c4, bool c8
     MGN_SCAN_LEVEL(m1, "row_shr:1 row_mask:0xf bank_mask:0xf")
     MGN_SCAN_LEVEL(m2, "row_shr:2 row_mask:0xf bank_mask:0xf")
     MGN_SCAN_LEVEL(m4, "row_shr:4 row_mask:0xf bank_mask:0xf")
-    MGN_SCAN_LEVEL(m8, "row_shr:8 row_mask:0xf bank_mask:0xf")
+    if (!SKIP8 || __builtin_amdgcn_ballot_w64(c8) != 0) {
+        MGN_SCAN_LEVEL(m8, "row_shr:8 row_mask:0xf bank_mask:0xf")
+    }
     MGN_SCAN_LEVEL(mx, "row_bcast:15 row_mask:0xa bank_mask:0xf")
 #undef MGN_SCAN_LEVEL
     PHASE_FENCE();
@@ -1552,7 +1556,7 @@ __global__ __launch_bounds__(MGN_BF_WAVES * 64, MGN_BF_WAVES / 4) void k_edge_bf
         const int st_in = max(start, c & 16);
         const bool c1 = (c - 1 >= st_in), c2 = (c - 2 >= st_in), c4 = (c - 4 >= st_in), c8 = (c - 8 >= st_in);
         const bool cx = (c >= 16) && (start <= 15);
-        segmented_scan<4>(acc, c1, c2, c4, c8, cx);
+        segmented_scan<4, true>(acc, c1, c2, c4, c8, cx);
         const bool tail = valid && ((c == 31) || (reff != rnext));
         const int r_first = __builtin_amdgcn_readfirstlane(reff);
         const bool sl = (start == 0) && (ix.r_before == r_first);
@@ -1804,7 +1808,7 @@ DEVINL void bf_edge_tile(const BfEdgeArgs& a, const BfEdgeCtx& cx, int tile, int
     const bool c1 = (c - 1 >= st_in), c2 = (c - 2 >= st_in), c4 = (c - 4 >= st_in), c8 = (c - 8 >= st_in);
     const bool cxr = (c >= 16) && (start <= 15);
 #ifndef MGN_EXP_NOSCAN
-    segmented_scan<4>(acc, c1, c2, c4, c8, cxr);
+    segmented_scan<4, true>(acc, c1, c2, c4, c8, cxr);
 #endif
     STAMP(6);
     const bool tail = valid && ((c == 31) || (reff != rnext));
