@@ -124,8 +124,22 @@ DEVINL void zero_frag(f32x16 (&x)[NT]) {
         for (int k = 0; k < 16; ++k) x[t][k] = 0.f;
 }
 
-template <int NT>
+// ASM = false: plain fmaxf (two instructions per element, but nothing the scheduler cannot see: k_node_step, which keeps the builtin
+// MFMAs, is 7 % slower with the asm form and its wait states)
+#ifdef MGN_RELU_FMAXF
+constexpr bool RELU_ASM_DEFAULT = false;
+#else
+constexpr bool RELU_ASM_DEFAULT = true;
+#endif
+template <int NT, bool ASM = RELU_ASM_DEFAULT>
 DEVINL void relu_frag(f32x16 (&x)[NT]) {
+    if constexpr (!ASM) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int k = 0; k < 16; ++k) x[t][k] = fmaxf(x[t][k], 0.f);
+        return;
+    }
 #ifndef MGN_RELU_FMAXF
     // x usually comes straight out of an MFMA chain, and hipcc's hazard recogniser does not cover an inline-asm reader of an MFMA
     // result (16 passes: 18 wait states before a VALU read): the wait states, tied to the registers

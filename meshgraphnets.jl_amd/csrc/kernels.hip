@@ -405,10 +405,10 @@ __global__ __launch_bounds__(512, 2) void k_node_step(const NodeArgs a) {
                 gen_hidden<NT>(acc, y, a.gen, lane, h);
                 gen_final<NT>(acc, y, a.gen, lane, h);
             } else {
-                relu_frag<NT>(acc);
+                relu_frag<NT, NODE_PAD>(acc);
                 tab_frag<NT>(y, tb + T_B2 * L, h);
                 mfma_chunk<NT, (NRES > 0), NODE_PAD>(y, acc, w2, lane);      // layer 2
-                relu_frag<NT>(y);
+                relu_frag<NT, NODE_PAD>(y);
                 tab_frag<NT>(acc, tb + T_B3 * L, h);
                 mfma_chunk<NT, (NRES > 1), NODE_PAD>(acc, y, w3, lane);      // layer 3
             }
