@@ -43,6 +43,8 @@ struct EdgeArgs {
     GenMlp gen;
     int32_t c16;            // 1: small graph, 16-row cooperative tiles on v_mfma_f32_16x16x4_f32 (both kernels of a step must agree:
                             //    the carry rows are then per 16-edge tile)
+    int32_t bf;             // 16-row kernels in bf16 mode: P, Q, Elat, AGG, CARRY are bf16 arrays in the bf16 kernels' layouts (passed
+                            //    through the float pointers); weights, tables and arithmetic stay fp32
 };
 
 struct NodeArgs {
@@ -68,6 +70,7 @@ struct NodeArgs {
     // 16-row kernels with two edge sets, mode 1: the second set's projection in the same launch (chunk[7] = WP, chunk[8] = WQ of
     // set 1, tabs2 = its tables: T_BQ holds b1 of set 1's edge MLP)
     float* P2; float* Q2; const float* tabs2;
+    int32_t bf;             // see EdgeArgs (V, AGG, CARRY, P, Q bf16)
     unsigned long long* stamps;  // diagnostic builds only (MGN_DIAG_STAMPS), else null
 };
 

@@ -668,6 +668,54 @@ DEVINL f32x4 c16_mfma(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_
 DEVINL int64_t c16_tile_idx(int64_t tile, int row, int bb, int q) {
     return (tile * 1024 + (q >> 1) * 64 + 32 * (q & 1) + row) + 128 * bb;
 }
+// ---- latent storage of the 16-row kernels: fp32 (tile-major float4 pieces / row-major rows) or, in bf16 mode (BF), the bf16
+// kernels' arrays: a row is 16 pieces of 8 bf16, piece 2 s + h holding features 32 (s >> 1) + 16 (s & 1) + 8 (j >> 2) + 4 h + (j & 3);
+// this lane's four features 16 bb + 4 q + (0..3) are elements 4 (q >> 1) .. + 3 of piece (s = bb, h = q & 1): one 8-byte access.
+// Tile-major: [tile][s][32 h + row] pieces; row-major: [row][2 s + h] pieces.  Arithmetic stays fp32 (conversion on load / store).
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+DEVINL f32x4 c16_unpack4(const uint2 w) {
+    const uint32_t a = w.x, b = w.y;
+    f32x4 r;
+    r[0] = __builtin_bit_cast(float, a << 16);
+    r[1] = __builtin_bit_cast(float, a & 0xFFFF0000u);
+    r[2] = __builtin_bit_cast(float, b << 16);
+    r[3] = __builtin_bit_cast(float, b & 0xFFFF0000u);
+    return r;
+}
+DEVINL uint2 c16_pack4(const f32x4 v) {
+    bf16x4 o;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) o[i] = (__bf16)v[i];
+    return __builtin_bit_cast(uint2, o);
+}
+DEVINL int64_t c16_bf_tile_off(int64_t tile, int row, int bb, int q) { return tile * 4096 + (int64_t)(bb * 64 + 32 * (q & 1) + row) * 8 + 4 * (q >> 1); }
+DEVINL int64_t c16_bf_row_off(int64_t r, int bb, int q) { return r * 128 + (2 * bb + (q & 1)) * 8 + 4 * (q >> 1); }
+template <bool BF>
+DEVINL f32x4 c16_ld_tile(const float* base, int64_t tile, int row, int bb, int q) {
+    if constexpr (BF) return c16_unpack4(*reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(base) + c16_bf_tile_off(tile, row, bb, q)));
+    else return reinterpret_cast<const f32x4*>(base)[c16_tile_idx(tile, row, bb, q)];
+}
+template <bool BF>
+DEVINL void c16_st_tile(float* base, int64_t tile, int row, int bb, int q, const f32x4 v) {
+    if constexpr (BF) *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(base) + c16_bf_tile_off(tile, row, bb, q)) = c16_pack4(v);
+    else reinterpret_cast<f32x4*>(base)[c16_tile_idx(tile, row, bb, q)] = v;
+}
+template <bool BF>
+DEVINL f32x4 c16_ld_row(const float* base, int64_t r, int bb, int q) {      // row-major [r][128]
+    if constexpr (BF) return c16_unpack4(*reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(base) + c16_bf_row_off(r, bb, q)));
+    else return reinterpret_cast<const f32x4*>(base)[r * 32 + q + 4 * bb];
+}
+template <bool BF>
+DEVINL void c16_st_row(float* base, int64_t r, int bb, int q, const f32x4 v) {
+    if constexpr (BF) *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(base) + c16_bf_row_off(r, bb, q)) = c16_pack4(v);
+    else reinterpret_cast<f32x4*>(base)[r * 32 + q + 4 * bb] = v;
+}
+// the value a bf16 store keeps (so that what is computed from a row equals what a later launch computes from the stored row)
+template <bool BF> DEVINL f32x4 c16_round(const f32x4 v) {
+    if constexpr (BF) return c16_unpack4(c16_pack4(v));
+    else return v;
+}
+
 // one L x L chunk: this wave's two output blocks; wt = chunk16 + w * 4096 floats ([bb][j][lane][4]).  The weight fragments come
 // from L2 (a launch of one or two tiles per CU cannot amortise an LDS preload) through a register ring C16_PF k-groups deep, pinned
 // by scheduling fences (hipcc otherwise sinks every request to just before its use), and a chain's first fragments can be requested
@@ -781,7 +829,7 @@ DEVINL void c16m_layer_norm(f32x4 (&mine)[RT][2], float* red, const f32x4 (&g)[2
     }
 }
 
-template <int RT>
+template <int RT, bool BF>
 __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_edge_coop16m(const EdgeArgs a) {
     constexpr int L = 128;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -831,9 +879,8 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
         // LDS; tables, the next layer's weights and the gathered rows are requested inside the layer-1 chain.
 #pragma unroll
         for (int t = 0; t < RT; ++t) {
-            const f32x4* E4 = reinterpret_cast<const f32x4*>(a.Elat);
-            xs[t][0] = E4[c16_tile_idx(tile[t], row[t], 2 * wave, q)];
-            xs[t][1] = E4[c16_tile_idx(tile[t], row[t], 2 * wave + 1, q)];
+            xs[t][0] = c16_ld_tile<BF>(a.Elat, tile[t], row[t], 2 * wave, q);
+            xs[t][1] = c16_ld_tile<BF>(a.Elat, tile[t], row[t], 2 * wave + 1, q);
         }
         C16Ring g1, g2;
         c16_prime(g1, w1, lane);
@@ -854,12 +901,10 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
         f32x4 pq[RT][2][2];
 #pragma unroll
         for (int t = 0; t < RT; ++t) {
-            const f32x4* P4 = reinterpret_cast<const f32x4*>(a.P) + (int64_t)s_[t] * 32 + q;
-            const f32x4* Q4 = reinterpret_cast<const f32x4*>(a.Q) + (int64_t)r_[t] * 32 + q;
-            pq[t][0][0] = P4[4 * (2 * wave)];
-            pq[t][0][1] = P4[4 * (2 * wave + 1)];
-            pq[t][1][0] = Q4[4 * (2 * wave)];
-            pq[t][1][1] = Q4[4 * (2 * wave + 1)];
+            pq[t][0][0] = c16_ld_row<BF>(a.P, s_[t], 2 * wave, q);
+            pq[t][0][1] = c16_ld_row<BF>(a.P, s_[t], 2 * wave + 1, q);
+            pq[t][1][0] = c16_ld_row<BF>(a.Q, r_[t], 2 * wave, q);
+            pq[t][1][1] = c16_ld_row<BF>(a.Q, r_[t], 2 * wave + 1, q);
         }
         c16m_chain<RT, 4, 8>(acc, x, w1, lane, g1);
 #pragma unroll
@@ -889,9 +934,8 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
 #pragma unroll
         for (int t = 0; t < RT; ++t) {
             if (valid[t]) {                                          // e <- e + e'
-                f32x4* E4 = reinterpret_cast<f32x4*>(a.Elat);
-                E4[c16_tile_idx(tile[t], row[t], 2 * wave, q)] = xs[t][0] + acc[t][0];
-                E4[c16_tile_idx(tile[t], row[t], 2 * wave + 1, q)] = xs[t][1] + acc[t][1];
+                c16_st_tile<BF>(a.Elat, tile[t], row[t], 2 * wave, q, xs[t][0] + acc[t][0]);
+                c16_st_tile<BF>(a.Elat, tile[t], row[t], 2 * wave + 1, q, xs[t][1] + acc[t][1]);
             }
             // segmented sum over runs of equal receiver within the 16-edge tile: the 16 rows of a tile are one DPP row (the same in all four lane groups)
             const int reff = valid[t] ? r_[t] : (-4 - n);
@@ -919,13 +963,12 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
             const bool sr = (n == 15) && ha[t] && (r_after[t] == reff);          // run continues into the next one
             if (tail) {
                 if (sl || sr) {
-                    f32x4* C4 = reinterpret_cast<f32x4*>(a.CARRY) + ((int64_t)2 * ht[t] + (sl ? 0 : 1)) * 32 + q;
-                    C4[4 * (2 * wave)] = acc[t][0];
-                    C4[4 * (2 * wave + 1)] = acc[t][1];
+                    const int64_t cr = (int64_t)2 * ht[t] + (sl ? 0 : 1);
+                    c16_st_row<BF>(a.CARRY, cr, 2 * wave, q, acc[t][0]);
+                    c16_st_row<BF>(a.CARRY, cr, 2 * wave + 1, q, acc[t][1]);
                 } else {
-                    f32x4* A4 = reinterpret_cast<f32x4*>(a.AGG);
-                    A4[c16_tile_idx(r_[t] >> 5, r_[t] & 31, 2 * wave, q)] = acc[t][0];
-                    A4[c16_tile_idx(r_[t] >> 5, r_[t] & 31, 2 * wave + 1, q)] = acc[t][1];
+                    c16_st_tile<BF>(a.AGG, r_[t] >> 5, r_[t] & 31, 2 * wave, q, acc[t][0]);
+                    c16_st_tile<BF>(a.AGG, r_[t] >> 5, r_[t] & 31, 2 * wave + 1, q, acc[t][1]);
                 }
             }
         }
@@ -940,25 +983,35 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
 // LayerNorm statistics are per-wave partials combined through LDS (c16m_layer_norm).  SETS = 2: the second set's aggregate is one
 // more layer-1 chain, and mode 1 projects P, Q of both sets.
 // this wave's slice of a node's aggregated messages: the node's AGG slot, or carry rows when its run of edges straddles tiles
+template <bool BF>
 DEVINL void c16_agg_slice(f32x4 (&as)[2], const int32_t* rowptr, const float* AGG, const float* CARRY, int64_t zero_row, bool valid, int nn,
                           int64_t tile, int row, int wave, int q) {
     const int a0 = rowptr[nn], a1 = rowptr[nn + 1];
     const int T1 = a0 >> 4, T2 = (a1 - 1) >> 4;
     const int extra = (valid && a1 > a0 && T2 > T1) ? (T2 - T1) : 0;
     const bool from_agg = valid && (a1 > a0) && !extra;
-    const f32x4* A4 = reinterpret_cast<const f32x4*>(AGG) + c16_tile_idx(tile, row, 2 * wave, q);
-    const f32x4* C4 = reinterpret_cast<const f32x4*>(CARRY) + (extra ? (int64_t)(2 * T1 + 1) : zero_row) * 32 + q + 4 * (2 * wave);
-    const f32x4* src = from_agg ? A4 : C4;
-    as[0] = src[0];
-    as[1] = src[from_agg ? 128 : 4];
+    if constexpr (BF) {
+        const int64_t cr = extra ? (int64_t)(2 * T1 + 1) : zero_row;
+        const uint16_t* A16 = reinterpret_cast<const uint16_t*>(AGG) + c16_bf_tile_off(tile, row, 2 * wave, q);
+        const uint16_t* C16 = reinterpret_cast<const uint16_t*>(CARRY) + c16_bf_row_off(cr, 2 * wave, q);
+        const uint16_t* src = from_agg ? A16 : C16;
+        as[0] = c16_unpack4(*reinterpret_cast<const uint2*>(src));
+        as[1] = c16_unpack4(*reinterpret_cast<const uint2*>(src + (from_agg ? 64 * 8 : 2 * 8)));      // next feature block: s + 1
+    } else {
+        const f32x4* A4 = reinterpret_cast<const f32x4*>(AGG) + c16_tile_idx(tile, row, 2 * wave, q);
+        const f32x4* C4 = reinterpret_cast<const f32x4*>(CARRY) + (extra ? (int64_t)(2 * T1 + 1) : zero_row) * 32 + q + 4 * (2 * wave);
+        const f32x4* src = from_agg ? A4 : C4;
+        as[0] = src[0];
+        as[1] = src[from_agg ? 128 : 4];
+    }
     for (int k = 1; __any(k <= extra); ++k)
         if (k <= extra) {
-            const f32x4* K4 = reinterpret_cast<const f32x4*>(CARRY) + (int64_t)2 * (T1 + k) * 32 + q + 4 * (2 * wave);
-            as[0] += K4[0];
-            as[1] += K4[4];
+            as[0] += c16_ld_row<BF>(CARRY, (int64_t)2 * (T1 + k), 2 * wave, q);
+            as[1] += c16_ld_row<BF>(CARRY, (int64_t)2 * (T1 + k), 2 * wave + 1, q);
         }
 }
 // P = v W_P, Q = v W_Q + bq for this wave's blocks of one edge set (ga primed with wp's first fragments; gb is primed here)
+template <bool BF>
 DEVINL void c16_project(const f32x4 (&v)[1][8], const float* wp, const float* wq, const float* bq, float* P, float* Q, bool valid, int nn,
                         int wave, int lane, int q, C16Ring& ga, C16Ring& gb, const float* next_wp) {
     f32x4 o[1][2];
@@ -966,20 +1019,18 @@ DEVINL void c16_project(const f32x4 (&v)[1][8], const float* wp, const float* wq
     c16_prime(gb, wq, lane);
     c16m_chain<1>(o, v, wp, lane, ga);
     if (valid) {
-        f32x4* P4 = reinterpret_cast<f32x4*>(P) + (int64_t)nn * 32 + q;
-        P4[4 * (2 * wave)] = o[0][0];
-        P4[4 * (2 * wave + 1)] = o[0][1];
+        c16_st_row<BF>(P, nn, 2 * wave, q, o[0][0]);
+        c16_st_row<BF>(P, nn, 2 * wave + 1, q, o[0][1]);
     }
     c16_tab(o[0], bq, wave, q);
     if (next_wp) c16_prime(ga, next_wp, lane);
     c16m_chain<1>(o, v, wq, lane, gb);
     if (valid) {
-        f32x4* Q4 = reinterpret_cast<f32x4*>(Q) + (int64_t)nn * 32 + q;
-        Q4[4 * (2 * wave)] = o[0][0];
-        Q4[4 * (2 * wave + 1)] = o[0][1];
+        c16_st_row<BF>(Q, nn, 2 * wave, q, o[0][0]);
+        c16_st_row<BF>(Q, nn, 2 * wave + 1, q, o[0][1]);
     }
 }
-template <int SETS>
+template <int SETS, bool BF>
 __global__ __launch_bounds__(256, 2) void k_node_coop16(const NodeArgs a) {
     constexpr int L = 128;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -1006,16 +1057,13 @@ __global__ __launch_bounds__(256, 2) void k_node_coop16(const NodeArgs a) {
         const int64_t tile = ht >> 1;
         const int row = 16 * (ht & 1) + n;
         f32x4 v[1][8], full[1][8], acc[1][2], vs[1][2];
-        {
-            const f32x4* V4 = reinterpret_cast<const f32x4*>(a.V);
-            vs[0][0] = V4[c16_tile_idx(tile, row, 2 * wave, q)];
-            vs[0][1] = V4[c16_tile_idx(tile, row, 2 * wave + 1, q)];
-        }
+        vs[0][0] = c16_ld_tile<BF>(a.V, tile, row, 2 * wave, q);
+        vs[0][1] = c16_ld_tile<BF>(a.V, tile, row, 2 * wave + 1, q);
         C16Ring ga, gb;
         if (a.mode != 2) {
             f32x4 as[2], as2[2];
-            c16_agg_slice(as, a.rowptr, a.AGG, a.CARRY, a.zero_row, valid, nn, tile, row, wave, q);
-            if constexpr (SETS == 2) c16_agg_slice(as2, a.rowptr2, a.AGG2, a.CARRY2, a.zero_row2, valid, nn, tile, row, wave, q);
+            c16_agg_slice<BF>(as, a.rowptr, a.AGG, a.CARRY, a.zero_row, valid, nn, tile, row, wave, q);
+            if constexpr (SETS == 2) c16_agg_slice<BF>(as2, a.rowptr2, a.AGG2, a.CARRY2, a.zero_row2, valid, nn, tile, row, wave, q);
             c16_prime(ga, wt(2), lane);
             c16_tab(acc[0], tabs + T_B1 * L, wave, q);
             xch0[(2 * wave) * 64 + lane] = vs[0][0];
@@ -1068,24 +1116,23 @@ __global__ __launch_bounds__(256, 2) void k_node_coop16(const NodeArgs a) {
             c16m_chain<1>(acc, full, wt(1), lane, r3);               // layer 3
             c16m_layer_norm<1>(acc, red, tg, tb, wave, n);
             STAMP16(5);
-            acc[0][0] += vs[0][0];                                   // v <- v + v'  (this wave's slice)
-            acc[0][1] += vs[0][1];
+            acc[0][0] = c16_round<BF>(acc[0][0] + vs[0][0]);         // v <- v + v'  (this wave's slice; the value the store keeps)
+            acc[0][1] = c16_round<BF>(acc[0][1] + vs[0][1]);
             if (valid) {
-                f32x4* V4 = reinterpret_cast<f32x4*>(a.V);
-                V4[c16_tile_idx(tile, row, 2 * wave, q)] = acc[0][0];
-                V4[c16_tile_idx(tile, row, 2 * wave + 1, q)] = acc[0][1];
+                c16_st_tile<BF>(a.V, tile, row, 2 * wave, q, acc[0][0]);
+                c16_st_tile<BF>(a.V, tile, row, 2 * wave + 1, q, acc[0][1]);
             }
             if (a.mode == 1) {                                       // P, Q of the next step, on the updated rows
                 c16m_exchange<1>(v, acc, xch1, wave, lane);
                 STAMP16(6);
-                c16_project(v, wt(4), wt(5), tabs + T_BQ * L, a.P, a.Q, valid, nn, wave, lane, q, r2, r3, SETS == 2 ? wt(7) : nullptr);
+                c16_project<BF>(v, wt(4), wt(5), tabs + T_BQ * L, a.P, a.Q, valid, nn, wave, lane, q, r2, r3, SETS == 2 ? wt(7) : nullptr);
                 if constexpr (SETS == 2)
-                    c16_project(v, wt(7), wt(8), a.tabs2 + (T_COUNT + T_BQ) * L, a.P2, a.Q2, valid, nn, wave, lane, q, r2, r3, nullptr);
+                    c16_project<BF>(v, wt(7), wt(8), a.tabs2 + (T_COUNT + T_BQ) * L, a.P2, a.Q2, valid, nn, wave, lane, q, r2, r3, nullptr);
             }
         } else {                                                     // projection only (before the first step; one set per launch)
             c16_prime(ga, wt(4), lane);
             c16m_exchange<1>(v, vs, xch0, wave, lane);
-            c16_project(v, wt(4), wt(5), tabs + T_BQ * L, a.P, a.Q, valid, nn, wave, lane, q, ga, gb, nullptr);
+            c16_project<BF>(v, wt(4), wt(5), tabs + T_BQ * L, a.P, a.Q, valid, nn, wave, lane, q, ga, gb, nullptr);
         }
         STAMP16(7);
         __syncthreads();
@@ -2496,9 +2543,14 @@ hipError_t launch_edge_step(int L, const EdgeArgs& a, hipStream_t s) {
         int rt = g_c16_rt ? g_c16_rt : (nht + num_cus() - 1) / num_cus();
         rt = rt < 1 ? 1 : (rt > 3 ? 3 : rt);
         LaunchCfg c16{(nht + rt - 1) / rt, 256, (size_t)rt * 2 * 8 * 64 * 16 + (size_t)rt * 2 * 64 * 4};
-        if (rt == 3) return launch_k(k_edge_coop16m<3>, a, c16, s);
-        if (rt == 2) return launch_k(k_edge_coop16m<2>, a, c16, s);
-        return launch_k(k_edge_coop16m<1>, a, c16, s);
+        if (a.bf) {
+            if (rt == 3) return launch_k(k_edge_coop16m<3, true>, a, c16, s);
+            if (rt == 2) return launch_k(k_edge_coop16m<2, true>, a, c16, s);
+            return launch_k(k_edge_coop16m<1, true>, a, c16, s);
+        }
+        if (rt == 3) return launch_k(k_edge_coop16m<3, false>, a, c16, s);
+        if (rt == 2) return launch_k(k_edge_coop16m<2, false>, a, c16, s);
+        return launch_k(k_edge_coop16m<1, false>, a, c16, s);
     }
     if (coop_ok(L, a.ntiles, a.chunk_t, true)) {   // small graph: 4 waves per tile
         LaunchCfg c4{a.ntiles, 256, coop_lds()};
@@ -2546,7 +2598,8 @@ hipError_t launch_node_step(int L, const NodeArgs& a, hipStream_t s) {
     }
     if (a.c16 && L == 128 && a.chunk_t[0]) {
         LaunchCfg c16{2 * a.ntiles, 256, (size_t)4 * 8 * 64 * 16 + 2 * 64 * 4};
-        return a.AGG2 ? launch_k(k_node_coop16<2>, a, c16, s) : launch_k(k_node_coop16<1>, a, c16, s);
+        if (a.bf) return a.AGG2 ? launch_k(k_node_coop16<2, true>, a, c16, s) : launch_k(k_node_coop16<1, true>, a, c16, s);
+        return a.AGG2 ? launch_k(k_node_coop16<2, false>, a, c16, s) : launch_k(k_node_coop16<1, false>, a, c16, s);
     }
     if (coop_ok(L, a.ntiles, a.chunk_t)) {
         LaunchCfg c4{a.ntiles, 256, coop_lds()};
@@ -2588,7 +2641,7 @@ hipError_t launch_project(int L, const NodeArgs& a, hipStream_t s) {
     LaunchCfg lc = tile_launch(L, a.ntiles, 2);
     if (!a.gen.use && a.c16 && L == 128 && a.chunk_t[0] && !a.AGG2 && a.mode == 2) {
         LaunchCfg c16{2 * a.ntiles, 256, (size_t)4 * 8 * 64 * 16 + 2 * 64 * 4};
-        return launch_k(k_node_coop16<1>, a, c16, s);
+        return a.bf ? launch_k(k_node_coop16<1, true>, a, c16, s) : launch_k(k_node_coop16<1, false>, a, c16, s);
     }
     if (!a.gen.use && a.tile0 == 0 && a.mode == 2 && coop_ok(L, a.ntiles, a.chunk_t)) {
         LaunchCfg c4{a.ntiles, 256, coop_lds()};

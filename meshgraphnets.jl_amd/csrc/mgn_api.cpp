@@ -321,8 +321,8 @@ void invalidate_static(mgn_engine* h) {
 // tile then), so the choice is made per handle and graph: fp32, L = 128, hidden_layers = 2, and the node launch and EVERY edge
 // set's launch in the cooperative size range
 int32_t use_c16(const mgn_engine* h) {
-    if (!(coop16_enabled() && h->cfg.dtype == MGN_F32 && h->cfg.L == 128 && h->cfg.hidden_layers == 2 && get_kernel_path() != 4 &&
-          launch_is_small(h->ntiles_n)))
+    // (bf16 mode included: the 16-row kernels then read and write the bf16 arrays and keep fp32 weights and arithmetic)
+    if (!(coop16_enabled() && h->cfg.L == 128 && h->cfg.hidden_layers == 2 && get_kernel_path() != 4 && launch_is_small(h->ntiles_n)))
         return 0;
     for (int q = 0; q < h->nsets; ++q)
         if (!(launch_is_small_edge(h->es[q].ntiles_e) && coop16_size(h->es[q].ntiles_e, h->ntiles_n))) return 0;
@@ -347,11 +347,12 @@ EdgeArgs edge_args(mgn_engine* h, int k, int q = 0) {
     a.rcv = es.d_rcv.as<int32_t>();
     a.E = h->g.set[q].e_local;
     a.ntiles = es.ntiles_e;
-    a.P = es.P.as<float>();
-    a.Q = es.Q.as<float>();
-    a.Elat = es.Elat.as<float>();
-    a.AGG = es.AGG.as<float>();
-    a.CARRY = es.CARRY.as<float>();
+    a.bf = h->cfg.dtype == MGN_BF16 ? 1 : 0;            // (only the 16-row kernels are launched with fp32 EdgeArgs in bf16 mode)
+    a.P = a.bf ? es.bP.as<float>() : es.P.as<float>();
+    a.Q = a.bf ? es.bQ.as<float>() : es.Q.as<float>();
+    a.Elat = a.bf ? es.bElat.as<float>() : es.Elat.as<float>();
+    a.AGG = a.bf ? es.bAGG.as<float>() : es.AGG.as<float>();
+    a.CARRY = a.bf ? es.bCARRY.as<float>() : es.CARRY.as<float>();
     for (int i = 0; i < 3; ++i) {
         a.chunk[i] = W(h, h->soff[k].e_ch[q][i]);
         a.chunk_t[i] = a.chunk[i] + (size_t)h->cfg.L * h->cfg.L;
@@ -379,11 +380,13 @@ NodeArgs node_args(mgn_engine* h, int k, int mode, int q = 0) {
     a.n = h->g.n_own;
     a.ntiles = h->ntiles_n;
     a.rowptr = h->es[0].d_rowptr.as<int32_t>();
-    a.V = h->V.as<float>();
-    a.AGG = h->es[0].AGG.as<float>();
-    a.CARRY = h->es[0].CARRY.as<float>();
-    a.P = h->es[q].P.as<float>();
-    a.Q = h->es[q].Q.as<float>();
+    const bool bf = h->cfg.dtype == MGN_BF16;           // (only the 16-row kernels are launched with fp32 NodeArgs in bf16 mode)
+    a.bf = bf ? 1 : 0;
+    a.V = bf ? h->bV.as<float>() : h->V.as<float>();
+    a.AGG = bf ? h->es[0].bAGG.as<float>() : h->es[0].AGG.as<float>();
+    a.CARRY = bf ? h->es[0].bCARRY.as<float>() : h->es[0].CARRY.as<float>();
+    a.P = bf ? h->es[q].bP.as<float>() : h->es[q].P.as<float>();
+    a.Q = bf ? h->es[q].bQ.as<float>() : h->es[q].Q.as<float>();
     for (int i = 0; i < 6; ++i) {
         a.chunk[i] = W(h, so.n_ch[i]);
         a.chunk_t[i] = a.chunk[i] + CH;
@@ -398,14 +401,14 @@ NodeArgs node_args(mgn_engine* h, int k, int mode, int q = 0) {
     }
     if (h->nsets > 1 && mode != 2) {
         a.rowptr2 = h->es[1].d_rowptr.as<int32_t>();
-        a.AGG2 = h->es[1].AGG.as<float>();
-        a.CARRY2 = h->es[1].CARRY.as<float>();
+        a.AGG2 = bf ? h->es[1].bAGG.as<float>() : h->es[1].AGG.as<float>();
+        a.CARRY2 = bf ? h->es[1].bCARRY.as<float>() : h->es[1].CARRY.as<float>();
         a.zero_row2 = 4 * tiles_or_one(h->es[1].ntiles_e);
         a.chunk[6] = W(h, so.n_ch[6]);
         a.chunk_t[6] = a.chunk[6] + CH;
         if (q == 0) {                                   // the 16-row kernels project both sets in one launch (mode 1)
-            a.P2 = h->es[1].P.as<float>();
-            a.Q2 = h->es[1].Q.as<float>();
+            a.P2 = bf ? h->es[1].bP.as<float>() : h->es[1].P.as<float>();
+            a.Q2 = bf ? h->es[1].bQ.as<float>() : h->es[1].Q.as<float>();
             a.tabs2 = W(h, so.p1_tabs);
             for (int i = 0; i < 2; ++i) {
                 a.chunk[7 + i] = W(h, so.p1_ch[i]);
@@ -1008,7 +1011,7 @@ int mgn_fwd_upload(mgn_handle* h, const float* nf, const float* ef) try {
 
 static int project_set(mgn_handle* h, int k, int q, int32_t tile0 = 0, int32_t ntiles = -1) {   // P,Q of set q for step k (k = mps: step 0)
     if (ntiles < 0) ntiles = h->ntiles_n;
-    if (is_bf16(h)) {
+    if (is_bf16(h) && !use_c16(h)) {
         BfNodeArgs b = bf_node_args(h, k, q, true);
         b.tile0 = tile0;
         b.ntiles = ntiles;
@@ -1108,7 +1111,7 @@ static int proc_edge_range(mgn_handle* h, int32_t k, int32_t phase) {   // phase
         const int32_t tb = boundary_tiles(h, q), nt = h->es[q].ntiles_e;
         const int32_t t0 = phase == 1 ? tb : 0, n = phase == 0 ? nt : (phase == 1 ? nt - tb : tb);
         if (n <= 0) continue;
-        if (is_bf16(h)) {
+        if (is_bf16(h) && !use_c16(h)) {
             BfEdgeArgs a = bf_edge_args(h, k, q);
             a.tile0 = t0;
             a.ntiles = n;
@@ -1149,7 +1152,7 @@ int mgn_proc_node(mgn_handle* h, int32_t k, int32_t project_next) try {
     if (k < 0 || k >= h->cfg.mps) return fail(h, MGN_E_ARG, "mgn_proc_node: step %d out of range", k);
     if (project_next && k + 1 >= h->cfg.mps) return fail(h, MGN_E_ARG, "mgn_proc_node: no step %d to project for", k + 1);
     ProfScope ps(h, F_NODE);
-    if (is_bf16(h)) {
+    if (is_bf16(h) && !use_c16(h)) {
         HIPCHK(h, launch_node_bf16(bf_node_args(h, k), h->stream));
         for (int q = 0; project_next && q < h->nsets; ++q)
             if (int rc = project_set(h, k, q)) return rc;
@@ -1178,7 +1181,7 @@ int mgn_proc_node_phase(mgn_handle* h, int32_t k, int32_t phase) try {
     const int ntb_all = (h->g.n_boundary + TILE - 1) / TILE;   // tiles that contain a boundary node
     const int ntb = ntb_all < h->ntiles_n ? ntb_all : h->ntiles_n;
     if (phase == 1 && k >= 0) {
-        if (is_bf16(h)) HIPCHK(h, launch_node_bf16(bf_node_args(h, k), h->stream));
+        if (is_bf16(h) && !use_c16(h)) HIPCHK(h, launch_node_bf16(bf_node_args(h, k), h->stream));
         else HIPCHK(h, launch_node_step(h->cfg.L, node_args(h, k, 0), h->stream));
     }
     const int32_t tile0 = phase == 1 ? 0 : ntb, nt = phase == 1 ? ntb : h->ntiles_n - ntb;

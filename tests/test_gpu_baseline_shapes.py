@@ -66,14 +66,21 @@ def test_mcyl_15_steps_fp32_every_kernel_family(mcyl, path):
         set_c16_row_tiles(old_rt)
 
 
-def test_mcyl_15_steps_bf16_band(mcyl):
-    m = mcyl
-    eng = engine_for(m["cfg"], dtype="bf16")
-    eng.set_params(m["ps"])
-    eng.set_graph(m["s"], m["r"], 2000)
-    v1, e1 = eng.processor_steps(m["v"], m["e"], 15)
-    l2 = lambda a, b: float(np.linalg.norm(a - b) / np.linalg.norm(b))
-    assert l2(v1, m["rv"]) <= 3e-2 and l2(e1, m["re"]) <= 3e-2, (l2(v1, m["rv"]), l2(e1, m["re"]))
+@pytest.mark.parametrize("path", [0, 1], ids=["auto: 16-row kernels on bf16 storage", "bf16 MFMA kernels"])
+def test_mcyl_15_steps_bf16_band(mcyl, path):
+    """bf16 mode on a graph this small runs the 16-row kernels (bf16 arrays, fp32 weights and arithmetic); kernel path 1 keeps
+    the bf16-MFMA kernels of the large meshes.  Both must sit in the bf16 band."""
+    old = set_kernel_path(path)
+    try:
+        m = mcyl
+        eng = engine_for(m["cfg"], dtype="bf16")
+        eng.set_params(m["ps"])
+        eng.set_graph(m["s"], m["r"], 2000)
+        v1, e1 = eng.processor_steps(m["v"], m["e"], 15)
+        l2 = lambda a, b: float(np.linalg.norm(a - b) / np.linalg.norm(b))
+        assert l2(v1, m["rv"]) <= 3e-2 and l2(e1, m["re"]) <= 3e-2, (l2(v1, m["rv"]), l2(e1, m["re"]))
+    finally:
+        set_kernel_path(old)
 
 
 def test_mcyl_forward_and_training_step(mcyl):

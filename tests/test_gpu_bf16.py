@@ -1,5 +1,5 @@
-"""GPU parity tests for the bf16 mode (BASELINE.json configs[2] precision): bf16 storage + bf16 MFMA in the processor,
-fp32 accumulate / LayerNorm / residual / aggregation.  Stated tolerance: relative L2 <= 3e-2 against
+"""GPU parity tests for the bf16 mode (BASELINE.json configs[2] precision): bf16 storage + bf16 MFMA in the processor (small graphs:
+bf16 storage + fp32 MFMA in the 16-row kernels), fp32 accumulate / LayerNorm / residual / aggregation.  Stated tolerance: relative L2 <= 3e-2 against
 the float64 oracle after 15 steps (LayerNorm re-centres every step)."""
 from importlib import import_module
 
@@ -19,6 +19,16 @@ TOL_BF16 = 3e-2
 
 def rel_l2(a, ref):
     return float(np.linalg.norm(np.asarray(a, np.float64) - ref) / np.linalg.norm(ref))
+
+
+@pytest.fixture(autouse=True, params=[0, 1], ids=["auto", "bf16-mfma"])
+def bf16_family(request):
+    """Small graphs in bf16 mode run the 16-row kernels on the bf16 arrays (fp32 weights and arithmetic) when the kernel family
+    is chosen automatically; kernel path 1 keeps the bf16-MFMA kernels that large meshes use.  Every test here covers both."""
+    from util import set_kernel_path
+    old = set_kernel_path(request.param)
+    yield request.param
+    set_kernel_path(old)
 
 
 @pytest.mark.parametrize("nsteps", [1, 15])

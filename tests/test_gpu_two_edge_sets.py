@@ -88,18 +88,23 @@ def test_gold_c_latents_after_one_step(kernel_path):
     assert rel_max(e2, g["e2_after_1"]) <= TOL_STEP * 2
 
 
-def test_gold_c_bf16_band():
-    g = np.load(GOLD)
-    cfg = cfg2(int(g["L"]), int(g["mps"]))
-    ps = params2(cfg, seed=int(g["seed"]), jitter=float(g["jitter"]))
-    N = g["nf"].shape[0]
-    eng = engine2(cfg, dtype="bf16")
-    eng.set_params(ps)
-    eng.set_graph(g["senders"], g["receivers"], N)
-    eng.set_edge_set(1, g["senders2"], g["receivers2"])
-    eng.set_edge_features(1, g["ef2"])
-    out = eng.forward(g["nf"], g["ef"])
-    assert rel_l2(out, g["out"]) <= TOL_BF16, rel_l2(out, g["out"])
+@pytest.mark.parametrize("path", [0, 1], ids=["auto: 16-row kernels on bf16 storage", "bf16 MFMA kernels"])
+def test_gold_c_bf16_band(path):
+    old = set_kernel_path(path)
+    try:
+        g = np.load(GOLD)
+        cfg = cfg2(int(g["L"]), int(g["mps"]))
+        ps = params2(cfg, seed=int(g["seed"]), jitter=float(g["jitter"]))
+        N = g["nf"].shape[0]
+        eng = engine2(cfg, dtype="bf16")
+        eng.set_params(ps)
+        eng.set_graph(g["senders"], g["receivers"], N)
+        eng.set_edge_set(1, g["senders2"], g["receivers2"])
+        eng.set_edge_features(1, g["ef2"])
+        out = eng.forward(g["nf"], g["ef"])
+        assert rel_l2(out, g["out"]) <= TOL_BF16, rel_l2(out, g["out"])
+    finally:
+        set_kernel_path(old)
 
 
 @pytest.mark.parametrize("L", [128, 64, 32])
@@ -141,7 +146,8 @@ def test_flag_mesh_15_steps_bf16_and_graph_replay():
     e = rng.standard_normal((E, 128)).astype(np.float32)
     e2 = rng.standard_normal((E2, 128)).astype(np.float32)
     rv, re, re2 = orc.processor_steps(ps, cfg, v, e, m["s"], m["r"], 15, set2=(e2, m["s2"], m["r2"]))
-    for dtype, tol in (("f32", None), ("bf16", TOL_BF16)):
+    for dtype, tol, path in (("f32", None, 0), ("bf16", TOL_BF16, 0), ("bf16", TOL_BF16, 1)):   # bf16: 16-row kernels on bf16 storage / bf16-MFMA kernels
+        old_path = set_kernel_path(path)
         eng = engine2(cfg, dtype=dtype)
         eng.set_params(ps)
         eng.set_graph(m["s"], m["r"], N)
@@ -156,6 +162,7 @@ def test_flag_mesh_15_steps_bf16_and_graph_replay():
                 assert rel_max(v1, rv) <= TOL_15 and rel_max(e1, re) <= TOL_15 and rel_max(e21, re2) <= TOL_15, rep
             else:
                 assert rel_l2(v1, rv) <= tol and rel_l2(e1, re) <= tol and rel_l2(e21, re2) <= tol, (rep, rel_l2(v1, rv))
+        set_kernel_path(old_path)
 
 
 def test_world_edges_change_between_steps():
