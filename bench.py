@@ -333,6 +333,31 @@ def main():
         if world > 1:
             out["per_rank"] = {"n_own": n_loc, "e_local": e_loc, "n_halo": eng.n_halo}
         if world == 1 and not args.no_secondary and args.dtype == "f32":
+            # opt-in edge kernel (NOT the headline): the edge MLP's three layers on the bf16 matrix cores at fp32 accuracy -- every fp32
+            # operand split exactly into three bf16 pieces, six of nine piece products kept (tests/test_gpu_fp32_split.py holds it to
+            # the fp32 tolerances and to the fp32-MFMA kernel's own error against float64)
+            import ctypes
+            lib = mgn_amd.load()
+            lib.mgn_debug_fp32_split.restype = ctypes.c_int
+            lib.mgn_debug_fp32_split.argtypes = [ctypes.c_int]
+            old_split = lib.mgn_debug_fp32_split(1)
+            try:
+                engs = mgn_amd.Engine(FN, FE, O, L, 2, MPS, device=local_rank)
+                engs.set_params(ps)
+                engs.set_graph(s, r, N)
+                engs.latents_randn(1234)
+                dts, profs = time_single(engs, 3, 1, barrier_sync)
+                ts = dts / (3 * MPS)
+                out["fp32_split_opt_in"] = {
+                    "workload": "same M-1M mesh, fp32 storage; k_edge_split (MGN_FP32_SPLIT=1): v_mfma_f32_32x32x16_bf16 on three-way split "
+                                "operands, six products per fp32 product, fp32 accumulate; node side unchanged",
+                    "ms_per_processor_step": ts * 1e3, "edges_per_s": E / ts, "edge_kernel_ms": profs["edge_step"]["avg_ms"],
+                    "node_side_ms": profs["node_step"]["avg_ms"],
+                    "note": "not the headline `value`: reported for the record; the node-side kernels run slower behind it (clocks)"}
+                engs.close()
+            finally:
+                lib.mgn_debug_fp32_split(old_split)
+        if world == 1 and not args.no_secondary and args.dtype == "f32":
             engb = mgn_amd.Engine(FN, FE, O, L, 2, MPS, device=local_rank, dtype="bf16")
             engb.set_params(ps)
             engb.set_graph(s, r, N)

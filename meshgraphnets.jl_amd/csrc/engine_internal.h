@@ -123,6 +123,10 @@ struct mgn_engine {
     DevBuf wbf, bV;
     struct BfStepOff { size_t e_ch[MAX_EDGE_SETS][3], n_ch[7], p1_ch[2]; };
     std::vector<BfStepOff> bsoff;
+    // opt-in fp32-on-bf16-matrix-cores edge kernel (k_edge_split): per step and set, the three chunks as 3 bf16 pieces each
+    DevBuf wsp;
+    struct SplitOff { size_t e_ch[MAX_EDGE_SETS][3]; };
+    std::vector<SplitOff> spoff;
     // static per-trajectory RHS inputs (mgn_set_static): cached encoded edge latents
     bool have_static = false;
     DevBuf stage;     // device staging image of caller-order latents (import / export)

@@ -45,6 +45,10 @@ struct EdgeArgs {
                             //    the carry rows are then per 16-edge tile)
     int32_t bf;             // 16-row kernels in bf16 mode: P, Q, Elat, AGG, CARRY are bf16 arrays in the bf16 kernels' layouts (passed
                             //    through the float pointers); weights, tables and arithmetic stay fp32
+    // opt-in (MGN_FP32_SPLIT=1 / mgn_debug_fp32_split): the three layers on the bf16 matrix cores with fp32 accuracy -- every fp32
+    // operand split into three bf16 pieces, six piece products kept (k_edge_split).  split[i]: chunk i as 3 x 16384 bf16 (hi, mid, lo
+    // pieces, the bf16 kernels' fragment order); null: not available
+    const uint16_t* split[3];
 };
 
 struct NodeArgs {
@@ -160,6 +164,8 @@ bool launch_is_small(int ntiles);
 bool launch_is_small_edge(int ntiles_e);   // the same rule for edge launches (<= 16 tiles per CU)
 int coop16_enabled();
 bool coop16_size(int ntiles_e, int ntiles_n);   // the launch wrappers' rule for the cooperative node kernels (<= 8 tiles per CU)
+int set_fp32_split(int on);     // debug/tests: 1 = k_edge_split for large fp32 launches (see EdgeArgs.split); returns the old value
+int fp32_split_enabled();
 int set_c16_row_tiles(int rt);  // debug/tests: 16-edge tiles per block of the small-graph edge kernel (0: chosen by size); returns the old value
 int set_kernel_path(int p);   // debug/tests: 0 auto, 1 resident, 2 streaming, 3 cooperative, 4 GEN (general hidden_layers) kernels; returns the old value
 int get_kernel_path();

@@ -155,6 +155,30 @@ inline uint16_t f32_to_bf16(float f) {   // round to nearest even (inputs are fi
 }
 // feature held by element j of piece (s, hh) of a bf16 row fragment (see kernels.hip, bf16 section)
 inline int bf_feature(int sidx, int hh, int j) { return 32 * (sidx >> 1) + 16 * (sidx & 1) + 8 * (j >> 2) + 4 * hh + (j & 3); }
+inline float bf16_to_f32(uint16_t b) {
+    const uint32_t u = (uint32_t)b << 16;
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+// the same chunk as three bf16 pieces with w = hi + mid + lo exactly (dst: 3 x 16384, each in the fragment order below)
+void pack_chunk_bf16(uint16_t* dst, const float* W, int ldw, int kbase);
+void pack_chunk_split(uint16_t* dst, const float* W, int ldw, int kbase) {
+    std::vector<float> r1((size_t)128 * 128), r2((size_t)128 * 128), w0((size_t)128 * 128);
+    for (int k = 0; k < 128; ++k)
+        for (int n = 0; n < 128; ++n) {
+            const float w = W[(size_t)(kbase + k) * ldw + n];
+            const float a = bf16_to_f32(f32_to_bf16(w));
+            const float ra = w - a;
+            const float b = bf16_to_f32(f32_to_bf16(ra));
+            w0[(size_t)k * 128 + n] = w;
+            r1[(size_t)k * 128 + n] = ra;
+            r2[(size_t)k * 128 + n] = ra - b;
+        }
+    pack_chunk_bf16(dst, w0.data(), 128, 0);
+    pack_chunk_bf16(dst + 16384, r1.data(), 128, 0);
+    pack_chunk_bf16(dst + 2 * 16384, r2.data(), 128, 0);
+}
 // 128 x 128 chunk of W (row-major [K][ldw], rows kbase..) -> bf16 fragment order [s][t][lane][8]
 void pack_chunk_bf16(uint16_t* dst, const float* W, int ldw, int kbase) {
     for (int sidx = 0; sidx < 8; ++sidx)
@@ -359,6 +383,8 @@ EdgeArgs edge_args(mgn_engine* h, int k, int q = 0) {
     }
     a.tabs = W(h, h->soff[k].e_tabs[q]);
     a.gen = gen_of(h, h->soff[k].e_gen[q], true);
+    for (int i = 0; i < 3; ++i)
+        a.split[i] = (!a.bf && k < (int)h->spoff.size() && h->wsp.p) ? h->wsp.as<uint16_t>() + h->spoff[k].e_ch[q][i] : nullptr;
     a.c16 = use_c16(h);
     a.stagger = h->stagger_edge;
     a.tile0 = 0;
@@ -697,6 +723,26 @@ int mgn_set_params(mgn_handle* h, const float* packed, size_t n) try {
             so.p1_tabs = add_tabs(nullptr, nullptr, nullptr, nullptr, nullptr, p + e1.b[0]);
         }
         h->soff.push_back(so);
+    }
+    h->spoff.clear();
+    if (c.dtype == MGN_F32 && L == 128 && c.hidden_layers == 2) {      // pieces for the opt-in k_edge_split (4.4 MB per edge set)
+        std::vector<uint16_t> ws((size_t)c.mps * S * 3 * 3 * 16384);
+        h->spoff.assign(c.mps, {});
+        size_t off = 0;
+        for (int k = 0; k < c.mps; ++k)
+            for (int q = 0; q < S; ++q) {
+                const MlpOff& me = h->es[q].pe[k];
+                const float* src[3] = {p + me.W[1], p + me.W[2], p + me.W[0]};
+                const int kb[3] = {0, 0, 2 * L};
+                for (int i = 0; i < 3; ++i) {
+                    pack_chunk_split(ws.data() + off, src[i], L, kb[i]);
+                    h->spoff[k].e_ch[q][i] = off;
+                    off += (size_t)3 * 16384;
+                }
+            }
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        HIPCHK(h, h->wsp.ensure(ws.size() * 2));
+        HIPCHK(h, hipMemcpy(h->wsp.p, ws.data(), ws.size() * 2, hipMemcpyHostToDevice));
     }
     if (c.dtype == MGN_BF16) {
         std::vector<uint16_t> wb;
@@ -2235,6 +2281,8 @@ int mgn_halo_exchange_host(mgn_handle* h, const float* own_rows, float* halo_row
 // kernels, 2 all-streaming, 3 cooperative 4-wave tiles.  Returns the previous value.
 int mgn_debug_kernel_path(int path) { return set_kernel_path(path); }
 int mgn_debug_c16_row_tiles(int rt) { return set_c16_row_tiles(rt); }
+// 1: large fp32 edge launches run k_edge_split (the three layers on the bf16 matrix cores at fp32 accuracy); returns the old value
+int mgn_debug_fp32_split(int on) { return set_fp32_split(on); }
 
 int mgn_debug_edge_stamps(mgn_handle* h, int32_t k, unsigned long long* out /* [32768] */) try {
     if (int rc = need(h, true, true)) return rc;

@@ -1,0 +1,102 @@
+"""Opt-in edge kernel k_edge_split (MGN_FP32_SPLIT=1 / mgn_debug_fp32_split): the three L x L layers of the edge MLP on the bf16
+matrix cores at fp32 accuracy -- every fp32 operand split exactly into three bf16 pieces, six of the nine piece products kept.
+It must meet the SAME tolerances against the float64 oracle as the fp32-MFMA kernels (it is not a reduced-precision mode), on a
+mesh large enough for the persistent kernels to be chosen, with ragged receiver runs, and with two edge sets."""
+import numpy as np
+import pytest
+import torch  # noqa: F401
+
+import mgn_oracle as orc
+from mgn_amd import synth
+from util import TOL_15, TOL_STEP, cfg_dict, engine_for, make_params, rel_max, set_fp32_split
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture
+def split_on():
+    old = set_fp32_split(1)
+    yield
+    set_fp32_split(old)
+
+
+def _mesh(nx=150):
+    pos, s, r = synth.mesh_1m(1234, nx, nx)          # 22 500 nodes, 133 k edges: 4 160 edge tiles > 16 per CU -> persistent kernels
+    return pos, s, r
+
+
+def test_split_numerics_of_one_layer_on_the_host():
+    """the arithmetic itself, in numpy: three-way bf16 split is exact, six terms beat a plain fp32 GEMM against float64"""
+    rng = np.random.default_rng(0)
+
+    def bf16(x):
+        u = np.asarray(x, np.float32).view(np.uint32).astype(np.uint64)
+        return (((u + 0x7FFF + ((u >> 16) & 1)) >> 16) << 16).astype(np.uint32).view(np.float32)
+
+    def split3(x):
+        a = bf16(x); r1 = (x - a).astype(np.float32); b = bf16(r1); r2 = (r1 - b).astype(np.float32)
+        return a, b, bf16(r2)
+
+    X = rng.standard_normal((2048, 128)).astype(np.float32)
+    W = (rng.uniform(-1, 1, (128, 128)) * np.sqrt(6 / 256)).astype(np.float32)
+    x1, x2, x3 = split3(X); w1, w2, w3 = split3(W)
+    assert np.array_equal((x1.astype(np.float64) + x2 + x3).astype(np.float32), X)
+    ref = X.astype(np.float64) @ W.astype(np.float64)
+    acc = np.zeros_like(X)
+    for a, b in ((x1, w3), (x2, w2), (x3, w1), (x1, w2), (x2, w1), (x1, w1)):
+        acc = (acc + a @ b).astype(np.float32)
+    e_split = np.abs(acc - ref).max() / np.abs(ref).max()
+    e_f32 = np.abs((X @ W) - ref).max() / np.abs(ref).max()
+    assert e_split <= 4e-7 and e_split <= 2 * e_f32, (e_split, e_f32)
+
+
+@pytest.mark.parametrize("nsteps,tol", [(1, TOL_STEP), (15, TOL_15)])
+def test_split_edge_kernel_meets_the_fp32_tolerances(split_on, nsteps, tol):
+    cfg = cfg_dict(mps=15)
+    pos, s, r = _mesh()
+    N, E = pos.shape[0], s.size
+    ps = make_params(cfg, jitter=0.05)
+    rng = np.random.default_rng(5)
+    v = rng.standard_normal((N, 128)).astype(np.float32)
+    e = rng.standard_normal((E, 128)).astype(np.float32)
+    rv, re = orc.processor_steps(ps, cfg, v, e, s, r, nsteps)
+    eng = engine_for(cfg)
+    eng.set_params(ps)
+    eng.set_graph(s, r, N)
+    v1, e1 = eng.processor_steps(v, e, nsteps)
+    err_split = (rel_max(v1, rv), rel_max(e1, re))
+    assert max(err_split) <= tol, err_split
+    # the device-resident entry (hipGraph replay) gives the same bits
+    eng.latents_import(v, e)
+    eng.processor_steps_dev(nsteps)
+    v2, e2 = eng.latents_export()
+    assert np.array_equal(v2, v1) and np.array_equal(e2, e1)
+    # and it is as close to float64 as the fp32-MFMA kernel is (not a reduced-precision mode)
+    set_fp32_split(0)
+    f32 = engine_for(cfg)
+    f32.set_params(ps)
+    f32.set_graph(s, r, N)
+    v3, e3 = f32.processor_steps(v, e, nsteps)
+    set_fp32_split(1)
+    err_f32 = (rel_max(v3, rv), rel_max(e3, re))
+    assert max(err_split) <= 2.0 * max(err_f32) + 1e-7, (err_split, err_f32)
+    assert not np.array_equal(e3, e1)          # (it really is the other kernel)
+
+
+def test_split_ragged_receivers(split_on):
+    """hub nodes (runs that straddle many tiles), empty receivers, a last partial tile"""
+    cfg = cfg_dict(mps=3)
+    N, E = 9000, 140001
+    s, r = synth.random_graph(N, E, 7)
+    r[: E // 3] = 17
+    r[E // 3: E // 3 + 5000] = 4000
+    ps = make_params(cfg)
+    rng = np.random.default_rng(2)
+    v = rng.standard_normal((N, 128)).astype(np.float32)
+    e = rng.standard_normal((E, 128)).astype(np.float32)
+    eng = engine_for(cfg)
+    eng.set_params(ps)
+    eng.set_graph(s, r, N)
+    v1, e1 = eng.processor_steps(v, e, 3)
+    rv, re = orc.processor_steps(ps, cfg, v, e, s, r, 3)
+    assert rel_max(v1, rv) <= TOL_15 and rel_max(e1, re) <= TOL_15, (rel_max(v1, rv), rel_max(e1, re))

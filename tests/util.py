@@ -55,3 +55,11 @@ def set_c16_row_tiles(rt):
     lib.mgn_debug_c16_row_tiles.restype = __import__("ctypes").c_int
     lib.mgn_debug_c16_row_tiles.argtypes = [__import__("ctypes").c_int]
     return lib.mgn_debug_c16_row_tiles(rt)
+
+
+def set_fp32_split(on):
+    """Opt-in edge kernel with its layers on the bf16 matrix cores at fp32 accuracy (tests only).  Returns the old value."""
+    lib = mgn_amd.load()
+    lib.mgn_debug_fp32_split.restype = __import__("ctypes").c_int
+    lib.mgn_debug_fp32_split.argtypes = [__import__("ctypes").c_int]
+    return lib.mgn_debug_fp32_split(on)
