@@ -100,3 +100,28 @@ def test_split_ragged_receivers(split_on):
     v1, e1 = eng.processor_steps(v, e, 3)
     rv, re = orc.processor_steps(ps, cfg, v, e, s, r, 3)
     assert rel_max(v1, rv) <= TOL_15 and rel_max(e1, re) <= TOL_15, (rel_max(v1, rv), rel_max(e1, re))
+
+
+def test_split_two_edge_sets(split_on):
+    """a cloth large enough for the persistent kernels (160 x 160: 25 600 nodes, mesh + world edges): k_edge_split per edge set"""
+    import mgn_amd
+    m = synth.mesh_flag(nx=160, ny=160, radius=0.012)
+    N, E, E2 = m["mesh_pos"].shape[0], m["s"].size, m["s2"].size
+    assert E > 16 * 256 * 32 and E2 > 1000                      # the mesh set is beyond the cooperative kernels' range
+    cfg = dict(Fn=12, Fe=7, O=3, L=128, hidden_layers=2, mps=2, Fe2=4)
+    ps = orc.init_params(12, 7, 3, 128, 2, 2, 1234, 0.05, Fe2=4)
+    rng = np.random.default_rng(11)
+    v = rng.standard_normal((N, 128)).astype(np.float32)
+    e = rng.standard_normal((E, 128)).astype(np.float32)
+    e2 = rng.standard_normal((E2, 128)).astype(np.float32)
+    eng = mgn_amd.Engine(12, 7, 3, 128, 2, 2, Fe2=4)
+    eng.set_params(ps)
+    eng.set_graph(m["s"], m["r"], N)
+    eng.set_edge_set(1, m["s2"], m["r2"])
+    eng.latents_import(v, e)
+    eng.edge_latents_import(1, e2)
+    eng.processor_steps_dev(2)
+    v1, e1 = eng.latents_export()
+    e21 = eng.edge_latents_export(1)
+    rv, re, re2 = orc.processor_steps(ps, cfg, v, e, m["s"], m["r"], 2, set2=(e2, m["s2"], m["r2"]))
+    assert rel_max(v1, rv) <= TOL_15 and rel_max(e1, re) <= TOL_15 and rel_max(e21, re2) <= TOL_15
