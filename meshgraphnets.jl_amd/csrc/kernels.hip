@@ -354,6 +354,10 @@ DEVINL void sp_split3(sp_bf16x8 (&hi)[8], sp_bf16x8 (&mid)[8], sp_bf16x8 (&lo)[8
 // p1 / p2 / p3: the chunk's hi / mid / lo piece ([s][t][lane] fragments of 8 bf16).  p1 is LDS-resident; G2 / G3: p2 / p3 stream
 // from L2 through a register ring SP_D (s, t) steps deep, pinned by scheduling fences (left to itself hipcc requests every streamed
 // fragment one MFMA before its use and waits out the whole L2 latency, 64 times per layer); the LDS fragments are read one step ahead.
+#ifndef MGN_SP_RELU_ASM
+#define MGN_SP_RELU_ASM 1      // one-instruction ReLU (3.919 -> 3.894 ms)
+#endif
+constexpr bool SP_RELU_ASM = MGN_SP_RELU_ASM != 0;
 #ifndef SP_D
 #define SP_D 3      // deeper rings spill (96 registers of operand pieces + 64 of accumulators): 2 / 3 / 4 deep = 3.91 / 3.87 / 3.92 ms
 #endif
@@ -449,11 +453,11 @@ __global__ __launch_bounds__(512, 2) void k_edge_split(const EdgeArgs a) {
         sp_split3(hi, mid, lo, y);                                   // y = the e tile, acc = P[s] + Q[r] (requested a tile ahead)
         __builtin_amdgcn_s_setprio(0);
         sp_layer<true, true>(acc, hi, mid, lo, l1h, g1 + 2048, g1 + 4096, lane);   // layer 1 (edge part)
-        relu_frag<NT, false>(acc);
+        relu_frag<NT, SP_RELU_ASM>(acc);
         sp_split3(hi, mid, lo, acc);
         tab_frag<NT>(y, tb + T_B2 * L, h);
         sp_layer<false, true>(y, hi, mid, lo, l2h, l2m, g2 + 4096, lane);          // layer 2
-        relu_frag<NT, false>(y);
+        relu_frag<NT, SP_RELU_ASM>(y);
         sp_split3(hi, mid, lo, y);
         tab_frag<NT>(acc, tb + T_B3 * L, h);
         sp_layer<true, true>(acc, hi, mid, lo, l3h, g3 + 2048, g3 + 4096, lane);   // layer 3
