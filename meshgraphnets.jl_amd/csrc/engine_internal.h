@@ -74,7 +74,7 @@ struct mgn_engine {
     hipStream_t own_stream = nullptr;
     bool host_only = false;
     int32_t node_split = 1;   // projection as its own launch (both chunks LDS-resident); MGN_NODE_SPLIT=0 fuses it
-    int32_t stagger_edge = 8, stagger_node = 8;  // tunables (MGN_STAGGER_EDGE / MGN_STAGGER_NODE)
+    int32_t stagger_edge = 0, stagger_node = 8;  // tunables (MGN_STAGGER_EDGE / MGN_STAGGER_NODE); edge: 0 since the padded MFMAs (sweep 0..64: 4.558 .. 4.621 ms)
 
     // parameters
     bool have_params = false;
