@@ -20,8 +20,8 @@ LIB = os.path.join(LIBDIR, "libmgn_hip.so")
 ORACLE_DIR = os.path.join(ROOT, "oracle")
 REF_LIB = os.path.join(ORACLE_DIR, "_build", "libmgn_ref.so")
 
-HIP_SOURCES = ["kernels.hip", "train.hip", "mgn_api.cpp", "mgn_train.cpp", "graph_host.cpp", "graph_prologue.cpp", "tfrecord.cpp", "comm.cpp", "graph_dev.hip"]
-HIP_HEADERS = ["kernels.h", "graph_host.h", "frag.hpp", "engine_internal.h", "train.h", "comm.h", "graph_dev.h", os.path.join(ROOT, "include", "mgn_hip.h")]
+HIP_SOURCES = ["kernels.hip", "split.hip", "train.hip", "mgn_api.cpp", "mgn_train.cpp", "graph_host.cpp", "graph_prologue.cpp", "tfrecord.cpp", "comm.cpp", "graph_dev.hip"]
+HIP_HEADERS = ["kernels.h", "graph_host.h", "frag.hpp", "tile_common.hpp", "engine_internal.h", "train.h", "comm.h", "graph_dev.h", os.path.join(ROOT, "include", "mgn_hip.h")]
 
 
 def _newer(target, deps):
@@ -38,16 +38,45 @@ def hipcc_path():
     raise RuntimeError("hipcc not found; the HIP extension cannot be built")
 
 
-def build_variant(name, flags, verbose=False):
-    """A/B experiments: compile the library with extra -D flags into lib/variants/<name>.so."""
+# extra flags per source.  split.hip: see its header (the SLP vectoriser's v_pk_add_f32 inside the MFMA stream).
+PER_FILE_FLAGS = {"split.hip": os.environ.get("MGN_SPLIT_FLAGS", "").split()}
+
+
+def _compile_objects(objdir, extra, force, deps, verbose, per_file=None):
+    """hipcc -c of every source into objdir (in parallel); returns the object paths."""
+    from concurrent.futures import ThreadPoolExecutor
+    os.makedirs(objdir, exist_ok=True)
+    hipcc = hipcc_path()
+    common = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-I", os.path.join(ROOT, "include")] + list(extra)
+    jobs, objs = [], []
+    for s in HIP_SOURCES:
+        src = os.path.join(CSRC, s)
+        o = os.path.join(objdir, s + ".o")
+        objs.append(o)
+        if force or _newer(o, deps):
+            pf = (per_file or PER_FILE_FLAGS).get(s, [])
+            jobs.append([hipcc] + common + list(pf) + ["-c", src, "-o", o])
+
+    def run(cmd):
+        if verbose:
+            print("[build]", " ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+
+    with ThreadPoolExecutor(max_workers=min(8, max(1, len(jobs)))) as ex:
+        list(ex.map(run, jobs))
+    return objs
+
+
+def build_variant(name, flags, verbose=False, per_file=None):
+    """A/B experiments: compile the library with extra -D flags into lib/variants/<name>.so.
+    per_file: {source: [flags]} replaces PER_FILE_FLAGS."""
     vdir = os.path.join(LIBDIR, "variants")
     os.makedirs(vdir, exist_ok=True)
     out = os.path.join(vdir, name + ".so")
-    cmd = [hipcc_path(), "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-shared", "-I", os.path.join(ROOT, "include")]
-    cmd += list(flags) + [os.path.join(CSRC, s) for s in HIP_SOURCES] + ["-o", out, "-ldl", "-lrt", "-lpthread"]
-    if verbose:
-        print("[build]", " ".join(cmd), flush=True)
+    objs = _compile_objects(os.path.join(vdir, "_obj_" + name), flags, True, [], verbose, per_file)
+    cmd = [hipcc_path(), "-shared", "-fPIC", "--offload-arch=gfx950", "-o", out] + objs + ["-ldl", "-lrt", "-lpthread"]
     subprocess.check_call(cmd)
+    shutil.rmtree(os.path.join(vdir, "_obj_" + name), ignore_errors=True)
     return out
 
 
@@ -57,21 +86,9 @@ def build_hip(force=False, verbose=True):
     if not force and not _newer(LIB, deps):
         return LIB
     os.makedirs(LIBDIR, exist_ok=True)
-    objdir = os.path.join(LIBDIR, "_obj")
-    os.makedirs(objdir, exist_ok=True)
-    hipcc = hipcc_path()
-    common = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-I", os.path.join(ROOT, "include")]
-    common += os.environ.get("MGN_HIPCC_FLAGS", "").split()  # experiments only (e.g. -DMGN_EXP_...)
-    objs = []
-    for s in srcs:
-        o = os.path.join(objdir, os.path.basename(s) + ".o")
-        if force or _newer(o, deps):
-            cmd = [hipcc] + common + ["-c", s, "-o", o]
-            if verbose:
-                print("[build]", " ".join(cmd), flush=True)
-            subprocess.check_call(cmd)
-        objs.append(o)
-    cmd = [hipcc, "-shared", "-fPIC", "--offload-arch=gfx950", "-o", LIB] + objs + ["-ldl", "-lrt", "-lpthread"]
+    extra = os.environ.get("MGN_HIPCC_FLAGS", "").split()  # experiments only (e.g. -DMGN_EXP_...)
+    objs = _compile_objects(os.path.join(LIBDIR, "_obj"), extra, force, deps, verbose)
+    cmd = [hipcc_path(), "-shared", "-fPIC", "--offload-arch=gfx950", "-o", LIB] + objs + ["-ldl", "-lrt", "-lpthread"]
     if verbose:
         print("[build]", " ".join(cmd), flush=True)
     subprocess.check_call(cmd)

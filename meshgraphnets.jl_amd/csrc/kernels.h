@@ -147,6 +147,7 @@ hipError_t launch_tile_bf16_to_f32(const uint16_t* src, float* dst, int64_t ntil
 hipError_t launch_gather_rows16(const uint16_t* src, const int32_t* idx, uint16_t* dst, int64_t rows, int dst_stride /* elements */, hipStream_t s);
 
 struct LaunchCfg { int blocks; int threads; size_t lds; };
+hipError_t launch_edge_split2(const EdgeArgs& a, const LaunchCfg& lc, hipStream_t s);   // split.hip
 
 struct LinComb {            // sum_j c[j] * k[j]
     int n;

@@ -27,6 +27,7 @@
 //     no zero-fill pass, bitwise reproducible.
 #include "frag.hpp"
 #include "kernels.h"
+#include "tile_common.hpp"
 
 #include <cstdlib>
 #include <mutex>
@@ -35,99 +36,6 @@
 namespace mgn {
 
 // (TileWalk: frag.hpp -- shared with the persistent training kernels)
-
-// Waves w and w+4 of a block share a SIMD and run the same program; started together they stay in
-// lockstep (both gather, then both want the MFMA pipe).  Delaying the second half once by about half a
-// tile period makes one wave's memory/VALU phase coincide with its partner's MFMA chain.
-DEVINL void stagger_second_half(int wave, int units) {
-    if (wave >= 4)
-        for (int i = 0; i < units; ++i) __builtin_amdgcn_s_sleep(127);
-}
-
-// Diagnostic build only (-DMGN_DIAG_STAMPS): s_memtime stamps per tile phase; no stamp executes in the
-// shipped kernel.  Values go to a buffer no other code reads.
-#ifdef MGN_DIAG_STAMPS
-#define STAMP(slot)                                                                              \
-    do {                                                                                         \
-        __builtin_amdgcn_sched_barrier(0);                                                       \
-        unsigned long long _t;                                                                   \
-        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t)::"memory");              \
-        __builtin_amdgcn_sched_barrier(0);                                                       \
-        if (a.stamps && blockIdx.x < 4 && stamp_tile < 24 && lane0 == 0)                         \
-            a.stamps[(((size_t)blockIdx.x * 8 + wave) * 24 + stamp_tile) * 8 + (slot)] = _t;     \
-    } while (0)
-// 16-row cooperative kernels: one half tile per block, 1024 blocks x 4 waves x 8 slots
-#define STAMP16(slot)                                                                            \
-    do {                                                                                         \
-        __builtin_amdgcn_sched_barrier(0);                                                       \
-        unsigned long long _t;                                                                   \
-        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t)::"memory");              \
-        __builtin_amdgcn_sched_barrier(0);                                                       \
-        if (a.stamps && blockIdx.x < 1024 && lane0 == 0)                                         \
-            a.stamps[((size_t)blockIdx.x * 4 + wave) * 8 + (slot)] = _t;                         \
-    } while (0)
-#else
-#define STAMP(slot) do {} while (0)
-#define STAMP16(slot) do {} while (0)
-#endif
-
-template <int CTRL, int ROWMASK>
-DEVINL float dpp_zero(float v) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROWMASK, 0xF, true));
-}
-
-// Segmented inclusive sum over runs of equal receiver inside a 32-row tile (lanes c = 0..31 of each half wave), in place on
-// NG groups of 16 registers.  c1 .. c8: "my run reaches back at least 1 / 2 / 4 / 8 rows inside my 16-lane DPP row",
-// cx: "my run continues from the previous DPP row".  One v_fmac_f32_dpp per register and level:
-//     v += dpp(v) * (condition ? 1 : 0)          (a single rounding: bitwise the sum v + dpp(v))
-// instead of v_add_f32_dpp + v_cndmask: 320 fewer VALU instructions per fp32 edge tile, and VALU issue time adds to MFMA time
-// on this part: edge kernel -2.4 % on M-1M.  DPP reads run with every lane active (a masked-out source
-// lane would read as 0 on gfx9), hence the multiplicative mask; invalid source lanes (row boundaries) read 0 (bound_ctrl).
-// Inline asm: hipcc has no builtin that yields the DPP form of fmac.  Hazards: a DPP read needs 2 wait states after a VALU
-// write of the same VGPR -- consecutive levels touch a register NG * 16 >= 16 instructions apart, and an s_nop covers the
-// first level.  MGN_SCAN_FMAC = 0 restores the two-instruction form (also the reference for tests of this helper).
-#ifndef MGN_SCAN_FMAC
-#define MGN_SCAN_FMAC 1
-#endif
-// SKIP8: the reach-8 level runs only when some run of the tile reaches back 8 rows (in-degree >= 9; a wave-uniform branch).
-// bf16 edge kernel 0.918 -> 0.907 ms on M-1M; the fp32 kernel gets 3 % SLOWER with the branch (same-box A/B), so only bf16 uses it.
-template <int NG, bool SKIP8 = false>
-DEVINL void segmented_scan(f32x16 (&acc)[NG], bool c1, bool c2, bool c4, bool c8, bool cx) {
-#if MGN_SCAN_FMAC
-    const float m1 = c1 ? 1.f : 0.f, m2 = c2 ? 1.f : 0.f, m4 = c4 ? 1.f : 0.f, m8 = c8 ? 1.f : 0.f, mx = cx ? 1.f : 0.f;
-#define MGN_SCAN_LEVEL(M, CTRL)                                                                                  \
-    _Pragma("unroll") for (int t = 0; t < NG; ++t)                                                               \
-        _Pragma("unroll") for (int k = 0; k < 16; ++k)                                                           \
-            asm volatile("v_fmac_f32_dpp %0, %0, %1 " CTRL " bound_ctrl:0" : "+v"(acc[t][k]) : "v"(M));
-    PHASE_FENCE();
-    asm volatile("s_nop 1");
-    MGN_SCAN_LEVEL(m1, "row_shr:1 row_mask:0xf bank_mask:0xf")
-    MGN_SCAN_LEVEL(m2, "row_shr:2 row_mask:0xf bank_mask:0xf")
-    MGN_SCAN_LEVEL(m4, "row_shr:4 row_mask:0xf bank_mask:0xf")
-    if (!SKIP8 || __builtin_amdgcn_ballot_w64(c8) != 0) {
-        MGN_SCAN_LEVEL(m8, "row_shr:8 row_mask:0xf bank_mask:0xf")
-    }
-    MGN_SCAN_LEVEL(mx, "row_bcast:15 row_mask:0xa bank_mask:0xf")
-#undef MGN_SCAN_LEVEL
-    PHASE_FENCE();
-#else
-#pragma unroll
-    for (int t = 0; t < NG; ++t) {
-        PHASE_FENCE();   // bound the scan's temporaries to one 16-register group at a time
-#pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            float v = acc[t][k];
-            float u;
-            u = v + dpp_zero<0x111, 0xF>(v); v = c1 ? u : v;   // row_shr:1
-            u = v + dpp_zero<0x112, 0xF>(v); v = c2 ? u : v;   // row_shr:2
-            u = v + dpp_zero<0x114, 0xF>(v); v = c4 ? u : v;   // row_shr:4
-            u = v + dpp_zero<0x118, 0xF>(v); v = c8 ? u : v;   // row_shr:8
-            u = v + dpp_zero<0x142, 0xA>(v); v = cx ? u : v;   // row_bcast:15 into rows 1 and 3
-            acc[t][k] = v;
-        }
-    }
-#endif
-}
 
 // ------------------------------------------------------------------------------------------------
 // General hidden-layer count (GenMlp, kernels.h).  acc enters with the pre-activation of the MLP's first layer.
@@ -161,43 +69,6 @@ DEVINL void gen_final(f32x16 (&acc)[NT], f32x16 (&y)[NT], const GenMlp& g, int l
 // chunk[0]=W2 chunk[1]=W3 chunk[2]=W1[2L:3L];  NRES leading chunks are LDS-resident.
 // Elat and AGG are tile-major; P, Q, CARRY row-major.
 // ================================================================================================
-struct EdgeIdx {
-    int s, r, r_before, r_after;
-};
-
-DEVINL EdgeIdx load_edge_idx(const EdgeArgs& a, int tile, int c) {
-    EdgeIdx ix;
-    const int64_t e0 = (int64_t)tile * TILE;
-    const int64_t eid = e0 + c;
-    const bool valid = eid < a.E;
-    ix.s = valid ? a.snd[eid] : 0;
-    ix.r = valid ? a.rcv[eid] : -1;                                   // -1 marks a padding lane
-    ix.r_before = (tile > 0) ? a.rcv[e0 - 1] : -2;                    // wave-uniform
-    ix.r_after = (e0 + TILE < a.E) ? a.rcv[e0 + TILE] : -3;           // wave-uniform
-    return ix;
-}
-
-// Branch-free form for the software-pipelined kernels: every load is unconditional (addresses clamped into the arrays), the
-// padding / boundary cases are selects on the loaded values.  With the conditional form hipcc puts `valid ? snd[eid] : 0` into an
-// EXEC-masked block together with everything that depends on it (the 64-bit row address of the later gather), and that block
-// starts with s_waitcnt vmcnt(0): the index load requested "ahead of time" is waited for on the spot, with every prefetch in
-// flight behind it.  Needs E >= 1 (a launch has at least one tile).
-DEVINL EdgeIdx load_edge_idx_nb(const int32_t* __restrict__ snd, const int32_t* __restrict__ rcv, int64_t E, int tile, int c) {
-    EdgeIdx ix;
-    const int64_t e0 = (int64_t)tile * TILE;
-    const int64_t eid = e0 + c;
-    const bool valid = eid < E;
-    const int64_t ec = valid ? eid : E - 1;
-    const int s_ = snd[ec], r_ = rcv[ec];
-    const int rb = rcv[e0 > 0 ? e0 - 1 : 0];                           // wave-uniform
-    const int ra = rcv[e0 + TILE < E ? e0 + TILE : E - 1];             // wave-uniform
-    ix.s = valid ? s_ : 0;
-    ix.r = valid ? r_ : -1;                                            // -1 marks a padding lane
-    ix.r_before = (tile > 0) ? rb : -2;
-    ix.r_after = (e0 + TILE < E) ? ra : -3;
-    return ix;
-}
-
 // Register plan (L = 128: three 64-VGPR arrays, nothing else of that size may be live, the kernel must not
 // spill: vmcnt retires in order, so a scratch reload issued behind the epilogue stores waits for all of them):
 //   layer 1   acc (init P[s]+Q[r], accumulates)   x = e tile (B operand)           y  free
@@ -334,7 +205,6 @@ __global__ __launch_bounds__(512, 2) void k_edge_step(const EdgeArgs a) {
 // correspondence).  Weights: the hi pieces of all three chunks and the mid piece of W2 are LDS-resident (128 KiB), the other five
 // pieces stream from L2.  The e tile is re-read for the residual (its registers hold the operand pieces during the layers).
 // ================================================================================================
-DEVINL void copy_to_lds16(uint16_t* dst, const uint16_t* __restrict__ src, int n, bool fast);
 typedef __bf16 sp_bf16x8 __attribute__((ext_vector_type(8)));
 DEVINL void sp_split3(sp_bf16x8 (&hi)[8], sp_bf16x8 (&mid)[8], sp_bf16x8 (&lo)[8], const f32x16 (&x)[4]) {
 #pragma unroll
@@ -343,6 +213,10 @@ DEVINL void sp_split3(sp_bf16x8 (&hi)[8], sp_bf16x8 (&mid)[8], sp_bf16x8 (&lo)[8
         for (int j = 0; j < 8; ++j) {
             const float v = x[s >> 1][8 * (s & 1) + j];
             const __bf16 a = (__bf16)v;
+#ifdef MGN_SP_WHATIF_NOSPLIT          // timing experiment only (wrong results): one conversion instead of the three-way split
+            hi[s][j] = a; mid[s][j] = a; lo[s][j] = a;
+            continue;
+#endif
             const float r1 = v - (float)a;
             const __bf16 b = (__bf16)r1;
             const float r2 = r1 - (float)b;
@@ -439,7 +313,9 @@ __global__ __launch_bounds__(512, 2) void k_edge_split(const EdgeArgs a) {
         add_frag<NT>(acc, row_ptr(a.Q, ix.r >= 0 ? ix.r : 0, L, h0), STRIDE_ROW);
         load_frag<NT>(y, tile_ptr(a.Elat, tw.tile, L, lane0), STRIDE_TILE);
     }
-    for (;;) {
+    int stamp_tile = 0;
+    (void)stamp_tile;
+    for (;; ++stamp_tile) {
         OPAQUE_LANE();
         const int tile = tw.tile;
         const int next = tile + tw.stride;
@@ -450,17 +326,36 @@ __global__ __launch_bounds__(512, 2) void k_edge_split(const EdgeArgs a) {
         const int r = valid ? ix.r : 0;
         f32x4* etile = tile_ptr(a.Elat, tile, L, lane);
         sp_bf16x8 hi[8], mid[8], lo[8];
+        STAMP(0);
         sp_split3(hi, mid, lo, y);                                   // y = the e tile, acc = P[s] + Q[r] (requested a tile ahead)
         __builtin_amdgcn_s_setprio(0);
+        STAMP(1);
+#ifdef MGN_SP_WHATIF_LDS              // timing experiment only (wrong results): every piece read from LDS
+        sp_layer<false, false>(acc, hi, mid, lo, l1h, l2h, l2m, lane);
+#else
         sp_layer<true, true>(acc, hi, mid, lo, l1h, g1 + 2048, g1 + 4096, lane);   // layer 1 (edge part)
+#endif
+        STAMP(2);
         relu_frag<NT, SP_RELU_ASM>(acc);
         sp_split3(hi, mid, lo, acc);
         tab_frag<NT>(y, tb + T_B2 * L, h);
+        STAMP(3);
+#ifdef MGN_SP_WHATIF_LDS
+        sp_layer<false, false>(y, hi, mid, lo, l2h, l2m, l3h, lane);
+#else
         sp_layer<false, true>(y, hi, mid, lo, l2h, l2m, g2 + 4096, lane);          // layer 2
+#endif
+        STAMP(4);
         relu_frag<NT, SP_RELU_ASM>(y);
         sp_split3(hi, mid, lo, y);
         tab_frag<NT>(acc, tb + T_B3 * L, h);
+        STAMP(5);
+#ifdef MGN_SP_WHATIF_LDS
+        sp_layer<false, false>(acc, hi, mid, lo, l3h, l1h, l2h, lane);
+#else
         sp_layer<true, true>(acc, hi, mid, lo, l3h, g3 + 2048, g3 + 4096, lane);   // layer 3
+#endif
+        STAMP(6);
         PHASE_FENCE();
         __builtin_amdgcn_s_setprio(MGN_PRIO);                        // memory / VALU phase: win issue arbitration
         load_frag<NT>(y, etile, STRIDE_TILE);                        // e again, for the residual (its registers held the weight ring)
@@ -468,6 +363,7 @@ __global__ __launch_bounds__(512, 2) void k_edge_split(const EdgeArgs a) {
 #pragma unroll
         for (int t = 0; t < NT; ++t) y[t] += acc[t];                 // e <- e + e'
         if (valid) store_frag<NT>(etile, STRIDE_TILE, y);            // padding rows of the last tile stay zero
+        STAMP(7);
         // ---- segmented sum of e' over runs of equal receiver: as in k_edge_step
         const int reff = valid ? r : (-4 - c);
         const int rprev = __shfl_up(reff, 1, 32);
@@ -502,23 +398,6 @@ __global__ __launch_bounds__(512, 2) void k_edge_split(const EdgeArgs a) {
 // chunk[0]=W2 chunk[1]=W3 chunk[2]=W1[0:L] chunk[3]=W1[L:2L] chunk[4]=WP chunk[5]=WQ
 // V and AGG tile-major; CARRY, P, Q row-major.  CARRY row 2*ntiles_e is the all-zero row.
 // ================================================================================================
-// PROJECT: also emit P,Q of the next step in the same launch (fewer launches: used for small meshes; on large
-// meshes the projection runs as k_project, where both of its chunks are LDS-resident).
-// aggregated messages of the tile's nodes: the node's AGG slot, or carry rows when its edge run straddles edge tiles.
-// A macro on purpose: as a (force-inlined) function the same code costs k_node_step<4,*> 37 spilled VGPRs.
-// Uses tile, nn, valid, lane, h, L of the enclosing tile loop.
-#define LOAD_AGGREGATE(NT_, y_, rowptr_, AGG_, CARRY_, zero_row_)                                                        \
-    do {                                                                                                                 \
-        const int a0 = valid ? (rowptr_)[nn] : 0, a1 = valid ? (rowptr_)[nn + 1] : 0;                                     \
-        const int T1 = a0 >> 5, T2 = (a1 - 1) >> 5;                                                                      \
-        const int extra = (a1 > a0 && T2 > T1) ? (T2 - T1) : 0;                                                          \
-        const bool from_agg = (a1 > a0) && !extra;                                                                       \
-        const f32x4* src0 = from_agg ? tile_ptr((AGG_), tile, L, lane)                                                   \
-                                     : row_ptr((CARRY_), extra ? (int64_t)(2 * T1 + 1) : (zero_row_), L, h);            \
-        load_frag<NT_>(y_, src0, from_agg ? STRIDE_TILE : STRIDE_ROW);                                                   \
-        for (int q = 1; __any(q <= extra); ++q)                                                                          \
-            if (q <= extra) add_frag<NT_>(y_, row_ptr((CARRY_), (int64_t)2 * (T1 + q), L, h), STRIDE_ROW);              \
-    } while (0)
 
 // NAGG = 2: a second edge set's aggregate (AGG2 / CARRY2 / rowptr2) is a further layer-1 input, chunk[6] streamed.
 #ifndef MGN_NODE_PAD
@@ -1707,15 +1586,6 @@ DEVINL void bf_chunk(f32x16 (&acc)[4], const bf16x8 (&in)[8], const bf16x8* w, i
 
 constexpr int BF_CH = 128 * 128;   // bf16 elements per chunk (32 KiB)
 
-// `fast`: launches of a few tiles per wave, where the preload is a large share of the kernel (see copy_to_lds_vec); long
-// persistent launches keep the plain loop (the batched copy costs them ~1 % in steady state, same-box A/B on M-1M)
-DEVINL void copy_to_lds16(uint16_t* dst, const uint16_t* __restrict__ src, int n, bool fast) {
-    const f32x4* s4 = reinterpret_cast<const f32x4*>(src);
-    f32x4* d4 = reinterpret_cast<f32x4*>(dst);
-    if (fast) copy_to_lds_vec(d4, s4, n / 8);
-    else
-        for (int i = threadIdx.x; i < n / 8; i += blockDim.x) d4[i] = s4[i];
-}
 
 #ifndef MGN_BF_WAVES
 #define MGN_BF_WAVES 12   // waves per block of the bf16 edge kernel: 3 per SIMD (<= 168 VGPRs)
@@ -2738,10 +2608,10 @@ hipError_t launch_edge_step(int L, const EdgeArgs& a, hipStream_t s) {
             lc.lds = (size_t)T_COUNT * L * 4 + 64;
             return launch_k(k_edge_step<4, 0>, a, lc, s);
         }
-        if (g_fp32_split && a.split[0] && g_path == 0) {   // opt-in: fp32 accuracy on the bf16 matrix cores (k_edge_split)
+        if (g_fp32_split && a.split[0] && g_path == 0) {   // fp32 accuracy on the bf16 matrix cores (split.hip; 1: first-generation k_edge_split)
             LaunchCfg ls = lc;
             ls.lds = (size_t)4 * 16384 * 2 + (size_t)T_COUNT * L * 4 + 64;
-            return launch_k(k_edge_split, a, ls, s);
+            return g_fp32_split == 1 ? launch_k(k_edge_split, a, ls, s) : launch_edge_split2(a, ls, s);
         }
         lc.lds += (size_t)MGN_EDGE_JR * 64 * 4 * 4;   // partially resident third chunk
         // Tail of the persistent walk: with r = ntiles / (8 waves x 256 blocks) rounds, a last round that is less than

@@ -1,0 +1,256 @@
+// fp32 processor kernels on the bf16 matrix cores at fp32 accuracy ("exact split" path).
+//
+// Replaces, for large fp32 launches at L = 128, the three fp32-MFMA kernels of a processor step (kernels.hip: k_edge_step,
+// k_node_step, k_project -- reference: the Processor of GraphNetCore called at src/solve.jl:200).  Storage, tables, LayerNorm,
+// residual, segmented scan, carry rows, launch geometry are those kernels'; only the L x L layers differ:
+//   * every fp32 operand is the exact sum of three bf16 values (x = x1 + x2 + x3, 3 x 8 significand bits); of the nine piece
+//     products of a * b the six with i + j <= 4 carry everything above 2^-24 relative; each product of two bf16 values is exact
+//     in fp32 and v_mfma_f32_32x32x16_bf16 accumulates in fp32: one L x L layer against float64 has max relative error 1.7e-7
+//     (a plain fp32 GEMM: 4.2e-7).  Six bf16 MFMAs cost 6 / 16 of the matrix time of the fp32 MFMA.
+//   * weights are split on the host (mgn_set_params: pack_chunk_split, [piece][s][t][lane][8 bf16]); activations are split IN the
+//     MFMA stream: the pieces of k-step s + 1 are computed (11 VALU instructions per pair of values, ReLU folded in) between the
+//     24 MFMAs of k-step s, where they issue in the shadow of the matrix pipe (tools/overlap_probe.hip: four VALU instructions
+//     per v_mfma_f32_32x32x16_bf16 are free, a separate split phase is not).  Only two k-steps' pieces are live, which leaves
+//     registers for rings of 6-8 streamed weight fragments per piece (an L2 round trip under load is ~1.5 k cycles).
+//   * the hi pieces of all chunks (+ one mid piece) are LDS-resident, the rest stream from L2 through those rings.
+// The accumulator layout of the two MFMA shapes is the same; element j of lane half h at k-step s is accumulator register
+// 8 (s & 1) + j of block s >> 1 (the bf16 kernels' correspondence), so a layer's output feeds the next layer without a shuffle.
+// Compiled with -fno-slp-vectorize (build.py): hipcc otherwise packs the split's subtractions into v_pk_add_f32, which holds the
+// matrix pipe for ~12 cycles each (tools/overlap_probe.hip).
+#include "kernels.h"
+#include "tile_common.hpp"
+
+namespace mgn {
+
+typedef __bf16 sp_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 sp_bf16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+DEVINL float sp_f(unsigned u) { return __builtin_bit_cast(float, u); }
+DEVINL unsigned sp_u(float f) { return __builtin_bit_cast(unsigned, f); }
+DEVINL unsigned sp_cvt_pk(float a, float b) {            // v_cvt_pk_bf16_f32: round to nearest even
+    sp_bf16x2 p;
+    p[0] = (__bf16)a;
+    p[1] = (__bf16)b;
+    return __builtin_bit_cast(unsigned, p);
+}
+// ReLU on the bits: a signed-integer max with 0 (negative floats, -0 and negative NaNs -> +0): one instruction the compiler can see
+DEVINL float sp_relu(float v) {
+    const int b = __builtin_bit_cast(int, v);
+    return __builtin_bit_cast(float, b > 0 ? b : 0);
+}
+// three-way split of a pair of values: v = hi + mid + lo exactly, each piece a bf16 (11 VALU instructions, 13 with the ReLU)
+struct SpPieces {            // the hi / mid / lo pieces of one k-step of a lane: 8 bf16 each (4 dwords)
+    unsigned h[4], m[4], l[4];
+};
+DEVINL sp_bf16x8 sp_op(const unsigned (&v)[4]) {
+    u32x4 q;
+    q[0] = v[0]; q[1] = v[1]; q[2] = v[2]; q[3] = v[3];
+    return __builtin_bit_cast(sp_bf16x8, q);
+}
+template <bool RELU>
+DEVINL void sp_split_pair(unsigned& hi, unsigned& mid, unsigned& lo, float v0, float v1) {
+    if constexpr (RELU) {
+        v0 = sp_relu(v0);
+        v1 = sp_relu(v1);
+    }
+    const unsigned h = sp_cvt_pk(v0, v1);
+    const float r0 = v0 - sp_f(h << 16), r1 = v1 - sp_f(h & 0xffff0000u);
+    const unsigned m = sp_cvt_pk(r0, r1);
+    const float q0 = r0 - sp_f(m << 16), q1 = r1 - sp_f(m & 0xffff0000u);
+    hi = h;
+    mid = m;
+    lo = sp_cvt_pk(q0, q1);
+}
+DEVINL sp_bf16x8 sp_wop(const u32x4& v) { return __builtin_bit_cast(sp_bf16x8, v); }
+
+#ifndef MGN_SP2_INTERLEAVE
+#define MGN_SP2_INTERLEAVE 1      // 1: pin "one MFMA, two VALU" inside every (s, t) group (sched_group_barrier)
+#endif
+
+// One L x L layer: acc += W^T in, `in` split on the fly.  p1 / p2 / p3: the chunk's hi / mid / lo piece ([s][t][lane] fragments of
+// 8 bf16).  p1 is LDS-resident; G2 / G3: p2 / p3 stream from L2 through register rings D (s, t) groups deep (else LDS too).  The
+// rings are pinned by scheduling fences: left to itself hipcc requests every streamed fragment one MFMA before its use.
+template <bool G2, bool G3, bool RELU, int D>
+DEVINL void sp_layer_otf(f32x16 (&acc)[4], const f32x16 (&in)[4], const u32x4* p1, const u32x4* p2, const u32x4* p3, int lane) {
+    const u32x4* w1 = p1 + lane;
+    const u32x4* w2 = p2 + lane;
+    const u32x4* w3 = p3 + lane;
+    u32x4 r2[G2 ? D : 1], r3[G3 ? D : 1];
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+        if constexpr (G2) r2[d] = w2[d * 64];
+        if constexpr (G3) r3[d] = w3[d * 64];
+    }
+    u32x4 n1 = w1[0], n2, n3;
+    if constexpr (!G2) n2 = w2[0];
+    if constexpr (!G3) n3 = w3[0];
+    SpPieces p;                                         // the pieces of k-step s
+#pragma unroll
+    for (int u = 0; u < 4; ++u) sp_split_pair<RELU>(p.h[u], p.m[u], p.l[u], in[0][2 * u], in[0][2 * u + 1]);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+        SpPieces n;                                     // ... and of k-step s + 1, one pair per (s, t) group
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int it = 4 * s + t;
+            const u32x4 a1 = n1;
+            u32x4 a2, a3;
+            if constexpr (G2) a2 = r2[it % D]; else a2 = n2;
+            if constexpr (G3) a3 = r3[it % D]; else a3 = n3;
+            if (it + 1 < 32) {
+                n1 = w1[(it + 1) * 64];
+                if constexpr (!G2) n2 = w2[(it + 1) * 64];
+                if constexpr (!G3) n3 = w3[(it + 1) * 64];
+            }
+            if (it + D < 32) {
+                if constexpr (G2) r2[it % D] = w2[(it + D) * 64];
+                if constexpr (G3) r3[it % D] = w3[(it + D) * 64];
+            }
+            if (s < 7) {
+                const int sn = s + 1;
+                sp_split_pair<RELU>(n.h[t], n.m[t], n.l[t], in[sn >> 1][8 * (sn & 1) + 2 * t], in[sn >> 1][8 * (sn & 1) + 2 * t + 1]);
+            }
+            const sp_bf16x8 bh = sp_op(p.h), bm = sp_op(p.m), bl = sp_op(p.l);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sp_wop(a3), bh, acc[t], 0, 0, 0);      // small terms first
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sp_wop(a2), bm, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sp_wop(a1), bl, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sp_wop(a2), bh, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sp_wop(a1), bm, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sp_wop(a1), bh, acc[t], 0, 0, 0);
+#if MGN_SP2_INTERLEAVE
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+#endif
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        p = n;
+    }
+}
+
+// ================================================================================================
+// Processor edge step (K3 + K4 + K5) on the split path.  chunk order as in k_edge_step: split[0] = W2, [1] = W3, [2] = W1[2L:3L].
+// LDS: hi of W1e, hi + mid of W2, hi of W3 (128 KiB) + tables.  The e tile is re-read for the residual (its registers carry the
+// second layer's output meanwhile).
+// ================================================================================================
+#ifndef MGN_SP2_D
+#define MGN_SP2_D 6
+#endif
+#ifndef MGN_SP2_D1
+#define MGN_SP2_D1 8       // layer 2 streams one piece only
+#endif
+__global__ __launch_bounds__(512, 2) void k_edge_split2(const EdgeArgs a) {
+    constexpr int NT = 4, L = 128, PC = 16384;                      // PC: bf16 elements per piece
+    constexpr int D = MGN_SP2_D, D1 = MGN_SP2_D1;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    uint16_t* wl = reinterpret_cast<uint16_t*>(smem);
+    {
+        const bool fast = a.ntiles <= 16 * 1024;
+        copy_to_lds16(wl, a.split[2], PC, fast);
+        copy_to_lds16(wl + PC, a.split[0], 2 * PC, fast);           // hi + mid of W2 are adjacent
+        copy_to_lds16(wl + 3 * PC, a.split[1], PC, fast);
+    }
+    float* tb = smem + 4 * PC / 2;
+    copy_to_lds(tb, a.tabs, T_COUNT * L);
+    __syncthreads();
+    const u32x4* l1h = reinterpret_cast<const u32x4*>(wl);
+    const u32x4* l2h = reinterpret_cast<const u32x4*>(wl + PC);
+    const u32x4* l2m = reinterpret_cast<const u32x4*>(wl + 2 * PC);
+    const u32x4* l3h = reinterpret_cast<const u32x4*>(wl + 3 * PC);
+    const u32x4* g1 = reinterpret_cast<const u32x4*>(a.split[2]);      // 2048 fragments per piece
+    const u32x4* g2 = reinterpret_cast<const u32x4*>(a.split[0]);
+    const u32x4* g3 = reinterpret_cast<const u32x4*>(a.split[1]);
+    const int lane0 = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    stagger_second_half(wave, a.stagger);
+    TileWalk tw(a.ntiles, wave);
+    tw.tile += a.tile0;
+    tw.end += a.tile0;
+    if (tw.tile >= tw.end) return;
+    f32x16 acc[NT], y[NT];
+    EdgeIdx ix = load_edge_idx_nb(a.snd, a.rcv, a.E, tw.tile, lane0 & 31);
+    {   // first tile: layer-1 accumulator P[s] + Q[r] (Q carries b1) and the e tile
+        const int h0 = lane0 >> 5;
+        load_frag<NT>(acc, row_ptr(a.P, ix.s, L, h0), STRIDE_ROW);
+        add_frag<NT>(acc, row_ptr(a.Q, ix.r >= 0 ? ix.r : 0, L, h0), STRIDE_ROW);
+        load_frag<NT>(y, tile_ptr(a.Elat, tw.tile, L, lane0), STRIDE_TILE);
+    }
+    int stamp_tile = 0;
+    (void)stamp_tile;
+    for (;; ++stamp_tile) {
+        OPAQUE_LANE();
+        const int tile = tw.tile;
+        const int next = tile + tw.stride;
+        const bool has_next = next < tw.end;
+        const int nxt = has_next ? next : tile;
+        const EdgeIdx ixn = load_edge_idx_nb(a.snd, a.rcv, a.E, nxt, c);
+        const bool valid = ix.r >= 0;
+        const int r = valid ? ix.r : 0;
+        f32x4* etile = tile_ptr(a.Elat, tile, L, lane);
+        STAMP(0);
+        __builtin_amdgcn_s_setprio(0);
+        sp_layer_otf<true, true, false, D>(acc, y, l1h, g1 + 2048, g1 + 4096, lane);   // layer 1 (edge part); y = e tile
+        STAMP(1);
+        tab_frag<NT>(y, tb + T_B2 * L, h);
+        STAMP(2);
+        sp_layer_otf<false, true, true, D1>(y, acc, l2h, l2m, g2 + 4096, lane);        // layer 2 (ReLU folded into the split)
+        STAMP(3);
+        tab_frag<NT>(acc, tb + T_B3 * L, h);
+        STAMP(4);
+        sp_layer_otf<true, true, true, D>(acc, y, l3h, g3 + 2048, g3 + 4096, lane);    // layer 3
+        STAMP(5);
+        PHASE_FENCE();
+        __builtin_amdgcn_s_setprio(MGN_PRIO);                        // memory / VALU phase: win issue arbitration
+        load_frag<NT>(y, etile, STRIDE_TILE);                        // e again, for the residual
+        layer_norm_frag<NT>(acc, tb + T_GAMMA * L, tb + T_BETA * L, h);   // acc = e'
+        STAMP(6);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) y[t] += acc[t];                 // e <- e + e'
+        if (valid) store_frag<NT>(etile, STRIDE_TILE, y);            // padding rows of the last tile stay zero
+        STAMP(7);
+        // ---- segmented sum of e' over runs of equal receiver: as in k_edge_step
+        const int reff = valid ? r : (-4 - c);
+        const int rprev = __shfl_up(reff, 1, 32);
+        const int rnext = __shfl_down(reff, 1, 32);
+        const bool head = (c == 0) || (reff != rprev);
+        const unsigned hm = (unsigned)__ballot(head);
+        const int start = 31 - __clz((int)(hm & (0xFFFFFFFFu >> (31 - c))));
+        const int st_in = max(start, c & 16);
+        const bool c1 = (c - 1 >= st_in), c2 = (c - 2 >= st_in), c4 = (c - 4 >= st_in), c8 = (c - 8 >= st_in);
+        const bool cx = (c >= 16) && (start <= 15);
+        segmented_scan<NT>(acc, c1, c2, c4, c8, cx);
+        const bool tail = valid && ((c == 31) || (reff != rnext));
+        const int r_first = __builtin_amdgcn_readfirstlane(reff);
+        const bool sl = (start == 0) && (ix.r_before == r_first);
+        const bool sr = (c == 31) && (ix.r_after == reff);
+        const bool to_carry = sl || sr;
+        f32x4* dst = to_carry ? row_ptr(a.CARRY, (int64_t)2 * tile + (sl ? 0 : 1), L, h) : tile_ptr(a.AGG, r >> 5, L, 32 * h + (r & 31));
+        if (tail) store_frag<NT>(dst, to_carry ? STRIDE_ROW : STRIDE_TILE, acc);
+        if (!has_next) break;
+        PHASE_FENCE();
+        // turnover: the next tile's layer-1 accumulator and e tile
+        load_frag<NT>(acc, row_ptr(a.P, ixn.s, L, h), STRIDE_ROW);
+        add_frag<NT>(acc, row_ptr(a.Q, ixn.r >= 0 ? ixn.r : 0, L, h), STRIDE_ROW);
+        load_frag<NT>(y, tile_ptr(a.Elat, nxt, L, lane), STRIDE_TILE);
+        ix = ixn;
+        tw.tile = next;
+    }
+}
+
+hipError_t launch_edge_split2(const EdgeArgs& a, const LaunchCfg& lc, hipStream_t s) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_edge_split2), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(k_edge_split2, dim3(lc.blocks), dim3(lc.threads), lc.lds, s, a);
+    return hipGetLastError();
+}
+
+}  // namespace mgn

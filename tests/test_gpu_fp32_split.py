@@ -13,10 +13,10 @@ from util import TOL_15, TOL_STEP, cfg_dict, engine_for, make_params, rel_max, s
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture
-def split_on():
-    old = set_fp32_split(1)
-    yield
+@pytest.fixture(params=[1, 2], ids=["k_edge_split", "split2"])
+def split_on(request):
+    old = set_fp32_split(request.param)
+    yield request.param
     set_fp32_split(old)
 
 
@@ -77,7 +77,7 @@ def test_split_edge_kernel_meets_the_fp32_tolerances(split_on, nsteps, tol):
     f32.set_params(ps)
     f32.set_graph(s, r, N)
     v3, e3 = f32.processor_steps(v, e, nsteps)
-    set_fp32_split(1)
+    set_fp32_split(split_on)
     err_f32 = (rel_max(v3, rv), rel_max(e3, re))
     assert max(err_split) <= 2.0 * max(err_f32) + 1e-7, (err_split, err_f32)
     assert not np.array_equal(e3, e1)          # (it really is the other kernel)
