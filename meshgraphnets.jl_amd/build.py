@@ -20,8 +20,8 @@ LIB = os.path.join(LIBDIR, "libmgn_hip.so")
 ORACLE_DIR = os.path.join(ROOT, "oracle")
 REF_LIB = os.path.join(ORACLE_DIR, "_build", "libmgn_ref.so")
 
-HIP_SOURCES = ["kernels.hip", "split.hip", "train.hip", "mgn_api.cpp", "mgn_train.cpp", "graph_host.cpp", "graph_prologue.cpp", "tfrecord.cpp", "comm.cpp", "graph_dev.hip"]
-HIP_HEADERS = ["kernels.h", "graph_host.h", "frag.hpp", "tile_common.hpp", "engine_internal.h", "train.h", "comm.h", "graph_dev.h", os.path.join(ROOT, "include", "mgn_hip.h")]
+HIP_SOURCES = ["kernels.hip", "split.hip", "split_ws.hip", "train.hip", "mgn_api.cpp", "mgn_train.cpp", "graph_host.cpp", "graph_prologue.cpp", "tfrecord.cpp", "comm.cpp", "graph_dev.hip"]
+HIP_HEADERS = ["kernels.h", "graph_host.h", "frag.hpp", "tile_common.hpp", "split_common.hpp", "engine_internal.h", "train.h", "comm.h", "graph_dev.h", os.path.join(ROOT, "include", "mgn_hip.h")]
 
 
 def _newer(target, deps):
@@ -39,7 +39,8 @@ def hipcc_path():
 
 
 # extra flags per source.  split.hip: see its header (the SLP vectoriser's v_pk_add_f32 inside the MFMA stream).
-PER_FILE_FLAGS = {"split.hip": os.environ.get("MGN_SPLIT_FLAGS", "").split()}
+PER_FILE_FLAGS = {"split.hip": os.environ.get("MGN_SPLIT_FLAGS", "").split(),
+                  "split_ws.hip": os.environ.get("MGN_SPLIT_WS_FLAGS", "-fno-slp-vectorize").split()}
 
 
 def _compile_objects(objdir, extra, force, deps, verbose, per_file=None):
@@ -54,7 +55,7 @@ def _compile_objects(objdir, extra, force, deps, verbose, per_file=None):
         o = os.path.join(objdir, s + ".o")
         objs.append(o)
         if force or _newer(o, deps):
-            pf = (per_file or PER_FILE_FLAGS).get(s, [])
+            pf = (per_file or {}).get(s, PER_FILE_FLAGS.get(s, []))
             jobs.append([hipcc] + common + list(pf) + ["-c", src, "-o", o])
 
     def run(cmd):

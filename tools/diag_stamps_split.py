@@ -16,6 +16,23 @@ st = out[:4 * 8 * 24 * 8].reshape(4, 8, 24, 8).astype(np.int64)
 names = ["split1", "L1", "relu+split2", "L2", "relu+split3", "L3", "reload e+LN+resid+store", "scan+tails+turnover(to next start)"]
 if os.environ.get("MGN_FP32_SPLIT") == "2":
     names = ["L1", "tab", "L2", "tab", "L3", "reload e+LN", "resid+store", "scan+tails+turnover(to next start)"]
+if os.environ.get("MGN_FP32_SPLIT") == "3" and os.environ.get("MGN_WS_K"):
+    # per-k-step stamps of one stage (library built with -DMGN_WS_DIAG_STAGE=n): slot s = the MFMAs of k-step s are issued
+    for b in range(2):
+        d = np.diff(st[b, :4, 2:20, :8], axis=-1)
+        for w in range(4):
+            print(f"block {b} wave {w}: cycles between k-step stamps 0..7:", [int(d[w, :, i].mean()) for i in range(7)],
+                  "iteration", int(np.diff(st[b, w, 2:20, 0]).mean()))
+    sys.exit(0)
+if os.environ.get("MGN_FP32_SPLIT") == "3":
+    names = ["S0 A.L1", "S1 B.L1", "S2 A.L2", "S3 B.L2", "S4 A.L3", "S5 B.L3", "rotate+barrier", "(to next S0)"]
+    for b in range(2):
+        ext = np.concatenate([st[b, :4, 2:20, :8], st[b, :4, 3:21, 0:1]], axis=-1)
+        d = np.diff(ext, axis=-1)
+        print(f"block {b}: mean cycles per stage (iterations 2..19; two tiles per iteration), rows = waves:")
+        for w in range(4):
+            print("  wave", w, {n: int(d[w, :, i].mean()) for i, n in enumerate(names)}, "iteration", int(np.diff(st[b, w, 2:20, 0]).mean()))
+    sys.exit(0)
 for b in range(2):
     ext = np.concatenate([st[b, :, 2:20, :8], st[b, :, 3:21, 0:1]], axis=-1)
     d = np.diff(ext, axis=-1)   # [wave][tile][phase]
