@@ -125,7 +125,7 @@ struct mgn_engine {
     std::vector<BfStepOff> bsoff;
     // opt-in fp32-on-bf16-matrix-cores edge kernel (k_edge_split): per step and set, the three chunks as 3 bf16 pieces each
     DevBuf wsp;
-    struct SplitOff { size_t e_ch[MAX_EDGE_SETS][3]; };
+    struct SplitOff { size_t e_ch[MAX_EDGE_SETS][3]; size_t n_ch[6]; bool have_n; };
     std::vector<SplitOff> spoff;
     // static per-trajectory RHS inputs (mgn_set_static): cached encoded edge latents
     bool have_static = false;

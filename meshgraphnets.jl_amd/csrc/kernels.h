@@ -76,6 +76,8 @@ struct NodeArgs {
     float* P2; float* Q2; const float* tabs2;
     int32_t bf;             // see EdgeArgs (V, AGG, CARRY, P, Q bf16)
     unsigned long long* stamps;  // diagnostic builds only (MGN_DIAG_STAMPS), else null
+    // split path (see EdgeArgs.split): chunk[0..5] as 3 x 16384 bf16 pieces each (k_node_split, k_project_split); null: not available
+    const uint16_t* split[6];
 };
 
 struct EncNodeArgs {
@@ -149,6 +151,8 @@ hipError_t launch_gather_rows16(const uint16_t* src, const int32_t* idx, uint16_
 struct LaunchCfg { int blocks; int threads; size_t lds; };
 hipError_t launch_edge_split2(const EdgeArgs& a, const LaunchCfg& lc, hipStream_t s);   // split.hip
 hipError_t launch_edge_ws(const EdgeArgs& a, hipStream_t s);                            // split_ws.hip
+hipError_t launch_node_split(const NodeArgs& a, const LaunchCfg& lc, hipStream_t s);    // split.hip
+hipError_t launch_project_split(const NodeArgs& a, const LaunchCfg& lc, hipStream_t s); // split.hip
 
 struct LinComb {            // sum_j c[j] * k[j]
     int n;

@@ -403,9 +403,6 @@ __global__ __launch_bounds__(512, 2) void k_edge_split(const EdgeArgs a) {
 #ifndef MGN_NODE_PAD
 #define MGN_NODE_PAD 0
 #endif
-#ifndef MGN_FAST_PRELOAD_TILES
-#define MGN_FAST_PRELOAD_TILES 8192     // node-side launches of up to 4 tiles per wave copy their weights with eight loads in flight
-#endif
 constexpr bool NODE_PAD = MGN_NODE_PAD != 0;
 template <int NT, int NRES, bool PROJECT, int NAGG = 1, bool GEN = false>
 __global__ __launch_bounds__(512, 2) void k_node_step(const NodeArgs a) {
@@ -2661,6 +2658,11 @@ hipError_t launch_node_step(int L, const NodeArgs& a, hipStream_t s) {
     }
     if (a.mode == 2) return launch_project(L, a, s);
     const bool proj = a.mode == 1;
+    if (g_fp32_split && g_path == 0 && L == 128 && !proj && !a.AGG2 && a.split[0] && !small_launch(a.ntiles)) {   // split path (split.hip)
+        LaunchCfg ls = tile_launch(L, a.ntiles, 2);
+        ls.lds = (size_t)4 * 16384 * 2 + (size_t)T_COUNT * L * 4 + 64;
+        return launch_node_split(a, ls, s);
+    }
     const int nres = resident_chunks(L, proj ? 6 : 4);
     const LaunchCfg lc = tile_launch(L, a.ntiles, nres);
     if (a.AGG2) {   // two edge sets: MLP only here, the host projects per set in separate launches
@@ -2706,6 +2708,11 @@ hipError_t launch_project(int L, const NodeArgs& a, hipStream_t s) {
         return launch_k(k_project<4, false>, a, lc, s);
     }
     if (L == 128) {
+        if (g_fp32_split && g_path == 0 && !a.gen.use && a.mode == 2 && a.split[4]) {   // split path (split.hip)
+            LaunchCfg ls = lc;
+            ls.lds = (size_t)4 * 16384 * 2 + (size_t)T_COUNT * L * 4 + 64;
+            return launch_project_split(a, ls, s);
+        }
         if (lc.threads == 512) lc.threads = MGN_PROJ_WAVES * 64;
         return launch_k(k_project<4, true>, a, lc, s);
     }

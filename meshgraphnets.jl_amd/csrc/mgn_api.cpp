@@ -449,6 +449,8 @@ NodeArgs node_args(mgn_engine* h, int k, int mode, int q = 0) {
     a.c16 = use_c16(h);
     a.stamps = h->d_stamps.as<unsigned long long>();
     a.tile0 = 0;
+    for (int i = 0; i < 6; ++i)
+        a.split[i] = (!bf && q == 0 && k < (int)h->spoff.size() && h->spoff[k].have_n && h->wsp.p) ? h->wsp.as<uint16_t>() + h->spoff[k].n_ch[i] : nullptr;
     return a;
 }
 
@@ -725,9 +727,10 @@ int mgn_set_params(mgn_handle* h, const float* packed, size_t n) try {
         h->soff.push_back(so);
     }
     h->spoff.clear();
-    if (c.dtype == MGN_F32 && L == 128 && c.hidden_layers == 2) {      // pieces for the opt-in k_edge_split (4.4 MB per edge set)
-        std::vector<uint16_t> ws((size_t)c.mps * S * 3 * 3 * 16384);
-        h->spoff.assign(c.mps, {});
+    if (c.dtype == MGN_F32 && L == 128 && c.hidden_layers == 2) {      // bf16 pieces of the split path (split.hip): 4.4 MB per edge set,
+        const bool node_side = S == 1;                                  //   8.8 MB for the node side (one edge set)
+        std::vector<uint16_t> ws((size_t)c.mps * S * 3 * 3 * 16384 + (node_side ? (size_t)(c.mps + 1) * 6 * 3 * 16384 : 0));
+        h->spoff.assign(c.mps + 1, {});
         size_t off = 0;
         for (int k = 0; k < c.mps; ++k)
             for (int q = 0; q < S; ++q) {
@@ -740,6 +743,18 @@ int mgn_set_params(mgn_handle* h, const float* packed, size_t n) try {
                     off += (size_t)3 * 16384;
                 }
             }
+        for (int k = 0; node_side && k <= c.mps; ++k) {                 // node MLP of step k + projection for step k + 1 (k = mps: the
+            const MlpOff& mn = h->pn[k < c.mps ? k : 0];                //   "project only" pseudo-step: step 0's own first layer)
+            const MlpOff& nx = h->es[0].pe[k + 1 < c.mps ? k + 1 : 0];
+            const float* src[6] = {p + mn.W[1], p + mn.W[2], p + mn.W[0], p + mn.W[0], p + nx.W[0], p + nx.W[0]};
+            const int kb[6] = {0, 0, 0, L, 0, L};
+            for (int i = 0; i < 6; ++i) {
+                pack_chunk_split(ws.data() + off, src[i], L, kb[i]);
+                h->spoff[k].n_ch[i] = off;
+                off += (size_t)3 * 16384;
+            }
+            h->spoff[k].have_n = true;
+        }
         HIPCHK(h, hipStreamSynchronize(h->stream));
         HIPCHK(h, h->wsp.ensure(ws.size() * 2));
         HIPCHK(h, hipMemcpy(h->wsp.p, ws.data(), ws.size() * 2, hipMemcpyHostToDevice));

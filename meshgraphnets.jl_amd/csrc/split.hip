@@ -201,6 +201,143 @@ __global__ __launch_bounds__(512, 2) void k_edge_split2(const EdgeArgs a) {
     }
 }
 
+// ================================================================================================
+// Processor node step (K6) on the split path: k_node_step<4, *, false>'s tile loop with its four L x L chunks on the bf16 matrix
+// cores.  split[]: the chunks in NodeArgs.chunk order (0: W2, 1: W3, 2: W1[0:L] (node part), 3: W1[L:2L] (aggregate part)), each as
+// hi / mid / lo pieces.  LDS: the four hi pieces (128 KiB) + tables; mid and lo stream from L2 (sp_layer_otf rings).  The V tile is
+// read again for the residual (its registers carry the aggregate and then the second layer's output meanwhile).
+// ================================================================================================
+__global__ __launch_bounds__(512, 2) void k_node_split(const NodeArgs a) {
+    constexpr int NT = 4, L = 128, PC = 16384, D = MGN_SP2_D;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    uint16_t* wl = reinterpret_cast<uint16_t*>(smem);
+    {
+        const bool fast = a.ntiles <= MGN_FAST_PRELOAD_TILES;
+        copy_to_lds16(wl, a.split[2], PC, fast);
+        copy_to_lds16(wl + PC, a.split[3], PC, fast);
+        copy_to_lds16(wl + 2 * PC, a.split[0], PC, fast);
+        copy_to_lds16(wl + 3 * PC, a.split[1], PC, fast);
+    }
+    float* tb = smem + 4 * PC / 2;
+    copy_to_lds(tb, a.tabs, T_COUNT * L);
+    __syncthreads();
+    const u32x4* lvh = reinterpret_cast<const u32x4*>(wl);
+    const u32x4* lah = reinterpret_cast<const u32x4*>(wl + PC);
+    const u32x4* l2h = reinterpret_cast<const u32x4*>(wl + 2 * PC);
+    const u32x4* l3h = reinterpret_cast<const u32x4*>(wl + 3 * PC);
+    const u32x4* gv = reinterpret_cast<const u32x4*>(a.split[2]);      // 2048 fragments per piece
+    const u32x4* ga = reinterpret_cast<const u32x4*>(a.split[3]);
+    const u32x4* g2 = reinterpret_cast<const u32x4*>(a.split[0]);
+    const u32x4* g3 = reinterpret_cast<const u32x4*>(a.split[1]);
+    const int lane0 = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    stagger_second_half(wave, a.stagger);
+    TileWalk tw(a.ntiles, wave, MGN_SPREAD_ROUNDS_NODE);
+    if (tw.tile >= tw.end) return;
+    f32x16 x[NT], acc[NT];
+    load_frag<NT>(x, tile_ptr(a.V, tw.tile, L, lane0), STRIDE_TILE);
+    for (;;) {
+        OPAQUE_LANE();
+        const int tile = tw.tile;
+        const int next = tile + tw.stride;
+        const bool has_next = next < tw.end;
+        const int n = tile * TILE + c;
+        const bool valid = n < a.n;
+        const int nn = valid ? n : 0;
+        f32x4* vtile = tile_ptr(a.V, tile, L, lane);
+        __builtin_amdgcn_s_setprio(0);
+        tab_frag<NT>(acc, tb + T_B1 * L, h);
+        sp_layer_otf<true, true, false, D>(acc, x, lvh, gv + 2048, gv + 4096, lane);      // layer 1, node part
+        LOAD_AGGREGATE(NT, x, a.rowptr, a.AGG, a.CARRY, a.zero_row);
+        sp_layer_otf<true, true, false, D>(acc, x, lah, ga + 2048, ga + 4096, lane);      // layer 1, aggregate part
+        tab_frag<NT>(x, tb + T_B2 * L, h);
+        sp_layer_otf<true, true, true, D>(x, acc, l2h, g2 + 2048, g2 + 4096, lane);       // layer 2 (ReLU folded into the split)
+        tab_frag<NT>(acc, tb + T_B3 * L, h);
+        sp_layer_otf<true, true, true, D>(acc, x, l3h, g3 + 2048, g3 + 4096, lane);       // layer 3
+        PHASE_FENCE();
+        __builtin_amdgcn_s_setprio(MGN_PRIO);
+        load_frag<NT>(x, vtile, STRIDE_TILE);                        // v again, for the residual
+        layer_norm_frag<NT>(acc, tb + T_GAMMA * L, tb + T_BETA * L, h);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) x[t] += acc[t];                 // v <- v + v'
+        if (valid) store_frag<NT>(vtile, STRIDE_TILE, x);
+        if (!has_next) break;
+        PHASE_FENCE();
+        load_frag<NT>(x, tile_ptr(a.V, next, L, lane), STRIDE_TILE);
+        tw.tile = next;
+    }
+}
+
+// P, Q projection of the next step (k_project) on the split path.  split[4] = WP, split[5] = WQ; LDS: hi + mid of both (128 KiB),
+// the lo pieces stream.  Tiles [tile0, tile0 + ntiles).
+__global__ __launch_bounds__(512, 2) void k_project_split(const NodeArgs a) {
+    constexpr int NT = 4, L = 128, PC = 16384, D1 = MGN_SP2_D1;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    uint16_t* wl = reinterpret_cast<uint16_t*>(smem);
+    {
+        const bool fast = a.ntiles <= MGN_FAST_PRELOAD_TILES;
+        copy_to_lds16(wl, a.split[4], 2 * PC, fast);                 // hi + mid are adjacent
+        copy_to_lds16(wl + 2 * PC, a.split[5], 2 * PC, fast);
+    }
+    float* tb = smem + 4 * PC / 2;
+    copy_to_lds(tb, a.tabs, T_COUNT * L);
+    __syncthreads();
+    const u32x4* lph = reinterpret_cast<const u32x4*>(wl);
+    const u32x4* lpm = reinterpret_cast<const u32x4*>(wl + PC);
+    const u32x4* lqh = reinterpret_cast<const u32x4*>(wl + 2 * PC);
+    const u32x4* lqm = reinterpret_cast<const u32x4*>(wl + 3 * PC);
+    const u32x4* gp = reinterpret_cast<const u32x4*>(a.split[4]);
+    const u32x4* gq = reinterpret_cast<const u32x4*>(a.split[5]);
+    const int lane0 = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    TileWalk tw(a.ntiles, wave, MGN_SPREAD_ROUNDS_NODE);
+    if (tw.tile >= tw.end) return;
+    f32x16 x[NT], acc[NT];
+    load_frag<NT>(x, tile_ptr(a.V, a.tile0 + tw.tile, L, lane0), STRIDE_TILE);
+    for (;;) {
+        OPAQUE_LANE();
+        const int tile = a.tile0 + tw.tile;
+        const int next = tw.tile + tw.stride;
+        const bool has_next = next < tw.end;
+        const int n = tile * TILE + c;
+        const bool valid = n < a.n;
+        const int nn = valid ? n : 0;
+        __builtin_amdgcn_s_setprio(0);
+        zero_frag<NT>(acc);
+        sp_layer_otf<false, true, false, D1>(acc, x, lph, lpm, gp + 4096, lane);
+        __builtin_amdgcn_s_setprio(MGN_PRIO);
+        if (valid) store_frag<NT>(row_ptr(a.P, nn, L, h), STRIDE_ROW, acc);
+        __builtin_amdgcn_s_setprio(0);
+        tab_frag<NT>(acc, tb + T_BQ * L, h);
+        sp_layer_otf<false, true, false, D1>(acc, x, lqh, lqm, gq + 4096, lane);
+        __builtin_amdgcn_s_setprio(MGN_PRIO);
+        if (valid) store_frag<NT>(row_ptr(a.Q, nn, L, h), STRIDE_ROW, acc);
+        if (!has_next) break;
+        PHASE_FENCE();
+        load_frag<NT>(x, tile_ptr(a.V, a.tile0 + next, L, lane), STRIDE_TILE);
+        tw.tile = next;
+    }
+}
+
+template <typename K, typename A>
+static hipError_t sp_launch(K kern, const A& a, const LaunchCfg& lc, hipStream_t s, bool& attr_set) {
+    if (!attr_set) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(lc.blocks), dim3(lc.threads), lc.lds, s, a);
+    return hipGetLastError();
+}
+hipError_t launch_node_split(const NodeArgs& a, const LaunchCfg& lc, hipStream_t s) {
+    static bool attr_set = false;
+    return sp_launch(k_node_split, a, lc, s, attr_set);
+}
+hipError_t launch_project_split(const NodeArgs& a, const LaunchCfg& lc, hipStream_t s) {
+    static bool attr_set = false;
+    return sp_launch(k_project_split, a, lc, s, attr_set);
+}
+
 hipError_t launch_edge_split2(const EdgeArgs& a, const LaunchCfg& lc, hipStream_t s) {
     static bool attr_set = false;
     if (!attr_set) {

@@ -5,6 +5,10 @@
 
 namespace mgn {
 
+#ifndef MGN_FAST_PRELOAD_TILES
+#define MGN_FAST_PRELOAD_TILES 8192     // node-side launches of up to 4 tiles per wave copy their weights with eight loads in flight
+#endif
+
 // Waves w and w+4 of a block share a SIMD and run the same program; started together they stay in
 // lockstep (both gather, then both want the MFMA pipe).  Delaying the second half once by about half a
 // tile period makes one wave's memory/VALU phase coincide with its partner's MFMA chain.
