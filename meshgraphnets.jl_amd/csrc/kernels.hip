@@ -2474,7 +2474,11 @@ static int resident_chunks(int L, int want) {
 static int g_path = [] { const char* e = getenv("MGN_KERNEL_PATH"); return e ? atoi(e) : 0; }();   // experiments
 int set_kernel_path(int p) { const int old = g_path; g_path = p; return old; }
 static int g_c16_rt = [] { const char* e = getenv("MGN_C16_RT"); return e ? atoi(e) : 0; }();   // 0: by size; 1..3: 16-edge tiles per block
-static int g_fp32_split = [] { const char* e = getenv("MGN_FP32_SPLIT"); return e ? atoi(e) : 0; }();
+// Large fp32 launches at L = 128, hidden_layers = 2 run on the bf16 matrix cores with every operand split exactly into three bf16
+// pieces (split.hip / split_ws.hip: fp32 storage, fp32 accumulation, error against float64 no worse than the fp32-MFMA kernels').
+// MGN_FP32_SPLIT: 0 = the fp32-MFMA kernels (v_mfma_f32_32x32x2_f32; bit-reproducible reference path), 2 = default,
+// 1 / 3 = the first-generation / weight-stationary edge kernels (A/B).
+static int g_fp32_split = [] { const char* e = getenv("MGN_FP32_SPLIT"); return e ? atoi(e) : 2; }();
 int set_fp32_split(int on) { const int old = g_fp32_split; g_fp32_split = on; return old; }
 int fp32_split_enabled() { return g_fp32_split; }
 int set_c16_row_tiles(int rt) { const int old = g_c16_rt; g_c16_rt = rt; return old; }
