@@ -2612,7 +2612,11 @@ hipError_t launch_edge_step(int L, const EdgeArgs& a, hipStream_t s) {
         if (g_fp32_split && a.split[0] && g_path == 0) {   // fp32 accuracy on the bf16 matrix cores (split.hip; 1: first-generation k_edge_split)
             LaunchCfg ls = lc;
             ls.lds = (size_t)4 * 16384 * 2 + (size_t)T_COUNT * L * 4 + 64;
-            if (g_fp32_split >= 3) return launch_edge_ws(a, s);           // weight-stationary kernel (split_ws.hip)
+            if (g_fp32_split == 4) {                                      // lock-step kernel with the shared LDS weight ring
+                ls.lds = (size_t)3 * 32768 + (size_t)3 * 16384 + (size_t)T_COUNT * L * 4 + 64;
+                return launch_edge_ring(a, ls, s);
+            }
+            if (g_fp32_split == 3) return launch_edge_ws(a, s);           // weight-stationary kernel (split_ws.hip)
             return g_fp32_split == 1 ? launch_k(k_edge_split, a, ls, s) : launch_edge_split2(a, ls, s);
         }
         lc.lds += (size_t)MGN_EDGE_JR * 64 * 4 * 4;   // partially resident third chunk

@@ -202,6 +202,207 @@ __global__ __launch_bounds__(512, 2) void k_edge_split2(const EdgeArgs a) {
 }
 
 // ================================================================================================
+// Lock-step variant of the edge step: the streamed weight pieces go through ONE LDS ring per block instead of eight per-wave
+// register rings.  k_edge_split2 reads 160 KiB of weight pieces per tile and wave from L2; stamps show what that costs: with ~100
+// KiB of requests queued per CU every other load of the tile (gathered P / Q rows, the e tile) waits thousands of cycles behind
+// them (38 k of a tile's 76 k cycles are its epilogue).  Here the eight waves of a block walk their tiles in lock-step, so that a
+// fragment fetched once serves all eight:
+//   * resident in LDS: the hi pieces of W1e, W2, W3 (96 KiB) + tables;
+//   * the mid and lo pieces of the layer in progress stream through three 16 KiB window buffers (8 (s, t) steps of both pieces):
+//     during window w every thread requests its 2 x 16 bytes of window w + 2 at the window's first step and stores them at its
+//     seventh; a barrier closes every window (12 per tile).  Three buffers, so that the one-step-ahead fragment reads may cross a
+//     window boundary: what they touch was written a whole window earlier.  12 windows per tile = 0 mod 3: the buffer of a window
+//     is the same for every tile.
+// L2 weight traffic per tile: 192 KiB per EIGHT tiles.  All waves run the same number of tiles (stores of padding tiles masked).
+// ================================================================================================
+constexpr int RG_W = 8;                         // steps per window
+constexpr int RG_BUF = 2 * RG_W * 64;           // u32x4 elements per window buffer: [piece (mid, lo)][step][lane]
+struct RingSrc {
+    const u32x4* mid[3];                        // global mid / lo pieces of layers 1..3 (W1e, W2, W3)
+    const u32x4* lo[3];
+};
+struct RingFrag {
+    u32x4 h, m, l;                              // fragments of the next step (read one step ahead)
+};
+DEVINL void ring_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+// first fragments of a layer (hi from its resident piece, mid / lo from the ring window 4 LYR)
+template <int LYR>
+DEVINL RingFrag ring_first(const u32x4* hi, const u32x4* ring, int lane) {
+    constexpr int b = (4 * LYR) % 3;
+    RingFrag f;
+    f.h = hi[lane];
+    f.m = ring[b * RG_BUF];                      // (`ring` carries the lane offset)
+    f.l = ring[b * RG_BUF + RG_W * 64];
+    return f;
+}
+// One L x L layer (layer LYR of the tile: global windows 4 LYR .. 4 LYR + 3).  nx: the fragments of step 0 in, those of the next
+// layer's step 0 out (LYR < 2; hi_next = that layer's resident hi piece).
+template <int LYR, bool RELU>
+DEVINL void sp_layer_ring(f32x16 (&acc)[4], const f32x16 (&in)[4], const u32x4* hi, const u32x4* hi_next, u32x4* ring, const RingSrc& src,
+                          RingFrag& nx, int lane, int tid) {
+    SpPieces p;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) sp_split_pair<RELU>(p.h[u], p.m[u], p.l[u], in[0][2 * u], in[0][2 * u + 1]);
+    u32x4 ld_m, ld_l;                            // this thread's share of window gw + 2 on its way to LDS
+    unsigned voff = (unsigned)tid * 16u;
+    asm volatile("" : "+v"(voff));
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+        SpPieces n;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int it = 4 * s + t;
+            const int gw = 4 * LYR + it / RG_W;                       // global window of this step
+            const u32x4 a1 = nx.h, a2 = nx.m, a3 = nx.l;
+            if (it % RG_W == 0) {                                      // request window gw + 2
+                const int g2 = (gw + 2) % 12, l2 = g2 / 4, w2 = g2 % 4;
+                // (uniform base + 32-bit lane offset: the scalar-base form of global_load; as twelve per-thread 64-bit pointers
+                // hipcc hoists them out of the tile loop and spills them)
+                ld_m = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(src.mid[l2] + w2 * RG_W * 64) + voff);
+                ld_l = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(src.lo[l2] + w2 * RG_W * 64) + voff);
+            }
+            if (it + 1 < 32) {
+                const int gn = 4 * LYR + (it + 1) / RG_W;
+                nx.h = hi[(it + 1) * 64 + lane];
+                nx.m = ring[(gn % 3) * RG_BUF + ((it + 1) % RG_W) * 64];
+                nx.l = ring[(gn % 3) * RG_BUF + RG_W * 64 + ((it + 1) % RG_W) * 64];
+            } else if (LYR < 2) {
+                nx = ring_first<(LYR + 1) % 3>(hi_next, ring, lane);   // (window 4 (LYR + 1): written two windows ago)
+            }
+            if (it % RG_W == RG_W - 2) {                               // ... and store it: its buffer was last read in window gw - 1
+                const int b2 = (gw + 2) % 3;
+                ring[b2 * RG_BUF + tid - lane] = ld_m;
+                ring[b2 * RG_BUF + RG_W * 64 + tid - lane] = ld_l;
+            }
+            if (s < 7) {
+                const int sn = s + 1;
+                sp_split_pair<RELU>(n.h[t], n.m[t], n.l[t], in[sn >> 1][8 * (sn & 1) + 2 * t], in[sn >> 1][8 * (sn & 1) + 2 * t + 1]);
+            }
+            const sp_bf16x8 bh = sp_op(p.h), bm = sp_op(p.m), bl = sp_op(p.l);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sp_wop(a3), bh, acc[t], 0, 0, 0);      // small terms first
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sp_wop(a2), bm, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sp_wop(a1), bl, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sp_wop(a2), bh, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sp_wop(a1), bm, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sp_wop(a1), bh, acc[t], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (it % RG_W == RG_W - 1) ring_barrier();                 // window closed: every wave has read it, window gw + 2 is in LDS
+        }
+        p = n;
+    }
+}
+
+__global__ __launch_bounds__(512, 2) void k_edge_ring(const EdgeArgs a) {
+    constexpr int NT = 4, L = 128, PC = 16384;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    uint16_t* wl = reinterpret_cast<uint16_t*>(smem);
+    copy_to_lds16(wl, a.split[2], PC, true);                         // hi of W1e, W2, W3
+    copy_to_lds16(wl + PC, a.split[0], PC, true);
+    copy_to_lds16(wl + 2 * PC, a.split[1], PC, true);
+    u32x4* ringbase = reinterpret_cast<u32x4*>(wl + 3 * PC);         // three window buffers (48 KiB)
+    float* tb = reinterpret_cast<float*>(ringbase + 3 * RG_BUF);
+    copy_to_lds(tb, a.tabs, T_COUNT * L);
+    const int tid = threadIdx.x;
+    RingSrc src;
+    {
+        const u32x4* g[3] = {reinterpret_cast<const u32x4*>(a.split[2]), reinterpret_cast<const u32x4*>(a.split[0]),
+                             reinterpret_cast<const u32x4*>(a.split[1])};
+#pragma unroll
+        for (int l = 0; l < 3; ++l) {
+            src.mid[l] = g[l] + 2048;
+            src.lo[l] = g[l] + 4096;
+        }
+#pragma unroll
+        for (int w = 0; w < 2; ++w) {                                 // windows 0 and 1 of layer 1
+            ringbase[w * RG_BUF + tid] = src.mid[0][w * RG_W * 64 + tid];
+            ringbase[w * RG_BUF + RG_W * 64 + tid] = src.lo[0][w * RG_W * 64 + tid];
+        }
+    }
+    __syncthreads();
+    const u32x4* l1h = reinterpret_cast<const u32x4*>(wl);
+    const u32x4* l2h = reinterpret_cast<const u32x4*>(wl + PC);
+    const u32x4* l3h = reinterpret_cast<const u32x4*>(wl + 2 * PC);
+    const int lane0 = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // lock-step: every wave of the block runs as many tiles as its wave 0 (the longest walk); padding tiles compute, store nothing
+    TileWalk tw0(a.ntiles, 0), tw(a.ntiles, wave);
+    if (tw0.tile >= tw0.end) return;
+    const int iters = (tw0.end - tw0.tile + tw0.stride - 1) / tw0.stride;
+    const int last = a.tile0 + tw0.tile + (iters - 1) * tw0.stride;   // a tile that exists (loads of padding tiles go there)
+    tw.tile += a.tile0;
+    tw.end += a.tile0;
+    auto clamp = [&](int t) { return t < tw.end ? t : last; };
+    f32x16 acc[NT], y[NT];
+    EdgeIdx ix = load_edge_idx_nb(a.snd, a.rcv, a.E, clamp(tw.tile), lane0 & 31);
+    {
+        const int h0 = lane0 >> 5;
+        load_frag<NT>(acc, row_ptr(a.P, ix.s, L, h0), STRIDE_ROW);
+        add_frag<NT>(acc, row_ptr(a.Q, ix.r >= 0 ? ix.r : 0, L, h0), STRIDE_ROW);
+        load_frag<NT>(y, tile_ptr(a.Elat, clamp(tw.tile), L, lane0), STRIDE_TILE);
+    }
+    int stamp_tile = 0;
+    (void)stamp_tile;
+    for (int j = 0; j < iters; ++j, ++stamp_tile) {
+        OPAQUE_LANE();
+        const bool on = tw.tile < tw.end;
+        const int tile = clamp(tw.tile);
+        const int nxt = clamp(tw.tile + tw.stride);
+        const EdgeIdx ixn = load_edge_idx_nb(a.snd, a.rcv, a.E, nxt, c);
+        const bool valid = on && ix.r >= 0;
+        const int r = ix.r >= 0 ? ix.r : 0;
+        f32x4* etile = tile_ptr(a.Elat, tile, L, lane);
+        u32x4* ring = ringbase + lane;
+        STAMP(0);
+        __builtin_amdgcn_s_setprio(0);
+        RingFrag nx = ring_first<0>(l1h, ring, lane);
+        sp_layer_ring<0, false>(acc, y, l1h, l2h, ring, src, nx, lane, tid);        // layer 1 (edge part); y = e tile
+        STAMP(1);
+        tab_frag<NT>(y, tb + T_B2 * L, h);
+        STAMP(2);
+        sp_layer_ring<1, true>(y, acc, l2h, l3h, ring, src, nx, lane, tid);         // layer 2 (ReLU folded into the split)
+        STAMP(3);
+        tab_frag<NT>(acc, tb + T_B3 * L, h);
+        STAMP(4);
+        sp_layer_ring<2, true>(acc, y, l3h, l1h, ring, src, nx, lane, tid);         // layer 3
+        STAMP(5);
+        PHASE_FENCE();
+        __builtin_amdgcn_s_setprio(MGN_PRIO);
+        load_frag<NT>(y, etile, STRIDE_TILE);                        // e again, for the residual
+        layer_norm_frag<NT>(acc, tb + T_GAMMA * L, tb + T_BETA * L, h);   // acc = e'
+        STAMP(6);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) y[t] += acc[t];                 // e <- e + e'
+        if (valid) store_frag<NT>(etile, STRIDE_TILE, y);            // padding rows / tiles store nothing
+        STAMP(7);
+        const int reff = ix.r >= 0 ? r : (-4 - c);
+        const int rprev = __shfl_up(reff, 1, 32);
+        const int rnext = __shfl_down(reff, 1, 32);
+        const bool head = (c == 0) || (reff != rprev);
+        const unsigned hm = (unsigned)__ballot(head);
+        const int start = 31 - __clz((int)(hm & (0xFFFFFFFFu >> (31 - c))));
+        const int st_in = max(start, c & 16);
+        const bool c1 = (c - 1 >= st_in), c2 = (c - 2 >= st_in), c4 = (c - 4 >= st_in), c8 = (c - 8 >= st_in);
+        const bool cx = (c >= 16) && (start <= 15);
+        segmented_scan<NT>(acc, c1, c2, c4, c8, cx);
+        const bool tail = valid && ((c == 31) || (reff != rnext));
+        const int r_first = __builtin_amdgcn_readfirstlane(reff);
+        const bool sl = (start == 0) && (ix.r_before == r_first);
+        const bool sr = (c == 31) && (ix.r_after == reff);
+        const bool to_carry = sl || sr;
+        f32x4* dst = to_carry ? row_ptr(a.CARRY, (int64_t)2 * tile + (sl ? 0 : 1), L, h) : tile_ptr(a.AGG, r >> 5, L, 32 * h + (r & 31));
+        if (tail) store_frag<NT>(dst, to_carry ? STRIDE_ROW : STRIDE_TILE, acc);
+        PHASE_FENCE();
+        // turnover: the next tile's layer-1 accumulator and e tile
+        load_frag<NT>(acc, row_ptr(a.P, ixn.s, L, h), STRIDE_ROW);
+        add_frag<NT>(acc, row_ptr(a.Q, ixn.r >= 0 ? ixn.r : 0, L, h), STRIDE_ROW);
+        load_frag<NT>(y, tile_ptr(a.Elat, nxt, L, lane), STRIDE_TILE);
+        ix = ixn;
+        tw.tile += tw.stride;
+    }
+}
+
+// ================================================================================================
 // Processor node step (K6) on the split path: k_node_step<4, *, false>'s tile loop with its four L x L chunks on the bf16 matrix
 // cores.  split[]: the chunks in NodeArgs.chunk order (0: W2, 1: W3, 2: W1[0:L] (node part), 3: W1[L:2L] (aggregate part)), each as
 // hi / mid / lo pieces.  LDS: the four hi pieces (128 KiB) + tables; mid and lo stream from L2 (sp_layer_otf rings).  The V tile is
@@ -328,6 +529,10 @@ static hipError_t sp_launch(K kern, const A& a, const LaunchCfg& lc, hipStream_t
     }
     hipLaunchKernelGGL(kern, dim3(lc.blocks), dim3(lc.threads), lc.lds, s, a);
     return hipGetLastError();
+}
+hipError_t launch_edge_ring(const EdgeArgs& a, const LaunchCfg& lc, hipStream_t s) {
+    static bool attr_set = false;
+    return sp_launch(k_edge_ring, a, lc, s, attr_set);
 }
 hipError_t launch_node_split(const NodeArgs& a, const LaunchCfg& lc, hipStream_t s) {
     static bool attr_set = false;

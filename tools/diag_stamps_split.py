@@ -14,7 +14,7 @@ f = eng.lib.mgn_debug_edge_stamps; f.restype = C.c_int; f.argtypes = [C.c_void_p
 assert f(eng.h, 1, out.ctypes.data_as(C.c_void_p)) == 0
 st = out[:4 * 8 * 24 * 8].reshape(4, 8, 24, 8).astype(np.int64)
 names = ["split1", "L1", "relu+split2", "L2", "relu+split3", "L3", "reload e+LN+resid+store", "scan+tails+turnover(to next start)"]
-if os.environ.get("MGN_FP32_SPLIT") == "2":
+if os.environ.get("MGN_FP32_SPLIT") in ("2", "4"):
     names = ["L1", "tab", "L2", "tab", "L3", "reload e+LN", "resid+store", "scan+tails+turnover(to next start)"]
 if os.environ.get("MGN_FP32_SPLIT") == "3" and os.environ.get("MGN_WS_K"):
     # per-k-step stamps of one stage (library built with -DMGN_WS_DIAG_STAGE=n): slot s = the MFMAs of k-step s are issued
