@@ -20,7 +20,7 @@ LIB = os.path.join(LIBDIR, "libmgn_hip.so")
 ORACLE_DIR = os.path.join(ROOT, "oracle")
 REF_LIB = os.path.join(ORACLE_DIR, "_build", "libmgn_ref.so")
 
-HIP_SOURCES = ["kernels.hip", "split.hip", "split_ws.hip", "train.hip", "mgn_api.cpp", "mgn_train.cpp", "graph_host.cpp", "graph_prologue.cpp", "tfrecord.cpp", "comm.cpp", "graph_dev.hip"]
+HIP_SOURCES = ["kernels.hip", "split.hip", "train.hip", "mgn_api.cpp", "mgn_train.cpp", "graph_host.cpp", "graph_prologue.cpp", "tfrecord.cpp", "comm.cpp", "graph_dev.hip"]
 HIP_HEADERS = ["kernels.h", "graph_host.h", "frag.hpp", "tile_common.hpp", "split_common.hpp", "engine_internal.h", "train.h", "comm.h", "graph_dev.h", os.path.join(ROOT, "include", "mgn_hip.h")]
 
 
@@ -39,8 +39,7 @@ def hipcc_path():
 
 
 # extra flags per source.  split.hip: see its header (the SLP vectoriser's v_pk_add_f32 inside the MFMA stream).
-PER_FILE_FLAGS = {"split.hip": os.environ.get("MGN_SPLIT_FLAGS", "").split(),
-                  "split_ws.hip": os.environ.get("MGN_SPLIT_WS_FLAGS", "-fno-slp-vectorize").split()}
+PER_FILE_FLAGS = {"split.hip": os.environ.get("MGN_SPLIT_FLAGS", "").split()}
 
 
 def _compile_objects(objdir, extra, force, deps, verbose, per_file=None):

@@ -45,8 +45,8 @@ struct EdgeArgs {
                             //    the carry rows are then per 16-edge tile)
     int32_t bf;             // 16-row kernels in bf16 mode: P, Q, Elat, AGG, CARRY are bf16 arrays in the bf16 kernels' layouts (passed
                             //    through the float pointers); weights, tables and arithmetic stay fp32
-    // opt-in (MGN_FP32_SPLIT=1 / mgn_debug_fp32_split): the three layers on the bf16 matrix cores with fp32 accuracy -- every fp32
-    // operand split into three bf16 pieces, six piece products kept (k_edge_split).  split[i]: chunk i as 3 x 16384 bf16 (hi, mid, lo
+    // split path (split.hip; MGN_FP32_SPLIT / mgn_debug_fp32_split): the three layers on the bf16 matrix cores with fp32 accuracy --
+    // every fp32 operand split into three bf16 pieces, six piece products kept.  split[i]: chunk i as 3 x 16384 bf16 (hi, mid, lo
     // pieces, the bf16 kernels' fragment order); null: not available
     const uint16_t* split[3];
 };
@@ -150,7 +150,6 @@ hipError_t launch_gather_rows16(const uint16_t* src, const int32_t* idx, uint16_
 
 struct LaunchCfg { int blocks; int threads; size_t lds; };
 hipError_t launch_edge_split2(const EdgeArgs& a, const LaunchCfg& lc, hipStream_t s);   // split.hip
-hipError_t launch_edge_ws(const EdgeArgs& a, hipStream_t s);                            // split_ws.hip
 hipError_t launch_edge_ring(const EdgeArgs& a, const LaunchCfg& lc, hipStream_t s);    // split.hip
 hipError_t launch_node_split(const NodeArgs& a, const LaunchCfg& lc, hipStream_t s);    // split.hip
 hipError_t launch_project_split(const NodeArgs& a, const LaunchCfg& lc, hipStream_t s); // split.hip
@@ -171,7 +170,7 @@ bool launch_is_small(int ntiles);
 bool launch_is_small_edge(int ntiles_e);   // the same rule for edge launches (<= 16 tiles per CU)
 int coop16_enabled();
 bool coop16_size(int ntiles_e, int ntiles_n);   // the launch wrappers' rule for the cooperative node kernels (<= 8 tiles per CU)
-int set_fp32_split(int on);     // debug/tests: 1 = k_edge_split for large fp32 launches (see EdgeArgs.split); returns the old value
+int set_fp32_split(int on);     // debug/tests: 0 = fp32-MFMA kernels, 1 = split path (default), 2 = split path with k_edge_split2; returns the old value
 int fp32_split_enabled();
 int set_c16_row_tiles(int rt);  // debug/tests: 16-edge tiles per block of the small-graph edge kernel (0: chosen by size); returns the old value
 int set_kernel_path(int p);   // debug/tests: 0 auto, 1 resident, 2 streaming, 3 cooperative, 4 GEN (general hidden_layers) kernels; returns the old value

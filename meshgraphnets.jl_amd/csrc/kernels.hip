@@ -195,205 +195,6 @@ __global__ __launch_bounds__(512, 2) void k_edge_step(const EdgeArgs a) {
 }
 
 // ================================================================================================
-// Opt-in: the edge step with its three L x L layers on the bf16 matrix cores at fp32 accuracy (tools/split_probe.hip).
-// Every fp32 operand is split exactly into three bf16 pieces (x = x1 + x2 + x3: 3 x 8 significand bits); of the nine piece
-// products the six with i + j <= 4 are kept (the dropped ones are below 2^-24 relative); each product of two bf16 values is exact
-// in fp32 and the MFMA accumulates in fp32.  Max relative error of a 128 x 128 layer against float64: 1.7e-7 (a plain fp32 GEMM:
-// 4.2e-7).  v_mfma_f32_32x32x16_bf16 has 16 x the rate of v_mfma_f32_32x32x2_f32, six terms cost 0.375 x the matrix time.
-// Storage, tables, LayerNorm, residual, scan, carry rows: exactly k_edge_step's (the accumulator layout of the two MFMA shapes is
-// the same, and element j of half h at k-step s is accumulator register 8 (s & 1) + j of block s >> 1 -- the bf16 kernels'
-// correspondence).  Weights: the hi pieces of all three chunks and the mid piece of W2 are LDS-resident (128 KiB), the other five
-// pieces stream from L2.  The e tile is re-read for the residual (its registers hold the operand pieces during the layers).
-// ================================================================================================
-typedef __bf16 sp_bf16x8 __attribute__((ext_vector_type(8)));
-DEVINL void sp_split3(sp_bf16x8 (&hi)[8], sp_bf16x8 (&mid)[8], sp_bf16x8 (&lo)[8], const f32x16 (&x)[4]) {
-#pragma unroll
-    for (int s = 0; s < 8; ++s)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const float v = x[s >> 1][8 * (s & 1) + j];
-            const __bf16 a = (__bf16)v;
-#ifdef MGN_SP_WHATIF_NOSPLIT          // timing experiment only (wrong results): one conversion instead of the three-way split
-            hi[s][j] = a; mid[s][j] = a; lo[s][j] = a;
-            continue;
-#endif
-            const float r1 = v - (float)a;
-            const __bf16 b = (__bf16)r1;
-            const float r2 = r1 - (float)b;
-            hi[s][j] = a;
-            mid[s][j] = b;
-            lo[s][j] = (__bf16)r2;
-        }
-}
-// p1 / p2 / p3: the chunk's hi / mid / lo piece ([s][t][lane] fragments of 8 bf16).  p1 is LDS-resident; G2 / G3: p2 / p3 stream
-// from L2 through a register ring SP_D (s, t) steps deep, pinned by scheduling fences (left to itself hipcc requests every streamed
-// fragment one MFMA before its use and waits out the whole L2 latency, 64 times per layer); the LDS fragments are read one step ahead.
-#ifndef MGN_SP_RELU_ASM
-#define MGN_SP_RELU_ASM 1      // one-instruction ReLU (3.919 -> 3.894 ms)
-#endif
-constexpr bool SP_RELU_ASM = MGN_SP_RELU_ASM != 0;
-#ifndef SP_D
-#define SP_D 3      // deeper rings spill (96 registers of operand pieces + 64 of accumulators): 2 / 3 / 4 deep = 3.91 / 3.87 / 3.92 ms
-#endif
-template <bool G2, bool G3>
-DEVINL void sp_layer(f32x16 (&acc)[4], const sp_bf16x8 (&hi)[8], const sp_bf16x8 (&mid)[8], const sp_bf16x8 (&lo)[8], const sp_bf16x8* p1,
-                     const sp_bf16x8* p2, const sp_bf16x8* p3, int lane) {
-    const sp_bf16x8* w1 = p1 + lane;
-    const sp_bf16x8* w2 = p2 + lane;
-    const sp_bf16x8* w3 = p3 + lane;
-    sp_bf16x8 r2[G2 ? SP_D : 1], r3[G3 ? SP_D : 1];
-#pragma unroll
-    for (int d = 0; d < SP_D; ++d) {
-        if constexpr (G2) r2[d] = w2[d * 64];
-        if constexpr (G3) r3[d] = w3[d * 64];
-    }
-    sp_bf16x8 n1 = w1[0], n2, n3;
-    if constexpr (!G2) n2 = w2[0];
-    if constexpr (!G3) n3 = w3[0];
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int it = 0; it < 32; ++it) {
-        const int s = it >> 2, t = it & 3;
-        const sp_bf16x8 a1 = n1;
-        sp_bf16x8 a2, a3;
-        if constexpr (G2) a2 = r2[it % SP_D]; else a2 = n2;
-        if constexpr (G3) a3 = r3[it % SP_D]; else a3 = n3;
-        if (it + 1 < 32) {
-            n1 = w1[(it + 1) * 64];
-            if constexpr (!G2) n2 = w2[(it + 1) * 64];
-            if constexpr (!G3) n3 = w3[(it + 1) * 64];
-        }
-        if (it + SP_D < 32) {
-            if constexpr (G2) r2[it % SP_D] = w2[(it + SP_D) * 64];
-            if constexpr (G3) r3[it % SP_D] = w3[(it + SP_D) * 64];
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3, hi[s], acc[t], 0, 0, 0);      // small terms first
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, mid[s], acc[t], 0, 0, 0);
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, lo[s], acc[t], 0, 0, 0);
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, hi[s], acc[t], 0, 0, 0);
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, mid[s], acc[t], 0, 0, 0);
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, hi[s], acc[t], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-    }
-}
-// chunk order as in k_edge_step: split[0] = W2, [1] = W3, [2] = W1[2L:3L]
-__global__ __launch_bounds__(512, 2) void k_edge_split(const EdgeArgs a) {
-    constexpr int NT = 4, L = 128, PC = 16384;                      // PC: bf16 elements per piece
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    uint16_t* wl = reinterpret_cast<uint16_t*>(smem);
-    {   // resident: hi of W1e, W2, W3 and mid of W2
-        const bool fast = a.ntiles <= 16 * 1024;
-        copy_to_lds16(wl, a.split[2], PC, fast);
-        copy_to_lds16(wl + PC, a.split[0], 2 * PC, fast);           // hi + mid of W2 are adjacent
-        copy_to_lds16(wl + 3 * PC, a.split[1], PC, fast);
-    }
-    float* tb = smem + 4 * PC / 2;
-    copy_to_lds(tb, a.tabs, T_COUNT * L);
-    __syncthreads();
-    const sp_bf16x8* l1h = reinterpret_cast<const sp_bf16x8*>(wl);
-    const sp_bf16x8* l2h = reinterpret_cast<const sp_bf16x8*>(wl + PC);
-    const sp_bf16x8* l2m = reinterpret_cast<const sp_bf16x8*>(wl + 2 * PC);
-    const sp_bf16x8* l3h = reinterpret_cast<const sp_bf16x8*>(wl + 3 * PC);
-    const sp_bf16x8* g1 = reinterpret_cast<const sp_bf16x8*>(a.split[2]);      // 2048 fragments per piece
-    const sp_bf16x8* g2 = reinterpret_cast<const sp_bf16x8*>(a.split[0]);
-    const sp_bf16x8* g3 = reinterpret_cast<const sp_bf16x8*>(a.split[1]);
-    const int lane0 = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    stagger_second_half(wave, a.stagger);
-    TileWalk tw(a.ntiles, wave);
-    tw.tile += a.tile0;
-    tw.end += a.tile0;
-    if (tw.tile >= tw.end) return;
-    f32x16 acc[NT], y[NT];
-    EdgeIdx ix = load_edge_idx_nb(a.snd, a.rcv, a.E, tw.tile, lane0 & 31);
-    {   // first tile: layer-1 accumulator P[s] + Q[r] (carry b1) and the e tile
-        const int h0 = lane0 >> 5;
-        load_frag<NT>(acc, row_ptr(a.P, ix.s, L, h0), STRIDE_ROW);
-        add_frag<NT>(acc, row_ptr(a.Q, ix.r >= 0 ? ix.r : 0, L, h0), STRIDE_ROW);
-        load_frag<NT>(y, tile_ptr(a.Elat, tw.tile, L, lane0), STRIDE_TILE);
-    }
-    int stamp_tile = 0;
-    (void)stamp_tile;
-    for (;; ++stamp_tile) {
-        OPAQUE_LANE();
-        const int tile = tw.tile;
-        const int next = tile + tw.stride;
-        const bool has_next = next < tw.end;
-        const int nxt = has_next ? next : tile;
-        const EdgeIdx ixn = load_edge_idx_nb(a.snd, a.rcv, a.E, nxt, c);
-        const bool valid = ix.r >= 0;
-        const int r = valid ? ix.r : 0;
-        f32x4* etile = tile_ptr(a.Elat, tile, L, lane);
-        sp_bf16x8 hi[8], mid[8], lo[8];
-        STAMP(0);
-        sp_split3(hi, mid, lo, y);                                   // y = the e tile, acc = P[s] + Q[r] (requested a tile ahead)
-        __builtin_amdgcn_s_setprio(0);
-        STAMP(1);
-#ifdef MGN_SP_WHATIF_LDS              // timing experiment only (wrong results): every piece read from LDS
-        sp_layer<false, false>(acc, hi, mid, lo, l1h, l2h, l2m, lane);
-#else
-        sp_layer<true, true>(acc, hi, mid, lo, l1h, g1 + 2048, g1 + 4096, lane);   // layer 1 (edge part)
-#endif
-        STAMP(2);
-        relu_frag<NT, SP_RELU_ASM>(acc);
-        sp_split3(hi, mid, lo, acc);
-        tab_frag<NT>(y, tb + T_B2 * L, h);
-        STAMP(3);
-#ifdef MGN_SP_WHATIF_LDS
-        sp_layer<false, false>(y, hi, mid, lo, l2h, l2m, l3h, lane);
-#else
-        sp_layer<false, true>(y, hi, mid, lo, l2h, l2m, g2 + 4096, lane);          // layer 2
-#endif
-        STAMP(4);
-        relu_frag<NT, SP_RELU_ASM>(y);
-        sp_split3(hi, mid, lo, y);
-        tab_frag<NT>(acc, tb + T_B3 * L, h);
-        STAMP(5);
-#ifdef MGN_SP_WHATIF_LDS
-        sp_layer<false, false>(acc, hi, mid, lo, l3h, l1h, l2h, lane);
-#else
-        sp_layer<true, true>(acc, hi, mid, lo, l3h, g3 + 2048, g3 + 4096, lane);   // layer 3
-#endif
-        STAMP(6);
-        PHASE_FENCE();
-        __builtin_amdgcn_s_setprio(MGN_PRIO);                        // memory / VALU phase: win issue arbitration
-        load_frag<NT>(y, etile, STRIDE_TILE);                        // e again, for the residual (its registers held the weight ring)
-        layer_norm_frag<NT>(acc, tb + T_GAMMA * L, tb + T_BETA * L, h);   // acc = e'
-#pragma unroll
-        for (int t = 0; t < NT; ++t) y[t] += acc[t];                 // e <- e + e'
-        if (valid) store_frag<NT>(etile, STRIDE_TILE, y);            // padding rows of the last tile stay zero
-        STAMP(7);
-        // ---- segmented sum of e' over runs of equal receiver: as in k_edge_step
-        const int reff = valid ? r : (-4 - c);
-        const int rprev = __shfl_up(reff, 1, 32);
-        const int rnext = __shfl_down(reff, 1, 32);
-        const bool head = (c == 0) || (reff != rprev);
-        const unsigned hm = (unsigned)__ballot(head);
-        const int start = 31 - __clz((int)(hm & (0xFFFFFFFFu >> (31 - c))));
-        const int st_in = max(start, c & 16);
-        const bool c1 = (c - 1 >= st_in), c2 = (c - 2 >= st_in), c4 = (c - 4 >= st_in), c8 = (c - 8 >= st_in);
-        const bool cx = (c >= 16) && (start <= 15);
-        segmented_scan<NT>(acc, c1, c2, c4, c8, cx);
-        const bool tail = valid && ((c == 31) || (reff != rnext));
-        const int r_first = __builtin_amdgcn_readfirstlane(reff);
-        const bool sl = (start == 0) && (ix.r_before == r_first);
-        const bool sr = (c == 31) && (ix.r_after == reff);
-        const bool to_carry = sl || sr;
-        f32x4* dst = to_carry ? row_ptr(a.CARRY, (int64_t)2 * tile + (sl ? 0 : 1), L, h) : tile_ptr(a.AGG, r >> 5, L, 32 * h + (r & 31));
-        if (tail) store_frag<NT>(dst, to_carry ? STRIDE_ROW : STRIDE_TILE, acc);
-        if (!has_next) break;
-        PHASE_FENCE();
-        // turnover: the next tile's layer-1 accumulator and e tile
-        load_frag<NT>(acc, row_ptr(a.P, ixn.s, L, h), STRIDE_ROW);
-        add_frag<NT>(acc, row_ptr(a.Q, ixn.r >= 0 ? ixn.r : 0, L, h), STRIDE_ROW);
-        load_frag<NT>(y, tile_ptr(a.Elat, nxt, L, lane), STRIDE_TILE);
-        ix = ixn;
-        tw.tile = next;
-    }
-}
-
-// ================================================================================================
 // Processor node step (K6) + projection of next step's P,Q.
 // chunk[0]=W2 chunk[1]=W3 chunk[2]=W1[0:L] chunk[3]=W1[L:2L] chunk[4]=WP chunk[5]=WQ
 // V and AGG tile-major; CARRY, P, Q row-major.  CARRY row 2*ntiles_e is the all-zero row.
@@ -2476,9 +2277,9 @@ int set_kernel_path(int p) { const int old = g_path; g_path = p; return old; }
 static int g_c16_rt = [] { const char* e = getenv("MGN_C16_RT"); return e ? atoi(e) : 0; }();   // 0: by size; 1..3: 16-edge tiles per block
 // Large fp32 launches at L = 128, hidden_layers = 2 run on the bf16 matrix cores with every operand split exactly into three bf16
 // pieces (split.hip / split_ws.hip: fp32 storage, fp32 accumulation, error against float64 no worse than the fp32-MFMA kernels').
-// MGN_FP32_SPLIT: 0 = the fp32-MFMA kernels (v_mfma_f32_32x32x2_f32; bit-reproducible reference path), 2 = default,
-// 1 / 3 = the first-generation / weight-stationary edge kernels (A/B).
-static int g_fp32_split = [] { const char* e = getenv("MGN_FP32_SPLIT"); return e ? atoi(e) : 2; }();
+// MGN_FP32_SPLIT: 0 = the fp32-MFMA kernels (v_mfma_f32_32x32x2_f32: the fp32 reference path), 1 = default (edge step: the
+// lock-step kernel with the shared LDS weight ring), 2 = the edge step with per-wave register rings (A/B).
+static int g_fp32_split = [] { const char* e = getenv("MGN_FP32_SPLIT"); return e ? atoi(e) : 1; }();
 int set_fp32_split(int on) { const int old = g_fp32_split; g_fp32_split = on; return old; }
 int fp32_split_enabled() { return g_fp32_split; }
 int set_c16_row_tiles(int rt) { const int old = g_c16_rt; g_c16_rt = rt; return old; }
@@ -2609,15 +2410,14 @@ hipError_t launch_edge_step(int L, const EdgeArgs& a, hipStream_t s) {
             lc.lds = (size_t)T_COUNT * L * 4 + 64;
             return launch_k(k_edge_step<4, 0>, a, lc, s);
         }
-        if (g_fp32_split && a.split[0] && g_path == 0) {   // fp32 accuracy on the bf16 matrix cores (split.hip; 1: first-generation k_edge_split)
+        if (g_fp32_split && a.split[0] && g_path == 0) {   // split path (split.hip): fp32 accuracy on the bf16 matrix cores
             LaunchCfg ls = lc;
-            ls.lds = (size_t)4 * 16384 * 2 + (size_t)T_COUNT * L * 4 + 64;
-            if (g_fp32_split == 4) {                                      // lock-step kernel with the shared LDS weight ring
-                ls.lds = (size_t)3 * 32768 + (size_t)3 * 16384 + (size_t)T_COUNT * L * 4 + 64;
-                return launch_edge_ring(a, ls, s);
+            if (g_fp32_split == 2) {
+                ls.lds = (size_t)4 * 16384 * 2 + (size_t)T_COUNT * L * 4 + 64;
+                return launch_edge_split2(a, ls, s);
             }
-            if (g_fp32_split == 3) return launch_edge_ws(a, s);           // weight-stationary kernel (split_ws.hip)
-            return g_fp32_split == 1 ? launch_k(k_edge_split, a, ls, s) : launch_edge_split2(a, ls, s);
+            ls.lds = (size_t)3 * 32768 + (size_t)3 * 16384 + (size_t)T_COUNT * L * 4 + 64;
+            return launch_edge_ring(a, ls, s);
         }
         lc.lds += (size_t)MGN_EDGE_JR * 64 * 4 * 4;   // partially resident third chunk
         // Tail of the persistent walk: with r = ntiles / (8 waves x 256 blocks) rounds, a last round that is less than

@@ -17,6 +17,8 @@
 // 8 (s & 1) + j of block s >> 1 (the bf16 kernels' correspondence), so a layer's output feeds the next layer without a shuffle.
 // Compiled with -fno-slp-vectorize (build.py): hipcc otherwise packs the split's subtractions into v_pk_add_f32, which holds the
 // matrix pipe for ~12 cycles each (tools/overlap_probe.hip).
+#include <cstdlib>
+
 #include "kernels.h"
 #include "tile_common.hpp"
 #include "split_common.hpp"
@@ -215,8 +217,14 @@ __global__ __launch_bounds__(512, 2) void k_edge_split2(const EdgeArgs a) {
 //     is the same for every tile.
 // L2 weight traffic per tile: 192 KiB per EIGHT tiles.  All waves run the same number of tiles (stores of padding tiles masked).
 // ================================================================================================
-constexpr int RG_W = 8;                         // steps per window
-constexpr int RG_BUF = 2 * RG_W * 64;           // u32x4 elements per window buffer: [piece (mid, lo)][step][lane]
+// (Tried and dropped, docs/experiments.md: two groups of four waves half a tile apart, with slot barriers or with group-local
+// LDS-counter barriers: 4.0-4.1 ms against 3.4 -- the epilogue's memory round trips then pace the other group's chains.)
+template <int W>
+struct Rg {
+    static constexpr int WPL = 32 / W;          // windows per layer
+    static constexpr int NW = 3 * WPL;          // windows per tile (a multiple of 3: window -> buffer is the same for every tile)
+    static constexpr int BUF = 2 * W * 64;      // u32x4 elements per window buffer: [piece (mid, lo)][step][lane]
+};
 struct RingSrc {
     const u32x4* mid[3];                        // global mid / lo pieces of layers 1..3 (W1e, W2, W3)
     const u32x4* lo[3];
@@ -225,21 +233,36 @@ struct RingFrag {
     u32x4 h, m, l;                              // fragments of the next step (read one step ahead)
 };
 DEVINL void ring_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-// first fragments of a layer (hi from its resident piece, mid / lo from the ring window 4 LYR)
-template <int LYR>
+// first fragments of a layer (hi from its resident piece, mid / lo from the ring window WPL * LYR); `ring` carries the lane offset
+template <int W, int LYR>
 DEVINL RingFrag ring_first(const u32x4* hi, const u32x4* ring, int lane) {
-    constexpr int b = (4 * LYR) % 3;
+    constexpr int b = (Rg<W>::WPL * LYR) % 3;
     RingFrag f;
     f.h = hi[lane];
-    f.m = ring[b * RG_BUF];                      // (`ring` carries the lane offset)
-    f.l = ring[b * RG_BUF + RG_W * 64];
+    f.m = ring[b * Rg<W>::BUF];
+    f.l = ring[b * Rg<W>::BUF + W * 64];
     return f;
 }
-// One L x L layer (layer LYR of the tile: global windows 4 LYR .. 4 LYR + 3).  nx: the fragments of step 0 in, those of the next
-// layer's step 0 out (LYR < 2; hi_next = that layer's resident hi piece).
-template <int LYR, bool RELU>
-DEVINL void sp_layer_ring(f32x16 (&acc)[4], const f32x16 (&in)[4], const u32x4* hi, const u32x4* hi_next, u32x4* ring, const RingSrc& src,
-                          RingFrag& nx, int lane, int tid) {
+// One L x L layer (layer LYR of the tile).  nx: the fragments of step 0 in, those of the next layer's step 0 out (LYR < 2;
+// hi_next = that layer's resident hi piece).  tid: thread index within the group that shares the ring.
+// Refill (RFS > 0): `in` is consumed k-step by k-step, and what a tile needs next from memory -- the P rows that complete layer 1,
+// the e tile for the residual behind layer 3 -- is 64 registers wide, which nothing has to spare.  So the registers of k-step s are
+// reloaded, as soon as the split has consumed them, with the two 16-byte pieces of k-step s + 2 of rf (piece m at rf[m * RFS]);
+// the pieces of k-steps 0 and 1 wait in a 16-register side buffer.  The last request goes out two k-steps before the layer ends;
+// `in` comes back holding rf's row in fragment order.  (In the epilogue these loads were two exposed memory round trips.)
+template <int W, int LYR, bool RELU, int RFS = 0>
+DEVINL void sp_layer_ring(f32x16 (&acc)[4], f32x16 (&in)[4], const u32x4* hi, const u32x4* hi_next, u32x4* ring, const RingSrc& src,
+                          RingFrag& nx, int lane, int tid, const f32x4* rf = nullptr) {
+#ifndef MGN_RING_ROT
+#define MGN_RING_ROT 2
+#endif
+    constexpr int ROT = MGN_RING_ROT;            // k-steps between a register's release and the use of what it is refilled with
+    f32x4 side[2 * ROT];
+    if constexpr (RFS > 0) {
+#pragma unroll
+        for (int m = 0; m < 2 * ROT; ++m) side[m] = rf[m * RFS];
+    }
+    constexpr int WPL = Rg<W>::WPL, NW = Rg<W>::NW, BUF = Rg<W>::BUF;
     SpPieces p;
 #pragma unroll
     for (int u = 0; u < 4; ++u) sp_split_pair<RELU>(p.h[u], p.m[u], p.l[u], in[0][2 * u], in[0][2 * u + 1]);
@@ -253,27 +276,27 @@ DEVINL void sp_layer_ring(f32x16 (&acc)[4], const f32x16 (&in)[4], const u32x4* 
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             const int it = 4 * s + t;
-            const int gw = 4 * LYR + it / RG_W;                       // global window of this step
+            const int gw = WPL * LYR + it / W;                        // global window of this step
             const u32x4 a1 = nx.h, a2 = nx.m, a3 = nx.l;
-            if (it % RG_W == 0) {                                      // request window gw + 2
-                const int g2 = (gw + 2) % 12, l2 = g2 / 4, w2 = g2 % 4;
-                // (uniform base + 32-bit lane offset: the scalar-base form of global_load; as twelve per-thread 64-bit pointers
+            if (it % W == 0) {                                         // request window gw + 2
+                const int g2 = (gw + 2) % NW, l2 = g2 / WPL, w2 = g2 % WPL;
+                // (uniform base + 32-bit lane offset: the scalar-base form of global_load; as per-thread 64-bit pointers
                 // hipcc hoists them out of the tile loop and spills them)
-                ld_m = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(src.mid[l2] + w2 * RG_W * 64) + voff);
-                ld_l = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(src.lo[l2] + w2 * RG_W * 64) + voff);
+                ld_m = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(src.mid[l2] + w2 * W * 64) + voff);
+                ld_l = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(src.lo[l2] + w2 * W * 64) + voff);
             }
             if (it + 1 < 32) {
-                const int gn = 4 * LYR + (it + 1) / RG_W;
+                const int gn = WPL * LYR + (it + 1) / W;
                 nx.h = hi[(it + 1) * 64 + lane];
-                nx.m = ring[(gn % 3) * RG_BUF + ((it + 1) % RG_W) * 64];
-                nx.l = ring[(gn % 3) * RG_BUF + RG_W * 64 + ((it + 1) % RG_W) * 64];
+                nx.m = ring[(gn % 3) * BUF + ((it + 1) % W) * 64];
+                nx.l = ring[(gn % 3) * BUF + W * 64 + ((it + 1) % W) * 64];
             } else if (LYR < 2) {
-                nx = ring_first<(LYR + 1) % 3>(hi_next, ring, lane);   // (window 4 (LYR + 1): written two windows ago)
+                nx = ring_first<W, (LYR + 1) % 3>(hi_next, ring, lane);   // (that window was written two windows ago)
             }
-            if (it % RG_W == RG_W - 2) {                               // ... and store it: its buffer was last read in window gw - 1
+            if (it % W == W - 2) {                                     // ... and store it: its buffer was last read in window gw - 1
                 const int b2 = (gw + 2) % 3;
-                ring[b2 * RG_BUF + tid - lane] = ld_m;
-                ring[b2 * RG_BUF + RG_W * 64 + tid - lane] = ld_l;
+                ring[b2 * BUF + tid - lane] = ld_m;
+                ring[b2 * BUF + W * 64 + tid - lane] = ld_l;
             }
             if (s < 7) {
                 const int sn = s + 1;
@@ -287,23 +310,65 @@ DEVINL void sp_layer_ring(f32x16 (&acc)[4], const f32x16 (&in)[4], const u32x4* 
             acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sp_wop(a1), bm, acc[t], 0, 0, 0);
             acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sp_wop(a1), bh, acc[t], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
-            if (it % RG_W == RG_W - 1) ring_barrier();                 // window closed: every wave has read it, window gw + 2 is in LDS
+            if (it % W == W - 1) ring_barrier();                       // window closed: every wave has read it, window gw + 2 is in LDS
         }
         p = n;
+        if constexpr (RFS > 0) {
+            // (the eight waves of a block run in lock-step: without a per-wave delay all sixteen gather instructions of a k-step
+            // reach the CU's memory pipeline at once; 64 line visits each)
+            if (s < 8 - ROT) {                                         // registers of k-step s <- pieces of k-step s + ROT
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const f32x4 v = rf[(2 * (s + ROT) + u) * RFS];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) in[s >> 1][8 * (s & 1) + 4 * u + i] = v[i];
+                }
+            }
+        }
+    }
+    if constexpr (RFS > 0) {                                           // un-rotate: k-step u's pieces sit in the registers of k-step u - 2
+        f32x16 r[4];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                r[u >> 1][8 * (u & 1) + j] = u < ROT ? side[2 * u + (j >> 2)][j & 3] : in[(u - ROT) >> 1][8 * ((u - ROT) & 1) + j];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) in[t] = r[t];
     }
 }
 
+// one level of the segmented scan (tile_common.hpp: segmented_scan) on the whole fragment
+#define RG_SCAN_LEVEL(ACC, COND, CTRL)                                                                                       \
+    do {                                                                                                                     \
+        const float m_ = (COND) ? 1.f : 0.f;                                                                                 \
+        _Pragma("unroll") for (int t_ = 0; t_ < 4; ++t_)                                                                     \
+            _Pragma("unroll") for (int k_ = 0; k_ < 16; ++k_)                                                                \
+                asm volatile("v_fmac_f32_dpp %0, %0, %1 " CTRL " bound_ctrl:0" : "+v"(ACC[t_][k_]) : "v"(m_));               \
+    } while (0)
+
+#ifdef MGN_RING_EPI_STAMPS     // diagnostic: the eight stamp slots on the epilogue (1: chains done ... 7: turnover requested)
+#define CST(k) do {} while (0)
+#define EST(k) STAMP(k)
+#else
+#define CST(k) STAMP(k)
+#define EST(k) do {} while (0)
+#endif
 __global__ __launch_bounds__(512, 2) void k_edge_ring(const EdgeArgs a) {
     constexpr int NT = 4, L = 128, PC = 16384;
+    constexpr int W = 8;
+    constexpr int BUF = Rg<W>::BUF;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     uint16_t* wl = reinterpret_cast<uint16_t*>(smem);
     copy_to_lds16(wl, a.split[2], PC, true);                         // hi of W1e, W2, W3
     copy_to_lds16(wl + PC, a.split[0], PC, true);
     copy_to_lds16(wl + 2 * PC, a.split[1], PC, true);
-    u32x4* ringbase = reinterpret_cast<u32x4*>(wl + 3 * PC);         // three window buffers (48 KiB)
-    float* tb = reinterpret_cast<float*>(ringbase + 3 * RG_BUF);
+    const int lane0 = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int tid = (int)threadIdx.x;
+    u32x4* ringbase = reinterpret_cast<u32x4*>(wl + 3 * PC);                    // three window buffers (48 KiB)
+    float* tb = reinterpret_cast<float*>(ringbase + 3 * BUF);
     copy_to_lds(tb, a.tabs, T_COUNT * L);
-    const int tid = threadIdx.x;
     RingSrc src;
     {
         const u32x4* g[3] = {reinterpret_cast<const u32x4*>(a.split[2]), reinterpret_cast<const u32x4*>(a.split[0]),
@@ -315,16 +380,14 @@ __global__ __launch_bounds__(512, 2) void k_edge_ring(const EdgeArgs a) {
         }
 #pragma unroll
         for (int w = 0; w < 2; ++w) {                                 // windows 0 and 1 of layer 1
-            ringbase[w * RG_BUF + tid] = src.mid[0][w * RG_W * 64 + tid];
-            ringbase[w * RG_BUF + RG_W * 64 + tid] = src.lo[0][w * RG_W * 64 + tid];
+            ringbase[w * BUF + tid] = src.mid[0][w * W * 64 + tid];
+            ringbase[w * BUF + W * 64 + tid] = src.lo[0][w * W * 64 + tid];
         }
     }
     __syncthreads();
     const u32x4* l1h = reinterpret_cast<const u32x4*>(wl);
     const u32x4* l2h = reinterpret_cast<const u32x4*>(wl + PC);
     const u32x4* l3h = reinterpret_cast<const u32x4*>(wl + 2 * PC);
-    const int lane0 = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     // lock-step: every wave of the block runs as many tiles as its wave 0 (the longest walk); padding tiles compute, store nothing
     TileWalk tw0(a.ntiles, 0), tw(a.ntiles, wave);
     if (tw0.tile >= tw0.end) return;
@@ -337,8 +400,7 @@ __global__ __launch_bounds__(512, 2) void k_edge_ring(const EdgeArgs a) {
     EdgeIdx ix = load_edge_idx_nb(a.snd, a.rcv, a.E, clamp(tw.tile), lane0 & 31);
     {
         const int h0 = lane0 >> 5;
-        load_frag<NT>(acc, row_ptr(a.P, ix.s, L, h0), STRIDE_ROW);
-        add_frag<NT>(acc, row_ptr(a.Q, ix.r >= 0 ? ix.r : 0, L, h0), STRIDE_ROW);
+        load_frag<NT>(acc, row_ptr(a.Q, ix.r >= 0 ? ix.r : 0, L, h0), STRIDE_ROW);
         load_frag<NT>(y, tile_ptr(a.Elat, clamp(tw.tile), L, lane0), STRIDE_TILE);
     }
     int stamp_tile = 0;
@@ -355,26 +417,65 @@ __global__ __launch_bounds__(512, 2) void k_edge_ring(const EdgeArgs a) {
         u32x4* ring = ringbase + lane;
         STAMP(0);
         __builtin_amdgcn_s_setprio(0);
-        RingFrag nx = ring_first<0>(l1h, ring, lane);
-        sp_layer_ring<0, false>(acc, y, l1h, l2h, ring, src, nx, lane, tid);        // layer 1 (edge part); y = e tile
-        STAMP(1);
+        RingFrag nx = ring_first<W, 0>(l1h, ring, lane);
+        // layer 1 (edge part): y = e tile in, P[s] out (acc entered with Q[r], which carries b1)
+        sp_layer_ring<W, 0, false, STRIDE_ROW>(acc, y, l1h, l2h, ring, src, nx, lane, tid, row_ptr(a.P, ix.s, L, h));
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] += y[t];
+        CST(1);
         tab_frag<NT>(y, tb + T_B2 * L, h);
-        STAMP(2);
-        sp_layer_ring<1, true>(y, acc, l2h, l3h, ring, src, nx, lane, tid);         // layer 2 (ReLU folded into the split)
-        STAMP(3);
+        CST(2);
+        sp_layer_ring<W, 1, true>(y, acc, l2h, l3h, ring, src, nx, lane, tid);      // layer 2 (ReLU folded into the split)
+        CST(3);
         tab_frag<NT>(acc, tb + T_B3 * L, h);
-        STAMP(4);
-        sp_layer_ring<2, true>(acc, y, l3h, l1h, ring, src, nx, lane, tid);         // layer 3
-        STAMP(5);
+        CST(4);
+        // layer 3: y = layer 2's output in, the e tile (for the residual) out
+        sp_layer_ring<W, 2, true, STRIDE_TILE>(acc, y, l3h, l1h, ring, src, nx, lane, tid, etile);
+        CST(5);
+        EST(1);
         PHASE_FENCE();
         __builtin_amdgcn_s_setprio(MGN_PRIO);
-        load_frag<NT>(y, etile, STRIDE_TILE);                        // e again, for the residual
-        layer_norm_frag<NT>(acc, tb + T_GAMMA * L, tb + T_BETA * L, h);   // acc = e'
-        STAMP(6);
+        {   // LayerNorm (layer_norm_frag of frag.hpp in four slices): acc = e'
+            constexpr float invL = 1.0f / 128;
+            float sm = 0.f;
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int k = 0; k < 16; ++k) sm += acc[t][k];
+            sm += __shfl_xor(sm, 32, 64);
+            const float mean = sm * invL;
+            float q = 0.f;
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    const float d = acc[t][k] - mean;
+                    acc[t][k] = d;
+                    q += d * d;
+                }
+            q += __shfl_xor(q, 32, 64);
+            const float rstd = 1.0f / sqrtf(q * invL + LN_EPS);
+            const f32x4* g4 = reinterpret_cast<const f32x4*>(tb + T_GAMMA * L) + h;
+            const f32x4* b4 = reinterpret_cast<const f32x4*>(tb + T_BETA * L) + h;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 gv = g4[2 * (4 * t + g)];
+                    const f32x4 bv = b4[2 * (4 * t + g)];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) acc[t][4 * g + i] = acc[t][4 * g + i] * rstd * gv[i] + bv[i];
+                }
+            }
+        }
+        CST(6);
+        EST(2);
 #pragma unroll
         for (int t = 0; t < NT; ++t) y[t] += acc[t];                 // e <- e + e'
         if (valid) store_frag<NT>(etile, STRIDE_TILE, y);            // padding rows / tiles store nothing
-        STAMP(7);
+        CST(7);
+        EST(3);
+        load_frag<NT>(y, tile_ptr(a.Elat, nxt, L, lane), STRIDE_TILE);   // the next tile's e, ahead of everything else of the turnover
         const int reff = ix.r >= 0 ? r : (-4 - c);
         const int rprev = __shfl_up(reff, 1, 32);
         const int rnext = __shfl_down(reff, 1, 32);
@@ -384,7 +485,16 @@ __global__ __launch_bounds__(512, 2) void k_edge_ring(const EdgeArgs a) {
         const int st_in = max(start, c & 16);
         const bool c1 = (c - 1 >= st_in), c2 = (c - 2 >= st_in), c4 = (c - 4 >= st_in), c8 = (c - 8 >= st_in);
         const bool cx = (c >= 16) && (start <= 15);
-        segmented_scan<NT>(acc, c1, c2, c4, c8, cx);
+        EST(4);
+        PHASE_FENCE();
+        asm volatile("s_nop 1");
+        RG_SCAN_LEVEL(acc, c1, "row_shr:1 row_mask:0xf bank_mask:0xf");
+        RG_SCAN_LEVEL(acc, c2, "row_shr:2 row_mask:0xf bank_mask:0xf");
+        RG_SCAN_LEVEL(acc, c4, "row_shr:4 row_mask:0xf bank_mask:0xf");
+        RG_SCAN_LEVEL(acc, c8, "row_shr:8 row_mask:0xf bank_mask:0xf");
+        RG_SCAN_LEVEL(acc, cx, "row_bcast:15 row_mask:0xa bank_mask:0xf");
+        PHASE_FENCE();
+        EST(5);
         const bool tail = valid && ((c == 31) || (reff != rnext));
         const int r_first = __builtin_amdgcn_readfirstlane(reff);
         const bool sl = (start == 0) && (ix.r_before == r_first);
@@ -392,11 +502,11 @@ __global__ __launch_bounds__(512, 2) void k_edge_ring(const EdgeArgs a) {
         const bool to_carry = sl || sr;
         f32x4* dst = to_carry ? row_ptr(a.CARRY, (int64_t)2 * tile + (sl ? 0 : 1), L, h) : tile_ptr(a.AGG, r >> 5, L, 32 * h + (r & 31));
         if (tail) store_frag<NT>(dst, to_carry ? STRIDE_ROW : STRIDE_TILE, acc);
+        EST(6);
         PHASE_FENCE();
-        // turnover: the next tile's layer-1 accumulator and e tile
-        load_frag<NT>(acc, row_ptr(a.P, ixn.s, L, h), STRIDE_ROW);
-        add_frag<NT>(acc, row_ptr(a.Q, ixn.r >= 0 ? ixn.r : 0, L, h), STRIDE_ROW);
-        load_frag<NT>(y, tile_ptr(a.Elat, nxt, L, lane), STRIDE_TILE);
+        // turnover: the next tile's layer-1 accumulator starts from Q[r] (P[s] arrives during the layer)
+        load_frag<NT>(acc, row_ptr(a.Q, ixn.r >= 0 ? ixn.r : 0, L, h), STRIDE_ROW);
+        EST(7);
         ix = ixn;
         tw.tile += tw.stride;
     }

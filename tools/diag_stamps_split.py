@@ -16,6 +16,8 @@ st = out[:4 * 8 * 24 * 8].reshape(4, 8, 24, 8).astype(np.int64)
 names = ["split1", "L1", "relu+split2", "L2", "relu+split3", "L3", "reload e+LN+resid+store", "scan+tails+turnover(to next start)"]
 if os.environ.get("MGN_FP32_SPLIT") in ("2", "4"):
     names = ["L1", "tab", "L2", "tab", "L3", "reload e+LN", "resid+store", "scan+tails+turnover(to next start)"]
+if os.environ.get("MGN_RING_EPI"):
+    names = ["chains", "LN", "resid+store e", "next e req + scan setup", "scan", "tail stores", "Q request", "to next tile top"]
 if os.environ.get("MGN_FP32_SPLIT") == "3" and os.environ.get("MGN_WS_K"):
     # per-k-step stamps of one stage (library built with -DMGN_WS_DIAG_STAGE=n): slot s = the MFMAs of k-step s are issued
     for b in range(2):
