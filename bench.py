@@ -26,7 +26,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: dense f32-input MFMA peak
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # same guide: dense bf16 MFMA peak (the headline figures with 2:1 sparsity are not used)
 PEAK_HBM_GBPS = 8000.0         # same guide: HBM3E ~8 TB/s
+SPLIT_PRODUCTS = 6             # bf16 piece products per fp32 product on the split path (csrc/split.hip)
 L, MPS, FN, FE, O = 128, 15, 9, 3, 2
 
 
@@ -100,10 +102,12 @@ def cpu_baseline(ps, budget_s=20.0):
                 host_cpus=os.cpu_count())
 
 
-def committed_traffic(kernel_substr, dtype="f32"):
+def committed_traffic(prefixes, dtype="f32"):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this same command
     (profiles/rNN/pmc_summary_bench_1m[_bf16].json, newest round first; separate --pmc FETCH_SIZE / WRITE_SIZE passes,
-    gfx950 x2 read correction as prescribed by the guide's HBM section).  None when no profile is committed."""
+    gfx950 x2 read correction as prescribed by the guide's HBM section).  `prefixes`: kernel-name prefixes as they appear in the
+    profile keys (the key of a round is matched by prefix, so that template arguments added later do not hide it).
+    (None, None) when no profile is committed."""
     name = "pmc_summary_bench_1m.json" if dtype == "f32" else "pmc_summary_bench_1m_bf16.json"
     pdir = os.path.join(ROOT, "profiles")
     try:
@@ -116,7 +120,8 @@ def committed_traffic(kernel_substr, dtype="f32"):
         except Exception:
             continue
         for k, v in d.items():
-            if kernel_substr in k and "derived" in v:
+            kk = k.replace("void ", "").replace("mgn::", "")
+            if any(kk.startswith(p) for p in prefixes) and "derived" in v and "hbm_bytes_per_launch_corrected" in v["derived"]:
                 return v["derived"]["hbm_bytes_per_launch_corrected"], f"profiles/{rd}/{name}"
     return None, None
 
@@ -131,6 +136,19 @@ def time_clean(eng, steps, warmup, sync):
         eng.processor_steps_dev(MPS)
     sync()
     return time.perf_counter() - t0
+
+
+def time_each(eng, steps, sync):
+    """the median of >= 20 individually timed passes (a separate pass: each step has its own bracket)"""
+    ts = []
+    for _ in range(steps):
+        sync()
+        t0 = time.perf_counter()
+        eng.processor_steps_dev(MPS)
+        sync()
+        ts.append(time.perf_counter() - t0)
+    ts.sort()
+    return ts[len(ts) // 2], ts[0]
 
 
 def kernel_split(eng, steps, sync):
@@ -151,11 +169,30 @@ def time_single(eng, steps, warmup, sync):
     return dt, kernel_split(eng, max(1, min(steps, 3)), sync)
 
 
-def comm_bootstrap(eng, rank, world):
+def rccl_loadable():
+    """can this process bind an RCCL library (the engine binds librccl at run time, MGN_RCCL_LIB or the loader's search path)"""
+    import ctypes
+    for cand in (os.environ.get("MGN_RCCL_LIB"), "librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"):
+        if not cand:
+            continue
+        try:
+            ctypes.CDLL(cand)
+            return True
+        except OSError:
+            continue
+    return False
+
+
+def comm_bootstrap(eng, rank, world, device_id):
     """One communicator id for all ranks of the job: rank 0 makes it (mgn_comm_unique_id), the launcher's rendezvous store
-    (torch.distributed env:// -- plumbing only) hands it to the others; without a store, a file on this node.  Should RCCL fail to
-    initialise on ANY rank, all ranks agree (through the store) to fall back to the library's shared-memory transport, so that the
-    run still measures the in-library schedule; the JSON line names the transport that was used."""
+    (torch.distributed env:// -- plumbing only) hands it to the others; without a store, a file on this node.
+    The transport is decided BEFORE any rank touches RCCL (ncclCommInitRank is collective and has no time-out: a fallback
+    agreed on afterwards hangs as soon as one rank's init does not fail): every rank publishes (host, device id, can it load
+    librccl) through the store; two ranks on one device or a rank without the library put ALL ranks on the library's
+    shared-memory transport.  The RCCL init itself runs under a watchdog that ends the process with a message.
+    Returns (store, transport)."""
+    import socket
+    import threading
     try:
         from torch.distributed import rendezvous
         store, _, _ = next(rendezvous("env://", rank, world))
@@ -166,24 +203,44 @@ def comm_bootstrap(eng, rank, world):
         sys.stderr.write(f"[bench] store rendezvous failed ({ex!r}); file bootstrap {path}\n")
         eng.comm_init_file(path, "rccl")
         return None, "rccl"
-    ok = True
-    try:
-        if rank == 0:
-            store.set("mgn_comm_id", eng.comm_unique_id("rccl"))
-        eng.comm_init(bytes(store.get("mgn_comm_id")), "rccl")
-    except Exception as ex:   # noqa: BLE001
-        sys.stderr.write(f"[bench] rank {rank}: RCCL communicator failed: {ex}\n")
-        ok = False
-    store.set(f"mgn_comm_ok_{rank}", b"1" if ok else b"0")
-    all_ok = all(bytes(store.get(f"mgn_comm_ok_{q}")) == b"1" for q in range(world))
-    if all_ok:
-        return store, "rccl"
-    if ok:
-        eng.comm_destroy()
+    store.set(f"mgn_dev_{rank}", f"{socket.gethostname()}|{device_id}|{int(rccl_loadable())}".encode())
+    devs = [bytes(store.get(f"mgn_dev_{q}")).decode().split("|") for q in range(world)]
+    distinct = len({(d[0], d[1]) for d in devs}) == world
+    loadable = all(d[2] == "1" for d in devs)
+    transport = "rccl" if (distinct and loadable) else "host"
     if rank == 0:
-        store.set("mgn_comm_id_host", eng.comm_unique_id("host"))
-    eng.comm_init(bytes(store.get("mgn_comm_id_host")), "host")
-    return store, "host (shared memory: RCCL did not initialise on every rank)"
+        store.set("mgn_comm_id", eng.comm_unique_id(transport))
+    cid = bytes(store.get("mgn_comm_id"))
+    limit = float(os.environ.get("MGN_COMM_TIMEOUT_S", "120"))
+
+    def give_up():
+        sys.stderr.write(f"[bench] rank {rank}: communicator init ({transport}) did not return within {limit:.0f} s; giving up\n")
+        sys.stderr.flush()
+        os._exit(3)
+
+    dog = threading.Timer(limit, give_up)
+    dog.daemon = True
+    dog.start()
+    try:
+        eng.comm_init(cid, transport)
+    finally:
+        dog.cancel()
+    why = "" if transport == "rccl" else (" (shared memory: " + ("several ranks share a device" if not distinct else "librccl not loadable on every rank") + ")")
+    return store, transport + why
+
+
+def relaunch_under_torchrun(args):
+    """`python bench.py --gpus N` without a launcher: start torch.distributed.run as a CHILD process -- before this process has
+    imported torch or touched the GPU (no exec after GPU initialisation on these boxes) -- and relay its output and exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    res = subprocess.run(cmd, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    raise SystemExit(res.returncode)
 
 
 def main():
@@ -203,6 +260,8 @@ def main():
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL across processes needs it on this driver
     if args.force_staged:
         os.environ["MGN_FORCE_STAGED"] = "1"
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        relaunch_under_torchrun(args)                          # (does not return)
     import numpy as np
     import torch
     import mgn_amd
@@ -211,8 +270,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus} (or without a launcher)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the engine has no CPU path")
     if os.environ.get("MGN_BENCH_ONE_GPU") == "1":   # tests on a one-GPU box: every rank on device 0 (RCCL refuses that: the
@@ -231,7 +289,11 @@ def main():
     t_setup = time.perf_counter()
     eng.set_graph(s, r, N, mesh_pos=pos)     # unsorted COO in: receiver sort / CSR / partition / halo lists are amortised here
     t_setup = time.perf_counter() - t_setup
-    store, transport = comm_bootstrap(eng, rank, world) if staged else (None, None)
+    try:
+        dev_id = str(torch.cuda.get_device_properties(local_rank).uuid)
+    except Exception:   # noqa: BLE001
+        dev_id = f"index{local_rank}"
+    store, transport = comm_bootstrap(eng, rank, world, dev_id) if staged else (None, None)
     eng.latents_randn(1234)
 
     def barrier_sync():
@@ -244,6 +306,10 @@ def main():
     dt = time_clean(eng, args.steps, args.warmup, barrier_sync)
     if staged:
         dt = float(eng.comm_allreduce([dt], "max")[0])      # MAX over ranks
+    t_med, t_min = time_each(eng, max(args.steps, 3), barrier_sync)
+    if staged:
+        t_med = float(eng.comm_allreduce([t_med], "max")[0])
+        setup_all = eng.comm_allreduce([t_setup if q == rank else 0.0 for q in range(world)], "sum")
     prof = kernel_split(eng, max(1, min(args.steps, 5)), barrier_sync)
 
     chk = eng.latents_checksum()
@@ -269,7 +335,7 @@ def main():
             # two index streams, one pass over the P, Q rows it gathers and the AGG rows it writes
             edge_bytes = 2.0 * L * 2 * e_loc + 8.0 * e_loc + 3.0 * 2.0 * L * n_loc
             ach = edge_bytes / t_edge / 1e9 if t_edge > 0 else 0.0
-            traffic, tsrc = committed_traffic("k_edge_bf16", "bf16") if (world == 1 and args.nx == 1000) else (None, None)
+            traffic, tsrc = committed_traffic(["k_edge_bf16"], "bf16") if (world == 1 and args.nx == 1000) else (None, None)
             roof = {"bound": "hbm", "kernel": "k_edge_bf16 (fused gather + edge MLP + LayerNorm + residual + segmented scatter, bf16 storage)",
                     "achieved": ach, "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": ach / PEAK_HBM_GBPS,
                     "bytes_per_launch": edge_bytes, "bytes_kind": "algorithmic: 2 L (2 E) latents R+W + 8 E indices + 3 x 2 L N (P, Q rows read once, AGG rows written)",
@@ -280,31 +346,74 @@ def main():
                                       "note": "SURVEY.md 8(d) compulsory bytes at 2-byte storage / wall time per step",
                                       "mfma_TFLOPs_executed": exec_flops_pass / MPS / t_step / 1e12, "mfma_peak_bf16_dense": 2500.0}
         else:
-            ach = flops_edge_kernel(e_loc) / t_edge / 1e12 if t_edge > 0 else 0.0
-            traffic, tsrc = committed_traffic("k_edge_step<4, 2>") if (world == 1 and args.nx == 1000) else (None, None)
-            roof = {"bound": "mfma", "kernel": "k_edge_step<4,2> (fused gather + edge MLP + LayerNorm + residual + segmented scatter)",
-                    "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS,
-                    "flops_per_launch": flops_edge_kernel(e_loc), "flops_kind": "MFMA flops executed by this kernel (98 304 per edge; "
-                    "layer 1 is factored so the v_s/v_r blocks run per node in k_node_step)",
-                    "avg_launch_ms": t_edge * 1e3, "launches": prof["edge_step"]["count"],
-                    "traffic": traffic, "traffic_source": tsrc,
-                    "traffic_unit": "bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE); algorithmic = 1117 B/edge",
-                    "algorithmic_bytes_per_launch": (1024.0 + 8.0 + 85.0) * e_loc,
-                    # what THIS kernel has to move at least, given the factored design: e latents R + W, index streams, and one
-                    # pass over the P, Q rows it gathers and the AGG rows it writes (3 x N x 512 B); gather re-reads come on top
-                    "kernel_compulsory_bytes_per_launch": (1024.0 + 8.0) * e_loc + 3.0 * 512.0 * n_loc}
-            roof["processor_step"] = {
-                "bound": "mfma", "executed_flops_per_step": exec_flops_pass / MPS, "achieved": exec_flops_pass / MPS / t_step / 1e12,
-                "peak": PEAK_F32_MFMA_TFLOPS * world, "unit": "TFLOP/s", "frac": exec_flops_pass / MPS / t_step / 1e12 / (PEAK_F32_MFMA_TFLOPS * world),
-                "note": "MFMA flops the kernels execute (edge 98 304 E; node side 196 608 N incl. the P / Q projection) / wall time per step",
-                "algorithmic_equivalent_TFLOPs": flops_algorithmic(E, N) / t_step / 1e12,
-                "algorithmic_equivalent_note": "SURVEY.md 8(d) flops of the UN-factored algorithm (163 840 E + 131 072 N) over the same time: "
-                                               "a speed-up of the factored design, not a fraction of any peak"}
+            import ctypes
+            lib = mgn_amd.load()
+            lib.mgn_debug_fp32_split.restype = ctypes.c_int
+            lib.mgn_debug_fp32_split.argtypes = [ctypes.c_int]
+            split_mode = lib.mgn_debug_fp32_split(0)            # query ...
+            lib.mgn_debug_fp32_split(split_mode)                # ... and restore
+            comp = (1024.0 + 8.0) * e_loc + 3.0 * 512.0 * n_loc
+            common = {"avg_launch_ms": t_edge * 1e3, "launches": prof["edge_step"]["count"],
+                      "traffic_unit": "bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE); algorithmic = 1117 B/edge",
+                      "algorithmic_bytes_per_launch": (1024.0 + 8.0 + 85.0) * e_loc,
+                      # what THIS kernel has to move at least, given the factored design: e latents R + W, index streams, and one
+                      # pass over the P, Q rows it gathers and the AGG rows it writes (3 x N x 512 B); gather re-reads come on top
+                      "kernel_compulsory_bytes_per_launch": comp}
+            if split_mode:
+                # fp32 storage, every L x L product as six exact bf16 products on v_mfma_f32_32x32x16_bf16, fp32 accumulation
+                # (csrc/split.hip).  The roofline is the bf16 dense peak with the flops the kernel EXECUTES: 6 x the fp32 count.
+                kname = "k_edge_ring" if split_mode == 1 else "k_edge_split2"
+                fl = SPLIT_PRODUCTS * flops_edge_kernel(e_loc)
+                ach = fl / t_edge / 1e12 if t_edge > 0 else 0.0
+                traffic, tsrc = committed_traffic([kname]) if (world == 1 and args.nx == 1000) else (None, None)
+                roof = {"bound": "mfma", "kernel": kname + " (fused gather + edge MLP + LayerNorm + residual + segmented scatter; fp32 operands as "
+                        "three bf16 pieces, six piece products per fp32 product, fp32 accumulate)",
+                        "achieved": ach, "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_BF16_MFMA_TFLOPS,
+                        "flops_per_launch": fl, "flops_kind": "bf16 MFMA flops executed by this kernel: 6 x 98 304 per edge (layer 1 is factored: the "
+                        "v_s / v_r blocks run per node); against the dense bf16 peak",
+                        "fp32_equivalent_TFLOPs": flops_edge_kernel(e_loc) / t_edge / 1e12 if t_edge > 0 else 0.0,
+                        "fp32_equivalent_note": "the same launch counted as the fp32 products it replaces (98 304 flop per edge): what an fp32-MFMA "
+                                                "kernel would have to sustain (its peak: 157.3)",
+                        "traffic": traffic, "traffic_source": tsrc, **common}
+                ex = SPLIT_PRODUCTS * exec_flops_pass / MPS
+                roof["processor_step"] = {
+                    "bound": "mfma", "executed_flops_per_step": ex, "achieved": ex / t_step / 1e12, "peak": PEAK_BF16_MFMA_TFLOPS * world,
+                    "unit": "TFLOP/s", "frac": ex / t_step / 1e12 / (PEAK_BF16_MFMA_TFLOPS * world),
+                    "note": "bf16 MFMA flops the kernels execute (6 x (98 304 E + 196 608 N)) / wall time per step",
+                    "fp32_equivalent_TFLOPs": exec_flops_pass / MPS / t_step / 1e12,
+                    "algorithmic_equivalent_TFLOPs": flops_algorithmic(E, N) / t_step / 1e12,
+                    "algorithmic_equivalent_note": "SURVEY.md 8(d) flops of the UN-factored fp32 algorithm (163 840 E + 131 072 N) over the same "
+                                                   "time: a speed-up of the design, not a fraction of any peak"}
+            else:
+                ach = flops_edge_kernel(e_loc) / t_edge / 1e12 if t_edge > 0 else 0.0
+                traffic, tsrc = committed_traffic(["k_edge_step<4, 2"]) if (world == 1 and args.nx == 1000) else (None, None)
+                roof = {"bound": "mfma", "kernel": "k_edge_step<4,2> (fused gather + edge MLP + LayerNorm + residual + segmented scatter; "
+                        "v_mfma_f32_32x32x2_f32)",
+                        "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS,
+                        "flops_per_launch": flops_edge_kernel(e_loc), "flops_kind": "MFMA flops executed by this kernel (98 304 per edge; "
+                        "layer 1 is factored so the v_s/v_r blocks run per node in k_node_step)",
+                        "traffic": traffic, "traffic_source": tsrc, **common}
+                roof["processor_step"] = {
+                    "bound": "mfma", "executed_flops_per_step": exec_flops_pass / MPS, "achieved": exec_flops_pass / MPS / t_step / 1e12,
+                    "peak": PEAK_F32_MFMA_TFLOPS * world, "unit": "TFLOP/s", "frac": exec_flops_pass / MPS / t_step / 1e12 / (PEAK_F32_MFMA_TFLOPS * world),
+                    "note": "MFMA flops the kernels execute (edge 98 304 E; node side 196 608 N incl. the P / Q projection) / wall time per step",
+                    "algorithmic_equivalent_TFLOPs": flops_algorithmic(E, N) / t_step / 1e12,
+                    "algorithmic_equivalent_note": "SURVEY.md 8(d) flops of the UN-factored algorithm (163 840 E + 131 072 N) over the same time: "
+                                                   "a speed-up of the factored design, not a fraction of any peak"}
         roof["kernel_timing"] = "separate pass after the timed region: HIP event pairs per launch on the launch stream (mgn_profile_enable)"
         roof["node_side"] = {"avg_launch_ms": t_node * 1e3, "launches": prof["node_step"]["count"],
-                             "achieved_TFLOPs": node_flops_pass / max(node_launches, 1) / t_node / 1e12 if t_node > 0 else 0.0}
+                             "achieved_TFLOPs_fp32_equivalent": node_flops_pass / max(node_launches, 1) / t_node / 1e12 if t_node > 0 else 0.0,
+                             "note": "node MLP + P / Q projection per event group; flops counted as fp32 products (x 6 executed on the split path)"}
         if prof["halo"]["count"]:
             roof["halo_pack_ms"] = prof["halo"]["avg_ms"]
+        if bf:
+            precision = "bf16 storage + bf16 MFMA"
+        elif split_mode:
+            precision = ("fp32 storage, bf16x3 split MFMA (every fp32 operand = three bf16 pieces, six exact piece products per fp32 "
+                         "product on v_mfma_f32_32x32x16_bf16), fp32 accumulate; MGN_FP32_SPLIT=0 gives the fp32-MFMA path reported under "
+                         "`fp32_mfma_path`")
+        else:
+            precision = "fp32 storage, fp32 MFMA (v_mfma_f32_32x32x2_f32; MGN_FP32_SPLIT=0)"
         out = {
             "metric": "processor-step edges/s",
             "value": E * MPS * args.steps / dt,
@@ -315,13 +424,16 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
             "ms_per_processor_step": t_step * 1e3,
+            "median": {"ms_per_step": t_med * 1e3, "value": E * MPS / t_med, "min_ms_per_step": t_min * 1e3,
+                       "note": f"SURVEY.md 8(d): median of {max(args.steps, 3)} individually bracketed passes (a separate pass; `value` is the "
+                               "driver contract's single bracket around all timed steps)"},
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
             "dtype": args.dtype,
             "data": "synthetic",
             "config": {"workload": f"M-1M jittered-grid triangulation {args.nx}x{args.nx}: N={N} nodes, E={E} directed edges, "
-                                   f"L=128, hidden_layers=2, {MPS} processor steps per bench step, {'bf16 storage + bf16 MFMA' if bf else 'fp32'} "
+                                   f"L=128, hidden_layers=2, {MPS} processor steps per bench step, {precision} "
                                    f"(BASELINE.json configs[3]{' mesh at configs[2] precision' if bf else ''})",
                        "partition": (f"edge-cut RCB over {world} GPU(s), halo exchange inside mgn_processor_steps_dev, transport {transport}"
                                      if world > 1 else "single partition"),
@@ -331,16 +443,13 @@ def main():
             "graph_setup_s": t_setup,   # once per trajectory (mgn_set_graph: sort by receiver, CSR, partition, upload), not in `value`
         }
         if world > 1:
-            out["per_rank"] = {"n_own": n_loc, "e_local": e_loc, "n_halo": eng.n_halo}
-        if world == 1 and not args.no_secondary and args.dtype == "f32":
-            # opt-in edge kernel (NOT the headline): the edge MLP's three layers on the bf16 matrix cores at fp32 accuracy -- every fp32
-            # operand split exactly into three bf16 pieces, six of nine piece products kept (tests/test_gpu_fp32_split.py holds it to
-            # the fp32 tolerances and to the fp32-MFMA kernel's own error against float64)
-            import ctypes
-            lib = mgn_amd.load()
-            lib.mgn_debug_fp32_split.restype = ctypes.c_int
-            lib.mgn_debug_fp32_split.argtypes = [ctypes.c_int]
-            old_split = lib.mgn_debug_fp32_split(1)
+            out["transport"] = transport
+            out["per_rank"] = {"n_own": n_loc, "e_local": e_loc, "n_halo": eng.n_halo,
+                               "graph_setup_s": [float(x) for x in setup_all],
+                               "graph_setup_note": "every rank ingests the global edge lists in mgn_set_graph and keeps its partition"}
+        if world == 1 and not args.no_secondary and args.dtype == "f32" and split_mode:
+            # the same workload on the fp32-MFMA kernels (v_mfma_f32_32x32x2_f32), for the record beside the split-path headline
+            lib.mgn_debug_fp32_split(0)
             try:
                 engs = mgn_amd.Engine(FN, FE, O, L, 2, MPS, device=local_rank)
                 engs.set_params(ps)
@@ -348,15 +457,17 @@ def main():
                 engs.latents_randn(1234)
                 dts, profs = time_single(engs, 3, 1, barrier_sync)
                 ts = dts / (3 * MPS)
-                out["fp32_split_opt_in"] = {
-                    "workload": "same M-1M mesh, fp32 storage; k_edge_split (MGN_FP32_SPLIT=1): v_mfma_f32_32x32x16_bf16 on three-way split "
-                                "operands, six products per fp32 product, fp32 accumulate; node side unchanged",
-                    "ms_per_processor_step": ts * 1e3, "edges_per_s": E / ts, "edge_kernel_ms": profs["edge_step"]["avg_ms"],
+                te = profs["edge_step"]["avg_ms"] * 1e-3
+                out["fp32_mfma_path"] = {
+                    "workload": "same M-1M mesh, fp32 storage, v_mfma_f32_32x32x2_f32 (MGN_FP32_SPLIT=0: the fp32 reference path; round-2 headline)",
+                    "ms_per_processor_step": ts * 1e3, "edges_per_s": E / ts, "edge_kernel_ms": te * 1e3,
                     "node_side_ms": profs["node_step"]["avg_ms"],
-                    "note": "not the headline `value`: reported for the record; the node-side kernels run slower behind it (clocks)"}
+                    "roofline": {"bound": "mfma", "kernel": "k_edge_step<4,2>", "achieved": flops_edge_kernel(E) / te / 1e12 if te > 0 else 0.0,
+                                 "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                                 "frac": flops_edge_kernel(E) / te / 1e12 / PEAK_F32_MFMA_TFLOPS if te > 0 else 0.0}}
                 engs.close()
             finally:
-                lib.mgn_debug_fp32_split(old_split)
+                lib.mgn_debug_fp32_split(split_mode)
         if world == 1 and not args.no_secondary and args.dtype == "f32":
             engb = mgn_amd.Engine(FN, FE, O, L, 2, MPS, device=local_rank, dtype="bf16")
             engb.set_params(ps)
@@ -372,7 +483,7 @@ def main():
                            "mfma_TFLOPs_algorithmic": flops_algorithmic(E, N) / tb / 1e12}
             eb_b = 2.0 * L * 2 * E + 8.0 * E + 3.0 * 2.0 * L * N
             te_b = profb["edge_step"]["avg_ms"] * 1e-3
-            trb, srcb = committed_traffic("k_edge_bf16", "bf16") if args.nx == 1000 else (None, None)
+            trb, srcb = committed_traffic(["k_edge_bf16"], "bf16") if args.nx == 1000 else (None, None)
             out["bf16"]["roofline"] = {"bound": "hbm", "kernel": "k_edge_bf16", "achieved": eb_b / te_b / 1e9 if te_b > 0 else 0.0,
                                        "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": eb_b / te_b / 1e9 / PEAK_HBM_GBPS if te_b > 0 else 0.0,
                                        "bytes_per_launch": eb_b, "traffic": trb, "traffic_source": srcb,

@@ -86,6 +86,15 @@ RcclApi* rccl_api(std::string& why) {
             return -1;                                                                                   \
         }                                                                                                \
     } while (0)
+// host transport: a failing rank also raises the shared abort flag, so that its peers leave their barrier at once
+#define HIPC_ABORT(expr)                                                                                 \
+    do {                                                                                                 \
+        hipError_t _e = (expr);                                                                          \
+        if (_e != hipSuccess) {                                                                          \
+            err = std::string(#expr) + " failed: " + hipGetErrorString(_e);                              \
+            return fail_abort();                                                                         \
+        }                                                                                                \
+    } while (0)
 #define NCCLC(expr)                                                                                      \
     do {                                                                                                 \
         ncclResult_t _r = (expr);                                                                        \
@@ -381,10 +390,10 @@ struct HostComm final : Comm {
         return 0;
     }
     int a2a_host(const void* send, const size_t* sbytes, const size_t* soff, void* recv, const size_t* rbytes, const size_t* roff) override {
-        if (publish(send, sbytes, soff, false, 0) != 0) return -1;
-        if (wait_barrier() != 0) return -1;
-        if (collect(recv, rbytes, roff) != 0) return -1;
-        return wait_barrier();
+        if (publish(send, sbytes, soff, false, 0) != 0) return fail_abort();
+        if (wait_barrier() != 0) return fail_abort();
+        if (collect(recv, rbytes, roff) != 0) return fail_abort();
+        return wait_barrier() != 0 ? fail_abort() : 0;
     }
     static size_t span(const size_t* bytes, const size_t* off, int n) {
         size_t m = 0;
@@ -394,39 +403,46 @@ struct HostComm final : Comm {
     }
     int a2a_start(const void* send, const size_t* sbytes, const size_t* soff, void* recv, const size_t* rbytes, const size_t* roff,
                   hipStream_t compute) override {
+        pend_recv = nullptr;                         // a failed start must not leave the previous exchange's target behind
+        pend_rbytes.clear();
+        pend_roff.clear();
         const size_t ns = span(sbytes, soff, nranks);
         if (ensure_stage(stage_s, cap_s, ns) != 0) return fail_abort();
-        if (ns) HIPC(hipMemcpyAsync(stage_s, send, ns, hipMemcpyDeviceToHost, compute));
-        HIPC(hipStreamSynchronize(compute));     // also: the H2D of the previous exchange has left stage_r
-        if (publish(stage_s, sbytes, soff, false, 0) != 0) return -1;
-        if (wait_barrier() != 0) return -1;
+        if (ns) HIPC_ABORT(hipMemcpyAsync(stage_s, send, ns, hipMemcpyDeviceToHost, compute));
+        HIPC_ABORT(hipStreamSynchronize(compute));     // also: the H2D of the previous exchange has left stage_r
+        if (publish(stage_s, sbytes, soff, false, 0) != 0) return fail_abort();
+        if (wait_barrier() != 0) return fail_abort();
         pend_recv = recv;
         pend_rbytes.assign(rbytes, rbytes + nranks);
         pend_roff.assign(roff, roff + nranks);
         return 0;
     }
     int a2a_finish(hipStream_t compute) override {
+        if (!pend_recv && pend_rbytes.empty()) { err = "a2a_finish without a pending a2a_start"; return fail_abort(); }
         const size_t nr = span(pend_rbytes.data(), pend_roff.data(), nranks);
         if (ensure_stage(stage_r, cap_r, nr) != 0) return fail_abort();
-        if (collect(stage_r, pend_rbytes.data(), pend_roff.data()) != 0) return -1;
-        if (wait_barrier() != 0) return -1;
+        if (collect(stage_r, pend_rbytes.data(), pend_roff.data()) != 0) return fail_abort();
+        if (wait_barrier() != 0) return fail_abort();
         for (int q = 0; q < nranks; ++q)
             if (pend_rbytes[q])
-                HIPC(hipMemcpyAsync(static_cast<char*>(pend_recv) + pend_roff[q], stage_r + pend_roff[q], pend_rbytes[q], hipMemcpyHostToDevice, compute));
+                HIPC_ABORT(hipMemcpyAsync(static_cast<char*>(pend_recv) + pend_roff[q], stage_r + pend_roff[q], pend_rbytes[q], hipMemcpyHostToDevice, compute));
+        pend_recv = nullptr;
+        pend_rbytes.clear();
+        pend_roff.clear();
         return 0;
     }
     int allgather(const void* send, size_t bytes, void* recv, hipStream_t compute) override {
         if (ensure_stage(stage_s, cap_s, bytes) != 0 || ensure_stage(stage_r, cap_r, bytes * nranks) != 0) return fail_abort();
-        if (bytes) HIPC(hipMemcpyAsync(stage_s, send, bytes, hipMemcpyDeviceToHost, compute));
-        HIPC(hipStreamSynchronize(compute));
-        if (publish(stage_s, nullptr, nullptr, true, bytes) != 0) return -1;
-        if (wait_barrier() != 0) return -1;
+        if (bytes) HIPC_ABORT(hipMemcpyAsync(stage_s, send, bytes, hipMemcpyDeviceToHost, compute));
+        HIPC_ABORT(hipStreamSynchronize(compute));
+        if (publish(stage_s, nullptr, nullptr, true, bytes) != 0) return fail_abort();
+        if (wait_barrier() != 0) return fail_abort();
         std::vector<size_t> rb(nranks, bytes), ro(nranks);
         for (int q = 0; q < nranks; ++q) ro[q] = (size_t)q * bytes;
-        if (collect(stage_r, rb.data(), ro.data()) != 0) return -1;
-        if (wait_barrier() != 0) return -1;
-        if (bytes) HIPC(hipMemcpyAsync(recv, stage_r, bytes * nranks, hipMemcpyHostToDevice, compute));
-        HIPC(hipStreamSynchronize(compute));
+        if (collect(stage_r, rb.data(), ro.data()) != 0) return fail_abort();
+        if (wait_barrier() != 0) return fail_abort();
+        if (bytes) HIPC_ABORT(hipMemcpyAsync(recv, stage_r, bytes * nranks, hipMemcpyHostToDevice, compute));
+        HIPC_ABORT(hipStreamSynchronize(compute));
         return 0;
     }
     int allreduce_f64(double* x, int n, int op, hipStream_t) override {

@@ -200,14 +200,18 @@ DEVINL f32x16 mfma32(float a, float b, f32x16 c) {
 }
 // wait states tied to the registers they protect (an untied `s_nop` statement is free to move away from them):
 // VALU writes of the operands -> first MFMA; last MFMAs -> VALU reads of the accumulators (16 passes: 18 wait states)
+// Safe by construction: the operands of a padded chain may have been written by the VALU (4 wait states would do) OR by a
+// compiler-issued MFMA of a neighbouring builtin chain (k_node_step<GEN> mixes the two), whose result a following MFMA may read
+// as its B operand only after 18 wait states -- and hipcc's hazard recogniser sees neither side of an inline-asm MFMA.  The
+// full 18 are therefore always supplied (14 extra idle clocks per chain of 64 x NT^2 MFMAs).
 template <int NT>
 DEVINL void mfma_chain_begin(f32x16 (&acc)[NT], const f32x16 (&in)[NT]) {
     if constexpr (NT == 4)
-        asm volatile("s_nop 3" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]) : "v"(in[0]), "v"(in[1]), "v"(in[2]), "v"(in[3]));
+        asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]) : "v"(in[0]), "v"(in[1]), "v"(in[2]), "v"(in[3]));
     else if constexpr (NT == 2)
-        asm volatile("s_nop 3" : "+v"(acc[0]), "+v"(acc[1]) : "v"(in[0]), "v"(in[1]));
+        asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" : "+v"(acc[0]), "+v"(acc[1]) : "v"(in[0]), "v"(in[1]));
     else
-        asm volatile("s_nop 3" : "+v"(acc[0]) : "v"(in[0]));
+        asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" : "+v"(acc[0]) : "v"(in[0]));
 }
 template <int NT>
 DEVINL void mfma_chain_end(f32x16 (&acc)[NT]) {

@@ -11,6 +11,8 @@
 #include <cstring>
 #include <ctime>
 #include <string>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <vector>
 
 #include "engine_internal.h"
@@ -2212,33 +2214,100 @@ int mgn_comm_init(mgn_handle* h, const void* id, size_t id_bytes, int32_t transp
     return MGN_OK;
 } MGN_CATCH(h)
 
+// File bootstrap of the communicator id (single node, no launcher store).  A file left behind by an earlier run (or a crash) must
+// never be taken for this run's id, so the id travels with a nonce and is confirmed both ways:
+//   rank 0: removes path, path.go and stale acks; writes path = {id, nonce}; waits until every other rank has written
+//           path.ack.<rank> = nonce; writes path.go = nonce; after the collective mgn_comm_init has returned removes every file.
+//   rank r: reads path, writes its ack with the nonce it read, waits for a path.go that carries the same nonce AND is not older
+//           than its own ack (a stale go predates it); on a different nonce it starts over with a fresh read of path.
+namespace {
+struct IdFile { unsigned char id[MGN_COMM_ID_BYTES]; uint64_t nonce; };
+bool write_atomic(const std::string& path, const void* data, size_t n) {
+    const std::string tmp = path + ".tmp";
+    FILE* f = fopen(tmp.c_str(), "wb");
+    if (!f) return false;
+    const bool ok = fwrite(data, 1, n, f) == n;
+    fclose(f);
+    return ok && rename(tmp.c_str(), path.c_str()) == 0;
+}
+bool read_exact(const std::string& path, void* data, size_t n) {
+    FILE* f = fopen(path.c_str(), "rb");
+    if (!f) return false;
+    const size_t got = fread(data, 1, n, f);
+    fclose(f);
+    return got == n;
+}
+double mtime_of(const std::string& path) {
+    struct stat st;
+    if (stat(path.c_str(), &st) != 0) return -1.0;
+    return (double)st.st_mtim.tv_sec + 1e-9 * (double)st.st_mtim.tv_nsec;
+}
+void nap20ms() {
+    struct timespec ts = {0, 20 * 1000 * 1000};
+    nanosleep(&ts, nullptr);
+}
+}  // namespace
+
 int mgn_comm_init_file(mgn_handle* h, const char* path, int32_t transport) try {
     if (!h || !path) return fail(h, MGN_E_ARG, "mgn_comm_init_file: null argument");
-    unsigned char id[MGN_COMM_ID_BYTES];
-    if (h->cfg.rank == 0) {
-        if (int rc = mgn_comm_unique_id(id, transport)) return fail(h, rc, "%s", mgn_last_error(nullptr));
-        const std::string tmp = std::string(path) + ".tmp";
-        FILE* f = fopen(tmp.c_str(), "wb");
-        if (!f || fwrite(id, 1, sizeof id, f) != sizeof id) { if (f) fclose(f); return fail(h, MGN_E_RCCL, "mgn_comm_init_file: cannot write %s", tmp.c_str()); }
-        fclose(f);
-        if (rename(tmp.c_str(), path) != 0) return fail(h, MGN_E_RCCL, "mgn_comm_init_file: cannot publish %s", path);
+    const double limit = getenv("MGN_COMM_TIMEOUT_S") ? atof(getenv("MGN_COMM_TIMEOUT_S")) : 120.0;
+    const std::string base(path), go = base + ".go";
+    const int rank = h->cfg.rank, nranks = h->cfg.nranks;
+    auto ack_of = [&](int r) { return base + ".ack." + std::to_string(r); };
+    IdFile rec{};
+    if (rank == 0) {
+        unlink(path);
+        unlink(go.c_str());
+        for (int r = 1; r < nranks; ++r) unlink(ack_of(r).c_str());
+        if (int rc = mgn_comm_unique_id(rec.id, transport)) return fail(h, rc, "%s", mgn_last_error(nullptr));
+        struct timespec now;
+        clock_gettime(CLOCK_REALTIME, &now);
+        rec.nonce = ((uint64_t)now.tv_sec << 32) ^ ((uint64_t)now.tv_nsec << 8) ^ (uint64_t)getpid();
+        FILE* ur = fopen("/dev/urandom", "rb");
+        if (ur) { uint64_t x = 0; if (fread(&x, 1, 8, ur) == 8) rec.nonce ^= x; fclose(ur); }
+        if (!write_atomic(base, &rec, sizeof rec)) return fail(h, MGN_E_RCCL, "mgn_comm_init_file: cannot write %s", path);
+        double waited = 0;
+        for (int r = 1; r < nranks; ++r)
+            for (;;) {
+                uint64_t n = 0;
+                if (read_exact(ack_of(r), &n, 8) && n == rec.nonce) break;
+                if (waited > limit) return fail(h, MGN_E_RCCL, "mgn_comm_init_file: timed out waiting for rank %d to acknowledge %s", r, path);
+                nap20ms();
+                waited += 0.02;
+            }
+        if (!write_atomic(go, &rec.nonce, 8)) return fail(h, MGN_E_RCCL, "mgn_comm_init_file: cannot write %s", go.c_str());
     } else {
         double waited = 0;
-        const double limit = getenv("MGN_COMM_TIMEOUT_S") ? atof(getenv("MGN_COMM_TIMEOUT_S")) : 120.0;
-        for (;;) {
-            FILE* f = fopen(path, "rb");
-            if (f) {
-                const size_t n = fread(id, 1, sizeof id, f);
-                fclose(f);
-                if (n == sizeof id) break;
+        for (bool confirmed = false; !confirmed;) {
+            while (!read_exact(base, &rec, sizeof rec)) {
+                if (waited > limit) return fail(h, MGN_E_RCCL, "mgn_comm_init_file: timed out waiting for rank 0 to write %s", path);
+                nap20ms();
+                waited += 0.02;
             }
-            if (waited > limit) return fail(h, MGN_E_RCCL, "mgn_comm_init_file: timed out waiting for rank 0 to write %s", path);
-            struct timespec ts = {0, 20 * 1000 * 1000};
-            nanosleep(&ts, nullptr);
-            waited += 0.02;
+            if (!write_atomic(ack_of(rank), &rec.nonce, 8)) return fail(h, MGN_E_RCCL, "mgn_comm_init_file: cannot write %s", ack_of(rank).c_str());
+            const double t_ack = mtime_of(ack_of(rank));
+            for (;;) {
+                uint64_t n = 0;
+                if (read_exact(go, &n, 8) && mtime_of(go) >= t_ack) {
+                    confirmed = n == rec.nonce;
+                    break;                                   // a go for another nonce: what this rank read was stale -> read again
+                }
+                IdFile cur{};
+                if (read_exact(base, &cur, sizeof cur) && cur.nonce != rec.nonce) break;   // rank 0 has published a new id meanwhile
+                if (waited > limit) return fail(h, MGN_E_RCCL, "mgn_comm_init_file: timed out waiting for rank 0 to confirm %s", path);
+                nap20ms();
+                waited += 0.02;
+            }
+            if (!confirmed) { nap20ms(); waited += 0.02; }
         }
     }
-    return mgn_comm_init(h, id, sizeof id, transport);
+    const int rc = mgn_comm_init(h, rec.id, MGN_COMM_ID_BYTES, transport);
+    if (rank == 0) {                                         // the collective init is over on every rank that could reach it
+        unlink(path);
+        unlink(go.c_str());
+        for (int r = 1; r < nranks; ++r) unlink(ack_of(r).c_str());
+    }
+    return rc;
 } MGN_CATCH(h)
 
 int mgn_comm_destroy(mgn_handle* h) try {

@@ -6,6 +6,7 @@ import multiprocessing as mp
 import os
 import sys
 import threading
+import time
 
 import numpy as np
 import pytest
@@ -89,6 +90,34 @@ def test_host_transport_processes_with_file_bootstrap(lib_built, tmp_path):
     [p.join(60) for p in procs]
     assert got == [(k, True, float(P)) for k in range(P)]
     assert all(p.exitcode == 0 for p in procs)
+
+
+def test_file_bootstrap_ignores_a_stale_id_file_and_cleans_up(lib_built, tmp_path):
+    """a second run with the same path (or a rerun after a crash) must not pick up the previous run's id.  The path is
+    pre-seeded with a well-formed but stale record, a stale go file and a stale ack; the run must complete with rank 0's fresh id
+    (the nonce handshake), twice in a row, and leave no file behind."""
+    P = 3
+    ctx = mp.get_context("spawn")
+    path = str(tmp_path / "comm.id")
+    stale = bytes(128) + (12345).to_bytes(8, "little")
+    for rnd in range(2):
+        with open(path, "wb") as f:
+            f.write(stale)
+        with open(path + ".go", "wb") as f:
+            f.write((12345).to_bytes(8, "little"))
+        with open(path + ".ack.1", "wb") as f:
+            f.write((12345).to_bytes(8, "little"))
+        q = ctx.Queue()
+        procs = [ctx.Process(target=_proc_main, args=(k, P, path, q)) for k in range(P)]
+        # the other ranks first: they find the stale files before rank 0 has removed them
+        [p.start() for p in procs[1:]]
+        time.sleep(0.3)
+        procs[0].start()
+        got = sorted(q.get(timeout=120) for _ in range(P))
+        [p.join(60) for p in procs]
+        assert got == [(k, True, float(P)) for k in range(P)], rnd
+        assert all(p.exitcode == 0 for p in procs)
+        assert not [f for f in os.listdir(tmp_path) if f.startswith("comm.id")], os.listdir(tmp_path)
 
 
 def test_comm_errors(lib_built, monkeypatch):

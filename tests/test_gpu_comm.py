@@ -360,6 +360,22 @@ def test_bench_two_ranks_under_torchrun_on_one_gpu(tmp_path):
     assert d["per_rank"]["n_halo"] > 0 and "transport" in d["config"]["partition"]
 
 
+def test_bench_two_gpus_without_a_launcher_on_one_gpu():
+    """`python bench.py --gpus 2` with no launcher (WORLD_SIZE unset): bench.py starts torch.distributed.run itself, as a child
+    process and before it has touched the GPU, and relays the JSON line and the exit code.  Both ranks sit on
+    device 0 here (MGN_BENCH_ONE_GPU), so the transport decision -- taken before any rank calls RCCL -- is the shared-memory one."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(MGN_BENCH_ONE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--nx", "200"],
+                         env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    assert res.returncode == 0 and len(lines) == 1, res.stdout[-1500:] + res.stderr[-3000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["latents_finite"]
+    assert d["transport"].startswith("host") and len(d["per_rank"]["graph_setup_s"]) == 2 and d["median"]["value"] > 0
+
+
 @pytest.mark.parametrize("P", [2, 3])
 def test_rollout_and_ode_step_on_a_partitioned_mesh(P):
     """rollout (reference src/solve.jl:42-68) and ode_step (:188-219) at nranks > 1: every rank passes the global arrays, integrates
