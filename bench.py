@@ -108,21 +108,22 @@ def committed_traffic(prefixes, dtype="f32"):
     gfx950 x2 read correction as prescribed by the guide's HBM section).  `prefixes`: kernel-name prefixes as they appear in the
     profile keys (the key of a round is matched by prefix, so that template arguments added later do not hide it).
     (None, None) when no profile is committed."""
-    name = "pmc_summary_bench_1m.json" if dtype == "f32" else "pmc_summary_bench_1m_bf16.json"
+    names = ["pmc_summary_bench_1m.json", "pmc_summary_bench_1m_fp32_mfma.json"] if dtype == "f32" else ["pmc_summary_bench_1m_bf16.json"]
     pdir = os.path.join(ROOT, "profiles")
     try:
         rounds = sorted((d for d in os.listdir(pdir) if d.startswith("r") and d[1:].isdigit()), reverse=True)
     except OSError:
         return None, None
     for rd in rounds:
-        try:
-            d = json.load(open(os.path.join(pdir, rd, name)))
-        except Exception:
-            continue
-        for k, v in d.items():
-            kk = k.replace("void ", "").replace("mgn::", "")
-            if any(kk.startswith(p) for p in prefixes) and "derived" in v and "hbm_bytes_per_launch_corrected" in v["derived"]:
-                return v["derived"]["hbm_bytes_per_launch_corrected"], f"profiles/{rd}/{name}"
+        for name in names:
+            try:
+                d = json.load(open(os.path.join(pdir, rd, name)))
+            except Exception:
+                continue
+            for k, v in d.items():
+                kk = k.replace("void ", "").replace("mgn::", "")
+                if any(kk.startswith(p) for p in prefixes) and "derived" in v and "hbm_bytes_per_launch_corrected" in v["derived"]:
+                    return v["derived"]["hbm_bytes_per_launch_corrected"], f"profiles/{rd}/{name}"
     return None, None
 
 
