@@ -331,97 +331,6 @@ def load_dataset(path, is_training):
 
 
 # ---- trajectory preparation (host side of SURVEY.md N3 / N4; arrays are [T][count][dim] like parse_data's) -------------
-def create_edges(dims, node_type, no_edges_node_types):
-    """create_edges(dims, node_type, no_edges_node_types) (reference src/dataset.jl:367-416): edges of a structured mesh
-    whose nodes are numbered by LinearIndices(dims) (x fastest, 1-based).  1-D: (i, i+1).  3-D: every node whose type is not
-    excluded is connected to its +x, +y, +z neighbour unless THAT neighbour's type is excluded; an excluded node gets one
-    self loop.  2-D is refused, like the reference.  `node_type`: 1-D array over the nodes (the reference reads
-    node_type[1, n, 1]).  Returns a list of [a, b] pairs, 1-based, in the reference's visiting order (x outermost)."""
-    dims = [int(d) for d in dims]
-    nt = np.asarray(node_type).reshape(-1)
-    excluded = set(int(t) for t in no_edges_node_types)
-    edges = []
-    if len(dims) == 1:
-        return [[i, i + 1] for i in range(1, dims[0])]
-    if len(dims) == 2:
-        raise ValueError("2D-Meshes are not supported yet")
-    if len(dims) != 3:
-        raise ValueError("dims must have 1 or 3 entries")
-    dx, dy, dz = dims
-    li = lambda x, y, z: x + dx * (y - 1) + dx * dy * (z - 1)          # 1-based LinearIndices((dx, dy, dz))
-    seen_loops = set()
-    for x in range(1, dx + 1):
-        for y in range(1, dy + 1):
-            for z in range(1, dz + 1):
-                me = li(x, y, z)
-                if int(nt[me - 1]) not in excluded:
-                    for cond, (sx, sy, sz) in ((x != dx, (1, 0, 0)), (y != dy, (0, 1, 0)), (z != dz, (0, 0, 1))):
-                        if cond:
-                            other = li(x + sx, y + sy, z + sz)
-                            if int(nt[other - 1]) not in excluded:
-                                edges.append([me, other])
-                elif me not in seen_loops:
-                    seen_loops.add(me)
-                    edges.append([me, me])
-    return edges
-
-
-def filter_edges(edges, node_type, no_edges_node_types, exclude_node_indices=()):
-    """The in-memory half of read_edges (reference src/dataset.jl:434-449; the HDF5 read stays on the Julia side): drop every
-    edge that touches a node of an excluded type or an explicitly excluded (1-based) node index."""
-    nt = np.asarray(node_type).reshape(-1)
-    excl = set(int(i) + 1 for i in np.nonzero(np.isin(nt, list(no_edges_node_types)))[0])
-    excl.update(int(i) for i in exclude_node_indices)
-    return [[int(a), int(b)] for a, b in edges if int(a) not in excl and int(b) not in excl]
-
-
-def add_targets(data, fields):
-    """add_targets!(data, fields, device) (reference src/dataset.jl:461-481), in place: every time-dependent array (more
-    than one step) loses its last step, and for the keys in `fields` the steps 2..T become "target|key" (ground truth of
-    the derivative-based strategies).  Keys that already start with "target|" are left alone."""
-    new = {}
-    for key, value in data.items():
-        if key.startswith("target|"):
-            continue
-        v = np.asarray(value)
-        if v.ndim > 2 and v.shape[0] > 1:
-            new[key] = v[:-1]
-            if key in fields:
-                new["target|" + key] = v[1:]
-    data.update(new)
-    return data
-
-
-def preprocess(data, noise_fields, noise_stddevs, types_noisy, random_order=False, window_size=0, seed=1234):
-    """preprocess!(data, noise_fields, noise_stddevs, types_noisy, ts, device) (reference src/dataset.jl:496-525), in
-    place: Gaussian noise N(0, sigma) on the listed fields, zeroed on every node whose type (node_type at the first step)
-    is not in `types_noisy`; then, for a derivative strategy with `random = true`, ONE permutation of the steps
-    (of the first `window_size` steps if it is non-zero) applied to every time-dependent key -- the reference re-seeds
-    its generator per key so that all keys are shuffled alike.  The generator is NumPy's, not Julia's MersenneTwister:
-    the distribution and the structure match, the individual draws do not."""
-    if len(noise_stddevs) != 1 and len(noise_stddevs) != len(noise_fields):
-        raise ValueError("DimensionMismatch: dimension of noise must be 1 or match noise fields")
-    rng = np.random.default_rng(seed)
-    types0 = np.asarray(data["node_type"])[0].reshape(-1)
-    quiet = ~np.isin(types0, list(types_noisy))
-    for i, nf in enumerate(noise_fields):
-        sigma = noise_stddevs[i] if len(noise_stddevs) > 1 else noise_stddevs[0]
-        v = np.asarray(data[nf], dtype=np.float32)
-        noise = rng.normal(0.0, sigma, size=v.shape).astype(np.float32)
-        noise[:, quiet, :] = 0
-        data[nf] = v + noise
-    if random_order:
-        for key in list(data.keys()):
-            v = np.asarray(data[key])
-            if key == "edges" or v.size == 1 or v.shape[0] == 1:
-                continue
-            n = v.shape[0] if window_size == 0 else window_size
-            perm = np.random.default_rng(seed).permutation(n)      # same permutation for every key
-            data[key] = v[perm]
-    return data
-
-
-# ---- solver-based training (SURVEY.md N2, second half) --------------------------------------------------------------
 def solver_training_euler(rhs, vjp, x0, gt, dt, val_mask, n_scale):
     """What train_step(::SolverStrategy) computes for SolverTraining with a fixed-step Euler solver (reference
     src/strategies.jl:175-196, 257-292), written as the discrete adjoint the sensitivity algorithm evaluates through VJPs of

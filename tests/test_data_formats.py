@@ -158,52 +158,3 @@ def test_corruption_is_detected(lib_built, tmp_path):
         next(rd)
     with pytest.raises(FileNotFoundError):
         ra.TFRecordReader(tmp_path / "nope.tfrecord")
-
-
-# ---- trajectory preparation mirrors (reference src/dataset.jl:367-525) ------------------------------------------------
-def test_create_edges_1d_3d_and_exclusions():
-    from mgn_amd import reference_api as ra
-    assert ra.create_edges([4], np.zeros(4, int), []) == [[1, 2], [2, 3], [3, 4]]
-    with pytest.raises(ValueError):
-        ra.create_edges([3, 3], np.zeros(9, int), [])
-    # 2 x 2 x 2 block, nothing excluded: 12 edges of a cube, x outermost / z innermost visiting order, x fastest numbering
-    e = ra.create_edges([2, 2, 2], np.zeros(8, int), [])
-    assert len(e) == 12 and e[0] == [1, 2] and e[1] == [1, 3] and e[2] == [1, 5]
-    assert sorted(map(tuple, e)) == sorted([(1, 2), (3, 4), (5, 6), (7, 8), (1, 3), (2, 4), (5, 7), (6, 8), (1, 5), (2, 6), (3, 7), (4, 8)])
-    # node 1 excluded: it keeps a single self loop; no edge starts at it, and no edge ends at an excluded node
-    nt = np.zeros(8, int); nt[0] = 9; nt[7] = 9
-    e = ra.create_edges([2, 2, 2], nt, [9])
-    assert e.count([1, 1]) == 1 and e.count([8, 8]) == 1
-    assert all(a == b or (a not in (1, 8) and b not in (1, 8)) for a, b in e)
-    assert len(e) == 2 + 6                       # 12 cube edges minus the 3 at node 1 and the 3 at node 8, plus two self loops
-
-
-def test_filter_edges_add_targets_preprocess():
-    from mgn_amd import reference_api as ra
-    edges = [[1, 2], [2, 3], [3, 4], [4, 1]]
-    assert ra.filter_edges(edges, [0, 5, 0, 0], [5]) == [[3, 4], [4, 1]]
-    assert ra.filter_edges(edges, [0, 0, 0, 0], [], exclude_node_indices=[4]) == [[1, 2], [2, 3]]
-    T, N = 5, 6
-    data = {"velocity": np.arange(T * N * 2, dtype=np.float32).reshape(T, N, 2), "mesh_pos": np.ones((T, N, 2), np.float32),
-            "node_type": np.tile(np.array([0, 0, 4, 4, 0, 6])[None, :, None], (T, 1, 1)), "dt": np.float32(0.01) * np.ones((1,)),
-            "target|old": np.zeros((T, N, 2), np.float32)}
-    full = data["velocity"].copy()
-    ra.add_targets(data, ["velocity"])
-    assert data["velocity"].shape[0] == T - 1 and np.array_equal(data["velocity"], full[:-1])
-    assert np.array_equal(data["target|velocity"], full[1:]) and "target|mesh_pos" not in data
-    assert data["mesh_pos"].shape[0] == T - 1 and data["node_type"].shape[0] == T - 1
-    assert data["target|old"].shape[0] == T and data["dt"].shape == (1,)
-    before = data["velocity"].copy()
-    with pytest.raises(ValueError):
-        ra.preprocess(dict(data), ["velocity"], [0.1, 0.2], [0])
-    ra.preprocess(data, ["velocity"], [0.5], [0])
-    d = data["velocity"] - before
-    noisy = np.isin(data["node_type"][0].reshape(-1), [0])
-    assert np.all(d[:, ~noisy, :] == 0) and np.all(np.abs(d[:, noisy, :]) > 0) and 0.2 < d[:, noisy, :].std() < 0.9
-    keep = {k: np.asarray(v).copy() for k, v in data.items()}
-    ra.preprocess(data, [], [0.0], [0], random_order=True)
-    perm = [int(np.nonzero((keep["velocity"] == data["velocity"][i]).all(axis=(1, 2)))[0][0]) for i in range(T - 1)]
-    assert sorted(perm) == list(range(T - 1))
-    for k in ("mesh_pos", "node_type", "target|velocity"):          # every key is shuffled by the same permutation
-        assert np.array_equal(data[k], keep[k][perm])
-    assert np.array_equal(data["dt"], keep["dt"])
