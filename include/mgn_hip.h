@@ -59,7 +59,13 @@ typedef struct mgn_config {
     int32_t n_edge_sets;   /* 0 or 1: the reference's single edge set (FeatureGraph, src/graph.jl:87-96);          */
                            /* 2: mesh edges + world edges (MGN-spec "per edge set"; flag_simple-shaped, BASELINE cfg-3) */
     int32_t Fe2;           /* edge input width of the second set (used when n_edge_sets == 2)                      */
+    int32_t ln_mode;       /* mgn_ln_mode: which LayerNorm GraphNetCore / Lux compute (the sources are not vendored:     */
+                           /* julia/spec_probe.jl tells).  MGN_LN_VAR_EPS (0, MGN-spec v1): (x - mean) / sqrt(var + eps);  */
+                           /* MGN_LN_STD_EPS: (x - mean) / (sqrt(var) + eps).  eps = 1e-5, biased variance, per row.       */
+                           /* Forward path only: mgn_step / mgn_ode_vjp are written for MGN_LN_VAR_EPS                     */
 } mgn_config;
+
+typedef enum { MGN_LN_VAR_EPS = 0, MGN_LN_STD_EPS = 1 } mgn_ln_mode;
 
 #define MGN_MAX_EDGE_SETS 2
 

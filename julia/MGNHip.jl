@@ -20,6 +20,7 @@ struct MgnConfig            # mirrors `mgn_config` (include/mgn_hip.h)
     Fn::Int32; Fe::Int32; O::Int32; L::Int32; hidden_layers::Int32; mps::Int32
     dtype::Int32; rank::Int32; nranks::Int32; device::Int32
     n_edge_sets::Int32; Fe2::Int32      # 1, 0: the reference's single edge set (src/graph.jl:87-96)
+    ln_mode::Int32                      # 0: (x - mean) / sqrt(var + eps); 1: (x - mean) / (sqrt(var) + eps) -- see julia/spec_probe.jl
 end
 
 function check(h::Ptr{Cvoid}, rc::Cint)
@@ -57,9 +58,10 @@ end
 
 # `rank` / `nranks`: this process's partition of an edge-cut mesh (one process per GPU; see comm_init!).  The reference
 # itself is single-device (src/MeshGraphNets.jl:255-263).
+# `ln_mode`: what julia/spec_probe.jl reports for the installed GraphNetCore / Lux (0 unless it says otherwise).
 function GraphNetwork(quantities, dims, e_norm, n_norm, o_norm, outputs, mps, layer_size, hidden_layers, ps; device = -1,
-        rank = 0, nranks = 1)
-    cfg = MgnConfig(quantities, dims + 1, outputs, layer_size, hidden_layers, mps, 0, rank, nranks, device, 1, 0)
+        rank = 0, nranks = 1, ln_mode = 0)
+    cfg = MgnConfig(quantities, dims + 1, outputs, layer_size, hidden_layers, mps, 0, rank, nranks, device, 1, 0, ln_mode)
     h = Ref{Ptr{Cvoid}}(C_NULL)
     rc = ccall((:mgn_create, LIB), Cint, (Ref{MgnConfig}, Ref{Ptr{Cvoid}}), cfg, h)
     rc == 0 || error(unsafe_string(ccall((:mgn_last_error, LIB), Cstring, (Ptr{Cvoid},), C_NULL)))

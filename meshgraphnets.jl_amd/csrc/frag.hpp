@@ -315,6 +315,17 @@ DEVINL void mfma_chunk_split(f32x16 (&acc)[NT], const f32x16 (&in)[NT], const fl
     MFMA_CHAIN_END(acc, NT);
 }
 
+// LayerNorm variant (spec_variant): slot T_LN of a table block holds (eps_in, eps_out) and
+//     rstd = 1 / (sqrt(var + eps_in) + eps_out).
+// MGN-spec v1 is (1e-5, 0): (x - mean) / sqrt(var + eps) -- bitwise what 1 / sqrtf(var + eps) gives (adding +0 is exact);
+// mgn_config.ln_mode = MGN_LN_STD_EPS makes it (0, 1e-5): (x - mean) / (std + eps), the form some LuxLib 0.5 releases used.
+// `gamma`: the block's T_GAMMA slot (L floats per slot).
+DEVINL float ln_rstd(float var, const float* gamma, int L) {
+    const float* p = gamma + (T_LN - T_GAMMA) * L;
+    return 1.0f / (sqrtf(var + p[0]) + p[1]);
+}
+DEVINL float ln_rstd_at(float var, const float* lnp) { return 1.0f / (sqrtf(var + lnp[0]) + lnp[1]); }   // lnp: the T_LN slot itself
+
 // LayerNorm over the row's L features: 16*NT in this lane + 16*NT in lane^32.  Biased variance.
 template <int NT>
 DEVINL void layer_norm_frag(f32x16 (&x)[NT], const float* gamma, const float* beta, int h) {
@@ -336,7 +347,7 @@ DEVINL void layer_norm_frag(f32x16 (&x)[NT], const float* gamma, const float* be
             q += d * d;
         }
     q += __shfl_xor(q, 32, 64);
-    const float rstd = 1.0f / sqrtf(q * invL + LN_EPS);
+    const float rstd = ln_rstd(q * invL, gamma, 32 * NT);
     const f32x4* g4 = reinterpret_cast<const f32x4*>(gamma) + h;
     const f32x4* b4 = reinterpret_cast<const f32x4*>(beta) + h;
 #pragma unroll
@@ -479,7 +490,7 @@ DEVINL void coop_layer_norm(f32x16& mine, const f32x16 (&full)[4], const float* 
             q += d * d;
         }
     q += __shfl_xor(q, 32, 64);
-    const float rstd = 1.0f / sqrtf(q * (1.0f / 128) + LN_EPS);
+    const float rstd = ln_rstd(q * (1.0f / 128), gamma, 128);
     f32x16 gq, bq;
     tab_quarter(gq, gamma, t, h);
     tab_quarter(bq, beta, t, h);
@@ -487,8 +498,8 @@ DEVINL void coop_layer_norm(f32x16& mine, const f32x16 (&full)[4], const float* 
     for (int k = 0; k < 16; ++k) mine[k] = (mine[k] - mean) * rstd * gq[k] + bq[k];
 }
 
-// same with gamma / beta quarters already in registers
-DEVINL void coop_layer_norm_reg(f32x16& mine, const f32x16 (&full)[4], const f32x16& gq, const f32x16& bq) {
+// same with gamma / beta quarters already in registers (lnp: the block's T_LN slot)
+DEVINL void coop_layer_norm_reg(f32x16& mine, const f32x16 (&full)[4], const f32x16& gq, const f32x16& bq, const float* lnp) {
     float s = 0.f;
 #pragma unroll
     for (int u = 0; u < 4; ++u)
@@ -505,7 +516,7 @@ DEVINL void coop_layer_norm_reg(f32x16& mine, const f32x16 (&full)[4], const f32
             q += d * d;
         }
     q += __shfl_xor(q, 32, 64);
-    const float rstd = 1.0f / sqrtf(q * (1.0f / 128) + LN_EPS);
+    const float rstd = ln_rstd_at(q * (1.0f / 128), lnp);
 #pragma unroll
     for (int k = 0; k < 16; ++k) mine[k] = (mine[k] - mean) * rstd * gq[k] + bq[k];
 }

@@ -10,7 +10,8 @@ constexpr int TILE = 32;        // rows (edges or nodes) per wave tile == MFMA 3
 constexpr int MAX_CHUNKS = 9;   // weight chunks (L x L, fragment order) a fused kernel may chain
 
 // Table slots (each L floats, fragment order) inside a kernel's `tabs` block.
-enum { T_B1 = 0, T_B2, T_B3, T_GAMMA, T_BETA, T_BQ, T_COUNT };
+// T_LN: the LayerNorm variant as two numbers (eps_in, eps_out): rstd = 1 / (sqrt(var + eps_in) + eps_out)  (frag.hpp: ln_rstd)
+enum { T_B1 = 0, T_B2, T_B3, T_GAMMA, T_BETA, T_BQ, T_LN, T_COUNT };
 
 // General hidden-layer count (reference Args.hidden_layers, src/MeshGraphNets.jl:35-38; MGN-spec: h hidden layers = h + 1 Dense).
 // The Dense layers AFTER the first one of an MLP: chunk[0 .. nmid-1] = the L x L middle layers (each followed by ReLU),

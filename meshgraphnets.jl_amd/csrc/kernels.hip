@@ -392,7 +392,7 @@ __global__ __launch_bounds__(256, 2) void k_edge_coop(const EdgeArgs a) {
         coop_chain_primed<FENCE>(acc, in, a.chunk_t[1] + tq * 4096, lane, ring3);  // layer 3
         coop_exchange(in, acc, xch0, wave, lane);                           // full pre-LN row (for the statistics)
         STAMP(5);
-        coop_layer_norm_reg(acc, in, gq, bq);                               // acc = this wave's quarter of e'
+        coop_layer_norm_reg(acc, in, gq, bq, a.tabs + T_LN * L);                               // acc = this wave's quarter of e'
         xq += acc;
         if (valid) store_quarter(etile, STRIDE_TILE, tq, xq);
         STAMP(6);
@@ -636,7 +636,7 @@ DEVINL void c16m_exchange(f32x4 (&full)[RT][8], const f32x4 (&mine)[RT][2], f32x
 // (sum, then sum of squared deviations), each a 32-feature partial per wave combined through red[t][wave][row] in LDS -- instead of
 // a third all-gather of the full rows and 4 x redundant statistics.
 template <int RT>
-DEVINL void c16m_layer_norm(f32x4 (&mine)[RT][2], float* red, const f32x4 (&g)[2], const f32x4 (&b)[2], int wave, int n) {
+DEVINL void c16m_layer_norm(f32x4 (&mine)[RT][2], float* red, const f32x4 (&g)[2], const f32x4 (&b)[2], int wave, int n, const float* lnp) {
     float mean[RT], rstd[RT];
 #pragma unroll
     for (int t = 0; t < RT; ++t) {
@@ -672,7 +672,7 @@ DEVINL void c16m_layer_norm(f32x4 (&mine)[RT][2], float* red, const f32x4 (&g)[2
 #pragma unroll
     for (int t = 0; t < RT; ++t) {
         const float v = (red2[(t * 4 + 0) * 16 + n] + red2[(t * 4 + 1) * 16 + n]) + (red2[(t * 4 + 2) * 16 + n] + red2[(t * 4 + 3) * 16 + n]);
-        rstd[t] = 1.0f / sqrtf(v * (1.0f / 128) + LN_EPS);
+        rstd[t] = ln_rstd_at(v * (1.0f / 128), lnp);
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -780,7 +780,7 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
         for (int t = 0; t < RT; ++t) { acc[t][0] = tb3[0]; acc[t][1] = tb3[1]; }
         c16m_chain<RT>(acc, x, w3, lane, g1);                        // layer 3
         STAMP16(5);
-        c16m_layer_norm<RT>(acc, red, tg, tb, wave, n);              // acc = this wave's slice of e'
+        c16m_layer_norm<RT>(acc, red, tg, tb, wave, n, tabs + T_LN * L);              // acc = this wave's slice of e'
         STAMP16(6);
 #pragma unroll
         for (int t = 0; t < RT; ++t) {
@@ -965,7 +965,7 @@ __global__ __launch_bounds__(256, 2) void k_node_coop16(const NodeArgs a) {
             acc[0][0] = tb3[0];
             acc[0][1] = tb3[1];
             c16m_chain<1>(acc, full, wt(1), lane, r3);               // layer 3
-            c16m_layer_norm<1>(acc, red, tg, tb, wave, n);
+            c16m_layer_norm<1>(acc, red, tg, tb, wave, n, tabs + T_LN * L);
             STAMP16(5);
             acc[0][0] = c16_round<BF>(acc[0][0] + vs[0][0]);         // v <- v + v'  (this wave's slice; the value the store keeps)
             acc[0][1] = c16_round<BF>(acc[0][1] + vs[0][1]);
@@ -1605,7 +1605,7 @@ DEVINL void layer_norm_frag_pk(f32x16 (&x)[4], const float* gamma, const float* 
         }
     float q = q2[0] + q2[1];
     q += __shfl_xor(q, 32, 64);
-    const float rstd = 1.0f / sqrtf(q * invL + LN_EPS);
+    const float rstd = ln_rstd(q * invL, gamma, 128);
     const f32x2 r2 = {rstd, rstd};
     const f32x4* g4 = reinterpret_cast<const f32x4*>(gamma) + h;
     const f32x4* b4 = reinterpret_cast<const f32x4*>(beta) + h;

@@ -54,6 +54,7 @@ bool cfg_ok(const mgn_config* c, std::string& why) {
     if (c->nranks < 1 || c->rank < 0 || c->rank >= c->nranks) { why = "bad rank/nranks"; return false; }
     if (c->n_edge_sets < 0 || c->n_edge_sets > MAX_EDGE_SETS) { why = "n_edge_sets must be 0, 1 or 2"; return false; }
     if (c->n_edge_sets == 2 && c->Fe2 < 1) { why = "Fe2 must be >= 1 with two edge sets"; return false; }
+    if (c->ln_mode != MGN_LN_VAR_EPS && c->ln_mode != MGN_LN_STD_EPS) { why = "ln_mode must be MGN_LN_VAR_EPS or MGN_LN_STD_EPS"; return false; }
     return true;
 }
 
@@ -619,10 +620,14 @@ int mgn_set_params(mgn_handle* h, const float* packed, size_t n) try {
     auto add_tabs = [&](const float* b1, const float* b2, const float* b3, const float* ga, const float* be, const float* bq) {
         const size_t off = f.size();
         f.resize(off + 2 * TB);          // fragment order, then natural feature order (16-row kernels)
-        const float* src[T_COUNT] = {b1, b2, b3, ga, be, bq};
+        const float* src[T_COUNT] = {b1, b2, b3, ga, be, bq, nullptr};
         for (int t = 0; t < T_COUNT; ++t) {
             pack_tab(f.data() + off + (size_t)t * L, src[t], L);
             for (int i = 0; i < L; ++i) f[off + TB + (size_t)t * L + i] = src[t] ? src[t][i] : 0.f;
+        }
+        for (int blk = 0; blk < 2; ++blk) {                    // T_LN: (eps_in, eps_out) of the LayerNorm variant (frag.hpp: ln_rstd)
+            f[off + blk * TB + (size_t)T_LN * L + 0] = c.ln_mode == MGN_LN_STD_EPS ? 0.f : 1e-5f;
+            f[off + blk * TB + (size_t)T_LN * L + 1] = c.ln_mode == MGN_LN_STD_EPS ? 1e-5f : 0.f;
         }
         return off;
     };

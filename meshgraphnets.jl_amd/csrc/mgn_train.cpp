@@ -118,6 +118,7 @@ int pack_training_weights(mgn_engine* h) {
             pack_tab(f.data() + off + (size_t)T_GAMMA * L, p + m.gamma, L);
             pack_tab(f.data() + off + (size_t)T_BETA * L, p + m.beta, L);
         }
+        f[off + (size_t)T_LN * L] = 1e-5f;                     // (eps_in, eps_out) = (1e-5, 0): MGN_LN_VAR_EPS, the only mode trained here
         return off;
     };
     auto build = [&](const MlpOff& m, bool need_input_grad) {
@@ -271,6 +272,8 @@ int train_prepare(mgn_handle* h, const char* who, size_t n_grads) {
     if (c.nranks != 1) return fail(h, MGN_E_STATE, "%s drives one partition", who);
     if (h->nsets != 1) return fail(h, MGN_E_STATE, "%s mirrors the reference's single-edge-set model (src/strategies.jl:418-422)", who);
     if (c.dtype != MGN_F32) return fail(h, MGN_E_STATE, "%s computes in fp32: create the handle with dtype MGN_F32", who);
+    if (c.ln_mode != MGN_LN_VAR_EPS)
+        return fail(h, MGN_E_UNSUPPORTED, "%s: the reverse pass is written for ln_mode = MGN_LN_VAR_EPS (the forward path has both)", who);
     if (c.hidden_layers != 2)
         return fail(h, MGN_E_UNSUPPORTED, "%s is implemented for hidden_layers = 2 (the reference's default, examples/cylinder_flow/cylinder_flow.jl:17); "
                                           "the forward path supports 1 .. 4", who);

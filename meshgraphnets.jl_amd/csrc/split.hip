@@ -454,7 +454,7 @@ __global__ __launch_bounds__(512, 2) void k_edge_ring(const EdgeArgs a) {
                     q += d * d;
                 }
             q += __shfl_xor(q, 32, 64);
-            const float rstd = 1.0f / sqrtf(q * invL + LN_EPS);
+            const float rstd = ln_rstd_at(q * invL, tb + T_LN * L);
             const f32x4* g4 = reinterpret_cast<const f32x4*>(tb + T_GAMMA * L) + h;
             const f32x4* b4 = reinterpret_cast<const f32x4*>(tb + T_BETA * L) + h;
 #pragma unroll

@@ -199,10 +199,22 @@ def init_params(Fn, Fe, O, L, hidden_layers, mps, seed=1234, ln_jitter=0.0, Fe2=
 # --------------------------------------------------------------------------------------------
 # Encode - Process - Decode  (mgn.model(graph, ps, st) at src/solve.jl:200)
 # --------------------------------------------------------------------------------------------
+# spec_variant switches (julia/spec_probe.jl tells which one GraphNetCore 0.3 / Lux 0.5 really compute).
+# Module-level on purpose: every function of the oracle (forward, reverse mode, rollout) follows them; tests set and restore them.
+#   LN_MODE: 0 = (x - mean) / sqrt(var + eps)  [MGN-spec v1]     1 = (x - mean) / (sqrt(var) + eps)
+#   LN_DIMS: "row" = statistics per node / edge over its L features [MGN-spec v1]
+#            "all" = statistics over the WHOLE array, rows included (Lux 0.5 LayerNorm(shape) with dims = Colon());
+#                    oracle only: a different model, not an engine mode (forward functions; the reverse mode assumes "row")
+LN_MODE = 0
+LN_DIMS = "row"
+
+
 def layer_norm(x, gamma, beta):
-    mu = x.mean(-1, keepdims=True)
-    var = ((x - mu) ** 2).mean(-1, keepdims=True)  # biased variance
-    return (x - mu) / np.sqrt(var + LN_EPS) * gamma + beta
+    ax = -1 if LN_DIMS == "row" else None
+    mu = x.mean(ax, keepdims=True)
+    var = ((x - mu) ** 2).mean(ax, keepdims=True)  # biased variance
+    den = np.sqrt(var + LN_EPS) if LN_MODE == 0 else np.sqrt(var) + LN_EPS
+    return (x - mu) / den * gamma + beta
 
 
 def mlp(x, p, hidden_layers):

@@ -186,6 +186,30 @@ def gold_hidden_layers():
     np.savez_compressed(os.path.join(HERE, "gold_f_hidden_layers.npz"), **d)
 
 
+def gold_ln_variants():
+    """GOLD-G: the [GNC-unverified] LayerNorm choices as data (spec_variant; julia/spec_probe.jl tells which
+    one the installed GraphNetCore / Lux compute).  Same inputs and parameters as GOLD-A-sized L = 128, mps = 3; three outputs:
+    MGN-spec v1, the (std + eps) denominator (engine: ln_mode = 1), and whole-array statistics (oracle only)."""
+    pos, cells, s, r = mesh()
+    N, E = pos.shape[0], s.size
+    L, mps = 128, 3
+    cfg = dict(Fn=9, Fe=3, O=2, L=L, hidden_layers=2, mps=mps)
+    ps = orc.init_params(9, 3, 2, L, 2, mps, seed=SEED + 7, ln_jitter=0.1)
+    rng = np.random.default_rng(SEED + 7)
+    nf = rng.standard_normal((N, 9)).astype(np.float32)
+    ef = rng.standard_normal((E, 3)).astype(np.float32)
+    d = dict(L=L, mps=mps, seed=SEED + 7, jitter=0.1, params_sha256=sha(ps), senders=s, receivers=r, nf=nf, ef=ef)
+    for name, mode, dims in (("out_v1", 0, "row"), ("out_std_eps", 1, "row"), ("out_whole_array", 0, "all")):
+        orc.LN_MODE, orc.LN_DIMS = mode, dims
+        try:
+            d[name] = orc.forward(ps, cfg, nf, ef, s, r)
+        finally:
+            orc.LN_MODE, orc.LN_DIMS = 0, "row"
+    np.savez_compressed(os.path.join(HERE, "gold_g_ln_variants.npz"), **d)
+    print("gold_g_ln_variants.npz", "v1 vs std_eps", np.abs(d["out_v1"] - d["out_std_eps"]).max(), "v1 vs whole-array",
+          np.abs(d["out_v1"] - d["out_whole_array"]).max())
+
+
 def kats():
     """Known-answer tests stored as data so every implementation reads the same file."""
     tri1 = np.array([[0, 1, 2]], np.int32)
@@ -203,6 +227,9 @@ if __name__ == "__main__":
     if "--hidden-layers" in sys.argv:
         gold_hidden_layers()
         sys.exit(0)
+    if "--ln-variants" in sys.argv:
+        gold_ln_variants()
+        sys.exit(0)
     if "--cyl-rollout" in sys.argv:       # ~40 minutes of float64 NumPy on 8 cores: generated separately
         gold_cyl_rollout()
         sys.exit(0)
@@ -211,4 +238,5 @@ if __name__ == "__main__":
     gold_rollout()
     gold_two_sets()
     gold_hidden_layers()
+    gold_ln_variants()
     kats()

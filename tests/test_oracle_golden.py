@@ -37,6 +37,26 @@ def test_oracle_reproduces_golden(name, snaps):
         assert rel_max(lat[k][1], g[f"e_after_{k}"]) < 1e-6
 
 
+def test_oracle_ln_variants_gold_g():
+    """GOLD-G: the LayerNorm spec variants as fixtures.  The (std + eps) denominator is a ~1e-5 relative
+    effect; whole-array statistics are a different model -- the fixture is there so that the day julia/spec_probe.jl names one of
+    them, the expected numbers already exist."""
+    g = load("gold_g_ln_variants.npz")
+    ps = orc.init_params(9, 3, 2, int(g["L"]), 2, int(g["mps"]), seed=int(g["seed"]), ln_jitter=float(g["jitter"]))
+    assert hashlib.sha256(ps.tobytes()).hexdigest() == str(g["params_sha256"])
+    cfg = dict(Fn=9, Fe=3, O=2, L=int(g["L"]), hidden_layers=2, mps=int(g["mps"]))
+    for name, mode, dims in (("out_v1", 0, "row"), ("out_std_eps", 1, "row"), ("out_whole_array", 0, "all")):
+        orc.LN_MODE, orc.LN_DIMS = mode, dims
+        try:
+            out = orc.forward(ps, cfg, g["nf"], g["ef"], g["senders"], g["receivers"])
+        finally:
+            orc.LN_MODE, orc.LN_DIMS = 0, "row"
+        assert rel_max(out, g[name]) < 1e-12, name
+    d1 = rel_max(g["out_std_eps"], g["out_v1"])
+    d2 = rel_max(g["out_whole_array"], g["out_v1"])
+    assert 1e-7 < d1 < 1e-3 and d2 > 1e-2, (d1, d2)
+
+
 def test_oracle_reproduces_gold_c_two_edge_sets():
     """GOLD-C: two edge sets (flag_simple-shaped widths).  Also pins that an EMPTY second set only contributes its
     zero aggregate (the node MLP still has the wider first layer)."""
