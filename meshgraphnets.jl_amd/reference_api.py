@@ -17,6 +17,8 @@ parse_edges are 0-based here; GraphNetwork(index_base=...) tells the engine whic
 """
 from __future__ import annotations
 
+import os
+
 import numpy as np
 
 from .engine import FeatureGraph
@@ -331,6 +333,28 @@ def load_dataset(path, is_training):
 
 
 # ---- trajectory preparation (host side of SURVEY.md N3 / N4; arrays are [T][count][dim] like parse_data's) -------------
+def dump_rollout(dump_dir, ti, mesh_pos, gt, prediction, error, timesteps, cells=None):
+    """The evaluation output of one trajectory (reference src/MeshGraphNets.jl:630-637: traj_ops / errors / timesteps / cells of
+    eval_network!) as a raw dump that julia/write_trajectories.jl turns into the reference's `trajectories.h5`
+    (`/<ti>/<name>/{data,size}`, src/MeshGraphNets.jl:638-669; HDF5 is not available on the engine side).
+    Arrays arrive in this module's [time][count][feat] / [count][feat] order and are written as the bytes of the Julia arrays
+    (feat x count x time: the same bytes); `size` is the Julia size.  ti is 1-based like the reference's trajectory counter."""
+    import json
+    d = os.path.join(str(dump_dir), str(int(ti)))
+    os.makedirs(d, exist_ok=True)
+    manifest = {}
+    items = {"mesh_pos": (mesh_pos, F32), "gt": (gt, F32), "prediction": (prediction, F32), "error": (error, F32), "timesteps": (timesteps, F32)}
+    if cells is not None:
+        items["cells"] = (cells, np.int32)
+    for name, (arr, dt) in items.items():
+        a = np.ascontiguousarray(arr, dtype=dt)
+        a.tofile(os.path.join(d, name + ".bin"))
+        manifest[name] = {"dtype": "Int32" if dt is np.int32 else "Float32", "size": list(reversed(a.shape))}
+    with open(os.path.join(d, "manifest.json"), "w") as f:
+        json.dump(manifest, f)
+    return d
+
+
 def solver_training_euler(rhs, vjp, x0, gt, dt, val_mask, n_scale):
     """What train_step(::SolverStrategy) computes for SolverTraining with a fixed-step Euler solver (reference
     src/strategies.jl:175-196, 257-292), written as the discrete adjoint the sensitivity algorithm evaluates through VJPs of

@@ -158,3 +158,19 @@ def test_corruption_is_detected(lib_built, tmp_path):
         next(rd)
     with pytest.raises(FileNotFoundError):
         ra.TFRecordReader(tmp_path / "nope.tfrecord")
+
+
+def test_dump_rollout_layout(tmp_path):
+    """N4 remainder: the raw dump julia/write_trajectories.jl converts to trajectories.h5 (reference src/MeshGraphNets.jl:638-669)
+    holds the bytes and the sizes of the Julia arrays"""
+    import json
+    T, N, O = 3, 5, 2
+    pred = np.arange(T * N * O, dtype=np.float32).reshape(T, N, O)
+    d = ra.dump_rollout(tmp_path, 1, np.zeros((N, 2), np.float32), pred, pred + 1, np.ones((T, O), np.float32), np.arange(T, dtype=np.float32),
+                        cells=np.zeros((4, 3), np.int32))
+    m = json.load(open(os.path.join(d, "manifest.json")))
+    assert m["prediction"] == {"dtype": "Float32", "size": [O, N, T]} and m["cells"]["dtype"] == "Int32" and m["cells"]["size"] == [3, 4]
+    raw = np.fromfile(os.path.join(d, "prediction.bin"), np.float32)
+    # Julia reads it column-major as (O x N x T): element (o, n, t) at o + O (n + N t)  ==  our [t][n][o]
+    assert raw[1 + O * (2 + N * 1)] == pred[1, 2, 1] + 1
+
