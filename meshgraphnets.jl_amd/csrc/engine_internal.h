@@ -123,7 +123,8 @@ struct mgn_engine {
     DevBuf wbf, bV;
     struct BfStepOff { size_t e_ch[MAX_EDGE_SETS][3], n_ch[7], p1_ch[2]; };
     std::vector<BfStepOff> bsoff;
-    // opt-in fp32-on-bf16-matrix-cores edge kernel (k_edge_split): per step and set, the three chunks as 3 bf16 pieces each
+    // split path (csrc/split.hip: fp32 storage, products on the bf16 matrix cores): per step and set the three edge chunks, per step the
+    // node MLP's four and the projection's two, as 3 bf16 pieces each
     DevBuf wsp;
     struct SplitOff { size_t e_ch[MAX_EDGE_SETS][3]; size_t n_ch[6]; bool have_n; };
     std::vector<SplitOff> spoff;

@@ -2370,7 +2370,8 @@ int mgn_halo_exchange_host(mgn_handle* h, const float* own_rows, float* halo_row
 // kernels, 2 all-streaming, 3 cooperative 4-wave tiles.  Returns the previous value.
 int mgn_debug_kernel_path(int path) { return set_kernel_path(path); }
 int mgn_debug_c16_row_tiles(int rt) { return set_c16_row_tiles(rt); }
-// 1: large fp32 edge launches run k_edge_split (the three layers on the bf16 matrix cores at fp32 accuracy); returns the old value
+// large fp32 launches: 1 split path (k_edge_ring + k_node_split + k_project_split: bf16 matrix cores at fp32 accuracy; the default),
+// 2 the same with k_edge_split2, 0 fp32-MFMA kernels; returns the old value
 int mgn_debug_fp32_split(int on) { return set_fp32_split(on); }
 
 int mgn_debug_edge_stamps(mgn_handle* h, int32_t k, unsigned long long* out /* [32768] */) try {

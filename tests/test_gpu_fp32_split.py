@@ -1,6 +1,6 @@
-"""Opt-in edge kernel k_edge_split (MGN_FP32_SPLIT=1 / mgn_debug_fp32_split): the three L x L layers of the edge MLP on the bf16
-matrix cores at fp32 accuracy -- every fp32 operand split exactly into three bf16 pieces, six of the nine piece products kept.
-It must meet the SAME tolerances against the float64 oracle as the fp32-MFMA kernels (it is not a reduced-precision mode), on a
+"""The split path (csrc/split.hip; MGN_FP32_SPLIT / mgn_debug_fp32_split: 1 = k_edge_ring, the default, 2 = k_edge_split2; node side
+k_node_split + k_project_split in both): the L x L layers on the bf16 matrix cores at fp32 accuracy -- every fp32 operand split exactly
+into three bf16 pieces, six of the nine piece products kept.  It must meet the SAME tolerances against the float64 oracle as the fp32-MFMA kernels (it is not a reduced-precision mode), on a
 mesh large enough for the persistent kernels to be chosen, with ragged receiver runs, and with two edge sets."""
 import numpy as np
 import pytest
@@ -103,7 +103,7 @@ def test_split_ragged_receivers(split_on):
 
 
 def test_split_two_edge_sets(split_on):
-    """a cloth large enough for the persistent kernels (160 x 160: 25 600 nodes, mesh + world edges): k_edge_split per edge set"""
+    """a cloth large enough for the persistent kernels (160 x 160: 25 600 nodes, mesh + world edges): the split edge kernel per edge set"""
     import mgn_amd
     m = synth.mesh_flag(nx=160, ny=160, radius=0.012)
     N, E, E2 = m["mesh_pos"].shape[0], m["s"].size, m["s2"].size

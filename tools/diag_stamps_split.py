@@ -1,5 +1,6 @@
-"""Diagnostic: per-tile phase durations of k_edge_split from s_memtime stamps (a library built with -DMGN_DIAG_STAMPS:
-build.build_variant("stamps", ["-DMGN_DIAG_STAMPS"]), MGN_LIB_PATH=.../variants/stamps.so, MGN_FP32_SPLIT=1)."""
+"""Diagnostic: per-tile phase durations of the split edge kernels (k_edge_ring, MGN_FP32_SPLIT=1; k_edge_split2, =2) from s_memtime
+stamps.  Needs a library built with -DMGN_DIAG_STAMPS: python tools/build_variant.py stamps -DMGN_DIAG_STAMPS, then
+MGN_LIB_PATH=<repo>/meshgraphnets.jl_amd/lib/variants/stamps.so python tools/diag_stamps_split.py [nx]."""
 import ctypes as C, os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -13,28 +14,9 @@ out = np.zeros(32768, np.uint64)
 f = eng.lib.mgn_debug_edge_stamps; f.restype = C.c_int; f.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
 assert f(eng.h, 1, out.ctypes.data_as(C.c_void_p)) == 0
 st = out[:4 * 8 * 24 * 8].reshape(4, 8, 24, 8).astype(np.int64)
-names = ["split1", "L1", "relu+split2", "L2", "relu+split3", "L3", "reload e+LN+resid+store", "scan+tails+turnover(to next start)"]
-if os.environ.get("MGN_FP32_SPLIT") in ("2", "4"):
-    names = ["L1", "tab", "L2", "tab", "L3", "reload e+LN", "resid+store", "scan+tails+turnover(to next start)"]
-if os.environ.get("MGN_RING_EPI"):
+names = ["L1", "tab", "L2", "tab", "L3", "reload e+LN", "resid+store", "scan+tails+turnover(to next start)"]
+if os.environ.get("MGN_RING_EPI"):      # library built with -DMGN_RING_EPI_STAMPS as well: the epilogue of k_edge_ring in detail
     names = ["chains", "LN", "resid+store e", "next e req + scan setup", "scan", "tail stores", "Q request", "to next tile top"]
-if os.environ.get("MGN_FP32_SPLIT") == "3" and os.environ.get("MGN_WS_K"):
-    # per-k-step stamps of one stage (library built with -DMGN_WS_DIAG_STAGE=n): slot s = the MFMAs of k-step s are issued
-    for b in range(2):
-        d = np.diff(st[b, :4, 2:20, :8], axis=-1)
-        for w in range(4):
-            print(f"block {b} wave {w}: cycles between k-step stamps 0..7:", [int(d[w, :, i].mean()) for i in range(7)],
-                  "iteration", int(np.diff(st[b, w, 2:20, 0]).mean()))
-    sys.exit(0)
-if os.environ.get("MGN_FP32_SPLIT") == "3":
-    names = ["S0 A.L1", "S1 B.L1", "S2 A.L2", "S3 B.L2", "S4 A.L3", "S5 B.L3", "rotate+barrier", "(to next S0)"]
-    for b in range(2):
-        ext = np.concatenate([st[b, :4, 2:20, :8], st[b, :4, 3:21, 0:1]], axis=-1)
-        d = np.diff(ext, axis=-1)
-        print(f"block {b}: mean cycles per stage (iterations 2..19; two tiles per iteration), rows = waves:")
-        for w in range(4):
-            print("  wave", w, {n: int(d[w, :, i].mean()) for i, n in enumerate(names)}, "iteration", int(np.diff(st[b, w, 2:20, 0]).mean()))
-    sys.exit(0)
 for b in range(2):
     ext = np.concatenate([st[b, :, 2:20, :8], st[b, :, 3:21, 0:1]], axis=-1)
     d = np.diff(ext, axis=-1)   # [wave][tile][phase]

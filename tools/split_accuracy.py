@@ -1,4 +1,4 @@
-"""Error against the float64 oracle of the fp32-MFMA edge kernel and of the opt-in bf16-split edge kernel (k_edge_split) on the same
+"""Error against the float64 oracle of the fp32-MFMA edge kernel and of the split path (csrc/split.hip; MGN_FP32_SPLIT 1 / 2) on the same
 inputs: max |x - ref| / max |ref| over node and edge latents after 1 and 15 processor steps (22 500-node mesh, L = 128)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
