@@ -250,15 +250,33 @@ DEVINL RingFrag ring_first(const u32x4* hi, const u32x4* ring, int lane) {
 // reloaded, as soon as the split has consumed them, with the two 16-byte pieces of k-step s + 2 of rf (piece m at rf[m * RFS]);
 // the pieces of k-steps 0 and 1 wait in a 16-register side buffer.  The last request goes out two k-steps before the layer ends;
 // `in` comes back holding rf's row in fragment order.  (In the epilogue these loads were two exposed memory round trips.)
-template <int W, int LYR, bool RELU, int RFS = 0>
+// When the requests go out (MGN_RING_REFILL_AT_REQUEST): 0 = two behind every k-step, side buffer at the top of the layer (the first
+// version); 1 = in batches of four right behind the window requests (vmcnt retires in order, so a request there is first waited for
+// at the NEXT window's LDS store, 5.4 k cycles later instead of 2.3-4.2 k): no gain, the e tile's latency is not what costs;
+// 2 (default) = one request every second step, and layer 3's side buffer requested the same way inside layer 2's last two k-steps
+// (NRFS, rf_next): 3.53 -> 3.46 ms.  What a request costs in the chain is its ISSUE: the eight waves are in lock-step, their
+// requests reach the CU's one memory pipeline together, and a wave whose request is not accepted issues no MFMA either (stamps:
+// every request adds ~500 cycles to its layer whether it hits L2 or not).
+template <int W, int LYR, bool RELU, int RFS = 0, int NRFS = 0>
 DEVINL void sp_layer_ring(f32x16 (&acc)[4], f32x16 (&in)[4], const u32x4* hi, const u32x4* hi_next, u32x4* ring, const RingSrc& src,
-                          RingFrag& nx, int lane, int tid, const f32x4* rf = nullptr) {
+                          RingFrag& nx, int lane, int tid, const f32x4* rf = nullptr, f32x4* side = nullptr,
+                          const f32x4* rf_next = nullptr) {
 #ifndef MGN_RING_ROT
 #define MGN_RING_ROT 2
 #endif
+#ifndef MGN_RING_REFILL_AT_REQUEST
+#define MGN_RING_REFILL_AT_REQUEST 2
+#endif
     constexpr int ROT = MGN_RING_ROT;            // k-steps between a register's release and the use of what it is refilled with
-    f32x4 side[2 * ROT];
-    if constexpr (RFS > 0) {
+#ifndef MGN_RING_SIDE_EARLY
+#define MGN_RING_SIDE_EARLY 1                // bit 0: layer 3's side buffer requested inside layer 2, bit 1: layer 1's in the epilogue before
+#endif
+    constexpr int MODE = MGN_RING_REFILL_AT_REQUEST;                  // 0: two requests behind each k-step, 1: with the window requests, 2: one per two steps
+    constexpr bool ATREQ = MODE == 1;
+    static_assert(MODE == 0 || ROT == 2, "the other schedules are written for a rotation of two k-steps");
+    f32x4 side_local[2 * ROT];
+    if constexpr (RFS > 0 && (MODE == 0 || !((MGN_RING_SIDE_EARLY >> (LYR == 0 ? 1 : 0)) & 1))) {
+        side = side_local;
 #pragma unroll
         for (int m = 0; m < 2 * ROT; ++m) side[m] = rf[m * RFS];
     }
@@ -284,6 +302,40 @@ DEVINL void sp_layer_ring(f32x16 (&acc)[4], f32x16 (&in)[4], const u32x4* hi, co
                 // hipcc hoists them out of the tile loop and spills them)
                 ld_m = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(src.mid[l2] + w2 * W * 64) + voff);
                 ld_l = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(src.lo[l2] + w2 * W * 64) + voff);
+                if constexpr (ATREQ && W == 8) {
+                    if constexpr (RFS > 0) {
+                        // the registers of k-steps s - 2 and s - 1 (released one and two k-steps ago: refilling k-step s's own as
+                        // well leaves the allocator nothing to work with, 70 spills)
+                        const int lo_k = s - 2, hi_k = s - 1;
+#pragma unroll
+                        for (int k = 0; k < 6; ++k)
+#pragma unroll
+                            for (int u = 0; u < 2; ++u) {
+                                if (k < lo_k || k > hi_k) continue;
+                                const f32x4 v = rf[(2 * (k + ROT) + u) * RFS];
+#pragma unroll
+                                for (int i = 0; i < 4; ++i) in[k >> 1][8 * (k & 1) + 4 * u + i] = v[i];
+                            }
+                    }
+                    if constexpr (NRFS > 0 && (MGN_RING_SIDE_EARLY & 1)) {
+                        if (s == 6) {
+#pragma unroll
+                            for (int m = 0; m < 2 * ROT; ++m) side[m] = rf_next[m * NRFS];
+                        }
+                    }
+                }
+            }
+            if constexpr (MODE == 2) {
+                if constexpr (RFS > 0) {
+                    if ((t & 1) && s < 8 - ROT) {                      // registers of k-step s (free since the step began), half t >> 1
+                        const f32x4 v = rf[(2 * (s + ROT) + (t >> 1)) * RFS];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) in[s >> 1][8 * (s & 1) + 4 * (t >> 1) + i] = v[i];
+                    }
+                }
+                if constexpr (NRFS > 0 && (MGN_RING_SIDE_EARLY & 1)) {
+                    if ((t & 1) && s >= 6) side[2 * (s - 6) + (t >> 1)] = rf_next[(2 * (s - 6) + (t >> 1)) * NRFS];
+                }
             }
             if (it + 1 < 32) {
                 const int gn = WPL * LYR + (it + 1) / W;
@@ -313,7 +365,7 @@ DEVINL void sp_layer_ring(f32x16 (&acc)[4], f32x16 (&in)[4], const u32x4* hi, co
             if (it % W == W - 1) ring_barrier();                       // window closed: every wave has read it, window gw + 2 is in LDS
         }
         p = n;
-        if constexpr (RFS > 0) {
+        if constexpr (RFS > 0 && MODE == 0) {
             // (the eight waves of a block run in lock-step: without a per-wave delay all sixteen gather instructions of a k-step
             // reach the CU's memory pipeline at once; 64 line visits each)
             if (s < 8 - ROT) {                                         // registers of k-step s <- pieces of k-step s + ROT
@@ -347,6 +399,34 @@ DEVINL void sp_layer_ring(f32x16 (&acc)[4], f32x16 (&in)[4], const u32x4* hi, co
                 asm volatile("v_fmac_f32_dpp %0, %0, %1 " CTRL " bound_ctrl:0" : "+v"(ACC[t_][k_]) : "v"(m_));               \
     } while (0)
 
+// the e tile leaves the chip once per step and comes back 3 GB later: cache policy of its stores / loads (A/B switches)
+#ifndef MGN_RING_ESTORE
+#define MGN_RING_ESTORE 0        // 0 plain, 1 nt, 2 sc1, 3 sc0 sc1
+#endif
+#ifndef MGN_RING_ELOAD
+#define MGN_RING_ELOAD 0         // 0 plain, 1 nt
+#endif
+DEVINL void ring_store_e(f32x4* p, const f32x16 (&x)[4]) {
+#pragma unroll
+    for (int m = 0; m < 16; ++m) {
+        f32x4 v;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = x[m >> 2][4 * (m & 3) + i];
+        f32x4* q = p + m * STRIDE_TILE;
+        if constexpr (MGN_RING_ESTORE == 1) __builtin_nontemporal_store(v, q);
+        else if constexpr (MGN_RING_ESTORE == 2) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(q), "v"(v) : "memory");
+        else if constexpr (MGN_RING_ESTORE == 3) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(q), "v"(v) : "memory");
+        else *q = v;
+    }
+}
+DEVINL void ring_load_e(f32x16 (&x)[4], const f32x4* p) {
+#pragma unroll
+    for (int m = 0; m < 16; ++m) {
+        const f32x4 v = MGN_RING_ELOAD ? __builtin_nontemporal_load(p + m * STRIDE_TILE) : p[m * STRIDE_TILE];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) x[m >> 2][4 * (m & 3) + i] = v[i];
+    }
+}
 #ifdef MGN_RING_EPI_STAMPS     // diagnostic: the eight stamp slots on the epilogue (1: chains done ... 7: turnover requested)
 #define CST(k) do {} while (0)
 #define EST(k) STAMP(k)
@@ -403,6 +483,12 @@ __global__ __launch_bounds__(512, 2) void k_edge_ring(const EdgeArgs a) {
         load_frag<NT>(acc, row_ptr(a.Q, ix.r >= 0 ? ix.r : 0, L, h0), STRIDE_ROW);
         load_frag<NT>(y, tile_ptr(a.Elat, clamp(tw.tile), L, lane0), STRIDE_TILE);
     }
+    f32x4 side[4];               // refill side buffer (sp_layer_ring): the first two k-steps of the P rows / of the e tile
+    {
+        const f32x4* p0 = row_ptr(a.P, ix.s, L, lane0 >> 5);
+#pragma unroll
+        for (int m = 0; m < 4; ++m) side[m] = p0[m * STRIDE_ROW];
+    }
     int stamp_tile = 0;
     (void)stamp_tile;
     for (int j = 0; j < iters; ++j, ++stamp_tile) {
@@ -415,22 +501,29 @@ __global__ __launch_bounds__(512, 2) void k_edge_ring(const EdgeArgs a) {
         const int r = ix.r >= 0 ? ix.r : 0;
         f32x4* etile = tile_ptr(a.Elat, tile, L, lane);
         u32x4* ring = ringbase + lane;
+#ifdef MGN_WHATIF          // diagnostic builds (wrong results): which memory stream costs what
+        const f32x4* etile_rd = (MGN_WHATIF & 1) ? tile_ptr(a.Elat, a.tile0 + wave, L, lane) : etile;
+        const int ps_row = (MGN_WHATIF & 4) ? (lane & 31) : ix.s;
+#else
+        const f32x4* etile_rd = etile;
+        const int ps_row = ix.s;
+#endif
         STAMP(0);
         __builtin_amdgcn_s_setprio(0);
         RingFrag nx = ring_first<W, 0>(l1h, ring, lane);
         // layer 1 (edge part): y = e tile in, P[s] out (acc entered with Q[r], which carries b1)
-        sp_layer_ring<W, 0, false, STRIDE_ROW>(acc, y, l1h, l2h, ring, src, nx, lane, tid, row_ptr(a.P, ix.s, L, h));
+        sp_layer_ring<W, 0, false, STRIDE_ROW>(acc, y, l1h, l2h, ring, src, nx, lane, tid, row_ptr(a.P, ps_row, L, h), side);
 #pragma unroll
         for (int t = 0; t < NT; ++t) acc[t] += y[t];
         CST(1);
         tab_frag<NT>(y, tb + T_B2 * L, h);
         CST(2);
-        sp_layer_ring<W, 1, true>(y, acc, l2h, l3h, ring, src, nx, lane, tid);      // layer 2 (ReLU folded into the split)
+        sp_layer_ring<W, 1, true, 0, STRIDE_TILE>(y, acc, l2h, l3h, ring, src, nx, lane, tid, nullptr, side, etile_rd);   // layer 2 (ReLU folded into the split)
         CST(3);
         tab_frag<NT>(acc, tb + T_B3 * L, h);
         CST(4);
         // layer 3: y = layer 2's output in, the e tile (for the residual) out
-        sp_layer_ring<W, 2, true, STRIDE_TILE>(acc, y, l3h, l1h, ring, src, nx, lane, tid, etile);
+        sp_layer_ring<W, 2, true, STRIDE_TILE>(acc, y, l3h, l1h, ring, src, nx, lane, tid, etile_rd, side);
         CST(5);
         EST(1);
         PHASE_FENCE();
@@ -472,10 +565,18 @@ __global__ __launch_bounds__(512, 2) void k_edge_ring(const EdgeArgs a) {
         EST(2);
 #pragma unroll
         for (int t = 0; t < NT; ++t) y[t] += acc[t];                 // e <- e + e'
-        if (valid) store_frag<NT>(etile, STRIDE_TILE, y);            // padding rows / tiles store nothing
+#if defined(MGN_WHATIF) && (MGN_WHATIF & 2)
+        if (valid && a.E < 0) store_frag<NT>(etile, STRIDE_TILE, y);
+#else
+        if (valid) ring_store_e(etile, y);                           // padding rows / tiles store nothing
+#endif
         CST(7);
         EST(3);
-        load_frag<NT>(y, tile_ptr(a.Elat, nxt, L, lane), STRIDE_TILE);   // the next tile's e, ahead of everything else of the turnover
+#if defined(MGN_WHATIF) && (MGN_WHATIF & 8)
+        load_frag<NT>(y, tile_ptr(a.Elat, a.tile0 + wave, L, lane), STRIDE_TILE);
+#else
+        ring_load_e(y, tile_ptr(a.Elat, nxt, L, lane));              // the next tile's e, ahead of everything else of the turnover
+#endif
         const int reff = ix.r >= 0 ? r : (-4 - c);
         const int rprev = __shfl_up(reff, 1, 32);
         const int rnext = __shfl_down(reff, 1, 32);
@@ -501,11 +602,26 @@ __global__ __launch_bounds__(512, 2) void k_edge_ring(const EdgeArgs a) {
         const bool sr = (c == 31) && (ix.r_after == reff);
         const bool to_carry = sl || sr;
         f32x4* dst = to_carry ? row_ptr(a.CARRY, (int64_t)2 * tile + (sl ? 0 : 1), L, h) : tile_ptr(a.AGG, r >> 5, L, 32 * h + (r & 31));
+#if defined(MGN_WHATIF) && (MGN_WHATIF & 32)
+        if (tail && a.E < 0) store_frag<NT>(dst, to_carry ? STRIDE_ROW : STRIDE_TILE, acc);
+#else
         if (tail) store_frag<NT>(dst, to_carry ? STRIDE_ROW : STRIDE_TILE, acc);
+#endif
         EST(6);
         PHASE_FENCE();
         // turnover: the next tile's layer-1 accumulator starts from Q[r] (P[s] arrives during the layer)
+#if defined(MGN_WHATIF) && (MGN_WHATIF & 16)
+        load_frag<NT>(acc, row_ptr(a.Q, lane & 31, L, h), STRIDE_ROW);
+#else
         load_frag<NT>(acc, row_ptr(a.Q, ixn.r >= 0 ? ixn.r : 0, L, h), STRIDE_ROW);
+#endif
+#if MGN_RING_REFILL_AT_REQUEST != 0 && (MGN_RING_SIDE_EARLY & 2)
+        {
+            const f32x4* pn = row_ptr(a.P, ixn.s, L, h);
+#pragma unroll
+            for (int m = 0; m < 4; ++m) side[m] = pn[m * STRIDE_ROW];
+        }
+#endif
         EST(7);
         ix = ixn;
         tw.tile += tw.stride;
