@@ -14,34 +14,53 @@ namespace mgn {
 
 namespace {
 
-// device offsets (floats into TrainState::w) of one MLP in training order
-struct TrainMlp {
-    const MlpOff* off = nullptr;
+// The training kernels (train.hip) run ONE shape: Dense - ReLU - Dense - ReLU - Dense (+ LayerNorm, + residual), the reference's
+// default hidden_layers = 2.  Other depths are expressed in that shape with identity slots, exactly (an identity product of an
+// fp32 row is that row; ReLU of a value that is already a ReLU output is that value, and its mask in the reverse pass is the
+// same mask):
+//   hidden_layers = 1:  [D0, I, D1]
+//   hidden_layers = 3:  [D0, I, I] -> [D1, D2, D3]        (the first block's output is ReLU(z0): no LayerNorm, no residual)
+//   hidden_layers = 4:  [D0, D1, I] -> [D2, D3, D4]
+// One such launch unit with its device offsets (floats into TrainState::w) in training order:
+struct TrainBlock {
     int nin = 1;                 // L-wide layer-1 input blocks
     int in_rows = 0;             // rows of W1 that exist (< L for the encoders: zero-padded chunk)
     size_t W1[3] = {0, 0, 0}, W2 = 0, W3 = 0, W2T = 0, W3T = 0, tabs = 0;
     size_t W1T[3] = {0, 0, 0};
-    bool has_w1t = false;
+    bool has_w1t = false, ln = false;
+    long gW[3] = {-1, -1, -1}, gb[3] = {-1, -1, -1};   // packed-parameter offsets of the three slots (-1: identity slot, nothing to learn)
+    long ggamma = -1, gbeta = -1;
+    int out_cols = 0;            // columns of slot 3 that exist (decoder: O)
 };
+struct TrainMlp {
+    int nblk = 1;
+    TrainBlock b[2];
+};
+// kept activations of one MLP instance: per block H1, H2, Y (arena offsets)
+struct Acts { size_t h[2][3] = {{0, 0, 0}, {0, 0, 0}}; };
 
 }  // namespace
 
 struct TrainState {
     bool packed = false, graph_ready = false;
-    bool factored = false;       // edge MLPs with a factored first layer (P = v W1s, Q = v W1r per node): large meshes
+    bool factored[MAX_EDGE_SETS] = {false, false};   // edge MLPs with a factored first layer (P = v W1s, Q = v W1r per node): large meshes
     bool recompute = false;      // processor MLPs keep only their inputs; H1 / H2 / Y are recomputed in the reverse pass
+    int nblk = 1;                // launch units per MLP (2 for hidden_layers 3, 4)
     DevBuf w;                    // training-order weights
-    std::vector<TrainMlp> mlp;   // 0 enc-node, 1 enc-edge, 2+2k edge k, 3+2k node k, last decoder
+    // enc-node, enc-edge (per set), per step: edge (per set), node; decoder
+    TrainMlp m_en, m_de, m_ee[MAX_EDGE_SETS];
+    std::vector<TrainMlp> m_pe[MAX_EDGE_SETS], m_pn;
     DevBuf arena, idx, grads, target, mask, loss;
     size_t arena_floats = 0;
-    int64_t cap_n = 0, cap_e = 0;
     // arena offsets (floats)
-    size_t nf_raw, ef_raw, nf_pad, ef_pad, enH[3], V0, eeH[3], E0, Enew, dH[3];
-    std::vector<size_t> eH[3], nH[3], Ek, Vk, agg;
-    static constexpr int GSETS = 4;   // gradient-buffer sets: the weight gradients of MLP i run beside the backward of MLPs i+1 .. i+3
+    size_t nf_raw, nf_pad, ef_raw[MAX_EDGE_SETS], ef_pad[MAX_EDGE_SETS], V0, Enew;
+    Acts a_en, a_de, a_ee[MAX_EDGE_SETS];
+    std::vector<Acts> a_pe[MAX_EDGE_SETS], a_pn;
+    std::vector<size_t> Ek[MAX_EDGE_SETS], Vk, agg[MAX_EDGE_SETS];
+    static constexpr int GSETS = 4;   // gradient-buffer sets: the weight gradients of unit i run beside the backward of units i+1 .. i+3
     int gsets = 1;                    // sets allocated for the current graph (GSETS on small meshes, else 1: no overlap)
     size_t GT[GSETS], GXH[GSETS], GY[GSETS], GZ2[GSETS], GZ1[GSETS];
-    size_t GXs, GXr, gV[2], gE[2], gAgg, Gout, gNF, io, pw, pb;
+    size_t GXs, GXr, GXB, gV[2], gE[MAX_EDGE_SETS][2], gAgg[MAX_EDGE_SETS], Gout, gNF, io, pw, pb;
     size_t Pn, Qn, SGs, SGr;     // factored first layer: per-node projections (forward) and summed GZ1 rows (backward)
     // weight gradients + their reductions go to a second stream (small meshes leave most of the chip idle during k_mlp_bwd)
     hipStream_t aux = nullptr;
@@ -64,8 +83,8 @@ struct TrainState {
         for (hipEvent_t e : ev_wg) if (e) (void)hipEventDestroy(e);
         if (aux) (void)hipStreamDestroy(aux);
     }
-    // idx buffer (int32): egid32 [E], perm_s [E], rowptr_s [N+1]
-    size_t i_egid = 0, i_perm = 0, i_rowptr_s = 0;
+    // idx buffer (int32), per edge set: egid32 [E], perm_s [E], rowptr_s [N+1]
+    size_t i_egid[MAX_EDGE_SETS] = {0, 0}, i_perm[MAX_EDGE_SETS] = {0, 0}, i_rowptr_s[MAX_EDGE_SETS] = {0, 0};
 };
 
 void train_invalidate(mgn_engine* h, int what) {
@@ -106,45 +125,72 @@ int pack_training_weights(mgn_engine* h) {
             }
         return add_chunk_from(tmp.data());
     };
-    auto add_tabs = [&](const MlpOff& m) {
-        const size_t off = f.size();
-        f.resize(off + (size_t)T_COUNT * L, 0.f);
-        std::vector<float> b3(L, 0.f);
-        for (int i = 0; i < m.out; ++i) b3[i] = p[m.b[2] + i];
-        pack_tab(f.data() + off + (size_t)T_B1 * L, p + m.b[0], L);
-        pack_tab(f.data() + off + (size_t)T_B2 * L, p + m.b[1], L);
-        pack_tab(f.data() + off + (size_t)T_B3 * L, b3.data(), L);
-        if (m.ln) {
-            pack_tab(f.data() + off + (size_t)T_GAMMA * L, p + m.gamma, L);
-            pack_tab(f.data() + off + (size_t)T_BETA * L, p + m.beta, L);
-        }
-        f[off + (size_t)T_LN * L] = 1e-5f;                     // (eps_in, eps_out) = (1e-5, 0): MGN_LN_VAR_EPS, the only mode trained here
-        return off;
-    };
+    std::fill(tmp.begin(), tmp.end(), 0.f);
+    for (int i = 0; i < L; ++i) tmp[(size_t)i * L + i] = 1.f;
+    const size_t ident = add_chunk_from(tmp.data());  // (its own transpose)
     auto build = [&](const MlpOff& m, bool need_input_grad) {
         TrainMlp t;
-        t.off = &m;
-        t.nin = m.in >= L ? m.in / L : 1;
-        t.in_rows = m.in >= L ? L : m.in;
-        for (int j = 0; j < t.nin; ++j) t.W1[j] = block(p + m.W[0], L, j * L, t.in_rows, L, false);
-        t.W2 = block(p + m.W[1], L, 0, L, L, false);
-        t.W3 = block(p + m.W[2], m.out, 0, L, m.out, false);
-        t.W2T = block(p + m.W[1], L, 0, L, L, true);
-        t.W3T = block(p + m.W[2], m.out, 0, L, m.out, true);
-        t.has_w1t = need_input_grad;
-        if (need_input_grad)
-            for (int j = 0; j < t.nin; ++j) t.W1T[j] = block(p + m.W[0], L, j * L, t.in_rows, L, true);
-        t.tabs = add_tabs(m);
+        const int nd = m.nl;                          // Dense layers: hidden_layers + 1
+        int plan[2][3] = {{0, 1, 2}, {-1, -1, -1}};
+        t.nblk = nd <= 3 ? 1 : 2;
+        if (nd == 2) { plan[0][1] = -1; plan[0][2] = 1; }
+        if (nd == 4) { plan[0][1] = plan[0][2] = -1; plan[1][0] = 1; plan[1][1] = 2; plan[1][2] = 3; }
+        if (nd == 5) { plan[0][2] = -1; plan[1][0] = 2; plan[1][1] = 3; plan[1][2] = 4; }
+        for (int bi = 0; bi < t.nblk; ++bi) {
+            TrainBlock& b = t.b[bi];
+            const int d0 = plan[bi][0], d1 = plan[bi][1], d2 = plan[bi][2];
+            const bool last = bi == t.nblk - 1;
+            b.nin = (bi == 0 && m.in >= L) ? m.in / L : 1;
+            b.in_rows = (bi == 0 && m.in < L) ? m.in : L;
+            b.has_w1t = need_input_grad || bi > 0;    // (a second block always hands its input gradient to the first)
+            for (int j = 0; j < b.nin; ++j) {
+                b.W1[j] = block(p + m.W[d0], L, j * L, b.in_rows, L, false);
+                if (b.has_w1t) b.W1T[j] = block(p + m.W[d0], L, j * L, b.in_rows, L, true);
+            }
+            b.gW[0] = (long)m.W[d0]; b.gb[0] = (long)m.b[d0];
+            if (d1 >= 0) {
+                b.W2 = block(p + m.W[d1], L, 0, L, L, false);
+                b.W2T = block(p + m.W[d1], L, 0, L, L, true);
+                b.gW[1] = (long)m.W[d1]; b.gb[1] = (long)m.b[d1];
+            } else b.W2 = b.W2T = ident;
+            b.out_cols = L;
+            if (d2 >= 0) {
+                b.out_cols = d2 == nd - 1 ? m.out : L;
+                b.W3 = block(p + m.W[d2], b.out_cols, 0, L, b.out_cols, false);
+                b.W3T = block(p + m.W[d2], b.out_cols, 0, L, b.out_cols, true);
+                b.gW[2] = (long)m.W[d2]; b.gb[2] = (long)m.b[d2];
+            } else b.W3 = b.W3T = ident;
+            b.ln = last && m.ln;
+            // tables: biases (zero behind an identity slot), LayerNorm parameters of the last block
+            const size_t off = f.size();
+            f.resize(off + (size_t)T_COUNT * L, 0.f);
+            std::vector<float> bias(L, 0.f);
+            pack_tab(f.data() + off + (size_t)T_B1 * L, p + m.b[d0], L);
+            if (d1 >= 0) pack_tab(f.data() + off + (size_t)T_B2 * L, p + m.b[d1], L);
+            if (d2 >= 0) {
+                for (int i = 0; i < b.out_cols; ++i) bias[i] = p[m.b[d2] + i];
+                pack_tab(f.data() + off + (size_t)T_B3 * L, bias.data(), L);
+            }
+            if (b.ln) {
+                pack_tab(f.data() + off + (size_t)T_GAMMA * L, p + m.gamma, L);
+                pack_tab(f.data() + off + (size_t)T_BETA * L, p + m.beta, L);
+                b.ggamma = (long)m.gamma; b.gbeta = (long)m.beta;
+            }
+            f[off + (size_t)T_LN * L] = 1e-5f;                 // (eps_in, eps_out) = (1e-5, 0): MGN_LN_VAR_EPS, the only mode trained here
+            b.tabs = off;
+        }
         return t;
     };
-    T.mlp.clear();
-    T.mlp.push_back(build(h->enc_node, true));    // input gradient: mgn_ode_vjp (d f / d x)
-    T.mlp.push_back(build(h->es[0].enc, false));
-    for (int k = 0; k < c.mps; ++k) {
-        T.mlp.push_back(build(h->es[0].pe[k], true));
-        T.mlp.push_back(build(h->pn[k], true));
+    T.nblk = c.hidden_layers >= 3 ? 2 : 1;
+    T.m_en = build(h->enc_node, true);                // input gradient: mgn_ode_vjp (d f / d x)
+    T.m_pn.clear();
+    for (int q = 0; q < h->nsets; ++q) {
+        T.m_ee[q] = build(h->es[q].enc, false);
+        T.m_pe[q].clear();
+        for (int k = 0; k < c.mps; ++k) T.m_pe[q].push_back(build(h->es[q].pe[k], true));
     }
-    T.mlp.push_back(build(h->dec, true));
+    for (int k = 0; k < c.mps; ++k) T.m_pn.push_back(build(h->pn[k], true));
+    T.m_de = build(h->dec, true);
     HIPCHK(h, hipStreamSynchronize(h->stream));
     HIPCHK(h, T.w.ensure(f.size() * 4));
     HIPCHK(h, hipMemcpy(T.w.p, f.data(), f.size() * 4, hipMemcpyHostToDevice));
@@ -156,22 +202,32 @@ int pack_training_weights(mgn_engine* h) {
 int prepare_graph(mgn_engine* h) {
     TrainState& T = *h->train;
     const LocalGraph& g = h->g;
-    const EdgeTopo& t = g.set[0];
-    const int L = h->cfg.L, mps = h->cfg.mps;
-    const int64_t N = g.n_own, E = t.e_local;
-    const size_t NL = (size_t)(N > 0 ? N : 1) * L, EL = (size_t)(E > 0 ? E : 1) * L;
-    // index arrays: edge_gid as int32, sender CSR over the receiver-sorted edge list
-    std::vector<int32_t> ix((size_t)2 * E + N + 1, 0);
-    T.i_egid = 0;
-    T.i_perm = E;
-    T.i_rowptr_s = 2 * E;
-    for (int64_t i = 0; i < E; ++i) ix[T.i_egid + i] = (int32_t)t.edge_gid[i];
-    {
-        int32_t* rp = ix.data() + T.i_rowptr_s;
+    const int L = h->cfg.L, mps = h->cfg.mps, S = h->nsets, NB = T.nblk;
+    const int64_t N = g.n_own;
+    const size_t NL = (size_t)(N > 0 ? N : 1) * L;
+    size_t EL[MAX_EDGE_SETS] = {0, 0}, ELmax = 0;
+    int64_t Emax = 0;
+    // index arrays per set: edge_gid as int32, sender CSR over the receiver-sorted edge list
+    std::vector<int32_t> ix;
+    for (int q = 0; q < S; ++q) {
+        const EdgeTopo& t = g.set[q];
+        const int64_t E = t.e_local;
+        if ((int64_t)t.snd.size() != E || (int64_t)t.edge_gid.size() != E)
+            return fail(h, MGN_E_STATE, "the training step needs the host copy of the edge lists: install the graph with mgn_set_graph / mgn_set_edge_set");
+        EL[q] = (size_t)(E > 0 ? E : 1) * L;
+        ELmax = std::max(ELmax, EL[q]);
+        Emax = std::max(Emax, E);
+        const size_t base = ix.size();
+        ix.resize(base + (size_t)2 * E + N + 1, 0);
+        T.i_egid[q] = base;
+        T.i_perm[q] = base + E;
+        T.i_rowptr_s[q] = base + 2 * E;
+        for (int64_t i = 0; i < E; ++i) ix[T.i_egid[q] + i] = (int32_t)t.edge_gid[i];
+        int32_t* rp = ix.data() + T.i_rowptr_s[q];
         for (int64_t i = 0; i < E; ++i) ++rp[t.snd[i] + 1];
         for (int64_t n = 0; n < N; ++n) rp[n + 1] += rp[n];
         std::vector<int32_t> cur(rp, rp + N);
-        for (int64_t i = 0; i < E; ++i) ix[T.i_perm + cur[t.snd[i]]++] = (int32_t)i;   // stable: ascending edge position
+        for (int64_t i = 0; i < E; ++i) ix[T.i_perm[q] + cur[t.snd[i]]++] = (int32_t)i;   // stable: ascending edge position
     }
     HIPCHK(h, hipStreamSynchronize(h->stream));
     HIPCHK(h, T.idx.ensure(ix.size() * 4));
@@ -179,65 +235,82 @@ int prepare_graph(mgn_engine* h) {
 
     size_t off = 0;
     auto take = [&](size_t n) { const size_t o = off; off += (n + 63) / 64 * 64; return o; };
+    auto take_acts = [&](size_t n) { Acts a; for (int b = 0; b < NB; ++b) for (int i = 0; i < 3; ++i) a.h[b][i] = take(n); return a; };
     T.nf_raw = take((size_t)N * h->cfg.Fn);
-    T.ef_raw = take((size_t)E * h->cfg.Fe);
     T.nf_pad = take(NL);
-    T.ef_pad = take(EL);
-    for (int i = 0; i < 3; ++i) T.enH[i] = take(NL);
-    for (int i = 0; i < 3; ++i) T.eeH[i] = take(EL);
-    for (int i = 0; i < 3; ++i) T.dH[i] = take(NL);
-    T.Enew = take(EL);
-    for (int i = 0; i < 3; ++i) { T.eH[i].assign(mps, 0); T.nH[i].assign(mps, 0); }
-    T.Ek.assign(mps + 1, 0);
+    T.a_en = take_acts(NL);
+    T.a_de = take_acts(NL);
+    for (int q = 0; q < S; ++q) {
+        T.ef_raw[q] = take((size_t)g.set[q].e_local * h->es[q].Fe);
+        T.ef_pad[q] = take(EL[q]);
+        T.a_ee[q] = take_acts(EL[q]);
+    }
+    T.Enew = take(ELmax);
     T.Vk.assign(mps + 1, 0);
-    T.agg.assign(mps, 0);
     T.Vk[0] = take(NL);
-    T.Ek[0] = take(EL);
-    // Kept activations of the processor: 3 (E + N) L floats per step when H1 / H2 / Y are stored.  Large meshes switch to
-    // recomputation (one more forward per MLP in the reverse pass, (E + 2 N) L floats per step kept): 15 steps of M-1M
+    for (int q = 0; q < S; ++q) {
+        T.Ek[q].assign(mps + 1, 0);
+        T.agg[q].assign(mps, 0);
+        T.a_pe[q].assign(mps, Acts());
+        T.Ek[q][0] = take(EL[q]);
+    }
+    T.a_pn.assign(mps, Acts());
+    // Kept activations of the processor: 3 (E + N) L floats per launch unit and step when H1 / H2 / Y are stored.  Large meshes
+    // switch to recomputation (one more forward per MLP in the reverse pass, (E + 2 N) L floats per step kept): 15 steps of M-1M
     // then need 61 GB instead of 270 GB.  MGN_TRAIN_RECOMPUTE = 0 / 1 overrides the size rule.
     {
-        const double stored = (double)mps * 3.0 * ((double)EL + (double)NL) * 4.0;
+        double rows = (double)NL;
+        for (int q = 0; q < S; ++q) rows += (double)EL[q];
+        const double stored = (double)mps * 3.0 * NB * rows * 4.0;
         T.recompute = stored > 48e9;
         if (const char* e = getenv("MGN_TRAIN_RECOMPUTE")) T.recompute = atoi(e) != 0;
     }
-    size_t shared_e[3] = {0, 0, 0}, shared_n[3] = {0, 0, 0};
-    if (T.recompute)
-        for (int i = 0; i < 3; ++i) { shared_e[i] = take(EL); shared_n[i] = take(NL); }
+    Acts shared_e[MAX_EDGE_SETS], shared_n;
+    if (T.recompute) {
+        for (int q = 0; q < S; ++q) shared_e[q] = take_acts(EL[q]);
+        shared_n = take_acts(NL);
+    }
     for (int k = 0; k < mps; ++k) {
-        for (int i = 0; i < 3; ++i) {
-            T.eH[i][k] = T.recompute ? shared_e[i] : take(EL);
-            T.nH[i][k] = T.recompute ? shared_n[i] : take(NL);
+        for (int q = 0; q < S; ++q) {
+            T.a_pe[q][k] = T.recompute ? shared_e[q] : take_acts(EL[q]);
+            T.agg[q][k] = take(NL);
+            T.Ek[q][k + 1] = take(EL[q]);
         }
-        T.agg[k] = take(NL);
-        T.Ek[k + 1] = take(EL);
+        T.a_pn[k] = T.recompute ? shared_n : take_acts(NL);
         T.Vk[k + 1] = take(NL);
     }
-    const size_t ML = NL > EL ? NL : EL;
+    const size_t ML = NL > ELmax ? NL : ELmax;
     // Above the cooperative range the first layer of the edge MLPs is factored as in the inference kernels: per NODE
     // P = v W1_sender, Q = v W1_receiver (2 chunk passes over N rows instead of 2 over E rows), backward and weight gradients
     // through the summed rows of GZ1 (gather <-> segmented-sum duality).  MGN_TRAIN_FACTORED = 0 / 1 overrides the size rule.
-    T.factored = !train_uses_coop(128, (int)((E + TILE - 1) / TILE));   // the size rule of the cooperative kernels, for every L
-    if (const char* e = getenv("MGN_TRAIN_FACTORED")) T.factored = atoi(e) != 0;
-    if (E == 0) T.factored = false;
+    bool any_fact = false, all_fact = true;
+    for (int q = 0; q < S; ++q) {
+        const int64_t E = g.set[q].e_local;
+        T.factored[q] = !train_uses_coop(128, (int)((E + TILE - 1) / TILE));   // the size rule of the cooperative kernels, for every L
+        if (const char* e = getenv("MGN_TRAIN_FACTORED")) T.factored[q] = atoi(e) != 0;
+        if (E == 0) T.factored[q] = false;
+        any_fact = any_fact || T.factored[q];
+        all_fact = all_fact && T.factored[q];
+    }
     // Small meshes (the cooperative-tile regime: a launch leaves most of the chip idle) get GSETS sets of gradient buffers so
     // that the parameter gradients can run on a second stream; larger ones fill the chip on their own and keep one set.
     {
         static const bool overlap_env = [] { const char* e = getenv("MGN_TRAIN_OVERLAP"); return !e || atoi(e) != 0; }();
-        const int64_t big = E > N ? E : N;
-        T.gsets = (overlap_env && !T.recompute && !T.factored && L == 128 && big <= 2048 * TILE) ? TrainState::GSETS : 1;   // (SGs / SGr are single buffers)
+        const int64_t big = Emax > N ? Emax : N;
+        T.gsets = (overlap_env && !T.recompute && !any_fact && L == 128 && big <= 2048 * TILE) ? TrainState::GSETS : 1;   // (SGs / SGr are single buffers)
     }
     for (int i = 0; i < T.gsets; ++i) { T.GT[i] = take(ML); T.GXH[i] = take(ML); T.GY[i] = take(ML); T.GZ2[i] = take(ML); T.GZ1[i] = take(ML); }
-    if (T.factored) { T.GXs = T.GXr = 0; T.Pn = take(NL); T.Qn = take(NL); T.SGs = take(NL); T.SGr = take(NL); }
-    else { T.GXs = take(EL); T.GXr = take(EL); T.Pn = T.Qn = T.SGs = T.SGr = 0; }
+    T.GXs = T.GXr = T.Pn = T.Qn = T.SGs = T.SGr = T.GXB = 0;
+    if (any_fact) { T.Pn = take(NL); T.Qn = take(NL); T.SGs = take(NL); T.SGr = take(NL); }
+    if (!all_fact) { T.GXs = take(ELmax); T.GXr = take(ELmax); }
+    if (NB > 1) T.GXB = take(ML);                      // gradient handed from an MLP's second launch unit to its first
     T.gV[0] = take(NL); T.gV[1] = take(NL);
-    T.gE[0] = take(EL); T.gE[1] = take(EL);
-    T.gAgg = take(NL);
+    for (int q = 0; q < S; ++q) { T.gE[q][0] = take(EL[q]); T.gE[q][1] = take(EL[q]); T.gAgg[q] = take(NL); }
     T.Gout = take(NL);
     T.gNF = take(NL);
     T.io = take((size_t)(N > 0 ? N : 1) * (2 * h->cfg.O + h->cfg.Fn + 1));
-    const int nb = std::max(wgrad_blocks(N), wgrad_blocks(E));
-    T.pw = take((size_t)5 * (nb > 0 ? nb : 1) * L * L);             // one partial-dW region per weight-gradient job of an MLP
+    const int nb = std::max(wgrad_blocks(N), wgrad_blocks(Emax));
+    T.pw = take((size_t)5 * (nb > 0 ? nb : 1) * L * L);             // one partial-dW region per weight-gradient job of a launch unit
     T.pb = take((size_t)WGRAD_MAX_JOBS * (nb > 0 ? nb : 1) * L);
     T.arena_floats = off;
     T.drop_graphs();
@@ -270,13 +343,12 @@ int train_prepare(mgn_handle* h, const char* who, size_t n_grads) {
     if (int rc = need(h, true, true)) return rc;
     const mgn_config& c = h->cfg;
     if (c.nranks != 1) return fail(h, MGN_E_STATE, "%s drives one partition", who);
-    if (h->nsets != 1) return fail(h, MGN_E_STATE, "%s mirrors the reference's single-edge-set model (src/strategies.jl:418-422)", who);
     if (c.dtype != MGN_F32) return fail(h, MGN_E_STATE, "%s computes in fp32: create the handle with dtype MGN_F32", who);
     if (c.ln_mode != MGN_LN_VAR_EPS)
         return fail(h, MGN_E_UNSUPPORTED, "%s: the reverse pass is written for ln_mode = MGN_LN_VAR_EPS (the forward path has both)", who);
-    if (c.hidden_layers != 2)
-        return fail(h, MGN_E_UNSUPPORTED, "%s is implemented for hidden_layers = 2 (the reference's default, examples/cylinder_flow/cylinder_flow.jl:17); "
-                                          "the forward path supports 1 .. 4", who);
+    for (int q = 1; q < h->nsets; ++q)
+        if (h->g.set[q].E > 0 && !h->es[q].have_ef)
+            return fail(h, MGN_E_STATE, "edge set %d has edges but no features: call mgn_set_edge_features after mgn_set_edge_set", q);
     if (n_grads != h->params.size()) return fail(h, MGN_E_ARG, "%s: grads has %zu floats, model has %zu", who, n_grads, h->params.size());
     if (!h->train) h->train = new (std::nothrow) TrainState();
     if (!h->train) return fail(h, MGN_E_OOM, "host allocation failed");
@@ -292,18 +364,24 @@ int train_run(mgn_handle* h, const TrainJob& J) {
     const mgn_config& c = h->cfg;
     TrainState& T = *h->train;
     const LocalGraph& g = h->g;
-    const int64_t N = g.n_own, E = g.set[0].e_local;
+    const int S = h->nsets;
+    const int64_t N = g.n_own;
     const int L = c.L, mps = c.mps, O = c.O;
     hipStream_t st = h->stream;
     float* A = T.arena.as<float>();
     const float* Wt = T.w.as<float>();
-    const int32_t* egid = T.idx.as<int32_t>() + T.i_egid;
-    const int32_t* perm_s = T.idx.as<int32_t>() + T.i_perm;
-    const int32_t* rowptr_s = T.idx.as<int32_t>() + T.i_rowptr_s;
-    const int32_t* snd = h->es[0].d_snd.as<int32_t>();
-    const int32_t* rcv = h->es[0].d_rcv.as<int32_t>();
-    const int32_t* rowptr = h->es[0].d_rowptr.as<int32_t>();
-    const int32_t nt_n = (int32_t)((N + TILE - 1) / TILE), nt_e = (int32_t)((E + TILE - 1) / TILE);
+    struct SetIdx { int64_t E; int32_t nt; const int32_t *egid, *perm_s, *rowptr_s, *snd, *rcv, *rowptr; } sx[MAX_EDGE_SETS] = {};
+    for (int q = 0; q < S; ++q) {
+        sx[q].E = g.set[q].e_local;
+        sx[q].nt = (int32_t)((sx[q].E + TILE - 1) / TILE);
+        sx[q].egid = T.idx.as<int32_t>() + T.i_egid[q];
+        sx[q].perm_s = T.idx.as<int32_t>() + T.i_perm[q];
+        sx[q].rowptr_s = T.idx.as<int32_t>() + T.i_rowptr_s[q];
+        sx[q].snd = h->es[q].d_snd.as<int32_t>();
+        sx[q].rcv = h->es[q].d_rcv.as<int32_t>();
+        sx[q].rowptr = h->es[q].d_rowptr.as<int32_t>();
+    }
+    const int32_t nt_n = (int32_t)((N + TILE - 1) / TILE);
     float* G = T.grads.as<float>();
 
     // ---- inputs
@@ -312,9 +390,9 @@ int train_run(mgn_handle* h, const TrainJob& J) {
     if (!J.vjp) {
         HIPCHK(h, hipMemcpyAsync(A + T.nf_raw, J.nf, (size_t)N * c.Fn * 4, hipMemcpyDefault, st));
         HIPCHK(h, launch_affine_pad(A + T.nf_raw, c.Fn, nullptr, 0, nullptr, nullptr, A + T.nf_pad, L, N, st));
-        if (E > 0) {
-            HIPCHK(h, hipMemcpyAsync(A + T.ef_raw, J.ef, (size_t)E * c.Fe * 4, hipMemcpyDefault, st));
-            HIPCHK(h, launch_affine_pad(A + T.ef_raw, c.Fe, nullptr, 0, nullptr, nullptr, A + T.ef_pad, L, E, st));
+        if (sx[0].E > 0) {
+            HIPCHK(h, hipMemcpyAsync(A + T.ef_raw[0], J.ef, (size_t)sx[0].E * c.Fe * 4, hipMemcpyDefault, st));
+            HIPCHK(h, launch_affine_pad(A + T.ef_raw[0], c.Fe, nullptr, 0, nullptr, nullptr, A + T.ef_pad[0], L, sx[0].E, st));
         }
         HIPCHK(h, hipMemcpyAsync(T.target.p, J.target, (size_t)N * O * 4, hipMemcpyDefault, st));
         HIPCHK(h, T.mask.ensure((size_t)J.nmask * 4));
@@ -328,48 +406,76 @@ int train_run(mgn_handle* h, const TrainJob& J) {
         if (J.val_mask) HIPCHK(h, hipMemcpyAsync(io + (size_t)N * (O + c.Fn), J.val_mask, (size_t)N * 4, hipMemcpyDefault, st));
         HIPCHK(h, launch_affine_pad(io, O, io + (size_t)2 * N * O, c.Fn - O, h->have_nnorm ? nrm : nullptr, h->have_nnorm ? nrm + c.Fn : nullptr,
                                     A + T.nf_pad, L, N, st));
-        if (E > 0) {
-            HIPCHK(h, hipMemcpyAsync(A + T.ef_raw, J.ef, (size_t)E * c.Fe * 4, hipMemcpyDefault, st));
-            HIPCHK(h, launch_affine_pad(A + T.ef_raw, c.Fe, nullptr, 0, h->have_enorm ? nrm + 2 * c.Fn : nullptr,
-                                        h->have_enorm ? nrm + 2 * c.Fn + c.Fe : nullptr, A + T.ef_pad, L, E, st));
+        if (sx[0].E > 0) {
+            HIPCHK(h, hipMemcpyAsync(A + T.ef_raw[0], J.ef, (size_t)sx[0].E * c.Fe * 4, hipMemcpyDefault, st));
+            HIPCHK(h, launch_affine_pad(A + T.ef_raw[0], c.Fe, nullptr, 0, h->have_enorm ? nrm + 2 * c.Fn : nullptr,
+                                        h->have_enorm ? nrm + 2 * c.Fn + c.Fe : nullptr, A + T.ef_pad[0], L, sx[0].E, st));
         }
     }
+    // further edge sets: the features installed by mgn_set_edge_features, as given (the forward path does not normalise them either)
+    for (int q = 1; q < S; ++q)
+        if (sx[q].E > 0)
+            HIPCHK(h, launch_affine_pad(h->es[q].d_ef.as<float>(), h->es[q].Fe, nullptr, 0, nullptr, nullptr, A + T.ef_pad[q], L, sx[q].E, st));
 
-    auto fwd = [&](const TrainMlp& m, int64_t rows, int32_t ntiles, const float* x0, const int32_t* i0, const float* x1, const int32_t* i1,
-                   const float* x2, const int32_t* i2, size_t h1, size_t h2, size_t y, const float* resid, float* out, float* lnout,
-                   bool keep = true) {
+    // One MLP forward = one or two launch units.  `in` carries rows / ntiles and the first unit's inputs (X, xidx, PRE, preidx);
+    // w1sel >= 0: only block w1sel of W1 is applied per row (the factored edge MLP: the e block).
+    // keep = false: first pass of recompute mode -- H1 / H2 / Y are regenerated right before the backward, not stored here
+    auto run_fwd = [&](const TrainMlp& m, const TrainFwdArgs& in, int w1sel, const Acts& act, const float* resid, float* out, float* lnout,
+                       bool keep) -> hipError_t {
+        for (int bi = 0; bi < m.nblk; ++bi) {
+            const TrainBlock& b = m.b[bi];
+            const bool last = bi == m.nblk - 1;
+            TrainFwdArgs a{};
+            a.rows = in.rows; a.ntiles = in.ntiles;
+            int nin = b.nin;
+            if (bi == 0) {
+                for (int j = 0; j < 3; ++j) { a.X[j] = in.X[j]; a.xidx[j] = in.xidx[j]; }
+                for (int j = 0; j < 2; ++j) { a.PRE[j] = in.PRE[j]; a.preidx[j] = in.preidx[j]; }
+                if (w1sel >= 0) { a.W1[0] = Wt + b.W1[w1sel]; nin = 1; }
+                else for (int j = 0; j < b.nin; ++j) a.W1[j] = Wt + b.W1[j];
+            } else {                                        // the second unit reads the first one's output (its Y: no LayerNorm, no residual)
+                a.X[0] = A + act.h[bi - 1][2];
+                a.W1[0] = Wt + b.W1[0];
+            }
+            a.W2 = Wt + b.W2; a.W3 = Wt + b.W3; a.tabs = Wt + b.tabs;
+            if (keep) { a.H1 = A + act.h[bi][0]; a.H2 = A + act.h[bi][1]; a.Y = A + act.h[bi][2]; }
+            if (last) { a.resid = resid; a.OUT = out; a.LNOUT = lnout; }
+            else if (!keep) a.OUT = A + act.h[bi][2];
+            a.ln = b.ln ? 1 : 0;
+            if (hipError_t e = launch_mlp_fwd(L, nin, a, st)) return e;
+        }
+        return hipSuccess;
+    };
+    auto fwd = [&](const TrainMlp& m, int64_t rows, int32_t ntiles, const float* x0, const int32_t* i0, const float* x1, const float* x2,
+                   const Acts& act, const float* resid, float* out, float* lnout, bool keep = true) {
         TrainFwdArgs a{};
         a.rows = rows; a.ntiles = ntiles;
         a.X[0] = x0; a.X[1] = x1; a.X[2] = x2;
-        a.xidx[0] = i0; a.xidx[1] = i1; a.xidx[2] = i2;
-        for (int j = 0; j < m.nin; ++j) a.W1[j] = Wt + m.W1[j];
-        a.W2 = Wt + m.W2; a.W3 = Wt + m.W3; a.tabs = Wt + m.tabs;
-        if (keep) { a.H1 = A + h1; a.H2 = A + h2; a.Y = A + y; }
-        a.resid = resid; a.OUT = out; a.LNOUT = lnout;
-        a.ln = m.off->ln ? 1 : 0;
-        return launch_mlp_fwd(L, m.nin, a, st);
+        a.xidx[0] = i0;
+        return run_fwd(m, a, -1, act, resid, out, lnout, keep);
     };
-
-    // edge MLP of step k: [v_s; v_r; e] -> 3 Dense + LayerNorm; with the factored first layer P[s] + Q[r] + e W1e
-    // keep = false: first pass of recompute mode -- H1 / H2 / Y are regenerated right before the backward, not stored here
-    auto fwd_edge = [&](const TrainMlp& m, int k, const float* resid, float* out, float* lnout, bool keep = true) -> hipError_t {
-        if (!T.factored)
-            return fwd(m, E, nt_e, A + T.Vk[k], snd, A + T.Vk[k], rcv, A + T.Ek[k], nullptr, T.eH[0][k], T.eH[1][k], T.eH[2][k], resid, out, lnout,
-                       keep);
+    // edge MLP of step k, set q: [v_s; v_r; e] -> MLP + LayerNorm; with the factored first layer P[s] + Q[r] + e W1e
+    auto fwd_edge = [&](int q, int k, const float* resid, float* out, float* lnout, bool keep = true) -> hipError_t {
+        const TrainMlp& m = T.m_pe[q][k];
+        TrainFwdArgs a{};
+        a.rows = sx[q].E; a.ntiles = sx[q].nt;
+        if (!T.factored[q]) {
+            a.X[0] = A + T.Vk[k]; a.xidx[0] = sx[q].snd;
+            a.X[1] = A + T.Vk[k]; a.xidx[1] = sx[q].rcv;
+            a.X[2] = A + T.Ek[q][k];
+            return run_fwd(m, a, -1, T.a_pe[q][k], resid, out, lnout, keep);
+        }
         Lin2Args p{};
         p.rows = N; p.ntiles = nt_n;
-        p.X0 = A + T.Vk[k]; p.W0 = Wt + m.W1[0]; p.W1 = Wt + m.W1[1];
+        p.X0 = A + T.Vk[k]; p.W0 = Wt + m.b[0].W1[0]; p.W1 = Wt + m.b[0].W1[1];
         p.OUT0 = A + T.Pn; p.OUT1 = A + T.Qn;
         if (hipError_t e = launch_lin2(L, p, st)) return e;
-        TrainFwdArgs a{};
-        a.rows = E; a.ntiles = nt_e;
-        a.X[0] = A + T.Ek[k];
-        a.W1[0] = Wt + m.W1[2]; a.W2 = Wt + m.W2; a.W3 = Wt + m.W3; a.tabs = Wt + m.tabs;
-        a.PRE[0] = A + T.Pn; a.preidx[0] = snd; a.PRE[1] = A + T.Qn; a.preidx[1] = rcv;
-        if (keep) { a.H1 = A + T.eH[0][k]; a.H2 = A + T.eH[1][k]; a.Y = A + T.eH[2][k]; }
-        a.resid = resid; a.OUT = out; a.LNOUT = lnout;
-        a.ln = m.off->ln ? 1 : 0;
-        return launch_mlp_fwd(L, 1, a, st);
+        a.X[0] = A + T.Ek[q][k];
+        a.PRE[0] = A + T.Pn; a.preidx[0] = sx[q].snd; a.PRE[1] = A + T.Qn; a.preidx[1] = sx[q].rcv;
+        return run_fwd(m, a, 2, T.a_pe[q][k], resid, out, lnout, keep);
+    };
+    auto fwd_node = [&](int k, const float* resid, float* out, bool keep = true) {
+        return fwd(T.m_pn[k], N, nt_n, A + T.Vk[k], nullptr, A + T.agg[0][k], S > 1 ? A + T.agg[1][k] : nullptr, T.a_pn[k], resid, out, nullptr, keep);
     };
 
     // Small meshes replay both launch sequences from hipGraphs (everything they touch lives at fixed addresses in the arena;
@@ -410,43 +516,41 @@ int train_run(mgn_handle* h, const TrainJob& J) {
     };
 
     // ---- forward, keeping activations
-    const TrainMlp& m_en = T.mlp[0];
-    const TrainMlp& m_ee = T.mlp[1];
-    const TrainMlp& m_de = T.mlp.back();
     auto forward_launches = [&]() -> int {
-    HIPCHK(h, fwd(m_en, N, nt_n, A + T.nf_pad, nullptr, nullptr, nullptr, nullptr, nullptr, T.enH[0], T.enH[1], T.enH[2], nullptr, A + T.Vk[0], nullptr));
-    HIPCHK(h, fwd(m_ee, E, nt_e, A + T.ef_pad, egid, nullptr, nullptr, nullptr, nullptr, T.eeH[0], T.eeH[1], T.eeH[2], nullptr, A + T.Ek[0], nullptr));
+    HIPCHK(h, fwd(T.m_en, N, nt_n, A + T.nf_pad, nullptr, nullptr, nullptr, T.a_en, nullptr, A + T.Vk[0], nullptr));
+    for (int q = 0; q < S; ++q)
+        HIPCHK(h, fwd(T.m_ee[q], sx[q].E, sx[q].nt, A + T.ef_pad[q], sx[q].egid, nullptr, nullptr, T.a_ee[q], nullptr, A + T.Ek[q][0], nullptr));
     for (int k = 0; k < mps; ++k) {
-        const TrainMlp& me = T.mlp[2 + 2 * k];
-        const TrainMlp& mn = T.mlp[3 + 2 * k];
-        HIPCHK(h, fwd_edge(me, k, A + T.Ek[k], A + T.Ek[k + 1], A + T.Enew, !T.recompute));
-        HIPCHK(h, launch_segment_sum(L, A + T.Enew, rowptr, nullptr, nullptr, A + T.agg[k], (int32_t)N, st));
-        HIPCHK(h, fwd(mn, N, nt_n, A + T.Vk[k], nullptr, A + T.agg[k], nullptr, nullptr, nullptr, T.nH[0][k], T.nH[1][k], T.nH[2][k], A + T.Vk[k],
-                      A + T.Vk[k + 1], nullptr, !T.recompute));
+        for (int q = 0; q < S; ++q) {
+            HIPCHK(h, fwd_edge(q, k, A + T.Ek[q][k], A + T.Ek[q][k + 1], A + T.Enew, !T.recompute));
+            HIPCHK(h, launch_segment_sum(L, A + T.Enew, sx[q].rowptr, nullptr, nullptr, A + T.agg[q][k], (int32_t)N, st));
+        }
+        HIPCHK(h, fwd_node(k, A + T.Vk[k], A + T.Vk[k + 1], !T.recompute));
     }
-    HIPCHK(h, fwd(m_de, N, nt_n, A + T.Vk[mps], nullptr, nullptr, nullptr, nullptr, nullptr, T.dH[0], T.dH[1], T.dH[2], nullptr, nullptr, nullptr));
+    HIPCHK(h, fwd(T.m_de, N, nt_n, A + T.Vk[mps], nullptr, nullptr, nullptr, T.a_de, nullptr, nullptr, nullptr));
     return MGN_OK;
     };
     if (int rc = graphed(0, forward_launches)) return rc;
+    const size_t y_out = T.a_de.h[T.m_de.nblk - 1][2];        // the decoder's output (its last unit's Y)
 
     // ---- seed of the reverse pass
     const int nlb = J.vjp ? 0 : loss_blocks(J.nmask);
     HIPCHK(h, hipMemsetAsync(A + T.Gout, 0, (size_t)N * L * 4, st));
     if (!J.vjp) {   // loss = mean(mse_reduce(target, out)[mask]) and its gradient w.r.t. out
         HIPCHK(h, T.loss.ensure((size_t)nlb * sizeof(double)));
-        HIPCHK(h, launch_loss(A + T.dH[2], L, T.target.as<float>(), O, T.mask.as<int32_t>(), J.nmask, J.mask_index_base, A + T.Gout,
+        HIPCHK(h, launch_loss(A + y_out, L, T.target.as<float>(), O, T.mask.as<int32_t>(), J.nmask, J.mask_index_base, A + T.Gout,
                               T.loss.as<double>(), st));
     } else {        // dx/dt = inverse_data(o_norm, out) .* val_mask  =>  d/d out = lambda .* val_mask .* out_scale
         const float* os = h->have_onorm ? nrm + 2 * c.Fn + 2 * c.Fe : nullptr;
         const float* vm = J.val_mask ? A + T.io + (size_t)N * (O + c.Fn) : nullptr;
-        HIPCHK(h, launch_vjp_seed(A + T.dH[2], L, O, A + T.io + (size_t)N * O, vm, os, os ? os + O : nullptr, A + T.Gout,
+        HIPCHK(h, launch_vjp_seed(A + y_out, L, O, A + T.io + (size_t)N * O, vm, os, os ? os + O : nullptr, A + T.Gout,
                                   J.dxdt ? T.target.as<float>() : nullptr, N, st));
     }
 
     // ---- backward
-    // activation backward of one MLP + all of its parameter gradients
-    // The parameter gradients of MLP i (k_wgrad + k_reduce_partials: they only read what k_mlp_bwd left in gradient-buffer
-    // set i & 1 and the kept activations) run on a second stream beside the activation backward of MLP i + 1.  Not in
+    // activation backward of one launch unit + all of its parameter gradients
+    // The parameter gradients of unit i (k_wgrad + k_reduce_partials: they only read what k_mlp_bwd left in gradient-buffer
+    // set i % gsets and the kept activations) run on a second stream beside the activation backward of the next units.  Not in
     // recompute mode (there the kept activations are shared buffers which the next step's recomputation overwrites) and not
     // on large meshes, which fill the chip on their own (prepare_graph).  MGN_TRAIN_OVERLAP = 0 keeps everything on one stream.
     const bool overlap = T.gsets > 1;
@@ -456,13 +560,14 @@ int train_run(mgn_handle* h, const TrainJob& J) {
         for (hipEvent_t& e : T.ev_wg) HIPCHK(h, hipEventCreateWithFlags(&e, hipEventDisableTiming));
     }
     int n_bwd = 0;
-    // `node_rows` > 0: the edge MLP with the factored first layer -- only the e block of W1 is unwound per edge (gx[0] /
-    // gxadd[0] / xin[0] describe it); the v blocks follow per node from the summed rows of GZ1 (SGs, SGr) after this call.
-    auto bwd = [&](const TrainMlp& m, int64_t rows, int32_t ntiles, const float* g0, const float* g1, const int32_t* g1i, size_t h1, size_t h2, size_t y,
-                   float* const gx[3], const float* const gxadd[3], const float* const xin[3], const int32_t* const xi[3],
-                   int64_t node_rows = 0, const float* vin = nullptr) -> int {
-        const bool fact = node_rows > 0;
-        const int nin_k = fact ? 1 : m.nin;               // input blocks the kernel unwinds
+    // `fq` >= 0: first unit of the edge MLP of set fq with the factored first layer -- only the e block of W1 is unwound per edge
+    // (gx[0] / gxadd[0] / xin[0] describe it); the v blocks follow per node from the summed rows of GZ1 (SGs, SGr) after this call.
+    auto bwd_unit = [&](const TrainBlock& b, int64_t rows, int32_t ntiles, const float* g0, const float* g1, const int32_t* g1i, const size_t (&hb)[3],
+                        float* const gx[3], const float* const gxadd[3], const float* const xin[3], const int32_t* const xi[3],
+                        int fq = -1, const float* vin = nullptr) -> int {
+        const bool fact = fq >= 0;
+        const int64_t node_rows = fact ? N : 0;
+        const int nin_k = fact ? 1 : b.nin;               // input blocks the kernel unwinds
         const int gs = overlap ? n_bwd % T.gsets : 0;
         hipStream_t wst = overlap ? T.aux : st;
         if (overlap && n_bwd >= T.gsets) HIPCHK(h, hipStreamWaitEvent(st, T.ev_wg[gs], 0));   // set gs is free again
@@ -470,27 +575,26 @@ int train_run(mgn_handle* h, const TrainJob& J) {
         TrainBwdArgs a{};
         a.rows = rows; a.ntiles = ntiles;
         a.G0 = g0; a.G1 = g1; a.g1idx = g1i;
-        a.Y = A + y; a.H2 = A + h2; a.H1 = A + h1;
-        a.W3T = Wt + m.W3T; a.W2T = Wt + m.W2T;
+        a.H1 = A + hb[0]; a.H2 = A + hb[1]; a.Y = A + hb[2];
+        a.W3T = Wt + b.W3T; a.W2T = Wt + b.W2T;
         for (int j = 0; j < nin_k; ++j) {
             const int jw = fact ? 2 : j;                   // factored: block 2 (e) of W1
-            a.W1T[j] = (m.has_w1t && gx[j]) ? Wt + m.W1T[jw] : nullptr;
+            a.W1T[j] = (b.has_w1t && gx[j]) ? Wt + b.W1T[jw] : nullptr;
             a.GX[j] = gx[j];
             a.GXadd[j] = gxadd[j];
         }
-        a.tabs = Wt + m.tabs;
-        a.ln = m.off->ln ? 1 : 0;
+        a.tabs = Wt + b.tabs;
+        a.ln = b.ln ? 1 : 0;
         a.GT = A + T.GT[gs]; a.GXH = A + T.GXH[gs]; a.GY = A + T.GY[gs]; a.GZ2 = A + T.GZ2[gs]; a.GZ1 = A + T.GZ1[gs];
         HIPCHK(h, launch_mlp_bwd(L, nin_k, a, st));
         if (fact) {   // gather <-> segmented-sum duality on GZ1 itself: SGr[n] = sum of GZ1 over edges received by n, SGs: sent by n
-            HIPCHK(h, launch_segment_sum_pair(L, A + T.GZ1[gs], rowptr, rowptr_s, perm_s, A + T.SGr, A + T.SGs, (int32_t)node_rows, st));
+            HIPCHK(h, launch_segment_sum_pair(L, A + T.GZ1[gs], sx[fq].rowptr, sx[fq].rowptr_s, sx[fq].perm_s, A + T.SGr, A + T.SGs, (int32_t)node_rows, st));
         }
         if (overlap) {
             HIPCHK(h, hipEventRecord(T.ev_bwd, st));
             HIPCHK(h, hipStreamWaitEvent(wst, T.ev_bwd, 0));
         }
-        // every parameter gradient of this MLP: one batched weight-gradient launch + one batched (ordered) reduction
-        const MlpOff& o = *m.off;
+        // every parameter gradient of this unit: one batched weight-gradient launch + one batched (ordered) reduction
         const int64_t lrows = rows > node_rows ? rows : node_rows;   // the launch covers its longest job (node jobs of a factored edge MLP)
         const int nb = wgrad_blocks(lrows);
         if (nb == 0) return MGN_OK;
@@ -499,6 +603,7 @@ int train_run(mgn_handle* h, const TrainJob& J) {
         int nw = 0;
         auto job = [&](const float* X, const int32_t* xi_, const float* Gm, long woff, int nrows, int cols, long boff, int bcols,
                        int64_t jrows = -1) {
+            if (woff < 0 && boff < 0) return;              // identity slot
             WgradJob& j = wb.job[wb.njobs];
             if (jrows < 0) jrows = rows;
             const int nbj = wgrad_blocks_of_job(lrows, jrows);     // blocks of this launch that hold rows of the job
@@ -512,76 +617,93 @@ int train_run(mgn_handle* h, const TrainJob& J) {
             if (boff >= 0) rb.job[rb.njobs++] = ReduceJob{j.pb, nbj, (int64_t)L, 1, bcols, L, G + boff};
             ++wb.njobs;
         };
-        job(A + h2, nullptr, A + T.GY[gs], (long)o.W[2], L, o.out, (long)o.b[2], o.out);
-        job(A + h1, nullptr, A + T.GZ2[gs], (long)o.W[1], L, L, (long)o.b[1], L);
+        job(A + hb[1], nullptr, A + T.GY[gs], b.gW[2], L, b.out_cols, b.gb[2], b.out_cols);
+        job(A + hb[0], nullptr, A + T.GZ2[gs], b.gW[1], L, L, b.gb[1], L);
         if (!fact) {
-            for (int j = 0; j < m.nin; ++j)
-                job(xin[j], xi[j], A + T.GZ1[gs], (long)(o.W[0] + (size_t)j * L * L), m.in_rows, L, j == 0 ? (long)o.b[0] : -1, L);
+            for (int j = 0; j < b.nin; ++j)
+                job(xin[j], xi[j], A + T.GZ1[gs], b.gW[0] + (long)j * L * L, b.in_rows, L, j == 0 ? b.gb[0] : -1, L);
         } else {   // dW1e = e^T GZ1 (+ db1) over the edges; dW1s = v^T SGs, dW1r = v^T SGr over the nodes
-            job(xin[0], xi[0], A + T.GZ1[gs], (long)(o.W[0] + (size_t)2 * L * L), L, L, (long)o.b[0], L);
-            job(vin, nullptr, A + T.SGs, (long)(o.W[0]), L, L, -1, L, node_rows);
-            job(vin, nullptr, A + T.SGr, (long)(o.W[0] + (size_t)L * L), L, L, -1, L, node_rows);
+            job(xin[0], xi[0], A + T.GZ1[gs], b.gW[0] + (long)2 * L * L, L, L, b.gb[0], L);
+            job(vin, nullptr, A + T.SGs, b.gW[0], L, L, -1, L, node_rows);
+            job(vin, nullptr, A + T.SGr, b.gW[0] + (long)L * L, L, L, -1, L, node_rows);
         }
-        if (o.ln) {
-            job(nullptr, nullptr, A + T.GXH[gs], -1, 0, 0, (long)o.gamma, L);
-            job(nullptr, nullptr, A + T.GT[gs], -1, 0, 0, (long)o.beta, L);
+        if (b.ln) {
+            job(nullptr, nullptr, A + T.GXH[gs], -1, 0, 0, b.ggamma, L);
+            job(nullptr, nullptr, A + T.GT[gs], -1, 0, 0, b.gbeta, L);
         }
+        if (wb.njobs == 0) return MGN_OK;
         HIPCHK(h, launch_wgrad(L, wb, lrows, wst));
         HIPCHK(h, launch_reduce_partials(rb, wst));
         if (overlap) HIPCHK(h, hipEventRecord(T.ev_wg[gs], wst));
         return MGN_OK;
     };
+    // one MLP: its second unit (if any) first, handing the gradient w.r.t. its input to the first through GXB
+    auto bwd = [&](const TrainMlp& m, int64_t rows, int32_t ntiles, const float* g0, const float* g1, const int32_t* g1i, const Acts& act,
+                   float* const gx[3], const float* const gxadd[3], const float* const xin[3], const int32_t* const xi[3],
+                   int fq = -1, const float* vin = nullptr) -> int {
+        if (m.nblk == 2) {
+            float* gx1[3] = {A + T.GXB, nullptr, nullptr};
+            const float* none[3] = {nullptr, nullptr, nullptr};
+            const float* xin1[3] = {A + act.h[0][2], nullptr, nullptr};
+            const int32_t* xi1[3] = {nullptr, nullptr, nullptr};
+            if (int rc = bwd_unit(m.b[1], rows, ntiles, g0, g1, g1i, act.h[1], gx1, none, xin1, xi1)) return rc;
+            return bwd_unit(m.b[0], rows, ntiles, A + T.GXB, nullptr, nullptr, act.h[0], gx, gxadd, xin, xi, fq, vin);
+        }
+        return bwd_unit(m.b[0], rows, ntiles, g0, g1, g1i, act.h[0], gx, gxadd, xin, xi, fq, vin);
+    };
 
     auto backward_launches = [&]() -> int {
     n_bwd = 0;
-    int cur = 0;   // gV[cur], gE[cur] hold the gradients w.r.t. the latents entering the part of the model already unwound
+    int cur = 0;   // gV[cur], gE[q][ecur] hold the gradients w.r.t. the latents entering the part of the model already unwound
     {
         float* gx[3] = {A + T.gV[cur], nullptr, nullptr};
         const float* gxadd[3] = {nullptr, nullptr, nullptr};
         const float* xin[3] = {A + T.Vk[mps], nullptr, nullptr};
         const int32_t* xi[3] = {nullptr, nullptr, nullptr};
-        if (int rc = bwd(m_de, N, nt_n, A + T.Gout, nullptr, nullptr, T.dH[0], T.dH[1], T.dH[2], gx, gxadd, xin, xi)) return rc;
+        if (int rc = bwd(T.m_de, N, nt_n, A + T.Gout, nullptr, nullptr, T.a_de, gx, gxadd, xin, xi)) return rc;
     }
-    HIPCHK(h, hipMemsetAsync(A + T.gE[cur], 0, (size_t)(E > 0 ? E : 1) * L * 4, st));
     int ecur = 0;
+    for (int q = 0; q < S; ++q) HIPCHK(h, hipMemsetAsync(A + T.gE[q][ecur], 0, (size_t)(sx[q].E > 0 ? sx[q].E : 1) * L * 4, st));
     for (int k = mps - 1; k >= 0; --k) {
-        const TrainMlp& me = T.mlp[2 + 2 * k];
-        const TrainMlp& mn = T.mlp[3 + 2 * k];
         const int nxt = cur ^ 1, enxt = ecur ^ 1;
-        if (T.recompute) {   // regenerate H1, H2, Y of both MLPs of this step from their kept inputs
-            HIPCHK(h, fwd(mn, N, nt_n, A + T.Vk[k], nullptr, A + T.agg[k], nullptr, nullptr, nullptr, T.nH[0][k], T.nH[1][k], T.nH[2][k], nullptr,
-                          nullptr, nullptr));
-            HIPCHK(h, fwd_edge(me, k, nullptr, nullptr, nullptr));
+        if (T.recompute) {   // regenerate H1, H2, Y of the MLPs of this step from their kept inputs
+            HIPCHK(h, fwd_node(k, nullptr, nullptr));
+            for (int q = 0; q < S; ++q) HIPCHK(h, fwd_edge(q, k, nullptr, nullptr, nullptr));
         }
-        {   // node MLP: v_{k+1} = v_k + MLP_v([v_k; agg_k])
-            float* gx[3] = {A + T.gV[nxt], A + T.gAgg, nullptr};
+        {   // node MLP: v_{k+1} = v_k + MLP_v([v_k; agg_k (per set)])
+            float* gx[3] = {A + T.gV[nxt], A + T.gAgg[0], S > 1 ? A + T.gAgg[1] : nullptr};
             const float* gxadd[3] = {A + T.gV[cur], nullptr, nullptr};
-            const float* xin[3] = {A + T.Vk[k], A + T.agg[k], nullptr};
+            const float* xin[3] = {A + T.Vk[k], A + T.agg[0][k], S > 1 ? A + T.agg[1][k] : nullptr};
             const int32_t* xi[3] = {nullptr, nullptr, nullptr};
-            if (int rc = bwd(mn, N, nt_n, A + T.gV[cur], nullptr, nullptr, T.nH[0][k], T.nH[1][k], T.nH[2][k], gx, gxadd, xin, xi)) return rc;
+            if (int rc = bwd(T.m_pn[k], N, nt_n, A + T.gV[cur], nullptr, nullptr, T.a_pn[k], gx, gxadd, xin, xi)) return rc;
         }
-        if (!T.factored) {   // edge MLP: e' feeds e_{k+1} = e_k + e' and agg_k[receiver]
-            float* gx[3] = {A + T.GXs, A + T.GXr, A + T.gE[enxt]};
-            const float* gxadd[3] = {nullptr, nullptr, A + T.gE[ecur]};
-            const float* xin[3] = {A + T.Vk[k], A + T.Vk[k], A + T.Ek[k]};
-            const int32_t* xi[3] = {snd, rcv, nullptr};
-            if (int rc = bwd(me, E, nt_e, A + T.gE[ecur], A + T.gAgg, rcv, T.eH[0][k], T.eH[1][k], T.eH[2][k], gx, gxadd, xin, xi)) return rc;
-            // gather duality: the gradients of v[receivers] / v[senders] are segmented sums over the receiver / sender CSR
-            HIPCHK(h, launch_segment_sum2(L, A + T.GXr, rowptr, A + T.GXs, rowptr_s, perm_s, A + T.gV[nxt], A + T.gV[nxt], (int32_t)N, st));
-        } else {             // factored first layer: per edge only the e block; the v blocks per node from SGs / SGr
-            float* gx[3] = {A + T.gE[enxt], nullptr, nullptr};
-            const float* gxadd[3] = {A + T.gE[ecur], nullptr, nullptr};
-            const float* xin[3] = {A + T.Ek[k], nullptr, nullptr};
-            const int32_t* xi[3] = {nullptr, nullptr, nullptr};
-            if (int rc = bwd(me, E, nt_e, A + T.gE[ecur], A + T.gAgg, rcv, T.eH[0][k], T.eH[1][k], T.eH[2][k], gx, gxadd, xin, xi, N, A + T.Vk[k]))
-                return rc;
-            Lin2Args q{};     // gV += SGs W1s^T + SGr W1r^T
-            q.rows = N; q.ntiles = nt_n;
-            q.X0 = A + T.SGs; q.X1 = A + T.SGr; q.W0 = Wt + me.W1T[0]; q.W1 = Wt + me.W1T[1];
-            q.ADD = A + T.gV[nxt]; q.OUT0 = A + T.gV[nxt];
-            HIPCHK(h, launch_lin2(L, q, st));
+        for (int q = 0; q < S; ++q) {
+            const TrainMlp& me = T.m_pe[q][k];
+            const int64_t E = sx[q].E;
+            if (!T.factored[q]) {   // edge MLP: e' feeds e_{k+1} = e_k + e' and agg_k[receiver]
+                float* gx[3] = {A + T.GXs, A + T.GXr, A + T.gE[q][enxt]};
+                const float* gxadd[3] = {nullptr, nullptr, A + T.gE[q][ecur]};
+                const float* xin[3] = {A + T.Vk[k], A + T.Vk[k], A + T.Ek[q][k]};
+                const int32_t* xi[3] = {sx[q].snd, sx[q].rcv, nullptr};
+                if (int rc = bwd(me, E, sx[q].nt, A + T.gE[q][ecur], A + T.gAgg[q], sx[q].rcv, T.a_pe[q][k], gx, gxadd, xin, xi)) return rc;
+                // gather duality: the gradients of v[receivers] / v[senders] are segmented sums over the receiver / sender CSR
+                HIPCHK(h, launch_segment_sum2(L, A + T.GXr, sx[q].rowptr, A + T.GXs, sx[q].rowptr_s, sx[q].perm_s, A + T.gV[nxt], A + T.gV[nxt],
+                                              (int32_t)N, st));
+            } else {             // factored first layer: per edge only the e block; the v blocks per node from SGs / SGr
+                float* gx[3] = {A + T.gE[q][enxt], nullptr, nullptr};
+                const float* gxadd[3] = {A + T.gE[q][ecur], nullptr, nullptr};
+                const float* xin[3] = {A + T.Ek[q][k], nullptr, nullptr};
+                const int32_t* xi[3] = {nullptr, nullptr, nullptr};
+                if (int rc = bwd(me, E, sx[q].nt, A + T.gE[q][ecur], A + T.gAgg[q], sx[q].rcv, T.a_pe[q][k], gx, gxadd, xin, xi, q, A + T.Vk[k]))
+                    return rc;
+                Lin2Args l2{};    // gV += SGs W1s^T + SGr W1r^T
+                l2.rows = N; l2.ntiles = nt_n;
+                l2.X0 = A + T.SGs; l2.X1 = A + T.SGr; l2.W0 = Wt + me.b[0].W1T[0]; l2.W1 = Wt + me.b[0].W1T[1];
+                l2.ADD = A + T.gV[nxt]; l2.OUT0 = A + T.gV[nxt];
+                HIPCHK(h, launch_lin2(L, l2, st));
+            }
+            if (E == 0) HIPCHK(h, hipMemsetAsync(A + T.gE[q][enxt], 0, (size_t)L * 4, st));
         }
-        if (E == 0) HIPCHK(h, hipMemsetAsync(A + T.gE[enxt], 0, (size_t)L * 4, st));
         cur = nxt;
         ecur = enxt;
     }
@@ -591,10 +713,12 @@ int train_run(mgn_handle* h, const TrainJob& J) {
         const float* gxadd[3] = {nullptr, nullptr, nullptr};
         const float* xin[3] = {A + T.nf_pad, nullptr, nullptr};
         const int32_t* xi[3] = {nullptr, nullptr, nullptr};
-        if (int rc = bwd(m_en, N, nt_n, A + T.gV[cur], nullptr, nullptr, T.enH[0], T.enH[1], T.enH[2], gx_n, gxadd, xin, xi)) return rc;
-        const float* xin_e[3] = {A + T.ef_pad, nullptr, nullptr};
-        const int32_t* xi_e[3] = {egid, nullptr, nullptr};
-        if (int rc = bwd(m_ee, E, nt_e, A + T.gE[ecur], nullptr, nullptr, T.eeH[0], T.eeH[1], T.eeH[2], gx, gxadd, xin_e, xi_e)) return rc;
+        if (int rc = bwd(T.m_en, N, nt_n, A + T.gV[cur], nullptr, nullptr, T.a_en, gx_n, gxadd, xin, xi)) return rc;
+        for (int q = 0; q < S; ++q) {
+            const float* xin_e[3] = {A + T.ef_pad[q], nullptr, nullptr};
+            const int32_t* xi_e[3] = {sx[q].egid, nullptr, nullptr};
+            if (int rc = bwd(T.m_ee[q], sx[q].E, sx[q].nt, A + T.gE[q][ecur], nullptr, nullptr, T.a_ee[q], gx, gxadd, xin_e, xi_e)) return rc;
+        }
     }
 
     if (overlap)                                         // join: the second stream is in order, its last events cover all of it

@@ -345,50 +345,64 @@ def _mlp_bwd(g, cache, p, h):
     return g, gp
 
 
-def model_vjp(packed, cfg, nf, ef, senders, receivers, seed, dtype=np.float64):
+def model_vjp(packed, cfg, nf, ef, senders, receivers, seed, dtype=np.float64, set2=None):
     """Reverse pass through model(graph): seed(out) -> cotangent of out.  Returns (out, packed parameter gradient,
-    cotangent of nf)."""
+    cotangent of nf).  set2 = (ef2, senders2, receivers2): the second edge set of MGN-spec (forward above)."""
     h = cfg["hidden_layers"]
     P = _unpack(packed, cfg, dtype)
-    if cfg.get("Fe2"):
-        raise NotImplementedError("model_vjp: single edge set (the reference's FeatureGraph)")
+    if bool(cfg.get("Fe2")) != (set2 is not None):
+        raise ValueError("model_vjp: cfg['Fe2'] and set2 go together")
     nf, ef = np.asarray(nf, dtype), np.asarray(ef, dtype)
     N = nf.shape[0]
+    L = cfg["L"]
+    sets = [("", senders, receivers)]
     v, c_en = _mlp_fwd(nf, P["enc_node"], h)
     e, c_ee = _mlp_fwd(ef, P["enc_edge"], h)
+    es, c_encs = [e], [c_ee]
+    if set2 is not None:
+        e2, c_ee2 = _mlp_fwd(np.asarray(set2[0], dtype), P["enc_edge2"], h)
+        es.append(e2)
+        c_encs.append(c_ee2)
+        sets.append(("2", set2[1], set2[2]))
     caches = []
     for k in range(cfg["mps"]):
-        e_new, c_e = _mlp_fwd(np.concatenate([v[senders], v[receivers], e], 1), P["proc%d_edge" % k], h)
-        agg = scatter_add(e_new, receivers, N)
-        v_new, c_v = _mlp_fwd(np.concatenate([v, agg], 1), P["proc%d_node" % k], h)
-        caches.append((c_e, c_v))
-        v, e = v + v_new, e + e_new
+        c_es, aggs, news = [], [], []
+        for (sfx, s_, r_), e_ in zip(sets, es):
+            e_new, c_e = _mlp_fwd(np.concatenate([v[s_], v[r_], e_], 1), P["proc%d_edge%s" % (k, sfx)], h)
+            aggs.append(scatter_add(e_new, r_, N))
+            c_es.append(c_e)
+            news.append(e_new)
+        v_new, c_v = _mlp_fwd(np.concatenate([v] + aggs, 1), P["proc%d_node" % k], h)
+        caches.append((c_es, c_v))
+        v = v + v_new
+        es = [e_ + n_ for e_, n_ in zip(es, news)]
     out, c_d = _mlp_fwd(v, P["decoder"], h)
 
     G = {}
     gv, G["decoder"] = _mlp_bwd(seed(out), c_d, P["decoder"], h)
-    ge = np.zeros_like(e)
-    L = cfg["L"]
+    ges = [np.zeros_like(e_) for e_ in es]
     for k in range(cfg["mps"] - 1, -1, -1):
-        c_e, c_v = caches[k]
-        g_in, G["proc%d_node" % k] = _mlp_bwd(gv, c_v, P["proc%d_node" % k], h)     # v_{k+1} = v_k + MLP_v([v_k; agg])
-        g_enew = ge + g_in[:, L:][receivers]                                        # e' feeds e_{k+1} and agg[receiver]
-        g_cat, G["proc%d_edge" % k] = _mlp_bwd(g_enew, c_e, P["proc%d_edge" % k], h)
+        c_es, c_v = caches[k]
+        g_in, G["proc%d_node" % k] = _mlp_bwd(gv, c_v, P["proc%d_node" % k], h)     # v_{k+1} = v_k + MLP_v([v_k; agg_1; agg_2])
         gv = gv + g_in[:, :L]
-        np.add.at(gv, senders, g_cat[:, :L])
-        np.add.at(gv, receivers, g_cat[:, L:2 * L])
-        ge = ge + g_cat[:, 2 * L:]
+        for q, (sfx, s_, r_) in enumerate(sets):
+            g_enew = ges[q] + g_in[:, (1 + q) * L:(2 + q) * L][r_]                 # e' feeds e_{k+1} and agg[receiver]
+            g_cat, G["proc%d_edge%s" % (k, sfx)] = _mlp_bwd(g_enew, c_es[q], P["proc%d_edge%s" % (k, sfx)], h)
+            np.add.at(gv, s_, g_cat[:, :L])
+            np.add.at(gv, r_, g_cat[:, L:2 * L])
+            ges[q] = ges[q] + g_cat[:, 2 * L:]
     g_nf, G["enc_node"] = _mlp_bwd(gv, c_en, P["enc_node"], h)
-    _, G["enc_edge"] = _mlp_bwd(ge, c_ee, P["enc_edge"], h)
+    for q, (sfx, _, _) in enumerate(sets):
+        _, G["enc_edge%s" % sfx] = _mlp_bwd(ges[q], c_encs[q], P["enc_edge%s" % sfx], h)
     chunks = []
-    for bname, tensors in model_layout(cfg["Fn"], cfg["Fe"], cfg["O"], cfg["L"], h, cfg["mps"]):
+    for bname, tensors in model_layout(cfg["Fn"], cfg["Fe"], cfg["O"], cfg["L"], h, cfg["mps"], cfg.get("Fe2")):
         for tname, shape in tensors:
             assert G[bname][tname].shape == tuple(shape)
             chunks.append(G[bname][tname].ravel())
     return out, np.concatenate(chunks), g_nf
 
 
-def step_grads(packed, cfg, nf, ef, senders, receivers, target, mask):
+def step_grads(packed, cfg, nf, ef, senders, receivers, target, mask, set2=None):
     """(gs, loss) of step!: loss = mean(mse_reduce(target, model(graph))[mask]); gs = d loss / d ps in packed order.
     mask: integer node indices (0-based here; Int32 1-based at the Julia boundary, src/MeshGraphNets.jl:352)."""
     target = np.asarray(target, np.float64)
@@ -399,11 +413,12 @@ def step_grads(packed, cfg, nf, ef, senders, receivers, target, mask):
         np.add.at(g_out, mask, 2.0 * (out[mask] - target[mask]) / mask.size)
         return g_out
 
-    out, gs, _ = model_vjp(packed, cfg, nf, ef, senders, receivers, seed)
+    out, gs, _ = model_vjp(packed, cfg, nf, ef, senders, receivers, seed, set2=set2)
     return gs, float(mse_reduce(target, out)[mask].mean())
 
 
-def ode_vjp(packed, cfg, x, node_type_onehot, ef_raw, senders, receivers, n_norm_fields, n_norm_type, e_norm, o_norm, val_mask, lam):
+def ode_vjp(packed, cfg, x, node_type_onehot, ef_raw, senders, receivers, n_norm_fields, n_norm_type, e_norm, o_norm, val_mask, lam,
+            set2=None):
     """Vector-Jacobian product of the RHS f = ode_rhs (no inflow overwrite) for solver-based training
     (src/strategies.jl:175-196): returns (lambda^T df/dx, lambda^T df/dps, f(x)).  Normalisers must be affine
     (frozen), given as objects with .affine(dim) -> (scale, shift)."""
@@ -413,13 +428,13 @@ def ode_vjp(packed, cfg, x, node_type_onehot, ef_raw, senders, receivers, n_norm
     ef = e_norm(ef_raw)
     vm = np.asarray(val_mask, np.float64).reshape(-1, 1)
     o_scale = np.broadcast_to(o_norm.std, (O,))            # inverse_data: out * std + mean
-    out, gs, g_nf = model_vjp(packed, cfg, nf, ef, senders, receivers, lambda out: np.asarray(lam, np.float64) * vm * o_scale)
+    out, gs, g_nf = model_vjp(packed, cfg, nf, ef, senders, receivers, lambda out: np.asarray(lam, np.float64) * vm * o_scale, set2=set2)
     n_scale, _ = n_norm_fields.affine(O)
     return g_nf[:, :O] * n_scale, gs, o_norm.inverse(out) * vm
 
 
-def loss_only(packed, cfg, nf, ef, senders, receivers, target, mask):
-    out = forward(packed, cfg, nf, ef, senders, receivers)
+def loss_only(packed, cfg, nf, ef, senders, receivers, target, mask, set2=None):
+    out = forward(packed, cfg, nf, ef, senders, receivers, set2=set2)
     return float(mse_reduce(target, out)[np.asarray(mask).reshape(-1)].mean())
 
 

@@ -1,0 +1,216 @@
+"""The training step beyond the reference's default shape: hidden_layers 1, 3, 4 (Args.hidden_layers,
+src/MeshGraphNets.jl:35-38) and the second edge set of MGN-spec, for mgn_step (GraphNetCore.step!, src/strategies.jl:418-422) and
+mgn_ode_vjp (the RHS pullback of the solver-based strategies, src/strategies.jl:175-196), against the float64 reverse-mode oracle
+(itself checked against finite differences for the same shapes on the CPU: tests/test_oracle_golden.py).  Every kernel regime the
+step has: cooperative tiles (small meshes), the factored first edge layer (mid-size), recomputation of the kept activations."""
+import os
+
+import numpy as np
+import pytest
+import torch   # noqa: F401  (before the engine's first HIP call)
+
+import mgn_amd
+import mgn_oracle as orc
+from mgn_amd import synth
+from util import rel_max, small_mesh
+
+pytestmark = pytest.mark.gpu
+
+TOL_LOSS = 1e-5
+TOL_GRAD = 2e-4      # as tests/test_gpu_training_step.py
+
+
+def check_grads(gs, ref, cfg, tol=TOL_GRAD):
+    off, worst = 0, ("", 0.0)
+    for bname, tensors in orc.model_layout(cfg["Fn"], cfg["Fe"], cfg["O"], cfg["L"], cfg["hidden_layers"], cfg["mps"], cfg.get("Fe2")):
+        for tname, shape in tensors:
+            n = int(np.prod(shape))
+            a, b = gs[off:off + n], ref[off:off + n]
+            scale = max(np.abs(b).max(), 1e-3 * np.abs(ref).max())
+            err = float(np.abs(a - b).max() / scale)
+            if err > worst[1]:
+                worst = (f"{bname}.{tname}", err)
+            off += n
+    assert off == ref.size == gs.size
+    assert worst[1] <= tol, worst
+    return worst
+
+
+def cfg_of(hl, L=128, mps=2, Fe2=None):
+    c = dict(Fn=9, Fe=3, O=2, L=L, hidden_layers=hl, mps=mps)
+    if Fe2:
+        c["Fe2"] = Fe2
+    return c
+
+
+def params_of(cfg, seed=7):
+    return orc.init_params(cfg["Fn"], cfg["Fe"], cfg["O"], cfg["L"], cfg["hidden_layers"], cfg["mps"], seed, 0.1, Fe2=cfg.get("Fe2"))
+
+
+def engine_of(cfg):
+    return mgn_amd.Engine(cfg["Fn"], cfg["Fe"], cfg["O"], cfg["L"], cfg["hidden_layers"], cfg["mps"], Fe2=cfg.get("Fe2"))
+
+
+def problem(cfg, N, E, seed=0, frac=0.6):
+    rng = np.random.default_rng(seed)
+    nf = rng.standard_normal((N, cfg["Fn"])).astype(np.float32)
+    ef = rng.standard_normal((E, cfg["Fe"])).astype(np.float32)
+    target = rng.standard_normal((N, cfg["O"])).astype(np.float32)
+    mask = np.sort(rng.choice(N, max(1, int(frac * N)), replace=False)).astype(np.int32)
+    return nf, ef, target, mask
+
+
+@pytest.mark.parametrize("hl,L,mps", [(1, 128, 3), (3, 128, 3), (4, 128, 2), (1, 64, 2), (3, 32, 2), (4, 64, 1)])
+def test_step_hidden_layers_small_mesh(hl, L, mps):
+    cfg = cfg_of(hl, L, mps)
+    pos, s, r = small_mesh(9, 7)
+    N, E = pos.shape[0], s.size
+    ps = params_of(cfg)
+    nf, ef, target, mask = problem(cfg, N, E)
+    eng = engine_of(cfg)
+    eng.set_params(ps)
+    eng.set_graph(s, r, N)
+    gs, loss = eng.step(nf, ef, target, mask)
+    ref, ref_loss = orc.step_grads(ps, cfg, nf, ef, s, r, target, mask)
+    assert abs(loss - ref_loss) <= TOL_LOSS * abs(ref_loss), (loss, ref_loss)
+    check_grads(gs, ref, cfg)
+    for _ in range(2):                                               # deterministic, also through the captured launch graphs
+        gs2, loss2 = eng.step(nf, ef, target, mask)
+        assert loss2 == loss and np.array_equal(gs, gs2)
+    # the forward the step differentiates is the forward the inference path computes
+    out = eng.forward(nf, ef)
+    assert abs(float(orc.mse_reduce(target, out)[mask].mean()) - loss) <= 1e-4 * abs(loss)
+
+
+@pytest.mark.parametrize("hl", [2, 3])
+def test_step_two_edge_sets_small_cloth(hl):
+    m = synth.mesh_flag(nx=14, ny=12, radius=0.09)
+    N, E, E2 = m["mesh_pos"].shape[0], m["s"].size, m["s2"].size
+    assert E2 > 20
+    cfg = dict(Fn=12, Fe=7, O=3, L=128, hidden_layers=hl, mps=2, Fe2=4)
+    # (seed 3 with hidden_layers = 3 puts ONE pre-activation of proc0_node within fp32 rounding of zero: the engine's summation order
+    # lands on the other side of the ReLU than float64 and everything upstream differs by 1e-3 -- the kink case described in
+    # tests/test_gpu_training_step.py::test_ode_vjp_matches_oracle_and_ode_step; one column of b2 / W2 off, all tensors behind it exact)
+    ps = params_of(cfg, seed=11 + hl)
+    rng = np.random.default_rng(1)
+    nf = rng.standard_normal((N, 12)).astype(np.float32)
+    target = rng.standard_normal((N, 3)).astype(np.float32)
+    mask = np.sort(rng.choice(N, N // 2, replace=False)).astype(np.int32)
+    eng = engine_of(cfg)
+    eng.set_params(ps)
+    eng.set_graph(m["s"], m["r"], N)
+    eng.set_edge_set(1, m["s2"], m["r2"])
+    with pytest.raises(mgn_amd.MgnError) as ei:                      # world-edge features missing
+        eng.step(nf, m["ef"], target, mask)
+    assert ei.value.code == -3
+    eng.set_edge_features(1, m["ef2"])
+    gs, loss = eng.step(nf, m["ef"], target, mask)
+    ref, ref_loss = orc.step_grads(ps, cfg, nf, m["ef"], m["s"], m["r"], target, mask, set2=(m["ef2"], m["s2"], m["r2"]))
+    assert abs(loss - ref_loss) <= TOL_LOSS * abs(ref_loss), (loss, ref_loss)
+    check_grads(gs, ref, cfg)
+    gs2, loss2 = eng.step(nf, m["ef"], target, mask)
+    assert loss2 == loss and np.array_equal(gs, gs2)
+    # a new world-edge set (the cloth moved): the step follows it
+    keep = np.arange(E2) % 3 != 0
+    s2b, r2b, ef2b = m["s2"][keep], m["r2"][keep], m["ef2"][keep]
+    eng.set_edge_set(1, s2b, r2b)
+    eng.set_edge_features(1, ef2b)
+    gs3, loss3 = eng.step(nf, m["ef"], target, mask)
+    ref3, ref_loss3 = orc.step_grads(ps, cfg, nf, m["ef"], m["s"], m["r"], target, mask, set2=(ef2b, s2b, r2b))
+    assert abs(loss3 - ref_loss3) <= TOL_LOSS * abs(ref_loss3)
+    check_grads(gs3, ref3, cfg)
+    # an empty second set: its edge MLPs get zero gradients, the rest matches the oracle with no world edges
+    eng.set_edge_set(1, np.zeros(0, np.int32), np.zeros(0, np.int32))
+    gs4, loss4 = eng.step(nf, m["ef"], target, mask)
+    ref4, ref_loss4 = orc.step_grads(ps, cfg, nf, m["ef"], m["s"], m["r"], target, mask,
+                                     set2=(np.zeros((0, 4), np.float32), np.zeros(0, np.int32), np.zeros(0, np.int32)))
+    assert abs(loss4 - ref_loss4) <= TOL_LOSS * abs(ref_loss4)
+    check_grads(gs4, ref4, cfg)
+
+
+@pytest.fixture
+def train_env():
+    saved = {k: os.environ.get(k) for k in ("MGN_TRAIN_RECOMPUTE", "MGN_TRAIN_FACTORED")}
+    yield os.environ
+    for k, v in saved.items():
+        if v is None:
+            os.environ.pop(k, None)
+        else:
+            os.environ[k] = v
+
+
+@pytest.mark.parametrize("hl,two_sets,recompute", [(3, False, 0), (1, False, 1), (4, False, 1), (2, True, 0), (3, True, 1)])
+def test_step_midsize_factored_and_recompute(train_env, hl, two_sets, recompute):
+    """a mesh beyond the cooperative range: factored first edge layer, eight-wave tiles; with and without recomputation"""
+    train_env["MGN_TRAIN_RECOMPUTE"] = str(recompute)
+    if two_sets:
+        m = synth.mesh_flag(nx=100, ny=100, radius=0.012)
+        N, s, r, ef = m["mesh_pos"].shape[0], m["s"], m["r"], m["ef"]
+        cfg = dict(Fn=12, Fe=7, O=3, L=128, hidden_layers=hl, mps=2, Fe2=4)
+        set2 = (m["ef2"], m["s2"], m["r2"])
+        assert m["s2"].size > 500
+    else:
+        pos, s, r = synth.mesh_1m(1234, 100, 100)
+        N = pos.shape[0]
+        cfg = cfg_of(hl, 128, 2)
+        ef = np.random.default_rng(9).standard_normal((s.size, 3)).astype(np.float32)
+        set2 = None
+    assert s.size > 16 * 256 * 32 // 4
+    ps = params_of(cfg, seed=5)
+    rng = np.random.default_rng(2)
+    nf = rng.standard_normal((N, cfg["Fn"])).astype(np.float32)
+    target = rng.standard_normal((N, cfg["O"])).astype(np.float32)
+    mask = np.sort(rng.choice(N, N // 3, replace=False)).astype(np.int32)
+    eng = engine_of(cfg)
+    eng.set_params(ps)
+    eng.set_graph(s, r, N)
+    if two_sets:
+        eng.set_edge_set(1, set2[1], set2[2])
+        eng.set_edge_features(1, set2[0])
+    gs, loss = eng.step(nf, ef, target, mask)
+    ref, ref_loss = orc.step_grads(ps, cfg, nf, ef, s, r, target, mask, set2=set2)
+    assert abs(loss - ref_loss) <= TOL_LOSS * abs(ref_loss), (loss, ref_loss)
+    # ~1e7 hidden units per evaluation: a few pre-activations lie within fp32 rounding of the ReLU kink and may fall on the other
+    # side than in float64 (one column of one weight gradient and what lies upstream of it move by ~1e-3 then).  Hence, as in
+    # tests/test_gpu_training_step.py::test_step_factored_first_layer_above_the_cooperative_range: relative L2 over the whole
+    # gradient, and the per-tensor bound with room for such a unit.
+    assert np.linalg.norm(gs - ref) <= 1e-3 * np.linalg.norm(ref), np.linalg.norm(gs - ref) / np.linalg.norm(ref)
+    check_grads(gs, ref, cfg, tol=5e-3)
+    gs2, loss2 = eng.step(nf, ef, target, mask)
+    assert loss2 == loss and np.array_equal(gs, gs2)
+
+
+@pytest.mark.parametrize("hl", [1, 3])
+def test_ode_vjp_hidden_layers(hl):
+    """mgn_ode_vjp for hidden_layers != 2: frozen normalisers and val_mask like mgn_ode_step"""
+    cfg = cfg_of(hl, 128, 3)
+    pos, cells, node_type, vel = synth.mesh_cyl(1234, 300)
+    s, r = synth.cells_to_edges(cells)
+    N = pos.shape[0]
+    ps = params_of(cfg)
+    rng = np.random.default_rng(4)
+    onehot = orc.one_hot(node_type, 7, 0).astype(np.float32)
+    ef_raw = orc.edge_features(pos, s, r).astype(np.float32)
+    x = vel.astype(np.float32)
+    lam = rng.standard_normal((N, 2)).astype(np.float32)
+    n_norm = orc.NormMeanStd(np.array([1.0, 0.1]), np.array([0.4, 0.2]))
+    t_norm = orc.NormMinMax(0.0, 1.0)
+    e_norm = orc.NormMeanStd(ef_raw.mean(0), ef_raw.std(0))
+    o_norm = orc.NormMeanStd(np.array([0.01, -0.02]), np.array([0.5, 0.4]))
+    vm = np.isin(node_type, [0, 5]).astype(np.float32)
+    ns, nsh = n_norm.affine(2)
+    ts, tsh = t_norm.affine(7)
+    es, esh = e_norm.affine(3)
+    eng = engine_of(cfg)
+    eng.set_params(ps)
+    eng.set_graph(s, r, N)
+    eng.set_norms(node=(np.concatenate([ns, ts]), np.concatenate([nsh, tsh])), edge=(es, esh), out=(o_norm.std, o_norm.mean))
+    xbar, gs, dxdt = eng.ode_vjp(x, onehot, ef_raw, lam, val_mask=vm, want_dxdt=True)
+    rx, rg, rf = orc.ode_vjp(ps, cfg, x, onehot, ef_raw, s, r, n_norm, t_norm, e_norm, o_norm, vm, lam)
+    assert rel_max(dxdt, rf) <= 1e-4
+    assert rel_max(dxdt, eng.ode_step(x, onehot, ef_raw, vm)) <= 1e-5
+    # (ReLU kinks: tests/test_gpu_training_step.py::test_ode_vjp_matches_oracle_and_ode_step -- the same robust criterion)
+    row_err = np.abs(xbar - rx).max(1) / np.abs(rx).max()
+    assert (row_err > TOL_GRAD).mean() <= 0.02, (row_err > TOL_GRAD).mean()
+    assert np.linalg.norm(xbar - rx) <= 5e-3 * np.linalg.norm(rx)
+    assert np.linalg.norm(gs - rg) <= 5e-3 * np.linalg.norm(rg)

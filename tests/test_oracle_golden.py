@@ -105,6 +105,42 @@ def test_step_grads_match_finite_differences():
             off += n
 
 
+@pytest.mark.parametrize("hidden_layers,two_sets", [(1, False), (3, False), (4, False), (2, True), (3, True)])
+def test_step_grads_match_finite_differences_general(hidden_layers, two_sets):
+    """the same for hidden_layers != 2 and for the second edge set of MGN-spec (the checker of mgn_step's general path)"""
+    Fe2 = 4 if two_sets else None
+    cfg = dict(Fn=9, Fe=3, O=2, L=32, hidden_layers=hidden_layers, mps=2)
+    if two_sets:
+        cfg["Fe2"] = Fe2
+    ps = orc.init_params(9, 3, 2, 32, hidden_layers, 2, seed=2, ln_jitter=0.1, Fe2=Fe2).astype(np.float64)
+    pos, cells = mgn_amd.synth.grid_mesh(5, 4, 3)
+    s, r = mgn_amd.synth.cells_to_edges(cells)
+    N, E = pos.shape[0], s.size
+    rng = np.random.default_rng(3)
+    nf, ef, tgt = rng.standard_normal((N, 9)), rng.standard_normal((E, 3)), rng.standard_normal((N, 2))
+    set2 = None
+    if two_sets:
+        s2 = rng.integers(0, N, 17).astype(np.int32)
+        r2 = np.sort(rng.integers(0, N, 17)).astype(np.int32)
+        set2 = (rng.standard_normal((17, Fe2)), s2, r2)
+    mask = np.array([0, 3, 4, 7, 11, 12, 12])
+    g, loss = orc.step_grads(ps, cfg, nf, ef, s, r, tgt, mask, set2=set2)
+    assert abs(loss - orc.loss_only(ps, cfg, nf, ef, s, r, tgt, mask, set2=set2)) < 1e-12
+    assert g.size == ps.size
+    off = 0
+    for bname, tensors in orc.model_layout(9, 3, 2, 32, hidden_layers, 2, Fe2):
+        for tname, shape in tensors:
+            n = int(np.prod(shape))
+            i = off + int(rng.integers(n))
+            hh = 1e-6
+            p1, p2 = ps.copy(), ps.copy()
+            p1[i] += hh
+            p2[i] -= hh
+            fd = (orc.loss_only(p1, cfg, nf, ef, s, r, tgt, mask, set2=set2) - orc.loss_only(p2, cfg, nf, ef, s, r, tgt, mask, set2=set2)) / (2 * hh)
+            assert abs(fd - g[i]) <= 1e-6 * max(abs(fd), 1.0), (bname, tname, fd, g[i])
+            off += n
+
+
 def test_param_count_matches_survey():
     # SURVEY.md A4: enc-node 34,560; enc-edge 33,792; per step edge 82,560 + node 66,176; decoder 33,282
     assert orc.param_count(9, 3, 2, 128, 2, 15) == 34560 + 33792 + 15 * (82560 + 66176) + 33282
