@@ -2401,12 +2401,16 @@ hipError_t launch_edge_step(int L, const EdgeArgs& a, hipStream_t s) {
         if (rt == 2) return launch_k(k_edge_coop16m<2, false>, a, c16, s);
         return launch_k(k_edge_coop16m<1, false>, a, c16, s);
     }
-    if (coop_ok(L, a.ntiles, a.chunk_t, true)) {   // small graph: 4 waves per tile
+    // where the ring kernel of the split path is available it takes over from the cooperative tiles at 3 tiles per CU already
+    // (four-wave blocks; 5 k nodes: 50 vs 68 us per step, 10 k: 85 vs 110, 16 k: 110 vs 146), the fp32-MFMA persistent kernels only at 16
+    static const int coop_edge_ring = [] { const char* e = getenv("MGN_COOP_EDGE_TILES_PER_CU_RING"); return e ? atoi(e) : 3; }();
+    const bool ring_ok = L == 128 && g_fp32_split == 1 && a.split[0] && g_path == 0;
+    if (coop_ok(L, a.ntiles, a.chunk_t, true) && !(ring_ok && a.ntiles > coop_edge_ring * num_cus())) {   // small graph: 4 waves per tile
         LaunchCfg c4{a.ntiles, 256, coop_lds()};
         return coop_fence(a.ntiles) ? launch_k(k_edge_coop<true>, a, c4, s) : launch_k(k_edge_coop<false>, a, c4, s);
     }
     if (L == 128) {
-        if (small_launch(a.ntiles)) {   // few tiles: the per-block LDS preload would dominate -> stream everything from L2
+        if (small_launch(a.ntiles) && !(ring_ok && a.ntiles > coop_edge_ring * num_cus())) {   // few tiles: the per-block LDS preload would dominate -> stream everything from L2
             lc.lds = (size_t)T_COUNT * L * 4 + 64;
             return launch_k(k_edge_step<4, 0>, a, lc, s);
         }
@@ -2417,6 +2421,17 @@ hipError_t launch_edge_step(int L, const EdgeArgs& a, hipStream_t s) {
                 return launch_edge_split2(a, ls, s);
             }
             ls.lds = (size_t)3 * 32768 + (size_t)3 * 16384 + (size_t)T_COUNT * L * 4 + 64;
+            static const int ring_waves = [] { const char* e = getenv("MGN_RING_WAVES"); return e ? atoi(e) : 0; }();   // 0: by size
+            // four-wave blocks (one wave per SIMD) up to 2.5 rounds of eight-wave blocks: 16 k nodes 75 vs 83 us, 25.6 k 115 vs 120,
+            // 40 k 175 vs 160 (docs/experiments.md)
+            if (ring_waves == 4 || (ring_waves == 0 && a.ntiles <= 20 * num_cus())) {
+                ls.threads = 256;
+                // as few blocks as the number of rounds allows (every block pays the 150 KiB LDS prologue)
+                const int rounds = (a.ntiles + 4 * num_cus() - 1) / (4 * num_cus());
+                int blocks = (a.ntiles + 4 * rounds - 1) / (4 * rounds);
+                if (blocks > num_cus()) blocks = num_cus();
+                ls.blocks = ((blocks + NUM_XCD - 1) / NUM_XCD) * NUM_XCD;
+            }
             return launch_edge_ring(a, ls, s);
         }
         lc.lds += (size_t)MGN_EDGE_JR * 64 * 4 * 4;   // partially resident third chunk

@@ -257,7 +257,7 @@ DEVINL RingFrag ring_first(const u32x4* hi, const u32x4* ring, int lane) {
 // (NRFS, rf_next): 3.53 -> 3.46 ms.  What a request costs in the chain is its ISSUE: the eight waves are in lock-step, their
 // requests reach the CU's one memory pipeline together, and a wave whose request is not accepted issues no MFMA either (stamps:
 // every request adds ~500 cycles to its layer whether it hits L2 or not).
-template <int W, int LYR, bool RELU, int RFS = 0, int NRFS = 0>
+template <int W, int LYR, bool RELU, int RFS = 0, int NRFS = 0, int NWV = 8>
 DEVINL void sp_layer_ring(f32x16 (&acc)[4], f32x16 (&in)[4], const u32x4* hi, const u32x4* hi_next, u32x4* ring, const RingSrc& src,
                           RingFrag& nx, int lane, int tid, const f32x4* rf = nullptr, f32x4* side = nullptr,
                           const f32x4* rf_next = nullptr) {
@@ -284,7 +284,8 @@ DEVINL void sp_layer_ring(f32x16 (&acc)[4], f32x16 (&in)[4], const u32x4* hi, co
     SpPieces p;
 #pragma unroll
     for (int u = 0; u < 4; ++u) sp_split_pair<RELU>(p.h[u], p.m[u], p.l[u], in[0][2 * u], in[0][2 * u + 1]);
-    u32x4 ld_m, ld_l;                            // this thread's share of window gw + 2 on its way to LDS
+    constexpr int LPT = 8 / NWV;                 // fragments per piece and thread in a window (NWV waves share the loading)
+    u32x4 ld_m[LPT], ld_l[LPT];                  // this thread's share of window gw + 2 on its way to LDS
     unsigned voff = (unsigned)tid * 16u;
     asm volatile("" : "+v"(voff));
     __builtin_amdgcn_sched_barrier(0);
@@ -300,8 +301,11 @@ DEVINL void sp_layer_ring(f32x16 (&acc)[4], f32x16 (&in)[4], const u32x4* hi, co
                 const int g2 = (gw + 2) % NW, l2 = g2 / WPL, w2 = g2 % WPL;
                 // (uniform base + 32-bit lane offset: the scalar-base form of global_load; as per-thread 64-bit pointers
                 // hipcc hoists them out of the tile loop and spills them)
-                ld_m = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(src.mid[l2] + w2 * W * 64) + voff);
-                ld_l = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(src.lo[l2] + w2 * W * 64) + voff);
+#pragma unroll
+                for (int i = 0; i < LPT; ++i) {
+                    ld_m[i] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(src.mid[l2] + w2 * W * 64 + i * NWV * 64) + voff);
+                    ld_l[i] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(src.lo[l2] + w2 * W * 64 + i * NWV * 64) + voff);
+                }
                 if constexpr (ATREQ && W == 8) {
                     if constexpr (RFS > 0) {
                         // the registers of k-steps s - 2 and s - 1 (released one and two k-steps ago: refilling k-step s's own as
@@ -347,8 +351,11 @@ DEVINL void sp_layer_ring(f32x16 (&acc)[4], f32x16 (&in)[4], const u32x4* hi, co
             }
             if (it % W == W - 2) {                                     // ... and store it: its buffer was last read in window gw - 1
                 const int b2 = (gw + 2) % 3;
-                ring[b2 * BUF + tid - lane] = ld_m;
-                ring[b2 * BUF + W * 64 + tid - lane] = ld_l;
+#pragma unroll
+                for (int i = 0; i < LPT; ++i) {
+                    ring[b2 * BUF + i * NWV * 64 + tid - lane] = ld_m[i];
+                    ring[b2 * BUF + W * 64 + i * NWV * 64 + tid - lane] = ld_l[i];
+                }
             }
             if (s < 7) {
                 const int sn = s + 1;
@@ -434,7 +441,11 @@ DEVINL void ring_load_e(f32x16 (&x)[4], const f32x4* p) {
 #define CST(k) STAMP(k)
 #define EST(k) do {} while (0)
 #endif
-__global__ __launch_bounds__(512, 2) void k_edge_ring(const EdgeArgs a) {
+// NWV waves per block: 8 (two per SIMD), or 4 (one per SIMD) for launches of a few rounds -- a round of 4-wave blocks takes half the
+// tiles and less than half the time of one of 8-wave blocks (nothing shares its SIMD's matrix pipe), so the last, partly filled round
+// costs less (launch_edge_ring picks).
+template <int NWV>
+__global__ __launch_bounds__(NWV * 64, NWV / 4) void k_edge_ring(const EdgeArgs a) {
     constexpr int NT = 4, L = 128, PC = 16384;
     constexpr int W = 8;
     constexpr int BUF = Rg<W>::BUF;
@@ -459,10 +470,12 @@ __global__ __launch_bounds__(512, 2) void k_edge_ring(const EdgeArgs a) {
             src.lo[l] = g[l] + 4096;
         }
 #pragma unroll
-        for (int w = 0; w < 2; ++w) {                                 // windows 0 and 1 of layer 1
-            ringbase[w * BUF + tid] = src.mid[0][w * W * 64 + tid];
-            ringbase[w * BUF + W * 64 + tid] = src.lo[0][w * W * 64 + tid];
-        }
+        for (int w = 0; w < 2; ++w)                                   // windows 0 and 1 of layer 1
+#pragma unroll
+            for (int i = 0; i < 8 / NWV; ++i) {
+                ringbase[w * BUF + i * NWV * 64 + tid] = src.mid[0][w * W * 64 + i * NWV * 64 + tid];
+                ringbase[w * BUF + W * 64 + i * NWV * 64 + tid] = src.lo[0][w * W * 64 + i * NWV * 64 + tid];
+            }
     }
     __syncthreads();
     const u32x4* l1h = reinterpret_cast<const u32x4*>(wl);
@@ -512,18 +525,18 @@ __global__ __launch_bounds__(512, 2) void k_edge_ring(const EdgeArgs a) {
         __builtin_amdgcn_s_setprio(0);
         RingFrag nx = ring_first<W, 0>(l1h, ring, lane);
         // layer 1 (edge part): y = e tile in, P[s] out (acc entered with Q[r], which carries b1)
-        sp_layer_ring<W, 0, false, STRIDE_ROW>(acc, y, l1h, l2h, ring, src, nx, lane, tid, row_ptr(a.P, ps_row, L, h), side);
+        sp_layer_ring<W, 0, false, STRIDE_ROW, 0, NWV>(acc, y, l1h, l2h, ring, src, nx, lane, tid, row_ptr(a.P, ps_row, L, h), side);
 #pragma unroll
         for (int t = 0; t < NT; ++t) acc[t] += y[t];
         CST(1);
         tab_frag<NT>(y, tb + T_B2 * L, h);
         CST(2);
-        sp_layer_ring<W, 1, true, 0, STRIDE_TILE>(y, acc, l2h, l3h, ring, src, nx, lane, tid, nullptr, side, etile_rd);   // layer 2 (ReLU folded into the split)
+        sp_layer_ring<W, 1, true, 0, STRIDE_TILE, NWV>(y, acc, l2h, l3h, ring, src, nx, lane, tid, nullptr, side, etile_rd);   // layer 2 (ReLU folded into the split)
         CST(3);
         tab_frag<NT>(acc, tb + T_B3 * L, h);
         CST(4);
         // layer 3: y = layer 2's output in, the e tile (for the residual) out
-        sp_layer_ring<W, 2, true, STRIDE_TILE>(acc, y, l3h, l1h, ring, src, nx, lane, tid, etile_rd, side);
+        sp_layer_ring<W, 2, true, STRIDE_TILE, 0, NWV>(acc, y, l3h, l1h, ring, src, nx, lane, tid, etile_rd, side);
         CST(5);
         EST(1);
         PHASE_FENCE();
@@ -757,8 +770,9 @@ static hipError_t sp_launch(K kern, const A& a, const LaunchCfg& lc, hipStream_t
     return hipGetLastError();
 }
 hipError_t launch_edge_ring(const EdgeArgs& a, const LaunchCfg& lc, hipStream_t s) {
-    static bool attr_set = false;
-    return sp_launch(k_edge_ring, a, lc, s, attr_set);
+    static bool attr_set8 = false, attr_set4 = false;
+    if (lc.threads == 256) return sp_launch(k_edge_ring<4>, a, lc, s, attr_set4);
+    return sp_launch(k_edge_ring<8>, a, lc, s, attr_set8);
 }
 hipError_t launch_node_split(const NodeArgs& a, const LaunchCfg& lc, hipStream_t s) {
     static bool attr_set = false;

@@ -83,6 +83,34 @@ def test_split_edge_kernel_meets_the_fp32_tolerances(split_on, nsteps, tol):
     assert not np.array_equal(e3, e1)          # (it really is the other kernel)
 
 
+@pytest.mark.parametrize("nx", [72, 100, 180])
+def test_split_ring_block_shapes(nx):
+    """the ring kernel's launch shapes by size: 3 - 20 tiles per CU run four-wave blocks (one partly filled round at 72 x 72, three
+    rounds at 100 x 100), above that eight-wave blocks (180 x 180: 6 040 tiles); below, the cooperative kernels keep the launch"""
+    cfg = cfg_dict(mps=2)
+    pos, s, r = synth.mesh_1m(77, nx, nx)
+    N, E = pos.shape[0], s.size
+    ps = make_params(cfg, jitter=0.05)
+    rng = np.random.default_rng(nx)
+    v = rng.standard_normal((N, 128)).astype(np.float32)
+    e = rng.standard_normal((E, 128)).astype(np.float32)
+    eng = engine_for(cfg)
+    eng.set_params(ps)
+    eng.set_graph(s, r, N)
+    v1, e1 = eng.processor_steps(v, e, 2)
+    rv, re = orc.processor_steps(ps, cfg, v, e, s, r, 2)
+    assert rel_max(v1, rv) <= TOL_15 and rel_max(e1, re) <= TOL_15, (rel_max(v1, rv), rel_max(e1, re))
+    old = set_fp32_split(0)
+    try:
+        f32 = engine_for(cfg)
+        f32.set_params(ps)
+        f32.set_graph(s, r, N)
+        v0, e0 = f32.processor_steps(v, e, 2)
+    finally:
+        set_fp32_split(old)
+    assert not np.array_equal(e0, e1)              # (the split path did run at this size)
+
+
 def test_split_ragged_receivers(split_on):
     """hub nodes (runs that straddle many tiles), empty receivers, a last partial tile"""
     cfg = cfg_dict(mps=3)
