@@ -687,6 +687,15 @@ __global__ __launch_bounds__(512, 2) void k_node_split(const NodeArgs a) {
         f32x4* vtile = tile_ptr(a.V, tile, L, lane);
         __builtin_amdgcn_s_setprio(0);
         tab_frag<NT>(acc, tb + T_B1 * L, h);
+#if defined(MGN_WHATIF_NODE) && (MGN_WHATIF_NODE & 1)   // diagnostic (wrong results): every piece from LDS
+        sp_layer_otf<false, false, false, D>(acc, x, lvh, lvh, lvh, lane);
+        LOAD_AGGREGATE(NT, x, a.rowptr, a.AGG, a.CARRY, a.zero_row);
+        sp_layer_otf<false, false, false, D>(acc, x, lah, lah, lah, lane);
+        tab_frag<NT>(x, tb + T_B2 * L, h);
+        sp_layer_otf<false, false, true, D>(x, acc, l2h, l2h, l2h, lane);
+        tab_frag<NT>(acc, tb + T_B3 * L, h);
+        sp_layer_otf<false, false, true, D>(acc, x, l3h, l3h, l3h, lane);
+#else
         sp_layer_otf<true, true, false, D>(acc, x, lvh, gv + 2048, gv + 4096, lane);      // layer 1, node part
         LOAD_AGGREGATE(NT, x, a.rowptr, a.AGG, a.CARRY, a.zero_row);
         sp_layer_otf<true, true, false, D>(acc, x, lah, ga + 2048, ga + 4096, lane);      // layer 1, aggregate part
@@ -694,13 +703,22 @@ __global__ __launch_bounds__(512, 2) void k_node_split(const NodeArgs a) {
         sp_layer_otf<true, true, true, D>(x, acc, l2h, g2 + 2048, g2 + 4096, lane);       // layer 2 (ReLU folded into the split)
         tab_frag<NT>(acc, tb + T_B3 * L, h);
         sp_layer_otf<true, true, true, D>(acc, x, l3h, g3 + 2048, g3 + 4096, lane);       // layer 3
+#endif
         PHASE_FENCE();
         __builtin_amdgcn_s_setprio(MGN_PRIO);
+#if defined(MGN_WHATIF_NODE) && (MGN_WHATIF_NODE & 2)   // diagnostic: the residual reads one cached tile per wave
+        load_frag<NT>(x, tile_ptr(a.V, wave, L, lane), STRIDE_TILE);
+#else
         load_frag<NT>(x, vtile, STRIDE_TILE);                        // v again, for the residual
+#endif
         layer_norm_frag<NT>(acc, tb + T_GAMMA * L, tb + T_BETA * L, h);
 #pragma unroll
         for (int t = 0; t < NT; ++t) x[t] += acc[t];                 // v <- v + v'
+#if defined(MGN_WHATIF_NODE) && (MGN_WHATIF_NODE & 4)   // diagnostic: no store
+        if (valid && a.n < 0) store_frag<NT>(vtile, STRIDE_TILE, x);
+#else
         if (valid) store_frag<NT>(vtile, STRIDE_TILE, x);
+#endif
         if (!has_next) break;
         PHASE_FENCE();
         load_frag<NT>(x, tile_ptr(a.V, next, L, lane), STRIDE_TILE);
@@ -744,12 +762,20 @@ __global__ __launch_bounds__(512, 2) void k_project_split(const NodeArgs a) {
         const int nn = valid ? n : 0;
         __builtin_amdgcn_s_setprio(0);
         zero_frag<NT>(acc);
+#if defined(MGN_WHATIF_NODE) && (MGN_WHATIF_NODE & 1)
+        sp_layer_otf<false, false, false, D1>(acc, x, lph, lpm, lpm, lane);
+#else
         sp_layer_otf<false, true, false, D1>(acc, x, lph, lpm, gp + 4096, lane);
+#endif
         __builtin_amdgcn_s_setprio(MGN_PRIO);
         if (valid) store_frag<NT>(row_ptr(a.P, nn, L, h), STRIDE_ROW, acc);
         __builtin_amdgcn_s_setprio(0);
         tab_frag<NT>(acc, tb + T_BQ * L, h);
+#if defined(MGN_WHATIF_NODE) && (MGN_WHATIF_NODE & 1)
+        sp_layer_otf<false, false, false, D1>(acc, x, lqh, lqm, lqm, lane);
+#else
         sp_layer_otf<false, true, false, D1>(acc, x, lqh, lqm, gq + 4096, lane);
+#endif
         __builtin_amdgcn_s_setprio(MGN_PRIO);
         if (valid) store_frag<NT>(row_ptr(a.Q, nn, L, h), STRIDE_ROW, acc);
         if (!has_next) break;
