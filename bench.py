@@ -568,7 +568,7 @@ def main():
             engt.close()
             # mid-size meshes (real CFD meshes, and the per-GPU share of M-1M on 8 GPUs): where the kernel families meet
             mids = {}
-            for nxm in (128, 300):
+            for nxm in (128, 300, 354):   # 354 x 354 = the per-GPU share of M-1M on 8 GPUs
                 posm, sm, rm = mgn_amd.synth.mesh_1m(1234, nxm, nxm)
                 engm = mgn_amd.Engine(FN, FE, O, L, 2, MPS, device=local_rank)
                 engm.set_params(ps)

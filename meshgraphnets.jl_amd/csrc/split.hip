@@ -484,7 +484,20 @@ __global__ __launch_bounds__(NWV * 64, NWV / 4) void k_edge_ring(const EdgeArgs 
     // lock-step: every wave of the block runs as many tiles as its wave 0 (the longest walk); padding tiles compute, store nothing
     TileWalk tw0(a.ntiles, 0), tw(a.ntiles, wave);
     if (tw0.tile >= tw0.end) return;
+#ifndef MGN_RING_PHASES
+#define MGN_RING_PHASES 2
+#endif
+#ifndef MGN_RING_PHASE_UNITS
+#define MGN_RING_PHASE_UNITS 10
+#endif
     const int iters = (tw0.end - tw0.tile + tw0.stride - 1) / tw0.stride;
+    // Blocks of one launch start together and keep the same period, so the memory phases (epilogues) of all CUs coincide.  Long
+    // launches start every second block of an XCD half a period (10 x 4 096 cycles) late: 3.454 -> 3.413 ms on M-1M (four or eight
+    // groups: the same; a quarter period: nothing) -- the bursts are not what binds the epilogue (docs/experiments.md).
+    if (MGN_RING_PHASES > 1 && iters >= 32) {
+        const int ph = (int)(blockIdx.x / NUM_XCD) % MGN_RING_PHASES;
+        for (int i = 0; i < ph * MGN_RING_PHASE_UNITS; ++i) __builtin_amdgcn_s_sleep(64);
+    }
     const int last = a.tile0 + tw0.tile + (iters - 1) * tw0.stride;   // a tile that exists (loads of padding tiles go there)
     tw.tile += a.tile0;
     tw.end += a.tile0;

@@ -234,3 +234,43 @@ def test_feature_stats_online_normaliser_accumulation():
         x = rng.standard_normal((4000, 9)).astype(np.float32) * 2 - 0.5
         ya, yb = a(x), b(x)
     assert np.allclose(ya, yb, rtol=1e-6, atol=1e-6)
+
+
+def test_compute_from_plain_c(tmp_path):
+    """The compute entry points driven from a C99 program (tests/c_abi/abi_gpu.c: no Python, no C++ between it and the library):
+    mgn_forward and mgn_step on a small mesh, against the oracle and bitwise against the same calls through ctypes."""
+    import os
+    import subprocess
+    import mgn_amd
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    libdir = os.path.dirname(mgn_amd.lib_path()) if hasattr(mgn_amd, "lib_path") else os.path.join(root, "meshgraphnets.jl_amd", "lib")
+    exe = str(tmp_path / "abi_gpu")
+    subprocess.check_call(["gcc", "-std=c99", "-pedantic", "-Wall", "-Wextra", "-Werror", os.path.join(root, "tests", "c_abi", "abi_gpu.c"),
+                           "-o", exe, "-L", libdir, "-lmgn_hip", "-Wl,-rpath," + libdir])
+    cfg = cfg_dict(mps=3)
+    pos, s, r = small_mesh(11, 8)
+    N, E = pos.shape[0], s.size
+    ps = make_params(cfg).astype(np.float32)
+    nf, ef = random_inputs(N, E, cfg, 5)
+    rng = np.random.default_rng(6)
+    target = rng.standard_normal((N, 2)).astype(np.float32)
+    mask = np.sort(rng.choice(N, N // 2, replace=False)).astype(np.int32)
+    with open(tmp_path / "in.bin", "wb") as f:
+        f.write(np.array([N, E, ps.size, cfg["mps"], mask.size], np.int32).tobytes())
+        for a in (s.astype(np.int32), r.astype(np.int32), mask, ps, nf, ef, target):
+            f.write(np.ascontiguousarray(a).tobytes())
+    run = subprocess.run([exe, str(tmp_path / "in.bin"), str(tmp_path / "out.bin")], capture_output=True, text=True, timeout=300)
+    assert run.returncode == 0 and "abi_gpu OK" in run.stdout, run.stdout + run.stderr
+    raw = np.fromfile(tmp_path / "out.bin", np.float32)
+    out_c, loss_c, gs_c = raw[:2 * N].reshape(N, 2), float(raw[2 * N]), raw[2 * N + 1:]
+    assert gs_c.size == ps.size
+    assert rel_max(out_c, orc.forward(ps, cfg, nf, ef, s, r)) <= TOL_15
+    ref_g, ref_loss = orc.step_grads(ps, cfg, nf, ef, s, r, target, mask)
+    assert abs(loss_c - ref_loss) <= 1e-5 * abs(ref_loss)
+    assert np.linalg.norm(gs_c - ref_g) <= 1e-3 * np.linalg.norm(ref_g)
+    eng = engine_for(cfg)
+    eng.set_params(ps)
+    eng.set_graph(s, r, N)
+    assert np.array_equal(eng.forward(nf, ef), out_c)
+    gs_py, loss_py = eng.step(nf, ef, target, mask)
+    assert loss_py == loss_c and np.array_equal(gs_py, gs_c)
