@@ -2302,6 +2302,10 @@ static bool coop_size(int ntiles, bool edge) { return g_path == 0 ? ntiles <= (e
 bool launch_is_small(int ntiles) { return coop_size(ntiles, false); }
 bool launch_is_small_edge(int ntiles_e) { return coop_size(ntiles_e, true); }
 
+// 1: node MLP + projection as ONE lock-step launch over an LDS ring (k_node_ring; parity-green, 1.215 vs 1.173 ms on M-1M: opt-in)
+static int g_node_ring = [] { const char* e = getenv("MGN_NODE_RING"); return e ? atoi(e) : 0; }();
+bool node_ring_size(int ntiles) { return g_node_ring && g_fp32_split == 1 && g_path == 0 && !small_launch(ntiles) && !coop_size(ntiles, false); }
+
 static LaunchCfg tile_launch(int L, int ntiles, int nres) {
     LaunchCfg lc;
     const int cus = num_cus();
@@ -2481,6 +2485,11 @@ hipError_t launch_node_step(int L, const NodeArgs& a, hipStream_t s) {
     }
     if (a.mode == 2) return launch_project(L, a, s);
     const bool proj = a.mode == 1;
+    if (proj && L == 128 && !a.AGG2 && a.split[0] && a.split[4] && node_ring_size(a.ntiles)) {   // split path, MLP + projection (split.hip)
+        LaunchCfg ls = tile_launch(L, a.ntiles, 2);
+        ls.lds = (size_t)3 * 3 * 8 * 64 * 16 + (size_t)T_COUNT * L * 4 + 64;
+        return launch_node_ring(a, ls, s);
+    }
     if (g_fp32_split && g_path == 0 && L == 128 && !proj && !a.AGG2 && a.split[0] && !small_launch(a.ntiles)) {   // split path (split.hip)
         LaunchCfg ls = tile_launch(L, a.ntiles, 2);
         ls.lds = (size_t)4 * 16384 * 2 + (size_t)T_COUNT * L * 4 + 64;

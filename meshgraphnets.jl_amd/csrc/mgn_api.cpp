@@ -1226,6 +1226,11 @@ int mgn_proc_node(mgn_handle* h, int32_t k, int32_t project_next) try {
             if (int rc = project_set(h, k, q)) return rc;
         return MGN_OK;
     }
+    // split path, one edge set, large launch: MLP and projection in ONE lock-step launch whose weight pieces pass through an LDS ring
+    if (project_next && h->nsets == 1 && h->cfg.L == 128 && node_ring_size(h->ntiles_n) && k < (int)h->spoff.size() && h->spoff[k].have_n && h->wsp.p) {
+        HIPCHK(h, launch_node_step(h->cfg.L, node_args(h, k, 1), h->stream));
+        return MGN_OK;
+    }
     // large meshes: MLP and projection as two launches (the projection then has both of its chunks LDS-resident);
     // small meshes are launch-latency-bound: one fused launch (M-cyl: 53.0 -> 50.8 us per step)
     if (project_next && !(h->nsets == 2 && use_c16(h)) && (h->nsets > 1 || (h->node_split && !launch_is_small(h->ntiles_n)))) {

@@ -739,6 +739,160 @@ __global__ __launch_bounds__(512, 2) void k_node_split(const NodeArgs a) {
     }
 }
 
+// ================================================================================================
+// Node MLP AND the P / Q projection of the next step in one launch, lock-step like k_edge_ring: the six chunks (W1v, W1a, W2, W3, WP,
+// WQ; 18 pieces, 576 KiB) pass through ONE LDS ring per block -- three window buffers of 24 KiB (8 (s, t) steps of hi, mid and lo),
+// 24 windows per tile, every thread fetches 3 x 16 bytes per window.  k_node_split + k_project_split stream 320 KiB of pieces per tile
+// and WAVE from L2 (what-if: 0.25 ms of the node side's 1.19), read V' again for the projection and need two launches; here a tile
+// costs 72 KiB of L2 traffic per wave and v' goes from the residual straight into the projection.  For a step that is followed by
+// another one on the same handle (mgn_proc_node(project_next)), one edge set, one partition.
+// OPT-IN (MGN_NODE_RING=1): parity-green, and no faster -- 1.215 vs 1.173 ms on M-1M.  The chains run at pipe speed here too; what
+// the node side loses is outside them (138 k cycles per round against 84 k of chains): the aggregate rows behind two dependent
+// row-pointer loads, the V tile read again, and the P / Q rows written lane = row (32 cache lines per store instruction).
+// ================================================================================================
+template <int W>
+struct Rn {
+    static constexpr int WPL = 32 / W;          // windows per chunk
+    static constexpr int BUF = 3 * W * 64;      // u32x4 elements per window buffer: [piece (hi, mid, lo)][step][lane]
+};
+struct RnFrag {
+    u32x4 h, m, l;
+};
+template <int W>
+DEVINL RnFrag rn_read(const u32x4* ring /* + lane */, int gw, int step) {
+    RnFrag f;
+    const u32x4* b = ring + (gw % 3) * Rn<W>::BUF + step * 64;
+    f.h = b[0];
+    f.m = b[W * 64];
+    f.l = b[2 * W * 64];
+    return f;
+}
+// chunk CH of NCH (NCH * WPL = 0 mod 3: a window's buffer is the same for every tile); src[c]: the three pieces of chunk c, 2048
+// fragments apart.  nx: the fragments of step 0 in, those of the next chunk's step 0 out.
+template <int W, int CH, int NCH, bool RELU>
+DEVINL void spn_layer(f32x16 (&acc)[4], const f32x16 (&in)[4], u32x4* ring, const u32x4* const (&src)[NCH], RnFrag& nx, int lane, int tid) {
+    constexpr int WPL = Rn<W>::WPL, NW = NCH * WPL, BUF = Rn<W>::BUF;
+    static_assert(NW % 3 == 0, "window -> buffer must not depend on the tile");
+    SpPieces p;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) sp_split_pair<RELU>(p.h[u], p.m[u], p.l[u], in[0][2 * u], in[0][2 * u + 1]);
+    u32x4 ld[3];                                 // this thread's share of window gw + 2 on its way to LDS
+    unsigned voff = (unsigned)tid * 16u;
+    asm volatile("" : "+v"(voff));
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+        SpPieces n;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int it = 4 * s + t;
+            const int gw = WPL * CH + it / W;
+            const u32x4 a1 = nx.h, a2 = nx.m, a3 = nx.l;
+            if (it % W == 0) {                                         // request window gw + 2
+                const int g2 = (gw + 2) % NW, c2 = g2 / WPL, w2 = g2 % WPL;
+#pragma unroll
+                for (int q = 0; q < 3; ++q)
+                    ld[q] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(src[c2] + q * 2048 + w2 * W * 64) + voff);
+            }
+            if (it + 1 < 32) nx = rn_read<W>(ring, WPL * CH + (it + 1) / W, (it + 1) % W);
+            else nx = rn_read<W>(ring, (WPL * (CH + 1)) % NW, 0);       // (that window was written two windows ago)
+            if (it % W == W - 2) {                                     // ... and store it: its buffer was last read in window gw - 1
+                const int b2 = (gw + 2) % 3;
+#pragma unroll
+                for (int q = 0; q < 3; ++q) ring[b2 * BUF + q * W * 64 + tid - lane] = ld[q];
+            }
+            if (s < 7) {
+                const int sn = s + 1;
+                sp_split_pair<RELU>(n.h[t], n.m[t], n.l[t], in[sn >> 1][8 * (sn & 1) + 2 * t], in[sn >> 1][8 * (sn & 1) + 2 * t + 1]);
+            }
+            const sp_bf16x8 bh = sp_op(p.h), bm = sp_op(p.m), bl = sp_op(p.l);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sp_wop(a3), bh, acc[t], 0, 0, 0);      // small terms first
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sp_wop(a2), bm, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sp_wop(a1), bl, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sp_wop(a2), bh, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sp_wop(a1), bm, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sp_wop(a1), bh, acc[t], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (it % W == W - 1) ring_barrier();                       // window closed: every wave has read it, window gw + 2 is in LDS
+        }
+        p = n;
+    }
+}
+
+__global__ __launch_bounds__(512, 2) void k_node_ring(const NodeArgs a) {
+    constexpr int NT = 4, L = 128, W = 8, NCH = 6;
+    constexpr int BUF = Rn<W>::BUF;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    u32x4* ringbase = reinterpret_cast<u32x4*>(smem);
+    float* tb = reinterpret_cast<float*>(ringbase + 3 * BUF);
+    copy_to_lds(tb, a.tabs, T_COUNT * L);
+    // chunks in the order of use: W1 (node part), W1 (aggregate part), W2, W3, WP, WQ
+    const u32x4* const src[NCH] = {reinterpret_cast<const u32x4*>(a.split[2]), reinterpret_cast<const u32x4*>(a.split[3]),
+                                   reinterpret_cast<const u32x4*>(a.split[0]), reinterpret_cast<const u32x4*>(a.split[1]),
+                                   reinterpret_cast<const u32x4*>(a.split[4]), reinterpret_cast<const u32x4*>(a.split[5])};
+    const int lane0 = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int tid = (int)threadIdx.x;
+#pragma unroll
+    for (int w = 0; w < 2; ++w)                                       // windows 0 and 1 of the first chunk
+#pragma unroll
+        for (int q = 0; q < 3; ++q) ringbase[w * BUF + q * W * 64 + tid] = src[0][q * 2048 + w * W * 64 + tid];
+    __syncthreads();
+    // lock-step: every wave of the block runs as many tiles as its wave 0 (the longest walk); padding tiles compute, store nothing
+    TileWalk tw0(a.ntiles, 0, MGN_SPREAD_ROUNDS_NODE), tw(a.ntiles, wave, MGN_SPREAD_ROUNDS_NODE);
+    if (tw0.tile >= tw0.end) return;
+    const int iters = (tw0.end - tw0.tile + tw0.stride - 1) / tw0.stride;
+    const int last = tw0.tile + (iters - 1) * tw0.stride;
+    auto clamp = [&](int t) { return t < tw.end ? t : last; };
+    f32x16 x[NT], acc[NT];
+    load_frag<NT>(x, tile_ptr(a.V, clamp(tw.tile), L, lane0), STRIDE_TILE);
+    RnFrag nx = rn_read<W>(ringbase + lane0, 0, 0);
+    for (int j = 0; j < iters; ++j) {
+        OPAQUE_LANE();
+        const bool on = tw.tile < tw.end;
+        const int tile = clamp(tw.tile);
+        const int next = clamp(tw.tile + tw.stride);
+        const int n = tile * TILE + c;
+        const bool valid = on && n < a.n;
+        const int nn = n < a.n ? n : 0;
+        f32x4* vtile = tile_ptr(a.V, tile, L, lane);
+        u32x4* ring = ringbase + lane;
+        __builtin_amdgcn_s_setprio(0);
+        tab_frag<NT>(acc, tb + T_B1 * L, h);
+        spn_layer<W, 0, NCH, false>(acc, x, ring, src, nx, lane, tid);                     // layer 1, node part
+        {
+            const bool valid = n < a.n;                                                    // (LOAD_AGGREGATE's view: padding tiles read a real tile)
+            LOAD_AGGREGATE(NT, x, a.rowptr, a.AGG, a.CARRY, a.zero_row);
+        }
+        spn_layer<W, 1, NCH, false>(acc, x, ring, src, nx, lane, tid);                     // layer 1, aggregate part
+        tab_frag<NT>(x, tb + T_B2 * L, h);
+        spn_layer<W, 2, NCH, true>(x, acc, ring, src, nx, lane, tid);                      // layer 2 (ReLU folded into the split)
+        tab_frag<NT>(acc, tb + T_B3 * L, h);
+        spn_layer<W, 3, NCH, true>(acc, x, ring, src, nx, lane, tid);                      // layer 3
+        PHASE_FENCE();
+        __builtin_amdgcn_s_setprio(MGN_PRIO);
+        load_frag<NT>(x, vtile, STRIDE_TILE);                        // v again, for the residual
+        layer_norm_frag<NT>(acc, tb + T_GAMMA * L, tb + T_BETA * L, h);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) x[t] += acc[t];                 // v <- v + v'
+        if (valid) store_frag<NT>(vtile, STRIDE_TILE, x);
+        PHASE_FENCE();
+        __builtin_amdgcn_s_setprio(0);
+        zero_frag<NT>(acc);
+        spn_layer<W, 4, NCH, false>(acc, x, ring, src, nx, lane, tid);                     // P = v W1s of the next step's edge MLP
+        __builtin_amdgcn_s_setprio(MGN_PRIO);
+        if (valid) store_frag<NT>(row_ptr(a.P, nn, L, h), STRIDE_ROW, acc);
+        __builtin_amdgcn_s_setprio(0);
+        tab_frag<NT>(acc, tb + T_BQ * L, h);
+        spn_layer<W, 5, NCH, false>(acc, x, ring, src, nx, lane, tid);                     // Q = v W1r + b1
+        __builtin_amdgcn_s_setprio(MGN_PRIO);
+        if (valid) store_frag<NT>(row_ptr(a.Q, nn, L, h), STRIDE_ROW, acc);
+        PHASE_FENCE();
+        load_frag<NT>(x, tile_ptr(a.V, next, L, lane), STRIDE_TILE);
+        tw.tile += tw.stride;
+    }
+}
+
 // P, Q projection of the next step (k_project) on the split path.  split[4] = WP, split[5] = WQ; LDS: hi + mid of both (128 KiB),
 // the lo pieces stream.  Tiles [tile0, tile0 + ntiles).
 __global__ __launch_bounds__(512, 2) void k_project_split(const NodeArgs a) {
@@ -816,6 +970,10 @@ hipError_t launch_edge_ring(const EdgeArgs& a, const LaunchCfg& lc, hipStream_t 
 hipError_t launch_node_split(const NodeArgs& a, const LaunchCfg& lc, hipStream_t s) {
     static bool attr_set = false;
     return sp_launch(k_node_split, a, lc, s, attr_set);
+}
+hipError_t launch_node_ring(const NodeArgs& a, const LaunchCfg& lc, hipStream_t s) {
+    static bool attr_set = false;
+    return sp_launch(k_node_ring, a, lc, s, attr_set);
 }
 hipError_t launch_project_split(const NodeArgs& a, const LaunchCfg& lc, hipStream_t s) {
     static bool attr_set = false;
