@@ -155,6 +155,7 @@ hipError_t launch_edge_ring(const EdgeArgs& a, const LaunchCfg& lc, hipStream_t 
 hipError_t launch_node_split(const NodeArgs& a, const LaunchCfg& lc, hipStream_t s);    // split.hip
 hipError_t launch_project_split(const NodeArgs& a, const LaunchCfg& lc, hipStream_t s); // split.hip
 hipError_t launch_node_ring(const NodeArgs& a, const LaunchCfg& lc, hipStream_t s);     // split.hip: node MLP + projection, one launch
+long node_ring_launches();
 bool node_ring_size(int ntiles);    // launch_node_step(mode 1) would run k_node_ring at this size (given split pieces, one edge set)
 
 struct LinComb {            // sum_j c[j] * k[j]

@@ -2304,6 +2304,8 @@ bool launch_is_small_edge(int ntiles_e) { return coop_size(ntiles_e, true); }
 
 // 1: node MLP + projection as ONE lock-step launch over an LDS ring (k_node_ring; parity-green, 1.215 vs 1.173 ms on M-1M: opt-in)
 static int g_node_ring = [] { const char* e = getenv("MGN_NODE_RING"); return e ? atoi(e) : 0; }();
+static long g_node_ring_launches = 0;          // tests: the opt-in kernel computes the same bits as the two-kernel path, so they count launches
+long node_ring_launches() { return g_node_ring_launches; }
 bool node_ring_size(int ntiles) { return g_node_ring && g_fp32_split == 1 && g_path == 0 && !small_launch(ntiles) && !coop_size(ntiles, false); }
 
 static LaunchCfg tile_launch(int L, int ntiles, int nres) {
@@ -2488,6 +2490,7 @@ hipError_t launch_node_step(int L, const NodeArgs& a, hipStream_t s) {
     if (proj && L == 128 && !a.AGG2 && a.split[0] && a.split[4] && node_ring_size(a.ntiles)) {   // split path, MLP + projection (split.hip)
         LaunchCfg ls = tile_launch(L, a.ntiles, 2);
         ls.lds = (size_t)3 * 3 * 8 * 64 * 16 + (size_t)T_COUNT * L * 4 + 64;
+        ++g_node_ring_launches;
         return launch_node_ring(a, ls, s);
     }
     if (g_fp32_split && g_path == 0 && L == 128 && !proj && !a.AGG2 && a.split[0] && !small_launch(a.ntiles)) {   // split path (split.hip)

@@ -2378,6 +2378,7 @@ int mgn_debug_c16_row_tiles(int rt) { return set_c16_row_tiles(rt); }
 // large fp32 launches: 1 split path (k_edge_ring + k_node_split + k_project_split: bf16 matrix cores at fp32 accuracy; the default),
 // 2 the same with k_edge_split2, 0 fp32-MFMA kernels; returns the old value
 int mgn_debug_fp32_split(int on) { return set_fp32_split(on); }
+long mgn_debug_node_ring_launches(void) { return node_ring_launches(); }   // launches of the opt-in k_node_ring so far (tests)
 
 int mgn_debug_edge_stamps(mgn_handle* h, int32_t k, unsigned long long* out /* [32768] */) try {
     if (int rc = need(h, true, true)) return rc;

@@ -153,3 +153,48 @@ def test_split_two_edge_sets(split_on):
     e21 = eng.edge_latents_export(1)
     rv, re, re2 = orc.processor_steps(ps, cfg, v, e, m["s"], m["r"], 2, set2=(e2, m["s2"], m["r2"]))
     assert rel_max(v1, rv) <= TOL_15 and rel_max(e1, re) <= TOL_15 and rel_max(e21, re2) <= TOL_15
+
+
+def test_node_ring_opt_in_kernel():
+    """MGN_NODE_RING=1 (read once per process, hence a child process): node MLP + projection of a step in one lock-step launch
+    (k_node_ring), on a mesh beyond the cooperative node kernels' range; same tolerances and, by construction, the same bits."""
+    import os
+    import subprocess
+    import sys
+    code = r'''
+import sys, numpy as np, torch
+import mgn_oracle as orc
+from mgn_amd import synth
+from util import TOL_15, cfg_dict, engine_for, make_params, rel_max
+cfg = cfg_dict(mps=3)
+pos, s, r = synth.mesh_1m(5, 260, 260)
+N, E = pos.shape[0], s.size
+assert (N + 31) // 32 > 8 * 256
+ps = make_params(cfg, jitter=0.05)
+rng = np.random.default_rng(1)
+v = rng.standard_normal((N, 128)).astype(np.float32)
+e = rng.standard_normal((E, 128)).astype(np.float32)
+eng = engine_for(cfg)
+eng.set_params(ps); eng.set_graph(s, r, N)
+v1, e1 = eng.processor_steps(v, e, 3)
+np.save(sys.argv[1], v1)
+import ctypes
+f = eng.lib.mgn_debug_node_ring_launches; f.restype = ctypes.c_long; f.argtypes = []
+print("ring launches", f())
+if len(sys.argv) > 2:
+    rv, re = orc.processor_steps(ps, cfg, v, e, s, r, 3)
+    assert rel_max(v1, rv) <= TOL_15 and rel_max(e1, re) <= TOL_15, (rel_max(v1, rv), rel_max(e1, re))
+print("child OK")
+'''
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PYTHONPATH=os.pathsep.join([root, os.path.join(root, "tests"), os.path.join(root, "oracle")]))
+    outs = []
+    for ring, check in (("1", ["check"]), ("0", [])):
+        env["MGN_NODE_RING"] = ring
+        f = "/tmp/mgn_node_ring_%s.npy" % ring
+        run = subprocess.run([sys.executable, "-c", code, f] + check, env=env, capture_output=True, text=True, timeout=600)
+        assert run.returncode == 0 and "child OK" in run.stdout, run.stdout[-2000:] + run.stderr[-2000:]
+        outs.append(np.load(f))
+        assert ("ring launches 2" in run.stdout) == (ring == "1"), run.stdout        # steps 0 and 1 project for a next step
+    # the same MFMA sequence per layer, only the weight fragments arrive another way: the bits are the two-kernel path's
+    assert np.array_equal(outs[0], outs[1])
