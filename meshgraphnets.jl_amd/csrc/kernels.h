@@ -152,6 +152,7 @@ hipError_t launch_gather_rows16(const uint16_t* src, const int32_t* idx, uint16_
 struct LaunchCfg { int blocks; int threads; size_t lds; };
 hipError_t launch_edge_split2(const EdgeArgs& a, const LaunchCfg& lc, hipStream_t s);   // split.hip
 hipError_t launch_edge_ring(const EdgeArgs& a, const LaunchCfg& lc, hipStream_t s);    // split.hip
+hipError_t launch_edge_ring2(const EdgeArgs& a, const LaunchCfg& lc, hipStream_t s);   // split.hip: two four-wave blocks per CU
 hipError_t launch_node_split(const NodeArgs& a, const LaunchCfg& lc, hipStream_t s);    // split.hip
 hipError_t launch_project_split(const NodeArgs& a, const LaunchCfg& lc, hipStream_t s); // split.hip
 hipError_t launch_node_ring(const NodeArgs& a, const LaunchCfg& lc, hipStream_t s);     // split.hip: node MLP + projection, one launch

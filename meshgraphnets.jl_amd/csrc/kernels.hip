@@ -2426,6 +2426,14 @@ hipError_t launch_edge_step(int L, const EdgeArgs& a, hipStream_t s) {
                 ls.lds = (size_t)4 * 16384 * 2 + (size_t)T_COUNT * L * 4 + 64;
                 return launch_edge_split2(a, ls, s);
             }
+            if (g_fp32_split == 3) {   // two independent four-wave blocks per CU, every piece through the block's own ring
+                ls.threads = 256;
+                ls.lds = (size_t)3 * 3 * 8 * 64 * 16 + (size_t)T_COUNT * L * 4 + 64;
+                int blocks = (a.ntiles + 3) / 4;
+                if (blocks > 2 * num_cus()) blocks = 2 * num_cus();
+                ls.blocks = ((blocks + NUM_XCD - 1) / NUM_XCD) * NUM_XCD;
+                return launch_edge_ring2(a, ls, s);
+            }
             ls.lds = (size_t)3 * 32768 + (size_t)3 * 16384 + (size_t)T_COUNT * L * 4 + 64;
             static const int ring_waves = [] { const char* e = getenv("MGN_RING_WAVES"); return e ? atoi(e) : 0; }();   // 0: by size
             // four-wave blocks (one wave per SIMD) up to 2.5 rounds of eight-wave blocks: 16 k nodes 75 vs 83 us, 25.6 k 115 vs 120,

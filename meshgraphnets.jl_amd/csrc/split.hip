@@ -769,14 +769,15 @@ DEVINL RnFrag rn_read(const u32x4* ring /* + lane */, int gw, int step) {
 }
 // chunk CH of NCH (NCH * WPL = 0 mod 3: a window's buffer is the same for every tile); src[c]: the three pieces of chunk c, 2048
 // fragments apart.  nx: the fragments of step 0 in, those of the next chunk's step 0 out.
-template <int W, int CH, int NCH, bool RELU>
+template <int W, int CH, int NCH, bool RELU, int NWV = 8>
 DEVINL void spn_layer(f32x16 (&acc)[4], const f32x16 (&in)[4], u32x4* ring, const u32x4* const (&src)[NCH], RnFrag& nx, int lane, int tid) {
     constexpr int WPL = Rn<W>::WPL, NW = NCH * WPL, BUF = Rn<W>::BUF;
+    constexpr int LPT = 8 / NWV;                 // fragments per piece and thread in a window
     static_assert(NW % 3 == 0, "window -> buffer must not depend on the tile");
     SpPieces p;
 #pragma unroll
     for (int u = 0; u < 4; ++u) sp_split_pair<RELU>(p.h[u], p.m[u], p.l[u], in[0][2 * u], in[0][2 * u + 1]);
-    u32x4 ld[3];                                 // this thread's share of window gw + 2 on its way to LDS
+    u32x4 ld[3 * LPT];                           // this thread's share of window gw + 2 on its way to LDS
     unsigned voff = (unsigned)tid * 16u;
     asm volatile("" : "+v"(voff));
     __builtin_amdgcn_sched_barrier(0);
@@ -792,14 +793,19 @@ DEVINL void spn_layer(f32x16 (&acc)[4], const f32x16 (&in)[4], u32x4* ring, cons
                 const int g2 = (gw + 2) % NW, c2 = g2 / WPL, w2 = g2 % WPL;
 #pragma unroll
                 for (int q = 0; q < 3; ++q)
-                    ld[q] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(src[c2] + q * 2048 + w2 * W * 64) + voff);
+#pragma unroll
+                    for (int i = 0; i < LPT; ++i)
+                        ld[q * LPT + i] =
+                            *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(src[c2] + q * 2048 + w2 * W * 64 + i * NWV * 64) + voff);
             }
             if (it + 1 < 32) nx = rn_read<W>(ring, WPL * CH + (it + 1) / W, (it + 1) % W);
             else nx = rn_read<W>(ring, (WPL * (CH + 1)) % NW, 0);       // (that window was written two windows ago)
             if (it % W == W - 2) {                                     // ... and store it: its buffer was last read in window gw - 1
                 const int b2 = (gw + 2) % 3;
 #pragma unroll
-                for (int q = 0; q < 3; ++q) ring[b2 * BUF + q * W * 64 + tid - lane] = ld[q];
+                for (int q = 0; q < 3; ++q)
+#pragma unroll
+                    for (int i = 0; i < LPT; ++i) ring[b2 * BUF + q * W * 64 + i * NWV * 64 + tid - lane] = ld[q * LPT + i];
             }
             if (s < 7) {
                 const int sn = s + 1;
@@ -893,6 +899,109 @@ __global__ __launch_bounds__(512, 2) void k_node_ring(const NodeArgs a) {
     }
 }
 
+// ================================================================================================
+// Edge step, TWO independent blocks per CU (MGN_FP32_SPLIT=3).  k_edge_ring's eight waves are in lock-step, so the two waves of a SIMD
+// are in their epilogues at the same time and the matrix pipe idles for half of the tile; the register-ring kernel (k_edge_split2) has
+// waves that overlap freely and drowns in 160 KiB of L2 weight traffic per tile and wave.  Here a block is four waves (one per SIMD)
+// with its OWN ring through which ALL pieces pass (72 KiB of LDS: two such blocks fit a CU; 72 KiB of L2 traffic per tile and wave)
+// and its own barrier, so the two blocks of a CU drift freely against each other: one's epilogue runs beside the other's chains.  The
+// second half of the grid starts half a period late.  No refill machinery: a block's exposed loads are the other block's matrix time.
+// ================================================================================================
+#ifndef MGN_RING2_PHASE_UNITS
+#define MGN_RING2_PHASE_UNITS 7
+#endif
+__global__ __launch_bounds__(256, 2) void k_edge_ring2(const EdgeArgs a) {
+    constexpr int NT = 4, L = 128, W = 8, NCH = 3, NWV = 4;
+    constexpr int BUF = Rn<W>::BUF;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    u32x4* ringbase = reinterpret_cast<u32x4*>(smem);
+    float* tb = reinterpret_cast<float*>(ringbase + 3 * BUF);
+    copy_to_lds(tb, a.tabs, T_COUNT * L);
+    const u32x4* const src[NCH] = {reinterpret_cast<const u32x4*>(a.split[2]), reinterpret_cast<const u32x4*>(a.split[0]),
+                                   reinterpret_cast<const u32x4*>(a.split[1])};      // W1e, W2, W3: three pieces each, 2048 fragments apart
+    const int lane0 = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int tid = (int)threadIdx.x;
+#pragma unroll
+    for (int w = 0; w < 2; ++w)
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+#pragma unroll
+            for (int i = 0; i < 8 / NWV; ++i)
+                ringbase[w * BUF + q * W * 64 + i * NWV * 64 + tid] = src[0][q * 2048 + w * W * 64 + i * NWV * 64 + tid];
+    __syncthreads();
+    TileWalk tw0(a.ntiles, 0), tw(a.ntiles, wave);
+    if (tw0.tile >= tw0.end) return;
+    const int iters = (tw0.end - tw0.tile + tw0.stride - 1) / tw0.stride;
+    if (iters >= 16 && blockIdx.x >= gridDim.x / 2)
+        for (int i = 0; i < MGN_RING2_PHASE_UNITS; ++i) __builtin_amdgcn_s_sleep(64);
+    const int last = a.tile0 + tw0.tile + (iters - 1) * tw0.stride;
+    tw.tile += a.tile0;
+    tw.end += a.tile0;
+    auto clamp = [&](int t) { return t < tw.end ? t : last; };
+    f32x16 acc[NT], y[NT];
+    EdgeIdx ix = load_edge_idx_nb(a.snd, a.rcv, a.E, clamp(tw.tile), lane0 & 31);
+    load_frag<NT>(acc, row_ptr(a.Q, ix.r >= 0 ? ix.r : 0, L, lane0 >> 5), STRIDE_ROW);
+    load_frag<NT>(y, tile_ptr(a.Elat, clamp(tw.tile), L, lane0), STRIDE_TILE);
+    RnFrag nx = rn_read<W>(ringbase + lane0, 0, 0);
+    for (int j = 0; j < iters; ++j) {
+        OPAQUE_LANE();
+        const bool on = tw.tile < tw.end;
+        const int tile = clamp(tw.tile);
+        const int nxt = clamp(tw.tile + tw.stride);
+        const EdgeIdx ixn = load_edge_idx_nb(a.snd, a.rcv, a.E, nxt, c);
+        const bool valid = on && ix.r >= 0;
+        const int r = ix.r >= 0 ? ix.r : 0;
+        f32x4* etile = tile_ptr(a.Elat, tile, L, lane);
+        u32x4* ring = ringbase + lane;
+        __builtin_amdgcn_s_setprio(0);
+        spn_layer<W, 0, NCH, false, NWV>(acc, y, ring, src, nx, lane, tid);          // layer 1, edge part (acc entered with Q[r], which carries b1)
+        load_frag<NT>(y, row_ptr(a.P, ix.s, L, h), STRIDE_ROW);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] += y[t];
+        tab_frag<NT>(y, tb + T_B2 * L, h);
+        spn_layer<W, 1, NCH, true, NWV>(y, acc, ring, src, nx, lane, tid);           // layer 2
+        tab_frag<NT>(acc, tb + T_B3 * L, h);
+        spn_layer<W, 2, NCH, true, NWV>(acc, y, ring, src, nx, lane, tid);           // layer 3
+        PHASE_FENCE();
+        __builtin_amdgcn_s_setprio(MGN_PRIO);
+        load_frag<NT>(y, etile, STRIDE_TILE);                                         // e again, for the residual
+        layer_norm_frag<NT>(acc, tb + T_GAMMA * L, tb + T_BETA * L, h);              // acc = e'
+#pragma unroll
+        for (int t = 0; t < NT; ++t) y[t] += acc[t];                                  // e <- e + e'
+        if (valid) store_frag<NT>(etile, STRIDE_TILE, y);
+        load_frag<NT>(y, tile_ptr(a.Elat, nxt, L, lane), STRIDE_TILE);               // the next tile's e
+        const int reff = ix.r >= 0 ? r : (-4 - c);
+        const int rprev = __shfl_up(reff, 1, 32);
+        const int rnext = __shfl_down(reff, 1, 32);
+        const bool head = (c == 0) || (reff != rprev);
+        const unsigned hm = (unsigned)__ballot(head);
+        const int start = 31 - __clz((int)(hm & (0xFFFFFFFFu >> (31 - c))));
+        const int st_in = max(start, c & 16);
+        const bool c1 = (c - 1 >= st_in), c2 = (c - 2 >= st_in), c4 = (c - 4 >= st_in), c8 = (c - 8 >= st_in);
+        const bool cx = (c >= 16) && (start <= 15);
+        PHASE_FENCE();
+        asm volatile("s_nop 1");
+        RG_SCAN_LEVEL(acc, c1, "row_shr:1 row_mask:0xf bank_mask:0xf");
+        RG_SCAN_LEVEL(acc, c2, "row_shr:2 row_mask:0xf bank_mask:0xf");
+        RG_SCAN_LEVEL(acc, c4, "row_shr:4 row_mask:0xf bank_mask:0xf");
+        RG_SCAN_LEVEL(acc, c8, "row_shr:8 row_mask:0xf bank_mask:0xf");
+        RG_SCAN_LEVEL(acc, cx, "row_bcast:15 row_mask:0xa bank_mask:0xf");
+        PHASE_FENCE();
+        const bool tail = valid && ((c == 31) || (reff != rnext));
+        const int r_first = __builtin_amdgcn_readfirstlane(reff);
+        const bool sl = (start == 0) && (ix.r_before == r_first);
+        const bool sr = (c == 31) && (ix.r_after == reff);
+        const bool to_carry = sl || sr;
+        f32x4* dst = to_carry ? row_ptr(a.CARRY, (int64_t)2 * tile + (sl ? 0 : 1), L, h) : tile_ptr(a.AGG, r >> 5, L, 32 * h + (r & 31));
+        if (tail) store_frag<NT>(dst, to_carry ? STRIDE_ROW : STRIDE_TILE, acc);
+        PHASE_FENCE();
+        load_frag<NT>(acc, row_ptr(a.Q, ixn.r >= 0 ? ixn.r : 0, L, h), STRIDE_ROW);
+        ix = ixn;
+        tw.tile += tw.stride;
+    }
+}
+
 // P, Q projection of the next step (k_project) on the split path.  split[4] = WP, split[5] = WQ; LDS: hi + mid of both (128 KiB),
 // the lo pieces stream.  Tiles [tile0, tile0 + ntiles).
 __global__ __launch_bounds__(512, 2) void k_project_split(const NodeArgs a) {
@@ -970,6 +1079,10 @@ hipError_t launch_edge_ring(const EdgeArgs& a, const LaunchCfg& lc, hipStream_t 
 hipError_t launch_node_split(const NodeArgs& a, const LaunchCfg& lc, hipStream_t s) {
     static bool attr_set = false;
     return sp_launch(k_node_split, a, lc, s, attr_set);
+}
+hipError_t launch_edge_ring2(const EdgeArgs& a, const LaunchCfg& lc, hipStream_t s) {
+    static bool attr_set = false;
+    return sp_launch(k_edge_ring2, a, lc, s, attr_set);
 }
 hipError_t launch_node_ring(const NodeArgs& a, const LaunchCfg& lc, hipStream_t s) {
     static bool attr_set = false;

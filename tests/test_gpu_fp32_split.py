@@ -13,7 +13,7 @@ from util import TOL_15, TOL_STEP, cfg_dict, engine_for, make_params, rel_max, s
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(params=[1, 2], ids=["ring", "split2"])
+@pytest.fixture(params=[1, 2, 3], ids=["ring", "split2", "ring2"])
 def split_on(request):
     old = set_fp32_split(request.param)
     yield request.param
