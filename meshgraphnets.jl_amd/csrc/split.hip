@@ -301,11 +301,13 @@ DEVINL void sp_layer_ring(f32x16 (&acc)[4], f32x16 (&in)[4], const u32x4* hi, co
                 const int g2 = (gw + 2) % NW, l2 = g2 / WPL, w2 = g2 % WPL;
                 // (uniform base + 32-bit lane offset: the scalar-base form of global_load; as per-thread 64-bit pointers
                 // hipcc hoists them out of the tile loop and spills them)
+#if !(defined(MGN_WHATIF_LOADER) && (MGN_WHATIF_LOADER & 1))     // diagnostic (wrong results): 1 = no window loads at all, 2 = no barriers
 #pragma unroll
                 for (int i = 0; i < LPT; ++i) {
                     ld_m[i] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(src.mid[l2] + w2 * W * 64 + i * NWV * 64) + voff);
                     ld_l[i] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(src.lo[l2] + w2 * W * 64 + i * NWV * 64) + voff);
                 }
+#endif
                 if constexpr (ATREQ && W == 8) {
                     if constexpr (RFS > 0) {
                         // the registers of k-steps s - 2 and s - 1 (released one and two k-steps ago: refilling k-step s's own as
@@ -351,11 +353,13 @@ DEVINL void sp_layer_ring(f32x16 (&acc)[4], f32x16 (&in)[4], const u32x4* hi, co
             }
             if (it % W == W - 2) {                                     // ... and store it: its buffer was last read in window gw - 1
                 const int b2 = (gw + 2) % 3;
+#if !(defined(MGN_WHATIF_LOADER) && (MGN_WHATIF_LOADER & 1))
 #pragma unroll
                 for (int i = 0; i < LPT; ++i) {
                     ring[b2 * BUF + i * NWV * 64 + tid - lane] = ld_m[i];
                     ring[b2 * BUF + W * 64 + i * NWV * 64 + tid - lane] = ld_l[i];
                 }
+#endif
             }
             if (s < 7) {
                 const int sn = s + 1;
@@ -369,7 +373,9 @@ DEVINL void sp_layer_ring(f32x16 (&acc)[4], f32x16 (&in)[4], const u32x4* hi, co
             acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sp_wop(a1), bm, acc[t], 0, 0, 0);
             acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sp_wop(a1), bh, acc[t], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
+#if !(defined(MGN_WHATIF_LOADER) && (MGN_WHATIF_LOADER & 2))
             if (it % W == W - 1) ring_barrier();                       // window closed: every wave has read it, window gw + 2 is in LDS
+#endif
         }
         p = n;
         if constexpr (RFS > 0 && MODE == 0) {
