@@ -111,10 +111,12 @@ def test_split_ring_block_shapes(nx):
     assert not np.array_equal(e0, e1)              # (the split path did run at this size)
 
 
-def test_split_ragged_receivers(split_on):
-    """hub nodes (runs that straddle many tiles), empty receivers, a last partial tile"""
+@pytest.mark.parametrize("E", [140001, 200003])
+def test_split_ragged_receivers(split_on, E):
+    """hub nodes (runs that straddle many tiles), empty receivers, a last partial tile; 140 001 edges run the ring kernel in four-wave
+    blocks, 200 003 in eight-wave blocks"""
     cfg = cfg_dict(mps=3)
-    N, E = 9000, 140001
+    N = 9000
     s, r = synth.random_graph(N, E, 7)
     r[: E // 3] = 17
     r[E // 3: E // 3 + 5000] = 4000
