@@ -775,8 +775,12 @@ DEVINL RnFrag rn_read(const u32x4* ring /* + lane */, int gw, int step) {
 }
 // chunk CH of NCH (NCH * WPL = 0 mod 3: a window's buffer is the same for every tile); src[c]: the three pieces of chunk c, 2048
 // fragments apart.  nx: the fragments of step 0 in, those of the next chunk's step 0 out.
-template <int W, int CH, int NCH, bool RELU, int NWV = 8>
-DEVINL void spn_layer(f32x16 (&acc)[4], const f32x16 (&in)[4], u32x4* ring, const u32x4* const (&src)[NCH], RnFrag& nx, int lane, int tid) {
+// RF: `in` is refilled, as the split releases its registers, with the sixteen 16-byte pieces rf[m * rfstride] (sp_layer_ring's
+// refill, schedule 2: one request every second step, pieces of k-step s + 2 into the registers of k-step s; the caller requested
+// pieces 0 .. 3 into `side` before the layer); `in` comes back holding them in fragment order.
+template <int W, int CH, int NCH, bool RELU, int NWV = 8, bool RF = false>
+DEVINL void spn_layer(f32x16 (&acc)[4], f32x16 (&in)[4], u32x4* ring, const u32x4* const (&src)[NCH], RnFrag& nx, int lane, int tid,
+                      const f32x4* rf = nullptr, int rfstride = 0, const f32x4* side = nullptr) {
     constexpr int WPL = Rn<W>::WPL, NW = NCH * WPL, BUF = Rn<W>::BUF;
     constexpr int LPT = 8 / NWV;                 // fragments per piece and thread in a window
     static_assert(NW % 3 == 0, "window -> buffer must not depend on the tile");
@@ -804,6 +808,13 @@ DEVINL void spn_layer(f32x16 (&acc)[4], const f32x16 (&in)[4], u32x4* ring, cons
                         ld[q * LPT + i] =
                             *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(src[c2] + q * 2048 + w2 * W * 64 + i * NWV * 64) + voff);
             }
+            if constexpr (RF) {
+                if ((t & 1) && s < 6) {                                // registers of k-step s (free since the step began), half t >> 1
+                    const f32x4 v = rf[(2 * (s + 2) + (t >> 1)) * rfstride];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) in[s >> 1][8 * (s & 1) + 4 * (t >> 1) + i] = v[i];
+                }
+            }
             if (it + 1 < 32) nx = rn_read<W>(ring, WPL * CH + (it + 1) / W, (it + 1) % W);
             else nx = rn_read<W>(ring, (WPL * (CH + 1)) % NW, 0);       // (that window was written two windows ago)
             if (it % W == W - 2) {                                     // ... and store it: its buffer was last read in window gw - 1
@@ -828,6 +839,15 @@ DEVINL void spn_layer(f32x16 (&acc)[4], const f32x16 (&in)[4], u32x4* ring, cons
             if (it % W == W - 1) ring_barrier();                       // window closed: every wave has read it, window gw + 2 is in LDS
         }
         p = n;
+    }
+    if constexpr (RF) {                                                // un-rotate: k-step u's pieces sit in the registers of k-step u - 2
+        f32x16 r[4];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) r[u >> 1][8 * (u & 1) + j] = u < 2 ? side[2 * u + (j >> 2)][j & 3] : in[(u - 2) >> 1][8 * ((u - 2) & 1) + j];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) in[t] = r[t];
     }
 }
 
@@ -859,6 +879,15 @@ __global__ __launch_bounds__(512, 2) void k_node_ring(const NodeArgs a) {
     f32x16 x[NT], acc[NT];
     load_frag<NT>(x, tile_ptr(a.V, clamp(tw.tile), L, lane0), STRIDE_TILE);
     RnFrag nx = rn_read<W>(ringbase + lane0, 0, 0);
+    // CSR bounds of this lane's node, one tile ahead (the aggregate's address depends on them)
+    auto bounds = [&](int t, int cc, int& b0, int& b1) {
+        const int nq = t * TILE + cc;
+        const int nc = nq < a.n ? nq : a.n - 1;
+        b0 = a.rowptr[nc];
+        b1 = nq < a.n ? a.rowptr[nc + 1] : b0;
+    };
+    int a0, a1;
+    bounds(clamp(tw.tile), lane0 & 31, a0, a1);
     for (int j = 0; j < iters; ++j) {
         OPAQUE_LANE();
         const bool on = tw.tile < tw.end;
@@ -870,12 +899,28 @@ __global__ __launch_bounds__(512, 2) void k_node_ring(const NodeArgs a) {
         f32x4* vtile = tile_ptr(a.V, tile, L, lane);
         u32x4* ring = ringbase + lane;
         __builtin_amdgcn_s_setprio(0);
+        int b0, b1;
+        bounds(next, c, b0, b1);
+        // where the aggregate of this node lies (LOAD_AGGREGATE's address logic); its rows arrive during the first chunk
+        const int T1 = a0 >> 5, T2 = (a1 - 1) >> 5;
+        const int extra = (a1 > a0 && T2 > T1) ? (T2 - T1) : 0;
+        const bool from_agg = (a1 > a0) && !extra;
+        const f32x4* agg0 = from_agg ? tile_ptr(a.AGG, tile, L, lane) : row_ptr(a.CARRY, extra ? (int64_t)(2 * T1 + 1) : a.zero_row, L, h);
+        const int aggs = from_agg ? STRIDE_TILE : STRIDE_ROW;
+        f32x4 side[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) side[m] = agg0[m * aggs];
         tab_frag<NT>(acc, tb + T_B1 * L, h);
+#if defined(MGN_WHATIF_NRING) && (MGN_WHATIF_NRING & 4)
         spn_layer<W, 0, NCH, false>(acc, x, ring, src, nx, lane, tid);                     // layer 1, node part
-        {
-            const bool valid = n < a.n;                                                    // (LOAD_AGGREGATE's view: padding tiles read a real tile)
-            LOAD_AGGREGATE(NT, x, a.rowptr, a.AGG, a.CARRY, a.zero_row);
-        }
+#else
+        spn_layer<W, 0, NCH, false, 8, true>(acc, x, ring, src, nx, lane, tid, agg0, aggs, side);   // layer 1, node part; x <- aggregate rows
+        for (int q = 1; __any(q <= extra); ++q)                                            // (a receiver whose run straddles more than two edge tiles)
+            if (q <= extra) add_frag<NT>(x, row_ptr(a.CARRY, (int64_t)2 * (T1 + q), L, h), STRIDE_ROW);
+#endif
+#if defined(MGN_WHATIF_NRING) && (MGN_WHATIF_NRING & 4)     // diagnostic builds (wrong results): what the memory phases cost
+        load_frag<NT>(x, tile_ptr(a.V, wave, L, lane), STRIDE_TILE);
+#endif
         spn_layer<W, 1, NCH, false>(acc, x, ring, src, nx, lane, tid);                     // layer 1, aggregate part
         tab_frag<NT>(x, tb + T_B2 * L, h);
         spn_layer<W, 2, NCH, true>(x, acc, ring, src, nx, lane, tid);                      // layer 2 (ReLU folded into the split)
@@ -883,24 +928,46 @@ __global__ __launch_bounds__(512, 2) void k_node_ring(const NodeArgs a) {
         spn_layer<W, 3, NCH, true>(acc, x, ring, src, nx, lane, tid);                      // layer 3
         PHASE_FENCE();
         __builtin_amdgcn_s_setprio(MGN_PRIO);
+#if defined(MGN_WHATIF_NRING) && (MGN_WHATIF_NRING & 1)
+        load_frag<NT>(x, tile_ptr(a.V, wave, L, lane), STRIDE_TILE);
+#else
         load_frag<NT>(x, vtile, STRIDE_TILE);                        // v again, for the residual
+#endif
         layer_norm_frag<NT>(acc, tb + T_GAMMA * L, tb + T_BETA * L, h);
 #pragma unroll
         for (int t = 0; t < NT; ++t) x[t] += acc[t];                 // v <- v + v'
+#if defined(MGN_WHATIF_NRING) && (MGN_WHATIF_NRING & 2)
+        if (valid && a.n < 0) store_frag<NT>(vtile, STRIDE_TILE, x);
+#else
         if (valid) store_frag<NT>(vtile, STRIDE_TILE, x);
+#endif
         PHASE_FENCE();
         __builtin_amdgcn_s_setprio(0);
         zero_frag<NT>(acc);
         spn_layer<W, 4, NCH, false>(acc, x, ring, src, nx, lane, tid);                     // P = v W1s of the next step's edge MLP
         __builtin_amdgcn_s_setprio(MGN_PRIO);
+#if defined(MGN_WHATIF_NRING) && (MGN_WHATIF_NRING & 2)
+        if (valid && a.n < 0) store_frag<NT>(row_ptr(a.P, nn, L, h), STRIDE_ROW, acc);
+#else
         if (valid) store_frag<NT>(row_ptr(a.P, nn, L, h), STRIDE_ROW, acc);
+#endif
         __builtin_amdgcn_s_setprio(0);
         tab_frag<NT>(acc, tb + T_BQ * L, h);
         spn_layer<W, 5, NCH, false>(acc, x, ring, src, nx, lane, tid);                     // Q = v W1r + b1
         __builtin_amdgcn_s_setprio(MGN_PRIO);
+#if defined(MGN_WHATIF_NRING) && (MGN_WHATIF_NRING & 2)
+        if (valid && a.n < 0) store_frag<NT>(row_ptr(a.Q, nn, L, h), STRIDE_ROW, acc);
+#else
         if (valid) store_frag<NT>(row_ptr(a.Q, nn, L, h), STRIDE_ROW, acc);
+#endif
         PHASE_FENCE();
+#if defined(MGN_WHATIF_NRING) && (MGN_WHATIF_NRING & 1)
+        load_frag<NT>(x, tile_ptr(a.V, wave, L, lane), STRIDE_TILE);
+#else
         load_frag<NT>(x, tile_ptr(a.V, next, L, lane), STRIDE_TILE);
+#endif
+        a0 = b0;
+        a1 = b1;
         tw.tile += tw.stride;
     }
 }
