@@ -1117,7 +1117,13 @@ __global__ __launch_bounds__(512, 2) void k_project_split(const NodeArgs a) {
         sp_layer_otf<false, true, false, D1>(acc, x, lph, lpm, gp + 4096, lane);
 #endif
         __builtin_amdgcn_s_setprio(MGN_PRIO);
+#if defined(MGN_WHATIF_NODE) && (MGN_WHATIF_NODE & 8)      // diagnostic: P / Q stored tile-major (coalesced) instead of row-major
+        if (valid) store_frag<NT>(tile_ptr(a.P, tile, L, lane), STRIDE_TILE, acc);
+#elif defined(MGN_WHATIF_NODE) && (MGN_WHATIF_NODE & 16)   // diagnostic: no P / Q stores
+        if (valid && a.n < 0) store_frag<NT>(row_ptr(a.P, nn, L, h), STRIDE_ROW, acc);
+#else
         if (valid) store_frag<NT>(row_ptr(a.P, nn, L, h), STRIDE_ROW, acc);
+#endif
         __builtin_amdgcn_s_setprio(0);
         tab_frag<NT>(acc, tb + T_BQ * L, h);
 #if defined(MGN_WHATIF_NODE) && (MGN_WHATIF_NODE & 1)
@@ -1126,7 +1132,13 @@ __global__ __launch_bounds__(512, 2) void k_project_split(const NodeArgs a) {
         sp_layer_otf<false, true, false, D1>(acc, x, lqh, lqm, gq + 4096, lane);
 #endif
         __builtin_amdgcn_s_setprio(MGN_PRIO);
+#if defined(MGN_WHATIF_NODE) && (MGN_WHATIF_NODE & 8)
+        if (valid) store_frag<NT>(tile_ptr(a.Q, tile, L, lane), STRIDE_TILE, acc);
+#elif defined(MGN_WHATIF_NODE) && (MGN_WHATIF_NODE & 16)
+        if (valid && a.n < 0) store_frag<NT>(row_ptr(a.Q, nn, L, h), STRIDE_ROW, acc);
+#else
         if (valid) store_frag<NT>(row_ptr(a.Q, nn, L, h), STRIDE_ROW, acc);
+#endif
         if (!has_next) break;
         PHASE_FENCE();
         load_frag<NT>(x, tile_ptr(a.V, a.tile0 + next, L, lane), STRIDE_TILE);
