@@ -48,6 +48,27 @@ DEVINL const f32x4* row_ptr(const float* base, int64_t row, int L, int h) {
     return reinterpret_cast<const f32x4*>(base + row * L) + h;
 }
 DEVINL f32x4* row_ptr(float* base, int64_t row, int L, int h) { return reinterpret_cast<f32x4*>(base + row * L) + h; }
+// P / Q / CARRY rows (the arrays that are read with lane = row gathers): stored in blocks of MGN_PROW_BLOCK = 8 rows, 32-byte piece m of
+// the block's rows side by side -- [row / 8][piece m][row % 8][h][4 floats] -- so that a gather instruction (one piece m of 32 rows)
+// finds the pieces of neighbouring rows in the same cache line (4 rows per 128-byte line) instead of one line per row.  Mesh senders
+// come in runs of consecutive node numbers: ~8 lines per gather instruction instead of ~18 on M-1M, and the rows of a node tile are
+// stored with fully coalesced 1 KiB instructions (tools/gather_probe.hip: a 32-row gather costs the CU 62 cycles per instruction, an
+// 8-line access 16-17).  Piece m of a row: prow_ptr(base, row, L, h)[m * STRIDE_PROW].  MGN_PROW_BLOCK=0: plain row-major (A/B).
+#ifndef MGN_PROW_BLOCK
+#define MGN_PROW_BLOCK 8
+#endif
+constexpr int STRIDE_PROW = MGN_PROW_BLOCK ? 2 * MGN_PROW_BLOCK : STRIDE_ROW;
+DEVINL int64_t prow_index(int64_t row, int L) {       // f32x4 index of (row, piece 0, h 0)
+#if MGN_PROW_BLOCK
+    return (row / MGN_PROW_BLOCK) * (int64_t)(MGN_PROW_BLOCK * L / 4) + (row % MGN_PROW_BLOCK) * 2;
+#else
+    return row * (L / 4);
+#endif
+}
+// f32x4 index of the X-th 16-byte piece of a row counted as in a plain row-major row (X = 2 m + h)
+DEVINL int64_t prow_f4(int64_t row, int X, int L) { return prow_index(row, L) + (X >> 1) * STRIDE_PROW + (X & 1); }
+DEVINL const f32x4* prow_ptr(const float* base, int64_t row, int L, int h) { return reinterpret_cast<const f32x4*>(base) + prow_index(row, L) + h; }
+DEVINL f32x4* prow_ptr(float* base, int64_t row, int L, int h) { return reinterpret_cast<f32x4*>(base) + prow_index(row, L) + h; }
 DEVINL const f32x4* tile_ptr(const float* base, int64_t tile, int L, int lane) {
     return reinterpret_cast<const f32x4*>(base + tile * (TILE * L)) + lane;
 }

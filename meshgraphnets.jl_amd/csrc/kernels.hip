@@ -112,8 +112,8 @@ __global__ __launch_bounds__(512, 2) void k_edge_step(const EdgeArgs a) {
     EdgeIdx ix = load_edge_idx_nb(a.snd, a.rcv, a.E, tw.tile, lane0 & 31);
     {
         const int h0 = lane0 >> 5;
-        load_frag<NT>(acc, row_ptr(a.P, ix.s, L, h0), STRIDE_ROW);
-        add_frag<NT>(acc, row_ptr(a.Q, ix.r >= 0 ? ix.r : 0, L, h0), STRIDE_ROW);
+        load_frag<NT>(acc, prow_ptr(a.P, ix.s, L, h0), STRIDE_PROW);
+        add_frag<NT>(acc, prow_ptr(a.Q, ix.r >= 0 ? ix.r : 0, L, h0), STRIDE_PROW);
         load_frag<NT>(x, tile_ptr(a.Elat, tw.tile, L, lane0), STRIDE_TILE);
     }
     int stamp_tile = 0;
@@ -179,14 +179,14 @@ __global__ __launch_bounds__(512, 2) void k_edge_step(const EdgeArgs a) {
         const bool sl = (start == 0) && (ix.r_before == r_first);   // run continues from the previous tile
         const bool sr = (c == 31) && (ix.r_after == reff);          // run continues into the next tile
         const bool to_carry = sl || sr;
-        f32x4* dst = to_carry ? row_ptr(a.CARRY, (int64_t)2 * tile + (sl ? 0 : 1), L, h)
+        f32x4* dst = to_carry ? prow_ptr(a.CARRY, (int64_t)2 * tile + (sl ? 0 : 1), L, h)
                               : tile_ptr(a.AGG, r >> 5, L, 32 * h + (r & 31));
-        if (tail) store_frag<NT>(dst, to_carry ? STRIDE_ROW : STRIDE_TILE, acc);
+        if (tail) store_frag<NT>(dst, to_carry ? STRIDE_PROW : STRIDE_TILE, acc);
         if (!has_next) break;
         PHASE_FENCE();
         // turnover: next accumulator init = P[s'] + Q[r'];  x <- e tile of the next tile
-        load_frag<NT>(acc, row_ptr(a.P, ixn.s, L, h), STRIDE_ROW);
-        add_frag<NT>(acc, row_ptr(a.Q, ixn.r >= 0 ? ixn.r : 0, L, h), STRIDE_ROW);
+        load_frag<NT>(acc, prow_ptr(a.P, ixn.s, L, h), STRIDE_PROW);
+        add_frag<NT>(acc, prow_ptr(a.Q, ixn.r >= 0 ? ixn.r : 0, L, h), STRIDE_PROW);
         load_frag<NT>(x, tile_ptr(a.Elat, nxt, L, lane), STRIDE_TILE);
         __builtin_amdgcn_s_setprio(0);
         ix = ixn;
@@ -277,10 +277,10 @@ __global__ __launch_bounds__(512, 2) void k_node_step(const NodeArgs a) {
         if constexpr (PROJECT) {
             zero_frag<NT>(acc);
             mfma_chunk<NT, (NRES > 4), NODE_PAD>(acc, v, wp, lane);
-            if (valid) store_frag<NT>(row_ptr(a.P, nn, L, h), STRIDE_ROW, acc);
+            if (valid) store_frag<NT>(prow_ptr(a.P, nn, L, h), STRIDE_PROW, acc);
             tab_frag<NT>(y, tb + T_BQ * L, h);
             mfma_chunk<NT, (NRES > 5), NODE_PAD>(y, v, wq, lane);
-            if (valid) store_frag<NT>(row_ptr(a.Q, nn, L, h), STRIDE_ROW, y);
+            if (valid) store_frag<NT>(prow_ptr(a.Q, nn, L, h), STRIDE_PROW, y);
         }
     }
 }
@@ -315,10 +315,10 @@ __global__ __launch_bounds__(MGN_PROJ_WAVES * 64, MGN_PROJ_WAVES / 4) void k_pro
         load_frag<NT>(v, tile_ptr(a.V, tile, L, lane), STRIDE_TILE);
         zero_frag<NT>(acc);
         mfma_chunk<NT, RES>(acc, v, RES ? smem : a.chunk[4], lane);
-        if (valid) store_frag<NT>(row_ptr(a.P, nn, L, h), STRIDE_ROW, acc);
+        if (valid) store_frag<NT>(prow_ptr(a.P, nn, L, h), STRIDE_PROW, acc);
         tab_frag<NT>(y, tb + T_BQ * L, h);
         mfma_chunk<NT, RES>(y, v, RES ? smem + CH : a.chunk[5], lane);
-        if (valid) store_frag<NT>(row_ptr(a.Q, nn, L, h), STRIDE_ROW, y);
+        if (valid) store_frag<NT>(prow_ptr(a.Q, nn, L, h), STRIDE_PROW, y);
     }
 }
 
@@ -368,8 +368,8 @@ __global__ __launch_bounds__(256, 2) void k_edge_coop(const EdgeArgs a) {
         // the gathered rows depend on the indices (a serial ~2 us); the e tile does not: the layer-1 chain starts from zero on
         // the e tile alone and P[s] + Q[r] (which carry b1) are added when it is done
         f32x16 pq, qq;
-        load_quarter(pq, row_ptr(a.P, ix.s, L, h), STRIDE_ROW, tq);
-        load_quarter(qq, row_ptr(a.Q, r, L, h), STRIDE_ROW, tq);
+        load_quarter(pq, prow_ptr(a.P, ix.s, L, h), STRIDE_PROW, tq);
+        load_quarter(qq, prow_ptr(a.Q, r, L, h), STRIDE_PROW, tq);
         STAMP(1);
         CoopRing ring2, ring3;
         coop_prime(ring2, a.chunk_t[0] + tq * 4096, lane);                  // layer 2's first fragments, ahead of time
@@ -416,9 +416,9 @@ __global__ __launch_bounds__(256, 2) void k_edge_coop(const EdgeArgs a) {
         const bool sl = (start == 0) && (ix.r_before == r_first);
         const bool sr = (c == 31) && (ix.r_after == reff);
         const bool to_carry = sl || sr;
-        f32x4* dst = to_carry ? row_ptr(a.CARRY, (int64_t)2 * tile + (sl ? 0 : 1), L, h)
+        f32x4* dst = to_carry ? prow_ptr(a.CARRY, (int64_t)2 * tile + (sl ? 0 : 1), L, h)
                               : tile_ptr(a.AGG, r >> 5, L, 32 * h + (r & 31));
-        if (tail) store_quarter(dst, to_carry ? STRIDE_ROW : STRIDE_TILE, tq, acc);
+        if (tail) store_quarter(dst, to_carry ? STRIDE_PROW : STRIDE_TILE, tq, acc);
         STAMP(7);
         __syncthreads();   // xch0 is rewritten by the next tile's first exchange
     }
@@ -479,10 +479,10 @@ __global__ __launch_bounds__(256, 2) void k_node_coop(const NodeArgs a) {
 #pragma unroll
                 for (int k = 0; k < 16; ++k) acc[k] = 0.f;
                 coop_chain_primed<FENCE>(acc, v, a.chunk_t[4] + tq * 4096, lane, rb);
-                if (valid) store_quarter(row_ptr(a.P, nn, L, h), STRIDE_ROW, tq, acc);
+                if (valid) store_quarter(prow_ptr(a.P, nn, L, h), STRIDE_PROW, tq, acc);
                 tab_quarter(acc, tb + T_BQ * L, tq, h);
                 coop_chain_primed<FENCE>(acc, v, a.chunk_t[5] + tq * 4096, lane, ra);
-                if (valid) store_quarter(row_ptr(a.Q, nn, L, h), STRIDE_ROW, tq, acc);
+                if (valid) store_quarter(prow_ptr(a.Q, nn, L, h), STRIDE_PROW, tq, acc);
             }
         }
         if (a.mode == 2) {
@@ -491,10 +491,10 @@ __global__ __launch_bounds__(256, 2) void k_node_coop(const NodeArgs a) {
 #pragma unroll
             for (int k = 0; k < 16; ++k) acc[k] = 0.f;
             coop_chain<FENCE>(acc, v, a.chunk_t[4] + tq * 4096, lane);
-            if (valid) store_quarter(row_ptr(a.P, nn, L, h), STRIDE_ROW, tq, acc);
+            if (valid) store_quarter(prow_ptr(a.P, nn, L, h), STRIDE_PROW, tq, acc);
             tab_quarter(acc, tb + T_BQ * L, tq, h);
             coop_chain_primed<FENCE>(acc, v, a.chunk_t[5] + tq * 4096, lane, rq);
-            if (valid) store_quarter(row_ptr(a.Q, nn, L, h), STRIDE_ROW, tq, acc);
+            if (valid) store_quarter(prow_ptr(a.Q, nn, L, h), STRIDE_PROW, tq, acc);
         }
         __syncthreads();
     }
@@ -554,12 +554,12 @@ DEVINL void c16_st_tile(float* base, int64_t tile, int row, int bb, int q, const
 template <bool BF>
 DEVINL f32x4 c16_ld_row(const float* base, int64_t r, int bb, int q) {      // row-major [r][128]
     if constexpr (BF) return c16_unpack4(*reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(base) + c16_bf_row_off(r, bb, q)));
-    else return reinterpret_cast<const f32x4*>(base)[r * 32 + q + 4 * bb];
+    else return reinterpret_cast<const f32x4*>(base)[prow_f4(r, q + 4 * bb, 128)];
 }
 template <bool BF>
 DEVINL void c16_st_row(float* base, int64_t r, int bb, int q, const f32x4 v) {
     if constexpr (BF) *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(base) + c16_bf_row_off(r, bb, q)) = c16_pack4(v);
-    else reinterpret_cast<f32x4*>(base)[r * 32 + q + 4 * bb] = v;
+    else reinterpret_cast<f32x4*>(base)[prow_f4(r, q + 4 * bb, 128)] = v;
 }
 // the value a bf16 store keeps (so that what is computed from a row equals what a later launch computes from the stored row)
 template <bool BF> DEVINL f32x4 c16_round(const f32x4 v) {
@@ -850,10 +850,10 @@ DEVINL void c16_agg_slice(f32x4 (&as)[2], const int32_t* rowptr, const float* AG
         as[1] = c16_unpack4(*reinterpret_cast<const uint2*>(src + (from_agg ? 64 * 8 : 2 * 8)));      // next feature block: s + 1
     } else {
         const f32x4* A4 = reinterpret_cast<const f32x4*>(AGG) + c16_tile_idx(tile, row, 2 * wave, q);
-        const f32x4* C4 = reinterpret_cast<const f32x4*>(CARRY) + (extra ? (int64_t)(2 * T1 + 1) : zero_row) * 32 + q + 4 * (2 * wave);
+        const f32x4* C4 = reinterpret_cast<const f32x4*>(CARRY) + prow_f4(extra ? (int64_t)(2 * T1 + 1) : zero_row, q + 4 * (2 * wave), 128);
         const f32x4* src = from_agg ? A4 : C4;
         as[0] = src[0];
-        as[1] = src[from_agg ? 128 : 4];
+        as[1] = src[from_agg ? 128 : 2 * STRIDE_PROW];                       // the next feature block: four 16-byte pieces = two 32-byte pieces on
     }
     for (int k = 1; __any(k <= extra); ++k)
         if (k <= extra) {
@@ -1054,10 +1054,10 @@ __global__ __launch_bounds__(512, 2) void k_enc_node(const EncNodeArgs a) {
         store_frag<NT>(tile_ptr(a.V, tw.tile, L, lane), STRIDE_TILE, acc);
         zero_frag<NT>(y);
         mfma_chunk<NT, (NRES > 2)>(y, acc, wp, lane);
-        if (valid) store_frag<NT>(row_ptr(a.P, nn, L, h), STRIDE_ROW, y);
+        if (valid) store_frag<NT>(prow_ptr(a.P, nn, L, h), STRIDE_PROW, y);
         tab_frag<NT>(y, tb + T_BQ * L, h);
         mfma_chunk<NT, (NRES > 3)>(y, acc, wq, lane);
-        if (valid) store_frag<NT>(row_ptr(a.Q, nn, L, h), STRIDE_ROW, y);
+        if (valid) store_frag<NT>(prow_ptr(a.Q, nn, L, h), STRIDE_PROW, y);
     }
 }
 
@@ -1120,10 +1120,10 @@ __global__ __launch_bounds__(256, 2) void k_enc_node_coop(const EncNodeArgs a) {
 #pragma unroll
         for (int k = 0; k < 16; ++k) acc[k] = 0.f;
         coop_chain_primed<FENCE>(acc, in, wp, lane, r2);
-        if (valid) store_quarter(row_ptr(a.P, nn, L, h), STRIDE_ROW, tq, acc);
+        if (valid) store_quarter(prow_ptr(a.P, nn, L, h), STRIDE_PROW, tq, acc);
         tab_quarter(acc, tb + T_BQ * L, tq, h);
         coop_chain_primed<FENCE>(acc, in, wq, lane, r3);
-        if (valid) store_quarter(row_ptr(a.Q, nn, L, h), STRIDE_ROW, tq, acc);
+        if (valid) store_quarter(prow_ptr(a.Q, nn, L, h), STRIDE_PROW, tq, acc);
         __syncthreads();
     }
 }
@@ -2107,7 +2107,15 @@ __global__ void k_gather_rows(const float* __restrict__ src, const int32_t* __re
     if (i >= rows * L4) return;
     const int64_t r = i / L4;
     const int q = (int)(i - r * L4);
-    reinterpret_cast<f32x4*>(dst)[r * dst4 + q] = reinterpret_cast<const f32x4*>(src)[(int64_t)idx[r] * L4 + q];
+    reinterpret_cast<f32x4*>(dst)[r * dst4 + q] = reinterpret_cast<const f32x4*>(src)[prow_f4(idx[r], q, 4 * L4)];      // src: P rows (frag.hpp: prow_ptr)
+}
+// halo unpack: plain rows of the receive buffer -> rows row0 .. of P
+__global__ void k_scatter_prows(const float* __restrict__ src, int src4, float* __restrict__ dst, int64_t row0, int64_t rows, int L4) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * L4) return;
+    const int64_t r = i / L4;
+    const int q = (int)(i - r * L4);
+    reinterpret_cast<f32x4*>(dst)[prow_f4(row0 + r, q, 4 * L4)] = reinterpret_cast<const f32x4*>(src)[r * src4 + q];
 }
 
 // caller-order row-major rows  <->  engine order, tile-major storage (mgn_latents_import / export on the device)
@@ -2636,6 +2644,13 @@ hipError_t launch_gather_rows(const float* src, const int32_t* idx, float* dst, 
     return hipGetLastError();
 }
 
+hipError_t launch_scatter_prows(const float* src, int src_stride, float* dst, int64_t row0, int64_t rows, int L, hipStream_t s) {
+    if (rows <= 0) return hipSuccess;
+    const int64_t n = rows * (L / 4);
+    hipLaunchKernelGGL(k_scatter_prows, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src, src_stride / 4, dst, row0, rows, L / 4);
+    return hipGetLastError();
+}
+bool prows_blocked() { return MGN_PROW_BLOCK != 0; }
 hipError_t launch_rows_to_tiles(const float* src, const int64_t* gid64, const int32_t* gid32, float* dst, int64_t rows, int L, hipStream_t s) {
     if (rows <= 0) return hipSuccess;
     const int64_t n = rows * (L / 4);

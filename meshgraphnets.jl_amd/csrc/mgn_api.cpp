@@ -248,8 +248,8 @@ int alloc_edge_set(mgn_engine* h, int q) {
     auto& es = h->es[q];
     const int64_t nte = tiles_or_one(es.ntiles_e), ntn = tiles_or_one(h->ntiles_n);
     struct { DevBuf* b; size_t bytes; } bufs[5] = {
-        {&es.P, (size_t)(g.n_own + g.n_halo + 1) * L * 4}, {&es.Q, (size_t)(g.n_own + 1) * L * 4},
-        {&es.Elat, tile_floats(nte, L) * 4}, {&es.AGG, tile_floats(ntn, L) * 4}, {&es.CARRY, (size_t)(4 * nte + 1) * L * 4}};
+        {&es.P, (size_t)(g.n_own + g.n_halo + 1 + 16) * L * 4}, {&es.Q, (size_t)(g.n_own + 1 + 16) * L * 4},    // (+ 16: rows live in blocks of eight)
+        {&es.Elat, tile_floats(nte, L) * 4}, {&es.AGG, tile_floats(ntn, L) * 4}, {&es.CARRY, (size_t)(4 * nte + 1 + 16) * L * 4}};
     // (CARRY: two rows per 32-edge tile, or per 16-edge tile with the 16-row cooperative kernels; its last row stays zero)
     // padding rows of the tile-major arrays and the zero row of CARRY (its last row) must read as 0
     for (auto& b : bufs) {
@@ -1868,7 +1868,7 @@ static int halo_plan(mgn_handle* h) {
     }
     // one edge set: the halo rows of P are one contiguous block in owner-rank order -- the layout of the receive buffer --
     // so the rows land there directly and no unpack copy runs
-    h->hx_direct = h->nsets == 1;
+    h->hx_direct = h->nsets == 1 && (is_bf16(h) || !prows_blocked());   // (fp32 P rows are not contiguous: blocks of eight)
     if (!h->host_only) {
         HIPCHK(h, h->halo_send.ensure(so ? so : 16));
         if (!h->hx_direct) HIPCHK(h, h->halo_recv.ensure(ro ? ro : 16));
@@ -2068,6 +2068,11 @@ int mgn_halo_unpack(mgn_handle* h, const void* recv_dev) try {
     ProfScope ps(h, F_HALO);
     const size_t b = is_bf16(h) ? 2 : 4, rowb = (size_t)h->cfg.L * b;
     for (int q = 0; q < h->nsets; ++q) {
+        if (!is_bf16(h) && prows_blocked()) {
+            HIPCHK(h, launch_scatter_prows(reinterpret_cast<const float*>(recv_dev) + (size_t)q * h->cfg.L, h->nsets * h->cfg.L, h->es[q].P.as<float>(),
+                                           g.n_own, g.n_halo, h->cfg.L, h->stream));
+            continue;
+        }
         char* dst = reinterpret_cast<char*>(is_bf16(h) ? h->es[q].bP.p : h->es[q].P.p) + (size_t)g.n_own * rowb;
         HIPCHK(h, hipMemcpy2DAsync(dst, rowb, reinterpret_cast<const char*>(recv_dev) + (size_t)q * rowb, (size_t)h->nsets * rowb, rowb,
                                    (size_t)g.n_halo, hipMemcpyDeviceToDevice, h->stream));

@@ -137,8 +137,8 @@ __global__ __launch_bounds__(512, 2) void k_edge_split2(const EdgeArgs a) {
     EdgeIdx ix = load_edge_idx_nb(a.snd, a.rcv, a.E, tw.tile, lane0 & 31);
     {   // first tile: layer-1 accumulator P[s] + Q[r] (Q carries b1) and the e tile
         const int h0 = lane0 >> 5;
-        load_frag<NT>(acc, row_ptr(a.P, ix.s, L, h0), STRIDE_ROW);
-        add_frag<NT>(acc, row_ptr(a.Q, ix.r >= 0 ? ix.r : 0, L, h0), STRIDE_ROW);
+        load_frag<NT>(acc, prow_ptr(a.P, ix.s, L, h0), STRIDE_PROW);
+        add_frag<NT>(acc, prow_ptr(a.Q, ix.r >= 0 ? ix.r : 0, L, h0), STRIDE_PROW);
         load_frag<NT>(y, tile_ptr(a.Elat, tw.tile, L, lane0), STRIDE_TILE);
     }
     int stamp_tile = 0;
@@ -190,13 +190,13 @@ __global__ __launch_bounds__(512, 2) void k_edge_split2(const EdgeArgs a) {
         const bool sl = (start == 0) && (ix.r_before == r_first);
         const bool sr = (c == 31) && (ix.r_after == reff);
         const bool to_carry = sl || sr;
-        f32x4* dst = to_carry ? row_ptr(a.CARRY, (int64_t)2 * tile + (sl ? 0 : 1), L, h) : tile_ptr(a.AGG, r >> 5, L, 32 * h + (r & 31));
-        if (tail) store_frag<NT>(dst, to_carry ? STRIDE_ROW : STRIDE_TILE, acc);
+        f32x4* dst = to_carry ? prow_ptr(a.CARRY, (int64_t)2 * tile + (sl ? 0 : 1), L, h) : tile_ptr(a.AGG, r >> 5, L, 32 * h + (r & 31));
+        if (tail) store_frag<NT>(dst, to_carry ? STRIDE_PROW : STRIDE_TILE, acc);
         if (!has_next) break;
         PHASE_FENCE();
         // turnover: the next tile's layer-1 accumulator and e tile
-        load_frag<NT>(acc, row_ptr(a.P, ixn.s, L, h), STRIDE_ROW);
-        add_frag<NT>(acc, row_ptr(a.Q, ixn.r >= 0 ? ixn.r : 0, L, h), STRIDE_ROW);
+        load_frag<NT>(acc, prow_ptr(a.P, ixn.s, L, h), STRIDE_PROW);
+        add_frag<NT>(acc, prow_ptr(a.Q, ixn.r >= 0 ? ixn.r : 0, L, h), STRIDE_PROW);
         load_frag<NT>(y, tile_ptr(a.Elat, nxt, L, lane), STRIDE_TILE);
         ix = ixn;
         tw.tile = next;
@@ -512,14 +512,14 @@ __global__ __launch_bounds__(NWV * 64, NWV / 4) void k_edge_ring(const EdgeArgs 
     EdgeIdx ix = load_edge_idx_nb(a.snd, a.rcv, a.E, clamp(tw.tile), lane0 & 31);
     {
         const int h0 = lane0 >> 5;
-        load_frag<NT>(acc, row_ptr(a.Q, ix.r >= 0 ? ix.r : 0, L, h0), STRIDE_ROW);
+        load_frag<NT>(acc, prow_ptr(a.Q, ix.r >= 0 ? ix.r : 0, L, h0), STRIDE_PROW);
         load_frag<NT>(y, tile_ptr(a.Elat, clamp(tw.tile), L, lane0), STRIDE_TILE);
     }
     f32x4 side[4];               // refill side buffer (sp_layer_ring): the first two k-steps of the P rows / of the e tile
     {
-        const f32x4* p0 = row_ptr(a.P, ix.s, L, lane0 >> 5);
+        const f32x4* p0 = prow_ptr(a.P, ix.s, L, lane0 >> 5);
 #pragma unroll
-        for (int m = 0; m < 4; ++m) side[m] = p0[m * STRIDE_ROW];
+        for (int m = 0; m < 4; ++m) side[m] = p0[m * STRIDE_PROW];
     }
     int stamp_tile = 0;
     (void)stamp_tile;
@@ -544,7 +544,7 @@ __global__ __launch_bounds__(NWV * 64, NWV / 4) void k_edge_ring(const EdgeArgs 
         __builtin_amdgcn_s_setprio(0);
         RingFrag nx = ring_first<W, 0>(l1h, ring, lane);
         // layer 1 (edge part): y = e tile in, P[s] out (acc entered with Q[r], which carries b1)
-        sp_layer_ring<W, 0, false, STRIDE_ROW, 0, NWV>(acc, y, l1h, l2h, ring, src, nx, lane, tid, row_ptr(a.P, ps_row, L, h), side);
+        sp_layer_ring<W, 0, false, STRIDE_PROW, 0, NWV>(acc, y, l1h, l2h, ring, src, nx, lane, tid, prow_ptr(a.P, ps_row, L, h), side);
 #pragma unroll
         for (int t = 0; t < NT; ++t) acc[t] += y[t];
         CST(1);
@@ -633,25 +633,25 @@ __global__ __launch_bounds__(NWV * 64, NWV / 4) void k_edge_ring(const EdgeArgs 
         const bool sl = (start == 0) && (ix.r_before == r_first);
         const bool sr = (c == 31) && (ix.r_after == reff);
         const bool to_carry = sl || sr;
-        f32x4* dst = to_carry ? row_ptr(a.CARRY, (int64_t)2 * tile + (sl ? 0 : 1), L, h) : tile_ptr(a.AGG, r >> 5, L, 32 * h + (r & 31));
+        f32x4* dst = to_carry ? prow_ptr(a.CARRY, (int64_t)2 * tile + (sl ? 0 : 1), L, h) : tile_ptr(a.AGG, r >> 5, L, 32 * h + (r & 31));
 #if defined(MGN_WHATIF) && (MGN_WHATIF & 32)
-        if (tail && a.E < 0) store_frag<NT>(dst, to_carry ? STRIDE_ROW : STRIDE_TILE, acc);
+        if (tail && a.E < 0) store_frag<NT>(dst, to_carry ? STRIDE_PROW : STRIDE_TILE, acc);
 #else
-        if (tail) store_frag<NT>(dst, to_carry ? STRIDE_ROW : STRIDE_TILE, acc);
+        if (tail) store_frag<NT>(dst, to_carry ? STRIDE_PROW : STRIDE_TILE, acc);
 #endif
         EST(6);
         PHASE_FENCE();
         // turnover: the next tile's layer-1 accumulator starts from Q[r] (P[s] arrives during the layer)
 #if defined(MGN_WHATIF) && (MGN_WHATIF & 16)
-        load_frag<NT>(acc, row_ptr(a.Q, lane & 31, L, h), STRIDE_ROW);
+        load_frag<NT>(acc, prow_ptr(a.Q, lane & 31, L, h), STRIDE_PROW);
 #else
-        load_frag<NT>(acc, row_ptr(a.Q, ixn.r >= 0 ? ixn.r : 0, L, h), STRIDE_ROW);
+        load_frag<NT>(acc, prow_ptr(a.Q, ixn.r >= 0 ? ixn.r : 0, L, h), STRIDE_PROW);
 #endif
 #if MGN_RING_REFILL_AT_REQUEST != 0 && (MGN_RING_SIDE_EARLY & 2)
         {
-            const f32x4* pn = row_ptr(a.P, ixn.s, L, h);
+            const f32x4* pn = prow_ptr(a.P, ixn.s, L, h);
 #pragma unroll
-            for (int m = 0; m < 4; ++m) side[m] = pn[m * STRIDE_ROW];
+            for (int m = 0; m < 4; ++m) side[m] = pn[m * STRIDE_PROW];
         }
 #endif
         EST(7);
@@ -905,8 +905,8 @@ __global__ __launch_bounds__(512, 2) void k_node_ring(const NodeArgs a) {
         const int T1 = a0 >> 5, T2 = (a1 - 1) >> 5;
         const int extra = (a1 > a0 && T2 > T1) ? (T2 - T1) : 0;
         const bool from_agg = (a1 > a0) && !extra;
-        const f32x4* agg0 = from_agg ? tile_ptr(a.AGG, tile, L, lane) : row_ptr(a.CARRY, extra ? (int64_t)(2 * T1 + 1) : a.zero_row, L, h);
-        const int aggs = from_agg ? STRIDE_TILE : STRIDE_ROW;
+        const f32x4* agg0 = from_agg ? tile_ptr(a.AGG, tile, L, lane) : prow_ptr(a.CARRY, extra ? (int64_t)(2 * T1 + 1) : a.zero_row, L, h);
+        const int aggs = from_agg ? STRIDE_TILE : STRIDE_PROW;
         f32x4 side[4];
 #pragma unroll
         for (int m = 0; m < 4; ++m) side[m] = agg0[m * aggs];
@@ -916,7 +916,7 @@ __global__ __launch_bounds__(512, 2) void k_node_ring(const NodeArgs a) {
 #else
         spn_layer<W, 0, NCH, false, 8, true>(acc, x, ring, src, nx, lane, tid, agg0, aggs, side);   // layer 1, node part; x <- aggregate rows
         for (int q = 1; __any(q <= extra); ++q)                                            // (a receiver whose run straddles more than two edge tiles)
-            if (q <= extra) add_frag<NT>(x, row_ptr(a.CARRY, (int64_t)2 * (T1 + q), L, h), STRIDE_ROW);
+            if (q <= extra) add_frag<NT>(x, prow_ptr(a.CARRY, (int64_t)2 * (T1 + q), L, h), STRIDE_PROW);
 #endif
 #if defined(MGN_WHATIF_NRING) && (MGN_WHATIF_NRING & 4)     // diagnostic builds (wrong results): what the memory phases cost
         load_frag<NT>(x, tile_ptr(a.V, wave, L, lane), STRIDE_TILE);
@@ -947,18 +947,18 @@ __global__ __launch_bounds__(512, 2) void k_node_ring(const NodeArgs a) {
         spn_layer<W, 4, NCH, false>(acc, x, ring, src, nx, lane, tid);                     // P = v W1s of the next step's edge MLP
         __builtin_amdgcn_s_setprio(MGN_PRIO);
 #if defined(MGN_WHATIF_NRING) && (MGN_WHATIF_NRING & 2)
-        if (valid && a.n < 0) store_frag<NT>(row_ptr(a.P, nn, L, h), STRIDE_ROW, acc);
+        if (valid && a.n < 0) store_frag<NT>(prow_ptr(a.P, nn, L, h), STRIDE_PROW, acc);
 #else
-        if (valid) store_frag<NT>(row_ptr(a.P, nn, L, h), STRIDE_ROW, acc);
+        if (valid) store_frag<NT>(prow_ptr(a.P, nn, L, h), STRIDE_PROW, acc);
 #endif
         __builtin_amdgcn_s_setprio(0);
         tab_frag<NT>(acc, tb + T_BQ * L, h);
         spn_layer<W, 5, NCH, false>(acc, x, ring, src, nx, lane, tid);                     // Q = v W1r + b1
         __builtin_amdgcn_s_setprio(MGN_PRIO);
 #if defined(MGN_WHATIF_NRING) && (MGN_WHATIF_NRING & 2)
-        if (valid && a.n < 0) store_frag<NT>(row_ptr(a.Q, nn, L, h), STRIDE_ROW, acc);
+        if (valid && a.n < 0) store_frag<NT>(prow_ptr(a.Q, nn, L, h), STRIDE_PROW, acc);
 #else
-        if (valid) store_frag<NT>(row_ptr(a.Q, nn, L, h), STRIDE_ROW, acc);
+        if (valid) store_frag<NT>(prow_ptr(a.Q, nn, L, h), STRIDE_PROW, acc);
 #endif
         PHASE_FENCE();
 #if defined(MGN_WHATIF_NRING) && (MGN_WHATIF_NRING & 1)
@@ -1014,7 +1014,7 @@ __global__ __launch_bounds__(256, 2) void k_edge_ring2(const EdgeArgs a) {
     auto clamp = [&](int t) { return t < tw.end ? t : last; };
     f32x16 acc[NT], y[NT];
     EdgeIdx ix = load_edge_idx_nb(a.snd, a.rcv, a.E, clamp(tw.tile), lane0 & 31);
-    load_frag<NT>(acc, row_ptr(a.Q, ix.r >= 0 ? ix.r : 0, L, lane0 >> 5), STRIDE_ROW);
+    load_frag<NT>(acc, prow_ptr(a.Q, ix.r >= 0 ? ix.r : 0, L, lane0 >> 5), STRIDE_PROW);
     load_frag<NT>(y, tile_ptr(a.Elat, clamp(tw.tile), L, lane0), STRIDE_TILE);
     RnFrag nx = rn_read<W>(ringbase + lane0, 0, 0);
     for (int j = 0; j < iters; ++j) {
@@ -1029,7 +1029,7 @@ __global__ __launch_bounds__(256, 2) void k_edge_ring2(const EdgeArgs a) {
         u32x4* ring = ringbase + lane;
         __builtin_amdgcn_s_setprio(0);
         spn_layer<W, 0, NCH, false, NWV>(acc, y, ring, src, nx, lane, tid);          // layer 1, edge part (acc entered with Q[r], which carries b1)
-        load_frag<NT>(y, row_ptr(a.P, ix.s, L, h), STRIDE_ROW);
+        load_frag<NT>(y, prow_ptr(a.P, ix.s, L, h), STRIDE_PROW);
 #pragma unroll
         for (int t = 0; t < NT; ++t) acc[t] += y[t];
         tab_frag<NT>(y, tb + T_B2 * L, h);
@@ -1066,10 +1066,10 @@ __global__ __launch_bounds__(256, 2) void k_edge_ring2(const EdgeArgs a) {
         const bool sl = (start == 0) && (ix.r_before == r_first);
         const bool sr = (c == 31) && (ix.r_after == reff);
         const bool to_carry = sl || sr;
-        f32x4* dst = to_carry ? row_ptr(a.CARRY, (int64_t)2 * tile + (sl ? 0 : 1), L, h) : tile_ptr(a.AGG, r >> 5, L, 32 * h + (r & 31));
-        if (tail) store_frag<NT>(dst, to_carry ? STRIDE_ROW : STRIDE_TILE, acc);
+        f32x4* dst = to_carry ? prow_ptr(a.CARRY, (int64_t)2 * tile + (sl ? 0 : 1), L, h) : tile_ptr(a.AGG, r >> 5, L, 32 * h + (r & 31));
+        if (tail) store_frag<NT>(dst, to_carry ? STRIDE_PROW : STRIDE_TILE, acc);
         PHASE_FENCE();
-        load_frag<NT>(acc, row_ptr(a.Q, ixn.r >= 0 ? ixn.r : 0, L, h), STRIDE_ROW);
+        load_frag<NT>(acc, prow_ptr(a.Q, ixn.r >= 0 ? ixn.r : 0, L, h), STRIDE_PROW);
         ix = ixn;
         tw.tile += tw.stride;
     }
@@ -1120,9 +1120,9 @@ __global__ __launch_bounds__(512, 2) void k_project_split(const NodeArgs a) {
 #if defined(MGN_WHATIF_NODE) && (MGN_WHATIF_NODE & 8)      // diagnostic: P / Q stored tile-major (coalesced) instead of row-major
         if (valid) store_frag<NT>(tile_ptr(a.P, tile, L, lane), STRIDE_TILE, acc);
 #elif defined(MGN_WHATIF_NODE) && (MGN_WHATIF_NODE & 16)   // diagnostic: no P / Q stores
-        if (valid && a.n < 0) store_frag<NT>(row_ptr(a.P, nn, L, h), STRIDE_ROW, acc);
+        if (valid && a.n < 0) store_frag<NT>(prow_ptr(a.P, nn, L, h), STRIDE_PROW, acc);
 #else
-        if (valid) store_frag<NT>(row_ptr(a.P, nn, L, h), STRIDE_ROW, acc);
+        if (valid) store_frag<NT>(prow_ptr(a.P, nn, L, h), STRIDE_PROW, acc);
 #endif
         __builtin_amdgcn_s_setprio(0);
         tab_frag<NT>(acc, tb + T_BQ * L, h);
@@ -1135,9 +1135,9 @@ __global__ __launch_bounds__(512, 2) void k_project_split(const NodeArgs a) {
 #if defined(MGN_WHATIF_NODE) && (MGN_WHATIF_NODE & 8)
         if (valid) store_frag<NT>(tile_ptr(a.Q, tile, L, lane), STRIDE_TILE, acc);
 #elif defined(MGN_WHATIF_NODE) && (MGN_WHATIF_NODE & 16)
-        if (valid && a.n < 0) store_frag<NT>(row_ptr(a.Q, nn, L, h), STRIDE_ROW, acc);
+        if (valid && a.n < 0) store_frag<NT>(prow_ptr(a.Q, nn, L, h), STRIDE_PROW, acc);
 #else
-        if (valid) store_frag<NT>(row_ptr(a.Q, nn, L, h), STRIDE_ROW, acc);
+        if (valid) store_frag<NT>(prow_ptr(a.Q, nn, L, h), STRIDE_PROW, acc);
 #endif
         if (!has_next) break;
         PHASE_FENCE();

@@ -163,10 +163,10 @@ DEVINL void copy_to_lds16(uint16_t* dst, const uint16_t* __restrict__ src, int n
         const int extra = (a1 > a0 && T2 > T1) ? (T2 - T1) : 0;                                                          \
         const bool from_agg = (a1 > a0) && !extra;                                                                       \
         const f32x4* src0 = from_agg ? tile_ptr((AGG_), tile, L, lane)                                                   \
-                                     : row_ptr((CARRY_), extra ? (int64_t)(2 * T1 + 1) : (zero_row_), L, h);            \
-        load_frag<NT_>(y_, src0, from_agg ? STRIDE_TILE : STRIDE_ROW);                                                   \
+                                     : prow_ptr((CARRY_), extra ? (int64_t)(2 * T1 + 1) : (zero_row_), L, h);            \
+        load_frag<NT_>(y_, src0, from_agg ? STRIDE_TILE : STRIDE_PROW);                                                   \
         for (int q = 1; __any(q <= extra); ++q)                                                                          \
-            if (q <= extra) add_frag<NT_>(y_, row_ptr((CARRY_), (int64_t)2 * (T1 + q), L, h), STRIDE_ROW);              \
+            if (q <= extra) add_frag<NT_>(y_, prow_ptr((CARRY_), (int64_t)2 * (T1 + q), L, h), STRIDE_PROW);              \
     } while (0)
 
 }  // namespace mgn
