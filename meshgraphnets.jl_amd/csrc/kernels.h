@@ -148,6 +148,7 @@ hipError_t launch_project_bf16(const BfNodeArgs& a, hipStream_t s);   // P,Q pro
 hipError_t launch_tile_f32_to_bf16(const float* src, uint16_t* dst, int64_t ntiles, hipStream_t s);
 hipError_t launch_tile_bf16_to_f32(const uint16_t* src, float* dst, int64_t ntiles, hipStream_t s);
 hipError_t launch_scatter_prows(const float* src, int src_stride /* floats */, float* dst, int64_t row0, int64_t rows, int L, hipStream_t s);   // plain rows -> P rows
+hipError_t launch_scatter_prows16(const uint16_t* src, int src_stride /* elements */, uint16_t* dst, int64_t row0, int64_t rows, hipStream_t s);
 bool prows_blocked();        // P / Q / CARRY rows are stored in blocks of eight (frag.hpp: prow_ptr)
 hipError_t launch_gather_rows16(const uint16_t* src, const int32_t* idx, uint16_t* dst, int64_t rows, int dst_stride /* elements */, hipStream_t s);
 

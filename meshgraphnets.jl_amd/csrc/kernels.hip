@@ -540,7 +540,15 @@ DEVINL uint2 c16_pack4(const f32x4 v) {
     return __builtin_bit_cast(uint2, o);
 }
 DEVINL int64_t c16_bf_tile_off(int64_t tile, int row, int bb, int q) { return tile * 4096 + (int64_t)(bb * 64 + 32 * (q & 1) + row) * 8 + 4 * (q >> 1); }
-DEVINL int64_t c16_bf_row_off(int64_t r, int bb, int q) { return r * 128 + (2 * bb + (q & 1)) * 8 + 4 * (q >> 1); }
+// bf16 P / Q / CARRY rows (16 pieces of 16 bytes): the blocks-of-eight layout of frag.hpp's prow_ptr, in 16-byte pieces
+DEVINL int64_t bf_prow_piece(int64_t row, int X) {            // piece X = 2 s + h of a row
+#if MGN_PROW_BLOCK
+    return (row / MGN_PROW_BLOCK) * (int64_t)(MGN_PROW_BLOCK * 16) + (X >> 1) * (2 * MGN_PROW_BLOCK) + (row % MGN_PROW_BLOCK) * 2 + (X & 1);
+#else
+    return row * 16 + X;
+#endif
+}
+DEVINL int64_t c16_bf_row_off(int64_t r, int bb, int q) { return bf_prow_piece(r, 2 * bb + (q & 1)) * 8 + 4 * (q >> 1); }
 template <bool BF>
 DEVINL f32x4 c16_ld_tile(const float* base, int64_t tile, int row, int bb, int q) {
     if constexpr (BF) return c16_unpack4(*reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(base) + c16_bf_tile_off(tile, row, bb, q)));
@@ -847,7 +855,7 @@ DEVINL void c16_agg_slice(f32x4 (&as)[2], const int32_t* rowptr, const float* AG
         const uint16_t* C16 = reinterpret_cast<const uint16_t*>(CARRY) + c16_bf_row_off(cr, 2 * wave, q);
         const uint16_t* src = from_agg ? A16 : C16;
         as[0] = c16_unpack4(*reinterpret_cast<const uint2*>(src));
-        as[1] = c16_unpack4(*reinterpret_cast<const uint2*>(src + (from_agg ? 64 * 8 : 2 * 8)));      // next feature block: s + 1
+        as[1] = c16_unpack4(*reinterpret_cast<const uint2*>(src + (from_agg ? 64 * 8 : STRIDE_PROW * 8)));      // next feature block: s + 1
     } else {
         const f32x4* A4 = reinterpret_cast<const f32x4*>(AGG) + c16_tile_idx(tile, row, 2 * wave, q);
         const f32x4* C4 = reinterpret_cast<const f32x4*>(CARRY) + prow_f4(extra ? (int64_t)(2 * T1 + 1) : zero_row, q + 4 * (2 * wave), 128);
@@ -1345,10 +1353,10 @@ __global__ __launch_bounds__(512, 2) void k_decode(const DecArgs a) {
 // of 8 bf16 in that order (piece 2s+h); weights are 32 KiB per chunk, so every chunk of a kernel is LDS-resident.
 // ================================================================================================
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-constexpr int BF_STRIDE_ROW = 2, BF_STRIDE_TILE = 64;   // in 16-byte pieces
+constexpr int BF_STRIDE_ROW = STRIDE_PROW, BF_STRIDE_TILE = 64;   // in 16-byte pieces (rows: blocks of eight, bf_prow_piece)
 
-DEVINL const bf16x8* bf_row_ptr(const uint16_t* base, int64_t row, int h) { return reinterpret_cast<const bf16x8*>(base + row * 128) + h; }
-DEVINL bf16x8* bf_row_ptr(uint16_t* base, int64_t row, int h) { return reinterpret_cast<bf16x8*>(base + row * 128) + h; }
+DEVINL const bf16x8* bf_row_ptr(const uint16_t* base, int64_t row, int h) { return reinterpret_cast<const bf16x8*>(base) + bf_prow_piece(row, h); }
+DEVINL bf16x8* bf_row_ptr(uint16_t* base, int64_t row, int h) { return reinterpret_cast<bf16x8*>(base) + bf_prow_piece(row, h); }
 DEVINL const bf16x8* bf_tile_ptr(const uint16_t* base, int64_t tile, int lane) { return reinterpret_cast<const bf16x8*>(base + tile * (TILE * 128)) + lane; }
 DEVINL bf16x8* bf_tile_ptr(uint16_t* base, int64_t tile, int lane) { return reinterpret_cast<bf16x8*>(base + tile * (TILE * 128)) + lane; }
 
@@ -1486,8 +1494,8 @@ DEVINL BfSel bf_selectors() {
     s.hi = __builtin_bit_cast(bf16x2, u1);
     return s;
 }
-DEVINL const u32x4* bfq_row_ptr(const uint16_t* base, int64_t row, int h) { return reinterpret_cast<const u32x4*>(base + row * 128) + h; }
-DEVINL u32x4* bfq_row_ptr(uint16_t* base, int64_t row, int h) { return reinterpret_cast<u32x4*>(base + row * 128) + h; }
+DEVINL const u32x4* bfq_row_ptr(const uint16_t* base, int64_t row, int h) { return reinterpret_cast<const u32x4*>(base) + bf_prow_piece(row, h); }
+DEVINL u32x4* bfq_row_ptr(uint16_t* base, int64_t row, int h) { return reinterpret_cast<u32x4*>(base) + bf_prow_piece(row, h); }
 DEVINL const u32x4* bfq_tile_ptr(const uint16_t* base, int64_t tile, int lane) { return reinterpret_cast<const u32x4*>(base + tile * (TILE * 128)) + lane; }
 DEVINL u32x4* bfq_tile_ptr(uint16_t* base, int64_t tile, int lane) { return reinterpret_cast<u32x4*>(base + tile * (TILE * 128)) + lane; }
 
@@ -2095,7 +2103,14 @@ __global__ void k_gather_rows16(const uint16_t* __restrict__ src, const int32_t*
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // one 16-byte piece; 16 per row
     if (i >= rows * 16) return;
     const int64_t r = i >> 4;
-    reinterpret_cast<f32x4*>(dst)[r * dst4 + (i & 15)] = reinterpret_cast<const f32x4*>(src)[(int64_t)idx[r] * 16 + (i & 15)];
+    reinterpret_cast<f32x4*>(dst)[r * dst4 + (i & 15)] = reinterpret_cast<const f32x4*>(src)[bf_prow_piece(idx[r], (int)(i & 15))];
+}
+// halo unpack, bf16: plain rows of the receive buffer -> rows row0 .. of bP
+__global__ void k_scatter_prows16(const uint16_t* __restrict__ src, int src4, uint16_t* __restrict__ dst, int64_t row0, int64_t rows) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * 16) return;
+    const int64_t r = i >> 4;
+    reinterpret_cast<f32x4*>(dst)[bf_prow_piece(row0 + r, (int)(i & 15))] = reinterpret_cast<const f32x4*>(src)[r * src4 + (i & 15)];
 }
 
 // ================================================================================================
@@ -2648,6 +2663,12 @@ hipError_t launch_scatter_prows(const float* src, int src_stride, float* dst, in
     if (rows <= 0) return hipSuccess;
     const int64_t n = rows * (L / 4);
     hipLaunchKernelGGL(k_scatter_prows, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src, src_stride / 4, dst, row0, rows, L / 4);
+    return hipGetLastError();
+}
+hipError_t launch_scatter_prows16(const uint16_t* src, int src_stride, uint16_t* dst, int64_t row0, int64_t rows, hipStream_t s) {
+    if (rows <= 0) return hipSuccess;
+    const int64_t n = rows * 16;
+    hipLaunchKernelGGL(k_scatter_prows16, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src, src_stride / 8, dst, row0, rows);
     return hipGetLastError();
 }
 bool prows_blocked() { return MGN_PROW_BLOCK != 0; }

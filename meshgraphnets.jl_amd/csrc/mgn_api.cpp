@@ -259,8 +259,8 @@ int alloc_edge_set(mgn_engine* h, int q) {
     if (h->cfg.dtype == MGN_BF16) {
         struct { DevBuf* b; size_t bytes; } bb[5] = {
             {&es.bElat, tile_floats(nte, L) * 2}, {&es.bAGG, tile_floats(ntn, L) * 2},
-            {&es.bP, (size_t)(g.n_own + g.n_halo + 1) * L * 2}, {&es.bQ, (size_t)(g.n_own + 1) * L * 2},
-            {&es.bCARRY, (size_t)(4 * nte + 1) * L * 2}};
+            {&es.bP, (size_t)(g.n_own + g.n_halo + 1 + 16) * L * 2}, {&es.bQ, (size_t)(g.n_own + 1 + 16) * L * 2},
+            {&es.bCARRY, (size_t)(4 * nte + 1 + 16) * L * 2}};
         for (auto& b : bb) {
             HIPCHK(h, b.b->ensure(b.bytes));
             HIPCHK(h, hipMemsetAsync(b.b->p, 0, b.bytes, h->stream));
@@ -1868,7 +1868,7 @@ static int halo_plan(mgn_handle* h) {
     }
     // one edge set: the halo rows of P are one contiguous block in owner-rank order -- the layout of the receive buffer --
     // so the rows land there directly and no unpack copy runs
-    h->hx_direct = h->nsets == 1 && (is_bf16(h) || !prows_blocked());   // (fp32 P rows are not contiguous: blocks of eight)
+    h->hx_direct = h->nsets == 1 && !prows_blocked();   // (P rows are not contiguous: blocks of eight)
     if (!h->host_only) {
         HIPCHK(h, h->halo_send.ensure(so ? so : 16));
         if (!h->hx_direct) HIPCHK(h, h->halo_recv.ensure(ro ? ro : 16));
@@ -2068,6 +2068,11 @@ int mgn_halo_unpack(mgn_handle* h, const void* recv_dev) try {
     ProfScope ps(h, F_HALO);
     const size_t b = is_bf16(h) ? 2 : 4, rowb = (size_t)h->cfg.L * b;
     for (int q = 0; q < h->nsets; ++q) {
+        if (is_bf16(h) && prows_blocked()) {
+            HIPCHK(h, launch_scatter_prows16(reinterpret_cast<const uint16_t*>(recv_dev) + (size_t)q * h->cfg.L, h->nsets * h->cfg.L,
+                                             h->es[q].bP.as<uint16_t>(), g.n_own, g.n_halo, h->stream));
+            continue;
+        }
         if (!is_bf16(h) && prows_blocked()) {
             HIPCHK(h, launch_scatter_prows(reinterpret_cast<const float*>(recv_dev) + (size_t)q * h->cfg.L, h->nsets * h->cfg.L, h->es[q].P.as<float>(),
                                            g.n_own, g.n_halo, h->cfg.L, h->stream));
