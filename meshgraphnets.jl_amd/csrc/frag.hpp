@@ -48,14 +48,15 @@ DEVINL const f32x4* row_ptr(const float* base, int64_t row, int L, int h) {
     return reinterpret_cast<const f32x4*>(base + row * L) + h;
 }
 DEVINL f32x4* row_ptr(float* base, int64_t row, int L, int h) { return reinterpret_cast<f32x4*>(base + row * L) + h; }
-// P / Q / CARRY rows (the arrays that are read with lane = row gathers): stored in blocks of MGN_PROW_BLOCK = 8 rows, 32-byte piece m of
-// the block's rows side by side -- [row / 8][piece m][row % 8][h][4 floats] -- so that a gather instruction (one piece m of 32 rows)
-// finds the pieces of neighbouring rows in the same cache line (4 rows per 128-byte line) instead of one line per row.  Mesh senders
-// come in runs of consecutive node numbers: ~8 lines per gather instruction instead of ~18 on M-1M, and the rows of a node tile are
-// stored with fully coalesced 1 KiB instructions (tools/gather_probe.hip: a 32-row gather costs the CU 62 cycles per instruction, an
-// 8-line access 16-17).  Piece m of a row: prow_ptr(base, row, L, h)[m * STRIDE_PROW].  MGN_PROW_BLOCK=0: plain row-major (A/B).
+// P / Q / CARRY rows (the arrays that are read with lane = row gathers) go through prow_ptr.  MGN_PROW_BLOCK = 8 (build option) stores
+// them in blocks of eight rows, 32-byte piece m of the block's rows side by side -- [row / 8][piece m][row % 8][h][4 floats] -- so that a
+// gather instruction (one piece m of 32 rows) finds the pieces of neighbouring rows in the same cache line and the rows of a node tile
+// are stored with coalesced 1 KiB instructions (tools/gather_probe.hip: a 32-row gather costs the CU 62 cycles per instruction, an
+// 8-line access 16-17): + 1.5 % on M-1M, whose node numbering is coherent -- and - 5..9 % (fp32) / - 34 % (bf16) on graphs whose
+// senders are scattered (a 128-byte line then carries 32 useful bytes: four times the gather traffic).  Default 0: plain row-major rows.
+// Piece m of a row: prow_ptr(base, row, L, h)[m * STRIDE_PROW].
 #ifndef MGN_PROW_BLOCK
-#define MGN_PROW_BLOCK 8
+#define MGN_PROW_BLOCK 0
 #endif
 constexpr int STRIDE_PROW = MGN_PROW_BLOCK ? 2 * MGN_PROW_BLOCK : STRIDE_ROW;
 DEVINL int64_t prow_index(int64_t row, int L) {       // f32x4 index of (row, piece 0, h 0)
