@@ -491,6 +491,37 @@ def main():
                                        "processor_step_frac": bytes_b / tb / 1e9 / PEAK_HBM_GBPS}
             engb.close()
         if world == 1 and not args.no_secondary and args.dtype == "f32":
+            # The same mesh under arbitrary node labels (DeepMind's trajectories; create_base_graph passes them through, reference
+            # src/graph.jl:30-36): mgn_set_graph re-numbers it breadth-first inside the engine (csrc/graph_host.cpp) -- against the
+            # coherent labels above, and against the scattered labels kept as they are (MGN_RENUMBER=0)
+            import ctypes as _C
+            lib_r = mgn_amd.load()
+            lib_r.mgn_debug_renumber.restype = _C.c_int
+            lib_r.mgn_debug_renumber.argtypes = [_C.c_int]
+            perm = np.random.default_rng(99).permutation(N).astype(np.int32)
+            sp, rp = perm[s], perm[r]
+            scat = {"workload": "same M-1M mesh, node labels randomly permuted; `renumbered`: the default (breadth-first order inside "
+                                "mgn_set_graph), `kept`: MGN_RENUMBER=0"}
+            for pol, key in ((1, "renumbered"), (0, "kept")):
+                oldp = lib_r.mgn_debug_renumber(pol)
+                try:
+                    for dtn in ("f32", "bf16"):
+                        engp = mgn_amd.Engine(FN, FE, O, L, 2, MPS, device=local_rank, dtype=dtn)
+                        engp.set_params(ps)
+                        t0 = time.perf_counter()
+                        engp.set_graph(sp, rp, N)
+                        tset = time.perf_counter() - t0
+                        engp.latents_randn(1234)
+                        dtp_, profp = time_single(engp, 3, 1, barrier_sync)
+                        scat[f"{key}_{dtn}"] = {"ms_per_processor_step": dtp_ / (3 * MPS) * 1e3, "edge_kernel_ms": profp["edge_step"]["avg_ms"],
+                                                "node_side_ms": profp["node_step"]["avg_ms"], "graph_setup_s": tset}
+                        engp.close()
+                finally:
+                    lib_r.mgn_debug_renumber(oldp)
+            scat["vs_coherent_f32"] = scat["renumbered_f32"]["ms_per_processor_step"] / (t_step * 1e3)
+            scat["vs_coherent_bf16"] = scat["renumbered_bf16"]["ms_per_processor_step"] / out["bf16"]["ms_per_processor_step"]
+            out["scattered_labels"] = scat
+        if world == 1 and not args.no_secondary and args.dtype == "f32":
             pos2, cells2, _, _ = mgn_amd.synth.mesh_cyl(1234, 2000)
             s2, r2 = mgn_amd.synth.cells_to_edges(cells2)
             eng2 = mgn_amd.Engine(FN, FE, O, L, 2, MPS, device=local_rank)

@@ -48,8 +48,8 @@ typedef struct mgn_config {
     int32_t O;             /* output width      (cylinder_flow: 2)                                */
     int32_t L;             /* latent width `layer_size`; HIP path supports 32, 64, 128            */
     int32_t hidden_layers; /* hidden layers per MLP (h + 1 Dense): 1 .. 4.  2 (the example's value) runs the tuned kernel */
-                           /* families; other counts run the general instantiations (forward path only: mgn_step / */
-                           /* mgn_ode_vjp and MGN_BF16 are specialised for 2 and refuse others)                    */
+                           /* families; other counts run the general instantiations (mgn_step / mgn_ode_vjp /      */
+                           /* mgn_forward_vjp follow it too; MGN_BF16 is specialised for 2 and refuses others)     */
     int32_t mps;           /* message passing steps                                               */
     int32_t dtype;         /* mgn_dtype: MGN_F32, or MGN_BF16 (L = 128: bf16 storage + bf16 MFMA in the processor, */
                            /* fp32 accumulate / LayerNorm / residual / aggregation; encoder, decoder in fp32)      */
@@ -78,6 +78,11 @@ typedef enum { MGN_LN_VAR_EPS = 0, MGN_LN_STD_EPS = 1 } mgn_ln_mode;
 typedef struct mgn_engine mgn_handle;
 
 /* ---- lifecycle ------------------------------------------------------------------------------ */
+/* Version of THIS header's structs and prototypes; bumped whenever mgn_config / mgn_rollout_desc grow or a prototype changes.  A
+ * binding compiled against another version must not call in (a shorter mgn_config would be read past its end): the Python and
+ * Julia bindings compare mgn_abi_version() with the constant they were written for before the first mgn_create. */
+#define MGN_ABI_VERSION 4
+int mgn_abi_version(void);
 int mgn_create(const mgn_config* cfg, mgn_handle** out);
 void mgn_destroy(mgn_handle* h);
 const char* mgn_last_error(const mgn_handle* h); /* h may be NULL: error of the last failed mgn_create */
@@ -207,7 +212,7 @@ int mgn_feature_stats(mgn_handle* h, const float* x, int64_t rows, int32_t dim, 
 /* ---- native rollout driver: the whole `rollout` of reference src/solve.jl:42-68 on the device:
  * ODEProblem(ode_func_eval, x0, (t0, t1), ...) solved with fixed-step Euler (`adaptive = false, dt = dt`) or an
  * adaptive Tsit5 (own tableau + PI step controller, tstops = saveat = t0 + i*saves_dt), the right-hand side being
- * ode_func_eval (inflow overwrite from `inflow_data[floor(t / saves_dt)]`, src/solve.jl:151-152, applied IN PLACE to
+ * ode_func_eval (inflow overwrite from `inflow_data[floor(t / saves_dt)]`, src/solve.jl:151-152 -- see inflow_rule --, applied IN PLACE to
  * the array the RHS is evaluated on, like the reference) -> ode_step (mgn_ode_step semantics).  No host round trip
  * per RHS; one small D2H (error norm) per adaptive step.  Normalisers must be set with mgn_set_norms.
  * With nranks > 1 (after mgn_comm_init) every rank passes the GLOBAL arrays and integrates the rows it owns; the error norm of
@@ -230,7 +235,20 @@ typedef struct mgn_rollout_desc {
     int32_t n_frames;
     float* out;                    /* [n_saves][N][O]                                                        */
     int32_t n_accept, n_reject, n_rhs; /* filled on return                                                   */
+    /* Which inflow frame a right-hand side at time t reads.  MGN_INFLOW_REFERENCE (0, the default of a zeroed descriptor): the
+     * reference's own expression `floor(Int, t / saves_dt) + 1` (src/solve.jl:151) evaluated in the solver's time type with no
+     * tolerance -- so a t an ulp below a frame boundary reads the previous frame, exactly as the reference does (in Float64,
+     * 0.29 / 0.01 floors to 28) -- and a frame outside inflow_data is MGN_E_ARG (reference: BoundsError).  MGN_INFLOW_TOLERANT:
+     * floor(t / saves_dt + 1e-3) (step k of a fixed-step solve reads frame k whatever its time type), clamped to the frames given.                                                              */
+    int32_t inflow_rule;
+    /* The solver's time type.  0: Float32, the type of the example's `0.0f0:0.01f0:5.99f0` (examples/cylinder_flow/cylinder_flow.jl:
+     * 79-93): t0, t1, dt, saves_dt above are the times, and every time operation is rounded to float.  1: Float64: the four
+     * *_f64 fields are the times (a Float64 0.01 is not a float), the float ones are ignored.  The integrator's time advances as
+     * OrdinaryDiffEq's does: t <- t + dt per accepted step, the stop's own value when a step ends on a stop.                */
+    int32_t time_f64;
+    double t0_f64, t1_f64, dt_f64, saves_dt_f64;
 } mgn_rollout_desc;
+typedef enum mgn_inflow_rule { MGN_INFLOW_REFERENCE = 0, MGN_INFLOW_TOLERANT = 1 } mgn_inflow_rule;
 int mgn_rollout(mgn_handle* h, mgn_rollout_desc* d);
 
 /* ---- training step -------------------------------------------------------
@@ -257,6 +275,16 @@ int mgn_step(mgn_handle* h, const float* nf, const float* ef, const float* targe
  * when dxdt != NULL, f(x) itself.  Every array argument may be a host or a device pointer (hipMemcpyDefault).       */
 int mgn_ode_vjp(mgn_handle* h, const float* x, const float* node_type_onehot, const float* ef_raw, const float* val_mask,
                 const float* lambda, float* dxdt, float* xbar, float* grads, size_t n_grads);
+
+/* Pullback of mgn_forward, i.e. of the model call `output, st = mgn.model(graph, ps, mgn.st)` at reference src/solve.jl:200 -- what
+ * Zygote needs from the shim when it differentiates ode_func_train / train_loss as written (src/strategies.jl:183-195: the
+ * normalisers, build_graph, inverse_data and `.* val_mask` around the model stay Julia code and are differentiated there).
+ * nf [N][Fn], ef [E][Fe]: the FeatureGraph as given to mgn_forward; ybar [N][O]: cotangent of the output; out [N][O] (may be NULL):
+ * the output itself; nfbar [N][Fn] = ybar^T d out / d nf; grads [n_grads] = ybar^T d out / d ps (packed order).  The edge
+ * features are constants of a trajectory (create_base_graph, src/graph.jl:25-55): no cotangent is formed for them.
+ * Restrictions and pointer kinds as mgn_step.                                                                              */
+int mgn_forward_vjp(mgn_handle* h, const float* nf, const float* ef, const float* ybar, float* out, float* nfbar, float* grads,
+                    size_t n_grads);
 
 /* ---- multi-GPU: the halo exchange lives INSIDE the library (SURVEY.md 8b "the engine owns ... RCCL communicators", 8e) ----
  * One process (or thread) per partition, one handle each (mgn_config.rank / nranks).  After mgn_comm_init every compute

@@ -31,8 +31,12 @@ class MgnRolloutDesc(C.Structure):
                 ("x0", C.POINTER(C.c_float)), ("node_type_onehot", C.POINTER(C.c_float)), ("ef_raw", C.POINTER(C.c_float)),
                 ("val_mask", C.POINTER(C.c_float)), ("inflow_mask", C.POINTER(C.c_uint8)), ("inflow_data", C.POINTER(C.c_float)),
                 ("n_frames", C.c_int32), ("out", C.POINTER(C.c_float)),
-                ("n_accept", C.c_int32), ("n_reject", C.c_int32), ("n_rhs", C.c_int32)]
+                ("n_accept", C.c_int32), ("n_reject", C.c_int32), ("n_rhs", C.c_int32),
+                ("inflow_rule", C.c_int32), ("time_f64", C.c_int32),
+                ("t0_f64", C.c_double), ("t1_f64", C.c_double), ("dt_f64", C.c_double), ("saves_dt_f64", C.c_double)]
 
+
+ABI_VERSION = 4      # MGN_ABI_VERSION of include/mgn_hip.h these mirrors were written against (tests/test_julia_shim.py compares)
 
 _f32p = C.POINTER(C.c_float)
 _i32p = C.POINTER(C.c_int32)
@@ -42,6 +46,7 @@ _H = C.c_void_p
 
 # name -> (restype, argtypes): must list exactly the symbols of include/mgn_hip.h (tests check this)
 PROTOTYPES = {
+    "mgn_abi_version": (C.c_int, []),
     "mgn_create": (C.c_int, [C.POINTER(MgnConfig), C.POINTER(_H)]),
     "mgn_destroy": (None, [_H]),
     "mgn_last_error": (C.c_char_p, [_H]),
@@ -79,6 +84,7 @@ PROTOTYPES = {
     "mgn_rollout": (C.c_int, [_H, C.POINTER(MgnRolloutDesc)]),
     "mgn_step": (C.c_int, [_H, _f32p, _f32p, _f32p, _i32p, C.c_int64, C.c_int32, _f32p, C.c_size_t, _f32p]),
     "mgn_ode_vjp": (C.c_int, [_H, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, C.c_size_t]),
+    "mgn_forward_vjp": (C.c_int, [_H, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, C.c_size_t]),
     "mgn_processor_steps": (C.c_int, [_H, _f32p, _f32p, C.c_int32]),
     "mgn_latents_import": (C.c_int, [_H, _f32p, _f32p]),
     "mgn_latents_export": (C.c_int, [_H, _f32p, _f32p]),
@@ -145,6 +151,8 @@ def load(path: str | None = None):
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.restype = res
         fn.argtypes = args
+    if lib.mgn_abi_version() != ABI_VERSION:   # the struct mirrors above are written for ONE version of include/mgn_hip.h
+        raise RuntimeError(f"{p} has ABI version {lib.mgn_abi_version()}, these bindings are written for {ABI_VERSION}: rebuild the library")
     if path is None:
         _lib = lib
     return lib

@@ -69,25 +69,59 @@ def _compile_objects(objdir, extra, force, deps, verbose, per_file=None):
 
 def build_variant(name, flags, verbose=False, per_file=None):
     """A/B experiments: compile the library with extra -D flags into lib/variants/<name>.so.
-    per_file: {source: [flags]} replaces PER_FILE_FLAGS."""
+    per_file: {source: [flags]} replaces PER_FILE_FLAGS.  Without global flags only the sources that have per-file flags are
+    compiled; the other objects are the default build's (lib/_obj, brought up to date first)."""
     vdir = os.path.join(LIBDIR, "variants")
     os.makedirs(vdir, exist_ok=True)
     out = os.path.join(vdir, name + ".so")
-    objs = _compile_objects(os.path.join(vdir, "_obj_" + name), flags, True, [], verbose, per_file)
+    objdir = os.path.join(vdir, "_obj_" + name)
+    if not flags and per_file:
+        build_hip(force=False, verbose=verbose)
+        os.makedirs(objdir, exist_ok=True)
+        objs = []
+        for s in HIP_SOURCES:
+            if per_file.get(s):
+                o = os.path.join(objdir, s + ".o")
+                cmd = [hipcc_path(), "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-I", os.path.join(ROOT, "include")] + list(per_file[s]) + ["-c", os.path.join(CSRC, s), "-o", o]
+                if verbose:
+                    print("[build]", " ".join(cmd), flush=True)
+                subprocess.check_call(cmd)
+                objs.append(o)
+            else:
+                objs.append(os.path.join(LIBDIR, "_obj", s + ".o"))
+    else:
+        objs = _compile_objects(objdir, flags, True, [], verbose, per_file)
     cmd = [hipcc_path(), "-shared", "-fPIC", "--offload-arch=gfx950", "-o", out] + objs + ["-ldl", "-lrt", "-lpthread"]
     subprocess.check_call(cmd)
-    shutil.rmtree(os.path.join(vdir, "_obj_" + name), ignore_errors=True)
+    shutil.rmtree(objdir, ignore_errors=True)
     return out
+
+
+def _flag_stamp(extra):
+    """What the objects of lib/_obj were compiled with: the global flags and every per-file flag set.  Part of the cache key --
+    MGN_PROW_BLOCK changes the P / Q / CARRY row layout in kernels.hip and split.hip, and objects that disagree on it
+    link fine and gather garbage (mgn_create also checks the constant of every translation unit)."""
+    return repr((list(extra), sorted((k, list(v)) for k, v in PER_FILE_FLAGS.items())))
 
 
 def build_hip(force=False, verbose=True):
     srcs = [os.path.join(CSRC, s) for s in HIP_SOURCES]
     deps = srcs + [h if os.path.isabs(h) else os.path.join(CSRC, h) for h in HIP_HEADERS]
+    extra = os.environ.get("MGN_HIPCC_FLAGS", "").split()  # experiments only (e.g. -DMGN_EXP_...)
+    objdir = os.path.join(LIBDIR, "_obj")
+    stamp_file = os.path.join(objdir, "flags.stamp")
+    stamp = _flag_stamp(extra)
+    have = open(stamp_file).read() if os.path.exists(stamp_file) else None
+    if have != stamp and (have is not None or os.path.isdir(objdir)):
+        force = True                                       # other flags than the cached objects were built with: rebuild all of them
     if not force and not _newer(LIB, deps):
         return LIB
-    os.makedirs(LIBDIR, exist_ok=True)
-    extra = os.environ.get("MGN_HIPCC_FLAGS", "").split()  # experiments only (e.g. -DMGN_EXP_...)
-    objs = _compile_objects(os.path.join(LIBDIR, "_obj"), extra, force, deps, verbose)
+    os.makedirs(objdir, exist_ok=True)
+    if os.path.exists(stamp_file):
+        os.remove(stamp_file)                              # (an interrupted build leaves no stamp: the next one starts over)
+    objs = _compile_objects(objdir, extra, force, deps, verbose)
+    with open(stamp_file, "w") as f:
+        f.write(stamp)
     cmd = [hipcc_path(), "-shared", "-fPIC", "--offload-arch=gfx950", "-o", LIB] + objs + ["-ldl", "-lrt", "-lpthread"]
     if verbose:
         print("[build]", " ".join(cmd), flush=True)

@@ -57,8 +57,62 @@ void rcb_partition(int32_t N, const float* pos, int32_t pos_dim, int32_t parts, 
     rcb_rec(idx, 0, N, 0, parts, pos, pos_dim, owner);
 }
 
+double locality_cost(const EdgeList& es, const std::vector<int32_t>& order_pos) {
+    double sum = 0.0;
+    int64_t n = 0;
+    for (int64_t i = 0; i < es.E; ++i) {
+        const int32_t a = order_pos[es.senders[i] - es.index_base], b = order_pos[es.receivers[i] - es.index_base];
+        if (a < 0 || b < 0) continue;
+        sum += (double)(a > b ? a - b : b - a);
+        ++n;
+    }
+    return n > 0 ? sum / (double)n : 0.0;
+}
+
+namespace {
+
+// Breadth-first order of the nodes `member` marks, over the edges of `es` (both directions), started from the lowest global id of
+// every connected component, neighbours in the order the edge list names them.  Deterministic: every rank derives the same order
+// from the same lists.  On a mesh the fronts are curves, so the ends of an edge land within one front width of each other -- the
+// locality a generator's own numbering has -- whatever labels the nodes arrived with (DeepMind's trajectories carry arbitrary ones
+// and create_base_graph passes them through, reference src/graph.jl:30-36).
+std::vector<int32_t> bfs_order(int32_t N, const EdgeList& es, const std::vector<uint8_t>& member) {
+    std::vector<int64_t> ptr((size_t)N + 1, 0);
+    auto in = [&](int64_t i, int32_t& a, int32_t& b) {
+        a = es.senders[i] - es.index_base;
+        b = es.receivers[i] - es.index_base;
+        return a != b && member[a] && member[b];
+    };
+    int32_t a, b;
+    for (int64_t i = 0; i < es.E; ++i)
+        if (in(i, a, b)) { ++ptr[(size_t)a + 1]; ++ptr[(size_t)b + 1]; }
+    for (int32_t i = 0; i < N; ++i) ptr[(size_t)i + 1] += ptr[i];
+    std::vector<int32_t> adj((size_t)ptr[N]);
+    std::vector<int64_t> cur(ptr.begin(), ptr.end() - 1);
+    for (int64_t i = 0; i < es.E; ++i)
+        if (in(i, a, b)) { adj[(size_t)cur[a]++] = b; adj[(size_t)cur[b]++] = a; }
+    std::vector<int32_t> order;
+    std::vector<uint8_t> seen((size_t)N, 0);
+    for (int32_t root = 0; root < N; ++root) {
+        if (!member[root] || seen[root]) continue;
+        size_t head = order.size();
+        order.push_back(root);
+        seen[root] = 1;
+        while (head < order.size()) {
+            const int32_t u = order[head++];
+            for (int64_t j = ptr[u]; j < ptr[(size_t)u + 1]; ++j) {
+                const int32_t v = adj[(size_t)j];
+                if (!seen[v]) { seen[v] = 1; order.push_back(v); }
+            }
+        }
+    }
+    return order;
+}
+
+}  // namespace
+
 std::string build_local_graph(int32_t N, int nsets, const EdgeList* sets, const float* pos, int32_t pos_dim,
-                              const int32_t* owner_in, int32_t rank, int32_t nranks, LocalGraph& g) {
+                              const int32_t* owner_in, int32_t rank, int32_t nranks, LocalGraph& g, int renumber) {
     if (N < 0) return "negative N";
     if (nsets < 1 || nsets > MAX_EDGE_SETS) return "bad number of edge sets";
     if (nranks < 1 || rank < 0 || rank >= nranks) return "bad rank/nranks";
@@ -95,9 +149,31 @@ std::string build_local_graph(int32_t N, int nsets, const EdgeList* sets, const 
                     const int32_t s = sets[k].senders[i] - sets[k].index_base, r = sets[k].receivers[i] - sets[k].index_base;
                     if (g.owner[s] == rank && g.owner[r] != rank) is_bnd[s] = 1;
                 }
-        for (int pass = 0; pass < 2; ++pass) {
+        // the order of the owned nodes inside the two groups: ascending global id, or breadth-first over the mesh (see header)
+        std::vector<int32_t> order;
+        if (renumber != 0 && sets[0].E > 0) {
+            std::vector<uint8_t> mine((size_t)N);
+            int32_t n_mine = 0;
+            for (int32_t i = 0; i < N; ++i) n_mine += (mine[i] = g.owner[i] == rank);
+            order = bfs_order(N, sets[0], mine);
+            bool use = renumber == 2;
+            if (!use) {
+                std::vector<int32_t> p_asc((size_t)N, -1), p_bfs((size_t)N, -1);
+                int32_t k = 0;
+                for (int32_t i = 0; i < N; ++i)
+                    if (mine[i]) p_asc[i] = k++;
+                for (size_t j = 0; j < order.size(); ++j) p_bfs[order[j]] = (int32_t)j;
+                use = locality_cost(sets[0], p_asc) > RENUMBER_GAIN * locality_cost(sets[0], p_bfs);
+            }
+            if (!use || (int32_t)order.size() != n_mine) order.clear();
+        }
+        g.renumbered = !order.empty();
+        if (order.empty())
             for (int32_t i = 0; i < N; ++i)
-                if (g.owner[i] == rank && (is_bnd[i] != 0) == (pass == 0)) {
+                if (g.owner[i] == rank) order.push_back(i);
+        for (int pass = 0; pass < 2; ++pass) {
+            for (int32_t i : order)
+                if ((is_bnd[i] != 0) == (pass == 0)) {
                     g2l[i] = (int32_t)g.own_gid.size();
                     g.own_gid.push_back(i);
                 }

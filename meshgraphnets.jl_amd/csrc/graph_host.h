@@ -27,7 +27,9 @@ struct LocalGraph {
     int32_t n_own = 0, n_halo = 0;
     int32_t n_boundary = 0;          // owned nodes that some peer lists as halo; they are numbered FIRST
     EdgeTopo set[MAX_EDGE_SETS];
-    std::vector<int32_t> own_gid;    // [n_own] global id of owned node i: boundary nodes (ascending), then interior (ascending)
+    std::vector<int32_t> own_gid;    // [n_own] global id of owned node i: boundary nodes, then interior; inside each group ascending, or
+                                     // in breadth-first order of the mesh when the numbering it arrived with is scattered (`renumbered`)
+    bool renumbered = false;
     std::vector<int32_t> halo_gid;   // [n_halo] grouped by owner rank, ascending gid inside a group (union over the edge sets)
     std::vector<int32_t> send_rows;  // [nranks] rows this rank sends to each peer per exchange
     std::vector<int32_t> recv_rows;  // [nranks] rows received from each peer (== halo group sizes)
@@ -51,7 +53,16 @@ struct EdgeList {
 // Build rank `rank`'s local graph from `nsets` edge sets over the same nodes.  Node ownership comes from
 // `owner` when given ([N], e.g. kept from an earlier call), else from rcb_partition(pos).  Halo / boundary /
 // send lists are the union over the sets.  Returns empty string on success, else an error message.
+// renumber: 0 = owned nodes in ascending global id (inside the boundary / interior groups), 2 = in breadth-first order of the mesh
+// (edge set 0), 1 = whichever of the two keeps the ends of an edge closer together (locality_cost; breadth-first only when it is
+// at least RENUMBER_GAIN times better: a mesh that arrives coherently numbered keeps its numbering).
+constexpr double RENUMBER_GAIN = 4.0;
 std::string build_local_graph(int32_t N, int nsets, const EdgeList* sets, const float* pos, int32_t pos_dim,
-                              const int32_t* owner, int32_t rank, int32_t nranks, LocalGraph& g);
+                              const int32_t* owner, int32_t rank, int32_t nranks, LocalGraph& g, int renumber = 1);
+
+// Mean |position(sender) - position(receiver)| over the edges of `es` whose two ends are both listed in `order_pos` (>= 0): what a
+// numbering costs the kernels that gather sender rows for receiver-sorted edge tiles (rows far apart share no cache line, no L2 set
+// of the XCD that sweeps the tile range, no TLB entry).
+double locality_cost(const EdgeList& es, const std::vector<int32_t>& order_pos);
 
 }  // namespace mgn

@@ -194,6 +194,9 @@ hipError_t launch_rows_to_tiles(const float* src, const int64_t* gid64, const in
 hipError_t launch_tiles_to_rows(const float* src, const int64_t* gid64, const int32_t* gid32, float* dst, int64_t rows, int L, hipStream_t s);
 hipError_t launch_randn_rows(float* dst, const int64_t* gid64, const int32_t* gid32, int64_t rows, int L,
                              uint64_t seed, hipStream_t s);
+// the MGN_PROW_BLOCK kernels.hip / split.hip were compiled with (mgn_create compares them with its own: frag.hpp prow_ptr)
+int kernels_prow_block();
+int split_prow_block();
 int checksum_partials();  // doubles written by launch_checksum: (sum, sumsq) per block, to be added in order
 hipError_t launch_checksum(const float* src, int64_t n, double* partials, hipStream_t s);
 

@@ -2700,4 +2700,6 @@ hipError_t launch_checksum(const float* src, int64_t n, double* partials, hipStr
     return hipGetLastError();
 }
 
+int kernels_prow_block() { return MGN_PROW_BLOCK; }
+
 }  // namespace mgn

@@ -515,9 +515,16 @@ inline bool is_bf16(const mgn_engine* h) { return h->cfg.dtype == MGN_BF16; }
 // =================================================================================================
 extern "C" {
 
+int mgn_abi_version(void) { return MGN_ABI_VERSION; }
+
 int mgn_create(const mgn_config* cfg, mgn_handle** out) try {
     if (!out) return fail(nullptr, MGN_E_ARG, "null out pointer");
     *out = nullptr;
+    // P / Q / CARRY rows are addressed through frag.hpp: prow_ptr in two translation units; objects compiled with different
+    // MGN_PROW_BLOCK link without complaint and gather garbage
+    if (kernels_prow_block() != split_prow_block())
+        return fail(nullptr, MGN_E_STATE, "mgn_create: this library was linked from objects that disagree on the P / Q row layout (MGN_PROW_BLOCK %d in kernels.hip, %d in split.hip): rebuild all of it",
+                    kernels_prow_block(), split_prow_block());
     std::string why;
     if (!cfg_ok(cfg, why)) return fail(nullptr, MGN_E_ARG, "mgn_create: %s", why.c_str());
     if (cfg->device == MGN_DEVICE_NONE) {
@@ -852,6 +859,12 @@ int mgn_set_norms(mgn_handle* h, const float* ns, const float* nsh, const float*
     return MGN_OK;
 } MGN_CATCH(h)
 
+// Node numbering policy of mgn_set_graph (graph_host.h: build_local_graph): 1 = keep the caller's numbering unless the breadth-first
+// order of the mesh is RENUMBER_GAIN times more local (DeepMind's trajectories carry arbitrary node numbers and create_base_graph
+// passes them through, reference src/graph.jl:30-36; the processor kernels gather sender rows and lose 4-9 % (fp32) / 25 % (bf16)
+// on a scattered numbering), 0 = never, 2 = always.  Invisible at the boundary: every array crosses it in the caller's order.
+static int g_renumber = [] { const char* e = getenv("MGN_RENUMBER"); return e ? atoi(e) : 1; }();
+
 // (re)build the local graph from the kept global edge lists and upload it.  keep_owner: node partition unchanged
 static int rebuild_graph(mgn_handle* h, int32_t N, const EdgeList* sets, const float* mesh_pos, int32_t pos_dim, bool keep_owner,
                          const char* who) {
@@ -862,7 +875,7 @@ static int rebuild_graph(mgn_handle* h, int32_t N, const EdgeList* sets, const f
     train_invalidate(h, 2);
     if (!h->host_only) { (void)hipStreamSynchronize(h->stream); drop_graph(h); }
     const std::string why = build_local_graph(N, h->nsets, sets, mesh_pos, pos_dim, keep_owner ? h->g.owner.data() : nullptr,
-                                              h->cfg.rank, h->cfg.nranks, h->g);
+                                              h->cfg.rank, h->cfg.nranks, h->g, g_renumber);
     if (!why.empty()) return fail(h, MGN_E_ARG, "%s: %s", who, why.c_str());
     const LocalGraph& g = h->g;
     for (int q = 0; q < h->nsets; ++q) h->es[q].ntiles_e = (int32_t)((g.set[q].e_local + TILE - 1) / TILE);
@@ -1455,6 +1468,11 @@ struct Rollout {
     uint8_t* mask;
     double* partial;
     int n_rhs = 0;
+    // the solver's time type (mgn_rollout_desc.time_f64): Float32 times are held in doubles and rounded after every operation
+    // (a double operation on two floats, rounded to float, IS the float operation)
+    bool f64 = false;
+    double sdt = 0.0;          // saves_dt in that type
+    double tt(double v) const { return f64 ? v : (double)(float)v; }
 
     // One right-hand side is ~35 launches; on a small mesh they are latency-bound, so each distinct (x, kout) pair of the
     // solver (1 for Euler, 7 for Tsit5) gets its launch sequence captured once and replayed (hipGraph).
@@ -1485,9 +1503,20 @@ struct Rollout {
     int rhs(float* x, double t, float* kout) {
         const mgn_config& c = h->cfg;
         if (mask && frames) {
-            int64_t fr = (int64_t)std::floor(t / d->saves_dt + 1e-6);
-            if (fr < 0) fr = 0;
-            if (fr >= d->n_frames) fr = d->n_frames - 1;
+            // data[field][:, :, floor(Int, t / saves_dt) + 1] (reference src/solve.jl:151): the quotient in the solver's own time type,
+            // no tolerance -- a t that sits an ulp below a frame boundary re-uses the previous frame there too -- and an index outside
+            // the data is the reference's BoundsError.  MGN_INFLOW_TOLERANT: nearest-below with a guard of 1e-3 frames (a Float32 time drifts by ~1e-4 frames), clamped.
+            int64_t fr;
+            if (d->inflow_rule == MGN_INFLOW_TOLERANT) {
+                fr = (int64_t)std::floor(t / sdt + 1e-3);
+                if (fr < 0) fr = 0;
+                if (fr >= d->n_frames) fr = d->n_frames - 1;
+            } else {
+                fr = (int64_t)std::floor(tt(t / sdt));
+                if (fr < 0 || fr >= d->n_frames)
+                    return fail(h, MGN_E_ARG, "mgn_rollout: inflow frame %lld at t = %.9g is outside the %d frames given (reference: BoundsError)",
+                                (long long)fr, t, d->n_frames);
+            }
             HIPCHK(h, launch_overwrite(x, frames + (size_t)fr * n, mask, nrows, c.O, h->stream));
         }
         ++n_rhs;
@@ -1553,8 +1582,12 @@ int mgn_rollout(mgn_handle* h, mgn_rollout_desc* d) try {
     if (h->nsets != 1) return fail(h, MGN_E_STATE, "%s mirrors the reference's single-edge-set RHS (src/solve.jl:188-219); this handle has two edge sets", "mgn_rollout");
     if (!d || !d->x0 || !d->out || !d->ef_raw || (c.Fn > c.O && !d->node_type_onehot)) return fail(h, MGN_E_ARG, "mgn_rollout: null argument");
     if (c.Fn < c.O) return fail(h, MGN_E_ARG, "mgn_rollout: Fn < O");
-    if (d->n_saves < 1 || d->saves_dt <= 0.f || d->t1 < d->t0) return fail(h, MGN_E_ARG, "mgn_rollout: bad time grid");
-    if (d->solver == 0 && d->dt <= 0.f) return fail(h, MGN_E_ARG, "mgn_rollout: Euler needs dt > 0");
+    const bool f64 = d->time_f64 != 0;
+    const double T0 = f64 ? d->t0_f64 : (double)d->t0, T1 = f64 ? d->t1_f64 : (double)d->t1, DT = f64 ? d->dt_f64 : (double)d->dt,
+                 SDT = f64 ? d->saves_dt_f64 : (double)d->saves_dt;
+    if (d->n_saves < 1 || !(SDT > 0.0) || T1 < T0) return fail(h, MGN_E_ARG, "mgn_rollout: bad time grid");
+    if (d->solver == 0 && !(DT > 0.0)) return fail(h, MGN_E_ARG, "mgn_rollout: Euler needs dt > 0");
+    if (d->inflow_rule != MGN_INFLOW_REFERENCE && d->inflow_rule != MGN_INFLOW_TOLERANT) return fail(h, MGN_E_ARG, "mgn_rollout: unknown inflow_rule");
     if (d->solver != 0 && d->solver != 1) return fail(h, MGN_E_ARG, "mgn_rollout: solver must be 0 (Euler) or 1 (Tsit5)");
     if ((d->inflow_mask != nullptr) != (d->inflow_data != nullptr)) return fail(h, MGN_E_ARG, "mgn_rollout: inflow mask and data go together");
     if (d->solver == 1 && (d->abstol <= 0.f || d->reltol <= 0.f)) return fail(h, MGN_E_ARG, "mgn_rollout: tolerances must be > 0");
@@ -1563,6 +1596,9 @@ int mgn_rollout(mgn_handle* h, mgn_rollout_desc* d) try {
     Rollout R;
     R.h = h;
     R.d = d;
+    R.f64 = f64;
+    R.sdt = SDT;
+    auto tt = [&](double v) { return R.tt(v); };
     const int32_t nloc = part ? g.n_own : g.N;        // rows of the state this handle integrates
     R.n = (int64_t)nloc * c.O;
     R.n_global = (int64_t)g.N * c.O;
@@ -1623,27 +1659,32 @@ int mgn_rollout(mgn_handle* h, mgn_rollout_desc* d) try {
         if (saved >= d->n_saves) return hipSuccess;
         return hipMemcpyAsync(R.saves + (size_t)saved++ * R.n, R.u, nb, hipMemcpyDeviceToDevice, h->stream);
     };
-    auto stop_time = [&](int i) { return (double)d->t0 + (double)i * (double)d->saves_dt; };
-    double t = d->t0;
+    auto stop_time = [&](int i) { return tt(T0 + (double)i * SDT); };
+    double t = T0;
     HIPCHK(h, save());   // solution at t0
 
     if (d->solver == 0) {
-        const double dt = d->dt;
-        const int64_t nsteps = (int64_t)std::llround(((double)d->t1 - (double)d->t0) / dt);
+        const double dt = DT;
+        const int64_t nsteps = (int64_t)std::llround((T1 - T0) / dt);
         for (int64_t i = 0; i < nsteps; ++i) {
             if (int rc = R.rhs(R.u, t, R.k[0])) return rc;
             LinComb lc{1, {1.f}, {R.k[0]}};
             HIPCHK(h, launch_lincomb(R.u, R.u, lc, (float)dt, R.n, h->stream));
-            t = (double)d->t0 + (double)(i + 1) * dt;
+            // the time the right-hand side sees is the integrator's own: t <- t + dt in its time type, step after step (a fixed-step
+            // solve has no stops to snap to but the end of the interval); t0 + (i + 1) dt would floor differently at frame boundaries
+            t = (i + 1 == nsteps && std::fabs(tt(t + dt) - T1) <= 1e-5 * SDT) ? T1 : tt(t + dt);
             ++d->n_accept;
-            while (saved < d->n_saves && stop_time(saved) <= t + 1e-9 * std::fabs(t) + 1e-12) HIPCHK(h, save());
+            // saveat: the state of the step that ends at the save point.  In its own time type the integrator's t drifts off the
+            // save grid by a few ulps per step (Float32: ~1e-6 s after 600 steps of 0.01 s); the reference interpolates there, which
+            // moves the saved state by (drift / dt) of one step's change -- far below the rollout tolerance -- so: the nearest step.
+            while (saved < d->n_saves && stop_time(saved) <= t + 0.25 * dt) HIPCHK(h, save());
         }
     } else {
         // adaptive Tsit5, PI controller (beta1 = 7/50, beta2 = 2/25, gamma = 0.9, qmin = 0.2, qmax = 10), tstops = saves
         const double beta1 = 7.0 / 50, beta2 = 2.0 / 25, gamma = 0.9, qmin = 0.2, qmax = 10.0;
         double qold = 1e-4;
         if (int rc = R.rhs(R.u, t, R.k[0])) return rc;     // k1 (FSAL afterwards)
-        double dt = d->dt;
+        double dt = DT;
         if (dt <= 0) {   // Hairer-Wanner starting step
             LinComb z{0, {}, {}};
             double d0, d1, d2;
@@ -1654,7 +1695,7 @@ int mgn_rollout(mgn_handle* h, mgn_rollout_desc* d) try {
             if (int rc = R.norm(R.u, R.u, l1, 1.f, &d1)) return rc;
             const double h0 = (d0 < 1e-5 || d1 < 1e-5) ? 1e-6 : 0.01 * d0 / d1;
             HIPCHK(h, launch_lincomb(R.utmp, R.u, l1, (float)h0, R.n, h->stream));
-            if (int rc = R.rhs(R.utmp, t + h0, R.k[1])) return rc;
+            if (int rc = R.rhs(R.utmp, tt(t + h0), R.k[1])) return rc;
             LinComb ld{2, {1.f, -1.f}, {R.k[1], R.k[0]}};
             if (int rc = R.norm(R.u, R.u, ld, (float)(1.0 / h0), &d2)) return rc;
             const double mx = d1 > d2 ? d1 : d2;
@@ -1662,11 +1703,11 @@ int mgn_rollout(mgn_handle* h, mgn_rollout_desc* d) try {
             dt = 100 * h0 < h1 ? 100 * h0 : h1;
             (void)z;
         }
-        const double tend = d->t1;
+        const double tend = T1;
         int guard = 0;
         // float32 descriptors: t1 and n*saves_dt may differ in the last ulp; an interval shorter than 1e-5 save
         // periods is not worth a step
-        while (t < tend - 1e-5 * (double)d->saves_dt && ++guard < 10000000) {
+        while (t < tend - 1e-5 * SDT && ++guard < 10000000) {
             double tstop = saved < d->n_saves ? stop_time(saved) : tend;
             if (tstop > tend) tstop = tend;
             bool hit_stop = false;
@@ -1677,7 +1718,8 @@ int mgn_rollout(mgn_handle* h, mgn_rollout_desc* d) try {
                 for (int j = 0; j < sidx; ++j) { lc.c[j] = (float)TS_A[sidx][j]; lc.k[j] = R.k[j]; }
                 float* dst = (sidx == 6) ? R.unew : R.utmp;
                 HIPCHK(h, launch_lincomb(dst, R.u, lc, (float)hstep, R.n, h->stream));
-                if (int rc = R.rhs(dst, t + TS_C[sidx] * hstep, R.k[sidx])) return rc;
+                // (a stage that lands on the stop itself sees the stop's time: c7 = 1)
+                if (int rc = R.rhs(dst, (sidx == 6 && hit_stop) ? tstop : tt(t + tt(TS_C[sidx] * hstep)), R.k[sidx])) return rc;
             }
             LinComb le{7, {}, {}};
             for (int j = 0; j < 7; ++j) { le.c[j] = (float)TS_BT[j]; le.k[j] = R.k[j]; }
@@ -1691,7 +1733,7 @@ int mgn_rollout(mgn_handle* h, mgn_rollout_desc* d) try {
                 qold = std::max(EEst, 1e-4);
                 std::swap(R.u, R.unew);
                 std::swap(R.k[0], R.k[6]);            // FSAL: k1 of the next step = f(unew)
-                t = hit_stop ? tstop : t + hstep;
+                t = hit_stop ? tstop : tt(t + hstep);
                 ++d->n_accept;
                 if (!hit_stop || hstep >= dt * (1 - 1e-9)) dt = hstep / q;   // a step cut by a stop does not shrink dt
                 else dt = std::max(dt, hstep / q);
@@ -2388,6 +2430,9 @@ int mgn_debug_c16_row_tiles(int rt) { return set_c16_row_tiles(rt); }
 // large fp32 launches: 1 split path (k_edge_ring + k_node_split + k_project_split: bf16 matrix cores at fp32 accuracy; the default),
 // 2 the same with k_edge_split2, 0 fp32-MFMA kernels; returns the old value
 int mgn_debug_fp32_split(int on) { return set_fp32_split(on); }
+// node numbering policy of the NEXT mgn_set_graph calls (0 never, 1 auto, 2 always breadth-first); returns the old value
+int mgn_debug_renumber(int mode) { const int old = g_renumber; g_renumber = mode; return old; }
+int mgn_debug_renumbered(const mgn_handle* h) { return h && h->have_graph && h->g.renumbered ? 1 : 0; }
 long mgn_debug_node_ring_launches(void) { return node_ring_launches(); }   // launches of the opt-in k_node_ring so far (tests)
 
 int mgn_debug_edge_stamps(mgn_handle* h, int32_t k, unsigned long long* out /* [32768] */) try {

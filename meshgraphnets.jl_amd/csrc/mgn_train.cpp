@@ -51,6 +51,7 @@ struct TrainState {
     TrainMlp m_en, m_de, m_ee[MAX_EDGE_SETS];
     std::vector<TrainMlp> m_pe[MAX_EDGE_SETS], m_pn;
     DevBuf arena, idx, grads, target, mask, loss;
+    std::vector<int32_t> g2l, mask_host;       // renumbered graph: caller's node id -> engine row; the mapped mask of the call
     size_t arena_floats = 0;
     // arena offsets (floats)
     size_t nf_raw, nf_pad, ef_raw[MAX_EDGE_SETS], ef_pad[MAX_EDGE_SETS], V0, Enew;
@@ -60,7 +61,7 @@ struct TrainState {
     static constexpr int GSETS = 4;   // gradient-buffer sets: the weight gradients of unit i run beside the backward of units i+1 .. i+3
     int gsets = 1;                    // sets allocated for the current graph (GSETS on small meshes, else 1: no overlap)
     size_t GT[GSETS], GXH[GSETS], GY[GSETS], GZ2[GSETS], GZ1[GSETS];
-    size_t GXs, GXr, GXB, gV[2], gE[MAX_EDGE_SETS][2], gAgg[MAX_EDGE_SETS], Gout, gNF, io, pw, pb;
+    size_t GXs, GXr, GXB, gV[2], gE[MAX_EDGE_SETS][2], gAgg[MAX_EDGE_SETS], Gout, gNF, io, ptmp, pw, pb;
     size_t Pn, Qn, SGs, SGr;     // factored first layer: per-node projections (forward) and summed GZ1 rows (backward)
     // weight gradients + their reductions go to a second stream (small meshes leave most of the chip idle during k_mlp_bwd)
     hipStream_t aux = nullptr;
@@ -309,6 +310,7 @@ int prepare_graph(mgn_engine* h) {
     T.Gout = take(NL);
     T.gNF = take(NL);
     T.io = take((size_t)(N > 0 ? N : 1) * (2 * h->cfg.O + h->cfg.Fn + 1));
+    T.ptmp = take((size_t)(N > 0 ? N : 1) * (size_t)std::max(h->cfg.Fn, h->cfg.O));      // row permutations of a renumbered graph
     const int nb = std::max(wgrad_blocks(N), wgrad_blocks(Emax));
     T.pw = take((size_t)5 * (nb > 0 ? nb : 1) * L * L);             // one partial-dW region per weight-gradient job of a launch unit
     T.pb = take((size_t)WGRAD_MAX_JOBS * (nb > 0 ? nb : 1) * L);
@@ -316,6 +318,11 @@ int prepare_graph(mgn_engine* h) {
     T.drop_graphs();
     HIPCHK(h, T.arena.ensure(off * 4));
     HIPCHK(h, T.target.ensure((size_t)(N > 0 ? N : 1) * h->cfg.O * 4));
+    T.g2l.clear();
+    if (h->g.renumbered) {
+        T.g2l.assign((size_t)h->g.N, 0);
+        for (int32_t i = 0; i < h->g.n_own; ++i) T.g2l[(size_t)h->g.own_gid[i]] = i;
+    }
     T.graph_ready = true;
     return MGN_OK;
 }
@@ -337,6 +344,9 @@ struct TrainJob {
     const float* x = nullptr; const float* onehot = nullptr; const float* val_mask = nullptr; const float* lambda = nullptr;
     float* dxdt = nullptr; float* xbar = nullptr;
     float* grads = nullptr;
+    // vjp of the model itself (mgn_forward_vjp): nf / ef as in step!, cotangent `lambda` of the output, gradient of all of nf out
+    bool fvjp = false;
+    float* nfbar = nullptr; float* out = nullptr;
 };
 
 int train_prepare(mgn_handle* h, const char* who, size_t n_grads) {
@@ -387,16 +397,43 @@ int train_run(mgn_handle* h, const TrainJob& J) {
     // ---- inputs
     const float* nrm = h->norms.as<float>();   // [node scale, shift (Fn) | edge scale, shift (Fe) | out scale, shift (O)]
     HIPCHK(h, hipMemsetAsync(G, 0, h->params.size() * 4, st));
-    if (!J.vjp) {
+    // A renumbered graph (graph_host.h: the engine's node order is not the caller's): per-node inputs are brought into the engine's
+    // order as they arrive and per-node results go back through the inverse; `mask` is mapped on the host.  Edges go by edge_gid already.
+    const bool renum = g.renumbered;
+    const int32_t* ngid = h->d_own_gid.as<int32_t>();
+    auto to_local = [&](float* buf, int width) -> hipError_t {            // buf [N][width]: caller's order -> engine's, in place
+        if (!renum || width <= 0) return hipSuccess;
+        if (hipError_t e = launch_permute_rows(A + T.ptmp, buf, ngid, N, width, false, st)) return e;
+        return hipMemcpyAsync(buf, A + T.ptmp, (size_t)N * width * 4, hipMemcpyDeviceToDevice, st);
+    };
+    auto to_global = [&](float* buf, int width) -> hipError_t {           // ... and back
+        if (!renum || width <= 0) return hipSuccess;
+        if (hipError_t e = launch_permute_rows(A + T.ptmp, buf, ngid, N, width, true, st)) return e;
+        return hipMemcpyAsync(buf, A + T.ptmp, (size_t)N * width * 4, hipMemcpyDeviceToDevice, st);
+    };
+    if (!J.vjp || J.fvjp) {
         HIPCHK(h, hipMemcpyAsync(A + T.nf_raw, J.nf, (size_t)N * c.Fn * 4, hipMemcpyDefault, st));
+        HIPCHK(h, to_local(A + T.nf_raw, c.Fn));
         HIPCHK(h, launch_affine_pad(A + T.nf_raw, c.Fn, nullptr, 0, nullptr, nullptr, A + T.nf_pad, L, N, st));
         if (sx[0].E > 0) {
             HIPCHK(h, hipMemcpyAsync(A + T.ef_raw[0], J.ef, (size_t)sx[0].E * c.Fe * 4, hipMemcpyDefault, st));
             HIPCHK(h, launch_affine_pad(A + T.ef_raw[0], c.Fe, nullptr, 0, nullptr, nullptr, A + T.ef_pad[0], L, sx[0].E, st));
         }
-        HIPCHK(h, hipMemcpyAsync(T.target.p, J.target, (size_t)N * O * 4, hipMemcpyDefault, st));
-        HIPCHK(h, T.mask.ensure((size_t)J.nmask * 4));
-        HIPCHK(h, hipMemcpyAsync(T.mask.p, J.mask, (size_t)J.nmask * 4, hipMemcpyDefault, st));
+        if (J.fvjp) {
+            HIPCHK(h, hipMemcpyAsync(A + T.io + (size_t)N * O, J.lambda, (size_t)N * O * 4, hipMemcpyDefault, st));
+            HIPCHK(h, to_local(A + T.io + (size_t)N * O, O));
+        } else {
+            HIPCHK(h, hipMemcpyAsync(T.target.p, J.target, (size_t)N * O * 4, hipMemcpyDefault, st));
+            HIPCHK(h, to_local(T.target.as<float>(), O));
+            HIPCHK(h, T.mask.ensure((size_t)J.nmask * 4));
+            if (renum) {                       // the caller's node ids -> engine rows (0-based from here on)
+                T.mask_host.resize((size_t)J.nmask);
+                for (int64_t i = 0; i < J.nmask; ++i) T.mask_host[(size_t)i] = T.g2l[(size_t)(J.mask[i] - J.mask_index_base)];
+                HIPCHK(h, hipMemcpyAsync(T.mask.p, T.mask_host.data(), (size_t)J.nmask * 4, hipMemcpyHostToDevice, st));
+            } else {
+                HIPCHK(h, hipMemcpyAsync(T.mask.p, J.mask, (size_t)J.nmask * 4, hipMemcpyDefault, st));
+            }
+        }
     } else {
         // RHS inputs exactly as mgn_ode_step takes them: nf = [n_norm(x); n_norm(onehot)], ef = e_norm(ef_raw)
         float* io = A + T.io;                  // x [N][O] | lambda [N][O] | onehot [N][Fn-O] | val_mask [N]
@@ -404,6 +441,10 @@ int train_run(mgn_handle* h, const TrainJob& J) {
         HIPCHK(h, hipMemcpyAsync(io + (size_t)N * O, J.lambda, (size_t)N * O * 4, hipMemcpyDefault, st));
         if (c.Fn > O) HIPCHK(h, hipMemcpyAsync(io + (size_t)2 * N * O, J.onehot, (size_t)N * (c.Fn - O) * 4, hipMemcpyDefault, st));
         if (J.val_mask) HIPCHK(h, hipMemcpyAsync(io + (size_t)N * (O + c.Fn), J.val_mask, (size_t)N * 4, hipMemcpyDefault, st));
+        HIPCHK(h, to_local(io, O));
+        HIPCHK(h, to_local(io + (size_t)N * O, O));
+        if (c.Fn > O) HIPCHK(h, to_local(io + (size_t)2 * N * O, c.Fn - O));
+        if (J.val_mask) HIPCHK(h, to_local(io + (size_t)N * (O + c.Fn), 1));
         HIPCHK(h, launch_affine_pad(io, O, io + (size_t)2 * N * O, c.Fn - O, h->have_nnorm ? nrm : nullptr, h->have_nnorm ? nrm + c.Fn : nullptr,
                                     A + T.nf_pad, L, N, st));
         if (sx[0].E > 0) {
@@ -538,8 +579,11 @@ int train_run(mgn_handle* h, const TrainJob& J) {
     HIPCHK(h, hipMemsetAsync(A + T.Gout, 0, (size_t)N * L * 4, st));
     if (!J.vjp) {   // loss = mean(mse_reduce(target, out)[mask]) and its gradient w.r.t. out
         HIPCHK(h, T.loss.ensure((size_t)nlb * sizeof(double)));
-        HIPCHK(h, launch_loss(A + y_out, L, T.target.as<float>(), O, T.mask.as<int32_t>(), J.nmask, J.mask_index_base, A + T.Gout,
+        HIPCHK(h, launch_loss(A + y_out, L, T.target.as<float>(), O, T.mask.as<int32_t>(), J.nmask, renum ? 0 : J.mask_index_base, A + T.Gout,
                               T.loss.as<double>(), st));
+    } else if (J.fvjp) {   // the cotangent of the model's output as given
+        HIPCHK(h, launch_vjp_seed(A + y_out, L, O, A + T.io + (size_t)N * O, nullptr, nullptr, nullptr, A + T.Gout,
+                                  J.out ? T.target.as<float>() : nullptr, N, st));
     } else {        // dx/dt = inverse_data(o_norm, out) .* val_mask  =>  d/d out = lambda .* val_mask .* out_scale
         const float* os = h->have_onorm ? nrm + 2 * c.Fn + 2 * c.Fe : nullptr;
         const float* vm = J.val_mask ? A + T.io + (size_t)N * (O + c.Fn) : nullptr;
@@ -732,11 +776,23 @@ int train_run(mgn_handle* h, const TrainJob& J) {
     HIPCHK(h, hipMemcpyAsync(J.grads, G, h->params.size() * 4, hipMemcpyDefault, st));
     if (!J.vjp) {
         HIPCHK(h, hipMemcpyAsync(lp.data(), T.loss.p, lp.size() * sizeof(double), hipMemcpyDeviceToHost, st));
+    } else if (J.fvjp) {
+        HIPCHK(h, launch_extract_cols(A + T.gNF, L, c.Fn, nullptr, A + T.io, N, st));
+        HIPCHK(h, to_global(A + T.io, c.Fn));
+        HIPCHK(h, hipMemcpyAsync(J.nfbar, A + T.io, (size_t)N * c.Fn * 4, hipMemcpyDefault, st));
+        if (J.out) {
+            HIPCHK(h, to_global(T.target.as<float>(), O));
+            HIPCHK(h, hipMemcpyAsync(J.out, T.target.p, (size_t)N * O * 4, hipMemcpyDefault, st));
+        }
     } else {
         // x enters through the node normaliser: xbar = (d / d nf)[:, 0:O] .* node_scale[0:O]
         HIPCHK(h, launch_extract_cols(A + T.gNF, L, O, h->have_nnorm ? nrm : nullptr, A + T.io, N, st));
+        HIPCHK(h, to_global(A + T.io, O));
         HIPCHK(h, hipMemcpyAsync(J.xbar, A + T.io, (size_t)N * O * 4, hipMemcpyDefault, st));
-        if (J.dxdt) HIPCHK(h, hipMemcpyAsync(J.dxdt, T.target.p, (size_t)N * O * 4, hipMemcpyDefault, st));
+        if (J.dxdt) {
+            HIPCHK(h, to_global(T.target.as<float>(), O));
+            HIPCHK(h, hipMemcpyAsync(J.dxdt, T.target.p, (size_t)N * O * 4, hipMemcpyDefault, st));
+        }
     }
     HIPCHK(h, hipStreamSynchronize(st));
     if (!J.vjp) {
@@ -780,6 +836,22 @@ extern "C" int mgn_ode_vjp(mgn_handle* h, const float* x, const float* node_type
     J.vjp = true;
     J.x = x; J.onehot = node_type_onehot; J.ef = ef_raw; J.val_mask = val_mask; J.lambda = lambda;
     J.dxdt = dxdt; J.xbar = xbar; J.grads = grads;
+    return train_run(h, J);
+} MGN_CATCH(h)
+
+// Pullback of mgn_forward == the model call `mgn.model(graph, ps, st)` at reference src/solve.jl:200 (what a ChainRulesCore.rrule of
+// the Julia shim's model function returns to Zygote inside the pullback of ode_func_train, src/strategies.jl:183-195): given the
+// cotangent ybar of the output, nfbar = ybar^T d out / d nf (all Fn columns) and grads = ybar^T d out / d ps.
+extern "C" int mgn_forward_vjp(mgn_handle* h, const float* nf, const float* ef, const float* ybar, float* out, float* nfbar, float* grads,
+                               size_t n_grads) try {
+    if (!h) return MGN_E_ARG;
+    if (!nf || !ybar || !nfbar || !grads) return fail(h, MGN_E_ARG, "mgn_forward_vjp: null argument");
+    if (int rc = train_prepare(h, "mgn_forward_vjp", n_grads)) return rc;
+    if (!ef && h->g.set[0].E > 0) return fail(h, MGN_E_ARG, "mgn_forward_vjp: null argument");
+    TrainJob J;
+    J.vjp = true;
+    J.fvjp = true;
+    J.nf = nf; J.ef = ef; J.lambda = ybar; J.out = out; J.nfbar = nfbar; J.grads = grads;
     return train_run(h, J);
 } MGN_CATCH(h)
 

@@ -15,8 +15,10 @@
 //   * the hi pieces of all chunks (+ one mid piece) are LDS-resident, the rest stream from L2 through those rings.
 // The accumulator layout of the two MFMA shapes is the same; element j of lane half h at k-step s is accumulator register
 // 8 (s & 1) + j of block s >> 1 (the bf16 kernels' correspondence), so a layer's output feeds the next layer without a shuffle.
-// Compiled with -fno-slp-vectorize (build.py): hipcc otherwise packs the split's subtractions into v_pk_add_f32, which holds the
-// matrix pipe for ~12 cycles each (tools/overlap_probe.hip).
+// (Packed fp32 VALU holds the matrix pipe for ~12 cycles per instruction, tools/overlap_probe.hip: none may appear inside a chain.  The
+// split's subtractions sit between inline-asm conversions and scheduling fences, where hipcc's SLP vectoriser does not pair them --
+// the shipped object has its v_pk_* instructions in the epilogue only -- so no -fno-slp-vectorize is passed; MGN_SPLIT_FLAGS adds it
+// for A/B runs.)
 #include <cstdlib>
 
 #include "kernels.h"
@@ -216,6 +218,18 @@ __global__ __launch_bounds__(512, 2) void k_edge_split2(const EdgeArgs a) {
 //     window boundary: what they touch was written a whole window earlier.  12 windows per tile = 0 mod 3: the buffer of a window
 //     is the same for every tile.
 // L2 weight traffic per tile: 192 KiB per EIGHT tiles.  All waves run the same number of tiles (stores of padding tiles masked).
+//
+// Turnover (round 4, MGN_RING_ENEXT = 1).  s_waitcnt vmcnt retires in order and counts stores: a load requested behind the tile's 16 KiB
+// of e stores is not "back" before those stores are acknowledged, so round 3's order -- residual, store e, THEN request the next tile's e
+// and Q rows -- put the store tail (6-15 k cycles for sixteen store instructions of eight lock-step waves) in front of the next tile's
+// first MFMA.  Now layer 3's refill brings the NEXT tile's e tile into the registers its input releases (twelve pieces inside the layer,
+// the last four at the start of the epilogue: requested inside the layer they are spilled where they land, with an s_waitcnt vmcnt(0) in
+// the chain), this tile's e is read a second time at the start of the epilogue into the registers the chain has just released (pieces,
+// fragments, loader staging: the Infinity Cache serves it while the LayerNorm runs), and only the Q gather is left behind the stores.
+// No scratch access in the tile loop (round 3: 16 spilled registers, three `s_waitcnt vmcnt(0)` + scratch_store in layer 2's chain).
+// M-1M, same box: 3.42-3.45 -> 3.11-3.13 ms.  What-if builds on this order (wrong results): no e store 2.80, e stores into one cached
+// tile per wave 3.02 (so 0.27 of the 0.36 ms the stores cost is their issue, not HBM), no aggregate stores 3.03, aggregate rows stored
+// row-major 3.13, every stream cached 2.60.
 // ================================================================================================
 // (Tried and dropped, docs/experiments.md: two groups of four waves half a tile apart, with slot barriers or with group-local
 // LDS-counter barriers: 4.0-4.1 ms against 3.4 -- the epilogue's memory round trips then pace the other group's chains.)
@@ -257,7 +271,7 @@ DEVINL RingFrag ring_first(const u32x4* hi, const u32x4* ring, int lane) {
 // (NRFS, rf_next): 3.53 -> 3.46 ms.  What a request costs in the chain is its ISSUE: the eight waves are in lock-step, their
 // requests reach the CU's one memory pipeline together, and a wave whose request is not accepted issues no MFMA either (stamps:
 // every request adds ~500 cycles to its layer whether it hits L2 or not).
-template <int W, int LYR, bool RELU, int RFS = 0, int NRFS = 0, int NWV = 8>
+template <int W, int LYR, bool RELU, int RFS = 0, int NRFS = 0, int NWV = 8, bool WRAP = false>
 DEVINL void sp_layer_ring(f32x16 (&acc)[4], f32x16 (&in)[4], const u32x4* hi, const u32x4* hi_next, u32x4* ring, const RingSrc& src,
                           RingFrag& nx, int lane, int tid, const f32x4* rf = nullptr, f32x4* side = nullptr,
                           const f32x4* rf_next = nullptr) {
@@ -274,8 +288,13 @@ DEVINL void sp_layer_ring(f32x16 (&acc)[4], f32x16 (&in)[4], const u32x4* hi, co
     constexpr int MODE = MGN_RING_REFILL_AT_REQUEST;                  // 0: two requests behind each k-step, 1: with the window requests, 2: one per two steps
     constexpr bool ATREQ = MODE == 1;
     static_assert(MODE == 0 || ROT == 2, "the other schedules are written for a rotation of two k-steps");
+    // WRAP (schedule 2 only; for a refill that is first used well after the layer, the e tile behind layer 3): no side buffer and no
+    // rotation -- the registers of k-step s take the pieces of k-step s, for s < 8 - ROT; the last ROT k-steps' pieces (in[3][16 - 8 ROT ..])
+    // are left to the caller, who requests them behind the layer (requested inside it they are spilled where they land, with an
+    // s_waitcnt vmcnt(0) in the middle of the chain: the 64 registers of `in` are free only when the layer is done).
+    static_assert(!WRAP || (MODE == 2 && RFS > 0), "the plain refill is written for schedule 2");
     f32x4 side_local[2 * ROT];
-    if constexpr (RFS > 0 && (MODE == 0 || !((MGN_RING_SIDE_EARLY >> (LYR == 0 ? 1 : 0)) & 1))) {
+    if constexpr (!WRAP && RFS > 0 && (MODE == 0 || !((MGN_RING_SIDE_EARLY >> (LYR == 0 ? 1 : 0)) & 1))) {
         side = side_local;
 #pragma unroll
         for (int m = 0; m < 2 * ROT; ++m) side[m] = rf[m * RFS];
@@ -334,7 +353,7 @@ DEVINL void sp_layer_ring(f32x16 (&acc)[4], f32x16 (&in)[4], const u32x4* hi, co
             if constexpr (MODE == 2) {
                 if constexpr (RFS > 0) {
                     if ((t & 1) && s < 8 - ROT) {                      // registers of k-step s (free since the step began), half t >> 1
-                        const f32x4 v = rf[(2 * (s + ROT) + (t >> 1)) * RFS];
+                        const f32x4 v = rf[(2 * (WRAP ? s : s + ROT) + (t >> 1)) * RFS];
 #pragma unroll
                         for (int i = 0; i < 4; ++i) in[s >> 1][8 * (s & 1) + 4 * (t >> 1) + i] = v[i];
                     }
@@ -391,7 +410,7 @@ DEVINL void sp_layer_ring(f32x16 (&acc)[4], f32x16 (&in)[4], const u32x4* hi, co
             }
         }
     }
-    if constexpr (RFS > 0) {                                           // un-rotate: k-step u's pieces sit in the registers of k-step u - 2
+    if constexpr (RFS > 0 && !WRAP) {                                  // un-rotate: k-step u's pieces sit in the registers of k-step u - 2
         f32x16 r[4];
 #pragma unroll
         for (int u = 0; u < 8; ++u)
@@ -438,6 +457,15 @@ DEVINL void ring_load_e(f32x16 (&x)[4], const f32x4* p) {
         const f32x4 v = MGN_RING_ELOAD ? __builtin_nontemporal_load(p + m * STRIDE_TILE) : p[m * STRIDE_TILE];
 #pragma unroll
         for (int i = 0; i < 4; ++i) x[m >> 2][4 * (m & 3) + i] = v[i];
+    }
+}
+// pieces 12 .. 15 (k-steps 6, 7) of an e tile: what sp_layer_ring's plain refill (WRAP) leaves to its caller
+DEVINL void ring_load_e_tail(f32x16 (&x)[4], const f32x4* p) {
+#pragma unroll
+    for (int m = 12; m < 16; ++m) {
+        const f32x4 v = p[m * STRIDE_TILE];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) x[3][4 * (m & 3) + i] = v[i];
     }
 }
 #ifdef MGN_RING_EPI_STAMPS     // diagnostic: the eight stamp slots on the epilogue (1: chains done ... 7: turnover requested)
@@ -492,6 +520,15 @@ __global__ __launch_bounds__(NWV * 64, NWV / 4) void k_edge_ring(const EdgeArgs 
     if (tw0.tile >= tw0.end) return;
 #ifndef MGN_RING_PHASES
 #define MGN_RING_PHASES 2
+#endif
+#ifndef MGN_RING_L3_WRAP
+#define MGN_RING_L3_WRAP 0       // 1: layer 3's refill without a side buffer (sp_layer_ring WRAP)
+#endif
+#ifndef MGN_RING_ENEXT_TAIL
+#define MGN_RING_ENEXT_TAIL 0    // where the last two k-steps of the next tile's e are requested: 0 = at the start of the epilogue (ahead of the e stores), 1 = at its end
+#endif
+#ifndef MGN_RING_ENEXT
+#define MGN_RING_ENEXT 1         // 1 (default): layer 3's refill fetches the NEXT tile's e, this tile's is read again in the epilogue; 2: and stored last (spills); 0: round 3's order
 #endif
 #ifndef MGN_RING_PHASE_UNITS
 #define MGN_RING_PHASE_UNITS 10
@@ -550,16 +587,39 @@ __global__ __launch_bounds__(NWV * 64, NWV / 4) void k_edge_ring(const EdgeArgs 
         CST(1);
         tab_frag<NT>(y, tb + T_B2 * L, h);
         CST(2);
+#if MGN_RING_L3_WRAP || MGN_RING_ENEXT
+        sp_layer_ring<W, 1, true, 0, 0, NWV>(y, acc, l2h, l3h, ring, src, nx, lane, tid);   // layer 2 (ReLU folded into the split)
+#else
         sp_layer_ring<W, 1, true, 0, STRIDE_TILE, NWV>(y, acc, l2h, l3h, ring, src, nx, lane, tid, nullptr, side, etile_rd);   // layer 2 (ReLU folded into the split)
+#endif
         CST(3);
         tab_frag<NT>(acc, tb + T_B3 * L, h);
         CST(4);
         // layer 3: y = layer 2's output in, the e tile (for the residual) out
+#if MGN_RING_ENEXT
+        // ... or the NEXT tile's e: nothing of the turnover then waits behind this tile's e stores (s_waitcnt vmcnt retires in order)
+#if defined(MGN_WHATIF) && (MGN_WHATIF & 8)
+        sp_layer_ring<W, 2, true, STRIDE_TILE, 0, NWV, true>(acc, y, l3h, l1h, ring, src, nx, lane, tid, tile_ptr(a.Elat, a.tile0 + wave, L, lane));
+#else
+        sp_layer_ring<W, 2, true, STRIDE_TILE, 0, NWV, true>(acc, y, l3h, l1h, ring, src, nx, lane, tid, tile_ptr(a.Elat, nxt, L, lane));
+#endif
+#elif MGN_RING_L3_WRAP
+        sp_layer_ring<W, 2, true, STRIDE_TILE, 0, NWV, true>(acc, y, l3h, l1h, ring, src, nx, lane, tid, etile_rd);
+        ring_load_e_tail(y, etile_rd);
+#else
         sp_layer_ring<W, 2, true, STRIDE_TILE, 0, NWV>(acc, y, l3h, l1h, ring, src, nx, lane, tid, etile_rd, side);
+#endif
         CST(5);
         EST(1);
         PHASE_FENCE();
         __builtin_amdgcn_s_setprio(MGN_PRIO);
+#if MGN_RING_ENEXT
+        f32x16 er[NT];               // this tile's e again, for the residual (y holds the next tile's): arrives during the LayerNorm
+        ring_load_e(er, etile_rd);
+#if MGN_RING_ENEXT_TAIL == 0
+        ring_load_e_tail(y, tile_ptr(a.Elat, nxt, L, lane));         // k-steps 6 and 7 of the next tile's e
+#endif
+#endif
         {   // LayerNorm (layer_norm_frag of frag.hpp in four slices): acc = e'
             constexpr float invL = 1.0f / 128;
             float sm = 0.f;
@@ -595,6 +655,21 @@ __global__ __launch_bounds__(NWV * 64, NWV / 4) void k_edge_ring(const EdgeArgs 
         }
         CST(6);
         EST(2);
+#if MGN_RING_ENEXT
+#pragma unroll
+        for (int t = 0; t < NT; ++t) er[t] += acc[t];                // e <- e + e'
+#if MGN_RING_ENEXT == 1
+#if defined(MGN_WHATIF) && (MGN_WHATIF & 2)
+        if (valid && a.E < 0) ring_store_e(etile, er);
+#elif defined(MGN_WHATIF) && (MGN_WHATIF & 64)          // the e stores issued, but into one tile per wave (no HBM traffic)
+        if (valid) ring_store_e(tile_ptr(a.Elat, a.tile0 + wave, L, lane), er);
+#else
+        if (valid) ring_store_e(etile, er);                          // padding rows / tiles store nothing
+#endif
+#endif
+        CST(7);
+        EST(3);
+#else
 #pragma unroll
         for (int t = 0; t < NT; ++t) y[t] += acc[t];                 // e <- e + e'
 #if defined(MGN_WHATIF) && (MGN_WHATIF & 2)
@@ -608,6 +683,7 @@ __global__ __launch_bounds__(NWV * 64, NWV / 4) void k_edge_ring(const EdgeArgs 
         load_frag<NT>(y, tile_ptr(a.Elat, a.tile0 + wave, L, lane), STRIDE_TILE);
 #else
         ring_load_e(y, tile_ptr(a.Elat, nxt, L, lane));              // the next tile's e, ahead of everything else of the turnover
+#endif
 #endif
         const int reff = ix.r >= 0 ? r : (-4 - c);
         const int rprev = __shfl_up(reff, 1, 32);
@@ -636,6 +712,8 @@ __global__ __launch_bounds__(NWV * 64, NWV / 4) void k_edge_ring(const EdgeArgs 
         f32x4* dst = to_carry ? prow_ptr(a.CARRY, (int64_t)2 * tile + (sl ? 0 : 1), L, h) : tile_ptr(a.AGG, r >> 5, L, 32 * h + (r & 31));
 #if defined(MGN_WHATIF) && (MGN_WHATIF & 32)
         if (tail && a.E < 0) store_frag<NT>(dst, to_carry ? STRIDE_PROW : STRIDE_TILE, acc);
+#elif defined(MGN_WHATIF) && (MGN_WHATIF & 128)         // aggregate rows stored row-major (4 lines per row instead of 32)
+        if (tail) store_frag<NT>(to_carry ? dst : prow_ptr(a.AGG, r, L, h), STRIDE_PROW, acc);
 #else
         if (tail) store_frag<NT>(dst, to_carry ? STRIDE_PROW : STRIDE_TILE, acc);
 #endif
@@ -653,6 +731,13 @@ __global__ __launch_bounds__(NWV * 64, NWV / 4) void k_edge_ring(const EdgeArgs 
 #pragma unroll
             for (int m = 0; m < 4; ++m) side[m] = pn[m * STRIDE_PROW];
         }
+#endif
+#if MGN_RING_ENEXT && MGN_RING_ENEXT_TAIL == 1
+        ring_load_e_tail(y, tile_ptr(a.Elat, nxt, L, lane));         // k-steps 6 and 7 of the next tile's e: first needed late in its layer 1
+#endif
+#if MGN_RING_ENEXT == 2
+        PHASE_FENCE();
+        if (valid) ring_store_e(etile, er);                          // the e stores last: every request of the turnover is older than they are
 #endif
         EST(7);
         ix = ixn;
@@ -1188,5 +1273,7 @@ hipError_t launch_edge_split2(const EdgeArgs& a, const LaunchCfg& lc, hipStream_
     hipLaunchKernelGGL(k_edge_split2, dim3(lc.blocks), dim3(lc.threads), lc.lds, s, a);
     return hipGetLastError();
 }
+
+int split_prow_block() { return MGN_PROW_BLOCK; }
 
 }  // namespace mgn

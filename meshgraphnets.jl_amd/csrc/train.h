@@ -81,6 +81,8 @@ hipError_t launch_segment_sum2(int L, const float* srcA, const int32_t* rowptrA,
 // dst [rows][L] = [ (srcA | srcB)[rows][wa + wb] * scale + shift | 0 ]   (srcB may be null with wb = 0; scale null: identity)
 hipError_t launch_affine_pad(const float* srcA, int wa, const float* srcB, int wb, const float* scale, const float* shift, float* dst, int L,
                              int64_t rows, hipStream_t s);
+// node rows between the caller's order and the engine's (a renumbered graph: graph_host.h): gather dst[i] = src[gid[i]], scatter dst[gid[i]] = src[i]
+hipError_t launch_permute_rows(float* dst, const float* src, const int32_t* gid, int64_t rows, int width, bool scatter, hipStream_t s);
 // seed of the RHS VJP (mgn_ode_vjp): G[n][o] = lambda[n][o] * val_mask[n] * os[o]; optionally dxdt = (Y * os + osh) .* val_mask
 hipError_t launch_vjp_seed(const float* Y, int L, int O, const float* lambda, const float* vm, const float* os, const float* osh, float* G,
                            float* dxdt, int64_t N, hipStream_t s);

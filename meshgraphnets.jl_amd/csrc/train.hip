@@ -603,6 +603,19 @@ __global__ void k_affine_pad(const float* __restrict__ srcA, int wa, const float
     dst[i] = v;
 }
 
+// rows of a [rows][width] array between the caller's node order and the engine's (gid[i] = caller's row of engine row i):
+// gather: dst[i] = src[gid[i]];  scatter: dst[gid[i]] = src[i]
+__global__ void k_permute_rows(float* __restrict__ dst, const float* __restrict__ src, const int32_t* __restrict__ gid, int64_t rows, int width,
+                               int scatter) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * width) return;
+    const int64_t r = i / width;
+    const int f = (int)(i - r * width);
+    const int64_t g = gid[r];
+    if (scatter) dst[g * width + f] = src[i];
+    else dst[i] = src[g * width + f];
+}
+
 // seed of the RHS VJP: dx/dt = (out * os + osh) .* val_mask  =>  G[n][o] = lambda[n][o] * val_mask[n] * os[o]
 __global__ void k_vjp_seed(const float* __restrict__ Y, int L, int O, const float* __restrict__ lambda, const float* __restrict__ vm,
                            const float* __restrict__ os, const float* __restrict__ osh, float* __restrict__ G, float* __restrict__ dxdt,
@@ -830,6 +843,13 @@ hipError_t launch_affine_pad(const float* srcA, int wa, const float* srcB, int w
     const int64_t tot = rows * L;
     if (tot <= 0) return hipSuccess;
     hipLaunchKernelGGL(k_affine_pad, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, srcA, wa, srcB, wb, scale, shift, dst, L, rows);
+    return hipGetLastError();
+}
+
+hipError_t launch_permute_rows(float* dst, const float* src, const int32_t* gid, int64_t rows, int width, bool scatter, hipStream_t s) {
+    const int64_t tot = rows * width;
+    if (tot <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_permute_rows, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, dst, src, gid, rows, width, scatter ? 1 : 0);
     return hipGetLastError();
 }
 

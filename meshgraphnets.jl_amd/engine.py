@@ -290,13 +290,18 @@ class Engine:
         return out
 
     def rollout(self, solver, x0, node_type_onehot, ef_raw, t0, t1, saves_dt, n_saves, dt=0.0, val_mask=None,
-                inflow_mask=None, inflow_data=None, abstol=1e-6, reltol=1e-3):
+                inflow_mask=None, inflow_data=None, abstol=1e-6, reltol=1e-3, inflow_rule="reference", time_type=np.float32):
         """Native device-side `rollout` (reference src/solve.jl:42-68).  solver: "Euler" (fixed dt) or "Tsit5".
+        inflow_rule: "reference" = `floor(Int, t / saves_dt) + 1` in the solver's time type, no tolerance, out of range raises
+        (src/solve.jl:151); "tolerant" = + 1e-3, clamped (step k reads frame k).  time_type: np.float32 (the example's `0.0f0:0.01f0:5.99f0`) or np.float64.
         Returns (sol_u [n_saves][N][O], stats dict)."""
         O, Fn = self.cfg.O, self.cfg.Fn
         d = _capi.MgnRolloutDesc()
         d.solver = {"Euler": 0, "Tsit5": 1}[solver]
         d.t0, d.t1, d.dt, d.saves_dt, d.n_saves, d.abstol, d.reltol = t0, t1, dt, saves_dt, n_saves, abstol, reltol
+        d.inflow_rule = {"reference": 0, "tolerant": 1}[inflow_rule]
+        d.time_f64 = 1 if np.dtype(time_type) == np.float64 else 0
+        d.t0_f64, d.t1_f64, d.dt_f64, d.saves_dt_f64 = t0, t1, dt, saves_dt
         x0 = _c32(x0, (self.N, O))
         oh = _c32(node_type_onehot, (self.N, Fn - O)) if Fn > O else None
         ef = _c32(ef_raw, (self.E, self.cfg.Fe))
@@ -358,6 +363,18 @@ class Engine:
         dxdt = np.zeros((self.N, O), np.float32) if want_dxdt else None
         self._chk(self.lib.mgn_ode_vjp(self.h, f32(x), f32(oh), f32(ef), f32(vm), f32(lam), f32(dxdt), f32(xbar), f32(gs), gs.size))
         return xbar, gs, dxdt
+
+    def forward_vjp(self, nf, ef, ybar, want_out=False):
+        """Pullback of forward() == of `mgn.model(graph, ps, st)` (src/solve.jl:200): ybar^T d out / d nf and ybar^T d out / d ps.
+        Returns (nfbar [N][Fn], gs [packed], out or None): what a ChainRulesCore.rrule of the Julia shim's model hands to Zygote."""
+        nf = _c32(nf, (self.N, self.cfg.Fn))
+        ef = _c32(ef, (self.E, self.cfg.Fe))
+        ybar = _c32(ybar, (self.N, self.cfg.O))
+        nfbar = np.zeros((self.N, self.cfg.Fn), np.float32)
+        gs = np.zeros(self.param_count, np.float32)
+        out = np.zeros((self.N, self.cfg.O), np.float32) if want_out else None
+        self._chk(self.lib.mgn_forward_vjp(self.h, f32(nf), f32(ef), f32(ybar), f32(out), f32(nfbar), f32(gs), gs.size))
+        return nfbar, gs, out
 
     def processor_steps(self, v, e, nsteps):
         v = _c32(v, (self.N, self.cfg.L)).copy()

@@ -220,7 +220,9 @@ def ode_func_eval(x, p, t):
     saves_dt): x[inflow_mask] = vcat(data[field][floor(t / saves_dt)] ...)[inflow_mask]."""
     (mgn, ps, data, inputs, fields, meta, target_fields, target_dict, node_type, edge_features, senders, receivers,
      val_mask, inflow_mask, saves_dt, pr) = p
-    k = int(np.floor(t / saves_dt + 1e-9))
+    # floor(Int, t / saves_dt) + 1 (1-based) in the type t and saves_dt arrive in, no tolerance (src/solve.jl:151): an IndexError
+    # here is the reference's BoundsError
+    k = int(np.floor(t / saves_dt))
     gt = np.concatenate([np.asarray(data[f], F32)[k] for f in target_fields], 1)
     x[inflow_mask] = gt[inflow_mask]   # IN PLACE, like the reference: the caller's (solver's) state is modified
     return ode_step(x, (mgn, ps, inputs, fields, meta, target_fields, target_dict, node_type, edge_features,
@@ -249,7 +251,7 @@ def rollout(solver, mgn, initial_state, fields, meta, target_fields, target_dict
             break
         dx = ode_func_eval(x, p, t)   # mutates the inflow rows of x (reference quirk, src/solve.jl:151-152)
         x = x + F32(dt) * dx
-        t = start + (i + 1) * dt
+        t = t + dt                    # the integrator's own time: t <- t + dt in the type start / dt arrive in (np.float32 or float)
     return np.stack(sol_u), np.array(sol_t)
 
 

@@ -458,19 +458,47 @@ def ode_rhs(packed, cfg, x, node_type_onehot, ef_raw, senders, receivers, n_norm
     return o_norm.inverse(out) * val_mask
 
 
-def euler_rollout(rhs, x0, dt, nsteps, inflow_mask=None, inflow_values=None):
+def inflow_frame(t, saves_dt, rule="reference", time_type=np.float64):
+    """0-based frame of the inflow data a right-hand side at time t reads: the reference's `floor(Int, t / saves_dt) + 1`
+    (src/solve.jl:151, 1-based there) with the quotient formed in the solver's time type and NO tolerance -- in Float64
+    0.29 / 0.01 = 28.999999999999996 floors to 28, so a step whose time sits an ulp below a frame boundary re-uses the previous
+    frame; this is what the reference computes and it is kept.  rule = "tolerant": floor(t / saves_dt + 1e-3) (step k reads frame k
+    whatever the time type: an accumulated Float32 time drifts by ~1e-4 frames)."""
+    T = np.dtype(time_type).type
+    if rule == "tolerant":
+        return int(np.floor(float(t) / float(saves_dt) + 1e-3))
+    return int(np.floor(T(T(t) / T(saves_dt))))
+
+
+def euler_times(t0, dt, nsteps, time_type=np.float64):
+    """The times a fixed-step integrator hands to its right-hand side: t <- t + dt in its time type, step after step
+    (OrdinaryDiffEq's loop footer adds dt to t and snaps only to tstops; `solve(...; adaptive = false, dt, saveat)` at
+    src/solve.jl:60 has none but the end of the interval)  [ODE-unverified: DifferentialEquations.jl cannot be run here]."""
+    T = np.dtype(time_type).type
+    ts, t = [], T(t0)
+    for _ in range(nsteps):
+        ts.append(t)
+        t = T(t + T(dt))
+    return ts
+
+
+def euler_rollout(rhs, x0, dt, nsteps, inflow_mask=None, inflow_values=None, rule=None, time_type=np.float64, saves_dt=None):
     """Fixed-step Euler (solve(prob, Euler(); adaptive=false, dt) at src/solve.jl:60).
     Reference quirk kept on purpose: ode_func_eval overwrites the inflow rows of the array the solver hands it
     IN PLACE (`x[inflow_mask] = ...`, src/solve.jl:151-152), and for an out-of-place Euler step that array is
     the integrator's own state, so the overwrite is part of the state the step starts from:
         x_k' = overwrite(x_k);  x_{k+1} = x_k' + dt * f(x_k').   Saved values are the x_k BEFORE the overwrite
-    of step k (saveat stores u after the step)."""
+    of step k (saveat stores u after the step).
+    rule = None: frame = step number (the fixtures GOLD-D / GOLD-E; equal to the tolerant rule); "reference" / "tolerant":
+    inflow_frame(t_k, saves_dt or dt, rule, time_type) on the integrator's own times (euler_times); rhs receives that t_k."""
     xs = [np.array(x0, np.float64)]
+    ts = euler_times(0.0, dt, nsteps, time_type) if rule is not None else [i * dt for i in range(nsteps)]
     for i in range(nsteps):
         xk = xs[-1].copy()
         if inflow_mask is not None:
-            xk[inflow_mask] = np.asarray(inflow_values[i], np.float64)[inflow_mask]
-        xs.append(xk + dt * rhs(xk, i * dt))
+            fr = i if rule is None else inflow_frame(ts[i], dt if saves_dt is None else saves_dt, rule, time_type)
+            xk[inflow_mask] = np.asarray(inflow_values[fr], np.float64)[inflow_mask]    # IndexError == the reference's BoundsError
+        xs.append(xk + dt * rhs(xk, ts[i]))
     return np.stack(xs)
 
 

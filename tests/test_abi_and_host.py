@@ -67,6 +67,55 @@ def test_no_gpu_means_no_compute(lib_built):
         assert ei.value.code == -2
 
 
+def test_locality_restoring_node_order(lib_built):
+    """mgn_set_graph numbers a mesh that arrives with scattered node labels in breadth-first order (graph_host.h), so that the ends of
+    an edge are close in the engine's row order again -- what the sender gathers of the processor kernels need -- and leaves a
+    coherently numbered mesh alone.  Invisible at the boundary: owned_nodes() is the map back."""
+    pos, cells = synth.grid_mesh(60, 45, 1)
+    s, r = synth.cells_to_edges(cells)
+    N = pos.shape[0]
+
+    def cost(e):
+        own = e.owned_nodes()
+        assert sorted(own.tolist()) == list(range(N))              # a permutation of all nodes
+        g2l = np.empty(N, np.int64)
+        g2l[own] = np.arange(N)
+        snd, rcv, rowptr = e.local_graph()
+        assert np.all(np.diff(rcv) >= 0) and np.array_equal(np.bincount(rcv, minlength=N), np.diff(rowptr))
+        return float(np.abs(snd.astype(np.int64) - rcv).mean()), own, g2l
+
+    e0 = Engine(9, 3, 2, device=MGN_DEVICE_NONE)
+    e0.set_graph(s, r, N)
+    c0, own0, _ = cost(e0)
+    assert not _renumbered(e0) and np.array_equal(own0, np.arange(N))
+    perm = np.random.default_rng(1).permutation(N).astype(np.int32)
+    sp, rp = perm[s], perm[r]
+    e1 = Engine(9, 3, 2, device=MGN_DEVICE_NONE)
+    e1.set_graph(sp, rp, N)
+    c1, own1, g2l1 = cost(e1)
+    assert _renumbered(e1) and c1 <= 3 * c0                        # as local as the generator's own numbering (within a small factor)
+    eid = e1.local_edges()
+    snd, rcv, _ = e1.local_graph()
+    assert np.array_equal(own1[snd], sp[eid]) and np.array_equal(own1[rcv], rp[eid])
+    old = _renumber_mode(0)                                         # policy 0: never
+    try:
+        e2 = Engine(9, 3, 2, device=MGN_DEVICE_NONE)
+        e2.set_graph(sp, rp, N)
+        c2, own2, _ = cost(e2)
+        assert not _renumbered(e2) and np.array_equal(own2, np.arange(N)) and c2 > 5 * c1
+        _renumber_mode(2)                                           # policy 2: always
+        e3 = Engine(9, 3, 2, device=MGN_DEVICE_NONE)
+        e3.set_graph(s, r, N)
+        assert _renumbered(e3)
+    finally:
+        _renumber_mode(old)
+    # disconnected pieces and isolated nodes keep every node exactly once
+    s4 = np.concatenate([sp, np.array([], np.int32)])
+    e4 = Engine(9, 3, 2, device=MGN_DEVICE_NONE)
+    e4.set_graph(s4, rp, N + 7)                                     # seven nodes without an edge
+    assert sorted(e4.owned_nodes().tolist()) == list(range(N + 7))
+
+
 def test_set_graph_argument_errors(lib_built):
     e = Engine(9, 3, 2, device=MGN_DEVICE_NONE)
     with pytest.raises(MgnError):
@@ -81,11 +130,29 @@ def test_set_graph_argument_errors(lib_built):
     assert e.e_local == 0 and e.n_own == 4
 
 
+def _renumber_mode(mode):
+    lib = mgn_amd.load()
+    lib.mgn_debug_renumber.restype = C.c_int
+    lib.mgn_debug_renumber.argtypes = [C.c_int]
+    return lib.mgn_debug_renumber(mode)
+
+
+def _renumbered(e):
+    e.lib.mgn_debug_renumbered.restype = C.c_int
+    e.lib.mgn_debug_renumbered.argtypes = [C.c_void_p]
+    return bool(e.lib.mgn_debug_renumbered(e.h))
+
+
 @pytest.mark.parametrize("P", [1, 2, 3, 4, 8])
-def test_partition_invariants(lib_built, P):
+@pytest.mark.parametrize("scattered", [False, True])
+def test_partition_invariants(lib_built, P, scattered):
     pos, cells = synth.grid_mesh(23, 17, 5)
     s, r = synth.cells_to_edges(cells)
     N, E = pos.shape[0], s.size
+    if scattered:      # the same mesh under arbitrary node labels (DeepMind's trajectories; create_base_graph passes them through,
+        perm = np.random.default_rng(3).permutation(N).astype(np.int32)     # reference src/graph.jl:30-36): label of old node i = perm[i]
+        s, r = perm[s], perm[r]
+        pos = pos[np.argsort(perm)]
     engs = []
     for rk in range(P):
         e = Engine(9, 3, 2, rank=rk, nranks=P, device=MGN_DEVICE_NONE)
@@ -99,7 +166,10 @@ def test_partition_invariants(lib_built, P):
         assert np.array_equal(e.node_owner(), owner)               # every rank computes the same partition
         own = e.owned_nodes()
         nb = e.boundary_count()
-        assert np.all(owner[own] == rk) and np.all(np.diff(own[:nb]) > 0) and np.all(np.diff(own[nb:]) > 0)
+        assert np.all(owner[own] == rk)
+        assert not (_renumbered(e) and not scattered)              # a coherent numbering is kept (a scattered one is replaced when
+        if not _renumbered(e):                                     # that buys a factor RENUMBER_GAIN: not on a 50-node partition)
+            assert np.all(np.diff(own[:nb]) > 0) and np.all(np.diff(own[nb:]) > 0)
         sidx_all = e.halo_send_index()
         assert set(sidx_all.tolist()) == set(range(nb))            # boundary nodes == send-listed nodes, numbered first
         seen_nodes[own] += 1

@@ -147,7 +147,7 @@ def test_rollout_100_steps_euler_on_mcyl_matches_gold_e():
     eng = _cyl_engine(p)
     dt, ns = float(g["dt"]), int(g["nsteps"])
     sol, st = eng.rollout("Euler", p["x0"], p["onehot"], p["ef_raw"], 0.0, ns * dt, dt, ns + 1, dt=dt, val_mask=p["val_mask"][:, 0],
-                          inflow_mask=p["inflow"][:, 0], inflow_data=p["gt"])
+                          inflow_mask=p["inflow"][:, 0], inflow_data=p["gt"], inflow_rule="tolerant")     # GOLD-E: frame k at step k
     assert st["n_rhs"] == 100 and sol.shape == (101, 2000, 2)
     assert rel_max(sol[1], g["euler_first"]) <= TOL_15
     ref = g["euler"].astype(np.float64)
@@ -165,7 +165,7 @@ def test_rollout_tsit5_101_saves_on_mcyl_matches_oracle_tsit5():
     eng = _cyl_engine(p)
     dt, ns = float(g["dt"]), int(g["nsteps"])
     sol, st = eng.rollout("Tsit5", p["x0"], p["onehot"], p["ef_raw"], 0.0, ns * dt, dt, ns + 1, val_mask=p["val_mask"][:, 0],
-                          inflow_mask=p["inflow"][:, 0], inflow_data=p["gt"], abstol=1e-6, reltol=1e-3)
+                          inflow_mask=p["inflow"][:, 0], inflow_data=p["gt"], abstol=1e-6, reltol=1e-3, inflow_rule="tolerant")
     assert sol.shape == (101, 2000, 2) and st["n_accept"] >= 100
     assert abs(st["n_accept"] - int(g["tsit5_accept"])) <= max(3, int(g["tsit5_accept"]) // 20)
     ref = g["tsit5"].astype(np.float64)

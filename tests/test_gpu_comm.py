@@ -394,7 +394,7 @@ def test_rollout_and_ode_step_on_a_partitioned_mesh(P):
         e.set_norms(node=(g["node_scale"], g["node_shift"]), edge=(g["edge_scale"], g["edge_shift"]), out=(g["out_scale"], g["out_shift"]))
 
     def run(e):
-        kw = dict(val_mask=g["val_mask"], inflow_mask=g["inflow_mask"][:, 0], inflow_data=g["gt"])
+        kw = dict(val_mask=g["val_mask"], inflow_mask=g["inflow_mask"][:, 0], inflow_data=g["gt"], inflow_rule="tolerant")
         eu, st = e.rollout("Euler", g["x0"], onehot, g["ef_raw"], 0.0, 10 * dt, dt, 11, dt=dt, **kw)
         ts, st2 = e.rollout("Tsit5", g["x0"], onehot, g["ef_raw"], 0.0, 10 * dt, dt, 11, abstol=1e-6, reltol=1e-3, **kw)
         f1 = e.ode_step(g["x0"].astype(np.float32), onehot, g["ef_raw"], g["val_mask"])
@@ -426,3 +426,55 @@ def test_rollout_and_ode_step_on_a_partitioned_mesh(P):
     assert np.array_equal(f1, f2)
     assert rel_max(eu, ref[0]) <= 1e-5 and rel_max(ts, ref[1]) <= 1e-5 and rel_max(f1, ref[2]) <= 1e-5
     assert np.linalg.norm(eu - g["xs"]) / np.linalg.norm(g["xs"]) <= 1e-3
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("P", [2, 4])
+def test_kat7_split_path_partitions_against_the_oracle(P, dtype):
+    """KAT-7 where the DEFAULT kernels run it (kernel path 0): a 150 x 150 slice of the M-1M generator (22 500 nodes, 133 k edges) in P
+    edge-cut partitions is large enough for the ring kernel of the split path (fp32) / the persistent bf16 kernels to take every
+    launch, interior and boundary tile ranges alike; the result is held to the float64 oracle (not only to the single-partition run)."""
+    from util import set_kernel_path
+    old = set_kernel_path(0)
+    try:
+        cfg = cfg_dict(mps=4)
+        pos, s, r = synth.mesh_1m(1234, 150, 150)
+        N, E = pos.shape[0], s.size
+        ps = make_params(cfg, jitter=0.05)
+        rng = np.random.default_rng(5)
+        v0 = rng.standard_normal((N, 128)).astype(np.float32)
+        e0 = rng.standard_normal((E, 128)).astype(np.float32)
+        kw = dict(dtype="bf16") if dtype == "bf16" else {}
+        single = engine_for(cfg, **kw)
+        single.set_params(ps)
+        single.set_graph(s, r, N)
+        v1, e1 = single.processor_steps(v0, e0, 4)
+        cid = mgn_amd.Engine.comm_unique_id("host")
+        vc, ec = np.zeros((N, 128), np.float32), np.zeros((E, 128), np.float32)
+        lock = threading.Lock()
+
+        def body(k):
+            e = engine_for(cfg, rank=k, nranks=P, device=0, **kw)
+            e.set_params(ps)
+            e.set_graph(s, r, N, mesh_pos=pos)
+            e.comm_init(cid, "host")
+            e.latents_import(v0, e0)
+            e.processor_steps_dev(4)
+            e.synchronize()
+            with lock:
+                e.latents_export(vc, ec)
+            n_halo = e.n_halo
+            e.comm_barrier()
+            e.close()
+            return n_halo
+
+        assert all(n > 0 for n in run_ranks(P, body))
+        rv, re = orc.processor_steps(ps, cfg, v0, e0, s, r, 4)
+        if dtype == "f32":
+            assert rel_max(vc, v1) <= 1e-5 and rel_max(ec, e1) <= 1e-5
+            assert rel_max(vc, rv) <= TOL_15 and rel_max(ec, re) <= TOL_15
+        else:       # bf16 storage: the band of tests/test_gpu_bf16.py (relative L2 against the float64 oracle)
+            for a, b in ((vc, rv), (ec, re), (v1, rv), (e1, re)):
+                assert np.linalg.norm(a - b) / np.linalg.norm(b) <= 3e-2
+    finally:
+        set_kernel_path(old)

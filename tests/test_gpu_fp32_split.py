@@ -157,7 +157,7 @@ def test_split_two_edge_sets(split_on):
     assert rel_max(v1, rv) <= TOL_15 and rel_max(e1, re) <= TOL_15 and rel_max(e21, re2) <= TOL_15
 
 
-def test_node_ring_opt_in_kernel():
+def test_node_ring_opt_in_kernel(tmp_path):
     """MGN_NODE_RING=1 (read once per process, hence a child process): node MLP + projection of a step in one lock-step launch
     (k_node_ring), on a mesh beyond the cooperative node kernels' range; same tolerances and, by construction, the same bits."""
     import os
@@ -193,7 +193,7 @@ print("child OK")
     outs = []
     for ring, check in (("1", ["check"]), ("0", [])):
         env["MGN_NODE_RING"] = ring
-        f = "/tmp/mgn_node_ring_%s.npy" % ring
+        f = str(tmp_path / ("mgn_node_ring_%s.npy" % ring))
         run = subprocess.run([sys.executable, "-c", code, f] + check, env=env, capture_output=True, text=True, timeout=600)
         assert run.returncode == 0 and "child OK" in run.stdout, run.stdout[-2000:] + run.stderr[-2000:]
         outs.append(np.load(f))

@@ -278,8 +278,10 @@ def test_native_rollout_euler_matches_gold_d():
     """N1: the device-side driver (mgn_rollout, Euler) against GOLD-D (float64 oracle through ode_func_eval)."""
     g, ps, cfg, eng, onehot = _gold_d_problem()
     dt = float(g["dt"])
+    # (Float64 times: the reference's frame rule reads frame k at step k for these ten steps -- oracle.euler_times; in Float32 it
+    # would not: test_rollout_inflow_frame_rule_is_the_reference_s)
     sol, st = eng.rollout("Euler", g["x0"], onehot, g["ef_raw"], 0.0, 10 * dt, dt, 11, dt=dt, val_mask=g["val_mask"],
-                          inflow_mask=g["inflow_mask"][:, 0], inflow_data=g["gt"])
+                          inflow_mask=g["inflow_mask"][:, 0], inflow_data=g["gt"], time_type=np.float64)
     assert st["n_rhs"] == 10 and sol.shape == g["xs"].shape
     assert np.linalg.norm(sol - g["xs"]) / np.linalg.norm(g["xs"]) <= TOL_ROLLOUT
     assert rel_max(sol[1], g["xs"][1]) <= TOL_15
@@ -303,7 +305,7 @@ def test_native_rollout_tsit5_matches_oracle_tsit5():
                            n_norm, orc.NormMinMax(0.0, 1.0), e_norm, o_norm, g["val_mask"][:, None])
 
     ref, rst = orc.tsit5_rollout(f, g["x0"], 0.0, 10 * dt, saves, abstol=1e-6, reltol=1e-3)
-    sol, st = eng.rollout("Tsit5", g["x0"], onehot, g["ef_raw"], 0.0, 10 * dt, dt, 11, val_mask=g["val_mask"],
+    sol, st = eng.rollout("Tsit5", g["x0"], onehot, g["ef_raw"], 0.0, 10 * dt, dt, 11, val_mask=g["val_mask"], inflow_rule="tolerant",
                           inflow_mask=inflow[:, 0], inflow_data=g["gt"], abstol=1e-6, reltol=1e-3)
     assert st["n_accept"] >= 10 and abs(st["n_accept"] - rst["n_accept"]) <= 2
     assert np.linalg.norm(sol - ref) / np.linalg.norm(ref) <= TOL_ROLLOUT
@@ -395,3 +397,47 @@ def test_edge_phases_equal_whole_edge_step(dtype):
     if dtype == "f32":
         rv, re = orc.processor_steps(ps, cfg, v0, e0, s, r, 1)
         assert rel_max(results[1][0], rv) <= TOL_STEP and rel_max(results[1][1], re) <= TOL_STEP
+
+
+def test_rollout_inflow_frame_rule_is_the_reference_s():
+    """Which inflow frame a right-hand side reads: `floor(Int, t / saves_dt) + 1` in the solver's time type, no tolerance
+    (reference src/solve.jl:151) on the integrator's own times t <- t + dt.  In Float32 (the example's `0.0f0:0.01f0:5.99f0`) the
+    sixth step of dt = 0.01 sits at t = 0.059999995 and reads frame 5 again; in Float64 the first stale frame is at step 10.  The
+    engine follows the oracle's restatement of that rule frame by frame, offers the tolerant rule as an option and turns a frame
+    outside the data into an error (reference: BoundsError)."""
+    g, ps, cfg, eng, onehot = _gold_d_problem()
+    dt = float(g["dt"])
+    rng = np.random.default_rng(7)
+    N = g["x0"].shape[0]
+    gt = (rng.standard_normal((17, N, 2)) * 0.3 + 1.0).astype(np.float32)       # one distinct frame per save point
+    n_norm = orc.NormMeanStd(-g["node_shift"][:2] / g["node_scale"][:2], 1 / g["node_scale"][:2])
+    e_norm = orc.NormMeanStd(-g["edge_shift"] / g["edge_scale"], 1 / g["edge_scale"])
+    o_norm = orc.NormMeanStd(g["out_shift"], g["out_scale"])
+    inflow = g["inflow_mask"]
+
+    def rhs(x, t):
+        return orc.ode_rhs(ps, cfg, x, onehot, g["ef_raw"], g["senders"], g["receivers"], n_norm, orc.NormMinMax(0.0, 1.0), e_norm, o_norm,
+                           g["val_mask"][:, None])
+
+    for T, ns, stale in ((np.float32, 12, 6), (np.float64, 15, 10)):
+        frames = [orc.inflow_frame(t, dt, "reference", T) for t in orc.euler_times(0.0, dt, ns, T)]
+        assert frames[:stale] == list(range(stale)) and frames[stale] == stale - 1        # the quirk itself
+        ref = orc.euler_rollout(rhs, g["x0"], dt, ns, inflow, gt, rule="reference", time_type=T)
+        sol, st = eng.rollout("Euler", g["x0"], onehot, g["ef_raw"], 0.0, ns * dt, dt, ns + 1, dt=dt, val_mask=g["val_mask"],
+                              inflow_mask=inflow[:, 0], inflow_data=gt, time_type=T)
+        assert st["n_rhs"] == ns
+        assert np.linalg.norm(sol - ref) / np.linalg.norm(ref) <= TOL_ROLLOUT
+        # ... and it is NOT what the step-number rule gives from the first stale frame on (the inflow rows differ)
+        tol = orc.euler_rollout(rhs, g["x0"], dt, ns, inflow, gt, rule="tolerant", time_type=T)
+        assert np.abs(ref[stale + 1] - tol[stale + 1]).max() > 1e-3
+        sol_t, _ = eng.rollout("Euler", g["x0"], onehot, g["ef_raw"], 0.0, ns * dt, dt, ns + 1, dt=dt, val_mask=g["val_mask"],
+                               inflow_mask=inflow[:, 0], inflow_data=gt, time_type=T, inflow_rule="tolerant")
+        assert np.linalg.norm(sol_t - tol) / np.linalg.norm(tol) <= TOL_ROLLOUT
+    # a frame beyond the data: the reference raises BoundsError, the engine MGN_E_ARG (no clamping)
+    with pytest.raises(mgn_amd.MgnError, match="inflow frame") as ei:
+        eng.rollout("Euler", g["x0"], onehot, g["ef_raw"], 0.0, 12 * dt, dt, 13, dt=dt, val_mask=g["val_mask"],
+                    inflow_mask=inflow[:, 0], inflow_data=gt[:5])
+    assert ei.value.code == -1                                                                          # MGN_E_ARG
+    sol_c, _ = eng.rollout("Euler", g["x0"], onehot, g["ef_raw"], 0.0, 12 * dt, dt, 13, dt=dt, val_mask=g["val_mask"],
+                           inflow_mask=inflow[:, 0], inflow_data=gt[:5], inflow_rule="tolerant")      # the tolerant rule clamps
+    assert np.isfinite(sol_c).all()

@@ -6,6 +6,7 @@ import pytest
 import torch   # before the engine's first HIP call (device-array test), or torch finds no GPU afterwards
 
 import mgn_oracle as orc
+import mgn_amd
 from mgn_amd import synth
 from util import cfg_dict, engine_for, make_params, rel_max, small_mesh
 
@@ -196,6 +197,52 @@ def test_ode_vjp_matches_oracle_and_ode_step():
                                           - eng.ode_step(x - eps * d, onehot, ef_raw, vm))).sum() / (2 * eps))
     an = float((xbar.astype(np.float64) * d).sum())
     assert abs(fd - an) <= 0.2 * abs(an), (fd, an)
+
+
+def test_forward_vjp_is_the_pullback_of_the_model_call():
+    """mgn_forward_vjp: the pullback of `output, st = mgn.model(graph, ps, mgn.st)` (reference src/solve.jl:200) -- what the Julia shim's
+    ChainRulesCore.rrule hands to Zygote when it differentiates ode_func_train as written (src/strategies.jl:183-195): for a cotangent
+    ybar of the output, ybar^T d out / d nf (all Fn columns) and ybar^T d out / d ps, against the oracle's reverse mode; composing it
+    with the Julia-side pieces (normalisers, inverse_data, val_mask) by hand reproduces mgn_ode_vjp."""
+    cfg = cfg_dict(mps=3)
+    pos, cells, node_type, vel = synth.mesh_cyl(1234, 300)
+    s, r = synth.cells_to_edges(cells)
+    N, E = pos.shape[0], s.size
+    ps = make_params(cfg)
+    rng = np.random.default_rng(11)
+    nf = rng.standard_normal((N, 9)).astype(np.float32)
+    ef = rng.standard_normal((E, 3)).astype(np.float32)
+    ybar = rng.standard_normal((N, 2)).astype(np.float32)
+    eng = engine_for(cfg)
+    eng.set_params(ps)
+    eng.set_graph(s, r, N)
+    nfbar, gs, out = eng.forward_vjp(nf, ef, ybar, want_out=True)
+    rout, rg, rnf = orc.model_vjp(ps, cfg, nf, ef, s, r, lambda o: ybar.astype(np.float64))
+    assert rel_max(out, rout) <= 1e-4
+    assert rel_max(out, eng.forward(nf, ef)) <= 1e-5
+    row_err = np.abs(nfbar - rnf).max(1) / np.abs(rnf).max()
+    assert np.quantile(row_err, 0.98) <= TOL_GRAD, np.quantile(row_err, 0.98)
+    assert np.linalg.norm(nfbar - rnf) <= 5e-3 * np.linalg.norm(rnf)
+    assert np.linalg.norm(gs - rg) <= 5e-3 * np.linalg.norm(rg)
+    check_grads(gs, rg, cfg, tol=2e-2)
+    # the chain rule around it, as Zygote would apply it to ode_step: nf = [n_norm(x); n_norm(onehot)], dx/dt = (out * os + osh) .* vm
+    onehot = orc.one_hot(node_type, 7, 0).astype(np.float32)
+    ef_raw = orc.edge_features(pos, s, r).astype(np.float32)
+    n_scale, n_shift = np.array([2.5, 5.0], np.float32), np.array([-2.5, -0.5], np.float32)
+    e_scale, e_shift = (1 / ef_raw.std(0)).astype(np.float32), (-ef_raw.mean(0) / ef_raw.std(0)).astype(np.float32)
+    o_scale, o_shift = np.array([0.5, 0.4], np.float32), np.array([0.01, -0.02], np.float32)
+    vm = np.isin(node_type, [0, 5]).astype(np.float32)
+    x = vel.astype(np.float32)
+    lam = rng.standard_normal((N, 2)).astype(np.float32)
+    eng.set_norms(node=(np.concatenate([n_scale, np.ones(7, np.float32)]), np.concatenate([n_shift, np.zeros(7, np.float32)])),
+                  edge=(e_scale, e_shift), out=(o_scale, o_shift))
+    xbar, gs_f, _ = eng.ode_vjp(x, onehot, ef_raw, lam, val_mask=vm)
+    nf2 = np.concatenate([x * n_scale + n_shift, onehot], 1)
+    nfbar2, gs2, _ = eng.forward_vjp(nf2, ef_raw * e_scale + e_shift, lam * vm[:, None] * o_scale)
+    assert np.linalg.norm(nfbar2[:, :2] * n_scale - xbar) <= 1e-4 * np.linalg.norm(xbar)
+    assert np.linalg.norm(gs2 - gs_f) <= 1e-4 * np.linalg.norm(gs_f)
+    with pytest.raises(mgn_amd.MgnError):                                  # null arguments: MGN_E_ARG, like the reference's ArgumentError
+        eng._chk(eng.lib.mgn_forward_vjp(eng.h, None, None, None, None, None, None, 0))
 
 
 def test_recompute_mode_gives_the_same_gradients(monkeypatch):

@@ -58,8 +58,31 @@ def set_c16_row_tiles(rt):
 
 
 def set_fp32_split(on):
-    """Opt-in edge kernel with its layers on the bf16 matrix cores at fp32 accuracy (tests only).  Returns the old value."""
+    """Large fp32 launches: 1 = the split path (bf16 matrix cores at fp32 accuracy: the default), 2 / 3 = its other edge kernels,
+    0 = the fp32-MFMA kernels (tests only).  Returns the old value."""
     lib = mgn_amd.load()
     lib.mgn_debug_fp32_split.restype = __import__("ctypes").c_int
     lib.mgn_debug_fp32_split.argtypes = [__import__("ctypes").c_int]
     return lib.mgn_debug_fp32_split(on)
+
+
+def set_renumber(mode):
+    """Node numbering policy of the next set_graph calls: 0 never, 1 auto (default), 2 always breadth-first (tests only)."""
+    lib = mgn_amd.load()
+    lib.mgn_debug_renumber.restype = __import__("ctypes").c_int
+    lib.mgn_debug_renumber.argtypes = [__import__("ctypes").c_int]
+    return lib.mgn_debug_renumber(mode)
+
+
+def renumbered(eng):
+    eng.lib.mgn_debug_renumbered.restype = __import__("ctypes").c_int
+    eng.lib.mgn_debug_renumbered.argtypes = [__import__("ctypes").c_void_p]
+    return bool(eng.lib.mgn_debug_renumbered(eng.h))
+
+
+def scatter_labels(pos, s, r, seed=0):
+    """The same mesh under arbitrary node labels (what DeepMind's trajectories carry; create_base_graph passes them through,
+    reference src/graph.jl:30-36).  Returns (pos', s', r', perm) with perm[old] = new label; per-node arrays go x' = x[argsort(perm)]."""
+    N = pos.shape[0]
+    perm = np.random.default_rng(seed).permutation(N).astype(np.int32)
+    return pos[np.argsort(perm)], perm[s], perm[r], perm
