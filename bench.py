@@ -597,6 +597,34 @@ def main():
                                                           "host in/out included", "ms_per_step": dtt * 1e3,
                                               "ms_per_step_device_arrays": dtd * 1e3, "loss_finite": bool(np.isfinite(loss_t))}
             engt.close()
+            # N2 at the headline size: one training step on M-1M itself (recompute mode, ~128 GB of kept inputs / gradients)
+            try:
+                engT = mgn_amd.Engine(FN, FE, O, L, 2, MPS, device=local_rank)
+                engT.set_params(ps)
+                engT.set_graph(s, r, N)
+                rngT = np.random.default_rng(0)
+                nfT = rngT.standard_normal((N, FN), dtype=np.float32)
+                efT = rngT.standard_normal((E, FE), dtype=np.float32)
+                tgT = rngT.standard_normal((N, O), dtype=np.float32)
+                mkT = np.arange(0, N, 2, dtype=np.int32)
+                engT.step(nfT, efT, tgT, mkT)                        # first call: weights repacked, arena allocated
+                t0 = time.perf_counter()
+                _, lossT = engT.step(nfT, efT, tgT, mkT)
+                dtT = time.perf_counter() - t0
+                # MFMA flops one step executes (fp32, v_mfma_f32_32x32x2_f32; first edge layer factored as in the forward kernels):
+                # per processor step  forward + recomputation 2 x (98 304 E + 196 608 N), backward (transposed chunks) 98 304 E + 196 608 N,
+                # weight gradients 98 304 E + 196 608 N  (docs/experiments.md, training step)
+                flT = MPS * 4.0 * (98304.0 * E + 196608.0 * N)
+                out["secondary"]["train_step_1m"] = {
+                    "workload": "mgn_step == step! on M-1M (N = 1 000 000, E = 5 992 002, L = 128, 15 steps, fp32 MFMA, recompute mode); host in/out included",
+                    "s_per_step": dtT, "loss_finite": bool(np.isfinite(lossT)),
+                    "roofline": {"bound": "mfma", "executed_flops_per_step": flT, "achieved": flT / dtT / 1e12, "peak": PEAK_F32_MFMA_TFLOPS,
+                                 "unit": "TFLOP/s", "frac": flT / dtT / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                                 "note": "processor MLPs only (encoders / decoder, segmented sums, reductions not counted)"}}
+                engT.close()
+                del nfT, efT, tgT
+            except Exception as ex:   # noqa: BLE001  (a box with less free memory than the 128 GB this needs)
+                out["secondary"]["train_step_1m"] = {"error": str(ex)[:200]}
             # mid-size meshes (real CFD meshes, and the per-GPU share of M-1M on 8 GPUs): where the kernel families meet
             mids = {}
             for nxm in (128, 300, 354):   # 354 x 354 = the per-GPU share of M-1M on 8 GPUs

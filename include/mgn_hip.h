@@ -63,9 +63,17 @@ typedef struct mgn_config {
                            /* julia/spec_probe.jl tells).  MGN_LN_VAR_EPS (0, MGN-spec v1): (x - mean) / sqrt(var + eps);  */
                            /* MGN_LN_STD_EPS: (x - mean) / (sqrt(var) + eps).  eps = 1e-5, biased variance, per row.       */
                            /* Forward path only: mgn_step / mgn_ode_vjp are written for MGN_LN_VAR_EPS                     */
+    int32_t ln_dims;       /* mgn_ln_dims: MGN_LN_ROWS (0, MGN-spec v1): LayerNorm statistics per node / edge over its L features.   */
+                           /* MGN_LN_ALL: over the WHOLE (L x rows) array of an MLP's output -- what Lux 0.5's LayerNorm(shape) computes  */
+                           /* when it is left at dims = Colon() (julia/spec_probe.jl tells which one the installed GraphNetCore / Lux    */
+                           /* run).  A different network, not a numerical variant: every LayerNorm then couples all rows, so the fused    */
+                           /* kernels cannot be used; the mode runs unfused (MLP kernel, grid-wide statistics pass, apply pass) behind     */
+                           /* mgn_forward and mgn_processor_steps: fp32, one partition, one edge set; the other compute entry points       */
+                           /* answer MGN_E_UNSUPPORTED                                                                                    */
 } mgn_config;
 
 typedef enum { MGN_LN_VAR_EPS = 0, MGN_LN_STD_EPS = 1 } mgn_ln_mode;
+typedef enum { MGN_LN_ROWS = 0, MGN_LN_ALL = 1 } mgn_ln_dims;
 
 #define MGN_MAX_EDGE_SETS 2
 

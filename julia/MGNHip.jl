@@ -48,6 +48,7 @@ struct MgnConfig            # mirrors `mgn_config` (include/mgn_hip.h), field fo
     n_edge_sets::Int32      # 1: the reference's single edge set (src/graph.jl:87-96)
     Fe2::Int32
     ln_mode::Int32          # 0: (x - mean) / sqrt(var + eps); 1: (x - mean) / (sqrt(var) + eps) -- see julia/spec_probe.jl
+    ln_dims::Int32          # 0: LayerNorm statistics per node / edge; 1: over the whole array (Lux LayerNorm(shape) at dims = Colon())
 end
 
 mutable struct MgnRolloutDesc   # mirrors `mgn_rollout_desc` (include/mgn_hip.h), field for field
@@ -113,12 +114,12 @@ end
 
 # `rank` / `nranks`: this process's partition of an edge-cut mesh (one process per GPU; see comm_init!).  The reference
 # itself is single-device (src/MeshGraphNets.jl:255-263).
-# `ln_mode`: what julia/spec_probe.jl reports for the installed GraphNetCore / Lux (0 unless it says otherwise).
+# `ln_mode`, `ln_dims`: what julia/spec_probe.jl reports for the installed GraphNetCore / Lux (0 unless it says otherwise).
 function GraphNetwork(quantities, dims, e_norm, n_norm, o_norm, outputs, mps, layer_size, hidden_layers, ps; device = -1,
-        rank = 0, nranks = 1, ln_mode = 0)
+        rank = 0, nranks = 1, ln_mode = 0, ln_dims = 0)
     v = ccall((:mgn_abi_version, LIB), Cint, ())
     v == ABI_VERSION || error("libmgn_hip.so has ABI version $v, this shim is written for $ABI_VERSION")
-    cfg = MgnConfig(quantities, dims + 1, outputs, layer_size, hidden_layers, mps, 0, rank, nranks, device, 1, 0, ln_mode)
+    cfg = MgnConfig(quantities, dims + 1, outputs, layer_size, hidden_layers, mps, 0, rank, nranks, device, 1, 0, ln_mode, ln_dims)
     h = Ref{Ptr{Cvoid}}(C_NULL)
     rc = ccall((:mgn_create, LIB), Cint, (Ref{MgnConfig}, Ref{Ptr{Cvoid}}), cfg, h)
     rc == 0 || error(unsafe_string(ccall((:mgn_last_error, LIB), Cstring, (Ptr{Cvoid},), C_NULL)))
@@ -188,9 +189,9 @@ written by `save!` below is picked up from `path`; the normalisers are the ones 
 on every start, online ones re-accumulate during the first `norm_steps` steps as in a fresh run).
 """
 function load(quantities, dims, e_norms, n_norms, o_norms, outputs, mps, layer_size, hidden_layers, opt, device, path;
-        hip_device = -1, ln_mode = 0)
+        hip_device = -1, ln_mode = 0, ln_dims = 0)
     mgn = GraphNetwork(quantities, dims, e_norms, n_norms, o_norms, outputs, mps, layer_size, hidden_layers, nothing;
-        device = hip_device, ln_mode = ln_mode)
+        device = hip_device, ln_mode = ln_mode, ln_dims = ln_dims)
     df_train, df_valid = LossLog(), LossLog()
     pfile = joinpath(path, CKPT_PARAMS)
     if isfile(pfile)

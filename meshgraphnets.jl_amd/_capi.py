@@ -22,7 +22,7 @@ MGN_COMM_RCCL, MGN_COMM_HOST = 0, 1
 
 class MgnConfig(C.Structure):
     _fields_ = [(n, C.c_int32) for n in
-                ("Fn", "Fe", "O", "L", "hidden_layers", "mps", "dtype", "rank", "nranks", "device", "n_edge_sets", "Fe2", "ln_mode")]
+                ("Fn", "Fe", "O", "L", "hidden_layers", "mps", "dtype", "rank", "nranks", "device", "n_edge_sets", "Fe2", "ln_mode", "ln_dims")]
 
 
 class MgnRolloutDesc(C.Structure):

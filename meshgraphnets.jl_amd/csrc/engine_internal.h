@@ -187,6 +187,9 @@ void pack_tab(float* dst, const float* vec, int L, int stride = 1);
 // mgn_train.cpp: drop training-side state that depends on the parameters (what & 1) or the graph (what & 2); free it all
 void train_invalidate(mgn_engine* h, int what);
 void train_free(mgn_engine* h);
+// mgn_config.ln_dims = MGN_LN_ALL (whole-array LayerNorm): the unfused forward (mgn_train.cpp)
+int lnall_forward(mgn_engine* h, const float* nf, const float* ef, float* out);
+int lnall_processor_steps(mgn_engine* h, float* v, float* e, int32_t nsteps);
 
 #define HIPCHK(h, expr)                                                                              \
     do {                                                                                             \

@@ -55,6 +55,11 @@ bool cfg_ok(const mgn_config* c, std::string& why) {
     if (c->n_edge_sets < 0 || c->n_edge_sets > MAX_EDGE_SETS) { why = "n_edge_sets must be 0, 1 or 2"; return false; }
     if (c->n_edge_sets == 2 && c->Fe2 < 1) { why = "Fe2 must be >= 1 with two edge sets"; return false; }
     if (c->ln_mode != MGN_LN_VAR_EPS && c->ln_mode != MGN_LN_STD_EPS) { why = "ln_mode must be MGN_LN_VAR_EPS or MGN_LN_STD_EPS"; return false; }
+    if (c->ln_dims != MGN_LN_ROWS && c->ln_dims != MGN_LN_ALL) { why = "ln_dims must be MGN_LN_ROWS or MGN_LN_ALL"; return false; }
+    if (c->ln_dims == MGN_LN_ALL && (c->dtype != MGN_F32 || c->nranks != 1 || c->n_edge_sets > 1)) {
+        why = "ln_dims = MGN_LN_ALL (whole-array LayerNorm) runs in fp32 on one partition with one edge set";
+        return false;
+    }
     return true;
 }
 
@@ -198,6 +203,10 @@ namespace mgn {
 int need(mgn_engine* h, bool params, bool graph) {
     if (!h) return MGN_E_ARG;
     if (h->host_only) return fail(h, MGN_E_HIP, "host-only handle (MGN_DEVICE_NONE): no compute path; create the handle on a HIP device");
+    // whole-array LayerNorm couples every row of an MLP's output: the fused kernels behind the other compute entry points cannot
+    // compute it (mgn_forward and mgn_processor_steps branch off to the unfused driver before they get here)
+    if (params && graph && h->cfg.ln_dims == MGN_LN_ALL)
+        return fail(h, MGN_E_UNSUPPORTED, "ln_dims = MGN_LN_ALL (whole-array LayerNorm) is served by mgn_forward and mgn_processor_steps only");
     if (params && !h->have_params) return fail(h, MGN_E_STATE, "mgn_set_params has not been called");
     if (graph && !h->have_graph) return fail(h, MGN_E_STATE, "mgn_set_graph has not been called");
     return MGN_OK;
@@ -875,7 +884,8 @@ static int rebuild_graph(mgn_handle* h, int32_t N, const EdgeList* sets, const f
     train_invalidate(h, 2);
     if (!h->host_only) { (void)hipStreamSynchronize(h->stream); drop_graph(h); }
     const std::string why = build_local_graph(N, h->nsets, sets, mesh_pos, pos_dim, keep_owner ? h->g.owner.data() : nullptr,
-                                              h->cfg.rank, h->cfg.nranks, h->g, g_renumber);
+                                              h->cfg.rank, h->cfg.nranks, h->g,
+                                              h->nsets == 1 ? g_renumber : 0);   // (world-edge sets are searched / installed in global ids)
     if (!why.empty()) return fail(h, MGN_E_ARG, "%s: %s", who, why.c_str());
     const LocalGraph& g = h->g;
     for (int q = 0; q < h->nsets; ++q) h->es[q].ntiles_e = (int32_t)((g.set[q].e_local + TILE - 1) / TILE);
@@ -1046,10 +1056,11 @@ static int upload_inputs(mgn_handle* h, const float* a, int wa, const float* b, 
     const LocalGraph& g = h->g;
     h->in_wa = wa;
     h->in_wb = wb;
-    if (h->cfg.nranks > 1) {
+    if (h->cfg.nranks > 1 || g.renumbered) {
         // a partition needs 1 / nranks of the inputs: gather the owned node rows and the local edge rows on the host and
         // upload those (M-1M on 8 GPUs: 13 MB instead of 108 MB per rank and forward); the encoders then read them in
-        // local order (null gid)
+        // local order (null gid).  A renumbered single partition (graph_host.h) goes the same way: everything on the device,
+        // the state of a right-hand side included, is in the engine's node order
         h->in_local = true;
         const EdgeTopo& t = g.set[0];
         const int Fe = h->cfg.Fe;
@@ -1328,7 +1339,7 @@ static int need_comm(mgn_handle* h, const char* who);
 static int upload_state(mgn_handle* h, const float* x) {
     const LocalGraph& g = h->g;
     const int O = h->cfg.O;
-    if (h->cfg.nranks == 1) {
+    if (h->cfg.nranks == 1 && !g.renumbered) {
         HIPCHK(h, hipMemcpyAsync(h->d_nfA.p, x, (size_t)g.N * O * 4, hipMemcpyHostToDevice, h->stream));
         return MGN_OK;
     }
@@ -1350,6 +1361,7 @@ static int run_processor(mgn_handle* h, int nsteps) {
 }
 
 int mgn_forward(mgn_handle* h, const float* nf, const float* ef, float* out) try {
+    if (h && !h->host_only && h->cfg.ln_dims == MGN_LN_ALL) return lnall_forward(h, nf, ef, out);
     if (int rc = need(h, true, true)) return rc;
     if (h->cfg.nranks != 1) return forward_partitioned(h, nf, ef, out);
     if (int rc = need_set_features(h)) return rc;
@@ -1599,6 +1611,7 @@ int mgn_rollout(mgn_handle* h, mgn_rollout_desc* d) try {
     R.f64 = f64;
     R.sdt = SDT;
     auto tt = [&](double v) { return R.tt(v); };
+    const bool loc = part || g.renumbered;            // the state lives in the engine's node order (owned rows): gathered in, scattered out
     const int32_t nloc = part ? g.n_own : g.N;        // rows of the state this handle integrates
     R.n = (int64_t)nloc * c.O;
     R.n_global = (int64_t)g.N * c.O;
@@ -1623,7 +1636,7 @@ int mgn_rollout(mgn_handle* h, mgn_rollout_desc* d) try {
     R.mask = d->inflow_mask ? (uint8_t*)(base + o_mask) : nullptr;
     R.partial = (double*)(base + o_part);
 
-    if (!part) {
+    if (!loc) {
         HIPCHK(h, hipMemcpyAsync(R.u, d->x0, nb, hipMemcpyHostToDevice, h->stream));
         if (R.frames) HIPCHK(h, hipMemcpyAsync(R.frames, d->inflow_data, fb, hipMemcpyHostToDevice, h->stream));
         if (R.mask) HIPCHK(h, hipMemcpyAsync(R.mask, d->inflow_mask, (size_t)g.N, hipMemcpyHostToDevice, h->stream));
@@ -1748,6 +1761,13 @@ int mgn_rollout(mgn_handle* h, mgn_rollout_desc* d) try {
     if (part) {     // every rank returns the complete solution
         for (int i = 0; i < d->n_saves; ++i)
             if (int rc = gather_rows_global(h, R.saves + (size_t)i * R.n, c.O, d->out + (size_t)i * g.N * c.O)) return rc;
+    } else if (loc) {   // one partition in the engine's own node order: back to the caller's
+        std::vector<float> sv((size_t)d->n_saves * R.n);
+        HIPCHK(h, hipMemcpyAsync(sv.data(), R.saves, sb, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        for (int i = 0; i < d->n_saves; ++i)
+            for (int32_t j = 0; j < g.n_own; ++j)
+                memcpy(d->out + ((size_t)i * g.N + (size_t)g.own_gid[j]) * c.O, sv.data() + ((size_t)i * g.n_own + j) * c.O, (size_t)c.O * 4);
     } else {
         HIPCHK(h, hipMemcpyAsync(d->out, R.saves, sb, hipMemcpyDeviceToHost, h->stream));
     }
@@ -2073,6 +2093,7 @@ int mgn_processor_steps_dev(mgn_handle* h, int32_t nsteps) try {
 } MGN_CATCH(h)
 
 int mgn_processor_steps(mgn_handle* h, float* v, float* e, int32_t nsteps) try {
+    if (h && !h->host_only && h->cfg.ln_dims == MGN_LN_ALL) return lnall_processor_steps(h, v, e, nsteps);
     if (int rc = need(h, true, true)) return rc;
     if (h->cfg.nranks != 1) return fail(h, MGN_E_STATE, "mgn_processor_steps drives one partition");
     if (int rc = mgn_latents_import(h, v, e)) return rc;
@@ -2178,9 +2199,10 @@ int mgn_set_static_mesh(mgn_handle* h, const int32_t* node_type, int32_t type_mi
     HIPCHK(h, h->gpos.ensure((size_t)g.N * pos_dim * 4));
     HIPCHK(h, hipMemcpyAsync(h->gtype.p, node_type, (size_t)g.N * 4, hipMemcpyDefault, h->stream));
     HIPCHK(h, hipMemcpyAsync(h->gpos.p, mesh_pos, (size_t)g.N * pos_dim * 4, hipMemcpyDefault, h->stream));
-    // one partition: owned nodes are numbered 0 .. N-1 in global order (no boundary block), local ids are global ids
-    HIPCHK(h, launch_one_hot(h->gtype.as<int32_t>(), nullptr, g.n_own, type_min, depth, h->d_nfB.as<float>(), h->stream));
-    HIPCHK(h, launch_edge_features_local(h->gpos.as<float>(), pos_dim, h->es[0].d_snd.as<int32_t>(), h->es[0].d_rcv.as<int32_t>(), nullptr,
+    // one partition: no boundary block; local ids are global ids unless mgn_set_graph renumbered the mesh (then through own_gid)
+    const int32_t* l2g = g.renumbered ? h->d_own_gid.as<int32_t>() : nullptr;
+    HIPCHK(h, launch_one_hot(h->gtype.as<int32_t>(), l2g, g.n_own, type_min, depth, h->d_nfB.as<float>(), h->stream));
+    HIPCHK(h, launch_edge_features_local(h->gpos.as<float>(), pos_dim, h->es[0].d_snd.as<int32_t>(), h->es[0].d_rcv.as<int32_t>(), l2g,
                                          g.set[0].e_local, h->es[0].d_ef.as<float>(), h->stream));
     h->have_mask = val_mask != nullptr;
     if (val_mask) {

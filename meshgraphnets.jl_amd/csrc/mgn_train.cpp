@@ -52,6 +52,9 @@ struct TrainState {
     std::vector<TrainMlp> m_pe[MAX_EDGE_SETS], m_pn;
     DevBuf arena, idx, grads, target, mask, loss;
     std::vector<int32_t> g2l, mask_host;       // renumbered graph: caller's node id -> engine row; the mapped mask of the call
+    // whole-array LayerNorm mode (lnall_*): its own small arena (no kept activations), the edge gids as int32
+    DevBuf la, la_idx;
+    bool la_ready = false;
     size_t arena_floats = 0;
     // arena offsets (floats)
     size_t nf_raw, nf_pad, ef_raw[MAX_EDGE_SETS], ef_pad[MAX_EDGE_SETS], V0, Enew;
@@ -91,7 +94,7 @@ struct TrainState {
 void train_invalidate(mgn_engine* h, int what) {
     if (!h || !h->train) return;
     if (what & 1) h->train->packed = false;
-    if (what & 2) h->train->graph_ready = false;
+    if (what & 2) { h->train->graph_ready = false; h->train->la_ready = false; }
 }
 
 void train_free(mgn_engine* h) {
@@ -838,6 +841,209 @@ extern "C" int mgn_ode_vjp(mgn_handle* h, const float* x, const float* node_type
     J.dxdt = dxdt; J.xbar = xbar; J.grads = grads;
     return train_run(h, J);
 } MGN_CATCH(h)
+
+// =====================================================================================================================================
+// mgn_config.ln_dims = MGN_LN_ALL: LayerNorm statistics over the whole (rows x L) output of an MLP -- what Lux 0.5's LayerNorm(shape)
+// computes when GraphNetCore leaves it at dims = Colon() (reference Project.toml:15,40; julia/spec_probe.jl tells).  Every LayerNorm
+// then couples all nodes / all edges, so nothing of it can be fused into a tile kernel: per MLP one launch of the training-forward
+// kernel with its own LayerNorm off (train.hip: k_mlp_fwd, weights in training order), one grid-wide statistics pass (double, fixed
+// order), one apply pass (+ residual).  Correct first: fp32-MFMA kernels, un-factored first edge layer, no kept activations.
+// Serves mgn_forward (the model call, reference src/solve.jl:200) and mgn_processor_steps.
+// =====================================================================================================================================
+namespace {
+
+struct LnAll {
+    mgn_engine* h;
+    TrainState& T;
+    hipStream_t st;
+    float* A;
+    const float* Wt;
+    int L;
+    int64_t N, E;
+    int32_t nt_n, nt_e;
+    const int32_t *snd, *rcv, *rowptr, *egid;
+    size_t V, Ecur, Y, Hb, agg, stats, part, nf_raw, nf_pad, ef_raw, ef_pad, tmp;
+    float eps_in, eps_out;
+
+    // Y <- MLP(x) without LayerNorm / residual (launch units chained through Hb)
+    hipError_t mlp(const TrainMlp& m, int64_t rows, int32_t ntiles, const float* x0, const int32_t* i0, const float* x1, const int32_t* i1,
+                   const float* x2, float* yout) {
+        for (int bi = 0; bi < m.nblk; ++bi) {
+            const TrainBlock& b = m.b[bi];
+            TrainFwdArgs a{};
+            a.rows = rows; a.ntiles = ntiles;
+            int nin = b.nin;
+            if (bi == 0) {
+                a.X[0] = x0; a.xidx[0] = i0; a.X[1] = x1; a.xidx[1] = i1; a.X[2] = x2;
+                for (int j = 0; j < b.nin; ++j) a.W1[j] = Wt + b.W1[j];
+            } else {
+                a.X[0] = A + Hb;
+                a.W1[0] = Wt + b.W1[0];
+                nin = 1;
+            }
+            a.W2 = Wt + b.W2; a.W3 = Wt + b.W3; a.tabs = Wt + b.tabs;
+            a.ln = 0;
+            a.OUT = bi == m.nblk - 1 ? yout : A + Hb;
+            if (hipError_t e = launch_mlp_fwd(L, nin, a, st)) return e;
+        }
+        return hipSuccess;
+    }
+    // LayerNorm over all rows x L values of y with the MLP's gamma / beta: lnout = LN(y), out = resid + LN(y)
+    hipError_t ln(const TrainMlp& m, const float* y, int64_t rows, const float* resid, float* out, float* lnout) {
+        const TrainBlock& b = m.b[m.nblk - 1];
+        const int64_t n = rows * L;
+        if (n <= 0) return hipSuccess;
+        if (hipError_t e = launch_array_stats(y, n, reinterpret_cast<double*>(A + part), eps_in, eps_out, A + stats, st)) return e;
+        return launch_ln_all_apply(y, A + stats, Wt + b.tabs + (size_t)T_GAMMA * L, Wt + b.tabs + (size_t)T_BETA * L, resid, out, lnout, n, L, st);
+    }
+    // one processor step on V / Ecur (engine order, row-major [rows][L])
+    int step(int k) {
+        float *v = A + V, *e = A + Ecur, *y = A + Y;
+        if (E > 0) {
+            HIPCHK(h, mlp(T.m_pe[0][k], E, nt_e, v, snd, v, rcv, e, y));
+            HIPCHK(h, ln(T.m_pe[0][k], y, E, e, e, y));                      // y <- e' = LN(MLP_e), e <- e + e'
+        }
+        HIPCHK(h, launch_segment_sum(L, y, rowptr, nullptr, nullptr, A + agg, (int32_t)N, st));
+        HIPCHK(h, mlp(T.m_pn[k], N, nt_n, v, nullptr, A + agg, nullptr, nullptr, y));
+        HIPCHK(h, ln(T.m_pn[k], y, N, v, v, nullptr));                       // v <- v + LN(MLP_v([v; agg]))
+        return MGN_OK;
+    }
+};
+
+int lnall_prepare(mgn_engine* h, const char* who, bool with_encoders) {
+    if (!h) return MGN_E_ARG;
+    if (h->host_only) return fail(h, MGN_E_HIP, "host-only handle (MGN_DEVICE_NONE): no compute path; create the handle on a HIP device");
+    if (!h->have_params) return fail(h, MGN_E_STATE, "mgn_set_params has not been called");
+    if (!h->have_graph) return fail(h, MGN_E_STATE, "mgn_set_graph has not been called");
+    if (!h->train) h->train = new (std::nothrow) TrainState();
+    if (!h->train) return fail(h, MGN_E_OOM, "host allocation failed");
+    TrainState& T = *h->train;
+    if (!T.packed)
+        if (int rc = pack_training_weights(h)) return rc;
+    (void)who; (void)with_encoders;
+    return MGN_OK;
+}
+
+LnAll lnall_layout(mgn_engine* h, bool with_inputs, size_t& floats) {
+    TrainState& T = *h->train;
+    const LocalGraph& g = h->g;
+    const mgn_config& c = h->cfg;
+    LnAll X{h, T, h->stream, nullptr, T.w.as<float>(), c.L, g.n_own, g.set[0].e_local, 0, 0, nullptr, nullptr, nullptr, nullptr};
+    X.nt_n = (int32_t)((X.N + TILE - 1) / TILE);
+    X.nt_e = (int32_t)((X.E + TILE - 1) / TILE);
+    const size_t NL = (size_t)(X.N > 0 ? X.N : 1) * c.L, EL = (size_t)(X.E > 0 ? X.E : 1) * c.L, ML = NL > EL ? NL : EL;
+    size_t off = 0;
+    auto take = [&](size_t n) { const size_t o = off; off += (n + 63) / 64 * 64; return o; };
+    X.V = take(NL); X.Ecur = take(EL); X.Y = take(ML); X.Hb = T.nblk > 1 ? take(ML) : 0; X.agg = take(NL);
+    X.stats = take(64); X.part = take((size_t)4 * array_stats_blocks());
+    X.tmp = take(ML);                                   // caller order <-> engine order staging
+    X.nf_raw = X.nf_pad = X.ef_raw = X.ef_pad = 0;
+    if (with_inputs) {
+        X.nf_raw = take((size_t)X.N * c.Fn); X.nf_pad = take(NL);
+        X.ef_raw = take((size_t)(X.E > 0 ? X.E : 1) * c.Fe); X.ef_pad = take(EL);
+    }
+    X.eps_in = c.ln_mode == MGN_LN_STD_EPS ? 0.f : 1e-5f;
+    X.eps_out = c.ln_mode == MGN_LN_STD_EPS ? 1e-5f : 0.f;
+    floats = off;
+    return X;
+}
+
+int lnall_bind(mgn_engine* h, LnAll& X, size_t floats) {
+    TrainState& T = *h->train;
+    const LocalGraph& g = h->g;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, T.la.ensure(floats * 4));
+    if (!T.la_ready) {
+        std::vector<int32_t> eg((size_t)(X.E > 0 ? X.E : 1), 0);
+        for (int64_t i = 0; i < X.E; ++i) eg[(size_t)i] = (int32_t)g.set[0].edge_gid[(size_t)i];
+        HIPCHK(h, T.la_idx.ensure(eg.size() * 4));
+        HIPCHK(h, hipMemcpy(T.la_idx.p, eg.data(), eg.size() * 4, hipMemcpyHostToDevice));
+        T.la_ready = true;
+    }
+    X.A = T.la.as<float>();
+    X.snd = h->es[0].d_snd.as<int32_t>();
+    X.rcv = h->es[0].d_rcv.as<int32_t>();
+    X.rowptr = h->es[0].d_rowptr.as<int32_t>();
+    X.egid = T.la_idx.as<int32_t>();
+    return MGN_OK;
+}
+
+}  // namespace
+
+namespace mgn {
+
+int lnall_forward(mgn_engine* h, const float* nf, const float* ef, float* out) {
+    if (int rc = lnall_prepare(h, "mgn_forward", true)) return rc;
+    const mgn_config& c = h->cfg;
+    const LocalGraph& g = h->g;
+    if (!nf || !out || (!ef && g.set[0].E > 0)) return fail(h, MGN_E_ARG, "mgn_forward: null argument");
+    size_t floats = 0;
+    LnAll X = lnall_layout(h, true, floats);
+    if (int rc = lnall_bind(h, X, floats)) return rc;
+    TrainState& T = X.T;
+    float* A = X.A;
+    hipStream_t st = X.st;
+    const int L = c.L;
+    const int32_t* ngid = h->d_own_gid.as<int32_t>();
+    // node features: caller's rows -> engine rows, padded to L; edge features stay in the caller's order and are gathered by edge id
+    HIPCHK(h, hipMemcpyAsync(A + X.tmp, nf, (size_t)X.N * c.Fn * 4, hipMemcpyDefault, st));
+    HIPCHK(h, launch_permute_rows(A + X.nf_raw, A + X.tmp, ngid, X.N, c.Fn, false, st));
+    HIPCHK(h, launch_affine_pad(A + X.nf_raw, c.Fn, nullptr, 0, nullptr, nullptr, A + X.nf_pad, L, X.N, st));
+    if (X.E > 0) {
+        HIPCHK(h, hipMemcpyAsync(A + X.ef_raw, ef, (size_t)g.set[0].E * c.Fe * 4, hipMemcpyDefault, st));
+        HIPCHK(h, launch_affine_pad(A + X.ef_raw, c.Fe, nullptr, 0, nullptr, nullptr, A + X.ef_pad, L, g.set[0].E, st));
+    }
+    // encoders
+    HIPCHK(h, X.mlp(T.m_en, X.N, X.nt_n, A + X.nf_pad, nullptr, nullptr, nullptr, nullptr, A + X.Y));
+    HIPCHK(h, X.ln(T.m_en, A + X.Y, X.N, nullptr, A + X.V, nullptr));
+    if (X.E > 0) {
+        HIPCHK(h, X.mlp(T.m_ee[0], X.E, X.nt_e, A + X.ef_pad, X.egid, nullptr, nullptr, nullptr, A + X.Y));
+        HIPCHK(h, X.ln(T.m_ee[0], A + X.Y, X.E, nullptr, A + X.Ecur, nullptr));
+    }
+    for (int k = 0; k < c.mps; ++k)
+        if (int rc = X.step(k)) return rc;
+    // decoder (no LayerNorm): the first O columns of its output, back in the caller's row order
+    HIPCHK(h, X.mlp(T.m_de, X.N, X.nt_n, A + X.V, nullptr, nullptr, nullptr, nullptr, A + X.Y));
+    HIPCHK(h, launch_extract_cols(A + X.Y, L, c.O, nullptr, A + X.agg, X.N, st));
+    HIPCHK(h, launch_permute_rows(A + X.tmp, A + X.agg, ngid, X.N, c.O, true, st));
+    HIPCHK(h, hipMemcpyAsync(out, A + X.tmp, (size_t)X.N * c.O * 4, hipMemcpyDefault, st));
+    HIPCHK(h, hipStreamSynchronize(st));
+    return MGN_OK;
+}
+
+int lnall_processor_steps(mgn_engine* h, float* v, float* e, int32_t nsteps) {
+    if (int rc = lnall_prepare(h, "mgn_processor_steps", false)) return rc;
+    const mgn_config& c = h->cfg;
+    const LocalGraph& g = h->g;
+    if (!v || (!e && g.set[0].E > 0)) return fail(h, MGN_E_ARG, "mgn_processor_steps: null argument");
+    if (nsteps < 0 || nsteps > c.mps) return fail(h, MGN_E_ARG, "mgn_processor_steps: nsteps out of range");
+    size_t floats = 0;
+    LnAll X = lnall_layout(h, false, floats);
+    if (int rc = lnall_bind(h, X, floats)) return rc;
+    float* A = X.A;
+    hipStream_t st = X.st;
+    const int L = c.L;
+    const int32_t* ngid = h->d_own_gid.as<int32_t>();
+    HIPCHK(h, hipMemcpyAsync(A + X.tmp, v, (size_t)X.N * L * 4, hipMemcpyDefault, st));
+    HIPCHK(h, launch_permute_rows(A + X.V, A + X.tmp, ngid, X.N, L, false, st));
+    if (X.E > 0) {
+        HIPCHK(h, hipMemcpyAsync(A + X.tmp, e, (size_t)X.E * L * 4, hipMemcpyDefault, st));
+        HIPCHK(h, launch_permute_rows(A + X.Ecur, A + X.tmp, X.egid, X.E, L, false, st));
+    }
+    for (int k = 0; k < nsteps; ++k)
+        if (int rc = X.step(k)) return rc;
+    HIPCHK(h, launch_permute_rows(A + X.tmp, A + X.V, ngid, X.N, L, true, st));
+    HIPCHK(h, hipMemcpyAsync(v, A + X.tmp, (size_t)X.N * L * 4, hipMemcpyDefault, st));
+    if (X.E > 0) {
+        HIPCHK(h, hipStreamSynchronize(st));
+        HIPCHK(h, launch_permute_rows(A + X.tmp, A + X.Ecur, X.egid, X.E, L, true, st));
+        HIPCHK(h, hipMemcpyAsync(e, A + X.tmp, (size_t)X.E * L * 4, hipMemcpyDefault, st));
+    }
+    HIPCHK(h, hipStreamSynchronize(st));
+    return MGN_OK;
+}
+
+}  // namespace mgn
 
 // Pullback of mgn_forward == the model call `mgn.model(graph, ps, st)` at reference src/solve.jl:200 (what a ChainRulesCore.rrule of
 // the Julia shim's model function returns to Zygote inside the pullback of ode_func_train, src/strategies.jl:183-195): given the

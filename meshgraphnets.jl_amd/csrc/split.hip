@@ -271,10 +271,15 @@ DEVINL RingFrag ring_first(const u32x4* hi, const u32x4* ring, int lane) {
 // (NRFS, rf_next): 3.53 -> 3.46 ms.  What a request costs in the chain is its ISSUE: the eight waves are in lock-step, their
 // requests reach the CU's one memory pipeline together, and a wave whose request is not accepted issues no MFMA either (stamps:
 // every request adds ~500 cycles to its layer whether it hits L2 or not).
-template <int W, int LYR, bool RELU, int RFS = 0, int NRFS = 0, int NWV = 8, bool WRAP = false>
+// QP (layer 1, MGN_RING_QPSTREAM): the gathered rows P[s] and Q[r] that complete the layer stream THROUGH it instead of waiting in 64 + 64
+// registers: the accumulator starts from zero, every 16-byte piece is requested eight (s, t) steps before it is added, and it is added
+// into accumulator t + 2 while the MFMAs of step (s, t) run on accumulator t (written two steps ago, read again in two).  Per
+// accumulator: its four P pieces are added at k-steps 2 .. 5, its four Q pieces two by two at k-steps 6 and 7.  Nothing of the
+// turnover is then requested behind the tile's e stores, and no register waits for a row.
+template <int W, int LYR, bool RELU, int RFS = 0, int NRFS = 0, int NWV = 8, bool WRAP = false, bool QP = false>
 DEVINL void sp_layer_ring(f32x16 (&acc)[4], f32x16 (&in)[4], const u32x4* hi, const u32x4* hi_next, u32x4* ring, const RingSrc& src,
                           RingFrag& nx, int lane, int tid, const f32x4* rf = nullptr, f32x4* side = nullptr,
-                          const f32x4* rf_next = nullptr) {
+                          const f32x4* rf_next = nullptr, const f32x4* qp_p = nullptr, const f32x4* qp_q = nullptr) {
 #ifndef MGN_RING_ROT
 #define MGN_RING_ROT 2
 #endif
@@ -307,6 +312,7 @@ DEVINL void sp_layer_ring(f32x16 (&acc)[4], f32x16 (&in)[4], const u32x4* hi, co
     u32x4 ld_m[LPT], ld_l[LPT];                  // this thread's share of window gw + 2 on its way to LDS
     unsigned voff = (unsigned)tid * 16u;
     asm volatile("" : "+v"(voff));
+    f32x4 qp[QP ? 4 : 1][QP ? 8 : 1];            // QP: the pieces in flight, per accumulator (SSA values: live from request to add)
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
@@ -316,6 +322,25 @@ DEVINL void sp_layer_ring(f32x16 (&acc)[4], f32x16 (&in)[4], const u32x4* hi, co
             const int it = 4 * s + t;
             const int gw = WPL * LYR + it / W;                        // global window of this step
             const u32x4 a1 = nx.h, a2 = nx.m, a3 = nx.l;
+            if constexpr (QP) {
+                constexpr int STR = STRIDE_PROW;
+                const int tt = (t + 2) & 3;                            // the accumulator these pieces belong to
+                if (s < 4) {
+                    qp[tt][s] = qp_p[(4 * tt + s) * STR];
+                } else if (s < 6) {
+                    qp[tt][4 + 2 * (s - 4)] = qp_q[(4 * tt + 2 * (s - 4)) * STR];
+                    qp[tt][5 + 2 * (s - 4)] = qp_q[(4 * tt + 2 * (s - 4) + 1) * STR];
+                }
+                if (s >= 2 && s < 6) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) acc[tt][4 * (s - 2) + i] += qp[tt][s - 2][i];
+                } else if (s >= 6) {
+#pragma unroll
+                    for (int u = 0; u < 2; ++u)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) acc[tt][4 * (2 * (s - 6) + u) + i] += qp[tt][4 + 2 * (s - 6) + u][i];
+                }
+            }
             if (it % W == 0) {                                         // request window gw + 2
                 const int g2 = (gw + 2) % NW, l2 = g2 / WPL, w2 = g2 % WPL;
                 // (uniform base + 32-bit lane offset: the scalar-base form of global_load; as per-thread 64-bit pointers
@@ -524,6 +549,9 @@ __global__ __launch_bounds__(NWV * 64, NWV / 4) void k_edge_ring(const EdgeArgs 
 #ifndef MGN_RING_L3_WRAP
 #define MGN_RING_L3_WRAP 0       // 1: layer 3's refill without a side buffer (sp_layer_ring WRAP)
 #endif
+#ifndef MGN_RING_QPSTREAM
+#define MGN_RING_QPSTREAM 0      // 1: P[s] / Q[r] rows stream through layer 1 (sp_layer_ring QP): no Q gather / side buffer in the turnover
+#endif
 #ifndef MGN_RING_ENEXT_TAIL
 #define MGN_RING_ENEXT_TAIL 0    // where the last two k-steps of the next tile's e are requested: 0 = at the start of the epilogue (ahead of the e stores), 1 = at its end
 #endif
@@ -549,15 +577,19 @@ __global__ __launch_bounds__(NWV * 64, NWV / 4) void k_edge_ring(const EdgeArgs 
     EdgeIdx ix = load_edge_idx_nb(a.snd, a.rcv, a.E, clamp(tw.tile), lane0 & 31);
     {
         const int h0 = lane0 >> 5;
+#if !MGN_RING_QPSTREAM
         load_frag<NT>(acc, prow_ptr(a.Q, ix.r >= 0 ? ix.r : 0, L, h0), STRIDE_PROW);
+#endif
         load_frag<NT>(y, tile_ptr(a.Elat, clamp(tw.tile), L, lane0), STRIDE_TILE);
     }
     f32x4 side[4];               // refill side buffer (sp_layer_ring): the first two k-steps of the P rows / of the e tile
+#if !MGN_RING_QPSTREAM
     {
         const f32x4* p0 = prow_ptr(a.P, ix.s, L, lane0 >> 5);
 #pragma unroll
         for (int m = 0; m < 4; ++m) side[m] = p0[m * STRIDE_PROW];
     }
+#endif
     int stamp_tile = 0;
     (void)stamp_tile;
     for (int j = 0; j < iters; ++j, ++stamp_tile) {
@@ -581,9 +613,15 @@ __global__ __launch_bounds__(NWV * 64, NWV / 4) void k_edge_ring(const EdgeArgs 
         __builtin_amdgcn_s_setprio(0);
         RingFrag nx = ring_first<W, 0>(l1h, ring, lane);
         // layer 1 (edge part): y = e tile in, P[s] out (acc entered with Q[r], which carries b1)
+#if MGN_RING_QPSTREAM
+        zero_frag<NT>(acc);
+        sp_layer_ring<W, 0, false, 0, 0, NWV, false, true>(acc, y, l1h, l2h, ring, src, nx, lane, tid, nullptr, nullptr, nullptr,
+                                                          prow_ptr(a.P, ps_row, L, h), prow_ptr(a.Q, r, L, h));
+#else
         sp_layer_ring<W, 0, false, STRIDE_PROW, 0, NWV>(acc, y, l1h, l2h, ring, src, nx, lane, tid, prow_ptr(a.P, ps_row, L, h), side);
 #pragma unroll
         for (int t = 0; t < NT; ++t) acc[t] += y[t];
+#endif
         CST(1);
         tab_frag<NT>(y, tb + T_B2 * L, h);
         CST(2);
@@ -720,12 +758,14 @@ __global__ __launch_bounds__(NWV * 64, NWV / 4) void k_edge_ring(const EdgeArgs 
         EST(6);
         PHASE_FENCE();
         // turnover: the next tile's layer-1 accumulator starts from Q[r] (P[s] arrives during the layer)
-#if defined(MGN_WHATIF) && (MGN_WHATIF & 16)
+#if MGN_RING_QPSTREAM
+        // (nothing to request: the rows stream through layer 1)
+#elif defined(MGN_WHATIF) && (MGN_WHATIF & 16)
         load_frag<NT>(acc, prow_ptr(a.Q, lane & 31, L, h), STRIDE_PROW);
 #else
         load_frag<NT>(acc, prow_ptr(a.Q, ixn.r >= 0 ? ixn.r : 0, L, h), STRIDE_PROW);
 #endif
-#if MGN_RING_REFILL_AT_REQUEST != 0 && (MGN_RING_SIDE_EARLY & 2)
+#if MGN_RING_REFILL_AT_REQUEST != 0 && (MGN_RING_SIDE_EARLY & 2) && !MGN_RING_QPSTREAM
         {
             const f32x4* pn = prow_ptr(a.P, ixn.s, L, h);
 #pragma unroll

@@ -81,6 +81,12 @@ hipError_t launch_segment_sum2(int L, const float* srcA, const int32_t* rowptrA,
 // dst [rows][L] = [ (srcA | srcB)[rows][wa + wb] * scale + shift | 0 ]   (srcB may be null with wb = 0; scale null: identity)
 hipError_t launch_affine_pad(const float* srcA, int wa, const float* srcB, int wb, const float* scale, const float* shift, float* dst, int L,
                              int64_t rows, hipStream_t s);
+// whole-array LayerNorm (mgn_config.ln_dims = MGN_LN_ALL): stats = (mean, 1 / (sqrt(var + eps_in) + eps_out)) over the n values of x
+// (double accumulation, fixed order; partial: 2 * array_stats_blocks() doubles), then t = (y - mean) * rden * gamma + beta
+int array_stats_blocks();
+hipError_t launch_array_stats(const float* x, int64_t n, double* partial, float eps_in, float eps_out, float* stats, hipStream_t s);
+hipError_t launch_ln_all_apply(const float* y, const float* stats, const float* gamma, const float* beta, const float* resid, float* out,
+                               float* lnout, int64_t n, int L, hipStream_t s);
 // node rows between the caller's order and the engine's (a renumbered graph: graph_host.h): gather dst[i] = src[gid[i]], scatter dst[gid[i]] = src[i]
 hipError_t launch_permute_rows(float* dst, const float* src, const int32_t* gid, int64_t rows, int width, bool scatter, hipStream_t s);
 // seed of the RHS VJP (mgn_ode_vjp): G[n][o] = lambda[n][o] * val_mask[n] * os[o]; optionally dxdt = (Y * os + osh) .* val_mask

@@ -616,6 +616,47 @@ __global__ void k_permute_rows(float* __restrict__ dst, const float* __restrict_
     else dst[i] = src[g * width + f];
 }
 
+// ---- whole-array LayerNorm (mgn_config.ln_dims = MGN_LN_ALL): statistics over ALL rows x L values of an MLP's output, then apply ----
+// partial[b] = (sum, sum of squares) of block b's grid-strided share, in double, lanes and waves added in a fixed order
+__global__ void k_array_stats(const float* __restrict__ x, int64_t n, double* __restrict__ partial) {
+    __shared__ double sh[2][4];
+    double s = 0.0, q = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const double v = (double)x[i];
+        s += v;
+        q += v * v;
+    }
+    for (int o = 32; o > 0; o >>= 1) { s += __shfl_down(s, o, 64); q += __shfl_down(q, o, 64); }
+    if ((threadIdx.x & 63) == 0) { sh[0][threadIdx.x >> 6] = s; sh[1][threadIdx.x >> 6] = q; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        partial[2 * blockIdx.x] = sh[0][0] + sh[0][1] + sh[0][2] + sh[0][3];
+        partial[2 * blockIdx.x + 1] = sh[1][0] + sh[1][1] + sh[1][2] + sh[1][3];
+    }
+}
+// stats = (mean, 1 / (sqrt(var + eps_in) + eps_out)): biased variance over the n values, blocks added in order
+__global__ void k_array_stats_final(const double* __restrict__ partial, int nb, int64_t n, float eps_in, float eps_out, float* __restrict__ stats) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    double s = 0.0, q = 0.0;
+    for (int b = 0; b < nb; ++b) { s += partial[2 * b]; q += partial[2 * b + 1]; }
+    const double mean = n > 0 ? s / (double)n : 0.0;
+    double var = n > 0 ? q / (double)n - mean * mean : 0.0;
+    if (var < 0.0) var = 0.0;
+    stats[0] = (float)mean;
+    stats[1] = (float)(1.0 / (sqrt(var + (double)eps_in) + (double)eps_out));
+}
+// t = (y - mean) * rden * gamma[f] + beta[f];  lnout = t;  out = (resid ? resid : 0) + t   (out may alias resid, lnout may alias y)
+__global__ void k_ln_all_apply(const float* y, const float* __restrict__ stats, const float* __restrict__ gamma, const float* __restrict__ beta,
+                               const float* resid, float* out, float* lnout, int64_t n, int L) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int f = (int)(i % L);
+    const float t = (y[i] - stats[0]) * stats[1] * gamma[f] + beta[f];
+    const float r = resid ? resid[i] : 0.f;
+    if (lnout) lnout[i] = t;
+    if (out) out[i] = r + t;
+}
+
 // seed of the RHS VJP: dx/dt = (out * os + osh) .* val_mask  =>  G[n][o] = lambda[n][o] * val_mask[n] * os[o]
 __global__ void k_vjp_seed(const float* __restrict__ Y, int L, int O, const float* __restrict__ lambda, const float* __restrict__ vm,
                            const float* __restrict__ os, const float* __restrict__ osh, float* __restrict__ G, float* __restrict__ dxdt,
@@ -843,6 +884,22 @@ hipError_t launch_affine_pad(const float* srcA, int wa, const float* srcB, int w
     const int64_t tot = rows * L;
     if (tot <= 0) return hipSuccess;
     hipLaunchKernelGGL(k_affine_pad, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, srcA, wa, srcB, wb, scale, shift, dst, L, rows);
+    return hipGetLastError();
+}
+
+int array_stats_blocks() { return 1024; }
+
+hipError_t launch_array_stats(const float* x, int64_t n, double* partial, float eps_in, float eps_out, float* stats, hipStream_t s) {
+    const int nb = array_stats_blocks();
+    hipLaunchKernelGGL(k_array_stats, dim3(nb), dim3(256), 0, s, x, n, partial);
+    hipLaunchKernelGGL(k_array_stats_final, dim3(1), dim3(64), 0, s, partial, nb, n, eps_in, eps_out, stats);
+    return hipGetLastError();
+}
+
+hipError_t launch_ln_all_apply(const float* y, const float* stats, const float* gamma, const float* beta, const float* resid, float* out,
+                               float* lnout, int64_t n, int L, hipStream_t s) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_ln_all_apply, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, y, stats, gamma, beta, resid, out, lnout, n, L);
     return hipGetLastError();
 }
 

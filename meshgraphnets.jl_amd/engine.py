@@ -55,12 +55,12 @@ def _host_or_device(a, shape, writable=False):
 class Engine:
     """One engine handle == one mesh partition on one GPU (rank/nranks select the partition)."""
 
-    def __init__(self, Fn, Fe, O, L=128, hidden_layers=2, mps=15, rank=0, nranks=1, device=-1, dtype="f32", Fe2=None, ln_mode=0):
+    def __init__(self, Fn, Fe, O, L=128, hidden_layers=2, mps=15, rank=0, nranks=1, device=-1, dtype="f32", Fe2=None, ln_mode=0, ln_dims=0):
         """Fe2: input width of a second edge set (world edges, MGN-spec "per edge set"); None = the reference's one set.
         ln_mode: 0 = (x - mean) / sqrt(var + eps) (MGN-spec v1), 1 = (x - mean) / (sqrt(var) + eps) (spec_variant)."""
         self.lib = _capi.load()
         self.cfg = MgnConfig(Fn, Fe, O, L, hidden_layers, mps, {"f32": 0, "bf16": 1}[dtype], rank, nranks, device,
-                             2 if Fe2 else 1, Fe2 or 0, ln_mode)
+                             2 if Fe2 else 1, Fe2 or 0, ln_mode, {0: 0, 1: 1, "rows": 0, "all": 1}[ln_dims])
         self.E2 = 0
         self.h = C.c_void_p()
         rc = self.lib.mgn_create(C.byref(self.cfg), C.byref(self.h))

@@ -99,3 +99,62 @@ def test_training_entry_points_refuse_the_variant_and_bad_modes_are_rejected():
     assert "ln_mode" in str(ei.value)
     with pytest.raises(MgnError):
         engine_for(cfg, ln_mode=7)
+
+
+@pytest.fixture
+def whole_array_oracle():
+    orc.LN_DIMS = "all"
+    yield
+    orc.LN_DIMS = "row"
+
+
+def test_whole_array_layernorm_is_an_engine_mode(whole_array_oracle):
+    """mgn_config.ln_dims = MGN_LN_ALL: LayerNorm statistics over the whole (L x rows) output of every MLP -- what Lux 0.5's
+    LayerNorm(shape) computes when it is left at dims = Colon() (reference Project.toml:15,40; julia/spec_probe.jl reports it).  The
+    engine reproduces the GOLD-G `out_whole_array` fixture, follows the oracle's LN_DIMS = "all" on a 22 500-node mesh (forward of the
+    whole model and processor steps, hidden_layers 2 and 3, both ln_mode denominators), is really the other network, and refuses the
+    entry points whose fused kernels cannot compute it."""
+    g = np.load(os.path.join(GOLD, "gold_g_ln_variants.npz"))
+    cfg = cfg_dict(L=int(g["L"]), mps=int(g["mps"]))
+    ps = orc.init_params(9, 3, 2, cfg["L"], 2, cfg["mps"], seed=int(g["seed"]), ln_jitter=float(g["jitter"]))
+    eng = engine_for(cfg, ln_dims="all")
+    eng.set_params(ps)
+    eng.set_graph(g["senders"], g["receivers"], g["nf"].shape[0])
+    out = eng.forward(g["nf"], g["ef"])
+    assert rel_max(out, g["out_whole_array"]) <= TOL_15
+    assert rel_max(out, g["out_v1"]) > 20 * rel_max(out, g["out_whole_array"])
+    for call in (lambda: eng.ode_step(np.zeros((48, 2), np.float32), np.zeros((48, 7), np.float32), g["ef"]), lambda: eng.latents_randn(1) or eng.processor_steps_dev(1),
+                 lambda: eng.step(g["nf"], g["ef"], np.zeros((48, 2), np.float32), np.arange(4, dtype=np.int32))):
+        with pytest.raises(MgnError) as ei:
+            call()
+        assert ei.value.code == -5                                  # MGN_E_UNSUPPORTED
+    eng.close()
+    # a mesh of the size the persistent kernels serve in the default mode (scattered labels on top: the mode goes through own_gid too)
+    from util import scatter_labels
+    pos, s, r = synth.mesh_1m(1234, 150, 150)
+    pos, s, r, _ = scatter_labels(pos, s, r, 4)
+    N, E = pos.shape[0], s.size
+    rng = np.random.default_rng(2)
+    for hl, mode in ((2, 0), (3, 1)):
+        cfg = dict(Fn=9, Fe=3, O=2, L=128, hidden_layers=hl, mps=2)
+        ps = orc.init_params(9, 3, 2, 128, hl, 2, seed=77 + hl, ln_jitter=0.1)
+        nf, ef = rng.standard_normal((N, 9)).astype(np.float32), rng.standard_normal((E, 3)).astype(np.float32)
+        v, e = rng.standard_normal((N, 128)).astype(np.float32), rng.standard_normal((E, 128)).astype(np.float32)
+        orc.LN_MODE = mode
+        try:
+            ref_out = orc.forward(ps, cfg, nf, ef, s, r)
+            rv, re = orc.processor_steps(ps, cfg, v, e, s, r, 2)
+        finally:
+            orc.LN_MODE = 0
+        eng = mgn_amd_engine(cfg, ln_dims="all", ln_mode=mode)
+        eng.set_params(ps)
+        eng.set_graph(s, r, N)
+        assert rel_max(eng.forward(nf, ef), ref_out) <= TOL_15, (hl, mode)
+        v1, e1 = eng.processor_steps(v, e, 2)
+        assert rel_max(v1, rv) <= TOL_15 and rel_max(e1, re) <= TOL_15, (hl, mode)
+        eng.close()
+
+
+def mgn_amd_engine(cfg, **kw):
+    import mgn_amd
+    return mgn_amd.Engine(cfg["Fn"], cfg["Fe"], cfg["O"], cfg["L"], cfg["hidden_layers"], cfg["mps"], **kw)
