@@ -200,10 +200,26 @@ def comm_bootstrap(eng, rank, world, device_id):
     except Exception as ex:   # noqa: BLE001
         if world > 1 and "MASTER_PORT" not in os.environ:
             raise
+        # No store: nothing can be agreed on before the collective init (are the devices distinct? can every rank load librccl?),
+        # and ncclCommInitRank has no time-out -- so this branch takes the library's shared-memory transport (one node by
+        # construction: the id travels through a file in /tmp), under the same watchdog as the store path.
         path = f"/tmp/mgn_comm_{os.environ.get('MASTER_PORT', '0')}_{os.getppid()}_{os.environ.get('TORCHELASTIC_RUN_ID', 'x')}.id"
-        sys.stderr.write(f"[bench] store rendezvous failed ({ex!r}); file bootstrap {path}\n")
-        eng.comm_init_file(path, "rccl")
-        return None, "rccl"
+        sys.stderr.write(f"[bench] store rendezvous failed ({ex!r}); file bootstrap {path}, shared-memory transport\n")
+        limit = float(os.environ.get("MGN_COMM_TIMEOUT_S", "120"))
+
+        def give_up_file():
+            sys.stderr.write(f"[bench] rank {rank}: file bootstrap did not complete within {limit:.0f} s; giving up\n")
+            sys.stderr.flush()
+            os._exit(3)
+
+        dog = threading.Timer(limit + 10.0, give_up_file)
+        dog.daemon = True
+        dog.start()
+        try:
+            eng.comm_init_file(path, "host")
+        finally:
+            dog.cancel()
+        return None, "host (shared memory: no rendezvous store to agree on RCCL)"
     store.set(f"mgn_dev_{rank}", f"{socket.gethostname()}|{device_id}|{int(rccl_loadable())}".encode())
     devs = [bytes(store.get(f"mgn_dev_{q}")).decode().split("|") for q in range(world)]
     distinct = len({(d[0], d[1]) for d in devs}) == world
@@ -353,6 +369,17 @@ def main():
             lib.mgn_debug_fp32_split.argtypes = [ctypes.c_int]
             split_mode = lib.mgn_debug_fp32_split(0)            # query ...
             lib.mgn_debug_fp32_split(split_mode)                # ... and restore
+            # the roofline is priced by the kernel family the edge launches RAN on (kernels.hip: launch_edge_step decides by size: a
+            # small --nx or a small per-rank partition runs the cooperative / fp32-MFMA kernels whatever the global switch says)
+            lib.mgn_debug_last_edge_kernel.restype = ctypes.c_int
+            lib.mgn_debug_last_edge_kernel.argtypes = []
+            fam = lib.mgn_debug_last_edge_kernel()
+            FAMILY = {1: "k_edge_step<.., GEN> (general hidden_layers)", 2: "k_edge_coop16m (16-row tiles)", 3: "k_edge_coop (4-wave tiles)",
+                      4: "k_edge_step<4,0> (all-streaming)", 5: "k_edge_split2", 6: "k_edge_ring2", 7: "k_edge_ring<8>", 8: "k_edge_ring<4>",
+                      9: "k_edge_step<4,2>"}
+            ran_split = fam in (5, 6, 7, 8)
+            if not ran_split:
+                split_mode = 0
             comp = (1024.0 + 8.0) * e_loc + 3.0 * 512.0 * n_loc
             common = {"avg_launch_ms": t_edge * 1e3, "launches": prof["edge_step"]["count"],
                       "traffic_unit": "bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE); algorithmic = 1117 B/edge",
@@ -363,7 +390,7 @@ def main():
             if split_mode:
                 # fp32 storage, every L x L product as six exact bf16 products on v_mfma_f32_32x32x16_bf16, fp32 accumulation
                 # (csrc/split.hip).  The roofline is the bf16 dense peak with the flops the kernel EXECUTES: 6 x the fp32 count.
-                kname = "k_edge_ring" if split_mode == 1 else "k_edge_split2"
+                kname = {5: "k_edge_split2", 6: "k_edge_ring2", 7: "k_edge_ring", 8: "k_edge_ring"}[fam]
                 fl = SPLIT_PRODUCTS * flops_edge_kernel(e_loc)
                 ach = fl / t_edge / 1e12 if t_edge > 0 else 0.0
                 traffic, tsrc = committed_traffic([kname]) if (world == 1 and args.nx == 1000) else (None, None)
@@ -388,8 +415,8 @@ def main():
             else:
                 ach = flops_edge_kernel(e_loc) / t_edge / 1e12 if t_edge > 0 else 0.0
                 traffic, tsrc = committed_traffic(["k_edge_step<4, 2"]) if (world == 1 and args.nx == 1000) else (None, None)
-                roof = {"bound": "mfma", "kernel": "k_edge_step<4,2> (fused gather + edge MLP + LayerNorm + residual + segmented scatter; "
-                        "v_mfma_f32_32x32x2_f32)",
+                roof = {"bound": "mfma", "kernel": FAMILY.get(fam, "k_edge_step<4,2>") + " (fused gather + edge MLP + LayerNorm + residual + segmented scatter; "
+                        "fp32 MFMA)",
                         "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS,
                         "flops_per_launch": flops_edge_kernel(e_loc), "flops_kind": "MFMA flops executed by this kernel (98 304 per edge; "
                         "layer 1 is factored so the v_s/v_r blocks run per node in k_node_step)",

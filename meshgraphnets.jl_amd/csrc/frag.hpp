@@ -48,15 +48,16 @@ DEVINL const f32x4* row_ptr(const float* base, int64_t row, int L, int h) {
     return reinterpret_cast<const f32x4*>(base + row * L) + h;
 }
 DEVINL f32x4* row_ptr(float* base, int64_t row, int L, int h) { return reinterpret_cast<f32x4*>(base + row * L) + h; }
-// P / Q / CARRY rows (the arrays that are read with lane = row gathers) go through prow_ptr.  MGN_PROW_BLOCK = 8 (build option) stores
-// them in blocks of eight rows, 32-byte piece m of the block's rows side by side -- [row / 8][piece m][row % 8][h][4 floats] -- so that a
-// gather instruction (one piece m of 32 rows) finds the pieces of neighbouring rows in the same cache line and the rows of a node tile
-// are stored with coalesced 1 KiB instructions (tools/gather_probe.hip: a 32-row gather costs the CU 62 cycles per instruction, an
-// 8-line access 16-17): + 1.5 % on M-1M, whose node numbering is coherent -- and - 5..9 % (fp32) / - 34 % (bf16) on graphs whose
-// senders are scattered (a 128-byte line then carries 32 useful bytes: four times the gather traffic).  Default 0: plain row-major rows.
+// P / Q / CARRY rows (the arrays that are read with lane = row gathers) go through prow_ptr.  MGN_PROW_BLOCK = 8 (the default since
+// round 4) stores them in blocks of eight rows, 32-byte piece m of the block's rows side by side -- [row / 8][piece m][row % 8][h][4 floats]
+// -- so that a gather instruction (one piece m of 32 rows) finds the pieces of neighbouring rows in the same cache line and the rows of
+// a node tile are stored with coalesced 1 KiB instructions (tools/gather_probe.hip: a 32-row gather costs the CU 62 cycles per
+// instruction, an 8-line access 16-17): node side - 5 %, step - 1.5 % on M-1M.  It needs a numbering in which the ends of an edge are
+// close (on scattered senders a 128-byte line carries 32 useful bytes: - 5..9 % fp32, - 34 % bf16 in round 3) -- which mgn_set_graph
+// now guarantees (graph_host.cpp: breadth-first renumbering of a mesh that arrives scattered).  -DMGN_PROW_BLOCK=0: plain row-major rows.
 // Piece m of a row: prow_ptr(base, row, L, h)[m * STRIDE_PROW].
 #ifndef MGN_PROW_BLOCK
-#define MGN_PROW_BLOCK 0
+#define MGN_PROW_BLOCK 8
 #endif
 constexpr int STRIDE_PROW = MGN_PROW_BLOCK ? 2 * MGN_PROW_BLOCK : STRIDE_ROW;
 DEVINL int64_t prow_index(int64_t row, int L) {       // f32x4 index of (row, piece 0, h 0)

@@ -178,6 +178,7 @@ bool launch_is_small(int ntiles);
 bool launch_is_small_edge(int ntiles_e);   // the same rule for edge launches (<= 16 tiles per CU)
 int coop16_enabled();
 bool coop16_size(int ntiles_e, int ntiles_n);   // the launch wrappers' rule for the cooperative node kernels (<= 8 tiles per CU)
+int last_edge_kernel();         // family of the last fp32 edge launch (kernels.hip: launch_edge_step)
 int set_fp32_split(int on);     // debug/tests: 0 = fp32-MFMA kernels, 1 = split path (default), 2 = split path with k_edge_split2; returns the old value
 int fp32_split_enabled();
 int set_c16_row_tiles(int rt);  // debug/tests: 16-edge tiles per block of the small-graph edge kernel (0: chosen by size); returns the old value

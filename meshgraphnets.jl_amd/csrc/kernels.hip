@@ -2410,13 +2410,21 @@ static bool coop_ok(int L, int ntiles, const float* const* chunk_t, bool edge = 
     return L == 128 && chunk_t[0] != nullptr && coop_size(ntiles, edge);
 }
 
+// which kernel family the last fp32 edge launch went to (bench.py labels its roofline with what RAN, not with the global switches):
+// 1 generic hidden_layers, 2 16-row small-graph, 3 cooperative 4-wave tiles, 4 all-streaming, 5 k_edge_split2, 6 k_edge_ring2,
+// 7 k_edge_ring<8>, 8 k_edge_ring<4>, 9 k_edge_step<4,2> (fp32-MFMA persistent)
+static int g_last_edge_kernel = 0;
+int last_edge_kernel() { return g_last_edge_kernel; }
+
 hipError_t launch_edge_step(int L, const EdgeArgs& a, hipStream_t s) {
     if (a.ntiles <= 0) return hipSuccess;
+    if (a.gen.use) g_last_edge_kernel = 1;
     if (a.gen.use) DISPATCH_GEN(L, (k_edge_step<4, 0, true>), (k_edge_step<2, 0, true>), (k_edge_step<1, 0, true>), a, a.ntiles);
     const int nres = resident_chunks(L, 3);
     LaunchCfg lc = tile_launch(L, a.ntiles, nres);
     if (a.c16 && L == 128 && a.chunk_t[0]) {        // small graph: 16-row tiles, 4 waves each (the handle decided for both kernels)
         // RT 16-edge tiles per block: about one block per CU (MGN_C16_RT = 1..3 pins it)
+        g_last_edge_kernel = 2;
         const int nht = 2 * a.ntiles;
         int rt = g_c16_rt ? g_c16_rt : (nht + num_cus() - 1) / num_cus();
         rt = rt < 1 ? 1 : (rt > 3 ? 3 : rt);
@@ -2435,11 +2443,13 @@ hipError_t launch_edge_step(int L, const EdgeArgs& a, hipStream_t s) {
     static const int coop_edge_ring = [] { const char* e = getenv("MGN_COOP_EDGE_TILES_PER_CU_RING"); return e ? atoi(e) : 3; }();
     const bool ring_ok = L == 128 && g_fp32_split == 1 && a.split[0] && g_path == 0;
     if (coop_ok(L, a.ntiles, a.chunk_t, true) && !(ring_ok && a.ntiles > coop_edge_ring * num_cus())) {   // small graph: 4 waves per tile
+        g_last_edge_kernel = 3;
         LaunchCfg c4{a.ntiles, 256, coop_lds()};
         return coop_fence(a.ntiles) ? launch_k(k_edge_coop<true>, a, c4, s) : launch_k(k_edge_coop<false>, a, c4, s);
     }
     if (L == 128) {
         if (small_launch(a.ntiles) && !(ring_ok && a.ntiles > coop_edge_ring * num_cus())) {   // few tiles: the per-block LDS preload would dominate -> stream everything from L2
+            g_last_edge_kernel = 4;
             lc.lds = (size_t)T_COUNT * L * 4 + 64;
             return launch_k(k_edge_step<4, 0>, a, lc, s);
         }
@@ -2447,6 +2457,7 @@ hipError_t launch_edge_step(int L, const EdgeArgs& a, hipStream_t s) {
             LaunchCfg ls = lc;
             if (g_fp32_split == 2) {
                 ls.lds = (size_t)4 * 16384 * 2 + (size_t)T_COUNT * L * 4 + 64;
+                g_last_edge_kernel = 5;
                 return launch_edge_split2(a, ls, s);
             }
             if (g_fp32_split == 3) {   // two independent four-wave blocks per CU, every piece through the block's own ring
@@ -2455,6 +2466,7 @@ hipError_t launch_edge_step(int L, const EdgeArgs& a, hipStream_t s) {
                 int blocks = (a.ntiles + 3) / 4;
                 if (blocks > 2 * num_cus()) blocks = 2 * num_cus();
                 ls.blocks = ((blocks + NUM_XCD - 1) / NUM_XCD) * NUM_XCD;
+                g_last_edge_kernel = 6;
                 return launch_edge_ring2(a, ls, s);
             }
             ls.lds = (size_t)3 * 32768 + (size_t)3 * 16384 + (size_t)T_COUNT * L * 4 + 64;
@@ -2469,8 +2481,10 @@ hipError_t launch_edge_step(int L, const EdgeArgs& a, hipStream_t s) {
                 if (blocks > num_cus()) blocks = num_cus();
                 ls.blocks = ((blocks + NUM_XCD - 1) / NUM_XCD) * NUM_XCD;
             }
+            g_last_edge_kernel = ls.threads == 256 ? 8 : 7;
             return launch_edge_ring(a, ls, s);
         }
+        g_last_edge_kernel = 9;
         lc.lds += (size_t)MGN_EDGE_JR * 64 * 4 * 4;   // partially resident third chunk
         // Tail of the persistent walk: with r = ntiles / (8 waves x 256 blocks) rounds, a last round that is less than
         // ~60 % full costs a whole tile-time (11.4 tiles per wave on an 8-GPU partition of M-1M: 5 %).  Those tiles go to

@@ -2452,6 +2452,7 @@ int mgn_debug_c16_row_tiles(int rt) { return set_c16_row_tiles(rt); }
 // large fp32 launches: 1 split path (k_edge_ring + k_node_split + k_project_split: bf16 matrix cores at fp32 accuracy; the default),
 // 2 the same with k_edge_split2, 0 fp32-MFMA kernels; returns the old value
 int mgn_debug_fp32_split(int on) { return set_fp32_split(on); }
+int mgn_debug_last_edge_kernel(void) { return last_edge_kernel(); }   // kernels.hip: which family the last fp32 edge launch ran on
 // node numbering policy of the NEXT mgn_set_graph calls (0 never, 1 auto, 2 always breadth-first); returns the old value
 int mgn_debug_renumber(int mode) { const int old = g_renumber; g_renumber = mode; return old; }
 int mgn_debug_renumbered(const mgn_handle* h) { return h && h->have_graph && h->g.renumbered ? 1 : 0; }

@@ -104,6 +104,12 @@ DEVINL void sp_layer_otf(f32x16 (&acc)[4], const f32x16 (&in)[4], const u32x4* p
 #ifndef MGN_SP2_D
 #define MGN_SP2_D 6
 #endif
+#ifndef MGN_NRING_VNEXT
+#define MGN_NRING_VNEXT 1        // k_node_ring: the next tile's V through the refill of the last chunk's input
+#endif
+#ifndef MGN_NODE_VNEXT_FIRST
+#define MGN_NODE_VNEXT_FIRST 1   // node-side split kernels: the next tile's V requested ahead of this tile's stores (0: round 3's order)
+#endif
 #ifndef MGN_SP2_D1
 #define MGN_SP2_D1 8       // layer 2 streams one piece only
 #endif
@@ -858,6 +864,14 @@ __global__ __launch_bounds__(512, 2) void k_node_split(const NodeArgs a) {
         layer_norm_frag<NT>(acc, tb + T_GAMMA * L, tb + T_BETA * L, h);
 #pragma unroll
         for (int t = 0; t < NT; ++t) x[t] += acc[t];                 // v <- v + v'
+#if MGN_NODE_VNEXT_FIRST
+        // the next tile's V is requested AHEAD of this tile's V stores, into the registers of v' (dead from here): s_waitcnt vmcnt
+        // retires in order and counts stores, so a load requested behind the sixteen stores is not back before they are acknowledged
+        // (k_edge_ring's turnover, docs/experiments.md round 4)
+        PHASE_FENCE();
+        if (has_next) load_frag<NT>(acc, tile_ptr(a.V, next, L, lane), STRIDE_TILE);
+        PHASE_FENCE();
+#endif
 #if defined(MGN_WHATIF_NODE) && (MGN_WHATIF_NODE & 4)   // diagnostic: no store
         if (valid && a.n < 0) store_frag<NT>(vtile, STRIDE_TILE, x);
 #else
@@ -865,7 +879,12 @@ __global__ __launch_bounds__(512, 2) void k_node_split(const NodeArgs a) {
 #endif
         if (!has_next) break;
         PHASE_FENCE();
+#if MGN_NODE_VNEXT_FIRST
+#pragma unroll
+        for (int t = 0; t < NT; ++t) x[t] = acc[t];
+#else
         load_frag<NT>(x, tile_ptr(a.V, next, L, lane), STRIDE_TILE);
+#endif
         tw.tile = next;
     }
 }
@@ -1078,7 +1097,17 @@ __global__ __launch_bounds__(512, 2) void k_node_ring(const NodeArgs a) {
 #endif
         __builtin_amdgcn_s_setprio(0);
         tab_frag<NT>(acc, tb + T_BQ * L, h);
+#if MGN_NRING_VNEXT
+        {   // the next tile's V arrives in the registers this last chunk's input releases: nothing is requested behind the Q stores
+            const f32x4* vn = tile_ptr(a.V, next, L, lane);
+            f32x4 sv[4];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) sv[m] = vn[m * STRIDE_TILE];
+            spn_layer<W, 5, NCH, false, 8, true>(acc, x, ring, src, nx, lane, tid, vn, STRIDE_TILE, sv);   // Q = v W1r + b1
+        }
+#else
         spn_layer<W, 5, NCH, false>(acc, x, ring, src, nx, lane, tid);                     // Q = v W1r + b1
+#endif
         __builtin_amdgcn_s_setprio(MGN_PRIO);
 #if defined(MGN_WHATIF_NRING) && (MGN_WHATIF_NRING & 2)
         if (valid && a.n < 0) store_frag<NT>(prow_ptr(a.Q, nn, L, h), STRIDE_PROW, acc);
@@ -1086,7 +1115,8 @@ __global__ __launch_bounds__(512, 2) void k_node_ring(const NodeArgs a) {
         if (valid) store_frag<NT>(prow_ptr(a.Q, nn, L, h), STRIDE_PROW, acc);
 #endif
         PHASE_FENCE();
-#if defined(MGN_WHATIF_NRING) && (MGN_WHATIF_NRING & 1)
+#if MGN_NRING_VNEXT
+#elif defined(MGN_WHATIF_NRING) && (MGN_WHATIF_NRING & 1)
         load_frag<NT>(x, tile_ptr(a.V, wave, L, lane), STRIDE_TILE);
 #else
         load_frag<NT>(x, tile_ptr(a.V, next, L, lane), STRIDE_TILE);
@@ -1257,6 +1287,11 @@ __global__ __launch_bounds__(512, 2) void k_project_split(const NodeArgs a) {
         sp_layer_otf<false, true, false, D1>(acc, x, lqh, lqm, gq + 4096, lane);
 #endif
         __builtin_amdgcn_s_setprio(MGN_PRIO);
+#if MGN_NODE_VNEXT_FIRST
+        PHASE_FENCE();
+        if (has_next) load_frag<NT>(x, tile_ptr(a.V, a.tile0 + next, L, lane), STRIDE_TILE);   // ahead of the Q stores (x is dead: both projections read it)
+        PHASE_FENCE();
+#endif
 #if defined(MGN_WHATIF_NODE) && (MGN_WHATIF_NODE & 8)
         if (valid) store_frag<NT>(tile_ptr(a.Q, tile, L, lane), STRIDE_TILE, acc);
 #elif defined(MGN_WHATIF_NODE) && (MGN_WHATIF_NODE & 16)
@@ -1265,8 +1300,10 @@ __global__ __launch_bounds__(512, 2) void k_project_split(const NodeArgs a) {
         if (valid) store_frag<NT>(prow_ptr(a.Q, nn, L, h), STRIDE_PROW, acc);
 #endif
         if (!has_next) break;
+#if !MGN_NODE_VNEXT_FIRST
         PHASE_FENCE();
         load_frag<NT>(x, tile_ptr(a.V, a.tile0 + next, L, lane), STRIDE_TILE);
+#endif
         tw.tile = next;
     }
 }

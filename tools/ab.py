@@ -18,10 +18,11 @@ for r in range(rounds):
         if n != "default":
             env["MGN_LIB_PATH"] = os.path.join(ROOT, "meshgraphnets.jl_amd", "lib", "variants", n + ".so")
         out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--nx", str(nx),
-                              "--no-cpu-baseline", "--no-secondary", "--dtype", dtype], env=env, capture_output=True, text=True).stdout
+                              "--no-cpu-baseline", "--no-secondary", "--dtype", dtype], env=env, capture_output=True, text=True)
+        err, out = out.stderr, out.stdout
         line = [l for l in out.splitlines() if l.startswith("{")]
         if not line:
-            print(n, "FAILED", out[-300:]); continue
+            print(n, "FAILED", out[-300:], err[-600:]); continue
         d = json.loads(line[-1]); rf = d["roofline"]
         res[n].append((rf["avg_launch_ms"], (rf.get("node_side") or rf.get("node_kernel"))["avg_launch_ms"], d["ms_per_processor_step"]))
 for n in names:
