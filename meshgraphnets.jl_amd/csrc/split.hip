@@ -108,7 +108,7 @@ DEVINL void sp_layer_otf(f32x16 (&acc)[4], const f32x16 (&in)[4], const u32x4* p
 #define MGN_NRING_VNEXT 1        // k_node_ring: the next tile's V through the refill of the last chunk's input
 #endif
 #ifndef MGN_NODE_VNEXT_FIRST
-#define MGN_NODE_VNEXT_FIRST 1   // node-side split kernels: the next tile's V requested ahead of this tile's stores (0: round 3's order)
+#define MGN_NODE_VNEXT_FIRST 0   // node-side split kernels: 1 = the next tile's V requested ahead of this tile's stores (1.178 vs 1.170 ms: nothing; the waves of these kernels are not in lock-step)
 #endif
 #ifndef MGN_SP2_D1
 #define MGN_SP2_D1 8       // layer 2 streams one piece only
@@ -416,12 +416,26 @@ DEVINL void sp_layer_ring(f32x16 (&acc)[4], f32x16 (&in)[4], const u32x4* hi, co
                 sp_split_pair<RELU>(n.h[t], n.m[t], n.l[t], in[sn >> 1][8 * (sn & 1) + 2 * t], in[sn >> 1][8 * (sn & 1) + 2 * t + 1]);
             }
             const sp_bf16x8 bh = sp_op(p.h), bm = sp_op(p.m), bl = sp_op(p.l);
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sp_wop(a3), bh, acc[t], 0, 0, 0);      // small terms first
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sp_wop(a2), bm, acc[t], 0, 0, 0);
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sp_wop(a1), bl, acc[t], 0, 0, 0);
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sp_wop(a2), bh, acc[t], 0, 0, 0);
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sp_wop(a1), bm, acc[t], 0, 0, 0);
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sp_wop(a1), bh, acc[t], 0, 0, 0);
+#ifdef MGN_WHATIF_MFMA16    // diagnostic (wrong results): the same operand traffic and matrix time on v_mfma_f32_16x16x32_bf16 -- what the
+                            // other shape's clock is worth to this kernel before anyone re-writes its layouts
+#define RING_MFMA(A_, B_)                                                                                          \
+            do {                                                                                                   \
+                f32x4 c0_, c1_;                                                                                    \
+                _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) { c0_[i_] = acc[t][i_]; c1_[i_] = acc[t][4 + i_]; } \
+                c0_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A_, B_, c0_, 0, 0, 0);                                \
+                c1_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A_, B_, c1_, 0, 0, 0);                                \
+                _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) { acc[t][i_] = c0_[i_]; acc[t][4 + i_] = c1_[i_]; } \
+            } while (0)
+#else
+#define RING_MFMA(A_, B_) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_, B_, acc[t], 0, 0, 0)
+#endif
+            RING_MFMA(sp_wop(a3), bh);      // small terms first
+            RING_MFMA(sp_wop(a2), bm);
+            RING_MFMA(sp_wop(a1), bl);
+            RING_MFMA(sp_wop(a2), bh);
+            RING_MFMA(sp_wop(a1), bm);
+            RING_MFMA(sp_wop(a1), bh);
+#undef RING_MFMA
             __builtin_amdgcn_sched_barrier(0);
 #if !(defined(MGN_WHATIF_LOADER) && (MGN_WHATIF_LOADER & 2))
             if (it % W == W - 1) ring_barrier();                       // window closed: every wave has read it, window gw + 2 is in LDS

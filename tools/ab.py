@@ -15,8 +15,12 @@ res = {n: [] for n in names}
 for r in range(rounds):
     for n in names:
         env = dict(os.environ)
-        if n != "default":
-            env["MGN_LIB_PATH"] = os.path.join(ROOT, "meshgraphnets.jl_amd", "lib", "variants", n + ".so")
+        lib, *sets = n.split("+")                 # "name+VAR=value+...": environment knobs on top of a library variant
+        for kv in sets:
+            k, v = kv.split("=", 1)
+            env[k] = v
+        if lib != "default":
+            env["MGN_LIB_PATH"] = os.path.join(ROOT, "meshgraphnets.jl_amd", "lib", "variants", lib + ".so")
         out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--nx", str(nx),
                               "--no-cpu-baseline", "--no-secondary", "--dtype", dtype], env=env, capture_output=True, text=True)
         err, out = out.stderr, out.stdout
