@@ -376,8 +376,8 @@ def main():
             fam = lib.mgn_debug_last_edge_kernel()
             FAMILY = {1: "k_edge_step<.., GEN> (general hidden_layers)", 2: "k_edge_coop16m (16-row tiles)", 3: "k_edge_coop (4-wave tiles)",
                       4: "k_edge_step<4,0> (all-streaming)", 5: "k_edge_split2", 6: "k_edge_ring2", 7: "k_edge_ring<8>", 8: "k_edge_ring<4>",
-                      9: "k_edge_step<4,2>"}
-            ran_split = fam in (5, 6, 7, 8)
+                      9: "k_edge_step<4,2>", 10: "k_edge_ring16<8>", 11: "k_edge_ring16<4>"}
+            ran_split = fam in (5, 6, 7, 8, 10, 11)
             if not ran_split:
                 split_mode = 0
             comp = (1024.0 + 8.0) * e_loc + 3.0 * 512.0 * n_loc
@@ -390,7 +390,7 @@ def main():
             if split_mode:
                 # fp32 storage, every L x L product as six exact bf16 products on v_mfma_f32_32x32x16_bf16, fp32 accumulation
                 # (csrc/split.hip).  The roofline is the bf16 dense peak with the flops the kernel EXECUTES: 6 x the fp32 count.
-                kname = {5: "k_edge_split2", 6: "k_edge_ring2", 7: "k_edge_ring", 8: "k_edge_ring"}[fam]
+                kname = {5: "k_edge_split2", 6: "k_edge_ring2", 7: "k_edge_ring", 8: "k_edge_ring", 10: "k_edge_ring16", 11: "k_edge_ring16"}[fam]
                 fl = SPLIT_PRODUCTS * flops_edge_kernel(e_loc)
                 ach = fl / t_edge / 1e12 if t_edge > 0 else 0.0
                 traffic, tsrc = committed_traffic([kname]) if (world == 1 and args.nx == 1000) else (None, None)

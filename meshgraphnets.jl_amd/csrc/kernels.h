@@ -50,6 +50,8 @@ struct EdgeArgs {
     // every fp32 operand split into three bf16 pieces, six piece products kept.  split[i]: chunk i as 3 x 16384 bf16 (hi, mid, lo
     // pieces, the bf16 kernels' fragment order); null: not available
     const uint16_t* split[3];
+    const uint16_t* split16[3];   // the same pieces in the fragment order of v_mfma_f32_16x16x32_bf16 (k_edge_ring16; mgn_api.cpp: pack_chunk16_bf16)
+    int32_t off32;                // 1: P, Q, AGG and CARRY are each shorter than 2 GiB, so k_edge_ring16 may address them with 32-bit lane offsets
 };
 
 struct NodeArgs {
@@ -154,6 +156,7 @@ hipError_t launch_gather_rows16(const uint16_t* src, const int32_t* idx, uint16_
 
 struct LaunchCfg { int blocks; int threads; size_t lds; };
 hipError_t launch_edge_split2(const EdgeArgs& a, const LaunchCfg& lc, hipStream_t s);   // split.hip
+hipError_t launch_edge_ring16(const EdgeArgs& a, const LaunchCfg& lc, hipStream_t s);   // split.hip: the ring kernel on v_mfma_f32_16x16x32_bf16
 hipError_t launch_edge_ring(const EdgeArgs& a, const LaunchCfg& lc, hipStream_t s);    // split.hip
 hipError_t launch_edge_ring2(const EdgeArgs& a, const LaunchCfg& lc, hipStream_t s);   // split.hip: two four-wave blocks per CU
 hipError_t launch_node_split(const NodeArgs& a, const LaunchCfg& lc, hipStream_t s);    // split.hip
@@ -181,6 +184,8 @@ bool coop16_size(int ntiles_e, int ntiles_n);   // the launch wrappers' rule for
 int last_edge_kernel();         // family of the last fp32 edge launch (kernels.hip: launch_edge_step)
 int set_fp32_split(int on);     // debug/tests: 0 = fp32-MFMA kernels, 1 = split path (default), 2 = split path with k_edge_split2; returns the old value
 int fp32_split_enabled();
+int set_edge_ring16(int on);    // 1: k_edge_ring16 (v_mfma_f32_16x16x32_bf16) where k_edge_ring would run; MGN_EDGE_RING16; returns the old value
+int edge_ring16_enabled();
 int set_c16_row_tiles(int rt);  // debug/tests: 16-edge tiles per block of the small-graph edge kernel (0: chosen by size); returns the old value
 int set_kernel_path(int p);   // debug/tests: 0 auto, 1 resident, 2 streaming, 3 cooperative, 4 GEN (general hidden_layers) kernels; returns the old value
 int get_kernel_path();

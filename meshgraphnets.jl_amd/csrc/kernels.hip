@@ -2305,6 +2305,9 @@ static int g_c16_rt = [] { const char* e = getenv("MGN_C16_RT"); return e ? atoi
 static int g_fp32_split = [] { const char* e = getenv("MGN_FP32_SPLIT"); return e ? atoi(e) : 1; }();
 int set_fp32_split(int on) { const int old = g_fp32_split; g_fp32_split = on; return old; }
 int fp32_split_enabled() { return g_fp32_split; }
+static int g_edge_ring16 = [] { const char* e = getenv("MGN_EDGE_RING16"); return e ? atoi(e) : 0; }();
+int set_edge_ring16(int on) { const int old = g_edge_ring16; g_edge_ring16 = on; return old; }
+int edge_ring16_enabled() { return g_edge_ring16; }
 int set_c16_row_tiles(int rt) { const int old = g_c16_rt; g_c16_rt = rt; return old; }
 int get_kernel_path() { return g_path; }
 static bool small_launch(int ntiles) { return g_path == 0 ? ntiles <= 4 * num_cus() : g_path >= 2; }
@@ -2480,6 +2483,10 @@ hipError_t launch_edge_step(int L, const EdgeArgs& a, hipStream_t s) {
                 int blocks = (a.ntiles + 4 * rounds - 1) / (4 * rounds);
                 if (blocks > num_cus()) blocks = num_cus();
                 ls.blocks = ((blocks + NUM_XCD - 1) / NUM_XCD) * NUM_XCD;
+            }
+            if (g_edge_ring16 && a.split16[0] && a.off32) {
+                g_last_edge_kernel = ls.threads == 256 ? 11 : 10;
+                return launch_edge_ring16(a, ls, s);
             }
             g_last_edge_kernel = ls.threads == 256 ? 8 : 7;
             return launch_edge_ring(a, ls, s);

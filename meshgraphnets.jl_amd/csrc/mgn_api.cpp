@@ -171,7 +171,8 @@ inline float bf16_to_f32(uint16_t b) {
 }
 // the same chunk as three bf16 pieces with w = hi + mid + lo exactly (dst: 3 x 16384, each in the fragment order below)
 void pack_chunk_bf16(uint16_t* dst, const float* W, int ldw, int kbase);
-void pack_chunk_split(uint16_t* dst, const float* W, int ldw, int kbase) {
+void pack_chunk16_bf16(uint16_t* dst, const float* W, int ldw, int kbase);
+void pack_chunk_split(uint16_t* dst, const float* W, int ldw, int kbase, bool frag16 = false) {
     std::vector<float> r1((size_t)128 * 128), r2((size_t)128 * 128), w0((size_t)128 * 128);
     for (int k = 0; k < 128; ++k)
         for (int n = 0; n < 128; ++n) {
@@ -183,9 +184,22 @@ void pack_chunk_split(uint16_t* dst, const float* W, int ldw, int kbase) {
             r1[(size_t)k * 128 + n] = ra;
             r2[(size_t)k * 128 + n] = ra - b;
         }
-    pack_chunk_bf16(dst, w0.data(), 128, 0);
-    pack_chunk_bf16(dst + 16384, r1.data(), 128, 0);
-    pack_chunk_bf16(dst + 2 * 16384, r2.data(), 128, 0);
+    auto pk = frag16 ? pack_chunk16_bf16 : pack_chunk_bf16;
+    pk(dst, w0.data(), 128, 0);
+    pk(dst + 16384, r1.data(), 128, 0);
+    pk(dst + 2 * 16384, r2.data(), 128, 0);
+}
+// the A fragments of v_mfma_f32_16x16x32_bf16 (k_edge_ring16, split.hip): step (ks, ob) = output block ob of k-step ks; lane
+// (r16 = lane & 15, g = lane >> 4) holds output 16 ob + r16, its element j input 16 (2 ks + (j >> 2)) + 4 g + (j & 3) -- the order in
+// which a lane's two accumulator blocks 2 ks, 2 ks + 1 of the layer before hold them
+void pack_chunk16_bf16(uint16_t* dst, const float* W, int ldw, int kbase) {
+    for (int ks = 0; ks < 4; ++ks)
+        for (int ob = 0; ob < 8; ++ob)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int j = 0; j < 8; ++j) {
+                    const int k = 16 * (2 * ks + (j >> 2)) + 4 * (lane >> 4) + (j & 3), n = 16 * ob + (lane & 15);
+                    dst[(((size_t)ks * 8 + ob) * 64 + lane) * 8 + j] = f32_to_bf16(W[(size_t)(kbase + k) * ldw + n]);
+                }
 }
 // 128 x 128 chunk of W (row-major [K][ldw], rows kbase..) -> bf16 fragment order [s][t][lane][8]
 void pack_chunk_bf16(uint16_t* dst, const float* W, int ldw, int kbase) {
@@ -397,6 +411,12 @@ EdgeArgs edge_args(mgn_engine* h, int k, int q = 0) {
     a.gen = gen_of(h, h->soff[k].e_gen[q], true);
     for (int i = 0; i < 3; ++i)
         a.split[i] = (!a.bf && k < (int)h->spoff.size() && h->wsp.p) ? h->wsp.as<uint16_t>() + h->spoff[k].e_ch[q][i] : nullptr;
+    for (int i = 0; i < 3; ++i)
+        a.split16[i] = (a.split[i] && h->spoff[k].e16_ch[q][i]) ? h->wsp.as<uint16_t>() + h->spoff[k].e16_ch[q][i] : nullptr;
+    {
+        const size_t lim = (size_t)1 << 31, rowb = (size_t)h->cfg.L * 4;
+        a.off32 = ((size_t)(h->g.n_own + h->g.n_halo + 32) * rowb < lim && ((size_t)2 * es.ntiles_e + 16) * rowb < lim) ? 1 : 0;
+    }
     a.c16 = use_c16(h);
     a.stagger = h->stagger_edge;
     a.tile0 = 0;
@@ -752,7 +772,8 @@ int mgn_set_params(mgn_handle* h, const float* packed, size_t n) try {
     h->spoff.clear();
     if (c.dtype == MGN_F32 && L == 128 && c.hidden_layers == 2) {      // bf16 pieces of the split path (split.hip): 4.4 MB per edge set,
         const bool node_side = S == 1;                                  //   8.8 MB for the node side (one edge set)
-        std::vector<uint16_t> ws((size_t)c.mps * S * 3 * 3 * 16384 + (node_side ? (size_t)(c.mps + 1) * 6 * 3 * 16384 : 0));
+        const bool ring16 = edge_ring16_enabled() != 0;                 // k_edge_ring16's fragment order next to the default one
+        std::vector<uint16_t> ws((size_t)c.mps * S * 3 * 3 * 16384 * (ring16 ? 2 : 1) + (node_side ? (size_t)(c.mps + 1) * 6 * 3 * 16384 : 0));
         h->spoff.assign(c.mps + 1, {});
         size_t off = 0;
         for (int k = 0; k < c.mps; ++k)
@@ -764,6 +785,12 @@ int mgn_set_params(mgn_handle* h, const float* packed, size_t n) try {
                     pack_chunk_split(ws.data() + off, src[i], L, kb[i]);
                     h->spoff[k].e_ch[q][i] = off;
                     off += (size_t)3 * 16384;
+                    h->spoff[k].e16_ch[q][i] = 0;
+                    if (ring16) {
+                        pack_chunk_split(ws.data() + off, src[i], L, kb[i], true);
+                        h->spoff[k].e16_ch[q][i] = off;
+                        off += (size_t)3 * 16384;
+                    }
                 }
             }
         for (int k = 0; node_side && k <= c.mps; ++k) {                 // node MLP of step k + projection for step k + 1 (k = mps: the
@@ -2452,6 +2479,9 @@ int mgn_debug_c16_row_tiles(int rt) { return set_c16_row_tiles(rt); }
 // large fp32 launches: 1 split path (k_edge_ring + k_node_split + k_project_split: bf16 matrix cores at fp32 accuracy; the default),
 // 2 the same with k_edge_split2, 0 fp32-MFMA kernels; returns the old value
 int mgn_debug_fp32_split(int on) { return set_fp32_split(on); }
+// 1: the edge kernel of the split path on v_mfma_f32_16x16x32_bf16 (k_edge_ring16); takes effect at the next mgn_set_params (its weight
+// fragments are packed there).  Returns the old value.  Environment: MGN_EDGE_RING16.
+int mgn_debug_edge_ring16(int on) { return set_edge_ring16(on); }
 int mgn_debug_last_edge_kernel(void) { return last_edge_kernel(); }   // kernels.hip: which family the last fp32 edge launch ran on
 // node numbering policy of the NEXT mgn_set_graph calls (0 never, 1 auto, 2 always breadth-first); returns the old value
 int mgn_debug_renumber(int mode) { const int old = g_renumber; g_renumber = mode; return old; }

@@ -8,15 +8,20 @@ import torch  # noqa: F401
 
 import mgn_oracle as orc
 from mgn_amd import synth
-from util import TOL_15, TOL_STEP, cfg_dict, engine_for, make_params, rel_max, set_fp32_split
+from util import TOL_15, TOL_STEP, cfg_dict, engine_for, make_params, rel_max, set_edge_ring16, set_fp32_split
 
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(params=[1, 2, 3], ids=["ring", "split2", "ring2"])
+@pytest.fixture(params=[1, 2, 3, 16], ids=["ring", "split2", "ring2", "ring16"])
 def split_on(request):
-    old = set_fp32_split(request.param)
-    yield request.param
+    """16: the ring kernel on v_mfma_f32_16x16x32_bf16 (k_edge_ring16: mode 1 + mgn_debug_edge_ring16; its fragments are packed at
+    set_params, so the switch is thrown before the engines are built)"""
+    mode = 1 if request.param == 16 else request.param
+    old = set_fp32_split(mode)
+    old16 = set_edge_ring16(1 if request.param == 16 else 0)
+    yield mode
+    set_edge_ring16(old16)
     set_fp32_split(old)
 
 
