@@ -80,7 +80,7 @@ struct NodeArgs {
     int32_t bf;             // see EdgeArgs (V, AGG, CARRY, P, Q bf16)
     unsigned long long* stamps;  // diagnostic builds only (MGN_DIAG_STAMPS), else null
     // split path (see EdgeArgs.split): chunk[0..5] as 3 x 16384 bf16 pieces each (k_node_split, k_project_split); null: not available
-    const uint16_t* split[6];
+    const uint16_t* split[7];     // [6]: W1[2L:3L], the second edge set's aggregate block (k_node_split<true>)
 };
 
 struct EncNodeArgs {
@@ -181,7 +181,8 @@ bool launch_is_small(int ntiles);
 bool launch_is_small_edge(int ntiles_e);   // the same rule for edge launches (<= 16 tiles per CU)
 int coop16_enabled();
 bool coop16_size(int ntiles_e, int ntiles_n);   // the launch wrappers' rule for the cooperative node kernels (<= 8 tiles per CU)
-int last_edge_kernel();         // family of the last fp32 edge launch (kernels.hip: launch_edge_step)
+int last_edge_kernel();
+int last_node_kernel();         // family of the last fp32 edge launch (kernels.hip: launch_edge_step)
 int set_fp32_split(int on);     // debug/tests: 0 = fp32-MFMA kernels, 1 = split path (default), 2 = split path with k_edge_split2; returns the old value
 int fp32_split_enabled();
 int set_edge_ring16(int on);    // 1: k_edge_ring16 (v_mfma_f32_16x16x32_bf16) where k_edge_ring would run; MGN_EDGE_RING16; returns the old value

@@ -2516,8 +2516,11 @@ hipError_t launch_edge_step(int L, const EdgeArgs& a, hipStream_t s) {
     if (L == 32) return launch_k(k_edge_step<1, 3>, a, lc, s);
     return hipErrorInvalidValue;
 }
+static int g_last_node_kernel = 0;    // family of the last node-MLP launch (tests / bench): 1 general, 2 16-row cooperative, 3 cooperative,
+int last_node_kernel() { return g_last_node_kernel; }   // 4 k_node_ring, 5 k_node_split, 6 k_node_split<two sets>, 7 fp32-MFMA k_node_step
 hipError_t launch_node_step(int L, const NodeArgs& a, hipStream_t s) {
     if (a.ntiles <= 0) return hipSuccess;
+    if (a.mode != 2) g_last_node_kernel = a.gen.use ? 1 : (a.c16 && L == 128 && a.chunk_t[0]) ? 2 : coop_ok(L, a.ntiles, a.chunk_t) ? 3 : 7;
     if (a.gen.use) {
         if (a.mode == 2) return launch_project(L, a, s);
         if (a.AGG2) {
@@ -2543,11 +2546,13 @@ hipError_t launch_node_step(int L, const NodeArgs& a, hipStream_t s) {
         LaunchCfg ls = tile_launch(L, a.ntiles, 2);
         ls.lds = (size_t)3 * 3 * 8 * 64 * 16 + (size_t)T_COUNT * L * 4 + 64;
         ++g_node_ring_launches;
+        g_last_node_kernel = 4;
         return launch_node_ring(a, ls, s);
     }
-    if (g_fp32_split && g_path == 0 && L == 128 && !proj && !a.AGG2 && a.split[0] && !small_launch(a.ntiles)) {   // split path (split.hip)
+    if (g_fp32_split && g_path == 0 && L == 128 && !proj && (!a.AGG2 || a.split[6]) && a.split[0] && !small_launch(a.ntiles)) {   // split path (split.hip)
         LaunchCfg ls = tile_launch(L, a.ntiles, 2);
         ls.lds = (size_t)4 * 16384 * 2 + (size_t)T_COUNT * L * 4 + 64;
+        g_last_node_kernel = a.AGG2 ? 6 : 5;
         return launch_node_split(a, ls, s);
     }
     const int nres = resident_chunks(L, proj ? 6 : 4);

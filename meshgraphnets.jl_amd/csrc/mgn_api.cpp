@@ -481,8 +481,13 @@ NodeArgs node_args(mgn_engine* h, int k, int mode, int q = 0) {
     a.c16 = use_c16(h);
     a.stamps = h->d_stamps.as<unsigned long long>();
     a.tile0 = 0;
-    for (int i = 0; i < 6; ++i)
-        a.split[i] = (!bf && q == 0 && k < (int)h->spoff.size() && h->spoff[k].have_n && h->wsp.p) ? h->wsp.as<uint16_t>() + h->spoff[k].n_ch[i] : nullptr;
+    const bool sp = !bf && k < (int)h->spoff.size() && h->spoff[k].have_n && h->wsp.p;
+    for (int i = 0; i < 6; ++i) a.split[i] = (sp && q == 0) ? h->wsp.as<uint16_t>() + h->spoff[k].n_ch[i] : nullptr;
+    if (sp && h->nsets == 2) {
+        if (q == 1)                                     // the projection of set 1 (mode 2): its WP / WQ pieces
+            for (int i = 0; i < 2; ++i) a.split[4 + i] = h->wsp.as<uint16_t>() + h->spoff[k].n2_ch[1 + i];
+        a.split[6] = h->wsp.as<uint16_t>() + h->spoff[k].n2_ch[0];
+    }
     return a;
 }
 
@@ -771,9 +776,9 @@ int mgn_set_params(mgn_handle* h, const float* packed, size_t n) try {
     }
     h->spoff.clear();
     if (c.dtype == MGN_F32 && L == 128 && c.hidden_layers == 2) {      // bf16 pieces of the split path (split.hip): 4.4 MB per edge set,
-        const bool node_side = S == 1;                                  //   8.8 MB for the node side (one edge set)
+        const bool node_side = S <= 2;                                  //   8.8 MB for the node side (+ 4.4 MB with a second edge set)
         const bool ring16 = edge_ring16_enabled() != 0;                 // k_edge_ring16's fragment order next to the default one
-        std::vector<uint16_t> ws((size_t)c.mps * S * 3 * 3 * 16384 * (ring16 ? 2 : 1) + (node_side ? (size_t)(c.mps + 1) * 6 * 3 * 16384 : 0));
+        std::vector<uint16_t> ws((size_t)c.mps * S * 3 * 3 * 16384 * (ring16 ? 2 : 1) + (node_side ? (size_t)(c.mps + 1) * (S == 2 ? 9 : 6) * 3 * 16384 : 0));
         h->spoff.assign(c.mps + 1, {});
         size_t off = 0;
         for (int k = 0; k < c.mps; ++k)
@@ -802,6 +807,16 @@ int mgn_set_params(mgn_handle* h, const float* packed, size_t n) try {
                 pack_chunk_split(ws.data() + off, src[i], L, kb[i]);
                 h->spoff[k].n_ch[i] = off;
                 off += (size_t)3 * 16384;
+            }
+            if (S == 2) {                                               // second edge set: its aggregate block of the node MLP, its projection
+                const MlpOff& n1 = h->es[1].pe[k + 1 < c.mps ? k + 1 : 0];
+                const float* src2[3] = {p + mn.W[0], p + n1.W[0], p + n1.W[0]};
+                const int kb2[3] = {2 * L, 0, L};
+                for (int i = 0; i < 3; ++i) {
+                    pack_chunk_split(ws.data() + off, src2[i], L, kb2[i]);
+                    h->spoff[k].n2_ch[i] = off;
+                    off += (size_t)3 * 16384;
+                }
             }
             h->spoff[k].have_n = true;
         }
@@ -2482,6 +2497,7 @@ int mgn_debug_fp32_split(int on) { return set_fp32_split(on); }
 // 1: the edge kernel of the split path on v_mfma_f32_16x16x32_bf16 (k_edge_ring16); takes effect at the next mgn_set_params (its weight
 // fragments are packed there).  Returns the old value.  Environment: MGN_EDGE_RING16.
 int mgn_debug_edge_ring16(int on) { return set_edge_ring16(on); }
+int mgn_debug_last_node_kernel(void) { return last_node_kernel(); }   // the same for the node MLP (codes: kernels.hip, launch_node_step)
 int mgn_debug_last_edge_kernel(void) { return last_edge_kernel(); }   // kernels.hip: which family the last fp32 edge launch ran on
 // node numbering policy of the NEXT mgn_set_graph calls (0 never, 1 auto, 2 always breadth-first); returns the old value
 int mgn_debug_renumber(int mode) { const int old = g_renumber; g_renumber = mode; return old; }

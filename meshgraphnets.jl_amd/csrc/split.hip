@@ -27,6 +27,23 @@
 
 namespace mgn {
 
+// Buffer descriptors (a wave-uniform 64-bit base in four scalar registers) + a 32-bit byte offset per lane + a scalar / immediate offset:
+// one address register per stream where 64-bit pointers cost a pair per 4 KiB of reach.  Used where registers are the limit.
+typedef unsigned int u32x4v __attribute__((ext_vector_type(4)));
+struct N16Buf { __amdgpu_buffer_rsrc_t r; };
+DEVINL N16Buf n16_buf(const void* base, int bytes = -1) { return {__builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, 0x00020000)}; }
+constexpr unsigned N16_DROP = 0x80000000u;      // a lane offset beyond every descriptor's range: the store is dropped, without a branch
+DEVINL f32x4 n16_ld(const N16Buf& b, unsigned voff, int soff) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(b.r, (int)voff, soff, 0));
+}
+DEVINL void n16_st(const N16Buf& b, unsigned voff, int soff, f32x4 v) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, v), b.r, (int)voff, soff, 0);
+}
+DEVINL u32x4 n16_ldu(const N16Buf& b, unsigned voff, int soff) { return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(b.r, (int)voff, soff, 0)); }
+
+#ifndef MGN_SP_BUFFER
+#define MGN_SP_BUFFER 1           // sp_layer_otf: streamed weight pieces through buffer descriptors (0: 64-bit pointers)
+#endif
 #ifndef MGN_SP2_INTERLEAVE
 #define MGN_SP2_INTERLEAVE 1      // 1: pin "one MFMA, two VALU" inside every (s, t) group (sched_group_barrier)
 #endif
@@ -34,18 +51,32 @@ namespace mgn {
 // One L x L layer: acc += W^T in, `in` split on the fly.  p1 / p2 / p3: the chunk's hi / mid / lo piece ([s][t][lane] fragments of
 // 8 bf16).  p1 is LDS-resident; G2 / G3: p2 / p3 stream from L2 through register rings D (s, t) groups deep (else LDS too).  The
 // rings are pinned by scheduling fences: left to itself hipcc requests every streamed fragment one MFMA before its use.
-template <bool G2, bool G3, bool RELU, int D>
+template <bool G2, bool G3, bool RELU, int D, bool G1 = false>
 DEVINL void sp_layer_otf(f32x16 (&acc)[4], const f32x16 (&in)[4], const u32x4* p1, const u32x4* p2, const u32x4* p3, int lane) {
     const u32x4* w1 = p1 + lane;
     const u32x4* w2 = p2 + lane;
     const u32x4* w3 = p3 + lane;
-    u32x4 r2[G2 ? D : 1], r3[G3 ? D : 1];
+#if MGN_SP_BUFFER
+    // streamed pieces through buffer descriptors: the lane's offset is ONE register for all of them, the fragment index a scalar
+    const N16Buf b1 = n16_buf(G1 ? p1 : nullptr), b2 = n16_buf(G2 ? p2 : nullptr), b3 = n16_buf(G3 ? p3 : nullptr);
+    const unsigned voff = (unsigned)lane * 16u;
+#define SP_G1(IDX) n16_ldu(b1, voff, (IDX) * 1024)
+#define SP_G2(IDX) n16_ldu(b2, voff, (IDX) * 1024)
+#define SP_G3(IDX) n16_ldu(b3, voff, (IDX) * 1024)
+#else
+#define SP_G1(IDX) w1[(IDX) * 64]
+#define SP_G2(IDX) w2[(IDX) * 64]
+#define SP_G3(IDX) w3[(IDX) * 64]
+#endif
+    u32x4 r1[G1 ? D : 1], r2[G2 ? D : 1], r3[G3 ? D : 1];      // G1: the hi piece streams from L2 as well (a chunk that has no room in LDS)
 #pragma unroll
     for (int d = 0; d < D; ++d) {
-        if constexpr (G2) r2[d] = w2[d * 64];
-        if constexpr (G3) r3[d] = w3[d * 64];
+        if constexpr (G1) r1[d] = SP_G1(d);
+        if constexpr (G2) r2[d] = SP_G2(d);
+        if constexpr (G3) r3[d] = SP_G3(d);
     }
-    u32x4 n1 = w1[0], n2, n3;
+    u32x4 n1, n2, n3;
+    if constexpr (!G1) n1 = w1[0];
     if constexpr (!G2) n2 = w2[0];
     if constexpr (!G3) n3 = w3[0];
     SpPieces p;                                         // the pieces of k-step s
@@ -58,18 +89,19 @@ DEVINL void sp_layer_otf(f32x16 (&acc)[4], const f32x16 (&in)[4], const u32x4* p
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             const int it = 4 * s + t;
-            const u32x4 a1 = n1;
-            u32x4 a2, a3;
+            u32x4 a1, a2, a3;
+            if constexpr (G1) a1 = r1[it % D]; else a1 = n1;
             if constexpr (G2) a2 = r2[it % D]; else a2 = n2;
             if constexpr (G3) a3 = r3[it % D]; else a3 = n3;
             if (it + 1 < 32) {
-                n1 = w1[(it + 1) * 64];
+                if constexpr (!G1) n1 = w1[(it + 1) * 64];
                 if constexpr (!G2) n2 = w2[(it + 1) * 64];
                 if constexpr (!G3) n3 = w3[(it + 1) * 64];
             }
             if (it + D < 32) {
-                if constexpr (G2) r2[it % D] = w2[(it + D) * 64];
-                if constexpr (G3) r3[it % D] = w3[(it + D) * 64];
+                if constexpr (G1) r1[it % D] = SP_G1(it + D);
+                if constexpr (G2) r2[it % D] = SP_G2(it + D);
+                if constexpr (G3) r3[it % D] = SP_G3(it + D);
             }
             if (s < 7) {
                 const int sn = s + 1;
@@ -95,6 +127,10 @@ DEVINL void sp_layer_otf(f32x16 (&acc)[4], const f32x16 (&in)[4], const u32x4* p
         p = n;
     }
 }
+
+#undef SP_G1
+#undef SP_G2
+#undef SP_G3
 
 // ================================================================================================
 // Processor edge step (K3 + K4 + K5) on the split path.  chunk order as in k_edge_step: split[0] = W2, [1] = W3, [2] = W1[2L:3L].
@@ -810,7 +846,13 @@ __global__ __launch_bounds__(NWV * 64, NWV / 4) void k_edge_ring(const EdgeArgs 
 // cores.  split[]: the chunks in NodeArgs.chunk order (0: W2, 1: W3, 2: W1[0:L] (node part), 3: W1[L:2L] (aggregate part)), each as
 // hi / mid / lo pieces.  LDS: the four hi pieces (128 KiB) + tables; mid and lo stream from L2 (sp_layer_otf rings).  The V tile is
 // read again for the residual (its registers carry the aggregate and then the second layer's output meanwhile).
+// TWO: a second edge set -- its aggregate is one more layer-1 block (split[6] = W1[2L:3L]); LDS is full with four hi pieces, so all
+// three pieces of that chunk stream from L2 (rings four groups deep: the same 48 ring registers as two rings of six).
 // ================================================================================================
+#ifndef MGN_SP2_D3
+#define MGN_SP2_D3 4
+#endif
+template <bool TWO>
 __global__ __launch_bounds__(512, 2) void k_node_split(const NodeArgs a) {
     constexpr int NT = 4, L = 128, PC = 16384, D = MGN_SP2_D;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -863,6 +905,11 @@ __global__ __launch_bounds__(512, 2) void k_node_split(const NodeArgs a) {
         sp_layer_otf<true, true, false, D>(acc, x, lvh, gv + 2048, gv + 4096, lane);      // layer 1, node part
         LOAD_AGGREGATE(NT, x, a.rowptr, a.AGG, a.CARRY, a.zero_row);
         sp_layer_otf<true, true, false, D>(acc, x, lah, ga + 2048, ga + 4096, lane);      // layer 1, aggregate part
+        if constexpr (TWO) {                                                              // layer 1, the second edge set's aggregate
+            const u32x4* gb = reinterpret_cast<const u32x4*>(a.split[6]);
+            LOAD_AGGREGATE(NT, x, a.rowptr2, a.AGG2, a.CARRY2, a.zero_row2);
+            sp_layer_otf<true, true, false, MGN_SP2_D3, true>(acc, x, gb, gb + 2048, gb + 4096, lane);
+        }
         tab_frag<NT>(x, tb + T_B2 * L, h);
         sp_layer_otf<true, true, true, D>(x, acc, l2h, g2 + 2048, g2 + 4096, lane);       // layer 2 (ReLU folded into the split)
         tab_frag<NT>(acc, tb + T_B3 * L, h);
@@ -1371,16 +1418,6 @@ DEVINL const f32x4* n16_prow_ptr(const float* base, int64_t row, int L, int g) {
 // offset per lane + a scalar / immediate block offset -- ONE address register per stream where 64-bit pointers cost four pairs (a
 // block is 2 KiB, the immediate of global_load reaches 4): the epilogue holds 160 data registers and has none to spare for addresses.
 // (launch_edge_step runs the kernel only where every array is shorter than 4 GiB: EdgeArgs::off32.)
-typedef unsigned int u32x4v __attribute__((ext_vector_type(4)));
-struct N16Buf { __amdgpu_buffer_rsrc_t r; };
-DEVINL N16Buf n16_buf(const void* base, int bytes = -1) { return {__builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, 0x00020000)}; }
-constexpr unsigned N16_DROP = 0x80000000u;      // a lane offset beyond every descriptor's range: the store is dropped, without a branch
-DEVINL f32x4 n16_ld(const N16Buf& b, unsigned voff, int soff) {
-    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(b.r, (int)voff, soff, 0));
-}
-DEVINL void n16_st(const N16Buf& b, unsigned voff, int soff, f32x4 v) {
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, v), b.r, (int)voff, soff, 0);
-}
 #define N16_LD(BUF, SOFF, OFF) n16_ld(BUF, OFF, SOFF)
 #define N16_ST(BUF, SOFF, OFF, V) n16_st(BUF, OFF, SOFF, V)
 // One L x L layer.  RF = 1: `in` is refilled with block fb of the stream (*rfb at fb * RFS * 16, lane offsets rfo0 / rfo1 per row block) rotated by one k-step (the pieces of blocks 0, 1 wait in side[rb][0 .. 1],
@@ -1624,11 +1661,12 @@ __global__ __launch_bounds__(NWV * 64, NWV / 4) void k_edge_ring16(const EdgeArg
         for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
             for (int fb = 0; fb < 8; ++fb) er[rb][fb] = (MGN_R16_WHATIF & 8) ? y[rb][fb & 3] : N16_LD(ecb, fb * TFB + 256 * rb, tile_off(r16, g));
-#if MGN_R16_TAIL == 0
+#if MGN_R16_TAIL != 1
 #pragma unroll
-        for (int rb = 0; rb < 2; ++rb)       // the blocks of the next tile's e that layer 3 did not take
+        for (int rb = 0; rb < 2; ++rb)       // the blocks of the next tile's e that layer 3 did not take (2: the first half of them)
 #pragma unroll
-            for (int fb = 2 * MGN_R16_RFKS; fb < 8; ++fb) y[rb][fb] = N16_LD(enb, fb * TFB + 256 * rb, tile_off(r16, g));
+            for (int fb = 2 * MGN_R16_RFKS; fb < (MGN_R16_TAIL == 2 ? MGN_R16_RFKS + 4 : 8); ++fb)
+                y[rb][fb] = N16_LD(enb, fb * TFB + 256 * rb, tile_off(r16, g));
 #endif
 #if MGN_R16_EPI_FENCE
         PHASE_FENCE();               // every request of the epilogue is in the queue before its first store (s_waitcnt vmcnt counts in order)
@@ -1760,7 +1798,7 @@ __global__ __launch_bounds__(NWV * 64, NWV / 4) void k_edge_ring16(const EdgeArg
             ir[rb] = irn[rb];
 #if MGN_R16_TAIL
 #pragma unroll                                                          // the blocks of the next tile's e that layer 3 did not take
-            for (int fb = 2 * MGN_R16_RFKS; fb < 8; ++fb) y[rb][fb] = N16_LD(enb, fb * TFB + 256 * rb, tile_off(r16, g));
+            for (int fb = (MGN_R16_TAIL == 2 ? MGN_R16_RFKS + 4 : 2 * MGN_R16_RFKS); fb < 8; ++fb) y[rb][fb] = N16_LD(enb, fb * TFB + 256 * rb, tile_off(r16, g));
 #endif
         }
         tw.tile += tw.stride;
@@ -1791,7 +1829,9 @@ hipError_t launch_edge_ring16(const EdgeArgs& a, const LaunchCfg& lc, hipStream_
 }
 hipError_t launch_node_split(const NodeArgs& a, const LaunchCfg& lc, hipStream_t s) {
     static bool attr_set = false;
-    return sp_launch(k_node_split, a, lc, s, attr_set);
+    static bool attr_set2 = false;
+    if (a.AGG2) return sp_launch(k_node_split<true>, a, lc, s, attr_set2);
+    return sp_launch(k_node_split<false>, a, lc, s, attr_set);
 }
 hipError_t launch_edge_ring2(const EdgeArgs& a, const LaunchCfg& lc, hipStream_t s) {
     static bool attr_set = false;

@@ -76,9 +76,20 @@ def mesh_cyl(seed: int = 1234, n_points: int = 2000):
 
 def world_edges(world_pos: np.ndarray, radius: float, mesh_senders: np.ndarray, mesh_receivers: np.ndarray):
     """Radius graph in world space without self loops and without pairs already joined by a mesh edge (DeepMind
-    flag/cloth world edges).  Dense O(N^2) distances: meant for cloth-sized meshes (N ~ 1.6k)."""
+    flag/cloth world edges).  Dense O(N^2) distances up to 8 k nodes (cloth-sized meshes; the order of the pairs is part of the
+    golden fixtures), a k-d tree above (pairs sorted by (sender, receiver): the same order)."""
     wp = np.asarray(world_pos, np.float64)
     n = wp.shape[0]
+    if n > 8192:
+        from scipy.spatial import cKDTree
+        pairs = cKDTree(wp).query_pairs(radius, output_type="ndarray")          # i < j, distance <= radius
+        d2p = ((wp[pairs[:, 0]] - wp[pairs[:, 1]]) ** 2).sum(-1)
+        pairs = pairs[d2p < radius * radius]
+        both = np.concatenate([pairs, pairs[:, ::-1]], 0).astype(np.int64)
+        key = both[:, 0] * n + both[:, 1]
+        mesh_key = np.asarray(mesh_senders, np.int64) * n + np.asarray(mesh_receivers, np.int64)
+        key = np.setdiff1d(key, mesh_key)                                        # sorted: (sender, receiver) order
+        return (key // n).astype(np.int32), (key % n).astype(np.int32)
     d2 = ((wp[:, None, :] - wp[None, :, :]) ** 2).sum(-1)
     close = d2 < radius * radius
     np.fill_diagonal(close, False)

@@ -162,6 +162,49 @@ def test_split_two_edge_sets(split_on):
     assert rel_max(v1, rv) <= TOL_15 and rel_max(e1, re) <= TOL_15 and rel_max(e21, re2) <= TOL_15
 
 
+def test_split_two_edge_sets_node_side():
+    """78 400 nodes (2 450 node tiles, beyond the cooperative kernels): the node MLP with the second set's aggregate block and both
+    projections run on the split path (k_node_split<true>: the fifth chunk's pieces all stream from L2)"""
+    import ctypes
+    import mgn_amd
+    m = synth.mesh_flag(nx=280, ny=280, radius=0.007)
+    N, E, E2 = m["mesh_pos"].shape[0], m["s"].size, m["s2"].size
+    assert N > 2048 * 32 and E2 > 1000
+    cfg = dict(Fn=12, Fe=7, O=3, L=128, hidden_layers=2, mps=2, Fe2=4)
+    ps = orc.init_params(12, 7, 3, 128, 2, 2, 1234, 0.05, Fe2=4)
+    rng = np.random.default_rng(12)
+    v = rng.standard_normal((N, 128)).astype(np.float32)
+    e = rng.standard_normal((E, 128)).astype(np.float32)
+    e2 = rng.standard_normal((E2, 128)).astype(np.float32)
+    eng = mgn_amd.Engine(12, 7, 3, 128, 2, 2, Fe2=4)
+    eng.set_params(ps)
+    eng.set_graph(m["s"], m["r"], N)
+    eng.set_edge_set(1, m["s2"], m["r2"])
+    eng.latents_import(v, e)
+    eng.edge_latents_import(1, e2)
+    eng.processor_steps_dev(2)
+    lib = mgn_amd.load()
+    lib.mgn_debug_last_node_kernel.restype = ctypes.c_int
+    assert lib.mgn_debug_last_node_kernel() == 6          # (kernels.hip, launch_node_step: k_node_split with two sets)
+    v1, e1 = eng.latents_export()
+    e21 = eng.edge_latents_export(1)
+    rv, re, re2 = orc.processor_steps(ps, cfg, v, e, m["s"], m["r"], 2, set2=(e2, m["s2"], m["r2"]))
+    assert rel_max(v1, rv) <= TOL_15 and rel_max(e1, re) <= TOL_15 and rel_max(e21, re2) <= TOL_15
+    old = set_fp32_split(0)                                # and as close to float64 as the fp32-MFMA kernels
+    try:
+        f32 = mgn_amd.Engine(12, 7, 3, 128, 2, 2, Fe2=4)
+        f32.set_params(ps)
+        f32.set_graph(m["s"], m["r"], N)
+        f32.set_edge_set(1, m["s2"], m["r2"])
+        f32.latents_import(v, e)
+        f32.edge_latents_import(1, e2)
+        f32.processor_steps_dev(2)
+        v0, _ = f32.latents_export()
+    finally:
+        set_fp32_split(old)
+    assert rel_max(v1, rv) <= 2.0 * rel_max(v0, rv) + 1e-7 and not np.array_equal(v0, v1)
+
+
 def test_node_ring_opt_in_kernel(tmp_path):
     """MGN_NODE_RING=1 (read once per process, hence a child process): node MLP + projection of a step in one lock-step launch
     (k_node_ring), on a mesh beyond the cooperative node kernels' range; same tolerances and, by construction, the same bits."""
