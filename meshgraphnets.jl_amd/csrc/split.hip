@@ -108,12 +108,25 @@ DEVINL void sp_layer_otf(f32x16 (&acc)[4], const f32x16 (&in)[4], const u32x4* p
                 sp_split_pair<RELU>(n.h[t], n.m[t], n.l[t], in[sn >> 1][8 * (sn & 1) + 2 * t], in[sn >> 1][8 * (sn & 1) + 2 * t + 1]);
             }
             const sp_bf16x8 bh = sp_op(p.h), bm = sp_op(p.m), bl = sp_op(p.l);
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sp_wop(a3), bh, acc[t], 0, 0, 0);      // small terms first
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sp_wop(a2), bm, acc[t], 0, 0, 0);
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sp_wop(a1), bl, acc[t], 0, 0, 0);
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sp_wop(a2), bh, acc[t], 0, 0, 0);
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sp_wop(a1), bm, acc[t], 0, 0, 0);
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sp_wop(a1), bh, acc[t], 0, 0, 0);
+#ifdef MGN_WHATIF_MFMA16_NODE   // diagnostic (wrong results): matrix time and operand traffic of this layer on v_mfma_f32_16x16x32_bf16
+#define OTF_MFMA(A_, B_)                                                                                               \
+            do {                                                                                                       \
+                f32x4 c0_, c1_;                                                                                        \
+                _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) { c0_[i_] = acc[t][i_]; c1_[i_] = acc[t][4 + i_]; }     \
+                c0_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A_, B_, c0_, 0, 0, 0);                                    \
+                c1_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A_, B_, c1_, 0, 0, 0);                                    \
+                _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) { acc[t][i_] = c0_[i_]; acc[t][4 + i_] = c1_[i_]; }     \
+            } while (0)
+#else
+#define OTF_MFMA(A_, B_) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_, B_, acc[t], 0, 0, 0)
+#endif
+            OTF_MFMA(sp_wop(a3), bh);      // small terms first
+            OTF_MFMA(sp_wop(a2), bm);
+            OTF_MFMA(sp_wop(a1), bl);
+            OTF_MFMA(sp_wop(a2), bh);
+            OTF_MFMA(sp_wop(a1), bm);
+            OTF_MFMA(sp_wop(a1), bh);
+#undef OTF_MFMA
 #if MGN_SP2_INTERLEAVE
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
@@ -849,6 +862,24 @@ __global__ __launch_bounds__(NWV * 64, NWV / 4) void k_edge_ring(const EdgeArgs 
 // TWO: a second edge set -- its aggregate is one more layer-1 block (split[6] = W1[2L:3L]); LDS is full with four hi pieces, so all
 // three pieces of that chunk stream from L2 (rings four groups deep: the same 48 ring registers as two rings of six).
 // ================================================================================================
+// priorities of the node-side split kernels: inside the MFMA chains the older wave of a SIMD (waves 0-3) and the younger one (4-7) may
+// differ, so that the pipe's arbiter pulls the two waves of a SIMD apart instead of letting them share every chain and then both wait
+// in their memory phases at once
+#ifndef MGN_NODE_CPRIO_OLD
+#define MGN_NODE_CPRIO_OLD 0
+#endif
+#ifndef MGN_NODE_CPRIO_YOUNG
+#define MGN_NODE_CPRIO_YOUNG 0
+#endif
+#ifndef MGN_NODE_MPRIO
+#define MGN_NODE_MPRIO MGN_PRIO
+#endif
+#define NODE_CHAIN_PRIO()                                                        \
+    do {                                                                         \
+        if (MGN_NODE_CPRIO_OLD == MGN_NODE_CPRIO_YOUNG) __builtin_amdgcn_s_setprio(MGN_NODE_CPRIO_OLD); \
+        else if (wave < 4) __builtin_amdgcn_s_setprio(MGN_NODE_CPRIO_OLD);       \
+        else __builtin_amdgcn_s_setprio(MGN_NODE_CPRIO_YOUNG);                   \
+    } while (0)
 #ifndef MGN_SP2_D3
 #define MGN_SP2_D3 4
 #endif
@@ -891,7 +922,7 @@ __global__ __launch_bounds__(512, 2) void k_node_split(const NodeArgs a) {
         const bool valid = n < a.n;
         const int nn = valid ? n : 0;
         f32x4* vtile = tile_ptr(a.V, tile, L, lane);
-        __builtin_amdgcn_s_setprio(0);
+        NODE_CHAIN_PRIO();
         tab_frag<NT>(acc, tb + T_B1 * L, h);
 #if defined(MGN_WHATIF_NODE) && (MGN_WHATIF_NODE & 1)   // diagnostic (wrong results): every piece from LDS
         sp_layer_otf<false, false, false, D>(acc, x, lvh, lvh, lvh, lane);
@@ -916,7 +947,7 @@ __global__ __launch_bounds__(512, 2) void k_node_split(const NodeArgs a) {
         sp_layer_otf<true, true, true, D>(acc, x, l3h, g3 + 2048, g3 + 4096, lane);       // layer 3
 #endif
         PHASE_FENCE();
-        __builtin_amdgcn_s_setprio(MGN_PRIO);
+        __builtin_amdgcn_s_setprio(MGN_NODE_MPRIO);
 #if defined(MGN_WHATIF_NODE) && (MGN_WHATIF_NODE & 2)   // diagnostic: the residual reads one cached tile per wave
         load_frag<NT>(x, tile_ptr(a.V, wave, L, lane), STRIDE_TILE);
 #else
@@ -1325,14 +1356,14 @@ __global__ __launch_bounds__(512, 2) void k_project_split(const NodeArgs a) {
         const int n = tile * TILE + c;
         const bool valid = n < a.n;
         const int nn = valid ? n : 0;
-        __builtin_amdgcn_s_setprio(0);
+        NODE_CHAIN_PRIO();
         zero_frag<NT>(acc);
 #if defined(MGN_WHATIF_NODE) && (MGN_WHATIF_NODE & 1)
         sp_layer_otf<false, false, false, D1>(acc, x, lph, lpm, lpm, lane);
 #else
         sp_layer_otf<false, true, false, D1>(acc, x, lph, lpm, gp + 4096, lane);
 #endif
-        __builtin_amdgcn_s_setprio(MGN_PRIO);
+        __builtin_amdgcn_s_setprio(MGN_NODE_MPRIO);
 #if defined(MGN_WHATIF_NODE) && (MGN_WHATIF_NODE & 8)      // diagnostic: P / Q stored tile-major (coalesced) instead of row-major
         if (valid) store_frag<NT>(tile_ptr(a.P, tile, L, lane), STRIDE_TILE, acc);
 #elif defined(MGN_WHATIF_NODE) && (MGN_WHATIF_NODE & 16)   // diagnostic: no P / Q stores
@@ -1340,14 +1371,14 @@ __global__ __launch_bounds__(512, 2) void k_project_split(const NodeArgs a) {
 #else
         if (valid) store_frag<NT>(prow_ptr(a.P, nn, L, h), STRIDE_PROW, acc);
 #endif
-        __builtin_amdgcn_s_setprio(0);
+        NODE_CHAIN_PRIO();
         tab_frag<NT>(acc, tb + T_BQ * L, h);
 #if defined(MGN_WHATIF_NODE) && (MGN_WHATIF_NODE & 1)
         sp_layer_otf<false, false, false, D1>(acc, x, lqh, lqm, lqm, lane);
 #else
         sp_layer_otf<false, true, false, D1>(acc, x, lqh, lqm, gq + 4096, lane);
 #endif
-        __builtin_amdgcn_s_setprio(MGN_PRIO);
+        __builtin_amdgcn_s_setprio(MGN_NODE_MPRIO);
 #if MGN_NODE_VNEXT_FIRST
         PHASE_FENCE();
         if (has_next) load_frag<NT>(x, tile_ptr(a.V, a.tile0 + next, L, lane), STRIDE_TILE);   // ahead of the Q stores (x is dead: both projections read it)
@@ -1527,6 +1558,14 @@ DEVINL void sp16_layer_ring(f32x4 (&acc)[2][8], f32x4 (&in)[2][8], const u32x4* 
     }
 }
 
+// sum over the four lane groups (lanes l, l ^ 16, l ^ 32, l ^ 48), the same value in all of them.  (v_permlane16 / 32_swap instead of the
+// two LDS-crossbar round trips, and the scan's carry between the row blocks as a DPP row rotation instead of 32 ds_swizzle: built, 3.198
+// vs 3.203 ms -- nothing -- and taken out again.)
+DEVINL float n16_sum4(float x) {
+    x += __shfl_xor(x, 16, 64);
+    x += __shfl_xor(x, 32, 64);
+    return x;
+}
 #define RG16_SCAN_LEVEL(ACC, COND, CTRL)                                                                                     \
     do {                                                                                                                     \
         const float m_ = (COND) ? 1.f : 0.f;                                                                                 \
@@ -1681,8 +1720,7 @@ __global__ __launch_bounds__(NWV * 64, NWV / 4) void k_edge_ring16(const EdgeArg
                 for (int fb = 0; fb < 8; ++fb)
 #pragma unroll
                     for (int i = 0; i < 4; ++i) sm += acc[rb][fb][i];
-                sm += __shfl_xor(sm, 16, 64);
-                sm += __shfl_xor(sm, 32, 64);
+                sm = n16_sum4(sm);
                 const float mean = sm * invL;
                 float q = 0.f;
 #pragma unroll
@@ -1693,8 +1731,7 @@ __global__ __launch_bounds__(NWV * 64, NWV / 4) void k_edge_ring16(const EdgeArg
                         acc[rb][fb][i] = d;
                         q += d * d;
                     }
-                q += __shfl_xor(q, 16, 64);
-                q += __shfl_xor(q, 32, 64);
+                q = n16_sum4(q);
                 rstd[rb] = ln_rstd_at(q * invL, tb + T_LN * L);
             }
             const f32x4* g4 = reinterpret_cast<const f32x4*>(tb + T_GAMMA * L) + g;
