@@ -1654,7 +1654,9 @@ __global__ __launch_bounds__(NWV * 64, NWV / 4) void k_edge_ring16(const EdgeArg
             side[rb][1] = N16_LD(Pb, PFB, po);
         }
     }
-    for (int j = 0; j < iters; ++j) {
+    int stamp_tile = 0;
+    (void)stamp_tile;
+    for (int j = 0; j < iters; ++j, ++stamp_tile) {
         int lane = lane0;
         asm volatile("" : "+v"(lane));
         const int r16 = lane & 15, g = lane >> 4;
@@ -1663,6 +1665,7 @@ __global__ __launch_bounds__(NWV * 64, NWV / 4) void k_edge_ring16(const EdgeArg
         const int nxt = clamp(tw.tile + tw.stride);
         u32x4* ring = ringbase + lane;
         __builtin_amdgcn_s_setprio(0);
+        STAMP(0);
         RingFrag nx = ring_first<W, 0>(l1h, ring, lane);
         // layer 1 (edge part): y = e tile in, P[s] out (acc entered with Q[r], which carries b1)
         sp16_layer_ring<W, 0, false, 1, N16_PROW_FB, NWV>(acc, y, l1h, l2h, ring, src, nx, lane, tid, &Pb, prow_off(is[0], g), prow_off(is[1], g), side);
@@ -1670,22 +1673,27 @@ __global__ __launch_bounds__(NWV * 64, NWV / 4) void k_edge_ring16(const EdgeArg
         for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
             for (int fb = 0; fb < 8; ++fb) acc[rb][fb] += y[rb][fb];
+        CST(1);
         {
             const f32x4* t4 = reinterpret_cast<const f32x4*>(tb + T_B2 * L) + g;
 #pragma unroll
             for (int fb = 0; fb < 8; ++fb) y[0][fb] = y[1][fb] = t4[4 * fb];
         }
+        CST(2);
         sp16_layer_ring<W, 1, true, 0, 0, NWV>(y, acc, l2h, l3h, ring, src, nx, lane, tid);      // layer 2 (ReLU folded into the split)
+        CST(3);
         {
             const f32x4* t4 = reinterpret_cast<const f32x4*>(tb + T_B3 * L) + g;
 #pragma unroll
             for (int fb = 0; fb < 8; ++fb) acc[0][fb] = acc[1][fb] = t4[4 * fb];
         }
+        CST(4);
         const N16Buf ecb = tile_buf(tile), enb = tile_buf(nxt);
         // layer 3: y = layer 2's output in, the NEXT tile's e out (blocks 0 .. 5; 6, 7 at the start of the epilogue)
         sp16_layer_ring<W, 2, true, 2, N16_TILE_FB, NWV, MGN_R16_RFKS>(acc, y, l3h, l1h, ring, src, nx, lane, tid, &enb, tile_off(r16, g),
                                                                        tile_off(r16, g) + 256u);
         PHASE_FENCE();
+        CST(5);
         __builtin_amdgcn_s_setprio(MGN_PRIO);
         // the indices the epilogue needs -- the next tile's rows, the receivers either side of this tile -- are requested here, not at
         // the top of the tile: nothing index-shaped stays live across the three layers (the allocator spilled them where they landed,
@@ -1748,6 +1756,7 @@ __global__ __launch_bounds__(NWV * 64, NWV / 4) void k_edge_ring16(const EdgeArg
 #endif
             }
         }
+        CST(6);
         bool valid[2];
 #pragma unroll
         for (int rb = 0; rb < 2; ++rb) {
@@ -1761,6 +1770,7 @@ __global__ __launch_bounds__(NWV * 64, NWV / 4) void k_edge_ring16(const EdgeArg
                 for (int fb = 0; fb < 8; ++fb) N16_ST(ecb, fb * TFB + 256 * rb, eo, er[rb][fb]);
             }
         }
+        CST(7);
         // ---- segmented sum of e' over runs of equal receiver: rows 0 .. 15 in block 0, 16 .. 31 in block 1, one DPP row per lane group
         const int cA = r16, cB = 16 + r16;
         const int reffA = ir[0] >= 0 ? ir[0] : (-4 - cA), reffB = ir[1] >= 0 ? ir[1] : (-4 - cB);
