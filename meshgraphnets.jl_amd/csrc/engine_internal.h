@@ -126,7 +126,7 @@ struct mgn_engine {
     // split path (csrc/split.hip: fp32 storage, products on the bf16 matrix cores): per step and set the three edge chunks, per step the
     // node MLP's four and the projection's two, as 3 bf16 pieces each
     DevBuf wsp;
-    struct SplitOff { size_t e_ch[MAX_EDGE_SETS][3], e16_ch[MAX_EDGE_SETS][3]; size_t n_ch[6], n2_ch[3]; bool have_n; };   // n2_ch (two edge sets): W1[2L:3L], WP / WQ of set 1
+    struct SplitOff { size_t e_ch[MAX_EDGE_SETS][3], e16_ch[MAX_EDGE_SETS][3]; size_t n_ch[6], n2_ch[3], n16_ch[9]; bool have_n; };   // n2_ch (two edge sets): W1[2L:3L], WP / WQ of set 1
     std::vector<SplitOff> spoff;
     // static per-trajectory RHS inputs (mgn_set_static): cached encoded edge latents
     bool have_static = false;

@@ -81,6 +81,7 @@ struct NodeArgs {
     unsigned long long* stamps;  // diagnostic builds only (MGN_DIAG_STAMPS), else null
     // split path (see EdgeArgs.split): chunk[0..5] as 3 x 16384 bf16 pieces each (k_node_split, k_project_split); null: not available
     const uint16_t* split[7];     // [6]: W1[2L:3L], the second edge set's aggregate block (k_node_split<true>)
+    const uint16_t* split16[9];   // chunk[0..8] as pieces in the 16x16x32 fragment order (k_node_coop16 on the split path); null: not available
 };
 
 struct EncNodeArgs {
@@ -187,6 +188,8 @@ int set_fp32_split(int on);     // debug/tests: 0 = fp32-MFMA kernels, 1 = split
 int fp32_split_enabled();
 int set_edge_ring16(int on);    // 1: k_edge_ring16 (v_mfma_f32_16x16x32_bf16) where k_edge_ring would run; MGN_EDGE_RING16; returns the old value
 int edge_ring16_enabled();
+int set_c16_split(int on);      // 16-row cooperative kernels on the split path (where fp32_split is on): bit 0 edge kernel at >= 2 row tiles, bit 1 node kernel (default 3), bit 2 edge kernel at one row tile too; MGN_C16_SPLIT
+int c16_split_enabled();
 int set_c16_row_tiles(int rt);  // debug/tests: 16-edge tiles per block of the small-graph edge kernel (0: chosen by size); returns the old value
 int set_kernel_path(int p);   // debug/tests: 0 auto, 1 resident, 2 streaming, 3 cooperative, 4 GEN (general hidden_layers) kernels; returns the old value
 int get_kernel_path();

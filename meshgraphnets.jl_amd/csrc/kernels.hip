@@ -28,6 +28,7 @@
 #include "frag.hpp"
 #include "kernels.h"
 #include "tile_common.hpp"
+#include "split_common.hpp"
 
 #include <cstdlib>
 #include <mutex>
@@ -688,19 +689,96 @@ DEVINL void c16m_layer_norm(f32x4 (&mine)[RT][2], float* red, const f32x4 (&g)[2
     }
 }
 
-template <int RT, bool BF>
+// ---- the same kernels on the split path (SP): the L x L chunks on v_mfma_f32_16x16x32_bf16, every fp32 operand as three bf16 pieces,
+// six piece products (split.hip) -- 48 RT MFMAs of 16 cycles per chunk and wave instead of 64 RT of 32.  The accumulator layout is the
+// fp32 kernels' (lane (n, q): features 16 ob + 4 q + i of row n), and k-step ks of the next layer takes blocks 2 ks, 2 ks + 1 -- exactly
+// the two blocks wave ks owns: a wave splits ITS slice (ReLU folded in) and the four waves exchange PIECES through LDS (12 KiB per tile
+// instead of 8, no redundant split).  Weight pieces: EdgeArgs / NodeArgs::split16 (mgn_api.cpp: pack_chunk16_bf16, [ks][ob][lane][8 bf16]).
+struct C16P { u32x4 h, m, l; };            // one k-step's B operand of a 16-row tile
+template <bool RELU>
+DEVINL C16P c16s_split(const f32x4 (&mine)[2]) {
+    C16P p;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        unsigned h, m, l;
+        sp_split_pair<RELU>(h, m, l, mine[u >> 1][2 * (u & 1)], mine[u >> 1][2 * (u & 1) + 1]);
+        p.h[u] = h; p.m[u] = m; p.l[u] = l;
+    }
+    return p;
+}
+template <int RT, bool RELU>
+DEVINL void c16s_exchange(C16P (&full)[RT][4], const f32x4 (&mine)[RT][2], u32x4* xch, int wave, int lane) {
+#pragma unroll
+    for (int t = 0; t < RT; ++t) {
+        const C16P p = c16s_split<RELU>(mine[t]);
+        xch[((t * 4 + wave) * 3 + 0) * 64 + lane] = p.h;
+        xch[((t * 4 + wave) * 3 + 1) * 64 + lane] = p.m;
+        xch[((t * 4 + wave) * 3 + 2) * 64 + lane] = p.l;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < RT; ++t)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            full[t][ks].h = xch[((t * 4 + ks) * 3 + 0) * 64 + lane];
+            full[t][ks].m = xch[((t * 4 + ks) * 3 + 1) * 64 + lane];
+            full[t][ks].l = xch[((t * 4 + ks) * 3 + 2) * 64 + lane];
+        }
+}
+// the weight pieces of a chunk stream from L2 through a register ring C16S_PF (k-step, block) steps deep; step s = 2 ks + j feeds
+// this wave's output block 2 wave + j
+#ifndef C16S_PF
+#define C16S_PF 3
+#endif
+struct C16SRing { u32x4 r[3 * C16S_PF]; };
+DEVINL const u32x4* c16s_w(const uint16_t* chunk, int wave, int lane) { return reinterpret_cast<const u32x4*>(chunk) + (2 * wave) * 64 + lane; }
+DEVINL void c16s_prime(C16SRing& g, const u32x4* wv) {
+#pragma unroll
+    for (int s = 0; s < C16S_PF; ++s)
+#pragma unroll
+        for (int pc = 0; pc < 3; ++pc) g.r[3 * s + pc] = wv[pc * 2048 + ((s >> 1) * 8 + (s & 1)) * 64];
+}
+template <int RT, int S0 = 0, int S1 = 8>
+DEVINL void c16s_chain(f32x4 (&acc)[RT][2], const C16P (&x)[RT][4], const u32x4* wv, C16SRing& g) {
+#pragma unroll
+    for (int s = S0; s < S1; ++s) {
+        const u32x4 a1 = g.r[3 * (s % C16S_PF)], a2 = g.r[3 * (s % C16S_PF) + 1], a3 = g.r[3 * (s % C16S_PF) + 2];
+        if (s + C16S_PF < 8) {
+            const int sn = s + C16S_PF;
+#pragma unroll
+            for (int pc = 0; pc < 3; ++pc) g.r[3 * (s % C16S_PF) + pc] = wv[pc * 2048 + ((sn >> 1) * 8 + (sn & 1)) * 64];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const int ks = s >> 1, j = s & 1;
+#pragma unroll
+        for (int t = 0; t < RT; ++t) {
+            const sp_bf16x8 bh = sp_wop(x[t][ks].h), bm = sp_wop(x[t][ks].m), bl = sp_wop(x[t][ks].l);
+            acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(sp_wop(a3), bh, acc[t][j], 0, 0, 0);      // small terms first
+            acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(sp_wop(a2), bm, acc[t][j], 0, 0, 0);
+            acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(sp_wop(a1), bl, acc[t][j], 0, 0, 0);
+            acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(sp_wop(a2), bh, acc[t][j], 0, 0, 0);
+            acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(sp_wop(a1), bm, acc[t][j], 0, 0, 0);
+            acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(sp_wop(a1), bh, acc[t][j], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+template <int RT, bool BF, bool SP = false>
 __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_edge_coop16m(const EdgeArgs a) {
     constexpr int L = 128;
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int XCH = SP ? RT * 12 * 64 : RT * 8 * 64;            // 16-byte slots of one exchange buffer (SP: pieces, 12 KiB per tile)
     f32x4* xch0 = reinterpret_cast<f32x4*>(smem);
-    f32x4* xch1 = xch0 + RT * 8 * 64;
-    float* red = reinterpret_cast<float*>(xch1 + RT * 8 * 64);      // LayerNorm partials: 2 x [RT][4 waves][16 rows]
+    f32x4* xch1 = xch0 + XCH;
+    float* red = reinterpret_cast<float*>(xch1 + XCH);              // LayerNorm partials: 2 x [RT][4 waves][16 rows]
     const int lane0 = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const float* tabs = a.tabs + T_COUNT * L;                       // natural feature order
     const float* w1 = a.chunk[2] + 2 * C16_CH + wave * 4096;
     const float* w2 = a.chunk[0] + 2 * C16_CH + wave * 4096;
     const float* w3 = a.chunk[1] + 2 * C16_CH + wave * 4096;
+
     const int ht0 = 2 * a.tile0, nht = 2 * a.ntiles;
     const int ngroups = (nht + RT - 1) / RT;
     for (int gi = blockIdx.x; gi < ngroups; gi += gridDim.x) {
@@ -708,6 +786,9 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
         int lane = lane0;
         asm volatile("" : "+v"(lane));      // keeps the (loop-invariant) weight and table loads inside the loop: hoisted, they spill
         const int n = lane & 15, q = lane >> 4;
+        const u32x4* s1 = SP ? c16s_w(a.split16[2], wave, lane) : nullptr;      // (lane folded in: the ring requests are this + constants)
+        const u32x4* s2 = SP ? c16s_w(a.split16[0], wave, lane) : nullptr;
+        const u32x4* s3 = SP ? c16s_w(a.split16[1], wave, lane) : nullptr;
         if ((int64_t)(ht0 + gi * RT) * 16 >= a.E) break;            // nothing but the empty tail of the last 32-row tile
         int ht[RT], s_[RT], r_[RT], r_before[RT], r_after[RT], row[RT];
         int64_t tile[RT];
@@ -742,21 +823,27 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
             xs[t][1] = c16_ld_tile<BF>(a.Elat, tile[t], row[t], 2 * wave + 1, q);
         }
         C16Ring g1, g2;
-        c16_prime(g1, w1, lane);
+        C16SRing h1, h2;
+        C16P xp[RT][4];
+        if constexpr (SP) c16s_prime(h1, s1);
+        else c16_prime(g1, w1, lane);
 #pragma unroll
         for (int t = 0; t < RT; ++t) acc[t][0] = acc[t][1] = f32x4{0.f, 0.f, 0.f, 0.f};
-        c16m_exchange<RT>(x, xs, xch0, wave, lane);
+        if constexpr (SP) c16s_exchange<RT, false>(xp, xs, reinterpret_cast<u32x4*>(xch0), wave, lane);
+        else c16m_exchange<RT>(x, xs, xch0, wave, lane);
         __builtin_amdgcn_sched_barrier(0);
         STAMP16(1);
         // layer 1: the e tile's part starts as soon as the tile and the first weights are here; the gathered P[s] + Q[r] (which
         // carry b1) are requested half way -- their addresses wait for the index loads, a serial round trip -- and added at the end
-        c16m_chain<RT, 0, 4>(acc, x, w1, lane, g1);
+        if constexpr (SP) c16s_chain<RT, 0, 4>(acc, xp, s1, h1);
+        else c16m_chain<RT, 0, 4>(acc, x, w1, lane, g1);
         f32x4 tb2[2], tb3[2], tg[2], tb[2];
         c16_tab(tb2, tabs + T_B2 * L, wave, q);
         c16_tab(tb3, tabs + T_B3 * L, wave, q);
         c16_tab(tg, tabs + T_GAMMA * L, wave, q);
         c16_tab(tb, tabs + T_BETA * L, wave, q);
-        c16_prime(g2, w2, lane);                                     // layer 2's first fragments
+        if constexpr (SP) c16s_prime(h2, s2);
+        else c16_prime(g2, w2, lane);                                // layer 2's first fragments
         f32x4 pq[RT][2][2];
 #pragma unroll
         for (int t = 0; t < RT; ++t) {
@@ -765,13 +852,27 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
             pq[t][1][0] = c16_ld_row<BF>(a.Q, r_[t], 2 * wave, q);
             pq[t][1][1] = c16_ld_row<BF>(a.Q, r_[t], 2 * wave + 1, q);
         }
-        c16m_chain<RT, 4, 8>(acc, x, w1, lane, g1);
+        if constexpr (SP) c16s_chain<RT, 4, 8>(acc, xp, s1, h1);
+        else c16m_chain<RT, 4, 8>(acc, x, w1, lane, g1);
 #pragma unroll
         for (int t = 0; t < RT; ++t) {
             acc[t][0] += pq[t][0][0] + pq[t][1][0];
             acc[t][1] += pq[t][0][1] + pq[t][1][1];
         }
         STAMP16(2);
+        if constexpr (SP) {                                          // (the ReLUs are folded into the split of the exchange)
+            c16s_prime(h1, s3);
+            c16s_exchange<RT, true>(xp, acc, reinterpret_cast<u32x4*>(xch1), wave, lane);
+            STAMP16(3);
+#pragma unroll
+            for (int t = 0; t < RT; ++t) { acc[t][0] = tb2[0]; acc[t][1] = tb2[1]; }
+            c16s_chain<RT>(acc, xp, s2, h2);                         // layer 2
+            STAMP16(4);
+            c16s_exchange<RT, true>(xp, acc, reinterpret_cast<u32x4*>(xch0), wave, lane);
+#pragma unroll
+            for (int t = 0; t < RT; ++t) { acc[t][0] = tb3[0]; acc[t][1] = tb3[1]; }
+            c16s_chain<RT>(acc, xp, s3, h1);                         // layer 3
+        } else {
 #pragma unroll
         for (int t = 0; t < RT; ++t) c16_relu(acc[t]);
         c16_prime(g1, w3, lane);
@@ -787,6 +888,7 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
 #pragma unroll
         for (int t = 0; t < RT; ++t) { acc[t][0] = tb3[0]; acc[t][1] = tb3[1]; }
         c16m_chain<RT>(acc, x, w3, lane, g1);                        // layer 3
+        }
         STAMP16(5);
         c16m_layer_norm<RT>(acc, red, tg, tb, wave, n, tabs + T_LN * L);              // acc = this wave's slice of e'
         STAMP16(6);
@@ -869,6 +971,41 @@ DEVINL void c16_agg_slice(f32x4 (&as)[2], const int32_t* rowptr, const float* AG
             as[1] += c16_ld_row<BF>(CARRY, (int64_t)2 * (T1 + k), 2 * wave + 1, q);
         }
 }
+// split path: one slice -> its pieces in an exchange buffer / all four k-steps' pieces back (no barrier: the caller's)
+template <bool RELU>
+DEVINL void c16s_put(u32x4* xch, const f32x4 (&mine)[2], int wave, int lane) {
+    const C16P p = c16s_split<RELU>(mine);
+    xch[(wave * 3 + 0) * 64 + lane] = p.h;
+    xch[(wave * 3 + 1) * 64 + lane] = p.m;
+    xch[(wave * 3 + 2) * 64 + lane] = p.l;
+}
+DEVINL void c16s_get(C16P (&full)[1][4], const u32x4* xch, int lane) {
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        full[0][ks].h = xch[(ks * 3 + 0) * 64 + lane];
+        full[0][ks].m = xch[(ks * 3 + 1) * 64 + lane];
+        full[0][ks].l = xch[(ks * 3 + 2) * 64 + lane];
+    }
+}
+template <bool BF>
+DEVINL void c16s_project(const C16P (&v)[1][4], const u32x4* wp, const u32x4* wq, const float* bq, float* P, float* Q, bool valid, int nn,
+                         int wave, int q, C16SRing& ga, C16SRing& gb, const u32x4* next_wp) {
+    f32x4 o[1][2];
+    o[0][0] = o[0][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    c16s_prime(gb, wq);
+    c16s_chain<1>(o, v, wp, ga);
+    if (valid) {
+        c16_st_row<BF>(P, nn, 2 * wave, q, o[0][0]);
+        c16_st_row<BF>(P, nn, 2 * wave + 1, q, o[0][1]);
+    }
+    c16_tab(o[0], bq, wave, q);
+    if (next_wp) c16s_prime(ga, next_wp);
+    c16s_chain<1>(o, v, wq, gb);
+    if (valid) {
+        c16_st_row<BF>(Q, nn, 2 * wave, q, o[0][0]);
+        c16_st_row<BF>(Q, nn, 2 * wave + 1, q, o[0][1]);
+    }
+}
 // P = v W_P, Q = v W_Q + bq for this wave's blocks of one edge set (ga primed with wp's first fragments; gb is primed here)
 template <bool BF>
 DEVINL void c16_project(const f32x4 (&v)[1][8], const float* wp, const float* wq, const float* bq, float* P, float* Q, bool valid, int nn,
@@ -889,25 +1026,28 @@ DEVINL void c16_project(const f32x4 (&v)[1][8], const float* wp, const float* wq
         c16_st_row<BF>(Q, nn, 2 * wave + 1, q, o[0][1]);
     }
 }
-template <int SETS, bool BF>
+template <int SETS, bool BF, bool SP = false>
 __global__ __launch_bounds__(256, 2) void k_node_coop16(const NodeArgs a) {
     constexpr int L = 128;
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int XCH = SP ? 12 * 64 : 8 * 64;                      // 16-byte slots of an exchange buffer (SP: pieces)
     f32x4* xch0 = reinterpret_cast<f32x4*>(smem);
-    f32x4* xch1 = xch0 + 8 * 64;
-    f32x4* xch2 = xch1 + 8 * 64;
-    f32x4* xch3 = xch2 + 8 * 64;                                     // (SETS == 2 only)
-    float* red = reinterpret_cast<float*>(xch2 + (SETS == 2 ? 2 : 1) * 8 * 64);
+    f32x4* xch1 = xch0 + XCH;
+    f32x4* xch2 = xch1 + XCH;
+    f32x4* xch3 = xch2 + XCH;                                        // (SETS == 2 only)
+    float* red = reinterpret_cast<float*>(xch2 + (SETS == 2 ? 2 : 1) * XCH);
     const int lane0 = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const float* tabs = a.tabs + T_COUNT * L;
     auto wt = [&](int ch) { return a.chunk[ch] + 2 * C16_CH + wave * 4096; };
+
     const int ht0 = 2 * a.tile0, nht = 2 * a.ntiles;
     for (int hi = blockIdx.x; hi < nht; hi += gridDim.x) {
         STAMP16(0);
         int lane = lane0;
         asm volatile("" : "+v"(lane));
         const int n = lane & 15, q = lane >> 4;
+        auto ws = [&](int ch) { return c16s_w(a.split16[ch], wave, lane); };    // (SP) the chunk's pieces, this wave's blocks
         const int ht = ht0 + hi;
         const int node = ht * 16 + n;
         if (ht * 16 >= a.n) break;
@@ -919,7 +1059,87 @@ __global__ __launch_bounds__(256, 2) void k_node_coop16(const NodeArgs a) {
         vs[0][0] = c16_ld_tile<BF>(a.V, tile, row, 2 * wave, q);
         vs[0][1] = c16_ld_tile<BF>(a.V, tile, row, 2 * wave + 1, q);
         C16Ring ga, gb;
-        if (a.mode != 2) {
+        if constexpr (SP) {
+            C16SRing ha, hb;
+            C16P vp[1][4], fp[1][4];
+            u32x4* const x0 = reinterpret_cast<u32x4*>(xch0);
+            u32x4* const x1 = reinterpret_cast<u32x4*>(xch1);
+            u32x4* const x2 = reinterpret_cast<u32x4*>(xch2);
+            u32x4* const x3 = reinterpret_cast<u32x4*>(xch3);
+            if (a.mode != 2) {
+                f32x4 as[2], as2[2];
+                c16_agg_slice<BF>(as, a.rowptr, a.AGG, a.CARRY, a.zero_row, valid, nn, tile, row, wave, q);
+                if constexpr (SETS == 2) c16_agg_slice<BF>(as2, a.rowptr2, a.AGG2, a.CARRY2, a.zero_row2, valid, nn, tile, row, wave, q);
+                c16s_prime(ha, ws(2));
+                c16_tab(acc[0], tabs + T_B1 * L, wave, q);
+                c16s_put<false>(x0, vs[0], wave, lane);
+                c16s_put<false>(x1, as, wave, lane);
+                if constexpr (SETS == 2) c16s_put<false>(x2, as2, wave, lane);
+                __syncthreads();
+                c16s_get(vp, x0, lane);
+                __builtin_amdgcn_sched_barrier(0);
+                STAMP16(1);
+                c16s_chain<1, 0, 4>(acc, vp, ws(2), ha);                 // layer 1, node part
+                f32x4 tb2[2], tb3[2], tg[2], tb[2];
+                c16_tab(tb2, tabs + T_B2 * L, wave, q);
+                c16_tab(tb3, tabs + T_B3 * L, wave, q);
+                c16_tab(tg, tabs + T_GAMMA * L, wave, q);
+                c16_tab(tb, tabs + T_BETA * L, wave, q);
+                c16s_prime(hb, ws(3));
+                c16s_chain<1, 4, 8>(acc, vp, ws(2), ha);
+                STAMP16(2);
+                c16s_prime(ha, ws(SETS == 2 ? 6 : 0));
+                __builtin_amdgcn_sched_barrier(0);                       // (the aggregate's pieces only now: 48 registers the node part no longer needs)
+                c16s_get(fp, x1, lane);
+                c16s_chain<1>(acc, fp, ws(3), hb);                       // layer 1, aggregate part
+                if constexpr (SETS == 2) {
+                    c16s_get(fp, x2, lane);
+                    c16s_prime(hb, ws(0));
+                    c16s_chain<1>(acc, fp, ws(6), ha);                   // layer 1, the second set's aggregate
+                }
+                C16SRing& r2 = SETS == 2 ? hb : ha;                      // the ring that holds layer 2's first fragments
+                C16SRing& r3 = SETS == 2 ? ha : hb;
+                STAMP16(3);
+                c16s_prime(r3, ws(1));
+                c16s_put<true>(SETS == 2 ? x3 : x2, acc[0], wave, lane); // (ReLU folded into the split)
+                __syncthreads();
+                c16s_get(fp, SETS == 2 ? x3 : x2, lane);
+                acc[0][0] = tb2[0];
+                acc[0][1] = tb2[1];
+                c16s_chain<1>(acc, fp, ws(0), r2);                       // layer 2
+                STAMP16(4);
+                if (a.mode == 1) c16s_prime(r2, ws(4));                  // the projection's first fragments
+                c16s_put<true>(x0, acc[0], wave, lane);
+                __syncthreads();
+                c16s_get(fp, x0, lane);
+                acc[0][0] = tb3[0];
+                acc[0][1] = tb3[1];
+                c16s_chain<1>(acc, fp, ws(1), r3);                       // layer 3
+                c16m_layer_norm<1>(acc, red, tg, tb, wave, n, tabs + T_LN * L);
+                STAMP16(5);
+                acc[0][0] = c16_round<BF>(acc[0][0] + vs[0][0]);         // v <- v + v'
+                acc[0][1] = c16_round<BF>(acc[0][1] + vs[0][1]);
+                if (valid) {
+                    c16_st_tile<BF>(a.V, tile, row, 2 * wave, q, acc[0][0]);
+                    c16_st_tile<BF>(a.V, tile, row, 2 * wave + 1, q, acc[0][1]);
+                }
+                if (a.mode == 1) {                                       // P, Q of the next step, on the updated rows
+                    c16s_put<false>(x1, acc[0], wave, lane);
+                    __syncthreads();
+                    c16s_get(vp, x1, lane);
+                    STAMP16(6);
+                    c16s_project<BF>(vp, ws(4), ws(5), tabs + T_BQ * L, a.P, a.Q, valid, nn, wave, q, r2, r3, SETS == 2 ? ws(7) : nullptr);
+                    if constexpr (SETS == 2)
+                        c16s_project<BF>(vp, ws(7), ws(8), a.tabs2 + (T_COUNT + T_BQ) * L, a.P2, a.Q2, valid, nn, wave, q, r2, r3, nullptr);
+                }
+            } else {                                                     // projection only (before the first step; one set per launch)
+                c16s_prime(ha, ws(4));
+                c16s_put<false>(x0, vs[0], wave, lane);
+                __syncthreads();
+                c16s_get(vp, x0, lane);
+                c16s_project<BF>(vp, ws(4), ws(5), tabs + T_BQ * L, a.P, a.Q, valid, nn, wave, q, ha, hb, nullptr);
+            }
+        } else if (a.mode != 2) {
             f32x4 as[2], as2[2];
             c16_agg_slice<BF>(as, a.rowptr, a.AGG, a.CARRY, a.zero_row, valid, nn, tile, row, wave, q);
             if constexpr (SETS == 2) c16_agg_slice<BF>(as2, a.rowptr2, a.AGG2, a.CARRY2, a.zero_row2, valid, nn, tile, row, wave, q);
@@ -2305,6 +2525,13 @@ static int g_c16_rt = [] { const char* e = getenv("MGN_C16_RT"); return e ? atoi
 static int g_fp32_split = [] { const char* e = getenv("MGN_FP32_SPLIT"); return e ? atoi(e) : 1; }();
 int set_fp32_split(int on) { const int old = g_fp32_split; g_fp32_split = on; return old; }
 int fp32_split_enabled() { return g_fp32_split; }
+// 16-row cooperative kernels on the split path: bit 0 the edge kernel (with two or three row tiles per block its chains are
+// matrix-bound on the fp32 pipe: 17.2 -> 14.1 us on the cylinder mesh), bit 1 the node kernel (one row tile per block streams 96 KiB of
+// weight pieces per chunk where the fp32 fragments are 64 and is bound by that stream either way: 11.6 -> 11.3 us), bit 2 the edge
+// kernel at one row tile per block as well.  Cylinder mesh, per processor step: 29.3 us (0), 26.1 (1), 25.8 (3, the default).
+static int g_c16_split = [] { const char* e = getenv("MGN_C16_SPLIT"); return e ? atoi(e) : 3; }();
+int set_c16_split(int on) { const int old = g_c16_split; g_c16_split = on; return old; }
+int c16_split_enabled() { return g_c16_split; }
 static int g_edge_ring16 = [] { const char* e = getenv("MGN_EDGE_RING16"); return e ? atoi(e) : 0; }();
 int set_edge_ring16(int on) { const int old = g_edge_ring16; g_edge_ring16 = on; return old; }
 int edge_ring16_enabled() { return g_edge_ring16; }
@@ -2432,6 +2659,18 @@ hipError_t launch_edge_step(int L, const EdgeArgs& a, hipStream_t s) {
         int rt = g_c16_rt ? g_c16_rt : (nht + num_cus() - 1) / num_cus();
         rt = rt < 1 ? 1 : (rt > 3 ? 3 : rt);
         LaunchCfg c16{(nht + rt - 1) / rt, 256, (size_t)rt * 2 * 8 * 64 * 16 + (size_t)rt * 2 * 64 * 4};
+        if (g_fp32_split && (g_c16_split & 1) && a.split16[0] && (rt >= 2 || (g_c16_split & 4))) {   // split path: bf16 matrix cores at fp32 accuracy (pieces exchanged: 12 KiB per tile)
+            c16.lds = (size_t)rt * 2 * 12 * 64 * 16 + (size_t)rt * 2 * 64 * 4;
+            g_last_edge_kernel = 12;
+            if (a.bf) {
+                if (rt == 3) return launch_k(k_edge_coop16m<3, true, true>, a, c16, s);
+                if (rt == 2) return launch_k(k_edge_coop16m<2, true, true>, a, c16, s);
+                return launch_k(k_edge_coop16m<1, true, true>, a, c16, s);
+            }
+            if (rt == 3) return launch_k(k_edge_coop16m<3, false, true>, a, c16, s);
+            if (rt == 2) return launch_k(k_edge_coop16m<2, false, true>, a, c16, s);
+            return launch_k(k_edge_coop16m<1, false, true>, a, c16, s);
+        }
         if (a.bf) {
             if (rt == 3) return launch_k(k_edge_coop16m<3, true>, a, c16, s);
             if (rt == 2) return launch_k(k_edge_coop16m<2, true>, a, c16, s);
@@ -2532,6 +2771,12 @@ hipError_t launch_node_step(int L, const NodeArgs& a, hipStream_t s) {
     }
     if (a.c16 && L == 128 && a.chunk_t[0]) {
         LaunchCfg c16{2 * a.ntiles, 256, (size_t)4 * 8 * 64 * 16 + 2 * 64 * 4};
+        if (g_fp32_split && (g_c16_split & 2) && a.split16[0] && (!a.AGG2 || a.split16[6])) {   // split path (pieces exchanged: 12 KiB per buffer)
+            c16.lds = (size_t)4 * 12 * 64 * 16 + 2 * 64 * 4;
+            if (a.mode != 2) g_last_node_kernel = 8;
+            if (a.bf) return a.AGG2 ? launch_k(k_node_coop16<2, true, true>, a, c16, s) : launch_k(k_node_coop16<1, true, true>, a, c16, s);
+            return a.AGG2 ? launch_k(k_node_coop16<2, false, true>, a, c16, s) : launch_k(k_node_coop16<1, false, true>, a, c16, s);
+        }
         if (a.bf) return a.AGG2 ? launch_k(k_node_coop16<2, true>, a, c16, s) : launch_k(k_node_coop16<1, true>, a, c16, s);
         return a.AGG2 ? launch_k(k_node_coop16<2, false>, a, c16, s) : launch_k(k_node_coop16<1, false>, a, c16, s);
     }
@@ -2588,6 +2833,10 @@ hipError_t launch_project(int L, const NodeArgs& a, hipStream_t s) {
     LaunchCfg lc = tile_launch(L, a.ntiles, 2);
     if (!a.gen.use && a.c16 && L == 128 && a.chunk_t[0] && !a.AGG2 && a.mode == 2) {
         LaunchCfg c16{2 * a.ntiles, 256, (size_t)4 * 8 * 64 * 16 + 2 * 64 * 4};
+        if (g_fp32_split && (g_c16_split & 2) && a.split16[4]) {
+            c16.lds = (size_t)4 * 12 * 64 * 16 + 2 * 64 * 4;
+            return a.bf ? launch_k(k_node_coop16<1, true, true>, a, c16, s) : launch_k(k_node_coop16<1, false, true>, a, c16, s);
+        }
         return a.bf ? launch_k(k_node_coop16<1, true>, a, c16, s) : launch_k(k_node_coop16<1, false>, a, c16, s);
     }
     if (!a.gen.use && a.tile0 == 0 && a.mode == 2 && coop_ok(L, a.ntiles, a.chunk_t)) {

@@ -409,10 +409,9 @@ EdgeArgs edge_args(mgn_engine* h, int k, int q = 0) {
     }
     a.tabs = W(h, h->soff[k].e_tabs[q]);
     a.gen = gen_of(h, h->soff[k].e_gen[q], true);
-    for (int i = 0; i < 3; ++i)
-        a.split[i] = (!a.bf && k < (int)h->spoff.size() && h->wsp.p) ? h->wsp.as<uint16_t>() + h->spoff[k].e_ch[q][i] : nullptr;
-    for (int i = 0; i < 3; ++i)
-        a.split16[i] = (a.split[i] && h->spoff[k].e16_ch[q][i]) ? h->wsp.as<uint16_t>() + h->spoff[k].e16_ch[q][i] : nullptr;
+    const bool have_sp = k < (int)h->spoff.size() && h->wsp.p;
+    for (int i = 0; i < 3; ++i) a.split[i] = (!a.bf && have_sp) ? h->wsp.as<uint16_t>() + h->spoff[k].e_ch[q][i] : nullptr;
+    for (int i = 0; i < 3; ++i) a.split16[i] = have_sp ? h->wsp.as<uint16_t>() + h->spoff[k].e16_ch[q][i] : nullptr;
     {
         const size_t lim = (size_t)1 << 31, rowb = (size_t)h->cfg.L * 4;
         a.off32 = ((size_t)(h->g.n_own + h->g.n_halo + 32) * rowb < lim && ((size_t)2 * es.ntiles_e + 16) * rowb < lim) ? 1 : 0;
@@ -481,12 +480,23 @@ NodeArgs node_args(mgn_engine* h, int k, int mode, int q = 0) {
     a.c16 = use_c16(h);
     a.stamps = h->d_stamps.as<unsigned long long>();
     a.tile0 = 0;
-    const bool sp = !bf && k < (int)h->spoff.size() && h->spoff[k].have_n && h->wsp.p;
+    const bool sp16 = k < (int)h->spoff.size() && h->spoff[k].have_n && h->wsp.p;
+    const bool sp = !bf && sp16;
     for (int i = 0; i < 6; ++i) a.split[i] = (sp && q == 0) ? h->wsp.as<uint16_t>() + h->spoff[k].n_ch[i] : nullptr;
     if (sp && h->nsets == 2) {
         if (q == 1)                                     // the projection of set 1 (mode 2): its WP / WQ pieces
             for (int i = 0; i < 2; ++i) a.split[4 + i] = h->wsp.as<uint16_t>() + h->spoff[k].n2_ch[1 + i];
         a.split[6] = h->wsp.as<uint16_t>() + h->spoff[k].n2_ch[0];
+    }
+    // the same chunks in the 16x16x32 fragment order, in NodeArgs.chunk numbering (16-row cooperative kernels on the split path)
+    for (int i = 0; i < 9; ++i) a.split16[i] = nullptr;
+    if (sp16) {
+        for (int i = 0; i < 6; ++i) a.split16[i] = h->wsp.as<uint16_t>() + h->spoff[k].n16_ch[i];
+        if (h->nsets == 2) {
+            for (int i = 0; i < 3; ++i) a.split16[6 + i] = h->wsp.as<uint16_t>() + h->spoff[k].n16_ch[6 + i];
+            if (q == 1)
+                for (int i = 0; i < 2; ++i) a.split16[4 + i] = a.split16[7 + i];
+        }
     }
     return a;
 }
@@ -775,48 +785,44 @@ int mgn_set_params(mgn_handle* h, const float* packed, size_t n) try {
         h->soff.push_back(so);
     }
     h->spoff.clear();
-    if (c.dtype == MGN_F32 && L == 128 && c.hidden_layers == 2) {      // bf16 pieces of the split path (split.hip): 4.4 MB per edge set,
+    if (L == 128 && c.hidden_layers == 2) {                            // bf16 pieces of the split path (split.hip): 4.4 MB per edge set,
         const bool node_side = S <= 2;                                  //   8.8 MB for the node side (+ 4.4 MB with a second edge set)
-        const bool ring16 = edge_ring16_enabled() != 0;                 // k_edge_ring16's fragment order next to the default one
-        std::vector<uint16_t> ws((size_t)c.mps * S * 3 * 3 * 16384 * (ring16 ? 2 : 1) + (node_side ? (size_t)(c.mps + 1) * (S == 2 ? 9 : 6) * 3 * 16384 : 0));
+        // every chunk twice: the 32x32x16 fragment order (k_edge_ring, k_node_split, k_project_split; fp32 storage only) and the
+        // 16x16x32 one (the 16-row cooperative kernels of small meshes -- in bf16 storage mode too, where they keep fp32-accurate
+        // arithmetic --, k_edge_ring16)
+        const bool f32 = c.dtype == MGN_F32;
+        std::vector<uint16_t> ws(((size_t)c.mps * S * 3 + (node_side ? (size_t)(c.mps + 1) * (S == 2 ? 9 : 6) : 0)) * (f32 ? 2 : 1) * 3 * 16384);
         h->spoff.assign(c.mps + 1, {});
         size_t off = 0;
+        auto put = [&](const float* src, int kb, size_t& o32, size_t& o16) {
+            o32 = 0;
+            if (f32) {
+                pack_chunk_split(ws.data() + off, src, L, kb);
+                o32 = off;
+                off += (size_t)3 * 16384;
+            }
+            pack_chunk_split(ws.data() + off, src, L, kb, true);
+            o16 = off;
+            off += (size_t)3 * 16384;
+        };
         for (int k = 0; k < c.mps; ++k)
             for (int q = 0; q < S; ++q) {
                 const MlpOff& me = h->es[q].pe[k];
                 const float* src[3] = {p + me.W[1], p + me.W[2], p + me.W[0]};
                 const int kb[3] = {0, 0, 2 * L};
-                for (int i = 0; i < 3; ++i) {
-                    pack_chunk_split(ws.data() + off, src[i], L, kb[i]);
-                    h->spoff[k].e_ch[q][i] = off;
-                    off += (size_t)3 * 16384;
-                    h->spoff[k].e16_ch[q][i] = 0;
-                    if (ring16) {
-                        pack_chunk_split(ws.data() + off, src[i], L, kb[i], true);
-                        h->spoff[k].e16_ch[q][i] = off;
-                        off += (size_t)3 * 16384;
-                    }
-                }
+                for (int i = 0; i < 3; ++i) put(src[i], kb[i], h->spoff[k].e_ch[q][i], h->spoff[k].e16_ch[q][i]);
             }
         for (int k = 0; node_side && k <= c.mps; ++k) {                 // node MLP of step k + projection for step k + 1 (k = mps: the
             const MlpOff& mn = h->pn[k < c.mps ? k : 0];                //   "project only" pseudo-step: step 0's own first layer)
             const MlpOff& nx = h->es[0].pe[k + 1 < c.mps ? k + 1 : 0];
             const float* src[6] = {p + mn.W[1], p + mn.W[2], p + mn.W[0], p + mn.W[0], p + nx.W[0], p + nx.W[0]};
             const int kb[6] = {0, 0, 0, L, 0, L};
-            for (int i = 0; i < 6; ++i) {
-                pack_chunk_split(ws.data() + off, src[i], L, kb[i]);
-                h->spoff[k].n_ch[i] = off;
-                off += (size_t)3 * 16384;
-            }
+            for (int i = 0; i < 6; ++i) put(src[i], kb[i], h->spoff[k].n_ch[i], h->spoff[k].n16_ch[i]);
             if (S == 2) {                                               // second edge set: its aggregate block of the node MLP, its projection
                 const MlpOff& n1 = h->es[1].pe[k + 1 < c.mps ? k + 1 : 0];
                 const float* src2[3] = {p + mn.W[0], p + n1.W[0], p + n1.W[0]};
                 const int kb2[3] = {2 * L, 0, L};
-                for (int i = 0; i < 3; ++i) {
-                    pack_chunk_split(ws.data() + off, src2[i], L, kb2[i]);
-                    h->spoff[k].n2_ch[i] = off;
-                    off += (size_t)3 * 16384;
-                }
+                for (int i = 0; i < 3; ++i) put(src2[i], kb2[i], h->spoff[k].n2_ch[i], h->spoff[k].n16_ch[6 + i]);
             }
             h->spoff[k].have_n = true;
         }
@@ -2497,6 +2503,7 @@ int mgn_debug_fp32_split(int on) { return set_fp32_split(on); }
 // 1: the edge kernel of the split path on v_mfma_f32_16x16x32_bf16 (k_edge_ring16); takes effect at the next mgn_set_params (its weight
 // fragments are packed there).  Returns the old value.  Environment: MGN_EDGE_RING16.
 int mgn_debug_edge_ring16(int on) { return set_edge_ring16(on); }
+int mgn_debug_c16_split(int on) { return set_c16_split(on); }   // bits: 1 edge kernel (default), 2 node kernel, 4 edge kernel at one row tile per block; 0: fp32 MFMA pipe (kernels.hip)
 int mgn_debug_last_node_kernel(void) { return last_node_kernel(); }   // the same for the node MLP (codes: kernels.hip, launch_node_step)
 int mgn_debug_last_edge_kernel(void) { return last_edge_kernel(); }   // kernels.hip: which family the last fp32 edge launch ran on
 // node numbering policy of the NEXT mgn_set_graph calls (0 never, 1 auto, 2 always breadth-first); returns the old value

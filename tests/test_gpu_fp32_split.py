@@ -8,7 +8,7 @@ import torch  # noqa: F401
 
 import mgn_oracle as orc
 from mgn_amd import synth
-from util import TOL_15, TOL_STEP, cfg_dict, engine_for, make_params, rel_max, set_edge_ring16, set_fp32_split
+from util import TOL_15, TOL_STEP, cfg_dict, engine_for, make_params, rel_max, set_c16_row_tiles, set_c16_split, set_edge_ring16, set_fp32_split, set_kernel_path
 
 pytestmark = pytest.mark.gpu
 
@@ -203,6 +203,47 @@ def test_split_two_edge_sets_node_side():
     finally:
         set_fp32_split(old)
     assert rel_max(v1, rv) <= 2.0 * rel_max(v0, rv) + 1e-7 and not np.array_equal(v0, v1)
+
+
+@pytest.mark.parametrize("rt", [0, 1, 2, 3])
+def test_split_16_row_kernels_on_the_cylinder_mesh(rt):
+    """cylinder_flow-sized mesh (N = 2 000, E = 11 954): the 16-row cooperative kernels on the split path (v_mfma_f32_16x16x32_bf16, pieces
+    exchanged through LDS) against the float64 oracle at the fp32 tolerances, for every number of row tiles per block, and no worse than
+    twice the error of the same kernels on the fp32 MFMA pipe"""
+    import ctypes
+    import mgn_amd
+    pos, cells, ntype, vel = synth.mesh_cyl(1234, 2000)
+    s, r = synth.cells_to_edges(cells)
+    cfg = cfg_dict(mps=15)
+    ps = make_params(cfg, jitter=0.05)
+    rng = np.random.default_rng(7)
+    v = rng.standard_normal((2000, 128)).astype(np.float32)
+    e = rng.standard_normal((s.size, 128)).astype(np.float32)
+    rv, re = orc.processor_steps(ps, cfg, v, e, s, r, 15)
+    lib = mgn_amd.load()
+    lib.mgn_debug_last_node_kernel.restype = ctypes.c_int
+    lib.mgn_debug_last_edge_kernel.restype = ctypes.c_int
+    old_p, old_rt = set_kernel_path(5 if rt else 0), set_c16_row_tiles(rt)
+    try:
+        out = {}
+        for on in (7, 0):                                    # every 16-row kernel on the split path / none
+            old = set_c16_split(on)
+            try:
+                eng = engine_for(cfg)
+                eng.set_params(ps)
+                eng.set_graph(s, r, 2000)
+                out[on] = eng.processor_steps(v, e, 15)
+                fam = (lib.mgn_debug_last_edge_kernel(), lib.mgn_debug_last_node_kernel())
+                assert fam == ((12, 8) if on else (2, 2)), fam
+            finally:
+                set_c16_split(old)
+        err = {on: max(rel_max(out[on][0], rv), rel_max(out[on][1], re)) for on in out}
+        assert err[7] <= TOL_15 and err[0] <= TOL_15, err
+        assert err[7] <= 2.0 * err[0] + 1e-7, err
+        assert not np.array_equal(out[7][1], out[0][1])
+    finally:
+        set_kernel_path(old_p)
+        set_c16_row_tiles(old_rt)
 
 
 def test_node_ring_opt_in_kernel(tmp_path):

@@ -66,6 +66,15 @@ def set_fp32_split(on):
     return lib.mgn_debug_fp32_split(on)
 
 
+def set_c16_split(on):
+    """16-row cooperative kernels (small meshes) on the split path, bit mask: 1 = the edge kernel at two or three row tiles per block,
+    2 = the node kernel (default 3 = both), 4 = the edge kernel at one row tile too; 0 = fp32-MFMA arithmetic.  Returns the old value."""
+    lib = mgn_amd.load()
+    lib.mgn_debug_c16_split.restype = __import__("ctypes").c_int
+    lib.mgn_debug_c16_split.argtypes = [__import__("ctypes").c_int]
+    return lib.mgn_debug_c16_split(on)
+
+
 def set_edge_ring16(on):
     """1: k_edge_ring16 (the ring kernel on v_mfma_f32_16x16x32_bf16) wherever k_edge_ring would run; read by set_params (fragment
     order) and by every launch.  Returns the old value."""

@@ -20,8 +20,12 @@ res = {n: [] for n in names}
 for rnd in range(3):
     for n in names:
         env = dict(os.environ)
-        if n != "default":
-            env["MGN_LIB_PATH"] = os.path.join(ROOT, "meshgraphnets.jl_amd", "lib", "variants", n + ".so")
+        lib, *sets = n.split("+")                 # "name+VAR=value+...": environment knobs on top of a library variant
+        for kv in sets:
+            k, v = kv.split("=", 1)
+            env[k] = v
+        if lib != "default":
+            env["MGN_LIB_PATH"] = os.path.join(ROOT, "meshgraphnets.jl_amd", "lib", "variants", lib + ".so")
         out = subprocess.run([sys.executable, "-c", CHILD], env=env, capture_output=True, text=True)
         l = [x for x in out.stdout.splitlines() if x.startswith("US_PER_STEP")]
         if l: res[n].append(float(l[0].split()[1]))
