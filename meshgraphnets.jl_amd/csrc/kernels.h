@@ -179,6 +179,7 @@ hipError_t launch_errnorm(const float* u, const float* unew, const LinComb& lc, 
 
 // L in {32,64,128}.  All return hipError_t of the launch.
 bool launch_is_small(int ntiles);
+bool node_split_size(int ntiles);   // the split-path node kernels take launches of this many node tiles (above two per CU)
 bool launch_is_small_edge(int ntiles_e);   // the same rule for edge launches (<= 16 tiles per CU)
 int coop16_enabled();
 bool coop16_size(int ntiles_e, int ntiles_n);   // the launch wrappers' rule for the cooperative node kernels (<= 8 tiles per CU)

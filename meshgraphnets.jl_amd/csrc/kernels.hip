@@ -2553,6 +2553,10 @@ bool coop16_size(int ntiles_e, int ntiles_n) {
 }
 static bool coop_size(int ntiles, bool edge) { return g_path == 0 ? ntiles <= (edge ? g_coop_edge : g_coop_node) * num_cus() : (g_path == 3 || g_path == 5); }
 bool launch_is_small(int ntiles) { return coop_size(ntiles, false); }
+// where the split-path node kernels (k_node_split + k_project_split) take the node side from the cooperative tiles: above two tiles per CU
+// (19.6 k nodes: 50 -> 43 us, 32 k: 66 -> 50, 62 k: 131 -> 98; at 16 k, two tiles per CU, the cooperative kernels are faster: 37 vs 48)
+static const int g_node_split_min = [] { const char* e = getenv("MGN_NODE_SPLIT_MIN_TILES_PER_CU"); return e ? atoi(e) : 2; }();
+bool node_split_size(int ntiles) { return g_fp32_split != 0 && g_path == 0 && ntiles > g_node_split_min * num_cus(); }
 bool launch_is_small_edge(int ntiles_e) { return coop_size(ntiles_e, true); }
 
 // 1: node MLP + projection as ONE lock-step launch over an LDS ring (k_node_ring; parity-green, 1.215 vs 1.173 ms on M-1M: opt-in)
@@ -2780,7 +2784,8 @@ hipError_t launch_node_step(int L, const NodeArgs& a, hipStream_t s) {
         if (a.bf) return a.AGG2 ? launch_k(k_node_coop16<2, true>, a, c16, s) : launch_k(k_node_coop16<1, true>, a, c16, s);
         return a.AGG2 ? launch_k(k_node_coop16<2, false>, a, c16, s) : launch_k(k_node_coop16<1, false>, a, c16, s);
     }
-    if (coop_ok(L, a.ntiles, a.chunk_t)) {
+    const bool split_node = L == 128 && a.mode == 0 && a.split[0] && (!a.AGG2 || a.split[6]) && node_split_size(a.ntiles);
+    if (coop_ok(L, a.ntiles, a.chunk_t) && !split_node) {
         LaunchCfg c4{a.ntiles, 256, coop_lds()};
         if (coop_fence(a.ntiles)) return a.AGG2 ? launch_k(k_node_coop<true, true>, a, c4, s) : launch_k(k_node_coop<false, true>, a, c4, s);
         return a.AGG2 ? launch_k(k_node_coop<true, false>, a, c4, s) : launch_k(k_node_coop<false, false>, a, c4, s);
@@ -2794,7 +2799,7 @@ hipError_t launch_node_step(int L, const NodeArgs& a, hipStream_t s) {
         g_last_node_kernel = 4;
         return launch_node_ring(a, ls, s);
     }
-    if (g_fp32_split && g_path == 0 && L == 128 && !proj && (!a.AGG2 || a.split[6]) && a.split[0] && !small_launch(a.ntiles)) {   // split path (split.hip)
+    if (split_node) {   // split path (split.hip)
         LaunchCfg ls = tile_launch(L, a.ntiles, 2);
         ls.lds = (size_t)4 * 16384 * 2 + (size_t)T_COUNT * L * 4 + 64;
         g_last_node_kernel = a.AGG2 ? 6 : 5;
@@ -2839,17 +2844,19 @@ hipError_t launch_project(int L, const NodeArgs& a, hipStream_t s) {
         }
         return a.bf ? launch_k(k_node_coop16<1, true>, a, c16, s) : launch_k(k_node_coop16<1, false>, a, c16, s);
     }
-    if (!a.gen.use && a.tile0 == 0 && a.mode == 2 && coop_ok(L, a.ntiles, a.chunk_t)) {
+    if (!a.gen.use && a.tile0 == 0 && a.mode == 2 && coop_ok(L, a.ntiles, a.chunk_t) && !(L == 128 && a.split[4] && node_split_size(a.ntiles))) {
         LaunchCfg c4{a.ntiles, 256, coop_lds()};
         if (coop_fence(a.ntiles)) return a.AGG2 ? launch_k(k_node_coop<true, true>, a, c4, s) : launch_k(k_node_coop<false, true>, a, c4, s);
         return a.AGG2 ? launch_k(k_node_coop<true, false>, a, c4, s) : launch_k(k_node_coop<false, false>, a, c4, s);
     }
-    if (L == 128 && small_launch(a.ntiles)) {
+    // (a.ntiles may be a part of the node tiles -- boundary / interior halves of a partition: the kernel family follows the part's size)
+    const bool split_ok = !a.gen.use && a.mode == 2 && a.split[4] && node_split_size(a.ntiles);
+    if (L == 128 && small_launch(a.ntiles) && !split_ok) {
         lc.lds = (size_t)T_COUNT * L * 4 + 64;
         return launch_k(k_project<4, false>, a, lc, s);
     }
     if (L == 128) {
-        if (g_fp32_split && g_path == 0 && !a.gen.use && a.mode == 2 && a.split[4]) {   // split path (split.hip)
+        if (split_ok) {   // split path (split.hip)
             LaunchCfg ls = lc;
             ls.lds = (size_t)4 * 16384 * 2 + (size_t)T_COUNT * L * 4 + 64;
             return launch_project_split(a, ls, s);

@@ -1305,7 +1305,9 @@ int mgn_proc_node(mgn_handle* h, int32_t k, int32_t project_next) try {
     }
     // large meshes: MLP and projection as two launches (the projection then has both of its chunks LDS-resident);
     // small meshes are launch-latency-bound: one fused launch (M-cyl: 53.0 -> 50.8 us per step)
-    if (project_next && !(h->nsets == 2 && use_c16(h)) && (h->nsets > 1 || (h->node_split && !launch_is_small(h->ntiles_n)))) {
+    // (... and from two tiles per CU where the split-path node kernels exist: they are two launches by construction)
+    const bool split_pair = !is_bf16(h) && h->cfg.L == 128 && k < (int)h->spoff.size() && h->spoff[k].have_n && h->wsp.p && node_split_size(h->ntiles_n);
+    if (project_next && !(h->nsets == 2 && use_c16(h)) && (h->nsets > 1 || split_pair || (h->node_split && !launch_is_small(h->ntiles_n)))) {
         // MLP (2 of its chunks LDS-resident, the others stream from L2), then per edge set the projection with both of
         // its chunks resident
         HIPCHK(h, launch_node_step(h->cfg.L, node_args(h, k, 0), h->stream));
