@@ -852,6 +852,28 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
             pq[t][1][0] = c16_ld_row<BF>(a.Q, r_[t], 2 * wave, q);
             pq[t][1][1] = c16_ld_row<BF>(a.Q, r_[t], 2 * wave + 1, q);
         }
+        // the index part of the segmented sum (run heads, scan masks, where a run's tail goes) while the gathered rows are on their way:
+        // two LDS round trips and a ballot per tile that would otherwise sit between the LayerNorm and the last stores
+        float sm1[RT], sm2[RT], sm4[RT], sm8[RT];
+        bool tailf[RT], to_carry[RT], sl_[RT];
+#pragma unroll
+        for (int t = 0; t < RT; ++t) {
+            const int reff = valid[t] ? r_[t] : (-4 - n);
+            const int rprev = __shfl_up(reff, 1, 16);
+            const int rnext = __shfl_down(reff, 1, 16);
+            const bool head = (n == 0) || (reff != rprev);
+            const unsigned hm = (unsigned)(__ballot(head) & 0xFFFFull);
+            const int start = 31 - __clz((int)(hm & (0xFFFFu >> (15 - n))));
+            sm1[t] = (n - 1 >= start) ? 1.f : 0.f;
+            sm2[t] = (n - 2 >= start) ? 1.f : 0.f;
+            sm4[t] = (n - 4 >= start) ? 1.f : 0.f;
+            sm8[t] = (n - 8 >= start) ? 1.f : 0.f;
+            tailf[t] = valid[t] && ((n == 15) || (reff != rnext));
+            const int r_first = __builtin_amdgcn_readfirstlane(reff);
+            sl_[t] = (start == 0) && hb[t] && (r_before[t] == r_first);           // run continues from the previous 16-edge tile
+            const bool sr = (n == 15) && ha[t] && (r_after[t] == reff);          // run continues into the next one
+            to_carry[t] = sl_[t] || sr;
+        }
         if constexpr (SP) c16s_chain<RT, 4, 8>(acc, xp, s1, h1);
         else c16m_chain<RT, 4, 8>(acc, x, w1, lane, g1);
 #pragma unroll
@@ -899,14 +921,7 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
                 c16_st_tile<BF>(a.Elat, tile[t], row[t], 2 * wave + 1, q, xs[t][1] + acc[t][1]);
             }
             // segmented sum over runs of equal receiver within the 16-edge tile: the 16 rows of a tile are one DPP row (the same in all four lane groups)
-            const int reff = valid[t] ? r_[t] : (-4 - n);
-            const int rprev = __shfl_up(reff, 1, 16);
-            const int rnext = __shfl_down(reff, 1, 16);
-            const bool head = (n == 0) || (reff != rprev);
-            const unsigned hm = (unsigned)(__ballot(head) & 0xFFFFull);
-            const int start = 31 - __clz((int)(hm & (0xFFFFu >> (15 - n))));
-            const float m1 = (n - 1 >= start) ? 1.f : 0.f, m2 = (n - 2 >= start) ? 1.f : 0.f, m4 = (n - 4 >= start) ? 1.f : 0.f,
-                        m8 = (n - 8 >= start) ? 1.f : 0.f;
+            const float m1 = sm1[t], m2 = sm2[t], m4 = sm4[t], m8 = sm8[t];
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -918,13 +933,9 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
                     v = __builtin_fmaf(dpp_zero<0x118, 0xF>(v), m8, v);
                     acc[t][j][i] = v;
                 }
-            const bool tail = valid[t] && ((n == 15) || (reff != rnext));
-            const int r_first = __builtin_amdgcn_readfirstlane(reff);
-            const bool sl = (start == 0) && hb[t] && (r_before[t] == r_first);   // run continues from the previous 16-edge tile
-            const bool sr = (n == 15) && ha[t] && (r_after[t] == reff);          // run continues into the next one
-            if (tail) {
-                if (sl || sr) {
-                    const int64_t cr = (int64_t)2 * ht[t] + (sl ? 0 : 1);
+            if (tailf[t]) {
+                if (to_carry[t]) {
+                    const int64_t cr = (int64_t)2 * ht[t] + (sl_[t] ? 0 : 1);
                     c16_st_row<BF>(a.CARRY, cr, 2 * wave, q, acc[t][0]);
                     c16_st_row<BF>(a.CARRY, cr, 2 * wave + 1, q, acc[t][1]);
                 } else {
