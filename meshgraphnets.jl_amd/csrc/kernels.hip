@@ -955,11 +955,13 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
 // LayerNorm statistics are per-wave partials combined through LDS (c16m_layer_norm).  SETS = 2: the second set's aggregate is one
 // more layer-1 chain, and mode 1 projects P, Q of both sets.
 // this wave's slice of a node's aggregated messages: the node's AGG slot, or carry rows when its run of edges straddles tiles
-template <bool BF>
+// CSH: log2 of the edge kernel's tile height -- 4 with the 16-row edge kernel (carry rows per 16-edge tile), 5 when the edge step ran a
+// 32-row kernel (k_edge_ring on a mid-size mesh: carry rows per 32-edge tile)
+template <bool BF, int CSH = 4>
 DEVINL void c16_agg_slice(f32x4 (&as)[2], const int32_t* rowptr, const float* AGG, const float* CARRY, int64_t zero_row, bool valid, int nn,
                           int64_t tile, int row, int wave, int q) {
     const int a0 = rowptr[nn], a1 = rowptr[nn + 1];
-    const int T1 = a0 >> 4, T2 = (a1 - 1) >> 4;
+    const int T1 = a0 >> CSH, T2 = (a1 - 1) >> CSH;
     const int extra = (valid && a1 > a0 && T2 > T1) ? (T2 - T1) : 0;
     const bool from_agg = valid && (a1 > a0) && !extra;
     if constexpr (BF) {
@@ -1037,7 +1039,7 @@ DEVINL void c16_project(const f32x4 (&v)[1][8], const float* wp, const float* wq
         c16_st_row<BF>(Q, nn, 2 * wave + 1, q, o[0][1]);
     }
 }
-template <int SETS, bool BF, bool SP = false>
+template <int SETS, bool BF, bool SP = false, int CSH = 4>
 __global__ __launch_bounds__(256, 2) void k_node_coop16(const NodeArgs a) {
     constexpr int L = 128;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -1079,8 +1081,8 @@ __global__ __launch_bounds__(256, 2) void k_node_coop16(const NodeArgs a) {
             u32x4* const x3 = reinterpret_cast<u32x4*>(xch3);
             if (a.mode != 2) {
                 f32x4 as[2], as2[2];
-                c16_agg_slice<BF>(as, a.rowptr, a.AGG, a.CARRY, a.zero_row, valid, nn, tile, row, wave, q);
-                if constexpr (SETS == 2) c16_agg_slice<BF>(as2, a.rowptr2, a.AGG2, a.CARRY2, a.zero_row2, valid, nn, tile, row, wave, q);
+                c16_agg_slice<BF, CSH>(as, a.rowptr, a.AGG, a.CARRY, a.zero_row, valid, nn, tile, row, wave, q);
+                if constexpr (SETS == 2) c16_agg_slice<BF, CSH>(as2, a.rowptr2, a.AGG2, a.CARRY2, a.zero_row2, valid, nn, tile, row, wave, q);
                 c16s_prime(ha, ws(2));
                 c16_tab(acc[0], tabs + T_B1 * L, wave, q);
                 c16s_put<false>(x0, vs[0], wave, lane);
@@ -1152,8 +1154,8 @@ __global__ __launch_bounds__(256, 2) void k_node_coop16(const NodeArgs a) {
             }
         } else if (a.mode != 2) {
             f32x4 as[2], as2[2];
-            c16_agg_slice<BF>(as, a.rowptr, a.AGG, a.CARRY, a.zero_row, valid, nn, tile, row, wave, q);
-            if constexpr (SETS == 2) c16_agg_slice<BF>(as2, a.rowptr2, a.AGG2, a.CARRY2, a.zero_row2, valid, nn, tile, row, wave, q);
+            c16_agg_slice<BF, CSH>(as, a.rowptr, a.AGG, a.CARRY, a.zero_row, valid, nn, tile, row, wave, q);
+            if constexpr (SETS == 2) c16_agg_slice<BF, CSH>(as2, a.rowptr2, a.AGG2, a.CARRY2, a.zero_row2, valid, nn, tile, row, wave, q);
             c16_prime(ga, wt(2), lane);
             c16_tab(acc[0], tabs + T_B1 * L, wave, q);
             xch0[(2 * wave) * 64 + lane] = vs[0][0];
@@ -2566,6 +2568,7 @@ static bool coop_size(int ntiles, bool edge) { return g_path == 0 ? ntiles <= (e
 bool launch_is_small(int ntiles) { return coop_size(ntiles, false); }
 // where the split-path node kernels (k_node_split + k_project_split) take the node side from the cooperative tiles: above two tiles per CU
 // (19.6 k nodes: 50 -> 43 us, 32 k: 66 -> 50, 62 k: 131 -> 98; at 16 k, two tiles per CU, the cooperative kernels are faster: 37 vs 48)
+static int g_node16_mid = [] { const char* e = getenv("MGN_NODE16_MID"); return e ? atoi(e) : 1; }();   // 0: cooperative 32-row node kernel (fp32 pipe) there
 static const int g_node_split_min = [] { const char* e = getenv("MGN_NODE_SPLIT_MIN_TILES_PER_CU"); return e ? atoi(e) : 2; }();
 bool node_split_size(int ntiles) { return g_fp32_split != 0 && g_path == 0 && ntiles > g_node_split_min * num_cus(); }
 bool launch_is_small_edge(int ntiles_e) { return coop_size(ntiles_e, true); }
@@ -2796,6 +2799,15 @@ hipError_t launch_node_step(int L, const NodeArgs& a, hipStream_t s) {
         return a.AGG2 ? launch_k(k_node_coop16<2, false>, a, c16, s) : launch_k(k_node_coop16<1, false>, a, c16, s);
     }
     const bool split_node = L == 128 && a.mode == 0 && a.split[0] && (!a.AGG2 || a.split[6]) && node_split_size(a.ntiles);
+    // between the 16-row kernels' range and the split-path node kernels (8 k .. 16 k nodes on a mesh): the edge step ran a 32-row
+    // kernel, the node side still fits half tiles of 16 rows two blocks per CU -- the 16-row node kernel on the split path, reading
+    // the 32-edge-tile carry rows (16 k nodes: 37 -> 2x us against the cooperative 32-row kernel on the fp32 pipe)
+    if (g_node16_mid && g_fp32_split && (g_c16_split & 2) && g_path == 0 && L == 128 && !a.bf && !a.AGG2 && a.mode != 2 && a.split16[0] &&
+        coop_ok(L, a.ntiles, a.chunk_t) && !split_node) {
+        LaunchCfg c16{2 * a.ntiles, 256, (size_t)4 * 12 * 64 * 16 + 2 * 64 * 4};
+        g_last_node_kernel = 9;
+        return launch_k(k_node_coop16<1, false, true, 5>, a, c16, s);
+    }
     if (coop_ok(L, a.ntiles, a.chunk_t) && !split_node) {
         LaunchCfg c4{a.ntiles, 256, coop_lds()};
         if (coop_fence(a.ntiles)) return a.AGG2 ? launch_k(k_node_coop<true, true>, a, c4, s) : launch_k(k_node_coop<false, true>, a, c4, s);
