@@ -764,6 +764,54 @@ DEVINL void c16s_chain(f32x4 (&acc)[RT][2], const C16P (&x)[RT][4], const u32x4*
     }
 }
 
+// four to six row tiles per block: the pieces of all tiles do not fit the registers (48 per tile) -- the exchange only publishes, and the
+// chain reads the pieces of ONE k-step at a time from the exchange buffer (12 registers per tile)
+template <int RT, bool RELU>
+DEVINL void c16s_publish(const f32x4 (&mine)[RT][2], u32x4* xch, int wave, int lane) {
+#pragma unroll
+    for (int t = 0; t < RT; ++t) {
+        const C16P p = c16s_split<RELU>(mine[t]);
+        xch[((t * 4 + wave) * 3 + 0) * 64 + lane] = p.h;
+        xch[((t * 4 + wave) * 3 + 1) * 64 + lane] = p.m;
+        xch[((t * 4 + wave) * 3 + 2) * 64 + lane] = p.l;
+    }
+    __syncthreads();
+}
+template <int RT, int S0 = 0, int S1 = 8>
+DEVINL void c16s_chain_lds(f32x4 (&acc)[RT][2], const u32x4* xch, int lane, const u32x4* wv, C16SRing& g) {
+    C16P x[RT];
+#pragma unroll
+    for (int s = S0; s < S1; ++s) {
+        const int ks = s >> 1, j = s & 1;
+        if (j == 0 || s == S0) {
+#pragma unroll
+            for (int t = 0; t < RT; ++t) {
+                x[t].h = xch[((t * 4 + ks) * 3 + 0) * 64 + lane];
+                x[t].m = xch[((t * 4 + ks) * 3 + 1) * 64 + lane];
+                x[t].l = xch[((t * 4 + ks) * 3 + 2) * 64 + lane];
+            }
+        }
+        const u32x4 a1 = g.r[3 * (s % C16S_PF)], a2 = g.r[3 * (s % C16S_PF) + 1], a3 = g.r[3 * (s % C16S_PF) + 2];
+        if (s + C16S_PF < 8) {
+            const int sn = s + C16S_PF;
+#pragma unroll
+            for (int pc = 0; pc < 3; ++pc) g.r[3 * (s % C16S_PF) + pc] = wv[pc * 2048 + ((sn >> 1) * 8 + (sn & 1)) * 64];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < RT; ++t) {
+            const sp_bf16x8 bh = sp_wop(x[t].h), bm = sp_wop(x[t].m), bl = sp_wop(x[t].l);
+            acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(sp_wop(a3), bh, acc[t][j], 0, 0, 0);
+            acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(sp_wop(a2), bm, acc[t][j], 0, 0, 0);
+            acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(sp_wop(a1), bl, acc[t][j], 0, 0, 0);
+            acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(sp_wop(a2), bh, acc[t][j], 0, 0, 0);
+            acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(sp_wop(a1), bm, acc[t][j], 0, 0, 0);
+            acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(sp_wop(a1), bh, acc[t][j], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
 template <int RT, bool BF, bool SP = false>
 __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_edge_coop16m(const EdgeArgs a) {
     constexpr int L = 128;
@@ -824,18 +872,23 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
         }
         C16Ring g1, g2;
         C16SRing h1, h2;
-        C16P xp[RT][4];
+        constexpr bool XL = SP && RT > 3;                             // pieces stay in the exchange buffer (c16s_chain_lds)
+        C16P xp[XL ? 1 : RT][4];
+        u32x4* const xs0 = reinterpret_cast<u32x4*>(xch0);
+        u32x4* const xs1 = reinterpret_cast<u32x4*>(xch1);
         if constexpr (SP) c16s_prime(h1, s1);
         else c16_prime(g1, w1, lane);
 #pragma unroll
         for (int t = 0; t < RT; ++t) acc[t][0] = acc[t][1] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if constexpr (SP) c16s_exchange<RT, false>(xp, xs, reinterpret_cast<u32x4*>(xch0), wave, lane);
+        if constexpr (XL) c16s_publish<RT, false>(xs, xs0, wave, lane);
+        else if constexpr (SP) c16s_exchange<RT, false>(xp, xs, xs0, wave, lane);
         else c16m_exchange<RT>(x, xs, xch0, wave, lane);
         __builtin_amdgcn_sched_barrier(0);
         STAMP16(1);
         // layer 1: the e tile's part starts as soon as the tile and the first weights are here; the gathered P[s] + Q[r] (which
         // carry b1) are requested half way -- their addresses wait for the index loads, a serial round trip -- and added at the end
-        if constexpr (SP) c16s_chain<RT, 0, 4>(acc, xp, s1, h1);
+        if constexpr (XL) c16s_chain_lds<RT, 0, 4>(acc, xs0, lane, s1, h1);
+        else if constexpr (SP) c16s_chain<RT, 0, 4>(acc, xp, s1, h1);
         else c16m_chain<RT, 0, 4>(acc, x, w1, lane, g1);
         f32x4 tb2[2], tb3[2], tg[2], tb[2];
         c16_tab(tb2, tabs + T_B2 * L, wave, q);
@@ -874,7 +927,8 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
             const bool sr = (n == 15) && ha[t] && (r_after[t] == reff);          // run continues into the next one
             to_carry[t] = sl_[t] || sr;
         }
-        if constexpr (SP) c16s_chain<RT, 4, 8>(acc, xp, s1, h1);
+        if constexpr (XL) c16s_chain_lds<RT, 4, 8>(acc, xs0, lane, s1, h1);
+        else if constexpr (SP) c16s_chain<RT, 4, 8>(acc, xp, s1, h1);
         else c16m_chain<RT, 4, 8>(acc, x, w1, lane, g1);
 #pragma unroll
         for (int t = 0; t < RT; ++t) {
@@ -882,15 +936,27 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
             acc[t][1] += pq[t][0][1] + pq[t][1][1];
         }
         STAMP16(2);
-        if constexpr (SP) {                                          // (the ReLUs are folded into the split of the exchange)
+        if constexpr (XL) {
             c16s_prime(h1, s3);
-            c16s_exchange<RT, true>(xp, acc, reinterpret_cast<u32x4*>(xch1), wave, lane);
+            c16s_publish<RT, true>(acc, xs1, wave, lane);
+            STAMP16(3);
+#pragma unroll
+            for (int t = 0; t < RT; ++t) { acc[t][0] = tb2[0]; acc[t][1] = tb2[1]; }
+            c16s_chain_lds<RT>(acc, xs1, lane, s2, h2);              // layer 2
+            STAMP16(4);
+            c16s_publish<RT, true>(acc, xs0, wave, lane);            // (xch0: every wave is past its layer-1 reads -- the barrier of the publish before)
+#pragma unroll
+            for (int t = 0; t < RT; ++t) { acc[t][0] = tb3[0]; acc[t][1] = tb3[1]; }
+            c16s_chain_lds<RT>(acc, xs0, lane, s3, h1);              // layer 3
+        } else if constexpr (SP) {                                   // (the ReLUs are folded into the split of the exchange)
+            c16s_prime(h1, s3);
+            c16s_exchange<RT, true>(xp, acc, xs1, wave, lane);
             STAMP16(3);
 #pragma unroll
             for (int t = 0; t < RT; ++t) { acc[t][0] = tb2[0]; acc[t][1] = tb2[1]; }
             c16s_chain<RT>(acc, xp, s2, h2);                         // layer 2
             STAMP16(4);
-            c16s_exchange<RT, true>(xp, acc, reinterpret_cast<u32x4*>(xch0), wave, lane);
+            c16s_exchange<RT, true>(xp, acc, xs0, wave, lane);
 #pragma unroll
             for (int t = 0; t < RT; ++t) { acc[t][0] = tb3[0]; acc[t][1] = tb3[1]; }
             c16s_chain<RT>(acc, xp, s3, h1);                         // layer 3
@@ -2675,7 +2741,11 @@ hipError_t launch_edge_step(int L, const EdgeArgs& a, hipStream_t s) {
         g_last_edge_kernel = 2;
         const int nht = 2 * a.ntiles;
         int rt = g_c16_rt ? g_c16_rt : (nht + num_cus() - 1) / num_cus();
-        rt = rt < 1 ? 1 : (rt > 3 ? 3 : rt);
+        const bool sp16 = g_fp32_split && (g_c16_split & 1) && a.split16[0];
+        // (four to six row tiles per block exist on the split path only: one round of blocks up to 24.5 k edges instead of a second,
+        // partly filled one behind three tiles per block -- 12.5 k edges: 35.4 -> 2x us per step)
+        const int rt_max = (sp16 && !a.bf && !g_c16_rt) ? 6 : 3;
+        rt = rt < 1 ? 1 : (rt > rt_max ? rt_max : rt);
         LaunchCfg c16{(nht + rt - 1) / rt, 256, (size_t)rt * 2 * 8 * 64 * 16 + (size_t)rt * 2 * 64 * 4};
         if (g_fp32_split && (g_c16_split & 1) && a.split16[0] && (rt >= 2 || (g_c16_split & 4))) {   // split path: bf16 matrix cores at fp32 accuracy (pieces exchanged: 12 KiB per tile)
             c16.lds = (size_t)rt * 2 * 12 * 64 * 16 + (size_t)rt * 2 * 64 * 4;
@@ -2685,6 +2755,9 @@ hipError_t launch_edge_step(int L, const EdgeArgs& a, hipStream_t s) {
                 if (rt == 2) return launch_k(k_edge_coop16m<2, true, true>, a, c16, s);
                 return launch_k(k_edge_coop16m<1, true, true>, a, c16, s);
             }
+            if (rt == 6) return launch_k(k_edge_coop16m<6, false, true>, a, c16, s);
+            if (rt == 5) return launch_k(k_edge_coop16m<5, false, true>, a, c16, s);
+            if (rt == 4) return launch_k(k_edge_coop16m<4, false, true>, a, c16, s);
             if (rt == 3) return launch_k(k_edge_coop16m<3, false, true>, a, c16, s);
             if (rt == 2) return launch_k(k_edge_coop16m<2, false, true>, a, c16, s);
             return launch_k(k_edge_coop16m<1, false, true>, a, c16, s);

@@ -246,6 +246,42 @@ def test_split_16_row_kernels_on_the_cylinder_mesh(rt):
         set_c16_row_tiles(old_rt)
 
 
+@pytest.mark.parametrize("n_pts", [2300, 3200, 3900], ids=["four row tiles", "five", "six"])
+def test_split_16_row_edge_kernel_with_four_to_six_row_tiles(n_pts):
+    """12.3 k .. 24.5 k edges: the 16-row edge kernel keeps one round of blocks by taking four to six row tiles per block (split path only;
+    the pieces then stay in the exchange buffer and the chains read one k-step at a time)"""
+    import ctypes
+    import mgn_amd
+    pos, cells, _, _ = synth.mesh_cyl(77, n_pts)
+    s, r = synth.cells_to_edges(cells)
+    N, E = pos.shape[0], s.size
+    assert 256 * 3 * 16 < E <= 256 * 6 * 16
+    cfg = cfg_dict(mps=4)
+    ps = make_params(cfg, jitter=0.05)
+    rng = np.random.default_rng(n_pts)
+    v = rng.standard_normal((N, 128)).astype(np.float32)
+    e = rng.standard_normal((E, 128)).astype(np.float32)
+    rv, re = orc.processor_steps(ps, cfg, v, e, s, r, 4)
+    eng = engine_for(cfg)
+    eng.set_params(ps)
+    eng.set_graph(s, r, N)
+    v1, e1 = eng.processor_steps(v, e, 4)
+    lib = mgn_amd.load()
+    lib.mgn_debug_last_edge_kernel.restype = ctypes.c_int
+    assert lib.mgn_debug_last_edge_kernel() == 12
+    assert rel_max(v1, rv) <= TOL_15 and rel_max(e1, re) <= TOL_15, (rel_max(v1, rv), rel_max(e1, re))
+    old = set_c16_split(0)
+    try:
+        f32 = engine_for(cfg)
+        f32.set_params(ps)
+        f32.set_graph(s, r, N)
+        v0, e0 = f32.processor_steps(v, e, 4)
+    finally:
+        set_c16_split(old)
+    assert max(rel_max(v1, rv), rel_max(e1, re)) <= 2.0 * max(rel_max(v0, rv), rel_max(e0, re)) + 1e-7
+    assert not np.array_equal(e0, e1)
+
+
 def test_node_ring_opt_in_kernel(tmp_path):
     """MGN_NODE_RING=1 (read once per process, hence a child process): node MLP + projection of a step in one lock-step launch
     (k_node_ring), on a mesh beyond the cooperative node kernels' range; same tolerances and, by construction, the same bits."""

@@ -1,4 +1,4 @@
-"""Soak of the small-mesh path (16-row cooperative kernels on the split path): meshes of changing size (one to three row tiles per block),
+"""Soak of the small-mesh path (16-row cooperative kernels on the split path): meshes of changing size (one to six row tiles per block),
 one and two edge sets, fp32 and bf16 storage; every configuration is run several times from the same latents and must give the same bits
 every time, finite.  python tools/soak_small.py [rounds]"""
 import os, sys
@@ -11,7 +11,7 @@ ps = bench.glorot_params()
 psf = bench.glorot_params(1234, 12, 7, 3, Fe2=4)
 bad = 0
 for rnd in range(rounds):
-    for n_pts in (400, 900, 1300, 2000):
+    for n_pts in (400, 900, 1300, 2000, 2300, 3200, 3900):
         pos, cells, _, _ = mgn_amd.synth.mesh_cyl(100 + rnd, n_pts)
         s, r = mgn_amd.synth.cells_to_edges(cells)
         for dt in ("f32", "bf16"):
