@@ -50,7 +50,7 @@ struct EdgeArgs {
     // every fp32 operand split into three bf16 pieces, six piece products kept.  split[i]: chunk i as 3 x 16384 bf16 (hi, mid, lo
     // pieces, the bf16 kernels' fragment order); null: not available
     const uint16_t* split[3];
-    const uint16_t* split16[3];   // the same pieces in the fragment order of v_mfma_f32_16x16x32_bf16 (k_edge_ring16; mgn_api.cpp: pack_chunk16_bf16)
+    const uint16_t* split16[3];   // the same pieces in the fragment order of v_mfma_f32_16x16x32_bf16 (k_edge_coop16m on the split path -- fp32 and bf16 storage --, k_edge_ring16; mgn_api.cpp: pack_chunk16_bf16)
     int32_t off32;                // 1: P, Q, AGG and CARRY are each shorter than 2 GiB, so k_edge_ring16 may address them with 32-bit lane offsets
 };
 

@@ -511,7 +511,9 @@ __global__ __launch_bounds__(256, 2) void k_node_coop(const NodeArgs a) {
 // accumulator layout of the instruction -- so an all-gather of the four waves' slices through LDS is the next layer's operand, and
 // k-step (bb, i) contracts register (bb, i) of every lane (weights in that order: pack_chunk16).  HBM storage is unchanged
 // (32-row tile-major): a half tile addresses rows 16 (ht & 1) + n of tile ht >> 1.  Carry rows are per 16-edge tile here
-// (EdgeArgs.c16: the edge and the node kernel of a step agree).
+// (EdgeArgs.c16: the edge and the node kernel of a step agree; the node kernel also runs behind a 32-row edge kernel on mid-size
+// meshes, CSH = 5).  SP (the default wherever the split path is on): the same kernels with their chunks on v_mfma_f32_16x16x32_bf16
+// and three-way split operands -- "the same kernels on the split path" further down.
 // ================================================================================================
 constexpr int C16_CH = 128 * 128;          // floats per chunk copy
 DEVINL f32x4 c16_mfma(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
