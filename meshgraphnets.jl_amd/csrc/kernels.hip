@@ -2093,12 +2093,19 @@ DEVINL void bf_load_aggregate(bf16x8 (&in)[8], f32x16 (&y)[4], const int32_t* __
     if (__any(extra > 0)) {
         zero_frag<4>(y);
         bf_unpack_add(y, in);
-        for (int q = 1; __any(q <= extra); ++q)
-            if (q <= extra) {
-                bf16x8 cr[8];
-                bf_load(cr, bf_row_ptr(CARRY, (int64_t)2 * (T1 + q), h), BF_STRIDE_ROW);
-                bf_unpack_add(y, cr);
-            }
+        {   // the second carry row of a run that straddles one tile boundary (the common case) without a loop: the other lanes add the
+            // zero row (tile_common.hpp: LOAD_AGGREGATE); hub nodes continue in the loop
+            bf16x8 cr[8];
+            bf_load(cr, bf_row_ptr(CARRY, extra >= 1 ? (int64_t)2 * (T1 + 1) : zero_row, h), BF_STRIDE_ROW);
+            bf_unpack_add(y, cr);
+        }
+        if (__any(extra >= 2))
+            for (int q = 2; __any(q <= extra); ++q)
+                if (q <= extra) {
+                    bf16x8 cr[8];
+                    bf_load(cr, bf_row_ptr(CARRY, (int64_t)2 * (T1 + q), h), BF_STRIDE_ROW);
+                    bf_unpack_add(y, cr);
+                }
         bf_pack(in, y);
     }
 }

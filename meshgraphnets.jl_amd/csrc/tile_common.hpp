@@ -156,6 +156,9 @@ DEVINL void copy_to_lds16(uint16_t* dst, const uint16_t* __restrict__ src, int n
 // aggregated messages of the tile's nodes: the node's AGG slot, or carry rows when its edge run straddles edge tiles.
 // A macro on purpose: as a (force-inlined) function the same code costs k_node_step<4,*> 37 spilled VGPRs.
 // Uses tile, nn, valid, lane, h, L of the enclosing tile loop.
+#ifndef MGN_AGG_PEEL
+#define MGN_AGG_PEEL 1
+#endif
 #define LOAD_AGGREGATE(NT_, y_, rowptr_, AGG_, CARRY_, zero_row_)                                                        \
     do {                                                                                                                 \
         const int a0 = valid ? (rowptr_)[nn] : 0, a1 = valid ? (rowptr_)[nn + 1] : 0;                                     \
@@ -165,8 +168,20 @@ DEVINL void copy_to_lds16(uint16_t* dst, const uint16_t* __restrict__ src, int n
         const f32x4* src0 = from_agg ? tile_ptr((AGG_), tile, L, lane)                                                   \
                                      : prow_ptr((CARRY_), extra ? (int64_t)(2 * T1 + 1) : (zero_row_), L, h);            \
         load_frag<NT_>(y_, src0, from_agg ? STRIDE_TILE : STRIDE_PROW);                                                   \
-        for (int q = 1; __any(q <= extra); ++q)                                                                          \
-            if (q <= extra) add_frag<NT_>(y_, prow_ptr((CARRY_), (int64_t)2 * (T1 + q), L, h), STRIDE_PROW);              \
+        /* a run that straddles ONE tile boundary (every 32 edges one node's does) is the common case: its second carry row   \
+           without a loop and without a branch (the other lanes add the zero row); only hub nodes enter the loop behind it -- \
+           as the loop's first trip this cost every tile 64 loop-carried register copies and a spill that was reloaded, with  \
+           s_waitcnt vmcnt(0), in the middle of the next chain */                                                            \
+        if (MGN_AGG_PEEL) {                                                                                              \
+            if (__any(extra >= 1))                                                                                       \
+                add_frag<NT_>(y_, prow_ptr((CARRY_), extra >= 1 ? (int64_t)2 * (T1 + 1) : (zero_row_), L, h), STRIDE_PROW); \
+            if (__any(extra >= 2))                                                                                       \
+                for (int q = 2; __any(q <= extra); ++q)                                                                  \
+                    if (q <= extra) add_frag<NT_>(y_, prow_ptr((CARRY_), (int64_t)2 * (T1 + q), L, h), STRIDE_PROW);      \
+        } else {                                                                                                         \
+            for (int q = 1; __any(q <= extra); ++q)                                                                      \
+                if (q <= extra) add_frag<NT_>(y_, prow_ptr((CARRY_), (int64_t)2 * (T1 + q), L, h), STRIDE_PROW);          \
+        }                                                                                                                \
     } while (0)
 
 }  // namespace mgn
