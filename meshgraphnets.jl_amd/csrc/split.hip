@@ -41,6 +41,9 @@ DEVINL void n16_st(const N16Buf& b, unsigned voff, int soff, f32x4 v) {
 }
 DEVINL u32x4 n16_ldu(const N16Buf& b, unsigned voff, int soff) { return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(b.r, (int)voff, soff, 0)); }
 
+#ifndef MGN_SP_CARRY
+#define MGN_SP_CARRY 1            // k_node_split, k_project_split: weight rings carried from chain to chain (needs MGN_SP_BUFFER)
+#endif
 #ifndef MGN_SP_BUFFER
 #define MGN_SP_BUFFER 1           // sp_layer_otf: streamed weight pieces through buffer descriptors (0: 64-bit pointers)
 #endif
@@ -51,8 +54,14 @@ DEVINL u32x4 n16_ldu(const N16Buf& b, unsigned voff, int soff) { return __builti
 // One L x L layer: acc += W^T in, `in` split on the fly.  p1 / p2 / p3: the chunk's hi / mid / lo piece ([s][t][lane] fragments of
 // 8 bf16).  p1 is LDS-resident; G2 / G3: p2 / p3 stream from L2 through register rings D (s, t) groups deep (else LDS too).  The
 // rings are pinned by scheduling fences: left to itself hipcc requests every streamed fragment one MFMA before its use.
-template <bool G2, bool G3, bool RELU, int D, bool G1 = false>
-DEVINL void sp_layer_otf(f32x16 (&acc)[4], const f32x16 (&in)[4], const u32x4* p1, const u32x4* p2, const u32x4* p3, int lane) {
+// The rings can be carried from chain to chain (SpRing, CARRY = 1): fragment f of a chain lives in slot (f + OFF) % D, and while the
+// last D steps of this chain release their slots the FIRST D fragments of the next chain (nx2 / nx3: its mid / lo pieces) are requested
+// into them -- its ring is full when it starts (offset (OFF + 32) % D) instead of every chain opening with an L2 round trip.
+// PRIMED: the ring came that way; NEXT: this chain primes the one behind it.
+template <int D> struct SpRing { u32x4 r2[D], r3[D]; };
+template <bool G2, bool G3, bool RELU, int D, bool G1 = false, int OFF = 0, bool PRIMED = false, bool NEXT = false>
+DEVINL void sp_layer_otf(f32x16 (&acc)[4], const f32x16 (&in)[4], const u32x4* p1, const u32x4* p2, const u32x4* p3, int lane,
+                         SpRing<D>* carry = nullptr, const u32x4* nx2 = nullptr, const u32x4* nx3 = nullptr) {
     const u32x4* w1 = p1 + lane;
     const u32x4* w2 = p2 + lane;
     const u32x4* w3 = p3 + lane;
@@ -68,13 +77,25 @@ DEVINL void sp_layer_otf(f32x16 (&acc)[4], const f32x16 (&in)[4], const u32x4* p
 #define SP_G2(IDX) w2[(IDX) * 64]
 #define SP_G3(IDX) w3[(IDX) * 64]
 #endif
+    static_assert(!(PRIMED || NEXT) || (MGN_SP_BUFFER && !G1), "ring carry-over is written for the descriptor path, mid / lo streams");
     u32x4 r1[G1 ? D : 1], r2[G2 ? D : 1], r3[G3 ? D : 1];      // G1: the hi piece streams from L2 as well (a chunk that has no room in LDS)
+    if constexpr (PRIMED) {
 #pragma unroll
-    for (int d = 0; d < D; ++d) {
-        if constexpr (G1) r1[d] = SP_G1(d);
-        if constexpr (G2) r2[d] = SP_G2(d);
-        if constexpr (G3) r3[d] = SP_G3(d);
+        for (int d = 0; d < D; ++d) {
+            if constexpr (G2) r2[d] = carry->r2[d];
+            if constexpr (G3) r3[d] = carry->r3[d];
+        }
+    } else {
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            if constexpr (G1) r1[d] = SP_G1(d);
+            if constexpr (G2) r2[(d + OFF) % D] = SP_G2(d);
+            if constexpr (G3) r3[(d + OFF) % D] = SP_G3(d);
+        }
     }
+#if MGN_SP_BUFFER
+    const N16Buf c2 = n16_buf(NEXT && G2 ? nx2 : nullptr), c3 = n16_buf(NEXT && G3 ? nx3 : nullptr);
+#endif
     u32x4 n1, n2, n3;
     if constexpr (!G1) n1 = w1[0];
     if constexpr (!G2) n2 = w2[0];
@@ -91,8 +112,8 @@ DEVINL void sp_layer_otf(f32x16 (&acc)[4], const f32x16 (&in)[4], const u32x4* p
             const int it = 4 * s + t;
             u32x4 a1, a2, a3;
             if constexpr (G1) a1 = r1[it % D]; else a1 = n1;
-            if constexpr (G2) a2 = r2[it % D]; else a2 = n2;
-            if constexpr (G3) a3 = r3[it % D]; else a3 = n3;
+            if constexpr (G2) a2 = r2[(it + OFF) % D]; else a2 = n2;
+            if constexpr (G3) a3 = r3[(it + OFF) % D]; else a3 = n3;
             if (it + 1 < 32) {
                 if constexpr (!G1) n1 = w1[(it + 1) * 64];
                 if constexpr (!G2) n2 = w2[(it + 1) * 64];
@@ -100,8 +121,13 @@ DEVINL void sp_layer_otf(f32x16 (&acc)[4], const f32x16 (&in)[4], const u32x4* p
             }
             if (it + D < 32) {
                 if constexpr (G1) r1[it % D] = SP_G1(it + D);
-                if constexpr (G2) r2[it % D] = SP_G2(it + D);
-                if constexpr (G3) r3[it % D] = SP_G3(it + D);
+                if constexpr (G2) r2[(it + OFF) % D] = SP_G2(it + D);
+                if constexpr (G3) r3[(it + OFF) % D] = SP_G3(it + D);
+            } else if constexpr (NEXT) {
+#if MGN_SP_BUFFER
+                if constexpr (G2) r2[(it + OFF) % D] = n16_ldu(c2, voff, (it + D - 32) * 1024);
+                if constexpr (G3) r3[(it + OFF) % D] = n16_ldu(c3, voff, (it + D - 32) * 1024);
+#endif
             }
             if (s < 7) {
                 const int sn = s + 1;
@@ -138,6 +164,13 @@ DEVINL void sp_layer_otf(f32x16 (&acc)[4], const f32x16 (&in)[4], const u32x4* p
             __builtin_amdgcn_sched_barrier(0);
         }
         p = n;
+    }
+    if constexpr (NEXT) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            if constexpr (G2) carry->r2[d] = r2[d];
+            if constexpr (G3) carry->r3[d] = r3[d];
+        }
     }
 }
 
@@ -933,6 +966,29 @@ __global__ __launch_bounds__(512, 2) void k_node_split(const NodeArgs a) {
         tab_frag<NT>(acc, tb + T_B3 * L, h);
         sp_layer_otf<false, false, true, D>(acc, x, l3h, l3h, l3h, lane);
 #else
+#if MGN_SP_CARRY
+        // the weight rings are carried from chain to chain: every chain requests the first fragments of the next one in its last steps
+        constexpr int O1 = 32 % D, O2 = 64 % D, O3 = 96 % D;
+        SpRing<D> rg;
+        sp_layer_otf<true, true, false, D, false, 0, false, true>(acc, x, lvh, gv + 2048, gv + 4096, lane, &rg, ga + 2048, ga + 4096);   // layer 1, node part
+        LOAD_AGGREGATE(NT, x, a.rowptr, a.AGG, a.CARRY, a.zero_row);
+        if constexpr (TWO) {
+            sp_layer_otf<true, true, false, D, false, O1, true, false>(acc, x, lah, ga + 2048, ga + 4096, lane, &rg);                  // aggregate part
+            const u32x4* gb = reinterpret_cast<const u32x4*>(a.split[6]);
+            LOAD_AGGREGATE(NT, x, a.rowptr2, a.AGG2, a.CARRY2, a.zero_row2);
+            sp_layer_otf<true, true, false, MGN_SP2_D3, true>(acc, x, gb, gb + 2048, gb + 4096, lane);                                 // the second set's aggregate
+            tab_frag<NT>(x, tb + T_B2 * L, h);
+            sp_layer_otf<true, true, true, D, false, 0, false, true>(x, acc, l2h, g2 + 2048, g2 + 4096, lane, &rg, g3 + 2048, g3 + 4096);   // layer 2
+            tab_frag<NT>(acc, tb + T_B3 * L, h);
+            sp_layer_otf<true, true, true, D, false, O1, true, false>(acc, x, l3h, g3 + 2048, g3 + 4096, lane, &rg);                   // layer 3
+        } else {
+            sp_layer_otf<true, true, false, D, false, O1, true, true>(acc, x, lah, ga + 2048, ga + 4096, lane, &rg, g2 + 2048, g2 + 4096);   // aggregate part
+            tab_frag<NT>(x, tb + T_B2 * L, h);
+            sp_layer_otf<true, true, true, D, false, O2, true, true>(x, acc, l2h, g2 + 2048, g2 + 4096, lane, &rg, g3 + 2048, g3 + 4096);    // layer 2
+            tab_frag<NT>(acc, tb + T_B3 * L, h);
+            sp_layer_otf<true, true, true, D, false, O3, true, false>(acc, x, l3h, g3 + 2048, g3 + 4096, lane, &rg);                  // layer 3
+        }
+#else
         sp_layer_otf<true, true, false, D>(acc, x, lvh, gv + 2048, gv + 4096, lane);      // layer 1, node part
         LOAD_AGGREGATE(NT, x, a.rowptr, a.AGG, a.CARRY, a.zero_row);
         sp_layer_otf<true, true, false, D>(acc, x, lah, ga + 2048, ga + 4096, lane);      // layer 1, aggregate part
@@ -945,6 +1001,7 @@ __global__ __launch_bounds__(512, 2) void k_node_split(const NodeArgs a) {
         sp_layer_otf<true, true, true, D>(x, acc, l2h, g2 + 2048, g2 + 4096, lane);       // layer 2 (ReLU folded into the split)
         tab_frag<NT>(acc, tb + T_B3 * L, h);
         sp_layer_otf<true, true, true, D>(acc, x, l3h, g3 + 2048, g3 + 4096, lane);       // layer 3
+#endif
 #endif
         PHASE_FENCE();
         __builtin_amdgcn_s_setprio(MGN_NODE_MPRIO);
@@ -1361,7 +1418,12 @@ __global__ __launch_bounds__(512, 2) void k_project_split(const NodeArgs a) {
 #if defined(MGN_WHATIF_NODE) && (MGN_WHATIF_NODE & 1)
         sp_layer_otf<false, false, false, D1>(acc, x, lph, lpm, lpm, lane);
 #else
+#if MGN_SP_CARRY
+        SpRing<D1> rg;                                               // WP's chain requests the first lo fragments of WQ in its last steps
+        sp_layer_otf<false, true, false, D1, false, 0, false, true>(acc, x, lph, lpm, gp + 4096, lane, &rg, nullptr, gq + 4096);
+#else
         sp_layer_otf<false, true, false, D1>(acc, x, lph, lpm, gp + 4096, lane);
+#endif
 #endif
         __builtin_amdgcn_s_setprio(MGN_NODE_MPRIO);
 #if defined(MGN_WHATIF_NODE) && (MGN_WHATIF_NODE & 8)      // diagnostic: P / Q stored tile-major (coalesced) instead of row-major
@@ -1376,7 +1438,11 @@ __global__ __launch_bounds__(512, 2) void k_project_split(const NodeArgs a) {
 #if defined(MGN_WHATIF_NODE) && (MGN_WHATIF_NODE & 1)
         sp_layer_otf<false, false, false, D1>(acc, x, lqh, lqm, lqm, lane);
 #else
+#if MGN_SP_CARRY
+        sp_layer_otf<false, true, false, D1, false, 32 % D1, true, false>(acc, x, lqh, lqm, gq + 4096, lane, &rg);
+#else
         sp_layer_otf<false, true, false, D1>(acc, x, lqh, lqm, gq + 4096, lane);
+#endif
 #endif
         __builtin_amdgcn_s_setprio(MGN_NODE_MPRIO);
 #if MGN_NODE_VNEXT_FIRST
