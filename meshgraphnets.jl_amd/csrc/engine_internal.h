@@ -78,6 +78,8 @@ struct mgn_engine {
 
     // parameters
     bool have_params = false;
+    bool packed_ok = false;     // the kernels' weight layouts (wfrag, wsp, wbf) are those of `params`: mgn_set_params only stores the vector,
+                                // the first compute call that reads them packs (a training loop -- set_params, step!, ... -- never does)
     std::vector<float> params;  // packed, host
     MlpOff enc_node, dec;
     std::vector<MlpOff> pn;
@@ -177,7 +179,8 @@ struct mgn_engine {
 namespace mgn {
 
 int fail(mgn_engine* h, int code, const char* fmt, ...);
-int need(mgn_engine* h, bool params, bool graph);
+int need(mgn_engine* h, bool params, bool graph, bool packed = true);   // packed = false: the caller reads h->params only (training, get_params)
+int pack_inference_weights(mgn_engine* h);
 // L x L chunk of W (row-major [K][ldw], rows kbase.., all L output columns) -> MFMA fragment order
 void pack_chunk(float* dst, const float* W, int ldw, int kbase, int L);
 void pack_chunk_tmajor(float* dst, const float* frag, int L);

@@ -214,7 +214,7 @@ void pack_chunk_bf16(uint16_t* dst, const float* W, int ldw, int kbase) {
 
 }  // namespace
 namespace mgn {
-int need(mgn_engine* h, bool params, bool graph) {
+int need(mgn_engine* h, bool params, bool graph, bool packed) {
     if (!h) return MGN_E_ARG;
     if (h->host_only) return fail(h, MGN_E_HIP, "host-only handle (MGN_DEVICE_NONE): no compute path; create the handle on a HIP device");
     // whole-array LayerNorm couples every row of an MLP's output: the fused kernels behind the other compute entry points cannot
@@ -223,6 +223,7 @@ int need(mgn_engine* h, bool params, bool graph) {
         return fail(h, MGN_E_UNSUPPORTED, "ln_dims = MGN_LN_ALL (whole-array LayerNorm) is served by mgn_forward and mgn_processor_steps only");
     if (params && !h->have_params) return fail(h, MGN_E_STATE, "mgn_set_params has not been called");
     if (graph && !h->have_graph) return fail(h, MGN_E_STATE, "mgn_set_graph has not been called");
+    if (params && packed && !h->packed_ok) return pack_inference_weights(h);
     return MGN_OK;
 }
 }  // namespace mgn
@@ -652,6 +653,21 @@ int mgn_set_params(mgn_handle* h, const float* packed, size_t n) try {
     if (n != want) return fail(h, MGN_E_ARG, "mgn_set_params: got %zu floats, model needs %zu", n, want);
     h->params.assign(packed, packed + n);
     train_invalidate(h, 1);
+    // The kernels' own weight layouts (three fp32 fragment orders, the bf16 pieces of the split path in two, the bf16 copies) take
+    // ~30 ms of host time for the 15-step model; a training loop sets new parameters before EVERY step! and its kernels pack their own
+    // (mgn_train.cpp) -- so they are built by the first call that reads them (need()), not here.
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    drop_graph(h);
+    invalidate_static(h);
+    h->packed_ok = false;
+    h->have_params = true;
+    return MGN_OK;
+} MGN_CATCH(h)
+}  // extern "C"
+
+namespace mgn {
+int pack_inference_weights(mgn_engine* h) {
+    layout_all(h);
     const float* p = h->params.data();
     const mgn_config& c = h->cfg;
     const int L = c.L;
@@ -880,12 +896,14 @@ int mgn_set_params(mgn_handle* h, const float* packed, size_t n) try {
     invalidate_static(h);
     HIPCHK(h, h->wfrag.ensure(f.size() * 4));
     HIPCHK(h, hipMemcpy(h->wfrag.p, f.data(), f.size() * 4, hipMemcpyHostToDevice));
-    h->have_params = true;
+    h->packed_ok = true;
     return MGN_OK;
-} MGN_CATCH(h)
+}
+}  // namespace mgn
+extern "C" {
 
 int mgn_get_params(mgn_handle* h, float* packed, size_t n) try {
-    if (int rc = need(h, true, false)) return rc;
+    if (int rc = need(h, true, false, false)) return rc;
     if (!packed || n != h->params.size()) return fail(h, MGN_E_ARG, "mgn_get_params: size mismatch");
     memcpy(packed, h->params.data(), n * sizeof(float));
     return MGN_OK;

@@ -66,6 +66,11 @@ struct WgradJob { const float* X; const int32_t* xidx; const float* G; int64_t r
 struct WgradBatch { int32_t njobs; int64_t rows_per_block; WgradJob job[WGRAD_MAX_JOBS]; };
 int wgrad_blocks(int64_t rows);
 int wgrad_blocks_of_job(int64_t launch_rows, int64_t job_rows);   // blocks of a launch sized for launch_rows that touch a job with fewer rows
+// one packed copy of the training weights: kind 0 = an L x L chunk in fragment order + its t-major copy at + L * L, from rows [r0, r0 + nr)
+// x cols [0, nc) of the matrix at params + src (leading dimension ldw; src < 0: the identity), zero-padded, transposed on request;
+// kind 1 = T_COUNT * L table floats copied from tabs + src
+struct PackJob { long long off, src; int ldw, r0, nr, nc, transpose, kind; };
+hipError_t launch_pack_train(int L, const PackJob* jobs, int njobs, const float* params, const float* tabs, float* out, hipStream_t s);
 hipError_t launch_wgrad(int L, WgradBatch wb, int64_t rows, hipStream_t s);
 // out[r * cols + c] = sum_b partial[b * block_stride + r * ld + c]   (fixed order: bitwise reproducible), one job per blockIdx.y
 constexpr int REDUCE_MAX_JOBS = 16;

@@ -834,6 +834,36 @@ int wgrad_blocks(int64_t rows) {
     return (int)((rows + rpb - 1) / rpb);
 }
 
+// the training weights from the parameter vector, on the device (mgn_train.cpp: pack_training_weights; the host twins are pack_chunk /
+// pack_chunk_tmajor of mgn_api.cpp): one block column per job
+__global__ void k_pack_train(const PackJob* __restrict__ jobs, const float* __restrict__ params, const float* __restrict__ tabs,
+                             float* __restrict__ out, int L) {
+    const PackJob jb = jobs[blockIdx.y];
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (jb.kind == 1) {
+        if (idx < T_COUNT * L) out[jb.off + idx] = tabs[jb.src + idx];
+        return;
+    }
+    const int NT = L / 32, J = L / 2;
+    if (idx >= L * L) return;
+    const int t = idx % NT, lane = (idx / NT) % 64, j = idx / (NT * 64);
+    const int hh = lane >> 5, i = lane & 31;
+    const int row = 32 * (j >> 4) + (j & 3) + 8 * ((j & 15) >> 2) + 4 * hh;      // phi(j, hh): the input feature of k-step j, half hh
+    const int col = 32 * t + i;
+    float v;
+    if (jb.src < 0) v = row == col ? 1.f : 0.f;
+    else if (jb.transpose) v = (col < jb.nr && row < jb.nc) ? params[jb.src + (long long)(jb.r0 + col) * jb.ldw + row] : 0.f;
+    else v = (row < jb.nr && col < jb.nc) ? params[jb.src + (long long)(jb.r0 + row) * jb.ldw + col] : 0.f;
+    out[jb.off + idx] = v;
+    out[jb.off + (long long)L * L + (((long long)t * (J / 4) + j / 4) * 64 + lane) * 4 + (j & 3)] = v;
+}
+hipError_t launch_pack_train(int L, const PackJob* jobs, int njobs, const float* params, const float* tabs, float* out, hipStream_t s) {
+    if (njobs <= 0) return hipSuccess;
+    const int n = L * L > T_COUNT * L ? L * L : T_COUNT * L;
+    hipLaunchKernelGGL(k_pack_train, dim3((n + 255) / 256, njobs), dim3(256), 0, s, jobs, params, tabs, out, L);
+    return hipGetLastError();
+}
+
 hipError_t launch_wgrad(int L, WgradBatch wb, int64_t rows, hipStream_t s) {
     const int nb = wgrad_blocks(rows);
     if (nb == 0 || wb.njobs <= 0) return hipSuccess;

@@ -21,6 +21,6 @@ for line in open(sys.argv[1]):
         print("  scattered vs coherent: f32 x%.3f, bf16 x%.3f" % (sc["vs_coherent_f32"], sc["vs_coherent_bf16"]))
     sec = d.get("secondary", {})
     if sec:
-        print("  M-cyl %.1f us/pstep | rollout Euler %.1f ms, Tsit5 %.1f ms | train step %.2f ms" % (
+        print("  M-cyl %.1f us/pstep | rollout Euler %.1f ms, Tsit5 %.1f ms | train step %.2f ms (%.2f with new parameters every step)" % (
             sec["us_per_processor_step"], sec["rollout_100_saves"]["Euler"]["ms_per_rollout"], sec["rollout_100_saves"]["Tsit5"]["ms_per_rollout"],
-            sec.get("train_step", {}).get("ms_per_step", 0.0)))
+            sec.get("train_step", {}).get("ms_per_step", 0.0), sec.get("train_step", {}).get("ms_per_iteration_with_new_params", 0.0)))
