@@ -13,6 +13,7 @@
 #include "comm.h"
 #include "graph_host.h"
 #include "kernels.h"
+#include "train.h"
 
 namespace mgn {
 
@@ -78,6 +79,8 @@ struct mgn_engine {
 
     // parameters
     bool have_params = false;
+    DevBuf d_params, d_wjobs;   // the parameter vector and the chunk list on the device: what k_pack_weights builds the layouts from
+    std::vector<mgn::WPackJob> wjobs;   // (the list, kept for mgn_debug_pack_check)
     bool packed_ok = false;     // the kernels' weight layouts (wfrag, wsp, wbf) are those of `params`: mgn_set_params only stores the vector,
                                 // the first compute call that reads them packs (a training loop -- set_params, step!, ... -- never does)
     std::vector<float> params;  // packed, host

@@ -16,6 +16,7 @@
 #include <vector>
 
 #include "engine_internal.h"
+#include "train.h"
 #include "graph_dev.h"
 
 using namespace mgn;
@@ -673,15 +674,23 @@ int pack_inference_weights(mgn_engine* h) {
     const int L = c.L;
     const size_t CH = (size_t)L * L, TB = (size_t)T_COUNT * L;
 
+    // The L x L chunks -- all but a megabyte of the ~60 MB of layouts -- are written ON THE DEVICE from the uploaded parameter vector
+    // (train.hip: k_pack_weights; the host twins pack_chunk / pack_chunk_tmajor / pack_chunk16 / pack_chunk_bf16 / pack_chunk16_bf16
+    // stay as their specification): the host describes them (WPackJob) and keeps packing the small things (tables, first-layer
+    // vectors) into `f`, whose chunk regions stay empty and are not uploaded (segments between them are).  30 ms -> ~3 ms per
+    // parameter change.
     std::vector<float> f;
+    std::vector<WPackJob> jobs;
+    std::vector<std::pair<size_t, size_t>> small;           // [begin, end) of what the host packed itself
+    size_t seg0 = 0;
     // every chunk is stored three times: [lane-interleaved fragment order][t-major order (cooperative 32-row kernels)]
     // [16x16x4 fragment order (cooperative 16-row kernels, L = 128)]: copies of the chunk at offset `off` live at off + CH, off + 2 CH
     auto add_chunk = [&](const float* Wm, int ldw, int kbase) {
         const size_t off = f.size();
+        if (off > seg0) small.push_back({seg0, off});
         f.resize(off + 3 * CH);
-        pack_chunk(f.data() + off, Wm, ldw, kbase, L);
-        pack_chunk_tmajor(f.data() + off + CH, f.data() + off, L);
-        if (L == 128) pack_chunk16(f.data() + off + 2 * CH, Wm, ldw, kbase);
+        seg0 = off + 3 * CH;
+        jobs.push_back({0, (long long)off, (long long)(Wm - p), ldw, kbase});
         return off;
     };
     auto add_tabs = [&](const float* b1, const float* b2, const float* b3, const float* ga, const float* be, const float* bq) {
@@ -807,17 +816,16 @@ int pack_inference_weights(mgn_engine* h) {
         // 16x16x32 one (the 16-row cooperative kernels of small meshes -- in bf16 storage mode too, where they keep fp32-accurate
         // arithmetic --, k_edge_ring16)
         const bool f32 = c.dtype == MGN_F32;
-        std::vector<uint16_t> ws(((size_t)c.mps * S * 3 + (node_side ? (size_t)(c.mps + 1) * (S == 2 ? 9 : 6) : 0)) * (f32 ? 2 : 1) * 3 * 16384);
         h->spoff.assign(c.mps + 1, {});
         size_t off = 0;
         auto put = [&](const float* src, int kb, size_t& o32, size_t& o16) {
             o32 = 0;
             if (f32) {
-                pack_chunk_split(ws.data() + off, src, L, kb);
+                jobs.push_back({1, (long long)off, (long long)(src - p), L, kb});
                 o32 = off;
                 off += (size_t)3 * 16384;
             }
-            pack_chunk_split(ws.data() + off, src, L, kb, true);
+            jobs.push_back({2, (long long)off, (long long)(src - p), L, kb});
             o16 = off;
             off += (size_t)3 * 16384;
         };
@@ -843,15 +851,14 @@ int pack_inference_weights(mgn_engine* h) {
             h->spoff[k].have_n = true;
         }
         HIPCHK(h, hipStreamSynchronize(h->stream));
-        HIPCHK(h, h->wsp.ensure(ws.size() * 2));
-        HIPCHK(h, hipMemcpy(h->wsp.p, ws.data(), ws.size() * 2, hipMemcpyHostToDevice));
+        HIPCHK(h, h->wsp.ensure(off * 2));
     }
+    size_t wb_size = 0;
     if (c.dtype == MGN_BF16) {
-        std::vector<uint16_t> wb;
         auto addb = [&](const float* Wm, int kbase) {
-            const size_t off = wb.size();
-            wb.resize(off + (size_t)L * L);
-            pack_chunk_bf16(wb.data() + off, Wm, L, kbase);
+            const size_t off = wb_size;
+            wb_size += (size_t)L * L;
+            jobs.push_back({3, (long long)off, (long long)(Wm - p), L, kbase});
             return off;
         };
         h->bsoff.assign(c.mps + 1, {});
@@ -888,14 +895,23 @@ int pack_inference_weights(mgn_engine* h) {
             h->bsoff[c.mps].p1_ch[1] = addb(p + e1.W[0], L);
         }
         HIPCHK(h, hipStreamSynchronize(h->stream));
-        HIPCHK(h, h->wbf.ensure(wb.size() * 2));
-        HIPCHK(h, hipMemcpy(h->wbf.p, wb.data(), wb.size() * 2, hipMemcpyHostToDevice));
+        HIPCHK(h, h->wbf.ensure(wb_size * 2));
     }
     HIPCHK(h, hipStreamSynchronize(h->stream));
     drop_graph(h);
     invalidate_static(h);
+    if (f.size() > seg0) small.push_back({seg0, f.size()});
     HIPCHK(h, h->wfrag.ensure(f.size() * 4));
-    HIPCHK(h, hipMemcpy(h->wfrag.p, f.data(), f.size() * 4, hipMemcpyHostToDevice));
+    HIPCHK(h, h->d_params.ensure(h->params.size() * 4));
+    HIPCHK(h, h->d_wjobs.ensure(jobs.size() * sizeof(WPackJob)));
+    HIPCHK(h, hipMemcpyAsync(h->d_params.p, p, h->params.size() * 4, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->d_wjobs.p, jobs.data(), jobs.size() * sizeof(WPackJob), hipMemcpyHostToDevice, h->stream));
+    for (const auto& sg : small)
+        HIPCHK(h, hipMemcpyAsync(h->wfrag.as<float>() + sg.first, f.data() + sg.first, (sg.second - sg.first) * 4, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, launch_pack_weights(L, h->d_wjobs.as<WPackJob>(), (int)jobs.size(), h->d_params.as<float>(), h->wfrag.as<float>(),
+                                  h->wsp.as<uint16_t>(), h->wbf.as<uint16_t>(), h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));       // (f and jobs are locals: their copies must have left the host)
+    h->wjobs = std::move(jobs);
     h->packed_ok = true;
     return MGN_OK;
 }
@@ -2523,6 +2539,37 @@ int mgn_debug_fp32_split(int on) { return set_fp32_split(on); }
 // 1: the edge kernel of the split path on v_mfma_f32_16x16x32_bf16 (k_edge_ring16); takes effect at the next mgn_set_params (its weight
 // fragments are packed there).  Returns the old value.  Environment: MGN_EDGE_RING16.
 int mgn_debug_edge_ring16(int on) { return set_edge_ring16(on); }
+// tests: every chunk the device packed (k_pack_weights) against the host functions that specify the layouts; returns the number of
+// elements that differ (0 = bitwise equal), < 0 on error
+long long mgn_debug_pack_check(mgn_handle* h) try {
+    if (int rc = need(h, true, false)) return -rc;
+    const int L = h->cfg.L;
+    const size_t CH = (size_t)L * L;
+    const float* p = h->params.data();
+    long long bad = 0;
+    std::vector<float> hf(3 * CH), df(3 * CH);
+    std::vector<uint16_t> hb(3 * 16384), db(3 * 16384);
+    for (const WPackJob& jb : h->wjobs) {
+        const float* W = p + jb.src;
+        if (jb.kind == 0) {
+            const size_t n = (L == 128 ? 3 : 2) * CH;
+            pack_chunk(hf.data(), W, jb.ldw, jb.kbase, L);
+            pack_chunk_tmajor(hf.data() + CH, hf.data(), L);
+            if (L == 128) pack_chunk16(hf.data() + 2 * CH, W, jb.ldw, jb.kbase);
+            if (hipMemcpy(df.data(), h->wfrag.as<float>() + jb.off, n * 4, hipMemcpyDeviceToHost) != hipSuccess) return -MGN_E_HIP;
+            for (size_t i = 0; i < n; ++i) bad += memcmp(&hf[i], &df[i], 4) != 0;
+        } else if (jb.kind == 3) {
+            pack_chunk_bf16(hb.data(), W, jb.ldw, jb.kbase);
+            if (hipMemcpy(db.data(), h->wbf.as<uint16_t>() + jb.off, 16384 * 2, hipMemcpyDeviceToHost) != hipSuccess) return -MGN_E_HIP;
+            for (size_t i = 0; i < 16384; ++i) bad += hb[i] != db[i];
+        } else {
+            pack_chunk_split(hb.data(), W, jb.ldw, jb.kbase, jb.kind == 2);
+            if (hipMemcpy(db.data(), h->wsp.as<uint16_t>() + jb.off, 3 * 16384 * 2, hipMemcpyDeviceToHost) != hipSuccess) return -MGN_E_HIP;
+            for (size_t i = 0; i < 3 * 16384; ++i) bad += hb[i] != db[i];
+        }
+    }
+    return bad;
+} catch (...) { return -MGN_E_OOM; }
 int mgn_debug_c16_split(int on) { return set_c16_split(on); }   // bits: 1 edge kernel (default), 2 node kernel, 4 edge kernel at one row tile per block; 0: fp32 MFMA pipe (kernels.hip)
 int mgn_debug_last_node_kernel(void) { return last_node_kernel(); }   // the same for the node MLP (codes: kernels.hip, launch_node_step)
 int mgn_debug_last_edge_kernel(void) { return last_edge_kernel(); }   // kernels.hip: which family the last fp32 edge launch ran on

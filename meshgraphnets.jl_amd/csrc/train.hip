@@ -834,6 +834,66 @@ int wgrad_blocks(int64_t rows) {
     return (int)((rows + rpb - 1) / rpb);
 }
 
+// the inference layouts from the parameter vector, on the device (mgn_api.cpp: pack_inference_weights)
+DEVINL uint16_t pk_bf16(float f) {                      // round to nearest even (finite weights)
+    unsigned u = __builtin_bit_cast(unsigned, f);
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+DEVINL float pk_f32(uint16_t b) { return __builtin_bit_cast(float, (unsigned)b << 16); }
+__global__ void k_pack_weights(const WPackJob* __restrict__ jobs, const float* __restrict__ params, float* __restrict__ wfrag,
+                               uint16_t* __restrict__ wsp, uint16_t* __restrict__ wbf, int L) {
+    const WPackJob jb = jobs[blockIdx.y];
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= L * L) return;
+    const float* W = params + jb.src + (long long)jb.kbase * jb.ldw;
+    if (jb.kind == 0) {
+        const int NT = L / 32, J = L / 2;
+        {   // fragment order + its t-major copy: element (j, lane, t)
+            const int t = idx % NT, lane = (idx / NT) % 64, j = idx / (NT * 64);
+            const int hh = lane >> 5, i = lane & 31;
+            const int row = 32 * (j >> 4) + (j & 3) + 8 * ((j & 15) >> 2) + 4 * hh;
+            const float v = W[(long long)row * jb.ldw + 32 * t + i];
+            wfrag[jb.off + idx] = v;
+            wfrag[jb.off + (long long)L * L + (((long long)t * (J / 4) + j / 4) * 64 + lane) * 4 + (j & 3)] = v;
+        }
+        if (L == 128) {   // 16x16x4 order: dst[(((w * 8 + bb) * 2 + j) * 64 + lane) * 4 + i] = W[16 bb + 4 (lane >> 4) + i][16 (2 w + j) + (lane & 15)]
+            const int i = idx & 3, lane = (idx >> 2) & 63, j = (idx >> 8) & 1, bb = (idx >> 9) & 7, w = idx >> 12;
+            wfrag[jb.off + 2LL * L * L + idx] = W[(long long)(16 * bb + 4 * (lane >> 4) + i) * jb.ldw + 16 * (2 * w + j) + (lane & 15)];
+        }
+        return;
+    }
+    // bf16 layouts (L = 128): element j of lane `lane` of fragment `fr`
+    const int j = idx & 7, lane = (idx >> 3) & 63, fr = idx >> 9;
+    int k, n;
+    if (jb.kind == 2) {           // [ks][ob][lane][8]: input 16 (2 ks + (j >> 2)) + 4 (lane >> 4) + (j & 3), output 16 ob + (lane & 15)
+        const int ks = fr >> 3, ob = fr & 7;
+        k = 16 * (2 * ks + (j >> 2)) + 4 * (lane >> 4) + (j & 3);
+        n = 16 * ob + (lane & 15);
+    } else {                      // [s][t][lane][8]: input 32 (s >> 1) + 16 (s & 1) + 8 (j >> 2) + 4 hh + (j & 3), output 32 t + i
+        const int sidx = fr >> 2, t = fr & 3, hh = lane >> 5, i = lane & 31;
+        k = 32 * (sidx >> 1) + 16 * (sidx & 1) + 8 * (j >> 2) + 4 * hh + (j & 3);
+        n = 32 * t + i;
+    }
+    const float w = W[(long long)k * jb.ldw + n];
+    if (jb.kind == 3) {
+        wbf[jb.off + idx] = pk_bf16(w);
+        return;
+    }
+    const uint16_t hi = pk_bf16(w);                     // w = hi + mid + lo exactly (split.hip)
+    const float r1 = w - pk_f32(hi);
+    const uint16_t mid = pk_bf16(r1);
+    const float r2 = r1 - pk_f32(mid);
+    wsp[jb.off + idx] = hi;
+    wsp[jb.off + 16384 + idx] = mid;
+    wsp[jb.off + 2 * 16384 + idx] = pk_bf16(r2);
+}
+hipError_t launch_pack_weights(int L, const WPackJob* jobs, int njobs, const float* params, float* wfrag, uint16_t* wsp, uint16_t* wbf, hipStream_t s) {
+    if (njobs <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_pack_weights, dim3((L * L + 255) / 256, njobs), dim3(256), 0, s, jobs, params, wfrag, wsp, wbf, L);
+    return hipGetLastError();
+}
+
 // the training weights from the parameter vector, on the device (mgn_train.cpp: pack_training_weights; the host twins are pack_chunk /
 // pack_chunk_tmajor of mgn_api.cpp): one block column per job
 __global__ void k_pack_train(const PackJob* __restrict__ jobs, const float* __restrict__ params, const float* __restrict__ tabs,

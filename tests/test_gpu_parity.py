@@ -274,3 +274,20 @@ def test_compute_from_plain_c(tmp_path):
     assert np.array_equal(eng.forward(nf, ef), out_c)
     gs_py, loss_py = eng.step(nf, ef, target, mask)
     assert loss_py == loss_c and np.array_equal(gs_py, gs_c)
+
+
+@pytest.mark.parametrize("dtype,L,hl,two", [("f32", 128, 2, False), ("f32", 128, 3, False), ("f32", 64, 2, False), ("bf16", 128, 2, True), ("f32", 128, 2, True)])
+def test_device_packed_weight_layouts_equal_the_host_specification(dtype, L, hl, two):
+    """the kernels' weight layouts are written on the device from the uploaded parameter vector (k_pack_weights); the host functions
+    pack_chunk / _tmajor / 16 / _bf16 / 16_bf16 / _split are their specification: every chunk must be bitwise equal"""
+    import ctypes
+    import mgn_amd
+    kw = dict(Fe2=4) if two else {}
+    eng = mgn_amd.Engine(9, 3, 2, L, hl, 3, dtype=dtype, **kw)
+    ps = orc.init_params(9, 3, 2, L, hl, 3, 77, 0.05, **kw)
+    eng.set_params(ps)
+    lib = mgn_amd.load()
+    lib.mgn_debug_pack_check.restype = ctypes.c_longlong
+    lib.mgn_debug_pack_check.argtypes = [ctypes.c_void_p]
+    assert lib.mgn_debug_pack_check(eng.h) == 0
+
