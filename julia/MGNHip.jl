@@ -108,7 +108,6 @@ mutable struct GraphNetwork
     e_norm
     n_norm
     o_norm
-    ps_hash::UInt
     graph_key::Tuple{Int, Int, UInt, UInt}     # (E, N, hash(senders), hash(receivers)) of the graph the engine holds
 end
 
@@ -123,7 +122,7 @@ function GraphNetwork(quantities, dims, e_norm, n_norm, o_norm, outputs, mps, la
     h = Ref{Ptr{Cvoid}}(C_NULL)
     rc = ccall((:mgn_create, LIB), Cint, (Ref{MgnConfig}, Ref{Ptr{Cvoid}}), cfg, h)
     rc == 0 || error(unsafe_string(ccall((:mgn_last_error, LIB), Cstring, (Ptr{Cvoid},), C_NULL)))
-    mgn = GraphNetwork(h[], cfg, identity, ps, NamedTuple(), e_norm, n_norm, o_norm, UInt(0), (-1, -1, UInt(0), UInt(0)))
+    mgn = GraphNetwork(h[], cfg, identity, ps, NamedTuple(), e_norm, n_norm, o_norm, (-1, -1, UInt(0), UInt(0)))
     mgn.model = (graph, ps_, st) -> (forward(mgn, graph, ps_), st)      # mgn.model(graph, ps, st) -> (output, st)
     finalizer(m -> ccall((:mgn_destroy, LIB), Cvoid, (Ptr{Cvoid},), m.handle), mgn)
     return mgn
@@ -252,11 +251,12 @@ end
 sync_graph!(mgn::GraphNetwork, graph, N) =
     graph_key(graph.senders, graph.receivers, N) == mgn.graph_key || set_trajectory_graph!(mgn, graph.senders, graph.receivers, N)
 
+# Called before every forward / step!: the optimiser updates `mgn.ps` in place (src/MeshGraphNets.jl:375-377), so the shim cannot know
+# whether it changed.  mgn_set_params compares with what it holds and returns at once when nothing did (0.3 ms for 9 MB); when something
+# did it only stores the vector (0.1 ms) -- the kernels' weight layouts are written on the device by the call that needs them.
 function sync_params!(mgn::GraphNetwork, packed::Vector{Float32})
-    hsh = hash(packed)
-    hsh == mgn.ps_hash && return
     check(mgn.handle, ccall((:mgn_set_params, LIB), Cint, (Ptr{Cvoid}, Ptr{Float32}, Csize_t), mgn.handle, packed, length(packed)))
-    mgn.ps_hash = hsh
+    return
 end
 
 # ---- the model: mgn.model(graph, ps, st) at src/solve.jl:200 ----------------------------------------------------------------------

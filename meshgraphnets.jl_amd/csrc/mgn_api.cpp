@@ -652,6 +652,9 @@ int mgn_set_params(mgn_handle* h, const float* packed, size_t n) try {
     if (int rc = need(h, false, false)) return rc;
     const size_t want = layout_all(h);
     if (n != want) return fail(h, MGN_E_ARG, "mgn_set_params: got %zu floats, model needs %zu", n, want);
+    // the same values again (a caller that cannot tell whether its parameters changed calls this before every forward: 0.3 ms for the
+    // comparison of 9 MB): nothing is invalidated, captured graphs and packed layouts stay
+    if (h->have_params && h->params.size() == n && memcmp(h->params.data(), packed, n * sizeof(float)) == 0) return MGN_OK;
     h->params.assign(packed, packed + n);
     train_invalidate(h, 1);
     // The kernels' own weight layouts (three fp32 fragment orders, the bf16 pieces of the split path in two, the bf16 copies) take

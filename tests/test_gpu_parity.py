@@ -291,3 +291,34 @@ def test_device_packed_weight_layouts_equal_the_host_specification(dtype, L, hl,
     lib.mgn_debug_pack_check.argtypes = [ctypes.c_void_p]
     assert lib.mgn_debug_pack_check(eng.h) == 0
 
+
+def test_set_params_with_unchanged_values_keeps_everything():
+    """a caller that cannot tell whether its parameters changed sets them before every call: the same values are recognised (nothing is
+    invalidated), new values are picked up by the next call of either kernel family"""
+    cfg = cfg_dict(mps=2)
+    ps = make_params(cfg, jitter=0.05)
+    pos, s, r = small_mesh()
+    N = pos.shape[0]
+    nf, ef = random_inputs(N, s.size, cfg)
+    eng = engine_for(cfg)
+    eng.set_params(ps)
+    eng.set_graph(s, r, N)
+    o1 = eng.forward(nf, ef)
+    eng.set_params(ps.copy())
+    o2 = eng.forward(nf, ef)
+    assert np.array_equal(o1, o2)
+    ps2 = (ps * np.float32(1.01)).astype(np.float32)
+    eng.set_params(ps2)
+    o3 = eng.forward(nf, ef)
+    ref = orc.forward(ps2, cfg, nf, ef, s, r)
+    assert rel_max(o3, ref) <= TOL_15 and not np.array_equal(o3, o1)
+    tgt = np.zeros((N, cfg["O"]), np.float32)
+    mask = np.arange(N, dtype=np.int32)
+    g1, l1 = eng.step(nf, ef, tgt, mask)
+    eng.set_params(ps)                                   # back to the first values: the training kernels see them too
+    g2, l2 = eng.step(nf, ef, tgt, mask)
+    assert l1 != l2
+    eng.set_params(ps.copy())
+    g3, l3 = eng.step(nf, ef, tgt, mask)
+    assert l3 == l2 and np.array_equal(g3, g2)
+
