@@ -104,7 +104,11 @@ int mgn_synchronize(mgn_handle* h);
 
 /* ---- parameters: mgn.ps (reference src/MeshGraphNets.jl:288,376-377) ------------------------- */
 /* Packed order (MGN-spec v1): enc-node, enc-edge, step1-edge, step1-node, ..., decoder;
- * within an MLP W1,b1,W2,b2,W3,b3,[ln_scale,ln_bias]; each W row-major [in][out].               */
+ * within an MLP W1,b1,W2,b2,W3,b3,[ln_scale,ln_bias]; each W row-major [in][out].
+ * mgn_set_params copies the vector (0.1 ms for the 15-step model) and is meant to be called whenever the caller's
+ * parameters MAY have changed -- the reference's loop updates them before every step! (src/MeshGraphNets.jl:375-377):
+ * values equal to the ones held invalidate nothing; new ones are turned into the kernels' layouts on the device by the
+ * next call that computes with them (1.5 ms for the inference kernels, 0.4 ms inside mgn_step).               */
 size_t mgn_param_count(const mgn_config* cfg);
 int mgn_set_params(mgn_handle* h, const float* packed, size_t n);
 int mgn_get_params(mgn_handle* h, float* packed, size_t n);
