@@ -97,7 +97,7 @@ end
 Mutable holder with the fields the reference reads and writes: `model`, `ps`, `st`, `e_norm`, `n_norm`, `o_norm`
 (src/solve.jl:54,200-208; src/graph.jl:80-93; src/MeshGraphNets.jl:288,376-377).  `ps` is ONE packed Vector{Float32} in
 MGN-spec order (pack_params): `Optimisers.setup(opt, mgn.ps)` / `Optimisers.update(opt_state, mgn.ps, gs[i])` work on it as on any
-array, and it is uploaded only when it changed.
+array; it is handed to the engine before every call (mgn_set_params recognises unchanged values: sync_params!).
 """
 mutable struct GraphNetwork
     handle::Ptr{Cvoid}
