@@ -19,6 +19,7 @@ import GraphNetCore
 import GraphNetCore: one_hot, triangles_to_edges, parse_edges, mse_reduce, inverse_data,
                      NormaliserOffline, NormaliserOfflineMinMax, NormaliserOfflineMeanStd, NormaliserOnline
 import ChainRulesCore
+import Serialization      # stdlib: normalisers + optimiser state of a checkpoint (load / save!)
 import ChainRulesCore: NoTangent, ZeroTangent, Tangent
 
 # what `using GraphNetCore` gave the reference, minus the five names replaced below
@@ -167,6 +168,15 @@ function init_params(cfg::MgnConfig; rng = nothing)
 end
 
 # ---- load / save!: the checkpoint surface of src/MeshGraphNets.jl:282-285,460-471,537-540 ----------------------------------------
+# What the unchanged call sites assume of GraphNetCore's pair (and what therefore round-trips here):
+#   * `eval_network` builds FRESH normalisers with calc_norms and relies on `load` to bring back the trained ones (:529-540): a
+#     cylinder_flow model normalises velocity (in and out) and the edge features with `NormaliserOnline` (:92,193-199), whose
+#     statistics exist nowhere but in the training run that accumulated them;
+#   * `train_network` resumes with `step = last(df_train.step)` (:324-325), already past `norm_steps`, so online normalisers never
+#     re-accumulate, and it keeps the optimiser state `load` returns (:287-289: `Optimisers.setup` only when it is `nothing`).
+# Four files in `path`: packed parameters (raw Float32), the loss log (CSV), the normalisers and the optimiser state (Julia's
+# Serialization stdlib).  GraphNetCore's own JLD2 checkpoints are NOT read (different parameter tree, and JLD2 is not a dependency of
+# this shim): a run started under GraphNetCore is continued by exporting its leaves once with `pack_params`.
 "Loss log with the two columns the reference reads (`df_train.step`, `df_valid.loss`, src/MeshGraphNets.jl:324-330,383)."
 mutable struct LossLog
     step::Vector{Int}
@@ -176,26 +186,85 @@ LossLog() = LossLog(Int[], Float32[])
 
 const CKPT_PARAMS = "mgn_hip_params.f32"      # packed parameters, raw little-endian Float32
 const CKPT_LOG = "mgn_hip_log.csv"            # kind,step,loss
+const CKPT_NORMS = "mgn_hip_norms.jls"        # snapshot((e_norm, n_norm, o_norm)): plain data, no device arrays, no closures
+const CKPT_OPT = "mgn_hip_opt_state.jls"      # the Optimisers.jl state tree of the packed vector (host arrays), as it is
+
+"""
+`snapshot(x)`: a normaliser (or a Dict / tuple of them) as plain data -- arrays as host `Array`s, numbers and strings as they are,
+structs as `(type = name, fields = Dict(field => snapshot))`, functions (the Lux device function a `NormaliserOnline` may keep)
+dropped.  Written without naming any field of GraphNetCore's types [GNC-unverified]: whatever they hold is what is stored.
+"""
+snapshot(x::AbstractArray{<:Number}) = Array(x)
+snapshot(x::AbstractArray) = map(snapshot, Array(x))
+snapshot(x::Union{Number, AbstractString, Symbol, Nothing}) = x
+snapshot(x::Function) = nothing
+snapshot(x::AbstractDict) = Dict(k => snapshot(v) for (k, v) in x)
+snapshot(x::Tuple) = map(snapshot, x)
+snapshot(x::NamedTuple) = map(snapshot, x)
+function snapshot(x)
+    isstructtype(typeof(x)) || return x
+    return (type = String(nameof(typeof(x))), fields = Dict(String(f) => snapshot(getfield(x, f)) for f in fieldnames(typeof(x))))
+end
+
+"""
+`restore(template, snap)`: the stored statistics put over a freshly built normaliser of the same kind (the ones `calc_norms` hands
+to `load`); returns the object to use.  Arrays are copied INTO the template's arrays (they stay on whatever device the template put
+them: `copyto!` crosses), other fields are set on mutable structs; an immutable struct whose scalars differ is rebuilt through its
+default constructor.  A kind mismatch (an online normaliser stored, an offline one passed) is an error, not a silent pick.
+"""
+restore(t::AbstractArray{<:Number}, s::AbstractArray{<:Number}) =
+    size(t) == size(s) ? copyto!(t, s) : copyto!(similar(t, eltype(t), size(s)), s)
+restore(t::Function, s) = t
+restore(t::AbstractDict, s::AbstractDict) = (for (k, v) in s; t[k] = haskey(t, k) ? restore(t[k], v) : v; end; t)
+restore(t::Tuple, s::Tuple) = map(restore, t, s)
+function restore(t, s)
+    (s isa NamedTuple && haskey(s, :type) && haskey(s, :fields)) || return s          # plain value: the stored one
+    String(nameof(typeof(t))) == s.type ||
+        throw(ArgumentError("checkpoint holds a $(s.type), load was handed a $(nameof(typeof(t))): build the normalisers as the training run did"))
+    names = fieldnames(typeof(t))
+    vals = [haskey(s.fields, String(f)) ? restore(getfield(t, f), s.fields[String(f)]) : getfield(t, f) for f in names]
+    if ismutable(t)
+        for (f, v) in zip(names, vals)
+            v === getfield(t, f) || setfield!(t, f, convert(fieldtype(typeof(t), f), v))
+        end
+        return t
+    end
+    all(v === getfield(t, f) || v == getfield(t, f) for (f, v) in zip(names, vals)) && return t     # arrays were filled in place
+    return typeof(t)(vals...)
+end
 
 """
     load(quantities, dims, e_norms, n_norms, o_norms, outputs, mps, layer_size, hidden_layers, opt, device, path)
         -> (mgn, opt_state, df_train, df_valid)
 
 Same call shape and return shape as GraphNetCore.load at src/MeshGraphNets.jl:282-285 and :537-540, so both call sites stay as they
-are.  `device` (the reference's Lux device function) is accepted and ignored: the engine owns its GPU memory; `opt_state` is returned
-as `nothing`, which the reference already handles (`isnothing(opt_state) && Optimisers.setup(opt, mgn.ps)`, :287-289).  A checkpoint
-written by `save!` below is picked up from `path`; the normalisers are the ones passed in (offline ones are rebuilt by calc_norms
-on every start, online ones re-accumulate during the first `norm_steps` steps as in a fresh run).
+are.  `device` (the reference's Lux device function) is accepted and ignored: the engine owns its GPU memory.  With a checkpoint
+written by `save!` below in `path`, everything `save!` was given comes back: the parameters, the loss log, the NORMALISERS (their
+stored statistics restored over `e_norms` / `n_norms` / `o_norms`, which `calc_norms` has just built empty: `eval_network` relies
+on this, :529-540) and `opt_state` (so a resumed run keeps its Adam moments; `nothing` only when there is no checkpoint or `opt` is
+`nothing`, which :287-289 turns into `Optimisers.setup(opt, mgn.ps)`).  A checkpoint that has parameters but no normaliser file (one
+written before this was stored) is refused when any passed normaliser is a `NormaliserOnline`: it would evaluate with empty statistics.
 """
 function load(quantities, dims, e_norms, n_norms, o_norms, outputs, mps, layer_size, hidden_layers, opt, device, path;
         hip_device = -1, ln_mode = 0, ln_dims = 0)
-    mgn = GraphNetwork(quantities, dims, e_norms, n_norms, o_norms, outputs, mps, layer_size, hidden_layers, nothing;
-        device = hip_device, ln_mode = ln_mode, ln_dims = ln_dims)
     df_train, df_valid = LossLog(), LossLog()
+    opt_state = nothing
     pfile = joinpath(path, CKPT_PARAMS)
-    if isfile(pfile)
-        ps = Vector{Float32}(undef, param_count(mgn.cfg))
-        read!(pfile, ps)
+    have = isfile(pfile)
+    if have
+        nfile = joinpath(path, CKPT_NORMS)
+        if isfile(nfile)
+            stored = Serialization.deserialize(nfile)
+            e_norms = restore(e_norms, stored.e_norm)
+            n_norms = restore(n_norms, stored.n_norm)
+            o_norms = restore(o_norms, stored.o_norm)
+        else
+            online(n) = n isa NormaliserOnline || (n isa AbstractDict && any(online, values(n)))
+            (online(e_norms) || online(n_norms) || online(o_norms)) &&
+                error("checkpoint in $path has no $CKPT_NORMS: its online normalisers' statistics were not saved and cannot be rebuilt")
+        end
+        ofile = joinpath(path, CKPT_OPT)
+        (opt !== nothing && isfile(ofile)) && (opt_state = Serialization.deserialize(ofile))
         lfile = joinpath(path, CKPT_LOG)
         if isfile(lfile)
             for line in eachline(lfile)
@@ -204,23 +273,50 @@ function load(quantities, dims, e_norms, n_norms, o_norms, outputs, mps, layer_s
                 push!(log.step, parse(Int, step)); push!(log.loss, parse(Float32, loss))
             end
         end
+    end
+    mgn = GraphNetwork(quantities, dims, e_norms, n_norms, o_norms, outputs, mps, layer_size, hidden_layers, nothing;
+        device = hip_device, ln_mode = ln_mode, ln_dims = ln_dims)
+    if have
+        ps = Vector{Float32}(undef, param_count(mgn.cfg))
+        filesize(pfile) == sizeof(ps) || error("checkpoint $pfile holds $(filesize(pfile)) bytes, this model has $(sizeof(ps))")
+        read!(pfile, ps)
     else
         ps = init_params(mgn.cfg)
     end
     mgn.ps = ps
-    return mgn, nothing, df_train, df_valid
+    return mgn, opt_state, df_train, df_valid
 end
 
-"`save!(mgn, opt_state, df_train, df_valid, step, loss, path; is_training = true)` as called at src/MeshGraphNets.jl:460-471."
+"""
+`save!(mgn, opt_state, df_train, df_valid, step, loss, path; is_training = true)` as called at src/MeshGraphNets.jl:460-471: appends
+(step, loss) to the training or the validation log and writes the whole state -- `mgn.ps`, `mgn.e_norm`, `mgn.n_norm`, `mgn.o_norm`
+(with whatever an online normaliser has accumulated so far) and `opt_state`.  Every file is written beside its target and renamed,
+so a run killed inside `save!` leaves the previous checkpoint whole.
+"""
 function save!(mgn::GraphNetwork, opt_state, df_train, df_valid, step, loss, path; is_training = true)
     mkpath(path)
     log = is_training ? df_train : df_valid
     push!(log.step, Int(step)); push!(log.loss, Float32(loss))
-    write(joinpath(path, CKPT_PARAMS), mgn.ps::Vector{Float32})
-    open(joinpath(path, CKPT_LOG), "w") do io
-        for (kind, l) in (("train", df_train), ("valid", df_valid)), i in eachindex(l.step)
-            println(io, kind, ',', l.step[i], ',', l.loss[i])
+    function atomically(f, name)
+        tmp = joinpath(path, name * ".tmp")
+        f(tmp)
+        mv(tmp, joinpath(path, name); force = true)
+    end
+    atomically(CKPT_NORMS) do tmp
+        Serialization.serialize(tmp, (e_norm = snapshot(mgn.e_norm), n_norm = snapshot(mgn.n_norm), o_norm = snapshot(mgn.o_norm)))
+    end
+    atomically(CKPT_OPT) do tmp
+        Serialization.serialize(tmp, opt_state)
+    end
+    atomically(CKPT_LOG) do tmp
+        open(tmp, "w") do io
+            for (kind, l) in (("train", df_train), ("valid", df_valid)), i in eachindex(l.step)
+                println(io, kind, ',', l.step[i], ',', l.loss[i])
+            end
         end
+    end
+    atomically(CKPT_PARAMS) do tmp              # last: `load` keys on this file
+        write(tmp, mgn.ps::Vector{Float32})
     end
     return nothing
 end

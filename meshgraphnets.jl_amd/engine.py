@@ -625,6 +625,63 @@ class GraphNetwork:
                              int(s[:16].sum()) if s.size else 0)
 
 
+def init_params(cfg, seed=None):
+    """Fresh parameters in packed order: Glorot-uniform weights, zero biases, LayerNorm scale 1 / bias 0 (the twin of
+    MGNHip.init_params; NumPy's draws).  cfg: (Fn, Fe, O, L, hidden_layers, mps)."""
+    Fn, Fe, O, L, h, mps = (int(x) for x in cfg)
+    rng = np.random.default_rng(seed)
+    parts = []
+
+    def mlp(fin, fout, ln):
+        dims = [fin] + [L] * h + [fout]
+        for a, b in zip(dims[:-1], dims[1:]):
+            lim = np.sqrt(6.0 / (a + b))
+            parts.append(((rng.random(a * b, dtype=np.float32) * 2 - 1) * lim).astype(np.float32))
+            parts.append(np.zeros(b, np.float32))
+        if ln:
+            parts.extend((np.ones(fout, np.float32), np.zeros(fout, np.float32)))
+
+    mlp(Fn, L, True)
+    mlp(Fe, L, True)
+    for _ in range(mps):
+        mlp(3 * L, L, True)
+        mlp(2 * L, L, True)
+    mlp(L, O, False)
+    return np.concatenate(parts)
+
+
+def load(quantities, dims, e_norms, n_norms, o_norms, outputs, mps, layer_size, hidden_layers, opt, device, path, index_base=0,
+         hip_device=-1, seed=None):
+    """`load(...) -> (mgn, opt_state, df_train, df_valid)` with the twelve positional arguments of the reference's call sites
+    (src/MeshGraphNets.jl:282-285, 537-540).  With a checkpoint written by `save` in `path`, ALL of its state comes back: parameters,
+    loss log, the normalisers' statistics restored over the freshly built `e_norms` / `n_norms` / `o_norms` (what `eval_network`
+    relies on, :529-540) and `opt_state` (kept on resume, :287-289; None without a checkpoint or when `opt` is None).  `device` (the
+    reference's Lux device function) is accepted and ignored."""
+    from . import checkpoint as ck
+    probe = _capi.load().mgn_param_count
+    cfg = MgnConfig(Fn=quantities, Fe=dims + 1, O=outputs, L=layer_size, hidden_layers=hidden_layers, mps=mps, n_edge_sets=1)
+    nparams = int(probe(C.byref(cfg)))
+    got = ck.read_checkpoint(path, nparams, e_norms, n_norms, o_norms, want_opt_state=opt is not None)
+    if got is None:
+        ps, opt_state, df_train, df_valid = init_params((quantities, dims + 1, outputs, layer_size, hidden_layers, mps), seed), None, ck.LossLog(), ck.LossLog()
+    else:
+        ps, e_norms, n_norms, o_norms, opt_state, df_train, df_valid = got
+    mgn = GraphNetwork(quantities, dims, e_norms, n_norms, o_norms, outputs, mps, layer_size, hidden_layers, ps=ps,
+                       index_base=index_base, device=hip_device)
+    return mgn, opt_state, df_train, df_valid
+
+
+def save(mgn, opt_state, df_train, df_valid, step, loss, path, is_training=True):
+    """`save!(mgn, opt_state, df_train, df_valid, step, loss, path; is_training)` (src/MeshGraphNets.jl:460-471): appends (step, loss)
+    to the training or validation log and writes parameters, normalisers (with whatever an online one has accumulated), optimiser
+    state and the log."""
+    from . import checkpoint as ck
+    log = df_train if is_training else df_valid
+    log.step.append(int(step))
+    log.loss.append(np.float32(loss))
+    ck.write_checkpoint(path, mgn.ps, mgn.e_norm, mgn.n_norm, mgn.o_norm, opt_state, df_train, df_valid)
+
+
 def step(mgn, graph, target, mask, loss_function=None):
     """GraphNetCore.step!(mgn, graph, target, mask, loss_function) as the reference calls it (src/strategies.jl:418-422):
     returns (gs, loss) with loss = mean(mse_reduce(target, mgn.model(graph))[mask]) and gs = d loss / d mgn.ps in packed
