@@ -2620,6 +2620,10 @@ int fp32_split_enabled() { return g_fp32_split; }
 static int g_c16_split = [] { const char* e = getenv("MGN_C16_SPLIT"); return e ? atoi(e) : 3; }();
 int set_c16_split(int on) { const int old = g_c16_split; g_c16_split = on; return old; }
 int c16_split_enabled() { return g_c16_split; }
+// two fp16 pieces and three products instead of three bf16 pieces and six (k_edge_ring_h, split.hip); MGN_SPLIT_F16=0: the bf16 pieces
+static int g_split_f16 = [] { const char* e = getenv("MGN_SPLIT_F16"); return e ? atoi(e) : 1; }();
+int set_split_f16(int on) { const int old = g_split_f16; g_split_f16 = on; return old; }
+int split_f16_enabled() { return g_split_f16; }
 static int g_edge_ring16 = [] { const char* e = getenv("MGN_EDGE_RING16"); return e ? atoi(e) : 0; }();
 int set_edge_ring16(int on) { const int old = g_edge_ring16; g_edge_ring16 = on; return old; }
 int edge_ring16_enabled() { return g_edge_ring16; }
@@ -2822,6 +2826,11 @@ hipError_t launch_edge_step(int L, const EdgeArgs& a, hipStream_t s) {
                 int blocks = (a.ntiles + 4 * rounds - 1) / (4 * rounds);
                 if (blocks > num_cus()) blocks = num_cus();
                 ls.blocks = ((blocks + NUM_XCD - 1) / NUM_XCD) * NUM_XCD;
+            }
+            if (g_split_f16 && a.splith[0] && !(g_edge_ring16 && a.split16[0] && a.off32)) {
+                ls.lds = edge_ring_h_lds();
+                g_last_edge_kernel = ls.threads == 256 ? 14 : 13;
+                return launch_edge_ring_h(a, ls, s);
             }
             if (g_edge_ring16 && a.split16[0] && a.off32) {
                 g_last_edge_kernel = ls.threads == 256 ? 11 : 10;

@@ -414,6 +414,13 @@ EdgeArgs edge_args(mgn_engine* h, int k, int q = 0) {
     const bool have_sp = k < (int)h->spoff.size() && h->wsp.p;
     for (int i = 0; i < 3; ++i) a.split[i] = (!a.bf && have_sp) ? h->wsp.as<uint16_t>() + h->spoff[k].e_ch[q][i] : nullptr;
     for (int i = 0; i < 3; ++i) a.split16[i] = have_sp ? h->wsp.as<uint16_t>() + h->spoff[k].e16_ch[q][i] : nullptr;
+    const bool have_h = have_sp && !a.bf && h->spoff[k].have_h;
+    for (int i = 0; i < 3; ++i) {
+        a.splith[i] = have_h ? h->wsp.as<uint16_t>() + h->spoff[k].eh_ch[q][i] : nullptr;
+        a.h2_s[i] = have_h ? h->spoff[k].eh_s[q][i] : 1.f;
+        a.h2_rs[i] = 1.f / a.h2_s[i];
+    }
+    a.h2_b2pos = have_h ? h->spoff[k].e_b2pos[q] : 0.f;
     {
         const size_t lim = (size_t)1 << 31, rowb = (size_t)h->cfg.L * 4;
         a.off32 = ((size_t)(h->g.n_own + h->g.n_halo + 32) * rowb < lim && ((size_t)2 * es.ntiles_e + 16) * rowb < lim) ? 1 : 0;
@@ -693,7 +700,7 @@ int pack_inference_weights(mgn_engine* h) {
         if (off > seg0) small.push_back({seg0, off});
         f.resize(off + 3 * CH);
         seg0 = off + 3 * CH;
-        jobs.push_back({0, (long long)off, (long long)(Wm - p), ldw, kbase});
+        jobs.push_back({0, (long long)off, (long long)(Wm - p), ldw, kbase, 1.f});
         return off;
     };
     auto add_tabs = [&](const float* b1, const float* b2, const float* b3, const float* ga, const float* be, const float* bq) {
@@ -824,13 +831,27 @@ int pack_inference_weights(mgn_engine* h) {
         auto put = [&](const float* src, int kb, size_t& o32, size_t& o16) {
             o32 = 0;
             if (f32) {
-                jobs.push_back({1, (long long)off, (long long)(src - p), L, kb});
+                jobs.push_back({1, (long long)off, (long long)(src - p), L, kb, 1.f});
                 o32 = off;
                 off += (size_t)3 * 16384;
             }
-            jobs.push_back({2, (long long)off, (long long)(src - p), L, kb});
+            jobs.push_back({2, (long long)off, (long long)(src - p), L, kb, 1.f});
             o16 = off;
             off += (size_t)3 * 16384;
+        };
+        // two fp16 pieces of the same chunk times a power of two that puts its largest entry into [2^14, 2^15) (split_common.hpp)
+        auto puth = [&](const float* src, int kb, size_t& oh, float& sc) {
+            float mx = 0.f;
+            for (int k = 0; k < L; ++k)
+                for (int n = 0; n < L; ++n) mx = std::max(mx, std::fabs(src[(size_t)(kb + k) * L + n]));
+            int e = 0;
+            (void)std::frexp(mx, &e);                                   // mx = m 2^e, m in [0.5, 1): floor(log2 mx) = e - 1
+            if (!(mx > 0.f) || e - 1 < -40) e = -39;
+            if (!std::isfinite(mx)) e = 128;
+            sc = std::ldexp(1.f, 15 - e);
+            jobs.push_back({4, (long long)off, (long long)(src - p), L, kb, sc});
+            oh = off;
+            off += (size_t)2 * 16384;
         };
         for (int k = 0; k < c.mps; ++k)
             for (int q = 0; q < S; ++q) {
@@ -838,6 +859,13 @@ int pack_inference_weights(mgn_engine* h) {
                 const float* src[3] = {p + me.W[1], p + me.W[2], p + me.W[0]};
                 const int kb[3] = {0, 0, 2 * L};
                 for (int i = 0; i < 3; ++i) put(src[i], kb[i], h->spoff[k].e_ch[q][i], h->spoff[k].e16_ch[q][i]);
+                if (f32) {
+                    for (int i = 0; i < 3; ++i) puth(src[i], kb[i], h->spoff[k].eh_ch[q][i], h->spoff[k].eh_s[q][i]);
+                    float bp = 0.f;
+                    for (int i = 0; i < L; ++i) bp = std::max(bp, p[me.b[1] + i]);
+                    h->spoff[k].e_b2pos[q] = bp;
+                    h->spoff[k].have_h = true;
+                }
             }
         for (int k = 0; node_side && k <= c.mps; ++k) {                 // node MLP of step k + projection for step k + 1 (k = mps: the
             const MlpOff& mn = h->pn[k < c.mps ? k : 0];                //   "project only" pseudo-step: step 0's own first layer)
@@ -861,7 +889,7 @@ int pack_inference_weights(mgn_engine* h) {
         auto addb = [&](const float* Wm, int kbase) {
             const size_t off = wb_size;
             wb_size += (size_t)L * L;
-            jobs.push_back({3, (long long)off, (long long)(Wm - p), L, kbase});
+            jobs.push_back({3, (long long)off, (long long)(Wm - p), L, kbase, 1.f});
             return off;
         };
         h->bsoff.assign(c.mps + 1, {});
@@ -2542,6 +2570,9 @@ int mgn_debug_fp32_split(int on) { return set_fp32_split(on); }
 // 1: the edge kernel of the split path on v_mfma_f32_16x16x32_bf16 (k_edge_ring16); takes effect at the next mgn_set_params (its weight
 // fragments are packed there).  Returns the old value.  Environment: MGN_EDGE_RING16.
 int mgn_debug_edge_ring16(int on) { return set_edge_ring16(on); }
+// 1 (default): the split path computes on two fp16 pieces per operand and three piece products (k_edge_ring_h), 0: on three bf16 pieces
+// and six products (k_edge_ring); returns the old value
+int mgn_debug_split_f16(int on) { return set_split_f16(on); }
 // tests: every chunk the device packed (k_pack_weights) against the host functions that specify the layouts; returns the number of
 // elements that differ (0 = bitwise equal), < 0 on error
 long long mgn_debug_pack_check(mgn_handle* h) try {

@@ -888,6 +888,330 @@ __global__ __launch_bounds__(NWV * 64, NWV / 4) void k_edge_ring(const EdgeArgs 
 }
 
 // ================================================================================================
+// k_edge_ring_h (round 5; MGN_FP32_SPLIT = 1, the default): k_edge_ring with every fp32 operand as TWO fp16 pieces and THREE piece
+// products per (k-step, output block) -- 288 v_mfma_f32_32x32x16_f16 per tile instead of 576 bf16 ones (split_common.hpp: why that is
+// still fp32 arithmetic).  Same lock-step ring, turnover, LayerNorm, scan, stores; what changes:
+//   * LDS: the hi pieces of W1e, W2, W3 resident (96 KiB); the lo piece of the layer in progress through three window buffers of W
+//     steps (W = 8: 8 KiB each, 12 windows and barriers per tile; every thread fetches ONE 16-byte fragment per window);
+//   * every operand is scaled by a power of two so that its lo piece is a normal fp16: the weights per chunk on the host
+//     (EdgeArgs.h2_s / h2_rs), the activations per ROW here -- lane = row, so the scale is one register and the row's output column
+//     is un-scaled by it exactly.  Layer 1 takes the row maximum of the e tile; layer 2 that of layer 1's finished output; layer 3 a
+//     bound, c2 max(acc, 0) + max(b2, 0), because layer 2's bias and un-scaling are folded into layer 3's split (FIN = 2): its
+//     accumulators are never "finished" as a fragment;
+//   * accumulators start from zero (the first MFMA of a block takes the constant), except layer 1's: Q[r] scaled INTO the
+//     accumulator's units (64 multiplications; P[s] is added by the FMA that un-scales), since nothing has 64 registers for Q.
+// ================================================================================================
+template <int W>
+struct Rh {
+    static constexpr int WPL = 32 / W;          // windows per layer
+    static constexpr int NW = 3 * WPL;          // windows per tile (a multiple of 3: window -> buffer is the same for every tile)
+    static constexpr int BUF = W * 64;          // u32x4 elements per window buffer: [step][lane] of the lo piece
+};
+struct RhFrag {
+    u32x4 h, l;                                 // fragments of the next step (read one step ahead)
+};
+template <int W, int LYR>
+DEVINL RhFrag rh_first(const u32x4* hi, const u32x4* ring, int lane) {
+    constexpr int b = (Rh<W>::WPL * LYR) % 3;
+    RhFrag f;
+    f.h = hi[lane];
+    f.l = ring[b * Rh<W>::BUF];
+    return f;
+}
+struct RhSrc {
+    const u32x4* lo[3];                         // global lo pieces of layers 1..3 (W1e, W2, W3)
+};
+// One L x L layer (sp_layer_ring with two pieces).  sx: the row's scale; FIN / cfin / btab: see h2_split_pair (btab = the bias table of
+// the layer BEFORE, lane half's offset included).  Refill: schedule 2 of sp_layer_ring (one request every second step; WRAP: no
+// rotation, the last two k-steps' pieces are the caller's).
+template <int W, int LYR, int FIN, int RFS = 0, int NWV = 8, bool WRAP = false>
+DEVINL void h2_layer_ring(f32x16 (&acc)[4], f32x16 (&in)[4], const u32x4* hi, const u32x4* hi_next, u32x4* ring, const RhSrc& src,
+                          RhFrag& nx, int lane, int tid, float sx, float cfin = 0.f, const float* btab = nullptr,
+                          const f32x4* rf = nullptr) {
+    constexpr int ROT = 2;
+    constexpr int WPL = Rh<W>::WPL, NW = Rh<W>::NW, BUF = Rh<W>::BUF;
+    f32x4 side[2 * ROT];
+    if constexpr (!WRAP && RFS > 0) {
+#pragma unroll
+        for (int m = 0; m < 2 * ROT; ++m) side[m] = rf[m * RFS];
+    }
+    // bias pair of (k-step sn, pair u): registers 8 (sn & 1) + 2 u, + 1 of block sn >> 1 (pack_tab's order)
+    auto bias = [&](int sn, int u) {
+        f32x2 b = {0.f, 0.f};
+        if constexpr (FIN == 2) b = *reinterpret_cast<const f32x2*>(btab + 8 * (4 * (sn >> 1) + 2 * (sn & 1) + (u >> 1)) + 2 * (u & 1));
+        return b;
+    };
+    unsigned ph[4], pl[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const f32x2 b = bias(0, u);
+        h2_split_pair<FIN>(ph[u], pl[u], in[0][2 * u], in[0][2 * u + 1], sx, cfin, b[0], b[1]);
+    }
+    constexpr int LPT = W / NWV;                 // fragments per thread in a window (NWV waves share the loading)
+    u32x4 ld_l[LPT];
+    unsigned voff = (unsigned)tid * 16u;
+    asm volatile("" : "+v"(voff));
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+        unsigned nh[4], nl[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int it = 4 * s + t;
+            const int gw = WPL * LYR + it / W;                        // global window of this step
+            const u32x4 a1 = nx.h, a2 = nx.l;
+            if (it % W == 0) {                                         // request window gw + 2
+                const int g2 = (gw + 2) % NW, l2 = g2 / WPL, w2 = g2 % WPL;
+#pragma unroll
+                for (int i = 0; i < LPT; ++i)
+                    ld_l[i] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(src.lo[l2] + w2 * W * 64 + i * NWV * 64) + voff);
+            }
+            if constexpr (RFS > 0) {
+                if ((t & 1) && s < 8 - ROT) {                          // registers of k-step s (free since the step began), half t >> 1
+                    const f32x4 v = rf[(2 * (WRAP ? s : s + ROT) + (t >> 1)) * RFS];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) in[s >> 1][8 * (s & 1) + 4 * (t >> 1) + i] = v[i];
+                }
+            }
+            if (it + 1 < 32) {
+                const int gn = WPL * LYR + (it + 1) / W;
+                nx.h = hi[(it + 1) * 64 + lane];
+                nx.l = ring[(gn % 3) * BUF + ((it + 1) % W) * 64];
+            } else if (LYR < 2) {
+                nx = rh_first<W, (LYR + 1) % 3>(hi_next, ring, lane);   // (that window was written two windows ago)
+            }
+            if (it % W == W - 2) {                                     // ... and store it: its buffer was last read in window gw - 1
+                const int b2 = (gw + 2) % 3;
+#pragma unroll
+                for (int i = 0; i < LPT; ++i) ring[b2 * BUF + i * NWV * 64 + tid - lane] = ld_l[i];
+            }
+            if (s < 7) {
+                const int sn = s + 1;
+                const f32x2 b = bias(sn, t);
+                h2_split_pair<FIN>(nh[t], nl[t], in[sn >> 1][8 * (sn & 1) + 2 * t], in[sn >> 1][8 * (sn & 1) + 2 * t + 1], sx, cfin, b[0], b[1]);
+            }
+            const sp_f16x8 bh = h2_op(ph), bl = h2_op(pl);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h2_wop(a2), bh, acc[t], 0, 0, 0);      // small terms first
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h2_wop(a1), bl, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h2_wop(a1), bh, acc[t], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (it % W == W - 1) ring_barrier();                       // window closed: every wave has read it, window gw + 2 is in LDS
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            ph[u] = nh[u];
+            pl[u] = nl[u];
+        }
+    }
+    if constexpr (RFS > 0 && !WRAP) {                                  // un-rotate: k-step u's pieces sit in the registers of k-step u - 2
+        f32x16 r[4];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                r[u >> 1][8 * (u & 1) + j] = u < ROT ? side[2 * u + (j >> 2)][j & 3] : in[(u - ROT) >> 1][8 * ((u - ROT) & 1) + j];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) in[t] = r[t];
+    }
+}
+
+#ifndef MGN_RINGH_PHASE_UNITS
+#define MGN_RINGH_PHASE_UNITS 6     // half a period of k_edge_ring_h in 4 096-cycle units (k_edge_ring: 10)
+#endif
+#ifndef MGN_RINGH_W
+#define MGN_RINGH_W 8            // steps per window of k_edge_ring_h (8: 12 barriers per tile; 16: 6)
+#endif
+template <int NWV>
+__global__ __launch_bounds__(NWV * 64, NWV / 4) void k_edge_ring_h(const EdgeArgs a) {
+    constexpr int NT = 4, L = 128, PC = 16384;
+    constexpr int W = MGN_RINGH_W;
+    constexpr int BUF = Rh<W>::BUF;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    uint16_t* wl = reinterpret_cast<uint16_t*>(smem);
+    copy_to_lds16(wl, a.splith[2], PC, true);                        // hi of W1e, W2, W3
+    copy_to_lds16(wl + PC, a.splith[0], PC, true);
+    copy_to_lds16(wl + 2 * PC, a.splith[1], PC, true);
+    const int lane0 = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int tid = (int)threadIdx.x;
+    u32x4* ringbase = reinterpret_cast<u32x4*>(wl + 3 * PC);                    // three window buffers
+    float* tb = reinterpret_cast<float*>(ringbase + 3 * BUF);
+    copy_to_lds(tb, a.tabs, T_COUNT * L);
+    RhSrc src;
+    {
+        const u32x4* g[3] = {reinterpret_cast<const u32x4*>(a.splith[2]), reinterpret_cast<const u32x4*>(a.splith[0]),
+                             reinterpret_cast<const u32x4*>(a.splith[1])};
+#pragma unroll
+        for (int l = 0; l < 3; ++l) src.lo[l] = g[l] + 2048;
+#pragma unroll
+        for (int w = 0; w < 2; ++w)                                   // windows 0 and 1 of layer 1
+#pragma unroll
+            for (int i = 0; i < W / NWV; ++i) ringbase[w * BUF + i * NWV * 64 + tid] = src.lo[0][w * W * 64 + i * NWV * 64 + tid];
+    }
+    __syncthreads();
+    const u32x4* l1h = reinterpret_cast<const u32x4*>(wl);
+    const u32x4* l2h = reinterpret_cast<const u32x4*>(wl + PC);
+    const u32x4* l3h = reinterpret_cast<const u32x4*>(wl + 2 * PC);
+    // chunk scales (layer order): s = what the host multiplied the chunk by, rs = 1 / s
+    const float sw1 = a.h2_s[2], rsw1 = a.h2_rs[2], rsw2 = a.h2_rs[0], rsw3 = a.h2_rs[1], b2pos = a.h2_b2pos;
+    // lock-step: every wave of the block runs as many tiles as its wave 0 (the longest walk); padding tiles compute, store nothing
+    TileWalk tw0(a.ntiles, 0), tw(a.ntiles, wave);
+    if (tw0.tile >= tw0.end) return;
+    const int iters = (tw0.end - tw0.tile + tw0.stride - 1) / tw0.stride;
+    if (MGN_RING_PHASES > 1 && iters >= 32) {                         // (k_edge_ring: every second block of an XCD half a period late)
+        const int ph = (int)(blockIdx.x / NUM_XCD) % MGN_RING_PHASES;
+        for (int i = 0; i < ph * MGN_RINGH_PHASE_UNITS; ++i) __builtin_amdgcn_s_sleep(64);
+    }
+    const int last = a.tile0 + tw0.tile + (iters - 1) * tw0.stride;   // a tile that exists (loads of padding tiles go there)
+    tw.tile += a.tile0;
+    tw.end += a.tile0;
+    auto clamp = [&](int t) { return t < tw.end ? t : last; };
+    f32x16 acc[NT], y[NT];
+    EdgeIdx ix = load_edge_idx_nb(a.snd, a.rcv, a.E, clamp(tw.tile), lane0 & 31);
+    {
+        const int h0 = lane0 >> 5;
+        load_frag<NT>(acc, prow_ptr(a.Q, ix.r >= 0 ? ix.r : 0, L, h0), STRIDE_PROW);
+        load_frag<NT>(y, tile_ptr(a.Elat, clamp(tw.tile), L, lane0), STRIDE_TILE);
+    }
+    int stamp_tile = 0;
+    (void)stamp_tile;
+    for (int j = 0; j < iters; ++j, ++stamp_tile) {
+        OPAQUE_LANE();
+        const bool on = tw.tile < tw.end;
+        const int tile = clamp(tw.tile);
+        const int nxt = clamp(tw.tile + tw.stride);
+        const EdgeIdx ixn = load_edge_idx_nb(a.snd, a.rcv, a.E, nxt, c);
+        const bool valid = on && ix.r >= 0;
+        const int r = ix.r >= 0 ? ix.r : 0;
+        f32x4* etile = tile_ptr(a.Elat, tile, L, lane);
+        u32x4* ring = ringbase + lane;
+        STAMP(0);
+        __builtin_amdgcn_s_setprio(0);
+        RhFrag nx = rh_first<W, 0>(l1h, ring, lane);
+        // layer 1 (edge part): y = e tile in, P[s] out; acc enters with Q[r] (which carries b1), put into the accumulator's units
+        const H2Scale x1 = h2_scale(h2_rowmax<true>(y));
+        {
+            const float cinv = x1.s * sw1;
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int k = 0; k < 16; ++k) acc[t][k] *= cinv;
+        }
+        h2_layer_ring<W, 0, 0, STRIDE_PROW, NWV>(acc, y, l1h, l2h, ring, src, nx, lane, tid, x1.s, 0.f, nullptr, prow_ptr(a.P, ix.s, L, h));
+        {
+            const float c1 = x1.rs * rsw1;
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int k = 0; k < 16; ++k) acc[t][k] = __builtin_fmaf(acc[t][k], c1, y[t][k]);
+        }
+        CST(1);
+        const H2Scale x2 = h2_scale(h2_rowmax<false>(acc));
+        zero_frag<NT>(y);
+        CST(2);
+        h2_layer_ring<W, 1, 1, 0, NWV>(y, acc, l2h, l3h, ring, src, nx, lane, tid, x2.s);   // layer 2 (ReLU folded into the split)
+        CST(3);
+        const float c2 = x2.rs * rsw2;
+        const H2Scale x3 = h2_scale(__builtin_fmaf(h2_rowmax<false>(y), c2, b2pos));
+        zero_frag<NT>(acc);
+        CST(4);
+        // layer 3: y = layer 2's accumulators in (bias, un-scaling and ReLU in the split), the NEXT tile's e out
+        h2_layer_ring<W, 2, 2, STRIDE_TILE, NWV, true>(acc, y, l3h, l1h, ring, src, nx, lane, tid, x3.s, c2, tb + T_B2 * L + 4 * h,
+                                                      tile_ptr(a.Elat, nxt, L, lane));
+        CST(5);
+        EST(1);
+        PHASE_FENCE();
+        __builtin_amdgcn_s_setprio(MGN_PRIO);
+        f32x16 er[NT];               // this tile's e again, for the residual (y holds the next tile's): arrives during the LayerNorm
+        ring_load_e(er, etile);
+        ring_load_e_tail(y, tile_ptr(a.Elat, nxt, L, lane));         // k-steps 6 and 7 of the next tile's e
+        {   // bias + un-scaling of layer 3, then LayerNorm: acc = e'
+            constexpr float invL = 1.0f / 128;
+            const float c3 = x3.rs * rsw3;
+            const f32x4* b34 = reinterpret_cast<const f32x4*>(tb + T_B3 * L) + h;
+            float sm = 0.f;
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 bv = b34[2 * (4 * t + g)];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const float v = __builtin_fmaf(acc[t][4 * g + i], c3, bv[i]);
+                        acc[t][4 * g + i] = v;
+                        sm += v;
+                    }
+                }
+            sm += __shfl_xor(sm, 32, 64);
+            const float mean = sm * invL;
+            float q = 0.f;
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    const float d = acc[t][k] - mean;
+                    acc[t][k] = d;
+                    q += d * d;
+                }
+            q += __shfl_xor(q, 32, 64);
+            const float rstd = ln_rstd_at(q * invL, tb + T_LN * L);
+            const f32x4* g4 = reinterpret_cast<const f32x4*>(tb + T_GAMMA * L) + h;
+            const f32x4* b4 = reinterpret_cast<const f32x4*>(tb + T_BETA * L) + h;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 gv = g4[2 * (4 * t + g)];
+                    const f32x4 bv = b4[2 * (4 * t + g)];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) acc[t][4 * g + i] = acc[t][4 * g + i] * rstd * gv[i] + bv[i];
+                }
+            }
+        }
+        CST(6);
+        EST(2);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) er[t] += acc[t];                // e <- e + e'
+        if (valid) ring_store_e(etile, er);                          // padding rows / tiles store nothing
+        CST(7);
+        EST(3);
+        const int reff = ix.r >= 0 ? r : (-4 - c);
+        const int rprev = __shfl_up(reff, 1, 32);
+        const int rnext = __shfl_down(reff, 1, 32);
+        const bool head = (c == 0) || (reff != rprev);
+        const unsigned hm = (unsigned)__ballot(head);
+        const int start = 31 - __clz((int)(hm & (0xFFFFFFFFu >> (31 - c))));
+        const int st_in = max(start, c & 16);
+        const bool c1 = (c - 1 >= st_in), c2s = (c - 2 >= st_in), c4 = (c - 4 >= st_in), c8 = (c - 8 >= st_in);
+        const bool cx = (c >= 16) && (start <= 15);
+        EST(4);
+        PHASE_FENCE();
+        asm volatile("s_nop 1");
+        RG_SCAN_LEVEL(acc, c1, "row_shr:1 row_mask:0xf bank_mask:0xf");
+        RG_SCAN_LEVEL(acc, c2s, "row_shr:2 row_mask:0xf bank_mask:0xf");
+        RG_SCAN_LEVEL(acc, c4, "row_shr:4 row_mask:0xf bank_mask:0xf");
+        RG_SCAN_LEVEL(acc, c8, "row_shr:8 row_mask:0xf bank_mask:0xf");
+        RG_SCAN_LEVEL(acc, cx, "row_bcast:15 row_mask:0xa bank_mask:0xf");
+        PHASE_FENCE();
+        EST(5);
+        const bool tail = valid && ((c == 31) || (reff != rnext));
+        const int r_first = __builtin_amdgcn_readfirstlane(reff);
+        const bool sl = (start == 0) && (ix.r_before == r_first);
+        const bool sr = (c == 31) && (ix.r_after == reff);
+        const bool to_carry = sl || sr;
+        f32x4* dst = to_carry ? prow_ptr(a.CARRY, (int64_t)2 * tile + (sl ? 0 : 1), L, h) : tile_ptr(a.AGG, r >> 5, L, 32 * h + (r & 31));
+        if (tail) store_frag<NT>(dst, to_carry ? STRIDE_PROW : STRIDE_TILE, acc);
+        EST(6);
+        PHASE_FENCE();
+        // turnover: the next tile's layer-1 accumulator starts from Q[r] (P[s] arrives during the layer)
+        load_frag<NT>(acc, prow_ptr(a.Q, ixn.r >= 0 ? ixn.r : 0, L, h), STRIDE_PROW);
+        EST(7);
+        ix = ixn;
+        tw.tile += tw.stride;
+    }
+}
+
+// ================================================================================================
 // Processor node step (K6) on the split path: k_node_step<4, *, false>'s tile loop with its four L x L chunks on the bf16 matrix
 // cores.  split[]: the chunks in NodeArgs.chunk order (0: W2, 1: W3, 2: W1[0:L] (node part), 3: W1[L:2L] (aggregate part)), each as
 // hi / mid / lo pieces.  LDS: the four hi pieces (128 KiB) + tables; mid and lo stream from L2 (sp_layer_otf rings).  The V tile is
@@ -1935,6 +2259,12 @@ hipError_t launch_edge_ring(const EdgeArgs& a, const LaunchCfg& lc, hipStream_t 
     if (lc.threads == 256) return sp_launch(k_edge_ring<4>, a, lc, s, attr_set4);
     return sp_launch(k_edge_ring<8>, a, lc, s, attr_set8);
 }
+hipError_t launch_edge_ring_h(const EdgeArgs& a, const LaunchCfg& lc, hipStream_t s) {
+    static bool attr_set8 = false, attr_set4 = false;
+    if (lc.threads == 256) return sp_launch(k_edge_ring_h<4>, a, lc, s, attr_set4);
+    return sp_launch(k_edge_ring_h<8>, a, lc, s, attr_set8);
+}
+size_t edge_ring_h_lds() { return (size_t)3 * 32768 + (size_t)3 * Rh<MGN_RINGH_W>::BUF * 16 + (size_t)T_COUNT * 128 * 4 + 64; }
 hipError_t launch_edge_ring16(const EdgeArgs& a, const LaunchCfg& lc, hipStream_t s) {
     static bool attr_set8 = false, attr_set4 = false;
     if (lc.threads == 256) return sp_launch(k_edge_ring16<4>, a, lc, s, attr_set4);

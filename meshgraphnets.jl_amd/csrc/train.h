@@ -69,8 +69,10 @@ int wgrad_blocks_of_job(int64_t launch_rows, int64_t job_rows);   // blocks of a
 // one L x L chunk of the inference layouts, from rows [kbase, kbase + L) of the matrix at params + src (leading dimension ldw).
 // kind 0: fp32, three copies at wfrag + off (fragment order, t-major at + L L, 16x16x4 order at + 2 L L when L = 128);
 // kind 1 / 2: the three exact bf16 pieces (hi, mid, lo; 16 384 each) at wsp + off in the 32x32x16 / 16x16x32 fragment order;
-// kind 3: one bf16 copy at wbf + off (bf16 storage mode).  The host functions of mgn_api.cpp with the same names are the specification.
-struct WPackJob { int kind; long long off, src; int ldw, kbase; };
+// kind 3: one bf16 copy at wbf + off (bf16 storage mode);
+// kind 4: the two fp16 pieces (hi, lo; 16 384 each) of the chunk times `scale` (a power of two) at wsp + off, 32x32x16 fragment order
+// (split_common.hpp).  The host functions of mgn_api.cpp with the same names are the specification.
+struct WPackJob { int kind; long long off, src; int ldw, kbase; float scale; };
 hipError_t launch_pack_weights(int L, const WPackJob* jobs, int njobs, const float* params, float* wfrag, uint16_t* wsp, uint16_t* wbf, hipStream_t s);
 // one packed copy of the training weights: kind 0 = an L x L chunk in fragment order + its t-major copy at + L * L, from rows [r0, r0 + nr)
 // x cols [0, nc) of the matrix at params + src (leading dimension ldw; src < 0: the identity), zero-padded, transposed on request;

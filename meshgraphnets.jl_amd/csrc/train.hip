@@ -880,6 +880,14 @@ __global__ void k_pack_weights(const WPackJob* __restrict__ jobs, const float* _
         wbf[jb.off + idx] = pk_bf16(w);
         return;
     }
+    if (jb.kind == 4) {                                 // w scale = hi + lo (+ <= 2^-23 relative), both fp16 (split_common.hpp)
+        const float ws = w * jb.scale;
+        const _Float16 hi = (_Float16)ws;
+        const _Float16 lo = (_Float16)(ws - (float)hi);
+        wsp[jb.off + idx] = __builtin_bit_cast(uint16_t, hi);
+        wsp[jb.off + 16384 + idx] = __builtin_bit_cast(uint16_t, lo);
+        return;
+    }
     const uint16_t hi = pk_bf16(w);                     // w = hi + mid + lo exactly (split.hip)
     const float r1 = w - pk_f32(hi);
     const uint16_t mid = pk_bf16(r1);

@@ -8,19 +8,22 @@ import torch  # noqa: F401
 
 import mgn_oracle as orc
 from mgn_amd import synth
-from util import TOL_15, TOL_STEP, cfg_dict, engine_for, make_params, rel_max, set_c16_row_tiles, set_c16_split, set_edge_ring16, set_fp32_split, set_kernel_path
+from util import TOL_15, TOL_STEP, cfg_dict, engine_for, make_params, rel_max, set_c16_row_tiles, set_c16_split, set_edge_ring16, set_fp32_split, set_kernel_path, set_split_f16
 
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(params=[1, 2, 3, 16], ids=["ring", "split2", "ring2", "ring16"])
+@pytest.fixture(params=[100, 1, 2, 3, 16], ids=["ring_h", "ring", "split2", "ring2", "ring16"])
 def split_on(request):
-    """16: the ring kernel on v_mfma_f32_16x16x32_bf16 (k_edge_ring16: mode 1 + mgn_debug_edge_ring16; its fragments are packed at
-    set_params, so the switch is thrown before the engines are built)"""
-    mode = 1 if request.param == 16 else request.param
+    """100: the default -- mode 1 on two fp16 pieces and three piece products (k_edge_ring_h); 1: the same mode on three bf16 pieces and
+    six products (k_edge_ring; mgn_debug_split_f16(0)); 16: that kernel on v_mfma_f32_16x16x32_bf16 (k_edge_ring16: mode 1 +
+    mgn_debug_edge_ring16; its fragments are packed at set_params, so the switch is thrown before the engines are built)"""
+    mode = 1 if request.param in (16, 100) else request.param
     old = set_fp32_split(mode)
     old16 = set_edge_ring16(1 if request.param == 16 else 0)
+    oldh = set_split_f16(1 if request.param == 100 else 0)
     yield mode
+    set_split_f16(oldh)
     set_edge_ring16(old16)
     set_fp32_split(old)
 
@@ -53,6 +56,41 @@ def test_split_numerics_of_one_layer_on_the_host():
     e_split = np.abs(acc - ref).max() / np.abs(ref).max()
     e_f32 = np.abs((X @ W) - ref).max() / np.abs(ref).max()
     assert e_split <= 4e-7 and e_split <= 2 * e_f32, (e_split, e_f32)
+
+
+def test_two_fp16_pieces_numerics_of_one_layer_on_the_host():
+    """the arithmetic of the default split path, in numpy: an operand times a power of two that puts the row's (chunk's) largest entry
+    into [2^14, 2^15) is hi + lo in fp16 to 2^-23; hi x hi + hi x lo + lo x hi beat a plain fp32 GEMM against float64 whatever the
+    scale of the inputs -- per ROW, which is what the kernels do -- and never overflow"""
+    rng = np.random.default_rng(0)
+
+    def scale(amax):
+        e = np.floor(np.log2(np.maximum(amax, 2.0 ** -40)))
+        return (2.0 ** (14 - e)).astype(np.float32)
+
+    def split2(x, s):
+        xs = (x * s).astype(np.float32)
+        hi = xs.astype(np.float16)
+        lo = (xs - hi.astype(np.float32)).astype(np.float16)
+        assert np.isfinite(hi.astype(np.float32)).all()
+        return hi.astype(np.float64), lo.astype(np.float64)
+
+    W = (rng.uniform(-1, 1, (128, 128)) * np.sqrt(6 / 256)).astype(np.float32)
+    sw = scale(np.abs(W).max())
+    wh, wl = split2(W, sw)
+    for row_scales in (np.ones(2048), 10.0 ** rng.uniform(-6, 6, 2048)):
+        X = (rng.standard_normal((2048, 128)) * row_scales[:, None]).astype(np.float32)
+        X[:, 64:] = np.maximum(X[:, 64:], 0)                                   # half of it ReLU-like
+        sx = scale(np.abs(X).max(1, keepdims=True))
+        xh, xl = split2(X, sx)
+        err_rep = np.abs((xh + xl) / sx - X).max(1) / np.abs(X).max(1)
+        assert err_rep.max() <= 2.0 ** -23
+        ref = X.astype(np.float64) @ W.astype(np.float64)
+        got = ((xh @ wl + xl @ wh + xh @ wh).astype(np.float32) / (sx * sw)).astype(np.float32)
+        den = np.abs(ref).max(1, keepdims=True)                                 # per row: the rows differ by twelve orders of magnitude
+        e_h2 = (np.abs(got - ref) / den).max()
+        e_f32 = (np.abs((X @ W) - ref) / den).max()
+        assert e_h2 <= 2.5e-7 and e_h2 <= e_f32, (e_h2, e_f32)
 
 
 @pytest.mark.parametrize("nsteps,tol", [(1, TOL_STEP), (15, TOL_15)])

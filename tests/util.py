@@ -75,6 +75,15 @@ def set_c16_split(on):
     return lib.mgn_debug_c16_split(on)
 
 
+def set_split_f16(on):
+    """Split path: 1 (default) = two fp16 pieces per operand, three piece products (k_edge_ring_h), 0 = three bf16 pieces, six products
+    (k_edge_ring).  Returns the old value."""
+    lib = mgn_amd.load()
+    lib.mgn_debug_split_f16.restype = __import__("ctypes").c_int
+    lib.mgn_debug_split_f16.argtypes = [__import__("ctypes").c_int]
+    return lib.mgn_debug_split_f16(on)
+
+
 def set_edge_ring16(on):
     """1: k_edge_ring16 (the ring kernel on v_mfma_f32_16x16x32_bf16) wherever k_edge_ring would run; read by set_params (fragment
     order) and by every launch.  Returns the old value."""
