@@ -28,7 +28,6 @@ sys.path.insert(0, ROOT)
 PEAK_F32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: dense f32-input MFMA peak
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # same guide: dense bf16 MFMA peak (the headline figures with 2:1 sparsity are not used)
 PEAK_HBM_GBPS = 8000.0         # same guide: HBM3E ~8 TB/s
-SPLIT_PRODUCTS = 6             # bf16 piece products per fp32 product on the split path (csrc/split.hip)
 L, MPS, FN, FE, O = 128, 15, 9, 3, 2
 
 
@@ -375,39 +374,64 @@ def main():
             lib.mgn_debug_last_edge_kernel.argtypes = []
             fam = lib.mgn_debug_last_edge_kernel()
             FAMILY = {1: "k_edge_step<.., GEN> (general hidden_layers)", 2: "k_edge_coop16m (16-row tiles)", 3: "k_edge_coop (4-wave tiles)",
-                      4: "k_edge_step<4,0> (all-streaming)", 5: "k_edge_split2", 6: "k_edge_ring2", 7: "k_edge_ring<8>", 8: "k_edge_ring<4>",
-                      9: "k_edge_step<4,2>", 10: "k_edge_ring16<8>", 11: "k_edge_ring16<4>"}
-            ran_split = fam in (5, 6, 7, 8, 10, 11)
-            if not ran_split:
-                split_mode = 0
+                      4: "k_edge_step<4,0> (all-streaming)", 7: "k_edge_ring<8>", 8: "k_edge_ring<4>", 9: "k_edge_step<4,2>",
+                      10: "k_edge_ring16<8>", 11: "k_edge_ring16<4>", 12: "k_edge_coop16m (16-row tiles, split path)",
+                      13: "k_edge_ring_h<8>", 14: "k_edge_ring_h<4>"}
+            # piece products per fp32 product of the family that ran: 6 (three bf16 pieces), 3 (two fp16 pieces), 0 = fp32 MFMA
+            products = {7: 6, 8: 6, 10: 6, 11: 6, 12: 6, 13: 3, 14: 3}.get(fam, 0)
+            split_mode = split_mode if products else 0
             comp = (1024.0 + 8.0) * e_loc + 3.0 * 512.0 * n_loc
+            alg_bytes = (1024.0 + 8.0 + 85.0) * e_loc
             common = {"avg_launch_ms": t_edge * 1e3, "launches": prof["edge_step"]["count"],
                       "traffic_unit": "bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE); algorithmic = 1117 B/edge",
-                      "algorithmic_bytes_per_launch": (1024.0 + 8.0 + 85.0) * e_loc,
+                      "algorithmic_bytes_per_launch": alg_bytes,
                       # what THIS kernel has to move at least, given the factored design: e latents R + W, index streams, and one
                       # pass over the P, Q rows it gathers and the AGG rows it writes (3 x N x 512 B); gather re-reads come on top
                       "kernel_compulsory_bytes_per_launch": comp}
-            if split_mode:
-                # fp32 storage, every L x L product as six exact bf16 products on v_mfma_f32_32x32x16_bf16, fp32 accumulation
-                # (csrc/split.hip).  The roofline is the bf16 dense peak with the flops the kernel EXECUTES: 6 x the fp32 count.
-                kname = {5: "k_edge_split2", 6: "k_edge_ring2", 7: "k_edge_ring", 8: "k_edge_ring", 10: "k_edge_ring16", 11: "k_edge_ring16"}[fam]
-                fl = SPLIT_PRODUCTS * flops_edge_kernel(e_loc)
+            if products:
+                # fp32 storage, every L x L product as `products` exact 16-bit piece products, fp32 accumulation (csrc/split.hip).  Two
+                # roofs: the dense 16-bit MFMA peak with the flops the kernel EXECUTES, and HBM with SURVEY 8(d)'s algorithmic bytes;
+                # the line's `bound` is whichever floor is the longer time for this kernel.
+                kname = FAMILY[fam].split("<")[0].split(" ")[0]
+                fl = products * flops_edge_kernel(e_loc)
                 ach = fl / t_edge / 1e12 if t_edge > 0 else 0.0
-                traffic, tsrc = committed_traffic([kname]) if (world == 1 and args.nx == 1000) else (None, None)
-                roof = {"bound": "mfma", "kernel": kname + " (fused gather + edge MLP + LayerNorm + residual + segmented scatter; fp32 operands as "
-                        "three bf16 pieces, six piece products per fp32 product, fp32 accumulate)",
-                        "achieved": ach, "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_BF16_MFMA_TFLOPS,
-                        "flops_per_launch": fl, "flops_kind": "bf16 MFMA flops executed by this kernel: 6 x 98 304 per edge (layer 1 is factored: the "
-                        "v_s / v_r blocks run per node); against the dense bf16 peak",
+                ach_b = alg_bytes / t_edge / 1e9 if t_edge > 0 else 0.0
+                traffic, tsrc = committed_traffic([kname + "<"]) if (world == 1 and args.nx == 1000) else (None, None)
+                pieces = ("two fp16 pieces after a power-of-two scaling per weight chunk and per activation row, three piece products"
+                          if products == 3 else "three bf16 pieces, six piece products")
+                mfma_roof = {"achieved": ach, "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_BF16_MFMA_TFLOPS,
+                             "flops_per_launch": fl, "floor_ms": fl / (PEAK_BF16_MFMA_TFLOPS * 1e12) * 1e3,
+                             "flops_kind": f"16-bit MFMA flops executed by this kernel: {products} x 98 304 per edge (layer 1 is factored: the "
+                                           "v_s / v_r blocks run per node); against the dense bf16 / fp16 peak"}
+                hbm_roof = {"achieved": ach_b, "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": ach_b / PEAK_HBM_GBPS,
+                            "bytes_per_launch": alg_bytes, "floor_ms": alg_bytes / (PEAK_HBM_GBPS * 1e9) * 1e3,
+                            "bytes_kind": "SURVEY.md 8(d) algorithmic bytes of the edge step: 1 024 B of e latents R + W + 8 B of indices + "
+                                          "512 N / E B of aggregates per edge"}
+                hbm_binds = hbm_roof["floor_ms"] > mfma_roof["floor_ms"]
+                bind, other = (hbm_roof, mfma_roof) if hbm_binds else (mfma_roof, hbm_roof)
+                roof = {"bound": "hbm" if hbm_binds else "mfma",
+                        "kernel": kname + f" (fused gather + edge MLP + LayerNorm + residual + segmented scatter; fp32 operands as {pieces}, "
+                        "fp32 accumulate)",
+                        **{k: bind[k] for k in ("achieved", "peak", "unit", "frac")},
+                        "binding_roof": bind, ("mfma_roof" if hbm_binds else "hbm_roof"): other,
+                        "bound_note": "the roof whose floor is the longer time for this kernel (both are given): with three piece products the "
+                                      "matrix floor (0.71 ms on M-1M) falls below the HBM floor (0.84 ms)" if hbm_binds else
+                                      "matrix floor above the HBM floor",
                         "fp32_equivalent_TFLOPs": flops_edge_kernel(e_loc) / t_edge / 1e12 if t_edge > 0 else 0.0,
                         "fp32_equivalent_note": "the same launch counted as the fp32 products it replaces (98 304 flop per edge): what an fp32-MFMA "
                                                 "kernel would have to sustain (its peak: 157.3)",
                         "traffic": traffic, "traffic_source": tsrc, **common}
-                ex = SPLIT_PRODUCTS * exec_flops_pass / MPS
+                ex = products * exec_flops_pass / MPS
+                bytes_step = 4.0 * L * (2 * E + 2 * N) + 8.0 * E
+                step_m = {"executed_flops_per_step": ex, "achieved": ex / t_step / 1e12, "peak": PEAK_BF16_MFMA_TFLOPS * world,
+                          "unit": "TFLOP/s", "frac": ex / t_step / 1e12 / (PEAK_BF16_MFMA_TFLOPS * world)}
+                step_h = {"algorithmic_bytes_per_step": bytes_step, "achieved": bytes_step / t_step / 1e9, "peak": PEAK_HBM_GBPS * world,
+                          "unit": "GB/s", "frac": bytes_step / t_step / 1e9 / (PEAK_HBM_GBPS * world)}
+                sb, so_ = (step_h, step_m) if hbm_binds else (step_m, step_h)
                 roof["processor_step"] = {
-                    "bound": "mfma", "executed_flops_per_step": ex, "achieved": ex / t_step / 1e12, "peak": PEAK_BF16_MFMA_TFLOPS * world,
-                    "unit": "TFLOP/s", "frac": ex / t_step / 1e12 / (PEAK_BF16_MFMA_TFLOPS * world),
-                    "note": "bf16 MFMA flops the kernels execute (6 x (98 304 E + 196 608 N)) / wall time per step",
+                    "bound": "hbm" if hbm_binds else "mfma", **sb, ("mfma_roof" if hbm_binds else "hbm_roof"): so_,
+                    "note": f"whole step: 16-bit MFMA flops executed ({products} x (98 304 E + 196 608 N)) and SURVEY.md 8(d) bytes "
+                            "(1 024 (E + N) + 8 E) over the wall time per step",
                     "fp32_equivalent_TFLOPs": exec_flops_pass / MPS / t_step / 1e12,
                     "algorithmic_equivalent_TFLOPs": flops_algorithmic(E, N) / t_step / 1e12,
                     "algorithmic_equivalent_note": "SURVEY.md 8(d) flops of the UN-factored fp32 algorithm (163 840 E + 131 072 N) over the same "
@@ -436,6 +460,11 @@ def main():
             roof["halo_pack_ms"] = prof["halo"]["avg_ms"]
         if bf:
             precision = "bf16 storage + bf16 MFMA"
+        elif split_mode and products == 3:
+            precision = ("fp32 storage, fp16x2 split MFMA (every fp32 operand = two fp16 pieces after a power-of-two scaling per weight "
+                         "chunk / per activation row, three exact piece products per fp32 product on v_mfma_f32_32x32x16_f16), fp32 "
+                         "accumulate; held to the fp32 tolerances against the float64 oracle; MGN_SPLIT_F16=0 gives the bf16x3 path "
+                         "(`bf16x3_path`), MGN_FP32_SPLIT=0 the fp32-MFMA path (`fp32_mfma_path`)")
         elif split_mode:
             precision = ("fp32 storage, bf16x3 split MFMA (every fp32 operand = three bf16 pieces, six exact piece products per fp32 "
                          "product on v_mfma_f32_32x32x16_bf16), fp32 accumulate; MGN_FP32_SPLIT=0 gives the fp32-MFMA path reported under "
@@ -496,6 +525,30 @@ def main():
                 engs.close()
             finally:
                 lib.mgn_debug_fp32_split(split_mode)
+        if world == 1 and not args.no_secondary and args.dtype == "f32" and split_mode and products == 3:
+            # ... and on the three-piece bf16 split (six products): round 3 / 4's headline path
+            lib.mgn_debug_split_f16.restype = ctypes.c_int
+            lib.mgn_debug_split_f16.argtypes = [ctypes.c_int]
+            oldh = lib.mgn_debug_split_f16(0)
+            try:
+                engs = mgn_amd.Engine(FN, FE, O, L, 2, MPS, device=local_rank)
+                engs.set_params(ps)
+                engs.set_graph(s, r, N)
+                engs.latents_randn(1234)
+                dts, profs = time_single(engs, 3, 1, barrier_sync)
+                ts = dts / (3 * MPS)
+                te = profs["edge_step"]["avg_ms"] * 1e-3
+                out["bf16x3_path"] = {
+                    "workload": "same M-1M mesh, fp32 storage, three bf16 pieces / six piece products (MGN_SPLIT_F16=0: k_edge_ring, k_node_split, "
+                                "k_project_split; the headline path of rounds 3 and 4)",
+                    "ms_per_processor_step": ts * 1e3, "edges_per_s": E / ts, "edge_kernel_ms": te * 1e3,
+                    "node_side_ms": profs["node_step"]["avg_ms"],
+                    "roofline": {"bound": "mfma", "kernel": "k_edge_ring", "achieved": 6 * flops_edge_kernel(E) / te / 1e12 if te > 0 else 0.0,
+                                 "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
+                                 "frac": 6 * flops_edge_kernel(E) / te / 1e12 / PEAK_BF16_MFMA_TFLOPS if te > 0 else 0.0}}
+                engs.close()
+            finally:
+                lib.mgn_debug_split_f16(oldh)
         if world == 1 and not args.no_secondary and args.dtype == "f32":
             engb = mgn_amd.Engine(FN, FE, O, L, 2, MPS, device=local_rank, dtype="bf16")
             engb.set_params(ps)

@@ -86,6 +86,9 @@ struct NodeArgs {
     // split path (see EdgeArgs.split): chunk[0..5] as 3 x 16384 bf16 pieces each (k_node_split, k_project_split); null: not available
     const uint16_t* split[7];     // [6]: W1[2L:3L], the second edge set's aggregate block (k_node_split<true>)
     const uint16_t* split16[9];   // chunk[0..8] as pieces in the 16x16x32 fragment order (k_node_coop16 on the split path); null: not available
+    // chunk[0..5] as two fp16 pieces times h2_s[i] (k_node_split_h, k_project_split_h; see EdgeArgs.splith); h2_b2pos = max(0, max_k b2[k])
+    const uint16_t* splith[6];
+    float h2_s[6], h2_rs[6], h2_b2pos;
 };
 
 struct EncNodeArgs {
@@ -160,17 +163,14 @@ bool prows_blocked();        // P / Q / CARRY rows are stored in blocks of eight
 hipError_t launch_gather_rows16(const uint16_t* src, const int32_t* idx, uint16_t* dst, int64_t rows, int dst_stride /* elements */, hipStream_t s);
 
 struct LaunchCfg { int blocks; int threads; size_t lds; };
-hipError_t launch_edge_split2(const EdgeArgs& a, const LaunchCfg& lc, hipStream_t s);   // split.hip
+hipError_t launch_node_split_h(const NodeArgs& a, const LaunchCfg& lc, hipStream_t s);    // split.hip: node MLP / projection on two fp16 pieces
+hipError_t launch_project_split_h(const NodeArgs& a, const LaunchCfg& lc, hipStream_t s);
 hipError_t launch_edge_ring_h(const EdgeArgs& a, const LaunchCfg& lc, hipStream_t s);    // split.hip: the ring kernel on two fp16 pieces, three products
 size_t edge_ring_h_lds();
 hipError_t launch_edge_ring16(const EdgeArgs& a, const LaunchCfg& lc, hipStream_t s);   // split.hip: the ring kernel on v_mfma_f32_16x16x32_bf16
 hipError_t launch_edge_ring(const EdgeArgs& a, const LaunchCfg& lc, hipStream_t s);    // split.hip
-hipError_t launch_edge_ring2(const EdgeArgs& a, const LaunchCfg& lc, hipStream_t s);   // split.hip: two four-wave blocks per CU
 hipError_t launch_node_split(const NodeArgs& a, const LaunchCfg& lc, hipStream_t s);    // split.hip
 hipError_t launch_project_split(const NodeArgs& a, const LaunchCfg& lc, hipStream_t s); // split.hip
-hipError_t launch_node_ring(const NodeArgs& a, const LaunchCfg& lc, hipStream_t s);     // split.hip: node MLP + projection, one launch
-long node_ring_launches();
-bool node_ring_size(int ntiles);    // launch_node_step(mode 1) would run k_node_ring at this size (given split pieces, one edge set)
 
 struct LinComb {            // sum_j c[j] * k[j]
     int n;
@@ -191,7 +191,7 @@ int coop16_enabled();
 bool coop16_size(int ntiles_e, int ntiles_n);   // the launch wrappers' rule for the cooperative node kernels (<= 8 tiles per CU)
 int last_edge_kernel();
 int last_node_kernel();         // family of the last fp32 edge launch (kernels.hip: launch_edge_step)
-int set_fp32_split(int on);     // debug/tests: 0 = fp32-MFMA kernels, 1 = split path (default), 2 = split path with k_edge_split2; returns the old value
+int set_fp32_split(int on);     // debug/tests: 0 = fp32-MFMA kernels, 1 = split path (default); returns the old value
 int fp32_split_enabled();
 int set_split_f16(int on);     // 1 (default): the split path on two fp16 pieces / three products where built (k_edge_ring_h), 0: three bf16 pieces / six products; MGN_SPLIT_F16; returns the old value
 int split_f16_enabled();

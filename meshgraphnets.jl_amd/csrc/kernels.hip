@@ -2652,11 +2652,6 @@ static const int g_node_split_min = [] { const char* e = getenv("MGN_NODE_SPLIT_
 bool node_split_size(int ntiles) { return g_fp32_split != 0 && g_path == 0 && ntiles > g_node_split_min * num_cus(); }
 bool launch_is_small_edge(int ntiles_e) { return coop_size(ntiles_e, true); }
 
-// 1: node MLP + projection as ONE lock-step launch over an LDS ring (k_node_ring; parity-green, 1.215 vs 1.173 ms on M-1M: opt-in)
-static int g_node_ring = [] { const char* e = getenv("MGN_NODE_RING"); return e ? atoi(e) : 0; }();
-static long g_node_ring_launches = 0;          // tests: the opt-in kernel computes the same bits as the two-kernel path, so they count launches
-long node_ring_launches() { return g_node_ring_launches; }
-bool node_ring_size(int ntiles) { return g_node_ring && g_fp32_split == 1 && g_path == 0 && !small_launch(ntiles) && !coop_size(ntiles, false); }
 
 static LaunchCfg tile_launch(int L, int ntiles, int nres) {
     LaunchCfg lc;
@@ -2738,8 +2733,9 @@ static bool coop_ok(int L, int ntiles, const float* const* chunk_t, bool edge = 
 }
 
 // which kernel family the last fp32 edge launch went to (bench.py labels its roofline with what RAN, not with the global switches):
-// 1 generic hidden_layers, 2 16-row small-graph, 3 cooperative 4-wave tiles, 4 all-streaming, 5 k_edge_split2, 6 k_edge_ring2,
-// 7 k_edge_ring<8>, 8 k_edge_ring<4>, 9 k_edge_step<4,2> (fp32-MFMA persistent)
+// 1 generic hidden_layers, 2 16-row small-graph, 3 cooperative 4-wave tiles, 4 all-streaming, (5, 6: kernels retired in round 5,)
+// 7 k_edge_ring<8>, 8 k_edge_ring<4>, 9 k_edge_step<4,2> (fp32-MFMA persistent), 10 / 11 k_edge_ring16<8 / 4>, 12 k_edge_coop16m on the
+// split path, 13 / 14 k_edge_ring_h<8 / 4> (two fp16 pieces: the default of large fp32 launches)
 static int g_last_edge_kernel = 0;
 int last_edge_kernel() { return g_last_edge_kernel; }
 
@@ -2801,20 +2797,6 @@ hipError_t launch_edge_step(int L, const EdgeArgs& a, hipStream_t s) {
         }
         if (g_fp32_split && a.split[0] && g_path == 0) {   // split path (split.hip): fp32 accuracy on the bf16 matrix cores
             LaunchCfg ls = lc;
-            if (g_fp32_split == 2) {
-                ls.lds = (size_t)4 * 16384 * 2 + (size_t)T_COUNT * L * 4 + 64;
-                g_last_edge_kernel = 5;
-                return launch_edge_split2(a, ls, s);
-            }
-            if (g_fp32_split == 3) {   // two independent four-wave blocks per CU, every piece through the block's own ring
-                ls.threads = 256;
-                ls.lds = (size_t)3 * 3 * 8 * 64 * 16 + (size_t)T_COUNT * L * 4 + 64;
-                int blocks = (a.ntiles + 3) / 4;
-                if (blocks > 2 * num_cus()) blocks = 2 * num_cus();
-                ls.blocks = ((blocks + NUM_XCD - 1) / NUM_XCD) * NUM_XCD;
-                g_last_edge_kernel = 6;
-                return launch_edge_ring2(a, ls, s);
-            }
             ls.lds = (size_t)3 * 32768 + (size_t)3 * 16384 + (size_t)T_COUNT * L * 4 + 64;
             static const int ring_waves = [] { const char* e = getenv("MGN_RING_WAVES"); return e ? atoi(e) : 0; }();   // 0: by size
             // four-wave blocks (one wave per SIMD) up to 2.5 rounds of eight-wave blocks: 16 k nodes 75 vs 83 us, 25.6 k 115 vs 120,
@@ -2865,7 +2847,7 @@ hipError_t launch_edge_step(int L, const EdgeArgs& a, hipStream_t s) {
     return hipErrorInvalidValue;
 }
 static int g_last_node_kernel = 0;    // family of the last node-MLP launch (tests / bench): 1 general, 2 16-row cooperative, 3 cooperative,
-int last_node_kernel() { return g_last_node_kernel; }   // 4 k_node_ring, 5 k_node_split, 6 k_node_split<two sets>, 7 fp32-MFMA k_node_step
+int last_node_kernel() { return g_last_node_kernel; }   // 5 k_node_split, 6 k_node_split<two sets>, 7 fp32-MFMA k_node_step, 8 / 9 16-row kernels on the split path, 10 k_node_split_h
 hipError_t launch_node_step(int L, const NodeArgs& a, hipStream_t s) {
     if (a.ntiles <= 0) return hipSuccess;
     if (a.mode != 2) g_last_node_kernel = a.gen.use ? 1 : (a.c16 && L == 128 && a.chunk_t[0]) ? 2 : coop_ok(L, a.ntiles, a.chunk_t) ? 3 : 7;
@@ -2906,16 +2888,13 @@ hipError_t launch_node_step(int L, const NodeArgs& a, hipStream_t s) {
     }
     if (a.mode == 2) return launch_project(L, a, s);
     const bool proj = a.mode == 1;
-    if (proj && L == 128 && !a.AGG2 && a.split[0] && a.split[4] && node_ring_size(a.ntiles)) {   // split path, MLP + projection (split.hip)
-        LaunchCfg ls = tile_launch(L, a.ntiles, 2);
-        ls.lds = (size_t)3 * 3 * 8 * 64 * 16 + (size_t)T_COUNT * L * 4 + 64;
-        ++g_node_ring_launches;
-        g_last_node_kernel = 4;
-        return launch_node_ring(a, ls, s);
-    }
     if (split_node) {   // split path (split.hip)
         LaunchCfg ls = tile_launch(L, a.ntiles, 2);
         ls.lds = (size_t)4 * 16384 * 2 + (size_t)T_COUNT * L * 4 + 64;
+        if (g_split_f16 && a.splith[0] && !a.AGG2) {   // two fp16 pieces, three products
+            g_last_node_kernel = 10;
+            return launch_node_split_h(a, ls, s);
+        }
         g_last_node_kernel = a.AGG2 ? 6 : 5;
         return launch_node_split(a, ls, s);
     }
@@ -2973,6 +2952,7 @@ hipError_t launch_project(int L, const NodeArgs& a, hipStream_t s) {
         if (split_ok) {   // split path (split.hip)
             LaunchCfg ls = lc;
             ls.lds = (size_t)4 * 16384 * 2 + (size_t)T_COUNT * L * 4 + 64;
+            if (g_split_f16 && a.splith[4]) return launch_project_split_h(a, ls, s);
             return launch_project_split(a, ls, s);
         }
         if (lc.threads == 512) lc.threads = MGN_PROJ_WAVES * 64;

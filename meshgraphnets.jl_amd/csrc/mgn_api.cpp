@@ -492,6 +492,13 @@ NodeArgs node_args(mgn_engine* h, int k, int mode, int q = 0) {
     const bool sp16 = k < (int)h->spoff.size() && h->spoff[k].have_n && h->wsp.p;
     const bool sp = !bf && sp16;
     for (int i = 0; i < 6; ++i) a.split[i] = (sp && q == 0) ? h->wsp.as<uint16_t>() + h->spoff[k].n_ch[i] : nullptr;
+    const bool sph = sp && q == 0 && h->nsets == 1 && h->spoff[k].have_h;        // two fp16 pieces (one edge set)
+    for (int i = 0; i < 6; ++i) {
+        a.splith[i] = sph ? h->wsp.as<uint16_t>() + h->spoff[k].nh_ch[i] : nullptr;
+        a.h2_s[i] = sph ? h->spoff[k].nh_s[i] : 1.f;
+        a.h2_rs[i] = 1.f / a.h2_s[i];
+    }
+    a.h2_b2pos = sph ? h->spoff[k].n_b2pos : 0.f;
     if (sp && h->nsets == 2) {
         if (q == 1)                                     // the projection of set 1 (mode 2): its WP / WQ pieces
             for (int i = 0; i < 2; ++i) a.split[4 + i] = h->wsp.as<uint16_t>() + h->spoff[k].n2_ch[1 + i];
@@ -873,6 +880,13 @@ int pack_inference_weights(mgn_engine* h) {
             const float* src[6] = {p + mn.W[1], p + mn.W[2], p + mn.W[0], p + mn.W[0], p + nx.W[0], p + nx.W[0]};
             const int kb[6] = {0, 0, 0, L, 0, L};
             for (int i = 0; i < 6; ++i) put(src[i], kb[i], h->spoff[k].n_ch[i], h->spoff[k].n16_ch[i]);
+            if (f32) {
+                for (int i = 0; i < 6; ++i) puth(src[i], kb[i], h->spoff[k].nh_ch[i], h->spoff[k].nh_s[i]);
+                float bp = 0.f;
+                for (int i = 0; i < L; ++i) bp = std::max(bp, p[mn.b[1] + i]);
+                h->spoff[k].n_b2pos = bp;
+                h->spoff[k].have_h = true;
+            }
             if (S == 2) {                                               // second edge set: its aggregate block of the node MLP, its projection
                 const MlpOff& n1 = h->es[1].pe[k + 1 < c.mps ? k + 1 : 0];
                 const float* src2[3] = {p + mn.W[0], p + n1.W[0], p + n1.W[0]};
@@ -1361,11 +1375,6 @@ int mgn_proc_node(mgn_handle* h, int32_t k, int32_t project_next) try {
         HIPCHK(h, launch_node_bf16(bf_node_args(h, k), h->stream));
         for (int q = 0; project_next && q < h->nsets; ++q)
             if (int rc = project_set(h, k, q)) return rc;
-        return MGN_OK;
-    }
-    // split path, one edge set, large launch: MLP and projection in ONE lock-step launch whose weight pieces pass through an LDS ring
-    if (project_next && h->nsets == 1 && h->cfg.L == 128 && node_ring_size(h->ntiles_n) && k < (int)h->spoff.size() && h->spoff[k].have_n && h->wsp.p) {
-        HIPCHK(h, launch_node_step(h->cfg.L, node_args(h, k, 1), h->stream));
         return MGN_OK;
     }
     // large meshes: MLP and projection as two launches (the projection then has both of its chunks LDS-resident);
@@ -2565,7 +2574,7 @@ int mgn_halo_exchange_host(mgn_handle* h, const float* own_rows, float* halo_row
 int mgn_debug_kernel_path(int path) { return set_kernel_path(path); }
 int mgn_debug_c16_row_tiles(int rt) { return set_c16_row_tiles(rt); }
 // large fp32 launches: 1 split path (k_edge_ring + k_node_split + k_project_split: bf16 matrix cores at fp32 accuracy; the default),
-// 2 the same with k_edge_split2, 0 fp32-MFMA kernels; returns the old value
+// 0 fp32-MFMA kernels; returns the old value
 int mgn_debug_fp32_split(int on) { return set_fp32_split(on); }
 // 1: the edge kernel of the split path on v_mfma_f32_16x16x32_bf16 (k_edge_ring16); takes effect at the next mgn_set_params (its weight
 // fragments are packed there).  Returns the old value.  Environment: MGN_EDGE_RING16.
@@ -2610,7 +2619,6 @@ int mgn_debug_last_edge_kernel(void) { return last_edge_kernel(); }   // kernels
 // node numbering policy of the NEXT mgn_set_graph calls (0 never, 1 auto, 2 always breadth-first); returns the old value
 int mgn_debug_renumber(int mode) { const int old = g_renumber; g_renumber = mode; return old; }
 int mgn_debug_renumbered(const mgn_handle* h) { return h && h->have_graph && h->g.renumbered ? 1 : 0; }
-long mgn_debug_node_ring_launches(void) { return node_ring_launches(); }   // launches of the opt-in k_node_ring so far (tests)
 
 int mgn_debug_edge_stamps(mgn_handle* h, int32_t k, unsigned long long* out /* [32768] */) try {
     if (int rc = need(h, true, true)) return rc;

@@ -11,7 +11,7 @@ import torch   # noqa: F401
 import mgn_oracle as orc
 from mgn_amd import synth
 from mgn_amd.engine import MgnError
-from util import TOL_15, cfg_dict, engine_for, make_params, random_inputs, rel_max, set_fp32_split, set_kernel_path, small_mesh
+from util import TOL_15, cfg_dict, engine_for, make_params, random_inputs, rel_max, set_fp32_split, set_kernel_path, set_split_f16, small_mesh
 
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
@@ -44,11 +44,11 @@ def test_gold_g_std_eps_in_every_kernel_family(path):
         set_kernel_path(old)
 
 
-@pytest.mark.parametrize("split", [0, 1, 2])
+@pytest.mark.parametrize("split", [0, 1, 101], ids=["fp32_mfma", "split_bf16x3", "split_f16x2"])
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
 def test_std_eps_on_a_mesh_large_enough_for_the_persistent_kernels(std_eps_oracle, split, dtype):
-    """22 500 nodes: the persistent fp32-MFMA kernels (split 0), the split path (k_edge_ring / k_edge_split2 + k_node_split), and the
-    bf16 kernels (their own packed LayerNorm)"""
+    """22 500 nodes: the persistent fp32-MFMA kernels (split 0), the split path on three bf16 pieces (k_edge_ring + k_node_split) and on two fp16 pieces
+    (101: k_edge_ring_h + k_node_split_h, the default), and the bf16 kernels (their own packed LayerNorm)"""
     if dtype == "bf16" and split:
         pytest.skip("the split path is an fp32 path")
     cfg = cfg_dict(mps=3)
@@ -59,13 +59,15 @@ def test_std_eps_on_a_mesh_large_enough_for_the_persistent_kernels(std_eps_oracl
     v = rng.standard_normal((N, 128)).astype(np.float32)
     e = rng.standard_normal((E, 128)).astype(np.float32)
     rv, re = orc.processor_steps(ps, cfg, v, e, s, r, 3)
-    old = set_fp32_split(split)
+    old = set_fp32_split(split % 100)
+    oldh = set_split_f16(1 if split == 101 else 0)
     try:
         eng = engine_for(cfg, ln_mode=1, dtype=dtype)
         eng.set_params(ps)
         eng.set_graph(s, r, N)
         v1, e1 = eng.processor_steps(v, e, 3)
     finally:
+        set_split_f16(oldh)
         set_fp32_split(old)
     if dtype == "bf16":
         rl2 = lambda a, b: float(np.linalg.norm(a.astype(np.float64) - b) / np.linalg.norm(b))
