@@ -62,7 +62,7 @@ typedef struct mgn_config {
     int32_t ln_mode;       /* mgn_ln_mode: which LayerNorm GraphNetCore / Lux compute (the sources are not vendored:     */
                            /* julia/spec_probe.jl tells).  MGN_LN_VAR_EPS (0, MGN-spec v1): (x - mean) / sqrt(var + eps);  */
                            /* MGN_LN_STD_EPS: (x - mean) / (sqrt(var) + eps).  eps = 1e-5, biased variance, per row.       */
-                           /* Forward path only: mgn_step / mgn_ode_vjp are written for MGN_LN_VAR_EPS                     */
+                           /* Every entry point follows it, the reverse passes (mgn_step, mgn_forward_vjp, mgn_ode_vjp) included */
     int32_t ln_dims;       /* mgn_ln_dims: MGN_LN_ROWS (0, MGN-spec v1): LayerNorm statistics per node / edge over its L features.   */
                            /* MGN_LN_ALL: over the WHOLE (L x rows) array of an MLP's output -- what Lux 0.5's LayerNorm(shape) computes  */
                            /* when it is left at dims = Colon() (julia/spec_probe.jl tells which one the installed GraphNetCore / Lux    */

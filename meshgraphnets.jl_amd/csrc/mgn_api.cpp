@@ -190,6 +190,22 @@ void pack_chunk_split(uint16_t* dst, const float* W, int ldw, int kbase, bool fr
     pk(dst + 16384, r1.data(), 128, 0);
     pk(dst + 2 * 16384, r2.data(), 128, 0);
 }
+// the same chunk times a power of two as two fp16 pieces, w scale = hi + lo (+ <= 2^-23 relative; split_common.hpp), both round to nearest
+// even (dst: 2 x 16384, the bf16 pieces' fragment order)
+void pack_chunk_split_h(uint16_t* dst, const float* W, int ldw, int kbase, float scale) {
+    for (int sidx = 0; sidx < 8; ++sidx)
+        for (int t = 0; t < 4; ++t)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int j = 0; j < 8; ++j) {
+                    const int hh = lane >> 5, i = lane & 31;
+                    const float ws = W[(size_t)(kbase + bf_feature(sidx, hh, j)) * ldw + 32 * t + i] * scale;
+                    const _Float16 hi = (_Float16)ws;
+                    const _Float16 lo = (_Float16)(ws - (float)hi);
+                    const size_t at = (((size_t)sidx * 4 + t) * 64 + lane) * 8 + j;
+                    memcpy(&dst[at], &hi, 2);
+                    memcpy(&dst[16384 + at], &lo, 2);
+                }
+}
 // the A fragments of v_mfma_f32_16x16x32_bf16 (k_edge_ring16, split.hip): step (ks, ob) = output block ob of k-step ks; lane
 // (r16 = lane & 15, g = lane >> 4) holds output 16 ob + r16, its element j input 16 (2 ks + (j >> 2)) + 4 g + (j & 3) -- the order in
 // which a lane's two accumulator blocks 2 ks, 2 ks + 1 of the layer before hold them
@@ -1183,11 +1199,12 @@ static int upload_inputs(mgn_handle* h, const float* a, int wa, const float* b, 
     const LocalGraph& g = h->g;
     h->in_wa = wa;
     h->in_wb = wb;
-    if (h->cfg.nranks > 1 || g.renumbered) {
+    if (h->cfg.nranks > 1) {
         // a partition needs 1 / nranks of the inputs: gather the owned node rows and the local edge rows on the host and
         // upload those (M-1M on 8 GPUs: 13 MB instead of 108 MB per rank and forward); the encoders then read them in
-        // local order (null gid).  A renumbered single partition (graph_host.h) goes the same way: everything on the device,
-        // the state of a right-hand side included, is in the engine's node order
+        // local order (null gid).  (A renumbered SINGLE partition, graph_host.h, uploads the caller's arrays as they are -- one
+        // contiguous copy each -- and the encoders gather through own_gid / edge_gid on the device: a host gather of 6 M edge rows
+        // costs tens of ms per forward.)
         h->in_local = true;
         const EdgeTopo& t = g.set[0];
         const int Fe = h->cfg.Fe;
@@ -2395,6 +2412,17 @@ int mgn_edge_set_export(mgn_handle* h, int32_t set, int32_t* senders, int32_t* r
         HIPCHK(h, hipMemcpyAsync(receivers, h->es[set].d_rcv.p, (size_t)E * 4, hipMemcpyDefault, h->stream));
     }
     HIPCHK(h, hipStreamSynchronize(h->stream));
+    // every array crosses the boundary in the CALLER's node numbering: a renumbered handle (graph_host.h) holds engine-order ids
+    if (h->g.renumbered && E > 0) {
+        hipPointerAttribute_t at{};
+        const bool dev = hipPointerGetAttributes(&at, senders) == hipSuccess && at.type == hipMemoryTypeDevice;
+        (void)hipGetLastError();
+        if (dev) return fail(h, MGN_E_UNSUPPORTED, "mgn_edge_set_export: device output on a renumbered handle (pass host arrays)");
+        for (int64_t j = 0; j < E; ++j) {
+            senders[j] = h->g.own_gid[(size_t)senders[j]];
+            receivers[j] = h->g.own_gid[(size_t)receivers[j]];
+        }
+    }
     return MGN_OK;
 } MGN_CATCH(h)
 
@@ -2605,6 +2633,10 @@ long long mgn_debug_pack_check(mgn_handle* h) try {
             pack_chunk_bf16(hb.data(), W, jb.ldw, jb.kbase);
             if (hipMemcpy(db.data(), h->wbf.as<uint16_t>() + jb.off, 16384 * 2, hipMemcpyDeviceToHost) != hipSuccess) return -MGN_E_HIP;
             for (size_t i = 0; i < 16384; ++i) bad += hb[i] != db[i];
+        } else if (jb.kind == 4) {
+            pack_chunk_split_h(hb.data(), W, jb.ldw, jb.kbase, jb.scale);
+            if (hipMemcpy(db.data(), h->wsp.as<uint16_t>() + jb.off, 2 * 16384 * 2, hipMemcpyDeviceToHost) != hipSuccess) return -MGN_E_HIP;
+            for (size_t i = 0; i < 2 * 16384; ++i) bad += hb[i] != db[i];
         } else {
             pack_chunk_split(hb.data(), W, jb.ldw, jb.kbase, jb.kind == 2);
             if (hipMemcpy(db.data(), h->wsp.as<uint16_t>() + jb.off, 3 * 16384 * 2, hipMemcpyDeviceToHost) != hipSuccess) return -MGN_E_HIP;

@@ -178,7 +178,8 @@ int pack_training_weights(mgn_engine* h) {
                 pack_tab(tb_ + (size_t)T_BETA * L, p + m.beta, L);
                 b.ggamma = (long)m.gamma; b.gbeta = (long)m.beta;
             }
-            tb_[(size_t)T_LN * L] = 1e-5f;                     // (eps_in, eps_out) = (1e-5, 0): MGN_LN_VAR_EPS, the only mode trained here
+            tb_[(size_t)T_LN * L] = c.ln_mode == MGN_LN_STD_EPS ? 0.f : 1e-5f;         // (eps_in, eps_out) of the LayerNorm variant
+            tb_[(size_t)T_LN * L + 1] = c.ln_mode == MGN_LN_STD_EPS ? 1e-5f : 0.f;     // (frag.hpp: ln_rstd_at; both are trained)
             b.tabs = off;
         }
         return t;
@@ -362,8 +363,6 @@ int train_prepare(mgn_handle* h, const char* who, size_t n_grads) {
     const mgn_config& c = h->cfg;
     if (c.nranks != 1) return fail(h, MGN_E_STATE, "%s drives one partition", who);
     if (c.dtype != MGN_F32) return fail(h, MGN_E_STATE, "%s computes in fp32: create the handle with dtype MGN_F32", who);
-    if (c.ln_mode != MGN_LN_VAR_EPS)
-        return fail(h, MGN_E_UNSUPPORTED, "%s: the reverse pass is written for ln_mode = MGN_LN_VAR_EPS (the forward path has both)", who);
     for (int q = 1; q < h->nsets; ++q)
         if (h->g.set[q].E > 0 && !h->es[q].have_ef)
             return fail(h, MGN_E_STATE, "edge set %d has edges but no features: call mgn_set_edge_features after mgn_set_edge_set", q);

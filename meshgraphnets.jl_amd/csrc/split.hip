@@ -991,7 +991,12 @@ __global__ __launch_bounds__(NWV * 64, NWV / 4) void k_edge_ring_h(const EdgeArg
 #pragma unroll
                 for (int k = 0; k < 16; ++k) acc[t][k] *= cinv;
         }
-        h2_layer_ring<W, 0, 0, STRIDE_PROW, NWV>(acc, y, l1h, l2h, ring, src, nx, lane, tid, x1.s, 0.f, nullptr, prow_ptr(a.P, ix.s, L, h));
+#if defined(MGN_WHATIF_H) && (MGN_WHATIF_H & 4)      // diagnostic builds (wrong results): which memory stream of this kernel costs what
+        const int ps_row = lane & 31;
+#else
+        const int ps_row = ix.s;
+#endif
+        h2_layer_ring<W, 0, 0, STRIDE_PROW, NWV>(acc, y, l1h, l2h, ring, src, nx, lane, tid, x1.s, 0.f, nullptr, prow_ptr(a.P, ps_row, L, h));
         {
             const float c1 = x1.rs * rsw1;
 #pragma unroll
@@ -1010,15 +1015,24 @@ __global__ __launch_bounds__(NWV * 64, NWV / 4) void k_edge_ring_h(const EdgeArg
         zero_frag<NT>(acc);
         CST(4);
         // layer 3: y = layer 2's accumulators in (bias, un-scaling and ReLU in the split), the NEXT tile's e out
-        h2_layer_ring<W, 2, 2, STRIDE_TILE, NWV, true>(acc, y, l3h, l1h, ring, src, nx, lane, tid, x3.s, c2, tb + T_B2 * L + 4 * h,
-                                                      tile_ptr(a.Elat, nxt, L, lane));
+#if defined(MGN_WHATIF_H) && (MGN_WHATIF_H & 16)
+        const f32x4* enext = tile_ptr(a.Elat, a.tile0 + wave, L, lane);
+#else
+        const f32x4* enext = tile_ptr(a.Elat, nxt, L, lane);
+#endif
+        h2_layer_ring<W, 2, 2, STRIDE_TILE, NWV, true>(acc, y, l3h, l1h, ring, src, nx, lane, tid, x3.s, c2, tb + T_B2 * L + 4 * h, enext);
         CST(5);
         EST(1);
         PHASE_FENCE();
         __builtin_amdgcn_s_setprio(MGN_PRIO);
         f32x16 er[NT];               // this tile's e again, for the residual (y holds the next tile's): arrives during the LayerNorm
+#if defined(MGN_WHATIF_H) && (MGN_WHATIF_H & 1)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) er[t] = acc[t];
+#else
         ring_load_e(er, etile);
-        ring_load_e_tail(y, tile_ptr(a.Elat, nxt, L, lane));         // k-steps 6 and 7 of the next tile's e
+#endif
+        ring_load_e_tail(y, enext);                                  // k-steps 6 and 7 of the next tile's e
         {   // bias + un-scaling of layer 3, then LayerNorm: acc = e'
             constexpr float invL = 1.0f / 128;
             const float c3 = x3.rs * rsw3;
@@ -1066,7 +1080,11 @@ __global__ __launch_bounds__(NWV * 64, NWV / 4) void k_edge_ring_h(const EdgeArg
         EST(2);
 #pragma unroll
         for (int t = 0; t < NT; ++t) er[t] += acc[t];                // e <- e + e'
+#if defined(MGN_WHATIF_H) && (MGN_WHATIF_H & 2)
+        if (valid && a.E < 0) ring_store_e(etile, er);
+#else
         if (valid) ring_store_e(etile, er);                          // padding rows / tiles store nothing
+#endif
         CST(7);
         EST(3);
         const int reff = ix.r >= 0 ? r : (-4 - c);
@@ -1094,11 +1112,19 @@ __global__ __launch_bounds__(NWV * 64, NWV / 4) void k_edge_ring_h(const EdgeArg
         const bool sr = (c == 31) && (ix.r_after == reff);
         const bool to_carry = sl || sr;
         f32x4* dst = to_carry ? prow_ptr(a.CARRY, (int64_t)2 * tile + (sl ? 0 : 1), L, h) : tile_ptr(a.AGG, r >> 5, L, 32 * h + (r & 31));
+#if defined(MGN_WHATIF_H) && (MGN_WHATIF_H & 32)
+        if (tail && a.E < 0) store_frag<NT>(dst, to_carry ? STRIDE_PROW : STRIDE_TILE, acc);
+#else
         if (tail) store_frag<NT>(dst, to_carry ? STRIDE_PROW : STRIDE_TILE, acc);
+#endif
         EST(6);
         PHASE_FENCE();
         // turnover: the next tile's layer-1 accumulator starts from Q[r] (P[s] arrives during the layer)
+#if defined(MGN_WHATIF_H) && (MGN_WHATIF_H & 8)
+        load_frag<NT>(acc, prow_ptr(a.Q, lane & 31, L, h), STRIDE_PROW);
+#else
         load_frag<NT>(acc, prow_ptr(a.Q, ixn.r >= 0 ? ixn.r : 0, L, h), STRIDE_PROW);
+#endif
         EST(7);
         ix = ixn;
         tw.tile += tw.stride;

@@ -170,7 +170,11 @@ __global__ __launch_bounds__(64 * WPB) void k_mlp_bwd(const TrainBwdArgs a) {
                 q += d * d;
             }
         q += __shfl_xor(q, 32, 64);
-        const float rstd = 1.0f / sqrtf(q * invL + LN_EPS);
+        // y = d / D, D = sqrt(var + eps_in) + eps_out (the T_LN slot: both LayerNorm variants, frag.hpp ln_rstd_at); dD / dx_i =
+        // d_i / (L sqrt(var + eps_in)), so the xhat term of the pullback carries kappa = D / sqrt(var + eps_in) (1 when eps_out = 0)
+        const float lsq = sqrtf(q * invL + a.tabs[T_LN * L]);
+        const float rstd = 1.0f / (lsq + a.tabs[T_LN * L + 1]);
+        const float kappa = lsq > 0.f ? (lsq + a.tabs[T_LN * L + 1]) / lsq : 1.f;
         tab_frag<NT>(acc, a.tabs + T_GAMMA * L, h);           // acc = gamma
         float m1 = 0.f, m2 = 0.f;
 #pragma unroll
@@ -188,7 +192,7 @@ __global__ __launch_bounds__(64 * WPB) void k_mlp_bwd(const TrainBwdArgs a) {
         m1 += __shfl_xor(m1, 32, 64);
         m2 += __shfl_xor(m2, 32, 64);
         m1 *= invL;
-        m2 *= invL;
+        m2 *= invL * kappa;
         if (rw.valid) store_frag<NT>(row_ptr(a.GXH, rw.row, L, h), STRIDE_ROW, acc);
 #pragma unroll
         for (int t = 0; t < NT; ++t)
@@ -355,7 +359,9 @@ __global__ __launch_bounds__(256, 2) void k_mlp_bwd_coop(const TrainBwdArgs a) {
                     v += d * d;
                 }
             v += __shfl_xor(v, 32, 64);
-            const float rstd = 1.0f / sqrtf(v * invL + LN_EPS);
+            const float lsq = sqrtf(v * invL + a.tabs[T_LN * L]);              // (see k_mlp_bwd)
+            const float rstd = 1.0f / (lsq + a.tabs[T_LN * L + 1]);
+            const float kappa = lsq > 0.f ? (lsq + a.tabs[T_LN * L + 1]) / lsq : 1.f;
             float m1 = 0.f, m2 = 0.f;
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
@@ -375,7 +381,7 @@ __global__ __launch_bounds__(256, 2) void k_mlp_bwd_coop(const TrainBwdArgs a) {
             m1 += __shfl_xor(m1, 32, 64);
             m2 += __shfl_xor(m2, 32, 64);
             m1 *= invL;
-            m2 *= invL;
+            m2 *= invL * kappa;
 #pragma unroll
             for (int t = 0; t < 4; ++t)
 #pragma unroll

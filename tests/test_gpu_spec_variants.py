@@ -89,16 +89,41 @@ def test_small_sizes_and_latent_widths(std_eps_oracle):
         assert rel_max(eng.forward(nf, ef), orc.forward(ps, cfg, nf, ef, s, r)) <= TOL_15, L
 
 
-def test_training_entry_points_refuse_the_variant_and_bad_modes_are_rejected():
+def test_training_under_the_std_eps_variant(std_eps_oracle):
+    """mgn_step, mgn_forward_vjp and mgn_ode_vjp under ln_mode = MGN_LN_STD_EPS: the pullback of y = d / (sqrt(var) + eps) has one more
+    factor than the default's (kappa = (sqrt(var) + eps) / sqrt(var) on the xhat term); against the oracle's reverse mode, which is
+    checked against finite differences in both modes on the CPU (tests/test_oracle_golden.py)."""
+    for L, nx in ((128, 8), (32, 8), (128, 40)):                    # cooperative kernels, L = 32, and the streaming kernels
+        cfg = cfg_dict(L=L, mps=2)
+        pos, s, r = small_mesh(nx, nx - 2)
+        N, E = pos.shape[0], s.size
+        ps = make_params(cfg, jitter=0.1)
+        nf, ef = random_inputs(N, E, cfg, 5)
+        rng = np.random.default_rng(L + nx)
+        target = rng.standard_normal((N, 2)).astype(np.float32)
+        mask = rng.choice(N, N // 2, replace=False).astype(np.int32)
+        eng = engine_for(cfg, ln_mode=1)
+        eng.set_params(ps)
+        eng.set_graph(s, r, N)
+        gs, loss = eng.step(nf, ef, target, mask)
+        g_ref, loss_ref = orc.step_grads(ps, cfg, nf, ef, s, r, target, mask)
+        assert abs(loss - loss_ref) <= 1e-5 * max(1.0, abs(loss_ref)), (L, nx)
+        assert np.linalg.norm(gs - g_ref) <= 2e-4 * np.linalg.norm(g_ref), (L, nx, np.linalg.norm(gs - g_ref) / np.linalg.norm(g_ref))
+        # and it is the other function: the default mode's gradient differs by more than that
+        orc.LN_MODE = 0
+        g_v1, _ = orc.step_grads(ps, cfg, nf, ef, s, r, target, mask)
+        orc.LN_MODE = 1
+        assert np.linalg.norm(g_v1 - g_ref) > 10 * np.linalg.norm(gs - g_ref)
+        ybar = rng.standard_normal((N, 2)).astype(np.float32)
+        nfbar, gps, _ = eng.forward_vjp(nf, ef, ybar)
+        _, gp_ref, nfbar_ref = orc.model_vjp(ps, cfg, nf, ef, s, r, lambda out: ybar.astype(np.float64))
+        assert np.linalg.norm(gps - gp_ref) <= 2e-4 * np.linalg.norm(gp_ref)
+        assert np.linalg.norm(nfbar - nfbar_ref) <= 2e-4 * np.linalg.norm(nfbar_ref)
+        eng.close()
+
+
+def test_bad_modes_are_rejected():
     cfg = cfg_dict(mps=2)
-    pos, s, r = small_mesh()
-    eng = engine_for(cfg, ln_mode=1)
-    eng.set_params(make_params(cfg))
-    eng.set_graph(s, r, pos.shape[0])
-    nf, ef = random_inputs(pos.shape[0], s.size, cfg)
-    with pytest.raises(MgnError) as ei:
-        eng.step(nf, ef, np.zeros((pos.shape[0], 2), np.float32), np.arange(4, dtype=np.int32))
-    assert "ln_mode" in str(ei.value)
     with pytest.raises(MgnError):
         engine_for(cfg, ln_mode=7)
 

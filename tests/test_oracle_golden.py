@@ -76,7 +76,15 @@ def test_oracle_reproduces_gold_c_two_edge_sets():
     assert rel_max(out0, g["out"]) > 1e-3
 
 
-def test_step_grads_match_finite_differences():
+@pytest.fixture(params=[0, 1], ids=["ln_var_eps", "ln_std_eps"])
+def ln_mode(request):
+    """both LayerNorm denominators (DESIGN.md spec_variant): the reverse mode follows orc.LN_MODE"""
+    orc.LN_MODE = request.param
+    yield request.param
+    orc.LN_MODE = 0
+
+
+def test_step_grads_match_finite_differences(ln_mode):
     """The hand-written reverse mode of the oracle (the checker of mgn_step) against central differences of its own
     float64 forward: loss = mean(mse_reduce(target, model(graph))[mask]) (reference src/strategies.jl:418-422)."""
     cfg = dict(Fn=9, Fe=3, O=2, L=32, hidden_layers=2, mps=2)

@@ -15,6 +15,8 @@ f = eng.lib.mgn_debug_edge_stamps; f.restype = C.c_int; f.argtypes = [C.c_void_p
 assert f(eng.h, 1, out.ctypes.data_as(C.c_void_p)) == 0
 st = out[:4 * 8 * 24 * 8].reshape(4, 8, 24, 8).astype(np.int64)
 names = ["L1", "tab", "L2", "tab", "L3", "reload e+LN", "resid+store", "scan+tails+turnover(to next start)"]
+if os.environ.get("MGN_SPLIT_F16", "1") != "0":   # k_edge_ring_h (the default): its stamps
+    names = ["rowmax + Q scale + L1 + P", "rowmax 2", "L2", "bound 3", "L3", "reload e + bias + LN", "resid + store e", "scan+tails+turnover(to next start)"]
 if os.environ.get("MGN_RING_EPI"):      # library built with -DMGN_RING_EPI_STAMPS as well: the epilogue of k_edge_ring in detail
     names = ["chains", "LN", "resid+store e", "next e req + scan setup", "scan", "tail stores", "Q request", "to next tile top"]
 for b in range(2):
