@@ -1195,16 +1195,19 @@ int mgn_boundary_count(const mgn_handle* h, int32_t* n_boundary) try {
 } MGN_CATCH(nullptr)
 
 // ---- staged pipeline ----------------------------------------------------------------------------
-static int upload_inputs(mgn_handle* h, const float* a, int wa, const float* b, int wb, const float* ef) {
+// engine_order: the node rows must sit on the device in the ENGINE's order even on one partition -- the callers that later overwrite
+// the state slot of d_nfA with rows in that order (mgn_set_static + mgn_ode_step(x), mgn_rollout)
+static int upload_inputs(mgn_handle* h, const float* a, int wa, const float* b, int wb, const float* ef, bool engine_order = false) {
     const LocalGraph& g = h->g;
     h->in_wa = wa;
     h->in_wb = wb;
-    if (h->cfg.nranks > 1) {
+    if (h->cfg.nranks > 1 || (engine_order && g.renumbered)) {
         // a partition needs 1 / nranks of the inputs: gather the owned node rows and the local edge rows on the host and
         // upload those (M-1M on 8 GPUs: 13 MB instead of 108 MB per rank and forward); the encoders then read them in
-        // local order (null gid).  (A renumbered SINGLE partition, graph_host.h, uploads the caller's arrays as they are -- one
-        // contiguous copy each -- and the encoders gather through own_gid / edge_gid on the device: a host gather of 6 M edge rows
-        // costs tens of ms per forward.)
+        // local order (null gid).  (A renumbered SINGLE partition, graph_host.h, uploads the caller's arrays as they are for
+        // mgn_forward and the one-shot mgn_ode_step -- one contiguous copy each -- and the encoders gather through own_gid / edge_gid on
+        // the device: a host gather of 6 M edge rows costs tens of ms per forward.  Where the state is kept in the engine's order
+        // (engine_order), it goes the partitions' way.)
         h->in_local = true;
         const EdgeTopo& t = g.set[0];
         const int Fe = h->cfg.Fe;
@@ -1535,7 +1538,7 @@ int mgn_set_static(mgn_handle* h, const float* onehot, const float* ef_raw, cons
     invalidate_static(h);
     {   // static inputs through the common upload (a partitioned handle keeps the rows it owns); the state slot is a placeholder
         std::vector<float> x0((size_t)g.N * c.O, 0.f);
-        if (int rc = upload_inputs(h, x0.data(), c.O, onehot, c.Fn - c.O, ef_raw)) return rc;
+        if (int rc = upload_inputs(h, x0.data(), c.O, onehot, c.Fn - c.O, ef_raw, true)) return rc;
         HIPCHK(h, hipStreamSynchronize(h->stream));
     }
     h->have_mask = val_mask != nullptr;
@@ -1798,7 +1801,7 @@ int mgn_rollout(mgn_handle* h, mgn_rollout_desc* d) try {
         HIPCHK(h, hipStreamSynchronize(h->stream));
     }
     // static inputs: one-hot node types, raw edge features, val_mask; the edge encoder runs ONCE per trajectory
-    if (int rc = upload_inputs(h, d->x0, c.O, d->node_type_onehot, c.Fn - c.O, d->ef_raw)) return rc;
+    if (int rc = upload_inputs(h, d->x0, c.O, d->node_type_onehot, c.Fn - c.O, d->ef_raw, true)) return rc;
     h->have_mask = d->val_mask != nullptr;
     if (d->val_mask) {
         HIPCHK(h, h->d_mask.ensure((size_t)g.N * 4));

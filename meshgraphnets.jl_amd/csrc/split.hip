@@ -795,18 +795,29 @@ __global__ __launch_bounds__(NWV * 64, NWV / 4) void k_edge_ring(const EdgeArgs 
 //   * accumulators start from zero (the first MFMA of a block takes the constant), except layer 1's: Q[r] scaled INTO the
 //     accumulator's units (64 multiplications; P[s] is added by the FMA that un-scales), since nothing has 64 registers for Q.
 // ================================================================================================
+#ifndef MGN_RINGH_AHEAD
+#define MGN_RINGH_AHEAD 2        // windows between a window's request and its first use: 2 (default) = three buffers, stored in the window it is
+#endif                           // requested in (k_edge_ring's scheme); 3 = four buffers, stored one window LATER (below): 2.401 vs 2.408 ms, nothing
 template <int W>
 struct Rh {
     static constexpr int WPL = 32 / W;          // windows per layer
-    static constexpr int NW = 3 * WPL;          // windows per tile (a multiple of 3: window -> buffer is the same for every tile)
+    static constexpr int NW = 3 * WPL;          // windows per tile
+    static constexpr int NB = MGN_RINGH_AHEAD + 1;   // window buffers; NW is a multiple of NB: window -> buffer is the same for every tile
     static constexpr int BUF = W * 64;          // u32x4 elements per window buffer: [step][lane] of the lo piece
+    static_assert(NW % NB == 0 && NW % 2 == 0, "static window -> buffer / slot mapping");
 };
+// s_waitcnt vmcnt retires in order: the LDS store of a window waits for its request AND for every older load -- the refill requests of
+// the window before (the next tile's e, straight from HBM), which then have 7 .. 13 steps to come back before they stall the chain
+// (stamps: the layers with a refill take twice the cycles of layer 2).  AHEAD = 3: a window is requested THREE windows ahead and
+// stored in the window AFTER the one it was requested in (two requests in flight per thread, four buffers): the refills get 15 .. 21 steps.
+// Measured: no difference -- what the refills cost is their issue into a memory pipeline that is still draining the tile's stores.
+template <int LPT> struct RhPend { u32x4 v[2][LPT]; };
 struct RhFrag {
     u32x4 h, l;                                 // fragments of the next step (read one step ahead)
 };
 template <int W, int LYR>
 DEVINL RhFrag rh_first(const u32x4* hi, const u32x4* ring, int lane) {
-    constexpr int b = (Rh<W>::WPL * LYR) % 3;
+    constexpr int b = (Rh<W>::WPL * LYR) % Rh<W>::NB;
     RhFrag f;
     f.h = hi[lane];
     f.l = ring[b * Rh<W>::BUF];
@@ -820,10 +831,10 @@ struct RhSrc {
 // rotation, the last two k-steps' pieces are the caller's).
 template <int W, int LYR, int FIN, int RFS = 0, int NWV = 8, bool WRAP = false>
 DEVINL void h2_layer_ring(f32x16 (&acc)[4], f32x16 (&in)[4], const u32x4* hi, const u32x4* hi_next, u32x4* ring, const RhSrc& src,
-                          RhFrag& nx, int lane, int tid, float sx, float cfin = 0.f, const float* btab = nullptr,
+                          RhFrag& nx, RhPend<W / NWV>& pend, int lane, int tid, float sx, float cfin = 0.f, const float* btab = nullptr,
                           const f32x4* rf = nullptr) {
     constexpr int ROT = 2;
-    constexpr int WPL = Rh<W>::WPL, NW = Rh<W>::NW, BUF = Rh<W>::BUF;
+    constexpr int WPL = Rh<W>::WPL, NW = Rh<W>::NW, BUF = Rh<W>::BUF, NB = Rh<W>::NB, AHEAD = MGN_RINGH_AHEAD;
     f32x4 side[2 * ROT];
     if constexpr (!WRAP && RFS > 0) {
 #pragma unroll
@@ -842,7 +853,6 @@ DEVINL void h2_layer_ring(f32x16 (&acc)[4], f32x16 (&in)[4], const u32x4* hi, co
         h2_split_pair<FIN>(ph[u], pl[u], in[0][2 * u], in[0][2 * u + 1], sx, cfin, b[0], b[1]);
     }
     constexpr int LPT = W / NWV;                 // fragments per thread in a window (NWV waves share the loading)
-    u32x4 ld_l[LPT];
     unsigned voff = (unsigned)tid * 16u;
     asm volatile("" : "+v"(voff));
     __builtin_amdgcn_sched_barrier(0);
@@ -854,11 +864,11 @@ DEVINL void h2_layer_ring(f32x16 (&acc)[4], f32x16 (&in)[4], const u32x4* hi, co
             const int it = 4 * s + t;
             const int gw = WPL * LYR + it / W;                        // global window of this step
             const u32x4 a1 = nx.h, a2 = nx.l;
-            if (it % W == 0) {                                         // request window gw + 2
-                const int g2 = (gw + 2) % NW, l2 = g2 / WPL, w2 = g2 % WPL;
+            if (it % W == 0) {                                         // request window gw + AHEAD
+                const int g2 = (gw + AHEAD) % NW, l2 = g2 / WPL, w2 = g2 % WPL;
 #pragma unroll
                 for (int i = 0; i < LPT; ++i)
-                    ld_l[i] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(src.lo[l2] + w2 * W * 64 + i * NWV * 64) + voff);
+                    pend.v[gw % 2][i] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(src.lo[l2] + w2 * W * 64 + i * NWV * 64) + voff);
             }
             if constexpr (RFS > 0) {
                 if ((t & 1) && s < 8 - ROT) {                          // registers of k-step s (free since the step began), half t >> 1
@@ -870,14 +880,15 @@ DEVINL void h2_layer_ring(f32x16 (&acc)[4], f32x16 (&in)[4], const u32x4* hi, co
             if (it + 1 < 32) {
                 const int gn = WPL * LYR + (it + 1) / W;
                 nx.h = hi[(it + 1) * 64 + lane];
-                nx.l = ring[(gn % 3) * BUF + ((it + 1) % W) * 64];
+                nx.l = ring[(gn % NB) * BUF + ((it + 1) % W) * 64];
             } else if (LYR < 2) {
                 nx = rh_first<W, (LYR + 1) % 3>(hi_next, ring, lane);   // (that window was written two windows ago)
             }
-            if (it % W == W - 2) {                                     // ... and store it: its buffer was last read in window gw - 1
-                const int b2 = (gw + 2) % 3;
+            if (it % W == W - 2) {                                     // store window gw + 2 (AHEAD 3: requested in window gw - 1): its buffer was
+                const int b2 = (gw + 2) % NB;                          // last read as window gw + 2 - NB
+                const int slot = AHEAD == 2 ? gw % 2 : (gw + 1) % 2;
 #pragma unroll
-                for (int i = 0; i < LPT; ++i) ring[b2 * BUF + i * NWV * 64 + tid - lane] = ld_l[i];
+                for (int i = 0; i < LPT; ++i) ring[b2 * BUF + i * NWV * 64 + tid - lane] = pend.v[slot][i];
             }
             if (s < 7) {
                 const int sn = s + 1;
@@ -912,6 +923,9 @@ DEVINL void h2_layer_ring(f32x16 (&acc)[4], f32x16 (&in)[4], const u32x4* hi, co
 #ifndef MGN_RINGH_PHASE_UNITS
 #define MGN_RINGH_PHASE_UNITS 6     // half a period of k_edge_ring_h in 4 096-cycle units (k_edge_ring: 10)
 #endif
+#ifndef MGN_RINGH_ESTORE_LAST
+#define MGN_RINGH_ESTORE_LAST 0   // (1 spills 64 registers in the epilogue: not run) 1: this tile's e stores behind the next tile's Q request (0: right behind the residual, k_edge_ring's order)
+#endif
 #ifndef MGN_RINGH_W
 #define MGN_RINGH_W 8            // steps per window of k_edge_ring_h (8: 12 barriers per tile; 16: 6)
 #endif
@@ -929,9 +943,10 @@ __global__ __launch_bounds__(NWV * 64, NWV / 4) void k_edge_ring_h(const EdgeArg
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int tid = (int)threadIdx.x;
     u32x4* ringbase = reinterpret_cast<u32x4*>(wl + 3 * PC);                    // three window buffers
-    float* tb = reinterpret_cast<float*>(ringbase + 3 * BUF);
+    float* tb = reinterpret_cast<float*>(ringbase + Rh<W>::NB * BUF);
     copy_to_lds(tb, a.tabs, T_COUNT * L);
     RhSrc src;
+    RhPend<W / NWV> pend;
     {
         const u32x4* g[3] = {reinterpret_cast<const u32x4*>(a.splith[2]), reinterpret_cast<const u32x4*>(a.splith[0]),
                              reinterpret_cast<const u32x4*>(a.splith[1])};
@@ -941,6 +956,11 @@ __global__ __launch_bounds__(NWV * 64, NWV / 4) void k_edge_ring_h(const EdgeArg
         for (int w = 0; w < 2; ++w)                                   // windows 0 and 1 of layer 1
 #pragma unroll
             for (int i = 0; i < W / NWV; ++i) ringbase[w * BUF + i * NWV * 64 + tid] = src.lo[0][w * W * 64 + i * NWV * 64 + tid];
+#pragma unroll
+        for (int i = 0; i < W / NWV; ++i) {                           // AHEAD 3: window 2 waits in the slot that window 0 stores from
+            pend.v[1][i] = src.lo[(2 * W) / 32][((2 * W) % 32) * 64 + i * NWV * 64 + tid];
+            pend.v[0][i] = pend.v[1][i];
+        }
     }
     __syncthreads();
     const u32x4* l1h = reinterpret_cast<const u32x4*>(wl);
@@ -996,7 +1016,7 @@ __global__ __launch_bounds__(NWV * 64, NWV / 4) void k_edge_ring_h(const EdgeArg
 #else
         const int ps_row = ix.s;
 #endif
-        h2_layer_ring<W, 0, 0, STRIDE_PROW, NWV>(acc, y, l1h, l2h, ring, src, nx, lane, tid, x1.s, 0.f, nullptr, prow_ptr(a.P, ps_row, L, h));
+        h2_layer_ring<W, 0, 0, STRIDE_PROW, NWV>(acc, y, l1h, l2h, ring, src, nx, pend, lane, tid, x1.s, 0.f, nullptr, prow_ptr(a.P, ps_row, L, h));
         {
             const float c1 = x1.rs * rsw1;
 #pragma unroll
@@ -1008,7 +1028,7 @@ __global__ __launch_bounds__(NWV * 64, NWV / 4) void k_edge_ring_h(const EdgeArg
         const H2Scale x2 = h2_scale(h2_rowmax<false>(acc));
         zero_frag<NT>(y);
         CST(2);
-        h2_layer_ring<W, 1, 1, 0, NWV>(y, acc, l2h, l3h, ring, src, nx, lane, tid, x2.s);   // layer 2 (ReLU folded into the split)
+        h2_layer_ring<W, 1, 1, 0, NWV>(y, acc, l2h, l3h, ring, src, nx, pend, lane, tid, x2.s);   // layer 2 (ReLU folded into the split)
         CST(3);
         const float c2 = x2.rs * rsw2;
         const H2Scale x3 = h2_scale(__builtin_fmaf(h2_rowmax<false>(y), c2, b2pos));
@@ -1020,7 +1040,7 @@ __global__ __launch_bounds__(NWV * 64, NWV / 4) void k_edge_ring_h(const EdgeArg
 #else
         const f32x4* enext = tile_ptr(a.Elat, nxt, L, lane);
 #endif
-        h2_layer_ring<W, 2, 2, STRIDE_TILE, NWV, true>(acc, y, l3h, l1h, ring, src, nx, lane, tid, x3.s, c2, tb + T_B2 * L + 4 * h, enext);
+        h2_layer_ring<W, 2, 2, STRIDE_TILE, NWV, true>(acc, y, l3h, l1h, ring, src, nx, pend, lane, tid, x3.s, c2, tb + T_B2 * L + 4 * h, enext);
         CST(5);
         EST(1);
         PHASE_FENCE();
@@ -1080,10 +1100,12 @@ __global__ __launch_bounds__(NWV * 64, NWV / 4) void k_edge_ring_h(const EdgeArg
         EST(2);
 #pragma unroll
         for (int t = 0; t < NT; ++t) er[t] += acc[t];                // e <- e + e'
+#if !MGN_RINGH_ESTORE_LAST
 #if defined(MGN_WHATIF_H) && (MGN_WHATIF_H & 2)
         if (valid && a.E < 0) ring_store_e(etile, er);
 #else
         if (valid) ring_store_e(etile, er);                          // padding rows / tiles store nothing
+#endif
 #endif
         CST(7);
         EST(3);
@@ -1120,10 +1142,22 @@ __global__ __launch_bounds__(NWV * 64, NWV / 4) void k_edge_ring_h(const EdgeArg
         EST(6);
         PHASE_FENCE();
         // turnover: the next tile's layer-1 accumulator starts from Q[r] (P[s] arrives during the layer)
-#if defined(MGN_WHATIF_H) && (MGN_WHATIF_H & 8)
+#if defined(MGN_WHATIF_H) && (MGN_WHATIF_H & 64)
+        zero_frag<NT>(acc);                                          // (no Q request at all: what the wait for it behind the stores costs)
+#elif defined(MGN_WHATIF_H) && (MGN_WHATIF_H & 8)
         load_frag<NT>(acc, prow_ptr(a.Q, lane & 31, L, h), STRIDE_PROW);
 #else
         load_frag<NT>(acc, prow_ptr(a.Q, ixn.r >= 0 ? ixn.r : 0, L, h), STRIDE_PROW);
+#endif
+#if MGN_RINGH_ESTORE_LAST
+        // the e stores LAST: s_waitcnt vmcnt retires in order and counts stores, so everything the next tile waits for first (its Q rows)
+        // is requested ahead of them; they drain under the next tile's layer 1
+        PHASE_FENCE();
+#if defined(MGN_WHATIF_H) && (MGN_WHATIF_H & 2)
+        if (valid && a.E < 0) ring_store_e(etile, er);
+#else
+        if (valid) ring_store_e(etile, er);                          // padding rows / tiles store nothing
+#endif
 #endif
         EST(7);
         ix = ixn;
@@ -2078,7 +2112,7 @@ hipError_t launch_edge_ring_h(const EdgeArgs& a, const LaunchCfg& lc, hipStream_
     if (lc.threads == 256) return sp_launch(k_edge_ring_h<4>, a, lc, s, attr_set4);
     return sp_launch(k_edge_ring_h<8>, a, lc, s, attr_set8);
 }
-size_t edge_ring_h_lds() { return (size_t)3 * 32768 + (size_t)3 * Rh<MGN_RINGH_W>::BUF * 16 + (size_t)T_COUNT * 128 * 4 + 64; }
+size_t edge_ring_h_lds() { return (size_t)3 * 32768 + (size_t)Rh<MGN_RINGH_W>::NB * Rh<MGN_RINGH_W>::BUF * 16 + (size_t)T_COUNT * 128 * 4 + 64; }
 hipError_t launch_edge_ring16(const EdgeArgs& a, const LaunchCfg& lc, hipStream_t s) {
     static bool attr_set8 = false, attr_set4 = false;
     if (lc.threads == 256) return sp_launch(k_edge_ring16<4>, a, lc, s, attr_set4);

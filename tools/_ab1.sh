@@ -1,2 +1,3 @@
 cd $GRAFT_REPO_ROOT
-python tools/ab.py default wh1 wh2 wh4 wh8 wh16 wh32 wh12 wh3 wh63 --rounds 2 2>&1 | tail -12
+python -m pytest tests/test_gpu_fp32_split.py tests/test_gpu_renumber.py -x -q 2>&1 | tail -4
+python tools/ab.py default ahead2 --rounds 3 2>&1 | tail -6
