@@ -133,7 +133,7 @@ struct mgn_engine {
     DevBuf wsp;
     struct SplitOff { size_t e_ch[MAX_EDGE_SETS][3], e16_ch[MAX_EDGE_SETS][3]; size_t n_ch[6], n2_ch[3], n16_ch[9]; bool have_n;
                       // two fp16 pieces (kind 4 of WPackJob): offsets, the power of two each chunk was multiplied by, max(0, max b2)
-                      size_t eh_ch[MAX_EDGE_SETS][3], nh_ch[6]; float eh_s[MAX_EDGE_SETS][3], nh_s[6], e_b2pos[MAX_EDGE_SETS], n_b2pos; bool have_h; };   // n2_ch (two edge sets): W1[2L:3L], WP / WQ of set 1
+                      size_t eh_ch[MAX_EDGE_SETS][3], nh_ch[6], e16h_ch[MAX_EDGE_SETS][3], n16h_ch[9]; float eh_s[MAX_EDGE_SETS][3], nh_s[9], e_b2pos[MAX_EDGE_SETS], n_b2pos; bool have_h; };   // n2_ch (two edge sets): W1[2L:3L], WP / WQ of set 1
     std::vector<SplitOff> spoff;
     // static per-trajectory RHS inputs (mgn_set_static): cached encoded edge latents
     bool have_static = false;

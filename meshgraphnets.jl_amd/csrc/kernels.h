@@ -55,6 +55,7 @@ struct EdgeArgs {
     // two-piece fp16 form of the same chunks (k_edge_ring_h; split_common.hpp): chunk i times the power of two h2_s[i] as 2 x 16384 fp16
     // (hi, lo; the bf16 pieces' fragment order), h2_rs[i] = 1 / h2_s[i]; h2_b2pos = max(0, max_k b2[k]); null: not available
     const uint16_t* splith[3];
+    const uint16_t* split16h[3];  // ... and in the 16x16x32 fragment order (k_edge_coop16m<.., 2>), the same scales
     float h2_s[3], h2_rs[3], h2_b2pos;
 };
 
@@ -88,7 +89,8 @@ struct NodeArgs {
     const uint16_t* split16[9];   // chunk[0..8] as pieces in the 16x16x32 fragment order (k_node_coop16 on the split path); null: not available
     // chunk[0..5] as two fp16 pieces times h2_s[i] (k_node_split_h, k_project_split_h; see EdgeArgs.splith); h2_b2pos = max(0, max_k b2[k])
     const uint16_t* splith[6];
-    float h2_s[6], h2_rs[6], h2_b2pos;
+    const uint16_t* split16h[9];  // chunk[0..8] in the 16x16x32 fragment order (k_node_coop16<.., 2>), scales h2_s[0..8]
+    float h2_s[9], h2_rs[9], h2_b2pos;
 };
 
 struct EncNodeArgs {

@@ -696,129 +696,174 @@ DEVINL void c16m_layer_norm(f32x4 (&mine)[RT][2], float* red, const f32x4 (&g)[2
 // fp32 kernels' (lane (n, q): features 16 ob + 4 q + i of row n), and k-step ks of the next layer takes blocks 2 ks, 2 ks + 1 -- exactly
 // the two blocks wave ks owns: a wave splits ITS slice (ReLU folded in) and the four waves exchange PIECES through LDS (12 KiB per tile
 // instead of 8, no redundant split).  Weight pieces: EdgeArgs / NodeArgs::split16 (mgn_api.cpp: pack_chunk16_bf16, [ks][ob][lane][8 bf16]).
-struct C16P { u32x4 h, m, l; };            // one k-step's B operand of a 16-row tile
+// SP = 2 (round 5, the default where the split path is on): TWO fp16 pieces and three piece products (split_common.hpp) -- 24 RT MFMAs per chunk
+// and wave.  A row's 128 features are spread over the four waves here, so the power-of-two scale is per (row, k-step): the wave that
+// owns a k-step's 32 features takes their maximum (two lane swaps), publishes 1 / scale beside the pieces, and the consumer un-scales every
+// k-step's partial sum as it adds it -- acc = fma(partial, rs_row x rs_chunk, acc): the accumulators stay in true units, so bias
+// initialisation, LayerNorm and everything else around the chains is the three-piece kernels' code.
+template <int NP> struct C16X { u32x4 p[NP]; float rs; };      // one k-step's B operand of a 16-row tile: its pieces (hi first), 1 / its row scale (NP = 2)
+typedef C16X<3> C16P;
+// largest magnitude (RELU: largest value, at least 0) of a row's 32 features held by this wave: 8 values per lane, lanes n, n + 16, n + 32, n + 48
 template <bool RELU>
-DEVINL C16P c16s_split(const f32x4 (&mine)[2]) {
-    C16P p;
+DEVINL float c16h_rowmax(const f32x4 (&mine)[2]) {
+    float m = 0.f;
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-        unsigned h, m, l;
-        sp_split_pair<RELU>(h, m, l, mine[u >> 1][2 * (u & 1)], mine[u >> 1][2 * (u & 1) + 1]);
-        p.h[u] = h; p.m[u] = m; p.l[u] = l;
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; i += 2) {
+            const float a = RELU ? mine[j][i] : __builtin_fabsf(mine[j][i]), b = RELU ? mine[j][i + 1] : __builtin_fabsf(mine[j][i + 1]);
+            m = __builtin_fmaxf(m, __builtin_fmaxf(a, b));
+        }
+    m = __builtin_fmaxf(m, __shfl_xor(m, 16, 64));
+    return __builtin_fmaxf(m, __shfl_xor(m, 32, 64));
+}
+template <bool RELU, int NP>
+DEVINL C16X<NP> c16s_split(const f32x4 (&mine)[2]) {
+    C16X<NP> p;
+    if constexpr (NP == 3) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            unsigned h, m, l;
+            sp_split_pair<RELU>(h, m, l, mine[u >> 1][2 * (u & 1)], mine[u >> 1][2 * (u & 1) + 1]);
+            p.p[0][u] = h; p.p[1][u] = m; p.p[2][u] = l;
+        }
+        p.rs = 1.f;
+    } else {
+        const H2Scale sc = h2_scale(c16h_rowmax<RELU>(mine));
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            unsigned h, l;
+            h2_split_pair<RELU ? 1 : 0>(h, l, mine[u >> 1][2 * (u & 1)], mine[u >> 1][2 * (u & 1) + 1], sc.s);
+            p.p[0][u] = h; p.p[1][u] = l;
+        }
+        p.rs = sc.rs;
     }
     return p;
 }
-template <int RT, bool RELU>
-DEVINL void c16s_exchange(C16P (&full)[RT][4], const f32x4 (&mine)[RT][2], u32x4* xch, int wave, int lane) {
+// exchange buffer of RT tiles: [tile][k-step = wave][piece][lane] 16-byte slots, then (NP = 2) [tile][k-step][row] floats of 1 / scale
+template <int RT, int NP> DEVINL float* c16s_scales(u32x4* xch) { return reinterpret_cast<float*>(xch + RT * 4 * NP * 64); }
+template <int RT, int NP> DEVINL const float* c16s_scales(const u32x4* xch) { return reinterpret_cast<const float*>(xch + RT * 4 * NP * 64); }
+template <int RT, bool RELU, int NP>
+DEVINL void c16s_publish(const f32x4 (&mine)[RT][2], u32x4* xch, int wave, int lane) {
 #pragma unroll
     for (int t = 0; t < RT; ++t) {
-        const C16P p = c16s_split<RELU>(mine[t]);
-        xch[((t * 4 + wave) * 3 + 0) * 64 + lane] = p.h;
-        xch[((t * 4 + wave) * 3 + 1) * 64 + lane] = p.m;
-        xch[((t * 4 + wave) * 3 + 2) * 64 + lane] = p.l;
+        const C16X<NP> p = c16s_split<RELU, NP>(mine[t]);
+#pragma unroll
+        for (int pc = 0; pc < NP; ++pc) xch[((t * 4 + wave) * NP + pc) * 64 + lane] = p.p[pc];
+        if constexpr (NP == 2) c16s_scales<RT, NP>(xch)[(t * 4 + wave) * 16 + (lane & 15)] = p.rs;      // (the four lane groups write the same value)
     }
     __syncthreads();
+}
+template <int RT, int NP>
+DEVINL void c16s_fetch(C16X<NP> (&x)[RT], const u32x4* xch, int ks, int lane) {      // the pieces of k-step ks of every tile
 #pragma unroll
-    for (int t = 0; t < RT; ++t)
+    for (int t = 0; t < RT; ++t) {
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            full[t][ks].h = xch[((t * 4 + ks) * 3 + 0) * 64 + lane];
-            full[t][ks].m = xch[((t * 4 + ks) * 3 + 1) * 64 + lane];
-            full[t][ks].l = xch[((t * 4 + ks) * 3 + 2) * 64 + lane];
-        }
+        for (int pc = 0; pc < NP; ++pc) x[t].p[pc] = xch[((t * 4 + ks) * NP + pc) * 64 + lane];
+        x[t].rs = NP == 2 ? c16s_scales<RT, NP>(xch)[(t * 4 + ks) * 16 + (lane & 15)] : 1.f;
+    }
+}
+template <int RT, bool RELU, int NP>
+DEVINL void c16s_exchange(C16X<NP> (&full)[RT][4], const f32x4 (&mine)[RT][2], u32x4* xch, int wave, int lane) {
+    c16s_publish<RT, RELU, NP>(mine, xch, wave, lane);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        C16X<NP> x[RT];
+        c16s_fetch<RT, NP>(x, xch, ks, lane);
+#pragma unroll
+        for (int t = 0; t < RT; ++t) full[t][ks] = x[t];
+    }
 }
 // the weight pieces of a chunk stream from L2 through a register ring C16S_PF (k-step, block) steps deep; step s = 2 ks + j feeds
 // this wave's output block 2 wave + j
 #ifndef C16S_PF
 #define C16S_PF 3
 #endif
-struct C16SRing { u32x4 r[3 * C16S_PF]; };
+template <int NP> struct C16SRingT { u32x4 r[NP * C16S_PF]; };
 DEVINL const u32x4* c16s_w(const uint16_t* chunk, int wave, int lane) { return reinterpret_cast<const u32x4*>(chunk) + (2 * wave) * 64 + lane; }
-DEVINL void c16s_prime(C16SRing& g, const u32x4* wv) {
+template <int NP>
+DEVINL void c16s_prime(C16SRingT<NP>& g, const u32x4* wv) {
 #pragma unroll
     for (int s = 0; s < C16S_PF; ++s)
 #pragma unroll
-        for (int pc = 0; pc < 3; ++pc) g.r[3 * s + pc] = wv[pc * 2048 + ((s >> 1) * 8 + (s & 1)) * 64];
+        for (int pc = 0; pc < NP; ++pc) g.r[NP * s + pc] = wv[pc * 2048 + ((s >> 1) * 8 + (s & 1)) * 64];
 }
-template <int RT, int S0 = 0, int S1 = 8>
-DEVINL void c16s_chain(f32x4 (&acc)[RT][2], const C16P (&x)[RT][4], const u32x4* wv, C16SRing& g) {
+// one (k-step, block) step of RT tiles: six bf16 products into the accumulator, or three fp16 products into a partial sum that is
+// un-scaled (c = 1 / (row scale x chunk scale)) as it is added
+template <int RT, int NP>
+DEVINL void c16s_step(f32x4 (&acc)[RT][2], const C16X<NP> (&x)[RT], int j, const u32x4 (&a)[NP], float rsw) {
+#pragma unroll
+    for (int t = 0; t < RT; ++t) {
+        if constexpr (NP == 3) {
+            const sp_bf16x8 bh = sp_wop(x[t].p[0]), bm = sp_wop(x[t].p[1]), bl = sp_wop(x[t].p[2]);
+            acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(sp_wop(a[2]), bh, acc[t][j], 0, 0, 0);      // small terms first
+            acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(sp_wop(a[1]), bm, acc[t][j], 0, 0, 0);
+            acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(sp_wop(a[0]), bl, acc[t][j], 0, 0, 0);
+            acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(sp_wop(a[1]), bh, acc[t][j], 0, 0, 0);
+            acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(sp_wop(a[0]), bm, acc[t][j], 0, 0, 0);
+            acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(sp_wop(a[0]), bh, acc[t][j], 0, 0, 0);
+        } else {
+            const sp_f16x8 bh = h2_wop(x[t].p[0]), bl = h2_wop(x[t].p[1]);
+            f32x4 part = {0.f, 0.f, 0.f, 0.f};
+            part = __builtin_amdgcn_mfma_f32_16x16x32_f16(h2_wop(a[1]), bh, part, 0, 0, 0);
+            part = __builtin_amdgcn_mfma_f32_16x16x32_f16(h2_wop(a[0]), bl, part, 0, 0, 0);
+            part = __builtin_amdgcn_mfma_f32_16x16x32_f16(h2_wop(a[0]), bh, part, 0, 0, 0);
+            const float c = x[t].rs * rsw;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[t][j][i] = __builtin_fmaf(part[i], c, acc[t][j][i]);
+        }
+    }
+}
+template <int RT, int S0 = 0, int S1 = 8, int NP = 3>
+DEVINL void c16s_chain(f32x4 (&acc)[RT][2], const C16X<NP> (&x)[RT][4], const u32x4* wv, C16SRingT<NP>& g, float rsw = 1.f) {
 #pragma unroll
     for (int s = S0; s < S1; ++s) {
-        const u32x4 a1 = g.r[3 * (s % C16S_PF)], a2 = g.r[3 * (s % C16S_PF) + 1], a3 = g.r[3 * (s % C16S_PF) + 2];
+        u32x4 a[NP];
+#pragma unroll
+        for (int pc = 0; pc < NP; ++pc) a[pc] = g.r[NP * (s % C16S_PF) + pc];
         if (s + C16S_PF < 8) {
             const int sn = s + C16S_PF;
 #pragma unroll
-            for (int pc = 0; pc < 3; ++pc) g.r[3 * (s % C16S_PF) + pc] = wv[pc * 2048 + ((sn >> 1) * 8 + (sn & 1)) * 64];
+            for (int pc = 0; pc < NP; ++pc) g.r[NP * (s % C16S_PF) + pc] = wv[pc * 2048 + ((sn >> 1) * 8 + (sn & 1)) * 64];
         }
         __builtin_amdgcn_sched_barrier(0);
         const int ks = s >> 1, j = s & 1;
+        C16X<NP> xk[RT];
 #pragma unroll
-        for (int t = 0; t < RT; ++t) {
-            const sp_bf16x8 bh = sp_wop(x[t][ks].h), bm = sp_wop(x[t][ks].m), bl = sp_wop(x[t][ks].l);
-            acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(sp_wop(a3), bh, acc[t][j], 0, 0, 0);      // small terms first
-            acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(sp_wop(a2), bm, acc[t][j], 0, 0, 0);
-            acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(sp_wop(a1), bl, acc[t][j], 0, 0, 0);
-            acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(sp_wop(a2), bh, acc[t][j], 0, 0, 0);
-            acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(sp_wop(a1), bm, acc[t][j], 0, 0, 0);
-            acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(sp_wop(a1), bh, acc[t][j], 0, 0, 0);
-        }
+        for (int t = 0; t < RT; ++t) xk[t] = x[t][ks];
+        c16s_step<RT, NP>(acc, xk, j, a, rsw);
         __builtin_amdgcn_sched_barrier(0);
     }
 }
 
 // four to six row tiles per block: the pieces of all tiles do not fit the registers (48 per tile) -- the exchange only publishes, and the
 // chain reads the pieces of ONE k-step at a time from the exchange buffer (12 registers per tile)
-template <int RT, bool RELU>
-DEVINL void c16s_publish(const f32x4 (&mine)[RT][2], u32x4* xch, int wave, int lane) {
-#pragma unroll
-    for (int t = 0; t < RT; ++t) {
-        const C16P p = c16s_split<RELU>(mine[t]);
-        xch[((t * 4 + wave) * 3 + 0) * 64 + lane] = p.h;
-        xch[((t * 4 + wave) * 3 + 1) * 64 + lane] = p.m;
-        xch[((t * 4 + wave) * 3 + 2) * 64 + lane] = p.l;
-    }
-    __syncthreads();
-}
-template <int RT, int S0 = 0, int S1 = 8>
-DEVINL void c16s_chain_lds(f32x4 (&acc)[RT][2], const u32x4* xch, int lane, const u32x4* wv, C16SRing& g) {
-    C16P x[RT];
+template <int RT, int S0 = 0, int S1 = 8, int NP = 3>
+DEVINL void c16s_chain_lds(f32x4 (&acc)[RT][2], const u32x4* xch, int lane, const u32x4* wv, C16SRingT<NP>& g, float rsw = 1.f) {
+    C16X<NP> x[RT];
 #pragma unroll
     for (int s = S0; s < S1; ++s) {
         const int ks = s >> 1, j = s & 1;
-        if (j == 0 || s == S0) {
+        if (j == 0 || s == S0) c16s_fetch<RT, NP>(x, xch, ks, lane);
+        u32x4 a[NP];
 #pragma unroll
-            for (int t = 0; t < RT; ++t) {
-                x[t].h = xch[((t * 4 + ks) * 3 + 0) * 64 + lane];
-                x[t].m = xch[((t * 4 + ks) * 3 + 1) * 64 + lane];
-                x[t].l = xch[((t * 4 + ks) * 3 + 2) * 64 + lane];
-            }
-        }
-        const u32x4 a1 = g.r[3 * (s % C16S_PF)], a2 = g.r[3 * (s % C16S_PF) + 1], a3 = g.r[3 * (s % C16S_PF) + 2];
+        for (int pc = 0; pc < NP; ++pc) a[pc] = g.r[NP * (s % C16S_PF) + pc];
         if (s + C16S_PF < 8) {
             const int sn = s + C16S_PF;
 #pragma unroll
-            for (int pc = 0; pc < 3; ++pc) g.r[3 * (s % C16S_PF) + pc] = wv[pc * 2048 + ((sn >> 1) * 8 + (sn & 1)) * 64];
+            for (int pc = 0; pc < NP; ++pc) g.r[NP * (s % C16S_PF) + pc] = wv[pc * 2048 + ((sn >> 1) * 8 + (sn & 1)) * 64];
         }
         __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int t = 0; t < RT; ++t) {
-            const sp_bf16x8 bh = sp_wop(x[t].h), bm = sp_wop(x[t].m), bl = sp_wop(x[t].l);
-            acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(sp_wop(a3), bh, acc[t][j], 0, 0, 0);
-            acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(sp_wop(a2), bm, acc[t][j], 0, 0, 0);
-            acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(sp_wop(a1), bl, acc[t][j], 0, 0, 0);
-            acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(sp_wop(a2), bh, acc[t][j], 0, 0, 0);
-            acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(sp_wop(a1), bm, acc[t][j], 0, 0, 0);
-            acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(sp_wop(a1), bh, acc[t][j], 0, 0, 0);
-        }
+        c16s_step<RT, NP>(acc, x, j, a, rsw);
         __builtin_amdgcn_sched_barrier(0);
     }
 }
-
-template <int RT, bool BF, bool SP = false>
+template <int RT, bool BF, int SP = 0>      // SP: 0 fp32 MFMA pipe, 1 three bf16 pieces, 2 two fp16 pieces
 __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_edge_coop16m(const EdgeArgs a) {
     constexpr int L = 128;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr int XCH = SP ? RT * 12 * 64 : RT * 8 * 64;            // 16-byte slots of one exchange buffer (SP: pieces, 12 KiB per tile)
+    constexpr int NP = SP == 2 ? 2 : 3;                             // pieces per operand on the split path
+    constexpr int XCH = SP ? RT * 4 * NP * 64 + (SP == 2 ? RT * 16 : 0) : RT * 8 * 64;   // 16-byte slots of one exchange buffer (SP: pieces, then 1 / scale per (tile, k-step, row))
     f32x4* xch0 = reinterpret_cast<f32x4*>(smem);
     f32x4* xch1 = xch0 + XCH;
     float* red = reinterpret_cast<float*>(xch1 + XCH);              // LayerNorm partials: 2 x [RT][4 waves][16 rows]
@@ -836,9 +881,11 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
         int lane = lane0;
         asm volatile("" : "+v"(lane));      // keeps the (loop-invariant) weight and table loads inside the loop: hoisted, they spill
         const int n = lane & 15, q = lane >> 4;
-        const u32x4* s1 = SP ? c16s_w(a.split16[2], wave, lane) : nullptr;      // (lane folded in: the ring requests are this + constants)
-        const u32x4* s2 = SP ? c16s_w(a.split16[0], wave, lane) : nullptr;
-        const u32x4* s3 = SP ? c16s_w(a.split16[1], wave, lane) : nullptr;
+        const uint16_t* const* sp16 = SP == 2 ? a.split16h : a.split16;
+        const u32x4* s1 = SP ? c16s_w(sp16[2], wave, lane) : nullptr;      // (lane folded in: the ring requests are this + constants)
+        const u32x4* s2 = SP ? c16s_w(sp16[0], wave, lane) : nullptr;
+        const u32x4* s3 = SP ? c16s_w(sp16[1], wave, lane) : nullptr;
+        const float rw1 = a.h2_rs[2], rw2 = a.h2_rs[0], rw3 = a.h2_rs[1];      // (SP = 2) 1 / the chunks' scales
         if ((int64_t)(ht0 + gi * RT) * 16 >= a.E) break;            // nothing but the empty tail of the last 32-row tile
         int ht[RT], s_[RT], r_[RT], r_before[RT], r_after[RT], row[RT];
         int64_t tile[RT];
@@ -873,24 +920,24 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
             xs[t][1] = c16_ld_tile<BF>(a.Elat, tile[t], row[t], 2 * wave + 1, q);
         }
         C16Ring g1, g2;
-        C16SRing h1, h2;
+        C16SRingT<NP> h1, h2;
         constexpr bool XL = SP && RT > 3;                             // pieces stay in the exchange buffer (c16s_chain_lds)
-        C16P xp[XL ? 1 : RT][4];
+        C16X<NP> xp[XL ? 1 : RT][4];
         u32x4* const xs0 = reinterpret_cast<u32x4*>(xch0);
         u32x4* const xs1 = reinterpret_cast<u32x4*>(xch1);
         if constexpr (SP) c16s_prime(h1, s1);
         else c16_prime(g1, w1, lane);
 #pragma unroll
         for (int t = 0; t < RT; ++t) acc[t][0] = acc[t][1] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if constexpr (XL) c16s_publish<RT, false>(xs, xs0, wave, lane);
-        else if constexpr (SP) c16s_exchange<RT, false>(xp, xs, xs0, wave, lane);
+        if constexpr (XL) c16s_publish<RT, false, NP>(xs, xs0, wave, lane);
+        else if constexpr (SP) c16s_exchange<RT, false, NP>(xp, xs, xs0, wave, lane);
         else c16m_exchange<RT>(x, xs, xch0, wave, lane);
         __builtin_amdgcn_sched_barrier(0);
         STAMP16(1);
         // layer 1: the e tile's part starts as soon as the tile and the first weights are here; the gathered P[s] + Q[r] (which
         // carry b1) are requested half way -- their addresses wait for the index loads, a serial round trip -- and added at the end
-        if constexpr (XL) c16s_chain_lds<RT, 0, 4>(acc, xs0, lane, s1, h1);
-        else if constexpr (SP) c16s_chain<RT, 0, 4>(acc, xp, s1, h1);
+        if constexpr (XL) c16s_chain_lds<RT, 0, 4, NP>(acc, xs0, lane, s1, h1, rw1);
+        else if constexpr (SP) c16s_chain<RT, 0, 4, NP>(acc, xp, s1, h1, rw1);
         else c16m_chain<RT, 0, 4>(acc, x, w1, lane, g1);
         f32x4 tb2[2], tb3[2], tg[2], tb[2];
         c16_tab(tb2, tabs + T_B2 * L, wave, q);
@@ -929,8 +976,8 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
             const bool sr = (n == 15) && ha[t] && (r_after[t] == reff);          // run continues into the next one
             to_carry[t] = sl_[t] || sr;
         }
-        if constexpr (XL) c16s_chain_lds<RT, 4, 8>(acc, xs0, lane, s1, h1);
-        else if constexpr (SP) c16s_chain<RT, 4, 8>(acc, xp, s1, h1);
+        if constexpr (XL) c16s_chain_lds<RT, 4, 8, NP>(acc, xs0, lane, s1, h1, rw1);
+        else if constexpr (SP) c16s_chain<RT, 4, 8, NP>(acc, xp, s1, h1, rw1);
         else c16m_chain<RT, 4, 8>(acc, x, w1, lane, g1);
 #pragma unroll
         for (int t = 0; t < RT; ++t) {
@@ -940,28 +987,28 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
         STAMP16(2);
         if constexpr (XL) {
             c16s_prime(h1, s3);
-            c16s_publish<RT, true>(acc, xs1, wave, lane);
+            c16s_publish<RT, true, NP>(acc, xs1, wave, lane);
             STAMP16(3);
 #pragma unroll
             for (int t = 0; t < RT; ++t) { acc[t][0] = tb2[0]; acc[t][1] = tb2[1]; }
-            c16s_chain_lds<RT>(acc, xs1, lane, s2, h2);              // layer 2
+            c16s_chain_lds<RT, 0, 8, NP>(acc, xs1, lane, s2, h2, rw2);   // layer 2
             STAMP16(4);
-            c16s_publish<RT, true>(acc, xs0, wave, lane);            // (xch0: every wave is past its layer-1 reads -- the barrier of the publish before)
+            c16s_publish<RT, true, NP>(acc, xs0, wave, lane);        // (xch0: every wave is past its layer-1 reads -- the barrier of the publish before)
 #pragma unroll
             for (int t = 0; t < RT; ++t) { acc[t][0] = tb3[0]; acc[t][1] = tb3[1]; }
-            c16s_chain_lds<RT>(acc, xs0, lane, s3, h1);              // layer 3
+            c16s_chain_lds<RT, 0, 8, NP>(acc, xs0, lane, s3, h1, rw3);   // layer 3
         } else if constexpr (SP) {                                   // (the ReLUs are folded into the split of the exchange)
             c16s_prime(h1, s3);
-            c16s_exchange<RT, true>(xp, acc, xs1, wave, lane);
+            c16s_exchange<RT, true, NP>(xp, acc, xs1, wave, lane);
             STAMP16(3);
 #pragma unroll
             for (int t = 0; t < RT; ++t) { acc[t][0] = tb2[0]; acc[t][1] = tb2[1]; }
-            c16s_chain<RT>(acc, xp, s2, h2);                         // layer 2
+            c16s_chain<RT, 0, 8, NP>(acc, xp, s2, h2, rw2);          // layer 2
             STAMP16(4);
-            c16s_exchange<RT, true>(xp, acc, xs0, wave, lane);
+            c16s_exchange<RT, true, NP>(xp, acc, xs0, wave, lane);
 #pragma unroll
             for (int t = 0; t < RT; ++t) { acc[t][0] = tb3[0]; acc[t][1] = tb3[1]; }
-            c16s_chain<RT>(acc, xp, s3, h1);                         // layer 3
+            c16s_chain<RT, 0, 8, NP>(acc, xp, s3, h1, rw3);          // layer 3
         } else {
 #pragma unroll
         for (int t = 0; t < RT; ++t) c16_relu(acc[t]);
@@ -1053,35 +1100,36 @@ DEVINL void c16_agg_slice(f32x4 (&as)[2], const int32_t* rowptr, const float* AG
         }
 }
 // split path: one slice -> its pieces in an exchange buffer / all four k-steps' pieces back (no barrier: the caller's)
-template <bool RELU>
+template <bool RELU, int NP>
 DEVINL void c16s_put(u32x4* xch, const f32x4 (&mine)[2], int wave, int lane) {
-    const C16P p = c16s_split<RELU>(mine);
-    xch[(wave * 3 + 0) * 64 + lane] = p.h;
-    xch[(wave * 3 + 1) * 64 + lane] = p.m;
-    xch[(wave * 3 + 2) * 64 + lane] = p.l;
+    const C16X<NP> p = c16s_split<RELU, NP>(mine);
+#pragma unroll
+    for (int pc = 0; pc < NP; ++pc) xch[(wave * NP + pc) * 64 + lane] = p.p[pc];
+    if constexpr (NP == 2) c16s_scales<1, NP>(xch)[wave * 16 + (lane & 15)] = p.rs;
 }
-DEVINL void c16s_get(C16P (&full)[1][4], const u32x4* xch, int lane) {
+template <int NP>
+DEVINL void c16s_get(C16X<NP> (&full)[1][4], const u32x4* xch, int lane) {
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-        full[0][ks].h = xch[(ks * 3 + 0) * 64 + lane];
-        full[0][ks].m = xch[(ks * 3 + 1) * 64 + lane];
-        full[0][ks].l = xch[(ks * 3 + 2) * 64 + lane];
+        C16X<NP> x[1];
+        c16s_fetch<1, NP>(x, xch, ks, lane);
+        full[0][ks] = x[0];
     }
 }
-template <bool BF>
-DEVINL void c16s_project(const C16P (&v)[1][4], const u32x4* wp, const u32x4* wq, const float* bq, float* P, float* Q, bool valid, int nn,
-                         int wave, int q, C16SRing& ga, C16SRing& gb, const u32x4* next_wp) {
+template <bool BF, int NP>
+DEVINL void c16s_project(const C16X<NP> (&v)[1][4], const u32x4* wp, const u32x4* wq, float rwp, float rwq, const float* bq, float* P, float* Q,
+                         bool valid, int nn, int wave, int q, C16SRingT<NP>& ga, C16SRingT<NP>& gb, const u32x4* next_wp) {
     f32x4 o[1][2];
     o[0][0] = o[0][1] = f32x4{0.f, 0.f, 0.f, 0.f};
     c16s_prime(gb, wq);
-    c16s_chain<1>(o, v, wp, ga);
+    c16s_chain<1, 0, 8, NP>(o, v, wp, ga, rwp);
     if (valid) {
         c16_st_row<BF>(P, nn, 2 * wave, q, o[0][0]);
         c16_st_row<BF>(P, nn, 2 * wave + 1, q, o[0][1]);
     }
     c16_tab(o[0], bq, wave, q);
     if (next_wp) c16s_prime(ga, next_wp);
-    c16s_chain<1>(o, v, wq, gb);
+    c16s_chain<1, 0, 8, NP>(o, v, wq, gb, rwq);
     if (valid) {
         c16_st_row<BF>(Q, nn, 2 * wave, q, o[0][0]);
         c16_st_row<BF>(Q, nn, 2 * wave + 1, q, o[0][1]);
@@ -1107,11 +1155,12 @@ DEVINL void c16_project(const f32x4 (&v)[1][8], const float* wp, const float* wq
         c16_st_row<BF>(Q, nn, 2 * wave + 1, q, o[0][1]);
     }
 }
-template <int SETS, bool BF, bool SP = false, int CSH = 4>
+template <int SETS, bool BF, int SP = 0, int CSH = 4>      // SP as in k_edge_coop16m
 __global__ __launch_bounds__(256, 2) void k_node_coop16(const NodeArgs a) {
     constexpr int L = 128;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr int XCH = SP ? 12 * 64 : 8 * 64;                      // 16-byte slots of an exchange buffer (SP: pieces)
+    constexpr int NP = SP == 2 ? 2 : 3;
+    constexpr int XCH = SP ? 4 * NP * 64 + (SP == 2 ? 16 : 0) : 8 * 64;   // 16-byte slots of an exchange buffer (SP: pieces + 1 / scale per (k-step, row))
     f32x4* xch0 = reinterpret_cast<f32x4*>(smem);
     f32x4* xch1 = xch0 + XCH;
     f32x4* xch2 = xch1 + XCH;
@@ -1128,7 +1177,8 @@ __global__ __launch_bounds__(256, 2) void k_node_coop16(const NodeArgs a) {
         int lane = lane0;
         asm volatile("" : "+v"(lane));
         const int n = lane & 15, q = lane >> 4;
-        auto ws = [&](int ch) { return c16s_w(a.split16[ch], wave, lane); };    // (SP) the chunk's pieces, this wave's blocks
+        auto ws = [&](int ch) { return c16s_w(SP == 2 ? a.split16h[ch] : a.split16[ch], wave, lane); };    // (SP) the chunk's pieces, this wave's blocks
+        auto rw = [&](int ch) { return a.h2_rs[ch]; };                 // (SP = 2) 1 / the chunk's scale
         const int ht = ht0 + hi;
         const int node = ht * 16 + n;
         if (ht * 16 >= a.n) break;
@@ -1141,8 +1191,8 @@ __global__ __launch_bounds__(256, 2) void k_node_coop16(const NodeArgs a) {
         vs[0][1] = c16_ld_tile<BF>(a.V, tile, row, 2 * wave + 1, q);
         C16Ring ga, gb;
         if constexpr (SP) {
-            C16SRing ha, hb;
-            C16P vp[1][4], fp[1][4];
+            C16SRingT<NP> ha, hb;
+            C16X<NP> vp[1][4], fp[1][4];
             u32x4* const x0 = reinterpret_cast<u32x4*>(xch0);
             u32x4* const x1 = reinterpret_cast<u32x4*>(xch1);
             u32x4* const x2 = reinterpret_cast<u32x4*>(xch2);
@@ -1153,49 +1203,49 @@ __global__ __launch_bounds__(256, 2) void k_node_coop16(const NodeArgs a) {
                 if constexpr (SETS == 2) c16_agg_slice<BF, CSH>(as2, a.rowptr2, a.AGG2, a.CARRY2, a.zero_row2, valid, nn, tile, row, wave, q);
                 c16s_prime(ha, ws(2));
                 c16_tab(acc[0], tabs + T_B1 * L, wave, q);
-                c16s_put<false>(x0, vs[0], wave, lane);
-                c16s_put<false>(x1, as, wave, lane);
-                if constexpr (SETS == 2) c16s_put<false>(x2, as2, wave, lane);
+                c16s_put<false, NP>(x0, vs[0], wave, lane);
+                c16s_put<false, NP>(x1, as, wave, lane);
+                if constexpr (SETS == 2) c16s_put<false, NP>(x2, as2, wave, lane);
                 __syncthreads();
                 c16s_get(vp, x0, lane);
                 __builtin_amdgcn_sched_barrier(0);
                 STAMP16(1);
-                c16s_chain<1, 0, 4>(acc, vp, ws(2), ha);                 // layer 1, node part
+                c16s_chain<1, 0, 4, NP>(acc, vp, ws(2), ha, rw(2));      // layer 1, node part
                 f32x4 tb2[2], tb3[2], tg[2], tb[2];
                 c16_tab(tb2, tabs + T_B2 * L, wave, q);
                 c16_tab(tb3, tabs + T_B3 * L, wave, q);
                 c16_tab(tg, tabs + T_GAMMA * L, wave, q);
                 c16_tab(tb, tabs + T_BETA * L, wave, q);
                 c16s_prime(hb, ws(3));
-                c16s_chain<1, 4, 8>(acc, vp, ws(2), ha);
+                c16s_chain<1, 4, 8, NP>(acc, vp, ws(2), ha, rw(2));
                 STAMP16(2);
                 c16s_prime(ha, ws(SETS == 2 ? 6 : 0));
                 __builtin_amdgcn_sched_barrier(0);                       // (the aggregate's pieces only now: 48 registers the node part no longer needs)
                 c16s_get(fp, x1, lane);
-                c16s_chain<1>(acc, fp, ws(3), hb);                       // layer 1, aggregate part
+                c16s_chain<1, 0, 8, NP>(acc, fp, ws(3), hb, rw(3));      // layer 1, aggregate part
                 if constexpr (SETS == 2) {
                     c16s_get(fp, x2, lane);
                     c16s_prime(hb, ws(0));
-                    c16s_chain<1>(acc, fp, ws(6), ha);                   // layer 1, the second set's aggregate
+                    c16s_chain<1, 0, 8, NP>(acc, fp, ws(6), ha, rw(6));  // layer 1, the second set's aggregate
                 }
-                C16SRing& r2 = SETS == 2 ? hb : ha;                      // the ring that holds layer 2's first fragments
-                C16SRing& r3 = SETS == 2 ? ha : hb;
+                C16SRingT<NP>& r2 = SETS == 2 ? hb : ha;                 // the ring that holds layer 2's first fragments
+                C16SRingT<NP>& r3 = SETS == 2 ? ha : hb;
                 STAMP16(3);
                 c16s_prime(r3, ws(1));
-                c16s_put<true>(SETS == 2 ? x3 : x2, acc[0], wave, lane); // (ReLU folded into the split)
+                c16s_put<true, NP>(SETS == 2 ? x3 : x2, acc[0], wave, lane); // (ReLU folded into the split)
                 __syncthreads();
                 c16s_get(fp, SETS == 2 ? x3 : x2, lane);
                 acc[0][0] = tb2[0];
                 acc[0][1] = tb2[1];
-                c16s_chain<1>(acc, fp, ws(0), r2);                       // layer 2
+                c16s_chain<1, 0, 8, NP>(acc, fp, ws(0), r2, rw(0));      // layer 2
                 STAMP16(4);
                 if (a.mode == 1) c16s_prime(r2, ws(4));                  // the projection's first fragments
-                c16s_put<true>(x0, acc[0], wave, lane);
+                c16s_put<true, NP>(x0, acc[0], wave, lane);
                 __syncthreads();
                 c16s_get(fp, x0, lane);
                 acc[0][0] = tb3[0];
                 acc[0][1] = tb3[1];
-                c16s_chain<1>(acc, fp, ws(1), r3);                       // layer 3
+                c16s_chain<1, 0, 8, NP>(acc, fp, ws(1), r3, rw(1));      // layer 3
                 c16m_layer_norm<1>(acc, red, tg, tb, wave, n, tabs + T_LN * L);
                 STAMP16(5);
                 acc[0][0] = c16_round<BF>(acc[0][0] + vs[0][0]);         // v <- v + v'
@@ -1205,20 +1255,20 @@ __global__ __launch_bounds__(256, 2) void k_node_coop16(const NodeArgs a) {
                     c16_st_tile<BF>(a.V, tile, row, 2 * wave + 1, q, acc[0][1]);
                 }
                 if (a.mode == 1) {                                       // P, Q of the next step, on the updated rows
-                    c16s_put<false>(x1, acc[0], wave, lane);
+                    c16s_put<false, NP>(x1, acc[0], wave, lane);
                     __syncthreads();
                     c16s_get(vp, x1, lane);
                     STAMP16(6);
-                    c16s_project<BF>(vp, ws(4), ws(5), tabs + T_BQ * L, a.P, a.Q, valid, nn, wave, q, r2, r3, SETS == 2 ? ws(7) : nullptr);
+                    c16s_project<BF, NP>(vp, ws(4), ws(5), rw(4), rw(5), tabs + T_BQ * L, a.P, a.Q, valid, nn, wave, q, r2, r3, SETS == 2 ? ws(7) : nullptr);
                     if constexpr (SETS == 2)
-                        c16s_project<BF>(vp, ws(7), ws(8), a.tabs2 + (T_COUNT + T_BQ) * L, a.P2, a.Q2, valid, nn, wave, q, r2, r3, nullptr);
+                        c16s_project<BF, NP>(vp, ws(7), ws(8), rw(7), rw(8), a.tabs2 + (T_COUNT + T_BQ) * L, a.P2, a.Q2, valid, nn, wave, q, r2, r3, nullptr);
                 }
             } else {                                                     // projection only (before the first step; one set per launch)
                 c16s_prime(ha, ws(4));
-                c16s_put<false>(x0, vs[0], wave, lane);
+                c16s_put<false, NP>(x0, vs[0], wave, lane);
                 __syncthreads();
                 c16s_get(vp, x0, lane);
-                c16s_project<BF>(vp, ws(4), ws(5), tabs + T_BQ * L, a.P, a.Q, valid, nn, wave, q, ha, hb, nullptr);
+                c16s_project<BF, NP>(vp, ws(4), ws(5), rw(4), rw(5), tabs + T_BQ * L, a.P, a.Q, valid, nn, wave, q, ha, hb, nullptr);
             }
         } else if (a.mode != 2) {
             f32x4 as[2], as2[2];
@@ -2758,18 +2808,21 @@ hipError_t launch_edge_step(int L, const EdgeArgs& a, hipStream_t s) {
         LaunchCfg c16{(nht + rt - 1) / rt, 256, (size_t)rt * 2 * 8 * 64 * 16 + (size_t)rt * 2 * 64 * 4};
         if (g_fp32_split && (g_c16_split & 1) && a.split16[0] && (rt >= 2 || (g_c16_split & 4))) {   // split path: bf16 matrix cores at fp32 accuracy (pieces exchanged: 12 KiB per tile)
             c16.lds = (size_t)rt * 2 * 12 * 64 * 16 + (size_t)rt * 2 * 64 * 4;
-            g_last_edge_kernel = 12;
+            const bool h2 = g_split_f16 && a.split16h[0] && rt <= 4;   // two fp16 pieces, three products (else three bf16 pieces, six; five and six row tiles spill with two)
+            g_last_edge_kernel = h2 ? 15 : 12;
+#define C16E(RT_, BF_) (h2 ? launch_k(k_edge_coop16m<RT_, BF_, 2>, a, c16, s) : launch_k(k_edge_coop16m<RT_, BF_, 1>, a, c16, s))
             if (a.bf) {
-                if (rt == 3) return launch_k(k_edge_coop16m<3, true, true>, a, c16, s);
-                if (rt == 2) return launch_k(k_edge_coop16m<2, true, true>, a, c16, s);
-                return launch_k(k_edge_coop16m<1, true, true>, a, c16, s);
+                if (rt == 3) return C16E(3, true);
+                if (rt == 2) return C16E(2, true);
+                return C16E(1, true);
             }
-            if (rt == 6) return launch_k(k_edge_coop16m<6, false, true>, a, c16, s);
-            if (rt == 5) return launch_k(k_edge_coop16m<5, false, true>, a, c16, s);
-            if (rt == 4) return launch_k(k_edge_coop16m<4, false, true>, a, c16, s);
-            if (rt == 3) return launch_k(k_edge_coop16m<3, false, true>, a, c16, s);
-            if (rt == 2) return launch_k(k_edge_coop16m<2, false, true>, a, c16, s);
-            return launch_k(k_edge_coop16m<1, false, true>, a, c16, s);
+            if (rt == 6) return C16E(6, false);
+            if (rt == 5) return C16E(5, false);
+            if (rt == 4) return C16E(4, false);
+            if (rt == 3) return C16E(3, false);
+            if (rt == 2) return C16E(2, false);
+            return C16E(1, false);
+#undef C16E
         }
         if (a.bf) {
             if (rt == 3) return launch_k(k_edge_coop16m<3, true>, a, c16, s);
@@ -2865,8 +2918,12 @@ hipError_t launch_node_step(int L, const NodeArgs& a, hipStream_t s) {
         if (g_fp32_split && (g_c16_split & 2) && a.split16[0] && (!a.AGG2 || a.split16[6])) {   // split path (pieces exchanged: 12 KiB per buffer)
             c16.lds = (size_t)4 * 12 * 64 * 16 + 2 * 64 * 4;
             if (a.mode != 2) g_last_node_kernel = 8;
-            if (a.bf) return a.AGG2 ? launch_k(k_node_coop16<2, true, true>, a, c16, s) : launch_k(k_node_coop16<1, true, true>, a, c16, s);
-            return a.AGG2 ? launch_k(k_node_coop16<2, false, true>, a, c16, s) : launch_k(k_node_coop16<1, false, true>, a, c16, s);
+            if (g_split_f16 && a.split16h[0] && (!a.AGG2 || a.split16h[6])) {      // two fp16 pieces
+                if (a.bf) return a.AGG2 ? launch_k(k_node_coop16<2, true, 2>, a, c16, s) : launch_k(k_node_coop16<1, true, 2>, a, c16, s);
+                return a.AGG2 ? launch_k(k_node_coop16<2, false, 2>, a, c16, s) : launch_k(k_node_coop16<1, false, 2>, a, c16, s);
+            }
+            if (a.bf) return a.AGG2 ? launch_k(k_node_coop16<2, true, 1>, a, c16, s) : launch_k(k_node_coop16<1, true, 1>, a, c16, s);
+            return a.AGG2 ? launch_k(k_node_coop16<2, false, 1>, a, c16, s) : launch_k(k_node_coop16<1, false, 1>, a, c16, s);
         }
         if (a.bf) return a.AGG2 ? launch_k(k_node_coop16<2, true>, a, c16, s) : launch_k(k_node_coop16<1, true>, a, c16, s);
         return a.AGG2 ? launch_k(k_node_coop16<2, false>, a, c16, s) : launch_k(k_node_coop16<1, false>, a, c16, s);
@@ -2879,7 +2936,8 @@ hipError_t launch_node_step(int L, const NodeArgs& a, hipStream_t s) {
         coop_ok(L, a.ntiles, a.chunk_t) && !split_node) {
         LaunchCfg c16{2 * a.ntiles, 256, (size_t)4 * 12 * 64 * 16 + 2 * 64 * 4};
         g_last_node_kernel = 9;
-        return launch_k(k_node_coop16<1, false, true, 5>, a, c16, s);
+        if (g_split_f16 && a.split16h[0]) return launch_k(k_node_coop16<1, false, 2, 5>, a, c16, s);
+        return launch_k(k_node_coop16<1, false, 1, 5>, a, c16, s);
     }
     if (coop_ok(L, a.ntiles, a.chunk_t) && !split_node) {
         LaunchCfg c4{a.ntiles, 256, coop_lds()};
@@ -2933,7 +2991,8 @@ hipError_t launch_project(int L, const NodeArgs& a, hipStream_t s) {
         LaunchCfg c16{2 * a.ntiles, 256, (size_t)4 * 8 * 64 * 16 + 2 * 64 * 4};
         if (g_fp32_split && (g_c16_split & 2) && a.split16[4]) {
             c16.lds = (size_t)4 * 12 * 64 * 16 + 2 * 64 * 4;
-            return a.bf ? launch_k(k_node_coop16<1, true, true>, a, c16, s) : launch_k(k_node_coop16<1, false, true>, a, c16, s);
+            if (g_split_f16 && a.split16h[4]) return a.bf ? launch_k(k_node_coop16<1, true, 2>, a, c16, s) : launch_k(k_node_coop16<1, false, 2>, a, c16, s);
+            return a.bf ? launch_k(k_node_coop16<1, true, 1>, a, c16, s) : launch_k(k_node_coop16<1, false, 1>, a, c16, s);
         }
         return a.bf ? launch_k(k_node_coop16<1, true>, a, c16, s) : launch_k(k_node_coop16<1, false>, a, c16, s);
     }

@@ -192,19 +192,27 @@ void pack_chunk_split(uint16_t* dst, const float* W, int ldw, int kbase, bool fr
 }
 // the same chunk times a power of two as two fp16 pieces, w scale = hi + lo (+ <= 2^-23 relative; split_common.hpp), both round to nearest
 // even (dst: 2 x 16384, the bf16 pieces' fragment order)
-void pack_chunk_split_h(uint16_t* dst, const float* W, int ldw, int kbase, float scale) {
+void pack_chunk_split_h(uint16_t* dst, const float* W, int ldw, int kbase, float scale, bool frag16 = false) {
+    auto put = [&](size_t at, int k, int n) {
+        const float ws = W[(size_t)(kbase + k) * ldw + n] * scale;
+        const _Float16 hi = (_Float16)ws;
+        const _Float16 lo = (_Float16)(ws - (float)hi);
+        memcpy(&dst[at], &hi, 2);
+        memcpy(&dst[16384 + at], &lo, 2);
+    };
+    if (frag16) {                                        // [ks][ob][lane][8] (pack_chunk16_bf16's order)
+        for (int ks = 0; ks < 4; ++ks)
+            for (int ob = 0; ob < 8; ++ob)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int j = 0; j < 8; ++j)
+                        put((((size_t)ks * 8 + ob) * 64 + lane) * 8 + j, 16 * (2 * ks + (j >> 2)) + 4 * (lane >> 4) + (j & 3), 16 * ob + (lane & 15));
+        return;
+    }
     for (int sidx = 0; sidx < 8; ++sidx)
         for (int t = 0; t < 4; ++t)
             for (int lane = 0; lane < 64; ++lane)
-                for (int j = 0; j < 8; ++j) {
-                    const int hh = lane >> 5, i = lane & 31;
-                    const float ws = W[(size_t)(kbase + bf_feature(sidx, hh, j)) * ldw + 32 * t + i] * scale;
-                    const _Float16 hi = (_Float16)ws;
-                    const _Float16 lo = (_Float16)(ws - (float)hi);
-                    const size_t at = (((size_t)sidx * 4 + t) * 64 + lane) * 8 + j;
-                    memcpy(&dst[at], &hi, 2);
-                    memcpy(&dst[16384 + at], &lo, 2);
-                }
+                for (int j = 0; j < 8; ++j)
+                    put((((size_t)sidx * 4 + t) * 64 + lane) * 8 + j, bf_feature(sidx, lane >> 5, j), 32 * t + (lane & 31));
 }
 // the A fragments of v_mfma_f32_16x16x32_bf16 (k_edge_ring16, split.hip): step (ks, ob) = output block ob of k-step ks; lane
 // (r16 = lane & 15, g = lane >> 4) holds output 16 ob + r16, its element j input 16 (2 ks + (j >> 2)) + 4 g + (j & 3) -- the order in
@@ -430,9 +438,10 @@ EdgeArgs edge_args(mgn_engine* h, int k, int q = 0) {
     const bool have_sp = k < (int)h->spoff.size() && h->wsp.p;
     for (int i = 0; i < 3; ++i) a.split[i] = (!a.bf && have_sp) ? h->wsp.as<uint16_t>() + h->spoff[k].e_ch[q][i] : nullptr;
     for (int i = 0; i < 3; ++i) a.split16[i] = have_sp ? h->wsp.as<uint16_t>() + h->spoff[k].e16_ch[q][i] : nullptr;
-    const bool have_h = have_sp && !a.bf && h->spoff[k].have_h;
+    const bool have_h = have_sp && h->spoff[k].have_h;
     for (int i = 0; i < 3; ++i) {
-        a.splith[i] = have_h ? h->wsp.as<uint16_t>() + h->spoff[k].eh_ch[q][i] : nullptr;
+        a.splith[i] = (have_h && !a.bf) ? h->wsp.as<uint16_t>() + h->spoff[k].eh_ch[q][i] : nullptr;
+        a.split16h[i] = have_h ? h->wsp.as<uint16_t>() + h->spoff[k].e16h_ch[q][i] : nullptr;
         a.h2_s[i] = have_h ? h->spoff[k].eh_s[q][i] : 1.f;
         a.h2_rs[i] = 1.f / a.h2_s[i];
     }
@@ -508,12 +517,31 @@ NodeArgs node_args(mgn_engine* h, int k, int mode, int q = 0) {
     const bool sp16 = k < (int)h->spoff.size() && h->spoff[k].have_n && h->wsp.p;
     const bool sp = !bf && sp16;
     for (int i = 0; i < 6; ++i) a.split[i] = (sp && q == 0) ? h->wsp.as<uint16_t>() + h->spoff[k].n_ch[i] : nullptr;
-    const bool sph = sp && q == 0 && h->nsets == 1 && h->spoff[k].have_h;        // two fp16 pieces (one edge set)
+    const bool sph = sp && q == 0 && h->nsets == 1 && h->spoff[k].have_h;        // two fp16 pieces, 32x32x16 order (fp32 storage, one edge set)
+    const bool sph16 = sp16 && h->spoff[k].have_h;                               // ... 16x16x32 order (16-row kernels: both storage modes, both sets)
+    for (int i = 0; i < 9; ++i) {
+        a.split16h[i] = nullptr;
+        a.h2_s[i] = 1.f;
+    }
     for (int i = 0; i < 6; ++i) {
         a.splith[i] = sph ? h->wsp.as<uint16_t>() + h->spoff[k].nh_ch[i] : nullptr;
-        a.h2_s[i] = sph ? h->spoff[k].nh_s[i] : 1.f;
-        a.h2_rs[i] = 1.f / a.h2_s[i];
+        if (sph16) {
+            a.split16h[i] = h->wsp.as<uint16_t>() + h->spoff[k].n16h_ch[i];
+            a.h2_s[i] = h->spoff[k].nh_s[i];
+        }
     }
+    if (sph16 && h->nsets == 2) {
+        for (int i = 0; i < 3; ++i) {
+            a.split16h[6 + i] = h->wsp.as<uint16_t>() + h->spoff[k].n16h_ch[6 + i];
+            a.h2_s[6 + i] = h->spoff[k].nh_s[6 + i];
+        }
+        if (q == 1)                                     // the projection of set 1 (mode 2): its WP / WQ pieces in slots 4, 5
+            for (int i = 0; i < 2; ++i) {
+                a.split16h[4 + i] = a.split16h[7 + i];
+                a.h2_s[4 + i] = a.h2_s[7 + i];
+            }
+    }
+    for (int i = 0; i < 9; ++i) a.h2_rs[i] = 1.f / a.h2_s[i];
     a.h2_b2pos = sph ? h->spoff[k].n_b2pos : 0.f;
     if (sp && h->nsets == 2) {
         if (q == 1)                                     // the projection of set 1 (mode 2): its WP / WQ pieces
@@ -862,8 +890,9 @@ int pack_inference_weights(mgn_engine* h) {
             o16 = off;
             off += (size_t)3 * 16384;
         };
-        // two fp16 pieces of the same chunk times a power of two that puts its largest entry into [2^14, 2^15) (split_common.hpp)
-        auto puth = [&](const float* src, int kb, size_t& oh, float& sc) {
+        // two fp16 pieces of the same chunk times a power of two that puts its largest entry into [2^14, 2^15) (split_common.hpp): in the
+        // 32x32x16 fragment order (fp32 storage: k_edge_ring_h, k_node_split_h, k_project_split_h) and in the 16x16x32 one (16-row kernels)
+        auto puth = [&](const float* src, int kb, size_t& oh, size_t& o16h, float& sc) {
             float mx = 0.f;
             for (int k = 0; k < L; ++k)
                 for (int n = 0; n < L; ++n) mx = std::max(mx, std::fabs(src[(size_t)(kb + k) * L + n]));
@@ -872,8 +901,14 @@ int pack_inference_weights(mgn_engine* h) {
             if (!(mx > 0.f) || e - 1 < -40) e = -39;
             if (!std::isfinite(mx)) e = 128;
             sc = std::ldexp(1.f, 15 - e);
-            jobs.push_back({4, (long long)off, (long long)(src - p), L, kb, sc});
-            oh = off;
+            oh = 0;
+            if (f32) {
+                jobs.push_back({4, (long long)off, (long long)(src - p), L, kb, sc});
+                oh = off;
+                off += (size_t)2 * 16384;
+            }
+            jobs.push_back({5, (long long)off, (long long)(src - p), L, kb, sc});
+            o16h = off;
             off += (size_t)2 * 16384;
         };
         for (int k = 0; k < c.mps; ++k)
@@ -882,13 +917,11 @@ int pack_inference_weights(mgn_engine* h) {
                 const float* src[3] = {p + me.W[1], p + me.W[2], p + me.W[0]};
                 const int kb[3] = {0, 0, 2 * L};
                 for (int i = 0; i < 3; ++i) put(src[i], kb[i], h->spoff[k].e_ch[q][i], h->spoff[k].e16_ch[q][i]);
-                if (f32) {
-                    for (int i = 0; i < 3; ++i) puth(src[i], kb[i], h->spoff[k].eh_ch[q][i], h->spoff[k].eh_s[q][i]);
-                    float bp = 0.f;
-                    for (int i = 0; i < L; ++i) bp = std::max(bp, p[me.b[1] + i]);
-                    h->spoff[k].e_b2pos[q] = bp;
-                    h->spoff[k].have_h = true;
-                }
+                for (int i = 0; i < 3; ++i) puth(src[i], kb[i], h->spoff[k].eh_ch[q][i], h->spoff[k].e16h_ch[q][i], h->spoff[k].eh_s[q][i]);
+                float bp = 0.f;
+                for (int i = 0; i < L; ++i) bp = std::max(bp, p[me.b[1] + i]);
+                h->spoff[k].e_b2pos[q] = bp;
+                h->spoff[k].have_h = true;
             }
         for (int k = 0; node_side && k <= c.mps; ++k) {                 // node MLP of step k + projection for step k + 1 (k = mps: the
             const MlpOff& mn = h->pn[k < c.mps ? k : 0];                //   "project only" pseudo-step: step 0's own first layer)
@@ -896,18 +929,18 @@ int pack_inference_weights(mgn_engine* h) {
             const float* src[6] = {p + mn.W[1], p + mn.W[2], p + mn.W[0], p + mn.W[0], p + nx.W[0], p + nx.W[0]};
             const int kb[6] = {0, 0, 0, L, 0, L};
             for (int i = 0; i < 6; ++i) put(src[i], kb[i], h->spoff[k].n_ch[i], h->spoff[k].n16_ch[i]);
-            if (f32) {
-                for (int i = 0; i < 6; ++i) puth(src[i], kb[i], h->spoff[k].nh_ch[i], h->spoff[k].nh_s[i]);
-                float bp = 0.f;
-                for (int i = 0; i < L; ++i) bp = std::max(bp, p[mn.b[1] + i]);
-                h->spoff[k].n_b2pos = bp;
-                h->spoff[k].have_h = true;
-            }
+            for (int i = 0; i < 6; ++i) puth(src[i], kb[i], h->spoff[k].nh_ch[i], h->spoff[k].n16h_ch[i], h->spoff[k].nh_s[i]);
+            float bp = 0.f;
+            for (int i = 0; i < L; ++i) bp = std::max(bp, p[mn.b[1] + i]);
+            h->spoff[k].n_b2pos = bp;
+            h->spoff[k].have_h = true;
             if (S == 2) {                                               // second edge set: its aggregate block of the node MLP, its projection
                 const MlpOff& n1 = h->es[1].pe[k + 1 < c.mps ? k + 1 : 0];
                 const float* src2[3] = {p + mn.W[0], p + n1.W[0], p + n1.W[0]};
                 const int kb2[3] = {2 * L, 0, L};
                 for (int i = 0; i < 3; ++i) put(src2[i], kb2[i], h->spoff[k].n2_ch[i], h->spoff[k].n16_ch[6 + i]);
+                size_t unused = 0;
+                for (int i = 0; i < 3; ++i) puth(src2[i], kb2[i], unused, h->spoff[k].n16h_ch[6 + i], h->spoff[k].nh_s[6 + i]);
             }
             h->spoff[k].have_n = true;
         }
@@ -2613,6 +2646,8 @@ int mgn_debug_edge_ring16(int on) { return set_edge_ring16(on); }
 // 1 (default): the split path computes on two fp16 pieces per operand and three piece products (k_edge_ring_h), 0: on three bf16 pieces
 // and six products (k_edge_ring); returns the old value
 int mgn_debug_split_f16(int on) { return set_split_f16(on); }
+// the same switch for the streaming kernels of the training step (train.hip: train_chunk); returns the old value
+int mgn_debug_train_f16(int on) { return set_train_f16(on); }
 // tests: every chunk the device packed (k_pack_weights) against the host functions that specify the layouts; returns the number of
 // elements that differ (0 = bitwise equal), < 0 on error
 long long mgn_debug_pack_check(mgn_handle* h) try {
@@ -2636,8 +2671,8 @@ long long mgn_debug_pack_check(mgn_handle* h) try {
             pack_chunk_bf16(hb.data(), W, jb.ldw, jb.kbase);
             if (hipMemcpy(db.data(), h->wbf.as<uint16_t>() + jb.off, 16384 * 2, hipMemcpyDeviceToHost) != hipSuccess) return -MGN_E_HIP;
             for (size_t i = 0; i < 16384; ++i) bad += hb[i] != db[i];
-        } else if (jb.kind == 4) {
-            pack_chunk_split_h(hb.data(), W, jb.ldw, jb.kbase, jb.scale);
+        } else if (jb.kind == 4 || jb.kind == 5) {
+            pack_chunk_split_h(hb.data(), W, jb.ldw, jb.kbase, jb.scale, jb.kind == 5);
             if (hipMemcpy(db.data(), h->wsp.as<uint16_t>() + jb.off, 2 * 16384 * 2, hipMemcpyDeviceToHost) != hipSuccess) return -MGN_E_HIP;
             for (size_t i = 0; i < 2 * 16384; ++i) bad += hb[i] != db[i];
         } else {

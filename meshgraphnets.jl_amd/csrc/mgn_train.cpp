@@ -120,10 +120,24 @@ int pack_training_weights(mgn_engine* h) {
     std::vector<PackJob> jobs;
     std::vector<float> tabs;                          // the tables, compact (T_COUNT * L per block), scattered by the same kernel
     // rows [r0, r0 + nr) x cols [0, nc) of W (leading dimension ldw), zero-padded to L x L; transposed on request
+    // L = 128: every chunk also as two fp16 pieces times a power of two that puts its largest entry into [2^14, 2^15) (split_common.hpp;
+    // the streaming kernels of large launches compute on them), at + 2 CH, and 1 / that power at + 3 CH
+    const bool pieces = L == 128;
     auto block = [&](const float* Wm, int ldw, int r0, int nr, int nc, bool transpose) {
         const size_t off = fsz;
-        fsz += 2 * CH;                                // fragment order, then the t-major copy (cooperative kernels) at + CH
-        jobs.push_back({(long long)off, Wm ? (long long)(Wm - p) : -1LL, ldw, r0, nr, nc, transpose ? 1 : 0, 0});
+        fsz += pieces ? 3 * CH + 4 : 2 * CH;          // fragment order, then the t-major copy (cooperative kernels) at + CH
+        float sc = 0.f;
+        if (pieces) {
+            float mx = Wm ? 0.f : 1.f;
+            for (int r = 0; Wm && r < nr; ++r)
+                for (int cc = 0; cc < nc; ++cc) mx = std::max(mx, std::fabs(Wm[(size_t)(r0 + r) * ldw + cc]));
+            int e = 0;
+            (void)std::frexp(mx, &e);
+            if (!(mx > 0.f) || e - 1 < -40) e = -39;
+            if (!std::isfinite(mx)) e = 128;
+            sc = std::ldexp(1.f, 15 - e);
+        }
+        jobs.push_back({(long long)off, Wm ? (long long)(Wm - p) : -1LL, ldw, r0, nr, nc, transpose ? 1 : 0, 0, sc});
         return off;
     };
     const size_t ident = block(nullptr, 0, 0, 0, 0, false);   // (its own transpose)
@@ -164,7 +178,7 @@ int pack_training_weights(mgn_engine* h) {
             const size_t off = fsz, tpos = tabs.size();
             fsz += (size_t)T_COUNT * L;
             tabs.resize(tpos + (size_t)T_COUNT * L, 0.f);
-            jobs.push_back({(long long)off, (long long)tpos, 0, 0, 0, 0, 0, 1});
+            jobs.push_back({(long long)off, (long long)tpos, 0, 0, 0, 0, 0, 1, 0.f});
             float* tb_ = tabs.data() + tpos;
             std::vector<float> bias(L, 0.f);
             pack_tab(tb_ + (size_t)T_B1 * L, p + m.b[d0], L);

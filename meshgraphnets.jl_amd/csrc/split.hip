@@ -27,28 +27,11 @@
 
 namespace mgn {
 
-// Buffer descriptors (a wave-uniform 64-bit base in four scalar registers) + a 32-bit byte offset per lane + a scalar / immediate offset:
-// one address register per stream where 64-bit pointers cost a pair per 4 KiB of reach.  Used where registers are the limit.
-typedef unsigned int u32x4v __attribute__((ext_vector_type(4)));
-struct N16Buf { __amdgpu_buffer_rsrc_t r; };
-DEVINL N16Buf n16_buf(const void* base, int bytes = -1) { return {__builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, 0x00020000)}; }
-constexpr unsigned N16_DROP = 0x80000000u;      // a lane offset beyond every descriptor's range: the store is dropped, without a branch
-DEVINL f32x4 n16_ld(const N16Buf& b, unsigned voff, int soff) {
-    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(b.r, (int)voff, soff, 0));
-}
-DEVINL void n16_st(const N16Buf& b, unsigned voff, int soff, f32x4 v) {
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, v), b.r, (int)voff, soff, 0);
-}
-DEVINL u32x4 n16_ldu(const N16Buf& b, unsigned voff, int soff) { return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(b.r, (int)voff, soff, 0)); }
-
 #ifndef MGN_SP_CARRY
 #define MGN_SP_CARRY 1            // k_node_split, k_project_split: weight rings carried from chain to chain (needs MGN_SP_BUFFER)
 #endif
 #ifndef MGN_SP_BUFFER
 #define MGN_SP_BUFFER 1           // sp_layer_otf: streamed weight pieces through buffer descriptors (0: 64-bit pointers)
-#endif
-#ifndef MGN_SP2_INTERLEAVE
-#define MGN_SP2_INTERLEAVE 1      // 1: pin "one MFMA, two VALU" inside every (s, t) group (sched_group_barrier)
 #endif
 
 // One L x L layer: acc += W^T in, `in` split on the fly.  p1 / p2 / p3: the chunk's hi / mid / lo piece ([s][t][lane] fragments of
@@ -1866,104 +1849,6 @@ __global__ __launch_bounds__(NWV * 64, NWV / 4) void k_edge_ring16(const EdgeArg
 // second chain's units, 2 x 64 VALU instructions; layer 2's split takes the RAW accumulators of layer 1 -- a ReLU and a power of two
 // commute -- with the row maximum taken on the raw values, so nothing is finished there.
 // ================================================================================================
-template <int D> struct SpRingH { u32x4 r[D]; };
-template <bool GL, int FIN, int D, int OFF = 0, bool PRIMED = false, bool NEXT = false>
-DEVINL void h2_layer_otf(f32x16 (&acc)[4], const f32x16 (&in)[4], const u32x4* p_hi, const u32x4* p_lo, int lane, float sx, float cfin = 0.f,
-                         const float* btab = nullptr, SpRingH<D>* carry = nullptr, const u32x4* nx_lo = nullptr) {
-    const u32x4* w1 = p_hi + lane;
-    const u32x4* w2 = p_lo + lane;
-    const N16Buf b2 = n16_buf(GL ? p_lo : nullptr);
-    const unsigned voff = (unsigned)lane * 16u;
-    static_assert(!(PRIMED || NEXT) || GL, "the ring carry-over belongs to a streamed lo piece");
-    u32x4 r2[GL ? D : 1];
-    if constexpr (GL) {
-        if constexpr (PRIMED) {
-#pragma unroll
-            for (int d = 0; d < D; ++d) r2[d] = carry->r[d];
-        } else {
-#pragma unroll
-            for (int d = 0; d < D; ++d) r2[(d + OFF) % D] = n16_ldu(b2, voff, d * 1024);
-        }
-    }
-    const N16Buf c2 = n16_buf(NEXT ? nx_lo : nullptr);
-    auto bias = [&](int sn, int u) {
-        f32x2 b = {0.f, 0.f};
-        if constexpr (FIN == 2) b = *reinterpret_cast<const f32x2*>(btab + 8 * (4 * (sn >> 1) + 2 * (sn & 1) + (u >> 1)) + 2 * (u & 1));
-        return b;
-    };
-    u32x4 n1 = w1[0], n2;
-    if constexpr (!GL) n2 = w2[0];
-    unsigned ph[4], pl[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-        const f32x2 b = bias(0, u);
-        h2_split_pair<FIN>(ph[u], pl[u], in[0][2 * u], in[0][2 * u + 1], sx, cfin, b[0], b[1]);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int s = 0; s < 8; ++s) {
-        unsigned nh[4], nl[4];
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const int it = 4 * s + t;
-            const u32x4 a1 = n1;
-            u32x4 a2;
-            if constexpr (GL) a2 = r2[(it + OFF) % D]; else a2 = n2;
-            if (it + 1 < 32) {
-                n1 = w1[(it + 1) * 64];
-                if constexpr (!GL) n2 = w2[(it + 1) * 64];
-            }
-            if constexpr (GL) {
-                if (it + D < 32) r2[(it + OFF) % D] = n16_ldu(b2, voff, (it + D) * 1024);
-                else if constexpr (NEXT) r2[(it + OFF) % D] = n16_ldu(c2, voff, (it + D - 32) * 1024);
-            }
-            if (s < 7) {
-                const int sn = s + 1;
-                const f32x2 b = bias(sn, t);
-                h2_split_pair<FIN>(nh[t], nl[t], in[sn >> 1][8 * (sn & 1) + 2 * t], in[sn >> 1][8 * (sn & 1) + 2 * t + 1], sx, cfin, b[0], b[1]);
-            }
-            const sp_f16x8 bh = h2_op(ph), bl = h2_op(pl);
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h2_wop(a2), bh, acc[t], 0, 0, 0);      // small terms first
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h2_wop(a1), bl, acc[t], 0, 0, 0);
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h2_wop(a1), bh, acc[t], 0, 0, 0);
-#if MGN_SP2_INTERLEAVE
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
-#endif
-            __builtin_amdgcn_sched_barrier(0);
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            ph[u] = nh[u];
-            pl[u] = nl[u];
-        }
-    }
-    if constexpr (NEXT) {
-#pragma unroll
-        for (int d = 0; d < D; ++d) carry->r[d] = r2[d];
-    }
-}
-template <int NT>
-DEVINL void h2_scale_frag(f32x16 (&x)[NT], float c) {
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int k = 0; k < 16; ++k) x[t][k] *= c;
-}
-// x <- x c + table (fragment order)
-template <int NT>
-DEVINL void h2_finish_frag(f32x16 (&x)[NT], float c, const float* tab, int h) {
-    const f32x4* t4 = reinterpret_cast<const f32x4*>(tab) + h;
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const f32x4 bv = t4[2 * (4 * t + g)];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) x[t][4 * g + i] = __builtin_fmaf(x[t][4 * g + i], c, bv[i]);
-        }
-}
 #ifndef MGN_SPH_D
 #define MGN_SPH_D 8              // depth of the lo-piece ring of k_node_split_h
 #endif

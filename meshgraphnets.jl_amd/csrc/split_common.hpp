@@ -114,4 +114,217 @@ DEVINL float h2_rowmax(const f32x16 (&x)[4]) {
     return __builtin_fmaxf(m, __shfl_xor(m, 32, 64));
 }
 
+// Buffer descriptors (a wave-uniform 64-bit base in four scalar registers) + a 32-bit byte offset per lane + a scalar / immediate offset:
+// one address register per stream where 64-bit pointers cost a pair per 4 KiB of reach.  Used where registers are the limit.
+typedef unsigned int u32x4v __attribute__((ext_vector_type(4)));
+struct N16Buf { __amdgpu_buffer_rsrc_t r; };
+DEVINL N16Buf n16_buf(const void* base, int bytes = -1) { return {__builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, 0x00020000)}; }
+constexpr unsigned N16_DROP = 0x80000000u;      // a lane offset beyond every descriptor's range: the store is dropped, without a branch
+DEVINL f32x4 n16_ld(const N16Buf& b, unsigned voff, int soff) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(b.r, (int)voff, soff, 0));
+}
+DEVINL void n16_st(const N16Buf& b, unsigned voff, int soff, f32x4 v) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, v), b.r, (int)voff, soff, 0);
+}
+DEVINL u32x4 n16_ldu(const N16Buf& b, unsigned voff, int soff) { return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(b.r, (int)voff, soff, 0)); }
+
+
+#ifndef MGN_SP2_INTERLEAVE
+#define MGN_SP2_INTERLEAVE 1      // 1: pin "one MFMA, n VALU" groups inside every (s, t) step (sched_group_barrier)
+#endif
+// One L x L layer on two fp16 pieces, `in` split on the fly with the row scale sx (split.hip: the node-side kernels; train.hip: the
+// streaming training kernels).  p_hi LDS-resident; p_lo LDS-resident too (GL = false) or streamed from L2 through ONE per-wave register
+// ring D fragments deep that can be carried from chain to chain (carry / PRIMED / NEXT / nx_lo: see sp_layer_otf in split.hip).
+template <int D> struct SpRingH { u32x4 r[D]; };
+template <bool GL, int FIN, int D, int OFF = 0, bool PRIMED = false, bool NEXT = false>
+DEVINL void h2_layer_otf(f32x16 (&acc)[4], const f32x16 (&in)[4], const u32x4* p_hi, const u32x4* p_lo, int lane, float sx, float cfin = 0.f,
+                         const float* btab = nullptr, SpRingH<D>* carry = nullptr, const u32x4* nx_lo = nullptr) {
+    const u32x4* w1 = p_hi + lane;
+    const u32x4* w2 = p_lo + lane;
+    const N16Buf b2 = n16_buf(GL ? p_lo : nullptr);
+    const unsigned voff = (unsigned)lane * 16u;
+    static_assert(!(PRIMED || NEXT) || GL, "the ring carry-over belongs to a streamed lo piece");
+    u32x4 r2[GL ? D : 1];
+    if constexpr (GL) {
+        if constexpr (PRIMED) {
+#pragma unroll
+            for (int d = 0; d < D; ++d) r2[d] = carry->r[d];
+        } else {
+#pragma unroll
+            for (int d = 0; d < D; ++d) r2[(d + OFF) % D] = n16_ldu(b2, voff, d * 1024);
+        }
+    }
+    const N16Buf c2 = n16_buf(NEXT ? nx_lo : nullptr);
+    auto bias = [&](int sn, int u) {
+        f32x2 b = {0.f, 0.f};
+        if constexpr (FIN == 2) b = *reinterpret_cast<const f32x2*>(btab + 8 * (4 * (sn >> 1) + 2 * (sn & 1) + (u >> 1)) + 2 * (u & 1));
+        return b;
+    };
+    u32x4 n1 = w1[0], n2;
+    if constexpr (!GL) n2 = w2[0];
+    unsigned ph[4], pl[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const f32x2 b = bias(0, u);
+        h2_split_pair<FIN>(ph[u], pl[u], in[0][2 * u], in[0][2 * u + 1], sx, cfin, b[0], b[1]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+        unsigned nh[4], nl[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int it = 4 * s + t;
+            const u32x4 a1 = n1;
+            u32x4 a2;
+            if constexpr (GL) a2 = r2[(it + OFF) % D]; else a2 = n2;
+            if (it + 1 < 32) {
+                n1 = w1[(it + 1) * 64];
+                if constexpr (!GL) n2 = w2[(it + 1) * 64];
+            }
+            if constexpr (GL) {
+                if (it + D < 32) r2[(it + OFF) % D] = n16_ldu(b2, voff, (it + D) * 1024);
+                else if constexpr (NEXT) r2[(it + OFF) % D] = n16_ldu(c2, voff, (it + D - 32) * 1024);
+            }
+            if (s < 7) {
+                const int sn = s + 1;
+                const f32x2 b = bias(sn, t);
+                h2_split_pair<FIN>(nh[t], nl[t], in[sn >> 1][8 * (sn & 1) + 2 * t], in[sn >> 1][8 * (sn & 1) + 2 * t + 1], sx, cfin, b[0], b[1]);
+            }
+            const sp_f16x8 bh = h2_op(ph), bl = h2_op(pl);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h2_wop(a2), bh, acc[t], 0, 0, 0);      // small terms first
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h2_wop(a1), bl, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h2_wop(a1), bh, acc[t], 0, 0, 0);
+#if MGN_SP2_INTERLEAVE
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
+#endif
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            ph[u] = nh[u];
+            pl[u] = nl[u];
+        }
+    }
+    if constexpr (NEXT) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) carry->r[d] = r2[d];
+    }
+}
+template <int NT>
+DEVINL void h2_scale_frag(f32x16 (&x)[NT], float c) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int k = 0; k < 16; ++k) x[t][k] *= c;
+}
+// x <- x c + table (fragment order)
+template <int NT>
+DEVINL void h2_finish_frag(f32x16 (&x)[NT], float c, const float* tab, int h) {
+    const f32x4* t4 = reinterpret_cast<const f32x4*>(tab) + h;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 bv = t4[2 * (4 * t + g)];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) x[t][4 * g + i] = __builtin_fmaf(x[t][4 * g + i], c, bv[i]);
+        }
+}
+
+// ---- cooperative 4-wave tiles (train.hip: k_mlp_fwd_coop / k_mlp_bwd_coop): wave t computes feature block t of acc += in W from the FULL
+// input row it holds, so the row scale is the wave's own business.  wp: the chunk's pieces + t * 64 + lane (hi fragment of k-step s at
+// wp[256 s], lo at wp[2048 + 256 s]); the sixteen fragments of a chain go through a ring four deep that can be primed ahead of time.
+constexpr int H2C_PF = 4;
+struct H2CoopRing { u32x4 r[H2C_PF]; };
+DEVINL const u32x4* h2c_w(const float* chunk, int t, int lane) { return reinterpret_cast<const u32x4*>(chunk + 2 * 128 * 128) + t * 64 + lane; }
+DEVINL u32x4 h2c_frag(const u32x4* wp, int m) { return wp[(m & 1) * 2048 + (m >> 1) * 256]; }      // fragment m of the chain: hi, lo of k-step m / 2
+DEVINL void h2c_prime(H2CoopRing& g, const u32x4* wp) {
+#pragma unroll
+    for (int m = 0; m < H2C_PF; ++m) g.r[m] = h2c_frag(wp, m);
+}
+DEVINL void h2c_chain_primed(f32x16& acc, const f32x16 (&in)[4], const u32x4* wp, H2CoopRing& g, float rsw) {
+    const H2Scale sx = h2_scale(h2_rowmax<true>(in));
+    f32x16 part;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) part[k] = 0.f;
+    unsigned ph[4], pl[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) h2_split_pair<0>(ph[u], pl[u], in[0][2 * u], in[0][2 * u + 1], sx.s);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+        const u32x4 a1 = g.r[(2 * s) % H2C_PF], a2 = g.r[(2 * s + 1) % H2C_PF];
+        if (2 * s + H2C_PF < 16) {
+            g.r[(2 * s) % H2C_PF] = h2c_frag(wp, 2 * s + H2C_PF);
+            g.r[(2 * s + 1) % H2C_PF] = h2c_frag(wp, 2 * s + 1 + H2C_PF);
+        }
+        unsigned nh[4], nl[4];
+        if (s < 7) {
+            const int sn = s + 1;
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                h2_split_pair<0>(nh[u], nl[u], in[sn >> 1][8 * (sn & 1) + 2 * u], in[sn >> 1][8 * (sn & 1) + 2 * u + 1], sx.s);
+        }
+        const sp_f16x8 bh = h2_op(ph), bl = h2_op(pl);
+        part = __builtin_amdgcn_mfma_f32_32x32x16_f16(h2_wop(a2), bh, part, 0, 0, 0);      // small terms first
+        part = __builtin_amdgcn_mfma_f32_32x32x16_f16(h2_wop(a1), bl, part, 0, 0, 0);
+        part = __builtin_amdgcn_mfma_f32_32x32x16_f16(h2_wop(a1), bh, part, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            ph[u] = nh[u];
+            pl[u] = nl[u];
+        }
+    }
+    const float c = sx.rs * rsw;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) acc[k] = __builtin_fmaf(part[k], c, acc[k]);
+}
+
+// out = in W (true units), nothing live across the chain but the input
+DEVINL void h2_chunk_set(f32x16 (&out)[4], const f32x16 (&in)[4], const float* w, int lane, float rsw) {
+    const H2Scale sx = h2_scale(h2_rowmax<true>(in));
+    zero_frag<4>(out);
+    const u32x4* p = reinterpret_cast<const u32x4*>(w);
+    h2_layer_otf<false, 0, 1>(out, in, p, p + 2048, lane, sx.s);
+    const float c = sx.rs * rsw;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int k = 0; k < 16; ++k) out[t][k] *= c;
+}
+// acc += in W without a third array: the accumulator is put INTO the chain's units (a power of two: exact while |acc| x scale < 2^127,
+// i.e. |acc| < 2^19 in the worst case of a 2^-40 row against a 2^-40 chunk), the chain accumulates on top, and it is brought back
+DEVINL void h2_chunk_inplace(f32x16 (&acc)[4], const f32x16 (&in)[4], const float* w, int lane, float rsw) {
+    const H2Scale sx = h2_scale(h2_rowmax<true>(in));
+    const float up = sx.s * (1.0f / rsw), c = sx.rs * rsw;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int k = 0; k < 16; ++k) acc[t][k] *= up;
+    const u32x4* p = reinterpret_cast<const u32x4*>(w);
+    h2_layer_otf<false, 0, 1>(acc, in, p, p + 2048, lane, sx.s);
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int k = 0; k < 16; ++k) acc[t][k] *= c;
+}
+// acc += in W for an fp32 accumulator in TRUE units: the chunk's two fp16 pieces (hi at w, lo 2048 fragments behind; multiplied by
+// 1 / rsw when they were packed) in LDS, the row's scale taken here, the partial sum un-scaled as it is added.  `part`: 64 registers
+// of scratch.  What the streaming training kernels call where they called mfma_chunk.
+DEVINL void h2_chunk(f32x16 (&acc)[4], const f32x16 (&in)[4], f32x16 (&part)[4], const float* w, int lane, float rsw) {
+    const H2Scale sx = h2_scale(h2_rowmax<true>(in));
+    zero_frag<4>(part);
+    const u32x4* p = reinterpret_cast<const u32x4*>(w);
+    h2_layer_otf<false, 0, 1>(part, in, p, p + 2048, lane, sx.s);
+    const float c = sx.rs * rsw;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int k = 0; k < 16; ++k) acc[t][k] = __builtin_fmaf(part[t][k], c, acc[t][k]);
+}
+
 }  // namespace mgn

@@ -41,7 +41,8 @@ struct TrainBwdArgs {
 
 hipError_t launch_mlp_fwd(int L, int nin, const TrainFwdArgs& a, hipStream_t s);
 hipError_t launch_mlp_bwd(int L, int nin, const TrainBwdArgs& a, hipStream_t s);
-bool train_uses_coop(int L, int ntiles);     // the cooperative 4-wave MLP kernels serve this launch size
+bool train_uses_coop(int L, int ntiles);
+int set_train_f16(int on);                 // 1 (default): streaming training kernels at L = 128 on two fp16 pieces / three products, 0: fp32 MFMA; returns the old value     // the cooperative 4-wave MLP kernels serve this launch size
 
 // Two L x L products per row tile (the per-node halves of the factored first edge layer):
 //   split  (X1 == null):  OUT0 = X0 W0,  OUT1 = X0 W1                     (P, Q of the forward)
@@ -71,13 +72,13 @@ int wgrad_blocks_of_job(int64_t launch_rows, int64_t job_rows);   // blocks of a
 // kind 1 / 2: the three exact bf16 pieces (hi, mid, lo; 16 384 each) at wsp + off in the 32x32x16 / 16x16x32 fragment order;
 // kind 3: one bf16 copy at wbf + off (bf16 storage mode);
 // kind 4: the two fp16 pieces (hi, lo; 16 384 each) of the chunk times `scale` (a power of two) at wsp + off, 32x32x16 fragment order
-// (split_common.hpp).  The host functions of mgn_api.cpp with the same names are the specification.
+// (split_common.hpp); kind 5: the same in the 16x16x32 fragment order.  The host functions of mgn_api.cpp with the same names are the specification.
 struct WPackJob { int kind; long long off, src; int ldw, kbase; float scale; };
 hipError_t launch_pack_weights(int L, const WPackJob* jobs, int njobs, const float* params, float* wfrag, uint16_t* wsp, uint16_t* wbf, hipStream_t s);
 // one packed copy of the training weights: kind 0 = an L x L chunk in fragment order + its t-major copy at + L * L, from rows [r0, r0 + nr)
 // x cols [0, nc) of the matrix at params + src (leading dimension ldw; src < 0: the identity), zero-padded, transposed on request;
 // kind 1 = T_COUNT * L table floats copied from tabs + src
-struct PackJob { long long off, src; int ldw, r0, nr, nc, transpose, kind; };
+struct PackJob { long long off, src; int ldw, r0, nr, nc, transpose, kind; float scale; };   // scale > 0 (L = 128): + the chunk's two fp16 pieces times scale at off + 2 L L (32x32x16 fragment order: hi, lo) and 1 / scale at off + 3 L L
 hipError_t launch_pack_train(int L, const PackJob* jobs, int njobs, const float* params, const float* tabs, float* out, hipStream_t s);
 hipError_t launch_wgrad(int L, WgradBatch wb, int64_t rows, hipStream_t s);
 // out[r * cols + c] = sum_b partial[b * block_stride + r * ld + c]   (fixed order: bitwise reproducible), one job per blockIdx.y

@@ -11,6 +11,7 @@
 #include <unordered_map>
 
 #include "frag.hpp"
+#include "split_common.hpp"
 
 namespace mgn {
 
@@ -65,7 +66,9 @@ DEVINL void stage_chunk(float* dst, const float* __restrict__ src) {
 #define CP_PREFETCH(next)                                                        \
     do {                                                                         \
         const float* nx_ = (next);                                               \
+        if (H2) __builtin_amdgcn_sched_barrier(0);     /* (H2: the staging registers must not overlap the chain's 240) */ \
         if (nx_) stage_chunk<CH, 64 * WPB>(smem + (cur ^ 1) * CH, nx_);                    \
+        if (H2) __builtin_amdgcn_sched_barrier(0);                               \
     } while (0)
 #define CP_W() (smem + cur * CH)
 #define CP_ADVANCE()     \
@@ -74,9 +77,28 @@ DEVINL void stage_chunk(float* dst, const float* __restrict__ src) {
         cur ^= 1;        \
     } while (0)
 
+// One chunk of a chain: acc += in W.  H2 (round 5: L = 128, the streaming kernels of large launches): W staged as its two fp16 pieces
+// (packed behind the two fp32 copies of every chunk, + 2 CH, times the power of two whose inverse sits at + 3 CH), the input split on
+// the fly with its row scale, three piece products -- 96 v_mfma_f32_32x32x16_f16 of 32 cycles instead of 256 v_mfma_f32_32x32x2_f32 of
+// 64 (split_common.hpp: h2_chunk_inplace).  Otherwise the fp32 MFMA chain on the fragment-order copy.
+template <int NT, bool H2>
+DEVINL void train_chunk(f32x16 (&acc)[NT], const f32x16 (&in)[NT], f32x16 (&part)[NT], const float* wlds, int lane, float rsw) {
+    if constexpr (H2) {
+        static_assert(NT == 4, "the fp16 pieces exist at L = 128");
+        (void)part;
+        h2_chunk_inplace(acc, in, wlds, lane, rsw);      // (in place: with a separate partial sum three 64-register arrays live across the chain and
+                                                         //  the multi-block kernels spill under two waves per SIMD)
+    } else {
+        mfma_chunk<NT, true>(acc, in, wlds, lane);
+    }
+}
+// where a chunk's staged data starts, and the inverse of its scale
+#define HW(p) (H2 ? ((p) ? (p) + 2 * CH : nullptr) : (p))
+#define HRS(p) (H2 ? (p)[3 * CH] : 1.f)
+
 // WPB waves (= tiles) per block share the staged chunks: 4, or 8 on large launches (two waves per SIMD: one's loads and stores
 // overlap the other's MFMA chain; 128 KiB of LDS allow one block per CU either way)
-template <int NT, int NIN, int WPB>
+template <int NT, int NIN, int WPB, bool H2 = false>
 __global__ __launch_bounds__(64 * WPB) void k_mlp_fwd(const TrainFwdArgs a) {
     constexpr int L = 32 * NT, CH = L * L;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -88,7 +110,7 @@ __global__ __launch_bounds__(64 * WPB) void k_mlp_fwd(const TrainFwdArgs a) {
     OPAQUE_LANE();
     RowRef rw = row_of(tile, c, a.rows);
     rw.valid = rw.valid && active;
-    CP_PRIME(a.W1[0]);
+    CP_PRIME(HW(a.W1[0]));
     f32x16 x[NT], acc[NT], y[NT];
     tab_frag<NT>(acc, a.tabs + T_B1 * L, h);
 #pragma unroll
@@ -96,22 +118,22 @@ __global__ __launch_bounds__(64 * WPB) void k_mlp_fwd(const TrainFwdArgs a) {
         if (a.PRE[i]) add_frag<NT>(acc, row_ptr(a.PRE[i], a.preidx[i] ? (int64_t)a.preidx[i][rw.rr] : rw.rr, L, h), STRIDE_ROW);
 #pragma unroll
     for (int j = 0; j < NIN; ++j) {
-        CP_PREFETCH(j + 1 < NIN ? a.W1[j + 1] : a.W2);
+        CP_PREFETCH(HW(j + 1 < NIN ? a.W1[j + 1] : a.W2));
         const int64_t src = a.xidx[j] ? (int64_t)a.xidx[j][rw.rr] : rw.rr;
         load_frag<NT>(x, row_ptr(a.X[j], src, L, h), STRIDE_ROW);
-        mfma_chunk<NT, true>(acc, x, CP_W(), lane);
+        train_chunk<NT, H2>(acc, x, y, CP_W(), lane, HRS(a.W1[j]));
         CP_ADVANCE();
     }
     relu_frag<NT>(acc);
     if (a.H1 && rw.valid) store_frag<NT>(row_ptr(a.H1, rw.row, L, h), STRIDE_ROW, acc);
-    CP_PREFETCH(a.W3);
+    CP_PREFETCH(HW(a.W3));
     tab_frag<NT>(y, a.tabs + T_B2 * L, h);
-    mfma_chunk<NT, true>(y, acc, CP_W(), lane);
+    train_chunk<NT, H2>(y, acc, x, CP_W(), lane, HRS(a.W2));
     CP_ADVANCE();
     relu_frag<NT>(y);
     if (a.H2 && rw.valid) store_frag<NT>(row_ptr(a.H2, rw.row, L, h), STRIDE_ROW, y);
     tab_frag<NT>(acc, a.tabs + T_B3 * L, h);
-    mfma_chunk<NT, true>(acc, y, CP_W(), lane);
+    train_chunk<NT, H2>(acc, y, x, CP_W(), lane, HRS(a.W3));
     if (a.Y && rw.valid) store_frag<NT>(row_ptr(a.Y, rw.row, L, h), STRIDE_ROW, acc);
     if (a.ln) layer_norm_frag<NT>(acc, a.tabs + T_GAMMA * L, a.tabs + T_BETA * L, h);
     if (a.LNOUT && rw.valid) store_frag<NT>(row_ptr(a.LNOUT, rw.row, L, h), STRIDE_ROW, acc);
@@ -132,7 +154,7 @@ DEVINL void mask_by_relu(f32x16 (&g)[NT], const f32x16 (&act)[NT]) {
         for (int k = 0; k < 16; ++k) g[t][k] = act[t][k] > 0.f ? g[t][k] : 0.f;
 }
 
-template <int NT, int NIN, int WPB>
+template <int NT, int NIN, int WPB, bool H2 = false>
 __global__ __launch_bounds__(64 * WPB) void k_mlp_bwd(const TrainBwdArgs a) {
     constexpr int L = 32 * NT, CH = L * L;
     constexpr float invL = 1.0f / L;
@@ -145,7 +167,7 @@ __global__ __launch_bounds__(64 * WPB) void k_mlp_bwd(const TrainBwdArgs a) {
     OPAQUE_LANE();
     RowRef rw = row_of(tile, c, a.rows);
     rw.valid = rw.valid && active;
-    CP_PRIME(a.W3T);
+    CP_PRIME(HW(a.W3T));
     f32x16 g[NT], y[NT], acc[NT];
     load_frag<NT>(g, row_ptr(a.G0, rw.rr, L, h), STRIDE_ROW);
     if (a.G1) add_frag<NT>(g, row_ptr(a.G1, a.g1idx ? (int64_t)a.g1idx[rw.rr] : rw.rr, L, h), STRIDE_ROW);
@@ -200,9 +222,9 @@ __global__ __launch_bounds__(64 * WPB) void k_mlp_bwd(const TrainBwdArgs a) {
             for (int k = 0; k < 16; ++k) g[t][k] = rstd * (g[t][k] - m1 - y[t][k] * m2);
     }
     if (rw.valid) store_frag<NT>(row_ptr(a.GY, rw.row, L, h), STRIDE_ROW, g);
-    CP_PREFETCH(a.W2T);
+    CP_PREFETCH(HW(a.W2T));
     zero_frag<NT>(acc);
-    mfma_chunk<NT, true>(acc, g, CP_W(), lane);               // gradient at H2
+    train_chunk<NT, H2>(acc, g, y, CP_W(), lane, HRS(a.W3T)); // gradient at H2
     CP_ADVANCE();
     load_frag<NT>(y, row_ptr(a.H2, rw.rr, L, h), STRIDE_ROW);
     mask_by_relu<NT>(acc, y);
@@ -213,9 +235,9 @@ __global__ __launch_bounds__(64 * WPB) void k_mlp_bwd(const TrainBwdArgs a) {
 #pragma unroll
     for (int j = NIN - 1; j >= 0; --j)
         if (a.W1T[j]) { nxt[j] = first >= 0 ? a.W1T[first] : nullptr; first = j; }
-    CP_PREFETCH(first >= 0 ? a.W1T[first] : nullptr);
+    CP_PREFETCH(HW(first >= 0 ? a.W1T[first] : nullptr));
     zero_frag<NT>(g);
-    mfma_chunk<NT, true>(g, acc, CP_W(), lane);               // gradient at H1
+    train_chunk<NT, H2>(g, acc, y, CP_W(), lane, HRS(a.W2T)); // gradient at H1
     CP_ADVANCE();
     load_frag<NT>(y, row_ptr(a.H1, rw.rr, L, h), STRIDE_ROW);
     mask_by_relu<NT>(g, y);
@@ -223,10 +245,10 @@ __global__ __launch_bounds__(64 * WPB) void k_mlp_bwd(const TrainBwdArgs a) {
 #pragma unroll
     for (int j = 0; j < NIN; ++j) {
         if (!a.W1T[j]) continue;
-        CP_PREFETCH(nxt[j]);
+        CP_PREFETCH(HW(nxt[j]));
         if (a.GXadd[j]) load_frag<NT>(acc, row_ptr(a.GXadd[j], rw.rr, L, h), STRIDE_ROW);
         else zero_frag<NT>(acc);
-        mfma_chunk<NT, true>(acc, g, CP_W(), lane);
+        train_chunk<NT, H2>(acc, g, y, CP_W(), lane, HRS(a.W1T[j]));
         CP_ADVANCE();
         if (rw.valid) store_frag<NT>(row_ptr(a.GX[j], rw.row, L, h), STRIDE_ROW, acc);
     }
@@ -250,7 +272,30 @@ DEVINL void add_quarter(f32x16& q, const f32x4* __restrict__ p, int stride, int 
 // The chains of these kernels pin their weight ring with scheduling fences (coop_chain_primed<true>, frag.hpp): with many
 // row-fragment registers live hipcc otherwise sinks each request to just before its use and every k-step group waits a full
 // L2 round trip (3-4 x the chain's MFMA time).
-template <int NIN>
+// a chain of the cooperative kernels on the fp32 MFMA pipe (t-major copy of the chunk, frag.hpp) or, H2, on two fp16 pieces (the pieces
+// packed behind the chunk's fp32 copies; split_common.hpp: h2c_chain_primed).  W: the chunk's base.
+template <bool H2> struct TRing;
+template <> struct TRing<false> { CoopRing r; };
+template <> struct TRing<true> { H2CoopRing r; };
+template <bool H2>
+DEVINL void t_prime(TRing<H2>& g, const float* W, int tq, int lane) {
+    if constexpr (H2) h2c_prime(g.r, h2c_w(W, tq, lane));
+    else coop_prime(g.r, W + 128 * 128 + tq * 4096, lane);
+}
+template <bool H2>
+DEVINL void t_chain_primed(f32x16& acc, const f32x16 (&in)[4], const float* W, int tq, int lane, TRing<H2>& g) {
+    if constexpr (H2) h2c_chain_primed(acc, in, h2c_w(W, tq, lane), g.r, W[3 * 128 * 128]);
+    else coop_chain_primed<true>(acc, in, W + 128 * 128 + tq * 4096, lane, g.r);
+}
+template <bool H2>
+DEVINL void t_chain(f32x16& acc, const f32x16 (&in)[4], const float* W, int tq, int lane) {
+    TRing<H2> g;
+    t_prime<H2>(g, W, tq, lane);
+    __builtin_amdgcn_sched_barrier(0);
+    t_chain_primed<H2>(acc, in, W, tq, lane, g);
+}
+
+template <int NIN, bool H2 = false>
 __global__ __launch_bounds__(256, 2) void k_mlp_fwd_coop(const TrainFwdArgs a) {
     constexpr int L = 128, CH = L * L, QS = 4096;     // QS: one wave's t-slice of a chunk
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -266,7 +311,7 @@ __global__ __launch_bounds__(256, 2) void k_mlp_fwd_coop(const TrainFwdArgs a) {
 #pragma unroll
         for (int j = 0; j < NIN; ++j) src[j] = a.xidx[j] ? (int64_t)a.xidx[j][rw.rr] : rw.rr;
         f32x16 xa[4], xb[4], acc;
-        CoopRing r2, r3;
+        TRing<H2> r2, r3;
         load_frag<4>(xa, row_ptr(a.X[0], src[0], L, h), STRIDE_ROW);
         if constexpr (NIN > 1) load_frag<4>(xb, row_ptr(a.X[1], src[1], L, h), STRIDE_ROW);
         tab_quarter(acc, a.tabs + T_B1 * L, tq, h);
@@ -276,29 +321,29 @@ __global__ __launch_bounds__(256, 2) void k_mlp_fwd_coop(const TrainFwdArgs a) {
         // Fences: without them hipcc sinks the (gathered, slow) row loads INTO the MFMA chains, a few pieces ahead of their use,
         // where they queue in front of the weight ring's loads (vmcnt retires in order) and every k-step waits for memory.
         PHASE_FENCE();
-        coop_chain<true>(acc, xa, a.W1[0] + CH + tq * QS, lane);
+        t_chain<H2>(acc, xa, a.W1[0], tq, lane);
         PHASE_FENCE();
         if constexpr (NIN > 2) load_frag<4>(xa, row_ptr(a.X[2], src[2], L, h), STRIDE_ROW);
-        if constexpr (NIN <= 2) coop_prime(r2, a.W2 + CH + tq * QS, lane);
+        if constexpr (NIN <= 2) t_prime<H2>(r2, a.W2, tq, lane);
         PHASE_FENCE();
-        if constexpr (NIN > 1) coop_chain<true>(acc, xb, a.W1[1] + CH + tq * QS, lane);
+        if constexpr (NIN > 1) t_chain<H2>(acc, xb, a.W1[1], tq, lane);
         PHASE_FENCE();
         if constexpr (NIN > 2) {
-            coop_prime(r2, a.W2 + CH + tq * QS, lane);
+            t_prime<H2>(r2, a.W2, tq, lane);
             PHASE_FENCE();
-            coop_chain<true>(acc, xa, a.W1[2] + CH + tq * QS, lane);
+            t_chain<H2>(acc, xa, a.W1[2], tq, lane);
         }
         relu_quarter(acc);
         if (a.H1 && rw.valid) store_quarter(row_ptr(a.H1, rw.row, L, h), STRIDE_ROW, tq, acc);
         coop_exchange(xa, acc, xch0, wave, lane);
-        coop_prime(r3, a.W3 + CH + tq * QS, lane);
+        t_prime<H2>(r3, a.W3, tq, lane);
         tab_quarter(acc, a.tabs + T_B2 * L, tq, h);
-        coop_chain_primed<true>(acc, xa, a.W2 + CH + tq * QS, lane, r2);
+        t_chain_primed<H2>(acc, xa, a.W2, tq, lane, r2);
         relu_quarter(acc);
         if (a.H2 && rw.valid) store_quarter(row_ptr(a.H2, rw.row, L, h), STRIDE_ROW, tq, acc);
         coop_exchange(xb, acc, xch1, wave, lane);
         tab_quarter(acc, a.tabs + T_B3 * L, tq, h);
-        coop_chain_primed<true>(acc, xb, a.W3 + CH + tq * QS, lane, r3);
+        t_chain_primed<H2>(acc, xb, a.W3, tq, lane, r3);
         if (a.Y && rw.valid) store_quarter(row_ptr(a.Y, rw.row, L, h), STRIDE_ROW, tq, acc);
         if (a.ln) {
             coop_exchange(xa, acc, xch0, wave, lane);                  // full pre-LN row for the statistics
@@ -319,7 +364,7 @@ DEVINL void mask_quarter(f32x16& g, const f32x16& act) {
     for (int k = 0; k < 16; ++k) g[k] = act[k] > 0.f ? g[k] : 0.f;
 }
 
-template <int NIN>
+template <int NIN, bool H2 = false>
 __global__ __launch_bounds__(256, 2) void k_mlp_bwd_coop(const TrainBwdArgs a) {
     constexpr int L = 128, CH = L * L, QS = 4096;
     constexpr float invL = 1.0f / L;
@@ -333,8 +378,8 @@ __global__ __launch_bounds__(256, 2) void k_mlp_bwd_coop(const TrainBwdArgs a) {
         OPAQUE_LANE();
         const RowRef rw = row_of(tile, c, a.rows);
         f32x16 g[4], y[4], acc, q;
-        CoopRing r3, r2;
-        coop_prime(r3, a.W3T + CH + tq * QS, lane);
+        TRing<H2> r3, r2;
+        t_prime<H2>(r3, a.W3T, tq, lane);
         // every wave holds the full upstream row (it is the B operand of the first chain) and repeats the row statistics
         load_frag<4>(g, row_ptr(a.G0, rw.rr, L, h), STRIDE_ROW);
         if (a.G1) add_frag<4>(g, row_ptr(a.G1, a.g1idx ? (int64_t)a.g1idx[rw.rr] : rw.rr, L, h), STRIDE_ROW);
@@ -388,12 +433,12 @@ __global__ __launch_bounds__(256, 2) void k_mlp_bwd_coop(const TrainBwdArgs a) {
                 for (int k = 0; k < 16; ++k) g[t][k] = rstd * (g[t][k] - m1 - y[t][k] * m2);
         }
         if (rw.valid) store_quarter(row_ptr(a.GY, rw.row, L, h), STRIDE_ROW, tq, pick_quarter(g, tq));
-        coop_prime(r2, a.W2T + CH + tq * QS, lane);
+        t_prime<H2>(r2, a.W2T, tq, lane);
         load_quarter(q, row_ptr(a.H2, rw.rr, L, h), STRIDE_ROW, tq);
         PHASE_FENCE();                                                 // (see k_mlp_fwd_coop: loads stay outside the chains)
 #pragma unroll
         for (int k = 0; k < 16; ++k) acc[k] = 0.f;
-        coop_chain_primed<true>(acc, g, a.W3T + CH + tq * QS, lane, r3);     // gradient at H2
+        t_chain_primed<H2>(acc, g, a.W3T, tq, lane, r3);     // gradient at H2
         mask_quarter(acc, q);
         if (rw.valid) store_quarter(row_ptr(a.GZ2, rw.row, L, h), STRIDE_ROW, tq, acc);
         coop_exchange(y, acc, xch0, wave, lane);
@@ -401,7 +446,7 @@ __global__ __launch_bounds__(256, 2) void k_mlp_bwd_coop(const TrainBwdArgs a) {
         PHASE_FENCE();
 #pragma unroll
         for (int k = 0; k < 16; ++k) acc[k] = 0.f;
-        coop_chain_primed<true>(acc, y, a.W2T + CH + tq * QS, lane, r2);     // gradient at H1
+        t_chain_primed<H2>(acc, y, a.W2T, tq, lane, r2);     // gradient at H1
         mask_quarter(acc, q);
         if (rw.valid) store_quarter(row_ptr(a.GZ1, rw.row, L, h), STRIDE_ROW, tq, acc);
         coop_exchange(g, acc, xch1, wave, lane);
@@ -413,7 +458,7 @@ __global__ __launch_bounds__(256, 2) void k_mlp_bwd_coop(const TrainBwdArgs a) {
 #pragma unroll
                 for (int k = 0; k < 16; ++k) acc[k] = 0.f;
             }
-            coop_chain<true>(acc, g, a.W1T[j] + CH + tq * QS, lane);
+            t_chain<H2>(acc, g, a.W1T[j], tq, lane);
             if (rw.valid) store_quarter(row_ptr(a.GX[j], rw.row, L, h), STRIDE_ROW, tq, acc);
         }
         __syncthreads();
@@ -423,7 +468,7 @@ __global__ __launch_bounds__(256, 2) void k_mlp_bwd_coop(const TrainBwdArgs a) {
 // ================================================================================================
 // two L x L products per row tile: the per-node halves of the factored first edge layer (see train.h, Lin2Args)
 // ================================================================================================
-template <int NT, int WPB>
+template <int NT, int WPB, bool H2 = false>
 __global__ __launch_bounds__(64 * WPB) void k_lin2(const Lin2Args a) {
     constexpr int L = 32 * NT, CH = L * L;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -435,10 +480,29 @@ __global__ __launch_bounds__(64 * WPB) void k_lin2(const Lin2Args a) {
     OPAQUE_LANE();
     RowRef rw = row_of(tile, c, a.rows);
     rw.valid = rw.valid && active;
-    CP_PRIME(a.W0);
+    CP_PRIME(HW(a.W0));
     f32x16 x[NT], acc[NT];
     load_frag<NT>(x, row_ptr(a.X0, rw.rr, L, h), STRIDE_ROW);
-    CP_PREFETCH(a.W1);
+    CP_PREFETCH(HW(a.W1));
+    if constexpr (H2) {
+        // (fp16 pieces: nothing but the input row lives across a chain -- with x, the accumulator and the partial sum all live the
+        // allocator spills 150 registers under two waves per SIMD)
+        if (a.X1) {      // merge: OUT0 = ADD + X0 W0 + X1 W1
+            h2_chunk_set(acc, x, CP_W(), lane, HRS(a.W0));
+            CP_ADVANCE();
+            if (a.ADD) add_frag<NT>(acc, row_ptr(a.ADD, rw.rr, L, h), STRIDE_ROW);
+            load_frag<NT>(x, row_ptr(a.X1, rw.rr, L, h), STRIDE_ROW);
+            h2_chunk_inplace(acc, x, CP_W(), lane, HRS(a.W1));
+            if (rw.valid) store_frag<NT>(row_ptr(a.OUT0, rw.row, L, h), STRIDE_ROW, acc);
+        } else {         // split: OUT0 = X0 W0, OUT1 = X0 W1
+            h2_chunk_set(acc, x, CP_W(), lane, HRS(a.W0));
+            CP_ADVANCE();
+            if (rw.valid) store_frag<NT>(row_ptr(a.OUT0, rw.row, L, h), STRIDE_ROW, acc);
+            h2_chunk_set(acc, x, CP_W(), lane, HRS(a.W1));
+            if (rw.valid) store_frag<NT>(row_ptr(a.OUT1, rw.row, L, h), STRIDE_ROW, acc);
+        }
+        return;
+    }
     if (a.X1) {      // merge
         if (a.ADD) load_frag<NT>(acc, row_ptr(a.ADD, rw.rr, L, h), STRIDE_ROW);
         else zero_frag<NT>(acc);
@@ -532,6 +596,121 @@ __global__ __launch_bounds__(64 * NT) void k_wgrad(const WgradBatch wb) {
         for (int t = 0; t < NT; ++t) {
             const float sb = bs[t] + __shfl_xor(bs[t], 32, 64);
             if (kk == 0) jb.pb[(size_t)blockIdx.x * L + 32 * t + m] = sb;
+        }
+    }
+}
+
+// The same on two fp16 pieces (L = 128; round 5): the reduction dimension is the ROW index, so an operand's scale has to be the same for
+// all rows of a k-step -- one power of two per wave for X and one for G, taken from a RUNNING maximum over the block's rows (the maximum
+// of the first step to begin with; when a later step exceeds it -- a wave-uniform branch, a handful of times per block -- the
+// accumulators are brought down by the same power of two).  v_mfma_f32_32x32x16_f16: A = X^T (lane (m, kh): feature 32 ti + m, rows
+// 8 kh .. 8 kh + 7 of the 16-row step), B = G (lane (n, kh): feature 32 t + n, the same rows); 12 MFMAs of 32 cycles per 16 rows
+// instead of 32 of 64.  Against the float64 oracle the gradients stay inside the tolerances of the fp32 kernels (the sum over thousands
+// of rows dominates both).
+DEVINL float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v = __builtin_fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__global__ __launch_bounds__(256) void k_wgrad_h(const WgradBatch wb) {
+    constexpr int NT = 4, L = 128;
+    const WgradJob& jb = wb.job[blockIdx.y];
+    const int64_t r0 = (int64_t)blockIdx.x * wb.rows_per_block;
+    if (r0 >= jb.rows) return;
+    const int64_t r1 = r0 + wb.rows_per_block < jb.rows ? r0 + wb.rows_per_block : jb.rows;
+    const int lane = threadIdx.x & 63, m = lane & 31, kh = lane >> 5;
+    const int ti = threadIdx.x >> 6;
+    const float* __restrict__ X = jb.X;
+    const float* __restrict__ G = jb.G;
+    const int32_t* __restrict__ xidx = jb.xidx;
+    const bool with_w = jb.pw != nullptr;
+    if (!with_w && ti != 0) return;              // column sums only: one wave
+    f32x16 acc[NT];
+    float bs[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        bs[t] = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) acc[t][k] = 0.f;
+    }
+    unsigned ea = 0, eb = 0;                     // exponent fields of the running maxima of |X| and |G| (wave-uniform; 0: none yet)
+    for (int64_t q = r0; q < r1; q += 16) {
+        float av[8], bv[NT][8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int64_t row = q + 8 * kh + u;
+            const bool ok = row < r1;
+            const int64_t rr = ok ? row : r0;
+            float xa = 0.f;
+            if (with_w) {
+                const int64_t src = xidx ? (int64_t)xidx[rr] : rr;
+                xa = X[src * L + 32 * ti + m];
+            }
+            av[u] = ok ? xa : 0.f;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const float gb = G[rr * L + 32 * t + m];
+                bv[t][u] = ok ? gb : 0.f;
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int u = 0; u < 8; ++u) bs[t] += bv[t][u];
+        if (!with_w) continue;
+        float ma = 0.f, mb = 0.f;
+#pragma unroll
+        for (int u = 0; u < 8; u += 2) ma = __builtin_fmaxf(ma, __builtin_fmaxf(__builtin_fabsf(av[u]), __builtin_fabsf(av[u + 1])));
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int u = 0; u < 8; u += 2) mb = __builtin_fmaxf(mb, __builtin_fmaxf(__builtin_fabsf(bv[t][u]), __builtin_fabsf(bv[t][u + 1])));
+        unsigned na = __builtin_amdgcn_readfirstlane(sp_u(wave_max(ma)) & 0x7f800000u);
+        unsigned nb = __builtin_amdgcn_readfirstlane(sp_u(wave_max(mb)) & 0x7f800000u);
+        na = na > H2_EXP_MIN ? na : H2_EXP_MIN;
+        nb = nb > H2_EXP_MIN ? nb : H2_EXP_MIN;
+        if (na > ea || nb > eb) {                // a larger operand than any before: the units of the accumulators follow (first step: from nothing)
+            const unsigned ta = na > ea ? na : ea, tb_ = nb > eb ? nb : eb;
+            if (ea != 0) {
+                const float down = sp_f((127u << 23) - (ta - ea) - (tb_ - eb));      // 2^-(exponent steps of X + of G)
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) acc[t][k] *= down;
+            }
+            ea = ta;
+            eb = tb_;
+        }
+        const float sa = sp_f((268u << 23) - ea), sb = sp_f((268u << 23) - eb);      // (h2_scale's s for the running maxima)
+        unsigned ah[4], al[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) h2_split_pair<0>(ah[u], al[u], av[2 * u], av[2 * u + 1], sa);
+        const sp_f16x8 Ah = h2_op(ah), Al = h2_op(al);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            unsigned bh[4], bl[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) h2_split_pair<0>(bh[u], bl[u], bv[t][2 * u], bv[t][2 * u + 1], sb);
+            const sp_f16x8 Bh = h2_op(bh), Bl = h2_op(bl);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Al, Bh, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, Bl, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, Bh, acc[t], 0, 0, 0);
+        }
+    }
+    // D layout of the 32x32 MFMA: register r of lane l holds D[(r&3) + 8(r>>2) + 4(l>>5)][l&31]
+    if (with_w) {
+        const float c = ea ? sp_f(ea - (14u << 23)) * sp_f(eb - (14u << 23)) : 0.f;      // 1 / (sa sb)
+        float* pw = jb.pw + (size_t)blockIdx.x * L * L;
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) pw[(size_t)(32 * ti + (r & 3) + 8 * (r >> 2) + 4 * kh) * L + 32 * t + m] = acc[t][r] * c;
+    }
+    if (ti == 0 && jb.pb) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const float sb_ = bs[t] + __shfl_xor(bs[t], 32, 64);
+            if (kh == 0) jb.pb[(size_t)blockIdx.x * L + 32 * t + m] = sb_;
         }
     }
 }
@@ -777,10 +956,13 @@ static hipError_t launch_coop(K kern, const A& a, int ntiles, hipStream_t s) {
 }
 
 bool train_uses_coop(int L, int ntiles) { return train_coop(L, ntiles); }
+// the streaming kernels at L = 128 compute on two fp16 pieces per operand, three piece products (train_chunk); MGN_TRAIN_F16=0: fp32 MFMA
+static int g_train_f16 = [] { const char* e = getenv("MGN_TRAIN_F16"); return e ? atoi(e) : 1; }();
+int set_train_f16(int on) { const int old = g_train_f16; g_train_f16 = on; return old; }
 
 hipError_t launch_lin2(int L, const Lin2Args& a, hipStream_t s) {
-    if (train_wpb8(L, a.ntiles)) return launch_tiles(k_lin2<4, 8>, a, a.ntiles, L, s, 8);
-    if (L == 128) return launch_tiles(k_lin2<4, 4>, a, a.ntiles, L, s);
+    if (train_wpb8(L, a.ntiles)) return g_train_f16 ? launch_tiles(k_lin2<4, 8, true>, a, a.ntiles, L, s, 8) : launch_tiles(k_lin2<4, 8>, a, a.ntiles, L, s, 8);
+    if (L == 128) return g_train_f16 ? launch_tiles(k_lin2<4, 4, true>, a, a.ntiles, L, s) : launch_tiles(k_lin2<4, 4>, a, a.ntiles, L, s);
     if (L == 64) return launch_tiles(k_lin2<2, 4>, a, a.ntiles, L, s);
     if (L == 32) return launch_tiles(k_lin2<1, 4>, a, a.ntiles, L, s);
     return hipErrorInvalidValue;
@@ -788,15 +970,30 @@ hipError_t launch_lin2(int L, const Lin2Args& a, hipStream_t s) {
 
 hipError_t launch_mlp_fwd(int L, int nin, const TrainFwdArgs& a, hipStream_t s) {
     if (train_coop(L, a.ntiles)) {
+        if (g_train_f16) {
+            if (nin == 1) return launch_coop(k_mlp_fwd_coop<1, true>, a, a.ntiles, s);
+            if (nin == 2) return launch_coop(k_mlp_fwd_coop<2, true>, a, a.ntiles, s);
+            if (nin == 3) return launch_coop(k_mlp_fwd_coop<3, true>, a, a.ntiles, s);
+        }
         if (nin == 1) return launch_coop(k_mlp_fwd_coop<1>, a, a.ntiles, s);
         if (nin == 2) return launch_coop(k_mlp_fwd_coop<2>, a, a.ntiles, s);
         if (nin == 3) return launch_coop(k_mlp_fwd_coop<3>, a, a.ntiles, s);
     }
 #define FWD_CASE(NT_, NIN_) if (L == 32 * NT_ && nin == NIN_) return launch_tiles(k_mlp_fwd<NT_, NIN_, 4>, a, a.ntiles, L, s)
     if (train_wpb8(L, a.ntiles)) {
+        if (g_train_f16) {
+            if (nin == 1) return launch_tiles(k_mlp_fwd<4, 1, 8, true>, a, a.ntiles, L, s, 8);
+            if (nin == 2) return launch_tiles(k_mlp_fwd<4, 2, 8, true>, a, a.ntiles, L, s, 8);
+            if (nin == 3) return launch_tiles(k_mlp_fwd<4, 3, 8, true>, a, a.ntiles, L, s, 8);
+        }
         if (nin == 1) return launch_tiles(k_mlp_fwd<4, 1, 8>, a, a.ntiles, L, s, 8);
         if (nin == 2) return launch_tiles(k_mlp_fwd<4, 2, 8>, a, a.ntiles, L, s, 8);
         if (nin == 3) return launch_tiles(k_mlp_fwd<4, 3, 8>, a, a.ntiles, L, s, 8);
+    }
+    if (L == 128 && g_train_f16) {
+        if (nin == 1) return launch_tiles(k_mlp_fwd<4, 1, 4, true>, a, a.ntiles, L, s);
+        if (nin == 2) return launch_tiles(k_mlp_fwd<4, 2, 4, true>, a, a.ntiles, L, s);
+        if (nin == 3) return launch_tiles(k_mlp_fwd<4, 3, 4, true>, a, a.ntiles, L, s);
     }
     FWD_CASE(4, 1); FWD_CASE(4, 2); FWD_CASE(4, 3);
     FWD_CASE(2, 1); FWD_CASE(2, 2); FWD_CASE(2, 3);
@@ -807,15 +1004,30 @@ hipError_t launch_mlp_fwd(int L, int nin, const TrainFwdArgs& a, hipStream_t s) 
 
 hipError_t launch_mlp_bwd(int L, int nin, const TrainBwdArgs& a, hipStream_t s) {
     if (train_coop(L, a.ntiles)) {
+        if (g_train_f16) {
+            if (nin == 1) return launch_coop(k_mlp_bwd_coop<1, true>, a, a.ntiles, s);
+            if (nin == 2) return launch_coop(k_mlp_bwd_coop<2, true>, a, a.ntiles, s);
+            if (nin == 3) return launch_coop(k_mlp_bwd_coop<3, true>, a, a.ntiles, s);
+        }
         if (nin == 1) return launch_coop(k_mlp_bwd_coop<1>, a, a.ntiles, s);
         if (nin == 2) return launch_coop(k_mlp_bwd_coop<2>, a, a.ntiles, s);
         if (nin == 3) return launch_coop(k_mlp_bwd_coop<3>, a, a.ntiles, s);
     }
 #define BWD_CASE(NT_, NIN_) if (L == 32 * NT_ && nin == NIN_) return launch_tiles(k_mlp_bwd<NT_, NIN_, 4>, a, a.ntiles, L, s)
     if (train_wpb8(L, a.ntiles)) {
+        if (g_train_f16) {
+            if (nin == 1) return launch_tiles(k_mlp_bwd<4, 1, 8, true>, a, a.ntiles, L, s, 8);
+            if (nin == 2) return launch_tiles(k_mlp_bwd<4, 2, 8, true>, a, a.ntiles, L, s, 8);
+            if (nin == 3) return launch_tiles(k_mlp_bwd<4, 3, 8, true>, a, a.ntiles, L, s, 8);
+        }
         if (nin == 1) return launch_tiles(k_mlp_bwd<4, 1, 8>, a, a.ntiles, L, s, 8);
         if (nin == 2) return launch_tiles(k_mlp_bwd<4, 2, 8>, a, a.ntiles, L, s, 8);
         if (nin == 3) return launch_tiles(k_mlp_bwd<4, 3, 8>, a, a.ntiles, L, s, 8);
+    }
+    if (L == 128 && g_train_f16) {
+        if (nin == 1) return launch_tiles(k_mlp_bwd<4, 1, 4, true>, a, a.ntiles, L, s);
+        if (nin == 2) return launch_tiles(k_mlp_bwd<4, 2, 4, true>, a, a.ntiles, L, s);
+        if (nin == 3) return launch_tiles(k_mlp_bwd<4, 3, 4, true>, a, a.ntiles, L, s);
     }
     BWD_CASE(4, 1); BWD_CASE(4, 2); BWD_CASE(4, 3);
     BWD_CASE(2, 1); BWD_CASE(2, 2); BWD_CASE(2, 3);
@@ -825,8 +1037,9 @@ hipError_t launch_mlp_bwd(int L, int nin, const TrainBwdArgs& a, hipStream_t s) 
 }
 
 static int64_t wgrad_rows_per_block(int64_t rows) {
+    static const int min_rows = [] { const char* e = getenv("MGN_WG_MIN_ROWS"); return e ? atoi(e) : WG_ROWS; }();   // (A/B: fewer, longer blocks = fewer partials to reduce)
     int64_t rpb = (rows + 1023) / 1024;              // at most 1024 blocks
-    if (rpb < WG_ROWS) rpb = WG_ROWS;
+    if (rpb < min_rows) rpb = min_rows;
     return (rpb + 2 * WG_UNROLL - 1) / (2 * WG_UNROLL) * (2 * WG_UNROLL);
 }
 int wgrad_blocks_of_job(int64_t launch_rows, int64_t job_rows) {
@@ -872,7 +1085,7 @@ __global__ void k_pack_weights(const WPackJob* __restrict__ jobs, const float* _
     // bf16 layouts (L = 128): element j of lane `lane` of fragment `fr`
     const int j = idx & 7, lane = (idx >> 3) & 63, fr = idx >> 9;
     int k, n;
-    if (jb.kind == 2) {           // [ks][ob][lane][8]: input 16 (2 ks + (j >> 2)) + 4 (lane >> 4) + (j & 3), output 16 ob + (lane & 15)
+    if (jb.kind == 2 || jb.kind == 5) {           // [ks][ob][lane][8]: input 16 (2 ks + (j >> 2)) + 4 (lane >> 4) + (j & 3), output 16 ob + (lane & 15)
         const int ks = fr >> 3, ob = fr & 7;
         k = 16 * (2 * ks + (j >> 2)) + 4 * (lane >> 4) + (j & 3);
         n = 16 * ob + (lane & 15);
@@ -886,7 +1099,7 @@ __global__ void k_pack_weights(const WPackJob* __restrict__ jobs, const float* _
         wbf[jb.off + idx] = pk_bf16(w);
         return;
     }
-    if (jb.kind == 4) {                                 // w scale = hi + lo (+ <= 2^-23 relative), both fp16 (split_common.hpp)
+    if (jb.kind == 4 || jb.kind == 5) {                 // w scale = hi + lo (+ <= 2^-23 relative), both fp16 (split_common.hpp)
         const float ws = w * jb.scale;
         const _Float16 hi = (_Float16)ws;
         const _Float16 lo = (_Float16)(ws - (float)hi);
@@ -930,6 +1143,22 @@ __global__ void k_pack_train(const PackJob* __restrict__ jobs, const float* __re
     else v = (row < jb.nr && col < jb.nc) ? params[jb.src + (long long)(jb.r0 + row) * jb.ldw + col] : 0.f;
     out[jb.off + idx] = v;
     out[jb.off + (long long)L * L + (((long long)t * (J / 4) + j / 4) * 64 + lane) * 4 + (j & 3)] = v;
+    if (jb.scale > 0.f && L == 128) {   // the same chunk as two fp16 pieces (h2_chunk): element jj of lane `ln` of fragment (s, tt) = W[k][n]
+        const int jj = idx & 7, ln = (idx >> 3) & 63, fr = idx >> 9;
+        const int sidx = fr >> 2, tt = fr & 3, hh2 = ln >> 5, i2 = ln & 31;
+        const int k = 32 * (sidx >> 1) + 16 * (sidx & 1) + 8 * (jj >> 2) + 4 * hh2 + (jj & 3), n = 32 * tt + i2;
+        float w;
+        if (jb.src < 0) w = k == n ? 1.f : 0.f;
+        else if (jb.transpose) w = (n < jb.nr && k < jb.nc) ? params[jb.src + (long long)(jb.r0 + n) * jb.ldw + k] : 0.f;
+        else w = (k < jb.nr && n < jb.nc) ? params[jb.src + (long long)(jb.r0 + k) * jb.ldw + n] : 0.f;
+        const float ws = w * jb.scale;
+        const _Float16 hi = (_Float16)ws;
+        const _Float16 lo = (_Float16)(ws - (float)hi);
+        uint16_t* pc = reinterpret_cast<uint16_t*>(out + jb.off + 2LL * L * L);
+        pc[idx] = __builtin_bit_cast(uint16_t, hi);
+        pc[16384 + idx] = __builtin_bit_cast(uint16_t, lo);
+        if (idx == 0) out[jb.off + 3LL * L * L] = 1.0f / jb.scale;
+    }
 }
 hipError_t launch_pack_train(int L, const PackJob* jobs, int njobs, const float* params, const float* tabs, float* out, hipStream_t s) {
     if (njobs <= 0) return hipSuccess;
@@ -943,7 +1172,8 @@ hipError_t launch_wgrad(int L, WgradBatch wb, int64_t rows, hipStream_t s) {
     if (nb == 0 || wb.njobs <= 0) return hipSuccess;
     wb.rows_per_block = wgrad_rows_per_block(rows);
     const dim3 grid(nb, wb.njobs);
-    if (L == 128) hipLaunchKernelGGL(k_wgrad<4>, grid, dim3(256), 0, s, wb);
+    if (L == 128 && g_train_f16) hipLaunchKernelGGL(k_wgrad_h, grid, dim3(256), 0, s, wb);
+    else if (L == 128) hipLaunchKernelGGL(k_wgrad<4>, grid, dim3(256), 0, s, wb);
     else if (L == 64) hipLaunchKernelGGL(k_wgrad<2>, grid, dim3(128), 0, s, wb);
     else if (L == 32) hipLaunchKernelGGL(k_wgrad<1>, grid, dim3(64), 0, s, wb);
     else return hipErrorInvalidValue;
