@@ -375,10 +375,10 @@ def main():
             fam = lib.mgn_debug_last_edge_kernel()
             FAMILY = {1: "k_edge_step<.., GEN> (general hidden_layers)", 2: "k_edge_coop16m (16-row tiles)", 3: "k_edge_coop (4-wave tiles)",
                       4: "k_edge_step<4,0> (all-streaming)", 7: "k_edge_ring<8>", 8: "k_edge_ring<4>", 9: "k_edge_step<4,2>",
-                      10: "k_edge_ring16<8>", 11: "k_edge_ring16<4>", 12: "k_edge_coop16m (16-row tiles, split path)",
+                      12: "k_edge_coop16m (16-row tiles, split path)",
                       13: "k_edge_ring_h<8>", 14: "k_edge_ring_h<4>", 15: "k_edge_coop16m (16-row tiles, two fp16 pieces)"}
             # piece products per fp32 product of the family that ran: 6 (three bf16 pieces), 3 (two fp16 pieces), 0 = fp32 MFMA
-            products = {7: 6, 8: 6, 10: 6, 11: 6, 12: 6, 13: 3, 14: 3, 15: 3}.get(fam, 0)
+            products = {7: 6, 8: 6, 12: 6, 13: 3, 14: 3, 15: 3}.get(fam, 0)
             split_mode = split_mode if products else 0
             comp = (1024.0 + 8.0) * e_loc + 3.0 * 512.0 * n_loc
             alg_bytes = (1024.0 + 8.0 + 85.0) * e_loc
@@ -705,12 +705,21 @@ def main():
                 # per processor step  forward + recomputation 2 x (98 304 E + 196 608 N), backward (transposed chunks) 98 304 E + 196 608 N,
                 # weight gradients 98 304 E + 196 608 N  (docs/experiments.md, training step)
                 flT = MPS * 4.0 * (98304.0 * E + 196608.0 * N)
+                # forward / recomputation / backward / layer-1 halves run on two fp16 pieces (3 piece products per fp32 product), the weight
+                # gradients on the fp32 MFMA pipe: 3/4 of the products at 3 x on the 16-bit pipe, 1/4 on the fp32 pipe
+                fl16, fl32 = 3.0 * 0.75 * flT, 0.25 * flT
+                floor_s = fl16 / (PEAK_BF16_MFMA_TFLOPS * 1e12) + fl32 / (PEAK_F32_MFMA_TFLOPS * 1e12)
                 out["secondary"]["train_step_1m"] = {
-                    "workload": "mgn_step == step! on M-1M (N = 1 000 000, E = 5 992 002, L = 128, 15 steps, fp32 MFMA, recompute mode); host in/out included",
+                    "workload": "mgn_step == step! on M-1M (N = 1 000 000, E = 5 992 002, L = 128, 15 steps; fp32 storage, forward / recomputation / "
+                                "backward MLP chains on two fp16 pieces (MGN_TRAIN_F16=0: fp32 MFMA), weight gradients on the fp32 MFMA pipe; "
+                                "recompute mode); host in/out included",
                     "s_per_step": dtT, "loss_finite": bool(np.isfinite(lossT)),
-                    "roofline": {"bound": "mfma", "executed_flops_per_step": flT, "achieved": flT / dtT / 1e12, "peak": PEAK_F32_MFMA_TFLOPS,
-                                 "unit": "TFLOP/s", "frac": flT / dtT / 1e12 / PEAK_F32_MFMA_TFLOPS,
-                                 "note": "processor MLPs only (encoders / decoder, segmented sums, reductions not counted)"}}
+                    "roofline": {"bound": "mfma", "fp32_products_per_step": flT, "executed_flops_16bit": fl16, "executed_flops_fp32": fl32,
+                                 "matrix_floor_s": floor_s, "frac": floor_s / dtT, "fp32_equivalent_TFLOPs": flT / dtT / 1e12,
+                                 "unit": "s", "achieved": dtT, "peak": floor_s,
+                                 "note": "matrix floor = 16-bit piece products at the dense 16-bit peak + the fp32 weight-gradient products at "
+                                         "157.3 TFLOP/s; the step is HBM-bound in its backward and weight-gradient launches (profiles/r05); processor "
+                                         "MLPs only (encoders / decoder, segmented sums, reductions not counted)"}}
                 engT.close()
                 del nfT, efT, tgT
             except Exception as ex:   # noqa: BLE001  (a box with less free memory than the 128 GB this needs)

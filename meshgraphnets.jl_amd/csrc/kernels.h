@@ -50,8 +50,7 @@ struct EdgeArgs {
     // every fp32 operand split into three bf16 pieces, six piece products kept.  split[i]: chunk i as 3 x 16384 bf16 (hi, mid, lo
     // pieces, the bf16 kernels' fragment order); null: not available
     const uint16_t* split[3];
-    const uint16_t* split16[3];   // the same pieces in the fragment order of v_mfma_f32_16x16x32_bf16 (k_edge_coop16m on the split path -- fp32 and bf16 storage --, k_edge_ring16; mgn_api.cpp: pack_chunk16_bf16)
-    int32_t off32;                // 1: P, Q, AGG and CARRY are each shorter than 2 GiB, so k_edge_ring16 may address them with 32-bit lane offsets
+    const uint16_t* split16[3];   // the same pieces in the fragment order of v_mfma_f32_16x16x32_bf16 (k_edge_coop16m on the split path, fp32 and bf16 storage; mgn_api.cpp: pack_chunk16_bf16)
     // two-piece fp16 form of the same chunks (k_edge_ring_h; split_common.hpp): chunk i times the power of two h2_s[i] as 2 x 16384 fp16
     // (hi, lo; the bf16 pieces' fragment order), h2_rs[i] = 1 / h2_s[i]; h2_b2pos = max(0, max_k b2[k]); null: not available
     const uint16_t* splith[3];
@@ -169,7 +168,6 @@ hipError_t launch_node_split_h(const NodeArgs& a, const LaunchCfg& lc, hipStream
 hipError_t launch_project_split_h(const NodeArgs& a, const LaunchCfg& lc, hipStream_t s);
 hipError_t launch_edge_ring_h(const EdgeArgs& a, const LaunchCfg& lc, hipStream_t s);    // split.hip: the ring kernel on two fp16 pieces, three products
 size_t edge_ring_h_lds();
-hipError_t launch_edge_ring16(const EdgeArgs& a, const LaunchCfg& lc, hipStream_t s);   // split.hip: the ring kernel on v_mfma_f32_16x16x32_bf16
 hipError_t launch_edge_ring(const EdgeArgs& a, const LaunchCfg& lc, hipStream_t s);    // split.hip
 hipError_t launch_node_split(const NodeArgs& a, const LaunchCfg& lc, hipStream_t s);    // split.hip
 hipError_t launch_project_split(const NodeArgs& a, const LaunchCfg& lc, hipStream_t s); // split.hip
@@ -197,8 +195,6 @@ int set_fp32_split(int on);     // debug/tests: 0 = fp32-MFMA kernels, 1 = split
 int fp32_split_enabled();
 int set_split_f16(int on);     // 1 (default): the split path on two fp16 pieces / three products where built (k_edge_ring_h), 0: three bf16 pieces / six products; MGN_SPLIT_F16; returns the old value
 int split_f16_enabled();
-int set_edge_ring16(int on);    // 1: k_edge_ring16 (v_mfma_f32_16x16x32_bf16) where k_edge_ring would run; MGN_EDGE_RING16; returns the old value
-int edge_ring16_enabled();
 int set_c16_split(int on);      // 16-row cooperative kernels on the split path (where fp32_split is on): bit 0 edge kernel at >= 2 row tiles, bit 1 node kernel (default 3), bit 2 edge kernel at one row tile too; MGN_C16_SPLIT
 int c16_split_enabled();
 int set_c16_row_tiles(int rt);  // debug/tests: 16-edge tiles per block of the small-graph edge kernel (0: chosen by size); returns the old value

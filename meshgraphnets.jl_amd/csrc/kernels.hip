@@ -788,10 +788,11 @@ DEVINL void c16s_prime(C16SRingT<NP>& g, const u32x4* wv) {
 #pragma unroll
         for (int pc = 0; pc < NP; ++pc) g.r[NP * s + pc] = wv[pc * 2048 + ((s >> 1) * 8 + (s & 1)) * 64];
 }
-// one (k-step, block) step of RT tiles: six bf16 products into the accumulator, or three fp16 products into a partial sum that is
-// un-scaled (c = 1 / (row scale x chunk scale)) as it is added
+// one (k-step, block) step of RT tiles: six bf16 products into the accumulator, or three fp16 products into a partial sum (zero-based) that
+// the caller un-scales as it adds it -- ONE STEP LATER (c16s_apply), behind the next step's MFMAs: a VALU instruction that reads an MFMA
+// result waits for the matrix pipe to drain it
 template <int RT, int NP>
-DEVINL void c16s_step(f32x4 (&acc)[RT][2], const C16X<NP> (&x)[RT], int j, const u32x4 (&a)[NP], float rsw) {
+DEVINL void c16s_step(f32x4 (&acc)[RT][2], f32x4 (&part)[RT], const C16X<NP> (&x)[RT], int j, const u32x4 (&a)[NP]) {
 #pragma unroll
     for (int t = 0; t < RT; ++t) {
         if constexpr (NP == 3) {
@@ -804,18 +805,24 @@ DEVINL void c16s_step(f32x4 (&acc)[RT][2], const C16X<NP> (&x)[RT], int j, const
             acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(sp_wop(a[0]), bh, acc[t][j], 0, 0, 0);
         } else {
             const sp_f16x8 bh = h2_wop(x[t].p[0]), bl = h2_wop(x[t].p[1]);
-            f32x4 part = {0.f, 0.f, 0.f, 0.f};
-            part = __builtin_amdgcn_mfma_f32_16x16x32_f16(h2_wop(a[1]), bh, part, 0, 0, 0);
-            part = __builtin_amdgcn_mfma_f32_16x16x32_f16(h2_wop(a[0]), bl, part, 0, 0, 0);
-            part = __builtin_amdgcn_mfma_f32_16x16x32_f16(h2_wop(a[0]), bh, part, 0, 0, 0);
-            const float c = x[t].rs * rsw;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) acc[t][j][i] = __builtin_fmaf(part[i], c, acc[t][j][i]);
+            f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            z = __builtin_amdgcn_mfma_f32_16x16x32_f16(h2_wop(a[1]), bh, z, 0, 0, 0);
+            z = __builtin_amdgcn_mfma_f32_16x16x32_f16(h2_wop(a[0]), bl, z, 0, 0, 0);
+            part[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(h2_wop(a[0]), bh, z, 0, 0, 0);
         }
     }
 }
+template <int RT>
+DEVINL void c16s_apply(f32x4 (&acc)[RT][2], const f32x4 (&part)[RT], const float (&c)[RT], int j) {
+#pragma unroll
+    for (int t = 0; t < RT; ++t)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[t][j][i] = __builtin_fmaf(part[t][i], c[t], acc[t][j][i]);
+}
 template <int RT, int S0 = 0, int S1 = 8, int NP = 3>
 DEVINL void c16s_chain(f32x4 (&acc)[RT][2], const C16X<NP> (&x)[RT][4], const u32x4* wv, C16SRingT<NP>& g, float rsw = 1.f) {
+    f32x4 part[2][RT];
+    float cprev[RT];
 #pragma unroll
     for (int s = S0; s < S1; ++s) {
         u32x4 a[NP];
@@ -831,9 +838,15 @@ DEVINL void c16s_chain(f32x4 (&acc)[RT][2], const C16X<NP> (&x)[RT][4], const u3
         C16X<NP> xk[RT];
 #pragma unroll
         for (int t = 0; t < RT; ++t) xk[t] = x[t][ks];
-        c16s_step<RT, NP>(acc, xk, j, a, rsw);
+        c16s_step<RT, NP>(acc, part[s & 1], xk, j, a);
+        if constexpr (NP == 2) {
+            if (s > S0) c16s_apply<RT>(acc, part[(s - 1) & 1], cprev, (s - 1) & 1);
+#pragma unroll
+            for (int t = 0; t < RT; ++t) cprev[t] = xk[t].rs * rsw;
+        }
         __builtin_amdgcn_sched_barrier(0);
     }
+    if constexpr (NP == 2) c16s_apply<RT>(acc, part[(S1 - 1) & 1], cprev, (S1 - 1) & 1);
 }
 
 // four to six row tiles per block: the pieces of all tiles do not fit the registers (48 per tile) -- the exchange only publishes, and the
@@ -841,6 +854,8 @@ DEVINL void c16s_chain(f32x4 (&acc)[RT][2], const C16X<NP> (&x)[RT][4], const u3
 template <int RT, int S0 = 0, int S1 = 8, int NP = 3>
 DEVINL void c16s_chain_lds(f32x4 (&acc)[RT][2], const u32x4* xch, int lane, const u32x4* wv, C16SRingT<NP>& g, float rsw = 1.f) {
     C16X<NP> x[RT];
+    f32x4 part[2][RT];
+    float cprev[RT];
 #pragma unroll
     for (int s = S0; s < S1; ++s) {
         const int ks = s >> 1, j = s & 1;
@@ -854,9 +869,15 @@ DEVINL void c16s_chain_lds(f32x4 (&acc)[RT][2], const u32x4* xch, int lane, cons
             for (int pc = 0; pc < NP; ++pc) g.r[NP * (s % C16S_PF) + pc] = wv[pc * 2048 + ((sn >> 1) * 8 + (sn & 1)) * 64];
         }
         __builtin_amdgcn_sched_barrier(0);
-        c16s_step<RT, NP>(acc, x, j, a, rsw);
+        c16s_step<RT, NP>(acc, part[s & 1], x, j, a);
+        if constexpr (NP == 2) {
+            if (s > S0) c16s_apply<RT>(acc, part[(s - 1) & 1], cprev, (s - 1) & 1);
+#pragma unroll
+            for (int t = 0; t < RT; ++t) cprev[t] = x[t].rs * rsw;
+        }
         __builtin_amdgcn_sched_barrier(0);
     }
+    if constexpr (NP == 2) c16s_apply<RT>(acc, part[(S1 - 1) & 1], cprev, (S1 - 1) & 1);
 }
 template <int RT, bool BF, int SP = 0>      // SP: 0 fp32 MFMA pipe, 1 three bf16 pieces, 2 two fp16 pieces
 __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_edge_coop16m(const EdgeArgs a) {
@@ -2674,9 +2695,6 @@ int c16_split_enabled() { return g_c16_split; }
 static int g_split_f16 = [] { const char* e = getenv("MGN_SPLIT_F16"); return e ? atoi(e) : 1; }();
 int set_split_f16(int on) { const int old = g_split_f16; g_split_f16 = on; return old; }
 int split_f16_enabled() { return g_split_f16; }
-static int g_edge_ring16 = [] { const char* e = getenv("MGN_EDGE_RING16"); return e ? atoi(e) : 0; }();
-int set_edge_ring16(int on) { const int old = g_edge_ring16; g_edge_ring16 = on; return old; }
-int edge_ring16_enabled() { return g_edge_ring16; }
 int set_c16_row_tiles(int rt) { const int old = g_c16_rt; g_c16_rt = rt; return old; }
 int get_kernel_path() { return g_path; }
 static bool small_launch(int ntiles) { return g_path == 0 ? ntiles <= 4 * num_cus() : g_path >= 2; }
@@ -2784,7 +2802,7 @@ static bool coop_ok(int L, int ntiles, const float* const* chunk_t, bool edge = 
 
 // which kernel family the last fp32 edge launch went to (bench.py labels its roofline with what RAN, not with the global switches):
 // 1 generic hidden_layers, 2 16-row small-graph, 3 cooperative 4-wave tiles, 4 all-streaming, (5, 6: kernels retired in round 5,)
-// 7 k_edge_ring<8>, 8 k_edge_ring<4>, 9 k_edge_step<4,2> (fp32-MFMA persistent), 10 / 11 k_edge_ring16<8 / 4>, 12 k_edge_coop16m on the
+// 7 k_edge_ring<8>, 8 k_edge_ring<4>, 9 k_edge_step<4,2> (fp32-MFMA persistent), (10, 11: retired,) 12 k_edge_coop16m on the
 // split path, 13 / 14 k_edge_ring_h<8 / 4> (two fp16 pieces: the default of large fp32 launches)
 static int g_last_edge_kernel = 0;
 int last_edge_kernel() { return g_last_edge_kernel; }
@@ -2862,14 +2880,10 @@ hipError_t launch_edge_step(int L, const EdgeArgs& a, hipStream_t s) {
                 if (blocks > num_cus()) blocks = num_cus();
                 ls.blocks = ((blocks + NUM_XCD - 1) / NUM_XCD) * NUM_XCD;
             }
-            if (g_split_f16 && a.splith[0] && !(g_edge_ring16 && a.split16[0] && a.off32)) {
+            if (g_split_f16 && a.splith[0]) {
                 ls.lds = edge_ring_h_lds();
                 g_last_edge_kernel = ls.threads == 256 ? 14 : 13;
                 return launch_edge_ring_h(a, ls, s);
-            }
-            if (g_edge_ring16 && a.split16[0] && a.off32) {
-                g_last_edge_kernel = ls.threads == 256 ? 11 : 10;
-                return launch_edge_ring16(a, ls, s);
             }
             g_last_edge_kernel = ls.threads == 256 ? 8 : 7;
             return launch_edge_ring(a, ls, s);

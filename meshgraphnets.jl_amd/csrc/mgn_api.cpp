@@ -214,7 +214,7 @@ void pack_chunk_split_h(uint16_t* dst, const float* W, int ldw, int kbase, float
                 for (int j = 0; j < 8; ++j)
                     put((((size_t)sidx * 4 + t) * 64 + lane) * 8 + j, bf_feature(sidx, lane >> 5, j), 32 * t + (lane & 31));
 }
-// the A fragments of v_mfma_f32_16x16x32_bf16 (k_edge_ring16, split.hip): step (ks, ob) = output block ob of k-step ks; lane
+// the A fragments of v_mfma_f32_16x16x32_bf16 (the 16-row kernels of kernels.hip on the split path): step (ks, ob) = output block ob of k-step ks; lane
 // (r16 = lane & 15, g = lane >> 4) holds output 16 ob + r16, its element j input 16 (2 ks + (j >> 2)) + 4 g + (j & 3) -- the order in
 // which a lane's two accumulator blocks 2 ks, 2 ks + 1 of the layer before hold them
 void pack_chunk16_bf16(uint16_t* dst, const float* W, int ldw, int kbase) {
@@ -446,10 +446,6 @@ EdgeArgs edge_args(mgn_engine* h, int k, int q = 0) {
         a.h2_rs[i] = 1.f / a.h2_s[i];
     }
     a.h2_b2pos = have_h ? h->spoff[k].e_b2pos[q] : 0.f;
-    {
-        const size_t lim = (size_t)1 << 31, rowb = (size_t)h->cfg.L * 4;
-        a.off32 = ((size_t)(h->g.n_own + h->g.n_halo + 32) * rowb < lim && ((size_t)2 * es.ntiles_e + 16) * rowb < lim) ? 1 : 0;
-    }
     a.c16 = use_c16(h);
     a.stagger = h->stagger_edge;
     a.tile0 = 0;
@@ -875,7 +871,7 @@ int pack_inference_weights(mgn_engine* h) {
         const bool node_side = S <= 2;                                  //   8.8 MB for the node side (+ 4.4 MB with a second edge set)
         // every chunk twice: the 32x32x16 fragment order (k_edge_ring, k_node_split, k_project_split; fp32 storage only) and the
         // 16x16x32 one (the 16-row cooperative kernels of small meshes -- in bf16 storage mode too, where they keep fp32-accurate
-        // arithmetic --, k_edge_ring16)
+        // arithmetic --)
         const bool f32 = c.dtype == MGN_F32;
         h->spoff.assign(c.mps + 1, {});
         size_t off = 0;
@@ -2640,9 +2636,6 @@ int mgn_debug_c16_row_tiles(int rt) { return set_c16_row_tiles(rt); }
 // large fp32 launches: 1 split path (k_edge_ring + k_node_split + k_project_split: bf16 matrix cores at fp32 accuracy; the default),
 // 0 fp32-MFMA kernels; returns the old value
 int mgn_debug_fp32_split(int on) { return set_fp32_split(on); }
-// 1: the edge kernel of the split path on v_mfma_f32_16x16x32_bf16 (k_edge_ring16); takes effect at the next mgn_set_params (its weight
-// fragments are packed there).  Returns the old value.  Environment: MGN_EDGE_RING16.
-int mgn_debug_edge_ring16(int on) { return set_edge_ring16(on); }
 // 1 (default): the split path computes on two fp16 pieces per operand and three piece products (k_edge_ring_h), 0: on three bf16 pieces
 // and six products (k_edge_ring); returns the old value
 int mgn_debug_split_f16(int on) { return set_split_f16(on); }

@@ -47,7 +47,7 @@ struct TrainState {
     bool recompute = false;      // processor MLPs keep only their inputs; H1 / H2 / Y are recomputed in the reverse pass
     int nblk = 1;                // launch units per MLP (2 for hidden_layers 3, 4)
     DevBuf w;                    // training-order weights
-    DevBuf pk_params, pk_tabs, pk_jobs;   // what k_pack_train builds them from: the parameter vector, the packed tables, the chunk list
+    DevBuf pk_params, pk_tabs, pk_jobs, pk_max;   // what k_pack_train builds them from: the parameter vector, the packed tables, the chunk list
     // enc-node, enc-edge (per set), per step: edge (per set), node; decoder
     TrainMlp m_en, m_de, m_ee[MAX_EDGE_SETS];
     std::vector<TrainMlp> m_pe[MAX_EDGE_SETS], m_pn;
@@ -126,17 +126,7 @@ int pack_training_weights(mgn_engine* h) {
     auto block = [&](const float* Wm, int ldw, int r0, int nr, int nc, bool transpose) {
         const size_t off = fsz;
         fsz += pieces ? 3 * CH + 4 : 2 * CH;          // fragment order, then the t-major copy (cooperative kernels) at + CH
-        float sc = 0.f;
-        if (pieces) {
-            float mx = Wm ? 0.f : 1.f;
-            for (int r = 0; Wm && r < nr; ++r)
-                for (int cc = 0; cc < nc; ++cc) mx = std::max(mx, std::fabs(Wm[(size_t)(r0 + r) * ldw + cc]));
-            int e = 0;
-            (void)std::frexp(mx, &e);
-            if (!(mx > 0.f) || e - 1 < -40) e = -39;
-            if (!std::isfinite(mx)) e = 128;
-            sc = std::ldexp(1.f, 15 - e);
-        }
+        const float sc = pieces ? 1.f : 0.f;          // (> 0: pieces wanted; their scale is found on the device, k_pack_absmax)
         jobs.push_back({(long long)off, Wm ? (long long)(Wm - p) : -1LL, ldw, r0, nr, nc, transpose ? 1 : 0, 0, sc});
         return off;
     };
@@ -213,10 +203,11 @@ int pack_training_weights(mgn_engine* h) {
     HIPCHK(h, T.pk_params.ensure(h->params.size() * 4));
     HIPCHK(h, T.pk_tabs.ensure(tabs.size() * 4));
     HIPCHK(h, T.pk_jobs.ensure(jobs.size() * sizeof(PackJob)));
+    HIPCHK(h, T.pk_max.ensure(jobs.size() * sizeof(unsigned)));
     HIPCHK(h, hipMemcpyAsync(T.pk_params.p, p, h->params.size() * 4, hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipMemcpyAsync(T.pk_tabs.p, tabs.data(), tabs.size() * 4, hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipMemcpyAsync(T.pk_jobs.p, jobs.data(), jobs.size() * sizeof(PackJob), hipMemcpyHostToDevice, h->stream));
-    HIPCHK(h, launch_pack_train(L, T.pk_jobs.as<PackJob>(), (int)jobs.size(), T.pk_params.as<float>(), T.pk_tabs.as<float>(), T.w.as<float>(), h->stream));
+    HIPCHK(h, launch_pack_train(L, T.pk_jobs.as<PackJob>(), (int)jobs.size(), T.pk_params.as<float>(), T.pk_tabs.as<float>(), T.pk_max.as<unsigned>(), T.w.as<float>(), h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));       // (jobs / tabs are locals: their copies must have left the host)
     HIPCHK(h, T.grads.ensure(h->params.size() * 4));
     T.packed = true;

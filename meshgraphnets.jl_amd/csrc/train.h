@@ -78,8 +78,8 @@ hipError_t launch_pack_weights(int L, const WPackJob* jobs, int njobs, const flo
 // one packed copy of the training weights: kind 0 = an L x L chunk in fragment order + its t-major copy at + L * L, from rows [r0, r0 + nr)
 // x cols [0, nc) of the matrix at params + src (leading dimension ldw; src < 0: the identity), zero-padded, transposed on request;
 // kind 1 = T_COUNT * L table floats copied from tabs + src
-struct PackJob { long long off, src; int ldw, r0, nr, nc, transpose, kind; float scale; };   // scale > 0 (L = 128): + the chunk's two fp16 pieces times scale at off + 2 L L (32x32x16 fragment order: hi, lo) and 1 / scale at off + 3 L L
-hipError_t launch_pack_train(int L, const PackJob* jobs, int njobs, const float* params, const float* tabs, float* out, hipStream_t s);
+struct PackJob { long long off, src; int ldw, r0, nr, nc, transpose, kind; float scale; };   // scale > 0 (L = 128): + the chunk's two fp16 pieces at off + 2 L L (32x32x16 fragment order: hi, lo), times the power of two that puts its largest entry into [2^14, 2^15) (taken on the device), and the inverse of that power at off + 3 L L
+hipError_t launch_pack_train(int L, const PackJob* jobs, int njobs, const float* params, const float* tabs, unsigned* jobmax /* [njobs] scratch */, float* out, hipStream_t s);
 hipError_t launch_wgrad(int L, WgradBatch wb, int64_t rows, hipStream_t s);
 // out[r * cols + c] = sum_b partial[b * block_stride + r * ld + c]   (fixed order: bitwise reproducible), one job per blockIdx.y
 constexpr int REDUCE_MAX_JOBS = 16;

@@ -600,121 +600,6 @@ __global__ __launch_bounds__(64 * NT) void k_wgrad(const WgradBatch wb) {
     }
 }
 
-// The same on two fp16 pieces (L = 128; round 5): the reduction dimension is the ROW index, so an operand's scale has to be the same for
-// all rows of a k-step -- one power of two per wave for X and one for G, taken from a RUNNING maximum over the block's rows (the maximum
-// of the first step to begin with; when a later step exceeds it -- a wave-uniform branch, a handful of times per block -- the
-// accumulators are brought down by the same power of two).  v_mfma_f32_32x32x16_f16: A = X^T (lane (m, kh): feature 32 ti + m, rows
-// 8 kh .. 8 kh + 7 of the 16-row step), B = G (lane (n, kh): feature 32 t + n, the same rows); 12 MFMAs of 32 cycles per 16 rows
-// instead of 32 of 64.  Against the float64 oracle the gradients stay inside the tolerances of the fp32 kernels (the sum over thousands
-// of rows dominates both).
-DEVINL float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) v = __builtin_fmaxf(v, __shfl_xor(v, o, 64));
-    return v;
-}
-__global__ __launch_bounds__(256) void k_wgrad_h(const WgradBatch wb) {
-    constexpr int NT = 4, L = 128;
-    const WgradJob& jb = wb.job[blockIdx.y];
-    const int64_t r0 = (int64_t)blockIdx.x * wb.rows_per_block;
-    if (r0 >= jb.rows) return;
-    const int64_t r1 = r0 + wb.rows_per_block < jb.rows ? r0 + wb.rows_per_block : jb.rows;
-    const int lane = threadIdx.x & 63, m = lane & 31, kh = lane >> 5;
-    const int ti = threadIdx.x >> 6;
-    const float* __restrict__ X = jb.X;
-    const float* __restrict__ G = jb.G;
-    const int32_t* __restrict__ xidx = jb.xidx;
-    const bool with_w = jb.pw != nullptr;
-    if (!with_w && ti != 0) return;              // column sums only: one wave
-    f32x16 acc[NT];
-    float bs[NT];
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        bs[t] = 0.f;
-#pragma unroll
-        for (int k = 0; k < 16; ++k) acc[t][k] = 0.f;
-    }
-    unsigned ea = 0, eb = 0;                     // exponent fields of the running maxima of |X| and |G| (wave-uniform; 0: none yet)
-    for (int64_t q = r0; q < r1; q += 16) {
-        float av[8], bv[NT][8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int64_t row = q + 8 * kh + u;
-            const bool ok = row < r1;
-            const int64_t rr = ok ? row : r0;
-            float xa = 0.f;
-            if (with_w) {
-                const int64_t src = xidx ? (int64_t)xidx[rr] : rr;
-                xa = X[src * L + 32 * ti + m];
-            }
-            av[u] = ok ? xa : 0.f;
-#pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                const float gb = G[rr * L + 32 * t + m];
-                bv[t][u] = ok ? gb : 0.f;
-            }
-        }
-#pragma unroll
-        for (int t = 0; t < NT; ++t)
-#pragma unroll
-            for (int u = 0; u < 8; ++u) bs[t] += bv[t][u];
-        if (!with_w) continue;
-        float ma = 0.f, mb = 0.f;
-#pragma unroll
-        for (int u = 0; u < 8; u += 2) ma = __builtin_fmaxf(ma, __builtin_fmaxf(__builtin_fabsf(av[u]), __builtin_fabsf(av[u + 1])));
-#pragma unroll
-        for (int t = 0; t < NT; ++t)
-#pragma unroll
-            for (int u = 0; u < 8; u += 2) mb = __builtin_fmaxf(mb, __builtin_fmaxf(__builtin_fabsf(bv[t][u]), __builtin_fabsf(bv[t][u + 1])));
-        unsigned na = __builtin_amdgcn_readfirstlane(sp_u(wave_max(ma)) & 0x7f800000u);
-        unsigned nb = __builtin_amdgcn_readfirstlane(sp_u(wave_max(mb)) & 0x7f800000u);
-        na = na > H2_EXP_MIN ? na : H2_EXP_MIN;
-        nb = nb > H2_EXP_MIN ? nb : H2_EXP_MIN;
-        if (na > ea || nb > eb) {                // a larger operand than any before: the units of the accumulators follow (first step: from nothing)
-            const unsigned ta = na > ea ? na : ea, tb_ = nb > eb ? nb : eb;
-            if (ea != 0) {
-                const float down = sp_f((127u << 23) - (ta - ea) - (tb_ - eb));      // 2^-(exponent steps of X + of G)
-#pragma unroll
-                for (int t = 0; t < NT; ++t)
-#pragma unroll
-                    for (int k = 0; k < 16; ++k) acc[t][k] *= down;
-            }
-            ea = ta;
-            eb = tb_;
-        }
-        const float sa = sp_f((268u << 23) - ea), sb = sp_f((268u << 23) - eb);      // (h2_scale's s for the running maxima)
-        unsigned ah[4], al[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) h2_split_pair<0>(ah[u], al[u], av[2 * u], av[2 * u + 1], sa);
-        const sp_f16x8 Ah = h2_op(ah), Al = h2_op(al);
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            unsigned bh[4], bl[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) h2_split_pair<0>(bh[u], bl[u], bv[t][2 * u], bv[t][2 * u + 1], sb);
-            const sp_f16x8 Bh = h2_op(bh), Bl = h2_op(bl);
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Al, Bh, acc[t], 0, 0, 0);
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, Bl, acc[t], 0, 0, 0);
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, Bh, acc[t], 0, 0, 0);
-        }
-    }
-    // D layout of the 32x32 MFMA: register r of lane l holds D[(r&3) + 8(r>>2) + 4(l>>5)][l&31]
-    if (with_w) {
-        const float c = ea ? sp_f(ea - (14u << 23)) * sp_f(eb - (14u << 23)) : 0.f;      // 1 / (sa sb)
-        float* pw = jb.pw + (size_t)blockIdx.x * L * L;
-#pragma unroll
-        for (int t = 0; t < NT; ++t)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) pw[(size_t)(32 * ti + (r & 3) + 8 * (r >> 2) + 4 * kh) * L + 32 * t + m] = acc[t][r] * c;
-    }
-    if (ti == 0 && jb.pb) {
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            const float sb_ = bs[t] + __shfl_xor(bs[t], 32, 64);
-            if (kh == 0) jb.pb[(size_t)blockIdx.x * L + 32 * t + m] = sb_;
-        }
-    }
-}
-
 // out[r * cols + c] = sum_b partial[b][r * ld + c], fixed order (bitwise reproducible); one job per blockIdx.y
 __global__ void k_reduce_partials(const ReduceBatch rb) {
     const ReduceJob& jb = rb.job[blockIdx.y];
@@ -1037,7 +922,7 @@ hipError_t launch_mlp_bwd(int L, int nin, const TrainBwdArgs& a, hipStream_t s) 
 }
 
 static int64_t wgrad_rows_per_block(int64_t rows) {
-    static const int min_rows = [] { const char* e = getenv("MGN_WG_MIN_ROWS"); return e ? atoi(e) : WG_ROWS; }();   // (A/B: fewer, longer blocks = fewer partials to reduce)
+    static const int min_rows = [] { const char* e = getenv("MGN_WG_MIN_ROWS"); return e ? atoi(e) : WG_ROWS; }();   // (A/B on the cylinder mesh: 64 / 128 rows 3.13 / 3.11 ms per step, 256: 3.68, 512: 4.90 -- a block's row loop is a latency chain)
     int64_t rpb = (rows + 1023) / 1024;              // at most 1024 blocks
     if (rpb < min_rows) rpb = min_rows;
     return (rpb + 2 * WG_UNROLL - 1) / (2 * WG_UNROLL) * (2 * WG_UNROLL);
@@ -1123,8 +1008,25 @@ hipError_t launch_pack_weights(int L, const WPackJob* jobs, int njobs, const flo
 
 // the training weights from the parameter vector, on the device (mgn_train.cpp: pack_training_weights; the host twins are pack_chunk /
 // pack_chunk_tmajor of mgn_api.cpp): one block column per job
+// element (k, n) of the L x L block a PackJob describes (zero-padded, transposed on request; src < 0: the identity)
+DEVINL float pack_elem(const PackJob& jb, const float* __restrict__ params, int k, int n) {
+    if (jb.src < 0) return k == n ? 1.f : 0.f;
+    if (jb.transpose) return (n < jb.nr && k < jb.nc) ? params[jb.src + (long long)(jb.r0 + n) * jb.ldw + k] : 0.f;
+    return (k < jb.nr && n < jb.nc) ? params[jb.src + (long long)(jb.r0 + k) * jb.ldw + n] : 0.f;
+}
+// largest magnitude of every chunk that wants fp16 pieces (scale > 0), as the bits of a non-negative float: the pieces' power of two is
+// taken from it ON THE DEVICE (a training loop packs new weights before every step: ~300 host passes over 16 K values were 2.7 ms of it)
+__global__ void k_pack_absmax(const PackJob* __restrict__ jobs, const float* __restrict__ params, unsigned* __restrict__ jobmax, int L) {
+    const PackJob jb = jobs[blockIdx.y];
+    if (jb.kind != 0 || !(jb.scale > 0.f)) return;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    float m = idx < L * L ? __builtin_fabsf(pack_elem(jb, params, idx / L, idx % L)) : 0.f;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) m = __builtin_fmaxf(m, __shfl_xor(m, o, 64));
+    if ((threadIdx.x & 63) == 0) atomicMax(jobmax + blockIdx.y, __builtin_bit_cast(unsigned, m));
+}
 __global__ void k_pack_train(const PackJob* __restrict__ jobs, const float* __restrict__ params, const float* __restrict__ tabs,
-                             float* __restrict__ out, int L) {
+                             const unsigned* __restrict__ jobmax, float* __restrict__ out, int L) {
     const PackJob jb = jobs[blockIdx.y];
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (jb.kind == 1) {
@@ -1143,27 +1045,27 @@ __global__ void k_pack_train(const PackJob* __restrict__ jobs, const float* __re
     else v = (row < jb.nr && col < jb.nc) ? params[jb.src + (long long)(jb.r0 + row) * jb.ldw + col] : 0.f;
     out[jb.off + idx] = v;
     out[jb.off + (long long)L * L + (((long long)t * (J / 4) + j / 4) * 64 + lane) * 4 + (j & 3)] = v;
-    if (jb.scale > 0.f && L == 128) {   // the same chunk as two fp16 pieces (h2_chunk): element jj of lane `ln` of fragment (s, tt) = W[k][n]
+    if (jb.scale > 0.f && L == 128) {   // the same chunk as two fp16 pieces (h2_chunk_inplace): element jj of lane `ln` of fragment (s, tt) = W[k][n]
         const int jj = idx & 7, ln = (idx >> 3) & 63, fr = idx >> 9;
         const int sidx = fr >> 2, tt = fr & 3, hh2 = ln >> 5, i2 = ln & 31;
         const int k = 32 * (sidx >> 1) + 16 * (sidx & 1) + 8 * (jj >> 2) + 4 * hh2 + (jj & 3), n = 32 * tt + i2;
-        float w;
-        if (jb.src < 0) w = k == n ? 1.f : 0.f;
-        else if (jb.transpose) w = (n < jb.nr && k < jb.nc) ? params[jb.src + (long long)(jb.r0 + n) * jb.ldw + k] : 0.f;
-        else w = (k < jb.nr && n < jb.nc) ? params[jb.src + (long long)(jb.r0 + k) * jb.ldw + n] : 0.f;
-        const float ws = w * jb.scale;
+        const H2Scale sc = h2_scale(__builtin_bit_cast(float, jobmax[blockIdx.y]));      // the chunk's largest entry lands in [2^14, 2^15)
+        const float ws = pack_elem(jb, params, k, n) * sc.s;
         const _Float16 hi = (_Float16)ws;
         const _Float16 lo = (_Float16)(ws - (float)hi);
         uint16_t* pc = reinterpret_cast<uint16_t*>(out + jb.off + 2LL * L * L);
         pc[idx] = __builtin_bit_cast(uint16_t, hi);
         pc[16384 + idx] = __builtin_bit_cast(uint16_t, lo);
-        if (idx == 0) out[jb.off + 3LL * L * L] = 1.0f / jb.scale;
+        if (idx == 0) out[jb.off + 3LL * L * L] = sc.rs;
     }
 }
-hipError_t launch_pack_train(int L, const PackJob* jobs, int njobs, const float* params, const float* tabs, float* out, hipStream_t s) {
+hipError_t launch_pack_train(int L, const PackJob* jobs, int njobs, const float* params, const float* tabs, unsigned* jobmax, float* out,
+                             hipStream_t s) {
     if (njobs <= 0) return hipSuccess;
     const int n = L * L > T_COUNT * L ? L * L : T_COUNT * L;
-    hipLaunchKernelGGL(k_pack_train, dim3((n + 255) / 256, njobs), dim3(256), 0, s, jobs, params, tabs, out, L);
+    if (hipError_t e = hipMemsetAsync(jobmax, 0, (size_t)njobs * sizeof(unsigned), s)) return e;
+    if (L == 128) hipLaunchKernelGGL(k_pack_absmax, dim3((L * L + 255) / 256, njobs), dim3(256), 0, s, jobs, params, jobmax, L);
+    hipLaunchKernelGGL(k_pack_train, dim3((n + 255) / 256, njobs), dim3(256), 0, s, jobs, params, tabs, jobmax, out, L);
     return hipGetLastError();
 }
 
@@ -1172,8 +1074,7 @@ hipError_t launch_wgrad(int L, WgradBatch wb, int64_t rows, hipStream_t s) {
     if (nb == 0 || wb.njobs <= 0) return hipSuccess;
     wb.rows_per_block = wgrad_rows_per_block(rows);
     const dim3 grid(nb, wb.njobs);
-    if (L == 128 && g_train_f16) hipLaunchKernelGGL(k_wgrad_h, grid, dim3(256), 0, s, wb);
-    else if (L == 128) hipLaunchKernelGGL(k_wgrad<4>, grid, dim3(256), 0, s, wb);
+    if (L == 128) hipLaunchKernelGGL(k_wgrad<4>, grid, dim3(256), 0, s, wb);
     else if (L == 64) hipLaunchKernelGGL(k_wgrad<2>, grid, dim3(128), 0, s, wb);
     else if (L == 32) hipLaunchKernelGGL(k_wgrad<1>, grid, dim3(64), 0, s, wb);
     else return hipErrorInvalidValue;

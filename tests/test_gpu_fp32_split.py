@@ -9,23 +9,19 @@ import torch  # noqa: F401
 
 import mgn_oracle as orc
 from mgn_amd import synth
-from util import TOL_15, TOL_STEP, cfg_dict, engine_for, make_params, rel_max, set_c16_row_tiles, set_c16_split, set_edge_ring16, set_fp32_split, set_kernel_path, set_split_f16
+from util import TOL_15, TOL_STEP, cfg_dict, engine_for, make_params, rel_max, set_c16_row_tiles, set_c16_split, set_fp32_split, set_kernel_path, set_split_f16
 
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(params=[100, 1, 16], ids=["ring_h", "ring", "ring16"])
+@pytest.fixture(params=[100, 1], ids=["ring_h", "ring"])
 def split_on(request):
-    """100: the default -- mode 1 on two fp16 pieces and three piece products (k_edge_ring_h); 1: the same mode on three bf16 pieces and
-    six products (k_edge_ring; mgn_debug_split_f16(0)); 16: that kernel on v_mfma_f32_16x16x32_bf16 (k_edge_ring16: mode 1 +
-    mgn_debug_edge_ring16; its fragments are packed at set_params, so the switch is thrown before the engines are built)"""
-    mode = 1 if request.param in (16, 100) else request.param
-    old = set_fp32_split(mode)
-    old16 = set_edge_ring16(1 if request.param == 16 else 0)
+    """100: the default -- mode 1 on two fp16 pieces and three piece products (k_edge_ring_h, k_node_split_h, k_project_split_h); 1: the same
+    mode on three bf16 pieces and six products (k_edge_ring, k_node_split, k_project_split; mgn_debug_split_f16(0))"""
+    old = set_fp32_split(1)
     oldh = set_split_f16(1 if request.param == 100 else 0)
-    yield mode
+    yield 1
     set_split_f16(oldh)
-    set_edge_ring16(old16)
     set_fp32_split(old)
 
 

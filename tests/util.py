@@ -84,15 +84,6 @@ def set_split_f16(on):
     return lib.mgn_debug_split_f16(on)
 
 
-def set_edge_ring16(on):
-    """1: k_edge_ring16 (the ring kernel on v_mfma_f32_16x16x32_bf16) wherever k_edge_ring would run; read by set_params (fragment
-    order) and by every launch.  Returns the old value."""
-    lib = mgn_amd.load()
-    lib.mgn_debug_edge_ring16.restype = __import__("ctypes").c_int
-    lib.mgn_debug_edge_ring16.argtypes = [__import__("ctypes").c_int]
-    return lib.mgn_debug_edge_ring16(on)
-
-
 def set_renumber(mode):
     """Node numbering policy of the next set_graph calls: 0 never, 1 auto (default), 2 always breadth-first (tests only)."""
     lib = mgn_amd.load()
