@@ -315,3 +315,59 @@ def test_split_16_row_edge_kernel_with_four_to_six_row_tiles(n_pts):
         set_c16_split(old)
     assert max(rel_max(v1, rv), rel_max(e1, re)) <= 2.0 * max(rel_max(v0, rv), rel_max(e0, re)) + 1e-7
     assert not np.array_equal(e0, e1)
+
+
+@pytest.mark.parametrize("mesh", ["persistent", "16-row"])
+def test_two_fp16_pieces_hold_rows_and_chunks_of_any_scale(mesh):
+    """What the power-of-two scaling of the fp16 split has to deliver: rows whose magnitudes are spread over eight orders, rows of zeros,
+    a row with one huge outlier, and weight chunks scaled apart by 10^6 -- every ROW of the result as accurate, relative to ITS largest
+    entry, as the fp32-MFMA kernels make it (a global max-norm would only see the largest rows), and nothing overflows."""
+    cfg = cfg_dict(mps=2)
+    if mesh == "persistent":
+        pos, s, r = synth.mesh_1m(5, 150, 150)
+        N = pos.shape[0]
+    else:
+        pos, cells, _, _ = synth.mesh_cyl(1234, 2000)
+        s, r = synth.cells_to_edges(cells)
+        N = pos.shape[0]
+    E = s.size
+    ps = make_params(cfg, jitter=0.05).copy()
+    lay = orc.model_layout(cfg["Fn"], cfg["Fe"], cfg["O"], cfg["L"], cfg["hidden_layers"], cfg["mps"])
+    off = 0
+    rng = np.random.default_rng(11)
+    for bname, tensors in lay:                                   # the chunks of the processor MLPs scaled apart (biases with their layer)
+        for tname, shape in tensors:
+            n = int(np.prod(shape))
+            if bname.startswith("proc") and tname in ("W1", "W2", "b1", "b2"):
+                ps[off:off + n] *= np.float32({"W1": 1e-3, "b1": 1e-3, "W2": 1e3, "b2": 1.0}[tname])
+            off += n
+    v = rng.standard_normal((N, 128)).astype(np.float32) * (10.0 ** rng.uniform(-4, 4, (N, 1))).astype(np.float32)
+    e = rng.standard_normal((E, 128)).astype(np.float32) * (10.0 ** rng.uniform(-4, 4, (E, 1))).astype(np.float32)
+    v[::97] = 0.0
+    e[::89] = 0.0
+    e[5::101, 17] = 3.0e7                                         # one outlier in an otherwise ordinary row
+    rv, re = orc.processor_steps(ps, cfg, v, e, s, r, 2)
+
+    def row_err(a, ref):
+        den = np.maximum(np.abs(ref).max(1), 1e-30)
+        return float((np.abs(a.astype(np.float64) - ref).max(1) / den).max())
+
+    out = {}
+    for name, (split, f16) in {"fp32_mfma": (0, 0), "f16x2": (1, 1), "bf16x3": (1, 0)}.items():
+        old, oldh = set_fp32_split(split), set_split_f16(f16)
+        olds = set_c16_split(3 if split else 0)
+        try:
+            eng = engine_for(cfg)
+            eng.set_params(ps)
+            eng.set_graph(s, r, N)
+            v1, e1 = eng.processor_steps(v, e, 2)
+            assert np.isfinite(v1).all() and np.isfinite(e1).all(), name
+            out[name] = max(row_err(v1, rv), row_err(e1, re))
+            eng.close()
+        finally:
+            set_c16_split(olds)
+            set_split_f16(oldh)
+            set_fp32_split(old)
+    assert out["fp32_mfma"] <= 2e-5, out
+    assert out["f16x2"] <= 2e-5 and out["f16x2"] <= 2.0 * out["fp32_mfma"] + 1e-6, out
+    assert out["bf16x3"] <= 2e-5, out
