@@ -68,8 +68,9 @@ typedef struct mgn_config {
                            /* when it is left at dims = Colon() (julia/spec_probe.jl tells which one the installed GraphNetCore / Lux    */
                            /* run).  A different network, not a numerical variant: every LayerNorm then couples all rows, so the fused    */
                            /* kernels cannot be used; the mode runs unfused (MLP kernel, grid-wide statistics pass, apply pass) behind     */
-                           /* mgn_forward and mgn_processor_steps: fp32, one partition, one edge set; the other compute entry points       */
-                           /* answer MGN_E_UNSUPPORTED                                                                                    */
+                           /* mgn_forward, mgn_processor_steps and the one-shot form of mgn_ode_step (normalisers, inverse_data and      */
+                           /* val_mask on the host): fp32, one partition, one edge set; the other compute entry points answer             */
+                           /* MGN_E_UNSUPPORTED                                                                                           */
 } mgn_config;
 
 typedef enum { MGN_LN_VAR_EPS = 0, MGN_LN_STD_EPS = 1 } mgn_ln_mode;

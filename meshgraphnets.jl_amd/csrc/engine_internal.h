@@ -98,6 +98,7 @@ struct mgn_engine {
 
     // norms (device): node scale/shift [Fn], edge [Fe], out [O]; null = identity
     DevBuf norms;
+    std::vector<float> norms_host;   // the same affine maps on the host (the whole-array LayerNorm mode's mgn_ode_step builds its inputs there)
     bool have_nnorm = false, have_enorm = false, have_onorm = false;
 
     // graph

@@ -245,7 +245,7 @@ int need(mgn_engine* h, bool params, bool graph, bool packed) {
     // whole-array LayerNorm couples every row of an MLP's output: the fused kernels behind the other compute entry points cannot
     // compute it (mgn_forward and mgn_processor_steps branch off to the unfused driver before they get here)
     if (params && graph && h->cfg.ln_dims == MGN_LN_ALL)
-        return fail(h, MGN_E_UNSUPPORTED, "ln_dims = MGN_LN_ALL (whole-array LayerNorm) is served by mgn_forward and mgn_processor_steps only");
+        return fail(h, MGN_E_UNSUPPORTED, "ln_dims = MGN_LN_ALL (whole-array LayerNorm) is served by mgn_forward, mgn_processor_steps and the one-shot mgn_ode_step only");
     if (params && !h->have_params) return fail(h, MGN_E_STATE, "mgn_set_params has not been called");
     if (graph && !h->have_graph) return fail(h, MGN_E_STATE, "mgn_set_graph has not been called");
     if (params && packed && !h->packed_ok) return pack_inference_weights(h);
@@ -1033,6 +1033,7 @@ int mgn_set_norms(mgn_handle* h, const float* ns, const float* nsh, const float*
     HIPCHK(h, hipStreamSynchronize(h->stream));
     HIPCHK(h, h->norms.ensure(v.size() * 4));
     HIPCHK(h, hipMemcpy(h->norms.p, v.data(), v.size() * 4, hipMemcpyHostToDevice));
+    h->norms_host = v;
     invalidate_static(h);
     h->have_nnorm = ns != nullptr;
     h->have_enorm = es != nullptr;
@@ -1585,7 +1586,42 @@ int mgn_set_static(mgn_handle* h, const float* onehot, const float* ef_raw, cons
     return MGN_OK;
 } MGN_CATCH(h)
 
+// ode_step under ln_dims = MGN_LN_ALL: build_graph's normalisation on the host, the unfused whole-array forward, inverse_data and
+// val_mask on the host (reference src/graph.jl:80-93, src/solve.jl:198-218).  The one-shot form only; a hedge, not a fast path.
+static int lnall_ode_step(mgn_handle* h, const float* x, const float* onehot, const float* ef_raw, const float* val_mask, float* dxdt) {
+    const mgn_config& c = h->cfg;
+    if (!h->have_params) return fail(h, MGN_E_STATE, "mgn_set_params has not been called");
+    if (!h->have_graph) return fail(h, MGN_E_STATE, "mgn_set_graph has not been called");
+    if (!x || !dxdt) return fail(h, MGN_E_ARG, "mgn_ode_step: null argument");
+    if (c.Fn < c.O) return fail(h, MGN_E_ARG, "mgn_ode_step: Fn < O");
+    if (!ef_raw || (c.Fn > c.O && !onehot))
+        return fail(h, MGN_E_UNSUPPORTED, "mgn_ode_step with ln_dims = MGN_LN_ALL takes the one-shot form (x, node_type_onehot, ef_raw[, val_mask]); "
+                                          "mgn_set_static's resident inputs belong to the fused kernels");
+    const int64_t N = h->g.N, E = h->g.set[0].E;
+    const float* nrm = h->norms_host.empty() ? nullptr : h->norms_host.data();   // [node scale, shift | edge scale, shift | out scale, shift]
+    const float* ns = (nrm && h->have_nnorm) ? nrm : nullptr;
+    const float* es = (nrm && h->have_enorm) ? nrm + 2 * c.Fn : nullptr;
+    const float* os = (nrm && h->have_onorm) ? nrm + 2 * c.Fn + 2 * c.Fe : nullptr;
+    std::vector<float> nf((size_t)N * c.Fn), ef((size_t)E * c.Fe), out((size_t)N * c.O);
+    const int W1 = c.Fn - c.O;
+    for (int64_t n = 0; n < N; ++n)
+        for (int f = 0; f < c.Fn; ++f) {
+            const float v = f < c.O ? x[n * c.O + f] : onehot[n * W1 + (f - c.O)];
+            nf[(size_t)n * c.Fn + f] = ns ? v * ns[f] + ns[c.Fn + f] : v;
+        }
+    for (int64_t j = 0; j < E; ++j)
+        for (int f = 0; f < c.Fe; ++f) ef[(size_t)j * c.Fe + f] = es ? ef_raw[j * c.Fe + f] * es[f] + es[c.Fe + f] : ef_raw[j * c.Fe + f];
+    if (int rc = lnall_forward(h, nf.data(), ef.data(), out.data())) return rc;
+    for (int64_t n = 0; n < N; ++n)
+        for (int o = 0; o < c.O; ++o) {
+            const float y = os ? out[(size_t)n * c.O + o] * os[o] + os[c.O + o] : out[(size_t)n * c.O + o];
+            dxdt[n * c.O + o] = val_mask ? y * val_mask[n] : y;
+        }
+    return MGN_OK;
+}
+
 int mgn_ode_step(mgn_handle* h, const float* x, const float* onehot, const float* ef_raw, const float* val_mask, float* dxdt) try {
+    if (h && !h->host_only && h->cfg.ln_dims == MGN_LN_ALL) return lnall_ode_step(h, x, onehot, ef_raw, val_mask, dxdt);
     if (int rc = need(h, true, true)) return rc;
     const mgn_config& c = h->cfg;
     if (h->cfg.nranks != 1) if (int rc = need_comm(h, "mgn_ode_step")) return rc;

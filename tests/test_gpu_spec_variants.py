@@ -139,8 +139,8 @@ def test_whole_array_layernorm_is_an_engine_mode(whole_array_oracle):
     """mgn_config.ln_dims = MGN_LN_ALL: LayerNorm statistics over the whole (L x rows) output of every MLP -- what Lux 0.5's
     LayerNorm(shape) computes when it is left at dims = Colon() (reference Project.toml:15,40; julia/spec_probe.jl reports it).  The
     engine reproduces the GOLD-G `out_whole_array` fixture, follows the oracle's LN_DIMS = "all" on a 22 500-node mesh (forward of the
-    whole model and processor steps, hidden_layers 2 and 3, both ln_mode denominators), is really the other network, and refuses the
-    entry points whose fused kernels cannot compute it."""
+    whole model and processor steps, hidden_layers 2 and 3, both ln_mode denominators) and in the one-shot right-hand side, is really the
+    other network, and refuses the entry points whose fused kernels cannot compute it."""
     g = np.load(os.path.join(GOLD, "gold_g_ln_variants.npz"))
     cfg = cfg_dict(L=int(g["L"]), mps=int(g["mps"]))
     ps = orc.init_params(9, 3, 2, cfg["L"], 2, cfg["mps"], seed=int(g["seed"]), ln_jitter=float(g["jitter"]))
@@ -150,7 +150,20 @@ def test_whole_array_layernorm_is_an_engine_mode(whole_array_oracle):
     out = eng.forward(g["nf"], g["ef"])
     assert rel_max(out, g["out_whole_array"]) <= TOL_15
     assert rel_max(out, g["out_v1"]) > 20 * rel_max(out, g["out_whole_array"])
-    for call in (lambda: eng.ode_step(np.zeros((48, 2), np.float32), np.zeros((48, 7), np.float32), g["ef"]), lambda: eng.latents_randn(1) or eng.processor_steps_dev(1),
+    # the right-hand side the Julia-driven solver calls once per evaluation (one-shot form): build_graph's normalisers, the model,
+    # inverse_data, val_mask -- against the oracle's ode_rhs under LN_DIMS = "all"
+    rng0 = np.random.default_rng(8)
+    N0 = g["nf"].shape[0]
+    x0 = (rng0.standard_normal((N0, 2)) * 0.3 + 1.0).astype(np.float32)
+    onehot0 = np.eye(7, dtype=np.float32)[rng0.integers(0, 7, N0)]
+    vm0 = (rng0.random(N0) < 0.7).astype(np.float32)
+    n_norm, t_norm = orc.NormMeanStd(np.array([1.0, 0.9]), np.array([0.31, 0.27])), orc.NormMinMax(0.0, 1.0)
+    e_norm, o_norm = orc.NormMeanStd(g["ef"].mean(0), g["ef"].std(0)), orc.NormMeanStd(np.array([0.01, -0.02]), np.array([0.5, 0.4]))
+    (ns, nsh), (ts, tsh), (es, esh) = n_norm.affine(2), t_norm.affine(7), e_norm.affine(3)
+    eng.set_norms(node=(np.concatenate([ns, ts]), np.concatenate([nsh, tsh])), edge=(es, esh), out=(o_norm.std, o_norm.mean))
+    d_ref = orc.ode_rhs(ps, cfg, x0, onehot0, g["ef"], g["senders"], g["receivers"], n_norm, t_norm, e_norm, o_norm, vm0[:, None])
+    assert rel_max(eng.ode_step(x0, onehot0, g["ef"], vm0), d_ref) <= TOL_15
+    for call in (lambda: eng.ode_step(x0), lambda: eng.latents_randn(1) or eng.processor_steps_dev(1),      # (resident-input form; fused kernels)
                  lambda: eng.step(g["nf"], g["ef"], np.zeros((48, 2), np.float32), np.arange(4, dtype=np.int32))):
         with pytest.raises(MgnError) as ei:
             call()
