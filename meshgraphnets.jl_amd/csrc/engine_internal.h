@@ -136,6 +136,10 @@ struct mgn_engine {
                       // two fp16 pieces (kind 4 of WPackJob): offsets, the power of two each chunk was multiplied by, max(0, max b2)
                       size_t eh_ch[MAX_EDGE_SETS][3], nh_ch[6], e16h_ch[MAX_EDGE_SETS][3], n16h_ch[9]; float eh_s[MAX_EDGE_SETS][3], nh_s[9], e_b2pos[MAX_EDGE_SETS], n_b2pos; bool have_h; };   // n2_ch (two edge sets): W1[2L:3L], WP / WQ of set 1
     std::vector<SplitOff> spoff;
+    // encoders / decoder on two fp16 pieces (kind 4 of WPackJob): offsets into wsp and the chunks' powers of two; have_ench: built
+    size_t enh_ch[4] = {0, 0, 0, 0}, eeh_ch[MAX_EDGE_SETS][2] = {}, deh_ch[2] = {0, 0};
+    float enh_s[4] = {1, 1, 1, 1}, eeh_s[MAX_EDGE_SETS][2] = {}, deh_s[2] = {1, 1};
+    bool have_ench = false;
     // static per-trajectory RHS inputs (mgn_set_static): cached encoded edge latents
     bool have_static = false;
     DevBuf stage;     // device staging image of caller-order latents (import / export)

@@ -104,6 +104,8 @@ struct EncNodeArgs {
     const float* chunk[MAX_CHUNKS];  // 0:W2 1:W3 2:WP 3:WQ
     const float* tabs;
     GenMlp gen;
+    const uint16_t* splith[4];       // the same chunks as two fp16 pieces (split_common.hpp), h2_rs[i] = 1 / chunk i's power of two; null: not built
+    float h2_rs[4];
 };
 
 struct EncEdgeArgs {
@@ -116,6 +118,8 @@ struct EncEdgeArgs {
     const float* chunk[MAX_CHUNKS];  // 0:W2 1:W3
     const float* tabs;
     GenMlp gen;
+    const uint16_t* splith[2];       // see EncNodeArgs
+    float h2_rs[2];
 };
 
 struct DecArgs {
@@ -131,6 +135,8 @@ struct DecArgs {
     const float* chunk[MAX_CHUNKS];  // 0:W1 1:W2
     const float* tabs;      // b1,b2
     GenMlp gen;             // decoder: chunk[0 .. nmid-1] = W2 .. W_h, no last chunk (L -> O runs on the VALU)
+    const uint16_t* splith[2];       // see EncNodeArgs
+    float h2_rs[2];
 };
 
 // ---- bf16 processor (BASELINE cfg-3 precision): bf16 storage + bf16 MFMA, fp32 accumulate / LayerNorm / residual /

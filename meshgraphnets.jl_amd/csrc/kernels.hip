@@ -1385,24 +1385,50 @@ DEVINL void first_layer(f32x16 (&acc)[NT], const float* w1f, int k, float xk, in
         }
 }
 
+// One chunk of an encoder / decoder chain: acc += in W on the fp32 MFMA pipe (fragment-order chunk in LDS or L2) or, H2 (round 5: L = 128,
+// the split path's switch), on the chunk's two fp16 pieces (split_common.hpp: h2_chunk_inplace; same 64 KiB per chunk, LDS or L2).
+template <int NT, bool RES, bool H2>
+DEVINL void enc_chunk(f32x16 (&acc)[NT], const f32x16 (&in)[NT], const float* w, int lane, float rsw) {
+    if constexpr (H2) {
+        static_assert(NT == 4, "the fp16 pieces exist at L = 128");
+        h2_chunk_inplace(acc, in, w, lane, rsw);
+    } else {
+        mfma_chunk<NT, RES>(acc, in, w, lane);
+    }
+}
+// the cooperative kernels' chains: this wave's feature block of acc += in W (fp32: t-major copy through CoopRing; H2: the pieces through H2CoopRing)
+template <bool H2> struct ERing;
+template <> struct ERing<false> { CoopRing r; };
+template <> struct ERing<true> { H2CoopRing r; };
+template <bool H2>
+DEVINL void e_prime(ERing<H2>& g, const float* chunk, const uint16_t* pieces, int tq, int lane) {
+    if constexpr (H2) h2c_prime(g.r, reinterpret_cast<const u32x4*>(pieces) + tq * 64 + lane);
+    else coop_prime(g.r, chunk + 128 * 128 + tq * 4096, lane);
+}
+template <bool H2, bool FENCE>
+DEVINL void e_chain_primed(f32x16& acc, const f32x16 (&in)[4], const float* chunk, const uint16_t* pieces, float rsw, int tq, int lane, ERing<H2>& g) {
+    if constexpr (H2) h2c_chain_primed(acc, in, reinterpret_cast<const u32x4*>(pieces) + tq * 64 + lane, g.r, rsw);
+    else coop_chain_primed<FENCE>(acc, in, chunk + 128 * 128 + tq * 4096, lane, g.r);
+}
+
 // ================================================================================================
 // Encoder, node side (K0a+K1) + projection of step-0 P,Q.  chunk[0]=W2 [1]=W3 [2]=WP [3]=WQ
 // ================================================================================================
-template <int NT, int NRES, bool GEN = false>
+template <int NT, int NRES, bool GEN = false, bool H2 = false>
 __global__ __launch_bounds__(512, 2) void k_enc_node(const EncNodeArgs a) {
     constexpr int L = 32 * NT, CH = 16 * NT * 64 * NT;
     extern __shared__ __attribute__((aligned(16))) float smem[];
 #pragma unroll
-    for (int r = 0; r < NRES; ++r) copy_to_lds(smem + r * CH, a.chunk[r], CH);
+    for (int r = 0; r < NRES; ++r) copy_to_lds(smem + r * CH, H2 ? reinterpret_cast<const float*>(a.splith[r]) : a.chunk[r], CH);
     float* tb = smem + NRES * CH;
     copy_to_lds(tb, a.tabs, T_COUNT * L);
     __syncthreads();
     const int lane0 = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const float* w2 = NRES > 0 ? smem : a.chunk[0];
-    const float* w3 = NRES > 1 ? smem + CH : a.chunk[1];
-    const float* wp = NRES > 2 ? smem + 2 * CH : a.chunk[2];
-    const float* wq = NRES > 3 ? smem + 3 * CH : a.chunk[3];
+    const float* w2 = NRES > 0 ? smem : (H2 ? reinterpret_cast<const float*>(a.splith[0]) : a.chunk[0]);
+    const float* w3 = NRES > 1 ? smem + CH : (H2 ? reinterpret_cast<const float*>(a.splith[1]) : a.chunk[1]);
+    const float* wp = NRES > 2 ? smem + 2 * CH : (H2 ? reinterpret_cast<const float*>(a.splith[2]) : a.chunk[2]);
+    const float* wq = NRES > 3 ? smem + 3 * CH : (H2 ? reinterpret_cast<const float*>(a.splith[3]) : a.chunk[3]);
 
     for (TileWalk tw(a.ntiles, wave); tw.tile < tw.end; tw.tile += tw.stride) {
         OPAQUE_LANE();
@@ -1424,19 +1450,19 @@ __global__ __launch_bounds__(512, 2) void k_enc_node(const EncNodeArgs a) {
         } else {
             relu_frag<NT>(acc);
             tab_frag<NT>(y, tb + T_B2 * L, h);
-            mfma_chunk<NT, (NRES > 0)>(y, acc, w2, lane);
+            enc_chunk<NT, (NRES > 0), H2>(y, acc, w2, lane, a.h2_rs[0]);
             relu_frag<NT>(y);
             tab_frag<NT>(acc, tb + T_B3 * L, h);
-            mfma_chunk<NT, (NRES > 1)>(acc, y, w3, lane);
+            enc_chunk<NT, (NRES > 1), H2>(acc, y, w3, lane, a.h2_rs[1]);
         }
         layer_norm_frag<NT>(acc, tb + T_GAMMA * L, tb + T_BETA * L, h);
         if (!valid) zero_frag<NT>(acc);                          // padding rows stay zero (checksums)
         store_frag<NT>(tile_ptr(a.V, tw.tile, L, lane), STRIDE_TILE, acc);
         zero_frag<NT>(y);
-        mfma_chunk<NT, (NRES > 2)>(y, acc, wp, lane);
+        enc_chunk<NT, (NRES > 2), H2>(y, acc, wp, lane, a.h2_rs[2]);
         if (valid) store_frag<NT>(prow_ptr(a.P, nn, L, h), STRIDE_PROW, y);
         tab_frag<NT>(y, tb + T_BQ * L, h);
-        mfma_chunk<NT, (NRES > 3)>(y, acc, wq, lane);
+        enc_chunk<NT, (NRES > 3), H2>(y, acc, wq, lane, a.h2_rs[3]);
         if (valid) store_frag<NT>(prow_ptr(a.Q, nn, L, h), STRIDE_PROW, y);
     }
 }
@@ -1446,7 +1472,7 @@ __global__ __launch_bounds__(512, 2) void k_enc_node(const EncNodeArgs a) {
 // mesh the one-wave-per-tile encoder / decoder cost 60 + 32 us of every 840 us right-hand side of a rollout.
 // ================================================================================================
 // chunk[0]=W2 [1]=W3 [2]=WP [3]=WQ; the t-major copy of a chunk follows its fragment-major copy (mgn_set_params)
-template <bool FENCE>
+template <bool FENCE, bool H2 = false>
 __global__ __launch_bounds__(256, 2) void k_enc_node_coop(const EncNodeArgs a) {
     constexpr int L = 128, CH = L * L;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -1458,10 +1484,6 @@ __global__ __launch_bounds__(256, 2) void k_enc_node_coop(const EncNodeArgs a) {
     const int lane0 = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int tq = wave;
-    const float* w2 = a.chunk[0] + CH + tq * 4096;
-    const float* w3 = a.chunk[1] + CH + tq * 4096;
-    const float* wp = a.chunk[2] + CH + tq * 4096;
-    const float* wq = a.chunk[3] + CH + tq * 4096;
     for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
         OPAQUE_LANE();
         const int n = tile * TILE + c;
@@ -1469,8 +1491,8 @@ __global__ __launch_bounds__(256, 2) void k_enc_node_coop(const EncNodeArgs a) {
         const int nn = valid ? n : 0;
         const int64_t g = a.gid ? a.gid[nn] : nn;     // null gid: the source rows are already in local order
         f32x16 in[4], acc;
-        CoopRing r2, r3;
-        coop_prime(r2, w2, lane);
+        ERing<H2> r2, r3;
+        e_prime<H2>(r2, a.chunk[0], a.splith[0], tq, lane);
         // layer 1 (a handful of input features: VALU), every wave the full row
         tab_frag<4>(in, tb + T_B1 * L, h);
         const int Fn = a.wa + a.wb;
@@ -1481,13 +1503,13 @@ __global__ __launch_bounds__(256, 2) void k_enc_node_coop(const EncNodeArgs a) {
         }
         relu_frag<4>(in);
         tab_quarter(acc, tb + T_B2 * L, tq, h);
-        coop_prime(r3, w3, lane);
-        coop_chain_primed<FENCE>(acc, in, w2, lane, r2);                            // layer 2
+        e_prime<H2>(r3, a.chunk[1], a.splith[1], tq, lane);
+        e_chain_primed<H2, FENCE>(acc, in, a.chunk[0], a.splith[0], a.h2_rs[0], tq, lane, r2);                            // layer 2
         relu_quarter(acc);
         coop_exchange(in, acc, xch0, wave, lane);
         tab_quarter(acc, tb + T_B3 * L, tq, h);
-        coop_prime(r2, wp, lane);
-        coop_chain_primed<FENCE>(acc, in, w3, lane, r3);                            // layer 3
+        e_prime<H2>(r2, a.chunk[2], a.splith[2], tq, lane);
+        e_chain_primed<H2, FENCE>(acc, in, a.chunk[1], a.splith[1], a.h2_rs[1], tq, lane, r3);                            // layer 3
         coop_exchange(in, acc, xch1, wave, lane);
         coop_layer_norm(acc, in, tb + T_GAMMA * L, tb + T_BETA * L, tq, h);
         if (!valid) {
@@ -1495,21 +1517,21 @@ __global__ __launch_bounds__(256, 2) void k_enc_node_coop(const EncNodeArgs a) {
             for (int k = 0; k < 16; ++k) acc[k] = 0.f;                        // padding rows stay zero (checksums)
         }
         store_quarter(tile_ptr(a.V, tile, L, lane), STRIDE_TILE, tq, acc);
-        coop_prime(r3, wq, lane);
+        e_prime<H2>(r3, a.chunk[3], a.splith[3], tq, lane);
         coop_exchange(in, acc, xch0, wave, lane);                            // full latent row for the projection
 #pragma unroll
         for (int k = 0; k < 16; ++k) acc[k] = 0.f;
-        coop_chain_primed<FENCE>(acc, in, wp, lane, r2);
+        e_chain_primed<H2, FENCE>(acc, in, a.chunk[2], a.splith[2], a.h2_rs[2], tq, lane, r2);
         if (valid) store_quarter(prow_ptr(a.P, nn, L, h), STRIDE_PROW, tq, acc);
         tab_quarter(acc, tb + T_BQ * L, tq, h);
-        coop_chain_primed<FENCE>(acc, in, wq, lane, r3);
+        e_chain_primed<H2, FENCE>(acc, in, a.chunk[3], a.splith[3], a.h2_rs[3], tq, lane, r3);
         if (valid) store_quarter(prow_ptr(a.Q, nn, L, h), STRIDE_PROW, tq, acc);
         __syncthreads();
     }
 }
 
 // edge encoder: chunk[0]=W2 [1]=W3
-template <bool FENCE>
+template <bool FENCE, bool H2 = false>
 __global__ __launch_bounds__(256, 2) void k_enc_edge_coop(const EncEdgeArgs a) {
     constexpr int L = 128, CH = L * L;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -1521,16 +1543,14 @@ __global__ __launch_bounds__(256, 2) void k_enc_edge_coop(const EncEdgeArgs a) {
     const int lane0 = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int tq = wave;
-    const float* w2 = a.chunk[0] + CH + tq * 4096;
-    const float* w3 = a.chunk[1] + CH + tq * 4096;
     for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
         OPAQUE_LANE();
         const int64_t eid = (int64_t)tile * TILE + c;
         const bool valid = eid < a.E;
         const int64_t g = a.gid ? a.gid[valid ? eid : 0] : (valid ? eid : 0);
         f32x16 in[4], acc;
-        CoopRing r2, r3;
-        coop_prime(r2, w2, lane);
+        ERing<H2> r2, r3;
+        e_prime<H2>(r2, a.chunk[0], a.splith[0], tq, lane);
         tab_frag<4>(in, tb + T_B1 * L, h);
         for (int k = 0; k < a.Fe; ++k) {
             float xk = a.ef[g * a.Fe + k];
@@ -1539,12 +1559,12 @@ __global__ __launch_bounds__(256, 2) void k_enc_edge_coop(const EncEdgeArgs a) {
         }
         relu_frag<4>(in);
         tab_quarter(acc, tb + T_B2 * L, tq, h);
-        coop_prime(r3, w3, lane);
-        coop_chain_primed<FENCE>(acc, in, w2, lane, r2);
+        e_prime<H2>(r3, a.chunk[1], a.splith[1], tq, lane);
+        e_chain_primed<H2, FENCE>(acc, in, a.chunk[0], a.splith[0], a.h2_rs[0], tq, lane, r2);
         relu_quarter(acc);
         coop_exchange(in, acc, xch0, wave, lane);
         tab_quarter(acc, tb + T_B3 * L, tq, h);
-        coop_chain_primed<FENCE>(acc, in, w3, lane, r3);
+        e_chain_primed<H2, FENCE>(acc, in, a.chunk[1], a.splith[1], a.h2_rs[1], tq, lane, r3);
         coop_exchange(in, acc, xch1, wave, lane);
         coop_layer_norm(acc, in, tb + T_GAMMA * L, tb + T_BETA * L, tq, h);
         if (!valid) {
@@ -1557,7 +1577,7 @@ __global__ __launch_bounds__(256, 2) void k_enc_edge_coop(const EncEdgeArgs a) {
 }
 
 // chunk[0]=W1 [1]=W2; last layer (L -> O) by wave 0 from the exchanged row
-template <bool FENCE>
+template <bool FENCE, bool H2 = false>
 __global__ __launch_bounds__(256, 2) void k_decode_coop(const DecArgs a) {
     constexpr int L = 128, CH = L * L;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -1569,23 +1589,21 @@ __global__ __launch_bounds__(256, 2) void k_decode_coop(const DecArgs a) {
     const int lane0 = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int tq = wave;
-    const float* w1 = a.chunk[0] + CH + tq * 4096;
-    const float* w2 = a.chunk[1] + CH + tq * 4096;
     for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
         OPAQUE_LANE();
         const int n = tile * TILE + c;
         const bool valid = n < a.n;
         const int nn = valid ? n : 0;
         f32x16 in[4], acc;
-        CoopRing r2;
-        coop_prime(r2, w2, lane);
+        ERing<H2> r2;
+        e_prime<H2>(r2, a.chunk[1], a.splith[1], tq, lane);
         load_frag<4>(in, tile_ptr(a.V, tile, L, lane), STRIDE_TILE);
         tab_quarter(acc, tb + T_B1 * L, tq, h);
-        coop_chain<FENCE>(acc, in, w1, lane);
+        { ERing<H2> r1; e_prime<H2>(r1, a.chunk[0], a.splith[0], tq, lane); __builtin_amdgcn_sched_barrier(0); e_chain_primed<H2, FENCE>(acc, in, a.chunk[0], a.splith[0], a.h2_rs[0], tq, lane, r1); }
         relu_quarter(acc);
         coop_exchange(in, acc, xch0, wave, lane);
         tab_quarter(acc, tb + T_B2 * L, tq, h);
-        coop_chain_primed<FENCE>(acc, in, w2, lane, r2);
+        e_chain_primed<H2, FENCE>(acc, in, a.chunk[1], a.splith[1], a.h2_rs[1], tq, lane, r2);
         relu_quarter(acc);
         coop_exchange(in, acc, xch1, wave, lane);
         if (wave == 0) {
@@ -1615,19 +1633,19 @@ __global__ __launch_bounds__(256, 2) void k_decode_coop(const DecArgs a) {
 // ================================================================================================
 // Encoder, edge side (K0b+K2).  chunk[0]=W2 [1]=W3
 // ================================================================================================
-template <int NT, int NRES, bool GEN = false>
+template <int NT, int NRES, bool GEN = false, bool H2 = false>
 __global__ __launch_bounds__(512, 2) void k_enc_edge(const EncEdgeArgs a) {
     constexpr int L = 32 * NT, CH = 16 * NT * 64 * NT;
     extern __shared__ __attribute__((aligned(16))) float smem[];
 #pragma unroll
-    for (int r = 0; r < NRES; ++r) copy_to_lds(smem + r * CH, a.chunk[r], CH);
+    for (int r = 0; r < NRES; ++r) copy_to_lds(smem + r * CH, H2 ? reinterpret_cast<const float*>(a.splith[r]) : a.chunk[r], CH);
     float* tb = smem + NRES * CH;
     copy_to_lds(tb, a.tabs, T_COUNT * L);
     __syncthreads();
     const int lane0 = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const float* w2 = NRES > 0 ? smem : a.chunk[0];
-    const float* w3 = NRES > 1 ? smem + CH : a.chunk[1];
+    const float* w2 = NRES > 0 ? smem : (H2 ? reinterpret_cast<const float*>(a.splith[0]) : a.chunk[0]);
+    const float* w3 = NRES > 1 ? smem + CH : (H2 ? reinterpret_cast<const float*>(a.splith[1]) : a.chunk[1]);
 
     for (TileWalk tw(a.ntiles, wave); tw.tile < tw.end; tw.tile += tw.stride) {
         OPAQUE_LANE();
@@ -1648,10 +1666,10 @@ __global__ __launch_bounds__(512, 2) void k_enc_edge(const EncEdgeArgs a) {
         } else {
             relu_frag<NT>(acc);
             tab_frag<NT>(y, tb + T_B2 * L, h);
-            mfma_chunk<NT, (NRES > 0)>(y, acc, w2, lane);
+            enc_chunk<NT, (NRES > 0), H2>(y, acc, w2, lane, a.h2_rs[0]);
             relu_frag<NT>(y);
             tab_frag<NT>(acc, tb + T_B3 * L, h);
-            mfma_chunk<NT, (NRES > 1)>(acc, y, w3, lane);
+            enc_chunk<NT, (NRES > 1), H2>(acc, y, w3, lane, a.h2_rs[1]);
         }
         layer_norm_frag<NT>(acc, tb + T_GAMMA * L, tb + T_BETA * L, h);
         if (!valid) zero_frag<NT>(acc);
@@ -1662,19 +1680,19 @@ __global__ __launch_bounds__(512, 2) void k_enc_edge(const EncEdgeArgs a) {
 // ================================================================================================
 // Decoder (K7) + inverse normaliser + val_mask epilogue (K8).  chunk[0]=W1 [1]=W2
 // ================================================================================================
-template <int NT, int NRES, bool GEN = false>
+template <int NT, int NRES, bool GEN = false, bool H2 = false>
 __global__ __launch_bounds__(512, 2) void k_decode(const DecArgs a) {
     constexpr int L = 32 * NT, CH = 16 * NT * 64 * NT;
     extern __shared__ __attribute__((aligned(16))) float smem[];
 #pragma unroll
-    for (int r = 0; r < NRES; ++r) copy_to_lds(smem + r * CH, a.chunk[r], CH);
+    for (int r = 0; r < NRES; ++r) copy_to_lds(smem + r * CH, H2 ? reinterpret_cast<const float*>(a.splith[r]) : a.chunk[r], CH);
     float* tb = smem + NRES * CH;
     copy_to_lds(tb, a.tabs, T_COUNT * L);
     __syncthreads();
     const int lane0 = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const float* w1 = NRES > 0 ? smem : a.chunk[0];
-    const float* w2 = NRES > 1 ? smem + CH : a.chunk[1];
+    const float* w1 = NRES > 0 ? smem : (H2 ? reinterpret_cast<const float*>(a.splith[0]) : a.chunk[0]);
+    const float* w2 = NRES > 1 ? smem + CH : (H2 ? reinterpret_cast<const float*>(a.splith[1]) : a.chunk[1]);
 
     for (TileWalk tw(a.ntiles, wave); tw.tile < tw.end; tw.tile += tw.stride) {
         OPAQUE_LANE();
@@ -1684,7 +1702,7 @@ __global__ __launch_bounds__(512, 2) void k_decode(const DecArgs a) {
         f32x16 v[NT], acc[NT];
         load_frag<NT>(v, tile_ptr(a.V, tw.tile, L, lane), STRIDE_TILE);
         tab_frag<NT>(acc, tb + T_B1 * L, h);
-        mfma_chunk<NT, (NRES > 0)>(acc, v, w1, lane);
+        enc_chunk<NT, (NRES > 0), H2>(acc, v, w1, lane, a.h2_rs[0]);
         if constexpr (GEN) {                                    // middle layers, then the L -> O layer below reads v
             gen_hidden<NT>(acc, v, a.gen, lane, h);
 #pragma unroll
@@ -1692,7 +1710,7 @@ __global__ __launch_bounds__(512, 2) void k_decode(const DecArgs a) {
         } else {
             relu_frag<NT>(acc);
             tab_frag<NT>(v, tb + T_B2 * L, h);
-            mfma_chunk<NT, (NRES > 1)>(v, acc, w2, lane);
+            enc_chunk<NT, (NRES > 1), H2>(v, acc, w2, lane, a.h2_rs[1]);
             relu_frag<NT>(v);
         }
         const float m = a.mask ? a.mask[a.gid ? a.gid[nn] : nn] : 1.0f;
@@ -2761,11 +2779,13 @@ static hipError_t launch_k(K kern, const A& a, const LaunchCfg& lc, hipStream_t 
         if ((NTILES) <= 0) return hipSuccess;                                                  \
         const int nres = resident_chunks(L, WANT);                                             \
         const LaunchCfg lc = tile_launch(L, NTILES, nres);                                     \
+        const bool h2_ = L == 128 && g_fp32_split && g_split_f16 && (ARGS).splith[0];          \
         if (L == 128 && small_launch(NTILES)) {                                                \
             LaunchCfg l0 = lc;                                                                 \
             l0.lds = (size_t)T_COUNT * L * 4 + 64;                                             \
-            return launch_k(KERN<4, 0>, ARGS, l0, s);                                          \
+            return h2_ ? launch_k(KERN<4, 0, false, true>, ARGS, l0, s) : launch_k(KERN<4, 0>, ARGS, l0, s); \
         }                                                                                      \
+        if (L == 128 && h2_) return launch_k(KERN<4, (WANT < 2 ? WANT : 2), false, true>, ARGS, lc, s); \
         if (L == 128) return launch_k(KERN<4, (WANT < 2 ? WANT : 2)>, ARGS, lc, s);            \
         if (L == 64) return launch_k(KERN<2, WANT>, ARGS, lc, s);                              \
         if (L == 32) return launch_k(KERN<1, WANT>, ARGS, lc, s);                              \
@@ -3039,6 +3059,7 @@ hipError_t launch_enc_node(int L, const EncNodeArgs& a, hipStream_t s) {
     if (a.gen.use) DISPATCH_GEN(L, (k_enc_node<4, 0, true>), (k_enc_node<2, 0, true>), (k_enc_node<1, 0, true>), a, a.ntiles);
     if (a.ntiles > 0 && L == 128 && coop_size(a.ntiles, false)) {
         LaunchCfg c4{a.ntiles, 256, coop_lds()};
+        if (g_fp32_split && g_split_f16 && a.splith[0]) return coop_fence(a.ntiles) ? launch_k(k_enc_node_coop<true, true>, a, c4, s) : launch_k(k_enc_node_coop<false, true>, a, c4, s);
         return coop_fence(a.ntiles) ? launch_k(k_enc_node_coop<true>, a, c4, s) : launch_k(k_enc_node_coop<false>, a, c4, s);
     }
     DISPATCH_L(k_enc_node, 4, a, a.ntiles);
@@ -3047,6 +3068,7 @@ hipError_t launch_enc_edge(int L, const EncEdgeArgs& a, hipStream_t s) {
     if (a.gen.use) DISPATCH_GEN(L, (k_enc_edge<4, 0, true>), (k_enc_edge<2, 0, true>), (k_enc_edge<1, 0, true>), a, a.ntiles);
     if (a.ntiles > 0 && L == 128 && coop_size(a.ntiles, true)) {
         LaunchCfg c4{a.ntiles, 256, coop_lds()};
+        if (g_fp32_split && g_split_f16 && a.splith[0]) return coop_fence(a.ntiles) ? launch_k(k_enc_edge_coop<true, true>, a, c4, s) : launch_k(k_enc_edge_coop<false, true>, a, c4, s);
         return coop_fence(a.ntiles) ? launch_k(k_enc_edge_coop<true>, a, c4, s) : launch_k(k_enc_edge_coop<false>, a, c4, s);
     }
     DISPATCH_L(k_enc_edge, 2, a, a.ntiles);
@@ -3055,6 +3077,7 @@ hipError_t launch_decode(int L, const DecArgs& a, hipStream_t s) {
     if (a.gen.use) DISPATCH_GEN(L, (k_decode<4, 0, true>), (k_decode<2, 0, true>), (k_decode<1, 0, true>), a, a.ntiles);
     if (a.ntiles > 0 && L == 128 && coop_size(a.ntiles, false)) {
         LaunchCfg c4{a.ntiles, 256, coop_lds()};
+        if (g_fp32_split && g_split_f16 && a.splith[0]) return coop_fence(a.ntiles) ? launch_k(k_decode_coop<true, true>, a, c4, s) : launch_k(k_decode_coop<false, true>, a, c4, s);
         return coop_fence(a.ntiles) ? launch_k(k_decode_coop<true>, a, c4, s) : launch_k(k_decode_coop<false>, a, c4, s);
     }
     DISPATCH_L(k_decode, 2, a, a.ntiles);

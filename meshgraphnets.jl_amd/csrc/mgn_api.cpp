@@ -940,6 +940,31 @@ int pack_inference_weights(mgn_engine* h) {
             }
             h->spoff[k].have_n = true;
         }
+        h->have_ench = false;
+        if (f32) {          // encoders and decoder (32x32x16 order only: their kernels are the 32-row ones)
+            size_t unused = 0;
+            auto only32 = [&](const float* src, int kb, size_t& oh, float& sc) {
+                const size_t before = jobs.size();
+                puth(src, kb, oh, unused, sc);
+                jobs.pop_back();                                          // (drop the 16x16x32 copy puth appended)
+                off -= (size_t)2 * 16384;
+                (void)before;
+            };
+            const MlpOff& mn = h->enc_node;
+            only32(p + mn.W[1], 0, h->enh_ch[0], h->enh_s[0]);
+            only32(p + mn.W[2], 0, h->enh_ch[1], h->enh_s[1]);
+            only32(p + e0.W[0], 0, h->enh_ch[2], h->enh_s[2]);
+            only32(p + e0.W[0], L, h->enh_ch[3], h->enh_s[3]);
+            for (int q = 0; q < S; ++q) {
+                const MlpOff& me = h->es[q].enc;
+                only32(p + me.W[1], 0, h->eeh_ch[q][0], h->eeh_s[q][0]);
+                only32(p + me.W[2], 0, h->eeh_ch[q][1], h->eeh_s[q][1]);
+            }
+            const MlpOff& md = h->dec;
+            only32(p + md.W[0], 0, h->deh_ch[0], h->deh_s[0]);
+            only32(p + md.W[1], 0, h->deh_ch[1], h->deh_s[1]);
+            h->have_ench = true;
+        }
         HIPCHK(h, hipStreamSynchronize(h->stream));
         HIPCHK(h, h->wsp.ensure(off * 2));
     }
@@ -1314,6 +1339,10 @@ static int encode_impl(mgn_handle* h, bool use_norms, bool nodes = true, bool ed
         a.P = h->es[0].P.as<float>();
         a.Q = h->es[0].Q.as<float>();
         for (int i = 0; i < 4; ++i) a.chunk[i] = W(h, h->en_ch[i]);
+        for (int i = 0; i < 4; ++i) {
+            a.splith[i] = (h->have_ench && h->wsp.p) ? h->wsp.as<uint16_t>() + h->enh_ch[i] : nullptr;
+            a.h2_rs[i] = h->have_ench ? 1.f / h->enh_s[i] : 1.f;
+        }
         a.tabs = W(h, h->en_tabs);
         a.gen = gen_of(h, h->en_gen, true);
         HIPCHK(h, launch_enc_node(c.L, a, h->stream));
@@ -1337,6 +1366,10 @@ static int encode_impl(mgn_handle* h, bool use_norms, bool nodes = true, bool ed
             b.w1f = W(h, es.ee_w1f);
             b.Elat = es.Elat.as<float>();
             for (int i = 0; i < 2; ++i) b.chunk[i] = W(h, es.ee_ch[i]);
+            for (int i = 0; i < 2; ++i) {
+                b.splith[i] = (h->have_ench && h->wsp.p) ? h->wsp.as<uint16_t>() + h->eeh_ch[q][i] : nullptr;
+                b.h2_rs[i] = h->have_ench ? 1.f / h->eeh_s[q][i] : 1.f;
+            }
             b.tabs = W(h, es.ee_tabs);
             b.gen = gen_of(h, es.ee_gen, true);
             HIPCHK(h, launch_enc_edge(c.L, b, h->stream));
@@ -1481,6 +1514,10 @@ static int decode_impl(mgn_handle* h, bool use_norms) {
     a.gid = h->d_own_gid.as<int32_t>();
     a.out = h->out_override ? h->out_override : h->d_out.as<float>();
     for (int i = 0; i < 2; ++i) a.chunk[i] = W(h, h->de_ch[i]);
+    for (int i = 0; i < 2; ++i) {
+        a.splith[i] = (h->have_ench && h->wsp.p) ? h->wsp.as<uint16_t>() + h->deh_ch[i] : nullptr;
+        a.h2_rs[i] = h->have_ench ? 1.f / h->deh_s[i] : 1.f;
+    }
     a.tabs = W(h, h->de_tabs);
     a.gen = gen_of(h, h->de_gen, false);
     HIPCHK(h, launch_decode(c.L, a, h->stream));

@@ -624,9 +624,17 @@ __global__ void k_segment_sum(const float* __restrict__ src, const int32_t* __re
     if (i >= (int64_t)n * L4) return;
     const int node = (int)(i / L4), q = (int)(i - (int64_t)node * L4);
     f32x4 s = add ? reinterpret_cast<const f32x4*>(add)[i] : f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int p = rowptr[node]; p < rowptr[node + 1]; ++p) {
+    const f32x4* S4 = reinterpret_cast<const f32x4*>(src);
+    int p = rowptr[node];
+    const int e1 = rowptr[node + 1];
+    for (; p + 4 <= e1; p += 4) {                        // (four rows in flight, added in order: see k_segment_sum2)
+        const int64_t r0 = perm ? perm[p] : p, r1 = perm ? perm[p + 1] : p + 1, r2 = perm ? perm[p + 2] : p + 2, r3 = perm ? perm[p + 3] : p + 3;
+        const f32x4 v0 = S4[r0 * L4 + q], v1 = S4[r1 * L4 + q], v2 = S4[r2 * L4 + q], v3 = S4[r3 * L4 + q];
+        s += v0; s += v1; s += v2; s += v3;
+    }
+    for (; p < e1; ++p) {
         const int64_t row = perm ? perm[p] : p;
-        s += reinterpret_cast<const f32x4*>(src)[row * L4 + q];
+        s += S4[row * L4 + q];
     }
     reinterpret_cast<f32x4*>(out)[i] = s;
 }
@@ -640,8 +648,25 @@ __global__ void k_segment_sum2(const float* __restrict__ srcA, const int32_t* __
     if (i >= (int64_t)n * L4) return;
     const int node = (int)(i / L4), q = (int)(i - (int64_t)node * L4);
     f32x4 s = reinterpret_cast<const f32x4*>(add)[i];
-    for (int p = rowptrA[node]; p < rowptrA[node + 1]; ++p) s += reinterpret_cast<const f32x4*>(srcA)[(int64_t)p * L4 + q];
-    for (int p = rowptrB[node]; p < rowptrB[node + 1]; ++p) s += reinterpret_cast<const f32x4*>(srcB)[(int64_t)permB[p] * L4 + q];
+    // four rows requested together, added in their order (a mesh node has ~6 rows per list: as a plain loop the launch was a chain of
+    // dependent L2 round trips, 19.6 us on the cylinder mesh)
+    const f32x4* A4 = reinterpret_cast<const f32x4*>(srcA);
+    const f32x4* B4 = reinterpret_cast<const f32x4*>(srcB);
+    int p = rowptrA[node];
+    const int ea = rowptrA[node + 1];
+    for (; p + 4 <= ea; p += 4) {
+        const f32x4 v0 = A4[(int64_t)p * L4 + q], v1 = A4[(int64_t)(p + 1) * L4 + q], v2 = A4[(int64_t)(p + 2) * L4 + q], v3 = A4[(int64_t)(p + 3) * L4 + q];
+        s += v0; s += v1; s += v2; s += v3;
+    }
+    for (; p < ea; ++p) s += A4[(int64_t)p * L4 + q];
+    p = rowptrB[node];
+    const int eb = rowptrB[node + 1];
+    for (; p + 4 <= eb; p += 4) {
+        const int r0 = permB[p], r1 = permB[p + 1], r2 = permB[p + 2], r3 = permB[p + 3];
+        const f32x4 v0 = B4[(int64_t)r0 * L4 + q], v1 = B4[(int64_t)r1 * L4 + q], v2 = B4[(int64_t)r2 * L4 + q], v3 = B4[(int64_t)r3 * L4 + q];
+        s += v0; s += v1; s += v2; s += v3;
+    }
+    for (; p < eb; ++p) s += B4[(int64_t)permB[p] * L4 + q];
     reinterpret_cast<f32x4*>(out)[i] = s;
 }
 
@@ -650,11 +675,25 @@ __global__ void k_segment_sum_pair(const float* __restrict__ src, const int32_t*
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (int64_t)n * L4) return;
     const int node = (int)(i / L4), q = (int)(i - (int64_t)node * L4);
+    const f32x4* S4 = reinterpret_cast<const f32x4*>(src);
     f32x4 s = {0.f, 0.f, 0.f, 0.f};
-    for (int p = rowptr_r[node]; p < rowptr_r[node + 1]; ++p) s += reinterpret_cast<const f32x4*>(src)[(int64_t)p * L4 + q];
+    int p = rowptr_r[node];
+    const int er = rowptr_r[node + 1];
+    for (; p + 4 <= er; p += 4) {                        // (four rows in flight, added in order: see k_segment_sum2)
+        const f32x4 v0 = S4[(int64_t)p * L4 + q], v1 = S4[(int64_t)(p + 1) * L4 + q], v2 = S4[(int64_t)(p + 2) * L4 + q], v3 = S4[(int64_t)(p + 3) * L4 + q];
+        s += v0; s += v1; s += v2; s += v3;
+    }
+    for (; p < er; ++p) s += S4[(int64_t)p * L4 + q];
     reinterpret_cast<f32x4*>(out_r)[i] = s;
     s = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int p = rowptr_s[node]; p < rowptr_s[node + 1]; ++p) s += reinterpret_cast<const f32x4*>(src)[(int64_t)perm_s[p] * L4 + q];
+    p = rowptr_s[node];
+    const int es = rowptr_s[node + 1];
+    for (; p + 4 <= es; p += 4) {
+        const int r0 = perm_s[p], r1 = perm_s[p + 1], r2 = perm_s[p + 2], r3 = perm_s[p + 3];
+        const f32x4 v0 = S4[(int64_t)r0 * L4 + q], v1 = S4[(int64_t)r1 * L4 + q], v2 = S4[(int64_t)r2 * L4 + q], v3 = S4[(int64_t)r3 * L4 + q];
+        s += v0; s += v1; s += v2; s += v3;
+    }
+    for (; p < es; ++p) s += S4[(int64_t)perm_s[p] * L4 + q];
     reinterpret_cast<f32x4*>(out_s)[i] = s;
 }
 
