@@ -321,17 +321,39 @@ def parse_data(example, meta):
     return out
 
 
+class Dataset:
+    """Dataset (reference src/dataset.jl:36-47): file, file_valid, meta, ch, ch_valid.  `ch` / `ch_valid` are iterators standing in for
+    the Channels; unpacking gives (meta, ch), the pair the TFRecord-only version of load_dataset returned."""
+
+    def __init__(self, file, file_valid, meta, ch, ch_valid):
+        self.file, self.file_valid, self.meta, self.ch, self.ch_valid = file, file_valid, meta, ch, ch_valid
+
+    def __iter__(self):
+        return iter((self.meta, self.ch))
+
+
 def load_dataset(path, is_training):
-    """load_dataset(path, is_training) (reference src/dataset.jl:89-117), TFRecord branch: returns (meta, iterator over
-    parsed trajectories).  The .jld2 / .h5 branches need HDF5 and stay on the Julia side."""
+    """load_dataset(path, is_training) (reference src/dataset.jl:89-172): `train` or `test` + `.tfrecord`, else `.jld2`, else `.h5`,
+    in that order of preference; training also opens the `valid` file of the same format.  The TFRecord arm yields parsed trajectories
+    (parse_data), the HDF5 / JLD2 arm the dictionaries of read_h5! (`dataset_h5.read_trajectory`; needs libhdf5, `hdf5_lite`)."""
     import json
     import os
-    with open(os.path.join(path, "meta.json")) as f:
-        meta = json.load(f)
-    file = os.path.join(path, ("train" if is_training else "test") + ".tfrecord")
-    if not os.path.isfile(file):
-        raise FileNotFoundError(file)
-    return meta, (parse_data(ex, meta) for ex in TFRecordReader(file))
+    filename = "train" if is_training else "test"
+    if os.path.isfile(os.path.join(path, filename + ".tfrecord")):
+        with open(os.path.join(path, "meta.json")) as f:
+            meta = json.load(f)
+        file, valid = os.path.join(path, filename + ".tfrecord"), os.path.join(path, "valid.tfrecord")
+
+        def records(f):                       # opened when first taken from, like the task behind TFRecord.jl's Channel
+            for ex in TFRecordReader(f):
+                yield parse_data(ex, meta)
+        return Dataset(file, valid, meta, records(file), records(valid) if is_training else None)
+    file = filename + (".jld2" if os.path.isfile(os.path.join(path, filename + ".jld2")) else ".h5")
+    if not os.path.isfile(os.path.join(path, file)):
+        raise FileNotFoundError(f"ArgumentError: {path} does not contain a {filename}.tfrecord or a {filename}.h5 file")
+    from . import dataset_h5
+    meta, ch, ch_valid = dataset_h5.load_dataset_h5(path, is_training, file)
+    return Dataset(os.path.join(path, file), os.path.join(path, "valid" + os.path.splitext(file)[1]), meta, ch, ch_valid)
 
 
 # ---- trajectory preparation (host side of SURVEY.md N3 / N4; arrays are [T][count][dim] like parse_data's) -------------
