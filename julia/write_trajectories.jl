@@ -4,8 +4,8 @@
 #
 # The reference writes `<out>/<solver>/trajectories.h5` with, per trajectory i (1-based) and name in
 # ("mesh_pos", "gt", "prediction", "error", "timesteps", "cells"), a group `/<i>/<name>` holding `data` (the array flattened in
-# Julia's column-major order) and `size` (its dimensions): src/MeshGraphNets.jl:638-669.  HDF5 is not available where the engine
-# is built and tested (no library, no h5py), so the engine side stops at a raw dump -- `reference_api.dump_rollout` writes, per
+# Julia's column-major order) and `size` (its dimensions): src/MeshGraphNets.jl:638-669.  The engine side writes that file itself where
+# libhdf5 is present (`dataset_h5.write_trajectories_h5`); on a host without it `reference_api.dump_rollout` writes, per
 # trajectory, `<dump_dir>/<i>/<name>.bin` (little-endian, the bytes of the Julia array: feature-major, then node, then time) and
 # `<dump_dir>/<i>/manifest.json` ({name: {"dtype": "Float32" | "Int32", "size": [..]}}) -- and this script, run where HDF5.jl exists,
 # produces the file the reference's plotting / comparison tools read.  Nothing else of eval_network! is replaced.

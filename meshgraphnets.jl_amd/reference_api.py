@@ -360,7 +360,8 @@ def load_dataset(path, is_training):
 def dump_rollout(dump_dir, ti, mesh_pos, gt, prediction, error, timesteps, cells=None):
     """The evaluation output of one trajectory (reference src/MeshGraphNets.jl:630-637: traj_ops / errors / timesteps / cells of
     eval_network!) as a raw dump that julia/write_trajectories.jl turns into the reference's `trajectories.h5`
-    (`/<ti>/<name>/{data,size}`, src/MeshGraphNets.jl:638-669; HDF5 is not available on the engine side).
+    (`/<ti>/<name>/{data,size}`, src/MeshGraphNets.jl:638-669) -- for hosts without libhdf5; with it, `dataset_h5.write_trajectories_h5`
+    writes the file directly.
     Arrays arrive in this module's [time][count][feat] / [count][feat] order and are written as the bytes of the Julia arrays
     (feat x count x time: the same bytes); `size` is the Julia size.  ti is 1-based like the reference's trajectory counter."""
     import json
