@@ -687,7 +687,7 @@ def main():
                                                           "host in/out included", "ms_per_step": dtt * 1e3,
                                               "ms_per_step_device_arrays": dtd * 1e3, "loss_finite": bool(np.isfinite(loss_t))}
             engt.close()
-            # N2 at the headline size: one training step on M-1M itself (recompute mode, ~128 GB of kept inputs / gradients)
+            # N2 at the headline size: one training step on M-1M itself (61 GB with every step recomputed + 10.7 GB per step stored)
             try:
                 engT = mgn_amd.Engine(FN, FE, O, L, 2, MPS, device=local_rank)
                 engT.set_params(ps)
@@ -701,19 +701,24 @@ def main():
                 t0 = time.perf_counter()
                 _, lossT = engT.step(nfT, efT, tgT, mkT)
                 dtT = time.perf_counter() - t0
+                import ctypes as _C
+                engT.lib.mgn_debug_train_keep_steps.argtypes = [_C.c_void_p]
+                keepT = int(engT.lib.mgn_debug_train_keep_steps(engT.h))   # processor steps whose H1 / H2 / Y are stored, not recomputed
                 # MFMA flops one step executes (fp32, v_mfma_f32_32x32x2_f32; first edge layer factored as in the forward kernels):
-                # per processor step  forward + recomputation 2 x (98 304 E + 196 608 N), backward (transposed chunks) 98 304 E + 196 608 N,
+                # per processor step  forward (+ recomputation where the step's activations are not stored) 1 or 2 x (98 304 E + 196 608 N), backward (transposed chunks) 98 304 E + 196 608 N,
                 # weight gradients 98 304 E + 196 608 N  (docs/experiments.md, training step)
-                flT = MPS * 4.0 * (98304.0 * E + 196608.0 * N)
+                flT = (4.0 * MPS - max(keepT, 0)) * (98304.0 * E + 196608.0 * N)
                 # forward / recomputation / backward / layer-1 halves run on two fp16 pieces (3 piece products per fp32 product), the weight
-                # gradients on the fp32 MFMA pipe: 3/4 of the products at 3 x on the 16-bit pipe, 1/4 on the fp32 pipe
-                fl16, fl32 = 3.0 * 0.75 * flT, 0.25 * flT
+                # gradients on the fp32 MFMA pipe: the weight-gradient products on the fp32 pipe, all others at 3 x on the 16-bit pipe
+                fl32 = MPS * (98304.0 * E + 196608.0 * N)
+                fl16 = 3.0 * (flT - fl32)
                 floor_s = fl16 / (PEAK_BF16_MFMA_TFLOPS * 1e12) + fl32 / (PEAK_F32_MFMA_TFLOPS * 1e12)
                 out["secondary"]["train_step_1m"] = {
                     "workload": "mgn_step == step! on M-1M (N = 1 000 000, E = 5 992 002, L = 128, 15 steps; fp32 storage, forward / recomputation / "
                                 "backward MLP chains on two fp16 pieces (MGN_TRAIN_F16=0: fp32 MFMA), weight gradients on the fp32 MFMA pipe; "
-                                "recompute mode); host in/out included",
-                    "s_per_step": dtT, "loss_finite": bool(np.isfinite(lossT)),
+                                "activations stored for `stored_steps` of the 15 processor steps -- as many as the device's free memory holds -- and "
+                                "recomputed in the reverse pass for the others); host in/out included",
+                    "s_per_step": dtT, "stored_steps": keepT, "loss_finite": bool(np.isfinite(lossT)),
                     "roofline": {"bound": "mfma", "fp32_products_per_step": flT, "executed_flops_16bit": fl16, "executed_flops_fp32": fl32,
                                  "matrix_floor_s": floor_s, "frac": floor_s / dtT, "fp32_equivalent_TFLOPs": flT / dtT / 1e12,
                                  "unit": "s", "achieved": dtT, "peak": floor_s,
@@ -722,7 +727,7 @@ def main():
                                          "MLPs only (encoders / decoder, segmented sums, reductions not counted)"}}
                 engT.close()
                 del nfT, efT, tgT
-            except Exception as ex:   # noqa: BLE001  (a box with less free memory than the 128 GB this needs)
+            except Exception as ex:   # noqa: BLE001  (a box with less free memory than the 61 GB this needs at least)
                 out["secondary"]["train_step_1m"] = {"error": str(ex)[:200]}
             # mid-size meshes (real CFD meshes, and the per-GPU share of M-1M on 8 GPUs): where the kernel families meet
             mids = {}

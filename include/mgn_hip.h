@@ -67,10 +67,11 @@ typedef struct mgn_config {
                            /* MGN_LN_ALL: over the WHOLE (L x rows) array of an MLP's output -- what Lux 0.5's LayerNorm(shape) computes  */
                            /* when it is left at dims = Colon() (julia/spec_probe.jl tells which one the installed GraphNetCore / Lux    */
                            /* run).  A different network, not a numerical variant: every LayerNorm then couples all rows, so the fused    */
-                           /* kernels cannot be used; the mode runs unfused (MLP kernel, grid-wide statistics pass, apply pass) behind     */
-                           /* mgn_forward, mgn_processor_steps and the one-shot form of mgn_ode_step (normalisers, inverse_data and      */
-                           /* val_mask on the host): fp32, one partition, one edge set; the other compute entry points answer             */
-                           /* MGN_E_UNSUPPORTED                                                                                           */
+                           /* tile kernels cannot be used; the mode runs unfused (MLP kernel with its LayerNorm off, grid-wide statistics    */
+                           /* in double, apply pass) behind mgn_forward, mgn_processor_steps, mgn_set_static + mgn_ode_step (both forms),   */
+                           /* mgn_rollout, and in both directions behind mgn_step, mgn_forward_vjp, mgn_ode_vjp: fp32, one partition, one  */
+                           /* edge set.  mgn_processor_steps_dev and the staged mgn_fwd_* entry points (the fused kernels' device-resident */
+                           /* arrays) answer MGN_E_UNSUPPORTED                                                                             */
 } mgn_config;
 
 typedef enum { MGN_LN_VAR_EPS = 0, MGN_LN_STD_EPS = 1 } mgn_ln_mode;

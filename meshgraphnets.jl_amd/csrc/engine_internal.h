@@ -151,6 +151,7 @@ struct mgn_engine {
     DevBuf V, d_nfA, d_nfB, d_out, d_mask, d_sum;
     int32_t in_wa = 0, in_wb = 0;
     bool have_mask = false;
+    bool lnall_edges = false;        // ln_dims = MGN_LN_ALL: the encoded edges of the resident static inputs sit in the whole-array arena
 
     // hipGraph of one mgn_processor_steps_dev(nsteps) pass: small meshes are launch-bound (3 kernels per step).
     // State machine per invalidation: first call runs eagerly (warms per-kernel attributes), second captures.
@@ -189,7 +190,7 @@ struct mgn_engine {
 namespace mgn {
 
 int fail(mgn_engine* h, int code, const char* fmt, ...);
-int need(mgn_engine* h, bool params, bool graph, bool packed = true);   // packed = false: the caller reads h->params only (training, get_params)
+int need(mgn_engine* h, bool params, bool graph, bool packed = true, bool lnall_ok = false);   // packed = false: the caller reads h->params only (training, get_params)
 int pack_inference_weights(mgn_engine* h);
 // L x L chunk of W (row-major [K][ldw], rows kbase.., all L output columns) -> MFMA fragment order
 void pack_chunk(float* dst, const float* W, int ldw, int kbase, int L);
@@ -203,6 +204,8 @@ void train_free(mgn_engine* h);
 // mgn_config.ln_dims = MGN_LN_ALL (whole-array LayerNorm): the unfused forward (mgn_train.cpp)
 int lnall_forward(mgn_engine* h, const float* nf, const float* ef, float* out);
 int lnall_processor_steps(mgn_engine* h, float* v, float* e, int32_t nsteps);
+int lnall_rhs_prepare(mgn_engine* h);                                              // binds the arena (may allocate / copy: outside of any capture)
+int lnall_rhs_dev(mgn_engine* h, const float* srcA, float* out, bool reuse_edges);  // the right-hand side on resident inputs; launches only
 
 #define HIPCHK(h, expr)                                                                              \
     do {                                                                                             \

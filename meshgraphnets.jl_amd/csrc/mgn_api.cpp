@@ -239,12 +239,12 @@ void pack_chunk_bf16(uint16_t* dst, const float* W, int ldw, int kbase) {
 
 }  // namespace
 namespace mgn {
-int need(mgn_engine* h, bool params, bool graph, bool packed) {
+int need(mgn_engine* h, bool params, bool graph, bool packed, bool lnall_ok) {
     if (!h) return MGN_E_ARG;
     if (h->host_only) return fail(h, MGN_E_HIP, "host-only handle (MGN_DEVICE_NONE): no compute path; create the handle on a HIP device");
     // whole-array LayerNorm couples every row of an MLP's output: the fused kernels behind the other compute entry points cannot
     // compute it (mgn_forward and mgn_processor_steps branch off to the unfused driver before they get here)
-    if (params && graph && h->cfg.ln_dims == MGN_LN_ALL)
+    if (params && graph && h->cfg.ln_dims == MGN_LN_ALL && !lnall_ok)
         return fail(h, MGN_E_UNSUPPORTED, "ln_dims = MGN_LN_ALL (whole-array LayerNorm) is served by mgn_forward, mgn_processor_steps and the one-shot mgn_ode_step only");
     if (params && !h->have_params) return fail(h, MGN_E_STATE, "mgn_set_params has not been called");
     if (graph && !h->have_graph) return fail(h, MGN_E_STATE, "mgn_set_graph has not been called");
@@ -385,6 +385,7 @@ int run_graphed(mgn_engine* h, hipGraphExec_t& exec, bool& warm, F&& launches) {
 // the resident right-hand side (mgn_set_static) and the hipGraph captured over its buffers go together
 void invalidate_static(mgn_engine* h) {
     h->have_static = false;
+    h->lnall_edges = false;
     if (h->rhs_exec) {
         if (!h->host_only) (void)hipStreamSynchronize(h->stream);
         (void)hipGraphExecDestroy(h->rhs_exec);
@@ -1595,7 +1596,8 @@ int mgn_forward(mgn_handle* h, const float* nf, const float* ef, float* out) try
 } MGN_CATCH(h)
 
 int mgn_set_static(mgn_handle* h, const float* onehot, const float* ef_raw, const float* val_mask) try {
-    if (int rc = need(h, true, true)) return rc;
+    const bool lnall = h && h->cfg.ln_dims == MGN_LN_ALL;
+    if (int rc = need(h, true, true, !lnall, true)) return rc;
     const mgn_config& c = h->cfg;
     if (c.nranks != 1) if (int rc = need_comm(h, "mgn_set_static")) return rc;
     if (h->nsets != 1) return fail(h, MGN_E_STATE, "mgn_set_static / mgn_ode_step / mgn_rollout mirror the reference's single-edge-set RHS (src/solve.jl:188-219)");
@@ -1612,6 +1614,12 @@ int mgn_set_static(mgn_handle* h, const float* onehot, const float* ef_raw, cons
     if (val_mask) {
         HIPCHK(h, h->d_mask.ensure((size_t)g.N * 4));
         HIPCHK(h, hipMemcpyAsync(h->d_mask.p, val_mask, (size_t)g.N * 4, hipMemcpyHostToDevice, h->stream));
+    }
+    if (lnall) {   // whole-array LayerNorm: the unfused right-hand side (mgn_train.cpp) encodes the edges on its first evaluation
+        if (int rc = lnall_rhs_prepare(h)) return rc;
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        h->have_static = true;
+        return MGN_OK;
     }
     if (int rc = encode_impl(h, true, false, true)) return rc;       // edge encoder: once per trajectory
     const bool bf = is_bf16(h);
@@ -1631,9 +1639,17 @@ static int lnall_ode_step(mgn_handle* h, const float* x, const float* onehot, co
     if (!h->have_graph) return fail(h, MGN_E_STATE, "mgn_set_graph has not been called");
     if (!x || !dxdt) return fail(h, MGN_E_ARG, "mgn_ode_step: null argument");
     if (c.Fn < c.O) return fail(h, MGN_E_ARG, "mgn_ode_step: Fn < O");
-    if (!ef_raw || (c.Fn > c.O && !onehot))
-        return fail(h, MGN_E_UNSUPPORTED, "mgn_ode_step with ln_dims = MGN_LN_ALL takes the one-shot form (x, node_type_onehot, ef_raw[, val_mask]); "
-                                          "mgn_set_static's resident inputs belong to the fused kernels");
+    if (!onehot && !ef_raw && !val_mask) {   // resident form: static inputs from mgn_set_static, only the state moves
+        if (!h->have_static) return fail(h, MGN_E_STATE, "mgn_ode_step without static inputs: call mgn_set_static first or pass them");
+        if (int rc = upload_state(h, x)) return rc;
+        if (int rc = lnall_rhs_prepare(h)) return rc;
+        HIPCHK(h, h->d_out.ensure((size_t)(h->g.n_own > 0 ? h->g.n_own : 1) * c.O * 4));
+        if (int rc = lnall_rhs_dev(h, h->d_nfA.as<float>(), h->d_out.as<float>(), h->lnall_edges)) return rc;
+        h->lnall_edges = true;
+        return mgn_fwd_download(h, dxdt);
+    }
+    if (!ef_raw || (c.Fn > c.O && !onehot)) return fail(h, MGN_E_ARG, "mgn_ode_step: null argument");
+    invalidate_static(h);   // the one-shot path overwrites the resident inputs
     const int64_t N = h->g.N, E = h->g.set[0].E;
     const float* nrm = h->norms_host.empty() ? nullptr : h->norms_host.data();   // [node scale, shift | edge scale, shift | out scale, shift]
     const float* ns = (nrm && h->have_nnorm) ? nrm : nullptr;
@@ -1738,8 +1754,14 @@ struct Rollout {
     std::vector<RhsGraph> graphs;
     bool warmed = false;
 
+    bool lnall_edges_done = false;
     int rhs_launches(float* x, float* kout) {
         const mgn_config& c = h->cfg;
+        if (c.ln_dims == MGN_LN_ALL) {     // the unfused whole-array right-hand side (mgn_train.cpp); its first evaluation encodes the edges
+            const int rc = lnall_rhs_dev(h, x, kout, lnall_edges_done);
+            lnall_edges_done = true;
+            return rc;
+        }
         h->srcA_override = x;
         h->out_override = kout;
         int rc = encode_impl(h, true, true, false);
@@ -1833,7 +1855,8 @@ struct Rollout {
 }  // namespace
 
 int mgn_rollout(mgn_handle* h, mgn_rollout_desc* d) try {
-    if (int rc = need(h, true, true)) return rc;
+    const bool lnall = h && h->cfg.ln_dims == MGN_LN_ALL;
+    if (int rc = need(h, true, true, !lnall, true)) return rc;
     const mgn_config& c = h->cfg;
     const bool part = c.nranks != 1;      // partitioned: every rank integrates the rows it owns; error norms are reduced over the ranks
     if (part) if (int rc = need_comm(h, "mgn_rollout")) return rc;
@@ -1909,8 +1932,12 @@ int mgn_rollout(mgn_handle* h, mgn_rollout_desc* d) try {
         HIPCHK(h, h->d_mask.ensure((size_t)g.N * 4));
         HIPCHK(h, hipMemcpyAsync(h->d_mask.p, d->val_mask, (size_t)g.N * 4, hipMemcpyHostToDevice, h->stream));
     }
-    if (int rc = encode_impl(h, true, false, true)) return rc;
-    HIPCHK(h, hipMemcpyAsync(base + R.elat0_off, is_bf16(h) ? h->es[0].bElat.p : h->es[0].Elat.p, is_bf16(h) ? eb / 2 : eb, hipMemcpyDeviceToDevice, h->stream));
+    if (lnall) {
+        if (int rc = lnall_rhs_prepare(h)) return rc;
+    } else {
+        if (int rc = encode_impl(h, true, false, true)) return rc;
+        HIPCHK(h, hipMemcpyAsync(base + R.elat0_off, is_bf16(h) ? h->es[0].bElat.p : h->es[0].Elat.p, is_bf16(h) ? eb / 2 : eb, hipMemcpyDeviceToDevice, h->stream));
+    }
 
     d->n_accept = d->n_reject = 0;
     int saved = 0;

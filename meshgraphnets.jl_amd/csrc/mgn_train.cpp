@@ -35,6 +35,7 @@ struct TrainBlock {
 struct TrainMlp {
     int nblk = 1;
     TrainBlock b[2];
+    int lnslot = -1;             // whole-array LayerNorm (ln_dims = MGN_LN_ALL): which (mean, rden, kappa) slot of the arena belongs to this MLP
 };
 // kept activations of one MLP instance: per block H1, H2, Y (arena offsets)
 struct Acts { size_t h[2][3] = {{0, 0, 0}, {0, 0, 0}}; };
@@ -44,7 +45,9 @@ struct Acts { size_t h[2][3] = {{0, 0, 0}, {0, 0, 0}}; };
 struct TrainState {
     bool packed = false, graph_ready = false;
     bool factored[MAX_EDGE_SETS] = {false, false};   // edge MLPs with a factored first layer (P = v W1s, Q = v W1r per node): large meshes
-    bool recompute = false;      // processor MLPs keep only their inputs; H1 / H2 / Y are recomputed in the reverse pass
+    bool recompute = false;      // some processor steps keep only their inputs; their H1 / H2 / Y are recomputed in the reverse pass
+    int keep_steps = 0;          // the LAST keep_steps processor steps store H1 / H2 / Y (all of them when !recompute)
+    bool kept(int k, int mps) const { return k >= mps - keep_steps; }
     int nblk = 1;                // launch units per MLP (2 for hidden_layers 3, 4)
     DevBuf w;                    // training-order weights
     DevBuf pk_params, pk_tabs, pk_jobs, pk_max;   // what k_pack_train builds them from: the parameter vector, the packed tables, the chunk list
@@ -67,6 +70,9 @@ struct TrainState {
     size_t GT[GSETS], GXH[GSETS], GY[GSETS], GZ2[GSETS], GZ1[GSETS];
     size_t GXs, GXr, GXB, gV[2], gE[MAX_EDGE_SETS][2], gAgg[MAX_EDGE_SETS], Gout, gNF, io, ptmp, pw, pb;
     size_t Pn, Qn, SGs, SGr;     // factored first layer: per-node projections (forward) and summed GZ1 rows (backward)
+    // whole-array LayerNorm in the training step: per-MLP statistics of the forward (64 floats each), the double partials of the two
+    // reductions, (m1, m2) of the pullback, the gradient w.r.t. the pre-LayerNorm output handed to k_mlp_bwd
+    size_t lnstats = 0, lnpart = 0, lnm = 0, GLN = 0;
     // weight gradients + their reductions go to a second stream (small meshes leave most of the chip idle during k_mlp_bwd)
     hipStream_t aux = nullptr;
     hipEvent_t ev_bwd = nullptr, ev_wg[GSETS] = {};
@@ -270,15 +276,33 @@ int prepare_graph(mgn_engine* h) {
         T.Ek[q][0] = take(EL[q]);
     }
     T.a_pn.assign(mps, Acts());
-    // Kept activations of the processor: 3 (E + N) L floats per launch unit and step when H1 / H2 / Y are stored.  Large meshes
-    // switch to recomputation (one more forward per MLP in the reverse pass, (E + 2 N) L floats per step kept): 15 steps of M-1M
-    // then need 61 GB instead of 270 GB.  MGN_TRAIN_RECOMPUTE = 0 / 1 overrides the size rule.
+    // Kept activations of the processor: 3 (E + N) L floats per launch unit and step when H1 / H2 / Y are stored.  Small meshes store
+    // them all.  Large ones store them for as many steps as the device's free memory holds (the last ones: the reverse pass meets them
+    // first) and recompute the rest in the reverse pass (one more forward per MLP; (E + 2 N) L floats per step kept): M-1M needs
+    // 61 GB with every step recomputed and 10.7 GB more per stored step, which is worth 4 ms of the step -- the part has 288 GB.
+    // MGN_TRAIN_RECOMPUTE = 0 / 1 forces all / none, MGN_TRAIN_KEEP_STEPS = n the count, MGN_TRAIN_RESERVE_GB what is left free (16).
     {
         double rows = (double)NL;
         for (int q = 0; q < S; ++q) rows += (double)EL[q];
-        const double stored = (double)mps * 3.0 * NB * rows * 4.0;
-        T.recompute = stored > 48e9;
-        if (const char* e = getenv("MGN_TRAIN_RECOMPUTE")) T.recompute = atoi(e) != 0;
+        const double per_step = 3.0 * NB * rows * 4.0, stored = (double)mps * per_step;
+        T.keep_steps = mps;
+        if (stored > 48e9) {
+            T.keep_steps = 0;
+            T.arena.release();                             // (an earlier graph's arena must not count as taken)
+            size_t free_b = 0, total_b = 0;
+            if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+                double reserve = 16e9;
+                if (const char* e = getenv("MGN_TRAIN_RESERVE_GB")) reserve = atof(e) * 1e9;
+                // what the arena takes with every step recomputed: inputs / aggregates per step, one shared set of activations, the
+                // gradient buffers (~ 6 (E + N) L) and the partial weight gradients
+                const double base = ((double)mps * (rows + (double)NL) + 12.0 * NB * rows) * 4.0 + 2e9;
+                const double room = (double)free_b - base - reserve;
+                if (room > 0) T.keep_steps = (int)std::min<double>((double)mps, room / per_step);
+            }
+        }
+        if (const char* e = getenv("MGN_TRAIN_RECOMPUTE")) T.keep_steps = atoi(e) != 0 ? 0 : mps;
+        if (const char* e = getenv("MGN_TRAIN_KEEP_STEPS")) T.keep_steps = std::max(0, std::min(mps, atoi(e)));
+        T.recompute = T.keep_steps < mps;
     }
     Acts shared_e[MAX_EDGE_SETS], shared_n;
     if (T.recompute) {
@@ -287,11 +311,11 @@ int prepare_graph(mgn_engine* h) {
     }
     for (int k = 0; k < mps; ++k) {
         for (int q = 0; q < S; ++q) {
-            T.a_pe[q][k] = T.recompute ? shared_e[q] : take_acts(EL[q]);
+            T.a_pe[q][k] = T.kept(k, mps) ? take_acts(EL[q]) : shared_e[q];
             T.agg[q][k] = take(NL);
             T.Ek[q][k + 1] = take(EL[q]);
         }
-        T.a_pn[k] = T.recompute ? shared_n : take_acts(NL);
+        T.a_pn[k] = T.kept(k, mps) ? take_acts(NL) : shared_n;
         T.Vk[k + 1] = take(NL);
     }
     const size_t ML = NL > ELmax ? NL : ELmax;
@@ -328,6 +352,19 @@ int prepare_graph(mgn_engine* h) {
     const int nb = std::max(wgrad_blocks(N), wgrad_blocks(Emax));
     T.pw = take((size_t)5 * (nb > 0 ? nb : 1) * L * L);             // one partial-dW region per weight-gradient job of a launch unit
     T.pb = take((size_t)WGRAD_MAX_JOBS * (nb > 0 ? nb : 1) * L);
+    if (h->cfg.ln_dims == MGN_LN_ALL) {
+        int slot = 0;
+        T.m_en.lnslot = slot++;
+        for (int q = 0; q < S; ++q) T.m_ee[q].lnslot = slot++;
+        for (int k = 0; k < mps; ++k) {
+            for (int q = 0; q < S; ++q) T.m_pe[q][k].lnslot = slot++;
+            T.m_pn[k].lnslot = slot++;
+        }
+        T.lnstats = take((size_t)64 * slot);
+        T.lnpart = take((size_t)2 * std::max<size_t>((size_t)2 * array_stats_blocks(), (size_t)2 * 128 * lnall_bwd_blocks()));
+        T.lnm = take(64);
+        T.GLN = take(ML);
+    }
     T.arena_floats = off;
     T.drop_graphs();
     HIPCHK(h, T.arena.ensure(off * 4));
@@ -364,7 +401,7 @@ struct TrainJob {
 };
 
 int train_prepare(mgn_handle* h, const char* who, size_t n_grads) {
-    if (int rc = need(h, true, true, false)) return rc;          // (the training kernels pack their own weights from h->params)
+    if (int rc = need(h, true, true, false, true)) return rc;    // (the training kernels pack their own weights from h->params)
     const mgn_config& c = h->cfg;
     if (c.nranks != 1) return fail(h, MGN_E_STATE, "%s drives one partition", who);
     if (c.dtype != MGN_F32) return fail(h, MGN_E_STATE, "%s computes in fp32: create the handle with dtype MGN_F32", who);
@@ -470,6 +507,10 @@ int train_run(mgn_handle* h, const TrainJob& J) {
         if (sx[q].E > 0)
             HIPCHK(h, launch_affine_pad(h->es[q].d_ef.as<float>(), h->es[q].Fe, nullptr, 0, nullptr, nullptr, A + T.ef_pad[q], L, sx[q].E, st));
 
+    // ln_dims = MGN_LN_ALL: every LayerNorm takes its statistics over the whole rows x L output of its MLP: the MLP
+    // kernels run without their row-wise LayerNorm; two reductions and an elementwise pass follow them in both directions
+    const bool lnall = c.ln_dims == MGN_LN_ALL;
+    const float ln_eps_in = c.ln_mode == MGN_LN_STD_EPS ? 0.f : 1e-5f, ln_eps_out = c.ln_mode == MGN_LN_STD_EPS ? 1e-5f : 0.f;
     // One MLP forward = one or two launch units.  `in` carries rows / ntiles and the first unit's inputs (X, xidx, PRE, preidx);
     // w1sel >= 0: only block w1sel of W1 is applied per row (the factored edge MLP: the e block).
     // keep = false: first pass of recompute mode -- H1 / H2 / Y are regenerated right before the backward, not stored here
@@ -495,7 +536,16 @@ int train_run(mgn_handle* h, const TrainJob& J) {
             if (last) { a.resid = resid; a.OUT = out; a.LNOUT = lnout; }
             else if (!keep) a.OUT = A + act.h[bi][2];
             a.ln = b.ln ? 1 : 0;
+            const bool wide = lnall && last && b.ln;      // whole-array LayerNorm: the kernel stops at Y, statistics and apply follow
+            if (wide) { a.ln = 0; a.resid = nullptr; a.OUT = nullptr; a.LNOUT = nullptr; a.Y = A + act.h[bi][2]; }
             if (hipError_t e = launch_mlp_fwd(L, nin, a, st)) return e;
+            if (wide && (out || lnout) && in.rows > 0) {  // (the recomputation of the reverse pass asks for neither: the statistics are kept)
+                float* stats = A + T.lnstats + (size_t)64 * m.lnslot;
+                const int64_t n = in.rows * L;
+                if (hipError_t e = launch_array_stats(a.Y, n, reinterpret_cast<double*>(A + T.lnpart), ln_eps_in, ln_eps_out, stats, st)) return e;
+                if (hipError_t e = launch_ln_all_apply(a.Y, stats, Wt + b.tabs + (size_t)T_GAMMA * L, Wt + b.tabs + (size_t)T_BETA * L, resid, out,
+                                                       lnout, n, L, st)) return e;
+            }
         }
         return hipSuccess;
     };
@@ -575,10 +625,10 @@ int train_run(mgn_handle* h, const TrainJob& J) {
         HIPCHK(h, fwd(T.m_ee[q], sx[q].E, sx[q].nt, A + T.ef_pad[q], sx[q].egid, nullptr, nullptr, T.a_ee[q], nullptr, A + T.Ek[q][0], nullptr));
     for (int k = 0; k < mps; ++k) {
         for (int q = 0; q < S; ++q) {
-            HIPCHK(h, fwd_edge(q, k, A + T.Ek[q][k], A + T.Ek[q][k + 1], A + T.Enew, !T.recompute));
+            HIPCHK(h, fwd_edge(q, k, A + T.Ek[q][k], A + T.Ek[q][k + 1], A + T.Enew, T.kept(k, mps)));
             HIPCHK(h, launch_segment_sum(L, A + T.Enew, sx[q].rowptr, nullptr, nullptr, A + T.agg[q][k], (int32_t)N, st));
         }
-        HIPCHK(h, fwd_node(k, A + T.Vk[k], A + T.Vk[k + 1], !T.recompute));
+        HIPCHK(h, fwd_node(k, A + T.Vk[k], A + T.Vk[k + 1], T.kept(k, mps)));
     }
     HIPCHK(h, fwd(T.m_de, N, nt_n, A + T.Vk[mps], nullptr, nullptr, nullptr, T.a_de, nullptr, nullptr, nullptr));
     return MGN_OK;
@@ -620,8 +670,9 @@ int train_run(mgn_handle* h, const TrainJob& J) {
     // (gx[0] / gxadd[0] / xin[0] describe it); the v blocks follow per node from the summed rows of GZ1 (SGs, SGr) after this call.
     auto bwd_unit = [&](const TrainBlock& b, int64_t rows, int32_t ntiles, const float* g0, const float* g1, const int32_t* g1i, const size_t (&hb)[3],
                         float* const gx[3], const float* const gxadd[3], const float* const xin[3], const int32_t* const xi[3],
-                        int fq = -1, const float* vin = nullptr) -> int {
+                        int fq = -1, const float* vin = nullptr, int lnslot = -1) -> int {
         const bool fact = fq >= 0;
+        const bool wide = lnall && b.ln;
         const int64_t node_rows = fact ? N : 0;
         const int nin_k = fact ? 1 : b.nin;               // input blocks the kernel unwinds
         const int gs = overlap ? n_bwd % T.gsets : 0;
@@ -642,6 +693,12 @@ int train_run(mgn_handle* h, const TrainJob& J) {
         a.tabs = Wt + b.tabs;
         a.ln = b.ln ? 1 : 0;
         a.GT = A + T.GT[gs]; a.GXH = A + T.GXH[gs]; a.GY = A + T.GY[gs]; a.GZ2 = A + T.GZ2[gs]; a.GZ1 = A + T.GZ1[gs];
+        if (wide && rows > 0) {   // pullback of the whole-array LayerNorm first: dgamma, dbeta, and the gradient at Y for a kernel without LayerNorm
+            HIPCHK(h, launch_lnall_bwd(g0, g1, g1i, A + hb[2], A + T.lnstats + (size_t)64 * lnslot, Wt + b.tabs + (size_t)T_GAMMA * L, rows, L,
+                                       reinterpret_cast<double*>(A + T.lnpart), A + T.lnm, G + b.ggamma, G + b.gbeta, A + T.GLN, st));
+            a.G0 = A + T.GLN; a.G1 = nullptr; a.g1idx = nullptr;
+            a.ln = 0;
+        }
         HIPCHK(h, launch_mlp_bwd(L, nin_k, a, st));
         if (fact) {   // gather <-> segmented-sum duality on GZ1 itself: SGr[n] = sum of GZ1 over edges received by n, SGs: sent by n
             HIPCHK(h, launch_segment_sum_pair(L, A + T.GZ1[gs], sx[fq].rowptr, sx[fq].rowptr_s, sx[fq].perm_s, A + T.SGr, A + T.SGs, (int32_t)node_rows, st));
@@ -683,7 +740,7 @@ int train_run(mgn_handle* h, const TrainJob& J) {
             job(vin, nullptr, A + T.SGs, b.gW[0], L, L, -1, L, node_rows);
             job(vin, nullptr, A + T.SGr, b.gW[0] + (long)L * L, L, L, -1, L, node_rows);
         }
-        if (b.ln) {
+        if (b.ln && !wide) {
             job(nullptr, nullptr, A + T.GXH[gs], -1, 0, 0, b.ggamma, L);
             job(nullptr, nullptr, A + T.GT[gs], -1, 0, 0, b.gbeta, L);
         }
@@ -702,10 +759,10 @@ int train_run(mgn_handle* h, const TrainJob& J) {
             const float* none[3] = {nullptr, nullptr, nullptr};
             const float* xin1[3] = {A + act.h[0][2], nullptr, nullptr};
             const int32_t* xi1[3] = {nullptr, nullptr, nullptr};
-            if (int rc = bwd_unit(m.b[1], rows, ntiles, g0, g1, g1i, act.h[1], gx1, none, xin1, xi1)) return rc;
-            return bwd_unit(m.b[0], rows, ntiles, A + T.GXB, nullptr, nullptr, act.h[0], gx, gxadd, xin, xi, fq, vin);
+            if (int rc = bwd_unit(m.b[1], rows, ntiles, g0, g1, g1i, act.h[1], gx1, none, xin1, xi1, -1, nullptr, m.lnslot)) return rc;
+            return bwd_unit(m.b[0], rows, ntiles, A + T.GXB, nullptr, nullptr, act.h[0], gx, gxadd, xin, xi, fq, vin, m.lnslot);
         }
-        return bwd_unit(m.b[0], rows, ntiles, g0, g1, g1i, act.h[0], gx, gxadd, xin, xi, fq, vin);
+        return bwd_unit(m.b[0], rows, ntiles, g0, g1, g1i, act.h[0], gx, gxadd, xin, xi, fq, vin, m.lnslot);
     };
 
     auto backward_launches = [&]() -> int {
@@ -722,7 +779,7 @@ int train_run(mgn_handle* h, const TrainJob& J) {
     for (int q = 0; q < S; ++q) HIPCHK(h, hipMemsetAsync(A + T.gE[q][ecur], 0, (size_t)(sx[q].E > 0 ? sx[q].E : 1) * L * 4, st));
     for (int k = mps - 1; k >= 0; --k) {
         const int nxt = cur ^ 1, enxt = ecur ^ 1;
-        if (T.recompute) {   // regenerate H1, H2, Y of the MLPs of this step from their kept inputs
+        if (!T.kept(k, mps)) {   // regenerate H1, H2, Y of the MLPs of this step from their kept inputs
             HIPCHK(h, fwd_node(k, nullptr, nullptr));
             for (int q = 0; q < S; ++q) HIPCHK(h, fwd_edge(q, k, nullptr, nullptr, nullptr));
         }
@@ -871,7 +928,7 @@ struct LnAll {
     int64_t N, E;
     int32_t nt_n, nt_e;
     const int32_t *snd, *rcv, *rowptr, *egid;
-    size_t V, Ecur, Y, Hb, agg, stats, part, nf_raw, nf_pad, ef_raw, ef_pad, tmp;
+    size_t V, Ecur, Y, Hb, agg, stats, part, nf_raw, nf_pad, ef_raw, ef_pad, tmp, E0;
     float eps_in, eps_out;
 
     // Y <- MLP(x) without LayerNorm / residual (launch units chained through Hb)
@@ -946,10 +1003,11 @@ LnAll lnall_layout(mgn_engine* h, bool with_inputs, size_t& floats) {
     X.V = take(NL); X.Ecur = take(EL); X.Y = take(ML); X.Hb = T.nblk > 1 ? take(ML) : 0; X.agg = take(NL);
     X.stats = take(64); X.part = take((size_t)4 * array_stats_blocks());
     X.tmp = take(ML);                                   // caller order <-> engine order staging
-    X.nf_raw = X.nf_pad = X.ef_raw = X.ef_pad = 0;
+    X.nf_raw = X.nf_pad = X.ef_raw = X.ef_pad = X.E0 = 0;
     if (with_inputs) {
         X.nf_raw = take((size_t)X.N * c.Fn); X.nf_pad = take(NL);
         X.ef_raw = take((size_t)(X.E > 0 ? X.E : 1) * c.Fe); X.ef_pad = take(EL);
+        X.E0 = take(EL);                                // the encoded edges of a trajectory (lnall_rhs_dev: the edge encoder runs once)
     }
     X.eps_in = c.ln_mode == MGN_LN_STD_EPS ? 0.f : 1e-5f;
     X.eps_out = c.ln_mode == MGN_LN_STD_EPS ? 1e-5f : 0.f;
@@ -983,6 +1041,7 @@ namespace mgn {
 
 int lnall_forward(mgn_engine* h, const float* nf, const float* ef, float* out) {
     if (int rc = lnall_prepare(h, "mgn_forward", true)) return rc;
+    h->lnall_edges = false;                             // (the arena is shared with the resident right-hand side)
     const mgn_config& c = h->cfg;
     const LocalGraph& g = h->g;
     if (!nf || !out || (!ef && g.set[0].E > 0)) return fail(h, MGN_E_ARG, "mgn_forward: null argument");
@@ -1022,6 +1081,7 @@ int lnall_forward(mgn_engine* h, const float* nf, const float* ef, float* out) {
 
 int lnall_processor_steps(mgn_engine* h, float* v, float* e, int32_t nsteps) {
     if (int rc = lnall_prepare(h, "mgn_processor_steps", false)) return rc;
+    h->lnall_edges = false;
     const mgn_config& c = h->cfg;
     const LocalGraph& g = h->g;
     if (!v || (!e && g.set[0].E > 0)) return fail(h, MGN_E_ARG, "mgn_processor_steps: null argument");
@@ -1049,6 +1109,60 @@ int lnall_processor_steps(mgn_engine* h, float* v, float* e, int32_t nsteps) {
         HIPCHK(h, hipMemcpyAsync(e, A + X.tmp, (size_t)X.E * L * 4, hipMemcpyDefault, st));
     }
     HIPCHK(h, hipStreamSynchronize(st));
+    return MGN_OK;
+}
+
+// The right-hand side on resident inputs under ln_dims = MGN_LN_ALL -- what encode_impl + run_processor + decode_impl (mgn_api.cpp) are to
+// the fused kernels: node inputs [state (srcA, in_wa columns) | static (d_nfB, in_wb columns)] and raw edge features as upload_inputs left
+// them (caller's order with own_gid / edge_gid, or the engine's order), build_graph's normalisers, the model, inverse_data, val_mask;
+// out [n_own][O] in the engine's order.  reuse_edges: the encoded edge latents of the trajectory are taken from the arena (static edge
+// features, frozen e_norm: the edge encoder runs once per trajectory).  Launches only -- no host copy, no synchronisation -- once
+// lnall_rhs_prepare has bound the arena, so the rollout driver can capture it.
+int lnall_rhs_prepare(mgn_engine* h) {
+    if (int rc = lnall_prepare(h, "right-hand side", true)) return rc;
+    size_t floats = 0;
+    LnAll X = lnall_layout(h, true, floats);
+    return lnall_bind(h, X, floats);
+}
+
+int lnall_rhs_dev(mgn_engine* h, const float* srcA, float* out, bool reuse_edges) {
+    const mgn_config& c = h->cfg;
+    size_t floats = 0;
+    LnAll X = lnall_layout(h, true, floats);
+    TrainState& T = X.T;
+    if (!T.la.p || T.la.bytes < floats * 4 || !T.la_ready) return fail(h, MGN_E_STATE, "whole-array LayerNorm: the right-hand side was not prepared");
+    X.A = T.la.as<float>();
+    X.snd = h->es[0].d_snd.as<int32_t>();
+    X.rcv = h->es[0].d_rcv.as<int32_t>();
+    X.rowptr = h->es[0].d_rowptr.as<int32_t>();
+    X.egid = T.la_idx.as<int32_t>();
+    float* A = X.A;
+    hipStream_t st = X.st;
+    const int L = c.L;
+    const float* nrm = h->norms.as<float>();
+    const int32_t* ngid = h->in_local ? nullptr : h->d_own_gid.as<int32_t>();
+    const float* ns = h->have_nnorm ? nrm : nullptr;
+    // node inputs: [srcA | srcB] normalised and padded to L, rows in the engine's order
+    float* padded = ngid ? A + X.tmp : A + X.nf_pad;
+    HIPCHK(h, launch_affine_pad(srcA, h->in_wa, h->d_nfB.as<float>(), h->in_wb, ns, ns ? ns + c.Fn : nullptr, padded, L, X.N, st));
+    if (ngid) HIPCHK(h, launch_permute_rows(A + X.nf_pad, A + X.tmp, ngid, X.N, L, false, st));
+    HIPCHK(h, X.mlp(T.m_en, X.N, X.nt_n, A + X.nf_pad, nullptr, nullptr, nullptr, nullptr, A + X.Y));
+    HIPCHK(h, X.ln(T.m_en, A + X.Y, X.N, nullptr, A + X.V, nullptr));
+    if (X.E > 0) {
+        if (!reuse_edges) {
+            const float* es = h->have_enorm ? nrm + 2 * c.Fn : nullptr;
+            HIPCHK(h, launch_affine_pad(h->es[0].d_ef.as<float>(), c.Fe, nullptr, 0, es, es ? es + c.Fe : nullptr, A + X.ef_pad, L, X.E, st));
+            HIPCHK(h, X.mlp(T.m_ee[0], X.E, X.nt_e, A + X.ef_pad, h->in_local ? nullptr : X.egid, nullptr, nullptr, nullptr, A + X.Y));
+            HIPCHK(h, X.ln(T.m_ee[0], A + X.Y, X.E, nullptr, A + X.E0, nullptr));
+        }
+        HIPCHK(h, hipMemcpyAsync(A + X.Ecur, A + X.E0, (size_t)X.E * L * 4, hipMemcpyDeviceToDevice, st));
+    }
+    for (int k = 0; k < c.mps; ++k)
+        if (int rc = X.step(k)) return rc;
+    HIPCHK(h, X.mlp(T.m_de, X.N, X.nt_n, A + X.V, nullptr, nullptr, nullptr, nullptr, A + X.Y));
+    const float* os = h->have_onorm ? nrm + 2 * c.Fn + 2 * c.Fe : nullptr;
+    HIPCHK(h, launch_rhs_epilogue(A + X.Y, L, c.O, os, os ? os + c.O : nullptr, h->have_mask ? h->d_mask.as<float>() : nullptr,
+                                  h->d_own_gid.as<int32_t>(), out, X.N, st));
     return MGN_OK;
 }
 
@@ -1095,3 +1209,6 @@ extern "C" int mgn_feature_stats(mgn_handle* h, const float* x, int64_t rows, in
         }
     return MGN_OK;
 } MGN_CATCH(h)
+
+// tests / bench: how many processor steps of the training arena keep their activations (-1: no training arena yet)
+extern "C" int mgn_debug_train_keep_steps(mgn_handle* h) { return (h && h->train && h->train->graph_ready) ? h->train->keep_steps : -1; }

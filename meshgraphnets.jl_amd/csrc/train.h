@@ -95,12 +95,21 @@ hipError_t launch_segment_sum2(int L, const float* srcA, const int32_t* rowptrA,
 // dst [rows][L] = [ (srcA | srcB)[rows][wa + wb] * scale + shift | 0 ]   (srcB may be null with wb = 0; scale null: identity)
 hipError_t launch_affine_pad(const float* srcA, int wa, const float* srcB, int wb, const float* scale, const float* shift, float* dst, int L,
                              int64_t rows, hipStream_t s);
-// whole-array LayerNorm (mgn_config.ln_dims = MGN_LN_ALL): stats = (mean, 1 / (sqrt(var + eps_in) + eps_out)) over the n values of x
+// whole-array LayerNorm (mgn_config.ln_dims = MGN_LN_ALL): stats = (mean, 1 / (sqrt(var + eps_in) + eps_out), kappa) over the n values of x
 // (double accumulation, fixed order; partial: 2 * array_stats_blocks() doubles), then t = (y - mean) * rden * gamma + beta
 int array_stats_blocks();
 hipError_t launch_array_stats(const float* x, int64_t n, double* partial, float eps_in, float eps_out, float* stats, hipStream_t s);
 hipError_t launch_ln_all_apply(const float* y, const float* stats, const float* gamma, const float* beta, const float* resid, float* out,
                                float* lnout, int64_t n, int L, hipStream_t s);
+// epilogue of a right-hand side: out [N][O] = (Y[:, 0:O] os + osh) .* mask[gid ? gid[row] : row]   (os / mask / gid may be null)
+hipError_t launch_rhs_epilogue(const float* Y, int L, int O, const float* os, const float* osh, const float* mask, const int32_t* gid, float* out,
+                               int64_t N, hipStream_t s);
+// reverse pass of the whole-array LayerNorm of one MLP: dgamma, dbeta (L floats each, written into the gradient vector), m = (m1, m2) scratch
+// (2 floats) and dY [rows][L] = rden (gamma G - m1 - xhat m2) with G = G0[row] (+ G1[g1idx ? g1idx[row] : row]);
+// partial: 2 * 128 * lnall_bwd_blocks() doubles; stats: launch_array_stats' (mean, rden, kappa) of the forward
+int lnall_bwd_blocks();
+hipError_t launch_lnall_bwd(const float* G0, const float* G1, const int32_t* g1idx, const float* Y, const float* stats, const float* gamma,
+                            int64_t rows, int L, double* partial, float* m, float* dgamma, float* dbeta, float* dY, hipStream_t s);
 // node rows between the caller's order and the engine's (a renumbered graph: graph_host.h): gather dst[i] = src[gid[i]], scatter dst[gid[i]] = src[i]
 hipError_t launch_permute_rows(float* dst, const float* src, const int32_t* gid, int64_t rows, int width, bool scatter, hipStream_t s);
 // seed of the RHS VJP (mgn_ode_vjp): G[n][o] = lambda[n][o] * val_mask[n] * os[o]; optionally dxdt = (Y * os + osh) .* val_mask

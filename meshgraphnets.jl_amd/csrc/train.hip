@@ -743,7 +743,8 @@ __global__ void k_array_stats(const float* __restrict__ x, int64_t n, double* __
         partial[2 * blockIdx.x + 1] = sh[1][0] + sh[1][1] + sh[1][2] + sh[1][3];
     }
 }
-// stats = (mean, 1 / (sqrt(var + eps_in) + eps_out)): biased variance over the n values, blocks added in order
+// stats = (mean, 1 / (sqrt(var + eps_in) + eps_out), kappa = (sqrt(var + eps_in) + eps_out) / sqrt(var + eps_in) -- the factor of the xhat term
+// of the pullback): biased variance over the n values, blocks added in order
 __global__ void k_array_stats_final(const double* __restrict__ partial, int nb, int64_t n, float eps_in, float eps_out, float* __restrict__ stats) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     double s = 0.0, q = 0.0;
@@ -751,8 +752,10 @@ __global__ void k_array_stats_final(const double* __restrict__ partial, int nb, 
     const double mean = n > 0 ? s / (double)n : 0.0;
     double var = n > 0 ? q / (double)n - mean * mean : 0.0;
     if (var < 0.0) var = 0.0;
+    const double lsq = sqrt(var + (double)eps_in);
     stats[0] = (float)mean;
-    stats[1] = (float)(1.0 / (sqrt(var + (double)eps_in) + (double)eps_out));
+    stats[1] = (float)(1.0 / (lsq + (double)eps_out));
+    stats[2] = lsq > 0.0 ? (float)((lsq + (double)eps_out) / lsq) : 1.f;
 }
 // t = (y - mean) * rden * gamma[f] + beta[f];  lnout = t;  out = (resid ? resid : 0) + t   (out may alias resid, lnout may alias y)
 __global__ void k_ln_all_apply(const float* y, const float* __restrict__ stats, const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -764,6 +767,79 @@ __global__ void k_ln_all_apply(const float* y, const float* __restrict__ stats, 
     const float r = resid ? resid[i] : 0.f;
     if (lnout) lnout[i] = t;
     if (out) out[i] = r + t;
+}
+
+// ---- reverse pass of the whole-array LayerNorm ----
+// t = gamma xhat + beta with xhat = (y - mean) rden over ALL rows x L values.  With G the gradient w.r.t. t (G = G0[row] (+ G1[g1idx[row]])):
+//   dbeta[f] = sum_rows G,  dgamma[f] = sum_rows G xhat,
+//   dy = rden (gamma G - m1 - xhat m2),  m1 = mean_all(gamma G) = sum_f gamma[f] dbeta[f] / n,  m2 = kappa mean_all(gamma G xhat) = kappa sum_f gamma[f] dgamma[f] / n
+// k_lnall_bwd_cols: per block the column sums of its rows in double (block b: rows 2 b + {0, 1}, stride 2 gridDim; fixed order);
+// k_lnall_bwd_cols_final: blocks added in order -> dbeta, dgamma (into the gradient vector), m = (m1, m2);  k_lnall_bwd_apply: dy.
+__global__ __launch_bounds__(256) void k_lnall_bwd_cols(const float* __restrict__ G0, const float* __restrict__ G1, const int32_t* __restrict__ g1idx,
+                                                        const float* __restrict__ Y, const float* __restrict__ stats, int64_t rows, int L,
+                                                        double* __restrict__ partial) {
+    __shared__ double sh[2][128];
+    const int f = threadIdx.x & 127, half = threadIdx.x >> 7;
+    const float mean = stats[0], rden = stats[1];
+    double sb = 0.0, sg = 0.0;
+    if (f < L)
+        for (int64_t r = (int64_t)blockIdx.x * 2 + half; r < rows; r += (int64_t)gridDim.x * 2) {
+            float g = G0[r * L + f];
+            if (G1) g += G1[(g1idx ? (int64_t)g1idx[r] : r) * L + f];
+            const float xh = (Y[r * L + f] - mean) * rden;
+            sb += (double)g;
+            sg += (double)(g * xh);
+        }
+    if (half == 1) { sh[0][f] = sb; sh[1][f] = sg; }
+    __syncthreads();
+    if (half == 0) {
+        partial[((size_t)blockIdx.x * 2 + 0) * 128 + f] = sb + sh[0][f];
+        partial[((size_t)blockIdx.x * 2 + 1) * 128 + f] = sg + sh[1][f];
+    }
+}
+__global__ __launch_bounds__(128) void k_lnall_bwd_cols_final(const double* __restrict__ partial, int nb, int64_t n, int L, const float* __restrict__ gamma,
+                                                              const float* __restrict__ stats, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                              float* __restrict__ m) {
+    __shared__ double sh[2][128];
+    const int f = threadIdx.x;
+    double sb = 0.0, sg = 0.0;
+    for (int b = 0; b < nb; ++b) { sb += partial[((size_t)b * 2 + 0) * 128 + f]; sg += partial[((size_t)b * 2 + 1) * 128 + f]; }
+    if (f < L) { dbeta[f] = (float)sb; dgamma[f] = (float)sg; }
+    sh[0][f] = f < L ? sb * (double)gamma[f] : 0.0;
+    sh[1][f] = f < L ? sg * (double)gamma[f] : 0.0;
+    __syncthreads();
+    if (f == 0) {
+        double a = 0.0, c = 0.0;
+        for (int i = 0; i < 128; ++i) { a += sh[0][i]; c += sh[1][i]; }
+        m[0] = n > 0 ? (float)(a / (double)n) : 0.f;
+        m[1] = n > 0 ? (float)((double)stats[2] * c / (double)n) : 0.f;
+    }
+}
+__global__ void k_lnall_bwd_apply(const float* __restrict__ G0, const float* __restrict__ G1, const int32_t* __restrict__ g1idx,
+                                  const float* __restrict__ Y, const float* __restrict__ stats, const float* __restrict__ gamma,
+                                  const float* __restrict__ m, float* __restrict__ dY, int64_t n, int L) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int64_t r = i / L;
+    const int f = (int)(i - r * L);
+    float g = G0[i];
+    if (G1) g += G1[(g1idx ? (int64_t)g1idx[r] : r) * L + f];
+    const float rden = stats[1];
+    const float xh = (Y[i] - stats[0]) * rden;
+    dY[i] = rden * (gamma[f] * g - m[0] - xh * m[1]);
+}
+
+// epilogue of a right-hand side (reference src/solve.jl:203-218): out[i][o] = (Y[i][o] os[o] + osh[o]) * (mask ? mask[gid ? gid[i] : i] : 1)
+__global__ void k_rhs_epilogue(const float* __restrict__ Y, int L, int O, const float* __restrict__ os, const float* __restrict__ osh,
+                               const float* __restrict__ mask, const int32_t* __restrict__ gid, float* __restrict__ out, int64_t N) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N * O) return;
+    const int64_t n = i / O;
+    const int o = (int)(i - n * O);
+    float y = Y[n * L + o];
+    if (os) y = y * os[o] + osh[o];
+    if (mask) y *= mask[gid ? (int64_t)gid[n] : n];
+    out[i] = y;
 }
 
 // seed of the RHS VJP: dx/dt = (out * os + osh) .* val_mask  =>  G[n][o] = lambda[n][o] * val_mask[n] * os[o]
@@ -1174,6 +1250,27 @@ hipError_t launch_ln_all_apply(const float* y, const float* stats, const float* 
                                float* lnout, int64_t n, int L, hipStream_t s) {
     if (n <= 0) return hipSuccess;
     hipLaunchKernelGGL(k_ln_all_apply, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, y, stats, gamma, beta, resid, out, lnout, n, L);
+    return hipGetLastError();
+}
+
+hipError_t launch_rhs_epilogue(const float* Y, int L, int O, const float* os, const float* osh, const float* mask, const int32_t* gid, float* out,
+                               int64_t N, hipStream_t s) {
+    const int64_t tot = N * O;
+    if (tot <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_rhs_epilogue, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, Y, L, O, os, osh, mask, gid, out, N);
+    return hipGetLastError();
+}
+
+int lnall_bwd_blocks() { return 1024; }
+
+hipError_t launch_lnall_bwd(const float* G0, const float* G1, const int32_t* g1idx, const float* Y, const float* stats, const float* gamma,
+                            int64_t rows, int L, double* partial, float* m, float* dgamma, float* dbeta, float* dY, hipStream_t s) {
+    if (L > 128) return hipErrorInvalidValue;
+    const int nb = lnall_bwd_blocks();
+    const int64_t n = rows * L;
+    hipLaunchKernelGGL(k_lnall_bwd_cols, dim3(nb), dim3(256), 0, s, G0, G1, g1idx, Y, stats, rows, L, partial);
+    hipLaunchKernelGGL(k_lnall_bwd_cols_final, dim3(1), dim3(128), 0, s, partial, nb, n, L, gamma, stats, dgamma, dbeta, m);
+    if (n > 0) hipLaunchKernelGGL(k_lnall_bwd_apply, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, G0, G1, g1idx, Y, stats, gamma, m, dY, n, L);
     return hipGetLastError();
 }
 

@@ -204,7 +204,8 @@ def init_params(Fn, Fe, O, L, hidden_layers, mps, seed=1234, ln_jitter=0.0, Fe2=
 #   LN_MODE: 0 = (x - mean) / sqrt(var + eps)  [MGN-spec v1]     1 = (x - mean) / (sqrt(var) + eps)
 #   LN_DIMS: "row" = statistics per node / edge over its L features [MGN-spec v1]
 #            "all" = statistics over the WHOLE array, rows included (Lux 0.5 LayerNorm(shape) with dims = Colon());
-#                    the engine's ln_dims = MGN_LN_ALL; forward functions only (the reverse mode assumes "row"; it follows LN_MODE)
+#                    the engine's ln_dims = MGN_LN_ALL.  Forward functions and the reverse mode follow it (the pullback's two means run
+#                    over the same set of entries as the statistics).
 LN_MODE = 0
 LN_DIMS = "row"
 
@@ -317,8 +318,9 @@ def _mlp_fwd(x, p, h):
         acts.append(a)
     cache = dict(acts=acts)
     if "ln_scale" in p:
-        mu = a.mean(-1, keepdims=True)
-        var = ((a - mu) ** 2).mean(-1, keepdims=True)
+        ax = -1 if LN_DIMS == "row" else None
+        mu = a.mean(ax, keepdims=True)
+        var = ((a - mu) ** 2).mean(ax, keepdims=True)
         # y = d / D with D = sqrt(var + eps) (LN_MODE 0) or sqrt(var) + eps (LN_MODE 1); dD / dx_i = d_i / (L s), s = sqrt(var [+ eps]):
         # the xhat term of the pullback carries kappa = D / s (1 in mode 0)
         s_ = np.sqrt(var + LN_EPS) if LN_MODE == 0 else np.sqrt(var)
@@ -326,7 +328,7 @@ def _mlp_fwd(x, p, h):
         rstd = 1.0 / den
         kappa = np.where(s_ > 0, den / np.where(s_ > 0, s_, 1.0), 1.0)
         xhat = (a - mu) * rstd
-        cache.update(xhat=xhat, rstd=rstd, kappa=kappa)
+        cache.update(xhat=xhat, rstd=rstd, kappa=kappa, ax=ax)
         a = xhat * p["ln_scale"] + p["ln_bias"]
     return a, cache
 
@@ -339,7 +341,8 @@ def _mlp_bwd(g, cache, p, h):
         gp["ln_scale"] = (g * xhat).sum(0)
         gp["ln_bias"] = g.sum(0)
         gg = g * p["ln_scale"]
-        g = rstd * (gg - gg.mean(-1, keepdims=True) - xhat * cache["kappa"] * (gg * xhat).mean(-1, keepdims=True))
+        ax = cache["ax"]
+        g = rstd * (gg - gg.mean(ax, keepdims=True) - xhat * cache["kappa"] * (gg * xhat).mean(ax, keepdims=True))
     acts = cache["acts"]
     for i in range(h + 1, 0, -1):
         if i <= h:

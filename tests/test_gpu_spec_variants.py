@@ -139,8 +139,8 @@ def test_whole_array_layernorm_is_an_engine_mode(whole_array_oracle):
     """mgn_config.ln_dims = MGN_LN_ALL: LayerNorm statistics over the whole (L x rows) output of every MLP -- what Lux 0.5's
     LayerNorm(shape) computes when it is left at dims = Colon() (reference Project.toml:15,40; julia/spec_probe.jl reports it).  The
     engine reproduces the GOLD-G `out_whole_array` fixture, follows the oracle's LN_DIMS = "all" on a 22 500-node mesh (forward of the
-    whole model and processor steps, hidden_layers 2 and 3, both ln_mode denominators) and in the one-shot right-hand side, is really the
-    other network, and refuses the entry points whose fused kernels cannot compute it."""
+    whole model and processor steps, hidden_layers 2 and 3, both ln_mode denominators), in the right-hand side (one-shot and resident forms)
+    and in the native rollout driver, is really the other network, and refuses the one entry point that belongs to the fused kernels."""
     g = np.load(os.path.join(GOLD, "gold_g_ln_variants.npz"))
     cfg = cfg_dict(L=int(g["L"]), mps=int(g["mps"]))
     ps = orc.init_params(9, 3, 2, cfg["L"], 2, cfg["mps"], seed=int(g["seed"]), ln_jitter=float(g["jitter"]))
@@ -163,11 +163,32 @@ def test_whole_array_layernorm_is_an_engine_mode(whole_array_oracle):
     eng.set_norms(node=(np.concatenate([ns, ts]), np.concatenate([nsh, tsh])), edge=(es, esh), out=(o_norm.std, o_norm.mean))
     d_ref = orc.ode_rhs(ps, cfg, x0, onehot0, g["ef"], g["senders"], g["receivers"], n_norm, t_norm, e_norm, o_norm, vm0[:, None])
     assert rel_max(eng.ode_step(x0, onehot0, g["ef"], vm0), d_ref) <= TOL_15
-    for call in (lambda: eng.ode_step(x0), lambda: eng.latents_randn(1) or eng.processor_steps_dev(1),      # (resident-input form; fused kernels)
-                 lambda: eng.step(g["nf"], g["ef"], np.zeros((48, 2), np.float32), np.arange(4, dtype=np.int32))):
-        with pytest.raises(MgnError) as ei:
-            call()
-        assert ei.value.code == -5                                  # MGN_E_UNSUPPORTED
+    # the resident form (mgn_set_static once per trajectory, then only the state moves): the edge encoder runs on the first evaluation
+    eng.set_static(onehot0, g["ef"], vm0)
+    assert rel_max(eng.ode_step(x0), d_ref) <= TOL_15
+    x1 = (x0 + 0.1 * rng0.standard_normal(x0.shape)).astype(np.float32)
+    d_ref1 = orc.ode_rhs(ps, cfg, x1, onehot0, g["ef"], g["senders"], g["receivers"], n_norm, t_norm, e_norm, o_norm, vm0[:, None])
+    assert rel_max(eng.ode_step(x1), d_ref1) <= TOL_15
+    # the native rollout driver on the same right-hand side (Euler with inflow rows; Tsit5 takes the same path per evaluation)
+    inflow = np.repeat((onehot0[:, 1] == 1)[:, None], 2, 1)
+    gt = (rng0.standard_normal((5, N0, 2)) * 0.3 + 1.0).astype(np.float32)
+    dt = 0.01
+
+    def rhs(xx, t):
+        return orc.ode_rhs(ps, cfg, xx, onehot0, g["ef"], g["senders"], g["receivers"], n_norm, t_norm, e_norm, o_norm, vm0[:, None])
+
+    ref = orc.euler_rollout(rhs, x0, dt, 4, inflow, gt)
+    sol, _ = eng.rollout("Euler", x0, onehot0, g["ef"], 0.0, 4 * dt, dt, 5, dt=dt, val_mask=vm0, inflow_mask=inflow[:, 0], inflow_data=gt,
+                         inflow_rule="tolerant")
+    assert np.linalg.norm(sol - ref) / np.linalg.norm(ref) <= 1e-4
+    sol5, st5 = eng.rollout("Tsit5", x0, onehot0, g["ef"], 0.0, 2 * dt, dt, 3, val_mask=vm0)
+    ref5 = orc.tsit5_rollout(lambda xx, t: rhs(xx, t), x0.astype(np.float64), 0.0, 2 * dt, [0.0, dt, 2 * dt])
+    assert np.linalg.norm(sol5 - np.stack(ref5[0])) / np.linalg.norm(np.stack(ref5[0])) <= 1e-3 and st5["n_rhs"] >= 7
+    # the fused kernels' device-resident processor entry point stays theirs
+    with pytest.raises(MgnError) as ei:
+        eng.latents_randn(1)
+        eng.processor_steps_dev(1)
+    assert ei.value.code == -5                                      # MGN_E_UNSUPPORTED
     eng.close()
     # a mesh of the size the persistent kernels serve in the default mode (scattered labels on top: the mode goes through own_gid too)
     from util import scatter_labels
@@ -198,3 +219,64 @@ def test_whole_array_layernorm_is_an_engine_mode(whole_array_oracle):
 def mgn_amd_engine(cfg, **kw):
     import mgn_amd
     return mgn_amd.Engine(cfg["Fn"], cfg["Fe"], cfg["O"], cfg["L"], cfg["hidden_layers"], cfg["mps"], **kw)
+
+
+@pytest.mark.parametrize("mode", [0, 1], ids=["var_eps", "std_eps"])
+def test_training_under_whole_array_layernorm(whole_array_oracle, mode, monkeypatch):
+    """mgn_step, mgn_forward_vjp and mgn_ode_vjp under ln_dims = MGN_LN_ALL: the pullback's two means run over the whole array (two
+    column reductions and an elementwise pass around an MLP backward without LayerNorm).  Against the oracle's reverse mode, which is
+    checked against finite differences under LN_DIMS = "all" on the CPU (tests/test_oracle_golden.py).  Cooperative kernels with graph
+    replay (nx = 8), L = 32, the streaming kernels with a factored first layer (nx = 40, recompute on and off), hidden_layers = 3."""
+    orc.LN_MODE = mode
+    try:
+        for L, nx, hl, recompute in ((128, 8, 2, None), (32, 8, 2, None), (128, 40, 2, "0"), (128, 40, 2, "1"), (128, 12, 3, None)):
+            if recompute is None:
+                monkeypatch.delenv("MGN_TRAIN_RECOMPUTE", raising=False)
+            else:
+                monkeypatch.setenv("MGN_TRAIN_RECOMPUTE", recompute)
+            cfg = dict(Fn=9, Fe=3, O=2, L=L, hidden_layers=hl, mps=2)
+            pos, s, r = small_mesh(nx, nx - 2)
+            N, E = pos.shape[0], s.size
+            ps = orc.init_params(9, 3, 2, L, hl, 2, seed=31 + L + hl, ln_jitter=0.1)
+            nf, ef = random_inputs(N, E, cfg, 5)
+            rng = np.random.default_rng(L + nx)
+            target = rng.standard_normal((N, 2)).astype(np.float32)
+            mask = rng.choice(N, N // 2, replace=False).astype(np.int32)
+            eng = mgn_amd_engine(cfg, ln_dims="all", ln_mode=mode)
+            eng.set_params(ps)
+            eng.set_graph(s, r, N)
+            g_ref, loss_ref = orc.step_grads(ps, cfg, nf, ef, s, r, target, mask)
+            for rep in range(3):                                     # eager, capture, replay on the small meshes
+                gs, loss = eng.step(nf, ef, target, mask)
+                assert abs(loss - loss_ref) <= 1e-5 * max(1.0, abs(loss_ref)), (L, nx, hl, rep)
+                err = np.linalg.norm(gs - g_ref) / np.linalg.norm(g_ref)
+                assert err <= 2e-4, (L, nx, hl, recompute, rep, err)
+            # it is the other network: the row-wise LayerNorm's gradient is far away
+            orc.LN_DIMS = "row"
+            g_row, _ = orc.step_grads(ps, cfg, nf, ef, s, r, target, mask)
+            orc.LN_DIMS = "all"
+            assert np.linalg.norm(g_row - g_ref) > 20 * np.linalg.norm(gs - g_ref)
+            ybar = rng.standard_normal((N, 2)).astype(np.float32)
+            nfbar, gps, out = eng.forward_vjp(nf, ef, ybar, want_out=True)
+            out_ref, gp_ref, nfbar_ref = orc.model_vjp(ps, cfg, nf, ef, s, r, lambda o: ybar.astype(np.float64))
+            assert rel_max(out, out_ref) <= TOL_15
+            # (4e-4 / 5e-4 on the 1 520-node mesh with a random cotangent: every LayerNorm couples all rows, rounding no longer stays in its row)
+            assert np.linalg.norm(gps - gp_ref) <= 1e-3 * np.linalg.norm(gp_ref)
+            assert np.linalg.norm(nfbar - nfbar_ref) <= 1e-3 * np.linalg.norm(nfbar_ref)
+            if L == 128 and nx == 8:                                 # the right-hand side's pullback (solver-based training)
+                x = (rng.standard_normal((N, 2)) * 0.3 + 1.0).astype(np.float32)
+                onehot = np.eye(7, dtype=np.float32)[rng.integers(0, 7, N)]
+                ef_raw = rng.standard_normal((E, 3)).astype(np.float32)
+                vm = (rng.random(N) < 0.7).astype(np.float32)
+                lam = rng.standard_normal((N, 2)).astype(np.float32)
+                n_norm, t_norm = orc.NormMeanStd(np.array([1.0, 0.9]), np.array([0.31, 0.27])), orc.NormMinMax(0.0, 1.0)
+                e_norm, o_norm = orc.NormMeanStd(ef_raw.mean(0), ef_raw.std(0)), orc.NormMeanStd(np.array([0.01, -0.02]), np.array([0.5, 0.4]))
+                (ns, nsh), (ts, tsh), (es, esh) = n_norm.affine(2), t_norm.affine(7), e_norm.affine(3)
+                eng.set_norms(node=(np.concatenate([ns, ts]), np.concatenate([nsh, tsh])), edge=(es, esh), out=(o_norm.std, o_norm.mean))
+                xbar, gso, dxdt = eng.ode_vjp(x, onehot, ef_raw, lam, val_mask=vm, want_dxdt=True)
+                rx, rg, rf = orc.ode_vjp(ps, cfg, x, onehot, ef_raw, s, r, n_norm, t_norm, e_norm, o_norm, vm, lam)
+                assert rel_max(dxdt, rf) <= TOL_15
+                assert np.linalg.norm(xbar - rx) <= 1e-3 * np.linalg.norm(rx) and np.linalg.norm(gso - rg) <= 2e-4 * np.linalg.norm(rg)
+            eng.close()
+    finally:
+        orc.LN_MODE = 0

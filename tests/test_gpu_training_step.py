@@ -246,20 +246,28 @@ def test_forward_vjp_is_the_pullback_of_the_model_call():
 
 
 def test_recompute_mode_gives_the_same_gradients(monkeypatch):
-    """Large meshes keep only the inputs of the processor MLPs and recompute H1 / H2 / Y in the reverse pass
-    (MGN_TRAIN_RECOMPUTE forces the mode): same forward arithmetic, so loss and gradients are bitwise equal."""
+    """Large meshes keep H1 / H2 / Y of as many processor steps as memory holds and recompute the others in the reverse pass from their
+    kept inputs (MGN_TRAIN_RECOMPUTE forces all or none, MGN_TRAIN_KEEP_STEPS the count): same forward arithmetic, so loss and
+    gradients are bitwise equal in every split."""
+    import ctypes as C
     cfg = cfg_dict(L=128, mps=3)
     pos, s, r = small_mesh(12, 9)
     ps = make_params(cfg)
     nf, ef, target, mask = problem(cfg, pos, s, r, seed=21)
     res = []
-    for mode in ("0", "1"):
-        monkeypatch.setenv("MGN_TRAIN_RECOMPUTE", mode)
+    for env, want in ((("MGN_TRAIN_RECOMPUTE", "0"), 3), (("MGN_TRAIN_RECOMPUTE", "1"), 0), (("MGN_TRAIN_KEEP_STEPS", "1"), 1),
+                      (("MGN_TRAIN_KEEP_STEPS", "2"), 2)):
+        monkeypatch.delenv("MGN_TRAIN_RECOMPUTE", raising=False)
+        monkeypatch.delenv("MGN_TRAIN_KEEP_STEPS", raising=False)
+        monkeypatch.setenv(*env)
         eng = engine_for(cfg)
         eng.set_params(ps)
         eng.set_graph(s, r, pos.shape[0])
         res.append(eng.step(nf, ef, target, mask))
-    assert res[0][1] == res[1][1] and np.array_equal(res[0][0], res[1][0])
+        eng.lib.mgn_debug_train_keep_steps.argtypes = [C.c_void_p]
+        assert eng.lib.mgn_debug_train_keep_steps(eng.h) == want
+    for other in res[1:]:
+        assert res[0][1] == other[1] and np.array_equal(res[0][0], other[0])
     ref, _ = orc.step_grads(ps, cfg, nf, ef, s, r, target, mask)
     check_grads(res[1][0], ref, cfg)
 

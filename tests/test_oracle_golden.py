@@ -76,12 +76,12 @@ def test_oracle_reproduces_gold_c_two_edge_sets():
     assert rel_max(out0, g["out"]) > 1e-3
 
 
-@pytest.fixture(params=[0, 1], ids=["ln_var_eps", "ln_std_eps"])
+@pytest.fixture(params=[(0, "row"), (1, "row"), (0, "all"), (1, "all")], ids=["ln_var_eps", "ln_std_eps", "ln_all_var_eps", "ln_all_std_eps"])
 def ln_mode(request):
-    """both LayerNorm denominators (DESIGN.md spec_variant): the reverse mode follows orc.LN_MODE"""
-    orc.LN_MODE = request.param
+    """both LayerNorm denominators and both statistics ranges (DESIGN.md spec_variant): the reverse mode follows orc.LN_MODE / orc.LN_DIMS"""
+    orc.LN_MODE, orc.LN_DIMS = request.param
     yield request.param
-    orc.LN_MODE = 0
+    orc.LN_MODE, orc.LN_DIMS = 0, "row"
 
 
 def test_step_grads_match_finite_differences(ln_mode):
