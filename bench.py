@@ -729,6 +729,27 @@ def main():
                 del nfT, efT, tgT
             except Exception as ex:   # noqa: BLE001  (a box with less free memory than the 61 GB this needs at least)
                 out["secondary"]["train_step_1m"] = {"error": str(ex)[:200]}
+            # spec hedge: whole-array LayerNorm (mgn_config.ln_dims = MGN_LN_ALL) -- the unfused driver's cost, from whole
+            # forwards (small host arrays in and out): one forward = encoders + 15 processor steps + decoder on the device
+            try:
+                engA = mgn_amd.Engine(FN, FE, O, L, 2, MPS, device=local_rank, ln_dims="all")
+                engA.set_params(ps)
+                engA.set_graph(s, r, N)
+                rngA = np.random.default_rng(1)
+                nfA = rngA.standard_normal((N, FN), dtype=np.float32)
+                efA = rngA.standard_normal((E, FE), dtype=np.float32)
+                engA.forward(nfA, efA)
+                t0 = time.perf_counter()
+                outA = engA.forward(nfA, efA)
+                dtA = time.perf_counter() - t0
+                out["secondary"]["whole_array_layernorm_1m"] = {
+                    "workload": "mgn_forward on M-1M under ln_dims = MGN_LN_ALL (what Lux 0.5's LayerNorm computes at dims = Colon()): per MLP the "
+                                "streaming MLP kernel without LayerNorm, grid-wide statistics in double, an apply pass; host in/out (132 MB) included",
+                    "ms_per_forward": dtA * 1e3, "ms_per_processor_step_upper_bound": dtA * 1e3 / MPS, "finite": bool(np.isfinite(outA).all())}
+                engA.close()
+                del nfA, efA
+            except Exception as ex:   # noqa: BLE001
+                out["secondary"]["whole_array_layernorm_1m"] = {"error": str(ex)[:200]}
             # mid-size meshes (real CFD meshes, and the per-GPU share of M-1M on 8 GPUs): where the kernel families meet
             mids = {}
             for nxm in (128, 300, 354):   # 354 x 354 = the per-GPU share of M-1M on 8 GPUs

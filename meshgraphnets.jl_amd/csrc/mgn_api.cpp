@@ -1084,7 +1084,7 @@ static int rebuild_graph(mgn_handle* h, int32_t N, const EdgeList* sets, const f
     if (!h->host_only) { (void)hipStreamSynchronize(h->stream); drop_graph(h); }
     const std::string why = build_local_graph(N, h->nsets, sets, mesh_pos, pos_dim, keep_owner ? h->g.owner.data() : nullptr,
                                               h->cfg.rank, h->cfg.nranks, h->g,
-                                              h->nsets == 1 ? g_renumber : 0);   // (world-edge sets are searched / installed in global ids)
+                                              g_renumber);   // (the numbering follows set 0 alone: a later mgn_set_edge_set / mgn_world_edges_dev keeps it)
     if (!why.empty()) return fail(h, MGN_E_ARG, "%s: %s", who, why.c_str());
     const LocalGraph& g = h->g;
     for (int q = 0; q < h->nsets; ++q) h->es[q].ntiles_e = (int32_t)((g.set[q].e_local + TILE - 1) / TILE);
@@ -2505,7 +2505,13 @@ int mgn_world_edges_dev(mgn_handle* h, int32_t set, const float* world_pos, int3
     HIPCHK(h, hipStreamSynchronize(h->stream));
     drop_graph(h);
     HIPCHK(h, h->gpos.ensure((size_t)g.N * dim * 4));
-    HIPCHK(h, hipMemcpyAsync(h->gpos.p, world_pos, (size_t)g.N * dim * 4, hipMemcpyDefault, h->stream));
+    if (g.renumbered) {   // the search runs in the engine's node numbering (set 0's adjacency is held in it): positions gathered through own_gid
+        HIPCHK(h, h->stage.ensure((size_t)g.N * dim * 4));
+        HIPCHK(h, hipMemcpyAsync(h->stage.p, world_pos, (size_t)g.N * dim * 4, hipMemcpyDefault, h->stream));
+        HIPCHK(h, launch_permute_rows(h->gpos.as<float>(), h->stage.as<float>(), h->d_own_gid.as<int32_t>(), g.N, dim, false, h->stream));
+    } else {
+        HIPCHK(h, hipMemcpyAsync(h->gpos.p, world_pos, (size_t)g.N * dim * 4, hipMemcpyDefault, h->stream));
+    }
     int64_t E = 0;
     const hipError_t e = dev_world_edges(h->gpos.as<float>(), dim, g.N, radius, h->es[0].d_rowptr.as<int32_t>(), h->es[0].d_snd.as<int32_t>(), h->gwork,
                                          es.d_snd, es.d_rcv, es.d_rowptr, &E, h->stream);

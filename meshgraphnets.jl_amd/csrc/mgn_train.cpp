@@ -928,8 +928,9 @@ struct LnAll {
     int64_t N, E;
     int32_t nt_n, nt_e;
     const int32_t *snd, *rcv, *rowptr, *egid;
-    size_t V, Ecur, Y, Hb, agg, stats, part, nf_raw, nf_pad, ef_raw, ef_pad, tmp, E0;
+    size_t V, Ecur, Y, Hb, agg, stats, part, nf_raw, nf_pad, ef_raw, ef_pad, tmp, E0, Pn, Qn;
     float eps_in, eps_out;
+    bool factored = false;       // large launches: the first edge layer per NODE (P = v W1s, Q = v W1r; launch_lin2) as in the training step
 
     // Y <- MLP(x) without LayerNorm / residual (launch units chained through Hb)
     hipError_t mlp(const TrainMlp& m, int64_t rows, int32_t ntiles, const float* x0, const int32_t* i0, const float* x1, const int32_t* i1,
@@ -965,7 +966,30 @@ struct LnAll {
     // one processor step on V / Ecur (engine order, row-major [rows][L])
     int step(int k) {
         float *v = A + V, *e = A + Ecur, *y = A + Y;
-        if (E > 0) {
+        if (E > 0 && factored) {
+            const TrainMlp& m = T.m_pe[0][k];
+            Lin2Args p{};
+            p.rows = N; p.ntiles = nt_n;
+            p.X0 = v; p.W0 = Wt + m.b[0].W1[0]; p.W1 = Wt + m.b[0].W1[1];
+            p.OUT0 = A + Pn; p.OUT1 = A + Qn;
+            HIPCHK(h, launch_lin2(L, p, st));
+            for (int bi = 0; bi < m.nblk; ++bi) {
+                const TrainBlock& b = m.b[bi];
+                TrainFwdArgs a{};
+                a.rows = E; a.ntiles = nt_e;
+                if (bi == 0) {
+                    a.X[0] = e; a.W1[0] = Wt + b.W1[2];
+                    a.PRE[0] = A + Pn; a.preidx[0] = snd; a.PRE[1] = A + Qn; a.preidx[1] = rcv;
+                } else {
+                    a.X[0] = A + Hb; a.W1[0] = Wt + b.W1[0];
+                }
+                a.W2 = Wt + b.W2; a.W3 = Wt + b.W3; a.tabs = Wt + b.tabs;
+                a.ln = 0;
+                a.OUT = bi == m.nblk - 1 ? y : A + Hb;
+                HIPCHK(h, launch_mlp_fwd(L, 1, a, st));
+            }
+            HIPCHK(h, ln(m, y, E, e, e, y));
+        } else if (E > 0) {
             HIPCHK(h, mlp(T.m_pe[0][k], E, nt_e, v, snd, v, rcv, e, y));
             HIPCHK(h, ln(T.m_pe[0][k], y, E, e, e, y));                      // y <- e' = LN(MLP_e), e <- e + e'
         }
@@ -1001,6 +1025,10 @@ LnAll lnall_layout(mgn_engine* h, bool with_inputs, size_t& floats) {
     size_t off = 0;
     auto take = [&](size_t n) { const size_t o = off; off += (n + 63) / 64 * 64; return o; };
     X.V = take(NL); X.Ecur = take(EL); X.Y = take(ML); X.Hb = T.nblk > 1 ? take(ML) : 0; X.agg = take(NL);
+    X.factored = !train_uses_coop(128, X.nt_e) && X.E > 0;
+    if (const char* e = getenv("MGN_TRAIN_FACTORED")) X.factored = atoi(e) != 0 && X.E > 0;
+    X.Pn = X.Qn = 0;
+    if (X.factored) { X.Pn = take(NL); X.Qn = take(NL); }
     X.stats = take(64); X.part = take((size_t)4 * array_stats_blocks());
     X.tmp = take(ML);                                   // caller order <-> engine order staging
     X.nf_raw = X.nf_pad = X.ef_raw = X.ef_pad = X.E0 = 0;

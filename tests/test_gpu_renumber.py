@@ -132,3 +132,47 @@ def test_partitions_of_a_scattered_mesh(P):
         g.latents_export(v, e_)
     rv, re = orc.processor_steps(ps, cfg, v0, e0, s, r, 3)
     assert rel_max(v, rv) <= TOL_15 and rel_max(e_, re) <= TOL_15
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_two_edge_sets_on_scattered_labels(dtype):
+    """A cloth mesh (mesh + world edges) under DeepMind-style arbitrary node labels: the handle is renumbered like a one-set handle (the
+    numbering follows the mesh set alone, so installing / re-searching the world set keeps V and the mesh latents valid); host-installed
+    world edges arrive in the caller's ids, the device search runs on positions gathered into the engine's order and exports the caller's ids."""
+    m = synth.mesh_flag(3, 30, 24, radius=0.06)
+    N = m["mesh_pos"].shape[0]
+    perm = np.random.default_rng(5).permutation(N).astype(np.int32)            # perm[old] = new label
+    inv = np.argsort(perm)
+    s, r, s2, r2 = perm[m["s"]], perm[m["r"]], perm[m["s2"]], perm[m["r2"]]
+    wpos = m["world_pos"][inv]
+    cfg = dict(Fn=12, Fe=7, O=3, L=128, hidden_layers=2, mps=3, Fe2=4)
+    ps = orc.init_params(12, 7, 3, 128, 2, 3, 5, 0.1, Fe2=4)
+    rng = np.random.default_rng(4)
+    nf = rng.standard_normal((N, 12)).astype(np.float32)
+    ref = orc.forward(ps, cfg, nf, m["ef"], s, r, set2=(m["ef2"], s2, r2))
+    tol = TOL_15 if dtype == "f32" else 3e-2
+    err = (lambda a: rel_max(a, ref)) if dtype == "f32" else (lambda a: float(np.linalg.norm(a - ref) / np.linalg.norm(ref)))
+    eng = mgn_amd.Engine(12, 7, 3, 128, 2, 3, Fe2=4, dtype=dtype)
+    eng.set_params(ps)
+    eng.set_graph(s, r, N)
+    assert renumbered(eng)
+    eng.set_edge_set(1, s2, r2)
+    assert renumbered(eng) and np.array_equal(np.sort(eng.owned_nodes()), np.arange(N))
+    eng.set_edge_features(1, m["ef2"])
+    assert err(eng.forward(nf, m["ef"])) <= tol
+    # device search on the same handle: the same SET of world edges in the caller's ids (receiver-major in the engine's numbering, so the
+    # order differs from the host search's), features computed on the device, the same model output
+    assert eng.world_edges_dev(1, wpos, 0.06) == s2.size
+    sd, rd = eng.edge_set_export(1)
+    key = lambda a, b: np.sort(a.astype(np.int64) * N + b)
+    assert np.array_equal(key(sd, rd), key(s2, r2))
+    assert err(eng.forward(nf, m["ef"])) <= tol
+    if dtype == "f32":    # training on the renumbered two-set handle (host-installed sets keep their lists)
+        eng.set_edge_set(1, s2, r2)
+        eng.set_edge_features(1, m["ef2"])
+        target = rng.standard_normal((N, 3)).astype(np.float32)
+        mask = np.sort(rng.choice(N, N // 2, replace=False)).astype(np.int32)
+        gs, loss = eng.step(nf, m["ef"], target, mask)
+        rgs, rloss = orc.step_grads(ps, cfg, nf, m["ef"], s, r, target, mask, set2=(m["ef2"], s2, r2))
+        assert abs(loss - rloss) <= 1e-5 * abs(rloss) and np.linalg.norm(gs - rgs) <= 5e-3 * np.linalg.norm(rgs)
+    eng.close()
