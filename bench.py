@@ -676,6 +676,10 @@ def main():
             # the loop the reference runs (src/MeshGraphNets.jl:375-377): the optimiser changes ps, so every iteration is
             # mgn_set_params + mgn_step -- the parameters go to the device once and the training layouts are packed there
             ps_it = ps.copy()
+            for _ in range(3):          # (the device-array calls above used other buffers: the launch graphs are captured again first)
+                ps_it *= np.float32(1.00001)
+                engt.set_params(ps_it)
+                engt.step(nft, eft, tgt, maskt)
             t0 = time.perf_counter()
             for _ in range(10):
                 ps_it *= np.float32(1.00001)

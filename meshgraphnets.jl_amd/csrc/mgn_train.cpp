@@ -65,9 +65,10 @@ struct TrainState {
     Acts a_en, a_de, a_ee[MAX_EDGE_SETS];
     std::vector<Acts> a_pe[MAX_EDGE_SETS], a_pn;
     std::vector<size_t> Ek[MAX_EDGE_SETS], Vk, agg[MAX_EDGE_SETS];
-    static constexpr int GSETS = 4;   // gradient-buffer sets: the weight gradients of unit i run beside the backward of units i+1 .. i+3
+    static constexpr int GSETS_MAX = 72;
+    static inline int GSETS = [] { const char* e = getenv("MGN_TRAIN_GSETS"); const int v = e ? atoi(e) : 4; return v < 1 ? 1 : (v > 72 ? 72 : v); }();   // gradient-buffer sets: the weight gradients of unit i run beside the backward of units i+1 .. i+3
     int gsets = 1;                    // sets allocated for the current graph (GSETS on small meshes, else 1: no overlap)
-    size_t GT[GSETS], GXH[GSETS], GY[GSETS], GZ2[GSETS], GZ1[GSETS];
+    size_t GT[GSETS_MAX], GXH[GSETS_MAX], GY[GSETS_MAX], GZ2[GSETS_MAX], GZ1[GSETS_MAX];
     size_t GXs, GXr, GXB, gV[2], gE[MAX_EDGE_SETS][2], gAgg[MAX_EDGE_SETS], Gout, gNF, io, ptmp, pw, pb;
     size_t Pn, Qn, SGs, SGr;     // factored first layer: per-node projections (forward) and summed GZ1 rows (backward)
     // whole-array LayerNorm in the training step: per-MLP statistics of the forward (64 floats each), the double partials of the two
@@ -75,7 +76,7 @@ struct TrainState {
     size_t lnstats = 0, lnpart = 0, lnm = 0, GLN = 0;
     // weight gradients + their reductions go to a second stream (small meshes leave most of the chip idle during k_mlp_bwd)
     hipStream_t aux = nullptr;
-    hipEvent_t ev_bwd = nullptr, ev_wg[GSETS] = {};
+    hipEvent_t ev_bwd = nullptr, ev_wg[GSETS_MAX] = {};
     // hipGraph replay of the two launch sequences over fixed buffers (small meshes): [0] forward, [1] backward of mgn_step,
     // [2] backward of mgn_ode_vjp (it also produces the input gradient).  Eager once, captured on the next call.
     hipGraphExec_t exec[3] = {nullptr, nullptr, nullptr};
@@ -745,8 +746,9 @@ int train_run(mgn_handle* h, const TrainJob& J) {
             job(nullptr, nullptr, A + T.GT[gs], -1, 0, 0, b.gbeta, L);
         }
         if (wb.njobs == 0) return MGN_OK;
-        HIPCHK(h, launch_wgrad(L, wb, lrows, wst));
-        HIPCHK(h, launch_reduce_partials(rb, wst));
+        static const int whatif = [] { const char* e = getenv("MGN_TRAIN_WHATIF"); return e ? atoi(e) : 0; }();   // diagnostic (wrong gradients): 1 no weight-gradient launches, 2 no reductions
+        if (!(whatif & 1)) HIPCHK(h, launch_wgrad(L, wb, lrows, wst));
+        if (!(whatif & 2)) HIPCHK(h, launch_reduce_partials(rb, wst));
         if (overlap) HIPCHK(h, hipEventRecord(T.ev_wg[gs], wst));
         return MGN_OK;
     };
