@@ -1644,8 +1644,13 @@ static int lnall_ode_step(mgn_handle* h, const float* x, const float* onehot, co
         if (int rc = upload_state(h, x)) return rc;
         if (int rc = lnall_rhs_prepare(h)) return rc;
         HIPCHK(h, h->d_out.ensure((size_t)(h->g.n_own > 0 ? h->g.n_own : 1) * c.O * 4));
-        if (int rc = lnall_rhs_dev(h, h->d_nfA.as<float>(), h->d_out.as<float>(), h->lnall_edges)) return rc;
-        h->lnall_edges = true;
+        if (!h->lnall_edges) {        // first evaluation of the trajectory: the edge encoder runs too (eager)
+            if (int rc = lnall_rhs_dev(h, h->d_nfA.as<float>(), h->d_out.as<float>(), false)) return rc;
+            h->lnall_edges = true;
+        } else {                      // afterwards the ~130 launches of a right-hand side replay from one launch graph (small meshes)
+            auto launches = [&]() -> int { return lnall_rhs_dev(h, h->d_nfA.as<float>(), h->d_out.as<float>(), true); };
+            if (int rc = run_graphed(h, h->rhs_exec, h->rhs_warm, launches)) return rc;
+        }
         return mgn_fwd_download(h, dxdt);
     }
     if (!ef_raw || (c.Fn > c.O && !onehot)) return fail(h, MGN_E_ARG, "mgn_ode_step: null argument");

@@ -362,9 +362,10 @@ int prepare_graph(mgn_engine* h) {
             T.m_pn[k].lnslot = slot++;
         }
         T.lnstats = take((size_t)64 * slot);
-        T.lnpart = take((size_t)2 * std::max<size_t>((size_t)2 * array_stats_blocks(), (size_t)2 * 128 * lnall_bwd_blocks()));
+        const size_t nt_max = (std::max<size_t>(NL, ELmax) / L + TILE - 1) / TILE;
+        T.lnpart = take((size_t)2 * std::max<size_t>({(size_t)2 * array_stats_blocks(), (size_t)2 * 128 * lnall_bwd_blocks(), (size_t)2 * 4 * nt_max}));
         T.lnm = take(64);
-        T.GLN = take(ML);
+        T.GLN = 0;
     }
     T.arena_floats = off;
     T.drop_graphs();
@@ -538,12 +539,14 @@ int train_run(mgn_handle* h, const TrainJob& J) {
             else if (!keep) a.OUT = A + act.h[bi][2];
             a.ln = b.ln ? 1 : 0;
             const bool wide = lnall && last && b.ln;      // whole-array LayerNorm: the kernel stops at Y, statistics and apply follow
+            const bool want_stats = wide && (out || lnout) && in.rows > 0;   // (the recomputation of the reverse pass asks for neither: the statistics are kept)
             if (wide) { a.ln = 0; a.resid = nullptr; a.OUT = nullptr; a.LNOUT = nullptr; a.Y = A + act.h[bi][2]; }
+            if (want_stats) a.STATS = reinterpret_cast<double*>(A + T.lnpart);   // the kernel leaves (sum, sum of squares) of Y per tile
             if (hipError_t e = launch_mlp_fwd(L, nin, a, st)) return e;
-            if (wide && (out || lnout) && in.rows > 0) {  // (the recomputation of the reverse pass asks for neither: the statistics are kept)
+            if (want_stats) {
                 float* stats = A + T.lnstats + (size_t)64 * m.lnslot;
                 const int64_t n = in.rows * L;
-                if (hipError_t e = launch_array_stats(a.Y, n, reinterpret_cast<double*>(A + T.lnpart), ln_eps_in, ln_eps_out, stats, st)) return e;
+                if (hipError_t e = launch_array_stats_final(a.STATS, train_fwd_stat_slots(L, in.ntiles), n, ln_eps_in, ln_eps_out, stats, st)) return e;
                 if (hipError_t e = launch_ln_all_apply(a.Y, stats, Wt + b.tabs + (size_t)T_GAMMA * L, Wt + b.tabs + (size_t)T_BETA * L, resid, out,
                                                        lnout, n, L, st)) return e;
             }
@@ -694,11 +697,12 @@ int train_run(mgn_handle* h, const TrainJob& J) {
         a.tabs = Wt + b.tabs;
         a.ln = b.ln ? 1 : 0;
         a.GT = A + T.GT[gs]; a.GXH = A + T.GXH[gs]; a.GY = A + T.GY[gs]; a.GZ2 = A + T.GZ2[gs]; a.GZ1 = A + T.GZ1[gs];
-        if (wide && rows > 0) {   // pullback of the whole-array LayerNorm first: dgamma, dbeta, and the gradient at Y for a kernel without LayerNorm
+        if (wide && rows > 0) {   // pullback of the whole-array LayerNorm: dgamma, dbeta and the two means first (two column reductions)
             HIPCHK(h, launch_lnall_bwd(g0, g1, g1i, A + hb[2], A + T.lnstats + (size_t)64 * lnslot, Wt + b.tabs + (size_t)T_GAMMA * L, rows, L,
-                                       reinterpret_cast<double*>(A + T.lnpart), A + T.lnm, G + b.ggamma, G + b.gbeta, A + T.GLN, st));
-            a.G0 = A + T.GLN; a.G1 = nullptr; a.g1idx = nullptr;
-            a.ln = 0;
+                                       reinterpret_cast<double*>(A + T.lnpart), A + T.lnm, G + b.ggamma, G + b.gbeta, nullptr, st));
+            a.ln = 2;                   // the kernel maps G to the gradient at Y as it loads it
+            a.LNS = A + T.lnstats + (size_t)64 * lnslot;
+            a.LNM = A + T.lnm;
         }
         HIPCHK(h, launch_mlp_bwd(L, nin_k, a, st));
         if (fact) {   // gather <-> segmented-sum duality on GZ1 itself: SGr[n] = sum of GZ1 over edges received by n, SGs: sent by n
@@ -932,6 +936,7 @@ struct LnAll {
     const int32_t *snd, *rcv, *rowptr, *egid;
     size_t V, Ecur, Y, Hb, agg, stats, part, nf_raw, nf_pad, ef_raw, ef_pad, tmp, E0, Pn, Qn;
     float eps_in, eps_out;
+    int64_t slots = 0;           // (sum, sum of squares) slots the last MLP launch left in `part` (TrainFwdArgs::STATS)
     bool factored = false;       // large launches: the first edge layer per NODE (P = v W1s, Q = v W1r; launch_lin2) as in the training step
 
     // Y <- MLP(x) without LayerNorm / residual (launch units chained through Hb)
@@ -953,6 +958,7 @@ struct LnAll {
             a.W2 = Wt + b.W2; a.W3 = Wt + b.W3; a.tabs = Wt + b.tabs;
             a.ln = 0;
             a.OUT = bi == m.nblk - 1 ? yout : A + Hb;
+            if (bi == m.nblk - 1 && b.ln) { a.STATS = reinterpret_cast<double*>(A + part); slots = train_fwd_stat_slots(L, ntiles); }
             if (hipError_t e = launch_mlp_fwd(L, nin, a, st)) return e;
         }
         return hipSuccess;
@@ -962,7 +968,7 @@ struct LnAll {
         const TrainBlock& b = m.b[m.nblk - 1];
         const int64_t n = rows * L;
         if (n <= 0) return hipSuccess;
-        if (hipError_t e = launch_array_stats(y, n, reinterpret_cast<double*>(A + part), eps_in, eps_out, A + stats, st)) return e;
+        if (hipError_t e = launch_array_stats_final(reinterpret_cast<const double*>(A + part), slots, n, eps_in, eps_out, A + stats, st)) return e;
         return launch_ln_all_apply(y, A + stats, Wt + b.tabs + (size_t)T_GAMMA * L, Wt + b.tabs + (size_t)T_BETA * L, resid, out, lnout, n, L, st);
     }
     // one processor step on V / Ecur (engine order, row-major [rows][L])
@@ -988,6 +994,7 @@ struct LnAll {
                 a.W2 = Wt + b.W2; a.W3 = Wt + b.W3; a.tabs = Wt + b.tabs;
                 a.ln = 0;
                 a.OUT = bi == m.nblk - 1 ? y : A + Hb;
+                if (bi == m.nblk - 1) { a.STATS = reinterpret_cast<double*>(A + part); slots = train_fwd_stat_slots(L, nt_e); }
                 HIPCHK(h, launch_mlp_fwd(L, 1, a, st));
             }
             HIPCHK(h, ln(m, y, E, e, e, y));
@@ -1031,7 +1038,8 @@ LnAll lnall_layout(mgn_engine* h, bool with_inputs, size_t& floats) {
     if (const char* e = getenv("MGN_TRAIN_FACTORED")) X.factored = atoi(e) != 0 && X.E > 0;
     X.Pn = X.Qn = 0;
     if (X.factored) { X.Pn = take(NL); X.Qn = take(NL); }
-    X.stats = take(64); X.part = take((size_t)4 * array_stats_blocks());
+    X.stats = take(64);
+    X.part = take(std::max<size_t>((size_t)4 * array_stats_blocks(), (size_t)16 * (size_t)std::max(X.nt_n, X.nt_e)));   // 2 doubles per slot
     X.tmp = take(ML);                                   // caller order <-> engine order staging
     X.nf_raw = X.nf_pad = X.ef_raw = X.ef_pad = X.E0 = 0;
     if (with_inputs) {

@@ -25,6 +25,9 @@ struct TrainFwdArgs {
     // factored first layer (edge MLP on large meshes): layer-1 pre-activation += PRE[i][preidx[i] ? preidx[i][row] : row]
     // (P = v W1_sender and Q = v W1_receiver, computed once per NODE by launch_lin2)
     const float* PRE[2]; const int32_t* preidx[2];
+    // whole-array LayerNorm (ln = 0 here): (sum, sum of squares) of this launch's valid part of Y per slot, in double -- slot = tile for the
+    // streaming kernels, 4 tile + wave for the cooperative ones (train_fwd_stat_slots); launch_array_stats_final adds the slots in order
+    double* STATS;
 };
 
 struct TrainBwdArgs {
@@ -33,7 +36,8 @@ struct TrainBwdArgs {
     const float* Y; const float* H2; const float* H1;
     const float* W3T; const float* W2T; const float* W1T[3];  // transposed chunks, fragment order; W1T[j] null: skip
     const float* tabs;                           // gamma in T_GAMMA
-    int32_t ln;
+    int32_t ln;                                  // 1: row-wise LayerNorm pullback here; 2: the whole-array one -- gy = rden (gamma g - m1 - xhat m2) with
+    const float* LNS; const float* LNM;          //    LNS = (mean, rden, kappa) of the forward and LNM = (m1, m2) of launch_lnall_bwd; 0: none
     float* GT; float* GXH;                       // ln: total upstream gradient and G * xhat (-> dbeta, dgamma by column sums)
     float* GY; float* GZ2; float* GZ1;           // gradients at the three Dense outputs (-> weight / bias gradients)
     float* GX[3]; const float* GXadd[3];         // GX[j][row] = (GXadd[j] ? GXadd[j][row] : 0) + GZ1[row] * W1T[j]
@@ -98,6 +102,8 @@ hipError_t launch_affine_pad(const float* srcA, int wa, const float* srcB, int w
 // whole-array LayerNorm (mgn_config.ln_dims = MGN_LN_ALL): stats = (mean, 1 / (sqrt(var + eps_in) + eps_out), kappa) over the n values of x
 // (double accumulation, fixed order; partial: 2 * array_stats_blocks() doubles), then t = (y - mean) * rden * gamma + beta
 int array_stats_blocks();
+int train_fwd_stat_slots(int L, int ntiles);     // slots a launch_mlp_fwd with TrainFwdArgs::STATS writes (2 doubles each)
+hipError_t launch_array_stats_final(const double* partial, int64_t slots, int64_t n, float eps_in, float eps_out, float* stats, hipStream_t s);
 hipError_t launch_array_stats(const float* x, int64_t n, double* partial, float eps_in, float eps_out, float* stats, hipStream_t s);
 hipError_t launch_ln_all_apply(const float* y, const float* stats, const float* gamma, const float* beta, const float* resid, float* out,
                                float* lnout, int64_t n, int L, hipStream_t s);
@@ -105,7 +111,8 @@ hipError_t launch_ln_all_apply(const float* y, const float* stats, const float* 
 hipError_t launch_rhs_epilogue(const float* Y, int L, int O, const float* os, const float* osh, const float* mask, const int32_t* gid, float* out,
                                int64_t N, hipStream_t s);
 // reverse pass of the whole-array LayerNorm of one MLP: dgamma, dbeta (L floats each, written into the gradient vector), m = (m1, m2) scratch
-// (2 floats) and dY [rows][L] = rden (gamma G - m1 - xhat m2) with G = G0[row] (+ G1[g1idx ? g1idx[row] : row]);
+// (2 floats) and -- dY != null -- dY [rows][L] = rden (gamma G - m1 - xhat m2) with G = G0[row] (+ G1[g1idx ? g1idx[row] : row])
+// (null: the MLP backward kernel applies that map as it loads G, TrainBwdArgs::ln = 2);
 // partial: 2 * 128 * lnall_bwd_blocks() doubles; stats: launch_array_stats' (mean, rden, kappa) of the forward
 int lnall_bwd_blocks();
 hipError_t launch_lnall_bwd(const float* G0, const float* G1, const int32_t* g1idx, const float* Y, const float* stats, const float* gamma,

@@ -135,6 +135,19 @@ __global__ __launch_bounds__(64 * WPB) void k_mlp_fwd(const TrainFwdArgs a) {
     tab_frag<NT>(acc, a.tabs + T_B3 * L, h);
     train_chunk<NT, H2>(acc, y, x, CP_W(), lane, HRS(a.W3));
     if (a.Y && rw.valid) store_frag<NT>(row_ptr(a.Y, rw.row, L, h), STRIDE_ROW, acc);
+    if (a.STATS) {                               // whole-array LayerNorm: this tile's (sum, sum of squares) of Y, lanes added in a fixed pattern
+        float s1 = 0.f, s2 = 0.f;
+        if (rw.valid) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int k = 0; k < 16; ++k) { s1 += acc[t][k]; s2 += acc[t][k] * acc[t][k]; }
+        }
+        double d1 = (double)s1, d2 = (double)s2;
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) { d1 += __shfl_xor(d1, o, 64); d2 += __shfl_xor(d2, o, 64); }
+        if (active && lane0 == 0) { a.STATS[2 * (int64_t)tile_raw] = d1; a.STATS[2 * (int64_t)tile_raw + 1] = d2; }
+    }
     if (a.ln) layer_norm_frag<NT>(acc, a.tabs + T_GAMMA * L, a.tabs + T_BETA * L, h);
     if (a.LNOUT && rw.valid) store_frag<NT>(row_ptr(a.LNOUT, rw.row, L, h), STRIDE_ROW, acc);
     if (a.resid) add_frag<NT>(acc, row_ptr(a.resid, rw.rr, L, h), STRIDE_ROW);
@@ -172,7 +185,19 @@ __global__ __launch_bounds__(64 * WPB) void k_mlp_bwd(const TrainBwdArgs a) {
     load_frag<NT>(g, row_ptr(a.G0, rw.rr, L, h), STRIDE_ROW);
     if (a.G1) add_frag<NT>(g, row_ptr(a.G1, a.g1idx ? (int64_t)a.g1idx[rw.rr] : rw.rr, L, h), STRIDE_ROW);
     if (!rw.valid) zero_frag<NT>(g);
-    if (a.ln) {
+    if (a.ln == 2) {                             // whole-array LayerNorm: gy = rden (gamma g - m1 - xhat m2), statistics and means given
+        load_frag<NT>(y, row_ptr(a.Y, rw.rr, L, h), STRIDE_ROW);
+        const float mean = a.LNS[0], rden = a.LNS[1], m1 = a.LNM[0], m2 = a.LNM[1];
+        tab_frag<NT>(acc, a.tabs + T_GAMMA * L, h);
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const float xh = (y[t][k] - mean) * rden;
+                g[t][k] = rw.valid ? rden * (acc[t][k] * g[t][k] - m1 - xh * m2) : 0.f;
+            }
+    }
+    if (a.ln == 1) {
         if (rw.valid) store_frag<NT>(row_ptr(a.GT, rw.row, L, h), STRIDE_ROW, g);
         load_frag<NT>(y, row_ptr(a.Y, rw.rr, L, h), STRIDE_ROW);
         float s = 0.f;
@@ -345,6 +370,17 @@ __global__ __launch_bounds__(256, 2) void k_mlp_fwd_coop(const TrainFwdArgs a) {
         tab_quarter(acc, a.tabs + T_B3 * L, tq, h);
         t_chain_primed<H2>(acc, xb, a.W3, tq, lane, r3);
         if (a.Y && rw.valid) store_quarter(row_ptr(a.Y, rw.row, L, h), STRIDE_ROW, tq, acc);
+        if (a.STATS) {                                                 // whole-array LayerNorm: (sum, sum of squares) of this wave's quarter of Y
+            float s1 = 0.f, s2 = 0.f;
+            if (rw.valid) {
+#pragma unroll
+                for (int k = 0; k < 16; ++k) { s1 += acc[k]; s2 += acc[k] * acc[k]; }
+            }
+            double d1 = (double)s1, d2 = (double)s2;
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) { d1 += __shfl_xor(d1, o, 64); d2 += __shfl_xor(d2, o, 64); }
+            if (lane0 == 0) { a.STATS[2 * ((int64_t)tile * 4 + wave)] = d1; a.STATS[2 * ((int64_t)tile * 4 + wave) + 1] = d2; }
+        }
         if (a.ln) {
             coop_exchange(xa, acc, xch0, wave, lane);                  // full pre-LN row for the statistics
             coop_layer_norm(acc, xa, a.tabs + T_GAMMA * L, a.tabs + T_BETA * L, tq, h);
@@ -384,7 +420,20 @@ __global__ __launch_bounds__(256, 2) void k_mlp_bwd_coop(const TrainBwdArgs a) {
         load_frag<4>(g, row_ptr(a.G0, rw.rr, L, h), STRIDE_ROW);
         if (a.G1) add_frag<4>(g, row_ptr(a.G1, a.g1idx ? (int64_t)a.g1idx[rw.rr] : rw.rr, L, h), STRIDE_ROW);
         if (!rw.valid) zero_frag<4>(g);
-        if (a.ln) {
+        if (a.ln == 2) {                                               // whole-array LayerNorm (see k_mlp_bwd)
+            load_frag<4>(y, row_ptr(a.Y, rw.rr, L, h), STRIDE_ROW);
+            const float mean = a.LNS[0], rden = a.LNS[1], m1 = a.LNM[0], m2 = a.LNM[1];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                tab_quarter(q, a.tabs + T_GAMMA * L, t, h);
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    const float xh = (y[t][k] - mean) * rden;
+                    g[t][k] = rw.valid ? rden * (q[k] * g[t][k] - m1 - xh * m2) : 0.f;
+                }
+            }
+        }
+        if (a.ln == 1) {
             if (rw.valid) store_quarter(row_ptr(a.GT, rw.row, L, h), STRIDE_ROW, tq, pick_quarter(g, tq));
             load_frag<4>(y, row_ptr(a.Y, rw.rr, L, h), STRIDE_ROW);
             float s = 0.f;
@@ -745,10 +794,22 @@ __global__ void k_array_stats(const float* __restrict__ x, int64_t n, double* __
 }
 // stats = (mean, 1 / (sqrt(var + eps_in) + eps_out), kappa = (sqrt(var + eps_in) + eps_out) / sqrt(var + eps_in) -- the factor of the xhat term
 // of the pullback): biased variance over the n values, blocks added in order
-__global__ void k_array_stats_final(const double* __restrict__ partial, int nb, int64_t n, float eps_in, float eps_out, float* __restrict__ stats) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+__global__ __launch_bounds__(1024) void k_array_stats_final(const double* __restrict__ partial, int64_t nb, int64_t n, float eps_in, float eps_out,
+                                                            float* __restrict__ stats) {
+    // thread t adds slots t, t + 1024, ... in order; a fixed tree adds the 1 024 sums: the same bits whatever ran first (as ONE thread
+    // over 1 024 partials this launch took ~0.1 ms -- more than the MLP kernel it follows on the cylinder mesh)
+    __shared__ double sh[2][1024];
     double s = 0.0, q = 0.0;
-    for (int b = 0; b < nb; ++b) { s += partial[2 * b]; q += partial[2 * b + 1]; }
+    for (int64_t b = threadIdx.x; b < nb; b += 1024) { s += partial[2 * b]; q += partial[2 * b + 1]; }
+    sh[0][threadIdx.x] = s;
+    sh[1][threadIdx.x] = q;
+    __syncthreads();
+    for (int w = 512; w >= 1; w >>= 1) {                // a fixed tree over the 1 024 sums
+        if ((int)threadIdx.x < w) { sh[0][threadIdx.x] += sh[0][threadIdx.x + w]; sh[1][threadIdx.x] += sh[1][threadIdx.x + w]; }
+        __syncthreads();
+    }
+    if (threadIdx.x != 0) return;                       // (no barrier below)
+    s = sh[0][0]; q = sh[1][0];
     const double mean = n > 0 ? s / (double)n : 0.0;
     double var = n > 0 ? q / (double)n - mean * mean : 0.0;
     if (var < 0.0) var = 0.0;
@@ -797,20 +858,31 @@ __global__ __launch_bounds__(256) void k_lnall_bwd_cols(const float* __restrict_
         partial[((size_t)blockIdx.x * 2 + 1) * 128 + f] = sg + sh[1][f];
     }
 }
-__global__ __launch_bounds__(128) void k_lnall_bwd_cols_final(const double* __restrict__ partial, int nb, int64_t n, int L, const float* __restrict__ gamma,
-                                                              const float* __restrict__ stats, float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                              float* __restrict__ m) {
-    __shared__ double sh[2][128];
-    const int f = threadIdx.x;
+__global__ __launch_bounds__(1024) void k_lnall_bwd_cols_final(const double* __restrict__ partial, int nb, int64_t n, int L, const float* __restrict__ gamma,
+                                                               const float* __restrict__ stats, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                               float* __restrict__ m) {
+    // group g (of 8) adds blocks g, g + 8, ... in order per feature; then feature f adds its 8 group sums in order; then thread 0 the features
+    __shared__ double sh[2][8][128];
+    const int f = threadIdx.x & 127, g = threadIdx.x >> 7;
     double sb = 0.0, sg = 0.0;
-    for (int b = 0; b < nb; ++b) { sb += partial[((size_t)b * 2 + 0) * 128 + f]; sg += partial[((size_t)b * 2 + 1) * 128 + f]; }
-    if (f < L) { dbeta[f] = (float)sb; dgamma[f] = (float)sg; }
-    sh[0][f] = f < L ? sb * (double)gamma[f] : 0.0;
-    sh[1][f] = f < L ? sg * (double)gamma[f] : 0.0;
+    for (int b = g; b < nb; b += 8) { sb += partial[((size_t)b * 2 + 0) * 128 + f]; sg += partial[((size_t)b * 2 + 1) * 128 + f]; }
+    sh[0][g][f] = sb;
+    sh[1][g][f] = sg;
     __syncthreads();
-    if (f == 0) {
+    if (g == 0) {
+        sb = 0.0; sg = 0.0;
+        for (int k = 0; k < 8; ++k) { sb += sh[0][k][f]; sg += sh[1][k][f]; }
+        if (f < L) { dbeta[f] = (float)sb; dgamma[f] = (float)sg; }
+    }
+    __syncthreads();
+    if (g == 0) {
+        sh[0][0][f] = f < L ? sb * (double)gamma[f] : 0.0;
+        sh[1][0][f] = f < L ? sg * (double)gamma[f] : 0.0;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
         double a = 0.0, c = 0.0;
-        for (int i = 0; i < 128; ++i) { a += sh[0][i]; c += sh[1][i]; }
+        for (int i = 0; i < 128; ++i) { a += sh[0][0][i]; c += sh[1][0][i]; }
         m[0] = n > 0 ? (float)(a / (double)n) : 0.f;
         m[1] = n > 0 ? (float)((double)stats[2] * c / (double)n) : 0.f;
     }
@@ -1244,11 +1316,18 @@ hipError_t launch_affine_pad(const float* srcA, int wa, const float* srcB, int w
 
 int array_stats_blocks() { return 1024; }
 
-hipError_t launch_array_stats(const float* x, int64_t n, double* partial, float eps_in, float eps_out, float* stats, hipStream_t s) {
-    const int nb = array_stats_blocks();
-    hipLaunchKernelGGL(k_array_stats, dim3(nb), dim3(256), 0, s, x, n, partial);
-    hipLaunchKernelGGL(k_array_stats_final, dim3(1), dim3(64), 0, s, partial, nb, n, eps_in, eps_out, stats);
+int train_fwd_stat_slots(int L, int ntiles) { return train_coop(L, ntiles) ? 4 * ntiles : ntiles; }
+
+hipError_t launch_array_stats_final(const double* partial, int64_t slots, int64_t n, float eps_in, float eps_out, float* stats, hipStream_t s) {
+    hipLaunchKernelGGL(k_array_stats_final, dim3(1), dim3(1024), 0, s, partial, slots, n, eps_in, eps_out, stats);
     return hipGetLastError();
+}
+
+hipError_t launch_array_stats(const float* x, int64_t n, double* partial, float eps_in, float eps_out, float* stats, hipStream_t s) {
+    int64_t nb = (n + 256 * 32 - 1) / (256 * 32);      // >= 32 values per thread; at most array_stats_blocks() blocks
+    nb = nb < 1 ? 1 : (nb > array_stats_blocks() ? array_stats_blocks() : nb);
+    hipLaunchKernelGGL(k_array_stats, dim3((unsigned)nb), dim3(256), 0, s, x, n, partial);
+    return launch_array_stats_final(partial, nb, n, eps_in, eps_out, stats, s);
 }
 
 hipError_t launch_ln_all_apply(const float* y, const float* stats, const float* gamma, const float* beta, const float* resid, float* out,
@@ -1271,11 +1350,12 @@ int lnall_bwd_blocks() { return 1024; }
 hipError_t launch_lnall_bwd(const float* G0, const float* G1, const int32_t* g1idx, const float* Y, const float* stats, const float* gamma,
                             int64_t rows, int L, double* partial, float* m, float* dgamma, float* dbeta, float* dY, hipStream_t s) {
     if (L > 128) return hipErrorInvalidValue;
-    const int nb = lnall_bwd_blocks();
+    int64_t nb64 = (rows + 63) / 64;                   // >= 32 rows per half block; at most lnall_bwd_blocks() blocks
+    const int nb = (int)(nb64 < 1 ? 1 : (nb64 > lnall_bwd_blocks() ? lnall_bwd_blocks() : nb64));
     const int64_t n = rows * L;
     hipLaunchKernelGGL(k_lnall_bwd_cols, dim3(nb), dim3(256), 0, s, G0, G1, g1idx, Y, stats, rows, L, partial);
-    hipLaunchKernelGGL(k_lnall_bwd_cols_final, dim3(1), dim3(128), 0, s, partial, nb, n, L, gamma, stats, dgamma, dbeta, m);
-    if (n > 0) hipLaunchKernelGGL(k_lnall_bwd_apply, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, G0, G1, g1idx, Y, stats, gamma, m, dY, n, L);
+    hipLaunchKernelGGL(k_lnall_bwd_cols_final, dim3(1), dim3(1024), 0, s, partial, nb, n, L, gamma, stats, dgamma, dbeta, m);
+    if (n > 0 && dY) hipLaunchKernelGGL(k_lnall_bwd_apply, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, G0, G1, g1idx, Y, stats, gamma, m, dY, n, L);
     return hipGetLastError();
 }
 
