@@ -971,6 +971,13 @@ struct LnAll {
         if (hipError_t e = launch_array_stats_final(reinterpret_cast<const double*>(A + part), slots, n, eps_in, eps_out, A + stats, st)) return e;
         return launch_ln_all_apply(y, A + stats, Wt + b.tabs + (size_t)T_GAMMA * L, Wt + b.tabs + (size_t)T_BETA * L, resid, out, lnout, n, L, st);
     }
+    // the edge half's LayerNorm, residual and aggregation in one pass over the receiver CSR (every edge has an owned receiver on one partition)
+    hipError_t ln_edges(const TrainMlp& m, const float* y, float* e) {
+        const TrainBlock& b = m.b[m.nblk - 1];
+        if (hipError_t er = launch_array_stats_final(reinterpret_cast<const double*>(A + part), slots, E * L, eps_in, eps_out, A + stats, st)) return er;
+        return launch_ln_all_apply_segsum(y, A + stats, Wt + b.tabs + (size_t)T_GAMMA * L, Wt + b.tabs + (size_t)T_BETA * L, e, rowptr, A + agg,
+                                          (int32_t)N, L, st);
+    }
     // one processor step on V / Ecur (engine order, row-major [rows][L])
     int step(int k) {
         float *v = A + V, *e = A + Ecur, *y = A + Y;
@@ -997,12 +1004,13 @@ struct LnAll {
                 if (bi == m.nblk - 1) { a.STATS = reinterpret_cast<double*>(A + part); slots = train_fwd_stat_slots(L, nt_e); }
                 HIPCHK(h, launch_mlp_fwd(L, 1, a, st));
             }
-            HIPCHK(h, ln(m, y, E, e, e, y));
+            HIPCHK(h, ln_edges(m, y, e));                                    // e <- e + LN(y), agg <- segmented sum of LN(y)
         } else if (E > 0) {
             HIPCHK(h, mlp(T.m_pe[0][k], E, nt_e, v, snd, v, rcv, e, y));
-            HIPCHK(h, ln(T.m_pe[0][k], y, E, e, e, y));                      // y <- e' = LN(MLP_e), e <- e + e'
+            HIPCHK(h, ln_edges(T.m_pe[0][k], y, e));
+        } else {
+            HIPCHK(h, launch_segment_sum(L, y, rowptr, nullptr, nullptr, A + agg, (int32_t)N, st));   // (no edges: zero aggregates)
         }
-        HIPCHK(h, launch_segment_sum(L, y, rowptr, nullptr, nullptr, A + agg, (int32_t)N, st));
         HIPCHK(h, mlp(T.m_pn[k], N, nt_n, v, nullptr, A + agg, nullptr, nullptr, y));
         HIPCHK(h, ln(T.m_pn[k], y, N, v, v, nullptr));                       // v <- v + LN(MLP_v([v; agg]))
         return MGN_OK;

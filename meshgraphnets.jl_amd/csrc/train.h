@@ -107,6 +107,9 @@ hipError_t launch_array_stats_final(const double* partial, int64_t slots, int64_
 hipError_t launch_array_stats(const float* x, int64_t n, double* partial, float eps_in, float eps_out, float* stats, hipStream_t s);
 hipError_t launch_ln_all_apply(const float* y, const float* stats, const float* gamma, const float* beta, const float* resid, float* out,
                                float* lnout, int64_t n, int L, hipStream_t s);
+// one pass over the receiver CSR: t = LN_all(y[p]); e[p] += t; agg[n] = sum of t over the edges node n receives (edge order)
+hipError_t launch_ln_all_apply_segsum(const float* y, const float* stats, const float* gamma, const float* beta, float* e, const int32_t* rowptr,
+                                      float* agg, int32_t n, int L, hipStream_t s);
 // epilogue of a right-hand side: out [N][O] = (Y[:, 0:O] os + osh) .* mask[gid ? gid[row] : row]   (os / mask / gid may be null)
 hipError_t launch_rhs_epilogue(const float* Y, int L, int O, const float* os, const float* osh, const float* mask, const int32_t* gid, float* out,
                                int64_t N, hipStream_t s);

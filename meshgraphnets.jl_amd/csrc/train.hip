@@ -830,6 +830,38 @@ __global__ void k_ln_all_apply(const float* y, const float* __restrict__ stats, 
     if (out) out[i] = r + t;
 }
 
+// the edge half of a processor step under the whole-array LayerNorm in one pass over the receiver CSR: t = LN(y[p]) (statistics given),
+// e[p] += t, agg[n] = sum of t over the edges n receives, added in edge order (k_segment_sum's order)
+__global__ void k_ln_all_apply_segsum(const float* __restrict__ y, const float* __restrict__ stats, const float* __restrict__ gamma,
+                                      const float* __restrict__ beta, float* __restrict__ e, const int32_t* __restrict__ rowptr,
+                                      float* __restrict__ agg, int32_t n, int L4) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)n * L4) return;
+    const int node = (int)(i / L4), q = (int)(i - (int64_t)node * L4);
+    const float mean = stats[0], rden = stats[1];
+    const f32x4 g4 = reinterpret_cast<const f32x4*>(gamma)[q], b4 = reinterpret_cast<const f32x4*>(beta)[q];
+    const f32x4* Y4 = reinterpret_cast<const f32x4*>(y);
+    f32x4* E4 = reinterpret_cast<f32x4*>(e);
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    auto one = [&](f32x4 v, f32x4 ev, int64_t p) {
+        f32x4 t;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) t[j] = (v[j] - mean) * rden * g4[j] + b4[j];
+        E4[p * L4 + q] = ev + t;
+        s += t;
+    };
+    int p = rowptr[node];
+    const int e1 = rowptr[node + 1];
+    for (; p + 2 <= e1; p += 2) {                        // two rows of each stream in flight, added in order
+        const f32x4 v0 = Y4[(int64_t)p * L4 + q], v1 = Y4[(int64_t)(p + 1) * L4 + q];
+        const f32x4 a0 = E4[(int64_t)p * L4 + q], a1 = E4[(int64_t)(p + 1) * L4 + q];
+        one(v0, a0, p);
+        one(v1, a1, p + 1);
+    }
+    for (; p < e1; ++p) one(Y4[(int64_t)p * L4 + q], E4[(int64_t)p * L4 + q], p);
+    reinterpret_cast<f32x4*>(agg)[i] = s;
+}
+
 // ---- reverse pass of the whole-array LayerNorm ----
 // t = gamma xhat + beta with xhat = (y - mean) rden over ALL rows x L values.  With G the gradient w.r.t. t (G = G0[row] (+ G1[g1idx[row]])):
 //   dbeta[f] = sum_rows G,  dgamma[f] = sum_rows G xhat,
@@ -1342,6 +1374,14 @@ hipError_t launch_rhs_epilogue(const float* Y, int L, int O, const float* os, co
     const int64_t tot = N * O;
     if (tot <= 0) return hipSuccess;
     hipLaunchKernelGGL(k_rhs_epilogue, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, Y, L, O, os, osh, mask, gid, out, N);
+    return hipGetLastError();
+}
+
+hipError_t launch_ln_all_apply_segsum(const float* y, const float* stats, const float* gamma, const float* beta, float* e, const int32_t* rowptr,
+                                      float* agg, int32_t n, int L, hipStream_t s) {
+    const int64_t tot = (int64_t)n * (L / 4);
+    if (tot <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_ln_all_apply_segsum, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, y, stats, gamma, beta, e, rowptr, agg, n, L / 4);
     return hipGetLastError();
 }
 
