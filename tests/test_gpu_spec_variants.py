@@ -280,3 +280,42 @@ def test_training_under_whole_array_layernorm(whole_array_oracle, mode, monkeypa
             eng.close()
     finally:
         orc.LN_MODE = 0
+
+
+@pytest.mark.parametrize("N,E,seed", [(5, 0, 0), (33, 31, 2), (40, 700, 3), (70, 2049, 5)])
+def test_whole_array_layernorm_on_ragged_graphs(whole_array_oracle, N, E, seed):
+    """no edges at all (an empty array has no statistics and nothing to normalise), isolated nodes, self loops, duplicate edges, a heavy
+    receiver: forward, processor steps, the right-hand side through the rollout driver, and the training step"""
+    import warnings
+    cfg = dict(Fn=9, Fe=3, O=2, L=128, hidden_layers=2, mps=2)
+    s, r = synth.random_graph(N, E, seed)
+    if E > 1000:
+        r[:1000] = 3
+    ps = orc.init_params(9, 3, 2, 128, 2, 2, seed=11 + seed, ln_jitter=0.1)
+    rng = np.random.default_rng(seed)
+    nf = rng.standard_normal((N, 9)).astype(np.float32)
+    ef = rng.standard_normal((E, 3)).astype(np.float32)
+    target = rng.standard_normal((N, 2)).astype(np.float32)
+    mask = np.arange(0, N, 2, dtype=np.int32)
+    eng = mgn_amd_engine(cfg, ln_dims="all")
+    eng.set_params(ps)
+    eng.set_graph(s, r, N)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")                              # (numpy's mean of an empty slice, E = 0)
+        ref = orc.forward(ps, cfg, nf, ef, s, r)
+        g_ref, loss_ref = orc.step_grads(ps, cfg, nf, ef, s, r, target, mask)
+    assert rel_max(eng.forward(nf, ef), ref) <= TOL_15
+    gs, loss = eng.step(nf, ef, target, mask)
+    assert np.isfinite(gs).all() and abs(loss - loss_ref) <= 1e-5 * max(1.0, abs(loss_ref))
+    assert np.linalg.norm(gs - g_ref) <= 1e-3 * np.linalg.norm(g_ref)
+    # Euler through the native driver == repeated right-hand sides (identity normalisers)
+    onehot = np.eye(7, dtype=np.float32)[rng.integers(0, 7, N)]
+    x = rng.standard_normal((N, 2)).astype(np.float32)
+    sol, _ = eng.rollout("Euler", x, onehot, ef, 0.0, 0.02, 0.01, 3, dt=0.01)
+    xs = x.astype(np.float64)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for k in range(2):
+            xs = xs + 0.01 * orc.forward(ps, cfg, np.concatenate([xs, onehot], 1), ef, s, r)
+    assert rel_max(sol[2], xs) <= 1e-4
+    eng.close()
