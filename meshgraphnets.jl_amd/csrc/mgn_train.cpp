@@ -56,6 +56,9 @@ struct TrainState {
     std::vector<TrainMlp> m_pe[MAX_EDGE_SETS], m_pn;
     DevBuf arena, idx, grads, target, mask, loss;
     std::vector<int32_t> g2l, mask_host;       // renumbered graph: caller's node id -> engine row; the mapped mask of the call
+    std::vector<int32_t> mask_seen;            // the (host) mask the device copy was made from, as the caller gave it
+    bool mask_valid = false;
+    int32_t mask_base = 0;
     // whole-array LayerNorm mode (lnall_*): its own small arena (no kept activations), the edge gids as int32
     DevBuf la, la_idx;
     bool la_ready = false;
@@ -66,7 +69,7 @@ struct TrainState {
     std::vector<Acts> a_pe[MAX_EDGE_SETS], a_pn;
     std::vector<size_t> Ek[MAX_EDGE_SETS], Vk, agg[MAX_EDGE_SETS];
     static constexpr int GSETS_MAX = 72;
-    static inline int GSETS = [] { const char* e = getenv("MGN_TRAIN_GSETS"); const int v = e ? atoi(e) : 4; return v < 1 ? 1 : (v > 72 ? 72 : v); }();   // gradient-buffer sets: the weight gradients of unit i run beside the backward of units i+1 .. i+3
+    static inline int GSETS = [] { const char* e = getenv("MGN_TRAIN_GSETS"); const int v = e ? atoi(e) : 4; return v < 2 ? 2 : (v > 72 ? 72 : v); }();   // gradient-buffer sets: the weight gradients of unit i run beside the backward of units i+1 .. i+3
     int gsets = 1;                    // sets allocated for the current graph (GSETS on small meshes, else 1: no overlap)
     size_t GT[GSETS_MAX], GXH[GSETS_MAX], GY[GSETS_MAX], GZ2[GSETS_MAX], GZ1[GSETS_MAX];
     size_t GXs, GXr, GXB, gV[2], gE[MAX_EDGE_SETS][2], gAgg[MAX_EDGE_SETS], Gout, gNF, io, ptmp, pw, pb;
@@ -351,7 +354,7 @@ int prepare_graph(mgn_engine* h) {
     T.io = take((size_t)(N > 0 ? N : 1) * (2 * h->cfg.O + h->cfg.Fn + 1));
     T.ptmp = take((size_t)(N > 0 ? N : 1) * (size_t)std::max(h->cfg.Fn, h->cfg.O));      // row permutations of a renumbered graph
     const int nb = std::max(wgrad_blocks(N), wgrad_blocks(Emax));
-    T.pw = take((size_t)5 * (nb > 0 ? nb : 1) * L * L);             // one partial-dW region per weight-gradient job of a launch unit
+    T.pw = take((size_t)5 * (T.gsets > 1 ? T.gsets / 2 : 1) * (nb > 0 ? nb : 1) * L * L);   // one partial-dW region per weight-gradient job of a launch (a group of units on small meshes)
     T.pb = take((size_t)WGRAD_MAX_JOBS * (nb > 0 ? nb : 1) * L);
     if (h->cfg.ln_dims == MGN_LN_ALL) {
         int slot = 0;
@@ -372,6 +375,7 @@ int prepare_graph(mgn_engine* h) {
     HIPCHK(h, T.arena.ensure(off * 4));
     HIPCHK(h, T.target.ensure((size_t)(N > 0 ? N : 1) * h->cfg.O * 4));
     T.g2l.clear();
+    T.mask_valid = false;
     if (h->g.renumbered) {
         T.g2l.assign((size_t)h->g.N, 0);
         for (int32_t i = 0; i < h->g.n_own; ++i) T.g2l[(size_t)h->g.own_gid[i]] = i;
@@ -447,7 +451,6 @@ int train_run(mgn_handle* h, const TrainJob& J) {
 
     // ---- inputs
     const float* nrm = h->norms.as<float>();   // [node scale, shift (Fn) | edge scale, shift (Fe) | out scale, shift (O)]
-    HIPCHK(h, hipMemsetAsync(G, 0, h->params.size() * 4, st));
     // A renumbered graph (graph_host.h: the engine's node order is not the caller's): per-node inputs are brought into the engine's
     // order as they arrive and per-node results go back through the inverse; `mask` is mapped on the host.  Edges go by edge_gid already.
     const bool renum = g.renumbered;
@@ -462,27 +465,64 @@ int train_run(mgn_handle* h, const TrainJob& J) {
         if (hipError_t e = launch_permute_rows(A + T.ptmp, buf, ngid, N, width, true, st)) return e;
         return hipMemcpyAsync(buf, A + T.ptmp, (size_t)N * width * 4, hipMemcpyDeviceToDevice, st);
     };
+    // An array the caller keeps on the device is read where it is; a host array is staged first.  Gather (renumbered graph) and padding
+    // run in the one kernel that reads it (as copy + permute + copy back + pad the eager prologue of a step was 14 launches, 0.24 ms on
+    // the cylinder mesh).
+    auto on_device = [&](const void* ptr) {
+        hipPointerAttribute_t at{};
+        const bool dev = ptr && hipPointerGetAttributes(&at, ptr) == hipSuccess && (at.type == hipMemoryTypeDevice || at.type == hipMemoryTypeManaged);
+        (void)hipGetLastError();
+        return dev;
+    };
+    auto staged = [&](const float* user, float* stage, size_t floats, const float*& out) -> hipError_t {
+        if (on_device(user)) { out = user; return hipSuccess; }
+        out = stage;
+        return hipMemcpyAsync(stage, user, floats * 4, hipMemcpyHostToDevice, st);
+    };
     if (!J.vjp || J.fvjp) {
-        HIPCHK(h, hipMemcpyAsync(A + T.nf_raw, J.nf, (size_t)N * c.Fn * 4, hipMemcpyDefault, st));
-        HIPCHK(h, to_local(A + T.nf_raw, c.Fn));
-        HIPCHK(h, launch_affine_pad(A + T.nf_raw, c.Fn, nullptr, 0, nullptr, nullptr, A + T.nf_pad, L, N, st));
+        const float* src = nullptr;
+        HIPCHK(h, staged(J.nf, A + T.nf_raw, (size_t)N * c.Fn, src));
+        HIPCHK(h, launch_affine_pad_gather(src, c.Fn, nullptr, 0, nullptr, nullptr, renum ? ngid : nullptr, A + T.nf_pad, L, N, st));
         if (sx[0].E > 0) {
-            HIPCHK(h, hipMemcpyAsync(A + T.ef_raw[0], J.ef, (size_t)sx[0].E * c.Fe * 4, hipMemcpyDefault, st));
-            HIPCHK(h, launch_affine_pad(A + T.ef_raw[0], c.Fe, nullptr, 0, nullptr, nullptr, A + T.ef_pad[0], L, sx[0].E, st));
+            HIPCHK(h, staged(J.ef, A + T.ef_raw[0], (size_t)sx[0].E * c.Fe, src));
+            HIPCHK(h, launch_affine_pad(src, c.Fe, nullptr, 0, nullptr, nullptr, A + T.ef_pad[0], L, sx[0].E, st));
         }
         if (J.fvjp) {
             HIPCHK(h, hipMemcpyAsync(A + T.io + (size_t)N * O, J.lambda, (size_t)N * O * 4, hipMemcpyDefault, st));
             HIPCHK(h, to_local(A + T.io + (size_t)N * O, O));
         } else {
-            HIPCHK(h, hipMemcpyAsync(T.target.p, J.target, (size_t)N * O * 4, hipMemcpyDefault, st));
-            HIPCHK(h, to_local(T.target.as<float>(), O));
-            HIPCHK(h, T.mask.ensure((size_t)J.nmask * 4));
-            if (renum) {                       // the caller's node ids -> engine rows (0-based from here on)
-                T.mask_host.resize((size_t)J.nmask);
-                for (int64_t i = 0; i < J.nmask; ++i) T.mask_host[(size_t)i] = T.g2l[(size_t)(J.mask[i] - J.mask_index_base)];
-                HIPCHK(h, hipMemcpyAsync(T.mask.p, T.mask_host.data(), (size_t)J.nmask * 4, hipMemcpyHostToDevice, st));
+            if (renum) {
+                HIPCHK(h, staged(J.target, A + T.ptmp, (size_t)N * O, src));
+                HIPCHK(h, launch_permute_rows(T.target.as<float>(), src, ngid, N, O, false, st));
             } else {
-                HIPCHK(h, hipMemcpyAsync(T.mask.p, J.mask, (size_t)J.nmask * 4, hipMemcpyDefault, st));
+                HIPCHK(h, hipMemcpyAsync(T.target.p, J.target, (size_t)N * O * 4, hipMemcpyDefault, st));
+            }
+            // the mask of the previous call is usually this call's (one trajectory, one mask: reference src/MeshGraphNets.jl:352): uploaded once
+            const bool mask_dev = on_device(J.mask);
+            const bool same = !mask_dev && T.mask_valid && T.mask_base == J.mask_index_base && (int64_t)T.mask_seen.size() == J.nmask &&
+                              (J.nmask == 0 || memcmp(T.mask_seen.data(), J.mask, (size_t)J.nmask * 4) == 0);
+            if (!same) {
+                HIPCHK(h, T.mask.ensure((size_t)J.nmask * 4));
+                T.mask_valid = false;
+                if (renum) {                       // the caller's node ids -> engine rows (0-based from here on)
+                    std::vector<int32_t> host_mask;
+                    const int32_t* mk = J.mask;
+                    if (mask_dev) {
+                        host_mask.resize((size_t)J.nmask);
+                        HIPCHK(h, hipMemcpy(host_mask.data(), J.mask, (size_t)J.nmask * 4, hipMemcpyDeviceToHost));
+                        mk = host_mask.data();
+                    }
+                    T.mask_host.resize((size_t)J.nmask);
+                    for (int64_t i = 0; i < J.nmask; ++i) T.mask_host[(size_t)i] = T.g2l[(size_t)(mk[i] - J.mask_index_base)];
+                    HIPCHK(h, hipMemcpyAsync(T.mask.p, T.mask_host.data(), (size_t)J.nmask * 4, hipMemcpyHostToDevice, st));
+                } else {
+                    HIPCHK(h, hipMemcpyAsync(T.mask.p, J.mask, (size_t)J.nmask * 4, hipMemcpyDefault, st));
+                }
+                if (!mask_dev) {
+                    T.mask_seen.assign(J.mask, J.mask + J.nmask);
+                    T.mask_base = J.mask_index_base;
+                    T.mask_valid = true;
+                }
             }
         }
     } else {
@@ -670,6 +710,40 @@ int train_run(mgn_handle* h, const TrainJob& J) {
         for (hipEvent_t& e : T.ev_wg) HIPCHK(h, hipEventCreateWithFlags(&e, hipEventDisableTiming));
     }
     int n_bwd = 0;
+    // Small meshes: the weight-gradient jobs of `group` consecutive launch units go out as ONE k_wgrad + ONE k_reduce_partials launch on the
+    // second stream (two groups of gradient-buffer sets in flight).  Per unit they were 66 launches per processor step!, each a
+    // cross-stream dependency both ways: the main stream's backward kernels started ~10 us apart (rocprofv3 timeline, docs/experiments.md)
+    // and the second stream was the critical path.  Same partial blocks (128 rows), same order of the reduction: the same bits.
+    static const int group_env = [] { const char* e = getenv("MGN_TRAIN_WG_GROUP"); return e ? atoi(e) : 1; }();
+    const int group = overlap ? std::max(1, std::min(group_env, T.gsets / 2)) : 1;
+    int64_t lrows_all = N;
+    for (int q = 0; q < S; ++q) lrows_all = std::max<int64_t>(lrows_all, sx[q].E);
+    WgradBatch pwb{};
+    ReduceBatch prb{};
+    int pnw = 0, punits = 0, nbatch = 0;
+    int64_t plrows = 0;
+    int set_batch[TrainState::GSETS_MAX];                // launch number that takes the weight gradients of the unit in each buffer set
+    for (int& v : set_batch) v = -1;
+    auto flush = [&]() -> int {
+        if (punits == 0) return MGN_OK;
+        hipStream_t wst = overlap ? T.aux : st;
+        if (overlap) {
+            HIPCHK(h, hipEventRecord(T.ev_bwd, st));
+            HIPCHK(h, hipStreamWaitEvent(wst, T.ev_bwd, 0));
+        }
+        if (pwb.njobs > 0 && wgrad_blocks(plrows) > 0) {
+            static const int whatif = [] { const char* e = getenv("MGN_TRAIN_WHATIF"); return e ? atoi(e) : 0; }();   // diagnostic (wrong gradients): 1 no weight-gradient launches, 2 no reductions
+            if (!(whatif & 1)) HIPCHK(h, launch_wgrad(L, pwb, plrows, wst));
+            if (!(whatif & 2)) HIPCHK(h, launch_reduce_partials(prb, wst));
+        }
+        if (overlap) HIPCHK(h, hipEventRecord(T.ev_wg[nbatch % TrainState::GSETS_MAX], wst));
+        ++nbatch;
+        pwb = WgradBatch{};
+        prb = ReduceBatch{};
+        pnw = punits = 0;
+        plrows = 0;
+        return MGN_OK;
+    };
     // `fq` >= 0: first unit of the edge MLP of set fq with the factored first layer -- only the e block of W1 is unwound per edge
     // (gx[0] / gxadd[0] / xin[0] describe it); the v blocks follow per node from the summed rows of GZ1 (SGs, SGr) after this call.
     auto bwd_unit = [&](const TrainBlock& b, int64_t rows, int32_t ntiles, const float* g0, const float* g1, const int32_t* g1i, const size_t (&hb)[3],
@@ -680,8 +754,13 @@ int train_run(mgn_handle* h, const TrainJob& J) {
         const int64_t node_rows = fact ? N : 0;
         const int nin_k = fact ? 1 : b.nin;               // input blocks the kernel unwinds
         const int gs = overlap ? n_bwd % T.gsets : 0;
-        hipStream_t wst = overlap ? T.aux : st;
-        if (overlap && n_bwd >= T.gsets) HIPCHK(h, hipStreamWaitEvent(st, T.ev_wg[gs], 0));   // set gs is free again
+        // buffer set gs is re-used: the launch that took its last occupant's weight gradients must have run (launches on the second stream are
+        // in order; their events are indexed by launch number)
+        if (overlap && set_batch[gs] >= 0) {
+            if (set_batch[gs] == nbatch && punits > 0)
+                if (int rc = flush()) return rc;
+            HIPCHK(h, hipStreamWaitEvent(st, T.ev_wg[set_batch[gs] % TrainState::GSETS_MAX], 0));
+        }
         ++n_bwd;
         TrainBwdArgs a{};
         a.rows = rows; a.ntiles = ntiles;
@@ -708,17 +787,19 @@ int train_run(mgn_handle* h, const TrainJob& J) {
         if (fact) {   // gather <-> segmented-sum duality on GZ1 itself: SGr[n] = sum of GZ1 over edges received by n, SGs: sent by n
             HIPCHK(h, launch_segment_sum_pair(L, A + T.GZ1[gs], sx[fq].rowptr, sx[fq].rowptr_s, sx[fq].perm_s, A + T.SGr, A + T.SGs, (int32_t)node_rows, st));
         }
-        if (overlap) {
-            HIPCHK(h, hipEventRecord(T.ev_bwd, st));
-            HIPCHK(h, hipStreamWaitEvent(wst, T.ev_bwd, 0));
-        }
-        // every parameter gradient of this unit: one batched weight-gradient launch + one batched (ordered) reduction
-        const int64_t lrows = rows > node_rows ? rows : node_rows;   // the launch covers its longest job (node jobs of a factored edge MLP)
+        // every parameter gradient of this unit: jobs of one batched weight-gradient launch + one batched (ordered) reduction
+        const int64_t lrows_u = rows > node_rows ? rows : node_rows;   // a launch covers its longest job (node jobs of a factored edge MLP)
+        const int64_t lrows = overlap ? lrows_all : lrows_u;           // (a group's launch: the longest job of the model; 128-row blocks either way)
         const int nb = wgrad_blocks(lrows);
-        if (nb == 0) return MGN_OK;
-        WgradBatch wb{};
-        ReduceBatch rb{};
-        int nw = 0;
+        if (pwb.njobs + 10 > WGRAD_MAX_JOBS || prb.njobs + 14 > REDUCE_MAX_JOBS)   // (a unit adds at most 8 + 12 jobs)
+            if (int rc = flush()) return rc;
+        ++punits;
+        set_batch[gs] = nbatch;
+        if (nb == 0 || lrows_u == 0) return punits >= group ? flush() : MGN_OK;
+        plrows = std::max(plrows, lrows);
+        WgradBatch& wb = pwb;
+        ReduceBatch& rb = prb;
+        int& nw = pnw;
         auto job = [&](const float* X, const int32_t* xi_, const float* Gm, long woff, int nrows, int cols, long boff, int bcols,
                        int64_t jrows = -1) {
             if (woff < 0 && boff < 0) return;              // identity slot
@@ -749,12 +830,7 @@ int train_run(mgn_handle* h, const TrainJob& J) {
             job(nullptr, nullptr, A + T.GXH[gs], -1, 0, 0, b.ggamma, L);
             job(nullptr, nullptr, A + T.GT[gs], -1, 0, 0, b.gbeta, L);
         }
-        if (wb.njobs == 0) return MGN_OK;
-        static const int whatif = [] { const char* e = getenv("MGN_TRAIN_WHATIF"); return e ? atoi(e) : 0; }();   // diagnostic (wrong gradients): 1 no weight-gradient launches, 2 no reductions
-        if (!(whatif & 1)) HIPCHK(h, launch_wgrad(L, wb, lrows, wst));
-        if (!(whatif & 2)) HIPCHK(h, launch_reduce_partials(rb, wst));
-        if (overlap) HIPCHK(h, hipEventRecord(T.ev_wg[gs], wst));
-        return MGN_OK;
+        return punits >= group ? flush() : MGN_OK;
     };
     // one MLP: its second unit (if any) first, handing the gradient w.r.t. its input to the first through GXB
     auto bwd = [&](const TrainMlp& m, int64_t rows, int32_t ntiles, const float* g0, const float* g1, const int32_t* g1i, const Acts& act,
@@ -772,7 +848,12 @@ int train_run(mgn_handle* h, const TrainJob& J) {
     };
 
     auto backward_launches = [&]() -> int {
+    HIPCHK(h, hipMemsetAsync(G, 0, h->params.size() * 4, st));   // (inside the replayed sequence: G is the engine's own buffer)
     n_bwd = 0;
+    pwb = WgradBatch{}; prb = ReduceBatch{};
+    pnw = punits = nbatch = 0;
+    plrows = 0;
+    for (int& v : set_batch) v = -1;
     int cur = 0;   // gV[cur], gE[q][ecur] hold the gradients w.r.t. the latents entering the part of the model already unwound
     {
         float* gx[3] = {A + T.gV[cur], nullptr, nullptr};
@@ -840,8 +921,9 @@ int train_run(mgn_handle* h, const TrainJob& J) {
         }
     }
 
-    if (overlap)                                         // join: the second stream is in order, its last events cover all of it
-        for (int i = 0; i < T.gsets && i < n_bwd; ++i) HIPCHK(h, hipStreamWaitEvent(st, T.ev_wg[i], 0));
+    if (int rc = flush()) return rc;                     // the units left over from the last full group
+    if (overlap && nbatch > 0)                           // join: the second stream is in order, its last event covers all of it
+        HIPCHK(h, hipStreamWaitEvent(st, T.ev_wg[(nbatch - 1) % TrainState::GSETS_MAX], 0));
     return MGN_OK;
     };
     if (int rc = graphed(J.vjp ? 2 : 1, backward_launches)) return rc;

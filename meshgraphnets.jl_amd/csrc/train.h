@@ -66,7 +66,7 @@ hipError_t launch_segment_sum_pair(int L, const float* src, const int32_t* rowpt
 //   dW[in][out] = sum_rows X[xidx ? xidx[row] : row][in] * G[row][out];   db[out] = sum_rows G[row][out]
 // The row range is split over wgrad_blocks(rows) blocks: pw [nblocks][L][L], pb [nblocks][L] hold per-block partials.
 // pw == null: column sums only (LayerNorm parameter gradients); pb == null: no column sums.
-constexpr int WGRAD_MAX_JOBS = 8;
+constexpr int WGRAD_MAX_JOBS = 32;   // (a launch may carry the jobs of several launch units: mgn_train.cpp, weight-gradient groups)
 struct WgradJob { const float* X; const int32_t* xidx; const float* G; int64_t rows; float* pw; float* pb; };
 struct WgradBatch { int32_t njobs; int64_t rows_per_block; WgradJob job[WGRAD_MAX_JOBS]; };
 int wgrad_blocks(int64_t rows);
@@ -86,7 +86,7 @@ struct PackJob { long long off, src; int ldw, r0, nr, nc, transpose, kind; float
 hipError_t launch_pack_train(int L, const PackJob* jobs, int njobs, const float* params, const float* tabs, unsigned* jobmax /* [njobs] scratch */, float* out, hipStream_t s);
 hipError_t launch_wgrad(int L, WgradBatch wb, int64_t rows, hipStream_t s);
 // out[r * cols + c] = sum_b partial[b * block_stride + r * ld + c]   (fixed order: bitwise reproducible), one job per blockIdx.y
-constexpr int REDUCE_MAX_JOBS = 16;
+constexpr int REDUCE_MAX_JOBS = 64;
 struct ReduceJob { const float* partial; int32_t nblocks; int64_t block_stride; int32_t nrows, cols, ld; float* out; };
 struct ReduceBatch { int32_t njobs; ReduceJob job[REDUCE_MAX_JOBS]; };
 hipError_t launch_reduce_partials(const ReduceBatch& rb, hipStream_t s);
@@ -99,6 +99,9 @@ hipError_t launch_segment_sum2(int L, const float* srcA, const int32_t* rowptrA,
 // dst [rows][L] = [ (srcA | srcB)[rows][wa + wb] * scale + shift | 0 ]   (srcB may be null with wb = 0; scale null: identity)
 hipError_t launch_affine_pad(const float* srcA, int wa, const float* srcB, int wb, const float* scale, const float* shift, float* dst, int L,
                              int64_t rows, hipStream_t s);
+// the same with a row gather: dst row r <- source row gid[r] (gid null: row r)
+hipError_t launch_affine_pad_gather(const float* srcA, int wa, const float* srcB, int wb, const float* scale, const float* shift, const int32_t* gid,
+                                    float* dst, int L, int64_t rows, hipStream_t s);
 // whole-array LayerNorm (mgn_config.ln_dims = MGN_LN_ALL): stats = (mean, 1 / (sqrt(var + eps_in) + eps_out), kappa) over the n values of x
 // (double accumulation, fixed order; partial: 2 * array_stats_blocks() doubles), then t = (y - mean) * rden * gamma + beta
 int array_stats_blocks();

@@ -746,16 +746,17 @@ __global__ void k_segment_sum_pair(const float* __restrict__ src, const int32_t*
     reinterpret_cast<f32x4*>(out_s)[i] = s;
 }
 
-// dst [rows][L] = [ (srcA | srcB)[rows][wa + wb] * scale + shift | 0 ]   (scale == null: identity)
+// dst [rows][L] = [ (srcA | srcB)[gid ? gid[row] : row][wa + wb] * scale + shift | 0 ]   (scale == null: identity)
 __global__ void k_affine_pad(const float* __restrict__ srcA, int wa, const float* __restrict__ srcB, int wb, const float* __restrict__ scale,
-                             const float* __restrict__ shift, float* __restrict__ dst, int L, int64_t rows) {
+                             const float* __restrict__ shift, const int32_t* __restrict__ gid, float* __restrict__ dst, int L, int64_t rows) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= rows * L) return;
     const int64_t r = i / L;
     const int f = (int)(i - r * L);
     float v = 0.f;
     if (f < wa + wb) {
-        v = f < wa ? srcA[r * wa + f] : srcB[r * wb + (f - wa)];
+        const int64_t sr = gid ? (int64_t)gid[r] : r;          // gid: dst row r <- source row gid[r] (the caller's order -> the engine's)
+        v = f < wa ? srcA[sr * wa + f] : srcB[sr * wb + (f - wa)];
         if (scale) v = v * scale[f] + shift[f];
     }
     dst[i] = v;
@@ -1338,12 +1339,16 @@ hipError_t launch_segment_sum_pair(int L, const float* src, const int32_t* rowpt
     return hipGetLastError();
 }
 
-hipError_t launch_affine_pad(const float* srcA, int wa, const float* srcB, int wb, const float* scale, const float* shift, float* dst, int L,
-                             int64_t rows, hipStream_t s) {
+hipError_t launch_affine_pad_gather(const float* srcA, int wa, const float* srcB, int wb, const float* scale, const float* shift, const int32_t* gid,
+                                    float* dst, int L, int64_t rows, hipStream_t s) {
     const int64_t tot = rows * L;
     if (tot <= 0) return hipSuccess;
-    hipLaunchKernelGGL(k_affine_pad, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, srcA, wa, srcB, wb, scale, shift, dst, L, rows);
+    hipLaunchKernelGGL(k_affine_pad, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, srcA, wa, srcB, wb, scale, shift, gid, dst, L, rows);
     return hipGetLastError();
+}
+hipError_t launch_affine_pad(const float* srcA, int wa, const float* srcB, int wb, const float* scale, const float* shift, float* dst, int L,
+                             int64_t rows, hipStream_t s) {
+    return launch_affine_pad_gather(srcA, wa, srcB, wb, scale, shift, nullptr, dst, L, rows, s);
 }
 
 int array_stats_blocks() { return 1024; }
