@@ -578,9 +578,9 @@ __global__ __launch_bounds__(64 * WPB) void k_lin2(const Lin2Args a) {
 // and all NT output blocks; a block owns a contiguous row range and writes its partial dW (and the column sums of G).
 // ================================================================================================
 #ifndef MGN_WG_ROWS
-#define MGN_WG_ROWS 64
+#define MGN_WG_ROWS 128
 #endif
-constexpr int WG_ROWS = MGN_WG_ROWS;    // rows per block at least (small meshes: many short blocks, the loads are latency-bound)
+constexpr int WG_ROWS = MGN_WG_ROWS;    // rows per block at least (k_wgrad_lds, cylinder mesh: 64 / 128 / 256 / 512 rows 2.49 / 2.41 / 2.56 / 3.39 ms per step: a block writes a 64 KiB partial whatever its rows)
 constexpr int WG_UNROLL = 8;   // k-steps (2 rows each) whose loads are issued together
 
 template <int NT>
@@ -631,6 +631,109 @@ __global__ __launch_bounds__(64 * NT) void k_wgrad(const WgradBatch wb) {
                 if (with_w) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bv[u][t], acc[t], 0, 0, 0);
                 bs[t] += bv[u][t];
             }
+    }
+    // D layout of the 32x32 MFMA: register r of lane l holds D[(r&3) + 8(r>>2) + 4(l>>5)][l&31]
+    if (with_w) {
+        float* pw = jb.pw + (size_t)blockIdx.x * L * L;
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) pw[(size_t)(32 * ti + (r & 3) + 8 * (r >> 2) + 4 * kk) * L + 32 * t + m] = acc[t][r];
+    }
+    if (ti == 0 && jb.pb) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const float sb = bs[t] + __shfl_xor(bs[t], 32, 64);
+            if (kk == 0) jb.pb[(size_t)blockIdx.x * L + 32 * t + m] = sb;
+        }
+    }
+}
+
+// The same product at L = 128 with the rows staged through LDS (round 5, second session).  k_wgrad's operands are 4-byte loads -- 40
+// vector-memory instructions of 256 bytes per wave and 16 rows, none of them in flight while the 32 MFMAs of those rows run: on the
+// cylinder mesh a block's row loop is a chain of L2 round trips (27 us per launch for 8 us of MFMAs), on M-1M the launch is bound by the
+// issue of those instructions.  Here the block's four waves fetch a chunk of 16 rows of X and of G with 16-byte loads (4 instructions per
+// wave), put it into LDS (row stride 132 floats: a column read meets 32 banks) and read the MFMA operands from there; the next chunk's
+// global loads are issued before this chunk's MFMAs (16 registers), the one after that's row indices before them.  Same MFMAs in the
+// same order as k_wgrad: the same bits.
+constexpr int WGL_ROWS = 16, WGL_LS = 132;
+__global__ __launch_bounds__(256) void k_wgrad_lds(const WgradBatch wb) {
+    constexpr int NT = 4, L = 128;
+    __shared__ __attribute__((aligned(16))) float sX[2][WGL_ROWS * WGL_LS];
+    __shared__ __attribute__((aligned(16))) float sG[2][WGL_ROWS * WGL_LS];
+    const WgradJob& jb = wb.job[blockIdx.y];
+    const int64_t r0 = (int64_t)blockIdx.x * wb.rows_per_block;
+    if (r0 >= jb.rows) return;
+    const int64_t r1 = r0 + wb.rows_per_block < jb.rows ? r0 + wb.rows_per_block : jb.rows;
+    const int lane = threadIdx.x & 63, m = lane & 31, kk = lane >> 5;
+    const int ti = threadIdx.x >> 6;
+    const float* __restrict__ X = jb.X;
+    const float* __restrict__ G = jb.G;
+    const int32_t* __restrict__ xidx = jb.xidx;
+    const bool with_w = jb.pw != nullptr;
+    f32x16 acc[NT];
+    float bs[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        bs[t] = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) acc[t][k] = 0.f;
+    }
+    // loader role: thread (lr = tid / 32, lc = tid % 32) moves 16 bytes of rows lr and lr + 8 of a chunk
+    const int lr = threadIdx.x >> 5, lc = threadIdx.x & 31;
+    const int nchunks = (int)((r1 - r0 + WGL_ROWS - 1) / WGL_ROWS);
+    int64_t src[2] = {0, 0}, srcn[2] = {0, 0};            // X rows of the chunk being fetched / of the one after it
+    auto rows_of = [&](int c, int64_t (&out)[2]) {
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const int64_t row = r0 + (int64_t)c * WGL_ROWS + lr + 8 * p;
+            const int64_t rr = row < r1 ? row : r0;
+            out[p] = (with_w && xidx) ? (int64_t)xidx[rr] : rr;
+        }
+    };
+    f32x4 xr[2], gr[2];
+    auto fetch = [&](int c) {                            // chunk c -> registers (rows past the end: row r0, zeroed when stored)
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const int64_t row = r0 + (int64_t)c * WGL_ROWS + lr + 8 * p;
+            const int64_t rr = row < r1 ? row : r0;
+            if (with_w) xr[p] = reinterpret_cast<const f32x4*>(X + src[p] * L)[lc];
+            gr[p] = reinterpret_cast<const f32x4*>(G + rr * L)[lc];
+        }
+    };
+    rows_of(0, src);
+    fetch(0);
+    if (nchunks > 1) rows_of(1, srcn);
+    for (int c = 0; c < nchunks; ++c) {
+        const int b = c & 1;
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const bool ok = r0 + (int64_t)c * WGL_ROWS + lr + 8 * p < r1;
+            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            if (with_w) *reinterpret_cast<f32x4*>(&sX[b][(lr + 8 * p) * WGL_LS + 4 * lc]) = ok ? xr[p] : z;
+            *reinterpret_cast<f32x4*>(&sG[b][(lr + 8 * p) * WGL_LS + 4 * lc]) = ok ? gr[p] : z;
+        }
+        __syncthreads();          // chunk c is in LDS; every wave is past its reads of chunk c - 1 (the buffer chunk c + 1 goes to)
+        if (c + 1 < nchunks) {
+            src[0] = srcn[0]; src[1] = srcn[1];
+            fetch(c + 1);
+            if (c + 2 < nchunks) rows_of(c + 2, srcn);
+        }
+        if (with_w || ti == 0) {
+#pragma unroll
+            for (int u = 0; u < WGL_ROWS / 2; ++u) {
+                const int row = 2 * u + kk;
+                const float av = with_w ? sX[b][row * WGL_LS + 32 * ti + m] : 0.f;
+                float bv[NT];
+#pragma unroll
+                for (int t = 0; t < NT; ++t) bv[t] = sG[b][row * WGL_LS + 32 * t + m];
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    if (with_w) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[t], acc[t], 0, 0, 0);
+                    bs[t] += bv[t];
+                }
+            }
+        }
     }
     // D layout of the 32x32 MFMA: register r of lane l holds D[(r&3) + 8(r>>2) + 4(l>>5)][l&31]
     if (with_w) {
@@ -1299,7 +1402,9 @@ hipError_t launch_wgrad(int L, WgradBatch wb, int64_t rows, hipStream_t s) {
     if (nb == 0 || wb.njobs <= 0) return hipSuccess;
     wb.rows_per_block = wgrad_rows_per_block(rows);
     const dim3 grid(nb, wb.njobs);
-    if (L == 128) hipLaunchKernelGGL(k_wgrad<4>, grid, dim3(256), 0, s, wb);
+    static const int lds = [] { const char* e = getenv("MGN_WGRAD_LDS"); return e ? atoi(e) : 1; }();   // 0: k_wgrad<4> (4-byte operand loads)
+    if (L == 128 && lds) hipLaunchKernelGGL(k_wgrad_lds, grid, dim3(256), 0, s, wb);
+    else if (L == 128) hipLaunchKernelGGL(k_wgrad<4>, grid, dim3(256), 0, s, wb);
     else if (L == 64) hipLaunchKernelGGL(k_wgrad<2>, grid, dim3(128), 0, s, wb);
     else if (L == 32) hipLaunchKernelGGL(k_wgrad<1>, grid, dim3(64), 0, s, wb);
     else return hipErrorInvalidValue;
