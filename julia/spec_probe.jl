@@ -6,7 +6,8 @@
 # choice DESIGN.md marks [GNC-unverified] is answered here, each with the engine / shim setting that matches:
 #   1. Dense layers per MLP for hidden_layers = 2         -> mgn_config.hidden_layers
 #   2. leaf order of the Lux Chain (weight, bias, scale, bias) -> pack_params(leaves) in julia/MGNHip.jl
-#   3. LayerNorm: denominator form and the axes of its statistics -> mgn_config.ln_mode / oracle LN_DIMS
+#   3. LayerNorm: denominator form and the axes of its statistics -> mgn_config.ln_mode / mgn_config.ln_dims (kw ln_mode / ln_dims of MGNHip.load);
+#      both are served by every entry point of the shim, training included (DESIGN.md section 2)
 using GraphNetCore, Lux, Random, Statistics
 
 rng = Random.Xoshiro(0)
@@ -31,8 +32,10 @@ y, _ = ln(x, pl, sl)
 mu = mean(x; dims = 1); sd = std(x; dims = 1, corrected = false)
 cand = Dict("per row, sqrt(var + eps)   -> ln_mode = 0 (MGN_LN_VAR_EPS), MGN-spec v1" => (x .- mu) ./ sqrt.(sd .^ 2 .+ 1f-5),
             "per row, sqrt(var) + eps   -> ln_mode = 1 (MGN_LN_STD_EPS)"              => (x .- mu) ./ (sd .+ 1f-5),
-            "WHOLE ARRAY statistics     -> not an engine mode: oracle LN_DIMS = \"all\", tests/golden/gold_g_ln_variants.npz" =>
-                (x .- mean(x)) ./ sqrt(var(x; corrected = false) + 1f-5))
+            "WHOLE ARRAY statistics, sqrt(var + eps) -> ln_dims = 1 (MGN_LN_ALL), ln_mode = 0" =>
+                (x .- mean(x)) ./ sqrt(var(x; corrected = false) + 1f-5),
+            "WHOLE ARRAY statistics, sqrt(var) + eps -> ln_dims = 1 (MGN_LN_ALL), ln_mode = 1   (LuxLib 0.5's layernorm at dims = Colon())" =>
+                (x .- mean(x)) ./ (std(x; corrected = false) + 1f-5))
 best = argmin(k -> maximum(abs.(cand[k] .- y)), collect(keys(cand)))
 println("3. LayerNorm((4,)) on a 4 x 3 matrix matches: ", best, "   (max |diff| ", maximum(abs.(cand[best] .- y)), ")")
 println("   eps of the layer: ", hasproperty(ln, :epsilon) ? ln.epsilon : "n/a", "  (engine: 1e-5)")
