@@ -337,6 +337,33 @@ def test_step_factored_first_layer_above_the_cooperative_range(monkeypatch):
     assert np.linalg.norm(res["1"][0] - res["0"][0]) <= 1e-3 * np.linalg.norm(ref)
 
 
+def test_stored_and_recomputed_steps_agree_beyond_32_bit_offsets(monkeypatch):
+    """The arena of a 250 000-node mesh with 15 processor steps holds 40 GB when every step's activations are stored (offsets beyond
+    2^32 bytes): all stored, seven of fifteen stored and none stored give the same bits; the size rule itself keeps them all (free memory
+    decides, and the part has it)."""
+    import ctypes as C
+    cfg = cfg_dict(L=128, mps=15)
+    pos, s, r = synth.mesh_1m(11, 500, 500)
+    ps = make_params(cfg)
+    nf, ef, target, mask = problem(cfg, pos, s, r, seed=8, frac=0.25)
+    res = []
+    for keep in ("15", "7", "0", None):
+        if keep is None:
+            monkeypatch.delenv("MGN_TRAIN_KEEP_STEPS", raising=False)
+        else:
+            monkeypatch.setenv("MGN_TRAIN_KEEP_STEPS", keep)
+        eng = engine_for(cfg)
+        eng.set_params(ps)
+        eng.set_graph(s, r, pos.shape[0])
+        res.append(eng.step(nf, ef, target, mask))
+        eng.lib.mgn_debug_train_keep_steps.argtypes = [C.c_void_p]
+        assert eng.lib.mgn_debug_train_keep_steps(eng.h) == (15 if keep is None else int(keep))
+        eng.close()
+    assert np.isfinite(res[0][0]).all() and np.isfinite(res[0][1])
+    for other in res[1:]:
+        assert other[1] == res[0][1] and np.array_equal(other[0], res[0][0])
+
+
 def test_solver_training_euler_discrete_adjoint():
     """train_step(::SolverTraining) with fixed-step Euler (reference src/strategies.jl:175-196, 257-292) through
     mgn_ode_step + mgn_ode_vjp, against the same discrete adjoint driven by the float64 oracle, and against a central
