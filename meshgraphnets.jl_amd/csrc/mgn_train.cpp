@@ -75,8 +75,8 @@ struct TrainState {
     size_t GXs, GXr, GXB, gV[2], gE[MAX_EDGE_SETS][2], gAgg[MAX_EDGE_SETS], Gout, gNF, io, ptmp, pw, pb;
     size_t Pn, Qn, SGs, SGr;     // factored first layer: per-node projections (forward) and summed GZ1 rows (backward)
     // whole-array LayerNorm in the training step: per-MLP statistics of the forward (64 floats each), the double partials of the two
-    // reductions, (m1, m2) of the pullback, the gradient w.r.t. the pre-LayerNorm output handed to k_mlp_bwd
-    size_t lnstats = 0, lnpart = 0, lnm = 0, GLN = 0;
+    // reductions, (m1, m2) of the pullback
+    size_t lnstats = 0, lnpart = 0, lnm = 0;
     // weight gradients + their reductions go to a second stream (small meshes leave most of the chip idle during k_mlp_bwd)
     hipStream_t aux = nullptr;
     hipEvent_t ev_bwd = nullptr, ev_wg[GSETS_MAX] = {};
@@ -368,7 +368,6 @@ int prepare_graph(mgn_engine* h) {
         const size_t nt_max = (std::max<size_t>(NL, ELmax) / L + TILE - 1) / TILE;
         T.lnpart = take((size_t)2 * std::max<size_t>({(size_t)2 * array_stats_blocks(), (size_t)2 * 128 * lnall_bwd_blocks(), (size_t)2 * 4 * nt_max}));
         T.lnm = take(64);
-        T.GLN = 0;
     }
     T.arena_floats = off;
     T.drop_graphs();
@@ -778,7 +777,7 @@ int train_run(mgn_handle* h, const TrainJob& J) {
         a.GT = A + T.GT[gs]; a.GXH = A + T.GXH[gs]; a.GY = A + T.GY[gs]; a.GZ2 = A + T.GZ2[gs]; a.GZ1 = A + T.GZ1[gs];
         if (wide && rows > 0) {   // pullback of the whole-array LayerNorm: dgamma, dbeta and the two means first (two column reductions)
             HIPCHK(h, launch_lnall_bwd(g0, g1, g1i, A + hb[2], A + T.lnstats + (size_t)64 * lnslot, Wt + b.tabs + (size_t)T_GAMMA * L, rows, L,
-                                       reinterpret_cast<double*>(A + T.lnpart), A + T.lnm, G + b.ggamma, G + b.gbeta, nullptr, st));
+                                       reinterpret_cast<double*>(A + T.lnpart), A + T.lnm, G + b.ggamma, G + b.gbeta, st));
             a.ln = 2;                   // the kernel maps G to the gradient at Y as it loads it
             a.LNS = A + T.lnstats + (size_t)64 * lnslot;
             a.LNM = A + T.lnm;

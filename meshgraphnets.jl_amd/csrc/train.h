@@ -116,13 +116,12 @@ hipError_t launch_ln_all_apply_segsum(const float* y, const float* stats, const 
 // epilogue of a right-hand side: out [N][O] = (Y[:, 0:O] os + osh) .* mask[gid ? gid[row] : row]   (os / mask / gid may be null)
 hipError_t launch_rhs_epilogue(const float* Y, int L, int O, const float* os, const float* osh, const float* mask, const int32_t* gid, float* out,
                                int64_t N, hipStream_t s);
-// reverse pass of the whole-array LayerNorm of one MLP: dgamma, dbeta (L floats each, written into the gradient vector), m = (m1, m2) scratch
-// (2 floats) and -- dY != null -- dY [rows][L] = rden (gamma G - m1 - xhat m2) with G = G0[row] (+ G1[g1idx ? g1idx[row] : row])
-// (null: the MLP backward kernel applies that map as it loads G, TrainBwdArgs::ln = 2);
-// partial: 2 * 128 * lnall_bwd_blocks() doubles; stats: launch_array_stats' (mean, rden, kappa) of the forward
+// reverse pass of the whole-array LayerNorm of one MLP: dgamma, dbeta (L floats each, written into the gradient vector) and m = (m1, m2)
+// (2 floats) for G = G0[row] (+ G1[g1idx ? g1idx[row] : row]); the MLP backward kernel then maps G to rden (gamma G - m1 - xhat m2) as it
+// loads it (TrainBwdArgs::ln = 2).  partial: 2 * 128 * lnall_bwd_blocks() doubles; stats: (mean, rden, kappa) of the forward
 int lnall_bwd_blocks();
 hipError_t launch_lnall_bwd(const float* G0, const float* G1, const int32_t* g1idx, const float* Y, const float* stats, const float* gamma,
-                            int64_t rows, int L, double* partial, float* m, float* dgamma, float* dbeta, float* dY, hipStream_t s);
+                            int64_t rows, int L, double* partial, float* m, float* dgamma, float* dbeta, hipStream_t s);
 // node rows between the caller's order and the engine's (a renumbered graph: graph_host.h): gather dst[i] = src[gid[i]], scatter dst[gid[i]] = src[i]
 hipError_t launch_permute_rows(float* dst, const float* src, const int32_t* gid, int64_t rows, int width, bool scatter, hipStream_t s);
 // seed of the RHS VJP (mgn_ode_vjp): G[n][o] = lambda[n][o] * val_mask[n] * os[o]; optionally dxdt = (Y * os + osh) .* val_mask

@@ -971,7 +971,8 @@ __global__ void k_ln_all_apply_segsum(const float* __restrict__ y, const float* 
 //   dbeta[f] = sum_rows G,  dgamma[f] = sum_rows G xhat,
 //   dy = rden (gamma G - m1 - xhat m2),  m1 = mean_all(gamma G) = sum_f gamma[f] dbeta[f] / n,  m2 = kappa mean_all(gamma G xhat) = kappa sum_f gamma[f] dgamma[f] / n
 // k_lnall_bwd_cols: per block the column sums of its rows in double (block b: rows 2 b + {0, 1}, stride 2 gridDim; fixed order);
-// k_lnall_bwd_cols_final: blocks added in order -> dbeta, dgamma (into the gradient vector), m = (m1, m2);  k_lnall_bwd_apply: dy.
+// k_lnall_bwd_cols_final: blocks added in order -> dbeta, dgamma (into the gradient vector), m = (m1, m2); the map G -> dy itself runs inside
+// the MLP backward kernels as they load G (TrainBwdArgs::ln = 2).
 __global__ __launch_bounds__(256) void k_lnall_bwd_cols(const float* __restrict__ G0, const float* __restrict__ G1, const int32_t* __restrict__ g1idx,
                                                         const float* __restrict__ Y, const float* __restrict__ stats, int64_t rows, int L,
                                                         double* __restrict__ partial) {
@@ -1022,19 +1023,6 @@ __global__ __launch_bounds__(1024) void k_lnall_bwd_cols_final(const double* __r
         m[0] = n > 0 ? (float)(a / (double)n) : 0.f;
         m[1] = n > 0 ? (float)((double)stats[2] * c / (double)n) : 0.f;
     }
-}
-__global__ void k_lnall_bwd_apply(const float* __restrict__ G0, const float* __restrict__ G1, const int32_t* __restrict__ g1idx,
-                                  const float* __restrict__ Y, const float* __restrict__ stats, const float* __restrict__ gamma,
-                                  const float* __restrict__ m, float* __restrict__ dY, int64_t n, int L) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const int64_t r = i / L;
-    const int f = (int)(i - r * L);
-    float g = G0[i];
-    if (G1) g += G1[(g1idx ? (int64_t)g1idx[r] : r) * L + f];
-    const float rden = stats[1];
-    const float xh = (Y[i] - stats[0]) * rden;
-    dY[i] = rden * (gamma[f] * g - m[0] - xh * m[1]);
 }
 
 // epilogue of a right-hand side (reference src/solve.jl:203-218): out[i][o] = (Y[i][o] os[o] + osh[o]) * (mask ? mask[gid ? gid[i] : i] : 1)
@@ -1498,14 +1486,13 @@ hipError_t launch_ln_all_apply_segsum(const float* y, const float* stats, const 
 int lnall_bwd_blocks() { return 1024; }
 
 hipError_t launch_lnall_bwd(const float* G0, const float* G1, const int32_t* g1idx, const float* Y, const float* stats, const float* gamma,
-                            int64_t rows, int L, double* partial, float* m, float* dgamma, float* dbeta, float* dY, hipStream_t s) {
+                            int64_t rows, int L, double* partial, float* m, float* dgamma, float* dbeta, hipStream_t s) {
     if (L > 128) return hipErrorInvalidValue;
     int64_t nb64 = (rows + 63) / 64;                   // >= 32 rows per half block; at most lnall_bwd_blocks() blocks
     const int nb = (int)(nb64 < 1 ? 1 : (nb64 > lnall_bwd_blocks() ? lnall_bwd_blocks() : nb64));
     const int64_t n = rows * L;
     hipLaunchKernelGGL(k_lnall_bwd_cols, dim3(nb), dim3(256), 0, s, G0, G1, g1idx, Y, stats, rows, L, partial);
     hipLaunchKernelGGL(k_lnall_bwd_cols_final, dim3(1), dim3(1024), 0, s, partial, nb, n, L, gamma, stats, dgamma, dbeta, m);
-    if (n > 0 && dY) hipLaunchKernelGGL(k_lnall_bwd_apply, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, G0, G1, g1idx, Y, stats, gamma, m, dY, n, L);
     return hipGetLastError();
 }
 
