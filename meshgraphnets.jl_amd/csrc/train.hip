@@ -654,7 +654,7 @@ __global__ __launch_bounds__(64 * NT) void k_wgrad(const WgradBatch wb) {
 // cylinder mesh a block's row loop is a chain of L2 round trips (27 us per launch for 8 us of MFMAs), on M-1M the launch is bound by the
 // issue of those instructions.  Here the block's four waves fetch a chunk of 16 rows of X and of G with 16-byte loads (4 instructions per
 // wave), put it into LDS (row stride 132 floats: a column read meets 32 banks) and read the MFMA operands from there; the next chunk's
-// global loads are issued before this chunk's MFMAs (16 registers), the one after that's row indices before them.  Same MFMAs in the
+// two chunks' global loads are in flight during a chunk's MFMAs (32 registers), row indices two chunks ahead of their rows.  Same MFMAs in the
 // same order as k_wgrad: the same bits.
 constexpr int WGL_ROWS = 16, WGL_LS = 132;
 __global__ __launch_bounds__(256) void k_wgrad_lds(const WgradBatch wb) {
@@ -679,20 +679,21 @@ __global__ __launch_bounds__(256) void k_wgrad_lds(const WgradBatch wb) {
 #pragma unroll
         for (int k = 0; k < 16; ++k) acc[t][k] = 0.f;
     }
-    // loader role: thread (lr = tid / 32, lc = tid % 32) moves 16 bytes of rows lr and lr + 8 of a chunk
+    // loader role: thread (lr = tid / 32, lc = tid % 32) moves 16 bytes of rows lr and lr + 8 of a chunk.  TWO chunks of global loads are in
+    // flight (one chunk of MFMAs is ~1 us: less than an HBM round trip under load), the X row indices of a chunk are read two chunks before
+    // its rows.
     const int lr = threadIdx.x >> 5, lc = threadIdx.x & 31;
     const int nchunks = (int)((r1 - r0 + WGL_ROWS - 1) / WGL_ROWS);
-    int64_t src[2] = {0, 0}, srcn[2] = {0, 0};            // X rows of the chunk being fetched / of the one after it
     auto rows_of = [&](int c, int64_t (&out)[2]) {
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
             const int64_t row = r0 + (int64_t)c * WGL_ROWS + lr + 8 * p;
-            const int64_t rr = row < r1 ? row : r0;
+            const int64_t rr = (c < nchunks && row < r1) ? row : r0;
             out[p] = (with_w && xidx) ? (int64_t)xidx[rr] : rr;
         }
     };
-    f32x4 xr[2], gr[2];
-    auto fetch = [&](int c) {                            // chunk c -> registers (rows past the end: row r0, zeroed when stored)
+    auto fetch = [&](int c, const int64_t (&src)[2], f32x4 (&xr)[2], f32x4 (&gr)[2]) {   // chunk c -> registers (rows past the end: row r0, zeroed when stored)
+        if (c >= nchunks) return;
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
             const int64_t row = r0 + (int64_t)c * WGL_ROWS + lr + 8 * p;
@@ -701,11 +702,7 @@ __global__ __launch_bounds__(256) void k_wgrad_lds(const WgradBatch wb) {
             gr[p] = reinterpret_cast<const f32x4*>(G + rr * L)[lc];
         }
     };
-    rows_of(0, src);
-    fetch(0);
-    if (nchunks > 1) rows_of(1, srcn);
-    for (int c = 0; c < nchunks; ++c) {
-        const int b = c & 1;
+    auto to_lds = [&](int c, int b, const f32x4 (&xr)[2], const f32x4 (&gr)[2]) {
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
             const bool ok = r0 + (int64_t)c * WGL_ROWS + lr + 8 * p < r1;
@@ -713,27 +710,43 @@ __global__ __launch_bounds__(256) void k_wgrad_lds(const WgradBatch wb) {
             if (with_w) *reinterpret_cast<f32x4*>(&sX[b][(lr + 8 * p) * WGL_LS + 4 * lc]) = ok ? xr[p] : z;
             *reinterpret_cast<f32x4*>(&sG[b][(lr + 8 * p) * WGL_LS + 4 * lc]) = ok ? gr[p] : z;
         }
-        __syncthreads();          // chunk c is in LDS; every wave is past its reads of chunk c - 1 (the buffer chunk c + 1 goes to)
-        if (c + 1 < nchunks) {
-            src[0] = srcn[0]; src[1] = srcn[1];
-            fetch(c + 1);
-            if (c + 2 < nchunks) rows_of(c + 2, srcn);
-        }
-        if (with_w || ti == 0) {
+    };
+    auto compute = [&](int b) {
+        if (!(with_w || ti == 0)) return;
 #pragma unroll
-            for (int u = 0; u < WGL_ROWS / 2; ++u) {
-                const int row = 2 * u + kk;
-                const float av = with_w ? sX[b][row * WGL_LS + 32 * ti + m] : 0.f;
-                float bv[NT];
+        for (int u = 0; u < WGL_ROWS / 2; ++u) {
+            const int row = 2 * u + kk;
+            const float av = with_w ? sX[b][row * WGL_LS + 32 * ti + m] : 0.f;
+            float bv[NT];
 #pragma unroll
-                for (int t = 0; t < NT; ++t) bv[t] = sG[b][row * WGL_LS + 32 * t + m];
+            for (int t = 0; t < NT; ++t) bv[t] = sG[b][row * WGL_LS + 32 * t + m];
 #pragma unroll
-                for (int t = 0; t < NT; ++t) {
-                    if (with_w) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[t], acc[t], 0, 0, 0);
-                    bs[t] += bv[t];
-                }
+            for (int t = 0; t < NT; ++t) {
+                if (with_w) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[t], acc[t], 0, 0, 0);
+                bs[t] += bv[t];
             }
         }
+    };
+    int64_t sa[2], sb2[2];                               // X rows of the chunks in slots A / B (then: of the chunks that follow them there)
+    f32x4 xa[2], ga[2], xb[2], gb[2];
+    rows_of(0, sa);
+    rows_of(1, sb2);
+    fetch(0, sa, xa, ga);
+    fetch(1, sb2, xb, gb);
+    rows_of(2, sa);
+    rows_of(3, sb2);
+    for (int c = 0; c < nchunks; c += 2) {
+        to_lds(c, 0, xa, ga);
+        __syncthreads();          // chunk c is in LDS; every wave is past its reads of chunk c - 1 (the buffer chunk c + 1 goes to)
+        fetch(c + 2, sa, xa, ga);
+        rows_of(c + 4, sa);
+        compute(0);
+        if (c + 1 >= nchunks) break;
+        to_lds(c + 1, 1, xb, gb);
+        __syncthreads();
+        fetch(c + 3, sb2, xb, gb);
+        rows_of(c + 5, sb2);
+        compute(1);
     }
     // D layout of the 32x32 MFMA: register r of lane l holds D[(r&3) + 8(r>>2) + 4(l>>5)][l&31]
     if (with_w) {
