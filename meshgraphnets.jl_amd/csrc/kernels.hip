@@ -2826,16 +2826,22 @@ static bool coop_ok(int L, int ntiles, const float* const* chunk_t, bool edge = 
 // split path, 13 / 14 k_edge_ring_h<8 / 4> (two fp16 pieces: the default of large fp32 launches)
 static int g_last_edge_kernel = 0;
 int last_edge_kernel() { return g_last_edge_kernel; }
+// the family of the launch that carries a set's edges: a launch over less than half of the set's tiles (the boundary tiles of a partitioned pass,
+// launched AFTER the interior ones) does not speak for the step
+#define SET_LAST_EDGE(A, CODE)                                                            \
+    do {                                                                                  \
+        if (2 * (int64_t)(A).ntiles * TILE >= (A).E) g_last_edge_kernel = (CODE);         \
+    } while (0)
 
 hipError_t launch_edge_step(int L, const EdgeArgs& a, hipStream_t s) {
     if (a.ntiles <= 0) return hipSuccess;
-    if (a.gen.use) g_last_edge_kernel = 1;
+    if (a.gen.use) SET_LAST_EDGE(a, 1);
     if (a.gen.use) DISPATCH_GEN(L, (k_edge_step<4, 0, true>), (k_edge_step<2, 0, true>), (k_edge_step<1, 0, true>), a, a.ntiles);
     const int nres = resident_chunks(L, 3);
     LaunchCfg lc = tile_launch(L, a.ntiles, nres);
     if (a.c16 && L == 128 && a.chunk_t[0]) {        // small graph: 16-row tiles, 4 waves each (the handle decided for both kernels)
         // RT 16-edge tiles per block: about one block per CU (MGN_C16_RT = 1..3 pins it)
-        g_last_edge_kernel = 2;
+        SET_LAST_EDGE(a, 2);
         const int nht = 2 * a.ntiles;
         int rt = g_c16_rt ? g_c16_rt : (nht + num_cus() - 1) / num_cus();
         const bool sp16 = g_fp32_split && (g_c16_split & 1) && a.split16[0];
@@ -2847,7 +2853,7 @@ hipError_t launch_edge_step(int L, const EdgeArgs& a, hipStream_t s) {
         if (g_fp32_split && (g_c16_split & 1) && a.split16[0] && (rt >= 2 || (g_c16_split & 4))) {   // split path: bf16 matrix cores at fp32 accuracy (pieces exchanged: 12 KiB per tile)
             c16.lds = (size_t)rt * 2 * 12 * 64 * 16 + (size_t)rt * 2 * 64 * 4;
             const bool h2 = g_split_f16 && a.split16h[0] && rt <= 4;   // two fp16 pieces, three products (else three bf16 pieces, six; five and six row tiles spill with two)
-            g_last_edge_kernel = h2 ? 15 : 12;
+            SET_LAST_EDGE(a, h2 ? 15 : 12);
 #define C16E(RT_, BF_) (h2 ? launch_k(k_edge_coop16m<RT_, BF_, 2>, a, c16, s) : launch_k(k_edge_coop16m<RT_, BF_, 1>, a, c16, s))
             if (a.bf) {
                 if (rt == 3) return C16E(3, true);
@@ -2876,13 +2882,13 @@ hipError_t launch_edge_step(int L, const EdgeArgs& a, hipStream_t s) {
     static const int coop_edge_ring = [] { const char* e = getenv("MGN_COOP_EDGE_TILES_PER_CU_RING"); return e ? atoi(e) : 3; }();
     const bool ring_ok = L == 128 && g_fp32_split == 1 && a.split[0] && g_path == 0;
     if (coop_ok(L, a.ntiles, a.chunk_t, true) && !(ring_ok && a.ntiles > coop_edge_ring * num_cus())) {   // small graph: 4 waves per tile
-        g_last_edge_kernel = 3;
+        SET_LAST_EDGE(a, 3);
         LaunchCfg c4{a.ntiles, 256, coop_lds()};
         return coop_fence(a.ntiles) ? launch_k(k_edge_coop<true>, a, c4, s) : launch_k(k_edge_coop<false>, a, c4, s);
     }
     if (L == 128) {
         if (small_launch(a.ntiles) && !(ring_ok && a.ntiles > coop_edge_ring * num_cus())) {   // few tiles: the per-block LDS preload would dominate -> stream everything from L2
-            g_last_edge_kernel = 4;
+            SET_LAST_EDGE(a, 4);
             lc.lds = (size_t)T_COUNT * L * 4 + 64;
             return launch_k(k_edge_step<4, 0>, a, lc, s);
         }
@@ -2902,13 +2908,13 @@ hipError_t launch_edge_step(int L, const EdgeArgs& a, hipStream_t s) {
             }
             if (g_split_f16 && a.splith[0]) {
                 ls.lds = edge_ring_h_lds();
-                g_last_edge_kernel = ls.threads == 256 ? 14 : 13;
+                SET_LAST_EDGE(a, ls.threads == 256 ? 14 : 13);
                 return launch_edge_ring_h(a, ls, s);
             }
-            g_last_edge_kernel = ls.threads == 256 ? 8 : 7;
+            SET_LAST_EDGE(a, ls.threads == 256 ? 8 : 7);
             return launch_edge_ring(a, ls, s);
         }
-        g_last_edge_kernel = 9;
+        SET_LAST_EDGE(a, 9);
         lc.lds += (size_t)MGN_EDGE_JR * 64 * 4 * 4;   // partially resident third chunk
         // Tail of the persistent walk: with r = ntiles / (8 waves x 256 blocks) rounds, a last round that is less than
         // ~60 % full costs a whole tile-time (11.4 tiles per wave on an 8-GPU partition of M-1M: 5 %).  Those tiles go to
