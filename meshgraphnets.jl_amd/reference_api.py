@@ -163,16 +163,24 @@ def inverse_data(norm, y):
 # ---- src/graph.jl ------------------------------------------------------------------------------------
 def create_base_graph(data, type_size, type_min, device=None):
     """Static part of the graph, once per trajectory.  data: dict with 'node_type' [N] (or [N][1]), 'mesh_pos'
-    [N][dims] and 'cells' [C][3] or 'edges' [n][2].  Returns (node_type_onehot, senders, receivers,
-    edge_features) like src/graph.jl:54 (0-based indices)."""
-    node_type = one_hot(np.asarray(data["node_type"]).reshape(-1), type_size - type_min + 1, -type_min)
+    [N][dims] and 'cells' [C][3] or 'edges' [n][2] (either index base, told apart as the reference does: by the presence of a 0).
+    Per-node arrays may carry a leading time axis ([T][N][..], what the dataset readers return): the first frame is taken, like
+    `data[...][:, :, 1]`.  Returns (node_type_onehot, senders, receivers, edge_features) like src/graph.jl:54 (0-based indices)."""
+    first = lambda a, nd: np.asarray(a)[0] if np.asarray(a).ndim > nd else np.asarray(a)     # noqa: E731  ([T][N][..] -> frame 1)
+    nt = np.asarray(data["node_type"])
+    nt = nt[0] if nt.ndim == 3 else nt
+    node_type = one_hot(nt.reshape(-1), type_size - type_min + 1, -type_min)
     if "cells" in data:
-        senders, receivers = triangles_to_edges(data["cells"])
+        senders, receivers = triangles_to_edges(first(data["cells"], 2))
     elif "edges" in data:
         senders, receivers = parse_edges(data["edges"])
     else:
         raise KeyError("Data does not contain cell or edge information!")
-    pos = np.asarray(data["mesh_pos"], F32)
+    # src/graph.jl:31-34, 39-42: lists that name a node 0 are 0-based and shifted to Julia's 1-based indices, all others are taken as 1-based
+    # already (the HDF5 arm's create_edges / read_edges produce those).  This module indexes from 0: the mirror image of that rule.
+    if senders.size and not ((senders == 0).any() or (receivers == 0).any()):
+        senders, receivers = senders - 1, receivers - 1
+    pos = np.asarray(first(data["mesh_pos"], 2), F32)
     rel = pos[senders] - pos[receivers]
     edge_features = np.concatenate([rel, np.linalg.norm(rel, axis=1, keepdims=True).astype(F32)], 1).astype(F32)
     return node_type, senders, receivers, edge_features
