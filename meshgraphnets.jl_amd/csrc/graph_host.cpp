@@ -121,11 +121,6 @@ std::string build_local_graph(int32_t N, int nsets, const EdgeList* sets, const 
         if (es.E < 0) return "negative E";
         if (es.E > 0 && (!es.senders || !es.receivers)) return "null senders/receivers";
         if (es.E >= ((int64_t)1 << 31)) return "E >= 2^31 not supported";
-        for (int64_t i = 0; i < es.E; ++i) {
-            const int64_t s = (int64_t)es.senders[i] - es.index_base, r = (int64_t)es.receivers[i] - es.index_base;
-            if (s < 0 || s >= N || r < 0 || r >= N)
-                return "edge index out of range at edge " + std::to_string(i) + " of set " + std::to_string(k);
-        }
     }
     std::vector<int32_t> owner_keep;
     if (owner_in) owner_keep.assign(owner_in, owner_in + N);   // owner_in may alias g.owner
@@ -136,6 +131,28 @@ std::string build_local_graph(int32_t N, int nsets, const EdgeList* sets, const 
     g.nsets = nsets;
     if (owner_in) g.owner.swap(owner_keep);
     else rcb_partition(N, pos, pos_dim, nranks, g.owner);
+    // One pass over the GLOBAL lists: range check, and -- on a partition -- the edges this rank has anything to do with (an end it owns:
+    // 1 / nranks of them plus the cut), in list order.  Every later pass walks those (a rank of eight read all 6 M edges of M-1M six times).
+    std::vector<int64_t> rel[MAX_EDGE_SETS];
+    for (int k = 0; k < nsets; ++k) {
+        const EdgeList& es = sets[k];
+        if (nranks > 1) rel[k].reserve((size_t)(es.E / nranks + es.E / 64 + 16));
+        for (int64_t i = 0; i < es.E; ++i) {
+            const int64_t s = (int64_t)es.senders[i] - es.index_base, r = (int64_t)es.receivers[i] - es.index_base;
+            if (s < 0 || s >= N || r < 0 || r >= N)
+                return "edge index out of range at edge " + std::to_string(i) + " of set " + std::to_string(k);
+            if (nranks > 1 && (g.owner[s] == rank || g.owner[r] == rank)) rel[k].push_back(i);
+        }
+    }
+    // edges of set k that touch this rank, in list order: fn(edge position, sender, receiver)
+    auto for_edges = [&](int k, auto&& fn) {
+        const EdgeList& es = sets[k];
+        if (nranks > 1) {
+            for (const int64_t i : rel[k]) fn(i, (int32_t)(es.senders[i] - es.index_base), (int32_t)(es.receivers[i] - es.index_base));
+        } else {
+            for (int64_t i = 0; i < es.E; ++i) fn(i, (int32_t)(es.senders[i] - es.index_base), (int32_t)(es.receivers[i] - es.index_base));
+        }
+    };
 
     // owned nodes: boundary nodes (senders of an edge received on another rank) first, then interior, each in
     // ascending global id.  Boundary-first lets the driver project the boundary tiles, start the halo exchange and
@@ -145,10 +162,9 @@ std::string build_local_graph(int32_t N, int nsets, const EdgeList* sets, const 
         std::vector<uint8_t> is_bnd(N, 0);
         if (nranks > 1)
             for (int k = 0; k < nsets; ++k)
-                for (int64_t i = 0; i < sets[k].E; ++i) {
-                    const int32_t s = sets[k].senders[i] - sets[k].index_base, r = sets[k].receivers[i] - sets[k].index_base;
+                for_edges(k, [&](int64_t, int32_t s, int32_t r) {
                     if (g.owner[s] == rank && g.owner[r] != rank) is_bnd[s] = 1;
-                }
+                });
         // the order of the owned nodes inside the two groups: ascending global id, or breadth-first over the mesh (see header)
         std::vector<int32_t> order;
         if (renumber != 0 && sets[0].E > 0) {
@@ -186,10 +202,9 @@ std::string build_local_graph(int32_t N, int nsets, const EdgeList* sets, const 
     {
         std::vector<uint8_t> is_halo(N, 0);
         for (int k = 0; k < nsets; ++k)
-            for (int64_t i = 0; i < sets[k].E; ++i) {
-                const int32_t s = sets[k].senders[i] - sets[k].index_base, r = sets[k].receivers[i] - sets[k].index_base;
+            for_edges(k, [&](int64_t, int32_t s, int32_t r) {
                 if (g.owner[r] == rank && g.owner[s] != rank) is_halo[s] = 1;
-            }
+            });
         g.recv_rows.assign(nranks, 0);
         for (int32_t i = 0; i < N; ++i)
             if (is_halo[i]) ++g.recv_rows[g.owner[i]];
@@ -213,28 +228,26 @@ std::string build_local_graph(int32_t N, int nsets, const EdgeList* sets, const 
         t.E = es.E;
         t.rowptr.assign((size_t)g.n_own + 1, 0);
         int64_t el = 0;
-        for (int64_t i = 0; i < es.E; ++i) {
-            const int32_t r = es.receivers[i] - es.index_base;
+        for_edges(k, [&](int64_t, int32_t, int32_t r) {
             if (g.owner[r] == rank) {
                 ++t.rowptr[(size_t)g2l[r] + 1];
                 ++el;
             }
-        }
+        });
         t.e_local = el;
         for (int32_t i = 0; i < g.n_own; ++i) t.rowptr[(size_t)i + 1] += t.rowptr[i];
         t.snd.assign(el, 0);
         t.rcv.assign(el, 0);
         t.edge_gid.assign(el, 0);
         std::vector<int32_t> cur(t.rowptr.begin(), t.rowptr.end() - 1);
-        for (int64_t i = 0; i < es.E; ++i) {
-            const int32_t s = es.senders[i] - es.index_base, r = es.receivers[i] - es.index_base;
-            if (g.owner[r] != rank) continue;
+        for_edges(k, [&](int64_t i, int32_t s, int32_t r) {
+            if (g.owner[r] != rank) return;
             const int32_t lr = g2l[r];
             const int32_t p = cur[lr]++;
             t.snd[p] = g2l[s];
             t.rcv[p] = lr;
             t.edge_gid[p] = i;
-        }
+        });
         t.halo_span = 0;
         for (int64_t p = el - 1; p >= 0; --p)
             if (t.snd[p] >= g.n_own) { t.halo_span = p + 1; break; }
@@ -246,11 +259,10 @@ std::string build_local_graph(int32_t N, int nsets, const EdgeList* sets, const 
     if (nranks > 1) {
         std::vector<std::vector<int32_t>> lists(nranks);
         for (int k = 0; k < nsets; ++k)
-            for (int64_t i = 0; i < sets[k].E; ++i) {
-                const int32_t s = sets[k].senders[i] - sets[k].index_base, r = sets[k].receivers[i] - sets[k].index_base;
+            for_edges(k, [&](int64_t, int32_t s, int32_t r) {
                 const int32_t q = g.owner[r];
                 if (g.owner[s] == rank && q != rank) lists[q].push_back(s);
-            }
+            });
         for (int32_t q = 0; q < nranks; ++q) {
             auto& l = lists[q];
             std::sort(l.begin(), l.end());
