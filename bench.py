@@ -754,6 +754,35 @@ def main():
                 del nfA, efA
             except Exception as ex:   # noqa: BLE001
                 out["secondary"]["whole_array_layernorm_1m"] = {"error": str(ex)[:200]}
+            # the same hedge on the cylinder mesh: right-hand side (resident inputs), 100-save Euler rollout, training step
+            try:
+                engB = mgn_amd.Engine(FN, FE, O, L, 2, MPS, device=local_rank, ln_dims="all")
+                engB.set_params(ps)
+                engB.set_graph(s2, r2, pos2.shape[0])
+                engB.set_static(onehot5, ef5, vm5)
+                for _ in range(4):
+                    engB.ode_step(vel5)
+                t0 = time.perf_counter()
+                for _ in range(20):
+                    engB.ode_step(vel5)
+                rhsB = (time.perf_counter() - t0) / 20
+                engB.rollout("Euler", vel5, onehot5, ef5, 0.0, 0.1, 0.01, 11, dt=0.01, val_mask=vm5)
+                t0 = time.perf_counter()
+                engB.rollout("Euler", vel5, onehot5, ef5, 0.0, 1.0, 0.01, 101, dt=0.01, val_mask=vm5)
+                roB = time.perf_counter() - t0
+                for _ in range(3):
+                    engB.step(nft, eft, tgt, maskt)
+                t0 = time.perf_counter()
+                for _ in range(10):
+                    engB.step(nft, eft, tgt, maskt)
+                stB = (time.perf_counter() - t0) / 10
+                out["secondary"]["whole_array_layernorm_cyl"] = {
+                    "workload": "M-cyl under ln_dims = MGN_LN_ALL: mgn_ode_step on resident inputs (launch-graph replay), native Euler rollout with 100 saves, "
+                                "mgn_step; host in/out included",
+                    "us_per_rhs": rhsB * 1e6, "euler_100_saves_ms": roB * 1e3, "train_step_ms": stB * 1e3}
+                engB.close()
+            except Exception as ex:   # noqa: BLE001
+                out["secondary"]["whole_array_layernorm_cyl"] = {"error": str(ex)[:200]}
             # mid-size meshes (real CFD meshes, and the per-GPU share of M-1M on 8 GPUs): where the kernel families meet
             mids = {}
             for nxm in (128, 300, 354):   # 354 x 354 = the per-GPU share of M-1M on 8 GPUs
