@@ -847,12 +847,14 @@ DEVINL void h2_layer_ring(f32x16 (&acc)[4], f32x16 (&in)[4], const u32x4* hi, co
             const int it = 4 * s + t;
             const int gw = WPL * LYR + it / W;                        // global window of this step
             const u32x4 a1 = nx.h, a2 = nx.l;
+#ifndef MGN_WHATIF_FREE        // (MGN_WHATIF_FREE = n: timing-only build, wrong results -- no ring traffic, no barriers, waves 4..7 start n x 8 k cycles late)
             if (it % W == 0) {                                         // request window gw + AHEAD
                 const int g2 = (gw + AHEAD) % NW, l2 = g2 / WPL, w2 = g2 % WPL;
 #pragma unroll
                 for (int i = 0; i < LPT; ++i)
-                    pend.v[gw % 2][i] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(src.lo[l2] + w2 * W * 64 + i * NWV * 64) + voff);
+                    pend.v[AHEAD == 2 ? 0 : gw % 2][i] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(src.lo[l2] + w2 * W * 64 + i * NWV * 64) + voff);
             }
+#endif
             if constexpr (RFS > 0) {
                 if ((t & 1) && s < 8 - ROT) {                          // registers of k-step s (free since the step began), half t >> 1
                     const f32x4 v = rf[(2 * (WRAP ? s : s + ROT) + (t >> 1)) * RFS];
@@ -867,12 +869,14 @@ DEVINL void h2_layer_ring(f32x16 (&acc)[4], f32x16 (&in)[4], const u32x4* hi, co
             } else if (LYR < 2) {
                 nx = rh_first<W, (LYR + 1) % 3>(hi_next, ring, lane);   // (that window was written two windows ago)
             }
+#ifndef MGN_WHATIF_FREE
             if (it % W == W - 2) {                                     // store window gw + 2 (AHEAD 3: requested in window gw - 1): its buffer was
                 const int b2 = (gw + 2) % NB;                          // last read as window gw + 2 - NB
-                const int slot = AHEAD == 2 ? gw % 2 : (gw + 1) % 2;
+                const int slot = AHEAD == 2 ? 0 : (gw + 1) % 2;      // (AHEAD 2: a window is stored in the window it is requested in -- one slot)
 #pragma unroll
                 for (int i = 0; i < LPT; ++i) ring[b2 * BUF + i * NWV * 64 + tid - lane] = pend.v[slot][i];
             }
+#endif
             if (s < 7) {
                 const int sn = s + 1;
                 const f32x2 b = bias(sn, t);
@@ -883,7 +887,9 @@ DEVINL void h2_layer_ring(f32x16 (&acc)[4], f32x16 (&in)[4], const u32x4* hi, co
             acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h2_wop(a1), bl, acc[t], 0, 0, 0);
             acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h2_wop(a1), bh, acc[t], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
+#ifndef MGN_WHATIF_FREE
             if (it % W == W - 1) ring_barrier();                       // window closed: every wave has read it, window gw + 2 is in LDS
+#endif
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -908,6 +914,9 @@ DEVINL void h2_layer_ring(f32x16 (&acc)[4], f32x16 (&in)[4], const u32x4* hi, co
 #endif
 #ifndef MGN_RINGH_ESTORE_LAST
 #define MGN_RINGH_ESTORE_LAST 0   // (1 spills 64 registers in the epilogue: not run) 1: this tile's e stores behind the next tile's Q request (0: right behind the residual, k_edge_ring's order)
+#endif
+#ifndef MGN_RINGH_SCAN_SKIP
+#define MGN_RINGH_SCAN_SKIP 1     // the scan's row_shr:8 level behind a wave-uniform branch (taken only by tiles with a receiver run of nine edges or more inside a 16-lane row)
 #endif
 #ifndef MGN_RINGH_W
 #define MGN_RINGH_W 8            // steps per window of k_edge_ring_h (8: 12 barriers per tile; 16: 6)
@@ -972,6 +981,10 @@ __global__ __launch_bounds__(NWV * 64, NWV / 4) void k_edge_ring_h(const EdgeArg
     }
     int stamp_tile = 0;
     (void)stamp_tile;
+#ifdef MGN_WHATIF_FREE
+    if (wave >= NWV / 2)
+        for (int i = 0; i < MGN_WHATIF_FREE; ++i) __builtin_amdgcn_s_sleep(127);
+#endif
     for (int j = 0; j < iters; ++j, ++stamp_tile) {
         OPAQUE_LANE();
         const bool on = tw.tile < tw.end;
@@ -1107,7 +1120,13 @@ __global__ __launch_bounds__(NWV * 64, NWV / 4) void k_edge_ring_h(const EdgeArg
         RG_SCAN_LEVEL(acc, c1, "row_shr:1 row_mask:0xf bank_mask:0xf");
         RG_SCAN_LEVEL(acc, c2s, "row_shr:2 row_mask:0xf bank_mask:0xf");
         RG_SCAN_LEVEL(acc, c4, "row_shr:4 row_mask:0xf bank_mask:0xf");
-        RG_SCAN_LEVEL(acc, c8, "row_shr:8 row_mask:0xf bank_mask:0xf");
+#if MGN_RINGH_SCAN_SKIP
+        // receiver runs of nine edges and more are rare on a mesh (M-1M: none): their level only where a lane of the tile needs it
+        if (__builtin_amdgcn_ballot_w64(c8) != 0)
+#endif
+        {
+            RG_SCAN_LEVEL(acc, c8, "row_shr:8 row_mask:0xf bank_mask:0xf");
+        }
         RG_SCAN_LEVEL(acc, cx, "row_bcast:15 row_mask:0xa bank_mask:0xf");
         PHASE_FENCE();
         EST(5);
