@@ -96,8 +96,9 @@ def cpu_baseline(ps, budget_s=20.0):
         steps += 1
     dt = time.time() - t0
     return dict(value=e * steps / dt, unit="edges/s", nodes_per_s=n * steps / dt, cores=mgn_ref.num_threads(),
-                kind="port", sample=f"{steps} processor step(s), L=128 fp32, on a 300x300 slice of the M-1M "
-                f"generator (N={n}, E={e}); oracle/mgn_ref.c with OpenMP on all host cores; {dt:.1f} s",
+                kind="port", sample=f"per-edge rate on a SLICE, not on the headline mesh: {steps} processor step(s), L=128 fp32, on a 300x300 "
+                f"slice of the M-1M generator (N={n}, E={e}); oracle/mgn_ref.c (the C restatement of MGN-spec, not the Julia path) with OpenMP "
+                f"on all host cores; {dt:.1f} s",
                 host_cpus=os.cpu_count())
 
 
@@ -124,6 +125,78 @@ def committed_traffic(prefixes, dtype="f32"):
                 if any(kk.startswith(p) for p in prefixes) and "derived" in v and "hbm_bytes_per_launch_corrected" in v["derived"]:
                     return v["derived"]["hbm_bytes_per_launch_corrected"], f"profiles/{rd}/{name}"
     return None, None
+
+
+def scaling_model(ps, pos, s, r, N, E, t_step_1gpu, device, sync, xgmi_link_GBps=153.0, exchange_latency_us=20.0):
+    """What 2 / 4 / 8 GPUs should give on this mesh, from ONE GPU (no multi-GPU node is available to the build): for P partitions the share
+    of a middle rank of the real RCB partition (real halo and send lists, interior / boundary tile split) is run through the staged
+    schedule of mgn_processor_steps_dev -- boundary projection, pack, interior projection + interior edge tiles, unpack, boundary edge
+    tiles, node update; engine.run_processor_staged, the Python twin of processor_pass_staged -- with the wire left out (the halo rows
+    are not refreshed: timing only).  The wire is then priced from the rank's real receive count at a stated link rate and latency and is
+    exposed only where it exceeds the interior work it overlaps with.  Predicted edges/s = E / predicted time per step."""
+    import torch
+    import mgn_amd
+    model = {"assumptions": {"xgmi_link_GBps": xgmi_link_GBps, "exchange_latency_us": exchange_latency_us,
+                             "note": "one process per GPU, one xGMI link per peer pair; the grouped ncclSend / ncclRecv of a step run on the communicator's "
+                                     "stream while the interior tiles run (csrc/mgn_api.cpp: processor_pass_staged); per-share times measured on one GPU, "
+                                     "wire time assumed, not measured"},
+             "one_gpu_ms_per_step": t_step_1gpu * 1e3}
+    for P in (2, 4, 8):
+        rk = P // 2
+        eng = mgn_amd.Engine(FN, FE, O, L, 2, MPS, rank=rk, nranks=P, device=device)
+        try:
+            eng.set_params(ps)
+            t0 = time.perf_counter()
+            eng.set_graph(s, r, N, mesh_pos=pos)
+            t_set = time.perf_counter() - t0
+            eng.latents_randn(1234)
+            nsend, nhalo, rowf = int(eng.halo_send_index().size), int(eng.n_halo), eng.halo_row_floats
+            send = torch.zeros(max(nsend, 1) * rowf, device=f"cuda:{device}")
+            recv = torch.zeros(max(nhalo, 1) * rowf, device=f"cuda:{device}")
+
+            class _Exchange:                                   # pack -> (wire: left out) -> unpack
+                def start(self_):
+                    eng.halo_pack(send.data_ptr())
+
+                def finish(self_):
+                    eng.halo_unpack(recv.data_ptr())
+
+            ex = _Exchange()
+            for _ in range(3):
+                mgn_amd.run_processor_staged([eng], ex, MPS)
+            sync()
+            k = 6
+            t0 = time.perf_counter()
+            for _ in range(k):
+                mgn_amd.run_processor_staged([eng], ex, MPS)
+            sync()
+            t_share = (time.perf_counter() - t0) / (k * MPS)
+            cost = {}
+            for name, fn, ptr in (("pack_us", eng.halo_pack, send.data_ptr()), ("unpack_us", eng.halo_unpack, recv.data_ptr())):
+                for _ in range(10):
+                    fn(ptr)
+                sync()
+                t0 = time.perf_counter()
+                for _ in range(100):
+                    fn(ptr)
+                sync()
+                cost[name] = (time.perf_counter() - t0) / 100 * 1e6
+            tiles_bnd, tiles_all = eng.edge_boundary_tiles(0)
+            tiles_int = tiles_all - tiles_bnd
+            wire_us = exchange_latency_us + nhalo * rowf * 4 / (xgmi_link_GBps * 1e3) / max(1, min(2, P - 1))   # strips: two neighbours, a link each
+            # the exchange overlaps with the interior projection and the interior edge tiles: ~ the interior share of the step
+            t_interior = t_share * tiles_int / max(tiles_int + tiles_bnd, 1)
+            exposed = max(0.0, wire_us * 1e-6 - t_interior)
+            t_pred = t_share + exposed
+            model[f"{P}_gpus"] = {"rank": rk, "n_own": int(eng.n_own), "n_halo": nhalo, "send_rows": nsend, "e_local": int(eng.e_local),
+                                  "edge_tiles_interior": int(tiles_int), "edge_tiles_boundary": int(tiles_bnd),
+                                  "share_ms_per_step_staged": t_share * 1e3, **cost, "wire_us_assumed": wire_us,
+                                  "wire_exposed_us": exposed * 1e6, "predicted_ms_per_step": t_pred * 1e3,
+                                  "predicted_edges_per_s": E / t_pred, "predicted_speedup": t_step_1gpu / t_pred,
+                                  "predicted_efficiency": t_step_1gpu / t_pred / P, "graph_setup_s": t_set}
+        finally:
+            eng.close()
+    return model
 
 
 def time_clean(eng, steps, warmup, sync):
@@ -803,6 +876,10 @@ def main():
                 mids[f"N={posm.shape[0]},E={sm.size}"] = {"us_per_processor_step": dtm / (km * MPS) * 1e6, "edges_per_s": sm.size * MPS * km / dtm}
                 engm.close()
             out["secondary"]["mid_size_meshes"] = mids
+            try:
+                out["secondary"]["scaling_model"] = scaling_model(ps, pos, s, r, N, E, t_step, local_rank, barrier_sync)
+            except Exception as ex:   # noqa: BLE001
+                out["secondary"]["scaling_model"] = {"error": str(ex)[:300]}
             # cfg-3: flag_simple-shaped cloth, mesh + world edges (two edge sets), 15 steps, bf16 (and fp32 beside it)
             mf = mgn_amd.synth.mesh_flag()
             Nf, Ef, Ef2 = mf["mesh_pos"].shape[0], mf["s"].size, mf["s2"].size

@@ -273,8 +273,11 @@ int mgn_rollout(mgn_handle* h, mgn_rollout_desc* d);
  *   target [N][O];  mask [nmask]: node indices (Int32, 1-based at the Julia boundary: mask_index_base = 1,
  *   src/MeshGraphNets.jl:352);  grads [n_grads = mgn_param_count]: packed order of mgn_set_params, so that
  *   Optimisers.update(opt_state, ps, gs) keeps working on the Julia side;  *loss: the scalar.
- * fp32, one partition, ln_mode = MGN_LN_VAR_EPS; hidden_layers 1 .. 4; with two edge sets the second set's features are the ones
- * installed by mgn_set_edge_features (as in mgn_forward).  Deterministic: gradients are reduced in a fixed order; the only atomic
+ * fp32, one partition; both ln_mode values and both ln_dims values; hidden_layers 1 .. 4; with two edge sets the second set's
+ * features are the ones installed by mgn_set_edge_features (as in mgn_forward).  Memory: a large mesh stores the activations of as
+ * many processor steps as the device's free memory (hipMemGetInfo) minus MGN_TRAIN_RESERVE_GB (16) holds and recomputes the others
+ * in the reverse pass -- the first handle on a device takes the stored steps, a later one recomputes; a refused allocation is retried
+ * with fewer stored steps, MGN_E_OOM only when the arena without any does not fit (M-1M: 61 GB + 10.7 GB per stored step).  Deterministic: gradients are reduced in a fixed order; the only atomic
  * (the scalar loss / per-node seed when `mask` lists a node twice) adds identical terms, so the order does not matter.
  * nf, ef, target and grads may be HOST or DEVICE pointers (copied with hipMemcpyDefault on the handle's stream): with
  * device arrays -- the reference keeps graph, ps and gs on the GPU, src/MeshGraphNets.jl:255-263 -- the optimiser update

@@ -188,6 +188,7 @@ const CKPT_PARAMS = "mgn_hip_params.f32"      # packed parameters, raw little-en
 const CKPT_LOG = "mgn_hip_log.csv"            # kind,step,loss
 const CKPT_NORMS = "mgn_hip_norms.jls"        # snapshot((e_norm, n_norm, o_norm)): plain data, no device arrays, no closures
 const CKPT_OPT = "mgn_hip_opt_state.jls"      # the Optimisers.jl state tree of the packed vector (host arrays), as it is
+const CKPT_MANIFEST = "mgn_hip_manifest.txt"   # name,size,checksum of the four files above, written last (checkpoint.py's twin)
 
 """
 `snapshot(x)`: a normaliser (or a Dict / tuple of them) as plain data -- arrays as host `Array`s, numbers and strings as they are,
@@ -252,6 +253,15 @@ function load(quantities, dims, e_norms, n_norms, o_norms, outputs, mps, layer_s
     pfile = joinpath(path, CKPT_PARAMS)
     have = isfile(pfile)
     if have
+        mfile = joinpath(path, CKPT_MANIFEST)
+        if isfile(mfile)               # (absent: a checkpoint written before the manifest existed -- taken as it is)
+            for line in eachline(mfile)
+                name, size, chk = split(line, ',')
+                f = joinpath(path, name)
+                (isfile(f) && filesize(f) == parse(Int, size) && file_checksum(f) == parse(UInt64, chk)) ||
+                    error("checkpoint in $path is torn: $name is not the file its manifest lists (a run was killed inside save!; the directory mixes two saves)")
+            end
+        end
         nfile = joinpath(path, CKPT_NORMS)
         if isfile(nfile)
             stored = Serialization.deserialize(nfile)
@@ -290,8 +300,9 @@ end
 """
 `save!(mgn, opt_state, df_train, df_valid, step, loss, path; is_training = true)` as called at src/MeshGraphNets.jl:460-471: appends
 (step, loss) to the training or the validation log and writes the whole state -- `mgn.ps`, `mgn.e_norm`, `mgn.n_norm`, `mgn.o_norm`
-(with whatever an online normaliser has accumulated so far) and `opt_state`.  Every file is written beside its target and renamed,
-so a run killed inside `save!` leaves the previous checkpoint whole.
+(with whatever an online normaliser has accumulated so far) and `opt_state`.  Every file is written beside its target and renamed, the manifest
+(sizes and checksums of the four files) last: a run killed inside `save!` leaves either the previous checkpoint whole or a directory whose
+manifest does not match, which `load` refuses instead of mixing the files of two saves.
 """
 function save!(mgn::GraphNetwork, opt_state, df_train, df_valid, step, loss, path; is_training = true)
     mkpath(path)
@@ -315,10 +326,27 @@ function save!(mgn::GraphNetwork, opt_state, df_train, df_valid, step, loss, pat
             end
         end
     end
-    atomically(CKPT_PARAMS) do tmp              # last: `load` keys on this file
+    atomically(CKPT_PARAMS) do tmp
         write(tmp, mgn.ps::Vector{Float32})
     end
+    atomically(CKPT_MANIFEST) do tmp            # last: sizes and checksums of the four -- `load` refuses a directory that mixes two saves
+        open(tmp, "w") do io
+            for name in (CKPT_NORMS, CKPT_OPT, CKPT_LOG, CKPT_PARAMS)
+                f = joinpath(path, name)
+                println(io, name, ',', filesize(f), ',', file_checksum(f))
+            end
+        end
+    end
     return nothing
+end
+
+"sum over the file's bytes b_i (i from 1) of i * b_i, modulo 2^64 (checkpoint.py: file_checksum)"
+function file_checksum(fname)
+    s = UInt64(0)
+    for (i, b) in enumerate(read(fname))
+        s += UInt64(i) * UInt64(b)
+    end
+    return s
 end
 
 # ---- graph -----------------------------------------------------------------------------------------------------------------------

@@ -9,7 +9,10 @@ files); `engine.load` / `engine.save` are the call-shaped wrappers.
 
 Files in a checkpoint directory: `mgn_hip_params.f32` (packed parameters, raw little-endian float32) and `mgn_hip_log.csv`
 (kind,step,loss) are the SAME files the Julia shim writes; the normalisers and the optimiser state are `.npz` here and Julia
-`Serialization` files there (neither side can read the other's object format).
+`Serialization` files there (neither side can read the other's object format).  `mgn_hip_manifest.txt`, written last, lists
+size and checksum of the other four: each file is renamed into place on its own, so a run killed between two renames leaves files of
+two saves side by side -- the manifest then does not match and `read_checkpoint` refuses the directory instead of resuming with the
+Adam moments of step k + 1 over the parameters of step k.
 """
 from __future__ import annotations
 
@@ -21,6 +24,7 @@ CKPT_PARAMS = "mgn_hip_params.f32"
 CKPT_LOG = "mgn_hip_log.csv"
 CKPT_NORMS = "mgn_hip_norms.npz"
 CKPT_OPT = "mgn_hip_opt_state.npz"
+CKPT_MANIFEST = "mgn_hip_manifest.txt"
 
 _SKIP_FIELDS = ("engine",)          # a NormaliserOnline may hold the Engine it reduces on: a handle, not state
 
@@ -108,10 +112,22 @@ def _atomic(path, name, write):
     os.replace(tmp, os.path.join(path, name))
 
 
+def file_checksum(fname):
+    """sum over the file's bytes b_i (i from 1) of i * b_i, modulo 2^64: the same three lines in julia/MGNHip.jl."""
+    b = np.fromfile(fname, np.uint8).astype(np.uint64)
+    with np.errstate(over="ignore"):
+        return int((np.arange(1, b.size + 1, dtype=np.uint64) * b).sum(dtype=np.uint64))
+
+
+def _manifest_lines(path, names):
+    return ["%s,%d,%d\n" % (n, os.path.getsize(os.path.join(path, n)), file_checksum(os.path.join(path, n))) for n in names]
+
+
 # ---- the four files ----------------------------------------------------------------------------------------------------------------
 def write_checkpoint(path, ps, e_norm, n_norm, o_norm, opt_state, df_train, df_valid):
-    """Everything `save!` is given.  Each file is written beside its target and renamed (a run killed inside leaves the previous
-    checkpoint whole); the parameters go last -- `read_checkpoint` keys on them."""
+    """Everything `save!` is given.  Each file is written beside its target and renamed, the manifest (sizes and checksums of the four)
+    last: a run killed inside leaves either the previous checkpoint whole or a directory whose manifest does not match, which
+    `read_checkpoint` refuses."""
     os.makedirs(path, exist_ok=True)
     norms = {}
     snapshot(e_norm, "e_norm", norms)
@@ -137,6 +153,12 @@ def write_checkpoint(path, ps, e_norm, n_norm, o_norm, opt_state, df_train, df_v
     _atomic(path, CKPT_LOG, w_log)
     _atomic(path, CKPT_PARAMS, lambda tmp: np.ascontiguousarray(ps, "<f4").tofile(tmp))
 
+    def w_manifest(tmp):
+        with open(tmp, "w") as f:
+            f.writelines(_manifest_lines(path, (CKPT_NORMS, CKPT_OPT, CKPT_LOG, CKPT_PARAMS)))
+
+    _atomic(path, CKPT_MANIFEST, w_manifest)
+
 
 def read_checkpoint(path, nparams, e_norm, n_norm, o_norm, want_opt_state=True):
     """-> None when `path` holds no checkpoint, else (ps, e_norm, n_norm, o_norm, opt_state, df_train, df_valid) with the stored
@@ -147,6 +169,14 @@ def read_checkpoint(path, nparams, e_norm, n_norm, o_norm, want_opt_state=True):
         return None
     if os.path.getsize(pfile) != 4 * nparams:
         raise ValueError("checkpoint %s holds %d bytes, this model has %d" % (pfile, os.path.getsize(pfile), 4 * nparams))
+    mfile = os.path.join(path, CKPT_MANIFEST)
+    if os.path.isfile(mfile):          # (absent: a checkpoint written before the manifest existed -- taken as it is)
+        for line in open(mfile):
+            name, size, chk = line.strip().split(",")
+            f = os.path.join(path, name)
+            if not os.path.isfile(f) or os.path.getsize(f) != int(size) or file_checksum(f) != int(chk):
+                raise ValueError("checkpoint in %s is torn: %s is not the file its manifest lists (a run was killed inside save!; the "
+                                 "directory mixes two saves)" % (path, name))
     ps = np.fromfile(pfile, "<f4").astype(np.float32)
     nfile = os.path.join(path, CKPT_NORMS)
     if os.path.isfile(nfile):

@@ -2550,17 +2550,26 @@ int mgn_edge_set_export(mgn_handle* h, int32_t set, int32_t* senders, int32_t* r
     if (h->cfg.nranks != 1) return fail(h, MGN_E_STATE, "mgn_edge_set_export drives one partition");
     const int64_t E = h->g.set[set].e_local;
     if (E > 0 && (!senders || !receivers)) return fail(h, MGN_E_ARG, "mgn_edge_set_export: null output");
+    // every array crosses the boundary in the CALLER's node numbering: a renumbered handle (graph_host.h) holds engine-order ids and maps
+    // them back on the host -- so it is decided BEFORE anything is written whether the outputs can be walked by the host (a device
+    // output on a renumbered handle is refused with its buffers untouched; an output the runtime cannot classify counts as device memory
+    // unless it is plain host memory the runtime has never seen)
+    if (h->g.renumbered && E > 0) {
+        for (const int32_t* p : {senders, receivers}) {
+            hipPointerAttribute_t at{};
+            const hipError_t e = hipPointerGetAttributes(&at, p);
+            (void)hipGetLastError();
+            const bool host_walkable = e == hipErrorInvalidValue /* unregistered host memory */ ||
+                                       (e == hipSuccess && (at.type == hipMemoryTypeHost || at.type == hipMemoryTypeUnregistered || at.type == hipMemoryTypeManaged));
+            if (!host_walkable) return fail(h, MGN_E_UNSUPPORTED, "mgn_edge_set_export: device output on a renumbered handle (pass host arrays)");
+        }
+    }
     if (E > 0) {
         HIPCHK(h, hipMemcpyAsync(senders, h->es[set].d_snd.p, (size_t)E * 4, hipMemcpyDefault, h->stream));
         HIPCHK(h, hipMemcpyAsync(receivers, h->es[set].d_rcv.p, (size_t)E * 4, hipMemcpyDefault, h->stream));
     }
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    // every array crosses the boundary in the CALLER's node numbering: a renumbered handle (graph_host.h) holds engine-order ids
     if (h->g.renumbered && E > 0) {
-        hipPointerAttribute_t at{};
-        const bool dev = hipPointerGetAttributes(&at, senders) == hipSuccess && at.type == hipMemoryTypeDevice;
-        (void)hipGetLastError();
-        if (dev) return fail(h, MGN_E_UNSUPPORTED, "mgn_edge_set_export: device output on a renumbered handle (pass host arrays)");
         for (int64_t j = 0; j < E; ++j) {
             senders[j] = h->g.own_gid[(size_t)senders[j]];
             receivers[j] = h->g.own_gid[(size_t)receivers[j]];

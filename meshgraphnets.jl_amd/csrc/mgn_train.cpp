@@ -258,120 +258,135 @@ int prepare_graph(mgn_engine* h) {
     HIPCHK(h, T.idx.ensure(ix.size() * 4));
     HIPCHK(h, hipMemcpy(T.idx.p, ix.data(), ix.size() * 4, hipMemcpyHostToDevice));
 
-    size_t off = 0;
-    auto take = [&](size_t n) { const size_t o = off; off += (n + 63) / 64 * 64; return o; };
-    auto take_acts = [&](size_t n) { Acts a; for (int b = 0; b < NB; ++b) for (int i = 0; i < 3; ++i) a.h[b][i] = take(n); return a; };
-    T.nf_raw = take((size_t)N * h->cfg.Fn);
-    T.nf_pad = take(NL);
-    T.a_en = take_acts(NL);
-    T.a_de = take_acts(NL);
-    for (int q = 0; q < S; ++q) {
-        T.ef_raw[q] = take((size_t)g.set[q].e_local * h->es[q].Fe);
-        T.ef_pad[q] = take(EL[q]);
-        T.a_ee[q] = take_acts(EL[q]);
-    }
-    T.Enew = take(ELmax);
-    T.Vk.assign(mps + 1, 0);
-    T.Vk[0] = take(NL);
-    for (int q = 0; q < S; ++q) {
-        T.Ek[q].assign(mps + 1, 0);
-        T.agg[q].assign(mps, 0);
-        T.a_pe[q].assign(mps, Acts());
-        T.Ek[q][0] = take(EL[q]);
-    }
-    T.a_pn.assign(mps, Acts());
-    // Kept activations of the processor: 3 (E + N) L floats per launch unit and step when H1 / H2 / Y are stored.  Small meshes store
-    // them all.  Large ones store them for as many steps as the device's free memory holds (the last ones: the reverse pass meets them
-    // first) and recompute the rest in the reverse pass (one more forward per MLP; (E + 2 N) L floats per step kept): M-1M needs
-    // 61 GB with every step recomputed and 10.7 GB more per stored step, which is worth 4 ms of the step -- the part has 288 GB.
-    // MGN_TRAIN_RECOMPUTE = 0 / 1 forces all / none, MGN_TRAIN_KEEP_STEPS = n the count, MGN_TRAIN_RESERVE_GB what is left free (16).
+    auto layout = [&](int keep) -> size_t {
+        size_t off = 0;
+        auto take = [&](size_t n) { const size_t o = off; off += (n + 63) / 64 * 64; return o; };
+        auto take_acts = [&](size_t n) { Acts a; for (int b = 0; b < NB; ++b) for (int i = 0; i < 3; ++i) a.h[b][i] = take(n); return a; };
+        T.nf_raw = take((size_t)N * h->cfg.Fn);
+        T.nf_pad = take(NL);
+        T.a_en = take_acts(NL);
+        T.a_de = take_acts(NL);
+        for (int q = 0; q < S; ++q) {
+            T.ef_raw[q] = take((size_t)g.set[q].e_local * h->es[q].Fe);
+            T.ef_pad[q] = take(EL[q]);
+            T.a_ee[q] = take_acts(EL[q]);
+        }
+        T.Enew = take(ELmax);
+        T.Vk.assign(mps + 1, 0);
+        T.Vk[0] = take(NL);
+        for (int q = 0; q < S; ++q) {
+            T.Ek[q].assign(mps + 1, 0);
+            T.agg[q].assign(mps, 0);
+            T.a_pe[q].assign(mps, Acts());
+            T.Ek[q][0] = take(EL[q]);
+        }
+        T.a_pn.assign(mps, Acts());
+        // Kept activations of the processor: 3 (E + N) L floats per launch unit and step when H1 / H2 / Y are stored.  Small meshes store
+        // them all.  Large ones store them for as many steps as the device's free memory holds (the last ones: the reverse pass meets them
+        // first) and recompute the rest in the reverse pass (one more forward per MLP; (E + 2 N) L floats per step kept): M-1M needs
+        // 61 GB with every step recomputed and 10.7 GB more per stored step, which is worth 4 ms of the step -- the part has 288 GB.
+        // The default takes what hipMemGetInfo reports free minus a reserve (MGN_TRAIN_RESERVE_GB, 16): the FIRST handle of a process (or the
+        // first process on a device) gets the stored steps, a later one sees what is left and recomputes; the size of the arena with no
+        // step stored is taken from a dry run of this very layout, and an allocation that fails all the same (another process took the
+        // memory between the query and the request) is retried with fewer stored steps, down to none (train_graph_build's caller).
+        // MGN_TRAIN_RECOMPUTE = 0 / 1 forces all / none, MGN_TRAIN_KEEP_STEPS = n the count.
+        T.keep_steps = keep;
+        T.recompute = T.keep_steps < mps;
+        Acts shared_e[MAX_EDGE_SETS], shared_n;
+        if (T.recompute) {
+            for (int q = 0; q < S; ++q) shared_e[q] = take_acts(EL[q]);
+            shared_n = take_acts(NL);
+        }
+        for (int k = 0; k < mps; ++k) {
+            for (int q = 0; q < S; ++q) {
+                T.a_pe[q][k] = T.kept(k, mps) ? take_acts(EL[q]) : shared_e[q];
+                T.agg[q][k] = take(NL);
+                T.Ek[q][k + 1] = take(EL[q]);
+            }
+            T.a_pn[k] = T.kept(k, mps) ? take_acts(NL) : shared_n;
+            T.Vk[k + 1] = take(NL);
+        }
+        const size_t ML = NL > ELmax ? NL : ELmax;
+        // Above the cooperative range the first layer of the edge MLPs is factored as in the inference kernels: per NODE
+        // P = v W1_sender, Q = v W1_receiver (2 chunk passes over N rows instead of 2 over E rows), backward and weight gradients
+        // through the summed rows of GZ1 (gather <-> segmented-sum duality).  MGN_TRAIN_FACTORED = 0 / 1 overrides the size rule.
+        bool any_fact = false, all_fact = true;
+        for (int q = 0; q < S; ++q) {
+            const int64_t E = g.set[q].e_local;
+            T.factored[q] = !train_uses_coop(128, (int)((E + TILE - 1) / TILE));   // the size rule of the cooperative kernels, for every L
+            if (const char* e = getenv("MGN_TRAIN_FACTORED")) T.factored[q] = atoi(e) != 0;
+            if (E == 0) T.factored[q] = false;
+            any_fact = any_fact || T.factored[q];
+            all_fact = all_fact && T.factored[q];
+        }
+        // Small meshes (the cooperative-tile regime: a launch leaves most of the chip idle) get GSETS sets of gradient buffers so
+        // that the parameter gradients can run on a second stream; larger ones fill the chip on their own and keep one set.
+        {
+            static const bool overlap_env = [] { const char* e = getenv("MGN_TRAIN_OVERLAP"); return !e || atoi(e) != 0; }();
+            const int64_t big = Emax > N ? Emax : N;
+            T.gsets = (overlap_env && !T.recompute && !any_fact && L == 128 && big <= 2048 * TILE) ? TrainState::GSETS : 1;   // (SGs / SGr are single buffers)
+        }
+        for (int i = 0; i < T.gsets; ++i) { T.GT[i] = take(ML); T.GXH[i] = take(ML); T.GY[i] = take(ML); T.GZ2[i] = take(ML); T.GZ1[i] = take(ML); }
+        T.GXs = T.GXr = T.Pn = T.Qn = T.SGs = T.SGr = T.GXB = 0;
+        if (any_fact) { T.Pn = take(NL); T.Qn = take(NL); T.SGs = take(NL); T.SGr = take(NL); }
+        if (!all_fact) { T.GXs = take(ELmax); T.GXr = take(ELmax); }
+        if (NB > 1) T.GXB = take(ML);                      // gradient handed from an MLP's second launch unit to its first
+        T.gV[0] = take(NL); T.gV[1] = take(NL);
+        for (int q = 0; q < S; ++q) { T.gE[q][0] = take(EL[q]); T.gE[q][1] = take(EL[q]); T.gAgg[q] = take(NL); }
+        T.Gout = take(NL);
+        T.gNF = take(NL);
+        T.io = take((size_t)(N > 0 ? N : 1) * (2 * h->cfg.O + h->cfg.Fn + 1));
+        T.ptmp = take((size_t)(N > 0 ? N : 1) * (size_t)std::max(h->cfg.Fn, h->cfg.O));      // row permutations of a renumbered graph
+        const int nb = std::max(wgrad_blocks(N), wgrad_blocks(Emax));
+        T.pw = take((size_t)5 * (T.gsets > 1 ? T.gsets / 2 : 1) * (nb > 0 ? nb : 1) * L * L);   // one partial-dW region per weight-gradient job of a launch (a group of units on small meshes)
+        T.pb = take((size_t)WGRAD_MAX_JOBS * (nb > 0 ? nb : 1) * L);
+        if (h->cfg.ln_dims == MGN_LN_ALL) {
+            int slot = 0;
+            T.m_en.lnslot = slot++;
+            for (int q = 0; q < S; ++q) T.m_ee[q].lnslot = slot++;
+            for (int k = 0; k < mps; ++k) {
+                for (int q = 0; q < S; ++q) T.m_pe[q][k].lnslot = slot++;
+                T.m_pn[k].lnslot = slot++;
+            }
+            T.lnstats = take((size_t)64 * slot);
+            const size_t nt_max = (std::max<size_t>(NL, ELmax) / L + TILE - 1) / TILE;
+            T.lnpart = take((size_t)2 * std::max<size_t>({(size_t)2 * array_stats_blocks(), (size_t)2 * 128 * lnall_bwd_blocks(), (size_t)2 * 4 * nt_max}));
+            T.lnm = take(64);
+        }
+        return off;
+    };
+    int keep0 = mps;
     {
         double rows = (double)NL;
         for (int q = 0; q < S; ++q) rows += (double)EL[q];
         const double per_step = 3.0 * NB * rows * 4.0, stored = (double)mps * per_step;
-        T.keep_steps = mps;
         if (stored > 48e9) {
-            T.keep_steps = 0;
+            keep0 = 0;
             T.arena.release();                             // (an earlier graph's arena must not count as taken)
             size_t free_b = 0, total_b = 0;
             if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
                 double reserve = 16e9;
                 if (const char* e = getenv("MGN_TRAIN_RESERVE_GB")) reserve = atof(e) * 1e9;
-                // what the arena takes with every step recomputed: inputs / aggregates per step, one shared set of activations, the
-                // gradient buffers (~ 6 (E + N) L) and the partial weight gradients
-                const double base = ((double)mps * (rows + (double)NL) + 12.0 * NB * rows) * 4.0 + 2e9;
+                const double base = (double)layout(0) * 4.0;          // the arena with every step recomputed: a dry run of the layout below
                 const double room = (double)free_b - base - reserve;
-                if (room > 0) T.keep_steps = (int)std::min<double>((double)mps, room / per_step);
+                if (room > 0) keep0 = (int)std::min<double>((double)mps, room / per_step);
             }
         }
-        if (const char* e = getenv("MGN_TRAIN_RECOMPUTE")) T.keep_steps = atoi(e) != 0 ? 0 : mps;
-        if (const char* e = getenv("MGN_TRAIN_KEEP_STEPS")) T.keep_steps = std::max(0, std::min(mps, atoi(e)));
-        T.recompute = T.keep_steps < mps;
+        if (const char* e = getenv("MGN_TRAIN_RECOMPUTE")) keep0 = atoi(e) != 0 ? 0 : mps;
+        if (const char* e = getenv("MGN_TRAIN_KEEP_STEPS")) keep0 = std::max(0, std::min(mps, atoi(e)));
     }
-    Acts shared_e[MAX_EDGE_SETS], shared_n;
-    if (T.recompute) {
-        for (int q = 0; q < S; ++q) shared_e[q] = take_acts(EL[q]);
-        shared_n = take_acts(NL);
-    }
-    for (int k = 0; k < mps; ++k) {
-        for (int q = 0; q < S; ++q) {
-            T.a_pe[q][k] = T.kept(k, mps) ? take_acts(EL[q]) : shared_e[q];
-            T.agg[q][k] = take(NL);
-            T.Ek[q][k + 1] = take(EL[q]);
-        }
-        T.a_pn[k] = T.kept(k, mps) ? take_acts(NL) : shared_n;
-        T.Vk[k + 1] = take(NL);
-    }
-    const size_t ML = NL > ELmax ? NL : ELmax;
-    // Above the cooperative range the first layer of the edge MLPs is factored as in the inference kernels: per NODE
-    // P = v W1_sender, Q = v W1_receiver (2 chunk passes over N rows instead of 2 over E rows), backward and weight gradients
-    // through the summed rows of GZ1 (gather <-> segmented-sum duality).  MGN_TRAIN_FACTORED = 0 / 1 overrides the size rule.
-    bool any_fact = false, all_fact = true;
-    for (int q = 0; q < S; ++q) {
-        const int64_t E = g.set[q].e_local;
-        T.factored[q] = !train_uses_coop(128, (int)((E + TILE - 1) / TILE));   // the size rule of the cooperative kernels, for every L
-        if (const char* e = getenv("MGN_TRAIN_FACTORED")) T.factored[q] = atoi(e) != 0;
-        if (E == 0) T.factored[q] = false;
-        any_fact = any_fact || T.factored[q];
-        all_fact = all_fact && T.factored[q];
-    }
-    // Small meshes (the cooperative-tile regime: a launch leaves most of the chip idle) get GSETS sets of gradient buffers so
-    // that the parameter gradients can run on a second stream; larger ones fill the chip on their own and keep one set.
-    {
-        static const bool overlap_env = [] { const char* e = getenv("MGN_TRAIN_OVERLAP"); return !e || atoi(e) != 0; }();
-        const int64_t big = Emax > N ? Emax : N;
-        T.gsets = (overlap_env && !T.recompute && !any_fact && L == 128 && big <= 2048 * TILE) ? TrainState::GSETS : 1;   // (SGs / SGr are single buffers)
-    }
-    for (int i = 0; i < T.gsets; ++i) { T.GT[i] = take(ML); T.GXH[i] = take(ML); T.GY[i] = take(ML); T.GZ2[i] = take(ML); T.GZ1[i] = take(ML); }
-    T.GXs = T.GXr = T.Pn = T.Qn = T.SGs = T.SGr = T.GXB = 0;
-    if (any_fact) { T.Pn = take(NL); T.Qn = take(NL); T.SGs = take(NL); T.SGr = take(NL); }
-    if (!all_fact) { T.GXs = take(ELmax); T.GXr = take(ELmax); }
-    if (NB > 1) T.GXB = take(ML);                      // gradient handed from an MLP's second launch unit to its first
-    T.gV[0] = take(NL); T.gV[1] = take(NL);
-    for (int q = 0; q < S; ++q) { T.gE[q][0] = take(EL[q]); T.gE[q][1] = take(EL[q]); T.gAgg[q] = take(NL); }
-    T.Gout = take(NL);
-    T.gNF = take(NL);
-    T.io = take((size_t)(N > 0 ? N : 1) * (2 * h->cfg.O + h->cfg.Fn + 1));
-    T.ptmp = take((size_t)(N > 0 ? N : 1) * (size_t)std::max(h->cfg.Fn, h->cfg.O));      // row permutations of a renumbered graph
-    const int nb = std::max(wgrad_blocks(N), wgrad_blocks(Emax));
-    T.pw = take((size_t)5 * (T.gsets > 1 ? T.gsets / 2 : 1) * (nb > 0 ? nb : 1) * L * L);   // one partial-dW region per weight-gradient job of a launch (a group of units on small meshes)
-    T.pb = take((size_t)WGRAD_MAX_JOBS * (nb > 0 ? nb : 1) * L);
-    if (h->cfg.ln_dims == MGN_LN_ALL) {
-        int slot = 0;
-        T.m_en.lnslot = slot++;
-        for (int q = 0; q < S; ++q) T.m_ee[q].lnslot = slot++;
-        for (int k = 0; k < mps; ++k) {
-            for (int q = 0; q < S; ++q) T.m_pe[q][k].lnslot = slot++;
-            T.m_pn[k].lnslot = slot++;
-        }
-        T.lnstats = take((size_t)64 * slot);
-        const size_t nt_max = (std::max<size_t>(NL, ELmax) / L + TILE - 1) / TILE;
-        T.lnpart = take((size_t)2 * std::max<size_t>({(size_t)2 * array_stats_blocks(), (size_t)2 * 128 * lnall_bwd_blocks(), (size_t)2 * 4 * nt_max}));
-        T.lnm = take(64);
+    T.drop_graphs();
+    size_t off = 0;
+    int test_fail = 0;                                    // MGN_TRAIN_TEST_FAIL_ALLOCS = n: the first n requests count as refused (tests of the retry)
+    if (const char* e = getenv("MGN_TRAIN_TEST_FAIL_ALLOCS")) test_fail = atoi(e);
+    for (int keep = keep0;; keep = keep / 2) {            // an allocation that fails is retried with fewer stored steps (none at last)
+        off = layout(keep);
+        if (test_fail-- <= 0 && T.arena.ensure(off * 4) == hipSuccess) break;
+        (void)hipGetLastError();
+        T.arena.release();
+        if (keep == 0) return fail(h, MGN_E_OOM, "training arena: %.1f GB with every processor step recomputed do not fit the device's free memory", (double)off * 4e-9);
     }
     T.arena_floats = off;
-    T.drop_graphs();
-    HIPCHK(h, T.arena.ensure(off * 4));
     HIPCHK(h, T.target.ensure((size_t)(N > 0 ? N : 1) * h->cfg.O * 4));
     T.g2l.clear();
     T.mask_valid = false;

@@ -915,6 +915,9 @@ DEVINL void h2_layer_ring(f32x16 (&acc)[4], f32x16 (&in)[4], const u32x4* hi, co
 #ifndef MGN_RINGH_ESTORE_LAST
 #define MGN_RINGH_ESTORE_LAST 0   // (1 spills 64 registers in the epilogue: not run) 1: this tile's e stores behind the next tile's Q request (0: right behind the residual, k_edge_ring's order)
 #endif
+#ifndef MGN_RINGH_STORE_INTERLEAVE
+#define MGN_RINGH_STORE_INTERLEAVE 1   // 1: a block's residual + e stores right behind its LayerNorm (0: all sixteen stores behind the LayerNorm)
+#endif
 #ifndef MGN_RINGH_SCAN_SKIP
 #define MGN_RINGH_SCAN_SKIP 1     // the scan's row_shr:8 level behind a wave-uniform branch (taken only by tiles with a receiver run of nine edges or more inside a 16-lane row)
 #endif
@@ -1090,13 +1093,29 @@ __global__ __launch_bounds__(NWV * 64, NWV / 4) void k_edge_ring_h(const EdgeArg
 #pragma unroll
                     for (int i = 0; i < 4; ++i) acc[t][4 * g + i] = acc[t][4 * g + i] * rstd * gv[i] + bv[i];
                 }
+#if MGN_RINGH_STORE_INTERLEAVE && !MGN_RINGH_ESTORE_LAST && !defined(MGN_WHATIF_H)
+                // the block's residual and its four stores right behind its LayerNorm: the stores of the first blocks are on their way while the
+                // others are still normalised
+                er[t] += acc[t];
+                if (valid) {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        f32x4 v;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) v[i] = er[t][4 * g + i];
+                        etile[(4 * t + g) * STRIDE_TILE] = v;
+                    }
+                }
+#endif
             }
         }
         CST(6);
         EST(2);
+#if !(MGN_RINGH_STORE_INTERLEAVE && !MGN_RINGH_ESTORE_LAST && !defined(MGN_WHATIF_H))
 #pragma unroll
         for (int t = 0; t < NT; ++t) er[t] += acc[t];                // e <- e + e'
-#if !MGN_RINGH_ESTORE_LAST
+#endif
+#if !MGN_RINGH_ESTORE_LAST && !(MGN_RINGH_STORE_INTERLEAVE && !defined(MGN_WHATIF_H))
 #if defined(MGN_WHATIF_H) && (MGN_WHATIF_H & 2)
         if (valid && a.E < 0) ring_store_e(etile, er);
 #else
@@ -1419,6 +1438,15 @@ __global__ __launch_bounds__(512, 2) void k_project_split(const NodeArgs a) {
 #ifndef MGN_SPH_D
 #define MGN_SPH_D 8              // depth of the lo-piece ring of k_node_split_h
 #endif
+#ifndef MGN_NODE_NEXT_FIRST
+#define MGN_NODE_NEXT_FIRST 0    // k_node_split_h: the next tile's v requested ahead of this tile's stores (the residual's sum goes to the other array)
+#endif
+#ifndef MGN_PROJ_VREFILL
+#define MGN_PROJ_VREFILL 0       // k_project_split_h: k-steps of the Q chain's input refilled with the next tile's v inside the chain
+#endif
+#ifndef MGN_NODE_VREFILL
+#define MGN_NODE_VREFILL 6       // k_node_split_h: k-steps of layer 3's input refilled with v (for the residual) inside the chain; 0: v requested after the chain
+#endif
 __global__ __launch_bounds__(512, 2) void k_node_split_h(const NodeArgs a) {
     constexpr int NT = 4, L = 128, PC = 16384, D = MGN_SPH_D;
     static_assert(32 % D == 0, "the carried ring keeps offset 0 from chain to chain");
@@ -1450,8 +1478,11 @@ __global__ __launch_bounds__(512, 2) void k_node_split_h(const NodeArgs a) {
     if (tw.tile >= tw.end) return;
     f32x16 x[NT], acc[NT];
     load_frag<NT>(x, tile_ptr(a.V, tw.tile, L, lane0), STRIDE_TILE);
-    for (;;) {
+    int stamp_tile = 0;
+    (void)stamp_tile;
+    for (;; ++stamp_tile) {
         OPAQUE_LANE();
+        STAMP(0);
         const int tile = tw.tile;
         const int next = tile + tw.stride;
         const bool has_next = next < tw.end;
@@ -1464,29 +1495,62 @@ __global__ __launch_bounds__(512, 2) void k_node_split_h(const NodeArgs a) {
         const H2Scale sv = h2_scale(h2_rowmax<true>(x));
         zero_frag<NT>(acc);
         h2_layer_otf<true, 0, D, 0, false, true>(acc, x, lvh, gv, lane, sv.s, 0.f, nullptr, &rg, ga);            // layer 1, node part
+        STAMP(1);
         LOAD_AGGREGATE(NT, x, a.rowptr, a.AGG, a.CARRY, a.zero_row);
         h2_finish_frag<NT>(acc, sv.rs * rswv, tb + T_B1 * L, h);                                                  // true units, b1 in
         const H2Scale sa = h2_scale(h2_rowmax<true>(x));
         h2_scale_frag<NT>(acc, sa.s * swa);                                                                       // the aggregate chain's units
+        STAMP(2);
         h2_layer_otf<true, 0, D, 0, true, true>(acc, x, lah, ga, lane, sa.s, 0.f, nullptr, &rg, g2);             // layer 1, aggregate part
+        STAMP(3);
         const H2Scale s2 = h2_scale(h2_rowmax<false>(acc));                                                       // (on the raw accumulators)
         zero_frag<NT>(x);
         h2_layer_otf<true, 1, D, 0, true, true>(x, acc, l2h, g2, lane, s2.s, 0.f, nullptr, &rg, g3);             // layer 2
+        STAMP(4);
         const float c2 = s2.rs * rsw2 * (sa.rs * rswa);
         const H2Scale s3 = h2_scale(__builtin_fmaf(h2_rowmax<false>(x), c2, b2pos));
         zero_frag<NT>(acc);
+#if MGN_NODE_VREFILL
+        // layer 3; the registers of its input are refilled, as the split releases them, with v again (for the residual)
+        h2_layer_otf<true, 2, D, 0, true, false, MGN_NODE_VREFILL, STRIDE_TILE>(acc, x, l3h, g3, lane, s3.s, c2, tb + T_B2 * L + 4 * h, &rg, nullptr, vtile);
+        STAMP(5);
+        PHASE_FENCE();
+        __builtin_amdgcn_s_setprio(MGN_NODE_MPRIO);
+        h2_load_tail<MGN_NODE_VREFILL, STRIDE_TILE>(x, vtile);
+#else
         h2_layer_otf<true, 2, D, 0, true, false>(acc, x, l3h, g3, lane, s3.s, c2, tb + T_B2 * L + 4 * h, &rg);   // layer 3
+        STAMP(5);
         PHASE_FENCE();
         __builtin_amdgcn_s_setprio(MGN_NODE_MPRIO);
         load_frag<NT>(x, vtile, STRIDE_TILE);                        // v again, for the residual
+#endif
         h2_finish_frag<NT>(acc, s3.rs * rsw3, tb + T_B3 * L, h);
         layer_norm_frag<NT>(acc, tb + T_GAMMA * L, tb + T_BETA * L, h);
+#if MGN_NODE_NEXT_FIRST
+        // the next tile's v is requested AHEAD of this tile's stores (s_waitcnt vmcnt retires in order and counts stores): it lands in acc's
+        // registers and moves over at the end of the tile (64 v_mov: hipcc spilled ~80 registers when the sum went to acc instead)
 #pragma unroll
         for (int t = 0; t < NT; ++t) x[t] += acc[t];                 // v <- v + v'
+        STAMP(6);
+        PHASE_FENCE();
+        load_frag<NT>(acc, tile_ptr(a.V, has_next ? next : tile, L, lane), STRIDE_TILE);   // (the last tile requests itself: no branch around the request)
+        PHASE_FENCE();
         if (valid) store_frag<NT>(vtile, STRIDE_TILE, x);
+        STAMP(7);
+        if (!has_next) break;
+        PHASE_FENCE();
+#pragma unroll
+        for (int t = 0; t < NT; ++t) x[t] = acc[t];
+#else
+#pragma unroll
+        for (int t = 0; t < NT; ++t) x[t] += acc[t];                 // v <- v + v'
+        STAMP(6);
+        if (valid) store_frag<NT>(vtile, STRIDE_TILE, x);
+        STAMP(7);
         if (!has_next) break;
         PHASE_FENCE();
         load_frag<NT>(x, tile_ptr(a.V, next, L, lane), STRIDE_TILE);
+#endif
         tw.tile = next;
     }
 }
@@ -1531,6 +1595,16 @@ __global__ __launch_bounds__(512, 2) void k_project_split_h(const NodeArgs a) {
         if (valid) store_frag<NT>(prow_ptr(a.P, nn, L, h), STRIDE_PROW, acc);
         NODE_CHAIN_PRIO();
         zero_frag<NT>(acc);
+#if MGN_PROJ_VREFILL
+        // the second chain's input registers are refilled, as the split releases them, with the NEXT tile's v
+        const f32x4* vnext = tile_ptr(a.V, a.tile0 + (has_next ? next : tw.tile), L, lane);
+        h2_layer_otf<false, 0, 1, 0, false, false, MGN_PROJ_VREFILL, STRIDE_TILE>(acc, x, lqh, lql, lane, sv.s, 0.f, nullptr, nullptr, nullptr, vnext);
+        __builtin_amdgcn_s_setprio(MGN_NODE_MPRIO);
+        h2_load_tail<MGN_PROJ_VREFILL, STRIDE_TILE>(x, vnext);
+        h2_finish_frag<NT>(acc, sv.rs * rswq, tb + T_BQ * L, h);
+        if (valid) store_frag<NT>(prow_ptr(a.Q, nn, L, h), STRIDE_PROW, acc);
+        if (!has_next) break;
+#else
         h2_layer_otf<false, 0, 1>(acc, x, lqh, lql, lane, sv.s);
         __builtin_amdgcn_s_setprio(MGN_NODE_MPRIO);
         h2_finish_frag<NT>(acc, sv.rs * rswq, tb + T_BQ * L, h);
@@ -1538,6 +1612,7 @@ __global__ __launch_bounds__(512, 2) void k_project_split_h(const NodeArgs a) {
         if (!has_next) break;
         PHASE_FENCE();
         load_frag<NT>(x, tile_ptr(a.V, a.tile0 + next, L, lane), STRIDE_TILE);
+#endif
         tw.tile = next;
     }
 }

@@ -135,10 +135,15 @@ DEVINL u32x4 n16_ldu(const N16Buf& b, unsigned voff, int soff) { return __builti
 // One L x L layer on two fp16 pieces, `in` split on the fly with the row scale sx (split.hip: the node-side kernels; train.hip: the
 // streaming training kernels).  p_hi LDS-resident; p_lo LDS-resident too (GL = false) or streamed from L2 through ONE per-wave register
 // ring D fragments deep that can be carried from chain to chain (carry / PRIMED / NEXT / nx_lo: see sp_layer_otf in split.hip).
+// Refill (RFN > 0; round 6): the registers of `in`'s k-step s are dead once step s has begun (its pieces were computed during step s - 1), so
+// k-steps 0 .. RFN - 1 are refilled, as they are released, with pieces 2 s, 2 s + 1 of what the caller needs NEXT from memory (rf: the
+// lane's pointer to piece 0, RFS: f32x4 stride between pieces) -- the loads travel while the chain runs; pieces 2 RFN .. 15 are the caller's
+// (h2_load_tail).  `in` is written through the const reference in that case only.
 template <int D> struct SpRingH { u32x4 r[D]; };
-template <bool GL, int FIN, int D, int OFF = 0, bool PRIMED = false, bool NEXT = false>
+template <bool GL, int FIN, int D, int OFF = 0, bool PRIMED = false, bool NEXT = false, int RFN = 0, int RFS = 0>
 DEVINL void h2_layer_otf(f32x16 (&acc)[4], const f32x16 (&in)[4], const u32x4* p_hi, const u32x4* p_lo, int lane, float sx, float cfin = 0.f,
-                         const float* btab = nullptr, SpRingH<D>* carry = nullptr, const u32x4* nx_lo = nullptr) {
+                         const float* btab = nullptr, SpRingH<D>* carry = nullptr, const u32x4* nx_lo = nullptr, const f32x4* rf = nullptr) {
+    f32x16 (&inw)[4] = const_cast<f32x16 (&)[4]>(in);
     const u32x4* w1 = p_hi + lane;
     const u32x4* w2 = p_lo + lane;
     const N16Buf b2 = n16_buf(GL ? p_lo : nullptr);
@@ -186,6 +191,13 @@ DEVINL void h2_layer_otf(f32x16 (&acc)[4], const f32x16 (&in)[4], const u32x4* p
                 if (it + D < 32) r2[(it + OFF) % D] = n16_ldu(b2, voff, (it + D) * 1024);
                 else if constexpr (NEXT) r2[(it + OFF) % D] = n16_ldu(c2, voff, (it + D - 32) * 1024);
             }
+            if constexpr (RFN > 0) {
+                if ((t & 1) && s < RFN) {                              // registers of k-step s, half t >> 1
+                    const f32x4 v = rf[(2 * s + (t >> 1)) * RFS];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) inw[s >> 1][8 * (s & 1) + 4 * (t >> 1) + i] = v[i];
+                }
+            }
             if (s < 7) {
                 const int sn = s + 1;
                 const f32x2 b = bias(sn, t);
@@ -211,6 +223,16 @@ DEVINL void h2_layer_otf(f32x16 (&acc)[4], const f32x16 (&in)[4], const u32x4* p
     if constexpr (NEXT) {
 #pragma unroll
         for (int d = 0; d < D; ++d) carry->r[d] = r2[d];
+    }
+}
+// pieces 2 RFN .. 15 of a fragment (what a chain's refill leaves to its caller)
+template <int RFN, int RFS>
+DEVINL void h2_load_tail(f32x16 (&x)[4], const f32x4* p) {
+#pragma unroll
+    for (int m = 2 * RFN; m < 16; ++m) {
+        const f32x4 v = p[m * RFS];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) x[m >> 2][4 * (m & 3) + i] = v[i];
     }
 }
 template <int NT>

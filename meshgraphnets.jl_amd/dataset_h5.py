@@ -121,7 +121,8 @@ def create_edges(dims, node_type, no_edges_node_types):
         raise ValueError("ArgumentError: 2D-Meshes are not supported yet")
     if len(dims) != 3:
         return edges
-    nt = np.asarray(node_type).reshape(-1)
+    nt = np.asarray(node_type)
+    nt = nt[0, :, 0] if nt.ndim == 3 else nt.reshape(-1)    # node_type[1, li, 1] of the reference's (dim, count, tl) array = [tl][count][dim] here
     excluded = set(int(x) for x in no_edges_node_types)
     dx, dy, dz = dims
     li = lambda x, y, z: dims_to_li(dims, (x, y, z))       # noqa: E731
@@ -150,12 +151,17 @@ def read_edges(traj, edge_key, node_type, no_edges_node_types, exclude_node_indi
     if edge_key not in traj:
         raise KeyError(f"Key '{edge_key}' not found in trajectory group '{traj.name}'")
     raw = traj.read(edge_key)
-    if raw.ndim != 1:
-        raise TypeError(f"MethodError: filter! on a {raw.ndim}-dimensional edge dataset (the reference needs a vector of pairs)")
+    rank = traj.rank(edge_key)
+    if rank != 1:
+        raise TypeError(f"MethodError: filter! on a {rank}-dimensional edge dataset (the reference needs a vector of pairs)")
     if raw.dtype.names:
         if len(raw.dtype.names) < 2:
             raise IndexError("BoundsError: edge elements need two fields")
         a, b = raw[raw.dtype.names[0]], raw[raw.dtype.names[1]]
+    elif raw.ndim == 2:                       # a vector of fixed arrays (H5T_ARRAY elements): numpy shows the element's axis
+        if raw.shape[1] < 2:
+            raise IndexError("BoundsError: edge elements need two entries")
+        a, b = raw[:, 0], raw[:, 1]
     else:
         raise IndexError("BoundsError: attempt to access a scalar edge element at index [2]")
     del node_type, no_edges_node_types
@@ -253,7 +259,10 @@ def read_h5(datafile, data_keys, meta, is_jld=False):
 
 def load_dataset_h5(path, is_training, file):
     """The `jld2` / `h5` arm of load_dataset (reference src/dataset.jl:118-166).  Returns (meta, generator over the training or test
-    trajectories, generator over the validation trajectories or None); meta gains n_trajectories (and n_trajectories_valid)."""
+    trajectories, generator over the validation trajectories or None); meta gains n_trajectories (and n_trajectories_valid).
+    Order of the trajectories: `keys(file)` -- HDF5.jl lists an .h5 file's links in name order, as here; JLD2.jl's `keys` of a .jld2 file
+    returns them in the order they were written, which libhdf5 cannot see unless the file tracks creation order, so for .jld2 files the
+    SET of trajectories is the reference's and their order may differ (name order here)."""
     with open(os.path.join(path, "meta.json")) as f:
         meta = json.load(f)
     is_jld = file.endswith("jld2")

@@ -250,6 +250,19 @@ class Group:
                 if ident >= 0:
                     closer(ident)
 
+    def rank(self, name):
+        """number of dimensions of the dataset's DATASPACE (a vector of array-typed elements has rank 1 and reads as a 2-d numpy array)"""
+        lib = self._lib
+        did = lib.H5Dopen2(self._id, name.encode(), H5P_DEFAULT)
+        if did < 0:
+            raise KeyError(f"dataset '{name}' not found in '{self.name}'")
+        sid = lib.H5Dget_space(did)
+        try:
+            return int(lib.H5Sget_simple_extent_ndims(sid))
+        finally:
+            lib.H5Sclose(sid)
+            lib.H5Dclose(did)
+
     def __getitem__(self, name):
         """`file[k]`: a group if the link is one, else the dataset's contents."""
         gid = self._lib.H5Gopen2(self._id, name.encode(), H5P_DEFAULT)

@@ -18,4 +18,7 @@ timeout 600 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ
 timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- "${CMD[@]}" > $OUT/pmc_fetch.log 2>&1
 timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- "${CMD[@]}" > $OUT/pmc_write.log 2>&1
 timeout 600 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum --output-format csv -d $OUT/pmc_tcc -- "${CMD[@]}" > $OUT/pmc_tcc.log 2>&1
+# (round 6) how many of the L2's memory-side requests are addressed to this device's DRAM (the others: IO / GMI) -- the Infinity Cache sits in
+# front of the memory controller, these counters do not tell its hits from misses
+timeout 600 rocprofv3 --pmc TCC_EA0_RDREQ_DRAM_sum TCC_EA0_WRREQ_DRAM_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_WRREQ_64B_sum --output-format csv -d $OUT/pmc_tcc2 -- "${CMD[@]}" > $OUT/pmc_tcc2.log 2>&1
 find $OUT -name "*.csv" | head -50

@@ -120,6 +120,9 @@ def line1d():
                 g["t"] = np.float32(0.5)
                 edges = np.array([(1, 2), (3, 2), (2, 3), (5, 6), (4, 5), (1, 3)], dtype=edge_t)
                 g["edge_list"] = edges
+                # the same pairs as a vector of fixed arrays (H5T_ARRAY[2] elements): read_edges' other documented element kind
+                arr = g.create_dataset("edge_list_arr", (6,), dtype=np.dtype(("<i4", (2,))))
+                arr[...] = np.array([(1, 2), (3, 2), (2, 3), (5, 6), (4, 5), (1, 3)], np.int32)
                 tag = os.path.basename(folder) + "/" + fname.split(".")[0] + "/" + name
                 expected[tag + "/mesh_pos"] = x[None, :, None]
                 expected[tag + "/node_type"] = kind[None, :, None]

@@ -39,7 +39,7 @@ def test_checkpoint_round_trips_all_four(tmp_path):
     va.step += [200]
     va.loss += [np.float32(0.125)]
     ck.write_checkpoint(str(tmp_path), ps, e, n, o, st, tr, va)
-    assert sorted(os.listdir(tmp_path)) == sorted([ck.CKPT_PARAMS, ck.CKPT_LOG, ck.CKPT_NORMS, ck.CKPT_OPT])   # no .tmp left behind
+    assert sorted(os.listdir(tmp_path)) == sorted([ck.CKPT_PARAMS, ck.CKPT_LOG, ck.CKPT_NORMS, ck.CKPT_OPT, ck.CKPT_MANIFEST])   # no .tmp left behind
 
     e2, n2, o2 = _norms(rng, accumulate=False)                     # what calc_norms hands to load: empty statistics
     x = rng.normal(2.0, 3.0, (7, 3)).astype(np.float32)
@@ -73,10 +73,39 @@ def test_checkpoint_refuses_what_would_evaluate_wrongly(tmp_path):
     with pytest.raises(ValueError, match="NormaliserOnline"):                          # kinds must match the training run's
         ck.read_checkpoint(str(tmp_path), 10, ra.NormaliserOfflineMeanStd(0.0, 1.0), *_norms(rng, False)[1:])
     os.remove(tmp_path / ck.CKPT_NORMS)                                                # a checkpoint from before normalisers were stored
+    os.remove(tmp_path / ck.CKPT_MANIFEST)                                             # (... and before the manifest)
     with pytest.raises(ValueError, match="online"):
         ck.read_checkpoint(str(tmp_path), 10, *_norms(rng, False))
     off = ra.NormaliserOfflineMinMax(0.0, 1.0)                                         # offline ones are rebuilt by calc_norms: fine
     assert ck.read_checkpoint(str(tmp_path), 10, off, {"node_type": off}, {"velocity": off}) is not None
+
+
+def test_checkpoint_torn_between_two_saves_is_refused(tmp_path):
+    """Every file is renamed into place on its own: a run killed between two renames leaves the normalisers / optimiser state of save
+    k + 1 beside the parameters of save k.  The manifest (written last) does not match then, and the directory is refused."""
+    import shutil
+    rng = np.random.default_rng(2)
+    e, n, o = _norms(rng)
+    opt = ck.Adam(1e-3)
+    ps = rng.normal(size=100).astype(np.float32)
+    st = opt.setup(ps)
+    a, b = tmp_path / "a", tmp_path / "b"
+    ck.write_checkpoint(str(a), ps, e, n, o, st, ck.LossLog(), ck.LossLog())
+    st2, ps2 = opt.update(st, ps, rng.normal(size=ps.size).astype(np.float32))
+    e(rng.normal(size=(10, 3)).astype(np.float32))
+    ck.write_checkpoint(str(b), ps2, e, n, o, st2, ck.LossLog(), ck.LossLog())
+    assert ck.read_checkpoint(str(a), ps.size, *_norms(rng, False)) is not None
+    for torn in (ck.CKPT_OPT, ck.CKPT_NORMS):                       # save k + 1 got as far as this file
+        d = tmp_path / ("torn_" + torn)
+        shutil.copytree(a, d)
+        shutil.copy(b / torn, d / torn)
+        with pytest.raises(ValueError, match="torn"):
+            ck.read_checkpoint(str(d), ps.size, *_norms(rng, False))
+    # the checksum is position-weighted: two files with the same bytes in another order differ
+    f1, f2 = tmp_path / "f1", tmp_path / "f2"
+    f1.write_bytes(bytes([1, 2, 3, 250]))
+    f2.write_bytes(bytes([250, 3, 2, 1]))
+    assert ck.file_checksum(str(f1)) == 1 + 4 + 9 + 1000 and ck.file_checksum(str(f1)) != ck.file_checksum(str(f2))
 
 
 def test_julia_shim_saves_and_loads_all_four():
@@ -85,6 +114,8 @@ def test_julia_shim_saves_and_loads_all_four():
     text = open(os.path.join(ROOT, "julia", "MGNHip.jl")).read()
     save = text[text.index("function save!("):text.index("# ---- graph ----")]
     load = text[text.index("function load("):text.index('"""\n`save!(')]
+    assert save.index("atomically(CKPT_MANIFEST)") > save.index("atomically(CKPT_PARAMS)") and "file_checksum(f) == parse(UInt64, chk)" in load
+    assert "mgn_hip_manifest.txt" in text and ck.CKPT_MANIFEST == "mgn_hip_manifest.txt"
     for const in ("CKPT_PARAMS", "CKPT_LOG", "CKPT_NORMS", "CKPT_OPT"):
         assert re.search(r"atomically\(%s\)" % const, save), const
         assert const in load, const

@@ -109,6 +109,13 @@ def test_whole_mesh_datasets_custom_edges_and_the_jld2_arm():
     assert t["u"].shape == (3, 6, 1) and t["dt"].shape == () and t["dt"] == np.float32(0.5)
     # custom edges: the compound dataset, minus edges touching exclude_node_indices = [6], sorted as vectors
     assert t["edges"].tolist() == [[1, 2], [1, 3], [2, 3], [3, 2], [4, 5]]
+    # ... and the same pairs stored as a vector of fixed arrays (H5T_ARRAY[2] elements; a rank-1 dataset that numpy shows as (E, 2))
+    with h5.File(os.path.join(GOLD, "line1d", "test.h5"), "r") as f:
+        g = f.open_group("only")
+        assert g.rank("edge_list_arr") == 1 and g.read("edge_list_arr").shape == (6, 2)
+        assert sorted(dh.read_edges(g, "edge_list_arr", None, [], [6])) == [[1, 2], [1, 3], [2, 3], [3, 2], [4, 5]]
+        with pytest.raises(TypeError, match="2-dimensional"):
+            dh.read_edges(g, "u", None, [], [])                 # a matrix is not a vector of pairs (Julia: MethodError in filter!)
     # train.jld2 is preferred over train.h5 (src/dataset.jl:94-100); no custom edges there: the 1-D chain
     jl = ra.load_dataset(os.path.join(GOLD, "line1d_jld"), True)
     assert jl.file.endswith("train.jld2") and jl.file_valid.endswith("valid.jld2")

@@ -272,6 +272,34 @@ def test_recompute_mode_gives_the_same_gradients(monkeypatch):
     check_grads(res[1][0], ref, cfg)
 
 
+def test_arena_allocation_is_retried_with_fewer_stored_steps(monkeypatch):
+    """The arena of a large mesh takes what the device reports free; a request that is refused all the same (another process was faster)
+    is retried with half the stored steps, down to none (MGN_TRAIN_TEST_FAIL_ALLOCS counts requests as refused): same bits, and a
+    clean MGN_E_OOM when even the arena without stored steps is refused."""
+    import ctypes as C
+    cfg = cfg_dict(L=128, mps=3)
+    pos, s, r = small_mesh(12, 9)
+    ps = make_params(cfg)
+    nf, ef, target, mask = problem(cfg, pos, s, r, seed=21)
+    res = []
+    for fails, want in ((0, 3), (1, 1), (2, 0)):
+        monkeypatch.setenv("MGN_TRAIN_TEST_FAIL_ALLOCS", str(fails))
+        eng = engine_for(cfg)
+        eng.set_params(ps)
+        eng.set_graph(s, r, pos.shape[0])
+        res.append(eng.step(nf, ef, target, mask))
+        eng.lib.mgn_debug_train_keep_steps.argtypes = [C.c_void_p]
+        assert eng.lib.mgn_debug_train_keep_steps(eng.h) == want
+    for other in res[1:]:
+        assert res[0][1] == other[1] and np.array_equal(res[0][0], other[0])
+    monkeypatch.setenv("MGN_TRAIN_TEST_FAIL_ALLOCS", "3")
+    eng = engine_for(cfg)
+    eng.set_params(ps)
+    eng.set_graph(s, r, pos.shape[0])
+    with pytest.raises(mgn_amd.MgnError):
+        eng.step(nf, ef, target, mask)
+
+
 def test_step_device_arrays_and_graph_replay():
     """nf / ef / target / grads may live on the device (hipMemcpyDefault, include/mgn_hip.h): same bits as the host call.  Four
     calls in a row take the small-mesh path through its three stages -- eager, hipGraph capture, replay (forward and backward
