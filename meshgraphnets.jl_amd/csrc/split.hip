@@ -1494,23 +1494,41 @@ __global__ __launch_bounds__(512, 2) void k_node_split_h(const NodeArgs a) {
         SpRingH<D> rg;
         const H2Scale sv = h2_scale(h2_rowmax<true>(x));
         zero_frag<NT>(acc);
+#ifdef MGN_WHATIF_NODEH          // timing-only build (wrong results): every lo piece read from LDS (the hi piece's bytes): what the L2 stream costs
+        h2_layer_otf<false, 0, 1>(acc, x, lvh, lvh, lane, sv.s);
+#else
         h2_layer_otf<true, 0, D, 0, false, true>(acc, x, lvh, gv, lane, sv.s, 0.f, nullptr, &rg, ga);            // layer 1, node part
+#endif
         STAMP(1);
         LOAD_AGGREGATE(NT, x, a.rowptr, a.AGG, a.CARRY, a.zero_row);
         h2_finish_frag<NT>(acc, sv.rs * rswv, tb + T_B1 * L, h);                                                  // true units, b1 in
         const H2Scale sa = h2_scale(h2_rowmax<true>(x));
         h2_scale_frag<NT>(acc, sa.s * swa);                                                                       // the aggregate chain's units
         STAMP(2);
+#ifdef MGN_WHATIF_NODEH
+        h2_layer_otf<false, 0, 1>(acc, x, lah, lah, lane, sa.s);
+#else
         h2_layer_otf<true, 0, D, 0, true, true>(acc, x, lah, ga, lane, sa.s, 0.f, nullptr, &rg, g2);             // layer 1, aggregate part
+#endif
         STAMP(3);
         const H2Scale s2 = h2_scale(h2_rowmax<false>(acc));                                                       // (on the raw accumulators)
         zero_frag<NT>(x);
+#ifdef MGN_WHATIF_NODEH
+        h2_layer_otf<false, 1, 1>(x, acc, l2h, l2h, lane, s2.s);
+#else
         h2_layer_otf<true, 1, D, 0, true, true>(x, acc, l2h, g2, lane, s2.s, 0.f, nullptr, &rg, g3);             // layer 2
+#endif
         STAMP(4);
         const float c2 = s2.rs * rsw2 * (sa.rs * rswa);
         const H2Scale s3 = h2_scale(__builtin_fmaf(h2_rowmax<false>(x), c2, b2pos));
         zero_frag<NT>(acc);
-#if MGN_NODE_VREFILL
+#ifdef MGN_WHATIF_NODEH
+        h2_layer_otf<false, 2, 1, 0, false, false, 6, STRIDE_TILE>(acc, x, l3h, l3h, lane, s3.s, c2, tb + T_B2 * L + 4 * h, nullptr, nullptr, vtile);
+        STAMP(5);
+        PHASE_FENCE();
+        __builtin_amdgcn_s_setprio(MGN_NODE_MPRIO);
+        h2_load_tail<6, STRIDE_TILE>(x, vtile);
+#elif MGN_NODE_VREFILL
         // layer 3; the registers of its input are refilled, as the split releases them, with v again (for the residual)
         h2_layer_otf<true, 2, D, 0, true, false, MGN_NODE_VREFILL, STRIDE_TILE>(acc, x, l3h, g3, lane, s3.s, c2, tb + T_B2 * L + 4 * h, &rg, nullptr, vtile);
         STAMP(5);
