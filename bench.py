@@ -876,6 +876,26 @@ def main():
                 mids[f"N={posm.shape[0]},E={sm.size}"] = {"us_per_processor_step": dtm / (km * MPS) * 1e6, "edges_per_s": sm.size * MPS * km / dtm}
                 engm.close()
             out["secondary"]["mid_size_meshes"] = mids
+            # what the memory system gives a plain device copy of an array of the e latents' size (read + write counted): the yardstick for
+            # the bytes per second the processor kernels move by the counters (roofline.traffic / avg_launch_ms)
+            try:
+                nbytes = int(E) * L * 4
+                src_t = torch.empty(nbytes // 4, dtype=torch.float32, device=f"cuda:{local_rank}").normal_()
+                dst_t = torch.empty_like(src_t)
+                for _ in range(3):
+                    dst_t.copy_(src_t)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(10):
+                    dst_t.copy_(src_t)
+                torch.cuda.synchronize()
+                tc = (time.perf_counter() - t0) / 10
+                out["secondary"]["memory_system"] = {"device_copy_GBps_read_plus_write": 2.0 * nbytes / tc / 1e9, "bytes_copied": nbytes,
+                                                     "note": "torch tensor copy (a streaming kernel) of an array of the e latents' size on this box; the edge "
+                                                             "kernel moves `roofline.traffic` bytes per launch in `avg_launch_ms`"}
+                del src_t, dst_t
+            except Exception as ex:   # noqa: BLE001
+                out["secondary"]["memory_system"] = {"error": str(ex)[:200]}
             try:
                 out["secondary"]["scaling_model"] = scaling_model(ps, pos, s, r, N, E, t_step, local_rank, barrier_sync)
             except Exception as ex:   # noqa: BLE001
