@@ -455,6 +455,12 @@ DEVINL void ring_store_e(f32x4* p, const f32x16 (&x)[4]) {
         else *q = v;
     }
 }
+DEVINL void ring_store_e_piece(f32x4* q, f32x4 v) {
+    if constexpr (MGN_RING_ESTORE == 1) __builtin_nontemporal_store(v, q);
+    else if constexpr (MGN_RING_ESTORE == 2) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(q), "v"(v) : "memory");
+    else if constexpr (MGN_RING_ESTORE == 3) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(q), "v"(v) : "memory");
+    else *q = v;
+}
 DEVINL void ring_load_e(f32x16 (&x)[4], const f32x4* p) {
 #pragma unroll
     for (int m = 0; m < 16; ++m) {
@@ -1103,7 +1109,7 @@ __global__ __launch_bounds__(NWV * 64, NWV / 4) void k_edge_ring_h(const EdgeArg
                         f32x4 v;
 #pragma unroll
                         for (int i = 0; i < 4; ++i) v[i] = er[t][4 * g + i];
-                        etile[(4 * t + g) * STRIDE_TILE] = v;
+                        ring_store_e_piece(etile + (4 * t + g) * STRIDE_TILE, v);
                     }
                 }
 #endif
