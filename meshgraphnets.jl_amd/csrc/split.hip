@@ -437,8 +437,8 @@ DEVINL void sp_layer_ring(f32x16 (&acc)[4], f32x16 (&in)[4], const u32x4* hi, co
 
 // the e tile leaves the chip once per step and comes back 3 GB later: cache policy of its stores / loads (A/B switches)
 #ifndef MGN_RING_ESTORE
-#define MGN_RING_ESTORE 0        // 0 plain, 1 nt, 2 sc1, 3 sc0 sc1
-#endif
+#define MGN_RING_ESTORE 3        // 0 plain, 1 nt, 2 sc1, 3 sc0 sc1.  Round 3 (MFMA-bound kernel): plain was best by 1.5 %; round 6 (k_edge_ring_h, bound by
+#endif                           // the memory system): write-through stores 2.344 -> 2.310 / 2.406 -> 2.369 ms (the lines do not sit dirty in L2 between the P / Q rows)
 #ifndef MGN_RING_ELOAD
 #define MGN_RING_ELOAD 0         // 0 plain, 1 nt
 #endif
@@ -461,6 +461,30 @@ DEVINL void ring_store_e_piece(f32x4* q, f32x4 v) {
     else if constexpr (MGN_RING_ESTORE == 3) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(q), "v"(v) : "memory");
     else *q = v;
 }
+// store_frag with a cache policy: 0 plain, 1 nt, 2 sc1, 3 sc0 sc1 (write-through at system scope: the line does not stay dirty in L2)
+template <int NT, int POL>
+DEVINL void store_frag_pol(f32x4* __restrict__ p, int stride, const f32x16 (&x)[NT]) {
+#pragma unroll
+    for (int m = 0; m < 4 * NT; ++m) {
+        f32x4 v;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = x[m >> 2][4 * (m & 3) + i];
+        f32x4* q = p + m * stride;
+        if constexpr (POL == 1) __builtin_nontemporal_store(v, q);
+        else if constexpr (POL == 2) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(q), "v"(v) : "memory");
+        else if constexpr (POL == 3) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(q), "v"(v) : "memory");
+        else *q = v;
+    }
+}
+#ifndef MGN_AGG_STORE
+#define MGN_AGG_STORE 0          // k_edge_ring_h: policy of the aggregate / carry-row stores
+#endif
+#ifndef MGN_NODE_STORE
+#define MGN_NODE_STORE 0         // k_node_split_h: policy of the v stores
+#endif
+#ifndef MGN_PROJ_STORE
+#define MGN_PROJ_STORE 0         // k_project_split_h: policy of the P / Q stores
+#endif
 DEVINL void ring_load_e(f32x16 (&x)[4], const f32x4* p) {
 #pragma unroll
     for (int m = 0; m < 16; ++m) {
@@ -1164,7 +1188,7 @@ __global__ __launch_bounds__(NWV * 64, NWV / 4) void k_edge_ring_h(const EdgeArg
 #if defined(MGN_WHATIF_H) && (MGN_WHATIF_H & 32)
         if (tail && a.E < 0) store_frag<NT>(dst, to_carry ? STRIDE_PROW : STRIDE_TILE, acc);
 #else
-        if (tail) store_frag<NT>(dst, to_carry ? STRIDE_PROW : STRIDE_TILE, acc);
+        if (tail) store_frag_pol<NT, MGN_AGG_STORE>(dst, to_carry ? STRIDE_PROW : STRIDE_TILE, acc);
 #endif
         EST(6);
         PHASE_FENCE();
@@ -1559,7 +1583,7 @@ __global__ __launch_bounds__(512, 2) void k_node_split_h(const NodeArgs a) {
         PHASE_FENCE();
         load_frag<NT>(acc, tile_ptr(a.V, has_next ? next : tile, L, lane), STRIDE_TILE);   // (the last tile requests itself: no branch around the request)
         PHASE_FENCE();
-        if (valid) store_frag<NT>(vtile, STRIDE_TILE, x);
+        if (valid) store_frag_pol<NT, MGN_NODE_STORE>(vtile, STRIDE_TILE, x);
         STAMP(7);
         if (!has_next) break;
         PHASE_FENCE();
@@ -1569,7 +1593,7 @@ __global__ __launch_bounds__(512, 2) void k_node_split_h(const NodeArgs a) {
 #pragma unroll
         for (int t = 0; t < NT; ++t) x[t] += acc[t];                 // v <- v + v'
         STAMP(6);
-        if (valid) store_frag<NT>(vtile, STRIDE_TILE, x);
+        if (valid) store_frag_pol<NT, MGN_NODE_STORE>(vtile, STRIDE_TILE, x);
         STAMP(7);
         if (!has_next) break;
         PHASE_FENCE();
@@ -1616,7 +1640,7 @@ __global__ __launch_bounds__(512, 2) void k_project_split_h(const NodeArgs a) {
         h2_layer_otf<false, 0, 1>(acc, x, lph, lpl, lane, sv.s);
         __builtin_amdgcn_s_setprio(MGN_NODE_MPRIO);
         h2_scale_frag<NT>(acc, sv.rs * rswp);
-        if (valid) store_frag<NT>(prow_ptr(a.P, nn, L, h), STRIDE_PROW, acc);
+        if (valid) store_frag_pol<NT, MGN_PROJ_STORE>(prow_ptr(a.P, nn, L, h), STRIDE_PROW, acc);
         NODE_CHAIN_PRIO();
         zero_frag<NT>(acc);
 #if MGN_PROJ_VREFILL
@@ -1626,13 +1650,13 @@ __global__ __launch_bounds__(512, 2) void k_project_split_h(const NodeArgs a) {
         __builtin_amdgcn_s_setprio(MGN_NODE_MPRIO);
         h2_load_tail<MGN_PROJ_VREFILL, STRIDE_TILE>(x, vnext);
         h2_finish_frag<NT>(acc, sv.rs * rswq, tb + T_BQ * L, h);
-        if (valid) store_frag<NT>(prow_ptr(a.Q, nn, L, h), STRIDE_PROW, acc);
+        if (valid) store_frag_pol<NT, MGN_PROJ_STORE>(prow_ptr(a.Q, nn, L, h), STRIDE_PROW, acc);
         if (!has_next) break;
 #else
         h2_layer_otf<false, 0, 1>(acc, x, lqh, lql, lane, sv.s);
         __builtin_amdgcn_s_setprio(MGN_NODE_MPRIO);
         h2_finish_frag<NT>(acc, sv.rs * rswq, tb + T_BQ * L, h);
-        if (valid) store_frag<NT>(prow_ptr(a.Q, nn, L, h), STRIDE_PROW, acc);
+        if (valid) store_frag_pol<NT, MGN_PROJ_STORE>(prow_ptr(a.Q, nn, L, h), STRIDE_PROW, acc);
         if (!has_next) break;
         PHASE_FENCE();
         load_frag<NT>(x, tile_ptr(a.V, a.tile0 + next, L, lane), STRIDE_TILE);
