@@ -437,8 +437,8 @@ DEVINL void sp_layer_ring(f32x16 (&acc)[4], f32x16 (&in)[4], const u32x4* hi, co
 
 // the e tile leaves the chip once per step and comes back 3 GB later: cache policy of its stores / loads (A/B switches)
 #ifndef MGN_RING_ESTORE
-#define MGN_RING_ESTORE 3        // 0 plain, 1 nt, 2 sc1, 3 sc0 sc1.  Round 3 (MFMA-bound kernel): plain was best by 1.5 %; round 6 (k_edge_ring_h, bound by
-#endif                           // the memory system): write-through stores 2.344 -> 2.310 / 2.406 -> 2.369 ms (the lines do not sit dirty in L2 between the P / Q rows)
+#define MGN_RING_ESTORE 0        // 0 plain, 1 nt, 2 sc1, 3 sc0 sc1 (2, 3: inline assembly -- A/B ONLY: the compiler does not see a store there, so neither its
+#endif                           // hazard recogniser nor its counters do; with 3 the eight-partition M-1M test lost reproducibility.  The product's write-through stores: MGN_RING_EST_BUF)
 #ifndef MGN_RING_ELOAD
 #define MGN_RING_ELOAD 0         // 0 plain, 1 nt
 #endif
@@ -842,10 +842,12 @@ struct RhSrc {
 // One L x L layer (sp_layer_ring with two pieces).  sx: the row's scale; FIN / cfin / btab: see h2_split_pair (btab = the bias table of
 // the layer BEFORE, lane half's offset included).  Refill: schedule 2 of sp_layer_ring (one request every second step; WRAP: no
 // rotation, the last two k-steps' pieces are the caller's).
-template <int W, int LYR, int FIN, int RFS = 0, int NWV = 8, bool WRAP = false>
+// RFPOL >= 0 (WRAP refill only): the refill's requests as buffer loads with these cache-policy bits (rfb: the tile's descriptor; lane offset
+// 16 lane, piece m at m KiB) instead of plain loads through `rf`.
+template <int W, int LYR, int FIN, int RFS = 0, int NWV = 8, bool WRAP = false, int RFPOL = -1>
 DEVINL void h2_layer_ring(f32x16 (&acc)[4], f32x16 (&in)[4], const u32x4* hi, const u32x4* hi_next, u32x4* ring, const RhSrc& src,
                           RhFrag& nx, RhPend<W / NWV>& pend, int lane, int tid, float sx, float cfin = 0.f, const float* btab = nullptr,
-                          const f32x4* rf = nullptr) {
+                          const f32x4* rf = nullptr, const N16Buf* rfb = nullptr) {
     constexpr int ROT = 2;
     constexpr int WPL = Rh<W>::WPL, NW = Rh<W>::NW, BUF = Rh<W>::BUF, NB = Rh<W>::NB, AHEAD = MGN_RINGH_AHEAD;
     f32x4 side[2 * ROT];
@@ -887,7 +889,9 @@ DEVINL void h2_layer_ring(f32x16 (&acc)[4], f32x16 (&in)[4], const u32x4* hi, co
 #endif
             if constexpr (RFS > 0) {
                 if ((t & 1) && s < 8 - ROT) {                          // registers of k-step s (free since the step began), half t >> 1
-                    const f32x4 v = rf[(2 * (WRAP ? s : s + ROT) + (t >> 1)) * RFS];
+                    f32x4 v;
+                    if constexpr (WRAP && RFPOL >= 0) v = n16_ld_pol<RFPOL>(*rfb, (unsigned)lane * 16u, (2 * s + (t >> 1)) * 1024);
+                    else v = rf[(2 * (WRAP ? s : s + ROT) + (t >> 1)) * RFS];
 #pragma unroll
                     for (int i = 0; i < 4; ++i) in[s >> 1][8 * (s & 1) + 4 * (t >> 1) + i] = v[i];
                 }
@@ -944,6 +948,18 @@ DEVINL void h2_layer_ring(f32x16 (&acc)[4], f32x16 (&in)[4], const u32x4* hi, co
 #endif
 #ifndef MGN_RINGH_ESTORE_LAST
 #define MGN_RINGH_ESTORE_LAST 0   // (1 spills 64 registers in the epilogue: not run) 1: this tile's e stores behind the next tile's Q request (0: right behind the residual, k_edge_ring's order)
+#endif
+#ifndef MGN_RING_EST_BUF
+#define MGN_RING_EST_BUF 0       // k_edge_ring_h (with MGN_RINGH_STORE_INTERLEAVE): the e stores as buffer stores with these policy bits (17 = sc0 sc1: write-through);
+                                 // 0: plain global stores.  As compiler-visible instructions write-through is worth nothing (2.299 -> 2.295 ms): the 1.5 % the
+                                 // inline-assembly form showed came with a lost reproducibility test (MGN_RING_ESTORE above)
+#endif
+#ifndef MGN_RING_ENEXT_POL
+#define MGN_RING_ENEXT_POL 0     // k_edge_ring_h: the next tile's e requests as buffer loads (a scalar descriptor + one lane offset: no 64-bit address arithmetic
+                                 // inside layer 3) with these cache-policy bits (1 sc0, 2 nt, 16 sc1; 0 = plain: 2.337 -> 2.304 ms, the policies add nothing); -1: global loads
+#endif
+#ifndef MGN_RING_ER_POL
+#define MGN_RING_ER_POL -1       // ... of the second read of this tile's e
 #endif
 #ifndef MGN_RINGH_STORE_INTERLEAVE
 #define MGN_RINGH_STORE_INTERLEAVE 1   // 1: a block's residual + e stores right behind its LayerNorm (0: all sixteen stores behind the LayerNorm)
@@ -1069,19 +1085,48 @@ __global__ __launch_bounds__(NWV * 64, NWV / 4) void k_edge_ring_h(const EdgeArg
 #else
         const f32x4* enext = tile_ptr(a.Elat, nxt, L, lane);
 #endif
+#if MGN_RING_ENEXT_POL >= 0
+        const N16Buf enb = n16_buf(a.Elat + (int64_t)nxt * (TILE * L), TILE * L * 4);      // (nxt is wave-uniform)
+        h2_layer_ring<W, 2, 2, STRIDE_TILE, NWV, true, MGN_RING_ENEXT_POL>(acc, y, l3h, l1h, ring, src, nx, pend, lane, tid, x3.s, c2, tb + T_B2 * L + 4 * h, enext, &enb);
+#else
         h2_layer_ring<W, 2, 2, STRIDE_TILE, NWV, true>(acc, y, l3h, l1h, ring, src, nx, pend, lane, tid, x3.s, c2, tb + T_B2 * L + 4 * h, enext);
+#endif
         CST(5);
         EST(1);
         PHASE_FENCE();
         __builtin_amdgcn_s_setprio(MGN_PRIO);
         f32x16 er[NT];               // this tile's e again, for the residual (y holds the next tile's): arrives during the LayerNorm
+#if MGN_RING_EST_BUF
+        const N16Buf esb = n16_buf(a.Elat + (int64_t)tile * (TILE * L), TILE * L * 4);
+#endif
 #if defined(MGN_WHATIF_H) && (MGN_WHATIF_H & 1)
 #pragma unroll
         for (int t = 0; t < NT; ++t) er[t] = acc[t];
 #else
+#if MGN_RING_ER_POL >= 0
+        {
+            const N16Buf erb = n16_buf(a.Elat + (int64_t)tile * (TILE * L), TILE * L * 4);
+#pragma unroll
+            for (int m = 0; m < 16; ++m) {
+                const f32x4 v = n16_ld_pol<MGN_RING_ER_POL>(erb, (unsigned)lane * 16u, m * 1024);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) er[m >> 2][4 * (m & 3) + i] = v[i];
+            }
+        }
+#else
         ring_load_e(er, etile);
 #endif
+#endif
+#if MGN_RING_ENEXT_POL >= 0
+#pragma unroll
+        for (int m = 12; m < 16; ++m) {
+            const f32x4 v = n16_ld_pol<MGN_RING_ENEXT_POL>(enb, (unsigned)lane * 16u, m * 1024);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) y[3][4 * (m & 3) + i] = v[i];
+        }
+#else
         ring_load_e_tail(y, enext);                                  // k-steps 6 and 7 of the next tile's e
+#endif
         {   // bias + un-scaling of layer 3, then LayerNorm: acc = e'
             constexpr float invL = 1.0f / 128;
             const float c3 = x3.rs * rsw3;
@@ -1127,6 +1172,17 @@ __global__ __launch_bounds__(NWV * 64, NWV / 4) void k_edge_ring_h(const EdgeArg
                 // the block's residual and its four stores right behind its LayerNorm: the stores of the first blocks are on their way while the
                 // others are still normalised
                 er[t] += acc[t];
+#if MGN_RING_EST_BUF
+                {   // as buffer stores (compiler-visible instructions, unlike ring_store_e_piece's inline assembly: hazards and counters are the compiler's)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        f32x4 v;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) v[i] = er[t][4 * g + i];
+                        if (valid) n16_st_pol<MGN_RING_EST_BUF>(esb, (unsigned)lane * 16u, (4 * t + g) * 1024, v);
+                    }
+                }
+#else
                 if (valid) {
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
@@ -1136,6 +1192,7 @@ __global__ __launch_bounds__(NWV * 64, NWV / 4) void k_edge_ring_h(const EdgeArg
                         ring_store_e_piece(etile + (4 * t + g) * STRIDE_TILE, v);
                     }
                 }
+#endif
 #endif
             }
         }
@@ -1474,6 +1531,9 @@ __global__ __launch_bounds__(512, 2) void k_project_split(const NodeArgs a) {
 #ifndef MGN_PROJ_VREFILL
 #define MGN_PROJ_VREFILL 0       // k_project_split_h: k-steps of the Q chain's input refilled with the next tile's v inside the chain
 #endif
+#ifndef MGN_NODE_VBUF
+#define MGN_NODE_VBUF 0          // k_node_split_h: its v loads (the refill inside layer 3, the next tile's v) as buffer loads through the tile's descriptor
+#endif
 #ifndef MGN_NODE_VREFILL
 #define MGN_NODE_VREFILL 6       // k_node_split_h: k-steps of layer 3's input refilled with v (for the residual) inside the chain; 0: v requested after the chain
 #endif
@@ -1560,11 +1620,20 @@ __global__ __launch_bounds__(512, 2) void k_node_split_h(const NodeArgs a) {
         h2_load_tail<6, STRIDE_TILE>(x, vtile);
 #elif MGN_NODE_VREFILL
         // layer 3; the registers of its input are refilled, as the split releases them, with v again (for the residual)
+#if MGN_NODE_VBUF
+        const N16Buf vb = n16_buf(a.V + (int64_t)tile * (TILE * L), TILE * L * 4);          // (tile is wave-uniform)
+        h2_layer_otf<true, 2, D, 0, true, false, MGN_NODE_VREFILL, STRIDE_TILE, true>(acc, x, l3h, g3, lane, s3.s, c2, tb + T_B2 * L + 4 * h, &rg, nullptr, vtile, &vb);
+        STAMP(5);
+        PHASE_FENCE();
+        __builtin_amdgcn_s_setprio(MGN_NODE_MPRIO);
+        h2_load_tile_buf<2 * MGN_NODE_VREFILL>(x, vb, lane);
+#else
         h2_layer_otf<true, 2, D, 0, true, false, MGN_NODE_VREFILL, STRIDE_TILE>(acc, x, l3h, g3, lane, s3.s, c2, tb + T_B2 * L + 4 * h, &rg, nullptr, vtile);
         STAMP(5);
         PHASE_FENCE();
         __builtin_amdgcn_s_setprio(MGN_NODE_MPRIO);
         h2_load_tail<MGN_NODE_VREFILL, STRIDE_TILE>(x, vtile);
+#endif
 #else
         h2_layer_otf<true, 2, D, 0, true, false>(acc, x, l3h, g3, lane, s3.s, c2, tb + T_B2 * L + 4 * h, &rg);   // layer 3
         STAMP(5);
@@ -1597,7 +1666,14 @@ __global__ __launch_bounds__(512, 2) void k_node_split_h(const NodeArgs a) {
         STAMP(7);
         if (!has_next) break;
         PHASE_FENCE();
+#if MGN_NODE_VBUF
+        {
+            const N16Buf nb = n16_buf(a.V + (int64_t)next * (TILE * L), TILE * L * 4);
+            h2_load_tile_buf<0>(x, nb, lane);
+        }
+#else
         load_frag<NT>(x, tile_ptr(a.V, next, L, lane), STRIDE_TILE);
+#endif
 #endif
         tw.tile = next;
     }

@@ -126,6 +126,14 @@ DEVINL f32x4 n16_ld(const N16Buf& b, unsigned voff, int soff) {
 DEVINL void n16_st(const N16Buf& b, unsigned voff, int soff, f32x4 v) {
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, v), b.r, (int)voff, soff, 0);
 }
+template <int AUX>      // cache policy bits of the buffer instruction: 1 sc0, 2 nt, 16 sc1
+DEVINL f32x4 n16_ld_pol(const N16Buf& b, unsigned voff, int soff) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(b.r, (int)voff, soff, AUX));
+}
+template <int AUX>
+DEVINL void n16_st_pol(const N16Buf& b, unsigned voff, int soff, f32x4 v) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, v), b.r, (int)voff, soff, AUX);
+}
 DEVINL u32x4 n16_ldu(const N16Buf& b, unsigned voff, int soff) { return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(b.r, (int)voff, soff, 0)); }
 
 
@@ -140,9 +148,11 @@ DEVINL u32x4 n16_ldu(const N16Buf& b, unsigned voff, int soff) { return __builti
 // lane's pointer to piece 0, RFS: f32x4 stride between pieces) -- the loads travel while the chain runs; pieces 2 RFN .. 15 are the caller's
 // (h2_load_tail).  `in` is written through the const reference in that case only.
 template <int D> struct SpRingH { u32x4 r[D]; };
-template <bool GL, int FIN, int D, int OFF = 0, bool PRIMED = false, bool NEXT = false, int RFN = 0, int RFS = 0>
+// RFBUF: the refill's requests as buffer loads (rfb: the tile's descriptor, lane offset 16 lane, piece m at m KiB; tile-major arrays only).
+template <bool GL, int FIN, int D, int OFF = 0, bool PRIMED = false, bool NEXT = false, int RFN = 0, int RFS = 0, bool RFBUF = false>
 DEVINL void h2_layer_otf(f32x16 (&acc)[4], const f32x16 (&in)[4], const u32x4* p_hi, const u32x4* p_lo, int lane, float sx, float cfin = 0.f,
-                         const float* btab = nullptr, SpRingH<D>* carry = nullptr, const u32x4* nx_lo = nullptr, const f32x4* rf = nullptr) {
+                         const float* btab = nullptr, SpRingH<D>* carry = nullptr, const u32x4* nx_lo = nullptr, const f32x4* rf = nullptr,
+                         const N16Buf* rfb = nullptr) {
     f32x16 (&inw)[4] = const_cast<f32x16 (&)[4]>(in);
     const u32x4* w1 = p_hi + lane;
     const u32x4* w2 = p_lo + lane;
@@ -193,7 +203,9 @@ DEVINL void h2_layer_otf(f32x16 (&acc)[4], const f32x16 (&in)[4], const u32x4* p
             }
             if constexpr (RFN > 0) {
                 if ((t & 1) && s < RFN) {                              // registers of k-step s, half t >> 1
-                    const f32x4 v = rf[(2 * s + (t >> 1)) * RFS];
+                    f32x4 v;
+                    if constexpr (RFBUF) v = n16_ld(*rfb, (unsigned)lane * 16u, (2 * s + (t >> 1)) * 1024);
+                    else v = rf[(2 * s + (t >> 1)) * RFS];
 #pragma unroll
                     for (int i = 0; i < 4; ++i) inw[s >> 1][8 * (s & 1) + 4 * (t >> 1) + i] = v[i];
                 }
@@ -231,6 +243,16 @@ DEVINL void h2_load_tail(f32x16 (&x)[4], const f32x4* p) {
 #pragma unroll
     for (int m = 2 * RFN; m < 16; ++m) {
         const f32x4 v = p[m * RFS];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) x[m >> 2][4 * (m & 3) + i] = v[i];
+    }
+}
+// pieces M0 .. 15 of a tile-major fragment through the tile's descriptor
+template <int M0>
+DEVINL void h2_load_tile_buf(f32x16 (&x)[4], const N16Buf& b, int lane) {
+#pragma unroll
+    for (int m = M0; m < 16; ++m) {
+        const f32x4 v = n16_ld(b, (unsigned)lane * 16u, m * 1024);
 #pragma unroll
         for (int i = 0; i < 4; ++i) x[m >> 2][4 * (m & 3) + i] = v[i];
     }
