@@ -803,6 +803,22 @@ def main():
                                          "157.3 TFLOP/s; the step is HBM-bound in its backward and weight-gradient launches (profiles/r05); processor "
                                          "MLPs only (encoders / decoder, segmented sums, reductions not counted)"}}
                 engT.close()
+                # ... and with NO step stored (every processor MLP's forward recomputed in the reverse pass: what a device that is not
+                # empty gets; 61 GB instead of 61 + 10.7 per stored step)
+                os.environ["MGN_TRAIN_KEEP_STEPS"] = "0"
+                try:
+                    engT = mgn_amd.Engine(FN, FE, O, L, 2, MPS, device=local_rank)
+                    engT.set_params(ps)
+                    engT.set_graph(s, r, N)
+                    engT.step(nfT, efT, tgT, mkT)
+                    t0 = time.perf_counter()
+                    _, lossT0 = engT.step(nfT, efT, tgT, mkT)
+                    dtT0 = time.perf_counter() - t0
+                    out["secondary"]["train_step_1m"]["s_per_step_no_stored_steps"] = dtT0
+                    out["secondary"]["train_step_1m"]["same_loss_without_stored_steps"] = bool(lossT0 == lossT)
+                    engT.close()
+                finally:
+                    del os.environ["MGN_TRAIN_KEEP_STEPS"]
                 del nfT, efT, tgT
             except Exception as ex:   # noqa: BLE001  (a box with less free memory than the 61 GB this needs at least)
                 out["secondary"]["train_step_1m"] = {"error": str(ex)[:200]}
