@@ -131,6 +131,18 @@ int mgn_set_norms(mgn_handle* h, const float* node_scale, const float* node_shif
 int mgn_set_graph(mgn_handle* h, int32_t N, int64_t E, const int32_t* senders, const int32_t* receivers,
                   int32_t index_base, const float* mesh_pos, int32_t pos_dim);
 
+/* Rank-local ingest of the same graph (nranks > 1 at scale: mgn_set_graph walks the GLOBAL edge lists on every rank).
+ * mgn_partition_nodes: the node partition mgn_set_graph would derive -- recursive coordinate bisection of mesh_pos [N][pos_dim], or
+ * contiguous index blocks when mesh_pos is NULL -- as owner[N]; deterministic, no handle needed, every rank gets the same map.
+ * mgn_set_graph_local: rank h->cfg.rank hands over only the edges it has an END of (sender or receiver owned; the others concern
+ * neither its tiles nor its send lists), in the order of the global list, with their positions edge_gid[E_touch] (ascending) in that
+ * list of E_global edges.  The handle ends up in exactly the state mgn_set_graph(N, E_global, ...) with the same partition leaves it
+ * in (tests/test_abi_and_host.py); arrays indexed by edge at the boundary ([E][Fe] inputs, latents) stay GLOBAL arrays, of which the
+ * rank touches the rows of its local edges.  One edge set; index_base as in mgn_set_graph.                                          */
+int mgn_partition_nodes(int32_t N, const float* mesh_pos, int32_t pos_dim, int32_t nranks, int32_t* owner);
+int mgn_set_graph_local(mgn_handle* h, int32_t N, const int32_t* owner, int64_t E_global, int64_t E_touch, const int32_t* senders,
+                        const int32_t* receivers, const int64_t* edge_gid, int32_t index_base);
+
 /* Second edge set (n_edge_sets == 2): topology of set `set` (>= 1) over the same N nodes, after mgn_set_graph and
  * as often as it changes (world edges are re-searched every step of a cloth rollout; the mesh set, the node
  * partition and the node order stay).  Edges live with their receiver's owner like mesh edges; with nranks > 1

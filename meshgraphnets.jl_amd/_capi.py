@@ -57,6 +57,8 @@ PROTOTYPES = {
     "mgn_get_params": (C.c_int, [_H, _f32p, C.c_size_t]),
     "mgn_set_norms": (C.c_int, [_H, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p]),
     "mgn_set_graph": (C.c_int, [_H, C.c_int32, C.c_int64, _i32p, _i32p, C.c_int32, _f32p, C.c_int32]),
+    "mgn_partition_nodes": (C.c_int, [C.c_int32, _f32p, C.c_int32, C.c_int32, _i32p]),
+    "mgn_set_graph_local": (C.c_int, [_H, C.c_int32, _i32p, C.c_int64, C.c_int64, _i32p, _i32p, _i64p, C.c_int32]),
     "mgn_set_edge_set": (C.c_int, [_H, C.c_int32, C.c_int64, _i32p, _i32p, C.c_int32]),
     "mgn_set_edge_features": (C.c_int, [_H, C.c_int32, _f32p]),
     "mgn_edge_set_info": (C.c_int, [_H, C.c_int32, _i64p, _i64p]),

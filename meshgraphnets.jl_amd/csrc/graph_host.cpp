@@ -120,7 +120,13 @@ std::string build_local_graph(int32_t N, int nsets, const EdgeList* sets, const 
         const EdgeList& es = sets[k];
         if (es.E < 0) return "negative E";
         if (es.E > 0 && (!es.senders || !es.receivers)) return "null senders/receivers";
-        if (es.E >= ((int64_t)1 << 31)) return "E >= 2^31 not supported";
+        if (es.E >= ((int64_t)1 << 31) || es.E_global >= ((int64_t)1 << 31)) return "E >= 2^31 not supported";
+        if (es.gid) {
+            if (es.E_global < es.E) return "rank-local edge list longer than the global list it is a part of";
+            for (int64_t i = 0; i < es.E; ++i)
+                if (es.gid[i] < 0 || es.gid[i] >= es.E_global || (i > 0 && es.gid[i] <= es.gid[i - 1]))
+                    return "rank-local edge list: global positions must be ascending and inside [0, E_global)";
+        }
     }
     std::vector<int32_t> owner_keep;
     if (owner_in) owner_keep.assign(owner_in, owner_in + N);   // owner_in may alias g.owner
@@ -225,7 +231,7 @@ std::string build_local_graph(int32_t N, int nsets, const EdgeList* sets, const 
     for (int k = 0; k < nsets; ++k) {
         const EdgeList& es = sets[k];
         EdgeTopo& t = g.set[k];
-        t.E = es.E;
+        t.E = es.gid ? es.E_global : es.E;
         t.rowptr.assign((size_t)g.n_own + 1, 0);
         int64_t el = 0;
         for_edges(k, [&](int64_t, int32_t, int32_t r) {
@@ -246,7 +252,7 @@ std::string build_local_graph(int32_t N, int nsets, const EdgeList* sets, const 
             const int32_t p = cur[lr]++;
             t.snd[p] = g2l[s];
             t.rcv[p] = lr;
-            t.edge_gid[p] = i;
+            t.edge_gid[p] = es.gid ? es.gid[i] : i;
         });
         t.halo_span = 0;
         for (int64_t p = el - 1; p >= 0; --p)

@@ -43,11 +43,15 @@ struct LocalGraph {
 void rcb_partition(int32_t N, const float* pos, int32_t pos_dim, int32_t parts, std::vector<int32_t>& owner);
 
 // Global description of one edge set as the caller hands it over.
+// gid != null (rank-local ingest, mgn_set_graph_local): the arrays hold only the E edges this rank has an end of, in ascending global
+// position gid[i] of a global list of E_global edges that the rank never sees.
 struct EdgeList {
     int64_t E = 0;
     const int32_t* senders = nullptr;
     const int32_t* receivers = nullptr;
     int32_t index_base = 0;
+    const int64_t* gid = nullptr;
+    int64_t E_global = -1;
 };
 
 // Build rank `rank`'s local graph from `nsets` edge sets over the same nodes.  Node ownership comes from

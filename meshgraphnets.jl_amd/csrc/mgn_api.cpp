@@ -1075,14 +1075,14 @@ static int g_renumber = [] { const char* e = getenv("MGN_RENUMBER"); return e ? 
 
 // (re)build the local graph from the kept global edge lists and upload it.  keep_owner: node partition unchanged
 static int rebuild_graph(mgn_handle* h, int32_t N, const EdgeList* sets, const float* mesh_pos, int32_t pos_dim, bool keep_owner,
-                         const char* who) {
+                         const char* who, const int32_t* owner_in = nullptr) {
     h->have_graph = false;
     h->hx_ready = false;
     h->all_gid.clear();
     invalidate_static(h);
     train_invalidate(h, 2);
     if (!h->host_only) { (void)hipStreamSynchronize(h->stream); drop_graph(h); }
-    const std::string why = build_local_graph(N, h->nsets, sets, mesh_pos, pos_dim, keep_owner ? h->g.owner.data() : nullptr,
+    const std::string why = build_local_graph(N, h->nsets, sets, mesh_pos, pos_dim, owner_in ? owner_in : (keep_owner ? h->g.owner.data() : nullptr),
                                               h->cfg.rank, h->cfg.nranks, h->g,
                                               g_renumber);   // (the numbering follows set 0 alone: a later mgn_set_edge_set / mgn_world_edges_dev keeps it)
     if (!why.empty()) return fail(h, MGN_E_ARG, "%s: %s", who, why.c_str());
@@ -1128,6 +1128,35 @@ int mgn_set_graph(mgn_handle* h, int32_t N, int64_t E, const int32_t* senders, c
         h->es[1].have_ef = false;
     }
     if (int rc = rebuild_graph(h, N, sets, mesh_pos, pos_dim, false, "mgn_set_graph")) return rc;
+    if (h->host_only) return MGN_OK;
+    if (int rc = alloc_latents(h)) return rc;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    h->have_graph = true;
+    return MGN_OK;
+} MGN_CATCH(h)
+
+// Rank-local ingest (SURVEY.md 8e at scale): what mgn_set_graph computes from the global lists, from the rank's own part of them.
+int mgn_partition_nodes(int32_t N, const float* mesh_pos, int32_t pos_dim, int32_t nranks, int32_t* owner) try {
+    if (N < 0 || nranks < 1 || (N > 0 && !owner) || (mesh_pos && pos_dim <= 0)) return MGN_E_ARG;
+    std::vector<int32_t> o;
+    rcb_partition(N, mesh_pos, pos_dim, nranks, o);
+    if (N > 0) memcpy(owner, o.data(), (size_t)N * 4);
+    return MGN_OK;
+} MGN_CATCH(nullptr)
+
+int mgn_set_graph_local(mgn_handle* h, int32_t N, const int32_t* owner, int64_t E_global, int64_t E_touch, const int32_t* senders,
+                        const int32_t* receivers, const int64_t* edge_gid, int32_t index_base) try {
+    if (!h) return MGN_E_ARG;
+    if (h->nsets != 1) return fail(h, MGN_E_UNSUPPORTED, "mgn_set_graph_local: one edge set (a second set is rebuilt from the global lists)");
+    if (index_base != 0 && index_base != 1) return fail(h, MGN_E_ARG, "mgn_set_graph_local: index_base must be 0 or 1");
+    if (N < 0 || (N > 0 && !owner)) return fail(h, MGN_E_ARG, "mgn_set_graph_local: null owner map");
+    if (E_touch < 0 || E_global < E_touch || (E_touch > 0 && (!senders || !receivers || !edge_gid)))
+        return fail(h, MGN_E_ARG, "mgn_set_graph_local: null or inconsistent edge arrays");
+    for (int32_t i = 0; i < N; ++i)
+        if (owner[i] < 0 || owner[i] >= h->cfg.nranks) return fail(h, MGN_E_ARG, "mgn_set_graph_local: owner[%d] = %d outside [0, nranks)", i, owner[i]);
+    EdgeList sets[MAX_EDGE_SETS];
+    sets[0] = {E_touch, senders, receivers, index_base, edge_gid, E_global};
+    if (int rc = rebuild_graph(h, N, sets, nullptr, 0, false, "mgn_set_graph_local", owner)) return rc;
     if (h->host_only) return MGN_OK;
     if (int rc = alloc_latents(h)) return rc;
     HIPCHK(h, hipStreamSynchronize(h->stream));

@@ -141,6 +141,33 @@ class Engine:
         self.N, self.E, self.E2 = int(N), int(s.size), 0
         self._refresh_partition()
 
+    @staticmethod
+    def partition_nodes(N, nranks, mesh_pos=None):
+        """owner[N]: the node partition mgn_set_graph derives (recursive coordinate bisection of mesh_pos, or index blocks)."""
+        lib = _capi.load()
+        owner = np.empty(int(N), np.int32)
+        pos, pd = None, 0
+        if mesh_pos is not None:
+            pos = _c32(mesh_pos)
+            pd = pos.shape[1]
+        rc = lib.mgn_partition_nodes(int(N), f32(pos), pd, int(nranks), i32(owner))
+        if rc != 0:
+            raise MgnError(rc, "mgn_partition_nodes")
+        return owner
+
+    def set_graph_local(self, senders, receivers, N, owner, index_base=0):
+        """Rank-local ingest: the same state as set_graph(senders, receivers, N) with the partition `owner`, from the edges this rank
+        has an end of (filtered here with numpy; a caller that holds only its part passes it to mgn_set_graph_local directly)."""
+        s = np.ascontiguousarray(senders, dtype=np.int32).ravel()
+        r = np.ascontiguousarray(receivers, dtype=np.int32).ravel()
+        owner = np.ascontiguousarray(owner, dtype=np.int32).ravel()
+        rank = self.cfg.rank
+        touch = np.nonzero((owner[s - index_base] == rank) | (owner[r - index_base] == rank))[0].astype(np.int64)
+        st, rt = np.ascontiguousarray(s[touch]), np.ascontiguousarray(r[touch])
+        self._chk(self.lib.mgn_set_graph_local(self.h, int(N), i32(owner), int(s.size), int(touch.size), i32(st), i32(rt), i64(touch), index_base))
+        self.N, self.E, self.E2 = int(N), int(s.size), 0
+        self._refresh_partition()
+
     def _refresh_partition(self):
         a, b, c = C.c_int32(), C.c_int32(), C.c_int64()
         self._chk(self.lib.mgn_partition_info(self.h, C.byref(a), C.byref(b), C.byref(c)))

@@ -203,6 +203,51 @@ def test_partition_invariants(lib_built, P, scattered):
             assert np.array_equal(own_p[sidx[off[q]:off[q + 1]]], engs[q].halo_nodes()[roff[p]:roff[p + 1]])
 
 
+@pytest.mark.parametrize("P", [2, 3, 8])
+@pytest.mark.parametrize("scattered", [False, True])
+def test_rank_local_ingest_builds_the_same_partition(lib_built, P, scattered):
+    """mgn_partition_nodes + mgn_set_graph_local: a rank that is handed only the edges it has an end of (with their positions in the global
+    list) ends up with the local graph mgn_set_graph derives from the global lists -- owned nodes and their order, halo rows, local edges
+    and their global positions, CSR, send lists."""
+    pos, cells = synth.grid_mesh(23, 17, 5)
+    s, r = synth.cells_to_edges(cells)
+    N = pos.shape[0]
+    if scattered:
+        perm = np.random.default_rng(3).permutation(N).astype(np.int32)
+        s, r = perm[s], perm[r]
+        pos = pos[np.argsort(perm)]
+    owner = Engine.partition_nodes(N, P, mesh_pos=pos)
+    for base in (0, 1):
+        for rk in range(P):
+            a = Engine(9, 3, 2, rank=rk, nranks=P, device=MGN_DEVICE_NONE)
+            a.set_graph(s + base, r + base, N, index_base=base, mesh_pos=pos)
+            assert np.array_equal(a.node_owner(), owner)
+            b = Engine(9, 3, 2, rank=rk, nranks=P, device=MGN_DEVICE_NONE)
+            b.set_graph_local(s + base, r + base, N, owner, index_base=base)
+            assert (a.n_own, a.n_halo, a.e_local, a.boundary_count()) == (b.n_own, b.n_halo, b.e_local, b.boundary_count())
+            assert np.array_equal(a.owned_nodes(), b.owned_nodes()) and np.array_equal(a.halo_nodes(), b.halo_nodes())
+            assert np.array_equal(a.local_edges(), b.local_edges())
+            for x, y in zip(a.local_graph(), b.local_graph()):
+                assert np.array_equal(x, y)
+            for x, y in zip(a.halo_counts(), b.halo_counts()):
+                assert np.array_equal(x, y)
+            assert np.array_equal(a.halo_send_index(), b.halo_send_index())
+            assert a.edge_set_info(0) == b.edge_set_info(0)                       # (global E, local E)
+            assert a.edge_boundary_tiles(0) == b.edge_boundary_tiles(0)
+    # without positions: contiguous index blocks, as mgn_set_graph falls back to
+    assert np.array_equal(Engine.partition_nodes(10, 4), np.array([0, 0, 0, 1, 1, 2, 2, 2, 3, 3], np.int32))
+    e = Engine(9, 3, 2, rank=0, nranks=P, device=MGN_DEVICE_NONE)
+    with pytest.raises(MgnError):                                              # positions that are not ascending
+        gid = np.array([3, 1], np.int64)
+        e._chk(e.lib.mgn_set_graph_local(e.h, N, owner.ctypes.data_as(C.POINTER(C.c_int32)), s.size, 2,
+                                         s[:2].ctypes.data_as(C.POINTER(C.c_int32)), r[:2].ctypes.data_as(C.POINTER(C.c_int32)),
+                                         gid.ctypes.data_as(C.POINTER(C.c_int64)), 0))
+    bad = owner.copy()
+    bad[0] = P
+    with pytest.raises(MgnError):                                              # an owner outside [0, nranks)
+        e.set_graph_local(s, r, N, bad)
+
+
 @pytest.mark.parametrize("P", [1, 3])
 def test_two_edge_sets_partition_union_halo(lib_built, P):
     """Second edge set (world edges): same node partition and order as with the mesh set alone when no halo changes;

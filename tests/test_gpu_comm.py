@@ -112,6 +112,41 @@ def test_kat7_in_library_schedule_equals_python_driven_bitwise(P, path):
         set_kernel_path(old)
 
 
+def test_forward_on_partitions_built_by_the_rank_local_ingest():
+    """mgn_partition_nodes + mgn_set_graph_local (every rank hands over only the edges it has an end of) in front of the same forward:
+    bitwise the output of handles built by mgn_set_graph from the global lists, and within tolerance of the oracle."""
+    cfg = cfg_dict(mps=3)
+    pos, cells = synth.grid_mesh(21, 19, 2)
+    s, r = synth.cells_to_edges(cells)
+    N, E = pos.shape[0], s.size
+    ps = make_params(cfg)
+    rng = np.random.default_rng(2)
+    nf, ef = rng.standard_normal((N, 9)).astype(np.float32), rng.standard_normal((E, 3)).astype(np.float32)
+    ref = orc.forward(ps, cfg, nf, ef, s, r)
+    owner = mgn_amd.Engine.partition_nodes(N, 3, mesh_pos=pos)
+    res = {}
+    for local in (False, True):
+        cid = mgn_amd.Engine.comm_unique_id("host")
+
+        def body(k):
+            e = engine_for(cfg, rank=k, nranks=3, device=0)
+            e.set_params(ps)
+            if local:
+                e.set_graph_local(s, r, N, owner)
+            else:
+                e.set_graph(s, r, N, mesh_pos=pos)
+            e.comm_init(cid, "host")
+            out = e.forward(nf, ef)
+            e.comm_barrier()
+            e.close()
+            return out
+
+        res[local] = run_ranks(3, body)
+    for a, b in zip(res[False], res[True]):
+        assert np.array_equal(a, b)
+    assert rel_max(res[True][0], ref) <= TOL_15
+
+
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
 def test_forward_at_nranks_3_returns_the_complete_output_on_every_rank(dtype):
     """mgn.model(graph, ps, st) (reference src/solve.jl:200) on a mesh cut in three: every rank passes the global FeatureGraph
