@@ -2360,7 +2360,10 @@ int mgn_processor_steps_dev(mgn_handle* h, int32_t nsteps) try {
     }
     // Graph replay only helps launch-bound (small) passes; it needs a capturable stream (not the null stream) and no
     // per-launch event records.
-    const bool graphable = h->use_graph && !h->prof && h->stream != nullptr && h->es[0].ntiles_e <= 16384;
+#ifndef MGN_GRAPH_MAX_TILES
+#define MGN_GRAPH_MAX_TILES 16384
+#endif
+    const bool graphable = h->use_graph && !h->prof && h->stream != nullptr && h->es[0].ntiles_e <= MGN_GRAPH_MAX_TILES;
     if (!graphable) return processor_pass(h, nsteps);
     if (h->graph_exec && h->graph_nsteps == nsteps) {
         HIPCHK(h, hipGraphLaunch(h->graph_exec, h->stream));
