@@ -449,9 +449,10 @@ def main():
             FAMILY = {1: "k_edge_step<.., GEN> (general hidden_layers)", 2: "k_edge_coop16m (16-row tiles)", 3: "k_edge_coop (4-wave tiles)",
                       4: "k_edge_step<4,0> (all-streaming)", 7: "k_edge_ring<8>", 8: "k_edge_ring<4>", 9: "k_edge_step<4,2>",
                       12: "k_edge_coop16m (16-row tiles, split path)",
-                      13: "k_edge_ring_h<8>", 14: "k_edge_ring_h<4>", 15: "k_edge_coop16m (16-row tiles, two fp16 pieces)"}
+                      13: "k_edge_ring_h<8>", 14: "k_edge_ring_h<4>", 15: "k_edge_coop16m (16-row tiles, two fp16 pieces)",
+                      16: "k_edge_ring_hs<8>", 17: "k_edge_ring_hs<4>"}
             # piece products per fp32 product of the family that ran: 6 (three bf16 pieces), 3 (two fp16 pieces), 0 = fp32 MFMA
-            products = {7: 6, 8: 6, 12: 6, 13: 3, 14: 3, 15: 3}.get(fam, 0)
+            products = {7: 6, 8: 6, 12: 6, 13: 3, 14: 3, 15: 3, 16: 3, 17: 3}.get(fam, 0)
             split_mode = split_mode if products else 0
             comp = (1024.0 + 8.0) * e_loc + 3.0 * 512.0 * n_loc
             alg_bytes = (1024.0 + 8.0 + 85.0) * e_loc

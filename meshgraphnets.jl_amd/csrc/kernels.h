@@ -174,6 +174,7 @@ hipError_t launch_node_split_h(const NodeArgs& a, const LaunchCfg& lc, hipStream
 hipError_t launch_project_split_h(const NodeArgs& a, const LaunchCfg& lc, hipStream_t s);
 hipError_t launch_edge_ring_h(const EdgeArgs& a, const LaunchCfg& lc, hipStream_t s);    // split.hip: the ring kernel on two fp16 pieces, three products
 size_t edge_ring_h_lds();
+int edge_ring_h_streamed();     // 1: launch_edge_ring_h runs k_edge_ring_hs (family codes 16 / 17), 0: k_edge_ring_h (13 / 14)
 hipError_t launch_edge_ring(const EdgeArgs& a, const LaunchCfg& lc, hipStream_t s);    // split.hip
 hipError_t launch_node_split(const NodeArgs& a, const LaunchCfg& lc, hipStream_t s);    // split.hip
 hipError_t launch_project_split(const NodeArgs& a, const LaunchCfg& lc, hipStream_t s); // split.hip

@@ -2908,7 +2908,7 @@ hipError_t launch_edge_step(int L, const EdgeArgs& a, hipStream_t s) {
             }
             if (g_split_f16 && a.splith[0]) {
                 ls.lds = edge_ring_h_lds();
-                SET_LAST_EDGE(a, ls.threads == 256 ? 14 : 13);
+                SET_LAST_EDGE(a, edge_ring_h_streamed() ? (ls.threads == 256 ? 17 : 16) : (ls.threads == 256 ? 14 : 13));
                 return launch_edge_ring_h(a, ls, s);
             }
             SET_LAST_EDGE(a, ls.threads == 256 ? 8 : 7);

@@ -1274,6 +1274,355 @@ __global__ __launch_bounds__(NWV * 64, NWV / 4) void k_edge_ring_h(const EdgeArg
 }
 
 // ================================================================================================
+// k_edge_ring_hs (round 6): k_edge_ring_h with NO resident weight piece -- hi and lo of the layer in progress both pass through the
+// window ring (windows of HS_W = 4 steps: 8 KiB = one 16-byte fragment per thread, three buffers, 24 windows and barriers per tile;
+// 24 KiB of L2 weight traffic per tile and wave instead of 12) -- and the 128 KiB of LDS this frees hold the tile's e: every wave
+// parks its e tile (16 KiB, its own region: no synchronisation) when the tile starts and takes it back for the residual.  e is read
+// from memory ONCE per step (k_edge_ring_h: twice, 3.07 GB per launch on M-1M through the Infinity Cache), the epilogue's burst of
+// requests loses its sixteen largest, and a block's LDS prologue is 28 KiB instead of 150.
+// ================================================================================================
+constexpr int HS_W = 4;
+#ifndef MGN_HS_REQ_STEP
+#define MGN_HS_REQ_STEP 0        // step of window gw (0 .. 3) at which window gw + MGN_HS_AHEAD is requested
+#endif
+#ifndef MGN_HS_AHEAD
+#define MGN_HS_AHEAD 4           // 3: two requests in flight (a request 7 steps before its LDS store), 4: three (11 steps).  M-1M: 2.336 (k_edge_ring_h) ->
+                                 // 2.340 with the request in the window of its store -> 2.288 / 2.260 / 2.245 / 2.250 at AHEAD 3 (request at step 2 / 0), 4, 5
+#endif
+struct Rs {
+    static constexpr int W = HS_W;
+    static constexpr int WPL = 32 / W;          // windows per layer: 8
+    static constexpr int NW = 3 * WPL;          // windows per tile: 24
+    static constexpr int NB = 3;                // window buffers (a window is requested two windows ahead and stored in the window it is requested in)
+    static constexpr int BUF = 2 * W * 64;      // u32x4 elements per buffer: [step][hi, lo][lane]
+    static constexpr int AHEAD = MGN_HS_AHEAD;  // windows between a window's request and its first use
+    static constexpr int SLOTS = AHEAD - 1;     // requests in flight per thread
+    static_assert(NW % NB == 0 && NW % SLOTS == 0 && AHEAD >= 3, "static window -> buffer / slot mapping");
+};
+template <int LYR>
+DEVINL RhFrag rs_first(const u32x4* ring) {
+    constexpr int b = (Rs::WPL * LYR) % Rs::NB;
+    RhFrag f;
+    f.h = ring[b * Rs::BUF];
+    f.l = ring[b * Rs::BUF + 64];
+    return f;
+}
+struct RsSrc {
+    const u32x4* w[3];                          // the chunks of layers 1..3 (W1e, W2, W3): hi piece at + 0, lo piece at + 2048 fragments
+};
+// element e of window w of a chunk (e = (step * 2 + piece) * 64 + lane): where it sits in the chunk's global pieces
+DEVINL const u32x4* rs_src(const u32x4* chunk, int w, int e) { return chunk + ((e >> 6) & 1) * 2048 + (w * Rs::W + (e >> 7)) * 64 + (e & 63); }
+// One L x L layer with both pieces from the ring.  Otherwise h2_layer_ring (same split, same products, same order; refill as there).
+template <int LYR, int FIN, int RFS = 0, int NWV = 8, bool WRAP = false>
+DEVINL void hs_layer_ring(f32x16 (&acc)[4], f32x16 (&in)[4], u32x4* ring, const RsSrc& src, RhFrag& nx, u32x4 (&pend)[Rs::SLOTS][Rs::BUF / (NWV * 64)], int lane,
+                          int tid, float sx, float cfin = 0.f, const float* btab = nullptr, const f32x4* rf = nullptr, const N16Buf* rfb = nullptr) {
+    constexpr int ROT = 2;
+    constexpr int W = Rs::W, WPL = Rs::WPL, NW = Rs::NW, BUF = Rs::BUF, NB = Rs::NB;
+    constexpr int LPT = BUF / (NWV * 64);        // fragments per thread in a window
+    f32x4 side[2 * ROT];
+    if constexpr (!WRAP && RFS > 0) {
+#pragma unroll
+        for (int m = 0; m < 2 * ROT; ++m) side[m] = rf[m * RFS];
+    }
+    auto bias = [&](int sn, int u) {
+        f32x2 b = {0.f, 0.f};
+        if constexpr (FIN == 2) b = *reinterpret_cast<const f32x2*>(btab + 8 * (4 * (sn >> 1) + 2 * (sn & 1) + (u >> 1)) + 2 * (u & 1));
+        return b;
+    };
+    unsigned ph[4], pl[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const f32x2 b = bias(0, u);
+        h2_split_pair<FIN>(ph[u], pl[u], in[0][2 * u], in[0][2 * u + 1], sx, cfin, b[0], b[1]);
+    }
+    // the thread's place inside a window, as a byte offset from the window's first hi fragment (one register, kept opaque: as 64-bit
+    // addresses per window hipcc hoists 24 of them out of the tile loop and spills)
+    unsigned voff[LPT];
+#pragma unroll
+    for (int i = 0; i < LPT; ++i) {
+        const int e = i * NWV * 64 + tid;
+        voff[i] = (unsigned)((((e >> 6) & 1) * 2048 + (e >> 7) * 64 + (e & 63)) * 16);
+        asm volatile("" : "+v"(voff[i]));
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+        unsigned nh[4], nl[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int it = 4 * s + t;
+            const int gw = WPL * LYR + it / W;                        // global window of this step
+            const u32x4 a1 = nx.h, a2 = nx.l;
+            // window gw + AHEAD is requested at step MGN_HS_REQ_STEP of window gw and goes to LDS at the last step of window gw + AHEAD - 2 (into
+            // the buffer that window gw + AHEAD - 3 has just closed on): AHEAD - 1 requests in flight, one register slot each
+            if (it % W == MGN_HS_REQ_STEP) {
+                const int g2 = (gw + Rs::AHEAD) % NW, l2 = g2 / WPL, w2 = g2 % WPL;
+#pragma unroll
+                for (int i = 0; i < LPT; ++i)
+                    pend[gw % Rs::SLOTS][i] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(src.w[l2] + w2 * W * 64) + voff[i]);
+            }
+            if constexpr (RFS > 0) {
+                if ((t & 1) && s < 8 - ROT) {                          // registers of k-step s (free since the step began), half t >> 1
+                    f32x4 v;
+                    if constexpr (WRAP) v = n16_ld(*rfb, (unsigned)lane * 16u, (2 * s + (t >> 1)) * 1024);
+                    else v = rf[(2 * (s + ROT) + (t >> 1)) * RFS];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) in[s >> 1][8 * (s & 1) + 4 * (t >> 1) + i] = v[i];
+                }
+            }
+            if (it + 1 < 32) {
+                const int gn = WPL * LYR + (it + 1) / W;
+                nx.h = ring[(gn % NB) * BUF + (((it + 1) % W) * 2) * 64];
+                nx.l = ring[(gn % NB) * BUF + (((it + 1) % W) * 2 + 1) * 64];
+            } else if (LYR < 2) {
+                nx = rs_first<(LYR + 1) % 3>(ring);                    // (that window was written two windows ago)
+            }
+            if (it % W == W - 1) {                                     // store window gw + 2 (requested in window gw + 2 - AHEAD): its buffer was last read as window gw - 1
+                const int b2 = (gw + 2) % NB;
+#pragma unroll
+                for (int i = 0; i < LPT; ++i) ring[b2 * BUF + i * NWV * 64 + tid - lane] = pend[(gw + 2 - Rs::AHEAD + NW) % Rs::SLOTS][i];
+            }
+            if (s < 7) {
+                const int sn = s + 1;
+                const f32x2 b = bias(sn, t);
+                h2_split_pair<FIN>(nh[t], nl[t], in[sn >> 1][8 * (sn & 1) + 2 * t], in[sn >> 1][8 * (sn & 1) + 2 * t + 1], sx, cfin, b[0], b[1]);
+            }
+            const sp_f16x8 bh = h2_op(ph), bl = h2_op(pl);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h2_wop(a2), bh, acc[t], 0, 0, 0);      // small terms first
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h2_wop(a1), bl, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h2_wop(a1), bh, acc[t], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (it % W == W - 1) ring_barrier();                       // window closed: every wave has read it, window gw + 2 is in LDS
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            ph[u] = nh[u];
+            pl[u] = nl[u];
+        }
+    }
+    if constexpr (RFS > 0 && !WRAP) {                                  // un-rotate: k-step u's pieces sit in the registers of k-step u - 2
+        f32x16 r[4];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                r[u >> 1][8 * (u & 1) + j] = u < ROT ? side[2 * u + (j >> 2)][j & 3] : in[(u - ROT) >> 1][8 * ((u - ROT) & 1) + j];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) in[t] = r[t];
+    }
+}
+template <int NWV>
+__global__ __launch_bounds__(NWV * 64, NWV / 4) void k_edge_ring_hs(const EdgeArgs a) {
+    constexpr int NT = 4, L = 128;
+    constexpr int BUF = Rs::BUF, LPT = BUF / (NWV * 64);
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lane0 = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int tid = (int)threadIdx.x;
+    u32x4* ringbase = reinterpret_cast<u32x4*>(smem);                            // three window buffers (24 KiB)
+    f32x4* park = reinterpret_cast<f32x4*>(ringbase + Rs::NB * BUF) + wave * 1024;   // this wave's e tile: [piece 16][lane 64] x 16 B
+    float* tb = reinterpret_cast<float*>(ringbase + Rs::NB * BUF) + NWV * 4096;
+    copy_to_lds(tb, a.tabs, T_COUNT * L);
+    RsSrc src;
+    u32x4 pend[Rs::SLOTS][LPT];
+    {
+        src.w[0] = reinterpret_cast<const u32x4*>(a.splith[2]);
+        src.w[1] = reinterpret_cast<const u32x4*>(a.splith[0]);
+        src.w[2] = reinterpret_cast<const u32x4*>(a.splith[1]);
+#pragma unroll
+        for (int w = 0; w < 2; ++w)                                   // windows 0 and 1 of layer 1
+#pragma unroll
+            for (int i = 0; i < LPT; ++i) ringbase[w * BUF + i * NWV * 64 + tid] = *rs_src(src.w[0], w, i * NWV * 64 + tid);
+#pragma unroll
+        for (int sl = 0; sl < Rs::SLOTS; ++sl)
+#pragma unroll
+            for (int i = 0; i < LPT; ++i) pend[sl][i] = *rs_src(src.w[0], 2, i * NWV * 64 + tid);
+#pragma unroll
+        for (int x = 2; x < Rs::AHEAD; ++x)                           // windows 2 .. AHEAD - 1 wait in the slots their stores will read
+#pragma unroll
+            for (int i = 0; i < LPT; ++i) pend[(x - Rs::AHEAD + Rs::NW) % Rs::SLOTS][i] = *rs_src(src.w[x / Rs::WPL], x % Rs::WPL, i * NWV * 64 + tid);
+    }
+    __syncthreads();
+    // chunk scales (layer order): s = what the host multiplied the chunk by, rs = 1 / s
+    const float sw1 = a.h2_s[2], rsw1 = a.h2_rs[2], rsw2 = a.h2_rs[0], rsw3 = a.h2_rs[1], b2pos = a.h2_b2pos;
+    // lock-step: every wave of the block runs as many tiles as its wave 0 (the longest walk); padding tiles compute, store nothing
+    TileWalk tw0(a.ntiles, 0), tw(a.ntiles, wave);
+    if (tw0.tile >= tw0.end) return;
+    const int iters = (tw0.end - tw0.tile + tw0.stride - 1) / tw0.stride;
+    if (MGN_RING_PHASES > 1 && iters >= 32) {                         // (k_edge_ring: every second block of an XCD half a period late)
+        const int ph = (int)(blockIdx.x / NUM_XCD) % MGN_RING_PHASES;
+        for (int i = 0; i < ph * MGN_RINGH_PHASE_UNITS; ++i) __builtin_amdgcn_s_sleep(64);
+    }
+    const int last = a.tile0 + tw0.tile + (iters - 1) * tw0.stride;   // a tile that exists (loads of padding tiles go there)
+    tw.tile += a.tile0;
+    tw.end += a.tile0;
+    auto clamp = [&](int t) { return t < tw.end ? t : last; };
+    f32x16 acc[NT], y[NT];
+    EdgeIdx ix = load_edge_idx_nb(a.snd, a.rcv, a.E, clamp(tw.tile), lane0 & 31);
+    {
+        const int h0 = lane0 >> 5;
+        load_frag<NT>(acc, prow_ptr(a.Q, ix.r >= 0 ? ix.r : 0, L, h0), STRIDE_PROW);
+        load_frag<NT>(y, tile_ptr(a.Elat, clamp(tw.tile), L, lane0), STRIDE_TILE);
+    }
+    int stamp_tile = 0;
+    (void)stamp_tile;
+    for (int j = 0; j < iters; ++j, ++stamp_tile) {
+        OPAQUE_LANE();
+        const bool on = tw.tile < tw.end;
+        const int tile = clamp(tw.tile);
+        const int nxt = clamp(tw.tile + tw.stride);
+        const EdgeIdx ixn = load_edge_idx_nb(a.snd, a.rcv, a.E, nxt, c);
+        const bool valid = on && ix.r >= 0;
+        const int r = ix.r >= 0 ? ix.r : 0;
+        f32x4* etile = tile_ptr(a.Elat, tile, L, lane);
+        u32x4* ring = ringbase + lane;
+        STAMP(0);
+        __builtin_amdgcn_s_setprio(0);
+        RhFrag nx = rs_first<0>(ring);
+#pragma unroll
+        for (int m = 0; m < 16; ++m) {                               // park this tile's e for the residual (the wave's own 16 KiB of LDS)
+            f32x4 v;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = y[m >> 2][4 * (m & 3) + i];
+            park[m * 64 + lane] = v;
+        }
+        // layer 1 (edge part): y = e tile in, P[s] out; acc enters with Q[r] (which carries b1), put into the accumulator's units
+        const H2Scale x1 = h2_scale(h2_rowmax<true>(y));
+        {
+            const float cinv = x1.s * sw1;
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int k = 0; k < 16; ++k) acc[t][k] *= cinv;
+        }
+        const int ps_row = ix.s;
+        hs_layer_ring<0, 0, STRIDE_PROW, NWV>(acc, y, ring, src, nx, pend, lane, tid, x1.s, 0.f, nullptr, prow_ptr(a.P, ps_row, L, h));
+        {
+            const float c1 = x1.rs * rsw1;
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int k = 0; k < 16; ++k) acc[t][k] = __builtin_fmaf(acc[t][k], c1, y[t][k]);
+        }
+        CST(1);
+        const H2Scale x2 = h2_scale(h2_rowmax<false>(acc));
+        zero_frag<NT>(y);
+        CST(2);
+        hs_layer_ring<1, 1, 0, NWV>(y, acc, ring, src, nx, pend, lane, tid, x2.s);   // layer 2 (ReLU folded into the split)
+        CST(3);
+        const float c2 = x2.rs * rsw2;
+        const H2Scale x3 = h2_scale(__builtin_fmaf(h2_rowmax<false>(y), c2, b2pos));
+        zero_frag<NT>(acc);
+        CST(4);
+        // layer 3: y = layer 2's accumulators in (bias, un-scaling and ReLU in the split), the NEXT tile's e out
+        const N16Buf enb = n16_buf(a.Elat + (int64_t)nxt * (TILE * L), TILE * L * 4);      // (nxt is wave-uniform)
+        hs_layer_ring<2, 2, STRIDE_TILE, NWV, true>(acc, y, ring, src, nx, pend, lane, tid, x3.s, c2, tb + T_B2 * L + 4 * h, nullptr, &enb);
+        CST(5);
+        EST(1);
+        PHASE_FENCE();
+        __builtin_amdgcn_s_setprio(MGN_PRIO);
+#pragma unroll
+        for (int m = 12; m < 16; ++m) {                              // k-steps 6 and 7 of the next tile's e
+            const f32x4 v = n16_ld(enb, (unsigned)lane * 16u, m * 1024);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) y[3][4 * (m & 3) + i] = v[i];
+        }
+        {   // bias + un-scaling of layer 3, then LayerNorm: acc = e'
+            constexpr float invL = 1.0f / 128;
+            const float c3 = x3.rs * rsw3;
+            const f32x4* b34 = reinterpret_cast<const f32x4*>(tb + T_B3 * L) + h;
+            float sm = 0.f;
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 bv = b34[2 * (4 * t + g)];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const float v = __builtin_fmaf(acc[t][4 * g + i], c3, bv[i]);
+                        acc[t][4 * g + i] = v;
+                        sm += v;
+                    }
+                }
+            sm += __shfl_xor(sm, 32, 64);
+            const float mean = sm * invL;
+            float q = 0.f;
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    const float d = acc[t][k] - mean;
+                    acc[t][k] = d;
+                    q += d * d;
+                }
+            q += __shfl_xor(q, 32, 64);
+            const float rstd = ln_rstd_at(q * invL, tb + T_LN * L);
+            const f32x4* g4 = reinterpret_cast<const f32x4*>(tb + T_GAMMA * L) + h;
+            const f32x4* b4 = reinterpret_cast<const f32x4*>(tb + T_BETA * L) + h;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 gv = g4[2 * (4 * t + g)];
+                    const f32x4 bv = b4[2 * (4 * t + g)];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) acc[t][4 * g + i] = acc[t][4 * g + i] * rstd * gv[i] + bv[i];
+                }
+                // the block's residual -- this tile's e comes back from the wave's LDS region -- and its four stores right behind its LayerNorm
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    f32x4 v = park[(4 * t + g) * 64 + lane];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) v[i] += acc[t][4 * g + i];
+                    if (valid) etile[(4 * t + g) * STRIDE_TILE] = v;
+                }
+            }
+        }
+        CST(6);
+        EST(2);
+        CST(7);
+        EST(3);
+        const int reff = ix.r >= 0 ? r : (-4 - c);
+        const int rprev = __shfl_up(reff, 1, 32);
+        const int rnext = __shfl_down(reff, 1, 32);
+        const bool head = (c == 0) || (reff != rprev);
+        const unsigned hm = (unsigned)__ballot(head);
+        const int start = 31 - __clz((int)(hm & (0xFFFFFFFFu >> (31 - c))));
+        const int st_in = max(start, c & 16);
+        const bool c1 = (c - 1 >= st_in), c2s = (c - 2 >= st_in), c4 = (c - 4 >= st_in), c8 = (c - 8 >= st_in);
+        const bool cx = (c >= 16) && (start <= 15);
+        EST(4);
+        PHASE_FENCE();
+        asm volatile("s_nop 1");
+        RG_SCAN_LEVEL(acc, c1, "row_shr:1 row_mask:0xf bank_mask:0xf");
+        RG_SCAN_LEVEL(acc, c2s, "row_shr:2 row_mask:0xf bank_mask:0xf");
+        RG_SCAN_LEVEL(acc, c4, "row_shr:4 row_mask:0xf bank_mask:0xf");
+        if (__builtin_amdgcn_ballot_w64(c8) != 0)                    // (receiver runs of nine edges and more: rare on a mesh)
+        {
+            RG_SCAN_LEVEL(acc, c8, "row_shr:8 row_mask:0xf bank_mask:0xf");
+        }
+        RG_SCAN_LEVEL(acc, cx, "row_bcast:15 row_mask:0xa bank_mask:0xf");
+        PHASE_FENCE();
+        EST(5);
+        const bool tail = valid && ((c == 31) || (reff != rnext));
+        const int r_first = __builtin_amdgcn_readfirstlane(reff);
+        const bool sl = (start == 0) && (ix.r_before == r_first);
+        const bool sr = (c == 31) && (ix.r_after == reff);
+        const bool to_carry = sl || sr;
+        f32x4* dst = to_carry ? prow_ptr(a.CARRY, (int64_t)2 * tile + (sl ? 0 : 1), L, h) : tile_ptr(a.AGG, r >> 5, L, 32 * h + (r & 31));
+        if (tail) store_frag<NT>(dst, to_carry ? STRIDE_PROW : STRIDE_TILE, acc);
+        EST(6);
+        PHASE_FENCE();
+        // turnover: the next tile's layer-1 accumulator starts from Q[r] (P[s] arrives during the layer)
+        load_frag<NT>(acc, prow_ptr(a.Q, ixn.r >= 0 ? ixn.r : 0, L, h), STRIDE_PROW);
+        EST(7);
+        ix = ixn;
+        tw.tile += tw.stride;
+    }
+}
+
+
+// ================================================================================================
 // Processor node step (K6) on the split path: k_node_step<4, *, false>'s tile loop with its four L x L chunks on the bf16 matrix
 // cores.  split[]: the chunks in NodeArgs.chunk order (0: W2, 1: W3, 2: W1[0:L] (node part), 3: W1[L:2L] (aggregate part)), each as
 // hi / mid / lo pieces.  LDS: the four hi pieces (128 KiB) + tables; mid and lo stream from L2 (sp_layer_otf rings).  The V tile is
@@ -1756,8 +2105,16 @@ hipError_t launch_edge_ring(const EdgeArgs& a, const LaunchCfg& lc, hipStream_t 
     if (lc.threads == 256) return sp_launch(k_edge_ring<4>, a, lc, s, attr_set4);
     return sp_launch(k_edge_ring<8>, a, lc, s, attr_set8);
 }
+static int g_ringh_stream = [] { const char* e = getenv("MGN_RINGH_STREAM"); return e ? atoi(e) : 1; }();   // 1 (default): k_edge_ring_hs (no resident weight piece, e parked in LDS: read once); 0: k_edge_ring_h
+int edge_ring_h_streamed() { return g_ringh_stream; }
 hipError_t launch_edge_ring_h(const EdgeArgs& a, const LaunchCfg& lc, hipStream_t s) {
-    static bool attr_set8 = false, attr_set4 = false;
+    static bool attr_set8 = false, attr_set4 = false, attr_s8 = false, attr_s4 = false;
+    if (g_ringh_stream) {
+        LaunchCfg ls = lc;
+        ls.lds = (size_t)Rs::NB * Rs::BUF * 16 + (size_t)(lc.threads / 64) * 16384 + (size_t)T_COUNT * 128 * 4 + 64;
+        if (lc.threads == 256) return sp_launch(k_edge_ring_hs<4>, a, ls, s, attr_s4);
+        return sp_launch(k_edge_ring_hs<8>, a, ls, s, attr_s8);
+    }
     if (lc.threads == 256) return sp_launch(k_edge_ring_h<4>, a, lc, s, attr_set4);
     return sp_launch(k_edge_ring_h<8>, a, lc, s, attr_set8);
 }
