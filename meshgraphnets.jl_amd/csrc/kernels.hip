@@ -2898,7 +2898,15 @@ hipError_t launch_edge_step(int L, const EdgeArgs& a, hipStream_t s) {
             static const int ring_waves = [] { const char* e = getenv("MGN_RING_WAVES"); return e ? atoi(e) : 0; }();   // 0: by size
             // four-wave blocks (one wave per SIMD) up to 2.5 rounds of eight-wave blocks: 16 k nodes 75 vs 83 us, 25.6 k 115 vs 120,
             // 40 k 175 vs 160 (docs/experiments.md)
-            if (ring_waves == 4 || (ring_waves == 0 && a.ntiles <= 20 * num_cus())) {
+            // k_edge_ring_hs (28 KiB of LDS prologue per block instead of 150): a round of four-wave blocks takes ~0.62 of a round of eight-wave
+            // blocks for half the tiles, so the shape with the shorter sum of rounds runs -- four waves up to 4 and from 8 to 12 tiles per CU
+            // (M-1M slices of 100 / 128 / 145 / 160 nodes a side: 34 vs 39, 57 vs 55, 59 vs 70, 79 vs 83 us for eight vs four waves)
+            bool four = a.ntiles <= 20 * num_cus();
+            if (g_split_f16 && a.splith[0] && edge_ring_h_streamed()) {
+                const int r4 = (a.ntiles + 4 * num_cus() - 1) / (4 * num_cus()), r8 = (a.ntiles + 8 * num_cus() - 1) / (8 * num_cus());
+                four = 0.62 * r4 < (double)r8;
+            }
+            if (ring_waves == 4 || (ring_waves == 0 && four)) {
                 ls.threads = 256;
                 // as few blocks as the number of rounds allows (every block pays the 150 KiB LDS prologue)
                 const int rounds = (a.ntiles + 4 * num_cus() - 1) / (4 * num_cus());
