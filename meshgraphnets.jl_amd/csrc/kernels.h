@@ -195,7 +195,9 @@ bool launch_is_small(int ntiles);
 bool node_split_size(int ntiles);   // the split-path node kernels take launches of this many node tiles (above two per CU)
 bool launch_is_small_edge(int ntiles_e);   // the same rule for edge launches (<= 16 tiles per CU)
 int coop16_enabled();
-bool coop16_size(int ntiles_e, int ntiles_n);   // the launch wrappers' rule for the cooperative node kernels (<= 8 tiles per CU)
+int set_c16_edge_tiles(int t);   // edge tiles per CU up to which a handle takes the 16-row kernels (0: 3, or 2 where k_edge_ring_hs is the next family); returns the old value
+bool ring_hs_default();          // fp32 launches above the cooperative range would run k_edge_ring_hs (split path on two fp16 pieces, streamed pieces)
+bool coop16_size(int ntiles_e, int ntiles_n, bool ring_hs = false);   // the launch wrappers' rule for the cooperative node kernels (<= 8 tiles per CU)
 int last_edge_kernel();
 int last_node_kernel();         // family of the last fp32 edge launch (kernels.hip: launch_edge_step)
 int set_fp32_split(int on);     // debug/tests: 0 = fp32-MFMA kernels, 1 = split path (default); returns the old value

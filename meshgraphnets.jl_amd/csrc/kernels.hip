@@ -2723,12 +2723,17 @@ static int g_coop_node = [] { const char* e = getenv("MGN_COOP_NODE_TILES_PER_CU
 static int g_coop16 = [] { const char* e = getenv("MGN_COOP16"); return e ? atoi(e) : 1; }();   // 16-row cooperative tiles on small graphs
 int coop16_enabled() { return (g_coop16 && (g_path == 0 || g_path == 5)) ? 1 : 0; }
 // the 16-row tiles pay while the launches are latency-bound: up to this many 32-row tiles per CU (size sweep, docs/experiments.md)
-static int g_c16_edge = [] { const char* e = getenv("MGN_C16_EDGE_TILES_PER_CU"); return e ? atoi(e) : 3; }();
+// (`ring_hs`: the handle's large-mesh edge kernel would be k_edge_ring_hs -- fp32, one edge set, two fp16 pieces -- whose 28 KiB LDS prologue
+// lets it take over a tile per CU earlier: 3 025 nodes 38 -> 35 us per step, 4 096 nodes 42 -> 37)
+static int g_c16_edge = [] { const char* e = getenv("MGN_C16_EDGE_TILES_PER_CU"); return e ? atoi(e) : 0; }();   // 0: 3, or 2 with ring_hs
 static int g_c16_node = [] { const char* e = getenv("MGN_C16_NODE_TILES_PER_CU"); return e ? atoi(e) : 1; }();
-bool coop16_size(int ntiles_e, int ntiles_n) {
+bool coop16_size(int ntiles_e, int ntiles_n, bool ring_hs) {
     if (g_path == 5) return true;
-    return ntiles_e <= g_c16_edge * num_cus() && ntiles_n <= g_c16_node * num_cus();
+    const int lim = g_c16_edge > 0 ? g_c16_edge : (ring_hs ? 2 : 3);
+    return ntiles_e <= lim * num_cus() && ntiles_n <= g_c16_node * num_cus();
 }
+int set_c16_edge_tiles(int t) { const int old = g_c16_edge; g_c16_edge = t; return old; }   // (tests: 0 = by the handle, n = n tiles per CU)
+bool ring_hs_default() { return g_fp32_split == 1 && g_split_f16 != 0 && g_path == 0 && edge_ring_h_streamed() != 0; }
 static bool coop_size(int ntiles, bool edge) { return g_path == 0 ? ntiles <= (edge ? g_coop_edge : g_coop_node) * num_cus() : (g_path == 3 || g_path == 5); }
 bool launch_is_small(int ntiles) { return coop_size(ntiles, false); }
 // where the split-path node kernels (k_node_split + k_project_split) take the node side from the cooperative tiles: above two tiles per CU
@@ -2879,8 +2884,9 @@ hipError_t launch_edge_step(int L, const EdgeArgs& a, hipStream_t s) {
     }
     // where the ring kernel of the split path is available it takes over from the cooperative tiles at 3 tiles per CU already
     // (four-wave blocks; 5 k nodes: 50 vs 68 us per step, 10 k: 85 vs 110, 16 k: 110 vs 146), the fp32-MFMA persistent kernels only at 16
-    static const int coop_edge_ring = [] { const char* e = getenv("MGN_COOP_EDGE_TILES_PER_CU_RING"); return e ? atoi(e) : 3; }();
+    static const int coop_edge_ring_env = [] { const char* e = getenv("MGN_COOP_EDGE_TILES_PER_CU_RING"); return e ? atoi(e) : 0; }();
     const bool ring_ok = L == 128 && g_fp32_split == 1 && a.split[0] && g_path == 0;
+    const int coop_edge_ring = coop_edge_ring_env > 0 ? coop_edge_ring_env : ((ring_ok && g_split_f16 && a.splith[0] && edge_ring_h_streamed()) ? 2 : 3);
     if (coop_ok(L, a.ntiles, a.chunk_t, true) && !(ring_ok && a.ntiles > coop_edge_ring * num_cus())) {   // small graph: 4 waves per tile
         SET_LAST_EDGE(a, 3);
         LaunchCfg c4{a.ntiles, 256, coop_lds()};

@@ -401,8 +401,9 @@ int32_t use_c16(const mgn_engine* h) {
     // (bf16 mode included: the 16-row kernels then read and write the bf16 arrays and keep fp32 weights and arithmetic)
     if (!(coop16_enabled() && h->cfg.L == 128 && h->cfg.hidden_layers == 2 && get_kernel_path() != 4 && launch_is_small(h->ntiles_n)))
         return 0;
+    const bool ring_hs = h->cfg.dtype == MGN_F32 && h->nsets == 1 && ring_hs_default();
     for (int q = 0; q < h->nsets; ++q)
-        if (!(launch_is_small_edge(h->es[q].ntiles_e) && coop16_size(h->es[q].ntiles_e, h->ntiles_n))) return 0;
+        if (!(launch_is_small_edge(h->es[q].ntiles_e) && coop16_size(h->es[q].ntiles_e, h->ntiles_n, ring_hs))) return 0;
     return 1;
 }
 
@@ -2785,6 +2786,7 @@ int mgn_halo_exchange_host(mgn_handle* h, const float* own_rows, float* halo_row
 // kernels, 2 all-streaming, 3 cooperative 4-wave tiles.  Returns the previous value.
 int mgn_debug_kernel_path(int path) { return set_kernel_path(path); }
 int mgn_debug_c16_row_tiles(int rt) { return set_c16_row_tiles(rt); }
+int mgn_debug_c16_edge_tiles(int t) { return set_c16_edge_tiles(t); }   // size limit of the 16-row kernels in edge tiles per CU (0: by the handle)
 // large fp32 launches: 1 split path (k_edge_ring + k_node_split + k_project_split: bf16 matrix cores at fp32 accuracy; the default),
 // 0 fp32-MFMA kernels; returns the old value
 int mgn_debug_fp32_split(int on) { return set_fp32_split(on); }

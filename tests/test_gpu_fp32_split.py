@@ -297,15 +297,31 @@ def test_split_16_row_edge_kernel_with_four_to_six_row_tiles(n_pts):
     v = rng.standard_normal((N, 128)).astype(np.float32)
     e = rng.standard_normal((E, 128)).astype(np.float32)
     rv, re = orc.processor_steps(ps, cfg, v, e, s, r, 4)
-    eng = engine_for(cfg)
-    eng.set_params(ps)
-    eng.set_graph(s, r, N)
-    v1, e1 = eng.processor_steps(v, e, 4)
     lib = mgn_amd.load()
     lib.mgn_debug_last_edge_kernel.restype = ctypes.c_int
+    lib.mgn_debug_c16_edge_tiles.restype = ctypes.c_int
+    lib.mgn_debug_c16_edge_tiles.argtypes = [ctypes.c_int]
+    # since round 6 a one-set fp32 handle leaves the 16-row kernels at two edge tiles per CU (k_edge_ring_hs takes over: its LDS prologue is
+    # 28 KiB); the five- and six-row-tile blocks are what other handles (two edge sets, bf16 storage) run up to three tiles per CU
+    if n_pts != 2300:
+        eng = engine_for(cfg)
+        eng.set_params(ps)
+        eng.set_graph(s, r, N)
+        vr, er_ = eng.processor_steps(v, e, 4)
+        assert lib.mgn_debug_last_edge_kernel() == 17                                 # k_edge_ring_hs<4>
+        assert rel_max(vr, rv) <= TOL_15 and rel_max(er_, re) <= TOL_15, (rel_max(vr, rv), rel_max(er_, re))
+    old_lim = lib.mgn_debug_c16_edge_tiles(3)
+    try:
+        eng = engine_for(cfg)
+        eng.set_params(ps)
+        eng.set_graph(s, r, N)
+        v1, e1 = eng.processor_steps(v, e, 4)
+    finally:
+        lib.mgn_debug_c16_edge_tiles(old_lim)
     assert lib.mgn_debug_last_edge_kernel() == (15 if n_pts == 2300 else 12)      # four row tiles on two fp16 pieces; five and six on three bf16 pieces (two spill)
     assert rel_max(v1, rv) <= TOL_15 and rel_max(e1, re) <= TOL_15, (rel_max(v1, rv), rel_max(e1, re))
     old = set_c16_split(0)
+    old_lim = lib.mgn_debug_c16_edge_tiles(3)
     try:
         f32 = engine_for(cfg)
         f32.set_params(ps)
@@ -313,6 +329,7 @@ def test_split_16_row_edge_kernel_with_four_to_six_row_tiles(n_pts):
         v0, e0 = f32.processor_steps(v, e, 4)
     finally:
         set_c16_split(old)
+        lib.mgn_debug_c16_edge_tiles(old_lim)
     assert max(rel_max(v1, rv), rel_max(e1, re)) <= 2.0 * max(rel_max(v0, rv), rel_max(e0, re)) + 1e-7
     assert not np.array_equal(e0, e1)
 
