@@ -212,6 +212,9 @@ int get_kernel_path();
 hipError_t launch_edge_step(int L, const EdgeArgs& a, hipStream_t s);
 hipError_t launch_node_step(int L, const NodeArgs& a, hipStream_t s);
 hipError_t launch_project(int L, const NodeArgs& a, hipStream_t s);   // mode-2 work with both chunks LDS-resident
+hipError_t launch_node_project_fused(int L, const NodeArgs& a, hipStream_t s, bool* launched);   // k_node_ring_hs where it applies (else *launched = false)
+hipError_t launch_node_ring_hs(const NodeArgs& a, const LaunchCfg& lc, hipStream_t s);            // split.hip
+int node_ring_hs_enabled();
 hipError_t launch_enc_node(int L, const EncNodeArgs& a, hipStream_t s);
 hipError_t launch_enc_edge(int L, const EncEdgeArgs& a, hipStream_t s);
 hipError_t launch_decode(int L, const DecArgs& a, hipStream_t s);

@@ -3038,6 +3038,23 @@ hipError_t launch_node_step(int L, const NodeArgs& a, hipStream_t s) {
     if (L == 32) return proj ? launch_k(k_node_step<1, 6, true>, a, lc, s) : launch_k(k_node_step<1, 4, false>, a, lc, s);
     return hipErrorInvalidValue;
 }
+// node MLP + residual + P / Q of the next step in one launch (split.hip: k_node_ring_hs) where launch_node_step + launch_project would run
+// k_node_split_h + k_project_split_h: fp32, one edge set, two fp16 pieces, whole node range.  *launched = false: not this size / mode.
+hipError_t launch_node_project_fused(int L, const NodeArgs& a, hipStream_t s, bool* launched) {
+    *launched = false;
+    if (!(node_ring_hs_enabled() && L == 128 && g_fp32_split == 1 && g_split_f16 && g_path == 0 && !a.bf && !a.AGG2 && !a.gen.use && a.mode == 0 &&
+          a.tile0 == 0 && a.splith[0] && a.splith[4] && a.splith[5] && node_split_size(a.ntiles)))
+        return hipSuccess;
+    LaunchCfg ls = tile_launch(L, a.ntiles, 2);
+    ls.threads = 512;
+    int blocks = (a.ntiles + 7) / 8;
+    if (blocks > num_cus()) blocks = num_cus();
+    ls.blocks = ((blocks + NUM_XCD - 1) / NUM_XCD) * NUM_XCD;
+    g_last_node_kernel = 11;
+    *launched = true;
+    return launch_node_ring_hs(a, ls, s);
+}
+
 hipError_t launch_project(int L, const NodeArgs& a, hipStream_t s) {
     if (a.ntiles <= 0) return hipSuccess;
     LaunchCfg lc = tile_launch(L, a.ntiles, 2);

@@ -1497,7 +1497,12 @@ int mgn_proc_node(mgn_handle* h, int32_t k, int32_t project_next) try {
     const bool split_pair = !is_bf16(h) && h->cfg.L == 128 && k < (int)h->spoff.size() && h->spoff[k].have_n && h->wsp.p && node_split_size(h->ntiles_n);
     if (project_next && !(h->nsets == 2 && use_c16(h)) && (h->nsets > 1 || split_pair || (h->node_split && !launch_is_small(h->ntiles_n)))) {
         // MLP (2 of its chunks LDS-resident, the others stream from L2), then per edge set the projection with both of
-        // its chunks resident
+        // its chunks resident -- or, one edge set on two fp16 pieces, both in one lock-step launch (k_node_ring_hs)
+        if (h->nsets == 1 && split_pair) {
+            bool fused = false;
+            HIPCHK(h, launch_node_project_fused(h->cfg.L, node_args(h, k, 0), h->stream, &fused));
+            if (fused) return MGN_OK;
+        }
         HIPCHK(h, launch_node_step(h->cfg.L, node_args(h, k, 0), h->stream));
         for (int q = 0; q < h->nsets; ++q)
             if (int rc = project_set(h, k, q)) return rc;

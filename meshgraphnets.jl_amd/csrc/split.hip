@@ -1289,17 +1289,19 @@ constexpr int HS_W = 4;
 #define MGN_HS_AHEAD 4           // 3: two requests in flight (a request 7 steps before its LDS store), 4: three (11 steps).  M-1M: 2.336 (k_edge_ring_h) ->
                                  // 2.340 with the request in the window of its store -> 2.288 / 2.260 / 2.245 / 2.250 at AHEAD 3 (request at step 2 / 0), 4, 5
 #endif
-struct Rs {
+template <int NCH>                              // NCH: chains (L x L products) per tile, all through the one ring
+struct RsT {
     static constexpr int W = HS_W;
-    static constexpr int WPL = 32 / W;          // windows per layer: 8
-    static constexpr int NW = 3 * WPL;          // windows per tile: 24
+    static constexpr int WPL = 32 / W;          // windows per chain: 8
+    static constexpr int NW = NCH * WPL;        // windows per tile
     static constexpr int NB = 3;                // window buffers (a window is requested two windows ahead and stored in the window it is requested in)
     static constexpr int BUF = 2 * W * 64;      // u32x4 elements per buffer: [step][hi, lo][lane]
     static constexpr int AHEAD = MGN_HS_AHEAD;  // windows between a window's request and its first use
     static constexpr int SLOTS = AHEAD - 1;     // requests in flight per thread
     static_assert(NW % NB == 0 && NW % SLOTS == 0 && AHEAD >= 3, "static window -> buffer / slot mapping");
 };
-template <int LYR>
+typedef RsT<3> Rs;                              // k_edge_ring_hs: three layers
+template <int LYR>                              // (window -> buffer is window % NB for every NCH: the first window of chain LYR)
 DEVINL RhFrag rs_first(const u32x4* ring) {
     constexpr int b = (Rs::WPL * LYR) % Rs::NB;
     RhFrag f;
@@ -1307,17 +1309,20 @@ DEVINL RhFrag rs_first(const u32x4* ring) {
     f.l = ring[b * Rs::BUF + 64];
     return f;
 }
-struct RsSrc {
-    const u32x4* w[3];                          // the chunks of layers 1..3 (W1e, W2, W3): hi piece at + 0, lo piece at + 2048 fragments
+template <int NCH>
+struct RsSrcT {
+    const u32x4* w[NCH];                        // the chunks of the tile's chains in their order: hi piece at + 0, lo piece at + 2048 fragments
 };
+typedef RsSrcT<3> RsSrc;
 // element e of window w of a chunk (e = (step * 2 + piece) * 64 + lane): where it sits in the chunk's global pieces
 DEVINL const u32x4* rs_src(const u32x4* chunk, int w, int e) { return chunk + ((e >> 6) & 1) * 2048 + (w * Rs::W + (e >> 7)) * 64 + (e & 63); }
 // One L x L layer with both pieces from the ring.  Otherwise h2_layer_ring (same split, same products, same order; refill as there).
-template <int LYR, int FIN, int RFS = 0, int NWV = 8, bool WRAP = false>
-DEVINL void hs_layer_ring(f32x16 (&acc)[4], f32x16 (&in)[4], u32x4* ring, const RsSrc& src, RhFrag& nx, u32x4 (&pend)[Rs::SLOTS][Rs::BUF / (NWV * 64)], int lane,
-                          int tid, float sx, float cfin = 0.f, const float* btab = nullptr, const f32x4* rf = nullptr, const N16Buf* rfb = nullptr) {
+// LYR: the chain's place among the NCH chains of a tile (the ring's schedule); WRAP refill: through the descriptor rfb.
+template <int LYR, int FIN, int RFS = 0, int NWV = 8, bool WRAP = false, int NCH = 3>
+DEVINL void hs_layer_ring(f32x16 (&acc)[4], f32x16 (&in)[4], u32x4* ring, const RsSrcT<NCH>& src, RhFrag& nx, u32x4 (&pend)[Rs::SLOTS][Rs::BUF / (NWV * 64)], int lane,
+                          int tid, float sx, float cfin = 0.f, const float* btab = nullptr, const f32x4* rf = nullptr, const N16Buf* rfb = nullptr, int rfs_rt = 0) {
     constexpr int ROT = 2;
-    constexpr int W = Rs::W, WPL = Rs::WPL, NW = Rs::NW, BUF = Rs::BUF, NB = Rs::NB;
+    constexpr int W = Rs::W, WPL = Rs::WPL, NW = RsT<NCH>::NW, BUF = Rs::BUF, NB = Rs::NB;
     constexpr int LPT = BUF / (NWV * 64);        // fragments per thread in a window
     f32x4 side[2 * ROT];
     if constexpr (!WRAP && RFS > 0) {
@@ -1361,10 +1366,11 @@ DEVINL void hs_layer_ring(f32x16 (&acc)[4], f32x16 (&in)[4], u32x4* ring, const 
                 for (int i = 0; i < LPT; ++i)
                     pend[gw % Rs::SLOTS][i] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(src.w[l2] + w2 * W * 64) + voff[i]);
             }
-            if constexpr (RFS > 0) {
+            if constexpr (RFS != 0) {
                 if ((t & 1) && s < 8 - ROT) {                          // registers of k-step s (free since the step began), half t >> 1
                     f32x4 v;
-                    if constexpr (WRAP) v = n16_ld(*rfb, (unsigned)lane * 16u, (2 * s + (t >> 1)) * 1024);
+                    if constexpr (WRAP && RFS < 0) v = rf[(int64_t)(2 * s + (t >> 1)) * rfs_rt];   // (per-lane pointer and stride: the aggregate rows)
+                    else if constexpr (WRAP) v = n16_ld(*rfb, (unsigned)lane * 16u, (2 * s + (t >> 1)) * 1024);
                     else v = rf[(2 * (s + ROT) + (t >> 1)) * RFS];
 #pragma unroll
                     for (int i = 0; i < 4; ++i) in[s >> 1][8 * (s & 1) + 4 * (t >> 1) + i] = v[i];
@@ -1374,8 +1380,8 @@ DEVINL void hs_layer_ring(f32x16 (&acc)[4], f32x16 (&in)[4], u32x4* ring, const 
                 const int gn = WPL * LYR + (it + 1) / W;
                 nx.h = ring[(gn % NB) * BUF + (((it + 1) % W) * 2) * 64];
                 nx.l = ring[(gn % NB) * BUF + (((it + 1) % W) * 2 + 1) * 64];
-            } else if (LYR < 2) {
-                nx = rs_first<(LYR + 1) % 3>(ring);                    // (that window was written two windows ago)
+            } else if (LYR < NCH - 1) {
+                nx = rs_first<LYR + 1>(ring);                          // (that window was written two windows ago)
             }
             if (it % W == W - 1) {                                     // store window gw + 2 (requested in window gw + 2 - AHEAD): its buffer was last read as window gw - 1
                 const int b2 = (gw + 2) % NB;
@@ -1880,6 +1886,10 @@ __global__ __launch_bounds__(512, 2) void k_project_split(const NodeArgs a) {
 #ifndef MGN_PROJ_VREFILL
 #define MGN_PROJ_VREFILL 0       // k_project_split_h: k-steps of the Q chain's input refilled with the next tile's v inside the chain
 #endif
+#ifndef MGN_NRH_AGG_REFILL
+#define MGN_NRH_AGG_REFILL 0     // k_node_ring_hs: 1 = the aggregate rows requested inside the first chain (built, parity green, no gain: 0.810 vs 0.806 ms --
+                                 // the phase costs its bytes, 0.6 GB, not its latency); 0: between the chains, LOAD_AGGREGATE as it is
+#endif
 #ifndef MGN_NODE_VBUF
 #define MGN_NODE_VBUF 0          // k_node_split_h: its v loads (the refill inside layer 3, the next tile's v) as buffer loads through the tile's descriptor
 #endif
@@ -2028,6 +2038,178 @@ __global__ __launch_bounds__(512, 2) void k_node_split_h(const NodeArgs a) {
     }
 }
 
+// ================================================================================================
+// k_node_ring_hs (round 6): node MLP + residual + P / Q projection of the NEXT step in ONE lock-step launch, every weight piece (six
+// chunks, hi and lo) through the window ring of k_edge_ring_hs, the freed LDS holding the tile's v for the residual.  Against
+// k_node_split_h + k_project_split_h: v is read once instead of three times (the residual's second read and the projection's read are
+// gone: 3.79 -> 2.6 GB per step on M-1M), one launch and one LDS prologue (28 KiB) instead of two (2 x 132 KiB).  The arithmetic of
+// the two kernels in their order: the same bits.  Chains of a tile: W1 node part, W1 aggregate part, W2, W3, WP, WQ (48 windows).
+// ================================================================================================
+__global__ __launch_bounds__(512, 2) void k_node_ring_hs(const NodeArgs a) {
+    constexpr int NT = 4, L = 128, NWV = 8, NCH = 6;
+    typedef RsT<NCH> R6;
+    constexpr int BUF = Rs::BUF, LPT = BUF / (NWV * 64);
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lane0 = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int tid = (int)threadIdx.x;
+    u32x4* ringbase = reinterpret_cast<u32x4*>(smem);
+    f32x4* park = reinterpret_cast<f32x4*>(ringbase + Rs::NB * BUF) + wave * 1024;   // this wave's v tile
+    float* tb = reinterpret_cast<float*>(ringbase + Rs::NB * BUF) + NWV * 4096;
+    copy_to_lds(tb, a.tabs, T_COUNT * L);
+    RsSrcT<NCH> src;
+    u32x4 pend[Rs::SLOTS][LPT];
+    {
+        const int order[NCH] = {2, 3, 0, 1, 4, 5};                    // NodeArgs.chunk numbering of the chains
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) src.w[i] = reinterpret_cast<const u32x4*>(a.splith[order[i]]);
+#pragma unroll
+        for (int w = 0; w < 2; ++w)
+#pragma unroll
+            for (int i = 0; i < LPT; ++i) ringbase[w * BUF + i * NWV * 64 + tid] = *rs_src(src.w[0], w, i * NWV * 64 + tid);
+#pragma unroll
+        for (int sl = 0; sl < Rs::SLOTS; ++sl)
+#pragma unroll
+            for (int i = 0; i < LPT; ++i) pend[sl][i] = *rs_src(src.w[0], 2, i * NWV * 64 + tid);
+#pragma unroll
+        for (int x = 2; x < Rs::AHEAD; ++x)
+#pragma unroll
+            for (int i = 0; i < LPT; ++i) pend[(x - Rs::AHEAD + R6::NW) % Rs::SLOTS][i] = *rs_src(src.w[x / Rs::WPL], x % Rs::WPL, i * NWV * 64 + tid);
+    }
+    __syncthreads();
+    const float rswv = a.h2_rs[2], swa = a.h2_s[3], rswa = a.h2_rs[3], rsw2 = a.h2_rs[0], rsw3 = a.h2_rs[1], b2pos = a.h2_b2pos;
+    const float rswp = a.h2_rs[4], rswq = a.h2_rs[5];
+    // lock-step: every wave of the block runs as many tiles as its wave 0; padding tiles compute on the last tile's rows and store nothing
+    TileWalk tw0(a.ntiles, 0, MGN_SPREAD_ROUNDS_NODE), tw(a.ntiles, wave, MGN_SPREAD_ROUNDS_NODE);
+    if (tw0.tile >= tw0.end) return;
+    const int iters = (tw0.end - tw0.tile + tw0.stride - 1) / tw0.stride;
+    const int last = tw0.tile + (iters - 1) * tw0.stride;
+    auto clamp = [&](int t) { return t < tw.end ? t : last; };
+    f32x16 x[NT], acc[NT];
+    load_frag<NT>(x, tile_ptr(a.V, clamp(tw.tile), L, lane0), STRIDE_TILE);
+    // the receiver CSR of the tile's rows, requested a tile ahead (the aggregate rows they point to are requested inside the first chain)
+    int ra0, ra1;
+    {
+        const int n0 = clamp(tw.tile) * TILE + (lane0 & 31);
+        ra0 = n0 < a.n ? a.rowptr[n0] : 0;
+        ra1 = n0 < a.n ? a.rowptr[n0 + 1] : 0;
+    }
+    for (int j = 0; j < iters; ++j) {
+        OPAQUE_LANE();
+        const bool on = tw.tile < tw.end;
+        const int tile = clamp(tw.tile);
+        const int nxt = clamp(tw.tile + tw.stride);
+        const int n = tile * TILE + c;
+        const bool valid = on && n < a.n;
+        const int nn = (n < a.n) ? n : 0;
+        u32x4* ring = ringbase + lane;
+        __builtin_amdgcn_s_setprio(0);
+        RhFrag nx = rs_first<0>(ring);
+#pragma unroll
+        for (int m = 0; m < 16; ++m) {                               // park v for the residual
+            f32x4 v;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = x[m >> 2][4 * (m & 3) + i];
+            park[m * 64 + lane] = v;
+        }
+        const H2Scale sv = h2_scale(h2_rowmax<true>(x));
+        zero_frag<NT>(acc);
+#if MGN_NRH_AGG_REFILL
+        // LOAD_AGGREGATE (tile_common.hpp) in two parts: where a row's sum lives is known from the CSR requested a tile ahead; its sixteen pieces
+        // are requested inside the chain, into the registers of v as the split releases them; straddling runs add their other carry rows behind it
+        const int T1 = ra0 >> 5, T2 = (ra1 - 1) >> 5;
+        const int extra = (ra1 > ra0 && T2 > T1) ? (T2 - T1) : 0;
+        const bool from_agg = (ra1 > ra0) && !extra;
+        const f32x4* src0 = from_agg ? tile_ptr(a.AGG, tile, L, lane) : prow_ptr(a.CARRY, extra ? (int64_t)(2 * T1 + 1) : a.zero_row, L, h);
+        const int astride = from_agg ? STRIDE_TILE : STRIDE_PROW;
+        hs_layer_ring<0, 0, -1, NWV, true, NCH>(acc, x, ring, src, nx, pend, lane, tid, sv.s, 0.f, nullptr, src0, nullptr, astride);   // layer 1, node part
+#pragma unroll
+        for (int m = 12; m < 16; ++m) {
+            const f32x4 v = src0[(int64_t)m * astride];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) x[3][4 * (m & 3) + i] = v[i];
+        }
+        if (__any(extra >= 1)) add_frag<NT>(x, prow_ptr(a.CARRY, extra >= 1 ? (int64_t)2 * (T1 + 1) : a.zero_row, L, h), STRIDE_PROW);
+        if (__any(extra >= 2))
+            for (int q = 2; __any(q <= extra); ++q)
+                if (q <= extra) add_frag<NT>(x, prow_ptr(a.CARRY, (int64_t)2 * (T1 + q), L, h), STRIDE_PROW);
+#else
+        hs_layer_ring<0, 0, 0, NWV, false, NCH>(acc, x, ring, src, nx, pend, lane, tid, sv.s);                    // layer 1, node part
+        {
+            const bool valid_row = n < a.n;                          // (LOAD_AGGREGATE reads `valid`, `nn`, `tile`: rows, not whether the tile stores)
+            const bool valid = valid_row;
+#if defined(MGN_WHATIF_NRH) && (MGN_WHATIF_NRH & 1)      // timing-only builds (wrong results): what each memory phase of this kernel costs
+            (void)valid;
+#else
+            LOAD_AGGREGATE(NT, x, a.rowptr, a.AGG, a.CARRY, a.zero_row);
+#endif
+        }
+#endif
+        h2_finish_frag<NT>(acc, sv.rs * rswv, tb + T_B1 * L, h);                                                  // true units, b1 in
+        const H2Scale sa = h2_scale(h2_rowmax<true>(x));
+        h2_scale_frag<NT>(acc, sa.s * swa);                                                                       // the aggregate chain's units
+        hs_layer_ring<1, 0, 0, NWV, false, NCH>(acc, x, ring, src, nx, pend, lane, tid, sa.s);                    // layer 1, aggregate part
+        const H2Scale s2 = h2_scale(h2_rowmax<false>(acc));
+        zero_frag<NT>(x);
+        hs_layer_ring<2, 1, 0, NWV, false, NCH>(x, acc, ring, src, nx, pend, lane, tid, s2.s);                    // layer 2
+        const float c2 = s2.rs * rsw2 * (sa.rs * rswa);
+        const H2Scale s3 = h2_scale(__builtin_fmaf(h2_rowmax<false>(x), c2, b2pos));
+        zero_frag<NT>(acc);
+        hs_layer_ring<3, 2, 0, NWV, false, NCH>(acc, x, ring, src, nx, pend, lane, tid, s3.s, c2, tb + T_B2 * L + 4 * h);   // layer 3
+        PHASE_FENCE();
+        __builtin_amdgcn_s_setprio(MGN_NODE_MPRIO);
+        h2_finish_frag<NT>(acc, s3.rs * rsw3, tb + T_B3 * L, h);
+        layer_norm_frag<NT>(acc, tb + T_GAMMA * L, tb + T_BETA * L, h);
+#pragma unroll
+        for (int m = 0; m < 16; ++m) {                               // v <- v + v' (v back from the wave's LDS region), stored and kept for the projection
+            const f32x4 v = park[m * 64 + lane];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) x[m >> 2][4 * (m & 3) + i] = v[i] + acc[m >> 2][4 * (m & 3) + i];
+        }
+#if defined(MGN_WHATIF_NRH) && (MGN_WHATIF_NRH & 2)
+        if (valid && a.n < 0) store_frag<NT>(tile_ptr(a.V, tile, L, lane), STRIDE_TILE, x);
+#else
+        if (valid) store_frag<NT>(tile_ptr(a.V, tile, L, lane), STRIDE_TILE, x);
+#endif
+        PHASE_FENCE();
+        __builtin_amdgcn_s_setprio(0);
+        const H2Scale sp = h2_scale(h2_rowmax<true>(x));
+        zero_frag<NT>(acc);
+        hs_layer_ring<4, 0, 0, NWV, false, NCH>(acc, x, ring, src, nx, pend, lane, tid, sp.s);                    // P = v W1s
+        __builtin_amdgcn_s_setprio(MGN_NODE_MPRIO);
+        h2_scale_frag<NT>(acc, sp.rs * rswp);
+#if defined(MGN_WHATIF_NRH) && (MGN_WHATIF_NRH & 4)
+        if (valid && a.n < 0) store_frag<NT>(prow_ptr(a.P, nn, L, h), STRIDE_PROW, acc);
+#else
+        if (valid) store_frag<NT>(prow_ptr(a.P, nn, L, h), STRIDE_PROW, acc);
+#endif
+        __builtin_amdgcn_s_setprio(0);
+        zero_frag<NT>(acc);
+        // Q = v W1r + b1; its input registers are refilled, as the split releases them, with the NEXT tile's v
+        const N16Buf vnb = n16_buf(a.V + (int64_t)nxt * (TILE * L), TILE * L * 4);
+        hs_layer_ring<5, 0, STRIDE_TILE, NWV, true, NCH>(acc, x, ring, src, nx, pend, lane, tid, sp.s, 0.f, nullptr, nullptr, &vnb);
+        __builtin_amdgcn_s_setprio(MGN_NODE_MPRIO);
+#pragma unroll
+        for (int m = 12; m < 16; ++m) {                              // k-steps 6 and 7 of the next tile's v
+            const f32x4 v = n16_ld(vnb, (unsigned)lane * 16u, m * 1024);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) x[3][4 * (m & 3) + i] = v[i];
+        }
+        {
+            const int n1 = nxt * TILE + c;                           // the next tile's CSR entries
+            ra0 = n1 < a.n ? a.rowptr[n1] : 0;
+            ra1 = n1 < a.n ? a.rowptr[n1 + 1] : 0;
+        }
+        h2_finish_frag<NT>(acc, sp.rs * rswq, tb + T_BQ * L, h);
+#if defined(MGN_WHATIF_NRH) && (MGN_WHATIF_NRH & 4)
+        if (valid && a.n < 0) store_frag<NT>(prow_ptr(a.Q, nn, L, h), STRIDE_PROW, acc);
+#else
+        if (valid) store_frag<NT>(prow_ptr(a.Q, nn, L, h), STRIDE_PROW, acc);
+#endif
+        tw.tile += tw.stride;
+    }
+}
+
 __global__ __launch_bounds__(512, 2) void k_project_split_h(const NodeArgs a) {
     constexpr int NT = 4, L = 128, PC = 16384;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -2128,6 +2310,15 @@ hipError_t launch_node_split(const NodeArgs& a, const LaunchCfg& lc, hipStream_t
 hipError_t launch_node_split_h(const NodeArgs& a, const LaunchCfg& lc, hipStream_t s) {
     static bool attr_set = false;
     return sp_launch(k_node_split_h, a, lc, s, attr_set);
+}
+static int g_node_ring_hs = [] { const char* e = getenv("MGN_NODE_RING_HS"); return e ? atoi(e) : 1; }();   // 1 (default): node MLP + projection as k_node_ring_hs where both would run; 0: k_node_split_h + k_project_split_h
+int node_ring_hs_enabled() { return g_node_ring_hs; }
+hipError_t launch_node_ring_hs(const NodeArgs& a, const LaunchCfg& lc, hipStream_t s) {
+    static bool attr_set = false;
+    LaunchCfg ls = lc;
+    ls.threads = 512;
+    ls.lds = (size_t)Rs::NB * Rs::BUF * 16 + (size_t)8 * 16384 + (size_t)T_COUNT * 128 * 4 + 64;
+    return sp_launch(k_node_ring_hs, a, ls, s, attr_set);
 }
 hipError_t launch_project_split_h(const NodeArgs& a, const LaunchCfg& lc, hipStream_t s) {
     static bool attr_set = false;
