@@ -1282,6 +1282,9 @@ __global__ __launch_bounds__(NWV * 64, NWV / 4) void k_edge_ring_h(const EdgeArg
 // requests loses its sixteen largest, and a block's LDS prologue is 28 KiB instead of 150.
 // ================================================================================================
 constexpr int HS_W = 4;
+#ifndef MGN_HS_PREMUL
+#define MGN_HS_PREMUL 0          // 1: the gathered Q rows are put into the accumulator's units block by block inside layer 1's first k-step (measured: no gain, 2.174 vs 2.165 ms)
+#endif
 #ifndef MGN_HS_REQ_STEP
 #define MGN_HS_REQ_STEP 0        // step of window gw (0 .. 3) at which window gw + MGN_HS_AHEAD is requested
 #endif
@@ -1318,9 +1321,11 @@ typedef RsSrcT<3> RsSrc;
 DEVINL const u32x4* rs_src(const u32x4* chunk, int w, int e) { return chunk + ((e >> 6) & 1) * 2048 + (w * Rs::W + (e >> 7)) * 64 + (e & 63); }
 // One L x L layer with both pieces from the ring.  Otherwise h2_layer_ring (same split, same products, same order; refill as there).
 // LYR: the chain's place among the NCH chains of a tile (the ring's schedule); WRAP refill: through the descriptor rfb.
-template <int LYR, int FIN, int RFS = 0, int NWV = 8, bool WRAP = false, int NCH = 3>
+// PREMUL: acc enters in other units (the gathered Q rows): block t is multiplied by `premul` at step (0, t), just ahead of its first product --
+// its four pieces are waited for there, not all sixteen before the chain.
+template <int LYR, int FIN, int RFS = 0, int NWV = 8, bool WRAP = false, int NCH = 3, bool PREMUL = false>
 DEVINL void hs_layer_ring(f32x16 (&acc)[4], f32x16 (&in)[4], u32x4* ring, const RsSrcT<NCH>& src, RhFrag& nx, u32x4 (&pend)[Rs::SLOTS][Rs::BUF / (NWV * 64)], int lane,
-                          int tid, float sx, float cfin = 0.f, const float* btab = nullptr, const f32x4* rf = nullptr, const N16Buf* rfb = nullptr, int rfs_rt = 0) {
+                          int tid, float sx, float cfin = 0.f, const float* btab = nullptr, const f32x4* rf = nullptr, const N16Buf* rfb = nullptr, int rfs_rt = 0, float premul = 1.f) {
     constexpr int ROT = 2;
     constexpr int W = Rs::W, WPL = Rs::WPL, NW = RsT<NCH>::NW, BUF = Rs::BUF, NB = Rs::NB;
     constexpr int LPT = BUF / (NWV * 64);        // fragments per thread in a window
@@ -1392,6 +1397,12 @@ DEVINL void hs_layer_ring(f32x16 (&acc)[4], f32x16 (&in)[4], u32x4* ring, const 
                 const int sn = s + 1;
                 const f32x2 b = bias(sn, t);
                 h2_split_pair<FIN>(nh[t], nl[t], in[sn >> 1][8 * (sn & 1) + 2 * t], in[sn >> 1][8 * (sn & 1) + 2 * t + 1], sx, cfin, b[0], b[1]);
+            }
+            if constexpr (PREMUL) {
+                if (s == 0) {
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) acc[t][k] *= premul;
+                }
             }
             const sp_f16x8 bh = h2_op(ph), bl = h2_op(pl);
             acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h2_wop(a2), bh, acc[t], 0, 0, 0);      // small terms first
@@ -1494,6 +1505,10 @@ __global__ __launch_bounds__(NWV * 64, NWV / 4) void k_edge_ring_hs(const EdgeAr
         }
         // layer 1 (edge part): y = e tile in, P[s] out; acc enters with Q[r] (which carries b1), put into the accumulator's units
         const H2Scale x1 = h2_scale(h2_rowmax<true>(y));
+        const int ps_row = ix.s;
+#if MGN_HS_PREMUL
+        hs_layer_ring<0, 0, STRIDE_PROW, NWV, false, 3, true>(acc, y, ring, src, nx, pend, lane, tid, x1.s, 0.f, nullptr, prow_ptr(a.P, ps_row, L, h), nullptr, 0, x1.s * sw1);
+#else
         {
             const float cinv = x1.s * sw1;
 #pragma unroll
@@ -1501,8 +1516,8 @@ __global__ __launch_bounds__(NWV * 64, NWV / 4) void k_edge_ring_hs(const EdgeAr
 #pragma unroll
                 for (int k = 0; k < 16; ++k) acc[t][k] *= cinv;
         }
-        const int ps_row = ix.s;
         hs_layer_ring<0, 0, STRIDE_PROW, NWV>(acc, y, ring, src, nx, pend, lane, tid, x1.s, 0.f, nullptr, prow_ptr(a.P, ps_row, L, h));
+#endif
         {
             const float c1 = x1.rs * rsw1;
 #pragma unroll
