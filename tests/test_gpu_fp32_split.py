@@ -151,6 +151,29 @@ def test_split_ring_block_shapes(nx):
     assert not np.array_equal(e0, e1)              # (the split path did run at this size)
 
 
+@pytest.mark.parametrize("nx", [128, 354])
+def test_processor_pass_is_bitwise_repeatable(nx):
+    """the same latents through the same 15 steps, five times: bit-identical every time.  The streamed kernels pass every weight piece
+    through a three-buffer LDS ring and park the tile's rows in LDS; a window overwritten before its last reader would show up
+    here as a difference between repeats (tools/soak_determinism.py: the same at five sizes up to M-1M, twelve repeats)"""
+    cfg = cfg_dict(mps=15)
+    pos, s, r = synth.mesh_1m(5, nx, nx)
+    N = pos.shape[0]
+    eng = engine_for(cfg)
+    eng.set_params(make_params(cfg, jitter=0.05))
+    eng.set_graph(s, r, N)
+    ref = None
+    for k in range(5):
+        eng.latents_randn(11)
+        eng.processor_steps_dev(15)
+        v, e = eng.latents_export()
+        if ref is None:
+            ref = (v.copy(), e.copy())
+            assert np.isfinite(v).all() and np.isfinite(e).all()
+        else:
+            assert np.array_equal(v, ref[0]) and np.array_equal(e, ref[1]), k
+
+
 @pytest.mark.parametrize("E", [140001, 200003])
 def test_split_ragged_receivers(split_on, E):
     """hub nodes (runs that straddle many tiles), empty receivers, a last partial tile; 140 001 edges run the ring kernel in four-wave
