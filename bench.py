@@ -786,22 +786,24 @@ def main():
                 # per processor step  forward (+ recomputation where the step's activations are not stored) 1 or 2 x (98 304 E + 196 608 N), backward (transposed chunks) 98 304 E + 196 608 N,
                 # weight gradients 98 304 E + 196 608 N  (docs/experiments.md, training step)
                 flT = (4.0 * MPS - max(keepT, 0)) * (98304.0 * E + 196608.0 * N)
-                # forward / recomputation / backward / layer-1 halves run on two fp16 pieces (3 piece products per fp32 product), the weight
-                # gradients on the fp32 MFMA pipe: the weight-gradient products on the fp32 pipe, all others at 3 x on the 16-bit pipe
-                fl32 = MPS * (98304.0 * E + 196608.0 * N)
+                # forward / recomputation / backward / layer-1 halves and (round 6: k_wgrad_h2) the weight gradients run on two fp16 pieces:
+                # 3 piece products per fp32 product on the 16-bit pipe (MGN_WGRAD_H2=0: the weight gradients on the fp32 MFMA pipe)
+                wg_h2 = os.environ.get("MGN_WGRAD_H2", "1") != "0"
+                fl32 = 0.0 if wg_h2 else MPS * (98304.0 * E + 196608.0 * N)
                 fl16 = 3.0 * (flT - fl32)
                 floor_s = fl16 / (PEAK_BF16_MFMA_TFLOPS * 1e12) + fl32 / (PEAK_F32_MFMA_TFLOPS * 1e12)
                 out["secondary"]["train_step_1m"] = {
                     "workload": "mgn_step == step! on M-1M (N = 1 000 000, E = 5 992 002, L = 128, 15 steps; fp32 storage, forward / recomputation / "
-                                "backward MLP chains on two fp16 pieces (MGN_TRAIN_F16=0: fp32 MFMA), weight gradients on the fp32 MFMA pipe; "
+                                "backward MLP chains and weight gradients on two fp16 pieces (MGN_TRAIN_F16=0: fp32 MFMA); "
                                 "activations stored for `stored_steps` of the 15 processor steps -- as many as the device's free memory holds -- and "
                                 "recomputed in the reverse pass for the others); host in/out included",
                     "s_per_step": dtT, "stored_steps": keepT, "loss_finite": bool(np.isfinite(lossT)),
                     "roofline": {"bound": "mfma", "fp32_products_per_step": flT, "executed_flops_16bit": fl16, "executed_flops_fp32": fl32,
                                  "matrix_floor_s": floor_s, "frac": floor_s / dtT, "fp32_equivalent_TFLOPs": flT / dtT / 1e12,
                                  "unit": "s", "achieved": dtT, "peak": floor_s,
-                                 "note": "matrix floor = 16-bit piece products at the dense 16-bit peak + the fp32 weight-gradient products at "
-                                         "157.3 TFLOP/s; the step is HBM-bound in its backward and weight-gradient launches (profiles/r05); processor "
+                                 "note": "matrix floor = 16-bit piece products at the dense 16-bit peak (+ fp32 weight-gradient products at 157.3 TFLOP/s "
+                                         "under MGN_WGRAD_H2=0); the step is HBM-bound: forward, backward and weight-gradient launches move their "
+                                         "20.7 / 30.9 / 15.6 GB at 4.7-5.4 TB/s (profiles/r06); processor "
                                          "MLPs only (encoders / decoder, segmented sums, reductions not counted)"}}
                 engT.close()
                 # ... and with NO step stored (every processor MLP's forward recomputed in the reverse pass: what a device that is not

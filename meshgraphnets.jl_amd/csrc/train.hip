@@ -765,6 +765,186 @@ __global__ __launch_bounds__(256) void k_wgrad_lds(const WgradBatch wb) {
     }
 }
 
+// Round 6: the same product on v_mfma_f32_32x32x16_f16 -- X and G as two fp16 pieces each (split_common.hpp), three piece products, fp32
+// accumulation.  The fp32 instruction above runs a 16-row k-block of one 32 x 32 output block in 8 x 64 cycles, the 16-bit one in 3 x 32: the
+// launch is left with its bytes (M-1M) and its latencies (cylinder mesh).  Rows are the reduction dimension, so one scale per operand has to
+// hold for all rows of an MFMA: a chunk of 32 rows (two k-steps) is scaled by the power of two of its own largest magnitude (per array: all
+// 128 features); the block's sum is kept in the units of the largest scales met so far (`rescale`) and un-scaled once, at the end.  The MFMA wants
+// eight ROWS of one feature per lane: 128 threads per array fetch (8 rows) x (4 features) each with eight 16-byte loads, split their 32
+// values and write four 16-byte units (feature f, row block kb) per piece -- the transposition happens in the registers of the loader.
+// LDS unit order within a row block: (f & 3) * 36 + (f >> 2): both the loaders' writes (features 4 lc + i, lc = 0..31) and the operand
+// reads (features 32 t + m, m = 0..31) meet every bank once.  Two barriers per chunk (its scale, its pieces), one LDS buffer; a chunk's
+// rows are requested two chunks ahead.  Same partial-block format as k_wgrad (k_reduce_partials sums them in order).
+constexpr int WH_ROWS = 32;                 // rows per chunk
+constexpr int WH_KB = WH_ROWS / 8;          // row blocks (one 16-byte unit of eight fp16 per feature and row block)
+constexpr int WH_UPK = 4 * 36;              // units per row block
+constexpr int WH_BUF = WH_KB * WH_UPK;      // units per (array, piece) of a buffer: 9 216 bytes
+constexpr size_t WH_LDS = (size_t)4 * WH_BUF * 16 + 4 * sizeof(float) + 4 * 128 * sizeof(float);
+DEVINL int wh_unit(int f, int kb) { return kb * WH_UPK + (f & 3) * 36 + (f >> 2); }
+
+#ifndef MGN_WH_WHATIF
+#define MGN_WH_WHATIF 0        // timing builds (wrong gradients): 1 no products, 2 no split / LDS writes, 4 no partial store, 8 no maxima, 16 no loads after the first two chunks
+#endif
+#ifndef MGN_WH_BLOCKS
+#define MGN_WH_BLOCKS 2         // blocks per CU (3: the operand reads of a chunk no longer fit the 168 registers -- 317 spilled)
+#endif
+__global__ __launch_bounds__(256, MGN_WH_BLOCKS) void k_wgrad_h2(const WgradBatch wb) {
+    constexpr int NT = 4, L = 128;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    u32x4* const sP = reinterpret_cast<u32x4*>(smem);                       // [X hi, X lo, G hi, G lo][WH_BUF]
+    float* const smax = smem + (size_t)4 * WH_BUF * 4;                      // [wave]: waves 0, 1 load X, waves 2, 3 load G
+    float* const sbs = smax + 4;                                             // [row group][feature]: column sums of G
+    const WgradJob& jb = wb.job[blockIdx.y];
+    const int64_t r0 = (int64_t)blockIdx.x * wb.rows_per_block;
+    if (r0 >= jb.rows) return;
+    const int64_t r1 = r0 + wb.rows_per_block < jb.rows ? r0 + wb.rows_per_block : jb.rows;
+    const int lane = threadIdx.x & 63, m = lane & 31, kg = lane >> 5;
+    const int ti = threadIdx.x >> 6;
+    const float* __restrict__ X = jb.X;
+    const float* __restrict__ G = jb.G;
+    const int32_t* __restrict__ xidx = jb.xidx;
+    const bool with_w = jb.pw != nullptr;
+    // loader role: array (X: threads 0..127, G: 128..255), row group rg (8 rows of the chunk), lc: features 4 lc .. 4 lc + 3
+    const int arr = threadIdx.x >> 7, rg = (threadIdx.x >> 5) & 3, lc = threadIdx.x & 31;
+    const bool loads = arr == 1 || with_w;
+    const int nchunks = (int)((r1 - r0 + WH_ROWS - 1) / WH_ROWS);
+    f32x16 acc[NT];
+    float bs[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int k = 0; k < 16; ++k) acc[t][k] = 0.f;
+
+    auto fetch = [&](int c, f32x4 (&d)[8]) {             // chunk c -> registers (rows past the end: row r0, zeroed in `amax_zero`)
+        if (c >= nchunks || !loads) return;
+        if (MGN_WH_WHATIF & 16) { if (c > 1) return; }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int64_t row = r0 + (int64_t)c * WH_ROWS + 8 * rg + j;
+            const int64_t rr = row < r1 ? row : r0;
+            if (arr == 0) {
+                const int64_t src = xidx ? (int64_t)xidx[rr] : rr;
+                d[j] = reinterpret_cast<const f32x4*>(X + src * L)[lc];
+            } else {
+                d[j] = reinterpret_cast<const f32x4*>(G + rr * L)[lc];
+            }
+        }
+    };
+    // zero the rows past the end, then: this wave's largest magnitude of chunk c -> its slot
+    auto amax_zero = [&](int c, f32x4 (&d)[8]) {
+        if (c >= nchunks) return;
+        if (MGN_WH_WHATIF & 8) { if (lane == 0 && c == 0) smax[ti] = 1.f; return; }
+        float mx = 0.f;
+        if (loads) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const bool ok = r0 + (int64_t)c * WH_ROWS + 8 * rg + j < r1;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    d[j][i] = ok ? d[j][i] : 0.f;
+                    mx = __builtin_fmaxf(mx, __builtin_fabsf(d[j][i]));
+                }
+            }
+        }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) mx = __builtin_fmaxf(mx, __shfl_xor(mx, o, 64));
+        if (lane == 0) smax[ti] = mx;
+    };
+    auto to_lds = [&](const f32x4 (&d)[8], float s) {
+        if (!loads || (MGN_WH_WHATIF & 2)) return;
+        u32x4* const ph = sP + (size_t)(2 * arr) * WH_BUF;
+        u32x4* const pl = ph + WH_BUF;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            unsigned hi[4], lo[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) h2_split_pair<0>(hi[j], lo[j], d[2 * j][i], d[2 * j + 1][i], s);
+            const int u = wh_unit(4 * lc + i, rg);
+            ph[u] = u32x4{hi[0], hi[1], hi[2], hi[3]};
+            pl[u] = u32x4{lo[0], lo[1], lo[2], lo[3]};
+            if (arr == 1) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) bs[i] += d[j][i];
+            }
+        }
+    };
+    auto compute = [&]() {
+        if (!with_w || (MGN_WH_WHATIF & 1)) return;
+        const u32x4* const xh = sP;
+#pragma unroll
+        for (int ks = 0; ks < WH_ROWS / 16; ++ks) {
+            const int ua = wh_unit(32 * ti + m, 2 * ks + kg);
+            const sp_f16x8 ah = h2_wop(xh[ua]), al = h2_wop(xh[WH_BUF + ua]);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const int ub = wh_unit(32 * t + m, 2 * ks + kg);
+                const sp_f16x8 bh = h2_wop(xh[2 * WH_BUF + ub]), bl = h2_wop(xh[3 * WH_BUF + ub]);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[t], 0, 0, 0);      // small terms first
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[t], 0, 0, 0);
+            }
+        }
+    };
+    // the running scales: the power of two of the largest magnitude met so far in each array.  When a chunk raises one, the sum so far
+    // moves to the new units (a power of two <= 1: exact up to underflow of terms 2^-100 below the new largest ones).
+    float runx = 0.f, rung = 0.f;                         // largest magnitudes so far
+    H2Scale sx = h2_scale(0.f), sg = h2_scale(0.f);
+    auto rescale = [&]() {
+        const float mx = __builtin_fmaxf(runx, __builtin_fmaxf(smax[0], smax[1])), mg = __builtin_fmaxf(rung, __builtin_fmaxf(smax[2], smax[3]));
+        runx = mx;
+        rung = mg;
+        const H2Scale nx = h2_scale(mx), ng = h2_scale(mg);
+        const float ratio = (nx.s * sx.rs) * (ng.s * sg.rs);      // new units / old units
+        sx = nx;
+        sg = ng;
+        if (__builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, ratio)) != 0x3f800000) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[t][r] *= ratio;
+        }
+    };
+    f32x4 da[8], db[8];                                   // chunks c and c + 1 (then: the chunks that follow them in their slots)
+    fetch(0, da);
+    fetch(1, db);
+    // two barriers per chunk (scale, pieces): a chunk's rows are requested two chunks before their first use -- with the scale published a
+    // chunk ahead (one barrier) they were used one chunk after their request and every chunk waited for the memory round trip
+    for (int c = 0; c < nchunks; c += 2) {
+        amax_zero(c, da);
+        __syncthreads();          // the scale of chunk c; every wave is past its reads of chunk c - 1's pieces
+        rescale();
+        to_lds(da, arr ? sg.s : sx.s);
+        fetch(c + 2, da);
+        __syncthreads();          // (every wave has read the maxima: the next chunk's may be written)
+        compute();
+        if (c + 1 >= nchunks) break;
+        amax_zero(c + 1, db);
+        __syncthreads();
+        rescale();
+        to_lds(db, arr ? sg.s : sx.s);
+        fetch(c + 3, db);
+        __syncthreads();
+        compute();
+    }
+    // D layout of the 32x32 MFMA: register r of lane l holds D[(r&3) + 8(r>>2) + 4(l>>5)][l&31]
+    if (with_w && !(MGN_WH_WHATIF & 4)) {
+        const float cc = sx.rs * sg.rs;                   // back from the scaled units
+        float* pw = jb.pw + (size_t)blockIdx.x * L * L;
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) pw[(size_t)(32 * ti + (r & 3) + 8 * (r >> 2) + 4 * kg) * L + 32 * t + m] = acc[t][r] * cc;
+    }
+    if (jb.pb) {                                          // column sums of G: the four row groups' sums in a fixed order
+        if (arr == 1) *reinterpret_cast<f32x4*>(&sbs[rg * L + 4 * lc]) = f32x4{bs[0], bs[1], bs[2], bs[3]};
+        __syncthreads();
+        if (threadIdx.x < L) {
+            const int f = threadIdx.x;
+            jb.pb[(size_t)blockIdx.x * L + f] = ((sbs[f] + sbs[L + f]) + sbs[2 * L + f]) + sbs[3 * L + f];
+        }
+    }
+}
+
 // out[r * cols + c] = sum_b partial[b][r * ld + c], fixed order (bitwise reproducible); one job per blockIdx.y
 __global__ void k_reduce_partials(const ReduceBatch rb) {
     const ReduceJob& jb = rb.job[blockIdx.y];
@@ -1246,7 +1426,14 @@ hipError_t launch_mlp_bwd(int L, int nin, const TrainBwdArgs& a, hipStream_t s) 
 }
 
 static int64_t wgrad_rows_per_block(int64_t rows) {
-    static const int min_rows = [] { const char* e = getenv("MGN_WG_MIN_ROWS"); return e ? atoi(e) : WG_ROWS; }();   // (A/B on the cylinder mesh: 64 / 128 rows 3.13 / 3.11 ms per step, 256: 3.68, 512: 4.90 -- a block's row loop is a latency chain)
+    // (A/B on the cylinder mesh, k_wgrad_lds: 64 / 128 rows 3.13 / 3.11 ms per step, 256: 3.68, 512: 4.90 -- a block's row loop is a latency chain;
+    // round 6, k_wgrad_h2 (two blocks per CU): 128 / 160 / 192 / 224 / 256 / 384 rows 2.45 / 2.39 / 2.38 / 2.43 / 2.53 / 2.90 ms, k_wgrad_lds 2.44 at 128, 2.48 at 192)
+    static const int min_rows = [] {
+        const char* e = getenv("MGN_WG_MIN_ROWS");
+        if (e) return atoi(e);
+        const char* h = getenv("MGN_WGRAD_H2");
+        return (h && atoi(h) == 0) ? WG_ROWS : 192;
+    }();
     int64_t rpb = (rows + 1023) / 1024;              // at most 1024 blocks
     if (rpb < min_rows) rpb = min_rows;
     return (rpb + 2 * WG_UNROLL - 1) / (2 * WG_UNROLL) * (2 * WG_UNROLL);
@@ -1404,7 +1591,12 @@ hipError_t launch_wgrad(int L, WgradBatch wb, int64_t rows, hipStream_t s) {
     wb.rows_per_block = wgrad_rows_per_block(rows);
     const dim3 grid(nb, wb.njobs);
     static const int lds = [] { const char* e = getenv("MGN_WGRAD_LDS"); return e ? atoi(e) : 1; }();   // 0: k_wgrad<4> (4-byte operand loads)
-    if (L == 128 && lds) hipLaunchKernelGGL(k_wgrad_lds, grid, dim3(256), 0, s, wb);
+    static const int h2 = [] { const char* e = getenv("MGN_WGRAD_H2"); return e ? atoi(e) : 1; }();      // 0: the fp32 MFMA forms
+    if (L == 128 && h2 && g_train_f16) {
+        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(k_wgrad_h2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)WH_LDS);
+        if (attr != hipSuccess) return attr;
+        hipLaunchKernelGGL(k_wgrad_h2, grid, dim3(256), WH_LDS, s, wb);
+    } else if (L == 128 && lds) hipLaunchKernelGGL(k_wgrad_lds, grid, dim3(256), 0, s, wb);
     else if (L == 128) hipLaunchKernelGGL(k_wgrad<4>, grid, dim3(256), 0, s, wb);
     else if (L == 64) hipLaunchKernelGGL(k_wgrad<2>, grid, dim3(128), 0, s, wb);
     else if (L == 32) hipLaunchKernelGGL(k_wgrad<1>, grid, dim3(64), 0, s, wb);
