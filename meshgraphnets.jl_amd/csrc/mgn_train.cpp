@@ -77,6 +77,7 @@ struct TrainState {
     // whole-array LayerNorm in the training step: per-MLP statistics of the forward (64 floats each), the double partials of the two
     // reductions, (m1, m2) of the pullback
     size_t lnstats = 0, lnpart = 0, lnm = 0;
+    size_t lnrow = 0;                 // (mean, 1 / denominator) per row of the MLP being unwound (TrainBwdArgs::LNROW)
     // weight gradients + their reductions go to a second stream (small meshes leave most of the chip idle during k_mlp_bwd)
     hipStream_t aux = nullptr;
     hipEvent_t ev_bwd = nullptr, ev_wg[GSETS_MAX] = {};
@@ -339,7 +340,8 @@ int prepare_graph(mgn_engine* h) {
         T.ptmp = take((size_t)(N > 0 ? N : 1) * (size_t)std::max(h->cfg.Fn, h->cfg.O));      // row permutations of a renumbered graph
         const int nb = std::max(wgrad_blocks(N), wgrad_blocks(Emax));
         T.pw = take((size_t)5 * (T.gsets > 1 ? T.gsets / 2 : 1) * (nb > 0 ? nb : 1) * L * L);   // one partial-dW region per weight-gradient job of a launch (a group of units on small meshes)
-        T.pb = take((size_t)WGRAD_MAX_JOBS * (nb > 0 ? nb : 1) * L);
+        T.pb = take((size_t)(WGRAD_MAX_JOBS + 1) * (nb > 0 ? nb : 1) * L);   // (+ 1: the second output of a LayerNorm job)
+        T.lnrow = take((size_t)2 * (ML / L));
         if (h->cfg.ln_dims == MGN_LN_ALL) {
             int slot = 0;
             T.m_en.lnslot = slot++;
@@ -790,6 +792,10 @@ int train_run(mgn_handle* h, const TrainJob& J) {
         a.tabs = Wt + b.tabs;
         a.ln = b.ln ? 1 : 0;
         a.GT = A + T.GT[gs]; a.GXH = A + T.GXH[gs]; a.GY = A + T.GY[gs]; a.GZ2 = A + T.GZ2[gs]; a.GZ1 = A + T.GZ1[gs];
+        // One stream (large meshes): the LayerNorm-parameter sums come from a job that re-reads G0 (+ G1) and Y -- they are intact until this
+        // unit's weight-gradient launch has run -- and the row statistics, instead of from GT / G xhat rows written here and read there.
+        const bool lnjob = b.ln && !wide && !overlap && rows > 0 && wgrad_ln_jobs(L) && !train_uses_coop(L, ntiles);   // (the cooperative backward kernels write GT / G xhat)
+        if (lnjob) { a.GT = nullptr; a.GXH = nullptr; a.LNROW = A + T.lnrow; }
         if (wide && rows > 0) {   // pullback of the whole-array LayerNorm: dgamma, dbeta and the two means first (two column reductions)
             HIPCHK(h, launch_lnall_bwd(g0, g1, g1i, A + hb[2], A + T.lnstats + (size_t)64 * lnslot, Wt + b.tabs + (size_t)T_GAMMA * L, rows, L,
                                        reinterpret_cast<double*>(A + T.lnpart), A + T.lnm, G + b.ggamma, G + b.gbeta, st));
@@ -840,7 +846,18 @@ int train_run(mgn_handle* h, const TrainJob& J) {
             job(vin, nullptr, A + T.SGs, b.gW[0], L, L, -1, L, node_rows);
             job(vin, nullptr, A + T.SGr, b.gW[0] + (long)L * L, L, L, -1, L, node_rows);
         }
-        if (b.ln && !wide) {
+        if (lnjob) {
+            WgradJob& j = wb.job[wb.njobs];
+            const int nbj = wgrad_blocks_of_job(lrows, rows);
+            j = WgradJob{};
+            j.G = g0; j.rows = rows;
+            j.Y = A + hb[2]; j.LNROW = A + T.lnrow; j.G1 = g1; j.g1idx = g1i;
+            j.pb = A + T.pb + (size_t)wb.njobs * nb * L;
+            j.pb2 = A + T.pb + (size_t)WGRAD_MAX_JOBS * nb * L;
+            rb.job[rb.njobs++] = ReduceJob{j.pb, nbj, (int64_t)L, 1, L, L, G + b.gbeta};
+            rb.job[rb.njobs++] = ReduceJob{j.pb2, nbj, (int64_t)L, 1, L, L, G + b.ggamma};
+            ++wb.njobs;
+        } else if (b.ln && !wide) {
             job(nullptr, nullptr, A + T.GXH[gs], -1, 0, 0, b.ggamma, L);
             job(nullptr, nullptr, A + T.GT[gs], -1, 0, 0, b.gbeta, L);
         }

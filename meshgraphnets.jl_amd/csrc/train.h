@@ -39,6 +39,7 @@ struct TrainBwdArgs {
     int32_t ln;                                  // 1: row-wise LayerNorm pullback here; 2: the whole-array one -- gy = rden (gamma g - m1 - xhat m2) with
     const float* LNS; const float* LNM;          //    LNS = (mean, rden, kappa) of the forward and LNM = (m1, m2) of launch_lnall_bwd; 0: none
     float* GT; float* GXH;                       // ln: total upstream gradient and G * xhat (-> dbeta, dgamma by column sums)
+    float* LNROW;                                // ln == 1, non-null: (mean, 1 / denominator) of every row instead of GT / GXH -- the LayerNorm job of the weight-gradient launch rebuilds both from G0 (+ G1) and Y (round 6: - 6 GB written per edge MLP on M-1M)
     float* GY; float* GZ2; float* GZ1;           // gradients at the three Dense outputs (-> weight / bias gradients)
     float* GX[3]; const float* GXadd[3];         // GX[j][row] = (GXadd[j] ? GXadd[j][row] : 0) + GZ1[row] * W1T[j]
 };
@@ -67,7 +68,13 @@ hipError_t launch_segment_sum_pair(int L, const float* src, const int32_t* rowpt
 // The row range is split over wgrad_blocks(rows) blocks: pw [nblocks][L][L], pb [nblocks][L] hold per-block partials.
 // pw == null: column sums only (LayerNorm parameter gradients); pb == null: no column sums.
 constexpr int WGRAD_MAX_JOBS = 32;   // (a launch may carry the jobs of several launch units: mgn_train.cpp, weight-gradient groups)
-struct WgradJob { const float* X; const int32_t* xidx; const float* G; int64_t rows; float* pw; float* pb; };
+struct WgradJob {
+    const float* X; const int32_t* xidx; const float* G; int64_t rows; float* pw; float* pb;
+    // LayerNorm job (Y != null; X == null, pw == null; k_wgrad_h2 only -- wgrad_ln_jobs()): g = G[row] + (G1 ? G1[g1idx ? g1idx[row] : row] : 0),
+    // xhat = (Y[row] - LNROW[2 row]) * LNROW[2 row + 1];  pb <- column sums of g (dbeta), pb2 <- column sums of g * xhat (dgamma)
+    const float* Y; const float* LNROW; const float* G1; const int32_t* g1idx; float* pb2;
+};
+bool wgrad_ln_jobs(int L);                   // the weight-gradient launch at this L takes LayerNorm jobs
 struct WgradBatch { int32_t njobs; int64_t rows_per_block; WgradJob job[WGRAD_MAX_JOBS]; };
 int wgrad_blocks(int64_t rows);
 int wgrad_blocks_of_job(int64_t launch_rows, int64_t job_rows);   // blocks of a launch sized for launch_rows that touch a job with fewer rows

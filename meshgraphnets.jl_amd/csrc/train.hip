@@ -198,7 +198,7 @@ __global__ __launch_bounds__(64 * WPB) void k_mlp_bwd(const TrainBwdArgs a) {
             }
     }
     if (a.ln == 1) {
-        if (rw.valid) store_frag<NT>(row_ptr(a.GT, rw.row, L, h), STRIDE_ROW, g);
+        if (a.GT && rw.valid) store_frag<NT>(row_ptr(a.GT, rw.row, L, h), STRIDE_ROW, g);
         load_frag<NT>(y, row_ptr(a.Y, rw.rr, L, h), STRIDE_ROW);
         float s = 0.f;
 #pragma unroll
@@ -222,6 +222,7 @@ __global__ __launch_bounds__(64 * WPB) void k_mlp_bwd(const TrainBwdArgs a) {
         const float lsq = sqrtf(q * invL + a.tabs[T_LN * L]);
         const float rstd = 1.0f / (lsq + a.tabs[T_LN * L + 1]);
         const float kappa = lsq > 0.f ? (lsq + a.tabs[T_LN * L + 1]) / lsq : 1.f;
+        if (a.LNROW && rw.valid && h == 0) *reinterpret_cast<float2*>(a.LNROW + 2 * rw.row) = float2{mean, rstd};
         tab_frag<NT>(acc, a.tabs + T_GAMMA * L, h);           // acc = gamma
         float m1 = 0.f, m2 = 0.f;
 #pragma unroll
@@ -240,7 +241,7 @@ __global__ __launch_bounds__(64 * WPB) void k_mlp_bwd(const TrainBwdArgs a) {
         m2 += __shfl_xor(m2, 32, 64);
         m1 *= invL;
         m2 *= invL * kappa;
-        if (rw.valid) store_frag<NT>(row_ptr(a.GXH, rw.row, L, h), STRIDE_ROW, acc);
+        if (a.GXH && rw.valid) store_frag<NT>(row_ptr(a.GXH, rw.row, L, h), STRIDE_ROW, acc);
 #pragma unroll
         for (int t = 0; t < NT; ++t)
 #pragma unroll
@@ -804,6 +805,59 @@ __global__ __launch_bounds__(256, MGN_WH_BLOCKS) void k_wgrad_h2(const WgradBatc
     const float* __restrict__ G = jb.G;
     const int32_t* __restrict__ xidx = jb.xidx;
     const bool with_w = jb.pw != nullptr;
+    if (jb.Y) {
+        // LayerNorm job: dbeta = column sums of g, dgamma = column sums of g * xhat, with g and xhat rebuilt from the arrays the backward
+        // kernel read (G0 (+ G1), Y) and the row statistics it left -- the same operations in the same order as there.  Thread (rl, lc):
+        // rows r0 + rl, r0 + rl + 8, ..., features 4 lc .. 4 lc + 3, four rows in flight; the eight row lanes are added in a fixed order.
+        const int rl = threadIdx.x >> 5, lc4 = threadIdx.x & 31;
+        const float* __restrict__ Y = jb.Y;
+        const float* __restrict__ G1 = jb.G1;
+        const int32_t* __restrict__ g1i = jb.g1idx;
+        const float2* __restrict__ ST = reinterpret_cast<const float2*>(jb.LNROW);
+        f32x4 sb = {0.f, 0.f, 0.f, 0.f}, sg = {0.f, 0.f, 0.f, 0.f};
+        for (int64_t row = r0 + rl; row < r1; row += 32) {
+            f32x4 gv[4], yv[4], g1v[4];
+            float2 st[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int64_t rr = row + 8 * u < r1 ? row + 8 * u : r0;
+                gv[u] = reinterpret_cast<const f32x4*>(G + rr * L)[lc4];
+                yv[u] = reinterpret_cast<const f32x4*>(Y + rr * L)[lc4];
+                st[u] = ST[rr];
+                if (G1) g1v[u] = reinterpret_cast<const f32x4*>(G1 + (g1i ? (int64_t)g1i[rr] : rr) * L)[lc4];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (row + 8 * u >= r1) break;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float gg = G1 ? gv[u][i] + g1v[u][i] : gv[u][i];
+                    // (one value at a time, fenced: as packed fp32 instructions with op_sel / neg on the loaded (mean, 1 / denominator) pair --
+                    // what hipcc makes of the plain expression, and of an fma form -- the sums of features 4 lc, 4 lc + 2, lc >= 16 differed from
+                    // run to run by ~1e-5 of their value, on every MLP alike; Y alone or the pair alone: stable.  docs/experiments.md)
+                    float d = yv[u][i] - st[u].x;
+                    asm volatile("" : "+v"(d));
+                    float xh = d * st[u].y;
+                    asm volatile("" : "+v"(xh));
+                    sb[i] += gg;
+                    sg[i] += gg * xh;
+                }
+            }
+        }
+        float* const red = smem;                          // [2][8 row lanes][L]
+        *reinterpret_cast<f32x4*>(&red[rl * L + 4 * lc4]) = sb;
+        *reinterpret_cast<f32x4*>(&red[(8 + rl) * L + 4 * lc4]) = sg;
+        __syncthreads();
+        {
+            const int which = threadIdx.x >> 7, f = threadIdx.x & 127;
+            float sum = 0.f;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) sum += red[(8 * which + q) * L + f];
+            float* const out = which ? jb.pb2 : jb.pb;
+            if (out) out[(size_t)blockIdx.x * L + f] = sum;
+        }
+        return;
+    }
     // loader role: array (X: threads 0..127, G: 128..255), row group rg (8 rows of the chunk), lc: features 4 lc .. 4 lc + 3
     const int arr = threadIdx.x >> 7, rg = (threadIdx.x >> 5) & 3, lc = threadIdx.x & 31;
     const bool loads = arr == 1 || with_w;
@@ -1438,6 +1492,14 @@ static int64_t wgrad_rows_per_block(int64_t rows) {
     if (rpb < min_rows) rpb = min_rows;
     return (rpb + 2 * WG_UNROLL - 1) / (2 * WG_UNROLL) * (2 * WG_UNROLL);
 }
+static bool wgrad_h2_on(int L) {
+    static const int h2 = [] { const char* e = getenv("MGN_WGRAD_H2"); return e ? atoi(e) : 1; }();      // 0: the fp32 MFMA forms
+    return L == 128 && h2 && g_train_f16;
+}
+bool wgrad_ln_jobs(int L) {
+    static const int on = [] { const char* e = getenv("MGN_WGRAD_LN_JOBS"); return e ? atoi(e) : 1; }();  // 0: GT / G xhat rows written by the backward kernel, two column-sum jobs
+    return on && wgrad_h2_on(L);
+}
 int wgrad_blocks_of_job(int64_t launch_rows, int64_t job_rows) {
     if (launch_rows <= 0 || job_rows <= 0) return 0;
     const int64_t rpb = wgrad_rows_per_block(launch_rows);
@@ -1591,8 +1653,7 @@ hipError_t launch_wgrad(int L, WgradBatch wb, int64_t rows, hipStream_t s) {
     wb.rows_per_block = wgrad_rows_per_block(rows);
     const dim3 grid(nb, wb.njobs);
     static const int lds = [] { const char* e = getenv("MGN_WGRAD_LDS"); return e ? atoi(e) : 1; }();   // 0: k_wgrad<4> (4-byte operand loads)
-    static const int h2 = [] { const char* e = getenv("MGN_WGRAD_H2"); return e ? atoi(e) : 1; }();      // 0: the fp32 MFMA forms
-    if (L == 128 && h2 && g_train_f16) {
+    if (wgrad_h2_on(L)) {
         static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(k_wgrad_h2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)WH_LDS);
         if (attr != hipSuccess) return attr;
         hipLaunchKernelGGL(k_wgrad_h2, grid, dim3(256), WH_LDS, s, wb);
