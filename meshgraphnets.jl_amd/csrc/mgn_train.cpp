@@ -77,6 +77,7 @@ struct TrainState {
     // whole-array LayerNorm in the training step: per-MLP statistics of the forward (64 floats each), the double partials of the two
     // reductions, (m1, m2) of the pullback
     size_t lnstats = 0, lnpart = 0, lnm = 0;
+    size_t segcarry = 0;              // carry rows of the fused aggregation (2 per edge tile; TrainFwdArgs::SEG_CARRY)
     size_t lnrow = 0;                 // (mean, 1 / denominator) per row of the MLP being unwound (TrainBwdArgs::LNROW)
     // weight gradients + their reductions go to a second stream (small meshes leave most of the chip idle during k_mlp_bwd)
     hipStream_t aux = nullptr;
@@ -342,6 +343,7 @@ int prepare_graph(mgn_engine* h) {
         T.pw = take((size_t)5 * (T.gsets > 1 ? T.gsets / 2 : 1) * (nb > 0 ? nb : 1) * L * L);   // one partial-dW region per weight-gradient job of a launch (a group of units on small meshes)
         T.pb = take((size_t)(WGRAD_MAX_JOBS + 1) * (nb > 0 ? nb : 1) * L);   // (+ 1: the second output of a LayerNorm job)
         T.lnrow = take((size_t)2 * (ML / L));
+        T.segcarry = take((size_t)2 * ((ELmax / L + TILE - 1) / TILE + 1) * L);
         if (h->cfg.ln_dims == MGN_LN_ALL) {
             int slot = 0;
             T.m_en.lnslot = slot++;
@@ -591,12 +593,12 @@ int train_run(mgn_handle* h, const TrainJob& J) {
             }
             a.W2 = Wt + b.W2; a.W3 = Wt + b.W3; a.tabs = Wt + b.tabs;
             if (keep) { a.H1 = A + act.h[bi][0]; a.H2 = A + act.h[bi][1]; a.Y = A + act.h[bi][2]; }
-            if (last) { a.resid = resid; a.OUT = out; a.LNOUT = lnout; }
+            if (last) { a.resid = resid; a.OUT = out; a.LNOUT = lnout; a.SEG_RCV = in.SEG_RCV; a.SEG_AGG = in.SEG_AGG; a.SEG_CARRY = in.SEG_CARRY; }
             else if (!keep) a.OUT = A + act.h[bi][2];
             a.ln = b.ln ? 1 : 0;
             const bool wide = lnall && last && b.ln;      // whole-array LayerNorm: the kernel stops at Y, statistics and apply follow
             const bool want_stats = wide && (out || lnout) && in.rows > 0;   // (the recomputation of the reverse pass asks for neither: the statistics are kept)
-            if (wide) { a.ln = 0; a.resid = nullptr; a.OUT = nullptr; a.LNOUT = nullptr; a.Y = A + act.h[bi][2]; }
+            if (wide) { a.ln = 0; a.resid = nullptr; a.OUT = nullptr; a.LNOUT = nullptr; a.SEG_RCV = nullptr; a.Y = A + act.h[bi][2]; }
             if (want_stats) a.STATS = reinterpret_cast<double*>(A + T.lnpart);   // the kernel leaves (sum, sum of squares) of Y per tile
             if (hipError_t e = launch_mlp_fwd(L, nin, a, st)) return e;
             if (want_stats) {
@@ -618,10 +620,12 @@ int train_run(mgn_handle* h, const TrainJob& J) {
         return run_fwd(m, a, -1, act, resid, out, lnout, keep);
     };
     // edge MLP of step k, set q: [v_s; v_r; e] -> MLP + LayerNorm; with the factored first layer P[s] + Q[r] + e W1e
-    auto fwd_edge = [&](int q, int k, const float* resid, float* out, float* lnout, bool keep = true) -> hipError_t {
+    // segagg != null: the launch aggregates e' itself (train.h: SEG_*; the caller follows up with launch_seg_fixup)
+    auto fwd_edge = [&](int q, int k, const float* resid, float* out, float* lnout, bool keep = true, float* segagg = nullptr) -> hipError_t {
         const TrainMlp& m = T.m_pe[q][k];
         TrainFwdArgs a{};
         a.rows = sx[q].E; a.ntiles = sx[q].nt;
+        if (segagg) { a.SEG_RCV = sx[q].rcv; a.SEG_AGG = segagg; a.SEG_CARRY = A + T.segcarry; }
         if (!T.factored[q]) {
             a.X[0] = A + T.Vk[k]; a.xidx[0] = sx[q].snd;
             a.X[1] = A + T.Vk[k]; a.xidx[1] = sx[q].rcv;
@@ -685,6 +689,11 @@ int train_run(mgn_handle* h, const TrainJob& J) {
         HIPCHK(h, fwd(T.m_ee[q], sx[q].E, sx[q].nt, A + T.ef_pad[q], sx[q].egid, nullptr, nullptr, T.a_ee[q], nullptr, A + T.Ek[q][0], nullptr));
     for (int k = 0; k < mps; ++k) {
         for (int q = 0; q < S; ++q) {
+            if (!lnall && sx[q].E > 0 && train_fwd_fused_agg(L, sx[q].nt)) {   // aggregation inside the edge launch (large meshes)
+                HIPCHK(h, fwd_edge(q, k, A + T.Ek[q][k], A + T.Ek[q][k + 1], nullptr, T.kept(k, mps), A + T.agg[q][k]));
+                HIPCHK(h, launch_seg_fixup(L, sx[q].rowptr, A + T.segcarry, A + T.agg[q][k], (int32_t)N, st));
+                continue;
+            }
             HIPCHK(h, fwd_edge(q, k, A + T.Ek[q][k], A + T.Ek[q][k + 1], A + T.Enew, T.kept(k, mps)));
             HIPCHK(h, launch_segment_sum(L, A + T.Enew, sx[q].rowptr, nullptr, nullptr, A + T.agg[q][k], (int32_t)N, st));
         }

@@ -21,6 +21,11 @@ struct TrainFwdArgs {
     float* H1; float* H2; float* Y;              // kept for the backward (null: not stored -- first pass of recompute mode)
     const float* resid; float* OUT;              // OUT = (resid ? resid : 0) + (ln ? LayerNorm(Y) : Y)
     float* LNOUT;                                // optional: LayerNorm(Y) alone (the message e' that is aggregated)
+    // round 6, streaming kernels (train_fwd_fused_agg): the aggregation of e' = LayerNorm(Y) over runs of equal receiver inside the launch instead
+    // of LNOUT + a segmented-sum pass -- rows are receiver-sorted, a run that lies inside a 32-row tile goes to SEG_AGG[receiver] (plain rows), the
+    // pieces of a run that crosses tile borders to SEG_CARRY rows 2 tile (the part that continues from the tile before) / 2 tile + 1 (the part
+    // that continues into the next); launch_seg_fixup adds the pieces up and zeroes the nodes without edges.  SEG_RCV: the receiver of every row.
+    const int32_t* SEG_RCV; float* SEG_AGG; float* SEG_CARRY;
     int32_t ln;
     // factored first layer (edge MLP on large meshes): layer-1 pre-activation += PRE[i][preidx[i] ? preidx[i][row] : row]
     // (P = v W1_sender and Q = v W1_receiver, computed once per NODE by launch_lin2)
@@ -45,6 +50,9 @@ struct TrainBwdArgs {
 };
 
 hipError_t launch_mlp_fwd(int L, int nin, const TrainFwdArgs& a, hipStream_t s);
+bool train_fwd_fused_agg(int L, int ntiles);   // the forward launch of this size takes SEG_* (streaming kernels at L = 128; MGN_TRAIN_FUSED_AGG = 0: never)
+// agg[n] = 0 for a node without edges, the sum of its carry rows for a node whose run of edges crosses tile borders (others: written by the forward kernel)
+hipError_t launch_seg_fixup(int L, const int32_t* rowptr, const float* carry, float* agg, int32_t n, hipStream_t s);
 hipError_t launch_mlp_bwd(int L, int nin, const TrainBwdArgs& a, hipStream_t s);
 bool train_uses_coop(int L, int ntiles);
 int set_train_f16(int on);                 // 1 (default): streaming training kernels at L = 128 on two fp16 pieces / three products, 0: fp32 MFMA; returns the old value     // the cooperative 4-wave MLP kernels serve this launch size

@@ -11,6 +11,7 @@
 #include <unordered_map>
 
 #include "frag.hpp"
+#include "tile_common.hpp"
 #include "split_common.hpp"
 
 namespace mgn {
@@ -150,8 +151,60 @@ __global__ __launch_bounds__(64 * WPB) void k_mlp_fwd(const TrainFwdArgs a) {
     }
     if (a.ln) layer_norm_frag<NT>(acc, a.tabs + T_GAMMA * L, a.tabs + T_BETA * L, h);
     if (a.LNOUT && rw.valid) store_frag<NT>(row_ptr(a.LNOUT, rw.row, L, h), STRIDE_ROW, acc);
+    if constexpr (NT == 4 && WPB == 8) {
+        if (a.SEG_RCV) {
+            // OUT = resid + e' from a second array (x is free), then the segmented sum of e' over runs of equal receiver as in the inference
+            // kernels (tile_common.hpp: segmented_scan; both halves of a row see the same structure)
+            if (a.OUT) {
+                if (a.resid) load_frag<NT>(x, row_ptr(a.resid, rw.rr, L, h), STRIDE_ROW);
+                else zero_frag<NT>(x);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) x[t] += acc[t];
+                if (rw.valid) store_frag<NT>(row_ptr(a.OUT, rw.row, L, h), STRIDE_ROW, x);
+            }
+            const int64_t e0 = (int64_t)tile * TILE;
+            const int r = a.SEG_RCV[rw.rr];
+            const int r_before = a.SEG_RCV[e0 > 0 ? e0 - 1 : 0], r_after = a.SEG_RCV[e0 + TILE < a.rows ? e0 + TILE : a.rows - 1];
+            const int reff = rw.valid ? r : (-4 - c);
+            const int rprev = __shfl_up(reff, 1, 32);
+            const int rnext = __shfl_down(reff, 1, 32);
+            const bool head = (c == 0) || (reff != rprev);
+            const unsigned hm = (unsigned)__ballot(head);
+            const int start = 31 - __clz((int)(hm & (0xFFFFFFFFu >> (31 - c))));
+            const int st_in = max(start, c & 16);
+            const bool c1 = (c - 1 >= st_in), c2 = (c - 2 >= st_in), c4 = (c - 4 >= st_in), c8 = (c - 8 >= st_in);
+            const bool cx = (c >= 16) && (start <= 15);
+            segmented_scan<NT>(acc, c1, c2, c4, c8, cx);
+            const bool tail = rw.valid && ((c == 31) || (reff != rnext));
+            const int r_first = __builtin_amdgcn_readfirstlane(reff);
+            const bool sl = (start == 0) && e0 > 0 && (r_before == r_first);            // the run continues from the tile before
+            const bool sr = (c == 31) && (e0 + TILE < a.rows) && (r_after == reff);     // ... into the next tile
+            const bool to_carry = sl || sr;
+            f32x4* dst = to_carry ? row_ptr(a.SEG_CARRY, (int64_t)2 * tile + (sl ? 0 : 1), L, h) : row_ptr(a.SEG_AGG, r, L, h);
+            if (tail) store_frag<NT>(dst, STRIDE_ROW, acc);
+            return;
+        }
+    }
     if (a.resid) add_frag<NT>(acc, row_ptr(a.resid, rw.rr, L, h), STRIDE_ROW);
     if (a.OUT && rw.valid) store_frag<NT>(row_ptr(a.OUT, rw.row, L, h), STRIDE_ROW, acc);
+}
+
+// the nodes the fused aggregation of k_mlp_fwd leaves open: no edges -> zeros; a run of edges over several tiles -> the sum of its carry rows
+__global__ void k_seg_fixup(const int32_t* __restrict__ rowptr, const float* __restrict__ carry, float* __restrict__ agg, int32_t n, int L4) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)n * L4) return;
+    const int node = (int)(i / L4), q = (int)(i - (int64_t)node * L4);
+    const int a0 = rowptr[node], a1 = rowptr[node + 1];
+    if (a1 > a0) {
+        const int T1 = a0 >> 5, T2 = (a1 - 1) >> 5;
+        if (T2 == T1) return;
+        const f32x4* C4 = reinterpret_cast<const f32x4*>(carry);
+        f32x4 s = C4[(int64_t)(2 * T1 + 1) * L4 + q];
+        for (int t = T1 + 1; t <= T2; ++t) s += C4[(int64_t)(2 * t) * L4 + q];
+        reinterpret_cast<f32x4*>(agg)[i] = s;
+    } else {
+        reinterpret_cast<f32x4*>(agg)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
 }
 
 // ================================================================================================
@@ -1399,6 +1452,16 @@ static hipError_t launch_coop(K kern, const A& a, int ntiles, hipStream_t s) {
 }
 
 bool train_uses_coop(int L, int ntiles) { return train_coop(L, ntiles); }
+bool train_fwd_fused_agg(int L, int ntiles) {
+    static const int on = [] { const char* e = getenv("MGN_TRAIN_FUSED_AGG"); return e ? atoi(e) : 1; }();
+    return on && L == 128 && !train_coop(L, ntiles) && train_wpb8(L, ntiles);
+}
+hipError_t launch_seg_fixup(int L, const int32_t* rowptr, const float* carry, float* agg, int32_t n, hipStream_t s) {
+    const int64_t tot = (int64_t)n * (L / 4);
+    if (tot <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_seg_fixup, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, rowptr, carry, agg, n, L / 4);
+    return hipGetLastError();
+}
 // the streaming kernels at L = 128 compute on two fp16 pieces per operand, three piece products (train_chunk); MGN_TRAIN_F16=0: fp32 MFMA
 static int g_train_f16 = [] { const char* e = getenv("MGN_TRAIN_F16"); return e ? atoi(e) : 1; }();
 int set_train_f16(int on) { const int old = g_train_f16; g_train_f16 = on; return old; }
