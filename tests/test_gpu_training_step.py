@@ -365,6 +365,37 @@ def test_step_factored_first_layer_above_the_cooperative_range(monkeypatch):
     assert np.linalg.norm(res["1"][0] - res["0"][0]) <= 1e-3 * np.linalg.norm(ref)
 
 
+def test_step_streaming_kernels_on_a_graph_with_hubs_and_isolated_nodes():
+    """The streaming kernels' own aggregation (round 6: a segmented scan inside the forward's edge launch, carry rows for runs that cross
+    32-edge tiles, a fix-up pass) and the LayerNorm job of the weight-gradient launch on a graph that is not a mesh: one node receives
+    300 edges (its run covers whole tiles), one in ten receives none, the rest 0-30; 2 300 edge tiles (above the cooperative range)."""
+    cfg = cfg_dict(L=128, mps=2)
+    rng = np.random.default_rng(31)
+    N, E = 9000, 73600
+    deg = rng.integers(0, 31, N)
+    deg[rng.choice(N, N // 10, replace=False)] = 0
+    deg[17] = 300
+    deg[N - 1] = 0
+    r = np.repeat(np.arange(N), deg)
+    r = np.concatenate([r, rng.integers(0, N, max(0, E - r.size))])[:E].astype(np.int32)
+    s = rng.integers(0, N, E).astype(np.int32)
+    perm = rng.permutation(E)                              # the caller's edge order is arbitrary
+    s, r = s[perm], r[perm]
+    assert (E + 31) // 32 > 2048 and np.bincount(r, minlength=N).max() >= 300 and (np.bincount(r, minlength=N) == 0).sum() > 100
+    pos = rng.random((N, 2)).astype(np.float32)
+    ps = make_params(cfg)
+    nf, ef, target, mask = problem(cfg, pos, s, r, seed=6, frac=0.3)
+    eng = engine_for(cfg)
+    eng.set_params(ps)
+    eng.set_graph(s, r, N)
+    gs, loss = eng.step(nf, ef, target, mask)
+    g2, l2 = eng.step(nf, ef, target, mask)
+    assert l2 == loss and np.array_equal(g2, gs)
+    ref, ref_loss = orc.step_grads(ps, cfg, nf, ef, s, r, target, mask)
+    assert abs(loss - ref_loss) <= TOL_LOSS * abs(ref_loss), (loss, ref_loss)
+    assert np.linalg.norm(gs - ref) <= 1e-3 * np.linalg.norm(ref), np.linalg.norm(gs - ref) / np.linalg.norm(ref)
+
+
 def test_stored_and_recomputed_steps_agree_beyond_32_bit_offsets(monkeypatch):
     """The arena of a 250 000-node mesh with 15 processor steps holds 40 GB when every step's activations are stored (offsets beyond
     2^32 bytes): all stored, seven of fifteen stored and none stored give the same bits; the size rule itself keeps them all (free memory
