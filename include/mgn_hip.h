@@ -69,9 +69,9 @@ typedef struct mgn_config {
                            /* run).  A different network, not a numerical variant: every LayerNorm then couples all rows, so the fused    */
                            /* tile kernels cannot be used; the mode runs unfused (MLP kernel with its LayerNorm off, grid-wide statistics    */
                            /* in double, apply pass) behind mgn_forward, mgn_processor_steps, mgn_set_static + mgn_ode_step (both forms),   */
-                           /* mgn_rollout, and in both directions behind mgn_step, mgn_forward_vjp, mgn_ode_vjp: fp32, one partition, one  */
-                           /* edge set.  mgn_processor_steps_dev and the staged mgn_fwd_* entry points (the fused kernels' device-resident */
-                           /* arrays) answer MGN_E_UNSUPPORTED                                                                             */
+                           /* mgn_rollout, mgn_processor_steps_dev (the resident latents pass through the same driver as rows), and in     */
+                           /* both directions behind mgn_step, mgn_forward_vjp, mgn_ode_vjp: fp32, one partition, one edge set.  The staged */
+                           /* per-step calls of the fused kernels (mgn_proc_*, mgn_fwd_*) answer MGN_E_UNSUPPORTED                          */
 } mgn_config;
 
 typedef enum { MGN_LN_VAR_EPS = 0, MGN_LN_STD_EPS = 1 } mgn_ln_mode;

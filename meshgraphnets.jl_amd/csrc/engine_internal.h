@@ -143,6 +143,7 @@ struct mgn_engine {
     // static per-trajectory RHS inputs (mgn_set_static): cached encoded edge latents
     bool have_static = false;
     DevBuf stage;     // device staging image of caller-order latents (import / export)
+    DevBuf lnall_v, lnall_e;   // mgn_processor_steps_dev under ln_dims = MGN_LN_ALL: the resident latents as caller-order rows for the unfused driver
     DevBuf gwork, gout, gpos, gtype;   // device-side graph prologue (csrc/graph_dev.hip): scratch, outputs, positions, node types
     DevBuf d_stamps;  // diagnostic builds only
     DevBuf ode;       // native rollout: state, stages, frames, saves, Elat0

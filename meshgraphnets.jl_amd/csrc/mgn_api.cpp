@@ -245,7 +245,7 @@ int need(mgn_engine* h, bool params, bool graph, bool packed, bool lnall_ok) {
     // whole-array LayerNorm couples every row of an MLP's output: the fused kernels behind the other compute entry points cannot
     // compute it (mgn_forward and mgn_processor_steps branch off to the unfused driver before they get here)
     if (params && graph && h->cfg.ln_dims == MGN_LN_ALL && !lnall_ok)
-        return fail(h, MGN_E_UNSUPPORTED, "ln_dims = MGN_LN_ALL (whole-array LayerNorm) is served by mgn_forward, mgn_processor_steps and the one-shot mgn_ode_step only");
+        return fail(h, MGN_E_UNSUPPORTED, "ln_dims = MGN_LN_ALL (whole-array LayerNorm) is not served by this entry point (the staged mgn_fwd_* / mgn_proc_* calls run the fused kernels only)");
     if (params && !h->have_params) return fail(h, MGN_E_STATE, "mgn_set_params has not been called");
     if (graph && !h->have_graph) return fail(h, MGN_E_STATE, "mgn_set_graph has not been called");
     if (params && packed && !h->packed_ok) return pack_inference_weights(h);
@@ -2356,7 +2356,32 @@ static int processor_pass(mgn_handle* h, int32_t nsteps) {
     return run_processor(h, nsteps);
 }
 
+// mgn_processor_steps_dev under ln_dims = MGN_LN_ALL (round 6): the resident latents leave their tiles as caller-order rows, the unfused
+// whole-array driver (mgn_train.cpp: lnall_processor_steps; it takes device pointers) advances them, they go back.  Two row <-> tile passes
+// per call on top of what mgn_processor_steps costs in this mode -- and no host copy.
+static int lnall_processor_steps_dev(mgn_handle* h, int32_t nsteps) {
+    if (int rc = need(h, true, true, true, true)) return rc;
+    if (nsteps < 0 || nsteps > h->cfg.mps) return fail(h, MGN_E_ARG, "nsteps must be in [0, mps]");
+    if (nsteps == 0) return MGN_OK;
+    const LocalGraph& g = h->g;
+    const EdgeTopo& t = g.set[0];
+    auto& es = h->es[0];
+    const int L = h->cfg.L;
+    HIPCHK(h, h->lnall_v.ensure((size_t)(g.N > 0 ? g.N : 1) * L * 4));
+    HIPCHK(h, h->lnall_e.ensure((size_t)(t.E > 0 ? t.E : 1) * L * 4));
+    HIPCHK(h, launch_tiles_to_rows(h->V.as<float>(), nullptr, h->d_own_gid.as<int32_t>(), h->lnall_v.as<float>(), g.n_own, L, h->stream));
+    if (t.e_local > 0)
+        HIPCHK(h, launch_tiles_to_rows(es.Elat.as<float>(), es.d_edge_gid.as<int64_t>(), nullptr, h->lnall_e.as<float>(), t.e_local, L, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (int rc = lnall_processor_steps(h, h->lnall_v.as<float>(), h->lnall_e.as<float>(), nsteps)) return rc;   // (synchronises its stream)
+    HIPCHK(h, launch_rows_to_tiles(h->lnall_v.as<float>(), nullptr, h->d_own_gid.as<int32_t>(), h->V.as<float>(), g.n_own, L, h->stream));
+    if (t.e_local > 0)
+        HIPCHK(h, launch_rows_to_tiles(h->lnall_e.as<float>(), es.d_edge_gid.as<int64_t>(), nullptr, es.Elat.as<float>(), t.e_local, L, h->stream));
+    return MGN_OK;
+}
+
 int mgn_processor_steps_dev(mgn_handle* h, int32_t nsteps) try {
+    if (h && !h->host_only && h->cfg.ln_dims == MGN_LN_ALL) return lnall_processor_steps_dev(h, nsteps);
     if (int rc = need(h, true, true)) return rc;
     if (nsteps < 0 || nsteps > h->cfg.mps) return fail(h, MGN_E_ARG, "nsteps must be in [0, mps]");
     if (nsteps == 0) return MGN_OK;

@@ -140,7 +140,8 @@ def test_whole_array_layernorm_is_an_engine_mode(whole_array_oracle):
     LayerNorm(shape) computes when it is left at dims = Colon() (reference Project.toml:15,40; julia/spec_probe.jl reports it).  The
     engine reproduces the GOLD-G `out_whole_array` fixture, follows the oracle's LN_DIMS = "all" on a 22 500-node mesh (forward of the
     whole model and processor steps, hidden_layers 2 and 3, both ln_mode denominators), in the right-hand side (one-shot and resident forms)
-    and in the native rollout driver, is really the other network, and refuses the one entry point that belongs to the fused kernels."""
+    and in the native rollout driver, is really the other network, serves the device-resident processor entry point through the same
+    driver, and refuses the staged per-step calls that belong to the fused kernels."""
     g = np.load(os.path.join(GOLD, "gold_g_ln_variants.npz"))
     cfg = cfg_dict(L=int(g["L"]), mps=int(g["mps"]))
     ps = orc.init_params(9, 3, 2, cfg["L"], 2, cfg["mps"], seed=int(g["seed"]), ln_jitter=float(g["jitter"]))
@@ -184,10 +185,20 @@ def test_whole_array_layernorm_is_an_engine_mode(whole_array_oracle):
     sol5, st5 = eng.rollout("Tsit5", x0, onehot0, g["ef"], 0.0, 2 * dt, dt, 3, val_mask=vm0)
     ref5 = orc.tsit5_rollout(lambda xx, t: rhs(xx, t), x0.astype(np.float64), 0.0, 2 * dt, [0.0, dt, 2 * dt])
     assert np.linalg.norm(sol5 - np.stack(ref5[0])) / np.linalg.norm(np.stack(ref5[0])) <= 1e-3 and st5["n_rhs"] >= 7
-    # the fused kernels' device-resident processor entry point stays theirs
+    # the device-resident processor entry point (round 6): the resident latents go through the unfused driver as rows and come back --
+    # the same bits as mgn_processor_steps on host arrays; the staged per-step calls of the fused kernels still answer MGN_E_UNSUPPORTED
+    rngl = np.random.default_rng(12)
+    v0 = rngl.standard_normal((N0, 128)).astype(np.float32)
+    e0 = rngl.standard_normal((g["ef"].shape[0], 128)).astype(np.float32)
+    v_host, e_host = eng.processor_steps(v0.copy(), e0.copy(), 2)
+    rv, re_ = orc.processor_steps(ps, cfg, v0, e0, g["senders"], g["receivers"], 2)
+    assert rel_max(v_host, rv) <= TOL_15 and rel_max(e_host, re_) <= TOL_15
+    eng.latents_import(v0, e0)
+    eng.processor_steps_dev(2)
+    v_dev, e_dev = eng.latents_export()
+    assert np.array_equal(v_dev, v_host) and np.array_equal(e_dev, e_host)
     with pytest.raises(MgnError) as ei:
-        eng.latents_randn(1)
-        eng.processor_steps_dev(1)
+        eng.proc_begin()
     assert ei.value.code == -5                                      # MGN_E_UNSUPPORTED
     eng.close()
     # a mesh of the size the persistent kernels serve in the default mode (scattered labels on top: the mode goes through own_gid too)
