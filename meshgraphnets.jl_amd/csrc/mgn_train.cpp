@@ -22,6 +22,8 @@ namespace {
 //   hidden_layers = 3:  [D0, I, I] -> [D1, D2, D3]        (the first block's output is ReLU(z0): no LayerNorm, no residual)
 //   hidden_layers = 4:  [D0, D1, I] -> [D2, D3, D4]
 // One such launch unit with its device offsets (floats into TrainState::w) in training order:
+constexpr int LNSUM_GROUPS = 64;   // first-level groups of the in-kernel LayerNorm-parameter sums
+
 struct TrainBlock {
     int nin = 1;                 // L-wide layer-1 input blocks
     int in_rows = 0;             // rows of W1 that exist (< L for the encoders: zero-padded chunk)
@@ -77,6 +79,7 @@ struct TrainState {
     // whole-array LayerNorm in the training step: per-MLP statistics of the forward (64 floats each), the double partials of the two
     // reductions, (m1, m2) of the pullback
     size_t lnstats = 0, lnpart = 0, lnm = 0;
+    size_t lnsum = 0, lnsum2 = 0;     // per-block LayerNorm-parameter sums of the streaming backward kernel and their first-level reduction (TrainBwdArgs::LNSUM)
     size_t segcarry = 0;              // carry rows of the fused aggregation (2 per edge tile; TrainFwdArgs::SEG_CARRY)
     size_t lnrow = 0;                 // (mean, 1 / denominator) per row of the MLP being unwound (TrainBwdArgs::LNROW)
     // weight gradients + their reductions go to a second stream (small meshes leave most of the chip idle during k_mlp_bwd)
@@ -343,6 +346,8 @@ int prepare_graph(mgn_engine* h) {
         T.pw = take((size_t)5 * (T.gsets > 1 ? T.gsets / 2 : 1) * (nb > 0 ? nb : 1) * L * L);   // one partial-dW region per weight-gradient job of a launch (a group of units on small meshes)
         T.pb = take((size_t)(WGRAD_MAX_JOBS + 1) * (nb > 0 ? nb : 1) * L);   // (+ 1: the second output of a LayerNorm job)
         T.lnrow = take((size_t)2 * (ML / L));
+        T.lnsum = take(((ML / L + TILE - 1) / TILE + 7) / 8 * (size_t)2 * L + 2 * L);
+        T.lnsum2 = take((size_t)LNSUM_GROUPS * 2 * L);
         T.segcarry = take((size_t)2 * ((ELmax / L + TILE - 1) / TILE + 1) * L);
         if (h->cfg.ln_dims == MGN_LN_ALL) {
             int slot = 0;
@@ -803,8 +808,10 @@ int train_run(mgn_handle* h, const TrainJob& J) {
         a.GT = A + T.GT[gs]; a.GXH = A + T.GXH[gs]; a.GY = A + T.GY[gs]; a.GZ2 = A + T.GZ2[gs]; a.GZ1 = A + T.GZ1[gs];
         // One stream (large meshes): the LayerNorm-parameter sums come from a job that re-reads G0 (+ G1) and Y -- they are intact until this
         // unit's weight-gradient launch has run -- and the row statistics, instead of from GT / G xhat rows written here and read there.
-        const bool lnjob = b.ln && !wide && !overlap && rows > 0 && wgrad_ln_jobs(L) && !train_uses_coop(L, ntiles);   // (the cooperative backward kernels write GT / G xhat)
+        const bool lnsum = b.ln && !wide && !overlap && rows > 0 && train_bwd_ln_sums(L, ntiles);     // the sums inside the backward kernel (per block) ...
+        const bool lnjob = !lnsum && b.ln && !wide && !overlap && rows > 0 && wgrad_ln_jobs(L) && !train_uses_coop(L, ntiles);   // ... or a job that re-reads G0 / Y (the cooperative backward kernels write GT / G xhat)
         if (lnjob) { a.GT = nullptr; a.GXH = nullptr; a.LNROW = A + T.lnrow; }
+        if (lnsum) { a.GT = nullptr; a.GXH = nullptr; a.LNSUM = A + T.lnsum; }
         if (wide && rows > 0) {   // pullback of the whole-array LayerNorm: dgamma, dbeta and the two means first (two column reductions)
             HIPCHK(h, launch_lnall_bwd(g0, g1, g1i, A + hb[2], A + T.lnstats + (size_t)64 * lnslot, Wt + b.tabs + (size_t)T_GAMMA * L, rows, L,
                                        reinterpret_cast<double*>(A + T.lnpart), A + T.lnm, G + b.ggamma, G + b.gbeta, st));
@@ -813,6 +820,8 @@ int train_run(mgn_handle* h, const TrainJob& J) {
             a.LNM = A + T.lnm;
         }
         HIPCHK(h, launch_mlp_bwd(L, nin_k, a, st));
+        if (lnsum)    // [blocks][2 L] -> [LNSUM_GROUPS][2 L], in order; the unit's reduction launch adds the groups
+            HIPCHK(h, launch_colsum_groups(A + T.lnsum, (ntiles + 7) / 8, 2 * L, LNSUM_GROUPS, A + T.lnsum2, st));
         if (fact) {   // gather <-> segmented-sum duality on GZ1 itself: SGr[n] = sum of GZ1 over edges received by n, SGs: sent by n
             HIPCHK(h, launch_segment_sum_pair(L, A + T.GZ1[gs], sx[fq].rowptr, sx[fq].rowptr_s, sx[fq].perm_s, A + T.SGr, A + T.SGs, (int32_t)node_rows, st));
         }
@@ -855,7 +864,11 @@ int train_run(mgn_handle* h, const TrainJob& J) {
             job(vin, nullptr, A + T.SGs, b.gW[0], L, L, -1, L, node_rows);
             job(vin, nullptr, A + T.SGr, b.gW[0] + (long)L * L, L, L, -1, L, node_rows);
         }
-        if (lnjob) {
+        if (lnsum) {
+            const int ng = std::min(LNSUM_GROUPS, (int)((ntiles + 7) / 8));
+            rb.job[rb.njobs++] = ReduceJob{A + T.lnsum2, ng, (int64_t)2 * L, 1, L, L, G + b.gbeta};
+            rb.job[rb.njobs++] = ReduceJob{A + T.lnsum2 + L, ng, (int64_t)2 * L, 1, L, L, G + b.ggamma};
+        } else if (lnjob) {
             WgradJob& j = wb.job[wb.njobs];
             const int nbj = wgrad_blocks_of_job(lrows, rows);
             j = WgradJob{};

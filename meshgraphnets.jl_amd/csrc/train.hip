@@ -220,6 +220,27 @@ DEVINL void mask_by_relu(f32x16 (&g)[NT], const f32x16 (&act)[NT]) {
         for (int k = 0; k < 16; ++k) g[t][k] = act[t][k] > 0.f ? g[t][k] : 0.f;
 }
 
+// column sums of a fragment block over the tile's 32 rows (lanes c = 0..31 of each half): an inclusive DPP scan in place -- reach 1, 2, 4, 8
+// inside the 16-lane rows, then lane 15 / 47 into the row above -- leaves the totals in lanes 31 and 63, which store them (feature of register
+// k of block t in half h: 32 t + 8 (k >> 2) + 4 h + (k & 3)).  DPP reads of a register follow its last VALU write by >= 16 instructions.
+DEVINL void colsum_block(f32x16& x, float* dst, int t, int c, int h) {
+#define MGN_COLSUM_LEVEL(CTRL)                                                                         \
+    _Pragma("unroll") for (int k = 0; k < 16; ++k)                                                     \
+        asm volatile("v_add_f32_dpp %0, %0, %0 " CTRL " bound_ctrl:0" : "+v"(x[k]));
+    asm volatile("s_nop 1");
+    MGN_COLSUM_LEVEL("row_shr:1 row_mask:0xf bank_mask:0xf")
+    MGN_COLSUM_LEVEL("row_shr:2 row_mask:0xf bank_mask:0xf")
+    MGN_COLSUM_LEVEL("row_shr:4 row_mask:0xf bank_mask:0xf")
+    MGN_COLSUM_LEVEL("row_shr:8 row_mask:0xf bank_mask:0xf")
+    MGN_COLSUM_LEVEL("row_bcast:15 row_mask:0xa bank_mask:0xf")
+#undef MGN_COLSUM_LEVEL
+    if (c == 31) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            *reinterpret_cast<f32x4*>(dst + 32 * t + 8 * g + 4 * h) = f32x4{x[4 * g], x[4 * g + 1], x[4 * g + 2], x[4 * g + 3]};
+    }
+}
+
 template <int NT, int NIN, int WPB, bool H2 = false>
 __global__ __launch_bounds__(64 * WPB) void k_mlp_bwd(const TrainBwdArgs a) {
     constexpr int L = 32 * NT, CH = L * L;
@@ -250,9 +271,19 @@ __global__ __launch_bounds__(64 * WPB) void k_mlp_bwd(const TrainBwdArgs a) {
                 g[t][k] = rw.valid ? rden * (acc[t][k] * g[t][k] - m1 - xh * m2) : 0.f;
             }
     }
+    [[maybe_unused]] float* const lnacc = smem + 2 * CH + wave * (2 * L);      // (LNSUM) this wave's [dbeta | dgamma] sums
     if (a.ln == 1) {
         if (a.GT && rw.valid) store_frag<NT>(row_ptr(a.GT, rw.row, L, h), STRIDE_ROW, g);
         load_frag<NT>(y, row_ptr(a.Y, rw.rr, L, h), STRIDE_ROW);
+        if constexpr (NT == 4 && WPB == 8) {
+            if (a.LNSUM) {                       // dbeta: the column sums of g, one block at a time through acc[0] (free here) while Y is on its way
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    acc[0] = g[t];
+                    colsum_block(acc[0], lnacc, t, c, h);
+                }
+            }
+        }
         float s = 0.f;
 #pragma unroll
         for (int t = 0; t < NT; ++t)
@@ -295,6 +326,12 @@ __global__ __launch_bounds__(64 * WPB) void k_mlp_bwd(const TrainBwdArgs a) {
         m1 *= invL;
         m2 *= invL * kappa;
         if (a.GXH && rw.valid) store_frag<NT>(row_ptr(a.GXH, rw.row, L, h), STRIDE_ROW, acc);
+        if constexpr (NT == 4 && WPB == 8) {
+            if (a.LNSUM) {                       // dgamma: the column sums of g * xhat, in place (acc is dead from here)
+#pragma unroll
+                for (int t = 0; t < NT; ++t) colsum_block(acc[t], lnacc + L, t, c, h);
+            }
+        }
 #pragma unroll
         for (int t = 0; t < NT; ++t)
 #pragma unroll
@@ -330,6 +367,35 @@ __global__ __launch_bounds__(64 * WPB) void k_mlp_bwd(const TrainBwdArgs a) {
         train_chunk<NT, H2>(acc, g, y, CP_W(), lane, HRS(a.W1T[j]));
         CP_ADVANCE();
         if (rw.valid) store_frag<NT>(row_ptr(a.GX[j], rw.row, L, h), STRIDE_ROW, acc);
+    }
+    if constexpr (NT == 4 && WPB == 8) {
+        if (a.ln == 1 && a.LNSUM) {              // the block's eight waves, added in order
+            __syncthreads();
+            if (threadIdx.x < 2 * L) {
+                const float* p = smem + 2 * CH + threadIdx.x;
+                float sum = 0.f;
+#pragma unroll
+                for (int w = 0; w < WPB; ++w) sum += p[w * 2 * L];
+                a.LNSUM[(size_t)blockIdx.x * (2 * L) + threadIdx.x] = sum;
+            }
+        }
+    }
+}
+
+// first level of the LNSUM reduction: group g of `groups` adds its range of blocks in order
+__global__ void k_colsum_groups(const float* __restrict__ part, int nblocks, int cols, int groups, float* __restrict__ out) {
+    const int per = (nblocks + groups - 1) / groups;
+    const int b0 = blockIdx.x * per, b1 = min(nblocks, b0 + per);
+    for (int cidx = threadIdx.x; cidx < cols; cidx += blockDim.x) {
+        float s = 0.f;
+        int b = b0;
+        for (; b + 4 <= b1; b += 4) {
+            const float v0 = part[(size_t)b * cols + cidx], v1 = part[(size_t)(b + 1) * cols + cidx];
+            const float v2 = part[(size_t)(b + 2) * cols + cidx], v3 = part[(size_t)(b + 3) * cols + cidx];
+            s += v0; s += v1; s += v2; s += v3;
+        }
+        for (; b < b1; ++b) s += part[(size_t)b * cols + cidx];
+        out[(size_t)blockIdx.x * cols + cidx] = s;
     }
 }
 
@@ -1414,9 +1480,9 @@ __global__ __launch_bounds__(256) void k_col_stats(const float* __restrict__ x, 
 // ================================================================================================
 // 4 tiles per block; two L x L chunk buffers of dynamic LDS (128 KiB at L = 128: the attribute is raised once per kernel)
 template <typename K, typename A>
-static hipError_t launch_tiles(K kern, const A& a, int ntiles, int L, hipStream_t s, int wpb = 4) {
+static hipError_t launch_tiles(K kern, const A& a, int ntiles, int L, hipStream_t s, int wpb = 4, size_t extra_lds = 0) {
     if (ntiles <= 0) return hipSuccess;
-    const size_t lds = (size_t)2 * L * L * sizeof(float);
+    const size_t lds = (size_t)2 * L * L * sizeof(float) + extra_lds;
     static std::mutex mu;
     static std::unordered_map<const void*, size_t> granted;
     {
@@ -1521,14 +1587,15 @@ hipError_t launch_mlp_bwd(int L, int nin, const TrainBwdArgs& a, hipStream_t s) 
     }
 #define BWD_CASE(NT_, NIN_) if (L == 32 * NT_ && nin == NIN_) return launch_tiles(k_mlp_bwd<NT_, NIN_, 4>, a, a.ntiles, L, s)
     if (train_wpb8(L, a.ntiles)) {
+        const size_t xl = a.LNSUM ? (size_t)8 * 2 * L * sizeof(float) : 0;       // the waves' column sums behind the two chunk buffers
         if (g_train_f16) {
-            if (nin == 1) return launch_tiles(k_mlp_bwd<4, 1, 8, true>, a, a.ntiles, L, s, 8);
-            if (nin == 2) return launch_tiles(k_mlp_bwd<4, 2, 8, true>, a, a.ntiles, L, s, 8);
-            if (nin == 3) return launch_tiles(k_mlp_bwd<4, 3, 8, true>, a, a.ntiles, L, s, 8);
+            if (nin == 1) return launch_tiles(k_mlp_bwd<4, 1, 8, true>, a, a.ntiles, L, s, 8, xl);
+            if (nin == 2) return launch_tiles(k_mlp_bwd<4, 2, 8, true>, a, a.ntiles, L, s, 8, xl);
+            if (nin == 3) return launch_tiles(k_mlp_bwd<4, 3, 8, true>, a, a.ntiles, L, s, 8, xl);
         }
-        if (nin == 1) return launch_tiles(k_mlp_bwd<4, 1, 8>, a, a.ntiles, L, s, 8);
-        if (nin == 2) return launch_tiles(k_mlp_bwd<4, 2, 8>, a, a.ntiles, L, s, 8);
-        if (nin == 3) return launch_tiles(k_mlp_bwd<4, 3, 8>, a, a.ntiles, L, s, 8);
+        if (nin == 1) return launch_tiles(k_mlp_bwd<4, 1, 8>, a, a.ntiles, L, s, 8, xl);
+        if (nin == 2) return launch_tiles(k_mlp_bwd<4, 2, 8>, a, a.ntiles, L, s, 8, xl);
+        if (nin == 3) return launch_tiles(k_mlp_bwd<4, 3, 8>, a, a.ntiles, L, s, 8, xl);
     }
     if (L == 128 && g_train_f16) {
         if (nin == 1) return launch_tiles(k_mlp_bwd<4, 1, 4, true>, a, a.ntiles, L, s);
@@ -1558,6 +1625,15 @@ static int64_t wgrad_rows_per_block(int64_t rows) {
 static bool wgrad_h2_on(int L) {
     static const int h2 = [] { const char* e = getenv("MGN_WGRAD_H2"); return e ? atoi(e) : 1; }();      // 0: the fp32 MFMA forms
     return L == 128 && h2 && g_train_f16;
+}
+bool train_bwd_ln_sums(int L, int ntiles) {
+    static const int on = [] { const char* e = getenv("MGN_TRAIN_BWD_LN_SUMS"); return e ? atoi(e) : 1; }();   // LayerNorm-parameter sums inside the streaming backward kernel (0: the LayerNorm job of the weight-gradient launch)
+    return on && L == 128 && !train_coop(L, ntiles) && train_wpb8(L, ntiles);
+}
+hipError_t launch_colsum_groups(const float* part, int nblocks, int cols, int groups, float* out, hipStream_t s) {
+    if (nblocks <= 0 || groups <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_colsum_groups, dim3(groups), dim3(256), 0, s, part, nblocks, cols, groups, out);
+    return hipGetLastError();
 }
 bool wgrad_ln_jobs(int L) {
     static const int on = [] { const char* e = getenv("MGN_WGRAD_LN_JOBS"); return e ? atoi(e) : 1; }();  // 0: GT / G xhat rows written by the backward kernel, two column-sum jobs
