@@ -819,10 +819,16 @@ int train_run(mgn_handle* h, const TrainJob& J) {
             a.LNS = A + T.lnstats + (size_t)64 * lnslot;
             a.LNM = A + T.lnm;
         }
+        const bool sgr = fact && rows > 0 && train_bwd_fused_sgr(L, ntiles);   // SGr inside the launch (segmented scan over the receiver runs of GZ1)
+        if (sgr) { a.SEG_RCV = sx[fq].rcv; a.SEG_OUT = A + T.SGr; a.SEG_CARRY = A + T.segcarry; }
         HIPCHK(h, launch_mlp_bwd(L, nin_k, a, st));
         if (lnsum)    // [blocks][2 L] -> [LNSUM_GROUPS][2 L], in order; the unit's reduction launch adds the groups
             HIPCHK(h, launch_colsum_groups(A + T.lnsum, (ntiles + 7) / 8, 2 * L, LNSUM_GROUPS, A + T.lnsum2, st));
         if (fact) {   // gather <-> segmented-sum duality on GZ1 itself: SGr[n] = sum of GZ1 over edges received by n, SGs: sent by n
+            if (sgr) {
+                HIPCHK(h, launch_seg_fixup(L, sx[fq].rowptr, A + T.segcarry, A + T.SGr, (int32_t)node_rows, st));
+                HIPCHK(h, launch_segment_sum(L, A + T.GZ1[gs], sx[fq].rowptr_s, sx[fq].perm_s, nullptr, A + T.SGs, (int32_t)node_rows, st));
+            } else
             HIPCHK(h, launch_segment_sum_pair(L, A + T.GZ1[gs], sx[fq].rowptr, sx[fq].rowptr_s, sx[fq].perm_s, A + T.SGr, A + T.SGs, (int32_t)node_rows, st));
         }
         // every parameter gradient of this unit: jobs of one batched weight-gradient launch + one batched (ordered) reduction

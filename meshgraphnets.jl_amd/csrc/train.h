@@ -44,6 +44,9 @@ struct TrainBwdArgs {
     int32_t ln;                                  // 1: row-wise LayerNorm pullback here; 2: the whole-array one -- gy = rden (gamma g - m1 - xhat m2) with
     const float* LNS; const float* LNM;          //    LNS = (mean, rden, kappa) of the forward and LNM = (m1, m2) of launch_lnall_bwd; 0: none
     float* GT; float* GXH;                       // ln: total upstream gradient and G * xhat (-> dbeta, dgamma by column sums)
+    // streaming kernels, 8 tiles per block (train_bwd_fused_sgr): the receiver-side segmented sum of GZ1 inside the launch, as the forward does it for e'
+    // (TrainFwdArgs::SEG_*): runs inside a tile to SEG_OUT[receiver], pieces of runs that cross tile borders to SEG_CARRY, launch_seg_fixup after it
+    const int32_t* SEG_RCV; float* SEG_OUT; float* SEG_CARRY;
     float* LNSUM;                                // ln == 1, non-null (streaming kernels, 8 tiles per block; train_bwd_ln_sums): [block][2][L] column sums of the block's rows of g (dbeta) and g * xhat (dgamma), reduced inside the kernel (DPP adds over a tile's 32 rows, the block's waves through LDS) -- neither GT / GXH nor LNROW is written then
     float* LNROW;                                // ln == 1, non-null: (mean, 1 / denominator) of every row instead of GT / GXH -- the LayerNorm job of the weight-gradient launch rebuilds both from G0 (+ G1) and Y (round 6: - 6 GB written per edge MLP on M-1M)
     float* GY; float* GZ2; float* GZ1;           // gradients at the three Dense outputs (-> weight / bias gradients)
@@ -83,6 +86,7 @@ struct WgradJob {
     // xhat = (Y[row] - LNROW[2 row]) * LNROW[2 row + 1];  pb <- column sums of g (dbeta), pb2 <- column sums of g * xhat (dgamma)
     const float* Y; const float* LNROW; const float* G1; const int32_t* g1idx; float* pb2;
 };
+bool train_bwd_fused_sgr(int L, int ntiles);  // the backward launch of this size takes SEG_* (MGN_TRAIN_FUSED_SGR)
 bool train_bwd_ln_sums(int L, int ntiles);   // the backward launch of this size takes LNSUM (MGN_TRAIN_BWD_LN_SUMS, default in train.hip)
 // out[g][c] = sum of part[b][c] over the g-th of `groups` equal ranges of the nblocks blocks, in order (c < cols): the first level of the LNSUM reduction
 hipError_t launch_colsum_groups(const float* part, int nblocks, int cols, int groups, float* out, hipStream_t s);

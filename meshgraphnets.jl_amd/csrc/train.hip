@@ -33,6 +33,32 @@ DEVINL RowRef row_of(int tile, int c, int64_t rows) {
 
 }  // namespace
 
+// the segmented sum of a fragment over runs of equal receiver inside a 32-row tile and its stores (k_mlp_bwd: GZ1 -> SGr): see k_mlp_fwd
+template <int NT>
+DEVINL void seg_sum_store(f32x16 (&acc)[NT], const int32_t* rcv, float* out, float* carry, int tile, int64_t rows, const RowRef& rw, int c, int h) {
+    constexpr int L = 32 * NT;
+    const int64_t e0 = (int64_t)tile * TILE;
+    const int r = rcv[rw.rr];
+    const int r_before = rcv[e0 > 0 ? e0 - 1 : 0], r_after = rcv[e0 + TILE < rows ? e0 + TILE : rows - 1];
+    const int reff = rw.valid ? r : (-4 - c);
+    const int rprev = __shfl_up(reff, 1, 32);
+    const int rnext = __shfl_down(reff, 1, 32);
+    const bool head = (c == 0) || (reff != rprev);
+    const unsigned hm = (unsigned)__ballot(head);
+    const int start = 31 - __clz((int)(hm & (0xFFFFFFFFu >> (31 - c))));
+    const int st_in = max(start, c & 16);
+    const bool c1 = (c - 1 >= st_in), c2 = (c - 2 >= st_in), c4 = (c - 4 >= st_in), c8 = (c - 8 >= st_in);
+    const bool cx = (c >= 16) && (start <= 15);
+    segmented_scan<NT>(acc, c1, c2, c4, c8, cx);
+    const bool tail = rw.valid && ((c == 31) || (reff != rnext));
+    const int r_first = __builtin_amdgcn_readfirstlane(reff);
+    const bool sl = (start == 0) && e0 > 0 && (r_before == r_first);
+    const bool sr = (c == 31) && (e0 + TILE < rows) && (r_after == reff);
+    const bool to_carry = sl || sr;
+    f32x4* dst = to_carry ? row_ptr(carry, (int64_t)2 * tile + (sl ? 0 : 1), L, h) : row_ptr(out, r, L, h);
+    if (tail) store_frag<NT>(dst, STRIDE_ROW, acc);
+}
+
 // ================================================================================================
 // forward of one 3-Dense MLP (+ LayerNorm, + residual), keeping H1, H2, Y
 // ================================================================================================
@@ -162,26 +188,7 @@ __global__ __launch_bounds__(64 * WPB) void k_mlp_fwd(const TrainFwdArgs a) {
                 for (int t = 0; t < NT; ++t) x[t] += acc[t];
                 if (rw.valid) store_frag<NT>(row_ptr(a.OUT, rw.row, L, h), STRIDE_ROW, x);
             }
-            const int64_t e0 = (int64_t)tile * TILE;
-            const int r = a.SEG_RCV[rw.rr];
-            const int r_before = a.SEG_RCV[e0 > 0 ? e0 - 1 : 0], r_after = a.SEG_RCV[e0 + TILE < a.rows ? e0 + TILE : a.rows - 1];
-            const int reff = rw.valid ? r : (-4 - c);
-            const int rprev = __shfl_up(reff, 1, 32);
-            const int rnext = __shfl_down(reff, 1, 32);
-            const bool head = (c == 0) || (reff != rprev);
-            const unsigned hm = (unsigned)__ballot(head);
-            const int start = 31 - __clz((int)(hm & (0xFFFFFFFFu >> (31 - c))));
-            const int st_in = max(start, c & 16);
-            const bool c1 = (c - 1 >= st_in), c2 = (c - 2 >= st_in), c4 = (c - 4 >= st_in), c8 = (c - 8 >= st_in);
-            const bool cx = (c >= 16) && (start <= 15);
-            segmented_scan<NT>(acc, c1, c2, c4, c8, cx);
-            const bool tail = rw.valid && ((c == 31) || (reff != rnext));
-            const int r_first = __builtin_amdgcn_readfirstlane(reff);
-            const bool sl = (start == 0) && e0 > 0 && (r_before == r_first);            // the run continues from the tile before
-            const bool sr = (c == 31) && (e0 + TILE < a.rows) && (r_after == reff);     // ... into the next tile
-            const bool to_carry = sl || sr;
-            f32x4* dst = to_carry ? row_ptr(a.SEG_CARRY, (int64_t)2 * tile + (sl ? 0 : 1), L, h) : row_ptr(a.SEG_AGG, r, L, h);
-            if (tail) store_frag<NT>(dst, STRIDE_ROW, acc);
+            seg_sum_store<NT>(acc, a.SEG_RCV, a.SEG_AGG, a.SEG_CARRY, tile, a.rows, rw, c, h);
             return;
         }
     }
@@ -369,6 +376,7 @@ __global__ __launch_bounds__(64 * WPB) void k_mlp_bwd(const TrainBwdArgs a) {
         if (rw.valid) store_frag<NT>(row_ptr(a.GX[j], rw.row, L, h), STRIDE_ROW, acc);
     }
     if constexpr (NT == 4 && WPB == 8) {
+        if (a.SEG_RCV) seg_sum_store<NT>(g, a.SEG_RCV, a.SEG_OUT, a.SEG_CARRY, tile, a.rows, rw, c, h);   // g = GZ1, dead from here: SGr
         if (a.ln == 1 && a.LNSUM) {              // the block's eight waves, added in order
             __syncthreads();
             if (threadIdx.x < 2 * L) {
@@ -1625,6 +1633,10 @@ static int64_t wgrad_rows_per_block(int64_t rows) {
 static bool wgrad_h2_on(int L) {
     static const int h2 = [] { const char* e = getenv("MGN_WGRAD_H2"); return e ? atoi(e) : 1; }();      // 0: the fp32 MFMA forms
     return L == 128 && h2 && g_train_f16;
+}
+bool train_bwd_fused_sgr(int L, int ntiles) {
+    static const int on = [] { const char* e = getenv("MGN_TRAIN_FUSED_SGR"); return e ? atoi(e) : 0; }();   // (built, parity green, same box 0.304 s against 0.302 with k_segment_sum_pair: off)
+    return on && L == 128 && !train_coop(L, ntiles) && train_wpb8(L, ntiles);
 }
 bool train_bwd_ln_sums(int L, int ntiles) {
     static const int on = [] { const char* e = getenv("MGN_TRAIN_BWD_LN_SUMS"); return e ? atoi(e) : 1; }();   // LayerNorm-parameter sums inside the streaming backward kernel (0: the LayerNorm job of the weight-gradient launch)
