@@ -180,6 +180,45 @@ def test_step_midsize_factored_and_recompute(train_env, hl, two_sets, recompute)
     assert loss2 == loss and np.array_equal(gs, gs2)
 
 
+@pytest.mark.parametrize("hl,two_sets", [(3, False), (1, False), (2, True)])
+def test_step_streaming_kernels_other_depths_and_two_edge_sets(hl, two_sets):
+    """above 2 048 edge tiles: the eight-wave streaming kernels with (round 6) the aggregation inside the forward's edge launch, the
+    LayerNorm-parameter sums inside the backward kernel and the weight gradients on fp16 pieces -- with two launch units per MLP
+    (hidden_layers = 3), with one Dense layer less (1), and with a second, small edge set beside the large one (its MLPs run the
+    cooperative kernels: both families in one step)"""
+    if two_sets:
+        m = synth.mesh_flag(nx=112, ny=112, radius=0.0105)
+        N, s, r, ef = m["mesh_pos"].shape[0], m["s"], m["r"], m["ef"]
+        cfg = dict(Fn=12, Fe=7, O=3, L=128, hidden_layers=hl, mps=2, Fe2=4)
+        set2 = (m["ef2"], m["s2"], m["r2"])
+        assert 100 < m["s2"].size < 2048 * 32
+    else:
+        pos, s, r = synth.mesh_1m(4321, 110, 110)
+        N = pos.shape[0]
+        cfg = cfg_of(hl, 128, 2)
+        ef = np.random.default_rng(9).standard_normal((s.size, 3)).astype(np.float32)
+        set2 = None
+    assert (s.size + 31) // 32 > 2048
+    ps = params_of(cfg, seed=6)
+    rng = np.random.default_rng(3)
+    nf = rng.standard_normal((N, cfg["Fn"])).astype(np.float32)
+    target = rng.standard_normal((N, cfg["O"])).astype(np.float32)
+    mask = np.sort(rng.choice(N, N // 3, replace=False)).astype(np.int32)
+    eng = engine_of(cfg)
+    eng.set_params(ps)
+    eng.set_graph(s, r, N)
+    if two_sets:
+        eng.set_edge_set(1, set2[1], set2[2])
+        eng.set_edge_features(1, set2[0])
+    gs, loss = eng.step(nf, ef, target, mask)
+    ref, ref_loss = orc.step_grads(ps, cfg, nf, ef, s, r, target, mask, set2=set2)
+    assert abs(loss - ref_loss) <= TOL_LOSS * abs(ref_loss), (loss, ref_loss)
+    assert np.linalg.norm(gs - ref) <= 1e-3 * np.linalg.norm(ref), np.linalg.norm(gs - ref) / np.linalg.norm(ref)
+    check_grads(gs, ref, cfg, tol=5e-3)
+    gs2, loss2 = eng.step(nf, ef, target, mask)
+    assert loss2 == loss and np.array_equal(gs, gs2)
+
+
 @pytest.mark.parametrize("hl", [1, 3])
 def test_ode_vjp_hidden_layers(hl):
     """mgn_ode_vjp for hidden_layers != 2: frozen normalisers and val_mask like mgn_ode_step"""
