@@ -148,6 +148,7 @@ struct mgn_engine {
     DevBuf d_stamps;  // diagnostic builds only
     DevBuf ode;       // native rollout: state, stages, frames, saves, Elat0
     const float* srcA_override = nullptr;  // rollout: encoder reads the node state from here instead of d_nfA
+    const float* elat_src_override = nullptr;   // right-hand sides on small meshes: step 0's edge kernel reads the trajectory's encoded edge latents from here (EdgeArgs::ElatSrc) instead of a restore copy into Elat
     float* out_override = nullptr;         // rollout: decoder writes dx/dt here instead of d_out
     DevBuf V, d_nfA, d_nfB, d_out, d_mask, d_sum;
     int32_t in_wa = 0, in_wb = 0;

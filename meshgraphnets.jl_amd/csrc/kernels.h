@@ -33,6 +33,7 @@ struct EdgeArgs {
     const float* P;         // [n_own+n_halo][L]  v * W1[0:L]      (sender part of edge-MLP layer 1)
     const float* Q;         // [n_own][L]         v * W1[L:2L]+b1  (receiver part + bias)
     float* Elat;            // tile-major [ntiles][16 pieces][64 lanes][4]: edge latents, updated in place
+    const float* ElatSrc;   // (k_edge_coop16m only; launch_edge_step refuses it elsewhere) non-null: the e rows are READ from this array of the same layout and written to Elat -- step 0 of a right-hand side reads the trajectory's encoded edges where they are kept, no restore copy
     float* AGG;             // tile-major over NODE tiles: per-receiver sums of e'
     float* CARRY;           // row-major [2*ntiles+1][L]: partial sums of receiver runs that straddle edge tiles; last row = 0
     const float* chunk[MAX_CHUNKS];  // 0:W2 1:W3 2:W1[2L:3L]   (fragment order)

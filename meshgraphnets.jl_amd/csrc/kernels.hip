@@ -937,8 +937,9 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
         // LDS; tables, the next layer's weights and the gathered rows are requested inside the layer-1 chain.
 #pragma unroll
         for (int t = 0; t < RT; ++t) {
-            xs[t][0] = c16_ld_tile<BF>(a.Elat, tile[t], row[t], 2 * wave, q);
-            xs[t][1] = c16_ld_tile<BF>(a.Elat, tile[t], row[t], 2 * wave + 1, q);
+            const float* const esrc = a.ElatSrc ? a.ElatSrc : a.Elat;
+            xs[t][0] = c16_ld_tile<BF>(esrc, tile[t], row[t], 2 * wave, q);
+            xs[t][1] = c16_ld_tile<BF>(esrc, tile[t], row[t], 2 * wave + 1, q);
         }
         C16Ring g1, g2;
         C16SRingT<NP> h1, h2;
@@ -2840,6 +2841,7 @@ int last_edge_kernel() { return g_last_edge_kernel; }
 
 hipError_t launch_edge_step(int L, const EdgeArgs& a, hipStream_t s) {
     if (a.ntiles <= 0) return hipSuccess;
+    if (a.gen.use && a.ElatSrc) return hipErrorInvalidValue;
     if (a.gen.use) SET_LAST_EDGE(a, 1);
     if (a.gen.use) DISPATCH_GEN(L, (k_edge_step<4, 0, true>), (k_edge_step<2, 0, true>), (k_edge_step<1, 0, true>), a, a.ntiles);
     const int nres = resident_chunks(L, 3);
@@ -2882,6 +2884,7 @@ hipError_t launch_edge_step(int L, const EdgeArgs& a, hipStream_t s) {
         if (rt == 2) return launch_k(k_edge_coop16m<2, false>, a, c16, s);
         return launch_k(k_edge_coop16m<1, false>, a, c16, s);
     }
+    if (a.ElatSrc) return hipErrorInvalidValue;      // only the 16-row kernel reads its e rows from a second array
     // where the ring kernel of the split path is available it takes over from the cooperative tiles at 3 tiles per CU already
     // (four-wave blocks; 5 k nodes: 50 vs 68 us per step, 10 k: 85 vs 110, 16 k: 110 vs 146), the fp32-MFMA persistent kernels only at 16
     static const int coop_edge_ring_env = [] { const char* e = getenv("MGN_COOP_EDGE_TILES_PER_CU_RING"); return e ? atoi(e) : 0; }();
