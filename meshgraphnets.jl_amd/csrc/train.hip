@@ -59,6 +59,26 @@ DEVINL void seg_sum_store(f32x16 (&acc)[NT], const int32_t* rcv, float* out, flo
     if (tail) store_frag<NT>(dst, STRIDE_ROW, acc);
 }
 
+// the kept activations are written once and read a whole pass later: stores that do not allocate in the caches (-DMGN_TRAIN_NT_STORES=1) were
+// tried -- M-1M step 0.308 -> 0.319 s on the same box -- and are off
+#ifndef MGN_TRAIN_NT_STORES
+#define MGN_TRAIN_NT_STORES 0
+#endif
+template <int NT>
+DEVINL void store_frag_keep(f32x4* __restrict__ p, int stride, const f32x16 (&x)[NT]) {
+#if MGN_TRAIN_NT_STORES
+#pragma unroll
+    for (int m = 0; m < 4 * NT; ++m) {
+        f32x4 v;
+        v[0] = x[m >> 2][4 * (m & 3) + 0]; v[1] = x[m >> 2][4 * (m & 3) + 1];
+        v[2] = x[m >> 2][4 * (m & 3) + 2]; v[3] = x[m >> 2][4 * (m & 3) + 3];
+        __builtin_nontemporal_store(v, &p[m * stride]);
+    }
+#else
+    store_frag<NT>(p, stride, x);
+#endif
+}
+
 // ================================================================================================
 // forward of one 3-Dense MLP (+ LayerNorm, + residual), keeping H1, H2, Y
 // ================================================================================================
@@ -152,16 +172,16 @@ __global__ __launch_bounds__(64 * WPB) void k_mlp_fwd(const TrainFwdArgs a) {
         CP_ADVANCE();
     }
     relu_frag<NT>(acc);
-    if (a.H1 && rw.valid) store_frag<NT>(row_ptr(a.H1, rw.row, L, h), STRIDE_ROW, acc);
+    if (a.H1 && rw.valid) store_frag_keep<NT>(row_ptr(a.H1, rw.row, L, h), STRIDE_ROW, acc);
     CP_PREFETCH(HW(a.W3));
     tab_frag<NT>(y, a.tabs + T_B2 * L, h);
     train_chunk<NT, H2>(y, acc, x, CP_W(), lane, HRS(a.W2));
     CP_ADVANCE();
     relu_frag<NT>(y);
-    if (a.H2 && rw.valid) store_frag<NT>(row_ptr(a.H2, rw.row, L, h), STRIDE_ROW, y);
+    if (a.H2 && rw.valid) store_frag_keep<NT>(row_ptr(a.H2, rw.row, L, h), STRIDE_ROW, y);
     tab_frag<NT>(acc, a.tabs + T_B3 * L, h);
     train_chunk<NT, H2>(acc, y, x, CP_W(), lane, HRS(a.W3));
-    if (a.Y && rw.valid) store_frag<NT>(row_ptr(a.Y, rw.row, L, h), STRIDE_ROW, acc);
+    if (a.Y && rw.valid) store_frag_keep<NT>(row_ptr(a.Y, rw.row, L, h), STRIDE_ROW, acc);
     if (a.STATS) {                               // whole-array LayerNorm: this tile's (sum, sum of squares) of Y, lanes added in a fixed pattern
         float s1 = 0.f, s2 = 0.f;
         if (rw.valid) {
