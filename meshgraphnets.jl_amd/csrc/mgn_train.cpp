@@ -79,6 +79,7 @@ struct TrainState {
     // whole-array LayerNorm in the training step: per-MLP statistics of the forward (64 floats each), the double partials of the two
     // reductions, (m1, m2) of the pullback
     size_t lnstats = 0, lnpart = 0, lnm = 0;
+    bool need_gt = true;              // GT / GXH are full arrays (else 64-float stubs: every LayerNorm'd unit runs with LNSUM)
     size_t lnsum = 0, lnsum2 = 0;     // per-block LayerNorm-parameter sums of the streaming backward kernel and their first-level reduction (TrainBwdArgs::LNSUM)
     size_t segcarry = 0;              // carry rows of the fused aggregation (2 per edge tile; TrainFwdArgs::SEG_CARRY)
     size_t lnrow = 0;                 // (mean, 1 / denominator) per row of the MLP being unwound (TrainBwdArgs::LNROW)
@@ -276,7 +277,13 @@ int prepare_graph(mgn_engine* h) {
             T.ef_pad[q] = take(EL[q]);
             T.a_ee[q] = take_acts(EL[q]);
         }
-        T.Enew = take(ELmax);
+        // e' = LayerNorm(Y) as an array of its own only where some edge set's forward does not aggregate inside its launch (train.h: SEG_*)
+        bool need_enew = h->cfg.ln_dims == MGN_LN_ALL;
+        for (int q = 0; q < S; ++q) {
+            const int64_t E = g.set[q].e_local;
+            need_enew = need_enew || !(E > 0 && train_fwd_fused_agg(L, (int)((E + TILE - 1) / TILE)));
+        }
+        T.Enew = take(need_enew ? ELmax : 64);
         T.Vk.assign(mps + 1, 0);
         T.Vk[0] = take(NL);
         for (int q = 0; q < S; ++q) {
@@ -331,7 +338,14 @@ int prepare_graph(mgn_engine* h) {
             const int64_t big = Emax > N ? Emax : N;
             T.gsets = (overlap_env && !T.recompute && !any_fact && L == 128 && big <= 2048 * TILE) ? TrainState::GSETS : 1;   // (SGs / SGr are single buffers)
         }
-        for (int i = 0; i < T.gsets; ++i) { T.GT[i] = take(ML); T.GXH[i] = take(ML); T.GY[i] = take(ML); T.GZ2[i] = take(ML); T.GZ1[i] = take(ML); }
+        // GT / G xhat rows only where some LayerNorm'd launch unit does not take its parameter sums inside the backward kernel (train.h: LNSUM)
+        bool need_gt = h->cfg.ln_dims == MGN_LN_ALL || T.gsets > 1 || !train_bwd_ln_sums(L, (int)((N + TILE - 1) / TILE));
+        for (int q = 0; q < S; ++q) {
+            const int64_t E = g.set[q].e_local;
+            need_gt = need_gt || (E > 0 && !train_bwd_ln_sums(L, (int)((E + TILE - 1) / TILE)));
+        }
+        T.need_gt = need_gt;
+        for (int i = 0; i < T.gsets; ++i) { T.GT[i] = take(need_gt ? ML : 64); T.GXH[i] = take(need_gt ? ML : 64); T.GY[i] = take(ML); T.GZ2[i] = take(ML); T.GZ1[i] = take(ML); }
         T.GXs = T.GXr = T.Pn = T.Qn = T.SGs = T.SGr = T.GXB = 0;
         if (any_fact) { T.Pn = take(NL); T.Qn = take(NL); T.SGs = take(NL); T.SGr = take(NL); }
         if (!all_fact) { T.GXs = take(ELmax); T.GXr = take(ELmax); }
@@ -812,6 +826,7 @@ int train_run(mgn_handle* h, const TrainJob& J) {
         const bool lnjob = !lnsum && b.ln && !wide && !overlap && rows > 0 && wgrad_ln_jobs(L) && !train_uses_coop(L, ntiles);   // ... or a job that re-reads G0 / Y (the cooperative backward kernels write GT / G xhat)
         if (lnjob) { a.GT = nullptr; a.GXH = nullptr; a.LNROW = A + T.lnrow; }
         if (lnsum) { a.GT = nullptr; a.GXH = nullptr; a.LNSUM = A + T.lnsum; }
+        if (b.ln && !wide && !lnsum && !T.need_gt && rows > 0) return fail(h, MGN_E_STATE, "training arena laid out without GT / GXH rows but a launch unit needs them");
         if (wide && rows > 0) {   // pullback of the whole-array LayerNorm: dgamma, dbeta and the two means first (two column reductions)
             HIPCHK(h, launch_lnall_bwd(g0, g1, g1i, A + hb[2], A + T.lnstats + (size_t)64 * lnslot, Wt + b.tabs + (size_t)T_GAMMA * L, rows, L,
                                        reinterpret_cast<double*>(A + T.lnpart), A + T.lnm, G + b.ggamma, G + b.gbeta, st));
