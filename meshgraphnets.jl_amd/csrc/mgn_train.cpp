@@ -22,6 +22,7 @@ namespace {
 //   hidden_layers = 3:  [D0, I, I] -> [D1, D2, D3]        (the first block's output is ReLU(z0): no LayerNorm, no residual)
 //   hidden_layers = 4:  [D0, D1, I] -> [D2, D3, D4]
 // One such launch unit with its device offsets (floats into TrainState::w) in training order:
+constexpr int DEFER_PB_JOBS = 12;  // column-sum slots per launch unit of the deferred reduction (a unit has at most 3 + 5 + 2)
 constexpr int LNSUM_GROUPS = 64;   // first-level groups of the in-kernel LayerNorm-parameter sums
 
 struct TrainBlock {
@@ -79,6 +80,9 @@ struct TrainState {
     // whole-array LayerNorm in the training step: per-MLP statistics of the forward (64 floats each), the double partials of the two
     // reductions, (m1, m2) of the pullback
     size_t lnstats = 0, lnpart = 0, lnm = 0;
+    bool defer_reduce = false;        // small meshes (second stream): every unit's partial sums are kept and reduced in a few launches at the end of the reverse pass
+    size_t pw_all = 0, pb_all = 0;    // ... their partial blocks: [unit][5][nb][L][L], [unit][DEFER_PB_JOBS][nb][L]
+    int defer_units = 0;
     bool need_gt = true;              // GT / GXH are full arrays (else 64-float stubs: every LayerNorm'd unit runs with LNSUM)
     size_t lnsum = 0, lnsum2 = 0;     // per-block LayerNorm-parameter sums of the streaming backward kernel and their first-level reduction (TrainBwdArgs::LNSUM)
     size_t segcarry = 0;              // carry rows of the fused aggregation (2 per edge tile; TrainFwdArgs::SEG_CARRY)
@@ -359,6 +363,18 @@ int prepare_graph(mgn_engine* h) {
         const int nb = std::max(wgrad_blocks(N), wgrad_blocks(Emax));
         T.pw = take((size_t)5 * (T.gsets > 1 ? T.gsets / 2 : 1) * (nb > 0 ? nb : 1) * L * L);   // one partial-dW region per weight-gradient job of a launch (a group of units on small meshes)
         T.pb = take((size_t)(WGRAD_MAX_JOBS + 1) * (nb > 0 ? nb : 1) * L);   // (+ 1: the second output of a LayerNorm job)
+        {   // Deferred reductions (MGN_TRAIN_DEFER_REDUCE = 1; built, same bits, off) where the weight gradients run on the second stream: the 33
+            // k_reduce_partials launches of a step as five at its end.
+            static const int defer_env = [] { const char* e = getenv("MGN_TRAIN_DEFER_REDUCE"); return e ? atoi(e) : 0; }();   // (measured: 2.54 ms against 2.36 -- the per-unit partial blocks, re-used, stay in the caches; 680 MB of them do not)
+            const int units = (2 + S + mps * (S + 1)) * NB;
+            const size_t per_unit = ((size_t)5 * L * L + (size_t)DEFER_PB_JOBS * L) * (nb > 0 ? nb : 1);
+            T.defer_reduce = defer_env && T.gsets > 1 && per_unit * units * 4 <= ((size_t)8 << 30);
+            T.defer_units = units;
+            if (T.defer_reduce) {
+                T.pw_all = take((size_t)units * 5 * (nb > 0 ? nb : 1) * L * L);
+                T.pb_all = take((size_t)units * DEFER_PB_JOBS * (nb > 0 ? nb : 1) * L);
+            }
+        }
         T.lnrow = take((size_t)2 * (ML / L));
         T.lnsum = take(((ML / L + TILE - 1) / TILE + 7) / 8 * (size_t)2 * L + 2 * L);
         T.lnsum2 = take((size_t)LNSUM_GROUPS * 2 * L);
@@ -766,6 +782,8 @@ int train_run(mgn_handle* h, const TrainJob& J) {
     ReduceBatch prb{};
     int pnw = 0, punits = 0, nbatch = 0;
     int64_t plrows = 0;
+    std::vector<ReduceJob> deferred;                     // (T.defer_reduce) the reductions of all units, launched behind the last weight-gradient launch
+    int unit_no = 0;
     int set_batch[TrainState::GSETS_MAX];                // launch number that takes the weight gradients of the unit in each buffer set
     for (int& v : set_batch) v = -1;
     auto flush = [&]() -> int {
@@ -859,6 +877,9 @@ int train_run(mgn_handle* h, const TrainJob& J) {
         WgradBatch& wb = pwb;
         ReduceBatch& rb = prb;
         int& nw = pnw;
+        const bool defer = T.defer_reduce && unit_no < T.defer_units;
+        const int this_unit = unit_no++;
+        int unw = 0, unb = 0;                                  // (deferred) weight / column-sum partial slots of this unit
         auto job = [&](const float* X, const int32_t* xi_, const float* Gm, long woff, int nrows, int cols, long boff, int bcols,
                        int64_t jrows = -1) {
             if (woff < 0 && boff < 0) return;              // identity slot
@@ -866,6 +887,14 @@ int train_run(mgn_handle* h, const TrainJob& J) {
             if (jrows < 0) jrows = rows;
             const int nbj = wgrad_blocks_of_job(lrows, jrows);     // blocks of this launch that hold rows of the job
             j.X = X; j.xidx = xi_; j.G = Gm; j.rows = jrows;
+            if (defer) {
+                j.pw = woff >= 0 ? A + T.pw_all + ((size_t)this_unit * 5 + unw) * nb * L * L : nullptr;
+                j.pb = boff >= 0 ? A + T.pb_all + ((size_t)this_unit * DEFER_PB_JOBS + unb) * nb * L : nullptr;
+                if (woff >= 0) { deferred.push_back(ReduceJob{j.pw, nbj, (int64_t)L * L, nrows, cols, L, G + woff}); ++unw; }
+                if (boff >= 0) { deferred.push_back(ReduceJob{j.pb, nbj, (int64_t)L, 1, bcols, L, G + boff}); ++unb; }
+                ++wb.njobs;
+                return;
+            }
             j.pw = woff >= 0 ? A + T.pw + (size_t)nw * nb * L * L : nullptr;
             j.pb = boff >= 0 ? A + T.pb + (size_t)wb.njobs * nb * L : nullptr;
             if (woff >= 0) {
@@ -924,6 +953,8 @@ int train_run(mgn_handle* h, const TrainJob& J) {
     auto backward_launches = [&]() -> int {
     HIPCHK(h, hipMemsetAsync(G, 0, h->params.size() * 4, st));   // (inside the replayed sequence: G is the engine's own buffer)
     n_bwd = 0;
+    unit_no = 0;
+    deferred.clear();
     pwb = WgradBatch{}; prb = ReduceBatch{};
     pnw = punits = nbatch = 0;
     plrows = 0;
@@ -996,6 +1027,19 @@ int train_run(mgn_handle* h, const TrainJob& J) {
     }
 
     if (int rc = flush()) return rc;                     // the units left over from the last full group
+    if (!deferred.empty()) {                             // every unit's reductions, REDUCE_MAX_JOBS per launch, behind the last weight-gradient launch
+        static const int whatif = [] { const char* e = getenv("MGN_TRAIN_WHATIF"); return e ? atoi(e) : 0; }();
+        hipStream_t wst = overlap ? T.aux : st;
+        for (size_t i = 0; i < deferred.size() && !(whatif & 2); i += REDUCE_MAX_JOBS) {
+            ReduceBatch rb{};
+            for (size_t j = i; j < deferred.size() && j < i + REDUCE_MAX_JOBS; ++j) rb.job[rb.njobs++] = deferred[j];
+            HIPCHK(h, launch_reduce_partials(rb, wst));
+        }
+        if (overlap) {
+            HIPCHK(h, hipEventRecord(T.ev_wg[nbatch % TrainState::GSETS_MAX], wst));
+            ++nbatch;
+        }
+    }
     if (overlap && nbatch > 0)                           // join: the second stream is in order, its last event covers all of it
         HIPCHK(h, hipStreamWaitEvent(st, T.ev_wg[(nbatch - 1) % TrainState::GSETS_MAX], 0));
     return MGN_OK;

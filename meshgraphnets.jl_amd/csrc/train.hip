@@ -1146,11 +1146,35 @@ __global__ __launch_bounds__(256, MGN_WH_BLOCKS) void k_wgrad_h2(const WgradBatc
     }
 }
 
-// out[r * cols + c] = sum_b partial[b][r * ld + c], fixed order (bitwise reproducible); one job per blockIdx.y
+#ifndef MGN_REDUCE_VEC
+#define MGN_REDUCE_VEC 0     // 1: four outputs per thread, eight blocks in flight -- cylinder-mesh step 2.44 ms against 2.38 (a quarter of the threads: fewer loads in flight overall)
+#endif
+// out[r * cols + c] = sum_b partial[b][r * ld + c], fixed order (bitwise reproducible); one job per blockIdx.y.  Four consecutive outputs per
+// thread where the shapes allow 16-byte accesses (cols = ld, a multiple of 4: every weight chunk and bias of the model but the decoder's
+// last layer), eight partial blocks in flight (-DMGN_REDUCE_VEC=1; measured slower, off).
 __global__ void k_reduce_partials(const ReduceBatch rb) {
     const ReduceJob& jb = rb.job[blockIdx.y];
+    const int total = jb.nrows * jb.cols;
+    if (MGN_REDUCE_VEC && jb.cols == jb.ld && (jb.cols & 3) == 0 && (jb.block_stride & 3) == 0 && ((reinterpret_cast<uintptr_t>(jb.out) | reinterpret_cast<uintptr_t>(jb.partial)) & 15) == 0) {
+        const int i4 = blockIdx.x * blockDim.x + threadIdx.x;
+        if (4 * i4 >= total) return;
+        const f32x4* __restrict__ p = reinterpret_cast<const f32x4*>(jb.partial) + i4;
+        const size_t bs4 = (size_t)jb.block_stride / 4;
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+        int b = 0;
+        for (; b + 8 <= jb.nblocks; b += 8) {
+            f32x4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = p[(size_t)(b + u) * bs4];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
+        for (; b < jb.nblocks; ++b) s += p[(size_t)b * bs4];
+        reinterpret_cast<f32x4*>(jb.out)[i4] = s;
+        return;
+    }
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= jb.nrows * jb.cols) return;
+    if (i >= total) return;
     const int r = i / jb.cols, cidx = i - r * jb.cols;
     const float* __restrict__ p = jb.partial + (size_t)r * jb.ld + cidx;
     float s = 0.f;
