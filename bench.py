@@ -794,7 +794,8 @@ def main():
                 floor_s = fl16 / (PEAK_BF16_MFMA_TFLOPS * 1e12) + fl32 / (PEAK_F32_MFMA_TFLOPS * 1e12)
                 out["secondary"]["train_step_1m"] = {
                     "workload": "mgn_step == step! on M-1M (N = 1 000 000, E = 5 992 002, L = 128, 15 steps; fp32 storage, forward / recomputation / "
-                                "backward MLP chains and weight gradients on two fp16 pieces (MGN_TRAIN_F16=0: fp32 MFMA); "
+                                "backward MLP chains and weight gradients on two fp16 pieces (MGN_TRAIN_F16=0: fp32 MFMA), the aggregation of e' inside the forward's edge "
+                                "launch and the LayerNorm-parameter sums inside the backward launches; "
                                 "activations stored for `stored_steps` of the 15 processor steps -- as many as the device's free memory holds -- and "
                                 "recomputed in the reverse pass for the others); host in/out included",
                     "s_per_step": dtT, "stored_steps": keepT, "loss_finite": bool(np.isfinite(lossT)),
