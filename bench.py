@@ -896,6 +896,44 @@ def main():
                 mids[f"N={posm.shape[0]},E={sm.size}"] = {"us_per_processor_step": dtm / (km * MPS) * 1e6, "edges_per_s": sm.size * MPS * km / dtm}
                 engm.close()
             out["secondary"]["mid_size_meshes"] = mids
+            # the shapes beside the headline's (hidden_layers and layer_size are free integers, a second edge set exists): what a
+            # processor step costs on the 125 k-node share there -- the fp32-MFMA generic kernels (hidden_layers != 2, L != 128) and the
+            # two-edge-set node side (three bf16 pieces) have not been moved to the streamed fp16 kernels; random small parameters, timing only
+            try:
+                shapes = {}
+                posm, sm, rm = mgn_amd.synth.mesh_1m(1234, 354, 354)
+                Nm = posm.shape[0]
+
+                def time_steps(engx, nedges):
+                    engx.latents_randn(1234)
+                    for _ in range(3):
+                        engx.processor_steps_dev(MPS)
+                    barrier_sync()
+                    t0 = time.perf_counter()
+                    for _ in range(10):
+                        engx.processor_steps_dev(MPS)
+                    barrier_sync()
+                    dtx = time.perf_counter() - t0
+                    v_, e_ = engx.latents_export()
+                    return {"us_per_processor_step": dtx / (10 * MPS) * 1e6, "edges_per_s": nedges * MPS * 10 / dtx, "finite": bool(np.isfinite(v_).all() and np.isfinite(e_).all())}
+
+                for name, (Lx, hl) in {"L=128,hidden_layers=3": (128, 3), "L=128,hidden_layers=1": (128, 1), "L=64,hidden_layers=2": (64, 2)}.items():
+                    engx = mgn_amd.Engine(FN, FE, O, Lx, hl, MPS, device=local_rank)
+                    engx.set_params((np.random.default_rng(5).standard_normal(engx.param_count) * 0.08).astype(np.float32))
+                    engx.set_graph(sm, rm, Nm)
+                    shapes[name] = time_steps(engx, sm.size)
+                    engx.close()
+                mf = mgn_amd.synth.mesh_flag(nx=354, ny=354, radius=0.0035)
+                eng2 = mgn_amd.Engine(12, 7, 3, L, 2, MPS, device=local_rank, Fe2=4)
+                eng2.set_params((np.random.default_rng(6).standard_normal(eng2.param_count) * 0.08).astype(np.float32))
+                eng2.set_graph(mf["s"], mf["r"], mf["mesh_pos"].shape[0])
+                eng2.set_edge_set(1, mf["s2"], mf["r2"])
+                shapes[f"L=128,two edge sets (mesh E={mf['s'].size}, world E={mf['s2'].size})"] = time_steps(eng2, mf["s"].size + mf["s2"].size)
+                eng2.close()
+                shapes["same mesh, default shape"] = mids.get(f"N={Nm},E={sm.size}")
+                out["secondary"]["other_shapes_125k"] = shapes
+            except Exception as ex:   # noqa: BLE001
+                out["secondary"]["other_shapes_125k"] = {"error": str(ex)[:300]}
             # what the memory system gives a plain device copy of an array of the e latents' size (read + write counted): the yardstick for
             # the bytes per second the processor kernels move by the counters (roofline.traffic / avg_launch_ms)
             try:
